@@ -1,0 +1,110 @@
+/* lmx_types.h — plain-C POD layouts shared by the C ABI (lumix_mi355.h), the CPU oracle (oracle/) and tests.
+ *
+ * Every struct here is byte-compatible with the LumixEngine type it names, so an engine-side adapter can
+ * reinterpret_cast instead of converting. Citations are relative to the reference tree (src/...).
+ */
+#ifndef LMX_TYPES_H
+#define LMX_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Frustum plane slots, core/geometry.h:73-83 (Frustum::Planes). EXTRA0/EXTRA1 duplicate NEAR
+ * (core/geometry.cpp:134-136, 343-345). */
+enum {
+	LMX_PLANE_NEAR = 0,
+	LMX_PLANE_FAR = 1,
+	LMX_PLANE_LEFT = 2,
+	LMX_PLANE_RIGHT = 3,
+	LMX_PLANE_TOP = 4,
+	LMX_PLANE_BOTTOM = 5,
+	LMX_PLANE_EXTRA0 = 6,
+	LMX_PLANE_EXTRA1 = 7,
+	LMX_PLANE_COUNT = 8
+};
+
+/* RenderableTypes, renderer/render_module.h:293-301. The u8 `type` of a culling cell / CullResult page. */
+enum {
+	LMX_TYPE_MESH = 0,
+	LMX_TYPE_DECAL = 1,
+	LMX_TYPE_LOCAL_LIGHT = 2,
+	LMX_TYPE_CURVE_DECAL = 3,
+	LMX_TYPE_PARTICLES = 4,
+	LMX_TYPE_COUNT = 5,
+	LMX_TYPE_ALL = 0xff /* culling_system.cpp:310-319: 0xff is reserved for "all types" */
+};
+
+/* ShiftedFrustum, core/geometry.h:102-153: 8 planes SoA + 8 corner points (fp32, relative to `origin`) + fp64 origin.
+ * sizeof == 256, alignas(16). */
+typedef struct LmxShiftedFrustum {
+	float xs[LMX_PLANE_COUNT];
+	float ys[LMX_PLANE_COUNT];
+	float zs[LMX_PLANE_COUNT];
+	float ds[LMX_PLANE_COUNT];
+	float points[8][3];
+	double origin[3];
+	double _pad; /* alignas(16) tail padding of the reference struct */
+} LmxShiftedFrustum;
+
+/* Frustum, core/geometry.h:29-99 (the cell-relative result of ShiftedFrustum::getRelative). sizeof == 224. */
+typedef struct LmxFrustum {
+	float xs[LMX_PLANE_COUNT];
+	float ys[LMX_PLANE_COUNT];
+	float zs[LMX_PLANE_COUNT];
+	float ds[LMX_PLANE_COUNT];
+	float points[8][3];
+} LmxFrustum;
+
+/* Transform, core/math.h:306-327: fp64 position, fp32 quaternion (x,y,z,w), fp32 non-uniform scale. sizeof == 56. */
+typedef struct LmxTransform {
+	double pos[3];
+	float rot[4];
+	float scale[3];
+	float _pad;
+} LmxTransform;
+
+/* LocalRigidTransform, core/math.h:262-270: fp32 position + quaternion. sizeof == 28. */
+typedef struct LmxLocalRigidTransform {
+	float pos[3];
+	float rot[4];
+} LmxLocalRigidTransform;
+
+/* Matrix, core/math.h:329-393: column-major 4x4 fp32, columns[c] = {x,y,z,w}. sizeof == 64. */
+typedef struct LmxMatrix {
+	float columns[4][4];
+} LmxMatrix;
+
+/* Mesh::Skin, renderer/model.h:81-84. sizeof == 24. */
+typedef struct LmxSkin {
+	float weights[4];
+	int16_t indices[4];
+} LmxSkin;
+
+/* Viewport, core/geometry.h:177-199 (only the fields Viewport::getFrustum() reads). Not layout-compatible. */
+typedef struct LmxViewport {
+	int32_t is_ortho;
+	float fov;
+	float ortho_size;
+	int32_t w;
+	int32_t h;
+	double pos[3];
+	float rot[4];
+	float near_plane;
+	float far_plane;
+} LmxViewport;
+
+enum {
+	LMX_CULL_CELL_SIZE = 300,        /* culling_system.cpp:75 */
+	LMX_CULL_PAGE_SPHERES = 201,     /* CellPage::MAX_COUNT, culling_system.cpp:59 */
+	LMX_CULLRESULT_PAGE_IDS = 1020,  /* culling_system.h:55 */
+	LMX_MAX_BONES = 196              /* Model::Bone::MAX_COUNT, renderer/model.h:155 */
+};
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

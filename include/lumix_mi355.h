@@ -1,0 +1,157 @@
+/* lumix_mi355.h — C ABI of liblumix_mi355.so: the MI355X (gfx950) implementation of LumixEngine's per-frame
+ * cull / transform / skin hot path.
+ *
+ * The reference exposes exactly one C symbol (`createPlugin`, src/engine/plugin.h:92-96); everything behind it is
+ * C++ vtables. This header is the seam a LumixEngine-side adapter binds instead (INTEGRATION.md shows the
+ * adapter): plain pointers and sizes, caller-owned host buffers, `int` error codes, no C++ or torch types.
+ * Each entry point cites the reference interface it replaces (paths relative to the reference tree).
+ *
+ * Threading: a context is bound to one GPU and one HIP stream. Mutating calls (build/add/remove/set*) come from
+ * one thread (the engine's update thread, like World::transformEntity delegates). lmx_cull() may be issued for
+ * several views per frame; each view has its own result slot (`view` argument), so results of different views
+ * never alias — the analogue of the reference returning an independent CullResult list per call
+ * (src/renderer/culling_system.cpp:321-369).
+ */
+#ifndef LUMIX_MI355_H
+#define LUMIX_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "lmx_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMX_API __attribute__((visibility("default")))
+
+typedef struct LmxContext LmxContext;
+
+enum {
+	LMX_OK = 0,
+	LMX_ERR_INVALID_ARGUMENT = 1,
+	LMX_ERR_NO_DEVICE = 2,     /* no HIP device / kernels cannot run: the product never falls back to the CPU */
+	LMX_ERR_HIP = 3,           /* a HIP runtime call failed; see lmx_last_error() */
+	LMX_ERR_OUT_OF_MEMORY = 4,
+	LMX_ERR_CAPACITY = 5,      /* caller buffer too small / too many views, frusta or types */
+	LMX_ERR_NOT_BUILT = 6      /* operation needs data that has not been uploaded yet */
+};
+
+enum {
+	LMX_MAX_FRUSTA = 8,  /* frusta tested in one pass over the spheres (config 5: 2 x 4 shadow cascades) */
+	LMX_MAX_TYPES = 8,   /* renderable types 0..7 (RenderableTypes::COUNT == 5, render_module.h:293-301) */
+	LMX_MAX_VIEWS = 8    /* concurrent result slots (main view + 4 cascades + light query, pipeline.cpp:1252-1285,3380) */
+};
+
+/* ---- context -------------------------------------------------------------------------------------------- */
+LMX_API int lmx_ctx_create(int device, LmxContext** out);
+LMX_API void lmx_ctx_destroy(LmxContext* ctx);
+/* Last error text of this context (or of the failed lmx_ctx_create when ctx == NULL). Never NULL. */
+LMX_API const char* lmx_last_error(const LmxContext* ctx);
+/* Use an external HIP stream (hipStream_t as void*) for all launches/copies; NULL restores the context's own. */
+LMX_API int lmx_ctx_set_stream(LmxContext* ctx, void* hip_stream);
+LMX_API int lmx_ctx_synchronize(LmxContext* ctx);
+/* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg). kernel ids: LMX_K_*. */
+enum {
+	LMX_K_CULL_CLASSIFY = 0,
+	LMX_K_CULL_SPHERES = 1,
+	LMX_K_XFORM_LEVEL = 2,
+	LMX_K_SPHERE_REFRESH = 3,
+	LMX_K_POSE_PALETTE = 4,
+	LMX_K_SKIN_VERTICES = 5,
+	LMX_K_COUNT = 6
+};
+LMX_API int lmx_profile_enable(LmxContext* ctx, int enable);
+LMX_API int lmx_profile_reset(LmxContext* ctx);
+/* Synchronizes, then returns accumulated device time (ms) and launch count of one kernel since the last reset. */
+LMX_API int lmx_profile_get(LmxContext* ctx, int kernel_id, double* total_ms, uint64_t* launches);
+
+/* ---- culling: CullingSystem, src/renderer/culling_system.h:58-77 -------------------------------------------
+ * Device layout: spheres sorted by (type, is_big, cell) in SoA chunks of 64; see DESIGN.md. */
+
+/* Bulk CullingSystem::add (culling_system.cpp:131-157) of n entities; replaces any previous content.
+ * pos_xyz: n x 3 doubles (world position), type < LMX_MAX_TYPES, entity >= 0 and unique. */
+LMX_API int lmx_cull_build(LmxContext* ctx, uint32_t n, const int32_t* entity, const uint8_t* type, const double* pos_xyz,
+	const float* radius);
+/* Incremental interface, same semantics as the virtuals of CullingSystem (culling_system.cpp:131-258).
+ * Changes are staged on the host mirror and reach the GPU at the next lmx_cull()/lmx_cull_flush(). */
+LMX_API int lmx_cull_add(LmxContext* ctx, int32_t entity, uint8_t type, const double pos[3], float radius);
+LMX_API int lmx_cull_remove(LmxContext* ctx, int32_t entity);
+LMX_API int lmx_cull_set(LmxContext* ctx, int32_t entity, const double pos[3], float radius);
+LMX_API int lmx_cull_set_position(LmxContext* ctx, int32_t entity, const double pos[3]);
+LMX_API int lmx_cull_set_radius(LmxContext* ctx, int32_t entity, float radius);
+LMX_API int lmx_cull_get_radius(LmxContext* ctx, int32_t entity, float* out_radius);
+LMX_API int lmx_cull_is_added(LmxContext* ctx, int32_t entity); /* 1 / 0 */
+LMX_API int lmx_cull_flush(LmxContext* ctx);
+/* Number of resident spheres / occupied (cell,type,is_big) groups / 64-sphere chunks on the device. */
+LMX_API int lmx_cull_stats(LmxContext* ctx, uint32_t* n_entities, uint32_t* n_cells, uint32_t* n_chunks);
+
+/* CullingSystem::cull(frustum[, type]) (culling_system.cpp:310-369) for n_frusta <= LMX_MAX_FRUSTA frusta in ONE
+ * pass over the spheres. type == LMX_TYPE_ALL (0xff) culls every type. Asynchronous on the context stream; the
+ * result stays in HBM in slot `view` until the next lmx_cull() on the same slot. */
+LMX_API int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, uint32_t n_frusta, uint8_t type);
+/* counts[f * LMX_MAX_TYPES + t] = visible entities of type t for frustum f (synchronizes the stream). */
+LMX_API int lmx_cull_counts(LmxContext* ctx, uint32_t view, uint32_t* counts /* [n_frusta][LMX_MAX_TYPES] */);
+/* Copies the visible ids of (frustum, type) to the host: the content of the CullResult pages of that type
+ * (culling_system.h:17-56). Order is unspecified, as in the reference (job scheduling + mutexed page list). */
+LMX_API int lmx_cull_read(LmxContext* ctx, uint32_t view, uint32_t frustum, uint8_t type, int32_t* out_ids, uint32_t cap,
+	uint32_t* out_count);
+/* Device-side view of a result for GPU consumers (sort keys, RCCL all-gather): ids of (frustum, type) start at
+ * d_ids + type_offsets[type] and number d_counts[frustum * LMX_MAX_TYPES + type]. All pointers are device memory
+ * except type_offsets (host, LMX_MAX_TYPES entries, in ids). */
+LMX_API int lmx_cull_device_result(LmxContext* ctx, uint32_t view, uint32_t frustum, const int32_t** d_ids, const uint32_t** d_counts,
+	uint32_t* type_offsets, uint32_t* capacity);
+
+/* ---- world transforms: World hierarchy, src/engine/world.cpp:255-282 ---------------------------------------
+ * The reference propagates eagerly (one recursive DFS per setTransform). The batch form: stage new root/local
+ * transforms, then lmx_world_propagate() recomputes child.world = parent.world.compose(child.local)
+ * (core/math.cpp:801-807) level by level; results equal the DFS bit for bit. */
+
+/* n entities, entity index = array index (EntityRef::index). parent[i] = -1 for roots.
+ * transforms[i] = world transform for roots, local transform (Hierarchy::local_transform) for children. */
+LMX_API int lmx_world_build(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxTransform* transforms);
+/* World::setTransform for roots / World::setLocalTransform for children (world.cpp:337-342, 741-753), staged. */
+LMX_API int lmx_world_set_transforms(LmxContext* ctx, uint32_t n, const int32_t* entity, const LmxTransform* transforms);
+/* RenderModuleImpl::onModelInstanceMoved binding (render_module.cpp:1544-1554): after propagation the culling
+ * sphere of entity[i] becomes (world.pos, model_radius[i] * maximum(scale.x, scale.y, scale.z)). */
+LMX_API int lmx_world_bind_culling(LmxContext* ctx, uint32_t n, const int32_t* entity, const float* model_radius);
+LMX_API int lmx_world_propagate(LmxContext* ctx);
+/* World::getTransforms() (world.h:65): AoS Transform[n] indexed by entity. */
+LMX_API int lmx_world_read_transforms(LmxContext* ctx, LmxTransform* out, uint32_t n);
+
+/* ---- skinning: Pose / Model, src/renderer/pose.cpp:63-134, src/renderer/model.cpp:103-137 -------------------- */
+
+/* Model bones: parents[i] < i (model.cpp:381-384), parents[root] = -1; bind = Model::Bone::transform (model
+ * space). The inverse bind pose is derived at load like model.cpp:404-413. Returns a model id. */
+LMX_API int lmx_skin_add_model(LmxContext* ctx, uint32_t n_bones, const int16_t* parents, const LmxLocalRigidTransform* bind,
+	int32_t first_nonroot, uint32_t* out_model);
+/* Mesh vertices + Mesh::Skin (model.h:81-84). Returns a mesh id. */
+LMX_API int lmx_skin_add_mesh(LmxContext* ctx, uint32_t n_verts, const float* positions_xyz, const LmxSkin* skin, uint32_t* out_mesh);
+/* Instances: instance i uses model[i] and mesh[i]. Replaces the instance table. */
+LMX_API int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* model, const uint32_t* mesh);
+/* Relative poses (what AnimationModule writes before Pose::computeAbsolute): instances back to back,
+ * positions n_bones x 3 floats, rotations n_bones x 4 floats per instance. */
+LMX_API int lmx_skin_upload_poses(LmxContext* ctx, const float* positions, const float* rotations, size_t n_bones_total);
+/* Pose::computeAbsolute -> computeSkinMatrices -> evaluateSkin for every instance; outputs stay in HBM. */
+LMX_API int lmx_skin_run(LmxContext* ctx);
+LMX_API int lmx_skin_read_vertices(LmxContext* ctx, uint32_t instance, float* out_xyz, uint32_t cap_verts);
+LMX_API int lmx_skin_read_palette(LmxContext* ctx, uint32_t instance, LmxMatrix* out, uint32_t cap_bones);
+LMX_API int lmx_skin_read_pose(LmxContext* ctx, uint32_t instance, float* out_pos, float* out_rot, uint32_t cap_bones);
+
+/* ---- host mirror of core/geometry.cpp frustum construction (per view, not per entity) ----------------------- */
+/* Viewport::getFrustum() (geometry.cpp:793-818). */
+LMX_API int lmx_viewport_frustum(const LmxViewport* viewport, LmxShiftedFrustum* out);
+/* ShiftedFrustum::computePerspective / computeOrtho, 7-argument overloads (geometry.cpp:502-533, 390-409). */
+LMX_API int lmx_frustum_perspective(const double pos[3], const float dir[3], const float up[3], float fov, float ratio, float near_d,
+	float far_d, LmxShiftedFrustum* out);
+LMX_API int lmx_frustum_ortho(const double pos[3], const float dir[3], const float up[3], float width, float height, float near_d,
+	float far_d, LmxShiftedFrustum* out);
+
+LMX_API const char* lmx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

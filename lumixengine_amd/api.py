@@ -1,0 +1,400 @@
+"""ctypes binding of liblumix_mi355.so (include/lumix_mi355.h) + thin host classes that mirror the reference's
+interfaces for the hot path (names and argument meaning follow the C++ originals):
+
+* :class:`CullingSystem`  — src/renderer/culling_system.h:58-77 (`add`, `remove`, `set`, `setPosition`, `setRadius`,
+  `getRadius`, `isAdded`, `cull`)
+* :class:`World`          — the transform/hierarchy subset of src/engine/world.h:49-209 in its batch form
+* :class:`Skinning`       — Pose::computeAbsolute + computeSkinMatrices + evaluateSkin (src/renderer/pose.cpp,
+  src/renderer/model.cpp:103-137) over many instances
+
+This module is plumbing for tests and bench.py; a LumixEngine build binds the same C ABI from C++.
+It never computes anything on the CPU: if the library or a gfx950 device is missing, it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "liblumix_mi355.so")
+
+MAX_FRUSTA, MAX_TYPES, MAX_VIEWS = 8, 8, 8
+TYPE_ALL = 0xFF
+(K_CULL_CLASSIFY, K_CULL_SPHERES, K_XFORM_LEVEL, K_SPHERE_REFRESH, K_POSE_PALETTE, K_SKIN_VERTICES) = range(6)
+KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices"]
+
+SHIFTED_FRUSTUM = np.dtype(
+    [("xs", "<f4", 8), ("ys", "<f4", 8), ("zs", "<f4", 8), ("ds", "<f4", 8), ("points", "<f4", (8, 3)), ("origin", "<f8", 3), ("_pad", "<f8")],
+    align=True,
+)
+TRANSFORM = np.dtype([("pos", "<f8", 3), ("rot", "<f4", 4), ("scale", "<f4", 3), ("_pad", "<f4")], align=True)
+LOCAL_RIGID = np.dtype([("pos", "<f4", 3), ("rot", "<f4", 4)], align=True)
+MATRIX = np.dtype([("columns", "<f4", (4, 4))], align=True)
+SKIN = np.dtype([("weights", "<f4", 4), ("indices", "<i2", 4)], align=True)
+VIEWPORT = np.dtype(
+    [("is_ortho", "<i4"), ("fov", "<f4"), ("ortho_size", "<f4"), ("w", "<i4"), ("h", "<i4"), ("pos", "<f8", 3), ("rot", "<f4", 4), ("near_plane", "<f4"), ("far_plane", "<f4")],
+    align=True,
+)
+
+# every symbol include/lumix_mi355.h declares: (name, restype, argtypes)
+_vp, _u32, _i32, _u8, _f32, _ci, _sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_uint8, C.c_float, C.c_int, C.c_size_t
+SYMBOLS = {
+    "lmx_ctx_create": (_ci, [_ci, C.POINTER(_vp)]),
+    "lmx_ctx_destroy": (None, [_vp]),
+    "lmx_last_error": (C.c_char_p, [_vp]),
+    "lmx_ctx_set_stream": (_ci, [_vp, _vp]),
+    "lmx_ctx_synchronize": (_ci, [_vp]),
+    "lmx_profile_enable": (_ci, [_vp, _ci]),
+    "lmx_profile_reset": (_ci, [_vp]),
+    "lmx_profile_get": (_ci, [_vp, _ci, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "lmx_cull_build": (_ci, [_vp, _u32, _vp, _vp, _vp, _vp]),
+    "lmx_cull_add": (_ci, [_vp, _i32, _u8, _vp, _f32]),
+    "lmx_cull_remove": (_ci, [_vp, _i32]),
+    "lmx_cull_set": (_ci, [_vp, _i32, _vp, _f32]),
+    "lmx_cull_set_position": (_ci, [_vp, _i32, _vp]),
+    "lmx_cull_set_radius": (_ci, [_vp, _i32, _f32]),
+    "lmx_cull_get_radius": (_ci, [_vp, _i32, C.POINTER(_f32)]),
+    "lmx_cull_is_added": (_ci, [_vp, _i32]),
+    "lmx_cull_flush": (_ci, [_vp]),
+    "lmx_cull_stats": (_ci, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "lmx_cull": (_ci, [_vp, _u32, _vp, _u32, _u8]),
+    "lmx_cull_counts": (_ci, [_vp, _u32, _vp]),
+    "lmx_cull_read": (_ci, [_vp, _u32, _u32, _u8, _vp, _u32, C.POINTER(_u32)]),
+    "lmx_cull_device_result": (_ci, [_vp, _u32, _u32, C.POINTER(_vp), C.POINTER(_vp), _vp, C.POINTER(_u32)]),
+    "lmx_world_build": (_ci, [_vp, _u32, _vp, _vp]),
+    "lmx_world_set_transforms": (_ci, [_vp, _u32, _vp, _vp]),
+    "lmx_world_bind_culling": (_ci, [_vp, _u32, _vp, _vp]),
+    "lmx_world_propagate": (_ci, [_vp]),
+    "lmx_world_read_transforms": (_ci, [_vp, _vp, _u32]),
+    "lmx_skin_add_model": (_ci, [_vp, _u32, _vp, _vp, _i32, C.POINTER(_u32)]),
+    "lmx_skin_add_mesh": (_ci, [_vp, _u32, _vp, _vp, C.POINTER(_u32)]),
+    "lmx_skin_set_instances": (_ci, [_vp, _u32, _vp, _vp]),
+    "lmx_skin_upload_poses": (_ci, [_vp, _vp, _vp, _sz]),
+    "lmx_skin_run": (_ci, [_vp]),
+    "lmx_skin_read_vertices": (_ci, [_vp, _u32, _vp, _u32]),
+    "lmx_skin_read_palette": (_ci, [_vp, _u32, _vp, _u32]),
+    "lmx_skin_read_pose": (_ci, [_vp, _u32, _vp, _vp, _u32]),
+    "lmx_viewport_frustum": (_ci, [_vp, _vp]),
+    "lmx_frustum_perspective": (_ci, [_vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
+    "lmx_frustum_ortho": (_ci, [_vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
+    "lmx_version": (C.c_char_p, []),
+}
+
+ERROR_NAMES = {1: "INVALID_ARGUMENT", 2: "NO_DEVICE", 3: "HIP", 4: "OUT_OF_MEMORY", 5: "CAPACITY", 6: "NOT_BUILT"}
+
+
+class LumixError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"LMX_ERR_{ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Loads liblumix_mi355.so and declares every exported entry point. Raises if the HIP extension is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -m lumixengine_amd.build` (there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64x3(v) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(3))
+
+
+def _f32x3(v) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(3))
+
+
+class Context:
+    """One GPU + one HIP stream (lmx_ctx_*)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.lmx_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise LumixError(rc, self.lib.lmx_last_error(None).decode())
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lmx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise LumixError(rc, self.lib.lmx_last_error(self.h).decode())
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self.check(self.lib.lmx_ctx_set_stream(self.h, hip_stream))
+
+    def synchronize(self):
+        self.check(self.lib.lmx_ctx_synchronize(self.h))
+
+    def profile_enable(self, on: bool = True):
+        self.check(self.lib.lmx_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self.check(self.lib.lmx_profile_reset(self.h))
+
+    def profile_get(self, kernel: int):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self.check(self.lib.lmx_profile_get(self.h, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+# ---- frusta (host mirror of core/geometry.cpp) ----------------------------------------------------------------
+def viewport_frustum(is_ortho=False, fov=float(np.deg2rad(60.0)), ortho_size=100.0, w=1920, h=1080, pos=(0, 0, 0), rot=(0, 0, 0, 1), near=0.1,
+                     far=10000.0) -> np.ndarray:
+    """Viewport::getFrustum() (core/geometry.cpp:793-818)."""
+    lib = load_library()
+    vp = np.zeros(1, VIEWPORT)
+    vp["is_ortho"], vp["fov"], vp["ortho_size"], vp["w"], vp["h"] = int(is_ortho), fov, ortho_size, w, h
+    vp["pos"], vp["rot"], vp["near_plane"], vp["far_plane"] = pos, rot, near, far
+    out = np.zeros(1, SHIFTED_FRUSTUM)
+    rc = lib.lmx_viewport_frustum(_ptr(vp), _ptr(out))
+    if rc:
+        raise LumixError(rc, "lmx_viewport_frustum")
+    return out
+
+
+def frustum_perspective(pos, direction, up, fov, ratio, near, far) -> np.ndarray:
+    out = np.zeros(1, SHIFTED_FRUSTUM)
+    rc = load_library().lmx_frustum_perspective(_ptr(_f64x3(pos)), _ptr(_f32x3(direction)), _ptr(_f32x3(up)), fov, ratio, near, far, _ptr(out))
+    if rc:
+        raise LumixError(rc, "lmx_frustum_perspective")
+    return out
+
+
+def frustum_ortho(pos, direction, up, width, height, near, far) -> np.ndarray:
+    out = np.zeros(1, SHIFTED_FRUSTUM)
+    rc = load_library().lmx_frustum_ortho(_ptr(_f64x3(pos)), _ptr(_f32x3(direction)), _ptr(_f32x3(up)), width, height, near, far, _ptr(out))
+    if rc:
+        raise LumixError(rc, "lmx_frustum_ortho")
+    return out
+
+
+class CullResult:
+    """Result of one cull call: the visible ids per (frustum, type), resident in HBM (view slot) until the slot is reused.
+
+    The reference returns a linked list of 4 KiB pages, each tagged with a renderable type (culling_system.h:17-56);
+    `ids(frustum, type)` is the concatenation of the pages of that type, `pages(...)` re-creates the page split.
+    """
+
+    def __init__(self, cs: "CullingSystem", view: int, n_frusta: int):
+        self.cs, self.view, self.n_frusta = cs, view, n_frusta
+        self._counts = None
+
+    def counts(self) -> np.ndarray:
+        if self._counts is None:
+            out = np.zeros((self.n_frusta, MAX_TYPES), np.uint32)
+            self.cs.ctx.check(self.cs.lib.lmx_cull_counts(self.cs.ctx.h, self.view, _ptr(out)))
+            self._counts = out
+        return self._counts
+
+    def count(self, frustum: int = 0) -> int:
+        return int(self.counts()[frustum].sum())
+
+    def ids(self, frustum: int = 0, type_: int = 0) -> np.ndarray:
+        n = int(self.counts()[frustum, type_])
+        out = np.zeros(n, np.int32)
+        got = C.c_uint32(0)
+        self.cs.ctx.check(self.cs.lib.lmx_cull_read(self.cs.ctx.h, self.view, frustum, type_, _ptr(out), n, C.byref(got)))
+        return out[: got.value]
+
+    def all_ids(self, frustum: int = 0):
+        """(ids, types) over all types, like walking the whole CullResult list."""
+        ids, types = [], []
+        for t in range(MAX_TYPES):
+            a = self.ids(frustum, t)
+            ids.append(a)
+            types.append(np.full(len(a), t, np.uint8))
+        return np.concatenate(ids), np.concatenate(types)
+
+    def pages(self, frustum: int = 0, type_: int = 0, page_ids: int = 1020):
+        a = self.ids(frustum, type_)
+        return [a[i : i + page_ids] for i in range(0, len(a), page_ids)]
+
+    def device_result(self, frustum: int = 0):
+        """(d_ids ptr, d_counts ptr, type_offsets[MAX_TYPES], capacity) for GPU-side consumers."""
+        d_ids, d_counts, cap = C.c_void_p(), C.c_void_p(), C.c_uint32(0)
+        offs = np.zeros(MAX_TYPES, np.uint32)
+        self.cs.ctx.check(self.cs.lib.lmx_cull_device_result(self.cs.ctx.h, self.view, frustum, C.byref(d_ids), C.byref(d_counts), _ptr(offs), C.byref(cap)))
+        return d_ids.value, d_counts.value, offs, cap.value
+
+
+class CullingSystem:
+    """GPU-backed CullingSystem (src/renderer/culling_system.h:58-77)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.lib = ctx.lib
+
+    # bulk form of `add` for scene load
+    def build(self, entity, type_, pos, radius):
+        entity = np.ascontiguousarray(entity, np.int32)
+        type_ = np.ascontiguousarray(type_, np.uint8)
+        pos = np.ascontiguousarray(pos, np.float64).reshape(-1, 3)
+        radius = np.ascontiguousarray(radius, np.float32)
+        assert len(entity) == len(type_) == len(pos) == len(radius)
+        self.ctx.check(self.lib.lmx_cull_build(self.ctx.h, len(entity), _ptr(entity), _ptr(type_), _ptr(pos), _ptr(radius)))
+
+    def add(self, entity: int, type_: int, pos, radius: float):
+        self.ctx.check(self.lib.lmx_cull_add(self.ctx.h, int(entity), int(type_), _ptr(_f64x3(pos)), float(radius)))
+
+    def remove(self, entity: int):
+        self.ctx.check(self.lib.lmx_cull_remove(self.ctx.h, int(entity)))
+
+    def set(self, entity: int, pos, radius: float):
+        self.ctx.check(self.lib.lmx_cull_set(self.ctx.h, int(entity), _ptr(_f64x3(pos)), float(radius)))
+
+    def setPosition(self, entity: int, pos):
+        self.ctx.check(self.lib.lmx_cull_set_position(self.ctx.h, int(entity), _ptr(_f64x3(pos))))
+
+    def setRadius(self, entity: int, radius: float):
+        self.ctx.check(self.lib.lmx_cull_set_radius(self.ctx.h, int(entity), float(radius)))
+
+    def getRadius(self, entity: int) -> float:
+        r = C.c_float(0)
+        self.ctx.check(self.lib.lmx_cull_get_radius(self.ctx.h, int(entity), C.byref(r)))
+        return r.value
+
+    def isAdded(self, entity: int) -> bool:
+        return bool(self.lib.lmx_cull_is_added(self.ctx.h, int(entity)))
+
+    def flush(self):
+        self.ctx.check(self.lib.lmx_cull_flush(self.ctx.h))
+
+    def stats(self):
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self.ctx.check(self.lib.lmx_cull_stats(self.ctx.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"entities": a.value, "cells": b.value, "chunks": c.value}
+
+    def cull(self, frusta: np.ndarray, type_: int = TYPE_ALL, view: int = 0) -> CullResult:
+        """cull(frustum[, type]); `frusta` may hold up to 8 ShiftedFrustum records tested in one pass."""
+        frusta = np.ascontiguousarray(frusta, SHIFTED_FRUSTUM).reshape(-1)
+        self.ctx.check(self.lib.lmx_cull(self.ctx.h, view, _ptr(frusta), len(frusta), type_))
+        return CullResult(self, view, len(frusta))
+
+
+class World:
+    """Batch form of World's transform hierarchy (src/engine/world.cpp:255-282)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.n = 0
+
+    def build(self, parent, transforms):
+        parent = np.ascontiguousarray(parent, np.int32)
+        transforms = np.ascontiguousarray(transforms, TRANSFORM)
+        assert len(parent) == len(transforms)
+        self.n = len(parent)
+        self.ctx.check(self.lib.lmx_world_build(self.ctx.h, self.n, _ptr(parent), _ptr(transforms)))
+
+    def setTransforms(self, entity, transforms):
+        """World::setTransform for roots / World::setLocalTransform for children, staged until propagate()."""
+        entity = np.ascontiguousarray(entity, np.int32)
+        transforms = np.ascontiguousarray(transforms, TRANSFORM)
+        assert len(entity) == len(transforms)
+        self.ctx.check(self.lib.lmx_world_set_transforms(self.ctx.h, len(entity), _ptr(entity), _ptr(transforms)))
+
+    def bindCulling(self, entity, model_radius):
+        entity = np.ascontiguousarray(entity, np.int32)
+        model_radius = np.ascontiguousarray(model_radius, np.float32)
+        self.ctx.check(self.lib.lmx_world_bind_culling(self.ctx.h, len(entity), _ptr(entity), _ptr(model_radius)))
+
+    def propagate(self):
+        self.ctx.check(self.lib.lmx_world_propagate(self.ctx.h))
+
+    def getTransforms(self) -> np.ndarray:
+        out = np.zeros(self.n, TRANSFORM)
+        self.ctx.check(self.lib.lmx_world_read_transforms(self.ctx.h, _ptr(out), self.n))
+        return out
+
+
+class Skinning:
+    """Pose -> palette -> skinned vertices for many model instances."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self._inst = []
+        self._models = {}
+        self._meshes = {}
+
+    def addModel(self, parents, bind, first_nonroot: int) -> int:
+        parents = np.ascontiguousarray(parents, np.int16)
+        bind = np.ascontiguousarray(bind, LOCAL_RIGID)
+        out = C.c_uint32(0)
+        self.ctx.check(self.lib.lmx_skin_add_model(self.ctx.h, len(parents), _ptr(parents), _ptr(bind), int(first_nonroot), C.byref(out)))
+        self._models[out.value] = len(parents)
+        return out.value
+
+    def addMesh(self, positions, skin) -> int:
+        positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        skin = np.ascontiguousarray(skin, SKIN)
+        out = C.c_uint32(0)
+        self.ctx.check(self.lib.lmx_skin_add_mesh(self.ctx.h, len(positions), _ptr(positions), _ptr(skin), C.byref(out)))
+        self._meshes[out.value] = len(positions)
+        return out.value
+
+    def setInstances(self, model, mesh):
+        model = np.ascontiguousarray(model, np.uint32)
+        mesh = np.ascontiguousarray(mesh, np.uint32)
+        self._inst = [(int(a), int(b)) for a, b in zip(model, mesh)] if len(model) <= 4096 else None
+        self._inst_model, self._inst_mesh = model, mesh
+        self.ctx.check(self.lib.lmx_skin_set_instances(self.ctx.h, len(model), _ptr(model), _ptr(mesh)))
+
+    def uploadPoses(self, positions, rotations):
+        positions = np.ascontiguousarray(positions, np.float32)
+        rotations = np.ascontiguousarray(rotations, np.float32)
+        n_bones_total = positions.size // 3
+        assert rotations.size == n_bones_total * 4
+        self.ctx.check(self.lib.lmx_skin_upload_poses(self.ctx.h, _ptr(positions), _ptr(rotations), n_bones_total))
+
+    def run(self):
+        self.ctx.check(self.lib.lmx_skin_run(self.ctx.h))
+
+    def readVertices(self, instance: int) -> np.ndarray:
+        n = self._meshes[int(self._inst_mesh[instance])]
+        out = np.zeros((n, 3), np.float32)
+        self.ctx.check(self.lib.lmx_skin_read_vertices(self.ctx.h, instance, _ptr(out), n))
+        return out
+
+    def readPalette(self, instance: int) -> np.ndarray:
+        n = self._models[int(self._inst_model[instance])]
+        out = np.zeros(n, MATRIX)
+        self.ctx.check(self.lib.lmx_skin_read_palette(self.ctx.h, instance, _ptr(out), n))
+        return out
+
+    def readPose(self, instance: int):
+        n = self._models[int(self._inst_model[instance])]
+        pos = np.zeros((n, 3), np.float32)
+        rot = np.zeros((n, 4), np.float32)
+        self.ctx.check(self.lib.lmx_skin_read_pose(self.ctx.h, instance, _ptr(pos), _ptr(rot), n))
+        return pos, rot

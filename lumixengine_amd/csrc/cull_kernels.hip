@@ -1,0 +1,216 @@
+// cull_kernels.hip — frustum culling of CullingSystem spheres on gfx950 (wave64).
+//
+// Replaces CullingSystemImpl::cullInternal / doCulling (src/renderer/culling_system.cpp:262-369) and the per-cell
+// ShiftedFrustum tests (src/core/geometry.cpp:99-178). Two kernels per cull:
+//
+//   k_cull_classify   1 thread per occupied (cell,type,is_big) group x frustum: fp64 origin shift, the
+//                     contains/intersects AABB tests, and the getRelative() offset -> 16 B per cell per frustum.
+//   k_cull_spheres    1 wave per 64-sphere chunk: chunk header (scalar load) -> per-lane cell slot via the
+//                     "new cell" bit mask + mbcnt -> 16-B cell-info gather (L2-resident) -> whole-wave early out
+//                     for rejected cells -> 8-plane test -> wave64 ballot compaction into an LDS staging list ->
+//                     ONE global atomic per (tile, frustum) and a coalesced flush of the visible ids.
+//
+// Built with -ffp-contract=off: the plane arithmetic must round exactly like the reference's scalar float4.
+#include "lmx_kernels.h"
+
+namespace lmx {
+
+namespace {
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void k_cull_classify(const CellKey* __restrict__ cells, uint32_t cell_begin, uint32_t n,
+	FrustaArg fr, float4* __restrict__ cellinfo, uint32_t cell_stride, uint32_t* __restrict__ counts) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (blockIdx.x == 0 && threadIdx.x < MAX_FRUSTA * MAX_TYPES) counts[threadIdx.x] = 0;
+	if (i >= n) return;
+	const uint32_t c = cell_begin + i;
+	const CellKey key = cells[c];
+	const bool dead = (key.meta & CELL_DEAD) != 0;
+	const bool big = (key.meta & 0x100u) != 0;
+#pragma unroll
+	for (int f = 0; f < F; ++f) {
+		V3 off = V3{0.f, 0.f, 0.f};
+		uint32_t cls = CELL_REJECT;
+		if (!dead) cls = classify_cell(fr.f[f], IV3{key.ix, key.iy, key.iz}, big, &off);
+		cellinfo[(size_t)f * cell_stride + c] = make_float4(off.x, off.y, off.z, __uint_as_float(cls));
+	}
+}
+
+// WAVES waves per block, CHW chunks per wave -> TILE = WAVES * CHW * 64 spheres per block.
+template <int F, int WAVES, int CHW>
+__global__ __launch_bounds__(WAVES * 64) void k_cull_spheres(const float4* __restrict__ spheres, const int32_t* __restrict__ ids,
+	const uint32_t* __restrict__ chunk_cell, const uint64_t* __restrict__ chunk_flags, const float4* __restrict__ cellinfo,
+	uint32_t cell_stride, FrustaArg fr, TypeTable tt, uint32_t ent_begin, int32_t* __restrict__ out_ids, uint32_t out_stride,
+	uint32_t* __restrict__ counts) {
+	constexpr int TILE = WAVES * CHW * 64;
+	__shared__ int32_t s_buf[F * TILE];
+	__shared__ uint32_t s_cnt[F];
+	__shared__ uint32_t s_base[F];
+
+	const uint32_t lane = lane_id();
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t tile_ent = ent_begin + blockIdx.x * (uint32_t)TILE; // first sphere slot of this tile
+
+	if (threadIdx.x < F) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+
+	// type of this tile (type ranges are TILE_ALIGN-aligned, so a tile never straddles two types)
+	uint32_t type = 0;
+#pragma unroll
+	for (int t = 0; t < MAX_TYPES; ++t) {
+		if (tile_ent >= tt.ent_start[t] && tile_ent < tt.ent_end[t]) type = t;
+	}
+
+	const uint32_t chunk0 = (tile_ent >> 6) + wave * CHW; // this wave's CHW consecutive chunks
+	const uint64_t le_mask = (~0ull >> (63u - lane)) & ~1ull; // bits 1..lane
+
+	// phase 1: chunk headers (wave-uniform -> scalar loads), per-lane cell slot, cell-info gather
+	uint32_t cell[CHW];
+#pragma unroll
+	for (int i = 0; i < CHW; ++i) {
+		const uint32_t base_cell = chunk_cell[chunk0 + i];
+		const uint64_t flags = chunk_flags[chunk0 + i];
+		cell[i] = base_cell + (uint32_t)__popcll(flags & le_mask);
+	}
+	float4 info[F][CHW];
+#pragma unroll
+	for (int f = 0; f < F; ++f) {
+#pragma unroll
+		for (int i = 0; i < CHW; ++i) info[f][i] = cellinfo[(size_t)f * cell_stride + cell[i]];
+	}
+
+	// phase 2: which chunks need their spheres / ids at all (whole-cell reject costs no sphere traffic)
+	bool need_id[CHW], need_sphere[CHW];
+#pragma unroll
+	for (int i = 0; i < CHW; ++i) {
+		bool any_live = false, any_test = false;
+#pragma unroll
+		for (int f = 0; f < F; ++f) {
+			const uint32_t cls = __float_as_uint(info[f][i].w);
+			any_live |= cls != CELL_REJECT;
+			any_test |= cls == CELL_TEST;
+		}
+		need_id[i] = __ballot(any_live) != 0;     // wave-uniform
+		need_sphere[i] = __ballot(any_test) != 0; // wave-uniform
+	}
+	int32_t id[CHW];
+	float4 sp[CHW];
+#pragma unroll
+	for (int i = 0; i < CHW; ++i) {
+		const uint32_t e = ((chunk0 + i) << 6) + lane;
+		id[i] = -1;
+		sp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+		if (need_id[i]) id[i] = ids[e];
+		if (need_sphere[i]) sp[i] = spheres[e];
+	}
+
+	// phase 3: plane tests + wave ballot compaction into the LDS staging lists
+#pragma unroll
+	for (int i = 0; i < CHW; ++i) {
+		if (!need_id[i]) continue;
+#pragma unroll
+		for (int f = 0; f < F; ++f) {
+			const uint32_t cls = __float_as_uint(info[f][i].w);
+			bool vis = cls == CELL_ACCEPT;
+			if (cls == CELL_TEST) {
+				vis = sphere_visible(fr.f[f], V3{info[f][i].x, info[f][i].y, info[f][i].z}, sp[i].x, sp[i].y, sp[i].z, sp[i].w);
+			}
+			vis = vis && id[i] >= 0;
+			const uint64_t mask = __ballot(vis);
+			if (mask != 0) {
+				uint32_t base = 0;
+				if (lane == 0) base = atomicAdd(&s_cnt[f], (uint32_t)__popcll(mask));
+				base = __builtin_amdgcn_readfirstlane(base);
+				if (vis) s_buf[f * TILE + base + mbcnt64(mask)] = id[i];
+			}
+		}
+	}
+	__syncthreads();
+
+	// one global atomic per (tile, frustum) with anything visible, then a coalesced flush
+	if (threadIdx.x < F) {
+		const uint32_t c = s_cnt[threadIdx.x];
+		s_base[threadIdx.x] = c ? atomicAdd(&counts[threadIdx.x * MAX_TYPES + type], c) : 0u;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int f = 0; f < F; ++f) {
+		const uint32_t c = s_cnt[f];
+		int32_t* dst = out_ids + (size_t)f * out_stride + tt.ent_start[type] + s_base[f];
+		for (uint32_t k = threadIdx.x; k < c; k += WAVES * 64) dst[k] = s_buf[f * TILE + k];
+	}
+}
+
+__global__ __launch_bounds__(256) void k_patch_spheres(float4* __restrict__ spheres, const uint32_t* __restrict__ slot,
+	const float4* __restrict__ value, uint32_t n) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n) spheres[slot[i]] = value[i];
+}
+
+template <int F>
+hipError_t classify_f(hipStream_t s, const CullDeviceView& v, uint32_t cell_begin, uint32_t n, const FrustaArg& fr, float4* cellinfo,
+	uint32_t cell_stride, uint32_t* counts) {
+	const uint32_t blocks = n ? (n + 255u) / 256u : 1u; // always >= 1 block: block 0 zeroes the counters
+	hipLaunchKernelGGL((k_cull_classify<F>), dim3(blocks), dim3(256), 0, s, v.cells, cell_begin, n, fr, cellinfo, cell_stride, counts);
+	return hipGetLastError();
+}
+
+template <int F, int WAVES, int CHW>
+hipError_t spheres_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
+	const FrustaArg& fr, const float4* cellinfo, uint32_t cell_stride, int32_t* out_ids, uint32_t out_stride, uint32_t* counts) {
+	constexpr uint32_t TILE = WAVES * CHW * 64;
+	static_assert(TILE_ALIGN % TILE == 0, "tiles must not straddle type ranges");
+	const uint32_t tiles = (ent_end - ent_begin) / TILE;
+	if (!tiles) return hipSuccess;
+	hipLaunchKernelGGL((k_cull_spheres<F, WAVES, CHW>), dim3(tiles), dim3(WAVES * 64), 0, s, v.spheres, v.ids, v.chunk_cell,
+		v.chunk_flags, cellinfo, cell_stride, fr, tt, ent_begin, out_ids, out_stride, counts);
+	return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t launch_cull_classify(hipStream_t s, const CullDeviceView& v, uint32_t cell_begin, uint32_t n, const FrustaArg& fr,
+	int n_frusta, float4* cellinfo, uint32_t cell_stride, uint32_t* counts) {
+	switch (n_frusta) {
+		case 1: return classify_f<1>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
+		case 2: return classify_f<2>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
+		case 3: return classify_f<3>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
+		case 4: return classify_f<4>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
+		case 5: return classify_f<5>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
+		case 6: return classify_f<6>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
+		case 7: return classify_f<7>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
+		case 8: return classify_f<8>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
+		default: return hipErrorInvalidValue;
+	}
+}
+
+hipError_t launch_cull_spheres(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
+	const FrustaArg& fr, int n_frusta, const float4* cellinfo, uint32_t cell_stride, int32_t* out_ids, uint32_t out_stride,
+	uint32_t* counts) {
+#define LMX_SPH(F, W, C) return spheres_f<F, W, C>(s, v, ent_begin, ent_end, tt, fr, cellinfo, cell_stride, out_ids, out_stride, counts)
+	switch (n_frusta) {
+		case 1: LMX_SPH(1, 8, 8); // TILE 4096, 16 KiB LDS
+		case 2: LMX_SPH(2, 8, 4); // TILE 2048, 16 KiB
+		case 3: LMX_SPH(3, 8, 4); // 24 KiB
+		case 4: LMX_SPH(4, 8, 4); // 32 KiB
+		case 5: LMX_SPH(5, 4, 4); // TILE 1024, 20 KiB
+		case 6: LMX_SPH(6, 4, 4);
+		case 7: LMX_SPH(7, 4, 4);
+		case 8: LMX_SPH(8, 4, 4); // 32 KiB
+		default: return hipErrorInvalidValue;
+	}
+#undef LMX_SPH
+}
+
+hipError_t launch_patch_spheres(hipStream_t s, float4* spheres, const uint32_t* slot, const float4* value, uint32_t n) {
+	if (!n) return hipSuccess;
+	hipLaunchKernelGGL(k_patch_spheres, dim3((n + 255u) / 256u), dim3(256), 0, s, spheres, slot, value, n);
+	return hipGetLastError();
+}
+
+} // namespace lmx

@@ -1,0 +1,91 @@
+// lmx_kernels.h — host-callable launchers of the gfx950 kernels (defined in *_kernels.hip) + shared device layouts.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lmx_math.h"
+
+namespace lmx {
+
+constexpr int MAX_FRUSTA = 8;
+constexpr int MAX_TYPES = 8;
+constexpr uint32_t CHUNK = 64;          // spheres per chunk = one wavefront
+constexpr uint32_t TILE_ALIGN = 4096;   // type ranges are padded to this many spheres (largest tile of any variant)
+constexpr uint32_t CELL_DEAD = 0x80000000u;
+
+// One (cell index, type, is_big) group. meta = type | is_big << 8 | CELL_DEAD.
+struct CellKey { int32_t ix, iy, iz; uint32_t meta; };
+
+// Per-type ranges in the padded sphere index space.
+struct TypeTable {
+	uint32_t ent_start[MAX_TYPES]; // first sphere slot of the type (multiple of TILE_ALIGN)
+	uint32_t ent_end[MAX_TYPES];   // end of the padded range (multiple of TILE_ALIGN)
+};
+
+struct FrustaArg { DevFrustum f[MAX_FRUSTA]; };
+
+struct CullDeviceView {
+	const float4* spheres;       // [n_padded] {rel.x, rel.y, rel.z, radius}, cell-relative fp32 (culling_system.cpp:100)
+	const int32_t* ids;          // [n_padded] entity index, -1 for padding
+	const uint32_t* chunk_cell;  // [n_padded / 64] cell slot of the first sphere of the chunk
+	const uint64_t* chunk_flags; // [n_padded / 64] bit l: sphere l of the chunk starts a new cell
+	const CellKey* cells;        // [n_cells]
+	uint32_t n_padded;
+	uint32_t n_cells;
+};
+
+// classify cells [cell_begin, cell_begin + n) for n_frusta frusta -> cellinfo[f * cell_stride + c] =
+// {offset.x, offset.y, offset.z, bits(class)}; also zeroes counts[0 .. MAX_FRUSTA * MAX_TYPES).
+hipError_t launch_cull_classify(hipStream_t s, const CullDeviceView& v, uint32_t cell_begin, uint32_t n, const FrustaArg& fr,
+	int n_frusta, float4* cellinfo, uint32_t cell_stride, uint32_t* counts);
+
+// test spheres [ent_begin, ent_end) (multiples of TILE_ALIGN, one type per tile) and compact visible ids into
+// out_ids[f * out_stride + tt.ent_start[type] + ...], counts[f * MAX_TYPES + type].
+hipError_t launch_cull_spheres(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
+	const FrustaArg& fr, int n_frusta, const float4* cellinfo, uint32_t cell_stride, int32_t* out_ids, uint32_t out_stride,
+	uint32_t* counts);
+
+// spheres[slot[i]] = value[i]
+hipError_t launch_patch_spheres(hipStream_t s, float4* spheres, const uint32_t* slot, const float4* value, uint32_t n);
+
+// ---- world transforms ------------------------------------------------------------------------------------
+struct WorldDevice {
+	// slot order = (level, parent slot); all arrays [n]
+	double* lpx; double* lpy; double* lpz; float4* lrot; float* lsx; float* lsy; float* lsz; // local (roots: unused)
+	double* wpx; double* wpy; double* wpz; float4* wrot; float* wsx; float* wsy; float* wsz; // world
+	const int32_t* parent_slot; // -1 for roots
+};
+// world[s] = compose(world[parent_slot[s]], local[s]) for s in [first, first + n)
+hipError_t launch_xform_level(hipStream_t s, const WorldDevice& w, uint32_t first, uint32_t n);
+// out[entity_of_slot[s]] = AoS Transform (56 B) for s in [0, n)
+hipError_t launch_xform_export(hipStream_t s, const WorldDevice& w, const int32_t* entity_of_slot, uint32_t n, void* out_transforms);
+// stage transforms (AoS LmxTransform, device memory) into the SoA arrays: roots -> world, children -> local
+hipError_t launch_xform_scatter(hipStream_t s, const WorldDevice& w, const int32_t* slot_of_entity, const int32_t* entity,
+	const void* transforms, uint32_t n);
+// culling sphere refresh for bound entities (see xform_kernels.hip). Entities that left their cell (or crossed the
+// is_big threshold) are appended to rebin[] for the host mirror to re-add.
+struct RebinItem { double pos[3]; float radius; uint32_t bound_index; };
+hipError_t launch_sphere_refresh(hipStream_t s, const WorldDevice& w, const uint32_t* bound_slot, const uint32_t* bound_sphere,
+	const float* model_radius, const uint32_t* sphere_cell, const CellKey* cells, float4* spheres, uint32_t n, uint32_t* rebin_count,
+	RebinItem* rebin);
+
+// ---- skinning --------------------------------------------------------------------------------------------
+struct SkinInstance {
+	uint32_t bone_offset;  // into pose arrays / palette (in bones)
+	uint32_t n_bones;
+	uint32_t model_offset; // into parents / inverse bind arrays (in bones)
+	int32_t first_nonroot;
+	uint32_t vert_offset;  // into mesh vertex arrays
+	uint32_t n_verts;
+	uint32_t out_offset;   // into output vertex array (in vertices)
+	uint32_t max_depth;    // deepest bone level of the model (root = 0)
+};
+// Pose::computeAbsolute + computeSkinMatrices per instance (one wave per instance)
+hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, float* pose_pos, float4* pose_rot,
+	const int16_t* parents, const uint8_t* depth, const float* inv_pos, const float4* inv_rot, float4* palette);
+// evaluateSkin over every vertex of every instance
+hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, uint32_t max_verts, const float* verts,
+	const float4* weights, const int16_t* indices, const float4* palette, float* out);
+
+} // namespace lmx

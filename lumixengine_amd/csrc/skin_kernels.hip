@@ -1,0 +1,147 @@
+// skin_kernels.hip — skeletal skinning on gfx950: absolute pose, matrix palette, linear-blend vertex transform.
+//
+//   k_pose_palette   one wave per model instance. Pose::computeAbsolute (src/renderer/pose.cpp:63-134, scalar
+//                    recurrence :129-130) is a chain over the bone tree: a bone only depends on its parent's final
+//                    value, so the wave walks the tree level by level (bone depth precomputed per model) with the
+//                    pose held in LDS; every bone is computed by exactly the reference's operations, so the result
+//                    is bit-identical to the index-order loop. Then computeSkinMatrices (src/renderer/model.cpp:
+//                    132-137): palette[i] = (pose[i] * inverse_bind[i]).toMatrix(), written as 4 x float4 per bone.
+//   k_skin_vertices  evaluateSkin (model.cpp:103-109): the instance's palette is staged in LDS as 3 rows x float4
+//                    per bone (row w of the blended matrix never reaches transformPoint, core/math.cpp:1231-1235),
+//                    each lane blends its 4 bone matrices element-wise in the reference's left-to-right order and
+//                    transforms one vertex. FMA-free VALU version: this is the parity reference of the skin path.
+#include "lmx_kernels.h"
+
+namespace lmx {
+
+namespace {
+
+constexpr int SKIN_MAX_BONES = 196; // Model::Bone::MAX_COUNT, renderer/model.h:155
+
+// Lanes of ONE wave exchange data through LDS: the LDS executes a wave's instructions in issue order, so only the
+// compiler has to be kept from reordering the accesses (wavefront-scope fences emit no instructions).
+__device__ __forceinline__ void wave_lds_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 4 waves per block, one instance per wave
+__global__ __launch_bounds__(256) void k_pose_palette(const SkinInstance* __restrict__ inst, uint32_t n_inst, float* __restrict__ pose_pos,
+	float4* __restrict__ pose_rot, const int16_t* __restrict__ parents, const uint8_t* __restrict__ depth,
+	const float* __restrict__ inv_pos, const float4* __restrict__ inv_rot, float4* __restrict__ palette) {
+	__shared__ float s_pos[4][SKIN_MAX_BONES * 3];
+	__shared__ float4 s_rot[4][SKIN_MAX_BONES];
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t ii = blockIdx.x * 4u + wave;
+	if (ii >= n_inst) return; // whole wave exits; no block-level barrier is used below
+	const SkinInstance in = inst[ii];
+	float* pos = s_pos[wave];
+	float4* rot = s_rot[wave];
+	float* gpos = pose_pos + (size_t)in.bone_offset * 3;
+	float4* grot = pose_rot + in.bone_offset;
+	for (uint32_t k = lane; k < in.n_bones * 3; k += 64) pos[k] = gpos[k];
+	for (uint32_t b = lane; b < in.n_bones; b += 64) rot[b] = grot[b];
+	wave_lds_sync();
+	const int16_t* par = parents + in.model_offset;
+	const uint8_t* dep = depth + in.model_offset;
+	const uint32_t max_depth = in.max_depth;
+	for (uint32_t d = 1; d <= max_depth; ++d) {
+		for (uint32_t b = lane; b < in.n_bones; b += 64) {
+			if (dep[b] == d && (int32_t)b >= in.first_nonroot) {
+				const int32_t p = par[b];
+				const float4 pr4 = rot[p];
+				const float4 r4 = rot[b];
+				const Q4 pr = Q4{pr4.x, pr4.y, pr4.z, pr4.w};
+				const V3 np = add(rotate(pr, V3{pos[3 * b], pos[3 * b + 1], pos[3 * b + 2]}), V3{pos[3 * p], pos[3 * p + 1], pos[3 * p + 2]});
+				const Q4 nr = qmul(pr, Q4{r4.x, r4.y, r4.z, r4.w});
+				pos[3 * b] = np.x; pos[3 * b + 1] = np.y; pos[3 * b + 2] = np.z;
+				rot[b] = make_float4(nr.x, nr.y, nr.z, nr.w);
+			}
+		}
+		wave_lds_sync();
+	}
+	const float* ipos = inv_pos + (size_t)in.model_offset * 3;
+	const float4* irot = inv_rot + in.model_offset;
+	for (uint32_t b = lane; b < in.n_bones; b += 64) {
+		const float4 r4 = rot[b];
+		const float4 ir = irot[b];
+		const V3 p = V3{pos[3 * b], pos[3 * b + 1], pos[3 * b + 2]};
+		const Mat4 m = skin_matrix(p, Q4{r4.x, r4.y, r4.z, r4.w}, V3{ipos[3 * b], ipos[3 * b + 1], ipos[3 * b + 2]}, Q4{ir.x, ir.y, ir.z, ir.w});
+		float4* out = palette + (size_t)(in.bone_offset + b) * 4;
+		out[0] = make_float4(m.c[0][0], m.c[0][1], m.c[0][2], m.c[0][3]);
+		out[1] = make_float4(m.c[1][0], m.c[1][1], m.c[1][2], m.c[1][3]);
+		out[2] = make_float4(m.c[2][0], m.c[2][1], m.c[2][2], m.c[2][3]);
+		out[3] = make_float4(m.c[3][0], m.c[3][1], m.c[3][2], m.c[3][3]);
+		// the pose becomes absolute in place (Pose::is_absolute = true, pose.cpp:133)
+		gpos[3 * b] = p.x; gpos[3 * b + 1] = p.y; gpos[3 * b + 2] = p.z;
+		grot[b] = r4;
+	}
+}
+
+constexpr int SKIN_VPB = 256; // vertices per block
+
+__global__ __launch_bounds__(256) void k_skin_vertices(const SkinInstance* __restrict__ inst, uint32_t blocks_per_inst,
+	const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices,
+	const float4* __restrict__ palette, float* __restrict__ out) {
+	__shared__ float4 s_rows[SKIN_MAX_BONES * 3];
+	const uint32_t ii = blockIdx.x / blocks_per_inst;
+	const uint32_t vb = blockIdx.x - ii * blocks_per_inst;
+	const SkinInstance in = inst[ii];
+	if (vb * SKIN_VPB >= in.n_verts) return; // block-uniform
+	// stage palette: global column-major 4 x float4 per bone -> LDS 3 rows {c0[r], c1[r], c2[r], c3[r]}
+	const float4* pal = palette + (size_t)in.bone_offset * 4;
+	for (uint32_t b = threadIdx.x; b < in.n_bones; b += 256) {
+		const float4 c0 = pal[4 * b], c1 = pal[4 * b + 1], c2 = pal[4 * b + 2], c3 = pal[4 * b + 3];
+		s_rows[3 * b] = make_float4(c0.x, c1.x, c2.x, c3.x);
+		s_rows[3 * b + 1] = make_float4(c0.y, c1.y, c2.y, c3.y);
+		s_rows[3 * b + 2] = make_float4(c0.z, c1.z, c2.z, c3.z);
+	}
+	__syncthreads();
+	const uint32_t v = vb * SKIN_VPB + threadIdx.x;
+	if (v >= in.n_verts) return;
+	const size_t gv = (size_t)in.vert_offset + v;
+	const float px = verts[3 * gv], py = verts[3 * gv + 1], pz = verts[3 * gv + 2];
+	const float4 w = weights[gv];
+	const int2 iw = reinterpret_cast<const int2*>(indices)[gv]; // 4 x i16, little endian
+	const int32_t i0 = (int16_t)(iw.x & 0xffff), i1 = iw.x >> 16, i2 = (int16_t)(iw.y & 0xffff), i3 = iw.y >> 16;
+	float o[3];
+#pragma unroll
+	for (int r = 0; r < 3; ++r) {
+		const float4 a = s_rows[3 * i0 + r], b = s_rows[3 * i1 + r], c = s_rows[3 * i2 + r], d = s_rows[3 * i3 + r];
+		// Matrix::operator*(float) and operator+ (math.cpp:1022-1071), left to right: ((A*w.x + B*w.y) + C*w.z) + D*w.w
+		const float m0 = a.x * w.x + b.x * w.y + c.x * w.z + d.x * w.w;
+		const float m1 = a.y * w.x + b.y * w.y + c.y * w.z + d.y * w.w;
+		const float m2 = a.z * w.x + b.z * w.y + c.z * w.z + d.z * w.w;
+		const float m3 = a.w * w.x + b.w * w.y + c.w * w.z + d.w * w.w;
+		// Matrix::transformPoint (math.cpp:1231-1235): c0.r*p.x + c1.r*p.y + c2.r*p.z + c3.r
+		o[r] = m0 * px + m1 * py + m2 * pz + m3;
+	}
+	const size_t ov = (size_t)in.out_offset + v;
+	out[3 * ov] = o[0];
+	out[3 * ov + 1] = o[1];
+	out[3 * ov + 2] = o[2];
+}
+
+} // namespace
+
+hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, float* pose_pos, float4* pose_rot,
+	const int16_t* parents, const uint8_t* depth, const float* inv_pos, const float4* inv_rot, float4* palette) {
+	if (!n_inst) return hipSuccess;
+	hipLaunchKernelGGL(k_pose_palette, dim3((n_inst + 3u) / 4u), dim3(256), 0, s, inst, n_inst, pose_pos, pose_rot, parents, depth,
+		inv_pos, inv_rot, palette);
+	return hipGetLastError();
+}
+
+hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, uint32_t max_verts, const float* verts,
+	const float4* weights, const int16_t* indices, const float4* palette, float* out) {
+	if (!n_inst || !max_verts) return hipSuccess;
+	const uint32_t bpi = (max_verts + SKIN_VPB - 1) / SKIN_VPB;
+	const uint64_t blocks = (uint64_t)bpi * n_inst;
+	if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_skin_vertices, dim3((uint32_t)blocks), dim3(256), 0, s, inst, bpi, verts, weights, indices, palette, out);
+	return hipGetLastError();
+}
+
+} // namespace lmx

@@ -1,0 +1,135 @@
+// xform_kernels.hip — hierarchical world-transform update of World on gfx950.
+//
+// The reference propagates eagerly and serially: World::transformEntity (src/engine/world.cpp:255-282) walks the
+// subtree of every written entity, child.world = my.compose(child.local) (src/core/math.cpp:801-807), and fires
+// the per-component `transformed` delegates, of which RenderModuleImpl::onModelInstanceMoved
+// (src/renderer/render_module.cpp:1544-1554) refreshes the culling sphere.
+//
+// Here nodes live in (level, parent-slot) order in SoA arrays; one launch per level computes every node of that
+// level from its parent's already-final world transform (fp64 position, fp32 rotation/scale, no FMA), so sibling
+// lanes read the same or adjacent parent slots. A fused pass refreshes the culling spheres of bound entities.
+#include "lmx_kernels.h"
+
+namespace lmx {
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_xform_level(WorldDevice w, uint32_t first, uint32_t n) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t s = first + i;
+	const int32_t p = w.parent_slot[s];
+	Xform parent, local;
+	const float4 pr = w.wrot[p];
+	parent.pos = DV3{w.wpx[p], w.wpy[p], w.wpz[p]};
+	parent.rot = Q4{pr.x, pr.y, pr.z, pr.w};
+	parent.scale = V3{w.wsx[p], w.wsy[p], w.wsz[p]};
+	const float4 lr = w.lrot[s];
+	local.pos = DV3{w.lpx[s], w.lpy[s], w.lpz[s]};
+	local.rot = Q4{lr.x, lr.y, lr.z, lr.w};
+	local.scale = V3{w.lsx[s], w.lsy[s], w.lsz[s]};
+	const Xform r = compose(parent, local);
+	w.wpx[s] = r.pos.x;
+	w.wpy[s] = r.pos.y;
+	w.wpz[s] = r.pos.z;
+	w.wrot[s] = make_float4(r.rot.x, r.rot.y, r.rot.z, r.rot.w);
+	w.wsx[s] = r.scale.x;
+	w.wsy[s] = r.scale.y;
+	w.wsz[s] = r.scale.z;
+}
+
+struct TransformAoS { double pos[3]; float rot[4]; float scale[3]; float pad; }; // core/math.h:306-327, 56 B
+
+__global__ __launch_bounds__(256) void k_xform_export(WorldDevice w, const int32_t* __restrict__ entity_of_slot, uint32_t n,
+	TransformAoS* __restrict__ out) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s >= n) return;
+	const float4 r = w.wrot[s];
+	TransformAoS t;
+	t.pos[0] = w.wpx[s]; t.pos[1] = w.wpy[s]; t.pos[2] = w.wpz[s];
+	t.rot[0] = r.x; t.rot[1] = r.y; t.rot[2] = r.z; t.rot[3] = r.w;
+	t.scale[0] = w.wsx[s]; t.scale[1] = w.wsy[s]; t.scale[2] = w.wsz[s];
+	t.pad = 0.f;
+	out[entity_of_slot[s]] = t;
+}
+
+// Stage new transforms: roots get their world transform (World::setTransform, world.cpp:337-342), children their
+// local transform (World::setLocalTransform, world.cpp:741-753). slot_of_entity maps entity -> slot.
+__global__ __launch_bounds__(256) void k_xform_scatter(WorldDevice w, const int32_t* __restrict__ slot_of_entity,
+	const int32_t* __restrict__ entity, const TransformAoS* __restrict__ tr, uint32_t n) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const int32_t s = slot_of_entity[entity[i]];
+	const TransformAoS t = tr[i];
+	if (w.parent_slot[s] < 0) {
+		w.wpx[s] = t.pos[0]; w.wpy[s] = t.pos[1]; w.wpz[s] = t.pos[2];
+		w.wrot[s] = make_float4(t.rot[0], t.rot[1], t.rot[2], t.rot[3]);
+		w.wsx[s] = t.scale[0]; w.wsy[s] = t.scale[1]; w.wsz[s] = t.scale[2];
+	} else {
+		w.lpx[s] = t.pos[0]; w.lpy[s] = t.pos[1]; w.lpz[s] = t.pos[2];
+		w.lrot[s] = make_float4(t.rot[0], t.rot[1], t.rot[2], t.rot[3]);
+		w.lsx[s] = t.scale[0]; w.lsy[s] = t.scale[1]; w.lsz[s] = t.scale[2];
+	}
+}
+
+// onModelInstanceMoved -> CullingSystem::set (culling_system.cpp:225-242): same cell and same is_big -> update
+// the sphere in place; otherwise the entity must be re-binned, which is reported through rebin_list.
+__global__ __launch_bounds__(256) void k_sphere_refresh(WorldDevice w, const uint32_t* __restrict__ bound_slot,
+	const uint32_t* __restrict__ bound_sphere, const float* __restrict__ model_radius, const uint32_t* __restrict__ sphere_cell,
+	const CellKey* __restrict__ cells, float4* __restrict__ spheres, uint32_t n, uint32_t* __restrict__ rebin_count,
+	RebinItem* __restrict__ rebin) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t s = bound_slot[i];
+	const uint32_t sph = bound_sphere[i];
+	const DV3 pos = DV3{w.wpx[s], w.wpy[s], w.wpz[s]};
+	const float radius = model_radius[i] * maximum3(w.wsx[s], w.wsy[s], w.wsz[s]);
+	const CellKey key = cells[sphere_cell[sph]];
+	const IV3 idx = cell_of(pos);
+	const bool was_big = (key.meta & 0x100u) != 0;
+	const bool same = idx.x == key.ix && idx.y == key.iy && idx.z == key.iz && was_big == is_big_radius(radius);
+	if (same) {
+		const V3 rel = to_v3(sub(pos, cell_origin(idx)));
+		spheres[sph] = make_float4(rel.x, rel.y, rel.z, radius);
+	} else {
+		const uint32_t k = atomicAdd(rebin_count, 1u);
+		RebinItem item;
+		item.pos[0] = pos.x; item.pos[1] = pos.y; item.pos[2] = pos.z;
+		item.radius = radius;
+		item.bound_index = i;
+		rebin[k] = item;
+	}
+}
+
+} // namespace
+
+hipError_t launch_xform_level(hipStream_t s, const WorldDevice& w, uint32_t first, uint32_t n) {
+	if (!n) return hipSuccess;
+	hipLaunchKernelGGL(k_xform_level, dim3((n + 255u) / 256u), dim3(256), 0, s, w, first, n);
+	return hipGetLastError();
+}
+
+hipError_t launch_xform_export(hipStream_t s, const WorldDevice& w, const int32_t* entity_of_slot, uint32_t n, void* out_transforms) {
+	if (!n) return hipSuccess;
+	hipLaunchKernelGGL(k_xform_export, dim3((n + 255u) / 256u), dim3(256), 0, s, w, entity_of_slot, n, (TransformAoS*)out_transforms);
+	return hipGetLastError();
+}
+
+hipError_t launch_xform_scatter(hipStream_t s, const WorldDevice& w, const int32_t* slot_of_entity, const int32_t* entity,
+	const void* transforms, uint32_t n) {
+	if (!n) return hipSuccess;
+	hipLaunchKernelGGL(k_xform_scatter, dim3((n + 255u) / 256u), dim3(256), 0, s, w, slot_of_entity, entity,
+		(const TransformAoS*)transforms, n);
+	return hipGetLastError();
+}
+
+hipError_t launch_sphere_refresh(hipStream_t s, const WorldDevice& w, const uint32_t* bound_slot, const uint32_t* bound_sphere,
+	const float* model_radius, const uint32_t* sphere_cell, const CellKey* cells, float4* spheres, uint32_t n, uint32_t* rebin_count,
+	RebinItem* rebin) {
+	if (!n) return hipSuccess;
+	hipLaunchKernelGGL(k_sphere_refresh, dim3((n + 255u) / 256u), dim3(256), 0, s, w, bound_slot, bound_sphere, model_radius,
+		sphere_cell, cells, spheres, n, rebin_count, rebin);
+	return hipGetLastError();
+}
+
+} // namespace lmx

@@ -1,0 +1,114 @@
+"""Seeded synthetic scenes for the BASELINE.json configs. Pure numpy, no oracle, no GPU.
+
+All generators are deterministic in ``seed`` (numpy PCG64) so the CPU oracle and the HIP path see identical
+inputs. Frusta are *not* built here: they come from the reference's own frustum construction (oracle) in tests
+or from ``lumixengine_amd.frustum`` (the host mirror of core/geometry.cpp) in the product.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+TRANSFORM = np.dtype([("pos", "<f8", 3), ("rot", "<f4", 4), ("scale", "<f4", 3), ("_pad", "<f4")], align=True)
+LOCAL_RIGID = np.dtype([("pos", "<f4", 3), ("rot", "<f4", 4)], align=True)
+SKIN = np.dtype([("weights", "<f4", 4), ("indices", "<i2", 4)], align=True)
+
+
+def cull_scene(n: int, half_extent: float, seed: int = 1, big_fraction: float = 0.001, mixed_types: bool = False):
+    """n bounding spheres in the cube [-half_extent, half_extent]^3 (fp64 positions).
+
+    radii: log-uniform in [0.5, 50]; ``big_fraction`` of them in (300, 900] ("big" cells, culling_system.cpp:140).
+    types: all MESH, or 90 % MESH / 5 % LOCAL_LIGHT / 5 % DECAL when ``mixed_types`` (config 5).
+    Returns dict(entity int32[n], type uint8[n], pos float64[n,3], radius float32[n]).
+    """
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-half_extent, half_extent, size=(n, 3))
+    radius = np.exp(rng.uniform(np.log(0.5), np.log(50.0), size=n)).astype(np.float32)
+    n_big = int(n * big_fraction)
+    if n_big:
+        idx = rng.choice(n, size=n_big, replace=False)
+        radius[idx] = rng.uniform(300.0, 900.0, size=n_big).astype(np.float32) + np.float32(1e-3)
+    if mixed_types:
+        r = rng.random(n)
+        type_ = np.where(r < 0.90, 0, np.where(r < 0.95, 2, 1)).astype(np.uint8)
+    else:
+        type_ = np.zeros(n, np.uint8)
+    entity = np.arange(n, dtype=np.int32)
+    return {"entity": entity, "type": type_, "pos": np.ascontiguousarray(pos), "radius": radius}
+
+
+def random_unit_quats(rng, n: int) -> np.ndarray:
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q.astype(np.float32)
+
+
+def random_transforms(rng, n: int, pos_extent: float, scale_lo=0.5, scale_hi=2.0) -> np.ndarray:
+    t = np.zeros(n, TRANSFORM)
+    t["pos"] = rng.uniform(-pos_extent, pos_extent, size=(n, 3))
+    t["rot"] = random_unit_quats(rng, n)
+    t["scale"] = rng.uniform(scale_lo, scale_hi, size=(n, 3)).astype(np.float32)
+    return t
+
+
+def hierarchy_chains(n_roots: int, depth: int, seed: int = 2, root_extent: float = 5000.0):
+    """n_roots chains of ``depth`` nodes (root + depth-1 descendants). Entity ids: level-major (roots first).
+
+    Returns dict(parent int32[n] (-1 for roots), local TRANSFORM[n] (for roots: the world transform)).
+    """
+    rng = np.random.default_rng(seed)
+    n = n_roots * depth
+    parent = np.full(n, -1, np.int32)
+    for lvl in range(1, depth):
+        parent[lvl * n_roots : (lvl + 1) * n_roots] = np.arange((lvl - 1) * n_roots, lvl * n_roots, dtype=np.int32)
+    local = random_transforms(rng, n, 10.0)
+    local["pos"][:n_roots] = rng.uniform(-root_extent, root_extent, size=(n_roots, 3))
+    return {"parent": parent, "local": local, "n_roots": n_roots, "depth": depth}
+
+
+def hierarchy_fans(n_roots: int, fanout: int, depth: int, seed: int = 3, root_extent: float = 5000.0):
+    """n_roots trees where every node of level < depth-1 has ``fanout`` children (1k roots x 10 x 10 x 10 in config 3)."""
+    rng = np.random.default_rng(seed)
+    counts = [n_roots * fanout**lvl for lvl in range(depth)]
+    n = sum(counts)
+    parent = np.full(n, -1, np.int32)
+    start = 0
+    for lvl in range(1, depth):
+        prev_start, prev_n = start, counts[lvl - 1]
+        start += prev_n
+        parent[start : start + counts[lvl]] = prev_start + np.arange(counts[lvl], dtype=np.int32) // fanout
+    local = random_transforms(rng, n, 10.0)
+    local["pos"][:n_roots] = rng.uniform(-root_extent, root_extent, size=(n_roots, 3))
+    return {"parent": parent, "local": local, "n_roots": n_roots, "depth": depth}
+
+
+def skeleton(n_bones: int = 64, seed: int = 4):
+    """Random bone tree with parent < child (renderer/model.cpp:381-384), random rigid bind pose (model space)."""
+    rng = np.random.default_rng(seed)
+    parents = np.full(n_bones, -1, np.int16)
+    for i in range(1, n_bones):
+        parents[i] = rng.integers(max(0, i - 8), i)
+    bind = np.zeros(n_bones, LOCAL_RIGID)
+    bind["pos"] = rng.uniform(-1.0, 1.0, size=(n_bones, 3)).astype(np.float32)
+    bind["rot"] = random_unit_quats(rng, n_bones)
+    return {"parents": parents, "bind": bind, "first_nonroot": 1}
+
+
+def relative_poses(n_instances: int, n_bones: int, seed: int = 5):
+    """Per-instance *relative* poses: random small offsets + random unit rotations (fp32)."""
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-0.5, 0.5, size=(n_instances, n_bones, 3)).astype(np.float32)
+    rot = random_unit_quats(rng, n_instances * n_bones).reshape(n_instances, n_bones, 4)
+    return pos, rot
+
+
+def skinned_mesh(n_verts: int, n_bones: int = 64, seed: int = 6):
+    """Vertex positions + Mesh::Skin{weights decoded from u16/65535 (model.cpp:542-550), 4 bone indices}."""
+    rng = np.random.default_rng(seed)
+    verts = rng.uniform(-1.0, 1.0, size=(n_verts, 3)).astype(np.float32)
+    w = rng.random((n_verts, 4))
+    w /= w.sum(axis=1, keepdims=True)
+    w16 = np.round(w * 65535.0).astype(np.uint16)
+    skin = np.zeros(n_verts, SKIN)
+    skin["weights"] = (w16.astype(np.float32) / np.float32(65535.0)).astype(np.float32)
+    skin["indices"] = rng.integers(0, n_bones, size=(n_verts, 4)).astype(np.int16)
+    return verts, skin

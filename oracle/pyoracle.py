@@ -1,0 +1,326 @@
+"""pyoracle — TEST INFRASTRUCTURE: ctypes bindings for the CPU oracle libraries.
+
+Two libraries export the same functions under different prefixes:
+
+* ``orc_*``  oracle/liblmx_oracle.so      plain-C restatement (oracle/lmx_oracle.c), always buildable
+* ``ref_*``  oracle/_ref/liblmx_ref.so    the reference's own math.cpp/geometry.cpp object code + driver shim
+                                           (oracle/ref/ref_shim.cpp); only buildable where /root/reference exists,
+                                           but the built .so travels with the repo snapshot
+
+Only tests/, bench.py's ``cpu_baseline`` leg and ``__graft_entry__.smoke()`` may import this module. The product
+package (lumixengine_amd) must never import it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liblmx_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "liblmx_ref.so")
+
+# numpy mirrors of include/lmx_types.h
+SHIFTED_FRUSTUM = np.dtype(
+    [("xs", "<f4", 8), ("ys", "<f4", 8), ("zs", "<f4", 8), ("ds", "<f4", 8), ("points", "<f4", (8, 3)), ("origin", "<f8", 3), ("_pad", "<f8")],
+    align=True,
+)
+FRUSTUM = np.dtype([("xs", "<f4", 8), ("ys", "<f4", 8), ("zs", "<f4", 8), ("ds", "<f4", 8), ("points", "<f4", (8, 3))], align=True)
+TRANSFORM = np.dtype([("pos", "<f8", 3), ("rot", "<f4", 4), ("scale", "<f4", 3), ("_pad", "<f4")], align=True)
+LOCAL_RIGID = np.dtype([("pos", "<f4", 3), ("rot", "<f4", 4)], align=True)
+MATRIX = np.dtype([("columns", "<f4", (4, 4))], align=True)
+SKIN = np.dtype([("weights", "<f4", 4), ("indices", "<i2", 4)], align=True)
+VIEWPORT = np.dtype(
+    [("is_ortho", "<i4"), ("fov", "<f4"), ("ortho_size", "<f4"), ("w", "<i4"), ("h", "<i4"), ("pos", "<f8", 3), ("rot", "<f4", 4), ("near_plane", "<f4"), ("far_plane", "<f4")],
+    align=True,
+)
+assert SHIFTED_FRUSTUM.itemsize == 256 and FRUSTUM.itemsize == 224 and TRANSFORM.itemsize == 56
+assert LOCAL_RIGID.itemsize == 28 and MATRIX.itemsize == 64 and SKIN.itemsize == 24
+
+
+def build(force: bool = False) -> None:
+    """Build the C oracle (always) and oracle/_ref (only where the reference tree exists)."""
+    args = ["make", "-s", "-f", os.path.join(HERE, "Makefile")]
+    if force:
+        args.append("-B")
+    subprocess.run(args + ["oracle"], check=True)
+    subprocess.run(args + ["ref"], check=True)
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64x3(v) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(3))
+
+
+def _f32x3(v) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(3))
+
+
+class Oracle:
+    """Uniform wrapper over either oracle library. ``kind`` is 'port' (orc_*) or 'reference' (ref_*)."""
+
+    def __init__(self, kind: str = "port"):
+        if kind == "port":
+            path, self.prefix = ORACLE_SO, "orc_"
+        elif kind == "reference":
+            path, self.prefix = REF_SO, "ref_"
+        else:
+            raise ValueError(kind)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not built (run oracle.pyoracle.build())")
+        self.kind = kind
+        self.lib = C.CDLL(path)
+        self._declare()
+
+    def _fn(self, name, restype, argtypes):
+        f = getattr(self.lib, self.prefix + name)
+        f.restype = restype
+        f.argtypes = argtypes
+        return f
+
+    def _declare(self):
+        vp, u32, i32, u8, f32, ci = C.c_void_p, C.c_uint32, C.c_int32, C.c_uint8, C.c_float, C.c_int
+        self.f_cs_create = self._fn("cs_create", vp, [])
+        self.f_cs_destroy = self._fn("cs_destroy", None, [vp])
+        self.f_cs_add = self._fn("cs_add", None, [vp, i32, u8, vp, f32])
+        self.f_cs_add_bulk = self._fn("cs_add_bulk", None, [vp, u32, vp, vp, vp, vp])
+        self.f_cs_remove = self._fn("cs_remove", None, [vp, i32])
+        self.f_cs_set = self._fn("cs_set", None, [vp, i32, vp, f32])
+        self.f_cs_set_position = self._fn("cs_set_position", None, [vp, i32, vp])
+        self.f_cs_set_radius = self._fn("cs_set_radius", None, [vp, i32, f32])
+        self.f_cs_get_radius = self._fn("cs_get_radius", f32, [vp, i32])
+        self.f_cs_is_added = self._fn("cs_is_added", ci, [vp, i32])
+        self.f_cs_cell_count = self._fn("cs_cell_count", u32, [vp])
+        self.f_cs_cull = self._fn("cs_cull", u32, [vp, vp, u8, ci, vp, vp, u32, vp])
+        self.f_viewport_frustum = self._fn("viewport_frustum", None, [vp, vp])
+        self.f_frustum_perspective = self._fn("frustum_perspective", None, [vp, vp, vp, f32, f32, f32, f32, vp])
+        self.f_frustum_ortho = self._fn("frustum_ortho", None, [vp, vp, vp, f32, f32, f32, f32, vp])
+        self.f_contains_aabb = self._fn("contains_aabb", ci, [vp, vp, vp])
+        self.f_intersects_aabb = self._fn("intersects_aabb", ci, [vp, vp, vp])
+        self.f_get_relative = self._fn("get_relative", None, [vp, vp, vp])
+        self.f_compose = self._fn("compose", None, [vp, vp, vp])
+        self.f_compute_local = self._fn("compute_local", None, [vp, vp, vp])
+        self.f_world_create = self._fn("world_create", vp, [u32])
+        self.f_world_destroy = self._fn("world_destroy", None, [vp])
+        self.f_world_init_transforms = self._fn("world_init_transforms", None, [vp, u32, vp, vp])
+        self.f_world_set_parents = self._fn("world_set_parents", None, [vp, u32, vp, vp])
+        self.f_world_set_transforms = self._fn("world_set_transforms", None, [vp, u32, vp, vp])
+        self.f_world_set_local_transforms = self._fn("world_set_local_transforms", None, [vp, u32, vp, vp])
+        self.f_world_get_transforms = self._fn("world_get_transforms", None, [vp, u32, vp])
+        self.f_world_get_local_transforms = self._fn("world_get_local_transforms", None, [vp, u32, vp])
+        self.f_world_bind_culling = self._fn("world_bind_culling", None, [vp, vp, u32, vp, vp])
+        self.f_pose_compute_absolute = self._fn("pose_compute_absolute", None, [vp, vp, vp, i32, u32, u32, ci])
+        self.f_invert_bind = self._fn("invert_bind", None, [vp, vp, u32])
+        self.f_skin_matrices = self._fn("skin_matrices", None, [vp, vp, vp, vp, u32, u32, ci])
+        self.f_evaluate_skin = self._fn("evaluate_skin", None, [vp, vp, vp, vp, u32, u32, u32, ci])
+        self.f_rand_fill = self._fn("rand_fill", None, [u32, u32, u32, vp])
+        self.f_describe = self._fn("describe", C.c_char_p, [])
+
+    def describe(self) -> str:
+        return self.f_describe().decode()
+
+    # ---- frusta -----------------------------------------------------------------------------------------
+    def viewport_frustum(self, is_ortho=False, fov=np.deg2rad(60.0), ortho_size=100.0, w=1920, h=1080, pos=(0, 0, 0), rot=(0, 0, 0, 1),
+                         near=0.1, far=10000.0) -> np.ndarray:
+        vp = np.zeros(1, VIEWPORT)
+        vp["is_ortho"], vp["fov"], vp["ortho_size"], vp["w"], vp["h"] = int(is_ortho), fov, ortho_size, w, h
+        vp["pos"], vp["rot"], vp["near_plane"], vp["far_plane"] = pos, rot, near, far
+        out = np.zeros(1, SHIFTED_FRUSTUM)
+        self.f_viewport_frustum(_ptr(vp), _ptr(out))
+        return out
+
+    def frustum_perspective(self, pos, direction, up, fov, ratio, near, far) -> np.ndarray:
+        out = np.zeros(1, SHIFTED_FRUSTUM)
+        self.f_frustum_perspective(_ptr(_f64x3(pos)), _ptr(_f32x3(direction)), _ptr(_f32x3(up)), fov, ratio, near, far, _ptr(out))
+        return out
+
+    def frustum_ortho(self, pos, direction, up, width, height, near, far) -> np.ndarray:
+        out = np.zeros(1, SHIFTED_FRUSTUM)
+        self.f_frustum_ortho(_ptr(_f64x3(pos)), _ptr(_f32x3(direction)), _ptr(_f32x3(up)), width, height, near, far, _ptr(out))
+        return out
+
+    def contains_aabb(self, frustum, pos, size) -> bool:
+        return bool(self.f_contains_aabb(_ptr(frustum), _ptr(_f64x3(pos)), _ptr(_f32x3(size))))
+
+    def intersects_aabb(self, frustum, pos, size) -> bool:
+        return bool(self.f_intersects_aabb(_ptr(frustum), _ptr(_f64x3(pos)), _ptr(_f32x3(size))))
+
+    def get_relative(self, frustum, origin) -> np.ndarray:
+        out = np.zeros(1, FRUSTUM)
+        self.f_get_relative(_ptr(frustum), _ptr(_f64x3(origin)), _ptr(out))
+        return out
+
+    # ---- transforms -------------------------------------------------------------------------------------
+    def compose(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        out = np.zeros(len(a), TRANSFORM)
+        for i in range(len(a)):
+            self.f_compose(_ptr(a[i : i + 1]), _ptr(b[i : i + 1]), _ptr(out[i : i + 1]))
+        return out
+
+    def compute_local(self, parent: np.ndarray, child: np.ndarray) -> np.ndarray:
+        out = np.zeros(len(parent), TRANSFORM)
+        for i in range(len(parent)):
+            self.f_compute_local(_ptr(parent[i : i + 1]), _ptr(child[i : i + 1]), _ptr(out[i : i + 1]))
+        return out
+
+    # ---- pose / skin ------------------------------------------------------------------------------------
+    def pose_compute_absolute(self, positions, rotations, parents, first_nonroot, n_threads=1):
+        """positions [I, B, 3] f32, rotations [I, B, 4] f32 (copied); returns absolute (positions, rotations)."""
+        pos = np.array(positions, dtype=np.float32, order="C", copy=True)
+        rot = np.array(rotations, dtype=np.float32, order="C", copy=True)
+        par = np.ascontiguousarray(parents, dtype=np.int16)
+        n_inst, count = pos.shape[0], pos.shape[1]
+        self.f_pose_compute_absolute(_ptr(pos), _ptr(rot), _ptr(par), int(first_nonroot), count, n_inst, n_threads)
+        return pos, rot
+
+    def invert_bind(self, bind: np.ndarray) -> np.ndarray:
+        bind = np.ascontiguousarray(bind, dtype=LOCAL_RIGID)
+        out = np.zeros(len(bind), LOCAL_RIGID)
+        self.f_invert_bind(_ptr(bind), _ptr(out), len(bind))
+        return out
+
+    def skin_matrices(self, pose_pos, pose_rot, inv_bind, n_threads=1) -> np.ndarray:
+        pos = np.ascontiguousarray(pose_pos, dtype=np.float32)
+        rot = np.ascontiguousarray(pose_rot, dtype=np.float32)
+        inv = np.ascontiguousarray(inv_bind, dtype=LOCAL_RIGID)
+        n_inst, count = pos.shape[0], pos.shape[1]
+        out = np.zeros((n_inst, count), MATRIX)
+        self.f_skin_matrices(_ptr(pos), _ptr(rot), _ptr(inv), _ptr(out), count, n_inst, n_threads)
+        return out
+
+    def evaluate_skin(self, verts, skin, palettes, n_threads=1) -> np.ndarray:
+        verts = np.ascontiguousarray(verts, dtype=np.float32)
+        skin = np.ascontiguousarray(skin, dtype=SKIN)
+        palettes = np.ascontiguousarray(palettes, dtype=MATRIX)
+        n_inst, n_bones = palettes.shape[0], palettes.shape[1]
+        out = np.zeros((n_inst, len(verts), 3), np.float32)
+        self.f_evaluate_skin(_ptr(verts), _ptr(skin), _ptr(palettes), _ptr(out), len(verts), n_bones, n_inst, n_threads)
+        return out
+
+    def rand_fill(self, u: int, v: int, n: int) -> np.ndarray:
+        out = np.zeros(n, np.uint32)
+        self.f_rand_fill(u, v, n, _ptr(out))
+        return out
+
+    def culling_system(self) -> "OracleCullingSystem":
+        return OracleCullingSystem(self)
+
+    def world(self, n_entities: int) -> "OracleWorld":
+        return OracleWorld(self, n_entities)
+
+
+class OracleCullingSystem:
+    """CullingSystem (renderer/culling_system.h:58-77) on the CPU oracle."""
+
+    def __init__(self, oracle: Oracle):
+        self.o = oracle
+        self.h = oracle.f_cs_create()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.o.f_cs_destroy(self.h)
+            self.h = None
+
+    def add(self, entity, type_, pos, radius):
+        self.o.f_cs_add(self.h, int(entity), int(type_), _ptr(_f64x3(pos)), float(radius))
+
+    def add_bulk(self, entity, type_, pos, radius):
+        entity = np.ascontiguousarray(entity, np.int32)
+        type_ = np.ascontiguousarray(type_, np.uint8)
+        pos = np.ascontiguousarray(pos, np.float64)
+        radius = np.ascontiguousarray(radius, np.float32)
+        self.o.f_cs_add_bulk(self.h, len(entity), _ptr(entity), _ptr(type_), _ptr(pos), _ptr(radius))
+
+    def remove(self, entity):
+        self.o.f_cs_remove(self.h, int(entity))
+
+    def set(self, entity, pos, radius):
+        self.o.f_cs_set(self.h, int(entity), _ptr(_f64x3(pos)), float(radius))
+
+    def set_position(self, entity, pos):
+        self.o.f_cs_set_position(self.h, int(entity), _ptr(_f64x3(pos)))
+
+    def set_radius(self, entity, radius):
+        self.o.f_cs_set_radius(self.h, int(entity), float(radius))
+
+    def get_radius(self, entity) -> float:
+        return float(self.o.f_cs_get_radius(self.h, int(entity)))
+
+    def is_added(self, entity) -> bool:
+        return bool(self.o.f_cs_is_added(self.h, int(entity)))
+
+    def cell_count(self) -> int:
+        return int(self.o.f_cs_cell_count(self.h))
+
+    def cull(self, frustum: np.ndarray, type_: int = 0xFF, n_threads: int = 1, cap: Optional[int] = None, want_ids=True):
+        """Returns (ids[int32], types[uint8], n_result_pages). Order is unspecified, like the reference's."""
+        if cap is None:
+            cap = int(self.o.f_cs_cull(self.h, _ptr(frustum), type_, n_threads, None, None, 0, None))
+        ids = np.zeros(cap, np.int32) if want_ids else None
+        types = np.zeros(cap, np.uint8) if want_ids else None
+        pages = C.c_uint32(0)
+        n = int(self.o.f_cs_cull(self.h, _ptr(frustum), type_, n_threads, _ptr(ids), _ptr(types), cap, C.byref(pages)))
+        if want_ids:
+            return ids[: min(n, cap)], types[: min(n, cap)], pages.value
+        return n, pages.value
+
+
+class OracleWorld:
+    """World transform/hierarchy subset (engine/world.cpp) on the CPU oracle."""
+
+    def __init__(self, oracle: Oracle, n_entities: int):
+        self.o = oracle
+        self.n = n_entities
+        self.h = oracle.f_world_create(n_entities)
+        self._cs = None
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.o.f_world_destroy(self.h)
+            self.h = None
+
+    def init_transforms(self, entity, tr):
+        entity = np.ascontiguousarray(entity, np.int32)
+        tr = np.ascontiguousarray(tr, TRANSFORM)
+        self.o.f_world_init_transforms(self.h, len(entity), _ptr(entity), _ptr(tr))
+
+    def set_parents(self, parent, child):
+        parent = np.ascontiguousarray(parent, np.int32)
+        child = np.ascontiguousarray(child, np.int32)
+        self.o.f_world_set_parents(self.h, len(child), _ptr(parent), _ptr(child))
+
+    def set_transforms(self, entity, tr):
+        entity = np.ascontiguousarray(entity, np.int32)
+        tr = np.ascontiguousarray(tr, TRANSFORM)
+        self.o.f_world_set_transforms(self.h, len(entity), _ptr(entity), _ptr(tr))
+
+    def set_local_transforms(self, entity, tr):
+        entity = np.ascontiguousarray(entity, np.int32)
+        tr = np.ascontiguousarray(tr, TRANSFORM)
+        self.o.f_world_set_local_transforms(self.h, len(entity), _ptr(entity), _ptr(tr))
+
+    def get_transforms(self) -> np.ndarray:
+        out = np.zeros(self.n, TRANSFORM)
+        self.o.f_world_get_transforms(self.h, self.n, _ptr(out))
+        return out
+
+    def get_local_transforms(self) -> np.ndarray:
+        out = np.zeros(self.n, TRANSFORM)
+        self.o.f_world_get_local_transforms(self.h, self.n, _ptr(out))
+        return out
+
+    def bind_culling(self, cs: OracleCullingSystem, entity, model_radius):
+        entity = np.ascontiguousarray(entity, np.int32)
+        model_radius = np.ascontiguousarray(model_radius, np.float32)
+        self._cs = cs
+        self.o.f_world_bind_culling(self.h, cs.h, len(entity), _ptr(entity), _ptr(model_radius))
+
+
+def have_reference() -> bool:
+    return os.path.exists(REF_SO)

@@ -1,0 +1,698 @@
+// ref_shim.cpp — TEST INFRASTRUCTURE. C-ABI shim over the *reference's own object code*.
+//
+// Compiled only where /root/reference exists (oracle/Makefile target `ref`), together with the reference's
+// src/core/math.cpp and src/core/geometry.cpp compiled in place; the result goes to oracle/_ref/liblmx_ref.so.
+// Every arithmetic operation below is executed by reference symbols (Vec3/DVec3/Quat/Transform/Matrix/
+// LocalRigidTransform/Frustum/ShiftedFrustum/Viewport methods and the scalar float4 of core/simd.h).
+// The *drivers* that cannot compile on Linux at this snapshot (core/sync.h:20-24 `#error`, missing float4
+// helpers for pose.cpp) are restated here, each citing the lines it follows:
+//   CullingSystemImpl            renderer/culling_system.cpp:23-384
+//   World hierarchy              engine/world.cpp:255-282, 337-361, 619-754
+//   Pose::computeAbsolute        renderer/pose.cpp:129-130 (scalar recurrence; the 4-wide path :69-127 is
+//                                arithmetically identical, see core/simd_math.h:47-91)
+//   invert/computeSkinMatrices/evaluateSkin   renderer/model.cpp:24-30, 132-137, 103-109
+//
+// Nothing in the product (lumixengine_amd/) may link or load this file; only tests/, bench.py's cpu_baseline
+// leg and __graft_entry__.smoke() do.
+
+#include "core/geometry.h"
+#include "core/math.h"
+#include "core/simd.h"
+#include "core/os.h"
+
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "lmx_types.h"
+
+using namespace Lumix;
+
+// the single link stub (declared core/os.h, used only by Lumix::rand(), core/math.cpp:1346)
+namespace Lumix::os {
+u64 Timer::getRawTimestamp() { return 1; }
+} // namespace Lumix::os
+
+static_assert(sizeof(ShiftedFrustum) == sizeof(LmxShiftedFrustum), "ShiftedFrustum layout");
+static_assert(sizeof(Frustum) == sizeof(LmxFrustum), "Frustum layout");
+static_assert(sizeof(Transform) == sizeof(LmxTransform), "Transform layout");
+static_assert(sizeof(LocalRigidTransform) == sizeof(LmxLocalRigidTransform), "LocalRigidTransform layout");
+static_assert(sizeof(Matrix) == sizeof(LmxMatrix), "Matrix layout");
+static_assert(sizeof(Sphere) == 16, "Sphere layout");
+
+static ShiftedFrustum toRef(const LmxShiftedFrustum* f) {
+	ShiftedFrustum r;
+	memcpy((void*)&r, f, sizeof(r));
+	return r;
+}
+static Transform toRef(const LmxTransform* t) {
+	Transform r;
+	memcpy((void*)&r, t, sizeof(r));
+	return r;
+}
+static void fromRef(const Transform& t, LmxTransform* out) {
+	memset(out, 0, sizeof(*out));
+	memcpy(out->pos, &t.pos, sizeof(out->pos));
+	memcpy(out->rot, &t.rot, sizeof(out->rot));
+	memcpy(out->scale, &t.scale, sizeof(out->scale));
+}
+static void fromRef(const ShiftedFrustum& f, LmxShiftedFrustum* out) {
+	memset(out, 0, sizeof(*out));
+	memcpy(out->xs, f.xs, sizeof(f.xs));
+	memcpy(out->ys, f.ys, sizeof(f.ys));
+	memcpy(out->zs, f.zs, sizeof(f.zs));
+	memcpy(out->ds, f.ds, sizeof(f.ds));
+	memcpy(out->points, f.points, sizeof(f.points));
+	memcpy(out->origin, &f.origin, sizeof(out->origin));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// culling system (driver restated, arithmetic = reference symbols)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr size_t PAGE_SIZE = 4096;
+
+struct CellIndices { // culling_system.cpp:23-40
+	CellIndices() {}
+	CellIndices(const DVec3& p, float cell_size, u8 type, bool is_big)
+		: pos(p * (1 / cell_size)), is_big(is_big), type(type) {}
+	bool operator==(const CellIndices& rhs) const { return pos == rhs.pos && type == rhs.type && is_big == rhs.is_big; }
+	IVec3 pos;
+	u8 type;
+	bool is_big;
+};
+
+struct CellIndicesHasher { // culling_system.cpp:43-50
+	size_t operator()(const CellIndices& i) const {
+		return (u32)i.pos.x * 73856093 + (u32)i.pos.y * 19349663 + (u32)i.pos.z * 83492791;
+	}
+};
+
+struct alignas(4096) CellPage { // culling_system.cpp:53-65
+	struct {
+		CellPage* next = nullptr;
+		CellPage* prev = nullptr;
+		DVec3 origin;
+		CellIndices indices;
+		int count = 0;
+	} header;
+	enum { MAX_COUNT = (PAGE_SIZE - sizeof(header)) / (sizeof(Sphere) + sizeof(i32)) };
+	Sphere spheres[MAX_COUNT];
+	i32 entities[MAX_COUNT];
+};
+static_assert(sizeof(CellPage) == PAGE_SIZE, "CellPage must be one page");
+static_assert((int)CellPage::MAX_COUNT == (int)LMX_CULL_PAGE_SPHERES, "201 slots");
+
+struct ResultPage { // CullResult, culling_system.h:17-56
+	struct {
+		ResultPage* next = nullptr;
+		u32 count = 0;
+		u8 type;
+	} header;
+	i32 entities[(4096 - sizeof(header)) / sizeof(i32)];
+};
+static_assert(sizeof(ResultPage) == PAGE_SIZE, "CullResult must be one page");
+
+struct PagedResultList { // PagedList<CullResult>, core/page_allocator.h:60-109 (mutex-guarded push)
+	ResultPage* begin = nullptr;
+	ResultPage* end = nullptr;
+	std::atomic_flag lock = ATOMIC_FLAG_INIT;
+	ResultPage* push() {
+		void* mem = aligned_alloc(PAGE_SIZE, PAGE_SIZE);
+		ResultPage* page = new (mem) ResultPage;
+		while (lock.test_and_set(std::memory_order_acquire)) {}
+		if (!begin) begin = end = page;
+		else { end->header.next = page; page->header.next = nullptr; end = page; }
+		lock.clear(std::memory_order_release);
+		return page;
+	}
+};
+
+// jobs::forEach stand-in, core/job_system.h:131-180: min(workers, steps) jobs pulling from one atomic cursor
+template <typename F> void forEachJob(u32 count, int n_threads, const F& f) {
+	if (n_threads <= 1 || count <= 1) {
+		for (u32 i = 0; i < count; ++i) f(i);
+		return;
+	}
+	std::atomic<u32> cursor{0};
+	auto worker = [&]() {
+		for (;;) {
+			const u32 i = cursor.fetch_add(1, std::memory_order_relaxed);
+			if (i >= count) return;
+			f(i);
+		}
+	};
+	std::vector<std::thread> threads;
+	const int n = n_threads < (int)count ? n_threads : (int)count;
+	for (int t = 1; t < n; ++t) threads.emplace_back(worker);
+	worker();
+	for (auto& t : threads) t.join();
+}
+
+struct CullingSystemRef {
+	std::unordered_map<CellIndices, CellPage*, CellIndicesHasher> m_cell_map;
+	std::vector<CellPage*> m_cells;
+	std::vector<Sphere*> m_entity_to_cell;
+	float m_cell_size = 300.0f; // culling_system.cpp:75
+
+	~CullingSystemRef() {
+		for (CellPage* p : m_cells) free(p);
+	}
+
+	static CellPage* newPage() {
+		void* mem = aligned_alloc(PAGE_SIZE, PAGE_SIZE);
+		return new (mem) CellPage;
+	}
+
+	Sphere* addToCell(CellPage& cell, i32 entity, const DVec3& pos, float radius) { // :98-128
+		const Vec3 rel_pos = Vec3(pos - cell.header.origin);
+		const int count = cell.header.count;
+		if (count < CellPage::MAX_COUNT - 1) {
+			cell.spheres[count] = {rel_pos, radius};
+			cell.entities[count] = entity;
+			++cell.header.count;
+			return &cell.spheres[count];
+		}
+		CellPage* new_cell = newPage();
+		new_cell->header.origin = cell.header.origin;
+		new_cell->header.indices = cell.header.indices;
+		new_cell->header.next = &cell;
+		new_cell->header.prev = cell.header.prev;
+		new_cell->header.next->header.prev = new_cell;
+		if (new_cell->header.prev) new_cell->header.prev->header.next = new_cell;
+		m_cells.push_back(new_cell);
+		if (!new_cell->header.prev) m_cell_map[new_cell->header.indices] = new_cell;
+		new_cell->spheres[0] = {rel_pos, radius};
+		new_cell->entities[0] = entity;
+		new_cell->header.count = 1;
+		return &new_cell->spheres[0];
+	}
+
+	void add(i32 entity, u8 type, const DVec3& pos, float radius) { // :131-157
+		if ((i32)m_entity_to_cell.size() <= entity) m_entity_to_cell.resize(entity + 1, nullptr);
+		const CellIndices i(pos, m_cell_size, type, radius > m_cell_size);
+		auto iter = m_cell_map.find(i);
+		if (iter == m_cell_map.end()) {
+			CellPage* new_cell = newPage();
+			new_cell->header.origin = i.pos * double(m_cell_size);
+			new_cell->header.indices = i;
+			iter = m_cell_map.emplace(i, new_cell).first;
+			m_cells.push_back(new_cell);
+		}
+		CellPage& cell = *iter->second;
+		m_entity_to_cell[entity] = addToCell(cell, entity, pos, radius);
+	}
+
+	CellPage& getCell(const Sphere& sphere) const { // :193-198
+		const intptr_t ptr = (intptr_t)&sphere;
+		return *(CellPage*)(ptr - (ptr % (intptr_t)PAGE_SIZE));
+	}
+
+	void remove(i32 entity) { // :160-190
+		if ((i32)m_entity_to_cell.size() <= entity) return;
+		const Sphere* sphere = m_entity_to_cell[entity];
+		if (!sphere) return;
+		CellPage& cell = getCell(*sphere);
+		if (cell.header.count == 1) {
+			if (!cell.header.prev) {
+				if (!cell.header.next) m_cell_map.erase(cell.header.indices);
+				else m_cell_map[cell.header.indices] = cell.header.next;
+			}
+			if (cell.header.prev) cell.header.prev->header.next = cell.header.next;
+			if (cell.header.next) cell.header.next->header.prev = cell.header.prev;
+			for (size_t k = 0; k < m_cells.size(); ++k) { // swapAndPopItem
+				if (m_cells[k] == &cell) { m_cells[k] = m_cells.back(); m_cells.pop_back(); break; }
+			}
+			free(&cell);
+		} else {
+			const int idx = int(sphere - cell.spheres);
+			const i32 last = cell.entities[cell.header.count - 1];
+			cell.entities[idx] = cell.entities[cell.header.count - 1];
+			cell.spheres[idx] = cell.spheres[cell.header.count - 1];
+			m_entity_to_cell[last] = &cell.spheres[idx];
+			--cell.header.count;
+		}
+		m_entity_to_cell[entity] = nullptr;
+	}
+
+	void setPosition(i32 entity, const DVec3& pos) { // :201-217
+		Sphere* sphere = m_entity_to_cell[entity];
+		CellPage& cell = getCell(*sphere);
+		const IVec3 new_indices(pos * (1 / m_cell_size));
+		if (new_indices == cell.header.indices.pos) {
+			sphere->position = Vec3(pos - cell.header.origin);
+			return;
+		}
+		const float radius = sphere->radius;
+		const u8 type = cell.header.indices.type;
+		remove(entity);
+		add(entity, type, pos, radius);
+	}
+
+	void set(i32 entity, const DVec3& pos, float radius) { // :225-242
+		Sphere* sphere = m_entity_to_cell[entity];
+		CellPage& cell = getCell(*sphere);
+		const IVec3 new_indices(pos * (1 / m_cell_size));
+		const bool was_big = cell.header.indices.is_big;
+		const bool is_big = radius > m_cell_size;
+		if (was_big == is_big && new_indices == cell.header.indices.pos) {
+			sphere->radius = radius;
+			sphere->position = Vec3(pos - cell.header.origin);
+			return;
+		}
+		const u8 type = cell.header.indices.type;
+		remove(entity);
+		add(entity, type, pos, radius);
+	}
+
+	void setRadius(i32 entity, float radius) { // :244-260
+		Sphere* sphere = m_entity_to_cell[entity];
+		CellPage& cell = getCell(*sphere);
+		const bool was_big = cell.header.indices.is_big;
+		const bool is_big = radius > m_cell_size;
+		if (was_big == is_big) {
+			sphere->radius = radius;
+			return;
+		}
+		const u8 type = cell.header.indices.type;
+		const DVec3 pos = cell.header.origin + sphere->position;
+		remove(entity);
+		add(entity, type, pos, radius);
+	}
+
+	// doCulling, :262-308 — the reference's scalar float4 (core/simd.h:203-449) does the arithmetic
+	void doCulling(const CellPage& cell, const Frustum& frustum, ResultPage* results, PagedResultList& list, u8 type) {
+		const Sphere* start = cell.spheres;
+		const Sphere* end = cell.spheres + cell.header.count;
+		const i32* sphere_to_entity_map = cell.entities;
+		const float4 px = f4Load(frustum.xs);
+		const float4 py = f4Load(frustum.ys);
+		const float4 pz = f4Load(frustum.zs);
+		const float4 pd = f4Load(frustum.ds);
+		const float4 px2 = f4Load(&frustum.xs[4]);
+		const float4 py2 = f4Load(&frustum.ys[4]);
+		const float4 pz2 = f4Load(&frustum.zs[4]);
+		const float4 pd2 = f4Load(&frustum.ds[4]);
+		int cursor = results->header.count;
+		int i = 0;
+		for (const Sphere* sphere = start; sphere < end; ++sphere, ++i) {
+			const float4 cx = f4Splat(sphere->position.x);
+			const float4 cy = f4Splat(sphere->position.y);
+			const float4 cz = f4Splat(sphere->position.z);
+			const float4 r = f4Splat(-sphere->radius);
+			float4 t = cx * px + cy * py + cz * pz + pd;
+			t = t - r;
+			if (f4MoveMask(t)) continue;
+			t = cx * px2 + cy * py2 + cz * pz2 + pd2;
+			t = t - r;
+			if (f4MoveMask(t)) continue;
+			if (cursor == (int)lengthOf(results->entities)) {
+				results->header.count = cursor;
+				results = list.push();
+				results->header.type = type;
+				cursor = 0;
+			}
+			results->entities[cursor] = sphere_to_entity_map[i];
+			++cursor;
+		}
+		results->header.count = cursor;
+	}
+
+	ResultPage* cullInternal(const ShiftedFrustum& frustum, u8 type, int n_threads) { // :321-369
+		if (m_cells.empty()) return nullptr;
+		PagedResultList list;
+		const Vec3 v3_cell_size(m_cell_size);
+		const Vec3 v3_2_cell_size(2 * m_cell_size);
+		forEachJob((u32)m_cells.size(), n_threads, [&](u32 cell_idx) {
+			ResultPage* result = nullptr;
+			CellPage& cell = *m_cells[cell_idx];
+			if (type != 0xff && cell.header.indices.type != type) return;
+			if (!result || result->header.type != cell.header.indices.type) {
+				result = list.push();
+				result->header.type = cell.header.indices.type;
+			}
+			if (cell.header.indices.is_big) {
+				doCulling(cell, frustum.getRelative(cell.header.origin), result, list, cell.header.indices.type);
+			} else if (frustum.containsAABB(cell.header.origin + v3_cell_size, v3_cell_size)) {
+				int to_cpy = cell.header.count;
+				int src_offset = 0;
+				while (to_cpy > 0) {
+					if (result->header.count == lengthOf(result->entities)) {
+						result = list.push();
+						result->header.type = cell.header.indices.type;
+					}
+					const int rem_space = lengthOf(result->entities) - result->header.count;
+					const int step = minimum(to_cpy, rem_space);
+					memcpy(result->entities + result->header.count, cell.entities + src_offset, step * sizeof(cell.entities[0]));
+					src_offset += step;
+					result->header.count += step;
+					to_cpy -= step;
+				}
+			} else if (frustum.intersectsAABB(cell.header.origin - v3_cell_size, v3_2_cell_size)) {
+				doCulling(cell, frustum.getRelative(cell.header.origin), result, list, cell.header.indices.type);
+			}
+		});
+		ResultPage* r = list.begin;
+		list.begin = list.end = nullptr;
+		return r;
+	}
+};
+
+} // namespace
+
+extern "C" {
+
+void* ref_cs_create(void) { return new CullingSystemRef; }
+void ref_cs_destroy(void* cs) { delete (CullingSystemRef*)cs; }
+void ref_cs_add(void* cs, int32_t entity, uint8_t type, const double* pos, float radius) {
+	((CullingSystemRef*)cs)->add(entity, type, DVec3(pos[0], pos[1], pos[2]), radius);
+}
+void ref_cs_add_bulk(void* cs, uint32_t n, const int32_t* entity, const uint8_t* type, const double* pos, const float* radius) {
+	for (uint32_t i = 0; i < n; ++i) ref_cs_add(cs, entity[i], type[i], pos + 3 * (size_t)i, radius[i]);
+}
+void ref_cs_remove(void* cs, int32_t entity) { ((CullingSystemRef*)cs)->remove(entity); }
+void ref_cs_set(void* cs, int32_t entity, const double* pos, float radius) {
+	((CullingSystemRef*)cs)->set(entity, DVec3(pos[0], pos[1], pos[2]), radius);
+}
+void ref_cs_set_position(void* cs, int32_t entity, const double* pos) {
+	((CullingSystemRef*)cs)->setPosition(entity, DVec3(pos[0], pos[1], pos[2]));
+}
+void ref_cs_set_radius(void* cs, int32_t entity, float radius) { ((CullingSystemRef*)cs)->setRadius(entity, radius); }
+float ref_cs_get_radius(void* cs, int32_t entity) { return ((CullingSystemRef*)cs)->m_entity_to_cell[entity]->radius; }
+int ref_cs_is_added(void* cs, int32_t entity) {
+	auto* c = (CullingSystemRef*)cs;
+	return entity >= 0 && entity < (int32_t)c->m_entity_to_cell.size() && c->m_entity_to_cell[entity] != nullptr;
+}
+uint32_t ref_cs_cell_count(void* cs) { return (uint32_t)((CullingSystemRef*)cs)->m_cells.size(); }
+
+// Runs one cull and flattens the CullResult page list into (id, type) arrays. Returns the total count and the
+// number of result pages the reference allocated (the page traffic is part of what the CPU path pays for).
+uint32_t ref_cs_cull(void* cs, const LmxShiftedFrustum* frustum, uint8_t type, int n_threads, int32_t* out_ids,
+	uint8_t* out_types, uint32_t cap, uint32_t* out_pages) {
+	const ShiftedFrustum f = toRef(frustum);
+	ResultPage* page = ((CullingSystemRef*)cs)->cullInternal(f, type, n_threads);
+	uint32_t n = 0, pages = 0;
+	while (page) {
+		for (u32 i = 0; i < page->header.count; ++i, ++n) {
+			if (n < cap) {
+				if (out_ids) out_ids[n] = page->entities[i];
+				if (out_types) out_types[n] = page->header.type;
+			}
+		}
+		ResultPage* tmp = page;
+		page = page->header.next;
+		free(tmp); // CullResult::free, culling_system.cpp:388-396
+		++pages;
+	}
+	if (out_pages) *out_pages = pages;
+	return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// frusta
+// ---------------------------------------------------------------------------------------------------------
+void ref_viewport_frustum(const LmxViewport* vp, LmxShiftedFrustum* out) { // Viewport::getFrustum(), geometry.cpp:793-818
+	Viewport v;
+	v.is_ortho = vp->is_ortho != 0;
+	v.fov = vp->fov;
+	v.ortho_size = vp->ortho_size;
+	v.w = vp->w;
+	v.h = vp->h;
+	v.pos = DVec3(vp->pos[0], vp->pos[1], vp->pos[2]);
+	v.rot = Quat(vp->rot[0], vp->rot[1], vp->rot[2], vp->rot[3]);
+	v.near = vp->near_plane;
+	v.far = vp->far_plane;
+	fromRef(v.getFrustum(), out);
+}
+
+void ref_frustum_perspective(const double* pos, const float* dir, const float* up, float fov, float ratio, float near_d,
+	float far_d, LmxShiftedFrustum* out) { // ShiftedFrustum::computePerspective, geometry.cpp:412-419 -> :470-499
+	ShiftedFrustum f;
+	memset((void*)&f, 0, sizeof(f));
+	f.computePerspective(DVec3(pos[0], pos[1], pos[2]), Vec3(dir[0], dir[1], dir[2]), Vec3(up[0], up[1], up[2]), fov, ratio, near_d, far_d);
+	fromRef(f, out);
+}
+
+void ref_frustum_ortho(const double* pos, const float* dir, const float* up, float width, float height, float near_d,
+	float far_d, LmxShiftedFrustum* out) { // ShiftedFrustum::computeOrtho, geometry.cpp:369-387 -> :390-409
+	ShiftedFrustum f;
+	memset((void*)&f, 0, sizeof(f));
+	f.computeOrtho(DVec3(pos[0], pos[1], pos[2]), Vec3(dir[0], dir[1], dir[2]), Vec3(up[0], up[1], up[2]), width, height, near_d, far_d);
+	fromRef(f, out);
+}
+
+int ref_contains_aabb(const LmxShiftedFrustum* f, const double* pos, const float* size) {
+	return toRef(f).containsAABB(DVec3(pos[0], pos[1], pos[2]), Vec3(size[0], size[1], size[2])) ? 1 : 0;
+}
+int ref_intersects_aabb(const LmxShiftedFrustum* f, const double* pos, const float* size) {
+	return toRef(f).intersectsAABB(DVec3(pos[0], pos[1], pos[2]), Vec3(size[0], size[1], size[2])) ? 1 : 0;
+}
+void ref_get_relative(const LmxShiftedFrustum* f, const double* origin, LmxFrustum* out) {
+	const Frustum r = toRef(f).getRelative(DVec3(origin[0], origin[1], origin[2]));
+	memcpy(out, &r, sizeof(*out));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// transforms + World hierarchy
+// ---------------------------------------------------------------------------------------------------------
+void ref_compose(const LmxTransform* a, const LmxTransform* b, LmxTransform* out) { // Transform::compose, math.cpp:801-807
+	fromRef(toRef(a).compose(toRef(b)), out);
+}
+void ref_compute_local(const LmxTransform* parent, const LmxTransform* child, LmxTransform* out) { // math.cpp:809-816
+	fromRef(Transform::computeLocal(toRef(parent), toRef(child)), out);
+}
+
+namespace {
+struct WorldRef {
+	struct Hierarchy { // engine/world.h:157-164
+		i32 entity;
+		i32 parent;
+		i32 first_child;
+		i32 next_sibling;
+		Transform local_transform;
+	};
+	std::vector<Transform> m_transforms;
+	std::vector<i32> m_entity_hierarchy; // EntityData::hierarchy
+	std::vector<Hierarchy> m_hierarchy;
+	// RenderModuleImpl::onModelInstanceMoved binding, render_module.cpp:1544-1554
+	CullingSystemRef* m_culling = nullptr;
+	std::vector<float> m_model_radius; // < 0: entity has no model instance
+
+	void transformed(i32 entity) {
+		if (!m_culling || m_model_radius[entity] < 0) return;
+		if (!ref_cs_is_added(m_culling, entity)) return;
+		const Transform& tr = m_transforms[entity];
+		m_culling->set(entity, tr.pos, m_model_radius[entity] * maximum(tr.scale.x, tr.scale.y, tr.scale.z));
+	}
+
+	void transformEntity(i32 entity, bool update_local) { // world.cpp:255-282
+		transformed(entity);
+		const i32 hierarchy_idx = m_entity_hierarchy[entity];
+		if (hierarchy_idx >= 0) {
+			Hierarchy& h = m_hierarchy[hierarchy_idx];
+			const Transform my_transform = m_transforms[entity];
+			if (update_local && h.parent >= 0) {
+				const Transform parent_tr = m_transforms[h.parent];
+				h.local_transform = Transform::computeLocal(parent_tr, my_transform);
+			}
+			i32 child = h.first_child;
+			while (child >= 0) {
+				const Hierarchy& child_h = m_hierarchy[m_entity_hierarchy[child]];
+				const Transform abs_tr = my_transform.compose(child_h.local_transform);
+				m_transforms[child] = abs_tr;
+				const i32 next = child_h.next_sibling; // (recursion never mutates m_hierarchy with update_local=false)
+				transformEntity(child, false);
+				child = next;
+			}
+		}
+	}
+
+	void collectGarbage(i32 entity) { // world.cpp:629-639
+		Hierarchy& h = m_hierarchy[m_entity_hierarchy[entity]];
+		if (h.parent >= 0) return;
+		if (h.first_child >= 0) return;
+		const Hierarchy last = m_hierarchy.back();
+		m_entity_hierarchy[last.entity] = m_entity_hierarchy[entity];
+		m_entity_hierarchy[entity] = -1;
+		h = last;
+		m_hierarchy.pop_back();
+	}
+
+	void setParent(i32 new_parent, i32 child) { // world.cpp:619-701 (cycle check omitted: callers build forests)
+		i32 child_idx = m_entity_hierarchy[child];
+		if (child_idx >= 0) {
+			const i32 old_parent = m_hierarchy[child_idx].parent;
+			if (old_parent >= 0) {
+				Hierarchy& old_parent_h = m_hierarchy[m_entity_hierarchy[old_parent]];
+				i32* x = &old_parent_h.first_child;
+				while (*x >= 0) {
+					if (*x == child) {
+						*x = m_hierarchy[m_entity_hierarchy[child]].next_sibling;
+						break;
+					}
+					x = &m_hierarchy[m_entity_hierarchy[*x]].next_sibling;
+				}
+				m_hierarchy[child_idx].parent = -1;
+				m_hierarchy[child_idx].next_sibling = -1;
+				collectGarbage(old_parent);
+				child_idx = m_entity_hierarchy[child];
+			}
+		} else if (new_parent >= 0) {
+			child_idx = (i32)m_hierarchy.size();
+			m_entity_hierarchy[child] = child_idx;
+			m_hierarchy.push_back({child, -1, -1, -1, Transform::IDENTITY});
+		}
+		if (new_parent >= 0) {
+			i32 new_parent_idx = m_entity_hierarchy[new_parent];
+			if (new_parent_idx < 0) {
+				new_parent_idx = (i32)m_hierarchy.size();
+				m_entity_hierarchy[new_parent] = new_parent_idx;
+				m_hierarchy.push_back({new_parent, -1, -1, -1, Transform::IDENTITY});
+			}
+			m_hierarchy[child_idx].parent = new_parent;
+			const Transform parent_tr = m_transforms[new_parent];
+			const Transform child_tr = m_transforms[child];
+			m_hierarchy[child_idx].local_transform = Transform::computeLocal(parent_tr, child_tr);
+			m_hierarchy[child_idx].next_sibling = m_hierarchy[new_parent_idx].first_child;
+			m_hierarchy[new_parent_idx].first_child = child;
+		} else {
+			if (child_idx >= 0) collectGarbage(child);
+		}
+	}
+
+	void setTransform(i32 entity, const Transform& tr) { // world.cpp:337-342
+		m_transforms[entity] = tr;
+		transformEntity(entity, true);
+	}
+
+	void setLocalTransform(i32 entity, const Transform& tr) { // world.cpp:741-753 -> updateGlobalTransform :704-712
+		const i32 hierarchy_idx = m_entity_hierarchy[entity];
+		if (hierarchy_idx < 0) {
+			setTransform(entity, tr);
+			return;
+		}
+		Hierarchy& h = m_hierarchy[hierarchy_idx];
+		h.local_transform = tr;
+		const Transform parent_tr = m_transforms[h.parent];
+		const Transform new_tr = parent_tr.compose(h.local_transform);
+		setTransform(entity, new_tr);
+	}
+};
+} // namespace
+
+void* ref_world_create(uint32_t n_entities) {
+	WorldRef* w = new WorldRef;
+	w->m_transforms.assign(n_entities, Transform::IDENTITY);
+	w->m_entity_hierarchy.assign(n_entities, -1);
+	w->m_model_radius.assign(n_entities, -1.f);
+	return w;
+}
+void ref_world_destroy(void* w) { delete (WorldRef*)w; }
+// raw write of m_transforms without propagation (entity creation: World::createEntity / emplaceEntity)
+void ref_world_init_transforms(void* w, uint32_t n, const int32_t* entity, const LmxTransform* tr) {
+	for (uint32_t i = 0; i < n; ++i) ((WorldRef*)w)->m_transforms[entity[i]] = toRef(&tr[i]);
+}
+void ref_world_set_parents(void* w, uint32_t n, const int32_t* parent, const int32_t* child) {
+	for (uint32_t i = 0; i < n; ++i) ((WorldRef*)w)->setParent(parent[i], child[i]);
+}
+void ref_world_set_transforms(void* w, uint32_t n, const int32_t* entity, const LmxTransform* tr) {
+	for (uint32_t i = 0; i < n; ++i) ((WorldRef*)w)->setTransform(entity[i], toRef(&tr[i]));
+}
+void ref_world_set_local_transforms(void* w, uint32_t n, const int32_t* entity, const LmxTransform* tr) {
+	for (uint32_t i = 0; i < n; ++i) ((WorldRef*)w)->setLocalTransform(entity[i], toRef(&tr[i]));
+}
+void ref_world_get_transforms(void* w, uint32_t n, LmxTransform* out) {
+	for (uint32_t i = 0; i < n; ++i) fromRef(((WorldRef*)w)->m_transforms[i], &out[i]);
+}
+void ref_world_get_local_transforms(void* w, uint32_t n, LmxTransform* out) { // World::getLocalTransform, world.cpp:756-766
+	WorldRef* world = (WorldRef*)w;
+	for (uint32_t i = 0; i < n; ++i) {
+		const i32 h = world->m_entity_hierarchy[i];
+		fromRef(h < 0 ? world->m_transforms[i] : world->m_hierarchy[h].local_transform, &out[i]);
+	}
+}
+void ref_world_bind_culling(void* w, void* cs, uint32_t n, const int32_t* entity, const float* model_radius) {
+	WorldRef* world = (WorldRef*)w;
+	world->m_culling = (CullingSystemRef*)cs;
+	for (uint32_t i = 0; i < n; ++i) world->m_model_radius[entity[i]] = model_radius[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pose / palette / linear-blend skin
+// ---------------------------------------------------------------------------------------------------------
+// Pose::computeAbsolute scalar recurrence, renderer/pose.cpp:129-130, over `n_instances` poses laid out back to back
+void ref_pose_compute_absolute(float* positions, float* rotations, const int16_t* parents, int32_t first_nonroot,
+	uint32_t count, uint32_t n_instances, int n_threads) {
+	forEachJob(n_instances, n_threads, [&](u32 inst) {
+		Vec3* pos = (Vec3*)(positions + (size_t)inst * count * 3);
+		Quat* rot = (Quat*)(rotations + (size_t)inst * count * 4);
+		for (u32 i = (u32)first_nonroot; i < count; ++i) {
+			const i32 parent = parents[i];
+			pos[i] = rot[parent].rotate(pos[i]) + pos[parent];
+			rot[i] = rot[parent] * rot[i];
+		}
+	});
+}
+
+void ref_invert_bind(const LmxLocalRigidTransform* bind, LmxLocalRigidTransform* out, uint32_t n) { // model.cpp:24-30
+	for (uint32_t i = 0; i < n; ++i) {
+		LocalRigidTransform tr;
+		memcpy((void*)&tr, &bind[i], sizeof(tr));
+		LocalRigidTransform result;
+		result.rot = tr.rot.conjugated();
+		result.pos = result.rot.rotate(-tr.pos);
+		memcpy(&out[i], &result, sizeof(result));
+	}
+}
+
+// computeSkinMatrices, model.cpp:132-137, for n_instances poses sharing one model's inverse bind
+void ref_skin_matrices(const float* pose_pos, const float* pose_rot, const LmxLocalRigidTransform* inv_bind, LmxMatrix* out,
+	uint32_t count, uint32_t n_instances, int n_threads) {
+	forEachJob(n_instances, n_threads, [&](u32 inst) {
+		const Vec3* pos = (const Vec3*)(pose_pos + (size_t)inst * count * 3);
+		const Quat* rot = (const Quat*)(pose_rot + (size_t)inst * count * 4);
+		Matrix* matrices = (Matrix*)(out + (size_t)inst * count);
+		for (u32 i = 0; i < count; ++i) {
+			LocalRigidTransform tmp = {pos[i], rot[i]};
+			LocalRigidTransform inv;
+			memcpy((void*)&inv, &inv_bind[i], sizeof(inv));
+			matrices[i] = (tmp * inv).toMatrix();
+		}
+	});
+}
+
+// evaluateSkin, model.cpp:103-109, for n_instances palettes over one mesh
+void ref_evaluate_skin(const float* verts, const LmxSkin* skin, const LmxMatrix* palettes, float* out, uint32_t n_verts,
+	uint32_t n_bones, uint32_t n_instances, int n_threads) {
+	forEachJob(n_instances, n_threads, [&](u32 inst) {
+		const Matrix* matrices = (const Matrix*)(palettes + (size_t)inst * n_bones);
+		float* o = out + (size_t)inst * n_verts * 3;
+		for (u32 v = 0; v < n_verts; ++v) {
+			const LmxSkin& s = skin[v];
+			const Vec3 p(verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]);
+			Matrix m = matrices[s.indices[0]] * s.weights[0] + matrices[s.indices[1]] * s.weights[1] +
+					   matrices[s.indices[2]] * s.weights[2] + matrices[s.indices[3]] * s.weights[3];
+			const Vec3 r = m.transformPoint(p);
+			o[3 * v] = r.x;
+			o[3 * v + 1] = r.y;
+			o[3 * v + 2] = r.z;
+		}
+	});
+}
+
+// Marsaglia generator used for seeded scenes, core/math.cpp:1333-1341
+void ref_rand_fill(uint32_t u, uint32_t v, uint32_t n, uint32_t* out) {
+	RandomGenerator g(u, v);
+	for (uint32_t i = 0; i < n; ++i) out[i] = g.rand();
+}
+
+const char* ref_describe(void) {
+	return "reference object code: src/core/math.cpp + src/core/geometry.cpp (g++ -O2 -msse2 -ffp-contract=off), "
+		   "drivers restated in oracle/ref/ref_shim.cpp";
+}
+
+} // extern "C"

@@ -1,0 +1,67 @@
+"""pytest configuration: `gpu` marker + shared fixtures (CPU oracle libraries, emulation shim)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with `-m gpu` on the GPU box")
+
+
+@pytest.fixture(scope="session")
+def oracle_port():
+    from oracle import pyoracle
+
+    if not os.path.exists(pyoracle.ORACLE_SO):
+        pyoracle.build()
+    return pyoracle.Oracle("port")
+
+
+@pytest.fixture(scope="session")
+def oracle_ref():
+    """The reference's own object code (oracle/_ref). Built here when /root/reference exists; prebuilt on the GPU box."""
+    from oracle import pyoracle
+
+    if not pyoracle.have_reference():
+        try:
+            pyoracle.build()
+        except Exception:
+            pass
+    if not pyoracle.have_reference():
+        pytest.skip("oracle/_ref/liblmx_ref.so not available (no reference tree and no prebuilt copy)")
+    return pyoracle.Oracle("reference")
+
+
+@pytest.fixture(scope="session")
+def emul_lib():
+    """Host emulation of the kernels' logic (tests/emul/emul_kernels.cpp), compiled with g++ -ffp-contract=off."""
+    import ctypes
+
+    src = os.path.join(ROOT, "tests", "emul", "emul_kernels.cpp")
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    out = os.path.join(out_dir, "libemul.so")
+    deps = [src] + [os.path.join(ROOT, "lumixengine_amd", "csrc", h) for h in ("lmx_math.h", "lmx_cull_layout.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.run(
+            ["g++", "-std=c++17", "-O2", "-msse2", "-mfpmath=sse", "-ffp-contract=off", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+             "-I" + os.path.join(ROOT, "lumixengine_amd", "csrc"), src, "-o", out],
+            check=True,
+        )
+    return ctypes.CDLL(out)
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """A lumixengine_amd Context on cuda:0. Fails (does not skip) when the HIP extension or the GPU is missing."""
+    from lumixengine_amd import api
+
+    ctx = api.Context(0)
+    yield ctx
+    ctx.close()

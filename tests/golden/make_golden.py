@@ -1,0 +1,95 @@
+"""Generates tests/golden/*.npz from the REFERENCE's own object code (oracle/_ref/liblmx_ref.so).
+
+Run in the development container, where /root/reference exists:
+
+    python tests/golden/make_golden.py
+
+The fixtures are committed; `/root/reference` does not exist on the GPU box, so tests only ever read the .npz files.
+Each file stores the inputs next to the outputs, so a fixture never depends on a random generator's stream.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from lumixengine_amd import scenes  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def cull_fixture(ref, sc, frusta):
+    cs = ref.culling_system()
+    cs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    out = {"entity": sc["entity"], "type": sc["type"], "pos": sc["pos"], "radius": sc["radius"], "frusta": frusta, "n_cells": np.array([cs.cell_count()])}
+    for f in range(len(frusta)):
+        ids, types, _ = cs.cull(frusta[f : f + 1])
+        order = np.lexsort((ids, types))
+        out[f"vis_ids_{f}"] = ids[order]
+        out[f"vis_types_{f}"] = types[order]
+    return out
+
+
+def main():
+    po.build()
+    ref = po.Oracle("reference")
+    print(ref.describe())
+    frusta = H.frusta(ref)
+    np.savez_compressed(os.path.join(OUT, "frusta.npz"), names=np.array([c[0] for c in H.CAMERAS]), frusta=frusta, cascades=H.cascade_frusta(ref))
+
+    np.savez_compressed(os.path.join(OUT, "cull_edge.npz"), **cull_fixture(ref, H.edge_case_scene(), frusta))
+    np.savez_compressed(os.path.join(OUT, "cull_mixed.npz"), **cull_fixture(ref, H.mixed_scene(), np.concatenate([frusta, H.cascade_frusta(ref)])))
+    # config 1 (100 k static MESH entities, 1 perspective frustum): inputs are regenerated from the seed by the test,
+    # guarded by a checksum; all 7 cameras are stored
+    sc = scenes.cull_scene(100_000, 3000.0, seed=1)
+    fx = cull_fixture(ref, sc, frusta)
+    for k in ("entity", "type", "pos", "radius"):
+        del fx[k]
+    fx["pos_sum"] = np.array([sc["pos"].sum(), np.abs(sc["pos"]).sum()])
+    fx["radius_sum"] = np.array([float(sc["radius"].astype(np.float64).sum())])
+    np.savez_compressed(os.path.join(OUT, "cull_config1.npz"), **fx)
+
+    # transforms
+    rng = np.random.default_rng(9)
+    a = scenes.random_transforms(rng, 256, 1.0e6)
+    b = scenes.random_transforms(rng, 256, 50.0)
+    h = scenes.hierarchy_fans(6, 3, 4, seed=3)
+    n = len(h["parent"])
+    w = ref.world(n)
+    roots = np.flatnonzero(h["parent"] < 0).astype(np.int32)
+    kids = np.flatnonzero(h["parent"] >= 0).astype(np.int32)
+    w.init_transforms(roots, h["local"][roots])
+    w.set_parents(h["parent"][kids], kids)
+    w.set_local_transforms(kids, h["local"][kids])
+    locals_ = w.get_local_transforms()
+    world0 = w.get_transforms()
+    new_root = scenes.random_transforms(rng, len(roots), 4000.0)
+    w.set_transforms(roots, new_root)
+    np.savez_compressed(
+        os.path.join(OUT, "transforms.npz"), a=a, b=b, compose=ref.compose(a, b), compute_local=ref.compute_local(a, b), parent=h["parent"],
+        locals=locals_, world0=world0, new_root=new_root, world1=w.get_transforms(),
+    )
+
+    # pose / palette / skin
+    sk = scenes.skeleton(64, seed=4)
+    pos, rot = scenes.relative_poses(4, 64, seed=5)
+    verts, skin = scenes.skinned_mesh(500, 64, seed=6)
+    inv = ref.invert_bind(sk["bind"])
+    apos, arot = ref.pose_compute_absolute(pos, rot, sk["parents"], sk["first_nonroot"])
+    pal = ref.skin_matrices(apos, arot, inv)
+    out = ref.evaluate_skin(verts, skin, pal)
+    np.savez_compressed(
+        os.path.join(OUT, "skin.npz"), parents=sk["parents"], bind=sk["bind"], first_nonroot=np.array([sk["first_nonroot"]]), rel_pos=pos, rel_rot=rot,
+        verts=verts, skin=skin, inv_bind=inv, abs_pos=apos, abs_rot=arot, palette=pal, skinned=out,
+    )
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
