@@ -1,0 +1,312 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json metric on MI355X: entities culled / s (+ skinned verts / s, transforms / s as extras).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload at N=1: BASELINE config 2 ("10M static entities, 1 frustum, 1xMI355X cull + compaction"), sparse variant
+(cube [-15000,15000]^3, ~1 M occupied cells), camera = the reference player's default viewport (fov 60 deg, 1920x1080,
+near 0.1, far 10000). One step = one cull of every resident entity: classify kernel + sphere/compaction
+kernel, visible ids left in HBM. For N>1 every rank owns its own 10 M entities (weak scaling, one process per GPU)
+and a step also all-gathers the visible-id lists over RCCL (counts, then the padded payload).
+
+value = entities resident on all ranks x frusta / wall time per step (max over ranks, barrier + synchronize on both
+sides of exactly K steps). Inputs are resident in HBM before the timed region starts; the frustum (256 B) is a kernel
+argument.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--entities", type=int, default=10_000_000, help="entities per GPU")
+    ap.add_argument("--variant", choices=["sparse", "dense"], default="sparse")
+    ap.add_argument("--no-extras", action="store_true", help="skip the dense-variant / transform / skin side measurements")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from lumixengine_amd import api, scenes
+    from lumixengine_amd import distributed as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    ctx = api.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launches and torch.cuda.synchronize() share one stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def timed(fn, steps):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        barrier()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        if world > 1:
+            t = torch.tensor([ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t.item())
+        return ms
+
+    # ---- the headline workload -----------------------------------------------------------------------------
+    N = args.entities
+    half = 15000.0 if args.variant == "sparse" else 5000.0
+    t0 = time.time()
+    sc = scenes.cull_scene(N, half, seed=2 + rank)
+    cs = api.CullingSystem(ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    stats = cs.stats()
+    log(f"[rank {rank}] scene {args.variant}: {N} entities, {stats['cells']} cells, {stats['chunks']} chunks, build {time.time() - t0:.1f}s")
+    frustum = api.viewport_frustum()  # default player viewport at the origin
+    n_frusta = 1
+
+    if world > 1:
+        n_padded = stats["chunks"] * 64
+        out_ids = torch.empty(n_frusta * n_padded, dtype=torch.int32, device="cuda")
+        out_counts = torch.zeros(api.MAX_FRUSTA * api.MAX_TYPES, dtype=torch.int32, device="cuda")
+        cs.bindOutput(0, out_ids.data_ptr(), out_ids.numel(), out_counts.data_ptr())
+
+        def step():
+            cs.cull(frustum)
+            # visible MESH ids of frustum 0 start at offset 0 of the bound buffer (type 0 is the first type range)
+            D.allgather_visible(out_ids.view(n_frusta, n_padded), out_counts.view(api.MAX_FRUSTA, api.MAX_TYPES)[:n_frusta, 0])
+    else:
+
+        def step():
+            cs.cull(frustum)
+
+    for _ in range(args.warmup):
+        step()
+    ms_per_step = timed(step, args.steps)
+    value = N * world * n_frusta / (ms_per_step * 1e-3)
+    res = cs.cull(frustum)
+    visible = int(res.counts()[0].sum())
+
+    # ---- roofline of the dominant kernel: same loop, HIP events around each launch on the launch stream -------
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    for _ in range(args.steps):
+        cs.cull(frustum)
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    ms_spheres, n_spheres = ctx.profile_get(api.K_CULL_SPHERES)
+    ms_classify, n_classify = ctx.profile_get(api.K_CULL_CLASSIFY)
+    avg_spheres_ms = ms_spheres / max(n_spheres, 1)
+    avg_classify_ms = ms_classify / max(n_classify, 1)
+    # algorithmic bytes of one cull launch: 16 B sphere + 4 B id per resident entity, 4 B per visible id
+    alg_bytes = 20.0 * N + 4.0 * visible
+    achieved = alg_bytes / (avg_spheres_ms * 1e-3) / 1e9
+    roofline = {
+        "kernel": "k_cull_spheres",
+        "bound": "hbm",
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 4),
+        "traffic": None,  # HBM bytes per launch from rocprofv3 PMC passes: see profiles/ and DESIGN.md
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "avg_launch_ms": round(avg_spheres_ms, 5),
+        "classify_kernel_avg_launch_ms": round(avg_classify_ms, 5),
+        "whole_cull_achieved_GBps": round((alg_bytes + 36.0 * stats["cells"]) / ((avg_spheres_ms + avg_classify_ms) * 1e-3) / 1e9, 1),
+        "note": "algorithmic bytes count every resident sphere although rejected cells are never fetched (hierarchical skip), so frac may exceed 1",
+    }
+
+    result = {
+        "metric": "entities_culled_per_sec",
+        "value": value,
+        "unit": "entities/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE config 2: {N} static entities per GPU ({args.variant}, cube +-{half:g}), 1 frustum (fov 60, 16:9, near 0.1, far 10000), cull + compaction",
+            "entities_per_gpu": N,
+            "frusta": n_frusta,
+            "cells_per_gpu": stats["cells"],
+            "visible_per_gpu": visible,
+            "sharding": "entities per rank, RCCL all-gather of visible ids" if world > 1 else "single GPU",
+        },
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_extras:
+            result["extra"] = extras(ctx, api, scenes, torch, timed, N, log)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(scenes, frustum, N, half, log)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def extras(ctx, api, scenes, torch, timed, N, log):
+    """Side measurements (not the headline `value`): dense config-2 variant, 8-frusta pass, config-3 transform + skin."""
+    out = {}
+    # dense variant of config 2 (cube +-5000: ~37 k cells, ~270 spheres per cell)
+    sc = scenes.cull_scene(N, 5000.0, seed=2)
+    cs = api.CullingSystem(ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    fr = api.viewport_frustum()
+    for _ in range(10):
+        cs.cull(fr)
+    ms = timed(lambda: cs.cull(fr), 100)
+    vis = int(cs.cull(fr).counts()[0].sum())
+    out["dense_entities_culled_per_sec"] = N / (ms * 1e-3)
+    out["dense_ms_per_cull"] = ms
+    out["dense_visible"] = vis
+    # worst case for the hierarchical skip: a frustum that contains no whole cell but touches all of them is not
+    # constructible; the closest is the camera far outside looking at the whole cube (every cell intersects or is inside)
+    big = api.viewport_frustum(pos=(0.0, 0.0, 60000.0), far=200000.0)
+    for _ in range(5):
+        cs.cull(big)
+    ms_all = timed(lambda: cs.cull(big), 50)
+    vis_all = int(cs.cull(big).counts()[0].sum())
+    out["dense_all_visible_ms_per_cull"] = ms_all
+    out["dense_all_visible_count"] = vis_all
+    out["dense_all_visible_GBps"] = (20.0 * N + 4.0 * vis_all) / (ms_all * 1e-3) / 1e9
+    del cs
+
+    # config 3 slice: 1 M entities, depth-4 chains, every root moved each frame (transform inputs resident in HBM)
+    h = scenes.hierarchy_chains(250_000, 4, seed=2)
+    n = len(h["parent"])
+    w = api.World(ctx)
+    w.build(h["parent"], h["local"])
+    roots = np.flatnonzero(h["parent"] < 0).astype(np.int32)
+    new_root = scenes.random_transforms(np.random.default_rng(1), len(roots), 4000.0)
+    d_ent = torch.from_numpy(roots).cuda()
+    d_tr = torch.from_numpy(new_root.view(np.uint8).reshape(len(roots), -1)).cuda()
+
+    def xform_step():
+        w.setTransformsDevice(len(roots), d_ent.data_ptr(), d_tr.data_ptr())
+        w.propagate()
+
+    for _ in range(10):
+        xform_step()
+    ms = timed(xform_step, 100)
+    n_child = n - len(roots)
+    out["transforms_per_sec"] = n_child / (ms * 1e-3)
+    out["transform_ms_per_frame"] = ms
+    out["transform_GBps_algorithmic"] = 156.0 * n_child / (ms * 1e-3) / 1e9
+    del w
+
+    # config 3 slice: skinned instances x 64 bones x 10 k verts, shared mesh (2 k instances = 20 M verts per frame)
+    n_inst, n_verts = 2000, 10_000
+    s = scenes.skeleton(64, seed=4)
+    verts, skin = scenes.skinned_mesh(n_verts, 64, seed=6)
+    sk = api.Skinning(ctx)
+    model = sk.addModel(s["parents"], s["bind"], s["first_nonroot"])
+    mesh = sk.addMesh(verts, skin)
+    sk.setInstances(np.full(n_inst, model, np.uint32), np.full(n_inst, mesh, np.uint32))
+    pos, rot = scenes.relative_poses(n_inst, 64, seed=5)
+    d_pos = torch.from_numpy(pos).cuda()
+    d_rot = torch.from_numpy(rot).cuda()
+
+    def skin_step():
+        sk.uploadPosesDevice(d_pos.data_ptr(), d_rot.data_ptr(), n_inst * 64)
+        sk.run()
+
+    for _ in range(5):
+        skin_step()
+    ms = timed(skin_step, 50)
+    out["skinned_verts_per_sec"] = n_inst * n_verts / (ms * 1e-3)
+    out["skin_ms_per_frame"] = ms
+    out["skin_instances"] = n_inst
+    out["skin_GBps_algorithmic_48B"] = 48.0 * n_inst * n_verts / (ms * 1e-3) / 1e9
+    out["skin_GBps_shared_mesh_floor_12B"] = 12.0 * n_inst * n_verts / (ms * 1e-3) / 1e9
+    log("extras:", json.dumps(out))
+    return out
+
+
+def cpu_baseline(scenes, frustum, N, half, log):
+    """The reference CPU path on this box's host cores: oracle/_ref (reference math/geometry object code + restated
+    CullingSystemImpl driver) when present, else the plain-C port. Bounded sample of the same workload: a quarter of the
+    entities in a cube shrunk to keep the density (entities per cell) of the GPU run, same frustum; jobs::forEach
+    stand-in on all host cores and on one. Baseline only - the GPU/CPU ratio says nothing about kernel quality."""
+    from oracle import pyoracle
+
+    cores = os.cpu_count() or 1
+    kind = "reference" if pyoracle.have_reference() else "port"
+    if kind == "port" and not os.path.exists(pyoracle.ORACLE_SO):
+        pyoracle.build()
+    o = pyoracle.Oracle(kind)
+    n = max(N // 4, 1)
+    sample_half = half * (n / N) ** (1.0 / 3.0)
+    sc = scenes.cull_scene(n, sample_half, seed=2)
+    ocs = o.culling_system()
+    t0 = time.time()
+    ocs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    t_add = time.time() - t0
+    fr = np.ascontiguousarray(frustum)
+
+    def measure(threads):
+        ocs.cull(fr, n_threads=threads, want_ids=False, cap=0)  # warm-up (fills the page pool)
+        times, t_start = [], time.time()
+        while len(times) < 20 and (time.time() - t_start) < 8.0:
+            t0 = time.perf_counter()
+            ocs.cull(fr, n_threads=threads, want_ids=False, cap=0)
+            times.append(time.perf_counter() - t0)
+        return float(np.median(times)), len(times)
+
+    multi, reps = measure(cores)
+    single, _ = measure(1)
+    visible, pages = ocs.cull(fr, n_threads=1, want_ids=False, cap=0)
+    best, used = (multi, cores) if multi <= single else (single, 1)
+    log(f"cpu baseline ({kind}): {n} entities, add {t_add:.1f}s, cull median {multi * 1e3:.1f} ms on {cores} threads, {single * 1e3:.1f} ms on 1 thread, {visible} visible, {pages} result pages")
+    return {
+        "value": n / best,
+        "unit": "entities/s",
+        "cores": used,
+        "kind": kind,
+        "sample": f"{n} entities in a cube of half-extent {sample_half:.0f} (same entities-per-cell density as the GPU workload), same frustum, median of {reps} culls; one CullResult page per visited cell page as in the reference ({pages} pages per cull)",
+        "all_cores_value": n / multi,
+        "all_cores": cores,
+        "single_thread_value": n / single,
+        "describe": o.describe(),
+    }
+
+
+if __name__ == "__main__":
+    main()

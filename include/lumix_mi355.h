@@ -103,6 +103,12 @@ LMX_API int lmx_cull_read(LmxContext* ctx, uint32_t view, uint32_t frustum, uint
 LMX_API int lmx_cull_device_result(LmxContext* ctx, uint32_t view, uint32_t frustum, const int32_t** d_ids, const uint32_t** d_counts,
 	uint32_t* type_offsets, uint32_t* capacity);
 
+/* Lets slot `view` write its result into caller-owned DEVICE memory (e.g. a buffer that is then handed to an RCCL
+ * all-gather) instead of library-owned buffers: d_ids holds ids_capacity int32 (>= n_frusta * 64 * n_chunks of
+ * lmx_cull_stats at cull time), d_counts LMX_MAX_FRUSTA * LMX_MAX_TYPES uint32. Frustum f's ids start at
+ * d_ids + f * (64 * n_chunks). Passing NULL pointers restores the library-owned buffers. */
+LMX_API int lmx_cull_bind_output(LmxContext* ctx, uint32_t view, void* d_ids, size_t ids_capacity, void* d_counts);
+
 /* ---- world transforms: World hierarchy, src/engine/world.cpp:255-282 ---------------------------------------
  * The reference propagates eagerly (one recursive DFS per setTransform). The batch form: stage new root/local
  * transforms, then lmx_world_propagate() recomputes child.world = parent.world.compose(child.local)
@@ -113,6 +119,8 @@ LMX_API int lmx_cull_device_result(LmxContext* ctx, uint32_t view, uint32_t frus
 LMX_API int lmx_world_build(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxTransform* transforms);
 /* World::setTransform for roots / World::setLocalTransform for children (world.cpp:337-342, 741-753), staged. */
 LMX_API int lmx_world_set_transforms(LmxContext* ctx, uint32_t n, const int32_t* entity, const LmxTransform* transforms);
+/* Same, with both arrays already in device memory (entity indices must be valid; they are not checked). */
+LMX_API int lmx_world_set_transforms_device(LmxContext* ctx, uint32_t n, const void* d_entity, const void* d_transforms);
 /* RenderModuleImpl::onModelInstanceMoved binding (render_module.cpp:1544-1554): after propagation the culling
  * sphere of entity[i] becomes (world.pos, model_radius[i] * maximum(scale.x, scale.y, scale.z)). */
 LMX_API int lmx_world_bind_culling(LmxContext* ctx, uint32_t n, const int32_t* entity, const float* model_radius);
@@ -133,6 +141,8 @@ LMX_API int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* 
 /* Relative poses (what AnimationModule writes before Pose::computeAbsolute): instances back to back,
  * positions n_bones x 3 floats, rotations n_bones x 4 floats per instance. */
 LMX_API int lmx_skin_upload_poses(LmxContext* ctx, const float* positions, const float* rotations, size_t n_bones_total);
+/* Same, from device memory (device-to-device copy on the context stream). */
+LMX_API int lmx_skin_upload_poses_device(LmxContext* ctx, const void* d_positions, const void* d_rotations, size_t n_bones_total);
 /* Pose::computeAbsolute -> computeSkinMatrices -> evaluateSkin for every instance; outputs stay in HBM. */
 LMX_API int lmx_skin_run(LmxContext* ctx);
 LMX_API int lmx_skin_read_vertices(LmxContext* ctx, uint32_t instance, float* out_xyz, uint32_t cap_verts);

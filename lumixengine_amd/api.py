@@ -63,9 +63,11 @@ SYMBOLS = {
     "lmx_cull": (_ci, [_vp, _u32, _vp, _u32, _u8]),
     "lmx_cull_counts": (_ci, [_vp, _u32, _vp]),
     "lmx_cull_read": (_ci, [_vp, _u32, _u32, _u8, _vp, _u32, C.POINTER(_u32)]),
+    "lmx_cull_bind_output": (_ci, [_vp, _u32, _vp, _sz, _vp]),
     "lmx_cull_device_result": (_ci, [_vp, _u32, _u32, C.POINTER(_vp), C.POINTER(_vp), _vp, C.POINTER(_u32)]),
     "lmx_world_build": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_world_set_transforms": (_ci, [_vp, _u32, _vp, _vp]),
+    "lmx_world_set_transforms_device": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_world_bind_culling": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_world_propagate": (_ci, [_vp]),
     "lmx_world_read_transforms": (_ci, [_vp, _vp, _u32]),
@@ -73,6 +75,7 @@ SYMBOLS = {
     "lmx_skin_add_mesh": (_ci, [_vp, _u32, _vp, _vp, C.POINTER(_u32)]),
     "lmx_skin_set_instances": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_skin_upload_poses": (_ci, [_vp, _vp, _vp, _sz]),
+    "lmx_skin_upload_poses_device": (_ci, [_vp, _vp, _vp, _sz]),
     "lmx_skin_run": (_ci, [_vp]),
     "lmx_skin_read_vertices": (_ci, [_vp, _u32, _vp, _u32]),
     "lmx_skin_read_palette": (_ci, [_vp, _u32, _vp, _u32]),
@@ -294,6 +297,10 @@ class CullingSystem:
         self.ctx.check(self.lib.lmx_cull_stats(self.ctx.h, C.byref(a), C.byref(b), C.byref(c)))
         return {"entities": a.value, "cells": b.value, "chunks": c.value}
 
+    def bindOutput(self, view: int, d_ids: Optional[int], ids_capacity: int, d_counts: Optional[int]):
+        """Result slot `view` writes into caller-owned device memory (raw pointers, e.g. torch tensors' data_ptr())."""
+        self.ctx.check(self.lib.lmx_cull_bind_output(self.ctx.h, view, d_ids, ids_capacity, d_counts))
+
     def cull(self, frusta: np.ndarray, type_: int = TYPE_ALL, view: int = 0) -> CullResult:
         """cull(frustum[, type]); `frusta` may hold up to 8 ShiftedFrustum records tested in one pass."""
         frusta = np.ascontiguousarray(frusta, SHIFTED_FRUSTUM).reshape(-1)
@@ -322,6 +329,10 @@ class World:
         transforms = np.ascontiguousarray(transforms, TRANSFORM)
         assert len(entity) == len(transforms)
         self.ctx.check(self.lib.lmx_world_set_transforms(self.ctx.h, len(entity), _ptr(entity), _ptr(transforms)))
+
+    def setTransformsDevice(self, n: int, d_entity: int, d_transforms: int):
+        """Same as setTransforms with both arrays already resident in HBM (raw device pointers)."""
+        self.ctx.check(self.lib.lmx_world_set_transforms_device(self.ctx.h, n, d_entity, d_transforms))
 
     def bindCulling(self, entity, model_radius):
         entity = np.ascontiguousarray(entity, np.int32)
@@ -376,6 +387,9 @@ class Skinning:
         n_bones_total = positions.size // 3
         assert rotations.size == n_bones_total * 4
         self.ctx.check(self.lib.lmx_skin_upload_poses(self.ctx.h, _ptr(positions), _ptr(rotations), n_bones_total))
+
+    def uploadPosesDevice(self, d_positions: int, d_rotations: int, n_bones_total: int):
+        self.ctx.check(self.lib.lmx_skin_upload_poses_device(self.ctx.h, d_positions, d_rotations, n_bones_total))
 
     def run(self):
         self.ctx.check(self.lib.lmx_skin_run(self.ctx.h))

@@ -57,6 +57,12 @@ struct CullView {
 	uint32_t ent_start[MAX_TYPES] = {};
 	uint32_t ent_cap[MAX_TYPES] = {};
 	bool valid = false;
+	// caller-owned result buffers (lmx_cull_bind_output)
+	int32_t* ext_out = nullptr;
+	size_t ext_out_cap = 0;
+	uint32_t* ext_counts = nullptr;
+	int32_t* out_ptr() const { return ext_out ? ext_out : out.p; }
+	uint32_t* counts_ptr() const { return ext_counts ? ext_counts : counts.p; }
 };
 
 struct CullState {
@@ -597,9 +603,14 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 	if (int rc = cull_flush(ctx)) return rc;
 	CullState& cs = ctx->cull;
 	CullView& v = cs.views[view];
-	LMX_HIP(ctx, v.counts.reserve(MAX_FRUSTA * MAX_TYPES));
 	LMX_HIP(ctx, v.cellinfo.reserve((size_t)std::max(cs.n_cells, 1u) * n_frusta));
-	LMX_HIP(ctx, v.out.reserve((size_t)std::max(cs.n_padded, 1u) * n_frusta));
+	if (v.ext_out) {
+		if (v.ext_out_cap < (size_t)cs.n_padded * n_frusta)
+			return fail(ctx, LMX_ERR_CAPACITY, "bound output holds %zu ids, need %zu", v.ext_out_cap, (size_t)cs.n_padded * n_frusta);
+	} else {
+		LMX_HIP(ctx, v.counts.reserve(MAX_FRUSTA * MAX_TYPES));
+		LMX_HIP(ctx, v.out.reserve((size_t)std::max(cs.n_padded, 1u) * n_frusta));
+	}
 	v.n_frusta = n_frusta;
 	v.cell_stride = cs.n_cells;
 	v.out_stride = cs.n_padded;
@@ -621,12 +632,12 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 	const CullDeviceView dv = cull_dev(cs);
 	{
 		ProfScope ps(ctx, LMX_K_CULL_CLASSIFY);
-		LMX_HIP(ctx, launch_cull_classify(ctx->stream, dv, cell_begin, cell_n, fr, (int)n_frusta, v.cellinfo.p, v.cell_stride, v.counts.p));
+		LMX_HIP(ctx, launch_cull_classify(ctx->stream, dv, cell_begin, cell_n, fr, (int)n_frusta, v.cellinfo.p, v.cell_stride, v.counts_ptr()));
 	}
 	{
 		ProfScope ps(ctx, LMX_K_CULL_SPHERES);
-		LMX_HIP(ctx, launch_cull_spheres(ctx->stream, dv, ent_begin, ent_end, cs.tt, fr, (int)n_frusta, v.cellinfo.p, v.cell_stride, v.out.p,
-			v.out_stride, v.counts.p));
+		LMX_HIP(ctx, launch_cull_spheres(ctx->stream, dv, ent_begin, ent_end, cs.tt, fr, (int)n_frusta, v.cellinfo.p, v.cell_stride, v.out_ptr(),
+			v.out_stride, v.counts_ptr()));
 	}
 	v.valid = true;
 	return LMX_OK;
@@ -638,7 +649,7 @@ int lmx_cull_counts(LmxContext* ctx, uint32_t view, uint32_t* counts) {
 	CullView& v = ctx->cull.views[view];
 	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
 	uint32_t all[MAX_FRUSTA * MAX_TYPES];
-	LMX_HIP(ctx, hipMemcpyAsync(all, v.counts.p, sizeof(all), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipMemcpyAsync(all, v.counts_ptr(), sizeof(all), hipMemcpyDeviceToHost, ctx->stream));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	memcpy(counts, all, sizeof(uint32_t) * v.n_frusta * MAX_TYPES);
 	return LMX_OK;
@@ -651,15 +662,28 @@ int lmx_cull_read(LmxContext* ctx, uint32_t view, uint32_t frustum, uint8_t type
 	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
 	if (frustum >= v.n_frusta || type >= MAX_TYPES) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "frustum %u / type %u out of range", frustum, type);
 	uint32_t c = 0;
-	LMX_HIP(ctx, hipMemcpyAsync(&c, v.counts.p + frustum * MAX_TYPES + type, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipMemcpyAsync(&c, v.counts_ptr() + frustum * MAX_TYPES + type, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (out_count) *out_count = c;
 	if (c > v.ent_cap[type]) return fail(ctx, LMX_ERR_HIP, "corrupt count %u > %u", c, v.ent_cap[type]);
 	if (!out_ids || c == 0) return LMX_OK;
 	if (c > cap) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u ids, got %u", c, cap);
-	LMX_HIP(ctx, hipMemcpyAsync(out_ids, v.out.p + (size_t)frustum * v.out_stride + v.ent_start[type], (size_t)c * sizeof(int32_t),
+	LMX_HIP(ctx, hipMemcpyAsync(out_ids, v.out_ptr() + (size_t)frustum * v.out_stride + v.ent_start[type], (size_t)c * sizeof(int32_t),
 		hipMemcpyDeviceToHost, ctx->stream));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+int lmx_cull_bind_output(LmxContext* ctx, uint32_t view, void* d_ids, size_t ids_capacity, void* d_counts) {
+	LMX_CHECK_CTX(ctx);
+	if (view >= LMX_MAX_VIEWS) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad view");
+	if ((d_ids == nullptr) != (d_counts == nullptr)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bind both buffers or neither");
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	CullView& v = ctx->cull.views[view];
+	v.ext_out = (int32_t*)d_ids;
+	v.ext_out_cap = d_ids ? ids_capacity : 0;
+	v.ext_counts = (uint32_t*)d_counts;
+	v.valid = false;
 	return LMX_OK;
 }
 
@@ -670,8 +694,8 @@ int lmx_cull_device_result(LmxContext* ctx, uint32_t view, uint32_t frustum, con
 	CullView& v = ctx->cull.views[view];
 	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
 	if (frustum >= v.n_frusta) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "frustum %u out of range", frustum);
-	if (d_ids) *d_ids = v.out.p + (size_t)frustum * v.out_stride;
-	if (d_counts) *d_counts = v.counts.p;
+	if (d_ids) *d_ids = v.out_ptr() + (size_t)frustum * v.out_stride;
+	if (d_counts) *d_counts = v.counts_ptr();
 	if (type_offsets) memcpy(type_offsets, v.ent_start, sizeof(v.ent_start));
 	if (capacity) *capacity = v.out_stride;
 	return LMX_OK;
@@ -765,6 +789,16 @@ int lmx_world_set_transforms(LmxContext* ctx, uint32_t n, const int32_t* entity,
 	LMX_HIP(ctx, hipMemcpy(w.d_stage_entity.p, entity, n * sizeof(int32_t), hipMemcpyHostToDevice));
 	LMX_HIP(ctx, hipMemcpy(w.d_stage_tr.p, transforms, n * sizeof(LmxTransform), hipMemcpyHostToDevice));
 	LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, w.d_stage_entity.p, w.d_stage_tr.p, n));
+	return LMX_OK;
+}
+
+int lmx_world_set_transforms_device(LmxContext* ctx, uint32_t n, const void* d_entity, const void* d_transforms) {
+	LMX_CHECK_CTX(ctx);
+	WorldState& w = ctx->world;
+	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
+	if (!n) return LMX_OK;
+	if (!d_entity || !d_transforms) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null device pointer");
+	LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, (const int32_t*)d_entity, d_transforms, n));
 	return LMX_OK;
 }
 
@@ -1002,6 +1036,18 @@ int lmx_skin_upload_poses(LmxContext* ctx, const float* positions, const float* 
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	LMX_HIP(ctx, hipMemcpy(sk.d_pose_pos.p, positions, n_bones_total * 3 * sizeof(float), hipMemcpyHostToDevice));
 	LMX_HIP(ctx, hipMemcpy(sk.d_pose_rot.p, rotations, n_bones_total * sizeof(float4), hipMemcpyHostToDevice));
+	sk.poses_uploaded = true;
+	return LMX_OK;
+}
+
+int lmx_skin_upload_poses_device(LmxContext* ctx, const void* d_positions, const void* d_rotations, size_t n_bones_total) {
+	LMX_CHECK_CTX(ctx);
+	SkinState& sk = ctx->skin;
+	if (n_bones_total != sk.bones_total) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "expected %zu bones over all instances, got %zu", sk.bones_total, n_bones_total);
+	if (!n_bones_total) return LMX_OK;
+	if (!d_positions || !d_rotations) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null device pointer");
+	LMX_HIP(ctx, hipMemcpyAsync(sk.d_pose_pos.p, d_positions, n_bones_total * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+	LMX_HIP(ctx, hipMemcpyAsync(sk.d_pose_rot.p, d_rotations, n_bones_total * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
 	sk.poses_uploaded = true;
 	return LMX_OK;
 }

@@ -479,8 +479,10 @@ static void map_erase(culling_system* cs, const cell_indices* key) {
 	}
 }
 
+static void* pool_allocate(void);
+static void pool_deallocate(void* p);
 static cell_page* page_new(void) {
-	cell_page* p = (cell_page*)aligned_alloc(ORC_PAGE_SIZE, ORC_PAGE_SIZE);
+	cell_page* p = (cell_page*)pool_allocate();
 	memset(p, 0, ORC_PAGE_SIZE);
 	return p;
 }
@@ -562,7 +564,7 @@ static void cs_remove(culling_system* cs, int32_t entity) {                     
 				break;
 			}
 		}
-		free(cell);
+		pool_deallocate(cell);
 	} else {
 		const int idx = (int)(s - cell->spheres);
 		const int32_t last = cell->entities[cell->header.count - 1];
@@ -623,6 +625,38 @@ static void cs_set_radius(culling_system* cs, int32_t entity, float radius) {   
 	cs_add(cs, entity, type, pos, radius);
 }
 
+/* PageAllocator stand-in, core/page_allocator.cpp:41-64: one pool for cell pages and result pages (the engine has a
+ * single PageAllocator). Freed pages are kept on a free list and handed out again, so a steady-state cull makes no
+ * OS / malloc calls (the reference: 512-entry lock-free ring + locked fallback); fresh pages come from 4 MiB slabs. */
+static struct { pthread_mutex_t mutex; void** pages; uint32_t n, cap; char* slab_cur; char* slab_end; } g_pool = {PTHREAD_MUTEX_INITIALIZER, NULL, 0, 0, NULL, NULL};
+
+static void* pool_allocate(void) {
+	void* p;
+	pthread_mutex_lock(&g_pool.mutex);
+	if (g_pool.n) {
+		p = g_pool.pages[--g_pool.n];
+	} else {
+		if (g_pool.slab_cur == g_pool.slab_end) { /* slabs are never returned to the OS (process-lifetime pool) */
+			const size_t bytes = (size_t)ORC_PAGE_SIZE * 1024;
+			g_pool.slab_cur = (char*)aligned_alloc(ORC_PAGE_SIZE, bytes);
+			g_pool.slab_end = g_pool.slab_cur + bytes;
+		}
+		p = g_pool.slab_cur;
+		g_pool.slab_cur += ORC_PAGE_SIZE;
+	}
+	pthread_mutex_unlock(&g_pool.mutex);
+	return p;
+}
+static void pool_deallocate(void* p) {
+	pthread_mutex_lock(&g_pool.mutex);
+	if (g_pool.n == g_pool.cap) {
+		g_pool.cap = g_pool.cap ? g_pool.cap * 2 : 1024;
+		g_pool.pages = (void**)realloc(g_pool.pages, sizeof(void*) * g_pool.cap);
+	}
+	g_pool.pages[g_pool.n++] = p;
+	pthread_mutex_unlock(&g_pool.mutex);
+}
+
 typedef struct {
 	result_page* begin;
 	result_page* end;
@@ -632,7 +666,7 @@ typedef struct {
 
 static result_page* rl_push(result_list* l) {                                                /* page_allocator.h:88-102 */
 	pthread_mutex_lock(&l->mutex);
-	result_page* page = (result_page*)aligned_alloc(ORC_PAGE_SIZE, ORC_PAGE_SIZE);
+	result_page* page = (result_page*)pool_allocate();
 	page->header.next = NULL;
 	page->header.count = 0;
 	if (!l->begin) l->begin = l->end = page;
@@ -721,7 +755,7 @@ ORC_API void* orc_cs_create(void) {
 }
 ORC_API void orc_cs_destroy(void* p) {
 	culling_system* cs = (culling_system*)p;
-	for (uint32_t i = 0; i < cs->n_cells; ++i) free(cs->cells[i]);
+	for (uint32_t i = 0; i < cs->n_cells; ++i) pool_deallocate(cs->cells[i]);
 	free(cs->cells);
 	free(cs->slots);
 	free(cs->entity_to_cell);
@@ -772,7 +806,7 @@ ORC_API uint32_t orc_cs_cull(void* p, const LmxShiftedFrustum* frustum, uint8_t 
 		}
 		result_page* tmp = page;
 		page = page->header.next;
-		free(tmp);
+		pool_deallocate(tmp);
 	}
 	if (out_pages) *out_pages = list.pages;
 	pthread_mutex_destroy(&list.mutex);

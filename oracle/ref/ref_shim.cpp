@@ -23,6 +23,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -86,9 +87,13 @@ struct CellIndices { // culling_system.cpp:23-40
 	bool is_big;
 };
 
-struct CellIndicesHasher { // culling_system.cpp:43-50
+struct CellIndicesHasher { // culling_system.cpp:43-50, then mixed: std::unordered_map (the stand-in for Lumix::HashMap)
+	// degrades badly on the raw value, and bucket placement has no influence on any result
 	size_t operator()(const CellIndices& i) const {
-		return (u32)i.pos.x * 73856093 + (u32)i.pos.y * 19349663 + (u32)i.pos.z * 83492791;
+		u64 h = (u32)i.pos.x * 73856093 + (u32)i.pos.y * 19349663 + (u32)i.pos.z * 83492791;
+		h ^= (u64)i.type << 40 | (u64)i.is_big << 48;
+		h *= 0x9E3779B97F4A7C15ull;
+		return (size_t)(h ^ (h >> 29));
 	}
 };
 
@@ -117,17 +122,52 @@ struct ResultPage { // CullResult, culling_system.h:17-56
 };
 static_assert(sizeof(ResultPage) == PAGE_SIZE, "CullResult must be one page");
 
+// PageAllocator stand-in, core/page_allocator.cpp:41-64: one pool for cell pages and result pages (the engine has a
+// single PageAllocator, engine.h:45). Freed pages go to a free list and are handed out again, so a steady-state cull
+// performs no OS / malloc calls (the reference: 512-entry lock-free ring + locked fallback). Fresh pages are carved from
+// 4 MiB slabs instead of one os::memReserve per page.
+struct PagePool {
+	std::mutex mutex;
+	std::vector<void*> free_pages;
+	std::vector<void*> slabs;
+	char* slab_cur = nullptr;
+	char* slab_end = nullptr;
+	void* allocate() {
+		std::lock_guard<std::mutex> guard(mutex);
+		void* p = nullptr;
+		if (!free_pages.empty()) {
+			p = free_pages.back();
+			free_pages.pop_back();
+		} else {
+			if (slab_cur == slab_end) {
+				const size_t bytes = PAGE_SIZE * 1024;
+				slab_cur = (char*)aligned_alloc(PAGE_SIZE, bytes);
+				slab_end = slab_cur + bytes;
+				slabs.push_back(slab_cur);
+			}
+			p = slab_cur;
+			slab_cur += PAGE_SIZE;
+		}
+		return p;
+	}
+	void deallocate(void* p) {
+		std::lock_guard<std::mutex> guard(mutex);
+		free_pages.push_back(p);
+	}
+	~PagePool() { for (void* p : slabs) free(p); }
+};
+static PagePool g_pages;
+
 struct PagedResultList { // PagedList<CullResult>, core/page_allocator.h:60-109 (mutex-guarded push)
 	ResultPage* begin = nullptr;
 	ResultPage* end = nullptr;
-	std::atomic_flag lock = ATOMIC_FLAG_INIT;
-	ResultPage* push() {
-		void* mem = aligned_alloc(PAGE_SIZE, PAGE_SIZE);
+	std::mutex mutex; // jobs::Mutex in the reference
+	ResultPage* push() { // page_allocator.h:88-102: allocation and linking both happen under the list mutex
+		std::lock_guard<std::mutex> guard(mutex);
+		void* mem = g_pages.allocate();
 		ResultPage* page = new (mem) ResultPage;
-		while (lock.test_and_set(std::memory_order_acquire)) {}
 		if (!begin) begin = end = page;
 		else { end->header.next = page; page->header.next = nullptr; end = page; }
-		lock.clear(std::memory_order_release);
 		return page;
 	}
 };
@@ -160,11 +200,11 @@ struct CullingSystemRef {
 	float m_cell_size = 300.0f; // culling_system.cpp:75
 
 	~CullingSystemRef() {
-		for (CellPage* p : m_cells) free(p);
+		for (CellPage* p : m_cells) g_pages.deallocate(p);
 	}
 
 	static CellPage* newPage() {
-		void* mem = aligned_alloc(PAGE_SIZE, PAGE_SIZE);
+		void* mem = g_pages.allocate();
 		return new (mem) CellPage;
 	}
 
@@ -227,7 +267,7 @@ struct CullingSystemRef {
 			for (size_t k = 0; k < m_cells.size(); ++k) { // swapAndPopItem
 				if (m_cells[k] == &cell) { m_cells[k] = m_cells.back(); m_cells.pop_back(); break; }
 			}
-			free(&cell);
+			g_pages.deallocate(&cell);
 		} else {
 			const int idx = int(sphere - cell.spheres);
 			const i32 last = cell.entities[cell.header.count - 1];
@@ -405,7 +445,7 @@ uint32_t ref_cs_cull(void* cs, const LmxShiftedFrustum* frustum, uint8_t type, i
 		}
 		ResultPage* tmp = page;
 		page = page->header.next;
-		free(tmp); // CullResult::free, culling_system.cpp:388-396
+		g_pages.deallocate(tmp); // CullResult::free, culling_system.cpp:388-396
 		++pages;
 	}
 	if (out_pages) *out_pages = pages;

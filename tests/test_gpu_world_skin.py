@@ -1,0 +1,217 @@
+"""Parity of the HIP transform-hierarchy and skinning paths against the oracle / golden fixtures. Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from lumixengine_amd import api, scenes
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def oracle_world(oracle, h):
+    n = len(h["parent"])
+    w = oracle.world(n)
+    roots = np.flatnonzero(h["parent"] < 0).astype(np.int32)
+    kids = np.flatnonzero(h["parent"] >= 0).astype(np.int32)
+    w.init_transforms(roots, h["local"][roots])
+    w.set_parents(h["parent"][kids], kids)
+    w.set_local_transforms(kids, h["local"][kids])
+    return w, roots, kids
+
+
+def gpu_inputs(ow, parent, roots):
+    """children: the oracle's stored Hierarchy::local_transform; roots: their world transform."""
+    tr = ow.get_local_transforms()
+    tr[roots] = ow.get_transforms()[roots]
+    return tr
+
+
+def test_world_golden(gpu_ctx):
+    g = np.load(os.path.join(G, "transforms.npz"))
+    parent = g["parent"]
+    roots = np.flatnonzero(parent < 0).astype(np.int32)
+    tr = np.ascontiguousarray(g["locals"]).copy()
+    tr[roots] = g["world0"][roots]
+    w = api.World(gpu_ctx)
+    w.build(parent, tr)
+    w.setTransforms(roots, g["new_root"])
+    w.propagate()
+    assert H.transforms_bits_equal(w.getTransforms(), g["world1"])
+
+
+@pytest.mark.parametrize("kind", ["chains", "fans", "flat"])
+def test_world_propagate_bit_exact(gpu_ctx, oracle_port, kind):
+    if kind == "chains":
+        h = scenes.hierarchy_chains(20000, 4, seed=2)
+    elif kind == "fans":
+        h = scenes.hierarchy_fans(50, 10, 4, seed=3)  # 50 x (1 + 10 + 100 + 1000)
+    else:
+        h = scenes.hierarchy_chains(5000, 1, seed=8)  # roots only
+    ow, roots, kids = oracle_world(oracle_port, h)
+    w = api.World(gpu_ctx)
+    w.build(h["parent"], gpu_inputs(ow, h["parent"], roots))
+    rng = np.random.default_rng(17)
+    for frame in range(3):
+        new_root = scenes.random_transforms(rng, len(roots), 4000.0)
+        ow.set_transforms(roots, new_root)
+        w.setTransforms(roots, new_root)
+        w.propagate()
+        assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms()), f"{kind} frame {frame}"
+
+
+def test_world_child_parent_order_independent(gpu_ctx, oracle_port):
+    """Entity indices of children may be smaller than their parents': slot order, not entity order, drives levels."""
+    h = scenes.hierarchy_fans(30, 3, 5, seed=13)
+    n = len(h["parent"])
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(n).astype(np.int32)  # new entity id of old entity i
+    parent = np.full(n, -1, np.int32)
+    local = np.zeros(n, api.TRANSFORM)
+    for old in range(n):
+        p = h["parent"][old]
+        parent[perm[old]] = -1 if p < 0 else perm[p]
+        local[perm[old]] = h["local"][old]
+    hp = {"parent": parent, "local": local}
+    n = len(parent)
+    ow = oracle_port.world(n)
+    roots = np.flatnonzero(parent < 0).astype(np.int32)
+    ow.init_transforms(roots, local[roots])
+    # parents must exist before children are attached: attach in BFS order
+    order, seen = list(roots), set(int(r) for r in roots)
+    children = {}
+    for e in range(n):
+        if parent[e] >= 0:
+            children.setdefault(int(parent[e]), []).append(e)
+    i = 0
+    while i < len(order):
+        for c in children.get(int(order[i]), []):
+            order.append(c)
+        i += 1
+    kids = np.array([e for e in order if parent[e] >= 0], np.int32)
+    ow.set_parents(parent[kids], kids)
+    ow.set_local_transforms(kids, local[kids])
+    w = api.World(gpu_ctx)
+    w.build(parent, gpu_inputs(ow, parent, roots))
+    new_root = scenes.random_transforms(rng, len(roots), 3000.0)
+    ow.set_transforms(roots, new_root)
+    w.setTransforms(roots, new_root)
+    w.propagate()
+    assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms())
+
+
+def test_world_moves_refresh_culling(gpu_ctx, oracle_port):
+    """transform -> sphere refresh -> cull, end to end (render_module.cpp:1544-1554 + culling_system.cpp:225-242)."""
+    h = scenes.hierarchy_chains(3000, 3, seed=4, root_extent=1500.0)
+    n = len(h["parent"])
+    rng = np.random.default_rng(33)
+    model_radius = rng.uniform(0.5, 40.0, n).astype(np.float32)
+    model_radius[:5] = 400.0  # a few spheres cross the is_big threshold when scales change
+    ow, roots, kids = oracle_world(oracle_port, h)
+    ocs = oracle_port.culling_system()
+    tr0 = ow.get_transforms()
+    ent = np.arange(n, dtype=np.int32)
+    r0 = model_radius * np.maximum(tr0["scale"][:, 0], np.maximum(tr0["scale"][:, 1], tr0["scale"][:, 2]))
+    ocs.add_bulk(ent, np.zeros(n, np.uint8), tr0["pos"], r0)
+    ow.bind_culling(ocs, ent, model_radius)
+
+    w = api.World(gpu_ctx)
+    w.build(h["parent"], gpu_inputs(ow, h["parent"], roots))
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(ent, np.zeros(n, np.uint8), tr0["pos"], r0)
+    w.bindCulling(ent, model_radius)
+    fr = np.concatenate([api.viewport_frustum(pos=(0, 0, 2000.0)), api.viewport_frustum(pos=(300.0, 50.0, -100.0), rot=H.quat_from_yaw_pitch(1.0, 0.1))])
+    for frame in range(4):
+        # small moves keep most entities in their cell (in-place refresh), large ones force re-binning
+        extent = 1500.0 if frame % 2 else 40.0
+        new_root = ow.get_transforms()[roots]
+        new_root["pos"] += rng.uniform(-extent, extent, size=(len(roots), 3))
+        new_root["scale"] = rng.uniform(0.5, 2.0, size=(len(roots), 3)).astype(np.float32)
+        ow.set_transforms(roots, new_root)
+        w.setTransforms(roots, new_root)
+        w.propagate()
+        assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms())
+        res = cs.cull(fr)
+        for f in range(len(fr)):
+            ids, types, _ = ocs.cull(fr[f : f + 1])
+            got_ids, got_types = res.all_ids(f)
+            H.assert_same_visible(H.sorted_by_type(got_ids, got_types), H.sorted_by_type(ids, types), f"frame {frame} frustum {f}")
+        for e in (0, 1, 2, 100, n - 1):
+            assert cs.getRadius(e) == ocs.get_radius(e)
+
+
+def test_skin_golden(gpu_ctx):
+    g = np.load(os.path.join(G, "skin.npz"))
+    sk = api.Skinning(gpu_ctx)
+    model = sk.addModel(g["parents"], g["bind"], int(g["first_nonroot"][0]))
+    mesh = sk.addMesh(g["verts"], g["skin"])
+    n_inst = g["rel_pos"].shape[0]
+    sk.setInstances([model] * n_inst, [mesh] * n_inst)
+    sk.uploadPoses(g["rel_pos"], g["rel_rot"])
+    sk.run()
+    for i in range(n_inst):
+        pos, rot = sk.readPose(i)
+        assert H.bits_equal(pos, g["abs_pos"][i]) and H.bits_equal(rot, g["abs_rot"][i])
+        assert H.bits_equal(sk.readPalette(i), g["palette"][i])
+        got, want = sk.readVertices(i), g["skinned"][i]
+        # north star: skinned positions within 1e-5 relative fp32; the FMA-free kernel is in fact bit-exact
+        assert np.allclose(got, want, rtol=1e-5, atol=0.0)
+        assert H.bits_equal(got, want)
+
+
+def test_skin_many_instances_vs_oracle(gpu_ctx, oracle_port):
+    """Two models (64 and 196 bones = Model::Bone::MAX_COUNT), three meshes with ragged vertex counts."""
+    sk = api.Skinning(gpu_ctx)
+    skel = [scenes.skeleton(64, seed=4), scenes.skeleton(196, seed=14), scenes.skeleton(1, seed=15)]
+    meshes = [scenes.skinned_mesh(1000, 64, seed=6), scenes.skinned_mesh(257, 196, seed=7), scenes.skinned_mesh(1, 1, seed=8)]
+    models = [sk.addModel(s["parents"], s["bind"], s["first_nonroot"] if len(s["parents"]) > 1 else -1) for s in skel]
+    mesh_ids = [sk.addMesh(v, s) for v, s in meshes]
+    rng = np.random.default_rng(2)
+    pick = rng.integers(0, 3, size=37)
+    sk.setInstances([models[k] for k in pick], [mesh_ids[k] for k in pick])
+    poses = [scenes.relative_poses(1, len(skel[k]["parents"]), seed=100 + i) for i, k in enumerate(pick)]
+    sk.uploadPoses(np.concatenate([p[0].reshape(-1, 3) for p in poses]), np.concatenate([p[1].reshape(-1, 4) for p in poses]))
+    sk.run()
+    for i, k in enumerate(pick):
+        s = skel[k]
+        fn = s["first_nonroot"] if len(s["parents"]) > 1 else 1
+        inv = oracle_port.invert_bind(s["bind"])
+        apos, arot = oracle_port.pose_compute_absolute(poses[i][0], poses[i][1], s["parents"], fn)
+        pal = oracle_port.skin_matrices(apos, arot, inv)
+        want = oracle_port.evaluate_skin(meshes[k][0], meshes[k][1], pal)[0]
+        assert H.bits_equal(sk.readPalette(i), pal[0]), f"instance {i} palette"
+        got = sk.readVertices(i)
+        assert np.allclose(got, want, rtol=1e-5, atol=0.0) and H.bits_equal(got, want), f"instance {i} vertices"
+
+
+def test_skin_config3_slice_properties(gpu_ctx, oracle_port):
+    """A slice of BASELINE config 3 (instances x 64 bones x 10 k verts, shared mesh): spot-checked against the oracle,
+    plus a linearity property — an identity pose on an identity-bind model leaves vertices where they were."""
+    n_inst, n_verts = 512, 10_000
+    s = scenes.skeleton(64, seed=4)
+    verts, skin = scenes.skinned_mesh(n_verts, 64, seed=6)
+    sk = api.Skinning(gpu_ctx)
+    model = sk.addModel(s["parents"], s["bind"], s["first_nonroot"])
+    mesh = sk.addMesh(verts, skin)
+    sk.setInstances([model] * n_inst, [mesh] * n_inst)
+    pos, rot = scenes.relative_poses(n_inst, 64, seed=5)
+    sk.uploadPoses(pos, rot)
+    sk.run()
+    inv = oracle_port.invert_bind(s["bind"])
+    for i in (0, 1, 255, 511):
+        apos, arot = oracle_port.pose_compute_absolute(pos[i : i + 1], rot[i : i + 1], s["parents"], s["first_nonroot"])
+        want = oracle_port.evaluate_skin(verts, skin, oracle_port.skin_matrices(apos, arot, inv))[0]
+        assert H.bits_equal(sk.readVertices(i), want)
+    # identity: bind = identity, pose = identity -> palette = identity -> weights sum (u16-quantised) scales the point
+    ident = np.zeros(64, api.LOCAL_RIGID)
+    ident["rot"][:, 3] = 1.0
+    sk2 = api.Skinning(gpu_ctx)
+    m2 = sk2.addModel(s["parents"], ident, s["first_nonroot"])
+    me2 = sk2.addMesh(verts, skin)
+    sk2.setInstances([m2], [me2])
+    sk2.uploadPoses(np.zeros((64, 3), np.float32), np.tile(np.array([0, 0, 0, 1], np.float32), (64, 1)))
+    sk2.run()
+    wsum = skin["weights"].sum(axis=1, dtype=np.float32)[:, None]
+    assert np.allclose(sk2.readVertices(0), verts * wsum, rtol=2e-6, atol=1e-7)
