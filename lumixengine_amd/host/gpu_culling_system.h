@@ -1,0 +1,126 @@
+// gpu_culling_system.h — C++ host side of the drop-in: a CullingSystem (src/renderer/culling_system.h:58-77) whose
+// cull() runs on an MI355X through the C ABI of liblumix_mi355.so.
+//
+// RenderModuleImpl owns its culling system through `UniquePtr<CullingSystem> m_culling_system`, created by the static
+// factory CullingSystem::create (src/renderer/render_module.cpp:3407,3569). GpuCullingSystem is a drop-in for that
+// member: same virtuals, same argument meaning, same ownership rules — cull() returns a linked list of 4 KiB
+// CullResult pages taken from the engine's PageAllocator, each page tagged with one renderable type, which the caller
+// frees with CullResult::free (src/renderer/culling_system.cpp:388-396); it returns nullptr when nothing is resident
+// (culling_system.cpp:322). Error convention of the reference: no exceptions; failures are logged and surface as an
+// empty result / ignored call (see lastError()).
+//
+// Threading: add/remove/set* arrive on the update thread; cull() may be called for several views per
+// frame from render jobs. Each concurrent cull() call takes its own result slot (LMX_MAX_VIEWS of them) under a mutex,
+// so calls serialise on the GPU stream but never alias results.
+#pragma once
+
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "lumix_mi355.h"
+
+#ifdef LMX_WITH_LUMIX_HEADERS
+	#include "core/geometry.h"
+	#include "core/math.h"
+	#include "core/page_allocator.h"
+	#include "renderer/culling_system.h"
+#else
+	#include "lumix_compat.h"
+#endif
+
+namespace Lumix {
+
+struct GpuCullingSystem final : CullingSystem {
+	GpuCullingSystem(PageAllocator& page_allocator, int device = 0) : m_page_allocator(page_allocator) {
+		if (lmx_ctx_create(device, &m_ctx) != LMX_OK) {
+			m_error = lmx_last_error(nullptr);
+			fprintf(stderr, "GpuCullingSystem: %s\n", m_error.c_str()); // the engine would logError(...)
+			m_ctx = nullptr;
+		}
+	}
+	~GpuCullingSystem() override { lmx_ctx_destroy(m_ctx); }
+
+	bool isValid() const { return m_ctx != nullptr; }
+	const std::string& lastError() const { return m_error; }
+	LmxContext* context() { return m_ctx; }
+
+	CullResult* cull(const ShiftedFrustum& frustum, u8 type) override { return cullInternal(frustum, type); } // culling_system.cpp:310-314
+	CullResult* cull(const ShiftedFrustum& frustum) override { return cullInternal(frustum, 0xff); }           // :316-319
+
+	bool isAdded(EntityRef entity) override { return m_ctx && lmx_cull_is_added(m_ctx, entity.index) != 0; }
+	void add(EntityRef entity, u8 type, const DVec3& pos, float radius) override {
+		const double p[3] = {pos.x, pos.y, pos.z};
+		check(lmx_cull_add(m_ctx, entity.index, type, p, radius));
+	}
+	void remove(EntityRef entity) override { check(lmx_cull_remove(m_ctx, entity.index)); }
+	void setPosition(EntityRef entity, const DVec3& pos) override {
+		const double p[3] = {pos.x, pos.y, pos.z};
+		check(lmx_cull_set_position(m_ctx, entity.index, p));
+	}
+	void setRadius(EntityRef entity, float radius) override { check(lmx_cull_set_radius(m_ctx, entity.index, radius)); }
+	void set(EntityRef entity, const DVec3& pos, float radius) override {
+		const double p[3] = {pos.x, pos.y, pos.z};
+		check(lmx_cull_set(m_ctx, entity.index, p, radius));
+	}
+	float getRadius(EntityRef entity) override {
+		float r = 0;
+		check(lmx_cull_get_radius(m_ctx, entity.index, &r));
+		return r;
+	}
+
+private:
+	bool check(int rc) {
+		if (rc == LMX_OK) return true;
+		m_error = m_ctx ? lmx_last_error(m_ctx) : "no context";
+		fprintf(stderr, "GpuCullingSystem: %s\n", m_error.c_str());
+		return false;
+	}
+
+	CullResult* newPage(u8 type) {
+		CullResult* page = new (m_page_allocator.allocate()) CullResult;
+		page->header.type = type;
+		return page;
+	}
+
+	CullResult* cullInternal(const ShiftedFrustum& frustum, u8 type) {
+		if (!m_ctx) return nullptr;
+		std::lock_guard<std::mutex> guard(m_mutex);
+		uint32_t n_entities = 0;
+		if (!check(lmx_cull_stats(m_ctx, &n_entities, nullptr, nullptr)) || n_entities == 0) return nullptr; // :322
+		const uint32_t view = m_next_view++ % LMX_MAX_VIEWS;
+		static_assert(sizeof(ShiftedFrustum) == sizeof(LmxShiftedFrustum), "layout");
+		if (!check(lmx_cull(m_ctx, view, reinterpret_cast<const LmxShiftedFrustum*>(&frustum), 1, type))) return nullptr;
+		uint32_t counts[LMX_MAX_TYPES];
+		if (!check(lmx_cull_counts(m_ctx, view, counts))) return nullptr;
+		CullResult* first = nullptr;
+		CullResult* last = nullptr;
+		constexpr uint32_t PAGE_IDS = sizeof(CullResult::entities) / sizeof(EntityRef);
+		for (uint32_t t = 0; t < LMX_MAX_TYPES; ++t) {
+			if (!counts[t]) continue;
+			m_scratch.resize(counts[t]);
+			uint32_t got = 0;
+			if (!check(lmx_cull_read(m_ctx, view, 0, (u8)t, m_scratch.data(), counts[t], &got))) break;
+			for (uint32_t i = 0; i < got; i += PAGE_IDS) {
+				CullResult* page = newPage((u8)t);
+				const uint32_t n = got - i < PAGE_IDS ? got - i : PAGE_IDS;
+				for (uint32_t k = 0; k < n; ++k) page->entities[k].index = m_scratch[i + k];
+				page->header.count = n;
+				if (last) last->header.next = page; else first = page;
+				last = page;
+			}
+		}
+		if (!first) first = newPage(type == 0xff ? 0 : type); // the reference returns >= 1 (possibly empty) page per visited cell
+		return first;
+	}
+
+	PageAllocator& m_page_allocator;
+	LmxContext* m_ctx = nullptr;
+	std::mutex m_mutex;
+	uint32_t m_next_view = 0;
+	std::vector<int32_t> m_scratch;
+	std::string m_error;
+};
+
+} // namespace Lumix

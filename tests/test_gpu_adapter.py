@@ -1,0 +1,79 @@
+"""The C++ host side (lumixengine_amd/host/gpu_culling_system.h: GpuCullingSystem : CullingSystem) driven through the
+reference's virtual interface by a small C++ program, compared with the CPU oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from lumixengine_amd import api
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "test_adapter.cpp")
+EXE = os.path.join(ROOT, "tests", "_build", "test_adapter")
+
+
+def build_adapter_test():
+    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    deps = [SRC, os.path.join(ROOT, "lumixengine_amd", "host", "gpu_culling_system.h"), os.path.join(ROOT, "lumixengine_amd", "host", "lumix_compat.h")]
+    if os.path.exists(EXE) and all(os.path.getmtime(d) <= os.path.getmtime(EXE) for d in deps):
+        return
+    lib_dir = os.path.join(ROOT, "lumixengine_amd")
+    subprocess.run(
+        ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "lumixengine_amd", "host"), SRC, "-o", EXE,
+         "-L" + lib_dir, "-llumix_mi355", "-Wl,-rpath," + lib_dir, "-pthread"],
+        check=True,
+    )
+
+
+def test_adapter_compiles_and_links():
+    """CPU check: the adapter builds against the standalone compat header and links the C ABI."""
+    from lumixengine_amd import build
+
+    if not os.path.exists(api.LIB_PATH):
+        build.build()
+    build_adapter_test()
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+def test_adapter_matches_oracle(tmp_path, oracle_port):
+    build_adapter_test()
+    sc = H.mixed_scene(30000, 2500.0, seed=12)
+    rng = np.random.default_rng(4)
+    n = len(sc["entity"])
+    n_moves = 3000
+    move_entity = rng.choice(sc["entity"][1:], size=n_moves, replace=False).astype(np.int32)
+    move_pos = rng.uniform(-2500, 2500, size=(n_moves, 3))
+    move_radius = rng.choice([5.0, 40.0, 299.0, 301.0, 650.0], size=n_moves).astype(np.float32)
+    fr = H.frusta(api)
+    inp, outp = tmp_path / "scene.bin", tmp_path / "visible.bin"
+    with open(inp, "wb") as f:
+        f.write(np.array([n, n_moves, len(fr)], np.uint32).tobytes())
+        for a in (sc["entity"].astype(np.int32), sc["type"].astype(np.uint8), sc["pos"].astype(np.float64), sc["radius"].astype(np.float32), move_entity,
+                  move_pos.astype(np.float64), move_radius, np.ascontiguousarray(fr)):
+            f.write(a.tobytes())
+    r = subprocess.run([EXE, str(inp), str(outp)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # the same sequence on the oracle
+    ocs = oracle_port.culling_system()
+    ocs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    for i in range(n_moves):
+        e = int(move_entity[i])
+        if i % 3 == 0:
+            ocs.set(e, move_pos[i], float(move_radius[i]))
+        elif i % 3 == 1:
+            ocs.set_position(e, move_pos[i])
+        else:
+            ocs.set_radius(e, float(move_radius[i]))
+    ocs.remove(int(sc["entity"][0]))
+    raw = np.fromfile(outp, dtype=np.int32)
+    cur = 0
+    for f in range(len(fr)):
+        total = int(raw[cur])
+        rec = raw[cur + 1 : cur + 1 + 2 * total].reshape(total, 2)
+        cur += 1 + 2 * total
+        ids, types, _ = ocs.cull(fr[f : f + 1], 0 if f % 2 else 0xFF)
+        H.assert_same_visible(H.sorted_by_type(rec[:, 1], rec[:, 0].astype(np.uint8)), H.sorted_by_type(ids, types), f"frustum {f}")
+    assert cur == len(raw)
