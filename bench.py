@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--variant", choices=["sparse", "dense"], default="sparse")
     ap.add_argument("--camera", choices=["default", "all_visible"], default="default",
                     help="all_visible: camera far outside looking at the whole cube (every sphere is fetched and visible) - the pure streaming case used to calibrate PMC byte counters")
+    ap.add_argument("--force-collective", action="store_true", help="run the N>1 code path (RCCL all-gather of visible ids) even with one rank")
     ap.add_argument("--no-extras", action="store_true", help="skip the dense-variant / transform / skin side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -60,15 +61,28 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_collective
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        # RCCL prints a version banner on the C-level stdout at communicator creation; stdout must carry the JSON line only
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     ctx = api.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launches and torch.cuda.synchronize() share one stream
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def timed(fn, steps):
@@ -80,7 +94,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         ms = (time.perf_counter() - t0) * 1e3 / steps
-        if world > 1:
+        if use_dist:
             t = torch.tensor([ms], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ms = float(t.item())
@@ -100,7 +114,7 @@ def main():
         frustum = api.viewport_frustum(pos=(0.0, 0.0, 4.0 * half), far=20.0 * half)
     n_frusta = 1
 
-    if world > 1:
+    if use_dist:
         n_padded = stats["chunks"] * 64
         out_ids = torch.empty(n_frusta * n_padded, dtype=torch.int32, device="cuda")
         out_counts = torch.zeros(api.MAX_FRUSTA * api.MAX_TYPES, dtype=torch.int32, device="cuda")
@@ -109,7 +123,8 @@ def main():
         def step():
             cs.cull(frustum)
             # visible MESH ids of frustum 0 start at offset 0 of the bound buffer (type 0 is the first type range)
-            D.allgather_visible(out_ids.view(n_frusta, n_padded), out_counts.view(api.MAX_FRUSTA, api.MAX_TYPES)[:n_frusta, 0])
+            gathered = D.allgather_visible(out_ids.view(n_frusta, n_padded), out_counts.view(api.MAX_FRUSTA, api.MAX_TYPES)[:n_frusta, 0])
+            return gathered
     else:
 
         def step():
@@ -208,9 +223,15 @@ def main():
             result["extra"] = extras(ctx, api, scenes, torch, timed, N, log)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(scenes, frustum, N, half, log)
+    if use_dist:
+        # sanity of the exchange step: every rank's list arrived with the advertised length
+        gathered = step()
+        got = [int(t.numel()) for t in gathered[0]]
+        result["config"]["allgather_visible_counts"] = got
+        assert len(got) == world and got[rank] == visible, (got, visible)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -258,6 +279,15 @@ def extras(ctx, api, scenes, torch, timed, N, log):
     for _ in range(10):
         xform_step()
     ms = timed(xform_step, 100)
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    for _ in range(20):
+        xform_step()
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    t_lvl, n_lvl = ctx.profile_get(api.K_XFORM_LEVEL)
+    out["xform_level_kernel_avg_ms"] = t_lvl / max(n_lvl, 1)
+    out["xform_level_launches_per_frame"] = n_lvl / 20
     n_child = n - len(roots)
     out["transforms_per_sec"] = n_child / (ms * 1e-3)
     out["transform_ms_per_frame"] = ms
@@ -283,6 +313,17 @@ def extras(ctx, api, scenes, torch, timed, N, log):
     for _ in range(5):
         skin_step()
     ms = timed(skin_step, 50)
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    for _ in range(20):
+        skin_step()
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    t_pp, n_pp = ctx.profile_get(api.K_POSE_PALETTE)
+    t_sv, n_sv = ctx.profile_get(api.K_SKIN_VERTICES)
+    out["pose_palette_kernel_avg_ms"] = t_pp / max(n_pp, 1)
+    out["skin_vertices_kernel_avg_ms"] = t_sv / max(n_sv, 1)
+    out["skin_vertices_kernel_verts_per_sec"] = n_inst * n_verts / (t_sv / max(n_sv, 1) * 1e-3)
     out["skinned_verts_per_sec"] = n_inst * n_verts / (ms * 1e-3)
     out["skin_ms_per_frame"] = ms
     out["skin_instances"] = n_inst

@@ -49,7 +49,8 @@ LMX_API int lmx_ctx_create(int device, LmxContext** out);
 LMX_API void lmx_ctx_destroy(LmxContext* ctx);
 /* Last error text of this context (or of the failed lmx_ctx_create when ctx == NULL). Never NULL. */
 LMX_API const char* lmx_last_error(const LmxContext* ctx);
-/* Use an external HIP stream (hipStream_t as void*) for all launches/copies; NULL restores the context's own. */
+/* Use an external HIP stream (hipStream_t as void*) for all launches/copies instead of the context's own non-blocking
+ * stream. NULL means the legacy default (null) stream, as everywhere in HIP. */
 LMX_API int lmx_ctx_set_stream(LmxContext* ctx, void* hip_stream);
 LMX_API int lmx_ctx_synchronize(LmxContext* ctx);
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg). kernel ids: LMX_K_*. */

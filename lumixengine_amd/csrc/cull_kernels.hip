@@ -11,6 +11,8 @@
 //                     ONE global atomic per (tile, frustum) and a coalesced flush of the visible ids.
 //
 // Built with -ffp-contract=off: the plane arithmetic must round exactly like the reference's scalar float4.
+#include <cstdlib>
+
 #include "lmx_kernels.h"
 
 namespace lmx {
@@ -146,6 +148,145 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_spheres(const float4* __res
 	}
 }
 
+// ---- fused variant: per-tile classification in LDS -----------------------------------------------------------
+// One launch per cull. Cell slots are consecutive along the sphere order, so the cells a tile touches are the range
+// [chunk_cell[first chunk], cell of the tile's last sphere]; the block classifies exactly those cells (one thread per
+// cell x frustum, same arithmetic as k_cull_classify) into LDS, votes whether anything in the tile survives, and only
+// then touches spheres/ids. Compared with classify + spheres this removes a kernel boundary, the 16 B/cell/frustum
+// round trip through global memory and one dependent gather per chunk. Cells straddling two tiles are classified by
+// both (harmless). The host guarantees cell_cap >= cells per tile (layout max) and falls back to the two-kernel path
+// when the LDS budget would not fit.
+template <int F, int WAVES, int CHW>
+__global__ __launch_bounds__(WAVES * 64) void k_cull_fused(const float4* __restrict__ spheres, const int32_t* __restrict__ ids,
+	const uint32_t* __restrict__ chunk_cell, const uint64_t* __restrict__ chunk_flags, const CellKey* __restrict__ tile_cells,
+	const uint32_t* __restrict__ tile_tab, FrustaArg fr, TypeTable tt, uint32_t ent_begin, uint32_t cell_cap,
+	int32_t* __restrict__ out_ids, uint32_t out_stride, uint32_t* __restrict__ counts, uint32_t* __restrict__ counts_next) {
+	constexpr int TILE = WAVES * CHW * 64;
+	constexpr int NCH = WAVES * CHW;
+	extern __shared__ float4 s_dyn[]; // [F * cell_cap] cell info | [F * TILE] staged ids | [F] counts | [F] bases
+	float4* s_info = s_dyn;
+	int32_t* s_buf = reinterpret_cast<int32_t*>(s_dyn + (size_t)F * cell_cap);
+	uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_buf + F * TILE);
+	uint32_t* s_base = s_cnt + F;
+
+	const uint32_t lane = lane_id();
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t tile_ent = ent_begin + blockIdx.x * (uint32_t)TILE;
+	const uint32_t tile_chunk = tile_ent >> 6;
+
+	// the counters of the NEXT cull on this view are cleared here (ping-pong), so no cull needs a separate memset
+	if (counts_next != nullptr && blockIdx.x == 0 && threadIdx.x < MAX_FRUSTA * MAX_TYPES) counts_next[threadIdx.x] = 0;
+	if (threadIdx.x < F) s_cnt[threadIdx.x] = 0;
+
+	// Everything the block needs first sits at addresses that depend on blockIdx only: {first cell, n cells} of the tile
+	// (scalar load) and the tile's cell keys (tile-major, stride cell_cap) - no dependent round trip before phase A.
+	const uint32_t chunk0 = tile_chunk + wave * CHW;
+	const uint32_t tile_index = tile_ent / (uint32_t)TILE;
+	const uint32_t first_cell = tile_tab[2 * tile_index];
+	const uint32_t n_cells = tile_tab[2 * tile_index + 1];
+	const CellKey* keys = tile_cells + (size_t)tile_index * cell_cap;
+
+	// phase A: classify the tile's cells into LDS
+	bool live = false;
+	for (uint32_t t = threadIdx.x; t < cell_cap; t += WAVES * 64) {
+		const CellKey key = keys[t]; // issued before n_cells is known; the tail of the slice holds dead keys
+		if (t < n_cells) {
+			const bool dead = (key.meta & CELL_DEAD) != 0;
+			const bool big = (key.meta & 0x100u) != 0;
+#pragma unroll
+			for (int f = 0; f < F; ++f) {
+				V3 off = V3{0.f, 0.f, 0.f};
+				uint32_t cls = CELL_REJECT;
+				if (!dead) cls = classify_cell(fr.f[f], IV3{key.ix, key.iy, key.iz}, big, &off);
+				s_info[f * cell_cap + t] = make_float4(off.x, off.y, off.z, __uint_as_float(cls));
+				live |= cls != CELL_REJECT;
+			}
+		}
+	}
+	if (!__syncthreads_or(live ? 1 : 0)) return; // nothing in this tile survives the per-cell tests
+
+	uint32_t type = 0;
+#pragma unroll
+	for (int t = 0; t < MAX_TYPES; ++t) {
+		if (tile_ent >= tt.ent_start[t] && tile_ent < tt.ent_end[t]) type = t;
+	}
+
+	// phase B: per-lane cell, class from LDS, spheres / ids only for chunks that need them. The wave's CHW chunks are
+	// processed in groups of GRP so that at most GRP chunks' worth of cell info / spheres / ids are live in registers
+	// (VGPR count decides how many tiles a CU keeps in flight, and this kernel is latency-bound).
+	const uint64_t le_mask = (~0ull >> (63u - lane)) & ~1ull; // bits 1..lane
+	constexpr int GRP = CHW > 4 ? 4 : CHW;
+#pragma unroll
+	for (int g = 0; g < CHW; g += GRP) {
+		__builtin_amdgcn_sched_barrier(0); // keep the groups' loads from being hoisted over each other (register peak)
+		float4 info[F][GRP];
+		bool need_id[GRP], need_sphere[GRP];
+		uint32_t base_cell[GRP];
+		uint64_t flags[GRP];
+#pragma unroll
+		for (int i = 0; i < GRP; ++i) {
+			base_cell[i] = chunk_cell[chunk0 + g + i];
+			flags[i] = chunk_flags[chunk0 + g + i];
+		}
+#pragma unroll
+		for (int i = 0; i < GRP; ++i) {
+			const uint32_t local = base_cell[i] + (uint32_t)__popcll(flags[i] & le_mask) - first_cell;
+			bool any_live = false, any_test = false;
+#pragma unroll
+			for (int f = 0; f < F; ++f) {
+				info[f][i] = s_info[f * cell_cap + local];
+				const uint32_t cls = __float_as_uint(info[f][i].w);
+				any_live |= cls != CELL_REJECT;
+				any_test |= cls == CELL_TEST;
+			}
+			need_id[i] = __ballot(any_live) != 0;
+			need_sphere[i] = __ballot(any_test) != 0;
+		}
+		int32_t id[GRP];
+		float4 sp[GRP];
+#pragma unroll
+		for (int i = 0; i < GRP; ++i) {
+			const uint32_t e = ((chunk0 + g + i) << 6) + lane;
+			id[i] = -1;
+			sp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (need_id[i]) id[i] = ids[e];
+			if (need_sphere[i]) sp[i] = spheres[e];
+		}
+#pragma unroll
+		for (int i = 0; i < GRP; ++i) {
+			if (!need_id[i]) continue;
+#pragma unroll
+			for (int f = 0; f < F; ++f) {
+				const uint32_t cls = __float_as_uint(info[f][i].w);
+				bool vis = cls == CELL_ACCEPT;
+				if (cls == CELL_TEST) {
+					vis = sphere_visible(fr.f[f], V3{info[f][i].x, info[f][i].y, info[f][i].z}, sp[i].x, sp[i].y, sp[i].z, sp[i].w);
+				}
+				vis = vis && id[i] >= 0;
+				const uint64_t mask = __ballot(vis);
+				if (mask != 0) {
+					uint32_t base = 0;
+					if (lane == 0) base = atomicAdd(&s_cnt[f], (uint32_t)__popcll(mask));
+					base = __builtin_amdgcn_readfirstlane(base);
+					if (vis) s_buf[f * TILE + base + mbcnt64(mask)] = id[i];
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < F) {
+		const uint32_t c = s_cnt[threadIdx.x];
+		s_base[threadIdx.x] = c ? atomicAdd(&counts[threadIdx.x * MAX_TYPES + type], c) : 0u;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int f = 0; f < F; ++f) {
+		const uint32_t c = s_cnt[f];
+		int32_t* dst = out_ids + (size_t)f * out_stride + tt.ent_start[type] + s_base[f];
+		for (uint32_t k = threadIdx.x; k < c; k += WAVES * 64) dst[k] = s_buf[f * TILE + k];
+	}
+}
+
 __global__ __launch_bounds__(256) void k_patch_spheres(float4* __restrict__ spheres, const uint32_t* __restrict__ slot,
 	const float4* __restrict__ value, uint32_t n) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -172,7 +313,53 @@ hipError_t spheres_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin,
 	return hipGetLastError();
 }
 
+template <int F, int WAVES, int CHW>
+hipError_t fused_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt, const FrustaArg& fr,
+	int32_t* out_ids, uint32_t out_stride, uint32_t* counts, uint32_t* counts_next) {
+	constexpr uint32_t TILE = WAVES * CHW * 64;
+	static_assert(TILE_ALIGN % TILE == 0, "tiles must not straddle type ranges");
+	constexpr int K = TILE == 4096 ? 0 : (TILE == 2048 ? 1 : 2);
+	const uint32_t tiles = (ent_end - ent_begin) / TILE;
+	if (!tiles) return hipSuccess;
+	const uint32_t cell_cap = v.tile_cap[K];
+	const size_t lds = fused_lds_bytes(F, TILE, cell_cap);
+	hipLaunchKernelGGL((k_cull_fused<F, WAVES, CHW>), dim3(tiles), dim3(WAVES * 64), lds, s, v.spheres, v.ids, v.chunk_cell, v.chunk_flags,
+		v.tile_cells[K], v.tile_tab[K], fr, tt, ent_begin, cell_cap, out_ids, out_stride, counts, counts_next);
+	return hipGetLastError();
+}
+
 } // namespace
+
+uint32_t cull_tile_size(int n_frusta) {
+	static const uint32_t f1_tile = [] { // experiment knob: LMX_CULL_TILE=2048 runs the 1-frustum kernel with 4 waves per block
+		const char* e = getenv("LMX_CULL_TILE");
+		return (e && atoi(e) == 2048) ? 2048u : 4096u;
+	}();
+	return n_frusta <= 1 ? f1_tile : (n_frusta <= 4 ? 2048u : 1024u);
+}
+
+size_t fused_lds_bytes(int n_frusta, uint32_t tile, uint32_t cell_cap) {
+	return (size_t)n_frusta * cell_cap * sizeof(float4) + (size_t)n_frusta * tile * sizeof(int32_t) + 2 * MAX_FRUSTA * sizeof(uint32_t);
+}
+
+hipError_t launch_cull_fused(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
+	const FrustaArg& fr, int n_frusta, int32_t* out_ids, uint32_t out_stride, uint32_t* counts, uint32_t* counts_next) {
+#define LMX_FUSED(F, W, C) return fused_f<F, W, C>(s, v, ent_begin, ent_end, tt, fr, out_ids, out_stride, counts, counts_next)
+	switch (n_frusta) {
+		case 1:
+			if (cull_tile_size(1) == 2048u) LMX_FUSED(1, 4, 8);
+			LMX_FUSED(1, 8, 8);
+		case 2: LMX_FUSED(2, 8, 4);
+		case 3: LMX_FUSED(3, 8, 4);
+		case 4: LMX_FUSED(4, 8, 4);
+		case 5: LMX_FUSED(5, 4, 4);
+		case 6: LMX_FUSED(6, 4, 4);
+		case 7: LMX_FUSED(7, 4, 4);
+		case 8: LMX_FUSED(8, 4, 4);
+		default: return hipErrorInvalidValue;
+	}
+#undef LMX_FUSED
+}
 
 hipError_t launch_cull_classify(hipStream_t s, const CullDeviceView& v, uint32_t cell_begin, uint32_t n, const FrustaArg& fr,
 	int n_frusta, float4* cellinfo, uint32_t cell_stride, uint32_t* counts) {
@@ -194,7 +381,9 @@ hipError_t launch_cull_spheres(hipStream_t s, const CullDeviceView& v, uint32_t 
 	uint32_t* counts) {
 #define LMX_SPH(F, W, C) return spheres_f<F, W, C>(s, v, ent_begin, ent_end, tt, fr, cellinfo, cell_stride, out_ids, out_stride, counts)
 	switch (n_frusta) {
-		case 1: LMX_SPH(1, 8, 8); // TILE 4096, 16 KiB LDS
+		case 1:
+			if (cull_tile_size(1) == 2048u) LMX_SPH(1, 4, 8);
+			LMX_SPH(1, 8, 8); // TILE 4096, 16 KiB LDS
 		case 2: LMX_SPH(2, 8, 4); // TILE 2048, 16 KiB
 		case 3: LMX_SPH(3, 8, 4); // 24 KiB
 		case 4: LMX_SPH(4, 8, 4); // 32 KiB

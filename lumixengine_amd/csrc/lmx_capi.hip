@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -61,8 +62,12 @@ struct CullView {
 	int32_t* ext_out = nullptr;
 	size_t ext_out_cap = 0;
 	uint32_t* ext_counts = nullptr;
+	// library-owned counters are double-buffered: the fused kernel clears the half the NEXT cull will use
+	uint32_t flip = 0;
+	bool next_half_is_zero = false;
 	int32_t* out_ptr() const { return ext_out ? ext_out : out.p; }
-	uint32_t* counts_ptr() const { return ext_counts ? ext_counts : counts.p; }
+	uint32_t* counts_ptr() const { return ext_counts ? ext_counts : counts.p + flip * (MAX_FRUSTA * MAX_TYPES); }
+	uint32_t* counts_other() const { return counts.p + (flip ^ 1u) * (MAX_FRUSTA * MAX_TYPES); }
 };
 
 struct CullState {
@@ -82,9 +87,14 @@ struct CullState {
 	DevBuf<uint32_t> chunk_cell;
 	DevBuf<uint64_t> chunk_flags;
 	DevBuf<CellKey> cells;
+	DevBuf<CellKey> tile_cells[3];
+	DevBuf<uint32_t> tile_tab[3];
+	uint32_t tile_cap[3] = {16, 16, 16};
 	DevBuf<uint32_t> sphere_cell; // per-slot cell index, only filled when a world binding needs it
 	std::vector<uint32_t> h_sphere_cell;
 	uint32_t n_padded = 0, n_cells = 0;
+	uint32_t max_tile_cells[3] = {0, 0, 0};
+	uint32_t n_dead_cells = 0;
 	TypeTable tt = {};
 	uint32_t cell_begin[MAX_TYPES] = {}, cell_end[MAX_TYPES] = {};
 	uint64_t generation = 0;
@@ -310,6 +320,8 @@ int cull_rebuild(LmxContext* ctx) {
 	}
 	cs.n_padded = (uint32_t)n_padded;
 	cs.n_cells = (uint32_t)lay.cells.size();
+	for (int k = 0; k < 3; ++k) cs.max_tile_cells[k] = lay.max_tile_cells[k];
+	cs.n_dead_cells = lay.n_dead_cells;
 	LMX_HIP(ctx, cs.spheres.reserve(std::max<size_t>(n_padded, 1)));
 	LMX_HIP(ctx, cs.ids.reserve(std::max<size_t>(n_padded, 1)));
 	LMX_HIP(ctx, cs.chunk_cell.reserve(std::max<size_t>(n_chunks, 1)));
@@ -323,6 +335,15 @@ int cull_rebuild(LmxContext* ctx) {
 		LMX_HIP(ctx, hipMemcpy(cs.chunk_cell.p, lay.chunk_cell.data(), n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(cs.chunk_flags.p, lay.chunk_flags.data(), n_chunks * sizeof(uint64_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(cs.cells.p, lay.cells.data(), cs.n_cells * sizeof(CellKey), hipMemcpyHostToDevice));
+	}
+	for (int k = 0; k < 3; ++k) {
+		cs.tile_cap[k] = lay.tile_cap[k];
+		LMX_HIP(ctx, cs.tile_cells[k].reserve(std::max<size_t>(lay.tile_cells[k].size(), 1)));
+		LMX_HIP(ctx, cs.tile_tab[k].reserve(std::max<size_t>(lay.tile_tab[k].size(), 1)));
+		if (!lay.tile_cells[k].empty()) {
+			LMX_HIP(ctx, hipMemcpy(cs.tile_cells[k].p, lay.tile_cells[k].data(), lay.tile_cells[k].size() * sizeof(CellKey), hipMemcpyHostToDevice));
+			LMX_HIP(ctx, hipMemcpy(cs.tile_tab[k].p, lay.tile_tab[k].data(), lay.tile_tab[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+		}
 	}
 	cs.rec_slot.swap(lay.rec_slot);
 	cs.h_sphere_cell.swap(lay.slot_cell);
@@ -357,6 +378,11 @@ CullDeviceView cull_dev(const CullState& cs) {
 	v.cells = cs.cells.p;
 	v.n_padded = cs.n_padded;
 	v.n_cells = cs.n_cells;
+	for (int k = 0; k < 3; ++k) {
+		v.tile_cells[k] = cs.tile_cells[k].p;
+		v.tile_tab[k] = cs.tile_tab[k].p;
+		v.tile_cap[k] = cs.tile_cap[k];
+	}
 	return v;
 }
 
@@ -410,7 +436,7 @@ const char* lmx_last_error(const LmxContext* ctx) { return ctx ? ctx->error.c_st
 int lmx_ctx_set_stream(LmxContext* ctx, void* hip_stream) {
 	LMX_CHECK_CTX(ctx);
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+	ctx->stream = (hipStream_t)hip_stream; // NULL is the legacy default (null) stream, as everywhere in HIP
 	return LMX_OK;
 }
 
@@ -587,10 +613,8 @@ int lmx_cull_stats(LmxContext* ctx, uint32_t* n_entities, uint32_t* n_cells, uin
 	LMX_CHECK_CTX(ctx);
 	if (int rc = cull_flush(ctx)) return rc;
 	const CullState& cs = ctx->cull;
-	uint32_t dead = 0;
-	for (int t = 0; t < MAX_TYPES; ++t) dead += cs.cell_end[t] > cs.cell_begin[t] ? 1u : 0u;
 	if (n_entities) *n_entities = (uint32_t)cs.recs.size();
-	if (n_cells) *n_cells = cs.n_cells - dead;
+	if (n_cells) *n_cells = cs.n_cells - cs.n_dead_cells;
 	if (n_chunks) *n_chunks = cs.n_padded / CHUNK;
 	return LMX_OK;
 }
@@ -603,12 +627,15 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 	if (int rc = cull_flush(ctx)) return rc;
 	CullState& cs = ctx->cull;
 	CullView& v = cs.views[view];
-	LMX_HIP(ctx, v.cellinfo.reserve((size_t)std::max(cs.n_cells, 1u) * n_frusta));
 	if (v.ext_out) {
 		if (v.ext_out_cap < (size_t)cs.n_padded * n_frusta)
 			return fail(ctx, LMX_ERR_CAPACITY, "bound output holds %zu ids, need %zu", v.ext_out_cap, (size_t)cs.n_padded * n_frusta);
 	} else {
-		LMX_HIP(ctx, v.counts.reserve(MAX_FRUSTA * MAX_TYPES));
+		if (!v.counts.p) {
+			LMX_HIP(ctx, v.counts.reserve(2 * MAX_FRUSTA * MAX_TYPES));
+			v.flip = 0;
+			v.next_half_is_zero = false;
+		}
 		LMX_HIP(ctx, v.out.reserve((size_t)std::max(cs.n_padded, 1u) * n_frusta));
 	}
 	v.n_frusta = n_frusta;
@@ -630,14 +657,40 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 		ent_end = cs.tt.ent_end[type];
 	}
 	const CullDeviceView dv = cull_dev(cs);
-	{
-		ProfScope ps(ctx, LMX_K_CULL_CLASSIFY);
-		LMX_HIP(ctx, launch_cull_classify(ctx->stream, dv, cell_begin, cell_n, fr, (int)n_frusta, v.cellinfo.p, v.cell_stride, v.counts_ptr()));
-	}
-	{
+	// fused single-launch path when the per-tile cell table fits the dynamic-LDS budget, else classify + spheres
+	const uint32_t tile = cull_tile_size((int)n_frusta);
+	const uint32_t tile_k = tile == 4096 ? 0 : (tile == 2048 ? 1 : 2);
+	const uint32_t cell_cap = cs.tile_cap[tile_k];
+	static const bool force_two_kernels = getenv("LMX_CULL_TWO_KERNELS") != nullptr;
+	const bool fused = !force_two_kernels && fused_lds_bytes((int)n_frusta, tile, cell_cap) <= 64 * 1024;
+	if (fused) {
+		uint32_t* counts_next = nullptr;
+		if (v.ext_counts) {
+			LMX_HIP(ctx, hipMemsetAsync(v.ext_counts, 0, sizeof(uint32_t) * MAX_FRUSTA * MAX_TYPES, ctx->stream));
+		} else {
+			v.flip ^= 1u;
+			if (!v.next_half_is_zero) LMX_HIP(ctx, hipMemsetAsync(v.counts_ptr(), 0, sizeof(uint32_t) * MAX_FRUSTA * MAX_TYPES, ctx->stream));
+			counts_next = v.counts_other();
+			v.next_half_is_zero = ent_end > ent_begin; // block 0 of the launch below clears it
+		}
 		ProfScope ps(ctx, LMX_K_CULL_SPHERES);
-		LMX_HIP(ctx, launch_cull_spheres(ctx->stream, dv, ent_begin, ent_end, cs.tt, fr, (int)n_frusta, v.cellinfo.p, v.cell_stride, v.out_ptr(),
-			v.out_stride, v.counts_ptr()));
+		LMX_HIP(ctx, launch_cull_fused(ctx->stream, dv, ent_begin, ent_end, cs.tt, fr, (int)n_frusta, v.out_ptr(), v.out_stride,
+			v.counts_ptr(), counts_next));
+	} else {
+		if (!v.ext_counts) {
+			v.flip ^= 1u;
+			v.next_half_is_zero = false;
+		}
+		LMX_HIP(ctx, v.cellinfo.reserve((size_t)std::max(cs.n_cells, 1u) * n_frusta));
+		{
+			ProfScope ps(ctx, LMX_K_CULL_CLASSIFY);
+			LMX_HIP(ctx, launch_cull_classify(ctx->stream, dv, cell_begin, cell_n, fr, (int)n_frusta, v.cellinfo.p, v.cell_stride, v.counts_ptr()));
+		}
+		{
+			ProfScope ps(ctx, LMX_K_CULL_SPHERES);
+			LMX_HIP(ctx, launch_cull_spheres(ctx->stream, dv, ent_begin, ent_end, cs.tt, fr, (int)n_frusta, v.cellinfo.p, v.cell_stride, v.out_ptr(),
+				v.out_stride, v.counts_ptr()));
+		}
 	}
 	v.valid = true;
 	return LMX_OK;

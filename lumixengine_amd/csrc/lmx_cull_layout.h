@@ -22,6 +22,12 @@ constexpr int LAYOUT_MAX_TYPES = 8;
 constexpr uint32_t LAYOUT_CHUNK = 64;
 constexpr uint32_t LAYOUT_TILE_ALIGN = 4096;
 constexpr uint32_t LAYOUT_CELL_DEAD = 0x80000000u;
+// No aligned block of LAYOUT_CELL_BLOCK slots touches more than LAYOUT_MAX_CELLS_PER_BLOCK cell slots (dead cells
+// included): the fused cull kernel keeps one tile's cell table in LDS (8 frusta x 240 cells x 16 B = 30 KiB for the
+// 1024-slot tile, 4 x 240 cells for the 4096-slot tile). Runs of tiny cells (e.g. "big" spheres, one per cell) are
+// spread over more blocks with dead padding, which costs slots but no sphere traffic (dead chunks are never fetched).
+constexpr uint32_t LAYOUT_CELL_BLOCK = 1024;
+constexpr uint32_t LAYOUT_MAX_CELLS_PER_BLOCK = 240;
 
 struct CullRec { // host mirror of one Sphere + its CellIndices (culling_system.cpp:23-40, 98-128)
 	IV3 cell;
@@ -46,6 +52,15 @@ struct CullLayout {
 	uint32_t ent_start[LAYOUT_MAX_TYPES], ent_end[LAYOUT_MAX_TYPES];
 	uint32_t cell_begin[LAYOUT_MAX_TYPES], cell_end[LAYOUT_MAX_TYPES];
 	uint32_t n_padded = 0;
+	uint32_t n_dead_cells = 0; // dead entries inside `cells`
+	// max number of distinct cell slots touched by one tile, for tile sizes 4096 / 2048 / 1024 spheres (fused kernel LDS)
+	uint32_t max_tile_cells[3] = {0, 0, 0};
+	// Per tile-size variant k (tile = 4096 >> k): the cell keys each tile touches, stored tile-major with a fixed stride
+	// tile_cap[k] (= max_tile_cells[k] rounded up to 16), so that a block finds its cells at an address that depends on
+	// blockIdx only (no dependent load), plus {first cell slot, number of cells} per tile.
+	uint32_t tile_cap[3] = {16, 16, 16};
+	std::vector<LayoutCell> tile_cells[3]; // [n_tiles_k * tile_cap[k]], unused tail entries are dead
+	std::vector<uint32_t> tile_tab[3];     // [n_tiles_k * 2] = {first_cell, n_cells}
 };
 
 // CullingSystemImpl::add, culling_system.cpp:131-157 + addToCell :100
@@ -99,51 +114,72 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 
 	size_t count_by_type[LAYOUT_MAX_TYPES] = {};
 	for (size_t i = 0; i < n; ++i) count_by_type[recs[i].type]++;
-	size_t n_padded = 0;
-	for (int t = 0; t < LAYOUT_MAX_TYPES; ++t) {
-		out.ent_start[t] = (uint32_t)n_padded;
-		// at least one dead slot per present type, so the dead cell is reachable through the flag chain
-		if (count_by_type[t]) n_padded += ((count_by_type[t] + 1 + LAYOUT_TILE_ALIGN - 1) / LAYOUT_TILE_ALIGN) * LAYOUT_TILE_ALIGN;
-		out.ent_end[t] = (uint32_t)n_padded;
-	}
-	if (n_padded > 0x7fffffffull) return false;
 
-	out.spheres.assign(n_padded, LayoutSphere{0.f, 0.f, 0.f, 0.f});
-	out.ids.assign(n_padded, -1);
-	out.slot_cell.assign(n_padded, 0);
+	out.spheres.clear();
+	out.ids.clear();
+	out.slot_cell.clear();
 	out.cells.clear();
+	out.spheres.reserve(n + n / 16 + LAYOUT_MAX_TYPES * LAYOUT_TILE_ALIGN);
+	out.ids.reserve(n + n / 16 + LAYOUT_MAX_TYPES * LAYOUT_TILE_ALIGN);
+	out.slot_cell.reserve(n + n / 16 + LAYOUT_MAX_TYPES * LAYOUT_TILE_ALIGN);
 	out.cells.reserve(n / 8 + 64);
 	out.rec_slot.assign(n, 0);
 
+	auto pad_to = [&](size_t boundary, uint32_t dead_cell) { // dead slots up to the next multiple of `boundary`
+		while (out.spheres.size() % boundary) {
+			out.spheres.push_back(LayoutSphere{0.f, 0.f, 0.f, 0.f});
+			out.ids.push_back(-1);
+			out.slot_cell.push_back(dead_cell);
+		}
+	};
+
 	size_t it = 0;
 	for (int t = 0; t < LAYOUT_MAX_TYPES; ++t) {
+		out.ent_start[t] = (uint32_t)out.spheres.size();
 		out.cell_begin[t] = (uint32_t)out.cells.size();
 		if (!count_by_type[t]) {
+			out.ent_end[t] = out.ent_start[t];
 			out.cell_end[t] = out.cell_begin[t];
 			continue;
 		}
-		size_t slot = out.ent_start[t];
 		bool have_prev = false;
 		uint64_t prev_hi = 0, prev_lo = 0;
-		for (size_t k = 0; k < count_by_type[t]; ++k, ++it, ++slot) {
+		uint32_t block_cells = 0; // distinct cell slots overlapping the current LAYOUT_CELL_BLOCK-slot block
+		for (size_t k = 0; k < count_by_type[t]; ++k, ++it) {
 			const SortItem& si = items[it];
 			const CullRec& r = recs[si.rec];
-			if (!have_prev || si.hi != prev_hi || si.lo != prev_lo) {
+			const bool new_cell = !have_prev || si.hi != prev_hi || si.lo != prev_lo;
+			if (out.spheres.size() % LAYOUT_CELL_BLOCK == 0) block_cells = new_cell ? 0 : 1; // a cell may continue into the block
+			if (new_cell) {
+				if (block_cells + 2 > LAYOUT_MAX_CELLS_PER_BLOCK) {
+					// this block already touches its quota of cells (one is kept for the dead cell): close it with dead slots
+					out.cells.push_back(LayoutCell{0, 0, 0, (uint32_t)t | LAYOUT_CELL_DEAD});
+					pad_to(LAYOUT_CELL_BLOCK, (uint32_t)out.cells.size() - 1);
+					block_cells = 0;
+				}
 				out.cells.push_back(LayoutCell{r.cell.x, r.cell.y, r.cell.z, (uint32_t)r.type | (r.big ? 0x100u : 0u)});
 				prev_hi = si.hi;
 				prev_lo = si.lo;
 				have_prev = true;
+				++block_cells;
 			}
-			out.slot_cell[slot] = (uint32_t)out.cells.size() - 1;
-			out.spheres[slot] = LayoutSphere{r.rel.x, r.rel.y, r.rel.z, r.radius};
-			out.ids[slot] = r.entity;
-			out.rec_slot[si.rec] = (uint32_t)slot;
+			out.rec_slot[si.rec] = (uint32_t)out.spheres.size();
+			out.slot_cell.push_back((uint32_t)out.cells.size() - 1);
+			out.spheres.push_back(LayoutSphere{r.rel.x, r.rel.y, r.rel.z, r.radius});
+			out.ids.push_back(r.entity);
 		}
+		// at least one dead slot per type, then pad the type range to the largest tile
 		out.cells.push_back(LayoutCell{0, 0, 0, (uint32_t)t | LAYOUT_CELL_DEAD});
 		const uint32_t dead = (uint32_t)out.cells.size() - 1;
-		for (; slot < out.ent_end[t]; ++slot) out.slot_cell[slot] = dead;
+		out.spheres.push_back(LayoutSphere{0.f, 0.f, 0.f, 0.f});
+		out.ids.push_back(-1);
+		out.slot_cell.push_back(dead);
+		pad_to(LAYOUT_TILE_ALIGN, dead);
+		out.ent_end[t] = (uint32_t)out.spheres.size();
 		out.cell_end[t] = (uint32_t)out.cells.size();
+		if (out.spheres.size() > 0x7fffffffull) return false;
 	}
+	const size_t n_padded = out.spheres.size();
 
 	const size_t n_chunks = n_padded / LAYOUT_CHUNK;
 	out.chunk_cell.resize(n_chunks);
@@ -158,6 +194,29 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 		out.chunk_flags[c] = flags;
 	}
 	out.n_padded = (uint32_t)n_padded;
+	out.n_dead_cells = 0;
+	for (const LayoutCell& c : out.cells) out.n_dead_cells += (c.meta & LAYOUT_CELL_DEAD) ? 1u : 0u;
+	for (int k = 0; k < 3; ++k) {
+		const size_t tile = (size_t)LAYOUT_TILE_ALIGN >> k;
+		uint32_t m = 0;
+		for (size_t b = 0; b + tile <= n_padded; b += tile) {
+			const uint32_t c = out.slot_cell[b + tile - 1] - out.slot_cell[b] + 1; // cell slots are consecutive along the sphere order
+			if (c > m) m = c;
+		}
+		out.max_tile_cells[k] = m;
+		const uint32_t cap = ((m > 0 ? m : 1u) + 15u) / 16u * 16u;
+		out.tile_cap[k] = cap;
+		const size_t n_tiles = n_padded / tile;
+		out.tile_cells[k].assign(n_tiles * cap, LayoutCell{0, 0, 0, LAYOUT_CELL_DEAD});
+		out.tile_tab[k].assign(n_tiles * 2, 0u);
+		for (size_t ti = 0; ti < n_tiles; ++ti) {
+			const uint32_t first = out.slot_cell[ti * tile];
+			const uint32_t cnt = out.slot_cell[ti * tile + tile - 1] - first + 1;
+			out.tile_tab[k][2 * ti] = first;
+			out.tile_tab[k][2 * ti + 1] = cnt;
+			for (uint32_t j = 0; j < cnt; ++j) out.tile_cells[k][ti * cap + j] = out.cells[first + j];
+		}
+	}
 	return true;
 }
 

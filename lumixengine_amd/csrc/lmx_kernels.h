@@ -33,6 +33,10 @@ struct CullDeviceView {
 	const CellKey* cells;        // [n_cells]
 	uint32_t n_padded;
 	uint32_t n_cells;
+	// fused kernel: per tile-size variant k (tile = 4096 >> k), tile-major cell keys + {first cell, n cells} per tile
+	const CellKey* tile_cells[3];
+	const uint32_t* tile_tab[3];
+	uint32_t tile_cap[3];
 };
 
 // classify cells [cell_begin, cell_begin + n) for n_frusta frusta -> cellinfo[f * cell_stride + c] =
@@ -45,6 +49,14 @@ hipError_t launch_cull_classify(hipStream_t s, const CullDeviceView& v, uint32_t
 hipError_t launch_cull_spheres(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
 	const FrustaArg& fr, int n_frusta, const float4* cellinfo, uint32_t cell_stride, int32_t* out_ids, uint32_t out_stride,
 	uint32_t* counts);
+
+// Fused single-launch variant (per-tile classification in LDS) for the tile size cull_tile_size(n_frusta); the layout
+// bounds the cells per tile, so fused_lds_bytes(...) always fits the 64 KiB dynamic-LDS limit (the caller still checks). counts must be zero on entry; counts_next (may be null) is
+// cleared for the following cull.
+uint32_t cull_tile_size(int n_frusta);
+size_t fused_lds_bytes(int n_frusta, uint32_t tile, uint32_t cell_cap);
+hipError_t launch_cull_fused(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
+	const FrustaArg& fr, int n_frusta, int32_t* out_ids, uint32_t out_stride, uint32_t* counts, uint32_t* counts_next);
 
 // spheres[slot[i]] = value[i]
 hipError_t launch_patch_spheres(hipStream_t s, float4* spheres, const uint32_t* slot, const float4* value, uint32_t n);

@@ -47,7 +47,20 @@ int emul_cull(uint32_t n, const int32_t* entity, const uint8_t* type, const doub
 			ent_begin = lay.ent_start[type_filter];
 			ent_end = lay.ent_end[type_filter];
 		}
+		// fused-kernel tile bookkeeping: the cells a tile touches are [first_cell, last_cell], bounded by the layout's max
+		const uint32_t tile = n_frusta <= 1 ? 4096u : (n_frusta <= 4 ? 2048u : 1024u);
+		const uint32_t tile_k = tile == 4096 ? 0 : (tile == 2048 ? 1 : 2);
+		const uint32_t nch = tile / 64;
 		for (uint32_t chunk = ent_begin / 64; chunk < ent_end / 64; ++chunk) {
+			const uint32_t tile_chunk = (chunk / nch) * nch;
+			const uint32_t tile_index = chunk / nch;
+			const uint32_t cap = lay.tile_cap[tile_k];
+			const uint32_t first_cell = lay.tile_tab[tile_k][2 * tile_index];
+			const uint32_t tile_n_cells = lay.tile_tab[tile_k][2 * tile_index + 1];
+			const uint32_t last_cell = lay.chunk_cell[tile_chunk + nch - 1] + (uint32_t)__builtin_popcountll(lay.chunk_flags[tile_chunk + nch - 1] & ~1ull);
+			if (first_cell != lay.chunk_cell[tile_chunk] || last_cell != first_cell + tile_n_cells - 1) return 3;
+			if (tile_n_cells > cap || tile_n_cells > lay.max_tile_cells[tile_k] || last_cell >= n_cells) return 4;
+			if (n_frusta <= 8 && (size_t)n_frusta * cap * 16 + (size_t)n_frusta * tile * 4 + 64 > 65536) return 6; // fused LDS budget
 			uint32_t t = 0;
 			for (int k = 0; k < LAYOUT_MAX_TYPES; ++k)
 				if (chunk * 64 >= lay.ent_start[k] && chunk * 64 < lay.ent_end[k]) t = (uint32_t)k;
@@ -57,6 +70,11 @@ int emul_cull(uint32_t n, const int32_t* entity, const uint8_t* type, const doub
 				const uint64_t le_mask = (~0ull >> (63u - lane)) & ~1ull;
 				const uint32_t cell = base_cell + (uint32_t)__builtin_popcountll(flags & le_mask);
 				if (cell != lay.slot_cell[chunk * 64 + lane]) return 2; // chunk header does not reproduce the slot->cell map
+				if (cell < first_cell || cell > last_cell) return 5;    // tile-local LDS index would be out of range
+				// phase A of the fused kernel: the class comes from the tile-major copy of the cell key
+				const LayoutCell tkey = lay.tile_cells[tile_k][(size_t)tile_index * cap + (cell - first_cell)];
+				const LayoutCell gkey = lay.cells[cell];
+				if (tkey.ix != gkey.ix || tkey.iy != gkey.iy || tkey.iz != gkey.iz || tkey.meta != gkey.meta) return 7;
 				const Info ci = info[cell];
 				const uint32_t e = chunk * 64 + lane;
 				const int32_t id = lay.ids[e];

@@ -118,3 +118,24 @@ def test_emulated_skin_matches_golden(emul_lib):
         assert H.bits_equal(pos, g["abs_pos"][inst]) and H.bits_equal(rot, g["abs_rot"][inst])
         assert H.bits_equal(pal, g["palette"][inst])
         assert H.bits_equal(out, g["skinned"][inst])
+
+
+def test_emulated_layout_cell_quota(emul_lib, oracle_port):
+    """Layout stress: one sphere per cell (quota padding every 247 cells) mixed with one cell holding 3000 spheres
+    (a cell spanning several 1024-slot blocks), for the 4096-, 2048- and 1024-slot tile variants (1, 4, 8 frusta)."""
+    g = np.arange(0, 20)
+    xx, yy, zz = np.meshgrid(g, g, g, indexing="ij")
+    lattice = np.stack([xx.ravel(), yy.ravel(), zz.ravel()], axis=1).astype(np.float64) * 300.0 + 150.0
+    rng = np.random.default_rng(8)
+    crowd = rng.uniform(0.0, 299.0, size=(3000, 3)) + np.array([900.0, 900.0, -1200.0])
+    pos = np.concatenate([lattice, crowd])
+    n = len(pos)
+    sc = {"entity": np.arange(n, dtype=np.int32), "type": (np.arange(n) % 3 == 0).astype(np.uint8), "pos": pos, "radius": rng.uniform(1.0, 350.0, n).astype(np.float32)}
+    cs = oracle_port.culling_system()
+    cs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    fr8 = H.cascade_frusta(oracle_port, 8)
+    for width in (1, 4, 8):
+        got, _ = emul_cull(emul_lib, sc, fr8[:width])
+        for f in range(width):
+            ids, types, _ = cs.cull(fr8[f : f + 1])
+            H.assert_same_visible(got[f], H.sorted_by_type(ids, types), f"width {width} frustum {f}")

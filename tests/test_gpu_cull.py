@@ -173,3 +173,26 @@ def test_cull_10m_properties(gpu_ctx):
     again = cs.cull(narrow, view=1)
     assert np.array_equal(np.sort(again.ids(0, 0)), a)
     assert len(np.unique(a)) == len(a)
+
+
+def test_cull_one_sphere_per_cell_layout_padding(gpu_ctx, oracle_port):
+    """One sphere per cell: the layout spreads such runs over more 1024-slot blocks (at most 240 cells per block, dead
+    padding in between) so the fused kernel's per-tile cell table always fits LDS. 8 frusta and 1 frustum vs the oracle."""
+    g = np.arange(0, 28)  # non-negative: int() truncation makes cells straddle zero (two lattice points in cell 0)
+    xx, yy, zz = np.meshgrid(g, g, g, indexing="ij")
+    pos = np.stack([xx.ravel(), yy.ravel(), zz.ravel()], axis=1).astype(np.float64) * 300.0 + 150.0
+    n = len(pos)
+    rng = np.random.default_rng(8)
+    sc = {"entity": np.arange(n, dtype=np.int32), "type": np.zeros(n, np.uint8), "pos": pos, "radius": rng.uniform(1.0, 200.0, n).astype(np.float32)}
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    st = cs.stats()
+    assert st["cells"] == n and st["chunks"] * 64 >= 4 * n  # 239 spheres per 1024-slot block
+    ocs = oracle_port.culling_system()
+    ocs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    fr8 = H.cascade_frusta(api, 8)
+    res = cs.cull(fr8)
+    for f in range(8):
+        H.assert_same_visible(gpu_visible(res, f), oracle_visible(ocs, fr8[f : f + 1]), f"8 frusta, frustum {f}")
+    fr1 = H.frusta(api, names=["origin_yaw_pitch"])
+    H.assert_same_visible(gpu_visible(cs.cull(fr1), 0), oracle_visible(ocs, fr1), "fused path")
