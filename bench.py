@@ -168,7 +168,7 @@ def main():
     achieved = alg_bytes / (avg_spheres_ms * 1e-3) / 1e9
     gbps = lambda b, ms: round(b / (ms * 1e-3) / 1e9, 1)
     roofline = {
-        "kernel": "k_cull_spheres",
+        "kernel": "k_cull_fused" if avg_classify_ms == 0.0 else "k_cull_spheres",
         "bound": "hbm",
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBPS,
@@ -262,6 +262,24 @@ def extras(ctx, api, scenes, torch, timed, N, log):
     out["dense_all_visible_GBps"] = (20.0 * N + 4.0 * vis_all) / (ms_all * 1e-3) / 1e9
     del cs
 
+    # config 5 flavour on one GPU: mixed renderable types, 8 ortho cascade frusta tested in ONE pass over the spheres
+    sc = scenes.cull_scene(N, 15000.0, seed=4, mixed_types=True)
+    cs = api.CullingSystem(ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    fr8 = np.concatenate([
+        api.viewport_frustum(is_ortho=True, ortho_size=[30.0, 90.0, 400.0, 1500.0][k % 4] * 4.0, w=1024, h=1024, near=0.0, far=20000.0,
+                             pos=(5.0 * k, 9000.0, -3.0 * k), rot=(-0.6, 0.25 * (k // 4), 0.0, 0.76))
+        for k in range(8)])
+    for _ in range(5):
+        cs.cull(fr8)
+    ms8 = timed(lambda: cs.cull(fr8), 50)
+    c8 = cs.cull(fr8).counts()
+    out["cull8_ms_per_pass"] = ms8
+    out["cull8_entity_frustum_tests_per_sec"] = 8.0 * N / (ms8 * 1e-3)
+    out["cull8_visible_per_frustum"] = [int(x) for x in c8.sum(axis=1)]
+    out["cull8_GBps_algorithmic"] = (20.0 * N + 4.0 * float(c8.sum())) / (ms8 * 1e-3) / 1e9
+    del cs
+
     # config 3 slice: 1 M entities, depth-4 chains, every root moved each frame (transform inputs resident in HBM)
     h = scenes.hierarchy_chains(250_000, 4, seed=2)
     n = len(h["parent"])
@@ -329,6 +347,81 @@ def extras(ctx, api, scenes, torch, timed, N, log):
     out["skin_instances"] = n_inst
     out["skin_GBps_algorithmic_48B"] = 48.0 * n_inst * n_verts / (ms * 1e-3) / 1e9
     out["skin_GBps_shared_mesh_floor_12B"] = 12.0 * n_inst * n_verts / (ms * 1e-3) / 1e9
+    del sk
+    # BASELINE config 3 as one simulated frame on one GPU: 1 M entities in depth-4 chains, every root moved, every entity
+    # bound to the culling system (dynamic set, refreshed on the device), one camera cull, 10 k skinned instances x 64 bones
+    # x 10 k vertices of one shared mesh. Inputs (new root transforms, relative poses) are resident in HBM.
+    h3 = scenes.hierarchy_chains(250_000, 4, seed=2, root_extent=6000.0)
+    n3 = len(h3["parent"])
+    w3 = api.World(ctx)
+    w3.build(h3["parent"], h3["local"])
+    cs3 = api.CullingSystem(ctx)
+    ent3 = np.arange(n3, dtype=np.int32)
+    rng3 = np.random.default_rng(3)
+    cs3.build(ent3, np.zeros(n3, np.uint8), rng3.uniform(-6000.0, 6000.0, size=(n3, 3)), np.ones(n3, np.float32))
+    w3.bindCulling(ent3, rng3.uniform(0.5, 20.0, n3).astype(np.float32))
+    roots3 = np.flatnonzero(h3["parent"] < 0).astype(np.int32)
+    d_ent3 = torch.from_numpy(roots3).cuda()
+    d_tr3 = torch.from_numpy(scenes.random_transforms(rng3, len(roots3), 6000.0).view(np.uint8).reshape(len(roots3), -1)).cuda()
+    n_inst3 = 10_000
+    sk3 = api.Skinning(ctx)
+    model3 = sk3.addModel(s["parents"], s["bind"], s["first_nonroot"])
+    mesh3 = sk3.addMesh(verts, skin)
+    sk3.setInstances(np.full(n_inst3, model3, np.uint32), np.full(n_inst3, mesh3, np.uint32))
+    pos3, rot3 = scenes.relative_poses(n_inst3, 64, seed=7)
+    d_pos3, d_rot3 = torch.from_numpy(pos3).cuda(), torch.from_numpy(rot3).cuda()
+    fr3 = api.viewport_frustum()
+
+    def frame3():
+        w3.setTransformsDevice(len(roots3), d_ent3.data_ptr(), d_tr3.data_ptr())
+        w3.propagate()
+        cs3.cull(fr3)
+        sk3.uploadPosesDevice(d_pos3.data_ptr(), d_rot3.data_ptr(), n_inst3 * 64)
+        sk3.run()
+
+    for _ in range(5):
+        frame3()
+    ms3 = timed(frame3, 50)
+    out["config3_frame_ms"] = ms3
+    out["config3_frames_per_sec"] = 1e3 / ms3
+    out["config3_visible"] = int(cs3.cull(fr3).counts()[0].sum())
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    for _ in range(10):
+        frame3()
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    out["config3_kernel_ms"] = {api.KERNEL_NAMES[k]: round(ctx.profile_get(k)[0] / 10, 5) for k in range(len(api.KERNEL_NAMES)) if ctx.profile_get(k)[1]}
+    del w3, cs3, sk3
+    # distinct meshes: every instance streams its own 36 B/vertex from HBM (the 48 B/vertex algorithmic figure is real traffic)
+    n_inst2 = 1500  # 540 MB of mesh data + 180 MB of output: well beyond the 256 MiB Infinity Cache
+    sk = api.Skinning(ctx)
+    model = sk.addModel(s["parents"], s["bind"], s["first_nonroot"])
+    rng = np.random.default_rng(9)
+    mesh_ids = []
+    for i in range(n_inst2):
+        v2 = np.roll(verts, i, axis=0)
+        mesh_ids.append(sk.addMesh(v2, np.roll(skin, i, axis=0)))
+    sk.setInstances(np.full(n_inst2, model, np.uint32), np.array(mesh_ids, np.uint32))
+    d_pos2, d_rot2 = d_pos[:n_inst2].contiguous(), d_rot[:n_inst2].contiguous()
+
+    def skin_step2():
+        sk.uploadPosesDevice(d_pos2.data_ptr(), d_rot2.data_ptr(), n_inst2 * 64)
+        sk.run()
+
+    for _ in range(5):
+        skin_step2()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    for _ in range(20):
+        skin_step2()
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    t_sv, n_sv = ctx.profile_get(api.K_SKIN_VERTICES)
+    out["skin_distinct_meshes_instances"] = n_inst2
+    out["skin_distinct_meshes_kernel_avg_ms"] = t_sv / max(n_sv, 1)
+    out["skin_distinct_meshes_verts_per_sec"] = n_inst2 * n_verts / (t_sv / max(n_sv, 1) * 1e-3)
+    out["skin_distinct_meshes_GBps_48B"] = 48.0 * n_inst2 * n_verts / (t_sv / max(n_sv, 1) * 1e-3) / 1e9
     log("extras:", json.dumps(out))
     return out
 

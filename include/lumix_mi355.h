@@ -61,7 +61,8 @@ enum {
 	LMX_K_SPHERE_REFRESH = 3,
 	LMX_K_POSE_PALETTE = 4,
 	LMX_K_SKIN_VERTICES = 5,
-	LMX_K_COUNT = 6
+	LMX_K_CULL_DYNAMIC = 6,
+	LMX_K_COUNT = 7
 };
 LMX_API int lmx_profile_enable(LmxContext* ctx, int enable);
 LMX_API int lmx_profile_reset(LmxContext* ctx);
@@ -85,7 +86,9 @@ LMX_API int lmx_cull_set_radius(LmxContext* ctx, int32_t entity, float radius);
 LMX_API int lmx_cull_get_radius(LmxContext* ctx, int32_t entity, float* out_radius);
 LMX_API int lmx_cull_is_added(LmxContext* ctx, int32_t entity); /* 1 / 0 */
 LMX_API int lmx_cull_flush(LmxContext* ctx);
-/* Number of resident spheres / occupied (cell,type,is_big) groups / 64-sphere chunks on the device. */
+/* Number of resident spheres / occupied (cell,type,is_big) groups of the static set / capacity of one frustum's output
+ * row in units of 64 ids (static + dynamic slots, padding included): a bound output buffer needs 64 * n_chunks ids per
+ * frustum. */
 LMX_API int lmx_cull_stats(LmxContext* ctx, uint32_t* n_entities, uint32_t* n_cells, uint32_t* n_chunks);
 
 /* CullingSystem::cull(frustum[, type]) (culling_system.cpp:310-369) for n_frusta <= LMX_MAX_FRUSTA frusta in ONE
@@ -123,7 +126,8 @@ LMX_API int lmx_world_set_transforms(LmxContext* ctx, uint32_t n, const int32_t*
 /* Same, with both arrays already in device memory (entity indices must be valid; they are not checked). */
 LMX_API int lmx_world_set_transforms_device(LmxContext* ctx, uint32_t n, const void* d_entity, const void* d_transforms);
 /* RenderModuleImpl::onModelInstanceMoved binding (render_module.cpp:1544-1554): after propagation the culling
- * sphere of entity[i] becomes (world.pos, model_radius[i] * maximum(scale.x, scale.y, scale.z)). */
+ * sphere of entity[i] becomes (world.pos, model_radius[i] * maximum(scale.x, scale.y, scale.z)). Bound entities are
+ * moved to the culling system's dynamic set (unsorted, re-binned implicitly by the cull kernel every frame). */
 LMX_API int lmx_world_bind_culling(LmxContext* ctx, uint32_t n, const int32_t* entity, const float* model_radius);
 LMX_API int lmx_world_propagate(LmxContext* ctx);
 /* World::getTransforms() (world.h:65): AoS Transform[n] indexed by entity. */
@@ -144,6 +148,12 @@ LMX_API int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* 
 LMX_API int lmx_skin_upload_poses(LmxContext* ctx, const float* positions, const float* rotations, size_t n_bones_total);
 /* Same, from device memory (device-to-device copy on the context stream). */
 LMX_API int lmx_skin_upload_poses_device(LmxContext* ctx, const void* d_positions, const void* d_rotations, size_t n_bones_total);
+/* Arithmetic of the vertex blend/transform (model.cpp:103-109). LMX_SKIN_FUSED (default): products fused into the adds
+ * (v_fma_f32), results within 1e-5 relative of the reference CPU path - the tolerance BASELINE's north star sets for
+ * skinned positions. LMX_SKIN_EXACT: separate multiplies and adds in the reference's order, bit-identical to it.
+ * Poses and palettes are always bit-identical. */
+enum { LMX_SKIN_FUSED = 0, LMX_SKIN_EXACT = 1 };
+LMX_API int lmx_skin_set_mode(LmxContext* ctx, int mode);
 /* Pose::computeAbsolute -> computeSkinMatrices -> evaluateSkin for every instance; outputs stay in HBM. */
 LMX_API int lmx_skin_run(LmxContext* ctx);
 LMX_API int lmx_skin_read_vertices(LmxContext* ctx, uint32_t instance, float* out_xyz, uint32_t cap_verts);

@@ -23,8 +23,8 @@ LIB_PATH = os.path.join(PKG, "liblumix_mi355.so")
 
 MAX_FRUSTA, MAX_TYPES, MAX_VIEWS = 8, 8, 8
 TYPE_ALL = 0xFF
-(K_CULL_CLASSIFY, K_CULL_SPHERES, K_XFORM_LEVEL, K_SPHERE_REFRESH, K_POSE_PALETTE, K_SKIN_VERTICES) = range(6)
-KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices"]
+(K_CULL_CLASSIFY, K_CULL_SPHERES, K_XFORM_LEVEL, K_SPHERE_REFRESH, K_POSE_PALETTE, K_SKIN_VERTICES, K_CULL_DYNAMIC) = range(7)
+KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices", "cull_dynamic"]
 
 SHIFTED_FRUSTUM = np.dtype(
     [("xs", "<f4", 8), ("ys", "<f4", 8), ("zs", "<f4", 8), ("ds", "<f4", 8), ("points", "<f4", (8, 3)), ("origin", "<f8", 3), ("_pad", "<f8")],
@@ -76,6 +76,7 @@ SYMBOLS = {
     "lmx_skin_set_instances": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_skin_upload_poses": (_ci, [_vp, _vp, _vp, _sz]),
     "lmx_skin_upload_poses_device": (_ci, [_vp, _vp, _vp, _sz]),
+    "lmx_skin_set_mode": (_ci, [_vp, _ci]),
     "lmx_skin_run": (_ci, [_vp]),
     "lmx_skin_read_vertices": (_ci, [_vp, _u32, _vp, _u32]),
     "lmx_skin_read_palette": (_ci, [_vp, _u32, _vp, _u32]),
@@ -390,6 +391,10 @@ class Skinning:
 
     def uploadPosesDevice(self, d_positions: int, d_rotations: int, n_bones_total: int):
         self.ctx.check(self.lib.lmx_skin_upload_poses_device(self.ctx.h, d_positions, d_rotations, n_bones_total))
+
+    def setMode(self, exact: bool):
+        """exact=True: FMA-free blend, bit-identical to the reference; False (default): fused multiply-adds, within 1e-5."""
+        self.ctx.check(self.lib.lmx_skin_set_mode(self.ctx.h, 1 if exact else 0))
 
     def run(self):
         self.ctx.check(self.lib.lmx_skin_run(self.ctx.h))

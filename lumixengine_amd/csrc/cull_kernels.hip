@@ -143,7 +143,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_spheres(const float4* __res
 #pragma unroll
 	for (int f = 0; f < F; ++f) {
 		const uint32_t c = s_cnt[f];
-		int32_t* dst = out_ids + (size_t)f * out_stride + tt.ent_start[type] + s_base[f];
+		int32_t* dst = out_ids + (size_t)f * out_stride + tt.out_start[type] + s_base[f];
 		for (uint32_t k = threadIdx.x; k < c; k += WAVES * 64) dst[k] = s_buf[f * TILE + k];
 	}
 }
@@ -282,8 +282,70 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_fused(const float4* __restr
 #pragma unroll
 	for (int f = 0; f < F; ++f) {
 		const uint32_t c = s_cnt[f];
-		int32_t* dst = out_ids + (size_t)f * out_stride + tt.ent_start[type] + s_base[f];
+		int32_t* dst = out_ids + (size_t)f * out_stride + tt.out_start[type] + s_base[f];
 		for (uint32_t k = threadIdx.x; k < c; k += WAVES * 64) dst[k] = s_buf[f * TILE + k];
+	}
+}
+
+// ---- dynamic set ------------------------------------------------------------------------------------------------
+// One thread per unsorted entity: cell index, is_big and the cell-relative fp32 position are derived from the fp64 world
+// position exactly like CullingSystemImpl::add / set would (culling_system.cpp:26-30,100,140), the cell is classified per
+// lane (no sharing between lanes: the set is not sorted) and the sphere is tested. ~350 VALU ops per entity and frustum,
+// 36 B per entity: the VALU-heavier, bandwidth-lighter sibling of the sorted path, used only for entities that move.
+constexpr int DYN_THREADS = 256;
+
+// A block handles TILE entities in TILE / 256 batches and stages the visible ids of the whole tile in LDS, so that the
+// global counter sees one atomic per (tile, frustum): the dynamic set is unsorted, visible entities are spread over every
+// block, and a 256-entity granule would put ~4 k returning atomics on one address per million entities.
+template <int TILE>
+__global__ __launch_bounds__(DYN_THREADS) void k_cull_dynamic(const double* __restrict__ px, const double* __restrict__ py,
+	const double* __restrict__ pz, const float* __restrict__ radius, const int32_t* __restrict__ ids, FrustaArg fr, int n_frusta,
+	TypeTable dyn_tt, uint32_t slot_begin, int32_t* __restrict__ out_ids, uint32_t out_stride, uint32_t* __restrict__ counts) {
+	extern __shared__ int32_t s_stage[]; // [n_frusta][TILE] staged ids | [MAX_FRUSTA] counts | [MAX_FRUSTA] bases
+	uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_stage + n_frusta * TILE);
+	uint32_t* s_base = s_cnt + MAX_FRUSTA;
+	const uint32_t lane = lane_id();
+	const uint32_t block_slot = slot_begin + blockIdx.x * (uint32_t)TILE;
+	uint32_t type = 0;
+#pragma unroll
+	for (int t = 0; t < MAX_TYPES; ++t) {
+		if (block_slot >= dyn_tt.ent_start[t] && block_slot < dyn_tt.ent_end[t]) type = t;
+	}
+	if (threadIdx.x < MAX_FRUSTA) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	for (uint32_t b = 0; b < TILE / DYN_THREADS; ++b) {
+		const uint32_t slot = block_slot + b * DYN_THREADS + threadIdx.x;
+		const int32_t id = ids[slot];
+		const DV3 pos = DV3{px[slot], py[slot], pz[slot]};
+		const float r = radius[slot];
+		const IV3 idx = cell_of(pos);
+		const bool big = is_big_radius(r);
+		const V3 rel = to_v3(sub(pos, cell_origin(idx))); // addToCell, culling_system.cpp:100
+		for (int f = 0; f < n_frusta; ++f) {
+			V3 off;
+			const uint32_t cls = classify_cell(fr.f[f], idx, big, &off);
+			bool vis = cls == CELL_ACCEPT;
+			if (cls == CELL_TEST) vis = sphere_visible(fr.f[f], off, rel.x, rel.y, rel.z, r);
+			vis = vis && id >= 0;
+			const uint64_t mask = __ballot(vis);
+			if (mask != 0) {
+				uint32_t base = 0;
+				if (lane == 0) base = atomicAdd(&s_cnt[f], (uint32_t)__popcll(mask));
+				base = __builtin_amdgcn_readfirstlane(base);
+				if (vis) s_stage[f * TILE + base + mbcnt64(mask)] = id;
+			}
+		}
+	}
+	__syncthreads();
+	if ((int)threadIdx.x < n_frusta) {
+		const uint32_t c = s_cnt[threadIdx.x];
+		s_base[threadIdx.x] = c ? atomicAdd(&counts[threadIdx.x * MAX_TYPES + type], c) : 0u;
+	}
+	__syncthreads();
+	for (int f = 0; f < n_frusta; ++f) {
+		const uint32_t c = s_cnt[f];
+		int32_t* dst = out_ids + (size_t)f * out_stride + dyn_tt.out_start[type] + s_base[f];
+		for (uint32_t k = threadIdx.x; k < c; k += DYN_THREADS) dst[k] = s_stage[f * TILE + k];
 	}
 }
 
@@ -394,6 +456,22 @@ hipError_t launch_cull_spheres(hipStream_t s, const CullDeviceView& v, uint32_t 
 		default: return hipErrorInvalidValue;
 	}
 #undef LMX_SPH
+}
+
+uint32_t cull_dynamic_tile(int n_frusta) { return n_frusta <= 2 ? 2048u : (n_frusta <= 4 ? 1024u : 512u); } // <= 16 KiB of staging
+
+hipError_t launch_cull_dynamic(hipStream_t s, const DynDeviceView& d, uint32_t slot_begin, uint32_t slot_end, const TypeTable& dyn_tt,
+	const FrustaArg& fr, int n_frusta, int32_t* out_ids, uint32_t out_stride, uint32_t* counts) {
+	const uint32_t tile = cull_dynamic_tile(n_frusta);
+	const uint32_t blocks = (slot_end - slot_begin) / tile;
+	if (!blocks) return hipSuccess;
+	const size_t lds = (size_t)n_frusta * tile * sizeof(int32_t) + 2 * MAX_FRUSTA * sizeof(uint32_t);
+#define LMX_DYN(T) hipLaunchKernelGGL(k_cull_dynamic<T>, dim3(blocks), dim3(DYN_THREADS), lds, s, d.px, d.py, d.pz, d.radius, d.ids, fr, n_frusta, dyn_tt, slot_begin, out_ids, out_stride, counts)
+	if (tile == 2048) LMX_DYN(2048);
+	else if (tile == 1024) LMX_DYN(1024);
+	else LMX_DYN(512);
+#undef LMX_DYN
+	return hipGetLastError();
 }
 
 hipError_t launch_patch_spheres(hipStream_t s, float4* spheres, const uint32_t* slot, const float4* value, uint32_t n) {

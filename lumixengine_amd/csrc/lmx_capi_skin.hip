@@ -1,0 +1,226 @@
+// lmx_capi_skin.hip — skinning entry points (include/lumix_mi355.h, "skinning" section): model / mesh registration, the
+// instance table, pose upload, and the pose -> palette -> vertex launches.
+#include "lmx_context.h"
+
+using namespace lmx;
+
+extern "C" {
+
+int lmx_skin_add_model(LmxContext* ctx, uint32_t n_bones, const int16_t* parents, const LmxLocalRigidTransform* bind, int32_t first_nonroot,
+	uint32_t* out_model) {
+	LMX_CHECK_CTX(ctx);
+	if (!n_bones || n_bones > LMX_MAX_BONES) return fail(ctx, LMX_ERR_CAPACITY, "n_bones %u not in [1,%d] (Model::Bone::MAX_COUNT)", n_bones, LMX_MAX_BONES);
+	if (!parents || !bind) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
+	if (first_nonroot < 0) first_nonroot = (int32_t)n_bones;
+	SkinState& sk = ctx->skin;
+	SkinModel m;
+	m.bone_offset = (uint32_t)sk.parents.size();
+	m.n_bones = n_bones;
+	m.first_nonroot = first_nonroot;
+	m.max_depth = 0;
+	std::vector<uint8_t> depth(n_bones, 0);
+	for (uint32_t i = 0; i < n_bones; ++i) {
+		const int32_t p = parents[i];
+		if (p >= (int32_t)i) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "parents[%u] = %d must precede the bone (model.cpp:381-384)", i, p);
+		if ((int32_t)i >= first_nonroot && p < 0) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bone %u >= first_nonroot has no parent", i);
+		// bones below first_nonroot are never touched by Pose::computeAbsolute (pose.cpp:66): depth 0
+		depth[i] = ((int32_t)i >= first_nonroot) ? (uint8_t)(depth[p] + 1) : 0;
+		m.max_depth = std::max<uint32_t>(m.max_depth, depth[i]);
+	}
+	for (uint32_t i = 0; i < n_bones; ++i) {
+		V3 ip;
+		Q4 ir;
+		invert_rigid(V3{bind[i].pos[0], bind[i].pos[1], bind[i].pos[2]}, Q4{bind[i].rot[0], bind[i].rot[1], bind[i].rot[2], bind[i].rot[3]}, &ip, &ir);
+		sk.parents.push_back(parents[i]);
+		sk.depth.push_back(depth[i]);
+		sk.inv_pos.push_back(ip.x);
+		sk.inv_pos.push_back(ip.y);
+		sk.inv_pos.push_back(ip.z);
+		sk.inv_rot.push_back(make_float4(ir.x, ir.y, ir.z, ir.w));
+	}
+	sk.models.push_back(m);
+	sk.models_dirty = true;
+	if (out_model) *out_model = (uint32_t)sk.models.size() - 1;
+	return LMX_OK;
+}
+
+int lmx_skin_add_mesh(LmxContext* ctx, uint32_t n_verts, const float* positions_xyz, const LmxSkin* skin, uint32_t* out_mesh) {
+	LMX_CHECK_CTX(ctx);
+	if (!n_verts || !positions_xyz || !skin) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "empty mesh / null input array");
+	SkinState& sk = ctx->skin;
+	SkinMesh m;
+	m.vert_offset = (uint32_t)(sk.verts.size() / 3);
+	m.n_verts = n_verts;
+	sk.verts.insert(sk.verts.end(), positions_xyz, positions_xyz + (size_t)n_verts * 3);
+	for (uint32_t v = 0; v < n_verts; ++v) {
+		sk.weights.push_back(make_float4(skin[v].weights[0], skin[v].weights[1], skin[v].weights[2], skin[v].weights[3]));
+		for (int k = 0; k < 4; ++k) {
+			if (skin[v].indices[k] < 0 || skin[v].indices[k] >= LMX_MAX_BONES) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "skin[%u].indices[%d] = %d out of range", v, k, skin[v].indices[k]);
+			sk.indices.push_back(skin[v].indices[k]);
+		}
+	}
+	sk.meshes.push_back(m);
+	sk.meshes_dirty = true;
+	if (out_mesh) *out_mesh = (uint32_t)sk.meshes.size() - 1;
+	return LMX_OK;
+}
+
+static int skin_upload_static(LmxContext* ctx) {
+	SkinState& sk = ctx->skin;
+	if (sk.models_dirty) {
+		const size_t nb = sk.parents.size();
+		LMX_HIP(ctx, sk.d_parents.reserve(nb));
+		LMX_HIP(ctx, sk.d_depth.reserve(nb));
+		LMX_HIP(ctx, sk.d_inv_pos.reserve(nb * 3));
+		LMX_HIP(ctx, sk.d_inv_rot.reserve(nb));
+		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		LMX_HIP(ctx, hipMemcpy(sk.d_parents.p, sk.parents.data(), nb * sizeof(int16_t), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(sk.d_depth.p, sk.depth.data(), nb * sizeof(uint8_t), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(sk.d_inv_pos.p, sk.inv_pos.data(), nb * 3 * sizeof(float), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(sk.d_inv_rot.p, sk.inv_rot.data(), nb * sizeof(float4), hipMemcpyHostToDevice));
+		sk.models_dirty = false;
+	}
+	if (sk.meshes_dirty) {
+		const size_t nv = sk.weights.size();
+		LMX_HIP(ctx, sk.d_verts.reserve(nv * 3));
+		LMX_HIP(ctx, sk.d_weights.reserve(nv));
+		LMX_HIP(ctx, sk.d_indices.reserve(nv * 4));
+		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		LMX_HIP(ctx, hipMemcpy(sk.d_verts.p, sk.verts.data(), nv * 3 * sizeof(float), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(sk.d_weights.p, sk.weights.data(), nv * sizeof(float4), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(sk.d_indices.p, sk.indices.data(), nv * 4 * sizeof(int16_t), hipMemcpyHostToDevice));
+		sk.meshes_dirty = false;
+	}
+	return LMX_OK;
+}
+
+int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* model, const uint32_t* mesh) {
+	LMX_CHECK_CTX(ctx);
+	if (n && (!model || !mesh)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
+	SkinState& sk = ctx->skin;
+	std::vector<SkinInstance> inst(n);
+	size_t bones = 0, verts = 0;
+	uint32_t max_verts = 0;
+	for (uint32_t i = 0; i < n; ++i) {
+		if (model[i] >= sk.models.size() || mesh[i] >= sk.meshes.size()) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "instance %u: unknown model/mesh id", i);
+		const SkinModel& mo = sk.models[model[i]];
+		const SkinMesh& me = sk.meshes[mesh[i]];
+		SkinInstance& in = inst[i];
+		if (bones + mo.n_bones > 0xffffffffull || verts + me.n_verts > 0xffffffffull) return fail(ctx, LMX_ERR_CAPACITY, "instance table exceeds 2^32 bones or vertices");
+		in.bone_offset = (uint32_t)bones;
+		in.n_bones = mo.n_bones;
+		in.model_offset = mo.bone_offset;
+		in.first_nonroot = mo.first_nonroot;
+		in.vert_offset = me.vert_offset;
+		in.n_verts = me.n_verts;
+		in.out_offset = (uint32_t)verts;
+		in.max_depth = mo.max_depth;
+		bones += mo.n_bones;
+		verts += me.n_verts;
+		max_verts = std::max(max_verts, me.n_verts);
+	}
+	sk.inst.swap(inst);
+	sk.bones_total = bones;
+	sk.verts_total = verts;
+	sk.max_verts = max_verts;
+	sk.poses_uploaded = false;
+	LMX_HIP(ctx, sk.d_inst.reserve(std::max<size_t>(n, 1)));
+	LMX_HIP(ctx, sk.d_pose_pos.reserve(std::max<size_t>(bones * 3, 1)));
+	LMX_HIP(ctx, sk.d_pose_rot.reserve(std::max<size_t>(bones, 1)));
+	LMX_HIP(ctx, sk.d_palette.reserve(std::max<size_t>(bones * 4, 1)));
+	LMX_HIP(ctx, sk.d_out.reserve(std::max<size_t>(verts * 3, 1)));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (n) LMX_HIP(ctx, hipMemcpy(sk.d_inst.p, sk.inst.data(), (size_t)n * sizeof(SkinInstance), hipMemcpyHostToDevice));
+	return LMX_OK;
+}
+
+int lmx_skin_upload_poses(LmxContext* ctx, const float* positions, const float* rotations, size_t n_bones_total) {
+	LMX_CHECK_CTX(ctx);
+	SkinState& sk = ctx->skin;
+	if (n_bones_total != sk.bones_total) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "expected %zu bones over all instances, got %zu", sk.bones_total, n_bones_total);
+	if (!n_bones_total) return LMX_OK;
+	if (!positions || !rotations) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	LMX_HIP(ctx, hipMemcpy(sk.d_pose_pos.p, positions, n_bones_total * 3 * sizeof(float), hipMemcpyHostToDevice));
+	LMX_HIP(ctx, hipMemcpy(sk.d_pose_rot.p, rotations, n_bones_total * sizeof(float4), hipMemcpyHostToDevice));
+	sk.poses_uploaded = true;
+	return LMX_OK;
+}
+
+int lmx_skin_upload_poses_device(LmxContext* ctx, const void* d_positions, const void* d_rotations, size_t n_bones_total) {
+	LMX_CHECK_CTX(ctx);
+	SkinState& sk = ctx->skin;
+	if (n_bones_total != sk.bones_total) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "expected %zu bones over all instances, got %zu", sk.bones_total, n_bones_total);
+	if (!n_bones_total) return LMX_OK;
+	if (!d_positions || !d_rotations) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null device pointer");
+	LMX_HIP(ctx, hipMemcpyAsync(sk.d_pose_pos.p, d_positions, n_bones_total * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+	LMX_HIP(ctx, hipMemcpyAsync(sk.d_pose_rot.p, d_rotations, n_bones_total * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+	sk.poses_uploaded = true;
+	return LMX_OK;
+}
+
+int lmx_skin_set_mode(LmxContext* ctx, int mode) {
+	LMX_CHECK_CTX(ctx);
+	if (mode != LMX_SKIN_FUSED && mode != LMX_SKIN_EXACT) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "unknown skin mode %d", mode);
+	ctx->skin.exact = mode == LMX_SKIN_EXACT;
+	return LMX_OK;
+}
+
+int lmx_skin_run(LmxContext* ctx) {
+	LMX_CHECK_CTX(ctx);
+	SkinState& sk = ctx->skin;
+	if (sk.inst.empty()) return LMX_OK;
+	if (!sk.poses_uploaded) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_skin_upload_poses has not been called for this instance table");
+	if (int rc = skin_upload_static(ctx)) return rc;
+	const uint32_t n = (uint32_t)sk.inst.size();
+	{
+		ProfScope ps(ctx, LMX_K_POSE_PALETTE);
+		LMX_HIP(ctx, launch_pose_palette(ctx->stream, sk.d_inst.p, n, sk.d_pose_pos.p, sk.d_pose_rot.p, sk.d_parents.p, sk.d_depth.p, sk.d_inv_pos.p,
+			sk.d_inv_rot.p, sk.d_palette.p));
+	}
+	{
+		ProfScope ps(ctx, LMX_K_SKIN_VERTICES);
+		LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, n, sk.max_verts, sk.d_verts.p, sk.d_weights.p, sk.d_indices.p, sk.d_palette.p,
+			sk.d_out.p, sk.exact));
+	}
+	// the poses are absolute now; running again needs fresh relative poses (Pose::is_absolute, pose.cpp:64)
+	sk.poses_uploaded = false;
+	return LMX_OK;
+}
+
+int lmx_skin_read_vertices(LmxContext* ctx, uint32_t instance, float* out_xyz, uint32_t cap_verts) {
+	LMX_CHECK_CTX(ctx);
+	SkinState& sk = ctx->skin;
+	if (instance >= sk.inst.size() || !out_xyz) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad instance/out");
+	const SkinInstance& in = sk.inst[instance];
+	if (cap_verts < in.n_verts) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u vertices", in.n_verts);
+	LMX_HIP(ctx, hipMemcpyAsync(out_xyz, sk.d_out.p + (size_t)in.out_offset * 3, (size_t)in.n_verts * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+int lmx_skin_read_palette(LmxContext* ctx, uint32_t instance, LmxMatrix* out, uint32_t cap_bones) {
+	LMX_CHECK_CTX(ctx);
+	SkinState& sk = ctx->skin;
+	if (instance >= sk.inst.size() || !out) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad instance/out");
+	const SkinInstance& in = sk.inst[instance];
+	if (cap_bones < in.n_bones) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u bones", in.n_bones);
+	LMX_HIP(ctx, hipMemcpyAsync(out, sk.d_palette.p + (size_t)in.bone_offset * 4, (size_t)in.n_bones * sizeof(LmxMatrix), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+int lmx_skin_read_pose(LmxContext* ctx, uint32_t instance, float* out_pos, float* out_rot, uint32_t cap_bones) {
+	LMX_CHECK_CTX(ctx);
+	SkinState& sk = ctx->skin;
+	if (instance >= sk.inst.size()) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad instance");
+	const SkinInstance& in = sk.inst[instance];
+	if (cap_bones < in.n_bones) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u bones", in.n_bones);
+	if (out_pos) LMX_HIP(ctx, hipMemcpyAsync(out_pos, sk.d_pose_pos.p + (size_t)in.bone_offset * 3, (size_t)in.n_bones * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+	if (out_rot) LMX_HIP(ctx, hipMemcpyAsync(out_rot, sk.d_pose_rot.p + in.bone_offset, (size_t)in.n_bones * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+
+} // extern "C"

@@ -1,0 +1,191 @@
+// lmx_capi_world.hip — batch form of World's transform hierarchy behind the C ABI (include/lumix_mi355.h, "world transforms").
+// Host side: BFS order of the hierarchy ((level, parent slot) slots), staging of new transforms, one k_xform_level launch per
+// level, and the RenderModule "moved" binding that refreshes the culling system's dynamic set on the device.
+#include "lmx_context.h"
+
+using namespace lmx;
+
+extern "C" {
+
+int lmx_world_build(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxTransform* transforms) {
+	LMX_CHECK_CTX(ctx);
+	if (n && (!parent || !transforms)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
+	WorldState& w = ctx->world;
+	w.built = false;
+	// children lists (CSR by parent), then BFS from the roots: slot order = (level, parent slot)
+	std::vector<uint32_t> child_start((size_t)n + 1, 0);
+	for (uint32_t e = 0; e < n; ++e) {
+		if (parent[e] >= (int32_t)n || parent[e] == (int32_t)e) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "parent[%u] = %d invalid", e, parent[e]);
+		if (parent[e] >= 0) child_start[(size_t)parent[e] + 1]++;
+	}
+	for (uint32_t e = 0; e < n; ++e) child_start[e + 1] += child_start[e];
+	std::vector<uint32_t> child_list(child_start[n]);
+	{
+		std::vector<uint32_t> cursor(child_start.begin(), child_start.end() - 1);
+		for (uint32_t e = 0; e < n; ++e)
+			if (parent[e] >= 0) child_list[cursor[parent[e]]++] = e;
+	}
+	w.entity_of_slot.clear();
+	w.entity_of_slot.reserve(n);
+	w.level_start.clear();
+	w.level_start.push_back(0);
+	for (uint32_t e = 0; e < n; ++e)
+		if (parent[e] < 0) w.entity_of_slot.push_back((int32_t)e);
+	size_t level_begin = 0;
+	while (level_begin < w.entity_of_slot.size()) {
+		const size_t level_end = w.entity_of_slot.size();
+		w.level_start.push_back((uint32_t)level_end);
+		for (size_t s = level_begin; s < level_end; ++s) {
+			const uint32_t e = (uint32_t)w.entity_of_slot[s];
+			for (uint32_t k = child_start[e]; k < child_start[e + 1]; ++k) w.entity_of_slot.push_back((int32_t)child_list[k]);
+		}
+		level_begin = level_end;
+	}
+	if (w.entity_of_slot.size() != n) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "hierarchy contains a cycle (%zu of %u entities reachable)", w.entity_of_slot.size(), n);
+	w.slot_of_entity.assign(n, -1);
+	for (uint32_t s = 0; s < n; ++s) w.slot_of_entity[w.entity_of_slot[s]] = (int32_t)s;
+	w.parent_slot.assign(n, -1);
+	for (uint32_t s = 0; s < n; ++s) {
+		const int32_t p = parent[w.entity_of_slot[s]];
+		w.parent_slot[s] = p < 0 ? -1 : w.slot_of_entity[p];
+	}
+	w.n = n;
+	const size_t cap = std::max(n, 1u);
+	for (auto& b : w.pos) LMX_HIP(ctx, b.reserve(cap));
+	for (auto& b : w.rot) LMX_HIP(ctx, b.reserve(cap));
+	for (auto& b : w.scl) LMX_HIP(ctx, b.reserve(cap));
+	LMX_HIP(ctx, w.d_parent_slot.reserve(cap));
+	LMX_HIP(ctx, w.d_slot_of_entity.reserve(cap));
+	LMX_HIP(ctx, w.d_entity_of_slot.reserve(cap));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (n) {
+		LMX_HIP(ctx, hipMemcpy(w.d_parent_slot.p, w.parent_slot.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(w.d_slot_of_entity.p, w.slot_of_entity.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(w.d_entity_of_slot.p, w.entity_of_slot.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+		// initial values: every entity's transform is staged through the scatter kernel (roots -> world, children -> local)
+		std::vector<int32_t> all(n);
+		for (uint32_t e = 0; e < n; ++e) all[e] = (int32_t)e;
+		LMX_HIP(ctx, w.d_stage_entity.reserve(n));
+		LMX_HIP(ctx, w.d_stage_tr.reserve(n));
+		LMX_HIP(ctx, hipMemcpy(w.d_stage_entity.p, all.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(w.d_stage_tr.p, transforms, n * sizeof(LmxTransform), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, w.d_stage_entity.p, w.d_stage_tr.p, n));
+	}
+	w.bound_entity.clear();
+	w.bound_radius.clear();
+	w.bound_generation = ~0ull;
+	w.built = true;
+	return LMX_OK;
+}
+
+int lmx_world_set_transforms(LmxContext* ctx, uint32_t n, const int32_t* entity, const LmxTransform* transforms) {
+	LMX_CHECK_CTX(ctx);
+	WorldState& w = ctx->world;
+	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
+	if (!n) return LMX_OK;
+	if (!entity || !transforms) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
+	for (uint32_t i = 0; i < n; ++i)
+		if (entity[i] < 0 || (uint32_t)entity[i] >= w.n) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity[%u] = %d out of range", i, entity[i]);
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // staging buffers may still be read by a previous scatter
+	LMX_HIP(ctx, w.d_stage_entity.reserve(n));
+	LMX_HIP(ctx, w.d_stage_tr.reserve(n));
+	LMX_HIP(ctx, hipMemcpy(w.d_stage_entity.p, entity, n * sizeof(int32_t), hipMemcpyHostToDevice));
+	LMX_HIP(ctx, hipMemcpy(w.d_stage_tr.p, transforms, n * sizeof(LmxTransform), hipMemcpyHostToDevice));
+	LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, w.d_stage_entity.p, w.d_stage_tr.p, n));
+	return LMX_OK;
+}
+
+int lmx_world_set_transforms_device(LmxContext* ctx, uint32_t n, const void* d_entity, const void* d_transforms) {
+	LMX_CHECK_CTX(ctx);
+	WorldState& w = ctx->world;
+	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
+	if (!n) return LMX_OK;
+	if (!d_entity || !d_transforms) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null device pointer");
+	LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, (const int32_t*)d_entity, d_transforms, n));
+	return LMX_OK;
+}
+
+int lmx_world_bind_culling(LmxContext* ctx, uint32_t n, const int32_t* entity, const float* model_radius) {
+	LMX_CHECK_CTX(ctx);
+	WorldState& w = ctx->world;
+	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
+	if (n && (!entity || !model_radius)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
+	for (uint32_t i = 0; i < n; ++i) {
+		if (entity[i] < 0 || (uint32_t)entity[i] >= w.n) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity[%u] = %d out of range", i, entity[i]);
+		if (!lmx_cull_is_added(ctx, entity[i])) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d is not in the culling system", entity[i]);
+	}
+	// bound entities move every frame: they live in the culling system's dynamic (unsorted) set from now on
+	for (uint32_t i = 0; i < n; ++i) {
+		if (!cull_make_dynamic(ctx, entity[i])) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d is not in the culling system", entity[i]);
+	}
+	w.bound_entity.assign(entity, entity + n);
+	w.bound_radius.assign(model_radius, model_radius + n);
+	w.bound_generation = ~0ull;
+	return LMX_OK;
+}
+
+static int world_upload_binding(LmxContext* ctx) {
+	WorldState& w = ctx->world;
+	CullState& cs = ctx->cull;
+	if (int rc = cull_flush(ctx)) return rc; // dynamic slots must be current
+	if (w.bound_generation == cs.dyn_generation) return LMX_OK;
+	const size_t n = w.bound_entity.size();
+	std::vector<uint32_t> slot(n), dyn(n);
+	for (size_t i = 0; i < n; ++i) {
+		const int32_t e = w.bound_entity[i];
+		if ((size_t)e >= cs.ent_to_dyn.size() || cs.ent_to_dyn[e] < 0)
+			return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bound entity %d was removed from the culling system; call lmx_world_bind_culling again", e);
+		slot[i] = (uint32_t)w.slot_of_entity[e];
+		dyn[i] = cs.dyn_slot[cs.ent_to_dyn[e]];
+	}
+	LMX_HIP(ctx, w.d_bound_slot.reserve(std::max<size_t>(n, 1)));
+	LMX_HIP(ctx, w.d_bound_dyn.reserve(std::max<size_t>(n, 1)));
+	LMX_HIP(ctx, w.d_bound_radius.reserve(std::max<size_t>(n, 1)));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (n) {
+		LMX_HIP(ctx, hipMemcpy(w.d_bound_slot.p, slot.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(w.d_bound_dyn.p, dyn.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(w.d_bound_radius.p, w.bound_radius.data(), n * sizeof(float), hipMemcpyHostToDevice));
+	}
+	w.bound_generation = cs.dyn_generation;
+	return LMX_OK;
+}
+
+int lmx_world_propagate(LmxContext* ctx) {
+	LMX_CHECK_CTX(ctx);
+	WorldState& w = ctx->world;
+	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
+	const WorldDevice dev = w.dev();
+	for (size_t l = 1; l + 1 < w.level_start.size(); ++l) {
+		ProfScope ps(ctx, LMX_K_XFORM_LEVEL);
+		LMX_HIP(ctx, launch_xform_level(ctx->stream, dev, w.level_start[l], w.level_start[l + 1] - w.level_start[l]));
+	}
+	if (!w.bound_entity.empty()) {
+		if (int rc = world_upload_binding(ctx)) return rc;
+		CullState& cs = ctx->cull;
+		{
+			ProfScope ps(ctx, LMX_K_SPHERE_REFRESH);
+			LMX_HIP(ctx, launch_sphere_refresh(ctx->stream, dev, w.d_bound_slot.p, w.d_bound_dyn.p, w.d_bound_radius.p, cs.dyn_px.p, cs.dyn_py.p,
+				cs.dyn_pz.p, cs.dyn_radius.p, (uint32_t)w.bound_entity.size()));
+		}
+		cs.dyn_mirror_stale = true; // the device copy of the dynamic set is now newer than the host mirror
+		cs.dyn_values_dirty = false;
+	}
+	return LMX_OK;
+}
+
+int lmx_world_read_transforms(LmxContext* ctx, LmxTransform* out, uint32_t n) {
+	LMX_CHECK_CTX(ctx);
+	WorldState& w = ctx->world;
+	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
+	if (n < w.n || !out) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u transforms", w.n);
+	if (!w.n) return LMX_OK;
+	LMX_HIP(ctx, w.d_export.reserve(w.n));
+	LMX_HIP(ctx, launch_xform_export(ctx->stream, w.dev(), w.d_entity_of_slot.p, w.n, w.d_export.p));
+	LMX_HIP(ctx, hipMemcpyAsync(out, w.d_export.p, (size_t)w.n * sizeof(LmxTransform), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+
+} // extern "C"

@@ -1,0 +1,249 @@
+// lmx_context.h — internal state behind the opaque LmxContext of include/lumix_mi355.h, shared by the lmx_capi_*.hip
+// translation units (context / culling / world transforms / skinning). Nothing here crosses the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lumix_mi355.h"
+#include "lmx_kernels.h"
+#include "lmx_cull_layout.h"
+
+namespace lmx {
+
+template <typename T> struct DevBuf {
+	T* p = nullptr;
+	size_t cap = 0; // elements
+	~DevBuf() { release(); }
+	void release() {
+		if (p) (void)hipFree(p);
+		p = nullptr;
+		cap = 0;
+	}
+	// grow-only; contents are NOT preserved
+	hipError_t reserve(size_t n) {
+		if (n <= cap) return hipSuccess;
+		release();
+		const size_t want = n + n / 8 + 64;
+		hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+		if (e != hipSuccess) {
+			p = nullptr;
+			return e;
+		}
+		cap = want;
+		return hipSuccess;
+	}
+};
+
+struct CullView {
+	DevBuf<float4> cellinfo; // two-kernel path only
+	DevBuf<int32_t> out;
+	DevBuf<uint32_t> counts;
+	uint32_t n_frusta = 0;
+	uint32_t out_stride = 0;
+	uint32_t cell_stride = 0;
+	uint32_t out_start[MAX_TYPES] = {};
+	uint32_t out_cap[MAX_TYPES] = {};
+	bool valid = false;
+	// caller-owned result buffers (lmx_cull_bind_output)
+	int32_t* ext_out = nullptr;
+	size_t ext_out_cap = 0;
+	uint32_t* ext_counts = nullptr;
+	// library-owned counters are double-buffered: the fused kernel clears the half the NEXT cull will use
+	uint32_t flip = 0;
+	bool next_half_is_zero = false;
+	int32_t* out_ptr() const { return ext_out ? ext_out : out.p; }
+	uint32_t* counts_ptr() const { return ext_counts ? ext_counts : counts.p + flip * (MAX_FRUSTA * MAX_TYPES); }
+	uint32_t* counts_other() const { return counts.p + (flip ^ 1u) * (MAX_FRUSTA * MAX_TYPES); }
+};
+
+// One entity of the dynamic set (see DynDeviceView): what CullingSystem::set(entity, pos, radius) was last called with.
+struct DynRec {
+	double pos[3];
+	float radius;
+	int32_t entity;
+	uint8_t type;
+};
+
+struct CullState {
+	// ---- static set: host mirror (one CullRec per entity) + sorted device layout -------------------------------
+	std::vector<CullRec> recs;
+	std::vector<int32_t> ent_to_rec; // entity -> index into recs, or -1
+	std::vector<uint32_t> rec_slot;  // rec -> device sphere slot, valid while !structure_dirty
+	bool structure_dirty = false;
+	bool built = false;
+	std::vector<uint32_t> patch_slot;
+	std::vector<float4> patch_val;
+	DevBuf<uint32_t> d_patch_slot;
+	DevBuf<float4> d_patch_val;
+	DevBuf<float4> spheres;
+	DevBuf<int32_t> ids;
+	DevBuf<uint32_t> chunk_cell;
+	DevBuf<uint64_t> chunk_flags;
+	DevBuf<CellKey> cells;
+	DevBuf<CellKey> tile_cells[3];
+	DevBuf<uint32_t> tile_tab[3];
+	uint32_t tile_cap[3] = {16, 16, 16};
+	uint32_t n_padded = 0, n_cells = 0, n_dead_cells = 0;
+	uint32_t max_tile_cells[3] = {0, 0, 0};
+	TypeTable tt = {};
+	uint32_t cell_begin[MAX_TYPES] = {}, cell_end[MAX_TYPES] = {};
+	// ---- dynamic set: entities bound to the world hierarchy, unsorted -----------------------------------------
+	std::vector<DynRec> dyn;
+	std::vector<int32_t> ent_to_dyn;  // entity -> index into dyn, or -1
+	std::vector<uint32_t> dyn_slot;   // dyn rec -> device slot, valid while !dyn_layout_dirty
+	bool dyn_layout_dirty = false;    // membership changed: slots must be reassigned
+	bool dyn_values_dirty = false;    // host changed pos / radius of a dynamic entity
+	bool dyn_mirror_stale = false;    // the device refreshed pos / radius (lmx_world_propagate): dyn[] is older
+	DevBuf<double> dyn_px, dyn_py, dyn_pz;
+	DevBuf<float> dyn_radius;
+	DevBuf<int32_t> dyn_ids;
+	uint32_t dyn_padded = 0;
+	TypeTable dyn_tt = {};
+	uint64_t dyn_generation = 0; // bumped whenever dyn_slot changes (world binding tables depend on it)
+	// ---- shared ---------------------------------------------------------------------------------------------
+	uint32_t out_total = 0; // ids per frustum row = sum over types of (static padded + dynamic padded)
+	CullView views[LMX_MAX_VIEWS];
+};
+
+struct WorldState {
+	uint32_t n = 0;
+	bool built = false;
+	std::vector<int32_t> slot_of_entity, entity_of_slot, parent_slot;
+	std::vector<uint32_t> level_start; // size levels + 1
+	DevBuf<double> pos[6];             // lpx lpy lpz wpx wpy wpz
+	DevBuf<float4> rot[2];             // lrot wrot
+	DevBuf<float> scl[6];              // lsx lsy lsz wsx wsy wsz
+	DevBuf<int32_t> d_parent_slot, d_slot_of_entity, d_entity_of_slot;
+	DevBuf<int32_t> d_stage_entity;
+	DevBuf<LmxTransform> d_stage_tr;
+	DevBuf<LmxTransform> d_export;
+	// culling binding (RenderModuleImpl::onModelInstanceMoved)
+	std::vector<int32_t> bound_entity;
+	std::vector<float> bound_radius;
+	DevBuf<uint32_t> d_bound_slot, d_bound_dyn;
+	DevBuf<float> d_bound_radius;
+	uint64_t bound_generation = ~0ull; // CullState::dyn_generation the device binding tables were built for
+	WorldDevice dev() {
+		WorldDevice w;
+		w.lpx = pos[0].p; w.lpy = pos[1].p; w.lpz = pos[2].p; w.lrot = rot[0].p; w.lsx = scl[0].p; w.lsy = scl[1].p; w.lsz = scl[2].p;
+		w.wpx = pos[3].p; w.wpy = pos[4].p; w.wpz = pos[5].p; w.wrot = rot[1].p; w.wsx = scl[3].p; w.wsy = scl[4].p; w.wsz = scl[5].p;
+		w.parent_slot = d_parent_slot.p;
+		return w;
+	}
+};
+
+struct SkinModel { uint32_t bone_offset, n_bones, max_depth; int32_t first_nonroot; };
+struct SkinMesh { uint32_t vert_offset, n_verts; };
+
+struct SkinState {
+	std::vector<SkinModel> models;
+	std::vector<SkinMesh> meshes;
+	// concatenated host copies (re-uploaded when models/meshes are added)
+	std::vector<int16_t> parents;
+	std::vector<uint8_t> depth;
+	std::vector<float> inv_pos;
+	std::vector<float4> inv_rot;
+	std::vector<float> verts;
+	std::vector<float4> weights;
+	std::vector<int16_t> indices;
+	bool models_dirty = false, meshes_dirty = false;
+	DevBuf<int16_t> d_parents;
+	DevBuf<uint8_t> d_depth;
+	DevBuf<float> d_inv_pos;
+	DevBuf<float4> d_inv_rot;
+	DevBuf<float> d_verts;
+	DevBuf<float4> d_weights;
+	DevBuf<int16_t> d_indices;
+	std::vector<SkinInstance> inst;
+	DevBuf<SkinInstance> d_inst;
+	DevBuf<float> d_pose_pos;
+	DevBuf<float4> d_pose_rot;
+	DevBuf<float4> d_palette;
+	DevBuf<float> d_out;
+	size_t bones_total = 0, verts_total = 0;
+	uint32_t max_verts = 0;
+	bool poses_uploaded = false;
+	bool exact = false;
+};
+
+
+struct ProfSlot { hipEvent_t a, b; int kernel; };
+
+
+} // namespace lmx
+
+struct LmxContext {
+	int device = 0;
+	hipStream_t own_stream = nullptr;
+	hipStream_t stream = nullptr;
+	std::string error;
+	bool profiling = false;
+	std::vector<lmx::ProfSlot> prof_pending;
+	std::vector<hipEvent_t> event_pool;
+	double prof_ms[LMX_K_COUNT] = {};
+	uint64_t prof_launches[LMX_K_COUNT] = {};
+	lmx::CullState cull;
+	lmx::WorldState world;
+	lmx::SkinState skin;
+};
+
+namespace lmx {
+
+int fail(LmxContext* ctx, int code, const char* fmt, ...); // records the message, returns `code`
+void prof_drain(LmxContext* ctx);
+int cull_flush(LmxContext* ctx);          // lmx_capi_cull.hip: make the device copy of the culling sets current
+int cull_dyn_sync_mirror(LmxContext* ctx); // dyn[] <- device when lmx_world_propagate refreshed it
+bool cull_make_dynamic(LmxContext* ctx, int32_t entity); // move an entity from the static to the dynamic set
+
+#define LMX_HIP(ctx, expr)                                                                                             \
+	do {                                                                                                               \
+		hipError_t e_ = (expr);                                                                                        \
+		if (e_ != hipSuccess)                                                                                          \
+			return lmx::fail(ctx, e_ == hipErrorOutOfMemory ? LMX_ERR_OUT_OF_MEMORY : LMX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+				hipGetErrorString(e_), __FILE__, __LINE__);                                                           \
+	} while (0)
+
+#define LMX_CHECK_CTX(ctx)                                                                                             \
+	do {                                                                                                               \
+		if (!(ctx)) return LMX_ERR_INVALID_ARGUMENT;                                                                   \
+		hipError_t e_ = hipSetDevice((ctx)->device);                                                                   \
+		if (e_ != hipSuccess) return lmx::fail(ctx, LMX_ERR_NO_DEVICE, "hipSetDevice(%d): %s", (ctx)->device, hipGetErrorString(e_)); \
+	} while (0)
+
+struct ProfScope { // records HIP events around one launch on the launch stream when profiling is enabled
+	LmxContext* ctx;
+	ProfSlot slot;
+	bool on;
+	ProfScope(LmxContext* c, int kernel) : ctx(c), on(c->profiling) {
+		if (!on) return;
+		slot.kernel = kernel;
+		slot.a = take();
+		slot.b = take();
+		(void)hipEventRecord(slot.a, ctx->stream);
+	}
+	~ProfScope() {
+		if (!on) return;
+		(void)hipEventRecord(slot.b, ctx->stream);
+		ctx->prof_pending.push_back(slot);
+	}
+	hipEvent_t take() {
+		if (!ctx->event_pool.empty()) {
+			hipEvent_t e = ctx->event_pool.back();
+			ctx->event_pool.pop_back();
+			return e;
+		}
+		hipEvent_t e = nullptr;
+		(void)hipEventCreate(&e);
+		return e;
+	}
+};
+
+} // namespace lmx

@@ -19,8 +19,9 @@ struct CellKey { int32_t ix, iy, iz; uint32_t meta; };
 
 // Per-type ranges in the padded sphere index space.
 struct TypeTable {
-	uint32_t ent_start[MAX_TYPES]; // first sphere slot of the type (multiple of TILE_ALIGN)
-	uint32_t ent_end[MAX_TYPES];   // end of the padded range (multiple of TILE_ALIGN)
+	uint32_t ent_start[MAX_TYPES]; // first slot of the type (static set: multiple of TILE_ALIGN, dynamic set: of 2048)
+	uint32_t ent_end[MAX_TYPES];   // end of the padded range
+	uint32_t out_start[MAX_TYPES]; // where the type's visible ids start in a frustum's output row (static + dynamic share it)
 };
 
 struct FrustaArg { DevFrustum f[MAX_FRUSTA]; };
@@ -58,6 +59,19 @@ size_t fused_lds_bytes(int n_frusta, uint32_t tile, uint32_t cell_cap);
 hipError_t launch_cull_fused(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
 	const FrustaArg& fr, int n_frusta, int32_t* out_ids, uint32_t out_stride, uint32_t* counts, uint32_t* counts_next);
 
+// Dynamic set: entities whose transform changes every frame (bound to the world hierarchy) are kept UNSORTED as world
+// position (fp64) + radius + id. Their cell, cell-relative position and per-cell class are recomputed per entity per cull
+// with exactly the arithmetic CullingSystem::set + cullInternal would apply (cell_of, classify_cell, sphere_visible), so
+// no re-binning is ever needed. Visible ids are appended to the same per-type output segments / counters as the static set.
+struct DynDeviceView {
+	const double* px; const double* py; const double* pz;
+	const float* radius;
+	const int32_t* ids; // -1 = padding
+	uint32_t n_padded;
+};
+hipError_t launch_cull_dynamic(hipStream_t s, const DynDeviceView& d, uint32_t slot_begin, uint32_t slot_end, const TypeTable& dyn_tt,
+	const FrustaArg& fr, int n_frusta, int32_t* out_ids, uint32_t out_stride, uint32_t* counts);
+
 // spheres[slot[i]] = value[i]
 hipError_t launch_patch_spheres(hipStream_t s, float4* spheres, const uint32_t* slot, const float4* value, uint32_t n);
 
@@ -75,12 +89,10 @@ hipError_t launch_xform_export(hipStream_t s, const WorldDevice& w, const int32_
 // stage transforms (AoS LmxTransform, device memory) into the SoA arrays: roots -> world, children -> local
 hipError_t launch_xform_scatter(hipStream_t s, const WorldDevice& w, const int32_t* slot_of_entity, const int32_t* entity,
 	const void* transforms, uint32_t n);
-// culling sphere refresh for bound entities (see xform_kernels.hip). Entities that left their cell (or crossed the
-// is_big threshold) are appended to rebin[] for the host mirror to re-add.
-struct RebinItem { double pos[3]; float radius; uint32_t bound_index; };
-hipError_t launch_sphere_refresh(hipStream_t s, const WorldDevice& w, const uint32_t* bound_slot, const uint32_t* bound_sphere,
-	const float* model_radius, const uint32_t* sphere_cell, const CellKey* cells, float4* spheres, uint32_t n, uint32_t* rebin_count,
-	RebinItem* rebin);
+// culling refresh for bound entities (RenderModuleImpl::onModelInstanceMoved, render_module.cpp:1544-1554): the dynamic
+// set's position / radius of bound entity i become (world.pos, model_radius[i] * maximum(scale.x, scale.y, scale.z))
+hipError_t launch_sphere_refresh(hipStream_t s, const WorldDevice& w, const uint32_t* bound_slot, const uint32_t* bound_dyn,
+	const float* model_radius, double* dyn_px, double* dyn_py, double* dyn_pz, float* dyn_radius, uint32_t n);
 
 // ---- skinning --------------------------------------------------------------------------------------------
 struct SkinInstance {
@@ -98,6 +110,6 @@ hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, uint32_t
 	const int16_t* parents, const uint8_t* depth, const float* inv_pos, const float4* inv_rot, float4* palette);
 // evaluateSkin over every vertex of every instance
 hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, uint32_t max_verts, const float* verts,
-	const float4* weights, const int16_t* indices, const float4* palette, float* out);
+	const float4* weights, const int16_t* indices, const float4* palette, float* out, bool exact);
 
 } // namespace lmx

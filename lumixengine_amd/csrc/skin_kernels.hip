@@ -45,13 +45,26 @@ __global__ __launch_bounds__(256) void k_pose_palette(const SkinInstance* __rest
 	for (uint32_t k = lane; k < in.n_bones * 3; k += 64) pos[k] = gpos[k];
 	for (uint32_t b = lane; b < in.n_bones; b += 64) rot[b] = grot[b];
 	wave_lds_sync();
+	// depth and parent of this lane's bones (bones lane, lane+64, lane+128, lane+192) live in registers for the walk
 	const int16_t* par = parents + in.model_offset;
 	const uint8_t* dep = depth + in.model_offset;
+	constexpr int BPL = (SKIN_MAX_BONES + 63) / 64; // bones per lane
+	int32_t my_parent[BPL];
+	uint32_t my_depth[BPL];
+#pragma unroll
+	for (int k = 0; k < BPL; ++k) {
+		const uint32_t b = lane + 64u * k;
+		const bool valid = b < in.n_bones && (int32_t)b >= in.first_nonroot;
+		my_parent[k] = valid ? (int32_t)par[b] : 0;
+		my_depth[k] = valid ? (uint32_t)dep[b] : 0u; // depth 0 = never recomputed (roots / out of range)
+	}
 	const uint32_t max_depth = in.max_depth;
 	for (uint32_t d = 1; d <= max_depth; ++d) {
-		for (uint32_t b = lane; b < in.n_bones; b += 64) {
-			if (dep[b] == d && (int32_t)b >= in.first_nonroot) {
-				const int32_t p = par[b];
+#pragma unroll
+		for (int k = 0; k < BPL; ++k) {
+			if (my_depth[k] == d) {
+				const uint32_t b = lane + 64u * k;
+				const int32_t p = my_parent[k];
 				const float4 pr4 = rot[p];
 				const float4 r4 = rot[b];
 				const Q4 pr = Q4{pr4.x, pr4.y, pr4.z, pr4.w};
@@ -89,10 +102,11 @@ __global__ __launch_bounds__(256) void k_pose_palette(const SkinInstance* __rest
 // l % COPIES. With 16 copies every lane of a ds_read_b128 service group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...:
 // 16 lanes with distinct l % 16, MI355X_MICROARCH.md LDS table) owns its own bank column -> conflict-free whatever the
 // indices. 48 KiB per block (64 bones x 16 copies, 128 x 8, 196 x 4), staged once per tile of thousands of vertices.
+typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int SKIN_THREADS = 512;
 constexpr int SKIN_LDS_SLOTS = 3072; // float4 slots = 48 KiB
 
-template <int COPIES>
+template <int COPIES, bool EXACT>
 __device__ __forceinline__ void skin_tile(const SkinInstance& in, uint32_t v_begin, uint32_t v_end, float4* s_rows,
 	const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices,
 	const float4* __restrict__ palette, float* __restrict__ out) {
@@ -108,51 +122,82 @@ __device__ __forceinline__ void skin_tile(const SkinInstance& in, uint32_t v_beg
 	__syncthreads();
 	const uint32_t col = threadIdx.x & (COPIES - 1);
 	const float4* rows = s_rows + col;
-	// software-pipelined: the next vertex's position / weights / indices are in flight while the current one is blended
+	// per-instance base pointers are wave-uniform (SGPRs); per-lane offsets stay 32-bit
+	struct F3 { float x, y, z; }; // 12-byte records: loaded / stored as one dwordx3 per lane
+	const F3* vbase = reinterpret_cast<const F3*>(verts) + in.vert_offset;
+	const float4* wbase = weights + in.vert_offset;
+	const int2* ibase = reinterpret_cast<const int2*>(indices) + in.vert_offset; // 4 x i16 per vertex, little endian
+	F3* obase = reinterpret_cast<F3*>(out) + in.out_offset;
 	struct VertexIn { float px, py, pz; float4 w; int2 iw; };
 	auto load = [&](uint32_t v) {
-		const size_t gv = (size_t)in.vert_offset + v;
 		VertexIn r;
-		r.px = verts[3 * gv];
-		r.py = verts[3 * gv + 1];
-		r.pz = verts[3 * gv + 2];
-		r.w = weights[gv];
-		r.iw = reinterpret_cast<const int2*>(indices)[gv]; // 4 x i16, little endian
+		const F3 p = vbase[v];
+		r.px = p.x;
+		r.py = p.y;
+		r.pz = p.z;
+		r.w = wbase[v];
+		r.iw = ibase[v];
 		return r;
 	};
-	uint32_t v = v_begin + threadIdx.x;
-	if (v >= v_end) return;
-	VertexIn cur = load(v);
-	for (;;) {
-		const uint32_t vn = v + SKIN_THREADS;
-		const bool has_next = vn < v_end;
-		VertexIn nxt = cur;
-		if (has_next) nxt = load(vn);
-		const float4 w = cur.w;
-		const int32_t i0 = (int16_t)(cur.iw.x & 0xffff), i1 = cur.iw.x >> 16, i2 = (int16_t)(cur.iw.y & 0xffff), i3 = cur.iw.y >> 16;
+	auto skin_one = [&](const VertexIn& c, uint32_t v) {
+		// bone indices are non-negative i16 (validated at lmx_skin_add_mesh): plain 16-bit fields, no sign extension
+		const float4* r0 = rows + (uint32_t)(c.iw.x & 0xffff) * (3 * COPIES);
+		const float4* r1 = rows + ((uint32_t)c.iw.x >> 16) * (3 * COPIES);
+		const float4* r2 = rows + (uint32_t)(c.iw.y & 0xffff) * (3 * COPIES);
+		const float4* r3 = rows + ((uint32_t)c.iw.y >> 16) * (3 * COPIES);
+		const float4 w = c.w;
 		float o[3];
 #pragma unroll
 		for (int r = 0; r < 3; ++r) {
-			const float4 a = rows[(3 * i0 + r) * COPIES], b = rows[(3 * i1 + r) * COPIES], c = rows[(3 * i2 + r) * COPIES],
-						 d = rows[(3 * i3 + r) * COPIES];
-			// Matrix::operator*(float) and operator+ (math.cpp:1022-1071), left to right: ((A*w.x + B*w.y) + C*w.z) + D*w.w
-			const float m0 = a.x * w.x + b.x * w.y + c.x * w.z + d.x * w.w;
-			const float m1 = a.y * w.x + b.y * w.y + c.y * w.z + d.y * w.w;
-			const float m2 = a.z * w.x + b.z * w.y + c.z * w.z + d.z * w.w;
-			const float m3 = a.w * w.x + b.w * w.y + c.w * w.z + d.w * w.w;
-			// Matrix::transformPoint (math.cpp:1231-1235): c0.r*p.x + c1.r*p.y + c2.r*p.z + c3.r
-			o[r] = m0 * cur.px + m1 * cur.py + m2 * cur.pz + m3;
+			const float4 A = r0[r * COPIES], B = r1[r * COPIES], C = r2[r * COPIES], D = r3[r * COPIES];
+			if constexpr (EXACT) {
+				// Matrix::operator*(float) and operator+ (math.cpp:1022-1071), left to right: ((A*w.x + B*w.y) + C*w.z) + D*w.w
+				const float m0 = A.x * w.x + B.x * w.y + C.x * w.z + D.x * w.w;
+				const float m1 = A.y * w.x + B.y * w.y + C.y * w.z + D.y * w.w;
+				const float m2 = A.z * w.x + B.z * w.y + C.z * w.z + D.z * w.w;
+				const float m3 = A.w * w.x + B.w * w.y + C.w * w.z + D.w * w.w;
+				// Matrix::transformPoint (math.cpp:1231-1235): c0.r*p.x + c1.r*p.y + c2.r*p.z + c3.r
+				o[r] = m0 * c.px + m1 * c.py + m2 * c.pz + m3;
+			} else {
+				// same association with the products fused into the adds, on register pairs (v_pk_fma_f32): the four
+				// floats of an LDS row land in consecutive VGPRs, so {x,y} and {z,w} are packed operands as they are.
+				const v2f a01 = {A.x, A.y}, a23 = {A.z, A.w}, b01 = {B.x, B.y}, b23 = {B.z, B.w};
+				const v2f c01 = {C.x, C.y}, c23 = {C.z, C.w}, d01 = {D.x, D.y}, d23 = {D.z, D.w};
+				const v2f wx = {w.x, w.x}, wy = {w.y, w.y}, wz = {w.z, w.z}, ww = {w.w, w.w};
+				v2f m01 = a01 * wx, m23 = a23 * wx;
+				m01 = __builtin_elementwise_fma(b01, wy, m01);
+				m23 = __builtin_elementwise_fma(b23, wy, m23);
+				m01 = __builtin_elementwise_fma(c01, wz, m01);
+				m23 = __builtin_elementwise_fma(c23, wz, m23);
+				m01 = __builtin_elementwise_fma(d01, ww, m01);
+				m23 = __builtin_elementwise_fma(d23, ww, m23);
+				o[r] = fmaf(m23.x, c.pz, fmaf(m01.y, c.py, m01.x * c.px)) + m23.y;
+			}
 		}
-		const size_t ov = (size_t)in.out_offset + v;
-		out[3 * ov] = o[0];
-		out[3 * ov + 1] = o[1];
-		out[3 * ov + 2] = o[2];
-		if (!has_next) break;
-		cur = nxt;
-		v = vn;
+		obase[v] = F3{o[0], o[1], o[2]};
+	};
+	// software-pipelined and unrolled by two (A / B ping-pong): the next vertex's loads are in flight while the current one
+	// is blended, and no register block is copied between iterations
+	uint32_t v = v_begin + threadIdx.x;
+	if (v >= v_end) return;
+	VertexIn a = load(v);
+	for (;;) {
+		const uint32_t vb = v + SKIN_THREADS;
+		const bool has_b = vb < v_end;
+		VertexIn b = a;
+		if (has_b) b = load(vb);
+		skin_one(a, v);
+		if (!has_b) break;
+		const uint32_t va = vb + SKIN_THREADS;
+		const bool has_a = va < v_end;
+		if (has_a) a = load(va);
+		skin_one(b, vb);
+		if (!has_a) break;
+		v = va;
 	}
 }
 
+template <bool EXACT>
 __global__ __launch_bounds__(SKIN_THREADS, 6) void k_skin_vertices(const SkinInstance* __restrict__ inst, uint32_t tiles_per_inst,
 	uint32_t tile_verts, const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices,
 	const float4* __restrict__ palette, float* __restrict__ out) {
@@ -163,9 +208,9 @@ __global__ __launch_bounds__(SKIN_THREADS, 6) void k_skin_vertices(const SkinIns
 	const uint32_t v_begin = tile * tile_verts;
 	if (v_begin >= in.n_verts) return; // block-uniform
 	const uint32_t v_end = min(v_begin + tile_verts, in.n_verts);
-	if (in.n_bones <= 64) skin_tile<16>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
-	else if (in.n_bones <= 128) skin_tile<8>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
-	else skin_tile<4>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
+	if (in.n_bones <= 64) skin_tile<16, EXACT>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
+	else if (in.n_bones <= 128) skin_tile<8, EXACT>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
+	else skin_tile<4, EXACT>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
 }
 
 } // namespace
@@ -179,7 +224,7 @@ hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, uint32_t
 }
 
 hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, uint32_t max_verts, const float* verts,
-	const float4* weights, const int16_t* indices, const float4* palette, float* out) {
+	const float4* weights, const int16_t* indices, const float4* palette, float* out, bool exact) {
 	if (!n_inst || !max_verts) return hipSuccess;
 	// tiles: as large as possible (the 48 KiB palette staging is paid per tile) while still giving the chip >= ~3000 blocks
 	const uint32_t max_tiles = (max_verts + 1023u) / 1024u;
@@ -189,8 +234,13 @@ hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, uint32_
 	const uint32_t tile_verts = (max_verts + tiles - 1) / tiles;
 	const uint64_t blocks = (uint64_t)tiles * n_inst;
 	if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-	hipLaunchKernelGGL(k_skin_vertices, dim3((uint32_t)blocks), dim3(SKIN_THREADS), 0, s, inst, tiles, tile_verts, verts, weights, indices,
-		palette, out);
+	if (exact) {
+		hipLaunchKernelGGL(k_skin_vertices<true>, dim3((uint32_t)blocks), dim3(SKIN_THREADS), 0, s, inst, tiles, tile_verts, verts, weights,
+			indices, palette, out);
+	} else {
+		hipLaunchKernelGGL(k_skin_vertices<false>, dim3((uint32_t)blocks), dim3(SKIN_THREADS), 0, s, inst, tiles, tile_verts, verts, weights,
+			indices, palette, out);
+	}
 	return hipGetLastError();
 }
 

@@ -72,33 +72,20 @@ __global__ __launch_bounds__(256) void k_xform_scatter(WorldDevice w, const int3
 	}
 }
 
-// onModelInstanceMoved -> CullingSystem::set (culling_system.cpp:225-242): same cell and same is_big -> update
-// the sphere in place; otherwise the entity must be re-binned, which is reported through rebin_list.
+// onModelInstanceMoved (render_module.cpp:1544-1554): CullingSystem::set(entity, tr.pos, bounding_radius * maximum(scale)).
+// Bound entities live in the culling system's dynamic set, which stores exactly these two values; the cell assignment
+// of CullingSystem::set is re-derived from them by the cull kernel, so nothing is re-binned here.
 __global__ __launch_bounds__(256) void k_sphere_refresh(WorldDevice w, const uint32_t* __restrict__ bound_slot,
-	const uint32_t* __restrict__ bound_sphere, const float* __restrict__ model_radius, const uint32_t* __restrict__ sphere_cell,
-	const CellKey* __restrict__ cells, float4* __restrict__ spheres, uint32_t n, uint32_t* __restrict__ rebin_count,
-	RebinItem* __restrict__ rebin) {
+	const uint32_t* __restrict__ bound_dyn, const float* __restrict__ model_radius, double* __restrict__ dyn_px,
+	double* __restrict__ dyn_py, double* __restrict__ dyn_pz, float* __restrict__ dyn_radius, uint32_t n) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) return;
 	const uint32_t s = bound_slot[i];
-	const uint32_t sph = bound_sphere[i];
-	const DV3 pos = DV3{w.wpx[s], w.wpy[s], w.wpz[s]};
-	const float radius = model_radius[i] * maximum3(w.wsx[s], w.wsy[s], w.wsz[s]);
-	const CellKey key = cells[sphere_cell[sph]];
-	const IV3 idx = cell_of(pos);
-	const bool was_big = (key.meta & 0x100u) != 0;
-	const bool same = idx.x == key.ix && idx.y == key.iy && idx.z == key.iz && was_big == is_big_radius(radius);
-	if (same) {
-		const V3 rel = to_v3(sub(pos, cell_origin(idx)));
-		spheres[sph] = make_float4(rel.x, rel.y, rel.z, radius);
-	} else {
-		const uint32_t k = atomicAdd(rebin_count, 1u);
-		RebinItem item;
-		item.pos[0] = pos.x; item.pos[1] = pos.y; item.pos[2] = pos.z;
-		item.radius = radius;
-		item.bound_index = i;
-		rebin[k] = item;
-	}
+	const uint32_t d = bound_dyn[i];
+	dyn_px[d] = w.wpx[s];
+	dyn_py[d] = w.wpy[s];
+	dyn_pz[d] = w.wpz[s];
+	dyn_radius[d] = model_radius[i] * maximum3(w.wsx[s], w.wsy[s], w.wsz[s]);
 }
 
 } // namespace
@@ -123,12 +110,11 @@ hipError_t launch_xform_scatter(hipStream_t s, const WorldDevice& w, const int32
 	return hipGetLastError();
 }
 
-hipError_t launch_sphere_refresh(hipStream_t s, const WorldDevice& w, const uint32_t* bound_slot, const uint32_t* bound_sphere,
-	const float* model_radius, const uint32_t* sphere_cell, const CellKey* cells, float4* spheres, uint32_t n, uint32_t* rebin_count,
-	RebinItem* rebin) {
+hipError_t launch_sphere_refresh(hipStream_t s, const WorldDevice& w, const uint32_t* bound_slot, const uint32_t* bound_dyn,
+	const float* model_radius, double* dyn_px, double* dyn_py, double* dyn_pz, float* dyn_radius, uint32_t n) {
 	if (!n) return hipSuccess;
-	hipLaunchKernelGGL(k_sphere_refresh, dim3((n + 255u) / 256u), dim3(256), 0, s, w, bound_slot, bound_sphere, model_radius,
-		sphere_cell, cells, spheres, n, rebin_count, rebin);
+	hipLaunchKernelGGL(k_sphere_refresh, dim3((n + 255u) / 256u), dim3(256), 0, s, w, bound_slot, bound_dyn, model_radius, dyn_px, dyn_py,
+		dyn_pz, dyn_radius, n);
 	return hipGetLastError();
 }
 

@@ -96,6 +96,34 @@ int emul_cull(uint32_t n, const int32_t* entity, const uint8_t* type, const doub
 	return 0;
 }
 
+// emulates k_cull_dynamic: every entity derives cell / is_big / cell-relative position from its fp64 position and
+// classifies its own cell; out_ids / out_types as in emul_cull
+int emul_cull_dynamic(uint32_t n, const int32_t* entity, const uint8_t* type, const double* pos, const float* radius,
+	const LmxShiftedFrustum* frusta, uint32_t n_frusta, int32_t* out_ids, uint8_t* out_types, uint32_t* out_counts) {
+	memset(out_counts, 0, sizeof(uint32_t) * n_frusta * LAYOUT_MAX_TYPES);
+	for (uint32_t f = 0; f < n_frusta; ++f) {
+		const DevFrustum fr = to_dev_frustum(frusta[f]);
+		uint32_t total = 0;
+		for (uint32_t i = 0; i < n; ++i) {
+			const DV3 p = DV3{pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+			const IV3 idx = cell_of(p);
+			const bool big = is_big_radius(radius[i]);
+			const V3 rel = to_v3(sub(p, cell_origin(idx)));
+			V3 off;
+			const uint32_t cls = classify_cell(fr, idx, big, &off);
+			bool vis = cls == CELL_ACCEPT;
+			if (cls == CELL_TEST) vis = sphere_visible(fr, off, rel.x, rel.y, rel.z, radius[i]);
+			if (vis) {
+				out_counts[f * LAYOUT_MAX_TYPES + type[i]]++;
+				out_ids[(size_t)f * n + total] = entity[i];
+				out_types[(size_t)f * n + total] = type[i];
+				++total;
+			}
+		}
+	}
+	return 0;
+}
+
 // emulates lmx_world_build + lmx_world_propagate (level order, compose) -> world transforms by entity
 int emul_world(uint32_t n, const int32_t* parent, const LmxTransform* tr, LmxTransform* out) {
 	std::vector<int> depth(n, -1);

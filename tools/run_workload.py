@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""Runs ONE hot-path workload in a loop so that rocprofv3 (kernel trace / PMC passes) sees only its kernels.
+
+    rocprofv3 --kernel-trace --stats --output-format csv -d out -- python tools/run_workload.py --workload skin --steps 20
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["cull_default", "cull_stream", "cull_dense", "cull8", "xform", "skin", "skin_distinct"], required=True)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--entities", type=int, default=10_000_000)
+    ap.add_argument("--instances", type=int, default=2000)
+    args = ap.parse_args()
+    import torch
+
+    from lumixengine_amd import api, scenes
+    from tests import helpers as H
+
+    ctx = api.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.workload.startswith("cull"):
+        half = 5000.0 if args.workload == "cull_dense" else 15000.0
+        sc = scenes.cull_scene(args.entities, half, seed=2, mixed_types=args.workload == "cull8")
+        cs = api.CullingSystem(ctx)
+        cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+        if args.workload == "cull_stream":
+            fr = api.viewport_frustum(pos=(0.0, 0.0, 4.0 * half), far=20.0 * half)
+        elif args.workload == "cull8":
+            fr = H.cascade_frusta(api, 8)
+        else:
+            fr = api.viewport_frustum()
+        for _ in range(args.steps):
+            cs.cull(fr)
+        ctx.synchronize()
+        print(args.workload, "visible", cs.cull(fr).counts().sum(axis=1))
+    elif args.workload == "xform":
+        h = scenes.hierarchy_chains(250_000, 4, seed=2)
+        w = api.World(ctx)
+        w.build(h["parent"], h["local"])
+        roots = np.flatnonzero(h["parent"] < 0).astype(np.int32)
+        new_root = scenes.random_transforms(np.random.default_rng(1), len(roots), 4000.0)
+        d_ent = torch.from_numpy(roots).cuda()
+        d_tr = torch.from_numpy(new_root.view(np.uint8).reshape(len(roots), -1)).cuda()
+        for _ in range(args.steps):
+            w.setTransformsDevice(len(roots), d_ent.data_ptr(), d_tr.data_ptr())
+            w.propagate()
+        ctx.synchronize()
+    else:
+        n_inst, n_verts = args.instances, 10_000
+        s = scenes.skeleton(64, seed=4)
+        sk = api.Skinning(ctx)
+        model = sk.addModel(s["parents"], s["bind"], s["first_nonroot"])
+        if args.workload == "skin":
+            verts, skin = scenes.skinned_mesh(n_verts, 64, seed=6)
+            mesh = sk.addMesh(verts, skin)
+            meshes = np.full(n_inst, mesh, np.uint32)
+        else:  # every instance has its own mesh: 48 B of HBM traffic per vertex
+            meshes = np.array([sk.addMesh(*scenes.skinned_mesh(n_verts, 64, seed=100 + i)) for i in range(n_inst)], np.uint32)
+        sk.setInstances(np.full(n_inst, model, np.uint32), meshes)
+        pos, rot = scenes.relative_poses(n_inst, 64, seed=5)
+        d_pos, d_rot = torch.from_numpy(pos).cuda(), torch.from_numpy(rot).cuda()
+        for _ in range(args.steps):
+            sk.uploadPosesDevice(d_pos.data_ptr(), d_rot.data_ptr(), n_inst * 64)
+            sk.run()
+        ctx.synchronize()
+    print("done", args.workload)
+
+
+if __name__ == "__main__":
+    main()
