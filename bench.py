@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--camera", choices=["default", "all_visible"], default="default",
                     help="all_visible: camera far outside looking at the whole cube (every sphere is fetched and visible) - the pure streaming case used to calibrate PMC byte counters")
     ap.add_argument("--force-collective", action="store_true", help="run the N>1 code path (RCCL all-gather of visible ids) even with one rank")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the default-camera loops (warm-up, timed, event-timed): the command whose rocprofv3 --kernel-trace --stats summary is committed under profiles/")
     ap.add_argument("--no-extras", action="store_true", help="skip the dense-variant / transform / skin side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -155,18 +157,24 @@ def main():
         return ms_s / max(n_s, 1), ms_c / max(n_c, 1)
 
     avg_spheres_ms, avg_classify_ms = kernel_times(frustum, args.steps, cold=False)
-    cold_spheres_ms, cold_classify_ms = kernel_times(frustum, min(args.steps, 50), cold=True)
-    # the pure streaming case on the same scene: a camera that sees the whole cube (every sphere fetched and visible)
-    stream_fr = api.viewport_frustum(pos=(0.0, 0.0, 4.0 * half), far=20.0 * half)
-    stream_visible = int(cs.cull(stream_fr).counts()[0].sum())
-    stream_warm_ms, _ = kernel_times(stream_fr, min(args.steps, 50), cold=False)
-    stream_cold_ms, _ = kernel_times(stream_fr, min(args.steps, 50), cold=True)
+    if args.headline_only:
+        cold_spheres_ms = cold_classify_ms = stream_warm_ms = stream_cold_ms = float("nan")
+        stream_visible = 0
+    else:
+        cold_spheres_ms, cold_classify_ms = kernel_times(frustum, min(args.steps, 50), cold=True)
+        # the pure streaming case on the same scene: a camera that sees the whole cube (every sphere fetched and visible)
+        stream_fr = api.viewport_frustum(pos=(0.0, 0.0, 4.0 * half), far=20.0 * half)
+        stream_visible = int(cs.cull(stream_fr).counts()[0].sum())
+        stream_warm_ms, _ = kernel_times(stream_fr, min(args.steps, 50), cold=False)
+        stream_cold_ms, _ = kernel_times(stream_fr, min(args.steps, 50), cold=True)
     del scrub
     # algorithmic bytes of one cull launch: 16 B sphere + 4 B id per resident entity, 4 B per visible id
     alg_bytes = 20.0 * N + 4.0 * visible
     stream_bytes = 20.0 * N + 4.0 * stream_visible
     achieved = alg_bytes / (avg_spheres_ms * 1e-3) / 1e9
-    gbps = lambda b, ms: round(b / (ms * 1e-3) / 1e9, 1)
+    gbps = lambda b, ms: None if ms != ms else round(b / (ms * 1e-3) / 1e9, 1)
+    rnd = lambda x, n: None if x != x else round(x, n)
+    traffic, traffic_note = load_traffic("k_cull_fused" if avg_classify_ms == 0.0 else "k_cull_spheres")
     roofline = {
         "kernel": "k_cull_fused" if avg_classify_ms == 0.0 else "k_cull_spheres",
         "bound": "hbm",
@@ -174,23 +182,23 @@ def main():
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4),
-        "traffic": None,  # HBM bytes per launch from rocprofv3 PMC passes: profiles/ and DESIGN.md §4
+        "traffic": traffic,  # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/)
+        "traffic_note": traffic_note,
         "algorithmic_bytes_per_launch": alg_bytes,
         "avg_launch_ms": round(avg_spheres_ms, 5),
         "classify_kernel_avg_launch_ms": round(avg_classify_ms, 5),
         "whole_cull_achieved_GBps": gbps(alg_bytes + 36.0 * stats["cells"], avg_spheres_ms + avg_classify_ms),
         # the back-to-back loop keeps the 200 MB working set in the 256 MiB Infinity Cache; cold = 1 GiB scrub before each cull
-        "cold_avg_launch_ms": round(cold_spheres_ms, 5),
+        "cold_avg_launch_ms": rnd(cold_spheres_ms, 5),
         "cold_achieved_GBps": gbps(alg_bytes, cold_spheres_ms),
-        "cold_frac": round(alg_bytes / (cold_spheres_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-        "cold_classify_avg_launch_ms": round(cold_classify_ms, 5),
+        "cold_frac": rnd(alg_bytes / (cold_spheres_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
         # streaming case (camera sees everything: no hierarchical skip, every algorithmic byte is really moved)
         "streaming_visible": stream_visible,
-        "streaming_warm_avg_launch_ms": round(stream_warm_ms, 5),
+        "streaming_warm_avg_launch_ms": rnd(stream_warm_ms, 5),
         "streaming_warm_GBps": gbps(stream_bytes, stream_warm_ms),
-        "streaming_cold_avg_launch_ms": round(stream_cold_ms, 5),
+        "streaming_cold_avg_launch_ms": rnd(stream_cold_ms, 5),
         "streaming_cold_GBps": gbps(stream_bytes, stream_cold_ms),
-        "streaming_cold_frac": round(stream_bytes / (stream_cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "streaming_cold_frac": rnd(stream_bytes / (stream_cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
         "note": "algorithmic bytes count every resident sphere although whole rejected cells are never fetched (the reference's per-cell reject), so `frac` of the default camera can exceed 1; streaming_cold_frac is the honest HBM-streaming efficiency of the kernel",
     }
 
@@ -233,6 +241,23 @@ def main():
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def load_traffic(kernel):
+    """HBM bytes per launch of the headline kernel, measured by separate rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    cannot share a pass) and committed as profiles/rNN/traffic.json. None when no such file travels with the repo."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not files:
+        return None, "no profiles/r*/traffic.json"
+    try:
+        t = json.load(open(files[-1])).get(kernel)
+        if not t:
+            return None, f"{os.path.relpath(files[-1], ROOT)} has no entry for {kernel}"
+        return t["hbm_bytes_per_launch"], f"{os.path.relpath(files[-1], ROOT)}: {t['note']}"
+    except Exception as e:  # noqa: BLE001 - a malformed profile file must not break the bench line
+        return None, f"unreadable traffic file: {e}"
 
 
 def extras(ctx, api, scenes, torch, timed, N, log):

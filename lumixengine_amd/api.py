@@ -61,6 +61,7 @@ SYMBOLS = {
     "lmx_cull_flush": (_ci, [_vp]),
     "lmx_cull_stats": (_ci, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "lmx_cull": (_ci, [_vp, _u32, _vp, _u32, _u8]),
+    "lmx_cull_set_pass_width": (_ci, [_vp, _u32]),
     "lmx_cull_counts": (_ci, [_vp, _u32, _vp]),
     "lmx_cull_read": (_ci, [_vp, _u32, _u32, _u8, _vp, _u32, C.POINTER(_u32)]),
     "lmx_cull_bind_output": (_ci, [_vp, _u32, _vp, _sz, _vp]),
@@ -301,6 +302,9 @@ class CullingSystem:
     def bindOutput(self, view: int, d_ids: Optional[int], ids_capacity: int, d_counts: Optional[int]):
         """Result slot `view` writes into caller-owned device memory (raw pointers, e.g. torch tensors' data_ptr())."""
         self.ctx.check(self.lib.lmx_cull_bind_output(self.ctx.h, view, d_ids, ids_capacity, d_counts))
+
+    def setPassWidth(self, frusta_per_pass: int):
+        self.ctx.check(self.lib.lmx_cull_set_pass_width(self.ctx.h, frusta_per_pass))
 
     def cull(self, frusta: np.ndarray, type_: int = TYPE_ALL, view: int = 0) -> CullResult:
         """cull(frustum[, type]); `frusta` may hold up to 8 ShiftedFrustum records tested in one pass."""

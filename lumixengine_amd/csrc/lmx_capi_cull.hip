@@ -548,10 +548,9 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 	const CullDeviceView dv = static_view(cs);
 	// static set: fused single-launch kernel; the layout bounds the cells per tile so its LDS table always fits. The
 	// classify + spheres pair stays available as an ablation / fallback (LMX_CULL_TWO_KERNELS=1).
-	const uint32_t tile = cull_tile_size((int)n_frusta);
-	const uint32_t tile_k = tile == 4096 ? 0 : (tile == 2048 ? 1 : 2);
 	static const bool force_two_kernels = getenv("LMX_CULL_TWO_KERNELS") != nullptr;
-	const bool fused = !force_two_kernels && fused_lds_bytes((int)n_frusta, tile, cs.tile_cap[tile_k]) <= 64 * 1024;
+	bool fused = !force_two_kernels;
+	for (int k = 0; k < 3 && fused; ++k) fused = fused_lds_bytes(k == 0 ? 1 : (k == 1 ? 4 : 8), TILE_ALIGN >> k, cs.tile_cap[k]) <= 64 * 1024;
 	if (fused) {
 		uint32_t* counts_next = nullptr;
 		if (v.ext_counts) {
@@ -560,11 +559,20 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 			v.flip ^= 1u;
 			if (!v.next_half_is_zero) LMX_HIP(ctx, hipMemsetAsync(v.counts_ptr(), 0, sizeof(uint32_t) * MAX_FRUSTA * MAX_TYPES, ctx->stream));
 			counts_next = v.counts_other();
-			v.next_half_is_zero = ent_end > ent_begin; // block 0 of the launch below clears it
+			v.next_half_is_zero = ent_end > ent_begin; // block 0 of the launch(es) below clears it
 		}
-		ProfScope ps(ctx, LMX_K_CULL_SPHERES);
-		LMX_HIP(ctx, launch_cull_fused(ctx->stream, dv, ent_begin, ent_end, cs.tt, fr, (int)n_frusta, v.out_ptr(), v.out_stride, v.counts_ptr(),
-			counts_next));
+		// The kernel is latency-bound, not bandwidth-bound: wide variants (many frusta per pass) hold more state per wave
+		// and run at lower occupancy, so a batch is split into passes of at most `pass_width` frusta.
+		const uint32_t pass_width = cs.pass_width;
+		for (uint32_t f0 = 0; f0 < n_frusta; f0 += pass_width) {
+			const uint32_t fw = std::min(pass_width, n_frusta - f0);
+			FrustaArg sub;
+			memset(&sub, 0, sizeof(sub));
+			for (uint32_t k = 0; k < fw; ++k) sub.f[k] = fr.f[f0 + k];
+			ProfScope ps(ctx, LMX_K_CULL_SPHERES);
+			LMX_HIP(ctx, launch_cull_fused(ctx->stream, dv, ent_begin, ent_end, cs.tt, sub, (int)fw, v.out_ptr() + (size_t)f0 * v.out_stride, v.out_stride,
+				v.counts_ptr() + f0 * MAX_TYPES, counts_next));
+		}
 	} else {
 		if (!v.ext_counts) {
 			v.flip ^= 1u;
@@ -594,6 +602,13 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 		LMX_HIP(ctx, launch_cull_dynamic(ctx->stream, dd, dyn_begin, dyn_end, cs.dyn_tt, fr, (int)n_frusta, v.out_ptr(), v.out_stride, v.counts_ptr()));
 	}
 	v.valid = true;
+	return LMX_OK;
+}
+
+int lmx_cull_set_pass_width(LmxContext* ctx, uint32_t frusta_per_pass) {
+	LMX_CHECK_CTX(ctx);
+	if (frusta_per_pass < 1 || frusta_per_pass > LMX_MAX_FRUSTA) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "pass width %u not in [1,%d]", frusta_per_pass, LMX_MAX_FRUSTA);
+	ctx->cull.pass_width = frusta_per_pass;
 	return LMX_OK;
 }
 

@@ -109,6 +109,7 @@ struct CullState {
 	TypeTable dyn_tt = {};
 	uint64_t dyn_generation = 0; // bumped whenever dyn_slot changes (world binding tables depend on it)
 	// ---- shared ---------------------------------------------------------------------------------------------
+	uint32_t pass_width = 1; // frusta tested per pass over the static set (lmx_cull_set_pass_width)
 	uint32_t out_total = 0; // ids per frustum row = sum over types of (static padded + dynamic padded)
 	CullView views[LMX_MAX_VIEWS];
 };

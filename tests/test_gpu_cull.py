@@ -37,11 +37,15 @@ def test_cull_matches_golden(gpu_ctx, fixture):
         for k in range(len(batch)):
             f = start + k
             H.assert_same_visible(gpu_visible(res, k), H.sorted_by_type(g[f"vis_ids_{f}"], g[f"vis_types_{f}"]), f"{fixture} batch {f}")
-    # every batch width 1..8 exercises its own kernel instantiation
-    for width in range(1, min(8, len(frusta)) + 1):
-        res = cs.cull(np.ascontiguousarray(frusta[:width]), view=2)
-        for k in range(width):
-            H.assert_same_visible(gpu_visible(res, k), H.sorted_by_type(g[f"vis_ids_{k}"], g[f"vis_types_{k}"]), f"width {width} frustum {k}")
+    # every pass width 1..8 is its own kernel instantiation (the default is one frustum per pass)
+    try:
+        for width in range(1, min(8, len(frusta)) + 1):
+            cs.setPassWidth(width)
+            res = cs.cull(np.ascontiguousarray(frusta[:8]), view=2)
+            for k in range(min(8, len(frusta))):
+                H.assert_same_visible(gpu_visible(res, k), H.sorted_by_type(g[f"vis_ids_{k}"], g[f"vis_types_{k}"]), f"width {width} frustum {k}")
+    finally:
+        cs.setPassWidth(1)
 
 
 def test_cull_config1_golden(gpu_ctx):

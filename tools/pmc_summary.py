@@ -12,10 +12,15 @@ import sys
 
 
 def short(name):
-    for k in ("k_cull_fused", "k_cull_spheres", "k_cull_classify", "k_xform_level", "k_xform_scatter", "k_sphere_refresh", "k_pose_palette", "k_skin_vertices", "k_patch_spheres"):
+    """kernel name + its template arguments, e.g. k_cull_fused<1, 8, 8>"""
+    import re
+
+    for k in ("k_cull_fused", "k_cull_spheres", "k_cull_classify", "k_cull_dynamic", "k_xform_level", "k_xform_scatter", "k_xform_export", "k_sphere_refresh",
+              "k_pose_palette", "k_skin_vertices", "k_patch_spheres"):
         if k in name:
-            return k
-    return name[:48]
+            m = re.search(re.escape(k) + r"(<[^>(]*>)?", name)
+            return m.group(0) if m else k
+    return name[:64]
 
 
 def main():
@@ -25,7 +30,15 @@ def main():
         for f in glob.glob(os.path.join(d, "*kernel_stats.csv")):
             with open(f) as fh:
                 for row in csv.DictReader(fh):
-                    entry.setdefault("kernel_stats", {})[short(row["Name"])] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]), "min_ns": float(row["MinNs"]), "max_ns": float(row["MaxNs"])}
+                    ks = entry.setdefault("kernel_stats", {})
+                    key, calls, avg = short(row["Name"]), int(row["Calls"]), float(row["AverageNs"])
+                    if key in ks:  # several instantiations behind one short name: merge
+                        old = ks[key]
+                        tot = old["calls"] + calls
+                        ks[key] = {"calls": tot, "avg_ns": (old["avg_ns"] * old["calls"] + avg * calls) / tot, "min_ns": min(old["min_ns"], float(row["MinNs"])),
+                                   "max_ns": max(old["max_ns"], float(row["MaxNs"]))}
+                    else:
+                        ks[key] = {"calls": calls, "avg_ns": avg, "min_ns": float(row["MinNs"]), "max_ns": float(row["MaxNs"])}
         for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
             acc = collections.defaultdict(list)
             with open(f) as fh:

@@ -38,10 +38,15 @@ def main():
             fr = H.cascade_frusta(api, 8)
         else:
             fr = api.viewport_frustum()
+        import time
+        for _ in range(5):
+            cs.cull(fr)
+        ctx.synchronize()
+        t0 = time.perf_counter()
         for _ in range(args.steps):
             cs.cull(fr)
         ctx.synchronize()
-        print(args.workload, "visible", cs.cull(fr).counts().sum(axis=1))
+        print(args.workload, "ms per cull %.4f" % ((time.perf_counter() - t0) * 1e3 / args.steps), "visible", cs.cull(fr).counts().sum(axis=1))
     elif args.workload == "xform":
         h = scenes.hierarchy_chains(250_000, 4, seed=2)
         w = api.World(ctx)
