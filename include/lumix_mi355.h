@@ -126,12 +126,24 @@ LMX_API int lmx_cull_bind_output(LmxContext* ctx, uint32_t view, void* d_ids, si
 /* n entities, entity index = array index (EntityRef::index). parent[i] = -1 for roots.
  * transforms[i] = world transform for roots, local transform (Hierarchy::local_transform) for children. */
 LMX_API int lmx_world_build(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxTransform* transforms);
+/* World::setParent (world.cpp:619-701): the child keeps its world transform and its local becomes
+ * Transform::computeLocal(parent world, child world); new_parent < 0 detaches the child. Cycles are rejected
+ * (LMX_ERR_INVALID_ARGUMENT, the reference logs "Hierarchy can not contain a cycle."). Editing operation: rebuilds the
+ * slot order on the host; culling bindings survive. */
+LMX_API int lmx_world_set_parent(LmxContext* ctx, int32_t new_parent, int32_t child);
+/* World::getLocalTransform (world.cpp:756-766) for every entity: Hierarchy::local_transform, or the world transform of
+ * entities without a parent. */
+LMX_API int lmx_world_read_local_transforms(LmxContext* ctx, LmxTransform* out, uint32_t n);
+/* Host-side Transform::compose / Transform::computeLocal (core/math.cpp:801-816), bit-identical to the engine's. */
+LMX_API int lmx_transform_compose(const LmxTransform* a, const LmxTransform* b, LmxTransform* out);
+LMX_API int lmx_transform_compute_local(const LmxTransform* parent, const LmxTransform* child, LmxTransform* out);
 /* World::setTransform for roots / World::setLocalTransform for children (world.cpp:337-342, 741-753), staged. */
 LMX_API int lmx_world_set_transforms(LmxContext* ctx, uint32_t n, const int32_t* entity, const LmxTransform* transforms);
 /* Same, with both arrays already in device memory (entity indices must be valid; they are not checked). */
 LMX_API int lmx_world_set_transforms_device(LmxContext* ctx, uint32_t n, const void* d_entity, const void* d_transforms);
 /* RenderModuleImpl::onModelInstanceMoved binding (render_module.cpp:1544-1554): after propagation the culling
- * sphere of entity[i] becomes (world.pos, model_radius[i] * maximum(scale.x, scale.y, scale.z)). Bound entities are
+ * sphere of entity[i] becomes (world.pos, model_radius[i] * maximum(scale.x, scale.y, scale.z)); model_radius[i] < 0
+ * binds the position only and keeps the radius (onDecalMoved / onPointLightMoved -> setPosition, :1568-1592). Bound entities are
  * moved to the culling system's dynamic set (unsorted, re-binned implicitly by the cull kernel every frame). */
 LMX_API int lmx_world_bind_culling(LmxContext* ctx, uint32_t n, const int32_t* entity, const float* model_radius);
 LMX_API int lmx_world_propagate(LmxContext* ctx);
@@ -164,6 +176,10 @@ LMX_API int lmx_skin_run(LmxContext* ctx);
 LMX_API int lmx_skin_read_vertices(LmxContext* ctx, uint32_t instance, float* out_xyz, uint32_t cap_verts);
 LMX_API int lmx_skin_read_palette(LmxContext* ctx, uint32_t instance, LmxMatrix* out, uint32_t cap_bones);
 LMX_API int lmx_skin_read_pose(LmxContext* ctx, uint32_t instance, float* out_pos, float* out_rot, uint32_t cap_bones);
+/* Also emit the dual-quaternion palette of the reference's own GPU skinning path (PipelineImpl::computeSkeletonDualQuats,
+ * renderer/pipeline.cpp:2680-2745): per bone a DualQuat {r.xyzw, d.xyzw} (core/math.h:257-260, 32 B) of pose * inverse bind. */
+LMX_API int lmx_skin_enable_dual_quats(LmxContext* ctx, int enable);
+LMX_API int lmx_skin_read_dual_quats(LmxContext* ctx, uint32_t instance, float* out /* 8 floats per bone */, uint32_t cap_bones);
 
 /* ---- host mirror of core/geometry.cpp frustum construction (per view, not per entity) ----------------------- */
 /* Viewport::getFrustum() (geometry.cpp:793-818). */

@@ -67,6 +67,10 @@ SYMBOLS = {
     "lmx_cull_bind_output": (_ci, [_vp, _u32, _vp, _sz, _vp]),
     "lmx_cull_device_result": (_ci, [_vp, _u32, _u32, C.POINTER(_vp), C.POINTER(_vp), _vp, C.POINTER(_u32)]),
     "lmx_world_build": (_ci, [_vp, _u32, _vp, _vp]),
+    "lmx_world_set_parent": (_ci, [_vp, _i32, _i32]),
+    "lmx_world_read_local_transforms": (_ci, [_vp, _vp, _u32]),
+    "lmx_transform_compose": (_ci, [_vp, _vp, _vp]),
+    "lmx_transform_compute_local": (_ci, [_vp, _vp, _vp]),
     "lmx_world_set_transforms": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_world_set_transforms_device": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_world_bind_culling": (_ci, [_vp, _u32, _vp, _vp]),
@@ -81,6 +85,8 @@ SYMBOLS = {
     "lmx_skin_run": (_ci, [_vp]),
     "lmx_skin_read_vertices": (_ci, [_vp, _u32, _vp, _u32]),
     "lmx_skin_read_palette": (_ci, [_vp, _u32, _vp, _u32]),
+    "lmx_skin_enable_dual_quats": (_ci, [_vp, _ci]),
+    "lmx_skin_read_dual_quats": (_ci, [_vp, _u32, _vp, _u32]),
     "lmx_skin_read_pose": (_ci, [_vp, _u32, _vp, _vp, _u32]),
     "lmx_viewport_frustum": (_ci, [_vp, _vp]),
     "lmx_frustum_perspective": (_ci, [_vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
@@ -200,6 +206,26 @@ def frustum_ortho(pos, direction, up, width, height, near, far) -> np.ndarray:
     rc = load_library().lmx_frustum_ortho(_ptr(_f64x3(pos)), _ptr(_f32x3(direction)), _ptr(_f32x3(up)), width, height, near, far, _ptr(out))
     if rc:
         raise LumixError(rc, "lmx_frustum_ortho")
+    return out
+
+
+def transform_compose(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Transform::compose (core/math.cpp:801-807), element-wise over two TRANSFORM arrays."""
+    lib = load_library()
+    a, b = np.ascontiguousarray(a, TRANSFORM), np.ascontiguousarray(b, TRANSFORM)
+    out = np.zeros(len(a), TRANSFORM)
+    for i in range(len(a)):
+        lib.lmx_transform_compose(_ptr(a[i : i + 1]), _ptr(b[i : i + 1]), _ptr(out[i : i + 1]))
+    return out
+
+
+def transform_compute_local(parent: np.ndarray, child: np.ndarray) -> np.ndarray:
+    """Transform::computeLocal (core/math.cpp:809-816)."""
+    lib = load_library()
+    parent, child = np.ascontiguousarray(parent, TRANSFORM), np.ascontiguousarray(child, TRANSFORM)
+    out = np.zeros(len(parent), TRANSFORM)
+    for i in range(len(parent)):
+        lib.lmx_transform_compute_local(_ptr(parent[i : i + 1]), _ptr(child[i : i + 1]), _ptr(out[i : i + 1]))
     return out
 
 
@@ -344,6 +370,15 @@ class World:
         model_radius = np.ascontiguousarray(model_radius, np.float32)
         self.ctx.check(self.lib.lmx_world_bind_culling(self.ctx.h, len(entity), _ptr(entity), _ptr(model_radius)))
 
+    def setParent(self, new_parent: int, child: int):
+        """World::setParent (world.cpp:619-701); new_parent < 0 detaches."""
+        self.ctx.check(self.lib.lmx_world_set_parent(self.ctx.h, int(new_parent), int(child)))
+
+    def getLocalTransforms(self) -> np.ndarray:
+        out = np.zeros(self.n, TRANSFORM)
+        self.ctx.check(self.lib.lmx_world_read_local_transforms(self.ctx.h, _ptr(out), self.n))
+        return out
+
     def propagate(self):
         self.ctx.check(self.lib.lmx_world_propagate(self.ctx.h))
 
@@ -413,6 +448,15 @@ class Skinning:
         n = self._models[int(self._inst_model[instance])]
         out = np.zeros(n, MATRIX)
         self.ctx.check(self.lib.lmx_skin_read_palette(self.ctx.h, instance, _ptr(out), n))
+        return out
+
+    def enableDualQuats(self, on: bool = True):
+        self.ctx.check(self.lib.lmx_skin_enable_dual_quats(self.ctx.h, int(on)))
+
+    def readDualQuats(self, instance: int) -> np.ndarray:
+        n = self._models[int(self._inst_model[instance])]
+        out = np.zeros((n, 8), np.float32)
+        self.ctx.check(self.lib.lmx_skin_read_dual_quats(self.ctx.h, instance, _ptr(out), n))
         return out
 
     def readPose(self, instance: int):

@@ -175,8 +175,9 @@ int lmx_skin_run(LmxContext* ctx) {
 	const uint32_t n = (uint32_t)sk.inst.size();
 	{
 		ProfScope ps(ctx, LMX_K_POSE_PALETTE);
+		if (sk.want_dual_quats) LMX_HIP(ctx, sk.d_dual_quats.reserve(std::max<size_t>(sk.bones_total * 2, 1)));
 		LMX_HIP(ctx, launch_pose_palette(ctx->stream, sk.d_inst.p, n, sk.d_pose_pos.p, sk.d_pose_rot.p, sk.d_parents.p, sk.d_depth.p, sk.d_inv_pos.p,
-			sk.d_inv_rot.p, sk.d_palette.p));
+			sk.d_inv_rot.p, sk.d_palette.p, sk.want_dual_quats ? sk.d_dual_quats.p : nullptr));
 	}
 	{
 		ProfScope ps(ctx, LMX_K_SKIN_VERTICES);
@@ -206,6 +207,24 @@ int lmx_skin_read_palette(LmxContext* ctx, uint32_t instance, LmxMatrix* out, ui
 	const SkinInstance& in = sk.inst[instance];
 	if (cap_bones < in.n_bones) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u bones", in.n_bones);
 	LMX_HIP(ctx, hipMemcpyAsync(out, sk.d_palette.p + (size_t)in.bone_offset * 4, (size_t)in.n_bones * sizeof(LmxMatrix), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+int lmx_skin_enable_dual_quats(LmxContext* ctx, int enable) {
+	LMX_CHECK_CTX(ctx);
+	ctx->skin.want_dual_quats = enable != 0;
+	return LMX_OK;
+}
+
+int lmx_skin_read_dual_quats(LmxContext* ctx, uint32_t instance, float* out, uint32_t cap_bones) {
+	LMX_CHECK_CTX(ctx);
+	SkinState& sk = ctx->skin;
+	if (instance >= sk.inst.size() || !out) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad instance/out");
+	if (!sk.want_dual_quats || !sk.d_dual_quats.p) return fail(ctx, LMX_ERR_NOT_BUILT, "dual-quaternion palette not enabled before lmx_skin_run");
+	const SkinInstance& in = sk.inst[instance];
+	if (cap_bones < in.n_bones) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u bones", in.n_bones);
+	LMX_HIP(ctx, hipMemcpyAsync(out, sk.d_dual_quats.p + (size_t)in.bone_offset * 2, (size_t)in.n_bones * 8 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return LMX_OK;
 }

@@ -7,9 +7,13 @@ using namespace lmx;
 
 extern "C" {
 
-int lmx_world_build(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxTransform* transforms) {
-	LMX_CHECK_CTX(ctx);
-	if (n && (!parent || !transforms)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
+} // extern "C"
+
+namespace {
+
+// (Re)build the slot order for `parent` and upload: transforms[e] = world transform for roots, Hierarchy::local_transform for
+// children; world_all (optional) additionally seeds the world values of every entity (re-parenting keeps them).
+int world_rebuild(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxTransform* transforms, const LmxTransform* world_all) {
 	WorldState& w = ctx->world;
 	w.built = false;
 	// children lists (CSR by parent), then BFS from the roots: slot order = (level, parent slot)
@@ -25,23 +29,26 @@ int lmx_world_build(LmxContext* ctx, uint32_t n, const int32_t* parent, const Lm
 		for (uint32_t e = 0; e < n; ++e)
 			if (parent[e] >= 0) child_list[cursor[parent[e]]++] = e;
 	}
-	w.entity_of_slot.clear();
-	w.entity_of_slot.reserve(n);
-	w.level_start.clear();
-	w.level_start.push_back(0);
+	std::vector<int32_t> entity_of_slot;
+	std::vector<uint32_t> level_start;
+	entity_of_slot.reserve(n);
+	level_start.push_back(0);
 	for (uint32_t e = 0; e < n; ++e)
-		if (parent[e] < 0) w.entity_of_slot.push_back((int32_t)e);
+		if (parent[e] < 0) entity_of_slot.push_back((int32_t)e);
 	size_t level_begin = 0;
-	while (level_begin < w.entity_of_slot.size()) {
-		const size_t level_end = w.entity_of_slot.size();
-		w.level_start.push_back((uint32_t)level_end);
+	while (level_begin < entity_of_slot.size()) {
+		const size_t level_end = entity_of_slot.size();
+		level_start.push_back((uint32_t)level_end);
 		for (size_t s = level_begin; s < level_end; ++s) {
-			const uint32_t e = (uint32_t)w.entity_of_slot[s];
-			for (uint32_t k = child_start[e]; k < child_start[e + 1]; ++k) w.entity_of_slot.push_back((int32_t)child_list[k]);
+			const uint32_t e = (uint32_t)entity_of_slot[s];
+			for (uint32_t k = child_start[e]; k < child_start[e + 1]; ++k) entity_of_slot.push_back((int32_t)child_list[k]);
 		}
 		level_begin = level_end;
 	}
-	if (w.entity_of_slot.size() != n) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "hierarchy contains a cycle (%zu of %u entities reachable)", w.entity_of_slot.size(), n);
+	if (entity_of_slot.size() != n) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "hierarchy contains a cycle (%zu of %u entities reachable)", entity_of_slot.size(), n);
+	w.entity_of_slot.swap(entity_of_slot);
+	w.level_start.swap(level_start);
+	w.parent.assign(parent, parent + n);
 	w.slot_of_entity.assign(n, -1);
 	for (uint32_t s = 0; s < n; ++s) w.slot_of_entity[w.entity_of_slot[s]] = (int32_t)s;
 	w.parent_slot.assign(n, -1);
@@ -62,19 +69,113 @@ int lmx_world_build(LmxContext* ctx, uint32_t n, const int32_t* parent, const Lm
 		LMX_HIP(ctx, hipMemcpy(w.d_parent_slot.p, w.parent_slot.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(w.d_slot_of_entity.p, w.slot_of_entity.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(w.d_entity_of_slot.p, w.entity_of_slot.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
-		// initial values: every entity's transform is staged through the scatter kernel (roots -> world, children -> local)
+		// every entity's transform is staged through the scatter kernel (roots -> world, children -> local)
 		std::vector<int32_t> all(n);
 		for (uint32_t e = 0; e < n; ++e) all[e] = (int32_t)e;
 		LMX_HIP(ctx, w.d_stage_entity.reserve(n));
 		LMX_HIP(ctx, w.d_stage_tr.reserve(n));
 		LMX_HIP(ctx, hipMemcpy(w.d_stage_entity.p, all.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+		if (world_all) {
+			LMX_HIP(ctx, hipMemcpy(w.d_stage_tr.p, world_all, n * sizeof(LmxTransform), hipMemcpyHostToDevice));
+			LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, w.d_stage_entity.p, w.d_stage_tr.p, n, true));
+			LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		}
 		LMX_HIP(ctx, hipMemcpy(w.d_stage_tr.p, transforms, n * sizeof(LmxTransform), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, w.d_stage_entity.p, w.d_stage_tr.p, n));
 	}
-	w.bound_entity.clear();
-	w.bound_radius.clear();
 	w.bound_generation = ~0ull;
 	w.built = true;
+	return LMX_OK;
+}
+
+// AoS Transform[n] by entity of either the world values or the stored locals
+int world_download(LmxContext* ctx, bool locals, LmxTransform* out) {
+	WorldState& w = ctx->world;
+	if (!w.n) return LMX_OK;
+	WorldDevice dev = w.dev();
+	if (locals) {
+		dev.wpx = dev.lpx; dev.wpy = dev.lpy; dev.wpz = dev.lpz; dev.wrot = dev.lrot; dev.wsx = dev.lsx; dev.wsy = dev.lsy; dev.wsz = dev.lsz;
+	}
+	LMX_HIP(ctx, w.d_export.reserve(w.n));
+	LMX_HIP(ctx, launch_xform_export(ctx->stream, dev, w.d_entity_of_slot.p, w.n, w.d_export.p));
+	LMX_HIP(ctx, hipMemcpyAsync(out, w.d_export.p, (size_t)w.n * sizeof(LmxTransform), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+Xform load_xform(const LmxTransform& t) {
+	Xform x;
+	x.pos = DV3{t.pos[0], t.pos[1], t.pos[2]};
+	x.rot = Q4{t.rot[0], t.rot[1], t.rot[2], t.rot[3]};
+	x.scale = V3{t.scale[0], t.scale[1], t.scale[2]};
+	return x;
+}
+
+void store_xform(const Xform& x, LmxTransform* t) {
+	memset(t, 0, sizeof(*t));
+	t->pos[0] = x.pos.x; t->pos[1] = x.pos.y; t->pos[2] = x.pos.z;
+	t->rot[0] = x.rot.x; t->rot[1] = x.rot.y; t->rot[2] = x.rot.z; t->rot[3] = x.rot.w;
+	t->scale[0] = x.scale.x; t->scale[1] = x.scale.y; t->scale[2] = x.scale.z;
+}
+
+} // namespace
+
+extern "C" {
+
+int lmx_world_build(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxTransform* transforms) {
+	LMX_CHECK_CTX(ctx);
+	if (n && (!parent || !transforms)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
+	WorldState& w = ctx->world;
+	w.bound_entity.clear();
+	w.bound_radius.clear();
+	return world_rebuild(ctx, n, parent, transforms, nullptr);
+}
+
+// World::setParent (world.cpp:619-701): the child keeps its world transform, its local becomes
+// Transform::computeLocal(parent world, child world) (math.cpp:809-816); new_parent < 0 detaches it. An editing
+// operation, not a per-frame one: the slot order is rebuilt on the host.
+int lmx_world_set_parent(LmxContext* ctx, int32_t new_parent, int32_t child) {
+	LMX_CHECK_CTX(ctx);
+	WorldState& w = ctx->world;
+	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
+	if (child < 0 || (uint32_t)child >= w.n || new_parent >= (int32_t)w.n) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity out of range");
+	for (int32_t a = new_parent; a >= 0; a = w.parent[a]) { // "Hierarchy can not contain a cycle." (world.cpp:621-626)
+		if (a == child) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d is an ancestor of %d: hierarchy can not contain a cycle", child, new_parent);
+	}
+	std::vector<LmxTransform> world(w.n), tr(w.n);
+	if (int rc = world_download(ctx, false, world.data())) return rc;
+	if (int rc = world_download(ctx, true, tr.data())) return rc;
+	std::vector<int32_t> parent = w.parent;
+	parent[child] = new_parent < 0 ? -1 : new_parent;
+	for (uint32_t e = 0; e < w.n; ++e)
+		if (parent[e] < 0) tr[e] = world[e];
+	if (new_parent >= 0) store_xform(compute_local(load_xform(world[new_parent]), load_xform(world[child])), &tr[child]);
+	return world_rebuild(ctx, w.n, parent.data(), tr.data(), world.data());
+}
+
+int lmx_world_read_local_transforms(LmxContext* ctx, LmxTransform* out, uint32_t n) { // World::getLocalTransform, world.cpp:756-766
+	LMX_CHECK_CTX(ctx);
+	WorldState& w = ctx->world;
+	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
+	if (n < w.n || !out) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u transforms", w.n);
+	std::vector<LmxTransform> world(w.n);
+	if (int rc = world_download(ctx, true, out)) return rc;
+	if (int rc = world_download(ctx, false, world.data())) return rc;
+	for (uint32_t e = 0; e < w.n; ++e)
+		if (w.parent[e] < 0) out[e] = world[e]; // entities without a parent: their transform (world.cpp:759)
+	return LMX_OK;
+}
+
+// Transform::compose / Transform::computeLocal (math.cpp:801-816) on the host, for adapters that edit hierarchies
+int lmx_transform_compose(const LmxTransform* a, const LmxTransform* b, LmxTransform* out) {
+	if (!a || !b || !out) return LMX_ERR_INVALID_ARGUMENT;
+	store_xform(compose(load_xform(*a), load_xform(*b)), out);
+	return LMX_OK;
+}
+
+int lmx_transform_compute_local(const LmxTransform* parent, const LmxTransform* child, LmxTransform* out) {
+	if (!parent || !child || !out) return LMX_ERR_INVALID_ARGUMENT;
+	store_xform(compute_local(load_xform(*parent), load_xform(*child)), out);
 	return LMX_OK;
 }
 

@@ -117,6 +117,7 @@ struct CullState {
 struct WorldState {
 	uint32_t n = 0;
 	bool built = false;
+	std::vector<int32_t> parent; // by entity, -1 for roots
 	std::vector<int32_t> slot_of_entity, entity_of_slot, parent_slot;
 	std::vector<uint32_t> level_start; // size levels + 1
 	DevBuf<double> pos[6];             // lpx lpy lpz wpx wpy wpz
@@ -173,6 +174,8 @@ struct SkinState {
 	uint32_t max_verts = 0;
 	bool poses_uploaded = false;
 	bool exact = false;
+	bool want_dual_quats = false;
+	DevBuf<float4> d_dual_quats;
 };
 
 

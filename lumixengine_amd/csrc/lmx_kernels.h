@@ -87,8 +87,9 @@ hipError_t launch_xform_level(hipStream_t s, const WorldDevice& w, uint32_t firs
 // out[entity_of_slot[s]] = AoS Transform (56 B) for s in [0, n)
 hipError_t launch_xform_export(hipStream_t s, const WorldDevice& w, const int32_t* entity_of_slot, uint32_t n, void* out_transforms);
 // stage transforms (AoS LmxTransform, device memory) into the SoA arrays: roots -> world, children -> local
+// (force_world: every entity's value goes to the world arrays)
 hipError_t launch_xform_scatter(hipStream_t s, const WorldDevice& w, const int32_t* slot_of_entity, const int32_t* entity,
-	const void* transforms, uint32_t n);
+	const void* transforms, uint32_t n, bool force_world = false);
 // culling refresh for bound entities (RenderModuleImpl::onModelInstanceMoved, render_module.cpp:1544-1554): the dynamic
 // set's position / radius of bound entity i become (world.pos, model_radius[i] * maximum(scale.x, scale.y, scale.z))
 hipError_t launch_sphere_refresh(hipStream_t s, const WorldDevice& w, const uint32_t* bound_slot, const uint32_t* bound_dyn,
@@ -107,7 +108,7 @@ struct SkinInstance {
 };
 // Pose::computeAbsolute + computeSkinMatrices per instance (one wave per instance)
 hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, float* pose_pos, float4* pose_rot,
-	const int16_t* parents, const uint8_t* depth, const float* inv_pos, const float4* inv_rot, float4* palette);
+	const int16_t* parents, const uint8_t* depth, const float* inv_pos, const float4* inv_rot, float4* palette, float4* dual_quats /* optional */);
 // evaluateSkin over every vertex of every instance
 hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, uint32_t max_verts, const float* verts,
 	const float4* weights, const int16_t* indices, const float4* palette, float* out, bool exact);

@@ -205,6 +205,21 @@ LMX_HD Mat4 skin_matrix(V3 pose_pos, Q4 pose_rot, V3 inv_pos, Q4 inv_rot) {
 	return m;
 }
 
+// (LocalRigidTransform{pose_pos, pose_rot} * inv_bind).toDualQuat(): the palette entry the reference's GPU skinning path
+// uploads (PipelineImpl::computeSkeletonDualQuats, renderer/pipeline.cpp:2680-2745; toDualQuat math.cpp:843-853)
+struct DualQ { Q4 r; Q4 d; };
+LMX_HD DualQ skin_dual_quat(V3 pose_pos, Q4 pose_rot, V3 inv_pos, Q4 inv_rot) {
+	const V3 p = add(rotate(pose_rot, inv_pos), pose_pos);
+	const Q4 q = qmul(pose_rot, inv_rot);
+	DualQ res;
+	res.r = q;
+	res.d = Q4{0.5f * (p.x * q.w + p.y * q.z - p.z * q.y),
+		0.5f * (-p.x * q.z + p.y * q.w + p.z * q.x),
+		0.5f * (p.x * q.y - p.y * q.x + p.z * q.w),
+		-0.5f * (p.x * q.x + p.y * q.y + p.z * q.z)};
+	return res;
+}
+
 // invert(LocalRigidTransform), model.cpp:24-30 (load time)
 LMX_HD void invert_rigid(V3 pos, Q4 rot, V3* out_pos, Q4* out_rot) {
 	*out_rot = conjugated(rot);

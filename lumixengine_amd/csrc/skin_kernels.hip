@@ -30,7 +30,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // 4 waves per block, one instance per wave
 __global__ __launch_bounds__(256) void k_pose_palette(const SkinInstance* __restrict__ inst, uint32_t n_inst, float* __restrict__ pose_pos,
 	float4* __restrict__ pose_rot, const int16_t* __restrict__ parents, const uint8_t* __restrict__ depth,
-	const float* __restrict__ inv_pos, const float4* __restrict__ inv_rot, float4* __restrict__ palette) {
+	const float* __restrict__ inv_pos, const float4* __restrict__ inv_rot, float4* __restrict__ palette, float4* __restrict__ dual_quats) {
 	__shared__ float s_pos[4][SKIN_MAX_BONES * 3];
 	__shared__ float4 s_rot[4][SKIN_MAX_BONES];
 	const uint32_t wave = threadIdx.x >> 6;
@@ -82,7 +82,14 @@ __global__ __launch_bounds__(256) void k_pose_palette(const SkinInstance* __rest
 		const float4 r4 = rot[b];
 		const float4 ir = irot[b];
 		const V3 p = V3{pos[3 * b], pos[3 * b + 1], pos[3 * b + 2]};
-		const Mat4 m = skin_matrix(p, Q4{r4.x, r4.y, r4.z, r4.w}, V3{ipos[3 * b], ipos[3 * b + 1], ipos[3 * b + 2]}, Q4{ir.x, ir.y, ir.z, ir.w});
+		const V3 ip = V3{ipos[3 * b], ipos[3 * b + 1], ipos[3 * b + 2]};
+		const Mat4 m = skin_matrix(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, Q4{ir.x, ir.y, ir.z, ir.w});
+		if (dual_quats != nullptr) { // the palette format of the reference's own GPU skinning path (32 B per bone)
+			const DualQ dq = skin_dual_quat(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, Q4{ir.x, ir.y, ir.z, ir.w});
+			float4* o = dual_quats + (size_t)(in.bone_offset + b) * 2;
+			o[0] = make_float4(dq.r.x, dq.r.y, dq.r.z, dq.r.w);
+			o[1] = make_float4(dq.d.x, dq.d.y, dq.d.z, dq.d.w);
+		}
 		float4* out = palette + (size_t)(in.bone_offset + b) * 4;
 		out[0] = make_float4(m.c[0][0], m.c[0][1], m.c[0][2], m.c[0][3]);
 		out[1] = make_float4(m.c[1][0], m.c[1][1], m.c[1][2], m.c[1][3]);
@@ -216,10 +223,10 @@ __global__ __launch_bounds__(SKIN_THREADS, 6) void k_skin_vertices(const SkinIns
 } // namespace
 
 hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, float* pose_pos, float4* pose_rot,
-	const int16_t* parents, const uint8_t* depth, const float* inv_pos, const float4* inv_rot, float4* palette) {
+	const int16_t* parents, const uint8_t* depth, const float* inv_pos, const float4* inv_rot, float4* palette, float4* dual_quats) {
 	if (!n_inst) return hipSuccess;
 	hipLaunchKernelGGL(k_pose_palette, dim3((n_inst + 3u) / 4u), dim3(256), 0, s, inst, n_inst, pose_pos, pose_rot, parents, depth,
-		inv_pos, inv_rot, palette);
+		inv_pos, inv_rot, palette, dual_quats);
 	return hipGetLastError();
 }
 

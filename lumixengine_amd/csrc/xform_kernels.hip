@@ -56,12 +56,12 @@ __global__ __launch_bounds__(256) void k_xform_export(WorldDevice w, const int32
 // Stage new transforms: roots get their world transform (World::setTransform, world.cpp:337-342), children their
 // local transform (World::setLocalTransform, world.cpp:741-753). slot_of_entity maps entity -> slot.
 __global__ __launch_bounds__(256) void k_xform_scatter(WorldDevice w, const int32_t* __restrict__ slot_of_entity,
-	const int32_t* __restrict__ entity, const TransformAoS* __restrict__ tr, uint32_t n) {
+	const int32_t* __restrict__ entity, const TransformAoS* __restrict__ tr, uint32_t n, int force_world) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) return;
 	const int32_t s = slot_of_entity[entity[i]];
 	const TransformAoS t = tr[i];
-	if (w.parent_slot[s] < 0) {
+	if (force_world || w.parent_slot[s] < 0) {
 		w.wpx[s] = t.pos[0]; w.wpy[s] = t.pos[1]; w.wpz[s] = t.pos[2];
 		w.wrot[s] = make_float4(t.rot[0], t.rot[1], t.rot[2], t.rot[3]);
 		w.wsx[s] = t.scale[0]; w.wsy[s] = t.scale[1]; w.wsz[s] = t.scale[2];
@@ -85,7 +85,10 @@ __global__ __launch_bounds__(256) void k_sphere_refresh(WorldDevice w, const uin
 	dyn_px[d] = w.wpx[s];
 	dyn_py[d] = w.wpy[s];
 	dyn_pz[d] = w.wpz[s];
-	dyn_radius[d] = model_radius[i] * maximum3(w.wsx[s], w.wsy[s], w.wsz[s]);
+	// model_radius < 0 marks a position-only binding: onDecalMoved / onPointLightMoved call CullingSystem::setPosition and
+	// keep the radius (render_module.cpp:1568-1592)
+	const float mr = model_radius[i];
+	if (!(mr < 0.f)) dyn_radius[d] = mr * maximum3(w.wsx[s], w.wsy[s], w.wsz[s]); // (a NaN model radius is not a marker)
 }
 
 } // namespace
@@ -103,10 +106,10 @@ hipError_t launch_xform_export(hipStream_t s, const WorldDevice& w, const int32_
 }
 
 hipError_t launch_xform_scatter(hipStream_t s, const WorldDevice& w, const int32_t* slot_of_entity, const int32_t* entity,
-	const void* transforms, uint32_t n) {
+	const void* transforms, uint32_t n, bool force_world) {
 	if (!n) return hipSuccess;
 	hipLaunchKernelGGL(k_xform_scatter, dim3((n + 255u) / 256u), dim3(256), 0, s, w, slot_of_entity, entity,
-		(const TransformAoS*)transforms, n);
+		(const TransformAoS*)transforms, n, force_world ? 1 : 0);
 	return hipGetLastError();
 }
 

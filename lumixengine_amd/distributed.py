@@ -62,6 +62,55 @@ def allgather_visible(ids: torch.Tensor, counts: torch.Tensor, group=None) -> Li
     return [[recv[r, f, : int(host_counts[r, f])] for r in range(world)] for f in range(F)]
 
 
+class VisibleExchange:
+    """Steady-state exchange of visible-id lists with ONE collective per frame and no host synchronisation.
+
+    Each rank's cull writes `[counts (n_counts int32) | ids]` into one contiguous device buffer (lmx_cull_bind_output can
+    point the kernel at it), and a frame sends the first `n_counts + cap` words of it with a single all-gather. `cap` is a
+    capacity chosen from earlier frames (visible sets change slowly from frame to frame), so the payload size never
+    depends on this frame's counts and the host never waits for them; `overflowed()` reports afterwards whether some
+    rank had more than `cap` visible ids, in which case the caller re-gathers that frame with `allgather_visible`.
+    Two buffers are used alternately and the collective runs asynchronously (`async_op=True`, RCCL's own stream), so the
+    next frame's cull overlaps this frame's exchange: throughput is max(cull, exchange) instead of their sum.
+    """
+
+    def __init__(self, n_counts: int, row: int, cap: int, device, group=None, dtype=torch.int32):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.n_counts, self.row, self.cap = n_counts, row, min(cap, row)
+        self.send = [torch.zeros(n_counts + row, dtype=dtype, device=device) for _ in range(2)]
+        self.recv = [torch.empty(self.world * (n_counts + self.cap), dtype=dtype, device=device) for _ in range(2)]
+        self.work = [None, None]
+        self.k = 0
+
+    def buffer(self):
+        """(index, send buffer) of the frame about to be culled; waits (on the stream, not the host) for the exchange that
+        last read this buffer."""
+        i = self.k & 1
+        if self.work[i] is not None:
+            self.work[i].wait()
+            self.work[i] = None
+        return i, self.send[i]
+
+    def exchange(self, i: int):
+        n = self.n_counts + self.cap
+        self.work[i] = dist.all_gather_into_tensor(self.recv[i], self.send[i][:n], group=self.group, async_op=True)
+        self.k += 1
+
+    def finish(self):
+        for i in range(2):
+            if self.work[i] is not None:
+                self.work[i].wait()
+                self.work[i] = None
+
+    def gathered(self, i: int):
+        """[world, n_counts + cap] view of the last completed exchange of buffer i (counts first, then ids)."""
+        return self.recv[i].view(self.world, self.n_counts + self.cap)
+
+    def overflowed(self, i: int, count_index: int = 0) -> bool:
+        return bool((self.gathered(i)[:, count_index] > self.cap).any().item())
+
+
 def concat_visible(gathered: Sequence[Sequence[torch.Tensor]]) -> List[torch.Tensor]:
     """Per frustum: concatenation over ranks = the global visible list (compare as a sorted set)."""
     return [torch.cat(list(per_rank)) if len(per_rank) else torch.empty(0, dtype=torch.int32) for per_rank in gathered]

@@ -1080,6 +1080,28 @@ ORC_API void orc_skin_matrices(const float* pose_pos, const float* pose_rot, con
 	for_each_job(n_instances, n_threads, palette_one, &j);
 }
 
+/* PipelineImpl::computeSkeletonDualQuats (renderer/pipeline.cpp:2680-2745): dq[i] = (pose[i] * inv_bind[i]).toDualQuat(),
+ * toDualQuat core/math.cpp:843-853 (the 4-wide path, core/simd_math.h:93-104, is the same arithmetic). out: 8 floats per
+ * bone {r.xyzw, d.xyzw} = DualQuat, core/math.h:257-260. */
+ORC_API void orc_dual_quats(const float* pose_pos, const float* pose_rot, const LmxLocalRigidTransform* inv_bind, float* out,
+	uint32_t count, uint32_t n_instances) {
+	for (uint32_t inst = 0; inst < n_instances; ++inst) {
+		const v3* pos = (const v3*)(pose_pos + (size_t)inst * count * 3);
+		const quat* rot = (const quat*)(pose_rot + (size_t)inst * count * 4);
+		float* o = out + (size_t)inst * count * 8;
+		for (uint32_t i = 0; i < count; ++i) {
+			const rigid inv = rigid_load(&inv_bind[i]);
+			const v3 p = v3_add(q_rotate(rot[i], inv.pos), pos[i]); /* LocalRigidTransform::operator*, math.cpp:859-861 */
+			const quat r = q_mul(rot[i], inv.rot);
+			o[8 * i + 0] = r.x; o[8 * i + 1] = r.y; o[8 * i + 2] = r.z; o[8 * i + 3] = r.w;
+			o[8 * i + 4] = 0.5f * (p.x * r.w + p.y * r.z - p.z * r.y);
+			o[8 * i + 5] = 0.5f * (-p.x * r.z + p.y * r.w + p.z * r.x);
+			o[8 * i + 6] = 0.5f * (p.x * r.y - p.y * r.x + p.z * r.w);
+			o[8 * i + 7] = -0.5f * (p.x * r.x + p.y * r.y + p.z * r.z);
+		}
+	}
+}
+
 typedef struct { const float* verts; const LmxSkin* skin; const LmxMatrix* palettes; float* out; uint32_t n_verts, n_bones; } skin_job;
 
 static void skin_one(void* ctx, uint32_t inst) {                                             /* evaluateSkin, model.cpp:103-109 */

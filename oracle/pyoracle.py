@@ -118,6 +118,7 @@ class Oracle:
         self.f_pose_compute_absolute = self._fn("pose_compute_absolute", None, [vp, vp, vp, i32, u32, u32, ci])
         self.f_invert_bind = self._fn("invert_bind", None, [vp, vp, u32])
         self.f_skin_matrices = self._fn("skin_matrices", None, [vp, vp, vp, vp, u32, u32, ci])
+        self.f_dual_quats = self._fn("dual_quats", None, [vp, vp, vp, vp, u32, u32])
         self.f_evaluate_skin = self._fn("evaluate_skin", None, [vp, vp, vp, vp, u32, u32, u32, ci])
         self.f_rand_fill = self._fn("rand_fill", None, [u32, u32, u32, vp])
         self.f_describe = self._fn("describe", C.c_char_p, [])
@@ -192,6 +193,16 @@ class Oracle:
         n_inst, count = pos.shape[0], pos.shape[1]
         out = np.zeros((n_inst, count), MATRIX)
         self.f_skin_matrices(_ptr(pos), _ptr(rot), _ptr(inv), _ptr(out), count, n_inst, n_threads)
+        return out
+
+    def dual_quats(self, pose_pos, pose_rot, inv_bind) -> np.ndarray:
+        """[I, B, 8] float32: DualQuat {r.xyzw, d.xyzw} palette of computeSkeletonDualQuats (pipeline.cpp:2680-2745)."""
+        pos = np.ascontiguousarray(pose_pos, dtype=np.float32)
+        rot = np.ascontiguousarray(pose_rot, dtype=np.float32)
+        inv = np.ascontiguousarray(inv_bind, dtype=LOCAL_RIGID)
+        n_inst, count = pos.shape[0], pos.shape[1]
+        out = np.zeros((n_inst, count, 8), np.float32)
+        self.f_dual_quats(_ptr(pos), _ptr(rot), _ptr(inv), _ptr(out), count, n_inst)
         return out
 
     def evaluate_skin(self, verts, skin, palettes, n_threads=1) -> np.ndarray:

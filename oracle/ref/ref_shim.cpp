@@ -705,6 +705,23 @@ void ref_skin_matrices(const float* pose_pos, const float* pose_rot, const LmxLo
 	});
 }
 
+// computeSkeletonDualQuats scalar tail, pipeline.cpp:2739-2743: (tmp * inverse_bind).toDualQuat() with the reference's symbols
+void ref_dual_quats(const float* pose_pos, const float* pose_rot, const LmxLocalRigidTransform* inv_bind, float* out, uint32_t count,
+	uint32_t n_instances) {
+	static_assert(sizeof(DualQuat) == 32, "DualQuat layout");
+	for (uint32_t inst = 0; inst < n_instances; ++inst) {
+		const Vec3* pos = (const Vec3*)(pose_pos + (size_t)inst * count * 3);
+		const Quat* rot = (const Quat*)(pose_rot + (size_t)inst * count * 4);
+		DualQuat* o = (DualQuat*)(out + (size_t)inst * count * 8);
+		for (u32 i = 0; i < count; ++i) {
+			LocalRigidTransform tmp = {pos[i], rot[i]};
+			LocalRigidTransform inv;
+			memcpy((void*)&inv, &inv_bind[i], sizeof(inv));
+			o[i] = (tmp * inv).toDualQuat();
+		}
+	}
+}
+
 // evaluateSkin, model.cpp:103-109, for n_instances palettes over one mesh
 void ref_evaluate_skin(const float* verts, const LmxSkin* skin, const LmxMatrix* palettes, float* out, uint32_t n_verts,
 	uint32_t n_bones, uint32_t n_instances, int n_threads) {

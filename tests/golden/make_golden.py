@@ -82,9 +82,10 @@ def main():
     apos, arot = ref.pose_compute_absolute(pos, rot, sk["parents"], sk["first_nonroot"])
     pal = ref.skin_matrices(apos, arot, inv)
     out = ref.evaluate_skin(verts, skin, pal)
+    dq = ref.dual_quats(apos, arot, inv)
     np.savez_compressed(
         os.path.join(OUT, "skin.npz"), parents=sk["parents"], bind=sk["bind"], first_nonroot=np.array([sk["first_nonroot"]]), rel_pos=pos, rel_rot=rot,
-        verts=verts, skin=skin, inv_bind=inv, abs_pos=apos, abs_rot=arot, palette=pal, skinned=out,
+        verts=verts, skin=skin, inv_bind=inv, abs_pos=apos, abs_rot=arot, palette=pal, skinned=out, dual_quats=dq,
     )
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -43,6 +43,28 @@ def _worker(rank, world, port, out_dir):
             counts[f] = len(v)
         gathered = D.allgather_visible(ids, counts)
         merged = D.concat_visible(gathered)
+        # steady-state form: one async all-gather of [counts | first cap ids] per frame, double-buffered
+        n_counts = len(fr)
+        cap_ids = max(int(t.numel()) for per in gathered for t in per) + 5  # the same on every rank
+        for f in range(len(fr)):
+            x = D.VisibleExchange(n_counts, cap, cap_ids, "cpu")
+            for frame in range(3):  # three frames through the two buffers
+                i, buf = x.buffer()
+                buf[:n_counts] = 0
+                buf[f] = counts[f]
+                buf[n_counts : n_counts + cap] = ids[f]
+                x.exchange(i)
+            x.finish()
+            g = x.gathered(i)
+            assert not x.overflowed(i, f)
+            one = torch.cat([g[r, n_counts : n_counts + int(g[r, f])] for r in range(world)])
+            assert torch.equal(torch.sort(one).values, torch.sort(merged[f]).values)
+            small = D.VisibleExchange(n_counts, cap, 1, "cpu")
+            j, buf = small.buffer()
+            buf[f] = counts[f]
+            small.exchange(j)
+            small.finish()
+            assert small.overflowed(j, f) == bool(int(torch.stack([t.new_tensor(t.numel()) for t in gathered[f]]).max()) > 1)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{f"f{f}": merged[f].numpy() for f in range(len(fr))}, owned=np.array([cap]))
     finally:
         dist.destroy_process_group()

@@ -82,3 +82,4 @@ def test_pose_palette_skin(oracle_port):
     pal = oracle_port.skin_matrices(apos, arot, inv)
     assert H.bits_equal(pal, g["palette"])
     assert H.bits_equal(oracle_port.evaluate_skin(g["verts"], g["skin"], pal), g["skinned"])
+    assert H.bits_equal(oracle_port.dual_quats(apos, arot, inv), g["dual_quats"])

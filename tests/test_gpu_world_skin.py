@@ -152,6 +152,7 @@ def test_skin_golden(gpu_ctx, exact):
     g = np.load(os.path.join(G, "skin.npz"))
     sk = api.Skinning(gpu_ctx)
     sk.setMode(exact)
+    sk.enableDualQuats(True)
     model = sk.addModel(g["parents"], g["bind"], int(g["first_nonroot"][0]))
     mesh = sk.addMesh(g["verts"], g["skin"])
     n_inst = g["rel_pos"].shape[0]
@@ -162,6 +163,7 @@ def test_skin_golden(gpu_ctx, exact):
         pos, rot = sk.readPose(i)
         assert H.bits_equal(pos, g["abs_pos"][i]) and H.bits_equal(rot, g["abs_rot"][i])
         assert H.bits_equal(sk.readPalette(i), g["palette"][i])
+        assert H.bits_equal(sk.readDualQuats(i), g["dual_quats"][i])  # computeSkeletonDualQuats, pipeline.cpp:2680-2745
         got, want = sk.readVertices(i), g["skinned"][i]
         assert close_1e5(got, want)
         if exact:  # LMX_SKIN_EXACT is FMA-free and bit-identical to the reference
@@ -271,3 +273,69 @@ def test_dynamic_set_matches_golden(gpu_ctx, fixture):
     finite = np.flatnonzero(np.isfinite(g["radius"]))[:5]
     for i in finite:
         assert cs.getRadius(int(ent[i])) == float(g["radius"][i])
+
+
+def test_world_set_parent_matches_oracle(gpu_ctx, oracle_port):
+    """World::setParent (world.cpp:619-701): re-parenting inside and across trees, detaching, cycle rejection; the stored
+    locals and the world transforms after the next root move must equal the reference's."""
+    h = scenes.hierarchy_fans(8, 3, 4, seed=21)
+    n = len(h["parent"])
+    ow, roots, kids = oracle_world(oracle_port, h)
+    w = api.World(gpu_ctx)
+    w.build(h["parent"], gpu_inputs(ow, h["parent"], roots))
+    rng = np.random.default_rng(6)
+    # one propagation first, so that the GPU world values of the children are the chain of stored locals (like the oracle's
+    # after its own root move)
+    first = scenes.random_transforms(rng, len(roots), 2000.0)
+    ow.set_transforms(roots, first)
+    w.setTransforms(roots, first)
+    w.propagate()
+    assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms())
+    parent = h["parent"].copy()
+    leaves = [e for e in range(n) if e not in set(parent.tolist())]
+    moves = [(int(roots[1]), int(leaves[0])), (int(leaves[3]), int(leaves[5])), (-1, int(kids[2])), (int(roots[0]), int(roots[3])), (int(kids[10]), int(leaves[7]))]
+    for new_parent, child in moves:
+        ow.set_parents(np.array([new_parent], np.int32), np.array([child], np.int32))
+        w.setParent(new_parent, child)
+        parent[child] = new_parent
+        assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms()), (new_parent, child)
+        got, want = w.getLocalTransforms(), ow.get_local_transforms()
+        has_parent = parent >= 0
+        assert H.transforms_bits_equal(got[has_parent], want[has_parent]), (new_parent, child)
+    with pytest.raises(api.LumixError):  # a node cannot become a child of its own descendant
+        w.setParent(int(leaves[0]), int(roots[1]))
+    cur_roots = np.flatnonzero(parent < 0).astype(np.int32)
+    new_root = scenes.random_transforms(rng, len(cur_roots), 3000.0)
+    ow.set_transforms(cur_roots, new_root)
+    w.setTransforms(cur_roots, new_root)
+    w.propagate()
+    assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms())
+
+
+def test_position_only_binding_keeps_radius(gpu_ctx, oracle_port):
+    """Lights / decals: onPointLightMoved / onDecalMoved call CullingSystem::setPosition (render_module.cpp:1568-1592)."""
+    n = 3000
+    rng = np.random.default_rng(12)
+    tr = scenes.random_transforms(rng, n, 1500.0)
+    radius = rng.uniform(1.0, 60.0, n).astype(np.float32)
+    types = np.full(n, 2, np.uint8)  # LOCAL_LIGHT
+    w = api.World(gpu_ctx)
+    w.build(np.full(n, -1, np.int32), tr)
+    cs = api.CullingSystem(gpu_ctx)
+    ent = np.arange(n, dtype=np.int32)
+    cs.build(ent, types, tr["pos"], radius)
+    ocs = oracle_port.culling_system()
+    ocs.add_bulk(ent, types, tr["pos"], radius)
+    w.bindCulling(ent, np.full(n, -1.0, np.float32))
+    moved = scenes.random_transforms(rng, n, 1500.0)
+    w.setTransforms(ent, moved)
+    w.propagate()
+    for e in range(n):
+        ocs.set_position(e, moved["pos"][e])
+    fr = H.frusta(api, names=["origin_identity", "origin_yaw_pitch"])
+    res = cs.cull(fr)
+    for f in range(len(fr)):
+        ids, tys, _ = ocs.cull(fr[f : f + 1])
+        got_ids, got_types = res.all_ids(f)
+        H.assert_same_visible(H.sorted_by_type(got_ids, got_types), H.sorted_by_type(ids, tys), f"frustum {f}")
+    assert cs.getRadius(17) == float(radius[17])

@@ -190,7 +190,7 @@ def test_pose_palette_skin_bit_exact(oracle_port, oracle_ref):
         apos, arot = o.pose_compute_absolute(pos, rot, sk["parents"], sk["first_nonroot"], n_threads=2)
         pal = o.skin_matrices(apos, arot, inv)
         sv = o.evaluate_skin(verts, skin, pal, n_threads=2)
-        out.append((inv, apos, arot, pal, sv))
+        out.append((inv, apos, arot, pal, sv, o.dual_quats(apos, arot, inv)))
     for x, y in zip(out[0], out[1]):
         assert H.bits_equal(np.ascontiguousarray(x), np.ascontiguousarray(y))
 
