@@ -165,6 +165,9 @@ LMX_API int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* 
 LMX_API int lmx_skin_upload_poses(LmxContext* ctx, const float* positions, const float* rotations, size_t n_bones_total);
 /* Same, from device memory (device-to-device copy on the context stream). */
 LMX_API int lmx_skin_upload_poses_device(LmxContext* ctx, const void* d_positions, const void* d_rotations, size_t n_bones_total);
+/* Zero-copy variant: lmx_skin_run reads the relative poses from this device memory every time it runs (the animation
+ * system's output buffer) and writes the absolute poses to the library's own arrays. NULL pointers end the borrowing. */
+LMX_API int lmx_skin_set_pose_source_device(LmxContext* ctx, const void* d_positions, const void* d_rotations, size_t n_bones_total);
 /* Arithmetic of the vertex blend/transform (model.cpp:103-109). LMX_SKIN_FUSED (default): products fused into the adds
  * (v_fma_f32), results within 1e-5 relative of the reference CPU path - the tolerance BASELINE's north star sets for
  * skinned positions. LMX_SKIN_EXACT: separate multiplies and adds in the reference's order, bit-identical to it.

@@ -81,6 +81,7 @@ SYMBOLS = {
     "lmx_skin_set_instances": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_skin_upload_poses": (_ci, [_vp, _vp, _vp, _sz]),
     "lmx_skin_upload_poses_device": (_ci, [_vp, _vp, _vp, _sz]),
+    "lmx_skin_set_pose_source_device": (_ci, [_vp, _vp, _vp, _sz]),
     "lmx_skin_set_mode": (_ci, [_vp, _ci]),
     "lmx_skin_run": (_ci, [_vp]),
     "lmx_skin_read_vertices": (_ci, [_vp, _u32, _vp, _u32]),
@@ -430,6 +431,10 @@ class Skinning:
 
     def uploadPosesDevice(self, d_positions: int, d_rotations: int, n_bones_total: int):
         self.ctx.check(self.lib.lmx_skin_upload_poses_device(self.ctx.h, d_positions, d_rotations, n_bones_total))
+
+    def setPoseSourceDevice(self, d_positions: Optional[int], d_rotations: Optional[int], n_bones_total: int):
+        """run() reads the relative poses straight from this device memory (no copy) every time."""
+        self.ctx.check(self.lib.lmx_skin_set_pose_source_device(self.ctx.h, d_positions, d_rotations, n_bones_total))
 
     def setMode(self, exact: bool):
         """exact=True: FMA-free blend, bit-identical to the reference; False (default): fused multiply-adds, within 1e-5."""

@@ -27,6 +27,15 @@ int lmx_skin_add_model(LmxContext* ctx, uint32_t n_bones, const int16_t* parents
 		depth[i] = ((int32_t)i >= first_nonroot) ? (uint8_t)(depth[p] + 1) : 0;
 		m.max_depth = std::max<uint32_t>(m.max_depth, depth[i]);
 	}
+	// bones that Pose::computeAbsolute touches, sorted by depth, + per-depth offsets: the level walk of k_pose_palette
+	m.lv_bones_offset = (uint32_t)sk.level_bones.size();
+	m.lv_off_offset = (uint32_t)sk.level_off.size();
+	sk.level_off.push_back(0);
+	for (uint32_t d = 1; d <= m.max_depth; ++d) {
+		for (uint32_t i = 0; i < n_bones; ++i)
+			if (depth[i] == d) sk.level_bones.push_back((uint16_t)i);
+		sk.level_off.push_back((uint16_t)(sk.level_bones.size() - m.lv_bones_offset));
+	}
 	for (uint32_t i = 0; i < n_bones; ++i) {
 		V3 ip;
 		Q4 ir;
@@ -70,14 +79,16 @@ static int skin_upload_static(LmxContext* ctx) {
 	if (sk.models_dirty) {
 		const size_t nb = sk.parents.size();
 		LMX_HIP(ctx, sk.d_parents.reserve(nb));
-		LMX_HIP(ctx, sk.d_depth.reserve(nb));
 		LMX_HIP(ctx, sk.d_inv_pos.reserve(nb * 3));
 		LMX_HIP(ctx, sk.d_inv_rot.reserve(nb));
 		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		LMX_HIP(ctx, hipMemcpy(sk.d_parents.p, sk.parents.data(), nb * sizeof(int16_t), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(sk.d_depth.p, sk.depth.data(), nb * sizeof(uint8_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(sk.d_inv_pos.p, sk.inv_pos.data(), nb * 3 * sizeof(float), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(sk.d_inv_rot.p, sk.inv_rot.data(), nb * sizeof(float4), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, sk.d_level_bones.reserve(std::max<size_t>(sk.level_bones.size(), 1)));
+		LMX_HIP(ctx, sk.d_level_off.reserve(std::max<size_t>(sk.level_off.size(), 1)));
+		if (!sk.level_bones.empty()) LMX_HIP(ctx, hipMemcpy(sk.d_level_bones.p, sk.level_bones.data(), sk.level_bones.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(sk.d_level_off.p, sk.level_off.data(), sk.level_off.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
 		sk.models_dirty = false;
 	}
 	if (sk.meshes_dirty) {
@@ -115,15 +126,28 @@ int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* model, c
 		in.n_verts = me.n_verts;
 		in.out_offset = (uint32_t)verts;
 		in.max_depth = mo.max_depth;
+		in.lv_bones_offset = mo.lv_bones_offset;
+		in.lv_off_offset = mo.lv_off_offset;
 		bones += mo.n_bones;
 		verts += me.n_verts;
 		max_verts = std::max(max_verts, me.n_verts);
+	}
+	// pose groups: runs of consecutive instances of one model, at most 16 / 8 / 4 (<= 64 / 128 / 196 bones) per group
+	sk.groups.clear();
+	for (uint32_t i = 0; i < n;) {
+		const uint32_t cap = sk.models[model[i]].n_bones <= 64 ? 16u : (sk.models[model[i]].n_bones <= 128 ? 8u : 4u);
+		uint32_t c = 1;
+		while (i + c < n && c < cap && model[i + c] == model[i]) ++c;
+		sk.groups.push_back(PoseGroup{i, c});
+		i += c;
 	}
 	sk.inst.swap(inst);
 	sk.bones_total = bones;
 	sk.verts_total = verts;
 	sk.max_verts = max_verts;
 	sk.poses_uploaded = false;
+	sk.borrowed_pos = nullptr;
+	sk.borrowed_rot = nullptr;
 	LMX_HIP(ctx, sk.d_inst.reserve(std::max<size_t>(n, 1)));
 	LMX_HIP(ctx, sk.d_pose_pos.reserve(std::max<size_t>(bones * 3, 1)));
 	LMX_HIP(ctx, sk.d_pose_rot.reserve(std::max<size_t>(bones, 1)));
@@ -131,6 +155,8 @@ int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* model, c
 	LMX_HIP(ctx, sk.d_out.reserve(std::max<size_t>(verts * 3, 1)));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (n) LMX_HIP(ctx, hipMemcpy(sk.d_inst.p, sk.inst.data(), (size_t)n * sizeof(SkinInstance), hipMemcpyHostToDevice));
+	LMX_HIP(ctx, sk.d_groups.reserve(std::max<size_t>(sk.groups.size(), 1)));
+	if (n) LMX_HIP(ctx, hipMemcpy(sk.d_groups.p, sk.groups.data(), sk.groups.size() * sizeof(PoseGroup), hipMemcpyHostToDevice));
 	return LMX_OK;
 }
 
@@ -159,6 +185,17 @@ int lmx_skin_upload_poses_device(LmxContext* ctx, const void* d_positions, const
 	return LMX_OK;
 }
 
+int lmx_skin_set_pose_source_device(LmxContext* ctx, const void* d_positions, const void* d_rotations, size_t n_bones_total) {
+	LMX_CHECK_CTX(ctx);
+	SkinState& sk = ctx->skin;
+	if ((d_positions == nullptr) != (d_rotations == nullptr)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "set both pointers or neither");
+	if (d_positions && n_bones_total != sk.bones_total) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "expected %zu bones over all instances, got %zu", sk.bones_total, n_bones_total);
+	sk.borrowed_pos = (const float*)d_positions;
+	sk.borrowed_rot = (const float4*)d_rotations;
+	sk.poses_uploaded = d_positions != nullptr;
+	return LMX_OK;
+}
+
 int lmx_skin_set_mode(LmxContext* ctx, int mode) {
 	LMX_CHECK_CTX(ctx);
 	if (mode != LMX_SKIN_FUSED && mode != LMX_SKIN_EXACT) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "unknown skin mode %d", mode);
@@ -176,16 +213,19 @@ int lmx_skin_run(LmxContext* ctx) {
 	{
 		ProfScope ps(ctx, LMX_K_POSE_PALETTE);
 		if (sk.want_dual_quats) LMX_HIP(ctx, sk.d_dual_quats.reserve(std::max<size_t>(sk.bones_total * 2, 1)));
-		LMX_HIP(ctx, launch_pose_palette(ctx->stream, sk.d_inst.p, n, sk.d_pose_pos.p, sk.d_pose_rot.p, sk.d_parents.p, sk.d_depth.p, sk.d_inv_pos.p,
-			sk.d_inv_rot.p, sk.d_palette.p, sk.want_dual_quats ? sk.d_dual_quats.p : nullptr));
+		const float* rel_pos = sk.borrowed_pos ? sk.borrowed_pos : sk.d_pose_pos.p;
+		const float4* rel_rot = sk.borrowed_rot ? sk.borrowed_rot : sk.d_pose_rot.p;
+		LMX_HIP(ctx, launch_pose_palette(ctx->stream, sk.d_inst.p, sk.d_groups.p, (uint32_t)sk.groups.size(), rel_pos, rel_rot, sk.d_pose_pos.p, sk.d_pose_rot.p,
+			sk.d_parents.p, sk.d_level_bones.p, sk.d_level_off.p, sk.d_inv_pos.p, sk.d_inv_rot.p, sk.d_palette.p, sk.want_dual_quats ? sk.d_dual_quats.p : nullptr));
 	}
 	{
 		ProfScope ps(ctx, LMX_K_SKIN_VERTICES);
 		LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, n, sk.max_verts, sk.d_verts.p, sk.d_weights.p, sk.d_indices.p, sk.d_palette.p,
 			sk.d_out.p, sk.exact));
 	}
-	// the poses are absolute now; running again needs fresh relative poses (Pose::is_absolute, pose.cpp:64)
-	sk.poses_uploaded = false;
+	// the library's poses are absolute now; running again needs fresh relative poses (Pose::is_absolute, pose.cpp:64) unless
+	// a borrowed source provides them every frame
+	sk.poses_uploaded = sk.borrowed_pos != nullptr;
 	return LMX_OK;
 }
 

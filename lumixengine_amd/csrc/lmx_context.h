@@ -142,7 +142,7 @@ struct WorldState {
 	}
 };
 
-struct SkinModel { uint32_t bone_offset, n_bones, max_depth; int32_t first_nonroot; };
+struct SkinModel { uint32_t bone_offset, n_bones, max_depth; int32_t first_nonroot; uint32_t lv_bones_offset, lv_off_offset; };
 struct SkinMesh { uint32_t vert_offset, n_verts; };
 
 struct SkinState {
@@ -151,6 +151,10 @@ struct SkinState {
 	// concatenated host copies (re-uploaded when models/meshes are added)
 	std::vector<int16_t> parents;
 	std::vector<uint8_t> depth;
+	std::vector<uint16_t> level_bones, level_off; // per model: bones sorted by depth + per-depth offsets (k_pose_palette)
+	DevBuf<uint16_t> d_level_bones, d_level_off;
+	std::vector<PoseGroup> groups;
+	DevBuf<PoseGroup> d_groups;
 	std::vector<float> inv_pos;
 	std::vector<float4> inv_rot;
 	std::vector<float> verts;
@@ -158,7 +162,6 @@ struct SkinState {
 	std::vector<int16_t> indices;
 	bool models_dirty = false, meshes_dirty = false;
 	DevBuf<int16_t> d_parents;
-	DevBuf<uint8_t> d_depth;
 	DevBuf<float> d_inv_pos;
 	DevBuf<float4> d_inv_rot;
 	DevBuf<float> d_verts;
@@ -175,6 +178,8 @@ struct SkinState {
 	bool poses_uploaded = false;
 	bool exact = false;
 	bool want_dual_quats = false;
+	const float* borrowed_pos = nullptr;  // lmx_skin_set_pose_source_device: relative poses read in place from caller memory
+	const float4* borrowed_rot = nullptr;
 	DevBuf<float4> d_dual_quats;
 };
 

@@ -105,10 +105,14 @@ struct SkinInstance {
 	uint32_t n_verts;
 	uint32_t out_offset;   // into output vertex array (in vertices)
 	uint32_t max_depth;    // deepest bone level of the model (root = 0)
+	uint32_t lv_bones_offset; // into level_bones: the model's bones >= first_nonroot sorted by depth
+	uint32_t lv_off_offset;   // into level_off: max_depth + 1 offsets (bones of depth d = [off[d-1], off[d]))
 };
-// Pose::computeAbsolute + computeSkinMatrices per instance (one wave per instance)
-hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, float* pose_pos, float4* pose_rot,
-	const int16_t* parents, const uint8_t* depth, const float* inv_pos, const float4* inv_rot, float4* palette, float4* dual_quats /* optional */);
+struct PoseGroup { uint32_t first_inst; uint32_t count; }; // consecutive instances of one model, count <= 16 / 8 / 4 by bone count
+// Pose::computeAbsolute + computeSkinMatrices (+ optional dual-quaternion palette), one wave per PoseGroup
+hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, const PoseGroup* groups, uint32_t n_groups, const float* rel_pos,
+	const float4* rel_rot, float* pose_pos, float4* pose_rot, const int16_t* parents, const uint16_t* level_bones, const uint16_t* level_off,
+	const float* inv_pos, const float4* inv_rot, float4* palette, float4* dual_quats /* optional */);
 // evaluateSkin over every vertex of every instance
 hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, uint32_t max_verts, const float* verts,
 	const float4* weights, const int16_t* indices, const float4* palette, float* out, bool exact);

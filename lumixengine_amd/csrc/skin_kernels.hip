@@ -1,11 +1,12 @@
 // skin_kernels.hip — skeletal skinning on gfx950: absolute pose, matrix palette, linear-blend vertex transform.
 //
-//   k_pose_palette   one wave per model instance. Pose::computeAbsolute (src/renderer/pose.cpp:63-134, scalar
-//                    recurrence :129-130) is a chain over the bone tree: a bone only depends on its parent's final
-//                    value, so the wave walks the tree level by level (bone depth precomputed per model) with the
-//                    pose held in LDS; every bone is computed by exactly the reference's operations, so the result
-//                    is bit-identical to the index-order loop. Then computeSkinMatrices (src/renderer/model.cpp:
-//                    132-137): palette[i] = (pose[i] * inverse_bind[i]).toMatrix(), written as 4 x float4 per bone.
+//   k_pose_palette   one wave per group of up to 16 instances of one model. Pose::computeAbsolute (src/renderer/
+//                    pose.cpp:63-134, scalar recurrence :129-130) is a chain over the bone tree: a bone only depends on
+//                    its parent's final value, so the wave walks the tree level by level with the group's poses in
+//                    LDS, lanes spread over (instance, bone of that level) pairs; every bone is computed by exactly the
+//                    reference's operations, so the result is bit-identical to the index-order loop. Then
+//                    computeSkinMatrices (src/renderer/model.cpp:132-137): palette[i] = (pose[i] * inverse_bind[i])
+//                    .toMatrix(), written as 4 x float4 per bone (+ optionally the dual-quaternion palette).
 //   k_skin_vertices  evaluateSkin (model.cpp:103-109): the instance's palette is staged in LDS as 3 rows x float4
 //                    per bone (row w of the blended matrix never reaches transformPoint, core/math.cpp:1231-1235),
 //                    replicated per bank column so the random bone-matrix reads are conflict-free; each lane blends
@@ -27,77 +28,92 @@ __device__ __forceinline__ void wave_lds_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// 4 waves per block, one instance per wave
-__global__ __launch_bounds__(256) void k_pose_palette(const SkinInstance* __restrict__ inst, uint32_t n_inst, float* __restrict__ pose_pos,
-	float4* __restrict__ pose_rot, const int16_t* __restrict__ parents, const uint8_t* __restrict__ depth,
+// One wave per GROUP of up to K consecutive instances of one model (K = 16 / 8 / 4 for <= 64 / 128 / 196 bones). A bone
+// only depends on its parent's final value, so the tree is walked level by level; the work items of a level are the
+// (instance, bone at that depth) pairs of the whole group, which fills the lanes even though a level of one skeleton holds
+// only a handful of bones (one instance per wave kept ~4 of 64 lanes busy and made this kernel VALU-bound). Poses live in
+// LDS bone-major ([bone][instance]) so that neighbouring lanes (instances) touch neighbouring banks. Every bone is computed by
+// exactly the reference's operations (pose.cpp:129-130), so the result is bit-identical to the index-order loop.
+constexpr int POSE_LDS_BONES = 1024; // K * n_bones <= 1024: 16 x 64, 8 x 128, 4 x 196
+
+__device__ __forceinline__ uint32_t pose_group_capacity(uint32_t n_bones) { return n_bones <= 64 ? 16u : (n_bones <= 128 ? 8u : 4u); }
+
+__global__ __launch_bounds__(64) void k_pose_palette(const SkinInstance* __restrict__ inst, const PoseGroup* __restrict__ groups,
+	const float* rel_pos, const float4* rel_rot, float* pose_pos, float4* pose_rot /* rel_* may alias pose_*: no __restrict__ */,
+	const int16_t* __restrict__ parents, const uint16_t* __restrict__ level_bones, const uint16_t* __restrict__ level_off,
 	const float* __restrict__ inv_pos, const float4* __restrict__ inv_rot, float4* __restrict__ palette, float4* __restrict__ dual_quats) {
-	__shared__ float s_pos[4][SKIN_MAX_BONES * 3];
-	__shared__ float4 s_rot[4][SKIN_MAX_BONES];
-	const uint32_t wave = threadIdx.x >> 6;
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t ii = blockIdx.x * 4u + wave;
-	if (ii >= n_inst) return; // whole wave exits; no block-level barrier is used below
-	const SkinInstance in = inst[ii];
-	float* pos = s_pos[wave];
-	float4* rot = s_rot[wave];
-	float* gpos = pose_pos + (size_t)in.bone_offset * 3;
-	float4* grot = pose_rot + in.bone_offset;
-	for (uint32_t k = lane; k < in.n_bones * 3; k += 64) pos[k] = gpos[k];
-	for (uint32_t b = lane; b < in.n_bones; b += 64) rot[b] = grot[b];
-	wave_lds_sync();
-	// depth and parent of this lane's bones (bones lane, lane+64, lane+128, lane+192) live in registers for the walk
-	const int16_t* par = parents + in.model_offset;
-	const uint8_t* dep = depth + in.model_offset;
-	constexpr int BPL = (SKIN_MAX_BONES + 63) / 64; // bones per lane
-	int32_t my_parent[BPL];
-	uint32_t my_depth[BPL];
-#pragma unroll
-	for (int k = 0; k < BPL; ++k) {
-		const uint32_t b = lane + 64u * k;
-		const bool valid = b < in.n_bones && (int32_t)b >= in.first_nonroot;
-		my_parent[k] = valid ? (int32_t)par[b] : 0;
-		my_depth[k] = valid ? (uint32_t)dep[b] : 0u; // depth 0 = never recomputed (roots / out of range)
+	__shared__ float4 s_rot[POSE_LDS_BONES];
+	__shared__ float s_pos[POSE_LDS_BONES * 3];
+	__shared__ int32_t s_parent[SKIN_MAX_BONES];
+	const uint32_t lane = threadIdx.x;
+	const PoseGroup g = groups[blockIdx.x];
+	const SkinInstance in = inst[g.first_inst]; // all instances of the group share the model; their bones are consecutive in memory
+	const uint32_t nb = in.n_bones;
+	const uint32_t K = pose_group_capacity(nb);
+	const uint32_t kshift = K == 16 ? 4u : (K == 8 ? 3u : 2u);
+	const size_t bone0 = in.bone_offset;
+	// stage relative poses: coalesced per instance, transposed to [bone][instance] in LDS
+	for (uint32_t k = 0; k < g.count; ++k) {
+		const size_t base = bone0 + (size_t)k * nb;
+		for (uint32_t b = lane; b < nb; b += 64) {
+			s_rot[b * K + k] = rel_rot[base + b];
+			const float* p = rel_pos + (base + b) * 3;
+			s_pos[(b * K + k) * 3] = p[0];
+			s_pos[(b * K + k) * 3 + 1] = p[1];
+			s_pos[(b * K + k) * 3 + 2] = p[2];
+		}
 	}
-	const uint32_t max_depth = in.max_depth;
-	for (uint32_t d = 1; d <= max_depth; ++d) {
-#pragma unroll
-		for (int k = 0; k < BPL; ++k) {
-			if (my_depth[k] == d) {
-				const uint32_t b = lane + 64u * k;
-				const int32_t p = my_parent[k];
-				const float4 pr4 = rot[p];
-				const float4 r4 = rot[b];
+	for (uint32_t b = lane; b < nb; b += 64) s_parent[b] = parents[in.model_offset + b];
+	wave_lds_sync();
+	const uint16_t* lv_off = level_off + in.lv_off_offset;     // lv_off[d - 1] .. lv_off[d]: bones of depth d
+	const uint16_t* lv_bones = level_bones + in.lv_bones_offset; // bones >= first_nonroot, sorted by depth
+	for (uint32_t d = 1; d <= in.max_depth; ++d) {
+		const uint32_t start = lv_off[d - 1];
+		const uint32_t items = ((uint32_t)lv_off[d] - start) << kshift;
+		for (uint32_t j = lane; j < items; j += 64) {
+			const uint32_t k = j & (K - 1);
+			if (k < g.count) {
+				const uint32_t b = lv_bones[start + (j >> kshift)];
+				const uint32_t ib = b * K + k, ip = (uint32_t)s_parent[b] * K + k;
+				const float4 pr4 = s_rot[ip];
+				const float4 r4 = s_rot[ib];
 				const Q4 pr = Q4{pr4.x, pr4.y, pr4.z, pr4.w};
-				const V3 np = add(rotate(pr, V3{pos[3 * b], pos[3 * b + 1], pos[3 * b + 2]}), V3{pos[3 * p], pos[3 * p + 1], pos[3 * p + 2]});
+				const V3 np = add(rotate(pr, V3{s_pos[3 * ib], s_pos[3 * ib + 1], s_pos[3 * ib + 2]}), V3{s_pos[3 * ip], s_pos[3 * ip + 1], s_pos[3 * ip + 2]});
 				const Q4 nr = qmul(pr, Q4{r4.x, r4.y, r4.z, r4.w});
-				pos[3 * b] = np.x; pos[3 * b + 1] = np.y; pos[3 * b + 2] = np.z;
-				rot[b] = make_float4(nr.x, nr.y, nr.z, nr.w);
+				s_pos[3 * ib] = np.x; s_pos[3 * ib + 1] = np.y; s_pos[3 * ib + 2] = np.z;
+				s_rot[ib] = make_float4(nr.x, nr.y, nr.z, nr.w);
 			}
 		}
 		wave_lds_sync();
 	}
+	// palette (computeSkinMatrices), optional dual quaternions, absolute pose write-back: coalesced per instance
 	const float* ipos = inv_pos + (size_t)in.model_offset * 3;
 	const float4* irot = inv_rot + in.model_offset;
-	for (uint32_t b = lane; b < in.n_bones; b += 64) {
-		const float4 r4 = rot[b];
-		const float4 ir = irot[b];
-		const V3 p = V3{pos[3 * b], pos[3 * b + 1], pos[3 * b + 2]};
-		const V3 ip = V3{ipos[3 * b], ipos[3 * b + 1], ipos[3 * b + 2]};
-		const Mat4 m = skin_matrix(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, Q4{ir.x, ir.y, ir.z, ir.w});
-		if (dual_quats != nullptr) { // the palette format of the reference's own GPU skinning path (32 B per bone)
-			const DualQ dq = skin_dual_quat(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, Q4{ir.x, ir.y, ir.z, ir.w});
-			float4* o = dual_quats + (size_t)(in.bone_offset + b) * 2;
-			o[0] = make_float4(dq.r.x, dq.r.y, dq.r.z, dq.r.w);
-			o[1] = make_float4(dq.d.x, dq.d.y, dq.d.z, dq.d.w);
+	for (uint32_t k = 0; k < g.count; ++k) {
+		const size_t base = bone0 + (size_t)k * nb;
+		for (uint32_t b = lane; b < nb; b += 64) {
+			const uint32_t ib = b * K + k;
+			const float4 r4 = s_rot[ib];
+			const float4 ir = irot[b];
+			const V3 p = V3{s_pos[3 * ib], s_pos[3 * ib + 1], s_pos[3 * ib + 2]};
+			const V3 ip = V3{ipos[3 * b], ipos[3 * b + 1], ipos[3 * b + 2]};
+			const Mat4 m = skin_matrix(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, Q4{ir.x, ir.y, ir.z, ir.w});
+			if (dual_quats != nullptr) { // the palette format of the reference's own GPU skinning path (32 B per bone)
+				const DualQ dq = skin_dual_quat(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, Q4{ir.x, ir.y, ir.z, ir.w});
+				float4* o = dual_quats + (base + b) * 2;
+				o[0] = make_float4(dq.r.x, dq.r.y, dq.r.z, dq.r.w);
+				o[1] = make_float4(dq.d.x, dq.d.y, dq.d.z, dq.d.w);
+			}
+			float4* out = palette + (base + b) * 4;
+			out[0] = make_float4(m.c[0][0], m.c[0][1], m.c[0][2], m.c[0][3]);
+			out[1] = make_float4(m.c[1][0], m.c[1][1], m.c[1][2], m.c[1][3]);
+			out[2] = make_float4(m.c[2][0], m.c[2][1], m.c[2][2], m.c[2][3]);
+			out[3] = make_float4(m.c[3][0], m.c[3][1], m.c[3][2], m.c[3][3]);
+			// the pose becomes absolute (Pose::is_absolute = true, pose.cpp:133)
+			float* gp = pose_pos + (base + b) * 3;
+			gp[0] = p.x; gp[1] = p.y; gp[2] = p.z;
+			pose_rot[base + b] = r4;
 		}
-		float4* out = palette + (size_t)(in.bone_offset + b) * 4;
-		out[0] = make_float4(m.c[0][0], m.c[0][1], m.c[0][2], m.c[0][3]);
-		out[1] = make_float4(m.c[1][0], m.c[1][1], m.c[1][2], m.c[1][3]);
-		out[2] = make_float4(m.c[2][0], m.c[2][1], m.c[2][2], m.c[2][3]);
-		out[3] = make_float4(m.c[3][0], m.c[3][1], m.c[3][2], m.c[3][3]);
-		// the pose becomes absolute in place (Pose::is_absolute = true, pose.cpp:133)
-		gpos[3 * b] = p.x; gpos[3 * b + 1] = p.y; gpos[3 * b + 2] = p.z;
-		grot[b] = r4;
 	}
 }
 
@@ -170,7 +186,10 @@ __device__ __forceinline__ void skin_tile(const SkinInstance& in, uint32_t v_beg
 				// floats of an LDS row land in consecutive VGPRs, so {x,y} and {z,w} are packed operands as they are.
 				const v2f a01 = {A.x, A.y}, a23 = {A.z, A.w}, b01 = {B.x, B.y}, b23 = {B.z, B.w};
 				const v2f c01 = {C.x, C.y}, c23 = {C.z, C.w}, d01 = {D.x, D.y}, d23 = {D.z, D.w};
-				const v2f wx = {w.x, w.x}, wy = {w.y, w.y}, wz = {w.z, w.z}, ww = {w.w, w.w};
+				// weight splats as shuffles of the loaded pairs, so that the broadcast folds into op_sel of v_pk_*_f32
+				const v2f w01 = {w.x, w.y}, w23 = {w.z, w.w};
+				const v2f wx = __builtin_shufflevector(w01, w01, 0, 0), wy = __builtin_shufflevector(w01, w01, 1, 1);
+				const v2f wz = __builtin_shufflevector(w23, w23, 0, 0), ww = __builtin_shufflevector(w23, w23, 1, 1);
 				v2f m01 = a01 * wx, m23 = a23 * wx;
 				m01 = __builtin_elementwise_fma(b01, wy, m01);
 				m23 = __builtin_elementwise_fma(b23, wy, m23);
@@ -222,11 +241,12 @@ __global__ __launch_bounds__(SKIN_THREADS, 6) void k_skin_vertices(const SkinIns
 
 } // namespace
 
-hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, float* pose_pos, float4* pose_rot,
-	const int16_t* parents, const uint8_t* depth, const float* inv_pos, const float4* inv_rot, float4* palette, float4* dual_quats) {
-	if (!n_inst) return hipSuccess;
-	hipLaunchKernelGGL(k_pose_palette, dim3((n_inst + 3u) / 4u), dim3(256), 0, s, inst, n_inst, pose_pos, pose_rot, parents, depth,
-		inv_pos, inv_rot, palette, dual_quats);
+hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, const PoseGroup* groups, uint32_t n_groups, const float* rel_pos,
+	const float4* rel_rot, float* pose_pos, float4* pose_rot, const int16_t* parents, const uint16_t* level_bones, const uint16_t* level_off,
+	const float* inv_pos, const float4* inv_rot, float4* palette, float4* dual_quats) {
+	if (!n_groups) return hipSuccess;
+	hipLaunchKernelGGL(k_pose_palette, dim3(n_groups), dim3(64), 0, s, inst, groups, rel_pos, rel_rot, pose_pos, pose_rot, parents, level_bones,
+		level_off, inv_pos, inv_rot, palette, dual_quats);
 	return hipGetLastError();
 }
 
