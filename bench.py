@@ -487,6 +487,13 @@ def extras(ctx, api, scenes, torch, timed, N, log):
     out["target_frame_10M_cull_100k_skinned_ms"] = ms4
     out["target_frames_per_sec_1gpu"] = 1e3 / ms4
     out["target_skinned_verts_per_sec"] = n_inst4 * n_verts / (ms4 * 1e-3)
+    # the same frame for a renderer that consumes only palettes / vertices (no absolute-pose store, lmx_skin_set_pose_writeback)
+    sk4.setPoseWriteback(False)
+    for _ in range(2):
+        frame4()
+    ms4b = timed(frame4, 10)
+    out["target_no_pose_store_frame_ms"] = ms4b
+    out["target_no_pose_store_frames_per_sec_1gpu"] = 1e3 / ms4b
     del cs4, sk4, d_pos4, d_rot4
     # distinct meshes: every instance streams its own 36 B/vertex from HBM (the 48 B/vertex algorithmic figure is real traffic)
     n_inst2 = 1500  # 540 MB of mesh data + 180 MB of output: well beyond the 256 MiB Infinity Cache

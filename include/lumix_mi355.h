@@ -179,6 +179,11 @@ LMX_API int lmx_skin_run(LmxContext* ctx);
 LMX_API int lmx_skin_read_vertices(LmxContext* ctx, uint32_t instance, float* out_xyz, uint32_t cap_verts);
 LMX_API int lmx_skin_read_palette(LmxContext* ctx, uint32_t instance, LmxMatrix* out, uint32_t cap_bones);
 LMX_API int lmx_skin_read_pose(LmxContext* ctx, uint32_t instance, float* out_pos, float* out_rot, uint32_t cap_bones);
+/* The reference keeps the absolute pose in the instance's Pose (Pose::is_absolute, pose.cpp:133) for bone attachments and
+ * the next consumer; lmx_skin_run stores it next to the palette by default (28 B per bone). A renderer that only consumes
+ * palettes / vertices can switch the store off: lmx_skin_read_pose then fails with LMX_ERR_NOT_BUILT, and uploaded (not
+ * borrowed) relative poses stay valid for the next run. */
+LMX_API int lmx_skin_set_pose_writeback(LmxContext* ctx, int enable);
 /* Also emit the dual-quaternion palette of the reference's own GPU skinning path (PipelineImpl::computeSkeletonDualQuats,
  * renderer/pipeline.cpp:2680-2745): per bone a DualQuat {r.xyzw, d.xyzw} (core/math.h:257-260, 32 B) of pose * inverse bind. */
 LMX_API int lmx_skin_enable_dual_quats(LmxContext* ctx, int enable);

@@ -86,6 +86,7 @@ SYMBOLS = {
     "lmx_skin_run": (_ci, [_vp]),
     "lmx_skin_read_vertices": (_ci, [_vp, _u32, _vp, _u32]),
     "lmx_skin_read_palette": (_ci, [_vp, _u32, _vp, _u32]),
+    "lmx_skin_set_pose_writeback": (_ci, [_vp, _ci]),
     "lmx_skin_enable_dual_quats": (_ci, [_vp, _ci]),
     "lmx_skin_read_dual_quats": (_ci, [_vp, _u32, _vp, _u32]),
     "lmx_skin_read_pose": (_ci, [_vp, _u32, _vp, _vp, _u32]),
@@ -454,6 +455,10 @@ class Skinning:
         out = np.zeros(n, MATRIX)
         self.ctx.check(self.lib.lmx_skin_read_palette(self.ctx.h, instance, _ptr(out), n))
         return out
+
+    def setPoseWriteback(self, on: bool = True):
+        """Store the absolute pose next to the palette (default) or not (readPose then fails)."""
+        self.ctx.check(self.lib.lmx_skin_set_pose_writeback(self.ctx.h, int(on)))
 
     def enableDualQuats(self, on: bool = True):
         self.ctx.check(self.lib.lmx_skin_enable_dual_quats(self.ctx.h, int(on)))

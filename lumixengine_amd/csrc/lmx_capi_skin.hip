@@ -28,13 +28,13 @@ int lmx_skin_add_model(LmxContext* ctx, uint32_t n_bones, const int16_t* parents
 		m.max_depth = std::max<uint32_t>(m.max_depth, depth[i]);
 	}
 	// bones that Pose::computeAbsolute touches, sorted by depth, + per-depth offsets: the level walk of k_pose_palette
-	m.lv_bones_offset = (uint32_t)sk.level_bones.size();
+	m.lv_items_offset = (uint32_t)sk.level_items.size();
 	m.lv_off_offset = (uint32_t)sk.level_off.size();
 	sk.level_off.push_back(0);
 	for (uint32_t d = 1; d <= m.max_depth; ++d) {
 		for (uint32_t i = 0; i < n_bones; ++i)
-			if (depth[i] == d) sk.level_bones.push_back((uint16_t)i);
-		sk.level_off.push_back((uint16_t)(sk.level_bones.size() - m.lv_bones_offset));
+			if (depth[i] == d) sk.level_items.push_back(i | ((uint32_t)parents[i] << 16));
+		sk.level_off.push_back((uint16_t)(sk.level_items.size() - m.lv_items_offset));
 	}
 	for (uint32_t i = 0; i < n_bones; ++i) {
 		V3 ip;
@@ -85,9 +85,9 @@ static int skin_upload_static(LmxContext* ctx) {
 		LMX_HIP(ctx, hipMemcpy(sk.d_parents.p, sk.parents.data(), nb * sizeof(int16_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(sk.d_inv_pos.p, sk.inv_pos.data(), nb * 3 * sizeof(float), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(sk.d_inv_rot.p, sk.inv_rot.data(), nb * sizeof(float4), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, sk.d_level_bones.reserve(std::max<size_t>(sk.level_bones.size(), 1)));
+		LMX_HIP(ctx, sk.d_level_items.reserve(std::max<size_t>(sk.level_items.size(), 1)));
 		LMX_HIP(ctx, sk.d_level_off.reserve(std::max<size_t>(sk.level_off.size(), 1)));
-		if (!sk.level_bones.empty()) LMX_HIP(ctx, hipMemcpy(sk.d_level_bones.p, sk.level_bones.data(), sk.level_bones.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+		if (!sk.level_items.empty()) LMX_HIP(ctx, hipMemcpy(sk.d_level_items.p, sk.level_items.data(), sk.level_items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(sk.d_level_off.p, sk.level_off.data(), sk.level_off.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
 		sk.models_dirty = false;
 	}
@@ -126,35 +126,83 @@ int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* model, c
 		in.n_verts = me.n_verts;
 		in.out_offset = (uint32_t)verts;
 		in.max_depth = mo.max_depth;
-		in.lv_bones_offset = mo.lv_bones_offset;
+		in.lv_items_offset = mo.lv_items_offset;
 		in.lv_off_offset = mo.lv_off_offset;
 		bones += mo.n_bones;
 		verts += me.n_verts;
 		max_verts = std::max(max_verts, me.n_verts);
 	}
-	// pose groups: runs of consecutive instances of one model, at most 16 / 8 / 4 (<= 64 / 128 / 196 bones) per group
-	sk.groups.clear();
+	// pose groups: runs of consecutive instances of one model, at most 16 / 8 / 4 (<= 64 / 128 / 196 bones) per group, stored by
+	// capacity class (one launch of k_pose_palette<KSHIFT> per class)
+	std::vector<PoseGroup> groups[3];
 	for (uint32_t i = 0; i < n;) {
-		const uint32_t cap = sk.models[model[i]].n_bones <= 64 ? 16u : (sk.models[model[i]].n_bones <= 128 ? 8u : 4u);
+		const uint32_t nbm = sk.models[model[i]].n_bones;
+		const uint32_t cls = nbm <= 64 ? 0u : (nbm <= 128 ? 1u : 2u);
+		const uint32_t cap = 16u >> cls;
 		uint32_t c = 1;
 		while (i + c < n && c < cap && model[i + c] == model[i]) ++c;
-		sk.groups.push_back(PoseGroup{i, c});
+		groups[cls].push_back(PoseGroup{i, c});
 		i += c;
+	}
+	sk.groups.clear();
+	for (int c = 0; c < 3; ++c) {
+		sk.n_groups[c] = (uint32_t)groups[c].size();
+		sk.groups.insert(sk.groups.end(), groups[c].begin(), groups[c].end());
+	}
+	// skinning work: runs of consecutive instances that share a mesh (and a bone count) go to k_skin_shared, which keeps the
+	// vertex records in registers across the run; everything else goes to k_skin_vertices, one instance at a time
+	sk.chunks.clear();
+	sk.solo.clear();
+	sk.solo_max_verts = 0;
+	{
+		struct Run { uint32_t first, count, tiles; };
+		std::vector<Run> runs;
+		uint64_t run_tiles = 0;
+		for (uint32_t i = 0; i < n;) {
+			uint32_t c = 1;
+			while (i + c < n && mesh[i + c] == mesh[i] && inst[i + c].n_bones == inst[i].n_bones) ++c;
+			if (c >= 2 && inst[i].n_verts >= 2048) {
+				const uint32_t tiles = (inst[i].n_verts + SKIN_SHARED_TILE_VERTS - 1) / SKIN_SHARED_TILE_VERTS;
+				runs.push_back(Run{i, c, tiles});
+				run_tiles += (uint64_t)c * tiles;
+			} else {
+				for (uint32_t k = 0; k < c; ++k) {
+					sk.solo.push_back(i + k);
+					sk.solo_max_verts = std::max(sk.solo_max_verts, inst[i + k].n_verts);
+				}
+			}
+			i += c;
+		}
+		// instances per block: as many as still leave ~6 blocks per CU (the mesh tile is loaded once per block)
+		const uint32_t per_block = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, run_tiles / 1536));
+		for (const Run& r : runs) {
+			const uint32_t nv = inst[r.first].n_verts;
+			const uint32_t tile_verts = ((nv + r.tiles - 1) / r.tiles + 63u) & ~63u;
+			for (uint32_t f = 0; f < r.count; f += per_block)
+				for (uint32_t t = 0; t < r.tiles; ++t)
+					if (t * tile_verts < nv) sk.chunks.push_back(SkinChunk{r.first + f, std::min(per_block, r.count - f), t * tile_verts, std::min(nv, (t + 1) * tile_verts)});
+		}
+		if (sk.chunks.empty()) sk.solo.clear(); // every instance: identity index
 	}
 	sk.inst.swap(inst);
 	sk.bones_total = bones;
 	sk.verts_total = verts;
 	sk.max_verts = max_verts;
 	sk.poses_uploaded = false;
+	sk.pose_is_absolute = false;
 	sk.borrowed_pos = nullptr;
 	sk.borrowed_rot = nullptr;
 	LMX_HIP(ctx, sk.d_inst.reserve(std::max<size_t>(n, 1)));
 	LMX_HIP(ctx, sk.d_pose_pos.reserve(std::max<size_t>(bones * 3, 1)));
 	LMX_HIP(ctx, sk.d_pose_rot.reserve(std::max<size_t>(bones, 1)));
-	LMX_HIP(ctx, sk.d_palette.reserve(std::max<size_t>(bones * 4, 1)));
+	LMX_HIP(ctx, sk.d_palette.reserve(std::max<size_t>(bones * 3, 1)));
 	LMX_HIP(ctx, sk.d_out.reserve(std::max<size_t>(verts * 3, 1)));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (n) LMX_HIP(ctx, hipMemcpy(sk.d_inst.p, sk.inst.data(), (size_t)n * sizeof(SkinInstance), hipMemcpyHostToDevice));
+	LMX_HIP(ctx, sk.d_chunks.reserve(std::max<size_t>(sk.chunks.size(), 1)));
+	LMX_HIP(ctx, sk.d_solo.reserve(std::max<size_t>(sk.solo.size(), 1)));
+	if (!sk.chunks.empty()) LMX_HIP(ctx, hipMemcpy(sk.d_chunks.p, sk.chunks.data(), sk.chunks.size() * sizeof(SkinChunk), hipMemcpyHostToDevice));
+	if (!sk.solo.empty()) LMX_HIP(ctx, hipMemcpy(sk.d_solo.p, sk.solo.data(), sk.solo.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	LMX_HIP(ctx, sk.d_groups.reserve(std::max<size_t>(sk.groups.size(), 1)));
 	if (n) LMX_HIP(ctx, hipMemcpy(sk.d_groups.p, sk.groups.data(), sk.groups.size() * sizeof(PoseGroup), hipMemcpyHostToDevice));
 	return LMX_OK;
@@ -170,6 +218,7 @@ int lmx_skin_upload_poses(LmxContext* ctx, const float* positions, const float* 
 	LMX_HIP(ctx, hipMemcpy(sk.d_pose_pos.p, positions, n_bones_total * 3 * sizeof(float), hipMemcpyHostToDevice));
 	LMX_HIP(ctx, hipMemcpy(sk.d_pose_rot.p, rotations, n_bones_total * sizeof(float4), hipMemcpyHostToDevice));
 	sk.poses_uploaded = true;
+	sk.pose_is_absolute = false;
 	return LMX_OK;
 }
 
@@ -182,6 +231,7 @@ int lmx_skin_upload_poses_device(LmxContext* ctx, const void* d_positions, const
 	LMX_HIP(ctx, hipMemcpyAsync(sk.d_pose_pos.p, d_positions, n_bones_total * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
 	LMX_HIP(ctx, hipMemcpyAsync(sk.d_pose_rot.p, d_rotations, n_bones_total * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
 	sk.poses_uploaded = true;
+	sk.pose_is_absolute = false;
 	return LMX_OK;
 }
 
@@ -215,17 +265,25 @@ int lmx_skin_run(LmxContext* ctx) {
 		if (sk.want_dual_quats) LMX_HIP(ctx, sk.d_dual_quats.reserve(std::max<size_t>(sk.bones_total * 2, 1)));
 		const float* rel_pos = sk.borrowed_pos ? sk.borrowed_pos : sk.d_pose_pos.p;
 		const float4* rel_rot = sk.borrowed_rot ? sk.borrowed_rot : sk.d_pose_rot.p;
-		LMX_HIP(ctx, launch_pose_palette(ctx->stream, sk.d_inst.p, sk.d_groups.p, (uint32_t)sk.groups.size(), rel_pos, rel_rot, sk.d_pose_pos.p, sk.d_pose_rot.p,
-			sk.d_parents.p, sk.d_level_bones.p, sk.d_level_off.p, sk.d_inv_pos.p, sk.d_inv_rot.p, sk.d_palette.p, sk.want_dual_quats ? sk.d_dual_quats.p : nullptr));
+		LMX_HIP(ctx, launch_pose_palette(ctx->stream, sk.d_inst.p, sk.d_groups.p, sk.n_groups, rel_pos, rel_rot, sk.pose_writeback ? sk.d_pose_pos.p : nullptr,
+			sk.pose_writeback ? sk.d_pose_rot.p : nullptr, sk.d_level_items.p, sk.d_level_off.p, sk.d_inv_pos.p, sk.d_inv_rot.p, sk.d_palette.p, sk.want_dual_quats ? sk.d_dual_quats.p : nullptr));
 	}
 	{
 		ProfScope ps(ctx, LMX_K_SKIN_VERTICES);
-		LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, n, sk.max_verts, sk.d_verts.p, sk.d_weights.p, sk.d_indices.p, sk.d_palette.p,
-			sk.d_out.p, sk.exact));
+		if (sk.chunks.empty()) {
+			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, nullptr, n, sk.max_verts, sk.d_verts.p, sk.d_weights.p, sk.d_indices.p, sk.d_palette.p,
+				sk.d_out.p, sk.exact));
+		} else {
+			LMX_HIP(ctx, launch_skin_shared(ctx->stream, sk.d_inst.p, sk.d_chunks.p, (uint32_t)sk.chunks.size(), sk.d_verts.p, sk.d_weights.p, sk.d_indices.p,
+				sk.d_palette.p, sk.d_out.p, sk.exact));
+			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, sk.d_solo.p, (uint32_t)sk.solo.size(), sk.solo_max_verts, sk.d_verts.p, sk.d_weights.p,
+				sk.d_indices.p, sk.d_palette.p, sk.d_out.p, sk.exact));
+		}
 	}
 	// the library's poses are absolute now; running again needs fresh relative poses (Pose::is_absolute, pose.cpp:64) unless
 	// a borrowed source provides them every frame
-	sk.poses_uploaded = sk.borrowed_pos != nullptr;
+	sk.poses_uploaded = sk.borrowed_pos != nullptr || !sk.pose_writeback;
+	sk.pose_is_absolute = sk.pose_writeback;
 	return LMX_OK;
 }
 
@@ -246,8 +304,17 @@ int lmx_skin_read_palette(LmxContext* ctx, uint32_t instance, LmxMatrix* out, ui
 	if (instance >= sk.inst.size() || !out) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad instance/out");
 	const SkinInstance& in = sk.inst[instance];
 	if (cap_bones < in.n_bones) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u bones", in.n_bones);
-	LMX_HIP(ctx, hipMemcpyAsync(out, sk.d_palette.p + (size_t)in.bone_offset * 4, (size_t)in.n_bones * sizeof(LmxMatrix), hipMemcpyDeviceToHost, ctx->stream));
+	// the palette is kept as the 3 rows evaluateSkin reads (48 B per bone); the constant 4th row is re-attached here
+	LMX_HIP(ctx, sk.d_palette_expanded.reserve(in.n_bones * 4));
+	LMX_HIP(ctx, launch_palette_expand(ctx->stream, sk.d_palette.p + (size_t)in.bone_offset * 3, in.n_bones, sk.d_palette_expanded.p));
+	LMX_HIP(ctx, hipMemcpyAsync(out, sk.d_palette_expanded.p, (size_t)in.n_bones * sizeof(LmxMatrix), hipMemcpyDeviceToHost, ctx->stream));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+int lmx_skin_set_pose_writeback(LmxContext* ctx, int enable) {
+	LMX_CHECK_CTX(ctx);
+	ctx->skin.pose_writeback = enable != 0;
 	return LMX_OK;
 }
 
@@ -275,6 +342,7 @@ int lmx_skin_read_pose(LmxContext* ctx, uint32_t instance, float* out_pos, float
 	if (instance >= sk.inst.size()) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad instance");
 	const SkinInstance& in = sk.inst[instance];
 	if (cap_bones < in.n_bones) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u bones", in.n_bones);
+	if (!sk.pose_is_absolute) return fail(ctx, LMX_ERR_NOT_BUILT, "no absolute pose: lmx_skin_run has not run, or pose write-back is disabled");
 	if (out_pos) LMX_HIP(ctx, hipMemcpyAsync(out_pos, sk.d_pose_pos.p + (size_t)in.bone_offset * 3, (size_t)in.n_bones * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
 	if (out_rot) LMX_HIP(ctx, hipMemcpyAsync(out_rot, sk.d_pose_rot.p + in.bone_offset, (size_t)in.n_bones * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -142,7 +142,7 @@ struct WorldState {
 	}
 };
 
-struct SkinModel { uint32_t bone_offset, n_bones, max_depth; int32_t first_nonroot; uint32_t lv_bones_offset, lv_off_offset; };
+struct SkinModel { uint32_t bone_offset, n_bones, max_depth; int32_t first_nonroot; uint32_t lv_items_offset, lv_off_offset; };
 struct SkinMesh { uint32_t vert_offset, n_verts; };
 
 struct SkinState {
@@ -151,9 +151,17 @@ struct SkinState {
 	// concatenated host copies (re-uploaded when models/meshes are added)
 	std::vector<int16_t> parents;
 	std::vector<uint8_t> depth;
-	std::vector<uint16_t> level_bones, level_off; // per model: bones sorted by depth + per-depth offsets (k_pose_palette)
-	DevBuf<uint16_t> d_level_bones, d_level_off;
-	std::vector<PoseGroup> groups;
+	std::vector<uint32_t> level_items; // per model: bone | parent << 16 of the bones >= first_nonroot, sorted by depth
+	std::vector<uint16_t> level_off;   // per model: max_depth + 1 offsets into its level_items (k_pose_palette)
+	DevBuf<uint32_t> d_level_items;
+	DevBuf<uint16_t> d_level_off;
+	std::vector<PoseGroup> groups;     // sorted by capacity class (16, 8, 4 instances per group)
+	uint32_t n_groups[3] = {0, 0, 0};
+	std::vector<SkinChunk> chunks;     // k_skin_shared work items (runs of instances sharing a mesh)
+	std::vector<uint32_t> solo;        // instances skinned by k_skin_vertices (empty + no chunks = all of them)
+	DevBuf<SkinChunk> d_chunks;
+	DevBuf<uint32_t> d_solo;
+	uint32_t solo_max_verts = 0;
 	DevBuf<PoseGroup> d_groups;
 	std::vector<float> inv_pos;
 	std::vector<float4> inv_rot;
@@ -178,6 +186,9 @@ struct SkinState {
 	bool poses_uploaded = false;
 	bool exact = false;
 	bool want_dual_quats = false;
+	bool pose_writeback = true;    // store the absolute pose (Pose::is_absolute) next to the palette
+	bool pose_is_absolute = false; // d_pose_* hold the absolute pose of the last run
+	DevBuf<float4> d_palette_expanded;
 	const float* borrowed_pos = nullptr;  // lmx_skin_set_pose_source_device: relative poses read in place from caller memory
 	const float4* borrowed_rot = nullptr;
 	DevBuf<float4> d_dual_quats;

@@ -105,16 +105,24 @@ struct SkinInstance {
 	uint32_t n_verts;
 	uint32_t out_offset;   // into output vertex array (in vertices)
 	uint32_t max_depth;    // deepest bone level of the model (root = 0)
-	uint32_t lv_bones_offset; // into level_bones: the model's bones >= first_nonroot sorted by depth
+	uint32_t lv_items_offset; // into level_items: the model's bones >= first_nonroot sorted by depth, as bone | parent << 16
 	uint32_t lv_off_offset;   // into level_off: max_depth + 1 offsets (bones of depth d = [off[d-1], off[d]))
 };
+// k_skin_shared work item: instances [first_inst, first_inst + count) share mesh and bone count; vertices [v_begin, v_end) of it
+struct SkinChunk { uint32_t first_inst, count, v_begin, v_end; };
 struct PoseGroup { uint32_t first_inst; uint32_t count; }; // consecutive instances of one model, count <= 16 / 8 / 4 by bone count
 // Pose::computeAbsolute + computeSkinMatrices (+ optional dual-quaternion palette), one wave per PoseGroup
-hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, const PoseGroup* groups, uint32_t n_groups, const float* rel_pos,
-	const float4* rel_rot, float* pose_pos, float4* pose_rot, const int16_t* parents, const uint16_t* level_bones, const uint16_t* level_off,
+hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, const PoseGroup* groups, const uint32_t n_groups[3] /* by capacity 16, 8, 4 */,
+	const float* rel_pos, const float4* rel_rot, float* pose_pos, float4* pose_rot, const uint32_t* level_items, const uint16_t* level_off,
 	const float* inv_pos, const float4* inv_rot, float4* palette, float4* dual_quats /* optional */);
+// palette rows (3 x float4 per bone) -> column-major 4 x 4 matrices
+hipError_t launch_palette_expand(hipStream_t s, const float4* rows, uint32_t n_bones, float4* out);
 // evaluateSkin over every vertex of every instance
-hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, uint32_t max_verts, const float* verts,
+hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, const uint32_t* inst_index /* optional subset */, uint32_t n_inst,
+	uint32_t max_verts, const float* verts, const float4* weights, const int16_t* indices, const float4* palette, float* out, bool exact);
+// the same for runs of consecutive instances that share a mesh and a bone count (vertex records held in registers)
+hipError_t launch_skin_shared(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float* verts,
 	const float4* weights, const int16_t* indices, const float4* palette, float* out, bool exact);
+constexpr uint32_t SKIN_SHARED_TILE_VERTS = 5120; // k_skin_shared: 1024 lanes x 5 vertex records
 
 } // namespace lmx

@@ -6,7 +6,8 @@
 //                    LDS, lanes spread over (instance, bone of that level) pairs; every bone is computed by exactly the
 //                    reference's operations, so the result is bit-identical to the index-order loop. Then
 //                    computeSkinMatrices (src/renderer/model.cpp:132-137): palette[i] = (pose[i] * inverse_bind[i])
-//                    .toMatrix(), written as 4 x float4 per bone (+ optionally the dual-quaternion palette).
+//                    .toMatrix(), written as its 3 non-constant rows (3 x float4 per bone) (+ optionally the
+//                    dual-quaternion palette).
 //   k_skin_vertices  evaluateSkin (model.cpp:103-109): the instance's palette is staged in LDS as 3 rows x float4
 //                    per bone (row w of the blended matrix never reaches transformPoint, core/math.cpp:1231-1235),
 //                    replicated per bank column so the random bone-matrix reads are conflict-free; each lane blends
@@ -18,6 +19,11 @@ namespace lmx {
 
 namespace {
 
+// tools/pose_probe.hip includes this file with LMX_PROBE_SKIP defined to time the phases of k_pose_palette separately
+#ifndef LMX_PROBE_SKIP
+#define LMX_PROBE_SKIP(bit) false
+#endif
+
 constexpr int SKIN_MAX_BONES = 196; // Model::Bone::MAX_COUNT, renderer/model.h:155
 
 // Lanes of ONE wave exchange data through LDS: the LDS executes a wave's instructions in issue order, so only the
@@ -28,53 +34,72 @@ __device__ __forceinline__ void wave_lds_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One wave per GROUP of up to K consecutive instances of one model (K = 16 / 8 / 4 for <= 64 / 128 / 196 bones). A bone
+// One block per GROUP of up to K consecutive instances of one model (K = 16 / 8 / 4 for <= 64 / 128 / 196 bones). A bone
 // only depends on its parent's final value, so the tree is walked level by level; the work items of a level are the
 // (instance, bone at that depth) pairs of the whole group, which fills the lanes even though a level of one skeleton holds
-// only a handful of bones (one instance per wave kept ~4 of 64 lanes busy and made this kernel VALU-bound). Poses live in
-// LDS bone-major ([bone][instance]) so that neighbouring lanes (instances) touch neighbouring banks. Every bone is computed by
-// exactly the reference's operations (pose.cpp:129-130), so the result is bit-identical to the index-order loop.
+// only a handful of bones. Poses live in LDS bone-major ([bone][instance]) so that neighbouring lanes (instances) touch
+// neighbouring banks. Every bone is computed by exactly the reference's operations (pose.cpp:129-130), so the result is
+// bit-identical to the index-order loop. The 4 waves of the block split the group's instances for the global loads and
+// stores (the kernel moves ~100 B per bone and is bound by the bytes the few LDS-limited blocks of a CU keep in flight) and
+// share the level walk; the global loads of a phase are issued back to back before anything waits on them.
+//
+// Palette layout in HBM: 3 rows x float4 per bone ({c0[r], c1[r], c2[r], c3[r]}, 48 B) — the rows evaluateSkin reads; row 3
+// of (pose * inverse_bind).toMatrix() is the constant (0, 0, 0, 1) (math.cpp:887-890) and is re-attached on read-back.
 constexpr int POSE_LDS_BONES = 1024; // K * n_bones <= 1024: 16 x 64, 8 x 128, 4 x 196
+constexpr int POSE_WAVES = 4;
 
-__device__ __forceinline__ uint32_t pose_group_capacity(uint32_t n_bones) { return n_bones <= 64 ? 16u : (n_bones <= 128 ? 8u : 4u); }
-
-__global__ __launch_bounds__(64) void k_pose_palette(const SkinInstance* __restrict__ inst, const PoseGroup* __restrict__ groups,
-	const float* rel_pos, const float4* rel_rot, float* pose_pos, float4* pose_rot /* rel_* may alias pose_*: no __restrict__ */,
-	const int16_t* __restrict__ parents, const uint16_t* __restrict__ level_bones, const uint16_t* __restrict__ level_off,
-	const float* __restrict__ inv_pos, const float4* __restrict__ inv_rot, float4* __restrict__ palette, float4* __restrict__ dual_quats) {
+template <int KSHIFT>
+__global__ __launch_bounds__(64 * POSE_WAVES) void k_pose_palette(const SkinInstance* __restrict__ inst, const PoseGroup* __restrict__ groups,
+	const float* rel_pos, const float4* rel_rot, float* pose_pos, float4* pose_rot /* rel_* may alias pose_*: no __restrict__; null = no write-back */,
+	const uint32_t* __restrict__ level_items, const uint16_t* __restrict__ level_off, const float* __restrict__ inv_pos,
+	const float4* __restrict__ inv_rot, float4* __restrict__ palette, float4* __restrict__ dual_quats) {
+	constexpr uint32_t K = 1u << KSHIFT;
+	constexpr uint32_t KW = K / POSE_WAVES; // instances per wave
 	__shared__ float4 s_rot[POSE_LDS_BONES];
 	__shared__ float s_pos[POSE_LDS_BONES * 3];
-	__shared__ int32_t s_parent[SKIN_MAX_BONES];
-	const uint32_t lane = threadIdx.x;
+	__shared__ uint32_t s_item[SKIN_MAX_BONES];     // bone | parent << 16, sorted by depth (bones >= first_nonroot only)
+	__shared__ uint16_t s_off[SKIN_MAX_BONES + 1];  // s_off[d - 1] .. s_off[d]: items of depth d
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const PoseGroup g = groups[blockIdx.x];
 	const SkinInstance in = inst[g.first_inst]; // all instances of the group share the model; their bones are consecutive in memory
 	const uint32_t nb = in.n_bones;
-	const uint32_t K = pose_group_capacity(nb);
-	const uint32_t kshift = K == 16 ? 4u : (K == 8 ? 3u : 2u);
 	const size_t bone0 = in.bone_offset;
-	// stage relative poses: coalesced per instance, transposed to [bone][instance] in LDS
-	for (uint32_t k = 0; k < g.count; ++k) {
-		const size_t base = bone0 + (size_t)k * nb;
-		for (uint32_t b = lane; b < nb; b += 64) {
-			s_rot[b * K + k] = rel_rot[base + b];
-			const float* p = rel_pos + (base + b) * 3;
-			s_pos[(b * K + k) * 3] = p[0];
-			s_pos[(b * K + k) * 3 + 1] = p[1];
-			s_pos[(b * K + k) * 3 + 2] = p[2];
+	// stage relative poses: coalesced per instance, transposed to [bone][instance] in LDS; wave w owns instances w, w + 4, ...
+	for (uint32_t b = lane; b < nb; b += 64) {
+		float4 r[KW];
+		float px[KW], py[KW], pz[KW];
+#pragma unroll
+		for (uint32_t kk = 0; kk < KW; ++kk) { // instances past the group's end re-read its first one (no branch around the loads)
+			const uint32_t k = wave + kk * POSE_WAVES < g.count && !LMX_PROBE_SKIP(4) ? wave + kk * POSE_WAVES : 0;
+			const size_t i = bone0 + (size_t)k * nb + b;
+			r[kk] = rel_rot[i];
+			px[kk] = rel_pos[i * 3];
+			py[kk] = rel_pos[i * 3 + 1];
+			pz[kk] = rel_pos[i * 3 + 2];
+		}
+#pragma unroll
+		for (uint32_t kk = 0; kk < KW; ++kk) {
+			const uint32_t k = wave + kk * POSE_WAVES;
+			if (k < g.count) {
+				s_rot[b * K + k] = r[kk];
+				s_pos[(b * K + k) * 3] = px[kk];
+				s_pos[(b * K + k) * 3 + 1] = py[kk];
+				s_pos[(b * K + k) * 3 + 2] = pz[kk];
+			}
 		}
 	}
-	for (uint32_t b = lane; b < nb; b += 64) s_parent[b] = parents[in.model_offset + b];
-	wave_lds_sync();
-	const uint16_t* lv_off = level_off + in.lv_off_offset;     // lv_off[d - 1] .. lv_off[d]: bones of depth d
-	const uint16_t* lv_bones = level_bones + in.lv_bones_offset; // bones >= first_nonroot, sorted by depth
-	for (uint32_t d = 1; d <= in.max_depth; ++d) {
-		const uint32_t start = lv_off[d - 1];
-		const uint32_t items = ((uint32_t)lv_off[d] - start) << kshift;
-		for (uint32_t j = lane; j < items; j += 64) {
+	const uint32_t n_items = level_off[in.lv_off_offset + in.max_depth];
+	for (uint32_t i = tid; i < n_items; i += 64 * POSE_WAVES) s_item[i] = level_items[in.lv_items_offset + i];
+	for (uint32_t i = tid; i <= in.max_depth; i += 64 * POSE_WAVES) s_off[i] = level_off[in.lv_off_offset + i];
+	__syncthreads();
+	for (uint32_t d = 1; d <= in.max_depth && !LMX_PROBE_SKIP(1); ++d) {
+		const uint32_t start = s_off[d - 1];
+		const uint32_t items = ((uint32_t)s_off[d] - start) << KSHIFT;
+		for (uint32_t j = tid; j < items; j += 64 * POSE_WAVES) {
 			const uint32_t k = j & (K - 1);
 			if (k < g.count) {
-				const uint32_t b = lv_bones[start + (j >> kshift)];
-				const uint32_t ib = b * K + k, ip = (uint32_t)s_parent[b] * K + k;
+				const uint32_t it = s_item[start + (j >> KSHIFT)];
+				const uint32_t ib = (it & 0xffffu) * K + k, ip = (it >> 16) * K + k;
 				const float4 pr4 = s_rot[ip];
 				const float4 r4 = s_rot[ib];
 				const Q4 pr = Q4{pr4.x, pr4.y, pr4.z, pr4.w};
@@ -84,74 +109,154 @@ __global__ __launch_bounds__(64) void k_pose_palette(const SkinInstance* __restr
 				s_rot[ib] = make_float4(nr.x, nr.y, nr.z, nr.w);
 			}
 		}
-		wave_lds_sync();
+		__syncthreads();
 	}
-	// palette (computeSkinMatrices), optional dual quaternions, absolute pose write-back: coalesced per instance
+	// palette (computeSkinMatrices), optional dual quaternions, optional absolute pose write-back
 	const float* ipos = inv_pos + (size_t)in.model_offset * 3;
 	const float4* irot = inv_rot + in.model_offset;
-	for (uint32_t k = 0; k < g.count; ++k) {
-		const size_t base = bone0 + (size_t)k * nb;
-		for (uint32_t b = lane; b < nb; b += 64) {
+	for (uint32_t b = lane; b < nb; b += 64) {
+		const float4 ir4 = irot[b];
+		const Q4 ir = Q4{ir4.x, ir4.y, ir4.z, ir4.w};
+		const V3 ip = V3{ipos[3 * b], ipos[3 * b + 1], ipos[3 * b + 2]};
+#pragma unroll
+		for (uint32_t kk = 0; kk < KW; ++kk) {
+			const uint32_t k = wave + kk * POSE_WAVES;
+			if (k >= g.count) break;
+			const size_t i = bone0 + (size_t)k * nb + b;
 			const uint32_t ib = b * K + k;
 			const float4 r4 = s_rot[ib];
-			const float4 ir = irot[b];
 			const V3 p = V3{s_pos[3 * ib], s_pos[3 * ib + 1], s_pos[3 * ib + 2]};
-			const V3 ip = V3{ipos[3 * b], ipos[3 * b + 1], ipos[3 * b + 2]};
-			const Mat4 m = skin_matrix(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, Q4{ir.x, ir.y, ir.z, ir.w});
+			const Mat4 m = skin_matrix(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, ir);
+			if (LMX_PROBE_SKIP(2) && m.c[0][0] != 123.f) continue;
 			if (dual_quats != nullptr) { // the palette format of the reference's own GPU skinning path (32 B per bone)
-				const DualQ dq = skin_dual_quat(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, Q4{ir.x, ir.y, ir.z, ir.w});
-				float4* o = dual_quats + (base + b) * 2;
+				const DualQ dq = skin_dual_quat(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, ir);
+				float4* o = dual_quats + i * 2;
 				o[0] = make_float4(dq.r.x, dq.r.y, dq.r.z, dq.r.w);
 				o[1] = make_float4(dq.d.x, dq.d.y, dq.d.z, dq.d.w);
 			}
-			float4* out = palette + (base + b) * 4;
-			out[0] = make_float4(m.c[0][0], m.c[0][1], m.c[0][2], m.c[0][3]);
-			out[1] = make_float4(m.c[1][0], m.c[1][1], m.c[1][2], m.c[1][3]);
-			out[2] = make_float4(m.c[2][0], m.c[2][1], m.c[2][2], m.c[2][3]);
-			out[3] = make_float4(m.c[3][0], m.c[3][1], m.c[3][2], m.c[3][3]);
-			// the pose becomes absolute (Pose::is_absolute = true, pose.cpp:133)
-			float* gp = pose_pos + (base + b) * 3;
-			gp[0] = p.x; gp[1] = p.y; gp[2] = p.z;
-			pose_rot[base + b] = r4;
+			float4* out = palette + i * 3;
+			out[0] = make_float4(m.c[0][0], m.c[1][0], m.c[2][0], m.c[3][0]);
+			out[1] = make_float4(m.c[0][1], m.c[1][1], m.c[2][1], m.c[3][1]);
+			out[2] = make_float4(m.c[0][2], m.c[1][2], m.c[2][2], m.c[3][2]);
+			if (pose_pos != nullptr) { // the pose becomes absolute (Pose::is_absolute = true, pose.cpp:133)
+				float* gp = pose_pos + i * 3;
+				gp[0] = p.x; gp[1] = p.y; gp[2] = p.z;
+				pose_rot[i] = r4;
+			}
 		}
 	}
 }
 
+// lmx_skin_read_palette: 3 x float4 rows -> the reference's column-major Matrix (row 3 = (0, 0, 0, 1), math.cpp:887-890)
+__global__ __launch_bounds__(256) void k_palette_expand(const float4* __restrict__ rows, uint32_t n_bones, float4* __restrict__ out) {
+	const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+	if (b >= n_bones) return;
+	const float4 r0 = rows[3 * b], r1 = rows[3 * b + 1], r2 = rows[3 * b + 2];
+	out[4 * b] = make_float4(r0.x, r1.x, r2.x, 0.f);
+	out[4 * b + 1] = make_float4(r0.y, r1.y, r2.y, 0.f);
+	out[4 * b + 2] = make_float4(r0.z, r1.z, r2.z, 0.f);
+	out[4 * b + 3] = make_float4(r0.w, r1.w, r2.w, 1.f);
+}
+
 // ---- linear-blend skinning ----------------------------------------------------------------------------------
-// One block skins a tile of one instance's vertices with that instance's palette staged in LDS as 3 rows x float4 per
-// bone. The bone indices of neighbouring vertices are unrelated in the worst case, so the 12 ds_read_b128 per vertex
-// would collide on LDS banks (16 random 16-B slots per service group -> ~3x serialisation). The palette is therefore
-// REPLICATED: copy c of every row lives in 16-B bank column c (slot = (bone*3 + row) * COPIES + c) and lane l reads copy
-// l % COPIES. With 16 copies every lane of a ds_read_b128 service group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...:
-// 16 lanes with distinct l % 16, MI355X_MICROARCH.md LDS table) owns its own bank column -> conflict-free whatever the
-// indices. 48 KiB per block (64 bones x 16 copies, 128 x 8, 196 x 4), staged once per tile of thousands of vertices.
+// A block skins vertices with one instance's palette staged in LDS as 3 rows x float4 per bone. The bone indices of
+// neighbouring vertices are unrelated in the worst case, so the 12 ds_read_b128 per vertex would collide on LDS banks (16
+// random 16-B slots per service group -> ~3x serialisation). The palette is therefore REPLICATED: copy c of every row lives
+// in 16-B bank column c (slot = (bone*3 + row) * COPIES + c) and lane l reads copy l % COPIES. With 16 copies every lane of a
+// ds_read_b128 service group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: 16 lanes with distinct l % 16,
+// MI355X_MICROARCH.md LDS table) owns its own bank column -> conflict-free whatever the indices. 48 KiB per palette
+// (64 bones x 16 copies, 128 x 8, 196 x 4).
+//
+// Two kernels share the blend:
+//   k_skin_vertices  one block = one tile of ONE instance's vertices; vertex records stream from memory. General path.
+//   k_skin_shared    one block = one tile of a mesh x a run of instances that share it: the vertex records are loaded ONCE
+//                    into registers and re-used for every instance of the run, palettes are double-buffered in LDS. A CU's
+//                    vector-memory path is in order, so in k_skin_vertices the (L2-resident) mesh loads queue behind the
+//                    stores waiting on HBM and the kernel runs at blend time + store time (tools/skin_probe.hip); here
+//                    the steady state issues stores only.
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int SKIN_THREADS = 512;
-constexpr int SKIN_LDS_SLOTS = 3072; // float4 slots = 48 KiB
+constexpr int SKIN_WAVES_PER_SIMD = 6; // 3 blocks of 8 waves per CU: <= 80 VGPRs, 48 KiB LDS each
+constexpr int SKIN_LDS_SLOTS = 3072;   // float4 slots = 48 KiB
+
+struct F3 { float x, y, z; }; // 12-byte records: loaded / stored as one dwordx3 per lane
+struct VertexIn { float px, py, pz; float4 w; int2 iw; };
+
+// evaluateSkin of one vertex (model.cpp:103-109) against the palette rows of its 4 bones in LDS (r0..r3 point at row 0 of
+// the lane's copy; rows are COPIES slots apart)
+template <int COPIES, bool EXACT>
+__device__ __forceinline__ F3 skin_blend_rows(const float4* r0, const float4* r1, const float4* r2, const float4* r3, const VertexIn& c) {
+	const float4 w = c.w;
+	float o[3];
+#pragma unroll
+	for (int r = 0; r < 3; ++r) {
+		float4 A, B, C, D;
+		if (LMX_PROBE_SKIP(16)) { A = w; B = c.w; C = make_float4(c.px, c.py, c.pz, w.x); D = make_float4(w.y, c.px, w.z, c.py); }
+		else { A = r0[r * COPIES]; B = r1[r * COPIES]; C = r2[r * COPIES]; D = r3[r * COPIES]; }
+		if constexpr (EXACT) {
+			// Matrix::operator*(float) and operator+ (math.cpp:1022-1071), left to right: ((A*w.x + B*w.y) + C*w.z) + D*w.w
+			const float m0 = A.x * w.x + B.x * w.y + C.x * w.z + D.x * w.w;
+			const float m1 = A.y * w.x + B.y * w.y + C.y * w.z + D.y * w.w;
+			const float m2 = A.z * w.x + B.z * w.y + C.z * w.z + D.z * w.w;
+			const float m3 = A.w * w.x + B.w * w.y + C.w * w.z + D.w * w.w;
+			// Matrix::transformPoint (math.cpp:1231-1235): c0.r*p.x + c1.r*p.y + c2.r*p.z + c3.r
+			o[r] = m0 * c.px + m1 * c.py + m2 * c.pz + m3;
+		} else {
+			// same association with the products fused into the adds, on register pairs (v_pk_fma_f32): the four
+			// floats of an LDS row land in consecutive VGPRs, so {x,y} and {z,w} are packed operands as they are.
+			const v2f a01 = {A.x, A.y}, a23 = {A.z, A.w}, b01 = {B.x, B.y}, b23 = {B.z, B.w};
+			const v2f c01 = {C.x, C.y}, c23 = {C.z, C.w}, d01 = {D.x, D.y}, d23 = {D.z, D.w};
+			// weight splats as shuffles of the loaded pairs, so that the broadcast folds into op_sel of v_pk_*_f32
+			const v2f w01 = {w.x, w.y}, w23 = {w.z, w.w};
+			const v2f wx = __builtin_shufflevector(w01, w01, 0, 0), wy = __builtin_shufflevector(w01, w01, 1, 1);
+			const v2f wz = __builtin_shufflevector(w23, w23, 0, 0), ww = __builtin_shufflevector(w23, w23, 1, 1);
+			v2f m01 = a01 * wx, m23 = a23 * wx;
+			m01 = __builtin_elementwise_fma(b01, wy, m01);
+			m23 = __builtin_elementwise_fma(b23, wy, m23);
+			m01 = __builtin_elementwise_fma(c01, wz, m01);
+			m23 = __builtin_elementwise_fma(c23, wz, m23);
+			m01 = __builtin_elementwise_fma(d01, ww, m01);
+			m23 = __builtin_elementwise_fma(d23, ww, m23);
+			o[r] = fmaf(m23.x, c.pz, fmaf(m01.y, c.py, m01.x * c.px)) + m23.y;
+		}
+	}
+	return F3{o[0], o[1], o[2]};
+}
+
+// `rows` already points at the lane's copy
+template <int COPIES, bool EXACT>
+__device__ __forceinline__ F3 skin_blend(const float4* rows, const VertexIn& c) {
+	// bone indices are non-negative i16 (validated at lmx_skin_add_mesh): plain 16-bit fields, no sign extension
+	return skin_blend_rows<COPIES, EXACT>(rows + (uint32_t)(c.iw.x & 0xffff) * (3 * COPIES), rows + ((uint32_t)c.iw.x >> 16) * (3 * COPIES),
+		rows + (uint32_t)(c.iw.y & 0xffff) * (3 * COPIES), rows + ((uint32_t)c.iw.y >> 16) * (3 * COPIES), c);
+}
+
+// Palette staging: every float4 of the instance's 3 x n_bones rows is read by ONE lane (a handful of load instructions per
+// block instead of one per slot) and written to its COPIES slots; the copy order is rotated by the lane so that the 8 lanes
+// of a ds_write_b128 service group, whose slots are COPIES * 16 B apart, land on 8 different bank columns.
+template <int COPIES>
+__device__ __forceinline__ float4 palette_fetch(const float4* __restrict__ pal, uint32_t n_rows, uint32_t f) {
+	return pal[f < n_rows ? f : 0u];
+}
+template <int COPIES>
+__device__ __forceinline__ void palette_spread(float4* s_rows, uint32_t n_rows, uint32_t f, float4 t) {
+	if (f < n_rows) {
+#pragma unroll
+		for (uint32_t c = 0; c < COPIES; ++c) s_rows[f * COPIES + ((c + f) & (COPIES - 1))] = t;
+	}
+}
 
 template <int COPIES, bool EXACT>
 __device__ __forceinline__ void skin_tile(const SkinInstance& in, uint32_t v_begin, uint32_t v_end, float4* s_rows,
 	const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices,
 	const float4* __restrict__ palette, float* __restrict__ out) {
-	// stage: global column-major 4 x float4 per bone -> LDS rows {c0[r], c1[r], c2[r], c3[r]}, COPIES times
-	const float4* pal = palette + (size_t)in.bone_offset * 4;
-	for (uint32_t e = threadIdx.x; e < in.n_bones * COPIES; e += SKIN_THREADS) {
-		const uint32_t b = e / COPIES, c = e % COPIES;
-		const float4 c0 = pal[4 * b], c1 = pal[4 * b + 1], c2 = pal[4 * b + 2], c3 = pal[4 * b + 3];
-		s_rows[(3 * b) * COPIES + c] = make_float4(c0.x, c1.x, c2.x, c3.x);
-		s_rows[(3 * b + 1) * COPIES + c] = make_float4(c0.y, c1.y, c2.y, c3.y);
-		s_rows[(3 * b + 2) * COPIES + c] = make_float4(c0.z, c1.z, c2.z, c3.z);
-	}
-	__syncthreads();
 	const uint32_t col = threadIdx.x & (COPIES - 1);
 	const float4* rows = s_rows + col;
 	// per-instance base pointers are wave-uniform (SGPRs); per-lane offsets stay 32-bit
-	struct F3 { float x, y, z; }; // 12-byte records: loaded / stored as one dwordx3 per lane
 	const F3* vbase = reinterpret_cast<const F3*>(verts) + in.vert_offset;
 	const float4* wbase = weights + in.vert_offset;
 	const int2* ibase = reinterpret_cast<const int2*>(indices) + in.vert_offset; // 4 x i16 per vertex, little endian
 	F3* obase = reinterpret_cast<F3*>(out) + in.out_offset;
-	struct VertexIn { float px, py, pz; float4 w; int2 iw; };
 	auto load = [&](uint32_t v) {
 		VertexIn r;
 		const F3 p = vbase[v];
@@ -163,50 +268,26 @@ __device__ __forceinline__ void skin_tile(const SkinInstance& in, uint32_t v_beg
 		return r;
 	};
 	auto skin_one = [&](const VertexIn& c, uint32_t v) {
-		// bone indices are non-negative i16 (validated at lmx_skin_add_mesh): plain 16-bit fields, no sign extension
-		const float4* r0 = rows + (uint32_t)(c.iw.x & 0xffff) * (3 * COPIES);
-		const float4* r1 = rows + ((uint32_t)c.iw.x >> 16) * (3 * COPIES);
-		const float4* r2 = rows + (uint32_t)(c.iw.y & 0xffff) * (3 * COPIES);
-		const float4* r3 = rows + ((uint32_t)c.iw.y >> 16) * (3 * COPIES);
-		const float4 w = c.w;
-		float o[3];
-#pragma unroll
-		for (int r = 0; r < 3; ++r) {
-			const float4 A = r0[r * COPIES], B = r1[r * COPIES], C = r2[r * COPIES], D = r3[r * COPIES];
-			if constexpr (EXACT) {
-				// Matrix::operator*(float) and operator+ (math.cpp:1022-1071), left to right: ((A*w.x + B*w.y) + C*w.z) + D*w.w
-				const float m0 = A.x * w.x + B.x * w.y + C.x * w.z + D.x * w.w;
-				const float m1 = A.y * w.x + B.y * w.y + C.y * w.z + D.y * w.w;
-				const float m2 = A.z * w.x + B.z * w.y + C.z * w.z + D.z * w.w;
-				const float m3 = A.w * w.x + B.w * w.y + C.w * w.z + D.w * w.w;
-				// Matrix::transformPoint (math.cpp:1231-1235): c0.r*p.x + c1.r*p.y + c2.r*p.z + c3.r
-				o[r] = m0 * c.px + m1 * c.py + m2 * c.pz + m3;
-			} else {
-				// same association with the products fused into the adds, on register pairs (v_pk_fma_f32): the four
-				// floats of an LDS row land in consecutive VGPRs, so {x,y} and {z,w} are packed operands as they are.
-				const v2f a01 = {A.x, A.y}, a23 = {A.z, A.w}, b01 = {B.x, B.y}, b23 = {B.z, B.w};
-				const v2f c01 = {C.x, C.y}, c23 = {C.z, C.w}, d01 = {D.x, D.y}, d23 = {D.z, D.w};
-				// weight splats as shuffles of the loaded pairs, so that the broadcast folds into op_sel of v_pk_*_f32
-				const v2f w01 = {w.x, w.y}, w23 = {w.z, w.w};
-				const v2f wx = __builtin_shufflevector(w01, w01, 0, 0), wy = __builtin_shufflevector(w01, w01, 1, 1);
-				const v2f wz = __builtin_shufflevector(w23, w23, 0, 0), ww = __builtin_shufflevector(w23, w23, 1, 1);
-				v2f m01 = a01 * wx, m23 = a23 * wx;
-				m01 = __builtin_elementwise_fma(b01, wy, m01);
-				m23 = __builtin_elementwise_fma(b23, wy, m23);
-				m01 = __builtin_elementwise_fma(c01, wz, m01);
-				m23 = __builtin_elementwise_fma(c23, wz, m23);
-				m01 = __builtin_elementwise_fma(d01, ww, m01);
-				m23 = __builtin_elementwise_fma(d23, ww, m23);
-				o[r] = fmaf(m23.x, c.pz, fmaf(m01.y, c.py, m01.x * c.px)) + m23.y;
-			}
-		}
-		obase[v] = F3{o[0], o[1], o[2]};
+		const F3 o = skin_blend<COPIES, EXACT>(rows, c);
+		if (LMX_PROBE_SKIP(8) && o.x != 123.25f) return;
+		obase[v] = o;
 	};
 	// software-pipelined and unrolled by two (A / B ping-pong): the next vertex's loads are in flight while the current one
-	// is blended, and no register block is copied between iterations
+	// is blended, and no register block is copied between iterations. (A deeper pipeline was measured and does not help.)
 	uint32_t v = v_begin + threadIdx.x;
-	if (v >= v_end) return;
-	VertexIn a = load(v);
+	const bool has_first = v < v_end;
+	VertexIn a = {};
+	if (has_first) a = load(v); // in flight during the palette staging
+	{
+		const float4* pal = palette + (size_t)in.bone_offset * 3;
+		const uint32_t n_rows = in.n_bones * 3;
+		const float4 t0 = palette_fetch<COPIES>(pal, n_rows, threadIdx.x);
+		const float4 t1 = palette_fetch<COPIES>(pal, n_rows, threadIdx.x + SKIN_THREADS); // 196 bones: 588 rows
+		palette_spread<COPIES>(s_rows, n_rows, threadIdx.x, t0);
+		palette_spread<COPIES>(s_rows, n_rows, threadIdx.x + SKIN_THREADS, t1);
+	}
+	__syncthreads();
+	if (!has_first) return;
 	for (;;) {
 		const uint32_t vb = v + SKIN_THREADS;
 		const bool has_b = vb < v_end;
@@ -224,12 +305,14 @@ __device__ __forceinline__ void skin_tile(const SkinInstance& in, uint32_t v_beg
 }
 
 template <bool EXACT>
-__global__ __launch_bounds__(SKIN_THREADS, 6) void k_skin_vertices(const SkinInstance* __restrict__ inst, uint32_t tiles_per_inst,
-	uint32_t tile_verts, const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices,
-	const float4* __restrict__ palette, float* __restrict__ out) {
+__global__ __launch_bounds__(SKIN_THREADS, SKIN_WAVES_PER_SIMD) void k_skin_vertices(const SkinInstance* __restrict__ inst,
+	const uint32_t* __restrict__ inst_index /* optional: the instances this launch covers */, uint32_t tiles_per_inst, uint32_t tile_verts,
+	const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices, const float4* __restrict__ palette,
+	float* __restrict__ out) {
 	__shared__ float4 s_rows[SKIN_LDS_SLOTS];
-	const uint32_t ii = blockIdx.x / tiles_per_inst;
+	uint32_t ii = blockIdx.x / tiles_per_inst;
 	const uint32_t tile = blockIdx.x - ii * tiles_per_inst;
+	if (inst_index != nullptr) ii = inst_index[ii];
 	const SkinInstance in = inst[ii];
 	const uint32_t v_begin = tile * tile_verts;
 	if (v_begin >= in.n_verts) return; // block-uniform
@@ -239,19 +322,109 @@ __global__ __launch_bounds__(SKIN_THREADS, 6) void k_skin_vertices(const SkinIns
 	else skin_tile<4, EXACT>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
 }
 
+// ---- shared-mesh runs: vertex records in registers, palettes double-buffered in LDS -------------------------------------
+constexpr int SHARED_THREADS = 1024; // 16 waves = 4 per SIMD at <= 128 VGPRs; one block per CU (2 x 48 KiB LDS)
+constexpr int SHARED_VPT = 5;        // vertex records per lane (9 VGPRs each) -> tiles of up to 5120 vertices
+
+static_assert(SHARED_THREADS * SHARED_VPT == SKIN_SHARED_TILE_VERTS, "host tiling and kernel disagree");
+
+template <int COPIES, bool EXACT>
+__device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const SkinChunk& ch, float4 (*s_rows)[SKIN_LDS_SLOTS],
+	const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices,
+	const float4* __restrict__ palette, float* __restrict__ out) {
+	const uint32_t tid = threadIdx.x;
+	const uint32_t col = tid & (COPIES - 1);
+	const F3* vbase = reinterpret_cast<const F3*>(verts) + in0.vert_offset;
+	const float4* wbase = weights + in0.vert_offset;
+	const int2* ibase = reinterpret_cast<const int2*>(indices) + in0.vert_offset;
+	// the lane's vertex records: loaded once, used for every instance of the chunk. The bone indices are kept as the 16-bit
+	// byte offsets of the bones' row 0 in the lane's palette copy ((bone * 3 * COPIES + col) * 16 < 48 KiB), two per register.
+	VertexIn vin[SHARED_VPT];
+#pragma unroll
+	for (int k = 0; k < SHARED_VPT; ++k) {
+		const uint32_t v = ch.v_begin + tid + k * SHARED_THREADS;
+		vin[k] = VertexIn{};
+		if (v < ch.v_end) {
+			const F3 p = vbase[v];
+			vin[k].px = p.x; vin[k].py = p.y; vin[k].pz = p.z;
+			vin[k].w = wbase[v];
+			const int2 iw = ibase[v];
+			const uint32_t b0 = (uint32_t)iw.x & 0xffffu, b1 = (uint32_t)iw.x >> 16, b2 = (uint32_t)iw.y & 0xffffu, b3 = (uint32_t)iw.y >> 16;
+			vin[k].iw.x = (int)(((b0 * (3 * COPIES) + col) * 16u) | (((b1 * (3 * COPIES) + col) * 16u) << 16));
+			vin[k].iw.y = (int)(((b2 * (3 * COPIES) + col) * 16u) | (((b3 * (3 * COPIES) + col) * 16u) << 16));
+		}
+	}
+	// the chunk's instances are consecutive and share mesh and bone count: their bones and outputs are consecutive too
+	const uint32_t n_rows = in0.n_bones * 3;
+	const float4* pal = palette + (size_t)in0.bone_offset * 3;
+	F3* obase = reinterpret_cast<F3*>(out) + in0.out_offset;
+	palette_spread<COPIES>(s_rows[0], n_rows, tid, palette_fetch<COPIES>(pal, n_rows, tid));
+	__syncthreads();
+	for (uint32_t j = 0; j < ch.count; ++j) {
+		// next palette: fetched BEFORE this instance's stores are issued (loads and stores share the in-order vmcnt, so the
+		// wait for it below only covers stores of the previous instance), spread into the other buffer after the blend
+		const bool more = j + 1 < ch.count;
+		float4 t = {};
+		if (more) t = palette_fetch<COPIES>(pal + (size_t)(j + 1) * n_rows, n_rows, tid);
+		const char* buf = reinterpret_cast<const char*>(s_rows[j & 1]);
+		F3* o = obase + (size_t)j * in0.n_verts;
+#pragma unroll
+		for (int k = 0; k < SHARED_VPT; ++k) {
+			const uint32_t v = ch.v_begin + tid + k * SHARED_THREADS;
+			if (v < ch.v_end) {
+				// opaque to the optimiser: nothing derived from the record (unpacked addresses, weight splats) is hoisted out
+				// of the instance loop into registers that do not exist
+				asm volatile("" : "+v"(vin[k].px), "+v"(vin[k].py), "+v"(vin[k].pz), "+v"(vin[k].w.x), "+v"(vin[k].w.y), "+v"(vin[k].w.z), "+v"(vin[k].w.w),
+					"+v"(vin[k].iw.x), "+v"(vin[k].iw.y));
+				const uint32_t o01 = (uint32_t)vin[k].iw.x, o23 = (uint32_t)vin[k].iw.y;
+				o[v] = skin_blend_rows<COPIES, EXACT>(reinterpret_cast<const float4*>(buf + (o01 & 0xffffu)), reinterpret_cast<const float4*>(buf + (o01 >> 16)),
+					reinterpret_cast<const float4*>(buf + (o23 & 0xffffu)), reinterpret_cast<const float4*>(buf + (o23 >> 16)), vin[k]);
+			}
+			__builtin_amdgcn_sched_barrier(0); // one vertex's 12 palette rows (48 VGPRs) in flight at a time
+		}
+		if (more) palette_spread<COPIES>(s_rows[(j + 1) & 1], n_rows, tid, t);
+		__syncthreads(); // buffer (j + 1) & 1 is complete; buffer j & 1 is free for instance j + 2
+	}
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(SHARED_THREADS) void k_skin_shared(const SkinInstance* __restrict__ inst, const SkinChunk* __restrict__ chunks,
+	const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices, const float4* __restrict__ palette,
+	float* __restrict__ out) {
+	__shared__ float4 s_rows[2][SKIN_LDS_SLOTS];
+	const SkinChunk ch = chunks[blockIdx.x];
+	const SkinInstance in0 = inst[ch.first_inst];
+	if (in0.n_bones <= 64) skin_shared_tile<16, EXACT>(in0, ch, s_rows, verts, weights, indices, palette, out);
+	else if (in0.n_bones <= 128) skin_shared_tile<8, EXACT>(in0, ch, s_rows, verts, weights, indices, palette, out);
+	else skin_shared_tile<4, EXACT>(in0, ch, s_rows, verts, weights, indices, palette, out);
+}
+
 } // namespace
 
-hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, const PoseGroup* groups, uint32_t n_groups, const float* rel_pos,
-	const float4* rel_rot, float* pose_pos, float4* pose_rot, const int16_t* parents, const uint16_t* level_bones, const uint16_t* level_off,
-	const float* inv_pos, const float4* inv_rot, float4* palette, float4* dual_quats) {
-	if (!n_groups) return hipSuccess;
-	hipLaunchKernelGGL(k_pose_palette, dim3(n_groups), dim3(64), 0, s, inst, groups, rel_pos, rel_rot, pose_pos, pose_rot, parents, level_bones,
-		level_off, inv_pos, inv_rot, palette, dual_quats);
+// groups are sorted by capacity class on the host: [0, n16) hold <= 16 instances of <= 64 bones, then 8 x <= 128, then 4 x <= 196
+hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, const PoseGroup* groups, const uint32_t n_groups[3], const float* rel_pos,
+	const float4* rel_rot, float* pose_pos, float4* pose_rot, const uint32_t* level_items, const uint16_t* level_off, const float* inv_pos,
+	const float4* inv_rot, float4* palette, float4* dual_quats) {
+	if (n_groups[0])
+		hipLaunchKernelGGL(k_pose_palette<4>, dim3(n_groups[0]), dim3(64 * POSE_WAVES), 0, s, inst, groups, rel_pos, rel_rot, pose_pos, pose_rot, level_items,
+			level_off, inv_pos, inv_rot, palette, dual_quats);
+	if (n_groups[1])
+		hipLaunchKernelGGL(k_pose_palette<3>, dim3(n_groups[1]), dim3(64 * POSE_WAVES), 0, s, inst, groups + n_groups[0], rel_pos, rel_rot, pose_pos, pose_rot,
+			level_items, level_off, inv_pos, inv_rot, palette, dual_quats);
+	if (n_groups[2])
+		hipLaunchKernelGGL(k_pose_palette<2>, dim3(n_groups[2]), dim3(64 * POSE_WAVES), 0, s, inst, groups + n_groups[0] + n_groups[1], rel_pos, rel_rot, pose_pos,
+			pose_rot, level_items, level_off, inv_pos, inv_rot, palette, dual_quats);
 	return hipGetLastError();
 }
 
-hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, uint32_t max_verts, const float* verts,
-	const float4* weights, const int16_t* indices, const float4* palette, float* out, bool exact) {
+hipError_t launch_palette_expand(hipStream_t s, const float4* rows, uint32_t n_bones, float4* out) {
+	if (!n_bones) return hipSuccess;
+	hipLaunchKernelGGL(k_palette_expand, dim3((n_bones + 255) / 256), dim3(256), 0, s, rows, n_bones, out);
+	return hipGetLastError();
+}
+
+hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, const uint32_t* inst_index, uint32_t n_inst, uint32_t max_verts,
+	const float* verts, const float4* weights, const int16_t* indices, const float4* palette, float* out, bool exact) {
 	if (!n_inst || !max_verts) return hipSuccess;
 	// tiles: as large as possible (the 48 KiB palette staging is paid per tile) while still giving the chip >= ~3000 blocks
 	const uint32_t max_tiles = (max_verts + 1023u) / 1024u;
@@ -262,12 +435,20 @@ hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, uint32_
 	const uint64_t blocks = (uint64_t)tiles * n_inst;
 	if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
 	if (exact) {
-		hipLaunchKernelGGL(k_skin_vertices<true>, dim3((uint32_t)blocks), dim3(SKIN_THREADS), 0, s, inst, tiles, tile_verts, verts, weights,
+		hipLaunchKernelGGL(k_skin_vertices<true>, dim3((uint32_t)blocks), dim3(SKIN_THREADS), 0, s, inst, inst_index, tiles, tile_verts, verts, weights,
 			indices, palette, out);
 	} else {
-		hipLaunchKernelGGL(k_skin_vertices<false>, dim3((uint32_t)blocks), dim3(SKIN_THREADS), 0, s, inst, tiles, tile_verts, verts, weights,
+		hipLaunchKernelGGL(k_skin_vertices<false>, dim3((uint32_t)blocks), dim3(SKIN_THREADS), 0, s, inst, inst_index, tiles, tile_verts, verts, weights,
 			indices, palette, out);
 	}
+	return hipGetLastError();
+}
+
+hipError_t launch_skin_shared(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float* verts,
+	const float4* weights, const int16_t* indices, const float4* palette, float* out, bool exact) {
+	if (!n_chunks) return hipSuccess;
+	if (exact) hipLaunchKernelGGL(k_skin_shared<true>, dim3(n_chunks), dim3(SHARED_THREADS), 0, s, inst, chunks, verts, weights, indices, palette, out);
+	else hipLaunchKernelGGL(k_skin_shared<false>, dim3(n_chunks), dim3(SHARED_THREADS), 0, s, inst, chunks, verts, weights, indices, palette, out);
 	return hipGetLastError();
 }
 

@@ -171,6 +171,72 @@ def test_skin_golden(gpu_ctx, exact):
     sk.setMode(False)
 
 
+def test_skin_groups_and_pose_writeback_switch(gpu_ctx, oracle_port):
+    """Runs of one model are walked 16 / 8 instances at a time (ragged last group, model change mid-run); with the absolute
+    pose store switched off the palettes and vertices are unchanged, readPose fails, and uploaded poses stay relative."""
+    sk = api.Skinning(gpu_ctx)
+    sk.setMode(True)
+    skel = [scenes.skeleton(64, seed=4), scenes.skeleton(100, seed=24)]
+    meshes = [scenes.skinned_mesh(300, 64, seed=6), scenes.skinned_mesh(129, 100, seed=7)]
+    models = [sk.addModel(s["parents"], s["bind"], s["first_nonroot"]) for s in skel]
+    mesh_ids = [sk.addMesh(v, s) for v, s in meshes]
+    pick = [0] * 37 + [1] * 19 + [0] * 3 + [1]
+    sk.setInstances([models[k] for k in pick], [mesh_ids[k] for k in pick])
+    poses = [scenes.relative_poses(1, len(skel[k]["parents"]), seed=300 + i) for i, k in enumerate(pick)]
+    rel_pos = np.concatenate([p[0].reshape(-1, 3) for p in poses])
+    rel_rot = np.concatenate([p[1].reshape(-1, 4) for p in poses])
+    sk.setPoseWriteback(False)
+    sk.uploadPoses(rel_pos, rel_rot)
+    want = []
+    for i, k in enumerate(pick):
+        s = skel[k]
+        apos, arot = oracle_port.pose_compute_absolute(poses[i][0], poses[i][1], s["parents"], s["first_nonroot"])
+        pal = oracle_port.skin_matrices(apos, arot, oracle_port.invert_bind(s["bind"]))
+        want.append((apos[0], arot[0], pal[0], oracle_port.evaluate_skin(meshes[k][0], meshes[k][1], pal)[0]))
+    for _ in range(2):  # the second run starts from the same (still relative) uploaded poses
+        sk.run()
+        for i in range(len(pick)):
+            assert H.bits_equal(sk.readPalette(i), want[i][2])
+            assert H.bits_equal(sk.readVertices(i), want[i][3])
+        with pytest.raises(api.LumixError):
+            sk.readPose(0)
+    sk.setPoseWriteback(True)
+    sk.run()
+    for i in range(len(pick)):
+        pos, rot = sk.readPose(i)
+        assert H.bits_equal(pos, want[i][0]) and H.bits_equal(rot, want[i][1])
+        assert H.bits_equal(sk.readPalette(i), want[i][2])
+    sk.setMode(False)
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_skin_shared_mesh_runs(gpu_ctx, oracle_port, exact):
+    """Runs of instances that share a mesh take the register-resident path (k_skin_shared: ragged tiles, 2 tiles per mesh,
+    8-copy palettes for 100 bones), single instances and small meshes the streaming one; both in one instance table."""
+    sk = api.Skinning(gpu_ctx)
+    sk.setMode(exact)
+    skel = [scenes.skeleton(64, seed=4), scenes.skeleton(100, seed=24), scenes.skeleton(64, seed=34)]
+    meshes = [scenes.skinned_mesh(5121, 64, seed=6), scenes.skinned_mesh(2049, 100, seed=7), scenes.skinned_mesh(700, 64, seed=8)]
+    models = [sk.addModel(s["parents"], s["bind"], s["first_nonroot"]) for s in skel]
+    mesh_ids = [sk.addMesh(v, s) for v, s in meshes]
+    # (model, mesh): a run of 9 on mesh 0 (two models with 64 bones: still one run), a single, a run of 3 on mesh 1, small meshes
+    pick = [(0, 0)] * 5 + [(2, 0)] * 4 + [(1, 1)] + [(0, 2)] * 3 + [(1, 1)] * 3 + [(0, 0)]
+    sk.setInstances([models[m] for m, _ in pick], [mesh_ids[g] for _, g in pick])
+    poses = [scenes.relative_poses(1, len(skel[m]["parents"]), seed=500 + i) for i, (m, _) in enumerate(pick)]
+    sk.uploadPoses(np.concatenate([p[0].reshape(-1, 3) for p in poses]), np.concatenate([p[1].reshape(-1, 4) for p in poses]))
+    sk.run()
+    for i, (m, g) in enumerate(pick):
+        s = skel[m]
+        apos, arot = oracle_port.pose_compute_absolute(poses[i][0], poses[i][1], s["parents"], s["first_nonroot"])
+        pal = oracle_port.skin_matrices(apos, arot, oracle_port.invert_bind(s["bind"]))
+        want = oracle_port.evaluate_skin(meshes[g][0], meshes[g][1], pal)[0]
+        got = sk.readVertices(i)
+        assert close_1e5(got, want), f"instance {i} vertices"
+        if exact:
+            assert H.bits_equal(got, want), f"instance {i} vertices (exact mode)"
+    sk.setMode(False)
+
+
 @pytest.mark.parametrize("exact", [True, False])
 def test_skin_many_instances_vs_oracle(gpu_ctx, oracle_port, exact):
     """Two models (64 and 196 bones = Model::Bone::MAX_COUNT), three meshes with ragged vertex counts."""

@@ -1,0 +1,44 @@
+// Development probe: times k_skin_vertices<false> with parts switched off (bit 8: vertex stores, 16: LDS palette reads).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I lumixengine_amd/csrc tools/skin_probe.hip -o tools/_build/skin_probe
+#include <hip/hip_runtime.h>
+__device__ int g_probe_mask;
+#define LMX_PROBE_SKIP(bit) ((g_probe_mask & (bit)) != 0)
+#include "skin_kernels.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace lmx;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+int main(int argc, char** argv) {
+	const uint32_t n_inst = argc > 1 ? atoi(argv[1]) : 20000, nb = 64, nv = 10000;
+	std::vector<SkinInstance> inst(n_inst);
+	for (uint32_t i = 0; i < n_inst; ++i) { SkinInstance in{}; in.bone_offset = i * nb; in.n_bones = nb; in.vert_offset = 0; in.n_verts = nv; in.out_offset = i * nv; inst[i] = in; }
+	std::vector<float> verts(nv * 3), w(nv * 4), pal((size_t)n_inst * nb * 12);
+	std::vector<int16_t> idx(nv * 4);
+	srand(3);
+	for (auto& v : verts) v = rand() / (float)RAND_MAX;
+	for (auto& v : w) v = 0.25f;
+	for (auto& v : idx) v = rand() % nb;
+	for (auto& v : pal) v = rand() / (float)RAND_MAX;
+	SkinInstance* d_inst; float *d_v, *d_out; float4 *d_w, *d_pal; int16_t* d_i;
+	CK(hipMalloc(&d_inst, inst.size() * sizeof(SkinInstance))); CK(hipMemcpy(d_inst, inst.data(), inst.size() * sizeof(SkinInstance), hipMemcpyHostToDevice));
+	CK(hipMalloc(&d_v, verts.size() * 4)); CK(hipMemcpy(d_v, verts.data(), verts.size() * 4, hipMemcpyHostToDevice));
+	CK(hipMalloc(&d_w, w.size() * 4)); CK(hipMemcpy(d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+	CK(hipMalloc(&d_i, idx.size() * 2)); CK(hipMemcpy(d_i, idx.data(), idx.size() * 2, hipMemcpyHostToDevice));
+	CK(hipMalloc(&d_pal, pal.size() * 4)); CK(hipMemcpy(d_pal, pal.data(), pal.size() * 4, hipMemcpyHostToDevice));
+	CK(hipMalloc(&d_out, (size_t)n_inst * nv * 12));
+	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	for (int mask : {0, 0}) {
+		CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_mask), &mask, sizeof(int)));
+		float best = 1e9f;
+		for (int it = 0; it < 5; ++it) {
+			CK(hipEventRecord(e0));
+			CK(launch_skin_vertices(0, d_inst, n_inst, nv, d_v, d_w, d_i, d_pal, d_out, false));
+			CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+			if (it && ms < best) best = ms;
+		}
+		printf("mask %2d (skip%s%s): %.4f ms  = %.3f ms per 1e9 verts\n", mask, mask & 8 ? " stores" : "", mask & 16 ? " lds" : "", best, best * 1e9 / ((double)n_inst * nv));
+	}
+	return 0;
+}

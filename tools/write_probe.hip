@@ -1,0 +1,45 @@
+// Development probe: pure-store bandwidth of one MI355X for the store shapes k_skin_vertices / k_pose_palette can use.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/write_probe.hip -o tools/_build/write_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+struct F3 { float x, y, z; };
+template <int NT> __global__ __launch_bounds__(256) void fill4(float4* p, size_t n, int per) {
+	size_t i = (size_t)blockIdx.x * 256 * per + threadIdx.x;
+	const float4 v = make_float4(1.f, 2.f, 3.f, (float)blockIdx.x);
+	for (int k = 0; k < per; ++k, i += 256) if (i < n) { if (NT) { typedef float v4 __attribute__((ext_vector_type(4))); __builtin_nontemporal_store(v4{v.x, v.y, v.z, v.w}, (v4*)(p + i)); } else p[i] = v; }
+}
+template <int NT> __global__ __launch_bounds__(256) void fill3(F3* p, size_t n, int per) {
+	size_t i = (size_t)blockIdx.x * 256 * per + threadIdx.x;
+	for (int k = 0; k < per; ++k, i += 256) if (i < n) {
+		if (NT) { float* f = (float*)(p + i); __builtin_nontemporal_store(1.f, f); __builtin_nontemporal_store(2.f, f + 1); __builtin_nontemporal_store((float)k, f + 2); }
+		else p[i] = F3{1.f, 2.f, (float)k};
+	}
+}
+__global__ __launch_bounds__(256) void copy4(const float4* __restrict__ a, float4* __restrict__ b, size_t n, int per) {
+	size_t i = (size_t)blockIdx.x * 256 * per + threadIdx.x;
+	for (int k = 0; k < per; ++k, i += 256) if (i < n) b[i] = a[i];
+}
+int main() {
+	const size_t bytes = (size_t)6 << 30;
+	char *a, *b; CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMemset(a, 0, bytes)); CK(hipMemset(b, 0, bytes));
+	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	auto time = [&](const char* name, auto launch, double moved) {
+		float best = 1e9f;
+		for (int it = 0; it < 4; ++it) { CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (it && ms < best) best = ms; }
+		printf("%-28s %8.3f ms  %7.1f GB/s\n", name, best, moved / best * 1e-6);
+	};
+	for (int per : {1, 4, 16}) {
+		const size_t n4 = bytes / 16, n3 = bytes / 12;
+		const unsigned g4 = (unsigned)((n4 + 256 * per - 1) / (256 * per)), g3 = (unsigned)((n3 + 256 * per - 1) / (256 * per));
+		printf("-- %d stores per thread\n", per);
+		time("fill float4", [&] { hipLaunchKernelGGL(fill4<0>, dim3(g4), dim3(256), 0, 0, (float4*)a, n4, per); }, (double)bytes);
+		time("fill float4 nt", [&] { hipLaunchKernelGGL(fill4<1>, dim3(g4), dim3(256), 0, 0, (float4*)a, n4, per); }, (double)bytes);
+		time("fill 12B", [&] { hipLaunchKernelGGL(fill3<0>, dim3(g3), dim3(256), 0, 0, (F3*)a, n3, per); }, (double)bytes);
+		time("fill 12B nt", [&] { hipLaunchKernelGGL(fill3<1>, dim3(g3), dim3(256), 0, 0, (F3*)a, n3, per); }, (double)bytes);
+		time("copy float4 (r+w bytes)", [&] { hipLaunchKernelGGL(copy4, dim3(g4), dim3(256), 0, 0, (const float4*)a, (float4*)b, n4, per); }, 2.0 * bytes);
+	}
+	time("hipMemsetAsync", [&] { CK(hipMemsetAsync(a, 1, bytes, 0)); }, (double)bytes);
+	return 0;
+}
