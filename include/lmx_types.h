@@ -103,6 +103,58 @@ enum {
 	LMX_MAX_BONES = 196              /* Model::Bone::MAX_COUNT, renderer/model.h:155 */
 };
 
+/* ---- createSortKeys inputs (renderer/pipeline.cpp:3789-3968) ---- */
+
+/* LODMeshIndices, renderer/model.h:129-133 */
+typedef struct LmxLodIndices {
+	int32_t from, to;
+} LmxLodIndices;
+
+/* The fields of Model that createSortKeys reads: m_lod_distances[MAX_LOD_COUNT] (squared distances, model.h:234),
+ * m_lod_indices[MAX_LOD_COUNT + 1] (model.h:233; entry 4 stays {0, -1}, model.cpp:98) and Mesh::type of its meshes. */
+typedef struct LmxKeysModel {
+	float lod_distances[4];
+	LmxLodIndices lod_indices[5];
+	uint32_t first_mesh; /* into the mesh-type table of lmx_keys_set_models */
+	uint32_t mesh_count;
+} LmxKeysModel;
+
+/* MeshMaterial (renderer/model.h:59-68) as createSortKeys sees it: sort_key and material->getLayer(). */
+typedef struct LmxMeshMaterial {
+	uint32_t sort_key;
+	uint8_t layer;
+	uint8_t _pad[3];
+} LmxMeshMaterial;
+
+enum { LMX_MESH_RIGID = 0, LMX_MESH_SKINNED = 1 };         /* Mesh::Type, renderer/model.h:86-89 */
+enum { LMX_MODEL_INSTANCE_MOVED = 1 << 3 };                  /* ModelInstance::MOVED, renderer/render_module.h:212 */
+
+/* DrawCommandTypes, renderer/pipeline.cpp:41-51 (bits 32..36 of a sort value) */
+enum {
+	LMX_DRAW_MESH = 0,
+	LMX_DRAW_AUTOINSTANCED = 1,
+	LMX_DRAW_SKINNED = 2,
+	LMX_DRAW_DECAL = 3,
+	LMX_DRAW_CURVE_DECAL = 4
+};
+#define LMX_SORT_KEY_BUCKET_SHIFT 56                         /* pipeline.cpp:70 */
+#define LMX_SORT_KEY_INSTANCED_FLAG (1ull << 55)             /* pipeline.cpp:71 */
+#define LMX_SORT_VALUE_INSTANCER_SHIFT 16                    /* pipeline.cpp:73 */
+#define LMX_SORT_VALUE_MESH_IDX_SHIFT 40                     /* pipeline.cpp:76 */
+#define LMX_SORT_VALUE_TYPE_SHIFT 32                         /* pipeline.cpp:77 */
+
+/* The per-view state createSortKeys reads (pipeline.cpp:3797-3832). */
+typedef struct LmxKeysView {
+	double camera_pos[3];             /* view.cp.pos */
+	double lod_ref_point[3];          /* m_viewport.pos */
+	float lod_multiplier;             /* Renderer::getLODMultiplier() */
+	float time_delta;                 /* Engine::getLastTimeDelta() */
+	uint32_t frame_number;            /* Renderer::frameNumber() % 0xffFFffFF */
+	uint8_t is_shadow;                /* view.cp.is_shadow */
+	uint8_t layer_to_bucket[255];     /* View::layer_to_bucket, 0xff = no bucket renders the layer (pipeline.cpp:1003-1020) */
+	uint8_t bucket_depth_sorted[256]; /* buckets[b].sort == BucketDesc::DEPTH */
+} LmxKeysView;
+
 #ifdef __cplusplus
 }
 #endif

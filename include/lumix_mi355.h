@@ -62,7 +62,8 @@ enum {
 	LMX_K_POSE_PALETTE = 4,
 	LMX_K_SKIN_VERTICES = 5,
 	LMX_K_CULL_DYNAMIC = 6,
-	LMX_K_COUNT = 7
+	LMX_K_SORT_KEYS = 7,
+	LMX_K_COUNT = 8
 };
 LMX_API int lmx_profile_enable(LmxContext* ctx, int enable);
 LMX_API int lmx_profile_reset(LmxContext* ctx);
@@ -197,6 +198,53 @@ LMX_API int lmx_frustum_perspective(const double pos[3], const float dir[3], con
 	float far_d, LmxShiftedFrustum* out);
 LMX_API int lmx_frustum_ortho(const double pos[3], const float dir[3], const float up[3], float width, float height, float near_d,
 	float far_d, LmxShiftedFrustum* out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Sort keys: PipelineImpl::createSortKeys (renderer/pipeline.cpp:3789-3968), the consumer of the visible list (SURVEY.md
+ * §8f rank 1). Runs on the device straight from a cull result (no read-back of the list): LOD selection per visible MESH
+ * entity (fp64 squared distance :3876, Model::getLODMeshIndices model.h:173-179, the ModelInstance::lod transition
+ * :3937-3957), one (SortKey, SortValue) pair per skinned / moved / depth-sorted mesh and per decal (:83-142), auto-instancer
+ * groups by mesh sort key (AutoInstancer::add :505-523) and one AUTOINSTANCED pair per non-empty group (:3958-3968), the
+ * list of model instances whose pose must be processed this frame (Pose::frame stamp :3889-3898) and the instances whose
+ * material overrides are dirty (:3879-3882). The reference runs one AutoInstancer per worker thread; the device run is the
+ * single-worker case (instancer index 0). Pair order is unspecified, as in the reference (per-worker page lists).
+ * ------------------------------------------------------------------------------------------------------------------ */
+LMX_API int lmx_keys_set_models(LmxContext* ctx, const LmxKeysModel* models, uint32_t n_models, const uint8_t* mesh_types, uint32_t n_meshes);
+/* Model instances by entity index (RenderModule::getModelInstances): model < 0 = entity has no model instance. Entity e's
+ * MeshMaterial span starts at mesh_materials[material_offset[e]] (ModelInstance::mesh_materials, indexed by mesh index). */
+LMX_API int lmx_keys_set_instances(LmxContext* ctx, uint32_t n_entities, const int32_t* model, const uint32_t* material_offset,
+	const LmxMeshMaterial* mesh_materials, uint32_t n_mesh_materials, const float* lod, const uint8_t* flags, const uint8_t* dirty,
+	const uint32_t* pose_frame);
+/* Decal / curve-decal materials by entity index: Material::getSortKey() and getLayer() (pipeline.cpp:83-89). */
+LMX_API int lmx_keys_set_decals(LmxContext* ctx, uint32_t n_entities, const uint32_t* decal_sort_key, const uint8_t* decal_layer,
+	const uint32_t* curve_sort_key, const uint8_t* curve_layer);
+/* World::getTransforms()[e].pos by entity index, from the host ... */
+LMX_API int lmx_keys_set_positions(LmxContext* ctx, const double* xyz, uint32_t n_entities);
+/* ... or read in place from the world hierarchy of this context (after lmx_world_propagate); 0 = back to the uploaded array. */
+LMX_API int lmx_keys_bind_world(LmxContext* ctx, int enable);
+/* createSortKeys for (view, frustum) of the last lmx_cull on that slot. max_sort_key = Renderer::getMaxSortKey(). Async. */
+LMX_API int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeysView* kv, uint32_t max_sort_key);
+/* Sorter::pack + radix sort by key (pipeline.cpp:411-440, radixSort): pairs in ascending key order, stable. */
+LMX_API int lmx_keys_sort(LmxContext* ctx);
+typedef struct LmxKeysCounts {
+	uint32_t pairs;            /* (key, value) pairs pushed to the sorter, AUTOINSTANCED ones included */
+	uint32_t instanced;        /* renderables added to auto-instancer groups */
+	uint32_t groups;           /* non-empty auto-instancer groups */
+	uint32_t poses;            /* model instances handed to the pose processor */
+	uint32_t dirty;            /* model instances queued for a material-override refresh */
+	uint32_t overflow;         /* != 0: an output buffer was too small (never with library-sized buffers) */
+} LmxKeysCounts;
+LMX_API int lmx_keys_counts(LmxContext* ctx, LmxKeysCounts* out); /* synchronizes the stream */
+LMX_API int lmx_keys_read_pairs(LmxContext* ctx, uint64_t* keys, uint64_t* values, uint32_t cap);
+/* Auto-instancer groups as CSR: group k (= mesh sort key k) holds values[offsets[k] .. offsets[k + 1]); offsets has
+ * max_sort_key + 2 entries. Order inside a group is unspecified. */
+LMX_API int lmx_keys_read_instancer(LmxContext* ctx, uint32_t* offsets, uint64_t* values, uint32_t cap_values);
+LMX_API int lmx_keys_read_poses(LmxContext* ctx, int32_t* entities, uint32_t cap);
+LMX_API int lmx_keys_read_dirty(LmxContext* ctx, int32_t* entities, uint32_t cap);
+/* ModelInstance::lod and Pose::frame after the run (both are updated in place on the device). */
+LMX_API int lmx_keys_read_state(LmxContext* ctx, float* lod, uint32_t* pose_frame, uint32_t n_entities);
+/* Device pointers of the last run for GPU consumers: pairs (keys, values, count on the device). */
+LMX_API int lmx_keys_device_pairs(LmxContext* ctx, const uint64_t** d_keys, const uint64_t** d_values, const uint32_t** d_count);
 
 LMX_API const char* lmx_version(void);
 

@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(PKG, "liblumix_mi355.so")
 MAX_FRUSTA, MAX_TYPES, MAX_VIEWS = 8, 8, 8
 TYPE_ALL = 0xFF
 (K_CULL_CLASSIFY, K_CULL_SPHERES, K_XFORM_LEVEL, K_SPHERE_REFRESH, K_POSE_PALETTE, K_SKIN_VERTICES, K_CULL_DYNAMIC) = range(7)
-KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices", "cull_dynamic"]
+KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices", "cull_dynamic", "sort_keys"]
 
 SHIFTED_FRUSTUM = np.dtype(
     [("xs", "<f4", 8), ("ys", "<f4", 8), ("zs", "<f4", 8), ("ds", "<f4", 8), ("points", "<f4", (8, 3)), ("origin", "<f8", 3), ("_pad", "<f8")],
@@ -34,6 +34,15 @@ TRANSFORM = np.dtype([("pos", "<f8", 3), ("rot", "<f4", 4), ("scale", "<f4", 3),
 LOCAL_RIGID = np.dtype([("pos", "<f4", 3), ("rot", "<f4", 4)], align=True)
 MATRIX = np.dtype([("columns", "<f4", (4, 4))], align=True)
 SKIN = np.dtype([("weights", "<f4", 4), ("indices", "<i2", 4)], align=True)
+LOD_INDICES = np.dtype([("from", "<i4"), ("to", "<i4")])
+KEYS_MODEL = np.dtype([("lod_distances", "<f4", 4), ("lod_indices", LOD_INDICES, 5), ("first_mesh", "<u4"), ("mesh_count", "<u4")], align=True)
+MESH_MATERIAL = np.dtype([("sort_key", "<u4"), ("layer", "u1"), ("_pad", "u1", 3)], align=True)
+KEYS_VIEW = np.dtype(
+    [("camera_pos", "<f8", 3), ("lod_ref_point", "<f8", 3), ("lod_multiplier", "<f4"), ("time_delta", "<f4"), ("frame_number", "<u4"), ("is_shadow", "u1"),
+     ("layer_to_bucket", "u1", 255), ("bucket_depth_sorted", "u1", 256)],
+    align=True,
+)
+KEYS_COUNTS = np.dtype([("pairs", "<u4"), ("instanced", "<u4"), ("groups", "<u4"), ("poses", "<u4"), ("dirty", "<u4"), ("overflow", "<u4")])
 VIEWPORT = np.dtype(
     [("is_ortho", "<i4"), ("fov", "<f4"), ("ortho_size", "<f4"), ("w", "<i4"), ("h", "<i4"), ("pos", "<f8", 3), ("rot", "<f4", 4), ("near_plane", "<f4"), ("far_plane", "<f4")],
     align=True,
@@ -90,6 +99,20 @@ SYMBOLS = {
     "lmx_skin_enable_dual_quats": (_ci, [_vp, _ci]),
     "lmx_skin_read_dual_quats": (_ci, [_vp, _u32, _vp, _u32]),
     "lmx_skin_read_pose": (_ci, [_vp, _u32, _vp, _vp, _u32]),
+    "lmx_keys_set_models": (_ci, [_vp, _vp, _u32, _vp, _u32]),
+    "lmx_keys_set_instances": (_ci, [_vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "lmx_keys_set_decals": (_ci, [_vp, _u32, _vp, _vp, _vp, _vp]),
+    "lmx_keys_set_positions": (_ci, [_vp, _vp, _u32]),
+    "lmx_keys_bind_world": (_ci, [_vp, _ci]),
+    "lmx_keys_run": (_ci, [_vp, _u32, _u32, _vp, _u32]),
+    "lmx_keys_sort": (_ci, [_vp]),
+    "lmx_keys_counts": (_ci, [_vp, _vp]),
+    "lmx_keys_read_pairs": (_ci, [_vp, _vp, _vp, _u32]),
+    "lmx_keys_read_instancer": (_ci, [_vp, _vp, _vp, _u32]),
+    "lmx_keys_read_poses": (_ci, [_vp, _vp, _u32]),
+    "lmx_keys_read_dirty": (_ci, [_vp, _vp, _u32]),
+    "lmx_keys_read_state": (_ci, [_vp, _vp, _vp, _u32]),
+    "lmx_keys_device_pairs": (_ci, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "lmx_viewport_frustum": (_ci, [_vp, _vp]),
     "lmx_frustum_perspective": (_ci, [_vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
     "lmx_frustum_ortho": (_ci, [_vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
@@ -388,6 +411,95 @@ class World:
         out = np.zeros(self.n, TRANSFORM)
         self.ctx.check(self.lib.lmx_world_read_transforms(self.ctx.h, _ptr(out), self.n))
         return out
+
+
+def keys_view(camera_pos=(0, 0, 0), lod_ref_point=None, lod_multiplier=1.0, time_delta=1 / 60, frame_number=1, is_shadow=False,
+              layer_to_bucket=None, bucket_depth_sorted=None) -> np.ndarray:
+    """LmxKeysView: the per-view state PipelineImpl::createSortKeys reads (pipeline.cpp:3797-3832)."""
+    kv = np.zeros(1, KEYS_VIEW)
+    kv["camera_pos"] = camera_pos
+    kv["lod_ref_point"] = camera_pos if lod_ref_point is None else lod_ref_point
+    kv["lod_multiplier"], kv["time_delta"], kv["frame_number"], kv["is_shadow"] = lod_multiplier, time_delta, frame_number, int(is_shadow)
+    kv["layer_to_bucket"] = 0xFF if layer_to_bucket is None else np.asarray(layer_to_bucket, np.uint8)
+    if bucket_depth_sorted is not None:
+        kv["bucket_depth_sorted"][0, : len(bucket_depth_sorted)] = np.asarray(bucket_depth_sorted, np.uint8)
+    return kv
+
+
+class SortKeys:
+    """PipelineImpl::createSortKeys (renderer/pipeline.cpp:3789-3968) on the visible list a cull left on the device."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.n_entities = 0
+        self.max_sort_key = 0
+
+    def setModels(self, models, mesh_types):
+        models = np.ascontiguousarray(models, KEYS_MODEL)
+        mesh_types = np.ascontiguousarray(mesh_types, np.uint8)
+        self.ctx.check(self.lib.lmx_keys_set_models(self.ctx.h, _ptr(models), len(models), _ptr(mesh_types), len(mesh_types)))
+
+    def setInstances(self, model, material_offset, mesh_materials, lod, flags, dirty, pose_frame):
+        model = np.ascontiguousarray(model, np.int32)
+        arrs = [np.ascontiguousarray(material_offset, np.uint32), np.ascontiguousarray(mesh_materials, MESH_MATERIAL), np.ascontiguousarray(lod, np.float32),
+                np.ascontiguousarray(flags, np.uint8), np.ascontiguousarray(dirty, np.uint8), np.ascontiguousarray(pose_frame, np.uint32)]
+        self.n_entities = len(model)
+        self.ctx.check(self.lib.lmx_keys_set_instances(self.ctx.h, len(model), _ptr(model), _ptr(arrs[0]), _ptr(arrs[1]), len(arrs[1]), _ptr(arrs[2]),
+                                                       _ptr(arrs[3]), _ptr(arrs[4]), _ptr(arrs[5])))
+
+    def setDecals(self, n_entities, decal_sort_key=None, decal_layer=None, curve_sort_key=None, curve_layer=None):
+        a = [None if x is None else np.ascontiguousarray(x, t) for x, t in ((decal_sort_key, np.uint32), (decal_layer, np.uint8), (curve_sort_key, np.uint32),
+                                                                             (curve_layer, np.uint8))]
+        self.ctx.check(self.lib.lmx_keys_set_decals(self.ctx.h, n_entities, *[None if x is None else _ptr(x) for x in a]))
+        self.n_entities = max(self.n_entities, n_entities)
+
+    def setPositions(self, xyz):
+        xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+        self.ctx.check(self.lib.lmx_keys_set_positions(self.ctx.h, _ptr(xyz), len(xyz)))
+
+    def bindWorld(self, on: bool = True):
+        self.ctx.check(self.lib.lmx_keys_bind_world(self.ctx.h, int(on)))
+
+    def run(self, kv, max_sort_key: int, view: int = 0, frustum: int = 0):
+        kv = np.ascontiguousarray(kv, KEYS_VIEW)
+        self.max_sort_key = int(max_sort_key)
+        self.ctx.check(self.lib.lmx_keys_run(self.ctx.h, view, frustum, _ptr(kv), self.max_sort_key))
+
+    def sort(self):
+        self.ctx.check(self.lib.lmx_keys_sort(self.ctx.h))
+
+    def counts(self) -> dict:
+        c = np.zeros(1, KEYS_COUNTS)
+        self.ctx.check(self.lib.lmx_keys_counts(self.ctx.h, _ptr(c)))
+        return {k: int(c[k][0]) for k in KEYS_COUNTS.names}
+
+    def readPairs(self):
+        n = self.counts()["pairs"]
+        keys, values = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        self.ctx.check(self.lib.lmx_keys_read_pairs(self.ctx.h, _ptr(keys), _ptr(values), n))
+        return keys, values
+
+    def readInstancer(self):
+        n = self.counts()["instanced"]
+        offsets, values = np.zeros(self.max_sort_key + 2, np.uint32), np.zeros(n, np.uint64)
+        self.ctx.check(self.lib.lmx_keys_read_instancer(self.ctx.h, _ptr(offsets), _ptr(values), n))
+        return offsets, values
+
+    def readPoses(self) -> np.ndarray:
+        out = np.zeros(self.counts()["poses"], np.int32)
+        self.ctx.check(self.lib.lmx_keys_read_poses(self.ctx.h, _ptr(out), len(out)))
+        return out
+
+    def readDirty(self) -> np.ndarray:
+        out = np.zeros(self.counts()["dirty"], np.int32)
+        self.ctx.check(self.lib.lmx_keys_read_dirty(self.ctx.h, _ptr(out), len(out)))
+        return out
+
+    def readState(self):
+        lod, frame = np.zeros(self.n_entities, np.float32), np.zeros(self.n_entities, np.uint32)
+        self.ctx.check(self.lib.lmx_keys_read_state(self.ctx.h, _ptr(lod), _ptr(frame), self.n_entities))
+        return lod, frame
 
 
 class Skinning:

@@ -1,0 +1,279 @@
+// keys_kernels.hip — PipelineImpl::createSortKeys (renderer/pipeline.cpp:3789-3968) on gfx950, straight from the visible list
+// a cull left in HBM.
+//
+//   k_keys_mesh      one lane per visible MESH entity: LOD selection (fp64 squared distance to the LOD reference point
+//                    :3876, Model::getLODMeshIndices model.h:173-179, the ModelInstance::lod transition :3937-3957) and
+//                    create_key (:3884-3935) for every mesh of the selected LOD range(s). The lanes of a wave walk their
+//                    mesh lists in lockstep so that every output append is ONE atomic per wave and list (ballot + mbcnt),
+//                    not one per element: returning atomics on one address serialise at ~90 per microsecond.
+//   k_keys_decal     DECAL / CURVE_DECAL pages (:3841-3868).
+//   k_keys_offsets   exclusive scan of the auto-instancer group sizes (AutoInstancer::instances, :452-523) -> CSR offsets
+//   k_keys_scatter   instancer records -> CSR values
+//   k_keys_groups    one AUTOINSTANCED pair per non-empty group (:3958-3968)
+// Integer work is bit-exact by construction; the two fp64 -> fp32 distances use the reference's operation order.
+#include "lmx_kernels.h"
+
+namespace lmx {
+
+namespace {
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t rank_in(uint64_t mask) {
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// wave-aggregated append: every lane with `want` gets a distinct index of a list whose length lives at *counter
+__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t* counter) {
+	const uint64_t mask = __ballot(want);
+	if (mask == 0) return 0;
+	uint32_t base = 0;
+	const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+	if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+	base = __shfl(base, (int)leader);
+	return base + rank_in(mask);
+}
+
+// histogram increment with one atomic per distinct key of the wave (a scene of one model puts every lane on one counter)
+__device__ __forceinline__ void wave_histogram(bool want, uint32_t key, uint32_t* hist) {
+	uint64_t todo = __ballot(want);
+	while (todo) {
+		const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+		const uint32_t k = (uint32_t)__shfl((int)key, (int)leader);
+		const uint64_t same = __ballot(want && key == k) & todo;
+		if (lane_id() == leader) atomicAdd(hist + k, (uint32_t)__popcll(same));
+		todo &= ~same;
+	}
+}
+
+__device__ __forceinline__ void load_pos(const KeysDevice& d, uint32_t e, double* x, double* y, double* z) {
+	if (d.slot_of_entity != nullptr) { // World::getTransforms()[e].pos out of the hierarchy's SoA
+		const int32_t s = d.slot_of_entity[e];
+		*x = d.wpx[s]; *y = d.wpy[s]; *z = d.wpz[s];
+	} else {
+		*x = d.pos_xyz[3 * (size_t)e]; *y = d.pos_xyz[3 * (size_t)e + 1]; *z = d.pos_xyz[3 * (size_t)e + 2];
+	}
+}
+
+// floatFlip, pipeline.cpp:57-60
+__device__ __forceinline__ uint32_t float_flip(uint32_t bits) {
+	const uint32_t mask = (uint32_t)(-(int32_t)(bits >> 31)) | 0x80000000u;
+	return bits ^ mask;
+}
+
+__global__ __launch_bounds__(256) void k_keys_mesh(KeysDevice d, const KeysViewDevice kv /* by value: captured at launch */, const int32_t* __restrict__ ids,
+	const uint32_t* __restrict__ n_visible) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	const uint32_t n = *n_visible;
+	if (i - (i & 63u) >= n) return; // whole wave past the end
+	// ranges of mesh indices this lane emits keys for: [from0, to0] then [from1, to1]
+	int32_t from0 = 0, to0 = -1, from1 = 0, to1 = -1;
+	uint32_t e = 0, mat0 = 0, first_mesh = 0;
+	bool moved = false, queue_dirty = false;
+	double px = 0, py = 0, pz = 0;
+	if (i < n) {
+		e = (uint32_t)ids[i];
+		const int32_t mdl = e < d.n_entities ? d.model[e] : -1;
+		if (mdl >= 0) {
+			const LmxKeysModel& m = d.models[mdl];
+			load_pos(d, e, &px, &py, &pz);
+			const double rx = px - kv.ref[0], ry = py - kv.ref[1], rz = pz - kv.ref[2];
+			const float squared_length = (float)(rx * rx + ry * ry + rz * rz); // float(squaredLength(pos - lod_ref_point)), math.cpp:397
+			const float sd = squared_length * kv.lod_multiplier_rcp;
+			uint32_t lod_idx = 4; // Model::getLODMeshIndices, model.h:173-179
+			if (sd < m.lod_distances[0]) lod_idx = 0;
+			else if (sd < m.lod_distances[1]) lod_idx = 1;
+			else if (sd < m.lod_distances[2]) lod_idx = 2;
+			else if (sd < m.lod_distances[3]) lod_idx = 3;
+			if (d.dirty[e]) {
+				queue_dirty = true; // queueMaterialOverrideRefresh(e); continue;  (:3879-3882)
+			} else {
+				mat0 = d.material_offset[e];
+				first_mesh = m.first_mesh;
+				moved = (d.flags[e] & LMX_MODEL_INSTANCE_MOVED) != 0;
+				float lod = d.lod[e];
+				if (lod != (float)lod_idx) { // :3937-3952
+					const float dl = (float)lod_idx - lod;
+					const float ad = fabsf(dl);
+					if (ad <= kv.time_delta) {
+						d.lod[e] = (float)lod_idx;
+						from0 = m.lod_indices[lod_idx].from; to0 = m.lod_indices[lod_idx].to;
+					} else {
+						if (!kv.is_shadow) { lod = lod + dl / ad * kv.time_delta; d.lod[e] = lod; }
+						const uint32_t cur = (uint32_t)lod;
+						from0 = m.lod_indices[cur].from; to0 = m.lod_indices[cur].to;
+						if (cur < 3) { from1 = m.lod_indices[cur + 1].from; to1 = m.lod_indices[cur + 1].to; }
+					}
+				} else {
+					from0 = m.lod_indices[lod_idx].from; to0 = m.lod_indices[lod_idx].to;
+				}
+			}
+		}
+	}
+	{
+		const uint32_t idx = wave_append(queue_dirty, d.counters + KEYS_N_DIRTY);
+		if (queue_dirty) { if (idx < d.cap_list) d.dirty_list[idx] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
+	}
+	const int32_t len0 = to0 >= from0 ? to0 - from0 + 1 : 0, len1 = to1 >= from1 ? to1 - from1 + 1 : 0;
+	for (int32_t it = 0; __ballot(it < len0 + len1) != 0; ++it) {
+		const bool has = it < len0 + len1;
+		const int32_t mesh_idx = it < len0 ? from0 + it : from1 + (it - len0);
+		bool push_pair = false, add_inst = false, push_pose = false;
+		uint64_t key = 0, value = 0;
+		uint32_t mesh_sort_key = 0;
+		if (has) { // create_key, :3884-3935
+			const LmxMeshMaterial mm = d.mesh_materials[mat0 + (uint32_t)mesh_idx];
+			const uint32_t bucket = kv.bucket_map[mm.layer];
+			mesh_sort_key = mm.sort_key;
+			if (d.mesh_types[first_mesh + (uint32_t)mesh_idx] == LMX_MESH_SKINNED) {
+				// Pose::frame stamp (:3889-3898): exactly one visit per frame hands the instance to the pose processor
+				if (d.pose_frame[e] != kv.frame_number) push_pose = atomicExch(d.pose_frame + e, kv.frame_number) != kv.frame_number;
+				value = (uint64_t)e | ((uint64_t)LMX_DRAW_SKINNED << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
+				key = (uint64_t)mm.sort_key | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT); // makeMeshSortKey(mesh_mat, u8 bucket)
+				push_pair = true;
+			} else if (moved && !kv.is_shadow) {
+				value = (uint64_t)e | ((uint64_t)LMX_DRAW_MESH << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
+				key = (uint64_t)mm.sort_key | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT);
+				push_pair = true;
+			} else if (bucket < 0xffu) {
+				value = (uint64_t)e | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT); // instancer.add(mesh_sort_key, value)
+				add_inst = true;
+			} else if (bucket < 0xffffu) { // depth sorted
+				const double cx = px - kv.cam[0], cy = py - kv.cam[1], cz = pz - kv.cam[2];
+				const float sl = (float)(cx * cx + cy * cy + cz * cz);
+				value = (uint64_t)e | ((uint64_t)LMX_DRAW_MESH << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
+				key = (uint64_t)float_flip(__float_as_uint(sl)) | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT); // makeDepthSortKey
+				push_pair = true;
+			}
+		}
+		uint32_t idx = wave_append(push_pair, d.counters + KEYS_N_PAIRS);
+		if (push_pair) { if (idx < d.cap_pairs) { d.keys[idx] = key; d.values[idx] = value; } else d.counters[KEYS_OVERFLOW] = 1; }
+		idx = wave_append(add_inst, d.counters + KEYS_N_RECS);
+		if (add_inst) { if (idx < d.cap_recs) { d.rec_key[idx] = mesh_sort_key; d.rec_value[idx] = value; } else d.counters[KEYS_OVERFLOW] = 1; }
+		const bool in_range = add_inst && mesh_sort_key <= d.max_sort_key;
+		if (add_inst && !in_range) d.counters[KEYS_OVERFLOW] = 2; // a mesh sort key above Renderer::getMaxSortKey(): the reference indexes out of bounds
+		wave_histogram(in_range, mesh_sort_key, d.group_count);
+		idx = wave_append(push_pose, d.counters + KEYS_N_POSES);
+		if (push_pose) { if (idx < d.cap_list) d.poses[idx] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
+	}
+}
+
+__global__ __launch_bounds__(256) void k_keys_decal(KeysDevice d, const KeysViewDevice kv, const int32_t* __restrict__ ids,
+	const uint32_t* __restrict__ n_visible, const uint32_t* __restrict__ sort_key, const uint8_t* __restrict__ layer, uint32_t draw_type) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	const uint32_t n = *n_visible;
+	if (i - (i & 63u) >= n) return;
+	bool push = false;
+	uint64_t key = 0, value = 0;
+	if (i < n) {
+		const uint32_t e = (uint32_t)ids[i];
+		if (e < d.n_entities) {
+			const uint8_t bucket = (uint8_t)kv.bucket_map[layer[e]]; // const u8 bucket = bucket_map[layer], :3845
+			if (bucket < 0xff) {
+				key = (uint64_t)sort_key[e] | ((uint64_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT); // makeDecalSortKey, :83-89
+				value = (uint64_t)e | ((uint64_t)draw_type << LMX_SORT_VALUE_TYPE_SHIFT);      // make(Curve)DecalSortValue, :125-131
+				push = true;
+			}
+		}
+	}
+	const uint32_t idx = wave_append(push, d.counters + KEYS_N_PAIRS);
+	if (push) { if (idx < d.cap_pairs) { d.keys[idx] = key; d.values[idx] = value; } else d.counters[KEYS_OVERFLOW] = 1; }
+}
+
+// one block: offsets[k] = sum of group_count[0..k), offsets[n_groups] = total; cursor[] zeroed; non-empty groups counted
+__global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
+	__shared__ uint32_t s_wave[16];
+	__shared__ uint32_t s_carry;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t n = d.max_sort_key + 1;
+	if (tid == 0) s_carry = 0;
+	__syncthreads();
+	uint32_t non_empty = 0;
+	for (uint32_t base = 0; base < n; base += 1024) {
+		const uint32_t k = base + tid;
+		const uint32_t c = k < n ? d.group_count[k] : 0;
+		non_empty += c != 0;
+		uint32_t incl = c; // inclusive scan inside the wave
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+			if (lane >= (uint32_t)o) incl += up;
+		}
+		if (lane == 63) s_wave[wave] = incl;
+		__syncthreads();
+		uint32_t before = s_carry;
+		for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
+		if (k < n) { d.group_offset[k] = before + incl - c; d.group_cursor[k] = 0; }
+		__syncthreads();
+		if (tid == 1023) s_carry = before + incl;
+		__syncthreads();
+	}
+	if (tid == 0) d.group_offset[n] = s_carry;
+	const uint64_t any = __ballot(true);
+	(void)any;
+	uint32_t total = non_empty;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) total += (uint32_t)__shfl_down((int)total, o);
+	if (lane == 0 && total) atomicAdd(d.counters + KEYS_N_GROUPS, total);
+}
+
+__global__ __launch_bounds__(256) void k_keys_scatter(KeysDevice d) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	const uint32_t n = min(d.counters[KEYS_N_RECS], d.cap_recs);
+	if (i - (i & 63u) >= n) return;
+	const bool has = i < n && d.rec_key[i] <= d.max_sort_key;
+	const uint32_t key = has ? d.rec_key[i] : 0;
+	// one cursor atomic per distinct key of the wave
+	uint64_t todo = __ballot(has);
+	uint32_t slot = 0;
+	while (todo) {
+		const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+		const uint32_t k = (uint32_t)__shfl((int)key, (int)leader);
+		const uint64_t same = __ballot(has && key == k) & todo;
+		uint32_t base = 0;
+		if (lane_id() == leader) base = atomicAdd(d.group_cursor + k, (uint32_t)__popcll(same));
+		base = (uint32_t)__shfl((int)base, (int)leader);
+		if (has && key == k && ((same >> lane_id()) & 1ull)) slot = d.group_offset[k] + base + rank_in(same);
+		todo &= ~same;
+	}
+	if (has) d.group_values[slot] = d.rec_value[i];
+}
+
+__global__ __launch_bounds__(256) void k_keys_groups(KeysDevice d, const KeysViewDevice kv) {
+	const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+	const uint32_t n = d.max_sort_key + 1;
+	if (k - (k & 63u) >= n) return;
+	bool push = false;
+	uint64_t key = 0, value = 0;
+	if (k < n && d.group_count[k] != 0) { // :3958-3968, instancer index 0
+		const uint64_t renderable = d.group_values[d.group_offset[k]]; // instances[i].begin->renderables[0]: any member, they share the material
+		const uint32_t entity_index = (uint32_t)(renderable & 0xffFFffull);
+		const uint32_t mesh_idx = (uint32_t)(renderable >> LMX_SORT_VALUE_MESH_IDX_SHIFT);
+		const uint8_t layer = d.mesh_materials[d.material_offset[entity_index] + mesh_idx].layer;
+		const uint8_t bucket = kv.layer_to_bucket[layer];
+		value = (uint64_t)k | ((uint64_t)LMX_DRAW_AUTOINSTANCED << LMX_SORT_VALUE_TYPE_SHIFT);               // makeAutoInstancedSortValue(i, 0)
+		key = (uint64_t)k | LMX_SORT_KEY_INSTANCED_FLAG | ((uint64_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT);  // makeAutoInstancedSortKey(i, bucket)
+		push = true;
+	}
+	const uint32_t idx = wave_append(push, d.counters + KEYS_N_PAIRS);
+	if (push) { if (idx < d.cap_pairs) { d.keys[idx] = key; d.values[idx] = value; } else d.counters[KEYS_OVERFLOW] = 1; }
+}
+
+} // namespace
+
+hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const int32_t* mesh_ids, const uint32_t* mesh_count,
+	uint32_t mesh_cap, const int32_t* decal_ids, const uint32_t* decal_count, uint32_t decal_cap, const int32_t* curve_ids,
+	const uint32_t* curve_count, uint32_t curve_cap) {
+	if (mesh_cap && d.model != nullptr) hipLaunchKernelGGL(k_keys_mesh, dim3((mesh_cap + 255) / 256), dim3(256), 0, s, d, view, mesh_ids, mesh_count);
+	if (decal_cap && d.decal_sort_key != nullptr)
+		hipLaunchKernelGGL(k_keys_decal, dim3((decal_cap + 255) / 256), dim3(256), 0, s, d, view, decal_ids, decal_count, d.decal_sort_key, d.decal_layer,
+			(uint32_t)LMX_DRAW_DECAL);
+	if (curve_cap && d.curve_sort_key != nullptr)
+		hipLaunchKernelGGL(k_keys_decal, dim3((curve_cap + 255) / 256), dim3(256), 0, s, d, view, curve_ids, curve_count, d.curve_sort_key, d.curve_layer,
+			(uint32_t)LMX_DRAW_CURVE_DECAL);
+	hipLaunchKernelGGL(k_keys_offsets, dim3(1), dim3(1024), 0, s, d);
+	if (d.cap_recs) hipLaunchKernelGGL(k_keys_scatter, dim3((d.cap_recs + 255) / 256), dim3(256), 0, s, d);
+	hipLaunchKernelGGL(k_keys_groups, dim3((d.max_sort_key + 256) / 256), dim3(256), 0, s, d, view);
+	return hipGetLastError();
+}
+
+} // namespace lmx

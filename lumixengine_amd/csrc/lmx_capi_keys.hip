@@ -1,0 +1,308 @@
+// lmx_capi_keys.hip — createSortKeys entry points (include/lumix_mi355.h, "sort keys" section): model / instance / material
+// tables, the per-view state, the launch chain of keys_kernels.hip and the read-backs.
+#include "lmx_context.h"
+
+#include <hipcub/hipcub.hpp>
+
+using namespace lmx;
+
+namespace {
+
+template <typename T> int upload(LmxContext* ctx, DevBuf<T>& buf, const T* src, size_t n) {
+	LMX_HIP(ctx, buf.reserve(std::max<size_t>(n, 1)));
+	if (n) LMX_HIP(ctx, hipMemcpyAsync(buf.p, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+	return LMX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int lmx_keys_set_models(LmxContext* ctx, const LmxKeysModel* models, uint32_t n_models, const uint8_t* mesh_types, uint32_t n_meshes) {
+	LMX_CHECK_CTX(ctx);
+	if ((n_models && !models) || (n_meshes && !mesh_types)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null model / mesh-type table");
+	KeysState& ks = ctx->keys;
+	uint32_t max_span = 1;
+	for (uint32_t i = 0; i < n_models; ++i) {
+		const LmxKeysModel& m = models[i];
+		if ((uint64_t)m.first_mesh + m.mesh_count > n_meshes) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "model %u: meshes [%u, +%u) outside the mesh-type table", i, m.first_mesh, m.mesh_count);
+		for (int l = 0; l < 5; ++l) {
+			const LmxLodIndices& li = m.lod_indices[l];
+			if (li.to < li.from) continue;
+			if (li.from < 0 || (uint32_t)li.to >= m.mesh_count) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "model %u: LOD %d = [%d, %d] outside its %u meshes", i, l, li.from, li.to, m.mesh_count);
+			max_span = std::max<uint32_t>(max_span, (uint32_t)(li.to - li.from + 1));
+		}
+	}
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (int rc = upload(ctx, ks.d_models, models, n_models)) return rc;
+	if (int rc = upload(ctx, ks.d_mesh_types, mesh_types, n_meshes)) return rc;
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	ks.models.assign(models, models + n_models);
+	ks.n_meshes = n_meshes;
+	ks.max_lod_span = max_span;
+	return LMX_OK;
+}
+
+int lmx_keys_set_instances(LmxContext* ctx, uint32_t n_entities, const int32_t* model, const uint32_t* material_offset,
+	const LmxMeshMaterial* mesh_materials, uint32_t n_mesh_materials, const float* lod, const uint8_t* flags, const uint8_t* dirty,
+	const uint32_t* pose_frame) {
+	LMX_CHECK_CTX(ctx);
+	if (n_entities && (!model || !material_offset || !lod || !flags || !dirty || !pose_frame)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null instance table");
+	if (n_mesh_materials && !mesh_materials) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null mesh-material table");
+	KeysState& ks = ctx->keys;
+	for (uint32_t e = 0; e < n_entities; ++e) {
+		if (model[e] < 0) continue;
+		if ((size_t)model[e] >= ks.models.size()) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %u: unknown model %d (lmx_keys_set_models first)", e, model[e]);
+		if ((uint64_t)material_offset[e] + ks.models[model[e]].mesh_count > n_mesh_materials)
+			return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %u: mesh materials [%u, +%u) outside the table", e, material_offset[e], ks.models[model[e]].mesh_count);
+		if (!(lod[e] >= 0.f && lod[e] <= 4.f)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %u: ModelInstance::lod %g outside [0, 4]", e, (double)lod[e]);
+	}
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (int rc = upload(ctx, ks.d_model, model, n_entities)) return rc;
+	if (int rc = upload(ctx, ks.d_material_offset, material_offset, n_entities)) return rc;
+	if (int rc = upload(ctx, ks.d_mesh_materials, mesh_materials, n_mesh_materials)) return rc;
+	if (int rc = upload(ctx, ks.d_lod, lod, n_entities)) return rc;
+	if (int rc = upload(ctx, ks.d_flags, flags, n_entities)) return rc;
+	if (int rc = upload(ctx, ks.d_dirty, dirty, n_entities)) return rc;
+	if (int rc = upload(ctx, ks.d_pose_frame, pose_frame, n_entities)) return rc;
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	ks.n_entities = n_entities;
+	ks.have_instances = true;
+	return LMX_OK;
+}
+
+int lmx_keys_set_decals(LmxContext* ctx, uint32_t n_entities, const uint32_t* decal_sort_key, const uint8_t* decal_layer,
+	const uint32_t* curve_sort_key, const uint8_t* curve_layer) {
+	LMX_CHECK_CTX(ctx);
+	if ((decal_sort_key == nullptr) != (decal_layer == nullptr) || (curve_sort_key == nullptr) != (curve_layer == nullptr))
+		return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "sort-key and layer tables come in pairs");
+	KeysState& ks = ctx->keys;
+	if (ks.have_instances && n_entities != ks.n_entities) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "decal tables cover %u entities, instance tables %u", n_entities, ks.n_entities);
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	ks.have_decals = decal_sort_key != nullptr;
+	ks.have_curves = curve_sort_key != nullptr;
+	if (ks.have_decals) {
+		if (int rc = upload(ctx, ks.d_decal_key, decal_sort_key, n_entities)) return rc;
+		if (int rc = upload(ctx, ks.d_decal_layer, decal_layer, n_entities)) return rc;
+	}
+	if (ks.have_curves) {
+		if (int rc = upload(ctx, ks.d_curve_key, curve_sort_key, n_entities)) return rc;
+		if (int rc = upload(ctx, ks.d_curve_layer, curve_layer, n_entities)) return rc;
+	}
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (!ks.have_instances) ks.n_entities = n_entities;
+	return LMX_OK;
+}
+
+int lmx_keys_set_positions(LmxContext* ctx, const double* xyz, uint32_t n_entities) {
+	LMX_CHECK_CTX(ctx);
+	if (n_entities && !xyz) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null positions");
+	KeysState& ks = ctx->keys;
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (int rc = upload(ctx, ks.d_pos, xyz, (size_t)n_entities * 3)) return rc;
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	ks.n_positions = n_entities;
+	return LMX_OK;
+}
+
+int lmx_keys_bind_world(LmxContext* ctx, int enable) {
+	LMX_CHECK_CTX(ctx);
+	ctx->keys.use_world = enable != 0;
+	return LMX_OK;
+}
+
+int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeysView* kv, uint32_t max_sort_key) {
+	LMX_CHECK_CTX(ctx);
+	if (!kv) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null view state");
+	if (view >= LMX_MAX_VIEWS) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad view");
+	if (max_sort_key >= (1u << 24)) return fail(ctx, LMX_ERR_CAPACITY, "max_sort_key %u: mesh sort keys occupy 24 bits (pipeline.cpp:66)", max_sort_key);
+	KeysState& ks = ctx->keys;
+	CullView& v = ctx->cull.views[view];
+	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
+	if (frustum >= v.n_frusta) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "frustum %u out of range", frustum);
+	if (!ks.have_instances && !ks.have_decals && !ks.have_curves) return fail(ctx, LMX_ERR_NOT_BUILT, "no instance / decal tables uploaded");
+	const WorldState& w = ctx->world;
+	if (ks.use_world) {
+		if (w.slot_of_entity.size() < ks.n_entities) return fail(ctx, LMX_ERR_NOT_BUILT, "world hierarchy covers %zu entities, instance tables %u", w.slot_of_entity.size(), ks.n_entities);
+	} else if (ks.have_instances && ks.n_positions < ks.n_entities) {
+		return fail(ctx, LMX_ERR_NOT_BUILT, "positions cover %u entities, instance tables %u", ks.n_positions, ks.n_entities);
+	}
+	// bucket_map, pipeline.cpp:3802-3812
+	KeysViewDevice hv;
+	memset(&hv, 0, sizeof(hv));
+	for (uint32_t i = 0; i < 255; ++i) {
+		uint32_t b = kv->layer_to_bucket[i];
+		if (b == 0xff) b = 0xffFFffFFu;
+		else if (kv->bucket_depth_sorted[b]) b |= 0x100;
+		hv.bucket_map[i] = b;
+		hv.layer_to_bucket[i] = kv->layer_to_bucket[i];
+	}
+	hv.is_shadow = kv->is_shadow != 0;
+	for (int k = 0; k < 3; ++k) { hv.cam[k] = kv->camera_pos[k]; hv.ref[k] = kv->lod_ref_point[k]; }
+	hv.lod_multiplier_rcp = 1 / kv->lod_multiplier; // const float global_lod_multiplier_rcp = 1 / global_lod_multiplier, :3799
+	hv.time_delta = kv->time_delta;
+	hv.frame_number = kv->frame_number;
+
+	auto seg_cap = [&](int t) { return (t + 1 < MAX_TYPES ? v.out_start[t + 1] : v.out_stride) - v.out_start[t]; };
+	const uint32_t mesh_cap = ks.have_instances ? seg_cap(LMX_TYPE_MESH) : 0, decal_cap = ks.have_decals ? seg_cap(LMX_TYPE_DECAL) : 0,
+		curve_cap = ks.have_curves ? seg_cap(LMX_TYPE_CURVE_DECAL) : 0;
+	// worst case: every visible mesh entity is between two LODs and pushes every mesh of both
+	const size_t cap_recs = (size_t)mesh_cap * ks.max_lod_span * 2;
+	const size_t cap_pairs = cap_recs + decal_cap + curve_cap + max_sort_key + 1;
+	if (cap_pairs > 0xffffffffull) return fail(ctx, LMX_ERR_CAPACITY, "sort-key capacity %zu exceeds 32 bits", cap_pairs);
+	LMX_HIP(ctx, ks.d_keys.reserve(std::max<size_t>(cap_pairs, 1)));
+	LMX_HIP(ctx, ks.d_values.reserve(std::max<size_t>(cap_pairs, 1)));
+	LMX_HIP(ctx, ks.d_rec_key.reserve(std::max<size_t>(cap_recs, 1)));
+	LMX_HIP(ctx, ks.d_rec_value.reserve(std::max<size_t>(cap_recs, 1)));
+	LMX_HIP(ctx, ks.d_group_values.reserve(std::max<size_t>(cap_recs, 1)));
+	LMX_HIP(ctx, ks.d_groups.reserve((size_t)(max_sort_key + 2) * 3));
+	LMX_HIP(ctx, ks.d_poses.reserve(std::max<size_t>(mesh_cap, 1)));
+	LMX_HIP(ctx, ks.d_dirty_list.reserve(std::max<size_t>(mesh_cap, 1)));
+	LMX_HIP(ctx, ks.d_counters.reserve(KEYS_COUNTERS));
+
+	ProfScope ps(ctx, LMX_K_SORT_KEYS);
+	LMX_HIP(ctx, hipMemsetAsync(ks.d_counters.p, 0, KEYS_COUNTERS * sizeof(uint32_t), ctx->stream));
+	LMX_HIP(ctx, hipMemsetAsync(ks.d_groups.p, 0, (size_t)(max_sort_key + 1) * sizeof(uint32_t), ctx->stream));
+	KeysDevice d;
+	memset(&d, 0, sizeof(d));
+	d.n_entities = ks.n_entities;
+	if (ks.have_instances) {
+		d.model = ks.d_model.p; d.material_offset = ks.d_material_offset.p; d.mesh_materials = ks.d_mesh_materials.p; d.models = ks.d_models.p;
+		d.mesh_types = ks.d_mesh_types.p; d.lod = ks.d_lod.p; d.flags = ks.d_flags.p; d.dirty = ks.d_dirty.p; d.pose_frame = ks.d_pose_frame.p;
+	}
+	if (ks.have_decals) { d.decal_sort_key = ks.d_decal_key.p; d.decal_layer = ks.d_decal_layer.p; }
+	if (ks.have_curves) { d.curve_sort_key = ks.d_curve_key.p; d.curve_layer = ks.d_curve_layer.p; }
+	if (ks.use_world) {
+		d.wpx = ctx->world.pos[3].p; d.wpy = ctx->world.pos[4].p; d.wpz = ctx->world.pos[5].p;
+		d.slot_of_entity = ctx->world.d_slot_of_entity.p;
+	} else {
+		d.pos_xyz = ks.d_pos.p;
+	}
+	d.keys = ks.d_keys.p; d.values = ks.d_values.p; d.cap_pairs = (uint32_t)cap_pairs;
+	d.rec_key = ks.d_rec_key.p; d.rec_value = ks.d_rec_value.p; d.cap_recs = (uint32_t)cap_recs;
+	d.max_sort_key = max_sort_key;
+	d.group_count = ks.d_groups.p; d.group_offset = ks.d_groups.p + (max_sort_key + 2); d.group_cursor = ks.d_groups.p + 2 * (size_t)(max_sort_key + 2);
+	d.group_values = ks.d_group_values.p;
+	d.poses = ks.d_poses.p; d.dirty_list = ks.d_dirty_list.p; d.cap_list = mesh_cap;
+	d.counters = ks.d_counters.p;
+	const int32_t* row = v.out_ptr() + (size_t)frustum * v.out_stride;
+	const uint32_t* counts = v.counts_ptr() + (size_t)frustum * MAX_TYPES;
+	LMX_HIP(ctx, launch_keys(ctx->stream, d, hv, row + v.out_start[LMX_TYPE_MESH], counts + LMX_TYPE_MESH, mesh_cap, row + v.out_start[LMX_TYPE_DECAL],
+		counts + LMX_TYPE_DECAL, decal_cap, row + v.out_start[LMX_TYPE_CURVE_DECAL], counts + LMX_TYPE_CURVE_DECAL, curve_cap));
+	ks.max_sort_key = max_sort_key;
+	ks.ran = true;
+	ks.sorted = false;
+	return LMX_OK;
+}
+
+static int keys_host_counters(LmxContext* ctx, uint32_t* c) {
+	KeysState& ks = ctx->keys;
+	if (!ks.ran) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_keys_run has not run");
+	LMX_HIP(ctx, hipMemcpyAsync(c, ks.d_counters.p, KEYS_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+int lmx_keys_counts(LmxContext* ctx, LmxKeysCounts* out) {
+	LMX_CHECK_CTX(ctx);
+	if (!out) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null out");
+	uint32_t c[KEYS_COUNTERS];
+	if (int rc = keys_host_counters(ctx, c)) return rc;
+	out->pairs = c[KEYS_N_PAIRS]; out->instanced = c[KEYS_N_RECS]; out->groups = c[KEYS_N_GROUPS]; out->poses = c[KEYS_N_POSES];
+	out->dirty = c[KEYS_N_DIRTY]; out->overflow = c[KEYS_OVERFLOW];
+	return LMX_OK;
+}
+
+int lmx_keys_sort(LmxContext* ctx) {
+	LMX_CHECK_CTX(ctx);
+	KeysState& ks = ctx->keys;
+	uint32_t c[KEYS_COUNTERS];
+	if (int rc = keys_host_counters(ctx, c)) return rc;
+	if (c[KEYS_OVERFLOW]) return fail(ctx, LMX_ERR_CAPACITY, "sort-key output overflowed (code %u)", c[KEYS_OVERFLOW]);
+	const uint32_t n = c[KEYS_N_PAIRS];
+	if (n > 1) {
+		LMX_HIP(ctx, ks.d_keys_alt.reserve(n));
+		LMX_HIP(ctx, ks.d_values_alt.reserve(n));
+		size_t temp = 0;
+		LMX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, temp, ks.d_keys.p, ks.d_keys_alt.p, ks.d_values.p, ks.d_values_alt.p, (int)n, 0, 64, ctx->stream));
+		LMX_HIP(ctx, ks.d_sort_temp.reserve(temp));
+		ProfScope ps(ctx, LMX_K_SORT_KEYS);
+		LMX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(ks.d_sort_temp.p, temp, ks.d_keys.p, ks.d_keys_alt.p, ks.d_values.p, ks.d_values_alt.p, (int)n, 0, 64, ctx->stream));
+		LMX_HIP(ctx, hipMemcpyAsync(ks.d_keys.p, ks.d_keys_alt.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+		LMX_HIP(ctx, hipMemcpyAsync(ks.d_values.p, ks.d_values_alt.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+	}
+	ks.sorted = true;
+	return LMX_OK;
+}
+
+int lmx_keys_read_pairs(LmxContext* ctx, uint64_t* keys, uint64_t* values, uint32_t cap) {
+	LMX_CHECK_CTX(ctx);
+	KeysState& ks = ctx->keys;
+	uint32_t c[KEYS_COUNTERS];
+	if (int rc = keys_host_counters(ctx, c)) return rc;
+	if (c[KEYS_OVERFLOW]) return fail(ctx, LMX_ERR_CAPACITY, "sort-key output overflowed (code %u)", c[KEYS_OVERFLOW]);
+	const uint32_t n = c[KEYS_N_PAIRS];
+	if (cap < n) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u pairs", n);
+	if (n && keys) LMX_HIP(ctx, hipMemcpyAsync(keys, ks.d_keys.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+	if (n && values) LMX_HIP(ctx, hipMemcpyAsync(values, ks.d_values.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+int lmx_keys_read_instancer(LmxContext* ctx, uint32_t* offsets, uint64_t* values, uint32_t cap_values) {
+	LMX_CHECK_CTX(ctx);
+	KeysState& ks = ctx->keys;
+	uint32_t c[KEYS_COUNTERS];
+	if (int rc = keys_host_counters(ctx, c)) return rc;
+	if (c[KEYS_OVERFLOW]) return fail(ctx, LMX_ERR_CAPACITY, "sort-key output overflowed (code %u)", c[KEYS_OVERFLOW]);
+	const uint32_t n = c[KEYS_N_RECS];
+	if (values && cap_values < n) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u instanced renderables", n);
+	if (offsets) LMX_HIP(ctx, hipMemcpyAsync(offsets, ks.d_groups.p + (ks.max_sort_key + 2), (size_t)(ks.max_sort_key + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	if (values && n) LMX_HIP(ctx, hipMemcpyAsync(values, ks.d_group_values.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+static int keys_read_list(LmxContext* ctx, int which, const int32_t* src, int32_t* entities, uint32_t cap) {
+	uint32_t c[KEYS_COUNTERS];
+	if (int rc = keys_host_counters(ctx, c)) return rc;
+	if (c[KEYS_OVERFLOW]) return fail(ctx, LMX_ERR_CAPACITY, "sort-key output overflowed (code %u)", c[KEYS_OVERFLOW]);
+	const uint32_t n = c[which];
+	if (cap < n) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u entities", n);
+	if (n && entities) LMX_HIP(ctx, hipMemcpyAsync(entities, src, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+int lmx_keys_read_poses(LmxContext* ctx, int32_t* entities, uint32_t cap) {
+	LMX_CHECK_CTX(ctx);
+	return keys_read_list(ctx, KEYS_N_POSES, ctx->keys.d_poses.p, entities, cap);
+}
+
+int lmx_keys_read_dirty(LmxContext* ctx, int32_t* entities, uint32_t cap) {
+	LMX_CHECK_CTX(ctx);
+	return keys_read_list(ctx, KEYS_N_DIRTY, ctx->keys.d_dirty_list.p, entities, cap);
+}
+
+int lmx_keys_read_state(LmxContext* ctx, float* lod, uint32_t* pose_frame, uint32_t n_entities) {
+	LMX_CHECK_CTX(ctx);
+	KeysState& ks = ctx->keys;
+	if (!ks.have_instances) return fail(ctx, LMX_ERR_NOT_BUILT, "no instance tables uploaded");
+	if (n_entities != ks.n_entities) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "expected %u entities", ks.n_entities);
+	if (lod && n_entities) LMX_HIP(ctx, hipMemcpyAsync(lod, ks.d_lod.p, (size_t)n_entities * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+	if (pose_frame && n_entities) LMX_HIP(ctx, hipMemcpyAsync(pose_frame, ks.d_pose_frame.p, (size_t)n_entities * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+int lmx_keys_device_pairs(LmxContext* ctx, const uint64_t** d_keys, const uint64_t** d_values, const uint32_t** d_count) {
+	LMX_CHECK_CTX(ctx);
+	KeysState& ks = ctx->keys;
+	if (!ks.ran) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_keys_run has not run");
+	if (d_keys) *d_keys = ks.d_keys.p;
+	if (d_values) *d_values = ks.d_values.p;
+	if (d_count) *d_count = ks.d_counters.p + KEYS_N_PAIRS;
+	return LMX_OK;
+}
+
+} // extern "C"

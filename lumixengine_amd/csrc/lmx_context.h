@@ -195,6 +195,29 @@ struct SkinState {
 };
 
 
+// createSortKeys (lmx_capi_keys.hip): entity-indexed model-instance tables, decal material tables, outputs of the last run
+struct KeysState {
+	std::vector<LmxKeysModel> models;
+	uint32_t n_meshes = 0, max_lod_span = 1;
+	uint32_t n_entities = 0, n_positions = 0, max_sort_key = 0;
+	bool have_instances = false, have_decals = false, have_curves = false, use_world = false, ran = false, sorted = false;
+	DevBuf<LmxKeysModel> d_models;
+	DevBuf<uint8_t> d_mesh_types;
+	DevBuf<int32_t> d_model;
+	DevBuf<uint32_t> d_material_offset;
+	DevBuf<LmxMeshMaterial> d_mesh_materials;
+	DevBuf<float> d_lod;
+	DevBuf<uint8_t> d_flags, d_dirty;
+	DevBuf<uint32_t> d_pose_frame;
+	DevBuf<uint32_t> d_decal_key, d_curve_key;
+	DevBuf<uint8_t> d_decal_layer, d_curve_layer;
+	DevBuf<double> d_pos;
+	DevBuf<uint64_t> d_keys, d_values, d_keys_alt, d_values_alt, d_rec_value, d_group_values;
+	DevBuf<uint32_t> d_rec_key, d_groups, d_counters;
+	DevBuf<int32_t> d_poses, d_dirty_list;
+	DevBuf<char> d_sort_temp;
+};
+
 struct ProfSlot { hipEvent_t a, b; int kernel; };
 
 
@@ -213,6 +236,7 @@ struct LmxContext {
 	lmx::CullState cull;
 	lmx::WorldState world;
 	lmx::SkinState skin;
+	lmx::KeysState keys;
 };
 
 namespace lmx {

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "lmx_math.h"
+#include "lmx_types.h"
 
 namespace lmx {
 
@@ -111,6 +112,51 @@ struct SkinInstance {
 // k_skin_shared work item: instances [first_inst, first_inst + count) share mesh and bone count; vertices [v_begin, v_end) of it
 struct SkinChunk { uint32_t first_inst, count, v_begin, v_end; };
 struct PoseGroup { uint32_t first_inst; uint32_t count; }; // consecutive instances of one model, count <= 16 / 8 / 4 by bone count
+// ---- createSortKeys (keys_kernels.hip) ----
+enum { KEYS_N_PAIRS = 0, KEYS_N_RECS = 1, KEYS_N_POSES = 2, KEYS_N_DIRTY = 3, KEYS_OVERFLOW = 4, KEYS_N_GROUPS = 5, KEYS_COUNTERS = 8 };
+struct KeysViewDevice { // what the kernels read of a LmxKeysView, bucket_map as built at pipeline.cpp:3802-3812
+	uint32_t bucket_map[255];
+	uint8_t layer_to_bucket[255];
+	uint8_t is_shadow;
+	double cam[3], ref[3];
+	float lod_multiplier_rcp, time_delta;
+	uint32_t frame_number;
+};
+struct KeysDevice {
+	// model instances by entity index, models, materials
+	uint32_t n_entities;
+	const int32_t* model;
+	const uint32_t* material_offset;
+	const LmxMeshMaterial* mesh_materials;
+	const LmxKeysModel* models;
+	const uint8_t* mesh_types;
+	float* lod;               // ModelInstance::lod, updated in place
+	const uint8_t* flags;
+	const uint8_t* dirty;
+	uint32_t* pose_frame;     // Pose::frame, updated in place
+	const uint32_t *decal_sort_key, *curve_sort_key;
+	const uint8_t *decal_layer, *curve_layer;
+	// positions: entity-indexed xyz, or the world hierarchy's SoA through slot_of_entity
+	const double* pos_xyz;
+	const double *wpx, *wpy, *wpz;
+	const int32_t* slot_of_entity;
+	// outputs
+	uint64_t *keys, *values;
+	uint32_t cap_pairs;
+	uint32_t* rec_key;
+	uint64_t* rec_value;
+	uint32_t cap_recs;
+	uint32_t max_sort_key;
+	uint32_t *group_count, *group_offset, *group_cursor; // [max_sort_key + 1], [+ 2], [+ 1]
+	uint64_t* group_values;
+	int32_t *poses, *dirty_list;
+	uint32_t cap_list;
+	uint32_t* counters;       // KEYS_*
+};
+hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const int32_t* mesh_ids, const uint32_t* mesh_count,
+	uint32_t mesh_cap, const int32_t* decal_ids, const uint32_t* decal_count, uint32_t decal_cap, const int32_t* curve_ids,
+	const uint32_t* curve_count, uint32_t curve_cap);
+
 // Pose::computeAbsolute + computeSkinMatrices (+ optional dual-quaternion palette), one wave per PoseGroup
 hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, const PoseGroup* groups, const uint32_t n_groups[3] /* by capacity 16, 8, 4 */,
 	const float* rel_pos, const float4* rel_rot, float* pose_pos, float4* pose_rot, const uint32_t* level_items, const uint16_t* level_off,

@@ -377,8 +377,9 @@ __device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const 
 				asm volatile("" : "+v"(vin[k].px), "+v"(vin[k].py), "+v"(vin[k].pz), "+v"(vin[k].w.x), "+v"(vin[k].w.y), "+v"(vin[k].w.z), "+v"(vin[k].w.w),
 					"+v"(vin[k].iw.x), "+v"(vin[k].iw.y));
 				const uint32_t o01 = (uint32_t)vin[k].iw.x, o23 = (uint32_t)vin[k].iw.y;
-				o[v] = skin_blend_rows<COPIES, EXACT>(reinterpret_cast<const float4*>(buf + (o01 & 0xffffu)), reinterpret_cast<const float4*>(buf + (o01 >> 16)),
+				const F3 r = skin_blend_rows<COPIES, EXACT>(reinterpret_cast<const float4*>(buf + (o01 & 0xffffu)), reinterpret_cast<const float4*>(buf + (o01 >> 16)),
 					reinterpret_cast<const float4*>(buf + (o23 & 0xffffu)), reinterpret_cast<const float4*>(buf + (o23 >> 16)), vin[k]);
+				if (!LMX_PROBE_SKIP(8) || r.x == 123.25f) o[v] = r;
 			}
 			__builtin_amdgcn_sched_barrier(0); // one vertex's 12 palette rows (48 VGPRs) in flight at a time
 		}

@@ -112,3 +112,52 @@ def skinned_mesh(n_verts: int, n_bones: int = 64, seed: int = 6):
     skin["weights"] = (w16.astype(np.float32) / np.float32(65535.0)).astype(np.float32)
     skin["indices"] = rng.integers(0, n_bones, size=(n_verts, 4)).astype(np.int16)
     return verts, skin
+
+
+def keys_scene(n_entities: int, types: np.ndarray, seed: int = 11, n_models: int = 6, max_sort_key: int = 63):
+    """Model-instance / material tables for createSortKeys over `n_entities` entities whose renderable types are `types`:
+    models with 1-4 LODs of 1-3 meshes (some skinned), per-entity material spans, LOD state in [0, 4], MOVED / dirty flags.
+    A mesh sort key identifies (mesh, material), so every key maps to one layer (pipeline.cpp:3958-3968 relies on it)."""
+    from .api import KEYS_MODEL, MESH_MATERIAL
+    rng = np.random.default_rng(seed)
+    models = np.zeros(n_models, KEYS_MODEL)
+    mesh_types = []
+    for m in range(n_models):
+        n_lods = int(rng.integers(1, 5))
+        dist = np.sort(rng.uniform(50.0, 4000.0, size=n_lods).astype(np.float32)) ** 2
+        models["lod_distances"][m] = np.finfo(np.float32).max  # Model::Model, model.cpp:99
+        models["lod_indices"][m]["from"], models["lod_indices"][m]["to"] = 0, -1
+        first = len(mesh_types)
+        k = 0
+        for lod in range(n_lods):
+            c = int(rng.integers(1, 4))
+            models["lod_indices"][m][lod] = (k, k + c - 1)
+            models["lod_distances"][m][lod] = dist[lod]
+            k += c
+        skinned = rng.random() < 0.3
+        mesh_types += [1 if skinned and rng.random() < 0.8 else 0 for _ in range(k)]
+        models["first_mesh"][m], models["mesh_count"][m] = first, k
+    n_layers = 6
+    key_layer = rng.integers(0, n_layers, size=max_sort_key + 1).astype(np.uint8)  # sort key -> layer
+    model = np.where(types == 0, rng.integers(0, n_models, size=n_entities), -1).astype(np.int32)
+    counts = np.where(model >= 0, models["mesh_count"][np.maximum(model, 0)], 0).astype(np.uint32)
+    material_offset = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint32)
+    mm = np.zeros(int(counts.sum()), MESH_MATERIAL)
+    mm["sort_key"] = rng.integers(0, max_sort_key + 1, size=len(mm))
+    mm["layer"] = key_layer[mm["sort_key"]]
+    lod = rng.integers(0, 5, size=n_entities).astype(np.float32)
+    frac = rng.random(n_entities) < 0.3
+    lod = np.where(frac, np.minimum(lod + rng.random(n_entities).astype(np.float32), np.float32(4.0)), lod).astype(np.float32)
+    flags = (rng.random(n_entities) < 0.2).astype(np.uint8) * 8 | 6  # MOVED | VALID | ENABLED
+    dirty = (rng.random(n_entities) < 0.05).astype(np.uint8)
+    pose_frame = np.where(rng.random(n_entities) < 0.5, 7, 6).astype(np.uint32)  # half already processed in frame 7
+    decal_key = rng.integers(0, 1 << 24, size=n_entities).astype(np.uint32)
+    decal_layer = rng.integers(0, n_layers, size=n_entities).astype(np.uint8)
+    # layers 0..5 -> buckets: 0, 1 plain; 2 depth-sorted; layer 3 not rendered; 4 -> bucket 1 again; 5 depth-sorted bucket 3
+    layer_to_bucket = np.full(255, 0xFF, np.uint8)
+    layer_to_bucket[:6] = [0, 1, 2, 0xFF, 1, 3]
+    bucket_depth_sorted = np.array([0, 0, 1, 1], np.uint8)
+    return {"models": models, "mesh_types": np.array(mesh_types, np.uint8), "model": model, "material_offset": material_offset, "mesh_materials": mm,
+            "lod": lod, "flags": flags, "dirty": dirty, "pose_frame": pose_frame, "decal_key": decal_key, "decal_layer": decal_layer,
+            "curve_key": decal_key[::-1].copy(), "curve_layer": decal_layer[::-1].copy(), "layer_to_bucket": layer_to_bucket,
+            "bucket_depth_sorted": bucket_depth_sorted, "max_sort_key": max_sort_key}

@@ -12,6 +12,7 @@
  *   src/engine/world.cpp              transformEntity / setParent / setTransform / setLocalTransform
  *   src/renderer/pose.cpp             Pose::computeAbsolute (scalar recurrence)
  *   src/renderer/model.cpp            invert, computeSkinMatrices, evaluateSkin
+ *   src/renderer/pipeline.cpp         createSortKeys (:3789-3968) — restated only, see the note at orc_create_sort_keys
  *
  * Pinning: the reference has NO tests or golden vectors for this path. The restatement is pinned
  * instead against the reference's own object code (oracle/_ref/liblmx_ref.so = reference math.cpp + geometry.cpp
@@ -1132,6 +1133,154 @@ ORC_API void orc_evaluate_skin(const float* verts, const LmxSkin* skin, const Lm
 }
 
 /* Marsaglia MWC generator, core/math.cpp:1333-1341 */
+/* ---- createSortKeys (renderer/pipeline.cpp:3789-3968), single worker ------------------------------------------------
+ * PARITY UNPINNED for this function: pipeline.cpp needs the whole renderer (DX12 back end, resources, job system) and cannot
+ * be compiled on its own, and the reference holds no test or golden vector for it; the restatement below follows the
+ * source line by line and is cross-checked only against an independent pure-Python restatement in tests/test_sort_keys.py.
+ *
+ * Inputs are the fields the function reads, entity-indexed like the reference's arrays: ModelInstance {model, mesh_materials,
+ * lod, flags, dirty, pose->frame} (render_module.h:206-226), Model {m_lod_distances, m_lod_indices, meshes[].type}
+ * (model.h:233-234, :86-89), MeshMaterial {sort_key, material->getLayer()} (model.h:59-68), World::getTransforms()[e].pos.
+ * The visible lists are the CullResult pages of one view, per type. Outputs keep the reference's insertion order:
+ * pairs = Sorter::Inserter::push order, then one AUTOINSTANCED pair per non-empty group in index order (:3958-3968);
+ * group_values = AutoInstancer groups in CSR form (instances[sort_key], insertion order inside a group). */
+typedef struct OrcKeysOut {
+	uint64_t* keys; uint64_t* values; uint32_t cap_pairs, n_pairs;
+	uint32_t* group_offsets; /* max_sort_key + 2 */
+	uint64_t* group_values; uint32_t cap_instanced, n_instanced;
+	int32_t* poses; uint32_t n_poses;
+	int32_t* dirty; uint32_t n_dirty;
+	uint32_t n_groups;
+} OrcKeysOut;
+
+static uint32_t orc_float_flip(uint32_t bits) { /* floatFlip, pipeline.cpp:57-60 */
+	const uint32_t mask = (uint32_t)(-(int32_t)(bits >> 31)) | 0x80000000u;
+	return bits ^ mask;
+}
+
+static uint32_t orc_lod_mesh_indices(const LmxKeysModel* m, float squared_distance) { /* Model::getLODMeshIndices, model.h:173-179 */
+	if (squared_distance < m->lod_distances[0]) return 0;
+	if (squared_distance < m->lod_distances[1]) return 1;
+	if (squared_distance < m->lod_distances[2]) return 2;
+	if (squared_distance < m->lod_distances[3]) return 3;
+	return 4;
+}
+
+ORC_API int orc_create_sort_keys(const LmxKeysView* kv, uint32_t max_sort_key, const int32_t* mesh_ids, uint32_t n_mesh, const int32_t* decal_ids,
+	uint32_t n_decal, const int32_t* curve_ids, uint32_t n_curve, const LmxKeysModel* models, const uint8_t* mesh_types, const int32_t* model,
+	const uint32_t* material_offset, const LmxMeshMaterial* mesh_materials, float* lod, const uint8_t* flags, const uint8_t* dirty,
+	uint32_t* pose_frame, const uint32_t* decal_key, const uint8_t* decal_layer, const uint32_t* curve_key, const uint8_t* curve_layer,
+	const double* pos_xyz, OrcKeysOut* out) {
+	uint32_t bucket_map[255]; /* :3802-3812 */
+	for (uint32_t i = 0; i < 255; ++i) {
+		bucket_map[i] = kv->layer_to_bucket[i];
+		if (bucket_map[i] == 0xff) bucket_map[i] = 0xffFFffFFu;
+		else if (kv->bucket_depth_sorted[bucket_map[i]]) bucket_map[i] |= 0x100;
+	}
+	const float global_lod_multiplier_rcp = 1 / kv->lod_multiplier; /* :3799 */
+	const float time_delta = kv->time_delta;
+	const uint32_t frame_number = kv->frame_number;
+	const int is_shadow = kv->is_shadow != 0;
+	out->n_pairs = out->n_instanced = out->n_poses = out->n_dirty = out->n_groups = 0;
+	/* AutoInstancer::add keeps per-key lists in insertion order: collect (key, value) records, then bucket them stably */
+	uint32_t* rec_key = (uint32_t*)malloc(sizeof(uint32_t) * (out->cap_instanced + 1));
+	uint64_t* rec_val = (uint64_t*)malloc(sizeof(uint64_t) * (out->cap_instanced + 1));
+	uint32_t n_rec = 0;
+	int rc = 0;
+#define ORC_PUSH(k, v) do { if (out->n_pairs >= out->cap_pairs) { rc = 1; goto done; } out->keys[out->n_pairs] = (k); out->values[out->n_pairs] = (v); ++out->n_pairs; } while (0)
+	/* pages arrive per type; LOCAL_LIGHT pages are skipped (:3840) */
+	for (uint32_t i = 0; i < n_decal; ++i) { /* :3841-3854 */
+		const uint32_t e = (uint32_t)decal_ids[i];
+		const uint8_t bucket = (uint8_t)bucket_map[decal_layer[e]];
+		if (bucket < 0xff) ORC_PUSH((uint64_t)decal_key[e] | ((uint64_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT), (uint64_t)e | ((uint64_t)LMX_DRAW_DECAL << LMX_SORT_VALUE_TYPE_SHIFT));
+	}
+	for (uint32_t i = 0; i < n_curve; ++i) { /* :3855-3868 */
+		const uint32_t e = (uint32_t)curve_ids[i];
+		const uint8_t bucket = (uint8_t)bucket_map[curve_layer[e]];
+		if (bucket < 0xff) ORC_PUSH((uint64_t)curve_key[e] | ((uint64_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT), (uint64_t)e | ((uint64_t)LMX_DRAW_CURVE_DECAL << LMX_SORT_VALUE_TYPE_SHIFT));
+	}
+	for (uint32_t i = 0; i < n_mesh; ++i) { /* :3869-3959 */
+		const uint32_t e = (uint32_t)mesh_ids[i];
+		if (model[e] < 0) continue; /* not a model instance: cannot be in a MESH page of the reference */
+		const LmxKeysModel* m = &models[model[e]];
+		const double px = pos_xyz[3 * (size_t)e], py = pos_xyz[3 * (size_t)e + 1], pz = pos_xyz[3 * (size_t)e + 2];
+		const double rx = px - kv->lod_ref_point[0], ry = py - kv->lod_ref_point[1], rz = pz - kv->lod_ref_point[2];
+		const float squared_length = (float)(rx * rx + ry * ry + rz * rz); /* float(squaredLength(pos - lod_ref_point)), math.cpp:397 */
+		const uint32_t lod_idx = orc_lod_mesh_indices(m, squared_length * global_lod_multiplier_rcp);
+		if (dirty[e]) { out->dirty[out->n_dirty++] = (int32_t)e; continue; } /* queueMaterialOverrideRefresh(e), :3879-3882 */
+		LmxLodIndices ranges[2];
+		int n_ranges = 0;
+		if (lod[e] != (float)lod_idx) { /* :3937-3952 */
+			const float d = (float)lod_idx - lod[e];
+			const float ad = fabsf(d);
+			if (ad <= time_delta) {
+				lod[e] = (float)lod_idx;
+				ranges[n_ranges++] = m->lod_indices[lod_idx];
+			} else {
+				if (!is_shadow) lod[e] += d / ad * time_delta;
+				const uint32_t cur_lod_idx = (uint32_t)lod[e];
+				ranges[n_ranges++] = m->lod_indices[cur_lod_idx];
+				if (cur_lod_idx < 3) ranges[n_ranges++] = m->lod_indices[cur_lod_idx + 1];
+			}
+		} else {
+			ranges[n_ranges++] = m->lod_indices[lod_idx];
+		}
+		for (int r = 0; r < n_ranges; ++r) {
+			for (int mesh_idx = ranges[r].from; mesh_idx <= ranges[r].to; ++mesh_idx) { /* create_key, :3884-3935 */
+				const LmxMeshMaterial* mesh_mat = &mesh_materials[material_offset[e] + (uint32_t)mesh_idx];
+				const uint32_t bucket = bucket_map[mesh_mat->layer];
+				const uint32_t mesh_sort_key = mesh_mat->sort_key;
+				if (mesh_types[m->first_mesh + (uint32_t)mesh_idx] == LMX_MESH_SKINNED) {
+					if (pose_frame[e] != frame_number) { pose_frame[e] = frame_number; out->poses[out->n_poses++] = (int32_t)e; } /* :3889-3898 */
+					ORC_PUSH((uint64_t)mesh_sort_key | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT),
+						(uint64_t)e | ((uint64_t)LMX_DRAW_SKINNED << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT));
+				} else if ((flags[e] & LMX_MODEL_INSTANCE_MOVED) && !is_shadow) {
+					ORC_PUSH((uint64_t)mesh_sort_key | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT),
+						(uint64_t)e | ((uint64_t)LMX_DRAW_MESH << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT));
+				} else if (bucket < 0xff) {
+					if (n_rec >= out->cap_instanced || mesh_sort_key > max_sort_key) { rc = 2; goto done; }
+					rec_key[n_rec] = mesh_sort_key; /* instancer.add(mesh_sort_key, value) */
+					rec_val[n_rec] = (uint64_t)e | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
+					++n_rec;
+				} else if (bucket < 0xffFF) { /* depth sorted */
+					const double cx = px - kv->camera_pos[0], cy = py - kv->camera_pos[1], cz = pz - kv->camera_pos[2];
+					const float sl = (float)(cx * cx + cy * cy + cz * cz);
+					uint32_t bits;
+					memcpy(&bits, &sl, 4);
+					ORC_PUSH((uint64_t)orc_float_flip(bits) | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT),
+						(uint64_t)e | ((uint64_t)LMX_DRAW_MESH << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT));
+				}
+			}
+		}
+	}
+	/* AutoInstancer groups -> CSR, stable */
+	memset(out->group_offsets, 0, sizeof(uint32_t) * (max_sort_key + 2));
+	for (uint32_t i = 0; i < n_rec; ++i) ++out->group_offsets[rec_key[i] + 1];
+	for (uint32_t k = 0; k <= max_sort_key; ++k) out->group_offsets[k + 1] += out->group_offsets[k];
+	{
+		uint32_t* cursor = (uint32_t*)calloc(max_sort_key + 1, sizeof(uint32_t));
+		for (uint32_t i = 0; i < n_rec; ++i) out->group_values[out->group_offsets[rec_key[i]] + cursor[rec_key[i]]++] = rec_val[i];
+		free(cursor);
+	}
+	out->n_instanced = n_rec;
+	for (uint32_t i = 0; i <= max_sort_key; ++i) { /* :3958-3968 */
+		if (out->group_offsets[i + 1] == out->group_offsets[i]) continue;
+		++out->n_groups;
+		const uint64_t renderable = out->group_values[out->group_offsets[i]]; /* instances[i].begin->renderables[0] */
+		const uint32_t entity_index = (uint32_t)(renderable & 0xffFFff);
+		const uint32_t mesh_idx = (uint32_t)(renderable >> LMX_SORT_VALUE_MESH_IDX_SHIFT);
+		const uint8_t layer = mesh_materials[material_offset[entity_index] + mesh_idx].layer;
+		const uint8_t bucket = kv->layer_to_bucket[layer];
+		ORC_PUSH((uint64_t)i | LMX_SORT_KEY_INSTANCED_FLAG | ((uint64_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT),
+			(uint64_t)i | ((uint64_t)0 << LMX_SORT_VALUE_INSTANCER_SHIFT) | ((uint64_t)LMX_DRAW_AUTOINSTANCED << LMX_SORT_VALUE_TYPE_SHIFT));
+	}
+#undef ORC_PUSH
+done:
+	free(rec_key);
+	free(rec_val);
+	return rc;
+}
+
 ORC_API void orc_rand_fill(uint32_t u, uint32_t v, uint32_t n, uint32_t* out) {
 	for (uint32_t i = 0; i < n; ++i) {
 		u = 36969 * (u & 65535) + (u >> 16);

@@ -122,6 +122,11 @@ class Oracle:
         self.f_evaluate_skin = self._fn("evaluate_skin", None, [vp, vp, vp, vp, u32, u32, u32, ci])
         self.f_rand_fill = self._fn("rand_fill", None, [u32, u32, u32, vp])
         self.f_describe = self._fn("describe", C.c_char_p, [])
+        # createSortKeys exists only as a restatement (pipeline.cpp cannot be compiled on its own: no ref_ twin)
+        self.f_create_sort_keys = getattr(self.lib, "orc_create_sort_keys", None)
+        if self.f_create_sort_keys is not None:
+            self.f_create_sort_keys.restype = C.c_int
+            self.f_create_sort_keys.argtypes = [vp, u32, vp, u32, vp, u32, vp, u32] + [vp] * 15
 
     def describe(self) -> str:
         return self.f_describe().decode()
@@ -213,6 +218,43 @@ class Oracle:
         out = np.zeros((n_inst, len(verts), 3), np.float32)
         self.f_evaluate_skin(_ptr(verts), _ptr(skin), _ptr(palettes), _ptr(out), len(verts), n_bones, n_inst, n_threads)
         return out
+
+    def create_sort_keys(self, kv, max_sort_key, mesh_ids, decal_ids, curve_ids, sc, pos_xyz, lod=None, pose_frame=None):
+        """PipelineImpl::createSortKeys, single worker (pipeline.cpp:3789-3968). `sc` = lumixengine_amd.scenes.keys_scene tables.
+        Returns a dict: keys, values (insertion order, AUTOINSTANCED pairs last), group_offsets, group_values, poses, dirty, lod, pose_frame."""
+        if self.f_create_sort_keys is None:
+            raise RuntimeError("createSortKeys is only restated in the port oracle")
+        from lumixengine_amd.api import KEYS_VIEW, KEYS_MODEL, MESH_MATERIAL
+        kv = np.ascontiguousarray(kv, KEYS_VIEW)
+        ids = [np.ascontiguousarray(x, np.int32) for x in (mesh_ids, decal_ids, curve_ids)]
+        models = np.ascontiguousarray(sc["models"], KEYS_MODEL)
+        mm = np.ascontiguousarray(sc["mesh_materials"], MESH_MATERIAL)
+        lod = np.array(sc["lod"] if lod is None else lod, np.float32)
+        pose_frame = np.array(sc["pose_frame"] if pose_frame is None else pose_frame, np.uint32)
+        span = int(max(1, (models["lod_indices"]["to"] - models["lod_indices"]["from"] + 1).max()))
+        cap_inst = len(ids[0]) * span * 2 + 1
+        cap_pairs = cap_inst + len(ids[1]) + len(ids[2]) + max_sort_key + 2
+        keys, values = np.zeros(cap_pairs, np.uint64), np.zeros(cap_pairs, np.uint64)
+        offsets, gvalues = np.zeros(max_sort_key + 2, np.uint32), np.zeros(cap_inst, np.uint64)
+        poses, dirty = np.zeros(len(ids[0]) + 1, np.int32), np.zeros(len(ids[0]) + 1, np.int32)
+
+        class Out(C.Structure):
+            _fields_ = [("keys", C.c_void_p), ("values", C.c_void_p), ("cap_pairs", C.c_uint32), ("n_pairs", C.c_uint32), ("group_offsets", C.c_void_p),
+                        ("group_values", C.c_void_p), ("cap_instanced", C.c_uint32), ("n_instanced", C.c_uint32), ("poses", C.c_void_p), ("n_poses", C.c_uint32),
+                        ("dirty", C.c_void_p), ("n_dirty", C.c_uint32), ("n_groups", C.c_uint32)]
+
+        out = Out(_ptr(keys), _ptr(values), cap_pairs, 0, _ptr(offsets), _ptr(gvalues), cap_inst, 0, _ptr(poses), 0, _ptr(dirty), 0, 0)
+        arrs = [np.ascontiguousarray(sc["mesh_types"], np.uint8), np.ascontiguousarray(sc["model"], np.int32), np.ascontiguousarray(sc["material_offset"], np.uint32),
+                np.ascontiguousarray(sc["flags"], np.uint8), np.ascontiguousarray(sc["dirty"], np.uint8), np.ascontiguousarray(sc["decal_key"], np.uint32),
+                np.ascontiguousarray(sc["decal_layer"], np.uint8), np.ascontiguousarray(sc["curve_key"], np.uint32), np.ascontiguousarray(sc["curve_layer"], np.uint8),
+                np.ascontiguousarray(pos_xyz, np.float64)]
+        rc = self.f_create_sort_keys(_ptr(kv), max_sort_key, _ptr(ids[0]), len(ids[0]), _ptr(ids[1]), len(ids[1]), _ptr(ids[2]), len(ids[2]), _ptr(models),
+                                     _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(mm), _ptr(lod), _ptr(arrs[3]), _ptr(arrs[4]), _ptr(pose_frame), _ptr(arrs[5]),
+                                     _ptr(arrs[6]), _ptr(arrs[7]), _ptr(arrs[8]), _ptr(arrs[9]), C.addressof(out))
+        if rc != 0:
+            raise RuntimeError(f"orc_create_sort_keys failed with {rc}")
+        return {"keys": keys[: out.n_pairs], "values": values[: out.n_pairs], "group_offsets": offsets, "group_values": gvalues[: out.n_instanced],
+                "poses": poses[: out.n_poses], "dirty": dirty[: out.n_dirty], "lod": lod, "pose_frame": pose_frame, "groups": out.n_groups}
 
     def rand_fill(self, u: int, v: int, n: int) -> np.ndarray:
         out = np.zeros(n, np.uint32)

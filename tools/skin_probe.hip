@@ -1,8 +1,11 @@
 // Development probe: times k_skin_vertices<false> with parts switched off (bit 8: vertex stores, 16: LDS palette reads).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I lumixengine_amd/csrc tools/skin_probe.hip -o tools/_build/skin_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DLMX_PROBE_MASK=<bits> -I lumixengine_amd/csrc tools/skin_probe.hip -o tools/_build/skin_probe_<bits>
+//   skin_probe_<bits> [instances] [instances per block] [1 = k_skin_shared, 0 = k_skin_vertices]
 #include <hip/hip_runtime.h>
-__device__ int g_probe_mask;
-#define LMX_PROBE_SKIP(bit) ((g_probe_mask & (bit)) != 0)
+#ifndef LMX_PROBE_MASK
+#define LMX_PROBE_MASK 0
+#endif
+#define LMX_PROBE_SKIP(bit) ((LMX_PROBE_MASK & (bit)) != 0) // compile-time: the probed kernel carries no extra code
 #include "skin_kernels.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -27,13 +30,20 @@ int main(int argc, char** argv) {
 	CK(hipMalloc(&d_i, idx.size() * 2)); CK(hipMemcpy(d_i, idx.data(), idx.size() * 2, hipMemcpyHostToDevice));
 	CK(hipMalloc(&d_pal, pal.size() * 4)); CK(hipMemcpy(d_pal, pal.data(), pal.size() * 4, hipMemcpyHostToDevice));
 	CK(hipMalloc(&d_out, (size_t)n_inst * nv * 12));
+	const uint32_t per_block = argc > 2 ? atoi(argv[2]) : 64, tile = 5056;
+	std::vector<SkinChunk> chunks;
+	for (uint32_t f = 0; f < n_inst; f += per_block)
+		for (uint32_t t = 0; t * tile < nv; ++t) chunks.push_back(SkinChunk{f, n_inst - f < per_block ? n_inst - f : per_block, t * tile, (t + 1) * tile < nv ? (t + 1) * tile : nv});
+	SkinChunk* d_chunks; CK(hipMalloc(&d_chunks, chunks.size() * sizeof(SkinChunk))); CK(hipMemcpy(d_chunks, chunks.data(), chunks.size() * sizeof(SkinChunk), hipMemcpyHostToDevice));
+	const bool shared = argc > 3 ? atoi(argv[3]) != 0 : true;
+	printf("%s kernel, %zu chunks of %u instances\n", shared ? "shared" : "streaming", chunks.size(), per_block);
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-	for (int mask : {0, 0}) {
-		CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_mask), &mask, sizeof(int)));
+	for (int mask : {LMX_PROBE_MASK}) {
 		float best = 1e9f;
 		for (int it = 0; it < 5; ++it) {
 			CK(hipEventRecord(e0));
-			CK(launch_skin_vertices(0, d_inst, n_inst, nv, d_v, d_w, d_i, d_pal, d_out, false));
+			if (shared) CK(launch_skin_shared(0, d_inst, d_chunks, (uint32_t)chunks.size(), d_v, d_w, d_i, d_pal, d_out, false));
+			else CK(launch_skin_vertices(0, d_inst, nullptr, n_inst, nv, d_v, d_w, d_i, d_pal, d_out, false));
 			CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
 			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
 			if (it && ms < best) best = ms;
