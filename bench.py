@@ -318,7 +318,37 @@ def extras(ctx, api, scenes, torch, timed, N, log):
     out["dense_all_visible_ms_per_cull"] = ms_all
     out["dense_all_visible_count"] = vis_all
     out["dense_all_visible_GBps"] = (20.0 * N + 4.0 * vis_all) / (ms_all * 1e-3) / 1e9
-    del cs
+
+    # createSortKeys straight from the device-resident visible list: LOD selection + sort keys +
+    # auto-instancer groups for every visible entity of the dense scene; the list never leaves HBM
+    ks = scenes.keys_scene(N, sc["type"], seed=12, max_sort_key=4095)
+    sk = api.SortKeys(ctx)
+    sk.setModels(ks["models"], ks["mesh_types"])
+    sk.setInstances(ks["model"], ks["material_offset"], ks["mesh_materials"], ks["lod"], ks["flags"], ks["dirty"], ks["pose_frame"])
+    sk.setPositions(sc["pos"])
+    frame_no = [100]
+    for name, frustum, visible in (("keys", fr, vis), ("keys_all_visible", big, vis_all)):
+        def cull_keys():
+            frame_no[0] += 1
+            cs.cull(frustum)
+            sk.run(api.keys_view(layer_to_bucket=ks["layer_to_bucket"], bucket_depth_sorted=ks["bucket_depth_sorted"], frame_number=frame_no[0]), 4095)
+        for _ in range(3):
+            cull_keys()
+        ms_k = timed(cull_keys, 20)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(5):
+            cull_keys()
+        ctx.synchronize()
+        ctx.profile_enable(False)
+        kid = api.KERNEL_NAMES.index("sort_keys")
+        k_ms = ctx.profile_get(kid)[0] / 5
+        cnt = sk.counts()
+        out[name + "_cull_plus_keys_ms"] = ms_k
+        out[name + "_kernels_ms"] = k_ms
+        out[name + "_visible_per_sec"] = visible / (k_ms * 1e-3) if k_ms else None
+        out[name + "_counts"] = cnt
+    del cs, sk, ks
 
     # config 5 flavour on one GPU: mixed renderable types, 8 ortho cascade frusta tested in ONE pass over the spheres
     sc = scenes.cull_scene(N, 15000.0, seed=4, mixed_types=True)

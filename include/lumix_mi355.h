@@ -211,7 +211,8 @@ LMX_API int lmx_frustum_ortho(const double pos[3], const float dir[3], const flo
  * ------------------------------------------------------------------------------------------------------------------ */
 LMX_API int lmx_keys_set_models(LmxContext* ctx, const LmxKeysModel* models, uint32_t n_models, const uint8_t* mesh_types, uint32_t n_meshes);
 /* Model instances by entity index (RenderModule::getModelInstances): model < 0 = entity has no model instance. Entity e's
- * MeshMaterial span starts at mesh_materials[material_offset[e]] (ModelInstance::mesh_materials, indexed by mesh index). */
+ * MeshMaterial span starts at mesh_materials[material_offset[e]] (ModelInstance::mesh_materials, indexed by mesh index).
+ * A call with a different n_entities drops decal tables uploaded for the previous entity range. */
 LMX_API int lmx_keys_set_instances(LmxContext* ctx, uint32_t n_entities, const int32_t* model, const uint32_t* material_offset,
 	const LmxMeshMaterial* mesh_materials, uint32_t n_mesh_materials, const float* lod, const uint8_t* flags, const uint8_t* dirty,
 	const uint32_t* pose_frame);

@@ -13,6 +13,8 @@
 // Integer work is bit-exact by construction; the two fp64 -> fp32 distances use the reference's operation order.
 #include "lmx_kernels.h"
 
+#include <algorithm>
+
 namespace lmx {
 
 namespace {
@@ -60,100 +62,151 @@ __device__ __forceinline__ uint32_t float_flip(uint32_t bits) {
 	return bits ^ mask;
 }
 
-__global__ __launch_bounds__(256) void k_keys_mesh(KeysDevice d, const KeysViewDevice kv /* by value: captured at launch */, const int32_t* __restrict__ ids,
-	const uint32_t* __restrict__ n_visible) {
-	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+constexpr int KEYS_BLOCK = 1024;
+
+// The visible list is walked in tiles of 1024 entities by a fixed-size grid. Per tile every lane first COUNTS what it will
+// emit, the block reserves its output ranges with one atomic per list (4 per 1024 entities: returning atomics on one address
+// retire at ~90 per microsecond chip-wide, one per wave and mesh was 15x slower than this kernel's memory work), and a second
+// walk writes at lane-private positions.
+__global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const KeysViewDevice kv /* by value: captured at launch */,
+	const int32_t* __restrict__ ids, const uint32_t* __restrict__ n_visible) {
+	__shared__ uint32_t s_wave[KEYS_BLOCK / 64][3]; // per wave: pairs | recs << 16, poses, dirty
+	__shared__ uint32_t s_base[4];
 	const uint32_t n = *n_visible;
-	if (i - (i & 63u) >= n) return; // whole wave past the end
-	// ranges of mesh indices this lane emits keys for: [from0, to0] then [from1, to1]
-	int32_t from0 = 0, to0 = -1, from1 = 0, to1 = -1;
-	uint32_t e = 0, mat0 = 0, first_mesh = 0;
-	bool moved = false, queue_dirty = false;
-	double px = 0, py = 0, pz = 0;
-	if (i < n) {
-		e = (uint32_t)ids[i];
-		const int32_t mdl = e < d.n_entities ? d.model[e] : -1;
-		if (mdl >= 0) {
-			const LmxKeysModel& m = d.models[mdl];
-			load_pos(d, e, &px, &py, &pz);
-			const double rx = px - kv.ref[0], ry = py - kv.ref[1], rz = pz - kv.ref[2];
-			const float squared_length = (float)(rx * rx + ry * ry + rz * rz); // float(squaredLength(pos - lod_ref_point)), math.cpp:397
-			const float sd = squared_length * kv.lod_multiplier_rcp;
-			uint32_t lod_idx = 4; // Model::getLODMeshIndices, model.h:173-179
-			if (sd < m.lod_distances[0]) lod_idx = 0;
-			else if (sd < m.lod_distances[1]) lod_idx = 1;
-			else if (sd < m.lod_distances[2]) lod_idx = 2;
-			else if (sd < m.lod_distances[3]) lod_idx = 3;
-			if (d.dirty[e]) {
-				queue_dirty = true; // queueMaterialOverrideRefresh(e); continue;  (:3879-3882)
-			} else {
-				mat0 = d.material_offset[e];
-				first_mesh = m.first_mesh;
-				moved = (d.flags[e] & LMX_MODEL_INSTANCE_MOVED) != 0;
-				float lod = d.lod[e];
-				if (lod != (float)lod_idx) { // :3937-3952
-					const float dl = (float)lod_idx - lod;
-					const float ad = fabsf(dl);
-					if (ad <= kv.time_delta) {
-						d.lod[e] = (float)lod_idx;
-						from0 = m.lod_indices[lod_idx].from; to0 = m.lod_indices[lod_idx].to;
-					} else {
-						if (!kv.is_shadow) { lod = lod + dl / ad * kv.time_delta; d.lod[e] = lod; }
-						const uint32_t cur = (uint32_t)lod;
-						from0 = m.lod_indices[cur].from; to0 = m.lod_indices[cur].to;
-						if (cur < 3) { from1 = m.lod_indices[cur + 1].from; to1 = m.lod_indices[cur + 1].to; }
-					}
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	for (uint32_t tile = blockIdx.x * KEYS_BLOCK; tile < n; tile += gridDim.x * KEYS_BLOCK) {
+		const uint32_t i = tile + threadIdx.x;
+		// ranges of mesh indices this lane emits keys for: [from0, to0] then [from1, to1]
+		int32_t from0 = 0, to0 = -1, from1 = 0, to1 = -1;
+		uint32_t e = 0, mat0 = 0, first_mesh = 0;
+		bool moved = false, queue_dirty = false;
+		double px = 0, py = 0, pz = 0;
+		if (i < n) {
+			e = (uint32_t)ids[i];
+			const int32_t mdl = e < d.n_entities ? d.model[e] : -1;
+			if (mdl >= 0) {
+				const LmxKeysModel& m = d.models[mdl];
+				load_pos(d, e, &px, &py, &pz);
+				const double rx = px - kv.ref[0], ry = py - kv.ref[1], rz = pz - kv.ref[2];
+				const float squared_length = (float)(rx * rx + ry * ry + rz * rz); // float(squaredLength(pos - lod_ref_point)), math.cpp:397
+				const float sd = squared_length * kv.lod_multiplier_rcp;
+				uint32_t lod_idx = 4; // Model::getLODMeshIndices, model.h:173-179
+				if (sd < m.lod_distances[0]) lod_idx = 0;
+				else if (sd < m.lod_distances[1]) lod_idx = 1;
+				else if (sd < m.lod_distances[2]) lod_idx = 2;
+				else if (sd < m.lod_distances[3]) lod_idx = 3;
+				if (d.dirty[e]) {
+					queue_dirty = true; // queueMaterialOverrideRefresh(e); continue;  (:3879-3882)
 				} else {
-					from0 = m.lod_indices[lod_idx].from; to0 = m.lod_indices[lod_idx].to;
+					mat0 = d.material_offset[e];
+					first_mesh = m.first_mesh;
+					moved = (d.flags[e] & LMX_MODEL_INSTANCE_MOVED) != 0;
+					float lod = d.lod[e];
+					if (lod != (float)lod_idx) { // :3937-3952
+						const float dl = (float)lod_idx - lod;
+						const float ad = fabsf(dl);
+						if (ad <= kv.time_delta) {
+							d.lod[e] = (float)lod_idx;
+							from0 = m.lod_indices[lod_idx].from; to0 = m.lod_indices[lod_idx].to;
+						} else {
+							if (!kv.is_shadow) { lod = lod + dl / ad * kv.time_delta; d.lod[e] = lod; }
+							const uint32_t cur = (uint32_t)lod;
+							from0 = m.lod_indices[cur].from; to0 = m.lod_indices[cur].to;
+							if (cur < 3) { from1 = m.lod_indices[cur + 1].from; to1 = m.lod_indices[cur + 1].to; }
+						}
+					} else {
+						from0 = m.lod_indices[lod_idx].from; to0 = m.lod_indices[lod_idx].to;
+					}
 				}
 			}
 		}
-	}
-	{
-		const uint32_t idx = wave_append(queue_dirty, d.counters + KEYS_N_DIRTY);
-		if (queue_dirty) { if (idx < d.cap_list) d.dirty_list[idx] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
-	}
-	const int32_t len0 = to0 >= from0 ? to0 - from0 + 1 : 0, len1 = to1 >= from1 ? to1 - from1 + 1 : 0;
-	for (int32_t it = 0; __ballot(it < len0 + len1) != 0; ++it) {
-		const bool has = it < len0 + len1;
-		const int32_t mesh_idx = it < len0 ? from0 + it : from1 + (it - len0);
-		bool push_pair = false, add_inst = false, push_pose = false;
-		uint64_t key = 0, value = 0;
-		uint32_t mesh_sort_key = 0;
-		if (has) { // create_key, :3884-3935
-			const LmxMeshMaterial mm = d.mesh_materials[mat0 + (uint32_t)mesh_idx];
-			const uint32_t bucket = kv.bucket_map[mm.layer];
-			mesh_sort_key = mm.sort_key;
+		const int32_t len0 = to0 >= from0 ? to0 - from0 + 1 : 0, len1 = to1 >= from1 ? to1 - from1 + 1 : 0;
+		// ---- walk 1: count (create_key's branches, :3884-3935)
+		uint32_t n_pairs = 0, n_recs = 0;
+		bool push_pose = false;
+		for (int32_t it = 0; it < len0 + len1; ++it) {
+			const int32_t mesh_idx = it < len0 ? from0 + it : from1 + (it - len0);
+			const uint32_t bucket = kv.bucket_map[d.mesh_materials[mat0 + (uint32_t)mesh_idx].layer];
 			if (d.mesh_types[first_mesh + (uint32_t)mesh_idx] == LMX_MESH_SKINNED) {
 				// Pose::frame stamp (:3889-3898): exactly one visit per frame hands the instance to the pose processor
-				if (d.pose_frame[e] != kv.frame_number) push_pose = atomicExch(d.pose_frame + e, kv.frame_number) != kv.frame_number;
-				value = (uint64_t)e | ((uint64_t)LMX_DRAW_SKINNED << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
-				key = (uint64_t)mm.sort_key | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT); // makeMeshSortKey(mesh_mat, u8 bucket)
-				push_pair = true;
-			} else if (moved && !kv.is_shadow) {
-				value = (uint64_t)e | ((uint64_t)LMX_DRAW_MESH << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
-				key = (uint64_t)mm.sort_key | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT);
-				push_pair = true;
-			} else if (bucket < 0xffu) {
-				value = (uint64_t)e | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT); // instancer.add(mesh_sort_key, value)
-				add_inst = true;
-			} else if (bucket < 0xffffu) { // depth sorted
-				const double cx = px - kv.cam[0], cy = py - kv.cam[1], cz = pz - kv.cam[2];
-				const float sl = (float)(cx * cx + cy * cy + cz * cz);
-				value = (uint64_t)e | ((uint64_t)LMX_DRAW_MESH << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
-				key = (uint64_t)float_flip(__float_as_uint(sl)) | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT); // makeDepthSortKey
-				push_pair = true;
-			}
+				if (!push_pose && d.pose_frame[e] != kv.frame_number) push_pose = atomicExch(d.pose_frame + e, kv.frame_number) != kv.frame_number;
+				++n_pairs;
+			} else if (moved && !kv.is_shadow) ++n_pairs;
+			else if (bucket < 0xffu) ++n_recs;
+			else if (bucket < 0xffffu) ++n_pairs;
 		}
-		uint32_t idx = wave_append(push_pair, d.counters + KEYS_N_PAIRS);
-		if (push_pair) { if (idx < d.cap_pairs) { d.keys[idx] = key; d.values[idx] = value; } else d.counters[KEYS_OVERFLOW] = 1; }
-		idx = wave_append(add_inst, d.counters + KEYS_N_RECS);
-		if (add_inst) { if (idx < d.cap_recs) { d.rec_key[idx] = mesh_sort_key; d.rec_value[idx] = value; } else d.counters[KEYS_OVERFLOW] = 1; }
-		const bool in_range = add_inst && mesh_sort_key <= d.max_sort_key;
-		if (add_inst && !in_range) d.counters[KEYS_OVERFLOW] = 2; // a mesh sort key above Renderer::getMaxSortKey(): the reference indexes out of bounds
-		wave_histogram(in_range, mesh_sort_key, d.group_count);
-		idx = wave_append(push_pose, d.counters + KEYS_N_POSES);
-		if (push_pose) { if (idx < d.cap_list) d.poses[idx] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
+		// ---- block-wide exclusive prefix of (pairs, recs) and ranks of the two flags; one atomic per list
+		uint32_t incl = n_pairs | (n_recs << 16); // <= 2 * span per lane, <= 64 * that per wave: 16 bits each
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+			if (lane >= (uint32_t)o) incl += up;
+		}
+		const uint64_t pose_mask = __ballot(push_pose), dirty_mask = __ballot(queue_dirty);
+		if (lane == 63) { s_wave[wave][0] = incl; s_wave[wave][1] = (uint32_t)__popcll(pose_mask); s_wave[wave][2] = (uint32_t)__popcll(dirty_mask); }
+		__syncthreads();
+		if (threadIdx.x < 4) {
+			uint32_t total = 0;
+			for (int w = 0; w < KEYS_BLOCK / 64; ++w)
+				total += threadIdx.x == 0 ? (s_wave[w][0] & 0xffffu) : threadIdx.x == 1 ? (s_wave[w][0] >> 16) : s_wave[w][threadIdx.x - 1];
+			const int which = threadIdx.x == 0 ? KEYS_N_PAIRS : threadIdx.x == 1 ? KEYS_N_RECS : threadIdx.x == 2 ? KEYS_N_POSES : KEYS_N_DIRTY;
+			s_base[threadIdx.x] = total ? atomicAdd(d.counters + which, total) : 0;
+		}
+		__syncthreads();
+		uint32_t pair_at = s_base[0] + (incl & 0xffffu) - n_pairs, rec_at = s_base[1] + (incl >> 16) - n_recs;
+		uint32_t pose_at = s_base[2] + rank_in(pose_mask), dirty_at = s_base[3] + rank_in(dirty_mask);
+		for (uint32_t w = 0; w < wave; ++w) {
+			pair_at += s_wave[w][0] & 0xffffu;
+			rec_at += s_wave[w][0] >> 16;
+			pose_at += s_wave[w][1];
+			dirty_at += s_wave[w][2];
+		}
+		__syncthreads(); // s_wave / s_base are rewritten by the next tile
+		if (queue_dirty) { if (dirty_at < d.cap_list) d.dirty_list[dirty_at] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
+		if (push_pose) { if (pose_at < d.cap_list) d.poses[pose_at] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
+		// ---- walk 2: emit, in lockstep over the wave so that the group histogram costs one atomic per distinct key and step
+		for (int32_t it = 0; __ballot(it < len0 + len1) != 0; ++it) {
+			const bool has = it < len0 + len1;
+			bool add_inst = false;
+			uint32_t mesh_sort_key = 0;
+			if (has) {
+				const int32_t mesh_idx = it < len0 ? from0 + it : from1 + (it - len0);
+				const LmxMeshMaterial mm = d.mesh_materials[mat0 + (uint32_t)mesh_idx];
+				const uint32_t bucket = kv.bucket_map[mm.layer];
+				mesh_sort_key = mm.sort_key;
+				bool push_pair = false;
+				uint64_t key = 0, value = 0;
+				if (d.mesh_types[first_mesh + (uint32_t)mesh_idx] == LMX_MESH_SKINNED) {
+					value = (uint64_t)e | ((uint64_t)LMX_DRAW_SKINNED << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
+					key = (uint64_t)mm.sort_key | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT); // makeMeshSortKey(mesh_mat, u8 bucket)
+					push_pair = true;
+				} else if (moved && !kv.is_shadow) {
+					value = (uint64_t)e | ((uint64_t)LMX_DRAW_MESH << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
+					key = (uint64_t)mm.sort_key | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT);
+					push_pair = true;
+				} else if (bucket < 0xffu) {
+					value = (uint64_t)e | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT); // instancer.add(mesh_sort_key, value)
+					add_inst = true;
+				} else if (bucket < 0xffffu) { // depth sorted
+					const double cx = px - kv.cam[0], cy = py - kv.cam[1], cz = pz - kv.cam[2];
+					const float sl = (float)(cx * cx + cy * cy + cz * cz);
+					value = (uint64_t)e | ((uint64_t)LMX_DRAW_MESH << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
+					key = (uint64_t)float_flip(__float_as_uint(sl)) | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT); // makeDepthSortKey
+					push_pair = true;
+				}
+				if (push_pair) {
+					if (pair_at < d.cap_pairs) { d.keys[pair_at] = key; d.values[pair_at] = value; } else d.counters[KEYS_OVERFLOW] = 1;
+					++pair_at;
+				}
+				if (add_inst) {
+					if (rec_at < d.cap_recs) { d.rec_key[rec_at] = mesh_sort_key; d.rec_value[rec_at] = value; } else d.counters[KEYS_OVERFLOW] = 1;
+					++rec_at;
+				}
+			}
+			const bool in_range = add_inst && mesh_sort_key <= d.max_sort_key;
+			if (add_inst && !in_range) d.counters[KEYS_OVERFLOW] = 2; // a mesh sort key above Renderer::getMaxSortKey(): the reference indexes out of bounds
+			wave_histogram(in_range, mesh_sort_key, d.group_count);
+		}
 	}
 }
 
@@ -217,25 +270,26 @@ __global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
 }
 
 __global__ __launch_bounds__(256) void k_keys_scatter(KeysDevice d) {
-	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
 	const uint32_t n = min(d.counters[KEYS_N_RECS], d.cap_recs);
-	if (i - (i & 63u) >= n) return;
-	const bool has = i < n && d.rec_key[i] <= d.max_sort_key;
-	const uint32_t key = has ? d.rec_key[i] : 0;
-	// one cursor atomic per distinct key of the wave
-	uint64_t todo = __ballot(has);
-	uint32_t slot = 0;
-	while (todo) {
-		const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
-		const uint32_t k = (uint32_t)__shfl((int)key, (int)leader);
-		const uint64_t same = __ballot(has && key == k) & todo;
-		uint32_t base = 0;
-		if (lane_id() == leader) base = atomicAdd(d.group_cursor + k, (uint32_t)__popcll(same));
-		base = (uint32_t)__shfl((int)base, (int)leader);
-		if (has && key == k && ((same >> lane_id()) & 1ull)) slot = d.group_offset[k] + base + rank_in(same);
-		todo &= ~same;
+	for (uint32_t tile = blockIdx.x * 256; tile < n; tile += gridDim.x * 256) {
+		const uint32_t i = tile + threadIdx.x;
+		const bool has = i < n && d.rec_key[i] <= d.max_sort_key;
+		const uint32_t key = has ? d.rec_key[i] : 0;
+		// one cursor atomic per distinct key of the wave
+		uint64_t todo = __ballot(has);
+		uint32_t slot = 0;
+		while (todo) {
+			const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+			const uint32_t k = (uint32_t)__shfl((int)key, (int)leader);
+			const uint64_t same = __ballot(has && key == k) & todo;
+			uint32_t base = 0;
+			if (lane_id() == leader) base = atomicAdd(d.group_cursor + k, (uint32_t)__popcll(same));
+			base = (uint32_t)__shfl((int)base, (int)leader);
+			if ((same >> lane_id()) & 1ull) slot = d.group_offset[k] + base + rank_in(same);
+			todo &= ~same;
+		}
+		if (has) d.group_values[slot] = d.rec_value[i];
 	}
-	if (has) d.group_values[slot] = d.rec_value[i];
 }
 
 __global__ __launch_bounds__(256) void k_keys_groups(KeysDevice d, const KeysViewDevice kv) {
@@ -263,7 +317,9 @@ __global__ __launch_bounds__(256) void k_keys_groups(KeysDevice d, const KeysVie
 hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const int32_t* mesh_ids, const uint32_t* mesh_count,
 	uint32_t mesh_cap, const int32_t* decal_ids, const uint32_t* decal_count, uint32_t decal_cap, const int32_t* curve_ids,
 	const uint32_t* curve_count, uint32_t curve_cap) {
-	if (mesh_cap && d.model != nullptr) hipLaunchKernelGGL(k_keys_mesh, dim3((mesh_cap + 255) / 256), dim3(256), 0, s, d, view, mesh_ids, mesh_count);
+	const uint32_t grid_cap = 256 * 8; // fixed-size grids walk the lists in tiles: the counts live on the device
+	if (mesh_cap && d.model != nullptr)
+		hipLaunchKernelGGL(k_keys_mesh, dim3(std::min((mesh_cap + KEYS_BLOCK - 1) / KEYS_BLOCK, grid_cap)), dim3(KEYS_BLOCK), 0, s, d, view, mesh_ids, mesh_count);
 	if (decal_cap && d.decal_sort_key != nullptr)
 		hipLaunchKernelGGL(k_keys_decal, dim3((decal_cap + 255) / 256), dim3(256), 0, s, d, view, decal_ids, decal_count, d.decal_sort_key, d.decal_layer,
 			(uint32_t)LMX_DRAW_DECAL);
@@ -271,7 +327,7 @@ hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice&
 		hipLaunchKernelGGL(k_keys_decal, dim3((curve_cap + 255) / 256), dim3(256), 0, s, d, view, curve_ids, curve_count, d.curve_sort_key, d.curve_layer,
 			(uint32_t)LMX_DRAW_CURVE_DECAL);
 	hipLaunchKernelGGL(k_keys_offsets, dim3(1), dim3(1024), 0, s, d);
-	if (d.cap_recs) hipLaunchKernelGGL(k_keys_scatter, dim3((d.cap_recs + 255) / 256), dim3(256), 0, s, d);
+	if (d.cap_recs) hipLaunchKernelGGL(k_keys_scatter, dim3(std::min((d.cap_recs + 255) / 256, grid_cap * 4)), dim3(256), 0, s, d);
 	hipLaunchKernelGGL(k_keys_groups, dim3((d.max_sort_key + 256) / 256), dim3(256), 0, s, d, view);
 	return hipGetLastError();
 }

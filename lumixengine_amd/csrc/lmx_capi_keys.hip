@@ -66,6 +66,7 @@ int lmx_keys_set_instances(LmxContext* ctx, uint32_t n_entities, const int32_t* 
 	if (int rc = upload(ctx, ks.d_dirty, dirty, n_entities)) return rc;
 	if (int rc = upload(ctx, ks.d_pose_frame, pose_frame, n_entities)) return rc;
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (n_entities != ks.n_entities) ks.have_decals = ks.have_curves = false; // decal tables of another entity range are dropped
 	ks.n_entities = n_entities;
 	ks.have_instances = true;
 	return LMX_OK;

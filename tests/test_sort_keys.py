@@ -212,11 +212,12 @@ def test_gpu_sort_keys_read_world_positions(gpu_ctx, oracle_port):
     sk = api.SortKeys(gpu_ctx)
     sk.setModels(sc["models"], sc["mesh_types"])
     sk.setInstances(sc["model"], sc["material_offset"], sc["mesh_materials"], sc["lod"], sc["flags"], sc["dirty"], sc["pose_frame"])
+    sk.setDecals(n)  # no decal tables: DECAL / CURVE_DECAL pages produce nothing
     sk.bindWorld(True)
     kv = api.keys_view(camera_pos=tuple(pos[0]), layer_to_bucket=sc["layer_to_bucket"], bucket_depth_sorted=sc["bucket_depth_sorted"], frame_number=7)
     res = cs.cull(fr)
     mesh_ids = res.ids(0, 0)
-    assert len(mesh_ids) > 50
+    assert len(mesh_ids) > 20
     sk.run(kv, sc["max_sort_key"])
     want = oracle_port.create_sort_keys(kv, sc["max_sort_key"], mesh_ids, [], [], sc, pos)
     keys, values = sk.readPairs()
