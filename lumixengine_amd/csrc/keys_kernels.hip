@@ -62,23 +62,26 @@ __device__ __forceinline__ uint32_t float_flip(uint32_t bits) {
 	return bits ^ mask;
 }
 
-constexpr int KEYS_BLOCK = 1024;
+constexpr int KEYS_BLOCK = 512; // 8 waves: 3 blocks per CU at 67 VGPRs
 
-// The visible list is walked in tiles of 1024 entities by a fixed-size grid. Per tile every lane first COUNTS what it will
-// emit, the block reserves its output ranges with one atomic per list (4 per 1024 entities: returning atomics on one address
+// The visible list is walked in tiles of 512 entities by a fixed-size grid. Per tile every lane first COUNTS what it will
+// emit, the block reserves its output ranges with one atomic per list (4 per 512 entities: returning atomics on one address
 // retire at ~90 per microsecond chip-wide, one per wave and mesh was 15x slower than this kernel's memory work), and a second
 // walk writes at lane-private positions.
 __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const KeysViewDevice kv /* by value: captured at launch */,
 	const int32_t* __restrict__ ids, const uint32_t* __restrict__ n_visible) {
 	__shared__ uint32_t s_wave[KEYS_BLOCK / 64][3]; // per wave: pairs | recs << 16, poses, dirty
 	__shared__ uint32_t s_base[4];
+	__shared__ uint32_t s_bucket[256]; // bucket_map: an LDS read instead of one more dependent global load per mesh
+	if (threadIdx.x < 255) s_bucket[threadIdx.x] = kv.bucket_map[threadIdx.x];
+	__syncthreads();
 	const uint32_t n = *n_visible;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	for (uint32_t tile = blockIdx.x * KEYS_BLOCK; tile < n; tile += gridDim.x * KEYS_BLOCK) {
 		const uint32_t i = tile + threadIdx.x;
 		// ranges of mesh indices this lane emits keys for: [from0, to0] then [from1, to1]
 		int32_t from0 = 0, to0 = -1, from1 = 0, to1 = -1;
-		uint32_t e = 0, mat0 = 0, first_mesh = 0;
+		uint32_t e = 0, mat0 = 0;
 		bool moved = false, queue_dirty = false;
 		double px = 0, py = 0, pz = 0;
 		if (i < n) {
@@ -99,7 +102,6 @@ __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const Ke
 					queue_dirty = true; // queueMaterialOverrideRefresh(e); continue;  (:3879-3882)
 				} else {
 					mat0 = d.material_offset[e];
-					first_mesh = m.first_mesh;
 					moved = (d.flags[e] & LMX_MODEL_INSTANCE_MOVED) != 0;
 					float lod = d.lod[e];
 					if (lod != (float)lod_idx) { // :3937-3952
@@ -126,8 +128,9 @@ __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const Ke
 		bool push_pose = false;
 		for (int32_t it = 0; it < len0 + len1; ++it) {
 			const int32_t mesh_idx = it < len0 ? from0 + it : from1 + (it - len0);
-			const uint32_t bucket = kv.bucket_map[d.mesh_materials[mat0 + (uint32_t)mesh_idx].layer];
-			if (d.mesh_types[first_mesh + (uint32_t)mesh_idx] == LMX_MESH_SKINNED) {
+			const LmxMeshMaterial mm = d.mesh_materials[mat0 + (uint32_t)mesh_idx]; // device copy: _pad[0] = Mesh::type of the model's mesh
+			const uint32_t bucket = s_bucket[mm.layer];
+			if (mm._pad[0] == LMX_MESH_SKINNED) {
 				// Pose::frame stamp (:3889-3898): exactly one visit per frame hands the instance to the pose processor
 				if (!push_pose && d.pose_frame[e] != kv.frame_number) push_pose = atomicExch(d.pose_frame + e, kv.frame_number) != kv.frame_number;
 				++n_pairs;
@@ -172,11 +175,11 @@ __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const Ke
 			if (has) {
 				const int32_t mesh_idx = it < len0 ? from0 + it : from1 + (it - len0);
 				const LmxMeshMaterial mm = d.mesh_materials[mat0 + (uint32_t)mesh_idx];
-				const uint32_t bucket = kv.bucket_map[mm.layer];
+				const uint32_t bucket = s_bucket[mm.layer];
 				mesh_sort_key = mm.sort_key;
 				bool push_pair = false;
 				uint64_t key = 0, value = 0;
-				if (d.mesh_types[first_mesh + (uint32_t)mesh_idx] == LMX_MESH_SKINNED) {
+				if (mm._pad[0] == LMX_MESH_SKINNED) {
 					value = (uint64_t)e | ((uint64_t)LMX_DRAW_SKINNED << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
 					key = (uint64_t)mm.sort_key | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT); // makeMeshSortKey(mesh_mat, u8 bucket)
 					push_pair = true;
@@ -275,20 +278,21 @@ __global__ __launch_bounds__(256) void k_keys_scatter(KeysDevice d) {
 		const uint32_t i = tile + threadIdx.x;
 		const bool has = i < n && d.rec_key[i] <= d.max_sort_key;
 		const uint32_t key = has ? d.rec_key[i] : 0;
-		// one cursor atomic per distinct key of the wave
+		// per distinct key of the wave: its first lane (leader), the number of lanes holding it and every lane's rank among
+		// them — ALU only; then ALL leaders reserve their cursor ranges at once (one memory round trip per wave, not one per key)
 		uint64_t todo = __ballot(has);
-		uint32_t slot = 0;
+		uint32_t leader_of = 0, rank = 0, count = 0;
 		while (todo) {
 			const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
 			const uint32_t k = (uint32_t)__shfl((int)key, (int)leader);
 			const uint64_t same = __ballot(has && key == k) & todo;
-			uint32_t base = 0;
-			if (lane_id() == leader) base = atomicAdd(d.group_cursor + k, (uint32_t)__popcll(same));
-			base = (uint32_t)__shfl((int)base, (int)leader);
-			if ((same >> lane_id()) & 1ull) slot = d.group_offset[k] + base + rank_in(same);
+			if ((same >> lane_id()) & 1ull) { leader_of = leader; rank = rank_in(same); count = (uint32_t)__popcll(same); }
 			todo &= ~same;
 		}
-		if (has) d.group_values[slot] = d.rec_value[i];
+		uint32_t base = 0;
+		if (has && leader_of == lane_id()) base = atomicAdd(d.group_cursor + key, count);
+		base = (uint32_t)__shfl((int)base, (int)leader_of);
+		if (has) d.group_values[d.group_offset[key] + base + rank] = d.rec_value[i];
 	}
 }
 

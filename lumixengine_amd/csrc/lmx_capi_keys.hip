@@ -38,6 +38,7 @@ int lmx_keys_set_models(LmxContext* ctx, const LmxKeysModel* models, uint32_t n_
 	if (int rc = upload(ctx, ks.d_mesh_types, mesh_types, n_meshes)) return rc;
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	ks.models.assign(models, models + n_models);
+	ks.mesh_types.assign(mesh_types, mesh_types + n_meshes);
 	ks.n_meshes = n_meshes;
 	ks.max_lod_span = max_span;
 	return LMX_OK;
@@ -57,10 +58,19 @@ int lmx_keys_set_instances(LmxContext* ctx, uint32_t n_entities, const int32_t* 
 			return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %u: mesh materials [%u, +%u) outside the table", e, material_offset[e], ks.models[model[e]].mesh_count);
 		if (!(lod[e] >= 0.f && lod[e] <= 4.f)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %u: ModelInstance::lod %g outside [0, 4]", e, (double)lod[e]);
 	}
+	// device copy of the material spans with Mesh::type of the model's mesh folded into the padding byte: one gather less
+	// on the device's dependent-load chain (entity -> model -> mesh type)
+	std::vector<LmxMeshMaterial> dev_mm(mesh_materials, mesh_materials + n_mesh_materials);
+	for (LmxMeshMaterial& m : dev_mm) m._pad[0] = m._pad[1] = m._pad[2] = 0;
+	for (uint32_t e = 0; e < n_entities; ++e) {
+		if (model[e] < 0) continue;
+		const LmxKeysModel& m = ks.models[model[e]];
+		for (uint32_t k = 0; k < m.mesh_count; ++k) dev_mm[material_offset[e] + k]._pad[0] = ks.mesh_types[m.first_mesh + k];
+	}
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (int rc = upload(ctx, ks.d_model, model, n_entities)) return rc;
 	if (int rc = upload(ctx, ks.d_material_offset, material_offset, n_entities)) return rc;
-	if (int rc = upload(ctx, ks.d_mesh_materials, mesh_materials, n_mesh_materials)) return rc;
+	if (int rc = upload(ctx, ks.d_mesh_materials, dev_mm.data(), n_mesh_materials)) return rc;
 	if (int rc = upload(ctx, ks.d_lod, lod, n_entities)) return rc;
 	if (int rc = upload(ctx, ks.d_flags, flags, n_entities)) return rc;
 	if (int rc = upload(ctx, ks.d_dirty, dirty, n_entities)) return rc;

@@ -198,6 +198,7 @@ struct SkinState {
 // createSortKeys (lmx_capi_keys.hip): entity-indexed model-instance tables, decal material tables, outputs of the last run
 struct KeysState {
 	std::vector<LmxKeysModel> models;
+	std::vector<uint8_t> mesh_types;
 	uint32_t n_meshes = 0, max_lod_span = 1;
 	uint32_t n_entities = 0, n_positions = 0, max_sort_key = 0;
 	bool have_instances = false, have_decals = false, have_curves = false, use_world = false, ran = false, sorted = false;

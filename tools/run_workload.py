@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["cull_default", "cull_stream", "cull_dense", "cull8", "xform", "skin", "skin_distinct"], required=True)
+    ap.add_argument("--workload", choices=["cull_default", "cull_stream", "cull_dense", "cull8", "xform", "skin", "skin_distinct", "keys"], required=True)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--entities", type=int, default=10_000_000)
     ap.add_argument("--instances", type=int, default=2000)
@@ -27,7 +27,22 @@ def main():
 
     ctx = api.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    if args.workload.startswith("cull"):
+    if args.workload == "keys":  # cull + createSortKeys on the dense 10 M scene, default camera (1 M visible)
+        sc = scenes.cull_scene(args.entities, 5000.0, seed=2)
+        cs = api.CullingSystem(ctx)
+        cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+        fr = api.viewport_frustum()
+        ks = scenes.keys_scene(args.entities, sc["type"], seed=12, max_sort_key=4095)
+        sk = api.SortKeys(ctx)
+        sk.setModels(ks["models"], ks["mesh_types"])
+        sk.setInstances(ks["model"], ks["material_offset"], ks["mesh_materials"], ks["lod"], ks["flags"], ks["dirty"], ks["pose_frame"])
+        sk.setPositions(sc["pos"])
+        for f in range(args.steps):
+            cs.cull(fr)
+            sk.run(api.keys_view(layer_to_bucket=ks["layer_to_bucket"], bucket_depth_sorted=ks["bucket_depth_sorted"], frame_number=100 + f), 4095)
+        ctx.synchronize()
+        print(sk.counts())
+    elif args.workload.startswith("cull"):
         half = 5000.0 if args.workload == "cull_dense" else 15000.0
         sc = scenes.cull_scene(args.entities, half, seed=2, mixed_types=args.workload == "cull8")
         cs = api.CullingSystem(ctx)
