@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["cull_default", "cull_stream", "cull_dense", "cull8", "xform", "skin", "skin_distinct", "keys"], required=True)
+    ap.add_argument("--workload", choices=["cull_default", "cull_stream", "cull_dense", "cull8", "xform", "skin", "skin_distinct", "keys", "target"], required=True)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--entities", type=int, default=10_000_000)
     ap.add_argument("--instances", type=int, default=2000)
@@ -73,6 +73,24 @@ def main():
         for _ in range(args.steps):
             w.setTransformsDevice(len(roots), d_ent.data_ptr(), d_tr.data_ptr())
             w.propagate()
+        ctx.synchronize()
+    elif args.workload == "target":  # north-star frame on one GPU: 10 M culled + 100 k skinned instances x 10 k verts (shared mesh)
+        sc = scenes.cull_scene(args.entities, 15000.0, seed=2)
+        cs = api.CullingSystem(ctx)
+        cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+        fr = api.viewport_frustum()
+        n_inst = 100_000
+        s = scenes.skeleton(64, seed=4)
+        sk = api.Skinning(ctx)
+        model = sk.addModel(s["parents"], s["bind"], s["first_nonroot"])
+        mesh = sk.addMesh(*scenes.skinned_mesh(10_000, 64, seed=6))
+        sk.setInstances(np.full(n_inst, model, np.uint32), np.full(n_inst, mesh, np.uint32))
+        pos, rot = scenes.relative_poses(n_inst, 64, seed=8)
+        d_pos, d_rot = torch.from_numpy(pos).cuda(), torch.from_numpy(rot).cuda()
+        sk.setPoseSourceDevice(d_pos.data_ptr(), d_rot.data_ptr(), n_inst * 64)
+        for _ in range(args.steps):
+            cs.cull(fr)
+            sk.run()
         ctx.synchronize()
     else:
         n_inst, n_verts = args.instances, 10_000
