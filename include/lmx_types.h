@@ -155,6 +155,63 @@ typedef struct LmxKeysView {
 	uint8_t bucket_depth_sorted[256]; /* buckets[b].sort == BucketDesc::DEPTH */
 } LmxKeysView;
 
+/* ---- animation sampling inputs (animation/animation.h:86-115, animation.cpp:29-204) ---- */
+
+typedef struct LmxAnimConstTranslation { /* Animation::ConstTranslationTrack */
+	float value[3];
+	uint16_t bone_index;
+	uint16_t _pad;
+} LmxAnimConstTranslation;
+
+typedef struct LmxAnimTranslationTrack { /* Animation::TranslationTrack: bit-packed, value = min + to_range * bits (in fp64, animation.cpp:313-316) */
+	float min[3];
+	float to_range[3];
+	uint16_t offset_bits;
+	uint16_t bone_index;
+	uint8_t bitsizes[3];
+	uint8_t _pad;
+} LmxAnimTranslationTrack;
+
+typedef struct LmxAnimConstRotation { /* Animation::ConstRotationTrack */
+	float value[4];
+	uint16_t bone_index;
+	uint16_t _pad;
+} LmxAnimConstRotation;
+
+typedef struct LmxAnimRotationTrack { /* Animation::RotationTrack: 3 packed channels + sign bit, the skipped one rebuilt from the norm */
+	float min[3];
+	float to_range[3];
+	uint16_t offset_bits;
+	uint16_t bone_index;
+	uint8_t bitsizes[3];
+	uint8_t skipped_channel;
+} LmxAnimRotationTrack;
+
+/* What AnimationSampler reads of an Animation resource. Streams hold frame_count + 1 frames (animation.cpp:464). */
+typedef struct LmxAnimation {
+	float fps;                               /* m_fps */
+	uint32_t frame_count;                    /* m_frame_count */
+	uint32_t length;                         /* getLength().raw(): Time units of 1 / 32768 s (animation.h:41) */
+	uint32_t translations_frame_size_bits;   /* m_translations_frame_size_bits */
+	uint32_t rotations_frame_size_bits;      /* m_rotations_frame_size_bits */
+	uint32_t n_const_translations, n_translations, n_const_rotations, n_rotations;
+	const LmxAnimConstTranslation* const_translations;
+	const LmxAnimTranslationTrack* translations;
+	const LmxAnimConstRotation* const_rotations;
+	const LmxAnimRotationTrack* rotations;
+	const uint8_t* translation_stream;
+	uint64_t translation_stream_size;
+	const uint8_t* rotation_stream;
+	uint64_t rotation_stream_size;
+	int32_t root_translation_track;          /* RootMotion::translation_track_idx, -1 = none (animation.cpp:320) */
+	int32_t root_rotation_track;             /* RootMotion::rotation_track_idx, -1 = none (animation.cpp:33) */
+	const float* root_pose_translations;     /* RootMotion::pose_translations, (frame_count + 1) x 3 */
+	const float* root_pose_rotations;        /* RootMotion::pose_rotations, (frame_count + 1) x 4 */
+} LmxAnimation;
+
+#define LMX_TIME_ONE_SECOND (1u << 15)       /* Time::ONE_SECOND, animation/animation.h:41 */
+#define LMX_ANIM_NONE 0xffffffffu
+
 #ifdef __cplusplus
 }
 #endif

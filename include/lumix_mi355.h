@@ -63,7 +63,8 @@ enum {
 	LMX_K_SKIN_VERTICES = 5,
 	LMX_K_CULL_DYNAMIC = 6,
 	LMX_K_SORT_KEYS = 7,
-	LMX_K_COUNT = 8
+	LMX_K_ANIM_UPDATE = 8,
+	LMX_K_COUNT = 9
 };
 LMX_API int lmx_profile_enable(LmxContext* ctx, int enable);
 LMX_API int lmx_profile_reset(LmxContext* ctx);
@@ -198,6 +199,26 @@ LMX_API int lmx_frustum_perspective(const double pos[3], const float dir[3], con
 	float far_d, LmxShiftedFrustum* out);
 LMX_API int lmx_frustum_ortho(const double pos[3], const float dir[3], const float up[3], float width, float height, float near_d,
 	float far_d, LmxShiftedFrustum* out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Animation sampling: AnimationModuleImpl::updateAnimable (animation/animation_module.cpp:439-472) for every instance of
+ * the skin instance table: pose = Model::getRelativePose (renderer/model.cpp:226-237), overwritten by
+ * Animation::getRelativePose without a bone mask (animation/animation.cpp:117-204, :294-311: constant tracks, bit-packed
+ * translation / rotation tracks of two neighbouring frames, lerp / simd_nlerp, blended with `weight` when it is < 0.9999),
+ * then the Animable's time advances by time_delta modulo the animation length (:458-470). The relative poses land in the
+ * pose buffers lmx_skin_run consumes, so animation -> absolute pose -> palette -> vertices never leaves HBM.
+ * ------------------------------------------------------------------------------------------------------------------ */
+LMX_API int lmx_anim_add(LmxContext* ctx, const LmxAnimation* animation, uint32_t* out_animation);
+/* Model::Bone::relative_transform of a model registered with lmx_skin_add_model (the pose an un-animated bone keeps). */
+LMX_API int lmx_anim_set_model_pose(LmxContext* ctx, uint32_t model, const LmxLocalRigidTransform* relative, uint32_t n_bones);
+/* One Animable per skin instance: animation id (LMX_ANIM_NONE = the instance keeps its model's relative pose) and
+ * Animable::time in Time units (1 / 32768 s, animation/animation.h:17-41). Times then live and advance on the device. */
+LMX_API int lmx_anim_set_animables(LmxContext* ctx, uint32_t n_instances, const uint32_t* animation, const uint32_t* time);
+LMX_API int lmx_anim_set_weight(LmxContext* ctx, float weight); /* SampleContext::weight, default 1 */
+LMX_API int lmx_anim_update(LmxContext* ctx, float time_delta);
+LMX_API int lmx_anim_read_times(LmxContext* ctx, uint32_t* time, uint32_t n_instances);
+/* The relative pose of an instance after lmx_anim_update (before lmx_skin_run turns it into the absolute one). */
+LMX_API int lmx_anim_read_pose(LmxContext* ctx, uint32_t instance, float* out_pos, float* out_rot, uint32_t cap_bones);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Sort keys: PipelineImpl::createSortKeys (renderer/pipeline.cpp:3789-3968), the consumer of the visible list (SURVEY.md

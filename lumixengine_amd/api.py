@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(PKG, "liblumix_mi355.so")
 MAX_FRUSTA, MAX_TYPES, MAX_VIEWS = 8, 8, 8
 TYPE_ALL = 0xFF
 (K_CULL_CLASSIFY, K_CULL_SPHERES, K_XFORM_LEVEL, K_SPHERE_REFRESH, K_POSE_PALETTE, K_SKIN_VERTICES, K_CULL_DYNAMIC) = range(7)
-KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices", "cull_dynamic", "sort_keys"]
+KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices", "cull_dynamic", "sort_keys", "anim_update"]
 
 SHIFTED_FRUSTUM = np.dtype(
     [("xs", "<f4", 8), ("ys", "<f4", 8), ("zs", "<f4", 8), ("ds", "<f4", 8), ("points", "<f4", (8, 3)), ("origin", "<f8", 3), ("_pad", "<f8")],
@@ -34,6 +34,35 @@ TRANSFORM = np.dtype([("pos", "<f8", 3), ("rot", "<f4", 4), ("scale", "<f4", 3),
 LOCAL_RIGID = np.dtype([("pos", "<f4", 3), ("rot", "<f4", 4)], align=True)
 MATRIX = np.dtype([("columns", "<f4", (4, 4))], align=True)
 SKIN = np.dtype([("weights", "<f4", 4), ("indices", "<i2", 4)], align=True)
+ANIM_CONST_TRANSLATION = np.dtype([("value", "<f4", 3), ("bone_index", "<u2"), ("_pad", "<u2")], align=True)
+ANIM_TRANSLATION_TRACK = np.dtype([("min", "<f4", 3), ("to_range", "<f4", 3), ("offset_bits", "<u2"), ("bone_index", "<u2"), ("bitsizes", "u1", 3), ("_pad", "u1")], align=True)
+ANIM_CONST_ROTATION = np.dtype([("value", "<f4", 4), ("bone_index", "<u2"), ("_pad", "<u2")], align=True)
+ANIM_ROTATION_TRACK = np.dtype([("min", "<f4", 3), ("to_range", "<f4", 3), ("offset_bits", "<u2"), ("bone_index", "<u2"), ("bitsizes", "u1", 3), ("skipped_channel", "u1")],
+                               align=True)
+
+
+class LmxAnimation(C.Structure):
+    """LmxAnimation of include/lmx_types.h."""
+    _fields_ = [("fps", C.c_float), ("frame_count", C.c_uint32), ("length", C.c_uint32), ("translations_frame_size_bits", C.c_uint32),
+                ("rotations_frame_size_bits", C.c_uint32), ("n_const_translations", C.c_uint32), ("n_translations", C.c_uint32),
+                ("n_const_rotations", C.c_uint32), ("n_rotations", C.c_uint32), ("const_translations", C.c_void_p), ("translations", C.c_void_p),
+                ("const_rotations", C.c_void_p), ("rotations", C.c_void_p), ("translation_stream", C.c_void_p), ("translation_stream_size", C.c_uint64),
+                ("rotation_stream", C.c_void_p), ("rotation_stream_size", C.c_uint64), ("root_translation_track", C.c_int32),
+                ("root_rotation_track", C.c_int32), ("root_pose_translations", C.c_void_p), ("root_pose_rotations", C.c_void_p)]
+
+
+def animation_struct(a: dict):
+    """(LmxAnimation, keep-alive list) from a lumixengine_amd.scenes.animation dict."""
+    keep = [np.ascontiguousarray(a["const_translations"], ANIM_CONST_TRANSLATION), np.ascontiguousarray(a["translations"], ANIM_TRANSLATION_TRACK),
+            np.ascontiguousarray(a["const_rotations"], ANIM_CONST_ROTATION), np.ascontiguousarray(a["rotations"], ANIM_ROTATION_TRACK),
+            np.ascontiguousarray(a["translation_stream"], np.uint8), np.ascontiguousarray(a["rotation_stream"], np.uint8),
+            np.ascontiguousarray(a["root_pose_translations"], np.float32), np.ascontiguousarray(a["root_pose_rotations"], np.float32)]
+    st = LmxAnimation(float(a["fps"]), int(a["frame_count"]), int(a["length"]), int(a["translations_frame_size_bits"]), int(a["rotations_frame_size_bits"]),
+                      len(keep[0]), len(keep[1]), len(keep[2]), len(keep[3]), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]), _ptr(keep[4]),
+                      len(keep[4]), _ptr(keep[5]), len(keep[5]), int(a["root_translation_track"]), int(a["root_rotation_track"]), _ptr(keep[6]), _ptr(keep[7]))
+    return st, keep
+
+
 LOD_INDICES = np.dtype([("from", "<i4"), ("to", "<i4")])
 KEYS_MODEL = np.dtype([("lod_distances", "<f4", 4), ("lod_indices", LOD_INDICES, 5), ("first_mesh", "<u4"), ("mesh_count", "<u4")], align=True)
 MESH_MATERIAL = np.dtype([("sort_key", "<u4"), ("layer", "u1"), ("_pad", "u1", 3)], align=True)
@@ -99,6 +128,13 @@ SYMBOLS = {
     "lmx_skin_enable_dual_quats": (_ci, [_vp, _ci]),
     "lmx_skin_read_dual_quats": (_ci, [_vp, _u32, _vp, _u32]),
     "lmx_skin_read_pose": (_ci, [_vp, _u32, _vp, _vp, _u32]),
+    "lmx_anim_add": (_ci, [_vp, _vp, C.POINTER(_u32)]),
+    "lmx_anim_set_model_pose": (_ci, [_vp, _u32, _vp, _u32]),
+    "lmx_anim_set_animables": (_ci, [_vp, _u32, _vp, _vp]),
+    "lmx_anim_set_weight": (_ci, [_vp, _f32]),
+    "lmx_anim_update": (_ci, [_vp, _f32]),
+    "lmx_anim_read_times": (_ci, [_vp, _vp, _u32]),
+    "lmx_anim_read_pose": (_ci, [_vp, _u32, _vp, _vp, _u32]),
     "lmx_keys_set_models": (_ci, [_vp, _vp, _u32, _vp, _u32]),
     "lmx_keys_set_instances": (_ci, [_vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "lmx_keys_set_decals": (_ci, [_vp, _u32, _vp, _vp, _vp, _vp]),
@@ -567,6 +603,39 @@ class Skinning:
         out = np.zeros(n, MATRIX)
         self.ctx.check(self.lib.lmx_skin_read_palette(self.ctx.h, instance, _ptr(out), n))
         return out
+
+    # ---- animation sampling (AnimationModuleImpl::updateAnimable for every instance) ----
+    def addAnimation(self, anim: dict) -> int:
+        st, keep = animation_struct(anim)
+        out = C.c_uint32(0)
+        self.ctx.check(self.lib.lmx_anim_add(self.ctx.h, C.addressof(st), C.byref(out)))
+        return out.value
+
+    def setModelPose(self, model: int, relative):
+        relative = np.ascontiguousarray(relative, LOCAL_RIGID)
+        self.ctx.check(self.lib.lmx_anim_set_model_pose(self.ctx.h, model, _ptr(relative), len(relative)))
+
+    def setAnimables(self, animation, time):
+        animation, time = np.ascontiguousarray(animation, np.uint32), np.ascontiguousarray(time, np.uint32)
+        self._n_animables = len(animation)
+        self.ctx.check(self.lib.lmx_anim_set_animables(self.ctx.h, len(animation), _ptr(animation), _ptr(time)))
+
+    def setAnimWeight(self, weight: float):
+        self.ctx.check(self.lib.lmx_anim_set_weight(self.ctx.h, float(weight)))
+
+    def updateAnimables(self, time_delta: float):
+        self.ctx.check(self.lib.lmx_anim_update(self.ctx.h, float(time_delta)))
+
+    def readTimes(self) -> np.ndarray:
+        out = np.zeros(self._n_animables, np.uint32)
+        self.ctx.check(self.lib.lmx_anim_read_times(self.ctx.h, _ptr(out), len(out)))
+        return out
+
+    def readRelativePose(self, instance: int):
+        n = self._models[int(self._inst_model[instance])]
+        pos, rot = np.zeros((n, 3), np.float32), np.zeros((n, 4), np.float32)
+        self.ctx.check(self.lib.lmx_anim_read_pose(self.ctx.h, instance, _ptr(pos), _ptr(rot), n))
+        return pos, rot
 
     def setPoseWriteback(self, on: bool = True):
         """Store the absolute pose next to the palette (default) or not (readPose then fails)."""

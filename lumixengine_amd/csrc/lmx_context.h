@@ -219,6 +219,34 @@ struct KeysState {
 	DevBuf<char> d_sort_temp;
 };
 
+// animation sampling (lmx_capi_anim.hip): Animation resources flattened into concatenated tables, one Animable per skin instance
+struct AnimState {
+	std::vector<AnimDevice> anims;
+	std::vector<int32_t> src;
+	std::vector<LmxAnimConstTranslation> ct;
+	std::vector<LmxAnimTranslationTrack> tt;
+	std::vector<LmxAnimConstRotation> cr;
+	std::vector<LmxAnimRotationTrack> rt;
+	std::vector<uint8_t> tstream, rstream;
+	std::vector<float> root_t;
+	std::vector<float4> root_r;
+	std::vector<float> rel_pos;    // Model::Bone::relative_transform of every skin model, by model bone offset
+	std::vector<float4> rel_rot;
+	bool tables_dirty = false;
+	uint32_t n_animables = 0;
+	float weight = 1.f;
+	DevBuf<AnimDevice> d_anims;
+	DevBuf<int32_t> d_src;
+	DevBuf<LmxAnimConstTranslation> d_ct;
+	DevBuf<LmxAnimTranslationTrack> d_tt;
+	DevBuf<LmxAnimConstRotation> d_cr;
+	DevBuf<LmxAnimRotationTrack> d_rt;
+	DevBuf<uint8_t> d_tstream, d_rstream;
+	DevBuf<float> d_root_t, d_rel_pos;
+	DevBuf<float4> d_root_r, d_rel_rot;
+	DevBuf<uint32_t> d_anim_of, d_time_of;
+};
+
 struct ProfSlot { hipEvent_t a, b; int kernel; };
 
 
@@ -238,6 +266,7 @@ struct LmxContext {
 	lmx::WorldState world;
 	lmx::SkinState skin;
 	lmx::KeysState keys;
+	lmx::AnimState anim;
 };
 
 namespace lmx {

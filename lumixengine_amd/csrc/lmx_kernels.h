@@ -112,6 +112,31 @@ struct SkinInstance {
 // k_skin_shared work item: instances [first_inst, first_inst + count) share mesh and bone count; vertices [v_begin, v_end) of it
 struct SkinChunk { uint32_t first_inst, count, v_begin, v_end; };
 struct PoseGroup { uint32_t first_inst; uint32_t count; }; // consecutive instances of one model, count <= 16 / 8 / 4 by bone count
+// ---- animation sampling (anim_kernels.hip) ----
+struct AnimDevice { // one Animation resource: offsets into the concatenated tables of AnimTables
+	float fps;
+	uint32_t frame_count, length, tfs_bits, rfs_bits;
+	uint32_t max_bone;                 // m_max_accessed_bone_index
+	uint32_t src_off;                  // 2 * (max_bone + 1) int32: translation / rotation source per bone
+	uint32_t ct_off, tt_off, cr_off, rt_off;
+	uint32_t tstream_off, rstream_off; // bytes, 8-byte aligned
+	int32_t root_translation_track, root_rotation_track;
+	uint32_t root_off;                 // frames, into root_translations / root_rotations
+};
+struct AnimTables {
+	const int32_t* src;
+	const LmxAnimConstTranslation* const_translations;
+	const LmxAnimTranslationTrack* translations;
+	const LmxAnimConstRotation* const_rotations;
+	const LmxAnimRotationTrack* rotations;
+	const uint8_t *translation_stream, *rotation_stream;
+	const float* root_translations;
+	const float4* root_rotations;
+};
+hipError_t launch_anim_update(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, const AnimDevice* anims, const AnimTables& t,
+	const uint32_t* anim_of_instance, uint32_t* time_of_instance, float time_delta, float weight, const float* model_rel_pos,
+	const float4* model_rel_rot, float* pose_pos, float4* pose_rot);
+
 // ---- createSortKeys (keys_kernels.hip) ----
 enum { KEYS_N_PAIRS = 0, KEYS_N_RECS = 1, KEYS_N_POSES = 2, KEYS_N_DIRTY = 3, KEYS_OVERFLOW = 4, KEYS_N_GROUPS = 5, KEYS_COUNTERS = 8 };
 struct KeysViewDevice { // what the kernels read of a LmxKeysView, bucket_map as built at pipeline.cpp:3802-3812

@@ -161,3 +161,74 @@ def keys_scene(n_entities: int, types: np.ndarray, seed: int = 11, n_models: int
             "lod": lod, "flags": flags, "dirty": dirty, "pose_frame": pose_frame, "decal_key": decal_key, "decal_layer": decal_layer,
             "curve_key": decal_key[::-1].copy(), "curve_layer": decal_layer[::-1].copy(), "layer_to_bucket": layer_to_bucket,
             "bucket_depth_sorted": bucket_depth_sorted, "max_sort_key": max_sort_key}
+
+
+def animation(n_bones: int = 64, frame_count: int = 30, fps: float = 30.0, seed: int = 21, root_motion: bool = True, bone_limit: int | None = None):
+    """A compressed animation in the layout AnimationSampler reads (animation/animation.h:86-115): per bone a constant or a
+    bit-packed translation track (or none) and a constant or bit-packed rotation track (3 channels + sign bit, the largest
+    component skipped), streams of frame_count + 1 frames (animation.cpp:464), optional root-motion tracks served from
+    uncompressed per-frame arrays (animation.cpp:33-37, :320)."""
+    from .api import ANIM_CONST_TRANSLATION, ANIM_TRANSLATION_TRACK, ANIM_CONST_ROTATION, ANIM_ROTATION_TRACK
+    rng = np.random.default_rng(seed)
+    nb = n_bones if bone_limit is None else bone_limit
+    ct, tt, cr, rt = [], [], [], []
+    for b in range(nb):
+        k = rng.integers(0, 4)
+        if k == 0:
+            ct.append(b)
+        elif k <= 2:
+            tt.append(b)
+        k = rng.integers(0, 5)
+        if k == 0:
+            cr.append(b)
+        elif k <= 3:
+            rt.append(b)
+    const_t = np.zeros(len(ct), ANIM_CONST_TRANSLATION)
+    const_t["bone_index"], const_t["value"] = ct, rng.uniform(-1, 1, size=(len(ct), 3))
+    const_r = np.zeros(len(cr), ANIM_CONST_ROTATION)
+    const_r["bone_index"], const_r["value"] = cr, random_unit_quats(rng, len(cr))
+    tracks_t = np.zeros(len(tt), ANIM_TRANSLATION_TRACK)
+    tracks_r = np.zeros(len(rt), ANIM_ROTATION_TRACK)
+    n_frames = frame_count + 1
+
+    def pack(tracks, with_sign):
+        off = 0
+        for i in range(len(tracks)):
+            bits = rng.integers(5, 17, size=3)
+            tracks["bitsizes"][i] = bits
+            tracks["offset_bits"][i] = off
+            off += int(bits.sum()) + (1 if with_sign else 0)
+        frame_bits = off
+        stream = np.zeros((frame_bits * n_frames + 7) // 8 + 8, np.uint8)
+        big = 0
+        for f in range(n_frames):
+            for i in range(len(tracks)):
+                pos = frame_bits * f + int(tracks["offset_bits"][i])
+                val, sh = 0, 0
+                if with_sign:
+                    val |= int(rng.integers(0, 2))
+                    sh = 1
+                for c in range(3):
+                    nbits = int(tracks["bitsizes"][i][c])
+                    val |= int(rng.integers(0, 1 << nbits)) << sh
+                    sh += nbits
+                big |= val << pos
+        raw = big.to_bytes(len(stream), "little")
+        stream[:] = np.frombuffer(raw, np.uint8)
+        return frame_bits, stream
+
+    tracks_t["bone_index"] = tt
+    tracks_t["min"] = rng.uniform(-1.0, 0.0, size=(len(tt), 3))
+    tfs, tstream = pack(tracks_t, False)
+    tracks_t["to_range"] = rng.uniform(0.5, 2.0, size=(len(tt), 3)) / ((1 << tracks_t["bitsizes"].astype(np.int64)) - 1)
+    tracks_r["bone_index"] = rt
+    tracks_r["skipped_channel"] = rng.integers(0, 4, size=len(rt))
+    tracks_r["min"] = np.float32(-0.70710678)
+    rfs, rstream = pack(tracks_r, True)
+    tracks_r["to_range"] = np.float32(1.41421356) / ((1 << tracks_r["bitsizes"].astype(np.int64)) - 1)
+    root_t = int(rng.integers(0, len(tt))) if root_motion and len(tt) else -1
+    root_r = int(rng.integers(0, len(rt))) if root_motion and len(rt) else -1
+    return {"fps": np.float32(fps), "frame_count": frame_count, "length": int(frame_count / fps * 32768), "translations_frame_size_bits": tfs,
+            "rotations_frame_size_bits": rfs, "const_translations": const_t, "translations": tracks_t, "const_rotations": const_r, "rotations": tracks_r,
+            "translation_stream": tstream, "rotation_stream": rstream, "root_translation_track": root_t, "root_rotation_track": root_r,
+            "root_pose_translations": rng.uniform(-2, 2, size=(n_frames, 3)).astype(np.float32), "root_pose_rotations": random_unit_quats(rng, n_frames)}

@@ -13,6 +13,7 @@
  *   src/renderer/pose.cpp             Pose::computeAbsolute (scalar recurrence)
  *   src/renderer/model.cpp            invert, computeSkinMatrices, evaluateSkin
  *   src/renderer/pipeline.cpp         createSortKeys (:3789-3968) — restated only, see the note at orc_create_sort_keys
+ *   src/animation/animation.cpp       AnimationSampler, updateAnimable — restated only, see the note at orc_update_animable
  *
  * Pinning: the reference has NO tests or golden vectors for this path. The restatement is pinned
  * instead against the reference's own object code (oracle/_ref/liblmx_ref.so = reference math.cpp + geometry.cpp
@@ -1279,6 +1280,136 @@ done:
 	free(rec_key);
 	free(rec_val);
 	return rc;
+}
+
+/* ---- animation sampling: AnimationModuleImpl::updateAnimable (animation_module.cpp:439-472) --------------------------
+ * = Model::getRelativePose (model.cpp:226-237) -> Animation::getRelativePose (animation.cpp:117-204, :294-311; no bone mask)
+ * -> time advance (:458-470). PARITY UNPINNED: animation.cpp needs the resource system and core/simd_math.h uses SSE
+ * intrinsics on a float4 that the non-MSVC core/simd.h does not define, so neither compiles here; restated from the source. */
+static void orc_simd_nlerp(const float* q1, const float* q2, float t, float* out) { /* core/simd_math.h:107-123 */
+	const float inv = 1.0f - t;
+	const float p0 = q1[0] * q2[0], p1 = q1[1] * q2[1], p2 = q1[2] * q2[2], p3 = q1[3] * q2[3];
+	const float d = (p0 + p1) + (p2 + p3); /* two _mm_hadd_ps */
+	if (d < 0) t = -t;
+	float q[4];
+	for (int i = 0; i < 4; ++i) q[i] = q1[i] * inv + q2[i] * t;
+	const float s0 = q[0] * q[0], s1 = q[1] * q[1], s2 = q[2] * q[2], s3 = q[3] * q[3];
+	const float l = 1 / sqrtf((s0 + s1) + (s2 + s3));
+	for (int i = 0; i < 4; ++i) out[i] = q[i] * l;
+}
+
+ORC_API void orc_nlerp(const float* q1, const float* q2, const float* t, float* out, uint32_t n) {
+	for (uint32_t i = 0; i < n; ++i) orc_simd_nlerp(q1 + 4 * i, q2 + 4 * i, t[i], out + 4 * i);
+}
+
+static float orc_unpack_channel(uint64_t val, float min, float to_float_range, uint32_t bitsize) { /* animation.cpp:313-316 */
+	const uint64_t mask = ((uint64_t)1 << bitsize) - 1;
+	return (float)(min + to_float_range * (double)(val & mask));
+}
+
+static void orc_anim_translation(const LmxAnimation* a, uint32_t frame, uint32_t track_idx, float* out) { /* Animation::getTranslation, :318-334 */
+	const LmxAnimTranslationTrack* track = &a->translations[track_idx];
+	if ((int32_t)track_idx == a->root_translation_track) { memcpy(out, a->root_pose_translations + 3 * (size_t)frame, 12); return; }
+	const uint32_t offset = a->translations_frame_size_bits * frame + track->offset_bits;
+	uint64_t tmp;
+	memcpy(&tmp, &a->translation_stream[offset / 8], sizeof(tmp));
+	tmp >>= offset & 7;
+	out[0] = orc_unpack_channel(tmp, track->min[0], track->to_range[0], track->bitsizes[0]);
+	tmp >>= track->bitsizes[0];
+	out[1] = orc_unpack_channel(tmp, track->min[1], track->to_range[1], track->bitsizes[1]);
+	tmp >>= track->bitsizes[1];
+	out[2] = orc_unpack_channel(tmp, track->min[2], track->to_range[2], track->bitsizes[2]);
+}
+
+static void orc_anim_rotation(const LmxAnimation* a, uint32_t frame, uint32_t track_idx, float t, float* out) { /* AnimationSampler::getRotation, :30-95 */
+	const LmxAnimRotationTrack* track = &a->rotations[track_idx];
+	if ((int32_t)track_idx == a->root_rotation_track) {
+		orc_simd_nlerp(a->root_pose_rotations + 4 * (size_t)frame, a->root_pose_rotations + 4 * (size_t)(frame + 1), t, out);
+		return;
+	}
+	const uint32_t offset1 = a->rotations_frame_size_bits * frame + track->offset_bits;
+	const uint32_t offset2 = offset1 + a->rotations_frame_size_bits;
+	uint64_t packed[2];
+	memcpy(&packed[0], &a->rotation_stream[offset1 / 8], 8);
+	packed[0] >>= offset1 & 7;
+	memcpy(&packed[1], &a->rotation_stream[offset2 / 8], 8);
+	packed[1] >>= offset2 & 7;
+	float q[2][4];
+	for (int k = 0; k < 2; ++k) {
+		const int is_negative = (int)(packed[k] & 1);
+		packed[k] >>= 1;
+		const uint64_t mask_x = ((uint64_t)1 << track->bitsizes[0]) - 1, mask_y = ((uint64_t)1 << track->bitsizes[1]) - 1, mask_z = ((uint64_t)1 << track->bitsizes[2]) - 1;
+		const uint64_t py = packed[k] >> track->bitsizes[0], pz = py >> track->bitsizes[1];
+		const float vx = track->min[0] + track->to_range[0] * (float)(packed[k] & mask_x);
+		const float vy = track->min[1] + track->to_range[1] * (float)(py & mask_y);
+		const float vz = track->min[2] + track->to_range[2] * (float)(pz & mask_z);
+		const float dot = vx * vx + vy * vy + vz * vz; /* dot(Vec3, Vec3), math.cpp: x*x + y*y + z*z */
+		const float rest = 1 - dot;
+		const float skipped = sqrtf(rest > 0.f ? rest : 0.f) * (is_negative ? -1 : 1); /* maximum(0.f, 1 - dot) */
+		switch (track->skipped_channel) {
+			case 0: q[k][0] = skipped; q[k][1] = vx; q[k][2] = vy; q[k][3] = vz; break;
+			case 1: q[k][0] = vx; q[k][1] = skipped; q[k][2] = vy; q[k][3] = vz; break;
+			case 2: q[k][0] = vx; q[k][1] = vy; q[k][2] = skipped; q[k][3] = vz; break;
+			default: q[k][0] = vx; q[k][1] = vy; q[k][2] = vz; q[k][3] = skipped; break;
+		}
+	}
+	orc_simd_nlerp(q[0], q[1], t, out);
+}
+
+/* one Animable: pose (n_bones x {pos[3], rot[4]}) <- model relative pose <- animation at `time`; returns the advanced time */
+ORC_API uint32_t orc_update_animable(const LmxAnimation* a, uint32_t time, float time_delta, float weight, const LmxLocalRigidTransform* model_relative,
+	uint32_t n_bones, float* pos, float* rot) {
+	for (uint32_t i = 0; i < n_bones; ++i) { /* Model::getRelativePose, model.cpp:226-237 */
+		memcpy(pos + 3 * i, model_relative[i].pos, 12);
+		memcpy(rot + 4 * i, model_relative[i].rot, 16);
+	}
+	if (!a) return time;
+	uint32_t max_bone = 0; /* m_max_accessed_bone_index, animation.cpp:369-393 */
+	for (uint32_t i = 0; i < a->n_const_translations; ++i) if (a->const_translations[i].bone_index > max_bone) max_bone = a->const_translations[i].bone_index;
+	for (uint32_t i = 0; i < a->n_translations; ++i) if (a->translations[i].bone_index > max_bone) max_bone = a->translations[i].bone_index;
+	for (uint32_t i = 0; i < a->n_const_rotations; ++i) if (a->const_rotations[i].bone_index > max_bone) max_bone = a->const_rotations[i].bone_index;
+	for (uint32_t i = 0; i < a->n_rotations; ++i) if (a->rotations[i].bone_index > max_bone) max_bone = a->rotations[i].bone_index;
+	if (max_bone < n_bones) { /* :120 */
+		const int use_weight = weight < 0.9999f; /* :294-311 */
+		float sample = (float)(time / (double)LMX_TIME_ONE_SECOND * a->fps); /* Time::toFrame */
+		const float hi = a->frame_count - 0.00001f;
+		sample = sample < 0.f ? 0.f : (sample > hi ? hi : sample); /* clamp, :132 */
+		const uint32_t sample_idx = (uint32_t)sample;
+		const float t = sample - sample_idx;
+		const float invw = 1.0f - weight;
+		for (uint32_t i = 0; i < a->n_const_translations; ++i) {
+			float* p = pos + 3 * a->const_translations[i].bone_index;
+			const float* v = a->const_translations[i].value;
+			for (int k = 0; k < 3; ++k) p[k] = use_weight ? p[k] * invw + v[k] * weight : v[k]; /* lerp(Vec3), math.cpp:194-201 */
+		}
+		for (uint32_t i = 0; i < a->n_translations; ++i) {
+			float a0[3], a1[3], ap[3];
+			orc_anim_translation(a, sample_idx, i, a0);
+			orc_anim_translation(a, sample_idx + 1, i, a1);
+			const float invt = 1.0f - t;
+			for (int k = 0; k < 3; ++k) ap[k] = a0[k] * invt + a1[k] * t;
+			float* p = pos + 3 * a->translations[i].bone_index;
+			for (int k = 0; k < 3; ++k) p[k] = use_weight ? p[k] * invw + ap[k] * weight : ap[k];
+		}
+		for (uint32_t i = 0; i < a->n_const_rotations; ++i) {
+			float* r = rot + 4 * a->const_rotations[i].bone_index;
+			if (use_weight) orc_simd_nlerp(r, a->const_rotations[i].value, weight, r);
+			else memcpy(r, a->const_rotations[i].value, 16);
+		}
+		for (uint32_t i = 0; i < a->n_rotations; ++i) {
+			float ar[4];
+			orc_anim_rotation(a, sample_idx, i, t, ar);
+			float* r = rot + 4 * a->rotations[i].bone_index;
+			if (use_weight) orc_simd_nlerp(r, ar, weight, r);
+			else memcpy(r, ar, 16);
+		}
+	}
+	const uint32_t l = a->length; /* animation_module.cpp:458-470 */
+	if (time_delta > 0) {
+		return (time + (uint32_t)(time_delta * LMX_TIME_ONE_SECOND)) % l;
+	}
+	const uint32_t dt = (uint32_t)(-time_delta * LMX_TIME_ONE_SECOND) % l;
+	return (time + l - dt) % l;
 }
 
 ORC_API void orc_rand_fill(uint32_t u, uint32_t v, uint32_t n, uint32_t* out) {
