@@ -524,6 +524,31 @@ def extras(ctx, api, scenes, torch, timed, N, log):
     ms4b = timed(frame4, 10)
     out["target_no_pose_store_frame_ms"] = ms4b
     out["target_no_pose_store_frames_per_sec_1gpu"] = 1e3 / ms4b
+    # ... and with the relative poses sampled on the device every frame (updateAnimable for all 100 k instances, SURVEY.md 8f
+    # rank 2) instead of read from a static buffer: animation -> absolute pose -> palette -> vertices never leaves HBM
+    sk4.setPoseWriteback(True)
+    sk4.setModelPose(model4, s["bind"])
+    anim4 = [sk4.addAnimation(scenes.animation(64, 60, 30.0, seed=70 + k)) for k in range(4)]
+    rng4 = np.random.default_rng(4)
+    sk4.setAnimables(np.array(anim4, np.uint32)[rng4.integers(0, 4, size=n_inst4)], rng4.integers(0, 2 << 15, size=n_inst4).astype(np.uint32))
+
+    def frame4a():
+        cs4.cull(fr4)
+        sk4.updateAnimables(1.0 / 240.0)
+        sk4.run()
+
+    for _ in range(2):
+        frame4a()
+    ms4a = timed(frame4a, 10)
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    for _ in range(5):
+        frame4a()
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    out["target_animated_frame_ms"] = ms4a
+    out["target_animated_frames_per_sec_1gpu"] = 1e3 / ms4a
+    out["target_animated_kernel_ms"] = {api.KERNEL_NAMES[k]: round(ctx.profile_get(k)[0] / 5, 5) for k in range(len(api.KERNEL_NAMES)) if ctx.profile_get(k)[1]}
     del cs4, sk4, d_pos4, d_rot4
     # distinct meshes: every instance streams its own 36 B/vertex from HBM (the 48 B/vertex algorithmic figure is real traffic)
     n_inst2 = 1500  # 540 MB of mesh data + 180 MB of output: well beyond the 256 MiB Infinity Cache
