@@ -173,8 +173,10 @@ LMX_API int lmx_skin_set_pose_source_device(LmxContext* ctx, const void* d_posit
 /* Arithmetic of the vertex blend/transform (model.cpp:103-109). LMX_SKIN_FUSED (default): products fused into the adds
  * (v_fma_f32), results within 1e-5 relative of the reference CPU path - the tolerance BASELINE's north star sets for
  * skinned positions. LMX_SKIN_EXACT: separate multiplies and adds in the reference's order, bit-identical to it.
- * Poses and palettes are always bit-identical. */
-enum { LMX_SKIN_FUSED = 0, LMX_SKIN_EXACT = 1 };
+ * Poses and palettes are always bit-identical. LMX_SKIN_DQS: the dual-quaternion blend of the reference's own GPU skinning
+ * path instead (the SKINNED branch of data/shaders/surface_base.hlsli:196-217 + transformByDualQuat, common.hlsli:632-636):
+ * model-space positions from the dual-quaternion palette; a different deformation than linear blending by design. */
+enum { LMX_SKIN_FUSED = 0, LMX_SKIN_EXACT = 1, LMX_SKIN_DQS = 2 };
 LMX_API int lmx_skin_set_mode(LmxContext* ctx, int mode);
 /* Pose::computeAbsolute -> computeSkinMatrices -> evaluateSkin for every instance; outputs stay in HBM. */
 LMX_API int lmx_skin_run(LmxContext* ctx);

@@ -538,6 +538,9 @@ class SortKeys:
         return lod, frame
 
 
+SKIN_FUSED, SKIN_EXACT, SKIN_DQS = 0, 1, 2
+
+
 class Skinning:
     """Pose -> palette -> skinned vertices for many model instances."""
 
@@ -585,9 +588,10 @@ class Skinning:
         """run() reads the relative poses straight from this device memory (no copy) every time."""
         self.ctx.check(self.lib.lmx_skin_set_pose_source_device(self.ctx.h, d_positions, d_rotations, n_bones_total))
 
-    def setMode(self, exact: bool):
-        """exact=True: FMA-free blend, bit-identical to the reference; False (default): fused multiply-adds, within 1e-5."""
-        self.ctx.check(self.lib.lmx_skin_set_mode(self.ctx.h, 1 if exact else 0))
+    def setMode(self, exact):
+        """True / 1: FMA-free linear blend, bit-identical to the reference; False / 0 (default): fused multiply-adds, within 1e-5;
+        2 (SKIN_DQS): the dual-quaternion blend of the reference's vertex shader."""
+        self.ctx.check(self.lib.lmx_skin_set_mode(self.ctx.h, int(exact)))
 
     def run(self):
         self.ctx.check(self.lib.lmx_skin_run(self.ctx.h))

@@ -248,8 +248,8 @@ int lmx_skin_set_pose_source_device(LmxContext* ctx, const void* d_positions, co
 
 int lmx_skin_set_mode(LmxContext* ctx, int mode) {
 	LMX_CHECK_CTX(ctx);
-	if (mode != LMX_SKIN_FUSED && mode != LMX_SKIN_EXACT) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "unknown skin mode %d", mode);
-	ctx->skin.exact = mode == LMX_SKIN_EXACT;
+	if (mode != LMX_SKIN_FUSED && mode != LMX_SKIN_EXACT && mode != LMX_SKIN_DQS) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "unknown skin mode %d", mode);
+	ctx->skin.mode = mode;
 	return LMX_OK;
 }
 
@@ -262,22 +262,24 @@ int lmx_skin_run(LmxContext* ctx) {
 	const uint32_t n = (uint32_t)sk.inst.size();
 	{
 		ProfScope ps(ctx, LMX_K_POSE_PALETTE);
-		if (sk.want_dual_quats) LMX_HIP(ctx, sk.d_dual_quats.reserve(std::max<size_t>(sk.bones_total * 2, 1)));
+		const bool dual_quats = sk.want_dual_quats || sk.mode == LMX_SKIN_DQS; // the DQS vertex blend reads the dual-quaternion palette
+		if (dual_quats) LMX_HIP(ctx, sk.d_dual_quats.reserve(std::max<size_t>(sk.bones_total * 2, 1)));
 		const float* rel_pos = sk.borrowed_pos ? sk.borrowed_pos : sk.d_pose_pos.p;
 		const float4* rel_rot = sk.borrowed_rot ? sk.borrowed_rot : sk.d_pose_rot.p;
 		LMX_HIP(ctx, launch_pose_palette(ctx->stream, sk.d_inst.p, sk.d_groups.p, sk.n_groups, rel_pos, rel_rot, sk.pose_writeback ? sk.d_pose_pos.p : nullptr,
-			sk.pose_writeback ? sk.d_pose_rot.p : nullptr, sk.d_level_items.p, sk.d_level_off.p, sk.d_inv_pos.p, sk.d_inv_rot.p, sk.d_palette.p, sk.want_dual_quats ? sk.d_dual_quats.p : nullptr));
+			sk.pose_writeback ? sk.d_pose_rot.p : nullptr, sk.d_level_items.p, sk.d_level_off.p, sk.d_inv_pos.p, sk.d_inv_rot.p, sk.d_palette.p, dual_quats ? sk.d_dual_quats.p : nullptr));
 	}
 	{
 		ProfScope ps(ctx, LMX_K_SKIN_VERTICES);
+		const float4* vertex_palette = sk.mode == LMX_SKIN_DQS ? sk.d_dual_quats.p : sk.d_palette.p;
 		if (sk.chunks.empty()) {
-			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, nullptr, n, sk.max_verts, sk.d_verts.p, sk.d_weights.p, sk.d_indices.p, sk.d_palette.p,
-				sk.d_out.p, sk.exact));
+			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, nullptr, n, sk.max_verts, sk.d_verts.p, sk.d_weights.p, sk.d_indices.p, vertex_palette,
+				sk.d_out.p, sk.mode));
 		} else {
 			LMX_HIP(ctx, launch_skin_shared(ctx->stream, sk.d_inst.p, sk.d_chunks.p, (uint32_t)sk.chunks.size(), sk.d_verts.p, sk.d_weights.p, sk.d_indices.p,
-				sk.d_palette.p, sk.d_out.p, sk.exact));
+				vertex_palette, sk.d_out.p, sk.mode));
 			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, sk.d_solo.p, (uint32_t)sk.solo.size(), sk.solo_max_verts, sk.d_verts.p, sk.d_weights.p,
-				sk.d_indices.p, sk.d_palette.p, sk.d_out.p, sk.exact));
+				sk.d_indices.p, vertex_palette, sk.d_out.p, sk.mode));
 		}
 	}
 	// the library's poses are absolute now; running again needs fresh relative poses (Pose::is_absolute, pose.cpp:64) unless
@@ -328,7 +330,7 @@ int lmx_skin_read_dual_quats(LmxContext* ctx, uint32_t instance, float* out, uin
 	LMX_CHECK_CTX(ctx);
 	SkinState& sk = ctx->skin;
 	if (instance >= sk.inst.size() || !out) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad instance/out");
-	if (!sk.want_dual_quats || !sk.d_dual_quats.p) return fail(ctx, LMX_ERR_NOT_BUILT, "dual-quaternion palette not enabled before lmx_skin_run");
+	if (!(sk.want_dual_quats || sk.mode == LMX_SKIN_DQS) || !sk.d_dual_quats.p) return fail(ctx, LMX_ERR_NOT_BUILT, "dual-quaternion palette not enabled before lmx_skin_run");
 	const SkinInstance& in = sk.inst[instance];
 	if (cap_bones < in.n_bones) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u bones", in.n_bones);
 	LMX_HIP(ctx, hipMemcpyAsync(out, sk.d_dual_quats.p + (size_t)in.bone_offset * 2, (size_t)in.n_bones * 8 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

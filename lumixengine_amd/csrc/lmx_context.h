@@ -184,7 +184,7 @@ struct SkinState {
 	size_t bones_total = 0, verts_total = 0;
 	uint32_t max_verts = 0;
 	bool poses_uploaded = false;
-	bool exact = false;
+	int mode = 0; // LMX_SKIN_FUSED / LMX_SKIN_EXACT / LMX_SKIN_DQS
 	bool want_dual_quats = false;
 	bool pose_writeback = true;    // store the absolute pose (Pose::is_absolute) next to the palette
 	bool pose_is_absolute = false; // d_pose_* hold the absolute pose of the last run

@@ -14,6 +14,7 @@
 //                    its 4 bone matrices element-wise in the reference's left-to-right order and transforms its
 //                    vertices. FMA-free VALU, bit-exact with the reference.
 #include "lmx_kernels.h"
+#include "lumix_mi355.h" // LMX_SKIN_* modes
 
 namespace lmx {
 
@@ -179,21 +180,55 @@ constexpr int SKIN_THREADS = 512;
 constexpr int SKIN_WAVES_PER_SIMD = 6; // 3 blocks of 8 waves per CU: <= 80 VGPRs, 48 KiB LDS each
 constexpr int SKIN_LDS_SLOTS = 3072;   // float4 slots = 48 KiB
 
+constexpr int skin_rows(int mode) { return mode == LMX_SKIN_DQS ? 2 : 3; } // LDS rows per bone: {real, dual} or the 3 matrix rows
+
 struct F3 { float x, y, z; }; // 12-byte records: loaded / stored as one dwordx3 per lane
 struct VertexIn { float px, py, pz; float4 w; int2 iw; };
 
 // evaluateSkin of one vertex (model.cpp:103-109) against the palette rows of its 4 bones in LDS (r0..r3 point at row 0 of
 // the lane's copy; rows are COPIES slots apart)
-template <int COPIES, bool EXACT>
+template <int COPIES, int MODE>
 __device__ __forceinline__ F3 skin_blend_rows(const float4* r0, const float4* r1, const float4* r2, const float4* r3, const VertexIn& c) {
 	const float4 w = c.w;
+	if constexpr (MODE == LMX_SKIN_DQS) {
+		// the SKINNED branch of the reference's vertex shader (data/shaders/surface_base.hlsli:196-217): dual quaternions of the 4
+		// bones blended with the weights' signs flipped towards bone 0's hemisphere, normalised by the real part's length, then
+		// transformByDualQuat (data/shaders/common.hlsli:632-636). Row 0 = real part, row 1 = dual part (DualQuat, math.h:257-260).
+		// bone by bone (two rows in flight at a time): mul(getBones(i), w) accumulated left to right as the shader does
+		const float4 ra = r0[0];
+		float4 qr, qd;
+		{
+			const float4 da = r0[COPIES];
+			qr = make_float4(ra.x * w.x, ra.y * w.x, ra.z * w.x, ra.w * w.x);
+			qd = make_float4(da.x * w.x, da.y * w.x, da.z * w.x, da.w * w.x);
+		}
+		auto accumulate = [&](const float4* rp, float weight) {
+			const float4 rb = rp[0], db = rp[COPIES];
+			const float ws = (rb.x * ra.x + rb.y * ra.y + rb.z * ra.z + rb.w * ra.w) < 0 ? -weight : weight;
+			qr = make_float4(qr.x + rb.x * ws, qr.y + rb.y * ws, qr.z + rb.z * ws, qr.w + rb.w * ws);
+			qd = make_float4(qd.x + db.x * ws, qd.y + db.y * ws, qd.z + db.z * ws, qd.w + db.w * ws);
+			__builtin_amdgcn_sched_barrier(0);
+		};
+		accumulate(r1, w.y);
+		accumulate(r2, w.z);
+		accumulate(r3, w.w);
+		const float inv_len = 1 / sqrtf(qr.x * qr.x + qr.y * qr.y + qr.z * qr.z + qr.w * qr.w); // dq *= 1 / length(dq[0])
+		qr = make_float4(qr.x * inv_len, qr.y * inv_len, qr.z * inv_len, qr.w * inv_len);
+		qd = make_float4(qd.x * inv_len, qd.y * inv_len, qd.z * inv_len, qd.w * inv_len);
+		// pos + 2 * cross(r.xyz, cross(r.xyz, pos) + r.w * pos) + 2 * (r.w * d.xyz - d.w * r.xyz + cross(r.xyz, d.xyz))
+		const float ix = (qr.y * c.pz - qr.z * c.py) + qr.w * c.px, iy = (qr.z * c.px - qr.x * c.pz) + qr.w * c.py, iz = (qr.x * c.py - qr.y * c.px) + qr.w * c.pz;
+		const float ox = qr.y * iz - qr.z * iy, oy = qr.z * ix - qr.x * iz, oz = qr.x * iy - qr.y * ix;
+		const float tx = (qr.w * qd.x - qd.w * qr.x) + (qr.y * qd.z - qr.z * qd.y), ty = (qr.w * qd.y - qd.w * qr.y) + (qr.z * qd.x - qr.x * qd.z),
+			tz = (qr.w * qd.z - qd.w * qr.z) + (qr.x * qd.y - qr.y * qd.x);
+		return F3{(c.px + 2 * ox) + 2 * tx, (c.py + 2 * oy) + 2 * ty, (c.pz + 2 * oz) + 2 * tz};
+	}
 	float o[3];
 #pragma unroll
 	for (int r = 0; r < 3; ++r) {
 		float4 A, B, C, D;
 		if (LMX_PROBE_SKIP(16)) { A = w; B = c.w; C = make_float4(c.px, c.py, c.pz, w.x); D = make_float4(w.y, c.px, w.z, c.py); }
 		else { A = r0[r * COPIES]; B = r1[r * COPIES]; C = r2[r * COPIES]; D = r3[r * COPIES]; }
-		if constexpr (EXACT) {
+		if constexpr (MODE == LMX_SKIN_EXACT) {
 			// Matrix::operator*(float) and operator+ (math.cpp:1022-1071), left to right: ((A*w.x + B*w.y) + C*w.z) + D*w.w
 			const float m0 = A.x * w.x + B.x * w.y + C.x * w.z + D.x * w.w;
 			const float m1 = A.y * w.x + B.y * w.y + C.y * w.z + D.y * w.w;
@@ -224,11 +259,11 @@ __device__ __forceinline__ F3 skin_blend_rows(const float4* r0, const float4* r1
 }
 
 // `rows` already points at the lane's copy
-template <int COPIES, bool EXACT>
+template <int COPIES, int MODE>
 __device__ __forceinline__ F3 skin_blend(const float4* rows, const VertexIn& c) {
 	// bone indices are non-negative i16 (validated at lmx_skin_add_mesh): plain 16-bit fields, no sign extension
-	return skin_blend_rows<COPIES, EXACT>(rows + (uint32_t)(c.iw.x & 0xffff) * (3 * COPIES), rows + ((uint32_t)c.iw.x >> 16) * (3 * COPIES),
-		rows + (uint32_t)(c.iw.y & 0xffff) * (3 * COPIES), rows + ((uint32_t)c.iw.y >> 16) * (3 * COPIES), c);
+	return skin_blend_rows<COPIES, MODE>(rows + (uint32_t)(c.iw.x & 0xffff) * (skin_rows(MODE) * COPIES), rows + ((uint32_t)c.iw.x >> 16) * (skin_rows(MODE) * COPIES),
+		rows + (uint32_t)(c.iw.y & 0xffff) * (skin_rows(MODE) * COPIES), rows + ((uint32_t)c.iw.y >> 16) * (skin_rows(MODE) * COPIES), c);
 }
 
 // Palette staging: every float4 of the instance's 3 x n_bones rows is read by ONE lane (a handful of load instructions per
@@ -246,7 +281,7 @@ __device__ __forceinline__ void palette_spread(float4* s_rows, uint32_t n_rows, 
 	}
 }
 
-template <int COPIES, bool EXACT>
+template <int COPIES, int MODE>
 __device__ __forceinline__ void skin_tile(const SkinInstance& in, uint32_t v_begin, uint32_t v_end, float4* s_rows,
 	const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices,
 	const float4* __restrict__ palette, float* __restrict__ out) {
@@ -268,7 +303,7 @@ __device__ __forceinline__ void skin_tile(const SkinInstance& in, uint32_t v_beg
 		return r;
 	};
 	auto skin_one = [&](const VertexIn& c, uint32_t v) {
-		const F3 o = skin_blend<COPIES, EXACT>(rows, c);
+		const F3 o = skin_blend<COPIES, MODE>(rows, c);
 		if (LMX_PROBE_SKIP(8) && o.x != 123.25f) return;
 		obase[v] = o;
 	};
@@ -279,8 +314,8 @@ __device__ __forceinline__ void skin_tile(const SkinInstance& in, uint32_t v_beg
 	VertexIn a = {};
 	if (has_first) a = load(v); // in flight during the palette staging
 	{
-		const float4* pal = palette + (size_t)in.bone_offset * 3;
-		const uint32_t n_rows = in.n_bones * 3;
+		const float4* pal = palette + (size_t)in.bone_offset * skin_rows(MODE);
+		const uint32_t n_rows = in.n_bones * skin_rows(MODE);
 		const float4 t0 = palette_fetch<COPIES>(pal, n_rows, threadIdx.x);
 		const float4 t1 = palette_fetch<COPIES>(pal, n_rows, threadIdx.x + SKIN_THREADS); // 196 bones: 588 rows
 		palette_spread<COPIES>(s_rows, n_rows, threadIdx.x, t0);
@@ -304,7 +339,7 @@ __device__ __forceinline__ void skin_tile(const SkinInstance& in, uint32_t v_beg
 	}
 }
 
-template <bool EXACT>
+template <int MODE>
 __global__ __launch_bounds__(SKIN_THREADS, SKIN_WAVES_PER_SIMD) void k_skin_vertices(const SkinInstance* __restrict__ inst,
 	const uint32_t* __restrict__ inst_index /* optional: the instances this launch covers */, uint32_t tiles_per_inst, uint32_t tile_verts,
 	const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices, const float4* __restrict__ palette,
@@ -317,9 +352,9 @@ __global__ __launch_bounds__(SKIN_THREADS, SKIN_WAVES_PER_SIMD) void k_skin_vert
 	const uint32_t v_begin = tile * tile_verts;
 	if (v_begin >= in.n_verts) return; // block-uniform
 	const uint32_t v_end = min(v_begin + tile_verts, in.n_verts);
-	if (in.n_bones <= 64) skin_tile<16, EXACT>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
-	else if (in.n_bones <= 128) skin_tile<8, EXACT>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
-	else skin_tile<4, EXACT>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
+	if (in.n_bones <= 64) skin_tile<16, MODE>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
+	else if (in.n_bones <= 128) skin_tile<8, MODE>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
+	else skin_tile<4, MODE>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
 }
 
 // ---- shared-mesh runs: vertex records in registers, palettes double-buffered in LDS -------------------------------------
@@ -328,7 +363,7 @@ constexpr int SHARED_VPT = 5;        // vertex records per lane (9 VGPRs each) -
 
 static_assert(SHARED_THREADS * SHARED_VPT == SKIN_SHARED_TILE_VERTS, "host tiling and kernel disagree");
 
-template <int COPIES, bool EXACT>
+template <int COPIES, int MODE>
 __device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const SkinChunk& ch, float4 (*s_rows)[SKIN_LDS_SLOTS],
 	const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices,
 	const float4* __restrict__ palette, float* __restrict__ out) {
@@ -338,7 +373,7 @@ __device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const 
 	const float4* wbase = weights + in0.vert_offset;
 	const int2* ibase = reinterpret_cast<const int2*>(indices) + in0.vert_offset;
 	// the lane's vertex records: loaded once, used for every instance of the chunk. The bone indices are kept as the 16-bit
-	// byte offsets of the bones' row 0 in the lane's palette copy ((bone * 3 * COPIES + col) * 16 < 48 KiB), two per register.
+	// byte offsets of the bones' row 0 in the lane's palette copy ((bone * rows * COPIES + col) * 16 < 48 KiB), two per register.
 	VertexIn vin[SHARED_VPT];
 #pragma unroll
 	for (int k = 0; k < SHARED_VPT; ++k) {
@@ -350,13 +385,13 @@ __device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const 
 			vin[k].w = wbase[v];
 			const int2 iw = ibase[v];
 			const uint32_t b0 = (uint32_t)iw.x & 0xffffu, b1 = (uint32_t)iw.x >> 16, b2 = (uint32_t)iw.y & 0xffffu, b3 = (uint32_t)iw.y >> 16;
-			vin[k].iw.x = (int)(((b0 * (3 * COPIES) + col) * 16u) | (((b1 * (3 * COPIES) + col) * 16u) << 16));
-			vin[k].iw.y = (int)(((b2 * (3 * COPIES) + col) * 16u) | (((b3 * (3 * COPIES) + col) * 16u) << 16));
+			vin[k].iw.x = (int)(((b0 * (skin_rows(MODE) * COPIES) + col) * 16u) | (((b1 * (skin_rows(MODE) * COPIES) + col) * 16u) << 16));
+			vin[k].iw.y = (int)(((b2 * (skin_rows(MODE) * COPIES) + col) * 16u) | (((b3 * (skin_rows(MODE) * COPIES) + col) * 16u) << 16));
 		}
 	}
 	// the chunk's instances are consecutive and share mesh and bone count: their bones and outputs are consecutive too
-	const uint32_t n_rows = in0.n_bones * 3;
-	const float4* pal = palette + (size_t)in0.bone_offset * 3;
+	const uint32_t n_rows = in0.n_bones * skin_rows(MODE);
+	const float4* pal = palette + (size_t)in0.bone_offset * skin_rows(MODE);
 	F3* obase = reinterpret_cast<F3*>(out) + in0.out_offset;
 	palette_spread<COPIES>(s_rows[0], n_rows, tid, palette_fetch<COPIES>(pal, n_rows, tid));
 	__syncthreads();
@@ -377,7 +412,7 @@ __device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const 
 				asm volatile("" : "+v"(vin[k].px), "+v"(vin[k].py), "+v"(vin[k].pz), "+v"(vin[k].w.x), "+v"(vin[k].w.y), "+v"(vin[k].w.z), "+v"(vin[k].w.w),
 					"+v"(vin[k].iw.x), "+v"(vin[k].iw.y));
 				const uint32_t o01 = (uint32_t)vin[k].iw.x, o23 = (uint32_t)vin[k].iw.y;
-				const F3 r = skin_blend_rows<COPIES, EXACT>(reinterpret_cast<const float4*>(buf + (o01 & 0xffffu)), reinterpret_cast<const float4*>(buf + (o01 >> 16)),
+				const F3 r = skin_blend_rows<COPIES, MODE>(reinterpret_cast<const float4*>(buf + (o01 & 0xffffu)), reinterpret_cast<const float4*>(buf + (o01 >> 16)),
 					reinterpret_cast<const float4*>(buf + (o23 & 0xffffu)), reinterpret_cast<const float4*>(buf + (o23 >> 16)), vin[k]);
 				if (!LMX_PROBE_SKIP(8) || r.x == 123.25f) o[v] = r;
 			}
@@ -388,16 +423,16 @@ __device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const 
 	}
 }
 
-template <bool EXACT>
+template <int MODE>
 __global__ __launch_bounds__(SHARED_THREADS) void k_skin_shared(const SkinInstance* __restrict__ inst, const SkinChunk* __restrict__ chunks,
 	const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices, const float4* __restrict__ palette,
 	float* __restrict__ out) {
 	__shared__ float4 s_rows[2][SKIN_LDS_SLOTS];
 	const SkinChunk ch = chunks[blockIdx.x];
 	const SkinInstance in0 = inst[ch.first_inst];
-	if (in0.n_bones <= 64) skin_shared_tile<16, EXACT>(in0, ch, s_rows, verts, weights, indices, palette, out);
-	else if (in0.n_bones <= 128) skin_shared_tile<8, EXACT>(in0, ch, s_rows, verts, weights, indices, palette, out);
-	else skin_shared_tile<4, EXACT>(in0, ch, s_rows, verts, weights, indices, palette, out);
+	if (in0.n_bones <= 64) skin_shared_tile<16, MODE>(in0, ch, s_rows, verts, weights, indices, palette, out);
+	else if (in0.n_bones <= 128) skin_shared_tile<8, MODE>(in0, ch, s_rows, verts, weights, indices, palette, out);
+	else skin_shared_tile<4, MODE>(in0, ch, s_rows, verts, weights, indices, palette, out);
 }
 
 } // namespace
@@ -425,7 +460,7 @@ hipError_t launch_palette_expand(hipStream_t s, const float4* rows, uint32_t n_b
 }
 
 hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, const uint32_t* inst_index, uint32_t n_inst, uint32_t max_verts,
-	const float* verts, const float4* weights, const int16_t* indices, const float4* palette, float* out, bool exact) {
+	const float* verts, const float4* weights, const int16_t* indices, const float4* palette, float* out, int mode) {
 	if (!n_inst || !max_verts) return hipSuccess;
 	// tiles: as large as possible (the 48 KiB palette staging is paid per tile) while still giving the chip >= ~3000 blocks
 	const uint32_t max_tiles = (max_verts + 1023u) / 1024u;
@@ -435,21 +470,20 @@ hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, const u
 	const uint32_t tile_verts = (max_verts + tiles - 1) / tiles;
 	const uint64_t blocks = (uint64_t)tiles * n_inst;
 	if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-	if (exact) {
-		hipLaunchKernelGGL(k_skin_vertices<true>, dim3((uint32_t)blocks), dim3(SKIN_THREADS), 0, s, inst, inst_index, tiles, tile_verts, verts, weights,
-			indices, palette, out);
-	} else {
-		hipLaunchKernelGGL(k_skin_vertices<false>, dim3((uint32_t)blocks), dim3(SKIN_THREADS), 0, s, inst, inst_index, tiles, tile_verts, verts, weights,
-			indices, palette, out);
-	}
+	const dim3 grid((uint32_t)blocks), block(SKIN_THREADS);
+	if (mode == LMX_SKIN_EXACT) hipLaunchKernelGGL(k_skin_vertices<LMX_SKIN_EXACT>, grid, block, 0, s, inst, inst_index, tiles, tile_verts, verts, weights, indices, palette, out);
+	else if (mode == LMX_SKIN_DQS) hipLaunchKernelGGL(k_skin_vertices<LMX_SKIN_DQS>, grid, block, 0, s, inst, inst_index, tiles, tile_verts, verts, weights, indices, palette, out);
+	else hipLaunchKernelGGL(k_skin_vertices<LMX_SKIN_FUSED>, grid, block, 0, s, inst, inst_index, tiles, tile_verts, verts, weights, indices, palette, out);
 	return hipGetLastError();
 }
 
 hipError_t launch_skin_shared(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float* verts,
-	const float4* weights, const int16_t* indices, const float4* palette, float* out, bool exact) {
+	const float4* weights, const int16_t* indices, const float4* palette, float* out, int mode) {
 	if (!n_chunks) return hipSuccess;
-	if (exact) hipLaunchKernelGGL(k_skin_shared<true>, dim3(n_chunks), dim3(SHARED_THREADS), 0, s, inst, chunks, verts, weights, indices, palette, out);
-	else hipLaunchKernelGGL(k_skin_shared<false>, dim3(n_chunks), dim3(SHARED_THREADS), 0, s, inst, chunks, verts, weights, indices, palette, out);
+	const dim3 grid(n_chunks), block(SHARED_THREADS);
+	if (mode == LMX_SKIN_EXACT) hipLaunchKernelGGL(k_skin_shared<LMX_SKIN_EXACT>, grid, block, 0, s, inst, chunks, verts, weights, indices, palette, out);
+	else if (mode == LMX_SKIN_DQS) hipLaunchKernelGGL(k_skin_shared<LMX_SKIN_DQS>, grid, block, 0, s, inst, chunks, verts, weights, indices, palette, out);
+	else hipLaunchKernelGGL(k_skin_shared<LMX_SKIN_FUSED>, grid, block, 0, s, inst, chunks, verts, weights, indices, palette, out);
 	return hipGetLastError();
 }
 

@@ -1412,6 +1412,40 @@ ORC_API uint32_t orc_update_animable(const LmxAnimation* a, uint32_t time, float
 	return (time + l - dt) % l;
 }
 
+/* Dual-quaternion skinning of the reference's vertex shader, SKINNED branch (data/shaders/surface_base.hlsli:196-217) with
+ * transformByDualQuat (data/shaders/common.hlsli:632-636): model-space position per vertex from the dual-quaternion palette
+ * (orc_dual_quats). HLSL leaves fusing / association to the shader compiler, so this is compared with a tolerance (1e-5
+ * relative), not bit for bit. dual_quats: n_inst x n_bones x {r.xyzw, d.xyzw}. */
+ORC_API void orc_evaluate_dq_skin(const float* verts, const LmxSkin* skin, const float* dual_quats, float* out, uint32_t n_verts, uint32_t n_bones,
+	uint32_t n_inst) {
+	for (uint32_t inst = 0; inst < n_inst; ++inst) {
+		const float* pal = dual_quats + (size_t)inst * n_bones * 8;
+		float* o = out + (size_t)inst * n_verts * 3;
+		for (uint32_t v = 0; v < n_verts; ++v) {
+			const float* ra = pal + 8 * skin[v].indices[0];
+			float qr[4], qd[4];
+			for (int k = 0; k < 4; ++k) { qr[k] = ra[k] * skin[v].weights[0]; qd[k] = ra[4 + k] * skin[v].weights[0]; } /* mul(getBones(x), weights.x) */
+			for (int b = 1; b < 4; ++b) {
+				const float* rb = pal + 8 * skin[v].indices[b];
+				const float dot = rb[0] * ra[0] + rb[1] * ra[1] + rb[2] * ra[2] + rb[3] * ra[3];
+				const float w = dot < 0 ? -skin[v].weights[b] : skin[v].weights[b];
+				for (int k = 0; k < 4; ++k) { qr[k] = qr[k] + rb[k] * w; qd[k] = qd[k] + rb[4 + k] * w; }
+			}
+			const float inv_len = 1 / sqrtf(qr[0] * qr[0] + qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3]); /* dq *= 1 / length(dq[0]) */
+			for (int k = 0; k < 4; ++k) { qr[k] *= inv_len; qd[k] *= inv_len; }
+			const float px = verts[3 * v], py = verts[3 * v + 1], pz = verts[3 * v + 2];
+			/* pos + 2 * cross(r.xyz, cross(r.xyz, pos) + r.w * pos) + 2 * (r.w * d.xyz - d.w * r.xyz + cross(r.xyz, d.xyz)) */
+			const float ix = (qr[1] * pz - qr[2] * py) + qr[3] * px, iy = (qr[2] * px - qr[0] * pz) + qr[3] * py, iz = (qr[0] * py - qr[1] * px) + qr[3] * pz;
+			const float ox = qr[1] * iz - qr[2] * iy, oy = qr[2] * ix - qr[0] * iz, oz = qr[0] * iy - qr[1] * ix;
+			const float tx = (qr[3] * qd[0] - qd[3] * qr[0]) + (qr[1] * qd[2] - qr[2] * qd[1]), ty = (qr[3] * qd[1] - qd[3] * qr[1]) + (qr[2] * qd[0] - qr[0] * qd[2]),
+				tz = (qr[3] * qd[2] - qd[3] * qr[2]) + (qr[0] * qd[1] - qr[1] * qd[0]);
+			o[3 * v] = (px + 2 * ox) + 2 * tx;
+			o[3 * v + 1] = (py + 2 * oy) + 2 * ty;
+			o[3 * v + 2] = (pz + 2 * oz) + 2 * tz;
+		}
+	}
+}
+
 ORC_API void orc_rand_fill(uint32_t u, uint32_t v, uint32_t n, uint32_t* out) {
 	for (uint32_t i = 0; i < n; ++i) {
 		u = 36969 * (u & 65535) + (u >> 16);

@@ -256,6 +256,18 @@ class Oracle:
         return {"keys": keys[: out.n_pairs], "values": values[: out.n_pairs], "group_offsets": offsets, "group_values": gvalues[: out.n_instanced],
                 "poses": poses[: out.n_poses], "dirty": dirty[: out.n_dirty], "lod": lod, "pose_frame": pose_frame, "groups": out.n_groups}
 
+    def evaluate_dq_skin(self, verts, skin, dual_quats) -> np.ndarray:
+        """Dual-quaternion vertex blend of the reference's shader (surface_base.hlsli:196-217); dual_quats [n_inst, n_bones, 8]. Port oracle only."""
+        verts = np.ascontiguousarray(verts, np.float32)
+        skin = np.ascontiguousarray(skin, SKIN)
+        dq = np.ascontiguousarray(dual_quats, np.float32)
+        n_inst, n_bones = dq.shape[0], dq.shape[1]
+        out = np.zeros((n_inst, len(verts), 3), np.float32)
+        f = self.lib.orc_evaluate_dq_skin
+        f.restype, f.argtypes = None, [C.c_void_p] * 4 + [C.c_uint32] * 3
+        f(_ptr(verts), _ptr(skin), _ptr(dq), _ptr(out), len(verts), n_bones, n_inst)
+        return out
+
     def nlerp(self, q1, q2, t) -> np.ndarray:
         """simd_nlerp, core/simd_math.h:107-123 (port oracle only)."""
         q1, q2, t = np.ascontiguousarray(q1, np.float32).reshape(-1, 4), np.ascontiguousarray(q2, np.float32).reshape(-1, 4), np.ascontiguousarray(t, np.float32)

@@ -209,6 +209,50 @@ def test_skin_groups_and_pose_writeback_switch(gpu_ctx, oracle_port):
     sk.setMode(False)
 
 
+def test_skin_dual_quaternion_blend(gpu_ctx, oracle_port):
+    """LMX_SKIN_DQS: the SKINNED branch of the reference's vertex shader (surface_base.hlsli:196-217, transformByDualQuat
+    common.hlsli:632-636) on the bit-exact dual-quaternion palette, through both vertex kernels (a run of 6 instances on a
+    2500-vertex mesh -> k_skin_shared, 3 single small ones -> k_skin_vertices). Tolerance 1e-5: HLSL does not pin association."""
+    sk = api.Skinning(gpu_ctx)
+    skel = [scenes.skeleton(64, seed=4), scenes.skeleton(100, seed=24)]
+    meshes = [scenes.skinned_mesh(2500, 64, seed=6), scenes.skinned_mesh(300, 100, seed=7)]
+    models = [sk.addModel(s["parents"], s["bind"], s["first_nonroot"]) for s in skel]
+    mesh_ids = [sk.addMesh(v, s) for v, s in meshes]
+    pick = [0] * 6 + [1, 0, 1]
+    sk.setInstances([models[k] for k in pick], [mesh_ids[k] for k in pick])
+    poses = [scenes.relative_poses(1, len(skel[k]["parents"]), seed=700 + i) for i, k in enumerate(pick)]
+    sk.uploadPoses(np.concatenate([p[0].reshape(-1, 3) for p in poses]), np.concatenate([p[1].reshape(-1, 4) for p in poses]))
+    sk.setMode(api.SKIN_DQS)
+    sk.run()
+    for i, k in enumerate(pick):
+        s = skel[k]
+        apos, arot = oracle_port.pose_compute_absolute(poses[i][0], poses[i][1], s["parents"], s["first_nonroot"])
+        dq = oracle_port.dual_quats(apos, arot, oracle_port.invert_bind(s["bind"]))
+        assert H.bits_equal(sk.readDualQuats(i), dq[0])
+        want = oracle_port.evaluate_dq_skin(meshes[k][0], meshes[k][1], dq)[0]
+        got = sk.readVertices(i)
+        assert close_1e5(got, want), f"instance {i}"
+        # a different deformation than linear blending, but of the same skeleton: same ballpark, not the same numbers
+        lbs = oracle_port.evaluate_skin(meshes[k][0], meshes[k][1], oracle_port.skin_matrices(apos, arot, oracle_port.invert_bind(s["bind"])))[0]
+        assert not np.allclose(got, lbs, rtol=1e-3, atol=1e-3)
+    # rigid case: all four weights on one bone -> DQS and LBS agree (a dual quaternion of one bone is that bone's rigid transform)
+    verts, skin = scenes.skinned_mesh(2100, 64, seed=9)
+    skin["indices"][:, 1:] = skin["indices"][:, :1]
+    one = sk.addMesh(verts, skin)
+    sk.setInstances([models[0]] * 2, [one] * 2)
+    p2 = scenes.relative_poses(2, 64, seed=31)
+    for mode in (api.SKIN_DQS, api.SKIN_EXACT):
+        sk.uploadPoses(p2[0].reshape(-1, 3), p2[1].reshape(-1, 4))
+        sk.setMode(mode)
+        sk.run()
+        if mode == api.SKIN_DQS:
+            dqs = [sk.readVertices(i) for i in range(2)]
+        else:
+            for i in range(2):
+                assert np.allclose(dqs[i], sk.readVertices(i), rtol=2e-4, atol=2e-4)
+    sk.setMode(api.SKIN_FUSED)
+
+
 @pytest.mark.parametrize("exact", [True, False])
 def test_skin_shared_mesh_runs(gpu_ctx, oracle_port, exact):
     """Runs of instances that share a mesh take the register-resident path (k_skin_shared: ragged tiles, 2 tiles per mesh,
