@@ -617,6 +617,39 @@ def cpu_baseline(scenes, frustum, N, half, log):
     single, _ = measure(1)
     visible, pages = ocs.cull(fr, n_threads=1, want_ids=False, cap=0)
     best, used = (multi, cores) if multi <= single else (single, 1)
+    # the other two metrics of SURVEY.md 8d, bounded samples, one thread and 8 threads (parallel over instances / roots)
+    other = {}
+    try:
+        sk = scenes.skeleton(64, seed=4)
+        verts, skin = scenes.skinned_mesh(10_000, 64, seed=6)
+        n_inst = 64
+        rp, rr = scenes.relative_poses(n_inst, 64, seed=5)
+        inv = o.invert_bind(sk["bind"])
+        for threads in (1, 8):
+            t0 = time.perf_counter()
+            apos, arot = o.pose_compute_absolute(rp, rr, sk["parents"], sk["first_nonroot"])
+            pal = o.skin_matrices(apos, arot, inv)
+            t1 = time.perf_counter()
+            o.evaluate_skin(verts, skin, pal, n_threads=threads)
+            t2 = time.perf_counter()
+            other[f"skin_verts_per_sec_{threads}thread"] = n_inst * len(verts) / (t2 - t1)
+            if threads == 1:
+                other["pose_palette_bones_per_sec_1thread"] = n_inst * 64 / (t1 - t0)
+        h = scenes.hierarchy_chains(50_000, 4, seed=2)
+        nn = len(h["parent"])
+        w = o.world(nn)
+        roots = np.flatnonzero(h["parent"] < 0).astype(np.int32)
+        kids = np.flatnonzero(h["parent"] >= 0).astype(np.int32)
+        w.init_transforms(roots, h["local"][roots])
+        w.set_parents(h["parent"][kids], kids)
+        w.set_local_transforms(kids, h["local"][kids])
+        new_root = scenes.random_transforms(np.random.default_rng(1), len(roots), 4000.0)
+        t0 = time.perf_counter()
+        w.set_transforms(roots, new_root)  # World::setTransform on every root: the DFS of world.cpp:255-282
+        other["transforms_per_sec_1thread"] = len(kids) / (time.perf_counter() - t0)
+        other["other_samples"] = f"skin: {n_inst} instances x 64 bones x {len(verts)} verts of one mesh; transforms: {len(roots)} roots x depth-4 chains, every root moved once"
+    except Exception as e:  # the headline baseline must survive a problem in the side measurements
+        other["other_error"] = repr(e)
     log(f"cpu baseline ({kind}): {n} entities, add {t_add:.1f}s, cull median {multi * 1e3:.1f} ms on {cores} threads, {single * 1e3:.1f} ms on 1 thread, {visible} visible, {pages} result pages")
     return {
         "value": n / best,
@@ -628,6 +661,7 @@ def cpu_baseline(scenes, frustum, N, half, log):
         "all_cores": cores,
         "single_thread_value": n / single,
         "describe": o.describe(),
+        **other,
     }
 
 

@@ -1,0 +1,148 @@
+"""Error behaviour of the C ABI on a live context: wrong calls return the documented LMX_ERR_* code with a message, touch
+nothing, and the context keeps working afterwards (the reference asserts or logs in the same situations)."""
+import numpy as np
+import pytest
+
+from lumixengine_amd import api, scenes
+
+pytestmark = pytest.mark.gpu
+
+INVALID, CAPACITY, NOT_BUILT = 1, 5, 6
+
+
+def expect(code, fn, *args, **kw):
+    with pytest.raises(api.LumixError) as e:
+        fn(*args, **kw)
+    assert e.value.code == code, str(e.value)
+    assert len(str(e.value)) > 20  # a message, not just a number
+    return str(e.value)
+
+
+def test_culling_errors(gpu_ctx):
+    sc = scenes.cull_scene(5000, 1500.0, seed=3)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    fr = api.viewport_frustum()
+    expect(CAPACITY, cs.cull, fr, view=api.MAX_VIEWS)
+    expect(CAPACITY, cs.cull, np.concatenate([fr] * 9))
+    res = cs.cull(fr)
+    n = int(res.counts()[0, 0])
+    assert n > 0
+    out = np.zeros(1, np.int32)
+    got = api.C.c_uint32(0)
+    rc = cs.lib.lmx_cull_read(gpu_ctx.h, 0, 0, 0, api._ptr(out), 1, api.C.byref(got))
+    assert rc == CAPACITY and b"room" in cs.lib.lmx_last_error(gpu_ctx.h)
+    rc = cs.lib.lmx_cull_read(gpu_ctx.h, 0, 5, 0, api._ptr(out), 1, api.C.byref(got))  # frustum 5 of a 1-frustum result
+    assert rc == INVALID
+    expect(INVALID, cs.add, int(sc["entity"][0]), 0, (0.0, 0.0, 0.0), 1.0)  # already added (the reference asserts, culling_system.cpp:133)
+    cs.remove(1 << 30)  # unknown entities are ignored, as in the reference (culling_system.cpp:162-165)
+    assert len(cs.cull(fr).ids(0, 0)) == n  # still fine
+
+
+def test_world_errors(gpu_ctx):
+    h = scenes.hierarchy_chains(20, 3, seed=2)
+    w = api.World(gpu_ctx)
+    w.build(h["parent"], h["local"])
+    w.propagate()
+    kids = np.flatnonzero(h["parent"] >= 0)
+    child = int(kids[0])
+    root = int(h["parent"][child])
+    while h["parent"][root] >= 0:
+        root = int(h["parent"][root])
+    msg = expect(INVALID, w.setParent, child, root)  # setParent(new_parent = a descendant, child = its root): root under its own descendant: "Hierarchy can not contain a cycle." (world.cpp:301-305)
+    assert "cycle" in msg
+    out = np.zeros(3, api.TRANSFORM)
+    assert w.lib.lmx_world_read_transforms(gpu_ctx.h, api._ptr(out), 3) != 0
+    bad_parent = h["parent"].copy()
+    bad_parent[0] = len(bad_parent) + 5
+    expect(INVALID, api.World(gpu_ctx).build, bad_parent, h["local"])
+    w2 = api.World(gpu_ctx)
+    w2.build(h["parent"], h["local"])
+    w2.propagate()
+    assert len(w2.getTransforms()) == len(h["parent"])
+
+
+def test_skin_errors(gpu_ctx):
+    sk = api.Skinning(gpu_ctx)
+    s = scenes.skeleton(8, seed=1)
+    bad = s["parents"].copy()
+    bad[3] = 5  # parent after child (model.cpp:381-384)
+    expect(INVALID, sk.addModel, bad, s["bind"], 1)
+    big = scenes.skeleton(197, seed=2)
+    expect(CAPACITY, sk.addModel, big["parents"], big["bind"], 1)  # Model::Bone::MAX_COUNT
+    model = sk.addModel(s["parents"], s["bind"], 1)
+    verts, skin = scenes.skinned_mesh(50, 8, seed=3)
+    bad_skin = skin.copy()
+    bad_skin["indices"][7, 2] = -1
+    expect(INVALID, sk.addMesh, verts, bad_skin)
+    mesh = sk.addMesh(verts, skin)
+    expect(INVALID, sk.setInstances, [model + 100], [mesh])
+    sk.setInstances([model] * 3, [mesh] * 3)
+    expect(NOT_BUILT, sk.run)  # no poses yet
+    pos, rot = scenes.relative_poses(3, 8, seed=4)
+    expect(INVALID, sk.uploadPoses, pos[:2].reshape(-1, 3), rot[:2].reshape(-1, 4))
+    sk.uploadPoses(pos.reshape(-1, 3), rot.reshape(-1, 4))
+    expect(INVALID, sk.setMode, 7)
+    sk.run()
+    expect(NOT_BUILT, sk.run)  # poses are absolute now (Pose::is_absolute, pose.cpp:64)
+    expect(NOT_BUILT, sk.readDualQuats, 0)
+    assert sk.readVertices(2).shape == (50, 3)
+
+
+def test_sort_key_errors(gpu_ctx):
+    sc = scenes.cull_scene(2000, 800.0, seed=5)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    cs.cull(api.viewport_frustum())
+    ks = scenes.keys_scene(2000, sc["type"], seed=6)
+    sk = api.SortKeys(gpu_ctx)
+    kv = api.keys_view(layer_to_bucket=ks["layer_to_bucket"], bucket_depth_sorted=ks["bucket_depth_sorted"])
+    bad_models = ks["models"].copy()
+    bad_models["lod_indices"][0][0] = (0, 99)
+    expect(INVALID, sk.setModels, bad_models, ks["mesh_types"])
+    sk.setModels(ks["models"], ks["mesh_types"])
+    bad_lod = ks["lod"].copy()
+    bad_lod[5] = 4.5
+    expect(INVALID, sk.setInstances, ks["model"], ks["material_offset"], ks["mesh_materials"], bad_lod, ks["flags"], ks["dirty"], ks["pose_frame"])
+    sk.setInstances(ks["model"], ks["material_offset"], ks["mesh_materials"], ks["lod"], ks["flags"], ks["dirty"], ks["pose_frame"])
+    sk.setPositions(sc["pos"][:100])
+    expect(NOT_BUILT, sk.run, kv, ks["max_sort_key"])  # positions do not cover the instance tables
+    sk.setPositions(sc["pos"])
+    expect(CAPACITY, sk.run, kv, 1 << 24)
+    expect(INVALID, sk.run, kv, ks["max_sort_key"], view=0, frustum=3)
+    sk.run(kv, ks["max_sort_key"])
+    assert sk.counts()["overflow"] == 0
+
+
+def test_animation_errors(gpu_ctx):
+    sk = api.Skinning(gpu_ctx)
+    s = scenes.skeleton(16, seed=1)
+    model = sk.addModel(s["parents"], s["bind"], 1)
+    mesh = sk.addMesh(*scenes.skinned_mesh(20, 16, seed=3))
+    sk.setInstances([model] * 2, [mesh] * 2)
+    a = scenes.animation(16, 5, 30.0, seed=9)
+    dup = dict(a)
+    dup["translations"] = a["translations"].copy()
+    dup["translations"]["bone_index"][1] = dup["translations"]["bone_index"][0]
+    expect(INVALID, sk.addAnimation, dup)  # two translation tracks on one bone
+    short = dict(a)
+    short["rotation_stream"] = a["rotation_stream"][:10]
+    expect(INVALID, sk.addAnimation, short)  # streams hold frame_count + 1 frames (animation.cpp:464)
+    wide = dict(a)
+    wide["rotations"] = a["rotations"].copy()
+    wide["rotations"]["bitsizes"][0] = (20, 20, 20)
+    expect(INVALID, sk.addAnimation, wide)
+    aid = sk.addAnimation(a)
+    expect(NOT_BUILT, sk.updateAnimables, 0.1)  # no animables yet
+    expect(INVALID, sk.setAnimables, [aid + 50, aid], [0, 0])
+    sk.setAnimables([aid, api_none()], [0, 0])
+    expect(NOT_BUILT, sk.updateAnimables, 0.1)  # the model's relative pose is missing
+    sk.setModelPose(model, s["bind"])
+    expect(INVALID, sk.setAnimWeight, 1.5)
+    sk.updateAnimables(0.1)
+    sk.run()
+    expect(NOT_BUILT, sk.readRelativePose, 0)  # absolute by now
+
+
+def api_none():
+    return 0xFFFFFFFF
