@@ -150,6 +150,16 @@ LMX_API int lmx_world_set_transforms_device(LmxContext* ctx, uint32_t n, const v
 LMX_API int lmx_world_bind_culling(LmxContext* ctx, uint32_t n, const int32_t* entity, const float* model_radius);
 LMX_API int lmx_world_propagate(LmxContext* ctx);
 /* World::getTransforms() (world.h:65): AoS Transform[n] indexed by entity. */
+/* Bone attachments (RenderModuleImpl::m_bone_attachments, updateBoneAttachment, renderer/render_module.cpp:377-404; called for
+ * every attachment of a parent whose pose changed, :1964-1981): attachment i moves `entity[i]` to
+ * transform(parent_entity[i]) . (absolute pose of bone bone_index[i] of skin instance skin_instance[i] . relative[i]), keeping the
+ * entity's own scale. Attached entities must be hierarchy roots (the reference moves them with World::setTransform) and may not
+ * hang off another attachment. lmx_world_update_bone_attachments runs after lmx_skin_run (absolute poses, pose write-back on)
+ * and before lmx_world_propagate, which carries the attached entities' subtrees and culling spheres along. lmx_world_build and
+ * lmx_world_set_parent drop the attachment table (slots are renumbered). */
+LMX_API int lmx_world_set_bone_attachments(LmxContext* ctx, uint32_t n, const int32_t* entity, const int32_t* parent_entity,
+	const uint32_t* skin_instance, const uint32_t* bone_index, const LmxLocalRigidTransform* relative);
+LMX_API int lmx_world_update_bone_attachments(LmxContext* ctx);
 LMX_API int lmx_world_read_transforms(LmxContext* ctx, LmxTransform* out, uint32_t n);
 
 /* ---- skinning: Pose / Model, src/renderer/pose.cpp:63-134, src/renderer/model.cpp:103-137 -------------------- */

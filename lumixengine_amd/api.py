@@ -114,6 +114,8 @@ SYMBOLS = {
     "lmx_world_bind_culling": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_world_propagate": (_ci, [_vp]),
     "lmx_world_read_transforms": (_ci, [_vp, _vp, _u32]),
+    "lmx_world_set_bone_attachments": (_ci, [_vp, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "lmx_world_update_bone_attachments": (_ci, [_vp]),
     "lmx_skin_add_model": (_ci, [_vp, _u32, _vp, _vp, _i32, C.POINTER(_u32)]),
     "lmx_skin_add_mesh": (_ci, [_vp, _u32, _vp, _vp, C.POINTER(_u32)]),
     "lmx_skin_set_instances": (_ci, [_vp, _u32, _vp, _vp]),
@@ -434,6 +436,15 @@ class World:
     def setParent(self, new_parent: int, child: int):
         """World::setParent (world.cpp:619-701); new_parent < 0 detaches."""
         self.ctx.check(self.lib.lmx_world_set_parent(self.ctx.h, int(new_parent), int(child)))
+
+    def setBoneAttachments(self, entity, parent_entity, skin_instance, bone_index, relative):
+        """RenderModuleImpl::m_bone_attachments: entity follows bone `bone_index` of `skin_instance`, posed on `parent_entity`."""
+        a = [np.ascontiguousarray(entity, np.int32), np.ascontiguousarray(parent_entity, np.int32), np.ascontiguousarray(skin_instance, np.uint32),
+             np.ascontiguousarray(bone_index, np.uint32), np.ascontiguousarray(relative, LOCAL_RIGID)]
+        self.ctx.check(self.lib.lmx_world_set_bone_attachments(self.ctx.h, len(a[0]), *[_ptr(x) for x in a]))
+
+    def updateBoneAttachments(self):
+        self.ctx.check(self.lib.lmx_world_update_bone_attachments(self.ctx.h))
 
     def getLocalTransforms(self) -> np.ndarray:
         out = np.zeros(self.n, TRANSFORM)

@@ -57,16 +57,16 @@ int lmx_skin_add_mesh(LmxContext* ctx, uint32_t n_verts, const float* positions_
 	LMX_CHECK_CTX(ctx);
 	if (!n_verts || !positions_xyz || !skin) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "empty mesh / null input array");
 	SkinState& sk = ctx->skin;
+	for (uint32_t v = 0; v < n_verts; ++v) // validate before anything is appended: a refused mesh leaves the tables untouched
+		for (int k = 0; k < 4; ++k)
+			if (skin[v].indices[k] < 0 || skin[v].indices[k] >= LMX_MAX_BONES) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "skin[%u].indices[%d] = %d out of range", v, k, skin[v].indices[k]);
 	SkinMesh m;
 	m.vert_offset = (uint32_t)(sk.verts.size() / 3);
 	m.n_verts = n_verts;
 	sk.verts.insert(sk.verts.end(), positions_xyz, positions_xyz + (size_t)n_verts * 3);
 	for (uint32_t v = 0; v < n_verts; ++v) {
 		sk.weights.push_back(make_float4(skin[v].weights[0], skin[v].weights[1], skin[v].weights[2], skin[v].weights[3]));
-		for (int k = 0; k < 4; ++k) {
-			if (skin[v].indices[k] < 0 || skin[v].indices[k] >= LMX_MAX_BONES) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "skin[%u].indices[%d] = %d out of range", v, k, skin[v].indices[k]);
-			sk.indices.push_back(skin[v].indices[k]);
-		}
+		for (int k = 0; k < 4; ++k) sk.indices.push_back(skin[v].indices[k]);
 	}
 	sk.meshes.push_back(m);
 	sk.meshes_dirty = true;

@@ -84,6 +84,7 @@ int world_rebuild(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxT
 		LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, w.d_stage_entity.p, w.d_stage_tr.p, n));
 	}
 	w.bound_generation = ~0ull;
+	w.n_attach = 0; // attachment slots refer to the previous slot order: lmx_world_set_bone_attachments again
 	w.built = true;
 	return LMX_OK;
 }
@@ -272,6 +273,53 @@ int lmx_world_propagate(LmxContext* ctx) {
 		cs.dyn_mirror_stale = true; // the device copy of the dynamic set is now newer than the host mirror
 		cs.dyn_values_dirty = false;
 	}
+	return LMX_OK;
+}
+
+int lmx_world_set_bone_attachments(LmxContext* ctx, uint32_t n, const int32_t* entity, const int32_t* parent_entity, const uint32_t* skin_instance,
+	const uint32_t* bone_index, const LmxLocalRigidTransform* relative) {
+	LMX_CHECK_CTX(ctx);
+	WorldState& w = ctx->world;
+	const SkinState& sk = ctx->skin;
+	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
+	if (n && (!entity || !parent_entity || !skin_instance || !bone_index || !relative)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
+	std::vector<BoneAttachDevice> att(n);
+	std::vector<uint8_t> attached(w.n, 0);
+	for (uint32_t i = 0; i < n; ++i) {
+		if (entity[i] < 0 || (uint32_t)entity[i] >= w.n || parent_entity[i] < 0 || (uint32_t)parent_entity[i] >= w.n)
+			return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "attachment %u: entity %d / parent %d out of range", i, entity[i], parent_entity[i]);
+		if (w.parent[entity[i]] >= 0) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "attachment %u: entity %d has a hierarchy parent; attached entities are moved with World::setTransform as roots", i, entity[i]);
+		if (attached[entity[i]]) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d is attached twice", entity[i]);
+		attached[entity[i]] = 1;
+		if (skin_instance[i] >= sk.inst.size()) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "attachment %u: unknown skin instance %u", i, skin_instance[i]);
+		if (bone_index[i] >= sk.inst[skin_instance[i]].n_bones) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "attachment %u: bone %u >= %u", i, bone_index[i], sk.inst[skin_instance[i]].n_bones);
+		BoneAttachDevice& a = att[i];
+		a.slot = (uint32_t)w.slot_of_entity[entity[i]];
+		a.parent_slot = (uint32_t)w.slot_of_entity[parent_entity[i]];
+		a.skin_instance = skin_instance[i];
+		a.bone = bone_index[i];
+		memcpy(a.rel_pos, relative[i].pos, sizeof(a.rel_pos));
+		memcpy(a.rel_rot, relative[i].rot, sizeof(a.rel_rot));
+	}
+	for (uint32_t i = 0; i < n; ++i) // one parallel pass: an attachment may not hang off another attachment's subtree root
+		if (attached[parent_entity[i]]) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "attachment %u: parent %d is itself a bone attachment (chains are not batched)", i, parent_entity[i]);
+	LMX_HIP(ctx, w.d_attach.reserve(std::max<size_t>(n, 1)));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (n) LMX_HIP(ctx, hipMemcpy(w.d_attach.p, att.data(), (size_t)n * sizeof(BoneAttachDevice), hipMemcpyHostToDevice));
+	w.n_attach = n;
+	w.attach_skin_instances = sk.inst.size();
+	return LMX_OK;
+}
+
+int lmx_world_update_bone_attachments(LmxContext* ctx) {
+	LMX_CHECK_CTX(ctx);
+	WorldState& w = ctx->world;
+	SkinState& sk = ctx->skin;
+	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
+	if (!w.n_attach) return LMX_OK;
+	if (w.attach_skin_instances != sk.inst.size()) return fail(ctx, LMX_ERR_NOT_BUILT, "the skin instance table changed; call lmx_world_set_bone_attachments again");
+	if (!sk.pose_is_absolute) return fail(ctx, LMX_ERR_NOT_BUILT, "bone attachments read the absolute pose (ASSERT(pose->is_absolute), render_module.cpp:424): run lmx_skin_run with pose write-back first");
+	LMX_HIP(ctx, launch_bone_attach(ctx->stream, w.dev(), w.d_attach.p, w.n_attach, sk.d_inst.p, sk.d_pose_pos.p, sk.d_pose_rot.p));
 	return LMX_OK;
 }
 

@@ -133,6 +133,9 @@ struct WorldState {
 	DevBuf<uint32_t> d_bound_slot, d_bound_dyn;
 	DevBuf<float> d_bound_radius;
 	uint64_t bound_generation = ~0ull; // CullState::dyn_generation the device binding tables were built for
+	DevBuf<BoneAttachDevice> d_attach;  // RenderModuleImpl::m_bone_attachments
+	uint32_t n_attach = 0;
+	size_t attach_skin_instances = 0;
 	WorldDevice dev() {
 		WorldDevice w;
 		w.lpx = pos[0].p; w.lpy = pos[1].p; w.lpz = pos[2].p; w.lrot = rot[0].p; w.lsx = scl[0].p; w.lsy = scl[1].p; w.lsz = scl[2].p;

@@ -112,6 +112,11 @@ struct SkinInstance {
 // k_skin_shared work item: instances [first_inst, first_inst + count) share mesh and bone count; vertices [v_begin, v_end) of it
 struct SkinChunk { uint32_t first_inst, count, v_begin, v_end; };
 struct PoseGroup { uint32_t first_inst; uint32_t count; }; // consecutive instances of one model, count <= 16 / 8 / 4 by bone count
+// ---- bone attachments (xform_kernels.hip) ----
+struct BoneAttachDevice { uint32_t slot, parent_slot, skin_instance, bone; float rel_pos[3]; float rel_rot[4]; };
+hipError_t launch_bone_attach(hipStream_t s, const WorldDevice& w, const BoneAttachDevice* att, uint32_t n, const SkinInstance* inst,
+	const float* pose_pos, const float4* pose_rot);
+
 // ---- animation sampling (anim_kernels.hip) ----
 struct AnimDevice { // one Animation resource: offsets into the concatenated tables of AnimTables
 	float fps;

@@ -78,6 +78,19 @@ LMX_HD Xform compose(const Xform& a, const Xform& rhs) {
 	r.scale = V3{a.scale.x * rhs.scale.x, a.scale.y * rhs.scale.y, a.scale.z * rhs.scale.z}; // math.cpp:459-461
 	return r;
 }
+// RenderModuleImpl::updateBoneAttachment (render_module.cpp:377-404): parent_entity_transform.compose(bone * relative) with
+// the attached entity's own scale kept. LocalRigidTransform::operator* math.cpp:859-861; Transform::compose(LocalRigidTransform)
+// math.cpp:763: {pos + rot.rotate(rhs.pos * scale), rot * rhs.rot, scale}; Vec3 * Vec3 is element-wise (math.cpp:459-461).
+LMX_HD Xform bone_attachment(const Xform& parent, V3 bone_pos, Q4 bone_rot, V3 rel_pos, Q4 rel_rot, V3 original_scale) {
+	const V3 bt_pos = add(rotate(bone_rot, rel_pos), bone_pos);
+	const Q4 bt_rot = qmul(bone_rot, rel_rot);
+	Xform r;
+	r.pos = add(parent.pos, rotate(parent.rot, V3{bt_pos.x * parent.scale.x, bt_pos.y * parent.scale.y, bt_pos.z * parent.scale.z}));
+	r.rot = qmul(parent.rot, bt_rot);
+	r.scale = original_scale;
+	return r;
+}
+
 // Transform::computeLocal, math.cpp:809-816 (host-side only: setParent / re-parenting, not in the per-frame pass)
 LMX_HD Xform compute_local(const Xform& parent, const Xform& child) {
 	const Q4 conj = conjugated(parent.rot);

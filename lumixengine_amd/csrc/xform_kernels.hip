@@ -105,6 +105,35 @@ hipError_t launch_xform_export(hipStream_t s, const WorldDevice& w, const int32_
 	return hipGetLastError();
 }
 
+// RenderModuleImpl::updateBoneAttachment (render_module.cpp:377-404) for every attachment: world transform of the attached
+// entity = parent entity's world transform . (absolute bone pose . relative transform), own scale kept. Attached entities are
+// hierarchy roots (World::setTransform writes their world transform; their subtrees follow in lmx_world_propagate).
+__global__ __launch_bounds__(256) void k_bone_attach(WorldDevice w, const BoneAttachDevice* __restrict__ att, uint32_t n,
+	const SkinInstance* __restrict__ inst, const float* __restrict__ pose_pos, const float4* __restrict__ pose_rot) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const BoneAttachDevice a = att[i];
+	const uint32_t ps = a.parent_slot, s = a.slot;
+	Xform parent;
+	parent.pos = DV3{w.wpx[ps], w.wpy[ps], w.wpz[ps]};
+	const float4 pr = w.wrot[ps];
+	parent.rot = Q4{pr.x, pr.y, pr.z, pr.w};
+	parent.scale = V3{w.wsx[ps], w.wsy[ps], w.wsz[ps]};
+	const size_t b = (size_t)inst[a.skin_instance].bone_offset + a.bone;
+	const float4 br = pose_rot[b];
+	const Xform r = bone_attachment(parent, V3{pose_pos[3 * b], pose_pos[3 * b + 1], pose_pos[3 * b + 2]}, Q4{br.x, br.y, br.z, br.w},
+		V3{a.rel_pos[0], a.rel_pos[1], a.rel_pos[2]}, Q4{a.rel_rot[0], a.rel_rot[1], a.rel_rot[2], a.rel_rot[3]}, V3{w.wsx[s], w.wsy[s], w.wsz[s]});
+	w.wpx[s] = r.pos.x; w.wpy[s] = r.pos.y; w.wpz[s] = r.pos.z;
+	w.wrot[s] = make_float4(r.rot.x, r.rot.y, r.rot.z, r.rot.w);
+}
+
+hipError_t launch_bone_attach(hipStream_t s, const WorldDevice& w, const BoneAttachDevice* att, uint32_t n, const SkinInstance* inst,
+	const float* pose_pos, const float4* pose_rot) {
+	if (!n) return hipSuccess;
+	hipLaunchKernelGGL(k_bone_attach, dim3((n + 255u) / 256u), dim3(256), 0, s, w, att, n, inst, pose_pos, pose_rot);
+	return hipGetLastError();
+}
+
 hipError_t launch_xform_scatter(hipStream_t s, const WorldDevice& w, const int32_t* slot_of_entity, const int32_t* entity,
 	const void* transforms, uint32_t n, bool force_world) {
 	if (!n) return hipSuccess;

@@ -139,6 +139,22 @@ static xform xform_compute_local(xform parent, xform child) {                   
 ORC_API void orc_compose(const LmxTransform* a, const LmxTransform* b, LmxTransform* out) {
 	xform_store(xform_compose(xform_load(a), xform_load(b)), out);
 }
+/* RenderModuleImpl::updateBoneAttachment, render_module.cpp:396-402: parent.compose(bone * relative), scale = the entity's own */
+ORC_API void orc_bone_attachment(const LmxTransform* parent, const float* bone_pos, const float* bone_rot, const LmxLocalRigidTransform* relative,
+	const float* original_scale, LmxTransform* out) {
+	const xform p = xform_load(parent);
+	const quat br = {bone_rot[0], bone_rot[1], bone_rot[2], bone_rot[3]}, rr = {relative->rot[0], relative->rot[1], relative->rot[2], relative->rot[3]};
+	const v3 rp = {relative->pos[0], relative->pos[1], relative->pos[2]}, bp = {bone_pos[0], bone_pos[1], bone_pos[2]};
+	const v3 bt_pos = v3_add(q_rotate(br, rp), bp); /* LocalRigidTransform::operator*, math.cpp:859-861 */
+	const quat bt_rot = q_mul(br, rr);
+	xform r; /* Transform::compose(const LocalRigidTransform&), math.cpp:763 */
+	const v3 scaled = {bt_pos.x * p.scale.x, bt_pos.y * p.scale.y, bt_pos.z * p.scale.z};
+	const v3 rot = q_rotate(p.rot, scaled);
+	r.pos.x = p.pos.x + rot.x; r.pos.y = p.pos.y + rot.y; r.pos.z = p.pos.z + rot.z; /* DVec3 + Vec3, math.cpp:514 */
+	r.rot = q_mul(p.rot, bt_rot);
+	r.scale.x = original_scale[0]; r.scale.y = original_scale[1]; r.scale.z = original_scale[2];
+	xform_store(r, out);
+}
 ORC_API void orc_compute_local(const LmxTransform* parent, const LmxTransform* child, LmxTransform* out) {
 	xform_store(xform_compute_local(xform_load(parent), xform_load(child)), out);
 }

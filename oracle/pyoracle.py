@@ -105,6 +105,7 @@ class Oracle:
         self.f_intersects_aabb = self._fn("intersects_aabb", ci, [vp, vp, vp])
         self.f_get_relative = self._fn("get_relative", None, [vp, vp, vp])
         self.f_compose = self._fn("compose", None, [vp, vp, vp])
+        self.f_bone_attachment = self._fn("bone_attachment", None, [vp, vp, vp, vp, vp, vp])
         self.f_compute_local = self._fn("compute_local", None, [vp, vp, vp])
         self.f_world_create = self._fn("world_create", vp, [u32])
         self.f_world_destroy = self._fn("world_destroy", None, [vp])
@@ -163,6 +164,17 @@ class Oracle:
         return out
 
     # ---- transforms -------------------------------------------------------------------------------------
+    def bone_attachment(self, parent, bone_pos, bone_rot, relative, original_scale) -> np.ndarray:
+        """updateBoneAttachment (render_module.cpp:396-402) per row: parent Transform[n], bone pose [n,3]/[n,4], relative LocalRigidTransform[n], scale [n,3]."""
+        parent = np.ascontiguousarray(parent, TRANSFORM)
+        bp, br = np.ascontiguousarray(bone_pos, np.float32).reshape(-1, 3), np.ascontiguousarray(bone_rot, np.float32).reshape(-1, 4)
+        rel = np.ascontiguousarray(relative, LOCAL_RIGID)
+        sc = np.ascontiguousarray(original_scale, np.float32).reshape(-1, 3)
+        out = np.zeros(len(parent), TRANSFORM)
+        for i in range(len(parent)):
+            self.f_bone_attachment(_ptr(parent[i : i + 1]), _ptr(bp[i : i + 1]), _ptr(br[i : i + 1]), _ptr(rel[i : i + 1]), _ptr(sc[i : i + 1]), _ptr(out[i : i + 1]))
+        return out
+
     def compose(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:
         out = np.zeros(len(a), TRANSFORM)
         for i in range(len(a)):

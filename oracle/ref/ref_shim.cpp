@@ -502,6 +502,17 @@ void ref_get_relative(const LmxShiftedFrustum* f, const double* origin, LmxFrust
 void ref_compose(const LmxTransform* a, const LmxTransform* b, LmxTransform* out) { // Transform::compose, math.cpp:801-807
 	fromRef(toRef(a).compose(toRef(b)), out);
 }
+// RenderModuleImpl::updateBoneAttachment, render_module.cpp:396-402, on the reference's own LocalRigidTransform::operator* and
+// Transform::compose(const LocalRigidTransform&) (math.cpp:859-861, :763)
+void ref_bone_attachment(const LmxTransform* parent, const float* bone_pos, const float* bone_rot, const LmxLocalRigidTransform* relative,
+	const float* original_scale, LmxTransform* out) {
+	const LocalRigidTransform bone_transform = {Vec3(bone_pos[0], bone_pos[1], bone_pos[2]), Quat(bone_rot[0], bone_rot[1], bone_rot[2], bone_rot[3])};
+	const LocalRigidTransform relative_transform = {Vec3(relative->pos[0], relative->pos[1], relative->pos[2]),
+		Quat(relative->rot[0], relative->rot[1], relative->rot[2], relative->rot[3])};
+	Transform result = toRef(parent).compose(bone_transform * relative_transform);
+	result.scale = Vec3(original_scale[0], original_scale[1], original_scale[2]);
+	fromRef(result, out);
+}
 void ref_compute_local(const LmxTransform* parent, const LmxTransform* child, LmxTransform* out) { // math.cpp:809-816
 	fromRef(Transform::computeLocal(toRef(parent), toRef(child)), out);
 }

@@ -87,6 +87,18 @@ def main():
         os.path.join(OUT, "skin.npz"), parents=sk["parents"], bind=sk["bind"], first_nonroot=np.array([sk["first_nonroot"]]), rel_pos=pos, rel_rot=rot,
         verts=verts, skin=skin, inv_bind=inv, abs_pos=apos, abs_rot=arot, palette=pal, skinned=out, dual_quats=dq,
     )
+    # bone attachments: updateBoneAttachment on the reference's own compose / LocalRigidTransform::operator*
+    n = 64
+    att_parent = scenes.random_transforms(rng, n, 5000.0)
+    att_rel = np.zeros(n, po.LOCAL_RIGID)
+    att_rel["pos"], att_rel["rot"] = rng.uniform(-1, 1, size=(n, 3)), scenes.random_unit_quats(rng, n)
+    att_scale = rng.uniform(0.5, 2.0, size=(n, 3)).astype(np.float32)
+    att_bone = rng.integers(0, 64, size=n).astype(np.uint32)
+    att_inst = rng.integers(0, 4, size=n).astype(np.uint32)
+    np.savez_compressed(
+        os.path.join(OUT, "attach.npz"), parent=att_parent, relative=att_rel, scale=att_scale, bone=att_bone, instance=att_inst,
+        result=ref.bone_attachment(att_parent, apos[att_inst, att_bone], arot[att_inst, att_bone], att_rel, att_scale),
+    )
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

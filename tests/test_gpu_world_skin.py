@@ -209,6 +209,47 @@ def test_skin_groups_and_pose_writeback_switch(gpu_ctx, oracle_port):
     sk.setMode(False)
 
 
+def test_bone_attachments_golden_and_subtrees(gpu_ctx, oracle_port):
+    """updateBoneAttachment for 64 attachments at once (render_module.cpp:377-404): attached roots against the golden from the
+    reference's object code, their children against the oracle's compose, bit for bit; the pose is the skin golden's."""
+    g, ga = np.load(os.path.join(G, "skin.npz")), np.load(os.path.join(G, "attach.npz"))
+    sk = api.Skinning(gpu_ctx)
+    sk.setMode(True)
+    model = sk.addModel(g["parents"], g["bind"], int(g["first_nonroot"][0]))
+    mesh = sk.addMesh(g["verts"], g["skin"])
+    n_inst = g["rel_pos"].shape[0]
+    sk.setInstances([model] * n_inst, [mesh] * n_inst)
+    sk.uploadPoses(g["rel_pos"], g["rel_rot"])
+    n = len(ga["parent"])
+    # entities: [0, n) parents (model instances), [n, 2n) attached roots, [2n, 3n) one child under every attached root
+    rng = np.random.default_rng(23)
+    tr = np.zeros(3 * n, api.TRANSFORM)
+    tr[:n] = ga["parent"]
+    tr[n : 2 * n] = scenes.random_transforms(rng, n, 100.0)
+    tr["scale"][n : 2 * n] = ga["scale"]
+    tr[2 * n :] = scenes.random_transforms(rng, n, 3.0)  # locals of the children
+    parent = np.full(3 * n, -1, np.int32)
+    parent[2 * n :] = np.arange(n, 2 * n)
+    w = api.World(gpu_ctx)
+    w.build(parent, tr)
+    w.setBoneAttachments(np.arange(n, 2 * n), np.arange(n), ga["instance"], ga["bone"], ga["relative"])
+    with pytest.raises(api.LumixError):
+        w.updateBoneAttachments()  # the pose is still relative (ASSERT(pose->is_absolute), render_module.cpp:424)
+    sk.run()
+    w.updateBoneAttachments()
+    w.propagate()
+    got = w.getTransforms()
+    assert H.transforms_bits_equal(got[n : 2 * n], ga["result"])
+    assert H.transforms_bits_equal(got[:n], ga["parent"])
+    assert H.transforms_bits_equal(got[2 * n :], oracle_port.compose(ga["result"], tr[2 * n :]))
+    # a chain (attachment hanging off an attached entity) and an attached non-root are refused
+    with pytest.raises(api.LumixError):
+        w.setBoneAttachments([n, n + 1], [0, n], [0, 0], [1, 1], ga["relative"][:2])
+    with pytest.raises(api.LumixError):
+        w.setBoneAttachments([2 * n], [0], [0], [1], ga["relative"][:1])
+    sk.setMode(False)
+
+
 def test_skin_dual_quaternion_blend(gpu_ctx, oracle_port):
     """LMX_SKIN_DQS: the SKINNED branch of the reference's vertex shader (surface_base.hlsli:196-217, transformByDualQuat
     common.hlsli:632-636) on the bit-exact dual-quaternion palette, through both vertex kernels (a run of 6 instances on a

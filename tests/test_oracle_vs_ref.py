@@ -127,6 +127,21 @@ def test_compose_and_compute_local_bit_exact(oracle_port, oracle_ref):
     assert H.transforms_bits_equal(oracle_port.compute_local(a, b), oracle_ref.compute_local(a, b))
 
 
+def test_bone_attachment_bit_exact(oracle_port, oracle_ref):
+    """updateBoneAttachment (render_module.cpp:396-402) on the reference's own LocalRigidTransform::operator* / Transform::compose."""
+    rng = np.random.default_rng(19)
+    n = 1500
+    parent = scenes.random_transforms(rng, n, 1.0e6)
+    bone_pos = rng.uniform(-2, 2, size=(n, 3)).astype(np.float32)
+    bone_rot = scenes.random_unit_quats(rng, n)
+    rel = np.zeros(n, po.LOCAL_RIGID)
+    rel["pos"], rel["rot"] = rng.uniform(-1, 1, size=(n, 3)), scenes.random_unit_quats(rng, n)
+    scale = rng.uniform(0.5, 2.0, size=(n, 3)).astype(np.float32)
+    a, b = oracle_port.bone_attachment(parent, bone_pos, bone_rot, rel, scale), oracle_ref.bone_attachment(parent, bone_pos, bone_rot, rel, scale)
+    assert H.transforms_bits_equal(a, b)
+    assert H.bits_equal(np.ascontiguousarray(a["scale"]), scale)
+
+
 @pytest.mark.parametrize("kind", ["chains", "fans"])
 def test_world_hierarchy_matches_reference(oracle_port, oracle_ref, kind):
     h = scenes.hierarchy_chains(500, 4, seed=2) if kind == "chains" else scenes.hierarchy_fans(20, 4, 4, seed=3)
