@@ -16,7 +16,8 @@ def short(name):
     import re
 
     for k in ("k_cull_fused", "k_cull_spheres", "k_cull_classify", "k_cull_dynamic", "k_xform_level", "k_xform_scatter", "k_xform_export", "k_sphere_refresh",
-              "k_pose_palette", "k_skin_vertices", "k_patch_spheres"):
+              "k_pose_palette", "k_skin_vertices", "k_skin_shared", "k_patch_spheres", "k_keys_mesh", "k_keys_decal", "k_keys_offsets", "k_keys_scatter",
+              "k_keys_groups", "k_anim_update", "k_bone_attach", "k_palette_expand"):
         if k in name:
             m = re.search(re.escape(k) + r"(<[^>(]*>)?", name)
             return m.group(0) if m else k
