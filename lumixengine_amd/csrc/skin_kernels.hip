@@ -49,6 +49,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 constexpr int POSE_LDS_BONES = 1024; // K * n_bones <= 1024: 16 x 64, 8 x 128, 4 x 196
 constexpr int POSE_WAVES = 4;
 
+// LDS slot of (bone, instance of the group): bone-major, with the instance index XOR-ed by the bone so that BOTH access
+// patterns are conflict-free — the level walk (neighbouring lanes = neighbouring instances of one bone: a permutation of one
+// row) and the staging / palette phases (neighbouring lanes = neighbouring bones of one instance: without the swizzle all lanes
+// of a ds_*_b128 service group hit one bank column, measured as 75 % of the kernel's LDS cycles).
+template <uint32_t K> __device__ __forceinline__ uint32_t pose_slot(uint32_t bone, uint32_t k) { return bone * K + (k ^ (bone & (K - 1))); }
+
 template <int KSHIFT>
 __global__ __launch_bounds__(64 * POSE_WAVES) void k_pose_palette(const SkinInstance* __restrict__ inst, const PoseGroup* __restrict__ groups,
 	const float* rel_pos, const float4* rel_rot, float* pose_pos, float4* pose_rot /* rel_* may alias pose_*: no __restrict__; null = no write-back */,
@@ -82,10 +88,11 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_pose_palette(const SkinInst
 		for (uint32_t kk = 0; kk < KW; ++kk) {
 			const uint32_t k = wave + kk * POSE_WAVES;
 			if (k < g.count) {
-				s_rot[b * K + k] = r[kk];
-				s_pos[(b * K + k) * 3] = px[kk];
-				s_pos[(b * K + k) * 3 + 1] = py[kk];
-				s_pos[(b * K + k) * 3 + 2] = pz[kk];
+				const uint32_t slot = pose_slot<K>(b, k);
+				s_rot[slot] = r[kk];
+				s_pos[slot * 3] = px[kk];
+				s_pos[slot * 3 + 1] = py[kk];
+				s_pos[slot * 3 + 2] = pz[kk];
 			}
 		}
 	}
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_pose_palette(const SkinInst
 			const uint32_t k = j & (K - 1);
 			if (k < g.count) {
 				const uint32_t it = s_item[start + (j >> KSHIFT)];
-				const uint32_t ib = (it & 0xffffu) * K + k, ip = (it >> 16) * K + k;
+				const uint32_t ib = pose_slot<K>(it & 0xffffu, k), ip = pose_slot<K>(it >> 16, k);
 				const float4 pr4 = s_rot[ip];
 				const float4 r4 = s_rot[ib];
 				const Q4 pr = Q4{pr4.x, pr4.y, pr4.z, pr4.w};
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_pose_palette(const SkinInst
 			const uint32_t k = wave + kk * POSE_WAVES;
 			if (k >= g.count) break;
 			const size_t i = bone0 + (size_t)k * nb + b;
-			const uint32_t ib = b * K + k;
+			const uint32_t ib = pose_slot<K>(b, k);
 			const float4 r4 = s_rot[ib];
 			const V3 p = V3{s_pos[3 * ib], s_pos[3 * ib + 1], s_pos[3 * ib + 2]};
 			const Mat4 m = skin_matrix(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, ir);
