@@ -88,11 +88,22 @@ def main():
             dist.barrier()
 
     def timed(fn, steps):
+        """K steps bracketed by barrier + synchronize. The host may run at most ~48 launches ahead of the GPU (an event every
+        16 steps, wait on the one recorded 32-48 steps earlier): the HIP runtime drains the whole queue once every several
+        hundred launches, which costs nothing when the GPU keeps up but shows up as one stall of backlog x kernel time (tens of
+        ms after ~850 queued 43 us culls, tools/_build/dbg_dense3.py) when a loop is GPU-paced and unbounded."""
         barrier()
         torch.cuda.synchronize()
+        events = []
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
             fn()
+            if (i & 15) == 15:
+                e = torch.cuda.Event()
+                e.record()
+                events.append(e)
+                if len(events) > 2:
+                    events.pop(0).synchronize()
         torch.cuda.synchronize()
         barrier()
         ms = (time.perf_counter() - t0) * 1e3 / steps
@@ -112,6 +123,13 @@ def main():
     stats = cs.stats()
     log(f"[rank {rank}] scene {args.variant}: {N} entities, {stats['cells']} cells, {stats['chunks']} chunks, build {time.time() - t0:.1f}s")
     frustum = api.viewport_frustum()  # default player viewport at the origin
+    # Process warm-up, outside every timed region: the HIP runtime pays a one-time ~50 ms stall around the 850th kernel launch
+    # of a process (measured: tools/_build/dbg4.py, a 3000-cull loop stalls once in launches 750-1000 and never again in the
+    # next 8000). Without this it lands in whichever timed loop crosses that count (a --steps 2000 run read 45 us per step
+    # instead of 20). 1200 culls of the real scene = 25 ms.
+    for _ in range(1200):
+        cs.cull(frustum)
+    torch.cuda.synchronize()
     if args.camera == "all_visible":
         frustum = api.viewport_frustum(pos=(0.0, 0.0, 4.0 * half), far=20.0 * half)
     n_frusta = 1
@@ -315,6 +333,14 @@ def extras(ctx, api, scenes, torch, timed, N, log):
         cs.cull(big)
     ms_all = timed(lambda: cs.cull(big), 50)
     vis_all = int(cs.cull(big).counts()[0].sum())
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    for _ in range(10):
+        cs.cull(big)
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    out["dense_all_visible_kernel_ms"] = ctx.profile_get(api.K_CULL_SPHERES)[0] / 10
+    out["dense_stats"] = cs.stats()
     out["dense_all_visible_ms_per_cull"] = ms_all
     out["dense_all_visible_count"] = vis_all
     out["dense_all_visible_GBps"] = (20.0 * N + 4.0 * vis_all) / (ms_all * 1e-3) / 1e9

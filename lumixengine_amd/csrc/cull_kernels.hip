@@ -159,7 +159,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_spheres(const float4* __res
 template <int F, int WAVES, int CHW>
 __global__ __launch_bounds__(WAVES * 64) void k_cull_fused(const float4* __restrict__ spheres, const int32_t* __restrict__ ids,
 	const uint32_t* __restrict__ chunk_cell, const uint64_t* __restrict__ chunk_flags, const CellKey* __restrict__ tile_cells,
-	const uint32_t* __restrict__ tile_tab, FrustaArg fr, TypeTable tt, uint32_t ent_begin, uint32_t cell_cap,
+	const uint32_t* __restrict__ tile_tab, const TileBox* __restrict__ tile_box, FrustaArg fr, TypeTable tt, uint32_t ent_begin, uint32_t cell_cap,
 	int32_t* __restrict__ out_ids, uint32_t out_stride, uint32_t* __restrict__ counts, uint32_t* __restrict__ counts_next) {
 	constexpr int TILE = WAVES * CHW * 64;
 	constexpr int NCH = WAVES * CHW;
@@ -182,6 +182,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_fused(const float4* __restr
 	// (scalar load) and the tile's cell keys (tile-major, stride cell_cap) - no dependent round trip before phase A.
 	const uint32_t chunk0 = tile_chunk + wave * CHW;
 	const uint32_t tile_index = tile_ent / (uint32_t)TILE;
+	// tile-level early out: the box of the tile's cell indices against every frustum of the pass (block-uniform; conservative,
+	// see tile_rejected). Most tiles of a large scene end here without touching their ~400 cell keys.
+	{
+		const TileBox box = tile_box[tile_index];
+		bool all_rejected = true;
+#pragma unroll
+		for (int f = 0; f < F; ++f) all_rejected = all_rejected && tile_rejected(fr.f[f], box);
+		if (all_rejected) return;
+	}
 	const uint32_t first_cell = tile_tab[2 * tile_index];
 	const uint32_t n_cells = tile_tab[2 * tile_index + 1];
 	const CellKey* keys = tile_cells + (size_t)tile_index * cell_cap;
@@ -386,7 +395,7 @@ hipError_t fused_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, u
 	const uint32_t cell_cap = v.tile_cap[K];
 	const size_t lds = fused_lds_bytes(F, TILE, cell_cap);
 	hipLaunchKernelGGL((k_cull_fused<F, WAVES, CHW>), dim3(tiles), dim3(WAVES * 64), lds, s, v.spheres, v.ids, v.chunk_cell, v.chunk_flags,
-		v.tile_cells[K], v.tile_tab[K], fr, tt, ent_begin, cell_cap, out_ids, out_stride, counts, counts_next);
+		v.tile_cells[K], v.tile_tab[K], v.tile_box[K], fr, tt, ent_begin, cell_cap, out_ids, out_stride, counts, counts_next);
 	return hipGetLastError();
 }
 

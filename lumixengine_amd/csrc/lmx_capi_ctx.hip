@@ -32,6 +32,12 @@ void prof_drain(LmxContext* ctx) {
 		ctx->event_pool.push_back(s.b);
 	}
 	ctx->prof_pending.clear();
+	// keep a small pool only: hundreds of live events slow the HIP runtime's queue management down (seen as ~0.7 ms per launch
+	// once the GPU, not the host, paces a launch loop)
+	while (ctx->event_pool.size() > 64) {
+		(void)hipEventDestroy(ctx->event_pool.back());
+		ctx->event_pool.pop_back();
+	}
 }
 
 } // namespace lmx

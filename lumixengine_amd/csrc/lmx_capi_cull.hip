@@ -92,9 +92,11 @@ int rebuild_static(LmxContext* ctx) {
 		cs.tile_cap[k] = lay.tile_cap[k];
 		LMX_HIP(ctx, cs.tile_cells[k].reserve(std::max<size_t>(lay.tile_cells[k].size(), 1)));
 		LMX_HIP(ctx, cs.tile_tab[k].reserve(std::max<size_t>(lay.tile_tab[k].size(), 1)));
+		LMX_HIP(ctx, cs.tile_box[k].reserve(std::max<size_t>(lay.tile_box[k].size(), 1)));
 		if (!lay.tile_cells[k].empty()) {
 			LMX_HIP(ctx, hipMemcpy(cs.tile_cells[k].p, lay.tile_cells[k].data(), lay.tile_cells[k].size() * sizeof(CellKey), hipMemcpyHostToDevice));
 			LMX_HIP(ctx, hipMemcpy(cs.tile_tab[k].p, lay.tile_tab[k].data(), lay.tile_tab[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+			LMX_HIP(ctx, hipMemcpy(cs.tile_box[k].p, lay.tile_box[k].data(), lay.tile_box[k].size() * sizeof(TileBox), hipMemcpyHostToDevice));
 		}
 	}
 	cs.rec_slot.swap(lay.rec_slot);
@@ -239,6 +241,7 @@ CullDeviceView static_view(const CullState& cs) {
 	for (int k = 0; k < 3; ++k) {
 		v.tile_cells[k] = cs.tile_cells[k].p;
 		v.tile_tab[k] = cs.tile_tab[k].p;
+		v.tile_box[k] = cs.tile_box[k].p;
 		v.tile_cap[k] = cs.tile_cap[k];
 	}
 	return v;

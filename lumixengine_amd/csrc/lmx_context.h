@@ -90,6 +90,7 @@ struct CullState {
 	DevBuf<CellKey> cells;
 	DevBuf<CellKey> tile_cells[3];
 	DevBuf<uint32_t> tile_tab[3];
+	DevBuf<TileBox> tile_box[3];
 	uint32_t tile_cap[3] = {16, 16, 16};
 	uint32_t n_padded = 0, n_cells = 0, n_dead_cells = 0;
 	uint32_t max_tile_cells[3] = {0, 0, 0};

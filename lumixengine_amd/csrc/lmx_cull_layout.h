@@ -1,7 +1,7 @@
 // lmx_cull_layout.h — pure-host construction of the device layout of the culling set (no HIP types), shared by
 // lmx_capi.hip (which uploads it) and the CPU-side layout tests.
 //
-// Spheres are sorted by (type, is_big, cell.x, cell.y, cell.z): every occupied CellIndices group of the reference
+// Spheres are sorted by (type, is_big, Morton code of the cell index): every occupied CellIndices group of the reference
 // (src/renderer/culling_system.cpp:23-40) becomes one contiguous run ("cell"), whatever number of 4 KiB CellPages
 // the reference would chain for it. Each type range is padded to TILE_ALIGN slots; padding slots carry id -1 and
 // belong to a per-type dead cell that the classify kernel always rejects. Cell slots are consecutive along the
@@ -61,6 +61,7 @@ struct CullLayout {
 	uint32_t tile_cap[3] = {16, 16, 16};
 	std::vector<LayoutCell> tile_cells[3]; // [n_tiles_k * tile_cap[k]], unused tail entries are dead
 	std::vector<uint32_t> tile_tab[3];     // [n_tiles_k * 2] = {first_cell, n_cells}
+	std::vector<TileBox> tile_box[3];      // [n_tiles_k]: cell-index box of the tile's live cells (k_cull_fused's tile-level early out)
 };
 
 // CullingSystemImpl::add, culling_system.cpp:131-157 + addToCell :100
@@ -96,14 +97,31 @@ inline DevFrustum to_dev_frustum(const LmxShiftedFrustum& f) {
 }
 
 // returns false when the set does not fit the 31-bit slot space
+// bits of a 21-bit value spread to every third bit (bit i -> bit 3 i)
+inline uint64_t spread3(uint64_t x) {
+	x &= 0x1fffffull;
+	x = (x | x << 32) & 0x1f00000000ffffull;
+	x = (x | x << 16) & 0x1f0000ff0000ffull;
+	x = (x | x << 8) & 0x100f00f00f00f00full;
+	x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+	x = (x | x << 2) & 0x1249249249249249ull;
+	return x;
+}
+
 inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out) {
 	struct SortItem { uint64_t hi, lo; uint32_t rec; };
 	const size_t n = recs.size();
 	std::vector<SortItem> items(n);
 	for (size_t i = 0; i < n; ++i) {
 		const CullRec& r = recs[i];
-		items[i].hi = ((uint64_t)r.type << 33) | ((uint64_t)(r.big ? 1 : 0) << 32) | (uint32_t)((uint32_t)r.cell.x ^ 0x80000000u);
-		items[i].lo = ((uint64_t)((uint32_t)r.cell.y ^ 0x80000000u) << 32) | (uint32_t)((uint32_t)r.cell.z ^ 0x80000000u);
+		// cells in Morton (Z-curve) order of their sign-biased indices: a tile of consecutive spheres then covers a compact
+		// block of cells, which is what makes the tile-level early out of k_cull_fused (tile_rejected) effective. 96 bits of
+		// Morton code = the interleaved high 11 bits of x, y, z (33 bits) above their interleaved low 21 bits (63 bits).
+		const uint32_t bx = (uint32_t)r.cell.x ^ 0x80000000u, by = (uint32_t)r.cell.y ^ 0x80000000u, bz = (uint32_t)r.cell.z ^ 0x80000000u;
+		const uint64_t m_hi = (spread3(bx >> 21) << 2) | (spread3(by >> 21) << 1) | spread3(bz >> 21);
+		const uint64_t m_lo = (spread3(bx & 0x1fffffu) << 2) | (spread3(by & 0x1fffffu) << 1) | spread3(bz & 0x1fffffu);
+		items[i].hi = ((uint64_t)r.type << 35) | ((uint64_t)(r.big ? 1 : 0) << 34) | m_hi;
+		items[i].lo = m_lo;
 		items[i].rec = (uint32_t)i;
 	}
 	std::sort(items.begin(), items.end(), [](const SortItem& a, const SortItem& b) {
@@ -209,12 +227,26 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 		const size_t n_tiles = n_padded / tile;
 		out.tile_cells[k].assign(n_tiles * cap, LayoutCell{0, 0, 0, LAYOUT_CELL_DEAD});
 		out.tile_tab[k].assign(n_tiles * 2, 0u);
+		out.tile_box[k].assign(n_tiles, TileBox{{0, 0, 0}, {0, 0, 0}, TILE_EMPTY, 0});
 		for (size_t ti = 0; ti < n_tiles; ++ti) {
 			const uint32_t first = out.slot_cell[ti * tile];
 			const uint32_t cnt = out.slot_cell[ti * tile + tile - 1] - first + 1;
 			out.tile_tab[k][2 * ti] = first;
 			out.tile_tab[k][2 * ti + 1] = cnt;
 			for (uint32_t j = 0; j < cnt; ++j) out.tile_cells[k][ti * cap + j] = out.cells[first + j];
+			TileBox box = {{INT32_MAX, INT32_MAX, INT32_MAX}, {INT32_MIN, INT32_MIN, INT32_MIN}, TILE_EMPTY, 0};
+			for (uint32_t j = 0; j < cnt; ++j) {
+				const LayoutCell& c = out.cells[first + j];
+				if (c.meta & LAYOUT_CELL_DEAD) continue;
+				box.flags &= ~(uint32_t)TILE_EMPTY;
+				if (c.meta & 0x100u) box.flags |= TILE_HAS_BIG;
+				const int32_t idx[3] = {c.ix, c.iy, c.iz};
+				for (int a = 0; a < 3; ++a) {
+					box.lo[a] = std::min(box.lo[a], idx[a]);
+					box.hi[a] = std::max(box.hi[a], idx[a]);
+				}
+			}
+			out.tile_box[k][ti] = box;
 		}
 	}
 	return true;

@@ -38,6 +38,7 @@ struct CullDeviceView {
 	// fused kernel: per tile-size variant k (tile = 4096 >> k), tile-major cell keys + {first cell, n cells} per tile
 	const CellKey* tile_cells[3];
 	const uint32_t* tile_tab[3];
+	const TileBox* tile_box[3];
 	uint32_t tile_cap[3];
 };
 

@@ -16,7 +16,11 @@
 
 using namespace lmx;
 
+static uint32_t g_tile_stats[3]; // tiles visited, tiles the tile-level box test ended, tiles whose cells are all CELL_REJECT
+
 extern "C" {
+
+void emul_tile_stats(uint32_t* out) { memcpy(out, g_tile_stats, sizeof(g_tile_stats)); }
 
 // emulates lmx_cull_build + lmx_cull over n_frusta frusta; out_ids / out_types are [n_frusta][n] (first
 // sum(out_counts[f]) entries used), out_counts [n_frusta][8]
@@ -28,6 +32,7 @@ int emul_cull(uint32_t n, const int32_t* entity, const uint8_t* type, const doub
 	if (!build_cull_layout(recs, lay)) return 1;
 	const size_t n_cells = lay.cells.size();
 	memset(out_counts, 0, sizeof(uint32_t) * n_frusta * LAYOUT_MAX_TYPES);
+	memset(g_tile_stats, 0, sizeof(g_tile_stats));
 	struct Info { float x, y, z; uint32_t cls; };
 	for (uint32_t f = 0; f < n_frusta; ++f) {
 		uint32_t total = 0;
@@ -61,6 +66,19 @@ int emul_cull(uint32_t n, const int32_t* entity, const uint8_t* type, const doub
 			if (first_cell != lay.chunk_cell[tile_chunk] || last_cell != first_cell + tile_n_cells - 1) return 3;
 			if (tile_n_cells > cap || tile_n_cells > lay.max_tile_cells[tile_k] || last_cell >= n_cells) return 4;
 			if (n_frusta <= 8 && (size_t)n_frusta * cap * 16 + (size_t)n_frusta * tile * 4 + 64 > 65536) return 6; // fused LDS budget
+			// tile-level early out of the fused kernel: it may only fire when every cell of the tile is rejected cell by cell
+			if (chunk == tile_chunk) { // once per tile
+				bool none = true;
+				for (uint32_t c = first_cell; c <= last_cell; ++c) none = none && info[c].cls == CELL_REJECT;
+				g_tile_stats[0]++;
+				g_tile_stats[2] += none ? 1u : 0u;
+				g_tile_stats[1] += tile_rejected(fr, lay.tile_box[tile_k][tile_index]) ? 1u : 0u;
+			}
+			if (tile_rejected(fr, lay.tile_box[tile_k][tile_index])) {
+				for (uint32_t c = first_cell; c <= last_cell; ++c)
+					if (info[c].cls != CELL_REJECT) return 8;
+				continue;
+			}
 			uint32_t t = 0;
 			for (int k = 0; k < LAYOUT_MAX_TYPES; ++k)
 				if (chunk * 64 >= lay.ent_start[k] && chunk * 64 < lay.ent_end[k]) t = (uint32_t)k;

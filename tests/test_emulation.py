@@ -73,6 +73,30 @@ def test_emulated_cull_config1_and_type_filter(emul_lib, oracle_port):
             H.assert_same_visible(got[f], H.sorted_by_type(ids, types), f"type {t}")
 
 
+@pytest.mark.parametrize("shift", [(0.0, 0.0, 0.0), (1.0e6, 50.0, -1.0e6)])
+def test_emulated_tile_early_out_is_conservative_and_effective(emul_lib, oracle_port, shift):
+    """k_cull_fused ends a tile before classifying its cells when the box of its cell indices is behind a plane (tile_rejected):
+    the emulation fails (code 8) if that ever fires on a tile with a surviving cell; results stay identical to the oracle; and
+    on a many-tile scene it removes most of the tiles whose cells are all rejected. Second case: the whole scene 1e6 units
+    from the origin (large cell indices, fp64 box arithmetic) with the camera in its middle."""
+    sc = scenes.cull_scene(600_000, 9000.0, seed=7, big_fraction=0.0005)
+    sc["pos"] = sc["pos"] + np.array(shift)
+    frusta = np.concatenate([oracle_port.viewport_frustum(pos=shift), oracle_port.viewport_frustum(pos=(shift[0] + 700.0, shift[1] - 40.0, shift[2] + 2500.0), rot=(0.0, 0.38268343, 0.0, 0.92387953), far=4000.0),
+                             H.frusta(oracle_port)[:3]])
+    cs = oracle_port.culling_system()
+    cs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    for f in range(len(frusta)):
+        got, _ = emul_cull(emul_lib, sc, frusta[f : f + 1])
+        ids, types, _ = cs.cull(frusta[f : f + 1])
+        H.assert_same_visible(got[0], H.sorted_by_type(ids, types), f"frustum {f}")
+        st = np.zeros(3, np.uint32)
+        emul_lib.emul_tile_stats(_p(st))
+        tiles, boxed, dead = (int(x) for x in st)
+        assert tiles >= 140 and boxed <= dead  # conservative: never more than the tiles that are really empty
+        if dead > 20:
+            assert boxed >= 0.6 * dead, f"frustum {f}: box test caught {boxed} of {dead} fully rejected tiles"
+
+
 def test_emulated_empty_and_tiny(emul_lib, oracle_port):
     fr = H.frusta(oracle_port)[:1]
     empty = {"entity": np.zeros(0, np.int32), "type": np.zeros(0, np.uint8), "pos": np.zeros((0, 3)), "radius": np.zeros(0, np.float32)}

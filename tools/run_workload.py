@@ -47,8 +47,8 @@ def main():
         sc = scenes.cull_scene(args.entities, half, seed=2, mixed_types=args.workload == "cull8")
         cs = api.CullingSystem(ctx)
         cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
-        if args.workload == "cull_stream":
-            fr = api.viewport_frustum(pos=(0.0, 0.0, 4.0 * half), far=20.0 * half)
+        if args.workload == "cull_stream" or os.environ.get("LMX_WORKLOAD_CAMERA") == "far":
+            fr = api.viewport_frustum(pos=(0.0, 0.0, 60000.0), far=200000.0) if args.workload == "cull_dense" else api.viewport_frustum(pos=(0.0, 0.0, 4.0 * half), far=20.0 * half)
         elif args.workload == "cull8":
             fr = H.cascade_frusta(api, 8)
         else:
