@@ -91,7 +91,7 @@ def main():
         """K steps bracketed by barrier + synchronize. The host may run at most ~48 launches ahead of the GPU (an event every
         16 steps, wait on the one recorded 32-48 steps earlier): the HIP runtime drains the whole queue once every several
         hundred launches, which costs nothing when the GPU keeps up but shows up as one stall of backlog x kernel time (tens of
-        ms after ~850 queued 43 us culls, tools/_build/dbg_dense3.py) when a loop is GPU-paced and unbounded."""
+        ms after ~850 queued 43 us culls, tools/hip_queue_stall_probe.py) when a loop is GPU-paced and unbounded."""
         barrier()
         torch.cuda.synchronize()
         events = []
@@ -124,7 +124,7 @@ def main():
     log(f"[rank {rank}] scene {args.variant}: {N} entities, {stats['cells']} cells, {stats['chunks']} chunks, build {time.time() - t0:.1f}s")
     frustum = api.viewport_frustum()  # default player viewport at the origin
     # Process warm-up, outside every timed region: the HIP runtime pays a one-time ~50 ms stall around the 850th kernel launch
-    # of a process (measured: tools/_build/dbg4.py, a 3000-cull loop stalls once in launches 750-1000 and never again in the
+    # of a process (measured: tools/hip_queue_stall_probe.py, a 3000-cull loop stalls once in launches 750-1000 and never again in the
     # next 8000). Without this it lands in whichever timed loop crosses that count (a --steps 2000 run read 45 us per step
     # instead of 20). 1200 culls of the real scene = 25 ms.
     for _ in range(1200):

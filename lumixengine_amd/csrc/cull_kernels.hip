@@ -403,8 +403,8 @@ hipError_t fused_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, u
 
 uint32_t cull_tile_size(int n_frusta) {
 	static const uint32_t f1_tile = [] { // experiment knob: LMX_CULL_TILE=2048 runs the 1-frustum kernel with 4 waves per block
-		const char* e = getenv("LMX_CULL_TILE");
-		return (e && atoi(e) == 2048) ? 2048u : 4096u;
+		const char* e = getenv("LMX_CULL_TILE"); // 2048 / 4096 force a tile size (8192 is the internal code for "always 4096")
+		return (e && atoi(e) == 2048) ? 2048u : ((e && atoi(e) == 4096) ? 8192u : 4096u);
 	}();
 	return n_frusta <= 1 ? f1_tile : (n_frusta <= 4 ? 2048u : 1024u);
 }
@@ -414,11 +414,14 @@ size_t fused_lds_bytes(int n_frusta, uint32_t tile, uint32_t cell_cap) {
 }
 
 hipError_t launch_cull_fused(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
-	const FrustaArg& fr, int n_frusta, int32_t* out_ids, uint32_t out_stride, uint32_t* counts, uint32_t* counts_next) {
+	const FrustaArg& fr, int n_frusta, int32_t* out_ids, uint32_t out_stride, uint32_t* counts, uint32_t* counts_next, bool small_tiles) {
 #define LMX_FUSED(F, W, C) return fused_f<F, W, C>(s, v, ent_begin, ent_end, tt, fr, out_ids, out_stride, counts, counts_next)
 	switch (n_frusta) {
 		case 1:
-			if (cull_tile_size(1) == 2048u) LMX_FUSED(1, 4, 8);
+			// 2048-sphere tiles when the frustum covers a small part of the scene (few surviving tiles: shorter per-block chain,
+			// 17.9 vs 19.6 us on the 10 M scene), 4096 when much of it is visible (the one returning atomic per block and
+			// list is then the limit: 42 vs 69 us with everything visible)
+			if (cull_tile_size(1) == 2048u || (small_tiles && cull_tile_size(1) != 8192u)) LMX_FUSED(1, 4, 8);
 			LMX_FUSED(1, 8, 8);
 		case 2: LMX_FUSED(2, 8, 4);
 		case 3: LMX_FUSED(3, 8, 4);

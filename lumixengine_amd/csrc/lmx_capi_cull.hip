@@ -75,6 +75,14 @@ int rebuild_static(LmxContext* ctx) {
 	cs.n_cells = (uint32_t)lay.cells.size();
 	cs.n_dead_cells = lay.n_dead_cells;
 	for (int k = 0; k < 3; ++k) cs.max_tile_cells[k] = lay.max_tile_cells[k];
+	for (int a = 0; a < 3; ++a) { cs.scene_lo[a] = INFINITY; cs.scene_hi[a] = -INFINITY; }
+	for (const TileBox& b : lay.tile_box[0]) { // world-space box of the occupied cells (static set)
+		if (b.flags & TILE_EMPTY) continue;
+		for (int a = 0; a < 3; ++a) {
+			cs.scene_lo[a] = std::min(cs.scene_lo[a], (double)CELL_SIZE * b.lo[a]);
+			cs.scene_hi[a] = std::max(cs.scene_hi[a], (double)CELL_SIZE * b.hi[a] + (double)CELL_SIZE);
+		}
+	}
 	LMX_HIP(ctx, cs.spheres.reserve(std::max<size_t>(n_padded, 1)));
 	LMX_HIP(ctx, cs.ids.reserve(std::max<size_t>(n_padded, 1)));
 	LMX_HIP(ctx, cs.chunk_cell.reserve(std::max<size_t>(n_chunks, 1)));
@@ -508,6 +516,25 @@ int lmx_cull_stats(LmxContext* ctx, uint32_t* n_entities, uint32_t* n_cells, uin
 	return LMX_OK;
 }
 
+// Share of the scene's bounding box that the frustum's bounding box covers (8 corner points + fp64 origin, geometry.h:102-153):
+// a launch-time hint for the tile size of the 1-frustum kernel, nothing the results depend on.
+static double frustum_scene_fraction(const CullState& cs, const LmxShiftedFrustum& f) {
+	double frac = 1.0;
+	for (int a = 0; a < 3; ++a) {
+		double lo = INFINITY, hi = -INFINITY;
+		for (int p = 0; p < 8; ++p) {
+			const double v = (double)f.points[p][a] + f.origin[a];
+			lo = std::min(lo, v);
+			hi = std::max(hi, v);
+		}
+		const double s_lo = cs.scene_lo[a], s_hi = cs.scene_hi[a];
+		if (!(s_hi > s_lo) || !(hi >= lo)) return 1.0; // empty scene / NaN frustum: no hint
+		const double overlap = std::min(hi, s_hi) - std::max(lo, s_lo);
+		frac *= overlap <= 0 ? 0.0 : overlap / (s_hi - s_lo);
+	}
+	return frac;
+}
+
 int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, uint32_t n_frusta, uint8_t type) {
 	LMX_CHECK_CTX(ctx);
 	if (view >= LMX_MAX_VIEWS) return fail(ctx, LMX_ERR_CAPACITY, "view %u >= LMX_MAX_VIEWS", view);
@@ -574,7 +601,7 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 			for (uint32_t k = 0; k < fw; ++k) sub.f[k] = fr.f[f0 + k];
 			ProfScope ps(ctx, LMX_K_CULL_SPHERES);
 			LMX_HIP(ctx, launch_cull_fused(ctx->stream, dv, ent_begin, ent_end, cs.tt, sub, (int)fw, v.out_ptr() + (size_t)f0 * v.out_stride, v.out_stride,
-				v.counts_ptr() + f0 * MAX_TYPES, counts_next));
+				v.counts_ptr() + f0 * MAX_TYPES, counts_next, fw == 1 && frustum_scene_fraction(cs, frusta[f0]) < 0.25));
 		}
 	} else {
 		if (!v.ext_counts) {

@@ -94,6 +94,7 @@ struct CullState {
 	uint32_t tile_cap[3] = {16, 16, 16};
 	uint32_t n_padded = 0, n_cells = 0, n_dead_cells = 0;
 	uint32_t max_tile_cells[3] = {0, 0, 0};
+	double scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0}; // world-space box of the static set's occupied cells
 	TypeTable tt = {};
 	uint32_t cell_begin[MAX_TYPES] = {}, cell_end[MAX_TYPES] = {};
 	// ---- dynamic set: entities bound to the world hierarchy, unsorted -----------------------------------------

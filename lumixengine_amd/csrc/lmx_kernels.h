@@ -59,7 +59,7 @@ hipError_t launch_cull_spheres(hipStream_t s, const CullDeviceView& v, uint32_t 
 uint32_t cull_tile_size(int n_frusta);
 size_t fused_lds_bytes(int n_frusta, uint32_t tile, uint32_t cell_cap);
 hipError_t launch_cull_fused(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
-	const FrustaArg& fr, int n_frusta, int32_t* out_ids, uint32_t out_stride, uint32_t* counts, uint32_t* counts_next);
+	const FrustaArg& fr, int n_frusta, int32_t* out_ids, uint32_t out_stride, uint32_t* counts, uint32_t* counts_next, bool small_tiles);
 
 // Dynamic set: entities whose transform changes every frame (bound to the world hierarchy) are kept UNSORTED as world
 // position (fp64) + radius + id. Their cell, cell-relative position and per-cell class are recomputed per entity per cull
