@@ -129,6 +129,40 @@ def test_oracle_update_animable_matches_second_restatement(oracle_port, weight, 
     assert not H.bits_equal(pos[0], np.array(sk["bind"]["pos"]))
 
 
+def load_unpinned_fixture():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unpinned_animation.npz"))
+    return g, scenes.animation(24, 12, 30.0, seed=int(g["anim_seed"][0])), scenes.skeleton(24, seed=int(g["skeleton_seed"][0]))
+
+
+def test_oracle_reproduces_committed_fixture(oracle_port):
+    """tests/golden/unpinned_animation.npz is a regression anchor written by the restated oracle (NOT reference output)."""
+    g, anim, sk = load_unpinned_fixture()
+    for tag, w, dt in (("w04", 0.4, 0.25), ("w1", 1.0, 1 / 60)):
+        pos, rot, nt = oracle_port.update_animables([anim], [0] * 4, g["times"], dt, w, sk["bind"])
+        assert H.bits_equal(pos, g["pos_" + tag]) and H.bits_equal(rot, g["rot_" + tag]) and np.array_equal(nt, g["times_" + tag])
+
+
+@pytest.mark.gpu
+def test_gpu_animation_matches_committed_fixture(gpu_ctx):
+    g, anim, s = load_unpinned_fixture()
+    sk = api.Skinning(gpu_ctx)
+    model = sk.addModel(s["parents"], s["bind"], s["first_nonroot"])
+    mesh = sk.addMesh(*scenes.skinned_mesh(30, 24, seed=3))
+    sk.setInstances([model] * 4, [mesh] * 4)
+    sk.setModelPose(model, s["bind"])
+    aid = sk.addAnimation(anim)
+    for tag, w, dt in (("w04", 0.4, 0.25), ("w1", 1.0, 1 / 60)):
+        sk.setAnimables([aid] * 4, g["times"])
+        sk.setAnimWeight(w)
+        sk.updateAnimables(dt)
+        for i in range(4):
+            pos, rot = sk.readRelativePose(i)
+            assert H.bits_equal(pos, g["pos_" + tag][i]) and H.bits_equal(rot, g["rot_" + tag][i])
+        assert np.array_equal(sk.readTimes(), g["times_" + tag])
+    sk.setAnimWeight(1.0)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("weight,dt", [(1.0, 1 / 60), (0.4, 0.25), (1.0, -0.4)])
 def test_gpu_animation_matches_oracle(gpu_ctx, oracle_port, weight, dt):

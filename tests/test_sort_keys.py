@@ -146,6 +146,53 @@ def test_oracle_matches_second_restatement(oracle_port, vi):
     assert (got["lod"] != sc["lod"]).any()
 
 
+def load_unpinned_fixture():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unpinned_sort_keys.npz"))
+    sc = scenes.keys_scene(len(g["types"]), g["types"], seed=int(g["scene_seed"][0]))
+    return g, sc
+
+
+def test_oracle_reproduces_committed_fixture(oracle_port):
+    """tests/golden/unpinned_sort_keys.npz is a regression anchor written by the restated oracle (NOT reference output)."""
+    g, sc = load_unpinned_fixture()
+    got = oracle_port.create_sort_keys(g["kv"], sc["max_sort_key"], g["mesh_ids"], g["decal_ids"], g["curve_ids"], sc, g["pos"])
+    order = np.lexsort((got["values"], got["keys"]))
+    assert np.array_equal(got["keys"][order], g["keys"]) and np.array_equal(got["values"][order], g["values"])
+    assert np.array_equal(got["group_offsets"], g["group_offsets"]) and np.array_equal(np.sort(got["poses"]), g["poses"])
+    assert H.bits_equal(got["lod"], g["lod"]) and np.array_equal(got["pose_frame"], g["pose_frame"])
+
+
+@pytest.mark.gpu
+def test_gpu_sort_keys_match_committed_fixture(gpu_ctx):
+    """The device path against the committed fixture: the visible lists are fed through a culling system whose frustum sees
+    exactly the fixture's visible entities (every other entity is parked far behind the camera)."""
+    g, sc = load_unpinned_fixture()
+    n = len(g["types"])
+    vis = np.zeros(n, bool)
+    for k in ("mesh_ids", "decal_ids", "curve_ids"):
+        vis[g[k]] = True
+    cull_pos = np.where(vis[:, None], np.array([0.0, 0.0, -50.0]), np.array([0.0, 0.0, 5000.0]))  # in front of / behind the camera
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(np.arange(n, dtype=np.int32), g["types"], cull_pos, np.full(n, 1.0, np.float32))
+    res = cs.cull(api.viewport_frustum(far=100.0))
+    assert sorted(res.ids(0, 0)) == sorted(g["mesh_ids"]) and sorted(res.ids(0, 1)) == sorted(g["decal_ids"]) and sorted(res.ids(0, 3)) == sorted(g["curve_ids"])
+    sk = api.SortKeys(gpu_ctx)
+    sk.setModels(sc["models"], sc["mesh_types"])
+    sk.setInstances(sc["model"], sc["material_offset"], sc["mesh_materials"], sc["lod"], sc["flags"], sc["dirty"], sc["pose_frame"])
+    sk.setDecals(n, sc["decal_key"], sc["decal_layer"], sc["curve_key"], sc["curve_layer"])
+    sk.setPositions(g["pos"])  # World::getTransforms()[e].pos: what createSortKeys measures distances to (not the culling spheres)
+    sk.run(g["kv"], sc["max_sort_key"])
+    keys, values = sk.readPairs()
+    order = np.lexsort((values, keys))
+    assert np.array_equal(keys[order], g["keys"]) and np.array_equal(values[order], g["values"])
+    offsets, _ = sk.readInstancer()
+    assert np.array_equal(offsets, g["group_offsets"])
+    assert np.array_equal(np.sort(sk.readPoses()), g["poses"]) and np.array_equal(np.sort(sk.readDirty()), g["dirty"])
+    lod, frame = sk.readState()
+    assert H.bits_equal(lod, g["lod"]) and np.array_equal(frame, g["pose_frame"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("vi", range(len(VIEWS)))
 def test_gpu_sort_keys_match_oracle(gpu_ctx, oracle_port, vi):
