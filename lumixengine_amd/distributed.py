@@ -80,6 +80,7 @@ class VisibleExchange:
         self.n_counts, self.row, self.cap = n_counts, row, min(cap, row)
         self.send = [torch.zeros(n_counts + row, dtype=dtype, device=device) for _ in range(2)]
         self.recv = [torch.empty(self.world * (n_counts + self.cap), dtype=dtype, device=device) for _ in range(2)]
+        self.send_head = [s[: n_counts + self.cap] for s in self.send]  # what a frame ships: sliced once, not per frame
         self.work = [None, None]
         self.k = 0
 
@@ -93,8 +94,7 @@ class VisibleExchange:
         return i, self.send[i]
 
     def exchange(self, i: int):
-        n = self.n_counts + self.cap
-        self.work[i] = dist.all_gather_into_tensor(self.recv[i], self.send[i][:n], group=self.group, async_op=True)
+        self.work[i] = dist.all_gather_into_tensor(self.recv[i], self.send_head[i], group=self.group, async_op=True)
         self.k += 1
 
     def finish(self):
