@@ -177,6 +177,11 @@ LMX_API int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* 
 LMX_API int lmx_skin_upload_poses(LmxContext* ctx, const float* positions, const float* rotations, size_t n_bones_total);
 /* Same, from device memory (device-to-device copy on the context stream). */
 LMX_API int lmx_skin_upload_poses_device(LmxContext* ctx, const void* d_positions, const void* d_rotations, size_t n_bones_total);
+/* Pose::blend(rhs, weight) (renderer/pose.cpp:30-41, nlerp core/math.cpp:677-691) for every instance: the library's relative
+ * poses (uploaded or sampled by lmx_anim_update) are blended with a second pose set of the same layout - what the Animator's
+ * blend stack does with each layer's pose (animation_module.cpp:602-636). weight <= 0.001 is a no-op, weight is clamped to 1. */
+LMX_API int lmx_skin_blend_poses(LmxContext* ctx, const float* positions, const float* rotations, size_t n_bones_total, float weight);
+LMX_API int lmx_skin_blend_poses_device(LmxContext* ctx, const void* d_positions, const void* d_rotations, size_t n_bones_total, float weight);
 /* Zero-copy variant: lmx_skin_run reads the relative poses from this device memory every time it runs (the animation
  * system's output buffer) and writes the absolute poses to the library's own arrays. NULL pointers end the borrowing. */
 LMX_API int lmx_skin_set_pose_source_device(LmxContext* ctx, const void* d_positions, const void* d_rotations, size_t n_bones_total);

@@ -122,6 +122,8 @@ SYMBOLS = {
     "lmx_skin_upload_poses": (_ci, [_vp, _vp, _vp, _sz]),
     "lmx_skin_upload_poses_device": (_ci, [_vp, _vp, _vp, _sz]),
     "lmx_skin_set_pose_source_device": (_ci, [_vp, _vp, _vp, _sz]),
+    "lmx_skin_blend_poses": (_ci, [_vp, _vp, _vp, _sz, _f32]),
+    "lmx_skin_blend_poses_device": (_ci, [_vp, _vp, _vp, _sz, _f32]),
     "lmx_skin_set_mode": (_ci, [_vp, _ci]),
     "lmx_skin_run": (_ci, [_vp]),
     "lmx_skin_read_vertices": (_ci, [_vp, _u32, _vp, _u32]),
@@ -651,6 +653,12 @@ class Skinning:
         pos, rot = np.zeros((n, 3), np.float32), np.zeros((n, 4), np.float32)
         self.ctx.check(self.lib.lmx_anim_read_pose(self.ctx.h, instance, _ptr(pos), _ptr(rot), n))
         return pos, rot
+
+    def blendPoses(self, positions, rotations, weight: float):
+        """Pose::blend(rhs, weight) of the library's relative poses with `positions` / `rotations` (all instances back to back)."""
+        positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        rotations = np.ascontiguousarray(rotations, np.float32).reshape(-1, 4)
+        self.ctx.check(self.lib.lmx_skin_blend_poses(self.ctx.h, _ptr(positions), _ptr(rotations), len(positions), float(weight)))
 
     def setPoseWriteback(self, on: bool = True):
         """Store the absolute pose next to the palette (default) or not (readPose then fails)."""

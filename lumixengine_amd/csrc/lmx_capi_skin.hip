@@ -235,6 +235,42 @@ int lmx_skin_upload_poses_device(LmxContext* ctx, const void* d_positions, const
 	return LMX_OK;
 }
 
+// Pose::blend(rhs, weight) (renderer/pose.cpp:30-41) of the library's relative poses with a second set of the same layout
+static int skin_blend(LmxContext* ctx, const float* d_pos, const float4* d_rot, size_t n_bones_total, float weight) {
+	SkinState& sk = ctx->skin;
+	if (!sk.poses_uploaded || sk.pose_is_absolute || sk.borrowed_pos) return fail(ctx, LMX_ERR_NOT_BUILT, "the library holds no relative poses to blend into (upload / lmx_anim_update first)");
+	if (weight <= 0.001f) return LMX_OK; // pose.cpp:33
+	weight = weight < 0.0f ? 0.0f : (weight > 1.0f ? 1.0f : weight); // clamp, pose.cpp:34
+	LMX_HIP(ctx, launch_pose_blend(ctx->stream, sk.d_pose_pos.p, sk.d_pose_rot.p, d_pos, d_rot, n_bones_total, weight));
+	return LMX_OK;
+}
+
+int lmx_skin_blend_poses_device(LmxContext* ctx, const void* d_positions, const void* d_rotations, size_t n_bones_total, float weight) {
+	LMX_CHECK_CTX(ctx);
+	SkinState& sk = ctx->skin;
+	if (n_bones_total != sk.bones_total) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "expected %zu bones over all instances, got %zu", sk.bones_total, n_bones_total);
+	if (!n_bones_total) return LMX_OK;
+	if (!d_positions || !d_rotations) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null device pointer");
+	if (!(weight == weight)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "weight is NaN");
+	return skin_blend(ctx, (const float*)d_positions, (const float4*)d_rotations, n_bones_total, weight);
+}
+
+int lmx_skin_blend_poses(LmxContext* ctx, const float* positions, const float* rotations, size_t n_bones_total, float weight) {
+	LMX_CHECK_CTX(ctx);
+	SkinState& sk = ctx->skin;
+	if (n_bones_total != sk.bones_total) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "expected %zu bones over all instances, got %zu", sk.bones_total, n_bones_total);
+	if (!n_bones_total) return LMX_OK;
+	if (!positions || !rotations) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
+	if (!(weight == weight)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "weight is NaN");
+	LMX_HIP(ctx, sk.d_blend_pos.reserve(n_bones_total * 3));
+	LMX_HIP(ctx, sk.d_blend_rot.reserve(n_bones_total));
+	LMX_HIP(ctx, hipMemcpyAsync(sk.d_blend_pos.p, positions, n_bones_total * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+	LMX_HIP(ctx, hipMemcpyAsync(sk.d_blend_rot.p, rotations, n_bones_total * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+	const int rc = skin_blend(ctx, sk.d_blend_pos.p, sk.d_blend_rot.p, n_bones_total, weight);
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the caller's arrays may be pageable: do not return before they are read
+	return rc;
+}
+
 int lmx_skin_set_pose_source_device(LmxContext* ctx, const void* d_positions, const void* d_rotations, size_t n_bones_total) {
 	LMX_CHECK_CTX(ctx);
 	SkinState& sk = ctx->skin;

@@ -194,6 +194,8 @@ struct SkinState {
 	bool pose_writeback = true;    // store the absolute pose (Pose::is_absolute) next to the palette
 	bool pose_is_absolute = false; // d_pose_* hold the absolute pose of the last run
 	DevBuf<float4> d_palette_expanded;
+	DevBuf<float> d_blend_pos;     // staging of lmx_skin_blend_poses (host variant)
+	DevBuf<float4> d_blend_rot;
 	const float* borrowed_pos = nullptr;  // lmx_skin_set_pose_source_device: relative poses read in place from caller memory
 	const float4* borrowed_rot = nullptr;
 	DevBuf<float4> d_dual_quats;

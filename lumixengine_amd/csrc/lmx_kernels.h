@@ -192,6 +192,8 @@ hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice&
 hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, const PoseGroup* groups, const uint32_t n_groups[3] /* by capacity 16, 8, 4 */,
 	const float* rel_pos, const float4* rel_rot, float* pose_pos, float4* pose_rot, const uint32_t* level_items, const uint16_t* level_off,
 	const float* inv_pos, const float4* inv_rot, float4* palette, float4* dual_quats /* optional */);
+// Pose::blend over all bones of all instances
+hipError_t launch_pose_blend(hipStream_t s, float* pos, float4* rot, const float* rhs_pos, const float4* rhs_rot, size_t n_bones, float weight);
 // palette rows (3 x float4 per bone) -> column-major 4 x 4 matrices
 hipError_t launch_palette_expand(hipStream_t s, const float4* rows, uint32_t n_bones, float4* out);
 // evaluateSkin over every vertex of every instance

@@ -155,6 +155,24 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_pose_palette(const SkinInst
 	}
 }
 
+// Pose::blend (renderer/pose.cpp:30-41) for every bone of every instance: positions = positions * inv + rhs * weight, rotations =
+// nlerp(rotations, rhs, weight) (core/math.cpp:677-691: left-to-right dot and length, t negated for the short way round)
+__global__ __launch_bounds__(256) void k_pose_blend(float* __restrict__ pos, float4* __restrict__ rot, const float* __restrict__ rhs_pos,
+	const float4* __restrict__ rhs_rot, size_t n_bones, float weight) {
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_bones) return;
+	const float inv = 1.0f - weight;
+	pos[3 * i] = pos[3 * i] * inv + rhs_pos[3 * i] * weight;
+	pos[3 * i + 1] = pos[3 * i + 1] * inv + rhs_pos[3 * i + 1] * weight;
+	pos[3 * i + 2] = pos[3 * i + 2] * inv + rhs_pos[3 * i + 2] * weight;
+	const float4 q1 = rot[i], q2 = rhs_rot[i];
+	float t = weight;
+	if (q1.x * q2.x + q1.y * q2.y + q1.z * q2.z + q1.w * q2.w < 0) t = -t;
+	float4 r = make_float4(q1.x * inv + q2.x * t, q1.y * inv + q2.y * t, q1.z * inv + q2.z * t, q1.w * inv + q2.w * t);
+	const float l = 1 / sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+	rot[i] = make_float4(r.x * l, r.y * l, r.z * l, r.w * l);
+}
+
 // lmx_skin_read_palette: 3 x float4 rows -> the reference's column-major Matrix (row 3 = (0, 0, 0, 1), math.cpp:887-890)
 __global__ __launch_bounds__(256) void k_palette_expand(const float4* __restrict__ rows, uint32_t n_bones, float4* __restrict__ out) {
 	const uint32_t b = blockIdx.x * 256 + threadIdx.x;
@@ -457,6 +475,12 @@ hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, const Po
 	if (n_groups[2])
 		hipLaunchKernelGGL(k_pose_palette<2>, dim3(n_groups[2]), dim3(64 * POSE_WAVES), 0, s, inst, groups + n_groups[0] + n_groups[1], rel_pos, rel_rot, pose_pos,
 			pose_rot, level_items, level_off, inv_pos, inv_rot, palette, dual_quats);
+	return hipGetLastError();
+}
+
+hipError_t launch_pose_blend(hipStream_t s, float* pos, float4* rot, const float* rhs_pos, const float4* rhs_rot, size_t n_bones, float weight) {
+	if (!n_bones) return hipSuccess;
+	hipLaunchKernelGGL(k_pose_blend, dim3((uint32_t)((n_bones + 255) / 256)), dim3(256), 0, s, pos, rot, rhs_pos, rhs_rot, n_bones, weight);
 	return hipGetLastError();
 }
 

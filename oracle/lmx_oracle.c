@@ -1044,6 +1044,31 @@ static rigid rigid_load(const LmxLocalRigidTransform* t) {
 	return r;
 }
 
+/* Pose::blend, renderer/pose.cpp:30-41; nlerp, core/math.cpp:677-691 */
+static quat q_nlerp(quat q1, quat q2, float t) {
+	quat res;
+	const float inv = 1.0f - t;
+	if (q1.x * q2.x + q1.y * q2.y + q1.z * q2.z + q1.w * q2.w < 0) t = -t;
+	res.x = q1.x * inv + q2.x * t;
+	res.y = q1.y * inv + q2.y * t;
+	res.z = q1.z * inv + q2.z * t;
+	res.w = q1.w * inv + q2.w * t;
+	const float l = 1 / sqrtf(res.x * res.x + res.y * res.y + res.z * res.z + res.w * res.w);
+	res.x *= l; res.y *= l; res.z *= l; res.w *= l;
+	return res;
+}
+ORC_API void orc_pose_blend(float* positions, float* rotations, const float* rhs_positions, const float* rhs_rotations, uint32_t count, float weight) {
+	if (weight <= 0.001f) return;
+	weight = weight < 0.0f ? 0.0f : (weight > 1.0f ? 1.0f : weight); /* clamp(weight, 0, 1), core/math.h */
+	const float inv = 1.0f - weight;
+	for (uint32_t i = 0; i < count; ++i) {
+		for (int k = 0; k < 3; ++k) positions[3 * i + k] = positions[3 * i + k] * inv + rhs_positions[3 * i + k] * weight;
+		const quat r = q_nlerp(q_make(rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]),
+			q_make(rhs_rotations[4 * i], rhs_rotations[4 * i + 1], rhs_rotations[4 * i + 2], rhs_rotations[4 * i + 3]), weight);
+		rotations[4 * i] = r.x; rotations[4 * i + 1] = r.y; rotations[4 * i + 2] = r.z; rotations[4 * i + 3] = r.w;
+	}
+}
+
 ORC_API void orc_invert_bind(const LmxLocalRigidTransform* bind, LmxLocalRigidTransform* out, uint32_t n) { /* model.cpp:24-30 */
 	for (uint32_t i = 0; i < n; ++i) {
 		const rigid tr = rigid_load(&bind[i]);

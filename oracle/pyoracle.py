@@ -118,6 +118,7 @@ class Oracle:
         self.f_world_bind_culling = self._fn("world_bind_culling", None, [vp, vp, u32, vp, vp])
         self.f_pose_compute_absolute = self._fn("pose_compute_absolute", None, [vp, vp, vp, i32, u32, u32, ci])
         self.f_invert_bind = self._fn("invert_bind", None, [vp, vp, u32])
+        self.f_pose_blend = self._fn("pose_blend", None, [vp, vp, vp, vp, u32, C.c_float])
         self.f_skin_matrices = self._fn("skin_matrices", None, [vp, vp, vp, vp, u32, u32, ci])
         self.f_dual_quats = self._fn("dual_quats", None, [vp, vp, vp, vp, u32, u32])
         self.f_evaluate_skin = self._fn("evaluate_skin", None, [vp, vp, vp, vp, u32, u32, u32, ci])
@@ -195,6 +196,14 @@ class Oracle:
         par = np.ascontiguousarray(parents, dtype=np.int16)
         n_inst, count = pos.shape[0], pos.shape[1]
         self.f_pose_compute_absolute(_ptr(pos), _ptr(rot), _ptr(par), int(first_nonroot), count, n_inst, n_threads)
+        return pos, rot
+
+    def pose_blend(self, positions, rotations, rhs_positions, rhs_rotations, weight):
+        """Pose::blend (pose.cpp:30-41): returns blended copies of (positions [..., 3], rotations [..., 4])."""
+        pos = np.array(positions, dtype=np.float32, order="C", copy=True)
+        rot = np.array(rotations, dtype=np.float32, order="C", copy=True)
+        rp, rr = np.ascontiguousarray(rhs_positions, np.float32), np.ascontiguousarray(rhs_rotations, np.float32)
+        self.f_pose_blend(_ptr(pos), _ptr(rot), _ptr(rp), _ptr(rr), pos.size // 3, float(weight))
         return pos, rot
 
     def invert_bind(self, bind: np.ndarray) -> np.ndarray:

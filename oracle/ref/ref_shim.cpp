@@ -676,6 +676,21 @@ void ref_world_bind_culling(void* w, void* cs, uint32_t n, const int32_t* entity
 // pose / palette / linear-blend skin
 // ---------------------------------------------------------------------------------------------------------
 // Pose::computeAbsolute scalar recurrence, renderer/pose.cpp:129-130, over `n_instances` poses laid out back to back
+// Pose::blend (renderer/pose.cpp:30-41) on the reference's own Vec3 operators, clamp and nlerp (core/math.cpp:677-691)
+void ref_pose_blend(float* positions, float* rotations, const float* rhs_positions, const float* rhs_rotations, uint32_t count, float weight) {
+	Vec3* pos = reinterpret_cast<Vec3*>(positions);
+	Quat* rot = reinterpret_cast<Quat*>(rotations);
+	const Vec3* rpos = reinterpret_cast<const Vec3*>(rhs_positions);
+	const Quat* rrot = reinterpret_cast<const Quat*>(rhs_rotations);
+	if (weight <= 0.001f) return;
+	weight = clamp(weight, 0.0f, 1.0f);
+	float inv = 1.0f - weight;
+	for (int i = 0, c = (int)count; i < c; ++i) {
+		pos[i] = pos[i] * inv + rpos[i] * weight;
+		rot[i] = nlerp(rot[i], rrot[i], weight);
+	}
+}
+
 void ref_pose_compute_absolute(float* positions, float* rotations, const int16_t* parents, int32_t first_nonroot,
 	uint32_t count, uint32_t n_instances, int n_threads) {
 	forEachJob(n_instances, n_threads, [&](u32 inst) {

@@ -99,6 +99,10 @@ def main():
         os.path.join(OUT, "attach.npz"), parent=att_parent, relative=att_rel, scale=att_scale, bone=att_bone, instance=att_inst,
         result=ref.bone_attachment(att_parent, apos[att_inst, att_bone], arot[att_inst, att_bone], att_rel, att_scale),
     )
+    # Pose::blend on the reference's own nlerp: the skin golden's relative poses blended with a second set
+    b_pos, b_rot = scenes.relative_poses(4, 64, seed=55)
+    blended = ref.pose_blend(pos, rot, b_pos, b_rot, 0.35)
+    np.savez_compressed(os.path.join(OUT, "blend.npz"), rhs_pos=b_pos, rhs_rot=b_rot, weight=np.array([0.35], np.float32), pos=blended[0], rot=blended[1])
     # ---- rows whose parity is UNPINNED (no compilable reference code, see oracle/lmx_oracle.c): regression anchors generated by
     # the restated oracle ("port"), not by reference object code. File names say so.
     port = po.Oracle("port")

@@ -209,6 +209,37 @@ def test_skin_groups_and_pose_writeback_switch(gpu_ctx, oracle_port):
     sk.setMode(False)
 
 
+def test_pose_blend_golden(gpu_ctx, oracle_port):
+    """Pose::blend (pose.cpp:30-41) of the skin golden's relative poses with a second set: bit-exact against the golden written by
+    the reference's own nlerp, and the chain into the palette stays bit-exact; thresholds (weight <= 0.001 no-op, clamp to 1)."""
+    g, gb = np.load(os.path.join(G, "skin.npz")), np.load(os.path.join(G, "blend.npz"))
+    sk = api.Skinning(gpu_ctx)
+    sk.setMode(True)
+    model = sk.addModel(g["parents"], g["bind"], int(g["first_nonroot"][0]))
+    mesh = sk.addMesh(g["verts"], g["skin"])
+    n_inst = g["rel_pos"].shape[0]
+    sk.setInstances([model] * n_inst, [mesh] * n_inst)
+    sk.uploadPoses(g["rel_pos"], g["rel_rot"])
+    sk.blendPoses(gb["rhs_pos"], gb["rhs_rot"], 0.0005)  # below the threshold: untouched
+    sk.blendPoses(gb["rhs_pos"], gb["rhs_rot"], float(gb["weight"][0]))
+    for i in range(n_inst):
+        pos, rot = sk.readRelativePose(i)
+        assert H.bits_equal(pos, gb["pos"][i]) and H.bits_equal(rot, gb["rot"][i])
+    sk.run()
+    apos, arot = oracle_port.pose_compute_absolute(gb["pos"], gb["rot"], g["parents"], int(g["first_nonroot"][0]))
+    pal = oracle_port.skin_matrices(apos, arot, oracle_port.invert_bind(g["bind"]))
+    for i in range(n_inst):
+        assert H.bits_equal(sk.readPalette(i), pal[i])
+    with pytest.raises(api.LumixError):
+        sk.blendPoses(gb["rhs_pos"], gb["rhs_rot"], 0.5)  # the poses are absolute now
+    sk.uploadPoses(g["rel_pos"], g["rel_rot"])
+    sk.blendPoses(gb["rhs_pos"], gb["rhs_rot"], 3.0)  # clamped to 1
+    want = oracle_port.pose_blend(g["rel_pos"], g["rel_rot"], gb["rhs_pos"], gb["rhs_rot"], 1.0)
+    pos, rot = sk.readRelativePose(2)
+    assert H.bits_equal(pos, want[0][2]) and H.bits_equal(rot, want[1][2])
+    sk.setMode(False)
+
+
 def test_bone_attachments_golden_and_subtrees(gpu_ctx, oracle_port):
     """updateBoneAttachment for 64 attachments at once (render_module.cpp:377-404): attached roots against the golden from the
     reference's object code, their children against the oracle's compose, bit for bit; the pose is the skin golden's."""

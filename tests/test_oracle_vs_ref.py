@@ -127,6 +127,22 @@ def test_compose_and_compute_local_bit_exact(oracle_port, oracle_ref):
     assert H.transforms_bits_equal(oracle_port.compute_local(a, b), oracle_ref.compute_local(a, b))
 
 
+@pytest.mark.parametrize("weight", [0.0005, 0.3, 0.9999, 1.7])
+def test_pose_blend_bit_exact(oracle_port, oracle_ref, weight):
+    """Pose::blend (pose.cpp:30-41) on the reference's own Vec3 operators and nlerp (math.cpp:677-691)."""
+    rng = np.random.default_rng(29)
+    n = 3000
+    pos, rpos = rng.uniform(-2, 2, size=(n, 3)).astype(np.float32), rng.uniform(-2, 2, size=(n, 3)).astype(np.float32)
+    rot, rrot = scenes.random_unit_quats(rng, n), scenes.random_unit_quats(rng, n)
+    a, b = oracle_port.pose_blend(pos, rot, rpos, rrot, weight), oracle_ref.pose_blend(pos, rot, rpos, rrot, weight)
+    assert H.bits_equal(a[0], b[0]) and H.bits_equal(a[1], b[1])
+    if weight <= 0.001:
+        assert H.bits_equal(a[0], pos) and H.bits_equal(a[1], rot)  # below the threshold nothing changes
+    else:
+        assert not H.bits_equal(a[1], rot)
+        assert ((rot * rrot).sum(axis=1) < 0).any()  # the short-way-round branch of nlerp is exercised
+
+
 def test_bone_attachment_bit_exact(oracle_port, oracle_ref):
     """updateBoneAttachment (render_module.cpp:396-402) on the reference's own LocalRigidTransform::operator* / Transform::compose."""
     rng = np.random.default_rng(19)
