@@ -353,17 +353,29 @@ def extras(ctx, api, scenes, torch, timed, N, log):
 
     # createSortKeys straight from the device-resident visible list: LOD selection + sort keys +
     # auto-instancer groups for every visible entity of the dense scene; the list never leaves HBM
-    ks = scenes.keys_scene(N, sc["type"], seed=12, max_sort_key=4095)
+    # two material populations: 256 distinct mesh sort keys (a scene built from a few hundred mesh / material pairs: the
+    # per-wave aggregation of the instancer atomics works) and 4096 uniformly random ones (its worst case: almost every lane
+    # of a wave holds a different key and the 16 KB of group counters take ~1.5 M atomics per million visible entities)
     sk = api.SortKeys(ctx)
-    sk.setModels(ks["models"], ks["mesh_types"])
-    sk.setInstances(ks["model"], ks["material_offset"], ks["mesh_materials"], ks["lod"], ks["flags"], ks["dirty"], ks["pose_frame"])
-    sk.setPositions(sc["pos"])
     frame_no = [100]
-    for name, frustum, visible in (("keys", fr, vis), ("keys_all_visible", big, vis_all)):
+    cases = []
+    for max_key in (255, 4095):
+        ks = scenes.keys_scene(N, sc["type"], seed=12, max_sort_key=max_key)
+        tag = "keys" if max_key == 255 else "keys_4096_random_sort_keys"
+        cases.append((tag, fr, vis, ks, max_key))
+        if max_key == 255:
+            cases.append(("keys_all_visible", big, vis_all, ks, max_key))
+    current = [None]
+    for name, frustum, visible, ks, max_key in cases:
+        if current[0] is not ks:
+            sk.setModels(ks["models"], ks["mesh_types"])
+            sk.setInstances(ks["model"], ks["material_offset"], ks["mesh_materials"], ks["lod"], ks["flags"], ks["dirty"], ks["pose_frame"])
+            sk.setPositions(sc["pos"])
+            current[0] = ks
         def cull_keys():
             frame_no[0] += 1
             cs.cull(frustum)
-            sk.run(api.keys_view(layer_to_bucket=ks["layer_to_bucket"], bucket_depth_sorted=ks["bucket_depth_sorted"], frame_number=frame_no[0]), 4095)
+            sk.run(api.keys_view(layer_to_bucket=ks["layer_to_bucket"], bucket_depth_sorted=ks["bucket_depth_sorted"], frame_number=frame_no[0]), max_key)
         for _ in range(3):
             cull_keys()
         ms_k = timed(cull_keys, 20)
@@ -380,7 +392,7 @@ def extras(ctx, api, scenes, torch, timed, N, log):
         out[name + "_kernels_ms"] = k_ms
         out[name + "_visible_per_sec"] = visible / (k_ms * 1e-3) if k_ms else None
         out[name + "_counts"] = cnt
-    del cs, sk, ks
+    del cs, sk, ks, cases
 
     # config 5 flavour on one GPU: mixed renderable types, 8 ortho cascade frusta tested in ONE pass over the spheres
     sc = scenes.cull_scene(N, 15000.0, seed=4, mixed_types=True)

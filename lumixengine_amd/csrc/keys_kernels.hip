@@ -77,6 +77,7 @@ __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const Ke
 	__syncthreads();
 	const uint32_t n = *n_visible;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t copy = blockIdx.x & (d.n_copies - 1); // this block's private row of the group counters
 	for (uint32_t tile = blockIdx.x * KEYS_BLOCK; tile < n; tile += gridDim.x * KEYS_BLOCK) {
 		const uint32_t i = tile + threadIdx.x;
 		// ranges of mesh indices this lane emits keys for: [from0, to0] then [from1, to1]
@@ -202,13 +203,13 @@ __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const Ke
 					++pair_at;
 				}
 				if (add_inst) {
-					if (rec_at < d.cap_recs) { d.rec_key[rec_at] = mesh_sort_key; d.rec_value[rec_at] = value; } else d.counters[KEYS_OVERFLOW] = 1;
+					if (rec_at < d.cap_recs) { d.rec_key[rec_at] = mesh_sort_key | (copy << 24); d.rec_value[rec_at] = value; } else d.counters[KEYS_OVERFLOW] = 1;
 					++rec_at;
 				}
 			}
 			const bool in_range = add_inst && mesh_sort_key <= d.max_sort_key;
 			if (add_inst && !in_range) d.counters[KEYS_OVERFLOW] = 2; // a mesh sort key above Renderer::getMaxSortKey(): the reference indexes out of bounds
-			wave_histogram(in_range, mesh_sort_key, d.group_count);
+			wave_histogram(in_range, mesh_sort_key, d.group_count + (size_t)copy * (d.max_sort_key + 1));
 		}
 	}
 }
@@ -235,7 +236,8 @@ __global__ __launch_bounds__(256) void k_keys_decal(KeysDevice d, const KeysView
 	if (push) { if (idx < d.cap_pairs) { d.keys[idx] = key; d.values[idx] = value; } else d.counters[KEYS_OVERFLOW] = 1; }
 }
 
-// one block: offsets[k] = sum of group_count[0..k), offsets[n_groups] = total; cursor[] zeroed; non-empty groups counted
+// one block: total[k] = sum over the copies of group_count[c][k]; group_count[c][k] becomes copy c's base inside group k (exclusive
+// prefix over the copies); offsets[k] = sum of total[0..k), offsets[n] = grand total; cursors zeroed; non-empty groups counted
 __global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
 	__shared__ uint32_t s_wave[16];
 	__shared__ uint32_t s_carry;
@@ -246,7 +248,17 @@ __global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
 	uint32_t non_empty = 0;
 	for (uint32_t base = 0; base < n; base += 1024) {
 		const uint32_t k = base + tid;
-		const uint32_t c = k < n ? d.group_count[k] : 0;
+		uint32_t c = 0;
+		if (k < n) {
+			for (uint32_t cp = 0; cp < d.n_copies; ++cp) {
+				const size_t at = (size_t)cp * n + k;
+				const uint32_t v = d.group_count[at];
+				d.group_count[at] = c;
+				d.group_cursor[at] = 0;
+				c += v;
+			}
+			d.group_total[k] = c;
+		}
 		non_empty += c != 0;
 		uint32_t incl = c; // inclusive scan inside the wave
 #pragma unroll
@@ -258,14 +270,12 @@ __global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
 		__syncthreads();
 		uint32_t before = s_carry;
 		for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
-		if (k < n) { d.group_offset[k] = before + incl - c; d.group_cursor[k] = 0; }
+		if (k < n) d.group_offset[k] = before + incl - c;
 		__syncthreads();
 		if (tid == 1023) s_carry = before + incl;
 		__syncthreads();
 	}
 	if (tid == 0) d.group_offset[n] = s_carry;
-	const uint64_t any = __ballot(true);
-	(void)any;
 	uint32_t total = non_empty;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) total += (uint32_t)__shfl_down((int)total, o);
@@ -274,25 +284,28 @@ __global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
 
 __global__ __launch_bounds__(256) void k_keys_scatter(KeysDevice d) {
 	const uint32_t n = min(d.counters[KEYS_N_RECS], d.cap_recs);
+	const uint32_t stride = d.max_sort_key + 1;
 	for (uint32_t tile = blockIdx.x * 256; tile < n; tile += gridDim.x * 256) {
 		const uint32_t i = tile + threadIdx.x;
-		const bool has = i < n && d.rec_key[i] <= d.max_sort_key;
-		const uint32_t key = has ? d.rec_key[i] : 0;
-		// per distinct key of the wave: its first lane (leader), the number of lanes holding it and every lane's rank among
-		// them — ALU only; then ALL leaders reserve their cursor ranges at once (one memory round trip per wave, not one per key)
+		const uint32_t packed = i < n ? d.rec_key[i] : 0; // mesh sort key | copy << 24
+		const uint32_t key = packed & 0xffffffu;
+		const bool has = i < n && key <= d.max_sort_key;
+		// per distinct (copy, key) of the wave: its first lane (leader), the number of lanes holding it and every lane's rank among
+		// them - ALU only; then ALL leaders reserve their cursor ranges at once (one memory round trip per wave, not one per key)
 		uint64_t todo = __ballot(has);
 		uint32_t leader_of = 0, rank = 0, count = 0;
 		while (todo) {
 			const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
-			const uint32_t k = (uint32_t)__shfl((int)key, (int)leader);
-			const uint64_t same = __ballot(has && key == k) & todo;
+			const uint32_t k = (uint32_t)__shfl((int)packed, (int)leader);
+			const uint64_t same = __ballot(has && packed == k) & todo;
 			if ((same >> lane_id()) & 1ull) { leader_of = leader; rank = rank_in(same); count = (uint32_t)__popcll(same); }
 			todo &= ~same;
 		}
+		const size_t at = (size_t)(packed >> 24) * stride + key;
 		uint32_t base = 0;
-		if (has && leader_of == lane_id()) base = atomicAdd(d.group_cursor + key, count);
+		if (has && leader_of == lane_id()) base = atomicAdd(d.group_cursor + at, count);
 		base = (uint32_t)__shfl((int)base, (int)leader_of);
-		if (has) d.group_values[d.group_offset[key] + base + rank] = d.rec_value[i];
+		if (has) d.group_values[d.group_offset[key] + d.group_count[at] + base + rank] = d.rec_value[i];
 	}
 }
 
@@ -302,7 +315,7 @@ __global__ __launch_bounds__(256) void k_keys_groups(KeysDevice d, const KeysVie
 	if (k - (k & 63u) >= n) return;
 	bool push = false;
 	uint64_t key = 0, value = 0;
-	if (k < n && d.group_count[k] != 0) { // :3958-3968, instancer index 0
+	if (k < n && d.group_total[k] != 0) { // :3958-3968, instancer index 0
 		const uint64_t renderable = d.group_values[d.group_offset[k]]; // instances[i].begin->renderables[0]: any member, they share the material
 		const uint32_t entity_index = (uint32_t)(renderable & 0xffFFffull);
 		const uint32_t mesh_idx = (uint32_t)(renderable >> LMX_SORT_VALUE_MESH_IDX_SHIFT);

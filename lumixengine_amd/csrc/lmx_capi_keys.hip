@@ -166,14 +166,18 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	LMX_HIP(ctx, ks.d_rec_key.reserve(std::max<size_t>(cap_recs, 1)));
 	LMX_HIP(ctx, ks.d_rec_value.reserve(std::max<size_t>(cap_recs, 1)));
 	LMX_HIP(ctx, ks.d_group_values.reserve(std::max<size_t>(cap_recs, 1)));
-	LMX_HIP(ctx, ks.d_groups.reserve((size_t)(max_sort_key + 2) * 3));
+	// privatised group counters: as many copies as keep the table under 256 k entries (64 for <= 4096 keys, 1 for > 128 k)
+	uint32_t n_copies = 64;
+	while (n_copies > 1 && (uint64_t)n_copies * (max_sort_key + 1) > 262144) n_copies >>= 1;
+	const size_t g = (size_t)max_sort_key + 1;
+	LMX_HIP(ctx, ks.d_groups.reserve(2 * n_copies * g + g + g + 1));
 	LMX_HIP(ctx, ks.d_poses.reserve(std::max<size_t>(mesh_cap, 1)));
 	LMX_HIP(ctx, ks.d_dirty_list.reserve(std::max<size_t>(mesh_cap, 1)));
 	LMX_HIP(ctx, ks.d_counters.reserve(KEYS_COUNTERS));
 
 	ProfScope ps(ctx, LMX_K_SORT_KEYS);
 	LMX_HIP(ctx, hipMemsetAsync(ks.d_counters.p, 0, KEYS_COUNTERS * sizeof(uint32_t), ctx->stream));
-	LMX_HIP(ctx, hipMemsetAsync(ks.d_groups.p, 0, (size_t)(max_sort_key + 1) * sizeof(uint32_t), ctx->stream));
+	LMX_HIP(ctx, hipMemsetAsync(ks.d_groups.p, 0, n_copies * g * sizeof(uint32_t), ctx->stream));
 	KeysDevice d;
 	memset(&d, 0, sizeof(d));
 	d.n_entities = ks.n_entities;
@@ -192,7 +196,9 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	d.keys = ks.d_keys.p; d.values = ks.d_values.p; d.cap_pairs = (uint32_t)cap_pairs;
 	d.rec_key = ks.d_rec_key.p; d.rec_value = ks.d_rec_value.p; d.cap_recs = (uint32_t)cap_recs;
 	d.max_sort_key = max_sort_key;
-	d.group_count = ks.d_groups.p; d.group_offset = ks.d_groups.p + (max_sort_key + 2); d.group_cursor = ks.d_groups.p + 2 * (size_t)(max_sort_key + 2);
+	d.n_copies = n_copies;
+	d.group_count = ks.d_groups.p; d.group_cursor = ks.d_groups.p + n_copies * g; d.group_total = ks.d_groups.p + 2 * n_copies * g; d.group_offset = d.group_total + g;
+	ks.offsets_at = 2 * n_copies * g + g;
 	d.group_values = ks.d_group_values.p;
 	d.poses = ks.d_poses.p; d.dirty_list = ks.d_dirty_list.p; d.cap_list = mesh_cap;
 	d.counters = ks.d_counters.p;
@@ -268,7 +274,7 @@ int lmx_keys_read_instancer(LmxContext* ctx, uint32_t* offsets, uint64_t* values
 	if (c[KEYS_OVERFLOW]) return fail(ctx, LMX_ERR_CAPACITY, "sort-key output overflowed (code %u)", c[KEYS_OVERFLOW]);
 	const uint32_t n = c[KEYS_N_RECS];
 	if (values && cap_values < n) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u instanced renderables", n);
-	if (offsets) LMX_HIP(ctx, hipMemcpyAsync(offsets, ks.d_groups.p + (ks.max_sort_key + 2), (size_t)(ks.max_sort_key + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	if (offsets) LMX_HIP(ctx, hipMemcpyAsync(offsets, ks.d_groups.p + ks.offsets_at, (size_t)(ks.max_sort_key + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	if (values && n) LMX_HIP(ctx, hipMemcpyAsync(values, ks.d_group_values.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return LMX_OK;

@@ -208,6 +208,7 @@ struct KeysState {
 	std::vector<uint8_t> mesh_types;
 	uint32_t n_meshes = 0, max_lod_span = 1;
 	uint32_t n_entities = 0, n_positions = 0, max_sort_key = 0;
+	size_t offsets_at = 0; // where the CSR offsets of the last run start inside d_groups
 	bool have_instances = false, have_decals = false, have_curves = false, use_world = false, ran = false, sorted = false;
 	DevBuf<LmxKeysModel> d_models;
 	DevBuf<uint8_t> d_mesh_types;

@@ -178,7 +178,14 @@ struct KeysDevice {
 	uint64_t* rec_value;
 	uint32_t cap_recs;
 	uint32_t max_sort_key;
-	uint32_t *group_count, *group_offset, *group_cursor; // [max_sort_key + 1], [+ 2], [+ 1]
+	// auto-instancer groups. The per-key counters are PRIVATISED: copy c (= block index mod n_copies) has its own count / cursor
+	// row, so the atomics of a scene with few distinct mesh sort keys (all of them on a handful of cache lines) spread over
+	// n_copies times as many lines. A record remembers its copy in bits 24..29 of rec_key.
+	uint32_t n_copies;         // power of two, <= 64
+	uint32_t *group_count;     // [n_copies][max_sort_key + 1]: per-copy sizes, turned into per-copy bases by k_keys_offsets
+	uint32_t *group_cursor;    // [n_copies][max_sort_key + 1]
+	uint32_t *group_total;     // [max_sort_key + 1]
+	uint32_t *group_offset;    // [max_sort_key + 2]
 	uint64_t* group_values;
 	int32_t *poses, *dirty_list;
 	uint32_t cap_list;
