@@ -257,7 +257,8 @@ LMX_API int lmx_keys_set_instances(LmxContext* ctx, uint32_t n_entities, const i
 /* Decal / curve-decal materials by entity index: Material::getSortKey() and getLayer() (pipeline.cpp:83-89). */
 LMX_API int lmx_keys_set_decals(LmxContext* ctx, uint32_t n_entities, const uint32_t* decal_sort_key, const uint8_t* decal_layer,
 	const uint32_t* curve_sort_key, const uint8_t* curve_layer);
-/* World::getTransforms()[e].pos by entity index, from the host ... */
+/* World::getTransforms()[e].pos by entity index, from the host (may be called every frame: ModelInstance::lod and Pose::frame keep
+ * the state the device advanced; lmx_keys_set_instances resets them to the uploaded values) ... */
 LMX_API int lmx_keys_set_positions(LmxContext* ctx, const double* xyz, uint32_t n_entities);
 /* ... or read in place from the world hierarchy of this context (after lmx_world_propagate); 0 = back to the uploaded array. */
 LMX_API int lmx_keys_bind_world(LmxContext* ctx, int enable);

@@ -47,15 +47,6 @@ __device__ __forceinline__ void wave_histogram(bool want, uint32_t key, uint32_t
 	}
 }
 
-__device__ __forceinline__ void load_pos(const KeysDevice& d, uint32_t e, double* x, double* y, double* z) {
-	if (d.slot_of_entity != nullptr) { // World::getTransforms()[e].pos out of the hierarchy's SoA
-		const int32_t s = d.slot_of_entity[e];
-		*x = d.wpx[s]; *y = d.wpy[s]; *z = d.wpz[s];
-	} else {
-		*x = d.pos_xyz[3 * (size_t)e]; *y = d.pos_xyz[3 * (size_t)e + 1]; *z = d.pos_xyz[3 * (size_t)e + 2];
-	}
-}
-
 // floatFlip, pipeline.cpp:57-60
 __device__ __forceinline__ uint32_t float_flip(uint32_t bits) {
 	const uint32_t mask = (uint32_t)(-(int32_t)(bits >> 31)) | 0x80000000u;
@@ -82,15 +73,22 @@ __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const Ke
 		const uint32_t i = tile + threadIdx.x;
 		// ranges of mesh indices this lane emits keys for: [from0, to0] then [from1, to1]
 		int32_t from0 = 0, to0 = -1, from1 = 0, to1 = -1;
-		uint32_t e = 0, mat0 = 0;
+		uint32_t e = 0, mat0 = 0, pose_stamp = 0;
 		bool moved = false, queue_dirty = false;
 		double px = 0, py = 0, pz = 0;
 		if (i < n) {
 			e = (uint32_t)ids[i];
-			const int32_t mdl = e < d.n_entities ? d.model[e] : -1;
+			KeysInstance in;
+			in.model = -1;
+			if (e < d.n_entities) in = d.inst[e]; // one 64-byte record
+			const int32_t mdl = in.model;
 			if (mdl >= 0) {
 				const LmxKeysModel& m = d.models[mdl];
-				load_pos(d, e, &px, &py, &pz);
+				px = in.pos[0]; py = in.pos[1]; pz = in.pos[2];
+				if (d.slot_of_entity != nullptr) { // World::getTransforms()[e].pos out of the hierarchy's SoA
+					const int32_t sl = d.slot_of_entity[e];
+					px = d.wpx[sl]; py = d.wpy[sl]; pz = d.wpz[sl];
+				}
 				const double rx = px - kv.ref[0], ry = py - kv.ref[1], rz = pz - kv.ref[2];
 				const float squared_length = (float)(rx * rx + ry * ry + rz * rz); // float(squaredLength(pos - lod_ref_point)), math.cpp:397
 				const float sd = squared_length * kv.lod_multiplier_rcp;
@@ -99,20 +97,21 @@ __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const Ke
 				else if (sd < m.lod_distances[1]) lod_idx = 1;
 				else if (sd < m.lod_distances[2]) lod_idx = 2;
 				else if (sd < m.lod_distances[3]) lod_idx = 3;
-				if (d.dirty[e]) {
+				if (in.dirty) {
 					queue_dirty = true; // queueMaterialOverrideRefresh(e); continue;  (:3879-3882)
 				} else {
-					mat0 = d.material_offset[e];
-					moved = (d.flags[e] & LMX_MODEL_INSTANCE_MOVED) != 0;
-					float lod = d.lod[e];
+					mat0 = in.material_offset;
+					moved = (in.flags & LMX_MODEL_INSTANCE_MOVED) != 0;
+					pose_stamp = in.pose_frame;
+					float lod = in.lod;
 					if (lod != (float)lod_idx) { // :3937-3952
 						const float dl = (float)lod_idx - lod;
 						const float ad = fabsf(dl);
 						if (ad <= kv.time_delta) {
-							d.lod[e] = (float)lod_idx;
+							d.inst[e].lod = (float)lod_idx;
 							from0 = m.lod_indices[lod_idx].from; to0 = m.lod_indices[lod_idx].to;
 						} else {
-							if (!kv.is_shadow) { lod = lod + dl / ad * kv.time_delta; d.lod[e] = lod; }
+							if (!kv.is_shadow) { lod = lod + dl / ad * kv.time_delta; d.inst[e].lod = lod; }
 							const uint32_t cur = (uint32_t)lod;
 							from0 = m.lod_indices[cur].from; to0 = m.lod_indices[cur].to;
 							if (cur < 3) { from1 = m.lod_indices[cur + 1].from; to1 = m.lod_indices[cur + 1].to; }
@@ -133,7 +132,10 @@ __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const Ke
 			const uint32_t bucket = s_bucket[mm.layer];
 			if (mm._pad[0] == LMX_MESH_SKINNED) {
 				// Pose::frame stamp (:3889-3898): exactly one visit per frame hands the instance to the pose processor
-				if (!push_pose && d.pose_frame[e] != kv.frame_number) push_pose = atomicExch(d.pose_frame + e, kv.frame_number) != kv.frame_number;
+				if (!push_pose && pose_stamp != kv.frame_number) {
+					push_pose = atomicExch(&d.inst[e].pose_frame, kv.frame_number) != kv.frame_number;
+					pose_stamp = kv.frame_number;
+				}
 				++n_pairs;
 			} else if (moved && !kv.is_shadow) ++n_pairs;
 			else if (bucket < 0xffu) ++n_recs;
@@ -209,7 +211,14 @@ __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const Ke
 			}
 			const bool in_range = add_inst && mesh_sort_key <= d.max_sort_key;
 			if (add_inst && !in_range) d.counters[KEYS_OVERFLOW] = 2; // a mesh sort key above Renderer::getMaxSortKey(): the reference indexes out of bounds
-			wave_histogram(in_range, mesh_sort_key, d.group_count + (size_t)copy * (d.max_sort_key + 1));
+			// with many private copies the counters are spread thinly enough for one atomic per lane; the per-wave de-duplication
+			// (one atomic per distinct key, ~15 scalar + vector instructions per key: 60 % of this kernel's time at 256 live keys)
+			// is kept for key ranges too large to privatise
+			if (d.n_copies >= 8) {
+				if (in_range) atomicAdd(d.group_count + (size_t)copy * (d.max_sort_key + 1) + mesh_sort_key, 1u);
+			} else {
+				wave_histogram(in_range, mesh_sort_key, d.group_count + (size_t)copy * (d.max_sort_key + 1));
+			}
 		}
 	}
 }
@@ -292,6 +301,11 @@ __global__ __launch_bounds__(256) void k_keys_scatter(KeysDevice d) {
 		const bool has = i < n && key <= d.max_sort_key;
 		// per distinct (copy, key) of the wave: its first lane (leader), the number of lanes holding it and every lane's rank among
 		// them - ALU only; then ALL leaders reserve their cursor ranges at once (one memory round trip per wave, not one per key)
+		const size_t at = (size_t)(packed >> 24) * stride + key;
+		if (d.n_copies >= 8) { // privatised cursors: one returning atomic per lane, all in flight together
+			if (has) d.group_values[d.group_offset[key] + d.group_count[at] + atomicAdd(d.group_cursor + at, 1u)] = d.rec_value[i];
+			continue;
+		}
 		uint64_t todo = __ballot(has);
 		uint32_t leader_of = 0, rank = 0, count = 0;
 		while (todo) {
@@ -301,7 +315,6 @@ __global__ __launch_bounds__(256) void k_keys_scatter(KeysDevice d) {
 			if ((same >> lane_id()) & 1ull) { leader_of = leader; rank = rank_in(same); count = (uint32_t)__popcll(same); }
 			todo &= ~same;
 		}
-		const size_t at = (size_t)(packed >> 24) * stride + key;
 		uint32_t base = 0;
 		if (has && leader_of == lane_id()) base = atomicAdd(d.group_cursor + at, count);
 		base = (uint32_t)__shfl((int)base, (int)leader_of);
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(256) void k_keys_groups(KeysDevice d, const KeysVie
 		const uint64_t renderable = d.group_values[d.group_offset[k]]; // instances[i].begin->renderables[0]: any member, they share the material
 		const uint32_t entity_index = (uint32_t)(renderable & 0xffFFffull);
 		const uint32_t mesh_idx = (uint32_t)(renderable >> LMX_SORT_VALUE_MESH_IDX_SHIFT);
-		const uint8_t layer = d.mesh_materials[d.material_offset[entity_index] + mesh_idx].layer;
+		const uint8_t layer = d.mesh_materials[d.inst[entity_index].material_offset + mesh_idx].layer;
 		const uint8_t bucket = kv.layer_to_bucket[layer];
 		value = (uint64_t)k | ((uint64_t)LMX_DRAW_AUTOINSTANCED << LMX_SORT_VALUE_TYPE_SHIFT);               // makeAutoInstancedSortValue(i, 0)
 		key = (uint64_t)k | LMX_SORT_KEY_INSTANCED_FLAG | ((uint64_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT);  // makeAutoInstancedSortKey(i, bucket)
@@ -335,7 +348,7 @@ hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice&
 	uint32_t mesh_cap, const int32_t* decal_ids, const uint32_t* decal_count, uint32_t decal_cap, const int32_t* curve_ids,
 	const uint32_t* curve_count, uint32_t curve_cap) {
 	const uint32_t grid_cap = 256 * 8; // fixed-size grids walk the lists in tiles: the counts live on the device
-	if (mesh_cap && d.model != nullptr)
+	if (mesh_cap && d.inst != nullptr)
 		hipLaunchKernelGGL(k_keys_mesh, dim3(std::min((mesh_cap + KEYS_BLOCK - 1) / KEYS_BLOCK, grid_cap)), dim3(KEYS_BLOCK), 0, s, d, view, mesh_ids, mesh_count);
 	if (decal_cap && d.decal_sort_key != nullptr)
 		hipLaunchKernelGGL(k_keys_decal, dim3((decal_cap + 255) / 256), dim3(256), 0, s, d, view, decal_ids, decal_count, d.decal_sort_key, d.decal_layer,

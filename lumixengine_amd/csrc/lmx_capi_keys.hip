@@ -2,6 +2,8 @@
 // tables, the per-view state, the launch chain of keys_kernels.hip and the read-backs.
 #include "lmx_context.h"
 
+#include <cstddef>
+
 #include <hipcub/hipcub.hpp>
 
 using namespace lmx;
@@ -68,14 +70,16 @@ int lmx_keys_set_instances(LmxContext* ctx, uint32_t n_entities, const int32_t* 
 		for (uint32_t k = 0; k < m.mesh_count; ++k) dev_mm[material_offset[e] + k]._pad[0] = ks.mesh_types[m.first_mesh + k];
 	}
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (int rc = upload(ctx, ks.d_model, model, n_entities)) return rc;
-	if (int rc = upload(ctx, ks.d_material_offset, material_offset, n_entities)) return rc;
 	if (int rc = upload(ctx, ks.d_mesh_materials, dev_mm.data(), n_mesh_materials)) return rc;
-	if (int rc = upload(ctx, ks.d_lod, lod, n_entities)) return rc;
-	if (int rc = upload(ctx, ks.d_flags, flags, n_entities)) return rc;
-	if (int rc = upload(ctx, ks.d_dirty, dirty, n_entities)) return rc;
-	if (int rc = upload(ctx, ks.d_pose_frame, pose_frame, n_entities)) return rc;
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	// one 64-byte record per entity (positions of an earlier lmx_keys_set_positions are kept)
+	ks.inst.resize(n_entities);
+	for (uint32_t e = 0; e < n_entities; ++e) {
+		KeysInstance& r = ks.inst[e];
+		r.model = model[e]; r.material_offset = material_offset[e]; r.lod = lod[e]; r.pose_frame = pose_frame[e]; r.flags = flags[e]; r.dirty = dirty[e];
+		memset(r.pad, 0, sizeof(r.pad));
+	}
+	ks.inst_dirty = true;
 	if (n_entities != ks.n_entities) ks.have_decals = ks.have_curves = false; // decal tables of another entity range are dropped
 	ks.n_entities = n_entities;
 	ks.have_instances = true;
@@ -109,9 +113,21 @@ int lmx_keys_set_positions(LmxContext* ctx, const double* xyz, uint32_t n_entiti
 	LMX_CHECK_CTX(ctx);
 	if (n_entities && !xyz) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null positions");
 	KeysState& ks = ctx->keys;
-	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (int rc = upload(ctx, ks.d_pos, xyz, (size_t)n_entities * 3)) return rc;
-	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (ks.inst.size() < n_entities) {
+		const size_t old_n = ks.inst.size();
+		ks.inst.resize(n_entities);
+		for (size_t e = old_n; e < n_entities; ++e) { memset(&ks.inst[e], 0, sizeof(KeysInstance)); ks.inst[e].model = -1; }
+	}
+	for (uint32_t e = 0; e < n_entities; ++e) memcpy(ks.inst[e].pos, xyz + 3 * (size_t)e, sizeof(double) * 3);
+	if (!ks.inst_dirty && ks.d_inst.p && ks.d_inst.cap >= ks.inst.size() && ks.inst.size() == ks.inst_uploaded) {
+		// the records are on the device already: only the positions are replaced (24 of every 64 bytes), ModelInstance::lod and
+		// Pose::frame keep the state the kernels advanced
+		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		LMX_HIP(ctx, hipMemcpy2D(reinterpret_cast<char*>(ks.d_inst.p) + offsetof(KeysInstance, pos), sizeof(KeysInstance), xyz, sizeof(double) * 3, sizeof(double) * 3, n_entities,
+			hipMemcpyHostToDevice));
+	} else {
+		ks.inst_dirty = true;
+	}
 	ks.n_positions = n_entities;
 	return LMX_OK;
 }
@@ -175,6 +191,13 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	LMX_HIP(ctx, ks.d_dirty_list.reserve(std::max<size_t>(mesh_cap, 1)));
 	LMX_HIP(ctx, ks.d_counters.reserve(KEYS_COUNTERS));
 
+	if (ks.inst_dirty) { // the host mirror changed (tables or positions): lod / Pose::frame restart from the uploaded values
+		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (int rc = upload(ctx, ks.d_inst, ks.inst.data(), ks.inst.size())) return rc;
+		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		ks.inst_dirty = false;
+		ks.inst_uploaded = ks.inst.size();
+	}
 	ProfScope ps(ctx, LMX_K_SORT_KEYS);
 	LMX_HIP(ctx, hipMemsetAsync(ks.d_counters.p, 0, KEYS_COUNTERS * sizeof(uint32_t), ctx->stream));
 	LMX_HIP(ctx, hipMemsetAsync(ks.d_groups.p, 0, n_copies * g * sizeof(uint32_t), ctx->stream));
@@ -182,16 +205,15 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	memset(&d, 0, sizeof(d));
 	d.n_entities = ks.n_entities;
 	if (ks.have_instances) {
-		d.model = ks.d_model.p; d.material_offset = ks.d_material_offset.p; d.mesh_materials = ks.d_mesh_materials.p; d.models = ks.d_models.p;
-		d.mesh_types = ks.d_mesh_types.p; d.lod = ks.d_lod.p; d.flags = ks.d_flags.p; d.dirty = ks.d_dirty.p; d.pose_frame = ks.d_pose_frame.p;
+		d.inst = ks.d_inst.p;
+		d.mesh_materials = ks.d_mesh_materials.p;
+		d.models = ks.d_models.p;
 	}
 	if (ks.have_decals) { d.decal_sort_key = ks.d_decal_key.p; d.decal_layer = ks.d_decal_layer.p; }
 	if (ks.have_curves) { d.curve_sort_key = ks.d_curve_key.p; d.curve_layer = ks.d_curve_layer.p; }
 	if (ks.use_world) {
 		d.wpx = ctx->world.pos[3].p; d.wpy = ctx->world.pos[4].p; d.wpz = ctx->world.pos[5].p;
 		d.slot_of_entity = ctx->world.d_slot_of_entity.p;
-	} else {
-		d.pos_xyz = ks.d_pos.p;
 	}
 	d.keys = ks.d_keys.p; d.values = ks.d_values.p; d.cap_pairs = (uint32_t)cap_pairs;
 	d.rec_key = ks.d_rec_key.p; d.rec_value = ks.d_rec_value.p; d.cap_recs = (uint32_t)cap_recs;
@@ -306,8 +328,13 @@ int lmx_keys_read_state(LmxContext* ctx, float* lod, uint32_t* pose_frame, uint3
 	KeysState& ks = ctx->keys;
 	if (!ks.have_instances) return fail(ctx, LMX_ERR_NOT_BUILT, "no instance tables uploaded");
 	if (n_entities != ks.n_entities) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "expected %u entities", ks.n_entities);
-	if (lod && n_entities) LMX_HIP(ctx, hipMemcpyAsync(lod, ks.d_lod.p, (size_t)n_entities * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-	if (pose_frame && n_entities) LMX_HIP(ctx, hipMemcpyAsync(pose_frame, ks.d_pose_frame.p, (size_t)n_entities * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	if (ks.inst_dirty) return fail(ctx, LMX_ERR_NOT_BUILT, "tables changed since the last lmx_keys_run");
+	const char* base = reinterpret_cast<const char*>(ks.d_inst.p);
+	if (lod && n_entities)
+		LMX_HIP(ctx, hipMemcpy2DAsync(lod, sizeof(float), base + offsetof(KeysInstance, lod), sizeof(KeysInstance), sizeof(float), n_entities, hipMemcpyDeviceToHost, ctx->stream));
+	if (pose_frame && n_entities)
+		LMX_HIP(ctx, hipMemcpy2DAsync(pose_frame, sizeof(uint32_t), base + offsetof(KeysInstance, pose_frame), sizeof(KeysInstance), sizeof(uint32_t), n_entities, hipMemcpyDeviceToHost,
+			ctx->stream));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return LMX_OK;
 }

@@ -212,15 +212,13 @@ struct KeysState {
 	bool have_instances = false, have_decals = false, have_curves = false, use_world = false, ran = false, sorted = false;
 	DevBuf<LmxKeysModel> d_models;
 	DevBuf<uint8_t> d_mesh_types;
-	DevBuf<int32_t> d_model;
-	DevBuf<uint32_t> d_material_offset;
+	std::vector<KeysInstance> inst; // host mirror of the per-entity records (tables + positions), uploaded when it changes
+	bool inst_dirty = false;
+	size_t inst_uploaded = 0; // records on the device
+	DevBuf<KeysInstance> d_inst;
 	DevBuf<LmxMeshMaterial> d_mesh_materials;
-	DevBuf<float> d_lod;
-	DevBuf<uint8_t> d_flags, d_dirty;
-	DevBuf<uint32_t> d_pose_frame;
 	DevBuf<uint32_t> d_decal_key, d_curve_key;
 	DevBuf<uint8_t> d_decal_layer, d_curve_layer;
-	DevBuf<double> d_pos;
 	DevBuf<uint64_t> d_keys, d_values, d_keys_alt, d_values_alt, d_rec_value, d_group_values;
 	DevBuf<uint32_t> d_rec_key, d_groups, d_counters;
 	DevBuf<int32_t> d_poses, d_dirty_list;

@@ -153,22 +153,27 @@ struct KeysViewDevice { // what the kernels read of a LmxKeysView, bucket_map as
 	float lod_multiplier_rcp, time_delta;
 	uint32_t frame_number;
 };
+// ModelInstance {model, mesh_materials, lod, flags, dirty, pose->frame} + World::getTransforms()[e].pos, one cache-line-friendly record
+struct alignas(64) KeysInstance {
+	double pos[3];
+	int32_t model;            // -1: the entity has no model instance
+	uint32_t material_offset;
+	float lod;
+	uint32_t pose_frame;
+	uint8_t flags, dirty;
+	uint8_t pad[22];
+};
+static_assert(sizeof(KeysInstance) == 64, "one record per 64-byte sector");
 struct KeysDevice {
-	// model instances by entity index, models, materials
+	// model instances by entity index: ONE 64-byte record per entity (the visible ids are in cell order, entity indices are not:
+	// seven separate per-entity arrays meant seven random 128-byte lines per visible entity and made the kernel traffic-bound)
 	uint32_t n_entities;
-	const int32_t* model;
-	const uint32_t* material_offset;
+	KeysInstance* inst;       // lod and pose_frame are updated in place
 	const LmxMeshMaterial* mesh_materials;
 	const LmxKeysModel* models;
-	const uint8_t* mesh_types;
-	float* lod;               // ModelInstance::lod, updated in place
-	const uint8_t* flags;
-	const uint8_t* dirty;
-	uint32_t* pose_frame;     // Pose::frame, updated in place
 	const uint32_t *decal_sort_key, *curve_sort_key;
 	const uint8_t *decal_layer, *curve_layer;
-	// positions: entity-indexed xyz, or the world hierarchy's SoA through slot_of_entity
-	const double* pos_xyz;
+	// positions: KeysInstance::pos, or the world hierarchy's SoA through slot_of_entity when bound
 	const double *wpx, *wpy, *wpz;
 	const int32_t* slot_of_entity;
 	// outputs

@@ -213,6 +213,8 @@ def test_gpu_sort_keys_match_oracle(gpu_ctx, oracle_port, vi):
     sk.setPositions(pos)
     lod, pose_frame = sc["lod"], sc["pose_frame"]
     for frame in range(2):
+        if frame == 1:
+            sk.setPositions(pos)  # per-frame position refresh: ModelInstance::lod / Pose::frame must keep the state of frame 0
         view = dict(VIEWS[vi])
         view["frame_number"] += frame
         kv = api.keys_view(layer_to_bucket=sc["layer_to_bucket"], bucket_depth_sorted=sc["bucket_depth_sorted"], **view)

@@ -32,14 +32,14 @@ def main():
         cs = api.CullingSystem(ctx)
         cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
         fr = api.viewport_frustum()
-        ks = scenes.keys_scene(args.entities, sc["type"], seed=12, max_sort_key=4095)
+        ks = scenes.keys_scene(args.entities, sc["type"], seed=12, max_sort_key=255)
         sk = api.SortKeys(ctx)
         sk.setModels(ks["models"], ks["mesh_types"])
         sk.setInstances(ks["model"], ks["material_offset"], ks["mesh_materials"], ks["lod"], ks["flags"], ks["dirty"], ks["pose_frame"])
         sk.setPositions(sc["pos"])
         for f in range(args.steps):
             cs.cull(fr)
-            sk.run(api.keys_view(layer_to_bucket=ks["layer_to_bucket"], bucket_depth_sorted=ks["bucket_depth_sorted"], frame_number=100 + f), 4095)
+            sk.run(api.keys_view(layer_to_bucket=ks["layer_to_bucket"], bucket_depth_sorted=ks["bucket_depth_sorted"], frame_number=100 + f), 255)
         ctx.synchronize()
         print(sk.counts())
     elif args.workload.startswith("cull"):
