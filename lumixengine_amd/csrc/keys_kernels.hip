@@ -7,7 +7,7 @@
 //                    mesh lists in lockstep so that every output append is ONE atomic per wave and list (ballot + mbcnt),
 //                    not one per element: returning atomics on one address serialise at ~90 per microsecond.
 //   k_keys_decal     DECAL / CURVE_DECAL pages (:3841-3868).
-//   k_keys_offsets   exclusive scan of the auto-instancer group sizes (AutoInstancer::instances, :452-523) -> CSR offsets
+//   k_keys_reduce_copies + k_keys_offsets   per-key sum over the private counter copies, then the exclusive scan of the group sizes (AutoInstancer::instances, :452-523) -> CSR offsets
 //   k_keys_scatter   instancer records -> CSR values
 //   k_keys_groups    one AUTOINSTANCED pair per non-empty group (:3958-3968)
 // Integer work is bit-exact by construction; the two fp64 -> fp32 distances use the reference's operation order.
@@ -245,8 +245,29 @@ __global__ __launch_bounds__(256) void k_keys_decal(KeysDevice d, const KeysView
 	if (push) { if (idx < d.cap_pairs) { d.keys[idx] = key; d.values[idx] = value; } else d.counters[KEYS_OVERFLOW] = 1; }
 }
 
-// one block: total[k] = sum over the copies of group_count[c][k]; group_count[c][k] becomes copy c's base inside group k (exclusive
-// prefix over the copies); offsets[k] = sum of total[0..k), offsets[n] = grand total; cursors zeroed; non-empty groups counted
+// one wave per key: lane c holds copy c's count; total[k] = their sum, group_count[c][k] becomes copy c's base inside group k
+// (exclusive prefix over the copies), cursors zeroed
+__global__ __launch_bounds__(256) void k_keys_reduce_copies(KeysDevice d) {
+	const uint32_t n = d.max_sort_key + 1;
+	const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63u;
+	if (k >= n) return;
+	const size_t at = (size_t)lane * n + k;
+	const uint32_t v = lane < d.n_copies ? d.group_count[at] : 0;
+	uint32_t incl = v;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+		if (lane >= (uint32_t)o) incl += up;
+	}
+	if (lane < d.n_copies) {
+		d.group_count[at] = incl - v;
+		d.group_cursor[at] = 0;
+	}
+	if (lane == 63) d.group_total[k] = incl;
+}
+
+// one block: offsets[k] = sum of total[0..k), offsets[n] = grand total; non-empty groups counted
 __global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
 	__shared__ uint32_t s_wave[16];
 	__shared__ uint32_t s_carry;
@@ -257,17 +278,7 @@ __global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
 	uint32_t non_empty = 0;
 	for (uint32_t base = 0; base < n; base += 1024) {
 		const uint32_t k = base + tid;
-		uint32_t c = 0;
-		if (k < n) {
-			for (uint32_t cp = 0; cp < d.n_copies; ++cp) {
-				const size_t at = (size_t)cp * n + k;
-				const uint32_t v = d.group_count[at];
-				d.group_count[at] = c;
-				d.group_cursor[at] = 0;
-				c += v;
-			}
-			d.group_total[k] = c;
-		}
+		const uint32_t c = k < n ? d.group_total[k] : 0;
 		non_empty += c != 0;
 		uint32_t incl = c; // inclusive scan inside the wave
 #pragma unroll
@@ -356,6 +367,7 @@ hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice&
 	if (curve_cap && d.curve_sort_key != nullptr)
 		hipLaunchKernelGGL(k_keys_decal, dim3((curve_cap + 255) / 256), dim3(256), 0, s, d, view, curve_ids, curve_count, d.curve_sort_key, d.curve_layer,
 			(uint32_t)LMX_DRAW_CURVE_DECAL);
+	hipLaunchKernelGGL(k_keys_reduce_copies, dim3((d.max_sort_key + 4) / 4), dim3(256), 0, s, d);
 	hipLaunchKernelGGL(k_keys_offsets, dim3(1), dim3(1024), 0, s, d);
 	if (d.cap_recs) hipLaunchKernelGGL(k_keys_scatter, dim3(std::min((d.cap_recs + 255) / 256, grid_cap * 4)), dim3(256), 0, s, d);
 	hipLaunchKernelGGL(k_keys_groups, dim3((d.max_sort_key + 256) / 256), dim3(256), 0, s, d, view);
