@@ -286,6 +286,26 @@ LMX_API int lmx_keys_read_state(LmxContext* ctx, float* lod, uint32_t* pose_fram
 /* Device pointers of the last run for GPU consumers: pairs (keys, values, count on the device). */
 LMX_API int lmx_keys_device_pairs(LmxContext* ctx, const uint64_t** d_keys, const uint64_t** d_values, const uint32_t** d_count);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Scene ingest: the part of a serialized World (World::serialize / deserialize, engine/world.cpp:837-1043, current
+ * WorldVersion, LZ4-compressed) that feeds lmx_world_build - entity transforms and Hierarchy records.
+ * Host-only, needs no context or device. Entities keep the indices of the file (EntityMap = identity: loading into an empty
+ * world). Module payloads (the blob's tail) are not read; legacy headers and uncompressed versions are rejected.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct LmxWorldBlobInfo {
+	uint32_t version, flags;                  /* WorldVersion, WorldSerializeFlags */
+	uint32_t n_modules;
+	uint32_t uncompressed_size, compressed_size;
+	uint32_t n_entities, max_entity_index;    /* valid entities in the file and the largest EntityRef::index among them */
+	uint32_t n_names, n_hierarchy;
+} LmxWorldBlobInfo;
+LMX_API int lmx_world_blob_info(const void* data, size_t size, LmxWorldBlobInfo* out);
+/* parent[e] / transforms[e] for e < n_slots (n_slots > max_entity_index) exactly as lmx_world_build takes them: roots carry their
+ * world transform, entities with a parent their Hierarchy::local_transform. Optional: world[e] = the serialized m_transforms[e]
+ * of every entity, valid[e] = 1 for entities present in the file (the others are detached identity placeholders). */
+LMX_API int lmx_world_blob_read(const void* data, size_t size, uint32_t n_slots, int32_t* parent, LmxTransform* transforms, LmxTransform* world,
+	uint8_t* valid);
+
 LMX_API const char* lmx_version(void);
 
 #ifdef __cplusplus

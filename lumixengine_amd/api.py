@@ -156,6 +156,8 @@ SYMBOLS = {
     "lmx_viewport_frustum": (_ci, [_vp, _vp]),
     "lmx_frustum_perspective": (_ci, [_vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
     "lmx_frustum_ortho": (_ci, [_vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
+    "lmx_world_blob_info": (_ci, [_vp, _sz, _vp]),
+    "lmx_world_blob_read": (_ci, [_vp, _sz, _u32, _vp, _vp, _vp, _vp]),
     "lmx_version": (C.c_char_p, []),
 }
 
@@ -460,6 +462,26 @@ class World:
         out = np.zeros(self.n, TRANSFORM)
         self.ctx.check(self.lib.lmx_world_read_transforms(self.ctx.h, _ptr(out), self.n))
         return out
+
+
+WORLD_BLOB_INFO = np.dtype([(k, "<u4") for k in ("version", "flags", "n_modules", "uncompressed_size", "compressed_size", "n_entities", "max_entity_index", "n_names",
+                                                  "n_hierarchy")])
+
+
+def world_blob_read(data: bytes):
+    """Serialized World (engine/world.cpp:837-1043) -> (info dict, parent, transforms for World.build, world transforms, valid). Host only."""
+    lib = load_library()
+    buf = np.frombuffer(data, np.uint8)
+    info = np.zeros(1, WORLD_BLOB_INFO)
+    rc = lib.lmx_world_blob_info(_ptr(buf), len(buf), _ptr(info))
+    if rc != 0:
+        raise LumixError(rc, "not a current, LZ4-compressed World blob")
+    n = int(info["max_entity_index"][0]) + 1 if info["n_entities"][0] else 0
+    parent, tr, world, valid = np.zeros(n, np.int32), np.zeros(n, TRANSFORM), np.zeros(n, TRANSFORM), np.zeros(n, np.uint8)
+    rc = lib.lmx_world_blob_read(_ptr(buf), len(buf), n, _ptr(parent), _ptr(tr), _ptr(world), _ptr(valid))
+    if rc != 0:
+        raise LumixError(rc, "World blob truncated or inconsistent")
+    return {k: int(info[k][0]) for k in WORLD_BLOB_INFO.names}, parent, tr, world, valid
 
 
 def keys_view(camera_pos=(0, 0, 0), lod_ref_point=None, lod_multiplier=1.0, time_delta=1 / 60, frame_number=1, is_shadow=False,

@@ -19,7 +19,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "liblumix_mi355.so")
 SOURCES = ["cull_kernels.hip", "xform_kernels.hip", "skin_kernels.hip", "lmx_capi_ctx.hip", "lmx_capi_cull.hip", "lmx_capi_world.hip",
-           "lmx_capi_skin.hip", "keys_kernels.hip", "lmx_capi_keys.hip", "anim_kernels.hip", "lmx_capi_anim.hip", "lmx_frustum.cpp"]
+           "lmx_capi_skin.hip", "keys_kernels.hip", "lmx_capi_keys.hip", "anim_kernels.hip", "lmx_capi_anim.hip", "lmx_frustum.cpp", "lmx_world_blob.cpp"]
 HEADERS = [os.path.join(CSRC, "lmx_math.h"), os.path.join(CSRC, "lmx_kernels.h"), os.path.join(CSRC, "lmx_cull_layout.h"), os.path.join(CSRC, "lmx_context.h"), os.path.join(ROOT, "include", "lumix_mi355.h"),
            os.path.join(ROOT, "include", "lmx_types.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",

@@ -499,6 +499,14 @@ void ref_get_relative(const LmxShiftedFrustum* f, const double* origin, LmxFrust
 // ---------------------------------------------------------------------------------------------------------
 // transforms + World hierarchy
 // ---------------------------------------------------------------------------------------------------------
+// Engine::compress / decompress (engine/engine.cpp:254-269) on the LZ4 the reference vendors (external/lz4/lz4.c)
+extern "C" int LZ4_compress_fast(const char* src, char* dst, int srcSize, int dstCapacity, int acceleration);
+extern "C" int LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstCapacity);
+extern "C" int LZ4_compressBound(int inputSize);
+int ref_lz4_compress(const uint8_t* src, int size, uint8_t* dst, int cap) { return LZ4_compress_fast((const char*)src, (char*)dst, size, cap, 1); }
+int ref_lz4_decompress(const uint8_t* src, int size, uint8_t* dst, int cap) { return LZ4_decompress_safe((const char*)src, (char*)dst, size, cap); }
+int ref_lz4_bound(int size) { return LZ4_compressBound(size); }
+
 void ref_compose(const LmxTransform* a, const LmxTransform* b, LmxTransform* out) { // Transform::compose, math.cpp:801-807
 	fromRef(toRef(a).compose(toRef(b)), out);
 }

@@ -103,6 +103,31 @@ def main():
     b_pos, b_rot = scenes.relative_poses(4, 64, seed=55)
     blended = ref.pose_blend(pos, rot, b_pos, b_rot, 0.35)
     np.savez_compressed(os.path.join(OUT, "blend.npz"), rhs_pos=b_pos, rhs_rot=b_rot, weight=np.array([0.35], np.float32), pos=blended[0], rot=blended[1])
+    # serialized World compressed by the LZ4 the reference vendors (external/lz4/lz4.c in oracle/_ref); the record layout is the
+    # restated writer of tests/helpers.py
+    from tests.test_world_blob import make_world, ref_lz4
+    wn, wents, wworld, whier, wh = make_world(seed=5)
+    wdata, wblob = H.write_world_blob(wents, wworld[wents], whier, names=[(wents[3], "crate"), (wents[5], "lamp")], compress=ref_lz4(ref))
+    open(os.path.join(OUT, "world_blob.bin"), "wb").write(wdata)
+    # expected arrays from the INPUTS of the writer (not from the parser under test)
+    wn_slots = max(wents) + 1
+    wparent = np.full(wn_slots, -1, np.int32)
+    wtr = np.zeros(wn_slots, po.TRANSFORM)
+    wtr["rot"][:, 3] = 1.0
+    wtr["scale"] = 1.0
+    wwtr = wtr.copy()
+    wvalid = np.zeros(wn_slots, np.uint8)
+    for e in wents:
+        wvalid[e] = 1
+        wwtr[e] = wworld[e]
+        if wh["parent"][e] >= 0:
+            wparent[e] = wh["parent"][e]
+            wtr[e] = wh["local"][e]
+        else:
+            wtr[e] = wworld[e]
+    import struct
+    unc, comp = struct.unpack_from("<II", wdata, len(wdata) - len(ref_lz4(ref)(wblob)) - 8)
+    np.savez_compressed(os.path.join(OUT, "world_blob.npz"), parent=wparent, transforms=wtr, world=wwtr, valid=wvalid, sizes=np.array([unc, comp]))
     # ---- rows whose parity is UNPINNED (no compilable reference code, see oracle/lmx_oracle.c): regression anchors generated by
     # the restated oracle ("port"), not by reference object code. File names say so.
     port = po.Oracle("port")

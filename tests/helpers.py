@@ -119,3 +119,36 @@ def bits_equal(a: np.ndarray, b: np.ndarray) -> bool:
 
 def transforms_bits_equal(a: np.ndarray, b: np.ndarray) -> bool:
     return all(bits_equal(np.ascontiguousarray(a[k]), np.ascontiguousarray(b[k])) for k in ("pos", "rot", "scale"))
+
+
+def write_world_blob(entities, world, hierarchy, module_names=("renderer", "animation"), names=None, partitions=False, compress=None):
+    """World::serialize (engine/world.cpp:837-898) for a world without module payloads: `entities` = valid entity indices, `world` =
+    Transform per listed entity, `hierarchy` = list of (entity, parent, first_child, next_sibling, local Transform). `compress` =
+    bytes -> bytes LZ4 block compressor (the reference's own, oracle/_ref). Test helper: restated writer, not reference code."""
+    import struct
+
+    def tr_bytes(t):
+        return struct.pack("<3d4f3f", *[float(x) for x in t["pos"]], *[float(x) for x in t["rot"]], *[float(x) for x in t["scale"]])
+
+    blob = bytearray(struct.pack("<I", len(entities)))
+    for e, t in zip(entities, world):
+        blob += struct.pack("<i", int(e)) + tr_bytes(t)
+        if partitions:
+            blob += struct.pack("<H", 0)
+    blob += struct.pack("<i", -1)
+    names = names or []
+    blob += struct.pack("<I", len(names))
+    for e, name in names:
+        blob += struct.pack("<i", int(e)) + name.encode() + b"\0"
+    blob += struct.pack("<I", len(hierarchy))
+    for (e, p, fc, ns, local) in hierarchy:
+        blob += struct.pack("<4i", int(e), int(p), int(fc), int(ns)) + tr_bytes(local)
+    blob += struct.pack("<i", 0)  # module count inside the blob: no payloads
+    packed = compress(bytes(blob))
+    out = bytearray(struct.pack("<II", 0x4C57524C, 6))  # WorldHeader {'LWRL', WorldVersion::LATEST}
+    out += struct.pack("<i", len(module_names))
+    for m in module_names:
+        out += m.encode() + b"\0"
+    out += struct.pack("<I", 1 if partitions else 0)
+    out += struct.pack("<II", len(blob), len(packed)) + packed
+    return bytes(out), bytes(blob)
