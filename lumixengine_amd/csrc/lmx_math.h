@@ -177,22 +177,24 @@ LMX_HD uint32_t classify_cell(const DevFrustum& f, IV3 idx, bool is_big, V3* out
 // Tile-level early out of k_cull_fused (no reference twin: a conservative bound on classify_cell). A tile of the sorted sphere
 // array covers a run of cells; `lo..hi` is the box of their cell indices. If the union of the cells' intersectsAABB boxes
 // ([300 * lo - 300, 300 * hi + 300] per axis) lies behind one frustum plane by more than `margin`, every cell of the tile is
-// CELL_REJECT: a cell's positive vertex is never further along the plane normal than the union box's, and the margin
-// (2 + 4e-6 * |vertex|_1, evaluated in fp64) exceeds the rounding of the per-cell fp32 evaluation (< 1e-6 * |vertex|_1) by
-// far. Tiles with big-sphere cells (always CELL_TEST) are never rejected here; NaN planes compare false and reject nothing.
+// CELL_REJECT: a cell's positive vertex is never further along the plane normal than the union box's. The box corners are formed
+// in fp64 and rounded once to fp32; the plane expression is then evaluated in fp32 like the per-cell test. Both evaluations err
+// by < 1.5e-6 * |vertex|_1 each (5 roundings of 2^-24 relative on terms bounded by |vertex|_1), the margin 2 + 4e-6 * |vertex|_1
+// covers their sum with room to spare. Tiles with big-sphere cells (always CELL_TEST) are never rejected here; NaN planes or
+// corners compare false and reject nothing.
 struct TileBox { int32_t lo[3], hi[3]; uint32_t flags, pad; };
 enum : uint32_t { TILE_EMPTY = 1, TILE_HAS_BIG = 2 };
 LMX_HD bool tile_rejected(const DevFrustum& f, const TileBox& b) {
 	if (b.flags & TILE_EMPTY) return true;
 	if (b.flags & TILE_HAS_BIG) return false;
 	const double cs = (double)CELL_SIZE;
-	const double lx = cs * b.lo[0] - cs - f.origin[0], ly = cs * b.lo[1] - cs - f.origin[1], lz = cs * b.lo[2] - cs - f.origin[2];
-	const double hx = cs * b.hi[0] + cs - f.origin[0], hy = cs * b.hi[1] + cs - f.origin[1], hz = cs * b.hi[2] + cs - f.origin[2];
+	const float lx = (float)(cs * b.lo[0] - cs - f.origin[0]), ly = (float)(cs * b.lo[1] - cs - f.origin[1]), lz = (float)(cs * b.lo[2] - cs - f.origin[2]);
+	const float hx = (float)(cs * b.hi[0] + cs - f.origin[0]), hy = (float)(cs * b.hi[1] + cs - f.origin[1]), hz = (float)(cs * b.hi[2] + cs - f.origin[2]);
 	for (int i = 0; i < 6; ++i) {
-		const double bx = f.nx[i] > 0.0f ? hx : lx, by = f.ny[i] > 0.0f ? hy : ly, bz = f.nz[i] > 0.0f ? hz : lz;
-		const double dp = (double)f.nx[i] * bx + (double)f.ny[i] * by + (double)f.nz[i] * bz;
-		const double margin = 2.0 + 4e-6 * ((bx < 0 ? -bx : bx) + (by < 0 ? -by : by) + (bz < 0 ? -bz : bz));
-		if (dp < -(double)f.d[i] - margin) return true;
+		const float bx = f.nx[i] > 0.0f ? hx : lx, by = f.ny[i] > 0.0f ? hy : ly, bz = f.nz[i] > 0.0f ? hz : lz;
+		const float dp = (f.nx[i] * bx) + (f.ny[i] * by) + (f.nz[i] * bz);
+		const float margin = 2.0f + 4e-6f * ((bx < 0 ? -bx : bx) + (by < 0 ? -by : by) + (bz < 0 ? -bz : bz));
+		if (dp < -f.d[i] - margin) return true;
 	}
 	return false;
 }
