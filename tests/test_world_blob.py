@@ -95,6 +95,27 @@ def test_lz4_block_decoder_matches_reference(oracle_ref):
         assert info["uncompressed_size"] == len(blob) and info["n_names"] == 1 and valid[0] == 1
 
 
+def test_lz4_decoder_property(oracle_ref):
+    """hypothesis: whatever byte string ends up inside the blob (as an entity name), the product's decoder reproduces what the
+    reference's compressor was given - sizes match and the world record after the name is still found."""
+    from hypothesis import given, settings, strategies as st
+
+    compress = ref_lz4(oracle_ref)
+    tr = scenes.random_transforms(np.random.default_rng(1), 2, 10.0)
+    chunk = st.one_of(st.binary(min_size=0, max_size=40), st.integers(1, 255).flatmap(lambda b: st.integers(1, 600).map(lambda n: bytes([b]) * n)),
+                      st.sampled_from([b"lumix", b"\x01\x02\x03\x04", b"abcabcabc"]).flatmap(lambda w: st.integers(1, 200).map(lambda n: w * n)))
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(chunk, min_size=0, max_size=12))
+    def run(parts):
+        raw = b"".join(parts).replace(b"\0", b"\1")
+        data, blob = H.write_world_blob([0, 7], tr, [(7, 0, -1, -1, tr[1])], names=[(0, raw.decode("latin1"))], compress=compress)
+        info, parent, t, w, valid = api.world_blob_read(data)
+        assert info["uncompressed_size"] == len(blob) and info["n_hierarchy"] == 1 and parent[7] == 0 and H.transforms_bits_equal(t[7:8], tr[1:2])
+
+    run()
+
+
 def test_malformed_blobs_are_rejected(oracle_ref):
     n, ents, world, hier, h = make_world()
     data, _ = H.write_world_blob(ents, world[ents], hier, compress=ref_lz4(oracle_ref))
