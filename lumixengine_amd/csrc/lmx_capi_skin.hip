@@ -63,6 +63,9 @@ int lmx_skin_add_mesh(LmxContext* ctx, uint32_t n_verts, const float* positions_
 	SkinMesh m;
 	m.vert_offset = (uint32_t)(sk.verts.size() / 3);
 	m.n_verts = n_verts;
+	m.max_bone = 0;
+	for (uint32_t v = 0; v < n_verts; ++v)
+		for (int k = 0; k < 4; ++k) m.max_bone = std::max<uint32_t>(m.max_bone, (uint32_t)skin[v].indices[k]);
 	sk.verts.insert(sk.verts.end(), positions_xyz, positions_xyz + (size_t)n_verts * 3);
 	for (uint32_t v = 0; v < n_verts; ++v) {
 		sk.weights.push_back(make_float4(skin[v].weights[0], skin[v].weights[1], skin[v].weights[2], skin[v].weights[3]));
@@ -117,6 +120,8 @@ int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* model, c
 		const SkinModel& mo = sk.models[model[i]];
 		const SkinMesh& me = sk.meshes[mesh[i]];
 		SkinInstance& in = inst[i];
+		// the vertex kernels index the instance's palette in LDS with the mesh's bone indices, unchecked
+		if (me.max_bone >= mo.n_bones) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "instance %u: its mesh references bone %u, its model has %u bones", i, me.max_bone, mo.n_bones);
 		if (bones + mo.n_bones > 0xffffffffull || verts + me.n_verts > 0xffffffffull) return fail(ctx, LMX_ERR_CAPACITY, "instance table exceeds 2^32 bones or vertices");
 		in.bone_offset = (uint32_t)bones;
 		in.n_bones = mo.n_bones;

@@ -148,7 +148,7 @@ struct WorldState {
 };
 
 struct SkinModel { uint32_t bone_offset, n_bones, max_depth; int32_t first_nonroot; uint32_t lv_items_offset, lv_off_offset; };
-struct SkinMesh { uint32_t vert_offset, n_verts; };
+struct SkinMesh { uint32_t vert_offset, n_verts, max_bone; }; // max_bone: the largest bone index its vertices reference
 
 struct SkinState {
 	std::vector<SkinModel> models;

@@ -77,6 +77,8 @@ def test_skin_errors(gpu_ctx):
     expect(INVALID, sk.addMesh, verts, bad_skin)
     mesh = sk.addMesh(verts, skin)
     expect(INVALID, sk.setInstances, [model + 100], [mesh])
+    wide = sk.addMesh(*scenes.skinned_mesh(50, 12, seed=4))  # references bones up to 11: not usable with the 8-bone model
+    expect(INVALID, sk.setInstances, [model], [wide])
     sk.setInstances([model] * 3, [mesh] * 3)
     expect(NOT_BUILT, sk.run)  # no poses yet
     pos, rot = scenes.relative_poses(3, 8, seed=4)
