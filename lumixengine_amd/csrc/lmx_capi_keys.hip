@@ -60,6 +60,8 @@ int lmx_keys_set_instances(LmxContext* ctx, uint32_t n_entities, const int32_t* 
 			return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %u: mesh materials [%u, +%u) outside the table", e, material_offset[e], ks.models[model[e]].mesh_count);
 		if (!(lod[e] >= 0.f && lod[e] <= 4.f)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %u: ModelInstance::lod %g outside [0, 4]", e, (double)lod[e]);
 	}
+	for (uint32_t i = 0; i < n_mesh_materials; ++i) // bucket_map / layer_to_bucket have 255 entries (pipeline.cpp:573, :3802)
+		if (mesh_materials[i].layer >= 255) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "mesh material %u: layer %u (layers are 0..254)", i, mesh_materials[i].layer);
 	// device copy of the material spans with Mesh::type of the model's mesh folded into the padding byte: one gather less
 	// on the device's dependent-load chain (entity -> model -> mesh type)
 	std::vector<LmxMeshMaterial> dev_mm(mesh_materials, mesh_materials + n_mesh_materials);
@@ -93,6 +95,8 @@ int lmx_keys_set_decals(LmxContext* ctx, uint32_t n_entities, const uint32_t* de
 		return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "sort-key and layer tables come in pairs");
 	KeysState& ks = ctx->keys;
 	if (ks.have_instances && n_entities != ks.n_entities) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "decal tables cover %u entities, instance tables %u", n_entities, ks.n_entities);
+	for (uint32_t e = 0; e < n_entities; ++e)
+		if ((decal_layer && decal_layer[e] >= 255) || (curve_layer && curve_layer[e] >= 255)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %u: decal layer 255 (layers are 0..254)", e);
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	ks.have_decals = decal_sort_key != nullptr;
 	ks.have_curves = curve_sort_key != nullptr;
