@@ -75,6 +75,48 @@ def test_struct_layouts(api):
     assert api.LOCAL_RIGID.itemsize == 28 and api.MATRIX.itemsize == 64 and api.SKIN.itemsize == 24
 
 
+def test_struct_layouts_match_the_c_header(api, tmp_path):
+    """Every POD the Python binding mirrors has the size and field offsets the C compiler gives include/lmx_types.h / lumix_mi355.h."""
+    import subprocess
+
+    structs = {
+        "LmxShiftedFrustum": (api.SHIFTED_FRUSTUM, ["xs", "points", "origin"]),
+        "LmxTransform": (api.TRANSFORM, ["pos", "rot", "scale"]),
+        "LmxLocalRigidTransform": (api.LOCAL_RIGID, ["pos", "rot"]),
+        "LmxSkin": (api.SKIN, ["weights", "indices"]),
+        "LmxKeysModel": (api.KEYS_MODEL, ["lod_distances", "lod_indices", "first_mesh", "mesh_count"]),
+        "LmxMeshMaterial": (api.MESH_MATERIAL, ["sort_key", "layer"]),
+        "LmxKeysView": (api.KEYS_VIEW, ["camera_pos", "lod_ref_point", "lod_multiplier", "time_delta", "frame_number", "is_shadow", "layer_to_bucket", "bucket_depth_sorted"]),
+        "LmxKeysCounts": (api.KEYS_COUNTS, ["pairs", "instanced", "groups", "poses", "dirty", "overflow"]),
+        "LmxAnimConstTranslation": (api.ANIM_CONST_TRANSLATION, ["value", "bone_index"]),
+        "LmxAnimTranslationTrack": (api.ANIM_TRANSLATION_TRACK, ["min", "to_range", "offset_bits", "bone_index", "bitsizes"]),
+        "LmxAnimConstRotation": (api.ANIM_CONST_ROTATION, ["value", "bone_index"]),
+        "LmxAnimRotationTrack": (api.ANIM_ROTATION_TRACK, ["min", "to_range", "offset_bits", "bone_index", "bitsizes", "skipped_channel"]),
+        "LmxWorldBlobInfo": (api.WORLD_BLOB_INFO, ["version", "flags", "n_modules", "uncompressed_size", "compressed_size", "n_entities", "max_entity_index", "n_names", "n_hierarchy"]),
+    }
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lumix_mi355.h"', "int main(void) {"]
+    for name, (_, fields) in structs.items():
+        lines.append(f'printf("{name} %zu", sizeof({name}));')
+        for f in fields:
+            lines.append(f'printf(" %zu", offsetof({name}, {f}));')
+        lines.append('printf("\\n");')
+    lines.append(f'printf("LmxAnimation %zu %zu %zu\\n", sizeof(LmxAnimation), offsetof(LmxAnimation, const_translations), offsetof(LmxAnimation, root_pose_rotations));')
+    lines.append("return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-std=c11", "-I", inc, str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    got = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in out}
+    for name, (dtype, fields) in structs.items():
+        want = [dtype.itemsize] + [dtype.fields[f][1] for f in fields]
+        assert got[name] == want, f"{name}: C {got[name]} vs numpy {want}"
+    import ctypes as C
+
+    assert got["LmxAnimation"] == [C.sizeof(api.LmxAnimation), api.LmxAnimation.const_translations.offset, api.LmxAnimation.root_pose_rotations.offset]
+
+
 def test_host_transform_utilities_match_oracle(api, oracle_port):
     """lmx_transform_compose / lmx_transform_compute_local (Transform::compose / computeLocal, core/math.cpp:801-816)."""
     from lumixengine_amd import scenes
