@@ -117,6 +117,30 @@ def test_struct_layouts_match_the_c_header(api, tmp_path):
     assert got["LmxAnimation"] == [C.sizeof(api.LmxAnimation), api.LmxAnimation.const_translations.offset, api.LmxAnimation.root_pose_rotations.offset]
 
 
+def test_integration_doc_covers_every_entry_point():
+    """INTEGRATION.md names the reference interface each C-ABI entry point replaces: no exported symbol may be missing from it."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "lumix_mi355.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = re.findall(r"LMX_API\s+[\w\s\*]+?\b(lmx_\w+)\s*\(", header)
+    assert len(names) > 70
+    missing = []
+    for n in names:
+        if n in doc:
+            continue
+        parts = n.split("_")
+        ok = False
+        for k in range(len(parts) - 1, 1, -1):  # `lmx_cull_add/remove/set` and `lmx_keys_read_*` style groupings
+            pre, post = "_".join(parts[:k]), "_".join(parts[k:])
+            ok = ok or pre + "_*" in doc or re.search(re.escape(pre) + r"[\w/]*?/" + re.escape(post) + r"\b", doc) is not None
+            ok = ok or re.search(re.escape(pre) + r"_[\w/]*\b" + re.escape(post), doc) is not None
+        if not ok:
+            missing.append(n)
+    assert not missing, missing
+
+
 def test_host_transform_utilities_match_oracle(api, oracle_port):
     """lmx_transform_compose / lmx_transform_compute_local (Transform::compose / computeLocal, core/math.cpp:801-816)."""
     from lumixengine_amd import scenes
