@@ -97,6 +97,36 @@ def test_emulated_tile_early_out_is_conservative_and_effective(emul_lib, oracle_
             assert boxed >= 0.6 * dead, f"frustum {f}: box test caught {boxed} of {dead} fully rejected tiles"
 
 
+def test_emulated_tile_early_out_random_cameras(emul_lib, oracle_port):
+    """The conservative box test under 24 random cameras (perspective and orthographic, inside / outside / far from the scene,
+    narrow and wide, short and long far planes): the emulation aborts with code 8 if a tile is dropped that holds a surviving
+    cell, and a few frusta are also compared id for id with the oracle."""
+    sc = scenes.cull_scene(250_000, 6000.0, seed=17, big_fraction=0.001)
+    cs = oracle_port.culling_system()
+    cs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    rng = np.random.default_rng(23)
+    boxed_total = 0
+    for k in range(24):
+        pos = rng.uniform(-9000, 9000, size=3) * (1.0 if k % 3 else 40.0)  # every third camera far outside the scene
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        if k % 4 == 3:
+            fr = oracle_port.viewport_frustum(is_ortho=True, ortho_size=float(rng.uniform(50, 4000)), w=1024, h=768, near=0.0, far=float(rng.uniform(500, 30000)), pos=tuple(pos),
+                                              rot=tuple(q))
+        else:
+            fr = oracle_port.viewport_frustum(fov=float(np.deg2rad(rng.uniform(10, 120))), w=1920, h=1080, near=float(rng.uniform(0.05, 5)), far=float(rng.uniform(300, 40000)),
+                                              pos=tuple(pos), rot=tuple(q))
+        got, _ = emul_cull(emul_lib, sc, fr)  # asserts rc == 0: code 8 would mean a non-conservative rejection
+        st = np.zeros(3, np.uint32)
+        emul_lib.emul_tile_stats(_p(st))
+        assert st[1] <= st[2]
+        boxed_total += int(st[1])
+        if k % 6 == 0:
+            ids, types, _ = cs.cull(fr)
+            H.assert_same_visible(got[0], H.sorted_by_type(ids, types), f"camera {k}")
+    assert boxed_total > 200  # the test does fire across these cameras
+
+
 def test_emulated_empty_and_tiny(emul_lib, oracle_port):
     fr = H.frusta(oracle_port)[:1]
     empty = {"entity": np.zeros(0, np.int32), "type": np.zeros(0, np.uint8), "pos": np.zeros((0, 3)), "radius": np.zeros(0, np.float32)}
