@@ -127,6 +127,35 @@ def test_compose_and_compute_local_bit_exact(oracle_port, oracle_ref):
     assert H.transforms_bits_equal(oracle_port.compute_local(a, b), oracle_ref.compute_local(a, b))
 
 
+def test_compose_and_compute_local_edge_values(oracle_port, oracle_ref):
+    """Zero / negative / denormal / huge scales (safeInverseScale, math.cpp), non-unit and zero quaternions, positions at 1e12 and
+    NaN / inf components: the restatement and the reference object code agree bit for bit (NaN results agree as NaN; their sign / payload depends on
+    the operand order each compiler chose and carries no meaning)."""
+    vals = [0.0, -0.0, 1.0, -1.0, 1e-42, -3.5e-39, 1e30, -1e30, np.inf, -np.inf, np.nan, 0.5, 2.0]
+    rng = np.random.default_rng(41)
+    n = 4000
+    def make():
+        t = scenes.random_transforms(rng, n, 1.0e6)
+        for field, width in (("scale", 3), ("rot", 4)):
+            pick = rng.random((n, width)) < 0.25
+            t[field] = np.where(pick, rng.choice(vals, size=(n, width)).astype(np.float32), t[field])
+        pick = rng.random((n, 3)) < 0.1
+        t["pos"] = np.where(pick, rng.choice([0.0, 1e12, -1e12, np.nan, np.inf, 1e-300], size=(n, 3)), t["pos"])
+        return t
+    a, b = make(), make()
+
+    def same(x, y):  # bit for bit, except that two NaNs may differ in sign / payload (operand order of the two compilations)
+        for f, u in (("pos", np.uint64), ("rot", np.uint32), ("scale", np.uint32)):
+            xv, yv = np.ascontiguousarray(x[f]), np.ascontiguousarray(y[f])
+            if not np.all((xv.view(u) == yv.view(u)) | (np.isnan(xv) & np.isnan(yv))):
+                return False
+        return True
+
+    with np.errstate(all="ignore"):
+        assert same(oracle_port.compose(a, b), oracle_ref.compose(a, b))
+        assert same(oracle_port.compute_local(a, b), oracle_ref.compute_local(a, b))
+
+
 @pytest.mark.parametrize("weight", [0.0005, 0.3, 0.9999, 1.7])
 def test_pose_blend_bit_exact(oracle_port, oracle_ref, weight):
     """Pose::blend (pose.cpp:30-41) on the reference's own Vec3 operators and nlerp (math.cpp:677-691)."""
