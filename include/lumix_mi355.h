@@ -72,14 +72,17 @@ LMX_API int lmx_profile_reset(LmxContext* ctx);
 LMX_API int lmx_profile_get(LmxContext* ctx, int kernel_id, double* total_ms, uint64_t* launches);
 
 /* ---- culling: CullingSystem, src/renderer/culling_system.h:58-77 -------------------------------------------
- * Device layout: spheres sorted by (type, is_big, cell) in SoA chunks of 64; see DESIGN.md. */
+ * Device layout: a static set of spheres sorted by (type, is_big, cell) in SoA chunks of 64, plus an unsorted dynamic set for
+ * entities that move every frame or were added since the static set was last compacted; see DESIGN.md. */
 
 /* Bulk CullingSystem::add (culling_system.cpp:131-157) of n entities; replaces any previous content.
  * pos_xyz: n x 3 doubles (world position), type < LMX_MAX_TYPES, entity >= 0 and unique. */
 LMX_API int lmx_cull_build(LmxContext* ctx, uint32_t n, const int32_t* entity, const uint8_t* type, const double* pos_xyz,
 	const float* radius);
-/* Incremental interface, same semantics as the virtuals of CullingSystem (culling_system.cpp:131-258).
- * Changes are staged on the host mirror and reach the GPU at the next lmx_cull()/lmx_cull_flush(). */
+/* Incremental interface, same semantics and the same O(1) cost as the virtuals of CullingSystem (culling_system.cpp:131-258).
+ * Changes are staged on the host mirror and reach the GPU as small patch records at the next lmx_cull()/lmx_cull_flush():
+ * an in-cell move rewrites one sphere, a removal leaves a tombstone, an added or re-celled entity lives in the unsorted
+ * dynamic set until the static set is compacted (automatically once the overflow exceeds 1/8 of it, or lmx_cull_compact). */
 LMX_API int lmx_cull_add(LmxContext* ctx, int32_t entity, uint8_t type, const double pos[3], float radius);
 LMX_API int lmx_cull_remove(LmxContext* ctx, int32_t entity);
 LMX_API int lmx_cull_set(LmxContext* ctx, int32_t entity, const double pos[3], float radius);
@@ -88,9 +91,19 @@ LMX_API int lmx_cull_set_radius(LmxContext* ctx, int32_t entity, float radius);
 LMX_API int lmx_cull_get_radius(LmxContext* ctx, int32_t entity, float* out_radius);
 LMX_API int lmx_cull_is_added(LmxContext* ctx, int32_t entity); /* 1 / 0 */
 LMX_API int lmx_cull_flush(LmxContext* ctx);
+/* The same add / set / remove for n entities in one ABI crossing (hosts that pay per call). */
+LMX_API int lmx_cull_add_many(LmxContext* ctx, uint32_t n, const int32_t* entity, const uint8_t* type, const double* pos_xyz, const float* radius);
+LMX_API int lmx_cull_set_many(LmxContext* ctx, uint32_t n, const int32_t* entity, const double* pos_xyz, const float* radius);
+LMX_API int lmx_cull_remove_many(LmxContext* ctx, uint32_t n, const int32_t* entity);
+/* Re-sort the static set now, folding in every entity added / re-celled since the last compaction and dropping tombstones
+ * (O(n): a loading-screen operation; never needed for correctness). */
+LMX_API int lmx_cull_compact(LmxContext* ctx);
+/* Bookkeeping of the incremental path: entities in the sorted set, bound to the world hierarchy, waiting in the overflow, and
+ * tombstones left in the sorted layout. Host-only, no synchronisation. */
+LMX_API int lmx_cull_update_stats(LmxContext* ctx, uint32_t* n_static, uint32_t* n_dynamic_bound, uint32_t* n_overflow, uint32_t* n_tombstones);
 /* Number of resident spheres / occupied (cell,type,is_big) groups of the static set / capacity of one frustum's output
- * row in units of 64 ids (static + dynamic slots, padding included): a bound output buffer needs 64 * n_chunks ids per
- * frustum. */
+ * row in units of 64 ids: a bound output buffer needs 64 * n_chunks ids per frustum. Compacts the static set first (the cell
+ * count is that of the sorted layout). */
 LMX_API int lmx_cull_stats(LmxContext* ctx, uint32_t* n_entities, uint32_t* n_cells, uint32_t* n_chunks);
 
 /* CullingSystem::cull(frustum[, type]) (culling_system.cpp:310-369) for n_frusta <= LMX_MAX_FRUSTA frusta in one
@@ -102,19 +115,45 @@ LMX_API int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* fr
  * (8 frusta over 10 M spheres: 0.17 ms at width 1, 0.32 ms at width 8); wider passes read the spheres fewer times and are
  * the better choice when the set is far larger than the 256 MiB Infinity Cache. */
 LMX_API int lmx_cull_set_pass_width(LmxContext* ctx, uint32_t frusta_per_pass);
+/* Kernel tuning knobs (no reference twin; results never depend on them). */
+enum {
+	LMX_CULL_OPT_TILE_VARIANT = 0,            /* 1-frustum kernel tile: -1 auto (default), 0 = 8 waves x 8 chunks (4096 spheres), 1 = 4 x 8, 2 = 8 x 4 (2048), 3 = 4 x 4 (1024) */
+	LMX_CULL_OPT_LANE_PARALLEL_TILE_TEST = 1, /* 1 (default): the tile-level box test of the 1-frustum kernel runs one plane per lane */
+	LMX_CULL_OPT_MAX_SHARDS = 2,              /* output shards (reservation counters) per renderable type, 1..64 (default 64) */
+	LMX_CULL_OPT_COUNTER_PAD = 3              /* 32-bit words between two shard counters, 1..64 (default 32 = one 128-byte line each) */
+};
+LMX_API int lmx_cull_set_option(LmxContext* ctx, int option, int value);
 /* counts[f * LMX_MAX_TYPES + t] = visible entities of type t for frustum f (synchronizes the stream). */
 LMX_API int lmx_cull_counts(LmxContext* ctx, uint32_t view, uint32_t* counts /* [n_frusta][LMX_MAX_TYPES] */);
 /* Copies the visible ids of (frustum, type) to the host: the content of the CullResult pages of that type
  * (culling_system.h:17-56). Order is unspecified, as in the reference (job scheduling + mutexed page list). */
 LMX_API int lmx_cull_read(LmxContext* ctx, uint32_t view, uint32_t frustum, uint8_t type, int32_t* out_ids, uint32_t cap,
 	uint32_t* out_count);
+/* All types of one frustum at once: out_counts[LMX_MAX_TYPES], ids of type 0 first, then type 1, ... (two host waits in
+ * total; what an adapter that rebuilds CullResult pages needs). */
+LMX_API int lmx_cull_read_all(LmxContext* ctx, uint32_t view, uint32_t frustum, int32_t* out_ids, uint32_t cap, uint32_t* out_counts);
 /* Device-side view of a result for GPU consumers (sort keys, RCCL all-gather): ids of (frustum, type) start at
  * d_ids + type_offsets[type] and number d_counts[frustum * LMX_MAX_TYPES + type]. All pointers are device memory
- * except type_offsets (host, LMX_MAX_TYPES entries, in ids). */
+ * except type_offsets (host, LMX_MAX_TYPES entries, in ids). The cull kernels leave the visible ids in up to a few hundred
+ * per-shard windows (lmx_cull_device_shards); this call gathers them into one contiguous list per type first (two small
+ * launches, once per cull result). */
 LMX_API int lmx_cull_device_result(LmxContext* ctx, uint32_t view, uint32_t frustum, const int32_t** d_ids, const uint32_t** d_counts,
 	uint32_t* type_offsets, uint32_t* capacity);
 
-/* Lets slot `view` write its result into caller-owned DEVICE memory (e.g. a buffer that is then handed to an RCCL
+/* The raw form of a result, as the cull kernels leave it: shard s of the frustum holds d_counts[s * count_stride] ids of
+ * renderable type d_shard_type[s] at d_ids + d_window_start[s]. The analogue of the reference's unordered list of CullResult
+ * pages; consumers that can walk several windows skip the gather of lmx_cull_device_result. All pointers are device memory. */
+typedef struct LmxCullShards {
+	const int32_t* d_ids;
+	const uint32_t* d_counts;
+	uint32_t count_stride;
+	const uint32_t* d_window_start;
+	const uint8_t* d_shard_type;
+	uint32_t n_shards;
+} LmxCullShards;
+LMX_API int lmx_cull_device_shards(LmxContext* ctx, uint32_t view, uint32_t frustum, LmxCullShards* out);
+
+/* Lets slot `view` write its (contiguous, per-type) result into caller-owned DEVICE memory (e.g. a buffer that is then handed to an RCCL
  * all-gather) instead of library-owned buffers: d_ids holds ids_capacity int32 (>= n_frusta * 64 * n_chunks of
  * lmx_cull_stats at cull time), d_counts LMX_MAX_FRUSTA * LMX_MAX_TYPES uint32. Frustum f's ids start at
  * d_ids + f * (64 * n_chunks). Passing NULL pointers restores the library-owned buffers. */

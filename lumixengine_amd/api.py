@@ -23,6 +23,7 @@ LIB_PATH = os.path.join(PKG, "liblumix_mi355.so")
 
 MAX_FRUSTA, MAX_TYPES, MAX_VIEWS = 8, 8, 8
 TYPE_ALL = 0xFF
+CULL_OPT_TILE_VARIANT, CULL_OPT_LANE_PARALLEL_TILE_TEST, CULL_OPT_MAX_SHARDS, CULL_OPT_COUNTER_PAD = range(4)
 (K_CULL_CLASSIFY, K_CULL_SPHERES, K_XFORM_LEVEL, K_SPHERE_REFRESH, K_POSE_PALETTE, K_SKIN_VERTICES, K_CULL_DYNAMIC) = range(7)
 KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices", "cull_dynamic", "sort_keys", "anim_update"]
 
@@ -97,6 +98,14 @@ SYMBOLS = {
     "lmx_cull_get_radius": (_ci, [_vp, _i32, C.POINTER(_f32)]),
     "lmx_cull_is_added": (_ci, [_vp, _i32]),
     "lmx_cull_flush": (_ci, [_vp]),
+    "lmx_cull_add_many": (_ci, [_vp, _u32, _vp, _vp, _vp, _vp]),
+    "lmx_cull_set_many": (_ci, [_vp, _u32, _vp, _vp, _vp]),
+    "lmx_cull_remove_many": (_ci, [_vp, _u32, _vp]),
+    "lmx_cull_compact": (_ci, [_vp]),
+    "lmx_cull_update_stats": (_ci, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "lmx_cull_set_option": (_ci, [_vp, _ci, _ci]),
+    "lmx_cull_read_all": (_ci, [_vp, _u32, _u32, _vp, _u32, _vp]),
+    "lmx_cull_device_shards": (_ci, [_vp, _u32, _u32, _vp]),
     "lmx_cull_stats": (_ci, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "lmx_cull": (_ci, [_vp, _u32, _vp, _u32, _u8]),
     "lmx_cull_set_pass_width": (_ci, [_vp, _u32]),
@@ -325,13 +334,12 @@ class CullResult:
         return out[: got.value]
 
     def all_ids(self, frustum: int = 0):
-        """(ids, types) over all types, like walking the whole CullResult list."""
-        ids, types = [], []
-        for t in range(MAX_TYPES):
-            a = self.ids(frustum, t)
-            ids.append(a)
-            types.append(np.full(len(a), t, np.uint8))
-        return np.concatenate(ids), np.concatenate(types)
+        """(ids, types) over all types, like walking the whole CullResult list (lmx_cull_read_all: two host waits)."""
+        n = int(self.counts()[frustum].sum())
+        out = np.zeros(max(n, 1), np.int32)
+        cnt = np.zeros(MAX_TYPES, np.uint32)
+        self.cs.ctx.check(self.cs.lib.lmx_cull_read_all(self.cs.ctx.h, self.view, frustum, _ptr(out), len(out), _ptr(cnt)))
+        return out[: int(cnt.sum())], np.repeat(np.arange(MAX_TYPES, dtype=np.uint8), cnt)
 
     def pages(self, frustum: int = 0, type_: int = 0, page_ids: int = 1020):
         a = self.ids(frustum, type_)
@@ -386,6 +394,36 @@ class CullingSystem:
 
     def flush(self):
         self.ctx.check(self.lib.lmx_cull_flush(self.ctx.h))
+
+    def addMany(self, entity, type_, pos, radius):
+        entity = np.ascontiguousarray(entity, np.int32)
+        type_ = np.ascontiguousarray(type_, np.uint8)
+        pos = np.ascontiguousarray(pos, np.float64).reshape(-1, 3)
+        radius = np.ascontiguousarray(radius, np.float32)
+        assert len(entity) == len(type_) == len(pos) == len(radius)
+        self.ctx.check(self.lib.lmx_cull_add_many(self.ctx.h, len(entity), _ptr(entity), _ptr(type_), _ptr(pos), _ptr(radius)))
+
+    def setMany(self, entity, pos, radius):
+        entity = np.ascontiguousarray(entity, np.int32)
+        pos = np.ascontiguousarray(pos, np.float64).reshape(-1, 3)
+        radius = np.ascontiguousarray(radius, np.float32)
+        assert len(entity) == len(pos) == len(radius)
+        self.ctx.check(self.lib.lmx_cull_set_many(self.ctx.h, len(entity), _ptr(entity), _ptr(pos), _ptr(radius)))
+
+    def removeMany(self, entity):
+        entity = np.ascontiguousarray(entity, np.int32)
+        self.ctx.check(self.lib.lmx_cull_remove_many(self.ctx.h, len(entity), _ptr(entity)))
+
+    def compact(self):
+        self.ctx.check(self.lib.lmx_cull_compact(self.ctx.h))
+
+    def updateStats(self):
+        v = [C.c_uint32(0) for _ in range(4)]
+        self.ctx.check(self.lib.lmx_cull_update_stats(self.ctx.h, *[C.byref(x) for x in v]))
+        return dict(zip(("static", "bound", "overflow", "tombstones"), (x.value for x in v)))
+
+    def setOption(self, option: int, value: int):
+        self.ctx.check(self.lib.lmx_cull_set_option(self.ctx.h, int(option), int(value)))
 
     def stats(self):
         a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)

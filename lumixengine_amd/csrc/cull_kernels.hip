@@ -1,16 +1,23 @@
 // cull_kernels.hip — frustum culling of CullingSystem spheres on gfx950 (wave64).
 //
 // Replaces CullingSystemImpl::cullInternal / doCulling (src/renderer/culling_system.cpp:262-369) and the per-cell
-// ShiftedFrustum tests (src/core/geometry.cpp:99-178). Two kernels per cull:
+// ShiftedFrustum tests (src/core/geometry.cpp:99-178). One launch per cull pass:
 //
-//   k_cull_classify   1 thread per occupied (cell,type,is_big) group x frustum: fp64 origin shift, the
-//                     contains/intersects AABB tests, and the getRelative() offset -> 16 B per cell per frustum.
-//   k_cull_spheres    1 wave per 64-sphere chunk: chunk header (scalar load) -> per-lane cell slot via the
-//                     "new cell" bit mask + mbcnt -> 16-B cell-info gather (L2-resident) -> whole-wave early out
-//                     for rejected cells -> 8-plane test -> wave64 ballot compaction into an LDS staging list ->
-//                     ONE global atomic per (tile, frustum) and a coalesced flush of the visible ids.
+//   k_cull_tile      block = one tile of WAVES x CHW x 64 consecutive spheres of the sorted static set.
+//                      0. tile-level box test (tile_status): REJECT ends the block, ACCEPT skips the per-cell work
+//                      A. MIXED tiles: one thread per cell x frustum classifies the tile's cells into LDS (fp64 origin shift,
+//                         the contains / intersects AABB tests, the getRelative() offset)
+//                      B. per wave, autonomous: chunk headers -> per-lane cell -> class from LDS -> ids / spheres fetched only
+//                         when a chunk needs them -> 6-plane test -> per-lane visibility bits
+//                      C. per wave: ONE returning atomic per frustum on the tile's output shard, then the visible ids go
+//                         straight from registers to the reserved range (wave64 ballot + mbcnt ranks)
+//   k_cull_dynamic   one thread per unsorted entity (moving / recently added entities), same arithmetic per entity
+//   k_cull_finalize / k_cull_consolidate   per-type totals and one contiguous list per (frustum, type) for consumers that want it
+//   k_apply_patches  O(1) add / remove / set between culls
 //
 // Built with -ffp-contract=off: the plane arithmetic must round exactly like the reference's scalar float4.
+#include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 
 #include "lmx_kernels.h"
@@ -23,290 +30,238 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
+__device__ __forceinline__ float readlane_f(float v, int lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
 
-template <int F>
-__global__ __launch_bounds__(256) void k_cull_classify(const CellKey* __restrict__ cells, uint32_t cell_begin, uint32_t n,
-	FrustaArg fr, float4* __restrict__ cellinfo, uint32_t cell_stride, uint32_t* __restrict__ counts) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (blockIdx.x == 0 && threadIdx.x < MAX_FRUSTA * MAX_TYPES) counts[threadIdx.x] = 0;
-	if (i >= n) return;
-	const uint32_t c = cell_begin + i;
-	const CellKey key = cells[c];
-	const bool dead = (key.meta & CELL_DEAD) != 0;
-	const bool big = (key.meta & 0x100u) != 0;
-#pragma unroll
-	for (int f = 0; f < F; ++f) {
-		V3 off = V3{0.f, 0.f, 0.f};
-		uint32_t cls = CELL_REJECT;
-		if (!dead) cls = classify_cell(fr.f[f], IV3{key.ix, key.iy, key.iz}, big, &off);
-		cellinfo[(size_t)f * cell_stride + c] = make_float4(off.x, off.y, off.z, __uint_as_float(cls));
+// Everything k_cull_tile needs besides the frusta. The frusta are the FIRST kernel argument (offset 0 of the kernarg segment):
+// the lane-parallel tile test reads plane k's coefficients with a per-lane load from there.
+// (pointers are separate __restrict__ kernel parameters: only then are the wave-uniform loads selected as scalar loads)
+struct TileScalars {
+	TypeTable tt;
+	uint32_t ent_begin, cell_cap, n_frusta;
+	uint32_t out_stride, cnt_pad, cnt_frustum_stride, n_zero;
+};
+
+// float index of DevFrustum members inside the kernarg segment (frustum 0)
+constexpr int KA_NX = 0, KA_NY = 6, KA_NZ = 12, KA_D = 18, KA_ORIGIN = 44;
+static_assert(sizeof(DevFrustum) == 200 && offsetof(DevFrustum, origin) == KA_ORIGIN * 4 && offsetof(DevFrustum, d) == KA_D * 4, "kernarg offsets of DevFrustum");
+
+// tile_status() of lmx_math.h for frustum 0, evaluated across the lanes of a wave: lanes 0..11 form the 12 box-corner
+// coordinates (fp64 shift, one rounding), lanes 0..5 then evaluate one plane each. Same expressions, same rounding, ~50 VALU
+// instructions per wave instead of ~300 uniform ones; on the default camera 95 % of the blocks do nothing else.
+__device__ __forceinline__ uint32_t tile_status_lanes(const TileBox* box, uint32_t lane) {
+	const float* ka = (const float*)__builtin_amdgcn_kernarg_segment_ptr();
+	const int32_t* bi = reinterpret_cast<const int32_t*>(box);
+	const uint32_t flags = (uint32_t)bi[6];
+	const uint32_t a = lane % 3u, kind = (lane / 3u) & 3u;
+	const int32_t idx = bi[(kind & 1u) * 3u + a];
+	const double org = reinterpret_cast<const double*>(ka + KA_ORIGIN)[a];
+	const uint32_t p = (lane & 7u) < 6u ? (lane & 7u) : 5u;
+	const float nx = ka[KA_NX + p], ny = ka[KA_NY + p], nz = ka[KA_NZ + p], d = ka[KA_D + p];
+	if (flags & TILE_EMPTY) return TILE_REJECT;
+	if (flags & TILE_HAS_BIG) return TILE_MIXED;
+	const double cs = (double)CELL_SIZE;
+	const double off = kind == 0u ? -cs : (kind == 3u ? 2 * cs : cs);
+	const float val = (float)(cs * idx + off - org);
+	const float lx = readlane_f(val, 0), ly = readlane_f(val, 1), lz = readlane_f(val, 2);
+	const float hx = readlane_f(val, 3), hy = readlane_f(val, 4), hz = readlane_f(val, 5);
+	const float clx = readlane_f(val, 6), cly = readlane_f(val, 7), clz = readlane_f(val, 8);
+	const float chx = readlane_f(val, 9), chy = readlane_f(val, 10), chz = readlane_f(val, 11);
+	const float b1 = max_f(abs_f(lx), abs_f(chx)) + max_f(abs_f(ly), abs_f(chy)) + max_f(abs_f(lz), abs_f(chz));
+	const float n1 = abs_f(nx) + abs_f(ny) + abs_f(nz);
+	const float margin = max_f(1.0f, n1) * (2.0f + 4e-6f * b1) + 1e-6f * abs_f(d);
+	bool rej, in;
+	{
+		const float bx = nx > 0.0f ? hx : lx, by = ny > 0.0f ? hy : ly, bz = nz > 0.0f ? hz : lz;
+		const float dp = (nx * bx) + (ny * by) + (nz * bz);
+		rej = dp < -d - margin;
 	}
+	{
+		const float bx = nx < 0.0f ? chx : clx, by = ny < 0.0f ? chy : cly, bz = nz < 0.0f ? chz : clz;
+		const float dp = (nx * bx) + (ny * by) + (nz * bz);
+		in = dp > -d + margin;
+	}
+	const bool plane_lane = lane < 6u;
+	if (__ballot(plane_lane && rej) != 0) return TILE_REJECT;
+	return __ballot(plane_lane && !in) == 0 ? TILE_ACCEPT : TILE_MIXED;
 }
 
-// WAVES waves per block, CHW chunks per wave -> TILE = WAVES * CHW * 64 spheres per block.
-template <int F, int WAVES, int CHW>
-__global__ __launch_bounds__(WAVES * 64) void k_cull_spheres(const float4* __restrict__ spheres, const int32_t* __restrict__ ids,
-	const uint32_t* __restrict__ chunk_cell, const uint64_t* __restrict__ chunk_flags, const float4* __restrict__ cellinfo,
-	uint32_t cell_stride, FrustaArg fr, TypeTable tt, uint32_t ent_begin, int32_t* __restrict__ out_ids, uint32_t out_stride,
-	uint32_t* __restrict__ counts) {
-	constexpr int TILE = WAVES * CHW * 64;
-	__shared__ int32_t s_buf[F * TILE];
-	__shared__ uint32_t s_cnt[F];
-	__shared__ uint32_t s_base[F];
+// LDS record of one (cell, frustum): the six cell-relative plane distances of ShiftedFrustum::getRelative and the cell's class
+struct alignas(16) CellInfo { float d[6]; uint32_t cls, pad; };
+static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustum)");
+
+// F == 1: the single-frustum kernel (the common case: one launch per view). F == 0: n_frusta (2..8) is a runtime value and every
+// per-frustum loop is a real loop, so registers do not scale with the number of frusta (8 unrolled copies needed 172 VGPRs and
+// 600 spilled SGPRs); FS is the stride of a chunk's visibility bits.
+template <int F, int WAVES, int CHW, bool LANEPAR>
+__global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg, const float4* __restrict__ g_spheres, const int32_t* __restrict__ g_ids,
+	const ChunkHdr* __restrict__ g_hdr, const CellKey* __restrict__ g_tile_cells, const uint32_t* __restrict__ g_tile_tab, const TileBox* __restrict__ g_tile_box,
+	const uint32_t* __restrict__ g_win_base, int32_t* __restrict__ g_out_ids, uint32_t* __restrict__ g_counts, uint32_t* __restrict__ g_counts_next, const TileScalars a) {
+	constexpr uint32_t TILE = WAVES * CHW * 64;
+	constexpr uint32_t THREADS = WAVES * 64;
+	constexpr int FS = F == 1 ? 1 : MAX_FRUSTA;
+	static_assert(CHW * FS <= 32, "visibility bits of a wave's chunks x frusta live in one register");
+	extern __shared__ CellInfo s_info[]; // [n_frusta * cell_cap] (MIXED tiles only)
+	// the frusta are read through the kernarg segment pointer: uniform scalar loads placed where they are used
+	const DevFrustum* __restrict__ frp = (const DevFrustum*)__builtin_amdgcn_kernarg_segment_ptr();
+	const int nf = F == 1 ? 1 : (int)a.n_frusta;
 
 	const uint32_t lane = lane_id();
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint32_t tile_ent = ent_begin + blockIdx.x * (uint32_t)TILE; // first sphere slot of this tile
-
-	if (threadIdx.x < F) s_cnt[threadIdx.x] = 0;
-	__syncthreads();
-
-	// type of this tile (type ranges are TILE_ALIGN-aligned, so a tile never straddles two types)
-	uint32_t type = 0;
-#pragma unroll
-	for (int t = 0; t < MAX_TYPES; ++t) {
-		if (tile_ent >= tt.ent_start[t] && tile_ent < tt.ent_end[t]) type = t;
-	}
-
-	const uint32_t chunk0 = (tile_ent >> 6) + wave * CHW; // this wave's CHW consecutive chunks
-	const uint64_t le_mask = (~0ull >> (63u - lane)) & ~1ull; // bits 1..lane
-
-	// phase 1: chunk headers (wave-uniform -> scalar loads), per-lane cell slot, cell-info gather
-	uint32_t cell[CHW];
-#pragma unroll
-	for (int i = 0; i < CHW; ++i) {
-		const uint32_t base_cell = chunk_cell[chunk0 + i];
-		const uint64_t flags = chunk_flags[chunk0 + i];
-		cell[i] = base_cell + (uint32_t)__popcll(flags & le_mask);
-	}
-	float4 info[F][CHW];
-#pragma unroll
-	for (int f = 0; f < F; ++f) {
-#pragma unroll
-		for (int i = 0; i < CHW; ++i) info[f][i] = cellinfo[(size_t)f * cell_stride + cell[i]];
-	}
-
-	// phase 2: which chunks need their spheres / ids at all (whole-cell reject costs no sphere traffic)
-	bool need_id[CHW], need_sphere[CHW];
-#pragma unroll
-	for (int i = 0; i < CHW; ++i) {
-		bool any_live = false, any_test = false;
-#pragma unroll
-		for (int f = 0; f < F; ++f) {
-			const uint32_t cls = __float_as_uint(info[f][i].w);
-			any_live |= cls != CELL_REJECT;
-			any_test |= cls == CELL_TEST;
-		}
-		need_id[i] = __ballot(any_live) != 0;     // wave-uniform
-		need_sphere[i] = __ballot(any_test) != 0; // wave-uniform
-	}
-	int32_t id[CHW];
-	float4 sp[CHW];
-#pragma unroll
-	for (int i = 0; i < CHW; ++i) {
-		const uint32_t e = ((chunk0 + i) << 6) + lane;
-		id[i] = -1;
-		sp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-		if (need_id[i]) id[i] = ids[e];
-		if (need_sphere[i]) sp[i] = spheres[e];
-	}
-
-	// phase 3: plane tests + wave ballot compaction into the LDS staging lists
-#pragma unroll
-	for (int i = 0; i < CHW; ++i) {
-		if (!need_id[i]) continue;
-#pragma unroll
-		for (int f = 0; f < F; ++f) {
-			const uint32_t cls = __float_as_uint(info[f][i].w);
-			bool vis = cls == CELL_ACCEPT;
-			if (cls == CELL_TEST) {
-				vis = sphere_visible(fr.f[f], V3{info[f][i].x, info[f][i].y, info[f][i].z}, sp[i].x, sp[i].y, sp[i].z, sp[i].w);
-			}
-			vis = vis && id[i] >= 0;
-			const uint64_t mask = __ballot(vis);
-			if (mask != 0) {
-				uint32_t base = 0;
-				if (lane == 0) base = atomicAdd(&s_cnt[f], (uint32_t)__popcll(mask));
-				base = __builtin_amdgcn_readfirstlane(base);
-				if (vis) s_buf[f * TILE + base + mbcnt64(mask)] = id[i];
-			}
-		}
-	}
-	__syncthreads();
-
-	// one global atomic per (tile, frustum) with anything visible, then a coalesced flush
-	if (threadIdx.x < F) {
-		const uint32_t c = s_cnt[threadIdx.x];
-		s_base[threadIdx.x] = c ? atomicAdd(&counts[threadIdx.x * MAX_TYPES + type], c) : 0u;
-	}
-	__syncthreads();
-#pragma unroll
-	for (int f = 0; f < F; ++f) {
-		const uint32_t c = s_cnt[f];
-		int32_t* dst = out_ids + (size_t)f * out_stride + tt.out_start[type] + s_base[f];
-		for (uint32_t k = threadIdx.x; k < c; k += WAVES * 64) dst[k] = s_buf[f * TILE + k];
-	}
-}
-
-// ---- fused variant: per-tile classification in LDS -----------------------------------------------------------
-// One launch per cull. Cell slots are consecutive along the sphere order, so the cells a tile touches are the range
-// [chunk_cell[first chunk], cell of the tile's last sphere]; the block classifies exactly those cells (one thread per
-// cell x frustum, same arithmetic as k_cull_classify) into LDS, votes whether anything in the tile survives, and only
-// then touches spheres/ids. Compared with classify + spheres this removes a kernel boundary, the 16 B/cell/frustum
-// round trip through global memory and one dependent gather per chunk. Cells straddling two tiles are classified by
-// both (harmless). The host guarantees cell_cap >= cells per tile (layout max) and falls back to the two-kernel path
-// when the LDS budget would not fit.
-template <int F, int WAVES, int CHW>
-__global__ __launch_bounds__(WAVES * 64) void k_cull_fused(const float4* __restrict__ spheres, const int32_t* __restrict__ ids,
-	const uint32_t* __restrict__ chunk_cell, const uint64_t* __restrict__ chunk_flags, const CellKey* __restrict__ tile_cells,
-	const uint32_t* __restrict__ tile_tab, const TileBox* __restrict__ tile_box, FrustaArg fr, TypeTable tt, uint32_t ent_begin, uint32_t cell_cap,
-	int32_t* __restrict__ out_ids, uint32_t out_stride, uint32_t* __restrict__ counts, uint32_t* __restrict__ counts_next) {
-	constexpr int TILE = WAVES * CHW * 64;
-	constexpr int NCH = WAVES * CHW;
-	extern __shared__ float4 s_dyn[]; // [F * cell_cap] cell info | [F * TILE] staged ids | [F] counts | [F] bases
-	float4* s_info = s_dyn;
-	int32_t* s_buf = reinterpret_cast<int32_t*>(s_dyn + (size_t)F * cell_cap);
-	uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_buf + F * TILE);
-	uint32_t* s_base = s_cnt + F;
-
-	const uint32_t lane = lane_id();
-	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint32_t tile_ent = ent_begin + blockIdx.x * (uint32_t)TILE;
-	const uint32_t tile_chunk = tile_ent >> 6;
+	const uint32_t tile_ent = a.ent_begin + blockIdx.x * TILE;
+	const uint32_t tile_index = tile_ent / TILE;
 
 	// the counters of the NEXT cull on this view are cleared here (ping-pong), so no cull needs a separate memset
-	if (counts_next != nullptr && blockIdx.x == 0 && threadIdx.x < MAX_FRUSTA * MAX_TYPES) counts_next[threadIdx.x] = 0;
-	if (threadIdx.x < F) s_cnt[threadIdx.x] = 0;
+	for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < a.n_zero; i += gridDim.x * THREADS) g_counts_next[i] = 0;
 
-	// Everything the block needs first sits at addresses that depend on blockIdx only: {first cell, n cells} of the tile
-	// (scalar load) and the tile's cell keys (tile-major, stride cell_cap) - no dependent round trip before phase A.
-	const uint32_t chunk0 = tile_chunk + wave * CHW;
-	const uint32_t tile_index = tile_ent / (uint32_t)TILE;
-	// tile-level early out: the box of the tile's cell indices against every frustum of the pass (block-uniform; conservative,
-	// see tile_rejected). Most tiles of a large scene end here without touching their ~400 cell keys.
-	{
-		// Low-coverage variant (2048-sphere tiles, chosen when the frustum covers little of the scene): ONE wave evaluates the
-		// test - it is block-uniform, and four copies of ~100 VALU instructions per tile were a third of the kernel's VALU time
-		// when 95 % of the tiles end here - the others wait at the barrier (17.0 -> 14.6 us). Elsewhere few tiles are
-		// rejected and the barrier would only add latency (+3 us with everything visible): every wave evaluates it.
-		if constexpr (F == 1 && WAVES == 4) {
-			__shared__ uint32_t s_tile_rejected;
-			if (wave == 0) {
-				const bool rejected = tile_rejected(fr.f[0], tile_box[tile_index]);
-				if (lane == 0) s_tile_rejected = rejected ? 1u : 0u;
-			}
-			__syncthreads();
-			if (s_tile_rejected) return;
-		} else {
-			const TileBox box = tile_box[tile_index];
-			bool all_rejected = true;
-#pragma unroll
-			for (int f = 0; f < F; ++f) all_rejected = all_rejected && tile_rejected(fr.f[f], box);
-			if (all_rejected) return;
+	// 0. tile-level test per frustum (2 bits each). Everything read here sits at addresses that depend on blockIdx only.
+	uint32_t st_bits = 0;
+	bool any_mixed = false, any_live = false;
+	if constexpr (LANEPAR) {
+		static_assert(F == 1, "the lane-parallel tile test handles one frustum");
+		st_bits = tile_status_lanes(g_tile_box + tile_index, lane);
+		any_mixed = st_bits == TILE_MIXED;
+		any_live = st_bits != TILE_REJECT;
+	} else {
+		const TileBox box = g_tile_box[tile_index];
+#pragma unroll 1
+		for (int f = 0; f < nf; ++f) {
+			const uint32_t st = tile_status(frp[f], box);
+			st_bits |= st << (2 * f);
+			any_mixed |= st == TILE_MIXED;
+			any_live |= st != TILE_REJECT;
 		}
 	}
-	const uint32_t first_cell = tile_tab[2 * tile_index];
-	const uint32_t n_cells = tile_tab[2 * tile_index + 1];
-	const CellKey* keys = tile_cells + (size_t)tile_index * cell_cap;
+	if (!any_live) return;
 
-	// phase A: classify the tile's cells into LDS
-	bool live = false;
-	for (uint32_t t = threadIdx.x; t < cell_cap; t += WAVES * 64) {
-		const CellKey key = keys[t]; // issued before n_cells is known; the tail of the slice holds dead keys
-		if (t < n_cells) {
-			const bool dead = (key.meta & CELL_DEAD) != 0;
-			const bool big = (key.meta & 0x100u) != 0;
+	uint32_t first_cell = 0;
+	if (any_mixed) {
+		// A. classify the tile's cells into LDS: class + the cell-relative plane distances (per cell, as the reference's getRelative)
+		first_cell = g_tile_tab[2 * tile_index];
+		const uint32_t n_cells = g_tile_tab[2 * tile_index + 1];
+		const CellKey* keys = g_tile_cells + (size_t)tile_index * a.cell_cap;
+		for (uint32_t t = threadIdx.x; t < a.cell_cap; t += THREADS) {
+			const CellKey key = keys[t]; // issued before n_cells is known; the tail of the slice holds dead keys
+			if (t < n_cells) {
+				const bool dead = (key.meta & CELL_DEAD) != 0;
+				const bool big = (key.meta & 0x100u) != 0;
+#pragma unroll 1
+				for (int f = 0; f < nf; ++f) {
+					CellInfo ci;
+					ci.cls = CELL_REJECT;
+					ci.pad = 0;
 #pragma unroll
-			for (int f = 0; f < F; ++f) {
-				V3 off = V3{0.f, 0.f, 0.f};
-				uint32_t cls = CELL_REJECT;
-				if (!dead) cls = classify_cell(fr.f[f], IV3{key.ix, key.iy, key.iz}, big, &off);
-				s_info[f * cell_cap + t] = make_float4(off.x, off.y, off.z, __uint_as_float(cls));
-				live |= cls != CELL_REJECT;
+					for (int k = 0; k < 6; ++k) ci.d[k] = 0.f;
+					if (!dead) {
+						V3 off;
+						ci.cls = classify_cell(frp[f], IV3{key.ix, key.iy, key.iz}, big, &off);
+						if (ci.cls == CELL_TEST) {
+#pragma unroll
+							for (int k = 0; k < 6; ++k) ci.d[k] = relative_plane_d(frp[f], off, k);
+						}
+					}
+					s_info[f * a.cell_cap + t] = ci;
+				}
 			}
 		}
+		// one barrier per MIXED tile. (A block-wide vote "does any cell survive" would let such a tile end here, but costs two more
+		// barriers on every MIXED tile; waves whose chunks all sit in rejected cells fall through below without loading anything.)
+		__syncthreads();
 	}
-	if (!__syncthreads_or(live ? 1 : 0)) return; // nothing in this tile survives the per-cell tests
 
+	// the tile's type and output shard (type ranges are TILE_ALIGN-aligned, so a tile never straddles two types)
 	uint32_t type = 0;
 #pragma unroll
 	for (int t = 0; t < MAX_TYPES; ++t) {
-		if (tile_ent >= tt.ent_start[t] && tile_ent < tt.ent_end[t]) type = t;
+		if (tile_ent >= a.tt.ent_start[t] && tile_ent < a.tt.ent_end[t]) type = t;
 	}
+	const uint32_t shard = a.tt.shard_first[type] + ((tile_ent - a.tt.ent_start[type]) / TILE_ALIGN) % a.tt.shard_n[type];
+	const uint32_t win = g_win_base[shard];
 
-	// phase B: per-lane cell, class from LDS, spheres / ids only for chunks that need them. The wave's CHW chunks are
-	// processed in groups of GRP so that at most GRP chunks' worth of cell info / spheres / ids are live in registers
-	// (VGPR count decides how many tiles a CU keeps in flight, and this kernel is latency-bound).
+	// B. this wave's CHW chunks, in groups of GRP so that at most GRP chunks' worth of spheres are live in registers
+	// (VGPR count decides how many tiles a CU keeps in flight)
+	const uint32_t chunk0 = (tile_ent >> 6) + wave * CHW;
 	const uint64_t le_mask = (~0ull >> (63u - lane)) & ~1ull; // bits 1..lane
 	constexpr int GRP = CHW > 4 ? 4 : CHW;
+	int32_t id[CHW];
+	uint32_t vis_bits = 0; // bit i * FS + f: sphere `lane` of chunk i is visible in frustum f
+	uint32_t mine = 0;     // lane f: this wave's visible count for frustum f
 #pragma unroll
 	for (int g = 0; g < CHW; g += GRP) {
 		__builtin_amdgcn_sched_barrier(0); // keep the groups' loads from being hoisted over each other (register peak)
-		float4 info[F][GRP];
+		uint32_t local[GRP];
 		bool need_id[GRP], need_sphere[GRP];
-		uint32_t base_cell[GRP];
-		uint64_t flags[GRP];
 #pragma unroll
 		for (int i = 0; i < GRP; ++i) {
-			base_cell[i] = chunk_cell[chunk0 + g + i];
-			flags[i] = chunk_flags[chunk0 + g + i];
-		}
-#pragma unroll
-		for (int i = 0; i < GRP; ++i) {
-			const uint32_t local = base_cell[i] + (uint32_t)__popcll(flags[i] & le_mask) - first_cell;
-			bool any_live = false, any_test = false;
-#pragma unroll
-			for (int f = 0; f < F; ++f) {
-				info[f][i] = s_info[f * cell_cap + local];
-				const uint32_t cls = __float_as_uint(info[f][i].w);
-				any_live |= cls != CELL_REJECT;
-				any_test |= cls == CELL_TEST;
+			bool lane_live = false, lane_test = false;
+			local[i] = 0;
+			if (any_mixed) {
+				const ChunkHdr h = g_hdr[chunk0 + g + i]; // wave-uniform: one 16-byte scalar load
+				local[i] = h.cell + (uint32_t)__popcll(h.flags & le_mask) - first_cell;
+#pragma unroll 1
+				for (int f = 0; f < nf; ++f) {
+					const uint32_t cls = s_info[f * a.cell_cap + local[i]].cls;
+					lane_live |= cls != CELL_REJECT;
+					lane_test |= cls == CELL_TEST;
+				}
+			} else {
+				lane_live = true; // no frustum is MIXED and at least one is ACCEPT
 			}
-			need_id[i] = __ballot(any_live) != 0;
-			need_sphere[i] = __ballot(any_test) != 0;
+			need_id[i] = __ballot(lane_live) != 0;     // wave-uniform
+			need_sphere[i] = __ballot(lane_test) != 0; // wave-uniform
 		}
-		int32_t id[GRP];
 		float4 sp[GRP];
 #pragma unroll
 		for (int i = 0; i < GRP; ++i) {
 			const uint32_t e = ((chunk0 + g + i) << 6) + lane;
-			id[i] = -1;
+			id[g + i] = -1;
 			sp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-			if (need_id[i]) id[i] = ids[e];
-			if (need_sphere[i]) sp[i] = spheres[e];
+			if (need_id[i]) id[g + i] = g_ids[e];
+			if (need_sphere[i]) sp[i] = g_spheres[e];
 		}
+#pragma unroll 1
+		for (int f = 0; f < nf; ++f) {
+			const uint32_t st = (st_bits >> (2 * f)) & 3u;
 #pragma unroll
-		for (int i = 0; i < GRP; ++i) {
-			if (!need_id[i]) continue;
+			for (int i = 0; i < GRP; ++i) {
+				if (!need_id[i]) continue;
+				bool vis;
+				if (any_mixed) {
+					const CellInfo* ci = &s_info[f * a.cell_cap + local[i]];
+					const uint32_t cls = ci->cls;
+					vis = cls == CELL_ACCEPT;
+					if (cls == CELL_TEST) {
+						float d[6];
 #pragma unroll
-			for (int f = 0; f < F; ++f) {
-				const uint32_t cls = __float_as_uint(info[f][i].w);
-				bool vis = cls == CELL_ACCEPT;
-				if (cls == CELL_TEST) {
-					vis = sphere_visible(fr.f[f], V3{info[f][i].x, info[f][i].y, info[f][i].z}, sp[i].x, sp[i].y, sp[i].z, sp[i].w);
+						for (int k = 0; k < 6; ++k) d[k] = ci->d[k];
+						vis = sphere_visible_d(frp[f], d, sp[i].x, sp[i].y, sp[i].z, sp[i].w);
+					}
+				} else {
+					vis = st == TILE_ACCEPT;
 				}
-				vis = vis && id[i] >= 0;
-				const uint64_t mask = __ballot(vis);
-				if (mask != 0) {
-					uint32_t base = 0;
-					if (lane == 0) base = atomicAdd(&s_cnt[f], (uint32_t)__popcll(mask));
-					base = __builtin_amdgcn_readfirstlane(base);
-					if (vis) s_buf[f * TILE + base + mbcnt64(mask)] = id[i];
-				}
+				vis = vis && id[g + i] >= 0;
+				const uint32_t c = (uint32_t)__popcll(__ballot(vis));
+				mine += lane == (uint32_t)f ? c : 0u;
+				vis_bits |= (vis ? 1u : 0u) << ((g + i) * FS + f);
 			}
 		}
 	}
-	__syncthreads();
-	if (threadIdx.x < F) {
-		const uint32_t c = s_cnt[threadIdx.x];
-		s_base[threadIdx.x] = c ? atomicAdd(&counts[threadIdx.x * MAX_TYPES + type], c) : 0u;
-	}
-	__syncthreads();
+
+	// C. reserve: lane f adds this wave's count for frustum f to the shard's counter (one atomic instruction for all frusta),
+	// then the ids go from registers to the reserved ranges in chunk order
+	uint32_t base_v = 0;
+	if (lane < (uint32_t)nf && mine != 0) base_v = atomicAdd(&g_counts[lane * a.cnt_frustum_stride + shard * a.cnt_pad], mine);
+#pragma unroll 1
+	for (int f = 0; f < nf; ++f) {
+		if (__builtin_amdgcn_readlane(mine, f) == 0) continue;
+		uint32_t run = __builtin_amdgcn_readlane(base_v, f) + win;
+		int32_t* dst = g_out_ids + (size_t)f * a.out_stride;
 #pragma unroll
-	for (int f = 0; f < F; ++f) {
-		const uint32_t c = s_cnt[f];
-		int32_t* dst = out_ids + (size_t)f * out_stride + tt.out_start[type] + s_base[f];
-		for (uint32_t k = threadIdx.x; k < c; k += WAVES * 64) dst[k] = s_buf[f * TILE + k];
+		for (int i = 0; i < CHW; ++i) {
+			const bool v = ((vis_bits >> (i * FS + f)) & 1u) != 0;
+			const uint64_t mask = __ballot(v);
+			if (v) dst[run + mbcnt64(mask)] = id[i];
+			run += (uint32_t)__popcll(mask);
+		}
 	}
 }
 
@@ -314,16 +269,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_fused(const float4* __restr
 // One thread per unsorted entity: cell index, is_big and the cell-relative fp32 position are derived from the fp64 world
 // position exactly like CullingSystemImpl::add / set would (culling_system.cpp:26-30,100,140), the cell is classified per
 // lane (no sharing between lanes: the set is not sorted) and the sphere is tested. ~350 VALU ops per entity and frustum,
-// 36 B per entity: the VALU-heavier, bandwidth-lighter sibling of the sorted path, used only for entities that move.
+// 36 B per entity: the VALU-heavier, bandwidth-lighter sibling of the sorted path, used for entities that move every frame
+// and for entities added since the static set was last compacted.
 constexpr int DYN_THREADS = 256;
 
-// A block handles TILE entities in TILE / 256 batches and stages the visible ids of the whole tile in LDS, so that the
-// global counter sees one atomic per (tile, frustum): the dynamic set is unsorted, visible entities are spread over every
-// block, and a 256-entity granule would put ~4 k returning atomics on one address per million entities.
+// A block handles TILE entities in TILE / 256 batches and stages the visible ids of the whole tile in LDS, so that a shard
+// counter sees one atomic per (tile, frustum): the set is unsorted, visible entities are spread thinly over every block.
 template <int TILE>
 __global__ __launch_bounds__(DYN_THREADS) void k_cull_dynamic(const double* __restrict__ px, const double* __restrict__ py,
 	const double* __restrict__ pz, const float* __restrict__ radius, const int32_t* __restrict__ ids, FrustaArg fr, int n_frusta,
-	TypeTable dyn_tt, uint32_t slot_begin, int32_t* __restrict__ out_ids, uint32_t out_stride, uint32_t* __restrict__ counts) {
+	TypeTable dyn_tt, uint32_t slot_begin, CullOut out) {
 	extern __shared__ int32_t s_stage[]; // [n_frusta][TILE] staged ids | [MAX_FRUSTA] counts | [MAX_FRUSTA] bases
 	uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_stage + n_frusta * TILE);
 	uint32_t* s_base = s_cnt + MAX_FRUSTA;
@@ -334,6 +289,7 @@ __global__ __launch_bounds__(DYN_THREADS) void k_cull_dynamic(const double* __re
 	for (int t = 0; t < MAX_TYPES; ++t) {
 		if (block_slot >= dyn_tt.ent_start[t] && block_slot < dyn_tt.ent_end[t]) type = t;
 	}
+	const uint32_t shard = dyn_tt.shard_first[type] + ((block_slot - dyn_tt.ent_start[type]) / 2048u) % dyn_tt.shard_n[type];
 	if (threadIdx.x < MAX_FRUSTA) s_cnt[threadIdx.x] = 0;
 	__syncthreads();
 	for (uint32_t b = 0; b < TILE / DYN_THREADS; ++b) {
@@ -362,137 +318,136 @@ __global__ __launch_bounds__(DYN_THREADS) void k_cull_dynamic(const double* __re
 	__syncthreads();
 	if ((int)threadIdx.x < n_frusta) {
 		const uint32_t c = s_cnt[threadIdx.x];
-		s_base[threadIdx.x] = c ? atomicAdd(&counts[threadIdx.x * MAX_TYPES + type], c) : 0u;
+		s_base[threadIdx.x] = c ? atomicAdd(&out.counts[threadIdx.x * out.cnt_frustum_stride + shard * out.cnt_pad], c) : 0u;
 	}
 	__syncthreads();
+	const uint32_t win = out.win_base[shard];
 	for (int f = 0; f < n_frusta; ++f) {
 		const uint32_t c = s_cnt[f];
-		int32_t* dst = out_ids + (size_t)f * out_stride + dyn_tt.out_start[type] + s_base[f];
+		int32_t* dst = out.ids + (size_t)f * out.stride + win + s_base[f];
 		for (uint32_t k = threadIdx.x; k < c; k += DYN_THREADS) dst[k] = s_stage[f * TILE + k];
 	}
 }
 
-__global__ __launch_bounds__(256) void k_patch_spheres(float4* __restrict__ spheres, const uint32_t* __restrict__ slot,
-	const float4* __restrict__ value, uint32_t n) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i < n) spheres[slot[i]] = value[i];
+// ---- patches ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_apply_patches(float4* __restrict__ spheres, int32_t* __restrict__ ids, DynDeviceView d,
+	const PatchSphere* __restrict__ ps, uint32_t n_ps, const PatchId* __restrict__ pi, uint32_t n_pi, const PatchDyn* __restrict__ pd, uint32_t n_pd) {
+	uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n_ps) {
+		const PatchSphere p = ps[i];
+		spheres[p.slot] = make_float4(p.x, p.y, p.z, p.radius);
+		return;
+	}
+	i -= n_ps;
+	if (i < n_pi) {
+		const PatchId p = pi[i];
+		ids[p.slot] = p.id;
+		return;
+	}
+	i -= n_pi;
+	if (i < n_pd) {
+		const PatchDyn p = pd[i];
+		d.px[p.slot] = p.px;
+		d.py[p.slot] = p.py;
+		d.pz[p.slot] = p.pz;
+		d.radius[p.slot] = p.radius;
+		d.ids[p.slot] = p.id;
+	}
 }
 
-template <int F>
-hipError_t classify_f(hipStream_t s, const CullDeviceView& v, uint32_t cell_begin, uint32_t n, const FrustaArg& fr, float4* cellinfo,
-	uint32_t cell_stride, uint32_t* counts) {
-	const uint32_t blocks = n ? (n + 255u) / 256u : 1u; // always >= 1 block: block 0 zeroes the counters
-	hipLaunchKernelGGL((k_cull_classify<F>), dim3(blocks), dim3(256), 0, s, v.cells, cell_begin, n, fr, cellinfo, cell_stride, counts);
-	return hipGetLastError();
+// ---- finalize / consolidate ---------------------------------------------------------------------------------------
+// One block per frustum: totals per type and the exclusive prefix of every shard inside its type (serial over <= a few hundred
+// shards per type, one lane per type).
+__global__ __launch_bounds__(64) void k_cull_finalize(const uint32_t* __restrict__ counts, uint32_t cnt_pad, uint32_t cnt_frustum_stride,
+	const uint8_t* __restrict__ shard_type, uint32_t n_shards, uint32_t* __restrict__ totals, uint32_t* __restrict__ pref) {
+	const uint32_t f = blockIdx.x;
+	const uint32_t t = threadIdx.x;
+	if (t >= MAX_TYPES) return;
+	uint32_t run = 0;
+	for (uint32_t s = 0; s < n_shards; ++s) {
+		if (shard_type[s] != t) continue;
+		pref[f * n_shards + s] = run;
+		run += counts[f * cnt_frustum_stride + s * cnt_pad];
+	}
+	totals[f * MAX_TYPES + t] = run;
 }
 
-template <int F, int WAVES, int CHW>
-hipError_t spheres_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
-	const FrustaArg& fr, const float4* cellinfo, uint32_t cell_stride, int32_t* out_ids, uint32_t out_stride, uint32_t* counts) {
-	constexpr uint32_t TILE = WAVES * CHW * 64;
-	static_assert(TILE_ALIGN % TILE == 0, "tiles must not straddle type ranges");
-	const uint32_t tiles = (ent_end - ent_begin) / TILE;
-	if (!tiles) return hipSuccess;
-	hipLaunchKernelGGL((k_cull_spheres<F, WAVES, CHW>), dim3(tiles), dim3(WAVES * 64), 0, s, v.spheres, v.ids, v.chunk_cell,
-		v.chunk_flags, cellinfo, cell_stride, fr, tt, ent_begin, out_ids, out_stride, counts);
-	return hipGetLastError();
+// grid (n_shards, n_frusta, splits): copies shard s of frustum f to its place in the type's contiguous list
+__global__ __launch_bounds__(256) void k_cull_consolidate(const int32_t* __restrict__ src, uint32_t src_stride, const uint32_t* __restrict__ win_base,
+	const uint32_t* __restrict__ counts, uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* __restrict__ shard_type,
+	const uint32_t* __restrict__ type_start, const uint32_t* __restrict__ pref, uint32_t n_shards, int32_t* __restrict__ dst, uint32_t dst_stride) {
+	const uint32_t s = blockIdx.x, f = blockIdx.y;
+	const uint32_t c = counts[f * cnt_frustum_stride + s * cnt_pad];
+	const int32_t* from = src + (size_t)f * src_stride + win_base[s];
+	int32_t* to = dst + (size_t)f * dst_stride + type_start[shard_type[s]] + pref[f * n_shards + s];
+	for (uint32_t k = blockIdx.z * 256u + threadIdx.x; k < c; k += gridDim.z * 256u) to[k] = from[k];
 }
 
-template <int F, int WAVES, int CHW>
-hipError_t fused_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt, const FrustaArg& fr,
-	int32_t* out_ids, uint32_t out_stride, uint32_t* counts, uint32_t* counts_next) {
+template <int F, int WAVES, int CHW, bool LANEPAR>
+hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt, const FrustaArg& fr, int n_frusta,
+	const CullOut& out) {
 	constexpr uint32_t TILE = WAVES * CHW * 64;
 	static_assert(TILE_ALIGN % TILE == 0, "tiles must not straddle type ranges");
 	constexpr int K = TILE == 4096 ? 0 : (TILE == 2048 ? 1 : 2);
 	const uint32_t tiles = (ent_end - ent_begin) / TILE;
 	if (!tiles) return hipSuccess;
-	const uint32_t cell_cap = v.tile_cap[K];
-	const size_t lds = fused_lds_bytes(F, TILE, cell_cap);
-	hipLaunchKernelGGL((k_cull_fused<F, WAVES, CHW>), dim3(tiles), dim3(WAVES * 64), lds, s, v.spheres, v.ids, v.chunk_cell, v.chunk_flags,
-		v.tile_cells[K], v.tile_tab[K], v.tile_box[K], fr, tt, ent_begin, cell_cap, out_ids, out_stride, counts, counts_next);
+	TileScalars a;
+	a.tt = tt;
+	a.ent_begin = ent_begin;
+	a.cell_cap = v.tile_cap[K];
+	a.n_frusta = (uint32_t)n_frusta;
+	a.out_stride = out.stride;
+	a.cnt_pad = out.cnt_pad;
+	a.cnt_frustum_stride = out.cnt_frustum_stride;
+	a.n_zero = out.n_zero;
+	hipLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, LANEPAR>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, fr, v.spheres, v.ids, v.hdr,
+		v.tile_cells[K], v.tile_tab[K], v.tile_box[K], out.win_base, out.ids, out.counts, out.counts_next, a);
 	return hipGetLastError();
 }
 
 } // namespace
 
-uint32_t cull_tile_size(int n_frusta) {
-	static const uint32_t f1_tile = [] { // experiment knob: LMX_CULL_TILE=2048 runs the 1-frustum kernel with 4 waves per block
-		const char* e = getenv("LMX_CULL_TILE"); // 2048 / 4096 force a tile size (8192 is the internal code for "always 4096")
-		return (e && atoi(e) == 2048) ? 2048u : ((e && atoi(e) == 4096) ? 8192u : 4096u);
-	}();
-	return n_frusta <= 1 ? f1_tile : (n_frusta <= 4 ? 2048u : 1024u);
+size_t cull_tile_lds_bytes(int n_frusta, uint32_t cell_cap) { return (size_t)n_frusta * cell_cap * sizeof(CellInfo); }
+
+uint32_t cull_tile_size(int n_frusta, int variant) {
+	if (n_frusta <= 1) return variant == 0 ? 4096u : (variant == 3 ? 1024u : 2048u);
+	return n_frusta <= 4 ? 2048u : 1024u;
 }
 
-size_t fused_lds_bytes(int n_frusta, uint32_t tile, uint32_t cell_cap) {
-	return (size_t)n_frusta * cell_cap * sizeof(float4) + (size_t)n_frusta * tile * sizeof(int32_t) + 2 * MAX_FRUSTA * sizeof(uint32_t);
-}
-
-hipError_t launch_cull_fused(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
-	const FrustaArg& fr, int n_frusta, int32_t* out_ids, uint32_t out_stride, uint32_t* counts, uint32_t* counts_next, bool small_tiles) {
-#define LMX_FUSED(F, W, C) return fused_f<F, W, C>(s, v, ent_begin, ent_end, tt, fr, out_ids, out_stride, counts, counts_next)
-	switch (n_frusta) {
-		case 1:
-			// 2048-sphere tiles when the frustum covers a small part of the scene (few surviving tiles: shorter per-block chain,
-			// 17.9 vs 19.6 us on the 10 M scene), 4096 when much of it is visible (the one returning atomic per block and
-			// list is then the limit: 42 vs 69 us with everything visible)
-			if (cull_tile_size(1) == 2048u || (small_tiles && cull_tile_size(1) != 8192u)) LMX_FUSED(1, 4, 8);
-			LMX_FUSED(1, 8, 8);
-		case 2: LMX_FUSED(2, 8, 4);
-		case 3: LMX_FUSED(3, 8, 4);
-		case 4: LMX_FUSED(4, 8, 4);
-		case 5: LMX_FUSED(5, 4, 4);
-		case 6: LMX_FUSED(6, 4, 4);
-		case 7: LMX_FUSED(7, 4, 4);
-		case 8: LMX_FUSED(8, 4, 4);
-		default: return hipErrorInvalidValue;
+hipError_t launch_cull_tile(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt, const FrustaArg& fr,
+	int n_frusta, const CullOut& out, int variant, bool lane_parallel_status) {
+#define LMX_TILE(F, W, C, L) return tile_f<F, W, C, L>(s, v, ent_begin, ent_end, tt, fr, n_frusta, out)
+	if (n_frusta < 1 || n_frusta > MAX_FRUSTA) return hipErrorInvalidValue;
+	if (n_frusta == 1) {
+		if (lane_parallel_status) {
+			switch (variant) {
+				case 0: LMX_TILE(1, 8, 8, true);
+				case 1: LMX_TILE(1, 4, 8, true);
+				case 2: LMX_TILE(1, 8, 4, true);
+				default: LMX_TILE(1, 4, 4, true);
+			}
+		}
+		switch (variant) {
+			case 0: LMX_TILE(1, 8, 8, false);
+			case 1: LMX_TILE(1, 4, 8, false);
+			case 2: LMX_TILE(1, 8, 4, false);
+			default: LMX_TILE(1, 4, 4, false);
+		}
 	}
-#undef LMX_FUSED
-}
-
-hipError_t launch_cull_classify(hipStream_t s, const CullDeviceView& v, uint32_t cell_begin, uint32_t n, const FrustaArg& fr,
-	int n_frusta, float4* cellinfo, uint32_t cell_stride, uint32_t* counts) {
-	switch (n_frusta) {
-		case 1: return classify_f<1>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
-		case 2: return classify_f<2>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
-		case 3: return classify_f<3>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
-		case 4: return classify_f<4>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
-		case 5: return classify_f<5>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
-		case 6: return classify_f<6>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
-		case 7: return classify_f<7>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
-		case 8: return classify_f<8>(s, v, cell_begin, n, fr, cellinfo, cell_stride, counts);
-		default: return hipErrorInvalidValue;
-	}
-}
-
-hipError_t launch_cull_spheres(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
-	const FrustaArg& fr, int n_frusta, const float4* cellinfo, uint32_t cell_stride, int32_t* out_ids, uint32_t out_stride,
-	uint32_t* counts) {
-#define LMX_SPH(F, W, C) return spheres_f<F, W, C>(s, v, ent_begin, ent_end, tt, fr, cellinfo, cell_stride, out_ids, out_stride, counts)
-	switch (n_frusta) {
-		case 1:
-			if (cull_tile_size(1) == 2048u) LMX_SPH(1, 4, 8);
-			LMX_SPH(1, 8, 8); // TILE 4096, 16 KiB LDS
-		case 2: LMX_SPH(2, 8, 4); // TILE 2048, 16 KiB
-		case 3: LMX_SPH(3, 8, 4); // 24 KiB
-		case 4: LMX_SPH(4, 8, 4); // 32 KiB
-		case 5: LMX_SPH(5, 4, 4); // TILE 1024, 20 KiB
-		case 6: LMX_SPH(6, 4, 4);
-		case 7: LMX_SPH(7, 4, 4);
-		case 8: LMX_SPH(8, 4, 4); // 32 KiB
-		default: return hipErrorInvalidValue;
-	}
-#undef LMX_SPH
+	if (n_frusta <= 4) LMX_TILE(0, 8, 4, false); // 2048-sphere tiles, <= 4 x 32 B of LDS per cell
+	LMX_TILE(0, 4, 4, false);                    // 1024-sphere tiles
+#undef LMX_TILE
 }
 
 uint32_t cull_dynamic_tile(int n_frusta) { return n_frusta <= 2 ? 2048u : (n_frusta <= 4 ? 1024u : 512u); } // <= 16 KiB of staging
 
 hipError_t launch_cull_dynamic(hipStream_t s, const DynDeviceView& d, uint32_t slot_begin, uint32_t slot_end, const TypeTable& dyn_tt,
-	const FrustaArg& fr, int n_frusta, int32_t* out_ids, uint32_t out_stride, uint32_t* counts) {
+	const FrustaArg& fr, int n_frusta, const CullOut& out) {
 	const uint32_t tile = cull_dynamic_tile(n_frusta);
 	const uint32_t blocks = (slot_end - slot_begin) / tile;
 	if (!blocks) return hipSuccess;
 	const size_t lds = (size_t)n_frusta * tile * sizeof(int32_t) + 2 * MAX_FRUSTA * sizeof(uint32_t);
-#define LMX_DYN(T) hipLaunchKernelGGL(k_cull_dynamic<T>, dim3(blocks), dim3(DYN_THREADS), lds, s, d.px, d.py, d.pz, d.radius, d.ids, fr, n_frusta, dyn_tt, slot_begin, out_ids, out_stride, counts)
+#define LMX_DYN(T) hipLaunchKernelGGL(k_cull_dynamic<T>, dim3(blocks), dim3(DYN_THREADS), lds, s, d.px, d.py, d.pz, d.radius, d.ids, fr, n_frusta, dyn_tt, slot_begin, out)
 	if (tile == 2048) LMX_DYN(2048);
 	else if (tile == 1024) LMX_DYN(1024);
 	else LMX_DYN(512);
@@ -500,9 +455,28 @@ hipError_t launch_cull_dynamic(hipStream_t s, const DynDeviceView& d, uint32_t s
 	return hipGetLastError();
 }
 
-hipError_t launch_patch_spheres(hipStream_t s, float4* spheres, const uint32_t* slot, const float4* value, uint32_t n) {
+hipError_t launch_apply_patches(hipStream_t s, float4* spheres, int32_t* ids, const DynDeviceView& d, const PatchSphere* ps, uint32_t n_ps,
+	const PatchId* pi, uint32_t n_pi, const PatchDyn* pd, uint32_t n_pd) {
+	const uint32_t n = n_ps + n_pi + n_pd;
 	if (!n) return hipSuccess;
-	hipLaunchKernelGGL(k_patch_spheres, dim3((n + 255u) / 256u), dim3(256), 0, s, spheres, slot, value, n);
+	hipLaunchKernelGGL(k_apply_patches, dim3((n + 255u) / 256u), dim3(256), 0, s, spheres, ids, d, ps, n_ps, pi, n_pi, pd, n_pd);
+	return hipGetLastError();
+}
+
+hipError_t launch_cull_finalize(hipStream_t s, const uint32_t* counts, uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* shard_type,
+	uint32_t n_shards, uint32_t n_frusta, uint32_t* totals, uint32_t* pref) {
+	if (!n_frusta) return hipSuccess;
+	hipLaunchKernelGGL(k_cull_finalize, dim3(n_frusta), dim3(64), 0, s, counts, cnt_pad, cnt_frustum_stride, shard_type, n_shards, totals, pref);
+	return hipGetLastError();
+}
+
+hipError_t launch_cull_consolidate(hipStream_t s, const int32_t* src, uint32_t src_stride, const uint32_t* win_base, const uint32_t* counts,
+	uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* shard_type, const uint32_t* type_start, const uint32_t* pref, uint32_t n_shards,
+	uint32_t n_frusta, uint32_t max_shard_cap, int32_t* dst, uint32_t dst_stride) {
+	if (!n_frusta || !n_shards) return hipSuccess;
+	const uint32_t splits = std::max(1u, std::min(64u, max_shard_cap / 4096u));
+	hipLaunchKernelGGL(k_cull_consolidate, dim3(n_shards, n_frusta, splits), dim3(256), 0, s, src, src_stride, win_base, counts, cnt_pad, cnt_frustum_stride,
+		shard_type, type_start, pref, n_shards, dst, dst_stride);
 	return hipGetLastError();
 }
 

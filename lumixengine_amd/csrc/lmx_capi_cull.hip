@@ -1,25 +1,31 @@
 // lmx_capi_cull.hip — CullingSystem behind the C ABI (include/lumix_mi355.h, "culling" section).
 //
 // Two resident sets, one visibility function:
-//   * static set   entities nobody moves every frame: host mirror of (cell, cell-relative sphere) per entity, device
-//                  layout sorted by (type, is_big, cell) with chunk headers and tile-major cell keys (lmx_cull_layout.h),
-//                  culled by the fused single-launch kernel (cull_kernels.hip). Structural changes (add / remove / a
-//                  set* that leaves the cell) rebuild the layout at the next cull; in-cell changes patch 16 B.
-//   * dynamic set  entities bound to the world hierarchy (lmx_world_bind_culling): unsorted world position (fp64) +
-//                  radius, refreshed on the device by lmx_world_propagate and culled by k_cull_dynamic, which re-derives
-//                  cell, cell-relative position and per-cell class per entity — what CullingSystem::set + cullInternal
-//                  would compute (culling_system.cpp:225-242, 321-369) — so moving entities are never re-binned.
-// Both kernels append to the same per-type output segments and counters.
+//   * static set   host mirror of (cell, cell-relative sphere) per entity + a device layout sorted by (type, is_big, cell)
+//                  with chunk headers and tile-major cell keys (lmx_cull_layout.h), culled by k_cull_tile. Between two
+//                  compactions the layout only takes O(1) patches: an in-cell move rewrites 16 B, a removal turns the id
+//                  into a tombstone (-1), and an entity that is added or leaves its cell goes to the dynamic set.
+//   * dynamic set  unsorted world position (fp64) + radius per entity: entities bound to the world hierarchy
+//                  (lmx_world_bind_culling, refreshed on the device by lmx_world_propagate) and the overflow of the static
+//                  set. k_cull_dynamic re-derives cell, cell-relative position and per-cell class per entity — what
+//                  CullingSystem::set + cullInternal would compute (culling_system.cpp:225-242, 321-369). Slots are
+//                  stable: add takes a free slot, remove frees one, both cost one 40-byte patch.
+// A compaction (structure rebuild) folds the unbound part of the dynamic set back into the sorted layout once it outgrows a
+// threshold; it is the only operation that costs O(n).
+// Both kernels write to per-shard output windows (see CullOut); k_cull_finalize / k_cull_consolidate turn those into per-type
+// totals and contiguous lists on demand.
 #include "lmx_context.h"
 
 using namespace lmx;
 
 namespace {
 
-static_assert(sizeof(LayoutSphere) == sizeof(float4) && sizeof(LayoutCell) == sizeof(CellKey), "layout PODs mirror the device types");
+static_assert(sizeof(LayoutSphere) == sizeof(float4) && sizeof(LayoutCell) == sizeof(CellKey) && sizeof(LayoutChunkHdr) == sizeof(ChunkHdr), "layout PODs mirror the device types");
 static_assert(LAYOUT_MAX_TYPES == MAX_TYPES && LAYOUT_CHUNK == CHUNK && LAYOUT_TILE_ALIGN == TILE_ALIGN && LAYOUT_CELL_DEAD == CELL_DEAD, "layout constants");
 
-constexpr uint32_t DYN_ALIGN = 2048; // largest k_cull_dynamic tile: a tile never straddles two types
+constexpr uint32_t DYN_ALIGN = 2048;       // largest k_cull_dynamic tile: a tile never straddles two types
+constexpr uint32_t DYN_MAX_SHARDS = 8;     // output shards per type of the dynamic set
+constexpr uint32_t COMPACT_MIN = 1u << 16; // overflow / tombstones tolerated before a compaction is considered at all
 
 enum class Where { NONE, STATIC, DYNAMIC };
 
@@ -36,25 +42,139 @@ Where locate(const CullState& cs, int32_t entity, uint32_t* index) {
 	return Where::NONE;
 }
 
-void mark_patch(CullState& cs, uint32_t rec) {
-	if (cs.structure_dirty || !cs.built) return;
-	const CullRec& r = cs.recs[rec];
-	cs.patch_slot.push_back(cs.rec_slot[rec]);
-	cs.patch_val.push_back(make_float4(r.rel.x, r.rel.y, r.rel.z, r.radius));
+bool layout_live(const CullState& cs) { return cs.built && !cs.structure_dirty; }
+
+// ---- dynamic set: slots and patches -----------------------------------------------------------------------------
+void queue_dyn_patch(CullState& cs, const DynRec& r, bool alive) {
+	if (r.slot == DYN_NO_SLOT || cs.dyn_layout_dirty) return; // the pending rebuild uploads the whole mirror
+	cs.q_dyn.push_back(PatchDyn{r.slot, alive ? r.entity : -1, r.radius, 0u, r.pos[0], r.pos[1], r.pos[2]});
 }
 
+uint32_t take_dyn_slot(CullState& cs, uint8_t type) {
+	if (cs.dyn_layout_dirty) return DYN_NO_SLOT;
+	if (!cs.dyn_free[type].empty()) {
+		const uint32_t s = cs.dyn_free[type].back();
+		cs.dyn_free[type].pop_back();
+		return s;
+	}
+	if (cs.dyn_next[type] < cs.dyn_tt.ent_end[type]) return cs.dyn_next[type]++;
+	cs.dyn_layout_dirty = true; // region full: the next flush reassigns every slot with more room
+	return DYN_NO_SLOT;
+}
+
+void dyn_append(CullState& cs, int32_t entity, uint8_t type, DV3 pos, float radius, bool bound) {
+	if ((size_t)entity >= cs.ent_to_dyn.size()) cs.ent_to_dyn.resize((size_t)entity + 1, -1);
+	cs.ent_to_dyn[entity] = (int32_t)cs.dyn.size();
+	DynRec r{{pos.x, pos.y, pos.z}, radius, entity, take_dyn_slot(cs, type), type, bound};
+	cs.dyn.push_back(r);
+	if (!bound) cs.n_unbound++;
+	queue_dyn_patch(cs, r, true);
+}
+
+void remove_dynamic(CullState& cs, uint32_t idx) {
+	const DynRec r = cs.dyn[idx];
+	queue_dyn_patch(cs, r, false);
+	if (r.slot != DYN_NO_SLOT && !cs.dyn_layout_dirty) cs.dyn_free[r.type].push_back(r.slot);
+	if (!r.bound) cs.n_unbound--;
+	const uint32_t last = (uint32_t)cs.dyn.size() - 1;
+	if (idx != last) {
+		cs.dyn[idx] = cs.dyn[last];
+		cs.ent_to_dyn[cs.dyn[idx].entity] = (int32_t)idx;
+	}
+	cs.dyn.pop_back();
+	cs.ent_to_dyn[r.entity] = -1;
+}
+
+// ---- static set: host mirror ops --------------------------------------------------------------------------------
+void remove_static(CullState& cs, uint32_t rec) { // culling_system.cpp:160-190: the device slot becomes a tombstone
+	const int32_t entity = cs.recs[rec].entity;
+	if (layout_live(cs)) {
+		cs.q_id.push_back(PatchId{cs.rec_slot[rec], -1});
+		cs.n_tombstones++;
+	}
+	const uint32_t last = (uint32_t)cs.recs.size() - 1;
+	if (rec != last) {
+		cs.recs[rec] = cs.recs[last];
+		cs.ent_to_rec[cs.recs[rec].entity] = (int32_t)rec;
+		if (layout_live(cs)) cs.rec_slot[rec] = cs.rec_slot[last];
+	}
+	cs.recs.pop_back();
+	if (layout_live(cs)) cs.rec_slot.pop_back();
+	cs.ent_to_rec[entity] = -1;
+}
+
+// remove(entity); add(entity, type, pos, radius) of culling_system.cpp:201-258 when the cell or the big flag changes
+void readd_static(CullState& cs, uint32_t rec, DV3 pos, float radius) {
+	const CullRec old = cs.recs[rec];
+	if (!layout_live(cs)) {
+		cs.recs[rec] = make_cull_rec(old.entity, old.type, pos, radius);
+		return;
+	}
+	remove_static(cs, rec);
+	dyn_append(cs, old.entity, old.type, pos, radius, false);
+}
+
+void mark_patch(CullState& cs, uint32_t rec) {
+	if (!layout_live(cs)) return;
+	const CullRec& r = cs.recs[rec];
+	cs.q_sphere.push_back(PatchSphere{cs.rec_slot[rec], r.rel.x, r.rel.y, r.rel.z, r.radius});
+}
+
+// What the reference's stored state (cell, cell-relative fp32 position) means as a world position:
+// cell.header.origin + sphere->position (culling_system.cpp:255)
+DV3 stored_position(DV3 pos) {
+	const IV3 idx = cell_of(pos);
+	const DV3 origin = cell_origin(idx);
+	return add(origin, to_v3(sub(pos, origin)));
+}
+
+DynDeviceView dyn_view(const CullState& cs) {
+	DynDeviceView dd;
+	dd.px = cs.dyn_px.p;
+	dd.py = cs.dyn_py.p;
+	dd.pz = cs.dyn_pz.p;
+	dd.radius = cs.dyn_radius.p;
+	dd.ids = cs.dyn_ids.p;
+	dd.n_padded = cs.dyn_padded;
+	return dd;
+}
+
+// Ship the queued patch records: one pinned staging copy, one asynchronous H2D copy, one kernel — no host wait.
 int apply_patches(LmxContext* ctx) {
 	CullState& cs = ctx->cull;
-	if (cs.patch_slot.empty()) return LMX_OK;
-	const size_t n = cs.patch_slot.size();
-	LMX_HIP(ctx, cs.d_patch_slot.reserve(n));
-	LMX_HIP(ctx, cs.d_patch_val.reserve(n));
-	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	LMX_HIP(ctx, hipMemcpy(cs.d_patch_slot.p, cs.patch_slot.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-	LMX_HIP(ctx, hipMemcpy(cs.d_patch_val.p, cs.patch_val.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-	LMX_HIP(ctx, launch_patch_spheres(ctx->stream, cs.spheres.p, cs.d_patch_slot.p, cs.d_patch_val.p, (uint32_t)n));
-	cs.patch_slot.clear();
-	cs.patch_val.clear();
+	const size_t n_ps = cs.q_sphere.size(), n_pi = cs.q_id.size(), n_pd = cs.q_dyn.size();
+	if (!(n_ps + n_pi + n_pd)) return LMX_OK;
+	const size_t b_ps = n_ps * sizeof(PatchSphere), b_pi = n_pi * sizeof(PatchId), b_pd = n_pd * sizeof(PatchDyn);
+	const size_t o_pd = 0, o_ps = (o_pd + b_pd + 15) & ~(size_t)15, o_pi = (o_ps + b_ps + 15) & ~(size_t)15; // PatchDyn needs 8-byte alignment
+	const size_t total = o_pi + b_pi;
+	PatchStaging& st = cs.staging;
+	const uint32_t k = st.next;
+	st.next ^= 1u;
+	if (!st.done[k]) LMX_HIP(ctx, hipEventCreateWithFlags(&st.done[k], hipEventDisableTiming));
+	else LMX_HIP(ctx, hipEventSynchronize(st.done[k])); // the copy that last used this half (two flushes ago) has long finished
+	if (st.cap[k] < total) {
+		if (st.host[k]) LMX_HIP(ctx, hipHostFree(st.host[k]));
+		st.host[k] = nullptr;
+		st.cap[k] = 0;
+		const size_t want = std::max<size_t>(total * 2, 1u << 16);
+		LMX_HIP(ctx, hipHostMalloc(&st.host[k], want, hipHostMallocDefault));
+		st.cap[k] = want;
+	}
+	if (cs.d_patch.cap < total) {
+		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // an earlier patch kernel may still read the old buffer
+		LMX_HIP(ctx, cs.d_patch.reserve(std::max<size_t>(total * 2, 1u << 16)));
+	}
+	char* h = (char*)st.host[k];
+	if (b_pd) memcpy(h + o_pd, cs.q_dyn.data(), b_pd);
+	if (b_ps) memcpy(h + o_ps, cs.q_sphere.data(), b_ps);
+	if (b_pi) memcpy(h + o_pi, cs.q_id.data(), b_pi);
+	LMX_HIP(ctx, hipMemcpyAsync(cs.d_patch.p, h, total, hipMemcpyHostToDevice, ctx->stream));
+	LMX_HIP(ctx, hipEventRecord(st.done[k], ctx->stream));
+	LMX_HIP(ctx, launch_apply_patches(ctx->stream, cs.spheres.p, cs.ids.p, dyn_view(cs), (const PatchSphere*)(cs.d_patch.p + o_ps), (uint32_t)n_ps,
+		(const PatchId*)(cs.d_patch.p + o_pi), (uint32_t)n_pi, (const PatchDyn*)(cs.d_patch.p + o_pd), (uint32_t)n_pd));
+	cs.q_sphere.clear();
+	cs.q_id.clear();
+	cs.q_dyn.clear();
 	return LMX_OK;
 }
 
@@ -68,8 +188,6 @@ int rebuild_static(LmxContext* ctx) {
 	for (int t = 0; t < MAX_TYPES; ++t) {
 		cs.tt.ent_start[t] = lay.ent_start[t];
 		cs.tt.ent_end[t] = lay.ent_end[t];
-		cs.cell_begin[t] = lay.cell_begin[t];
-		cs.cell_end[t] = lay.cell_end[t];
 	}
 	cs.n_padded = (uint32_t)n_padded;
 	cs.n_cells = (uint32_t)lay.cells.size();
@@ -83,18 +201,14 @@ int rebuild_static(LmxContext* ctx) {
 			cs.scene_hi[a] = std::max(cs.scene_hi[a], (double)CELL_SIZE * b.hi[a] + (double)CELL_SIZE);
 		}
 	}
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the buffers below may be reallocated; copies from pageable memory are synchronous anyway
 	LMX_HIP(ctx, cs.spheres.reserve(std::max<size_t>(n_padded, 1)));
 	LMX_HIP(ctx, cs.ids.reserve(std::max<size_t>(n_padded, 1)));
-	LMX_HIP(ctx, cs.chunk_cell.reserve(std::max<size_t>(n_chunks, 1)));
-	LMX_HIP(ctx, cs.chunk_flags.reserve(std::max<size_t>(n_chunks, 1)));
-	LMX_HIP(ctx, cs.cells.reserve(std::max<size_t>(cs.n_cells, 1)));
-	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // synchronous copies from pageable memory: the layout dies with this function
+	LMX_HIP(ctx, cs.hdr.reserve(std::max<size_t>(n_chunks, 1)));
 	if (n_padded) {
 		LMX_HIP(ctx, hipMemcpy(cs.spheres.p, lay.spheres.data(), n_padded * sizeof(float4), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(cs.ids.p, lay.ids.data(), n_padded * sizeof(int32_t), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(cs.chunk_cell.p, lay.chunk_cell.data(), n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(cs.chunk_flags.p, lay.chunk_flags.data(), n_chunks * sizeof(uint64_t), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(cs.cells.p, lay.cells.data(), cs.n_cells * sizeof(CellKey), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(cs.hdr.p, lay.hdr.data(), n_chunks * sizeof(ChunkHdr), hipMemcpyHostToDevice));
 	}
 	for (int k = 0; k < 3; ++k) {
 		cs.tile_cap[k] = lay.tile_cap[k];
@@ -108,14 +222,17 @@ int rebuild_static(LmxContext* ctx) {
 		}
 	}
 	cs.rec_slot.swap(lay.rec_slot);
+	cs.block_live.swap(lay.block_live);
 	cs.structure_dirty = false;
 	cs.built = true;
-	cs.patch_slot.clear();
-	cs.patch_val.clear();
+	cs.n_tombstones = 0;
+	cs.q_sphere.clear();
+	cs.q_id.clear();
 	return LMX_OK;
 }
 
-// (Re)assign device slots of the dynamic set (grouped by type, each type padded to DYN_ALIGN) and upload everything.
+// (Re)assign the device slots of the dynamic set: one region per type, padded to DYN_ALIGN, with room to grow
+// (region = 1.5 x live + one tile), and upload everything.
 int rebuild_dynamic(LmxContext* ctx) {
 	CullState& cs = ctx->cull;
 	const size_t n = cs.dyn.size();
@@ -124,34 +241,35 @@ int rebuild_dynamic(LmxContext* ctx) {
 	size_t padded = 0;
 	for (int t = 0; t < MAX_TYPES; ++t) {
 		cs.dyn_tt.ent_start[t] = (uint32_t)padded;
-		padded += (count_by_type[t] + DYN_ALIGN - 1) / DYN_ALIGN * DYN_ALIGN;
+		if (count_by_type[t]) padded += (count_by_type[t] + count_by_type[t] / 2 + DYN_ALIGN) / DYN_ALIGN * DYN_ALIGN;
 		cs.dyn_tt.ent_end[t] = (uint32_t)padded;
+		cs.dyn_free[t].clear();
 	}
 	if (padded > 0x7fffffffull) return fail(ctx, LMX_ERR_CAPACITY, "too many dynamic spheres (%zu)", n);
 	std::vector<double> px(padded, 0.0), py(padded, 0.0), pz(padded, 0.0);
 	std::vector<float> radius(padded, 0.f);
 	std::vector<int32_t> ids(padded, -1);
-	cs.dyn_slot.assign(n, 0);
 	size_t cursor[MAX_TYPES];
 	for (int t = 0; t < MAX_TYPES; ++t) cursor[t] = cs.dyn_tt.ent_start[t];
 	for (size_t i = 0; i < n; ++i) {
-		const DynRec& r = cs.dyn[i];
+		DynRec& r = cs.dyn[i];
 		const size_t s = cursor[r.type]++;
-		cs.dyn_slot[i] = (uint32_t)s;
+		r.slot = (uint32_t)s;
 		px[s] = r.pos[0];
 		py[s] = r.pos[1];
 		pz[s] = r.pos[2];
 		radius[s] = r.radius;
 		ids[s] = r.entity;
 	}
+	for (int t = 0; t < MAX_TYPES; ++t) cs.dyn_next[t] = (uint32_t)cursor[t];
 	cs.dyn_padded = (uint32_t)padded;
 	const size_t cap = std::max<size_t>(padded, 1);
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	LMX_HIP(ctx, cs.dyn_px.reserve(cap));
 	LMX_HIP(ctx, cs.dyn_py.reserve(cap));
 	LMX_HIP(ctx, cs.dyn_pz.reserve(cap));
 	LMX_HIP(ctx, cs.dyn_radius.reserve(cap));
 	LMX_HIP(ctx, cs.dyn_ids.reserve(cap));
-	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (padded) {
 		LMX_HIP(ctx, hipMemcpy(cs.dyn_px.p, px.data(), padded * sizeof(double), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(cs.dyn_py.p, py.data(), padded * sizeof(double), hipMemcpyHostToDevice));
@@ -160,92 +278,114 @@ int rebuild_dynamic(LmxContext* ctx) {
 		LMX_HIP(ctx, hipMemcpy(cs.dyn_ids.p, ids.data(), padded * sizeof(int32_t), hipMemcpyHostToDevice));
 	}
 	cs.dyn_layout_dirty = false;
-	cs.dyn_values_dirty = false;
+	cs.q_dyn.clear();
 	cs.dyn_generation++;
 	return LMX_OK;
 }
 
-// host-side changes of pos / radius of dynamic entities: re-upload the four value arrays (slots are unchanged)
-int upload_dynamic_values(LmxContext* ctx) {
+// Output shards: per type, the windows of the static set's shards, then those of the dynamic set's. A static window holds
+// exactly the live ids of its blocks; a dynamic window the slots of its tiles.
+int recompute_out_layout(LmxContext* ctx) {
 	CullState& cs = ctx->cull;
-	const size_t padded = cs.dyn_padded;
-	if (padded) {
-		std::vector<double> px(padded, 0.0), py(padded, 0.0), pz(padded, 0.0);
-		std::vector<float> radius(padded, 0.f);
-		for (size_t i = 0; i < cs.dyn.size(); ++i) {
-			const size_t s = cs.dyn_slot[i];
-			px[s] = cs.dyn[i].pos[0];
-			py[s] = cs.dyn[i].pos[1];
-			pz[s] = cs.dyn[i].pos[2];
-			radius[s] = cs.dyn[i].radius;
+	cs.shard_type.clear();
+	cs.win_base.clear();
+	uint32_t off = 0, max_cap = 0;
+	for (int t = 0; t < MAX_TYPES; ++t) {
+		cs.type_start[t] = off;
+		const uint32_t s_blocks = (cs.tt.ent_end[t] - cs.tt.ent_start[t]) / TILE_ALIGN;
+		const uint32_t s_n = std::min(s_blocks, std::max(1u, cs.max_shards));
+		cs.tt.shard_first[t] = (uint32_t)cs.win_base.size();
+		cs.tt.shard_n[t] = s_n;
+		if (s_n) {
+			std::vector<uint32_t> cap(s_n, 0u);
+			const uint32_t b0 = cs.tt.ent_start[t] / TILE_ALIGN;
+			for (uint32_t b = 0; b < s_blocks; ++b) cap[b % s_n] += cs.block_live[b0 + b];
+			for (uint32_t k = 0; k < s_n; ++k) {
+				cs.win_base.push_back(off);
+				cs.shard_type.push_back((uint8_t)t);
+				off += cap[k];
+				max_cap = std::max(max_cap, cap[k]);
+			}
 		}
-		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		LMX_HIP(ctx, hipMemcpy(cs.dyn_px.p, px.data(), padded * sizeof(double), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(cs.dyn_py.p, py.data(), padded * sizeof(double), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(cs.dyn_pz.p, pz.data(), padded * sizeof(double), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(cs.dyn_radius.p, radius.data(), padded * sizeof(float), hipMemcpyHostToDevice));
+		const uint32_t d_blocks = (cs.dyn_tt.ent_end[t] - cs.dyn_tt.ent_start[t]) / DYN_ALIGN;
+		const uint32_t d_n = std::min(d_blocks, DYN_MAX_SHARDS);
+		cs.dyn_tt.shard_first[t] = (uint32_t)cs.win_base.size();
+		cs.dyn_tt.shard_n[t] = d_n;
+		for (uint32_t k = 0; k < d_n; ++k) {
+			const uint32_t cap = ((d_blocks - k + d_n - 1) / d_n) * DYN_ALIGN; // blocks k, k + d_n, ...
+			cs.win_base.push_back(off);
+			cs.shard_type.push_back((uint8_t)t);
+			off += cap;
+			max_cap = std::max(max_cap, cap);
+		}
+		cs.type_cap[t] = off - cs.type_start[t];
 	}
-	cs.dyn_values_dirty = false;
+	cs.out_total = off;
+	cs.n_shards = (uint32_t)cs.win_base.size();
+	cs.max_shard_cap = max_cap;
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	LMX_HIP(ctx, cs.d_win_base.reserve(std::max<size_t>(cs.n_shards, 1)));
+	LMX_HIP(ctx, cs.d_shard_type.reserve(std::max<size_t>(cs.n_shards, 1)));
+	LMX_HIP(ctx, cs.d_type_start.reserve(MAX_TYPES));
+	if (cs.n_shards) {
+		LMX_HIP(ctx, hipMemcpy(cs.d_win_base.p, cs.win_base.data(), cs.n_shards * sizeof(uint32_t), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(cs.d_shard_type.p, cs.shard_type.data(), cs.n_shards, hipMemcpyHostToDevice));
+	}
+	LMX_HIP(ctx, hipMemcpy(cs.d_type_start.p, cs.type_start, sizeof(cs.type_start), hipMemcpyHostToDevice));
+	for (CullView& v : cs.views) {
+		v.valid = v.finalized = v.consolidated = false;
+		v.cnt_words = 0; // counters are re-sized (and zeroed) by the next cull on the view
+	}
 	return LMX_OK;
 }
 
-void recompute_out_layout(CullState& cs) {
-	uint32_t off = 0;
-	for (int t = 0; t < MAX_TYPES; ++t) {
-		cs.tt.out_start[t] = off;
-		cs.dyn_tt.out_start[t] = off;
-		off += (cs.tt.ent_end[t] - cs.tt.ent_start[t]) + (cs.dyn_tt.ent_end[t] - cs.dyn_tt.ent_start[t]);
+// Move the unbound part of the dynamic set back into the static mirror (the next rebuild sorts it in).
+void fold_overflow(CullState& cs) {
+	for (uint32_t i = (uint32_t)cs.dyn.size(); i-- > 0;) {
+		if (cs.dyn[i].bound) continue;
+		const DynRec r = cs.dyn[i];
+		remove_dynamic(cs, i); // swaps the last record into i: already visited
+		if ((size_t)r.entity >= cs.ent_to_rec.size()) cs.ent_to_rec.resize((size_t)r.entity + 1, -1);
+		cs.ent_to_rec[r.entity] = (int32_t)cs.recs.size();
+		cs.recs.push_back(make_cull_rec(r.entity, r.type, DV3{r.pos[0], r.pos[1], r.pos[2]}, r.radius));
 	}
-	cs.out_total = off;
 }
 
-void readd_static(CullState& cs, uint32_t rec, DV3 pos, float radius) { // remove(entity); add(entity, type, pos, radius)
-	const CullRec old = cs.recs[rec];
-	cs.recs[rec] = make_cull_rec(old.entity, old.type, pos, radius);
-	cs.structure_dirty = true;
+bool wants_compaction(const CullState& cs) {
+	if (!layout_live(cs)) return true;
+	const size_t n_static = cs.recs.size();
+	return cs.n_unbound > std::max<size_t>(COMPACT_MIN, n_static / 8) || cs.n_tombstones > std::max<size_t>(COMPACT_MIN, n_static / 4);
 }
 
-void remove_static(CullState& cs, uint32_t rec) {
-	const int32_t entity = cs.recs[rec].entity;
-	const uint32_t last = (uint32_t)cs.recs.size() - 1;
-	if (rec != last) {
-		cs.recs[rec] = cs.recs[last];
-		cs.ent_to_rec[cs.recs[rec].entity] = (int32_t)rec;
+int flush_impl(LmxContext* ctx, bool force_compaction) {
+	CullState& cs = ctx->cull;
+	bool layout_changed = false;
+	if (wants_compaction(cs) || (force_compaction && (cs.n_unbound || cs.n_tombstones))) {
+		if (cs.built && cs.n_unbound) {
+			cs.structure_dirty = true; // from here on the mirror ops below must not queue patches against the old layout
+			fold_overflow(cs);
+		}
+		cs.structure_dirty = true;
+		if (int rc = rebuild_static(ctx)) return rc;
+		layout_changed = true;
 	}
-	cs.recs.pop_back();
-	cs.ent_to_rec[entity] = -1;
-	cs.structure_dirty = true;
-}
-
-void remove_dynamic(CullState& cs, uint32_t idx) {
-	const int32_t entity = cs.dyn[idx].entity;
-	const uint32_t last = (uint32_t)cs.dyn.size() - 1;
-	if (idx != last) {
-		cs.dyn[idx] = cs.dyn[last];
-		cs.ent_to_dyn[cs.dyn[idx].entity] = (int32_t)idx;
+	if (cs.dyn_layout_dirty) {
+		if (int rc = cull_dyn_sync_mirror(ctx)) return rc; // keep what the device refreshed before slots move
+		if (int rc = rebuild_dynamic(ctx)) return rc;
+		layout_changed = true;
 	}
-	cs.dyn.pop_back();
-	cs.ent_to_dyn[entity] = -1;
-	cs.dyn_layout_dirty = true;
-}
-
-// What the reference's stored state (cell, cell-relative fp32 position) means as a world position:
-// cell.header.origin + sphere->position (culling_system.cpp:255)
-DV3 stored_position(DV3 pos) {
-	const IV3 idx = cell_of(pos);
-	const DV3 origin = cell_origin(idx);
-	return add(origin, to_v3(sub(pos, origin)));
+	if (layout_changed) {
+		if (int rc = recompute_out_layout(ctx)) return rc;
+	}
+	return apply_patches(ctx);
 }
 
 CullDeviceView static_view(const CullState& cs) {
 	CullDeviceView v;
 	v.spheres = cs.spheres.p;
 	v.ids = cs.ids.p;
-	v.chunk_cell = cs.chunk_cell.p;
-	v.chunk_flags = cs.chunk_flags.p;
-	v.cells = cs.cells.p;
+	v.hdr = cs.hdr.p;
 	v.n_padded = cs.n_padded;
-	v.n_cells = cs.n_cells;
 	for (int k = 0; k < 3; ++k) {
 		v.tile_cells[k] = cs.tile_cells[k].p;
 		v.tile_tab[k] = cs.tile_tab[k].p;
@@ -259,11 +399,13 @@ CullDeviceView static_view(const CullState& cs) {
 
 namespace lmx {
 
+// dyn[] <- device for the entities lmx_world_propagate refreshes (the host is the only writer of everything else)
 int cull_dyn_sync_mirror(LmxContext* ctx) {
 	CullState& cs = ctx->cull;
 	if (!cs.dyn_mirror_stale) return LMX_OK;
 	cs.dyn_mirror_stale = false;
-	if (cs.dyn_layout_dirty || !cs.dyn_padded) return LMX_OK; // (propagate always flushes first, so slots are current)
+	if (!cs.dyn_padded) return LMX_OK;
+	if (int rc = apply_patches(ctx)) return rc; // host-side sets queued since the refresh are newer than what the device holds
 	const size_t padded = cs.dyn_padded;
 	std::vector<double> px(padded), py(padded), pz(padded);
 	std::vector<float> radius(padded);
@@ -272,12 +414,12 @@ int cull_dyn_sync_mirror(LmxContext* ctx) {
 	LMX_HIP(ctx, hipMemcpy(py.data(), cs.dyn_py.p, padded * sizeof(double), hipMemcpyDeviceToHost));
 	LMX_HIP(ctx, hipMemcpy(pz.data(), cs.dyn_pz.p, padded * sizeof(double), hipMemcpyDeviceToHost));
 	LMX_HIP(ctx, hipMemcpy(radius.data(), cs.dyn_radius.p, padded * sizeof(float), hipMemcpyDeviceToHost));
-	for (size_t i = 0; i < cs.dyn.size(); ++i) {
-		const size_t s = cs.dyn_slot[i];
-		cs.dyn[i].pos[0] = px[s];
-		cs.dyn[i].pos[1] = py[s];
-		cs.dyn[i].pos[2] = pz[s];
-		cs.dyn[i].radius = radius[s];
+	for (DynRec& r : cs.dyn) {
+		if (!r.bound || r.slot == DYN_NO_SLOT || r.slot >= padded) continue;
+		r.pos[0] = px[r.slot];
+		r.pos[1] = py[r.slot];
+		r.pos[2] = pz[r.slot];
+		r.radius = radius[r.slot];
 	}
 	return LMX_OK;
 }
@@ -286,38 +428,55 @@ bool cull_make_dynamic(LmxContext* ctx, int32_t entity) {
 	CullState& cs = ctx->cull;
 	uint32_t idx;
 	const Where w = locate(cs, entity, &idx);
-	if (w == Where::DYNAMIC) return true;
+	if (w == Where::DYNAMIC) {
+		if (!cs.dyn[idx].bound) {
+			cs.dyn[idx].bound = true;
+			cs.n_unbound--;
+		}
+		return true;
+	}
 	if (w != Where::STATIC) return false;
 	const CullRec r = cs.recs[idx];
 	const DV3 pos = add(cell_origin(r.cell), r.rel);
 	remove_static(cs, idx);
-	if ((size_t)entity >= cs.ent_to_dyn.size()) cs.ent_to_dyn.resize((size_t)entity + 1, -1);
-	cs.ent_to_dyn[entity] = (int32_t)cs.dyn.size();
-	cs.dyn.push_back(DynRec{{pos.x, pos.y, pos.z}, r.radius, entity, r.type});
-	cs.dyn_layout_dirty = true;
+	dyn_append(cs, entity, r.type, pos, r.radius, true);
 	return true;
 }
 
-int cull_flush(LmxContext* ctx) {
+void cull_unbind(LmxContext* ctx, int32_t entity) {
 	CullState& cs = ctx->cull;
-	bool layout_changed = false;
-	if (cs.structure_dirty || !cs.built) {
-		if (int rc = rebuild_static(ctx)) return rc;
-		layout_changed = true;
-	} else if (int rc = apply_patches(ctx)) {
-		return rc;
+	uint32_t idx;
+	if (locate(cs, entity, &idx) == Where::DYNAMIC && cs.dyn[idx].bound) {
+		cs.dyn[idx].bound = false;
+		cs.n_unbound++;
 	}
-	if (cs.dyn_layout_dirty) {
-		if (int rc = cull_dyn_sync_mirror(ctx)) return rc; // keep what the device refreshed before slots move
-		if (int rc = rebuild_dynamic(ctx)) return rc;
-		layout_changed = true;
-	} else if (cs.dyn_values_dirty) {
-		if (int rc = upload_dynamic_values(ctx)) return rc;
+}
+
+int cull_flush(LmxContext* ctx) { return flush_impl(ctx, false); }
+
+int cull_view_finalize(LmxContext* ctx, CullView& v) {
+	CullState& cs = ctx->cull;
+	if (v.finalized) return LMX_OK;
+	LMX_HIP(ctx, v.totals.reserve(MAX_FRUSTA * MAX_TYPES));
+	LMX_HIP(ctx, v.pref.reserve(std::max<size_t>((size_t)MAX_FRUSTA * cs.n_shards, 1)));
+	uint32_t* totals = v.ext_counts ? v.ext_counts : v.totals.p;
+	LMX_HIP(ctx, launch_cull_finalize(ctx->stream, v.counts_ptr(), cs.cnt_pad, cs.n_shards * cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, v.n_frusta, totals, v.pref.p));
+	v.finalized = true;
+	return LMX_OK;
+}
+
+int cull_view_consolidate(LmxContext* ctx, CullView& v) {
+	CullState& cs = ctx->cull;
+	if (v.consolidated) return LMX_OK;
+	if (int rc = cull_view_finalize(ctx, v)) return rc;
+	int32_t* dst = v.ext_out;
+	if (!dst) {
+		LMX_HIP(ctx, v.cons.reserve(std::max<size_t>((size_t)v.out_stride * v.n_frusta, 1)));
+		dst = v.cons.p;
 	}
-	if (layout_changed) {
-		recompute_out_layout(cs);
-		for (CullView& v : cs.views) v.valid = false;
-	}
+	LMX_HIP(ctx, launch_cull_consolidate(ctx->stream, v.out.p, v.out_stride, cs.d_win_base.p, v.counts_ptr(), cs.cnt_pad, cs.n_shards * cs.cnt_pad, cs.d_shard_type.p,
+		cs.d_type_start.p, v.pref.p, cs.n_shards, v.n_frusta, cs.max_shard_cap, dst, v.out_stride));
+	v.consolidated = true;
 	return LMX_OK;
 }
 
@@ -336,11 +495,14 @@ int lmx_cull_build(LmxContext* ctx, uint32_t n, const int32_t* entity, const uin
 		max_entity = std::max(max_entity, entity[i]);
 	}
 	cs.recs.clear();
-	cs.recs.reserve(n);
 	cs.dyn.clear();
 	cs.ent_to_dyn.clear();
+	cs.n_unbound = 0;
 	cs.dyn_layout_dirty = true;
 	cs.dyn_mirror_stale = false;
+	cs.q_sphere.clear();
+	cs.q_id.clear();
+	cs.q_dyn.clear();
 	cs.ent_to_rec.assign((size_t)max_entity + 1, -1);
 	cs.structure_dirty = true;
 	for (uint32_t i = 0; i < n; ++i) {
@@ -350,8 +512,11 @@ int lmx_cull_build(LmxContext* ctx, uint32_t n, const int32_t* entity, const uin
 			return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d added twice", entity[i]);
 		}
 		cs.ent_to_rec[entity[i]] = (int32_t)i;
-		cs.recs.push_back(make_cull_rec(entity[i], type[i], DV3{pos_xyz[3 * (size_t)i], pos_xyz[3 * (size_t)i + 1], pos_xyz[3 * (size_t)i + 2]}, radius[i]));
 	}
+	cs.recs.resize(n);
+	parallel_ranges(n, [&](size_t b, size_t e) {
+		for (size_t i = b; i < e; ++i) cs.recs[i] = make_cull_rec(entity[i], type[i], DV3{pos_xyz[3 * i], pos_xyz[3 * i + 1], pos_xyz[3 * i + 2]}, radius[i]);
+	});
 	return cull_flush(ctx);
 }
 
@@ -362,6 +527,10 @@ int lmx_cull_add(LmxContext* ctx, int32_t entity, uint8_t type, const double pos
 	CullState& cs = ctx->cull;
 	uint32_t idx;
 	if (locate(cs, entity, &idx) != Where::NONE) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d already added", entity);
+	if (layout_live(cs)) {
+		dyn_append(cs, entity, type, DV3{pos[0], pos[1], pos[2]}, radius, false); // sorted in by the next compaction
+		return LMX_OK;
+	}
 	if ((size_t)entity >= cs.ent_to_rec.size()) cs.ent_to_rec.resize((size_t)entity + 1, -1);
 	cs.ent_to_rec[entity] = (int32_t)cs.recs.size();
 	cs.recs.push_back(make_cull_rec(entity, type, DV3{pos[0], pos[1], pos[2]}, radius));
@@ -375,10 +544,7 @@ int lmx_cull_remove(LmxContext* ctx, int32_t entity) { // culling_system.cpp:160
 	uint32_t idx;
 	switch (locate(cs, entity, &idx)) {
 		case Where::STATIC: remove_static(cs, idx); break;
-		case Where::DYNAMIC:
-			if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
-			remove_dynamic(cs, idx);
-			break;
+		case Where::DYNAMIC: remove_dynamic(cs, idx); break;
 		case Where::NONE: break;
 	}
 	return LMX_OK;
@@ -404,11 +570,10 @@ int lmx_cull_set(LmxContext* ctx, int32_t entity, const double pos[3], float rad
 			return LMX_OK;
 		}
 		case Where::DYNAMIC: {
-			if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
 			DynRec& r = cs.dyn[idx];
 			r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
 			r.radius = radius;
-			cs.dyn_values_dirty = true;
+			queue_dyn_patch(cs, r, true);
 			return LMX_OK;
 		}
 		case Where::NONE: break;
@@ -435,10 +600,12 @@ int lmx_cull_set_position(LmxContext* ctx, int32_t entity, const double pos[3]) 
 			return LMX_OK;
 		}
 		case Where::DYNAMIC: {
-			if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
+			if (cs.dyn[idx].bound) { // the radius the patch carries must be the one the device last computed
+				if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
+			}
 			DynRec& r = cs.dyn[idx];
 			r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
-			cs.dyn_values_dirty = true;
+			queue_dyn_patch(cs, r, true);
 			return LMX_OK;
 		}
 		case Where::NONE: break;
@@ -462,7 +629,9 @@ int lmx_cull_set_radius(LmxContext* ctx, int32_t entity, float radius) { // cull
 			return LMX_OK;
 		}
 		case Where::DYNAMIC: {
-			if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
+			if (cs.dyn[idx].bound) {
+				if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
+			}
 			DynRec& r = cs.dyn[idx];
 			if (is_big_radius(r.radius) != is_big_radius(radius)) {
 				// the reference re-adds at origin + fp32 relative position, which loses the low bits of the position
@@ -470,7 +639,7 @@ int lmx_cull_set_radius(LmxContext* ctx, int32_t entity, float radius) { // cull
 				r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
 			}
 			r.radius = radius;
-			cs.dyn_values_dirty = true;
+			queue_dyn_patch(cs, r, true);
 			return LMX_OK;
 		}
 		case Where::NONE: break;
@@ -487,7 +656,9 @@ int lmx_cull_get_radius(LmxContext* ctx, int32_t entity, float* out_radius) {
 			if (out_radius) *out_radius = cs.recs[idx].radius;
 			return LMX_OK;
 		case Where::DYNAMIC:
-			if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
+			if (cs.dyn[idx].bound) {
+				if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
+			}
 			if (out_radius) *out_radius = cs.dyn[idx].radius;
 			return LMX_OK;
 		case Where::NONE: break;
@@ -501,23 +672,66 @@ int lmx_cull_is_added(LmxContext* ctx, int32_t entity) {
 	return locate(ctx->cull, entity, &idx) != Where::NONE ? 1 : 0;
 }
 
+// Batched forms of add / remove for hosts that pay per call (ctypes, scripting): same semantics, one ABI crossing.
+int lmx_cull_add_many(LmxContext* ctx, uint32_t n, const int32_t* entity, const uint8_t* type, const double* pos_xyz, const float* radius) {
+	LMX_CHECK_CTX(ctx);
+	if (n && (!entity || !type || !pos_xyz || !radius)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
+	for (uint32_t i = 0; i < n; ++i) {
+		if (int rc = lmx_cull_add(ctx, entity[i], type[i], pos_xyz + 3 * (size_t)i, radius[i])) return rc;
+	}
+	return LMX_OK;
+}
+
+int lmx_cull_set_many(LmxContext* ctx, uint32_t n, const int32_t* entity, const double* pos_xyz, const float* radius) {
+	LMX_CHECK_CTX(ctx);
+	if (n && (!entity || !pos_xyz || !radius)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
+	for (uint32_t i = 0; i < n; ++i) {
+		if (int rc = lmx_cull_set(ctx, entity[i], pos_xyz + 3 * (size_t)i, radius[i])) return rc;
+	}
+	return LMX_OK;
+}
+
+int lmx_cull_remove_many(LmxContext* ctx, uint32_t n, const int32_t* entity) {
+	LMX_CHECK_CTX(ctx);
+	if (n && !entity) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
+	for (uint32_t i = 0; i < n; ++i) {
+		if (int rc = lmx_cull_remove(ctx, entity[i])) return rc;
+	}
+	return LMX_OK;
+}
+
 int lmx_cull_flush(LmxContext* ctx) {
 	LMX_CHECK_CTX(ctx);
 	return cull_flush(ctx);
 }
 
+int lmx_cull_compact(LmxContext* ctx) {
+	LMX_CHECK_CTX(ctx);
+	return flush_impl(ctx, true);
+}
+
 int lmx_cull_stats(LmxContext* ctx, uint32_t* n_entities, uint32_t* n_cells, uint32_t* n_chunks) {
 	LMX_CHECK_CTX(ctx);
-	if (int rc = cull_flush(ctx)) return rc;
+	if (int rc = flush_impl(ctx, true)) return rc; // the cell count below is that of the sorted layout: fold the overflow in first
 	const CullState& cs = ctx->cull;
 	if (n_entities) *n_entities = (uint32_t)(cs.recs.size() + cs.dyn.size());
 	if (n_cells) *n_cells = cs.n_cells - cs.n_dead_cells;
-	if (n_chunks) *n_chunks = cs.out_total / CHUNK;
+	if (n_chunks) *n_chunks = (cs.out_total + CHUNK - 1) / CHUNK;
+	return LMX_OK;
+}
+
+int lmx_cull_update_stats(LmxContext* ctx, uint32_t* n_static, uint32_t* n_dynamic_bound, uint32_t* n_overflow, uint32_t* n_tombstones) {
+	LMX_CHECK_CTX(ctx);
+	const CullState& cs = ctx->cull;
+	if (n_static) *n_static = (uint32_t)cs.recs.size();
+	if (n_dynamic_bound) *n_dynamic_bound = (uint32_t)(cs.dyn.size() - cs.n_unbound);
+	if (n_overflow) *n_overflow = cs.n_unbound;
+	if (n_tombstones) *n_tombstones = cs.n_tombstones;
 	return LMX_OK;
 }
 
 // Share of the scene's bounding box that the frustum's bounding box covers (8 corner points + fp64 origin, geometry.h:102-153):
-// a launch-time hint for the tile size of the 1-frustum kernel, nothing the results depend on.
+// a launch-time hint for the tile shape of the 1-frustum kernel, nothing the results depend on.
 static double frustum_scene_fraction(const CullState& cs, const LmxShiftedFrustum& f) {
 	double frac = 1.0;
 	for (int a = 0; a < 3; ++a) {
@@ -543,95 +757,76 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 	if (int rc = cull_flush(ctx)) return rc;
 	CullState& cs = ctx->cull;
 	CullView& v = cs.views[view];
-	const size_t row = std::max(cs.out_total, 1u);
-	if (v.ext_out) {
-		if (v.ext_out_cap < (size_t)cs.out_total * n_frusta)
-			return fail(ctx, LMX_ERR_CAPACITY, "bound output holds %zu ids, need %zu", v.ext_out_cap, (size_t)cs.out_total * n_frusta);
-	} else {
-		if (!v.counts.p) {
-			LMX_HIP(ctx, v.counts.reserve(2 * MAX_FRUSTA * MAX_TYPES));
-			v.flip = 0;
-			v.next_half_is_zero = false;
-		}
-		LMX_HIP(ctx, v.out.reserve(row * n_frusta));
+	if (v.ext_out && v.ext_out_cap < (size_t)cs.out_total * n_frusta)
+		return fail(ctx, LMX_ERR_CAPACITY, "bound output holds %zu ids, need %zu", v.ext_out_cap, (size_t)cs.out_total * n_frusta);
+	const uint32_t cnt_frustum_stride = cs.n_shards * cs.cnt_pad;
+	const uint32_t cnt_words = std::max(1u, MAX_FRUSTA * cnt_frustum_stride);
+	if (v.cnt_words != cnt_words) { // first cull on this view / the shard layout changed: both halves start from zero
+		LMX_HIP(ctx, v.counts.reserve(2 * (size_t)cnt_words));
+		v.cnt_words = cnt_words;
+		v.flip = 0;
+		LMX_HIP(ctx, hipMemsetAsync(v.counts.p, 0, 2 * (size_t)cnt_words * sizeof(uint32_t), ctx->stream));
+		v.next_half_is_zero = true;
 	}
+	LMX_HIP(ctx, v.out.reserve(std::max<size_t>((size_t)cs.out_total * n_frusta, 1)));
 	v.n_frusta = n_frusta;
-	v.cell_stride = cs.n_cells;
 	v.out_stride = cs.out_total;
+	v.valid = v.finalized = v.consolidated = false;
 	for (int t = 0; t < MAX_TYPES; ++t) {
-		v.out_start[t] = cs.tt.out_start[t];
-		v.out_cap[t] = (cs.tt.ent_end[t] - cs.tt.ent_start[t]) + (cs.dyn_tt.ent_end[t] - cs.dyn_tt.ent_start[t]);
+		v.out_start[t] = cs.type_start[t];
+		v.out_cap[t] = cs.type_cap[t];
 	}
 	FrustaArg fr;
 	memset(&fr, 0, sizeof(fr));
 	for (uint32_t f = 0; f < n_frusta; ++f) fr.f[f] = to_dev_frustum(frusta[f]);
 
-	uint32_t cell_begin = 0, cell_n = cs.n_cells, ent_begin = 0, ent_end = cs.n_padded, dyn_begin = 0, dyn_end = cs.dyn_padded;
+	uint32_t ent_begin = 0, ent_end = cs.n_padded, dyn_begin = 0, dyn_end = cs.dyn_padded;
 	if (type != LMX_TYPE_ALL) {
-		cell_begin = cs.cell_begin[type];
-		cell_n = cs.cell_end[type] - cs.cell_begin[type];
 		ent_begin = cs.tt.ent_start[type];
 		ent_end = cs.tt.ent_end[type];
 		dyn_begin = cs.dyn_tt.ent_start[type];
 		dyn_end = cs.dyn_tt.ent_end[type];
 	}
+	// counters: this cull uses the half the previous one cleared; its first static launch clears the other half
+	v.flip ^= 1u;
+	if (!v.next_half_is_zero) LMX_HIP(ctx, hipMemsetAsync(v.counts_ptr(), 0, (size_t)cnt_words * sizeof(uint32_t), ctx->stream));
+	v.next_half_is_zero = ent_end > ent_begin;
+	CullOut out;
+	out.ids = v.out.p;
+	out.stride = v.out_stride;
+	out.win_base = cs.d_win_base.p;
+	out.counts = v.counts_ptr();
+	out.cnt_pad = cs.cnt_pad;
+	out.cnt_frustum_stride = cnt_frustum_stride;
+	out.counts_next = v.counts_other();
+	out.n_zero = cnt_words;
 	const CullDeviceView dv = static_view(cs);
-	// static set: fused single-launch kernel; the layout bounds the cells per tile so its LDS table always fits. The
-	// classify + spheres pair stays available as an ablation / fallback (LMX_CULL_TWO_KERNELS=1).
-	static const bool force_two_kernels = getenv("LMX_CULL_TWO_KERNELS") != nullptr;
-	bool fused = !force_two_kernels;
-	for (int k = 0; k < 3 && fused; ++k) fused = fused_lds_bytes(k == 0 ? 1 : (k == 1 ? 4 : 8), TILE_ALIGN >> k, cs.tile_cap[k]) <= 64 * 1024;
-	if (fused) {
-		uint32_t* counts_next = nullptr;
-		if (v.ext_counts) {
-			LMX_HIP(ctx, hipMemsetAsync(v.ext_counts, 0, sizeof(uint32_t) * MAX_FRUSTA * MAX_TYPES, ctx->stream));
-		} else {
-			v.flip ^= 1u;
-			if (!v.next_half_is_zero) LMX_HIP(ctx, hipMemsetAsync(v.counts_ptr(), 0, sizeof(uint32_t) * MAX_FRUSTA * MAX_TYPES, ctx->stream));
-			counts_next = v.counts_other();
-			v.next_half_is_zero = ent_end > ent_begin; // block 0 of the launch(es) below clears it
-		}
-		// The kernel is latency-bound, not bandwidth-bound: wide variants (many frusta per pass) hold more state per wave
-		// and run at lower occupancy, so a batch is split into passes of at most `pass_width` frusta.
-		const uint32_t pass_width = cs.pass_width;
-		for (uint32_t f0 = 0; f0 < n_frusta; f0 += pass_width) {
-			const uint32_t fw = std::min(pass_width, n_frusta - f0);
-			FrustaArg sub;
-			memset(&sub, 0, sizeof(sub));
-			for (uint32_t k = 0; k < fw; ++k) sub.f[k] = fr.f[f0 + k];
-			ProfScope ps(ctx, LMX_K_CULL_SPHERES);
-			LMX_HIP(ctx, launch_cull_fused(ctx->stream, dv, ent_begin, ent_end, cs.tt, sub, (int)fw, v.out_ptr() + (size_t)f0 * v.out_stride, v.out_stride,
-				v.counts_ptr() + f0 * MAX_TYPES, counts_next, fw == 1 && frustum_scene_fraction(cs, frusta[f0]) < 0.25));
-		}
-	} else {
-		if (!v.ext_counts) {
-			v.flip ^= 1u;
-			v.next_half_is_zero = false;
-		}
-		LMX_HIP(ctx, v.cellinfo.reserve((size_t)std::max(cs.n_cells, 1u) * n_frusta));
-		{
-			ProfScope ps(ctx, LMX_K_CULL_CLASSIFY);
-			LMX_HIP(ctx, launch_cull_classify(ctx->stream, dv, cell_begin, cell_n, fr, (int)n_frusta, v.cellinfo.p, v.cell_stride, v.counts_ptr()));
-		}
-		{
-			ProfScope ps(ctx, LMX_K_CULL_SPHERES);
-			LMX_HIP(ctx, launch_cull_spheres(ctx->stream, dv, ent_begin, ent_end, cs.tt, fr, (int)n_frusta, v.cellinfo.p, v.cell_stride, v.out_ptr(),
-				v.out_stride, v.counts_ptr()));
-		}
+	// The kernel is latency-bound for small frusta: wide variants (many frusta per pass) hold more state per wave and run at lower
+	// occupancy, so a batch is split into passes of at most `pass_width` frusta.
+	const uint32_t pass_width = cs.pass_width;
+	for (uint32_t f0 = 0; f0 < n_frusta; f0 += pass_width) {
+		const uint32_t fw = std::min(pass_width, n_frusta - f0);
+		FrustaArg sub;
+		memset(&sub, 0, sizeof(sub));
+		for (uint32_t k = 0; k < fw; ++k) sub.f[k] = fr.f[f0 + k];
+		CullOut po = out;
+		po.ids = out.ids + (size_t)f0 * out.stride;
+		po.counts = out.counts + (size_t)f0 * cnt_frustum_stride;
+		int variant = cs.tile_variant;
+		if (variant < 0) variant = (fw == 1 && frustum_scene_fraction(cs, frusta[f0]) < 0.25) ? 1 : 0; // few surviving tiles -> shorter per-block chain
+		ProfScope ps(ctx, LMX_K_CULL_SPHERES);
+		LMX_HIP(ctx, launch_cull_tile(ctx->stream, dv, ent_begin, ent_end, cs.tt, sub, (int)fw, po, variant, cs.lane_parallel));
 	}
-	// dynamic set: appended to the same segments / counters
+	// dynamic set: its own shards of the same rows / counters
 	if (dyn_end > dyn_begin) {
-		DynDeviceView dd;
-		dd.px = cs.dyn_px.p;
-		dd.py = cs.dyn_py.p;
-		dd.pz = cs.dyn_pz.p;
-		dd.radius = cs.dyn_radius.p;
-		dd.ids = cs.dyn_ids.p;
-		dd.n_padded = cs.dyn_padded;
+		CullOut po = out;
+		po.counts_next = nullptr;
+		po.n_zero = 0;
 		ProfScope ps(ctx, LMX_K_CULL_DYNAMIC);
-		LMX_HIP(ctx, launch_cull_dynamic(ctx->stream, dd, dyn_begin, dyn_end, cs.dyn_tt, fr, (int)n_frusta, v.out_ptr(), v.out_stride, v.counts_ptr()));
+		LMX_HIP(ctx, launch_cull_dynamic(ctx->stream, dyn_view(cs), dyn_begin, dyn_end, cs.dyn_tt, fr, (int)n_frusta, po));
 	}
 	v.valid = true;
+	if (v.ext_out) return cull_view_consolidate(ctx, v); // a bound output receives the contiguous form right away
 	return LMX_OK;
 }
 
@@ -642,13 +837,40 @@ int lmx_cull_set_pass_width(LmxContext* ctx, uint32_t frusta_per_pass) {
 	return LMX_OK;
 }
 
+int lmx_cull_set_option(LmxContext* ctx, int option, int value) {
+	LMX_CHECK_CTX(ctx);
+	CullState& cs = ctx->cull;
+	switch (option) {
+		case LMX_CULL_OPT_TILE_VARIANT:
+			if (value < -1 || value > 3) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "tile variant %d not in [-1,3]", value);
+			cs.tile_variant = value;
+			return LMX_OK;
+		case LMX_CULL_OPT_LANE_PARALLEL_TILE_TEST: cs.lane_parallel = value != 0; return LMX_OK;
+		case LMX_CULL_OPT_MAX_SHARDS:
+			if (value < 1 || value > (int)LAYOUT_MAX_SHARDS) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "max shards %d not in [1,%u]", value, LAYOUT_MAX_SHARDS);
+			cs.max_shards = (uint32_t)value;
+			if (cs.built) return recompute_out_layout(ctx);
+			return LMX_OK;
+		case LMX_CULL_OPT_COUNTER_PAD:
+			if (value < 1 || value > 64) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "counter pad %d not in [1,64]", value);
+			cs.cnt_pad = (uint32_t)value;
+			for (CullView& v : cs.views) {
+				v.valid = v.finalized = v.consolidated = false;
+				v.cnt_words = 0;
+			}
+			return LMX_OK;
+		default: return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "unknown cull option %d", option);
+	}
+}
+
 int lmx_cull_counts(LmxContext* ctx, uint32_t view, uint32_t* counts) {
 	LMX_CHECK_CTX(ctx);
 	if (view >= LMX_MAX_VIEWS || !counts) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad view/counts");
 	CullView& v = ctx->cull.views[view];
 	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
+	if (int rc = cull_view_finalize(ctx, v)) return rc;
 	uint32_t all[MAX_FRUSTA * MAX_TYPES];
-	LMX_HIP(ctx, hipMemcpyAsync(all, v.counts_ptr(), sizeof(all), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipMemcpyAsync(all, v.totals_ptr(), sizeof(uint32_t) * v.n_frusta * MAX_TYPES, hipMemcpyDeviceToHost, ctx->stream));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	memcpy(counts, all, sizeof(uint32_t) * v.n_frusta * MAX_TYPES);
 	return LMX_OK;
@@ -660,15 +882,44 @@ int lmx_cull_read(LmxContext* ctx, uint32_t view, uint32_t frustum, uint8_t type
 	CullView& v = ctx->cull.views[view];
 	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
 	if (frustum >= v.n_frusta || type >= MAX_TYPES) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "frustum %u / type %u out of range", frustum, type);
+	if (int rc = cull_view_consolidate(ctx, v)) return rc;
 	uint32_t c = 0;
-	LMX_HIP(ctx, hipMemcpyAsync(&c, v.counts_ptr() + frustum * MAX_TYPES + type, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipMemcpyAsync(&c, v.totals_ptr() + frustum * MAX_TYPES + type, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (out_count) *out_count = c;
 	if (c > v.out_cap[type]) return fail(ctx, LMX_ERR_HIP, "corrupt count %u > %u", c, v.out_cap[type]);
 	if (!out_ids || c == 0) return LMX_OK;
 	if (c > cap) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u ids, got %u", c, cap);
-	LMX_HIP(ctx, hipMemcpyAsync(out_ids, v.out_ptr() + (size_t)frustum * v.out_stride + v.out_start[type], (size_t)c * sizeof(int32_t),
+	LMX_HIP(ctx, hipMemcpyAsync(out_ids, v.cons_ptr() + (size_t)frustum * v.out_stride + v.out_start[type], (size_t)c * sizeof(int32_t),
 		hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+// All types of one frustum with two host waits (totals, then every non-empty type's ids): what the CullResult adapter needs.
+int lmx_cull_read_all(LmxContext* ctx, uint32_t view, uint32_t frustum, int32_t* out_ids, uint32_t cap, uint32_t* out_counts) {
+	LMX_CHECK_CTX(ctx);
+	if (view >= LMX_MAX_VIEWS || !out_counts) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad view / counts");
+	CullView& v = ctx->cull.views[view];
+	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
+	if (frustum >= v.n_frusta) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "frustum %u out of range", frustum);
+	if (int rc = cull_view_consolidate(ctx, v)) return rc;
+	LMX_HIP(ctx, hipMemcpyAsync(out_counts, v.totals_ptr() + frustum * MAX_TYPES, sizeof(uint32_t) * MAX_TYPES, hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	size_t total = 0;
+	for (int t = 0; t < MAX_TYPES; ++t) {
+		if (out_counts[t] > v.out_cap[t]) return fail(ctx, LMX_ERR_HIP, "corrupt count %u > %u", out_counts[t], v.out_cap[t]);
+		total += out_counts[t];
+	}
+	if (!total) return LMX_OK;
+	if (!out_ids || total > cap) return fail(ctx, LMX_ERR_CAPACITY, "need room for %zu ids, got %u", total, cap);
+	size_t at = 0;
+	for (int t = 0; t < MAX_TYPES; ++t) {
+		if (!out_counts[t]) continue;
+		LMX_HIP(ctx, hipMemcpyAsync(out_ids + at, v.cons_ptr() + (size_t)frustum * v.out_stride + v.out_start[t], (size_t)out_counts[t] * sizeof(int32_t),
+			hipMemcpyDeviceToHost, ctx->stream));
+		at += out_counts[t];
+	}
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return LMX_OK;
 }
@@ -682,7 +933,7 @@ int lmx_cull_bind_output(LmxContext* ctx, uint32_t view, void* d_ids, size_t ids
 	v.ext_out = (int32_t*)d_ids;
 	v.ext_out_cap = d_ids ? ids_capacity : 0;
 	v.ext_counts = (uint32_t*)d_counts;
-	v.valid = false;
+	v.valid = v.finalized = v.consolidated = false;
 	return LMX_OK;
 }
 
@@ -693,10 +944,27 @@ int lmx_cull_device_result(LmxContext* ctx, uint32_t view, uint32_t frustum, con
 	CullView& v = ctx->cull.views[view];
 	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
 	if (frustum >= v.n_frusta) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "frustum %u out of range", frustum);
-	if (d_ids) *d_ids = v.out_ptr() + (size_t)frustum * v.out_stride;
-	if (d_counts) *d_counts = v.counts_ptr();
+	if (int rc = cull_view_consolidate(ctx, v)) return rc;
+	if (d_ids) *d_ids = v.cons_ptr() + (size_t)frustum * v.out_stride;
+	if (d_counts) *d_counts = v.totals_ptr();
 	if (type_offsets) memcpy(type_offsets, v.out_start, sizeof(v.out_start));
 	if (capacity) *capacity = v.out_stride;
+	return LMX_OK;
+}
+
+int lmx_cull_device_shards(LmxContext* ctx, uint32_t view, uint32_t frustum, LmxCullShards* out) {
+	LMX_CHECK_CTX(ctx);
+	if (view >= LMX_MAX_VIEWS || !out) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad view / out");
+	CullState& cs = ctx->cull;
+	CullView& v = cs.views[view];
+	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
+	if (frustum >= v.n_frusta) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "frustum %u out of range", frustum);
+	out->d_ids = v.out.p + (size_t)frustum * v.out_stride;
+	out->d_counts = v.counts_ptr() + (size_t)frustum * cs.n_shards * cs.cnt_pad;
+	out->count_stride = cs.cnt_pad;
+	out->d_window_start = cs.d_win_base.p;
+	out->d_shard_type = cs.d_shard_type.p;
+	out->n_shards = cs.n_shards;
 	return LMX_OK;
 }
 

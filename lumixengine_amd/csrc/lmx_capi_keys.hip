@@ -228,8 +228,9 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	d.group_values = ks.d_group_values.p;
 	d.poses = ks.d_poses.p; d.dirty_list = ks.d_dirty_list.p; d.cap_list = mesh_cap;
 	d.counters = ks.d_counters.p;
-	const int32_t* row = v.out_ptr() + (size_t)frustum * v.out_stride;
-	const uint32_t* counts = v.counts_ptr() + (size_t)frustum * MAX_TYPES;
+	if (int rc = cull_view_consolidate(ctx, v)) return rc; // the key kernels walk one contiguous list per type
+	const int32_t* row = v.cons_ptr() + (size_t)frustum * v.out_stride;
+	const uint32_t* counts = v.totals_ptr() + (size_t)frustum * MAX_TYPES;
 	LMX_HIP(ctx, launch_keys(ctx->stream, d, hv, row + v.out_start[LMX_TYPE_MESH], counts + LMX_TYPE_MESH, mesh_cap, row + v.out_start[LMX_TYPE_DECAL],
 		counts + LMX_TYPE_DECAL, decal_cap, row + v.out_start[LMX_TYPE_CURVE_DECAL], counts + LMX_TYPE_CURVE_DECAL, curve_cap));
 	ks.max_sort_key = max_sort_key;

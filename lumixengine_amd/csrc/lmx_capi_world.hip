@@ -216,7 +216,10 @@ int lmx_world_bind_culling(LmxContext* ctx, uint32_t n, const int32_t* entity, c
 		if (entity[i] < 0 || (uint32_t)entity[i] >= w.n) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity[%u] = %d out of range", i, entity[i]);
 		if (!lmx_cull_is_added(ctx, entity[i])) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d is not in the culling system", entity[i]);
 	}
-	// bound entities move every frame: they live in the culling system's dynamic (unsorted) set from now on
+	// bound entities move every frame: they live in the culling system's dynamic (unsorted) set from now on; entities of the
+	// previous binding that are not bound again keep their last refreshed sphere and rejoin the sorted set at its next compaction
+	if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
+	for (int32_t e : w.bound_entity) cull_unbind(ctx, e);
 	for (uint32_t i = 0; i < n; ++i) {
 		if (!cull_make_dynamic(ctx, entity[i])) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d is not in the culling system", entity[i]);
 	}
@@ -238,7 +241,7 @@ static int world_upload_binding(LmxContext* ctx) {
 		if ((size_t)e >= cs.ent_to_dyn.size() || cs.ent_to_dyn[e] < 0)
 			return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bound entity %d was removed from the culling system; call lmx_world_bind_culling again", e);
 		slot[i] = (uint32_t)w.slot_of_entity[e];
-		dyn[i] = cs.dyn_slot[cs.ent_to_dyn[e]];
+		dyn[i] = cs.dyn[cs.ent_to_dyn[e]].slot;
 	}
 	LMX_HIP(ctx, w.d_bound_slot.reserve(std::max<size_t>(n, 1)));
 	LMX_HIP(ctx, w.d_bound_dyn.reserve(std::max<size_t>(n, 1)));
@@ -270,8 +273,7 @@ int lmx_world_propagate(LmxContext* ctx) {
 			LMX_HIP(ctx, launch_sphere_refresh(ctx->stream, dev, w.d_bound_slot.p, w.d_bound_dyn.p, w.d_bound_radius.p, cs.dyn_px.p, cs.dyn_py.p,
 				cs.dyn_pz.p, cs.dyn_radius.p, (uint32_t)w.bound_entity.size()));
 		}
-		cs.dyn_mirror_stale = true; // the device copy of the dynamic set is now newer than the host mirror
-		cs.dyn_values_dirty = false;
+		cs.dyn_mirror_stale = true; // the device copy of the bound entities is now newer than the host mirror
 	}
 	return LMX_OK;
 }

@@ -43,25 +43,29 @@ template <typename T> struct DevBuf {
 };
 
 struct CullView {
-	DevBuf<float4> cellinfo; // two-kernel path only
-	DevBuf<int32_t> out;
-	DevBuf<uint32_t> counts;
+	DevBuf<int32_t> out;      // raw result: [n_frusta][out_total], one window per output shard
+	DevBuf<uint32_t> counts;  // [2][cnt_words] shard counters, double-buffered: the cull kernel clears the half the NEXT cull uses
+	DevBuf<uint32_t> totals;  // [MAX_FRUSTA][MAX_TYPES] visible ids per (frustum, type)            (k_cull_finalize)
+	DevBuf<uint32_t> pref;    // [MAX_FRUSTA][n_shards] offset of a shard inside its type's contiguous list (k_cull_finalize)
+	DevBuf<int32_t> cons;     // [n_frusta][out_total] one contiguous list per (frustum, type)       (k_cull_consolidate)
 	uint32_t n_frusta = 0;
 	uint32_t out_stride = 0;
-	uint32_t cell_stride = 0;
+	uint32_t cnt_words = 0;   // words per half of `counts`
 	uint32_t out_start[MAX_TYPES] = {};
 	uint32_t out_cap[MAX_TYPES] = {};
-	bool valid = false;
-	// caller-owned result buffers (lmx_cull_bind_output)
+	bool valid = false;       // holds a cull result
+	bool finalized = false;   // totals / pref are current for that result
+	bool consolidated = false;
+	// caller-owned buffers for the CONSOLIDATED result (lmx_cull_bind_output)
 	int32_t* ext_out = nullptr;
 	size_t ext_out_cap = 0;
 	uint32_t* ext_counts = nullptr;
-	// library-owned counters are double-buffered: the fused kernel clears the half the NEXT cull will use
 	uint32_t flip = 0;
 	bool next_half_is_zero = false;
-	int32_t* out_ptr() const { return ext_out ? ext_out : out.p; }
-	uint32_t* counts_ptr() const { return ext_counts ? ext_counts : counts.p + flip * (MAX_FRUSTA * MAX_TYPES); }
-	uint32_t* counts_other() const { return counts.p + (flip ^ 1u) * (MAX_FRUSTA * MAX_TYPES); }
+	uint32_t* counts_ptr() const { return counts.p + flip * cnt_words; }
+	uint32_t* counts_other() const { return counts.p + (flip ^ 1u) * cnt_words; }
+	const int32_t* cons_ptr() const { return ext_out ? ext_out : cons.p; }
+	const uint32_t* totals_ptr() const { return ext_counts ? ext_counts : totals.p; }
 };
 
 // One entity of the dynamic set (see DynDeviceView): what CullingSystem::set(entity, pos, radius) was last called with.
@@ -69,7 +73,25 @@ struct DynRec {
 	double pos[3];
 	float radius;
 	int32_t entity;
+	uint32_t slot;  // device slot, DYN_NO_SLOT until the next rebuild_dynamic when the type's region was full
 	uint8_t type;
+	bool bound;     // refreshed on the device by lmx_world_propagate (never folded back into the static set)
+};
+constexpr uint32_t DYN_NO_SLOT = 0xffffffffu;
+
+// Pinned host staging buffer for the patch records of one flush, double-buffered (the host refills one half while the copy of
+// the other may still be in flight).
+struct PatchStaging {
+	void* host[2] = {nullptr, nullptr};
+	size_t cap[2] = {0, 0};
+	hipEvent_t done[2] = {nullptr, nullptr};
+	uint32_t next = 0;
+	~PatchStaging() {
+		for (int i = 0; i < 2; ++i) {
+			if (host[i]) (void)hipHostFree(host[i]);
+			if (done[i]) (void)hipEventDestroy(done[i]);
+		}
+	}
 };
 
 struct CullState {
@@ -77,42 +99,55 @@ struct CullState {
 	std::vector<CullRec> recs;
 	std::vector<int32_t> ent_to_rec; // entity -> index into recs, or -1
 	std::vector<uint32_t> rec_slot;  // rec -> device sphere slot, valid while !structure_dirty
-	bool structure_dirty = false;
+	bool structure_dirty = false;    // the device layout must be rebuilt from recs (first build / compaction)
 	bool built = false;
-	std::vector<uint32_t> patch_slot;
-	std::vector<float4> patch_val;
-	DevBuf<uint32_t> d_patch_slot;
-	DevBuf<float4> d_patch_val;
+	uint32_t n_tombstones = 0;       // slots of the device layout whose entity was removed or moved to the dynamic set
 	DevBuf<float4> spheres;
 	DevBuf<int32_t> ids;
-	DevBuf<uint32_t> chunk_cell;
-	DevBuf<uint64_t> chunk_flags;
-	DevBuf<CellKey> cells;
+	DevBuf<ChunkHdr> hdr;
 	DevBuf<CellKey> tile_cells[3];
 	DevBuf<uint32_t> tile_tab[3];
 	DevBuf<TileBox> tile_box[3];
 	uint32_t tile_cap[3] = {16, 16, 16};
 	uint32_t n_padded = 0, n_cells = 0, n_dead_cells = 0;
 	uint32_t max_tile_cells[3] = {0, 0, 0};
+	std::vector<uint32_t> block_live; // live ids per TILE_ALIGN-slot block at build time (capacity of the output shards)
 	double scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0}; // world-space box of the static set's occupied cells
 	TypeTable tt = {};
-	uint32_t cell_begin[MAX_TYPES] = {}, cell_end[MAX_TYPES] = {};
-	// ---- dynamic set: entities bound to the world hierarchy, unsorted -----------------------------------------
+	// ---- dynamic set: entities bound to the world hierarchy + entities added / re-celled since the last compaction ----
 	std::vector<DynRec> dyn;
 	std::vector<int32_t> ent_to_dyn;  // entity -> index into dyn, or -1
-	std::vector<uint32_t> dyn_slot;   // dyn rec -> device slot, valid while !dyn_layout_dirty
-	bool dyn_layout_dirty = false;    // membership changed: slots must be reassigned
-	bool dyn_values_dirty = false;    // host changed pos / radius of a dynamic entity
-	bool dyn_mirror_stale = false;    // the device refreshed pos / radius (lmx_world_propagate): dyn[] is older
+	uint32_t n_unbound = 0;           // dyn records that are not bound to the hierarchy (folded into the static set by a compaction)
+	bool dyn_layout_dirty = false;    // a type's region is full (or the set was reset): regions / slots must be reassigned
+	bool dyn_mirror_stale = false;    // the device refreshed pos / radius of bound entities (lmx_world_propagate): dyn[] is older
 	DevBuf<double> dyn_px, dyn_py, dyn_pz;
 	DevBuf<float> dyn_radius;
 	DevBuf<int32_t> dyn_ids;
 	uint32_t dyn_padded = 0;
 	TypeTable dyn_tt = {};
-	uint64_t dyn_generation = 0; // bumped whenever dyn_slot changes (world binding tables depend on it)
-	// ---- shared ---------------------------------------------------------------------------------------------
-	uint32_t pass_width = 1; // frusta tested per pass over the static set (lmx_cull_set_pass_width)
-	uint32_t out_total = 0; // ids per frustum row = sum over types of (static padded + dynamic padded)
+	uint32_t dyn_next[MAX_TYPES] = {};           // first never-used slot of the type's region
+	std::vector<uint32_t> dyn_free[MAX_TYPES];   // slots freed by removals
+	uint64_t dyn_generation = 0; // bumped whenever slots are reassigned (world binding tables depend on it)
+	// ---- O(1) updates between culls ---------------------------------------------------------------------------
+	std::vector<PatchSphere> q_sphere;
+	std::vector<PatchId> q_id;
+	std::vector<PatchDyn> q_dyn;
+	DevBuf<char> d_patch;
+	PatchStaging staging;
+	// ---- output shards ----------------------------------------------------------------------------------------
+	uint32_t n_shards = 0, max_shard_cap = 0;
+	std::vector<uint8_t> shard_type;
+	std::vector<uint32_t> win_base;
+	DevBuf<uint32_t> d_win_base, d_type_start;
+	DevBuf<uint8_t> d_shard_type;
+	uint32_t type_start[MAX_TYPES] = {}, type_cap[MAX_TYPES] = {};
+	// ---- tuning (lmx_cull_set_option) -------------------------------------------------------------------------
+	uint32_t pass_width = 1;   // frusta tested per pass over the static set
+	int tile_variant = -1;     // -1: chosen per cull from the frustum's coverage of the scene
+	bool lane_parallel = true; // tile-level box test evaluated one plane per lane (1-frustum kernels)
+	uint32_t max_shards = LAYOUT_MAX_SHARDS; // output shards per type of the static set
+	uint32_t cnt_pad = 32;     // words between shard counters (32 = one 128-byte line each)
+	uint32_t out_total = 0;    // ids per frustum row = sum of the shard capacities
 	CullView views[LMX_MAX_VIEWS];
 };
 
@@ -281,7 +316,10 @@ int fail(LmxContext* ctx, int code, const char* fmt, ...); // records the messag
 void prof_drain(LmxContext* ctx);
 int cull_flush(LmxContext* ctx);          // lmx_capi_cull.hip: make the device copy of the culling sets current
 int cull_dyn_sync_mirror(LmxContext* ctx); // dyn[] <- device when lmx_world_propagate refreshed it
-bool cull_make_dynamic(LmxContext* ctx, int32_t entity); // move an entity from the static to the dynamic set
+bool cull_make_dynamic(LmxContext* ctx, int32_t entity); // move an entity to the dynamic set and mark it as bound to the hierarchy
+void cull_unbind(LmxContext* ctx, int32_t entity);       // the entity is no longer refreshed by lmx_world_propagate
+int cull_view_finalize(LmxContext* ctx, CullView& v);    // per-type totals of the view's result
+int cull_view_consolidate(LmxContext* ctx, CullView& v); // + one contiguous id list per (frustum, type)
 
 #define LMX_HIP(ctx, expr)                                                                                             \
 	do {                                                                                                               \

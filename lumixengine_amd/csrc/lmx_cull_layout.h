@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
+#include <thread>
 #include <vector>
 
 #include "lmx_math.h"
@@ -40,19 +42,25 @@ struct CullRec { // host mirror of one Sphere + its CellIndices (culling_system.
 
 struct LayoutSphere { float x, y, z, radius; };
 struct LayoutCell { int32_t ix, iy, iz; uint32_t meta; }; // meta = type | is_big << 8 | LAYOUT_CELL_DEAD
+// Header of one 64-sphere chunk: cell slot of its first sphere + bit l = "sphere l starts the next cell" (one 16-byte scalar load)
+struct LayoutChunkHdr { uint32_t cell, pad; uint64_t flags; };
+// The visible ids of a type are written to up to LAYOUT_MAX_SHARDS windows ("shards"): the 4096-slot block b of a type reserves
+// its output in shard b % n_shards of that type, so the returning atomics of one cull spread over that many counters instead of
+// serialising on one address (~88 per microsecond chip-wide on gfx950). A window's capacity is the number of live ids its blocks hold.
+constexpr uint32_t LAYOUT_MAX_SHARDS = 64;
 
 struct CullLayout {
 	std::vector<LayoutSphere> spheres; // [n_padded]
 	std::vector<int32_t> ids;          // [n_padded]
 	std::vector<uint32_t> slot_cell;   // [n_padded]
 	std::vector<LayoutCell> cells;     // [n_cells] (including one dead cell per present type)
-	std::vector<uint32_t> chunk_cell;  // [n_padded / 64]
-	std::vector<uint64_t> chunk_flags; // [n_padded / 64]
+	std::vector<LayoutChunkHdr> hdr;   // [n_padded / 64]
 	std::vector<uint32_t> rec_slot;    // [recs] -> sphere slot
 	uint32_t ent_start[LAYOUT_MAX_TYPES], ent_end[LAYOUT_MAX_TYPES];
 	uint32_t cell_begin[LAYOUT_MAX_TYPES], cell_end[LAYOUT_MAX_TYPES];
 	uint32_t n_padded = 0;
 	uint32_t n_dead_cells = 0; // dead entries inside `cells`
+	std::vector<uint32_t> block_live;  // [n_padded / LAYOUT_TILE_ALIGN] live ids per block (capacities of the output shards)
 	// max number of distinct cell slots touched by one tile, for tile sizes 4096 / 2048 / 1024 spheres (fused kernel LDS)
 	uint32_t max_tile_cells[3] = {0, 0, 0};
 	// Per tile-size variant k (tile = 4096 >> k): the cell keys each tile touches, stored tile-major with a fixed stride
@@ -96,7 +104,6 @@ inline DevFrustum to_dev_frustum(const LmxShiftedFrustum& f) {
 	return d;
 }
 
-// returns false when the set does not fit the 31-bit slot space
 // bits of a 21-bit value spread to every third bit (bit i -> bit 3 i)
 inline uint64_t spread3(uint64_t x) {
 	x &= 0x1fffffull;
@@ -108,23 +115,71 @@ inline uint64_t spread3(uint64_t x) {
 	return x;
 }
 
+// ---- small host-side parallel helpers (scene load / layout rebuild of 10^7..10^8 spheres) ------------------------------
+inline unsigned layout_threads(size_t n) {
+	if (n < (1u << 18)) return 1;
+	const unsigned hw = std::thread::hardware_concurrency();
+	return std::max(1u, std::min(hw ? hw : 1u, 32u));
+}
+template <typename Fn> inline void parallel_ranges(size_t n, Fn fn) { // fn(begin, end) over a partition of [0, n)
+	const unsigned t = layout_threads(n);
+	if (t <= 1) {
+		fn((size_t)0, n);
+		return;
+	}
+	std::vector<std::thread> th;
+	th.reserve(t);
+	for (unsigned k = 0; k < t; ++k) th.emplace_back([=] { fn(n * k / t, n * (k + 1) / t); });
+	for (std::thread& x : th) x.join();
+}
+template <typename T, typename Less> inline void parallel_sort(std::vector<T>& v, Less less) {
+	const size_t n = v.size();
+	unsigned t = layout_threads(n);
+	unsigned parts = 1;
+	while (parts * 2 <= t) parts *= 2;
+	if (parts <= 1) {
+		std::sort(v.begin(), v.end(), less);
+		return;
+	}
+	{
+		std::vector<std::thread> th;
+		for (unsigned k = 0; k < parts; ++k) th.emplace_back([&v, n, k, parts, less] { std::sort(v.begin() + n * k / parts, v.begin() + n * (k + 1) / parts, less); });
+		for (std::thread& x : th) x.join();
+	}
+	std::vector<T> tmp(n);
+	std::vector<T>*src = &v, *dst = &tmp;
+	for (unsigned width = 1; width < parts; width *= 2) { // pairwise merges of sorted runs, one thread per pair
+		std::vector<std::thread> th;
+		for (unsigned k = 0; k < parts; k += 2 * width) {
+			const size_t a = n * k / parts, m = n * (k + width) / parts, b = n * (k + 2 * width) / parts;
+			th.emplace_back([src, dst, a, m, b, less] { std::merge(src->begin() + a, src->begin() + m, src->begin() + m, src->begin() + b, dst->begin() + a, less); });
+		}
+		for (std::thread& x : th) x.join();
+		std::swap(src, dst);
+	}
+	if (src != &v) v.swap(tmp);
+}
+
+// returns false when the set does not fit the 31-bit slot space
 inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out) {
 	struct SortItem { uint64_t hi, lo; uint32_t rec; };
 	const size_t n = recs.size();
 	std::vector<SortItem> items(n);
-	for (size_t i = 0; i < n; ++i) {
-		const CullRec& r = recs[i];
-		// cells in Morton (Z-curve) order of their sign-biased indices: a tile of consecutive spheres then covers a compact
-		// block of cells, which is what makes the tile-level early out of k_cull_fused (tile_rejected) effective. 96 bits of
-		// Morton code = the interleaved high 11 bits of x, y, z (33 bits) above their interleaved low 21 bits (63 bits).
-		const uint32_t bx = (uint32_t)r.cell.x ^ 0x80000000u, by = (uint32_t)r.cell.y ^ 0x80000000u, bz = (uint32_t)r.cell.z ^ 0x80000000u;
-		const uint64_t m_hi = (spread3(bx >> 21) << 2) | (spread3(by >> 21) << 1) | spread3(bz >> 21);
-		const uint64_t m_lo = (spread3(bx & 0x1fffffu) << 2) | (spread3(by & 0x1fffffu) << 1) | spread3(bz & 0x1fffffu);
-		items[i].hi = ((uint64_t)r.type << 35) | ((uint64_t)(r.big ? 1 : 0) << 34) | m_hi;
-		items[i].lo = m_lo;
-		items[i].rec = (uint32_t)i;
-	}
-	std::sort(items.begin(), items.end(), [](const SortItem& a, const SortItem& b) {
+	parallel_ranges(n, [&](size_t b, size_t e) {
+		for (size_t i = b; i < e; ++i) {
+			const CullRec& r = recs[i];
+			// cells in Morton (Z-curve) order of their sign-biased indices: a tile of consecutive spheres then covers a compact
+			// block of cells, which is what makes the tile-level tests of k_cull_tile (tile_status) effective. 96 bits of
+			// Morton code = the interleaved high 11 bits of x, y, z (33 bits) above their interleaved low 21 bits (63 bits).
+			const uint32_t bx = (uint32_t)r.cell.x ^ 0x80000000u, by = (uint32_t)r.cell.y ^ 0x80000000u, bz = (uint32_t)r.cell.z ^ 0x80000000u;
+			const uint64_t m_hi = (spread3(bx >> 21) << 2) | (spread3(by >> 21) << 1) | spread3(bz >> 21);
+			const uint64_t m_lo = (spread3(bx & 0x1fffffu) << 2) | (spread3(by & 0x1fffffu) << 1) | spread3(bz & 0x1fffffu);
+			items[i].hi = ((uint64_t)r.type << 35) | ((uint64_t)(r.big ? 1 : 0) << 34) | m_hi;
+			items[i].lo = m_lo;
+			items[i].rec = (uint32_t)i;
+		}
+	});
+	parallel_sort(items, [](const SortItem& a, const SortItem& b) {
 		if (a.hi != b.hi) return a.hi < b.hi;
 		if (a.lo != b.lo) return a.lo < b.lo;
 		return a.rec < b.rec;
@@ -198,24 +253,34 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 		if (out.spheres.size() > 0x7fffffffull) return false;
 	}
 	const size_t n_padded = out.spheres.size();
+	{ std::vector<SortItem>().swap(items); }
 
 	const size_t n_chunks = n_padded / LAYOUT_CHUNK;
-	out.chunk_cell.resize(n_chunks);
-	out.chunk_flags.resize(n_chunks);
-	for (size_t c = 0; c < n_chunks; ++c) {
-		const size_t base = c * LAYOUT_CHUNK;
-		out.chunk_cell[c] = out.slot_cell[base];
-		uint64_t flags = 0;
-		for (uint32_t l = 1; l < LAYOUT_CHUNK; ++l) {
-			if (out.slot_cell[base + l] != out.slot_cell[base + l - 1]) flags |= 1ull << l;
+	out.hdr.resize(n_chunks);
+	parallel_ranges(n_chunks, [&](size_t cb, size_t ce) {
+		for (size_t c = cb; c < ce; ++c) {
+			const size_t base = c * LAYOUT_CHUNK;
+			uint64_t flags = 0;
+			for (uint32_t l = 1; l < LAYOUT_CHUNK; ++l) {
+				if (out.slot_cell[base + l] != out.slot_cell[base + l - 1]) flags |= 1ull << l;
+			}
+			out.hdr[c] = LayoutChunkHdr{out.slot_cell[base], 0u, flags};
 		}
-		out.chunk_flags[c] = flags;
-	}
+	});
 	out.n_padded = (uint32_t)n_padded;
 	out.n_dead_cells = 0;
 	for (const LayoutCell& c : out.cells) out.n_dead_cells += (c.meta & LAYOUT_CELL_DEAD) ? 1u : 0u;
+	out.block_live.assign(n_padded / LAYOUT_TILE_ALIGN, 0u);
+	parallel_ranges(out.block_live.size(), [&](size_t bb, size_t be) {
+		for (size_t b = bb; b < be; ++b) {
+			uint32_t live = 0;
+			for (uint32_t l = 0; l < LAYOUT_TILE_ALIGN; ++l) live += out.ids[b * LAYOUT_TILE_ALIGN + l] >= 0 ? 1u : 0u;
+			out.block_live[b] = live;
+		}
+	});
 	for (int k = 0; k < 3; ++k) {
 		const size_t tile = (size_t)LAYOUT_TILE_ALIGN >> k;
+		const size_t n_tiles = n_padded / tile;
 		uint32_t m = 0;
 		for (size_t b = 0; b + tile <= n_padded; b += tile) {
 			const uint32_t c = out.slot_cell[b + tile - 1] - out.slot_cell[b] + 1; // cell slots are consecutive along the sphere order
@@ -224,30 +289,31 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 		out.max_tile_cells[k] = m;
 		const uint32_t cap = ((m > 0 ? m : 1u) + 15u) / 16u * 16u;
 		out.tile_cap[k] = cap;
-		const size_t n_tiles = n_padded / tile;
 		out.tile_cells[k].assign(n_tiles * cap, LayoutCell{0, 0, 0, LAYOUT_CELL_DEAD});
 		out.tile_tab[k].assign(n_tiles * 2, 0u);
 		out.tile_box[k].assign(n_tiles, TileBox{{0, 0, 0}, {0, 0, 0}, TILE_EMPTY, 0});
-		for (size_t ti = 0; ti < n_tiles; ++ti) {
-			const uint32_t first = out.slot_cell[ti * tile];
-			const uint32_t cnt = out.slot_cell[ti * tile + tile - 1] - first + 1;
-			out.tile_tab[k][2 * ti] = first;
-			out.tile_tab[k][2 * ti + 1] = cnt;
-			for (uint32_t j = 0; j < cnt; ++j) out.tile_cells[k][ti * cap + j] = out.cells[first + j];
-			TileBox box = {{INT32_MAX, INT32_MAX, INT32_MAX}, {INT32_MIN, INT32_MIN, INT32_MIN}, TILE_EMPTY, 0};
-			for (uint32_t j = 0; j < cnt; ++j) {
-				const LayoutCell& c = out.cells[first + j];
-				if (c.meta & LAYOUT_CELL_DEAD) continue;
-				box.flags &= ~(uint32_t)TILE_EMPTY;
-				if (c.meta & 0x100u) box.flags |= TILE_HAS_BIG;
-				const int32_t idx[3] = {c.ix, c.iy, c.iz};
-				for (int a = 0; a < 3; ++a) {
-					box.lo[a] = std::min(box.lo[a], idx[a]);
-					box.hi[a] = std::max(box.hi[a], idx[a]);
+		parallel_ranges(n_tiles, [&, k, tile, cap](size_t tb, size_t te) {
+			for (size_t ti = tb; ti < te; ++ti) {
+				const uint32_t first = out.slot_cell[ti * tile];
+				const uint32_t cnt = out.slot_cell[ti * tile + tile - 1] - first + 1;
+				out.tile_tab[k][2 * ti] = first;
+				out.tile_tab[k][2 * ti + 1] = cnt;
+				TileBox box = {{INT32_MAX, INT32_MAX, INT32_MAX}, {INT32_MIN, INT32_MIN, INT32_MIN}, TILE_EMPTY, 0};
+				for (uint32_t j = 0; j < cnt; ++j) {
+					const LayoutCell& c = out.cells[first + j];
+					out.tile_cells[k][ti * cap + j] = c;
+					if (c.meta & LAYOUT_CELL_DEAD) continue;
+					box.flags &= ~(uint32_t)TILE_EMPTY;
+					if (c.meta & 0x100u) box.flags |= TILE_HAS_BIG;
+					const int32_t idx[3] = {c.ix, c.iy, c.iz};
+					for (int a = 0; a < 3; ++a) {
+						box.lo[a] = std::min(box.lo[a], idx[a]);
+						box.hi[a] = std::max(box.hi[a], idx[a]);
+					}
 				}
+				out.tile_box[k][ti] = box;
 			}
-			out.tile_box[k][ti] = box;
-		}
+		});
 	}
 	return true;
 }

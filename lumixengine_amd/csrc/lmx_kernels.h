@@ -17,65 +17,81 @@ constexpr uint32_t CELL_DEAD = 0x80000000u;
 
 // One (cell index, type, is_big) group. meta = type | is_big << 8 | CELL_DEAD.
 struct CellKey { int32_t ix, iy, iz; uint32_t meta; };
+// Header of a 64-sphere chunk: cell slot of its first sphere, bit l of flags = "sphere l starts the next cell".
+struct ChunkHdr { uint32_t cell, pad; uint64_t flags; };
 
-// Per-type ranges in the padded sphere index space.
+// Per-type ranges in the padded slot space of one set (static or dynamic) + the type's output shards.
 struct TypeTable {
-	uint32_t ent_start[MAX_TYPES]; // first slot of the type (static set: multiple of TILE_ALIGN, dynamic set: of 2048)
-	uint32_t ent_end[MAX_TYPES];   // end of the padded range
-	uint32_t out_start[MAX_TYPES]; // where the type's visible ids start in a frustum's output row (static + dynamic share it)
+	uint32_t ent_start[MAX_TYPES];   // first slot of the type (static set: multiple of TILE_ALIGN, dynamic set: of 2048)
+	uint32_t ent_end[MAX_TYPES];     // end of the padded range
+	uint32_t shard_first[MAX_TYPES]; // global index of the first output shard the type's tiles of this set reserve from
+	uint32_t shard_n[MAX_TYPES];     // number of shards: block b (TILE_ALIGN slots) of the type uses shard_first + b % shard_n
 };
 
 struct FrustaArg { DevFrustum f[MAX_FRUSTA]; };
 
 struct CullDeviceView {
 	const float4* spheres;       // [n_padded] {rel.x, rel.y, rel.z, radius}, cell-relative fp32 (culling_system.cpp:100)
-	const int32_t* ids;          // [n_padded] entity index, -1 for padding
-	const uint32_t* chunk_cell;  // [n_padded / 64] cell slot of the first sphere of the chunk
-	const uint64_t* chunk_flags; // [n_padded / 64] bit l: sphere l of the chunk starts a new cell
-	const CellKey* cells;        // [n_cells]
+	const int32_t* ids;          // [n_padded] entity index, -1 for padding and removed entities
+	const ChunkHdr* hdr;         // [n_padded / 64]
 	uint32_t n_padded;
-	uint32_t n_cells;
-	// fused kernel: per tile-size variant k (tile = 4096 >> k), tile-major cell keys + {first cell, n cells} per tile
+	// per tile-size variant k (tile = 4096 >> k): tile-major cell keys + {first cell, n cells} + cell-index box per tile
 	const CellKey* tile_cells[3];
 	const uint32_t* tile_tab[3];
 	const TileBox* tile_box[3];
 	uint32_t tile_cap[3];
 };
 
-// classify cells [cell_begin, cell_begin + n) for n_frusta frusta -> cellinfo[f * cell_stride + c] =
-// {offset.x, offset.y, offset.z, bits(class)}; also zeroes counts[0 .. MAX_FRUSTA * MAX_TYPES).
-hipError_t launch_cull_classify(hipStream_t s, const CullDeviceView& v, uint32_t cell_begin, uint32_t n, const FrustaArg& fr,
-	int n_frusta, float4* cellinfo, uint32_t cell_stride, uint32_t* counts);
+// Where a cull writes. The visible ids of (frustum f, shard s) go to ids[f * stride + win_base[s] + k], k < the shard's counter
+// counts[f * cnt_frustum_stride + s * cnt_pad]; counters sit cnt_pad words apart (own cache line: same-line atomics serialise).
+// Every launch also clears counts_next[0 .. n_zero) (the counters of the following cull on this view, ping-pong).
+struct CullOut {
+	int32_t* ids;
+	uint32_t stride;
+	const uint32_t* win_base;
+	uint32_t* counts;
+	uint32_t cnt_pad, cnt_frustum_stride;
+	uint32_t* counts_next;
+	uint32_t n_zero;
+};
 
-// test spheres [ent_begin, ent_end) (multiples of TILE_ALIGN, one type per tile) and compact visible ids into
-// out_ids[f * out_stride + tt.ent_start[type] + ...], counts[f * MAX_TYPES + type].
-hipError_t launch_cull_spheres(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
-	const FrustaArg& fr, int n_frusta, const float4* cellinfo, uint32_t cell_stride, int32_t* out_ids, uint32_t out_stride,
-	uint32_t* counts);
+// k_cull_tile over the static set's slots [ent_begin, ent_end) (multiples of TILE_ALIGN). `variant` picks the tile shape of the
+// 1-frustum kernel: 0 = 8 waves x 8 chunks (4096), 1 = 4 x 8 (2048), 2 = 8 x 4 (2048), 3 = 4 x 4 (1024); ignored for n_frusta > 1.
+// lane_parallel_status: the tile-level box test is evaluated one plane per lane (1-frustum kernels only).
+size_t cull_tile_lds_bytes(int n_frusta, uint32_t cell_cap);
+uint32_t cull_tile_size(int n_frusta, int variant);
+hipError_t launch_cull_tile(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
+	const FrustaArg& fr, int n_frusta, const CullOut& out, int variant, bool lane_parallel_status);
 
-// Fused single-launch variant (per-tile classification in LDS) for the tile size cull_tile_size(n_frusta); the layout
-// bounds the cells per tile, so fused_lds_bytes(...) always fits the 64 KiB dynamic-LDS limit (the caller still checks). counts must be zero on entry; counts_next (may be null) is
-// cleared for the following cull.
-uint32_t cull_tile_size(int n_frusta);
-size_t fused_lds_bytes(int n_frusta, uint32_t tile, uint32_t cell_cap);
-hipError_t launch_cull_fused(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
-	const FrustaArg& fr, int n_frusta, int32_t* out_ids, uint32_t out_stride, uint32_t* counts, uint32_t* counts_next, bool small_tiles);
-
-// Dynamic set: entities whose transform changes every frame (bound to the world hierarchy) are kept UNSORTED as world
-// position (fp64) + radius + id. Their cell, cell-relative position and per-cell class are recomputed per entity per cull
-// with exactly the arithmetic CullingSystem::set + cullInternal would apply (cell_of, classify_cell, sphere_visible), so
-// no re-binning is ever needed. Visible ids are appended to the same per-type output segments / counters as the static set.
+// Dynamic set: entities whose transform changes every frame (bound to the world hierarchy) and entities added / re-celled since
+// the last compaction of the static set are kept UNSORTED as world position (fp64) + radius + id. Their cell, cell-relative
+// position and per-cell class are recomputed per entity per cull with exactly the arithmetic CullingSystem::set + cullInternal
+// would apply (cell_of, classify_cell, sphere_visible), so no re-binning is ever needed.
 struct DynDeviceView {
-	const double* px; const double* py; const double* pz;
-	const float* radius;
-	const int32_t* ids; // -1 = padding
+	double* px; double* py; double* pz;
+	float* radius;
+	int32_t* ids; // -1 = free slot
 	uint32_t n_padded;
 };
 hipError_t launch_cull_dynamic(hipStream_t s, const DynDeviceView& d, uint32_t slot_begin, uint32_t slot_end, const TypeTable& dyn_tt,
-	const FrustaArg& fr, int n_frusta, int32_t* out_ids, uint32_t out_stride, uint32_t* counts);
+	const FrustaArg& fr, int n_frusta, const CullOut& out);
+uint32_t cull_dynamic_tile(int n_frusta);
 
-// spheres[slot[i]] = value[i]
-hipError_t launch_patch_spheres(hipStream_t s, float4* spheres, const uint32_t* slot, const float4* value, uint32_t n);
+// Patch records staged by the host between two culls (CullingSystem::add / remove / set* are O(1): culling_system.cpp:131-258)
+struct PatchSphere { uint32_t slot; float x, y, z, radius; };                 // static set: in-cell move / radius change
+struct PatchId { uint32_t slot; int32_t id; };                                 // static set: removal (tombstone, id = -1)
+struct PatchDyn { uint32_t slot; int32_t id; float radius; uint32_t pad; double px, py, pz; }; // dynamic set: add / remove / set
+hipError_t launch_apply_patches(hipStream_t s, float4* spheres, int32_t* ids, const DynDeviceView& d, const PatchSphere* ps, uint32_t n_ps,
+	const PatchId* pi, uint32_t n_pi, const PatchDyn* pd, uint32_t n_pd);
+
+// Per-(frustum, type) totals and per-(frustum, shard) offsets of the consolidated lists: totals[f * MAX_TYPES + t], pref[f * n_shards + s]
+// (offset of shard s inside its type's consolidated list). shard_type[s] = renderable type of shard s.
+hipError_t launch_cull_finalize(hipStream_t s, const uint32_t* counts, uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* shard_type,
+	uint32_t n_shards, uint32_t n_frusta, uint32_t* totals, uint32_t* pref);
+// One contiguous list per (frustum, type): dst[f * dst_stride + type_start[type] + pref + k] = src[f * src_stride + win_base[s] + k]
+hipError_t launch_cull_consolidate(hipStream_t s, const int32_t* src, uint32_t src_stride, const uint32_t* win_base, const uint32_t* counts,
+	uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* shard_type, const uint32_t* type_start /* device, [MAX_TYPES] */, const uint32_t* pref,
+	uint32_t n_shards, uint32_t n_frusta, uint32_t max_shard_cap, int32_t* dst, uint32_t dst_stride);
 
 // ---- world transforms ------------------------------------------------------------------------------------
 struct WorldDevice {

@@ -110,10 +110,15 @@ LMX_HD float maximum3(float a, float b, float c) {                              
 
 // ---- culling cells, renderer/culling_system.cpp:23-40,131-157 --------------------------------------------
 constexpr float CELL_SIZE = 300.0f;                                                          // culling_system.cpp:75
-// CellIndices ctor: IVec3(pos * (1 / cell_size)) — double * float -> double, C cast truncates toward zero
+// CellIndices ctor: IVec3(pos * (1 / cell_size)) — double * float -> double, C cast truncates toward zero. The cast is
+// x86's cvttsd2si on the reference's platforms: NaN and values outside int32 give INT32_MIN ("integer indefinite"). The GPU's
+// v_cvt_i32_f64 saturates instead (NaN -> 0), so the conversion is spelled out to keep host mirror, oracle and kernels identical.
+LMX_HD int32_t trunc_i32(double v) {
+	return (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000u;
+}
 LMX_HD IV3 cell_of(DV3 pos) {
 	const float inv = 1 / CELL_SIZE;
-	return IV3{(int32_t)(pos.x * inv), (int32_t)(pos.y * inv), (int32_t)(pos.z * inv)};
+	return IV3{trunc_i32(pos.x * inv), trunc_i32(pos.y * inv), trunc_i32(pos.z * inv)};
 }
 // header.origin = i.pos * double(m_cell_size) (IVec3::operator*(double), math.cpp:149-152)
 LMX_HD DV3 cell_origin(IV3 i) {
@@ -174,46 +179,78 @@ LMX_HD uint32_t classify_cell(const DevFrustum& f, IV3 idx, bool is_big, V3* out
 	return CELL_REJECT;
 }
 
-// Tile-level early out of k_cull_fused (no reference twin: a conservative bound on classify_cell). A tile of the sorted sphere
-// array covers a run of cells; `lo..hi` is the box of their cell indices. If the union of the cells' intersectsAABB boxes
-// ([300 * lo - 300, 300 * hi + 300] per axis) lies behind one frustum plane by more than `margin`, every cell of the tile is
-// CELL_REJECT: a cell's positive vertex is never further along the plane normal than the union box's. The box corners are formed
-// in fp64 and rounded once to fp32; the plane expression is then evaluated in fp32 like the per-cell test. Both evaluations err
-// by < 1.5e-6 * |vertex|_1 each (5 roundings of 2^-24 relative on terms bounded by |vertex|_1), the margin 2 + 4e-6 * |vertex|_1
-// covers their sum with room to spare. Tiles with big-sphere cells (always CELL_TEST) are never rejected here; NaN planes or
-// corners compare false and reject nothing.
+// Tile-level tests of k_cull_tile (no reference twin: conservative bounds on classify_cell). A tile of the sorted sphere array
+// covers a run of cells; `lo..hi` is the box of their cell indices.
+//   * TILE_REJECT: the union of the cells' intersectsAABB boxes ([300 lo - 300, 300 hi + 300] per axis) lies behind one frustum
+//     plane by more than `margin`: a cell's positive vertex is never further along the plane normal than the union box's, so
+//     every cell of the tile is CELL_REJECT.
+//   * TILE_ACCEPT: the union of the cells' containsAABB boxes ([300 lo + 300, 300 hi + 600], the reference's +300 quirk included)
+//     lies inside every plane by more than `margin`: every cell's negative vertex passes, so every cell is CELL_ACCEPT.
+//   * TILE_MIXED: anything else - the cells are classified one by one.
+// Corners are formed in fp64 and rounded once; the plane expression is evaluated in fp32 like the per-cell test. Error budget:
+// each evaluation (this one and the per-cell one it stands in for) errs by < 6 * 2^-24 * sum_i |n_i b_i| <= 3.6e-7 * |n|_inf *
+// B1, where B1 = sum over axes of the box's largest |coordinate| bounds |b|_1 of EVERY cell vertex inside the union box (not just
+// of the vertex picked here), and the comparison's right-hand side -d -+ margin rounds by <= 2^-24 (|d| + margin). The margin
+// max(1, |n|_1) * (2 + 4e-6 * B1) + 1e-6 * |d| covers the sum several times over for any plane scale. Tiles holding big-sphere cells
+// (always CELL_TEST) are TILE_MIXED; NaN planes / corners compare false and give TILE_MIXED.
 struct TileBox { int32_t lo[3], hi[3]; uint32_t flags, pad; };
 enum : uint32_t { TILE_EMPTY = 1, TILE_HAS_BIG = 2 };
-LMX_HD bool tile_rejected(const DevFrustum& f, const TileBox& b) {
-	if (b.flags & TILE_EMPTY) return true;
-	if (b.flags & TILE_HAS_BIG) return false;
+enum TileStatus : uint32_t { TILE_REJECT = 0, TILE_ACCEPT = 1, TILE_MIXED = 2 };
+LMX_HD float abs_f(float v) { return v < 0 ? -v : v; }
+LMX_HD float max_f(float a, float b) { return a > b ? a : b; }
+LMX_HD uint32_t tile_status(const DevFrustum& f, const TileBox& b) {
+	if (b.flags & TILE_EMPTY) return TILE_REJECT;
+	if (b.flags & TILE_HAS_BIG) return TILE_MIXED;
 	const double cs = (double)CELL_SIZE;
+	// intersectsAABB union box
 	const float lx = (float)(cs * b.lo[0] - cs - f.origin[0]), ly = (float)(cs * b.lo[1] - cs - f.origin[1]), lz = (float)(cs * b.lo[2] - cs - f.origin[2]);
 	const float hx = (float)(cs * b.hi[0] + cs - f.origin[0]), hy = (float)(cs * b.hi[1] + cs - f.origin[1]), hz = (float)(cs * b.hi[2] + cs - f.origin[2]);
+	// containsAABB union box
+	const float clx = (float)(cs * b.lo[0] + cs - f.origin[0]), cly = (float)(cs * b.lo[1] + cs - f.origin[1]), clz = (float)(cs * b.lo[2] + cs - f.origin[2]);
+	const float chx = (float)(cs * b.hi[0] + 2 * cs - f.origin[0]), chy = (float)(cs * b.hi[1] + 2 * cs - f.origin[1]), chz = (float)(cs * b.hi[2] + 2 * cs - f.origin[2]);
+	const float b1 = max_f(abs_f(lx), abs_f(chx)) + max_f(abs_f(ly), abs_f(chy)) + max_f(abs_f(lz), abs_f(chz));
+	bool inside = true;
 	for (int i = 0; i < 6; ++i) {
-		const float bx = f.nx[i] > 0.0f ? hx : lx, by = f.ny[i] > 0.0f ? hy : ly, bz = f.nz[i] > 0.0f ? hz : lz;
-		const float dp = (f.nx[i] * bx) + (f.ny[i] * by) + (f.nz[i] * bz);
-		const float margin = 2.0f + 4e-6f * ((bx < 0 ? -bx : bx) + (by < 0 ? -by : by) + (bz < 0 ? -bz : bz));
-		if (dp < -f.d[i] - margin) return true;
+		const float n1 = abs_f(f.nx[i]) + abs_f(f.ny[i]) + abs_f(f.nz[i]);
+		const float margin = max_f(1.0f, n1) * (2.0f + 4e-6f * b1) + 1e-6f * abs_f(f.d[i]);
+		{ // positive vertex of the intersects box
+			const float bx = f.nx[i] > 0.0f ? hx : lx, by = f.ny[i] > 0.0f ? hy : ly, bz = f.nz[i] > 0.0f ? hz : lz;
+			const float dp = (f.nx[i] * bx) + (f.ny[i] * by) + (f.nz[i] * bz);
+			if (dp < -f.d[i] - margin) return TILE_REJECT;
+		}
+		{ // negative vertex of the contains box
+			const float bx = f.nx[i] < 0.0f ? chx : clx, by = f.ny[i] < 0.0f ? chy : cly, bz = f.nz[i] < 0.0f ? chz : clz;
+			const float dp = (f.nx[i] * bx) + (f.ny[i] * by) + (f.nz[i] * bz);
+			if (!(dp > -f.d[i] + margin)) inside = false;
+		}
 	}
-	return false;
+	return inside ? TILE_ACCEPT : TILE_MIXED;
 }
+LMX_HD bool tile_rejected(const DevFrustum& f, const TileBox& b) { return tile_status(f, b) == TILE_REJECT; }
 
-// doCulling for one sphere, culling_system.cpp:283-306, against the cell-relative planes of getRelative
-// (geometry.cpp:121-149, setPlane :421-427): d_k = -dot(point_k + offset, n_k);
+// ShiftedFrustum::getRelative for one plane (geometry.cpp:121-149, setPlane :421-427): the plane is re-anchored on its corner
+// point shifted by offset = Vec3(frustum.origin - cell_origin): d_k = -dot(point_k + offset, n_k). Per cell, not per sphere.
+LMX_HD float relative_plane_d(const DevFrustum& f, V3 offset, int k) {
+	const V3 n = V3{f.nx[k], f.ny[k], f.nz[k]};
+	const V3 q = add(V3{f.px[k], f.py[k], f.pz[k]}, offset);
+	return -dot(q, n);
+}
+// doCulling for one sphere, culling_system.cpp:283-306, against the cell-relative planes:
 // t = ((cx*nx + cy*ny) + cz*nz) + d; t = t - (-r); culled iff t < 0 (scalar f4MoveMask, simd.h:332-338).
-LMX_HD bool sphere_visible(const DevFrustum& f, V3 offset, float cx, float cy, float cz, float radius) {
+LMX_HD bool sphere_visible_d(const DevFrustum& f, const float d[6], float cx, float cy, float cz, float radius) {
 	const float r = -radius;
 	bool culled = false;
 	for (int k = 0; k < 6; ++k) {
-		const V3 n = V3{f.nx[k], f.ny[k], f.nz[k]};
-		const V3 q = add(V3{f.px[k], f.py[k], f.pz[k]}, offset);
-		const float d = -dot(q, n);
-		float t = cx * n.x + cy * n.y + cz * n.z + d;
+		float t = cx * f.nx[k] + cy * f.ny[k] + cz * f.nz[k] + d[k];
 		t = t - r;
 		culled = culled || (t < 0);
 	}
 	return !culled;
+}
+LMX_HD bool sphere_visible(const DevFrustum& f, V3 offset, float cx, float cy, float cz, float radius) {
+	float d[6];
+	for (int k = 0; k < 6; ++k) d[k] = relative_plane_d(f, offset, k);
+	return sphere_visible_d(f, d, cx, cy, cz, radius);
 }
 
 // ---- pose / palette / skin -------------------------------------------------------------------------------

@@ -10,8 +10,8 @@
 // empty result / ignored call (see lastError()).
 //
 // Threading: add/remove/set* arrive on the update thread; cull() may be called for several views per
-// frame from render jobs. Each concurrent cull() call takes its own result slot (LMX_MAX_VIEWS of them) under a mutex,
-// so calls serialise on the GPU stream but never alias results.
+// frame from render jobs. Every call takes the adapter's mutex; each cull() uses its own result slot (LMX_MAX_VIEWS of
+// them), so calls serialise on the GPU stream but never alias results.
 #pragma once
 
 #include <cstdio>
@@ -49,23 +49,38 @@ struct GpuCullingSystem final : CullingSystem {
 	CullResult* cull(const ShiftedFrustum& frustum, u8 type) override { return cullInternal(frustum, type); } // culling_system.cpp:310-314
 	CullResult* cull(const ShiftedFrustum& frustum) override { return cullInternal(frustum, 0xff); }           // :316-319
 
-	bool isAdded(EntityRef entity) override { return m_ctx && lmx_cull_is_added(m_ctx, entity.index) != 0; }
+	// add / remove / set* arrive on the update thread while render jobs may be inside cull(): the C ABI context is not
+	// re-entrant, so every call takes the adapter's mutex (uncontended in the engine's frame structure)
+	bool isAdded(EntityRef entity) override {
+		std::lock_guard<std::mutex> guard(m_mutex);
+		return m_ctx && lmx_cull_is_added(m_ctx, entity.index) != 0;
+	}
 	void add(EntityRef entity, u8 type, const DVec3& pos, float radius) override {
 		const double p[3] = {pos.x, pos.y, pos.z};
+		std::lock_guard<std::mutex> guard(m_mutex);
 		check(lmx_cull_add(m_ctx, entity.index, type, p, radius));
 	}
-	void remove(EntityRef entity) override { check(lmx_cull_remove(m_ctx, entity.index)); }
+	void remove(EntityRef entity) override {
+		std::lock_guard<std::mutex> guard(m_mutex);
+		check(lmx_cull_remove(m_ctx, entity.index));
+	}
 	void setPosition(EntityRef entity, const DVec3& pos) override {
 		const double p[3] = {pos.x, pos.y, pos.z};
+		std::lock_guard<std::mutex> guard(m_mutex);
 		check(lmx_cull_set_position(m_ctx, entity.index, p));
 	}
-	void setRadius(EntityRef entity, float radius) override { check(lmx_cull_set_radius(m_ctx, entity.index, radius)); }
+	void setRadius(EntityRef entity, float radius) override {
+		std::lock_guard<std::mutex> guard(m_mutex);
+		check(lmx_cull_set_radius(m_ctx, entity.index, radius));
+	}
 	void set(EntityRef entity, const DVec3& pos, float radius) override {
 		const double p[3] = {pos.x, pos.y, pos.z};
+		std::lock_guard<std::mutex> guard(m_mutex);
 		check(lmx_cull_set(m_ctx, entity.index, p, radius));
 	}
 	float getRadius(EntityRef entity) override {
 		float r = 0;
+		std::lock_guard<std::mutex> guard(m_mutex);
 		check(lmx_cull_get_radius(m_ctx, entity.index, &r));
 		return r;
 	}
@@ -87,29 +102,31 @@ private:
 	CullResult* cullInternal(const ShiftedFrustum& frustum, u8 type) {
 		if (!m_ctx) return nullptr;
 		std::lock_guard<std::mutex> guard(m_mutex);
-		uint32_t n_entities = 0;
-		if (!check(lmx_cull_stats(m_ctx, &n_entities, nullptr, nullptr)) || n_entities == 0) return nullptr; // :322
+		uint32_t n_static = 0, n_bound = 0, n_overflow = 0;
+		if (!check(lmx_cull_update_stats(m_ctx, &n_static, &n_bound, &n_overflow, nullptr))) return nullptr;
+		if (n_static + n_bound + n_overflow == 0) return nullptr; // no cells: culling_system.cpp:322
 		const uint32_t view = m_next_view++ % LMX_MAX_VIEWS;
 		static_assert(sizeof(ShiftedFrustum) == sizeof(LmxShiftedFrustum), "layout");
 		if (!check(lmx_cull(m_ctx, view, reinterpret_cast<const LmxShiftedFrustum*>(&frustum), 1, type))) return nullptr;
+		// two host waits per cull: the per-type totals, then the ids of every non-empty type in one batch of copies
 		uint32_t counts[LMX_MAX_TYPES];
-		if (!check(lmx_cull_counts(m_ctx, view, counts))) return nullptr;
+		m_scratch.resize((size_t)n_static + n_bound + n_overflow);
+		if (!check(lmx_cull_read_all(m_ctx, view, 0, m_scratch.data(), (uint32_t)m_scratch.size(), counts))) return nullptr;
 		CullResult* first = nullptr;
 		CullResult* last = nullptr;
 		constexpr uint32_t PAGE_IDS = sizeof(CullResult::entities) / sizeof(EntityRef);
+		size_t at = 0;
 		for (uint32_t t = 0; t < LMX_MAX_TYPES; ++t) {
-			if (!counts[t]) continue;
-			m_scratch.resize(counts[t]);
-			uint32_t got = 0;
-			if (!check(lmx_cull_read(m_ctx, view, 0, (u8)t, m_scratch.data(), counts[t], &got))) break;
+			const uint32_t got = counts[t];
 			for (uint32_t i = 0; i < got; i += PAGE_IDS) {
 				CullResult* page = newPage((u8)t);
 				const uint32_t n = got - i < PAGE_IDS ? got - i : PAGE_IDS;
-				for (uint32_t k = 0; k < n; ++k) page->entities[k].index = m_scratch[i + k];
+				for (uint32_t k = 0; k < n; ++k) page->entities[k].index = m_scratch[at + i + k];
 				page->header.count = n;
 				if (last) last->header.next = page; else first = page;
 				last = page;
 			}
+			at += got;
 		}
 		if (!first) first = newPage(type == 0xff ? 0 : type); // the reference returns >= 1 (possibly empty) page per visited cell
 		return first;

@@ -16,16 +16,29 @@
 
 using namespace lmx;
 
-static uint32_t g_tile_stats[3]; // tiles visited, tiles the tile-level box test ended, tiles whose cells are all CELL_REJECT
+// tiles visited, tiles ended by TILE_REJECT, tiles whose cells are all CELL_REJECT, tiles taken by TILE_ACCEPT, tiles whose live cells are all CELL_ACCEPT
+static uint32_t g_tile_stats[5];
 
 extern "C" {
 
 void emul_tile_stats(uint32_t* out) { memcpy(out, g_tile_stats, sizeof(g_tile_stats)); }
 
+// tile_status for a hand-built box (tests of the margin with scaled / adversarial planes)
+uint32_t emul_tile_status(const LmxShiftedFrustum* f, const int32_t* lo, const int32_t* hi, uint32_t flags) {
+	TileBox b = {{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}, flags, 0};
+	return tile_status(to_dev_frustum(*f), b);
+}
+// classify_cell for one cell
+uint32_t emul_classify_cell(const LmxShiftedFrustum* f, const int32_t* idx, int big) {
+	V3 off;
+	return classify_cell(to_dev_frustum(*f), IV3{idx[0], idx[1], idx[2]}, big != 0, &off);
+}
+
 // emulates lmx_cull_build + lmx_cull over n_frusta frusta; out_ids / out_types are [n_frusta][n] (first
-// sum(out_counts[f]) entries used), out_counts [n_frusta][8]
-int emul_cull(uint32_t n, const int32_t* entity, const uint8_t* type, const double* pos, const float* radius,
-	const LmxShiftedFrustum* frusta, uint32_t n_frusta, uint8_t type_filter, int32_t* out_ids, uint8_t* out_types, uint32_t* out_counts) {
+// sum(out_counts[f]) entries used), out_counts [n_frusta][8]. `tile_variant`: tile size of the 1-frustum kernel
+// (0: 4096, 1 / 2: 2048, 3: 1024), as lmx_cull_set_option(LMX_CULL_OPT_TILE_VARIANT).
+int emul_cull_variant(uint32_t n, const int32_t* entity, const uint8_t* type, const double* pos, const float* radius,
+	const LmxShiftedFrustum* frusta, uint32_t n_frusta, uint8_t type_filter, int tile_variant, int32_t* out_ids, uint8_t* out_types, uint32_t* out_counts) {
 	std::vector<CullRec> recs(n);
 	for (uint32_t i = 0; i < n; ++i) recs[i] = make_cull_rec(entity[i], type[i], DV3{pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]}, radius[i]);
 	CullLayout lay;
@@ -33,27 +46,37 @@ int emul_cull(uint32_t n, const int32_t* entity, const uint8_t* type, const doub
 	const size_t n_cells = lay.cells.size();
 	memset(out_counts, 0, sizeof(uint32_t) * n_frusta * LAYOUT_MAX_TYPES);
 	memset(g_tile_stats, 0, sizeof(g_tile_stats));
-	struct Info { float x, y, z; uint32_t cls; };
+	// the live ids of every TILE_ALIGN block must add up to what the shard windows are sized for
+	if (lay.block_live.size() != lay.n_padded / LAYOUT_TILE_ALIGN) return 9;
+	{
+		size_t live = 0;
+		for (uint32_t b : lay.block_live) live += b;
+		if (live != n) return 9;
+	}
+	struct Info { float d[6]; uint32_t cls; };
 	for (uint32_t f = 0; f < n_frusta; ++f) {
 		uint32_t total = 0;
 		const DevFrustum fr = to_dev_frustum(frusta[f]);
-		// k_cull_classify
+		// phase A of k_cull_tile for every cell (the kernel does it tile by tile into LDS): class + cell-relative plane distances
 		std::vector<Info> info(n_cells);
 		for (size_t c = 0; c < n_cells; ++c) {
 			const LayoutCell key = lay.cells[c];
-			V3 off = V3{0, 0, 0};
-			uint32_t cls = CELL_REJECT;
-			if (!(key.meta & LAYOUT_CELL_DEAD)) cls = classify_cell(fr, IV3{key.ix, key.iy, key.iz}, (key.meta & 0x100u) != 0, &off);
-			info[c] = Info{off.x, off.y, off.z, cls};
+			Info ci = {{0, 0, 0, 0, 0, 0}, CELL_REJECT};
+			if (!(key.meta & LAYOUT_CELL_DEAD)) {
+				V3 off;
+				ci.cls = classify_cell(fr, IV3{key.ix, key.iy, key.iz}, (key.meta & 0x100u) != 0, &off);
+				if (ci.cls == CELL_TEST)
+					for (int k = 0; k < 6; ++k) ci.d[k] = relative_plane_d(fr, off, k);
+			}
+			info[c] = ci;
 		}
-		// k_cull_spheres, chunk by chunk, lane by lane
 		uint32_t ent_begin = 0, ent_end = lay.n_padded;
 		if (type_filter != 0xff) {
 			ent_begin = lay.ent_start[type_filter];
 			ent_end = lay.ent_end[type_filter];
 		}
-		// fused-kernel tile bookkeeping: the cells a tile touches are [first_cell, last_cell], bounded by the layout's max
-		const uint32_t tile = n_frusta <= 1 ? 4096u : (n_frusta <= 4 ? 2048u : 1024u);
+		// tile bookkeeping: the cells a tile touches are [first_cell, last_cell], bounded by the layout's max
+		const uint32_t tile = n_frusta <= 1 ? (tile_variant == 0 ? 4096u : (tile_variant == 3 ? 1024u : 2048u)) : (n_frusta <= 4 ? 2048u : 1024u);
 		const uint32_t tile_k = tile == 4096 ? 0 : (tile == 2048 ? 1 : 2);
 		const uint32_t nch = tile / 64;
 		for (uint32_t chunk = ent_begin / 64; chunk < ent_end / 64; ++chunk) {
@@ -62,44 +85,61 @@ int emul_cull(uint32_t n, const int32_t* entity, const uint8_t* type, const doub
 			const uint32_t cap = lay.tile_cap[tile_k];
 			const uint32_t first_cell = lay.tile_tab[tile_k][2 * tile_index];
 			const uint32_t tile_n_cells = lay.tile_tab[tile_k][2 * tile_index + 1];
-			const uint32_t last_cell = lay.chunk_cell[tile_chunk + nch - 1] + (uint32_t)__builtin_popcountll(lay.chunk_flags[tile_chunk + nch - 1] & ~1ull);
-			if (first_cell != lay.chunk_cell[tile_chunk] || last_cell != first_cell + tile_n_cells - 1) return 3;
+			const LayoutChunkHdr last_hdr = lay.hdr[tile_chunk + nch - 1];
+			const uint32_t last_cell = last_hdr.cell + (uint32_t)__builtin_popcountll(last_hdr.flags & ~1ull);
+			if (first_cell != lay.hdr[tile_chunk].cell || last_cell != first_cell + tile_n_cells - 1) return 3;
 			if (tile_n_cells > cap || tile_n_cells > lay.max_tile_cells[tile_k] || last_cell >= n_cells) return 4;
-			if (n_frusta <= 8 && (size_t)n_frusta * cap * 16 + (size_t)n_frusta * tile * 4 + 64 > 65536) return 6; // fused LDS budget
-			// tile-level early out of the fused kernel: it may only fire when every cell of the tile is rejected cell by cell
+			if (n_frusta <= 8 && (size_t)n_frusta * cap * 32 > 65536) return 6; // LDS budget of the per-tile cell table
+			const uint32_t st = tile_status(fr, lay.tile_box[tile_k][tile_index]);
 			if (chunk == tile_chunk) { // once per tile
-				bool none = true;
-				for (uint32_t c = first_cell; c <= last_cell; ++c) none = none && info[c].cls == CELL_REJECT;
+				bool none = true, all_in = true, any_cell = false;
+				for (uint32_t c = first_cell; c <= last_cell; ++c) {
+					none = none && info[c].cls == CELL_REJECT;
+					if (lay.cells[c].meta & LAYOUT_CELL_DEAD) continue;
+					any_cell = true;
+					all_in = all_in && info[c].cls == CELL_ACCEPT;
+				}
 				g_tile_stats[0]++;
+				g_tile_stats[1] += st == TILE_REJECT ? 1u : 0u;
 				g_tile_stats[2] += none ? 1u : 0u;
-				g_tile_stats[1] += tile_rejected(fr, lay.tile_box[tile_k][tile_index]) ? 1u : 0u;
+				g_tile_stats[3] += st == TILE_ACCEPT ? 1u : 0u;
+				g_tile_stats[4] += (any_cell && all_in) ? 1u : 0u;
 			}
-			if (tile_rejected(fr, lay.tile_box[tile_k][tile_index])) {
+			// the tile-level verdicts may only fire when the cell-by-cell classification agrees for every cell of the tile
+			if (st == TILE_REJECT) {
 				for (uint32_t c = first_cell; c <= last_cell; ++c)
 					if (info[c].cls != CELL_REJECT) return 8;
 				continue;
 			}
+			if (st == TILE_ACCEPT) {
+				for (uint32_t c = first_cell; c <= last_cell; ++c)
+					if (!(lay.cells[c].meta & LAYOUT_CELL_DEAD) && info[c].cls != CELL_ACCEPT) return 10;
+			}
 			uint32_t t = 0;
 			for (int k = 0; k < LAYOUT_MAX_TYPES; ++k)
 				if (chunk * 64 >= lay.ent_start[k] && chunk * 64 < lay.ent_end[k]) t = (uint32_t)k;
-			const uint32_t base_cell = lay.chunk_cell[chunk];
-			const uint64_t flags = lay.chunk_flags[chunk];
+			const LayoutChunkHdr h = lay.hdr[chunk];
 			for (uint32_t lane = 0; lane < 64; ++lane) {
 				const uint64_t le_mask = (~0ull >> (63u - lane)) & ~1ull;
-				const uint32_t cell = base_cell + (uint32_t)__builtin_popcountll(flags & le_mask);
+				const uint32_t cell = h.cell + (uint32_t)__builtin_popcountll(h.flags & le_mask);
 				if (cell != lay.slot_cell[chunk * 64 + lane]) return 2; // chunk header does not reproduce the slot->cell map
 				if (cell < first_cell || cell > last_cell) return 5;    // tile-local LDS index would be out of range
-				// phase A of the fused kernel: the class comes from the tile-major copy of the cell key
+				// phase A: the class comes from the tile-major copy of the cell key
 				const LayoutCell tkey = lay.tile_cells[tile_k][(size_t)tile_index * cap + (cell - first_cell)];
 				const LayoutCell gkey = lay.cells[cell];
 				if (tkey.ix != gkey.ix || tkey.iy != gkey.iy || tkey.iz != gkey.iz || tkey.meta != gkey.meta) return 7;
-				const Info ci = info[cell];
 				const uint32_t e = chunk * 64 + lane;
 				const int32_t id = lay.ids[e];
-				bool vis = ci.cls == CELL_ACCEPT;
-				if (ci.cls == CELL_TEST) {
-					const LayoutSphere s = lay.spheres[e];
-					vis = sphere_visible(fr, V3{ci.x, ci.y, ci.z}, s.x, s.y, s.z, s.radius);
+				bool vis;
+				if (st == TILE_MIXED) {
+					const Info& ci = info[cell];
+					vis = ci.cls == CELL_ACCEPT;
+					if (ci.cls == CELL_TEST) {
+						const LayoutSphere s = lay.spheres[e];
+						vis = sphere_visible_d(fr, ci.d, s.x, s.y, s.z, s.radius);
+					}
+				} else {
+					vis = true; // TILE_ACCEPT: ids are copied without looking at cells or spheres
 				}
 				vis = vis && id >= 0;
 				if (vis) {
@@ -112,6 +152,11 @@ int emul_cull(uint32_t n, const int32_t* entity, const uint8_t* type, const doub
 		}
 	}
 	return 0;
+}
+
+int emul_cull(uint32_t n, const int32_t* entity, const uint8_t* type, const double* pos, const float* radius,
+	const LmxShiftedFrustum* frusta, uint32_t n_frusta, uint8_t type_filter, int32_t* out_ids, uint8_t* out_types, uint32_t* out_counts) {
+	return emul_cull_variant(n, entity, type, pos, radius, frusta, n_frusta, type_filter, 0, out_ids, out_types, out_counts);
 }
 
 // emulates k_cull_dynamic: every entity derives cell / is_big / cell-relative position from its fp64 position and

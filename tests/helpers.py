@@ -152,3 +152,71 @@ def write_world_blob(entities, world, hierarchy, module_names=("renderer", "anim
     out += struct.pack("<I", 1 if partitions else 0)
     out += struct.pack("<II", len(blob), len(packed)) + packed
     return bytes(out), bytes(blob)
+
+
+# ---- BASELINE config 2 at full size: scenes, cameras and a deterministic update stream ------------------------------------
+CONFIG2_SCENES = {
+    # name: (half extent, mixed renderable types) - 10 M entities each, seed 2 (the scene bench.py times is "sparse" without types)
+    "sparse_mixed": (15000.0, True),
+    "dense": (5000.0, False),
+}
+
+
+def config2_cameras(builder):
+    """[(name, frustum)] for the 10 M parity test: the default player camera (bench.py's), a yaw/pitch camera, SURVEY.md 8d's
+    off-origin camera at (1e6, 50, -1e6) (sees nothing of a scene around the origin: exercises the fp64 shift), a narrow camera
+    (selects the 2048-sphere tile variant) and a camera outside that sees the whole cube (every tile TILE_ACCEPT)."""
+    return [
+        ("default", builder.viewport_frustum()),
+        ("yaw_pitch", builder.viewport_frustum(pos=(120.5, -30.25, 400.0), rot=quat_from_yaw_pitch(0.7, -0.3))),
+        ("far_origin", builder.viewport_frustum(pos=(1.0e6, 50.0, -1.0e6), rot=quat_from_yaw_pitch(2.1, 0.2))),
+        ("narrow", builder.viewport_frustum(pos=(-800.0, 120.0, 300.0), rot=quat_from_yaw_pitch(-1.3, 0.1), fov=float(np.deg2rad(20.0)), far=4000.0)),
+        ("all_visible", builder.viewport_frustum(pos=(0.0, 0.0, 60000.0), far=300000.0)),
+    ]
+
+
+def churn_stream(pos: np.ndarray, half_extent: float, frames: int, per_frame: int, seed: int = 77):
+    """Deterministic update stream for a scene whose entities 0..n-1 sit at `pos`: per frame `per_frame` removals of distinct
+    alive entities, `per_frame` adds of new entity ids (n, n+1, ...) and per_frame // 2 `set` calls on entities the stream never
+    removes - every other one stays within a unit of its old position (in-cell move: a 16-byte patch), the rest jump anywhere
+    (cell change: tombstone + overflow). Yields dicts of numpy arrays."""
+    n = len(pos)
+    rng = np.random.default_rng(seed)
+    victims = rng.permutation(n)[: frames * per_frame * 2].astype(np.int32)
+    next_id = n
+    for f in range(frames):
+        rem = victims[f * per_frame : (f + 1) * per_frame]
+        add_ids = np.arange(next_id, next_id + per_frame, dtype=np.int32)
+        next_id += per_frame
+        add_pos = rng.uniform(-half_extent, half_extent, size=(per_frame, 3))
+        add_r = np.exp(rng.uniform(np.log(0.5), np.log(50.0), size=per_frame)).astype(np.float32)
+        add_r[:: 97] = np.float32(420.0)  # a few big ones
+        add_t = (rng.random(per_frame) < 0.1).astype(np.uint8) * 2
+        movers = victims[(frames + f) * per_frame : (frames + f) * per_frame + per_frame // 2]  # never removed by this stream
+        set_pos = rng.uniform(-half_extent, half_extent, size=(len(movers), 3))
+        near = np.arange(len(movers)) % 2 == 0
+        set_pos[near] = pos[movers[near]] + rng.uniform(-1.0, 1.0, size=(int(near.sum()), 3))
+        set_r = np.exp(rng.uniform(np.log(0.5), np.log(50.0), size=len(movers))).astype(np.float32)
+        yield dict(remove=rem, add_ids=add_ids, add_type=add_t, add_pos=add_pos, add_radius=add_r, set_ids=movers, set_pos=set_pos, set_radius=set_r)
+
+
+def visible_digest(ids: np.ndarray, types: np.ndarray):
+    """Parity form of a large result: per-type counts + sha256 over the per-type sorted id lists (types ascending)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    counts = [0] * 8
+    for t in range(8):
+        a = np.sort(ids[types == t]).astype(np.int32)
+        counts[t] = int(len(a))
+        h.update(a.tobytes())
+    return counts, h.hexdigest()
+
+
+def array_digest(*arrays):
+    import hashlib
+
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()

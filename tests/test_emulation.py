@@ -89,9 +89,10 @@ def test_emulated_tile_early_out_is_conservative_and_effective(emul_lib, oracle_
         got, _ = emul_cull(emul_lib, sc, frusta[f : f + 1])
         ids, types, _ = cs.cull(frusta[f : f + 1])
         H.assert_same_visible(got[0], H.sorted_by_type(ids, types), f"frustum {f}")
-        st = np.zeros(3, np.uint32)
+        st = np.zeros(5, np.uint32)
         emul_lib.emul_tile_stats(_p(st))
-        tiles, boxed, dead = (int(x) for x in st)
+        tiles, boxed, dead = (int(x) for x in st[:3])
+        assert int(st[3]) <= int(st[4])  # TILE_ACCEPT never more often than the tiles whose cells are all accepted
         assert tiles >= 140 and boxed <= dead  # conservative: never more than the tiles that are really empty
         if dead > 20:
             assert boxed >= 0.6 * dead, f"frustum {f}: box test caught {boxed} of {dead} fully rejected tiles"
@@ -117,7 +118,7 @@ def test_emulated_tile_early_out_random_cameras(emul_lib, oracle_port):
             fr = oracle_port.viewport_frustum(fov=float(np.deg2rad(rng.uniform(10, 120))), w=1920, h=1080, near=float(rng.uniform(0.05, 5)), far=float(rng.uniform(300, 40000)),
                                               pos=tuple(pos), rot=tuple(q))
         got, _ = emul_cull(emul_lib, sc, fr)  # asserts rc == 0: code 8 would mean a non-conservative rejection
-        st = np.zeros(3, np.uint32)
+        st = np.zeros(5, np.uint32)
         emul_lib.emul_tile_stats(_p(st))
         assert st[1] <= st[2]
         boxed_total += int(st[1])
@@ -211,3 +212,91 @@ def test_emulated_dynamic_set_matches_golden(emul_lib):
         for f in range(nf):
             k = int(counts[f].sum())
             H.assert_same_visible(H.sorted_by_type(ids[f, :k], types[f, :k]), H.sorted_by_type(g[f"vis_ids_{f}"], g[f"vis_types_{f}"]), f"{fixture} frustum {f}")
+
+
+def test_emulated_tile_accept_is_conservative_and_effective(emul_lib, oracle_port):
+    """TILE_ACCEPT (the tile's ids are copied without looking at cells or spheres) may only fire when every live cell of the tile
+    is CELL_ACCEPT cell by cell (the emulation aborts with code 10 otherwise), and a camera that sees most of the scene takes
+    most fully-inside tiles that way. All four tile shapes of the 1-frustum kernel."""
+    sc = scenes.cull_scene(400_000, 6000.0, seed=19, big_fraction=0.0)
+    cs = oracle_port.culling_system()
+    cs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    cams = [oracle_port.viewport_frustum(pos=(0.0, 0.0, 30000.0), far=100000.0), oracle_port.viewport_frustum(pos=(0.0, 9000.0, 9000.0), rot=tuple(H.quat_from_yaw_pitch(0.0, -0.8)), far=40000.0),
+            oracle_port.viewport_frustum(is_ortho=True, ortho_size=7000.0, w=1024, h=1024, near=0.0, far=30000.0, pos=(0.0, 0.0, 15000.0))]
+    n, accepted_total = len(sc["entity"]), 0
+    for k, fr in enumerate(cams):
+        want_ids, want_types, _ = cs.cull(fr)
+        for variant in range(4):
+            ids = np.zeros((1, n), np.int32)
+            types = np.zeros((1, n), np.uint8)
+            counts = np.zeros((1, 8), np.uint32)
+            rc = emul_lib.emul_cull_variant(C.c_uint32(n), _p(np.ascontiguousarray(sc["entity"], np.int32)), _p(np.ascontiguousarray(sc["type"], np.uint8)),
+                                            _p(np.ascontiguousarray(sc["pos"], np.float64)), _p(np.ascontiguousarray(sc["radius"], np.float32)), _p(np.ascontiguousarray(fr)),
+                                            C.c_uint32(1), C.c_uint8(0xFF), C.c_int(variant), _p(ids), _p(types), _p(counts))
+            assert rc == 0, f"camera {k} variant {variant}: emulation failed with {rc}"
+            c = int(counts.sum())
+            H.assert_same_visible(H.sorted_by_type(ids[0, :c], types[0, :c]), H.sorted_by_type(want_ids, want_types), f"camera {k} variant {variant}")
+            st = np.zeros(5, np.uint32)
+            emul_lib.emul_tile_stats(_p(st))
+            assert st[3] <= st[4]
+            if st[4] > 20:
+                assert st[3] >= 0.6 * st[4], f"camera {k} variant {variant}: TILE_ACCEPT took {st[3]} of {st[4]} fully accepted tiles"
+            accepted_total += int(st[3])
+    assert accepted_total > 300
+
+
+def test_tile_status_margin_under_plane_scaling_and_adversarial_boxes(emul_lib, oracle_port):
+    """The tile-level verdicts guard a bit-exact contract with a rounding margin. The C ABI accepts any 256-byte ShiftedFrustum, so
+    the margin must hold for non-unit plane normals too (it scales with |n|_1 and |d|): frusta whose planes are scaled by
+    1e-3 .. 1e5 (same half-spaces, different rounding), origins up to 1e9, boxes whose corners sit within a few ulps of a plane.
+    For every box: TILE_REJECT => every cell of the box is CELL_REJECT, TILE_ACCEPT => every cell is CELL_ACCEPT."""
+    rng = np.random.default_rng(41)
+    checked = {0: 0, 1: 0, 2: 0}
+    for trial in range(160):
+        origin = rng.uniform(-1, 1, 3) * (10.0 ** rng.uniform(0, 9))
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        if trial % 3 == 0:
+            fr = oracle_port.viewport_frustum(is_ortho=True, ortho_size=float(rng.uniform(200, 3000)), w=1024, h=1024, near=0.0, far=float(rng.uniform(600, 9000)), pos=tuple(origin),
+                                              rot=(0, 0, 0, 1) if trial % 6 == 0 else tuple(q))
+        else:
+            fr = oracle_port.viewport_frustum(fov=float(np.deg2rad(rng.uniform(20, 110))), near=float(rng.uniform(0.1, 2)), far=float(rng.uniform(900, 20000)), pos=tuple(origin), rot=tuple(q))
+        fr = fr.copy()
+        scale = np.float32(10.0 ** rng.uniform(-3, 5)) if trial % 2 else np.float32(1.0)
+        for k in ("xs", "ys", "zs", "ds"):
+            fr[k] = (fr[k] * scale).astype(np.float32)
+        base = np.floor(origin / 300.0).astype(np.int64)
+        for _ in range(60):
+            lo = base + rng.integers(-14, 14, 3)
+            hi = lo + rng.integers(0, 5, 3)
+            if np.abs(lo).max() > 2**30 or np.abs(hi).max() > 2**30:
+                continue
+            lo32, hi32 = lo.astype(np.int32), hi.astype(np.int32)
+            st = emul_lib.emul_tile_status(_p(fr), _p(lo32), _p(hi32), C.c_uint32(0))
+            checked[st] += 1
+            if st == 2:
+                continue
+            for ix in range(lo[0], hi[0] + 1):
+                for iy in range(lo[1], hi[1] + 1):
+                    for iz in range(lo[2], hi[2] + 1):
+                        cls = emul_lib.emul_classify_cell(_p(fr), _p(np.array([ix, iy, iz], np.int32)), C.c_int(0))
+                        assert cls == st, f"trial {trial}: tile verdict {st} but cell ({ix},{iy},{iz}) classifies as {cls} (plane scale {scale}, origin {origin})"
+    assert checked[0] > 500 and checked[1] > 20 and checked[2] > 500, checked
+    # axis-aligned ortho frustum: boxes whose faces coincide with the planes up to a few ulps must come out MIXED or agree cell by cell
+    fr = oracle_port.viewport_frustum(is_ortho=True, ortho_size=1200.0, w=1024, h=1024, near=0.0, far=2400.0, pos=(0.0, 0.0, 0.0), rot=(0, 0, 0, 1))
+    for dx in (-1200.0, -900.0, -600.0, 600.0, 900.0, 1200.0):
+        for ulps in range(-3, 4):
+            f2 = fr.copy()
+            o = np.float64(dx)
+            for _ in range(abs(ulps)):
+                o = np.nextafter(o, np.inf if ulps > 0 else -np.inf)
+            f2["origin"][0][0] = o
+            for lo_x in range(-8, 8):
+                lo32, hi32 = np.array([lo_x, -2, -6], np.int32), np.array([lo_x + 1, 1, -1], np.int32)
+                st = emul_lib.emul_tile_status(_p(f2), _p(lo32), _p(hi32), C.c_uint32(0))
+                if st == 2:
+                    continue
+                for ix in (lo_x, lo_x + 1):
+                    for iy in range(-2, 2):
+                        for iz in range(-6, 0):
+                            assert emul_lib.emul_classify_cell(_p(f2), _p(np.array([ix, iy, iz], np.int32)), C.c_int(0)) == st

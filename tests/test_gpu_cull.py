@@ -1,5 +1,7 @@
 """Parity of the HIP cull path (through the C ABI) against the CPU oracle and the golden fixtures. Needs an MI355X."""
+import json
 import os
+import time
 
 import numpy as np
 import pytest
@@ -154,8 +156,99 @@ def test_cull_1m_vs_oracle(gpu_ctx, oracle_port, variant):
         H.assert_same_visible(gpu_visible(res, f), oracle_visible(ocs, fr[f : f + 1]), f"{variant}/{f}")
 
 
+def _digest(res, frustum=0):
+    ids, types = res.all_ids(frustum)
+    return H.visible_digest(ids, types)
+
+
+@pytest.mark.parametrize("scene", list(H.CONFIG2_SCENES))
+def test_cull_config2_10m_bit_exact(gpu_ctx, scene):
+    """BASELINE config 2 at full size (10 M entities, sparse with mixed types / dense): the visible ids of every camera, every tile
+    variant of the 1-frustum kernel, 8 cascade frusta in passes of width 1 / 4 / 8 and an update stream of 20 frames x (1000
+    removes + 1000 adds + 500 sets) are compared with the reference CPU path through committed digests (per-type counts +
+    sha256 of the sorted id lists, tests/golden/make_golden_10m.py: a 10 M oracle run costs minutes and 4 GB of result pages)."""
+    g = json.load(open(os.path.join(G, "cull_10m.json")))
+    n, rec = g["n"], g["scenes"][scene]
+    half, mixed = H.CONFIG2_SCENES[scene]
+    sc = scenes.cull_scene(n, half, seed=2, mixed_types=mixed)
+    assert H.array_digest(sc["entity"], sc["type"], sc["pos"], sc["radius"]) == rec["scene_sha"], "the scene generator's random stream differs from the one the digests were made with"
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    assert cs.stats()["cells"] == rec["cells"]
+    cams = H.config2_cameras(api)
+
+    def check(res, want, what, frustum=0):
+        counts, sha = _digest(res, frustum)
+        assert counts == want["counts"], f"{scene} {what}: visible counts {counts} vs reference {want['counts']}"
+        assert sha == want["sha256"], f"{scene} {what}: same counts, different ids"
+
+    for cam, fr in cams:
+        check(cs.cull(fr), rec["cameras"][cam], cam)
+    try:
+        for variant in range(4):
+            for lanepar in (0, 1):
+                cs.setOption(api.CULL_OPT_TILE_VARIANT, variant)
+                cs.setOption(api.CULL_OPT_LANE_PARALLEL_TILE_TEST, lanepar)
+                for cam, fr in cams:
+                    if cam in ("default", "narrow", "all_visible"):
+                        check(cs.cull(fr, view=1), rec["cameras"][cam], f"{cam} variant {variant} lane-parallel {lanepar}")
+        cs.setOption(api.CULL_OPT_TILE_VARIANT, -1)
+        cs.setOption(api.CULL_OPT_LANE_PARALLEL_TILE_TEST, 1)
+        for shards, pad in ((1, 1), (7, 16), (64, 32)):
+            cs.setOption(api.CULL_OPT_MAX_SHARDS, shards)
+            cs.setOption(api.CULL_OPT_COUNTER_PAD, pad)
+            check(cs.cull(cams[4][1], view=2), rec["cameras"]["all_visible"], f"{shards} shards, pad {pad}")
+            check(cs.cull(cams[0][1], view=2), rec["cameras"]["default"], f"{shards} shards, pad {pad}")
+    finally:
+        cs.setOption(api.CULL_OPT_TILE_VARIANT, -1)
+        cs.setOption(api.CULL_OPT_LANE_PARALLEL_TILE_TEST, 1)
+        cs.setOption(api.CULL_OPT_MAX_SHARDS, 64)
+        cs.setOption(api.CULL_OPT_COUNTER_PAD, 32)
+    if not mixed:
+        return
+    fr8 = H.cascade_frusta(api, 8)
+    try:
+        for width in (1, 4, 8):
+            cs.setPassWidth(width)
+            res = cs.cull(fr8)
+            for k in range(8):
+                check(res, rec["cascades"][k], f"cascade {k}, pass width {width}", frustum=k)
+    finally:
+        cs.setPassWidth(1)
+    # update stream: O(1) patches, no rebuild of the sorted set (the overflow stays far below the compaction threshold)
+    fr = cams[0][1]
+    for _ in range(3):
+        cs.cull(fr)
+    gpu_ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        cs.cull(fr)
+    gpu_ctx.synchronize()
+    t_cull = (time.perf_counter() - t0) / 20
+    t_frames = []
+    for f, ops in enumerate(H.churn_stream(sc["pos"], half, 20, 1000)):
+        t0 = time.perf_counter()
+        cs.removeMany(ops["remove"])
+        cs.addMany(ops["add_ids"], ops["add_type"], ops["add_pos"], ops["add_radius"])
+        cs.setMany(ops["set_ids"], ops["set_pos"], ops["set_radius"])
+        res = cs.cull(fr)
+        gpu_ctx.synchronize()
+        t_frames.append(time.perf_counter() - t0)
+        if str(f) in rec["churn"]:
+            check(res, rec["churn"][str(f)], f"update stream frame {f}")
+    st = cs.updateStats()
+    # nothing was rebuilt: 20 x 1000 adds + the sets that left their cell (every other one by construction, a few more by chance)
+    assert 25_000 <= st["overflow"] <= 25_500 and st["tombstones"] == st["overflow"], st
+    assert np.median(t_frames) - t_cull < 2e-3, f"2500 updates add {1e6 * (np.median(t_frames) - t_cull):.0f} us to a {1e6 * t_cull:.0f} us cull"
+    # a compaction folds everything back into the sorted layout: same visible set
+    cs.compact()
+    st = cs.updateStats()
+    assert st["overflow"] == 0 and st["tombstones"] == 0
+    check(cs.cull(fr), rec["churn"]["19"], "after compaction")
+
+
 def test_cull_10m_properties(gpu_ctx):
-    """BASELINE config 2 size (10 M): size-independent properties instead of a CPU comparison.
+    """BASELINE config 2 size (10 M): size-independent properties next to the digest comparison above.
 
     * a frustum containing the whole scene returns every id exactly once;
     * culling is idempotent and independent of the batch a frustum is evaluated in;
@@ -177,6 +270,51 @@ def test_cull_10m_properties(gpu_ctx):
     again = cs.cull(narrow, view=1)
     assert np.array_equal(np.sort(again.ids(0, 0)), a)
     assert len(np.unique(a)) == len(a)
+
+
+def test_cull_update_stream_vs_oracle(gpu_ctx, oracle_port):
+    """The O(1) update path against the live oracle at 300 k entities: removals (tombstones), adds and cross-cell sets (overflow in
+    the dynamic set), in-cell sets (sphere patches), a growing overflow region (slot reassignment), re-adding removed entities,
+    and an explicit compaction in the middle of the stream."""
+    n, half = 300_000, 4500.0
+    sc = scenes.cull_scene(n, half, seed=9, mixed_types=True)
+    cs = api.CullingSystem(gpu_ctx)
+    ocs = oracle_port.culling_system()
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    ocs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    fr = H.frusta(api, names=["origin_identity", "origin_yaw_pitch", "ortho_cascade_large"])
+    removed = []
+    for f, ops in enumerate(H.churn_stream(sc["pos"], half, 12, 3000, seed=5)):
+        cs.removeMany(ops["remove"])
+        cs.addMany(ops["add_ids"], ops["add_type"], ops["add_pos"], ops["add_radius"])
+        cs.setMany(ops["set_ids"], ops["set_pos"], ops["set_radius"])
+        for e in ops["remove"]:
+            ocs.remove(int(e))
+        for i in range(len(ops["add_ids"])):
+            ocs.add(int(ops["add_ids"][i]), int(ops["add_type"][i]), ops["add_pos"][i], float(ops["add_radius"][i]))
+        for i in range(len(ops["set_ids"])):
+            ocs.set(int(ops["set_ids"][i]), ops["set_pos"][i], float(ops["set_radius"][i]))
+        removed.extend(int(e) for e in ops["remove"][:50])
+        if f % 3 == 2:  # bring some removed entities back (they now live in the overflow) and touch overflow entities again
+            back = removed[-100:]
+            for e in back:
+                cs.add(e, 0, sc["pos"][e], 7.5)
+                ocs.add(e, 0, sc["pos"][e], 7.5)
+            for e in ops["add_ids"][:40]:
+                cs.setRadius(int(e), 301.0)
+                ocs.set_radius(int(e), 301.0)
+                cs.setPosition(int(e), (12.0, 3.0, -40.0))
+                ocs.set_position(int(e), (12.0, 3.0, -40.0))
+            for e in ops["add_ids"][40:60]:
+                cs.remove(int(e))
+                ocs.remove(int(e))
+            removed = removed[:-100]
+        if f == 6:
+            cs.compact()
+        res = cs.cull(fr)
+        for k in range(len(fr)):
+            H.assert_same_visible(gpu_visible(res, k), oracle_visible(ocs, fr[k : k + 1]), f"frame {f} frustum {k}")
+    assert cs.stats()["cells"] == ocs.cell_count()
 
 
 def test_cull_one_sphere_per_cell_layout_padding(gpu_ctx, oracle_port):
