@@ -175,67 +175,86 @@ def main():
     res = cs.cull(frustum)
     visible = int(res.counts()[0].sum())
 
-    # ---- roofline of the dominant kernel: same loop, HIP events around each launch on the launch stream -------
+    # ---- roofline of the dominant kernel (k_cull_tile): HIP events around each launch on the launch stream -------------------
+    # Three regimes of the same kernel on the same 10 M geometry:
+    #   default camera   hierarchical skip: ~95 % of the tiles end at the tile-level box test. Latency regime; the algorithmic
+    #                    bytes (20 B per RESIDENT entity) are mostly never moved, so it is reported as an effective rate only.
+    #   all_accept       a camera that sees the whole cube: every tile is TILE_ACCEPT, ids are copied: 4 B read + 4 B written per entity.
+    #   all_test         the same positions with radii in (300, 330]: every cell is a "big" cell (culling_system.cpp:140,342-344) and
+    #                    skips the AABB pre-test, so every sphere is fetched and tested: 16 B + 4 B read per entity + 4 B per visible
+    #                    id. Here moved bytes == algorithmic bytes: this leg, cache-cold, is `roofline.frac`.
     scrub = torch.zeros(1 << 30, dtype=torch.uint8, device="cuda")  # 1 GiB > 256 MiB Infinity Cache
 
-    def kernel_times(fr, steps, cold):
-        """avg device ms of (k_cull_spheres, k_cull_classify) over `steps` culls; cold: evict the MALL before each cull"""
+    def kernel_times(csys, fr, steps, cold):
+        """avg device ms of k_cull_tile over `steps` culls; cold: evict the MALL before each cull"""
         ctx.profile_reset()
         ctx.profile_enable(True)
         for _ in range(steps):
             if cold:
                 scrub.add_(1)
-            cs.cull(fr)
+            csys.cull(fr)
         ctx.synchronize()
         ctx.profile_enable(False)
         ms_s, n_s = ctx.profile_get(api.K_CULL_SPHERES)
-        ms_c, n_c = ctx.profile_get(api.K_CULL_CLASSIFY)
-        return ms_s / max(n_s, 1), ms_c / max(n_c, 1)
+        return ms_s / max(n_s, 1)
 
-    avg_spheres_ms, avg_classify_ms = kernel_times(frustum, args.steps, cold=False)
-    if args.headline_only:
-        cold_spheres_ms = cold_classify_ms = stream_warm_ms = stream_cold_ms = float("nan")
-        stream_visible = 0
-    else:
-        cold_spheres_ms, cold_classify_ms = kernel_times(frustum, min(args.steps, 50), cold=True)
-        # the pure streaming case on the same scene: a camera that sees the whole cube (every sphere fetched and visible)
-        stream_fr = api.viewport_frustum(pos=(0.0, 0.0, 4.0 * half), far=20.0 * half)
-        stream_visible = int(cs.cull(stream_fr).counts()[0].sum())
-        stream_warm_ms, _ = kernel_times(stream_fr, min(args.steps, 50), cold=False)
-        stream_cold_ms, _ = kernel_times(stream_fr, min(args.steps, 50), cold=True)
-    del scrub
-    # algorithmic bytes of one cull launch (SURVEY.md §8d): 16 B sphere + 4 B id per resident entity, 4 B per visible id
-    alg_bytes = 20.0 * N + 4.0 * visible
-    stream_bytes = 20.0 * N + 4.0 * stream_visible
-    achieved = alg_bytes / (avg_spheres_ms * 1e-3) / 1e9
     gbps = lambda b, ms: None if ms != ms else round(b / (ms * 1e-3) / 1e9, 1)
     rnd = lambda x, n: None if x != x else round(x, n)
-    traffic, traffic_note = load_traffic("k_cull_fused" if avg_classify_ms == 0.0 else "k_cull_spheres")
+    frac = lambda b, ms: None if ms != ms else round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+    avg_default_ms = kernel_times(cs, frustum, args.steps, cold=False)
+    alg_bytes = 20.0 * N + 4.0 * visible
+    legs = {"default_camera": {
+        "visible": visible, "warm_avg_launch_ms": rnd(avg_default_ms, 5), "algorithmic_bytes": alg_bytes,
+        "effective_GBps": gbps(alg_bytes, avg_default_ms),
+        "note": "effective rate: 20 B per resident entity although ~95 % of the tiles are rejected by their box and never fetched; not a roofline fraction",
+    }}
+    nan = float("nan")
+    test_cold_ms = test_warm_ms = nan
+    test_bytes = 0.0
+    if not args.headline_only:
+        legs["default_camera"]["cold_avg_launch_ms"] = rnd(kernel_times(cs, frustum, min(args.steps, 50), cold=True), 5)
+        accept_fr = api.viewport_frustum(pos=(0.0, 0.0, 4.0 * half), far=20.0 * half)
+        accept_visible = int(cs.cull(accept_fr).counts()[0].sum())
+        acc_warm = kernel_times(cs, accept_fr, min(args.steps, 50), cold=False)
+        acc_cold = kernel_times(cs, accept_fr, min(args.steps, 50), cold=True)
+        acc_bytes = 8.0 * N  # 4 B id read + 4 B id written per entity; cell keys and spheres are not touched
+        legs["all_accept"] = {"visible": accept_visible, "moved_bytes": acc_bytes, "warm_avg_launch_ms": rnd(acc_warm, 5), "cold_avg_launch_ms": rnd(acc_cold, 5),
+                              "warm_GBps": gbps(acc_bytes, acc_warm), "cold_GBps": gbps(acc_bytes, acc_cold), "warm_frac": frac(acc_bytes, acc_warm), "cold_frac": frac(acc_bytes, acc_cold),
+                              "vs_20B_formula_cold_GBps": gbps(20.0 * N + 4.0 * accept_visible, acc_cold)}
+        # all_test: same positions, every sphere "big" -> every cell CELL_TEST
+        sc_t = dict(sc)
+        sc_t["radius"] = np.random.default_rng(5).uniform(300.5, 330.0, size=N).astype(np.float32)
+        cs_t = api.CullingSystem(ctx)
+        cs_t.build(sc_t["entity"], sc_t["type"], sc_t["pos"], sc_t["radius"])
+        for _ in range(20):
+            cs_t.cull(frustum)
+        test_visible = int(cs_t.cull(frustum).counts()[0].sum())
+        test_bytes = 20.0 * N + 4.0 * test_visible
+        test_warm_ms = kernel_times(cs_t, frustum, min(args.steps, 50), cold=False)
+        test_cold_ms = kernel_times(cs_t, frustum, min(args.steps, 50), cold=True)
+        legs["all_test"] = {"visible": test_visible, "moved_bytes": test_bytes, "warm_avg_launch_ms": rnd(test_warm_ms, 5), "cold_avg_launch_ms": rnd(test_cold_ms, 5),
+                            "warm_GBps": gbps(test_bytes, test_warm_ms), "cold_GBps": gbps(test_bytes, test_cold_ms), "warm_frac": frac(test_bytes, test_warm_ms),
+                            "cold_frac": frac(test_bytes, test_cold_ms), "cells": cs_t.stats()["cells"]}
+        del cs_t, sc_t
+    del scrub
+    traffic, traffic_note = load_traffic("k_cull_tile:all_test")
+    roof_ms = test_cold_ms if test_cold_ms == test_cold_ms else avg_default_ms
+    roof_bytes = test_bytes if test_cold_ms == test_cold_ms else alg_bytes
     roofline = {
-        "kernel": "k_cull_fused" if avg_classify_ms == 0.0 else "k_cull_spheres",
+        "kernel": "k_cull_tile",
         "bound": "hbm",
-        "achieved": round(achieved, 1),
+        "leg": "all_test, cache-cold (every sphere fetched and tested: moved bytes == SURVEY.md 8d's 20 B/entity + 4 B/visible id)" if test_cold_ms == test_cold_ms
+               else "default camera only (--headline-only): effective rate, NOT a roofline fraction",
+        "achieved": round(roof_bytes / (roof_ms * 1e-3) / 1e9, 1),
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBPS, 4),
-        "traffic": traffic,  # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/)
-        "traffic_note": traffic_note,
-        "algorithmic_bytes_per_launch": alg_bytes,
-        "avg_launch_ms": round(avg_spheres_ms, 5),
-        "classify_kernel_avg_launch_ms": round(avg_classify_ms, 5),
-        "whole_cull_achieved_GBps": gbps(alg_bytes + 36.0 * stats["cells"], avg_spheres_ms + avg_classify_ms),
-        # the back-to-back loop keeps the 200 MB working set in the 256 MiB Infinity Cache; cold = 1 GiB scrub before each cull
-        "cold_avg_launch_ms": rnd(cold_spheres_ms, 5),
-        "cold_achieved_GBps": gbps(alg_bytes, cold_spheres_ms),
-        "cold_frac": rnd(alg_bytes / (cold_spheres_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-        # streaming case (camera sees everything: no hierarchical skip, every algorithmic byte is really moved)
-        "streaming_visible": stream_visible,
-        "streaming_warm_avg_launch_ms": rnd(stream_warm_ms, 5),
-        "streaming_warm_GBps": gbps(stream_bytes, stream_warm_ms),
-        "streaming_cold_avg_launch_ms": rnd(stream_cold_ms, 5),
-        "streaming_cold_GBps": gbps(stream_bytes, stream_cold_ms),
-        "streaming_cold_frac": rnd(stream_bytes / (stream_cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-        "note": "algorithmic bytes count every resident sphere although whole rejected cells are never fetched (the reference's per-cell reject), so `frac` of the default camera can exceed 1; streaming_cold_frac is the honest HBM-streaming efficiency of the kernel",
+        "frac": round(roof_bytes / (roof_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "traffic": traffic,  # HBM bytes per launch of the all_test leg: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed under profiles/
+        "traffic_source": traffic_note,
+        "algorithmic_bytes_per_launch": roof_bytes,
+        "avg_launch_ms": round(roof_ms, 5),
+        "measured_copy_ceiling_GBps": 6290.0,
+        "legs": legs,
     }
 
     result = {
@@ -301,8 +320,9 @@ def step_and_drain(step, xchg, steps):
 
 
 def load_traffic(kernel):
-    """HBM bytes per launch of the headline kernel, measured by separate rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    cannot share a pass) and committed as profiles/rNN/traffic.json. None when no such file travels with the repo."""
+    """HBM bytes per launch of the roofline leg, measured by separate rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot
+    share a pass; tools/collect_traffic.sh) and COMMITTED as profiles/rNN/traffic.json - a builder-side measurement of the same
+    command, not of this run. None when no such file travels with the repo."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
@@ -312,7 +332,7 @@ def load_traffic(kernel):
         t = json.load(open(files[-1])).get(kernel)
         if not t:
             return None, f"{os.path.relpath(files[-1], ROOT)} has no entry for {kernel}"
-        return t["hbm_bytes_per_launch"], f"{os.path.relpath(files[-1], ROOT)}: {t['note']}"
+        return t["hbm_bytes_per_launch"], f"committed file {os.path.relpath(files[-1], ROOT)} (not measured in this run): {t['note']}"
     except Exception as e:  # noqa: BLE001 - a malformed profile file must not break the bench line
         return None, f"unreadable traffic file: {e}"
 

@@ -117,7 +117,7 @@ LMX_API int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* fr
 LMX_API int lmx_cull_set_pass_width(LmxContext* ctx, uint32_t frusta_per_pass);
 /* Kernel tuning knobs (no reference twin; results never depend on them). */
 enum {
-	LMX_CULL_OPT_TILE_VARIANT = 0,            /* 1-frustum kernel tile: -1 auto (default), 0 = 8 waves x 8 chunks (4096 spheres), 1 = 4 x 8, 2 = 8 x 4 (2048), 3 = 4 x 4 (1024) */
+	LMX_CULL_OPT_TILE_VARIANT = 0,            /* 1-frustum kernel tile: -1 auto (default), 0 = 8 waves x 8 chunks (4096 spheres), 1 = 4 x 8, 2 = 8 x 4 (2048), 3 = 4 x 4 (1024), 4 / 5 = 1 / 0 with all 8 chunks' loads in flight */
 	LMX_CULL_OPT_LANE_PARALLEL_TILE_TEST = 1, /* 1 (default): the tile-level box test of the 1-frustum kernel runs one plane per lane */
 	LMX_CULL_OPT_MAX_SHARDS = 2,              /* output shards (reservation counters) per renderable type, 1..64 (default 64) */
 	LMX_CULL_OPT_COUNTER_PAD = 3              /* 32-bit words between two shard counters, 1..64 (default 32 = one 128-byte line each) */
@@ -178,8 +178,14 @@ LMX_API int lmx_world_read_local_transforms(LmxContext* ctx, LmxTransform* out, 
 /* Host-side Transform::compose / Transform::computeLocal (core/math.cpp:801-816), bit-identical to the engine's. */
 LMX_API int lmx_transform_compose(const LmxTransform* a, const LmxTransform* b, LmxTransform* out);
 LMX_API int lmx_transform_compute_local(const LmxTransform* parent, const LmxTransform* child, LmxTransform* out);
-/* World::setTransform for roots / World::setLocalTransform for children (world.cpp:337-342, 741-753), staged. */
+/* World::setTransform for roots / World::setLocalTransform for children (world.cpp:337-342, 741-753), staged until
+ * lmx_world_propagate. Exactly like the reference, a child written this way gets world = parent.compose(local) and its STORED
+ * local is then re-derived as Transform::computeLocal(parent, world) (world.cpp:266-269 reached through :704-712) - which is
+ * what later frames compose with. The writes of one batch are applied as if issued ancestors-first (level order). */
 LMX_API int lmx_world_set_transforms(LmxContext* ctx, uint32_t n, const int32_t* entity, const LmxTransform* transforms);
+/* World::setTransform (world-space write, world.cpp:337-342) on any entity: an entity with a parent keeps the given world
+ * transform and its local becomes computeLocal(parent world, world); its subtree follows at the next lmx_world_propagate. */
+LMX_API int lmx_world_set_world_transforms(LmxContext* ctx, uint32_t n, const int32_t* entity, const LmxTransform* transforms);
 /* Same, with both arrays already in device memory (entity indices must be valid; they are not checked). */
 LMX_API int lmx_world_set_transforms_device(LmxContext* ctx, uint32_t n, const void* d_entity, const void* d_transforms);
 /* RenderModuleImpl::onModelInstanceMoved binding (render_module.cpp:1544-1554): after propagation the culling

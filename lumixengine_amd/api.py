@@ -119,6 +119,7 @@ SYMBOLS = {
     "lmx_transform_compose": (_ci, [_vp, _vp, _vp]),
     "lmx_transform_compute_local": (_ci, [_vp, _vp, _vp]),
     "lmx_world_set_transforms": (_ci, [_vp, _u32, _vp, _vp]),
+    "lmx_world_set_world_transforms": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_world_set_transforms_device": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_world_bind_culling": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_world_propagate": (_ci, [_vp]),
@@ -465,6 +466,13 @@ class World:
         transforms = np.ascontiguousarray(transforms, TRANSFORM)
         assert len(entity) == len(transforms)
         self.ctx.check(self.lib.lmx_world_set_transforms(self.ctx.h, len(entity), _ptr(entity), _ptr(transforms)))
+
+    def setWorldTransforms(self, entity, transforms):
+        """World::setTransform (world-space) on any entity, staged until propagate()."""
+        entity = np.ascontiguousarray(entity, np.int32)
+        transforms = np.ascontiguousarray(transforms, TRANSFORM)
+        assert len(entity) == len(transforms)
+        self.ctx.check(self.lib.lmx_world_set_world_transforms(self.ctx.h, len(entity), _ptr(entity), _ptr(transforms)))
 
     def setTransformsDevice(self, n: int, d_entity: int, d_transforms: int):
         """Same as setTransforms with both arrays already resident in HBM (raw device pointers)."""

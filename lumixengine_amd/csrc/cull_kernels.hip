@@ -92,7 +92,7 @@ static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustu
 // F == 1: the single-frustum kernel (the common case: one launch per view). F == 0: n_frusta (2..8) is a runtime value and every
 // per-frustum loop is a real loop, so registers do not scale with the number of frusta (8 unrolled copies needed 172 VGPRs and
 // 600 spilled SGPRs); FS is the stride of a chunk's visibility bits.
-template <int F, int WAVES, int CHW, bool LANEPAR>
+template <int F, int WAVES, int CHW, int GRP, bool LANEPAR>
 __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg, const float4* __restrict__ g_spheres, const int32_t* __restrict__ g_ids,
 	const ChunkHdr* __restrict__ g_hdr, const CellKey* __restrict__ g_tile_cells, const uint32_t* __restrict__ g_tile_tab, const TileBox* __restrict__ g_tile_box,
 	const uint32_t* __restrict__ g_win_base, int32_t* __restrict__ g_out_ids, uint32_t* __restrict__ g_counts, uint32_t* __restrict__ g_counts_next, const TileScalars a) {
@@ -112,6 +112,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg
 
 	// the counters of the NEXT cull on this view are cleared here (ping-pong), so no cull needs a separate memset
 	for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < a.n_zero; i += gridDim.x * THREADS) g_counts_next[i] = 0;
+
+	// The headers of this wave's chunks sit at an address that depends on blockIdx only: lane i fetches header i now, so the
+	// (HBM-cold) load runs under the tile test and the cell classification instead of after them; a chunk's header is then
+	// broadcast from its lane (v_readlane) when the chunk is processed.
+	const uint32_t chunk0 = (tile_ent >> 6) + wave * CHW;
+	const uint4 hdr_v = reinterpret_cast<const uint4*>(g_hdr)[chunk0 + (lane < (uint32_t)CHW ? lane : 0u)];
 
 	// 0. tile-level test per frustum (2 bits each). Everything read here sits at addresses that depend on blockIdx only.
 	uint32_t st_bits = 0;
@@ -179,9 +185,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg
 
 	// B. this wave's CHW chunks, in groups of GRP so that at most GRP chunks' worth of spheres are live in registers
 	// (VGPR count decides how many tiles a CU keeps in flight)
-	const uint32_t chunk0 = (tile_ent >> 6) + wave * CHW;
 	const uint64_t le_mask = (~0ull >> (63u - lane)) & ~1ull; // bits 1..lane
-	constexpr int GRP = CHW > 4 ? 4 : CHW;
+	static_assert(CHW % GRP == 0, "groups tile the wave's chunks");
 	int32_t id[CHW];
 	uint32_t vis_bits = 0; // bit i * FS + f: sphere `lane` of chunk i is visible in frustum f
 	uint32_t mine = 0;     // lane f: this wave's visible count for frustum f
@@ -195,8 +200,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg
 			bool lane_live = false, lane_test = false;
 			local[i] = 0;
 			if (any_mixed) {
-				const ChunkHdr h = g_hdr[chunk0 + g + i]; // wave-uniform: one 16-byte scalar load
-				local[i] = h.cell + (uint32_t)__popcll(h.flags & le_mask) - first_cell;
+				const uint32_t h_cell = __builtin_amdgcn_readlane(hdr_v.x, g + i);
+				const uint64_t h_flags = (uint64_t)__builtin_amdgcn_readlane(hdr_v.z, g + i) | ((uint64_t)__builtin_amdgcn_readlane(hdr_v.w, g + i) << 32);
+				local[i] = h_cell + (uint32_t)__popcll(h_flags & le_mask) - first_cell;
 #pragma unroll 1
 				for (int f = 0; f < nf; ++f) {
 					const uint32_t cls = s_info[f * a.cell_cap + local[i]].cls;
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(256) void k_cull_consolidate(const int32_t* __restr
 	for (uint32_t k = blockIdx.z * 256u + threadIdx.x; k < c; k += gridDim.z * 256u) to[k] = from[k];
 }
 
-template <int F, int WAVES, int CHW, bool LANEPAR>
+template <int F, int WAVES, int CHW, int GRP, bool LANEPAR>
 hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt, const FrustaArg& fr, int n_frusta,
 	const CullOut& out) {
 	constexpr uint32_t TILE = WAVES * CHW * 64;
@@ -400,7 +406,7 @@ hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, ui
 	a.cnt_pad = out.cnt_pad;
 	a.cnt_frustum_stride = out.cnt_frustum_stride;
 	a.n_zero = out.n_zero;
-	hipLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, LANEPAR>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, fr, v.spheres, v.ids, v.hdr,
+	hipLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, LANEPAR>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, fr, v.spheres, v.ids, v.hdr,
 		v.tile_cells[K], v.tile_tab[K], v.tile_box[K], out.win_base, out.ids, out.counts, out.counts_next, a);
 	return hipGetLastError();
 }
@@ -410,32 +416,36 @@ hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, ui
 size_t cull_tile_lds_bytes(int n_frusta, uint32_t cell_cap) { return (size_t)n_frusta * cell_cap * sizeof(CellInfo); }
 
 uint32_t cull_tile_size(int n_frusta, int variant) {
-	if (n_frusta <= 1) return variant == 0 ? 4096u : (variant == 3 ? 1024u : 2048u);
+	if (n_frusta <= 1) return (variant == 0 || variant == 5) ? 4096u : (variant == 3 ? 1024u : 2048u);
 	return n_frusta <= 4 ? 2048u : 1024u;
 }
 
 hipError_t launch_cull_tile(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt, const FrustaArg& fr,
 	int n_frusta, const CullOut& out, int variant, bool lane_parallel_status) {
-#define LMX_TILE(F, W, C, L) return tile_f<F, W, C, L>(s, v, ent_begin, ent_end, tt, fr, n_frusta, out)
+#define LMX_TILE(F, W, C, G, L) return tile_f<F, W, C, G, L>(s, v, ent_begin, ent_end, tt, fr, n_frusta, out)
 	if (n_frusta < 1 || n_frusta > MAX_FRUSTA) return hipErrorInvalidValue;
 	if (n_frusta == 1) {
 		if (lane_parallel_status) {
 			switch (variant) {
-				case 0: LMX_TILE(1, 8, 8, true);
-				case 1: LMX_TILE(1, 4, 8, true);
-				case 2: LMX_TILE(1, 8, 4, true);
-				default: LMX_TILE(1, 4, 4, true);
+				case 0: LMX_TILE(1, 8, 8, 4, true);
+				case 1: LMX_TILE(1, 4, 8, 4, true);
+				case 2: LMX_TILE(1, 8, 4, 4, true);
+				case 3: LMX_TILE(1, 4, 4, 4, true);
+				case 4: LMX_TILE(1, 4, 8, 8, true);
+				default: LMX_TILE(1, 8, 8, 8, true);
 			}
 		}
 		switch (variant) {
-			case 0: LMX_TILE(1, 8, 8, false);
-			case 1: LMX_TILE(1, 4, 8, false);
-			case 2: LMX_TILE(1, 8, 4, false);
-			default: LMX_TILE(1, 4, 4, false);
+			case 0: LMX_TILE(1, 8, 8, 4, false);
+			case 1: LMX_TILE(1, 4, 8, 4, false);
+			case 2: LMX_TILE(1, 8, 4, 4, false);
+			case 3: LMX_TILE(1, 4, 4, 4, false);
+			case 4: LMX_TILE(1, 4, 8, 8, false);
+			default: LMX_TILE(1, 8, 8, 8, false);
 		}
 	}
-	if (n_frusta <= 4) LMX_TILE(0, 8, 4, false); // 2048-sphere tiles, <= 4 x 32 B of LDS per cell
-	LMX_TILE(0, 4, 4, false);                    // 1024-sphere tiles
+	if (n_frusta <= 4) LMX_TILE(0, 8, 4, 4, false); // 2048-sphere tiles, <= 4 x 32 B of LDS per cell
+	LMX_TILE(0, 4, 4, 4, false);                    // 1024-sphere tiles
 #undef LMX_TILE
 }
 

@@ -47,7 +47,15 @@ bool layout_live(const CullState& cs) { return cs.built && !cs.structure_dirty; 
 // ---- dynamic set: slots and patches -----------------------------------------------------------------------------
 void queue_dyn_patch(CullState& cs, const DynRec& r, bool alive) {
 	if (r.slot == DYN_NO_SLOT || cs.dyn_layout_dirty) return; // the pending rebuild uploads the whole mirror
-	cs.q_dyn.push_back(PatchDyn{r.slot, alive ? r.entity : -1, r.radius, 0u, r.pos[0], r.pos[1], r.pos[2]});
+	const PatchDyn p{r.slot, alive ? r.entity : -1, r.radius, 0u, r.pos[0], r.pos[1], r.pos[2]};
+	if (cs.q_dyn_at.size() < cs.dyn_padded) cs.q_dyn_at.resize(cs.dyn_padded, ~0u);
+	uint32_t& at = cs.q_dyn_at[r.slot];
+	if (at != ~0u) { // a freed slot taken again / an entity set twice before the next flush: the last write wins
+		cs.q_dyn[at] = p;
+		return;
+	}
+	at = (uint32_t)cs.q_dyn.size();
+	cs.q_dyn.push_back(p);
 }
 
 uint32_t take_dyn_slot(CullState& cs, uint8_t type) {
@@ -117,7 +125,14 @@ void readd_static(CullState& cs, uint32_t rec, DV3 pos, float radius) {
 void mark_patch(CullState& cs, uint32_t rec) {
 	if (!layout_live(cs)) return;
 	const CullRec& r = cs.recs[rec];
-	cs.q_sphere.push_back(PatchSphere{cs.rec_slot[rec], r.rel.x, r.rel.y, r.rel.z, r.radius});
+	const PatchSphere p{cs.rec_slot[rec], r.rel.x, r.rel.y, r.rel.z, r.radius};
+	auto it = cs.q_sphere_at.find(p.slot);
+	if (it != cs.q_sphere_at.end()) {
+		cs.q_sphere[it->second] = p;
+		return;
+	}
+	cs.q_sphere_at.emplace(p.slot, (uint32_t)cs.q_sphere.size());
+	cs.q_sphere.push_back(p);
 }
 
 // What the reference's stored state (cell, cell-relative fp32 position) means as a world position:
@@ -126,6 +141,16 @@ DV3 stored_position(DV3 pos) {
 	const IV3 idx = cell_of(pos);
 	const DV3 origin = cell_origin(idx);
 	return add(origin, to_v3(sub(pos, origin)));
+}
+
+void clear_static_queues(CullState& cs) {
+	cs.q_sphere.clear();
+	cs.q_sphere_at.clear();
+	cs.q_id.clear();
+}
+void clear_dyn_queue(CullState& cs) {
+	for (const PatchDyn& p : cs.q_dyn) cs.q_dyn_at[p.slot] = ~0u;
+	cs.q_dyn.clear();
 }
 
 DynDeviceView dyn_view(const CullState& cs) {
@@ -172,9 +197,8 @@ int apply_patches(LmxContext* ctx) {
 	LMX_HIP(ctx, hipEventRecord(st.done[k], ctx->stream));
 	LMX_HIP(ctx, launch_apply_patches(ctx->stream, cs.spheres.p, cs.ids.p, dyn_view(cs), (const PatchSphere*)(cs.d_patch.p + o_ps), (uint32_t)n_ps,
 		(const PatchId*)(cs.d_patch.p + o_pi), (uint32_t)n_pi, (const PatchDyn*)(cs.d_patch.p + o_pd), (uint32_t)n_pd));
-	cs.q_sphere.clear();
-	cs.q_id.clear();
-	cs.q_dyn.clear();
+	clear_static_queues(cs);
+	clear_dyn_queue(cs);
 	return LMX_OK;
 }
 
@@ -226,8 +250,7 @@ int rebuild_static(LmxContext* ctx) {
 	cs.structure_dirty = false;
 	cs.built = true;
 	cs.n_tombstones = 0;
-	cs.q_sphere.clear();
-	cs.q_id.clear();
+	clear_static_queues(cs);
 	return LMX_OK;
 }
 
@@ -279,6 +302,7 @@ int rebuild_dynamic(LmxContext* ctx) {
 	}
 	cs.dyn_layout_dirty = false;
 	cs.q_dyn.clear();
+	cs.q_dyn_at.assign(padded, ~0u);
 	cs.dyn_generation++;
 	return LMX_OK;
 }
@@ -500,9 +524,9 @@ int lmx_cull_build(LmxContext* ctx, uint32_t n, const int32_t* entity, const uin
 	cs.n_unbound = 0;
 	cs.dyn_layout_dirty = true;
 	cs.dyn_mirror_stale = false;
-	cs.q_sphere.clear();
-	cs.q_id.clear();
+	clear_static_queues(cs);
 	cs.q_dyn.clear();
+	cs.q_dyn_at.clear();
 	cs.ent_to_rec.assign((size_t)max_entity + 1, -1);
 	cs.structure_dirty = true;
 	for (uint32_t i = 0; i < n; ++i) {
@@ -842,7 +866,7 @@ int lmx_cull_set_option(LmxContext* ctx, int option, int value) {
 	CullState& cs = ctx->cull;
 	switch (option) {
 		case LMX_CULL_OPT_TILE_VARIANT:
-			if (value < -1 || value > 3) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "tile variant %d not in [-1,3]", value);
+			if (value < -1 || value > 5) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "tile variant %d not in [-1,5]", value);
 			cs.tile_variant = value;
 			return LMX_OK;
 		case LMX_CULL_OPT_LANE_PARALLEL_TILE_TEST: cs.lane_parallel = value != 0; return LMX_OK;

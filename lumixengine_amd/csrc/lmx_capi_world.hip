@@ -64,7 +64,9 @@ int world_rebuild(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxT
 	LMX_HIP(ctx, w.d_parent_slot.reserve(cap));
 	LMX_HIP(ctx, w.d_slot_of_entity.reserve(cap));
 	LMX_HIP(ctx, w.d_entity_of_slot.reserve(cap));
+	LMX_HIP(ctx, w.d_dirty.reserve(cap));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	LMX_HIP(ctx, hipMemset(w.d_dirty.p, 0, cap));
 	if (n) {
 		LMX_HIP(ctx, hipMemcpy(w.d_parent_slot.p, w.parent_slot.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(w.d_slot_of_entity.p, w.slot_of_entity.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -77,11 +79,11 @@ int world_rebuild(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxT
 		LMX_HIP(ctx, hipMemcpy(w.d_stage_entity.p, all.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
 		if (world_all) {
 			LMX_HIP(ctx, hipMemcpy(w.d_stage_tr.p, world_all, n * sizeof(LmxTransform), hipMemcpyHostToDevice));
-			LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, w.d_stage_entity.p, w.d_stage_tr.p, n, true));
+			LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, w.d_stage_entity.p, w.d_stage_tr.p, n, XF_STAGE_RAW_WORLD));
 			LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		}
 		LMX_HIP(ctx, hipMemcpy(w.d_stage_tr.p, transforms, n * sizeof(LmxTransform), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, w.d_stage_entity.p, w.d_stage_tr.p, n));
+		LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, w.d_stage_entity.p, w.d_stage_tr.p, n, XF_STAGE_RAW));
 	}
 	w.bound_generation = ~0ull;
 	w.n_attach = 0; // attachment slots refer to the previous slot order: lmx_world_set_bone_attachments again
@@ -180,8 +182,7 @@ int lmx_transform_compute_local(const LmxTransform* parent, const LmxTransform* 
 	return LMX_OK;
 }
 
-int lmx_world_set_transforms(LmxContext* ctx, uint32_t n, const int32_t* entity, const LmxTransform* transforms) {
-	LMX_CHECK_CTX(ctx);
+static int world_stage(LmxContext* ctx, uint32_t n, const int32_t* entity, const LmxTransform* transforms, int mode) {
 	WorldState& w = ctx->world;
 	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
 	if (!n) return LMX_OK;
@@ -193,8 +194,18 @@ int lmx_world_set_transforms(LmxContext* ctx, uint32_t n, const int32_t* entity,
 	LMX_HIP(ctx, w.d_stage_tr.reserve(n));
 	LMX_HIP(ctx, hipMemcpy(w.d_stage_entity.p, entity, n * sizeof(int32_t), hipMemcpyHostToDevice));
 	LMX_HIP(ctx, hipMemcpy(w.d_stage_tr.p, transforms, n * sizeof(LmxTransform), hipMemcpyHostToDevice));
-	LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, w.d_stage_entity.p, w.d_stage_tr.p, n));
+	LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, w.d_stage_entity.p, w.d_stage_tr.p, n, mode));
 	return LMX_OK;
+}
+
+int lmx_world_set_transforms(LmxContext* ctx, uint32_t n, const int32_t* entity, const LmxTransform* transforms) {
+	LMX_CHECK_CTX(ctx);
+	return world_stage(ctx, n, entity, transforms, XF_STAGE_SET_LOCAL);
+}
+
+int lmx_world_set_world_transforms(LmxContext* ctx, uint32_t n, const int32_t* entity, const LmxTransform* transforms) {
+	LMX_CHECK_CTX(ctx);
+	return world_stage(ctx, n, entity, transforms, XF_STAGE_SET_WORLD);
 }
 
 int lmx_world_set_transforms_device(LmxContext* ctx, uint32_t n, const void* d_entity, const void* d_transforms) {
@@ -203,7 +214,7 @@ int lmx_world_set_transforms_device(LmxContext* ctx, uint32_t n, const void* d_e
 	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
 	if (!n) return LMX_OK;
 	if (!d_entity || !d_transforms) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null device pointer");
-	LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, (const int32_t*)d_entity, d_transforms, n));
+	LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, (const int32_t*)d_entity, d_transforms, n, XF_STAGE_SET_LOCAL));
 	return LMX_OK;
 }
 

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "lumix_mi355.h"
@@ -129,9 +130,13 @@ struct CullState {
 	std::vector<uint32_t> dyn_free[MAX_TYPES];   // slots freed by removals
 	uint64_t dyn_generation = 0; // bumped whenever slots are reassigned (world binding tables depend on it)
 	// ---- O(1) updates between culls ---------------------------------------------------------------------------
+	// at most ONE pending record per slot (the patch kernel applies a batch in parallel): a second change of a slot
+	// overwrites its pending record
 	std::vector<PatchSphere> q_sphere;
 	std::vector<PatchId> q_id;
 	std::vector<PatchDyn> q_dyn;
+	std::unordered_map<uint32_t, uint32_t> q_sphere_at; // static slot -> index into q_sphere
+	std::vector<uint32_t> q_dyn_at;                     // dynamic slot -> index into q_dyn, or ~0u
 	DevBuf<char> d_patch;
 	PatchStaging staging;
 	// ---- output shards ----------------------------------------------------------------------------------------
@@ -161,6 +166,7 @@ struct WorldState {
 	DevBuf<float4> rot[2];             // lrot wrot
 	DevBuf<float> scl[6];              // lsx lsy lsz wsx wsy wsz
 	DevBuf<int32_t> d_parent_slot, d_slot_of_entity, d_entity_of_slot;
+	DevBuf<uint8_t> d_dirty;
 	DevBuf<int32_t> d_stage_entity;
 	DevBuf<LmxTransform> d_stage_tr;
 	DevBuf<LmxTransform> d_export;
@@ -178,6 +184,7 @@ struct WorldState {
 		w.lpx = pos[0].p; w.lpy = pos[1].p; w.lpz = pos[2].p; w.lrot = rot[0].p; w.lsx = scl[0].p; w.lsy = scl[1].p; w.lsz = scl[2].p;
 		w.wpx = pos[3].p; w.wpy = pos[4].p; w.wpz = pos[5].p; w.wrot = rot[1].p; w.wsx = scl[3].p; w.wsy = scl[4].p; w.wsz = scl[5].p;
 		w.parent_slot = d_parent_slot.p;
+		w.dirty = d_dirty.p;
 		return w;
 	}
 };

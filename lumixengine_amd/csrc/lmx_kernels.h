@@ -56,7 +56,8 @@ struct CullOut {
 };
 
 // k_cull_tile over the static set's slots [ent_begin, ent_end) (multiples of TILE_ALIGN). `variant` picks the tile shape of the
-// 1-frustum kernel: 0 = 8 waves x 8 chunks (4096), 1 = 4 x 8 (2048), 2 = 8 x 4 (2048), 3 = 4 x 4 (1024); ignored for n_frusta > 1.
+// 1-frustum kernel: 0 = 8 waves x 8 chunks (4096), 1 = 4 x 8 (2048), 2 = 8 x 4 (2048), 3 = 4 x 4 (1024) with 4 chunks' loads in flight per
+// wave, 4 = 4 x 8 and 5 = 8 x 8 with all 8 in flight; ignored for n_frusta > 1.
 // lane_parallel_status: the tile-level box test is evaluated one plane per lane (1-frustum kernels only).
 size_t cull_tile_lds_bytes(int n_frusta, uint32_t cell_cap);
 uint32_t cull_tile_size(int n_frusta, int variant);
@@ -99,15 +100,17 @@ struct WorldDevice {
 	double* lpx; double* lpy; double* lpz; float4* lrot; float* lsx; float* lsy; float* lsz; // local (roots: unused)
 	double* wpx; double* wpy; double* wpz; float4* wrot; float* wsx; float* wsy; float* wsz; // world
 	const int32_t* parent_slot; // -1 for roots
+	uint8_t* dirty;             // XF_* mark per slot: what was staged since the last propagation
 };
+enum : uint8_t { XF_CLEAN = 0, XF_SET_LOCAL = 1, XF_SET_WORLD = 2 };
+enum { XF_STAGE_RAW = 0, XF_STAGE_RAW_WORLD = 1, XF_STAGE_SET_LOCAL = 2, XF_STAGE_SET_WORLD = 3 };
 // world[s] = compose(world[parent_slot[s]], local[s]) for s in [first, first + n)
 hipError_t launch_xform_level(hipStream_t s, const WorldDevice& w, uint32_t first, uint32_t n);
 // out[entity_of_slot[s]] = AoS Transform (56 B) for s in [0, n)
 hipError_t launch_xform_export(hipStream_t s, const WorldDevice& w, const int32_t* entity_of_slot, uint32_t n, void* out_transforms);
-// stage transforms (AoS LmxTransform, device memory) into the SoA arrays: roots -> world, children -> local
-// (force_world: every entity's value goes to the world arrays)
+// stage transforms (AoS LmxTransform, device memory) into the SoA arrays; mode = XF_STAGE_* (see k_xform_scatter)
 hipError_t launch_xform_scatter(hipStream_t s, const WorldDevice& w, const int32_t* slot_of_entity, const int32_t* entity,
-	const void* transforms, uint32_t n, bool force_world = false);
+	const void* transforms, uint32_t n, int mode);
 // culling refresh for bound entities (RenderModuleImpl::onModelInstanceMoved, render_module.cpp:1544-1554): the dynamic
 // set's position / radius of bound entity i become (world.pos, model_radius[i] * maximum(scale.x, scale.y, scale.z))
 hipError_t launch_sphere_refresh(hipStream_t s, const WorldDevice& w, const uint32_t* bound_slot, const uint32_t* bound_dyn,

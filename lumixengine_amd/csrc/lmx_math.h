@@ -91,7 +91,8 @@ LMX_HD Xform bone_attachment(const Xform& parent, V3 bone_pos, Q4 bone_rot, V3 r
 	return r;
 }
 
-// Transform::computeLocal, math.cpp:809-816 (host-side only: setParent / re-parenting, not in the per-frame pass)
+// Transform::computeLocal, math.cpp:809-816 (setParent / re-parenting on the host; k_xform_level for entities written through
+// World::setLocalTransform / setTransform, which re-derive the stored local)
 LMX_HD Xform compute_local(const Xform& parent, const Xform& child) {
 	const Q4 conj = conjugated(parent.rot);
 	const DV3 rp = rotate(conj, DV3{-parent.pos.x, -parent.pos.y, -parent.pos.z});

@@ -14,28 +14,54 @@ namespace lmx {
 
 namespace {
 
+// dirty[s]: what the host staged for node s since the last propagation (cleared here).
+//   XF_CLEAN      world = parent.compose(local)                                  (World::transformEntity's descent, world.cpp:271-280)
+//   XF_SET_LOCAL  World::setLocalTransform (world.cpp:741-753 -> updateGlobalTransform :704-712 -> setTransform :337-342 ->
+//                 transformEntity(update_local = true) :266-269): world = parent.compose(local), then the stored local is RE-DERIVED
+//                 as Transform::computeLocal(parent, world) (math.cpp:809-816) - lossy, and what later frames compose with
+//   XF_SET_WORLD  World::setTransform on an entity with a parent: the world transform is the staged one, local = computeLocal(parent, world)
 __global__ __launch_bounds__(256) void k_xform_level(WorldDevice w, uint32_t first, uint32_t n) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) return;
 	const uint32_t s = first + i;
 	const int32_t p = w.parent_slot[s];
+	const uint8_t dirty = w.dirty[s];
 	Xform parent, local;
 	const float4 pr = w.wrot[p];
 	parent.pos = DV3{w.wpx[p], w.wpy[p], w.wpz[p]};
 	parent.rot = Q4{pr.x, pr.y, pr.z, pr.w};
 	parent.scale = V3{w.wsx[p], w.wsy[p], w.wsz[p]};
-	const float4 lr = w.lrot[s];
-	local.pos = DV3{w.lpx[s], w.lpy[s], w.lpz[s]};
-	local.rot = Q4{lr.x, lr.y, lr.z, lr.w};
-	local.scale = V3{w.lsx[s], w.lsy[s], w.lsz[s]};
-	const Xform r = compose(parent, local);
-	w.wpx[s] = r.pos.x;
-	w.wpy[s] = r.pos.y;
-	w.wpz[s] = r.pos.z;
-	w.wrot[s] = make_float4(r.rot.x, r.rot.y, r.rot.z, r.rot.w);
-	w.wsx[s] = r.scale.x;
-	w.wsy[s] = r.scale.y;
-	w.wsz[s] = r.scale.z;
+	Xform r;
+	if (dirty != XF_SET_WORLD) {
+		const float4 lr = w.lrot[s];
+		local.pos = DV3{w.lpx[s], w.lpy[s], w.lpz[s]};
+		local.rot = Q4{lr.x, lr.y, lr.z, lr.w};
+		local.scale = V3{w.lsx[s], w.lsy[s], w.lsz[s]};
+		r = compose(parent, local);
+		w.wpx[s] = r.pos.x;
+		w.wpy[s] = r.pos.y;
+		w.wpz[s] = r.pos.z;
+		w.wrot[s] = make_float4(r.rot.x, r.rot.y, r.rot.z, r.rot.w);
+		w.wsx[s] = r.scale.x;
+		w.wsy[s] = r.scale.y;
+		w.wsz[s] = r.scale.z;
+	} else {
+		const float4 wr = w.wrot[s];
+		r.pos = DV3{w.wpx[s], w.wpy[s], w.wpz[s]};
+		r.rot = Q4{wr.x, wr.y, wr.z, wr.w};
+		r.scale = V3{w.wsx[s], w.wsy[s], w.wsz[s]};
+	}
+	if (dirty != XF_CLEAN) {
+		const Xform l = compute_local(parent, r);
+		w.lpx[s] = l.pos.x;
+		w.lpy[s] = l.pos.y;
+		w.lpz[s] = l.pos.z;
+		w.lrot[s] = make_float4(l.rot.x, l.rot.y, l.rot.z, l.rot.w);
+		w.lsx[s] = l.scale.x;
+		w.lsy[s] = l.scale.y;
+		w.lsz[s] = l.scale.z;
+		w.dirty[s] = XF_CLEAN;
+	}
 }
 
 struct TransformAoS { double pos[3]; float rot[4]; float scale[3]; float pad; }; // core/math.h:306-327, 56 B
@@ -53,22 +79,27 @@ __global__ __launch_bounds__(256) void k_xform_export(WorldDevice w, const int32
 	out[entity_of_slot[s]] = t;
 }
 
-// Stage new transforms: roots get their world transform (World::setTransform, world.cpp:337-342), children their
-// local transform (World::setLocalTransform, world.cpp:741-753). slot_of_entity maps entity -> slot.
+// Stage new transforms. mode XF_STAGE_SET_LOCAL: roots get their world transform (World::setTransform, world.cpp:337-342), children
+// their local transform + the XF_SET_LOCAL mark (World::setLocalTransform, world.cpp:741-753); XF_STAGE_SET_WORLD: World::setTransform
+// on any entity (children keep the staged world transform, XF_SET_WORLD mark); XF_STAGE_RAW: roots -> world, children -> stored local
+// as is (scene load: Hierarchy::local_transform comes from the file); XF_STAGE_RAW_WORLD: every value to the world arrays.
 __global__ __launch_bounds__(256) void k_xform_scatter(WorldDevice w, const int32_t* __restrict__ slot_of_entity,
-	const int32_t* __restrict__ entity, const TransformAoS* __restrict__ tr, uint32_t n, int force_world) {
+	const int32_t* __restrict__ entity, const TransformAoS* __restrict__ tr, uint32_t n, int mode) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) return;
 	const int32_t s = slot_of_entity[entity[i]];
 	const TransformAoS t = tr[i];
-	if (force_world || w.parent_slot[s] < 0) {
+	const bool is_root = w.parent_slot[s] < 0;
+	if (mode == XF_STAGE_RAW_WORLD || mode == XF_STAGE_SET_WORLD || is_root) {
 		w.wpx[s] = t.pos[0]; w.wpy[s] = t.pos[1]; w.wpz[s] = t.pos[2];
 		w.wrot[s] = make_float4(t.rot[0], t.rot[1], t.rot[2], t.rot[3]);
 		w.wsx[s] = t.scale[0]; w.wsy[s] = t.scale[1]; w.wsz[s] = t.scale[2];
+		if (mode == XF_STAGE_SET_WORLD && !is_root) w.dirty[s] = XF_SET_WORLD;
 	} else {
 		w.lpx[s] = t.pos[0]; w.lpy[s] = t.pos[1]; w.lpz[s] = t.pos[2];
 		w.lrot[s] = make_float4(t.rot[0], t.rot[1], t.rot[2], t.rot[3]);
 		w.lsx[s] = t.scale[0]; w.lsy[s] = t.scale[1]; w.lsz[s] = t.scale[2];
+		if (mode == XF_STAGE_SET_LOCAL) w.dirty[s] = XF_SET_LOCAL;
 	}
 }
 
@@ -135,10 +166,10 @@ hipError_t launch_bone_attach(hipStream_t s, const WorldDevice& w, const BoneAtt
 }
 
 hipError_t launch_xform_scatter(hipStream_t s, const WorldDevice& w, const int32_t* slot_of_entity, const int32_t* entity,
-	const void* transforms, uint32_t n, bool force_world) {
+	const void* transforms, uint32_t n, int mode) {
 	if (!n) return hipSuccess;
 	hipLaunchKernelGGL(k_xform_scatter, dim3((n + 255u) / 256u), dim3(256), 0, s, w, slot_of_entity, entity,
-		(const TransformAoS*)transforms, n, force_world ? 1 : 0);
+		(const TransformAoS*)transforms, n, mode);
 	return hipGetLastError();
 }
 

@@ -76,7 +76,7 @@ int emul_cull_variant(uint32_t n, const int32_t* entity, const uint8_t* type, co
 			ent_end = lay.ent_end[type_filter];
 		}
 		// tile bookkeeping: the cells a tile touches are [first_cell, last_cell], bounded by the layout's max
-		const uint32_t tile = n_frusta <= 1 ? (tile_variant == 0 ? 4096u : (tile_variant == 3 ? 1024u : 2048u)) : (n_frusta <= 4 ? 2048u : 1024u);
+		const uint32_t tile = n_frusta <= 1 ? ((tile_variant == 0 || tile_variant == 5) ? 4096u : (tile_variant == 3 ? 1024u : 2048u)) : (n_frusta <= 4 ? 2048u : 1024u);
 		const uint32_t tile_k = tile == 4096 ? 0 : (tile == 2048 ? 1 : 2);
 		const uint32_t nch = tile / 64;
 		for (uint32_t chunk = ent_begin / 64; chunk < ent_end / 64; ++chunk) {

@@ -62,6 +62,81 @@ def test_world_propagate_bit_exact(gpu_ctx, oracle_port, kind):
         assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms()), f"{kind} frame {frame}"
 
 
+def _depths(parent):
+    depth = np.zeros(len(parent), np.int32)
+    order = np.argsort(parent, kind="stable")  # not a topological order in general: iterate to a fixed point
+    changed = True
+    while changed:
+        changed = False
+        for e in order:
+            p = parent[e]
+            d = 0 if p < 0 else depth[p] + 1
+            if d != depth[e]:
+                depth[e] = d
+                changed = True
+    return depth
+
+
+@pytest.mark.parametrize("kind", ["chains", "fans"])
+def test_world_child_writes_bit_exact(gpu_ctx, oracle_port, kind):
+    """World::setLocalTransform and World::setTransform on entities WITH a parent (world.cpp:741-753, :337-342): the reference
+    re-derives the stored local with Transform::computeLocal after composing (world.cpp:266-269), which is lossy, and later frames
+    compose with that re-derived local. Several frames of interleaved root moves, child local writes and child world-space writes
+    (issued ancestors-first, as the batch form defines) must give bit-identical world AND local transforms."""
+    h = scenes.hierarchy_chains(3000, 4, seed=21) if kind == "chains" else scenes.hierarchy_fans(20, 6, 4, seed=22)
+    ow, roots, kids = oracle_world(oracle_port, h)
+    parent = h["parent"]
+    depth = _depths(parent)
+    w = api.World(gpu_ctx)
+    w.build(parent, gpu_inputs(ow, parent, roots))
+    rng = np.random.default_rng(31)
+    n = len(parent)
+    for frame in range(5):
+        picked = rng.permutation(n)[: n // 3].astype(np.int32)
+        how = rng.integers(0, 2, size=len(picked))  # 0: setLocalTransform (roots: setTransform), 1: world-space setTransform
+        tr = scenes.random_transforms(rng, len(picked), 50.0)
+        tr["pos"][parent[picked] < 0] *= 60.0
+        # oracle: eager calls, ancestors first
+        for d in range(int(depth.max()) + 1):
+            sel = np.flatnonzero(depth[picked] == d)
+            for i in sel:
+                e = picked[i : i + 1]
+                if how[i] == 1 or parent[e[0]] < 0:
+                    ow.set_transforms(e, tr[i : i + 1])
+                else:
+                    ow.set_local_transforms(e, tr[i : i + 1])
+        # device: two staged batches, one propagation
+        loc = (how == 0) | (parent[picked] < 0)
+        w.setTransforms(picked[loc], tr[loc])
+        w.setWorldTransforms(picked[~loc], tr[~loc])
+        w.propagate()
+        assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms()), f"{kind} frame {frame}: world transforms"
+        got_l, want_l = w.getLocalTransforms(), ow.get_local_transforms()
+        assert H.transforms_bits_equal(got_l[kids], want_l[kids]), f"{kind} frame {frame}: stored locals"
+    # and the re-derived locals are what a plain root move composes with afterwards
+    new_root = scenes.random_transforms(rng, len(roots), 4000.0)
+    ow.set_transforms(roots, new_root)
+    w.setTransforms(roots, new_root)
+    w.propagate()
+    assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms())
+
+
+def test_world_config3_full_size(gpu_ctx, oracle_port):
+    """BASELINE config 3's hierarchy at full size: 1 M entities = 250 k roots x chains of depth 4, every root moved every frame,
+    bit-exact against the reference's DFS (the CPU walks it in tens of milliseconds)."""
+    h = scenes.hierarchy_chains(250_000, 4, seed=2)
+    ow, roots, kids = oracle_world(oracle_port, h)
+    w = api.World(gpu_ctx)
+    w.build(h["parent"], gpu_inputs(ow, h["parent"], roots))
+    rng = np.random.default_rng(1)
+    for frame in range(2):
+        new_root = scenes.random_transforms(rng, len(roots), 4000.0)
+        ow.set_transforms(roots, new_root)
+        w.setTransforms(roots, new_root)
+        w.propagate()
+        assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms()), f"frame {frame}"
+
+
 def test_world_child_parent_order_independent(gpu_ctx, oracle_port):
     """Entity indices of children may be smaller than their parents': slot order, not entity order, drives levels."""
     h = scenes.hierarchy_fans(30, 3, 5, seed=13)
