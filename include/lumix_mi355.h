@@ -162,11 +162,18 @@ LMX_API int lmx_cull_bind_output(LmxContext* ctx, uint32_t view, void* d_ids, si
 /* ---- world transforms: World hierarchy, src/engine/world.cpp:255-282 ---------------------------------------
  * The reference propagates eagerly (one recursive DFS per setTransform). The batch form: stage new root/local
  * transforms, then lmx_world_propagate() recomputes child.world = parent.world.compose(child.local)
- * (core/math.cpp:801-807) level by level; results equal the DFS bit for bit. */
+ * (core/math.cpp:801-807) level by level for exactly the nodes those DFS walks would visit (written nodes and their
+ * subtrees); results equal the DFS bit for bit. */
 
 /* n entities, entity index = array index (EntityRef::index). parent[i] = -1 for roots.
  * transforms[i] = world transform for roots, local transform (Hierarchy::local_transform) for children. */
 LMX_API int lmx_world_build(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxTransform* transforms);
+/* The same from a live World: world_transforms[i] = World::getTransforms()[i] for EVERY entity, local_transforms[i] =
+ * Hierarchy::local_transform for entities with a parent (ignored for the others). Nothing is recomputed until something is
+ * written: a stored local that went through Transform::computeLocal does not reproduce the stored world transform bit for
+ * bit, and the reference only recomposes the subtrees it visits (world.cpp:255-282) - so does lmx_world_propagate. */
+LMX_API int lmx_world_build_with_world(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxTransform* local_transforms,
+	const LmxTransform* world_transforms);
 /* World::setParent (world.cpp:619-701): the child keeps its world transform and its local becomes
  * Transform::computeLocal(parent world, child world); new_parent < 0 detaches the child. Cycles are rejected
  * (LMX_ERR_INVALID_ARGUMENT, the reference logs "Hierarchy can not contain a cycle."). Editing operation: rebuilds the

@@ -114,6 +114,7 @@ SYMBOLS = {
     "lmx_cull_bind_output": (_ci, [_vp, _u32, _vp, _sz, _vp]),
     "lmx_cull_device_result": (_ci, [_vp, _u32, _u32, C.POINTER(_vp), C.POINTER(_vp), _vp, C.POINTER(_u32)]),
     "lmx_world_build": (_ci, [_vp, _u32, _vp, _vp]),
+    "lmx_world_build_with_world": (_ci, [_vp, _u32, _vp, _vp, _vp]),
     "lmx_world_set_parent": (_ci, [_vp, _i32, _i32]),
     "lmx_world_read_local_transforms": (_ci, [_vp, _vp, _u32]),
     "lmx_transform_compose": (_ci, [_vp, _vp, _vp]),
@@ -459,6 +460,15 @@ class World:
         assert len(parent) == len(transforms)
         self.n = len(parent)
         self.ctx.check(self.lib.lmx_world_build(self.ctx.h, self.n, _ptr(parent), _ptr(transforms)))
+
+    def buildWithWorld(self, parent, local_transforms, world_transforms):
+        """Mirror of a live World: the stored world transform of every entity + Hierarchy::local_transform of the parented ones."""
+        parent = np.ascontiguousarray(parent, np.int32)
+        local_transforms = np.ascontiguousarray(local_transforms, TRANSFORM)
+        world_transforms = np.ascontiguousarray(world_transforms, TRANSFORM)
+        assert len(parent) == len(local_transforms) == len(world_transforms)
+        self.n = len(parent)
+        self.ctx.check(self.lib.lmx_world_build_with_world(self.ctx.h, self.n, _ptr(parent), _ptr(local_transforms), _ptr(world_transforms)))
 
     def setTransforms(self, entity, transforms):
         """World::setTransform for roots / World::setLocalTransform for children, staged until propagate()."""

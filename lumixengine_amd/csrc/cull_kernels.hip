@@ -113,12 +113,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg
 	// the counters of the NEXT cull on this view are cleared here (ping-pong), so no cull needs a separate memset
 	for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < a.n_zero; i += gridDim.x * THREADS) g_counts_next[i] = 0;
 
-	// The headers of this wave's chunks sit at an address that depends on blockIdx only: lane i fetches header i now, so the
-	// (HBM-cold) load runs under the tile test and the cell classification instead of after them; a chunk's header is then
-	// broadcast from its lane (v_readlane) when the chunk is processed.
-	const uint32_t chunk0 = (tile_ent >> 6) + wave * CHW;
-	const uint4 hdr_v = reinterpret_cast<const uint4*>(g_hdr)[chunk0 + (lane < (uint32_t)CHW ? lane : 0u)];
-
 	// 0. tile-level test per frustum (2 bits each). Everything read here sits at addresses that depend on blockIdx only.
 	uint32_t st_bits = 0;
 	bool any_mixed = false, any_live = false;
@@ -184,7 +178,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg
 	const uint32_t win = g_win_base[shard];
 
 	// B. this wave's CHW chunks, in groups of GRP so that at most GRP chunks' worth of spheres are live in registers
-	// (VGPR count decides how many tiles a CU keeps in flight)
+	// (VGPR count decides how many tiles a CU keeps in flight). Fetching the headers at kernel start through lanes (one vector
+	// load + v_readlane) instead of scalar loads here measured no gain, HBM-cold included: other waves cover the load.
+	const uint32_t chunk0 = (tile_ent >> 6) + wave * CHW;
 	const uint64_t le_mask = (~0ull >> (63u - lane)) & ~1ull; // bits 1..lane
 	static_assert(CHW % GRP == 0, "groups tile the wave's chunks");
 	int32_t id[CHW];
@@ -200,9 +196,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg
 			bool lane_live = false, lane_test = false;
 			local[i] = 0;
 			if (any_mixed) {
-				const uint32_t h_cell = __builtin_amdgcn_readlane(hdr_v.x, g + i);
-				const uint64_t h_flags = (uint64_t)__builtin_amdgcn_readlane(hdr_v.z, g + i) | ((uint64_t)__builtin_amdgcn_readlane(hdr_v.w, g + i) << 32);
-				local[i] = h_cell + (uint32_t)__popcll(h_flags & le_mask) - first_cell;
+				const ChunkHdr h = g_hdr[chunk0 + g + i]; // wave-uniform: one 16-byte scalar load
+				local[i] = h.cell + (uint32_t)__popcll(h.flags & le_mask) - first_cell;
 #pragma unroll 1
 				for (int f = 0; f < nf; ++f) {
 					const uint32_t cls = s_info[f * a.cell_cap + local[i]].cls;

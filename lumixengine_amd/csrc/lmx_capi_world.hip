@@ -66,7 +66,9 @@ int world_rebuild(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxT
 	LMX_HIP(ctx, w.d_entity_of_slot.reserve(cap));
 	LMX_HIP(ctx, w.d_dirty.reserve(cap));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	LMX_HIP(ctx, hipMemset(w.d_dirty.p, 0, cap));
+	// scene load from locals (no world values given): every node counts as moved, so the first propagation derives all world
+	// transforms; with world values (re-parenting, lmx_world_build_with_world) nothing is recomputed until something is written
+	LMX_HIP(ctx, hipMemset(w.d_dirty.p, world_all ? 0 : XF_MOVED, cap));
 	if (n) {
 		LMX_HIP(ctx, hipMemcpy(w.d_parent_slot.p, w.parent_slot.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(w.d_slot_of_entity.p, w.slot_of_entity.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -132,6 +134,18 @@ int lmx_world_build(LmxContext* ctx, uint32_t n, const int32_t* parent, const Lm
 	w.bound_entity.clear();
 	w.bound_radius.clear();
 	return world_rebuild(ctx, n, parent, transforms, nullptr);
+}
+
+int lmx_world_build_with_world(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxTransform* local_transforms, const LmxTransform* world_transforms) {
+	LMX_CHECK_CTX(ctx);
+	if (n && (!parent || !local_transforms || !world_transforms)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
+	WorldState& w = ctx->world;
+	w.bound_entity.clear();
+	w.bound_radius.clear();
+	std::vector<LmxTransform> tr(local_transforms, local_transforms + n);
+	for (uint32_t e = 0; e < n; ++e)
+		if (parent[e] < 0) tr[e] = world_transforms[e];
+	return world_rebuild(ctx, n, parent, tr.data(), world_transforms);
 }
 
 // World::setParent (world.cpp:619-701): the child keeps its world transform, its local becomes
@@ -276,6 +290,7 @@ int lmx_world_propagate(LmxContext* ctx) {
 		ProfScope ps(ctx, LMX_K_XFORM_LEVEL);
 		LMX_HIP(ctx, launch_xform_level(ctx->stream, dev, w.level_start[l], w.level_start[l + 1] - w.level_start[l]));
 	}
+	if (w.n) LMX_HIP(ctx, hipMemsetAsync(w.d_dirty.p, 0, w.n, ctx->stream)); // the frame's "moved" marks end here
 	if (!w.bound_entity.empty()) {
 		if (int rc = world_upload_binding(ctx)) return rc;
 		CullState& cs = ctx->cull;

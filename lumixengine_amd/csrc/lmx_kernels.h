@@ -102,7 +102,7 @@ struct WorldDevice {
 	const int32_t* parent_slot; // -1 for roots
 	uint8_t* dirty;             // XF_* mark per slot: what was staged since the last propagation
 };
-enum : uint8_t { XF_CLEAN = 0, XF_SET_LOCAL = 1, XF_SET_WORLD = 2 };
+enum : uint8_t { XF_CLEAN = 0, XF_SET_LOCAL = 1, XF_SET_WORLD = 2, XF_MOVED = 4 };
 enum { XF_STAGE_RAW = 0, XF_STAGE_RAW_WORLD = 1, XF_STAGE_SET_LOCAL = 2, XF_STAGE_SET_WORLD = 3 };
 // world[s] = compose(world[parent_slot[s]], local[s]) for s in [first, first + n)
 hipError_t launch_xform_level(hipStream_t s, const WorldDevice& w, uint32_t first, uint32_t n);

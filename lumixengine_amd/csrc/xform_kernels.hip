@@ -14,7 +14,10 @@ namespace lmx {
 
 namespace {
 
-// dirty[s]: what the host staged for node s since the last propagation (cleared here).
+// dirty[s] & 3: what the host staged for node s since the last propagation; dirty[s] & XF_MOVED: the node's world transform
+// changed in this propagation (roots: staged; others: recomputed by this kernel). A node is recomputed only when its parent moved
+// or it was staged itself - exactly the nodes the reference's DFS visits. (Recomputing an untouched node from its stored local is
+// NOT a no-op: locals re-derived by computeLocal do not reproduce the stored world transform bit for bit.)
 //   XF_CLEAN      world = parent.compose(local)                                  (World::transformEntity's descent, world.cpp:271-280)
 //   XF_SET_LOCAL  World::setLocalTransform (world.cpp:741-753 -> updateGlobalTransform :704-712 -> setTransform :337-342 ->
 //                 transformEntity(update_local = true) :266-269): world = parent.compose(local), then the stored local is RE-DERIVED
@@ -25,7 +28,8 @@ __global__ __launch_bounds__(256) void k_xform_level(WorldDevice w, uint32_t fir
 	if (i >= n) return;
 	const uint32_t s = first + i;
 	const int32_t p = w.parent_slot[s];
-	const uint8_t dirty = w.dirty[s];
+	const uint8_t dirty = w.dirty[s] & 3u;
+	if (dirty == XF_CLEAN && !(w.dirty[p] & XF_MOVED)) return;
 	Xform parent, local;
 	const float4 pr = w.wrot[p];
 	parent.pos = DV3{w.wpx[p], w.wpy[p], w.wpz[p]};
@@ -60,8 +64,8 @@ __global__ __launch_bounds__(256) void k_xform_level(WorldDevice w, uint32_t fir
 		w.lsx[s] = l.scale.x;
 		w.lsy[s] = l.scale.y;
 		w.lsz[s] = l.scale.z;
-		w.dirty[s] = XF_CLEAN;
 	}
+	w.dirty[s] = XF_MOVED;
 }
 
 struct TransformAoS { double pos[3]; float rot[4]; float scale[3]; float pad; }; // core/math.h:306-327, 56 B
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(256) void k_xform_scatter(WorldDevice w, const int3
 		w.wrot[s] = make_float4(t.rot[0], t.rot[1], t.rot[2], t.rot[3]);
 		w.wsx[s] = t.scale[0]; w.wsy[s] = t.scale[1]; w.wsz[s] = t.scale[2];
 		if (mode == XF_STAGE_SET_WORLD && !is_root) w.dirty[s] = XF_SET_WORLD;
+		else if (mode != XF_STAGE_RAW_WORLD && mode != XF_STAGE_RAW) w.dirty[s] = XF_MOVED; // a root moved: its subtree follows
 	} else {
 		w.lpx[s] = t.pos[0]; w.lpy[s] = t.pos[1]; w.lpz[s] = t.pos[2];
 		w.lrot[s] = make_float4(t.rot[0], t.rot[1], t.rot[2], t.rot[3]);
@@ -156,6 +161,7 @@ __global__ __launch_bounds__(256) void k_bone_attach(WorldDevice w, const BoneAt
 		V3{a.rel_pos[0], a.rel_pos[1], a.rel_pos[2]}, Q4{a.rel_rot[0], a.rel_rot[1], a.rel_rot[2], a.rel_rot[3]}, V3{w.wsx[s], w.wsy[s], w.wsz[s]});
 	w.wpx[s] = r.pos.x; w.wpy[s] = r.pos.y; w.wpz[s] = r.pos.z;
 	w.wrot[s] = make_float4(r.rot.x, r.rot.y, r.rot.z, r.rot.w);
+	w.dirty[s] = XF_MOVED; // World::setTransform on the attached entity: its subtree follows in lmx_world_propagate
 }
 
 hipError_t launch_bone_attach(hipStream_t s, const WorldDevice& w, const BoneAttachDevice* att, uint32_t n, const SkinInstance* inst,

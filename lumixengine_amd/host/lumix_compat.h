@@ -7,7 +7,11 @@
 //   CullResult                 src/renderer/culling_system.h:17-56   (one 4096-byte page, 1020 ids)
 //   CullingSystem              src/renderer/culling_system.h:58-77
 //   PageAllocator              src/core/page_allocator.h:16-33 (allocate / deallocate of 4096-byte pages)
-// Nothing here is copied from the reference sources; it restates the public shape of those types.
+//   Quat / Transform           src/core/math.h:200-327 (Transform = 56 B == LmxTransform)
+//   EntityPtr, World (read side), Pose, Model (skeleton side), Mesh::Skin, ModelInstance, RenderModule (pose hand-off)
+//                              the members world_sync.h / pose_bridge.h call, as small in-memory mocks
+// These are interface shims for standalone test builds: they restate the public shape of those types (CullResult and the
+// CullingSystem vtable necessarily member for member); inside the engine the real headers are used instead.
 #pragma once
 
 #include <cstdint>
@@ -23,13 +27,37 @@ using u8 = uint8_t;
 using u32 = uint32_t;
 using i32 = int32_t;
 
+using i16 = int16_t;
+using u16 = uint16_t;
+
 struct EntityRef {
 	i32 index = -1;
 	bool operator==(const EntityRef& rhs) const { return rhs.index == index; }
 };
+struct EntityPtr {
+	i32 index = -1;
+	bool isValid() const { return index >= 0; }
+	explicit operator EntityRef() const { return EntityRef{index}; }
+};
 
 struct Vec3 { float x, y, z; };
+struct Vec4 { float x, y, z, w; };
 struct DVec3 { double x, y, z; };
+struct Quat { float x, y, z, w; };
+struct Transform { DVec3 pos; Quat rot; Vec3 scale; };
+struct LocalRigidTransform { Vec3 pos; Quat rot; };
+static_assert(sizeof(Transform) == sizeof(LmxTransform) && sizeof(LocalRigidTransform) == sizeof(LmxLocalRigidTransform), "handed to the C ABI as is");
+
+template <typename T> struct Span {
+	T* m_begin = nullptr;
+	T* m_end = nullptr;
+	Span() {}
+	Span(T* b, uint64_t len) : m_begin(b), m_end(b + len) {}
+	T& operator[](u32 i) const { return m_begin[i]; }
+	u32 length() const { return (u32)(m_end - m_begin); }
+	T* begin() const { return m_begin; }
+	T* end() const { return m_end; }
+};
 
 struct alignas(16) ShiftedFrustum {
 	float xs[8], ys[8], zs[8], ds[8];
@@ -94,6 +122,58 @@ struct CullingSystem {
 	virtual void setRadius(EntityRef entity, float radius) = 0;
 	virtual void set(EntityRef entity, const DVec3& pos, float radius) = 0;
 	virtual float getRadius(EntityRef entity) = 0;
+};
+
+// ---- mocks of the engine objects the world / pose bridges read and write (standalone tests only) ---------------------------
+struct World { // read side of engine/world.h:49-209 + the transform array
+	std::vector<Transform> transforms; // m_transforms
+	std::vector<Transform> locals;     // Hierarchy::local_transform
+	std::vector<i32> parents;
+	const Transform* getTransforms() const { return transforms.data(); }
+	EntityPtr getParent(EntityRef e) const { return EntityPtr{parents[e.index]}; }
+	Transform getLocalTransform(EntityRef e) const { return parents[e.index] < 0 ? transforms[e.index] : locals[e.index]; }
+	EntityPtr getFirstEntity() const { return EntityPtr{transforms.empty() ? -1 : 0}; }
+	EntityPtr getNextEntity(EntityRef e) const { return EntityPtr{e.index + 1 < (i32)transforms.size() ? e.index + 1 : -1}; }
+};
+
+struct Pose { // renderer/pose.h:15-35
+	bool is_absolute = false;
+	u32 count = 0;
+	Vec3* positions = nullptr;
+	Quat* rotations = nullptr;
+};
+
+struct Mesh { // renderer/model.h:81-131 (what evaluateSkin reads)
+	struct Skin { Vec4 weights; i16 indices[4]; };
+	struct VertexArray { std::vector<Vec3> v; int size() const { return (int)v.size(); } const Vec3* begin() const { return v.data(); } } vertices;
+	struct SkinArray { std::vector<Skin> v; int size() const { return (int)v.size(); } const Skin* begin() const { return v.data(); } } skin;
+};
+
+struct Model { // renderer/model.h:140-215 (skeleton side)
+	struct Bone { LocalRigidTransform transform; LocalRigidTransform relative_transform; };
+	std::vector<Bone> bones;
+	std::vector<i16> parents;
+	int first_nonroot = 0;
+	std::vector<Mesh> meshes;
+	float origin_bounding_radius = 1.f;
+	Span<const Bone> getBones() const { return Span<const Bone>(bones.data(), bones.size()); }
+	Span<const i16> getParents() const { return Span<const i16>(parents.data(), parents.size()); }
+	int getFirstNonrootBoneIndex() const { return first_nonroot; }
+	int getMeshCount() const { return (int)meshes.size(); }
+	const Mesh& getMesh(u32 i) const { return meshes[i]; }
+	float getOriginBoundingRadius() const { return origin_bounding_radius; }
+};
+
+struct ModelInstance { // renderer/render_module.h:206-226 (the members the bridges touch)
+	Model* model = nullptr;
+	Pose* pose = nullptr;
+};
+
+struct RenderModule { // renderer/render_module.h:402-403, 461-462
+	std::vector<ModelInstance> instances; // indexed by entity.index
+	Pose* lockPose(EntityRef e) { return instances[e.index].pose; }
+	void unlockPose(EntityRef, bool) {}
+	Span<ModelInstance> getModelInstances() { return Span<ModelInstance>(instances.data(), instances.size()); }
 };
 
 } // namespace Lumix

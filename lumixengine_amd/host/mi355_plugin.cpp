@@ -1,0 +1,164 @@
+// mi355_plugin.cpp — the engine-side module of the MI355X hot path: an ISystem / IModule pair registered through
+// LUMIX_PLUGIN_ENTRY (src/engine/plugin.h:37-96; the renderer's own instance: src/renderer/renderer.cpp:1410-1413).
+//
+// Compiled inside a LumixEngine tree (-DLMX_WITH_LUMIX_HEADERS, include paths of the engine's src/ and this repository's
+// include/ + lumixengine_amd/host/). It is NOT built by this repository's build scripts: the reference does not compile on Linux
+// at this snapshot (src/core/sync.h:20-24 is `#error "Not implemented"`); tests/test_plugin_compile.py checks it with
+// -fsyntax-only against a copy of the reference's headers in which that one line is patched.
+//
+// What the module owns and does per frame (Engine::update, src/engine/engine.cpp:289-341):
+//   createModules   world.addModule(Mi355Module)                                    (world.cpp:218-235)
+//   init            mirror the World's hierarchy (WorldSync::build), find the "renderer" module, register skeletons / meshes
+//   update          propagate the frame's staged transform writes level by level on the GPU (+ culling sphere refresh),
+//                   gather relative poses through lockPose / unlockPose, run pose -> palette -> skin, store absolute poses back
+//   createGpuCullingSystem   what RenderModuleImpl's constructor calls instead of CullingSystem::create (render_module.cpp:3569)
+#include "core/allocator.h"
+#include "core/page_allocator.h"
+#include "engine/engine.h"
+#include "engine/plugin.h"
+#include "engine/world.h"
+#include "renderer/culling_system.h"
+#include "renderer/model.h"
+#include "renderer/pose.h"
+#include "renderer/render_module.h"
+
+#include "gpu_culling_system.h"
+#include "pose_bridge.h"
+#include "world_sync.h"
+
+namespace Lumix {
+
+// Drop-in for `m_culling_system = CullingSystem::create(m_allocator, engine.getPageAllocator())` (render_module.cpp:3569):
+// same signature, same ownership (UniquePtr destroyed through the same IAllocator).
+UniquePtr<CullingSystem> createGpuCullingSystem(IAllocator& allocator, PageAllocator& page_allocator) {
+	return UniquePtr<GpuCullingSystem>::create(allocator, page_allocator);
+}
+
+struct Mi355Module final : IModule {
+	Mi355Module(ISystem& system, Engine& engine, World& world)
+		: m_system(system)
+		, m_engine(engine)
+		, m_world(world) {
+		if (lmx_ctx_create(0, &m_ctx) != LMX_OK) m_ctx = nullptr; // logged by the system; the module then idles
+	}
+	~Mi355Module() override { lmx_ctx_destroy(m_ctx); }
+
+	const char* getName() const override { return "mi355_hot_path"; }
+	ISystem& getSystem() const override { return m_system; }
+	World& getWorld() override { return m_world; }
+	// GPU state is derived data: it is rebuilt from the World and the renderer's components, never serialized
+	void serialize(OutputMemoryStream&) override {}
+	void deserialize(InputMemoryStream&, const EntityMap&, i32) override { m_dirty = true; }
+	i32 getVersion() const override { return 0; }
+
+	void init() override {
+		m_render_module = static_cast<RenderModule*>(m_world.getModule("renderer"));
+		m_dirty = true;
+	}
+	void startGame() override { m_dirty = true; }
+
+	// staged writes: game code (or a script binding) calls these instead of World::setTransform / setLocalTransform
+	void setTransform(EntityRef e, const Transform& t) { if (m_sync) m_sync->setTransform(e, t); }
+	void setLocalTransform(EntityRef e, const Transform& t) { if (m_sync) m_sync->setLocalTransform(e, t); }
+	LmxContext* context() { return m_ctx; }
+
+	void update(float) override {
+		if (!m_ctx) return;
+		if (m_dirty) rebuild();
+		if (!m_sync) return;
+		// 1. every transformEntity DFS of the frame + onModelInstanceMoved for bound entities, on the device
+		m_sync->propagate();
+		// the engine's own array is the hand-back: World::getTransforms() readers see the propagated frame
+		m_sync->readTransforms(const_cast<Transform*>(m_world.getTransforms()), m_sync->entityCount());
+		// 2. relative poses -> absolute poses, palettes, skinned vertices
+		if (m_render_module && m_poses && !m_skinned.empty()) {
+			if (m_poses->gather(*m_render_module) && m_poses->run()) m_poses->scatter(*m_render_module);
+		}
+	}
+
+private:
+	// Mirror World + RenderModule state: hierarchy, culling bindings of model instances, skeletons / meshes / skinned instances
+	void rebuild() {
+		m_dirty = false;
+		if (!m_sync) m_sync = UniquePtr<WorldSync>::create(m_engine.getAllocator(), m_ctx);
+		if (!m_sync->build(m_world)) return;
+		if (!m_render_module) return;
+		Span<ModelInstance> instances = m_render_module->getModelInstances();
+		m_bound.clear();
+		m_bound_radius.clear();
+		m_skinned.clear();
+		m_skinned_models.clear();
+		m_skinned_meshes.clear();
+		m_skinned_bones.clear();
+		if (!m_poses) m_poses = UniquePtr<PoseBridge>::create(m_engine.getAllocator(), m_ctx);
+		Model* last_model = nullptr;
+		i32 last_model_id = -1, last_mesh_id = -1;
+		for (u32 i = 0; i < instances.length(); ++i) {
+			ModelInstance& mi = instances[i];
+			if (!(mi.flags & ModelInstance::VALID) || !mi.model || !mi.model->isReady()) continue;
+			const EntityRef e{(i32)i};
+			// onModelInstanceMoved: radius = model->getOriginBoundingRadius() * maximum(scale) (render_module.cpp:1553-1554)
+			m_bound.push_back(e);
+			m_bound_radius.push_back(mi.model->getOriginBoundingRadius());
+			if (!mi.pose || mi.pose->count == 0) continue;
+			if (mi.model != last_model) { // instances of one model are usually consecutive: register each skeleton / mesh once per run
+				last_model = mi.model;
+				last_model_id = m_poses->addModel(*mi.model);
+				last_mesh_id = -1;
+				for (int m = 0; m < mi.model->getMeshCount(); ++m) {
+					if (mi.model->getMesh(m).type == Mesh::SKINNED) {
+						last_mesh_id = m_poses->addMesh(mi.model->getMesh(m));
+						break;
+					}
+				}
+			}
+			if (last_model_id < 0 || last_mesh_id < 0) continue;
+			m_skinned.push_back(e);
+			m_skinned_models.push_back(last_model_id);
+			m_skinned_meshes.push_back(last_mesh_id);
+			m_skinned_bones.push_back(mi.pose->count);
+		}
+		// entities handed to bindCulling must already be in the culling system: RenderModuleImpl added them through
+		// CullingSystem::add when the model became ready (render_module.cpp:2880-2940) - the GpuCullingSystem shares m_ctx
+		if (!m_bound.empty()) m_sync->bindCulling(m_bound.begin(), m_bound_radius.data(), (u32)m_bound.size());
+		if (!m_skinned.empty())
+			m_poses->setInstances(m_skinned.begin(), m_skinned_models.data(), m_skinned_meshes.data(), m_skinned_bones.data(), (u32)m_skinned.size());
+	}
+
+	ISystem& m_system;
+	Engine& m_engine;
+	World& m_world;
+	LmxContext* m_ctx = nullptr;
+	RenderModule* m_render_module = nullptr;
+	UniquePtr<WorldSync> m_sync;
+	UniquePtr<PoseBridge> m_poses;
+	bool m_dirty = true;
+	struct EntityList {
+		std::vector<EntityRef> v;
+		void clear() { v.clear(); }
+		void push_back(EntityRef e) { v.push_back(e); }
+		bool empty() const { return v.empty(); }
+		size_t size() const { return v.size(); }
+		const EntityRef* begin() const { return v.data(); }
+	} m_bound, m_skinned;
+	std::vector<float> m_bound_radius;
+	std::vector<i32> m_skinned_models, m_skinned_meshes;
+	std::vector<u32> m_skinned_bones;
+};
+
+struct Mi355System final : ISystem {
+	explicit Mi355System(Engine& engine) : m_engine(engine) {}
+	const char* getName() const override { return "mi355"; }
+	void serialize(OutputMemoryStream&) const override {}
+	bool deserialize(i32, InputMemoryStream&) override { return true; }
+	void createModules(World& world) override {
+		world.addModule(UniquePtr<Mi355Module>::create(m_engine.getAllocator(), *this, m_engine, world)); // world.cpp:218-235
+	}
+	Engine& m_engine;
+};
+
+} // namespace Lumix
+
+LUMIX_PLUGIN_ENTRY(mi355) {
+	return LUMIX_NEW(engine.getAllocator(), Lumix::Mi355System)(engine);
+}

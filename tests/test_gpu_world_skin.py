@@ -88,7 +88,7 @@ def test_world_child_writes_bit_exact(gpu_ctx, oracle_port, kind):
     parent = h["parent"]
     depth = _depths(parent)
     w = api.World(gpu_ctx)
-    w.build(parent, gpu_inputs(ow, parent, roots))
+    w.buildWithWorld(parent, ow.get_local_transforms(), ow.get_transforms())
     rng = np.random.default_rng(31)
     n = len(parent)
     for frame in range(5):
