@@ -159,6 +159,26 @@ LMX_API int lmx_cull_device_shards(LmxContext* ctx, uint32_t view, uint32_t frus
  * d_ids + f * (64 * n_chunks). Passing NULL pointers restores the library-owned buffers. */
 LMX_API int lmx_cull_bind_output(LmxContext* ctx, uint32_t view, void* d_ids, size_t ids_capacity, void* d_counts);
 
+/* ---- exchange: multi-GPU all-gather of visible-entity lists (no reference twin: the reference is single-process) -------------
+ * One process per GPU, every rank's context holds a disjoint share of the entities (partition by the reference's cell hash, or by
+ * index). Culling needs no communication; the one exchange step per frame is a single ncclAllGather (RCCL over xGMI) of a fixed-size
+ * record per rank: LMX_MAX_TYPES counts followed by ids_per_rank ids (types packed back to back). The record is written by the
+ * cull's gather kernels, the collective runs on a side stream, frames are double-buffered. RCCL is loaded on first use. */
+typedef struct LmxExchange LmxExchange;
+/* ncclGetUniqueId: rank 0 calls this and ships the 128 bytes to the other ranks over any side channel (the engine's network layer,
+ * a file, torch.distributed in bench.py). */
+LMX_API int lmx_exchange_unique_id(void* out_id_128_bytes);
+LMX_API int lmx_exchange_create(LmxContext* ctx, int rank, int world, const void* unique_id_128_bytes, uint32_t ids_per_rank, LmxExchange** out);
+LMX_API void lmx_exchange_destroy(LmxExchange* x);
+/* One frame of this rank: lmx_cull(frustum, type) into result slot 0 / 1 (alternating; the views of the same index are used), then
+ * the all-gather of its record, asynchronously. *out_slot identifies the frame for the calls below. */
+LMX_API int lmx_exchange_cull(LmxExchange* x, const LmxShiftedFrustum* frustum, uint8_t type, uint32_t* out_slot);
+LMX_API int lmx_exchange_wait(LmxExchange* x, uint32_t slot);
+/* Device view: rank r's record = d_records + r * record_words (counts, then ids). sum(counts) > ids_per_rank means that rank's
+ * list was clipped (re-create the exchange with a larger capacity). gathered_event: hipEvent_t recorded after the collective. */
+LMX_API int lmx_exchange_result(LmxExchange* x, uint32_t slot, const int32_t** d_records, uint32_t* record_words, void** gathered_event);
+LMX_API int lmx_exchange_read(LmxExchange* x, uint32_t slot, int rank, uint32_t* out_counts, int32_t* out_ids, uint32_t cap);
+
 /* ---- world transforms: World hierarchy, src/engine/world.cpp:255-282 ---------------------------------------
  * The reference propagates eagerly (one recursive DFS per setTransform). The batch form: stage new root/local
  * transforms, then lmx_world_propagate() recomputes child.world = parent.world.compose(child.local)

@@ -113,6 +113,13 @@ SYMBOLS = {
     "lmx_cull_read": (_ci, [_vp, _u32, _u32, _u8, _vp, _u32, C.POINTER(_u32)]),
     "lmx_cull_bind_output": (_ci, [_vp, _u32, _vp, _sz, _vp]),
     "lmx_cull_device_result": (_ci, [_vp, _u32, _u32, C.POINTER(_vp), C.POINTER(_vp), _vp, C.POINTER(_u32)]),
+    "lmx_exchange_unique_id": (_ci, [_vp]),
+    "lmx_exchange_create": (_ci, [_vp, _ci, _ci, _vp, _u32, C.POINTER(_vp)]),
+    "lmx_exchange_destroy": (None, [_vp]),
+    "lmx_exchange_cull": (_ci, [_vp, _vp, _u8, C.POINTER(_u32)]),
+    "lmx_exchange_wait": (_ci, [_vp, _u32]),
+    "lmx_exchange_result": (_ci, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_vp)]),
+    "lmx_exchange_read": (_ci, [_vp, _u32, _ci, _vp, _vp, _u32]),
     "lmx_world_build": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_world_build_with_world": (_ci, [_vp, _u32, _vp, _vp, _vp]),
     "lmx_world_set_parent": (_ci, [_vp, _i32, _i32]),
@@ -444,6 +451,47 @@ class CullingSystem:
         frusta = np.ascontiguousarray(frusta, SHIFTED_FRUSTUM).reshape(-1)
         self.ctx.check(self.lib.lmx_cull(self.ctx.h, view, _ptr(frusta), len(frusta), type_))
         return CullResult(self, view, len(frusta))
+
+
+def exchange_unique_id() -> bytes:
+    """ncclGetUniqueId (rank 0): 128 opaque bytes every rank passes to VisibleExchange."""
+    buf = np.zeros(128, np.uint8)
+    rc = load_library().lmx_exchange_unique_id(_ptr(buf))
+    if rc:
+        raise LumixError(rc, "lmx_exchange_unique_id (is RCCL installed?)")
+    return buf.tobytes()
+
+
+class VisibleExchange:
+    """lmx_exchange_*: per frame one cull of this rank's entities + one RCCL all-gather of [8 counts | cap ids] per rank."""
+
+    def __init__(self, ctx: Context, rank: int, world: int, unique_id: bytes, ids_per_rank: int):
+        self.ctx, self.lib, self.rank, self.world, self.cap = ctx, ctx.lib, rank, world, int(ids_per_rank)
+        uid = np.frombuffer(unique_id, np.uint8).copy()
+        h = C.c_void_p()
+        ctx.check(self.lib.lmx_exchange_create(ctx.h, rank, world, _ptr(uid), self.cap, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lmx_exchange_destroy(self.h)
+            self.h = None
+
+    def cull(self, frustum: np.ndarray, type_: int = TYPE_ALL) -> int:
+        frustum = np.ascontiguousarray(frustum, SHIFTED_FRUSTUM).reshape(-1)
+        slot = C.c_uint32(0)
+        self.ctx.check(self.lib.lmx_exchange_cull(self.h, _ptr(frustum), type_, C.byref(slot)))
+        return slot.value
+
+    def wait(self, slot: int):
+        self.ctx.check(self.lib.lmx_exchange_wait(self.h, slot))
+
+    def read(self, slot: int, rank: int):
+        """(counts[8], ids) of one rank's gathered record (ids of type 0 first; clipped to the exchange capacity)."""
+        counts = np.zeros(MAX_TYPES, np.uint32)
+        ids = np.zeros(self.cap, np.int32)
+        self.ctx.check(self.lib.lmx_exchange_read(self.h, slot, rank, _ptr(counts), _ptr(ids), self.cap))
+        return counts, ids[: min(int(counts.sum()), self.cap)]
 
 
 class World:

@@ -19,7 +19,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "liblumix_mi355.so")
 SOURCES = ["cull_kernels.hip", "xform_kernels.hip", "skin_kernels.hip", "lmx_capi_ctx.hip", "lmx_capi_cull.hip", "lmx_capi_world.hip",
-           "lmx_capi_skin.hip", "keys_kernels.hip", "lmx_capi_keys.hip", "anim_kernels.hip", "lmx_capi_anim.hip", "lmx_frustum.cpp", "lmx_world_blob.cpp"]
+           "lmx_capi_skin.hip", "lmx_capi_exchange.hip", "keys_kernels.hip", "lmx_capi_keys.hip", "anim_kernels.hip", "lmx_capi_anim.hip", "lmx_frustum.cpp", "lmx_world_blob.cpp"]
 HEADERS = [os.path.join(CSRC, "lmx_math.h"), os.path.join(CSRC, "lmx_kernels.h"), os.path.join(CSRC, "lmx_cull_layout.h"), os.path.join(CSRC, "lmx_context.h"), os.path.join(ROOT, "include", "lumix_mi355.h"),
            os.path.join(ROOT, "include", "lmx_types.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
@@ -61,7 +61,7 @@ def build(force: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(_compile, SOURCES))
     if _stale(LIB, objs):
-        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -358,30 +358,47 @@ __global__ __launch_bounds__(256) void k_apply_patches(float4* __restrict__ sphe
 
 // ---- finalize / consolidate ---------------------------------------------------------------------------------------
 // One block per frustum: totals per type and the exclusive prefix of every shard inside its type (serial over <= a few hundred
-// shards per type, one lane per type).
+// shards per type, one lane per type). packed_start (optional): where type t starts when the types of a frustum are packed back
+// to back (type 0 first) - the layout of the exchange's send buffer.
 __global__ __launch_bounds__(64) void k_cull_finalize(const uint32_t* __restrict__ counts, uint32_t cnt_pad, uint32_t cnt_frustum_stride,
-	const uint8_t* __restrict__ shard_type, uint32_t n_shards, uint32_t* __restrict__ totals, uint32_t* __restrict__ pref) {
+	const uint8_t* __restrict__ shard_type, uint32_t n_shards, uint32_t* __restrict__ totals, uint32_t* __restrict__ pref, uint32_t* __restrict__ packed_start) {
+	__shared__ uint32_t s_tot[MAX_TYPES];
 	const uint32_t f = blockIdx.x;
 	const uint32_t t = threadIdx.x;
-	if (t >= MAX_TYPES) return;
-	uint32_t run = 0;
-	for (uint32_t s = 0; s < n_shards; ++s) {
-		if (shard_type[s] != t) continue;
-		pref[f * n_shards + s] = run;
-		run += counts[f * cnt_frustum_stride + s * cnt_pad];
+	if (t < MAX_TYPES) {
+		uint32_t run = 0;
+		for (uint32_t s = 0; s < n_shards; ++s) {
+			if (shard_type[s] != t) continue;
+			pref[f * n_shards + s] = run;
+			run += counts[f * cnt_frustum_stride + s * cnt_pad];
+		}
+		totals[f * MAX_TYPES + t] = run;
+		s_tot[t] = run;
 	}
-	totals[f * MAX_TYPES + t] = run;
+	__syncthreads();
+	if (packed_start != nullptr && t < MAX_TYPES) {
+		uint32_t at = 0;
+		for (uint32_t k = 0; k < t; ++k) at += s_tot[k];
+		packed_start[f * MAX_TYPES + t] = at;
+	}
 }
 
-// grid (n_shards, n_frusta, splits): copies shard s of frustum f to its place in the type's contiguous list
+// grid (n_shards, n_frusta, splits): copies shard s of frustum f to its place in the type's contiguous list. type_start is
+// indexed [f * type_start_stride + type] (stride 0: the same capacity-based starts for every frustum; MAX_TYPES: packed starts).
+// Ids that would land at or beyond dst_cap (per frustum row) are dropped: a fixed-size send buffer reports the overflow through
+// its totals instead.
 __global__ __launch_bounds__(256) void k_cull_consolidate(const int32_t* __restrict__ src, uint32_t src_stride, const uint32_t* __restrict__ win_base,
 	const uint32_t* __restrict__ counts, uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* __restrict__ shard_type,
-	const uint32_t* __restrict__ type_start, const uint32_t* __restrict__ pref, uint32_t n_shards, int32_t* __restrict__ dst, uint32_t dst_stride) {
+	const uint32_t* __restrict__ type_start, uint32_t type_start_stride, const uint32_t* __restrict__ pref, uint32_t n_shards, int32_t* __restrict__ dst,
+	uint32_t dst_stride, uint32_t dst_cap) {
 	const uint32_t s = blockIdx.x, f = blockIdx.y;
 	const uint32_t c = counts[f * cnt_frustum_stride + s * cnt_pad];
 	const int32_t* from = src + (size_t)f * src_stride + win_base[s];
-	int32_t* to = dst + (size_t)f * dst_stride + type_start[shard_type[s]] + pref[f * n_shards + s];
-	for (uint32_t k = blockIdx.z * 256u + threadIdx.x; k < c; k += gridDim.z * 256u) to[k] = from[k];
+	const uint32_t at = type_start[f * type_start_stride + shard_type[s]] + pref[f * n_shards + s];
+	int32_t* to = dst + (size_t)f * dst_stride + at;
+	const uint32_t room = at < dst_cap ? dst_cap - at : 0u;
+	const uint32_t n = c < room ? c : room;
+	for (uint32_t k = blockIdx.z * 256u + threadIdx.x; k < n; k += gridDim.z * 256u) to[k] = from[k];
 }
 
 template <int F, int WAVES, int CHW, int GRP, bool LANEPAR>
@@ -469,19 +486,19 @@ hipError_t launch_apply_patches(hipStream_t s, float4* spheres, int32_t* ids, co
 }
 
 hipError_t launch_cull_finalize(hipStream_t s, const uint32_t* counts, uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* shard_type,
-	uint32_t n_shards, uint32_t n_frusta, uint32_t* totals, uint32_t* pref) {
+	uint32_t n_shards, uint32_t n_frusta, uint32_t* totals, uint32_t* pref, uint32_t* packed_start) {
 	if (!n_frusta) return hipSuccess;
-	hipLaunchKernelGGL(k_cull_finalize, dim3(n_frusta), dim3(64), 0, s, counts, cnt_pad, cnt_frustum_stride, shard_type, n_shards, totals, pref);
+	hipLaunchKernelGGL(k_cull_finalize, dim3(n_frusta), dim3(64), 0, s, counts, cnt_pad, cnt_frustum_stride, shard_type, n_shards, totals, pref, packed_start);
 	return hipGetLastError();
 }
 
 hipError_t launch_cull_consolidate(hipStream_t s, const int32_t* src, uint32_t src_stride, const uint32_t* win_base, const uint32_t* counts,
-	uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* shard_type, const uint32_t* type_start, const uint32_t* pref, uint32_t n_shards,
-	uint32_t n_frusta, uint32_t max_shard_cap, int32_t* dst, uint32_t dst_stride) {
+	uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* shard_type, const uint32_t* type_start, uint32_t type_start_stride, const uint32_t* pref,
+	uint32_t n_shards, uint32_t n_frusta, uint32_t max_shard_cap, int32_t* dst, uint32_t dst_stride, uint32_t dst_cap) {
 	if (!n_frusta || !n_shards) return hipSuccess;
 	const uint32_t splits = std::max(1u, std::min(64u, max_shard_cap / 4096u));
 	hipLaunchKernelGGL(k_cull_consolidate, dim3(n_shards, n_frusta, splits), dim3(256), 0, s, src, src_stride, win_base, counts, cnt_pad, cnt_frustum_stride,
-		shard_type, type_start, pref, n_shards, dst, dst_stride);
+		shard_type, type_start, type_start_stride, pref, n_shards, dst, dst_stride, dst_cap);
 	return hipGetLastError();
 }
 

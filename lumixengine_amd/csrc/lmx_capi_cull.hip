@@ -484,7 +484,7 @@ int cull_view_finalize(LmxContext* ctx, CullView& v) {
 	LMX_HIP(ctx, v.totals.reserve(MAX_FRUSTA * MAX_TYPES));
 	LMX_HIP(ctx, v.pref.reserve(std::max<size_t>((size_t)MAX_FRUSTA * cs.n_shards, 1)));
 	uint32_t* totals = v.ext_counts ? v.ext_counts : v.totals.p;
-	LMX_HIP(ctx, launch_cull_finalize(ctx->stream, v.counts_ptr(), cs.cnt_pad, cs.n_shards * cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, v.n_frusta, totals, v.pref.p));
+	LMX_HIP(ctx, launch_cull_finalize(ctx->stream, v.counts_ptr(), cs.cnt_pad, cs.n_shards * cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, v.n_frusta, totals, v.pref.p, nullptr));
 	v.finalized = true;
 	return LMX_OK;
 }
@@ -499,7 +499,7 @@ int cull_view_consolidate(LmxContext* ctx, CullView& v) {
 		dst = v.cons.p;
 	}
 	LMX_HIP(ctx, launch_cull_consolidate(ctx->stream, v.out.p, v.out_stride, cs.d_win_base.p, v.counts_ptr(), cs.cnt_pad, cs.n_shards * cs.cnt_pad, cs.d_shard_type.p,
-		cs.d_type_start.p, v.pref.p, cs.n_shards, v.n_frusta, cs.max_shard_cap, dst, v.out_stride));
+		cs.d_type_start.p, 0, v.pref.p, cs.n_shards, v.n_frusta, cs.max_shard_cap, dst, v.out_stride, 0xffffffffu));
 	v.consolidated = true;
 	return LMX_OK;
 }

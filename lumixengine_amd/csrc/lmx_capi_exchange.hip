@@ -1,0 +1,190 @@
+// lmx_capi_exchange.hip — multi-GPU exchange of visible-entity lists behind the C ABI (include/lumix_mi355.h, "exchange").
+//
+// One process per GPU; every rank owns a disjoint set of entities (visibility depends only on the frustum and the
+// entity's own cell, so the cull itself needs no communication). The only exchange step of a frame is ONE ncclAllGather (RCCL over
+// xGMI) of a fixed-size record per rank: [8 per-type counts | cap visible ids, types packed back to back]. The cull's raw result is
+// gathered straight into the send buffer by the finalize / consolidate kernels (no staging copy), the collective runs on a side
+// stream ordered by events, and frames are double-buffered so that the next cull overlaps the previous frame's gather. No torch,
+// no host wait in the steady state. RCCL is loaded with dlopen at the first lmx_exchange_* call: single-GPU users of the library
+// do not need it.
+#include <dlfcn.h>
+
+#include "lmx_context.h"
+
+using namespace lmx;
+
+namespace {
+
+// the handful of RCCL entry points used (rccl.h: ncclGetUniqueId :187, ncclCommInitRank :220, ncclCommDestroy :260, ncclAllGather :678)
+struct NcclUniqueId { char internal[128]; };
+typedef void* NcclComm;
+struct Rccl {
+	void* lib = nullptr;
+	int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+	int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
+	int (*CommDestroy)(NcclComm) = nullptr;
+	int (*AllGather)(const void*, void*, size_t, int /* ncclDataType_t */, NcclComm, hipStream_t) = nullptr;
+	const char* (*GetErrorString)(int) = nullptr;
+	const char* error = nullptr;
+};
+constexpr int NCCL_INT32 = 2; // ncclInt32 (rccl.h ncclDataType_t)
+
+Rccl& rccl() {
+	static Rccl r = [] {
+		Rccl x;
+		for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+			x.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+			if (x.lib) break;
+		}
+		if (!x.lib) {
+			x.error = "librccl.so.1 not found";
+			return x;
+		}
+		x.GetUniqueId = (decltype(x.GetUniqueId))dlsym(x.lib, "ncclGetUniqueId");
+		x.CommInitRank = (decltype(x.CommInitRank))dlsym(x.lib, "ncclCommInitRank");
+		x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.lib, "ncclCommDestroy");
+		x.AllGather = (decltype(x.AllGather))dlsym(x.lib, "ncclAllGather");
+		x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.lib, "ncclGetErrorString");
+		if (!x.GetUniqueId || !x.CommInitRank || !x.CommDestroy || !x.AllGather) x.error = "librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+		return x;
+	}();
+	return r;
+}
+
+} // namespace
+
+struct LmxExchange {
+	LmxContext* ctx = nullptr;
+	NcclComm comm = nullptr;
+	int rank = 0, world = 1;
+	uint32_t cap = 0;      // ids per rank record
+	uint32_t record = 0;   // words per rank record = LMX_MAX_TYPES + cap
+	hipStream_t side = nullptr;
+	DevBuf<int32_t> send[2], recv[2];
+	DevBuf<uint32_t> packed_start[2];
+	hipEvent_t culled[2] = {nullptr, nullptr}, gathered[2] = {nullptr, nullptr};
+	bool in_flight[2] = {false, false};
+	uint32_t next = 0;
+};
+
+extern "C" {
+
+int lmx_exchange_unique_id(void* out_id_128_bytes) {
+	if (!out_id_128_bytes) return LMX_ERR_INVALID_ARGUMENT;
+	Rccl& r = rccl();
+	if (r.error) return LMX_ERR_NO_DEVICE;
+	NcclUniqueId id;
+	if (r.GetUniqueId(&id) != 0) return LMX_ERR_HIP;
+	memcpy(out_id_128_bytes, &id, sizeof(id));
+	return LMX_OK;
+}
+
+int lmx_exchange_create(LmxContext* ctx, int rank, int world, const void* unique_id_128_bytes, uint32_t ids_per_rank, LmxExchange** out) {
+	LMX_CHECK_CTX(ctx);
+	if (!out || !unique_id_128_bytes || world < 1 || rank < 0 || rank >= world || ids_per_rank == 0) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad exchange arguments");
+	Rccl& r = rccl();
+	if (r.error) return fail(ctx, LMX_ERR_NO_DEVICE, "RCCL is not available: %s", r.error);
+	LmxExchange* x = new LmxExchange;
+	x->ctx = ctx;
+	x->rank = rank;
+	x->world = world;
+	x->cap = ids_per_rank;
+	x->record = LMX_MAX_TYPES + ids_per_rank;
+	NcclUniqueId id;
+	memcpy(&id, unique_id_128_bytes, sizeof(id));
+	const int rc = r.CommInitRank(&x->comm, world, id, rank);
+	if (rc != 0) {
+		const char* msg = r.GetErrorString ? r.GetErrorString(rc) : "?";
+		delete x;
+		return fail(ctx, LMX_ERR_HIP, "ncclCommInitRank failed: %s", msg);
+	}
+	LMX_HIP(ctx, hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking));
+	for (int i = 0; i < 2; ++i) {
+		LMX_HIP(ctx, x->send[i].reserve(x->record));
+		LMX_HIP(ctx, x->recv[i].reserve((size_t)x->record * world));
+		LMX_HIP(ctx, x->packed_start[i].reserve(MAX_FRUSTA * MAX_TYPES));
+		LMX_HIP(ctx, hipEventCreateWithFlags(&x->culled[i], hipEventDisableTiming));
+		LMX_HIP(ctx, hipEventCreateWithFlags(&x->gathered[i], hipEventDisableTiming));
+	}
+	*out = x;
+	return LMX_OK;
+}
+
+void lmx_exchange_destroy(LmxExchange* x) {
+	if (!x) return;
+	(void)hipStreamSynchronize(x->side);
+	if (x->comm) (void)rccl().CommDestroy(x->comm);
+	for (int i = 0; i < 2; ++i) {
+		if (x->culled[i]) (void)hipEventDestroy(x->culled[i]);
+		if (x->gathered[i]) (void)hipEventDestroy(x->gathered[i]);
+	}
+	if (x->side) (void)hipStreamDestroy(x->side);
+	delete x;
+}
+
+// One frame of this rank: cull `frustum` over the entities this context holds (result slot = view `slot`), pack the visible ids of
+// all types behind their 8 counts, and enqueue the all-gather of the record on the side stream. Returns the slot (0 / 1) to pass to
+// lmx_exchange_wait / lmx_exchange_result; the slot's previous gather must have been waited for or is waited for here.
+int lmx_exchange_cull(LmxExchange* x, const LmxShiftedFrustum* frustum, uint8_t type, uint32_t* out_slot) {
+	if (!x) return LMX_ERR_INVALID_ARGUMENT;
+	LmxContext* ctx = x->ctx;
+	LMX_CHECK_CTX(ctx);
+	const uint32_t k = x->next;
+	x->next ^= 1u;
+	// the send / recv buffers of this slot are free once its previous gather has finished: the cull stream waits for it (device-side)
+	if (x->in_flight[k]) LMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, x->gathered[k], 0));
+	if (int rc = lmx_cull(ctx, k, frustum, 1, type)) return rc;
+	CullState& cs = ctx->cull;
+	CullView& v = cs.views[k];
+	// per-type totals straight into the record's header, packed type starts, then the ids behind the header (clipped to cap)
+	LMX_HIP(ctx, v.pref.reserve(std::max<size_t>((size_t)MAX_FRUSTA * cs.n_shards, 1)));
+	uint32_t* header = reinterpret_cast<uint32_t*>(x->send[k].p);
+	LMX_HIP(ctx, launch_cull_finalize(ctx->stream, v.counts_ptr(), cs.cnt_pad, cs.n_shards * cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, 1, header, v.pref.p, x->packed_start[k].p));
+	LMX_HIP(ctx, launch_cull_consolidate(ctx->stream, v.out.p, v.out_stride, cs.d_win_base.p, v.counts_ptr(), cs.cnt_pad, cs.n_shards * cs.cnt_pad, cs.d_shard_type.p,
+		x->packed_start[k].p, MAX_TYPES, v.pref.p, cs.n_shards, 1, cs.max_shard_cap, x->send[k].p + MAX_TYPES, 0, x->cap));
+	LMX_HIP(ctx, hipEventRecord(x->culled[k], ctx->stream));
+	LMX_HIP(ctx, hipStreamWaitEvent(x->side, x->culled[k], 0));
+	const int rc = rccl().AllGather(x->send[k].p, x->recv[k].p, x->record, NCCL_INT32, x->comm, x->side);
+	if (rc != 0) return fail(ctx, LMX_ERR_HIP, "ncclAllGather failed: %s", rccl().GetErrorString ? rccl().GetErrorString(rc) : "?");
+	LMX_HIP(ctx, hipEventRecord(x->gathered[k], x->side));
+	x->in_flight[k] = true;
+	if (out_slot) *out_slot = k;
+	return LMX_OK;
+}
+
+// Host wait for the gather of `slot` (a consumer on another stream can instead make that stream wait: lmx_exchange_result's event).
+int lmx_exchange_wait(LmxExchange* x, uint32_t slot) {
+	if (!x || slot > 1) return LMX_ERR_INVALID_ARGUMENT;
+	LmxContext* ctx = x->ctx;
+	LMX_CHECK_CTX(ctx);
+	if (x->in_flight[slot]) LMX_HIP(ctx, hipEventSynchronize(x->gathered[slot]));
+	return LMX_OK;
+}
+
+// Device view of the gathered records of `slot`: rank r's record starts at d_records + r * record_words: LMX_MAX_TYPES counts
+// (what the rank saw, also when it exceeds ids_per_rank: an overflow is visible as sum(counts) > ids_per_rank), then the ids,
+// type 0 first. `gathered_event` (hipEvent_t as void*) is recorded when the collective has finished.
+int lmx_exchange_result(LmxExchange* x, uint32_t slot, const int32_t** d_records, uint32_t* record_words, void** gathered_event) {
+	if (!x || slot > 1) return LMX_ERR_INVALID_ARGUMENT;
+	if (d_records) *d_records = x->recv[slot].p;
+	if (record_words) *record_words = x->record;
+	if (gathered_event) *gathered_event = x->gathered[slot];
+	return LMX_OK;
+}
+
+// Host copy of one rank's record: counts[LMX_MAX_TYPES] and min(sum(counts), ids_per_rank, cap) ids. Waits for the gather.
+int lmx_exchange_read(LmxExchange* x, uint32_t slot, int rank, uint32_t* out_counts, int32_t* out_ids, uint32_t cap) {
+	if (!x || slot > 1 || rank < 0 || rank >= x->world || !out_counts) return LMX_ERR_INVALID_ARGUMENT;
+	LmxContext* ctx = x->ctx;
+	LMX_CHECK_CTX(ctx);
+	if (int rc = lmx_exchange_wait(x, slot)) return rc;
+	const int32_t* rec = x->recv[slot].p + (size_t)rank * x->record;
+	LMX_HIP(ctx, hipMemcpy(out_counts, rec, sizeof(uint32_t) * MAX_TYPES, hipMemcpyDeviceToHost));
+	uint64_t total = 0;
+	for (int t = 0; t < MAX_TYPES; ++t) total += out_counts[t];
+	const uint32_t n = (uint32_t)std::min<uint64_t>(total, std::min(x->cap, cap));
+	if (n && out_ids) LMX_HIP(ctx, hipMemcpy(out_ids, rec + MAX_TYPES, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+	return LMX_OK;
+}
+
+} // extern "C"

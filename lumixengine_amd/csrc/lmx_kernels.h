@@ -86,13 +86,15 @@ hipError_t launch_apply_patches(hipStream_t s, float4* spheres, int32_t* ids, co
 	const PatchId* pi, uint32_t n_pi, const PatchDyn* pd, uint32_t n_pd);
 
 // Per-(frustum, type) totals and per-(frustum, shard) offsets of the consolidated lists: totals[f * MAX_TYPES + t], pref[f * n_shards + s]
-// (offset of shard s inside its type's consolidated list). shard_type[s] = renderable type of shard s.
+// (offset of shard s inside its type's consolidated list). shard_type[s] = renderable type of shard s. packed_start (optional):
+// [f * MAX_TYPES + t] = start of type t when the types of a frustum are packed back to back.
 hipError_t launch_cull_finalize(hipStream_t s, const uint32_t* counts, uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* shard_type,
-	uint32_t n_shards, uint32_t n_frusta, uint32_t* totals, uint32_t* pref);
-// One contiguous list per (frustum, type): dst[f * dst_stride + type_start[type] + pref + k] = src[f * src_stride + win_base[s] + k]
+	uint32_t n_shards, uint32_t n_frusta, uint32_t* totals, uint32_t* pref, uint32_t* packed_start);
+// One contiguous list per (frustum, type): dst[f * dst_stride + type_start[f * type_start_stride + type] + pref + k] = src[f * src_stride + win_base[s] + k],
+// clipped to dst_cap ids per frustum row
 hipError_t launch_cull_consolidate(hipStream_t s, const int32_t* src, uint32_t src_stride, const uint32_t* win_base, const uint32_t* counts,
-	uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* shard_type, const uint32_t* type_start /* device, [MAX_TYPES] */, const uint32_t* pref,
-	uint32_t n_shards, uint32_t n_frusta, uint32_t max_shard_cap, int32_t* dst, uint32_t dst_stride);
+	uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* shard_type, const uint32_t* type_start /* device */, uint32_t type_start_stride,
+	const uint32_t* pref, uint32_t n_shards, uint32_t n_frusta, uint32_t max_shard_cap, int32_t* dst, uint32_t dst_stride, uint32_t dst_cap);
 
 // ---- world transforms ------------------------------------------------------------------------------------
 struct WorldDevice {
