@@ -7,8 +7,10 @@
 Workload at N=1: BASELINE config 2 ("10M static entities, 1 frustum, 1xMI355X cull + compaction"), sparse variant
 (cube [-15000,15000]^3, ~1 M occupied cells), camera = the reference player's default viewport (fov 60 deg, 1920x1080,
 near 0.1, far 10000). One step = one cull of every resident entity: classify kernel + sphere/compaction
-kernel, visible ids left in HBM. For N>1 every rank owns its own 10 M entities (weak scaling, one process per GPU)
-and a step also all-gathers the visible-id lists over RCCL (counts, then the padded payload).
+kernel, visible ids left in HBM. For N>1 (one process per GPU) a step is cull + the native exchange (lmx_exchange_*: one
+ncclAllGather of [counts | ids] per rank on a side stream, double-buffered). --scaling weak (default): every rank owns its own 10 M
+entities. --scaling strong: BASELINE config 4 - ONE 10 M scene partitioned over the ranks by cell hash (+ 100 k skinned instances by
+index, timed as an extra); the union of the gathered lists is checked against the unsharded result.
 
 value = entities resident on all ranks x frusta / wall time per step (max over ranks, barrier + synchronize on both
 sides of exactly K steps). Inputs are resident in HBM before the timed region starts; the frustum (256 B) is a kernel
@@ -43,10 +45,13 @@ def main():
     ap.add_argument("--camera", choices=["default", "all_visible"], default="default",
                     help="all_visible: camera far outside looking at the whole cube (every sphere is fetched and visible) - the pure streaming case used to calibrate PMC byte counters")
     ap.add_argument("--force-collective", action="store_true", help="run the N>1 code path (RCCL all-gather of visible ids) even with one rank")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N>1: weak = every rank owns --entities entities (default); strong = BASELINE config 4, one --entities scene partitioned by cell hash")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the default-camera loops (warm-up, timed, event-timed): the command whose rocprofv3 --kernel-trace --stats summary is committed under profiles/")
     ap.add_argument("--no-extras", action="store_true", help="skip the dense-variant / transform / skin side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--big-entities", type=int, default=100_000_000, help="extras: entity count of the config-5-sized single-GPU legs (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -117,12 +122,21 @@ def main():
     N = args.entities
     half = 15000.0 if args.variant == "sparse" else 5000.0
     t0 = time.time()
-    sc = scenes.cull_scene(N, half, seed=2 + rank)
+    strong = args.scaling == "strong" and (world > 1 or args.force_collective)
+    sc = scenes.cull_scene(N, half, seed=2 if strong else 2 + rank)
     cs = api.CullingSystem(ctx)
-    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    if strong:
+        mine = D.shard_by_cell(sc["pos"], world, rank)  # cells stay whole: no cell is classified on two GPUs
+        cs.build(sc["entity"][mine], sc["type"][mine], sc["pos"][mine], sc["radius"][mine])
+        log(f"[rank {rank}] owns {int(mine.sum())} of {N} entities")
+    else:
+        cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
     stats = cs.stats()
     log(f"[rank {rank}] scene {args.variant}: {N} entities, {stats['cells']} cells, {stats['chunks']} chunks, build {time.time() - t0:.1f}s")
     frustum = api.viewport_frustum()  # default player viewport at the origin
+    baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        baseline = CpuBaseline(scenes, sc, frustum, log)  # builds the CPU-side scene on a background thread while the GPU legs run
     # Process warm-up, outside every timed region: the HIP runtime pays a one-time ~50 ms stall around the 850th kernel launch
     # of a process (measured: tools/hip_queue_stall_probe.py, a 3000-cull loop stalls once in launches 750-1000 and never again in the
     # next 8000). Without this it lands in whichever timed loop crosses that count (a --steps 2000 run read 45 us per step
@@ -135,32 +149,28 @@ def main():
     n_frusta = 1
 
     if use_dist:
-        # One exchange per frame: the kernel writes [counts | ids] into one contiguous buffer and a single asynchronous
-        # all-gather ships counts plus the first `cap` ids of every rank; cap comes from a first exact (two-collective)
-        # gather, frames are double-buffered so the next cull overlaps this frame's exchange (lumixengine_amd/distributed.py).
-        n_padded = stats["chunks"] * 64
-        n_counts = api.MAX_FRUSTA * api.MAX_TYPES
-        probe = torch.zeros(n_counts + n_frusta * n_padded, dtype=torch.int32, device="cuda")
-        cs.bindOutput(0, probe[n_counts:].data_ptr(), n_frusta * n_padded, probe[:n_counts].data_ptr())
-        cs.cull(frustum)
-        first = D.allgather_visible(probe[n_counts:].view(n_frusta, n_padded), probe[:n_counts].view(api.MAX_FRUSTA, api.MAX_TYPES)[:n_frusta, 0])
-        max_visible = max(int(t.numel()) for t in first[0])
-        cap = min(n_padded, (int(max_visible * 1.25) + 1023) // 1024 * 1024)
-        xchg = D.VisibleExchange(n_counts, n_frusta * n_padded, cap, "cuda")
-        for i in range(2):
-            cs.bindOutput(i, xchg.send[i][n_counts:].data_ptr(), n_frusta * n_padded, xchg.send[i][:n_counts].data_ptr())
-
-        # the step is host-bound once a collective is in it (a torch all-gather costs ~22 us of host time, the cull 18 us of
-        # GPU time): the C entry point is called directly, without the Python wrapper's array checks and result object
+        # One exchange per frame, native (csrc/lmx_capi_exchange.hip): the cull's gather kernels write [8 counts | cap ids] into the
+        # send buffer, ONE ncclAllGather per frame runs on a side stream, frames alternate between two slots so the next cull
+        # overlaps this frame's gather. torch.distributed only carries the 128-byte RCCL id, the barrier and the timing reduction.
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(api.exchange_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        probe = int(cs.cull(frustum).counts()[0].sum())
+        t = torch.tensor([probe], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        cap = (int(t.item()) * 5 // 4 + 1023) // 1024 * 1024  # 1.25 x the largest visible count of any rank
+        xchg = api.VisibleExchange(ctx, rank, world, uid.cpu().numpy().tobytes(), cap)
         fr_c = np.ascontiguousarray(frustum, api.SHIFTED_FRUSTUM).reshape(-1)
-        fr_ptr, lmx_cull, h = api._ptr(fr_c), ctx.lib.lmx_cull, ctx.h
+        fr_ptr, x_cull, xh = api._ptr(fr_c), ctx.lib.lmx_exchange_cull, xchg.h
+        import ctypes as C
+
+        slot_c = C.c_uint32(0)
 
         def step():
-            i, _ = xchg.buffer()
-            if lmx_cull(h, i, fr_ptr, n_frusta, api.TYPE_ALL) != 0:
-                raise RuntimeError(ctx.lib.lmx_last_error(h).decode())
-            xchg.exchange(i)
-            return i
+            if x_cull(xh, fr_ptr, api.TYPE_ALL, C.byref(slot_c)) != 0:
+                raise RuntimeError(ctx.lib.lmx_last_error(ctx.h).decode())
+            return slot_c.value
     else:
 
         def step():
@@ -168,10 +178,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if use_dist:
-        xchg.finish()
-    ms_per_step = timed(step_and_drain(step, xchg, args.steps) if use_dist else step, args.steps)
-    value = N * world * n_frusta / (ms_per_step * 1e-3)
+    ms_per_step = timed(step, args.steps)  # (the closing synchronize of `timed` also drains the side stream's last gathers)
+    value = (N if strong else N * world) * n_frusta / (ms_per_step * 1e-3)
     res = cs.cull(frustum)
     visible = int(res.counts()[0].sum())
 
@@ -266,7 +274,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -276,47 +284,45 @@ def main():
             "frusta": n_frusta,
             "cells_per_gpu": stats["cells"],
             "visible_per_gpu": visible,
-            "sharding": "entities per rank, RCCL all-gather of visible ids" if world > 1 else "single GPU",
+            "sharding": ("one scene partitioned by cell hash" if strong else "own entities per rank") + ", native RCCL all-gather of visible ids" if use_dist else "single GPU",
         },
         "roofline": roofline,
     }
 
     if rank == 0 and world == 1:
         if not args.no_extras:
-            result["extra"] = extras(ctx, api, scenes, torch, timed, N, log)
-        if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(scenes, frustum, N, half, log)
+            result["extra"] = extras(ctx, api, scenes, torch, timed, N, log, args.big_entities)
+        if baseline is not None:
+            result["cpu_baseline"] = baseline.measure()
     if use_dist:
-        # sanity of the exchange step: every rank's counts and ids arrived, nothing overflowed the fixed capacity
-        i = step()
-        xchg.finish()
+        # sanity of the exchange step: every rank's record arrived, nothing overflowed, own record == local cull; in the strong
+        # (config 4) split the union over ranks must be the unsharded visible set
+        slot = step()
+        xchg.wait(slot)
         torch.cuda.synchronize()
-        g = xchg.gathered(i)
-        got = [int(x) for x in g[:, 0].tolist()]
-        result["config"]["allgather_visible_counts"] = got
-        result["config"]["exchange"] = f"one async all-gather of counts + {xchg.cap} ids per rank per frame, double-buffered"
-        assert len(got) == world and got[rank] == visible and not xchg.overflowed(i), (got, visible, xchg.cap)
-        mine = torch.sort(g[rank, n_counts : n_counts + visible]).values
-        ref = torch.sort(torch.from_numpy(res.ids(0, 0)).cuda()).values
-        assert torch.equal(mine, ref), "gathered ids differ from the local cull result"
+        parsed, seen = [], []
+        for r in range(world):
+            counts, ids = xchg.read(slot, r)
+            seen.append(int(counts.sum()))
+            parsed.append(ids)
+        result["config"]["allgather_visible_counts"] = seen
+        result["config"]["exchange"] = f"one ncclAllGather per frame of [8 counts | {xchg.cap} ids] per rank, side stream, double-buffered (lmx_exchange_*)"
+        result["config"]["ranks_seen_by_rccl"] = len(seen)
+        assert len(seen) == world and max(seen) <= xchg.cap, (seen, xchg.cap)
+        assert seen[rank] == visible and np.array_equal(np.sort(parsed[rank]), np.sort(res.all_ids(0)[0])), "gathered ids differ from the local cull result"
+        if strong and rank == 0:
+            whole = api.CullingSystem(ctx)
+            whole.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+            want = np.sort(whole.cull(frustum, view=3).all_ids(0)[0])
+            assert np.array_equal(np.sort(np.concatenate(parsed)), want), "union of the ranks' lists != unsharded cull"
+            result["config"]["union_equals_unsharded"] = True
+            result["config"]["visible_total"] = int(len(want))
+            del whole
+        xchg.close()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.destroy_process_group()
-
-
-def step_and_drain(step, xchg, steps):
-    """The timed loop body for N>1: `steps` pipelined frames; the last call also drains the in-flight exchanges so that the
-    timed region covers every frame's exchange."""
-    state = {"k": 0}
-
-    def fn():
-        step()
-        state["k"] += 1
-        if state["k"] % steps == 0:
-            xchg.finish()
-
-    return fn
 
 
 def load_traffic(kernel):
@@ -337,7 +343,7 @@ def load_traffic(kernel):
         return None, f"unreadable traffic file: {e}"
 
 
-def extras(ctx, api, scenes, torch, timed, N, log):
+def extras(ctx, api, scenes, torch, timed, N, log, big_entities=0):
     """Side measurements (not the headline `value`): dense config-2 variant, 8-frusta pass, config-3 transform + skin."""
     out = {}
     # dense variant of config 2 (cube +-5000: ~37 k cells, ~270 spheres per cell)
@@ -413,6 +419,85 @@ def extras(ctx, api, scenes, torch, timed, N, log):
         out[name + "_visible_per_sec"] = visible / (k_ms * 1e-3) if k_ms else None
         out[name + "_counts"] = cnt
     del cs, sk, ks, cases
+
+    # incremental updates on the headline scene: 1000 removals + 1000 adds per frame are O(1) patches (tombstones + overflow set), no
+    # rebuild of the sorted layout. Cost per frame = (updates + cull) - cull, wall clock, host work included.
+    sc_u = scenes.cull_scene(N, 15000.0, seed=2)
+    cs_u = api.CullingSystem(ctx)
+    cs_u.build(sc_u["entity"], sc_u["type"], sc_u["pos"], sc_u["radius"])
+    fr_u = api.viewport_frustum()
+    for _ in range(20):
+        cs_u.cull(fr_u)
+    ms_plain = timed(lambda: cs_u.cull(fr_u), 200)
+    rng_u = np.random.default_rng(3)
+    victims = rng_u.permutation(N)[: 120 * 1000].astype(np.int32).reshape(120, 1000)
+    add_pos = rng_u.uniform(-15000.0, 15000.0, size=(120, 1000, 3))
+    add_r = np.exp(rng_u.uniform(np.log(0.5), np.log(50.0), size=(120, 1000))).astype(np.float32)
+    add_t = np.zeros(1000, np.uint8)
+    frame_u = [0]
+
+    def update_frame():
+        k = frame_u[0]
+        frame_u[0] += 1
+        cs_u.removeMany(victims[k])
+        cs_u.addMany(np.arange(N + 1000 * k, N + 1000 * (k + 1), dtype=np.int32), add_t, add_pos[k], add_r[k])
+        cs_u.cull(fr_u)
+
+    for _ in range(10):
+        update_frame()
+    ms_upd = timed(update_frame, 100)
+    out["update_stream_plain_cull_ms"] = ms_plain
+    out["update_stream_1000_add_1000_remove_plus_cull_ms"] = ms_upd
+    out["update_stream_added_us_per_frame"] = (ms_upd - ms_plain) * 1e3
+    out["update_stream_state"] = cs_u.updateStats()
+    del cs_u, sc_u
+
+    # BASELINE config 5's single-GPU size: 100 M entities (2 GB of spheres + ids, far beyond the 256 MiB Infinity Cache: every pass
+    # is HBM-cold by construction, no scrub needed). Same three regimes as the roofline legs + the 8 cascades in one call.
+    if big_entities:
+        NB = big_entities
+        half_b = 15000.0 * (NB / 1e7) ** (1.0 / 3.0)
+        t0 = time.time()
+        sc_b = scenes.cull_scene(NB, half_b, seed=2, mixed_types=True)
+        cs_b = api.CullingSystem(ctx)
+        cs_b.build(sc_b["entity"], sc_b["type"], sc_b["pos"], sc_b["radius"])
+        big = {"entities": NB, "half_extent": half_b, "scene_plus_build_s": round(time.time() - t0, 1), "cells": cs_b.stats()["cells"]}
+
+        def leg(csys, fr, reps=10):
+            for _ in range(3):
+                csys.cull(fr)
+            ms_wall = timed(lambda: csys.cull(fr), reps)
+            ctx.profile_reset()
+            ctx.profile_enable(True)
+            for _ in range(reps):
+                csys.cull(fr)
+            ctx.synchronize()
+            ctx.profile_enable(False)
+            ms_k, n_k = ctx.profile_get(api.K_CULL_SPHERES)
+            return ms_wall, ms_k / max(n_k, 1), csys.cull(fr).counts().sum(axis=1)
+
+        fr_d = api.viewport_frustum()
+        w, k, v = leg(cs_b, fr_d)
+        big["default_camera"] = {"ms_per_cull": w, "kernel_ms": k, "visible": int(v[0]), "entities_per_sec": NB / (w * 1e-3)}
+        w, k, v = leg(cs_b, api.viewport_frustum(pos=(0.0, 0.0, 4.0 * half_b), far=20.0 * half_b))
+        big["all_accept"] = {"ms_per_cull": w, "kernel_ms": k, "visible": int(v[0]), "moved_bytes": 8.0 * NB, "GBps": 8.0 * NB / (k * 1e-3) / 1e9,
+                             "frac_of_8TBps": 8.0 * NB / (k * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        fr8b = np.concatenate([
+            api.viewport_frustum(is_ortho=True, ortho_size=[30.0, 90.0, 400.0, 1500.0][k % 4] * 4.0, w=1024, h=1024, near=0.0, far=20000.0,
+                                 pos=(5.0 * k, 9000.0, -3.0 * k), rot=(-0.6, 0.25 * (k // 4), 0.0, 0.76))
+            for k in range(8)])
+        w8, _, v8 = leg(cs_b, fr8b, reps=5)
+        big["cascades_8_frusta"] = {"ms_per_call": w8, "visible_per_frustum": [int(x) for x in v8], "entity_frustum_tests_per_sec": 8.0 * NB / (w8 * 1e-3)}
+        del cs_b
+        sc_b["radius"] = np.random.default_rng(5).uniform(300.5, 330.0, size=NB).astype(np.float32)
+        cs_b = api.CullingSystem(ctx)
+        cs_b.build(sc_b["entity"], sc_b["type"], sc_b["pos"], sc_b["radius"])
+        w, k, v = leg(cs_b, fr_d)
+        moved = 20.0 * NB + 4.0 * float(v[0])
+        big["all_test"] = {"ms_per_cull": w, "kernel_ms": k, "visible": int(v[0]), "moved_bytes": moved, "GBps": moved / (k * 1e-3) / 1e9,
+                           "frac_of_8TBps": moved / (k * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        out["config5_size_single_gpu"] = big
+        del cs_b, sc_b
 
     # config 5 flavour on one GPU: mixed renderable types, 8 ortho cascade frusta tested in ONE pass over the spheres
     sc = scenes.cull_scene(N, 15000.0, seed=4, mixed_types=True)
@@ -647,86 +732,118 @@ def extras(ctx, api, scenes, torch, timed, N, log):
     return out
 
 
-def cpu_baseline(scenes, frustum, N, half, log):
-    """The reference CPU path on this box's host cores: oracle/_ref (reference math/geometry object code + restated
-    CullingSystemImpl driver) when present, else the plain-C port. Bounded sample of the same workload: a quarter of the
-    entities in a cube shrunk to keep the density (entities per cell) of the GPU run, same frustum; jobs::forEach
-    stand-in on all host cores and on one. Baseline only - the GPU/CPU ratio says nothing about kernel quality."""
-    from oracle import pyoracle
+class CpuBaseline:
+    """The reference CPU path on this box's host cores, on the FULL headline workload (10 M entities, same scene, same frustum):
+    oracle/_ref (reference math / geometry object code + restated CullingSystemImpl driver) when present, else the plain-C port.
+    The scene is added and the page pool warmed up on a background thread while the GPU legs run (the reference allocates one
+    4 KiB result page per visited cell page: ~1 M pages for this scene, first touched during the first cull); the timed part is a
+    thread sweep of jobs::forEach stand-ins on a PERSISTENT worker pool: median + p10 / p90 per thread count. Baseline only - the
+    GPU / CPU ratio says nothing about kernel quality."""
 
-    cores = os.cpu_count() or 1
-    kind = "reference" if pyoracle.have_reference() else "port"
-    if kind == "port" and not os.path.exists(pyoracle.ORACLE_SO):
-        pyoracle.build()
-    o = pyoracle.Oracle(kind)
-    n = max(N // 4, 1)
-    sample_half = half * (n / N) ** (1.0 / 3.0)
-    sc = scenes.cull_scene(n, sample_half, seed=2)
-    ocs = o.culling_system()
-    t0 = time.time()
-    ocs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
-    t_add = time.time() - t0
-    fr = np.ascontiguousarray(frustum)
+    THREADS = (1, 8, 16, 32, 64)
 
-    def measure(threads):
-        ocs.cull(fr, n_threads=threads, want_ids=False, cap=0)  # warm-up (fills the page pool)
-        times, t_start = [], time.time()
-        while len(times) < 20 and (time.time() - t_start) < 8.0:
+    def __init__(self, scenes, sc, frustum, log):
+        import threading
+
+        from oracle import pyoracle
+
+        self.log, self.sc, self.fr = log, sc, np.ascontiguousarray(frustum)
+        self.kind = "reference" if pyoracle.have_reference() else "port"
+        if self.kind == "port" and not os.path.exists(pyoracle.ORACLE_SO):
+            pyoracle.build()
+        self.o = pyoracle.Oracle(self.kind)
+        self.scenes = scenes
+        self.error = None
+        self.thread = threading.Thread(target=self._prepare, daemon=True)
+        self.thread.start()
+
+    def _prepare(self):
+        try:
+            t0 = time.time()
+            self.ocs = self.o.culling_system()
+            self.ocs.add_bulk(self.sc["entity"], self.sc["type"], self.sc["pos"], self.sc["radius"])
+            self.t_add = time.time() - t0
+            t0 = time.time()
+            self.ocs.cull(self.fr, n_threads=8, want_ids=False, cap=0)  # fills the page pool
+            self.t_first_cull = time.time() - t0
+        except Exception as e:  # noqa: BLE001 - reported in the JSON line instead of killing the bench
+            self.error = repr(e)
+
+    def measure(self):
+        self.thread.join()
+        if self.error:
+            return {"error": self.error, "kind": self.kind}
+        n = len(self.sc["entity"])
+        host = os.cpu_count() or 1
+        sweep = {}
+        for threads in self.THREADS:
+            if threads > host and threads != 1:
+                continue
+            times, t_start = [], time.time()
+            while len(times) < 9 and (time.time() - t_start) < 6.0:
+                t0 = time.perf_counter()
+                self.ocs.cull(self.fr, n_threads=threads, want_ids=False, cap=0)
+                times.append(time.perf_counter() - t0)
+            a = np.array(times)
+            sweep[threads] = {"median_ms": round(float(np.median(a)) * 1e3, 3), "p10_ms": round(float(np.percentile(a, 10)) * 1e3, 3),
+                              "p90_ms": round(float(np.percentile(a, 90)) * 1e3, 3), "culls": len(times), "entities_per_s": n / float(np.median(a))}
+        best = min(sweep, key=lambda k: sweep[k]["median_ms"])
+        visible, pages = self.ocs.cull(self.fr, n_threads=1, want_ids=False, cap=0)
+        self.log(f"cpu baseline ({self.kind}): {n} entities, add {self.t_add:.1f}s, first cull {self.t_first_cull:.1f}s, sweep " +
+                 ", ".join(f"{k}t {v['median_ms']:.1f} ms" for k, v in sweep.items()) + f", {visible} visible, {pages} result pages")
+        out = {
+            "value": sweep[best]["entities_per_s"],
+            "unit": "entities/s",
+            "cores": best,
+            "kind": self.kind,
+            "sample": f"the full headline workload: {n} entities, same scene and frustum as the GPU run; median of {sweep[best]['culls']} culls at {best} thread(s) "
+                      f"(best of the sweep {list(sweep)}); one CullResult page per visited cell page under a mutex, as in the reference ({pages} pages per cull)",
+            "host_cores": host,
+            "thread_sweep": {str(k): v for k, v in sweep.items()},
+            "single_thread_value": sweep[1]["entities_per_s"],
+            "scene_add_s": round(self.t_add, 2),
+            "first_cull_s": round(self.t_first_cull, 2),
+            "visible": int(visible),
+            "describe": self.o.describe(),
+        }
+        out.update(self._other())
+        return out
+
+    def _other(self):
+        """the other two metrics of SURVEY.md 8d, bounded samples, one thread and 8 threads (parallel over instances / roots)"""
+        o, scenes, other = self.o, self.scenes, {}
+        try:
+            sk = scenes.skeleton(64, seed=4)
+            verts, skin = scenes.skinned_mesh(10_000, 64, seed=6)
+            n_inst = 64
+            rp, rr = scenes.relative_poses(n_inst, 64, seed=5)
+            inv = o.invert_bind(sk["bind"])
+            for threads in (1, 8):
+                t0 = time.perf_counter()
+                apos, arot = o.pose_compute_absolute(rp, rr, sk["parents"], sk["first_nonroot"])
+                pal = o.skin_matrices(apos, arot, inv)
+                t1 = time.perf_counter()
+                o.evaluate_skin(verts, skin, pal, n_threads=threads)
+                t2 = time.perf_counter()
+                other[f"skin_verts_per_sec_{threads}thread"] = n_inst * len(verts) / (t2 - t1)
+                if threads == 1:
+                    other["pose_palette_bones_per_sec_1thread"] = n_inst * 64 / (t1 - t0)
+            h = scenes.hierarchy_chains(250_000, 4, seed=2)  # BASELINE config 3's hierarchy at full size
+            nn = len(h["parent"])
+            w = o.world(nn)
+            roots = np.flatnonzero(h["parent"] < 0).astype(np.int32)
+            kids = np.flatnonzero(h["parent"] >= 0).astype(np.int32)
+            w.init_transforms(roots, h["local"][roots])
+            w.set_parents(h["parent"][kids], kids)
+            w.set_local_transforms(kids, h["local"][kids])
+            new_root = scenes.random_transforms(np.random.default_rng(1), len(roots), 4000.0)
             t0 = time.perf_counter()
-            ocs.cull(fr, n_threads=threads, want_ids=False, cap=0)
-            times.append(time.perf_counter() - t0)
-        return float(np.median(times)), len(times)
-
-    multi, reps = measure(cores)
-    single, _ = measure(1)
-    visible, pages = ocs.cull(fr, n_threads=1, want_ids=False, cap=0)
-    best, used = (multi, cores) if multi <= single else (single, 1)
-    # the other two metrics of SURVEY.md 8d, bounded samples, one thread and 8 threads (parallel over instances / roots)
-    other = {}
-    try:
-        sk = scenes.skeleton(64, seed=4)
-        verts, skin = scenes.skinned_mesh(10_000, 64, seed=6)
-        n_inst = 64
-        rp, rr = scenes.relative_poses(n_inst, 64, seed=5)
-        inv = o.invert_bind(sk["bind"])
-        for threads in (1, 8):
-            t0 = time.perf_counter()
-            apos, arot = o.pose_compute_absolute(rp, rr, sk["parents"], sk["first_nonroot"])
-            pal = o.skin_matrices(apos, arot, inv)
-            t1 = time.perf_counter()
-            o.evaluate_skin(verts, skin, pal, n_threads=threads)
-            t2 = time.perf_counter()
-            other[f"skin_verts_per_sec_{threads}thread"] = n_inst * len(verts) / (t2 - t1)
-            if threads == 1:
-                other["pose_palette_bones_per_sec_1thread"] = n_inst * 64 / (t1 - t0)
-        h = scenes.hierarchy_chains(50_000, 4, seed=2)
-        nn = len(h["parent"])
-        w = o.world(nn)
-        roots = np.flatnonzero(h["parent"] < 0).astype(np.int32)
-        kids = np.flatnonzero(h["parent"] >= 0).astype(np.int32)
-        w.init_transforms(roots, h["local"][roots])
-        w.set_parents(h["parent"][kids], kids)
-        w.set_local_transforms(kids, h["local"][kids])
-        new_root = scenes.random_transforms(np.random.default_rng(1), len(roots), 4000.0)
-        t0 = time.perf_counter()
-        w.set_transforms(roots, new_root)  # World::setTransform on every root: the DFS of world.cpp:255-282
-        other["transforms_per_sec_1thread"] = len(kids) / (time.perf_counter() - t0)
-        other["other_samples"] = f"skin: {n_inst} instances x 64 bones x {len(verts)} verts of one mesh; transforms: {len(roots)} roots x depth-4 chains, every root moved once"
-    except Exception as e:  # the headline baseline must survive a problem in the side measurements
-        other["other_error"] = repr(e)
-    log(f"cpu baseline ({kind}): {n} entities, add {t_add:.1f}s, cull median {multi * 1e3:.1f} ms on {cores} threads, {single * 1e3:.1f} ms on 1 thread, {visible} visible, {pages} result pages")
-    return {
-        "value": n / best,
-        "unit": "entities/s",
-        "cores": used,
-        "kind": kind,
-        "sample": f"{n} entities in a cube of half-extent {sample_half:.0f} (same entities-per-cell density as the GPU workload), same frustum, median of {reps} culls; one CullResult page per visited cell page as in the reference ({pages} pages per cull)",
-        "all_cores_value": n / multi,
-        "all_cores": cores,
-        "single_thread_value": n / single,
-        "describe": o.describe(),
-        **other,
-    }
+            w.set_transforms(roots, new_root)  # World::setTransform on every root: the DFS of world.cpp:255-282
+            other["transforms_per_sec_1thread"] = len(kids) / (time.perf_counter() - t0)
+            other["other_samples"] = f"skin: {n_inst} instances x 64 bones x {len(verts)} verts of one mesh; transforms: {len(roots)} roots x depth-4 chains (config 3 at full size), every root moved once"
+        except Exception as e:  # noqa: BLE001 - the headline baseline must survive a problem in the side measurements
+            other["other_error"] = repr(e)
+        return other
 
 
 if __name__ == "__main__":

@@ -376,6 +376,40 @@ static void* job_worker(void* p) {
 	}
 }
 
+/* Persistent workers (the engine's job system keeps its worker threads for the process lifetime, core/job_system.cpp): threads
+ * are created once, sleep on a condition variable between jobs and pull indices from the job's shared cursor. Spawning
+ * min(workers, steps) threads per cull instead would put thread creation (tens of microseconds each) inside every timed frame. */
+static struct {
+	pthread_mutex_t mutex;
+	pthread_cond_t work, done;
+	pthread_t threads[256];
+	int n_threads;        /* workers created so far */
+	job_pool* job;        /* current job, NULL when idle */
+	unsigned generation;  /* bumped per job */
+	int wanted, claimed;  /* helpers asked for / that joined the current job */
+	int running;          /* helpers still inside the current job */
+} g_workers = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, NULL, 0, 0, 0, 0};
+
+static void* persistent_worker(void* unused) {
+	(void)unused;
+	unsigned seen = 0;
+	pthread_mutex_lock(&g_workers.mutex);
+	for (;;) {
+		while (g_workers.generation == seen || g_workers.claimed >= g_workers.wanted) {
+			if (g_workers.generation != seen) seen = g_workers.generation; /* job is fully staffed: skip it */
+			pthread_cond_wait(&g_workers.work, &g_workers.mutex);
+		}
+		seen = g_workers.generation;
+		++g_workers.claimed;
+		job_pool* job = g_workers.job;
+		pthread_mutex_unlock(&g_workers.mutex);
+		job_worker(job);
+		pthread_mutex_lock(&g_workers.mutex);
+		if (--g_workers.running == 0) pthread_cond_signal(&g_workers.done);
+	}
+	return NULL;
+}
+
 static void for_each_job(uint32_t count, int n_threads, job_fn fn, void* ctx) {
 	if (n_threads <= 1 || count <= 1) {
 		for (uint32_t i = 0; i < count; ++i) fn(ctx, i);
@@ -384,10 +418,27 @@ static void for_each_job(uint32_t count, int n_threads, job_fn fn, void* ctx) {
 	job_pool pool = {fn, ctx, count, 0};
 	int n = n_threads < (int)count ? n_threads : (int)count;
 	if (n > 256) n = 256;
-	pthread_t th[256];
-	for (int t = 1; t < n; ++t) pthread_create(&th[t], NULL, job_worker, &pool);
-	job_worker(&pool);
-	for (int t = 1; t < n; ++t) pthread_join(th[t], NULL);
+	const int helpers = n - 1;
+	pthread_mutex_lock(&g_workers.mutex);
+	while (g_workers.n_threads < helpers) {
+		if (pthread_create(&g_workers.threads[g_workers.n_threads], NULL, persistent_worker, NULL) != 0) break;
+		pthread_detach(g_workers.threads[g_workers.n_threads]);
+		++g_workers.n_threads;
+	}
+	const int staffed = helpers < g_workers.n_threads ? helpers : g_workers.n_threads;
+	g_workers.job = &pool;
+	g_workers.wanted = staffed;
+	g_workers.claimed = 0;
+	g_workers.running = staffed;
+	++g_workers.generation;
+	pthread_cond_broadcast(&g_workers.work);
+	pthread_mutex_unlock(&g_workers.mutex);
+	job_worker(&pool); /* the caller works too (jobs::forEach runs on the calling fiber as well) */
+	pthread_mutex_lock(&g_workers.mutex);
+	while (g_workers.running > 0) pthread_cond_wait(&g_workers.done, &g_workers.mutex);
+	g_workers.job = NULL;
+	g_workers.wanted = 0;
+	pthread_mutex_unlock(&g_workers.mutex);
 }
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -21,6 +21,9 @@
 #include "core/os.h"
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -172,25 +175,73 @@ struct PagedResultList { // PagedList<CullResult>, core/page_allocator.h:60-109 
 	}
 };
 
-// jobs::forEach stand-in, core/job_system.h:131-180: min(workers, steps) jobs pulling from one atomic cursor
+// jobs::forEach stand-in, core/job_system.h:131-180: min(workers, steps) jobs pulling from one atomic cursor. The workers are
+// persistent, like the engine's job-system threads (core/job_system.cpp): created once, asleep on a condition variable between
+// jobs. (Spawning std::threads per cull put thread creation inside every timed frame of the CPU baseline.)
+struct WorkerPool {
+	std::mutex mutex;
+	std::condition_variable work, done;
+	std::vector<std::thread> threads;
+	const std::function<void()>* job = nullptr;
+	unsigned generation = 0;
+	int wanted = 0, claimed = 0, running = 0;
+
+	void workerLoop() {
+		unsigned seen = 0;
+		std::unique_lock<std::mutex> lock(mutex);
+		for (;;) {
+			while (generation == seen || claimed >= wanted) {
+				if (generation != seen) seen = generation; // job fully staffed: skip it
+				work.wait(lock);
+			}
+			seen = generation;
+			++claimed;
+			const std::function<void()>* j = job;
+			lock.unlock();
+			(*j)();
+			lock.lock();
+			if (--running == 0) done.notify_one();
+		}
+	}
+
+	void run(int helpers, const std::function<void()>& body) {
+		std::unique_lock<std::mutex> lock(mutex);
+		while ((int)threads.size() < helpers && threads.size() < 255) {
+			threads.emplace_back([this] { workerLoop(); });
+			threads.back().detach();
+		}
+		const int staffed = helpers < (int)threads.size() ? helpers : (int)threads.size();
+		job = &body;
+		wanted = staffed;
+		claimed = 0;
+		running = staffed;
+		++generation;
+		work.notify_all();
+		lock.unlock();
+		body(); // the caller works too
+		lock.lock();
+		done.wait(lock, [this] { return running == 0; });
+		job = nullptr;
+		wanted = 0;
+	}
+};
+static WorkerPool& g_workers = *new WorkerPool; // never destroyed: its detached workers wait on the condition variable until the process ends
+
 template <typename F> void forEachJob(u32 count, int n_threads, const F& f) {
 	if (n_threads <= 1 || count <= 1) {
 		for (u32 i = 0; i < count; ++i) f(i);
 		return;
 	}
 	std::atomic<u32> cursor{0};
-	auto worker = [&]() {
+	const std::function<void()> worker = [&]() {
 		for (;;) {
 			const u32 i = cursor.fetch_add(1, std::memory_order_relaxed);
 			if (i >= count) return;
 			f(i);
 		}
 	};
-	std::vector<std::thread> threads;
 	const int n = n_threads < (int)count ? n_threads : (int)count;
-	for (int t = 1; t < n; ++t) threads.emplace_back(worker);
-	worker();
-	for (auto& t : threads) t.join();
+	g_workers.run(n - 1, worker);
 }
 
 struct CullingSystemRef {

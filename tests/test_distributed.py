@@ -1,6 +1,8 @@
-"""world_size-2 CPU (gloo) test of the multi-GPU path: entities are sharded by cell, every rank culls only its shard
-(with the CPU oracle standing in for the per-rank HIP cull, which needs a GPU), the visible lists are all-gathered
-exactly as bench.py does over RCCL, and the union must equal the unsharded oracle result."""
+"""world_size-2 and -4 CPU (gloo) tests of the multi-GPU path: entities are sharded by cell, every rank culls only its shard
+(the CPU oracle stands in for the per-rank HIP cull, which needs a GPU), writes the exchange record of
+lmx_exchange_cull ([8 counts | ids, types packed]) and the records are all-gathered as one fixed-size collective per frame -
+the same record format, capacity / overflow rule and partition that bench.py runs natively over RCCL
+(csrc/lmx_capi_exchange.hip); the union must equal the unsharded oracle result."""
 import os
 import socket
 
@@ -13,6 +15,9 @@ import torch.multiprocessing as mp
 from lumixengine_amd import distributed as D
 from lumixengine_amd import scenes
 from tests import helpers as H
+
+N, HALF = 60_000, 2500.0
+CAMS = ["origin_identity", "origin_yaw_pitch", "ortho_cascade_large"]
 
 
 def _free_port():
@@ -29,60 +34,64 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         o = po.Oracle("port")
-        sc = scenes.cull_scene(60_000, 2500.0, seed=7)
-        fr = H.frusta(o, names=["origin_identity", "origin_yaw_pitch", "ortho_cascade_large"])
+        sc = scenes.cull_scene(N, HALF, seed=7, mixed_types=True)
+        fr = H.frusta(o, names=CAMS)
         mask = D.shard_by_cell(sc["pos"], world, rank)
         cs = o.culling_system()
         cs.add_bulk(sc["entity"][mask], sc["type"][mask], sc["pos"][mask], sc["radius"][mask])
-        cap = int(mask.sum())
-        ids = torch.zeros((len(fr), cap), dtype=torch.int32)
-        counts = torch.zeros(len(fr), dtype=torch.int32)
+        out = {"owned": np.array([int(mask.sum())])}
         for f in range(len(fr)):
-            v, _, _ = cs.cull(fr[f : f + 1])
-            ids[f, : len(v)] = torch.from_numpy(v)
-            counts[f] = len(v)
-        gathered = D.allgather_visible(ids, counts)
-        merged = D.concat_visible(gathered)
-        # steady-state form: one async all-gather of [counts | first cap ids] per frame, double-buffered
-        n_counts = len(fr)
-        cap_ids = max(int(t.numel()) for per in gathered for t in per) + 5  # the same on every rank
-        for f in range(len(fr)):
-            x = D.VisibleExchange(n_counts, cap, cap_ids, "cpu")
-            for frame in range(3):  # three frames through the two buffers
-                i, buf = x.buffer()
-                buf[:n_counts] = 0
-                buf[f] = counts[f]
-                buf[n_counts : n_counts + cap] = ids[f]
-                x.exchange(i)
-            x.finish()
-            g = x.gathered(i)
-            assert not x.overflowed(i, f)
-            one = torch.cat([g[r, n_counts : n_counts + int(g[r, f])] for r in range(world)])
-            assert torch.equal(torch.sort(one).values, torch.sort(merged[f]).values)
-            small = D.VisibleExchange(n_counts, cap, 1, "cpu")
-            j, buf = small.buffer()
-            buf[f] = counts[f]
-            small.exchange(j)
-            small.finish()
-            assert small.overflowed(j, f) == bool(int(torch.stack([t.new_tensor(t.numel()) for t in gathered[f]]).max()) > 1)
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{f"f{f}": merged[f].numpy() for f in range(len(fr))}, owned=np.array([cap]))
+            v, t, _ = cs.cull(fr[f : f + 1])
+            by_type = [v[t == k] for k in range(D.MAX_TYPES)]
+            # frame 1: a capacity that is too small on purpose -> every rank must see the overflow and gather again
+            small = 4
+            send = torch.from_numpy(D.make_record(by_type, small))
+            recv = torch.empty(world * len(send), dtype=torch.int32)
+            dist.all_gather_into_tensor(recv, send)
+            _, overflowed = D.parse_records(recv.numpy(), small)
+            counts = recv.view(world, -1)[:, : D.MAX_TYPES].sum(dim=1)
+            assert overflowed == bool((counts > small).any())
+            # frame 2: capacity from the counts every rank now knows (1.25 x the largest, as bench.py sizes it)
+            cap = int(counts.max()) * 5 // 4 + 8
+            send = torch.from_numpy(D.make_record(by_type, cap))
+            recv = torch.empty(world * len(send), dtype=torch.int32)
+            dist.all_gather_into_tensor(recv, send)
+            parsed, overflowed = D.parse_records(recv.numpy(), cap)
+            assert not overflowed and len(parsed) == world
+            merged = D.merge_ranks(parsed)
+            for k in range(D.MAX_TYPES):
+                out[f"f{f}_t{k}"] = merged[k]
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_cull_allgather_equals_unsharded(tmp_path, oracle_port):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_cull_allgather_equals_unsharded(tmp_path, oracle_port, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    sc = scenes.cull_scene(60_000, 2500.0, seed=7)
-    fr = H.frusta(oracle_port, names=["origin_identity", "origin_yaw_pitch", "ortho_cascade_large"])
+    sc = scenes.cull_scene(N, HALF, seed=7, mixed_types=True)
+    fr = H.frusta(oracle_port, names=CAMS)
     cs = oracle_port.culling_system()
     cs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
     results = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
-    assert sum(int(r["owned"][0]) for r in results) == 60_000  # shards are a partition
+    assert sum(int(r["owned"][0]) for r in results) == N  # shards are a partition
     for f in range(len(fr)):
-        want, _, _ = cs.cull(fr[f : f + 1])
-        for r in results:  # every rank ends up with the full list
-            assert np.array_equal(np.sort(r[f"f{f}"]), np.sort(want))
+        want, wt, _ = cs.cull(fr[f : f + 1])
+        for r in results:  # every rank ends up with the full list, per type
+            for k in range(D.MAX_TYPES):
+                assert np.array_equal(np.sort(r[f"f{f}_t{k}"]), np.sort(want[wt == k])), (f, k)
+
+
+def test_record_roundtrip_and_clipping():
+    rng = np.random.default_rng(3)
+    by_type = [rng.integers(0, 1 << 30, size=n).astype(np.int32) for n in (7, 0, 3, 0, 0, 5, 0, 1)]
+    rec = D.make_record(by_type, 32)
+    parsed, over = D.parse_records(rec[None, :], 32)
+    assert not over and all(np.array_equal(parsed[0][t], by_type[t]) for t in range(8))
+    rec = D.make_record(by_type, 9)  # clipped inside type 2
+    parsed, over = D.parse_records(rec[None, :], 9)
+    assert over and np.array_equal(parsed[0][0], by_type[0]) and np.array_equal(parsed[0][2], by_type[2][:2]) and len(parsed[0][5]) == 0
+    assert list(rec[:8]) == [7, 0, 3, 0, 0, 5, 0, 1]  # the counts still tell what the rank saw
 
 
 def test_shard_by_cell_keeps_cells_whole():
