@@ -193,13 +193,20 @@ def main():
     #                    id. Here moved bytes == algorithmic bytes: this leg, cache-cold, is `roofline.frac`.
     scrub = torch.zeros(1 << 30, dtype=torch.uint8, device="cuda")  # 1 GiB > 256 MiB Infinity Cache
 
+    scrub32 = scrub.view(torch.int32)
+
     def kernel_times(csys, fr, steps, cold):
-        """avg device ms of k_cull_tile over `steps` culls; cold: evict the MALL before each cull"""
+        """avg device ms of k_cull_tile over `steps` culls. cold: evict the Infinity Cache before every cull - True / "read": a 1 GiB
+        read-only reduction (the cache is left full of CLEAN lines: the cull's misses go to HBM and evict for free); "write": a 1 GiB
+        read-modify-write (left full of DIRTY lines: every miss of the cull first writes a victim line back, i.e. the kernel shares
+        HBM with ~200 MB of write-backs it did not cause - reported, but not the roofline leg)."""
         ctx.profile_reset()
         ctx.profile_enable(True)
         for _ in range(steps):
-            if cold:
+            if cold == "write":
                 scrub.add_(1)
+            elif cold:
+                scrub32.sum()
             csys.cull(fr)
         ctx.synchronize()
         ctx.profile_enable(False)
@@ -225,10 +232,11 @@ def main():
         accept_visible = int(cs.cull(accept_fr).counts()[0].sum())
         acc_warm = kernel_times(cs, accept_fr, min(args.steps, 50), cold=False)
         acc_cold = kernel_times(cs, accept_fr, min(args.steps, 50), cold=True)
+        acc_coldw = kernel_times(cs, accept_fr, min(args.steps, 50), cold="write")
         acc_bytes = 8.0 * N  # 4 B id read + 4 B id written per entity; cell keys and spheres are not touched
         legs["all_accept"] = {"visible": accept_visible, "moved_bytes": acc_bytes, "warm_avg_launch_ms": rnd(acc_warm, 5), "cold_avg_launch_ms": rnd(acc_cold, 5),
                               "warm_GBps": gbps(acc_bytes, acc_warm), "cold_GBps": gbps(acc_bytes, acc_cold), "warm_frac": frac(acc_bytes, acc_warm), "cold_frac": frac(acc_bytes, acc_cold),
-                              "vs_20B_formula_cold_GBps": gbps(20.0 * N + 4.0 * accept_visible, acc_cold)}
+                              "cold_after_dirty_scrub_frac": frac(acc_bytes, acc_coldw), "vs_20B_formula_cold_GBps": gbps(20.0 * N + 4.0 * accept_visible, acc_cold)}
         # all_test: same positions, every sphere "big" -> every cell CELL_TEST
         sc_t = dict(sc)
         sc_t["radius"] = np.random.default_rng(5).uniform(300.5, 330.0, size=N).astype(np.float32)
@@ -240,9 +248,12 @@ def main():
         test_bytes = 20.0 * N + 4.0 * test_visible
         test_warm_ms = kernel_times(cs_t, frustum, min(args.steps, 50), cold=False)
         test_cold_ms = kernel_times(cs_t, frustum, min(args.steps, 50), cold=True)
+        test_coldw_ms = kernel_times(cs_t, frustum, min(args.steps, 50), cold="write")
         legs["all_test"] = {"visible": test_visible, "moved_bytes": test_bytes, "warm_avg_launch_ms": rnd(test_warm_ms, 5), "cold_avg_launch_ms": rnd(test_cold_ms, 5),
                             "warm_GBps": gbps(test_bytes, test_warm_ms), "cold_GBps": gbps(test_bytes, test_cold_ms), "warm_frac": frac(test_bytes, test_warm_ms),
-                            "cold_frac": frac(test_bytes, test_cold_ms), "cells": cs_t.stats()["cells"]}
+                            "cold_frac": frac(test_bytes, test_cold_ms), "cold_after_dirty_scrub_avg_launch_ms": rnd(test_coldw_ms, 5),
+                            "cold_after_dirty_scrub_frac": frac(test_bytes, test_coldw_ms), "cells": cs_t.stats()["cells"],
+                            "note": "warm = back-to-back frames (SURVEY.md 8d: 'measure with >= 100 back-to-back frames'; the 200 MB working set stays in the 256 MiB Infinity Cache); cold = after a 1 GiB read-only scrub; the 100 M extra (config5_size_single_gpu.all_test) is HBM-cold by size"}
         del cs_t, sc_t
     del scrub
     traffic, traffic_note = load_traffic("k_cull_tile:all_test")
@@ -251,7 +262,7 @@ def main():
     roofline = {
         "kernel": "k_cull_tile",
         "bound": "hbm",
-        "leg": "all_test, cache-cold (every sphere fetched and tested: moved bytes == SURVEY.md 8d's 20 B/entity + 4 B/visible id)" if test_cold_ms == test_cold_ms
+        "leg": "all_test, cache-cold after a read-only 1 GiB scrub (every sphere fetched and tested: moved bytes == SURVEY.md 8d's 20 B/entity + 4 B/visible id)" if test_cold_ms == test_cold_ms
                else "default camera only (--headline-only): effective rate, NOT a roofline fraction",
         "achieved": round(roof_bytes / (roof_ms * 1e-3) / 1e9, 1),
         "peak": HBM_PEAK_GBPS,
@@ -309,7 +320,8 @@ def main():
         result["config"]["exchange"] = f"one ncclAllGather per frame of [8 counts | {xchg.cap} ids] per rank, side stream, double-buffered (lmx_exchange_*)"
         result["config"]["ranks_seen_by_rccl"] = len(seen)
         assert len(seen) == world and max(seen) <= xchg.cap, (seen, xchg.cap)
-        assert seen[rank] == visible and np.array_equal(np.sort(parsed[rank]), np.sort(res.all_ids(0)[0])), "gathered ids differ from the local cull result"
+        local = cs.cull(frustum, view=2)  # (view 0 / 1 hold exchange frames, `res` is long overwritten by the roofline legs)
+        assert seen[rank] == visible and np.array_equal(np.sort(parsed[rank]), np.sort(local.all_ids(0)[0])), "gathered ids differ from the local cull result"
         if strong and rank == 0:
             whole = api.CullingSystem(ctx)
             whole.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
@@ -458,7 +470,7 @@ def extras(ctx, api, scenes, torch, timed, N, log, big_entities=0):
         NB = big_entities
         half_b = 15000.0 * (NB / 1e7) ** (1.0 / 3.0)
         t0 = time.time()
-        sc_b = scenes.cull_scene(NB, half_b, seed=2, mixed_types=True)
+        sc_b = scenes.cull_scene(NB, half_b, seed=2)  # the 10 M legs' scene at ten times the size
         cs_b = api.CullingSystem(ctx)
         cs_b.build(sc_b["entity"], sc_b["type"], sc_b["pos"], sc_b["radius"])
         big = {"entities": NB, "half_extent": half_b, "scene_plus_build_s": round(time.time() - t0, 1), "cells": cs_b.stats()["cells"]}

@@ -429,6 +429,7 @@ int cull_dyn_sync_mirror(LmxContext* ctx) {
 	if (!cs.dyn_mirror_stale) return LMX_OK;
 	cs.dyn_mirror_stale = false;
 	if (!cs.dyn_padded) return LMX_OK;
+	LMX_CHECK_CTX(ctx); // reached from host-only entry points too
 	if (int rc = apply_patches(ctx)) return rc; // host-side sets queued since the refresh are newer than what the device holds
 	const size_t padded = cs.dyn_padded;
 	std::vector<double> px(padded), py(padded), pz(padded);
@@ -544,8 +545,7 @@ int lmx_cull_build(LmxContext* ctx, uint32_t n, const int32_t* entity, const uin
 	return cull_flush(ctx);
 }
 
-int lmx_cull_add(LmxContext* ctx, int32_t entity, uint8_t type, const double pos[3], float radius) { // culling_system.cpp:131-157
-	LMX_CHECK_CTX(ctx);
+static int cull_add_impl(LmxContext* ctx, int32_t entity, uint8_t type, const double pos[3], float radius) { // culling_system.cpp:131-157
 	if (entity < 0 || !pos) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad entity/pos");
 	if (type >= MAX_TYPES) return fail(ctx, LMX_ERR_CAPACITY, "type %u >= LMX_MAX_TYPES", type);
 	CullState& cs = ctx->cull;
@@ -562,8 +562,7 @@ int lmx_cull_add(LmxContext* ctx, int32_t entity, uint8_t type, const double pos
 	return LMX_OK;
 }
 
-int lmx_cull_remove(LmxContext* ctx, int32_t entity) { // culling_system.cpp:160-190 (unknown entities are ignored, :162-165)
-	LMX_CHECK_CTX(ctx);
+static int cull_remove_impl(LmxContext* ctx, int32_t entity) { // culling_system.cpp:160-190 (unknown entities are ignored, :162-165)
 	CullState& cs = ctx->cull;
 	uint32_t idx;
 	switch (locate(cs, entity, &idx)) {
@@ -574,8 +573,7 @@ int lmx_cull_remove(LmxContext* ctx, int32_t entity) { // culling_system.cpp:160
 	return LMX_OK;
 }
 
-int lmx_cull_set(LmxContext* ctx, int32_t entity, const double pos[3], float radius) { // culling_system.cpp:225-242
-	LMX_CHECK_CTX(ctx);
+static int cull_set_impl(LmxContext* ctx, int32_t entity, const double pos[3], float radius) { // culling_system.cpp:225-242
 	if (!pos) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null pos");
 	CullState& cs = ctx->cull;
 	uint32_t idx;
@@ -603,6 +601,20 @@ int lmx_cull_set(LmxContext* ctx, int32_t entity, const double pos[3], float rad
 		case Where::NONE: break;
 	}
 	return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d is not in the culling system", entity);
+}
+
+// add / remove / set only touch the host mirror and the patch queues: no HIP call, no hipSetDevice per entity
+int lmx_cull_add(LmxContext* ctx, int32_t entity, uint8_t type, const double pos[3], float radius) {
+	if (!ctx) return LMX_ERR_INVALID_ARGUMENT;
+	return cull_add_impl(ctx, entity, type, pos, radius);
+}
+int lmx_cull_remove(LmxContext* ctx, int32_t entity) {
+	if (!ctx) return LMX_ERR_INVALID_ARGUMENT;
+	return cull_remove_impl(ctx, entity);
+}
+int lmx_cull_set(LmxContext* ctx, int32_t entity, const double pos[3], float radius) {
+	if (!ctx) return LMX_ERR_INVALID_ARGUMENT;
+	return cull_set_impl(ctx, entity, pos, radius);
 }
 
 int lmx_cull_set_position(LmxContext* ctx, int32_t entity, const double pos[3]) { // culling_system.cpp:201-217
@@ -698,28 +710,28 @@ int lmx_cull_is_added(LmxContext* ctx, int32_t entity) {
 
 // Batched forms of add / remove for hosts that pay per call (ctypes, scripting): same semantics, one ABI crossing.
 int lmx_cull_add_many(LmxContext* ctx, uint32_t n, const int32_t* entity, const uint8_t* type, const double* pos_xyz, const float* radius) {
-	LMX_CHECK_CTX(ctx);
+	if (!ctx) return LMX_ERR_INVALID_ARGUMENT;
 	if (n && (!entity || !type || !pos_xyz || !radius)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
 	for (uint32_t i = 0; i < n; ++i) {
-		if (int rc = lmx_cull_add(ctx, entity[i], type[i], pos_xyz + 3 * (size_t)i, radius[i])) return rc;
+		if (int rc = cull_add_impl(ctx, entity[i], type[i], pos_xyz + 3 * (size_t)i, radius[i])) return rc;
 	}
 	return LMX_OK;
 }
 
 int lmx_cull_set_many(LmxContext* ctx, uint32_t n, const int32_t* entity, const double* pos_xyz, const float* radius) {
-	LMX_CHECK_CTX(ctx);
+	if (!ctx) return LMX_ERR_INVALID_ARGUMENT;
 	if (n && (!entity || !pos_xyz || !radius)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
 	for (uint32_t i = 0; i < n; ++i) {
-		if (int rc = lmx_cull_set(ctx, entity[i], pos_xyz + 3 * (size_t)i, radius[i])) return rc;
+		if (int rc = cull_set_impl(ctx, entity[i], pos_xyz + 3 * (size_t)i, radius[i])) return rc;
 	}
 	return LMX_OK;
 }
 
 int lmx_cull_remove_many(LmxContext* ctx, uint32_t n, const int32_t* entity) {
-	LMX_CHECK_CTX(ctx);
+	if (!ctx) return LMX_ERR_INVALID_ARGUMENT;
 	if (n && !entity) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
 	for (uint32_t i = 0; i < n; ++i) {
-		if (int rc = lmx_cull_remove(ctx, entity[i])) return rc;
+		if (int rc = cull_remove_impl(ctx, entity[i])) return rc;
 	}
 	return LMX_OK;
 }

@@ -42,6 +42,8 @@ int lmx_keys_set_models(LmxContext* ctx, const LmxKeysModel* models, uint32_t n_
 	ks.models.assign(models, models + n_models);
 	ks.mesh_types.assign(mesh_types, mesh_types + n_meshes);
 	ks.n_meshes = n_meshes;
+	// k_keys_mesh scans a lane's (pairs, records) counts as two 16-bit fields of one word: 64 lanes x 2 x span must stay below 2^16
+	if (max_span > 511) return fail(ctx, LMX_ERR_CAPACITY, "a LOD range of %u meshes exceeds the 511 the key kernel's packed scan holds", max_span);
 	ks.max_lod_span = max_span;
 	return LMX_OK;
 }

@@ -88,7 +88,8 @@ int world_rebuild(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxT
 		LMX_HIP(ctx, launch_xform_scatter(ctx->stream, w.dev(), w.d_slot_of_entity.p, w.d_stage_entity.p, w.d_stage_tr.p, n, XF_STAGE_RAW));
 	}
 	w.bound_generation = ~0ull;
-	w.n_attach = 0; // attachment slots refer to the previous slot order: lmx_world_set_bone_attachments again
+	if (w.n_attach) w.attach_invalidated = true; // attachment slots refer to the previous slot order: lmx_world_set_bone_attachments again
+	w.n_attach = 0;
 	w.built = true;
 	return LMX_OK;
 }
@@ -335,6 +336,7 @@ int lmx_world_set_bone_attachments(LmxContext* ctx, uint32_t n, const int32_t* e
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (n) LMX_HIP(ctx, hipMemcpy(w.d_attach.p, att.data(), (size_t)n * sizeof(BoneAttachDevice), hipMemcpyHostToDevice));
 	w.n_attach = n;
+	w.attach_invalidated = false;
 	w.attach_skin_instances = sk.inst.size();
 	return LMX_OK;
 }
@@ -344,6 +346,7 @@ int lmx_world_update_bone_attachments(LmxContext* ctx) {
 	WorldState& w = ctx->world;
 	SkinState& sk = ctx->skin;
 	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
+	if (w.attach_invalidated) return fail(ctx, LMX_ERR_NOT_BUILT, "the hierarchy was rebuilt (lmx_world_build / lmx_world_set_parent) after the attachments were set; call lmx_world_set_bone_attachments again");
 	if (!w.n_attach) return LMX_OK;
 	if (w.attach_skin_instances != sk.inst.size()) return fail(ctx, LMX_ERR_NOT_BUILT, "the skin instance table changed; call lmx_world_set_bone_attachments again");
 	if (!sk.pose_is_absolute) return fail(ctx, LMX_ERR_NOT_BUILT, "bone attachments read the absolute pose (ASSERT(pose->is_absolute), render_module.cpp:424): run lmx_skin_run with pose write-back first");

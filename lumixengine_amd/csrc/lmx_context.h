@@ -178,6 +178,7 @@ struct WorldState {
 	uint64_t bound_generation = ~0ull; // CullState::dyn_generation the device binding tables were built for
 	DevBuf<BoneAttachDevice> d_attach;  // RenderModuleImpl::m_bone_attachments
 	uint32_t n_attach = 0;
+	bool attach_invalidated = false;    // a hierarchy rebuild renumbered the slots the attachment table refers to
 	size_t attach_skin_instances = 0;
 	WorldDevice dev() {
 		WorldDevice w;

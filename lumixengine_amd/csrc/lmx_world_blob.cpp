@@ -3,6 +3,7 @@
 // entity names (skipped), hierarchy records. Module payloads that follow are not read. Pure host code, no device needed.
 #include <cstdint>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "lumix_mi355.h"
@@ -100,7 +101,14 @@ int parse(const void* data, size_t size, Parsed& out) {
 	out.info.uncompressed_size = in.read<uint32_t>();
 	out.info.compressed_size = in.read<uint32_t>();
 	if (in.overflow || in.pos + out.info.compressed_size > size) return LMX_ERR_INVALID_ARGUMENT;
-	out.blob.resize(out.info.uncompressed_size);
+	// an LZ4 block expands at most 255 x (a run of 0xff length bytes per 255 literals / match bytes): a header that claims more is
+	// corrupt, and the claim must not be handed to the allocator unchecked (up to 4 GiB from an untrusted file)
+	if ((uint64_t)out.info.uncompressed_size > (uint64_t)out.info.compressed_size * 255u + 64u) return LMX_ERR_INVALID_ARGUMENT;
+	try {
+		out.blob.resize(out.info.uncompressed_size);
+	} catch (const std::bad_alloc&) {
+		return LMX_ERR_OUT_OF_MEMORY;
+	}
 	const long got = lz4_block_decode(in.p + in.pos, out.info.compressed_size, out.blob.data(), out.blob.size());
 	if (got != (long)out.blob.size()) return LMX_ERR_INVALID_ARGUMENT; // Engine::decompress: result == output.length()
 

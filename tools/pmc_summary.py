@@ -15,7 +15,7 @@ def short(name):
     """kernel name + its template arguments, e.g. k_cull_fused<1, 8, 8>"""
     import re
 
-    for k in ("k_cull_fused", "k_cull_spheres", "k_cull_classify", "k_cull_dynamic", "k_xform_level", "k_xform_scatter", "k_xform_export", "k_sphere_refresh",
+    for k in ("k_cull_tile", "k_cull_finalize", "k_cull_consolidate", "k_apply_patches", "k_cull_fused", "k_cull_spheres", "k_cull_classify", "k_cull_dynamic", "k_xform_level", "k_xform_scatter", "k_xform_export", "k_sphere_refresh",
               "k_pose_palette", "k_skin_vertices", "k_skin_shared", "k_patch_spheres", "k_keys_mesh", "k_keys_decal", "k_keys_offsets", "k_keys_scatter",
               "k_keys_groups", "k_anim_update", "k_bone_attach", "k_palette_expand"):
         if k in name:

@@ -15,10 +15,12 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["cull_default", "cull_stream", "cull_dense", "cull8", "xform", "skin", "skin_distinct", "keys", "target"], required=True)
+    ap.add_argument("--workload", choices=["cull_default", "cull_stream", "cull_all_test", "cull_dense", "cull8", "xform", "skin", "skin_distinct", "keys", "target"], required=True)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--entities", type=int, default=10_000_000)
     ap.add_argument("--instances", type=int, default=2000)
+    ap.add_argument("--cold", choices=["none", "read", "write"], default="none",
+                    help="evict the Infinity Cache before every cull: read = 1 GiB read-only reduction (clean lines), write = 1 GiB read-modify-write")
     args = ap.parse_args()
     import torch
 
@@ -43,8 +45,10 @@ def main():
         ctx.synchronize()
         print(sk.counts())
     elif args.workload.startswith("cull"):
-        half = 5000.0 if args.workload == "cull_dense" else 15000.0
+        half = 5000.0 if args.workload == "cull_dense" else 15000.0 * (args.entities / 1e7) ** (1.0 / 3.0)
         sc = scenes.cull_scene(args.entities, half, seed=2, mixed_types=args.workload == "cull8")
+        if args.workload == "cull_all_test":  # every sphere "big" (radius > 300): every cell CELL_TEST, every sphere fetched and tested
+            sc["radius"] = np.random.default_rng(5).uniform(300.5, 330.0, size=args.entities).astype(np.float32)
         cs = api.CullingSystem(ctx)
         cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
         if args.workload == "cull_stream" or os.environ.get("LMX_WORKLOAD_CAMERA") == "far":
@@ -54,11 +58,16 @@ def main():
         else:
             fr = api.viewport_frustum()
         import time
+        scrub = torch.zeros(1 << 30, dtype=torch.uint8, device="cuda") if args.cold != "none" else None
         for _ in range(5):
             cs.cull(fr)
         ctx.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
+            if args.cold == "read":
+                scrub.view(torch.int32).sum()
+            elif args.cold == "write":
+                scrub.add_(1)
             cs.cull(fr)
         ctx.synchronize()
         print(args.workload, "ms per cull %.4f" % ((time.perf_counter() - t0) * 1e3 / args.steps), "visible", cs.cull(fr).counts().sum(axis=1))
