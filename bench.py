@@ -183,6 +183,36 @@ def main():
     res = cs.cull(frustum)
     visible = int(res.counts()[0].sum())
 
+    dist_info = {}
+    if use_dist:
+        # sanity of the exchange step: every rank's record arrived, nothing overflowed, own record == local cull; in the strong
+        # (config 4) split the union over ranks must be the unsharded visible set
+        slot = step()
+        xchg.wait(slot)
+        torch.cuda.synchronize()
+        parsed, seen = [], []
+        for r in range(world):
+            counts, ids = xchg.read(slot, r)
+            seen.append(int(counts.sum()))
+            parsed.append(ids)
+        dist_info["allgather_visible_counts"] = seen
+        dist_info["exchange"] = f"one ncclAllGather per frame of [8 counts | {xchg.cap} ids] per rank, side stream, double-buffered (lmx_exchange_*)"
+        dist_info["ranks_seen_by_rccl"] = len(seen)
+        assert len(seen) == world and max(seen) <= xchg.cap, (seen, xchg.cap)
+        local = cs.cull(frustum, view=2)  # (view 0 / 1 hold exchange frames, `res` is long overwritten by the roofline legs)
+        assert seen[rank] == visible and np.array_equal(np.sort(parsed[rank]), np.sort(local.all_ids(0)[0])), "gathered ids differ from the local cull result"
+        if strong and rank == 0:
+            ctx_whole = api.Context(local_rank)  # a context of its own: a context holds ONE culling set, and this rank's shard stays resident
+            whole = api.CullingSystem(ctx_whole)
+            whole.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+            want = np.sort(whole.cull(frustum).all_ids(0)[0])
+            assert np.array_equal(np.sort(np.concatenate(parsed)), want), "union of the ranks' lists != unsharded cull"
+            dist_info["union_equals_unsharded"] = True
+            dist_info["visible_total"] = int(len(want))
+            del whole
+            ctx_whole.close()
+        xchg.close()
+
     # ---- roofline of the dominant kernel (k_cull_tile): HIP events around each launch on the launch stream -------------------
     # Three regimes of the same kernel on the same 10 M geometry:
     #   default camera   hierarchical skip: ~95 % of the tiles end at the tile-level box test. Latency regime; the algorithmic
@@ -300,37 +330,12 @@ def main():
         "roofline": roofline,
     }
 
+    result["config"].update(dist_info)
     if rank == 0 and world == 1:
         if not args.no_extras:
             result["extra"] = extras(ctx, api, scenes, torch, timed, N, log, args.big_entities)
         if baseline is not None:
             result["cpu_baseline"] = baseline.measure()
-    if use_dist:
-        # sanity of the exchange step: every rank's record arrived, nothing overflowed, own record == local cull; in the strong
-        # (config 4) split the union over ranks must be the unsharded visible set
-        slot = step()
-        xchg.wait(slot)
-        torch.cuda.synchronize()
-        parsed, seen = [], []
-        for r in range(world):
-            counts, ids = xchg.read(slot, r)
-            seen.append(int(counts.sum()))
-            parsed.append(ids)
-        result["config"]["allgather_visible_counts"] = seen
-        result["config"]["exchange"] = f"one ncclAllGather per frame of [8 counts | {xchg.cap} ids] per rank, side stream, double-buffered (lmx_exchange_*)"
-        result["config"]["ranks_seen_by_rccl"] = len(seen)
-        assert len(seen) == world and max(seen) <= xchg.cap, (seen, xchg.cap)
-        local = cs.cull(frustum, view=2)  # (view 0 / 1 hold exchange frames, `res` is long overwritten by the roofline legs)
-        assert seen[rank] == visible and np.array_equal(np.sort(parsed[rank]), np.sort(local.all_ids(0)[0])), "gathered ids differ from the local cull result"
-        if strong and rank == 0:
-            whole = api.CullingSystem(ctx)
-            whole.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
-            want = np.sort(whole.cull(frustum, view=3).all_ids(0)[0])
-            assert np.array_equal(np.sort(np.concatenate(parsed)), want), "union of the ranks' lists != unsharded cull"
-            result["config"]["union_equals_unsharded"] = True
-            result["config"]["visible_total"] = int(len(want))
-            del whole
-        xchg.close()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:

@@ -30,6 +30,7 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4))); // a 16-byte access the compiler may only assume 4-byte aligned
 __device__ __forceinline__ float readlane_f(float v, int lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
 
 // Everything k_cull_tile needs besides the frusta. The frusta are the FIRST kernel argument (offset 0 of the kernarg segment):
@@ -57,8 +58,9 @@ __device__ __forceinline__ uint32_t tile_status_lanes(const TileBox* box, uint32
 	const double org = reinterpret_cast<const double*>(ka + KA_ORIGIN)[a];
 	const uint32_t p = (lane & 7u) < 6u ? (lane & 7u) : 5u;
 	const float nx = ka[KA_NX + p], ny = ka[KA_NY + p], nz = ka[KA_NZ + p], d = ka[KA_D + p];
-	if (flags & TILE_EMPTY) return TILE_REJECT;
-	if (flags & TILE_HAS_BIG) return TILE_MIXED;
+	const uint32_t hi = flags << 2; // the caller also wants the tile's flags
+	if (flags & TILE_EMPTY) return TILE_REJECT | hi;
+	if (flags & TILE_HAS_BIG) return TILE_MIXED | hi;
 	const double cs = (double)CELL_SIZE;
 	const double off = kind == 0u ? -cs : (kind == 3u ? 2 * cs : cs);
 	const float val = (float)(cs * idx + off - org);
@@ -81,8 +83,8 @@ __device__ __forceinline__ uint32_t tile_status_lanes(const TileBox* box, uint32
 		in = dp > -d + margin;
 	}
 	const bool plane_lane = lane < 6u;
-	if (__ballot(plane_lane && rej) != 0) return TILE_REJECT;
-	return __ballot(plane_lane && !in) == 0 ? TILE_ACCEPT : TILE_MIXED;
+	if (__ballot(plane_lane && rej) != 0) return TILE_REJECT | hi;
+	return (__ballot(plane_lane && !in) == 0 ? TILE_ACCEPT : TILE_MIXED) | hi;
 }
 
 // LDS record of one (cell, frustum): the six cell-relative plane distances of ShiftedFrustum::getRelative and the cell's class
@@ -114,15 +116,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg
 	for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < a.n_zero; i += gridDim.x * THREADS) g_counts_next[i] = 0;
 
 	// 0. tile-level test per frustum (2 bits each). Everything read here sits at addresses that depend on blockIdx only.
-	uint32_t st_bits = 0;
+	uint32_t st_bits = 0, tile_flags = 0;
 	bool any_mixed = false, any_live = false;
 	if constexpr (LANEPAR) {
 		static_assert(F == 1, "the lane-parallel tile test handles one frustum");
-		st_bits = tile_status_lanes(g_tile_box + tile_index, lane);
+		const uint32_t r = tile_status_lanes(g_tile_box + tile_index, lane);
+		st_bits = r & 3u;
+		tile_flags = r >> 2;
 		any_mixed = st_bits == TILE_MIXED;
 		any_live = st_bits != TILE_REJECT;
 	} else {
 		const TileBox box = g_tile_box[tile_index];
+		tile_flags = box.flags;
 #pragma unroll 1
 		for (int f = 0; f < nf; ++f) {
 			const uint32_t st = tile_status(frp[f], box);
@@ -176,6 +181,29 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg
 	}
 	const uint32_t shard = a.tt.shard_first[type] + ((tile_ent - a.tt.ent_start[type]) / TILE_ALIGN) % a.tt.shard_n[type];
 	const uint32_t win = g_win_base[shard];
+
+	// Accepted tile without padding or tombstones (1-frustum kernels): its ids are a straight copy. The wave's count is known
+	// (CHW x 64), so the reservation is issued before the loads instead of after them, and ids move 16 bytes per lane.
+	if constexpr (F == 1) {
+		if (!any_mixed && (tile_flags & TILE_DENSE)) {
+			constexpr uint32_t PER_WAVE = CHW * 64;
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd(&g_counts[shard * a.cnt_pad], PER_WAVE);
+			const uint4* src = reinterpret_cast<const uint4*>(g_ids + ((size_t)((tile_ent >> 6) + wave * CHW) << 6));
+			uint4 v[CHW / 4];
+#pragma unroll
+			for (int k = 0; k < CHW / 4; ++k) v[k] = src[k * 64 + lane];
+			base = __builtin_amdgcn_readfirstlane(base) + win;
+			// the reserved range starts at an arbitrary id: 16-byte stores need 4-byte alignment only on global memory
+			int32_t* dst = g_out_ids + base;
+#pragma unroll
+			for (int k = 0; k < CHW / 4; ++k) {
+				u32x4_a4 t = {v[k].x, v[k].y, v[k].z, v[k].w};
+				*reinterpret_cast<u32x4_a4*>(dst + (k * 64 + lane) * 4) = t; // global_store_dwordx4, lanes contiguous: 1 KiB per instruction
+			}
+			return;
+		}
+	}
 
 	// B. this wave's CHW chunks, in groups of GRP so that at most GRP chunks' worth of spheres are live in registers
 	// (VGPR count decides how many tiles a CU keeps in flight). Fetching the headers at kernel start through lanes (one vector
@@ -331,8 +359,9 @@ __global__ __launch_bounds__(DYN_THREADS) void k_cull_dynamic(const double* __re
 }
 
 // ---- patches ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_apply_patches(float4* __restrict__ spheres, int32_t* __restrict__ ids, DynDeviceView d,
-	const PatchSphere* __restrict__ ps, uint32_t n_ps, const PatchId* __restrict__ pi, uint32_t n_pi, const PatchDyn* __restrict__ pd, uint32_t n_pd) {
+__global__ __launch_bounds__(256) void k_apply_patches(float4* __restrict__ spheres, int32_t* __restrict__ ids, TileBox* __restrict__ box0,
+	TileBox* __restrict__ box1, TileBox* __restrict__ box2, DynDeviceView d, const PatchSphere* __restrict__ ps, uint32_t n_ps,
+	const PatchId* __restrict__ pi, uint32_t n_pi, const PatchDyn* __restrict__ pd, uint32_t n_pd) {
 	uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i < n_ps) {
 		const PatchSphere p = ps[i];
@@ -343,6 +372,11 @@ __global__ __launch_bounds__(256) void k_apply_patches(float4* __restrict__ sphe
 	if (i < n_pi) {
 		const PatchId p = pi[i];
 		ids[p.slot] = p.id;
+		if (p.id < 0) { // a tombstone: the tiles holding the slot are no longer a straight copy when accepted
+			atomicAnd(&box0[p.slot >> 12].flags, ~(uint32_t)TILE_DENSE);
+			atomicAnd(&box1[p.slot >> 11].flags, ~(uint32_t)TILE_DENSE);
+			atomicAnd(&box2[p.slot >> 10].flags, ~(uint32_t)TILE_DENSE);
+		}
 		return;
 	}
 	i -= n_pi;
@@ -477,11 +511,11 @@ hipError_t launch_cull_dynamic(hipStream_t s, const DynDeviceView& d, uint32_t s
 	return hipGetLastError();
 }
 
-hipError_t launch_apply_patches(hipStream_t s, float4* spheres, int32_t* ids, const DynDeviceView& d, const PatchSphere* ps, uint32_t n_ps,
-	const PatchId* pi, uint32_t n_pi, const PatchDyn* pd, uint32_t n_pd) {
+hipError_t launch_apply_patches(hipStream_t s, float4* spheres, int32_t* ids, TileBox* const tile_box[3], const DynDeviceView& d, const PatchSphere* ps,
+	uint32_t n_ps, const PatchId* pi, uint32_t n_pi, const PatchDyn* pd, uint32_t n_pd) {
 	const uint32_t n = n_ps + n_pi + n_pd;
 	if (!n) return hipSuccess;
-	hipLaunchKernelGGL(k_apply_patches, dim3((n + 255u) / 256u), dim3(256), 0, s, spheres, ids, d, ps, n_ps, pi, n_pi, pd, n_pd);
+	hipLaunchKernelGGL(k_apply_patches, dim3((n + 255u) / 256u), dim3(256), 0, s, spheres, ids, tile_box[0], tile_box[1], tile_box[2], d, ps, n_ps, pi, n_pi, pd, n_pd);
 	return hipGetLastError();
 }
 

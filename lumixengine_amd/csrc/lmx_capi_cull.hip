@@ -195,7 +195,8 @@ int apply_patches(LmxContext* ctx) {
 	if (b_pi) memcpy(h + o_pi, cs.q_id.data(), b_pi);
 	LMX_HIP(ctx, hipMemcpyAsync(cs.d_patch.p, h, total, hipMemcpyHostToDevice, ctx->stream));
 	LMX_HIP(ctx, hipEventRecord(st.done[k], ctx->stream));
-	LMX_HIP(ctx, launch_apply_patches(ctx->stream, cs.spheres.p, cs.ids.p, dyn_view(cs), (const PatchSphere*)(cs.d_patch.p + o_ps), (uint32_t)n_ps,
+	TileBox* const boxes[3] = {cs.tile_box[0].p, cs.tile_box[1].p, cs.tile_box[2].p};
+	LMX_HIP(ctx, launch_apply_patches(ctx->stream, cs.spheres.p, cs.ids.p, boxes, dyn_view(cs), (const PatchSphere*)(cs.d_patch.p + o_ps), (uint32_t)n_ps,
 		(const PatchId*)(cs.d_patch.p + o_pi), (uint32_t)n_pi, (const PatchDyn*)(cs.d_patch.p + o_pd), (uint32_t)n_pd));
 	clear_static_queues(cs);
 	clear_dyn_queue(cs);

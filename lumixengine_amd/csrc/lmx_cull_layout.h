@@ -299,6 +299,9 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 				out.tile_tab[k][2 * ti] = first;
 				out.tile_tab[k][2 * ti + 1] = cnt;
 				TileBox box = {{INT32_MAX, INT32_MAX, INT32_MAX}, {INT32_MIN, INT32_MIN, INT32_MIN}, TILE_EMPTY, 0};
+				bool dense = true; // a tile without padding slots: an accepted tile is then a straight copy of its ids
+				for (size_t e = ti * tile; e < (ti + 1) * tile && dense; ++e) dense = out.ids[e] >= 0;
+				if (dense) box.flags |= TILE_DENSE;
 				for (uint32_t j = 0; j < cnt; ++j) {
 					const LayoutCell& c = out.cells[first + j];
 					out.tile_cells[k][ti * cap + j] = c;

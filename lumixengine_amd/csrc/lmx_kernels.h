@@ -82,8 +82,9 @@ uint32_t cull_dynamic_tile(int n_frusta);
 struct PatchSphere { uint32_t slot; float x, y, z, radius; };                 // static set: in-cell move / radius change
 struct PatchId { uint32_t slot; int32_t id; };                                 // static set: removal (tombstone, id = -1)
 struct PatchDyn { uint32_t slot; int32_t id; float radius; uint32_t pad; double px, py, pz; }; // dynamic set: add / remove / set
-hipError_t launch_apply_patches(hipStream_t s, float4* spheres, int32_t* ids, const DynDeviceView& d, const PatchSphere* ps, uint32_t n_ps,
-	const PatchId* pi, uint32_t n_pi, const PatchDyn* pd, uint32_t n_pd);
+// (a tombstone also clears TILE_DENSE of the tiles that hold its slot, in all three tile-size variants)
+hipError_t launch_apply_patches(hipStream_t s, float4* spheres, int32_t* ids, TileBox* const tile_box[3], const DynDeviceView& d, const PatchSphere* ps,
+	uint32_t n_ps, const PatchId* pi, uint32_t n_pi, const PatchDyn* pd, uint32_t n_pd);
 
 // Per-(frustum, type) totals and per-(frustum, shard) offsets of the consolidated lists: totals[f * MAX_TYPES + t], pref[f * n_shards + s]
 // (offset of shard s inside its type's consolidated list). shard_type[s] = renderable type of shard s. packed_start (optional):

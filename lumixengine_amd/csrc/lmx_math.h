@@ -195,7 +195,7 @@ LMX_HD uint32_t classify_cell(const DevFrustum& f, IV3 idx, bool is_big, V3* out
 // max(1, |n|_1) * (2 + 4e-6 * B1) + 1e-6 * |d| covers the sum several times over for any plane scale. Tiles holding big-sphere cells
 // (always CELL_TEST) are TILE_MIXED; NaN planes / corners compare false and give TILE_MIXED.
 struct TileBox { int32_t lo[3], hi[3]; uint32_t flags, pad; };
-enum : uint32_t { TILE_EMPTY = 1, TILE_HAS_BIG = 2 };
+enum : uint32_t { TILE_EMPTY = 1, TILE_HAS_BIG = 2, TILE_DENSE = 4 }; // TILE_DENSE: every slot of the tile holds a live id (no padding, no tombstone)
 enum TileStatus : uint32_t { TILE_REJECT = 0, TILE_ACCEPT = 1, TILE_MIXED = 2 };
 LMX_HD float abs_f(float v) { return v < 0 ? -v : v; }
 LMX_HD float max_f(float a, float b) { return a > b ? a : b; }

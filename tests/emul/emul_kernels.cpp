@@ -91,6 +91,11 @@ int emul_cull_variant(uint32_t n, const int32_t* entity, const uint8_t* type, co
 			if (tile_n_cells > cap || tile_n_cells > lay.max_tile_cells[tile_k] || last_cell >= n_cells) return 4;
 			if (n_frusta <= 8 && (size_t)n_frusta * cap * 32 > 65536) return 6; // LDS budget of the per-tile cell table
 			const uint32_t st = tile_status(fr, lay.tile_box[tile_k][tile_index]);
+			if (chunk == tile_chunk) { // TILE_DENSE (accepted tile = straight copy of its ids) <=> no slot of the tile is padding
+				bool all_live = true;
+				for (uint32_t e = tile_chunk * 64; e < (tile_chunk + nch) * 64; ++e) all_live = all_live && lay.ids[e] >= 0;
+				if (all_live != ((lay.tile_box[tile_k][tile_index].flags & TILE_DENSE) != 0)) return 11;
+			}
 			if (chunk == tile_chunk) { // once per tile
 				bool none = true, all_in = true, any_cell = false;
 				for (uint32_t c = first_cell; c <= last_cell; ++c) {

@@ -283,7 +283,9 @@ def test_cull_update_stream_vs_oracle(gpu_ctx, oracle_port):
     ocs = oracle_port.culling_system()
     cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
     ocs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
-    fr = H.frusta(api, names=["origin_identity", "origin_yaw_pitch", "ortho_cascade_large"])
+    # the last camera sees the whole scene: its tiles are accepted as a whole, and the ones that received a tombstone must have
+    # lost their "straight copy" (TILE_DENSE) status
+    fr = np.concatenate([H.frusta(api, names=["origin_identity", "origin_yaw_pitch", "ortho_cascade_large"]), api.viewport_frustum(pos=(0.0, 0.0, 30000.0), far=100000.0)])
     removed = []
     for f, ops in enumerate(H.churn_stream(sc["pos"], half, 12, 3000, seed=5)):
         cs.removeMany(ops["remove"])

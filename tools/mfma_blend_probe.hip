@@ -114,10 +114,11 @@ int main(int argc, char** argv) {
 	}
 	std::vector<float> o1(n * 3), o2(n * 3);
 	CK(hipMemcpy(o1.data(), d_o1, n * 12, hipMemcpyDeviceToHost)); CK(hipMemcpy(o2.data(), d_o2, n * 12, hipMemcpyDeviceToHost));
-	double max_rel = 0;
-	for (int i = 0; i < n * 3; ++i) max_rel = fmax(max_rel, fabs(o1[i] - o2[i]) / fmax(1e-6, fabs(o1[i])));
+	double max_rel = 0, scale = 0; // largest difference relative to the largest output (outputs are sums over `reps` skinned positions)
+	for (int i = 0; i < n * 3; ++i) scale = fmax(scale, fabs(o1[i]));
+	for (int i = 0; i < n * 3; ++i) max_rel = fmax(max_rel, fabs(o1[i] - o2[i]) / scale);
 	const double per = (double)n * reps;
-	printf("{\"vertices\": %d, \"reps\": %d, \"valu_ms\": %.4f, \"mfma_ms\": %.4f, \"valu_ns_per_vertex\": %.4f, \"mfma_ns_per_vertex\": %.4f, \"mfma_over_valu\": %.2f, \"max_rel_diff\": %.3g}\n",
+	printf("{\"vertices\": %d, \"reps\": %d, \"valu_ms\": %.4f, \"mfma_ms\": %.4f, \"valu_ns_per_vertex\": %.4f, \"mfma_ns_per_vertex\": %.4f, \"mfma_over_valu\": %.2f, \"max_diff_over_max_output\": %.3g}\n",
 		n, reps, ms_valu, ms_mfma, ms_valu * 1e6 / per, ms_mfma * 1e6 / per, ms_mfma / ms_valu, max_rel);
 	return 0;
 }
