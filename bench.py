@@ -73,17 +73,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         # RCCL prints a version banner on the C-level stdout at communicator creation; stdout must carry the JSON line only
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with c_stdout_to_stderr():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
 
     ctx = api.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launches and torch.cuda.synchronize() share one stream
@@ -160,7 +153,12 @@ def main():
         t = torch.tensor([probe], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         cap = (int(t.item()) * 5 // 4 + 1023) // 1024 * 1024  # 1.25 x the largest visible count of any rank
-        xchg = api.VisibleExchange(ctx, rank, world, uid.cpu().numpy().tobytes(), cap)
+        log(f"[rank {rank}] exchange: creating the RCCL communicator (ids per rank {cap})")
+        with c_stdout_to_stderr():
+            xchg = api.VisibleExchange(ctx, rank, world, uid.cpu().numpy().tobytes(), cap)
+            step_probe = xchg.cull(frustum)  # the first collective creates RCCL's channels (and may print)
+            xchg.wait(step_probe)
+        log(f"[rank {rank}] exchange ready")
         fr_c = np.ascontiguousarray(frustum, api.SHIFTED_FRUSTUM).reshape(-1)
         fr_ptr, x_cull, xh = api._ptr(fr_c), ctx.lib.lmx_exchange_cull, xchg.h
         import ctypes as C
@@ -211,7 +209,9 @@ def main():
             dist_info["visible_total"] = int(len(want))
             del whole
             ctx_whole.close()
+        log(f"[rank {rank}] exchange verified: {dist_info}")
         xchg.close()
+        log(f"[rank {rank}] exchange closed")
 
     # ---- roofline of the dominant kernel (k_cull_tile): HIP events around each launch on the launch stream -------------------
     # Three regimes of the same kernel on the same 10 M geometry:
@@ -340,6 +340,28 @@ def main():
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+class c_stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block; the C library's own stdout buffer is flushed before fd 1 is restored
+    (RCCL 2.26 printf's its banner into that buffer: without the flush it would surface on the real stdout at exit, after the JSON line)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import ctypes
+
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
 
 
 def load_traffic(kernel):

@@ -391,29 +391,41 @@ __global__ __launch_bounds__(256) void k_apply_patches(float4* __restrict__ sphe
 }
 
 // ---- finalize / consolidate ---------------------------------------------------------------------------------------
-// One block per frustum: totals per type and the exclusive prefix of every shard inside its type (serial over <= a few hundred
-// shards per type, one lane per type). packed_start (optional): where type t starts when the types of a frustum are packed back
-// to back (type 0 first) - the layout of the exchange's send buffer.
-__global__ __launch_bounds__(64) void k_cull_finalize(const uint32_t* __restrict__ counts, uint32_t cnt_pad, uint32_t cnt_frustum_stride,
+// One block per frustum: totals per type and the exclusive prefix of every shard inside its type. The counters sit on separate
+// cache lines, so they are loaded in parallel (one per thread) and scanned in LDS; a lane per type walking them serially took
+// 21 us for 65 shards. Shards of one type are contiguous in shard order. packed_start (optional): where type t starts when the
+// types of a frustum are packed back to back (type 0 first) - the layout of the exchange's send buffer.
+constexpr int FIN_THREADS = 256;
+constexpr int FIN_MAX_SHARDS = 1024; // 8 types x (64 static + 8 dynamic) = 576 at most
+__global__ __launch_bounds__(FIN_THREADS) void k_cull_finalize(const uint32_t* __restrict__ counts, uint32_t cnt_pad, uint32_t cnt_frustum_stride,
 	const uint8_t* __restrict__ shard_type, uint32_t n_shards, uint32_t* __restrict__ totals, uint32_t* __restrict__ pref, uint32_t* __restrict__ packed_start) {
+	__shared__ uint32_t s_cnt[FIN_MAX_SHARDS];
+	__shared__ uint8_t s_type[FIN_MAX_SHARDS];
 	__shared__ uint32_t s_tot[MAX_TYPES];
 	const uint32_t f = blockIdx.x;
 	const uint32_t t = threadIdx.x;
-	if (t < MAX_TYPES) {
-		uint32_t run = 0;
-		for (uint32_t s = 0; s < n_shards; ++s) {
-			if (shard_type[s] != t) continue;
-			pref[f * n_shards + s] = run;
-			run += counts[f * cnt_frustum_stride + s * cnt_pad];
-		}
-		totals[f * MAX_TYPES + t] = run;
-		s_tot[t] = run;
+	if (t < MAX_TYPES) s_tot[t] = 0;
+	for (uint32_t s = t; s < n_shards; s += FIN_THREADS) {
+		s_cnt[s] = counts[f * cnt_frustum_stride + s * cnt_pad];
+		s_type[s] = shard_type[s];
 	}
 	__syncthreads();
-	if (packed_start != nullptr && t < MAX_TYPES) {
-		uint32_t at = 0;
-		for (uint32_t k = 0; k < t; ++k) at += s_tot[k];
-		packed_start[f * MAX_TYPES + t] = at;
+	// per shard: sum of the counts of the earlier shards of its type (<= 72 of them, contiguous, in LDS)
+	for (uint32_t s = t; s < n_shards; s += FIN_THREADS) {
+		const uint8_t ty = s_type[s];
+		uint32_t run = 0;
+		for (uint32_t k = s; k-- > 0 && s_type[k] == ty;) run += s_cnt[k];
+		pref[f * n_shards + s] = run;
+		if (s + 1 == n_shards || s_type[s + 1] != ty) s_tot[ty] = run + s_cnt[s]; // the last shard of a type knows the total
+	}
+	__syncthreads();
+	if (t < MAX_TYPES) {
+		totals[f * MAX_TYPES + t] = s_tot[t];
+		if (packed_start != nullptr) {
+			uint32_t at = 0;
+			for (uint32_t k = 0; k < t; ++k) at += s_tot[k];
+			packed_start[f * MAX_TYPES + t] = at;
+		}
 	}
 }
 
@@ -522,7 +534,8 @@ hipError_t launch_apply_patches(hipStream_t s, float4* spheres, int32_t* ids, Ti
 hipError_t launch_cull_finalize(hipStream_t s, const uint32_t* counts, uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* shard_type,
 	uint32_t n_shards, uint32_t n_frusta, uint32_t* totals, uint32_t* pref, uint32_t* packed_start) {
 	if (!n_frusta) return hipSuccess;
-	hipLaunchKernelGGL(k_cull_finalize, dim3(n_frusta), dim3(64), 0, s, counts, cnt_pad, cnt_frustum_stride, shard_type, n_shards, totals, pref, packed_start);
+	if (n_shards > (uint32_t)FIN_MAX_SHARDS) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_cull_finalize, dim3(n_frusta), dim3(FIN_THREADS), 0, s, counts, cnt_pad, cnt_frustum_stride, shard_type, n_shards, totals, pref, packed_start);
 	return hipGetLastError();
 }
 

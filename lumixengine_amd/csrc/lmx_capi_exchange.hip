@@ -32,9 +32,15 @@ constexpr int NCCL_INT32 = 2; // ncclInt32 (rccl.h ncclDataType_t)
 Rccl& rccl() {
 	static Rccl r = [] {
 		Rccl x;
-		for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-			x.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+		// A process must not end up with two RCCL runtimes (e.g. the copy PyTorch bundles and the system one): first take whatever
+		// is already loaded, only then load one.
+		for (const char* name : {"librccl.so.1", "librccl.so"}) {
+			x.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
 			if (x.lib) break;
+		}
+		for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+			if (x.lib) break;
+			x.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
 		}
 		if (!x.lib) {
 			x.error = "librccl.so.1 not found";
