@@ -485,6 +485,15 @@ def extras(ctx, api, scenes, torch, timed, N, log, big_entities=0):
     for _ in range(10):
         update_frame()
     ms_upd = timed(update_frame, 100)
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    for _ in range(5):
+        update_frame()
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    t_patch, n_patch = ctx.profile_get(api.K_CULL_PATCH)
+    t_dyn, n_dyn = ctx.profile_get(api.K_CULL_DYNAMIC)
+    out["update_stream_device_us_per_frame"] = {"patch_copy_plus_kernel": 1e3 * t_patch / max(n_patch, 1), "overflow_set_cull_kernel": 1e3 * t_dyn / max(n_dyn, 1)}
     out["update_stream_plain_cull_ms"] = ms_plain
     out["update_stream_1000_add_1000_remove_plus_cull_ms"] = ms_upd
     out["update_stream_added_us_per_frame"] = (ms_upd - ms_plain) * 1e3

@@ -64,7 +64,8 @@ enum {
 	LMX_K_CULL_DYNAMIC = 6,
 	LMX_K_SORT_KEYS = 7,
 	LMX_K_ANIM_UPDATE = 8,
-	LMX_K_COUNT = 9
+	LMX_K_CULL_PATCH = 9, /* the copy + k_apply_patches launch that ships queued add / remove / set records */
+	LMX_K_COUNT = 10
 };
 LMX_API int lmx_profile_enable(LmxContext* ctx, int enable);
 LMX_API int lmx_profile_reset(LmxContext* ctx);

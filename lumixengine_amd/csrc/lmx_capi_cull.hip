@@ -193,6 +193,7 @@ int apply_patches(LmxContext* ctx) {
 	if (b_pd) memcpy(h + o_pd, cs.q_dyn.data(), b_pd);
 	if (b_ps) memcpy(h + o_ps, cs.q_sphere.data(), b_ps);
 	if (b_pi) memcpy(h + o_pi, cs.q_id.data(), b_pi);
+	ProfScope ps(ctx, LMX_K_CULL_PATCH);
 	LMX_HIP(ctx, hipMemcpyAsync(cs.d_patch.p, h, total, hipMemcpyHostToDevice, ctx->stream));
 	LMX_HIP(ctx, hipEventRecord(st.done[k], ctx->stream));
 	TileBox* const boxes[3] = {cs.tile_box[0].p, cs.tile_box[1].p, cs.tile_box[2].p};

@@ -13,7 +13,8 @@
  *   src/renderer/pose.cpp             Pose::computeAbsolute (scalar recurrence)
  *   src/renderer/model.cpp            invert, computeSkinMatrices, evaluateSkin
  *   src/renderer/pipeline.cpp         createSortKeys (:3789-3968) — restated only, see the note at orc_create_sort_keys
- *   src/animation/animation.cpp       AnimationSampler, updateAnimable — restated only, see the note at orc_update_animable
+ *   src/animation/animation.cpp       AnimationSampler, updateAnimable — pinned against the reference's own sampler code
+ *                                     sliced into oracle/_ref (oracle/ref/slice_animation.py), see orc_update_animable
  *
  * Pinning: the reference has NO tests or golden vectors for this path. The restatement is pinned
  * instead against the reference's own object code (oracle/_ref/liblmx_ref.so = reference math.cpp + geometry.cpp
@@ -1376,8 +1377,10 @@ done:
 
 /* ---- animation sampling: AnimationModuleImpl::updateAnimable (animation_module.cpp:439-472) --------------------------
  * = Model::getRelativePose (model.cpp:226-237) -> Animation::getRelativePose (animation.cpp:117-204, :294-311; no bone mask)
- * -> time advance (:458-470). PARITY UNPINNED: animation.cpp needs the resource system and core/simd_math.h uses SSE
- * intrinsics on a float4 that the non-MSVC core/simd.h does not define, so neither compiles here; restated from the source. */
+ * -> time advance (:458-470). Pinned bit for bit against the reference's own sampler: oracle/ref/slice_animation.py cuts
+ * AnimationSampler, Animation::getTranslation / getRotation / unpackChannel / getRelativePose, simd_nlerp and the SSE branch of
+ * core/simd.h out of /root/reference at build time, oracle/ref/anim_shim.cpp compiles them into oracle/_ref/liblmx_ref.so
+ * (ref_update_animable); tests/test_oracle_vs_ref.py::test_animation_sampling_bit_exact. */
 static void orc_simd_nlerp(const float* q1, const float* q2, float t, float* out) { /* core/simd_math.h:107-123 */
 	const float inv = 1.0f - t;
 	const float p0 = q1[0] * q2[0], p1 = q1[1] * q2[1], p2 = q1[2] * q2[2], p3 = q1[3] * q2[3];

@@ -302,7 +302,9 @@ class Oracle:
         """AnimationModuleImpl::updateAnimable per instance (animation_module.cpp:439-472): returns (pos [n, bones, 3], rot [n, bones, 4],
         new times). `anims` = list of lumixengine_amd.scenes.animation dicts, anim_of_instance < 0 or 0xffffffff = no animation."""
         from lumixengine_amd.api import animation_struct, LOCAL_RIGID
-        f = self.lib.orc_update_animable
+        # 'port': the plain-C restatement; 'reference': the reference's own AnimationSampler / simd_nlerp code, sliced out of
+        # animation.cpp / simd*.h at build time and compiled into oracle/_ref (oracle/ref/anim_shim.cpp)
+        f = getattr(self.lib, self.prefix + "update_animable")
         f.restype = C.c_uint32
         f.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         structs = [animation_struct(a) for a in anims]

@@ -128,8 +128,8 @@ def main():
     import struct
     unc, comp = struct.unpack_from("<II", wdata, len(wdata) - len(ref_lz4(ref)(wblob)) - 8)
     np.savez_compressed(os.path.join(OUT, "world_blob.npz"), parent=wparent, transforms=wtr, world=wwtr, valid=wvalid, sizes=np.array([unc, comp]))
-    # ---- rows whose parity is UNPINNED (no compilable reference code, see oracle/lmx_oracle.c): regression anchors generated by
-    # the restated oracle ("port"), not by reference object code. File names say so.
+    # ---- createSortKeys: parity UNPINNED (pipeline.cpp has no compilable slice, see oracle/lmx_oracle.c): a regression anchor generated
+    # by the restated oracle ("port"), not by reference object code. The file name says so.
     port = po.Oracle("port")
     from lumixengine_amd import api as lapi  # dtypes only (no GPU needed)
 
@@ -149,12 +149,13 @@ def main():
         keys=got["keys"][order], values=got["values"][order], group_offsets=got["group_offsets"], poses=np.sort(got["poses"]), dirty=np.sort(got["dirty"]),
         lod=got["lod"], pose_frame=got["pose_frame"], scene_seed=np.array([78]),
     )
+    # animation sampling: outputs of the reference's own sampler (oracle/ref/slice_animation.py + anim_shim.cpp in oracle/_ref)
     sk24 = scenes.skeleton(24, seed=4)
     anim = scenes.animation(24, 12, 30.0, seed=31)
     times = np.array([0, 5000, 13000, 1 << 20], np.uint32)
-    apos2, arot2, nt = port.update_animables([anim], [0, 0, 0, 0], times, 0.25, 0.4, sk24["bind"])
-    bpos, brot, nt1 = port.update_animables([anim], [0, 0, 0, 0], times, 1 / 60, 1.0, sk24["bind"])
-    np.savez_compressed(os.path.join(OUT, "unpinned_animation.npz"), times=times, pos_w04=apos2, rot_w04=arot2, times_w04=nt, pos_w1=bpos, rot_w1=brot, times_w1=nt1,
+    apos2, arot2, nt = ref.update_animables([anim], [0, 0, 0, 0], times, 0.25, 0.4, sk24["bind"])
+    bpos, brot, nt1 = ref.update_animables([anim], [0, 0, 0, 0], times, 1 / 60, 1.0, sk24["bind"])
+    np.savez_compressed(os.path.join(OUT, "animation.npz"), times=times, pos_w04=apos2, rot_w04=arot2, times_w04=nt, pos_w1=bpos, rot_w1=brot, times_w1=nt1,
                         anim_seed=np.array([31]), skeleton_seed=np.array([4]))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

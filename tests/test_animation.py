@@ -1,6 +1,8 @@
 """Animation sampling (AnimationModuleImpl::updateAnimable, animation_module.cpp:439-472; AnimationSampler, animation.cpp:29-204;
 simd_nlerp, core/simd_math.h:107-123): oracle vs an independent pure-Python restatement (CPU), HIP path vs the oracle (GPU),
-bit for bit. PARITY UNPINNED for this row: animation.cpp / simd_math.h do not compile outside the engine (see oracle/lmx_oracle.c)."""
+bit for bit. Pinned: tests/test_oracle_vs_ref.py::test_animation_sampling_bit_exact compares the oracle with the reference's own
+sampler (cut out of animation.cpp / simd.h / simd_math.h into oracle/_ref at build time), and tests/golden/animation.npz is that
+sampler's output."""
 import numpy as np
 import pytest
 
@@ -129,15 +131,15 @@ def test_oracle_update_animable_matches_second_restatement(oracle_port, weight, 
     assert not H.bits_equal(pos[0], np.array(sk["bind"]["pos"]))
 
 
-def load_unpinned_fixture():
+def load_fixture():
     import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unpinned_animation.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "animation.npz"))
     return g, scenes.animation(24, 12, 30.0, seed=int(g["anim_seed"][0])), scenes.skeleton(24, seed=int(g["skeleton_seed"][0]))
 
 
 def test_oracle_reproduces_committed_fixture(oracle_port):
-    """tests/golden/unpinned_animation.npz is a regression anchor written by the restated oracle (NOT reference output)."""
-    g, anim, sk = load_unpinned_fixture()
+    """tests/golden/animation.npz is output of the reference's sampler compiled into oracle/_ref (tests/golden/make_golden.py)."""
+    g, anim, sk = load_fixture()
     for tag, w, dt in (("w04", 0.4, 0.25), ("w1", 1.0, 1 / 60)):
         pos, rot, nt = oracle_port.update_animables([anim], [0] * 4, g["times"], dt, w, sk["bind"])
         assert H.bits_equal(pos, g["pos_" + tag]) and H.bits_equal(rot, g["rot_" + tag]) and np.array_equal(nt, g["times_" + tag])
@@ -145,7 +147,7 @@ def test_oracle_reproduces_committed_fixture(oracle_port):
 
 @pytest.mark.gpu
 def test_gpu_animation_matches_committed_fixture(gpu_ctx):
-    g, anim, s = load_unpinned_fixture()
+    g, anim, s = load_fixture()
     sk = api.Skinning(gpu_ctx)
     model = sk.addModel(s["parents"], s["bind"], s["first_nonroot"])
     mesh = sk.addMesh(*scenes.skinned_mesh(30, 24, seed=3))

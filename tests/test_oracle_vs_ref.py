@@ -257,3 +257,28 @@ def test_pose_palette_skin_bit_exact(oracle_port, oracle_ref):
 
 def test_marsaglia_generator(oracle_port, oracle_ref):
     assert np.array_equal(oracle_port.rand_fill(521288629, 362436069, 1000), oracle_ref.rand_fill(521288629, 362436069, 1000))
+
+
+@pytest.mark.parametrize("weight,dt", [(1.0, 1.0 / 60.0), (0.35, 0.25), (0.9999, -0.1), (0.0, 2.5)])
+def test_animation_sampling_bit_exact(oracle_port, oracle_ref, weight, dt):
+    """SURVEY.md 8f rank 2 PINNED: the plain-C restatement of updateAnimable / AnimationSampler / simd_nlerp against the reference's
+    OWN sampling code - AnimationSampler::getRelativePose<false, use_weight>, getRotation (bit-packed rotation tracks, skipped
+    channel, root-motion track), Animation::getTranslation / unpackChannel, simd_nlerp on the SSE float4 - cut out of
+    animation.cpp / simd.h / simd_math.h at build time and compiled into oracle/_ref (oracle/ref/slice_animation.py, anim_shim.cpp).
+    Random animations with constant, packed and root-motion tracks, 5..16 bits per channel, times across the whole clip and beyond
+    its end (clamped), a bone limit that makes the clip skip the skeleton (m_max_accessed_bone_index >= pose.count)."""
+    from lumixengine_amd import scenes
+
+    sk = scenes.skeleton(48, seed=31)
+    anims = [scenes.animation(48, 30, 30.0, seed=200 + k, root_motion=(k % 2 == 0)) for k in range(5)] + [scenes.animation(64, 12, 24.0, seed=260, bone_limit=64)]
+    rng = np.random.default_rng(17)
+    n = 160
+    pick = rng.integers(-1, len(anims), size=n)
+    times = rng.integers(0, 40_000, size=n).astype(np.uint32)
+    times[:6] = [0, 1, 32767, 32768, 65535, 40_000]
+    a = oracle_port.update_animables(anims, pick, times, dt, weight, sk["bind"])
+    b = oracle_ref.update_animables(anims, pick, times, dt, weight, sk["bind"])
+    assert H.bits_equal(a[0], b[0]), "positions differ"
+    assert H.bits_equal(a[1], b[1]), "rotations differ"
+    assert np.array_equal(a[2], b[2]), "advanced times differ"
+    assert np.abs(a[1]).max() <= 1.0001 and len(np.unique(a[2])) > 10

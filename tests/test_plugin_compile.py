@@ -2,7 +2,7 @@
 IModule pair and LUMIX_PLUGIN_ENTRY) against the reference's REAL headers.
 
 The reference does not build on Linux at this snapshot: src/core/sync.h:20-24 is `#error "Not implemented"` for SRWLock. The test
-copies /root/reference/src into a scratch directory (tests/_build/ref_src, git-ignored, never committed), replaces that one line
+copies /root/reference/src into a temporary directory OUTSIDE the repository (removed when the module's tests end), replaces that one line
 with a pthread_rwlock_t member, and compiles the host code with -fsyntax-only (the engine itself cannot be linked here). Skipped
 where /root/reference does not exist (the GPU box)."""
 import os
@@ -21,14 +21,16 @@ FLAGS = ["-std=c++20", "-fsyntax-only", "-fno-exceptions", "-fno-rtti", "-DNDEBU
 def ref_src():
     if not os.path.isdir(os.path.join(REF, "src")):
         pytest.skip("no reference tree on this machine")
-    dst = os.path.join(ROOT, "tests", "_build", "ref_src")
-    shutil.rmtree(dst, ignore_errors=True)
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="lmx_ref_src_")
+    dst = os.path.join(tmp, "src")
     shutil.copytree(os.path.join(REF, "src"), dst)
     sync = os.path.join(dst, "core", "sync.h")
     text = open(sync).read()
     assert text.count('#error "Not implemented"') >= 1
     open(sync, "w").write(text.replace('#error "Not implemented"', "pthread_rwlock_t lock;", 1))
-    return dst
+    yield dst
+    shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _compile(ref_src, source, extra=()):
