@@ -12,7 +12,8 @@
  *   src/engine/world.cpp              transformEntity / setParent / setTransform / setLocalTransform
  *   src/renderer/pose.cpp             Pose::computeAbsolute (scalar recurrence)
  *   src/renderer/model.cpp            invert, computeSkinMatrices, evaluateSkin
- *   src/renderer/pipeline.cpp         createSortKeys (:3789-3968) — restated only, see the note at orc_create_sort_keys
+ *   src/renderer/pipeline.cpp         createSortKeys (:3789-3968) — pinned against the reference's own function sliced into
+ *                                     oracle/_ref (oracle/ref/slice_sort_keys.py), see orc_create_sort_keys
  *   src/animation/animation.cpp       AnimationSampler, updateAnimable — pinned against the reference's own sampler code
  *                                     sliced into oracle/_ref (oracle/ref/slice_animation.py), see orc_update_animable
  *
@@ -1228,9 +1229,11 @@ ORC_API void orc_evaluate_skin(const float* verts, const LmxSkin* skin, const Lm
 
 /* Marsaglia MWC generator, core/math.cpp:1333-1341 */
 /* ---- createSortKeys (renderer/pipeline.cpp:3789-3968), single worker ------------------------------------------------
- * PARITY UNPINNED for this function: pipeline.cpp needs the whole renderer (DX12 back end, resources, job system) and cannot
- * be compiled on its own, and the reference holds no test or golden vector for it; the restatement below follows the
- * source line by line and is cross-checked only against an independent pure-Python restatement in tests/test_sort_keys.py.
+ * Pinned bit for bit, in insertion order, against the reference's own function: pipeline.cpp as a file needs the whole renderer, but
+ * oracle/ref/slice_sort_keys.py cuts createSortKeys' body, Sorter / Inserter, AutoInstancer, View, the key / value makers, floatFlip,
+ * CullResult, PagedListIterator, MeshMaterial, ModelInstance, Model::getLODMeshIndices out of /root/reference at build time and
+ * oracle/ref/keys_shim.cpp compiles them between stand-ins for the engine into oracle/_ref/liblmx_ref.so (ref_create_sort_keys);
+ * tests/test_oracle_vs_ref.py::test_create_sort_keys_bit_exact. A second pure-Python restatement lives in tests/test_sort_keys.py.
  *
  * Inputs are the fields the function reads, entity-indexed like the reference's arrays: ModelInstance {model, mesh_materials,
  * lod, flags, dirty, pose->frame} (render_module.h:206-226), Model {m_lod_distances, m_lod_indices, meshes[].type}

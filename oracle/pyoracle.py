@@ -125,7 +125,7 @@ class Oracle:
         self.f_rand_fill = self._fn("rand_fill", None, [u32, u32, u32, vp])
         self.f_describe = self._fn("describe", C.c_char_p, [])
         # createSortKeys exists only as a restatement (pipeline.cpp cannot be compiled on its own: no ref_ twin)
-        self.f_create_sort_keys = getattr(self.lib, "orc_create_sort_keys", None)
+        self.f_create_sort_keys = getattr(self.lib, self.prefix + "create_sort_keys", None)
         if self.f_create_sort_keys is not None:
             self.f_create_sort_keys.restype = C.c_int
             self.f_create_sort_keys.argtypes = [vp, u32, vp, u32, vp, u32, vp, u32] + [vp] * 15
@@ -244,7 +244,7 @@ class Oracle:
         """PipelineImpl::createSortKeys, single worker (pipeline.cpp:3789-3968). `sc` = lumixengine_amd.scenes.keys_scene tables.
         Returns a dict: keys, values (insertion order, AUTOINSTANCED pairs last), group_offsets, group_values, poses, dirty, lod, pose_frame."""
         if self.f_create_sort_keys is None:
-            raise RuntimeError("createSortKeys is only restated in the port oracle")
+            raise RuntimeError("this oracle library has no create_sort_keys (rebuild oracle/_ref)")
         from lumixengine_amd.api import KEYS_VIEW, KEYS_MODEL, MESH_MATERIAL
         kv = np.ascontiguousarray(kv, KEYS_VIEW)
         ids = [np.ascontiguousarray(x, np.int32) for x in (mesh_ids, decal_ids, curve_ids)]
@@ -273,7 +273,7 @@ class Oracle:
                                      _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(mm), _ptr(lod), _ptr(arrs[3]), _ptr(arrs[4]), _ptr(pose_frame), _ptr(arrs[5]),
                                      _ptr(arrs[6]), _ptr(arrs[7]), _ptr(arrs[8]), _ptr(arrs[9]), C.addressof(out))
         if rc != 0:
-            raise RuntimeError(f"orc_create_sort_keys failed with {rc}")
+            raise RuntimeError(f"{self.prefix}create_sort_keys failed with {rc}")
         return {"keys": keys[: out.n_pairs], "values": values[: out.n_pairs], "group_offsets": offsets, "group_values": gvalues[: out.n_instanced],
                 "poses": poses[: out.n_poses], "dirty": dirty[: out.n_dirty], "lod": lod, "pose_frame": pose_frame, "groups": out.n_groups}
 

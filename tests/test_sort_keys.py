@@ -2,8 +2,8 @@
 path vs the oracle on the visible lists of real culls (GPU). Integer outputs are compared bit for bit as sorted multisets
 (the reference's pair order depends on worker scheduling); ModelInstance::lod / Pose::frame state is compared element-wise.
 
-PARITY UNPINNED: pipeline.cpp cannot be compiled on its own and the reference has no tests for it, so the oracle for this
-row is a restatement checked only against the second restatement below."""
+Pinned: tests/test_oracle_vs_ref.py::test_create_sort_keys_bit_exact compares the oracle with the reference's own createSortKeys
+(cut out of pipeline.cpp into oracle/_ref at build time), and tests/golden/sort_keys.npz is that code's output."""
 import numpy as np
 import pytest
 
@@ -146,16 +146,16 @@ def test_oracle_matches_second_restatement(oracle_port, vi):
     assert (got["lod"] != sc["lod"]).any()
 
 
-def load_unpinned_fixture():
+def load_fixture():
     import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "unpinned_sort_keys.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sort_keys.npz"))
     sc = scenes.keys_scene(len(g["types"]), g["types"], seed=int(g["scene_seed"][0]))
     return g, sc
 
 
 def test_oracle_reproduces_committed_fixture(oracle_port):
-    """tests/golden/unpinned_sort_keys.npz is a regression anchor written by the restated oracle (NOT reference output)."""
-    g, sc = load_unpinned_fixture()
+    """tests/golden/sort_keys.npz is output of the reference's createSortKeys compiled into oracle/_ref (tests/golden/make_golden.py)."""
+    g, sc = load_fixture()
     got = oracle_port.create_sort_keys(g["kv"], sc["max_sort_key"], g["mesh_ids"], g["decal_ids"], g["curve_ids"], sc, g["pos"])
     order = np.lexsort((got["values"], got["keys"]))
     assert np.array_equal(got["keys"][order], g["keys"]) and np.array_equal(got["values"][order], g["values"])
@@ -167,7 +167,7 @@ def test_oracle_reproduces_committed_fixture(oracle_port):
 def test_gpu_sort_keys_match_committed_fixture(gpu_ctx):
     """The device path against the committed fixture: the visible lists are fed through a culling system whose frustum sees
     exactly the fixture's visible entities (every other entity is parked far behind the camera)."""
-    g, sc = load_unpinned_fixture()
+    g, sc = load_fixture()
     n = len(g["types"])
     vis = np.zeros(n, bool)
     for k in ("mesh_ids", "decal_ids", "curve_ids"):
