@@ -782,11 +782,12 @@ def extras(ctx, api, scenes, torch, timed, N, log, big_entities=0):
 
 class CpuBaseline:
     """The reference CPU path on this box's host cores, on the FULL headline workload (10 M entities, same scene, same frustum):
-    oracle/_ref (reference math / geometry object code + restated CullingSystemImpl driver) when present, else the plain-C port.
-    The scene is added and the page pool warmed up on a background thread while the GPU legs run (the reference allocates one
-    4 KiB result page per visited cell page: ~1 M pages for this scene, first touched during the first cull); the timed part is a
-    thread sweep of jobs::forEach stand-ins on a PERSISTENT worker pool: median + p10 / p90 per thread count. Baseline only - the
-    GPU / CPU ratio says nothing about kernel quality."""
+    oracle/_ref (the reference's OWN culling_system.cpp + page_allocator.cpp + math / geometry, compiled in place; threads, Mutex and
+    os::mem* underneath are stand-ins) when present, else the plain-C port. The scene is added and the page pool warmed up on a
+    background thread while the GPU legs run (the reference allocates - and constructs, 1020 EntityRef{-1} each - one 4 KiB result
+    page per visited cell page: ~1 M pages for this scene); the timed part is a thread sweep of the reference's jobs::forEach on a
+    PERSISTENT worker pool: median + p10 / p90 per thread count. The plain-C port, which does not construct the page bodies, is timed
+    next to it ("port"). Baseline only - the GPU / CPU ratio says nothing about kernel quality."""
 
     THREADS = (1, 8, 16, 32, 64)
 
@@ -814,6 +815,17 @@ class CpuBaseline:
             t0 = time.time()
             self.ocs.cull(self.fr, n_threads=8, want_ids=False, cap=0)  # fills the page pool
             self.t_first_cull = time.time() - t0
+            self.port_cs = None
+            import psutil
+
+            if self.kind == "reference" and psutil.virtual_memory().available > (64 << 30):  # the restatement next to it (another ~8 GiB of pages)
+                from oracle import pyoracle
+
+                if not os.path.exists(pyoracle.ORACLE_SO):
+                    pyoracle.build()
+                self.port_cs = pyoracle.Oracle("port").culling_system()
+                self.port_cs.add_bulk(self.sc["entity"], self.sc["type"], self.sc["pos"], self.sc["radius"])
+                self.port_cs.cull(self.fr, n_threads=8, want_ids=False, cap=0)
         except Exception as e:  # noqa: BLE001 - reported in the JSON line instead of killing the bench
             self.error = repr(e)
 
@@ -845,7 +857,7 @@ class CpuBaseline:
             "cores": best,
             "kind": self.kind,
             "sample": f"the full headline workload: {n} entities, same scene and frustum as the GPU run; median of {sweep[best]['culls']} culls at {best} thread(s) "
-                      f"(best of the sweep {list(sweep)}); one CullResult page per visited cell page under a mutex, as in the reference ({pages} pages per cull)",
+                      f"(best of the sweep {list(sweep)}); one CullResult page per visited cell page, constructed and linked under a mutex, as in the reference ({pages} pages per cull)",
             "host_cores": host,
             "thread_sweep": {str(k): v for k, v in sweep.items()},
             "single_thread_value": sweep[1]["entities_per_s"],
@@ -854,6 +866,17 @@ class CpuBaseline:
             "visible": int(visible),
             "describe": self.o.describe(),
         }
+        if getattr(self, "port_cs", None) is not None:
+            port = {}
+            for threads in (1, 8):
+                a = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    self.port_cs.cull(self.fr, n_threads=threads, want_ids=False, cap=0)
+                    a.append(time.perf_counter() - t0)
+                port[str(threads)] = {"median_ms": round(float(np.median(a)) * 1e3, 3), "entities_per_s": n / float(np.median(a))}
+            out["port"] = {"note": "oracle/lmx_oracle.c (plain-C restatement; result pages are linked but their bodies not constructed)", "thread_sweep": port}
+            self.port_cs = None
         out.update(self._other())
         return out
 

@@ -18,8 +18,9 @@
  *                                     sliced into oracle/_ref (oracle/ref/slice_animation.py), see orc_update_animable
  *
  * Pinning: the reference has NO tests or golden vectors for this path. The restatement is pinned
- * instead against the reference's own object code (oracle/_ref/liblmx_ref.so = reference math.cpp + geometry.cpp
- * compiled in place, see oracle/Makefile) by tests/test_oracle_vs_ref.py, and against the golden fixtures under
+ * instead against the reference's own object code (oracle/_ref/liblmx_ref.so = reference math.cpp + geometry.cpp +
+ * culling_system.cpp + page_allocator.cpp compiled in place, animation sampler and createSortKeys sliced from their files,
+ * see oracle/Makefile) by tests/test_oracle_vs_ref.py, and against the golden fixtures under
  * tests/golden/ that were generated from that library (tests/golden/make_golden.py).
  *
  * Build: gcc -std=c11 -O2 -msse2 -mfpmath=sse -ffp-contract=off (no FMA contraction, IEEE fp32/fp64, like the

@@ -5,8 +5,8 @@
 // Every arithmetic operation below is executed by reference symbols (Vec3/DVec3/Quat/Transform/Matrix/
 // LocalRigidTransform/Frustum/ShiftedFrustum/Viewport methods and the scalar float4 of core/simd.h).
 // The *drivers* that cannot compile on Linux at this snapshot (core/sync.h:20-24 `#error`, missing float4
-// helpers for pose.cpp) are restated here, each citing the lines it follows:
-//   CullingSystemImpl            renderer/culling_system.cpp:23-384
+// helpers for pose.cpp) are restated here, each citing the lines it follows (the culling system is NOT among them: the reference's
+// culling_system.cpp itself is compiled, see cull_shim.cpp):
 //   World hierarchy              engine/world.cpp:255-282, 337-361, 619-754
 //   Pose::computeAbsolute        renderer/pose.cpp:129-130 (scalar recurrence; the 4-wide path :69-127 is
 //                                arithmetically identical, see core/simd_math.h:47-91)
@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "lmx_types.h"
+#include "worker_pool.h"
 
 using namespace Lumix;
 
@@ -74,434 +75,12 @@ static void fromRef(const ShiftedFrustum& f, LmxShiftedFrustum* out) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// culling system (driver restated, arithmetic = reference symbols)
+// culling system: the reference's own renderer/culling_system.cpp + core/page_allocator.cpp, compiled in place; the C entry points
+// (ref_cs_*) live in oracle/ref/cull_shim.cpp. The World below reaches it through them.
 // ---------------------------------------------------------------------------------------------------------
-namespace {
-
-constexpr size_t PAGE_SIZE = 4096;
-
-struct CellIndices { // culling_system.cpp:23-40
-	CellIndices() {}
-	CellIndices(const DVec3& p, float cell_size, u8 type, bool is_big)
-		: pos(p * (1 / cell_size)), is_big(is_big), type(type) {}
-	bool operator==(const CellIndices& rhs) const { return pos == rhs.pos && type == rhs.type && is_big == rhs.is_big; }
-	IVec3 pos;
-	u8 type;
-	bool is_big;
-};
-
-struct CellIndicesHasher { // culling_system.cpp:43-50, then mixed: std::unordered_map (the stand-in for Lumix::HashMap)
-	// degrades badly on the raw value, and bucket placement has no influence on any result
-	size_t operator()(const CellIndices& i) const {
-		u64 h = (u32)i.pos.x * 73856093 + (u32)i.pos.y * 19349663 + (u32)i.pos.z * 83492791;
-		h ^= (u64)i.type << 40 | (u64)i.is_big << 48;
-		h *= 0x9E3779B97F4A7C15ull;
-		return (size_t)(h ^ (h >> 29));
-	}
-};
-
-struct alignas(4096) CellPage { // culling_system.cpp:53-65
-	struct {
-		CellPage* next = nullptr;
-		CellPage* prev = nullptr;
-		DVec3 origin;
-		CellIndices indices;
-		int count = 0;
-	} header;
-	enum { MAX_COUNT = (PAGE_SIZE - sizeof(header)) / (sizeof(Sphere) + sizeof(i32)) };
-	Sphere spheres[MAX_COUNT];
-	i32 entities[MAX_COUNT];
-};
-static_assert(sizeof(CellPage) == PAGE_SIZE, "CellPage must be one page");
-static_assert((int)CellPage::MAX_COUNT == (int)LMX_CULL_PAGE_SPHERES, "201 slots");
-
-struct ResultPage { // CullResult, culling_system.h:17-56
-	struct {
-		ResultPage* next = nullptr;
-		u32 count = 0;
-		u8 type;
-	} header;
-	i32 entities[(4096 - sizeof(header)) / sizeof(i32)];
-};
-static_assert(sizeof(ResultPage) == PAGE_SIZE, "CullResult must be one page");
-
-// PageAllocator stand-in, core/page_allocator.cpp:41-64: one pool for cell pages and result pages (the engine has a
-// single PageAllocator, engine.h:45). Freed pages go to a free list and are handed out again, so a steady-state cull
-// performs no OS / malloc calls (the reference: 512-entry lock-free ring + locked fallback). Fresh pages are carved from
-// 4 MiB slabs instead of one os::memReserve per page.
-struct PagePool {
-	std::mutex mutex;
-	std::vector<void*> free_pages;
-	std::vector<void*> slabs;
-	char* slab_cur = nullptr;
-	char* slab_end = nullptr;
-	void* allocate() {
-		std::lock_guard<std::mutex> guard(mutex);
-		void* p = nullptr;
-		if (!free_pages.empty()) {
-			p = free_pages.back();
-			free_pages.pop_back();
-		} else {
-			if (slab_cur == slab_end) {
-				const size_t bytes = PAGE_SIZE * 1024;
-				slab_cur = (char*)aligned_alloc(PAGE_SIZE, bytes);
-				slab_end = slab_cur + bytes;
-				slabs.push_back(slab_cur);
-			}
-			p = slab_cur;
-			slab_cur += PAGE_SIZE;
-		}
-		return p;
-	}
-	void deallocate(void* p) {
-		std::lock_guard<std::mutex> guard(mutex);
-		free_pages.push_back(p);
-	}
-	~PagePool() { for (void* p : slabs) free(p); }
-};
-static PagePool g_pages;
-
-struct PagedResultList { // PagedList<CullResult>, core/page_allocator.h:60-109 (mutex-guarded push)
-	ResultPage* begin = nullptr;
-	ResultPage* end = nullptr;
-	std::mutex mutex; // jobs::Mutex in the reference
-	ResultPage* push() { // page_allocator.h:88-102: allocation and linking both happen under the list mutex
-		std::lock_guard<std::mutex> guard(mutex);
-		void* mem = g_pages.allocate();
-		ResultPage* page = new (mem) ResultPage;
-		if (!begin) begin = end = page;
-		else { end->header.next = page; page->header.next = nullptr; end = page; }
-		return page;
-	}
-};
-
-// jobs::forEach stand-in, core/job_system.h:131-180: min(workers, steps) jobs pulling from one atomic cursor. The workers are
-// persistent, like the engine's job-system threads (core/job_system.cpp): created once, asleep on a condition variable between
-// jobs. (Spawning std::threads per cull put thread creation inside every timed frame of the CPU baseline.)
-struct WorkerPool {
-	std::mutex mutex;
-	std::condition_variable work, done;
-	std::vector<std::thread> threads;
-	const std::function<void()>* job = nullptr;
-	unsigned generation = 0;
-	int wanted = 0, claimed = 0, running = 0;
-
-	void workerLoop() {
-		unsigned seen = 0;
-		std::unique_lock<std::mutex> lock(mutex);
-		for (;;) {
-			while (generation == seen || claimed >= wanted) {
-				if (generation != seen) seen = generation; // job fully staffed: skip it
-				work.wait(lock);
-			}
-			seen = generation;
-			++claimed;
-			const std::function<void()>* j = job;
-			lock.unlock();
-			(*j)();
-			lock.lock();
-			if (--running == 0) done.notify_one();
-		}
-	}
-
-	void run(int helpers, const std::function<void()>& body) {
-		std::unique_lock<std::mutex> lock(mutex);
-		while ((int)threads.size() < helpers && threads.size() < 255) {
-			threads.emplace_back([this] { workerLoop(); });
-			threads.back().detach();
-		}
-		const int staffed = helpers < (int)threads.size() ? helpers : (int)threads.size();
-		job = &body;
-		wanted = staffed;
-		claimed = 0;
-		running = staffed;
-		++generation;
-		work.notify_all();
-		lock.unlock();
-		body(); // the caller works too
-		lock.lock();
-		done.wait(lock, [this] { return running == 0; });
-		job = nullptr;
-		wanted = 0;
-	}
-};
-static WorkerPool& g_workers = *new WorkerPool; // never destroyed: its detached workers wait on the condition variable until the process ends
-
-template <typename F> void forEachJob(u32 count, int n_threads, const F& f) {
-	if (n_threads <= 1 || count <= 1) {
-		for (u32 i = 0; i < count; ++i) f(i);
-		return;
-	}
-	std::atomic<u32> cursor{0};
-	const std::function<void()> worker = [&]() {
-		for (;;) {
-			const u32 i = cursor.fetch_add(1, std::memory_order_relaxed);
-			if (i >= count) return;
-			f(i);
-		}
-	};
-	const int n = n_threads < (int)count ? n_threads : (int)count;
-	g_workers.run(n - 1, worker);
-}
-
-struct CullingSystemRef {
-	std::unordered_map<CellIndices, CellPage*, CellIndicesHasher> m_cell_map;
-	std::vector<CellPage*> m_cells;
-	std::vector<Sphere*> m_entity_to_cell;
-	float m_cell_size = 300.0f; // culling_system.cpp:75
-
-	~CullingSystemRef() {
-		for (CellPage* p : m_cells) g_pages.deallocate(p);
-	}
-
-	static CellPage* newPage() {
-		void* mem = g_pages.allocate();
-		return new (mem) CellPage;
-	}
-
-	Sphere* addToCell(CellPage& cell, i32 entity, const DVec3& pos, float radius) { // :98-128
-		const Vec3 rel_pos = Vec3(pos - cell.header.origin);
-		const int count = cell.header.count;
-		if (count < CellPage::MAX_COUNT - 1) {
-			cell.spheres[count] = {rel_pos, radius};
-			cell.entities[count] = entity;
-			++cell.header.count;
-			return &cell.spheres[count];
-		}
-		CellPage* new_cell = newPage();
-		new_cell->header.origin = cell.header.origin;
-		new_cell->header.indices = cell.header.indices;
-		new_cell->header.next = &cell;
-		new_cell->header.prev = cell.header.prev;
-		new_cell->header.next->header.prev = new_cell;
-		if (new_cell->header.prev) new_cell->header.prev->header.next = new_cell;
-		m_cells.push_back(new_cell);
-		if (!new_cell->header.prev) m_cell_map[new_cell->header.indices] = new_cell;
-		new_cell->spheres[0] = {rel_pos, radius};
-		new_cell->entities[0] = entity;
-		new_cell->header.count = 1;
-		return &new_cell->spheres[0];
-	}
-
-	void add(i32 entity, u8 type, const DVec3& pos, float radius) { // :131-157
-		if ((i32)m_entity_to_cell.size() <= entity) m_entity_to_cell.resize(entity + 1, nullptr);
-		const CellIndices i(pos, m_cell_size, type, radius > m_cell_size);
-		auto iter = m_cell_map.find(i);
-		if (iter == m_cell_map.end()) {
-			CellPage* new_cell = newPage();
-			new_cell->header.origin = i.pos * double(m_cell_size);
-			new_cell->header.indices = i;
-			iter = m_cell_map.emplace(i, new_cell).first;
-			m_cells.push_back(new_cell);
-		}
-		CellPage& cell = *iter->second;
-		m_entity_to_cell[entity] = addToCell(cell, entity, pos, radius);
-	}
-
-	CellPage& getCell(const Sphere& sphere) const { // :193-198
-		const intptr_t ptr = (intptr_t)&sphere;
-		return *(CellPage*)(ptr - (ptr % (intptr_t)PAGE_SIZE));
-	}
-
-	void remove(i32 entity) { // :160-190
-		if ((i32)m_entity_to_cell.size() <= entity) return;
-		const Sphere* sphere = m_entity_to_cell[entity];
-		if (!sphere) return;
-		CellPage& cell = getCell(*sphere);
-		if (cell.header.count == 1) {
-			if (!cell.header.prev) {
-				if (!cell.header.next) m_cell_map.erase(cell.header.indices);
-				else m_cell_map[cell.header.indices] = cell.header.next;
-			}
-			if (cell.header.prev) cell.header.prev->header.next = cell.header.next;
-			if (cell.header.next) cell.header.next->header.prev = cell.header.prev;
-			for (size_t k = 0; k < m_cells.size(); ++k) { // swapAndPopItem
-				if (m_cells[k] == &cell) { m_cells[k] = m_cells.back(); m_cells.pop_back(); break; }
-			}
-			g_pages.deallocate(&cell);
-		} else {
-			const int idx = int(sphere - cell.spheres);
-			const i32 last = cell.entities[cell.header.count - 1];
-			cell.entities[idx] = cell.entities[cell.header.count - 1];
-			cell.spheres[idx] = cell.spheres[cell.header.count - 1];
-			m_entity_to_cell[last] = &cell.spheres[idx];
-			--cell.header.count;
-		}
-		m_entity_to_cell[entity] = nullptr;
-	}
-
-	void setPosition(i32 entity, const DVec3& pos) { // :201-217
-		Sphere* sphere = m_entity_to_cell[entity];
-		CellPage& cell = getCell(*sphere);
-		const IVec3 new_indices(pos * (1 / m_cell_size));
-		if (new_indices == cell.header.indices.pos) {
-			sphere->position = Vec3(pos - cell.header.origin);
-			return;
-		}
-		const float radius = sphere->radius;
-		const u8 type = cell.header.indices.type;
-		remove(entity);
-		add(entity, type, pos, radius);
-	}
-
-	void set(i32 entity, const DVec3& pos, float radius) { // :225-242
-		Sphere* sphere = m_entity_to_cell[entity];
-		CellPage& cell = getCell(*sphere);
-		const IVec3 new_indices(pos * (1 / m_cell_size));
-		const bool was_big = cell.header.indices.is_big;
-		const bool is_big = radius > m_cell_size;
-		if (was_big == is_big && new_indices == cell.header.indices.pos) {
-			sphere->radius = radius;
-			sphere->position = Vec3(pos - cell.header.origin);
-			return;
-		}
-		const u8 type = cell.header.indices.type;
-		remove(entity);
-		add(entity, type, pos, radius);
-	}
-
-	void setRadius(i32 entity, float radius) { // :244-260
-		Sphere* sphere = m_entity_to_cell[entity];
-		CellPage& cell = getCell(*sphere);
-		const bool was_big = cell.header.indices.is_big;
-		const bool is_big = radius > m_cell_size;
-		if (was_big == is_big) {
-			sphere->radius = radius;
-			return;
-		}
-		const u8 type = cell.header.indices.type;
-		const DVec3 pos = cell.header.origin + sphere->position;
-		remove(entity);
-		add(entity, type, pos, radius);
-	}
-
-	// doCulling, :262-308 — the reference's scalar float4 (core/simd.h:203-449) does the arithmetic
-	void doCulling(const CellPage& cell, const Frustum& frustum, ResultPage* results, PagedResultList& list, u8 type) {
-		const Sphere* start = cell.spheres;
-		const Sphere* end = cell.spheres + cell.header.count;
-		const i32* sphere_to_entity_map = cell.entities;
-		const float4 px = f4Load(frustum.xs);
-		const float4 py = f4Load(frustum.ys);
-		const float4 pz = f4Load(frustum.zs);
-		const float4 pd = f4Load(frustum.ds);
-		const float4 px2 = f4Load(&frustum.xs[4]);
-		const float4 py2 = f4Load(&frustum.ys[4]);
-		const float4 pz2 = f4Load(&frustum.zs[4]);
-		const float4 pd2 = f4Load(&frustum.ds[4]);
-		int cursor = results->header.count;
-		int i = 0;
-		for (const Sphere* sphere = start; sphere < end; ++sphere, ++i) {
-			const float4 cx = f4Splat(sphere->position.x);
-			const float4 cy = f4Splat(sphere->position.y);
-			const float4 cz = f4Splat(sphere->position.z);
-			const float4 r = f4Splat(-sphere->radius);
-			float4 t = cx * px + cy * py + cz * pz + pd;
-			t = t - r;
-			if (f4MoveMask(t)) continue;
-			t = cx * px2 + cy * py2 + cz * pz2 + pd2;
-			t = t - r;
-			if (f4MoveMask(t)) continue;
-			if (cursor == (int)lengthOf(results->entities)) {
-				results->header.count = cursor;
-				results = list.push();
-				results->header.type = type;
-				cursor = 0;
-			}
-			results->entities[cursor] = sphere_to_entity_map[i];
-			++cursor;
-		}
-		results->header.count = cursor;
-	}
-
-	ResultPage* cullInternal(const ShiftedFrustum& frustum, u8 type, int n_threads) { // :321-369
-		if (m_cells.empty()) return nullptr;
-		PagedResultList list;
-		const Vec3 v3_cell_size(m_cell_size);
-		const Vec3 v3_2_cell_size(2 * m_cell_size);
-		forEachJob((u32)m_cells.size(), n_threads, [&](u32 cell_idx) {
-			ResultPage* result = nullptr;
-			CellPage& cell = *m_cells[cell_idx];
-			if (type != 0xff && cell.header.indices.type != type) return;
-			if (!result || result->header.type != cell.header.indices.type) {
-				result = list.push();
-				result->header.type = cell.header.indices.type;
-			}
-			if (cell.header.indices.is_big) {
-				doCulling(cell, frustum.getRelative(cell.header.origin), result, list, cell.header.indices.type);
-			} else if (frustum.containsAABB(cell.header.origin + v3_cell_size, v3_cell_size)) {
-				int to_cpy = cell.header.count;
-				int src_offset = 0;
-				while (to_cpy > 0) {
-					if (result->header.count == lengthOf(result->entities)) {
-						result = list.push();
-						result->header.type = cell.header.indices.type;
-					}
-					const int rem_space = lengthOf(result->entities) - result->header.count;
-					const int step = minimum(to_cpy, rem_space);
-					memcpy(result->entities + result->header.count, cell.entities + src_offset, step * sizeof(cell.entities[0]));
-					src_offset += step;
-					result->header.count += step;
-					to_cpy -= step;
-				}
-			} else if (frustum.intersectsAABB(cell.header.origin - v3_cell_size, v3_2_cell_size)) {
-				doCulling(cell, frustum.getRelative(cell.header.origin), result, list, cell.header.indices.type);
-			}
-		});
-		ResultPage* r = list.begin;
-		list.begin = list.end = nullptr;
-		return r;
-	}
-};
-
-} // namespace
-
 extern "C" {
-
-void* ref_cs_create(void) { return new CullingSystemRef; }
-void ref_cs_destroy(void* cs) { delete (CullingSystemRef*)cs; }
-void ref_cs_add(void* cs, int32_t entity, uint8_t type, const double* pos, float radius) {
-	((CullingSystemRef*)cs)->add(entity, type, DVec3(pos[0], pos[1], pos[2]), radius);
-}
-void ref_cs_add_bulk(void* cs, uint32_t n, const int32_t* entity, const uint8_t* type, const double* pos, const float* radius) {
-	for (uint32_t i = 0; i < n; ++i) ref_cs_add(cs, entity[i], type[i], pos + 3 * (size_t)i, radius[i]);
-}
-void ref_cs_remove(void* cs, int32_t entity) { ((CullingSystemRef*)cs)->remove(entity); }
-void ref_cs_set(void* cs, int32_t entity, const double* pos, float radius) {
-	((CullingSystemRef*)cs)->set(entity, DVec3(pos[0], pos[1], pos[2]), radius);
-}
-void ref_cs_set_position(void* cs, int32_t entity, const double* pos) {
-	((CullingSystemRef*)cs)->setPosition(entity, DVec3(pos[0], pos[1], pos[2]));
-}
-void ref_cs_set_radius(void* cs, int32_t entity, float radius) { ((CullingSystemRef*)cs)->setRadius(entity, radius); }
-float ref_cs_get_radius(void* cs, int32_t entity) { return ((CullingSystemRef*)cs)->m_entity_to_cell[entity]->radius; }
-int ref_cs_is_added(void* cs, int32_t entity) {
-	auto* c = (CullingSystemRef*)cs;
-	return entity >= 0 && entity < (int32_t)c->m_entity_to_cell.size() && c->m_entity_to_cell[entity] != nullptr;
-}
-uint32_t ref_cs_cell_count(void* cs) { return (uint32_t)((CullingSystemRef*)cs)->m_cells.size(); }
-
-// Runs one cull and flattens the CullResult page list into (id, type) arrays. Returns the total count and the
-// number of result pages the reference allocated (the page traffic is part of what the CPU path pays for).
-uint32_t ref_cs_cull(void* cs, const LmxShiftedFrustum* frustum, uint8_t type, int n_threads, int32_t* out_ids,
-	uint8_t* out_types, uint32_t cap, uint32_t* out_pages) {
-	const ShiftedFrustum f = toRef(frustum);
-	ResultPage* page = ((CullingSystemRef*)cs)->cullInternal(f, type, n_threads);
-	uint32_t n = 0, pages = 0;
-	while (page) {
-		for (u32 i = 0; i < page->header.count; ++i, ++n) {
-			if (n < cap) {
-				if (out_ids) out_ids[n] = page->entities[i];
-				if (out_types) out_types[n] = page->header.type;
-			}
-		}
-		ResultPage* tmp = page;
-		page = page->header.next;
-		g_pages.deallocate(tmp); // CullResult::free, culling_system.cpp:388-396
-		++pages;
-	}
-	if (out_pages) *out_pages = pages;
-	return n;
-}
+int ref_cs_is_added(void* cs, int32_t entity);
+void ref_cs_set(void* cs, int32_t entity, const double* pos, float radius);
 
 // ---------------------------------------------------------------------------------------------------------
 // frusta
@@ -589,14 +168,15 @@ struct WorldRef {
 	std::vector<i32> m_entity_hierarchy; // EntityData::hierarchy
 	std::vector<Hierarchy> m_hierarchy;
 	// RenderModuleImpl::onModelInstanceMoved binding, render_module.cpp:1544-1554
-	CullingSystemRef* m_culling = nullptr;
+	void* m_culling = nullptr; // a ref_cs_create handle
 	std::vector<float> m_model_radius; // < 0: entity has no model instance
 
 	void transformed(i32 entity) {
 		if (!m_culling || m_model_radius[entity] < 0) return;
 		if (!ref_cs_is_added(m_culling, entity)) return;
 		const Transform& tr = m_transforms[entity];
-		m_culling->set(entity, tr.pos, m_model_radius[entity] * maximum(tr.scale.x, tr.scale.y, tr.scale.z));
+		const double pos[3] = {tr.pos.x, tr.pos.y, tr.pos.z};
+		ref_cs_set(m_culling, entity, pos, m_model_radius[entity] * maximum(tr.scale.x, tr.scale.y, tr.scale.z));
 	}
 
 	void transformEntity(i32 entity, bool update_local) { // world.cpp:255-282
@@ -727,7 +307,7 @@ void ref_world_get_local_transforms(void* w, uint32_t n, LmxTransform* out) { //
 }
 void ref_world_bind_culling(void* w, void* cs, uint32_t n, const int32_t* entity, const float* model_radius) {
 	WorldRef* world = (WorldRef*)w;
-	world->m_culling = (CullingSystemRef*)cs;
+	world->m_culling = cs;
 	for (uint32_t i = 0; i < n; ++i) world->m_model_radius[entity[i]] = model_radius[i];
 }
 
@@ -752,7 +332,7 @@ void ref_pose_blend(float* positions, float* rotations, const float* rhs_positio
 
 void ref_pose_compute_absolute(float* positions, float* rotations, const int16_t* parents, int32_t first_nonroot,
 	uint32_t count, uint32_t n_instances, int n_threads) {
-	forEachJob(n_instances, n_threads, [&](u32 inst) {
+	lmx_ref::forEachJob(n_instances, n_threads, [&](u32 inst) {
 		Vec3* pos = (Vec3*)(positions + (size_t)inst * count * 3);
 		Quat* rot = (Quat*)(rotations + (size_t)inst * count * 4);
 		for (u32 i = (u32)first_nonroot; i < count; ++i) {
@@ -777,7 +357,7 @@ void ref_invert_bind(const LmxLocalRigidTransform* bind, LmxLocalRigidTransform*
 // computeSkinMatrices, model.cpp:132-137, for n_instances poses sharing one model's inverse bind
 void ref_skin_matrices(const float* pose_pos, const float* pose_rot, const LmxLocalRigidTransform* inv_bind, LmxMatrix* out,
 	uint32_t count, uint32_t n_instances, int n_threads) {
-	forEachJob(n_instances, n_threads, [&](u32 inst) {
+	lmx_ref::forEachJob(n_instances, n_threads, [&](u32 inst) {
 		const Vec3* pos = (const Vec3*)(pose_pos + (size_t)inst * count * 3);
 		const Quat* rot = (const Quat*)(pose_rot + (size_t)inst * count * 4);
 		Matrix* matrices = (Matrix*)(out + (size_t)inst * count);
@@ -810,7 +390,7 @@ void ref_dual_quats(const float* pose_pos, const float* pose_rot, const LmxLocal
 // evaluateSkin, model.cpp:103-109, for n_instances palettes over one mesh
 void ref_evaluate_skin(const float* verts, const LmxSkin* skin, const LmxMatrix* palettes, float* out, uint32_t n_verts,
 	uint32_t n_bones, uint32_t n_instances, int n_threads) {
-	forEachJob(n_instances, n_threads, [&](u32 inst) {
+	lmx_ref::forEachJob(n_instances, n_threads, [&](u32 inst) {
 		const Matrix* matrices = (const Matrix*)(palettes + (size_t)inst * n_bones);
 		float* o = out + (size_t)inst * n_verts * 3;
 		for (u32 v = 0; v < n_verts; ++v) {
@@ -833,8 +413,10 @@ void ref_rand_fill(uint32_t u, uint32_t v, uint32_t n, uint32_t* out) {
 }
 
 const char* ref_describe(void) {
-	return "reference object code: src/core/math.cpp + src/core/geometry.cpp (g++ -O2 -msse2 -ffp-contract=off), "
-		   "drivers restated in oracle/ref/ref_shim.cpp";
+	return "reference object code (g++ -O2 -msse2 -ffp-contract=off): src/core/math.cpp + geometry.cpp, renderer/culling_system.cpp + "
+		   "core/page_allocator.cpp + core/linux/atomic.cpp compiled in place (job threads, Mutex, os::mem* underneath are stand-ins), "
+		   "animation sampler and createSortKeys sliced from animation.cpp / pipeline.cpp; World / pose / skin drivers restated in "
+		   "oracle/ref/ref_shim.cpp";
 }
 
 } // extern "C"
