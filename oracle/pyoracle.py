@@ -429,6 +429,25 @@ class OracleWorld:
         self.o.f_world_get_local_transforms(self.h, self.n, _ptr(out))
         return out
 
+    def serialize(self, flags: int = 0) -> bytes:
+        """World::serialize (engine/world.cpp:837-897) - reference oracle only (the real World)."""
+        f = self.o.lib.ref_world_serialize
+        f.restype, f.argtypes = C.c_uint32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        n = f(self.h, flags, None, 0)
+        buf = C.create_string_buffer(n)
+        assert f(self.h, flags, buf, n) == n
+        return buf.raw
+
+    def set_name(self, entity: int, name: str):
+        f = self.o.lib.ref_world_set_name
+        f.restype, f.argtypes = None, [C.c_void_p, C.c_int32, C.c_char_p]
+        f(self.h, int(entity), name.encode())
+
+    def destroy_entity(self, entity: int):
+        f = self.o.lib.ref_world_destroy_entity
+        f.restype, f.argtypes = None, [C.c_void_p, C.c_int32]
+        f(self.h, int(entity))
+
     def bind_culling(self, cs: OracleCullingSystem, entity, model_radius):
         entity = np.ascontiguousarray(entity, np.int32)
         model_radius = np.ascontiguousarray(model_radius, np.float32)

@@ -16,6 +16,9 @@
 #include "lmx_types.h"
 
 namespace Lumix {
+// Everything below lives in Lumix::anim_shim: liblmx_ref.so also holds real engine object code (cull_shim.cpp / world_shim.cpp), and
+// same-named inline members of the stand-ins (Array, Pose, Model) would be merged with the real ones at link time.
+namespace anim_shim {
 
 // ---- src/core/simd.h, SSE branch + src/core/simd_math.h simd_nlerp (sliced) ----
 #include "gen/simd_sse.inc"
@@ -66,9 +69,11 @@ Animation::Animation() : m_root_motion(*(IAllocator*)nullptr) {}
 #include "gen/anim_sampler.inc"
 #include "gen/anim_methods.inc"
 
+} // namespace anim_shim
 } // namespace Lumix
 
 using namespace Lumix;
+using namespace Lumix::anim_shim;
 
 // AnimationModuleImpl::updateAnimable for one Animable (animation/animation_module.cpp:439-472): Model::getRelativePose
 // (renderer/model.cpp:226-237) into the pose, the reference's Animation::getRelativePose on it, then the time advance (restated: five

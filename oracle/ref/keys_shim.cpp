@@ -27,10 +27,16 @@
 
 namespace Lumix {
 
-// ---- stand-ins (mine) ----
 // core/atomic.h declares compareExchangePtr(void* volatile*, ...); core/linux/atomic.cpp (compiled in place into oracle/_ref/atomic.o)
 // defines a different overload, so the declared one is provided here with the same builtin.
 bool compareExchangePtr(void* volatile* value, void* exchange, void* comperand) { return __sync_bool_compare_and_swap(value, comperand, exchange); }
+
+// Everything below - stand-ins and sliced code alike - lives in Lumix::keys_shim: liblmx_ref.so also holds the real PageAllocator,
+// World, jobs:: ... (cull_shim.cpp / world_shim.cpp), and same-named inline members would be merged with them at link time.
+// Unqualified names (Vec3, DVec3, Transform, Array, IAllocator, EntityRef, ...) still resolve to the enclosing Lumix.
+namespace keys_shim {
+
+// ---- stand-ins (mine) ----
 
 struct MallocAllocator : IAllocator {
 	void* allocate(size_t size, size_t align) override {
@@ -167,9 +173,11 @@ struct PipelineImpl {
 	std::vector<i32> refresh_queue;
 };
 
+} // namespace keys_shim
 } // namespace Lumix
 
 using namespace Lumix;
+using namespace Lumix::keys_shim;
 
 namespace {
 struct KeysOut { // = OrcKeysOut of oracle/lmx_oracle.c

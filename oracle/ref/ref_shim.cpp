@@ -4,10 +4,9 @@
 // src/core/math.cpp and src/core/geometry.cpp compiled in place; the result goes to oracle/_ref/liblmx_ref.so.
 // Every arithmetic operation below is executed by reference symbols (Vec3/DVec3/Quat/Transform/Matrix/
 // LocalRigidTransform/Frustum/ShiftedFrustum/Viewport methods and the scalar float4 of core/simd.h).
-// The *drivers* that cannot compile on Linux at this snapshot (core/sync.h:20-24 `#error`, missing float4
-// helpers for pose.cpp) are restated here, each citing the lines it follows (the culling system is NOT among them: the reference's
-// culling_system.cpp itself is compiled, see cull_shim.cpp):
-//   World hierarchy              engine/world.cpp:255-282, 337-361, 619-754
+// The *drivers* that cannot compile outside the engine (pose.cpp / model.cpp need the resource system and renderer) are restated
+// here, each citing the lines it follows. The culling system and the World are NOT among them: the reference's culling_system.cpp
+// and world.cpp themselves are compiled, see cull_shim.cpp / world_shim.cpp.
 //   Pose::computeAbsolute        renderer/pose.cpp:129-130 (scalar recurrence; the 4-wide path :69-127 is
 //                                arithmetically identical, see core/simd_math.h:47-91)
 //   invert/computeSkinMatrices/evaluateSkin   renderer/model.cpp:24-30, 132-137, 103-109
@@ -79,8 +78,6 @@ static void fromRef(const ShiftedFrustum& f, LmxShiftedFrustum* out) {
 // (ref_cs_*) live in oracle/ref/cull_shim.cpp. The World below reaches it through them.
 // ---------------------------------------------------------------------------------------------------------
 extern "C" {
-int ref_cs_is_added(void* cs, int32_t entity);
-void ref_cs_set(void* cs, int32_t entity, const double* pos, float radius);
 
 // ---------------------------------------------------------------------------------------------------------
 // frusta
@@ -155,161 +152,8 @@ void ref_compute_local(const LmxTransform* parent, const LmxTransform* child, Lm
 	fromRef(Transform::computeLocal(toRef(parent), toRef(child)), out);
 }
 
-namespace {
-struct WorldRef {
-	struct Hierarchy { // engine/world.h:157-164
-		i32 entity;
-		i32 parent;
-		i32 first_child;
-		i32 next_sibling;
-		Transform local_transform;
-	};
-	std::vector<Transform> m_transforms;
-	std::vector<i32> m_entity_hierarchy; // EntityData::hierarchy
-	std::vector<Hierarchy> m_hierarchy;
-	// RenderModuleImpl::onModelInstanceMoved binding, render_module.cpp:1544-1554
-	void* m_culling = nullptr; // a ref_cs_create handle
-	std::vector<float> m_model_radius; // < 0: entity has no model instance
-
-	void transformed(i32 entity) {
-		if (!m_culling || m_model_radius[entity] < 0) return;
-		if (!ref_cs_is_added(m_culling, entity)) return;
-		const Transform& tr = m_transforms[entity];
-		const double pos[3] = {tr.pos.x, tr.pos.y, tr.pos.z};
-		ref_cs_set(m_culling, entity, pos, m_model_radius[entity] * maximum(tr.scale.x, tr.scale.y, tr.scale.z));
-	}
-
-	void transformEntity(i32 entity, bool update_local) { // world.cpp:255-282
-		transformed(entity);
-		const i32 hierarchy_idx = m_entity_hierarchy[entity];
-		if (hierarchy_idx >= 0) {
-			Hierarchy& h = m_hierarchy[hierarchy_idx];
-			const Transform my_transform = m_transforms[entity];
-			if (update_local && h.parent >= 0) {
-				const Transform parent_tr = m_transforms[h.parent];
-				h.local_transform = Transform::computeLocal(parent_tr, my_transform);
-			}
-			i32 child = h.first_child;
-			while (child >= 0) {
-				const Hierarchy& child_h = m_hierarchy[m_entity_hierarchy[child]];
-				const Transform abs_tr = my_transform.compose(child_h.local_transform);
-				m_transforms[child] = abs_tr;
-				const i32 next = child_h.next_sibling; // (recursion never mutates m_hierarchy with update_local=false)
-				transformEntity(child, false);
-				child = next;
-			}
-		}
-	}
-
-	void collectGarbage(i32 entity) { // world.cpp:629-639
-		Hierarchy& h = m_hierarchy[m_entity_hierarchy[entity]];
-		if (h.parent >= 0) return;
-		if (h.first_child >= 0) return;
-		const Hierarchy last = m_hierarchy.back();
-		m_entity_hierarchy[last.entity] = m_entity_hierarchy[entity];
-		m_entity_hierarchy[entity] = -1;
-		h = last;
-		m_hierarchy.pop_back();
-	}
-
-	void setParent(i32 new_parent, i32 child) { // world.cpp:619-701 (cycle check omitted: callers build forests)
-		i32 child_idx = m_entity_hierarchy[child];
-		if (child_idx >= 0) {
-			const i32 old_parent = m_hierarchy[child_idx].parent;
-			if (old_parent >= 0) {
-				Hierarchy& old_parent_h = m_hierarchy[m_entity_hierarchy[old_parent]];
-				i32* x = &old_parent_h.first_child;
-				while (*x >= 0) {
-					if (*x == child) {
-						*x = m_hierarchy[m_entity_hierarchy[child]].next_sibling;
-						break;
-					}
-					x = &m_hierarchy[m_entity_hierarchy[*x]].next_sibling;
-				}
-				m_hierarchy[child_idx].parent = -1;
-				m_hierarchy[child_idx].next_sibling = -1;
-				collectGarbage(old_parent);
-				child_idx = m_entity_hierarchy[child];
-			}
-		} else if (new_parent >= 0) {
-			child_idx = (i32)m_hierarchy.size();
-			m_entity_hierarchy[child] = child_idx;
-			m_hierarchy.push_back({child, -1, -1, -1, Transform::IDENTITY});
-		}
-		if (new_parent >= 0) {
-			i32 new_parent_idx = m_entity_hierarchy[new_parent];
-			if (new_parent_idx < 0) {
-				new_parent_idx = (i32)m_hierarchy.size();
-				m_entity_hierarchy[new_parent] = new_parent_idx;
-				m_hierarchy.push_back({new_parent, -1, -1, -1, Transform::IDENTITY});
-			}
-			m_hierarchy[child_idx].parent = new_parent;
-			const Transform parent_tr = m_transforms[new_parent];
-			const Transform child_tr = m_transforms[child];
-			m_hierarchy[child_idx].local_transform = Transform::computeLocal(parent_tr, child_tr);
-			m_hierarchy[child_idx].next_sibling = m_hierarchy[new_parent_idx].first_child;
-			m_hierarchy[new_parent_idx].first_child = child;
-		} else {
-			if (child_idx >= 0) collectGarbage(child);
-		}
-	}
-
-	void setTransform(i32 entity, const Transform& tr) { // world.cpp:337-342
-		m_transforms[entity] = tr;
-		transformEntity(entity, true);
-	}
-
-	void setLocalTransform(i32 entity, const Transform& tr) { // world.cpp:741-753 -> updateGlobalTransform :704-712
-		const i32 hierarchy_idx = m_entity_hierarchy[entity];
-		if (hierarchy_idx < 0) {
-			setTransform(entity, tr);
-			return;
-		}
-		Hierarchy& h = m_hierarchy[hierarchy_idx];
-		h.local_transform = tr;
-		const Transform parent_tr = m_transforms[h.parent];
-		const Transform new_tr = parent_tr.compose(h.local_transform);
-		setTransform(entity, new_tr);
-	}
-};
-} // namespace
-
-void* ref_world_create(uint32_t n_entities) {
-	WorldRef* w = new WorldRef;
-	w->m_transforms.assign(n_entities, Transform::IDENTITY);
-	w->m_entity_hierarchy.assign(n_entities, -1);
-	w->m_model_radius.assign(n_entities, -1.f);
-	return w;
-}
-void ref_world_destroy(void* w) { delete (WorldRef*)w; }
-// raw write of m_transforms without propagation (entity creation: World::createEntity / emplaceEntity)
-void ref_world_init_transforms(void* w, uint32_t n, const int32_t* entity, const LmxTransform* tr) {
-	for (uint32_t i = 0; i < n; ++i) ((WorldRef*)w)->m_transforms[entity[i]] = toRef(&tr[i]);
-}
-void ref_world_set_parents(void* w, uint32_t n, const int32_t* parent, const int32_t* child) {
-	for (uint32_t i = 0; i < n; ++i) ((WorldRef*)w)->setParent(parent[i], child[i]);
-}
-void ref_world_set_transforms(void* w, uint32_t n, const int32_t* entity, const LmxTransform* tr) {
-	for (uint32_t i = 0; i < n; ++i) ((WorldRef*)w)->setTransform(entity[i], toRef(&tr[i]));
-}
-void ref_world_set_local_transforms(void* w, uint32_t n, const int32_t* entity, const LmxTransform* tr) {
-	for (uint32_t i = 0; i < n; ++i) ((WorldRef*)w)->setLocalTransform(entity[i], toRef(&tr[i]));
-}
-void ref_world_get_transforms(void* w, uint32_t n, LmxTransform* out) {
-	for (uint32_t i = 0; i < n; ++i) fromRef(((WorldRef*)w)->m_transforms[i], &out[i]);
-}
-void ref_world_get_local_transforms(void* w, uint32_t n, LmxTransform* out) { // World::getLocalTransform, world.cpp:756-766
-	WorldRef* world = (WorldRef*)w;
-	for (uint32_t i = 0; i < n; ++i) {
-		const i32 h = world->m_entity_hierarchy[i];
-		fromRef(h < 0 ? world->m_transforms[i] : world->m_hierarchy[h].local_transform, &out[i]);
-	}
-}
-void ref_world_bind_culling(void* w, void* cs, uint32_t n, const int32_t* entity, const float* model_radius) {
-	WorldRef* world = (WorldRef*)w;
-	world->m_culling = cs;
-	for (uint32_t i = 0; i < n; ++i) world->m_model_radius[entity[i]] = model_radius[i];
-}
+// World hierarchy: the reference's own engine/world.cpp, compiled in place; the C entry points (ref_world_*) live in
+// oracle/ref/world_shim.cpp.
 
 // ---------------------------------------------------------------------------------------------------------
 // pose / palette / linear-blend skin

@@ -66,6 +66,7 @@ def main():
     w.set_parents(h["parent"][kids], kids)
     w.set_local_transforms(kids, h["local"][kids])
     locals_ = w.get_local_transforms()
+    locals_[roots] = w.get_transforms()[roots]  # a root's hierarchy record holds indeterminate memory in the reference (world.cpp:681-687): not part of the fixture
     world0 = w.get_transforms()
     new_root = scenes.random_transforms(rng, len(roots), 4000.0)
     w.set_transforms(roots, new_root)
@@ -125,6 +126,15 @@ def main():
             wtr[e] = wh["local"][e]
         else:
             wtr[e] = wworld[e]
+    # the reference's own World::serialize (engine/world.cpp compiled in place into oracle/_ref) on a real World
+    from tests.test_world_blob import make_reference_world
+    rw, rh, rgone = make_reference_world(ref)
+    open(os.path.join(OUT, "world_blob_ref.bin"), "wb").write(rw.serialize(1))
+    ralive = np.ones(len(rh["parent"]), np.uint8)
+    ralive[rgone] = 0
+    np.savez_compressed(os.path.join(OUT, "world_blob_ref.npz"), parent=np.where(ralive.astype(bool), rh["parent"], -1).astype(np.int32), alive=ralive,
+                        world=rw.get_transforms(), local=np.where((rh["parent"] >= 0)[:, None], rw.get_local_transforms().view(np.uint8).reshape(len(ralive), -1),
+                                                                rw.get_transforms().view(np.uint8).reshape(len(ralive), -1)).view(po.TRANSFORM).reshape(-1))
     import struct
     unc, comp = struct.unpack_from("<II", wdata, len(wdata) - len(ref_lz4(ref)(wblob)) - 8)
     np.savez_compressed(os.path.join(OUT, "world_blob.npz"), parent=wparent, transforms=wtr, world=wwtr, valid=wvalid, sizes=np.array([unc, comp]))

@@ -121,16 +121,20 @@ def transforms_bits_equal(a: np.ndarray, b: np.ndarray) -> bool:
     return all(bits_equal(np.ascontiguousarray(a[k]), np.ascontiguousarray(b[k])) for k in ("pos", "rot", "scale"))
 
 
-def write_world_blob(entities, world, hierarchy, module_names=("renderer", "animation"), names=None, partitions=False, compress=None):
+def write_world_blob(entities, world, hierarchy, module_names=("renderer", "animation"), names=None, partitions=False, compress=None, n_slots=None):
     """World::serialize (engine/world.cpp:837-898) for a world without module payloads: `entities` = valid entity indices, `world` =
     Transform per listed entity, `hierarchy` = list of (entity, parent, first_child, next_sibling, local Transform). `compress` =
-    bytes -> bytes LZ4 block compressor (the reference's own, oracle/_ref). Test helper: restated writer, not reference code."""
+    bytes -> bytes LZ4 block compressor (the reference's own, oracle/_ref). `n_slots` = m_entities.size(), the blob's first field
+    (entity SLOTS, valid or not; default: highest listed index + 1). Test helper: restated writer, byte-identical to the reference's
+    own World::serialize where both can express the world (tests/test_world_blob.py::test_restated_writer_matches_reference_serializer)."""
     import struct
 
     def tr_bytes(t):
         return struct.pack("<3d4f3f", *[float(x) for x in t["pos"]], *[float(x) for x in t["rot"]], *[float(x) for x in t["scale"]])
 
-    blob = bytearray(struct.pack("<I", len(entities)))
+    if n_slots is None:
+        n_slots = (max(int(e) for e in entities) + 1) if len(entities) else 0
+    blob = bytearray(struct.pack("<I", n_slots))
     for e, t in zip(entities, world):
         blob += struct.pack("<i", int(e)) + tr_bytes(t)
         if partitions:

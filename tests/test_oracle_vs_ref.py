@@ -211,7 +211,10 @@ def test_world_hierarchy_matches_reference(oracle_port, oracle_ref, kind):
         w.set_transforms(roots, new_root)
         w.set_local_transforms(inner, new_inner)
     assert H.transforms_bits_equal(worlds[0].get_transforms(), worlds[1].get_transforms())
-    assert H.transforms_bits_equal(worlds[0].get_local_transforms(), worlds[1].get_local_transforms())
+    # stored locals: compared for entities that HAVE a parent. For a root with children the reference's Hierarchy record is emplaced
+    # without initialising local_transform (world.cpp:681-687), so World::getLocalTransform returns indeterminate memory for it.
+    kids = h["parent"] >= 0
+    assert H.transforms_bits_equal(worlds[0].get_local_transforms()[kids], worlds[1].get_local_transforms()[kids])
 
 
 def test_world_moves_refresh_culling_spheres(oracle_port, oracle_ref):

@@ -1,7 +1,9 @@
 """Scene ingest (World::serialize / deserialize, engine/world.cpp:837-1043): the product's host-side parser and its own LZ4 block
 decoder, against blobs compressed by the LZ4 the reference vendors (external/lz4/lz4.c compiled in place into oracle/_ref) and
-against the committed fixture tests/golden/world_blob.bin. The World record layout itself is restated (world.cpp does not compile
-outside the engine): tests/helpers.write_world_blob."""
+against the committed fixtures. Two sources of bytes: the reference's OWN World::serialize (engine/world.cpp compiled in place into
+oracle/_ref: a real World built with createEntity / setParent / setLocalTransform / destroyEntity / setEntityName, then serialized;
+tests/golden/world_blob_ref.bin), and a restated writer (tests/helpers.write_world_blob) for layouts the real World cannot produce
+here (module names in the header, hand-made hierarchy records, adversarial names)."""
 import ctypes as C
 import os
 
@@ -59,12 +61,107 @@ def check(data, n, ents, world, hier, h):
             assert parent[e] == -1 and valid[e] == 0 and tuple(tr[e]["rot"]) == (0, 0, 0, 1) and tuple(tr[e]["scale"]) == (1, 1, 1)
 
 
+def make_reference_world(oracle_ref, seed=5):
+    """A real World (reference object code): fan hierarchy, three leaves destroyed (holes in the entity list), two names."""
+    h = scenes.hierarchy_fans(12, 3, 3, seed=seed)
+    n = len(h["parent"])
+    w = oracle_ref.world(n)
+    roots, kids = np.flatnonzero(h["parent"] < 0).astype(np.int32), np.flatnonzero(h["parent"] >= 0).astype(np.int32)
+    w.init_transforms(roots, h["local"][roots])
+    w.set_parents(h["parent"][kids], kids)
+    w.set_local_transforms(kids, h["local"][kids])
+    has_child = np.zeros(n, bool)
+    has_child[h["parent"][kids]] = True
+    gone = [int(e) for e in np.flatnonzero(~has_child & (h["parent"] >= 0))[[1, 7, 20]]]
+    for e in gone:
+        w.destroy_entity(e)
+    w.set_name(3, "crate")
+    w.set_name(5, "lamp")
+    return w, h, gone
+
+
+def check_against_world(data, w, h, gone, flags):
+    info, parent, tr, wtr, valid = api.world_blob_read(data)
+    n = len(h["parent"])
+    alive = np.ones(n, bool)
+    alive[gone] = False
+    assert info["version"] == 6 and info["flags"] == flags and info["n_entities"] == int(alive.sum()) and info["n_names"] == 2
+    assert np.array_equal(valid[:n].astype(bool), alive)
+    want_parent = np.where(alive, h["parent"], -1)
+    assert np.array_equal(parent[:n], want_parent)
+    wt, lt = w.get_transforms(), w.get_local_transforms()
+    kids, roots = alive & (h["parent"] >= 0), alive & (h["parent"] < 0)
+    assert H.transforms_bits_equal(wtr[:n][alive], wt[alive])
+    assert H.transforms_bits_equal(tr[:n][kids], lt[kids]) and H.transforms_bits_equal(tr[:n][roots], wt[roots])
+    return info, parent, tr, wtr, valid
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_parser_reads_reference_world_serialize(oracle_ref, flags):
+    """The product's parser + LZ4 decoder on the bytes of the reference's own World::serialize (flags: HAS_PARTITIONS)."""
+    w, h, gone = make_reference_world(oracle_ref)
+    data = w.serialize(flags)
+    check_against_world(data, w, h, gone, flags)
+
+
+def test_restated_writer_matches_reference_serializer(oracle_ref):
+    """tests/helpers.write_world_blob (used for the hand-made layouts below) against World::serialize, byte for byte, on a world both
+    can express: no modules, the real World's hierarchy record order read back from its own blob."""
+    import struct
+    w, h, gone = make_reference_world(oracle_ref)
+    data = w.serialize(0)
+    info, parent, tr, wtr, valid = api.world_blob_read(data)
+    ents = [int(e) for e in np.flatnonzero(valid)]
+    # hierarchy records in file order, decoded from the reference's uncompressed blob with the product's own LZ4 decoder
+    ref_lz4(oracle_ref)  # declares the argtypes
+    unc, comp = struct.unpack_from("<II", data, 16)  # WorldHeader (8) + module count (4, = 0) + flags (4)
+    assert 24 + comp == len(data) and unc == info["uncompressed_size"]
+    buf = C.create_string_buffer(unc)
+    assert oracle_ref.lib.ref_lz4_decompress(data[24:], comp, buf, unc) == unc
+    raw = buf.raw
+    off = 4 + len(ents) * (4 + 52) + 4
+    n_names = struct.unpack_from("<I", raw, off)[0]
+    off += 4
+    names = []
+    for _ in range(n_names):
+        e = struct.unpack_from("<i", raw, off)[0]
+        end = raw.index(b"\0", off + 4)
+        names.append((e, raw[off + 4:end].decode()))
+        off = end + 1
+    n_h = struct.unpack_from("<I", raw, off)[0]
+    off += 4
+    hier = []
+    for _ in range(n_h):
+        e, p, fc, ns = struct.unpack_from("<4i", raw, off)
+        local = np.zeros(1, tr.dtype)
+        vals = struct.unpack_from("<3d4f3f", raw, off + 16)
+        local["pos"], local["rot"], local["scale"] = vals[0:3], vals[3:7], vals[7:10]
+        hier.append((e, p, fc, ns, local[0]))
+        off += 16 + 52
+    mine, blob = H.write_world_blob(ents, wtr[ents], hier, module_names=(), names=names, compress=ref_lz4(oracle_ref), n_slots=len(h["parent"]))
+    assert blob == raw and mine == data
+
+
 @pytest.mark.parametrize("partitions", [False, True])
 def test_blob_roundtrip_with_reference_lz4(oracle_ref, partitions):
     n, ents, world, hier, h = make_world(partitions=partitions)
     data, blob = H.write_world_blob(ents, world[ents], hier, names=[(ents[3], "crate"), (ents[5], "lamp")], partitions=partitions, compress=ref_lz4(oracle_ref))
     assert len(data) < len(blob) + 64  # it did compress (transforms repeat little, names / indices do)
     check(data, n, ents, world, hier, h)
+
+
+def test_committed_reference_fixture():
+    """tests/golden/world_blob_ref.bin is the output of the reference's own World::serialize (tests/golden/make_golden.py)."""
+    data = open(os.path.join(G, "world_blob_ref.bin"), "rb").read()
+    g = np.load(os.path.join(G, "world_blob_ref.npz"))
+    info, parent, tr, wtr, valid = api.world_blob_read(data)
+    n = len(g["parent"])
+    alive = g["alive"].astype(bool)
+    assert np.array_equal(parent[:n], g["parent"]) and np.array_equal(valid[:n].astype(bool), alive)
+    assert H.transforms_bits_equal(wtr[:n][alive], g["world"][alive])
+    kids = alive & (g["parent"] >= 0)
+    assert H.transforms_bits_equal(tr[:n][kids], g["local"][kids])
+    assert info["n_names"] == 2 and info["flags"] == 1
 
 
 def test_committed_fixture():
