@@ -10,7 +10,7 @@
  *   src/core/math.cpp                 Vec3/DVec3/Quat/Transform/LocalRigidTransform/Matrix arithmetic
  *   src/core/simd.h                   scalar float4 fallback (f4MoveMask == `x < 0`, :332-338)
  *   src/engine/world.cpp              transformEntity / setParent / setTransform / setLocalTransform
- *   src/renderer/pose.cpp             Pose::computeAbsolute (scalar recurrence)
+ *   src/renderer/pose.cpp             Pose::computeAbsolute (scalar recurrence; bit-identical to the reference's 4-wide path, pinned)
  *   src/renderer/model.cpp            invert, computeSkinMatrices, evaluateSkin
  *   src/renderer/pipeline.cpp         createSortKeys (:3789-3968) — pinned against the reference's own function sliced into
  *                                     oracle/_ref (oracle/ref/slice_sort_keys.py), see orc_create_sort_keys
@@ -19,7 +19,8 @@
  *
  * Pinning: the reference has NO tests or golden vectors for this path. The restatement is pinned
  * instead against the reference's own object code (oracle/_ref/liblmx_ref.so = reference math.cpp + geometry.cpp +
- * culling_system.cpp + page_allocator.cpp compiled in place, animation sampler and createSortKeys sliced from their files,
+ * culling_system.cpp + page_allocator.cpp + world.cpp compiled in place; pose / palette / skin code, animation sampler and
+ * createSortKeys sliced from pose.cpp / model.cpp / pipeline.cpp / animation.cpp at build time,
  * see oracle/Makefile) by tests/test_oracle_vs_ref.py, and against the golden fixtures under
  * tests/golden/ that were generated from that library (tests/golden/make_golden.py).
  *

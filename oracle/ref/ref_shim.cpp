@@ -4,9 +4,10 @@
 // src/core/math.cpp and src/core/geometry.cpp compiled in place; the result goes to oracle/_ref/liblmx_ref.so.
 // Every arithmetic operation below is executed by reference symbols (Vec3/DVec3/Quat/Transform/Matrix/
 // LocalRigidTransform/Frustum/ShiftedFrustum/Viewport methods and the scalar float4 of core/simd.h).
-// The *drivers* that cannot compile outside the engine (pose.cpp / model.cpp need the resource system and renderer) are restated
-// here, each citing the lines it follows. The culling system and the World are NOT among them: the reference's culling_system.cpp
-// and world.cpp themselves are compiled, see cull_shim.cpp / world_shim.cpp.
+// What is left in THIS file are thin wrappers over reference symbols (frusta, compose / computeLocal, bone attachment, LZ4, the random
+// generator). The culling system, the World, the pose / palette / skin code, the animation sampler and createSortKeys are the
+// reference's own code too: compiled in place or sliced at build time, see cull_shim.cpp, world_shim.cpp, pose_shim.cpp, anim_shim.cpp,
+// keys_shim.cpp.
 //   Pose::computeAbsolute        renderer/pose.cpp:129-130 (scalar recurrence; the 4-wide path :69-127 is
 //                                arithmetically identical, see core/simd_math.h:47-91)
 //   invert/computeSkinMatrices/evaluateSkin   renderer/model.cpp:24-30, 132-137, 103-109
@@ -155,102 +156,8 @@ void ref_compute_local(const LmxTransform* parent, const LmxTransform* child, Lm
 // World hierarchy: the reference's own engine/world.cpp, compiled in place; the C entry points (ref_world_*) live in
 // oracle/ref/world_shim.cpp.
 
-// ---------------------------------------------------------------------------------------------------------
-// pose / palette / linear-blend skin
-// ---------------------------------------------------------------------------------------------------------
-// Pose::computeAbsolute scalar recurrence, renderer/pose.cpp:129-130, over `n_instances` poses laid out back to back
-// Pose::blend (renderer/pose.cpp:30-41) on the reference's own Vec3 operators, clamp and nlerp (core/math.cpp:677-691)
-void ref_pose_blend(float* positions, float* rotations, const float* rhs_positions, const float* rhs_rotations, uint32_t count, float weight) {
-	Vec3* pos = reinterpret_cast<Vec3*>(positions);
-	Quat* rot = reinterpret_cast<Quat*>(rotations);
-	const Vec3* rpos = reinterpret_cast<const Vec3*>(rhs_positions);
-	const Quat* rrot = reinterpret_cast<const Quat*>(rhs_rotations);
-	if (weight <= 0.001f) return;
-	weight = clamp(weight, 0.0f, 1.0f);
-	float inv = 1.0f - weight;
-	for (int i = 0, c = (int)count; i < c; ++i) {
-		pos[i] = pos[i] * inv + rpos[i] * weight;
-		rot[i] = nlerp(rot[i], rrot[i], weight);
-	}
-}
+// pose / palette / linear-blend skin / dual quaternions: the reference's own code, sliced at build time - see oracle/ref/pose_shim.cpp.
 
-void ref_pose_compute_absolute(float* positions, float* rotations, const int16_t* parents, int32_t first_nonroot,
-	uint32_t count, uint32_t n_instances, int n_threads) {
-	lmx_ref::forEachJob(n_instances, n_threads, [&](u32 inst) {
-		Vec3* pos = (Vec3*)(positions + (size_t)inst * count * 3);
-		Quat* rot = (Quat*)(rotations + (size_t)inst * count * 4);
-		for (u32 i = (u32)first_nonroot; i < count; ++i) {
-			const i32 parent = parents[i];
-			pos[i] = rot[parent].rotate(pos[i]) + pos[parent];
-			rot[i] = rot[parent] * rot[i];
-		}
-	});
-}
-
-void ref_invert_bind(const LmxLocalRigidTransform* bind, LmxLocalRigidTransform* out, uint32_t n) { // model.cpp:24-30
-	for (uint32_t i = 0; i < n; ++i) {
-		LocalRigidTransform tr;
-		memcpy((void*)&tr, &bind[i], sizeof(tr));
-		LocalRigidTransform result;
-		result.rot = tr.rot.conjugated();
-		result.pos = result.rot.rotate(-tr.pos);
-		memcpy(&out[i], &result, sizeof(result));
-	}
-}
-
-// computeSkinMatrices, model.cpp:132-137, for n_instances poses sharing one model's inverse bind
-void ref_skin_matrices(const float* pose_pos, const float* pose_rot, const LmxLocalRigidTransform* inv_bind, LmxMatrix* out,
-	uint32_t count, uint32_t n_instances, int n_threads) {
-	lmx_ref::forEachJob(n_instances, n_threads, [&](u32 inst) {
-		const Vec3* pos = (const Vec3*)(pose_pos + (size_t)inst * count * 3);
-		const Quat* rot = (const Quat*)(pose_rot + (size_t)inst * count * 4);
-		Matrix* matrices = (Matrix*)(out + (size_t)inst * count);
-		for (u32 i = 0; i < count; ++i) {
-			LocalRigidTransform tmp = {pos[i], rot[i]};
-			LocalRigidTransform inv;
-			memcpy((void*)&inv, &inv_bind[i], sizeof(inv));
-			matrices[i] = (tmp * inv).toMatrix();
-		}
-	});
-}
-
-// computeSkeletonDualQuats scalar tail, pipeline.cpp:2739-2743: (tmp * inverse_bind).toDualQuat() with the reference's symbols
-void ref_dual_quats(const float* pose_pos, const float* pose_rot, const LmxLocalRigidTransform* inv_bind, float* out, uint32_t count,
-	uint32_t n_instances) {
-	static_assert(sizeof(DualQuat) == 32, "DualQuat layout");
-	for (uint32_t inst = 0; inst < n_instances; ++inst) {
-		const Vec3* pos = (const Vec3*)(pose_pos + (size_t)inst * count * 3);
-		const Quat* rot = (const Quat*)(pose_rot + (size_t)inst * count * 4);
-		DualQuat* o = (DualQuat*)(out + (size_t)inst * count * 8);
-		for (u32 i = 0; i < count; ++i) {
-			LocalRigidTransform tmp = {pos[i], rot[i]};
-			LocalRigidTransform inv;
-			memcpy((void*)&inv, &inv_bind[i], sizeof(inv));
-			o[i] = (tmp * inv).toDualQuat();
-		}
-	}
-}
-
-// evaluateSkin, model.cpp:103-109, for n_instances palettes over one mesh
-void ref_evaluate_skin(const float* verts, const LmxSkin* skin, const LmxMatrix* palettes, float* out, uint32_t n_verts,
-	uint32_t n_bones, uint32_t n_instances, int n_threads) {
-	lmx_ref::forEachJob(n_instances, n_threads, [&](u32 inst) {
-		const Matrix* matrices = (const Matrix*)(palettes + (size_t)inst * n_bones);
-		float* o = out + (size_t)inst * n_verts * 3;
-		for (u32 v = 0; v < n_verts; ++v) {
-			const LmxSkin& s = skin[v];
-			const Vec3 p(verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]);
-			Matrix m = matrices[s.indices[0]] * s.weights[0] + matrices[s.indices[1]] * s.weights[1] +
-					   matrices[s.indices[2]] * s.weights[2] + matrices[s.indices[3]] * s.weights[3];
-			const Vec3 r = m.transformPoint(p);
-			o[3 * v] = r.x;
-			o[3 * v + 1] = r.y;
-			o[3 * v + 2] = r.z;
-		}
-	});
-}
-
-// Marsaglia generator used for seeded scenes, core/math.cpp:1333-1341
 void ref_rand_fill(uint32_t u, uint32_t v, uint32_t n, uint32_t* out) {
 	RandomGenerator g(u, v);
 	for (uint32_t i = 0; i < n; ++i) out[i] = g.rand();
@@ -259,8 +166,9 @@ void ref_rand_fill(uint32_t u, uint32_t v, uint32_t n, uint32_t* out) {
 const char* ref_describe(void) {
 	return "reference object code (g++ -O2 -msse2 -ffp-contract=off): src/core/math.cpp + geometry.cpp, renderer/culling_system.cpp + "
 		   "core/page_allocator.cpp + core/linux/atomic.cpp compiled in place (job threads, Mutex, os::mem* underneath are stand-ins), "
-		   "animation sampler and createSortKeys sliced from animation.cpp / pipeline.cpp; World / pose / skin drivers restated in "
-		   "oracle/ref/ref_shim.cpp";
+		   "engine/world.cpp + core string / stream / hash / log / allocators compiled in place; animation sampler, createSortKeys, "
+		   "Pose::blend / computeAbsolute / computeRelative, computeSkeletonDualQuats, invert / computeSkinMatrices / evaluateSkin sliced "
+		   "from animation.cpp / pipeline.cpp / pose.cpp / model.cpp at build time";
 }
 
 } // extern "C"

@@ -40,10 +40,8 @@ def block(text, anchor, open_ch="{", close_ch="}", trailer=""):
     return text[a:end]
 
 
-def main():
-    ref, out = sys.argv[1], sys.argv[2]
-    os.makedirs(out, exist_ok=True)
-    src = os.path.join(ref, "src")
+def sse_branch(src):
+    """the `float4 = __m128` branch of src/core/simd.h without its operator overloads"""
     simd = open(os.path.join(src, "core", "simd.h")).read()
     cond = "#if defined _WIN32 && !defined __clang__"
     first = simd.index(cond)
@@ -62,6 +60,14 @@ def main():
         body = cut[cut.index("{"):]
         assert body.count("_mm_") in (1, 2), body
         sse = sse.replace(cut, "// (operator overload dropped: built-in vector operator, see slice_animation.py)")
+    return sse
+
+
+def main():
+    ref, out = sys.argv[1], sys.argv[2]
+    os.makedirs(out, exist_ok=True)
+    src = os.path.join(ref, "src")
+    sse = sse_branch(src)
     open(os.path.join(out, "simd_sse.inc"), "w").write(sse + "\n")
 
     sm = open(os.path.join(src, "core", "simd_math.h")).read()

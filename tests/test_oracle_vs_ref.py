@@ -243,10 +243,35 @@ def test_world_moves_refresh_culling_spheres(oracle_port, oracle_ref):
     assert H.transforms_bits_equal(results[0][1], results[1][1])
 
 
-def test_pose_palette_skin_bit_exact(oracle_port, oracle_ref):
-    sk = scenes.skeleton(64, seed=4)
-    pos, rot = scenes.relative_poses(8, 64, seed=5)
-    verts, skin = scenes.skinned_mesh(3000, 64, seed=6)
+def simd_path_groups(parents, first_nonroot):
+    """how many aligned groups of four bones take Pose::computeAbsolute's 4-wide path (pose.cpp:66-76: i % 4 == 0, i + 4 <= count, all four
+    parents < i), walking exactly like the reference does"""
+    n, i, groups = len(parents), first_nonroot, 0
+    while i < n:
+        if i % 4 == 0 and i + 4 <= n and all(0 <= int(parents[i + j]) < i for j in range(4)):
+            groups += 1
+            i += 4
+        else:
+            i += 1
+    return groups
+
+
+@pytest.mark.parametrize("shape", ["random64", "wide", "chain", "odd37", "tiny3"])
+def test_pose_palette_skin_bit_exact(oracle_port, oracle_ref, shape):
+    """The scalar restatement against the reference's own Pose::computeAbsolute - whose aligned groups of four bones go through the 4-wide
+    SOA rotate / quaternion product of simd_math.h - computeSkeletonDualQuats (4-wide toDualQuat batches + scalar tail),
+    computeSkinMatrices, evaluateSkin and invert, sliced from pose.cpp / pipeline.cpp / model.cpp into oracle/_ref. Skeleton shapes
+    that send every group ("wide"), some groups ("random64", "odd37") and no group ("chain", "tiny3") down the SIMD path."""
+    n_bones = {"random64": 64, "wide": 64, "chain": 32, "odd37": 37, "tiny3": 3}[shape]
+    sk = scenes.skeleton(n_bones, seed=4)
+    if shape == "wide":  # every bone hangs off a bone of an earlier group of four
+        sk["parents"][1:] = [max(0, (i // 4) * 4 - 1 - (i % 3)) if i >= 4 else 0 for i in range(1, n_bones)]
+    elif shape == "chain":
+        sk["parents"][1:] = np.arange(n_bones - 1)
+    groups = simd_path_groups(sk["parents"], sk["first_nonroot"])
+    assert {"random64": groups > 2, "wide": groups == 15, "chain": groups == 0, "odd37": groups > 0, "tiny3": groups == 0}[shape], groups
+    pos, rot = scenes.relative_poses(8, n_bones, seed=5)
+    verts, skin = scenes.skinned_mesh(3000, n_bones, seed=6)
     out = []
     for o in (oracle_port, oracle_ref):
         inv = o.invert_bind(sk["bind"])
