@@ -94,7 +94,7 @@ static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustu
 // F == 1: the single-frustum kernel (the common case: one launch per view). F == 0: n_frusta (2..8) is a runtime value and every
 // per-frustum loop is a real loop, so registers do not scale with the number of frusta (8 unrolled copies needed 172 VGPRs and
 // 600 spilled SGPRs); FS is the stride of a chunk's visibility bits.
-template <int F, int WAVES, int CHW, int GRP, bool LANEPAR>
+template <int F, int WAVES, int CHW, int GRP, int LANEPAR>
 __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg, const float4* __restrict__ g_spheres, const int32_t* __restrict__ g_ids,
 	const ChunkHdr* __restrict__ g_hdr, const CellKey* __restrict__ g_tile_cells, const uint32_t* __restrict__ g_tile_tab, const TileBox* __restrict__ g_tile_box,
 	const uint32_t* __restrict__ g_win_base, int32_t* __restrict__ g_out_ids, uint32_t* __restrict__ g_counts, uint32_t* __restrict__ g_counts_next, const TileScalars a) {
@@ -118,9 +118,24 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg
 	// 0. tile-level test per frustum (2 bits each). Everything read here sits at addresses that depend on blockIdx only.
 	uint32_t st_bits = 0, tile_flags = 0;
 	bool any_mixed = false, any_live = false;
-	if constexpr (LANEPAR) {
+	if constexpr (LANEPAR != 0) {
 		static_assert(F == 1, "the lane-parallel tile test handles one frustum");
-		const uint32_t r = tile_status_lanes(g_tile_box + tile_index, lane);
+		uint32_t r;
+		if constexpr (LANEPAR == 2) {
+			// wave 0 alone evaluates the verdict and hands it to the others through LDS: on a launch where most tiles are rejected
+			// here, the other waves' ~80 VALU instructions each were most of what the chip executed (all-rejected launch of 4883
+			// tiles: 8.9 -> 7.3 us, the headline camera 13.1 -> 11.9 us; a launch of the same shape that does nothing takes 1.8 us,
+			// with one dependent load per block 2.8 us - tools/launch_floor_probe.hip)
+			__shared__ uint32_t s_verdict;
+			if (wave == 0) {
+				const uint32_t v = tile_status_lanes(g_tile_box + tile_index, lane);
+				if (lane == 0) s_verdict = v;
+			}
+			__syncthreads();
+			r = s_verdict;
+		} else {
+			r = tile_status_lanes(g_tile_box + tile_index, lane);
+		}
 		st_bits = r & 3u;
 		tile_flags = r >> 2;
 		any_mixed = st_bits == TILE_MIXED;
@@ -447,7 +462,7 @@ __global__ __launch_bounds__(256) void k_cull_consolidate(const int32_t* __restr
 	for (uint32_t k = blockIdx.z * 256u + threadIdx.x; k < n; k += gridDim.z * 256u) to[k] = from[k];
 }
 
-template <int F, int WAVES, int CHW, int GRP, bool LANEPAR>
+template <int F, int WAVES, int CHW, int GRP, int LANEPAR>
 hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt, const FrustaArg& fr, int n_frusta,
 	const CullOut& out) {
 	constexpr uint32_t TILE = WAVES * CHW * 64;
@@ -479,31 +494,26 @@ uint32_t cull_tile_size(int n_frusta, int variant) {
 }
 
 hipError_t launch_cull_tile(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt, const FrustaArg& fr,
-	int n_frusta, const CullOut& out, int variant, bool lane_parallel_status) {
+	int n_frusta, const CullOut& out, int variant, int lane_parallel_status) {
 #define LMX_TILE(F, W, C, G, L) return tile_f<F, W, C, G, L>(s, v, ent_begin, ent_end, tt, fr, n_frusta, out)
 	if (n_frusta < 1 || n_frusta > MAX_FRUSTA) return hipErrorInvalidValue;
 	if (n_frusta == 1) {
-		if (lane_parallel_status) {
-			switch (variant) {
-				case 0: LMX_TILE(1, 8, 8, 4, true);
-				case 1: LMX_TILE(1, 4, 8, 4, true);
-				case 2: LMX_TILE(1, 8, 4, 4, true);
-				case 3: LMX_TILE(1, 4, 4, 4, true);
-				case 4: LMX_TILE(1, 4, 8, 8, true);
-				default: LMX_TILE(1, 8, 8, 8, true);
-			}
+#define LMX_TILE_VARIANTS(L) \
+		switch (variant) { \
+			case 0: LMX_TILE(1, 8, 8, 4, L); \
+			case 1: LMX_TILE(1, 4, 8, 4, L); \
+			case 2: LMX_TILE(1, 8, 4, 4, L); \
+			case 3: LMX_TILE(1, 4, 4, 4, L); \
+			case 4: LMX_TILE(1, 4, 8, 8, L); \
+			default: LMX_TILE(1, 8, 8, 8, L); \
 		}
-		switch (variant) {
-			case 0: LMX_TILE(1, 8, 8, 4, false);
-			case 1: LMX_TILE(1, 4, 8, 4, false);
-			case 2: LMX_TILE(1, 8, 4, 4, false);
-			case 3: LMX_TILE(1, 4, 4, 4, false);
-			case 4: LMX_TILE(1, 4, 8, 8, false);
-			default: LMX_TILE(1, 8, 8, 8, false);
-		}
+		if (lane_parallel_status == 2) LMX_TILE_VARIANTS(2)
+		if (lane_parallel_status == 1) LMX_TILE_VARIANTS(1)
+		LMX_TILE_VARIANTS(0)
+#undef LMX_TILE_VARIANTS
 	}
-	if (n_frusta <= 4) LMX_TILE(0, 8, 4, 4, false); // 2048-sphere tiles, <= 4 x 32 B of LDS per cell
-	LMX_TILE(0, 4, 4, 4, false);                    // 1024-sphere tiles
+	if (n_frusta <= 4) LMX_TILE(0, 8, 4, 4, 0); // 2048-sphere tiles, <= 4 x 32 B of LDS per cell
+	LMX_TILE(0, 4, 4, 4, 0);                    // 1024-sphere tiles
 #undef LMX_TILE
 }
 

@@ -114,6 +114,7 @@ struct CullState {
 	uint32_t max_tile_cells[3] = {0, 0, 0};
 	std::vector<uint32_t> block_live; // live ids per TILE_ALIGN-slot block at build time (capacity of the output shards)
 	double scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0}; // world-space box of the static set's occupied cells
+	double big_tile_fraction = 0;                             // share of the non-empty tiles that hold a big sphere (never rejected as a whole)
 	TypeTable tt = {};
 	// ---- dynamic set: entities bound to the world hierarchy + entities added / re-celled since the last compaction ----
 	std::vector<DynRec> dyn;
@@ -149,7 +150,7 @@ struct CullState {
 	// ---- tuning (lmx_cull_set_option) -------------------------------------------------------------------------
 	uint32_t pass_width = 1;   // frusta tested per pass over the static set
 	int tile_variant = -1;     // -1: chosen per cull from the frustum's coverage of the scene
-	bool lane_parallel = true; // tile-level box test evaluated one plane per lane (1-frustum kernels)
+	int lane_parallel = 2;     // tile-level box test of the 1-frustum kernels: 0 = uniform code in every wave, 1 = one plane per lane in every wave, 2 = one plane per lane in wave 0, verdict through LDS
 	uint32_t max_shards = LAYOUT_MAX_SHARDS; // output shards per type of the static set
 	uint32_t cnt_pad = 32;     // words between shard counters (32 = one 128-byte line each)
 	uint32_t out_total = 0;    // ids per frustum row = sum of the shard capacities

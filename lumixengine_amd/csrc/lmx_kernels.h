@@ -62,7 +62,7 @@ struct CullOut {
 size_t cull_tile_lds_bytes(int n_frusta, uint32_t cell_cap);
 uint32_t cull_tile_size(int n_frusta, int variant);
 hipError_t launch_cull_tile(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
-	const FrustaArg& fr, int n_frusta, const CullOut& out, int variant, bool lane_parallel_status);
+	const FrustaArg& fr, int n_frusta, const CullOut& out, int variant, int lane_parallel_status);
 
 // Dynamic set: entities whose transform changes every frame (bound to the world hierarchy) and entities added / re-celled since
 // the last compaction of the static set are kept UNSORTED as world position (fp64) + radius + id. Their cell, cell-relative

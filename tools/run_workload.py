@@ -51,8 +51,14 @@ def main():
             sc["radius"] = np.random.default_rng(5).uniform(300.5, 330.0, size=args.entities).astype(np.float32)
         cs = api.CullingSystem(ctx)
         cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+        if "LMX_TILE_TEST_MODE" in os.environ:
+            cs.setOption(api.CULL_OPT_LANE_PARALLEL_TILE_TEST, int(os.environ["LMX_TILE_TEST_MODE"]))
+        if "LMX_TILE_VARIANT" in os.environ:
+            cs.setOption(api.CULL_OPT_TILE_VARIANT, int(os.environ["LMX_TILE_VARIANT"]))
         if args.workload == "cull_stream" or os.environ.get("LMX_WORKLOAD_CAMERA") == "far":
             fr = api.viewport_frustum(pos=(0.0, 0.0, 60000.0), far=200000.0) if args.workload == "cull_dense" else api.viewport_frustum(pos=(0.0, 0.0, 4.0 * half), far=20.0 * half)
+        elif os.environ.get("LMX_WORKLOAD_CAMERA") == "nothing":  # every tile rejected by the tile-level test: the kernel's floor
+            fr = api.viewport_frustum(pos=(1.0e6, 50.0, -1.0e6))
         elif args.workload == "cull8":
             fr = H.cascade_frusta(api, 8)
         else:
