@@ -87,6 +87,26 @@ __device__ __forceinline__ uint32_t tile_status_lanes(const TileBox* box, uint32
 	return (__ballot(plane_lane && !in) == 0 ? TILE_ACCEPT : TILE_MIXED) | hi;
 }
 
+// sphere_visible_d() of lmx_math.h on packed fp32: two planes per v_pk_mul_f32 / v_pk_add_f32, every product and sum rounded on its own
+// exactly like the scalar expression ((cx*nx + cy*ny) + cz*nz) + d, then t - (-r) == t + r. The all-test launch was issue-bound (69 % of
+// all SIMD cycles were VALU, profiles/r02/cull_all_test_counters.json); the plane arithmetic is half of its VALU instructions.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const float d[6], float cx, float cy, float cz, float radius) {
+	const v2f x2 = {cx, cx}, y2 = {cy, cy}, z2 = {cz, cz}, r2 = {radius, radius};
+	bool culled = false;
+#pragma unroll
+	for (int k = 0; k < 6; k += 2) {
+		const v2f nx = {f.nx[k], f.nx[k + 1]}, ny = {f.ny[k], f.ny[k + 1]}, nz = {f.nz[k], f.nz[k + 1]}, dd = {d[k], d[k + 1]};
+		v2f t = x2 * nx;
+		t = t + y2 * ny;
+		t = t + z2 * nz;
+		t = t + dd;
+		t = t + r2;
+		culled = culled || (t.x < 0) || (t.y < 0);
+	}
+	return !culled;
+}
+
 // LDS record of one (cell, frustum): the six cell-relative plane distances of ShiftedFrustum::getRelative and the cell's class
 struct alignas(16) CellInfo { float d[6]; uint32_t cls, pad; };
 static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustum)");
@@ -277,7 +297,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg
 						float d[6];
 #pragma unroll
 						for (int k = 0; k < 6; ++k) d[k] = ci->d[k];
-						vis = sphere_visible_d(frp[f], d, sp[i].x, sp[i].y, sp[i].z, sp[i].w);
+						vis = sphere_visible_d_pk(frp[f], d, sp[i].x, sp[i].y, sp[i].z, sp[i].w);
 					}
 				} else {
 					vis = st == TILE_ACCEPT;
