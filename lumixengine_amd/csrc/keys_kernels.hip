@@ -56,9 +56,9 @@ __device__ __forceinline__ uint32_t float_flip(uint32_t bits) {
 constexpr int KEYS_BLOCK = 512; // 8 waves: 3 blocks per CU at 67 VGPRs
 
 // The visible list is walked in tiles of 512 entities by a fixed-size grid. Per tile every lane first COUNTS what it will
-// emit, the block reserves its output ranges with one atomic per list (4 per 512 entities: returning atomics on one address
-// retire at ~90 per microsecond chip-wide, one per wave and mesh was 15x slower than this kernel's memory work), and a second
-// walk writes at lane-private positions.
+// emit, the block reserves its four output ranges with two 64-bit atomics on two cache lines (returning atomics on one line retire at
+// ~90 per microsecond chip-wide: one per wave and mesh was 15x slower than this kernel's memory work), and a second walk writes at
+// lane-private positions.
 __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const KeysViewDevice kv /* by value: captured at launch */,
 	const int32_t* __restrict__ ids, const uint32_t* __restrict__ n_visible) {
 	__shared__ uint32_t s_wave[KEYS_BLOCK / 64][3]; // per wave: pairs | recs << 16, poses, dirty
@@ -151,12 +151,16 @@ __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const Ke
 		const uint64_t pose_mask = __ballot(push_pose), dirty_mask = __ballot(queue_dirty);
 		if (lane == 63) { s_wave[wave][0] = incl; s_wave[wave][1] = (uint32_t)__popcll(pose_mask); s_wave[wave][2] = (uint32_t)__popcll(dirty_mask); }
 		__syncthreads();
-		if (threadIdx.x < 4) {
-			uint32_t total = 0;
-			for (int w = 0; w < KEYS_BLOCK / 64; ++w)
-				total += threadIdx.x == 0 ? (s_wave[w][0] & 0xffffu) : threadIdx.x == 1 ? (s_wave[w][0] >> 16) : s_wave[w][threadIdx.x - 1];
-			const int which = threadIdx.x == 0 ? KEYS_N_PAIRS : threadIdx.x == 1 ? KEYS_N_RECS : threadIdx.x == 2 ? KEYS_N_POSES : KEYS_N_DIRTY;
-			s_base[threadIdx.x] = total ? atomicAdd(d.counters + which, total) : 0;
+		if (threadIdx.x < 2) { // thread 0: {pairs, recs}, thread 1: {poses, dirty} - one 64-bit returning atomic each
+			uint32_t lo = 0, hi = 0;
+			for (int w = 0; w < KEYS_BLOCK / 64; ++w) {
+				lo += threadIdx.x == 0 ? (s_wave[w][0] & 0xffffu) : s_wave[w][1];
+				hi += threadIdx.x == 0 ? (s_wave[w][0] >> 16) : s_wave[w][2];
+			}
+			unsigned long long base = 0;
+			if (lo | hi) base = atomicAdd(reinterpret_cast<unsigned long long*>(d.counters + (threadIdx.x == 0 ? KEYS_N_PAIRS : KEYS_N_POSES)), (unsigned long long)lo | ((unsigned long long)hi << 32));
+			s_base[2 * threadIdx.x] = (uint32_t)base;
+			s_base[2 * threadIdx.x + 1] = (uint32_t)(base >> 32);
 		}
 		__syncthreads();
 		uint32_t pair_at = s_base[0] + (incl & 0xffffu) - n_pairs, rec_at = s_base[1] + (incl >> 16) - n_recs;

@@ -166,7 +166,10 @@ hipError_t launch_anim_update(hipStream_t s, const SkinInstance* inst, uint32_t 
 	const float4* model_rel_rot, float* pose_pos, float4* pose_rot);
 
 // ---- createSortKeys (keys_kernels.hip) ----
-enum { KEYS_N_PAIRS = 0, KEYS_N_RECS = 1, KEYS_N_POSES = 2, KEYS_N_DIRTY = 3, KEYS_OVERFLOW = 4, KEYS_N_GROUPS = 5, KEYS_COUNTERS = 8 };
+// Counter words. {pairs, recs} and {poses, dirty} are two 64-bit cells on their own 128-byte lines: k_keys_mesh reserves a tile's four
+// output ranges with two returning atomics on two lines instead of four on one (measured: no change of the kernel's 124 us per
+// million visible entities - it is bound by its random 64-byte gathers and line write-backs, see DESIGN.md - but half the atomics).
+enum { KEYS_N_PAIRS = 0, KEYS_N_RECS = 1, KEYS_N_POSES = 32, KEYS_N_DIRTY = 33, KEYS_OVERFLOW = 64, KEYS_N_GROUPS = 96, KEYS_COUNTERS = 128 };
 struct KeysViewDevice { // what the kernels read of a LmxKeysView, bucket_map as built at pipeline.cpp:3802-3812
 	uint32_t bucket_map[255];
 	uint8_t layer_to_bucket[255];
