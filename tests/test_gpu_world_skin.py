@@ -217,6 +217,46 @@ def test_world_moves_refresh_culling(gpu_ctx, oracle_port):
             assert cs.getRadius(e) == ocs.get_radius(e)
 
 
+def test_rebinding_keeps_moved_spheres(gpu_ctx, oracle_port):
+    """bind A, propagate (spheres of A move on the device), bind A + B, cull WITHOUT another propagate: the entities of the first
+    binding keep their moved spheres (the rebuild of the dynamic set must not re-upload a stale host mirror), also when an entity
+    is dropped from the new list (it stays where the last refresh put it)."""
+    h = scenes.hierarchy_chains(1200, 3, seed=14, root_extent=1200.0)
+    n = len(h["parent"])
+    rng = np.random.default_rng(5)
+    model_radius = rng.uniform(0.5, 30.0, n).astype(np.float32)
+    ow, roots, kids = oracle_world(oracle_port, h)
+    ocs = oracle_port.culling_system()
+    tr0 = ow.get_transforms()
+    ent = np.arange(n, dtype=np.int32)
+    r0 = model_radius * tr0["scale"].max(axis=1)
+    ocs.add_bulk(ent, np.zeros(n, np.uint8), tr0["pos"], r0)
+    first = ent[: n // 2]
+    ow.bind_culling(ocs, first, model_radius[first])
+    w = api.World(gpu_ctx)
+    w.build(h["parent"], gpu_inputs(ow, h["parent"], roots))
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(ent, np.zeros(n, np.uint8), tr0["pos"], r0)
+    w.bindCulling(first, model_radius[first])
+    new_root = ow.get_transforms()[roots]
+    new_root["pos"] += rng.uniform(-900.0, 900.0, size=(len(roots), 3))
+    ow.set_transforms(roots, new_root)
+    w.setTransforms(roots, new_root)
+    w.propagate()
+    # second binding: everything except entity first[3], plus the other half
+    second = np.concatenate([np.delete(first, 3), ent[n // 2:]])
+    ow.bind_culling(ocs, second, model_radius[second])
+    w.bindCulling(second, model_radius[second])
+    fr = np.concatenate([api.viewport_frustum(pos=(0, 0, 1500.0)), api.viewport_frustum(pos=(-200.0, 30.0, 100.0), rot=H.quat_from_yaw_pitch(-0.8, 0.05))])
+    res = cs.cull(fr)
+    for f in range(len(fr)):
+        ids, types, _ = ocs.cull(fr[f : f + 1])
+        got_ids, got_types = res.all_ids(f)
+        H.assert_same_visible(H.sorted_by_type(got_ids, got_types), H.sorted_by_type(ids, types), f"frustum {f}")
+    for e in (0, 3, int(first[3]), n // 2 - 1, n - 1):
+        assert cs.getRadius(e) == ocs.get_radius(e)
+
+
 def close_1e5(got, want):
     """north star: skinned vertex positions within 1e-5 relative fp32 (relative to the magnitude of the positions)"""
     return np.allclose(got, want, rtol=1e-5, atol=1e-5 * float(np.abs(want).max()))
