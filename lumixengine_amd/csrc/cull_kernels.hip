@@ -89,7 +89,7 @@ __device__ __forceinline__ uint32_t tile_status_lanes(const TileBox* box, uint32
 
 // sphere_visible_d() of lmx_math.h on packed fp32: two planes per v_pk_mul_f32 / v_pk_add_f32, every product and sum rounded on its own
 // exactly like the scalar expression ((cx*nx + cy*ny) + cz*nz) + d, then t - (-r) == t + r. The all-test launch was issue-bound (69 % of
-// all SIMD cycles were VALU, profiles/r02/cull_all_test_counters.json); the plane arithmetic is half of its VALU instructions.
+// all SIMD cycles were VALU, profiles/r02/cull_all_test_counters_before_packed_fp32.json); the plane arithmetic is half of its VALU instructions.
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const float d[6], float cx, float cy, float cz, float radius) {
 	const v2f x2 = {cx, cx}, y2 = {cy, cy}, z2 = {cz, cz}, r2 = {radius, radius};

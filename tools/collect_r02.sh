@@ -24,6 +24,8 @@ pmc() { # name, command...
 W="python $ROOT/tools/run_workload.py"
 prof bench_headline python "$ROOT/bench.py" --headline-only --no-extras --no-cpu-baseline
 grep -h '^{' "$OUT/bench_headline.log" > "$OUT/bench_headline_under_rocprof.json" 2>/dev/null
+LMX_WORKLOAD_CAMERA=nothing prof cull_nothing_visible $W --workload cull_default --steps 200
+prof cull_default $W --workload cull_default --steps 200
 prof cull_all_test_warm $W --workload cull_all_test --steps 40
 prof cull_all_test_cold $W --workload cull_all_test --steps 40 --cold read
 prof cull_all_test_coldw $W --workload cull_all_test --steps 40 --cold write
@@ -37,4 +39,9 @@ pmc default $W --workload cull_default --steps 30
 pmc all_test_100m $W --workload cull_all_test --entities 100000000 --steps 8
 for w in xform skin keys target; do prof "$w" $W --workload "$w" --steps 12; done
 prof skin_distinct $W --workload skin_distinct --instances 1500 --steps 12
+# SQ counters (separate --pmc passes, kernel trace only) of the all-test leg and of the keys kernels
+bash "$ROOT/tools/collect_counters.sh" "$OUT/cnt" "cull_all_test keys" > "$OUT/cnt.log" 2>&1
+cp "$OUT/cnt/summary.json" "$OUT/cull_all_test_and_keys_counters.json" 2>/dev/null
+rm -rf "$OUT/cnt"
+"$ROOT/tools/_build/launch_floor_probe" > "$OUT/launch_floor.json" 2> /dev/null
 ls -la "$OUT"
