@@ -244,7 +244,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg
 	// (VGPR count decides how many tiles a CU keeps in flight). Fetching the headers at kernel start through lanes (one vector
 	// load + v_readlane) instead of scalar loads here measured no gain, HBM-cold included: other waves cover the load.
 	const uint32_t chunk0 = (tile_ent >> 6) + wave * CHW;
-	const uint64_t le_mask = (~0ull >> (63u - lane)) & ~1ull; // bits 1..lane
 	static_assert(CHW % GRP == 0, "groups tile the wave's chunks");
 	int32_t id[CHW];
 	uint32_t vis_bits = 0; // bit i * FS + f: sphere `lane` of chunk i is visible in frustum f
@@ -260,7 +259,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg
 			local[i] = 0;
 			if (any_mixed) {
 				const ChunkHdr h = g_hdr[chunk0 + g + i]; // wave-uniform: one 16-byte scalar load
-				local[i] = h.cell + (uint32_t)__popcll(h.flags & le_mask) - first_cell;
+				local[i] = h.cell + mbcnt64(h.flags >> 1) - first_cell; // cell boundaries at positions 1..lane: two v_mbcnt on a wave-uniform mask
 #pragma unroll 1
 				for (int f = 0; f < nf; ++f) {
 					const uint32_t cls = s_info[f * a.cell_cap + local[i]].cls;
