@@ -126,12 +126,13 @@ void mark_patch(CullState& cs, uint32_t rec) {
 	if (!layout_live(cs)) return;
 	const CullRec& r = cs.recs[rec];
 	const PatchSphere p{cs.rec_slot[rec], r.rel.x, r.rel.y, r.rel.z, r.radius};
-	auto it = cs.q_sphere_at.find(p.slot);
-	if (it != cs.q_sphere_at.end()) {
-		cs.q_sphere[it->second] = p;
+	if (cs.q_sphere_at.size() < cs.n_padded) cs.q_sphere_at.resize(cs.n_padded, ~0u);
+	uint32_t& at = cs.q_sphere_at[p.slot];
+	if (at != ~0u) { // set twice before the next flush: the last write wins
+		cs.q_sphere[at] = p;
 		return;
 	}
-	cs.q_sphere_at.emplace(p.slot, (uint32_t)cs.q_sphere.size());
+	at = (uint32_t)cs.q_sphere.size();
 	cs.q_sphere.push_back(p);
 }
 
@@ -144,8 +145,8 @@ DV3 stored_position(DV3 pos) {
 }
 
 void clear_static_queues(CullState& cs) {
+	for (const PatchSphere& p : cs.q_sphere) if (p.slot < cs.q_sphere_at.size()) cs.q_sphere_at[p.slot] = ~0u;
 	cs.q_sphere.clear();
-	cs.q_sphere_at.clear();
 	cs.q_id.clear();
 }
 void clear_dyn_queue(CullState& cs) {
@@ -164,7 +165,9 @@ DynDeviceView dyn_view(const CullState& cs) {
 	return dd;
 }
 
-// Ship the queued patch records: one pinned staging copy, one asynchronous H2D copy, one kernel — no host wait.
+// Ship the queued patch records: one copy into pinned, device-visible host memory and ONE kernel that reads the records from there
+// (a frame's records are tens of KB; the H2D copy call alone cost more host time than the 2000 mirror updates it carried) - no host
+// wait: the two staging halves alternate, a half is rewritten two flushes after the kernel that read it was enqueued.
 int apply_patches(LmxContext* ctx) {
 	CullState& cs = ctx->cull;
 	const size_t n_ps = cs.q_sphere.size(), n_pi = cs.q_id.size(), n_pd = cs.q_dyn.size();
@@ -176,29 +179,27 @@ int apply_patches(LmxContext* ctx) {
 	const uint32_t k = st.next;
 	st.next ^= 1u;
 	if (!st.done[k]) LMX_HIP(ctx, hipEventCreateWithFlags(&st.done[k], hipEventDisableTiming));
-	else LMX_HIP(ctx, hipEventSynchronize(st.done[k])); // the copy that last used this half (two flushes ago) has long finished
+	else LMX_HIP(ctx, hipEventSynchronize(st.done[k])); // the kernel that last read this half (two flushes ago) has long finished
 	if (st.cap[k] < total) {
 		if (st.host[k]) LMX_HIP(ctx, hipHostFree(st.host[k]));
 		st.host[k] = nullptr;
+		st.dev[k] = nullptr;
 		st.cap[k] = 0;
 		const size_t want = std::max<size_t>(total * 2, 1u << 16);
-		LMX_HIP(ctx, hipHostMalloc(&st.host[k], want, hipHostMallocDefault));
+		LMX_HIP(ctx, hipHostMalloc(&st.host[k], want, hipHostMallocMapped));
+		LMX_HIP(ctx, hipHostGetDevicePointer(&st.dev[k], st.host[k], 0));
 		st.cap[k] = want;
-	}
-	if (cs.d_patch.cap < total) {
-		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // an earlier patch kernel may still read the old buffer
-		LMX_HIP(ctx, cs.d_patch.reserve(std::max<size_t>(total * 2, 1u << 16)));
 	}
 	char* h = (char*)st.host[k];
 	if (b_pd) memcpy(h + o_pd, cs.q_dyn.data(), b_pd);
 	if (b_ps) memcpy(h + o_ps, cs.q_sphere.data(), b_ps);
 	if (b_pi) memcpy(h + o_pi, cs.q_id.data(), b_pi);
+	const char* d = (const char*)st.dev[k];
 	ProfScope ps(ctx, LMX_K_CULL_PATCH);
-	LMX_HIP(ctx, hipMemcpyAsync(cs.d_patch.p, h, total, hipMemcpyHostToDevice, ctx->stream));
-	LMX_HIP(ctx, hipEventRecord(st.done[k], ctx->stream));
 	TileBox* const boxes[3] = {cs.tile_box[0].p, cs.tile_box[1].p, cs.tile_box[2].p};
-	LMX_HIP(ctx, launch_apply_patches(ctx->stream, cs.spheres.p, cs.ids.p, boxes, dyn_view(cs), (const PatchSphere*)(cs.d_patch.p + o_ps), (uint32_t)n_ps,
-		(const PatchId*)(cs.d_patch.p + o_pi), (uint32_t)n_pi, (const PatchDyn*)(cs.d_patch.p + o_pd), (uint32_t)n_pd));
+	LMX_HIP(ctx, launch_apply_patches(ctx->stream, cs.spheres.p, cs.ids.p, boxes, dyn_view(cs), (const PatchSphere*)(d + o_ps), (uint32_t)n_ps,
+		(const PatchId*)(d + o_pi), (uint32_t)n_pi, (const PatchDyn*)(d + o_pd), (uint32_t)n_pd));
+	LMX_HIP(ctx, hipEventRecord(st.done[k], ctx->stream));
 	clear_static_queues(cs);
 	clear_dyn_queue(cs);
 	return LMX_OK;
@@ -714,11 +715,41 @@ int lmx_cull_is_added(LmxContext* ctx, int32_t entity) {
 	return locate(ctx->cull, entity, &idx) != Where::NONE ? 1 : 0;
 }
 
-// Batched forms of add / remove for hosts that pay per call (ctypes, scripting): same semantics, one ABI crossing.
+// Batched forms of add / remove / set for hosts that pay per call (ctypes, scripting): same semantics, one ABI crossing. An update
+// touches 3-5 random entries of tables that hold one element per entity (entity -> record, record, record -> device slot): with 10 M
+// entities every one of them is a DRAM miss, and the misses of ONE update depend on each other. The batch forms run a two-stage
+// software prefetch ahead of the update loop (entity -> record index PF_FAR updates ahead, the record and its slot PF_NEAR ahead), so
+// the misses of neighbouring updates overlap.
+constexpr uint32_t PF_FAR = 24, PF_NEAR = 12;
+static inline void prefetch_update(const CullState& cs, const int32_t* entity, uint32_t n, uint32_t i) {
+	if (i + PF_FAR < n) {
+		const int32_t e = entity[i + PF_FAR];
+		if (e >= 0) {
+			if ((size_t)e < cs.ent_to_rec.size()) __builtin_prefetch(&cs.ent_to_rec[e]);
+			if ((size_t)e < cs.ent_to_dyn.size()) __builtin_prefetch(&cs.ent_to_dyn[e]);
+		}
+	}
+	if (i + PF_NEAR < n) {
+		const int32_t e = entity[i + PF_NEAR];
+		if (e >= 0 && (size_t)e < cs.ent_to_rec.size()) {
+			const int32_t r = cs.ent_to_rec[e]; // prefetched PF_FAR - PF_NEAR updates ago; may be stale by the time it is used: a hint only
+			if (r >= 0 && (size_t)r < cs.recs.size()) {
+				__builtin_prefetch(&cs.recs[r]);
+				if ((size_t)r < cs.rec_slot.size()) __builtin_prefetch(&cs.rec_slot[r]);
+			}
+		}
+		if (e >= 0 && (size_t)e < cs.ent_to_dyn.size()) {
+			const int32_t d = cs.ent_to_dyn[e];
+			if (d >= 0 && (size_t)d < cs.dyn.size()) __builtin_prefetch(&cs.dyn[d]);
+		}
+	}
+}
+
 int lmx_cull_add_many(LmxContext* ctx, uint32_t n, const int32_t* entity, const uint8_t* type, const double* pos_xyz, const float* radius) {
 	if (!ctx) return LMX_ERR_INVALID_ARGUMENT;
 	if (n && (!entity || !type || !pos_xyz || !radius)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
 	for (uint32_t i = 0; i < n; ++i) {
+		prefetch_update(ctx->cull, entity, n, i);
 		if (int rc = cull_add_impl(ctx, entity[i], type[i], pos_xyz + 3 * (size_t)i, radius[i])) return rc;
 	}
 	return LMX_OK;
@@ -728,6 +759,7 @@ int lmx_cull_set_many(LmxContext* ctx, uint32_t n, const int32_t* entity, const 
 	if (!ctx) return LMX_ERR_INVALID_ARGUMENT;
 	if (n && (!entity || !pos_xyz || !radius)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
 	for (uint32_t i = 0; i < n; ++i) {
+		prefetch_update(ctx->cull, entity, n, i);
 		if (int rc = cull_set_impl(ctx, entity[i], pos_xyz + 3 * (size_t)i, radius[i])) return rc;
 	}
 	return LMX_OK;
@@ -737,6 +769,7 @@ int lmx_cull_remove_many(LmxContext* ctx, uint32_t n, const int32_t* entity) {
 	if (!ctx) return LMX_ERR_INVALID_ARGUMENT;
 	if (n && !entity) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
 	for (uint32_t i = 0; i < n; ++i) {
+		prefetch_update(ctx->cull, entity, n, i);
 		if (int rc = cull_remove_impl(ctx, entity[i])) return rc;
 	}
 	return LMX_OK;
