@@ -3,9 +3,11 @@
 Two libraries export the same functions under different prefixes:
 
 * ``orc_*``  oracle/liblmx_oracle.so      plain-C restatement (oracle/lmx_oracle.c), always buildable
-* ``ref_*``  oracle/_ref/liblmx_ref.so    the reference's own math.cpp/geometry.cpp object code + driver shim
-                                           (oracle/ref/ref_shim.cpp); only buildable where /root/reference exists,
-                                           but the built .so travels with the repo snapshot
+* ``ref_*``  oracle/_ref/liblmx_ref.so    the reference's OWN code: math.cpp, geometry.cpp, culling_system.cpp, page_allocator.cpp,
+                                           world.cpp compiled in place; pose / palette / skin code, the animation sampler and
+                                           createSortKeys sliced out of their files at build time (oracle/ref/*_shim.cpp,
+                                           slice_*.py); only buildable where /root/reference exists, but the built .so travels
+                                           with the repo snapshot
 
 Only tests/, bench.py's ``cpu_baseline`` leg and ``__graft_entry__.smoke()`` may import this module. The product
 package (lumixengine_amd) must never import it.
