@@ -536,18 +536,26 @@ hipError_t launch_cull_tile(hipStream_t s, const CullDeviceView& v, uint32_t ent
 #undef LMX_TILE
 }
 
-uint32_t cull_dynamic_tile(int n_frusta) { return n_frusta <= 2 ? 2048u : (n_frusta <= 4 ? 1024u : 512u); } // <= 16 KiB of staging
+// Slots per block: at most 16 KiB of staging, and small enough that the launch has ~2000 blocks: a block walks its tile in batches
+// of 256 one after the other (load -> ~350 VALU -> LDS append), so a small set on few large tiles is a handful of CUs each waiting
+// on its own chain of loads (160 k overflow entities on 80 blocks: 14 us; on 640 blocks of 256: see DESIGN.md).
+uint32_t cull_dynamic_tile(int n_frusta, uint32_t n_slots) {
+	uint32_t tile = n_frusta <= 2 ? 2048u : (n_frusta <= 4 ? 1024u : 512u);
+	while (tile > 256u && n_slots / tile < 2048u) tile >>= 1;
+	return tile;
+}
 
 hipError_t launch_cull_dynamic(hipStream_t s, const DynDeviceView& d, uint32_t slot_begin, uint32_t slot_end, const TypeTable& dyn_tt,
 	const FrustaArg& fr, int n_frusta, const CullOut& out) {
-	const uint32_t tile = cull_dynamic_tile(n_frusta);
+	const uint32_t tile = cull_dynamic_tile(n_frusta, slot_end - slot_begin);
 	const uint32_t blocks = (slot_end - slot_begin) / tile;
 	if (!blocks) return hipSuccess;
 	const size_t lds = (size_t)n_frusta * tile * sizeof(int32_t) + 2 * MAX_FRUSTA * sizeof(uint32_t);
 #define LMX_DYN(T) hipLaunchKernelGGL(k_cull_dynamic<T>, dim3(blocks), dim3(DYN_THREADS), lds, s, d.px, d.py, d.pz, d.radius, d.ids, fr, n_frusta, dyn_tt, slot_begin, out)
 	if (tile == 2048) LMX_DYN(2048);
 	else if (tile == 1024) LMX_DYN(1024);
-	else LMX_DYN(512);
+	else if (tile == 512) LMX_DYN(512);
+	else LMX_DYN(256);
 #undef LMX_DYN
 	return hipGetLastError();
 }

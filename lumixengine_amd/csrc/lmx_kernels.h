@@ -76,7 +76,7 @@ struct DynDeviceView {
 };
 hipError_t launch_cull_dynamic(hipStream_t s, const DynDeviceView& d, uint32_t slot_begin, uint32_t slot_end, const TypeTable& dyn_tt,
 	const FrustaArg& fr, int n_frusta, const CullOut& out);
-uint32_t cull_dynamic_tile(int n_frusta);
+uint32_t cull_dynamic_tile(int n_frusta, uint32_t n_slots);
 
 // Patch records staged by the host between two culls (CullingSystem::add / remove / set* are O(1): culling_system.cpp:131-258)
 struct PatchSphere { uint32_t slot; float x, y, z, radius; };                 // static set: in-cell move / radius change
