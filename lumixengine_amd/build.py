@@ -23,7 +23,7 @@ SOURCES = ["cull_kernels.hip", "xform_kernels.hip", "skin_kernels.hip", "lmx_cap
 HEADERS = [os.path.join(CSRC, "lmx_math.h"), os.path.join(CSRC, "lmx_kernels.h"), os.path.join(CSRC, "lmx_cull_layout.h"), os.path.join(CSRC, "lmx_context.h"), os.path.join(ROOT, "include", "lumix_mi355.h"),
            os.path.join(ROOT, "include", "lmx_types.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("LMX_HIPCC_EXTRA", "").split()  # experiments: -DLMX_...=n
 
 
 def hipcc() -> str:
