@@ -187,6 +187,14 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 
 	size_t count_by_type[LAYOUT_MAX_TYPES] = {};
 	for (size_t i = 0; i < n; ++i) count_by_type[recs[i].type]++;
+	// The placement loop below is a serial state machine (padding rules). What it reads and writes per sphere is made sequential
+	// first: the records gathered into sorted order and, afterwards, the slots scattered back to record order are the two random
+	// passes over the 10^7..10^8 entries, and both run on all threads.
+	std::vector<CullRec> sorted(n);
+	parallel_ranges(n, [&](size_t b, size_t e) {
+		for (size_t i = b; i < e; ++i) sorted[i] = recs[items[i].rec];
+	});
+	std::vector<uint32_t> slot_of_sorted(n);
 
 	out.spheres.clear();
 	out.ids.clear();
@@ -220,7 +228,7 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 		uint32_t block_cells = 0; // distinct cell slots overlapping the current LAYOUT_CELL_BLOCK-slot block
 		for (size_t k = 0; k < count_by_type[t]; ++k, ++it) {
 			const SortItem& si = items[it];
-			const CullRec& r = recs[si.rec];
+			const CullRec& r = sorted[it];
 			const bool new_cell = !have_prev || si.hi != prev_hi || si.lo != prev_lo;
 			if (out.spheres.size() % LAYOUT_CELL_BLOCK == 0) block_cells = new_cell ? 0 : 1; // a cell may continue into the block
 			if (new_cell) {
@@ -236,7 +244,7 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 				have_prev = true;
 				++block_cells;
 			}
-			out.rec_slot[si.rec] = (uint32_t)out.spheres.size();
+			slot_of_sorted[it] = (uint32_t)out.spheres.size();
 			out.slot_cell.push_back((uint32_t)out.cells.size() - 1);
 			out.spheres.push_back(LayoutSphere{r.rel.x, r.rel.y, r.rel.z, r.radius});
 			out.ids.push_back(r.entity);
@@ -253,7 +261,10 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 		if (out.spheres.size() > 0x7fffffffull) return false;
 	}
 	const size_t n_padded = out.spheres.size();
-	{ std::vector<SortItem>().swap(items); }
+	parallel_ranges(n, [&](size_t b, size_t e) {
+		for (size_t i = b; i < e; ++i) out.rec_slot[items[i].rec] = slot_of_sorted[i];
+	});
+	{ std::vector<SortItem>().swap(items); std::vector<CullRec>().swap(sorted); std::vector<uint32_t>().swap(slot_of_sorted); }
 
 	const size_t n_chunks = n_padded / LAYOUT_CHUNK;
 	out.hdr.resize(n_chunks);
