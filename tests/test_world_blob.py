@@ -242,3 +242,39 @@ def test_gpu_world_from_blob(gpu_ctx, oracle_port):
     level1 = kids[np.isin(parent[kids], roots)]
     assert len(level1) > 10
     assert H.transforms_bits_equal(got[level1], oracle_port.compose(tr[parent[level1]], tr[level1]))
+
+
+@pytest.mark.gpu
+def test_gpu_world_from_reference_blob(gpu_ctx, oracle_ref):
+    """The reference's own World (real engine/world.cpp), serialized by its own World::serialize, parsed by the product and loaded the
+    way World::deserialize loads it - stored world transforms AND stored locals taken as they are (a child's stored local is the one
+    computeLocal re-derived, so recomposing it would not reproduce the stored world bit for bit). Then both worlds get the same root
+    moves and child-local writes: the device hierarchy stays bit-identical to the reference World, frame after frame."""
+    rw, h, gone = make_reference_world(oracle_ref)
+    data = rw.serialize(1)
+    assert data == open(os.path.join(G, "world_blob_ref.bin"), "rb").read()  # the committed fixture is this world
+    info, parent, tr, wtr, valid = api.world_blob_read(data)
+    n = len(h["parent"])
+    alive = np.ones(n, bool)
+    alive[gone] = False
+    w = api.World(gpu_ctx)
+    w.buildWithWorld(parent, tr, wtr)
+    kids = alive & (h["parent"] >= 0)
+    roots = np.flatnonzero(alive & (h["parent"] < 0)).astype(np.int32)
+    assert H.transforms_bits_equal(w.getTransforms()[:n][alive], rw.get_transforms()[alive])
+    assert H.transforms_bits_equal(w.getLocalTransforms()[:n][kids], rw.get_local_transforms()[kids])
+    rng = np.random.default_rng(23)
+    from tests.test_gpu_world_skin import _depths
+    depth = _depths(h["parent"])
+    for frame in range(3):
+        new_root = scenes.random_transforms(rng, len(roots), 2000.0)
+        inner = rng.choice(np.flatnonzero(kids), size=20, replace=False).astype(np.int32)
+        inner = inner[np.argsort(depth[inner], kind="stable")]  # the batch form applies a frame's writes ancestors first
+        new_inner = scenes.random_transforms(rng, len(inner), 5.0)
+        rw.set_transforms(roots, new_root)
+        rw.set_local_transforms(inner, new_inner)
+        w.setTransforms(roots, new_root)
+        w.setTransforms(inner, new_inner)  # setLocalTransform for parented entities
+        w.propagate()
+        assert H.transforms_bits_equal(w.getTransforms()[:n][alive], rw.get_transforms()[alive]), frame
+        assert H.transforms_bits_equal(w.getLocalTransforms()[:n][kids], rw.get_local_transforms()[kids]), frame
