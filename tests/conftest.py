@@ -38,6 +38,12 @@ def oracle_ref():
     return pyoracle.Oracle("reference")
 
 
+@pytest.fixture(params=["port", "reference"])
+def live_oracle(request):
+    """Both CPU checkers in turn: the plain-C restatement and the reference's own code (skipped where oracle/_ref is unavailable)."""
+    return request.getfixturevalue("oracle_port" if request.param == "port" else "oracle_ref")
+
+
 @pytest.fixture(scope="session")
 def emul_lib():
     """Host emulation of the kernels' logic (tests/emul/emul_kernels.cpp), compiled with g++ -ffp-contract=off."""

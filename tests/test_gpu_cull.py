@@ -96,8 +96,9 @@ def test_cull_empty_and_tiny(gpu_ctx):
     assert cs.cull(fr).count(0) == 0
 
 
-def test_cull_incremental_ops(gpu_ctx, oracle_port):
+def test_cull_incremental_ops(gpu_ctx, live_oracle):
     """CullingSystem::add/remove/set/setPosition/setRadius (culling_system.cpp:131-258) against the oracle."""
+    oracle_port = live_oracle
     rng = np.random.default_rng(21)
     sc = H.mixed_scene(4000, 1200.0, seed=5)
     cs = api.CullingSystem(gpu_ctx)
@@ -273,10 +274,11 @@ def test_cull_10m_properties(gpu_ctx):
     assert len(np.unique(a)) == len(a)
 
 
-def test_cull_update_stream_vs_oracle(gpu_ctx, oracle_port):
+def test_cull_update_stream_vs_oracle(gpu_ctx, live_oracle):
     """The O(1) update path against the live oracle at 300 k entities: removals (tombstones), adds and cross-cell sets (overflow in
     the dynamic set), in-cell sets (sphere patches), a growing overflow region (slot reassignment), re-adding removed entities,
     and an explicit compaction in the middle of the stream."""
+    oracle_port = live_oracle
     n, half = 300_000, 4500.0
     sc = scenes.cull_scene(n, half, seed=9, mixed_types=True)
     cs = api.CullingSystem(gpu_ctx)

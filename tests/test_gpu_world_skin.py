@@ -78,11 +78,12 @@ def _depths(parent):
 
 
 @pytest.mark.parametrize("kind", ["chains", "fans"])
-def test_world_child_writes_bit_exact(gpu_ctx, oracle_port, kind):
+def test_world_child_writes_bit_exact(gpu_ctx, live_oracle, kind):
     """World::setLocalTransform and World::setTransform on entities WITH a parent (world.cpp:741-753, :337-342): the reference
     re-derives the stored local with Transform::computeLocal after composing (world.cpp:266-269), which is lossy, and later frames
     compose with that re-derived local. Several frames of interleaved root moves, child local writes and child world-space writes
     (issued ancestors-first, as the batch form defines) must give bit-identical world AND local transforms."""
+    oracle_port = live_oracle
     h = scenes.hierarchy_chains(3000, 4, seed=21) if kind == "chains" else scenes.hierarchy_fans(20, 6, 4, seed=22)
     ow, roots, kids = oracle_world(oracle_port, h)
     parent = h["parent"]
@@ -177,8 +178,9 @@ def test_world_child_parent_order_independent(gpu_ctx, oracle_port):
     assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms())
 
 
-def test_world_moves_refresh_culling(gpu_ctx, oracle_port):
+def test_world_moves_refresh_culling(gpu_ctx, live_oracle):
     """transform -> sphere refresh -> cull, end to end (render_module.cpp:1544-1554 + culling_system.cpp:225-242)."""
+    oracle_port = live_oracle
     h = scenes.hierarchy_chains(3000, 3, seed=4, root_extent=1500.0)
     n = len(h["parent"])
     rng = np.random.default_rng(33)
