@@ -167,8 +167,9 @@ def test_gpu_animation_matches_committed_fixture(gpu_ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("weight,dt", [(1.0, 1 / 60), (0.4, 0.25), (1.0, -0.4)])
-def test_gpu_animation_matches_oracle(gpu_ctx, oracle_port, weight, dt):
+def test_gpu_animation_matches_oracle(gpu_ctx, live_oracle, weight, dt):
     """Three consecutive frames of animation -> absolute pose -> palette on the device, every stage bit-exact."""
+    oracle_port = live_oracle
     skel = [scenes.skeleton(64, seed=4), scenes.skeleton(100, seed=24)]
     anims = [scenes.animation(64, 30, 30.0, seed=41), scenes.animation(64, 9, 24.0, seed=42, root_motion=False), scenes.animation(100, 20, 60.0, seed=43),
              scenes.animation(100, 6, 30.0, seed=44, bone_limit=90)]

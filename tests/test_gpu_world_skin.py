@@ -288,9 +288,10 @@ def test_skin_golden(gpu_ctx, exact):
     sk.setMode(False)
 
 
-def test_skin_groups_and_pose_writeback_switch(gpu_ctx, oracle_port):
+def test_skin_groups_and_pose_writeback_switch(gpu_ctx, live_oracle):
     """Runs of one model are walked 16 / 8 instances at a time (ragged last group, model change mid-run); with the absolute
     pose store switched off the palettes and vertices are unchanged, readPose fails, and uploaded poses stay relative."""
+    oracle_port = live_oracle
     sk = api.Skinning(gpu_ctx)
     sk.setMode(True)
     skel = [scenes.skeleton(64, seed=4), scenes.skeleton(100, seed=24)]
@@ -443,9 +444,10 @@ def test_skin_dual_quaternion_blend(gpu_ctx, oracle_port):
 
 
 @pytest.mark.parametrize("exact", [True, False])
-def test_skin_shared_mesh_runs(gpu_ctx, oracle_port, exact):
+def test_skin_shared_mesh_runs(gpu_ctx, live_oracle, exact):
     """Runs of instances that share a mesh take the register-resident path (k_skin_shared: ragged tiles, 2 tiles per mesh,
     8-copy palettes for 100 bones), single instances and small meshes the streaming one; both in one instance table."""
+    oracle_port = live_oracle
     sk = api.Skinning(gpu_ctx)
     sk.setMode(exact)
     skel = [scenes.skeleton(64, seed=4), scenes.skeleton(100, seed=24), scenes.skeleton(64, seed=34)]
@@ -471,8 +473,9 @@ def test_skin_shared_mesh_runs(gpu_ctx, oracle_port, exact):
 
 
 @pytest.mark.parametrize("exact", [True, False])
-def test_skin_many_instances_vs_oracle(gpu_ctx, oracle_port, exact):
+def test_skin_many_instances_vs_oracle(gpu_ctx, live_oracle, exact):
     """Two models (64 and 196 bones = Model::Bone::MAX_COUNT), three meshes with ragged vertex counts."""
+    oracle_port = live_oracle
     sk = api.Skinning(gpu_ctx)
     sk.setMode(exact)
     skel = [scenes.skeleton(64, seed=4), scenes.skeleton(196, seed=14), scenes.skeleton(1, seed=15)]
@@ -574,9 +577,10 @@ def test_dynamic_set_matches_golden(gpu_ctx, fixture):
         assert cs.getRadius(int(ent[i])) == float(g["radius"][i])
 
 
-def test_world_set_parent_matches_oracle(gpu_ctx, oracle_port):
+def test_world_set_parent_matches_oracle(gpu_ctx, live_oracle):
     """World::setParent (world.cpp:619-701): re-parenting inside and across trees, detaching, cycle rejection; the stored
     locals and the world transforms after the next root move must equal the reference's."""
+    oracle_port = live_oracle
     h = scenes.hierarchy_fans(8, 3, 4, seed=21)
     n = len(h["parent"])
     ow, roots, kids = oracle_world(oracle_port, h)

@@ -195,8 +195,9 @@ def test_gpu_sort_keys_match_committed_fixture(gpu_ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("vi", range(len(VIEWS)))
-def test_gpu_sort_keys_match_oracle(gpu_ctx, oracle_port, vi):
+def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi):
     """cull -> createSortKeys on the device, two consecutive frames (LOD / pose-frame state carried on the device)."""
+    oracle_port = live_oracle
     base = scenes.cull_scene(60_000, 2500.0, seed=31, big_fraction=0.002)
     n = len(base["entity"])
     types = make_types(n, 4)
