@@ -384,6 +384,7 @@ void fold_overflow(CullState& cs) {
 
 bool wants_compaction(const CullState& cs) {
 	if (!layout_live(cs)) return true;
+	if (!cs.auto_compaction) return false; // the host schedules lmx_cull_compact itself (loading screen, level streaming boundary)
 	const size_t n_static = cs.recs.size();
 	return cs.n_unbound > std::max<size_t>(COMPACT_MIN, n_static / 8) || cs.n_tombstones > std::max<size_t>(COMPACT_MIN, n_static / 4);
 }
@@ -928,6 +929,7 @@ int lmx_cull_set_option(LmxContext* ctx, int option, int value) {
 			if (value < 0 || value > 2) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "tile test mode %d not in [0,2]", value);
 			cs.lane_parallel = value;
 			return LMX_OK;
+		case LMX_CULL_OPT_AUTO_COMPACTION: cs.auto_compaction = value != 0; return LMX_OK;
 		case LMX_CULL_OPT_MAX_SHARDS:
 			if (value < 1 || value > (int)LAYOUT_MAX_SHARDS) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "max shards %d not in [1,%u]", value, LAYOUT_MAX_SHARDS);
 			cs.max_shards = (uint32_t)value;

@@ -150,6 +150,7 @@ struct CullState {
 	// ---- tuning (lmx_cull_set_option) -------------------------------------------------------------------------
 	uint32_t pass_width = 1;   // frusta tested per pass over the static set
 	int tile_variant = -1;     // -1: chosen per cull from the frustum's coverage of the scene
+	bool auto_compaction = true; // false: overflow / tombstones accumulate until the host calls lmx_cull_compact
 	int lane_parallel = 2;     // tile-level box test of the 1-frustum kernels: 0 = uniform code in every wave, 1 = one plane per lane in every wave, 2 = one plane per lane in wave 0, verdict through LDS
 	uint32_t max_shards = LAYOUT_MAX_SHARDS; // output shards per type of the static set
 	uint32_t cnt_pad = 32;     // words between shard counters (32 = one 128-byte line each)

@@ -343,3 +343,35 @@ def test_cull_one_sphere_per_cell_layout_padding(gpu_ctx, oracle_port):
         H.assert_same_visible(gpu_visible(res, f), oracle_visible(ocs, fr8[f : f + 1]), f"8 frusta, frustum {f}")
     fr1 = H.frusta(api, names=["origin_yaw_pitch"])
     H.assert_same_visible(gpu_visible(cs.cull(fr1), 0), oracle_visible(ocs, fr1), "fused path")
+
+
+def test_cull_auto_compaction_switch(gpu_ctx, oracle_port):
+    """LMX_CULL_OPT_AUTO_COMPACTION = 0: the overflow set grows past the automatic threshold (max(65536, n / 8)) without a re-sort until
+    the host asks for one; results are the oracle's before and after."""
+    n, extra = 100_000, 70_000
+    sc = scenes.cull_scene(n + extra, 3000.0, seed=13)
+    cs = api.CullingSystem(gpu_ctx)
+    ocs = oracle_port.culling_system()
+    cs.build(sc["entity"][:n], sc["type"][:n], sc["pos"][:n], sc["radius"][:n])
+    ocs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    fr = H.frusta(api, names=["origin_identity", "origin_yaw_pitch"])
+    try:
+        cs.setOption(api.CULL_OPT_AUTO_COMPACTION, 0)
+        cs.addMany(sc["entity"][n:], sc["type"][n:], sc["pos"][n:], sc["radius"][n:])
+        res = cs.cull(fr)
+        assert cs.updateStats()["overflow"] == extra  # above the threshold, still unsorted
+        for k in range(len(fr)):
+            H.assert_same_visible(gpu_visible(res, k), oracle_visible(ocs, fr[k : k + 1]), f"overflow, frustum {k}")
+        cs.compact()
+        res = cs.cull(fr)
+        assert cs.updateStats()["overflow"] == 0 and cs.updateStats()["static"] == n + extra
+        for k in range(len(fr)):
+            H.assert_same_visible(gpu_visible(res, k), oracle_visible(ocs, fr[k : k + 1]), f"compacted, frustum {k}")
+        cs.setOption(api.CULL_OPT_AUTO_COMPACTION, 1)
+        cs.removeMany(sc["entity"][:10])
+        for e in sc["entity"][:10]:
+            ocs.remove(int(e))
+        res = cs.cull(fr)
+        H.assert_same_visible(gpu_visible(res, 0), oracle_visible(ocs, fr[0:1]), "after re-enabling")
+    finally:
+        cs.setOption(api.CULL_OPT_AUTO_COMPACTION, 1)
