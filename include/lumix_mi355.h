@@ -134,6 +134,10 @@ LMX_API int lmx_cull_read(LmxContext* ctx, uint32_t view, uint32_t frustum, uint
 /* All types of one frustum at once: out_counts[LMX_MAX_TYPES], ids of type 0 first, then type 1, ... (two host waits in
  * total; what an adapter that rebuilds CullResult pages needs). */
 LMX_API int lmx_cull_read_all(LmxContext* ctx, uint32_t view, uint32_t frustum, int32_t* out_ids, uint32_t cap, uint32_t* out_counts);
+/* The same list with (normally) one host wait: *out_ids points into pinned host memory owned by the library (type 0's ids first,
+ * out_counts[LMX_MAX_TYPES] per type), valid until the next lmx_cull_map_all on this view. The copy is enqueued before the count is
+ * known, sized from the previous call on this view; a list that outgrew it costs a second wait. */
+LMX_API int lmx_cull_map_all(LmxContext* ctx, uint32_t view, uint32_t frustum, const int32_t** out_ids, uint32_t* out_counts);
 /* Device-side view of a result for GPU consumers (sort keys, RCCL all-gather): ids of (frustum, type) start at
  * d_ids + type_offsets[type] and number d_counts[frustum * LMX_MAX_TYPES + type]. All pointers are device memory
  * except type_offsets (host, LMX_MAX_TYPES entries, in ids). The cull kernels leave the visible ids in up to a few hundred

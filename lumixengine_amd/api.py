@@ -106,6 +106,7 @@ SYMBOLS = {
     "lmx_cull_update_stats": (_ci, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "lmx_cull_set_option": (_ci, [_vp, _ci, _ci]),
     "lmx_cull_read_all": (_ci, [_vp, _u32, _u32, _vp, _u32, _vp]),
+    "lmx_cull_map_all": (_ci, [_vp, _u32, _u32, _vp, _vp]),
     "lmx_cull_device_shards": (_ci, [_vp, _u32, _u32, _vp]),
     "lmx_cull_stats": (_ci, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "lmx_cull": (_ci, [_vp, _u32, _vp, _u32, _u8]),
@@ -350,6 +351,16 @@ class CullResult:
         cnt = np.zeros(MAX_TYPES, np.uint32)
         self.cs.ctx.check(self.cs.lib.lmx_cull_read_all(self.cs.ctx.h, self.view, frustum, _ptr(out), len(out), _ptr(cnt)))
         return out[: int(cnt.sum())], np.repeat(np.arange(MAX_TYPES, dtype=np.uint8), cnt)
+
+    def map_all(self, frustum: int = 0):
+        """(ids, types) like all_ids, through lmx_cull_map_all (normally one host wait; the ids are copied out of the library's pinned
+        buffer here - a C caller reads them in place)."""
+        p = C.POINTER(C.c_int32)()
+        cnt = np.zeros(MAX_TYPES, np.uint32)
+        self.cs.ctx.check(self.cs.lib.lmx_cull_map_all(self.cs.ctx.h, self.view, frustum, C.byref(p), _ptr(cnt)))
+        n = int(cnt.sum())
+        ids = np.frombuffer(C.string_at(p, 4 * n), np.int32) if n else np.zeros(0, np.int32)
+        return ids, np.repeat(np.arange(MAX_TYPES, dtype=np.uint8), cnt)
 
     def pages(self, frustum: int = 0, type_: int = 0, page_ids: int = 1020):
         a = self.ids(frustum, type_)

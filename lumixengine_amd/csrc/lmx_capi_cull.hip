@@ -1008,6 +1008,57 @@ int lmx_cull_read_all(LmxContext* ctx, uint32_t view, uint32_t frustum, int32_t*
 	return LMX_OK;
 }
 
+// All types of one frustum with (normally) ONE host wait: the gather kernels pack [counts | ids, type 0 first] into one device
+// record, and the copy into pinned host memory is enqueued right behind them for as many ids as the previous call on this view
+// returned (+25 %): frames are coherent, so the guess almost always covers the list; when it does not, the rest follows with a second
+// wait. The caller reads the ids in place: *out_ids stays valid until the next lmx_cull_map_all on this view.
+// (Letting the gather kernel store straight into mapped host memory was measured too: 4-byte stores over PCIe, 0.49 ms for 334 k ids.)
+int lmx_cull_map_all(LmxContext* ctx, uint32_t view, uint32_t frustum, const int32_t** out_ids, uint32_t* out_counts) {
+	LMX_CHECK_CTX(ctx);
+	if (view >= LMX_MAX_VIEWS || !out_counts || !out_ids) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad view / null output");
+	CullState& cs = ctx->cull;
+	CullView& v = cs.views[view];
+	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
+	if (frustum >= v.n_frusta) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "frustum %u out of range", frustum);
+	const size_t need = (size_t)MAX_TYPES + v.out_stride;
+	if (v.map_words < need) {
+		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // nothing may still write the old buffer
+		if (v.map_host) LMX_HIP(ctx, hipHostFree(v.map_host));
+		v.map_host = nullptr;
+		v.map_words = 0;
+		const size_t want = need + need / 4 + 1024;
+		LMX_HIP(ctx, hipHostMalloc(&v.map_host, want * sizeof(int32_t), hipHostMallocDefault));
+		LMX_HIP(ctx, v.map_rec.reserve(want));
+		v.map_words = want;
+	}
+	LMX_HIP(ctx, v.map_pref.reserve(std::max<size_t>(cs.n_shards, 1)));
+	LMX_HIP(ctx, v.map_start.reserve(MAX_TYPES));
+	const uint32_t cnt_frustum_stride = cs.n_shards * cs.cnt_pad;
+	const uint32_t* counts = v.counts_ptr() + (size_t)frustum * cnt_frustum_stride;
+	uint32_t* header = reinterpret_cast<uint32_t*>(v.map_rec.p);
+	LMX_HIP(ctx, launch_cull_finalize(ctx->stream, counts, cs.cnt_pad, cnt_frustum_stride, cs.d_shard_type.p, cs.n_shards, 1, header, v.map_pref.p, v.map_start.p));
+	LMX_HIP(ctx, launch_cull_consolidate(ctx->stream, v.out.p + (size_t)frustum * v.out_stride, v.out_stride, cs.d_win_base.p, counts, cs.cnt_pad, cnt_frustum_stride,
+		cs.d_shard_type.p, v.map_start.p, MAX_TYPES, v.map_pref.p, cs.n_shards, 1, cs.max_shard_cap, v.map_rec.p + MAX_TYPES, 0, v.out_stride));
+	const size_t guess = std::min<size_t>(v.out_stride, v.map_guess);
+	LMX_HIP(ctx, hipMemcpyAsync(v.map_host, v.map_rec.p, (MAX_TYPES + guess) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const uint32_t* h = reinterpret_cast<const uint32_t*>(v.map_host);
+	size_t total = 0;
+	for (int t = 0; t < MAX_TYPES; ++t) {
+		if (h[t] > v.out_cap[t]) return fail(ctx, LMX_ERR_HIP, "corrupt count %u > %u", h[t], v.out_cap[t]);
+		out_counts[t] = h[t];
+		total += h[t];
+	}
+	if (total > guess) { // the list outgrew the guess: fetch the rest (second wait, this frame only)
+		LMX_HIP(ctx, hipMemcpyAsync(reinterpret_cast<int32_t*>(v.map_host) + MAX_TYPES + guess, v.map_rec.p + MAX_TYPES + guess, (total - guess) * sizeof(int32_t),
+			hipMemcpyDeviceToHost, ctx->stream));
+		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	v.map_guess = total + total / 4 + 1024;
+	*out_ids = reinterpret_cast<const int32_t*>(v.map_host) + MAX_TYPES;
+	return LMX_OK;
+}
+
 int lmx_cull_bind_output(LmxContext* ctx, uint32_t view, void* d_ids, size_t ids_capacity, void* d_counts) {
 	LMX_CHECK_CTX(ctx);
 	if (view >= LMX_MAX_VIEWS) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad view");

@@ -63,6 +63,16 @@ struct CullView {
 	uint32_t* ext_counts = nullptr;
 	uint32_t flip = 0;
 	bool next_half_is_zero = false;
+	// lmx_cull_map_all: [MAX_TYPES counts | ids, type 0 first] gathered into map_rec, copied into pinned host memory
+	void* map_host = nullptr;
+	size_t map_words = 0;
+	size_t map_guess = 4096; // ids the next call copies before it knows the count
+	DevBuf<int32_t> map_rec;
+	DevBuf<uint32_t> map_pref, map_start;
+	~CullView() { if (map_host) (void)hipHostFree(map_host); }
+	CullView() = default;
+	CullView(const CullView&) = delete;
+	CullView& operator=(const CullView&) = delete;
 	uint32_t* counts_ptr() const { return counts.p + flip * cnt_words; }
 	uint32_t* counts_other() const { return counts.p + (flip ^ 1u) * cnt_words; }
 	const int32_t* cons_ptr() const { return ext_out ? ext_out : cons.p; }

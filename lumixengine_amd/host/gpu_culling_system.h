@@ -108,10 +108,10 @@ private:
 		const uint32_t view = m_next_view++ % LMX_MAX_VIEWS;
 		static_assert(sizeof(ShiftedFrustum) == sizeof(LmxShiftedFrustum), "layout");
 		if (!check(lmx_cull(m_ctx, view, reinterpret_cast<const LmxShiftedFrustum*>(&frustum), 1, type))) return nullptr;
-		// two host waits per cull: the per-type totals, then the ids of every non-empty type in one batch of copies
+		// normally one host wait per cull: totals + ids arrive as one record in the library's pinned host memory, read in place
 		uint32_t counts[LMX_MAX_TYPES];
-		m_scratch.resize((size_t)n_static + n_bound + n_overflow);
-		if (!check(lmx_cull_read_all(m_ctx, view, 0, m_scratch.data(), (uint32_t)m_scratch.size(), counts))) return nullptr;
+		const int32_t* ids = nullptr;
+		if (!check(lmx_cull_map_all(m_ctx, view, 0, &ids, counts))) return nullptr;
 		CullResult* first = nullptr;
 		CullResult* last = nullptr;
 		constexpr uint32_t PAGE_IDS = sizeof(CullResult::entities) / sizeof(EntityRef);
@@ -121,7 +121,7 @@ private:
 			for (uint32_t i = 0; i < got; i += PAGE_IDS) {
 				CullResult* page = newPage((u8)t);
 				const uint32_t n = got - i < PAGE_IDS ? got - i : PAGE_IDS;
-				for (uint32_t k = 0; k < n; ++k) page->entities[k].index = m_scratch[at + i + k];
+				for (uint32_t k = 0; k < n; ++k) page->entities[k].index = ids[at + i + k];
 				page->header.count = n;
 				if (last) last->header.next = page; else first = page;
 				last = page;
@@ -136,7 +136,6 @@ private:
 	LmxContext* m_ctx = nullptr;
 	std::mutex m_mutex;
 	uint32_t m_next_view = 0;
-	std::vector<int32_t> m_scratch;
 	std::string m_error;
 };
 

@@ -375,3 +375,22 @@ def test_cull_auto_compaction_switch(gpu_ctx, oracle_port):
         H.assert_same_visible(gpu_visible(res, 0), oracle_visible(ocs, fr[0:1]), "after re-enabling")
     finally:
         cs.setOption(api.CULL_OPT_AUTO_COMPACTION, 1)
+
+
+def test_cull_map_all_equals_read_all(gpu_ctx):
+    """lmx_cull_map_all (gather kernels write into pinned mapped host memory, one host wait) returns what lmx_cull_read_all returns,
+    per frustum, types in order; the mapped view survives reading another frustum's list only until the next map on that view."""
+    sc = H.mixed_scene(60_000, 2500.0, seed=17)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    fr = H.frusta(api, names=["origin_identity", "origin_yaw_pitch", "ortho_cascade_large"])
+    res = cs.cull(fr)
+    for f in range(len(fr)):
+        want_ids, want_types = res.all_ids(f)
+        ids, types = res.map_all(f)
+        assert np.array_equal(types, want_types) and len(ids) == len(want_ids)
+        for t in range(api.MAX_TYPES):
+            assert np.array_equal(np.sort(ids[types == t]), np.sort(want_ids[want_types == t]))
+    empty = cs.cull(api.viewport_frustum(pos=(1.0e6, 0.0, 0.0)))
+    ids, types = empty.map_all(0)
+    assert len(ids) == 0 and len(types) == 0
