@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="only the default-camera loops (warm-up, timed, event-timed): the command whose rocprofv3 --kernel-trace --stats summary is committed under profiles/")
     ap.add_argument("--no-extras", action="store_true", help="skip the dense-variant / transform / skin side measurements")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc child passes; quote the committed profiles/rNN/traffic.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--big-entities", type=int, default=100_000_000, help="extras: entity count of the config-5-sized single-GPU legs (0 = skip)")
     args = ap.parse_args()
@@ -286,7 +287,11 @@ def main():
                             "note": "warm = back-to-back frames (SURVEY.md 8d: 'measure with >= 100 back-to-back frames'; the 200 MB working set stays in the 256 MiB Infinity Cache); cold = after a 1 GiB read-only scrub; the 100 M extra (config5_size_single_gpu.all_test) is HBM-cold by size"}
         del cs_t, sc_t
     del scrub
-    traffic, traffic_note = load_traffic("k_cull_tile:all_test")
+    traffic, traffic_note = (None, None)
+    if rank == 0 and world == 1 and not args.headline_only and not args.no_live_traffic:
+        traffic, traffic_note = measure_traffic_live(log)
+    if traffic is None:
+        traffic, traffic_note = load_traffic("k_cull_tile:all_test")
     roof_ms = test_cold_ms if test_cold_ms == test_cold_ms else avg_default_ms
     roof_bytes = test_bytes if test_cold_ms == test_cold_ms else alg_bytes
     roofline = {
@@ -298,7 +303,7 @@ def main():
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": round(roof_bytes / (roof_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-        "traffic": traffic,  # HBM bytes per launch of the all_test leg: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed under profiles/
+        "traffic": traffic,  # HBM bytes per launch of the all_test leg: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, run as child processes of THIS bench (rank 0, N = 1); the committed profiles/rNN/traffic.json only when rocprofv3 is unavailable (traffic_source says which)
         "traffic_source": traffic_note,
         "algorithmic_bytes_per_launch": roof_bytes,
         "avg_launch_ms": round(roof_ms, 5),
@@ -362,6 +367,55 @@ class c_stdout_to_stderr:
         os.dup2(self.saved, 1)
         os.close(self.saved)
         return False
+
+
+def measure_traffic_live(log):
+    """HBM bytes per launch of the roofline leg's kernel, measured in THIS run: two rocprofv3 passes (--pmc FETCH_SIZE, then --pmc
+    WRITE_SIZE: they cannot share a pass; kernel trace only) over tools/run_workload.py --workload cull_all_test --cold read - the same
+    scene, camera and scrub as the all_test cold leg above - in a child process. Returns (bytes, note) or (None, None) when
+    rocprofv3 is missing / fails / times out (the committed profiles/rNN/traffic.json is quoted then)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, None
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="lmx_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "run_workload.py"), "--workload", "cull_all_test", "--steps", "16", "--cold", "read"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=180)
+            if r.returncode != 0:
+                log(f"live traffic: rocprofv3 --pmc {counter} failed with {r.returncode}")
+                return None, None
+            v = []
+            for root, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        with open(os.path.join(root, f)) as fh:
+                            for row in csv.DictReader(fh):
+                                if "k_cull_tile" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                                    v.append(float(row["Counter_Value"]))
+            if len(v) < 8:
+                log(f"live traffic: only {len(v)} {counter} samples")
+                return None, None
+            v = v[len(v) // 4:]  # drop the warm-up launches (not scrubbed)
+            vals[counter] = sum(v) / len(v)
+    except Exception as e:  # noqa: BLE001 - never let the profiler break the bench line
+        log(f"live traffic: {e!r}")
+        return None, None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = vals["FETCH_SIZE"] * 1024.0 * 2.0, vals["WRITE_SIZE"] * 1024.0  # KiB; FETCH_SIZE doubled per the guide's gfx950 correction
+    log(f"live traffic: FETCH_SIZE {vals['FETCH_SIZE']:.0f} KiB (x2), WRITE_SIZE {vals['WRITE_SIZE']:.0f} KiB per launch")
+    return int(round(fetch + write)), ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+                                       "tools/run_workload.py --workload cull_all_test --cold read (child processes, same scene / camera / scrub as the all_test cold leg); "
+                                       "FETCH_SIZE doubled per the guide's gfx950 correction")
 
 
 def load_traffic(kernel):
