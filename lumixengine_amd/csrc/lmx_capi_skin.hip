@@ -61,15 +61,19 @@ int lmx_skin_add_mesh(LmxContext* ctx, uint32_t n_verts, const float* positions_
 		for (int k = 0; k < 4; ++k)
 			if (skin[v].indices[k] < 0 || skin[v].indices[k] >= LMX_MAX_BONES) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "skin[%u].indices[%d] = %d out of range", v, k, skin[v].indices[k]);
 	SkinMesh m;
-	m.vert_offset = (uint32_t)(sk.verts.size() / 3);
+	m.vert_offset = (uint32_t)(sk.mesh.size() / 2);
 	m.n_verts = n_verts;
 	m.max_bone = 0;
 	for (uint32_t v = 0; v < n_verts; ++v)
 		for (int k = 0; k < 4; ++k) m.max_bone = std::max<uint32_t>(m.max_bone, (uint32_t)skin[v].indices[k]);
-	sk.verts.insert(sk.verts.end(), positions_xyz, positions_xyz + (size_t)n_verts * 3);
+	static_assert(LMX_MAX_BONES <= 256, "bone indices are packed as u8");
+	sk.mesh.reserve(sk.mesh.size() + 2 * (size_t)n_verts);
 	for (uint32_t v = 0; v < n_verts; ++v) {
-		sk.weights.push_back(make_float4(skin[v].weights[0], skin[v].weights[1], skin[v].weights[2], skin[v].weights[3]));
-		for (int k = 0; k < 4; ++k) sk.indices.push_back(skin[v].indices[k]);
+		const uint32_t idx = (uint32_t)skin[v].indices[0] | ((uint32_t)skin[v].indices[1] << 8) | ((uint32_t)skin[v].indices[2] << 16) | ((uint32_t)skin[v].indices[3] << 24);
+		float idx_bits;
+		std::memcpy(&idx_bits, &idx, 4);
+		sk.mesh.push_back(make_float4(skin[v].weights[0], skin[v].weights[1], skin[v].weights[2], skin[v].weights[3]));
+		sk.mesh.push_back(make_float4(positions_xyz[3 * (size_t)v], positions_xyz[3 * (size_t)v + 1], positions_xyz[3 * (size_t)v + 2], idx_bits));
 	}
 	sk.meshes.push_back(m);
 	sk.meshes_dirty = true;
@@ -95,14 +99,9 @@ static int skin_upload_static(LmxContext* ctx) {
 		sk.models_dirty = false;
 	}
 	if (sk.meshes_dirty) {
-		const size_t nv = sk.weights.size();
-		LMX_HIP(ctx, sk.d_verts.reserve(nv * 3));
-		LMX_HIP(ctx, sk.d_weights.reserve(nv));
-		LMX_HIP(ctx, sk.d_indices.reserve(nv * 4));
+		LMX_HIP(ctx, sk.d_mesh.reserve(std::max<size_t>(sk.mesh.size(), 1)));
 		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		LMX_HIP(ctx, hipMemcpy(sk.d_verts.p, sk.verts.data(), nv * 3 * sizeof(float), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(sk.d_weights.p, sk.weights.data(), nv * sizeof(float4), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(sk.d_indices.p, sk.indices.data(), nv * 4 * sizeof(int16_t), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(sk.d_mesh.p, sk.mesh.data(), sk.mesh.size() * sizeof(float4), hipMemcpyHostToDevice));
 		sk.meshes_dirty = false;
 	}
 	return LMX_OK;
@@ -313,14 +312,13 @@ int lmx_skin_run(LmxContext* ctx) {
 	{
 		ProfScope ps(ctx, LMX_K_SKIN_VERTICES);
 		const float4* vertex_palette = sk.mode == LMX_SKIN_DQS ? sk.d_dual_quats.p : sk.d_palette.p;
-		if (sk.chunks.empty()) {
-			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, nullptr, n, sk.max_verts, sk.d_verts.p, sk.d_weights.p, sk.d_indices.p, vertex_palette,
+		if (sk.chunks.empty() || sk.mode == LMX_SKIN_DQS) { // (DQS: k_skin_shared's resident records leave too few registers for the dual-quaternion blend)
+			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, nullptr, n, sk.max_verts, sk.d_mesh.p, vertex_palette,
 				sk.d_out.p, sk.mode));
 		} else {
-			LMX_HIP(ctx, launch_skin_shared(ctx->stream, sk.d_inst.p, sk.d_chunks.p, (uint32_t)sk.chunks.size(), sk.d_verts.p, sk.d_weights.p, sk.d_indices.p,
+			LMX_HIP(ctx, launch_skin_shared(ctx->stream, sk.d_inst.p, sk.d_chunks.p, (uint32_t)sk.chunks.size(), sk.d_mesh.p,
 				vertex_palette, sk.d_out.p, sk.mode));
-			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, sk.d_solo.p, (uint32_t)sk.solo.size(), sk.solo_max_verts, sk.d_verts.p, sk.d_weights.p,
-				sk.d_indices.p, vertex_palette, sk.d_out.p, sk.mode));
+			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, sk.d_solo.p, (uint32_t)sk.solo.size(), sk.solo_max_verts, sk.d_mesh.p, vertex_palette, sk.d_out.p, sk.mode));
 		}
 	}
 	// the library's poses are absolute now; running again needs fresh relative poses (Pose::is_absolute, pose.cpp:64) unless

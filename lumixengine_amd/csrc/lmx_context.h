@@ -225,16 +225,12 @@ struct SkinState {
 	DevBuf<PoseGroup> d_groups;
 	std::vector<float> inv_pos;
 	std::vector<float4> inv_rot;
-	std::vector<float> verts;
-	std::vector<float4> weights;
-	std::vector<int16_t> indices;
+	std::vector<float4> mesh; // 2 per vertex: {w0, w1, w2, w3}, {x, y, z, bone indices as 4 x u8} (skin_kernels.hip: RawVertex)
 	bool models_dirty = false, meshes_dirty = false;
 	DevBuf<int16_t> d_parents;
 	DevBuf<float> d_inv_pos;
 	DevBuf<float4> d_inv_rot;
-	DevBuf<float> d_verts;
-	DevBuf<float4> d_weights;
-	DevBuf<int16_t> d_indices;
+	DevBuf<float4> d_mesh;
 	std::vector<SkinInstance> inst;
 	DevBuf<SkinInstance> d_inst;
 	DevBuf<float> d_pose_pos;

@@ -235,10 +235,11 @@ hipError_t launch_pose_blend(hipStream_t s, float* pos, float4* rot, const float
 hipError_t launch_palette_expand(hipStream_t s, const float4* rows, uint32_t n_bones, float4* out);
 // evaluateSkin over every vertex of every instance
 hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, const uint32_t* inst_index /* optional subset */, uint32_t n_inst,
-	uint32_t max_verts, const float* verts, const float4* weights, const int16_t* indices, const float4* palette /* 3 rows per bone, or the dual quaternions in LMX_SKIN_DQS */, float* out, int mode);
+	uint32_t max_verts, const float4* mesh /* 2 x float4 per vertex: weights | (position, 4 x u8 bone indices) */,
+	const float4* palette /* 3 rows per bone, or the dual quaternions in LMX_SKIN_DQS */, float* out, int mode);
 // the same for runs of consecutive instances that share a mesh and a bone count (vertex records held in registers)
-hipError_t launch_skin_shared(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float* verts,
-	const float4* weights, const int16_t* indices, const float4* palette /* 3 rows per bone, or the dual quaternions in LMX_SKIN_DQS */, float* out, int mode);
+hipError_t launch_skin_shared(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh,
+	const float4* palette /* 3 rows per bone, or the dual quaternions in LMX_SKIN_DQS */, float* out, int mode);
 constexpr uint32_t SKIN_SHARED_TILE_VERTS = 5120; // k_skin_shared: 1024 lanes x 5 vertex records
 
 } // namespace lmx

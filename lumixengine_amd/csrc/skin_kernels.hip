@@ -204,11 +204,27 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int SKIN_THREADS = 512;
 constexpr int SKIN_WAVES_PER_SIMD = 6; // 3 blocks of 8 waves per CU: <= 80 VGPRs, 48 KiB LDS each
 constexpr int SKIN_LDS_SLOTS = 3072;   // float4 slots = 48 KiB
+#ifndef LMX_SKIN_PIPE
+#define LMX_SKIN_PIPE 2
+#endif
+constexpr int SKIN_PIPE = LMX_SKIN_PIPE; // k_skin_vertices: vertex records in flight per lane (see skin_tile)
 
 constexpr int skin_rows(int mode) { return mode == LMX_SKIN_DQS ? 2 : 3; } // LDS rows per bone: {real, dual} or the 3 matrix rows
 
 struct F3 { float x, y, z; }; // 12-byte records: loaded / stored as one dwordx3 per lane
 struct VertexIn { float px, py, pz; float4 w; int2 iw; };
+typedef float v4f __attribute__((ext_vector_type(4)));
+// A vertex record as the mesh table holds it and as the loads define it: two 16-byte register tuples.
+//   a = the 4 bone weights;  b = (position.xyz, the 4 bone indices as 4 x u8 - Model::Bone::MAX_COUNT is 196, model.h:155)
+// Built by lmx_skin_add_mesh from the engine's arrays: 32 bytes per vertex in two dwordx4 loads, where positions (12 B) + weights
+// (16 B) + i16 indices (8 B) in three arrays cost 36 bytes and three loads.
+struct RawVertex { v4f a, b; };
+__device__ __forceinline__ RawVertex load_vertex(const float4* __restrict__ mesh, uint32_t v) {
+	RawVertex r;
+	__builtin_memcpy(&r.a, mesh + 2 * (size_t)v, sizeof(float4));
+	__builtin_memcpy(&r.b, mesh + 2 * (size_t)v + 1, sizeof(float4));
+	return r;
+}
 
 // evaluateSkin of one vertex (model.cpp:103-109) against the palette rows of its 4 bones in LDS (r0..r3 point at row 0 of
 // the lane's copy; rows are COPIES slots apart)
@@ -285,90 +301,98 @@ __device__ __forceinline__ F3 skin_blend_rows(const float4* r0, const float4* r1
 
 // `rows` already points at the lane's copy
 template <int COPIES, int MODE>
-__device__ __forceinline__ F3 skin_blend(const float4* rows, const VertexIn& c) {
-	// bone indices are non-negative i16 (validated at lmx_skin_add_mesh): plain 16-bit fields, no sign extension
-	return skin_blend_rows<COPIES, MODE>(rows + (uint32_t)(c.iw.x & 0xffff) * (skin_rows(MODE) * COPIES), rows + ((uint32_t)c.iw.x >> 16) * (skin_rows(MODE) * COPIES),
-		rows + (uint32_t)(c.iw.y & 0xffff) * (skin_rows(MODE) * COPIES), rows + ((uint32_t)c.iw.y >> 16) * (skin_rows(MODE) * COPIES), c);
+__device__ __forceinline__ F3 skin_blend(const float4* rows, const RawVertex& r) {
+	VertexIn c;
+	c.px = r.b.x; c.py = r.b.y; c.pz = r.b.z;
+	c.w = make_float4(r.a.x, r.a.y, r.a.z, r.a.w);
+	const uint32_t idx = __float_as_uint(r.b.w);
+	constexpr uint32_t STRIDE = skin_rows(MODE) * COPIES;
+	return skin_blend_rows<COPIES, MODE>(rows + (idx & 0xffu) * STRIDE, rows + ((idx >> 8) & 0xffu) * STRIDE, rows + ((idx >> 16) & 0xffu) * STRIDE,
+		rows + (idx >> 24) * STRIDE, c);
 }
 
-// Palette staging: every float4 of the instance's 3 x n_bones rows is read by ONE lane (a handful of load instructions per
-// block instead of one per slot) and written to its COPIES slots; the copy order is rotated by the lane so that the 8 lanes
-// of a ds_write_b128 service group, whose slots are COPIES * 16 B apart, land on 8 different bank columns.
+// Palette staging: COPIES / 4 lanes share a row; each fetches the row's float4 (one 16-byte load, the lanes of a row coalesce)
+// and writes FOUR of its COPIES slots. Work item `w` = (row f = w / LPR, quarter q = w % LPR), n_rows * LPR items per palette:
+// 768 for 64 bones x 16 copies or 128 bones x 8, 588 for 196 bones x 4 - every wave of the block takes part. (One lane per row
+// writing all 16 copies put the whole 48 KiB - ~620 cycles of the ds_write_b128 path - on three waves at the end of every
+// instance of k_skin_shared while the other thirteen sat at the barrier: 17 % of that kernel, tools/skin_probe.hip mask 32.)
+// The copy written in step i is rotated by the row so that the 8 lanes of a ds_write_b128 service group (consecutive lanes =
+// 8 / LPR rows x LPR quarters) land on 8 different 16-byte bank columns.
 template <int COPIES>
-__device__ __forceinline__ float4 palette_fetch(const float4* __restrict__ pal, uint32_t n_rows, uint32_t f) {
+__device__ __forceinline__ float4 palette_fetch(const float4* __restrict__ pal, uint32_t n_rows, uint32_t w) {
+	constexpr uint32_t LPR = COPIES / 4;
+	const uint32_t f = w / LPR;
 	return pal[f < n_rows ? f : 0u];
 }
 template <int COPIES>
-__device__ __forceinline__ void palette_spread(float4* s_rows, uint32_t n_rows, uint32_t f, float4 t) {
+__device__ __forceinline__ void palette_spread(float4* s_rows, uint32_t n_rows, uint32_t w, float4 t) {
+	constexpr uint32_t LPR = COPIES / 4;
+	const uint32_t f = w / LPR, q = w % LPR;
 	if (f < n_rows) {
+		const uint32_t rot = COPIES == 4 ? (f >> 1) : LPR * f;
 #pragma unroll
-		for (uint32_t c = 0; c < COPIES; ++c) s_rows[f * COPIES + ((c + f) & (COPIES - 1))] = t;
+		for (uint32_t i = 0; i < 4; ++i) s_rows[f * COPIES + ((q + LPR * i + rot) & (COPIES - 1))] = t;
 	}
 }
+constexpr uint32_t palette_items(uint32_t max_rows, uint32_t copies) { return max_rows * (copies / 4); }
 
 template <int COPIES, int MODE>
 __device__ __forceinline__ void skin_tile(const SkinInstance& in, uint32_t v_begin, uint32_t v_end, float4* s_rows,
-	const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices,
-	const float4* __restrict__ palette, float* __restrict__ out) {
+	const float4* __restrict__ mesh, const float4* __restrict__ palette, float* __restrict__ out) {
 	const uint32_t col = threadIdx.x & (COPIES - 1);
 	const float4* rows = s_rows + col;
 	// per-instance base pointers are wave-uniform (SGPRs); per-lane offsets stay 32-bit
-	const F3* vbase = reinterpret_cast<const F3*>(verts) + in.vert_offset;
-	const float4* wbase = weights + in.vert_offset;
-	const int2* ibase = reinterpret_cast<const int2*>(indices) + in.vert_offset; // 4 x i16 per vertex, little endian
+	const float4* mbase = mesh + 2 * (size_t)in.vert_offset;
 	F3* obase = reinterpret_cast<F3*>(out) + in.out_offset;
-	auto load = [&](uint32_t v) {
-		VertexIn r;
-		const F3 p = vbase[v];
-		r.px = p.x;
-		r.py = p.y;
-		r.pz = p.z;
-		r.w = wbase[v];
-		r.iw = ibase[v];
-		return r;
-	};
-	auto skin_one = [&](const VertexIn& c, uint32_t v) {
-		const F3 o = skin_blend<COPIES, MODE>(rows, c);
-		if (LMX_PROBE_SKIP(8) && o.x != 123.25f) return;
-		obase[v] = o;
-	};
-	// software-pipelined and unrolled by two (A / B ping-pong): the next vertex's loads are in flight while the current one
-	// is blended, and no register block is copied between iterations. (A deeper pipeline was measured and does not help.)
-	uint32_t v = v_begin + threadIdx.x;
-	const bool has_first = v < v_end;
-	VertexIn a = {};
-	if (has_first) a = load(v); // in flight during the palette staging
+	// records travel through the pipeline as the register TUPLES the loads define: carried as scalars, the compiler copied every
+	// freshly loaded tuple into the loop-carried scalars right behind the load - and waited for it there
+	auto load = [&](uint32_t v) { return load_vertex(mbase, v); };
+	// Software pipeline, SKIN_PIPE vertex records deep, WITHOUT a branch in the steady state: loads and stores retire through one
+	// in-order counter (vmcnt), so waiting for the record loaded SKIN_PIPE steps ago also waits for every store older than it,
+	// and the compiler only emits the exact `s_waitcnt vmcnt(N)` when it can count the operations in between. With the loads /
+	// stores under `if (v < v_end)` it emitted vmcnt(0) at the loop header: each wave drained its previous store to HBM before
+	// blending the next vertex, and the kernel ran at blend time + store time. Now lanes and steps past the tile's end are CLAMPED
+	// to its last vertex (they recompute and rewrite the same 12 bytes), every load / store is unconditional, a wave keeps
+	// SKIN_PIPE - 1 stores in flight, and the wait covers only stores at least that many steps old.
+	const uint32_t v_last = v_end - 1; // v_begin < v_end (checked by the kernel)
+	const uint32_t v0 = v_begin + threadIdx.x;
+	RawVertex rec[SKIN_PIPE];
+#pragma unroll
+	for (int d = 0; d < SKIN_PIPE; ++d) rec[d] = load(min(v0 + d * SKIN_THREADS, v_last)); // in flight during the palette staging
 	{
 		const float4* pal = palette + (size_t)in.bone_offset * skin_rows(MODE);
 		const uint32_t n_rows = in.n_bones * skin_rows(MODE);
+		// <= 768 work items (64 x 3 rows x 4 lanes, 128 x 3 x 2, 196 x 3 x 1) on 512 lanes: two passes, both loads in flight
 		const float4 t0 = palette_fetch<COPIES>(pal, n_rows, threadIdx.x);
-		const float4 t1 = palette_fetch<COPIES>(pal, n_rows, threadIdx.x + SKIN_THREADS); // 196 bones: 588 rows
+		const float4 t1 = palette_fetch<COPIES>(pal, n_rows, threadIdx.x + SKIN_THREADS);
 		palette_spread<COPIES>(s_rows, n_rows, threadIdx.x, t0);
 		palette_spread<COPIES>(s_rows, n_rows, threadIdx.x + SKIN_THREADS, t1);
 	}
 	__syncthreads();
-	if (!has_first) return;
-	for (;;) {
-		const uint32_t vb = v + SKIN_THREADS;
-		const bool has_b = vb < v_end;
-		VertexIn b = a;
-		if (has_b) b = load(vb);
-		skin_one(a, v);
-		if (!has_b) break;
-		const uint32_t va = vb + SKIN_THREADS;
-		const bool has_a = va < v_end;
-		if (has_a) a = load(va);
-		skin_one(b, vb);
-		if (!has_a) break;
-		v = va;
+	const uint32_t n_steps = (v_end - v_begin + SKIN_THREADS - 1) / SKIN_THREADS; // block-uniform
+	for (uint32_t it = 0; it < n_steps; it += SKIN_PIPE) {
+#pragma unroll
+		for (int d = 0; d < SKIN_PIPE; ++d) {
+			const uint32_t v = min(v0 + (it + d) * SKIN_THREADS, v_last);
+			// opaque to the optimiser: whatever it derives from the record (packed operand pairs, LDS addresses) is formed HERE, at the
+			// use, not right behind the loads two steps earlier, where it would have to wait for them
+			asm volatile("" : "+v"(rec[d].a), "+v"(rec[d].b));
+			F3 o = skin_blend<COPIES, MODE>(rows, rec[d]);
+			// the blend is COMPLETE here (pure arithmetic is otherwise free to sink below the refill, towards the store, which keeps the
+			// old record alive and forces the refill into fresh registers + copies at the loop latch, waited for with vmcnt)
+			asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z));
+			__builtin_amdgcn_sched_barrier(0); // the refill goes into the registers the blend has just finished with: no copies
+			rec[d] = load(min(v0 + (it + d + SKIN_PIPE) * SKIN_THREADS, v_last));
+			if (!LMX_PROBE_SKIP(8) || o.x == 123.25f) obase[v] = o;
+			__builtin_amdgcn_sched_barrier(0);
+		}
 	}
 }
 
 template <int MODE>
 __global__ __launch_bounds__(SKIN_THREADS, SKIN_WAVES_PER_SIMD) void k_skin_vertices(const SkinInstance* __restrict__ inst,
 	const uint32_t* __restrict__ inst_index /* optional: the instances this launch covers */, uint32_t tiles_per_inst, uint32_t tile_verts,
-	const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices, const float4* __restrict__ palette,
-	float* __restrict__ out) {
+	const float4* __restrict__ mesh, const float4* __restrict__ palette, float* __restrict__ out) {
 	__shared__ float4 s_rows[SKIN_LDS_SLOTS];
 	uint32_t ii = blockIdx.x / tiles_per_inst;
 	const uint32_t tile = blockIdx.x - ii * tiles_per_inst;
@@ -377,87 +401,92 @@ __global__ __launch_bounds__(SKIN_THREADS, SKIN_WAVES_PER_SIMD) void k_skin_vert
 	const uint32_t v_begin = tile * tile_verts;
 	if (v_begin >= in.n_verts) return; // block-uniform
 	const uint32_t v_end = min(v_begin + tile_verts, in.n_verts);
-	if (in.n_bones <= 64) skin_tile<16, MODE>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
-	else if (in.n_bones <= 128) skin_tile<8, MODE>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
-	else skin_tile<4, MODE>(in, v_begin, v_end, s_rows, verts, weights, indices, palette, out);
+	if (in.n_bones <= 64) skin_tile<16, MODE>(in, v_begin, v_end, s_rows, mesh, palette, out);
+	else if (in.n_bones <= 128) skin_tile<8, MODE>(in, v_begin, v_end, s_rows, mesh, palette, out);
+	else skin_tile<4, MODE>(in, v_begin, v_end, s_rows, mesh, palette, out);
 }
 
 // ---- shared-mesh runs: vertex records in registers, palettes double-buffered in LDS -------------------------------------
 constexpr int SHARED_THREADS = 1024; // 16 waves = 4 per SIMD at <= 128 VGPRs; one block per CU (2 x 48 KiB LDS)
 constexpr int SHARED_VPT = 5;        // vertex records per lane (9 VGPRs each) -> tiles of up to 5120 vertices
+#ifndef LMX_SHARED_SPREAD_AFTER
+#define LMX_SHARED_SPREAD_AFTER 3
+#endif
+constexpr int SHARED_SPREAD_AFTER = LMX_SHARED_SPREAD_AFTER; // the next palette is spread into LDS after this vertex of the lane's five
 
 static_assert(SHARED_THREADS * SHARED_VPT == SKIN_SHARED_TILE_VERTS, "host tiling and kernel disagree");
 
 template <int COPIES, int MODE>
 __device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const SkinChunk& ch, float4 (*s_rows)[SKIN_LDS_SLOTS],
-	const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices,
-	const float4* __restrict__ palette, float* __restrict__ out) {
+	const float4* __restrict__ mesh, const float4* __restrict__ palette, float* __restrict__ out) {
 	const uint32_t tid = threadIdx.x;
 	const uint32_t col = tid & (COPIES - 1);
-	const F3* vbase = reinterpret_cast<const F3*>(verts) + in0.vert_offset;
-	const float4* wbase = weights + in0.vert_offset;
-	const int2* ibase = reinterpret_cast<const int2*>(indices) + in0.vert_offset;
-	// the lane's vertex records: loaded once, used for every instance of the chunk. The bone indices are kept as the 16-bit
-	// byte offsets of the bones' row 0 in the lane's palette copy ((bone * rows * COPIES + col) * 16 < 48 KiB), two per register.
-	VertexIn vin[SHARED_VPT];
+	const float4* mbase = mesh + 2 * (size_t)in0.vert_offset;
+	// the lane's vertex records: loaded once, used for every instance of the chunk, kept as loaded (8 VGPRs each: weights | position,
+	// 4 x u8 bone indices). The LDS addresses of a vertex's four bones are rebuilt from the index bytes for every instance
+	// (8 VALU instructions) - cheaper than the 5 VGPRs that keeping them as byte offsets cost: the kernel sits at the 128-VGPR limit.
+	// Lanes past the tile's end take its LAST vertex (they recompute and rewrite the same 12 bytes): every load and store below is
+	// unconditional, which is what lets the compiler COUNT them - see the s_waitcnt note at the instance loop.
+	const uint32_t v_last = ch.v_end - 1; // chunks are never empty
+	RawVertex vin[SHARED_VPT];
 #pragma unroll
-	for (int k = 0; k < SHARED_VPT; ++k) {
-		const uint32_t v = ch.v_begin + tid + k * SHARED_THREADS;
-		vin[k] = VertexIn{};
-		if (v < ch.v_end) {
-			const F3 p = vbase[v];
-			vin[k].px = p.x; vin[k].py = p.y; vin[k].pz = p.z;
-			vin[k].w = wbase[v];
-			const int2 iw = ibase[v];
-			const uint32_t b0 = (uint32_t)iw.x & 0xffffu, b1 = (uint32_t)iw.x >> 16, b2 = (uint32_t)iw.y & 0xffffu, b3 = (uint32_t)iw.y >> 16;
-			vin[k].iw.x = (int)(((b0 * (skin_rows(MODE) * COPIES) + col) * 16u) | (((b1 * (skin_rows(MODE) * COPIES) + col) * 16u) << 16));
-			vin[k].iw.y = (int)(((b2 * (skin_rows(MODE) * COPIES) + col) * 16u) | (((b3 * (skin_rows(MODE) * COPIES) + col) * 16u) << 16));
-		}
-	}
+	for (int k = 0; k < SHARED_VPT; ++k) vin[k] = load_vertex(mbase, min(ch.v_begin + tid + k * SHARED_THREADS, v_last));
 	// the chunk's instances are consecutive and share mesh and bone count: their bones and outputs are consecutive too
 	const uint32_t n_rows = in0.n_bones * skin_rows(MODE);
 	const float4* pal = palette + (size_t)in0.bone_offset * skin_rows(MODE);
 	F3* obase = reinterpret_cast<F3*>(out) + in0.out_offset;
 	palette_spread<COPIES>(s_rows[0], n_rows, tid, palette_fetch<COPIES>(pal, n_rows, tid));
+	// every load so far (vertex records, first palette) is complete before the loop: the compiler's s_waitcnt placement merges the
+	// loop-entry state into the steady state, and with loads possibly pending at the entry it tightens the waits INSIDE the loop
+	__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
 	__syncthreads();
 	for (uint32_t j = 0; j < ch.count; ++j) {
-		// next palette: fetched BEFORE this instance's stores are issued (loads and stores share the in-order vmcnt, so the
-		// wait for it below only covers stores of the previous instance), spread into the other buffer after the blend
-		const bool more = j + 1 < ch.count;
+		// Next palette: fetched BEFORE this instance's stores are issued. Loads and stores retire through ONE in-order counter
+		// (vmcnt), so the wait for this load, placed after k of the lane's stores, must be `s_waitcnt vmcnt(k)`: it then covers only
+		// stores of the previous instance. The compiler emits that count only when it can count: with a store (or this load) under
+		// a branch it falls back to vmcnt(0) and every wave drains all of its stores once per instance. Hence: no branch around a
+		// load or a store in this loop; lanes past the end of the tile or the palette are clamped, the last instance re-fetches
+		// its own palette. (Measured, tools/skin_probe.hip, per 1e9 vertices: fetching two instances ahead - so that the wait only
+		// covers stores nearly two instances old - changes nothing, 3.1 ms either way; what the staging costs is the 48 KiB of
+		// LDS writes per instance, 0.26 ms, and the palette's own HBM read next to a store-bound stream, 0.23 ms.)
 		float4 t = {};
-		if (more) t = palette_fetch<COPIES>(pal + (size_t)(j + 1) * n_rows, n_rows, tid);
-		const char* buf = reinterpret_cast<const char*>(s_rows[j & 1]);
+		if (LMX_PROBE_SKIP(256)) t = make_float4((float)j, (float)tid, 1.f, 2.f); // probe: the LDS writes without the load
+		else if (!LMX_PROBE_SKIP(32)) t = palette_fetch<COPIES>(pal + (size_t)min(j + 1, ch.count - 1) * n_rows, n_rows, tid);
+		__builtin_amdgcn_sched_barrier(0); // the load stays here, ahead of the stores
+		const float4* rows = s_rows[LMX_PROBE_SKIP(32) ? 0 : (j & 1)] + col;
 		F3* o = obase + (size_t)j * in0.n_verts;
 #pragma unroll
 		for (int k = 0; k < SHARED_VPT; ++k) {
-			const uint32_t v = ch.v_begin + tid + k * SHARED_THREADS;
-			if (v < ch.v_end) {
-				// opaque to the optimiser: nothing derived from the record (unpacked addresses, weight splats) is hoisted out
-				// of the instance loop into registers that do not exist
-				asm volatile("" : "+v"(vin[k].px), "+v"(vin[k].py), "+v"(vin[k].pz), "+v"(vin[k].w.x), "+v"(vin[k].w.y), "+v"(vin[k].w.z), "+v"(vin[k].w.w),
-					"+v"(vin[k].iw.x), "+v"(vin[k].iw.y));
-				const uint32_t o01 = (uint32_t)vin[k].iw.x, o23 = (uint32_t)vin[k].iw.y;
-				const F3 r = skin_blend_rows<COPIES, MODE>(reinterpret_cast<const float4*>(buf + (o01 & 0xffffu)), reinterpret_cast<const float4*>(buf + (o01 >> 16)),
-					reinterpret_cast<const float4*>(buf + (o23 & 0xffffu)), reinterpret_cast<const float4*>(buf + (o23 >> 16)), vin[k]);
-				if (!LMX_PROBE_SKIP(8) || r.x == 123.25f) o[v] = r;
+			const uint32_t v = min(ch.v_begin + tid + k * SHARED_THREADS, v_last);
+			// opaque to the optimiser: nothing derived from the record (LDS addresses, operand pairs) is hoisted out of the instance
+			// loop into registers that do not exist
+			asm volatile("" : "+v"(vin[k].a), "+v"(vin[k].b));
+			const F3 r = skin_blend<COPIES, MODE>(rows, vin[k]);
+			if (!LMX_PROBE_SKIP(8) || r.x == 123.25f) o[v] = r;
+			if (!LMX_PROBE_SKIP(128)) __builtin_amdgcn_sched_barrier(0); // one vertex's 12 palette rows (48 VGPRs) in flight at a time
+			if (k == SHARED_SPREAD_AFTER && !LMX_PROBE_SKIP(32)) {
+				// the next palette goes into the other buffer late in the instance (sooner, the wait for its load stalls: 3.6 ms
+				// after vertex 0 or 1), by every wave (4 ds_write_b128 each). `t` is used by every lane here: without that its load
+				// is sunk into palette_spread's branch, behind the stores, and waited for with vmcnt(0). (After the last instance:
+				// into the idle buffer, never read.)
+				asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
+				palette_spread<COPIES>(s_rows[(j + 1) & 1], n_rows, tid, t);
+				__builtin_amdgcn_sched_barrier(0);
 			}
-			__builtin_amdgcn_sched_barrier(0); // one vertex's 12 palette rows (48 VGPRs) in flight at a time
 		}
-		if (more) palette_spread<COPIES>(s_rows[(j + 1) & 1], n_rows, tid, t);
-		__syncthreads(); // buffer (j + 1) & 1 is complete; buffer j & 1 is free for instance j + 2
+		if (!LMX_PROBE_SKIP(64)) __syncthreads(); // buffer (j + 1) & 1 is complete; buffer j & 1 is free for instance j + 2
 	}
 }
 
 template <int MODE>
 __global__ __launch_bounds__(SHARED_THREADS) void k_skin_shared(const SkinInstance* __restrict__ inst, const SkinChunk* __restrict__ chunks,
-	const float* __restrict__ verts, const float4* __restrict__ weights, const int16_t* __restrict__ indices, const float4* __restrict__ palette,
-	float* __restrict__ out) {
+	const float4* __restrict__ mesh, const float4* __restrict__ palette, float* __restrict__ out) {
 	__shared__ float4 s_rows[2][SKIN_LDS_SLOTS];
 	const SkinChunk ch = chunks[blockIdx.x];
 	const SkinInstance in0 = inst[ch.first_inst];
-	if (in0.n_bones <= 64) skin_shared_tile<16, MODE>(in0, ch, s_rows, verts, weights, indices, palette, out);
-	else if (in0.n_bones <= 128) skin_shared_tile<8, MODE>(in0, ch, s_rows, verts, weights, indices, palette, out);
-	else skin_shared_tile<4, MODE>(in0, ch, s_rows, verts, weights, indices, palette, out);
+	if (in0.n_bones <= 64) skin_shared_tile<16, MODE>(in0, ch, s_rows, mesh, palette, out);
+	else if (in0.n_bones <= 128) skin_shared_tile<8, MODE>(in0, ch, s_rows, mesh, palette, out);
+	else skin_shared_tile<4, MODE>(in0, ch, s_rows, mesh, palette, out);
 }
 
 } // namespace
@@ -491,7 +520,7 @@ hipError_t launch_palette_expand(hipStream_t s, const float4* rows, uint32_t n_b
 }
 
 hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, const uint32_t* inst_index, uint32_t n_inst, uint32_t max_verts,
-	const float* verts, const float4* weights, const int16_t* indices, const float4* palette, float* out, int mode) {
+	const float4* mesh, const float4* palette, float* out, int mode) {
 	if (!n_inst || !max_verts) return hipSuccess;
 	// tiles: as large as possible (the 48 KiB palette staging is paid per tile) while still giving the chip >= ~3000 blocks
 	const uint32_t max_tiles = (max_verts + 1023u) / 1024u;
@@ -502,19 +531,19 @@ hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, const u
 	const uint64_t blocks = (uint64_t)tiles * n_inst;
 	if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
 	const dim3 grid((uint32_t)blocks), block(SKIN_THREADS);
-	if (mode == LMX_SKIN_EXACT) hipLaunchKernelGGL(k_skin_vertices<LMX_SKIN_EXACT>, grid, block, 0, s, inst, inst_index, tiles, tile_verts, verts, weights, indices, palette, out);
-	else if (mode == LMX_SKIN_DQS) hipLaunchKernelGGL(k_skin_vertices<LMX_SKIN_DQS>, grid, block, 0, s, inst, inst_index, tiles, tile_verts, verts, weights, indices, palette, out);
-	else hipLaunchKernelGGL(k_skin_vertices<LMX_SKIN_FUSED>, grid, block, 0, s, inst, inst_index, tiles, tile_verts, verts, weights, indices, palette, out);
+	if (mode == LMX_SKIN_EXACT) hipLaunchKernelGGL(k_skin_vertices<LMX_SKIN_EXACT>, grid, block, 0, s, inst, inst_index, tiles, tile_verts, mesh, palette, out);
+	else if (mode == LMX_SKIN_DQS) hipLaunchKernelGGL(k_skin_vertices<LMX_SKIN_DQS>, grid, block, 0, s, inst, inst_index, tiles, tile_verts, mesh, palette, out);
+	else hipLaunchKernelGGL(k_skin_vertices<LMX_SKIN_FUSED>, grid, block, 0, s, inst, inst_index, tiles, tile_verts, mesh, palette, out);
 	return hipGetLastError();
 }
 
-hipError_t launch_skin_shared(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float* verts,
-	const float4* weights, const int16_t* indices, const float4* palette, float* out, int mode) {
+hipError_t launch_skin_shared(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh,
+	const float4* palette, float* out, int mode) {
 	if (!n_chunks) return hipSuccess;
 	const dim3 grid(n_chunks), block(SHARED_THREADS);
-	if (mode == LMX_SKIN_EXACT) hipLaunchKernelGGL(k_skin_shared<LMX_SKIN_EXACT>, grid, block, 0, s, inst, chunks, verts, weights, indices, palette, out);
-	else if (mode == LMX_SKIN_DQS) hipLaunchKernelGGL(k_skin_shared<LMX_SKIN_DQS>, grid, block, 0, s, inst, chunks, verts, weights, indices, palette, out);
-	else hipLaunchKernelGGL(k_skin_shared<LMX_SKIN_FUSED>, grid, block, 0, s, inst, chunks, verts, weights, indices, palette, out);
+	if (mode == LMX_SKIN_EXACT) hipLaunchKernelGGL(k_skin_shared<LMX_SKIN_EXACT>, grid, block, 0, s, inst, chunks, mesh, palette, out);
+	else if (mode == LMX_SKIN_DQS) return hipErrorInvalidValue; // the dual-quaternion blend needs ~75 VGPRs of its own: with five resident records it spilled (284 B of scratch per lane); lmx_skin_run sends LMX_SKIN_DQS through k_skin_vertices (61 VGPRs)
+	else hipLaunchKernelGGL(k_skin_shared<LMX_SKIN_FUSED>, grid, block, 0, s, inst, chunks, mesh, palette, out);
 	return hipGetLastError();
 }
 

@@ -1,6 +1,12 @@
-// Development probe: times k_skin_vertices<false> with parts switched off (bit 8: vertex stores, 16: LDS palette reads).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DLMX_PROBE_MASK=<bits> -I lumixengine_amd/csrc tools/skin_probe.hip -o tools/_build/skin_probe_<bits>
+// Development probe: times k_skin_vertices / k_skin_shared with parts compiled out. LMX_PROBE_MASK bits:
+//     8 vertex stores      16 LDS palette reads      32 palette staging (fetch + spread; every instance reads buffer 0)
+//    64 per-instance barrier (k_skin_shared)      128 per-vertex scheduling barrier      256 staging without its global load
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DLMX_PROBE_MASK=<bits> -I lumixengine_amd/csrc -I include tools/skin_probe.hip -o tools/_build/skin_probe_<bits>
 //   skin_probe_<bits> [instances] [instances per block] [1 = k_skin_shared, 0 = k_skin_vertices]
+// Round-2 readings, 20 000 instances x 10 000 vertices x 64 bones, ms per 1e9 vertices (k_skin_shared): all 3.1-3.2 | no stores 1.36 |
+// no LDS reads 2.2 | neither 0.79 | no staging 2.59 | no staging, no stores 0.93 | staging without its load 2.85 |
+// no staging, no barrier 3.16 (the barrier keeps a block's waves on ONE instance's 61 KB of output: without it the store stream
+// loses locality). A bare 12-byte fill of the same shape: 2.0-2.4 (tools/write_probe.hip, tools/lds_store_probe.hip).
 #include <hip/hip_runtime.h>
 #ifndef LMX_PROBE_MASK
 #define LMX_PROBE_MASK 0
@@ -9,6 +15,7 @@
 #include "skin_kernels.hip"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 using namespace lmx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -16,18 +23,19 @@ int main(int argc, char** argv) {
 	const uint32_t n_inst = argc > 1 ? atoi(argv[1]) : 20000, nb = 64, nv = 10000;
 	std::vector<SkinInstance> inst(n_inst);
 	for (uint32_t i = 0; i < n_inst; ++i) { SkinInstance in{}; in.bone_offset = i * nb; in.n_bones = nb; in.vert_offset = 0; in.n_verts = nv; in.out_offset = i * nv; inst[i] = in; }
-	std::vector<float> verts(nv * 3), w(nv * 4), pal((size_t)n_inst * nb * 12);
-	std::vector<int16_t> idx(nv * 4);
+	std::vector<float4> mesh(nv * 2);
+	std::vector<float> pal((size_t)n_inst * nb * 12);
 	srand(3);
-	for (auto& v : verts) v = rand() / (float)RAND_MAX;
-	for (auto& v : w) v = 0.25f;
-	for (auto& v : idx) v = rand() % nb;
+	for (uint32_t v = 0; v < nv; ++v) {
+		const uint32_t idx = (uint32_t)(rand() % nb) | ((uint32_t)(rand() % nb) << 8) | ((uint32_t)(rand() % nb) << 16) | ((uint32_t)(rand() % nb) << 24);
+		float bits; memcpy(&bits, &idx, 4);
+		mesh[2 * v] = make_float4(0.25f, 0.25f, 0.25f, 0.25f);
+		mesh[2 * v + 1] = make_float4(rand() / (float)RAND_MAX, rand() / (float)RAND_MAX, rand() / (float)RAND_MAX, bits);
+	}
 	for (auto& v : pal) v = rand() / (float)RAND_MAX;
-	SkinInstance* d_inst; float *d_v, *d_out; float4 *d_w, *d_pal; int16_t* d_i;
+	SkinInstance* d_inst; float* d_out; float4 *d_mesh, *d_pal;
 	CK(hipMalloc(&d_inst, inst.size() * sizeof(SkinInstance))); CK(hipMemcpy(d_inst, inst.data(), inst.size() * sizeof(SkinInstance), hipMemcpyHostToDevice));
-	CK(hipMalloc(&d_v, verts.size() * 4)); CK(hipMemcpy(d_v, verts.data(), verts.size() * 4, hipMemcpyHostToDevice));
-	CK(hipMalloc(&d_w, w.size() * 4)); CK(hipMemcpy(d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
-	CK(hipMalloc(&d_i, idx.size() * 2)); CK(hipMemcpy(d_i, idx.data(), idx.size() * 2, hipMemcpyHostToDevice));
+	CK(hipMalloc(&d_mesh, mesh.size() * 16)); CK(hipMemcpy(d_mesh, mesh.data(), mesh.size() * 16, hipMemcpyHostToDevice));
 	CK(hipMalloc(&d_pal, pal.size() * 4)); CK(hipMemcpy(d_pal, pal.data(), pal.size() * 4, hipMemcpyHostToDevice));
 	CK(hipMalloc(&d_out, (size_t)n_inst * nv * 12));
 	const uint32_t per_block = argc > 2 ? atoi(argv[2]) : 64, tile = 5056;
@@ -42,8 +50,8 @@ int main(int argc, char** argv) {
 		float best = 1e9f;
 		for (int it = 0; it < 5; ++it) {
 			CK(hipEventRecord(e0));
-			if (shared) CK(launch_skin_shared(0, d_inst, d_chunks, (uint32_t)chunks.size(), d_v, d_w, d_i, d_pal, d_out, false));
-			else CK(launch_skin_vertices(0, d_inst, nullptr, n_inst, nv, d_v, d_w, d_i, d_pal, d_out, false));
+			if (shared) CK(launch_skin_shared(0, d_inst, d_chunks, (uint32_t)chunks.size(), d_mesh, d_pal, d_out, false));
+			else CK(launch_skin_vertices(0, d_inst, nullptr, n_inst, nv, d_mesh, d_pal, d_out, false));
 			CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
 			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
 			if (it && ms < best) best = ms;
