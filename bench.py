@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the dense-variant / transform / skin side measurements")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc child passes; quote the committed profiles/rNN/traffic.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skinned-instances", type=int, default=100_000, help="--scaling strong: skinned instances of BASELINE config 4, sharded by index (0 = skip)")
     ap.add_argument("--big-entities", type=int, default=100_000_000, help="extras: entity count of the config-5-sized single-GPU legs (0 = skip)")
     args = ap.parse_args()
 
@@ -211,6 +212,36 @@ def main():
             del whole
             ctx_whole.close()
         log(f"[rank {rank}] exchange verified: {dist_info}")
+        if strong and args.skinned_instances:
+            # the rest of BASELINE config 4: 100 k skinned instances (one shared 10 k-vertex mesh, 64 bones) sharded by index - no
+            # exchange, every rank skins its own instances - next to its cell shard of the scene. One simulated frame = cull of the
+            # shard + exchange + pose -> palette -> vertices of the rank's instances; MAX over ranks, like the headline.
+            mine_i = D.shard_by_index(args.skinned_instances, world, rank)
+            s_sk = scenes.skeleton(64, seed=4)
+            verts_sk, skin_sk = scenes.skinned_mesh(10_000, 64, seed=6)
+            sk = api.Skinning(ctx)
+            model_sk = sk.addModel(s_sk["parents"], s_sk["bind"], s_sk["first_nonroot"])
+            mesh_sk = sk.addMesh(verts_sk, skin_sk)
+            sk.setInstances(np.full(len(mine_i), model_sk, np.uint32), np.full(len(mine_i), mesh_sk, np.uint32))
+            pos_sk, rot_sk = scenes.relative_poses(len(mine_i), 64, seed=8 + rank)
+            d_pos_sk, d_rot_sk = torch.from_numpy(pos_sk).cuda(), torch.from_numpy(rot_sk).cuda()
+            del pos_sk, rot_sk
+            sk.setPoseSourceDevice(d_pos_sk.data_ptr(), d_rot_sk.data_ptr(), len(mine_i) * 64)
+
+            def frame_c4():
+                step()
+                sk.run()
+
+            for _ in range(2):
+                frame_c4()
+            ms_c4 = timed(frame_c4, 10)
+            dist_info["config4_frame"] = {
+                "skinned_instances_total": args.skinned_instances, "skinned_instances_this_rank": int(len(mine_i)), "verts_per_instance": 10_000,
+                "ms_per_frame_max_over_ranks": ms_c4, "frames_per_sec": 1e3 / ms_c4,
+                "skinned_verts_per_sec_all_ranks": args.skinned_instances * 10_000 / (ms_c4 * 1e-3),
+                "what": "cull of the rank's cell shard + native all-gather + pose/palette/vertex kernels of the rank's instances (shard_by_index)"}
+            log(f"[rank {rank}] config 4 frame: {dist_info['config4_frame']}")
+            del sk, d_pos_sk, d_rot_sk
         xchg.close()
         log(f"[rank {rank}] exchange closed")
 

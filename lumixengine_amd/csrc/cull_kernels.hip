@@ -218,16 +218,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg
 	const uint32_t win = g_win_base[shard];
 
 	// Accepted tile without padding or tombstones (1-frustum kernels): its ids are a straight copy. The wave's count is known
-	// (CHW x 64), so the reservation is issued before the loads instead of after them, and ids move 16 bytes per lane.
+	// (CHW x 64), so the reservation does not have to wait for the loads' results, and ids move 16 bytes per lane.
 	if constexpr (F == 1) {
 		if (!any_mixed && (tile_flags & TILE_DENSE)) {
 			constexpr uint32_t PER_WAVE = CHW * 64;
-			uint32_t base = 0;
-			if (lane == 0) base = atomicAdd(&g_counts[shard * a.cnt_pad], PER_WAVE);
 			const uint4* src = reinterpret_cast<const uint4*>(g_ids + ((size_t)((tile_ent >> 6) + wave * CHW) << 6));
 			uint4 v[CHW / 4];
 #pragma unroll
 			for (int k = 0; k < CHW / 4; ++k) v[k] = src[k * 64 + lane];
+			// the reservation goes out BEHIND the loads, in the same breath: the compiler waits for a returning atomic at the end of
+			// its `lane == 0` branch (vmcnt(0)), so issued first it stood, one full round trip, in front of the loads
+			__builtin_amdgcn_sched_barrier(0);
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd(&g_counts[shard * a.cnt_pad], PER_WAVE);
 			base = __builtin_amdgcn_readfirstlane(base) + win;
 			// the reserved range starts at an arbitrary id: 16-byte stores need 4-byte alignment only on global memory
 			int32_t* dst = g_out_ids + base;

@@ -10,12 +10,14 @@
 //   createModules   world.addModule(Mi355Module)                                    (world.cpp:218-235)
 //   init            mirror the World's hierarchy (WorldSync::build), find the "renderer" module, register skeletons / meshes
 //   update          propagate the frame's staged transform writes level by level on the GPU (+ culling sphere refresh),
-//                   gather relative poses through lockPose / unlockPose, run pose -> palette -> skin, store absolute poses back
+//                   gather relative poses through lockPose / unlockPose, run pose -> palette -> skin, move bone-attached entities,
+//                   store absolute poses back
 //   createGpuCullingSystem   what RenderModuleImpl's constructor calls instead of CullingSystem::create (render_module.cpp:3569)
 #include "core/allocator.h"
 #include "core/page_allocator.h"
 #include "engine/engine.h"
 #include "engine/plugin.h"
+#include "engine/reflection.h"
 #include "engine/world.h"
 #include "renderer/culling_system.h"
 #include "renderer/model.h"
@@ -72,7 +74,13 @@ struct Mi355Module final : IModule {
 		m_sync->readTransforms(const_cast<Transform*>(m_world.getTransforms()), m_sync->entityCount());
 		// 2. relative poses -> absolute poses, palettes, skinned vertices
 		if (m_render_module && m_poses && !m_skinned.empty()) {
-			if (m_poses->gather(*m_render_module) && m_poses->run()) m_poses->scatter(*m_render_module);
+			if (m_poses->gather(*m_render_module) && m_poses->run()) {
+				// 3. bone attachments follow the fresh absolute poses on the device (RenderModuleImpl::updateBoneAttachment,
+				//    render_module.cpp:377-404, for every attachment of a moved pose, :1964-1981); the attached roots' subtrees and
+				//    culling spheres are carried by the next propagate
+				if (m_n_attachments) lmx_world_update_bone_attachments(m_ctx);
+				m_poses->scatter(*m_render_module);
+			}
 		}
 	}
 
@@ -123,6 +131,44 @@ private:
 		if (!m_bound.empty()) m_sync->bindCulling(m_bound.begin(), m_bound_radius.data(), (u32)m_bound.size());
 		if (!m_skinned.empty())
 			m_poses->setInstances(m_skinned.begin(), m_skinned_models.data(), m_skinned_meshes.data(), m_skinned_bones.data(), (u32)m_skinned.size());
+		bindBoneAttachments();
+	}
+
+	// RenderModuleImpl::m_bone_attachments through the module's public accessors (render_module.h:404-413): attached entity ->
+	// {parent entity, bone index, relative transform}; the parent must be one of the skinned instances registered above.
+	// getBoneAttachmentRotation hands the stored quaternion out as Euler angles (render_module.cpp:484-487): Quat::fromEuler of
+	// them equals the stored rotation only up to rounding. A tree that wants updateBoneAttachment's results bit for bit adds a
+	// `LocalRigidTransform getBoneAttachmentTransform(EntityRef)` accessor to RenderModule (one line) - or takes
+	// the attachments from the serialized scene, where the quaternion is stored as is (render_module.cpp:895-902).
+	void bindBoneAttachments() {
+		m_n_attachments = 0;
+		if (!m_render_module || m_skinned.empty()) return;
+		const ComponentType attachment_type = reflection::getComponentType("bone_attachment");
+		std::vector<i32> entity, parent;
+		std::vector<u32> instance, bone;
+		std::vector<LmxLocalRigidTransform> relative;
+		for (EntityPtr it = m_world.getFirstEntity(); it.isValid(); it = m_world.getNextEntity((EntityRef)it)) {
+			const EntityRef e = (EntityRef)it;
+			if (!m_world.hasComponent(e, attachment_type)) continue;
+			const EntityPtr p = m_render_module->getBoneAttachmentParent(e);
+			const int b = m_render_module->getBoneAttachmentBone(e);
+			if (!p.isValid() || b < 0) continue; // updateBoneAttachment returns early for these (:378, :393-397)
+			u32 inst = 0;
+			while (inst < (u32)m_skinned.size() && m_skinned.begin()[inst].index != p.index) ++inst;
+			if (inst == (u32)m_skinned.size() || (u32)b >= m_skinned_bones[inst]) continue; // parent without a pose / bone out of range (:386-397)
+			const Vec3 pos = m_render_module->getBoneAttachmentPosition(e);
+			Quat rot;
+			rot.fromEuler(m_render_module->getBoneAttachmentRotation(e));
+			LmxLocalRigidTransform rel = {{pos.x, pos.y, pos.z}, {rot.x, rot.y, rot.z, rot.w}};
+			entity.push_back(e.index);
+			parent.push_back(p.index);
+			instance.push_back(inst);
+			bone.push_back((u32)b);
+			relative.push_back(rel);
+		}
+		if (entity.empty()) return;
+		if (lmx_world_set_bone_attachments(m_ctx, (u32)entity.size(), entity.data(), parent.data(), instance.data(), bone.data(), relative.data()) == LMX_OK)
+			m_n_attachments = (u32)entity.size();
 	}
 
 	ISystem& m_system;
@@ -133,6 +179,7 @@ private:
 	UniquePtr<WorldSync> m_sync;
 	UniquePtr<PoseBridge> m_poses;
 	bool m_dirty = true;
+	u32 m_n_attachments = 0;
 	struct EntityList {
 		std::vector<EntityRef> v;
 		void clear() { v.clear(); }
