@@ -717,6 +717,22 @@ def extras(ctx, api, scenes, torch, timed, N, log, big_entities=0):
     out["skin_instances"] = n_inst
     out["skin_GBps_algorithmic_48B"] = 48.0 * n_inst * n_verts / (ms * 1e-3) / 1e9
     out["skin_GBps_shared_mesh_floor_12B"] = 12.0 * n_inst * n_verts / (ms * 1e-3) / 1e9
+    # the same slice through the dual-quaternion path (32-byte palette + the shader's DQ vertex blend) and in
+    # LMX_SKIN_EXACT (the mode that is bit-identical to evaluateSkin)
+    for mode_name, mode in (("dqs", api.SKIN_DQS), ("exact", api.SKIN_EXACT)):
+        sk.setMode(mode)
+        for _ in range(3):
+            skin_step()
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(10):
+            skin_step()
+        ctx.synchronize()
+        ctx.profile_enable(False)
+        t_m, n_m = ctx.profile_get(api.K_SKIN_VERTICES)
+        out[f"skin_{mode_name}_vertex_kernel_avg_ms"] = t_m / max(n_m, 1)
+        out[f"skin_{mode_name}_verts_per_sec"] = n_inst * n_verts / (t_m / max(n_m, 1) * 1e-3)
+    sk.setMode(api.SKIN_FUSED)
     del sk
     # BASELINE config 3 as one simulated frame on one GPU: 1 M entities in depth-4 chains, every root moved, every entity
     # bound to the culling system (dynamic set, refreshed on the device), one camera cull, 10 k skinned instances x 64 bones
@@ -832,7 +848,7 @@ def extras(ctx, api, scenes, torch, timed, N, log, big_entities=0):
     out["target_animated_frames_per_sec_1gpu"] = 1e3 / ms4a
     out["target_animated_kernel_ms"] = {api.KERNEL_NAMES[k]: round(ctx.profile_get(k)[0] / 5, 5) for k in range(len(api.KERNEL_NAMES)) if ctx.profile_get(k)[1]}
     del cs4, sk4, d_pos4, d_rot4
-    # distinct meshes: every instance streams its own 36 B/vertex from HBM (the 48 B/vertex algorithmic figure is real traffic)
+    # distinct meshes: every instance streams its own 32-byte vertex records from HBM (44 B/vertex moved; SURVEY.md's algorithmic figure is 48)
     n_inst2 = 1500  # 540 MB of mesh data + 180 MB of output: well beyond the 256 MiB Infinity Cache
     sk = api.Skinning(ctx)
     model = sk.addModel(s["parents"], s["bind"], s["first_nonroot"])
