@@ -260,8 +260,13 @@ def test_rebinding_keeps_moved_spheres(gpu_ctx, oracle_port):
 
 
 def close_1e5(got, want):
-    """north star: skinned vertex positions within 1e-5 relative fp32 (relative to the magnitude of the positions)"""
-    return np.allclose(got, want, rtol=1e-5, atol=1e-5 * float(np.abs(want).max()))
+    """north star: skinned vertex positions within 1e-5 relative fp32 - PER VERTEX: every component within 1e-5 of that vertex's own
+    magnitude (max |component|), floored at 1 % of the mesh's extent (a vertex that lands next to the origin is still the sum of
+    terms as large as the skeleton: its rounding error does not shrink with it)."""
+    got = np.asarray(got, np.float64).reshape(-1, 3)
+    want = np.asarray(want, np.float64).reshape(-1, 3)
+    scale = np.maximum(np.abs(want).max(axis=1), 1e-2 * float(np.abs(want).max()))
+    return bool((np.abs(got - want).max(axis=1) <= 1e-5 * scale).all())
 
 
 @pytest.mark.parametrize("exact", [True, False])
