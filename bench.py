@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the dense-variant / transform / skin side measurements")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc child passes; quote the committed profiles/rNN/traffic.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--default-stream", action="store_true", help="N > 1: launch on the legacy default stream (the pre-round-2 behaviour, for comparison)")
     ap.add_argument("--skinned-instances", type=int, default=100_000, help="--scaling strong: skinned instances of BASELINE config 4, sharded by index (0 = skip)")
     ap.add_argument("--big-entities", type=int, default=100_000_000, help="extras: entity count of the config-5-sized single-GPU legs (0 = skip)")
     args = ap.parse_args()
@@ -80,8 +81,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if use_dist and not args.default_stream:
+        # N > 1: launches go to a stream of their own, not the legacy default stream. Every event record / stream wait that involves
+        # the default stream makes the runtime look at all other blocking streams, and a step of the exchange path issues four of them
+        # (measured with a world of one rank: 41 us of host time per step on the default stream - 15.6 us for ONE record + wait pair).
+        torch.cuda.set_stream(torch.cuda.Stream())
     ctx = api.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launches and torch.cuda.synchronize() share one stream
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # launches, the events of `timed` and torch.cuda.synchronize() share one stream
 
     def barrier():
         if use_dist:

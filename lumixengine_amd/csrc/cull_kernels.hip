@@ -484,6 +484,37 @@ __global__ __launch_bounds__(256) void k_cull_consolidate(const int32_t* __restr
 	for (uint32_t k = blockIdx.z * 256u + threadIdx.x; k < n; k += gridDim.z * 256u) to[k] = from[k];
 }
 
+// One launch instead of finalize + consolidate for the PACKED record [MAX_TYPES counts | ids, types back to back] of ONE frustum
+// (the exchange's send buffer, lmx_cull_map_all's host record). Shards are ordered by type (recompute_out_layout), so a shard's
+// place in the packed list is the plain exclusive prefix of the counts of ALL shards before it: every block sums those <= 575
+// counters itself (one per thread, separate cache lines, L2 hits) instead of waiting for a one-block scan kernel - 7 us of GPU time
+// and one launch less per frame. Block (0, 0) also writes the per-type totals. grid (n_shards, splits).
+__global__ __launch_bounds__(256) void k_cull_pack(const int32_t* __restrict__ src, const uint32_t* __restrict__ win_base, const uint32_t* __restrict__ counts,
+	uint32_t cnt_pad, const uint8_t* __restrict__ shard_type, uint32_t n_shards, uint32_t* __restrict__ header, int32_t* __restrict__ dst, uint32_t dst_cap) {
+	__shared__ uint32_t s_part[4];
+	__shared__ uint32_t s_tot[MAX_TYPES];
+	const uint32_t s = blockIdx.x, t = threadIdx.x;
+	uint32_t before = 0;
+	for (uint32_t k = t; k < s; k += 256u) before += counts[k * cnt_pad]; // (<= 3 iterations)
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) before += (uint32_t)__shfl_xor((int)before, o);
+	if ((t & 63u) == 0) s_part[t >> 6] = before;
+	if (s == 0 && blockIdx.y == 0 && t < MAX_TYPES) s_tot[t] = 0;
+	__syncthreads();
+	const uint32_t at = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+	const uint32_t c = counts[s * cnt_pad];
+	if (s == 0 && blockIdx.y == 0) { // totals per type: what the rank saw, also beyond dst_cap
+		for (uint32_t k = t; k < n_shards; k += 256u) atomicAdd(&s_tot[shard_type[k]], counts[k * cnt_pad]);
+		__syncthreads();
+		if (t < MAX_TYPES) header[t] = s_tot[t];
+	}
+	const int32_t* from = src + win_base[s];
+	int32_t* to = dst + at;
+	const uint32_t room = at < dst_cap ? dst_cap - at : 0u;
+	const uint32_t n = c < room ? c : room;
+	for (uint32_t k = blockIdx.y * 256u + t; k < n; k += gridDim.y * 256u) to[k] = from[k];
+}
+
 template <int F, int WAVES, int CHW, int GRP, int LANEPAR>
 hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt, const FrustaArg& fr, int n_frusta,
 	const CullOut& out) {
@@ -586,6 +617,15 @@ hipError_t launch_cull_consolidate(hipStream_t s, const int32_t* src, uint32_t s
 	const uint32_t splits = std::max(1u, std::min(64u, max_shard_cap / 4096u));
 	hipLaunchKernelGGL(k_cull_consolidate, dim3(n_shards, n_frusta, splits), dim3(256), 0, s, src, src_stride, win_base, counts, cnt_pad, cnt_frustum_stride,
 		shard_type, type_start, type_start_stride, pref, n_shards, dst, dst_stride, dst_cap);
+	return hipGetLastError();
+}
+
+hipError_t launch_cull_pack(hipStream_t s, const int32_t* src, const uint32_t* win_base, const uint32_t* counts, uint32_t cnt_pad, const uint8_t* shard_type,
+	uint32_t n_shards, uint32_t max_shard_cap, uint32_t* header, int32_t* dst, uint32_t dst_cap) {
+	if (!n_shards) return hipSuccess;
+	if (n_shards > (uint32_t)FIN_MAX_SHARDS) return hipErrorInvalidValue;
+	const uint32_t splits = std::max(1u, std::min(64u, max_shard_cap / 4096u));
+	hipLaunchKernelGGL(k_cull_pack, dim3(n_shards, splits), dim3(256), 0, s, src, win_base, counts, cnt_pad, shard_type, n_shards, header, dst, dst_cap);
 	return hipGetLastError();
 }
 

@@ -1036,9 +1036,8 @@ int lmx_cull_map_all(LmxContext* ctx, uint32_t view, uint32_t frustum, const int
 	const uint32_t cnt_frustum_stride = cs.n_shards * cs.cnt_pad;
 	const uint32_t* counts = v.counts_ptr() + (size_t)frustum * cnt_frustum_stride;
 	uint32_t* header = reinterpret_cast<uint32_t*>(v.map_rec.p);
-	LMX_HIP(ctx, launch_cull_finalize(ctx->stream, counts, cs.cnt_pad, cnt_frustum_stride, cs.d_shard_type.p, cs.n_shards, 1, header, v.map_pref.p, v.map_start.p));
-	LMX_HIP(ctx, launch_cull_consolidate(ctx->stream, v.out.p + (size_t)frustum * v.out_stride, v.out_stride, cs.d_win_base.p, counts, cs.cnt_pad, cnt_frustum_stride,
-		cs.d_shard_type.p, v.map_start.p, MAX_TYPES, v.map_pref.p, cs.n_shards, 1, cs.max_shard_cap, v.map_rec.p + MAX_TYPES, 0, v.out_stride));
+	LMX_HIP(ctx, launch_cull_pack(ctx->stream, v.out.p + (size_t)frustum * v.out_stride, cs.d_win_base.p, counts, cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, cs.max_shard_cap,
+		header, v.map_rec.p + MAX_TYPES, v.out_stride));
 	const size_t guess = std::min<size_t>(v.out_stride, v.map_guess);
 	LMX_HIP(ctx, hipMemcpyAsync(v.map_host, v.map_rec.p, (MAX_TYPES + guess) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -142,12 +142,10 @@ int lmx_exchange_cull(LmxExchange* x, const LmxShiftedFrustum* frustum, uint8_t 
 	if (int rc = lmx_cull(ctx, k, frustum, 1, type)) return rc;
 	CullState& cs = ctx->cull;
 	CullView& v = cs.views[k];
-	// per-type totals straight into the record's header, packed type starts, then the ids behind the header (clipped to cap)
-	LMX_HIP(ctx, v.pref.reserve(std::max<size_t>((size_t)MAX_FRUSTA * cs.n_shards, 1)));
+	// per-type totals straight into the record's header and the ids behind it (clipped to cap), one launch (k_cull_pack)
 	uint32_t* header = reinterpret_cast<uint32_t*>(x->send[k].p);
-	LMX_HIP(ctx, launch_cull_finalize(ctx->stream, v.counts_ptr(), cs.cnt_pad, cs.n_shards * cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, 1, header, v.pref.p, x->packed_start[k].p));
-	LMX_HIP(ctx, launch_cull_consolidate(ctx->stream, v.out.p, v.out_stride, cs.d_win_base.p, v.counts_ptr(), cs.cnt_pad, cs.n_shards * cs.cnt_pad, cs.d_shard_type.p,
-		x->packed_start[k].p, MAX_TYPES, v.pref.p, cs.n_shards, 1, cs.max_shard_cap, x->send[k].p + MAX_TYPES, 0, x->cap));
+	LMX_HIP(ctx, launch_cull_pack(ctx->stream, v.out.p, cs.d_win_base.p, v.counts_ptr(), cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, cs.max_shard_cap, header,
+		x->send[k].p + MAX_TYPES, x->cap));
 	LMX_HIP(ctx, hipEventRecord(x->culled[k], ctx->stream));
 	LMX_HIP(ctx, hipStreamWaitEvent(x->side, x->culled[k], 0));
 	const int rc = rccl().AllGather(x->send[k].p, x->recv[k].p, x->record, NCCL_INT32, x->comm, x->side);
