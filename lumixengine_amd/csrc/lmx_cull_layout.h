@@ -187,84 +187,118 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 
 	size_t count_by_type[LAYOUT_MAX_TYPES] = {};
 	for (size_t i = 0; i < n; ++i) count_by_type[recs[i].type]++;
-	// The placement loop below is a serial state machine (padding rules). What it reads and writes per sphere is made sequential
-	// first: the records gathered into sorted order and, afterwards, the slots scattered back to record order are the two random
-	// passes over the 10^7..10^8 entries, and both run on all threads.
+	// Placement. The padding rules are a serial state machine, but its state only changes at CELL boundaries: the spheres are cut
+	// into cells in parallel, the state machine walks the ~n / 10 cells (not the n spheres), and the spheres / ids / cell slots are
+	// written in parallel from the cells' start slots. The two random passes over the 10^7..10^8 entries (records gathered into
+	// sorted order, slots scattered back to record order) run on all threads as well.
 	std::vector<CullRec> sorted(n);
+	std::vector<uint8_t> starts_cell(n); // sorted[i] is the first sphere of a (type, is_big, cell) group
 	parallel_ranges(n, [&](size_t b, size_t e) {
-		for (size_t i = b; i < e; ++i) sorted[i] = recs[items[i].rec];
-	});
-	std::vector<uint32_t> slot_of_sorted(n);
-
-	out.spheres.clear();
-	out.ids.clear();
-	out.slot_cell.clear();
-	out.cells.clear();
-	out.spheres.reserve(n + n / 16 + LAYOUT_MAX_TYPES * LAYOUT_TILE_ALIGN);
-	out.ids.reserve(n + n / 16 + LAYOUT_MAX_TYPES * LAYOUT_TILE_ALIGN);
-	out.slot_cell.reserve(n + n / 16 + LAYOUT_MAX_TYPES * LAYOUT_TILE_ALIGN);
-	out.cells.reserve(n / 8 + 64);
-	out.rec_slot.assign(n, 0);
-
-	auto pad_to = [&](size_t boundary, uint32_t dead_cell) { // dead slots up to the next multiple of `boundary`
-		while (out.spheres.size() % boundary) {
-			out.spheres.push_back(LayoutSphere{0.f, 0.f, 0.f, 0.f});
-			out.ids.push_back(-1);
-			out.slot_cell.push_back(dead_cell);
+		for (size_t i = b; i < e; ++i) {
+			sorted[i] = recs[items[i].rec];
+			starts_cell[i] = i == 0 || items[i].hi != items[i - 1].hi || items[i].lo != items[i - 1].lo; // (type is part of `hi`)
 		}
-	};
-
-	size_t it = 0;
+	});
+	std::vector<size_t> group_first; // sorted index of every group's first sphere, + n
+	{
+		const unsigned T = layout_threads(n);
+		std::vector<size_t> cnt(T + 1, 0);
+		{
+			std::vector<std::thread> th;
+			for (unsigned k = 0; k < T; ++k) th.emplace_back([&, k] {
+				size_t c = 0;
+				for (size_t i = n * k / T; i < n * (k + 1) / T; ++i) c += starts_cell[i];
+				cnt[k + 1] = c;
+			});
+			for (std::thread& x : th) x.join();
+		}
+		for (unsigned k = 0; k < T; ++k) cnt[k + 1] += cnt[k];
+		group_first.resize(cnt[T] + 1);
+		{
+			std::vector<std::thread> th;
+			for (unsigned k = 0; k < T; ++k) th.emplace_back([&, k] {
+				size_t at = cnt[k];
+				for (size_t i = n * k / T; i < n * (k + 1) / T; ++i) if (starts_cell[i]) group_first[at++] = i;
+			});
+			for (std::thread& x : th) x.join();
+		}
+		group_first.back() = n;
+	}
+	{ std::vector<uint8_t>().swap(starts_cell); }
+	const size_t n_groups = group_first.size() - 1;
+	std::vector<uint32_t> group_slot(n_groups), group_cell(n_groups); // first sphere slot / index into out.cells of every group
+	struct Pad { uint32_t begin, end, dead_cell; };
+	std::vector<Pad> pads;
+	out.cells.clear();
+	out.cells.reserve(n_groups + n_groups / 64 + 2 * LAYOUT_MAX_TYPES + 64);
+	uint64_t pos = 0;
+	auto round_up = [](uint64_t v, uint64_t a) { return (v + a - 1) / a * a; };
+	size_t g = 0;
 	for (int t = 0; t < LAYOUT_MAX_TYPES; ++t) {
-		out.ent_start[t] = (uint32_t)out.spheres.size();
+		out.ent_start[t] = (uint32_t)pos;
 		out.cell_begin[t] = (uint32_t)out.cells.size();
 		if (!count_by_type[t]) {
 			out.ent_end[t] = out.ent_start[t];
 			out.cell_end[t] = out.cell_begin[t];
 			continue;
 		}
-		bool have_prev = false;
-		uint64_t prev_hi = 0, prev_lo = 0;
 		uint32_t block_cells = 0; // distinct cell slots overlapping the current LAYOUT_CELL_BLOCK-slot block
-		for (size_t k = 0; k < count_by_type[t]; ++k, ++it) {
-			const SortItem& si = items[it];
-			const CullRec& r = sorted[it];
-			const bool new_cell = !have_prev || si.hi != prev_hi || si.lo != prev_lo;
-			if (out.spheres.size() % LAYOUT_CELL_BLOCK == 0) block_cells = new_cell ? 0 : 1; // a cell may continue into the block
-			if (new_cell) {
-				if (block_cells + 2 > LAYOUT_MAX_CELLS_PER_BLOCK) {
-					// this block already touches its quota of cells (one is kept for the dead cell): close it with dead slots
-					out.cells.push_back(LayoutCell{0, 0, 0, (uint32_t)t | LAYOUT_CELL_DEAD});
-					pad_to(LAYOUT_CELL_BLOCK, (uint32_t)out.cells.size() - 1);
-					block_cells = 0;
-				}
-				out.cells.push_back(LayoutCell{r.cell.x, r.cell.y, r.cell.z, (uint32_t)r.type | (r.big ? 0x100u : 0u)});
-				prev_hi = si.hi;
-				prev_lo = si.lo;
-				have_prev = true;
-				++block_cells;
+		for (; g < n_groups && sorted[group_first[g]].type == (uint8_t)t; ++g) {
+			const CullRec& r = sorted[group_first[g]];
+			const uint64_t size = group_first[g + 1] - group_first[g];
+			if (pos % LAYOUT_CELL_BLOCK == 0) block_cells = 0;
+			if (block_cells + 2 > LAYOUT_MAX_CELLS_PER_BLOCK) {
+				// this block already touches its quota of cells (one is kept for the dead cell): close it with dead slots
+				out.cells.push_back(LayoutCell{0, 0, 0, (uint32_t)t | LAYOUT_CELL_DEAD});
+				const uint64_t to = round_up(pos, LAYOUT_CELL_BLOCK);
+				pads.push_back(Pad{(uint32_t)pos, (uint32_t)to, (uint32_t)out.cells.size() - 1});
+				pos = to;
+				block_cells = 0;
 			}
-			slot_of_sorted[it] = (uint32_t)out.spheres.size();
-			out.slot_cell.push_back((uint32_t)out.cells.size() - 1);
-			out.spheres.push_back(LayoutSphere{r.rel.x, r.rel.y, r.rel.z, r.radius});
-			out.ids.push_back(r.entity);
+			out.cells.push_back(LayoutCell{r.cell.x, r.cell.y, r.cell.z, (uint32_t)r.type | (r.big ? 0x100u : 0u)});
+			++block_cells;
+			group_slot[g] = (uint32_t)pos;
+			group_cell[g] = (uint32_t)out.cells.size() - 1;
+			// a cell that continues into the next block is the one cell that block has seen so far
+			if (round_up(pos + 1, LAYOUT_CELL_BLOCK) <= pos + size - 1) block_cells = 1;
+			pos += size;
+			if (pos > 0x7fffffffull) return false;
 		}
 		// at least one dead slot per type, then pad the type range to the largest tile
 		out.cells.push_back(LayoutCell{0, 0, 0, (uint32_t)t | LAYOUT_CELL_DEAD});
-		const uint32_t dead = (uint32_t)out.cells.size() - 1;
-		out.spheres.push_back(LayoutSphere{0.f, 0.f, 0.f, 0.f});
-		out.ids.push_back(-1);
-		out.slot_cell.push_back(dead);
-		pad_to(LAYOUT_TILE_ALIGN, dead);
-		out.ent_end[t] = (uint32_t)out.spheres.size();
+		const uint64_t to = round_up(pos + 1, LAYOUT_TILE_ALIGN);
+		pads.push_back(Pad{(uint32_t)pos, (uint32_t)to, (uint32_t)out.cells.size() - 1});
+		pos = to;
+		out.ent_end[t] = (uint32_t)pos;
 		out.cell_end[t] = (uint32_t)out.cells.size();
-		if (out.spheres.size() > 0x7fffffffull) return false;
+		if (pos > 0x7fffffffull) return false;
 	}
-	const size_t n_padded = out.spheres.size();
-	parallel_ranges(n, [&](size_t b, size_t e) {
-		for (size_t i = b; i < e; ++i) out.rec_slot[items[i].rec] = slot_of_sorted[i];
+	const size_t n_padded = (size_t)pos;
+	out.spheres.resize(n_padded);
+	out.ids.resize(n_padded);
+	out.slot_cell.resize(n_padded);
+	out.rec_slot.assign(n, 0);
+	for (const Pad& p : pads) {
+		for (uint32_t s = p.begin; s < p.end; ++s) {
+			out.spheres[s] = LayoutSphere{0.f, 0.f, 0.f, 0.f};
+			out.ids[s] = -1;
+			out.slot_cell[s] = p.dead_cell;
+		}
+	}
+	parallel_ranges(n_groups, [&](size_t gb, size_t ge) {
+		for (size_t k = gb; k < ge; ++k) {
+			uint32_t slot = group_slot[k];
+			const uint32_t cell = group_cell[k];
+			for (size_t i = group_first[k]; i < group_first[k + 1]; ++i, ++slot) {
+				const CullRec& r = sorted[i];
+				out.spheres[slot] = LayoutSphere{r.rel.x, r.rel.y, r.rel.z, r.radius};
+				out.ids[slot] = r.entity;
+				out.slot_cell[slot] = cell;
+				out.rec_slot[items[i].rec] = slot;
+			}
+		}
 	});
-	{ std::vector<SortItem>().swap(items); std::vector<CullRec>().swap(sorted); std::vector<uint32_t>().swap(slot_of_sorted); }
+	{ std::vector<SortItem>().swap(items); std::vector<CullRec>().swap(sorted); std::vector<size_t>().swap(group_first); }
 
 	const size_t n_chunks = n_padded / LAYOUT_CHUNK;
 	out.hdr.resize(n_chunks);
