@@ -622,7 +622,7 @@ hipError_t launch_cull_consolidate(hipStream_t s, const int32_t* src, uint32_t s
 
 hipError_t launch_cull_pack(hipStream_t s, const int32_t* src, const uint32_t* win_base, const uint32_t* counts, uint32_t cnt_pad, const uint8_t* shard_type,
 	uint32_t n_shards, uint32_t max_shard_cap, uint32_t* header, int32_t* dst, uint32_t dst_cap) {
-	if (!n_shards) return hipSuccess;
+	if (!n_shards) return hipMemsetAsync(header, 0, MAX_TYPES * sizeof(uint32_t), s); // an empty set still reports its (zero) counts
 	if (n_shards > (uint32_t)FIN_MAX_SHARDS) return hipErrorInvalidValue;
 	const uint32_t splits = std::max(1u, std::min(64u, max_shard_cap / 4096u));
 	hipLaunchKernelGGL(k_cull_pack, dim3(n_shards, splits), dim3(256), 0, s, src, win_base, counts, cnt_pad, shard_type, n_shards, header, dst, dst_cap);

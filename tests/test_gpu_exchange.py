@@ -51,3 +51,13 @@ def test_exchange_single_rank_matches_oracle(gpu_ctx, oracle_port):
         assert np.all(np.isin(ids, np.concatenate(want[0])))
     finally:
         small.close()
+    # a rank that owns nothing (a strong split with fewer occupied cells than ranks): its record still reports zero counts
+    cs.build(np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros((0, 3)), np.zeros(0, np.float32))
+    empty = api.VisibleExchange(gpu_ctx, 0, 1, api.exchange_unique_id(), 64)
+    try:
+        for _ in range(3):  # both slots
+            slot = empty.cull(cams[0])
+            counts, ids = empty.read(slot, 0)
+            assert int(counts.sum()) == 0 and len(ids) == 0
+    finally:
+        empty.close()
