@@ -10,6 +10,7 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -132,32 +133,63 @@ template <typename Fn> inline void parallel_ranges(size_t n, Fn fn) { // fn(begi
 	for (unsigned k = 0; k < t; ++k) th.emplace_back([=] { fn(n * k / t, n * (k + 1) / t); });
 	for (std::thread& x : th) x.join();
 }
+// Sample sort: splitters from a sorted sample cut the keys into 4 x threads buckets, items are scattered to their buckets and the
+// buckets sorted independently - every pass runs on all threads. (The merge sort this replaces ended in log2(threads) rounds of
+// ever fewer, ever longer merges - the last one a single thread over the whole array - and was the long pole of the layout build.)
+// `less` must be a strict total order (the layout's keys end in the record index), so the result does not depend on the algorithm.
 template <typename T, typename Less> inline void parallel_sort(std::vector<T>& v, Less less) {
 	const size_t n = v.size();
-	unsigned t = layout_threads(n);
-	unsigned parts = 1;
-	while (parts * 2 <= t) parts *= 2;
-	if (parts <= 1) {
+	const unsigned t = layout_threads(n);
+	if (t <= 1) {
 		std::sort(v.begin(), v.end(), less);
 		return;
 	}
-	{
+	const unsigned n_buckets = t * 4, oversample = 32;
+	std::vector<T> sample(n_buckets * oversample);
+	for (size_t i = 0; i < sample.size(); ++i) sample[i] = v[(n / sample.size()) * i + (n / sample.size()) / 2];
+	std::sort(sample.begin(), sample.end(), less);
+	std::vector<T> split(n_buckets - 1);
+	for (unsigned k = 0; k + 1 < n_buckets; ++k) split[k] = sample[(k + 1) * oversample];
+	auto run = [&](auto fn) { // fn(thread index) on t threads
 		std::vector<std::thread> th;
-		for (unsigned k = 0; k < parts; ++k) th.emplace_back([&v, n, k, parts, less] { std::sort(v.begin() + n * k / parts, v.begin() + n * (k + 1) / parts, less); });
+		th.reserve(t);
+		for (unsigned k = 0; k < t; ++k) th.emplace_back([=] { fn(k); });
 		for (std::thread& x : th) x.join();
+	};
+	std::vector<uint16_t> bucket(n);
+	std::vector<size_t> count((size_t)t * n_buckets, 0); // [thread][bucket]
+	run([&](unsigned k) {
+		size_t* c = &count[(size_t)k * n_buckets];
+		for (size_t i = n * k / t; i < n * (k + 1) / t; ++i) {
+			const unsigned bk = (unsigned)(std::upper_bound(split.begin(), split.end(), v[i], less) - split.begin());
+			bucket[i] = (uint16_t)bk;
+			++c[bk];
+		}
+	});
+	std::vector<size_t> bucket_begin(n_buckets + 1, 0);
+	{
+		size_t at = 0;
+		for (unsigned bk = 0; bk < n_buckets; ++bk) { // bucket-major, thread-minor: every (thread, bucket) pair gets its own range
+			bucket_begin[bk] = at;
+			for (unsigned k = 0; k < t; ++k) {
+				const size_t c = count[(size_t)k * n_buckets + bk];
+				count[(size_t)k * n_buckets + bk] = at;
+				at += c;
+			}
+		}
+		bucket_begin[n_buckets] = at;
 	}
 	std::vector<T> tmp(n);
-	std::vector<T>*src = &v, *dst = &tmp;
-	for (unsigned width = 1; width < parts; width *= 2) { // pairwise merges of sorted runs, one thread per pair
-		std::vector<std::thread> th;
-		for (unsigned k = 0; k < parts; k += 2 * width) {
-			const size_t a = n * k / parts, m = n * (k + width) / parts, b = n * (k + 2 * width) / parts;
-			th.emplace_back([src, dst, a, m, b, less] { std::merge(src->begin() + a, src->begin() + m, src->begin() + m, src->begin() + b, dst->begin() + a, less); });
-		}
-		for (std::thread& x : th) x.join();
-		std::swap(src, dst);
-	}
-	if (src != &v) v.swap(tmp);
+	run([&](unsigned k) {
+		size_t* at = &count[(size_t)k * n_buckets];
+		for (size_t i = n * k / t; i < n * (k + 1) / t; ++i) tmp[at[bucket[i]]++] = v[i];
+	});
+	{ std::vector<uint16_t>().swap(bucket); }
+	std::atomic<unsigned> next{0};
+	run([&](unsigned) {
+		for (unsigned bk = next.fetch_add(1); bk < n_buckets; bk = next.fetch_add(1)) std::sort(tmp.begin() + bucket_begin[bk], tmp.begin() + bucket_begin[bk + 1], less);
+	});
+	v.swap(tmp);
 }
 
 // returns false when the set does not fit the 31-bit slot space
