@@ -73,6 +73,18 @@ def test_emulated_cull_config1_and_type_filter(emul_lib, oracle_port):
             H.assert_same_visible(got[f], H.sorted_by_type(ids, types), f"type {t}")
 
 
+def test_emulated_cull_threaded_layout_build(emul_lib, oracle_port):
+    """>= 2^18 spheres: the layout build takes its multi-threaded path (sample sort, cells cut and filled in parallel)."""
+    sc = scenes.cull_scene(400_000, 6000.0, seed=21, mixed_types=True)
+    fr = H.frusta(oracle_port)[:3]
+    cs = oracle_port.culling_system()
+    cs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    got, _ = emul_cull(emul_lib, sc, fr)
+    for f in range(len(fr)):
+        ids, types, _ = cs.cull(fr[f : f + 1])
+        H.assert_same_visible(got[f], H.sorted_by_type(ids, types), H.CAMERAS[f][0])
+
+
 @pytest.mark.parametrize("shift", [(0.0, 0.0, 0.0), (1.0e6, 50.0, -1.0e6)])
 def test_emulated_tile_early_out_is_conservative_and_effective(emul_lib, oracle_port, shift):
     """k_cull_fused ends a tile before classifying its cells when the box of its cell indices is behind a plane (tile_rejected):
