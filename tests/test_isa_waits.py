@@ -1,0 +1,72 @@
+"""ISA-level contract of the skinning kernels' steady-state loops (no GPU needed: hipcc -S for gfx950).
+
+On gfx9-family parts vector loads and stores retire through ONE in-order counter (vmcnt). A wait the compiler cannot count becomes
+`s_waitcnt vmcnt(0)`: the wave then drains every store it has in flight. Round 2 found exactly that in both vertex kernels (loads /
+stores under per-lane branches): k_skin_vertices ran at blend time + store time. The kernels are now written so that the compiler
+CAN count (clamped lanes, no branch around a load or a store, records carried as register tuples) - this test keeps it that way:
+inside the instance / vertex loops of the default (LMX_SKIN_FUSED) kernels there is no vmcnt(0), no scratch access, and the wait
+that is there leaves stores in flight."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "lumixengine_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def skin_isa(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "skin.s"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+           "-o", str(out), os.path.join(CSRC, "skin_kernels.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return out.read_text().splitlines()
+
+
+def kernel_body(lines, mangled_part):
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and mangled_part in l and ":" in l)  # the kernel's label line
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    return lines[start : end + 1]
+
+
+def loops(body):
+    """{header label: [instruction lines of every block LLVM annotates as part of that loop]}"""
+    out, current = {}, None
+    for l in body:
+        m = re.match(r"^(\.LBB\d+_\d+):.*=>This (Inner )?Loop Header", l)
+        if m:
+            current = m.group(1)[2:]  # "BB10_8"
+            out.setdefault(current, [])
+            continue
+        if l.startswith(".LBB") or l.startswith("; %bb."):
+            m = re.search(r"in Loop: Header=(BB\d+_\d+)", l)
+            current = m.group(1) if m else None
+            if current is not None:
+                out.setdefault(current, [])
+            continue
+        if current is not None and l.startswith("\t") and not l.lstrip().startswith(";"):
+            out[current].append(l.strip())
+    return out
+
+
+@pytest.mark.parametrize("kernel, min_stores", [("13k_skin_sharedILi0E", 5), ("13k_skin_sharedILi1E", 5), ("15k_skin_verticesILi0E", 2)])
+def test_vertex_loops_keep_stores_in_flight(skin_isa, kernel, min_stores):
+    body = kernel_body(skin_isa, kernel)
+    assert not any("scratch_" in l for l in body), "the kernel spills"
+    vertex_loops = {h: ins for h, ins in loops(body).items() if sum("global_store_dwordx3" in i for i in ins) >= min_stores}
+    assert len(vertex_loops) == 3, f"one store loop per palette-replication class expected, found {sorted(vertex_loops)}"
+    for h, ins in vertex_loops.items():
+        waits = [int(m.group(1)) for i in ins for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", i)] if m]
+        assert waits, f"loop {h}: no vmcnt wait at all?"
+        assert min(waits) >= 1, f"loop {h} drains its stores: vmcnt waits {waits}"
+    if kernel.startswith("13k_skin_shared"):
+        # one wait per instance, behind four of the lane's five stores: the palette load issued before them
+        for h, ins in vertex_loops.items():
+            assert [w for i in ins for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", i)] if m for w in [int(m.group(1))]] == [4], h
