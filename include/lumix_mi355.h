@@ -384,6 +384,38 @@ LMX_API int lmx_world_blob_info(const void* data, size_t size, LmxWorldBlobInfo*
 LMX_API int lmx_world_blob_read(const void* data, size_t size, uint32_t n_slots, int32_t* parent, LmxTransform* transforms, LmxTransform* world,
 	uint8_t* valid);
 
+/* The "renderer" module's payload inside a serialized World (RenderModuleImpl::serialize / deserialize,
+ * renderer/render_module.cpp:962-976, :1225-1250): what the skinning / attachment path needs from a scene file - which entity
+ * carries which model (serializeModelInstances :650-679) and the bone attachments (serializeBoneAttachments :581-590, records of
+ * bone name hash, entity, parent entity, relative LocalRigidTransform). Module payloads are not size-prefixed (world.cpp:877-882):
+ * the reader finds the module by its header (NUL-terminated name + version) after the hierarchy records and walks the renderer's
+ * sections in order - cameras, model instances, lights, terrains, particle systems, bone attachments, probes, decals, instanced
+ * models, procedural geometries. RenderModuleVersion 16..18 (what the reference's shipped demo/maps carry; LATEST = 18). Checked on every
+ * .unv under the reference's demo/maps: each payload is consumed to the byte where the next module's header starts
+ * (tests/test_world_blob.py). Host-only. */
+/* Where module `name`'s payload starts in the decompressed blob (right behind its header) and its serialized version;
+ * LMX_ERR_INVALID_ARGUMENT when the file has no such module. */
+LMX_API int lmx_world_blob_find_module(const void* data, size_t size, const char* name, uint32_t* payload_offset, int32_t* version);
+typedef struct LmxRenderBlobInfo {
+	int32_t version;                       /* RenderModuleVersion of the payload */
+	uint32_t payload_offset, payload_size; /* in the decompressed blob; payload_size = 0 when procedural geometries are present (not walked) */
+	uint32_t n_cameras, n_model_instance_slots, n_model_instances, n_point_lights, n_environments, n_terrains, n_particle_systems,
+		n_bone_attachments, n_environment_probes, n_reflection_probes, n_decals, n_curve_decals, n_instanced_models, n_procedural_geometries;
+	uint32_t model_paths_size;             /* bytes of the NUL-separated model path table */
+} LmxRenderBlobInfo;
+typedef struct LmxBlobBoneAttachment {
+	uint64_t bone_name_hash;               /* BoneNameHash = StableHash of the bone's name (core/hash.h:44-76): Model::getBoneIndex resolves it;
+	                                          version <= 17 stored a bone index instead (low 32 bits here) */
+	int32_t entity, parent_entity;
+	LmxLocalRigidTransform relative;
+} LmxBlobBoneAttachment;
+LMX_API int lmx_render_blob_info(const void* data, size_t size, LmxRenderBlobInfo* out);
+LMX_API int lmx_render_blob_read_bone_attachments(const void* data, size_t size, uint32_t cap, LmxBlobBoneAttachment* out);
+/* flags[e] = ModelInstance::Flags of entity e (0: no model instance; VALID = 4), path_offset[e] = offset of its model's path in
+ * `paths` (0xffffffff: none), for e < n_slots (>= n_model_instance_slots); paths: the file's path table, model_paths_size bytes. */
+LMX_API int lmx_render_blob_read_model_instances(const void* data, size_t size, uint32_t n_slots, uint8_t* flags, uint32_t* path_offset, char* paths,
+	uint32_t paths_cap);
+
 LMX_API const char* lmx_version(void);
 
 #ifdef __cplusplus

@@ -178,6 +178,10 @@ SYMBOLS = {
     "lmx_frustum_ortho": (_ci, [_vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
     "lmx_world_blob_info": (_ci, [_vp, _sz, _vp]),
     "lmx_world_blob_read": (_ci, [_vp, _sz, _u32, _vp, _vp, _vp, _vp]),
+    "lmx_world_blob_find_module": (_ci, [_vp, _sz, C.c_char_p, C.POINTER(_u32), C.POINTER(_i32)]),
+    "lmx_render_blob_info": (_ci, [_vp, _sz, _vp]),
+    "lmx_render_blob_read_bone_attachments": (_ci, [_vp, _sz, _u32, _vp]),
+    "lmx_render_blob_read_model_instances": (_ci, [_vp, _sz, _u32, _vp, _vp, _vp, _u32]),
     "lmx_version": (C.c_char_p, []),
 }
 
@@ -598,6 +602,49 @@ def world_blob_read(data: bytes):
     if rc != 0:
         raise LumixError(rc, "World blob truncated or inconsistent")
     return {k: int(info[k][0]) for k in WORLD_BLOB_INFO.names}, parent, tr, world, valid
+
+
+RENDER_BLOB_INFO = np.dtype([(k, np.int32 if k == "version" else np.uint32) for k in (
+    "version", "payload_offset", "payload_size", "n_cameras", "n_model_instance_slots", "n_model_instances", "n_point_lights", "n_environments", "n_terrains",
+    "n_particle_systems", "n_bone_attachments", "n_environment_probes", "n_reflection_probes", "n_decals", "n_curve_decals", "n_instanced_models",
+    "n_procedural_geometries", "model_paths_size")])
+BLOB_BONE_ATTACHMENT = np.dtype([("bone_name_hash", np.uint64), ("entity", np.int32), ("parent_entity", np.int32), ("pos", np.float32, 3), ("rot", np.float32, 4), ("_pad", np.uint32)])
+
+
+def world_blob_find_module(data: bytes, name: str):
+    """(payload offset in the decompressed blob, serialized version) of module `name`, or None. Host only."""
+    lib = load_library()
+    buf = np.frombuffer(data, np.uint8)
+    off, ver = _u32(0), _i32(0)
+    rc = lib.lmx_world_blob_find_module(_ptr(buf), len(buf), name.encode(), C.byref(off), C.byref(ver))
+    return None if rc != 0 else (int(off.value), int(ver.value))
+
+
+def render_blob_read(data: bytes):
+    """The "renderer" module's payload of a serialized World (render_module.cpp:962-976): (info dict, bone attachments, {entity: model path}).
+    Host only."""
+    lib = load_library()
+    buf = np.frombuffer(data, np.uint8)
+    info = np.zeros(1, RENDER_BLOB_INFO)
+    rc = lib.lmx_render_blob_info(_ptr(buf), len(buf), _ptr(info))
+    if rc != 0:
+        raise LumixError(rc, "no readable renderer payload (RenderModuleVersion 16..18) in this World blob")
+    att = np.zeros(int(info["n_bone_attachments"][0]), BLOB_BONE_ATTACHMENT)
+    rc = lib.lmx_render_blob_read_bone_attachments(_ptr(buf), len(buf), len(att), _ptr(att) if len(att) else None)
+    if rc != 0:
+        raise LumixError(rc, "bone attachment records truncated")
+    n = int(info["n_model_instance_slots"][0])
+    flags, off = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint32)
+    paths = np.zeros(max(int(info["model_paths_size"][0]), 1), np.uint8)
+    rc = lib.lmx_render_blob_read_model_instances(_ptr(buf), len(buf), n, _ptr(flags), _ptr(off), _ptr(paths), len(paths))
+    if rc != 0:
+        raise LumixError(rc, "model instance records truncated")
+    table = paths.tobytes()
+    models = {}
+    for e in range(n):
+        if flags[e] & 4:
+            models[e] = None if off[e] == 0xFFFFFFFF else table[off[e] : table.index(b"\0", off[e])].decode()
+    return {k: int(info[k][0]) for k in RENDER_BLOB_INFO.names}, att, models
 
 
 def keys_view(camera_pos=(0, 0, 0), lod_ref_point=None, lod_multiplier=1.0, time_delta=1 / 60, frame_number=1, is_shadow=False,

@@ -139,9 +139,203 @@ int parse(const void* data, size_t size, Parsed& out) {
 	return LMX_OK;
 }
 
+// ---- the renderer module's payload (render_module.cpp:1225-1250) ------------------------------------------------------------
+constexpr int32_t RENDER_VERSION_MIN = 16, RENDER_VERSION_LATEST = 18; // RenderModuleVersion, render_module.h:303-324
+
+struct RenderParsed {
+	LmxRenderBlobInfo info;
+	size_t paths_at = 0, instances_at = 0, attachments_at = 0;
+};
+
+// Module payloads carry no size: a module is found by its header - the name as a NUL-terminated string (preceded by the i32
+// module count or by the previous payload) followed by a plausible i32 version.
+bool find_module(const Parsed& p, const char* name, size_t* payload_at, int32_t* version) {
+	Reader s{p.blob.data(), p.blob.size(), p.hierarchy_at};
+	s.skip((size_t)p.info.n_hierarchy * (16 + 24 + 16 + 12));
+	const int32_t n_modules = s.read<int32_t>();
+	if (s.overflow || n_modules <= 0) return false;
+	const size_t len = strlen(name), first = s.pos;
+	for (size_t at = first; at + len + 1 + 4 <= p.blob.size(); ++at) {
+		if (memcmp(p.blob.data() + at, name, len + 1) != 0) continue;
+		if (at != first && at < first + 5) continue; // (a later module's name starts behind the previous module's version + payload)
+		int32_t v;
+		memcpy(&v, p.blob.data() + at + len + 1, 4);
+		if (v < 0 || v > 255) continue;
+		*payload_at = at + len + 1 + 4;
+		*version = v;
+		return true;
+	}
+	return false;
+}
+
+int parse_renderer(const void* data, size_t size, Parsed& p, RenderParsed& out) {
+	memset(&out.info, 0, sizeof(out.info));
+	if (int rc = parse(data, size, p)) return rc;
+	size_t at = 0;
+	int32_t version = 0;
+	if (!find_module(p, "renderer", &at, &version)) return LMX_ERR_INVALID_ARGUMENT;
+	LmxRenderBlobInfo& info = out.info;
+	info.version = version;
+	info.payload_offset = (uint32_t)at;
+	if (version < RENDER_VERSION_MIN || version > RENDER_VERSION_LATEST) return LMX_ERR_INVALID_ARGUMENT; // older layouts are not restated
+	Reader s{p.blob.data(), p.blob.size(), at};
+	// cameras (:979-1014): entity, fov, near, far, ortho_size, screen_width, screen_height, is_ortho, film grain, 5 depth-of-field fields
+	info.n_cameras = s.read<uint32_t>();
+	for (uint32_t i = 0; i < info.n_cameras && !s.overflow; ++i) s.skip(4 + 6 * 4 + 1 + 4 + 1 + 4 * 4);
+	// model instances (:1051-1098): path table, then per entity slot flags (u8) [+ path offset + material overrides when VALID]
+	info.model_paths_size = s.read<uint32_t>();
+	out.paths_at = s.pos;
+	s.skip(info.model_paths_size);
+	info.n_model_instance_slots = s.read<uint32_t>();
+	out.instances_at = s.pos;
+	for (uint32_t i = 0; i < info.n_model_instance_slots && !s.overflow; ++i) {
+		const uint8_t flags = s.read<uint8_t>();
+		if (!(flags & 4u)) continue; // ModelInstance::VALID
+		++info.n_model_instances;
+		s.skip(4);
+		if (version > 15) { // MATERIAL_OVERRIDE: one path per mesh
+			const uint32_t n = s.read<uint32_t>();
+			for (uint32_t k = 0; k < n && !s.overflow; ++k) s.skip_string();
+		} else {
+			s.skip_string();
+		}
+	}
+	// lights (:1100-1161): PointLight raw (48 B), environments field by field, the active global light
+	info.n_point_lights = s.read<uint32_t>();
+	s.skip((size_t)info.n_point_lights * 48);
+	info.n_environments = s.read<uint32_t>();
+	for (uint32_t i = 0; i < info.n_environments && !s.overflow; ++i) {
+		s.skip(12 + 4 + 4 + 4 + 16 + 4); // light_color, direct, indirect, entity, cascades, flags
+		s.skip_string();                 // sky cubemap
+		s.skip(4 + 5 * 12 + 6 * 4 + 1);  // sky intensity, 5 colours, sunlight strength .. fog_top, atmo_enabled
+		s.skip(1);                       // godrays_enabled
+		s.skip(1 + 4 + 4);               // clouds (> CLOUDS)
+		s.skip(4);                       // fog_density (> FOG_DENSITY)
+	}
+	s.skip(4);
+	// terrains (:1213-1224, terrain.cpp:323-357)
+	info.n_terrains = (uint32_t)s.read<int32_t>();
+	for (uint32_t i = 0; i < info.n_terrains && !s.overflow; ++i) {
+		s.skip(4 + 8);
+		s.skip_string();
+		s.skip(4 + 4 + 4 + 4);
+		const int32_t grass = s.read<int32_t>();
+		for (int32_t k = 0; k < grass && !s.overflow; ++k) {
+			s.skip_string();
+			s.skip(4 + 4 + 4);
+		}
+	}
+	// particle systems (:919-934, particle_system.cpp:463-475): entity, autodestroy, resource path
+	info.n_particle_systems = s.read<uint32_t>();
+	for (uint32_t i = 0; i < info.n_particle_systems && !s.overflow; ++i) {
+		s.skip(4 + 1);
+		s.skip_string();
+	}
+	// bone attachments (:895-914)
+	info.n_bone_attachments = s.read<uint32_t>();
+	out.attachments_at = s.pos;
+	s.skip((size_t)info.n_bone_attachments * ((version > 17 ? 8 : 4) + 4 + 4 + 28));
+	// probes (:877-892 raw EnvironmentProbe 136 B; :829-847 guid, flags, size, half_extents), decals (:731-775)
+	info.n_environment_probes = s.read<uint32_t>();
+	s.skip((size_t)info.n_environment_probes * (4 + 136));
+	info.n_reflection_probes = s.read<uint32_t>();
+	s.skip((size_t)info.n_reflection_probes * (4 + 8 + 4 + 4 + 12));
+	info.n_decals = s.read<uint32_t>();
+	for (uint32_t i = 0; i < info.n_decals && !s.overflow; ++i) {
+		s.skip(4 + 12 + 8);
+		s.skip_string();
+	}
+	info.n_curve_decals = s.read<uint32_t>();
+	for (uint32_t i = 0; i < info.n_curve_decals && !s.overflow; ++i) {
+		s.skip(4 + 8 + 4 + 8 + 8);
+		s.skip_string();
+	}
+	if (version <= 16 && s.read<uint32_t>() != 0) return LMX_ERR_INVALID_ARGUMENT; // deserializeFurs (:725-729): the count must be 0
+	info.n_instanced_models = s.read<uint32_t>(); // (:703-723) entity, model path, instances (32 B each)
+	for (uint32_t i = 0; i < info.n_instanced_models && !s.overflow; ++i) {
+		s.skip(4);
+		s.skip_string();
+		const uint32_t n = s.read<uint32_t>();
+		s.skip((size_t)n * 32);
+	}
+	info.n_procedural_geometries = s.read<uint32_t>();
+	if (s.overflow) return LMX_ERR_INVALID_ARGUMENT;
+	info.payload_size = info.n_procedural_geometries ? 0u : (uint32_t)(s.pos - at); // vertex declarations are not walked
+	return LMX_OK;
+}
+
 } // namespace
 
 extern "C" {
+
+int lmx_world_blob_find_module(const void* data, size_t size, const char* name, uint32_t* payload_offset, int32_t* version) {
+	if (!name || !name[0]) return LMX_ERR_INVALID_ARGUMENT;
+	Parsed p;
+	if (int rc = parse(data, size, p)) return rc;
+	size_t at = 0;
+	int32_t v = 0;
+	if (!find_module(p, name, &at, &v)) return LMX_ERR_INVALID_ARGUMENT;
+	if (payload_offset) *payload_offset = (uint32_t)at;
+	if (version) *version = v;
+	return LMX_OK;
+}
+
+int lmx_render_blob_info(const void* data, size_t size, LmxRenderBlobInfo* out) {
+	if (!out) return LMX_ERR_INVALID_ARGUMENT;
+	Parsed p;
+	RenderParsed r;
+	const int rc = parse_renderer(data, size, p, r);
+	*out = r.info;
+	return rc;
+}
+
+int lmx_render_blob_read_bone_attachments(const void* data, size_t size, uint32_t cap, LmxBlobBoneAttachment* out) {
+	Parsed p;
+	RenderParsed r;
+	if (int rc = parse_renderer(data, size, p, r)) return rc;
+	if (r.info.n_bone_attachments > cap) return LMX_ERR_CAPACITY;
+	if (r.info.n_bone_attachments && !out) return LMX_ERR_INVALID_ARGUMENT;
+	Reader s{p.blob.data(), p.blob.size(), r.attachments_at};
+	for (uint32_t i = 0; i < r.info.n_bone_attachments; ++i) {
+		LmxBlobBoneAttachment a;
+		memset(&a, 0, sizeof(a));
+		a.bone_name_hash = r.info.version > 17 ? s.read<uint64_t>() : (uint64_t)(uint32_t)s.read<int32_t>();
+		a.entity = s.read<int32_t>();
+		a.parent_entity = s.read<int32_t>();
+		for (int k = 0; k < 3; ++k) a.relative.pos[k] = s.read<float>();
+		for (int k = 0; k < 4; ++k) a.relative.rot[k] = s.read<float>();
+		out[i] = a;
+	}
+	return s.overflow ? LMX_ERR_INVALID_ARGUMENT : LMX_OK;
+}
+
+int lmx_render_blob_read_model_instances(const void* data, size_t size, uint32_t n_slots, uint8_t* flags, uint32_t* path_offset, char* paths, uint32_t paths_cap) {
+	if (!flags || !path_offset) return LMX_ERR_INVALID_ARGUMENT;
+	Parsed p;
+	RenderParsed r;
+	if (int rc = parse_renderer(data, size, p, r)) return rc;
+	if (n_slots < r.info.n_model_instance_slots || (r.info.model_paths_size && (!paths || paths_cap < r.info.model_paths_size))) return LMX_ERR_CAPACITY;
+	if (r.info.model_paths_size) memcpy(paths, p.blob.data() + r.paths_at, r.info.model_paths_size);
+	for (uint32_t e = 0; e < n_slots; ++e) {
+		flags[e] = 0;
+		path_offset[e] = 0xffffffffu;
+	}
+	Reader s{p.blob.data(), p.blob.size(), r.instances_at};
+	for (uint32_t e = 0; e < r.info.n_model_instance_slots; ++e) {
+		const uint8_t f = s.read<uint8_t>();
+		if (!(f & 4u)) continue;
+		flags[e] = f;
+		path_offset[e] = s.read<uint32_t>();
+		if (path_offset[e] != 0xffffffffu && path_offset[e] >= r.info.model_paths_size) return LMX_ERR_INVALID_ARGUMENT;
+		if (r.info.version > 15) {
+			const uint32_t n = s.read<uint32_t>();
+			for (uint32_t k = 0; k < n && !s.overflow; ++k) s.skip_string();
+		} else {
+			s.skip_string();
+		}
+	}
+	return s.overflow ? LMX_ERR_INVALID_ARGUMENT : LMX_OK;
+}
 
 int lmx_world_blob_info(const void* data, size_t size, LmxWorldBlobInfo* out) {
 	if (!out) return LMX_ERR_INVALID_ARGUMENT;

@@ -16,6 +16,64 @@ from tests import helpers as H
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
+DEMO_MAPS = sorted(__import__("glob").glob("/root/reference/demo/maps/*/*.unv"))  # worlds written by the reference's own editor / engine
+
+
+@pytest.mark.skipif(not DEMO_MAPS, reason="no reference tree on this machine")
+def test_reference_demo_maps(oracle_port):
+    """Every serialized world the reference ships (demo/maps/*/*.unv, RenderModuleVersion 16 and 18, eight modules each) through the
+    product's host-side readers: the World part (entities, names, hierarchy) and the "renderer" module's payload. Checks that only
+    real files can give: the renderer's sections are consumed to the very byte where the next module's header ("animation") starts;
+    a child's stored world transform is its parent's composed with its stored local one; bone attachments point at entities that
+    exist and at parents that carry a model."""
+    seen_attachment = False
+    for path in DEMO_MAPS:
+        data = open(path, "rb").read()
+        name = os.path.basename(path)
+        info, parent, tr, world, valid = api.world_blob_read(data)
+        assert info["n_modules"] == 8 and int(valid.sum()) == info["n_entities"] > 0, name
+        norms = np.linalg.norm(world["rot"][valid == 1], axis=1)
+        assert np.all(np.abs(norms - 1.0) < 1e-4), name
+        kids = np.flatnonzero(parent >= 0)
+        assert len(kids) <= info["n_hierarchy"] and np.all(valid[kids] == 1) and np.all(valid[parent[kids]] == 1), name
+        if len(kids):
+            comp = oracle_port.compose(world[parent[kids]], tr[kids])
+            want = world[kids]
+            scale = 1.0 + np.abs(want["pos"]).max()
+            assert np.abs(comp["pos"] - want["pos"]).max() <= 1e-5 * scale, name
+            rot_err = np.minimum(np.abs(comp["rot"] - want["rot"]).max(axis=1), np.abs(comp["rot"] + want["rot"]).max(axis=1))  # q and -q: one rotation
+            assert rot_err.max() <= 1e-5 and np.array_equal(comp["scale"], want["scale"]), name
+        rinfo, att, models = api.render_blob_read(data)
+        assert rinfo["version"] in (16, 18) and rinfo["n_procedural_geometries"] == 0, name
+        nxt = api.world_blob_find_module(data, "animation")
+        assert nxt is not None and rinfo["payload_offset"] + rinfo["payload_size"] + len("animation") + 1 + 4 == nxt[0], f"{name}: the renderer payload is not consumed exactly"
+        assert api.world_blob_find_module(data, "renderer") == (rinfo["payload_offset"], rinfo["version"]) and api.world_blob_find_module(data, "no_such_module") is None
+        assert len(models) == rinfo["n_model_instances"] and all(valid[e] == 1 for e in models), name
+        assert all(m is None or m.endswith(".fbx") for m in models.values()), name
+        for a in att:
+            seen_attachment = True
+            assert valid[a["entity"]] == 1 and valid[a["parent_entity"]] == 1 and int(a["parent_entity"]) in models, name
+            assert abs(float(np.linalg.norm(a["rot"])) - 1.0) < 1e-5 and a["bone_name_hash"] != 0, name
+        if name == "demo.unv":  # the one shipped map with a bone attachment: an entity on a bone of the animated character
+            assert rinfo["version"] == 18 and len(att) == 1 and (int(att[0]["entity"]), int(att[0]["parent_entity"])) == (45, 1)
+            assert int(att[0]["bone_name_hash"]) == 0x14F8EDF489CA4120 and models[1] == "models/ybot/ybot.fbx"
+            assert (rinfo["n_cameras"], rinfo["n_model_instances"], rinfo["n_particle_systems"], rinfo["n_decals"]) == (1, 49, 1, 1)
+        if name == "anim_stress_test.unv":
+            assert rinfo["version"] == 16 and rinfo["n_model_instances"] == 5626 and sorted(set(models.values())) == ["engine/models/plane.fbx", "models/ybot/ybot.fbx"]
+        if name == "terrain_test.unv":
+            assert rinfo["n_terrains"] == 1
+        if name == "instanced_models.unv":
+            assert rinfo["n_instanced_models"] == 2
+    assert seen_attachment
+
+
+def test_render_blob_rejects_garbage():
+    junk = np.random.default_rng(1).integers(0, 256, size=4096, dtype=np.uint8).tobytes()
+    with pytest.raises(api.LumixError):
+        api.render_blob_read(junk)
+    assert api.world_blob_find_module(junk, "renderer") is None
+
+
 def ref_lz4(oracle_ref):
     lib = oracle_ref.lib
     for f in (lib.ref_lz4_compress, lib.ref_lz4_decompress):
