@@ -85,6 +85,41 @@ def test_emulated_cull_threaded_layout_build(emul_lib, oracle_port):
         H.assert_same_visible(got[f], H.sorted_by_type(ids, types), H.CAMERAS[f][0])
 
 
+DEMO_MAPS = sorted(__import__("glob").glob("/root/reference/demo/maps/*/*.unv"))
+
+
+@pytest.mark.skipif(not DEMO_MAPS, reason="no reference tree on this machine")
+def test_emulated_cull_on_the_reference_demo_scenes(emul_lib, oracle_port):
+    """Entity placements as real scenes have them (the worlds the reference ships: stacks of boxes, rows of characters, a few huge
+    ground planes - not uniform noise): every entity that carries a model becomes a sphere around its serialized world position
+    (radius 0.9 x its largest scale component; the models' own bounding radii live in the .fbx files), culled by the emulated device
+    path and by the oracle, every camera."""
+    from lumixengine_amd import api
+
+    fr = H.frusta(oracle_port)
+    checked = 0
+    for path in DEMO_MAPS:
+        data = open(path, "rb").read()
+        _, _, _, world, valid = api.world_blob_read(data)
+        _, _, models = api.render_blob_read(data)
+        ents = np.array(sorted(e for e in models if valid[e]), np.int32)
+        if len(ents) < 2:
+            continue
+        sc = {"entity": ents, "type": np.zeros(len(ents), np.uint8), "pos": np.ascontiguousarray(world["pos"][ents]),
+              "radius": (0.9 * world["scale"][ents].max(axis=1)).astype(np.float32)}
+        cs = oracle_port.culling_system()
+        cs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+        got, _ = emul_cull(emul_lib, sc, fr)
+        some_visible = False
+        for f in range(len(fr)):
+            ids, types, _ = cs.cull(fr[f : f + 1])
+            H.assert_same_visible(got[f], H.sorted_by_type(ids, types), f"{os.path.basename(path)} / {H.CAMERAS[f][0]}")
+            some_visible |= len(ids) > 0
+        assert some_visible, path
+        checked += 1
+    assert checked >= 8
+
+
 @pytest.mark.parametrize("shift", [(0.0, 0.0, 0.0), (1.0e6, 50.0, -1.0e6)])
 def test_emulated_tile_early_out_is_conservative_and_effective(emul_lib, oracle_port, shift):
     """k_cull_fused ends a tile before classifying its cells when the box of its cell indices is behind a plane (tile_rejected):
