@@ -93,6 +93,8 @@ def test_struct_layouts_match_the_c_header(api, tmp_path):
         "LmxAnimConstRotation": (api.ANIM_CONST_ROTATION, ["value", "bone_index"]),
         "LmxAnimRotationTrack": (api.ANIM_ROTATION_TRACK, ["min", "to_range", "offset_bits", "bone_index", "bitsizes", "skipped_channel"]),
         "LmxWorldBlobInfo": (api.WORLD_BLOB_INFO, ["version", "flags", "n_modules", "uncompressed_size", "compressed_size", "n_entities", "max_entity_index", "n_names", "n_hierarchy"]),
+        "LmxRenderBlobInfo": (api.RENDER_BLOB_INFO, list(api.RENDER_BLOB_INFO.names)),
+        "LmxBlobBoneAttachment": (api.BLOB_BONE_ATTACHMENT, ["bone_name_hash", "entity", "parent_entity"]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lumix_mi355.h"', "int main(void) {"]
     for name, (_, fields) in structs.items():
