@@ -221,15 +221,11 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 	for (size_t i = 0; i < n; ++i) count_by_type[recs[i].type]++;
 	// Placement. The padding rules are a serial state machine, but its state only changes at CELL boundaries: the spheres are cut
 	// into cells in parallel, the state machine walks the ~n / 10 cells (not the n spheres), and the spheres / ids / cell slots are
-	// written in parallel from the cells' start slots. The two random passes over the 10^7..10^8 entries (records gathered into
-	// sorted order, slots scattered back to record order) run on all threads as well.
-	std::vector<CullRec> sorted(n);
-	std::vector<uint8_t> starts_cell(n); // sorted[i] is the first sphere of a (type, is_big, cell) group
+	// written in parallel from the cells' start slots - the one random pass over the 10^7..10^8 records (read in sorted order, slot
+	// written back in record order) runs on all threads.
+	std::vector<uint8_t> starts_cell(n); // the i-th sphere in sorted order is the first of a (type, is_big, cell) group
 	parallel_ranges(n, [&](size_t b, size_t e) {
-		for (size_t i = b; i < e; ++i) {
-			sorted[i] = recs[items[i].rec];
-			starts_cell[i] = i == 0 || items[i].hi != items[i - 1].hi || items[i].lo != items[i - 1].lo; // (type is part of `hi`)
-		}
+		for (size_t i = b; i < e; ++i) starts_cell[i] = i == 0 || items[i].hi != items[i - 1].hi || items[i].lo != items[i - 1].lo; // (type is part of `hi`)
 	});
 	std::vector<size_t> group_first; // sorted index of every group's first sphere, + n
 	{
@@ -275,8 +271,8 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 			continue;
 		}
 		uint32_t block_cells = 0; // distinct cell slots overlapping the current LAYOUT_CELL_BLOCK-slot block
-		for (; g < n_groups && sorted[group_first[g]].type == (uint8_t)t; ++g) {
-			const CullRec& r = sorted[group_first[g]];
+		for (; g < n_groups && recs[items[group_first[g]].rec].type == (uint8_t)t; ++g) {
+			const CullRec& r = recs[items[group_first[g]].rec];
 			const uint64_t size = group_first[g + 1] - group_first[g];
 			if (pos % LAYOUT_CELL_BLOCK == 0) block_cells = 0;
 			if (block_cells + 2 > LAYOUT_MAX_CELLS_PER_BLOCK) {
@@ -322,7 +318,7 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 			uint32_t slot = group_slot[k];
 			const uint32_t cell = group_cell[k];
 			for (size_t i = group_first[k]; i < group_first[k + 1]; ++i, ++slot) {
-				const CullRec& r = sorted[i];
+				const CullRec& r = recs[items[i].rec];
 				out.spheres[slot] = LayoutSphere{r.rel.x, r.rel.y, r.rel.z, r.radius};
 				out.ids[slot] = r.entity;
 				out.slot_cell[slot] = cell;
@@ -330,7 +326,7 @@ inline bool build_cull_layout(const std::vector<CullRec>& recs, CullLayout& out)
 			}
 		}
 	});
-	{ std::vector<SortItem>().swap(items); std::vector<CullRec>().swap(sorted); std::vector<size_t>().swap(group_first); }
+	{ std::vector<SortItem>().swap(items); std::vector<size_t>().swap(group_first); }
 
 	const size_t n_chunks = n_padded / LAYOUT_CHUNK;
 	out.hdr.resize(n_chunks);
