@@ -47,6 +47,18 @@ enum {
 /* ---- context -------------------------------------------------------------------------------------------- */
 LMX_API int lmx_ctx_create(int device, LmxContext** out);
 LMX_API void lmx_ctx_destroy(LmxContext* ctx);
+/* ONE context per World, shared by every adapter of that World. The reference creates one CullingSystem per RenderModuleImpl
+ * (src/renderer/render_module.cpp:3569) and moves its spheres from onModelInstanceMoved (:1544-1554) on the SAME object; here the
+ * culling set, the transform hierarchy and the skinning tables of one World live in one LmxContext, and the engine-side pieces that
+ * are created independently of each other - the CullingSystem replacement inside RenderModuleImpl, the plugin's IModule - find it
+ * through a process-wide registry keyed by the World's address. acquire creates the context on first use and counts references;
+ * release destroys it with the last one. `key` is only compared, never dereferenced. */
+LMX_API int lmx_ctx_acquire_shared(const void* key, int device, LmxContext** out);
+LMX_API void lmx_ctx_release_shared(LmxContext* ctx);
+/* A context is not re-entrant. Adapters that share one (update thread: add / set / propagate; render jobs: cull) serialise on the
+ * context's own recursive lock. */
+LMX_API void lmx_ctx_lock(LmxContext* ctx);
+LMX_API void lmx_ctx_unlock(LmxContext* ctx);
 /* Last error text of this context (or of the failed lmx_ctx_create when ctx == NULL). Never NULL. */
 LMX_API const char* lmx_last_error(const LmxContext* ctx);
 /* Use an external HIP stream (hipStream_t as void*) for all launches/copies instead of the context's own non-blocking
@@ -122,7 +134,8 @@ enum {
 	LMX_CULL_OPT_LANE_PARALLEL_TILE_TEST = 1, /* tile-level box test of the 1-frustum kernel: 0 = uniform code in every wave, 1 = one plane per lane in every wave, 2 (default) = one plane per lane in wave 0 only, verdict handed over through LDS */
 	LMX_CULL_OPT_MAX_SHARDS = 2,              /* output shards (reservation counters) per renderable type, 1..64 (default 64) */
 	LMX_CULL_OPT_COUNTER_PAD = 3,             /* 32-bit words between two shard counters, 1..64 (default 32 = one 128-byte line each) */
-	LMX_CULL_OPT_AUTO_COMPACTION = 4          /* 1 (default): the sorted set is re-built (O(n log n) on the host, ~0.5 s at 10 M) when the overflow set exceeds max(65536, n/8) or the tombstones max(65536, n/4); 0: never on its own - the host calls lmx_cull_compact when a hitch is acceptable */
+	LMX_CULL_OPT_AUTO_COMPACTION = 4,         /* 1 (default): the sorted set is re-built (O(n log n) on the host, ~0.5 s at 10 M) when the overflow set exceeds max(65536, n/8) or the tombstones max(65536, n/4); 0: never on its own - the host calls lmx_cull_compact when a hitch is acceptable */
+	LMX_CULL_OPT_DEVICE_OWNS_BOUND = 5        /* 1: lmx_cull_set / set_position / set_radius on an entity bound with lmx_world_bind_culling are accepted and dropped - lmx_world_propagate has already refreshed its sphere on the device (what the adapter sets while it replays the engine's `transformed` delegates, whose RenderModuleImpl::onModelInstanceMoved would repeat the refresh per entity on the host); 0 (default): they apply */
 };
 LMX_API int lmx_cull_set_option(LmxContext* ctx, int option, int value);
 /* counts[f * LMX_MAX_TYPES + t] = visible entities of type t for frustum f (synchronizes the stream). */
@@ -138,6 +151,10 @@ LMX_API int lmx_cull_read_all(LmxContext* ctx, uint32_t view, uint32_t frustum, 
  * out_counts[LMX_MAX_TYPES] per type), valid until the next lmx_cull_map_all on this view. The copy is enqueued before the count is
  * known, sized from the previous call on this view; a list that outgrew it costs a second wait. */
 LMX_API int lmx_cull_map_all(LmxContext* ctx, uint32_t view, uint32_t frustum, const int32_t** out_ids, uint32_t* out_counts);
+/* The same for ALL frusta of the view's last lmx_cull in one go - the frame's views (the reference culls 4 shadow cascades + the main
+ * view + a light query per frame, pipeline.cpp:1036-1045, :1252-1258) as one lmx_cull with n_frusta frusta and ONE host wait:
+ * out_ids[f] / out_counts[f * LMX_MAX_TYPES + t] per frustum, valid until the next cull or map on this view. */
+LMX_API int lmx_cull_map_many(LmxContext* ctx, uint32_t view, uint32_t n_frusta, const int32_t** out_ids, uint32_t* out_counts);
 /* Device-side view of a result for GPU consumers (sort keys, RCCL all-gather): ids of (frustum, type) start at
  * d_ids + type_offsets[type] and number d_counts[frustum * LMX_MAX_TYPES + type]. All pointers are device memory
  * except type_offsets (host, LMX_MAX_TYPES entries, in ids). The cull kernels leave the visible ids in up to a few hundred
@@ -239,6 +256,13 @@ LMX_API int lmx_world_set_bone_attachments(LmxContext* ctx, uint32_t n, const in
 	const uint32_t* skin_instance, const uint32_t* bone_index, const LmxLocalRigidTransform* relative);
 LMX_API int lmx_world_update_bone_attachments(LmxContext* ctx);
 LMX_API int lmx_world_read_transforms(LmxContext* ctx, LmxTransform* out, uint32_t n);
+/* The entities whose world transform changed in the LAST lmx_world_propagate (staged writes, their subtrees, bone attachments): what
+ * World::transformEntity would have visited (world.cpp:255-282). lmx_world_track_moved(1) makes propagate collect them on the device
+ * (one compaction pass instead of the plain clear of the marks); lmx_world_read_moved copies the list - entity indices and their new
+ * world transforms, in no particular order - to the host. out_n is the number moved, also when it exceeds `cap` (LMX_ERR_CAPACITY:
+ * nothing is copied; read everything with lmx_world_read_transforms instead). The hand-back of a frame costs what moved, not n. */
+LMX_API int lmx_world_track_moved(LmxContext* ctx, int enable);
+LMX_API int lmx_world_read_moved(LmxContext* ctx, int32_t* entity, LmxTransform* transforms, uint32_t cap, uint32_t* out_n);
 
 /* ---- skinning: Pose / Model, src/renderer/pose.cpp:63-134, src/renderer/model.cpp:103-137 -------------------- */
 
@@ -274,6 +298,12 @@ LMX_API int lmx_skin_set_mode(LmxContext* ctx, int mode);
 /* Pose::computeAbsolute -> computeSkinMatrices -> evaluateSkin for every instance; outputs stay in HBM. */
 LMX_API int lmx_skin_run(LmxContext* ctx);
 LMX_API int lmx_skin_read_vertices(LmxContext* ctx, uint32_t instance, float* out_xyz, uint32_t cap_verts);
+/* Instances [first, first + n) in ONE copy: their outputs are consecutive in HBM in instance order (out = sum of the meshes' vertex
+ * counts, in order). What a renderer-side consumer (or a full-size parity check) reads instead of n single-instance calls. */
+LMX_API int lmx_skin_read_vertices_range(LmxContext* ctx, uint32_t first_instance, uint32_t n_instances, float* out_xyz, size_t cap_verts);
+/* The skinned positions where they lie: device pointer to 3 floats per vertex, instances back to back (valid until the next
+ * lmx_skin_set_instances), and the total vertex count. Stream-ordered after lmx_skin_run on the context stream. */
+LMX_API int lmx_skin_device_output(LmxContext* ctx, const float** d_xyz, size_t* n_verts_total);
 LMX_API int lmx_skin_read_palette(LmxContext* ctx, uint32_t instance, LmxMatrix* out, uint32_t cap_bones);
 LMX_API int lmx_skin_read_pose(LmxContext* ctx, uint32_t instance, float* out_pos, float* out_rot, uint32_t cap_bones);
 /* The reference keeps the absolute pose in the instance's Pose (Pose::is_absolute, pose.cpp:133) for bone attachments and

@@ -19,11 +19,11 @@ from typing import Optional, Sequence
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "liblumix_mi355.so")
+LIB_PATH = os.environ.get("LMX_LIB_PATH") or os.path.join(PKG, "liblumix_mi355.so")  # LMX_LIB_PATH: tools/ sweeps over kernel build variants
 
 MAX_FRUSTA, MAX_TYPES, MAX_VIEWS = 8, 8, 8
 TYPE_ALL = 0xFF
-CULL_OPT_TILE_VARIANT, CULL_OPT_LANE_PARALLEL_TILE_TEST, CULL_OPT_MAX_SHARDS, CULL_OPT_COUNTER_PAD, CULL_OPT_AUTO_COMPACTION = range(5)
+CULL_OPT_TILE_VARIANT, CULL_OPT_LANE_PARALLEL_TILE_TEST, CULL_OPT_MAX_SHARDS, CULL_OPT_COUNTER_PAD, CULL_OPT_AUTO_COMPACTION, CULL_OPT_DEVICE_OWNS_BOUND = range(6)
 (K_CULL_CLASSIFY, K_CULL_SPHERES, K_XFORM_LEVEL, K_SPHERE_REFRESH, K_POSE_PALETTE, K_SKIN_VERTICES, K_CULL_DYNAMIC) = range(7)
 KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices", "cull_dynamic", "sort_keys", "anim_update", "cull_patch"]
 K_CULL_PATCH = 9
@@ -84,6 +84,10 @@ _vp, _u32, _i32, _u8, _f32, _ci, _sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_ui
 SYMBOLS = {
     "lmx_ctx_create": (_ci, [_ci, C.POINTER(_vp)]),
     "lmx_ctx_destroy": (None, [_vp]),
+    "lmx_ctx_acquire_shared": (_ci, [_vp, _ci, C.POINTER(_vp)]),
+    "lmx_ctx_release_shared": (None, [_vp]),
+    "lmx_ctx_lock": (None, [_vp]),
+    "lmx_ctx_unlock": (None, [_vp]),
     "lmx_last_error": (C.c_char_p, [_vp]),
     "lmx_ctx_set_stream": (_ci, [_vp, _vp]),
     "lmx_ctx_synchronize": (_ci, [_vp]),
@@ -107,6 +111,7 @@ SYMBOLS = {
     "lmx_cull_set_option": (_ci, [_vp, _ci, _ci]),
     "lmx_cull_read_all": (_ci, [_vp, _u32, _u32, _vp, _u32, _vp]),
     "lmx_cull_map_all": (_ci, [_vp, _u32, _u32, _vp, _vp]),
+    "lmx_cull_map_many": (_ci, [_vp, _u32, _u32, _vp, _vp]),
     "lmx_cull_device_shards": (_ci, [_vp, _u32, _u32, _vp]),
     "lmx_cull_stats": (_ci, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "lmx_cull": (_ci, [_vp, _u32, _vp, _u32, _u8]),
@@ -134,6 +139,8 @@ SYMBOLS = {
     "lmx_world_bind_culling": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_world_propagate": (_ci, [_vp]),
     "lmx_world_read_transforms": (_ci, [_vp, _vp, _u32]),
+    "lmx_world_track_moved": (_ci, [_vp, _ci]),
+    "lmx_world_read_moved": (_ci, [_vp, _vp, _vp, _u32, C.POINTER(_u32)]),
     "lmx_world_set_bone_attachments": (_ci, [_vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "lmx_world_update_bone_attachments": (_ci, [_vp]),
     "lmx_skin_add_model": (_ci, [_vp, _u32, _vp, _vp, _i32, C.POINTER(_u32)]),
@@ -147,6 +154,8 @@ SYMBOLS = {
     "lmx_skin_set_mode": (_ci, [_vp, _ci]),
     "lmx_skin_run": (_ci, [_vp]),
     "lmx_skin_read_vertices": (_ci, [_vp, _u32, _vp, _u32]),
+    "lmx_skin_read_vertices_range": (_ci, [_vp, _u32, _u32, _vp, C.c_size_t]),
+    "lmx_skin_device_output": (_ci, [_vp, _vp, _vp]),
     "lmx_skin_read_palette": (_ci, [_vp, _u32, _vp, _u32]),
     "lmx_skin_set_pose_writeback": (_ci, [_vp, _ci]),
     "lmx_skin_enable_dual_quats": (_ci, [_vp, _ci]),
@@ -583,6 +592,17 @@ class World:
         self.ctx.check(self.lib.lmx_world_read_transforms(self.ctx.h, _ptr(out), self.n))
         return out
 
+    def trackMoved(self, on: bool = True):
+        """propagate() collects the entities whose world transform changed (what World::transformEntity would have visited)."""
+        self.ctx.check(self.lib.lmx_world_track_moved(self.ctx.h, int(on)))
+
+    def readMoved(self):
+        """(entity int32[k], TRANSFORM[k]) moved by the propagate() calls since the last read; an entity moved by two of them is listed twice, newest last."""
+        cap = max(2 * self.n, 1)
+        ent, tr, n = np.zeros(cap, np.int32), np.zeros(cap, TRANSFORM), _u32(0)
+        self.ctx.check(self.lib.lmx_world_read_moved(self.ctx.h, _ptr(ent), _ptr(tr), cap, C.byref(n)))
+        return ent[: n.value].copy(), tr[: n.value].copy()
+
 
 WORLD_BLOB_INFO = np.dtype([(k, "<u4") for k in ("version", "flags", "n_modules", "uncompressed_size", "compressed_size", "n_entities", "max_entity_index", "n_names",
                                                   "n_hierarchy")])
@@ -799,6 +819,19 @@ class Skinning:
         out = np.zeros((n, 3), np.float32)
         self.ctx.check(self.lib.lmx_skin_read_vertices(self.ctx.h, instance, _ptr(out), n))
         return out
+
+    def readVerticesRange(self, first: int, count: int) -> np.ndarray:
+        """Skinned positions of instances [first, first + count) in one copy: float32 [total vertices, 3], instances back to back."""
+        n = int(sum(self._meshes[int(m)] for m in self._inst_mesh[first : first + count]))
+        out = np.empty((n, 3), np.float32)
+        self.ctx.check(self.lib.lmx_skin_read_vertices_range(self.ctx.h, first, count, _ptr(out), n))
+        return out
+
+    def deviceOutput(self):
+        """(device pointer, total vertices) of the skinned positions in HBM (3 floats per vertex, instances back to back)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self.ctx.check(self.lib.lmx_skin_device_output(self.ctx.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
 
     def readPalette(self, instance: int) -> np.ndarray:
         n = self._models[int(self._inst_model[instance])]

@@ -82,6 +82,52 @@ void lmx_ctx_destroy(LmxContext* ctx) {
 	delete ctx;
 }
 
+// ---- one context per World (registry keyed by the World's address) ------------------------------------------------------------
+namespace {
+struct SharedEntry { const void* key; int device; LmxContext* ctx; int refs; };
+std::mutex g_shared_mutex;
+std::vector<SharedEntry> g_shared;
+} // namespace
+
+int lmx_ctx_acquire_shared(const void* key, int device, LmxContext** out) {
+	if (!out || !key) return LMX_ERR_INVALID_ARGUMENT;
+	*out = nullptr;
+	std::lock_guard<std::mutex> guard(g_shared_mutex);
+	for (SharedEntry& e : g_shared) {
+		if (e.key == key && e.device == device) {
+			++e.refs;
+			*out = e.ctx;
+			return LMX_OK;
+		}
+	}
+	LmxContext* ctx = nullptr;
+	if (int rc = lmx_ctx_create(device, &ctx)) return rc;
+	g_shared.push_back(SharedEntry{key, device, ctx, 1});
+	*out = ctx;
+	return LMX_OK;
+}
+
+void lmx_ctx_release_shared(LmxContext* ctx) {
+	if (!ctx) return;
+	{
+		std::lock_guard<std::mutex> guard(g_shared_mutex);
+		for (size_t i = 0; i < g_shared.size(); ++i) {
+			if (g_shared[i].ctx != ctx) continue;
+			if (--g_shared[i].refs > 0) return;
+			g_shared.erase(g_shared.begin() + i);
+			break;
+		}
+	}
+	lmx_ctx_destroy(ctx); // last reference (or a context that never was in the registry)
+}
+
+void lmx_ctx_lock(LmxContext* ctx) {
+	if (ctx) ctx->lock.lock();
+}
+void lmx_ctx_unlock(LmxContext* ctx) {
+	if (ctx) ctx->lock.unlock();
+}
+
 const char* lmx_last_error(const LmxContext* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
 int lmx_ctx_set_stream(LmxContext* ctx, void* hip_stream) {

@@ -601,6 +601,7 @@ static int cull_set_impl(LmxContext* ctx, int32_t entity, const double pos[3], f
 		}
 		case Where::DYNAMIC: {
 			DynRec& r = cs.dyn[idx];
+			if (r.bound && cs.device_owns_bound) return LMX_OK; // lmx_world_propagate already refreshed this sphere on the device
 			r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
 			r.radius = radius;
 			queue_dyn_patch(cs, r, true);
@@ -645,6 +646,7 @@ int lmx_cull_set_position(LmxContext* ctx, int32_t entity, const double pos[3]) 
 		}
 		case Where::DYNAMIC: {
 			if (cs.dyn[idx].bound) { // the radius the patch carries must be the one the device last computed
+				if (cs.device_owns_bound) return LMX_OK;
 				if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
 			}
 			DynRec& r = cs.dyn[idx];
@@ -674,6 +676,7 @@ int lmx_cull_set_radius(LmxContext* ctx, int32_t entity, float radius) { // cull
 		}
 		case Where::DYNAMIC: {
 			if (cs.dyn[idx].bound) {
+				if (cs.device_owns_bound) return LMX_OK;
 				if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
 			}
 			DynRec& r = cs.dyn[idx];
@@ -930,6 +933,7 @@ int lmx_cull_set_option(LmxContext* ctx, int option, int value) {
 			cs.lane_parallel = value;
 			return LMX_OK;
 		case LMX_CULL_OPT_AUTO_COMPACTION: cs.auto_compaction = value != 0; return LMX_OK;
+		case LMX_CULL_OPT_DEVICE_OWNS_BOUND: cs.device_owns_bound = value != 0; return LMX_OK;
 		case LMX_CULL_OPT_MAX_SHARDS:
 			if (value < 1 || value > (int)LAYOUT_MAX_SHARDS) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "max shards %d not in [1,%u]", value, LAYOUT_MAX_SHARDS);
 			cs.max_shards = (uint32_t)value;
@@ -1013,49 +1017,75 @@ int lmx_cull_read_all(LmxContext* ctx, uint32_t view, uint32_t frustum, int32_t*
 // returned (+25 %): frames are coherent, so the guess almost always covers the list; when it does not, the rest follows with a second
 // wait. The caller reads the ids in place: *out_ids stays valid until the next lmx_cull_map_all on this view.
 // (Letting the gather kernel store straight into mapped host memory was measured too: 4-byte stores over PCIe, 0.49 ms for 334 k ids.)
-int lmx_cull_map_all(LmxContext* ctx, uint32_t view, uint32_t frustum, const int32_t** out_ids, uint32_t* out_counts) {
-	LMX_CHECK_CTX(ctx);
-	if (view >= LMX_MAX_VIEWS || !out_counts || !out_ids) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad view / null output");
+// Records [MAX_TYPES counts | ids, types back to back] of frusta [first, first + n) of a view, each packed by one k_cull_pack launch into
+// its own area of map_rec and copied into pinned host memory - counts + the first map_guess ids before the count is known - with ONE
+// host wait for all of them (a second one only for a frustum whose list outgrew its guess, this frame only).
+static int cull_map_range(LmxContext* ctx, CullView& v, uint32_t first, uint32_t n, const int32_t** out_ids, uint32_t* out_counts) {
 	CullState& cs = ctx->cull;
-	CullView& v = cs.views[view];
-	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
-	if (frustum >= v.n_frusta) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "frustum %u out of range", frustum);
-	const size_t need = (size_t)MAX_TYPES + v.out_stride;
-	if (v.map_words < need) {
+	const size_t need = (size_t)MAX_TYPES + v.out_stride; // words per record area
+	if (v.map_words < need || v.map_frusta < v.n_frusta) {
 		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // nothing may still write the old buffer
 		if (v.map_host) LMX_HIP(ctx, hipHostFree(v.map_host));
 		v.map_host = nullptr;
 		v.map_words = 0;
 		const size_t want = need + need / 4 + 1024;
-		LMX_HIP(ctx, hipHostMalloc(&v.map_host, want * sizeof(int32_t), hipHostMallocDefault));
-		LMX_HIP(ctx, v.map_rec.reserve(want));
+		const size_t areas = std::max<size_t>(v.n_frusta, v.map_frusta);
+		LMX_HIP(ctx, hipHostMalloc(&v.map_host, want * areas * sizeof(int32_t), hipHostMallocDefault));
+		LMX_HIP(ctx, v.map_rec.reserve(want * areas));
 		v.map_words = want;
+		v.map_frusta = areas;
 	}
-	LMX_HIP(ctx, v.map_pref.reserve(std::max<size_t>(cs.n_shards, 1)));
-	LMX_HIP(ctx, v.map_start.reserve(MAX_TYPES));
 	const uint32_t cnt_frustum_stride = cs.n_shards * cs.cnt_pad;
-	const uint32_t* counts = v.counts_ptr() + (size_t)frustum * cnt_frustum_stride;
-	uint32_t* header = reinterpret_cast<uint32_t*>(v.map_rec.p);
-	LMX_HIP(ctx, launch_cull_pack(ctx->stream, v.out.p + (size_t)frustum * v.out_stride, cs.d_win_base.p, counts, cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, cs.max_shard_cap,
-		header, v.map_rec.p + MAX_TYPES, v.out_stride));
-	const size_t guess = std::min<size_t>(v.out_stride, v.map_guess);
-	LMX_HIP(ctx, hipMemcpyAsync(v.map_host, v.map_rec.p, (MAX_TYPES + guess) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+	size_t guess[MAX_FRUSTA];
+	for (uint32_t k = 0; k < n; ++k) {
+		const uint32_t f = first + k;
+		const uint32_t* counts = v.counts_ptr() + (size_t)f * cnt_frustum_stride;
+		int32_t* rec = v.map_rec.p + (size_t)f * v.map_words;
+		LMX_HIP(ctx, launch_cull_pack(ctx->stream, v.out.p + (size_t)f * v.out_stride, cs.d_win_base.p, counts, cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, cs.max_shard_cap,
+			reinterpret_cast<uint32_t*>(rec), rec + MAX_TYPES, v.out_stride));
+		guess[k] = std::min<size_t>(v.out_stride, v.map_guess[f]);
+		LMX_HIP(ctx, hipMemcpyAsync(reinterpret_cast<int32_t*>(v.map_host) + (size_t)f * v.map_words, rec, (MAX_TYPES + guess[k]) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+	}
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	const uint32_t* h = reinterpret_cast<const uint32_t*>(v.map_host);
-	size_t total = 0;
-	for (int t = 0; t < MAX_TYPES; ++t) {
-		if (h[t] > v.out_cap[t]) return fail(ctx, LMX_ERR_HIP, "corrupt count %u > %u", h[t], v.out_cap[t]);
-		out_counts[t] = h[t];
-		total += h[t];
+	bool more = false;
+	for (uint32_t k = 0; k < n; ++k) {
+		const uint32_t f = first + k;
+		int32_t* host = reinterpret_cast<int32_t*>(v.map_host) + (size_t)f * v.map_words;
+		const uint32_t* h = reinterpret_cast<const uint32_t*>(host);
+		size_t total = 0;
+		for (int t = 0; t < MAX_TYPES; ++t) {
+			if (h[t] > v.out_cap[t]) return fail(ctx, LMX_ERR_HIP, "corrupt count %u > %u", h[t], v.out_cap[t]);
+			out_counts[k * MAX_TYPES + t] = h[t];
+			total += h[t];
+		}
+		if (total > guess[k]) { // the list outgrew the guess: fetch the rest (second wait, this frame only)
+			LMX_HIP(ctx, hipMemcpyAsync(host + MAX_TYPES + guess[k], v.map_rec.p + (size_t)f * v.map_words + MAX_TYPES + guess[k], (total - guess[k]) * sizeof(int32_t),
+				hipMemcpyDeviceToHost, ctx->stream));
+			more = true;
+		}
+		v.map_guess[f] = total + total / 4 + 1024;
+		out_ids[k] = host + MAX_TYPES;
 	}
-	if (total > guess) { // the list outgrew the guess: fetch the rest (second wait, this frame only)
-		LMX_HIP(ctx, hipMemcpyAsync(reinterpret_cast<int32_t*>(v.map_host) + MAX_TYPES + guess, v.map_rec.p + MAX_TYPES + guess, (total - guess) * sizeof(int32_t),
-			hipMemcpyDeviceToHost, ctx->stream));
-		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	}
-	v.map_guess = total + total / 4 + 1024;
-	*out_ids = reinterpret_cast<const int32_t*>(v.map_host) + MAX_TYPES;
+	if (more) LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return LMX_OK;
+}
+
+int lmx_cull_map_all(LmxContext* ctx, uint32_t view, uint32_t frustum, const int32_t** out_ids, uint32_t* out_counts) {
+	LMX_CHECK_CTX(ctx);
+	if (view >= LMX_MAX_VIEWS || !out_counts || !out_ids) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad view / null output");
+	CullView& v = ctx->cull.views[view];
+	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
+	if (frustum >= v.n_frusta) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "frustum %u out of range", frustum);
+	return cull_map_range(ctx, v, frustum, 1, out_ids, out_counts);
+}
+
+int lmx_cull_map_many(LmxContext* ctx, uint32_t view, uint32_t n_frusta, const int32_t** out_ids, uint32_t* out_counts) {
+	LMX_CHECK_CTX(ctx);
+	if (view >= LMX_MAX_VIEWS || !out_counts || !out_ids) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad view / null output");
+	CullView& v = ctx->cull.views[view];
+	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
+	if (n_frusta != v.n_frusta) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "the view holds %u frusta, not %u", v.n_frusta, n_frusta);
+	return cull_map_range(ctx, v, 0, n_frusta, out_ids, out_counts);
 }
 
 int lmx_cull_bind_output(LmxContext* ctx, uint32_t view, void* d_ids, size_t ids_capacity, void* d_counts) {

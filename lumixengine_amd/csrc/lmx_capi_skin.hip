@@ -339,6 +339,30 @@ int lmx_skin_read_vertices(LmxContext* ctx, uint32_t instance, float* out_xyz, u
 	return LMX_OK;
 }
 
+int lmx_skin_read_vertices_range(LmxContext* ctx, uint32_t first_instance, uint32_t n_instances, float* out_xyz, size_t cap_verts) {
+	LMX_CHECK_CTX(ctx);
+	SkinState& sk = ctx->skin;
+	if (!out_xyz || (size_t)first_instance + n_instances > sk.inst.size()) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad instance range/out");
+	if (!n_instances) return LMX_OK;
+	const SkinInstance& a = sk.inst[first_instance];
+	const SkinInstance& b = sk.inst[first_instance + n_instances - 1];
+	const size_t n = (size_t)b.out_offset + b.n_verts - a.out_offset; // outputs are laid out in instance order
+	if (cap_verts < n) return fail(ctx, LMX_ERR_CAPACITY, "need room for %zu vertices", n);
+	LMX_HIP(ctx, hipMemcpyAsync(out_xyz, sk.d_out.p + (size_t)a.out_offset * 3, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return LMX_OK;
+}
+
+int lmx_skin_device_output(LmxContext* ctx, const float** d_xyz, size_t* n_verts_total) {
+	LMX_CHECK_CTX(ctx);
+	SkinState& sk = ctx->skin;
+	if (!d_xyz || !n_verts_total) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null out pointer");
+	if (sk.inst.empty()) return fail(ctx, LMX_ERR_NOT_BUILT, "no skinned instances");
+	*d_xyz = sk.d_out.p;
+	*n_verts_total = (size_t)sk.inst.back().out_offset + sk.inst.back().n_verts;
+	return LMX_OK;
+}
+
 int lmx_skin_read_palette(LmxContext* ctx, uint32_t instance, LmxMatrix* out, uint32_t cap_bones) {
 	LMX_CHECK_CTX(ctx);
 	SkinState& sk = ctx->skin;

@@ -65,6 +65,10 @@ int world_rebuild(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxT
 	LMX_HIP(ctx, w.d_slot_of_entity.reserve(cap));
 	LMX_HIP(ctx, w.d_entity_of_slot.reserve(cap));
 	LMX_HIP(ctx, w.d_dirty.reserve(cap));
+	if (w.track_moved) { // two propagations per frame (staged writes, bone-attached subtrees) fit between two reads
+		LMX_HIP(ctx, w.d_moved_entity.reserve(cap * 2));
+		LMX_HIP(ctx, w.d_moved_tr.reserve(cap * 2));
+	}
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	// scene load from locals (no world values given): every node counts as moved, so the first propagation derives all world
 	// transforms; with world values (re-parenting, lmx_world_build_with_world) nothing is recomputed until something is written
@@ -291,7 +295,11 @@ int lmx_world_propagate(LmxContext* ctx) {
 		ProfScope ps(ctx, LMX_K_XFORM_LEVEL);
 		LMX_HIP(ctx, launch_xform_level(ctx->stream, dev, w.level_start[l], w.level_start[l + 1] - w.level_start[l]));
 	}
-	if (w.n) LMX_HIP(ctx, hipMemsetAsync(w.d_dirty.p, 0, w.n, ctx->stream)); // the frame's "moved" marks end here
+	if (w.n && w.track_moved) { // the frame's "moved" marks end here: collected for the hand-back, then cleared
+		LMX_HIP(ctx, launch_xform_collect_moved(ctx->stream, dev, w.d_entity_of_slot.p, w.n, w.n * 2u, w.d_moved_entity.p, w.d_moved_tr.p, w.d_moved_count.p));
+	} else if (w.n) {
+		LMX_HIP(ctx, hipMemsetAsync(w.d_dirty.p, 0, w.n, ctx->stream));
+	}
 	if (!w.bound_entity.empty()) {
 		if (int rc = world_upload_binding(ctx)) return rc;
 		CullState& cs = ctx->cull;
@@ -351,6 +359,47 @@ int lmx_world_update_bone_attachments(LmxContext* ctx) {
 	if (w.attach_skin_instances != sk.inst.size()) return fail(ctx, LMX_ERR_NOT_BUILT, "the skin instance table changed; call lmx_world_set_bone_attachments again");
 	if (!sk.pose_is_absolute) return fail(ctx, LMX_ERR_NOT_BUILT, "bone attachments read the absolute pose (ASSERT(pose->is_absolute), render_module.cpp:424): run lmx_skin_run with pose write-back first");
 	LMX_HIP(ctx, launch_bone_attach(ctx->stream, w.dev(), w.d_attach.p, w.n_attach, sk.d_inst.p, sk.d_pose_pos.p, sk.d_pose_rot.p));
+	return LMX_OK;
+}
+
+int lmx_world_track_moved(LmxContext* ctx, int enable) {
+	LMX_CHECK_CTX(ctx);
+	WorldState& w = ctx->world;
+	w.track_moved = enable != 0;
+	if (w.track_moved) {
+		LMX_HIP(ctx, w.d_moved_count.reserve(1));
+		LMX_HIP(ctx, hipMemsetAsync(w.d_moved_count.p, 0, sizeof(uint32_t), ctx->stream));
+		if (w.built) {
+			LMX_HIP(ctx, w.d_moved_entity.reserve(std::max<size_t>((size_t)w.n * 2, 1)));
+			LMX_HIP(ctx, w.d_moved_tr.reserve(std::max<size_t>((size_t)w.n * 2, 1)));
+		}
+	}
+	return LMX_OK;
+}
+
+int lmx_world_read_moved(LmxContext* ctx, int32_t* entity, LmxTransform* transforms, uint32_t cap, uint32_t* out_n) {
+	LMX_CHECK_CTX(ctx);
+	WorldState& w = ctx->world;
+	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
+	if (!w.track_moved) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_track_moved(1) first");
+	if (!out_n) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null out_n");
+	uint32_t n = 0;
+	LMX_HIP(ctx, hipMemcpyAsync(&n, w.d_moved_count.p, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*out_n = n;
+	// (an entity can be listed twice when a frame propagated twice - staged writes, then bone-attached subtrees; later entries are newer)
+	const uint32_t stored = std::min(n, w.n * 2u); // what the lists can hold: see the reservation in world_rebuild
+	if (n > stored) { // more than two propagations without a read: the overflow was counted, not stored
+		LMX_HIP(ctx, hipMemsetAsync(w.d_moved_count.p, 0, sizeof(uint32_t), ctx->stream));
+		return fail(ctx, LMX_ERR_CAPACITY, "%u moved records since the last read exceed the list (%u): read every transform with lmx_world_read_transforms", n, stored);
+	}
+	if (n > cap || (n && (!entity || !transforms))) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u moved entities", n);
+	if (n) {
+		LMX_HIP(ctx, hipMemcpyAsync(entity, w.d_moved_entity.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+		LMX_HIP(ctx, hipMemcpyAsync(transforms, w.d_moved_tr.p, (size_t)n * sizeof(LmxTransform), hipMemcpyDeviceToHost, ctx->stream));
+	}
+	LMX_HIP(ctx, hipMemsetAsync(w.d_moved_count.p, 0, sizeof(uint32_t), ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return LMX_OK;
 }
 

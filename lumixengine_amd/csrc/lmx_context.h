@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -66,7 +67,8 @@ struct CullView {
 	// lmx_cull_map_all: [MAX_TYPES counts | ids, type 0 first] gathered into map_rec, copied into pinned host memory
 	void* map_host = nullptr;
 	size_t map_words = 0;
-	size_t map_guess = 4096; // ids the next call copies before it knows the count
+	size_t map_guess[LMX_MAX_FRUSTA] = {4096, 4096, 4096, 4096, 4096, 4096, 4096, 4096}; // ids (per frustum) the next call copies before it knows the count
+	size_t map_frusta = 0;   // record areas the buffers were sized for
 	DevBuf<int32_t> map_rec;
 	DevBuf<uint32_t> map_pref, map_start;
 	~CullView() { if (map_host) (void)hipHostFree(map_host); }
@@ -160,6 +162,7 @@ struct CullState {
 	// ---- tuning (lmx_cull_set_option) -------------------------------------------------------------------------
 	uint32_t pass_width = 1;   // frusta tested per pass over the static set
 	int tile_variant = -1;     // -1: chosen per cull from the frustum's coverage of the scene
+	bool device_owns_bound = false; // LMX_CULL_OPT_DEVICE_OWNS_BOUND: set* calls on hierarchy-bound entities are dropped
 	bool auto_compaction = true; // false: overflow / tombstones accumulate until the host calls lmx_cull_compact
 	int lane_parallel = 2;     // tile-level box test of the 1-frustum kernels: 0 = uniform code in every wave, 1 = one plane per lane in every wave, 2 = one plane per lane in wave 0, verdict through LDS
 	uint32_t max_shards = LAYOUT_MAX_SHARDS; // output shards per type of the static set
@@ -182,6 +185,11 @@ struct WorldState {
 	DevBuf<int32_t> d_stage_entity;
 	DevBuf<LmxTransform> d_stage_tr;
 	DevBuf<LmxTransform> d_export;
+	// the moved list of the last propagation(s) (lmx_world_track_moved / lmx_world_read_moved)
+	bool track_moved = false;
+	DevBuf<int32_t> d_moved_entity;
+	DevBuf<LmxTransform> d_moved_tr;
+	DevBuf<uint32_t> d_moved_count;
 	// culling binding (RenderModuleImpl::onModelInstanceMoved)
 	std::vector<int32_t> bound_entity;
 	std::vector<float> bound_radius;
@@ -310,6 +318,7 @@ struct ProfSlot { hipEvent_t a, b; int kernel; };
 } // namespace lmx
 
 struct LmxContext {
+	std::recursive_mutex lock; // lmx_ctx_lock / lmx_ctx_unlock: adapters sharing the context serialise here
 	int device = 0;
 	hipStream_t own_stream = nullptr;
 	hipStream_t stream = nullptr;

@@ -114,6 +114,9 @@ enum { XF_STAGE_RAW = 0, XF_STAGE_RAW_WORLD = 1, XF_STAGE_SET_LOCAL = 2, XF_STAG
 hipError_t launch_xform_level(hipStream_t s, const WorldDevice& w, uint32_t first, uint32_t n);
 // out[entity_of_slot[s]] = AoS Transform (56 B) for s in [0, n)
 hipError_t launch_xform_export(hipStream_t s, const WorldDevice& w, const int32_t* entity_of_slot, uint32_t n, void* out_transforms);
+// append {entity, world transform} of every slot marked XF_MOVED to the lists (ballot-compacted, one atomic per wave) and clear all marks
+hipError_t launch_xform_collect_moved(hipStream_t s, const WorldDevice& w, const int32_t* entity_of_slot, uint32_t n, uint32_t cap, int32_t* out_entity,
+	void* out_transforms, uint32_t* count);
 // stage transforms (AoS LmxTransform, device memory) into the SoA arrays; mode = XF_STAGE_* (see k_xform_scatter)
 hipError_t launch_xform_scatter(hipStream_t s, const WorldDevice& w, const int32_t* slot_of_entity, const int32_t* entity,
 	const void* transforms, uint32_t n, int mode);

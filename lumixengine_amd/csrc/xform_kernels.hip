@@ -83,6 +83,34 @@ __global__ __launch_bounds__(256) void k_xform_export(WorldDevice w, const int32
 	out[entity_of_slot[s]] = t;
 }
 
+// The hand-back of a frame: what World::transformEntity would have visited. One pass over the marks: moved slots append
+// {entity, world transform} to the lists (wave64 ballot + mbcnt ranks, ONE returning atomic per wave), every mark is cleared.
+// `count` keeps running across launches (a frame may propagate twice: staged writes, then bone-attached subtrees); entries
+// beyond `cap` are counted but not stored.
+__global__ __launch_bounds__(256) void k_xform_collect_moved(WorldDevice w, const int32_t* __restrict__ entity_of_slot, uint32_t n, uint32_t cap,
+	int32_t* __restrict__ out_entity, TransformAoS* __restrict__ out_tr, uint32_t* __restrict__ count) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	const bool moved = s < n && (w.dirty[s] & XF_MOVED) != 0;
+	const uint64_t mask = __ballot(moved);
+	if (s < n && w.dirty[s] != 0) w.dirty[s] = 0;
+	if (mask == 0) return;
+	const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	uint32_t base = 0;
+	if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(mask));
+	base = __builtin_amdgcn_readfirstlane(base);
+	if (!moved) return;
+	const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+	if (at >= cap) return;
+	const float4 r = w.wrot[s];
+	TransformAoS t;
+	t.pos[0] = w.wpx[s]; t.pos[1] = w.wpy[s]; t.pos[2] = w.wpz[s];
+	t.rot[0] = r.x; t.rot[1] = r.y; t.rot[2] = r.z; t.rot[3] = r.w;
+	t.scale[0] = w.wsx[s]; t.scale[1] = w.wsy[s]; t.scale[2] = w.wsz[s];
+	t.pad = 0.f;
+	out_entity[at] = entity_of_slot[s];
+	out_tr[at] = t;
+}
+
 // Stage new transforms. mode XF_STAGE_SET_LOCAL: roots get their world transform (World::setTransform, world.cpp:337-342), children
 // their local transform + the XF_SET_LOCAL mark (World::setLocalTransform, world.cpp:741-753); XF_STAGE_SET_WORLD: World::setTransform
 // on any entity (children keep the staged world transform, XF_SET_WORLD mark); XF_STAGE_RAW: roots -> world, children -> stored local
@@ -132,6 +160,13 @@ __global__ __launch_bounds__(256) void k_sphere_refresh(WorldDevice w, const uin
 hipError_t launch_xform_level(hipStream_t s, const WorldDevice& w, uint32_t first, uint32_t n) {
 	if (!n) return hipSuccess;
 	hipLaunchKernelGGL(k_xform_level, dim3((n + 255u) / 256u), dim3(256), 0, s, w, first, n);
+	return hipGetLastError();
+}
+
+hipError_t launch_xform_collect_moved(hipStream_t s, const WorldDevice& w, const int32_t* entity_of_slot, uint32_t n, uint32_t cap, int32_t* out_entity,
+	void* out_transforms, uint32_t* count) {
+	if (!n) return hipSuccess;
+	hipLaunchKernelGGL(k_xform_collect_moved, dim3((n + 255u) / 256u), dim3(256), 0, s, w, entity_of_slot, n, cap, out_entity, (TransformAoS*)out_transforms, count);
 	return hipGetLastError();
 }
 

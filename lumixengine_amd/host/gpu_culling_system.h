@@ -10,12 +10,15 @@
 // empty result / ignored call (see lastError()).
 //
 // Threading: add/remove/set* arrive on the update thread; cull() may be called for several views per
-// frame from render jobs. Every call takes the adapter's mutex; each cull() uses its own result slot (LMX_MAX_VIEWS of
-// them), so calls serialise on the GPU stream but never alias results.
+// frame from render jobs. The C ABI context is not re-entrant, and it is SHARED with the plugin's module (one LmxContext per
+// World: the culling set, the transform hierarchy that refreshes its spheres and the skinning tables are one device-side
+// object, as the reference's CullingSystem and RenderModuleImpl::onModelInstanceMoved work on one object): every call takes
+// the context's own recursive lock (lmx_ctx_lock), not a lock of this adapter. Each cull() uses its own result slot
+// (LMX_MAX_VIEWS of them), so calls serialise on the GPU stream but never alias results; cullMany() culls all views of a
+// frame in one pass over the spheres with one host wait.
 #pragma once
 
 #include <cstdio>
-#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,14 +36,19 @@
 namespace Lumix {
 
 struct GpuCullingSystem final : CullingSystem {
+	// a context of its own (tests, tools, an engine without the plugin module)
 	GpuCullingSystem(PageAllocator& page_allocator, int device = 0) : m_page_allocator(page_allocator) {
-		if (lmx_ctx_create(device, &m_ctx) != LMX_OK) {
-			m_error = lmx_last_error(nullptr);
-			fprintf(stderr, "GpuCullingSystem: %s\n", m_error.c_str()); // the engine would logError(...)
-			m_ctx = nullptr;
-		}
+		if (lmx_ctx_create(device, &m_ctx) != LMX_OK) noContext();
 	}
-	~GpuCullingSystem() override { lmx_ctx_destroy(m_ctx); }
+	// THE drop-in form: the context of `world_key` (the address of the World the RenderModule belongs to), shared with every other
+	// adapter of that World - the Mi355Module that propagates its transforms finds the same culling set under the same key
+	GpuCullingSystem(PageAllocator& page_allocator, const void* world_key, int device = 0) : m_page_allocator(page_allocator), m_shared(true) {
+		if (lmx_ctx_acquire_shared(world_key, device, &m_ctx) != LMX_OK) noContext();
+	}
+	~GpuCullingSystem() override {
+		if (m_shared) lmx_ctx_release_shared(m_ctx);
+		else lmx_ctx_destroy(m_ctx);
+	}
 
 	bool isValid() const { return m_ctx != nullptr; }
 	const std::string& lastError() const { return m_error; }
@@ -49,43 +57,76 @@ struct GpuCullingSystem final : CullingSystem {
 	CullResult* cull(const ShiftedFrustum& frustum, u8 type) override { return cullInternal(frustum, type); } // culling_system.cpp:310-314
 	CullResult* cull(const ShiftedFrustum& frustum) override { return cullInternal(frustum, 0xff); }           // :316-319
 
-	// add / remove / set* arrive on the update thread while render jobs may be inside cull(): the C ABI context is not
-	// re-entrant, so every call takes the adapter's mutex (uncontended in the engine's frame structure)
+	// add / remove / set* arrive on the update thread while render jobs may be inside cull(): every call takes the context's lock
+	// (uncontended in the engine's frame structure)
 	bool isAdded(EntityRef entity) override {
-		std::lock_guard<std::mutex> guard(m_mutex);
+		CtxLock guard(m_ctx);
 		return m_ctx && lmx_cull_is_added(m_ctx, entity.index) != 0;
 	}
 	void add(EntityRef entity, u8 type, const DVec3& pos, float radius) override {
 		const double p[3] = {pos.x, pos.y, pos.z};
-		std::lock_guard<std::mutex> guard(m_mutex);
+		CtxLock guard(m_ctx);
 		check(lmx_cull_add(m_ctx, entity.index, type, p, radius));
 	}
 	void remove(EntityRef entity) override {
-		std::lock_guard<std::mutex> guard(m_mutex);
+		CtxLock guard(m_ctx);
 		check(lmx_cull_remove(m_ctx, entity.index));
 	}
 	void setPosition(EntityRef entity, const DVec3& pos) override {
 		const double p[3] = {pos.x, pos.y, pos.z};
-		std::lock_guard<std::mutex> guard(m_mutex);
+		CtxLock guard(m_ctx);
 		check(lmx_cull_set_position(m_ctx, entity.index, p));
 	}
 	void setRadius(EntityRef entity, float radius) override {
-		std::lock_guard<std::mutex> guard(m_mutex);
+		CtxLock guard(m_ctx);
 		check(lmx_cull_set_radius(m_ctx, entity.index, radius));
 	}
 	void set(EntityRef entity, const DVec3& pos, float radius) override {
 		const double p[3] = {pos.x, pos.y, pos.z};
-		std::lock_guard<std::mutex> guard(m_mutex);
+		CtxLock guard(m_ctx);
 		check(lmx_cull_set(m_ctx, entity.index, p, radius));
 	}
 	float getRadius(EntityRef entity) override {
 		float r = 0;
-		std::lock_guard<std::mutex> guard(m_mutex);
+		CtxLock guard(m_ctx);
 		check(lmx_cull_get_radius(m_ctx, entity.index, &r));
 		return r;
 	}
 
+	// All views of a frame in ONE pass over the spheres and ONE host wait (the reference culls its 4 shadow cascades, the main view
+	// and a light query one after the other, each a jobs::forEach over every cell: pipeline.cpp:1036-1045, :1252-1258). out[f] receives
+	// what cull(frusta[f], type) would return: a list of CullResult pages (nullptr when nothing is resident), freed by the caller.
+	bool cullMany(const ShiftedFrustum* frusta, u32 n_frusta, u8 type, CullResult** out) {
+		for (u32 f = 0; f < n_frusta; ++f) out[f] = nullptr;
+		if (!m_ctx || n_frusta == 0 || n_frusta > LMX_MAX_FRUSTA) return false;
+		CtxLock guard(m_ctx);
+		uint32_t n_static = 0, n_bound = 0, n_overflow = 0;
+		if (!check(lmx_cull_update_stats(m_ctx, &n_static, &n_bound, &n_overflow, nullptr))) return false;
+		if (n_static + n_bound + n_overflow == 0) return true; // no cells: culling_system.cpp:322
+		const uint32_t view = m_next_view++ % LMX_MAX_VIEWS;
+		if (!check(lmx_cull(m_ctx, view, reinterpret_cast<const LmxShiftedFrustum*>(frusta), n_frusta, type))) return false;
+		uint32_t counts[LMX_MAX_FRUSTA * LMX_MAX_TYPES];
+		const int32_t* ids[LMX_MAX_FRUSTA];
+		if (!check(lmx_cull_map_many(m_ctx, view, n_frusta, ids, counts))) return false;
+		for (u32 f = 0; f < n_frusta; ++f) out[f] = toPages(ids[f], counts + f * LMX_MAX_TYPES, type);
+		return true;
+	}
+
 private:
+	struct CtxLock { // the context's own recursive lock: shared with the other adapters of the World
+		explicit CtxLock(LmxContext* c) : ctx(c) { lmx_ctx_lock(ctx); }
+		~CtxLock() { lmx_ctx_unlock(ctx); }
+		CtxLock(const CtxLock&) = delete;
+		CtxLock& operator=(const CtxLock&) = delete;
+		LmxContext* ctx;
+	};
+
+	void noContext() {
+		m_error = lmx_last_error(nullptr);
+		fprintf(stderr, "GpuCullingSystem: %s\n", m_error.c_str()); // the engine would logError(...)
+		m_ctx = nullptr;
+	}
+
 	bool check(int rc) {
 		if (rc == LMX_OK) return true;
 		m_error = m_ctx ? lmx_last_error(m_ctx) : "no context";
@@ -99,19 +140,8 @@ private:
 		return page;
 	}
 
-	CullResult* cullInternal(const ShiftedFrustum& frustum, u8 type) {
-		if (!m_ctx) return nullptr;
-		std::lock_guard<std::mutex> guard(m_mutex);
-		uint32_t n_static = 0, n_bound = 0, n_overflow = 0;
-		if (!check(lmx_cull_update_stats(m_ctx, &n_static, &n_bound, &n_overflow, nullptr))) return nullptr;
-		if (n_static + n_bound + n_overflow == 0) return nullptr; // no cells: culling_system.cpp:322
-		const uint32_t view = m_next_view++ % LMX_MAX_VIEWS;
-		static_assert(sizeof(ShiftedFrustum) == sizeof(LmxShiftedFrustum), "layout");
-		if (!check(lmx_cull(m_ctx, view, reinterpret_cast<const LmxShiftedFrustum*>(&frustum), 1, type))) return nullptr;
-		// normally one host wait per cull: totals + ids arrive as one record in the library's pinned host memory, read in place
-		uint32_t counts[LMX_MAX_TYPES];
-		const int32_t* ids = nullptr;
-		if (!check(lmx_cull_map_all(m_ctx, view, 0, &ids, counts))) return nullptr;
+	// [ids of type 0 | type 1 | ...] + per-type counts -> linked 4 KiB CullResult pages of 1020 ids, one type per page
+	CullResult* toPages(const int32_t* ids, const uint32_t* counts, u8 type) {
 		CullResult* first = nullptr;
 		CullResult* last = nullptr;
 		constexpr uint32_t PAGE_IDS = sizeof(CullResult::entities) / sizeof(EntityRef);
@@ -132,9 +162,25 @@ private:
 		return first;
 	}
 
+	CullResult* cullInternal(const ShiftedFrustum& frustum, u8 type) {
+		if (!m_ctx) return nullptr;
+		CtxLock guard(m_ctx);
+		uint32_t n_static = 0, n_bound = 0, n_overflow = 0;
+		if (!check(lmx_cull_update_stats(m_ctx, &n_static, &n_bound, &n_overflow, nullptr))) return nullptr;
+		if (n_static + n_bound + n_overflow == 0) return nullptr; // no cells: culling_system.cpp:322
+		const uint32_t view = m_next_view++ % LMX_MAX_VIEWS;
+		static_assert(sizeof(ShiftedFrustum) == sizeof(LmxShiftedFrustum), "layout");
+		if (!check(lmx_cull(m_ctx, view, reinterpret_cast<const LmxShiftedFrustum*>(&frustum), 1, type))) return nullptr;
+		// normally one host wait per cull: totals + ids arrive as one record in the library's pinned host memory, read in place
+		uint32_t counts[LMX_MAX_TYPES];
+		const int32_t* ids = nullptr;
+		if (!check(lmx_cull_map_all(m_ctx, view, 0, &ids, counts))) return nullptr;
+		return toPages(ids, counts, type);
+	}
+
 	PageAllocator& m_page_allocator;
 	LmxContext* m_ctx = nullptr;
-	std::mutex m_mutex;
+	bool m_shared = false;
 	uint32_t m_next_view = 0;
 	std::string m_error;
 };

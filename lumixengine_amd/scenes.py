@@ -36,6 +36,25 @@ def cull_scene(n: int, half_extent: float, seed: int = 1, big_fraction: float = 
     return {"entity": entity, "type": type_, "pos": np.ascontiguousarray(pos), "radius": radius}
 
 
+def all_test_radii(n: int) -> np.ndarray:
+    """Radii of the roofline leg's scene: every sphere in (300, 330], so every cell is a "big" cell (culling_system.cpp:140,342-344),
+    every cell is CELL_TEST and every sphere is fetched and tested (bench.py `all_test`, tests/golden/cull_bench_scenes.json)."""
+    return np.random.default_rng(5).uniform(300.5, 330.0, size=n).astype(np.float32)
+
+
+def scaled_half_extent(n: int) -> float:
+    """Half extent of the cube that keeps BASELINE config 2's density (10 M in +-15000: ~10 spheres per 300-unit cell) at n entities."""
+    return 15000.0 * (n / 1e7) ** (1.0 / 3.0)
+
+
+def config5_cascade_kwargs(n: int = 8):
+    """viewport_frustum(**kw) arguments of the 8 ortho shadow-cascade frusta (2 light directions x 4 cascades, growing extents; the
+    reference builds its cascades from split distances {0.1, 3, 10, 60, 150}, pipeline.cpp:734-827) that bench.py's config-5 legs and
+    the 100 M parity test cull in one call. One definition for the bench, the tests and the golden generator."""
+    return [dict(is_ortho=True, ortho_size=[30.0, 90.0, 400.0, 1500.0][k % 4] * 4.0, w=1024, h=1024, near=0.0, far=20000.0,
+                 pos=(5.0 * k, 9000.0, -3.0 * k), rot=(-0.6, 0.25 * (k // 4), 0.0, 0.76)) for k in range(n)]
+
+
 def random_unit_quats(rng, n: int) -> np.ndarray:
     q = rng.normal(size=(n, 4))
     q /= np.linalg.norm(q, axis=1, keepdims=True)

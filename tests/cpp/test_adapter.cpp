@@ -3,6 +3,7 @@
 // Reads a scene written by tests/test_gpu_adapter.py, writes the visible (type, id) pairs back for comparison with
 // the CPU oracle. Needs an MI355X.
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -57,6 +58,25 @@ int main(int argc, char** argv) {
 			}
 		}
 		if (res) res->free(pages);
+	}
+	// the frame's views in one pass over the spheres and one host wait: the same ids as one cull per view
+	{
+		const uint32_t nf = n_frusta < LMX_MAX_FRUSTA ? n_frusta : (uint32_t)LMX_MAX_FRUSTA;
+		CullResult* many[LMX_MAX_FRUSTA];
+		if (!gpu.cullMany(frusta.data(), nf, 0xff, many)) return 7;
+		for (uint32_t f = 0; f < nf; ++f) {
+			CullResult* one = cs.cull(frusta[f]);
+			std::vector<int64_t> a, b;
+			for (const CullResult* p = many[f]; p; p = p->header.next)
+				for (uint32_t i = 0; i < p->header.count; ++i) a.push_back(((int64_t)p->header.type << 32) | (uint32_t)p->entities[i].index);
+			for (const CullResult* p = one; p; p = p->header.next)
+				for (uint32_t i = 0; i < p->header.count; ++i) b.push_back(((int64_t)p->header.type << 32) | (uint32_t)p->entities[i].index);
+			std::sort(a.begin(), a.end());
+			std::sort(b.begin(), b.end());
+			if (many[f]) many[f]->free(pages);
+			if (one) one->free(pages);
+			if (a != b) { fprintf(stderr, "cullMany view %u: %zu ids vs %zu\n", f, a.size(), b.size()); return 8; }
+		}
 	}
 	fclose(out);
 	fclose(in);

@@ -217,6 +217,13 @@ def visible_digest(ids: np.ndarray, types: np.ndarray):
     return counts, h.hexdigest()
 
 
+def ids_digest(ids: np.ndarray) -> str:
+    """sha256 of the sorted visible ids regardless of renderable type (what bench.py asserts for the scenes it times)."""
+    import hashlib
+
+    return hashlib.sha256(np.sort(np.asarray(ids, np.int32)).tobytes()).hexdigest()
+
+
 def array_digest(*arrays):
     import hashlib
 

@@ -249,6 +249,65 @@ def test_cull_config2_10m_bit_exact(gpu_ctx, scene):
     check(cs.cull(fr), rec["churn"]["19"], "after compaction")
 
 
+def _bench_scene(name):
+    """(record, scene arrays) of one of the scenes bench.py times, regenerated from its seed and checked against the digest of the
+    arrays the reference culled (tests/golden/make_golden_bench_scenes.py)."""
+    rec = json.load(open(os.path.join(G, "cull_bench_scenes.json")))["scenes"][name]
+    sc = scenes.cull_scene(rec["n"], scenes.scaled_half_extent(rec["n"]), seed=rec["seed"], mixed_types=rec["mixed"])
+    if rec["all_test_radii"]:
+        sc["radius"] = scenes.all_test_radii(rec["n"])
+    assert H.array_digest(sc["entity"], sc["type"], sc["pos"], sc["radius"]) == rec["scene_sha"], "the scene generator's random stream differs from the one the digests were made with"
+    return rec, sc
+
+
+def _check_digest(res, want, what, frustum=0):
+    counts, sha = _digest(res, frustum)
+    assert counts == want["counts"], f"{what}: visible counts {counts} vs reference {want['counts']}"
+    assert sha == want["sha256"], f"{what}: same counts, different ids"
+
+
+@pytest.mark.parametrize("name", ["sparse_10m", "all_test_10m"])
+def test_cull_bench_scenes_10m_digest(gpu_ctx, name):
+    """The EXACT 10 M scenes bench.py times - its headline scene (sparse, one renderable type, seed 2) and its roofline leg
+    (the same positions, every sphere "big": every sphere fetched and tested) - against the reference's own CullingSystemImpl
+    (digests in tests/golden/cull_bench_scenes.json): the ids, not just the counts bench.py used to print."""
+    rec, sc = _bench_scene(name)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    cams = dict(H.config2_cameras(api))
+    for cam, want in rec["cameras"].items():
+        _check_digest(cs.cull(cams[cam]), want, f"{name} {cam}")
+    # what bench.py itself asserts: the digest regardless of type
+    ids, _ = cs.cull(cams["default"]).all_ids(0)
+    assert H.ids_digest(ids) == rec["cameras"]["default"]["all_types_sha256"]
+
+
+@pytest.mark.parametrize("name", ["config5_100m", "all_test_100m"])
+def test_cull_config5_100m_digest(gpu_ctx, name):
+    """BASELINE config 5's size on one GPU: 100 M entities (2 GB of spheres + ids), mixed renderable types 90 / 5 / 5. The default
+    camera and the 8 shadow-cascade frusta of one frame - as one lmx_cull call in passes of width 1, 4 and 8 (one pass over the
+    spheres tests all 8 frusta, culling_system.cpp:321-369 run 8 times in the reference) - against digests the reference's own
+    CullingSystemImpl produced for the same seeded scene, culled there in 16 shards of whole cells (an entity's visibility depends
+    only on its own cell; tests/golden/make_golden_bench_scenes.py says why and how). all_test_100m: the HBM-cold-by-size roofline
+    extra of bench.py (every sphere fetched and tested)."""
+    rec, sc = _bench_scene(name)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    del sc
+    _check_digest(cs.cull(api.viewport_frustum()), rec["cameras"]["default"], f"{name} default")
+    if "cascade0" not in rec["cameras"]:
+        return
+    fr8 = np.concatenate([api.viewport_frustum(**kw) for kw in scenes.config5_cascade_kwargs()])
+    try:
+        for width in (1, 4, 8):
+            cs.setPassWidth(width)
+            res = cs.cull(fr8, view=1)
+            for k in range(8):
+                _check_digest(res, rec["cameras"][f"cascade{k}"], f"{name} cascade {k}, pass width {width}", frustum=k)
+    finally:
+        cs.setPassWidth(1)
+
+
 def test_cull_10m_properties(gpu_ctx):
     """BASELINE config 2 size (10 M): size-independent properties next to the digest comparison above.
 

@@ -259,6 +259,64 @@ def test_rebinding_keeps_moved_spheres(gpu_ctx, oracle_port):
         assert cs.getRadius(e) == ocs.get_radius(e)
 
 
+def test_world_moved_list_is_what_the_dfs_visits(gpu_ctx, oracle_port):
+    """lmx_world_track_moved / lmx_world_read_moved: the per-frame hand-back lists exactly the entities World::transformEntity visits
+    (world.cpp:255-282: the written entity and its whole subtree) with their new world transforms, nothing else; two propagations
+    between reads accumulate; the list is empty when nothing was written."""
+    h = scenes.hierarchy_fans(40, 4, 4, seed=13)
+    n = len(h["parent"])
+    ow, roots, kids = oracle_world(oracle_port, h)
+    w = api.World(gpu_ctx)
+    w.trackMoved(True)
+    try:
+        w.buildWithWorld(h["parent"], gpu_inputs(ow, h["parent"], roots), ow.get_transforms())
+        w.propagate()
+        ent, _ = w.readMoved()
+        assert len(ent) == 0, "a mirrored World moves nothing until something is written"
+        rng = np.random.default_rng(3)
+        children = [[] for _ in range(n)]
+        for c in kids:
+            children[h["parent"][c]].append(int(c))
+
+        def subtree(e):
+            out, stack = [], [int(e)]
+            while stack:
+                x = stack.pop()
+                out.append(x)
+                stack += children[x]
+            return out
+
+        picked = rng.choice(roots, 5, replace=False).astype(np.int32)
+        new_root = scenes.random_transforms(rng, len(picked), 3000.0)
+        kid = np.array([kids[7], kids[300]], np.int32)  # two children in other subtrees
+        kid = kid[[int(k) not in sum((subtree(r) for r in picked), []) for k in kid]]
+        new_kid = scenes.random_transforms(rng, len(kid), 5.0)
+        ow.set_transforms(picked, new_root)
+        ow.set_local_transforms(kid, new_kid)
+        w.setTransforms(picked, new_root)
+        w.setTransforms(kid, new_kid)
+        w.propagate()
+        ent, tr = w.readMoved()
+        want = sorted(sum((subtree(e) for e in list(picked) + list(kid)), []))
+        assert sorted(ent.tolist()) == want
+        assert H.transforms_bits_equal(tr, ow.get_transforms()[ent])
+        # two propagations before one read: both frames' movers are listed, later entries are newer
+        second = scenes.random_transforms(rng, 1, 3000.0)
+        for frame_tr in (new_root[:1], second):
+            ow.set_transforms(picked[:1], frame_tr)
+            w.setTransforms(picked[:1], frame_tr)
+            w.propagate()
+        ent, tr = w.readMoved()
+        sub = sorted(subtree(picked[0]))
+        assert sorted(ent.tolist()) == sorted(sub + sub)
+        last = {int(e): i for i, e in enumerate(ent)}
+        idx = np.array([last[e] for e in sub])
+        assert H.transforms_bits_equal(tr[idx], ow.get_transforms()[np.array(sub)])
+        assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms())
+    finally:
+        w.trackMoved(False)
+
+
 def close_1e5(got, want):
     """north star: skinned vertex positions within 1e-5 relative fp32 - PER VERTEX: every component within 1e-5 of that vertex's own
     magnitude (max |component|), floored at 1 % of the mesh's extent (a vertex that lands next to the origin is still the sum of
@@ -448,6 +506,45 @@ def test_skin_dual_quaternion_blend(gpu_ctx, oracle_port):
     sk.setMode(api.SKIN_FUSED)
 
 
+def test_skin_dqs_bounded_by_exact_evaluation(gpu_ctx, oracle_port):
+    """f3: LMX_SKIN_DQS held to an extended-precision evaluation of the shader's own expressions (surface_base.hlsli:196-217,
+    common.hlsli:632-636; tests/dq_exact.py states the bound and why HLSL admits no bit-exact target), on the adversarial case -
+    antipodal quaternions, hemisphere tests decided by rounding (both signs admissible), real parts with w ~ 0, nearly cancelling
+    blends - and on an ordinary skeleton. tests/test_dq_blend_bound.py holds the plain-C restatement to the same bound, so
+    HIP == restatement within 1e-5 (test_skin_dual_quaternion_blend) is no longer the only anchor of this path."""
+    from tests import dq_exact as DQ
+
+    pos, rot, verts, skin = DQ.adversarial_case()
+    nb = len(pos)
+    ident = np.zeros(nb, api.LOCAL_RIGID)
+    ident["rot"][:, 3] = 1.0
+    sk = api.Skinning(gpu_ctx)
+    # every bone a root with an identity bind pose: the absolute pose IS the uploaded pose, the palette its dual quaternion
+    flat = sk.addModel(np.full(nb, -1, np.int16), ident, nb)
+    s = scenes.skeleton(64, seed=4)
+    tree = sk.addModel(s["parents"], s["bind"], s["first_nonroot"])
+    rverts, rskin = scenes.skinned_mesh(5000, 64, seed=6)
+    m_adv, m_rnd = sk.addMesh(verts, skin), sk.addMesh(rverts, rskin)
+    sk.setInstances([flat, tree], [m_adv, m_rnd])
+    rpos, rrot = scenes.relative_poses(1, 64, seed=706)
+    sk.uploadPoses(np.concatenate([pos, rpos[0]]), np.concatenate([rot, rrot[0]]))
+    sk.setMode(api.SKIN_DQS)
+    try:
+        sk.run()
+        dq_adv = oracle_port.dual_quats(pos[None], rot[None], ident)[0]
+        apos, arot = oracle_port.pose_compute_absolute(rpos, rrot, s["parents"], s["first_nonroot"])
+        dq_rnd = oracle_port.dual_quats(apos, arot, oracle_port.invert_bind(s["bind"]))[0]
+        for i, (v, sn, dq, what) in enumerate(((verts, skin, dq_adv, "adversarial"), (rverts, rskin, dq_rnd, "random"))):
+            assert H.bits_equal(sk.readDualQuats(i), dq), what  # the palette itself is pinned bit for bit (a18)
+            got = sk.readVertices(i)
+            cands, bounds = DQ.dq_skin_candidates(v, sn, dq)
+            ok = DQ.within_bound(got, cands, bounds)
+            assert ok.all(), f"{what}: {int((~ok).sum())} vertices outside the bound, worst ratio {DQ.worst_ratio(got, cands, bounds):.2f}, first {np.flatnonzero(~ok)[:8]}"
+        assert DQ.worst_ratio(sk.readVertices(1), *DQ.dq_skin_candidates(rverts, rskin, dq_rnd)) < 0.5  # well inside on ordinary inputs
+    finally:
+        sk.setMode(api.SKIN_FUSED)
+
+
 @pytest.mark.parametrize("exact", [True, False])
 def test_skin_shared_mesh_runs(gpu_ctx, live_oracle, exact):
     """Runs of instances that share a mesh take the register-resident path (k_skin_shared: ragged tiles, 2 tiles per mesh,
@@ -542,6 +639,51 @@ def test_skin_config3_slice_properties(gpu_ctx, oracle_port):
     sk2.run()
     wsum = skin["weights"].sum(axis=1, dtype=np.float32)[:, None]
     assert np.allclose(sk2.readVertices(0), verts * wsum, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("config", ["config3_10k", "config4_100k"])
+def test_skin_full_size_digest(gpu_ctx, oracle_port, config):
+    """BASELINE config 3 / 4 at their FULL instance counts (10 k / 100 k instances of one 10 k-vertex mesh, 64 bones: 10^8 / 10^9
+    vertices). LMX_SKIN_EXACT: sha256 of every skinned position, read back in blocks of 1000 instances, against the digests the
+    reference's own pose / palette / evaluateSkin code (model.cpp:103-137, pose.cpp:63-134) produced for the same seeded inputs
+    (tests/golden/make_golden_skin_full.py). LMX_SKIN_FUSED: a strided sample that touches every block of instances, <= 1e-5
+    relative against the live oracle (the north star's tolerance for skinned positions)."""
+    import hashlib
+    import json
+
+    g = json.load(open(os.path.join(G, "skin_full.json")))
+    rec, n_verts, block = g["configs"][config], g["n_verts"], g["block"]
+    n_inst = rec["instances"]
+    s = scenes.skeleton(g["n_bones"], seed=4)
+    verts, skin = scenes.skinned_mesh(n_verts, g["n_bones"], seed=6)
+    pos, rot = scenes.relative_poses(n_inst, g["n_bones"], seed=5)
+    assert H.array_digest(s["parents"], s["bind"], verts, skin, pos, rot) == rec["inputs_sha"], "the generators' random streams differ from the ones the digests were made with"
+    sk = api.Skinning(gpu_ctx)
+    model = sk.addModel(s["parents"], s["bind"], s["first_nonroot"])
+    mesh = sk.addMesh(verts, skin)
+    sk.setInstances(np.full(n_inst, model, np.uint32), np.full(n_inst, mesh, np.uint32))
+    sk.setPoseWriteback(False)  # uploaded relative poses stay valid for the second run
+    try:
+        sk.setMode(True)
+        sk.uploadPoses(pos, rot)
+        sk.run()
+        whole = hashlib.sha256()
+        for k, b in enumerate(range(0, n_inst, block)):
+            raw = sk.readVerticesRange(b, min(block, n_inst - b)).tobytes()
+            assert hashlib.sha256(raw).hexdigest()[:16] == rec["block_sha16"][k], f"{config}: instances [{b}, {b + block}) differ from the reference"
+            whole.update(raw)
+        assert whole.hexdigest() == rec["sha256"]
+        sk.setMode(False)
+        sk.run()
+        inv = oracle_port.invert_bind(s["bind"])
+        stride = 97 if n_inst <= 10_000 else 997
+        for i in list(range(0, n_inst, stride)) + [n_inst - 1]:
+            apos, arot = oracle_port.pose_compute_absolute(pos[i : i + 1], rot[i : i + 1], s["parents"], s["first_nonroot"])
+            want = oracle_port.evaluate_skin(verts, skin, oracle_port.skin_matrices(apos, arot, inv))[0]
+            assert close_1e5(sk.readVertices(i), want), f"{config}: FUSED instance {i}"
+    finally:
+        sk.setPoseWriteback(True)
+        sk.setMode(api.SKIN_FUSED)
 
 
 @pytest.mark.parametrize("fixture", ["cull_edge.npz", "cull_mixed.npz"])
