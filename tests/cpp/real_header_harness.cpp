@@ -313,19 +313,31 @@ int testModule(bool two_contexts, IAllocator& heap, PageAllocator& pages) {
 		// semantics "the frame's writes applied in hierarchy order, the last write of an entity wins": the reference side applies them so.
 		// Frames 0..3 write entities of ONE depth (disjoint subtrees: the delegate counts must then agree exactly); frames 4, 5 mix depths
 		// and add direct World writes by engine code that does not know the module.
-		std::vector<Write> writes;
+		std::vector<Write> writes, direct;
 		std::vector<i32> at(n, -1);
+		std::vector<bool> is_direct(n, false);
+		if (frame >= 4) {
+			for (int k = 0; k < 40; ++k) {
+				const u32 e = rng.below(n_roots) & ~1u; // roots with a model instance
+				if (is_direct[e]) continue;
+				is_direct[e] = true;
+				direct.push_back(Write{e, true, randomTransform(rng, 2500.0)});
+			}
+		}
 		for (int k = 0; k < 700; ++k) {
 			u32 e = rng.below(n);
 			if (frame < 4) {
 				for (int tries = 0; depth[e] != frame % 4 && tries < 64; ++tries) e = rng.below(n);
 				if (depth[e] != frame % 4) continue;
 			}
+			if (is_direct[e]) continue; // written directly this frame
 			Write w{e, parent[e] < 0 || rng.below(3) == 0, randomTransform(rng, parent[e] < 0 ? 2500.0 : 25.0)};
 			if (at[e] >= 0) writes[at[e]] = w;
 			else { at[e] = (i32)writes.size(); writes.push_back(w); }
 		}
 		std::stable_sort(writes.begin(), writes.end(), [&](const Write& a, const Write& b) { return depth[a.e] < depth[b.e]; });
+		// reference: ALL of the frame's writes in hierarchy order - the direct ones are roots, so they come first
+		for (const Write& w : direct) ref_world.setTransform(EntityRef{(i32)w.e}, w.t);
 		for (const Write& w : writes) {
 			if (w.world_space) {
 				module->setTransform(EntityRef{(i32)w.e}, w.t);
@@ -336,16 +348,9 @@ int testModule(bool two_contexts, IAllocator& heap, PageAllocator& pages) {
 			}
 			++staged;
 		}
-		if (frame >= 4) {
-			for (int k = 0; k < 40; ++k) {
-				const u32 e = rng.below(n_roots) & ~1u; // roots with a model instance
-				if (at[e] >= 0) continue;              // (not also written through the module this frame)
-				at[e] = 0;
-				const Transform t = randomTransform(rng, 2500.0);
-				world.setTransform(EntityRef{(i32)e}, t);
-				ref_world.setTransform(EntityRef{(i32)e}, t);
-			}
-		}
+		// engine code that does not know the module writes the World directly, at any point of the frame (here: after the module's
+		// writes were staged): the World runs its own DFS now, the mirror takes the written roots at the next propagation
+		for (const Write& w : direct) world.setTransform(EntityRef{(i32)w.e}, w.t);
 		module->update(0.016f);
 		char what[64];
 		snprintf(what, sizeof(what), "frame %d", frame);

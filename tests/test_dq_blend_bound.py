@@ -17,7 +17,7 @@ def _identity_inv(n):
 
 
 def _palette(oracle, pos, rot):
-    return oracle.dual_quats(pos[None], rot[None], _identity_inv(len(pos)))[0]
+    return oracle.dual_quats(pos[None], rot[None], oracle.invert_bind(_identity_inv(len(pos))))[0]
 
 
 def test_oracle_dq_blend_within_bound_adversarial(oracle_port):

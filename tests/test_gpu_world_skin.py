@@ -531,7 +531,7 @@ def test_skin_dqs_bounded_by_exact_evaluation(gpu_ctx, oracle_port):
     sk.setMode(api.SKIN_DQS)
     try:
         sk.run()
-        dq_adv = oracle_port.dual_quats(pos[None], rot[None], ident)[0]
+        dq_adv = oracle_port.dual_quats(pos[None], rot[None], oracle_port.invert_bind(ident))[0]  # (the reference's conj negates w: -q, the same rotation)
         apos, arot = oracle_port.pose_compute_absolute(rpos, rrot, s["parents"], s["first_nonroot"])
         dq_rnd = oracle_port.dual_quats(apos, arot, oracle_port.invert_bind(s["bind"]))[0]
         for i, (v, sn, dq, what) in enumerate(((verts, skin, dq_adv, "adversarial"), (rverts, rskin, dq_rnd, "random"))):

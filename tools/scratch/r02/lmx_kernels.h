@@ -139,9 +139,7 @@ struct SkinInstance {
 	uint32_t lv_off_offset;   // into level_off: max_depth + 1 offsets (bones of depth d = [off[d-1], off[d]))
 };
 // k_skin_shared work item: instances [first_inst, first_inst + count) share mesh and bone count; vertices [v_begin, v_end) of it
-// (the tile's records live in the mesh table with TILE-LOCAL bone indices: rec_offset = the mesh's first record there, in vertices;
-// tile_bones[bones_at .. + n_tile_bones) = the model bones the tile references, in local-index order)
-struct SkinChunk { uint32_t first_inst, count, v_begin, v_end, rec_offset, bones_at, n_tile_bones, pad; };
+struct SkinChunk { uint32_t first_inst, count, v_begin, v_end; };
 struct PoseGroup { uint32_t first_inst; uint32_t count; }; // consecutive instances of one model, count <= 16 / 8 / 4 by bone count
 // ---- bone attachments (xform_kernels.hip) ----
 struct BoneAttachDevice { uint32_t slot, parent_slot, skin_instance, bone; float rel_pos[3]; float rel_rot[4]; };
@@ -246,8 +244,8 @@ hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, const u
 	uint32_t max_verts, const float4* mesh /* 2 x float4 per vertex: weights | (position, 4 x u8 bone indices) */,
 	const float4* palette /* 3 rows per bone, or the dual quaternions in LMX_SKIN_DQS */, float* out, int mode);
 // the same for runs of consecutive instances that share a mesh and a bone count (vertex records held in registers)
-hipError_t launch_skin_shared(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh_local,
-	const uint8_t* tile_bones, const float4* palette, float* out, int mode);
+hipError_t launch_skin_shared(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh,
+	const float4* palette /* 3 rows per bone, or the dual quaternions in LMX_SKIN_DQS */, float* out, int mode);
 constexpr uint32_t SKIN_SHARED_TILE_VERTS = 5120; // k_skin_shared: 1024 lanes x 5 vertex records
 
 } // namespace lmx

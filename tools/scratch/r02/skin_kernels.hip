@@ -406,210 +406,87 @@ __global__ __launch_bounds__(SKIN_THREADS, SKIN_WAVES_PER_SIMD) void k_skin_vert
 	else skin_tile<4, MODE>(in, v_begin, v_end, s_rows, mesh, palette, out);
 }
 
-// ---- shared-mesh runs: vertex records in registers, palettes double-buffered in LDS, staged by LDS-DMA ----------------------
+// ---- shared-mesh runs: vertex records in registers, palettes double-buffered in LDS -------------------------------------
 constexpr int SHARED_THREADS = 1024; // 16 waves = 4 per SIMD at <= 128 VGPRs; one block per CU (2 x 48 KiB LDS)
-constexpr int SHARED_WAVES = SHARED_THREADS / 64;
-constexpr int SHARED_VPT = 5;        // vertex records per lane (8 VGPRs each) -> tiles of up to 5120 vertices
-// experiment knobs (tools/skin_probe.hip builds the variants; the defaults are what measured best)
-#ifndef LMX_SHARED_NT
-#define LMX_SHARED_NT 1    // non-temporal output stores (the 12 GB of positions are never read back by this kernel)
+constexpr int SHARED_VPT = 5;        // vertex records per lane (9 VGPRs each) -> tiles of up to 5120 vertices
+#ifndef LMX_SHARED_SPREAD_AFTER
+#define LMX_SHARED_SPREAD_AFTER 3
 #endif
-#ifndef LMX_SHARED_ST16
-#define LMX_SHARED_ST16 0  // 1: four lanes' 12-byte results transposed (DPP) into three 16-byte stores
-#endif
-#ifndef LMX_SHARED_ZSKIP
-#define LMX_SHARED_ZSKIP 1 // LMX_SKIN_FUSED: bone slots whose weight is zero for a whole wave are not read from LDS
-#endif
+constexpr int SHARED_SPREAD_AFTER = LMX_SHARED_SPREAD_AFTER; // the next palette is spread into LDS after this vertex of the lane's five
 
 static_assert(SHARED_THREADS * SHARED_VPT == SKIN_SHARED_TILE_VERTS, "host tiling and kernel disagree");
 
-// One palette staging instruction: 64 lanes x 16 bytes from per-lane global addresses (wave-uniform base + 32-bit lane offset)
-// straight into 1 KiB of LDS at a wave-uniform address (LDS-DMA: no VGPR round trip, no ds_write - the 48 KiB of replicated rows
-// per instance cost 13 cycles per ds_write_b128 wave-instruction on the VGPR -> LDS path, MI355X_MICROARCH.md "LDS"). The
-// replication happens on the SOURCE side: the COPIES lanes of a row fetch the same 16 bytes (one request), the destination is
-// linear. Inline asm because (a) M0 carries the LDS address and is compiler-reserved, (b) the compiler must NOT count this
-// operation: it would drain vmcnt to 0 at the next barrier (cdna_hip_programming.md, "Pipelining across barriers"), i.e. every
-// store of the wave once per instance; the kernel waits for it itself with an exact count.
-__device__ __forceinline__ void lds_dma_16(uint32_t lane_byte_offset, const void* uniform_base, uint32_t lds_byte_address) {
-	uint32_t keep;
-	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-				 : "=&s"(keep)
-				 : "v"(lane_byte_offset), "s"(uniform_base), "s"(lds_byte_address)
-				 : "memory");
-}
-
-typedef float v3f_a4 __attribute__((ext_vector_type(3), aligned(4)));
-typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
-
-// one vertex's result to out[v] (12 bytes, lanes contiguous: 768 bytes per wave-instruction)
-__device__ __forceinline__ void store_position(F3* dst, const F3& r) {
-#if LMX_SHARED_NT
-	v3f_a4 t = {r.x, r.y, r.z};
-	__builtin_nontemporal_store(t, reinterpret_cast<v3f_a4*>(dst));
-#else
-	*dst = r;
-#endif
-}
-
-// The same 768 bytes as three 16-byte stores per four lanes: lane p of a quad stores words [4p, 4p + 4) of the quad's twelve
-// floats (x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3), lane 3 stores nothing. Three quad-permute DPP moves + selects.
-// `wave_dst` = &out[first vertex of the wave]; only for waves whose 64 vertices are consecutive (not clamped at the tile's end).
-__device__ __forceinline__ void store_position_quad16(F3* wave_dst, const F3& r, uint32_t lane) {
-	const uint32_t p = lane & 3u;
-	const int xi = __float_as_int(r.x), yi = __float_as_int(r.y), zi = __float_as_int(r.z);
-	// quad_perm [a, b, c, d] = a | b << 2 | c << 4 | d << 6: lane k of a quad reads lane perm[k]
-	const int xs = __builtin_amdgcn_mov_dpp(xi, 1 | 2 << 2 | 3 << 4 | 3 << 6, 0xf, 0xf, true); // lane0 <- x1, lane1 <- x2, lane2 <- x3
-	const int ys = __builtin_amdgcn_mov_dpp(yi, 0 | 2 << 2 | 3 << 4 | 3 << 6, 0xf, 0xf, true); // lane1 <- y2, lane2 <- y3
-	const int zs = __builtin_amdgcn_mov_dpp(zi, 0 | 1 << 2 | 3 << 4 | 3 << 6, 0xf, 0xf, true); // lane2 <- z3
-	const int w0 = p == 0 ? xi : (p == 1 ? yi : zi);
-	const int w1 = p == 0 ? yi : (p == 1 ? zi : xs);
-	const int w2 = p == 0 ? zi : (p == 1 ? xs : ys);
-	const int w3 = p == 0 ? xs : (p == 1 ? ys : zs);
-	if (p != 3u) {
-		v4f_a4 t = {__int_as_float(w0), __int_as_float(w1), __int_as_float(w2), __int_as_float(w3)};
-		v4f_a4* dst = reinterpret_cast<v4f_a4*>(reinterpret_cast<float*>(wave_dst) + (lane >> 2) * 12u + p * 4u);
-#if LMX_SHARED_NT
-		__builtin_nontemporal_store(t, dst);
-#else
-		*dst = t;
-#endif
-	}
-}
-
-// evaluateSkin with wave-uniform skipping of bone slots (LMX_SKIN_FUSED): `skip` bit k set = slot k's weight is zero in every
-// lane of the wave, its three rows are neither read from LDS nor multiplied (0 * row added exactly nothing)
-template <int COPIES>
-__device__ __forceinline__ F3 skin_blend_fused_skip(const float4* rows, const RawVertex& rv, uint32_t skip) {
-	constexpr uint32_t STRIDE = 3 * COPIES;
-	const uint32_t idx = __float_as_uint(rv.b.w);
-	const float4* r0 = rows + (idx & 0xffu) * STRIDE;
-	const float4* r1 = rows + ((idx >> 8) & 0xffu) * STRIDE;
-	const float4* r2 = rows + ((idx >> 16) & 0xffu) * STRIDE;
-	const float4* r3 = rows + (idx >> 24) * STRIDE;
-	const v2f w01 = {rv.a.x, rv.a.y}, w23 = {rv.a.z, rv.a.w};
-	const v2f wx = __builtin_shufflevector(w01, w01, 0, 0), wy = __builtin_shufflevector(w01, w01, 1, 1);
-	const v2f wz = __builtin_shufflevector(w23, w23, 0, 0), ww = __builtin_shufflevector(w23, w23, 1, 1);
-	float o[3];
-#pragma unroll
-	for (int r = 0; r < 3; ++r) {
-		const float4 A = r0[r * COPIES];
-		v2f m01 = v2f{A.x, A.y} * wx, m23 = v2f{A.z, A.w} * wx;
-		if (!(skip & 1u)) {
-			const float4 B = r1[r * COPIES];
-			m01 = __builtin_elementwise_fma(v2f{B.x, B.y}, wy, m01);
-			m23 = __builtin_elementwise_fma(v2f{B.z, B.w}, wy, m23);
-		}
-		if (!(skip & 2u)) {
-			const float4 C = r2[r * COPIES];
-			m01 = __builtin_elementwise_fma(v2f{C.x, C.y}, wz, m01);
-			m23 = __builtin_elementwise_fma(v2f{C.z, C.w}, wz, m23);
-		}
-		if (!(skip & 4u)) {
-			const float4 D = r3[r * COPIES];
-			m01 = __builtin_elementwise_fma(v2f{D.x, D.y}, ww, m01);
-			m23 = __builtin_elementwise_fma(v2f{D.z, D.w}, ww, m23);
-		}
-		o[r] = fmaf(m23.x, rv.b.z, fmaf(m01.y, rv.b.y, m01.x * rv.b.x)) + m23.y;
-	}
-	return F3{o[0], o[1], o[2]};
-}
-
-// A chunk = one tile of <= 5120 vertices of a mesh x a run of consecutive instances that share the mesh. The tile's vertex records
-// carry TILE-LOCAL bone indices: only the palette rows of the bones the tile references (SkinChunk::n_tile_bones of them, listed in
-// tile_bones) are staged, in the order of that list. On the reference's demo character a tile touches 13-16 of 52 bones
-// (tools/fbx_skin_stats.cpp); the synthetic worst-case mesh (4 random bones of 64 per vertex) touches all of them.
 template <int COPIES, int MODE>
 __device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const SkinChunk& ch, float4 (*s_rows)[SKIN_LDS_SLOTS],
-	const float4* __restrict__ mesh_local, const uint8_t* __restrict__ tile_bones, const float4* __restrict__ palette, float* __restrict__ out) {
-	constexpr uint32_t RPI = 64 / COPIES;               // palette rows one staging instruction covers
-	constexpr uint32_t MAX_DMA = (SKIN_LDS_SLOTS / 64 + SHARED_WAVES - 1) / SHARED_WAVES; // staging instructions per wave: 3
+	const float4* __restrict__ mesh, const float4* __restrict__ palette, float* __restrict__ out) {
 	const uint32_t tid = threadIdx.x;
-	const uint32_t lane = tid & 63u;
-	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const uint32_t col = tid & (COPIES - 1);
-	const float4* mbase = mesh_local + 2 * (size_t)ch.rec_offset;
-	// the lane's vertex records: loaded once, used for every instance of the chunk, kept as loaded (8 VGPRs each). Lanes past the
-	// tile's end take its LAST vertex (they recompute and rewrite the same 12 bytes): every store below is unconditional.
+	const float4* mbase = mesh + 2 * (size_t)in0.vert_offset;
+	// the lane's vertex records: loaded once, used for every instance of the chunk, kept as loaded (8 VGPRs each: weights | position,
+	// 4 x u8 bone indices). The LDS addresses of a vertex's four bones are rebuilt from the index bytes for every instance
+	// (8 VALU instructions) - cheaper than the 5 VGPRs that keeping them as byte offsets cost: the kernel sits at the 128-VGPR limit.
+	// Lanes past the tile's end take its LAST vertex (they recompute and rewrite the same 12 bytes): every load and store below is
+	// unconditional, which is what lets the compiler COUNT them - see the s_waitcnt note at the instance loop.
 	const uint32_t v_last = ch.v_end - 1; // chunks are never empty
 	RawVertex vin[SHARED_VPT];
 #pragma unroll
 	for (int k = 0; k < SHARED_VPT; ++k) vin[k] = load_vertex(mbase, min(ch.v_begin + tid + k * SHARED_THREADS, v_last));
-	// staging plan of this lane, the same for every instance: row r of the tile-local palette = row (r % 3) of bone tile_bones[r / 3]
-	const uint32_t n_rows = ch.n_tile_bones * 3u;
-	const uint32_t n_dma = (n_rows + RPI - 1) / RPI;    // wave w issues instructions w, w + 16, w + 32 (< n_dma)
-	uint32_t src_off[MAX_DMA];
-#pragma unroll
-	for (uint32_t k = 0; k < MAX_DMA; ++k) {
-		const uint32_t r = min((wave + k * SHARED_WAVES) * RPI + lane / COPIES, n_rows - 1);
-		const uint32_t lb = r / 3u;
-		src_off[k] = ((uint32_t)tile_bones[ch.bones_at + lb] * 3u + (r - lb * 3u)) * (uint32_t)sizeof(float4);
-	}
-	const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&s_rows[0][0]) + wave * 1024u;
-	const size_t pal_stride = (size_t)in0.n_bones * 3;  // float4 per instance (consecutive instances: consecutive palettes)
-	const float4* pal = palette + (size_t)in0.bone_offset * 3;
-	auto stage = [&](uint32_t instance, uint32_t buffer) {
-		const float4* base = pal + instance * pal_stride;
-		const uint32_t dst = lds0 + buffer * (uint32_t)(SKIN_LDS_SLOTS * sizeof(float4));
-#pragma unroll
-		for (uint32_t k = 0; k < MAX_DMA; ++k) {
-			if (wave + k * SHARED_WAVES < n_dma) lds_dma_16(src_off[k], base, dst + k * SHARED_WAVES * 1024u); // wave-uniform branch
-		}
-	};
-	uint32_t skip[SHARED_VPT];
-#pragma unroll
-	for (int k = 0; k < SHARED_VPT; ++k) {
-		skip[k] = 0;
-		if constexpr (MODE == LMX_SKIN_FUSED && LMX_SHARED_ZSKIP != 0) {
-			skip[k] = (__ballot(vin[k].a.y != 0.f) == 0 ? 1u : 0u) | (__ballot(vin[k].a.z != 0.f) == 0 ? 2u : 0u) | (__ballot(vin[k].a.w != 0.f) == 0 ? 4u : 0u);
-		}
-	}
+	// the chunk's instances are consecutive and share mesh and bone count: their bones and outputs are consecutive too
+	const uint32_t n_rows = in0.n_bones * skin_rows(MODE);
+	const float4* pal = palette + (size_t)in0.bone_offset * skin_rows(MODE);
 	F3* obase = reinterpret_cast<F3*>(out) + in0.out_offset;
-	stage(0, 0);
-	// vertex records and the first palette have landed before anyone passes the barrier (the DMA is counted by vmcnt like any load,
-	// but not by the compiler: the wait is explicit). vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding).
-	__builtin_amdgcn_s_waitcnt(0x0F70);
+	palette_spread<COPIES>(s_rows[0], n_rows, tid, palette_fetch<COPIES>(pal, n_rows, tid));
+	// every load so far (vertex records, first palette) is complete before the loop: the compiler's s_waitcnt placement merges the
+	// loop-entry state into the steady state, and with loads possibly pending at the entry it tightens the waits INSIDE the loop
+	__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
 	__syncthreads();
 	for (uint32_t j = 0; j < ch.count; ++j) {
-		// Next palette: issued BEFORE this instance's stores. Loads, DMA and stores retire through ONE in-order counter (vmcnt): the
-		// wait at the end of the instance, placed after the lane's SHARED_VPT stores, is vmcnt(SHARED_VPT) - it covers the DMA and
-		// stores of the previous instance, never this instance's own. (After the last instance: its own palette again, into the idle
-		// buffer, never read.)
-		stage(min(j + 1, ch.count - 1), (j + 1) & 1);
-		const float4* rows = s_rows[j & 1] + col;
+		// Next palette: fetched BEFORE this instance's stores are issued. Loads and stores retire through ONE in-order counter
+		// (vmcnt), so the wait for this load, placed after k of the lane's stores, must be `s_waitcnt vmcnt(k)`: it then covers only
+		// stores of the previous instance. The compiler emits that count only when it can count: with a store (or this load) under
+		// a branch it falls back to vmcnt(0) and every wave drains all of its stores once per instance. Hence: no branch around a
+		// load or a store in this loop; lanes past the end of the tile or the palette are clamped, the last instance re-fetches
+		// its own palette. (Measured, tools/skin_probe.hip, per 1e9 vertices: fetching two instances ahead - so that the wait only
+		// covers stores nearly two instances old - changes nothing, 3.1 ms either way; what the staging costs is the 48 KiB of
+		// LDS writes per instance, 0.26 ms, and the palette's own HBM read next to a store-bound stream, 0.23 ms.)
+		float4 t = {};
+		if (LMX_PROBE_SKIP(256)) t = make_float4((float)j, (float)tid, 1.f, 2.f); // probe: the LDS writes without the load
+		else if (!LMX_PROBE_SKIP(32)) t = palette_fetch<COPIES>(pal + (size_t)min(j + 1, ch.count - 1) * n_rows, n_rows, tid);
+		__builtin_amdgcn_sched_barrier(0); // the load stays here, ahead of the stores
+		const float4* rows = s_rows[LMX_PROBE_SKIP(32) ? 0 : (j & 1)] + col;
 		F3* o = obase + (size_t)j * in0.n_verts;
 #pragma unroll
 		for (int k = 0; k < SHARED_VPT; ++k) {
-			const uint32_t v_wave = ch.v_begin + wave * 64u + k * SHARED_THREADS; // first vertex of this wave's step
-			const uint32_t v = min(v_wave + lane, v_last);
+			const uint32_t v = min(ch.v_begin + tid + k * SHARED_THREADS, v_last);
 			// opaque to the optimiser: nothing derived from the record (LDS addresses, operand pairs) is hoisted out of the instance
 			// loop into registers that do not exist
 			asm volatile("" : "+v"(vin[k].a), "+v"(vin[k].b));
-			F3 r;
-			if constexpr (MODE == LMX_SKIN_FUSED && LMX_SHARED_ZSKIP != 0) r = skin_blend_fused_skip<COPIES>(rows, vin[k], __builtin_amdgcn_readfirstlane(skip[k]));
-			else r = skin_blend<COPIES, MODE>(rows, vin[k]);
-#if LMX_SHARED_ST16
-			if (v_wave + 63u <= v_last) store_position_quad16(o + v_wave, r, lane); // wave-uniform: 64 consecutive vertices
-			else store_position(o + v, r);
-#else
-			store_position(o + v, r);
-#endif
-			__builtin_amdgcn_sched_barrier(0); // one vertex's 12 palette rows (48 VGPRs) in flight at a time
+			const F3 r = skin_blend<COPIES, MODE>(rows, vin[k]);
+			if (!LMX_PROBE_SKIP(8) || r.x == 123.25f) o[v] = r;
+			if (!LMX_PROBE_SKIP(128)) __builtin_amdgcn_sched_barrier(0); // one vertex's 12 palette rows (48 VGPRs) in flight at a time
+			if (k == SHARED_SPREAD_AFTER && !LMX_PROBE_SKIP(32)) {
+				// the next palette goes into the other buffer late in the instance (sooner, the wait for its load stalls: 3.6 ms
+				// after vertex 0 or 1), by every wave (4 ds_write_b128 each). `t` is used by every lane here: without that its load
+				// is sunk into palette_spread's branch, behind the stores, and waited for with vmcnt(0). (After the last instance:
+				// into the idle buffer, never read.)
+				asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
+				palette_spread<COPIES>(s_rows[(j + 1) & 1], n_rows, tid, t);
+				__builtin_amdgcn_sched_barrier(0);
+			}
 		}
-		static_assert(SHARED_VPT == 5, "the wait below counts this instance's stores");
-		__builtin_amdgcn_s_waitcnt(0x0F75); // vmcnt(5): the next palette's DMA (and everything older) has landed
-		__syncthreads();                     // buffer (j + 1) & 1 is complete for every wave; buffer j & 1 is free for instance j + 2
+		if (!LMX_PROBE_SKIP(64)) __syncthreads(); // buffer (j + 1) & 1 is complete; buffer j & 1 is free for instance j + 2
 	}
 }
 
 template <int MODE>
 __global__ __launch_bounds__(SHARED_THREADS) void k_skin_shared(const SkinInstance* __restrict__ inst, const SkinChunk* __restrict__ chunks,
-	const float4* __restrict__ mesh_local, const uint8_t* __restrict__ tile_bones, const float4* __restrict__ palette, float* __restrict__ out) {
+	const float4* __restrict__ mesh, const float4* __restrict__ palette, float* __restrict__ out) {
 	__shared__ float4 s_rows[2][SKIN_LDS_SLOTS];
 	const SkinChunk ch = chunks[blockIdx.x];
 	const SkinInstance in0 = inst[ch.first_inst];
-	if (ch.n_tile_bones <= 64) skin_shared_tile<16, MODE>(in0, ch, s_rows, mesh_local, tile_bones, palette, out);
-	else if (ch.n_tile_bones <= 128) skin_shared_tile<8, MODE>(in0, ch, s_rows, mesh_local, tile_bones, palette, out);
-	else skin_shared_tile<4, MODE>(in0, ch, s_rows, mesh_local, tile_bones, palette, out);
+	if (in0.n_bones <= 64) skin_shared_tile<16, MODE>(in0, ch, s_rows, mesh, palette, out);
+	else if (in0.n_bones <= 128) skin_shared_tile<8, MODE>(in0, ch, s_rows, mesh, palette, out);
+	else skin_shared_tile<4, MODE>(in0, ch, s_rows, mesh, palette, out);
 }
 
 } // namespace
@@ -660,13 +537,13 @@ hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, const u
 	return hipGetLastError();
 }
 
-hipError_t launch_skin_shared(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh_local,
-	const uint8_t* tile_bones, const float4* palette, float* out, int mode) {
+hipError_t launch_skin_shared(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh,
+	const float4* palette, float* out, int mode) {
 	if (!n_chunks) return hipSuccess;
 	const dim3 grid(n_chunks), block(SHARED_THREADS);
-	if (mode == LMX_SKIN_EXACT) hipLaunchKernelGGL(k_skin_shared<LMX_SKIN_EXACT>, grid, block, 0, s, inst, chunks, mesh_local, tile_bones, palette, out);
+	if (mode == LMX_SKIN_EXACT) hipLaunchKernelGGL(k_skin_shared<LMX_SKIN_EXACT>, grid, block, 0, s, inst, chunks, mesh, palette, out);
 	else if (mode == LMX_SKIN_DQS) return hipErrorInvalidValue; // the dual-quaternion blend needs ~75 VGPRs of its own: with five resident records it spilled (284 B of scratch per lane); lmx_skin_run sends LMX_SKIN_DQS through k_skin_vertices (61 VGPRs)
-	else hipLaunchKernelGGL(k_skin_shared<LMX_SKIN_FUSED>, grid, block, 0, s, inst, chunks, mesh_local, tile_bones, palette, out);
+	else hipLaunchKernelGGL(k_skin_shared<LMX_SKIN_FUSED>, grid, block, 0, s, inst, chunks, mesh, palette, out);
 	return hipGetLastError();
 }
 
