@@ -75,6 +75,36 @@ int lmx_skin_add_mesh(LmxContext* ctx, uint32_t n_verts, const float* positions_
 		sk.mesh.push_back(make_float4(skin[v].weights[0], skin[v].weights[1], skin[v].weights[2], skin[v].weights[3]));
 		sk.mesh.push_back(make_float4(positions_xyz[3 * (size_t)v], positions_xyz[3 * (size_t)v + 1], positions_xyz[3 * (size_t)v + 2], idx_bits));
 	}
+	// k_skin_shared's tiling of the mesh (<= SKIN_SHARED_TILE_VERTS vertices per tile, equal shares rounded up to whole waves) and,
+	// per tile, the bones it references + a copy of its records whose index bytes point into that list: the kernel stages only those
+	// bones' palette rows (a tile of a real character touches a fraction of the skeleton; tools/fbx_skin_stats.cpp)
+	m.n_tiles = (n_verts + SKIN_SHARED_TILE_VERTS - 1) / SKIN_SHARED_TILE_VERTS;
+	m.tile_verts = ((n_verts + m.n_tiles - 1) / m.n_tiles + 63u) & ~63u;
+	m.tiles_at = (uint32_t)sk.tiles.size();
+	sk.mesh_local.resize(sk.mesh.size());
+	for (uint32_t t = 0; t < m.n_tiles; ++t) {
+		const uint32_t v0 = t * m.tile_verts, v1 = std::min(n_verts, (t + 1) * m.tile_verts);
+		int16_t local_of[LMX_MAX_BONES];
+		std::fill(local_of, local_of + LMX_MAX_BONES, (int16_t)-1);
+		SkinTile tile{(uint32_t)sk.tile_bones.size(), 0};
+		for (uint32_t v = v0; v < v1; ++v) {
+			uint32_t idx = 0;
+			for (int k = 0; k < 4; ++k) {
+				const int b = skin[v].indices[k];
+				if (local_of[b] < 0) {
+					local_of[b] = (int16_t)tile.n_bones++;
+					sk.tile_bones.push_back((uint8_t)b);
+				}
+				idx |= (uint32_t)local_of[b] << (8 * k);
+			}
+			float idx_bits;
+			std::memcpy(&idx_bits, &idx, 4);
+			const size_t at = 2 * ((size_t)m.vert_offset + v);
+			sk.mesh_local[at] = sk.mesh[at];
+			sk.mesh_local[at + 1] = make_float4(sk.mesh[at + 1].x, sk.mesh[at + 1].y, sk.mesh[at + 1].z, idx_bits);
+		}
+		sk.tiles.push_back(tile);
+	}
 	sk.meshes.push_back(m);
 	sk.meshes_dirty = true;
 	if (out_mesh) *out_mesh = (uint32_t)sk.meshes.size() - 1;
@@ -102,6 +132,10 @@ static int skin_upload_static(LmxContext* ctx) {
 		LMX_HIP(ctx, sk.d_mesh.reserve(std::max<size_t>(sk.mesh.size(), 1)));
 		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		LMX_HIP(ctx, hipMemcpy(sk.d_mesh.p, sk.mesh.data(), sk.mesh.size() * sizeof(float4), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, sk.d_mesh_local.reserve(std::max<size_t>(sk.mesh_local.size(), 1)));
+		LMX_HIP(ctx, sk.d_tile_bones.reserve(std::max<size_t>(sk.tile_bones.size(), 1)));
+		LMX_HIP(ctx, hipMemcpy(sk.d_mesh_local.p, sk.mesh_local.data(), sk.mesh_local.size() * sizeof(float4), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(sk.d_tile_bones.p, sk.tile_bones.data(), sk.tile_bones.size(), hipMemcpyHostToDevice));
 		sk.meshes_dirty = false;
 	}
 	return LMX_OK;
@@ -159,15 +193,15 @@ int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* model, c
 	sk.solo.clear();
 	sk.solo_max_verts = 0;
 	{
-		struct Run { uint32_t first, count, tiles; };
+		struct Run { uint32_t first, count, tiles, mesh; };
 		std::vector<Run> runs;
 		uint64_t run_tiles = 0;
 		for (uint32_t i = 0; i < n;) {
 			uint32_t c = 1;
 			while (i + c < n && mesh[i + c] == mesh[i] && inst[i + c].n_bones == inst[i].n_bones) ++c;
 			if (c >= 2 && inst[i].n_verts >= 2048) {
-				const uint32_t tiles = (inst[i].n_verts + SKIN_SHARED_TILE_VERTS - 1) / SKIN_SHARED_TILE_VERTS;
-				runs.push_back(Run{i, c, tiles});
+				const uint32_t tiles = sk.meshes[mesh[i]].n_tiles;
+				runs.push_back(Run{i, c, tiles, mesh[i]});
 				run_tiles += (uint64_t)c * tiles;
 			} else {
 				for (uint32_t k = 0; k < c; ++k) {
@@ -181,10 +215,15 @@ int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* model, c
 		const uint32_t per_block = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, run_tiles / 1536));
 		for (const Run& r : runs) {
 			const uint32_t nv = inst[r.first].n_verts;
-			const uint32_t tile_verts = ((nv + r.tiles - 1) / r.tiles + 63u) & ~63u;
+			const SkinMesh& me = sk.meshes[r.mesh];
+			const uint32_t tile_verts = me.tile_verts;
 			for (uint32_t f = 0; f < r.count; f += per_block)
-				for (uint32_t t = 0; t < r.tiles; ++t)
-					if (t * tile_verts < nv) sk.chunks.push_back(SkinChunk{r.first + f, std::min(per_block, r.count - f), t * tile_verts, std::min(nv, (t + 1) * tile_verts)});
+				for (uint32_t t = 0; t < r.tiles; ++t) {
+					if (t * tile_verts >= nv) continue;
+					const SkinTile& tile = sk.tiles[me.tiles_at + t];
+					sk.chunks.push_back(SkinChunk{r.first + f, std::min(per_block, r.count - f), t * tile_verts, std::min(nv, (t + 1) * tile_verts), me.vert_offset,
+						tile.bones_at, tile.n_bones, 0u});
+				}
 		}
 		if (sk.chunks.empty()) sk.solo.clear(); // every instance: identity index
 	}
@@ -316,7 +355,7 @@ int lmx_skin_run(LmxContext* ctx) {
 			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, nullptr, n, sk.max_verts, sk.d_mesh.p, vertex_palette,
 				sk.d_out.p, sk.mode));
 		} else {
-			LMX_HIP(ctx, launch_skin_shared(ctx->stream, sk.d_inst.p, sk.d_chunks.p, (uint32_t)sk.chunks.size(), sk.d_mesh.p,
+			LMX_HIP(ctx, launch_skin_shared(ctx->stream, sk.d_inst.p, sk.d_chunks.p, (uint32_t)sk.chunks.size(), sk.d_mesh_local.p, sk.d_tile_bones.p,
 				vertex_palette, sk.d_out.p, sk.mode));
 			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, sk.d_solo.p, (uint32_t)sk.solo.size(), sk.solo_max_verts, sk.d_mesh.p, vertex_palette, sk.d_out.p, sk.mode));
 		}

@@ -211,7 +211,10 @@ struct WorldState {
 };
 
 struct SkinModel { uint32_t bone_offset, n_bones, max_depth; int32_t first_nonroot; uint32_t lv_items_offset, lv_off_offset; };
-struct SkinMesh { uint32_t vert_offset, n_verts, max_bone; }; // max_bone: the largest bone index its vertices reference
+// max_bone: the largest bone index its vertices reference. k_skin_shared's view of the mesh: tiles of tile_verts vertices
+// (tiles_at .. + n_tiles in SkinState::tiles), each with the list of bones it references and records that index into that list.
+struct SkinMesh { uint32_t vert_offset, n_verts, max_bone, tile_verts, n_tiles, tiles_at; };
+struct SkinTile { uint32_t bones_at, n_bones; }; // into SkinState::tile_bones
 
 struct SkinState {
 	std::vector<SkinModel> models;
@@ -233,6 +236,11 @@ struct SkinState {
 	DevBuf<PoseGroup> d_groups;
 	std::vector<float> inv_pos;
 	std::vector<float4> inv_rot;
+	std::vector<float4> mesh_local;    // the same records with TILE-LOCAL bone indices (k_skin_shared), same vertex offsets as `mesh`
+	std::vector<SkinTile> tiles;
+	std::vector<uint8_t> tile_bones;   // per tile: the model bones it references, in local-index order
+	DevBuf<float4> d_mesh_local;
+	DevBuf<uint8_t> d_tile_bones;
 	std::vector<float4> mesh; // 2 per vertex: {w0, w1, w2, w3}, {x, y, z, bone indices as 4 x u8} (skin_kernels.hip: RawVertex)
 	bool models_dirty = false, meshes_dirty = false;
 	DevBuf<int16_t> d_parents;

@@ -67,6 +67,12 @@ def test_vertex_loops_keep_stores_in_flight(skin_isa, kernel, min_stores):
         assert waits, f"loop {h}: no vmcnt wait at all?"
         assert min(waits) >= 1, f"loop {h} drains its stores: vmcnt waits {waits}"
     if kernel.startswith("13k_skin_shared"):
-        # one wait per instance, behind four of the lane's five stores: the palette load issued before them
+        # one compiler-counted wait per instance, behind four of the lane's five stores: the row load of the VGPR staging path, issued
+        # at the top of the instance AFTER the LDS-DMA part of the staging (global_load_lds: invisible to the compiler's counting, older
+        # than the row load, so the same wait covers it); the position stores are non-temporal
         for h, ins in vertex_loops.items():
             assert [w for i in ins for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", i)] if m for w in [int(m.group(1))]] == [4], h
+            dma = [k for k, i in enumerate(ins) if "global_load_lds_dwordx4" in i]
+            loads = [k for k, i in enumerate(ins) if re.search(r"global_load_dwordx4", i) and "lds" not in i]
+            assert 1 <= len(dma) <= 3 and len(loads) == 1, (h, dma, loads)
+            assert all(" nt" in i for i in ins if "global_store_dwordx3" in i), f"loop {h}: the position stores are not non-temporal"

@@ -336,52 +336,6 @@ __device__ __forceinline__ void palette_spread(float4* s_rows, uint32_t n_rows, 
 }
 constexpr uint32_t palette_items(uint32_t max_rows, uint32_t copies) { return max_rows * (copies / 4); }
 
-// experiment knobs (tools/skin_probe.hip builds the variants; the defaults are what measured best, DESIGN.md)
-#ifndef LMX_SHARED_NT
-#define LMX_SHARED_NT 1    // non-temporal output stores (the 12 GB of positions are never read back by this kernel)
-#endif
-#ifndef LMX_SHARED_ST16
-#define LMX_SHARED_ST16 0  // 1: four lanes' 12-byte results transposed (DPP) into three 16-byte stores (measured: slower)
-#endif
-
-typedef float v3f_a4 __attribute__((ext_vector_type(3), aligned(4)));
-typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
-
-// one vertex's result to out[v] (12 bytes, lanes contiguous: 768 bytes per wave-instruction)
-__device__ __forceinline__ void store_position(F3* dst, const F3& r) {
-#if LMX_SHARED_NT
-	v3f_a4 t = {r.x, r.y, r.z};
-	__builtin_nontemporal_store(t, reinterpret_cast<v3f_a4*>(dst));
-#else
-	*dst = r;
-#endif
-}
-
-// The same 768 bytes as three 16-byte stores per four lanes: lane p of a quad stores words [4p, 4p + 4) of the quad's twelve
-// floats (x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3), lane 3 stores nothing. Three quad-permute DPP moves + selects.
-// `wave_dst` = &out[first vertex of the wave]; only for waves whose 64 vertices are consecutive (not clamped at the tile's end).
-__device__ __forceinline__ void store_position_quad16(F3* wave_dst, const F3& r, uint32_t lane) {
-	const uint32_t p = lane & 3u;
-	const int xi = __float_as_int(r.x), yi = __float_as_int(r.y), zi = __float_as_int(r.z);
-	// quad_perm [a, b, c, d] = a | b << 2 | c << 4 | d << 6: lane k of a quad reads lane perm[k]
-	const int xs = __builtin_amdgcn_mov_dpp(xi, 1 | 2 << 2 | 3 << 4 | 3 << 6, 0xf, 0xf, true); // lane0 <- x1, lane1 <- x2, lane2 <- x3
-	const int ys = __builtin_amdgcn_mov_dpp(yi, 0 | 2 << 2 | 3 << 4 | 3 << 6, 0xf, 0xf, true); // lane1 <- y2, lane2 <- y3
-	const int zs = __builtin_amdgcn_mov_dpp(zi, 0 | 1 << 2 | 3 << 4 | 3 << 6, 0xf, 0xf, true); // lane2 <- z3
-	const int w0 = p == 0 ? xi : (p == 1 ? yi : zi);
-	const int w1 = p == 0 ? yi : (p == 1 ? zi : xs);
-	const int w2 = p == 0 ? zi : (p == 1 ? xs : ys);
-	const int w3 = p == 0 ? xs : (p == 1 ? ys : zs);
-	if (p != 3u) {
-		v4f_a4 t = {__int_as_float(w0), __int_as_float(w1), __int_as_float(w2), __int_as_float(w3)};
-		v4f_a4* dst = reinterpret_cast<v4f_a4*>(reinterpret_cast<float*>(wave_dst) + (lane >> 2) * 12u + p * 4u);
-#if LMX_SHARED_NT
-		__builtin_nontemporal_store(t, dst);
-#else
-		*dst = t;
-#endif
-	}
-}
-
 template <int COPIES, int MODE>
 __device__ __forceinline__ void skin_tile(const SkinInstance& in, uint32_t v_begin, uint32_t v_end, float4* s_rows,
 	const float4* __restrict__ mesh, const float4* __restrict__ palette, float* __restrict__ out) {
@@ -429,7 +383,7 @@ __device__ __forceinline__ void skin_tile(const SkinInstance& in, uint32_t v_beg
 			asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z));
 			__builtin_amdgcn_sched_barrier(0); // the refill goes into the registers the blend has just finished with: no copies
 			rec[d] = load(min(v0 + (it + d + SKIN_PIPE) * SKIN_THREADS, v_last));
-			if (!LMX_PROBE_SKIP(8) || o.x == 123.25f) store_position(obase + v, o);
+			if (!LMX_PROBE_SKIP(8) || o.x == 123.25f) obase[v] = o;
 			__builtin_amdgcn_sched_barrier(0);
 		}
 	}
@@ -452,20 +406,30 @@ __global__ __launch_bounds__(SKIN_THREADS, SKIN_WAVES_PER_SIMD) void k_skin_vert
 	else skin_tile<4, MODE>(in, v_begin, v_end, s_rows, mesh, palette, out);
 }
 
-// ---- shared-mesh runs: vertex records in registers, palettes double-buffered in LDS ---------------------------------------------
+// ---- shared-mesh runs: vertex records in registers, palettes double-buffered in LDS, staged by LDS-DMA ----------------------
 constexpr int SHARED_THREADS = 1024; // 16 waves = 4 per SIMD at <= 128 VGPRs; one block per CU (2 x 48 KiB LDS)
+constexpr int SHARED_WAVES = SHARED_THREADS / 64;
 constexpr int SHARED_VPT = 5;        // vertex records per lane (8 VGPRs each) -> tiles of up to 5120 vertices
-#ifndef LMX_SHARED_SPREAD_AFTER
-#define LMX_SHARED_SPREAD_AFTER 3
+// experiment knobs (tools/skin_probe.hip builds the variants; the defaults are what measured best, DESIGN.md)
+#ifndef LMX_SHARED_NT
+#define LMX_SHARED_NT 1    // non-temporal output stores (the 12 GB of positions are never read back by this kernel)
 #endif
-constexpr int SHARED_SPREAD_AFTER = LMX_SHARED_SPREAD_AFTER; // the next palette is spread into LDS after this vertex of the lane's five
+#ifndef LMX_SHARED_ST16
+#define LMX_SHARED_ST16 0  // 1: four lanes' 12-byte results transposed (DPP) into three 16-byte stores
+#endif
+#ifndef LMX_SHARED_ZSKIP
+#define LMX_SHARED_ZSKIP 1 // LMX_SKIN_FUSED: bone slots whose weight is zero for a whole wave are not read from LDS
+#endif
+
 static_assert(SHARED_THREADS * SHARED_VPT == SKIN_SHARED_TILE_VERTS, "host tiling and kernel disagree");
 
 // One palette staging instruction: 64 lanes x 16 bytes from per-lane global addresses (wave-uniform base + 32-bit lane offset)
-// straight into 1 KiB of LDS at a wave-uniform address (LDS-DMA: no VGPR round trip). Inline asm because (a) M0 carries the LDS
-// address and is compiler-reserved, (b) the compiler must NOT count this operation: it would drain vmcnt to 0 at the next barrier
-// (cdna_hip_programming.md, "Pipelining across barriers"), i.e. every store of the wave once per instance; the issuing wave waits
-// for it itself with an exact count.
+// straight into 1 KiB of LDS at a wave-uniform address (LDS-DMA: no VGPR round trip, no ds_write - the 48 KiB of replicated rows
+// per instance cost 13 cycles per ds_write_b128 wave-instruction on the VGPR -> LDS path, MI355X_MICROARCH.md "LDS"). The
+// replication happens on the SOURCE side: the COPIES lanes of a row fetch the same 16 bytes (one request), the destination is
+// linear. Inline asm because (a) M0 carries the LDS address and is compiler-reserved, (b) the compiler must NOT count this
+// operation: it would drain vmcnt to 0 at the next barrier (cdna_hip_programming.md, "Pipelining across barriers"), i.e. every
+// store of the wave once per instance; the kernel waits for it itself with an exact count.
 __device__ __forceinline__ void lds_dma_16(uint32_t lane_byte_offset, const void* uniform_base, uint32_t lds_byte_address) {
 	uint32_t keep;
 	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -474,99 +438,148 @@ __device__ __forceinline__ void lds_dma_16(uint32_t lane_byte_offset, const void
 				 : "memory");
 }
 
-#ifndef LMX_SHARED_DMA_NUM
-#define LMX_SHARED_DMA_NUM 1 // share of the palette rows staged by LDS-DMA = NUM / DEN, the rest goes VGPR -> ds_write
+typedef float v3f_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// one vertex's result to out[v] (12 bytes, lanes contiguous: 768 bytes per wave-instruction)
+__device__ __forceinline__ void store_position(F3* dst, const F3& r) {
+#if LMX_SHARED_NT
+	v3f_a4 t = {r.x, r.y, r.z};
+	__builtin_nontemporal_store(t, reinterpret_cast<v3f_a4*>(dst));
+#else
+	*dst = r;
 #endif
-#ifndef LMX_SHARED_DMA_DEN
-#define LMX_SHARED_DMA_DEN 2
+}
+
+// The same 768 bytes as three 16-byte stores per four lanes: lane p of a quad stores words [4p, 4p + 4) of the quad's twelve
+// floats (x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3), lane 3 stores nothing. Three quad-permute DPP moves + selects.
+// `wave_dst` = &out[first vertex of the wave]; only for waves whose 64 vertices are consecutive (not clamped at the tile's end).
+__device__ __forceinline__ void store_position_quad16(F3* wave_dst, const F3& r, uint32_t lane) {
+	const uint32_t p = lane & 3u;
+	const int xi = __float_as_int(r.x), yi = __float_as_int(r.y), zi = __float_as_int(r.z);
+	// quad_perm [a, b, c, d] = a | b << 2 | c << 4 | d << 6: lane k of a quad reads lane perm[k]
+	const int xs = __builtin_amdgcn_mov_dpp(xi, 1 | 2 << 2 | 3 << 4 | 3 << 6, 0xf, 0xf, true); // lane0 <- x1, lane1 <- x2, lane2 <- x3
+	const int ys = __builtin_amdgcn_mov_dpp(yi, 0 | 2 << 2 | 3 << 4 | 3 << 6, 0xf, 0xf, true); // lane1 <- y2, lane2 <- y3
+	const int zs = __builtin_amdgcn_mov_dpp(zi, 0 | 1 << 2 | 3 << 4 | 3 << 6, 0xf, 0xf, true); // lane2 <- z3
+	const int w0 = p == 0 ? xi : (p == 1 ? yi : zi);
+	const int w1 = p == 0 ? yi : (p == 1 ? zi : xs);
+	const int w2 = p == 0 ? zi : (p == 1 ? xs : ys);
+	const int w3 = p == 0 ? xs : (p == 1 ? ys : zs);
+	if (p != 3u) {
+		v4f_a4 t = {__int_as_float(w0), __int_as_float(w1), __int_as_float(w2), __int_as_float(w3)};
+		v4f_a4* dst = reinterpret_cast<v4f_a4*>(reinterpret_cast<float*>(wave_dst) + (lane >> 2) * 12u + p * 4u);
+#if LMX_SHARED_NT
+		__builtin_nontemporal_store(t, dst);
+#else
+		*dst = t;
 #endif
+	}
+}
+
+// evaluateSkin over the first N bone slots only (LMX_SKIN_FUSED): the caller knows that slots >= N carry weight zero in every lane
+// of the wave (0 * row adds exactly nothing), so their rows are neither read from LDS nor multiplied. Straight-line code per N:
+// a branch around each single read would serialise the reads (a wait behind every conditional one).
+template <int COPIES, int N>
+__device__ __forceinline__ F3 skin_blend_fused_n(const float4* rows, const RawVertex& rv) {
+	constexpr uint32_t STRIDE = 3 * COPIES;
+	const uint32_t idx = __float_as_uint(rv.b.w);
+	const float4* r0 = rows + (idx & 0xffu) * STRIDE;
+	const float4* r1 = rows + ((idx >> 8) & 0xffu) * STRIDE;
+	const float4* r2 = rows + ((idx >> 16) & 0xffu) * STRIDE;
+	const float4* r3 = rows + (idx >> 24) * STRIDE;
+	const v2f w01 = {rv.a.x, rv.a.y}, w23 = {rv.a.z, rv.a.w};
+	const v2f wx = __builtin_shufflevector(w01, w01, 0, 0), wy = __builtin_shufflevector(w01, w01, 1, 1);
+	const v2f wz = __builtin_shufflevector(w23, w23, 0, 0), ww = __builtin_shufflevector(w23, w23, 1, 1);
+	float o[3];
+#pragma unroll
+	for (int r = 0; r < 3; ++r) {
+		const float4 A = r0[r * COPIES];
+		v2f m01 = v2f{A.x, A.y} * wx, m23 = v2f{A.z, A.w} * wx;
+		if constexpr (N > 1) {
+			const float4 B = r1[r * COPIES];
+			m01 = __builtin_elementwise_fma(v2f{B.x, B.y}, wy, m01);
+			m23 = __builtin_elementwise_fma(v2f{B.z, B.w}, wy, m23);
+		}
+		if constexpr (N > 2) {
+			const float4 C = r2[r * COPIES];
+			m01 = __builtin_elementwise_fma(v2f{C.x, C.y}, wz, m01);
+			m23 = __builtin_elementwise_fma(v2f{C.z, C.w}, wz, m23);
+		}
+		if constexpr (N > 3) {
+			const float4 D = r3[r * COPIES];
+			m01 = __builtin_elementwise_fma(v2f{D.x, D.y}, ww, m01);
+			m23 = __builtin_elementwise_fma(v2f{D.z, D.w}, ww, m23);
+		}
+		o[r] = fmaf(m23.x, rv.b.z, fmaf(m01.y, rv.b.y, m01.x * rv.b.x)) + m23.y;
+	}
+	return F3{o[0], o[1], o[2]};
+}
 
 // A chunk = one tile of <= 5120 vertices of a mesh x a run of consecutive instances that share the mesh. The tile's vertex records
 // carry TILE-LOCAL bone indices: only the palette rows of the bones the tile references (SkinChunk::n_tile_bones of them, listed in
 // tile_bones) are staged, in the order of that list. On the reference's demo character a tile touches 13-16 of 52 bones
 // (tools/fbx_skin_stats.cpp); the synthetic worst-case mesh (4 random bones of 64 per vertex) touches all of them.
-//
-// Staging of the replicated palette (48 KiB per instance for 64 bones) is SPLIT between the two paths a CU has into LDS, because
-// each alone became the bound (profiles/r03/skin_ab_*.txt; ms per 1e9 vertices, worst-case mesh, round 2's kernel 3.14-3.25):
-//   * LDS-DMA (global_load_lds_dwordx4, replication on the source side: the COPIES lanes of a row fetch the same 16 bytes, no VGPR
-//     round trip, no ds_write): alone 2.83 WITH OR WITHOUT the stores - the DMA path moves ~12 B per cycle and CU whatever the source;
-//   * VGPR -> 4 x ds_write_b128 per staging lane (round 2's way): alone 3.02 - the ds_write wave-instructions cost 13 cycles each
-//     on the VGPR -> LDS path, and the row's global load puts a vmcnt wait behind four of every wave's stores.
-// Rows [0, r_dma) go by DMA, issued at the top of the instance BEFORE the row load of the VGPR path: the compiler's own counted
-// wait for that load (`vmcnt(4)`, the loop's only one) then covers the older DMAs too - in-order counter - without knowing them.
-// Measured and NOT kept: the unique rows by DMA into a ring + LDS -> LDS replication (3.05: the ds_writes stay); three 16-byte
-// stores per four lanes instead of four 12-byte ones (+0.3); skipping the LDS reads of zero-weight slots (LMX_SKIN_FUSED; -6 % on a
-// character-like mesh, +6 % on the worst case, and a second copy of the loop spilled). Non-temporal stores: -0.15 ... -0.75.
 template <int COPIES, int MODE>
 __device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const SkinChunk& ch, float4 (*s_rows)[SKIN_LDS_SLOTS],
 	const float4* __restrict__ mesh_local, const uint8_t* __restrict__ tile_bones, const float4* __restrict__ palette, float* __restrict__ out) {
-	constexpr uint32_t LPR = COPIES / 4;   // VGPR path: lanes per palette row
-	constexpr uint32_t RPI = 64 / COPIES;  // DMA path: palette rows one instruction covers (1 KiB of LDS)
-	constexpr uint32_t SHARED_WAVES = SHARED_THREADS / 64;
-	constexpr uint32_t MAX_DMA = (SKIN_LDS_SLOTS / 64 + SHARED_WAVES - 1) / SHARED_WAVES; // DMA instructions per wave: <= 3
+	constexpr uint32_t RPI = 64 / COPIES;               // palette rows one staging instruction covers
+	constexpr uint32_t MAX_DMA = (SKIN_LDS_SLOTS / 64 + SHARED_WAVES - 1) / SHARED_WAVES; // staging instructions per wave: 3
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const uint32_t col = tid & (COPIES - 1);
 	const float4* mbase = mesh_local + 2 * (size_t)ch.rec_offset;
 	// the lane's vertex records: loaded once, used for every instance of the chunk, kept as loaded (8 VGPRs each). Lanes past the
-	// tile's end take its LAST vertex (they recompute and rewrite the same 12 bytes): every store is unconditional.
+	// tile's end take its LAST vertex (they recompute and rewrite the same 12 bytes): every store below is unconditional.
 	const uint32_t v_last = ch.v_end - 1; // chunks are never empty
 	RawVertex vin[SHARED_VPT];
 #pragma unroll
 	for (int k = 0; k < SHARED_VPT; ++k) vin[k] = load_vertex(mbase, min(ch.v_begin + tid + k * SHARED_THREADS, v_last));
-	// staging plan, the same for every instance: row f of the tile-local palette = row (f % 3) of bone tile_bones[f / 3]
+	// staging plan of this lane, the same for every instance: row r of the tile-local palette = row (r % 3) of bone tile_bones[r / 3]
 	const uint32_t n_rows = ch.n_tile_bones * 3u;
-	const uint32_t n_dma = (n_rows * LMX_SHARED_DMA_NUM / LMX_SHARED_DMA_DEN) / RPI; // DMA instructions per palette (whole instructions only)
-	const uint32_t r_dma = n_dma * RPI;                                              // rows [0, r_dma) by DMA, [r_dma, n_rows) through VGPRs
-	auto global_row = [&](uint32_t f) { // float4 index of tile-local row f inside an instance's palette
-		const uint32_t lb = f / 3u;
-		return (uint32_t)tile_bones[ch.bones_at + lb] * 3u + (f - lb * 3u);
-	};
-	uint32_t dma_off[MAX_DMA];
+	const uint32_t n_dma = (n_rows + RPI - 1) / RPI;    // wave w issues instructions w, w + 16, w + 32 (< n_dma)
+	uint32_t src_off[MAX_DMA];
 #pragma unroll
-	for (uint32_t k = 0; k < MAX_DMA; ++k) dma_off[k] = global_row(min((wave + k * SHARED_WAVES) * RPI + lane / COPIES, n_rows - 1)) * (uint32_t)sizeof(float4);
-	const uint32_t f = r_dma + tid / LPR;                // VGPR path: the row this lane fetches and writes four copies of
-	const bool stages = f < n_rows;
-	const uint32_t src_row = global_row(stages ? f : 0u); // (lanes without an item re-fetch row 0: no branch around the load)
+	for (uint32_t k = 0; k < MAX_DMA; ++k) {
+		const uint32_t r = min((wave + k * SHARED_WAVES) * RPI + lane / COPIES, n_rows - 1);
+		const uint32_t lb = r / 3u;
+		src_off[k] = ((uint32_t)tile_bones[ch.bones_at + lb] * 3u + (r - lb * 3u)) * (uint32_t)sizeof(float4);
+	}
 	const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&s_rows[0][0]) + wave * 1024u;
-	const size_t pal_stride = (size_t)in0.n_bones * 3;   // float4 per instance (consecutive instances: consecutive palettes)
+	const size_t pal_stride = (size_t)in0.n_bones * 3;  // float4 per instance (consecutive instances: consecutive palettes)
 	const float4* pal = palette + (size_t)in0.bone_offset * 3;
-	auto stage_dma = [&](uint32_t instance, uint32_t buffer) {
+	auto stage = [&](uint32_t instance, uint32_t buffer) {
 		const float4* base = pal + instance * pal_stride;
 		const uint32_t dst = lds0 + buffer * (uint32_t)(SKIN_LDS_SLOTS * sizeof(float4));
 #pragma unroll
 		for (uint32_t k = 0; k < MAX_DMA; ++k) {
-			if (wave + k * SHARED_WAVES < n_dma) lds_dma_16(dma_off[k], base, dst + k * SHARED_WAVES * 1024u); // wave-uniform branch
+			if (wave + k * SHARED_WAVES < n_dma) lds_dma_16(src_off[k], base, dst + k * SHARED_WAVES * 1024u); // wave-uniform branch
 		}
 	};
-	auto spread = [&](uint32_t buffer, float4 t) { // palette_spread for row f (rows below r_dma belong to the DMA)
-		if (stages) {
-			const uint32_t q = tid % LPR;
-			const uint32_t rot = COPIES == 4 ? (f >> 1) : LPR * f;
+	// slots in use per vertex step, wave-uniform: 1 + the last slot with a non-zero weight in any lane (real meshes sort a vertex's
+	// influences by weight and pad with zeros: 1.0-1.2 influences per control point on the reference's demo character)
+	uint32_t n_slots = 0; // 3 bits per step
 #pragma unroll
-			for (uint32_t i = 0; i < 4; ++i) s_rows[buffer][f * COPIES + ((q + LPR * i + rot) & (COPIES - 1))] = t;
+	for (int k = 0; k < SHARED_VPT; ++k) {
+		uint32_t n = 4;
+		if constexpr (MODE == LMX_SKIN_FUSED && LMX_SHARED_ZSKIP != 0) {
+			n = __ballot(vin[k].a.w != 0.f) != 0 ? 4u : (__ballot(vin[k].a.z != 0.f) != 0 ? 3u : (__ballot(vin[k].a.y != 0.f) != 0 ? 2u : 1u));
 		}
-	};
+		n_slots |= n << (3 * k);
+	}
+	n_slots = __builtin_amdgcn_readfirstlane(n_slots);
 	F3* obase = reinterpret_cast<F3*>(out) + in0.out_offset;
-	const uint32_t last = ch.count - 1;
-	stage_dma(0, 0);
-	spread(0, pal[src_row]);
-	// every load so far (vertex records, first palette incl. its DMA part, which the compiler does not know) is complete before the
-	// loop; the compiler's s_waitcnt placement merges the loop-entry state into the steady state, and with loads possibly pending
-	// at the entry it tightens the waits INSIDE the loop. vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding).
+	stage(0, 0);
+	// vertex records and the first palette have landed before anyone passes the barrier (the DMA is counted by vmcnt like any load,
+	// but not by the compiler: the wait is explicit). vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding).
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
-	for (uint32_t j = 0; j <= last; ++j) {
-		// Next palette: DMA part first, then the row load of the VGPR part, both BEFORE this instance's stores. Loads, DMA and stores
-		// retire through ONE in-order counter (vmcnt): the wait for the row load, placed after k of the lane's stores, must be
-		// `s_waitcnt vmcnt(k)` - it then covers the row load, the older DMAs and the stores of the previous instance, never this
-		// instance's own. The compiler emits that count only when it can count: no branch around a compiler-visible load or a store
-		// in this loop (lanes past the end of the tile or the palette are clamped, the last instance re-stages its own palette).
-		const uint32_t next = min(j + 1, last);
-		stage_dma(next, (j + 1) & 1);
-		float4 t = pal[next * pal_stride + src_row];
-		__builtin_amdgcn_sched_barrier(0); // the load stays here, ahead of the stores
+	for (uint32_t j = 0; j < ch.count; ++j) {
+		// Next palette: issued BEFORE this instance's stores. Loads, DMA and stores retire through ONE in-order counter (vmcnt): the
+		// wait at the end of the instance, placed after the lane's SHARED_VPT stores, is vmcnt(SHARED_VPT) - it covers the DMA and
+		// stores of the previous instance, never this instance's own. (After the last instance: its own palette again, into the idle
+		// buffer, never read.)
+		stage(min(j + 1, ch.count - 1), (j + 1) & 1);
 		const float4* rows = s_rows[j & 1] + col;
 		F3* o = obase + (size_t)j * in0.n_verts;
 #pragma unroll
@@ -576,7 +589,16 @@ __device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const 
 			// opaque to the optimiser: nothing derived from the record (LDS addresses, operand pairs) is hoisted out of the instance
 			// loop into registers that do not exist
 			asm volatile("" : "+v"(vin[k].a), "+v"(vin[k].b));
-			const F3 r = skin_blend<COPIES, MODE>(rows, vin[k]);
+			F3 r;
+			if constexpr (MODE == LMX_SKIN_FUSED && LMX_SHARED_ZSKIP != 0) {
+				const uint32_t n = (n_slots >> (3 * k)) & 7u; // wave-uniform
+				if (n == 4) r = skin_blend<COPIES, MODE>(rows, vin[k]);
+				else if (n == 1) r = skin_blend_fused_n<COPIES, 1>(rows, vin[k]);
+				else if (n == 2) r = skin_blend_fused_n<COPIES, 2>(rows, vin[k]);
+				else r = skin_blend_fused_n<COPIES, 3>(rows, vin[k]);
+			} else {
+				r = skin_blend<COPIES, MODE>(rows, vin[k]);
+			}
 			if (!LMX_PROBE_SKIP(8) || r.x == 123.25f) {
 #if LMX_SHARED_ST16
 				if (v_wave + 63u <= v_last) store_position_quad16(o + v_wave, r, lane); // wave-uniform: 64 consecutive vertices
@@ -586,16 +608,10 @@ __device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const 
 #endif
 			}
 			__builtin_amdgcn_sched_barrier(0); // one vertex's 12 palette rows (48 VGPRs) in flight at a time
-			if (k == SHARED_SPREAD_AFTER) {
-				// the VGPR part of the next palette goes into the other buffer late in the instance (sooner, the wait for its load
-				// stalls). `t` is used by every lane here: without that its load is sunk into the branch, behind the stores, and
-				// waited for with vmcnt(0). (After the last instance: into the idle buffer, never read.)
-				asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
-				spread((j + 1) & 1, t);
-				__builtin_amdgcn_sched_barrier(0);
-			}
 		}
-		__syncthreads(); // buffer (j + 1) & 1 is complete for every wave; buffer j & 1 is free for instance j + 2
+		static_assert(SHARED_VPT == 5, "the wait below counts this instance's stores");
+		__builtin_amdgcn_s_waitcnt(0x0F75); // vmcnt(5): the next palette's DMA (and everything older) has landed
+		__syncthreads();                     // buffer (j + 1) & 1 is complete for every wave; buffer j & 1 is free for instance j + 2
 	}
 }
 

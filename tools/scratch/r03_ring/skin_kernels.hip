@@ -474,36 +474,30 @@ __device__ __forceinline__ void lds_dma_16(uint32_t lane_byte_offset, const void
 				 : "memory");
 }
 
-#ifndef LMX_SHARED_DMA_NUM
-#define LMX_SHARED_DMA_NUM 1 // share of the palette rows staged by LDS-DMA = NUM / DEN, the rest goes VGPR -> ds_write
-#endif
-#ifndef LMX_SHARED_DMA_DEN
-#define LMX_SHARED_DMA_DEN 2
-#endif
+constexpr int SHARED_RING = 3;          // unique palettes in flight: one being replicated, one landed, one landing
+constexpr int SHARED_RING_ROWS = 640;   // >= 3 rows x 196 bones, a multiple of the 64 rows one staging instruction moves
 
 // A chunk = one tile of <= 5120 vertices of a mesh x a run of consecutive instances that share the mesh. The tile's vertex records
 // carry TILE-LOCAL bone indices: only the palette rows of the bones the tile references (SkinChunk::n_tile_bones of them, listed in
 // tile_bones) are staged, in the order of that list. On the reference's demo character a tile touches 13-16 of 52 bones
 // (tools/fbx_skin_stats.cpp); the synthetic worst-case mesh (4 random bones of 64 per vertex) touches all of them.
 //
-// Staging of the replicated palette (48 KiB per instance for 64 bones) is SPLIT between the two paths a CU has into LDS, because
-// each alone became the bound (profiles/r03/skin_ab_*.txt; ms per 1e9 vertices, worst-case mesh, round 2's kernel 3.14-3.25):
-//   * LDS-DMA (global_load_lds_dwordx4, replication on the source side: the COPIES lanes of a row fetch the same 16 bytes, no VGPR
-//     round trip, no ds_write): alone 2.83 WITH OR WITHOUT the stores - the DMA path moves ~12 B per cycle and CU whatever the source;
-//   * VGPR -> 4 x ds_write_b128 per staging lane (round 2's way): alone 3.02 - the ds_write wave-instructions cost 13 cycles each
-//     on the VGPR -> LDS path, and the row's global load puts a vmcnt wait behind four of every wave's stores.
-// Rows [0, r_dma) go by DMA, issued at the top of the instance BEFORE the row load of the VGPR path: the compiler's own counted
-// wait for that load (`vmcnt(4)`, the loop's only one) then covers the older DMAs too - in-order counter - without knowing them.
-// Measured and NOT kept: the unique rows by DMA into a ring + LDS -> LDS replication (3.05: the ds_writes stay); three 16-byte
-// stores per four lanes instead of four 12-byte ones (+0.3); skipping the LDS reads of zero-weight slots (LMX_SKIN_FUSED; -6 % on a
-// character-like mesh, +6 % on the worst case, and a second copy of the loop spilled). Non-temporal stores: -0.15 ... -0.75.
+// Staging, two steps. (1) The palette's UNIQUE rows (3 KiB for 64 bones) travel global -> LDS by LDS-DMA, two instances ahead, into a
+// ring of three small buffers: 1-10 instructions per palette, issued by the block's first waves, waited for by those waves only
+// (`vmcnt(5)`: the five stores behind it stay in flight) - the other waves never wait on the vector-memory counter inside the
+// loop, their stores just stream. (2) Late in the instance before its use, every staging lane reads its row from the ring
+// (one ds_read_b128) and writes FOUR of the row's COPIES slots of the replicated palette (4 ds_write_b128).
+// Round 2 fetched the row into a VGPR with a global load at the top of the instance: the wait for it, placed behind four of the
+// lane's stores, was `vmcnt(4)` for EVERY wave - each wave drained the previous instance's stores once per instance.
+// Measured and NOT kept (profiles/r03/skin_ab_*.txt, tools/scratch/r03_dma/): the REPLICATED palette written by LDS-DMA (replication
+// on the source side, no ds_write at all) - the DMA path moves ~12 B per cycle and CU whatever the source, so 48 KiB per instance
+// became the bound (2.83 ms per 1e9 vertices with or without the stores); three 16-byte stores per four lanes instead of four
+// 12-byte ones (+0.3 ms); skipping the LDS reads of bone slots whose weight is zero for a whole wave (LMX_SKIN_FUSED; -6 % on a
+// character-like mesh, +6 % on the worst-case mesh for the dispatch, and a second specialised copy of the loop spilled).
 template <int COPIES, int MODE>
-__device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const SkinChunk& ch, float4 (*s_rows)[SKIN_LDS_SLOTS],
+__device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const SkinChunk& ch, float4 (*s_rows)[SKIN_LDS_SLOTS], float4 (*s_ring)[SHARED_RING_ROWS],
 	const float4* __restrict__ mesh_local, const uint8_t* __restrict__ tile_bones, const float4* __restrict__ palette, float* __restrict__ out) {
-	constexpr uint32_t LPR = COPIES / 4;   // VGPR path: lanes per palette row
-	constexpr uint32_t RPI = 64 / COPIES;  // DMA path: palette rows one instruction covers (1 KiB of LDS)
-	constexpr uint32_t SHARED_WAVES = SHARED_THREADS / 64;
-	constexpr uint32_t MAX_DMA = (SKIN_LDS_SLOTS / 64 + SHARED_WAVES - 1) / SHARED_WAVES; // DMA instructions per wave: <= 3
+	constexpr uint32_t LPR = COPIES / 4; // lanes per palette row in the replication step
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -517,56 +511,33 @@ __device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const 
 	for (int k = 0; k < SHARED_VPT; ++k) vin[k] = load_vertex(mbase, min(ch.v_begin + tid + k * SHARED_THREADS, v_last));
 	// staging plan, the same for every instance: row f of the tile-local palette = row (f % 3) of bone tile_bones[f / 3]
 	const uint32_t n_rows = ch.n_tile_bones * 3u;
-	const uint32_t n_dma = (n_rows * LMX_SHARED_DMA_NUM / LMX_SHARED_DMA_DEN) / RPI; // DMA instructions per palette (whole instructions only)
-	const uint32_t r_dma = n_dma * RPI;                                              // rows [0, r_dma) by DMA, [r_dma, n_rows) through VGPRs
-	auto global_row = [&](uint32_t f) { // float4 index of tile-local row f inside an instance's palette
-		const uint32_t lb = f / 3u;
-		return (uint32_t)tile_bones[ch.bones_at + lb] * 3u + (f - lb * 3u);
-	};
-	uint32_t dma_off[MAX_DMA];
-#pragma unroll
-	for (uint32_t k = 0; k < MAX_DMA; ++k) dma_off[k] = global_row(min((wave + k * SHARED_WAVES) * RPI + lane / COPIES, n_rows - 1)) * (uint32_t)sizeof(float4);
-	const uint32_t f = r_dma + tid / LPR;                // VGPR path: the row this lane fetches and writes four copies of
-	const bool stages = f < n_rows;
-	const uint32_t src_row = global_row(stages ? f : 0u); // (lanes without an item re-fetch row 0: no branch around the load)
-	const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&s_rows[0][0]) + wave * 1024u;
-	const size_t pal_stride = (size_t)in0.n_bones * 3;   // float4 per instance (consecutive instances: consecutive palettes)
+	const uint32_t n_dma = (n_rows + 63u) / 64u;        // wave w < n_dma moves rows [64 w, 64 w + 64)
+	uint32_t src_off = 0;
+	if (wave < n_dma) {
+		const uint32_t r = min(wave * 64u + lane, n_rows - 1);
+		const uint32_t lb = r / 3u;
+		src_off = ((uint32_t)tile_bones[ch.bones_at + lb] * 3u + (r - lb * 3u)) * (uint32_t)sizeof(float4);
+	}
+	const uint32_t ring0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&s_ring[0][0]) + wave * 1024u;
+	const size_t pal_stride = (size_t)in0.n_bones * 3;  // float4 per instance (consecutive instances: consecutive palettes)
 	const float4* pal = palette + (size_t)in0.bone_offset * 3;
-	auto stage_dma = [&](uint32_t instance, uint32_t buffer) {
-		const float4* base = pal + instance * pal_stride;
-		const uint32_t dst = lds0 + buffer * (uint32_t)(SKIN_LDS_SLOTS * sizeof(float4));
-#pragma unroll
-		for (uint32_t k = 0; k < MAX_DMA; ++k) {
-			if (wave + k * SHARED_WAVES < n_dma) lds_dma_16(dma_off[k], base, dst + k * SHARED_WAVES * 1024u); // wave-uniform branch
-		}
-	};
-	auto spread = [&](uint32_t buffer, float4 t) { // palette_spread for row f (rows below r_dma belong to the DMA)
-		if (stages) {
-			const uint32_t q = tid % LPR;
-			const uint32_t rot = COPIES == 4 ? (f >> 1) : LPR * f;
-#pragma unroll
-			for (uint32_t i = 0; i < 4; ++i) s_rows[buffer][f * COPIES + ((q + LPR * i + rot) & (COPIES - 1))] = t;
-		}
-	};
-	F3* obase = reinterpret_cast<F3*>(out) + in0.out_offset;
 	const uint32_t last = ch.count - 1;
-	stage_dma(0, 0);
-	spread(0, pal[src_row]);
-	// every load so far (vertex records, first palette incl. its DMA part, which the compiler does not know) is complete before the
-	// loop; the compiler's s_waitcnt placement merges the loop-entry state into the steady state, and with loads possibly pending
-	// at the entry it tightens the waits INSIDE the loop. vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding).
+	auto fetch_unique = [&](uint32_t instance) { // (past the run's end: its last palette again, into a slot nobody reads)
+		if (wave < n_dma) lds_dma_16(src_off, pal + min(instance, last) * pal_stride, ring0 + (instance % SHARED_RING) * (uint32_t)(SHARED_RING_ROWS * sizeof(float4)));
+	};
+	const uint32_t f = min(tid / LPR, n_rows - 1);      // the row this lane replicates (lanes beyond the palette: palette_spread skips them)
+	auto replicate = [&](uint32_t instance) { palette_spread<COPIES>(s_rows[instance & 1], n_rows, tid, s_ring[instance % SHARED_RING][f]); };
+	F3* obase = reinterpret_cast<F3*>(out) + in0.out_offset;
+	fetch_unique(0);
+	fetch_unique(1);
+	// vertex records and the first two unique palettes have landed before anyone passes the barrier (the DMA is counted by vmcnt
+	// like any load, but not by the compiler: the wait is explicit). vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding).
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
+	replicate(0);
+	__syncthreads();
 	for (uint32_t j = 0; j <= last; ++j) {
-		// Next palette: DMA part first, then the row load of the VGPR part, both BEFORE this instance's stores. Loads, DMA and stores
-		// retire through ONE in-order counter (vmcnt): the wait for the row load, placed after k of the lane's stores, must be
-		// `s_waitcnt vmcnt(k)` - it then covers the row load, the older DMAs and the stores of the previous instance, never this
-		// instance's own. The compiler emits that count only when it can count: no branch around a compiler-visible load or a store
-		// in this loop (lanes past the end of the tile or the palette are clamped, the last instance re-stages its own palette).
-		const uint32_t next = min(j + 1, last);
-		stage_dma(next, (j + 1) & 1);
-		float4 t = pal[next * pal_stride + src_row];
-		__builtin_amdgcn_sched_barrier(0); // the load stays here, ahead of the stores
+		fetch_unique(j + 2); // into the ring slot of palette j - 1, replicated an instance ago
 		const float4* rows = s_rows[j & 1] + col;
 		F3* o = obase + (size_t)j * in0.n_verts;
 #pragma unroll
@@ -587,15 +558,14 @@ __device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const 
 			}
 			__builtin_amdgcn_sched_barrier(0); // one vertex's 12 palette rows (48 VGPRs) in flight at a time
 			if (k == SHARED_SPREAD_AFTER) {
-				// the VGPR part of the next palette goes into the other buffer late in the instance (sooner, the wait for its load
-				// stalls). `t` is used by every lane here: without that its load is sunk into the branch, behind the stores, and
-				// waited for with vmcnt(0). (After the last instance: into the idle buffer, never read.)
-				asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
-				spread((j + 1) & 1, t);
+				replicate(j + 1); // the next instance's palette: ring -> the other replicated buffer (after the last instance: never read)
 				__builtin_amdgcn_sched_barrier(0);
 			}
 		}
-		__syncthreads(); // buffer (j + 1) & 1 is complete for every wave; buffer j & 1 is free for instance j + 2
+		static_assert(SHARED_VPT == 5, "the wait below counts this instance's stores");
+		// only the waves that issued a DMA at the top of this instance wait for it: vmcnt(5) = the five stores behind it stay in flight
+		if (wave < n_dma) __builtin_amdgcn_s_waitcnt(0x0F75);
+		__syncthreads(); // replicated buffer (j + 1) & 1 and ring slot (j + 2) % 3 are complete for every wave
 	}
 }
 
@@ -603,11 +573,12 @@ template <int MODE>
 __global__ __launch_bounds__(SHARED_THREADS) void k_skin_shared(const SkinInstance* __restrict__ inst, const SkinChunk* __restrict__ chunks,
 	const float4* __restrict__ mesh_local, const uint8_t* __restrict__ tile_bones, const float4* __restrict__ palette, float* __restrict__ out) {
 	__shared__ float4 s_rows[2][SKIN_LDS_SLOTS];
+	__shared__ float4 s_ring[SHARED_RING][SHARED_RING_ROWS];
 	const SkinChunk ch = chunks[blockIdx.x];
 	const SkinInstance in0 = inst[ch.first_inst];
-	if (ch.n_tile_bones <= 64) skin_shared_tile<16, MODE>(in0, ch, s_rows, mesh_local, tile_bones, palette, out);
-	else if (ch.n_tile_bones <= 128) skin_shared_tile<8, MODE>(in0, ch, s_rows, mesh_local, tile_bones, palette, out);
-	else skin_shared_tile<4, MODE>(in0, ch, s_rows, mesh_local, tile_bones, palette, out);
+	if (ch.n_tile_bones <= 64) skin_shared_tile<16, MODE>(in0, ch, s_rows, s_ring, mesh_local, tile_bones, palette, out);
+	else if (ch.n_tile_bones <= 128) skin_shared_tile<8, MODE>(in0, ch, s_rows, s_ring, mesh_local, tile_bones, palette, out);
+	else skin_shared_tile<4, MODE>(in0, ch, s_rows, s_ring, mesh_local, tile_bones, palette, out);
 }
 
 } // namespace
