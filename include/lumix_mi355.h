@@ -151,6 +151,9 @@ LMX_API int lmx_cull_read_all(LmxContext* ctx, uint32_t view, uint32_t frustum, 
  * out_counts[LMX_MAX_TYPES] per type), valid until the next lmx_cull_map_all on this view. The copy is enqueued before the count is
  * known, sized from the previous call on this view; a list that outgrew it costs a second wait. */
 LMX_API int lmx_cull_map_all(LmxContext* ctx, uint32_t view, uint32_t frustum, const int32_t** out_ids, uint32_t* out_counts);
+/* The same packed record [LMX_MAX_TYPES counts | ids, types back to back] left in HBM, stream-ordered, NO host wait: "one cull incl.
+ * compaction" for a consumer that stays on the device. Valid until the next lmx_cull_pack_device on this view. */
+LMX_API int lmx_cull_pack_device(LmxContext* ctx, uint32_t view, uint32_t frustum, const int32_t** d_record, uint32_t* record_words);
 /* The same for ALL frusta of the view's last lmx_cull in one go - the frame's views (the reference culls 4 shadow cascades + the main
  * view + a light query per frame, pipeline.cpp:1036-1045, :1252-1258) as one lmx_cull with n_frusta frusta and ONE host wait:
  * out_ids[f] / out_counts[f * LMX_MAX_TYPES + t] per frustum, valid until the next cull or map on this view. */
@@ -196,6 +199,11 @@ LMX_API void lmx_exchange_destroy(LmxExchange* x);
 /* One frame of this rank: lmx_cull(frustum, type) into result slot 0 / 1 (alternating; the views of the same index are used), then
  * the all-gather of its record, asynchronously. *out_slot identifies the frame for the calls below. */
 LMX_API int lmx_exchange_cull(LmxExchange* x, const LmxShiftedFrustum* frustum, uint8_t type, uint32_t* out_slot);
+/* The frame's views in ONE collective: cull n_frusta frusta (<= LMX_MAX_FRUSTA; every rank the same number) in one pass over the rank's
+ * spheres and all-gather n_frusta x [LMX_MAX_TYPES counts | ids_per_rank / n_frusta ids] per rank - config 5's 8 cascades are one
+ * exchange step, not eight. lmx_exchange_cull is the n_frusta = 1 case. lmx_exchange_read_many reads one (rank, frustum) sub-record. */
+LMX_API int lmx_exchange_cull_many(LmxExchange* x, const LmxShiftedFrustum* frusta, uint32_t n_frusta, uint8_t type, uint32_t* out_slot);
+LMX_API int lmx_exchange_read_many(LmxExchange* x, uint32_t slot, int rank, uint32_t frustum, uint32_t* out_counts, int32_t* out_ids, uint32_t cap);
 LMX_API int lmx_exchange_wait(LmxExchange* x, uint32_t slot);
 /* Device view: rank r's record = d_records + r * record_words (counts, then ids). sum(counts) > ids_per_rank means that rank's
  * list was clipped (re-create the exchange with a larger capacity). gathered_event: hipEvent_t recorded after the collective. */

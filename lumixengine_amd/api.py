@@ -112,6 +112,7 @@ SYMBOLS = {
     "lmx_cull_read_all": (_ci, [_vp, _u32, _u32, _vp, _u32, _vp]),
     "lmx_cull_map_all": (_ci, [_vp, _u32, _u32, _vp, _vp]),
     "lmx_cull_map_many": (_ci, [_vp, _u32, _u32, _vp, _vp]),
+    "lmx_cull_pack_device": (_ci, [_vp, _u32, _u32, _vp, _vp]),
     "lmx_cull_device_shards": (_ci, [_vp, _u32, _u32, _vp]),
     "lmx_cull_stats": (_ci, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "lmx_cull": (_ci, [_vp, _u32, _vp, _u32, _u8]),
@@ -124,6 +125,8 @@ SYMBOLS = {
     "lmx_exchange_create": (_ci, [_vp, _ci, _ci, _vp, _u32, C.POINTER(_vp)]),
     "lmx_exchange_destroy": (None, [_vp]),
     "lmx_exchange_cull": (_ci, [_vp, _vp, _u8, C.POINTER(_u32)]),
+    "lmx_exchange_cull_many": (_ci, [_vp, _vp, _u32, _u8, C.POINTER(_u32)]),
+    "lmx_exchange_read_many": (_ci, [_vp, _u32, _ci, _u32, _vp, _vp, _u32]),
     "lmx_exchange_wait": (_ci, [_vp, _u32]),
     "lmx_exchange_result": (_ci, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_vp)]),
     "lmx_exchange_read": (_ci, [_vp, _u32, _ci, _vp, _vp, _u32]),
@@ -471,6 +474,12 @@ class CullingSystem:
     def setPassWidth(self, frusta_per_pass: int):
         self.ctx.check(self.lib.lmx_cull_set_pass_width(self.ctx.h, frusta_per_pass))
 
+    def packDevice(self, view: int = 0, frustum: int = 0):
+        """(device pointer, words) of the packed record [8 counts | ids, types back to back] of the view's last cull - no host wait."""
+        p, n = C.c_void_p(), _u32(0)
+        self.ctx.check(self.lib.lmx_cull_pack_device(self.ctx.h, view, frustum, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
     def cull(self, frusta: np.ndarray, type_: int = TYPE_ALL, view: int = 0) -> CullResult:
         """cull(frustum[, type]); `frusta` may hold up to 8 ShiftedFrustum records tested in one pass."""
         frusta = np.ascontiguousarray(frusta, SHIFTED_FRUSTUM).reshape(-1)
@@ -507,6 +516,22 @@ class VisibleExchange:
         slot = C.c_uint32(0)
         self.ctx.check(self.lib.lmx_exchange_cull(self.h, _ptr(frustum), type_, C.byref(slot)))
         return slot.value
+
+    def cullMany(self, frusta: np.ndarray, type_: int = TYPE_ALL) -> int:
+        """The frame's views (<= 8 frusta, the same number on every rank) in one pass + ONE all-gather; returns the slot."""
+        frusta = np.ascontiguousarray(frusta, SHIFTED_FRUSTUM).reshape(-1)
+        slot = C.c_uint32(0)
+        self.ctx.check(self.lib.lmx_exchange_cull_many(self.h, _ptr(frusta), len(frusta), type_, C.byref(slot)))
+        self._n_frusta = len(frusta)
+        return slot.value
+
+    def readMany(self, slot: int, rank: int, frustum: int):
+        """(counts[8], ids) of one (rank, frustum) sub-record; ids clipped to ids_per_rank // n_frusta."""
+        cap_f = self.cap // max(getattr(self, "_n_frusta", 1), 1)
+        counts = np.zeros(MAX_TYPES, np.uint32)
+        ids = np.zeros(cap_f, np.int32)
+        self.ctx.check(self.lib.lmx_exchange_read_many(self.h, slot, rank, frustum, _ptr(counts), _ptr(ids), cap_f))
+        return counts, ids[: min(int(counts.sum()), cap_f)]
 
     def wait(self, slot: int):
         self.ctx.check(self.lib.lmx_exchange_wait(self.h, slot))

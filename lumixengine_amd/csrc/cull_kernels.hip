@@ -90,9 +90,35 @@ __device__ __forceinline__ uint32_t tile_status_lanes(const TileBox* box, uint32
 // sphere_visible_d() of lmx_math.h on packed fp32: two planes per v_pk_mul_f32 / v_pk_add_f32, every product and sum rounded on its own
 // exactly like the scalar expression ((cx*nx + cy*ny) + cz*nz) + d, then t - (-r) == t + r. The all-test launch was issue-bound (69 % of
 // all SIMD cycles were VALU, profiles/r02/cull_all_test_counters_before_packed_fp32.json); the plane arithmetic is half of its VALU instructions.
+// experiment knobs (tools/cull_sweep.py over build variants; the defaults are what measured best)
+#ifndef LMX_CULL_NT_LOADS
+#define LMX_CULL_NT_LOADS 1   // the streamed spheres / ids are loaded non-temporally in the streaming tile variants (every sphere is read once per cull): cache-cold all-test launch 43.8-44.3 -> 42.8 us, back-to-back 37.0-37.4 -> 37.9 us (profiles/r03/cull_ab_variants.txt)
+#endif
+#ifndef LMX_CULL_MIN3
+#define LMX_CULL_MIN3 0       // 1: `any t < 0` as min(t...) < 0 (fminf ignores NaN like the comparisons do, -0.0 < 0 is false either way): no measurable change
+#endif
+// Measured and NOT kept (profiles/r03/cull_ab_variants.txt): touching the NEXT tile's box / cell keys / chunk headers at block start
+// (global_load_lds into a scratch corner, nothing waits): +2-3 us in every regime, cold included; capping the kernel at 80 SGPRs so
+// that 8 instead of 7 blocks are resident per CU (MI355X_MICROARCH.md "Residency"): within noise.
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const float d[6], float cx, float cy, float cz, float radius) {
 	const v2f x2 = {cx, cx}, y2 = {cy, cy}, z2 = {cz, cz}, r2 = {radius, radius};
+#if LMX_CULL_MIN3
+	v2f tt[3];
+#pragma unroll
+	for (int k = 0; k < 6; k += 2) {
+		const v2f nx = {f.nx[k], f.nx[k + 1]}, ny = {f.ny[k], f.ny[k + 1]}, nz = {f.nz[k], f.nz[k + 1]}, dd = {d[k], d[k + 1]};
+		v2f t = x2 * nx;
+		t = t + y2 * ny;
+		t = t + z2 * nz;
+		t = t + dd;
+		tt[k / 2] = t + r2;
+	}
+	// culled <=> some t < 0 <=> the minimum over the non-NaN t is < 0 (fminf returns the other operand for a NaN, all NaN -> NaN < 0 false)
+	const float m = fminf(fminf(fminf(tt[0].x, tt[0].y), fminf(tt[1].x, tt[1].y)), fminf(tt[2].x, tt[2].y));
+	return !(m < 0);
+#else
 	bool culled = false;
 #pragma unroll
 	for (int k = 0; k < 6; k += 2) {
@@ -105,6 +131,7 @@ __device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const f
 		culled = culled || (t.x < 0) || (t.y < 0);
 	}
 	return !culled;
+#endif
 }
 
 // LDS record of one (cell, frustum): the six cell-relative plane distances of ShiftedFrustum::getRelative and the cell's class
@@ -114,8 +141,17 @@ static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustu
 // F == 1: the single-frustum kernel (the common case: one launch per view). F == 0: n_frusta (2..8) is a runtime value and every
 // per-frustum loop is a real loop, so registers do not scale with the number of frusta (8 unrolled copies needed 172 VGPRs and
 // 600 spilled SGPRs); FS is the stride of a chunk's visibility bits.
+#ifndef LMX_CULL_MAX_SGPR
+#define LMX_CULL_MAX_SGPR 0   // n > 0: cap the kernel's SGPRs (256-thread blocks are admitted 8 per CU only up to 80 SGPRs, 7 at 82-96: MI355X_MICROARCH.md "Residency")
+#endif
+#if LMX_CULL_MAX_SGPR
+#define LMX_CULL_SGPR_ATTR __attribute__((amdgpu_num_sgpr(LMX_CULL_MAX_SGPR)))
+#else
+#define LMX_CULL_SGPR_ATTR
+#endif
+
 template <int F, int WAVES, int CHW, int GRP, int LANEPAR>
-__global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg, const float4* __restrict__ g_spheres, const int32_t* __restrict__ g_ids,
+__global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(const FrustaArg fr_arg, const float4* __restrict__ g_spheres, const int32_t* __restrict__ g_ids,
 	const ChunkHdr* __restrict__ g_hdr, const CellKey* __restrict__ g_tile_cells, const uint32_t* __restrict__ g_tile_tab, const TileBox* __restrict__ g_tile_box,
 	const uint32_t* __restrict__ g_win_base, int32_t* __restrict__ g_out_ids, uint32_t* __restrict__ g_counts, uint32_t* __restrict__ g_counts_next, const TileScalars a) {
 	constexpr uint32_t TILE = WAVES * CHW * 64;
@@ -281,8 +317,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_cull_tile(const FrustaArg fr_arg
 			const uint32_t e = ((chunk0 + g + i) << 6) + lane;
 			id[g + i] = -1;
 			sp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-			if (need_id[i]) id[g + i] = g_ids[e];
-			if (need_sphere[i]) sp[i] = g_spheres[e];
+#if LMX_CULL_NT_LOADS
+			if constexpr (GRP < CHW) { // the streaming variants: every sphere is read once per cull and nothing of it is reused
+				if (need_id[i]) id[g + i] = __builtin_nontemporal_load(g_ids + e);
+				if (need_sphere[i]) {
+					typedef float v4f __attribute__((ext_vector_type(4)));
+					const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g_spheres) + e);
+					sp[i] = make_float4(t.x, t.y, t.z, t.w);
+				}
+			} else
+#endif
+			{
+				if (need_id[i]) id[g + i] = g_ids[e];
+				if (need_sphere[i]) sp[i] = g_spheres[e];
+			}
 		}
 #pragma unroll 1
 		for (int f = 0; f < nf; ++f) {

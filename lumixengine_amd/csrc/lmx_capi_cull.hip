@@ -1070,6 +1070,29 @@ static int cull_map_range(LmxContext* ctx, CullView& v, uint32_t first, uint32_t
 	return LMX_OK;
 }
 
+// The packed record of one frustum left in HBM, no host wait: what a device-side consumer of "one cull incl. compaction" reads
+// (bench.py's timed step; the exchange packs into its own send buffer the same way).
+int lmx_cull_pack_device(LmxContext* ctx, uint32_t view, uint32_t frustum, const int32_t** d_record, uint32_t* record_words) {
+	LMX_CHECK_CTX(ctx);
+	if (view >= LMX_MAX_VIEWS || !d_record) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad view / null output");
+	CullState& cs = ctx->cull;
+	CullView& v = cs.views[view];
+	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
+	if (frustum >= v.n_frusta) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "frustum %u out of range", frustum);
+	const size_t need = (size_t)MAX_TYPES + v.out_stride;
+	if (v.pack_words < need) {
+		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		LMX_HIP(ctx, v.pack_rec.reserve(need + need / 4 + 1024));
+		v.pack_words = need + need / 4 + 1024;
+	}
+	const uint32_t* counts = v.counts_ptr() + (size_t)frustum * cs.n_shards * cs.cnt_pad;
+	LMX_HIP(ctx, launch_cull_pack(ctx->stream, v.out.p + (size_t)frustum * v.out_stride, cs.d_win_base.p, counts, cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, cs.max_shard_cap,
+		reinterpret_cast<uint32_t*>(v.pack_rec.p), v.pack_rec.p + MAX_TYPES, v.out_stride));
+	*d_record = v.pack_rec.p;
+	if (record_words) *record_words = (uint32_t)need;
+	return LMX_OK;
+}
+
 int lmx_cull_map_all(LmxContext* ctx, uint32_t view, uint32_t frustum, const int32_t** out_ids, uint32_t* out_counts) {
 	LMX_CHECK_CTX(ctx);
 	if (view >= LMX_MAX_VIEWS || !out_counts || !out_ids) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad view / null output");

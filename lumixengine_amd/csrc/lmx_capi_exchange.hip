@@ -63,8 +63,9 @@ struct LmxExchange {
 	LmxContext* ctx = nullptr;
 	NcclComm comm = nullptr;
 	int rank = 0, world = 1;
-	uint32_t cap = 0;      // ids per rank record
-	uint32_t record = 0;   // words per rank record = LMX_MAX_TYPES + cap
+	uint32_t cap = 0;      // ids per rank record (all frusta of a frame together)
+	uint32_t record = 0;   // words per rank record of the slot's last frame = n_frusta * (LMX_MAX_TYPES + cap / n_frusta)
+	uint32_t n_frusta[2] = {1, 1}, cap_f[2] = {0, 0}; // layout of each slot's last frame
 	hipStream_t side = nullptr;
 	DevBuf<int32_t> send[2], recv[2];
 	DevBuf<uint32_t> packed_start[2];
@@ -74,6 +75,8 @@ struct LmxExchange {
 };
 
 extern "C" {
+
+void lmx_exchange_destroy(LmxExchange* x);
 
 int lmx_exchange_unique_id(void* out_id_128_bytes) {
 	if (!out_id_128_bytes) return LMX_ERR_INVALID_ARGUMENT;
@@ -88,6 +91,7 @@ int lmx_exchange_unique_id(void* out_id_128_bytes) {
 int lmx_exchange_create(LmxContext* ctx, int rank, int world, const void* unique_id_128_bytes, uint32_t ids_per_rank, LmxExchange** out) {
 	LMX_CHECK_CTX(ctx);
 	if (!out || !unique_id_128_bytes || world < 1 || rank < 0 || rank >= world || ids_per_rank == 0) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad exchange arguments");
+	if (ids_per_rank > 0x7fffffffu - LMX_MAX_FRUSTA * LMX_MAX_TYPES) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "ids_per_rank %u does not fit a 32-bit record", ids_per_rank);
 	Rccl& r = rccl();
 	if (r.error) return fail(ctx, LMX_ERR_NO_DEVICE, "RCCL is not available: %s", r.error);
 	LmxExchange* x = new LmxExchange;
@@ -96,6 +100,8 @@ int lmx_exchange_create(LmxContext* ctx, int rank, int world, const void* unique
 	x->world = world;
 	x->cap = ids_per_rank;
 	x->record = LMX_MAX_TYPES + ids_per_rank;
+	x->cap_f[0] = x->cap_f[1] = ids_per_rank;
+	const size_t max_record = (size_t)MAX_FRUSTA * MAX_TYPES + ids_per_rank; // any split of the capacity over <= 8 frusta fits
 	NcclUniqueId id;
 	memcpy(&id, unique_id_128_bytes, sizeof(id));
 	const int rc = r.CommInitRank(&x->comm, world, id, rank);
@@ -104,13 +110,22 @@ int lmx_exchange_create(LmxContext* ctx, int rank, int world, const void* unique
 		delete x;
 		return fail(ctx, LMX_ERR_HIP, "ncclCommInitRank failed: %s", msg);
 	}
-	LMX_HIP(ctx, hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking));
-	for (int i = 0; i < 2; ++i) {
-		LMX_HIP(ctx, x->send[i].reserve(x->record));
-		LMX_HIP(ctx, x->recv[i].reserve((size_t)x->record * world));
-		LMX_HIP(ctx, x->packed_start[i].reserve(MAX_FRUSTA * MAX_TYPES));
-		LMX_HIP(ctx, hipEventCreateWithFlags(&x->culled[i], hipEventDisableTiming));
-		LMX_HIP(ctx, hipEventCreateWithFlags(&x->gathered[i], hipEventDisableTiming));
+	// from here on a failure must not leak the communicator (the other ranks would be left with a half-alive one), the side stream,
+	// the events or the buffers: everything goes through lmx_exchange_destroy
+	auto setup = [&]() -> int {
+		LMX_HIP(ctx, hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking));
+		for (int i = 0; i < 2; ++i) {
+			LMX_HIP(ctx, x->send[i].reserve(max_record));
+			LMX_HIP(ctx, x->recv[i].reserve(max_record * world));
+			LMX_HIP(ctx, x->packed_start[i].reserve(MAX_FRUSTA * MAX_TYPES));
+			LMX_HIP(ctx, hipEventCreateWithFlags(&x->culled[i], hipEventDisableTiming));
+			LMX_HIP(ctx, hipEventCreateWithFlags(&x->gathered[i], hipEventDisableTiming));
+		}
+		return LMX_OK;
+	};
+	if (int rc2 = setup()) {
+		lmx_exchange_destroy(x);
+		return rc2;
 	}
 	*out = x;
 	return LMX_OK;
@@ -128,33 +143,48 @@ void lmx_exchange_destroy(LmxExchange* x) {
 	delete x;
 }
 
-// One frame of this rank: cull `frustum` over the entities this context holds (result slot = view `slot`), pack the visible ids of
-// all types behind their 8 counts, and enqueue the all-gather of the record on the side stream. Returns the slot (0 / 1) to pass to
-// lmx_exchange_wait / lmx_exchange_result; the slot's previous gather must have been waited for or is waited for here.
-int lmx_exchange_cull(LmxExchange* x, const LmxShiftedFrustum* frustum, uint8_t type, uint32_t* out_slot) {
+// One frame of this rank: cull the frame's n_frusta views (the reference culls its 4 shadow cascades + main view + light query per
+// frame, pipeline.cpp:1036-1045, :1252-1258) over the entities this context holds, in one lmx_cull (result slot = view `slot`), pack
+// every frustum's visible ids behind its 8 counts, and enqueue ONE all-gather of the whole record on the side stream:
+//     rank record = n_frusta x [LMX_MAX_TYPES counts | cap / n_frusta ids, types packed back to back]
+// Every rank must pass the same n_frusta. Returns the slot (0 / 1) to pass to lmx_exchange_wait / lmx_exchange_result; the slot's
+// previous gather must have been waited for or is waited for here.
+int lmx_exchange_cull_many(LmxExchange* x, const LmxShiftedFrustum* frusta, uint32_t n_frusta, uint8_t type, uint32_t* out_slot) {
 	if (!x) return LMX_ERR_INVALID_ARGUMENT;
 	LmxContext* ctx = x->ctx;
 	LMX_CHECK_CTX(ctx);
+	if (n_frusta < 1 || n_frusta > LMX_MAX_FRUSTA) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "n_frusta %u not in [1,%d]", n_frusta, LMX_MAX_FRUSTA);
+	const uint32_t cap_f = x->cap / n_frusta;
+	if (cap_f == 0) return fail(ctx, LMX_ERR_CAPACITY, "%u ids per rank cannot be split over %u frusta", x->cap, n_frusta);
 	const uint32_t k = x->next;
 	x->next ^= 1u;
 	// the send / recv buffers of this slot are free once its previous gather has finished: the cull stream waits for it (device-side)
 	if (x->in_flight[k]) LMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, x->gathered[k], 0));
-	if (int rc = lmx_cull(ctx, k, frustum, 1, type)) return rc;
+	if (int rc = lmx_cull(ctx, k, frusta, n_frusta, type)) return rc;
 	CullState& cs = ctx->cull;
 	CullView& v = cs.views[k];
-	// per-type totals straight into the record's header and the ids behind it (clipped to cap), one launch (k_cull_pack)
-	uint32_t* header = reinterpret_cast<uint32_t*>(x->send[k].p);
-	LMX_HIP(ctx, launch_cull_pack(ctx->stream, v.out.p, cs.d_win_base.p, v.counts_ptr(), cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, cs.max_shard_cap, header,
-		x->send[k].p + MAX_TYPES, x->cap));
+	// per frustum: per-type totals straight into its sub-record's header and the ids behind it (clipped to cap_f), one launch each (k_cull_pack)
+	const uint32_t sub = MAX_TYPES + cap_f;
+	const uint32_t cnt_frustum_stride = cs.n_shards * cs.cnt_pad;
+	for (uint32_t f = 0; f < n_frusta; ++f) {
+		int32_t* rec = x->send[k].p + (size_t)f * sub;
+		LMX_HIP(ctx, launch_cull_pack(ctx->stream, v.out.p + (size_t)f * v.out_stride, cs.d_win_base.p, v.counts_ptr() + (size_t)f * cnt_frustum_stride, cs.cnt_pad, cs.d_shard_type.p,
+			cs.n_shards, cs.max_shard_cap, reinterpret_cast<uint32_t*>(rec), rec + MAX_TYPES, cap_f));
+	}
+	x->n_frusta[k] = n_frusta;
+	x->cap_f[k] = cap_f;
+	x->record = n_frusta * sub;
 	LMX_HIP(ctx, hipEventRecord(x->culled[k], ctx->stream));
 	LMX_HIP(ctx, hipStreamWaitEvent(x->side, x->culled[k], 0));
-	const int rc = rccl().AllGather(x->send[k].p, x->recv[k].p, x->record, NCCL_INT32, x->comm, x->side);
+	const int rc = rccl().AllGather(x->send[k].p, x->recv[k].p, (size_t)n_frusta * sub, NCCL_INT32, x->comm, x->side);
 	if (rc != 0) return fail(ctx, LMX_ERR_HIP, "ncclAllGather failed: %s", rccl().GetErrorString ? rccl().GetErrorString(rc) : "?");
 	LMX_HIP(ctx, hipEventRecord(x->gathered[k], x->side));
 	x->in_flight[k] = true;
 	if (out_slot) *out_slot = k;
 	return LMX_OK;
 }
+
+int lmx_exchange_cull(LmxExchange* x, const LmxShiftedFrustum* frustum, uint8_t type, uint32_t* out_slot) { return lmx_exchange_cull_many(x, frustum, 1, type, out_slot); }
 
 // Host wait for the gather of `slot` (a consumer on another stream can instead make that stream wait: lmx_exchange_result's event).
 int lmx_exchange_wait(LmxExchange* x, uint32_t slot) {
@@ -171,24 +201,30 @@ int lmx_exchange_wait(LmxExchange* x, uint32_t slot) {
 int lmx_exchange_result(LmxExchange* x, uint32_t slot, const int32_t** d_records, uint32_t* record_words, void** gathered_event) {
 	if (!x || slot > 1) return LMX_ERR_INVALID_ARGUMENT;
 	if (d_records) *d_records = x->recv[slot].p;
-	if (record_words) *record_words = x->record;
+	if (record_words) *record_words = x->n_frusta[slot] * (MAX_TYPES + x->cap_f[slot]);
 	if (gathered_event) *gathered_event = x->gathered[slot];
 	return LMX_OK;
 }
 
-// Host copy of one rank's record: counts[LMX_MAX_TYPES] and min(sum(counts), ids_per_rank, cap) ids. Waits for the gather.
-int lmx_exchange_read(LmxExchange* x, uint32_t slot, int rank, uint32_t* out_counts, int32_t* out_ids, uint32_t cap) {
-	if (!x || slot > 1 || rank < 0 || rank >= x->world || !out_counts) return LMX_ERR_INVALID_ARGUMENT;
+// Host copy of one (rank, frustum) sub-record of `slot`: counts[LMX_MAX_TYPES] and min(sum(counts), ids per frustum, cap) ids. Waits for
+// the gather. (A clipped list is visible as sum(counts) > the slot's ids per frustum = ids_per_rank / n_frusta.)
+int lmx_exchange_read_many(LmxExchange* x, uint32_t slot, int rank, uint32_t frustum, uint32_t* out_counts, int32_t* out_ids, uint32_t cap) {
+	if (!x || slot > 1 || rank < 0 || rank >= x->world || !out_counts || frustum >= x->n_frusta[slot]) return LMX_ERR_INVALID_ARGUMENT;
 	LmxContext* ctx = x->ctx;
 	LMX_CHECK_CTX(ctx);
 	if (int rc = lmx_exchange_wait(x, slot)) return rc;
-	const int32_t* rec = x->recv[slot].p + (size_t)rank * x->record;
+	const uint32_t sub = MAX_TYPES + x->cap_f[slot];
+	const int32_t* rec = x->recv[slot].p + (size_t)rank * x->n_frusta[slot] * sub + (size_t)frustum * sub;
 	LMX_HIP(ctx, hipMemcpy(out_counts, rec, sizeof(uint32_t) * MAX_TYPES, hipMemcpyDeviceToHost));
 	uint64_t total = 0;
 	for (int t = 0; t < MAX_TYPES; ++t) total += out_counts[t];
-	const uint32_t n = (uint32_t)std::min<uint64_t>(total, std::min(x->cap, cap));
+	const uint32_t n = (uint32_t)std::min<uint64_t>(total, std::min(x->cap_f[slot], cap));
 	if (n && out_ids) LMX_HIP(ctx, hipMemcpy(out_ids, rec + MAX_TYPES, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
 	return LMX_OK;
+}
+
+int lmx_exchange_read(LmxExchange* x, uint32_t slot, int rank, uint32_t* out_counts, int32_t* out_ids, uint32_t cap) {
+	return lmx_exchange_read_many(x, slot, rank, 0, out_counts, out_ids, cap);
 }
 
 } // extern "C"

@@ -71,6 +71,8 @@ struct CullView {
 	size_t map_frusta = 0;   // record areas the buffers were sized for
 	DevBuf<int32_t> map_rec;
 	DevBuf<uint32_t> map_pref, map_start;
+	DevBuf<int32_t> pack_rec; // lmx_cull_pack_device: the packed record of one frustum, left on the device
+	size_t pack_words = 0;
 	~CullView() { if (map_host) (void)hipHostFree(map_host); }
 	CullView() = default;
 	CullView(const CullView&) = delete;

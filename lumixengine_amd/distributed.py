@@ -72,3 +72,24 @@ def parse_records(records: np.ndarray, ids_per_rank: int) -> Tuple[List[List[np.
 def merge_ranks(parsed: List[List[np.ndarray]]) -> List[np.ndarray]:
     """Per type: concatenation over ranks = the global visible list (compare as a sorted set)."""
     return [np.concatenate([rank[t] for rank in parsed]) if parsed else np.zeros(0, np.int32) for t in range(MAX_TYPES)]
+
+
+def make_frame_record(ids_by_frustum_and_type: List[List[np.ndarray]], ids_per_rank: int) -> np.ndarray:
+    """One rank's record of a FRAME of n_frusta views as lmx_exchange_cull_many writes it: n_frusta sub-records
+    [MAX_TYPES counts | ids_per_rank // n_frusta ids], one collective for all of them (config 5: 8 cascades = one all-gather)."""
+    n = len(ids_by_frustum_and_type)
+    cap_f = ids_per_rank // n
+    return np.concatenate([make_record(by_type, cap_f) for by_type in ids_by_frustum_and_type])
+
+
+def parse_frame_records(records: np.ndarray, n_frusta: int, ids_per_rank: int):
+    """all-gathered frame records -> (ids[frustum][rank][type], overflowed)."""
+    cap_f = ids_per_rank // n_frusta
+    sub = MAX_TYPES + cap_f
+    records = np.asarray(records).reshape(-1, n_frusta, sub)
+    out, overflowed = [], False
+    for f in range(n_frusta):
+        parsed, over = parse_records(records[:, f, :], cap_f)
+        out.append(parsed)
+        overflowed |= over
+    return out, overflowed

@@ -133,6 +133,27 @@ def skinned_mesh(n_verts: int, n_bones: int = 64, seed: int = 6):
     return verts, skin
 
 
+def skinned_mesh_character(n_verts: int, n_bones: int = 52, seed: int = 6, run: int = 190, second_every: int = 6):
+    """A mesh with the skinning statistics of a real character instead of skinned_mesh()'s worst case: consecutive vertices follow one
+    bone (`run` vertices per bone: a limb at a time), every `second_every`-th vertex is also influenced by the neighbouring bone,
+    influences are sorted by weight and zero-padded. The reference's demo character (demo/models/ybot/ybot.fbx, read with the OpenFBX
+    the reference vendors: tools/fbx_skin_stats.cpp) has 52 bones, 1.0-1.2 influences per control point, and a tile of 5120 consecutive
+    control points touches 13.5-15.7 bones on average, 24-27 at most - this generator sits at the upper end (27-28 per tile)."""
+    rng = np.random.default_rng(seed)
+    verts = rng.uniform(-1.0, 1.0, size=(n_verts, 3)).astype(np.float32)
+    v = np.arange(n_verts)
+    b0 = (v // run) % n_bones
+    b1 = (b0 + 1) % n_bones
+    two = (v % second_every) == 0
+    w1 = np.where(two, rng.uniform(0.1, 0.5, size=n_verts), 0.0)
+    w16 = np.stack([np.round((1.0 - w1) * 65535.0), np.round(w1 * 65535.0), np.zeros(n_verts), np.zeros(n_verts)], axis=1)
+    skin = np.zeros(n_verts, SKIN)
+    skin["weights"] = (w16.astype(np.float32) / np.float32(65535.0)).astype(np.float32)
+    skin["indices"][:, 0] = b0
+    skin["indices"][:, 1] = np.where(two, b1, 0)
+    return verts, skin
+
+
 def keys_scene(n_entities: int, types: np.ndarray, seed: int = 11, n_models: int = 6, max_sort_key: int = 63):
     """Model-instance / material tables for createSortKeys over `n_entities` entities whose renderable types are `types`:
     models with 1-4 LODs of 1-3 meshes (some skinned), per-entity material spans, LOD state in [0, 4], MOVED / dirty flags.

@@ -61,6 +61,24 @@ def _worker(rank, world, port, out_dir):
             merged = D.merge_ranks(parsed)
             for k in range(D.MAX_TYPES):
                 out[f"f{f}_t{k}"] = merged[k]
+        # the frame's views in ONE collective (lmx_exchange_cull_many): n_frusta sub-records of ids_per_rank // n_frusta ids each
+        per_frustum = []
+        for f in range(len(fr)):
+            v, t, _ = cs.cull(fr[f : f + 1])
+            per_frustum.append([v[t == k] for k in range(D.MAX_TYPES)])
+        cap = (max(sum(len(a) for a in bt) for bt in per_frustum) * 5 // 4 + 8) * len(fr)
+        t_cap = torch.tensor([cap], dtype=torch.int64)
+        dist.all_reduce(t_cap, op=dist.ReduceOp.MAX)  # every rank the same capacity (bench.py: all_reduce MAX of the probe counts)
+        cap = int(t_cap.item())
+        send = torch.from_numpy(D.make_frame_record(per_frustum, cap))
+        recv = torch.empty(world * len(send), dtype=torch.int32)
+        dist.all_gather_into_tensor(recv, send)
+        frame, overflowed = D.parse_frame_records(recv.numpy(), len(fr), cap)
+        assert not overflowed and len(frame) == len(fr) and all(len(p) == world for p in frame)
+        for f in range(len(fr)):
+            merged = D.merge_ranks(frame[f])
+            for k in range(D.MAX_TYPES):
+                assert np.array_equal(np.sort(merged[k]), np.sort(out[f"f{f}_t{k}"])), "one collective per frame != one collective per view"
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
     finally:
         dist.destroy_process_group()

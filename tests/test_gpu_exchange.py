@@ -36,6 +36,19 @@ def test_exchange_single_rank_matches_oracle(gpu_ctx, oracle_port):
                 assert not over
                 for t in range(8):
                     assert np.array_equal(np.sort(parsed[0][t]), want[(frame - 1) % len(cams)][t]), (frame, t)
+        # the frame's views in ONE collective (config 5: the cascades of a frame are one exchange step): n sub-records of cap // n ids
+        big = api.VisibleExchange(gpu_ctx, 0, 1, api.exchange_unique_id(), cap * len(cams))
+        try:
+            for frame in range(3):  # both slots, the third re-uses the first
+                slot_m = big.cullMany(cams)
+                for f in range(len(cams)):
+                    counts, ids = big.readMany(slot_m, 0, f)
+                    at = 0
+                    for t in range(8):
+                        assert int(counts[t]) == len(want[f][t]) and np.array_equal(np.sort(ids[at : at + int(counts[t])]), want[f][t]), (frame, f, t)
+                        at += int(counts[t])
+        finally:
+            big.close()
         # type filter
         slot = x.cull(cams[0], 2)
         counts, ids = x.read(slot, 0)

@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--settings", default="all", help="all | best: only variants 0 and 1 with the lane-parallel tile test")
+    ap.add_argument("--variants", default="", help="comma-separated tile variants to run with the default tile test (overrides --settings), e.g. 1,4")
+    ap.add_argument("--no-coldw", action="store_true", help="skip the dirty-scrub leg")
+    ap.add_argument("--tag", default="", help="label copied into every record (e.g. the build variant behind LMX_LIB_PATH)")
     args = ap.parse_args()
     import torch
 
@@ -70,6 +73,7 @@ def main():
     cams = {
         "default": api.viewport_frustum(),
         "all_visible": api.viewport_frustum(pos=(0.0, 0.0, 4.0 * half), far=20.0 * half),
+        "nothing": api.viewport_frustum(pos=(0.0, 0.0, -5.0 * half)),  # looks away from the scene: every tile ends at the tile-level test
     }
 
     for scene_name in ("sparse", "all_test"):
@@ -84,12 +88,14 @@ def main():
         for _ in range(300 if N <= 20_000_000 else 20):
             cs.cull(cams["default"])
         ctx.synchronize()
-        legs = [("default", cams["default"])] + ([("all_visible", cams["all_visible"])] if scene_name == "sparse" else [])
+        legs = [("default", cams["default"])] + ([("all_visible", cams["all_visible"]), ("nothing", cams["nothing"])] if scene_name == "sparse" else [])
         settings = []
         for variant in ((0, 1, 3, 4, 5) if args.settings == "best" else (0, 1, 2, 3, 4, 5)):
             for lanepar in ((1,) if args.settings == "best" else (1, 0)):
                 settings.append(dict(variant=variant, lanepar=lanepar, shards=64, pad=32))
-        if not args.quick:
+        if args.variants:
+            settings = [dict(variant=int(v), lanepar=2, shards=64, pad=32) for v in args.variants.split(",")]
+        if not args.quick and not args.variants:
             for shards, pad in ((1, 32), (8, 32), (16, 32), (64, 1), (64, 16)):
                 settings.append(dict(variant=0, lanepar=1, shards=shards, pad=pad))
                 settings.append(dict(variant=1, lanepar=1, shards=shards, pad=pad))
@@ -102,10 +108,10 @@ def main():
                 for _ in range(5):
                     res = cs.cull(fr)
                 vis = int(res.counts()[0].sum())
-                rec = dict(scene=scene_name, leg=leg, visible=vis, **st)
+                rec = dict(tag=args.tag, scene=scene_name, leg=leg, visible=vis, **st)
                 rec["warm_kernel_us"] = 1e3 * kernel_ms(cs, fr, args.reps, cold=None)
                 rec["cold_kernel_us"] = 1e3 * kernel_ms(cs, fr, max(10, args.reps // 2), cold="r")
-                rec["coldw_kernel_us"] = 1e3 * kernel_ms(cs, fr, max(10, args.reps // 2), cold="w")
+                rec["coldw_kernel_us"] = float("nan") if args.no_coldw else 1e3 * kernel_ms(cs, fr, max(10, args.reps // 2), cold="w")
                 rec["wall_us"] = 1e3 * wall_ms(cs, fr, args.reps * (5 if N <= 20_000_000 else 1))
                 if scene_name == "all_test":
                     moved = 20.0 * N + 4.0 * vis
