@@ -87,6 +87,54 @@ __device__ __forceinline__ uint32_t tile_status_lanes(const TileBox* box, uint32
 	return (__ballot(plane_lane && !in) == 0 ? TILE_ACCEPT : TILE_MIXED) | hi;
 }
 
+// tile_status() for up to 8 frusta at once: lane 6 f + k evaluates plane k of frustum f (<= 48 lanes), every lane forms the box
+// corners of ITS frustum itself (fp64 shift, one rounding: the expressions of tile_status(), no cross-lane traffic), the per-frustum
+// verdicts come out of two ballots. ~110 instructions for one wave instead of ~300 uniform ones per frustum for every wave: with the
+// per-frustum loop a launch of the 8-cascade pass spent most of its instructions here. Returns 2 status bits per frustum; *flags = the
+// tile's flags.
+__device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, uint32_t lane, int nf, uint32_t* flags_out) {
+	const float* ka = (const float*)__builtin_amdgcn_kernarg_segment_ptr();
+	const int32_t* bi = reinterpret_cast<const int32_t*>(box);
+	const uint32_t flags = (uint32_t)bi[6];
+	*flags_out = flags;
+	if (flags & TILE_EMPTY) return 0u; // TILE_REJECT == 0 for every frustum
+	uint32_t all_mixed = 0;
+	for (int f = 0; f < nf; ++f) all_mixed |= (uint32_t)TILE_MIXED << (2 * f);
+	if (flags & TILE_HAS_BIG) return all_mixed;
+	const uint32_t f = lane / 6u < (uint32_t)nf ? lane / 6u : (uint32_t)nf - 1u, k = lane % 6u;
+	const bool plane_lane = lane < (uint32_t)nf * 6u;
+	const float* fr = ka + f * (uint32_t)(sizeof(DevFrustum) / sizeof(float));
+	const float nx = fr[KA_NX + k], ny = fr[KA_NY + k], nz = fr[KA_NZ + k], d = fr[KA_D + k];
+	const double* org = reinterpret_cast<const double*>(fr + KA_ORIGIN);
+	const double cs = (double)CELL_SIZE;
+	const double ox = org[0], oy = org[1], oz = org[2];
+	const float lx = (float)(cs * bi[0] - cs - ox), ly = (float)(cs * bi[1] - cs - oy), lz = (float)(cs * bi[2] - cs - oz);
+	const float hx = (float)(cs * bi[3] + cs - ox), hy = (float)(cs * bi[4] + cs - oy), hz = (float)(cs * bi[5] + cs - oz);
+	const float clx = (float)(cs * bi[0] + cs - ox), cly = (float)(cs * bi[1] + cs - oy), clz = (float)(cs * bi[2] + cs - oz);
+	const float chx = (float)(cs * bi[3] + 2 * cs - ox), chy = (float)(cs * bi[4] + 2 * cs - oy), chz = (float)(cs * bi[5] + 2 * cs - oz);
+	const float b1 = max_f(abs_f(lx), abs_f(chx)) + max_f(abs_f(ly), abs_f(chy)) + max_f(abs_f(lz), abs_f(chz));
+	const float n1 = abs_f(nx) + abs_f(ny) + abs_f(nz);
+	const float margin = max_f(1.0f, n1) * (2.0f + 4e-6f * b1) + 1e-6f * abs_f(d);
+	bool rej, in;
+	{
+		const float bx = nx > 0.0f ? hx : lx, by = ny > 0.0f ? hy : ly, bz = nz > 0.0f ? hz : lz;
+		const float dp = (nx * bx) + (ny * by) + (nz * bz);
+		rej = dp < -d - margin;
+	}
+	{
+		const float bx = nx < 0.0f ? chx : clx, by = ny < 0.0f ? chy : cly, bz = nz < 0.0f ? chz : clz;
+		const float dp = (nx * bx) + (ny * by) + (nz * bz);
+		in = dp > -d + margin;
+	}
+	const uint64_t rej_mask = __ballot(plane_lane && rej), out_mask = __ballot(plane_lane && !in);
+	uint32_t st_bits = 0;
+	for (int g = 0; g < nf; ++g) {
+		const uint32_t r = (uint32_t)(rej_mask >> (6 * g)) & 63u, o = (uint32_t)(out_mask >> (6 * g)) & 63u;
+		st_bits |= (r != 0 ? (uint32_t)TILE_REJECT : (o == 0 ? (uint32_t)TILE_ACCEPT : (uint32_t)TILE_MIXED)) << (2 * g);
+	}
+	return st_bits;
+}
+
 // sphere_visible_d() of lmx_math.h on packed fp32: two planes per v_pk_mul_f32 / v_pk_add_f32, every product and sum rounded on its own
 // exactly like the scalar expression ((cx*nx + cy*ny) + cz*nz) + d, then t - (-r) == t + r. The all-test launch was issue-bound (69 % of
 // all SIMD cycles were VALU, profiles/r02/cull_all_test_counters_before_packed_fp32.json); the plane arithmetic is half of its VALU instructions.
@@ -197,12 +245,22 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 		any_mixed = st_bits == TILE_MIXED;
 		any_live = st_bits != TILE_REJECT;
 	} else {
-		const TileBox box = g_tile_box[tile_index];
-		tile_flags = box.flags;
+		// several frusta: wave 0 evaluates every (frustum, plane) pair on its own lane and hands the verdicts to the other waves
+		__shared__ uint32_t s_verdict_multi[2];
+		if (wave == 0) {
+			uint32_t fl;
+			const uint32_t v = tile_status_lanes_multi(g_tile_box + tile_index, lane, nf, &fl);
+			if (lane == 0) {
+				s_verdict_multi[0] = v;
+				s_verdict_multi[1] = fl;
+			}
+		}
+		__syncthreads();
+		st_bits = __builtin_amdgcn_readfirstlane(s_verdict_multi[0]);
+		tile_flags = __builtin_amdgcn_readfirstlane(s_verdict_multi[1]);
 #pragma unroll 1
 		for (int f = 0; f < nf; ++f) {
-			const uint32_t st = tile_status(frp[f], box);
-			st_bits |= st << (2 * f);
+			const uint32_t st = (st_bits >> (2 * f)) & 3u;
 			any_mixed |= st == TILE_MIXED;
 			any_live |= st != TILE_REJECT;
 		}
@@ -215,28 +273,38 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 		first_cell = g_tile_tab[2 * tile_index];
 		const uint32_t n_cells = g_tile_tab[2 * tile_index + 1];
 		const CellKey* keys = g_tile_cells + (size_t)tile_index * a.cell_cap;
-		for (uint32_t t = threadIdx.x; t < a.cell_cap; t += THREADS) {
-			const CellKey key = keys[t]; // issued before n_cells is known; the tail of the slice holds dead keys
-			if (t < n_cells) {
-				const bool dead = (key.meta & CELL_DEAD) != 0;
-				const bool big = (key.meta & 0x100u) != 0;
-#pragma unroll 1
-				for (int f = 0; f < nf; ++f) {
-					CellInfo ci;
-					ci.cls = CELL_REJECT;
-					ci.pad = 0;
+		auto classify = [&](uint32_t t, int f, const CellKey key) {
+			const bool dead = (key.meta & CELL_DEAD) != 0;
+			const bool big = (key.meta & 0x100u) != 0;
+			CellInfo ci;
+			ci.cls = CELL_REJECT;
+			ci.pad = 0;
 #pragma unroll
-					for (int k = 0; k < 6; ++k) ci.d[k] = 0.f;
-					if (!dead) {
-						V3 off;
-						ci.cls = classify_cell(frp[f], IV3{key.ix, key.iy, key.iz}, big, &off);
-						if (ci.cls == CELL_TEST) {
+			for (int k = 0; k < 6; ++k) ci.d[k] = 0.f;
+			if (!dead) {
+				V3 off;
+				ci.cls = classify_cell(frp[f], IV3{key.ix, key.iy, key.iz}, big, &off);
+				if (ci.cls == CELL_TEST) {
 #pragma unroll
-							for (int k = 0; k < 6; ++k) ci.d[k] = relative_plane_d(frp[f], off, k);
-						}
-					}
-					s_info[f * a.cell_cap + t] = ci;
+					for (int k = 0; k < 6; ++k) ci.d[k] = relative_plane_d(frp[f], off, k);
 				}
+			}
+			s_info[f * a.cell_cap + t] = ci;
+		};
+		if constexpr (F == 1) {
+			for (uint32_t t = threadIdx.x; t < a.cell_cap; t += THREADS) {
+				const CellKey key = keys[t]; // issued before n_cells is known; the tail of the slice holds dead keys
+				if (t < n_cells) classify(t, 0, key);
+			}
+		} else {
+			// Several frusta: the (cell, frustum) pairs are spread over the WAVES - a wave (or a group of waves) takes one frustum at a
+			// time, so the frustum stays wave-uniform (scalar loads) - and only the frusta whose tile verdict is MIXED are classified at
+			// all: a REJECTED / ACCEPTED frustum needs no per-cell work (phase B reads its verdict from st_bits). One thread per cell
+			// looping over all frusta kept ~100 of a block's 256-512 lanes busy for 8 x ~300 instructions: more than the spheres' own test.
+			const uint32_t wpf = (uint32_t)nf >= (uint32_t)WAVES ? 1u : (uint32_t)WAVES / (uint32_t)nf; // waves per frustum
+			for (uint32_t f = wave / wpf; f < (uint32_t)nf; f += (uint32_t)WAVES / wpf) {
+				if (((st_bits >> (2 * f)) & 3u) != TILE_MIXED) continue;
+				for (uint32_t t = (wave % wpf) * 64u + lane; t < n_cells; t += wpf * 64u) classify(t, (int)f, keys[t]);
 			}
 		}
 		// one barrier per MIXED tile. (A block-wide vote "does any cell survive" would let such a tile end here, but costs two more
@@ -301,6 +369,14 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 				local[i] = h.cell + mbcnt64(h.flags >> 1) - first_cell; // cell boundaries at positions 1..lane: two v_mbcnt on a wave-uniform mask
 #pragma unroll 1
 				for (int f = 0; f < nf; ++f) {
+					if constexpr (F != 1) { // frusta the tile-level test settled carry no per-cell records
+						const uint32_t st = (st_bits >> (2 * f)) & 3u;
+						if (st == TILE_REJECT) continue;
+						if (st == TILE_ACCEPT) {
+							lane_live = true;
+							continue;
+						}
+					}
 					const uint32_t cls = s_info[f * a.cell_cap + local[i]].cls;
 					lane_live |= cls != CELL_REJECT;
 					lane_test |= cls == CELL_TEST;
@@ -335,11 +411,14 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 #pragma unroll 1
 		for (int f = 0; f < nf; ++f) {
 			const uint32_t st = (st_bits >> (2 * f)) & 3u;
+			if constexpr (F != 1) {
+				if (st == TILE_REJECT) continue; // nothing of this tile is visible in frustum f
+			}
 #pragma unroll
 			for (int i = 0; i < GRP; ++i) {
 				if (!need_id[i]) continue;
 				bool vis;
-				if (any_mixed) {
+				if (any_mixed && (F == 1 || st == TILE_MIXED)) {
 					const CellInfo* ci = &s_info[f * a.cell_cap + local[i]];
 					const uint32_t cls = ci->cls;
 					vis = cls == CELL_ACCEPT;
