@@ -147,7 +147,9 @@ __device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, 
 #endif
 // Measured and NOT kept (profiles/r03/cull_ab_variants.txt): touching the NEXT tile's box / cell keys / chunk headers at block start
 // (global_load_lds into a scratch corner, nothing waits): +2-3 us in every regime, cold included; capping the kernel at 80 SGPRs so
-// that 8 instead of 7 blocks are resident per CU (MI355X_MICROARCH.md "Residency"): within noise.
+// that 8 instead of 7 blocks are resident per CU (MI355X_MICROARCH.md "Residency"): within noise; a persistent grid for the streaming
+// launches (1628 resident blocks x 3 tiles each: no ragged last round, one block start-up per 3 tiles): 67 instead of 42 VGPRs for
+// the loop around the tile body, all-test launch 37.3 -> 43.5 us back to back, 43.0 -> 47.9 us cache-cold.
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const float d[6], float cx, float cy, float cz, float radius) {

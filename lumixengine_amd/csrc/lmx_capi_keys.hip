@@ -35,6 +35,9 @@ int lmx_keys_set_models(LmxContext* ctx, const LmxKeysModel* models, uint32_t n_
 			max_span = std::max<uint32_t>(max_span, (uint32_t)(li.to - li.from + 1));
 		}
 	}
+	// k_keys_mesh scans a lane's (pairs, records) counts as two 16-bit fields of one word: 64 lanes x 2 x span must stay below 2^16.
+	// Checked BEFORE anything is uploaded or assigned: a refused table leaves the previous one in place.
+	if (max_span > 511) return fail(ctx, LMX_ERR_CAPACITY, "a LOD range of %u meshes exceeds the 511 the key kernel's packed scan holds", max_span);
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (int rc = upload(ctx, ks.d_models, models, n_models)) return rc;
 	if (int rc = upload(ctx, ks.d_mesh_types, mesh_types, n_meshes)) return rc;
@@ -42,8 +45,6 @@ int lmx_keys_set_models(LmxContext* ctx, const LmxKeysModel* models, uint32_t n_
 	ks.models.assign(models, models + n_models);
 	ks.mesh_types.assign(mesh_types, mesh_types + n_meshes);
 	ks.n_meshes = n_meshes;
-	// k_keys_mesh scans a lane's (pairs, records) counts as two 16-bit fields of one word: 64 lanes x 2 x span must stay below 2^16
-	if (max_span > 511) return fail(ctx, LMX_ERR_CAPACITY, "a LOD range of %u meshes exceeds the 511 the key kernel's packed scan holds", max_span);
 	ks.max_lod_span = max_span;
 	return LMX_OK;
 }

@@ -208,6 +208,38 @@ static int world_stage(LmxContext* ctx, uint32_t n, const int32_t* entity, const
 	if (!entity || !transforms) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
 	for (uint32_t i = 0; i < n; ++i)
 		if (entity[i] < 0 || (uint32_t)entity[i] >= w.n) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity[%u] = %d out of range", i, entity[i]);
+	// The scatter kernel runs one thread per record: two records of ONE entity in a batch would race (SoA components of the two mixed).
+	// The reference applies writes one by one - the last one wins - so only the last record of an entity is staged.
+	std::vector<int32_t> ent_dedup;
+	std::vector<LmxTransform> tr_dedup;
+	{
+		if (w.stage_mark.size() < w.n) w.stage_mark.assign(w.n, 0);
+		const uint32_t stamp = ++w.stage_stamp;
+		if (stamp == 0) { // wrapped
+			std::fill(w.stage_mark.begin(), w.stage_mark.end(), 0u);
+			w.stage_stamp = 1;
+		}
+		bool dup = false;
+		for (uint32_t i = 0; i < n && !dup; ++i) {
+			dup = w.stage_mark[entity[i]] == w.stage_stamp;
+			w.stage_mark[entity[i]] = w.stage_stamp;
+		}
+		if (dup) {
+			const uint32_t stamp2 = ++w.stage_stamp;
+			(void)stamp2;
+			ent_dedup.reserve(n);
+			tr_dedup.reserve(n);
+			for (uint32_t i = n; i-- > 0;) { // from the back: the first record seen of an entity is its last write
+				if (w.stage_mark[entity[i]] == w.stage_stamp) continue;
+				w.stage_mark[entity[i]] = w.stage_stamp;
+				ent_dedup.push_back(entity[i]);
+				tr_dedup.push_back(transforms[i]);
+			}
+			entity = ent_dedup.data();
+			transforms = tr_dedup.data();
+			n = (uint32_t)ent_dedup.size();
+		}
+	}
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // staging buffers may still be read by a previous scatter
 	LMX_HIP(ctx, w.d_stage_entity.reserve(n));
 	LMX_HIP(ctx, w.d_stage_tr.reserve(n));

@@ -187,6 +187,8 @@ struct WorldState {
 	DevBuf<int32_t> d_stage_entity;
 	DevBuf<LmxTransform> d_stage_tr;
 	DevBuf<LmxTransform> d_export;
+	std::vector<uint32_t> stage_mark; // per entity: the staging call that last wrote it (duplicate detection, last write wins)
+	uint32_t stage_stamp = 0;
 	// the moved list of the last propagation(s) (lmx_world_track_moved / lmx_world_read_moved)
 	bool track_moved = false;
 	DevBuf<int32_t> d_moved_entity;

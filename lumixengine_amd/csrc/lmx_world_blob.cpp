@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "lumix_mi355.h"
@@ -78,6 +79,7 @@ long lz4_block_decode(const uint8_t* src, size_t src_size, uint8_t* dst, size_t 
 struct Parsed {
 	LmxWorldBlobInfo info;
 	std::vector<uint8_t> blob;
+	std::vector<std::string> module_names; // serializeModuleList, world.cpp:780-786: what the payload section may contain, in any order
 	size_t entities_at = 0, hierarchy_at = 0;
 	bool partitions = false;
 };
@@ -93,8 +95,12 @@ int parse(const void* data, size_t size, Parsed& out) {
 	out.info.version = version;
 	const int32_t n_modules = in.read<int32_t>(); // serializeModuleList, world.cpp:780-786
 	if (n_modules < 0) return LMX_ERR_INVALID_ARGUMENT;
-	for (int32_t i = 0; i < n_modules; ++i)
+	out.module_names.clear();
+	for (int32_t i = 0; i < n_modules; ++i) {
+		const size_t from = in.pos;
 		if (!in.skip_string()) return LMX_ERR_INVALID_ARGUMENT;
+		out.module_names.emplace_back(reinterpret_cast<const char*>(in.p + from));
+	}
 	out.info.n_modules = (uint32_t)n_modules;
 	out.info.flags = in.read<uint32_t>();
 	out.partitions = (out.info.flags & WORLD_HAS_PARTITIONS) != 0;
@@ -147,9 +153,28 @@ struct RenderParsed {
 	size_t paths_at = 0, instances_at = 0, attachments_at = 0;
 };
 
+// true when `at` is where a module payload may end: the end of the blob or the header of another module of the file's module list
+// (its name as a NUL-terminated string followed by a plausible i32 version)
+bool at_module_boundary(const Parsed& p, size_t at) {
+	if (at == p.blob.size()) return true;
+	for (const std::string& n : p.module_names) {
+		const size_t len = n.size();
+		if (at + len + 1 + 4 > p.blob.size() || memcmp(p.blob.data() + at, n.c_str(), len + 1) != 0) continue;
+		int32_t v;
+		memcpy(&v, p.blob.data() + at + len + 1, 4);
+		if (v >= 0 && v <= 255) return true;
+	}
+	return false;
+}
+
 // Module payloads carry no size: a module is found by its header - the name as a NUL-terminated string (preceded by the i32
-// module count or by the previous payload) followed by a plausible i32 version.
+// module count or by the previous payload) followed by a plausible i32 version. A byte sequence inside an earlier payload can look
+// like one: the scan only accepts names the file's own module list holds, and the renderer walk below re-checks that the payload it
+// walked ENDS on a module boundary (a false start would have to end on one too).
 bool find_module(const Parsed& p, const char* name, size_t* payload_at, int32_t* version) {
+	bool listed = false;
+	for (const std::string& n : p.module_names) listed |= n == name;
+	if (!listed) return false;
 	Reader s{p.blob.data(), p.blob.size(), p.hierarchy_at};
 	s.skip((size_t)p.info.n_hierarchy * (16 + 24 + 16 + 12));
 	const int32_t n_modules = s.read<int32_t>();
@@ -261,6 +286,8 @@ int parse_renderer(const void* data, size_t size, Parsed& p, RenderParsed& out) 
 	info.n_procedural_geometries = s.read<uint32_t>();
 	if (s.overflow) return LMX_ERR_INVALID_ARGUMENT;
 	info.payload_size = info.n_procedural_geometries ? 0u : (uint32_t)(s.pos - at); // vertex declarations are not walked
+	// the walk must end where the next module begins (or the blob ends): a payload found at a look-alike byte sequence does not
+	if (!info.n_procedural_geometries && !at_module_boundary(p, s.pos)) return LMX_ERR_INVALID_ARGUMENT;
 	return LMX_OK;
 }
 
@@ -315,6 +342,8 @@ int lmx_render_blob_read_model_instances(const void* data, size_t size, uint32_t
 	RenderParsed r;
 	if (int rc = parse_renderer(data, size, p, r)) return rc;
 	if (n_slots < r.info.n_model_instance_slots || (r.info.model_paths_size && (!paths || paths_cap < r.info.model_paths_size))) return LMX_ERR_CAPACITY;
+	// callers strlen() paths + path_offset[i]: the table must end in a NUL (every offset below is checked to lie inside it)
+	if (r.info.model_paths_size && p.blob[r.paths_at + r.info.model_paths_size - 1] != 0) return LMX_ERR_INVALID_ARGUMENT;
 	if (r.info.model_paths_size) memcpy(paths, p.blob.data() + r.paths_at, r.info.model_paths_size);
 	for (uint32_t e = 0; e < n_slots; ++e) {
 		flags[e] = 0;

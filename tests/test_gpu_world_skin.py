@@ -259,6 +259,29 @@ def test_rebinding_keeps_moved_spheres(gpu_ctx, oracle_port):
         assert cs.getRadius(e) == ocs.get_radius(e)
 
 
+def test_world_duplicate_writes_last_one_wins(gpu_ctx, oracle_port):
+    """Two writes to ONE entity in a batch: the reference applies writes one by one, so the last one stands (world.cpp:337-342); the
+    batch keeps only the last record of an entity (the scatter kernel runs one thread per record - two records would race)."""
+    h = scenes.hierarchy_chains(300, 3, seed=17)
+    ow, roots, kids = oracle_world(oracle_port, h)
+    w = api.World(gpu_ctx)
+    w.build(h["parent"], gpu_inputs(ow, h["parent"], roots))
+    w.propagate()
+    rng = np.random.default_rng(5)
+    ent = np.concatenate([roots[:50], roots[:50][::-1], roots[10:20]]).astype(np.int32)  # every one of the 50 twice, ten of them three times
+    tr = scenes.random_transforms(rng, len(ent), 2000.0)
+    ow.set_transforms(ent, tr)  # one by one, in order
+    w.setTransforms(ent, tr)
+    w.propagate()
+    assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms())
+    kid = np.concatenate([kids[:40], kids[:40]]).astype(np.int32)
+    tk = scenes.random_transforms(rng, len(kid), 5.0)
+    ow.set_local_transforms(kid, tk)
+    w.setTransforms(kid, tk)
+    w.propagate()
+    assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms())
+
+
 def test_world_moved_list_is_what_the_dfs_visits(gpu_ctx, oracle_port):
     """lmx_world_track_moved / lmx_world_read_moved: the per-frame hand-back lists exactly the entities World::transformEntity visits
     (world.cpp:255-282: the written entity and its whole subtree) with their new world transforms, nothing else; two propagations
