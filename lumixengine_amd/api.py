@@ -24,6 +24,7 @@ LIB_PATH = os.environ.get("LMX_LIB_PATH") or os.path.join(PKG, "liblumix_mi355.s
 MAX_FRUSTA, MAX_TYPES, MAX_VIEWS = 8, 8, 8
 TYPE_ALL = 0xFF
 CULL_OPT_TILE_VARIANT, CULL_OPT_LANE_PARALLEL_TILE_TEST, CULL_OPT_MAX_SHARDS, CULL_OPT_COUNTER_PAD, CULL_OPT_AUTO_COMPACTION, CULL_OPT_DEVICE_OWNS_BOUND = range(6)
+WORLD_OPT_FUSED_LEVELS = 0
 (K_CULL_CLASSIFY, K_CULL_SPHERES, K_XFORM_LEVEL, K_SPHERE_REFRESH, K_POSE_PALETTE, K_SKIN_VERTICES, K_CULL_DYNAMIC) = range(7)
 KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices", "cull_dynamic", "sort_keys", "anim_update", "cull_patch"]
 K_CULL_PATCH = 9
@@ -142,6 +143,7 @@ SYMBOLS = {
     "lmx_world_bind_culling": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_world_propagate": (_ci, [_vp]),
     "lmx_world_read_transforms": (_ci, [_vp, _vp, _u32]),
+    "lmx_world_set_option": (_ci, [_vp, _ci, _ci]),
     "lmx_world_track_moved": (_ci, [_vp, _ci]),
     "lmx_world_read_moved": (_ci, [_vp, _vp, _vp, _u32, C.POINTER(_u32)]),
     "lmx_world_set_bone_attachments": (_ci, [_vp, _u32, _vp, _vp, _vp, _vp, _vp]),
@@ -616,6 +618,10 @@ class World:
         out = np.zeros(self.n, TRANSFORM)
         self.ctx.check(self.lib.lmx_world_read_transforms(self.ctx.h, _ptr(out), self.n))
         return out
+
+    def setOption(self, option: int, value: int):
+        """WORLD_OPT_FUSED_LEVELS: 1 = hierarchies of <= 8 levels propagate in one launch, 0 (default) = one launch per level."""
+        self.ctx.check(self.lib.lmx_world_set_option(self.ctx.h, option, value))
 
     def trackMoved(self, on: bool = True):
         """propagate() collects the entities whose world transform changed (what World::transformEntity would have visited)."""

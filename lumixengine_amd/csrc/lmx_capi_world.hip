@@ -65,6 +65,7 @@ int world_rebuild(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxT
 	LMX_HIP(ctx, w.d_slot_of_entity.reserve(cap));
 	LMX_HIP(ctx, w.d_entity_of_slot.reserve(cap));
 	LMX_HIP(ctx, w.d_dirty.reserve(cap));
+	LMX_HIP(ctx, w.d_moved_out.reserve(cap));
 	if (w.track_moved) { // two propagations per frame (staged writes, bone-attached subtrees) fit between two reads
 		LMX_HIP(ctx, w.d_moved_entity.reserve(cap * 2));
 		LMX_HIP(ctx, w.d_moved_tr.reserve(cap * 2));
@@ -73,10 +74,26 @@ int world_rebuild(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxT
 	// scene load from locals (no world values given): every node counts as moved, so the first propagation derives all world
 	// transforms; with world values (re-parenting, lmx_world_build_with_world) nothing is recomputed until something is written
 	LMX_HIP(ctx, hipMemset(w.d_dirty.p, world_all ? 0 : XF_MOVED, cap));
+	LMX_HIP(ctx, hipMemset(w.d_moved_out.p, 0, cap));
 	if (n) {
 		LMX_HIP(ctx, hipMemcpy(w.d_parent_slot.p, w.parent_slot.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(w.d_slot_of_entity.p, w.slot_of_entity.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(w.d_entity_of_slot.p, w.entity_of_slot.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+		// ancestor table of shallow hierarchies: k-th ancestor slot per slot (k_xform_fused reads its chain with independent loads)
+		const size_t n_levels = w.level_start.size() - 1;
+		w.n_anc = 0;
+		if (n_levels >= 2 && n_levels <= XF_FUSED_LEVELS) {
+			w.n_anc = (uint32_t)n_levels - 1;
+			std::vector<int32_t> anc((size_t)w.n_anc * n);
+			for (uint32_t s = 0; s < n; ++s) anc[s] = w.parent_slot[s];
+			for (uint32_t k = 1; k < w.n_anc; ++k)
+				for (uint32_t s = 0; s < n; ++s) {
+					const int32_t a = anc[(size_t)(k - 1) * n + s];
+					anc[(size_t)k * n + s] = a >= 0 ? w.parent_slot[a] : -1;
+				}
+			LMX_HIP(ctx, w.d_ancestors.reserve(anc.size()));
+			LMX_HIP(ctx, hipMemcpy(w.d_ancestors.p, anc.data(), anc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+		}
 		// every entity's transform is staged through the scatter kernel (roots -> world, children -> local)
 		std::vector<int32_t> all(n);
 		for (uint32_t e = 0; e < n; ++e) all[e] = (int32_t)e;
@@ -323,14 +340,25 @@ int lmx_world_propagate(LmxContext* ctx) {
 	WorldState& w = ctx->world;
 	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
 	const WorldDevice dev = w.dev();
-	for (size_t l = 1; l + 1 < w.level_start.size(); ++l) {
-		ProfScope ps(ctx, LMX_K_XFORM_LEVEL);
-		LMX_HIP(ctx, launch_xform_level(ctx->stream, dev, w.level_start[l], w.level_start[l + 1] - w.level_start[l]));
-	}
-	if (w.n && w.track_moved) { // the frame's "moved" marks end here: collected for the hand-back, then cleared
-		LMX_HIP(ctx, launch_xform_collect_moved(ctx->stream, dev, w.d_entity_of_slot.p, w.n, w.n * 2u, w.d_moved_entity.p, w.d_moved_tr.p, w.d_moved_count.p));
-	} else if (w.n) {
-		LMX_HIP(ctx, hipMemsetAsync(w.d_dirty.p, 0, w.n, ctx->stream));
+	const size_t n_levels = w.level_start.size() - 1;
+	if (w.fused_levels && n_levels >= 1 && n_levels <= XF_FUSED_LEVELS) {
+		// shallow hierarchy: every level in one launch + one pass that re-derives written locals, collects the moved list, clears the marks
+		if (n_levels > 1) {
+			ProfScope ps(ctx, LMX_K_XFORM_LEVEL);
+			LMX_HIP(ctx, launch_xform_fused(ctx->stream, dev, w.d_moved_out.p, w.d_ancestors.p, w.n, w.n_anc, w.level_start[1], w.n - w.level_start[1]));
+		}
+		LMX_HIP(ctx, launch_xform_finalize(ctx->stream, dev, w.d_moved_out.p, w.d_entity_of_slot.p, w.n, w.n * 2u, w.d_moved_entity.p, w.d_moved_tr.p,
+			w.track_moved ? w.d_moved_count.p : nullptr));
+	} else {
+		for (size_t l = 1; l + 1 < w.level_start.size(); ++l) {
+			ProfScope ps(ctx, LMX_K_XFORM_LEVEL);
+			LMX_HIP(ctx, launch_xform_level(ctx->stream, dev, w.level_start[l], w.level_start[l + 1] - w.level_start[l]));
+		}
+		if (w.n && w.track_moved) { // the frame's "moved" marks end here: collected for the hand-back, then cleared
+			LMX_HIP(ctx, launch_xform_collect_moved(ctx->stream, dev, w.d_entity_of_slot.p, w.n, w.n * 2u, w.d_moved_entity.p, w.d_moved_tr.p, w.d_moved_count.p));
+		} else if (w.n) {
+			LMX_HIP(ctx, hipMemsetAsync(w.d_dirty.p, 0, w.n, ctx->stream));
+		}
 	}
 	if (!w.bound_entity.empty()) {
 		if (int rc = world_upload_binding(ctx)) return rc;
@@ -391,6 +419,13 @@ int lmx_world_update_bone_attachments(LmxContext* ctx) {
 	if (w.attach_skin_instances != sk.inst.size()) return fail(ctx, LMX_ERR_NOT_BUILT, "the skin instance table changed; call lmx_world_set_bone_attachments again");
 	if (!sk.pose_is_absolute) return fail(ctx, LMX_ERR_NOT_BUILT, "bone attachments read the absolute pose (ASSERT(pose->is_absolute), render_module.cpp:424): run lmx_skin_run with pose write-back first");
 	LMX_HIP(ctx, launch_bone_attach(ctx->stream, w.dev(), w.d_attach.p, w.n_attach, sk.d_inst.p, sk.d_pose_pos.p, sk.d_pose_rot.p));
+	return LMX_OK;
+}
+
+int lmx_world_set_option(LmxContext* ctx, int option, int value) {
+	LMX_CHECK_CTX(ctx);
+	if (option != LMX_WORLD_OPT_FUSED_LEVELS) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "unknown world option %d", option);
+	ctx->world.fused_levels = value != 0;
 	return LMX_OK;
 }
 

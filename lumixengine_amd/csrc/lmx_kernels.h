@@ -114,6 +114,13 @@ enum { XF_STAGE_RAW = 0, XF_STAGE_RAW_WORLD = 1, XF_STAGE_SET_LOCAL = 2, XF_STAG
 hipError_t launch_xform_level(hipStream_t s, const WorldDevice& w, uint32_t first, uint32_t n);
 // out[entity_of_slot[s]] = AoS Transform (56 B) for s in [0, n)
 hipError_t launch_xform_export(hipStream_t s, const WorldDevice& w, const int32_t* entity_of_slot, uint32_t n, void* out_transforms);
+// shallow hierarchies (<= XF_FUSED_LEVELS levels): every non-root node in ONE launch (each re-composes down from its topmost written
+// ancestor), then one pass that re-derives the locals of written children, collects the moved list (count != nullptr) and clears the marks
+constexpr uint32_t XF_FUSED_LEVELS = 8;
+hipError_t launch_xform_fused(hipStream_t s, const WorldDevice& w, uint8_t* moved_out, const int32_t* ancestors /* [n_anc][n_slots]: k-th ancestor slot or -1 */,
+	uint32_t n_slots, uint32_t n_anc, uint32_t first_nonroot, uint32_t n_nonroot);
+hipError_t launch_xform_finalize(hipStream_t s, const WorldDevice& w, uint8_t* moved_out, const int32_t* entity_of_slot, uint32_t n, uint32_t cap, int32_t* out_entity,
+	void* out_transforms, uint32_t* count);
 // append {entity, world transform} of every slot marked XF_MOVED to the lists (ballot-compacted, one atomic per wave) and clear all marks
 hipError_t launch_xform_collect_moved(hipStream_t s, const WorldDevice& w, const int32_t* entity_of_slot, uint32_t n, uint32_t cap, int32_t* out_entity,
 	void* out_transforms, uint32_t* count);

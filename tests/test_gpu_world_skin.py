@@ -259,13 +259,52 @@ def test_rebinding_keeps_moved_spheres(gpu_ctx, oracle_port):
         assert cs.getRadius(e) == ocs.get_radius(e)
 
 
+@pytest.mark.parametrize("depth, fused", [(4, 1), (4, 0), (8, 1), (12, 1)])
+def test_world_fused_and_per_level_propagation_bit_exact(gpu_ctx, oracle_port, depth, fused):
+    """The one-launch form (every node re-composes down from its topmost written ancestor, hierarchies of <= 8 levels) and the one-launch-
+    per-level form (deeper hierarchies, or LMX_WORLD_OPT_FUSED_LEVELS = 0) against World::transformEntity (world.cpp:255-282), bit for bit,
+    world transforms and stored locals: moved roots, children written in local space under moved and unmoved parents, children written in
+    world space, several levels written in one frame (applied in hierarchy order on the reference side: the semantics of a batch)."""
+    h = scenes.hierarchy_chains(120, depth, seed=31)
+    n = len(h["parent"])
+    ow, roots, kids = oracle_world(oracle_port, h)
+    w = api.World(gpu_ctx)
+    w.setOption(api.WORLD_OPT_FUSED_LEVELS, fused)
+    try:
+        w.buildWithWorld(h["parent"], gpu_inputs(ow, h["parent"], roots), ow.get_transforms())  # a mirror of the live World: nothing is recomputed
+        w.propagate()
+        assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms())
+        rng = np.random.default_rng(depth * 10 + fused)
+        level = np.zeros(n, np.int32)
+        for e in range(n):
+            p, d = h["parent"][e], 0
+            while p >= 0:
+                p, d = h["parent"][p], d + 1
+            level[e] = d
+        for frame in range(4):
+            picked = rng.choice(n, 90, replace=False)
+            picked = picked[np.argsort(level[picked], kind="stable")]  # hierarchy order = what a batch means
+            world_space = (level[picked] == 0) | (rng.random(len(picked)) < 0.3)
+            tr = scenes.random_transforms(rng, len(picked), 50.0)
+            for e, ws, t in zip(picked, world_space, tr):
+                (ow.set_transforms if ws else ow.set_local_transforms)(np.array([e], np.int32), t[None])
+            w.setWorldTransforms(picked[world_space].astype(np.int32), tr[world_space])
+            w.setTransforms(picked[~world_space].astype(np.int32), tr[~world_space])
+            w.propagate()
+            assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms()), f"frame {frame}: world transforms"
+            got_l, want_l = w.getLocalTransforms(), ow.get_local_transforms()
+            assert H.transforms_bits_equal(got_l[kids], want_l[kids]), f"frame {frame}: stored locals"
+    finally:
+        w.setOption(api.WORLD_OPT_FUSED_LEVELS, 0)
+
+
 def test_world_duplicate_writes_last_one_wins(gpu_ctx, oracle_port):
     """Two writes to ONE entity in a batch: the reference applies writes one by one, so the last one stands (world.cpp:337-342); the
     batch keeps only the last record of an entity (the scatter kernel runs one thread per record - two records would race)."""
     h = scenes.hierarchy_chains(300, 3, seed=17)
     ow, roots, kids = oracle_world(oracle_port, h)
     w = api.World(gpu_ctx)
-    w.build(h["parent"], gpu_inputs(ow, h["parent"], roots))
+    w.buildWithWorld(h["parent"], gpu_inputs(ow, h["parent"], roots), ow.get_transforms())
     w.propagate()
     rng = np.random.default_rng(5)
     ent = np.concatenate([roots[:50], roots[:50][::-1], roots[10:20]]).astype(np.int32)  # every one of the 50 twice, ten of them three times

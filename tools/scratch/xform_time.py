@@ -1,0 +1,46 @@
+"""transform step (scatter of 250 k roots + propagate of 750 k children, config 3's hierarchy) with the fused and the per-level form"""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from lumixengine_amd import api, scenes
+ctx = api.Context(0)
+ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+h = scenes.hierarchy_chains(250_000, 4, seed=2)
+n = len(h["parent"])
+roots = np.flatnonzero(h["parent"] < 0).astype(np.int32)
+new_root = scenes.random_transforms(np.random.default_rng(1), len(roots), 4000.0)
+d_ent = torch.from_numpy(roots).cuda()
+d_tr = torch.from_numpy(new_root.view(np.uint8).reshape(len(roots), -1)).cuda()
+for fused in (0, 1):
+    for track in (0,):
+        w = api.World(ctx)
+        w.setOption(api.WORLD_OPT_FUSED_LEVELS, fused)
+        w.trackMoved(bool(track))
+        w.build(h["parent"], h["local"])
+        def step():
+            w.setTransformsDevice(len(roots), d_ent.data_ptr(), d_tr.data_ptr())
+            w.propagate()
+        for _ in range(20):
+            step()
+        if track:
+            w.readMoved()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            step()
+            if track:
+                pass
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / 200
+        ctx.profile_reset(); ctx.profile_enable(True)
+        for _ in range(20):
+            step()
+        ctx.synchronize(); ctx.profile_enable(False)
+        t_l, n_l = ctx.profile_get(api.K_XFORM_LEVEL)
+        print(f"fused {fused} track_moved {track}: {ms * 1e3:7.2f} us per step, level kernel(s) {1e3 * t_l / 20:7.2f} us per step in {n_l // 20} launch(es), {156.0 * (n - len(roots)) / (ms * 1e-3) / 1e9:7.1f} GB/s algorithmic", flush=True)
+        if track:
+            w.readMoved()
+        w.trackMoved(False)
+        w.setOption(api.WORLD_OPT_FUSED_LEVELS, 0)
+        del w
