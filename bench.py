@@ -687,6 +687,48 @@ def extras(ctx, api, scenes, torch, timed, N, log, big_entities=0):
     out["update_stream_state"] = cs_u.updateStats()
     del cs_u, sc_u
 
+    # the reference's add never stalls (culling_system.cpp:131-190): 2 M adds into the 10 M scene, 1000 per frame, every frame culled, with
+    # the overflow reserve sized for the stream and no automatic compaction: slowest / median frame, and what the 2 M unsorted
+    # overflow entities cost per cull at the end
+    sc_s = scenes.cull_scene(N, 15000.0, seed=2)
+    cs_s = api.CullingSystem(ctx)
+    n_add_frames, per_frame = (2000, 1000) if N >= 10_000_000 else (200, 1000)
+    cs_s.setOption(api.CULL_OPT_AUTO_COMPACTION, 0)
+    cs_s.setOption(api.CULL_OPT_OVERFLOW_RESERVE, n_add_frames * per_frame + 65536)
+    cs_s.build(sc_s["entity"], sc_s["type"], sc_s["pos"], sc_s["radius"])
+    fr_s = api.viewport_frustum()
+    for _ in range(20):
+        cs_s.cull(fr_s)
+    ctx.synchronize()
+    rng_s = np.random.default_rng(12)
+    add_pos = rng_s.uniform(-15000.0, 15000.0, size=(n_add_frames * per_frame, 3))
+    add_rad = np.exp(rng_s.uniform(np.log(0.5), np.log(50.0), size=n_add_frames * per_frame)).astype(np.float32)
+    add_typ = np.zeros(per_frame, np.uint8)
+    t_add = []
+    for f in range(n_add_frames):
+        a0, a1 = f * per_frame, (f + 1) * per_frame
+        ids_f = np.arange(N + a0, N + a1, dtype=np.int32)
+        t0 = time.perf_counter()
+        cs_s.addMany(ids_f, add_typ, add_pos[a0:a1], add_rad[a0:a1])
+        cs_s.cull(fr_s)
+        ctx.synchronize()
+        t_add.append(time.perf_counter() - t0)
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    for _ in range(10):
+        cs_s.cull(fr_s)
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    t_dyn_s, n_dyn_s = ctx.profile_get(api.K_CULL_DYNAMIC)
+    ta = np.array(t_add[5:])
+    out["add_stream"] = {"adds": n_add_frames * per_frame, "per_frame": per_frame, "frames": n_add_frames, "max_frame_ms": float(ta.max()) * 1e3,
+                         "p99_frame_ms": float(np.percentile(ta, 99)) * 1e3, "median_frame_ms": float(np.median(ta)) * 1e3,
+                         "overflow_cull_kernel_ms_at_end": t_dyn_s / max(n_dyn_s, 1), "state": cs_s.updateStats(),
+                         "note": "frame = addMany(1000) + cull + host wait; LMX_CULL_OPT_AUTO_COMPACTION 0, LMX_CULL_OPT_OVERFLOW_RESERVE = the stream's size: adds take free overflow slots, nothing is re-sorted or re-uploaded"}
+    cs_s.setOption(api.CULL_OPT_OVERFLOW_RESERVE, 0)
+    cs_s.setOption(api.CULL_OPT_AUTO_COMPACTION, 1)
+    del cs_s, sc_s, add_pos, add_rad
+
     # BASELINE config 5's single-GPU size: 100 M entities (2 GB of spheres + ids, far beyond the 256 MiB Infinity Cache: every pass
     # is HBM-cold by construction, no scrub needed). Same three regimes as the roofline legs + the 8 cascades in one call.
     if big_entities:

@@ -135,7 +135,8 @@ enum {
 	LMX_CULL_OPT_MAX_SHARDS = 2,              /* output shards (reservation counters) per renderable type, 1..64 (default 64) */
 	LMX_CULL_OPT_COUNTER_PAD = 3,             /* 32-bit words between two shard counters, 1..64 (default 32 = one 128-byte line each) */
 	LMX_CULL_OPT_AUTO_COMPACTION = 4,         /* 1 (default): the sorted set is re-built (O(n log n) on the host, ~0.5 s at 10 M) when the overflow set exceeds max(65536, n/8) or the tombstones max(65536, n/4); 0: never on its own - the host calls lmx_cull_compact when a hitch is acceptable */
-	LMX_CULL_OPT_DEVICE_OWNS_BOUND = 5        /* 1: lmx_cull_set / set_position / set_radius on an entity bound with lmx_world_bind_culling are accepted and dropped - lmx_world_propagate has already refreshed its sphere on the device (what the adapter sets while it replays the engine's `transformed` delegates, whose RenderModuleImpl::onModelInstanceMoved would repeat the refresh per entity on the host); 0 (default): they apply */
+	LMX_CULL_OPT_DEVICE_OWNS_BOUND = 5,       /* 1: lmx_cull_set / set_position / set_radius on an entity bound with lmx_world_bind_culling are accepted and dropped - lmx_world_propagate has already refreshed its sphere on the device (what the adapter sets while it replays the engine's `transformed` delegates, whose RenderModuleImpl::onModelInstanceMoved would repeat the refresh per entity on the host); 0 (default): they apply */
+	LMX_CULL_OPT_OVERFLOW_RESERVE = 6         /* n >= 0 (default 0): free slots kept in the unsorted overflow set for entities added (or moved to another cell) after the sorted set was built. The reference's add / remove never stall (culling_system.cpp:131-190); here an add takes a free overflow slot in O(1), and only when a type's overflow region is FULL is the whole overflow set laid out again (a host pass + re-upload: milliseconds at 10^6 entities). With AUTO_COMPACTION = 0 and a reserve that covers the churn between two lmx_cull_compact calls (a loading screen, a streaming boundary) no frame ever pays for either; the overflow entities cost k_cull_dynamic's ~350 instead of ~27 instructions per cull until then */
 };
 LMX_API int lmx_cull_set_option(LmxContext* ctx, int option, int value);
 /* counts[f * LMX_MAX_TYPES + t] = visible entities of type t for frustum f (synchronizes the stream). */

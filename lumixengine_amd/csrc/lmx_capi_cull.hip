@@ -256,6 +256,7 @@ int rebuild_static(LmxContext* ctx) {
 	cs.block_live.swap(lay.block_live);
 	cs.structure_dirty = false;
 	cs.built = true;
+	if (cs.overflow_reserve) cs.dyn_layout_dirty = true; // the reserve follows the new static set's type shares
 	cs.n_tombstones = 0;
 	clear_static_queues(cs);
 	return LMX_OK;
@@ -268,10 +269,19 @@ int rebuild_dynamic(LmxContext* ctx) {
 	const size_t n = cs.dyn.size();
 	size_t count_by_type[MAX_TYPES] = {};
 	for (const DynRec& r : cs.dyn) count_by_type[r.type]++;
+	// LMX_CULL_OPT_OVERFLOW_RESERVE: room for that many more entities, shared out over the renderable types by their share of the
+	// static set, so that adds / re-celling sets between compactions take free slots and never trigger this function again
+	size_t static_by_type[MAX_TYPES] = {}, static_total = 0;
+	for (int t = 0; t < MAX_TYPES; ++t) {
+		static_by_type[t] = cs.tt.ent_end[t] - cs.tt.ent_start[t];
+		static_total += static_by_type[t];
+	}
 	size_t padded = 0;
 	for (int t = 0; t < MAX_TYPES; ++t) {
 		cs.dyn_tt.ent_start[t] = (uint32_t)padded;
-		if (count_by_type[t]) padded += (count_by_type[t] + count_by_type[t] / 2 + DYN_ALIGN) / DYN_ALIGN * DYN_ALIGN;
+		size_t want = count_by_type[t] ? count_by_type[t] + count_by_type[t] / 2 + DYN_ALIGN : 0;
+		if (cs.overflow_reserve && static_by_type[t]) want = std::max<size_t>(want, count_by_type[t] + (size_t)((double)cs.overflow_reserve * static_by_type[t] / static_total) + DYN_ALIGN);
+		if (want) padded += want / DYN_ALIGN * DYN_ALIGN;
 		cs.dyn_tt.ent_end[t] = (uint32_t)padded;
 		cs.dyn_free[t].clear();
 	}
@@ -934,6 +944,11 @@ int lmx_cull_set_option(LmxContext* ctx, int option, int value) {
 			return LMX_OK;
 		case LMX_CULL_OPT_AUTO_COMPACTION: cs.auto_compaction = value != 0; return LMX_OK;
 		case LMX_CULL_OPT_DEVICE_OWNS_BOUND: cs.device_owns_bound = value != 0; return LMX_OK;
+		case LMX_CULL_OPT_OVERFLOW_RESERVE:
+			if (value < 0) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "overflow reserve %d < 0", value);
+			cs.overflow_reserve = (uint32_t)value;
+			if (value) cs.dyn_layout_dirty = true; // the next flush lays the dynamic set out with the reserve
+			return LMX_OK;
 		case LMX_CULL_OPT_MAX_SHARDS:
 			if (value < 1 || value > (int)LAYOUT_MAX_SHARDS) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "max shards %d not in [1,%u]", value, LAYOUT_MAX_SHARDS);
 			cs.max_shards = (uint32_t)value;

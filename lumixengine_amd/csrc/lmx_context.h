@@ -164,6 +164,7 @@ struct CullState {
 	// ---- tuning (lmx_cull_set_option) -------------------------------------------------------------------------
 	uint32_t pass_width = 1;   // frusta tested per pass over the static set
 	int tile_variant = -1;     // -1: chosen per cull from the frustum's coverage of the scene
+	uint32_t overflow_reserve = 0; // LMX_CULL_OPT_OVERFLOW_RESERVE: slots kept free in the dynamic set for entities added / re-celled between compactions
 	bool device_owns_bound = false; // LMX_CULL_OPT_DEVICE_OWNS_BOUND: set* calls on hierarchy-bound entities are dropped
 	bool auto_compaction = true; // false: overflow / tombstones accumulate until the host calls lmx_cull_compact
 	int lane_parallel = 2;     // tile-level box test of the 1-frustum kernels: 0 = uniform code in every wave, 1 = one plane per lane in every wave, 2 = one plane per lane in wave 0, verdict through LDS
