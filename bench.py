@@ -270,14 +270,14 @@ def main():
             del whole
             ctx_whole.close()
         log(f"[rank {rank}] exchange verified: {dist_info}")
-        if strong and args.skinned_instances:
-            # the rest of BASELINE config 4: 100 k skinned instances (one shared 10 k-vertex mesh, 64 bones) sharded by index - no
-            # exchange, every rank skins its own instances - next to its cell shard of the scene. One simulated frame = cull of the
-            # shard + exchange + pose -> palette -> vertices of the rank's instances; MAX over ranks, like the headline.
+        def config4_frame(ctx_x, step_x, note):
+            """The rest of BASELINE config 4 next to a rank's cell shard of the one 10 M scene: 100 k skinned instances (one shared
+            10 k-vertex mesh, 64 bones) sharded by index - no exchange, every rank skins its own. One simulated frame = cull of the
+            shard + exchange (`step_x`) + pose -> palette -> vertices of the rank's instances; MAX over ranks, like the headline."""
             mine_i = D.shard_by_index(args.skinned_instances, world, rank)
             s_sk = scenes.skeleton(64, seed=4)
             verts_sk, skin_sk = scenes.skinned_mesh(10_000, 64, seed=6)
-            sk = api.Skinning(ctx)
+            sk = api.Skinning(ctx_x)
             model_sk = sk.addModel(s_sk["parents"], s_sk["bind"], s_sk["first_nonroot"])
             mesh_sk = sk.addMesh(verts_sk, skin_sk)
             sk.setInstances(np.full(len(mine_i), model_sk, np.uint32), np.full(len(mine_i), mesh_sk, np.uint32))
@@ -287,19 +287,72 @@ def main():
             sk.setPoseSourceDevice(d_pos_sk.data_ptr(), d_rot_sk.data_ptr(), len(mine_i) * 64)
 
             def frame_c4():
-                step()
+                step_x()
                 sk.run()
 
             for _ in range(2):
                 frame_c4()
             ms_c4 = timed(frame_c4, 10)
-            dist_info["config4_frame"] = {
-                "skinned_instances_total": args.skinned_instances, "skinned_instances_this_rank": int(len(mine_i)), "verts_per_instance": 10_000,
+            out = {
+                "scaling": "strong", "entities_total": N, "skinned_instances_total": args.skinned_instances,
+                "skinned_instances_this_rank": int(len(mine_i)), "verts_per_instance": 10_000,
                 "ms_per_frame_max_over_ranks": ms_c4, "frames_per_sec": 1e3 / ms_c4,
                 "skinned_verts_per_sec_all_ranks": args.skinned_instances * 10_000 / (ms_c4 * 1e-3),
-                "what": "cull of the rank's cell shard + native all-gather + pose/palette/vertex kernels of the rank's instances (shard_by_index)"}
-            log(f"[rank {rank}] config 4 frame: {dist_info['config4_frame']}")
+                "what": "cull of the rank's cell shard + native all-gather + pose/palette/vertex kernels of the rank's instances (shard_by_index)" + note}
+            log(f"[rank {rank}] config 4 frame: {out}")
             del sk, d_pos_sk, d_rot_sk
+            return out
+
+        if strong and args.skinned_instances:
+            dist_info["config4_frame"] = config4_frame(ctx, step, "")
+        elif not strong and args.skinned_instances and not args.no_extras and not args.headline_only:
+            # weak run (the driver's SCALE line): the strong-scaling frame of BASELINE config 4 rides along as an extra, in a context
+            # and a communicator of its own, so one `--gpus N` run yields both curves; N = 1's point is extra.target_frames_per_sec
+            try:
+                sc4 = sc if rank == 0 else scenes.cull_scene(N, half, seed=2)  # (rank 0's weak scene IS seed 2)
+                mine4 = D.shard_by_cell(sc4["pos"], world, rank)
+                ctx4 = api.Context(local_rank)
+                ctx4.set_stream(torch.cuda.current_stream().cuda_stream)
+                cs4 = api.CullingSystem(ctx4)
+                cs4.build(sc4["entity"][mine4], sc4["type"][mine4], sc4["pos"][mine4], sc4["radius"][mine4])
+                uid4 = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    uid4.copy_(torch.frombuffer(bytearray(api.exchange_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid4, 0)
+                t4 = torch.tensor([int(cs4.cull(frustum).counts()[0].sum())], dtype=torch.int64, device="cuda")
+                t4_sum = t4.clone()
+                dist.all_reduce(t4, op=dist.ReduceOp.MAX)
+                dist.all_reduce(t4_sum, op=dist.ReduceOp.SUM)
+                cap4 = (int(t4.item()) * 5 // 4 + 1023) // 1024 * 1024
+                with c_stdout_to_stderr():
+                    xchg4 = api.VisibleExchange(ctx4, rank, world, uid4.cpu().numpy().tobytes(), cap4)
+                    xchg4.wait(xchg4.cull(frustum))
+                xh4, slot4 = xchg4.h, C.c_uint32(0)
+
+                def step4():
+                    if x_cull(xh4, fr_ptr, api.TYPE_ALL, C.byref(slot4)) != 0:
+                        raise RuntimeError(ctx4.lib.lmx_last_error(ctx4.h).decode())
+
+                c4 = config4_frame(ctx4, step4, "; measured in the weak run as an extra")
+                c4["visible_total"] = int(t4_sum.item())
+                want4 = None
+                if args.variant == "sparse" and N == 10_000_000 and args.camera == "default":
+                    try:
+                        want4 = sum(json.load(open(os.path.join(ROOT, "tests", "golden", "cull_bench_scenes.json")))["scenes"]["sparse_10m"]["cameras"]["default"]["counts"])
+                    except Exception:  # noqa: BLE001
+                        want4 = None
+                if want4 is not None:
+                    assert c4["visible_total"] == want4, f"config 4: the ranks' shards see {c4['visible_total']} ids, the reference {want4}"
+                    c4["visible_total_is"] = "the reference's count (tests/golden/cull_bench_scenes.json)"
+                dist_info["config4_frame"] = c4
+                xchg4.close()
+                del cs4
+                ctx4.close()
+            except AssertionError:
+                raise
+            except Exception as e:  # noqa: BLE001 - an extra must not take the headline line with it
+                dist_info["config4_frame"] = {"error": repr(e)}
+                log(f"[rank {rank}] config 4 extra failed: {e!r}")
         xchg.close()
         log(f"[rank {rank}] exchange closed")
 

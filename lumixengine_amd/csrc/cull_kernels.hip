@@ -145,6 +145,9 @@ __device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, 
 #ifndef LMX_CULL_MIN3
 #define LMX_CULL_MIN3 0       // 1: `any t < 0` as min(t...) < 0 (fminf ignores NaN like the comparisons do, -0.0 < 0 is false either way): no measurable change
 #endif
+#ifndef LMX_CULL_PLANE_SKIP
+#define LMX_CULL_PLANE_SKIP 0 // 1: phase A notes per CELL_TEST cell which plane pairs can cull one of its spheres at all (lmx_math.h: relevant_plane_pairs, checked by tests/test_emulation.py), a wave evaluates the union over its lanes. Measured and NOT kept: on the all-test scene only 21 % of the pairs drop out (a cell outside the frustum is usually outside one plane of two or three pairs), and the uniform branches around the packed pairs cost 14 VGPRs, 56 more scalar loads and 2 SGPRs (82: 7 instead of 8 resident blocks per CU) - all-test launch 37.7 -> 45.0 us back to back, 43.0 -> 51.3 us cache-cold, even the nothing-visible launch 9.3 -> 10.8 us (profiles/r03/cull_ab_variants.txt)
+#endif
 // Measured and NOT kept (profiles/r03/cull_ab_variants.txt): touching the NEXT tile's box / cell keys / chunk headers at block start
 // (global_load_lds into a scratch corner, nothing waits): +2-3 us in every regime, cold included; capping the kernel at 80 SGPRs so
 // that 8 instead of 7 blocks are resident per CU (MI355X_MICROARCH.md "Residency"): within noise; a persistent grid for the streaming
@@ -152,7 +155,7 @@ __device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, 
 // the loop around the tile body, all-test launch 37.3 -> 43.5 us back to back, 43.0 -> 47.9 us cache-cold.
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const float d[6], float cx, float cy, float cz, float radius) {
+__device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const float d[6], float cx, float cy, float cz, float radius, uint32_t pairs = 7u) {
 	const v2f x2 = {cx, cx}, y2 = {cy, cy}, z2 = {cz, cz}, r2 = {radius, radius};
 #if LMX_CULL_MIN3
 	v2f tt[3];
@@ -172,6 +175,7 @@ __device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const f
 	bool culled = false;
 #pragma unroll
 	for (int k = 0; k < 6; k += 2) {
+		if (!((pairs >> (k >> 1)) & 1u)) continue; // wave-uniform
 		const v2f nx = {f.nx[k], f.nx[k + 1]}, ny = {f.ny[k], f.ny[k + 1]}, nz = {f.nz[k], f.nz[k + 1]}, dd = {d[k], d[k + 1]};
 		v2f t = x2 * nx;
 		t = t + y2 * ny;
@@ -185,7 +189,7 @@ __device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const f
 }
 
 // LDS record of one (cell, frustum): the six cell-relative plane distances of ShiftedFrustum::getRelative and the cell's class
-struct alignas(16) CellInfo { float d[6]; uint32_t cls, pad; };
+struct alignas(16) CellInfo { float d[6]; uint32_t cls, pairs; }; // pairs: relevant_plane_pairs() of a CELL_TEST cell
 static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustum)");
 
 // F == 1: the single-frustum kernel (the common case: one launch per view). F == 0: n_frusta (2..8) is a runtime value and every
@@ -207,6 +211,9 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 	constexpr uint32_t TILE = WAVES * CHW * 64;
 	constexpr uint32_t THREADS = WAVES * 64;
 	constexpr int FS = F == 1 ? 1 : MAX_FRUSTA;
+	// plane-pair skipping in the streaming variants only (as the non-temporal loads): its uniform branches cost the all-loads-in-flight
+	// variant 22 VGPRs (60 -> 82: 5 instead of 8 waves per SIMD), and that variant runs where few chunks are tested at all
+	constexpr bool PLANE_SKIP = LMX_CULL_PLANE_SKIP != 0 && GRP < CHW;
 	static_assert(CHW * FS <= 32, "visibility bits of a wave's chunks x frusta live in one register");
 	extern __shared__ CellInfo s_info[]; // [n_frusta * cell_cap] (MIXED tiles only)
 	// the frusta are read through the kernarg segment pointer: uniform scalar loads placed where they are used
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			const bool big = (key.meta & 0x100u) != 0;
 			CellInfo ci;
 			ci.cls = CELL_REJECT;
-			ci.pad = 0;
+			ci.pairs = 7u;
 #pragma unroll
 			for (int k = 0; k < 6; ++k) ci.d[k] = 0.f;
 			if (!dead) {
@@ -289,6 +296,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 				if (ci.cls == CELL_TEST) {
 #pragma unroll
 					for (int k = 0; k < 6; ++k) ci.d[k] = relative_plane_d(frp[f], off, k);
+					if constexpr (PLANE_SKIP) ci.pairs = relevant_plane_pairs(frp[f], IV3{key.ix, key.iy, key.iz}, ci.d);
 				}
 			}
 			s_info[f * a.cell_cap + t] = ci;
@@ -425,10 +433,17 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 					const uint32_t cls = ci->cls;
 					vis = cls == CELL_ACCEPT;
 					if (cls == CELL_TEST) {
+						// the plane pairs this wave evaluates for the chunk: the union over its CELL_TEST lanes - the lanes active here (a lane
+						// whose radius is negative or NaN keeps all three: relevant_plane_pairs bounds t, not t + r)
+						uint32_t pairs = 7u;
+						if constexpr (PLANE_SKIP) {
+							const uint32_t lane_pairs = sp[i].w >= 0.f ? ci->pairs : 7u;
+							pairs = (__ballot((lane_pairs & 1u) != 0) != 0 ? 1u : 0u) | (__ballot((lane_pairs & 2u) != 0) != 0 ? 2u : 0u) | (__ballot((lane_pairs & 4u) != 0) != 0 ? 4u : 0u);
+						}
 						float d[6];
 #pragma unroll
 						for (int k = 0; k < 6; ++k) d[k] = ci->d[k];
-						vis = sphere_visible_d_pk(frp[f], d, sp[i].x, sp[i].y, sp[i].z, sp[i].w);
+						vis = sphere_visible_d_pk(frp[f], d, sp[i].x, sp[i].y, sp[i].z, sp[i].w, pairs);
 					}
 				} else {
 					vis = st == TILE_ACCEPT;

@@ -947,7 +947,15 @@ int lmx_cull_set_option(LmxContext* ctx, int option, int value) {
 		case LMX_CULL_OPT_OVERFLOW_RESERVE:
 			if (value < 0) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "overflow reserve %d < 0", value);
 			cs.overflow_reserve = (uint32_t)value;
-			if (value) cs.dyn_layout_dirty = true; // the next flush lays the dynamic set out with the reserve
+			if (value) {
+				cs.dyn_layout_dirty = true; // the next flush lays the dynamic set out with the reserve
+				// the host mirror of the overflow gets its room now as well: a std::vector that doubles under an add copies tens of MB
+				// at 10 M entities (measured: one 8.6 ms frame in a stream of 2 M adds, the entity -> overflow table crossing 10 M ids)
+				const size_t ids = std::max(cs.ent_to_dyn.size(), cs.ent_to_rec.size());
+				cs.ent_to_dyn.reserve(ids + (size_t)value);
+				if (cs.ent_to_dyn.size() < ids) cs.ent_to_dyn.resize(ids, -1);
+				cs.dyn.reserve(cs.dyn.size() + (size_t)value);
+			}
 			return LMX_OK;
 		case LMX_CULL_OPT_MAX_SHARDS:
 			if (value < 1 || value > (int)LAYOUT_MAX_SHARDS) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "max shards %d not in [1,%u]", value, LAYOUT_MAX_SHARDS);
