@@ -356,7 +356,9 @@ def main():
         xchg.close()
         log(f"[rank {rank}] exchange closed")
 
-    # ---- roofline of the dominant kernel (k_cull_tile): HIP events around each launch on the launch stream -------------------
+    # ---- roofline of the dominant kernel (k_cull_tile): a HIP event pair per launch, on the launch stream, filled by the launch itself
+    # (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps - what rocprofv3's kernel trace reports. Events recorded
+    # around the launch also time the command processor's work on the pair: +3 us, 7 % of the 40 us all-test launch) ------------
     # Three regimes of the same kernel on the same 10 M geometry:
     #   default camera   hierarchical skip: ~95 % of the tiles end at the tile-level box test. Latency regime; the algorithmic
     #                    bytes (20 B per RESIDENT entity) are mostly never moved, so it is reported as an effective rate only.
@@ -477,6 +479,7 @@ def main():
         "traffic_source": traffic_note,
         "algorithmic_bytes_per_launch": roof_bytes,
         "avg_launch_ms": round(roof_ms, 5),
+        "avg_launch_ms_is": "mean over the leg's launches of hipEventElapsedTime on the event pair the launch itself fills (hipExtLaunchKernelGGL start / stop events on the launch stream): the dispatch's begin -> end, as in rocprofv3's kernel trace",
         "measured_copy_ceiling_GBps": 6290.0,
         "legs": legs,
     }

@@ -22,6 +22,8 @@
 
 #include "lmx_kernels.h"
 
+#include <hip/hip_ext.h>
+
 namespace lmx {
 
 namespace {
@@ -666,7 +668,13 @@ hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, ui
 	static_assert(TILE_ALIGN % TILE == 0, "tiles must not straddle type ranges");
 	constexpr int K = TILE == 4096 ? 0 : (TILE == 2048 ? 1 : 2);
 	const uint32_t tiles = (ent_end - ent_begin) / TILE;
-	if (!tiles) return hipSuccess;
+	if (!tiles) {
+		if (out.ev_start != nullptr) { // keep the profiling pair valid
+			(void)hipEventRecord(out.ev_start, s);
+			(void)hipEventRecord(out.ev_stop, s);
+		}
+		return hipSuccess;
+	}
 	TileScalars a;
 	a.tt = tt;
 	a.ent_begin = ent_begin;
@@ -676,8 +684,12 @@ hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, ui
 	a.cnt_pad = out.cnt_pad;
 	a.cnt_frustum_stride = out.cnt_frustum_stride;
 	a.n_zero = out.n_zero;
-	hipLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, LANEPAR>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, fr, v.spheres, v.ids, v.hdr,
-		v.tile_cells[K], v.tile_tab[K], v.tile_box[K], out.win_base, out.ids, out.counts, out.counts_next, a);
+	if (out.ev_start != nullptr) // profiling: the events receive the dispatch's own begin / end timestamps
+		hipExtLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, LANEPAR>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, out.ev_start, out.ev_stop, 0, fr,
+			v.spheres, v.ids, v.hdr, v.tile_cells[K], v.tile_tab[K], v.tile_box[K], out.win_base, out.ids, out.counts, out.counts_next, a);
+	else
+		hipLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, LANEPAR>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, fr, v.spheres, v.ids, v.hdr,
+			v.tile_cells[K], v.tile_tab[K], v.tile_box[K], out.win_base, out.ids, out.counts, out.counts_next, a);
 	return hipGetLastError();
 }
 

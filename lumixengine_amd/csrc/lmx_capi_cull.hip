@@ -907,7 +907,9 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 		// (its duration is the latency of the surviving tiles), a launch that streams the whole set 2 % longer: picked by how much of the
 		// set's bounding box the frustum's bounding box overlaps.
 		const int variant = cs.tile_variant >= 0 ? cs.tile_variant : (fw == 1 && frustum_box_overlap(cs, frusta[f0]) < 0.25 ? 4 : 1);
-		ProfScope ps(ctx, LMX_K_CULL_SPHERES);
+		ProfScope ps(ctx, LMX_K_CULL_SPHERES, true);
+		po.ev_start = ps.slot.a;
+		po.ev_stop = ps.slot.b;
 		LMX_HIP(ctx, launch_cull_tile(ctx->stream, dv, ent_begin, ent_end, cs.tt, sub, (int)fw, po, variant, cs.lane_parallel));
 	}
 	// dynamic set: its own shards of the same rows / counters

@@ -382,16 +382,18 @@ struct ProfScope { // records HIP events around one launch on the launch stream 
 	LmxContext* ctx;
 	ProfSlot slot;
 	bool on;
-	ProfScope(LmxContext* c, int kernel) : ctx(c), on(c->profiling) {
+	bool ext; // the launch itself fills the events (hipExtLaunchKernelGGL: the dispatch's own timestamps)
+	ProfScope(LmxContext* c, int kernel, bool launch_records = false) : ctx(c), on(c->profiling), ext(launch_records) {
+		slot.a = slot.b = nullptr;
 		if (!on) return;
 		slot.kernel = kernel;
 		slot.a = take();
 		slot.b = take();
-		(void)hipEventRecord(slot.a, ctx->stream);
+		if (!ext) (void)hipEventRecord(slot.a, ctx->stream);
 	}
 	~ProfScope() {
 		if (!on) return;
-		(void)hipEventRecord(slot.b, ctx->stream);
+		if (!ext) (void)hipEventRecord(slot.b, ctx->stream);
 		ctx->prof_pending.push_back(slot);
 	}
 	hipEvent_t take() {

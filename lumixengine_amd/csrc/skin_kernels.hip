@@ -49,11 +49,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 constexpr int POSE_LDS_BONES = 1024; // K * n_bones <= 1024: 16 x 64, 8 x 128, 4 x 196
 constexpr int POSE_WAVES = 4;
 
-// LDS slot of (bone, instance of the group): bone-major, with the instance index XOR-ed by the bone so that BOTH access
-// patterns are conflict-free — the level walk (neighbouring lanes = neighbouring instances of one bone: a permutation of one
-// row) and the staging / palette phases (neighbouring lanes = neighbouring bones of one instance: without the swizzle all lanes
-// of a ds_*_b128 service group hit one bank column, measured as 75 % of the kernel's LDS cycles).
-template <uint32_t K> __device__ __forceinline__ uint32_t pose_slot(uint32_t bone, uint32_t k) { return bone * K + (k ^ (bone & (K - 1))); }
+// LDS slot of (bone, instance of the group): bone-major, plain. Every phase maps neighbouring lanes to neighbouring INSTANCES of one
+// bone (lane -> instance lane % K, bone lane / K), so a wave touches 64 consecutive slots: conflict-free for the 16-byte rotations
+// and the 4-byte position planes alike. (Round 2 mapped the staging / palette lanes to neighbouring bones of one instance and
+// XOR-ed the instance index by the bone to spread them over the bank columns; that swizzle made two bones of the level walk that
+// share a ds_*_b128 service group collide instead - SQ_LDS_BANK_CONFLICT was 31 % of the kernel's LDS cycles.)
+template <uint32_t K> __device__ __forceinline__ uint32_t pose_slot(uint32_t bone, uint32_t k) { return bone * K + k; }
 
 template <int KSHIFT>
 __global__ __launch_bounds__(64 * POSE_WAVES) void k_pose_palette(const SkinInstance* __restrict__ inst, const PoseGroup* __restrict__ groups,
@@ -61,59 +62,64 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_pose_palette(const SkinInst
 	const uint32_t* __restrict__ level_items, const uint16_t* __restrict__ level_off, const float* __restrict__ inv_pos,
 	const float4* __restrict__ inv_rot, float4* __restrict__ palette, float4* __restrict__ dual_quats) {
 	constexpr uint32_t K = 1u << KSHIFT;
-	constexpr uint32_t KW = K / POSE_WAVES; // instances per wave
+	constexpr uint32_t THREADS = 64 * POSE_WAVES;
+	constexpr uint32_t BONES_PER_STEP = THREADS / K; // (instance, bone) pairs of one step: K instances x this many bones
+	constexpr uint32_t STEPS = 4;                    // loads of this many steps are issued before the first is used
 	__shared__ float4 s_rot[POSE_LDS_BONES];
-	__shared__ float s_pos[POSE_LDS_BONES * 3];
+	__shared__ float s_px[POSE_LDS_BONES], s_py[POSE_LDS_BONES], s_pz[POSE_LDS_BONES];
 	__shared__ uint32_t s_item[SKIN_MAX_BONES];     // bone | parent << 16, sorted by depth (bones >= first_nonroot only)
 	__shared__ uint16_t s_off[SKIN_MAX_BONES + 1];  // s_off[d - 1] .. s_off[d]: items of depth d
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t tid = threadIdx.x;
 	const PoseGroup g = groups[blockIdx.x];
 	const SkinInstance in = inst[g.first_inst]; // all instances of the group share the model; their bones are consecutive in memory
 	const uint32_t nb = in.n_bones;
 	const size_t bone0 = in.bone_offset;
-	// stage relative poses: coalesced per instance, transposed to [bone][instance] in LDS; wave w owns instances w, w + 4, ...
-	for (uint32_t b = lane; b < nb; b += 64) {
-		float4 r[KW];
-		float px[KW], py[KW], pz[KW];
+	const uint32_t k = tid & (K - 1), b_lane = tid >> KSHIFT; // this thread's instance of the group and its bone within a step
+	const bool k_live = k < g.count;
+	const size_t inst_base = bone0 + (size_t)(k_live && !LMX_PROBE_SKIP(4) ? k : 0u) * nb; // instances past the group's end re-read its first one (no branch around the loads)
+	// stage relative poses into LDS, [bone][instance]. Per instruction a wave reads, for each of its K instances, 64 / K consecutive
+	// bones: runs of 64 bytes (rotations, K = 16) - the same number of 64-byte sectors as 64 consecutive bones of one instance
+	for (uint32_t b0 = 0; b0 < nb; b0 += BONES_PER_STEP * STEPS) {
+		float4 r[STEPS];
+		float px[STEPS], py[STEPS], pz[STEPS];
 #pragma unroll
-		for (uint32_t kk = 0; kk < KW; ++kk) { // instances past the group's end re-read its first one (no branch around the loads)
-			const uint32_t k = wave + kk * POSE_WAVES < g.count && !LMX_PROBE_SKIP(4) ? wave + kk * POSE_WAVES : 0;
-			const size_t i = bone0 + (size_t)k * nb + b;
-			r[kk] = rel_rot[i];
-			px[kk] = rel_pos[i * 3];
-			py[kk] = rel_pos[i * 3 + 1];
-			pz[kk] = rel_pos[i * 3 + 2];
+		for (uint32_t st = 0; st < STEPS; ++st) {
+			const uint32_t b = b0 + st * BONES_PER_STEP + b_lane;
+			const size_t i = inst_base + (b < nb ? b : nb - 1); // bones past the skeleton's end re-read its last one
+			r[st] = rel_rot[i];
+			px[st] = rel_pos[i * 3];
+			py[st] = rel_pos[i * 3 + 1];
+			pz[st] = rel_pos[i * 3 + 2];
 		}
 #pragma unroll
-		for (uint32_t kk = 0; kk < KW; ++kk) {
-			const uint32_t k = wave + kk * POSE_WAVES;
-			if (k < g.count) {
+		for (uint32_t st = 0; st < STEPS; ++st) {
+			const uint32_t b = b0 + st * BONES_PER_STEP + b_lane;
+			if (b < nb && k_live) {
 				const uint32_t slot = pose_slot<K>(b, k);
-				s_rot[slot] = r[kk];
-				s_pos[slot * 3] = px[kk];
-				s_pos[slot * 3 + 1] = py[kk];
-				s_pos[slot * 3 + 2] = pz[kk];
+				s_rot[slot] = r[st];
+				s_px[slot] = px[st];
+				s_py[slot] = py[st];
+				s_pz[slot] = pz[st];
 			}
 		}
 	}
 	const uint32_t n_items = level_off[in.lv_off_offset + in.max_depth];
-	for (uint32_t i = tid; i < n_items; i += 64 * POSE_WAVES) s_item[i] = level_items[in.lv_items_offset + i];
-	for (uint32_t i = tid; i <= in.max_depth; i += 64 * POSE_WAVES) s_off[i] = level_off[in.lv_off_offset + i];
+	for (uint32_t i = tid; i < n_items; i += THREADS) s_item[i] = level_items[in.lv_items_offset + i];
+	for (uint32_t i = tid; i <= in.max_depth; i += THREADS) s_off[i] = level_off[in.lv_off_offset + i];
 	__syncthreads();
 	for (uint32_t d = 1; d <= in.max_depth && !LMX_PROBE_SKIP(1); ++d) {
 		const uint32_t start = s_off[d - 1];
-		const uint32_t items = ((uint32_t)s_off[d] - start) << KSHIFT;
-		for (uint32_t j = tid; j < items; j += 64 * POSE_WAVES) {
-			const uint32_t k = j & (K - 1);
-			if (k < g.count) {
-				const uint32_t it = s_item[start + (j >> KSHIFT)];
+		const uint32_t items = (uint32_t)s_off[d] - start;
+		for (uint32_t j = b_lane; j < items; j += BONES_PER_STEP) {
+			if (k_live) {
+				const uint32_t it = s_item[start + j];
 				const uint32_t ib = pose_slot<K>(it & 0xffffu, k), ip = pose_slot<K>(it >> 16, k);
 				const float4 pr4 = s_rot[ip];
 				const float4 r4 = s_rot[ib];
 				const Q4 pr = Q4{pr4.x, pr4.y, pr4.z, pr4.w};
-				const V3 np = add(rotate(pr, V3{s_pos[3 * ib], s_pos[3 * ib + 1], s_pos[3 * ib + 2]}), V3{s_pos[3 * ip], s_pos[3 * ip + 1], s_pos[3 * ip + 2]});
+				const V3 np = add(rotate(pr, V3{s_px[ib], s_py[ib], s_pz[ib]}), V3{s_px[ip], s_py[ip], s_pz[ip]});
 				const Q4 nr = qmul(pr, Q4{r4.x, r4.y, r4.z, r4.w});
-				s_pos[3 * ib] = np.x; s_pos[3 * ib + 1] = np.y; s_pos[3 * ib + 2] = np.z;
+				s_px[ib] = np.x; s_py[ib] = np.y; s_pz[ib] = np.z;
 				s_rot[ib] = make_float4(nr.x, nr.y, nr.z, nr.w);
 			}
 		}
@@ -122,35 +128,31 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_pose_palette(const SkinInst
 	// palette (computeSkinMatrices), optional dual quaternions, optional absolute pose write-back
 	const float* ipos = inv_pos + (size_t)in.model_offset * 3;
 	const float4* irot = inv_rot + in.model_offset;
-	for (uint32_t b = lane; b < nb; b += 64) {
+	for (uint32_t b = b_lane; b < nb; b += BONES_PER_STEP) {
+		if (!k_live) break;
 		const float4 ir4 = irot[b];
 		const Q4 ir = Q4{ir4.x, ir4.y, ir4.z, ir4.w};
 		const V3 ip = V3{ipos[3 * b], ipos[3 * b + 1], ipos[3 * b + 2]};
-#pragma unroll
-		for (uint32_t kk = 0; kk < KW; ++kk) {
-			const uint32_t k = wave + kk * POSE_WAVES;
-			if (k >= g.count) break;
-			const size_t i = bone0 + (size_t)k * nb + b;
-			const uint32_t ib = pose_slot<K>(b, k);
-			const float4 r4 = s_rot[ib];
-			const V3 p = V3{s_pos[3 * ib], s_pos[3 * ib + 1], s_pos[3 * ib + 2]};
-			const Mat4 m = skin_matrix(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, ir);
-			if (LMX_PROBE_SKIP(2) && m.c[0][0] != 123.f) continue;
-			if (dual_quats != nullptr) { // the palette format of the reference's own GPU skinning path (32 B per bone)
-				const DualQ dq = skin_dual_quat(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, ir);
-				float4* o = dual_quats + i * 2;
-				o[0] = make_float4(dq.r.x, dq.r.y, dq.r.z, dq.r.w);
-				o[1] = make_float4(dq.d.x, dq.d.y, dq.d.z, dq.d.w);
-			}
-			float4* out = palette + i * 3;
-			out[0] = make_float4(m.c[0][0], m.c[1][0], m.c[2][0], m.c[3][0]);
-			out[1] = make_float4(m.c[0][1], m.c[1][1], m.c[2][1], m.c[3][1]);
-			out[2] = make_float4(m.c[0][2], m.c[1][2], m.c[2][2], m.c[3][2]);
-			if (pose_pos != nullptr) { // the pose becomes absolute (Pose::is_absolute = true, pose.cpp:133)
-				float* gp = pose_pos + i * 3;
-				gp[0] = p.x; gp[1] = p.y; gp[2] = p.z;
-				pose_rot[i] = r4;
-			}
+		const size_t i = bone0 + (size_t)k * nb + b;
+		const uint32_t ib = pose_slot<K>(b, k);
+		const float4 r4 = s_rot[ib];
+		const V3 p = V3{s_px[ib], s_py[ib], s_pz[ib]};
+		const Mat4 m = skin_matrix(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, ir);
+		if (LMX_PROBE_SKIP(2) && m.c[0][0] != 123.f) continue;
+		if (dual_quats != nullptr) { // the palette format of the reference's own GPU skinning path (32 B per bone)
+			const DualQ dq = skin_dual_quat(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, ir);
+			float4* o = dual_quats + i * 2;
+			o[0] = make_float4(dq.r.x, dq.r.y, dq.r.z, dq.r.w);
+			o[1] = make_float4(dq.d.x, dq.d.y, dq.d.z, dq.d.w);
+		}
+		float4* out = palette + i * 3;
+		out[0] = make_float4(m.c[0][0], m.c[1][0], m.c[2][0], m.c[3][0]);
+		out[1] = make_float4(m.c[0][1], m.c[1][1], m.c[2][1], m.c[3][1]);
+		out[2] = make_float4(m.c[0][2], m.c[1][2], m.c[2][2], m.c[3][2]);
+		if (pose_pos != nullptr) { // the pose becomes absolute (Pose::is_absolute = true, pose.cpp:133)
+			float* gp = pose_pos + i * 3;
+			gp[0] = p.x; gp[1] = p.y; gp[2] = p.z;
+			pose_rot[i] = r4;
 		}
 	}
 }
