@@ -130,6 +130,7 @@ struct World { // read side of engine/world.h:49-209 + the transform array
 	std::vector<Transform> locals;     // Hierarchy::local_transform
 	std::vector<i32> parents;
 	const Transform* getTransforms() const { return transforms.data(); }
+	bool hasEntity(EntityRef e) const { return e.index >= 0 && e.index < (i32)transforms.size(); }
 	EntityPtr getParent(EntityRef e) const { return EntityPtr{parents[e.index]}; }
 	Transform getLocalTransform(EntityRef e) const { return parents[e.index] < 0 ? transforms[e.index] : locals[e.index]; }
 	EntityPtr getFirstEntity() const { return EntityPtr{transforms.empty() ? -1 : 0}; }

@@ -2,9 +2,11 @@
 // LUMIX_PLUGIN_ENTRY (src/engine/plugin.h:37-96; the renderer's own instance: src/renderer/renderer.cpp:1410-1413).
 //
 // Compiled inside a LumixEngine tree (-DLMX_WITH_LUMIX_HEADERS, include paths of the engine's src/ and this repository's
-// include/ + lumixengine_amd/host/). It is NOT built by this repository's build scripts: the reference does not compile on Linux
-// at this snapshot (src/core/sync.h:20-24 is `#error "Not implemented"`); tests/test_plugin_compile.py checks it with
-// -fsyntax-only against a copy of the reference's headers in which that one line is patched.
+// include/ + lumixengine_amd/host/). The reference as a whole does not compile on Linux at this snapshot (src/core/sync.h:20-24 is
+// `#error "Not implemented"`), so this repository checks the file two ways against a copy of the reference's headers in which that
+// one line is patched: tests/test_plugin_compile.py (syntax + object code + exported entry points) and, on the GPU,
+// oracle/_ref/real_header_harness (tests/cpp/real_header_harness.cpp: this object code linked with the reference's engine/world.cpp,
+// driven through IModule::update on a real World and compared with a CPU-only World frame by frame).
 //
 // What the module owns and does per frame (Engine::update, src/engine/engine.cpp:289-341):
 //   createModules   world.addModule(Mi355Module)                                    (world.cpp:218-235)
@@ -117,7 +119,8 @@ struct Mi355Module final : IModule {
 					lmx_ctx_lock(m_ctx);
 					const bool ok = lmx_world_update_bone_attachments(m_ctx) == LMX_OK;
 					lmx_ctx_unlock(m_ctx);
-					if (!ok || !m_sync->propagate()) fail("bone attachments", lmx_last_error(m_ctx));
+					if (!ok) fail("bone attachments", lmx_last_error(m_ctx));
+					else if (!m_sync->propagate()) fail("propagating bone-attached subtrees", m_sync->lastError());
 				}
 				m_poses->scatter(*m_render_module);
 			}

@@ -61,8 +61,16 @@ struct WorldSync {
 			memcpy(&m_stage_world[e.index], &transforms[e.index], sizeof(Transform));
 		}
 		m_n = n;
-		m_staged.clear();
+		// writes staged before a structural change (an entity created or destroyed mid-frame re-mirrors the World) are not in the World
+		// yet: they stay staged for the entities that still exist
+		std::vector<Staged> keep;
+		keep.swap(m_staged);
 		m_staged_at.assign(n, -1);
+		for (const Staged& st : keep) {
+			if ((u32)st.entity >= n || !world.hasEntity(EntityRef{st.entity})) continue;
+			m_staged_at[st.entity] = (int32_t)m_staged.size();
+			m_staged.push_back(st);
+		}
 		Lock guard(m_ctx);
 		return check(lmx_world_track_moved(m_ctx, 1)) && check(lmx_world_build_with_world(m_ctx, n, m_parent.data(), m_stage.data(), m_stage_world.data()));
 	}

@@ -51,6 +51,9 @@ int main(int argc, char** argv) {
 	if (sync.entityCount() != n) return 4;
 	for (uint32_t i = 0; i < n_local; ++i) sync.setLocalTransform(EntityRef{local_e[i]}, local_t[i]);
 	for (uint32_t i = 0; i < n_world; ++i) sync.setTransform(EntityRef{world_e[i]}, world_t[i]);
+	// an entity created or destroyed mid-frame makes the module re-mirror the World: writes staged before that are not in the World
+	// yet and must survive the rebuild (the expected output below assumes every staged write is applied)
+	if (!sync.build(world)) { fprintf(stderr, "rebuild: %s\n", sync.lastError()); return 4; }
 	if (!sync.propagate()) { fprintf(stderr, "propagate: %s\n", sync.lastError()); return 5; }
 	std::vector<Transform> result(n), locals(n);
 	// the module writes into the engine's own array: const_cast<Transform*>(world.getTransforms())
