@@ -9,6 +9,8 @@
 // do not need it.
 #include <dlfcn.h>
 
+#include <cstdlib>
+
 #include "lmx_context.h"
 
 using namespace lmx;
@@ -32,11 +34,20 @@ constexpr int NCCL_INT32 = 2; // ncclInt32 (rccl.h ncclDataType_t)
 Rccl& rccl() {
 	static Rccl r = [] {
 		Rccl x;
+		// LMX_RCCL_LIBRARY: an explicit library instead of the system's RCCL (a site's own build; the several-ranks-on-one-GPU test double
+		// of tests/cpp/loopback_rccl.cpp). Loaded RTLD_LOCAL: its nccl* symbols must not shadow a real RCCL in the process.
+		if (const char* path = getenv("LMX_RCCL_LIBRARY")) {
+			x.lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+			if (!x.lib) {
+				x.error = "LMX_RCCL_LIBRARY could not be loaded";
+				return x;
+			}
+		}
 		// A process must not end up with two RCCL runtimes (e.g. the copy PyTorch bundles and the system one): first take whatever
 		// is already loaded, only then load one.
 		for (const char* name : {"librccl.so.1", "librccl.so"}) {
-			x.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
 			if (x.lib) break;
+			x.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
 		}
 		for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
 			if (x.lib) break;

@@ -74,3 +74,82 @@ def test_exchange_single_rank_matches_oracle(gpu_ctx, oracle_port):
             assert int(counts.sum()) == 0 and len(ids) == 0
     finally:
         empty.close()
+
+
+def _loopback_library():
+    """tests/cpp/loopback_rccl.cpp -> tests/_build/libloopback_rccl.so (g++ against the HIP runtime; host code only)"""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "cpp", "loopback_rccl.cpp")
+    out = os.path.join(root, "tests", "_build", "libloopback_rccl.so")
+    if not os.path.exists(out) or os.path.getmtime(src) > os.path.getmtime(out):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", out,
+                        "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"], check=True)
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_exchange_ranks_on_one_gpu_loopback(tmp_path, oracle_port, world):
+    """The exchange with a world of 2 / 4 ranks on this box's one GPU: one process per rank, each with its own context and its cell shard of one
+    scene, the collective carried by a shared-memory test double of the five RCCL entry points (RCCL itself refuses two ranks on one
+    device). Everything around the wire is the product's: the per-rank / per-frustum record layout, the peers' offsets in the receive
+    buffer, slot alternation over 6 pipelined frames, the type filter, the F-frusta record, clipping. Every rank must read, for every
+    rank r, exactly the oracle's visible ids that live in r's shard."""
+    import os
+    import subprocess
+    import sys
+
+    lib = _loopback_library()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LMX_RCCL_LIBRARY=lib, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.exchange_rank", str(r), str(world), str(tmp_path)], cwd=root, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=600)[0].decode(errors="replace"))
+        except subprocess.TimeoutExpired:
+            p.kill()  # (the exact process this test started)
+            logs.append(p.communicate()[0].decode(errors="replace") + "\n[timed out]")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+
+    sc = scenes.cull_scene(120_000, 4000.0, seed=13, mixed_types=True)
+    ocs = oracle_port.culling_system()
+    ocs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    cams = H.frusta(api, names=["origin_identity", "origin_yaw_pitch", "narrow_fov", "ortho_cascade_large"])
+    got = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    owned = [set(got[r]["owned"].tolist()) for r in range(world)]
+    assert len(set().union(*owned)) == sum(len(o) for o in owned) == len(sc["entity"])  # disjoint, complete
+    want = []  # [camera][rank][type] -> sorted ids
+    for f in range(len(cams)):
+        ids, types, _ = ocs.cull(cams[f : f + 1])
+        want.append([[np.sort(np.array([i for i in ids[types == t] if i in owned[r]], np.int32)) for t in range(8)] for r in range(world)])
+        assert sum(len(a) for r in range(world) for a in want[f][r]) == len(ids)
+
+    def check(counts, ids, w, what):
+        at = 0
+        for t in range(8):
+            assert int(counts[t]) == len(w[t]), (what, t, int(counts[t]), len(w[t]))
+            assert np.array_equal(np.sort(ids[at : at + int(counts[t])]), w[t]), (what, t)
+            at += int(counts[t])
+        assert at == len(ids)
+
+    for reader in range(world):
+        g = got[reader]
+        for frame in range(5):
+            for r in range(world):
+                check(g[f"single_f{frame}_r{r}_counts"], g[f"single_f{frame}_r{r}_ids"], want[frame % len(cams)][r], ("single", reader, frame, r))
+        for frame in range(3):
+            for r in range(world):
+                for f in range(len(cams)):
+                    check(g[f"many_f{frame}_r{r}_c{f}_counts"], g[f"many_f{frame}_r{r}_c{f}_ids"], want[f][r], ("many", reader, frame, r, f))
+        for r in range(world):
+            c, ids = g[f"type2_r{r}_counts"], g[f"type2_r{r}_ids"]
+            assert int(c[2]) == len(want[0][r][2]) and int(c.sum()) == int(c[2]) and np.array_equal(np.sort(ids), want[0][r][2])
+            c, ids = g[f"small_r{r}_counts"], g[f"small_r{r}_ids"]
+            total = sum(len(a) for a in want[0][r])
+            assert int(c.sum()) == total and len(ids) == min(total, 64)  # the counts tell what the rank saw; the ids are clipped
+            assert set(ids.tolist()) <= set(np.concatenate(want[0][r]).tolist())
