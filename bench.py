@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--default-stream", action="store_true", help="N > 1: launch on the legacy default stream (the pre-round-2 behaviour, for comparison)")
     ap.add_argument("--skinned-instances", type=int, default=100_000, help="--scaling strong: skinned instances of BASELINE config 4, sharded by index (0 = skip)")
+    ap.add_argument("--ranks-share-gpu", action="store_true",
+                    help="TEST MODE for the N > 1 code path on a one-GPU box: every rank uses cuda:0, torch.distributed runs on gloo, and the exchange's collective must be carried by LMX_RCCL_LIBRARY = tests/_build/libloopback_rccl.so (RCCL refuses two ranks on one device). Checks that the path runs and what it ships; its timings mean nothing")
     ap.add_argument("--big-entities", type=int, default=100_000_000, help="extras: entity count of the config-5-sized single-GPU legs (0 = skip)")
     args = ap.parse_args()
 
@@ -102,6 +104,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    if args.ranks_share_gpu:
+        if not os.environ.get("LMX_RCCL_LIBRARY"):
+            raise SystemExit("--ranks-share-gpu needs LMX_RCCL_LIBRARY (tests/cpp/loopback_rccl.cpp): RCCL refuses two ranks on one device")
+        local_rank = 0
+    red_dev = "cpu" if args.ranks_share_gpu else "cuda"  # where torch.distributed's few scalars live (gloo in the test mode)
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_collective
     if use_dist:
@@ -109,7 +116,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         # RCCL prints a version banner on the C-level stdout at communicator creation; stdout must carry the JSON line only
         with c_stdout_to_stderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            if args.ranks_share_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -146,7 +156,7 @@ def main():
         barrier()
         ms = (time.perf_counter() - t0) * 1e3 / steps
         if use_dist:
-            t = torch.tensor([ms], dtype=torch.float64, device="cuda")
+            t = torch.tensor([ms], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ms = float(t.item())
         return ms
@@ -185,12 +195,12 @@ def main():
         # One exchange per frame, native (csrc/lmx_capi_exchange.hip): the cull's gather kernels write [8 counts | cap ids] into the
         # send buffer, ONE ncclAllGather per frame runs on a side stream, frames alternate between two slots so the next cull
         # overlaps this frame's gather. torch.distributed only carries the 128-byte RCCL id, the barrier and the timing reduction.
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        uid = torch.zeros(128, dtype=torch.uint8, device=red_dev)
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(api.exchange_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, 0)
         probe = int(cs.cull(frustum).counts()[0].sum())
-        t = torch.tensor([probe], dtype=torch.int64, device="cuda")
+        t = torch.tensor([probe], dtype=torch.int64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         cap = (int(t.item()) * 5 // 4 + 1023) // 1024 * 1024  # 1.25 x the largest visible count of any rank
         log(f"[rank {rank}] exchange: creating the RCCL communicator (ids per rank {cap})")
@@ -315,11 +325,11 @@ def main():
                 ctx4.set_stream(torch.cuda.current_stream().cuda_stream)
                 cs4 = api.CullingSystem(ctx4)
                 cs4.build(sc4["entity"][mine4], sc4["type"][mine4], sc4["pos"][mine4], sc4["radius"][mine4])
-                uid4 = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                uid4 = torch.zeros(128, dtype=torch.uint8, device=red_dev)
                 if rank == 0:
                     uid4.copy_(torch.frombuffer(bytearray(api.exchange_unique_id()), dtype=torch.uint8))
                 dist.broadcast(uid4, 0)
-                t4 = torch.tensor([int(cs4.cull(frustum).counts()[0].sum())], dtype=torch.int64, device="cuda")
+                t4 = torch.tensor([int(cs4.cull(frustum).counts()[0].sum())], dtype=torch.int64, device=red_dev)
                 t4_sum = t4.clone()
                 dist.all_reduce(t4, op=dist.ReduceOp.MAX)
                 dist.all_reduce(t4_sum, op=dist.ReduceOp.SUM)
@@ -517,6 +527,8 @@ def main():
     result["config"]["visible_ids"] = ids_checked  # 'reference': sha256 of the sorted ids == the reference CullingSystemImpl's on the same seeded scene
 
     result["config"].update(dist_info)
+    if args.ranks_share_gpu:
+        result["config"]["TEST_MODE"] = "--ranks-share-gpu: all ranks on cuda:0, gloo + shared-memory collective (tests/cpp/loopback_rccl.cpp); timings are meaningless"
     if rank == 0 and world == 1:
         if not args.no_extras:
             result["extra"] = extras(ctx, api, scenes, torch, timed, N, log, args.big_entities)
