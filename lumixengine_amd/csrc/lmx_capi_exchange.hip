@@ -9,6 +9,8 @@
 // do not need it.
 #include <dlfcn.h>
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 
 #include "lmx_context.h"
@@ -71,6 +73,10 @@ Rccl& rccl() {
 } // namespace
 
 struct LmxExchange {
+	// LMX_EXCHANGE_TRACE=1: host time of every API call of a step, summed and printed by lmx_exchange_destroy (a measurement aid)
+	bool trace = false;
+	double t_host[8] = {};
+	uint64_t t_steps = 0;
 	LmxContext* ctx = nullptr;
 	NcclComm comm = nullptr;
 	int rank = 0, world = 1;
@@ -107,6 +113,7 @@ int lmx_exchange_create(LmxContext* ctx, int rank, int world, const void* unique
 	if (r.error) return fail(ctx, LMX_ERR_NO_DEVICE, "RCCL is not available: %s", r.error);
 	LmxExchange* x = new LmxExchange;
 	x->ctx = ctx;
+	x->trace = getenv("LMX_EXCHANGE_TRACE") != nullptr;
 	x->rank = rank;
 	x->world = world;
 	x->cap = ids_per_rank;
@@ -144,6 +151,11 @@ int lmx_exchange_create(LmxContext* ctx, int rank, int world, const void* unique
 
 void lmx_exchange_destroy(LmxExchange* x) {
 	if (!x) return;
+	if (x->trace && x->t_steps) {
+		const double n = (double)x->t_steps;
+		fprintf(stderr, "lmx_exchange trace (%llu steps, host us per step): wait-for-slot %.2f | lmx_cull %.2f | pack launches %.2f | event record %.2f | side stream wait %.2f | ncclAllGather %.2f | event record (side) %.2f\n",
+			(unsigned long long)x->t_steps, x->t_host[0] / n, x->t_host[1] / n, x->t_host[2] / n, x->t_host[3] / n, x->t_host[4] / n, x->t_host[5] / n, x->t_host[6] / n);
+	}
 	(void)hipStreamSynchronize(x->side);
 	if (x->comm) (void)rccl().CommDestroy(x->comm);
 	for (int i = 0; i < 2; ++i) {
@@ -169,9 +181,19 @@ int lmx_exchange_cull_many(LmxExchange* x, const LmxShiftedFrustum* frusta, uint
 	if (cap_f == 0) return fail(ctx, LMX_ERR_CAPACITY, "%u ids per rank cannot be split over %u frusta", x->cap, n_frusta);
 	const uint32_t k = x->next;
 	x->next ^= 1u;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto lap = [&](int i, std::chrono::steady_clock::time_point& t) {
+		if (!x->trace) return;
+		const auto t1 = now();
+		x->t_host[i] += std::chrono::duration<double, std::micro>(t1 - t).count();
+		t = t1;
+	};
+	auto t = now();
 	// the send / recv buffers of this slot are free once its previous gather has finished: the cull stream waits for it (device-side)
 	if (x->in_flight[k]) LMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, x->gathered[k], 0));
+	lap(0, t);
 	if (int rc = lmx_cull(ctx, k, frusta, n_frusta, type)) return rc;
+	lap(1, t);
 	CullState& cs = ctx->cull;
 	CullView& v = cs.views[k];
 	// per frustum: per-type totals straight into its sub-record's header and the ids behind it (clipped to cap_f), one launch each (k_cull_pack)
@@ -185,11 +207,17 @@ int lmx_exchange_cull_many(LmxExchange* x, const LmxShiftedFrustum* frusta, uint
 	x->n_frusta[k] = n_frusta;
 	x->cap_f[k] = cap_f;
 	x->record = n_frusta * sub;
+	lap(2, t);
 	LMX_HIP(ctx, hipEventRecord(x->culled[k], ctx->stream));
+	lap(3, t);
 	LMX_HIP(ctx, hipStreamWaitEvent(x->side, x->culled[k], 0));
+	lap(4, t);
 	const int rc = rccl().AllGather(x->send[k].p, x->recv[k].p, (size_t)n_frusta * sub, NCCL_INT32, x->comm, x->side);
 	if (rc != 0) return fail(ctx, LMX_ERR_HIP, "ncclAllGather failed: %s", rccl().GetErrorString ? rccl().GetErrorString(rc) : "?");
+	lap(5, t);
 	LMX_HIP(ctx, hipEventRecord(x->gathered[k], x->side));
+	lap(6, t);
+	x->t_steps += x->trace ? 1 : 0;
 	x->in_flight[k] = true;
 	if (out_slot) *out_slot = k;
 	return LMX_OK;
