@@ -114,6 +114,10 @@ LMX_API int lmx_cull_compact(LmxContext* ctx);
 /* Bookkeeping of the incremental path: entities in the sorted set, bound to the world hierarchy, waiting in the overflow, and
  * tombstones left in the sorted layout. Host-only, no synchronisation. */
 LMX_API int lmx_cull_update_stats(LmxContext* ctx, uint32_t* n_static, uint32_t* n_dynamic_bound, uint32_t* n_overflow, uint32_t* n_tombstones);
+/* LMX_CULL_OPT_ASYNC_COMPACTION: what the worker has done so far (host-only, no sync; any pointer may be null). *state: 0 idle,
+   1 requested, 2 running, 3 a re-sorted set is ready for the next flush, 4 the last job failed (lmx_last_error), -1 the option is off.
+   jobs = re-sorts finished, swaps = sets traded, ops_replayed_at_swaps = operations the update thread replayed inside those flushes. */
+LMX_API int lmx_cull_async_stats(LmxContext* ctx, int* state, uint64_t* jobs, uint64_t* swaps, uint64_t* ops_replayed_at_swaps);
 /* Number of resident spheres / occupied (cell,type,is_big) groups of the static set / capacity of one frustum's output
  * row in units of 64 ids: a bound output buffer needs 64 * n_chunks ids per frustum. Compacts the static set first (the cell
  * count is that of the sorted layout). */
@@ -136,7 +140,8 @@ enum {
 	LMX_CULL_OPT_COUNTER_PAD = 3,             /* 32-bit words between two shard counters, 1..64 (default 32 = one 128-byte line each) */
 	LMX_CULL_OPT_AUTO_COMPACTION = 4,         /* 1 (default): the sorted set is re-built (O(n log n) on the host, ~0.5 s at 10 M) when the overflow set exceeds max(65536, n/8) or the tombstones max(65536, n/4); 0: never on its own - the host calls lmx_cull_compact when a hitch is acceptable */
 	LMX_CULL_OPT_DEVICE_OWNS_BOUND = 5,       /* 1: lmx_cull_set / set_position / set_radius on an entity bound with lmx_world_bind_culling are accepted and dropped - lmx_world_propagate has already refreshed its sphere on the device (what the adapter sets while it replays the engine's `transformed` delegates, whose RenderModuleImpl::onModelInstanceMoved would repeat the refresh per entity on the host); 0 (default): they apply */
-	LMX_CULL_OPT_OVERFLOW_RESERVE = 6         /* n >= 0 (default 0): free slots kept in the unsorted overflow set for entities added (or moved to another cell) after the sorted set was built. The reference's add / remove never stall (culling_system.cpp:131-190); here an add takes a free overflow slot in O(1), and only when a type's overflow region is FULL is the whole overflow set laid out again (a host pass + re-upload: milliseconds at 10^6 entities). With AUTO_COMPACTION = 0 and a reserve that covers the churn between two lmx_cull_compact calls (a loading screen, a streaming boundary) no frame ever pays for either; the overflow entities cost k_cull_dynamic's ~350 instead of ~27 instructions per cull until then */
+	LMX_CULL_OPT_OVERFLOW_RESERVE = 6,        /* n >= 0 (default 0): free slots kept in the unsorted overflow set for entities added (or moved to another cell) after the sorted set was built. The reference's add / remove never stall (culling_system.cpp:131-190); here an add takes a free overflow slot in O(1), and only when a type's overflow region is FULL is the whole overflow set laid out again (a host pass + re-upload: milliseconds at 10^6 entities). With AUTO_COMPACTION = 0 and a reserve that covers the churn between two lmx_cull_compact calls (a loading screen, a streaming boundary) no frame ever pays for either; the overflow entities cost k_cull_dynamic's ~350 instead of ~27 instructions per cull until then */
+	LMX_CULL_OPT_ASYNC_COMPACTION = 7         /* 1: the re-sort of the sorted set runs on a worker thread, on a second complete copy of the sets (host mirror + device arrays: twice the memory), and the copy trades places with the live set inside a flush in O(1) + a replay of the operations of the last frame or two: no frame pays the O(n) step (the reference's add / remove / set never stall, culling_system.cpp:131-258). Every effective add / remove / set* / bind is also appended to a 40-byte operation log. Switching it on copies the host mirror once (O(n)); lmx_cull_build and lmx_cull_compact stay synchronous and re-seed the copy. Results are the same id sets as without it; 0 (default): the re-sort happens inside the flush that finds the thresholds exceeded */
 };
 LMX_API int lmx_cull_set_option(LmxContext* ctx, int option, int value);
 /* counts[f * LMX_MAX_TYPES + t] = visible entities of type t for frustum f (synchronizes the stream). */

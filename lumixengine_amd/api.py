@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("LMX_LIB_PATH") or os.path.join(PKG, "liblumix_mi355.s
 
 MAX_FRUSTA, MAX_TYPES, MAX_VIEWS = 8, 8, 8
 TYPE_ALL = 0xFF
-CULL_OPT_TILE_VARIANT, CULL_OPT_LANE_PARALLEL_TILE_TEST, CULL_OPT_MAX_SHARDS, CULL_OPT_COUNTER_PAD, CULL_OPT_AUTO_COMPACTION, CULL_OPT_DEVICE_OWNS_BOUND, CULL_OPT_OVERFLOW_RESERVE = range(7)
+CULL_OPT_TILE_VARIANT, CULL_OPT_LANE_PARALLEL_TILE_TEST, CULL_OPT_MAX_SHARDS, CULL_OPT_COUNTER_PAD, CULL_OPT_AUTO_COMPACTION, CULL_OPT_DEVICE_OWNS_BOUND, CULL_OPT_OVERFLOW_RESERVE, CULL_OPT_ASYNC_COMPACTION = range(8)
 WORLD_OPT_FUSED_LEVELS = 0
 (K_CULL_CLASSIFY, K_CULL_SPHERES, K_XFORM_LEVEL, K_SPHERE_REFRESH, K_POSE_PALETTE, K_SKIN_VERTICES, K_CULL_DYNAMIC) = range(7)
 KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices", "cull_dynamic", "sort_keys", "anim_update", "cull_patch"]
@@ -109,6 +109,7 @@ SYMBOLS = {
     "lmx_cull_remove_many": (_ci, [_vp, _u32, _vp]),
     "lmx_cull_compact": (_ci, [_vp]),
     "lmx_cull_update_stats": (_ci, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "lmx_cull_async_stats": (_ci, [_vp, C.POINTER(_ci), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "lmx_cull_set_option": (_ci, [_vp, _ci, _ci]),
     "lmx_cull_read_all": (_ci, [_vp, _u32, _u32, _vp, _u32, _vp]),
     "lmx_cull_map_all": (_ci, [_vp, _u32, _u32, _vp, _vp]),
@@ -460,6 +461,12 @@ class CullingSystem:
         v = [C.c_uint32(0) for _ in range(4)]
         self.ctx.check(self.lib.lmx_cull_update_stats(self.ctx.h, *[C.byref(x) for x in v]))
         return dict(zip(("static", "bound", "overflow", "tombstones"), (x.value for x in v)))
+
+    def asyncStats(self):
+        """LMX_CULL_OPT_ASYNC_COMPACTION: {"state": -1 off / 0 idle / 1 requested / 2 running / 3 ready / 4 failed, "jobs", "swaps", "ops_replayed_at_swaps"}"""
+        st, jobs, swaps, ops = C.c_int(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self.ctx.check(self.lib.lmx_cull_async_stats(self.ctx.h, C.byref(st), C.byref(jobs), C.byref(swaps), C.byref(ops)))
+        return {"state": st.value, "jobs": jobs.value, "swaps": swaps.value, "ops_replayed_at_swaps": ops.value}
 
     def setOption(self, option: int, value: int):
         self.ctx.check(self.lib.lmx_cull_set_option(self.ctx.h, int(option), int(value)))

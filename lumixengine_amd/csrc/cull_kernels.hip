@@ -735,6 +735,32 @@ uint32_t cull_dynamic_tile(int n_frusta, uint32_t n_slots) {
 	return tile;
 }
 
+// Asynchronous compaction, at the swap: the spheres of the OLD dynamic set that still exist in the NEW one keep what the device last
+// computed for them (bound entities are refreshed by k_sphere_refresh, not by the host). One thread per old slot; new_slot_of_entity is
+// the new set's entity -> slot table as of the end of the worker's catch-up - an entry that went stale since then (the entity was
+// removed, its slot given to another one) is caught by comparing the id the new slot holds NOW.
+__global__ __launch_bounds__(256) void k_dyn_carry_over(const double* __restrict__ opx, const double* __restrict__ opy, const double* __restrict__ opz,
+	const float* __restrict__ oradius, const int32_t* __restrict__ oids, uint32_t n_old, double* __restrict__ npx, double* __restrict__ npy, double* __restrict__ npz,
+	float* __restrict__ nradius, const int32_t* __restrict__ nids, uint32_t n_new, const int32_t* __restrict__ new_slot_of_entity, uint32_t n_entities) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s >= n_old) return;
+	const int32_t e = oids[s];
+	if (e < 0 || (uint32_t)e >= n_entities) return;
+	const int32_t t = new_slot_of_entity[e];
+	if (t < 0 || (uint32_t)t >= n_new || nids[t] != e) return;
+	npx[t] = opx[s];
+	npy[t] = opy[s];
+	npz[t] = opz[s];
+	nradius[t] = oradius[s];
+}
+
+hipError_t launch_dyn_carry_over(hipStream_t s, const DynDeviceView& from, const DynDeviceView& to, const int32_t* new_slot_of_entity, uint32_t n_entities) {
+	if (!from.n_padded || !to.n_padded || !n_entities) return hipSuccess;
+	hipLaunchKernelGGL(k_dyn_carry_over, dim3((from.n_padded + 255u) / 256u), dim3(256), 0, s, from.px, from.py, from.pz, from.radius, from.ids, from.n_padded, to.px, to.py,
+		to.pz, to.radius, to.ids, to.n_padded, new_slot_of_entity, n_entities);
+	return hipGetLastError();
+}
+
 hipError_t launch_cull_dynamic(hipStream_t s, const DynDeviceView& d, uint32_t slot_begin, uint32_t slot_end, const TypeTable& dyn_tt,
 	const FrustaArg& fr, int n_frusta, const CullOut& out) {
 	const uint32_t tile = cull_dynamic_tile(n_frusta, slot_end - slot_begin);

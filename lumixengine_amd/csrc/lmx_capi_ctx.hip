@@ -10,13 +10,16 @@ thread_local std::string g_create_error;
 
 namespace lmx {
 
+thread_local std::string* t_fail_sink = nullptr;
+
 int fail(LmxContext* ctx, int code, const char* fmt, ...) {
 	char buf[512];
 	va_list ap;
 	va_start(ap, fmt);
 	vsnprintf(buf, sizeof(buf), fmt, ap);
 	va_end(ap);
-	if (ctx) ctx->error = buf;
+	if (t_fail_sink) *t_fail_sink = buf;
+	else if (ctx) ctx->error = buf;
 	else g_create_error = buf;
 	return code;
 }
@@ -75,6 +78,7 @@ int lmx_ctx_create(int device, LmxContext** out) {
 void lmx_ctx_destroy(LmxContext* ctx) {
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
+	cull_async_shutdown(ctx); // joins the asynchronous compaction's worker, if one runs
 	(void)hipStreamSynchronize(ctx->stream);
 	prof_drain(ctx);
 	for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);

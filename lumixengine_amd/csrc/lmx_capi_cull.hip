@@ -16,6 +16,9 @@
 // totals and contiguous lists on demand.
 #include "lmx_context.h"
 
+#include <condition_variable>
+#include <thread>
+
 using namespace lmx;
 
 namespace {
@@ -29,7 +32,53 @@ constexpr uint32_t COMPACT_MIN = 1u << 16; // overflow / tombstones tolerated be
 
 enum class Where { NONE, STATIC, DYNAMIC };
 
-Where locate(const CullState& cs, int32_t entity, uint32_t* index) {
+// ---- asynchronous compaction: types (the machinery is further down) -------------------------------------------------------------
+enum : uint8_t { OP_ADD, OP_REMOVE, OP_SET, OP_SET_POS, OP_SET_RADIUS, OP_BIND, OP_UNBIND };
+struct CullOp { // one EFFECTIVE mutation of the live set, replayed onto the shadow set
+	double pos[3];
+	float radius;
+	int32_t entity;
+	uint8_t op, type;
+};
+} // namespace
+
+namespace lmx {
+struct CullAsync {
+	enum State : int { IDLE, REQUESTED, RUNNING, READY, FAILED, QUIT };
+	CullSet shadow;                 // owned by the worker while RUNNING, by the update thread otherwise
+	std::vector<CullOp> log_local;  // update thread only: operations since the last hand-over
+	std::vector<CullOp> log_shared; // under `mu`: operations the shadow set has not seen yet
+	std::mutex mu;
+	std::condition_variable cv;
+	State state = IDLE;             // under `mu`
+	std::thread worker;
+	hipStream_t stream = nullptr;   // the worker's own (non-blocking) stream
+	hipEvent_t swapped = nullptr;   // recorded on the context's stream when the sets trade places: the worker's uploads into what WAS the live set wait for it
+	bool swapped_pending = false;
+	uint32_t overflow_reserve = 0;  // copy of the tuning value for the job in flight
+	std::string error;              // the worker's failure (state FAILED)
+	DevBuf<int32_t> d_new_slot;     // entity -> dynamic slot of the shadow set (bound spheres are copied device to device at the swap)
+	uint32_t n_new_slot = 0;
+	uint64_t jobs_done = 0, swaps = 0, ops_replayed_at_swap = 0;
+};
+} // namespace lmx
+
+namespace {
+
+inline void async_log(CullState& cs, uint8_t op, int32_t entity, uint8_t type, const double* pos, float radius) {
+	if (!cs.async) return;
+	CullOp o;
+	o.pos[0] = pos ? pos[0] : 0.0;
+	o.pos[1] = pos ? pos[1] : 0.0;
+	o.pos[2] = pos ? pos[2] : 0.0;
+	o.radius = radius;
+	o.entity = entity;
+	o.op = op;
+	o.type = type;
+	cs.async->log_local.push_back(o);
+}
+
+Where locate(const CullSet& cs, int32_t entity, uint32_t* index) {
 	if (entity < 0) return Where::NONE;
 	if ((size_t)entity < cs.ent_to_rec.size() && cs.ent_to_rec[entity] >= 0) {
 		*index = (uint32_t)cs.ent_to_rec[entity];
@@ -42,10 +91,10 @@ Where locate(const CullState& cs, int32_t entity, uint32_t* index) {
 	return Where::NONE;
 }
 
-bool layout_live(const CullState& cs) { return cs.built && !cs.structure_dirty; }
+bool layout_live(const CullSet& cs) { return cs.built && !cs.structure_dirty; }
 
 // ---- dynamic set: slots and patches -----------------------------------------------------------------------------
-void queue_dyn_patch(CullState& cs, const DynRec& r, bool alive) {
+void queue_dyn_patch(CullSet& cs, const DynRec& r, bool alive) {
 	if (r.slot == DYN_NO_SLOT || cs.dyn_layout_dirty) return; // the pending rebuild uploads the whole mirror
 	const PatchDyn p{r.slot, alive ? r.entity : -1, r.radius, 0u, r.pos[0], r.pos[1], r.pos[2]};
 	if (cs.q_dyn_at.size() < cs.dyn_padded) cs.q_dyn_at.resize(cs.dyn_padded, ~0u);
@@ -58,7 +107,7 @@ void queue_dyn_patch(CullState& cs, const DynRec& r, bool alive) {
 	cs.q_dyn.push_back(p);
 }
 
-uint32_t take_dyn_slot(CullState& cs, uint8_t type) {
+uint32_t take_dyn_slot(CullSet& cs, uint8_t type) {
 	if (cs.dyn_layout_dirty) return DYN_NO_SLOT;
 	if (!cs.dyn_free[type].empty()) {
 		const uint32_t s = cs.dyn_free[type].back();
@@ -70,7 +119,7 @@ uint32_t take_dyn_slot(CullState& cs, uint8_t type) {
 	return DYN_NO_SLOT;
 }
 
-void dyn_append(CullState& cs, int32_t entity, uint8_t type, DV3 pos, float radius, bool bound) {
+void dyn_append(CullSet& cs, int32_t entity, uint8_t type, DV3 pos, float radius, bool bound) {
 	if ((size_t)entity >= cs.ent_to_dyn.size()) cs.ent_to_dyn.resize((size_t)entity + 1, -1);
 	cs.ent_to_dyn[entity] = (int32_t)cs.dyn.size();
 	DynRec r{{pos.x, pos.y, pos.z}, radius, entity, take_dyn_slot(cs, type), type, bound};
@@ -79,7 +128,7 @@ void dyn_append(CullState& cs, int32_t entity, uint8_t type, DV3 pos, float radi
 	queue_dyn_patch(cs, r, true);
 }
 
-void remove_dynamic(CullState& cs, uint32_t idx) {
+void remove_dynamic(CullSet& cs, uint32_t idx) {
 	const DynRec r = cs.dyn[idx];
 	queue_dyn_patch(cs, r, false);
 	if (r.slot != DYN_NO_SLOT && !cs.dyn_layout_dirty) cs.dyn_free[r.type].push_back(r.slot);
@@ -94,7 +143,7 @@ void remove_dynamic(CullState& cs, uint32_t idx) {
 }
 
 // ---- static set: host mirror ops --------------------------------------------------------------------------------
-void remove_static(CullState& cs, uint32_t rec) { // culling_system.cpp:160-190: the device slot becomes a tombstone
+void remove_static(CullSet& cs, uint32_t rec) { // culling_system.cpp:160-190: the device slot becomes a tombstone
 	const int32_t entity = cs.recs[rec].entity;
 	if (layout_live(cs)) {
 		cs.q_id.push_back(PatchId{cs.rec_slot[rec], -1});
@@ -112,7 +161,7 @@ void remove_static(CullState& cs, uint32_t rec) { // culling_system.cpp:160-190:
 }
 
 // remove(entity); add(entity, type, pos, radius) of culling_system.cpp:201-258 when the cell or the big flag changes
-void readd_static(CullState& cs, uint32_t rec, DV3 pos, float radius) {
+void readd_static(CullSet& cs, uint32_t rec, DV3 pos, float radius) {
 	const CullRec old = cs.recs[rec];
 	if (!layout_live(cs)) {
 		cs.recs[rec] = make_cull_rec(old.entity, old.type, pos, radius);
@@ -122,7 +171,7 @@ void readd_static(CullState& cs, uint32_t rec, DV3 pos, float radius) {
 	dyn_append(cs, old.entity, old.type, pos, radius, false);
 }
 
-void mark_patch(CullState& cs, uint32_t rec) {
+void mark_patch(CullSet& cs, uint32_t rec) {
 	if (!layout_live(cs)) return;
 	const CullRec& r = cs.recs[rec];
 	const PatchSphere p{cs.rec_slot[rec], r.rel.x, r.rel.y, r.rel.z, r.radius};
@@ -144,17 +193,17 @@ DV3 stored_position(DV3 pos) {
 	return add(origin, to_v3(sub(pos, origin)));
 }
 
-void clear_static_queues(CullState& cs) {
+void clear_static_queues(CullSet& cs) {
 	for (const PatchSphere& p : cs.q_sphere) if (p.slot < cs.q_sphere_at.size()) cs.q_sphere_at[p.slot] = ~0u;
 	cs.q_sphere.clear();
 	cs.q_id.clear();
 }
-void clear_dyn_queue(CullState& cs) {
+void clear_dyn_queue(CullSet& cs) {
 	for (const PatchDyn& p : cs.q_dyn) cs.q_dyn_at[p.slot] = ~0u;
 	cs.q_dyn.clear();
 }
 
-DynDeviceView dyn_view(const CullState& cs) {
+DynDeviceView dyn_view(const CullSet& cs) {
 	DynDeviceView dd;
 	dd.px = cs.dyn_px.p;
 	dd.py = cs.dyn_py.p;
@@ -168,8 +217,7 @@ DynDeviceView dyn_view(const CullState& cs) {
 // Ship the queued patch records: one copy into pinned, device-visible host memory and ONE kernel that reads the records from there
 // (a frame's records are tens of KB; the H2D copy call alone cost more host time than the 2000 mirror updates it carried) - no host
 // wait: the two staging halves alternate, a half is rewritten two flushes after the kernel that read it was enqueued.
-int apply_patches(LmxContext* ctx) {
-	CullState& cs = ctx->cull;
+int apply_patches_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, bool profile) {
 	const size_t n_ps = cs.q_sphere.size(), n_pi = cs.q_id.size(), n_pd = cs.q_dyn.size();
 	if (!(n_ps + n_pi + n_pd)) return LMX_OK;
 	const size_t b_ps = n_ps * sizeof(PatchSphere), b_pi = n_pi * sizeof(PatchId), b_pd = n_pd * sizeof(PatchDyn);
@@ -195,19 +243,24 @@ int apply_patches(LmxContext* ctx) {
 	if (b_ps) memcpy(h + o_ps, cs.q_sphere.data(), b_ps);
 	if (b_pi) memcpy(h + o_pi, cs.q_id.data(), b_pi);
 	const char* d = (const char*)st.dev[k];
-	ProfScope ps(ctx, LMX_K_CULL_PATCH);
 	TileBox* const boxes[3] = {cs.tile_box[0].p, cs.tile_box[1].p, cs.tile_box[2].p};
-	LMX_HIP(ctx, launch_apply_patches(ctx->stream, cs.spheres.p, cs.ids.p, boxes, dyn_view(cs), (const PatchSphere*)(d + o_ps), (uint32_t)n_ps,
-		(const PatchId*)(d + o_pi), (uint32_t)n_pi, (const PatchDyn*)(d + o_pd), (uint32_t)n_pd));
-	LMX_HIP(ctx, hipEventRecord(st.done[k], ctx->stream));
+	if (profile) { // (the profiler's event pool belongs to the update thread: the worker of the asynchronous compaction passes false)
+		ProfScope ps(ctx, LMX_K_CULL_PATCH);
+		LMX_HIP(ctx, launch_apply_patches(stream, cs.spheres.p, cs.ids.p, boxes, dyn_view(cs), (const PatchSphere*)(d + o_ps), (uint32_t)n_ps,
+			(const PatchId*)(d + o_pi), (uint32_t)n_pi, (const PatchDyn*)(d + o_pd), (uint32_t)n_pd));
+	} else {
+		LMX_HIP(ctx, launch_apply_patches(stream, cs.spheres.p, cs.ids.p, boxes, dyn_view(cs), (const PatchSphere*)(d + o_ps), (uint32_t)n_ps,
+			(const PatchId*)(d + o_pi), (uint32_t)n_pi, (const PatchDyn*)(d + o_pd), (uint32_t)n_pd));
+	}
+	LMX_HIP(ctx, hipEventRecord(st.done[k], stream));
 	clear_static_queues(cs);
 	clear_dyn_queue(cs);
 	return LMX_OK;
 }
+int apply_patches(LmxContext* ctx) { return apply_patches_on(ctx, ctx->cull, ctx->stream, true); }
 
 // Rebuild the static device layout from the host mirror (lmx_cull_layout.h) and upload it.
-int rebuild_static(LmxContext* ctx) {
-	CullState& cs = ctx->cull;
+int rebuild_static_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, uint32_t overflow_reserve) {
 	CullLayout lay;
 	if (!build_cull_layout(cs.recs, lay)) return fail(ctx, LMX_ERR_CAPACITY, "too many spheres (%zu)", cs.recs.size());
 	const size_t n_padded = lay.n_padded;
@@ -232,14 +285,16 @@ int rebuild_static(LmxContext* ctx) {
 		}
 	}
 	cs.big_tile_fraction = live_tiles ? (double)big_tiles / (double)live_tiles : 0.0;
-	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the buffers below may be reallocated; copies from pageable memory are synchronous anyway
+	// the buffers below may be reallocated; the copies are ordered on `stream` - the context's for the synchronous path, the worker's own
+	// for the asynchronous compaction (a plain hipMemcpy would go through the null stream and order itself against every blocking stream)
+	LMX_HIP(ctx, hipStreamSynchronize(stream));
 	LMX_HIP(ctx, cs.spheres.reserve(std::max<size_t>(n_padded, 1)));
 	LMX_HIP(ctx, cs.ids.reserve(std::max<size_t>(n_padded, 1)));
 	LMX_HIP(ctx, cs.hdr.reserve(std::max<size_t>(n_chunks, 1)));
 	if (n_padded) {
-		LMX_HIP(ctx, hipMemcpy(cs.spheres.p, lay.spheres.data(), n_padded * sizeof(float4), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(cs.ids.p, lay.ids.data(), n_padded * sizeof(int32_t), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(cs.hdr.p, lay.hdr.data(), n_chunks * sizeof(ChunkHdr), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpyAsync(cs.spheres.p, lay.spheres.data(), n_padded * sizeof(float4), hipMemcpyHostToDevice, stream));
+		LMX_HIP(ctx, hipMemcpyAsync(cs.ids.p, lay.ids.data(), n_padded * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+		LMX_HIP(ctx, hipMemcpyAsync(cs.hdr.p, lay.hdr.data(), n_chunks * sizeof(ChunkHdr), hipMemcpyHostToDevice, stream));
 	}
 	for (int k = 0; k < 3; ++k) {
 		cs.tile_cap[k] = lay.tile_cap[k];
@@ -247,25 +302,27 @@ int rebuild_static(LmxContext* ctx) {
 		LMX_HIP(ctx, cs.tile_tab[k].reserve(std::max<size_t>(lay.tile_tab[k].size(), 1)));
 		LMX_HIP(ctx, cs.tile_box[k].reserve(std::max<size_t>(lay.tile_box[k].size(), 1)));
 		if (!lay.tile_cells[k].empty()) {
-			LMX_HIP(ctx, hipMemcpy(cs.tile_cells[k].p, lay.tile_cells[k].data(), lay.tile_cells[k].size() * sizeof(CellKey), hipMemcpyHostToDevice));
-			LMX_HIP(ctx, hipMemcpy(cs.tile_tab[k].p, lay.tile_tab[k].data(), lay.tile_tab[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-			LMX_HIP(ctx, hipMemcpy(cs.tile_box[k].p, lay.tile_box[k].data(), lay.tile_box[k].size() * sizeof(TileBox), hipMemcpyHostToDevice));
+			LMX_HIP(ctx, hipMemcpyAsync(cs.tile_cells[k].p, lay.tile_cells[k].data(), lay.tile_cells[k].size() * sizeof(CellKey), hipMemcpyHostToDevice, stream));
+			LMX_HIP(ctx, hipMemcpyAsync(cs.tile_tab[k].p, lay.tile_tab[k].data(), lay.tile_tab[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+			LMX_HIP(ctx, hipMemcpyAsync(cs.tile_box[k].p, lay.tile_box[k].data(), lay.tile_box[k].size() * sizeof(TileBox), hipMemcpyHostToDevice, stream));
 		}
 	}
+	LMX_HIP(ctx, hipStreamSynchronize(stream)); // `lay` is about to go
 	cs.rec_slot.swap(lay.rec_slot);
 	cs.block_live.swap(lay.block_live);
 	cs.structure_dirty = false;
 	cs.built = true;
-	if (cs.overflow_reserve) cs.dyn_layout_dirty = true; // the reserve follows the new static set's type shares
+	if (overflow_reserve) cs.dyn_layout_dirty = true; // the reserve follows the new static set's type shares
 	cs.n_tombstones = 0;
 	clear_static_queues(cs);
 	return LMX_OK;
 }
+int rebuild_static(LmxContext* ctx) { return rebuild_static_on(ctx, ctx->cull, ctx->stream, ctx->cull.overflow_reserve);
+}
 
 // (Re)assign the device slots of the dynamic set: one region per type, padded to DYN_ALIGN, with room to grow
 // (region = 1.5 x live + one tile), and upload everything.
-int rebuild_dynamic(LmxContext* ctx) {
-	CullState& cs = ctx->cull;
+int rebuild_dynamic_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, uint32_t overflow_reserve) {
 	const size_t n = cs.dyn.size();
 	size_t count_by_type[MAX_TYPES] = {};
 	for (const DynRec& r : cs.dyn) count_by_type[r.type]++;
@@ -280,7 +337,7 @@ int rebuild_dynamic(LmxContext* ctx) {
 	for (int t = 0; t < MAX_TYPES; ++t) {
 		cs.dyn_tt.ent_start[t] = (uint32_t)padded;
 		size_t want = count_by_type[t] ? count_by_type[t] + count_by_type[t] / 2 + DYN_ALIGN : 0;
-		if (cs.overflow_reserve && static_by_type[t]) want = std::max<size_t>(want, count_by_type[t] + (size_t)((double)cs.overflow_reserve * static_by_type[t] / static_total) + DYN_ALIGN);
+		if (overflow_reserve && static_by_type[t]) want = std::max<size_t>(want, count_by_type[t] + (size_t)((double)overflow_reserve * static_by_type[t] / static_total) + DYN_ALIGN);
 		if (want) padded += want / DYN_ALIGN * DYN_ALIGN;
 		cs.dyn_tt.ent_end[t] = (uint32_t)padded;
 		cs.dyn_free[t].clear();
@@ -304,18 +361,19 @@ int rebuild_dynamic(LmxContext* ctx) {
 	for (int t = 0; t < MAX_TYPES; ++t) cs.dyn_next[t] = (uint32_t)cursor[t];
 	cs.dyn_padded = (uint32_t)padded;
 	const size_t cap = std::max<size_t>(padded, 1);
-	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(stream));
 	LMX_HIP(ctx, cs.dyn_px.reserve(cap));
 	LMX_HIP(ctx, cs.dyn_py.reserve(cap));
 	LMX_HIP(ctx, cs.dyn_pz.reserve(cap));
 	LMX_HIP(ctx, cs.dyn_radius.reserve(cap));
 	LMX_HIP(ctx, cs.dyn_ids.reserve(cap));
 	if (padded) {
-		LMX_HIP(ctx, hipMemcpy(cs.dyn_px.p, px.data(), padded * sizeof(double), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(cs.dyn_py.p, py.data(), padded * sizeof(double), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(cs.dyn_pz.p, pz.data(), padded * sizeof(double), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(cs.dyn_radius.p, radius.data(), padded * sizeof(float), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, hipMemcpy(cs.dyn_ids.p, ids.data(), padded * sizeof(int32_t), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpyAsync(cs.dyn_px.p, px.data(), padded * sizeof(double), hipMemcpyHostToDevice, stream));
+		LMX_HIP(ctx, hipMemcpyAsync(cs.dyn_py.p, py.data(), padded * sizeof(double), hipMemcpyHostToDevice, stream));
+		LMX_HIP(ctx, hipMemcpyAsync(cs.dyn_pz.p, pz.data(), padded * sizeof(double), hipMemcpyHostToDevice, stream));
+		LMX_HIP(ctx, hipMemcpyAsync(cs.dyn_radius.p, radius.data(), padded * sizeof(float), hipMemcpyHostToDevice, stream));
+		LMX_HIP(ctx, hipMemcpyAsync(cs.dyn_ids.p, ids.data(), padded * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+		LMX_HIP(ctx, hipStreamSynchronize(stream)); // the staging vectors are about to go
 	}
 	cs.dyn_layout_dirty = false;
 	cs.q_dyn.clear();
@@ -323,6 +381,7 @@ int rebuild_dynamic(LmxContext* ctx) {
 	cs.dyn_generation++;
 	return LMX_OK;
 }
+int rebuild_dynamic(LmxContext* ctx) { return rebuild_dynamic_on(ctx, ctx->cull, ctx->stream, ctx->cull.overflow_reserve); }
 
 // Output shards: per type, the windows of the static set's shards, then those of the dynamic set's. A static window holds
 // exactly the live ids of its blocks; a dynamic window the slots of its tiles.
@@ -381,7 +440,7 @@ int recompute_out_layout(LmxContext* ctx) {
 }
 
 // Move the unbound part of the dynamic set back into the static mirror (the next rebuild sorts it in).
-void fold_overflow(CullState& cs) {
+void fold_overflow(CullSet& cs) {
 	for (uint32_t i = (uint32_t)cs.dyn.size(); i-- > 0;) {
 		if (cs.dyn[i].bound) continue;
 		const DynRec r = cs.dyn[i];
@@ -390,6 +449,457 @@ void fold_overflow(CullState& cs) {
 		cs.ent_to_rec[r.entity] = (int32_t)cs.recs.size();
 		cs.recs.push_back(make_cull_rec(r.entity, r.type, DV3{r.pos[0], r.pos[1], r.pos[2]}, r.radius));
 	}
+}
+
+// ---- the mutating operations, on a given set ------------------------------------------------------------------------------------
+// `cs` is the context's live set for the public entry points and the SHADOW set when the asynchronous compaction replays the
+// operation log (replay = true: no device round trips, and LMX_CULL_OPT_DEVICE_OWNS_BOUND - a statement about the live device set at
+// the time of the call - is not consulted: only operations that took effect are logged). `*effective` = the set changed.
+static int cull_add_impl(LmxContext* ctx, CullSet& cs, int32_t entity, uint8_t type, const double pos[3], float radius) { // culling_system.cpp:131-157
+	if (entity < 0 || !pos) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad entity/pos");
+	if (type >= MAX_TYPES) return fail(ctx, LMX_ERR_CAPACITY, "type %u >= LMX_MAX_TYPES", type);
+	uint32_t idx;
+	if (locate(cs, entity, &idx) != Where::NONE) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d already added", entity);
+	if (layout_live(cs)) {
+		dyn_append(cs, entity, type, DV3{pos[0], pos[1], pos[2]}, radius, false); // sorted in by the next compaction
+		return LMX_OK;
+	}
+	if ((size_t)entity >= cs.ent_to_rec.size()) cs.ent_to_rec.resize((size_t)entity + 1, -1);
+	cs.ent_to_rec[entity] = (int32_t)cs.recs.size();
+	cs.recs.push_back(make_cull_rec(entity, type, DV3{pos[0], pos[1], pos[2]}, radius));
+	cs.structure_dirty = true;
+	return LMX_OK;
+}
+
+static int cull_remove_impl(CullSet& cs, int32_t entity, bool* effective) { // culling_system.cpp:160-190 (unknown entities are ignored, :162-165)
+	uint32_t idx;
+	*effective = true;
+	switch (locate(cs, entity, &idx)) {
+		case Where::STATIC: remove_static(cs, idx); break;
+		case Where::DYNAMIC: remove_dynamic(cs, idx); break;
+		case Where::NONE: *effective = false; break;
+	}
+	return LMX_OK;
+}
+
+static int cull_set_impl(LmxContext* ctx, CullSet& cs, bool device_owns_bound, int32_t entity, const double pos[3], float radius, bool* effective) { // culling_system.cpp:225-242
+	*effective = false;
+	if (!pos) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null pos");
+	uint32_t idx;
+	const DV3 p = DV3{pos[0], pos[1], pos[2]};
+	switch (locate(cs, entity, &idx)) {
+		case Where::STATIC: {
+			CullRec& r = cs.recs[idx];
+			const IV3 c = cell_of(p);
+			if (r.big == is_big_radius(radius) && c.x == r.cell.x && c.y == r.cell.y && c.z == r.cell.z) {
+				r.radius = radius;
+				r.rel = to_v3(sub(p, cell_origin(r.cell)));
+				mark_patch(cs, idx);
+			} else {
+				readd_static(cs, idx, p, radius);
+			}
+			*effective = true;
+			return LMX_OK;
+		}
+		case Where::DYNAMIC: {
+			DynRec& r = cs.dyn[idx];
+			if (r.bound && device_owns_bound) return LMX_OK; // lmx_world_propagate already refreshed this sphere on the device
+			r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
+			r.radius = radius;
+			queue_dyn_patch(cs, r, true);
+			*effective = true;
+			return LMX_OK;
+		}
+		case Where::NONE: break;
+	}
+	return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d is not in the culling system", entity);
+}
+
+static int cull_set_position_impl(LmxContext* ctx, CullSet& cs, bool device_owns_bound, bool replay, int32_t entity, const double pos[3], bool* effective) { // culling_system.cpp:201-217
+	*effective = false;
+	if (!pos) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null pos");
+	uint32_t idx;
+	const DV3 p = DV3{pos[0], pos[1], pos[2]};
+	switch (locate(cs, entity, &idx)) {
+		case Where::STATIC: {
+			CullRec& r = cs.recs[idx];
+			const IV3 c = cell_of(p);
+			if (c.x == r.cell.x && c.y == r.cell.y && c.z == r.cell.z) {
+				r.rel = to_v3(sub(p, cell_origin(r.cell)));
+				mark_patch(cs, idx);
+			} else {
+				readd_static(cs, idx, p, r.radius);
+			}
+			*effective = true;
+			return LMX_OK;
+		}
+		case Where::DYNAMIC: {
+			if (cs.dyn[idx].bound) { // the radius the patch carries must be the one the device last computed
+				if (device_owns_bound) return LMX_OK;
+				if (!replay) { // (the shadow set's copy of a bound sphere is overwritten from the live device set when the sets trade places)
+					if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
+				}
+			}
+			DynRec& r = cs.dyn[idx];
+			r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
+			queue_dyn_patch(cs, r, true);
+			*effective = true;
+			return LMX_OK;
+		}
+		case Where::NONE: break;
+	}
+	return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d is not in the culling system", entity);
+}
+
+static int cull_set_radius_impl(LmxContext* ctx, CullSet& cs, bool device_owns_bound, bool replay, int32_t entity, float radius, bool* effective) { // culling_system.cpp:244-260
+	*effective = false;
+	uint32_t idx;
+	switch (locate(cs, entity, &idx)) {
+		case Where::STATIC: {
+			CullRec& r = cs.recs[idx];
+			if (r.big == is_big_radius(radius)) {
+				r.radius = radius;
+				mark_patch(cs, idx);
+			} else {
+				readd_static(cs, idx, add(cell_origin(r.cell), r.rel), radius); // pos = cell.header.origin + sphere->position
+			}
+			*effective = true;
+			return LMX_OK;
+		}
+		case Where::DYNAMIC: {
+			if (cs.dyn[idx].bound) {
+				if (device_owns_bound) return LMX_OK;
+				if (!replay) {
+					if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
+				}
+			}
+			DynRec& r = cs.dyn[idx];
+			if (is_big_radius(r.radius) != is_big_radius(radius)) {
+				// the reference re-adds at origin + fp32 relative position, which loses the low bits of the position
+				const DV3 p = stored_position(DV3{r.pos[0], r.pos[1], r.pos[2]});
+				r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
+			}
+			r.radius = radius;
+			queue_dyn_patch(cs, r, true);
+			*effective = true;
+			return LMX_OK;
+		}
+		case Where::NONE: break;
+	}
+	return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d is not in the culling system", entity);
+}
+
+
+// lmx_world_bind_culling / unbind on a given set (see cull_make_dynamic)
+static bool make_dynamic_impl(CullSet& cs, int32_t entity) {
+	uint32_t idx;
+	const Where w = locate(cs, entity, &idx);
+	if (w == Where::DYNAMIC) {
+		if (!cs.dyn[idx].bound) {
+			cs.dyn[idx].bound = true;
+			cs.n_unbound--;
+		}
+		return true;
+	}
+	if (w != Where::STATIC) return false;
+	const CullRec r = cs.recs[idx];
+	const DV3 pos = add(cell_origin(r.cell), r.rel);
+	remove_static(cs, idx);
+	dyn_append(cs, entity, r.type, pos, r.radius, true);
+	return true;
+}
+static void unbind_impl(CullSet& cs, int32_t entity) {
+	uint32_t idx;
+	if (locate(cs, entity, &idx) == Where::DYNAMIC && cs.dyn[idx].bound) {
+		cs.dyn[idx].bound = false;
+		cs.n_unbound++;
+	}
+}
+
+
+// ---- asynchronous compaction (LMX_CULL_OPT_ASYNC_COMPACTION) ----------------------------------------------------------------------
+// The re-sort of the static set is the one O(n) step of the culling system (0.4-0.5 s at 10 M entities). With this option it runs on a
+// worker thread, on a SECOND complete copy of the sets (host mirror + device arrays): the shadow set.
+//   * Every effective add / remove / set* / bind of the live set is also appended to an operation log (40 bytes, no lock: the log is
+//     handed to the worker once per flush).
+//   * A job (requested by lmx_cull_flush when the live set's overflow / tombstones pass the usual thresholds): the worker replays the
+//     log onto the shadow set's mirror, folds its overflow into its static mirror, builds and uploads a fresh layout on its own
+//     stream, then keeps replaying newer log segments - now as O(1) patches on the shadow's device arrays - until a segment is short.
+//   * The swap, on the update thread inside a flush: the last few operations are replayed, the two sets trade places (O(1): vectors and
+//     device buffers swap storage), the spheres of hierarchy-bound entities - refreshed on the device, not by the host - are copied
+//     device to device from the old set, and the output shards are re-derived. The old live set, which has seen every operation, is
+//     the next job's shadow.
+// What a frame pays: the log appends, and one swap of a few hundred replayed operations per compaction.
+int async_replay(LmxContext* ctx, CullSet& cs, const CullOp* ops, size_t n) {
+	for (size_t i = 0; i < n; ++i) {
+		const CullOp& o = ops[i];
+		bool eff;
+		int rc = LMX_OK;
+		switch (o.op) {
+			case OP_ADD: rc = cull_add_impl(ctx, cs, o.entity, o.type, o.pos, o.radius); break;
+			case OP_REMOVE: rc = cull_remove_impl(cs, o.entity, &eff); break;
+			case OP_SET: rc = cull_set_impl(ctx, cs, false, o.entity, o.pos, o.radius, &eff); break;
+			case OP_SET_POS: rc = cull_set_position_impl(ctx, cs, false, true, o.entity, o.pos, &eff); break;
+			case OP_SET_RADIUS: rc = cull_set_radius_impl(ctx, cs, false, true, o.entity, o.radius, &eff); break;
+			case OP_BIND: rc = make_dynamic_impl(cs, o.entity) ? LMX_OK : LMX_ERR_INVALID_ARGUMENT; break;
+			case OP_UNBIND: unbind_impl(cs, o.entity); break;
+			default: rc = LMX_ERR_INVALID_ARGUMENT;
+		}
+		if (rc != LMX_OK) return rc; // the shadow set has drifted from the live one: the job fails, the caller falls back to the synchronous path
+	}
+	return LMX_OK;
+}
+
+
+constexpr size_t ASYNC_SHORT_SEGMENT = 4096; // a log segment this short ends the catch-up: the swap replays what arrived meanwhile
+
+int async_job(LmxContext* ctx, CullAsync& a) {
+	CullSet& sh = a.shadow;
+	std::vector<CullOp> seg;
+	{
+		std::lock_guard<std::mutex> g(a.mu);
+		seg.swap(a.log_shared);
+	}
+	// 1. mirror-only replay (no patches: the layout is about to be rebuilt), fold, rebuild both sets of the shadow
+	sh.structure_dirty = true;
+	sh.dyn_layout_dirty = true;
+	clear_static_queues(sh);
+	sh.q_dyn.clear();
+	if (int rc = async_replay(ctx, sh, seg.data(), seg.size())) return rc;
+	fold_overflow(sh);
+	if (a.swapped_pending) { // kernels enqueued on the context's stream before the last swap may still read what is now the shadow set
+		LMX_HIP(ctx, hipStreamWaitEvent(a.stream, a.swapped, 0));
+		a.swapped_pending = false;
+	}
+	if (int rc = rebuild_static_on(ctx, sh, a.stream, a.overflow_reserve)) return rc;
+	if (int rc = rebuild_dynamic_on(ctx, sh, a.stream, a.overflow_reserve)) return rc;
+	// 2. catch up: newer segments as O(1) patches on the shadow's own device arrays
+	for (int round = 0; round < 64; ++round) {
+		seg.clear();
+		{
+			std::lock_guard<std::mutex> g(a.mu);
+			seg.swap(a.log_shared);
+		}
+		if (int rc = async_replay(ctx, sh, seg.data(), seg.size())) return rc;
+		if (sh.dyn_layout_dirty) { // a type's region of the shadow's dynamic set ran full during the replay
+			if (int rc = rebuild_dynamic_on(ctx, sh, a.stream, a.overflow_reserve)) return rc;
+		}
+		if (int rc = apply_patches_on(ctx, sh, a.stream, false)) return rc;
+		if (seg.size() < ASYNC_SHORT_SEGMENT) break;
+	}
+	// 3. entity -> dynamic slot of the shadow set, for the device-to-device copy of bound spheres at the swap
+	a.n_new_slot = 0;
+	bool any_bound = false;
+	for (const DynRec& r : sh.dyn) any_bound = any_bound || r.bound;
+	if (any_bound) {
+		std::vector<int32_t> slot(sh.ent_to_dyn.size(), -1);
+		for (const DynRec& r : sh.dyn)
+			if (r.slot != DYN_NO_SLOT) slot[r.entity] = (int32_t)r.slot;
+		LMX_HIP(ctx, a.d_new_slot.reserve(std::max<size_t>(slot.size(), 1)));
+		if (!slot.empty()) LMX_HIP(ctx, hipMemcpyAsync(a.d_new_slot.p, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice, a.stream));
+		LMX_HIP(ctx, hipStreamSynchronize(a.stream));
+		a.n_new_slot = (uint32_t)slot.size();
+	}
+	LMX_HIP(ctx, hipStreamSynchronize(a.stream));
+	return LMX_OK;
+}
+
+void async_worker(LmxContext* ctx, CullAsync* a) {
+	(void)hipSetDevice(ctx->device);
+	t_layout_thread_cap = 8; // a background re-sort: a quarter of what a synchronous build takes
+	t_fail_sink = &a->error; // the worker's errors must not land in LmxContext::error (the update thread may be writing it): fail() honours this
+	for (;;) {
+		{
+			std::unique_lock<std::mutex> g(a->mu);
+			a->cv.wait(g, [&] { return a->state == CullAsync::REQUESTED || a->state == CullAsync::QUIT; });
+			if (a->state == CullAsync::QUIT) return;
+			a->state = CullAsync::RUNNING;
+		}
+		a->error.clear();
+		const int rc = async_job(ctx, *a);
+		std::lock_guard<std::mutex> g(a->mu);
+		if (a->state == CullAsync::QUIT) return;
+		a->state = rc == LMX_OK ? CullAsync::READY : CullAsync::FAILED;
+		a->jobs_done++;
+	}
+}
+
+// update thread: hand the operations of this flush to the log the worker reads
+void async_publish_log(CullAsync& a) {
+	if (a.log_local.empty()) return;
+	std::lock_guard<std::mutex> g(a.mu);
+	a.log_shared.insert(a.log_shared.end(), a.log_local.begin(), a.log_local.end());
+	a.log_local.clear();
+}
+
+CullAsync::State async_state(CullAsync& a) {
+	std::lock_guard<std::mutex> g(a.mu);
+	return a.state;
+}
+
+// The shadow set := a copy of the live set's host mirror (O(n), once: when the option is switched on, after lmx_cull_build and after
+// a synchronous compaction); its device arrays are rebuilt by the first job anyway.
+void async_reseed(CullState& cs) {
+	CullAsync& a = *cs.async;
+	CullSet& sh = a.shadow;
+	sh.recs = cs.recs;
+	sh.ent_to_rec = cs.ent_to_rec;
+	sh.rec_slot.clear();
+	sh.dyn = cs.dyn;
+	sh.ent_to_dyn = cs.ent_to_dyn;
+	sh.n_unbound = cs.n_unbound;
+	sh.built = cs.built;
+	sh.structure_dirty = true;
+	sh.dyn_layout_dirty = true;
+	sh.n_tombstones = 0;
+	clear_static_queues(sh);
+	sh.q_dyn.clear();
+	a.log_local.clear();
+	std::lock_guard<std::mutex> g(a.mu);
+	a.log_shared.clear();
+}
+
+void async_wait_idle(CullAsync& a) { // update thread: let a running job finish (its result is discarded by the caller)
+	for (;;) {
+		const CullAsync::State st = async_state(a);
+		if (st != CullAsync::REQUESTED && st != CullAsync::RUNNING) return;
+		std::this_thread::yield();
+	}
+}
+
+int recompute_out_layout(LmxContext* ctx);
+
+// update thread, inside a flush, the worker's job is READY: the sets trade places
+int async_swap(LmxContext* ctx) {
+	CullState& cs = ctx->cull;
+	CullAsync& a = *cs.async;
+	CullSet& sh = a.shadow;
+	// what happened since the worker's last segment (normally a frame or two of operations)
+	std::vector<CullOp> tail;
+	{
+		std::lock_guard<std::mutex> g(a.mu);
+		tail.swap(a.log_shared);
+	}
+	tail.insert(tail.end(), a.log_local.begin(), a.log_local.end());
+	a.log_local.clear();
+	a.ops_replayed_at_swap += tail.size();
+	if (int rc = async_replay(ctx, sh, tail.data(), tail.size())) return rc;
+	if (sh.dyn_layout_dirty) {
+		if (int rc = rebuild_dynamic_on(ctx, sh, ctx->stream, cs.overflow_reserve)) return rc;
+		a.n_new_slot = 0; // slots moved: fall back to the host copy of the bound spheres below
+	}
+	if (int rc = apply_patches(ctx)) return rc;                                // the live set's pending patches (its device ids / positions are read below)
+	if (int rc = apply_patches_on(ctx, sh, ctx->stream, true)) return rc;      // ordered behind the worker's uploads: its stream was synchronised before READY
+	// spheres of hierarchy-bound entities live on the device (k_sphere_refresh): old set -> new set, slot by slot through the entity id
+	bool any_bound = false;
+	for (const DynRec& r : sh.dyn) {
+		if (r.bound) {
+			any_bound = true;
+			break;
+		}
+	}
+	if (any_bound) {
+		if (a.n_new_slot && cs.dyn_padded) {
+			LMX_HIP(ctx, launch_dyn_carry_over(ctx->stream, dyn_view(cs), dyn_view(sh), a.d_new_slot.p, a.n_new_slot));
+		} else {
+			if (int rc = cull_dyn_sync_mirror(ctx)) return rc; // (rare path: O(bound entities) on the host)
+			for (DynRec& r : sh.dyn) {
+				uint32_t idx;
+				if (!r.bound || locate(cs, r.entity, &idx) != Where::DYNAMIC) continue;
+				const DynRec& o = cs.dyn[idx];
+				r.pos[0] = o.pos[0]; r.pos[1] = o.pos[1]; r.pos[2] = o.pos[2];
+				r.radius = o.radius;
+				queue_dyn_patch(sh, r, true);
+			}
+			if (int rc = apply_patches_on(ctx, sh, ctx->stream, true)) return rc;
+		}
+	}
+	const uint64_t generation = std::max(cs.dyn_generation, sh.dyn_generation) + 1;
+	static_cast<CullSet&>(cs).swap_with(sh);
+	cs.dyn_generation = generation; // the world's binding tables (slots of bound entities) are re-derived at the next propagation
+	sh.dyn_generation = generation;
+	if (any_bound) cs.dyn_mirror_stale = true; // the host copies of bound spheres are older than the device's
+	// the old live set is the next shadow: it has seen every operation; its device arrays are dead weight until the next job rebuilds them
+	sh.structure_dirty = true;
+	sh.dyn_layout_dirty = true;
+	clear_static_queues(sh);
+	sh.q_dyn.clear();
+	sh.q_sphere_at.clear();
+	if (!a.swapped) LMX_HIP(ctx, hipEventCreateWithFlags(&a.swapped, hipEventDisableTiming));
+	LMX_HIP(ctx, hipEventRecord(a.swapped, ctx->stream));
+	a.swapped_pending = true;
+	a.swaps++;
+	{
+		std::lock_guard<std::mutex> g(a.mu);
+		a.state = CullAsync::IDLE;
+	}
+	return recompute_out_layout(ctx);
+}
+
+bool wants_compaction(const CullState& cs);
+
+// update thread, every flush of a live layout while the option is on. Returns LMX_OK; *handled = the sets were swapped.
+int async_poll(LmxContext* ctx, bool* swapped) {
+	CullState& cs = ctx->cull;
+	CullAsync& a = *cs.async;
+	*swapped = false;
+	async_publish_log(a);
+	const CullAsync::State st = async_state(a);
+	if (st == CullAsync::READY) {
+		if (int rc = async_swap(ctx)) { // could not adopt the shadow set: start over from a copy of the live one
+			async_reseed(cs);
+			std::lock_guard<std::mutex> g(a.mu);
+			a.state = CullAsync::IDLE;
+			return rc;
+		}
+		*swapped = true;
+		return LMX_OK;
+	}
+	if (st == CullAsync::FAILED) {
+		fail(ctx, LMX_ERR_HIP, "asynchronous compaction failed: %s", a.error.c_str());
+		async_reseed(cs);
+		std::lock_guard<std::mutex> g(a.mu);
+		a.state = CullAsync::IDLE;
+		return LMX_OK; // the live set is intact; the next request starts from a fresh copy
+	}
+	if (st == CullAsync::IDLE && cs.auto_compaction && wants_compaction(cs)) {
+		a.overflow_reserve = cs.overflow_reserve;
+		std::lock_guard<std::mutex> g(a.mu);
+		a.state = CullAsync::REQUESTED;
+		a.cv.notify_one();
+	}
+	return LMX_OK;
+}
+
+int async_enable(LmxContext* ctx) {
+	CullState& cs = ctx->cull;
+	if (cs.async) return LMX_OK;
+	CullAsync* a = new CullAsync;
+	hipError_t e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+	if (e != hipSuccess) {
+		delete a;
+		return fail(ctx, LMX_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+	}
+	cs.async = a;
+	async_reseed(cs);
+	a->worker = std::thread(async_worker, ctx, a);
+	return LMX_OK;
+}
+
+void async_disable(CullState& cs) {
+	CullAsync* a = cs.async;
+	if (!a) return;
+	async_wait_idle(*a);
+	{
+		std::lock_guard<std::mutex> g(a->mu);
+		a->state = CullAsync::QUIT;
+		a->cv.notify_one();
+	}
+	if (a->worker.joinable()) a->worker.join();
+	if (a->stream) (void)hipStreamDestroy(a->stream);
+	if (a->swapped) (void)hipEventDestroy(a->swapped);
+	cs.async = nullptr;
+	delete a;
 }
 
 bool wants_compaction(const CullState& cs) {
@@ -402,7 +912,16 @@ bool wants_compaction(const CullState& cs) {
 int flush_impl(LmxContext* ctx, bool force_compaction) {
 	CullState& cs = ctx->cull;
 	bool layout_changed = false;
-	if (wants_compaction(cs) || (force_compaction && (cs.n_unbound || cs.n_tombstones))) {
+	bool compact = wants_compaction(cs) || (force_compaction && (cs.n_unbound || cs.n_tombstones));
+	if (cs.async && layout_live(cs) && !force_compaction) {
+		// the re-sort belongs to the worker: hand it this flush's operations, adopt its result if one is ready, ask for a job when due
+		bool swapped = false;
+		if (int rc = async_poll(ctx, &swapped)) return rc;
+		compact = false;
+		(void)swapped; // (async_swap re-derived the output layout itself)
+	}
+	if (compact && cs.async) async_wait_idle(*cs.async); // a synchronous rebuild (first build, lmx_cull_compact): the shadow set is re-seeded below
+	if (compact) {
 		if (cs.built && cs.n_unbound) {
 			cs.structure_dirty = true; // from here on the mirror ops below must not queue patches against the old layout
 			fold_overflow(cs);
@@ -410,6 +929,11 @@ int flush_impl(LmxContext* ctx, bool force_compaction) {
 		cs.structure_dirty = true;
 		if (int rc = rebuild_static(ctx)) return rc;
 		layout_changed = true;
+		if (cs.async) { // the live set changed outside the operation log
+			async_reseed(cs);
+			std::lock_guard<std::mutex> g(cs.async->mu);
+			if (cs.async->state != CullAsync::QUIT) cs.async->state = CullAsync::IDLE;
+		}
 	}
 	if (cs.dyn_layout_dirty) {
 		if (int rc = cull_dyn_sync_mirror(ctx)) return rc; // keep what the device refreshed before slots move
@@ -422,7 +946,7 @@ int flush_impl(LmxContext* ctx, bool force_compaction) {
 	return apply_patches(ctx);
 }
 
-CullDeviceView static_view(const CullState& cs) {
+CullDeviceView static_view(const CullSet& cs) {
 	CullDeviceView v;
 	v.spheres = cs.spheres.p;
 	v.ids = cs.ids.p;
@@ -468,34 +992,19 @@ int cull_dyn_sync_mirror(LmxContext* ctx) {
 }
 
 bool cull_make_dynamic(LmxContext* ctx, int32_t entity) {
-	CullState& cs = ctx->cull;
-	uint32_t idx;
-	const Where w = locate(cs, entity, &idx);
-	if (w == Where::DYNAMIC) {
-		if (!cs.dyn[idx].bound) {
-			cs.dyn[idx].bound = true;
-			cs.n_unbound--;
-		}
-		return true;
-	}
-	if (w != Where::STATIC) return false;
-	const CullRec r = cs.recs[idx];
-	const DV3 pos = add(cell_origin(r.cell), r.rel);
-	remove_static(cs, idx);
-	dyn_append(cs, entity, r.type, pos, r.radius, true);
+	if (!make_dynamic_impl(ctx->cull, entity)) return false;
+	async_log(ctx->cull, OP_BIND, entity, 0, nullptr, 0.f);
 	return true;
 }
 
 void cull_unbind(LmxContext* ctx, int32_t entity) {
-	CullState& cs = ctx->cull;
-	uint32_t idx;
-	if (locate(cs, entity, &idx) == Where::DYNAMIC && cs.dyn[idx].bound) {
-		cs.dyn[idx].bound = false;
-		cs.n_unbound++;
-	}
+	unbind_impl(ctx->cull, entity);
+	async_log(ctx->cull, OP_UNBIND, entity, 0, nullptr, 0.f);
 }
 
 int cull_flush(LmxContext* ctx) { return flush_impl(ctx, false); }
+
+void cull_async_shutdown(LmxContext* ctx) { async_disable(ctx->cull); }
 
 int cull_view_finalize(LmxContext* ctx, CullView& v) {
 	CullState& cs = ctx->cull;
@@ -563,145 +1072,42 @@ int lmx_cull_build(LmxContext* ctx, uint32_t n, const int32_t* entity, const uin
 	return cull_flush(ctx);
 }
 
-static int cull_add_impl(LmxContext* ctx, int32_t entity, uint8_t type, const double pos[3], float radius) { // culling_system.cpp:131-157
-	if (entity < 0 || !pos) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad entity/pos");
-	if (type >= MAX_TYPES) return fail(ctx, LMX_ERR_CAPACITY, "type %u >= LMX_MAX_TYPES", type);
-	CullState& cs = ctx->cull;
-	uint32_t idx;
-	if (locate(cs, entity, &idx) != Where::NONE) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d already added", entity);
-	if (layout_live(cs)) {
-		dyn_append(cs, entity, type, DV3{pos[0], pos[1], pos[2]}, radius, false); // sorted in by the next compaction
-		return LMX_OK;
-	}
-	if ((size_t)entity >= cs.ent_to_rec.size()) cs.ent_to_rec.resize((size_t)entity + 1, -1);
-	cs.ent_to_rec[entity] = (int32_t)cs.recs.size();
-	cs.recs.push_back(make_cull_rec(entity, type, DV3{pos[0], pos[1], pos[2]}, radius));
-	cs.structure_dirty = true;
-	return LMX_OK;
-}
-
-static int cull_remove_impl(LmxContext* ctx, int32_t entity) { // culling_system.cpp:160-190 (unknown entities are ignored, :162-165)
-	CullState& cs = ctx->cull;
-	uint32_t idx;
-	switch (locate(cs, entity, &idx)) {
-		case Where::STATIC: remove_static(cs, idx); break;
-		case Where::DYNAMIC: remove_dynamic(cs, idx); break;
-		case Where::NONE: break;
-	}
-	return LMX_OK;
-}
-
-static int cull_set_impl(LmxContext* ctx, int32_t entity, const double pos[3], float radius) { // culling_system.cpp:225-242
-	if (!pos) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null pos");
-	CullState& cs = ctx->cull;
-	uint32_t idx;
-	const DV3 p = DV3{pos[0], pos[1], pos[2]};
-	switch (locate(cs, entity, &idx)) {
-		case Where::STATIC: {
-			CullRec& r = cs.recs[idx];
-			const IV3 c = cell_of(p);
-			if (r.big == is_big_radius(radius) && c.x == r.cell.x && c.y == r.cell.y && c.z == r.cell.z) {
-				r.radius = radius;
-				r.rel = to_v3(sub(p, cell_origin(r.cell)));
-				mark_patch(cs, idx);
-			} else {
-				readd_static(cs, idx, p, radius);
-			}
-			return LMX_OK;
-		}
-		case Where::DYNAMIC: {
-			DynRec& r = cs.dyn[idx];
-			if (r.bound && cs.device_owns_bound) return LMX_OK; // lmx_world_propagate already refreshed this sphere on the device
-			r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
-			r.radius = radius;
-			queue_dyn_patch(cs, r, true);
-			return LMX_OK;
-		}
-		case Where::NONE: break;
-	}
-	return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d is not in the culling system", entity);
-}
-
 // add / remove / set only touch the host mirror and the patch queues: no HIP call, no hipSetDevice per entity
 int lmx_cull_add(LmxContext* ctx, int32_t entity, uint8_t type, const double pos[3], float radius) {
 	if (!ctx) return LMX_ERR_INVALID_ARGUMENT;
-	return cull_add_impl(ctx, entity, type, pos, radius);
+	const int rc = cull_add_impl(ctx, ctx->cull, entity, type, pos, radius);
+	if (rc == LMX_OK) async_log(ctx->cull, OP_ADD, entity, type, pos, radius);
+	return rc;
 }
 int lmx_cull_remove(LmxContext* ctx, int32_t entity) {
 	if (!ctx) return LMX_ERR_INVALID_ARGUMENT;
-	return cull_remove_impl(ctx, entity);
+	bool effective;
+	const int rc = cull_remove_impl(ctx->cull, entity, &effective);
+	if (rc == LMX_OK && effective) async_log(ctx->cull, OP_REMOVE, entity, 0, nullptr, 0.f);
+	return rc;
 }
 int lmx_cull_set(LmxContext* ctx, int32_t entity, const double pos[3], float radius) {
 	if (!ctx) return LMX_ERR_INVALID_ARGUMENT;
-	return cull_set_impl(ctx, entity, pos, radius);
+	bool effective;
+	const int rc = cull_set_impl(ctx, ctx->cull, ctx->cull.device_owns_bound, entity, pos, radius, &effective);
+	if (rc == LMX_OK && effective) async_log(ctx->cull, OP_SET, entity, 0, pos, radius);
+	return rc;
 }
 
 int lmx_cull_set_position(LmxContext* ctx, int32_t entity, const double pos[3]) { // culling_system.cpp:201-217
 	LMX_CHECK_CTX(ctx);
-	if (!pos) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null pos");
-	CullState& cs = ctx->cull;
-	uint32_t idx;
-	const DV3 p = DV3{pos[0], pos[1], pos[2]};
-	switch (locate(cs, entity, &idx)) {
-		case Where::STATIC: {
-			CullRec& r = cs.recs[idx];
-			const IV3 c = cell_of(p);
-			if (c.x == r.cell.x && c.y == r.cell.y && c.z == r.cell.z) {
-				r.rel = to_v3(sub(p, cell_origin(r.cell)));
-				mark_patch(cs, idx);
-			} else {
-				readd_static(cs, idx, p, r.radius);
-			}
-			return LMX_OK;
-		}
-		case Where::DYNAMIC: {
-			if (cs.dyn[idx].bound) { // the radius the patch carries must be the one the device last computed
-				if (cs.device_owns_bound) return LMX_OK;
-				if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
-			}
-			DynRec& r = cs.dyn[idx];
-			r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
-			queue_dyn_patch(cs, r, true);
-			return LMX_OK;
-		}
-		case Where::NONE: break;
-	}
-	return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d is not in the culling system", entity);
+	bool effective;
+	const int rc = cull_set_position_impl(ctx, ctx->cull, ctx->cull.device_owns_bound, false, entity, pos, &effective);
+	if (rc == LMX_OK && effective) async_log(ctx->cull, OP_SET_POS, entity, 0, pos, 0.f);
+	return rc;
 }
 
 int lmx_cull_set_radius(LmxContext* ctx, int32_t entity, float radius) { // culling_system.cpp:244-260
 	LMX_CHECK_CTX(ctx);
-	CullState& cs = ctx->cull;
-	uint32_t idx;
-	switch (locate(cs, entity, &idx)) {
-		case Where::STATIC: {
-			CullRec& r = cs.recs[idx];
-			if (r.big == is_big_radius(radius)) {
-				r.radius = radius;
-				mark_patch(cs, idx);
-			} else {
-				readd_static(cs, idx, add(cell_origin(r.cell), r.rel), radius); // pos = cell.header.origin + sphere->position
-			}
-			return LMX_OK;
-		}
-		case Where::DYNAMIC: {
-			if (cs.dyn[idx].bound) {
-				if (cs.device_owns_bound) return LMX_OK;
-				if (int rc = cull_dyn_sync_mirror(ctx)) return rc;
-			}
-			DynRec& r = cs.dyn[idx];
-			if (is_big_radius(r.radius) != is_big_radius(radius)) {
-				// the reference re-adds at origin + fp32 relative position, which loses the low bits of the position
-				const DV3 p = stored_position(DV3{r.pos[0], r.pos[1], r.pos[2]});
-				r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
-			}
-			r.radius = radius;
-			queue_dyn_patch(cs, r, true);
-			return LMX_OK;
-		}
-		case Where::NONE: break;
-	}
-	return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "entity %d is not in the culling system", entity);
+	bool effective;
+	const int rc = cull_set_radius_impl(ctx, ctx->cull, ctx->cull.device_owns_bound, false, entity, radius, &effective);
+	if (rc == LMX_OK && effective) async_log(ctx->cull, OP_SET_RADIUS, entity, 0, nullptr, radius);
+	return rc;
 }
 
 int lmx_cull_get_radius(LmxContext* ctx, int32_t entity, float* out_radius) {
@@ -735,7 +1141,7 @@ int lmx_cull_is_added(LmxContext* ctx, int32_t entity) {
 // software prefetch ahead of the update loop (entity -> record index PF_FAR updates ahead, the record and its slot PF_NEAR ahead), so
 // the misses of neighbouring updates overlap.
 constexpr uint32_t PF_FAR = 24, PF_NEAR = 12;
-static inline void prefetch_update(const CullState& cs, const int32_t* entity, uint32_t n, uint32_t i) {
+static inline void prefetch_update(const CullSet& cs, const int32_t* entity, uint32_t n, uint32_t i) {
 	if (i + PF_FAR < n) {
 		const int32_t e = entity[i + PF_FAR];
 		if (e >= 0) {
@@ -764,7 +1170,8 @@ int lmx_cull_add_many(LmxContext* ctx, uint32_t n, const int32_t* entity, const 
 	if (n && (!entity || !type || !pos_xyz || !radius)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
 	for (uint32_t i = 0; i < n; ++i) {
 		prefetch_update(ctx->cull, entity, n, i);
-		if (int rc = cull_add_impl(ctx, entity[i], type[i], pos_xyz + 3 * (size_t)i, radius[i])) return rc;
+		if (int rc = cull_add_impl(ctx, ctx->cull, entity[i], type[i], pos_xyz + 3 * (size_t)i, radius[i])) return rc;
+		async_log(ctx->cull, OP_ADD, entity[i], type[i], pos_xyz + 3 * (size_t)i, radius[i]);
 	}
 	return LMX_OK;
 }
@@ -774,7 +1181,9 @@ int lmx_cull_set_many(LmxContext* ctx, uint32_t n, const int32_t* entity, const 
 	if (n && (!entity || !pos_xyz || !radius)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
 	for (uint32_t i = 0; i < n; ++i) {
 		prefetch_update(ctx->cull, entity, n, i);
-		if (int rc = cull_set_impl(ctx, entity[i], pos_xyz + 3 * (size_t)i, radius[i])) return rc;
+		bool effective;
+		if (int rc = cull_set_impl(ctx, ctx->cull, ctx->cull.device_owns_bound, entity[i], pos_xyz + 3 * (size_t)i, radius[i], &effective)) return rc;
+		if (effective) async_log(ctx->cull, OP_SET, entity[i], 0, pos_xyz + 3 * (size_t)i, radius[i]);
 	}
 	return LMX_OK;
 }
@@ -784,7 +1193,9 @@ int lmx_cull_remove_many(LmxContext* ctx, uint32_t n, const int32_t* entity) {
 	if (n && !entity) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null input array");
 	for (uint32_t i = 0; i < n; ++i) {
 		prefetch_update(ctx->cull, entity, n, i);
-		if (int rc = cull_remove_impl(ctx, entity[i])) return rc;
+		bool effective;
+		if (int rc = cull_remove_impl(ctx->cull, entity[i], &effective)) return rc;
+		if (effective) async_log(ctx->cull, OP_REMOVE, entity[i], 0, nullptr, 0.f);
 	}
 	return LMX_OK;
 }
@@ -816,6 +1227,19 @@ int lmx_cull_update_stats(LmxContext* ctx, uint32_t* n_static, uint32_t* n_dynam
 	if (n_dynamic_bound) *n_dynamic_bound = (uint32_t)(cs.dyn.size() - cs.n_unbound);
 	if (n_overflow) *n_overflow = cs.n_unbound;
 	if (n_tombstones) *n_tombstones = cs.n_tombstones;
+	return LMX_OK;
+}
+
+int lmx_cull_async_stats(LmxContext* ctx, int* state, uint64_t* jobs, uint64_t* swaps, uint64_t* ops_replayed_at_swaps) {
+	if (!ctx) return LMX_ERR_INVALID_ARGUMENT;
+	CullAsync* a = ctx->cull.async;
+	if (state) *state = a ? (int)async_state(*a) : -1;
+	if (a) {
+		std::lock_guard<std::mutex> g(a->mu);
+		if (jobs) *jobs = a->jobs_done;
+	} else if (jobs) *jobs = 0;
+	if (swaps) *swaps = a ? a->swaps : 0;
+	if (ops_replayed_at_swaps) *ops_replayed_at_swaps = a ? a->ops_replayed_at_swap : 0;
 	return LMX_OK;
 }
 
@@ -946,6 +1370,10 @@ int lmx_cull_set_option(LmxContext* ctx, int option, int value) {
 			return LMX_OK;
 		case LMX_CULL_OPT_AUTO_COMPACTION: cs.auto_compaction = value != 0; return LMX_OK;
 		case LMX_CULL_OPT_DEVICE_OWNS_BOUND: cs.device_owns_bound = value != 0; return LMX_OK;
+		case LMX_CULL_OPT_ASYNC_COMPACTION:
+			if (value) return async_enable(ctx);
+			async_disable(cs);
+			return LMX_OK;
 		case LMX_CULL_OPT_OVERFLOW_RESERVE:
 			if (value < 0) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "overflow reserve %d < 0", value);
 			cs.overflow_reserve = (uint32_t)value;

@@ -29,6 +29,13 @@ template <typename T> struct DevBuf {
 		p = nullptr;
 		cap = 0;
 	}
+	DevBuf() = default;
+	DevBuf(const DevBuf&) = delete;
+	DevBuf& operator=(const DevBuf&) = delete;
+	void swap(DevBuf& o) {
+		std::swap(p, o.p);
+		std::swap(cap, o.cap);
+	}
 	// grow-only; contents are NOT preserved
 	hipError_t reserve(size_t n) {
 		if (n <= cap) return hipSuccess;
@@ -102,6 +109,18 @@ struct PatchStaging {
 	size_t cap[2] = {0, 0};
 	hipEvent_t done[2] = {nullptr, nullptr};
 	uint32_t next = 0;
+	PatchStaging() = default;
+	PatchStaging(const PatchStaging&) = delete;
+	PatchStaging& operator=(const PatchStaging&) = delete;
+	void swap(PatchStaging& o) {
+		for (int i = 0; i < 2; ++i) {
+			std::swap(host[i], o.host[i]);
+			std::swap(dev[i], o.dev[i]);
+			std::swap(cap[i], o.cap[i]);
+			std::swap(done[i], o.done[i]);
+		}
+		std::swap(next, o.next);
+	}
 	~PatchStaging() {
 		for (int i = 0; i < 2; ++i) {
 			if (host[i]) (void)hipHostFree(host[i]);
@@ -110,7 +129,10 @@ struct PatchStaging {
 	}
 };
 
-struct CullState {
+// One complete copy of the culling sets: host mirror + device layout of the static set, the dynamic set, the pending patch queues.
+// A context has ONE live set (CullState derives from it); with LMX_CULL_OPT_ASYNC_COMPACTION a second, shadow set exists that a worker
+// thread re-sorts in the background (lmx_capi_cull.hip, "asynchronous compaction") and that trades places with the live one in O(1).
+struct CullSet {
 	// ---- static set: host mirror (one CullRec per entity) + sorted device layout -------------------------------
 	std::vector<CullRec> recs;
 	std::vector<int32_t> ent_to_rec; // entity -> index into recs, or -1
@@ -154,6 +176,61 @@ struct CullState {
 	std::vector<uint32_t> q_sphere_at; // static slot -> index into q_sphere, ~0u = no pending record (a hash map here cost 0.7 us per set)
 	std::vector<uint32_t> q_dyn_at;                     // dynamic slot -> index into q_dyn, or ~0u
 	PatchStaging staging;
+	// everything above trades places with `o` (O(1): vectors and device buffers swap their storage)
+	void swap_with(CullSet& o) {
+		recs.swap(o.recs);
+		ent_to_rec.swap(o.ent_to_rec);
+		rec_slot.swap(o.rec_slot);
+		std::swap(structure_dirty, o.structure_dirty);
+		std::swap(built, o.built);
+		std::swap(n_tombstones, o.n_tombstones);
+		spheres.swap(o.spheres);
+		ids.swap(o.ids);
+		hdr.swap(o.hdr);
+		for (int k = 0; k < 3; ++k) {
+			tile_cells[k].swap(o.tile_cells[k]);
+			tile_tab[k].swap(o.tile_tab[k]);
+			tile_box[k].swap(o.tile_box[k]);
+			std::swap(tile_cap[k], o.tile_cap[k]);
+			std::swap(max_tile_cells[k], o.max_tile_cells[k]);
+			std::swap(scene_lo[k], o.scene_lo[k]);
+			std::swap(scene_hi[k], o.scene_hi[k]);
+		}
+		std::swap(n_padded, o.n_padded);
+		std::swap(n_cells, o.n_cells);
+		std::swap(n_dead_cells, o.n_dead_cells);
+		block_live.swap(o.block_live);
+		std::swap(big_tile_fraction, o.big_tile_fraction);
+		std::swap(tt, o.tt);
+		dyn.swap(o.dyn);
+		ent_to_dyn.swap(o.ent_to_dyn);
+		std::swap(n_unbound, o.n_unbound);
+		std::swap(dyn_layout_dirty, o.dyn_layout_dirty);
+		std::swap(dyn_mirror_stale, o.dyn_mirror_stale);
+		dyn_px.swap(o.dyn_px);
+		dyn_py.swap(o.dyn_py);
+		dyn_pz.swap(o.dyn_pz);
+		dyn_radius.swap(o.dyn_radius);
+		dyn_ids.swap(o.dyn_ids);
+		std::swap(dyn_padded, o.dyn_padded);
+		std::swap(dyn_tt, o.dyn_tt);
+		for (int t = 0; t < MAX_TYPES; ++t) {
+			std::swap(dyn_next[t], o.dyn_next[t]);
+			dyn_free[t].swap(o.dyn_free[t]);
+		}
+		std::swap(dyn_generation, o.dyn_generation);
+		q_sphere.swap(o.q_sphere);
+		q_id.swap(o.q_id);
+		q_dyn.swap(o.q_dyn);
+		q_sphere_at.swap(o.q_sphere_at);
+		q_dyn_at.swap(o.q_dyn_at);
+		staging.swap(o.staging);
+	}
+};
+
+struct CullAsync; // lmx_capi_cull.hip
+
+struct CullState : CullSet {
 	// ---- output shards ----------------------------------------------------------------------------------------
 	uint32_t n_shards = 0, max_shard_cap = 0;
 	std::vector<uint8_t> shard_type;
@@ -167,6 +244,7 @@ struct CullState {
 	uint32_t overflow_reserve = 0; // LMX_CULL_OPT_OVERFLOW_RESERVE: slots kept free in the dynamic set for entities added / re-celled between compactions
 	bool device_owns_bound = false; // LMX_CULL_OPT_DEVICE_OWNS_BOUND: set* calls on hierarchy-bound entities are dropped
 	bool auto_compaction = true; // false: overflow / tombstones accumulate until the host calls lmx_cull_compact
+	CullAsync* async = nullptr;  // LMX_CULL_OPT_ASYNC_COMPACTION: shadow set + worker thread (owned; lmx_capi_cull.hip)
 	int lane_parallel = 2;     // tile-level box test of the 1-frustum kernels: 0 = uniform code in every wave, 1 = one plane per lane in every wave, 2 = one plane per lane in wave 0, verdict through LDS
 	uint32_t max_shards = LAYOUT_MAX_SHARDS; // output shards per type of the static set
 	uint32_t cnt_pad = 32;     // words between shard counters (32 = one 128-byte line each)
@@ -355,6 +433,8 @@ struct LmxContext {
 namespace lmx {
 
 int fail(LmxContext* ctx, int code, const char* fmt, ...); // records the message, returns `code`
+extern thread_local std::string* t_fail_sink; // non-null on a library-owned thread: fail() writes there instead of LmxContext::error
+void cull_async_shutdown(LmxContext* ctx);   // lmx_capi_cull.hip: stop the asynchronous compaction's worker (context teardown)
 void prof_drain(LmxContext* ctx);
 int cull_flush(LmxContext* ctx);          // lmx_capi_cull.hip: make the device copy of the culling sets current
 int cull_dyn_sync_mirror(LmxContext* ctx); // dyn[] <- device when lmx_world_propagate refreshed it

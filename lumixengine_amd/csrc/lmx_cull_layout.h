@@ -117,10 +117,11 @@ inline uint64_t spread3(uint64_t x) {
 }
 
 // ---- small host-side parallel helpers (scene load / layout rebuild of 10^7..10^8 spheres) ------------------------------
+inline thread_local unsigned t_layout_thread_cap = 32; // the asynchronous compaction's worker lowers it: a background re-sort should not take the machine
 inline unsigned layout_threads(size_t n) {
 	if (n < (1u << 18)) return 1;
 	const unsigned hw = std::thread::hardware_concurrency();
-	return std::max(1u, std::min(hw ? hw : 1u, 32u));
+	return std::max(1u, std::min(hw ? hw : 1u, t_layout_thread_cap));
 }
 template <typename Fn> inline void parallel_ranges(size_t n, Fn fn) { // fn(begin, end) over a partition of [0, n)
 	const unsigned t = layout_threads(n);

@@ -77,6 +77,7 @@ struct DynDeviceView {
 	int32_t* ids; // -1 = free slot
 	uint32_t n_padded;
 };
+hipError_t launch_dyn_carry_over(hipStream_t s, const DynDeviceView& from, const DynDeviceView& to, const int32_t* new_slot_of_entity, uint32_t n_entities);
 hipError_t launch_cull_dynamic(hipStream_t s, const DynDeviceView& d, uint32_t slot_begin, uint32_t slot_end, const TypeTable& dyn_tt,
 	const FrustaArg& fr, int n_frusta, const CullOut& out);
 uint32_t cull_dynamic_tile(int n_frusta, uint32_t n_slots);

@@ -350,6 +350,91 @@ def test_cull_add_stream_never_stalls(gpu_ctx, oracle_port):
         cs.setOption(api.CULL_OPT_AUTO_COMPACTION, 1)
 
 
+def test_cull_async_compaction_stream(gpu_ctx, oracle_port):
+    """LMX_CULL_OPT_ASYNC_COMPACTION: the re-sort of the static set on a worker thread, against a second copy of the sets, traded with
+    the live one inside a flush. A 600 k-entity scene takes 2000 adds + 500 removes + 500 moves per frame (the thresholds of the
+    automatic compaction are crossed every ~40 frames) with a cull per frame; the visible set is compared with the oracle every few
+    frames - in particular right after every swap - several sets must have been traded, the update thread must have replayed only a
+    small tail of operations at each swap, and no frame may take anywhere near what a synchronous re-sort of this set costs."""
+    n, half = 600_000, 6000.0
+    sc = scenes.cull_scene(n, half, seed=31, mixed_types=True)
+    cs = api.CullingSystem(gpu_ctx)
+    try:
+        cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+        t0 = time.perf_counter()
+        cs.compact()  # nothing to do: measures nothing; the synchronous cost is measured below on a dirty set
+        cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 1)
+        assert cs.asyncStats()["state"] == 0
+        ocs = oracle_port.culling_system()
+        ocs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+        alive = list(range(n))
+        pos_of = {}
+        next_id = n
+        rng = np.random.default_rng(5)
+        cams = H.frusta(api, names=["origin_identity", "origin_yaw_pitch", "narrow_fov"])
+        t_frames, swaps_seen, checked_after_swap = [], 0, 0
+        frame = 0
+        deadline = time.time() + 240
+        while (swaps_seen < 3 or frame < 150) and time.time() < deadline:
+            k_add, k_rm, k_mv = 2000, 500, 500
+            ids = np.arange(next_id, next_id + k_add, dtype=np.int32)
+            next_id += k_add
+            p_add = rng.uniform(-half, half, size=(k_add, 3))
+            r_add = np.exp(rng.uniform(np.log(0.5), np.log(60.0), size=k_add)).astype(np.float32)
+            t_add = rng.integers(0, 3, k_add).astype(np.uint8)
+            pick = rng.choice(len(alive), size=k_rm + k_mv, replace=False)
+            rm = np.array([alive[i] for i in pick[:k_rm]], np.int32)
+            mv = np.array([alive[i] for i in pick[k_rm:]], np.int32)
+            p_mv = rng.uniform(-half, half, size=(k_mv, 3))
+            r_mv = np.exp(rng.uniform(np.log(0.5), np.log(400.0), size=k_mv)).astype(np.float32)  # some cross the big-sphere threshold
+            for i in sorted(pick[:k_rm].tolist(), reverse=True):
+                alive[i] = alive[-1]
+                alive.pop()
+            alive.extend(ids.tolist())
+            ocs.add_bulk(ids, t_add, p_add, r_add)
+            for e in rm.tolist():
+                ocs.remove(e)
+            for j, e in enumerate(mv.tolist()):
+                ocs.set(e, p_mv[j], float(r_mv[j]))
+            fr = cams[frame % len(cams) : frame % len(cams) + 1]
+            t1 = time.perf_counter()
+            cs.addMany(ids, t_add, p_add, r_add)
+            cs.removeMany(rm)
+            cs.setMany(mv, p_mv, r_mv)
+            res = cs.cull(fr)
+            gpu_ctx.synchronize()
+            t_frames.append(time.perf_counter() - t1)
+            st = cs.asyncStats()
+            assert st["state"] != 4, "the asynchronous compaction failed"
+            swapped = st["swaps"] > swaps_seen
+            swaps_seen = st["swaps"]
+            if swapped or frame % 25 == 0:
+                H.assert_same_visible(gpu_visible(res, 0), oracle_visible(ocs, fr), f"frame {frame} (swaps {swaps_seen})")
+                checked_after_swap += 1 if swapped else 0
+            frame += 1
+            time.sleep(0.002)  # a frame of a real engine lasts milliseconds: the worker's catch-up must be able to outrun the update stream
+        st = cs.asyncStats()
+        assert st["swaps"] >= 3 and checked_after_swap >= 3, (st, frame)
+        assert st["ops_replayed_at_swaps"] <= st["swaps"] * 40_000, st  # a few frames' worth per swap, not the build's whole backlog
+        us = cs.updateStats()
+        assert us["static"] + us["overflow"] == len(alive), (us, len(alive))
+        # the synchronous re-sort of the same set, for scale
+        cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 0)
+        assert cs.asyncStats()["state"] == -1
+        ids = np.arange(next_id, next_id + 100_000, dtype=np.int32)
+        cs.addMany(ids, np.zeros(len(ids), np.uint8), rng.uniform(-half, half, size=(len(ids), 3)), np.ones(len(ids), np.float32))
+        t1 = time.perf_counter()
+        cs.compact()
+        gpu_ctx.synchronize()
+        t_sync = time.perf_counter() - t1
+        t = np.array(t_frames[3:])
+        print(f"async compaction: {frame} frames, {st['swaps']} swaps, {st['ops_replayed_at_swaps']} ops replayed at swaps; slowest frame {1e3 * t.max():.2f} ms, "
+              f"median {1e3 * np.median(t):.3f} ms; synchronous re-sort {1e3 * t_sync:.1f} ms")
+        assert t.max() < 0.5 * t_sync, f"slowest frame {1e3 * t.max():.2f} ms vs a synchronous re-sort of {1e3 * t_sync:.1f} ms"
+    finally:
+        cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 0)
+
+
 def test_cull_10m_properties(gpu_ctx):
     """BASELINE config 2 size (10 M): size-independent properties next to the digest comparison above.
 
