@@ -435,6 +435,69 @@ def test_cull_async_compaction_stream(gpu_ctx, oracle_port):
         cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 0)
 
 
+def test_cull_async_compaction_lifecycle(oracle_port):
+    """The worker of LMX_CULL_OPT_ASYNC_COMPACTION against everything that can cut across a running job: a synchronous lmx_cull_compact,
+    a fresh lmx_cull_build, switching the option off, and tearing the context down - each right after a job was requested. Results stay
+    the oracle's, nothing hangs, nothing crashes."""
+    ctx = api.Context(0)
+    try:
+        n, half = 400_000, 5000.0
+        sc = scenes.cull_scene(n, half, seed=37)
+        cs = api.CullingSystem(ctx)
+        cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+        ocs = oracle_port.culling_system()
+        ocs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+        fr = api.viewport_frustum()
+        rng = np.random.default_rng(3)
+        next_id = [n]
+
+        def burst(k):  # enough adds to cross the compaction threshold (max(65536, n / 8)) in one go
+            ids = np.arange(next_id[0], next_id[0] + k, dtype=np.int32)
+            next_id[0] += k
+            p = rng.uniform(-half, half, size=(k, 3))
+            r = np.exp(rng.uniform(np.log(0.5), np.log(60.0), size=k)).astype(np.float32)
+            ocs.add_bulk(ids, np.zeros(k, np.uint8), p, r)
+            cs.addMany(ids, np.zeros(k, np.uint8), p, r)
+
+        def same(what):
+            H.assert_same_visible(gpu_visible(cs.cull(fr), 0), oracle_visible(ocs, fr), what)
+
+        cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 1)
+        burst(80_000)
+        same("job requested")  # the flush inside this cull asks for the job
+        assert cs.asyncStats()["state"] in (1, 2, 3)
+        cs.compact()  # synchronous re-sort while the job runs: waits for it, discards it, re-seeds the shadow set
+        st = cs.updateStats()
+        assert st["overflow"] == 0 and cs.asyncStats()["state"] == 0
+        same("after a synchronous compaction")
+        burst(80_000)
+        same("second job requested")
+        sc2 = scenes.cull_scene(150_000, 3000.0, seed=38)  # a new scene while the job runs
+        cs.build(sc2["entity"], sc2["type"], sc2["pos"], sc2["radius"])
+        ocs = oracle_port.culling_system()
+        ocs.add_bulk(sc2["entity"], sc2["type"], sc2["pos"], sc2["radius"])
+        next_id[0] = 150_000
+        same("after lmx_cull_build")
+        burst(70_000)
+        same("third job requested")
+        deadline = time.time() + 60
+        while cs.asyncStats()["swaps"] == 0 and time.time() < deadline:  # let this one finish: the swap happens inside a cull's flush
+            same("waiting for the swap")
+            time.sleep(0.005)
+        assert cs.asyncStats()["swaps"] >= 1
+        same("after the swap")
+        burst(70_000)
+        same("fourth job requested")
+        cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 0)  # off while the job runs
+        assert cs.asyncStats()["state"] == -1
+        same("option off")
+        cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 1)
+        burst(70_000)
+        same("fifth job requested")
+    finally:
+        ctx.close()  # with a job possibly still running: the teardown joins the worker
+
+
 def test_cull_10m_properties(gpu_ctx):
     """BASELINE config 2 size (10 M): size-independent properties next to the digest comparison above.
 

@@ -219,6 +219,79 @@ def test_world_moves_refresh_culling(gpu_ctx, live_oracle):
             assert cs.getRadius(e) == ocs.get_radius(e)
 
 
+def test_world_bound_spheres_survive_async_compaction(gpu_ctx, oracle_port):
+    """LMX_CULL_OPT_ASYNC_COMPACTION with hierarchy-bound entities: their spheres are refreshed on the device (k_sphere_refresh), never
+    by the host, so when the re-sorted copy of the sets trades places with the live one they must be carried over device to device
+    (k_dyn_carry_over) - including the entities that did NOT move in the frames around the swap, whose only up-to-date copy is the old
+    device set. 9000 bound entities in chains + 150 k static ones; every frame moves a tenth of the roots and adds 3000 static
+    entities (the compaction thresholds are crossed every ~22 frames); the visible set is the oracle's after every swap."""
+    import time
+
+    h = scenes.hierarchy_chains(3000, 3, seed=41, root_extent=2500.0)
+    n = len(h["parent"])
+    rng = np.random.default_rng(12)
+    model_radius = rng.uniform(0.5, 40.0, n).astype(np.float32)
+    ow, roots, kids = oracle_world(oracle_port, h)
+    ocs = oracle_port.culling_system()
+    tr0 = ow.get_transforms()
+    ent = np.arange(n, dtype=np.int32)
+    r0 = model_radius * tr0["scale"].max(axis=1)
+    ocs.add_bulk(ent, np.zeros(n, np.uint8), tr0["pos"], r0)
+    n_static = 150_000
+    s_ent = np.arange(n, n + n_static, dtype=np.int32)
+    s_pos = rng.uniform(-3000.0, 3000.0, size=(n_static, 3))
+    s_rad = np.exp(rng.uniform(np.log(0.5), np.log(60.0), size=n_static)).astype(np.float32)
+    ocs.add_bulk(s_ent, np.ones(n_static, np.uint8), s_pos, s_rad)
+    ow.bind_culling(ocs, ent, model_radius)
+
+    w = api.World(gpu_ctx)
+    w.build(h["parent"], gpu_inputs(ow, h["parent"], roots))
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(np.concatenate([ent, s_ent]), np.concatenate([np.zeros(n, np.uint8), np.ones(n_static, np.uint8)]), np.concatenate([tr0["pos"], s_pos]),
+             np.concatenate([r0, s_rad]))
+    w.bindCulling(ent, model_radius)
+    fr = np.concatenate([api.viewport_frustum(pos=(0, 0, 2000.0)), api.viewport_frustum(pos=(300.0, 50.0, -100.0), rot=H.quat_from_yaw_pitch(1.0, 0.1))])
+    try:
+        cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 1)
+        next_id = n + n_static
+        swaps_seen, checked_after_swap, frame = 0, 0, 0
+        deadline = time.time() + 240
+        while (swaps_seen < 2 or frame < 60) and time.time() < deadline:
+            moved = roots if frame < 2 else rng.choice(roots, size=len(roots) // 10, replace=False)
+            new_root = ow.get_transforms()[moved]
+            new_root["pos"] += rng.uniform(-300.0, 300.0, size=(len(moved), 3))
+            new_root["scale"] = rng.uniform(0.5, 2.0, size=(len(moved), 3)).astype(np.float32)
+            ow.set_transforms(moved, new_root)
+            w.setTransforms(moved, new_root)
+            w.propagate()
+            k = 3000
+            ids = np.arange(next_id, next_id + k, dtype=np.int32)
+            next_id += k
+            p = rng.uniform(-3000.0, 3000.0, size=(k, 3))
+            r = np.exp(rng.uniform(np.log(0.5), np.log(60.0), size=k)).astype(np.float32)
+            ocs.add_bulk(ids, np.ones(k, np.uint8), p, r)
+            cs.addMany(ids, np.ones(k, np.uint8), p, r)
+            res = cs.cull(fr)
+            st = cs.asyncStats()
+            assert st["state"] != 4, "the asynchronous compaction failed"
+            swapped = st["swaps"] > swaps_seen
+            swaps_seen = st["swaps"]
+            if swapped or frame % 10 == 0:
+                for f in range(len(fr)):
+                    ids_o, types_o, _ = ocs.cull(fr[f : f + 1])
+                    got_ids, got_types = res.all_ids(f)
+                    H.assert_same_visible(H.sorted_by_type(got_ids, got_types), H.sorted_by_type(ids_o, types_o), f"frame {frame} frustum {f} (swaps {swaps_seen})")
+                for e in (0, 1, 2, 100, n - 1):
+                    assert cs.getRadius(e) == ocs.get_radius(e)
+                checked_after_swap += 1 if swapped else 0
+            frame += 1
+            time.sleep(0.002)
+        assert swaps_seen >= 2 and checked_after_swap >= 2, (cs.asyncStats(), frame)
+        assert H.transforms_bits_equal(w.getTransforms(), ow.get_transforms())
+    finally:
+        cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 0)
+
+
 def test_rebinding_keeps_moved_spheres(gpu_ctx, oracle_port):
     """bind A, propagate (spheres of A move on the device), bind A + B, cull WITHOUT another propagate: the entities of the first
     binding keep their moved spheres (the rebuild of the dynamic set must not re-upload a stale host mirror), also when an entity
