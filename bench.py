@@ -762,7 +762,8 @@ def extras(ctx, api, scenes, torch, timed, N, log, big_entities=0):
     cs_s = api.CullingSystem(ctx)
     n_add_frames, per_frame = (2000, 1000) if N >= 10_000_000 else (200, 1000)
     cs_s.setOption(api.CULL_OPT_AUTO_COMPACTION, 0)
-    cs_s.setOption(api.CULL_OPT_OVERFLOW_RESERVE, n_add_frames * per_frame + 65536)
+    async_adds = 300_000 if N >= 10_000_000 else 30_000  # the second leg below: adds that arrive while the worker re-sorts
+    cs_s.setOption(api.CULL_OPT_OVERFLOW_RESERVE, n_add_frames * per_frame + async_adds + 65536)
     cs_s.build(sc_s["entity"], sc_s["type"], sc_s["pos"], sc_s["radius"])
     fr_s = api.viewport_frustum()
     for _ in range(20):
@@ -793,9 +794,55 @@ def extras(ctx, api, scenes, torch, timed, N, log, big_entities=0):
                          "p99_frame_ms": float(np.percentile(ta, 99)) * 1e3, "median_frame_ms": float(np.median(ta)) * 1e3,
                          "overflow_cull_kernel_ms_at_end": t_dyn_s / max(n_dyn_s, 1), "state": cs_s.updateStats(),
                          "note": "frame = addMany(1000) + cull + host wait; LMX_CULL_OPT_AUTO_COMPACTION 0, LMX_CULL_OPT_OVERFLOW_RESERVE = the stream's size: adds take free overflow slots, nothing is re-sorted or re-uploaded"}
+    # ... and the re-sort itself off the frame (LMX_CULL_OPT_ASYNC_COMPACTION): the set now holds N sorted + 2 M unsorted entities, well
+    # past the compaction threshold (N / 8). With the option on, the next flush asks the worker for a job: it folds the 2 M into the
+    # sorted set and re-sorts all of it on a second copy of the sets while the frames go on - 100 adds + a cull each, paced at 1 kHz
+    # (a frame of a real engine lasts milliseconds; the worker's catch-up has to outrun the update stream) - until the sets trade places
+    t0 = time.perf_counter()
+    cs_s.setOption(api.CULL_OPT_ASYNC_COMPACTION, 1)  # copies the host mirror once (O(n))
+    t_enable = time.perf_counter() - t0
+    cs_s.setOption(api.CULL_OPT_AUTO_COMPACTION, 1)
+    next_id = N + n_add_frames * per_frame
+    per_async, t_async, t_request, t_swap, frames_after_swap = 100, [], None, None, 0
+    pos_a = rng_s.uniform(-15000.0, 15000.0, size=(async_adds, 3))
+    rad_a = np.exp(rng_s.uniform(np.log(0.5), np.log(50.0), size=async_adds)).astype(np.float32)
+    typ_a = np.zeros(per_async, np.uint8)
+    t_start = time.perf_counter()
+    f = 0
+    while (f + 1) * per_async <= async_adds and time.perf_counter() - t_start < 12.0:
+        a0, a1 = f * per_async, (f + 1) * per_async
+        ids_f = np.arange(next_id + a0, next_id + a1, dtype=np.int32)
+        t0 = time.perf_counter()
+        cs_s.addMany(ids_f, typ_a, pos_a[a0:a1], rad_a[a0:a1])
+        cs_s.cull(fr_s)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        t_async.append(t1 - t0)
+        st_a = cs_s.asyncStats()
+        if t_request is None and st_a["state"] in (1, 2, 3):
+            t_request = t1
+        if t_swap is None and st_a["swaps"] >= 1:
+            t_swap, frames_after_swap = t1, 0
+        f += 1
+        if t_swap is not None:
+            frames_after_swap += 1
+            if frames_after_swap > 100:  # a hundred frames on the re-sorted set, then done
+                break
+        pause = 1e-3 - (time.perf_counter() - t0)
+        if pause > 0:
+            time.sleep(pause)
+    st_a = cs_s.asyncStats()
+    tb = np.array(t_async[2:]) if len(t_async) > 2 else np.array([float("nan")])
+    out["add_stream_async_compaction"] = {
+        "frames": len(t_async), "adds_per_frame": per_async, "swaps": st_a["swaps"], "ops_replayed_at_swaps": st_a["ops_replayed_at_swaps"],
+        "request_to_swap_s": None if (t_request is None or t_swap is None) else t_swap - t_request, "enable_copy_s": t_enable,
+        "max_frame_ms": float(tb.max()) * 1e3, "p99_frame_ms": float(np.percentile(tb, 99)) * 1e3, "median_frame_ms": float(np.median(tb)) * 1e3,
+        "state_after": cs_s.updateStats(),
+        "note": "frame = addMany(100) + cull + host wait while a worker thread folds 2 M overflow entities into the sorted set and re-sorts all 12 M of it on a second copy of the sets; the swap (an O(1) trade + a replay of the last frames' operations) happens inside one of these frames"}
+    cs_s.setOption(api.CULL_OPT_ASYNC_COMPACTION, 0)
     cs_s.setOption(api.CULL_OPT_OVERFLOW_RESERVE, 0)
     cs_s.setOption(api.CULL_OPT_AUTO_COMPACTION, 1)
-    del cs_s, sc_s, add_pos, add_rad
+    del cs_s, sc_s, add_pos, add_rad, pos_a, rad_a
 
     # BASELINE config 5's single-GPU size: 100 M entities (2 GB of spheres + ids, far beyond the 256 MiB Infinity Cache: every pass
     # is HBM-cold by construction, no scrub needed). Same three regimes as the roofline legs + the 8 cascades in one call.

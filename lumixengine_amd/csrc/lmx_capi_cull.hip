@@ -34,6 +34,7 @@ enum class Where { NONE, STATIC, DYNAMIC };
 
 // ---- asynchronous compaction: types (the machinery is further down) -------------------------------------------------------------
 enum : uint8_t { OP_ADD, OP_REMOVE, OP_SET, OP_SET_POS, OP_SET_RADIUS, OP_BIND, OP_UNBIND };
+struct PinnedUploader; // further down
 struct CullOp { // one EFFECTIVE mutation of the live set, replayed onto the shadow set
 	double pos[3];
 	float radius;
@@ -53,6 +54,7 @@ struct CullAsync {
 	State state = IDLE;             // under `mu`
 	std::thread worker;
 	hipStream_t stream = nullptr;   // the worker's own (non-blocking) stream
+	PinnedUploader* uploader = nullptr; // its host -> device copies go through pinned staging buffers
 	hipEvent_t swapped = nullptr;   // recorded on the context's stream when the sets trade places: the worker's uploads into what WAS the live set wait for it
 	bool swapped_pending = false;
 	uint32_t overflow_reserve = 0;  // copy of the tuning value for the job in flight
@@ -217,6 +219,56 @@ DynDeviceView dyn_view(const CullSet& cs) {
 // Ship the queued patch records: one copy into pinned, device-visible host memory and ONE kernel that reads the records from there
 // (a frame's records are tens of KB; the H2D copy call alone cost more host time than the 2000 mirror updates it carried) - no host
 // wait: the two staging halves alternate, a half is rewritten two flushes after the kernel that read it was enqueued.
+// Host -> device copies of the asynchronous compaction's worker go through two pinned staging buffers, chunk by chunk: a
+// hipMemcpyAsync from PAGEABLE memory is staged by the runtime in a way that held up the context's own stream for the length of the
+// whole upload (measured: one 32 ms frame while 400 MB of a re-sorted 12 M-entity set went up; tools/scratch/async_stream_probe.py).
+struct PinnedUploader {
+	static constexpr size_t CHUNK = 4u << 20;
+	void* buf[2] = {nullptr, nullptr};
+	hipEvent_t ev[2] = {nullptr, nullptr};
+	bool used[2] = {false, false};
+	int k = 0;
+	hipStream_t stream = nullptr;
+	hipError_t init(hipStream_t s) {
+		stream = s;
+		for (int i = 0; i < 2; ++i) {
+			hipError_t e = hipHostMalloc(&buf[i], CHUNK, hipHostMallocDefault);
+			if (e != hipSuccess) return e;
+			e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+			if (e != hipSuccess) return e;
+		}
+		return hipSuccess;
+	}
+	void destroy() {
+		for (int i = 0; i < 2; ++i) {
+			if (buf[i]) (void)hipHostFree(buf[i]);
+			if (ev[i]) (void)hipEventDestroy(ev[i]);
+			buf[i] = nullptr;
+			ev[i] = nullptr;
+		}
+	}
+	hipError_t copy(void* dst, const void* src, size_t bytes) {
+		for (size_t off = 0; off < bytes; off += CHUNK) {
+			const size_t n = std::min(CHUNK, bytes - off);
+			if (used[k]) {
+				hipError_t e = hipEventSynchronize(ev[k]);
+				if (e != hipSuccess) return e;
+			}
+			memcpy(buf[k], (const char*)src + off, n);
+			hipError_t e = hipMemcpyAsync((char*)dst + off, buf[k], n, hipMemcpyHostToDevice, stream);
+			if (e != hipSuccess) return e;
+			e = hipEventRecord(ev[k], stream);
+			if (e != hipSuccess) return e;
+			used[k] = true;
+			k ^= 1;
+		}
+		return hipSuccess;
+	}
+};
+inline hipError_t upload(PinnedUploader* up, void* dst, const void* src, size_t bytes, hipStream_t stream) {
+	return up ? up->copy(dst, src, bytes) : hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+}
+
 int apply_patches_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, bool profile) {
 	const size_t n_ps = cs.q_sphere.size(), n_pi = cs.q_id.size(), n_pd = cs.q_dyn.size();
 	if (!(n_ps + n_pi + n_pd)) return LMX_OK;
@@ -260,7 +312,7 @@ int apply_patches_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, bool prof
 int apply_patches(LmxContext* ctx) { return apply_patches_on(ctx, ctx->cull, ctx->stream, true); }
 
 // Rebuild the static device layout from the host mirror (lmx_cull_layout.h) and upload it.
-int rebuild_static_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, uint32_t overflow_reserve) {
+int rebuild_static_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, uint32_t overflow_reserve, PinnedUploader* up = nullptr) {
 	CullLayout lay;
 	if (!build_cull_layout(cs.recs, lay)) return fail(ctx, LMX_ERR_CAPACITY, "too many spheres (%zu)", cs.recs.size());
 	const size_t n_padded = lay.n_padded;
@@ -292,9 +344,9 @@ int rebuild_static_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, uint32_t
 	LMX_HIP(ctx, cs.ids.reserve(std::max<size_t>(n_padded, 1)));
 	LMX_HIP(ctx, cs.hdr.reserve(std::max<size_t>(n_chunks, 1)));
 	if (n_padded) {
-		LMX_HIP(ctx, hipMemcpyAsync(cs.spheres.p, lay.spheres.data(), n_padded * sizeof(float4), hipMemcpyHostToDevice, stream));
-		LMX_HIP(ctx, hipMemcpyAsync(cs.ids.p, lay.ids.data(), n_padded * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-		LMX_HIP(ctx, hipMemcpyAsync(cs.hdr.p, lay.hdr.data(), n_chunks * sizeof(ChunkHdr), hipMemcpyHostToDevice, stream));
+		LMX_HIP(ctx, upload(up, cs.spheres.p, lay.spheres.data(), n_padded * sizeof(float4), stream));
+		LMX_HIP(ctx, upload(up, cs.ids.p, lay.ids.data(), n_padded * sizeof(int32_t), stream));
+		LMX_HIP(ctx, upload(up, cs.hdr.p, lay.hdr.data(), n_chunks * sizeof(ChunkHdr), stream));
 	}
 	for (int k = 0; k < 3; ++k) {
 		cs.tile_cap[k] = lay.tile_cap[k];
@@ -302,9 +354,9 @@ int rebuild_static_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, uint32_t
 		LMX_HIP(ctx, cs.tile_tab[k].reserve(std::max<size_t>(lay.tile_tab[k].size(), 1)));
 		LMX_HIP(ctx, cs.tile_box[k].reserve(std::max<size_t>(lay.tile_box[k].size(), 1)));
 		if (!lay.tile_cells[k].empty()) {
-			LMX_HIP(ctx, hipMemcpyAsync(cs.tile_cells[k].p, lay.tile_cells[k].data(), lay.tile_cells[k].size() * sizeof(CellKey), hipMemcpyHostToDevice, stream));
-			LMX_HIP(ctx, hipMemcpyAsync(cs.tile_tab[k].p, lay.tile_tab[k].data(), lay.tile_tab[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-			LMX_HIP(ctx, hipMemcpyAsync(cs.tile_box[k].p, lay.tile_box[k].data(), lay.tile_box[k].size() * sizeof(TileBox), hipMemcpyHostToDevice, stream));
+			LMX_HIP(ctx, upload(up, cs.tile_cells[k].p, lay.tile_cells[k].data(), lay.tile_cells[k].size() * sizeof(CellKey), stream));
+			LMX_HIP(ctx, upload(up, cs.tile_tab[k].p, lay.tile_tab[k].data(), lay.tile_tab[k].size() * sizeof(uint32_t), stream));
+			LMX_HIP(ctx, upload(up, cs.tile_box[k].p, lay.tile_box[k].data(), lay.tile_box[k].size() * sizeof(TileBox), stream));
 		}
 	}
 	LMX_HIP(ctx, hipStreamSynchronize(stream)); // `lay` is about to go
@@ -322,7 +374,7 @@ int rebuild_static(LmxContext* ctx) { return rebuild_static_on(ctx, ctx->cull, c
 
 // (Re)assign the device slots of the dynamic set: one region per type, padded to DYN_ALIGN, with room to grow
 // (region = 1.5 x live + one tile), and upload everything.
-int rebuild_dynamic_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, uint32_t overflow_reserve) {
+int rebuild_dynamic_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, uint32_t overflow_reserve, PinnedUploader* up = nullptr) {
 	const size_t n = cs.dyn.size();
 	size_t count_by_type[MAX_TYPES] = {};
 	for (const DynRec& r : cs.dyn) count_by_type[r.type]++;
@@ -368,11 +420,11 @@ int rebuild_dynamic_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, uint32_
 	LMX_HIP(ctx, cs.dyn_radius.reserve(cap));
 	LMX_HIP(ctx, cs.dyn_ids.reserve(cap));
 	if (padded) {
-		LMX_HIP(ctx, hipMemcpyAsync(cs.dyn_px.p, px.data(), padded * sizeof(double), hipMemcpyHostToDevice, stream));
-		LMX_HIP(ctx, hipMemcpyAsync(cs.dyn_py.p, py.data(), padded * sizeof(double), hipMemcpyHostToDevice, stream));
-		LMX_HIP(ctx, hipMemcpyAsync(cs.dyn_pz.p, pz.data(), padded * sizeof(double), hipMemcpyHostToDevice, stream));
-		LMX_HIP(ctx, hipMemcpyAsync(cs.dyn_radius.p, radius.data(), padded * sizeof(float), hipMemcpyHostToDevice, stream));
-		LMX_HIP(ctx, hipMemcpyAsync(cs.dyn_ids.p, ids.data(), padded * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+		LMX_HIP(ctx, upload(up, cs.dyn_px.p, px.data(), padded * sizeof(double), stream));
+		LMX_HIP(ctx, upload(up, cs.dyn_py.p, py.data(), padded * sizeof(double), stream));
+		LMX_HIP(ctx, upload(up, cs.dyn_pz.p, pz.data(), padded * sizeof(double), stream));
+		LMX_HIP(ctx, upload(up, cs.dyn_radius.p, radius.data(), padded * sizeof(float), stream));
+		LMX_HIP(ctx, upload(up, cs.dyn_ids.p, ids.data(), padded * sizeof(int32_t), stream));
 		LMX_HIP(ctx, hipStreamSynchronize(stream)); // the staging vectors are about to go
 	}
 	cs.dyn_layout_dirty = false;
@@ -671,8 +723,8 @@ int async_job(LmxContext* ctx, CullAsync& a) {
 		LMX_HIP(ctx, hipStreamWaitEvent(a.stream, a.swapped, 0));
 		a.swapped_pending = false;
 	}
-	if (int rc = rebuild_static_on(ctx, sh, a.stream, a.overflow_reserve)) return rc;
-	if (int rc = rebuild_dynamic_on(ctx, sh, a.stream, a.overflow_reserve)) return rc;
+	if (int rc = rebuild_static_on(ctx, sh, a.stream, a.overflow_reserve, a.uploader)) return rc;
+	if (int rc = rebuild_dynamic_on(ctx, sh, a.stream, a.overflow_reserve, a.uploader)) return rc;
 	// 2. catch up: newer segments as O(1) patches on the shadow's own device arrays
 	for (int round = 0; round < 64; ++round) {
 		seg.clear();
@@ -682,7 +734,7 @@ int async_job(LmxContext* ctx, CullAsync& a) {
 		}
 		if (int rc = async_replay(ctx, sh, seg.data(), seg.size())) return rc;
 		if (sh.dyn_layout_dirty) { // a type's region of the shadow's dynamic set ran full during the replay
-			if (int rc = rebuild_dynamic_on(ctx, sh, a.stream, a.overflow_reserve)) return rc;
+			if (int rc = rebuild_dynamic_on(ctx, sh, a.stream, a.overflow_reserve, a.uploader)) return rc;
 		}
 		if (int rc = apply_patches_on(ctx, sh, a.stream, false)) return rc;
 		if (seg.size() < ASYNC_SHORT_SEGMENT) break;
@@ -696,7 +748,7 @@ int async_job(LmxContext* ctx, CullAsync& a) {
 		for (const DynRec& r : sh.dyn)
 			if (r.slot != DYN_NO_SLOT) slot[r.entity] = (int32_t)r.slot;
 		LMX_HIP(ctx, a.d_new_slot.reserve(std::max<size_t>(slot.size(), 1)));
-		if (!slot.empty()) LMX_HIP(ctx, hipMemcpyAsync(a.d_new_slot.p, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice, a.stream));
+		if (!slot.empty()) LMX_HIP(ctx, upload(a.uploader, a.d_new_slot.p, slot.data(), slot.size() * sizeof(int32_t), a.stream));
 		LMX_HIP(ctx, hipStreamSynchronize(a.stream));
 		a.n_new_slot = (uint32_t)slot.size();
 	}
@@ -880,6 +932,15 @@ int async_enable(LmxContext* ctx) {
 		delete a;
 		return fail(ctx, LMX_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
 	}
+	a->uploader = new PinnedUploader;
+	e = a->uploader->init(a->stream);
+	if (e != hipSuccess) {
+		a->uploader->destroy();
+		delete a->uploader;
+		(void)hipStreamDestroy(a->stream);
+		delete a;
+		return fail(ctx, LMX_ERR_HIP, "pinned staging for the asynchronous compaction: %s", hipGetErrorString(e));
+	}
 	cs.async = a;
 	async_reseed(cs);
 	a->worker = std::thread(async_worker, ctx, a);
@@ -896,6 +957,10 @@ void async_disable(CullState& cs) {
 		a->cv.notify_one();
 	}
 	if (a->worker.joinable()) a->worker.join();
+	if (a->uploader) {
+		a->uploader->destroy();
+		delete a->uploader;
+	}
 	if (a->stream) (void)hipStreamDestroy(a->stream);
 	if (a->swapped) (void)hipEventDestroy(a->swapped);
 	cs.async = nullptr;
