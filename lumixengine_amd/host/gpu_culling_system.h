@@ -51,6 +51,13 @@ struct GpuCullingSystem final : CullingSystem {
 	}
 
 	bool isValid() const { return m_ctx != nullptr; }
+	// The reference's add / remove / set* never stall a frame (culling_system.cpp:131-258). Here the sorted set is re-sorted now and then
+	// (O(n): 0.5 s at 10 M entities); with this on, that happens on a worker thread against a second copy of the sets, and the copy is
+	// traded with the live set inside a later cull (LMX_CULL_OPT_ASYNC_COMPACTION). createGpuCullingSystem() switches it on.
+	bool setAsyncCompaction(bool on) {
+		CtxLock guard(m_ctx);
+		return m_ctx && check(lmx_cull_set_option(m_ctx, LMX_CULL_OPT_ASYNC_COMPACTION, on ? 1 : 0));
+	}
 	const std::string& lastError() const { return m_error; }
 	LmxContext* context() { return m_ctx; }
 

@@ -43,7 +43,9 @@ namespace Lumix {
 // ownership (UniquePtr destroyed through the same IAllocator), plus the World the RenderModule belongs to (RenderModuleImpl has it
 // as m_world) - the key under which the plugin's module finds the same context.
 UniquePtr<CullingSystem> createGpuCullingSystem(IAllocator& allocator, PageAllocator& page_allocator, World& world) {
-	return UniquePtr<GpuCullingSystem>::create(allocator, page_allocator, static_cast<const void*>(&world));
+	UniquePtr<GpuCullingSystem> cs = UniquePtr<GpuCullingSystem>::create(allocator, page_allocator, static_cast<const void*>(&world));
+	if (cs.get() && cs->isValid()) cs->setAsyncCompaction(true); // a game's culling system must never stall a frame (culling_system.cpp:131-258 do not)
+	return cs;
 }
 
 struct Mi355Module final : IModule {
