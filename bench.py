@@ -832,12 +832,25 @@ def extras(ctx, api, scenes, torch, timed, N, log, big_entities=0):
         if pause > 0:
             time.sleep(pause)
     st_a = cs_s.asyncStats()
+    # the layout the worker built against the one the synchronous path builds from the same mirror: same visible ids
+    sha_async = ids_sha256(cs_s.cull(fr_s).all_ids(0)[0])
+    cs_s.setOption(api.CULL_OPT_ASYNC_COMPACTION, 0)
+    ids_x = np.arange(next_id + async_adds, next_id + async_adds + 10, dtype=np.int32)  # (something to fold, so that lmx_cull_compact re-sorts)
+    cs_s.addMany(ids_x, np.zeros(10, np.uint8), np.full((10, 3), 1.0e7), np.ones(10, np.float32))  # far outside every frustum
+    t0 = time.perf_counter()
+    cs_s.compact()
+    ctx.synchronize()
+    t_sync_compact = time.perf_counter() - t0
+    sha_sync = ids_sha256(cs_s.cull(fr_s).all_ids(0)[0])
+    if sha_async != sha_sync:
+        raise SystemExit("bench: visible ids after the asynchronous compaction differ from those after a synchronous one")
     tb = np.array(t_async[2:]) if len(t_async) > 2 else np.array([float("nan")])
     out["add_stream_async_compaction"] = {
         "frames": len(t_async), "adds_per_frame": per_async, "swaps": st_a["swaps"], "ops_replayed_at_swaps": st_a["ops_replayed_at_swaps"],
         "request_to_swap_s": None if (t_request is None or t_swap is None) else t_swap - t_request, "enable_copy_s": t_enable,
         "max_frame_ms": float(tb.max()) * 1e3, "p99_frame_ms": float(np.percentile(tb, 99)) * 1e3, "median_frame_ms": float(np.median(tb)) * 1e3,
-        "state_after": cs_s.updateStats(),
+        "state_after": cs_s.updateStats(), "synchronous_compaction_of_the_same_set_s": t_sync_compact,
+        "visible_ids": "equal to those of the synchronously re-sorted set (sha256)",
         "note": "frame = addMany(100) + cull + host wait while a worker thread folds 2 M overflow entities into the sorted set and re-sorts all 12 M of it on a second copy of the sets; the swap (an O(1) trade + a replay of the last frames' operations) happens inside one of these frames"}
     cs_s.setOption(api.CULL_OPT_ASYNC_COMPACTION, 0)
     cs_s.setOption(api.CULL_OPT_OVERFLOW_RESERVE, 0)
