@@ -116,8 +116,10 @@ LMX_API int lmx_cull_compact(LmxContext* ctx);
 LMX_API int lmx_cull_update_stats(LmxContext* ctx, uint32_t* n_static, uint32_t* n_dynamic_bound, uint32_t* n_overflow, uint32_t* n_tombstones);
 /* LMX_CULL_OPT_ASYNC_COMPACTION: what the worker has done so far (host-only, no sync; any pointer may be null). *state: 0 idle,
    1 requested, 2 running, 3 a re-sorted set is ready for the next flush, 4 the last job failed (lmx_last_error), -1 the option is off.
-   jobs = re-sorts finished, swaps = sets traded, ops_replayed_at_swaps = operations the update thread replayed inside those flushes. */
-LMX_API int lmx_cull_async_stats(LmxContext* ctx, int* state, uint64_t* jobs, uint64_t* swaps, uint64_t* ops_replayed_at_swaps);
+   jobs = re-sorts finished, swaps = sets traded, ops_replayed_at_swaps = operations the update thread replayed inside those flushes,
+   log_drains = jobs that only brought the second copy's mirror up to date (the operation log had passed 2^20 entries with no re-sort due:
+   in-cell moves patch the sorted set in place). */
+LMX_API int lmx_cull_async_stats(LmxContext* ctx, int* state, uint64_t* jobs, uint64_t* swaps, uint64_t* ops_replayed_at_swaps, uint64_t* log_drains);
 /* Number of resident spheres / occupied (cell,type,is_big) groups of the static set / capacity of one frustum's output
  * row in units of 64 ids: a bound output buffer needs 64 * n_chunks ids per frustum. Compacts the static set first (the cell
  * count is that of the sorted layout). */

@@ -109,7 +109,7 @@ SYMBOLS = {
     "lmx_cull_remove_many": (_ci, [_vp, _u32, _vp]),
     "lmx_cull_compact": (_ci, [_vp]),
     "lmx_cull_update_stats": (_ci, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
-    "lmx_cull_async_stats": (_ci, [_vp, C.POINTER(_ci), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "lmx_cull_async_stats": (_ci, [_vp, C.POINTER(_ci), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "lmx_cull_set_option": (_ci, [_vp, _ci, _ci]),
     "lmx_cull_read_all": (_ci, [_vp, _u32, _u32, _vp, _u32, _vp]),
     "lmx_cull_map_all": (_ci, [_vp, _u32, _u32, _vp, _vp]),
@@ -463,10 +463,10 @@ class CullingSystem:
         return dict(zip(("static", "bound", "overflow", "tombstones"), (x.value for x in v)))
 
     def asyncStats(self):
-        """LMX_CULL_OPT_ASYNC_COMPACTION: {"state": -1 off / 0 idle / 1 requested / 2 running / 3 ready / 4 failed, "jobs", "swaps", "ops_replayed_at_swaps"}"""
-        st, jobs, swaps, ops = C.c_int(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
-        self.ctx.check(self.lib.lmx_cull_async_stats(self.ctx.h, C.byref(st), C.byref(jobs), C.byref(swaps), C.byref(ops)))
-        return {"state": st.value, "jobs": jobs.value, "swaps": swaps.value, "ops_replayed_at_swaps": ops.value}
+        """LMX_CULL_OPT_ASYNC_COMPACTION: {"state": -1 off / 0 idle / 1 requested / 2 running / 3 ready / 4 failed, "jobs", "swaps", "ops_replayed_at_swaps", "log_drains"}"""
+        st, jobs, swaps, ops, drains = C.c_int(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self.ctx.check(self.lib.lmx_cull_async_stats(self.ctx.h, C.byref(st), C.byref(jobs), C.byref(swaps), C.byref(ops), C.byref(drains)))
+        return {"state": st.value, "jobs": jobs.value, "swaps": swaps.value, "ops_replayed_at_swaps": ops.value, "log_drains": drains.value}
 
     def setOption(self, option: int, value: int):
         self.ctx.check(self.lib.lmx_cull_set_option(self.ctx.h, int(option), int(value)))

@@ -58,6 +58,8 @@ struct CullAsync {
 	hipEvent_t swapped = nullptr;   // recorded on the context's stream when the sets trade places: the worker's uploads into what WAS the live set wait for it
 	bool swapped_pending = false;
 	uint32_t overflow_reserve = 0;  // copy of the tuning value for the job in flight
+	bool drain_only = false;        // the job in flight only brings the shadow's mirror up to date (the log had grown long with no re-sort due)
+	uint64_t drains = 0;
 	std::string error;              // the worker's failure (state FAILED)
 	DevBuf<int32_t> d_new_slot;     // entity -> dynamic slot of the shadow set (bound spheres are copied device to device at the swap)
 	uint32_t n_new_slot = 0;
@@ -703,6 +705,7 @@ int async_replay(LmxContext* ctx, CullSet& cs, const CullOp* ops, size_t n) {
 }
 
 
+constexpr size_t ASYNC_LOG_LIMIT = 1u << 20;     // operations (40 MB) the log may hold with no job due before a drain job brings the shadow up to date
 constexpr size_t ASYNC_SHORT_SEGMENT = 4096; // a log segment this short ends the catch-up: the swap replays what arrived meanwhile
 
 int async_job(LmxContext* ctx, CullAsync& a) {
@@ -718,6 +721,7 @@ int async_job(LmxContext* ctx, CullAsync& a) {
 	clear_static_queues(sh);
 	sh.q_dyn.clear();
 	if (int rc = async_replay(ctx, sh, seg.data(), seg.size())) return rc;
+	if (a.drain_only) return LMX_OK; // the shadow's mirror is current again; no re-sort was due
 	fold_overflow(sh);
 	if (a.swapped_pending) { // kernels enqueued on the context's stream before the last swap may still read what is now the shadow set
 		LMX_HIP(ctx, hipStreamWaitEvent(a.stream, a.swapped, 0));
@@ -771,7 +775,12 @@ void async_worker(LmxContext* ctx, CullAsync* a) {
 		const int rc = async_job(ctx, *a);
 		std::lock_guard<std::mutex> g(a->mu);
 		if (a->state == CullAsync::QUIT) return;
-		a->state = rc == LMX_OK ? CullAsync::READY : CullAsync::FAILED;
+		if (rc != LMX_OK) a->state = CullAsync::FAILED;
+		else if (a->drain_only) {
+			a->state = CullAsync::IDLE;
+			a->drains++;
+			continue;
+		} else a->state = CullAsync::READY;
 		a->jobs_done++;
 	}
 }
@@ -914,11 +923,22 @@ int async_poll(LmxContext* ctx, bool* swapped) {
 		a.state = CullAsync::IDLE;
 		return LMX_OK; // the live set is intact; the next request starts from a fresh copy
 	}
-	if (st == CullAsync::IDLE && cs.auto_compaction && wants_compaction(cs)) {
-		a.overflow_reserve = cs.overflow_reserve;
-		std::lock_guard<std::mutex> g(a.mu);
-		a.state = CullAsync::REQUESTED;
-		a.cv.notify_one();
+	if (st == CullAsync::IDLE) {
+		const bool resort = cs.auto_compaction && wants_compaction(cs);
+		// in-cell moves patch the sorted set in place and never make a re-sort due: the log must not grow without bound meanwhile
+		size_t backlog;
+		{
+			std::lock_guard<std::mutex> g(a.mu);
+			backlog = a.log_shared.size();
+		}
+		const bool drain = !resort && backlog > std::max<size_t>(ASYNC_LOG_LIMIT, cs.recs.size() / 4);
+		if (resort || drain) {
+			a.overflow_reserve = cs.overflow_reserve;
+			a.drain_only = drain;
+			std::lock_guard<std::mutex> g(a.mu);
+			a.state = CullAsync::REQUESTED;
+			a.cv.notify_one();
+		}
 	}
 	return LMX_OK;
 }
@@ -1295,14 +1315,18 @@ int lmx_cull_update_stats(LmxContext* ctx, uint32_t* n_static, uint32_t* n_dynam
 	return LMX_OK;
 }
 
-int lmx_cull_async_stats(LmxContext* ctx, int* state, uint64_t* jobs, uint64_t* swaps, uint64_t* ops_replayed_at_swaps) {
+int lmx_cull_async_stats(LmxContext* ctx, int* state, uint64_t* jobs, uint64_t* swaps, uint64_t* ops_replayed_at_swaps, uint64_t* log_drains) {
 	if (!ctx) return LMX_ERR_INVALID_ARGUMENT;
 	CullAsync* a = ctx->cull.async;
 	if (state) *state = a ? (int)async_state(*a) : -1;
 	if (a) {
 		std::lock_guard<std::mutex> g(a->mu);
 		if (jobs) *jobs = a->jobs_done;
-	} else if (jobs) *jobs = 0;
+		if (log_drains) *log_drains = a->drains;
+	} else {
+		if (jobs) *jobs = 0;
+		if (log_drains) *log_drains = 0;
+	}
 	if (swaps) *swaps = a ? a->swaps : 0;
 	if (ops_replayed_at_swaps) *ops_replayed_at_swaps = a ? a->ops_replayed_at_swap : 0;
 	return LMX_OK;

@@ -488,7 +488,27 @@ def test_cull_async_compaction_lifecycle(oracle_port):
         same("after the swap")
         burst(70_000)
         same("fourth job requested")
-        cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 0)  # off while the job runs
+        # in-cell moves never make a re-sort due (they patch the sorted set in place): the operation log is bounded by drain jobs
+        deadline = time.time() + 60
+        while cs.asyncStats()["state"] != 0 and time.time() < deadline:
+            same("waiting for the fourth job")
+            time.sleep(0.005)
+        drains0 = cs.asyncStats()["log_drains"]
+        some = sc2["entity"][:50_000]
+        base = sc2["pos"][:50_000]
+        for k in range(30):  # 1.5 M set calls, every one a tiny move inside the entity's cell (or across its border: both are fine)
+            p = base + rng.uniform(-0.01, 0.01, size=base.shape)
+            cs.setMany(some, p, sc2["radius"][:50_000])
+            cs.cull(fr)
+            time.sleep(0.002)
+        for j in range(len(some)):  # the oracle takes the final positions
+            ocs.set(int(some[j]), p[j], float(sc2["radius"][j]))
+        deadline = time.time() + 30
+        while cs.asyncStats()["log_drains"] == drains0 and time.time() < deadline:
+            cs.cull(fr)
+            time.sleep(0.005)
+        assert cs.asyncStats()["log_drains"] > drains0, cs.asyncStats()
+        cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 0)  # off while a job may run
         assert cs.asyncStats()["state"] == -1
         same("option off")
         cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 1)
