@@ -468,6 +468,28 @@ def main():
         finally:
             cs_t.setPassWidth(1)
         del cs_t, sc_t
+        # the same regime - every cell CELL_TEST, every sphere fetched and tested - reached the config-2-faithful way: NORMAL radii, the
+        # cells classified by the AABB pre-tests (phase A's full work), under an orthographic slab camera that every cell of a one-layer
+        # scene straddles (scenes.slab_scene / slab_frustum_kwargs). ~40 % of the spheres are visible: 4 B per visible id matter here.
+        if N >= 1_000_000 and args.variant == "sparse" and args.camera == "default":
+            sc_b = scenes.slab_scene(N, seed=2)
+            fr_b = api.viewport_frustum(**scenes.slab_frustum_kwargs(sc_b["half"]))
+            cs_b = api.CullingSystem(ctx)
+            cs_b.build(sc_b["entity"], sc_b["type"], sc_b["pos"], sc_b["radius"])
+            for _ in range(20):
+                cs_b.cull(fr_b)
+            res_b = cs_b.cull(fr_b)
+            slab_visible = int(res_b.counts()[0].sum())
+            slab_checked = check_ids(res_b, "slab_10m", "slab") if (N == 10_000_000 and rank == 0) else "unchecked"
+            slab_bytes = 20.0 * N + 4.0 * slab_visible
+            slab_warm = kernel_times(cs_b, fr_b, min(args.steps, 50), cold=False)
+            slab_cold = kernel_times(cs_b, fr_b, min(args.steps, 50), cold=True)
+            legs["all_cell_test_normal_radii"] = {
+                "visible": slab_visible, "moved_bytes": slab_bytes, "warm_avg_launch_ms": rnd(slab_warm, 5), "cold_avg_launch_ms": rnd(slab_cold, 5),
+                "warm_GBps": gbps(slab_bytes, slab_warm), "cold_GBps": gbps(slab_bytes, slab_cold), "warm_frac": frac(slab_bytes, slab_warm), "cold_frac": frac(slab_bytes, slab_cold),
+                "cells": cs_b.stats()["cells"], "visible_ids": slab_checked,
+                "note": "scenes.slab_scene: normal radii, one layer of cells, every cell straddles the ortho slab camera's near and far plane -> CELL_TEST through containsAABB / intersectsAABB (no big-sphere shortcut)"}
+            del cs_b, sc_b
     del scrub
     traffic, traffic_note = (None, None)
     if rank == 0 and world == 1 and not args.headline_only and not args.no_live_traffic:

@@ -42,6 +42,32 @@ def all_test_radii(n: int) -> np.ndarray:
     return np.random.default_rng(5).uniform(300.5, 330.0, size=n).astype(np.float32)
 
 
+def slab_half_extent(n: int) -> float:
+    """half side of slab_scene(n): a square of cells with ~10.2 spheres each"""
+    return float(int(np.ceil(np.sqrt(n / 10.2))) * 150.0)
+
+
+def slab_scene(n: int, seed: int = 2):
+    """n spheres of NORMAL radii (0.5 .. 50) in one layer of culling cells (y in (10, 290)), ~10 per 300-unit cell like BASELINE config 2:
+    under slab_frustum_kwargs() every occupied cell straddles the frustum's near and far plane, so every cell comes out CELL_TEST through
+    the reference's AABB pre-tests (culling_system.cpp:342-363) - the config-2-faithful "every sphere is fetched and tested" case, where the
+    all_test_radii() scene reaches it through the big-sphere shortcut (which skips the pre-tests)."""
+    rng = np.random.default_rng(seed)
+    half = slab_half_extent(n)
+    pos = np.empty((n, 3))
+    pos[:, 0] = rng.uniform(-half, half, n)
+    pos[:, 1] = rng.uniform(10.0, 290.0, n)
+    pos[:, 2] = rng.uniform(-half, half, n)
+    radius = np.exp(rng.uniform(np.log(0.5), np.log(50.0), size=n)).astype(np.float32)
+    return {"entity": np.arange(n, dtype=np.int32), "type": np.zeros(n, np.uint8), "pos": pos, "radius": radius, "half": half}
+
+
+def slab_frustum_kwargs(half: float):
+    """viewport_frustum(**kw): an orthographic camera above slab_scene looking straight down, as wide as the slab, its depth range the
+    100 units between y = 200 and y = 100: no cell of the layer is inside it, every one intersects it."""
+    return dict(is_ortho=True, ortho_size=half + 900.0, w=1024, h=1024, near=0.0, far=100.0, pos=(0.0, 200.0, 0.0), rot=(-0.70710678, 0.0, 0.0, 0.70710678))
+
+
 def scaled_half_extent(n: int) -> float:
     """Half extent of the cube that keeps BASELINE config 2's density (10 M in +-15000: ~10 spheres per 300-unit cell) at n entities."""
     return 15000.0 * (n / 1e7) ** (1.0 / 3.0)

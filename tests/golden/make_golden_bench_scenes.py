@@ -9,6 +9,7 @@ Scenes (lumixengine_amd/scenes.py, all seeded):
   all_test_10m    the same positions, radii = all_test_radii()                  bench.py's roofline leg
   config5_100m    cull_scene(100 M, +-32317, seed 2, mixed types 90/5/5)        BASELINE config 5's size: default camera + 8 cascades
   all_test_100m   the 100 M positions with all_test_radii(), one type           bench.py's HBM-cold-by-size roofline extra
+  slab_10m        slab_scene(10 M): normal radii, one layer of cells, ortho slab camera    bench.py's all-CELL_TEST leg with the AABB pre-tests
 
 Generator = the reference's own CullingSystemImpl object code (oracle/_ref: renderer/culling_system.cpp compiled in place). The
 reference keeps one 4 KiB page per (cell, type) and pushes one 4 KiB result page per visited cell: ~70 GB for the 100 M scene in one
@@ -80,11 +81,15 @@ def main():
     def want(name):
         return (not only or name in only) and not (args.skip_100m and name.endswith("100m"))
 
-    def run(name, n, mixed, all_test, cams, n_shards):
+    def run(name, n, mixed, all_test, cams, n_shards, slab=False):
         if not want(name):
             return
         half = scenes.scaled_half_extent(n)
-        sc = scenes.cull_scene(n, half, seed=2, mixed_types=mixed)
+        if slab:
+            sc = scenes.slab_scene(n, seed=2)
+            half = sc["half"]
+        else:
+            sc = scenes.cull_scene(n, half, seed=2, mixed_types=mixed)
         if all_test:
             sc["radius"] = scenes.all_test_radii(n)
         rec = {"n": n, "half": half, "seed": 2, "mixed": mixed, "all_test_radii": all_test, "shards_used_by_generator": n_shards,
@@ -108,6 +113,8 @@ def main():
     run("all_test_10m", 10_000_000, False, True, default, 1)
     run("config5_100m", 100_000_000, True, False, default + cascades, 16)
     run("all_test_100m", 100_000_000, False, True, default, 16)
+    slab_half = scenes.slab_half_extent(10_000_000)
+    run("slab_10m", 10_000_000, False, False, [("slab", o.viewport_frustum(**scenes.slab_frustum_kwargs(slab_half)))], 4, slab=True)
     print("written", OUT, round(time.time() - t0), "s")
 
 

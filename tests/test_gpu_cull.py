@@ -253,7 +253,10 @@ def _bench_scene(name):
     """(record, scene arrays) of one of the scenes bench.py times, regenerated from its seed and checked against the digest of the
     arrays the reference culled (tests/golden/make_golden_bench_scenes.py)."""
     rec = json.load(open(os.path.join(G, "cull_bench_scenes.json")))["scenes"][name]
-    sc = scenes.cull_scene(rec["n"], scenes.scaled_half_extent(rec["n"]), seed=rec["seed"], mixed_types=rec["mixed"])
+    if name.startswith("slab"):
+        sc = scenes.slab_scene(rec["n"], seed=rec["seed"])
+    else:
+        sc = scenes.cull_scene(rec["n"], scenes.scaled_half_extent(rec["n"]), seed=rec["seed"], mixed_types=rec["mixed"])
     if rec["all_test_radii"]:
         sc["radius"] = scenes.all_test_radii(rec["n"])
     assert H.array_digest(sc["entity"], sc["type"], sc["pos"], sc["radius"]) == rec["scene_sha"], "the scene generator's random stream differs from the one the digests were made with"
@@ -280,6 +283,23 @@ def test_cull_bench_scenes_10m_digest(gpu_ctx, name):
     # what bench.py itself asserts: the digest regardless of type
     ids, _ = cs.cull(cams["default"]).all_ids(0)
     assert H.ids_digest(ids) == rec["cameras"]["default"]["all_types_sha256"]
+
+
+def test_cull_slab_all_cell_test_digest(gpu_ctx):
+    """bench.py's all-CELL_TEST leg with NORMAL radii: 10 M spheres in one layer of cells under an orthographic slab camera that every
+    cell straddles, so every cell is classified CELL_TEST by the AABB pre-tests (culling_system.cpp:342-363) and every sphere is
+    tested; 4.34 M of them are visible. Ids against the reference's CullingSystemImpl, for every tile variant of the kernel."""
+    rec, sc = _bench_scene("slab_10m")
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    assert cs.stats()["cells"] == rec["cells"]
+    fr = api.viewport_frustum(**scenes.slab_frustum_kwargs(sc["half"]))
+    try:
+        for variant in (-1, 0, 1, 2, 3, 4, 5):
+            cs.setOption(api.CULL_OPT_TILE_VARIANT, variant)
+            _check_digest(cs.cull(fr), rec["cameras"]["slab"], f"slab variant {variant}")
+    finally:
+        cs.setOption(api.CULL_OPT_TILE_VARIANT, -1)
 
 
 @pytest.mark.parametrize("name", ["config5_100m", "all_test_100m"])
