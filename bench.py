@@ -734,6 +734,19 @@ def extras(ctx, api, scenes, torch, timed, N, log, big_entities=0):
         out[name + "_kernels_ms"] = k_ms
         out[name + "_visible_per_sec"] = visible / (k_ms * 1e-3) if k_ms else None
         out[name + "_counts"] = cnt
+        if name == "keys":  # the same leg through the entity-indexed tables only (LMX_KEYS_OPT_SLOT_ORDER 0: rounds 1 / 2's path)
+            sk.setOption(api.KEYS_OPT_SLOT_ORDER, 0)
+            for _ in range(3):
+                cull_keys()
+            ctx.profile_reset()
+            ctx.profile_enable(True)
+            for _ in range(5):
+                cull_keys()
+            ctx.synchronize()
+            ctx.profile_enable(False)
+            out["keys_kernels_ms_entity_indexed_tables"] = ctx.profile_get(kid)[0] / 5
+            sk.setOption(api.KEYS_OPT_SLOT_ORDER, 1)
+    sk.setOption(api.KEYS_OPT_SLOT_ORDER, 0)  # the legs below have no key tables: their culls should not emit slots
     del cs, sk, ks, cases
 
     # incremental updates on the headline scene: 1000 removals + 1000 adds per frame are O(1) patches (tombstones + overflow set), no

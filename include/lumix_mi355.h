@@ -391,6 +391,13 @@ LMX_API int lmx_keys_set_decals(LmxContext* ctx, uint32_t n_entities, const uint
 LMX_API int lmx_keys_set_positions(LmxContext* ctx, const double* xyz, uint32_t n_entities);
 /* ... or read in place from the world hierarchy of this context (after lmx_world_propagate); 0 = back to the uploaded array. */
 LMX_API int lmx_keys_bind_world(LmxContext* ctx, int enable);
+/* LMX_KEYS_OPT_SLOT_ORDER (default 1): the per-entity tables are mirrored in the order of the culling system's sorted set, the culls
+   also emit the slot of every visible id, and the key kernels read entities of the sorted set through that mirror (sequential instead
+   of one random cache line per table and entity). ModelInstance::lod / Pose::frame of those entities then live in the mirror and are
+   handed back to the entity-indexed records whenever a slot dies (removal, move to the overflow set, re-sort) and before
+   lmx_keys_read_state. 0: entity-indexed tables only. Results do not depend on it. */
+enum { LMX_KEYS_OPT_SLOT_ORDER = 0 };
+LMX_API int lmx_keys_set_option(LmxContext* ctx, int option, int value);
 /* createSortKeys for (view, frustum) of the last lmx_cull on that slot. max_sort_key = Renderer::getMaxSortKey(). Async. */
 LMX_API int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeysView* kv, uint32_t max_sort_key);
 /* Sorter::pack + radix sort by key (pipeline.cpp:411-440, radixSort): pairs in ascending key order, stable. */

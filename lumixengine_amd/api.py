@@ -24,6 +24,7 @@ LIB_PATH = os.environ.get("LMX_LIB_PATH") or os.path.join(PKG, "liblumix_mi355.s
 MAX_FRUSTA, MAX_TYPES, MAX_VIEWS = 8, 8, 8
 TYPE_ALL = 0xFF
 CULL_OPT_TILE_VARIANT, CULL_OPT_LANE_PARALLEL_TILE_TEST, CULL_OPT_MAX_SHARDS, CULL_OPT_COUNTER_PAD, CULL_OPT_AUTO_COMPACTION, CULL_OPT_DEVICE_OWNS_BOUND, CULL_OPT_OVERFLOW_RESERVE, CULL_OPT_ASYNC_COMPACTION = range(8)
+KEYS_OPT_SLOT_ORDER = 0
 WORLD_OPT_FUSED_LEVELS = 0
 (K_CULL_CLASSIFY, K_CULL_SPHERES, K_XFORM_LEVEL, K_SPHERE_REFRESH, K_POSE_PALETTE, K_SKIN_VERTICES, K_CULL_DYNAMIC) = range(7)
 KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices", "cull_dynamic", "sort_keys", "anim_update", "cull_patch"]
@@ -179,6 +180,7 @@ SYMBOLS = {
     "lmx_keys_set_decals": (_ci, [_vp, _u32, _vp, _vp, _vp, _vp]),
     "lmx_keys_set_positions": (_ci, [_vp, _vp, _u32]),
     "lmx_keys_bind_world": (_ci, [_vp, _ci]),
+    "lmx_keys_set_option": (_ci, [_vp, _ci, _ci]),
     "lmx_keys_run": (_ci, [_vp, _u32, _u32, _vp, _u32]),
     "lmx_keys_sort": (_ci, [_vp]),
     "lmx_keys_counts": (_ci, [_vp, _vp]),
@@ -752,6 +754,9 @@ class SortKeys:
 
     def bindWorld(self, on: bool = True):
         self.ctx.check(self.lib.lmx_keys_bind_world(self.ctx.h, int(on)))
+
+    def setOption(self, option: int, value: int):
+        self.ctx.check(self.lib.lmx_keys_set_option(self.ctx.h, int(option), int(value)))
 
     def run(self, kv, max_sort_key: int, view: int = 0, frustum: int = 0):
         kv = np.ascontiguousarray(kv, KEYS_VIEW)

@@ -42,6 +42,7 @@ struct TileScalars {
 	TypeTable tt;
 	uint32_t ent_begin, cell_cap, n_frusta;
 	uint32_t out_stride, cnt_pad, cnt_frustum_stride, n_zero;
+	int32_t* out_slots; // SLOTS kernels only
 };
 
 // float index of DevFrustum members inside the kernarg segment (frustum 0)
@@ -206,10 +207,11 @@ static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustu
 #define LMX_CULL_SGPR_ATTR
 #endif
 
-template <int F, int WAVES, int CHW, int GRP, int LANEPAR>
+template <int F, int WAVES, int CHW, int GRP, int LANEPAR, int SLOTS_I>
 __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(const FrustaArg fr_arg, const float4* __restrict__ g_spheres, const int32_t* __restrict__ g_ids,
 	const ChunkHdr* __restrict__ g_hdr, const CellKey* __restrict__ g_tile_cells, const uint32_t* __restrict__ g_tile_tab, const TileBox* __restrict__ g_tile_box,
 	const uint32_t* __restrict__ g_win_base, int32_t* __restrict__ g_out_ids, uint32_t* __restrict__ g_counts, uint32_t* __restrict__ g_counts_next, const TileScalars a) {
+	constexpr bool SLOTS = SLOTS_I != 0; // also write the slot of every visible id (CullOut::slots)
 	constexpr uint32_t TILE = WAVES * CHW * 64;
 	constexpr uint32_t THREADS = WAVES * 64;
 	constexpr int FS = F == 1 ? 1 : MAX_FRUSTA;
@@ -355,6 +357,16 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 				u32x4_a4 t = {v[k].x, v[k].y, v[k].z, v[k].w};
 				*reinterpret_cast<u32x4_a4*>(dst + (k * 64 + lane) * 4) = t; // global_store_dwordx4, lanes contiguous: 1 KiB per instruction
 			}
+			if constexpr (SLOTS) { // the slots of a dense tile are consecutive
+				int32_t* sdst = a.out_slots + base;
+				const uint32_t s0 = ((tile_ent >> 6) + wave * CHW) << 6;
+#pragma unroll
+				for (int k = 0; k < CHW / 4; ++k) {
+					const uint32_t s = s0 + (k * 64 + lane) * 4;
+					u32x4_a4 t = {s, s + 1, s + 2, s + 3};
+					*reinterpret_cast<u32x4_a4*>(sdst + (k * 64 + lane) * 4) = t;
+				}
+			}
 			return;
 		}
 	}
@@ -472,6 +484,9 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			const bool v = ((vis_bits >> (i * FS + f)) & 1u) != 0;
 			const uint64_t mask = __ballot(v);
 			if (v) dst[run + mbcnt64(mask)] = id[i];
+			if constexpr (SLOTS) {
+				if (v) (a.out_slots + (size_t)f * a.out_stride)[run + mbcnt64(mask)] = (int32_t)(((chunk0 + i) << 6) + lane);
+			}
 			run += (uint32_t)__popcll(mask);
 		}
 	}
@@ -538,6 +553,10 @@ __global__ __launch_bounds__(DYN_THREADS) void k_cull_dynamic(const double* __re
 		const uint32_t c = s_cnt[f];
 		int32_t* dst = out.ids + (size_t)f * out.stride + win + s_base[f];
 		for (uint32_t k = threadIdx.x; k < c; k += DYN_THREADS) dst[k] = s_stage[f * TILE + k];
+		if (out.slots != nullptr) { // ids of the dynamic set carry no static slot
+			int32_t* sdst = out.slots + (size_t)f * out.stride + win + s_base[f];
+			for (uint32_t k = threadIdx.x; k < c; k += DYN_THREADS) sdst[k] = -1;
+		}
 	}
 }
 
@@ -661,7 +680,7 @@ __global__ __launch_bounds__(256) void k_cull_pack(const int32_t* __restrict__ s
 	for (uint32_t k = blockIdx.y * 256u + t; k < n; k += gridDim.y * 256u) to[k] = from[k];
 }
 
-template <int F, int WAVES, int CHW, int GRP, int LANEPAR>
+template <int F, int WAVES, int CHW, int GRP, int LANEPAR, int SLOTS_I>
 hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt, const FrustaArg& fr, int n_frusta,
 	const CullOut& out) {
 	constexpr uint32_t TILE = WAVES * CHW * 64;
@@ -684,11 +703,12 @@ hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, ui
 	a.cnt_pad = out.cnt_pad;
 	a.cnt_frustum_stride = out.cnt_frustum_stride;
 	a.n_zero = out.n_zero;
+	a.out_slots = out.slots;
 	if (out.ev_start != nullptr) // profiling: the events receive the dispatch's own begin / end timestamps
-		hipExtLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, LANEPAR>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, out.ev_start, out.ev_stop, 0, fr,
+		hipExtLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, LANEPAR, SLOTS_I>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, out.ev_start, out.ev_stop, 0, fr,
 			v.spheres, v.ids, v.hdr, v.tile_cells[K], v.tile_tab[K], v.tile_box[K], out.win_base, out.ids, out.counts, out.counts_next, a);
 	else
-		hipLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, LANEPAR>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, fr, v.spheres, v.ids, v.hdr,
+		hipLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, LANEPAR, SLOTS_I>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, fr, v.spheres, v.ids, v.hdr,
 			v.tile_cells[K], v.tile_tab[K], v.tile_box[K], out.win_base, out.ids, out.counts, out.counts_next, a);
 	return hipGetLastError();
 }
@@ -704,7 +724,7 @@ uint32_t cull_tile_size(int n_frusta, int variant) {
 
 hipError_t launch_cull_tile(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt, const FrustaArg& fr,
 	int n_frusta, const CullOut& out, int variant, int lane_parallel_status) {
-#define LMX_TILE(F, W, C, G, L) return tile_f<F, W, C, G, L>(s, v, ent_begin, ent_end, tt, fr, n_frusta, out)
+#define LMX_TILE(F, W, C, G, L) return out.slots ? tile_f<F, W, C, G, L, 1>(s, v, ent_begin, ent_end, tt, fr, n_frusta, out) : tile_f<F, W, C, G, L, 0>(s, v, ent_begin, ent_end, tt, fr, n_frusta, out)
 	if (n_frusta < 1 || n_frusta > MAX_FRUSTA) return hipErrorInvalidValue;
 	if (n_frusta == 1) {
 #define LMX_TILE_VARIANTS(L) \

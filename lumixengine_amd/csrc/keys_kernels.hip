@@ -60,7 +60,7 @@ constexpr int KEYS_BLOCK = 512; // 8 waves: 3 blocks per CU at 67 VGPRs
 // ~90 per microsecond chip-wide: one per wave and mesh was 15x slower than this kernel's memory work), and a second walk writes at
 // lane-private positions.
 __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const KeysViewDevice kv /* by value: captured at launch */,
-	const int32_t* __restrict__ ids, const uint32_t* __restrict__ n_visible) {
+	const int32_t* __restrict__ ids, const int32_t* __restrict__ slots /* optional: static-set slot per id, -1 = dynamic set */, const uint32_t* __restrict__ n_visible) {
 	__shared__ uint32_t s_wave[KEYS_BLOCK / 64][3]; // per wave: pairs | recs << 16, poses, dirty
 	__shared__ uint32_t s_base[4];
 	__shared__ uint32_t s_bucket[256]; // bucket_map: an LDS read instead of one more dependent global load per mesh
@@ -76,11 +76,20 @@ __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const Ke
 		uint32_t e = 0, mat0 = 0, pose_stamp = 0;
 		bool moved = false, queue_dirty = false;
 		double px = 0, py = 0, pz = 0;
+		KeysInstance* rec = nullptr;                   // the entity's record: by slot for the sorted set, by entity otherwise
+		const LmxMeshMaterial* mmb = d.mesh_materials; // ... and the table its material_offset points into
 		if (i < n) {
 			e = (uint32_t)ids[i];
 			KeysInstance in;
 			in.model = -1;
-			if (e < d.n_entities) in = d.inst[e]; // one 64-byte record
+			const int32_t sl = slots != nullptr ? slots[i] : -1;
+			if (sl >= 0) {
+				rec = d.inst_s + sl;
+				mmb = d.mm_s;
+			} else if (e < d.n_entities) {
+				rec = d.inst + e;
+			}
+			if (rec != nullptr) in = *rec; // one 64-byte record
 			const int32_t mdl = in.model;
 			if (mdl >= 0) {
 				const LmxKeysModel& m = d.models[mdl];
@@ -108,10 +117,10 @@ __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const Ke
 						const float dl = (float)lod_idx - lod;
 						const float ad = fabsf(dl);
 						if (ad <= kv.time_delta) {
-							d.inst[e].lod = (float)lod_idx;
+							rec->lod = (float)lod_idx;
 							from0 = m.lod_indices[lod_idx].from; to0 = m.lod_indices[lod_idx].to;
 						} else {
-							if (!kv.is_shadow) { lod = lod + dl / ad * kv.time_delta; d.inst[e].lod = lod; }
+							if (!kv.is_shadow) { lod = lod + dl / ad * kv.time_delta; rec->lod = lod; }
 							const uint32_t cur = (uint32_t)lod;
 							from0 = m.lod_indices[cur].from; to0 = m.lod_indices[cur].to;
 							if (cur < 3) { from1 = m.lod_indices[cur + 1].from; to1 = m.lod_indices[cur + 1].to; }
@@ -128,12 +137,12 @@ __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const Ke
 		bool push_pose = false;
 		for (int32_t it = 0; it < len0 + len1; ++it) {
 			const int32_t mesh_idx = it < len0 ? from0 + it : from1 + (it - len0);
-			const LmxMeshMaterial mm = d.mesh_materials[mat0 + (uint32_t)mesh_idx]; // device copy: _pad[0] = Mesh::type of the model's mesh
+			const LmxMeshMaterial mm = mmb[mat0 + (uint32_t)mesh_idx]; // device copy: _pad[0] = Mesh::type of the model's mesh
 			const uint32_t bucket = s_bucket[mm.layer];
 			if (mm._pad[0] == LMX_MESH_SKINNED) {
 				// Pose::frame stamp (:3889-3898): exactly one visit per frame hands the instance to the pose processor
 				if (!push_pose && pose_stamp != kv.frame_number) {
-					push_pose = atomicExch(&d.inst[e].pose_frame, kv.frame_number) != kv.frame_number;
+					push_pose = atomicExch(&rec->pose_frame, kv.frame_number) != kv.frame_number;
 					pose_stamp = kv.frame_number;
 				}
 				++n_pairs;
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const Ke
 			uint32_t mesh_sort_key = 0;
 			if (has) {
 				const int32_t mesh_idx = it < len0 ? from0 + it : from1 + (it - len0);
-				const LmxMeshMaterial mm = d.mesh_materials[mat0 + (uint32_t)mesh_idx];
+				const LmxMeshMaterial mm = mmb[mat0 + (uint32_t)mesh_idx];
 				const uint32_t bucket = s_bucket[mm.layer];
 				mesh_sort_key = mm.sort_key;
 				bool push_pair = false;
@@ -357,14 +366,99 @@ __global__ __launch_bounds__(256) void k_keys_groups(KeysDevice d, const KeysVie
 	if (push) { if (idx < d.cap_pairs) { d.keys[idx] = key; d.values[idx] = value; } else d.counters[KEYS_OVERFLOW] = 1; }
 }
 
+// ---- slot-ordered mirror of the instance tables ------------------------------------------------------------------------------------
+// The cull emits visible ids in the order of the sorted set; entity indices are unrelated to it, so the entity-indexed 64-byte records
+// (and the per-instance material spans) were fetched one random 128-byte line each: 285 B fetched + 126 B written per visible entity.
+// The mirror holds the same records by static slot, and the material spans packed in slot order; lod / Pose::frame of an entity of the
+// sorted set live in its slot record and go back to the entity-indexed record whenever the slot dies (tombstone, re-sort).
+__global__ __launch_bounds__(256) void k_keys_mirror_count(const int32_t* __restrict__ slot_ids, uint32_t n_slots, const KeysInstance* __restrict__ inst,
+	uint32_t n_entities, const LmxKeysModel* __restrict__ models, uint32_t* __restrict__ count /* [n_slots + 1] */) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s > n_slots) return;
+	uint32_t c = 0;
+	if (s < n_slots) {
+		const int32_t e = slot_ids[s];
+		if (e >= 0 && (uint32_t)e < n_entities) {
+			const int32_t m = inst[e].model;
+			if (m >= 0) c = models[m].mesh_count;
+		}
+	}
+	count[s] = c;
+}
+
+__global__ __launch_bounds__(256) void k_keys_mirror_fill(const int32_t* __restrict__ slot_ids, uint32_t n_slots, const KeysInstance* __restrict__ inst,
+	uint32_t n_entities, const LmxKeysModel* __restrict__ models, const LmxMeshMaterial* __restrict__ mesh_materials, const uint32_t* __restrict__ offset,
+	KeysInstance* __restrict__ inst_s, LmxMeshMaterial* __restrict__ mm_s) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s >= n_slots) return;
+	KeysInstance r;
+	memset(&r, 0, sizeof(r));
+	r.model = -1;
+	const int32_t e = slot_ids[s];
+	if (e >= 0 && (uint32_t)e < n_entities) {
+		r = inst[e];
+		if (r.model >= 0) {
+			const uint32_t n = models[r.model].mesh_count, from = r.material_offset, to = offset[s];
+			for (uint32_t k = 0; k < n; ++k) mm_s[to + k] = mesh_materials[from + k];
+			r.material_offset = to;
+		}
+	}
+	inst_s[s] = r;
+}
+
+// lod / Pose::frame of the entities of slots [0, n_slots) (or of the slots the id patches are about to turn into tombstones) back
+// into the entity-indexed records
+__device__ __forceinline__ void mirror_hand_back(uint32_t s, const int32_t* slot_ids, const KeysInstance* inst_s, KeysInstance* inst, uint32_t n_entities) {
+	const int32_t e = slot_ids[s];
+	if (e < 0 || (uint32_t)e >= n_entities) return;
+	const KeysInstance& r = inst_s[s];
+	if (r.model < 0) return;
+	inst[e].lod = r.lod;
+	inst[e].pose_frame = r.pose_frame;
+}
+__global__ __launch_bounds__(256) void k_keys_mirror_sync(const int32_t* __restrict__ slot_ids, uint32_t n_slots, const KeysInstance* __restrict__ inst_s,
+	KeysInstance* __restrict__ inst, uint32_t n_entities) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s < n_slots) mirror_hand_back(s, slot_ids, inst_s, inst, n_entities);
+}
+__global__ __launch_bounds__(256) void k_keys_mirror_carry(const PatchId* __restrict__ patches, uint32_t n, const int32_t* __restrict__ slot_ids, uint32_t n_slots,
+	const KeysInstance* __restrict__ inst_s, KeysInstance* __restrict__ inst, uint32_t n_entities) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const PatchId p = patches[i];
+	if (p.id < 0 && p.slot < n_slots) mirror_hand_back(p.slot, slot_ids, inst_s, inst, n_entities);
+}
+
 } // namespace
 
-hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const int32_t* mesh_ids, const uint32_t* mesh_count,
+hipError_t launch_keys_mirror_count(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models, uint32_t* count) {
+	hipLaunchKernelGGL(k_keys_mirror_count, dim3((n_slots + 1 + 255u) / 256u), dim3(256), 0, s, slot_ids, n_slots, inst, n_entities, models, count);
+	return hipGetLastError();
+}
+hipError_t launch_keys_mirror_fill(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models,
+	const LmxMeshMaterial* mesh_materials, const uint32_t* offset, KeysInstance* inst_s, LmxMeshMaterial* mm_s) {
+	if (!n_slots) return hipSuccess;
+	hipLaunchKernelGGL(k_keys_mirror_fill, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, slot_ids, n_slots, inst, n_entities, models, mesh_materials, offset, inst_s, mm_s);
+	return hipGetLastError();
+}
+hipError_t launch_keys_mirror_sync(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, KeysInstance* inst, uint32_t n_entities) {
+	if (!n_slots) return hipSuccess;
+	hipLaunchKernelGGL(k_keys_mirror_sync, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, slot_ids, n_slots, inst_s, inst, n_entities);
+	return hipGetLastError();
+}
+hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint32_t n, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, KeysInstance* inst,
+	uint32_t n_entities) {
+	if (!n) return hipSuccess;
+	hipLaunchKernelGGL(k_keys_mirror_carry, dim3((n + 255u) / 256u), dim3(256), 0, s, patches, n, slot_ids, n_slots, inst_s, inst, n_entities);
+	return hipGetLastError();
+}
+
+hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const int32_t* mesh_ids, const int32_t* mesh_slots, const uint32_t* mesh_count,
 	uint32_t mesh_cap, const int32_t* decal_ids, const uint32_t* decal_count, uint32_t decal_cap, const int32_t* curve_ids,
 	const uint32_t* curve_count, uint32_t curve_cap) {
 	const uint32_t grid_cap = 256 * 8; // fixed-size grids walk the lists in tiles: the counts live on the device
 	if (mesh_cap && d.inst != nullptr)
-		hipLaunchKernelGGL(k_keys_mesh, dim3(std::min((mesh_cap + KEYS_BLOCK - 1) / KEYS_BLOCK, grid_cap)), dim3(KEYS_BLOCK), 0, s, d, view, mesh_ids, mesh_count);
+		hipLaunchKernelGGL(k_keys_mesh, dim3(std::min((mesh_cap + KEYS_BLOCK - 1) / KEYS_BLOCK, grid_cap)), dim3(KEYS_BLOCK), 0, s, d, view, mesh_ids, mesh_slots, mesh_count);
 	if (decal_cap && d.decal_sort_key != nullptr)
 		hipLaunchKernelGGL(k_keys_decal, dim3((decal_cap + 255) / 256), dim3(256), 0, s, d, view, decal_ids, decal_count, d.decal_sort_key, d.decal_layer,
 			(uint32_t)LMX_DRAW_DECAL);

@@ -16,6 +16,7 @@
 // totals and contiguous lists on demand.
 #include "lmx_context.h"
 
+#include <atomic>
 #include <condition_variable>
 #include <thread>
 
@@ -298,6 +299,9 @@ int apply_patches_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, bool prof
 	if (b_pi) memcpy(h + o_pi, cs.q_id.data(), b_pi);
 	const char* d = (const char*)st.dev[k];
 	TileBox* const boxes[3] = {cs.tile_box[0].p, cs.tile_box[1].p, cs.tile_box[2].p};
+	if (&cs == static_cast<CullSet*>(&ctx->cull) && n_pi) { // a slot about to become a tombstone: its per-slot sort-key state follows the entity
+		if (int rc = keys_before_tombstones(ctx, (const PatchId*)(d + o_pi), (uint32_t)n_pi)) return rc;
+	}
 	if (profile) { // (the profiler's event pool belongs to the update thread: the worker of the asynchronous compaction passes false)
 		ProfScope ps(ctx, LMX_K_CULL_PATCH);
 		LMX_HIP(ctx, launch_apply_patches(stream, cs.spheres.p, cs.ids.p, boxes, dyn_view(cs), (const PatchSphere*)(d + o_ps), (uint32_t)n_ps,
@@ -371,7 +375,12 @@ int rebuild_static_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, uint32_t
 	clear_static_queues(cs);
 	return LMX_OK;
 }
-int rebuild_static(LmxContext* ctx) { return rebuild_static_on(ctx, ctx->cull, ctx->stream, ctx->cull.overflow_reserve);
+std::atomic<uint64_t> g_layout_generation{1};
+int rebuild_static(LmxContext* ctx) {
+	if (int rc = keys_before_layout_change(ctx)) return rc; // per-slot state of the sort-key tables goes back to its entity-indexed home first
+	if (int rc = rebuild_static_on(ctx, ctx->cull, ctx->stream, ctx->cull.overflow_reserve)) return rc;
+	ctx->cull.layout_generation = g_layout_generation++;
+	return LMX_OK;
 }
 
 // (Re)assign the device slots of the dynamic set: one region per type, padded to DYN_ALIGN, with room to grow
@@ -875,8 +884,10 @@ int async_swap(LmxContext* ctx) {
 			if (int rc = apply_patches_on(ctx, sh, ctx->stream, true)) return rc;
 		}
 	}
+	if (int rc = keys_before_layout_change(ctx)) return rc; // (reads the OLD set's slot -> id array)
 	const uint64_t generation = std::max(cs.dyn_generation, sh.dyn_generation) + 1;
 	static_cast<CullSet&>(cs).swap_with(sh);
+	cs.layout_generation = g_layout_generation++;
 	cs.dyn_generation = generation; // the world's binding tables (slots of bound entities) are re-derived at the next propagation
 	sh.dyn_generation = generation;
 	if (any_bound) cs.dyn_mirror_stale = true; // the host copies of bound spheres are older than the device's
@@ -1113,6 +1124,11 @@ int cull_view_consolidate(LmxContext* ctx, CullView& v) {
 	}
 	LMX_HIP(ctx, launch_cull_consolidate(ctx->stream, v.out.p, v.out_stride, cs.d_win_base.p, v.counts_ptr(), cs.cnt_pad, cs.n_shards * cs.cnt_pad, cs.d_shard_type.p,
 		cs.d_type_start.p, 0, v.pref.p, cs.n_shards, v.n_frusta, cs.max_shard_cap, dst, v.out_stride, 0xffffffffu));
+	if (v.has_slots) { // the same gather for the slots
+		LMX_HIP(ctx, v.cons_slots.reserve(std::max<size_t>((size_t)v.out_stride * v.n_frusta, 1)));
+		LMX_HIP(ctx, launch_cull_consolidate(ctx->stream, v.out_slots.p, v.out_stride, cs.d_win_base.p, v.counts_ptr(), cs.cnt_pad, cs.n_shards * cs.cnt_pad, cs.d_shard_type.p,
+			cs.d_type_start.p, 0, v.pref.p, cs.n_shards, v.n_frusta, cs.max_shard_cap, v.cons_slots.p, v.out_stride, 0xffffffffu));
+	}
 	v.consolidated = true;
 	return LMX_OK;
 }
@@ -1372,6 +1388,8 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 		v.next_half_is_zero = true;
 	}
 	LMX_HIP(ctx, v.out.reserve(std::max<size_t>((size_t)cs.out_total * n_frusta, 1)));
+	if (cs.emit_slots) LMX_HIP(ctx, v.out_slots.reserve(std::max<size_t>((size_t)cs.out_total * n_frusta, 1)));
+	v.has_slots = cs.emit_slots;
 	v.n_frusta = n_frusta;
 	v.out_stride = cs.out_total;
 	v.valid = v.finalized = v.consolidated = false;
@@ -1403,6 +1421,7 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 	out.cnt_frustum_stride = cnt_frustum_stride;
 	out.counts_next = v.counts_other();
 	out.n_zero = cnt_words;
+	out.slots = cs.emit_slots ? v.out_slots.p : nullptr;
 	const CullDeviceView dv = static_view(cs);
 	// The kernel is latency-bound for small frusta: wide variants (many frusta per pass) hold more state per wave and run at lower
 	// occupancy, so a batch is split into passes of at most `pass_width` frusta.
@@ -1414,6 +1433,7 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 		for (uint32_t k = 0; k < fw; ++k) sub.f[k] = fr.f[f0 + k];
 		CullOut po = out;
 		po.ids = out.ids + (size_t)f0 * out.stride;
+		if (out.slots) po.slots = out.slots + (size_t)f0 * out.stride;
 		po.counts = out.counts + (size_t)f0 * cnt_frustum_stride;
 		// 2048-sphere tiles of 4 waves x 8 chunks measured best in every regime (default camera, all-accept, all-test; 10 M and 100 M).
 		// With all 8 chunks' loads in flight (variant 4, 66 VGPRs) a launch in which few tiles survive the tile-level test is 7 % shorter

@@ -18,6 +18,53 @@ template <typename T> int upload(LmxContext* ctx, DevBuf<T>& buf, const T* src, 
 
 } // namespace
 
+namespace lmx {
+
+// (Re)build the slot-ordered mirror for the culling system's current static layout, if it is not current already.
+static int keys_build_mirror(LmxContext* ctx) {
+	KeysState& ks = ctx->keys;
+	CullState& cs = ctx->cull;
+	if (ks.mirror_valid && ks.mirror_generation == cs.layout_generation && ks.mirror_slots == cs.n_padded) return LMX_OK;
+	if (int rc = keys_before_layout_change(ctx)) return rc; // (a mirror of an older layout cannot exist here - the layout change dropped it - but be safe)
+	const uint32_t n_slots = cs.n_padded;
+	if (!n_slots || !ks.d_inst.p) return LMX_OK; // nothing sorted / no tables: the entity-indexed path
+	LMX_HIP(ctx, ks.d_inst_s.reserve(n_slots));
+	LMX_HIP(ctx, ks.d_mm_s.reserve(std::max<size_t>(ks.n_mesh_materials, 1)));
+	LMX_HIP(ctx, ks.d_mm_count.reserve((size_t)n_slots + 1));
+	LMX_HIP(ctx, ks.d_mm_off.reserve((size_t)n_slots + 1));
+	LMX_HIP(ctx, launch_keys_mirror_count(ctx->stream, cs.ids.p, n_slots, ks.d_inst.p, ks.n_entities, ks.d_models.p, ks.d_mm_count.p));
+	size_t temp = 0;
+	LMX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, temp, ks.d_mm_count.p, ks.d_mm_off.p, (int)(n_slots + 1), ctx->stream));
+	LMX_HIP(ctx, ks.d_scan_temp.reserve(temp));
+	LMX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ks.d_scan_temp.p, temp, ks.d_mm_count.p, ks.d_mm_off.p, (int)(n_slots + 1), ctx->stream));
+	LMX_HIP(ctx, launch_keys_mirror_fill(ctx->stream, cs.ids.p, n_slots, ks.d_inst.p, ks.n_entities, ks.d_models.p, ks.d_mesh_materials.p, ks.d_mm_off.p, ks.d_inst_s.p,
+		ks.d_mm_s.p));
+	ks.mirror_valid = true;
+	ks.mirror_generation = cs.layout_generation;
+	ks.mirror_slots = n_slots;
+	return LMX_OK;
+}
+
+// The static layout is about to change (re-sort, the asynchronous compaction's swap) or the tables are about to be replaced in part:
+// lod / Pose::frame of the sorted set's entities go back to the entity-indexed records, the mirror is dropped (rebuilt by the next run).
+int keys_before_layout_change(LmxContext* ctx) {
+	KeysState& ks = ctx->keys;
+	if (!ks.mirror_valid) return LMX_OK;
+	ks.mirror_valid = false;
+	LMX_HIP(ctx, launch_keys_mirror_sync(ctx->stream, ctx->cull.ids.p, std::min(ks.mirror_slots, ctx->cull.n_padded), ks.d_inst_s.p, ks.d_inst.p, ks.n_entities));
+	return LMX_OK;
+}
+
+// These id patches are about to turn slots into tombstones (removal, move to the overflow set): the state follows the entity.
+int keys_before_tombstones(LmxContext* ctx, const PatchId* d_patches, uint32_t n) {
+	KeysState& ks = ctx->keys;
+	if (!ks.mirror_valid || !n) return LMX_OK;
+	LMX_HIP(ctx, launch_keys_mirror_carry(ctx->stream, d_patches, n, ctx->cull.ids.p, std::min(ks.mirror_slots, ctx->cull.n_padded), ks.d_inst_s.p, ks.d_inst.p, ks.n_entities));
+	return LMX_OK;
+}
+
+} // namespace lmx
+
 extern "C" {
 
 int lmx_keys_set_models(LmxContext* ctx, const LmxKeysModel* models, uint32_t n_models, const uint8_t* mesh_types, uint32_t n_meshes) {
@@ -42,6 +89,7 @@ int lmx_keys_set_models(LmxContext* ctx, const LmxKeysModel* models, uint32_t n_
 	if (int rc = upload(ctx, ks.d_models, models, n_models)) return rc;
 	if (int rc = upload(ctx, ks.d_mesh_types, mesh_types, n_meshes)) return rc;
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	ks.mirror_valid = false; // (mesh counts may have changed; set_instances follows)
 	ks.models.assign(models, models + n_models);
 	ks.mesh_types.assign(mesh_types, mesh_types + n_meshes);
 	ks.n_meshes = n_meshes;
@@ -85,9 +133,12 @@ int lmx_keys_set_instances(LmxContext* ctx, uint32_t n_entities, const int32_t* 
 		memset(r.pad, 0, sizeof(r.pad));
 	}
 	ks.inst_dirty = true;
+	ks.mirror_valid = false; // lod / Pose::frame restart from the uploaded values: nothing to hand back
+	ks.n_mesh_materials = n_mesh_materials;
 	if (n_entities != ks.n_entities) ks.have_decals = ks.have_curves = false; // decal tables of another entity range are dropped
 	ks.n_entities = n_entities;
 	ks.have_instances = true;
+	if (ks.slot_order) ctx->cull.emit_slots = true; // the culls from now on also emit the static-set slot of every visible id
 	return LMX_OK;
 }
 
@@ -126,6 +177,7 @@ int lmx_keys_set_positions(LmxContext* ctx, const double* xyz, uint32_t n_entiti
 		for (size_t e = old_n; e < n_entities; ++e) { memset(&ks.inst[e], 0, sizeof(KeysInstance)); ks.inst[e].model = -1; }
 	}
 	for (uint32_t e = 0; e < n_entities; ++e) memcpy(ks.inst[e].pos, xyz + 3 * (size_t)e, sizeof(double) * 3);
+	if (int rc = keys_before_layout_change(ctx)) return rc; // the slot-ordered mirror holds positions too: it is rebuilt by the next lmx_keys_run
 	if (!ks.inst_dirty && ks.d_inst.p && ks.d_inst.cap >= ks.inst.size() && ks.inst.size() == ks.inst_uploaded) {
 		// the records are on the device already: only the positions are replaced (24 of every 64 bytes), ModelInstance::lod and
 		// Pose::frame keep the state the kernels advanced
@@ -142,6 +194,19 @@ int lmx_keys_set_positions(LmxContext* ctx, const double* xyz, uint32_t n_entiti
 int lmx_keys_bind_world(LmxContext* ctx, int enable) {
 	LMX_CHECK_CTX(ctx);
 	ctx->keys.use_world = enable != 0;
+	return LMX_OK;
+}
+
+int lmx_keys_set_option(LmxContext* ctx, int option, int value) {
+	LMX_CHECK_CTX(ctx);
+	if (option != LMX_KEYS_OPT_SLOT_ORDER) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "unknown sort-key option %d", option);
+	KeysState& ks = ctx->keys;
+	if (!value) {
+		if (int rc = keys_before_layout_change(ctx)) return rc; // hand the state back, drop the mirror
+		ctx->cull.emit_slots = false;
+	}
+	ks.slot_order = value != 0;
+	if (ks.slot_order && ks.have_instances) ctx->cull.emit_slots = true;
 	return LMX_OK;
 }
 
@@ -205,6 +270,18 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 		ks.inst_dirty = false;
 		ks.inst_uploaded = ks.inst.size();
 	}
+	// slot order: from now on the culls also emit the static-set slot of every visible id; a view culled before that (or with the
+	// option off) is walked through the entity-indexed tables
+	CullState& cs = ctx->cull;
+	const int32_t* mesh_slots = nullptr;
+	if (ks.slot_order && ks.have_instances) {
+		cs.emit_slots = true;
+		if (v.has_slots) {
+			if (int rc = keys_build_mirror(ctx)) return rc;
+		}
+	} else if (ks.mirror_valid) {
+		if (int rc = keys_before_layout_change(ctx)) return rc;
+	}
 	ProfScope ps(ctx, LMX_K_SORT_KEYS);
 	LMX_HIP(ctx, hipMemsetAsync(ks.d_counters.p, 0, KEYS_COUNTERS * sizeof(uint32_t), ctx->stream));
 	LMX_HIP(ctx, hipMemsetAsync(ks.d_groups.p, 0, n_copies * g * sizeof(uint32_t), ctx->stream));
@@ -215,6 +292,8 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 		d.inst = ks.d_inst.p;
 		d.mesh_materials = ks.d_mesh_materials.p;
 		d.models = ks.d_models.p;
+		d.inst_s = ks.mirror_valid ? ks.d_inst_s.p : nullptr;
+		d.mm_s = ks.mirror_valid ? ks.d_mm_s.p : nullptr;
 	}
 	if (ks.have_decals) { d.decal_sort_key = ks.d_decal_key.p; d.decal_layer = ks.d_decal_layer.p; }
 	if (ks.have_curves) { d.curve_sort_key = ks.d_curve_key.p; d.curve_layer = ks.d_curve_layer.p; }
@@ -234,7 +313,8 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	if (int rc = cull_view_consolidate(ctx, v)) return rc; // the key kernels walk one contiguous list per type
 	const int32_t* row = v.cons_ptr() + (size_t)frustum * v.out_stride;
 	const uint32_t* counts = v.totals_ptr() + (size_t)frustum * MAX_TYPES;
-	LMX_HIP(ctx, launch_keys(ctx->stream, d, hv, row + v.out_start[LMX_TYPE_MESH], counts + LMX_TYPE_MESH, mesh_cap, row + v.out_start[LMX_TYPE_DECAL],
+	if (ks.mirror_valid && v.has_slots && ks.slot_order) mesh_slots = v.cons_slots.p + (size_t)frustum * v.out_stride + v.out_start[LMX_TYPE_MESH];
+	LMX_HIP(ctx, launch_keys(ctx->stream, d, hv, row + v.out_start[LMX_TYPE_MESH], mesh_slots, counts + LMX_TYPE_MESH, mesh_cap, row + v.out_start[LMX_TYPE_DECAL],
 		counts + LMX_TYPE_DECAL, decal_cap, row + v.out_start[LMX_TYPE_CURVE_DECAL], counts + LMX_TYPE_CURVE_DECAL, curve_cap));
 	ks.max_sort_key = max_sort_key;
 	ks.ran = true;
@@ -337,6 +417,8 @@ int lmx_keys_read_state(LmxContext* ctx, float* lod, uint32_t* pose_frame, uint3
 	if (!ks.have_instances) return fail(ctx, LMX_ERR_NOT_BUILT, "no instance tables uploaded");
 	if (n_entities != ks.n_entities) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "expected %u entities", ks.n_entities);
 	if (ks.inst_dirty) return fail(ctx, LMX_ERR_NOT_BUILT, "tables changed since the last lmx_keys_run");
+	if (ks.mirror_valid) // entities of the sorted set keep lod / Pose::frame in their slot records
+		LMX_HIP(ctx, launch_keys_mirror_sync(ctx->stream, ctx->cull.ids.p, ks.mirror_slots, ks.d_inst_s.p, ks.d_inst.p, ks.n_entities));
 	const char* base = reinterpret_cast<const char*>(ks.d_inst.p);
 	if (lod && n_entities)
 		LMX_HIP(ctx, hipMemcpy2DAsync(lod, sizeof(float), base + offsetof(KeysInstance, lod), sizeof(KeysInstance), sizeof(float), n_entities, hipMemcpyDeviceToHost, ctx->stream));

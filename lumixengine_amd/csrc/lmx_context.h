@@ -57,6 +57,8 @@ struct CullView {
 	DevBuf<uint32_t> totals;  // [MAX_FRUSTA][MAX_TYPES] visible ids per (frustum, type)            (k_cull_finalize)
 	DevBuf<uint32_t> pref;    // [MAX_FRUSTA][n_shards] offset of a shard inside its type's contiguous list (k_cull_finalize)
 	DevBuf<int32_t> cons;     // [n_frusta][out_total] one contiguous list per (frustum, type)       (k_cull_consolidate)
+	DevBuf<int32_t> out_slots, cons_slots; // CullState::emit_slots: the static-set slot of every id of `out` / `cons` (-1: dynamic set)
+	bool has_slots = false;   // this view's result was culled with emit_slots on
 	uint32_t n_frusta = 0;
 	uint32_t out_stride = 0;
 	uint32_t cnt_words = 0;   // words per half of `counts`
@@ -245,6 +247,8 @@ struct CullState : CullSet {
 	bool device_owns_bound = false; // LMX_CULL_OPT_DEVICE_OWNS_BOUND: set* calls on hierarchy-bound entities are dropped
 	bool auto_compaction = true; // false: overflow / tombstones accumulate until the host calls lmx_cull_compact
 	CullAsync* async = nullptr;  // LMX_CULL_OPT_ASYNC_COMPACTION: shadow set + worker thread (owned; lmx_capi_cull.hip)
+	bool emit_slots = false;     // culls also write the static-set slot of every visible id (switched on by the sort-key tables' slot-ordered mirror)
+	uint64_t layout_generation = 0; // a process-wide unique number per build of the static layout (consumers that mirror it by slot compare)
 	int lane_parallel = 2;     // tile-level box test of the 1-frustum kernels: 0 = uniform code in every wave, 1 = one plane per lane in every wave, 2 = one plane per lane in wave 0, verdict through LDS
 	uint32_t max_shards = LAYOUT_MAX_SHARDS; // output shards per type of the static set
 	uint32_t cnt_pad = 32;     // words between shard counters (32 = one 128-byte line each)
@@ -377,6 +381,16 @@ struct KeysState {
 	DevBuf<uint32_t> d_rec_key, d_groups, d_counters;
 	DevBuf<int32_t> d_poses, d_dirty_list;
 	DevBuf<char> d_sort_temp;
+	// slot-ordered mirror of d_inst / d_mesh_materials for the entities of the culling system's sorted set (keys_kernels.hip)
+	bool slot_order = true;          // lmx_keys_set_option(LMX_KEYS_OPT_SLOT_ORDER)
+	bool mirror_valid = false;
+	uint64_t mirror_generation = 0;  // CullState::layout_generation the mirror was built for
+	uint32_t mirror_slots = 0;       // n_padded of that layout
+	size_t n_mesh_materials = 0;
+	DevBuf<KeysInstance> d_inst_s;
+	DevBuf<LmxMeshMaterial> d_mm_s;
+	DevBuf<uint32_t> d_mm_count, d_mm_off;
+	DevBuf<char> d_scan_temp;
 };
 
 // animation sampling (lmx_capi_anim.hip): Animation resources flattened into concatenated tables, one Animable per skin instance
@@ -435,6 +449,8 @@ namespace lmx {
 int fail(LmxContext* ctx, int code, const char* fmt, ...); // records the message, returns `code`
 extern thread_local std::string* t_fail_sink; // non-null on a library-owned thread: fail() writes there instead of LmxContext::error
 void cull_async_shutdown(LmxContext* ctx);   // lmx_capi_cull.hip: stop the asynchronous compaction's worker (context teardown)
+int keys_before_layout_change(LmxContext* ctx); // lmx_capi_keys.hip: the slot-ordered mirror of the sort-key tables hands its state back (the static layout is about to change)
+int keys_before_tombstones(LmxContext* ctx, const PatchId* d_patches, uint32_t n); // ... for the slots of these id patches (device-visible records; enqueued BEFORE the patch kernel)
 void prof_drain(LmxContext* ctx);
 int cull_flush(LmxContext* ctx);          // lmx_capi_cull.hip: make the device copy of the culling sets current
 int cull_dyn_sync_mirror(LmxContext* ctx); // dyn[] <- device when lmx_world_propagate refreshed it

@@ -56,6 +56,9 @@ struct CullOut {
 	// profiling only (lmx_profile_enable): the dispatch's OWN begin / end timestamps go into these events (hipExtLaunchKernelGGL) -
 	// events recorded around the launch also time ~3 us of command processing per pair, 7 % of a 40 us kernel
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+	// optional, parallel to `ids` (same stride, same windows): the STATIC-SET SLOT every visible id came from, -1 for ids of the dynamic
+	// set. Consumers that keep per-entity tables in slot order (the sort-key kernels) read them with the locality of the sorted set.
+	int32_t* slots = nullptr;
 };
 
 // k_cull_tile over the static set's slots [ent_begin, ent_end) (multiples of TILE_ALIGN). `variant` picks the tile shape of the
@@ -214,6 +217,10 @@ struct KeysDevice {
 	uint32_t n_entities;
 	KeysInstance* inst;       // lod and pose_frame are updated in place
 	const LmxMeshMaterial* mesh_materials;
+	// the same records in STATIC-SLOT order (the order the cull emits visible ids in), material_offset pointing into mm_s: entities of
+	// the sorted set are read with the locality of the set; ids of the dynamic set (slot -1) take the entity-indexed tables above
+	KeysInstance* inst_s;
+	const LmxMeshMaterial* mm_s;
 	const LmxKeysModel* models;
 	const uint32_t *decal_sort_key, *curve_sort_key;
 	const uint8_t *decal_layer, *curve_layer;
@@ -240,7 +247,13 @@ struct KeysDevice {
 	uint32_t cap_list;
 	uint32_t* counters;       // KEYS_*
 };
-hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const int32_t* mesh_ids, const uint32_t* mesh_count,
+hipError_t launch_keys_mirror_count(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models, uint32_t* count);
+hipError_t launch_keys_mirror_fill(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models,
+	const LmxMeshMaterial* mesh_materials, const uint32_t* offset, KeysInstance* inst_s, LmxMeshMaterial* mm_s);
+hipError_t launch_keys_mirror_sync(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, KeysInstance* inst, uint32_t n_entities);
+hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint32_t n, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, KeysInstance* inst,
+	uint32_t n_entities);
+hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const int32_t* mesh_ids, const int32_t* mesh_slots, const uint32_t* mesh_count,
 	uint32_t mesh_cap, const int32_t* decal_ids, const uint32_t* decal_count, uint32_t decal_cap, const int32_t* curve_ids,
 	const uint32_t* curve_count, uint32_t curve_cap);
 

@@ -245,6 +245,85 @@ def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("slot_order", [1, 0])
+def test_gpu_sort_keys_slot_order_under_updates(gpu_ctx, oracle_port, slot_order):
+    """LMX_KEYS_OPT_SLOT_ORDER: the instance tables mirrored in the order of the culling system's sorted set. ModelInstance::lod and
+    Pose::frame of an entity of the sorted set then live in its slot record and must follow the entity when the slot dies. Seven frames
+    of cull -> createSortKeys with removals, moves out of the cell (to the overflow set), in-cell moves, re-adds and a re-sort in
+    between: every frame's pairs / groups / poses / dirty list and the carried state equal the oracle's, with the mirror and without."""
+    base = scenes.cull_scene(60_000, 2500.0, seed=33, big_fraction=0.002)
+    n = len(base["entity"])
+    types = make_types(n, 4)
+    pos = base["pos"].copy()
+    radius = base["radius"].copy()
+    sc = keys_scene_for(types, seed=47)
+    cs = api.CullingSystem(gpu_ctx)
+    ocs = oracle_port.culling_system()
+    sk = api.SortKeys(gpu_ctx)
+    try:
+        sk.setOption(api.KEYS_OPT_SLOT_ORDER, slot_order)
+        sk.setModels(sc["models"], sc["mesh_types"])
+        sk.setInstances(sc["model"], sc["material_offset"], sc["mesh_materials"], sc["lod"], sc["flags"], sc["dirty"], sc["pose_frame"])
+        sk.setDecals(n, sc["decal_key"], sc["decal_layer"], sc["curve_key"], sc["curve_layer"])
+        kpos = pos.copy()  # the positions the key tables know (World::getTransforms as of the last refresh)
+        sk.setPositions(kpos)
+        cs.build(base["entity"], types, pos, radius)
+        ocs.add_bulk(base["entity"], types, pos, radius)
+        fr = api.viewport_frustum(pos=VIEWS[0]["camera_pos"], far=3000.0)
+        lod, pose_frame = sc["lod"], sc["pose_frame"]
+        rng = np.random.default_rng(9)
+        removed = []
+        for frame in range(7):
+            view = dict(VIEWS[0])
+            view["frame_number"] += frame
+            kv = api.keys_view(layer_to_bucket=sc["layer_to_bucket"], bucket_depth_sorted=sc["bucket_depth_sorted"], **view)
+            res = cs.cull(fr)
+            ids = {t: res.ids(0, t) for t in (0, 1, 3)}
+            oids, otypes, _ = ocs.cull(fr)
+            for t in (0, 1, 3):
+                assert np.array_equal(np.sort(ids[t]), np.sort(oids[otypes == t])), (frame, t)
+            sk.run(kv, sc["max_sort_key"])
+            assert sk.counts()["overflow"] == 0
+            want = oracle_port.create_sort_keys(kv, sc["max_sort_key"], ids[0], ids[1], ids[3], sc, kpos, lod=lod, pose_frame=pose_frame)
+            keys, values = sk.readPairs()
+            offsets, gvalues = sk.readInstancer()
+            got = canon(keys, values, offsets, gvalues, sk.readPoses(), sk.readDirty())
+            exp = canon(want["keys"], want["values"], want["group_offsets"], want["group_values"], want["poses"], want["dirty"])
+            for k in ("pairs", "groups", "poses", "dirty"):
+                assert got[k] == exp[k], f"frame {frame}: {k}"
+            lod, pose_frame = want["lod"], want["pose_frame"]
+            if frame in (2, 6):  # (reading hands the mirror's state back; the frames in between rely on the hand-back at the tombstones)
+                glod, gframe = sk.readState()
+                assert H.bits_equal(glod, lod) and H.bits_equal(gframe, pose_frame), f"frame {frame}: state"
+            # ---- updates between the frames, on entities that were just visible (their lod / Pose::frame state is hot)
+            vis = ids[0]
+            pick = rng.choice(vis, size=min(600, len(vis)), replace=False)
+            rm, out_of_cell, in_cell = pick[:200], pick[200:400], pick[400:]
+            for e in removed:  # last frame's removals come back where they were
+                cs.add(int(e), int(types[e]), pos[e], float(radius[e]))
+                ocs.add_bulk(np.array([e], np.int32), types[e : e + 1], pos[e : e + 1], radius[e : e + 1])
+            for e in rm:
+                cs.remove(int(e))
+                ocs.remove(int(e))
+            removed = list(rm)
+            for e in out_of_cell:  # a move of a few cells, still in view: the entity goes to the overflow set, its state must follow
+                pos[e] = pos[e] + rng.uniform(-700.0, 700.0, 3)
+                cs.set(int(e), pos[e], float(radius[e]))
+                ocs.set(int(e), pos[e], float(radius[e]))
+            for e in in_cell:
+                pos[e] = pos[e] + rng.uniform(-0.5, 0.5, 3)
+                cs.set(int(e), pos[e], float(radius[e]))
+                ocs.set(int(e), pos[e], float(radius[e]))
+            if frame == 4:  # one refresh of the positions the LOD distances use (the frames before it rely on the hand-back at the tombstones alone)
+                kpos = pos.copy()
+                sk.setPositions(kpos)
+            if frame == 3:
+                cs.compact()  # a re-sort: every slot changes
+    finally:
+        sk.setOption(api.KEYS_OPT_SLOT_ORDER, 1)
+
+
+@pytest.mark.gpu
 def test_gpu_sort_keys_read_world_positions(gpu_ctx, oracle_port):
     """Positions taken in place from the world hierarchy (World::getTransforms()[e].pos) instead of an uploaded array."""
     h = scenes.hierarchy_fans(40, 5, 4, seed=3)
