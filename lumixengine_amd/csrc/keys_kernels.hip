@@ -59,7 +59,10 @@ constexpr int KEYS_BLOCK = 512; // 8 waves: 3 blocks per CU at 67 VGPRs
 // emit, the block reserves its four output ranges with two 64-bit atomics on two cache lines (returning atomics on one line retire at
 // ~90 per microsecond chip-wide: one per wave and mesh was 15x slower than this kernel's memory work), and a second walk writes at
 // lane-private positions.
-__global__ __launch_bounds__(KEYS_BLOCK) void k_keys_mesh(KeysDevice d, const KeysViewDevice kv /* by value: captured at launch */,
+#ifndef LMX_KEYS_MIN_WAVES
+#define LMX_KEYS_MIN_WAVES 6 // waves per SIMD the register allocation aims at. 8 (64 VGPRs + 44 B of scratch per lane) measured no gain: 91.3 / 95.2 us against 89.3 / 91.3 (tools/scratch/keys_ab.sh) - the kernel is not short of waves
+#endif
+__global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(KeysDevice d, const KeysViewDevice kv /* by value: captured at launch */,
 	const int32_t* __restrict__ ids, const int32_t* __restrict__ slots /* optional: static-set slot per id, -1 = dynamic set */, const uint32_t* __restrict__ n_visible) {
 	__shared__ uint32_t s_wave[KEYS_BLOCK / 64][3]; // per wave: pairs | recs << 16, poses, dirty
 	__shared__ uint32_t s_base[4];
