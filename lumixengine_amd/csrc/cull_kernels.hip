@@ -87,7 +87,19 @@ __device__ __forceinline__ uint32_t tile_status_lanes(const TileBox* box, uint32
 	}
 	const bool plane_lane = lane < 6u;
 	if (__ballot(plane_lane && rej) != 0) return TILE_REJECT | hi;
-	return (__ballot(plane_lane && !in) == 0 ? TILE_ACCEPT : TILE_MIXED) | hi;
+	if (__ballot(plane_lane && !in) == 0) return TILE_ACCEPT | hi;
+#if LMX_CULL_TILE_PLANE_MASK
+	// MIXED: the planes every cell of the tile passes in both per-cell tests (lmx_math.h: tile_plane_skip_mask) go into bits 8..13
+	bool skip;
+	{
+		const float bx = nx < 0.0f ? chx : lx, by = ny < 0.0f ? chy : ly, bz = nz < 0.0f ? chz : lz;
+		const float dp = (nx * bx) + (ny * by) + (nz * bz);
+		skip = dp > -d + margin;
+	}
+	return TILE_MIXED | hi | (((uint32_t)__ballot(plane_lane && skip) & 63u) << 8);
+#else
+	return TILE_MIXED | hi;
+#endif
 }
 
 // tile_status() for up to 8 frusta at once: lane 6 f + k evaluates plane k of frustum f (<= 48 lanes), every lane forms the box
@@ -144,6 +156,12 @@ __device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, 
 // experiment knobs (tools/cull_sweep.py over build variants; the defaults are what measured best)
 #ifndef LMX_CULL_NT_LOADS
 #define LMX_CULL_NT_LOADS 1   // the streamed spheres / ids are loaded non-temporally in the streaming tile variants (every sphere is read once per cull): cache-cold all-test launch 43.8-44.3 -> 42.8 us, back-to-back 37.0-37.4 -> 37.9 us (profiles/r03/cull_ab_variants.txt)
+#endif
+#ifndef LMX_CULL_STAGE_IDS
+#define LMX_CULL_STAGE_IDS 0 // 1: (1-frustum kernels) a wave compacts its visible ids in LDS and writes them with full-width stores instead of one partial-width store per chunk. Measured (profiles/r03/cull_ab_variants.txt): the launch with 43 % visible 47.6 -> 46.0 us, but the headline camera's step +0.3 us and its cache-cold launch +0.9 us (8 KiB more LDS per block, one more wait at the wave's end): off
+#endif
+#ifndef LMX_CULL_TILE_PLANE_MASK
+#define LMX_CULL_TILE_PLANE_MASK 1 // 1-frustum kernels: phase A leaves out the planes the whole tile is known to pass (lmx_math.h: tile_plane_skip_mask; the emulation re-classifies every cell with and without). Launch with every cell CELL_TEST through the AABB pre-tests: 49.9 -> 47.6 us; nothing else moves
 #endif
 #ifndef LMX_CULL_MIN3
 #define LMX_CULL_MIN3 0       // 1: `any t < 0` as min(t...) < 0 (fminf ignores NaN like the comparisons do, -0.0 < 0 is false either way): no measurable change
@@ -233,7 +251,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 	for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < a.n_zero; i += gridDim.x * THREADS) g_counts_next[i] = 0;
 
 	// 0. tile-level test per frustum (2 bits each). Everything read here sits at addresses that depend on blockIdx only.
-	uint32_t st_bits = 0, tile_flags = 0;
+	uint32_t st_bits = 0, tile_flags = 0, plane_skip = 0;
 	bool any_mixed = false, any_live = false;
 	if constexpr (LANEPAR != 0) {
 		static_assert(F == 1, "the lane-parallel tile test handles one frustum");
@@ -254,7 +272,8 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			r = tile_status_lanes(g_tile_box + tile_index, lane);
 		}
 		st_bits = r & 3u;
-		tile_flags = r >> 2;
+		tile_flags = (r >> 2) & 63u;
+		plane_skip = __builtin_amdgcn_readfirstlane((r >> 8) & 63u);
 		any_mixed = st_bits == TILE_MIXED;
 		any_live = st_bits != TILE_REJECT;
 	} else {
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			for (int k = 0; k < 6; ++k) ci.d[k] = 0.f;
 			if (!dead) {
 				V3 off;
-				ci.cls = classify_cell(frp[f], IV3{key.ix, key.iy, key.iz}, big, &off);
+				ci.cls = classify_cell(frp[f], IV3{key.ix, key.iy, key.iz}, big, &off, F == 1 ? plane_skip : 0u);
 				if (ci.cls == CELL_TEST) {
 #pragma unroll
 					for (int k = 0; k < 6; ++k) ci.d[k] = relative_plane_d(frp[f], off, k);
@@ -379,6 +398,12 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 	int32_t id[CHW];
 	uint32_t vis_bits = 0; // bit i * FS + f: sphere `lane` of chunk i is visible in frustum f
 	uint32_t mine = 0;     // lane f: this wave's visible count for frustum f
+	// 1-frustum kernels: the wave's visible ids (and slots) are compacted in LDS as they are found - the write-out below is then a
+	// handful of full-width stores instead of one partial-width store per chunk (156 k of them on a launch with 43 % visible)
+	constexpr bool STAGE = F == 1 && LMX_CULL_STAGE_IDS != 0;
+	__shared__ int32_t s_stage_ids[STAGE ? WAVES : 1][STAGE ? CHW * 64 : 1];
+	__shared__ int32_t s_stage_slots[STAGE && SLOTS ? WAVES : 1][STAGE && SLOTS ? CHW * 64 : 1];
+	uint32_t staged = 0; // wave-uniform
 #pragma unroll
 	for (int g = 0; g < CHW; g += GRP) {
 		__builtin_amdgcn_sched_barrier(0); // keep the groups' loads from being hoisted over each other (register peak)
@@ -463,13 +488,37 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 					vis = st == TILE_ACCEPT;
 				}
 				vis = vis && id[g + i] >= 0;
-				const uint32_t c = (uint32_t)__popcll(__ballot(vis));
-				mine += lane == (uint32_t)f ? c : 0u;
-				vis_bits |= (vis ? 1u : 0u) << ((g + i) * FS + f);
+				if constexpr (STAGE) {
+					const uint64_t mask = __ballot(vis);
+					if (vis) {
+						s_stage_ids[wave][staged + mbcnt64(mask)] = id[g + i];
+						if constexpr (SLOTS) s_stage_slots[wave][staged + mbcnt64(mask)] = (int32_t)(((chunk0 + g + i) << 6) + lane);
+					}
+					staged += (uint32_t)__popcll(mask);
+				} else {
+					const uint32_t c = (uint32_t)__popcll(__ballot(vis));
+					mine += lane == (uint32_t)f ? c : 0u;
+					vis_bits |= (vis ? 1u : 0u) << ((g + i) * FS + f);
+				}
 			}
 		}
 	}
 
+	if constexpr (STAGE) {
+		// C (1 frustum). one reservation for the wave, then the compacted ids leave LDS 64 lanes at a time
+		if (staged == 0) return;
+		uint32_t base = 0;
+		if (lane == 0) base = atomicAdd(&g_counts[shard * a.cnt_pad], staged);
+		base = __builtin_amdgcn_readfirstlane(base) + win;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the wave's own LDS writes above: issue order is execution order, only the compiler must not move the reads up)
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		for (uint32_t k = lane; k < staged; k += 64u) {
+			g_out_ids[base + k] = s_stage_ids[wave][k];
+			if constexpr (SLOTS) a.out_slots[base + k] = s_stage_slots[wave][k];
+		}
+		return;
+	}
 	// C. reserve: lane f adds this wave's count for frustum f to the shard's counter (one atomic instruction for all frusta),
 	// then the ids go from registers to the reserved ranges in chunk order
 	uint32_t base_v = 0;

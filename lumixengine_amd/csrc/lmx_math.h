@@ -144,7 +144,10 @@ enum CellClass : uint32_t { CELL_REJECT = 0, CELL_ACCEPT = 1, CELL_TEST = 2 };
 
 // Per-cell classification, culling_system.cpp:342-363 + geometry.cpp:99-118 / 159-178.
 // Returns the class and the getRelative() offset Vec3(frustum.origin - cell_origin) (geometry.cpp:124).
-LMX_HD uint32_t classify_cell(const DevFrustum& f, IV3 idx, bool is_big, V3* out_offset) {
+// `skip`: planes (bit i) every cell of the caller's tile is known to pass in BOTH tests below (tile_plane_skip_mask): they are
+// left out - the verdict is the same by construction, the tile-level bound carries the rounding margin. The planes are walked
+// through the set bits of the remaining mask (a real loop with a wave-uniform trip count on the device, not six predicated bodies).
+LMX_HD uint32_t classify_cell(const DevFrustum& f, IV3 idx, bool is_big, V3* out_offset, uint32_t skip = 0u) {
 	const DV3 origin = cell_origin(idx);
 	const DV3 forigin = DV3{f.origin[0], f.origin[1], f.origin[2]};
 	*out_offset = to_v3(sub(forigin, origin));
@@ -154,7 +157,8 @@ LMX_HD uint32_t classify_cell(const DevFrustum& f, IV3 idx, bool is_big, V3* out
 		const V3 rel = to_v3(sub(add(origin, cs), forigin));
 		const V3 hi = add(rel, cs);
 		bool inside = true;
-		for (int i = 0; i < 6; ++i) {
+		for (uint32_t todo = ~skip & 63u; todo != 0; todo &= todo - 1) {
+			const int i = __builtin_ctz(todo);
 			const float bx = f.nx[i] < 0.0f ? hi.x : rel.x;
 			const float by = f.ny[i] < 0.0f ? hi.y : rel.y;
 			const float bz = f.nz[i] < 0.0f ? hi.z : rel.z;
@@ -168,7 +172,8 @@ LMX_HD uint32_t classify_cell(const DevFrustum& f, IV3 idx, bool is_big, V3* out
 		const V3 rel = to_v3(sub(sub(origin, cs), forigin));
 		const V3 hi = add(rel, cs2);
 		bool hit = true;
-		for (int i = 0; i < 6; ++i) {
+		for (uint32_t todo = ~skip & 63u; todo != 0; todo &= todo - 1) {
+			const int i = __builtin_ctz(todo);
 			const float bx = f.nx[i] > 0.0f ? hi.x : rel.x;
 			const float by = f.ny[i] > 0.0f ? hi.y : rel.y;
 			const float bz = f.nz[i] > 0.0f ? hi.z : rel.z;
@@ -228,6 +233,26 @@ LMX_HD uint32_t tile_status(const DevFrustum& f, const TileBox& b) {
 	return inside ? TILE_ACCEPT : TILE_MIXED;
 }
 LMX_HD bool tile_rejected(const DevFrustum& f, const TileBox& b) { return tile_status(f, b) == TILE_REJECT; }
+// Planes (bit i) that every cell of a MIXED tile passes in both of classify_cell's tests: the NEGATIVE vertex (w.r.t. the plane's
+// normal) of the union of all the cells' containsAABB and intersectsAABB boxes ([300 lo - 300, 300 hi + 600] per axis) lies inside
+// the plane by more than the margin of tile_status() - every vertex either per-cell test picks for that plane lies further inside.
+// Phase A of k_cull_tile then evaluates the remaining planes only (a frustum much larger than a tile: one or two of six).
+LMX_HD uint32_t tile_plane_skip_mask(const DevFrustum& f, const TileBox& b) {
+	if (b.flags & (TILE_EMPTY | TILE_HAS_BIG)) return 0u;
+	const double cs = (double)CELL_SIZE;
+	const float lx = (float)(cs * b.lo[0] - cs - f.origin[0]), ly = (float)(cs * b.lo[1] - cs - f.origin[1]), lz = (float)(cs * b.lo[2] - cs - f.origin[2]);
+	const float chx = (float)(cs * b.hi[0] + 2 * cs - f.origin[0]), chy = (float)(cs * b.hi[1] + 2 * cs - f.origin[1]), chz = (float)(cs * b.hi[2] + 2 * cs - f.origin[2]);
+	const float b1 = max_f(abs_f(lx), abs_f(chx)) + max_f(abs_f(ly), abs_f(chy)) + max_f(abs_f(lz), abs_f(chz));
+	uint32_t mask = 0;
+	for (int i = 0; i < 6; ++i) {
+		const float n1 = abs_f(f.nx[i]) + abs_f(f.ny[i]) + abs_f(f.nz[i]);
+		const float margin = max_f(1.0f, n1) * (2.0f + 4e-6f * b1) + 1e-6f * abs_f(f.d[i]);
+		const float bx = f.nx[i] < 0.0f ? chx : lx, by = f.ny[i] < 0.0f ? chy : ly, bz = f.nz[i] < 0.0f ? chz : lz;
+		const float dp = (f.nx[i] * bx) + (f.ny[i] * by) + (f.nz[i] * bz);
+		if (dp > -f.d[i] + margin) mask |= 1u << i;
+	}
+	return mask;
+}
 
 // ShiftedFrustum::getRelative for one plane (geometry.cpp:121-149, setPlane :421-427): the plane is re-anchored on its corner
 // point shifted by offset = Vec3(frustum.origin - cell_origin): d_k = -dot(point_k + offset, n_k). Per cell, not per sphere.

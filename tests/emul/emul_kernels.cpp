@@ -18,12 +18,14 @@ using namespace lmx;
 
 // tiles visited, tiles ended by TILE_REJECT, tiles whose cells are all CELL_REJECT, tiles taken by TILE_ACCEPT, tiles whose live cells are all CELL_ACCEPT
 static uint32_t g_tile_stats[5];
-static uint64_t g_pair_stats[2]; // plane pairs of MIXED-tile chunks holding CELL_TEST lanes: {possible, evaluated}
+static uint64_t g_pair_stats[2];
+static uint64_t g_skip_stats[2]; // planes of MIXED tiles: {possible, left out by tile_plane_skip_mask} // plane pairs of MIXED-tile chunks holding CELL_TEST lanes: {possible, evaluated}
 
 extern "C" {
 
 void emul_tile_stats(uint32_t* out) { memcpy(out, g_tile_stats, sizeof(g_tile_stats)); }
 void emul_pair_stats(uint64_t* out) { memcpy(out, g_pair_stats, sizeof(g_pair_stats)); }
+void emul_skip_stats(uint64_t* out) { memcpy(out, g_skip_stats, sizeof(g_skip_stats)); }
 
 // tile_status for a hand-built box (tests of the margin with scaled / adversarial planes)
 uint32_t emul_tile_status(const LmxShiftedFrustum* f, const int32_t* lo, const int32_t* hi, uint32_t flags) {
@@ -70,6 +72,7 @@ int emul_cull_variant(uint32_t n, const int32_t* entity, const uint8_t* type, co
 	memset(out_counts, 0, sizeof(uint32_t) * n_frusta * LAYOUT_MAX_TYPES);
 	memset(g_tile_stats, 0, sizeof(g_tile_stats));
 	memset(g_pair_stats, 0, sizeof(g_pair_stats));
+	memset(g_skip_stats, 0, sizeof(g_skip_stats));
 	// the live ids of every TILE_ALIGN block must add up to what the shard windows are sized for
 	if (lay.block_live.size() != lay.n_padded / LAYOUT_TILE_ALIGN) return 9;
 	{
@@ -145,6 +148,17 @@ int emul_cull_variant(uint32_t n, const int32_t* entity, const uint8_t* type, co
 			if (st == TILE_ACCEPT) {
 				for (uint32_t c = first_cell; c <= last_cell; ++c)
 					if (!(lay.cells[c].meta & LAYOUT_CELL_DEAD) && info[c].cls != CELL_ACCEPT) return 10;
+			}
+			if (st == TILE_MIXED && chunk == tile_chunk) { // phase A leaves out the planes the whole tile is known to pass: same class for every cell
+				const uint32_t skip = tile_plane_skip_mask(fr, lay.tile_box[tile_k][tile_index]);
+				g_skip_stats[0] += 6;
+				g_skip_stats[1] += (uint64_t)__builtin_popcount(skip);
+				for (uint32_t c = first_cell; c <= last_cell && skip; ++c) {
+					const LayoutCell key = lay.cells[c];
+					if (key.meta & LAYOUT_CELL_DEAD) continue;
+					V3 off;
+					if (classify_cell(fr, IV3{key.ix, key.iy, key.iz}, (key.meta & 0x100u) != 0, &off, skip) != info[c].cls) return 13;
+				}
 			}
 			uint32_t t = 0;
 			for (int k = 0; k < LAYOUT_MAX_TYPES; ++k)

@@ -425,3 +425,38 @@ def test_plane_pair_skipping_on_scenes(emul_lib, oracle_port):
     st = np.zeros(2, np.uint64)
     emul_lib.emul_pair_stats(_p(st))
     assert st[0] > 0 and st[1] < 0.9 * st[0], st  # (10 M entities: 79 % of the pairs stay - why the knob does not pay)
+
+
+def test_tile_plane_skip_mask_on_scenes(emul_lib, oracle_port):
+    """Phase A of k_cull_tile classifies a MIXED tile's cells against the planes tile_plane_skip_mask() leaves (the others every cell of
+    the tile is known to pass in both AABB tests): the emulation re-classifies every cell of every MIXED tile with the mask and
+    aborts (code 13) on any difference - here on the slab scene of bench.py's all-CELL_TEST leg (its ortho camera straddles every cell
+    with two planes only: four of six planes drop out), on scenes far from the origin and under planes scaled by 1e-3 .. 1e5."""
+    n = 300_000
+    sc = scenes.slab_scene(n, seed=2)
+    fr = oracle_port.viewport_frustum(**scenes.slab_frustum_kwargs(sc["half"]))
+    cs = oracle_port.culling_system()
+    cs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    got, _ = emul_cull(emul_lib, sc, fr)
+    ids, types, _ = cs.cull(fr)
+    H.assert_same_visible(got[0], H.sorted_by_type(ids, types), "slab")
+    st = np.zeros(2, np.uint64)
+    emul_lib.emul_skip_stats(_p(st))
+    assert st[0] > 0 and st[1] >= 0.6 * st[0], st  # 4 of 6 planes for tiles well inside the slab camera's footprint
+    rng = np.random.default_rng(19)
+    sc2 = scenes.cull_scene(200_000, 5000.0, seed=18, big_fraction=0.001)
+    skipped = 0
+    for trial in range(12):
+        shift = rng.uniform(-1, 1, 3) * (10.0 ** rng.uniform(0, 8))
+        moved = dict(sc2)
+        moved["pos"] = sc2["pos"] + shift
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        f2 = oracle_port.viewport_frustum(fov=float(np.deg2rad(rng.uniform(30, 100))), near=0.5, far=float(rng.uniform(2000, 12000)), pos=tuple(shift + rng.uniform(-3000, 3000, 3)), rot=tuple(q)).copy()
+        scale = np.float32(10.0 ** rng.uniform(-3, 5)) if trial % 2 else np.float32(1.0)
+        for k in ("xs", "ys", "zs", "ds"):
+            f2[k] = (f2[k] * scale).astype(np.float32)
+        emul_cull(emul_lib, moved, f2)  # asserts rc == 0
+        emul_lib.emul_skip_stats(_p(st))
+        skipped += int(st[1])
+    assert skipped > 100

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["cull_default", "cull_stream", "cull_all_test", "cull_dense", "cull8", "xform", "skin", "skin_distinct", "keys", "target"], required=True)
+    ap.add_argument("--workload", choices=["cull_default", "cull_stream", "cull_all_test", "cull_slab", "cull_dense", "cull8", "xform", "skin", "skin_distinct", "keys", "target"], required=True)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--entities", type=int, default=10_000_000)
     ap.add_argument("--instances", type=int, default=2000)
@@ -49,6 +49,8 @@ def main():
         sc = scenes.cull_scene(args.entities, half, seed=2, mixed_types=args.workload == "cull8")
         if args.workload == "cull_all_test":  # every sphere "big" (radius > 300): every cell CELL_TEST, every sphere fetched and tested
             sc["radius"] = np.random.default_rng(5).uniform(300.5, 330.0, size=args.entities).astype(np.float32)
+        if args.workload == "cull_slab":  # normal radii, one layer of cells, ortho slab camera: every cell CELL_TEST through the AABB pre-tests
+            sc = scenes.slab_scene(args.entities, seed=2)
         cs = api.CullingSystem(ctx)
         cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
         if "LMX_TILE_TEST_MODE" in os.environ:
@@ -59,6 +61,8 @@ def main():
             fr = api.viewport_frustum(pos=(0.0, 0.0, 60000.0), far=200000.0) if args.workload == "cull_dense" else api.viewport_frustum(pos=(0.0, 0.0, 4.0 * half), far=20.0 * half)
         elif os.environ.get("LMX_WORKLOAD_CAMERA") == "nothing":  # every tile rejected by the tile-level test: the kernel's floor
             fr = api.viewport_frustum(pos=(1.0e6, 50.0, -1.0e6))
+        elif args.workload == "cull_slab":
+            fr = api.viewport_frustum(**scenes.slab_frustum_kwargs(sc["half"]))
         elif args.workload == "cull8":
             fr = H.cascade_frusta(api, 8)
         else:
