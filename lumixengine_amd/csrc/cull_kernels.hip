@@ -158,7 +158,7 @@ __device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, 
 #define LMX_CULL_NT_LOADS 1   // the streamed spheres / ids are loaded non-temporally in the streaming tile variants (every sphere is read once per cull): cache-cold all-test launch 43.8-44.3 -> 42.8 us, back-to-back 37.0-37.4 -> 37.9 us (profiles/r03/cull_ab_variants.txt)
 #endif
 #ifndef LMX_CULL_STAGE_IDS
-#define LMX_CULL_STAGE_IDS 0 // 1: (1-frustum kernels) a wave compacts its visible ids in LDS and writes them with full-width stores instead of one partial-width store per chunk. Measured (profiles/r03/cull_ab_variants.txt): the launch with 43 % visible 47.6 -> 46.0 us, but the headline camera's step +0.3 us and its cache-cold launch +0.9 us (8 KiB more LDS per block, one more wait at the wave's end): off
+#define LMX_CULL_STAGE_IDS 1 // (1-frustum STREAMING variants) a wave compacts its visible ids in LDS and writes them with full-width stores instead of one partial-width store per chunk: the launch with 43 % visible 47.6 -> 46.0 us. In the latency variant (all 8 chunks in flight: the headline camera) it cost +0.3 us per step and +0.9 us cache-cold (8 KiB more LDS per block, one more wait at the wave's end): not compiled in there (profiles/r03/cull_ab_variants.txt)
 #endif
 #ifndef LMX_CULL_TILE_PLANE_MASK
 #define LMX_CULL_TILE_PLANE_MASK 1 // 1-frustum kernels: phase A leaves out the planes the whole tile is known to pass (lmx_math.h: tile_plane_skip_mask; the emulation re-classifies every cell with and without). Launch with every cell CELL_TEST through the AABB pre-tests: 49.9 -> 47.6 us; nothing else moves
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 	uint32_t mine = 0;     // lane f: this wave's visible count for frustum f
 	// 1-frustum kernels: the wave's visible ids (and slots) are compacted in LDS as they are found - the write-out below is then a
 	// handful of full-width stores instead of one partial-width store per chunk (156 k of them on a launch with 43 % visible)
-	constexpr bool STAGE = F == 1 && LMX_CULL_STAGE_IDS != 0;
+	constexpr bool STAGE = F == 1 && GRP < CHW && LMX_CULL_STAGE_IDS != 0; // streaming variants only (as the non-temporal loads): the latency variant pays for the extra LDS and the wait at the wave's end
 	__shared__ int32_t s_stage_ids[STAGE ? WAVES : 1][STAGE ? CHW * 64 : 1];
 	__shared__ int32_t s_stage_slots[STAGE && SLOTS ? WAVES : 1][STAGE && SLOTS ? CHW * 64 : 1];
 	uint32_t staged = 0; // wave-uniform
