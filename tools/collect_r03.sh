@@ -19,6 +19,9 @@ if [ "$WHAT" = "stats" ] || [ "$WHAT" = "all" ]; then
 	prof cull_all_test_warm $W --workload cull_all_test --steps 40
 	prof cull_all_test_cold $W --workload cull_all_test --steps 40 --cold read
 	prof cull_all_test_100m $W --workload cull_all_test --steps 12 --entities 100000000
+	prof cull_slab_warm $W --workload cull_slab --steps 40
+	prof cull_slab_cold $W --workload cull_slab --steps 40 --cold read
+	prof keys $W --workload keys --steps 12
 	prof cull8 $W --workload cull8 --steps 20
 	prof target $W --workload target --steps 12
 	prof skin $W --workload skin --steps 12
