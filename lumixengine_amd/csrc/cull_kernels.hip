@@ -163,6 +163,9 @@ __device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, 
 #ifndef LMX_CULL_TILE_PLANE_MASK
 #define LMX_CULL_TILE_PLANE_MASK 1 // 1-frustum kernels: phase A leaves out the planes the whole tile is known to pass (lmx_math.h: tile_plane_skip_mask; the emulation re-classifies every cell with and without). Launch with every cell CELL_TEST through the AABB pre-tests: 49.9 -> 47.6 us; nothing else moves
 #endif
+#ifndef LMX_PACK_EARLY_EXIT
+#define LMX_PACK_EARLY_EXIT 1 // k_cull_pack: blocks without a slice of their shard's window leave at once, the others fetch their first ids under the prefix of the counters
+#endif
 #ifndef LMX_CULL_MIN3
 #define LMX_CULL_MIN3 0       // 1: `any t < 0` as min(t...) < 0 (fminf ignores NaN like the comparisons do, -0.0 < 0 is false either way): no measurable change
 #endif
@@ -708,25 +711,40 @@ __global__ __launch_bounds__(256) void k_cull_pack(const int32_t* __restrict__ s
 	__shared__ uint32_t s_part[4];
 	__shared__ uint32_t s_tot[MAX_TYPES];
 	const uint32_t s = blockIdx.x, t = threadIdx.x;
+	const bool totals_block = s == 0 && blockIdx.y == 0;
+	const uint32_t c = counts[s * cnt_pad];
+	// a block whose slice of the shard's window is empty has nothing to place (most of them when little is visible: the grid is sized
+	// for a full window), and the others fetch their first ids now, under the prefix of the counters instead of behind it
+#if LMX_PACK_EARLY_EXIT
+	if (blockIdx.y * 256u >= c && !totals_block) return;
+#endif
+	const int32_t* from = src + win_base[s];
+	const uint32_t k0 = blockIdx.y * 256u + t;
+#if LMX_PACK_EARLY_EXIT
+	const int32_t first = k0 < c ? from[k0] : 0;
+#endif
 	uint32_t before = 0;
 	for (uint32_t k = t; k < s; k += 256u) before += counts[k * cnt_pad]; // (<= 3 iterations)
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) before += (uint32_t)__shfl_xor((int)before, o);
 	if ((t & 63u) == 0) s_part[t >> 6] = before;
-	if (s == 0 && blockIdx.y == 0 && t < MAX_TYPES) s_tot[t] = 0;
+	if (totals_block && t < MAX_TYPES) s_tot[t] = 0;
 	__syncthreads();
 	const uint32_t at = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-	const uint32_t c = counts[s * cnt_pad];
-	if (s == 0 && blockIdx.y == 0) { // totals per type: what the rank saw, also beyond dst_cap
+	if (totals_block) { // totals per type: what the rank saw, also beyond dst_cap
 		for (uint32_t k = t; k < n_shards; k += 256u) atomicAdd(&s_tot[shard_type[k]], counts[k * cnt_pad]);
 		__syncthreads();
 		if (t < MAX_TYPES) header[t] = s_tot[t];
 	}
-	const int32_t* from = src + win_base[s];
 	int32_t* to = dst + at;
 	const uint32_t room = at < dst_cap ? dst_cap - at : 0u;
 	const uint32_t n = c < room ? c : room;
-	for (uint32_t k = blockIdx.y * 256u + t; k < n; k += gridDim.y * 256u) to[k] = from[k];
+#if LMX_PACK_EARLY_EXIT
+	if (k0 < n) to[k0] = first;
+	for (uint32_t k = k0 + gridDim.y * 256u; k < n; k += gridDim.y * 256u) to[k] = from[k];
+#else
+	for (uint32_t k = k0; k < n; k += gridDim.y * 256u) to[k] = from[k];
+#endif
 }
 
 template <int F, int WAVES, int CHW, int GRP, int LANEPAR, int SLOTS_I>
