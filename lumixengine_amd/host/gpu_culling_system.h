@@ -26,6 +26,7 @@
 
 #ifdef LMX_WITH_LUMIX_HEADERS
 	#include "core/geometry.h"
+	#include "core/log.h"
 	#include "core/math.h"
 	#include "core/page_allocator.h"
 	#include "renderer/culling_system.h"
@@ -128,16 +129,24 @@ private:
 		LmxContext* ctx;
 	};
 
+	void report() { // the reference's error convention: log and carry on (no exceptions)
+#ifdef LMX_WITH_LUMIX_HEADERS
+		logError("GpuCullingSystem: ", m_error.c_str());
+#else
+		fprintf(stderr, "GpuCullingSystem: %s\n", m_error.c_str());
+#endif
+	}
+
 	void noContext() {
 		m_error = lmx_last_error(nullptr);
-		fprintf(stderr, "GpuCullingSystem: %s\n", m_error.c_str()); // the engine would logError(...)
+		report();
 		m_ctx = nullptr;
 	}
 
 	bool check(int rc) {
 		if (rc == LMX_OK) return true;
 		m_error = m_ctx ? lmx_last_error(m_ctx) : "no context";
-		fprintf(stderr, "GpuCullingSystem: %s\n", m_error.c_str());
+		report();
 		return false;
 	}
 
