@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <vector>
+#include <unistd.h>
 
 #include "shell_engine.h" // oracle/ref: an Engine that owns an allocator (mine)
 
@@ -230,6 +231,33 @@ void testCullingSystem(IAllocator& heap, PageAllocator& pages) {
 		CHECK(a.v == b.v, "cullMany view %u: %zu vs reference %zu", f, a.v.size(), b.v.size());
 	}
 	printf("culling system: %u entities, 6000 interleaved calls, %zu views: identical to CullingSystemImpl\n", next, frusta.size());
+
+	// what createGpuCullingSystem() switches on for the engine: the re-sort of the sorted set on a worker thread. 80 000 more entities
+	// push the overflow past the compaction threshold; updates and culls go on while the worker re-sorts, and after the sets have traded
+	// places every view is still the reference's.
+	GpuCullingSystem* g = static_cast<GpuCullingSystem*>(gpu.get());
+	CHECK(g->setAsyncCompaction(true), "setAsyncCompaction: %s", g->lastError().c_str());
+	alive.resize(next + 80000 + 16, false);
+	for (u32 k = 0; k < 80000; ++k) add(next++);
+	uint64_t swaps = 0;
+	int state = 0;
+	for (int frame = 0; frame < 4000 && swaps == 0; ++frame) {
+		for (int k = 0; k < 20; ++k) { // the update stream does not stop for the worker
+			const u32 e = rng.below(next);
+			if (!alive[e]) continue;
+			const DVec3 p(rng.uni(-3200, 3200), rng.uni(-3200, 3200), rng.uni(-3200, 3200));
+			const float radius = (float)rng.uni(0.5, 60.0);
+			if (k % 5 == 0) { gpu->remove(EntityRef{(i32)e}); ref->remove(EntityRef{(i32)e}); alive[e] = false; }
+			else { gpu->set(EntityRef{(i32)e}, p, radius); ref->set(EntityRef{(i32)e}, p, radius); }
+		}
+		if (frame % 50 == 0) sameVisible(*gpu, *ref, frusta[frame / 50 % frusta.size()], pages, "while the worker re-sorts");
+		else if (CullResult* r = gpu->cull(frusta[0])) r->free(pages);
+		CHECK(lmx_cull_async_stats(g->context(), &state, nullptr, &swaps, nullptr, nullptr) == LMX_OK && state != 4, "asynchronous compaction failed");
+		usleep(1000);
+	}
+	CHECK(swaps >= 1, "the sets never traded places (state %d)", state);
+	for (size_t f = 0; f < frusta.size(); ++f) sameVisible(*gpu, *ref, frusta[f], pages, "after the asynchronous compaction");
+	printf("culling system: asynchronous compaction of %u entities under an update stream: identical to CullingSystemImpl\n", next);
 }
 
 // ---- part 2: World + plugin module + culling system of one World ----------------------------------------------------------------------

@@ -54,6 +54,7 @@ def test_real_header_harness_one_context_per_world():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "real-header harness OK" in r.stdout
     assert "identical to CullingSystemImpl" in r.stdout and "transforms bit-identical" in r.stdout
+    assert "asynchronous compaction of" in r.stdout  # the worker re-sorted and the sets traded places under the update stream
 
 
 @pytest.mark.gpu
