@@ -19,6 +19,7 @@
 #pragma once
 
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -167,7 +168,8 @@ private:
 			for (uint32_t i = 0; i < got; i += PAGE_IDS) {
 				CullResult* page = newPage((u8)t);
 				const uint32_t n = got - i < PAGE_IDS ? got - i : PAGE_IDS;
-				for (uint32_t k = 0; k < n; ++k) page->entities[k].index = ids[at + i + k];
+				static_assert(sizeof(EntityRef) == sizeof(int32_t), "EntityRef is its index");
+				memcpy(static_cast<void*>(page->entities), ids + at + i, (size_t)n * sizeof(int32_t));
 				page->header.count = n;
 				if (last) last->header.next = page; else first = page;
 				last = page;
