@@ -450,8 +450,16 @@ int lmx_world_read_moved(LmxContext* ctx, int32_t* entity, LmxTransform* transfo
 	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
 	if (!w.track_moved) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_track_moved(1) first");
 	if (!out_n) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null out_n");
+	// the count and - sized from the last frame's count - the records travel together: one host wait per frame in the steady state
+	// (the copies below the wait only run when this frame moved more than the guess covers)
 	uint32_t n = 0;
+	const uint32_t list_cap = w.n * 2u;
+	const uint32_t ahead = (entity && transforms) ? std::min(std::min(w.moved_guess, cap), list_cap) : 0u;
 	LMX_HIP(ctx, hipMemcpyAsync(&n, w.d_moved_count.p, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+	if (ahead) {
+		LMX_HIP(ctx, hipMemcpyAsync(entity, w.d_moved_entity.p, (size_t)ahead * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+		LMX_HIP(ctx, hipMemcpyAsync(transforms, w.d_moved_tr.p, (size_t)ahead * sizeof(LmxTransform), hipMemcpyDeviceToHost, ctx->stream));
+	}
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	*out_n = n;
 	// (an entity can be listed twice when a frame propagated twice - staged writes, then bone-attached subtrees; later entries are newer)
@@ -461,12 +469,13 @@ int lmx_world_read_moved(LmxContext* ctx, int32_t* entity, LmxTransform* transfo
 		return fail(ctx, LMX_ERR_CAPACITY, "%u moved records since the last read exceed the list (%u): read every transform with lmx_world_read_transforms", n, stored);
 	}
 	if (n > cap || (n && (!entity || !transforms))) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u moved entities", n);
-	if (n) {
-		LMX_HIP(ctx, hipMemcpyAsync(entity, w.d_moved_entity.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-		LMX_HIP(ctx, hipMemcpyAsync(transforms, w.d_moved_tr.p, (size_t)n * sizeof(LmxTransform), hipMemcpyDeviceToHost, ctx->stream));
+	if (n > ahead) { // the rest of a frame that moved more than the guess
+		LMX_HIP(ctx, hipMemcpyAsync(entity + ahead, w.d_moved_entity.p + ahead, (size_t)(n - ahead) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+		LMX_HIP(ctx, hipMemcpyAsync(transforms + ahead, w.d_moved_tr.p + ahead, (size_t)(n - ahead) * sizeof(LmxTransform), hipMemcpyDeviceToHost, ctx->stream));
 	}
-	LMX_HIP(ctx, hipMemsetAsync(w.d_moved_count.p, 0, sizeof(uint32_t), ctx->stream));
-	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	LMX_HIP(ctx, hipMemsetAsync(w.d_moved_count.p, 0, sizeof(uint32_t), ctx->stream)); // (stream-ordered behind the copies; the next propagation is behind it)
+	if (n > ahead) LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	w.moved_guess = n + n / 4 + 64;
 	return LMX_OK;
 }
 

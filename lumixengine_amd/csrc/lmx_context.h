@@ -281,6 +281,7 @@ struct WorldState {
 	DevBuf<int32_t> d_moved_entity;
 	DevBuf<LmxTransform> d_moved_tr;
 	DevBuf<uint32_t> d_moved_count;
+	uint32_t moved_guess = 1024; // records lmx_world_read_moved copies before it knows the count (last frame's count x 1.25)
 	// culling binding (RenderModuleImpl::onModelInstanceMoved)
 	std::vector<int32_t> bound_entity;
 	std::vector<float> bound_radius;
