@@ -148,3 +148,46 @@ def test_animation_errors(gpu_ctx):
 
 def api_none():
     return 0xFFFFFFFF
+
+
+def test_round3_entry_points_errors(gpu_ctx):
+    """The entry points added in round 3: wrong calls answer with the documented code and leave the context usable."""
+    lib, h, C = gpu_ctx.lib, gpu_ctx.h, api.C
+    sc = scenes.cull_scene(4000, 1200.0, seed=5)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    fr = api.viewport_frustum()
+    n = len(cs.cull(fr).ids(0, 0))
+    # options
+    expect(INVALID, cs.setOption, 99, 1)
+    expect(INVALID, cs.setOption, api.CULL_OPT_OVERFLOW_RESERVE, -5)
+    assert lib.lmx_keys_set_option(h, 7, 1) == INVALID and b"option" in lib.lmx_last_error(h)
+    assert lib.lmx_world_set_option(h, 3, 1) == INVALID
+    # asynchronous compaction: stats work with the option off (-1), on, and with null pointers; switching it twice is fine
+    st = cs.asyncStats()
+    assert st["state"] == -1 and st["jobs"] == 0
+    cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 1)
+    cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 1)
+    assert cs.asyncStats()["state"] == 0
+    assert lib.lmx_cull_async_stats(h, None, None, None, None, None) == 0
+    assert lib.lmx_cull_async_stats(None, None, None, None, None, None) == INVALID
+    cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 0)
+    cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 0)
+    assert cs.asyncStats()["state"] == -1
+    # many-frusta mapping: frustum count beyond the result's
+    res = cs.cull(np.concatenate([fr, fr]))
+    ids_p = (C.c_void_p * 8)()
+    counts = np.zeros(8 * 8, np.uint32)
+    assert lib.lmx_cull_map_many(h, 0, 3, ids_p, api._ptr(counts)) == INVALID
+    assert lib.lmx_cull_map_many(h, 0, 2, ids_p, api._ptr(counts)) == 0 and int(counts[:8].sum()) == n
+    # packed device record of a frustum the view does not hold
+    rec, words = C.c_void_p(), C.c_uint32(0)
+    assert lib.lmx_cull_pack_device(h, 0, 5, C.byref(rec), C.byref(words)) == INVALID
+    # moved list without tracking / without a hierarchy
+    w = api.World(gpu_ctx)
+    ent = np.zeros(4, np.int32)
+    tr = np.zeros(4, api.TRANSFORM)
+    got = C.c_uint32(0)
+    rc = lib.lmx_world_read_moved(h, api._ptr(ent), api._ptr(tr), 4, C.byref(got))
+    assert rc == NOT_BUILT and len(lib.lmx_last_error(h)) > 10
+    assert len(cs.cull(fr).ids(0, 0)) == n  # the context still works
