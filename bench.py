@@ -10,8 +10,9 @@ near 0.1, far 10000). One step = one cull of every resident enti
 contiguous record [8 per-type counts | ids] left in HBM (k_cull_tile + k_cull_pack: SURVEY.md 8d's "wall time of one cull incl.
 compaction"). The JSON line also carries, next to `value` (an EFFECTIVE rate: the default camera rejects ~95 % of the tiles by their
 boxes, so most resident bytes are never moved), `value_cull_only` (round 1 / 2's step: k_cull_tile alone, ids left in per-shard
-windows) and `value_streaming` (entities / s of the kernel when every sphere is fetched and tested, cache-cold: the regime
-`roofline` describes). The ids the timed camera produces are checked against the reference's sha256 (tests/golden/). For N>1 (one process per GPU) a step is cull + the native exchange (lmx_exchange_*: one
+windows), `value_incl_host_readback` (the visible ids in HOST memory: cull + lmx_cull_map_all, one host wait, PCIe included - the
+second form of SURVEY.md 8d's metric; never `value`) and `value_streaming` (entities / s of the kernel when every sphere is fetched and
+tested, cache-cold: the regime `roofline` describes). The ids the timed camera produces are checked against the reference's sha256 (tests/golden/). For N>1 (one process per GPU) a step is cull + the native exchange (lmx_exchange_*: one
 ncclAllGather of [counts | ids] per rank on a side stream, double-buffered). --scaling weak (default): every rank owns its own 10 M
 entities. --scaling strong: BASELINE config 4 - ONE 10 M scene partitioned over the ranks by cell hash (+ 100 k skinned instances by
 index, timed as an extra); the union of the gathered lists is checked against the unsharded result.
@@ -234,9 +235,20 @@ def main():
         step()
     ms_per_step = timed(step, args.steps)  # (the closing synchronize of `timed` also drains the side stream's last gathers)
     value = (N if strong else N * world) * n_frusta / (ms_per_step * 1e-3)
-    ms_cull_only = None
+    ms_cull_only = ms_host_list = None
     if not use_dist:
         ms_cull_only = timed(lambda: cs.cull(frustum), args.steps)  # rounds 1 / 2's step: the cull kernel alone, ids in shard windows
+        # SURVEY.md 8d (i), second form: the list on the HOST - what the CullingSystem adapter does per view: cull + lmx_cull_map_all (packed
+        # record copied into the library's pinned buffer, sized from the previous frame; ONE host wait), PCIe included
+        ids_p, cnt8 = C.POINTER(C.c_int32)(), (C.c_uint32 * 8)()
+
+        def step_host():
+            if lib.lmx_cull(h, 0, fr_ptr, 1, api.TYPE_ALL) != 0 or lib.lmx_cull_map_all(h, 0, 0, C.byref(ids_p), cnt8) != 0:
+                raise RuntimeError(lib.lmx_last_error(h).decode())
+
+        for _ in range(5):
+            step_host()
+        ms_host_list = timed(step_host, min(args.steps, 100))
     res = cs.cull(frustum)
     visible = int(res.counts()[0].sum())
     # identity of what was timed: the ids, not just their number, against the reference's CullingSystemImpl (same seeded scene)
@@ -544,6 +556,9 @@ def main():
     if ms_cull_only is not None:
         result["value_cull_only"] = N * world / (ms_cull_only * 1e-3)
         result["ms_per_step_cull_only"] = ms_cull_only
+        result["value_incl_host_readback"] = N * world / (ms_host_list * 1e-3)
+        result["ms_per_step_incl_host_readback"] = ms_host_list
+        result["value_incl_host_readback_is"] = "cull + lmx_cull_map_all: the visible ids (and the 8 per-type counts) in host memory, one host wait per cull, PCIe included - what GpuCullingSystem::cull pays per view before it builds the CullResult pages; never `value`"
     if test_cold_ms == test_cold_ms:
         result["value_streaming"] = N / (test_cold_ms * 1e-3)  # every sphere fetched and tested, cache-cold: what roofline.frac is the fraction of
     result["config"]["visible_ids"] = ids_checked  # 'reference': sha256 of the sorted ids == the reference CullingSystemImpl's on the same seeded scene
