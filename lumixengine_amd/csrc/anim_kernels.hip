@@ -136,6 +136,8 @@ __global__ __launch_bounds__(64) void k_anim_update(const SkinInstance* __restri
 		gp[0] = p.x; gp[1] = p.y; gp[2] = p.z;
 		pose_rot[in.bone_offset + b] = r;
 	}
+	// (one wave per block: every lane has read time_of_instance[ii] before lane 0 replaces it - no instruction, the ordering made explicit)
+	__builtin_amdgcn_wave_barrier();
 	if (threadIdx.x == 0 && has_anim) { // animation_module.cpp:458-470
 		const uint32_t l = a.length;
 		uint32_t nt;

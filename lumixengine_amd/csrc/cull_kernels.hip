@@ -240,7 +240,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 	// variant 22 VGPRs (60 -> 82: 5 instead of 8 waves per SIMD), and that variant runs where few chunks are tested at all
 	constexpr bool PLANE_SKIP = LMX_CULL_PLANE_SKIP != 0 && GRP < CHW;
 	static_assert(CHW * FS <= 32, "visibility bits of a wave's chunks x frusta live in one register");
-	extern __shared__ CellInfo s_info[]; // [n_frusta * cell_cap] (MIXED tiles only)
+	LMX_DYNAMIC_LDS(CellInfo, s_info); // [n_frusta * cell_cap] (MIXED tiles only)
 	// the frusta are read through the kernarg segment pointer: uniform scalar loads placed where they are used
 	const DevFrustum* __restrict__ frp = (const DevFrustum*)__builtin_amdgcn_kernarg_segment_ptr();
 	const int nf = F == 1 ? 1 : (int)a.n_frusta;
@@ -558,7 +558,7 @@ template <int TILE>
 __global__ __launch_bounds__(DYN_THREADS) void k_cull_dynamic(const double* __restrict__ px, const double* __restrict__ py,
 	const double* __restrict__ pz, const float* __restrict__ radius, const int32_t* __restrict__ ids, FrustaArg fr, int n_frusta,
 	TypeTable dyn_tt, uint32_t slot_begin, CullOut out) {
-	extern __shared__ int32_t s_stage[]; // [n_frusta][TILE] staged ids | [MAX_FRUSTA] counts | [MAX_FRUSTA] bases
+	LMX_DYNAMIC_LDS(int32_t, s_stage); // [n_frusta][TILE] staged ids | [MAX_FRUSTA] counts | [MAX_FRUSTA] bases
 	uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_stage + n_frusta * TILE);
 	uint32_t* s_base = s_cnt + MAX_FRUSTA;
 	const uint32_t lane = lane_id();

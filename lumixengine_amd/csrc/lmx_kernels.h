@@ -7,6 +7,12 @@
 #include "lmx_math.h"
 #include "lmx_types.h"
 
+// Dynamic LDS of a launch. (tests/hostsim compiles these sources for the CPU and supplies its own definition: there the block is
+// a buffer of the simulated device, not an `extern __shared__` array.)
+#ifndef LMX_DYNAMIC_LDS
+#define LMX_DYNAMIC_LDS(T, name) extern __shared__ T name[]
+#endif
+
 namespace lmx {
 
 constexpr int MAX_FRUSTA = 8;

@@ -469,11 +469,15 @@ static_assert(SHARED_THREADS * SHARED_VPT == SKIN_SHARED_TILE_VERTS, "host tilin
 // (cdna_hip_programming.md, "Pipelining across barriers"), i.e. every store of the wave once per instance; the issuing wave waits
 // for it itself with an exact count.
 __device__ __forceinline__ void lds_dma_16(uint32_t lane_byte_offset, const void* uniform_base, uint32_t lds_byte_address) {
+#ifdef LMX_HOSTSIM // tests/hostsim executes this source on the CPU: the instruction's effect, lane by lane
+	memcpy(static_cast<char*>(hostsim::lds_pointer(lds_byte_address)) + 16u * hostsim::lane(), static_cast<const char*>(uniform_base) + lane_byte_offset, 16);
+#else
 	uint32_t keep;
 	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
 				 : "=&s"(keep)
 				 : "v"(lane_byte_offset), "s"(uniform_base), "s"(lds_byte_address)
 				 : "memory");
+#endif
 }
 
 #ifndef LMX_SHARED_DMA_NUM

@@ -10,8 +10,37 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_addoption(parser):
+    parser.addoption(
+        "--hostsim", action="store", nargs="?", const="plain", default=None, metavar="SANITIZERS",
+        help="run the `-m gpu` tests against tests/hostsim: the kernel and C-ABI SOURCES compiled for the CPU, every lane a fiber "
+             "(test infrastructure for the GPU-less container; optional value: -fsanitize list, e.g. address,undefined)")
+
+
+def hostsim_active() -> bool:
+    """True when the tests run against the simulated device (wall-clock assertions make no sense there)."""
+    return os.environ.get("LMX_HOSTSIM") == "1"
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with `-m gpu` on the GPU box")
+    mode = config.getoption("--hostsim")
+    if mode:
+        from tests.hostsim import build as hostsim_build
+
+        lib = hostsim_build.build(sanitize="" if mode == "plain" else mode)
+        lib_dir = os.path.dirname(lib)
+        alias = os.path.join(lib_dir, "liblumix_mi355.so")  # the C++ harnesses link -llumix_mi355: they find this one first
+        if not os.path.islink(alias):
+            try:
+                os.symlink(os.path.basename(lib), alias)
+            except FileExistsError:
+                pass
+        os.environ["LMX_LIB_PATH"] = lib
+        os.environ["LMX_HOSTSIM"] = "1"
+        os.environ["LD_LIBRARY_PATH"] = lib_dir + os.pathsep + os.environ.get("LD_LIBRARY_PATH", "")
+        # the exchange's collective: the shared-memory stand-in for RCCL, built against the simulated device
+        os.environ["LMX_RCCL_LIBRARY"] = hostsim_build.build_loopback(sanitize="" if mode == "plain" else mode)
 
 
 @pytest.fixture(scope="session")

@@ -1,9 +1,14 @@
 """Shared test inputs: cameras, edge-case culling scenes, comparison helpers."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from lumixengine_amd import scenes
+
+# pytest --hostsim (tests/conftest.py): the kernels run lane by lane on the CPU - results are checked as on the GPU, wall-clock bounds are not
+TIMELESS = os.environ.get("LMX_HOSTSIM") == "1"
 
 
 def quat_from_yaw_pitch(yaw: float, pitch: float) -> np.ndarray:

@@ -1,0 +1,521 @@
+// hostsim_runtime.cpp — TEST INFRASTRUCTURE (see include/hip/hip_runtime.h): the simulated device behind the HIP entry points
+// the C ABI uses, and the lane scheduler that executes a kernel's source once per lane.
+//
+// Execution model
+//   * one block at a time per host thread; each lane of the block is a fiber with its own stack;
+//   * a lane runs until it finishes or reaches a rendezvous: a wave-level one (wave_exchange: every cross-lane operation and the
+//     wave barrier) or the block barrier;
+//   * when every live lane of the block waits, the scheduler resolves, per wave, ONE convergence group: the lanes waiting at the
+//     lowest code address (the return address of wave_exchange inside the kernel: the operation's own location, because all
+//     wrappers are always_inline). Lanes of a wave that wait at different locations are on divergent paths; with the code layout
+//     compilers produce for structured control flow the lower address is the path that has not reconverged yet, so it goes first
+//     and the lanes further down keep waiting, as a wave's reconvergence stack would make them. The group's lanes form the
+//     operation's EXEC mask. wave_exchange is declared `convergent`, so the optimiser may not duplicate or sink the calls;
+//   * the block barrier opens when no wave group is pending and every live lane waits at it.
+// Streams are synchronous: an operation is complete when its call returns (a legal, maximally ordered schedule).
+// Device and pinned memory are heap memory.
+#include <hip/hip_runtime.h>
+
+#include <sys/mman.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HOSTSIM_ASAN 1
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+
+asm(R"(
+.text
+.globl hostsim_switch
+.hidden hostsim_switch
+.type hostsim_switch,@function
+hostsim_switch:
+	pushq %rbp
+	pushq %rbx
+	pushq %r12
+	pushq %r13
+	pushq %r14
+	pushq %r15
+	movq %rsp, (%rdi)
+	movq %rsi, %rsp
+	popq %r15
+	popq %r14
+	popq %r13
+	popq %r12
+	popq %rbx
+	popq %rbp
+	ret
+.size hostsim_switch,.-hostsim_switch
+)");
+extern "C" void hostsim_switch(void** save_sp, void* load_sp);
+
+namespace hostsim {
+
+thread_local Tls tls;
+
+namespace {
+
+constexpr uint32_t MAX_LANES = 1024;
+enum LaneState : uint8_t { RUNNABLE, WAIT_WAVE, WAIT_BLOCK, DONE };
+
+struct Fiber {
+	void* sp;
+	LaneIds ids;
+	LaneState state;
+	const void* site;
+	uint64_t post;
+#ifdef HOSTSIM_ASAN
+	void* fake_stack;
+#endif
+};
+
+struct Worker {
+	void* sched_sp = nullptr;
+	char* stacks = nullptr;
+	size_t stack_bytes = 0;
+	Fiber* current = nullptr;
+	LaneEntry entry = nullptr;
+	void* closure = nullptr;
+	std::vector<unsigned char> dyn_lds;
+	Fiber fibers[MAX_LANES];
+	WaveSnapshot snap[MAX_LANES / 64];
+#ifdef HOSTSIM_ASAN
+	void* sched_fake = nullptr;
+	const void* sched_bottom = nullptr;
+	size_t sched_size = 0;
+#endif
+	~Worker() {
+		if (stacks) munmap(stacks, stack_bytes * MAX_LANES);
+	}
+};
+
+thread_local Worker* t_worker = nullptr;
+thread_local hipError_t t_last_error = hipSuccess;
+thread_local char t_lds_anchor;
+
+size_t env_size(const char* name, size_t dflt) {
+	const char* v = getenv(name);
+	if (!v || !*v) return dflt;
+	const long long n = atoll(v);
+	return n > 0 ? (size_t)n : dflt;
+}
+
+Worker* worker() {
+	if (t_worker) return t_worker;
+	static thread_local struct Holder { Worker* w = nullptr; ~Holder() { delete w; } } holder;
+	Worker* w = new Worker;
+#ifdef HOSTSIM_ASAN
+	w->stack_bytes = env_size("HOSTSIM_STACK_KB", 512) * 1024;
+#else
+	w->stack_bytes = env_size("HOSTSIM_STACK_KB", 128) * 1024;
+#endif
+	void* p = mmap(nullptr, w->stack_bytes * MAX_LANES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+	if (p == MAP_FAILED) {
+		fprintf(stderr, "hostsim: cannot map %zu bytes of lane stacks\n", w->stack_bytes * MAX_LANES);
+		abort();
+	}
+	w->stacks = static_cast<char*>(p);
+	holder.w = w;
+	t_worker = w;
+	return w;
+}
+
+[[noreturn]] void fiber_main() {
+	Worker* w = t_worker;
+#ifdef HOSTSIM_ASAN
+	__sanitizer_finish_switch_fiber(nullptr, &w->sched_bottom, &w->sched_size);
+#endif
+	w->entry(w->closure);
+	Fiber* f = w->current;
+	f->state = DONE;
+#ifdef HOSTSIM_ASAN
+	__sanitizer_start_switch_fiber(nullptr, w->sched_bottom, w->sched_size); // this fiber's fake stack is released
+#endif
+	hostsim_switch(&f->sp, w->sched_sp);
+	__builtin_unreachable();
+}
+
+void yield_to_scheduler() {
+	Worker* w = t_worker;
+	Fiber* f = w->current;
+#ifdef HOSTSIM_ASAN
+	__sanitizer_start_switch_fiber(&f->fake_stack, w->sched_bottom, w->sched_size);
+#endif
+	hostsim_switch(&f->sp, w->sched_sp);
+#ifdef HOSTSIM_ASAN
+	__sanitizer_finish_switch_fiber(f->fake_stack, &w->sched_bottom, &w->sched_size);
+#endif
+}
+
+void resume(Worker* w, Fiber* f) {
+	w->current = f;
+	tls.ids = &f->ids;
+#ifdef HOSTSIM_ASAN
+	const size_t index = (size_t)(f - w->fibers);
+	__sanitizer_start_switch_fiber(&w->sched_fake, w->stacks + index * w->stack_bytes, w->stack_bytes);
+#endif
+	hostsim_switch(&w->sched_sp, f->sp);
+#ifdef HOSTSIM_ASAN
+	__sanitizer_finish_switch_fiber(w->sched_fake, nullptr, nullptr);
+#endif
+}
+
+struct LaunchDesc {
+	dim3 grid, block;
+	size_t dyn_lds;
+	const void* kernarg;
+	LaneEntry entry;
+	void* closure;
+};
+
+void run_block(Worker* w, const LaunchDesc& L, uint64_t linear_block) {
+	const uint32_t n_lanes = L.block.x * L.block.y * L.block.z;
+	const uint32_t n_waves = (n_lanes + 63) / 64;
+	tls.bid = Idx3{(uint32_t)(linear_block % L.grid.x), (uint32_t)(linear_block / L.grid.x % L.grid.y), (uint32_t)(linear_block / ((uint64_t)L.grid.x * L.grid.y))};
+	tls.bdim = Idx3{L.block.x, L.block.y, L.block.z};
+	tls.gdim = Idx3{L.grid.x, L.grid.y, L.grid.z};
+	tls.kernarg = L.kernarg;
+	tls.dyn_lds = w->dyn_lds.data();
+	w->entry = L.entry;
+	w->closure = L.closure;
+	for (uint32_t i = 0; i < n_lanes; ++i) {
+		Fiber& f = w->fibers[i];
+		f.ids.tid = Idx3{i % L.block.x, i / L.block.x % L.block.y, i / (L.block.x * L.block.y)};
+		f.ids.lane = i & 63u;
+		f.ids.wave = i >> 6;
+		f.state = RUNNABLE;
+		f.site = nullptr;
+		f.post = 0;
+		// initial frame: six callee-saved registers, the entry point as return address, one slot that keeps the ABI's alignment
+		void** top = reinterpret_cast<void**>(w->stacks + (size_t)(i + 1) * w->stack_bytes);
+		top[-1] = nullptr;
+		top[-2] = reinterpret_cast<void*>(&fiber_main);
+		for (int k = 3; k <= 8; ++k) top[-k] = nullptr;
+		f.sp = top - 8;
+#ifdef HOSTSIM_ASAN
+		f.fake_stack = nullptr;
+#endif
+	}
+	uint32_t live = n_lanes;
+	while (live) {
+		for (uint32_t i = 0; i < n_lanes; ++i) {
+			Fiber& f = w->fibers[i];
+			if (f.state != RUNNABLE) continue;
+			resume(w, &f);
+			if (f.state == DONE) --live;
+		}
+		if (!live) break;
+		bool any_group = false;
+		uint32_t at_barrier = 0;
+		for (uint32_t wv = 0; wv < n_waves; ++wv) {
+			const uint32_t lo = wv * 64, hi = lo + 64 < n_lanes ? lo + 64 : n_lanes;
+			const void* site = nullptr;
+			for (uint32_t i = lo; i < hi; ++i) {
+				const Fiber& f = w->fibers[i];
+				if (f.state == WAIT_BLOCK) ++at_barrier;
+				if (f.state == WAIT_WAVE && (!site || f.site < site)) site = f.site;
+			}
+			if (!site) continue;
+			WaveSnapshot& s = w->snap[wv];
+			s.exec = 0;
+			s.nonzero = 0;
+			s.first = 64;
+			for (uint32_t i = lo; i < hi; ++i) {
+				Fiber& f = w->fibers[i];
+				s.val[i - lo] = f.post; // lanes outside the group: what they posted last (a stale register)
+				if (f.state != WAIT_WAVE || f.site != site) continue;
+				s.exec |= 1ull << (i - lo);
+				if (f.post) s.nonzero |= 1ull << (i - lo);
+				if (s.first == 64) s.first = i - lo;
+				f.state = RUNNABLE;
+			}
+			any_group = true;
+		}
+		if (any_group) continue;
+		if (at_barrier != live) {
+			fprintf(stderr, "hostsim: block (%u,%u,%u) is stuck: %u live lanes, %u at the block barrier, none at a wave operation\n", tls.bid.x, tls.bid.y, tls.bid.z, live, at_barrier);
+			abort();
+		}
+		for (uint32_t i = 0; i < n_lanes; ++i)
+			if (w->fibers[i].state == WAIT_BLOCK) w->fibers[i].state = RUNNABLE;
+	}
+}
+
+// ---- optional pool: blocks of one launch spread over host threads (HOSTSIM_THREADS > 1) -------------------------------------------
+struct Pool {
+	std::mutex launch_lock; // one launch at a time uses the pool
+	std::mutex m;
+	std::condition_variable cv_work, cv_done;
+	std::vector<std::thread> threads;
+	const LaunchDesc* desc = nullptr;
+	std::atomic<uint64_t> next{0};
+	uint64_t n_blocks = 0;
+	uint64_t generation = 0;
+	uint32_t busy = 0;
+	bool stop = false;
+
+	void work(const LaunchDesc& L) {
+		Worker* w = worker();
+		if (w->dyn_lds.size() < L.dyn_lds) w->dyn_lds.resize(L.dyn_lds);
+		for (;;) {
+			const uint64_t b = next.fetch_add(1, std::memory_order_relaxed);
+			if (b >= n_blocks) break;
+			run_block(w, L, b);
+		}
+	}
+	void thread_main() {
+		uint64_t seen = 0;
+		std::unique_lock<std::mutex> lk(m);
+		for (;;) {
+			cv_work.wait(lk, [&] { return stop || generation != seen; });
+			if (stop) return;
+			seen = generation;
+			const LaunchDesc* d = desc;
+			lk.unlock();
+			work(*d);
+			lk.lock();
+			if (--busy == 0) cv_done.notify_all();
+		}
+	}
+	void run(const LaunchDesc& L, uint64_t blocks, uint32_t n_threads) {
+		std::lock_guard<std::mutex> guard(launch_lock);
+		while (threads.size() + 1 < n_threads) threads.emplace_back([this] { thread_main(); });
+		{
+			std::lock_guard<std::mutex> lk(m);
+			desc = &L;
+			n_blocks = blocks;
+			next.store(0);
+			busy = (uint32_t)threads.size();
+			++generation;
+		}
+		cv_work.notify_all();
+		work(L);
+		std::unique_lock<std::mutex> lk(m);
+		cv_done.wait(lk, [&] { return busy == 0; });
+	}
+	~Pool() {
+		{
+			std::lock_guard<std::mutex> lk(m);
+			stop = true;
+		}
+		cv_work.notify_all();
+		for (std::thread& t : threads) t.join();
+	}
+};
+
+Pool& pool() {
+	static Pool* p = new Pool; // never destroyed: worker threads must not be joined from a static destructor of a dlopen'ed library
+	return *p;
+}
+
+struct Event { double ms; bool recorded; };
+double now_ms() {
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+void note_launch_error(hipError_t e) { t_last_error = e; }
+
+__attribute__((noinline, convergent)) const WaveSnapshot* wave_exchange(uint64_t value) {
+	Worker* w = t_worker;
+	Fiber* f = w->current;
+	f->post = value;
+	f->site = __builtin_return_address(0);
+	f->state = WAIT_WAVE;
+	yield_to_scheduler();
+	return &t_worker->snap[f->ids.wave];
+}
+
+__attribute__((noinline, convergent)) void block_barrier() {
+	Fiber* f = t_worker->current;
+	f->state = WAIT_BLOCK;
+	yield_to_scheduler();
+}
+
+void* lds_pointer(uint32_t lds_byte_address) {
+	// a __shared__ object is thread-local storage of this library: its address shares the upper half with the anchor's unless the
+	// thread's block happens to straddle a 4 GiB boundary
+	const uint64_t anchor = reinterpret_cast<uint64_t>(&t_lds_anchor);
+	uint64_t best = 0, best_dist = ~0ull;
+	for (int k = -1; k <= 1; ++k) {
+		const uint64_t cand = (((anchor >> 32) + (uint64_t)(int64_t)k) << 32) | lds_byte_address;
+		const uint64_t dist = cand > anchor ? cand - anchor : anchor - cand;
+		if (dist < best_dist) {
+			best_dist = dist;
+			best = cand;
+		}
+	}
+	return reinterpret_cast<void*>(best);
+}
+
+int mov_dpp(int v, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+	const WaveSnapshot* s = wave_exchange((uint64_t)(uint32_t)v);
+	const uint32_t l = tls.ids->lane, row = l & ~15u, in_row = l & 15u;
+	int src = -1;
+	if (ctrl >= 0 && ctrl <= 0xff) src = (int)((l & ~3u) + (((uint32_t)ctrl >> (2 * (l & 3u))) & 3u)); // quad_perm
+	else if (ctrl >= 0x101 && ctrl <= 0x10f) src = in_row + (uint32_t)(ctrl - 0x100) < 16 ? (int)(l + (uint32_t)(ctrl - 0x100)) : -1; // row_shl
+	else if (ctrl >= 0x111 && ctrl <= 0x11f) src = in_row >= (uint32_t)(ctrl - 0x110) ? (int)(l - (uint32_t)(ctrl - 0x110)) : -1; // row_shr
+	else if (ctrl >= 0x121 && ctrl <= 0x12f) src = (int)(row + ((in_row + 16 - (uint32_t)(ctrl - 0x120)) & 15u)); // row_ror
+	else if (ctrl == 0x140) src = (int)(row + 15 - in_row); // row_mirror
+	else if (ctrl == 0x141) src = (int)((l & ~7u) + 7 - (l & 7u)); // row_half_mirror
+	else {
+		fprintf(stderr, "hostsim: DPP control 0x%x is not modelled\n", ctrl);
+		abort();
+	}
+	const bool row_on = (row_mask >> (l >> 4)) & 1, bank_on = (bank_mask >> ((l >> 2) & 3)) & 1;
+	if (!row_on || !bank_on) return v;
+	if (src < 0 || !((s->exec >> src) & 1)) return bound_ctrl ? 0 : v;
+	return (int)(uint32_t)s->val[src];
+}
+
+void run_grid(dim3 grid, dim3 block, size_t dyn_lds_bytes, const void* kernarg, LaneEntry entry, void* closure) {
+	const uint64_t n_lanes = (uint64_t)block.x * block.y * block.z;
+	const uint64_t n_blocks = (uint64_t)grid.x * grid.y * grid.z;
+	if (!n_lanes || n_lanes > MAX_LANES || !n_blocks || dyn_lds_bytes > 160 * 1024) {
+		t_last_error = hipErrorInvalidValue;
+		return;
+	}
+	LaunchDesc L{grid, block, dyn_lds_bytes, kernarg, entry, closure};
+	static const uint32_t n_threads = (uint32_t)env_size("HOSTSIM_THREADS", 1);
+	if (n_threads > 1 && n_blocks >= 4) {
+		pool().run(L, n_blocks, n_threads);
+		return;
+	}
+	Worker* w = worker();
+	if (w->dyn_lds.size() < dyn_lds_bytes) w->dyn_lds.resize(dyn_lds_bytes);
+	for (uint64_t b = 0; b < n_blocks; ++b) run_block(w, L, b);
+}
+
+} // namespace hostsim
+
+// ---- the HIP entry points the C ABI uses ------------------------------------------------------------------------------------------
+using hostsim::t_last_error;
+
+extern "C" {
+
+hipError_t hipGetDeviceCount(int* count) {
+	*count = 1;
+	return hipSuccess;
+}
+hipError_t hipSetDevice(int device) { return device == 0 ? hipSuccess : hipErrorInvalidDevice; }
+hipError_t hipGetDevice(int* device) {
+	*device = 0;
+	return hipSuccess;
+}
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int device) {
+	if (device != 0) return hipErrorInvalidDevice;
+	memset(prop, 0, sizeof(*prop));
+	snprintf(prop->name, sizeof(prop->name), "hostsim (kernel sources executed on the CPU)");
+	snprintf(prop->gcnArchName, sizeof(prop->gcnArchName), "gfx950:hostsim");
+	prop->totalGlobalMem = 288ull << 30;
+	prop->multiProcessorCount = 256;
+	prop->warpSize = 64;
+	prop->maxThreadsPerBlock = 1024;
+	prop->sharedMemPerBlock = 160 * 1024;
+	prop->major = 9;
+	prop->minor = 5;
+	return hipSuccess;
+}
+hipError_t hipGetLastError(void) {
+	const hipError_t e = t_last_error;
+	t_last_error = hipSuccess;
+	return e;
+}
+const char* hipGetErrorString(hipError_t e) {
+	switch (e) {
+		case hipSuccess: return "no error";
+		case hipErrorInvalidValue: return "invalid argument";
+		case hipErrorOutOfMemory: return "out of memory";
+		case hipErrorNoDevice: return "no device";
+		case hipErrorInvalidDevice: return "invalid device ordinal";
+		case hipErrorNotReady: return "not ready";
+		default: return "unknown error";
+	}
+}
+hipError_t hipMalloc(void** p, size_t bytes) {
+	*p = nullptr;
+	if (!bytes) return hipSuccess;
+	if (bytes > (64ull << 30)) return hipErrorOutOfMemory;
+	void* q = aligned_alloc(256, (bytes + 255) / 256 * 256);
+	if (!q) return hipErrorOutOfMemory;
+	*p = q;
+	return hipSuccess;
+}
+hipError_t hipFree(void* p) {
+	free(p);
+	return hipSuccess;
+}
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
+hipError_t hipHostFree(void* p) {
+	free(p);
+	return hipSuccess;
+}
+hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) {
+	*dev = host;
+	return hipSuccess;
+}
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) {
+	if (bytes) memmove(dst, src, bytes);
+	return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t) { return hipMemcpy(dst, src, bytes, kind); }
+hipError_t hipMemcpy2D(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind) {
+	if (width > dpitch || width > spitch) return hipErrorInvalidValue;
+	for (size_t r = 0; r < height; ++r) memmove(static_cast<char*>(dst) + r * dpitch, static_cast<const char*>(src) + r * spitch, width);
+	return hipSuccess;
+}
+hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind, hipStream_t) {
+	return hipMemcpy2D(dst, dpitch, src, spitch, width, height, kind);
+}
+hipError_t hipMemset(void* dst, int value, size_t bytes) {
+	if (bytes) memset(dst, value, bytes);
+	return hipSuccess;
+}
+hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t) { return hipMemset(dst, value, bytes); }
+hipError_t hipStreamCreate(hipStream_t* s) {
+	*s = reinterpret_cast<hipStream_t>(new int(0));
+	return hipSuccess;
+}
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+hipError_t hipStreamDestroy(hipStream_t s) {
+	delete reinterpret_cast<int*>(s);
+	return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) {
+	*e = reinterpret_cast<hipEvent_t>(new hostsim::Event{0.0, false});
+	return hipSuccess;
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+hipError_t hipEventDestroy(hipEvent_t e) {
+	delete reinterpret_cast<hostsim::Event*>(e);
+	return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+	hostsim::Event* ev = reinterpret_cast<hostsim::Event*>(e);
+	ev->ms = hostsim::now_ms();
+	ev->recorded = true;
+	return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+	const hostsim::Event* ea = reinterpret_cast<const hostsim::Event*>(a);
+	const hostsim::Event* eb = reinterpret_cast<const hostsim::Event*>(b);
+	if (!ea->recorded || !eb->recorded) return hipErrorInvalidValue;
+	*ms = (float)(eb->ms - ea->ms);
+	return hipSuccess;
+}
+
+} // extern "C"

@@ -18,6 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run_bench(extra, port):
+    if os.environ.get("LMX_HOSTSIM") == "1":
+        pytest.skip("bench.py times a GPU (torch.cuda streams and events): not under pytest --hostsim")
     env = dict(os.environ, LMX_RCCL_LIBRARY=_loopback_library())
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--ranks-share-gpu", "--entities", "1000000",

@@ -241,7 +241,7 @@ def test_cull_config2_10m_bit_exact(gpu_ctx, scene):
     st = cs.updateStats()
     # nothing was rebuilt: 20 x 1000 adds + the sets that left their cell (every other one by construction, a few more by chance)
     assert 25_000 <= st["overflow"] <= 25_500 and st["tombstones"] == st["overflow"], st
-    assert np.median(t_frames) - t_cull < 2e-3, f"2500 updates add {1e6 * (np.median(t_frames) - t_cull):.0f} us to a {1e6 * t_cull:.0f} us cull"
+    assert H.TIMELESS or np.median(t_frames) - t_cull < 2e-3, f"2500 updates add {1e6 * (np.median(t_frames) - t_cull):.0f} us to a {1e6 * t_cull:.0f} us cull"
     # a compaction folds everything back into the sorted layout: same visible set
     cs.compact()
     st = cs.updateStats()
@@ -364,7 +364,7 @@ def test_cull_add_stream_never_stalls(gpu_ctx, oracle_port):
         st = cs.updateStats()
         assert st["overflow"] == frames * per and st["tombstones"] == 0, st
         t = np.array(t_frames[3:])
-        assert t.max() < 2e-3, f"slowest frame {1e3 * t.max():.2f} ms (median {1e6 * np.median(t):.0f} us): an add stalled"
+        assert H.TIMELESS or t.max() < 2e-3, f"slowest frame {1e3 * t.max():.2f} ms (median {1e6 * np.median(t):.0f} us): an add stalled"
     finally:
         cs.setOption(api.CULL_OPT_OVERFLOW_RESERVE, 0)
         cs.setOption(api.CULL_OPT_AUTO_COMPACTION, 1)
@@ -450,7 +450,7 @@ def test_cull_async_compaction_stream(gpu_ctx, oracle_port):
         t = np.array(t_frames[3:])
         print(f"async compaction: {frame} frames, {st['swaps']} swaps, {st['ops_replayed_at_swaps']} ops replayed at swaps; slowest frame {1e3 * t.max():.2f} ms, "
               f"median {1e3 * np.median(t):.3f} ms; synchronous re-sort {1e3 * t_sync:.1f} ms")
-        assert t.max() < 0.5 * t_sync, f"slowest frame {1e3 * t.max():.2f} ms vs a synchronous re-sort of {1e3 * t_sync:.1f} ms"
+        assert H.TIMELESS or t.max() < 0.5 * t_sync, f"slowest frame {1e3 * t.max():.2f} ms vs a synchronous re-sort of {1e3 * t_sync:.1f} ms"
     finally:
         cs.setOption(api.CULL_OPT_ASYNC_COMPACTION, 0)
 

@@ -81,6 +81,8 @@ def _loopback_library():
     import os
     import subprocess
 
+    if os.environ.get("LMX_HOSTSIM") == "1":  # pytest --hostsim: conftest built the stand-in against the simulated device
+        return os.environ["LMX_RCCL_LIBRARY"]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(root, "tests", "cpp", "loopback_rccl.cpp")
     out = os.path.join(root, "tests", "_build", "libloopback_rccl.so")
