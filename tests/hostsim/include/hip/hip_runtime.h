@@ -326,12 +326,12 @@ template <typename T> static __forceinline__ T __shfl_xor(T v, int mask, int wid
 namespace hostsim {
 template <typename T> struct StoreBytes { static constexpr size_t value = sizeof(T); };
 template <typename E, int N> struct StoreBytes<E __attribute__((ext_vector_type(N)))> { static constexpr size_t value = sizeof(E) * N; };
-template <typename V, typename P> static __forceinline__ void nontemporal_store(const V& v, P* p) { memcpy(p, &v, StoreBytes<V>::value); }
-template <typename P> static __forceinline__ P nontemporal_load(const P* p) {
+template <typename V> static __forceinline__ void nontemporal_store(const V& v, void* p) { memcpy(p, &v, StoreBytes<V>::value); }
+template <typename P> static __forceinline__ P nontemporal_load(const void* p) {
 	P v;
 	memcpy(&v, p, StoreBytes<P>::value);
 	return v;
 }
 } // namespace hostsim
-#define __builtin_nontemporal_store(value, pointer) ::hostsim::nontemporal_store((value), (pointer))
-#define __builtin_nontemporal_load(pointer) ::hostsim::nontemporal_load(pointer)
+#define __builtin_nontemporal_store(value, pointer) ::hostsim::nontemporal_store((value), static_cast<void*>(pointer))
+#define __builtin_nontemporal_load(pointer) ::hostsim::nontemporal_load<std::remove_cv_t<std::remove_pointer_t<decltype(pointer)>>>(static_cast<const void*>(pointer))
