@@ -29,7 +29,6 @@ static_assert(LAYOUT_MAX_TYPES == MAX_TYPES && LAYOUT_CHUNK == CHUNK && LAYOUT_T
 
 constexpr uint32_t DYN_ALIGN = 2048;       // largest k_cull_dynamic tile: a tile never straddles two types
 constexpr uint32_t DYN_MAX_SHARDS = 8;     // output shards per type of the dynamic set
-constexpr uint32_t COMPACT_MIN = 1u << 16; // overflow / tombstones tolerated before a compaction is considered at all
 
 enum class Where { NONE, STATIC, DYNAMIC };
 
@@ -1002,7 +1001,7 @@ bool wants_compaction(const CullState& cs) {
 	if (!layout_live(cs)) return true;
 	if (!cs.auto_compaction) return false; // the host schedules lmx_cull_compact itself (loading screen, level streaming boundary)
 	const size_t n_static = cs.recs.size();
-	return cs.n_unbound > std::max<size_t>(COMPACT_MIN, n_static / 8) || cs.n_tombstones > std::max<size_t>(COMPACT_MIN, n_static / 4);
+	return cs.n_unbound > std::max<size_t>(cs.compaction_min, n_static / 8) || cs.n_tombstones > std::max<size_t>(cs.compaction_min, n_static / 4);
 }
 
 int flush_impl(LmxContext* ctx, bool force_compaction) {
@@ -1478,6 +1477,10 @@ int lmx_cull_set_option(LmxContext* ctx, int option, int value) {
 			cs.lane_parallel = value;
 			return LMX_OK;
 		case LMX_CULL_OPT_AUTO_COMPACTION: cs.auto_compaction = value != 0; return LMX_OK;
+		case LMX_CULL_OPT_COMPACTION_MIN:
+			if (value < 1) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "compaction minimum %d < 1", value);
+			cs.compaction_min = (uint32_t)value;
+			return LMX_OK;
 		case LMX_CULL_OPT_DEVICE_OWNS_BOUND: cs.device_owns_bound = value != 0; return LMX_OK;
 		case LMX_CULL_OPT_ASYNC_COMPACTION:
 			if (value) return async_enable(ctx);

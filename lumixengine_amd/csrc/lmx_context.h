@@ -246,6 +246,7 @@ struct CullState : CullSet {
 	uint32_t overflow_reserve = 0; // LMX_CULL_OPT_OVERFLOW_RESERVE: slots kept free in the dynamic set for entities added / re-celled between compactions
 	bool device_owns_bound = false; // LMX_CULL_OPT_DEVICE_OWNS_BOUND: set* calls on hierarchy-bound entities are dropped
 	bool auto_compaction = true; // false: overflow / tombstones accumulate until the host calls lmx_cull_compact
+	uint32_t compaction_min = 1u << 16; // overflow entities / tombstones tolerated before a compaction is considered at all (LMX_CULL_OPT_COMPACTION_MIN)
 	CullAsync* async = nullptr;  // LMX_CULL_OPT_ASYNC_COMPACTION: shadow set + worker thread (owned; lmx_capi_cull.hip)
 	bool emit_slots = false;     // culls also write the static-set slot of every visible id (switched on by the sort-key tables' slot-ordered mirror)
 	uint64_t layout_generation = 0; // a process-wide unique number per build of the static layout (consumers that mirror it by slot compare)

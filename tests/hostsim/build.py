@@ -43,6 +43,8 @@ def build(force: bool = False, sanitize: str = "", opt: str = "-O2") -> str:
              "-Wno-ignored-attributes", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-I" + inc, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     if sanitize:
         flags += ["-fsanitize=" + sanitize, "-fno-omit-frame-pointer"]
+        if "undefined" in sanitize:
+            flags += ["-fno-sanitize=function"]  # the RCCL entry points come out of dlsym: their parameter structs are declared on both sides
 
     def stale(target, deps):
         return force or not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)

@@ -30,6 +30,17 @@
 #define HOSTSIM_ASAN 1
 #include <sanitizer/common_interface_defs.h>
 #endif
+#if __has_feature(thread_sanitizer)
+// ThreadSanitizer: every lane is announced as a fiber of the host thread; switches synchronise (lanes of a block run one after the
+// other on one thread), so what is reported are races between HOST threads - the asynchronous compaction's worker against the frame
+#define HOSTSIM_TSAN 1
+extern "C" {
+void* __tsan_get_current_fiber(void);
+void* __tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void* fiber);
+void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+}
+#endif
 #endif
 
 asm(R"(
@@ -75,6 +86,9 @@ struct Fiber {
 #ifdef HOSTSIM_ASAN
 	void* fake_stack;
 #endif
+#ifdef HOSTSIM_TSAN
+	void* tsan_fiber;
+#endif
 };
 
 struct Worker {
@@ -91,6 +105,9 @@ struct Worker {
 	void* sched_fake = nullptr;
 	const void* sched_bottom = nullptr;
 	size_t sched_size = 0;
+#endif
+#ifdef HOSTSIM_TSAN
+	void* sched_tsan = nullptr;
 #endif
 	~Worker() {
 		if (stacks) munmap(stacks, stack_bytes * MAX_LANES);
@@ -139,6 +156,9 @@ Worker* worker() {
 #ifdef HOSTSIM_ASAN
 	__sanitizer_start_switch_fiber(nullptr, w->sched_bottom, w->sched_size); // this fiber's fake stack is released
 #endif
+#ifdef HOSTSIM_TSAN
+	__tsan_switch_to_fiber(w->sched_tsan, 0);
+#endif
 	hostsim_switch(&f->sp, w->sched_sp);
 	__builtin_unreachable();
 }
@@ -148,6 +168,9 @@ void yield_to_scheduler() {
 	Fiber* f = w->current;
 #ifdef HOSTSIM_ASAN
 	__sanitizer_start_switch_fiber(&f->fake_stack, w->sched_bottom, w->sched_size);
+#endif
+#ifdef HOSTSIM_TSAN
+	__tsan_switch_to_fiber(w->sched_tsan, 0);
 #endif
 	hostsim_switch(&f->sp, w->sched_sp);
 #ifdef HOSTSIM_ASAN
@@ -161,6 +184,9 @@ void resume(Worker* w, Fiber* f) {
 #ifdef HOSTSIM_ASAN
 	const size_t index = (size_t)(f - w->fibers);
 	__sanitizer_start_switch_fiber(&w->sched_fake, w->stacks + index * w->stack_bytes, w->stack_bytes);
+#endif
+#ifdef HOSTSIM_TSAN
+	__tsan_switch_to_fiber(f->tsan_fiber, 0);
 #endif
 	hostsim_switch(&w->sched_sp, f->sp);
 #ifdef HOSTSIM_ASAN
@@ -203,7 +229,13 @@ void run_block(Worker* w, const LaunchDesc& L, uint64_t linear_block) {
 #ifdef HOSTSIM_ASAN
 		f.fake_stack = nullptr;
 #endif
+#ifdef HOSTSIM_TSAN
+		f.tsan_fiber = __tsan_create_fiber(0);
+#endif
 	}
+#ifdef HOSTSIM_TSAN
+	w->sched_tsan = __tsan_get_current_fiber();
+#endif
 	uint32_t live = n_lanes;
 	while (live) {
 		for (uint32_t i = 0; i < n_lanes; ++i) {
@@ -247,6 +279,9 @@ void run_block(Worker* w, const LaunchDesc& L, uint64_t linear_block) {
 		for (uint32_t i = 0; i < n_lanes; ++i)
 			if (w->fibers[i].state == WAIT_BLOCK) w->fibers[i].state = RUNNABLE;
 	}
+#ifdef HOSTSIM_TSAN
+	for (uint32_t i = 0; i < n_lanes; ++i) __tsan_destroy_fiber(w->fibers[i].tsan_fiber);
+#endif
 }
 
 // ---- optional pool: blocks of one launch spread over host threads (HOSTSIM_THREADS > 1) -------------------------------------------

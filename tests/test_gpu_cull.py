@@ -683,3 +683,15 @@ def test_cull_map_all_equals_read_all(gpu_ctx):
     empty = cs.cull(api.viewport_frustum(pos=(1.0e6, 0.0, 0.0)))
     ids, types = empty.map_all(0)
     assert len(ids) == 0 and len(types) == 0
+
+
+@pytest.mark.parametrize("seed", [2, 4, 8, 16, 19, 27])
+def test_cull_fuzz(oracle_port, seed):
+    """tests/fuzz_cull.py: random interleavings of single / batched add, remove, set*, explicit and automatic re-sorts (synchronous and
+    on the worker: these seeds see up to 16 swaps), scene reloads, entity indices re-used, NaN / inf / negative radii, positions on
+    cell boundaries and at 1e6 - every cull (random cameras, 1-8 frusta, type filters, views, tile variants, pass widths, all three
+    read paths) against the oracle (culling_system.cpp:131-369)."""
+    from tests import fuzz_cull
+
+    st = fuzz_cull.run(seed, 300, oracle_port)
+    assert st["culls"] > 30
