@@ -93,7 +93,7 @@ def _loopback_library():
     return out
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_exchange_ranks_on_one_gpu_loopback(tmp_path, oracle_port, world):
     """The exchange with a world of 2 / 4 ranks on this box's one GPU: one process per rank, each with its own context and its cell shard of one
     scene, the collective carried by a shared-memory test double of the five RCCL entry points (RCCL itself refuses two ranks on one

@@ -924,3 +924,14 @@ def test_position_only_binding_keeps_radius(gpu_ctx, oracle_port):
         got_ids, got_types = res.all_ids(f)
         H.assert_same_visible(H.sorted_by_type(got_ids, got_types), H.sorted_by_type(ids, tys), f"frustum {f}")
     assert cs.getRadius(17) == float(radius[17])
+
+
+@pytest.mark.parametrize("seed", [0, 4, 8, 13, 14, 17])
+def test_skin_fuzz(gpu_ctx, oracle_port, seed):
+    """tests/fuzz_skin.py: random skeletons (1..196 bones), meshes on and around every tile size of both vertex kernels, meshes that
+    use all bones / a handful / one limb at a time, instance tables of runs and singles; palettes bit-exact, vertices bit-exact
+    (LMX_SKIN_EXACT) or within 1e-5 (pose.cpp:63-134, model.cpp:103-137)."""
+    from tests import fuzz_skin
+
+    st = fuzz_skin.run(seed, oracle_port, ctx=gpu_ctx)
+    assert st["checked"] >= 3
