@@ -43,6 +43,8 @@ def build(force: bool = False, sanitize: str = "", opt: str = "-O2") -> str:
              "-Wno-ignored-attributes", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-I" + inc, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     if sanitize:
         flags += ["-fsanitize=" + sanitize, "-fno-omit-frame-pointer"]
+        if "thread" in sanitize:
+            flags += ["-mllvm", "-tsan-instrument-func-entry-exit=0"]  # lanes share their wave's fiber: no per-lane shadow call stacks
         if "undefined" in sanitize:
             flags += ["-fno-sanitize=function"]  # the RCCL entry points come out of dlsym: their parameter structs are declared on both sides
 
@@ -52,7 +54,10 @@ def build(force: bool = False, sanitize: str = "", opt: str = "-O2") -> str:
     def compile_one(path):
         obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(path))[0] + ".o")
         if stale(obj, [path] + headers):
-            r = subprocess.run([CLANG] + flags + ["-x", "c++", "-c", path, "-o", obj], capture_output=True, text=True)
+            use = list(flags)
+            if "thread" in sanitize and os.path.basename(path) == "hostsim_runtime.cpp":  # the scheduler itself is not the subject
+                use = [f for f in use if not f.startswith("-fsanitize=")] + ["-DHOSTSIM_WITH_TSAN=1"]
+            r = subprocess.run([CLANG] + use + ["-x", "c++", "-c", path, "-o", obj], capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"hostsim: compiling {os.path.basename(path)} failed:\n{r.stdout}\n{r.stderr}")
         return obj

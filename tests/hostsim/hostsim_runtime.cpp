@@ -30,7 +30,10 @@
 #define HOSTSIM_ASAN 1
 #include <sanitizer/common_interface_defs.h>
 #endif
-#if __has_feature(thread_sanitizer)
+#endif
+#if defined(HOSTSIM_WITH_TSAN)
+// (this file itself is compiled WITHOUT -fsanitize=thread, with -DHOSTSIM_WITH_TSAN: the scheduler's own bookkeeping is touched from
+// every fiber and is not the subject)
 // ThreadSanitizer: every lane is announced as a fiber of the host thread; switches synchronise (lanes of a block run one after the
 // other on one thread), so what is reported are races between HOST threads - the asynchronous compaction's worker against the frame
 #define HOSTSIM_TSAN 1
@@ -39,8 +42,14 @@ void* __tsan_get_current_fiber(void);
 void* __tsan_create_fiber(unsigned flags);
 void __tsan_destroy_fiber(void* fiber);
 void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+void __tsan_acquire(void* addr);
+void __tsan_release(void* addr);
 }
-#endif
+// HOSTSIM_RACE=1 (with --sanitize thread): kernel-level race detection. Every WAVE of a block is one ThreadSanitizer fiber (its lanes run
+// in lockstep on the hardware: they are one thread of execution), switches between waves do NOT synchronise, and the only
+// happens-before edges are the ones the hardware gives: launch -> every wave, __syncthreads() between the waves of a block, every wave ->
+// the host after the launch. Waves of different blocks are never ordered. A conflicting pair of plain accesses to LDS or global memory
+// that the kernel does not order by a barrier or make atomic is then reported as a data race - on the GPU it would be one.
 #endif
 
 asm(R"(
@@ -108,6 +117,9 @@ struct Worker {
 #endif
 #ifdef HOSTSIM_TSAN
 	void* sched_tsan = nullptr;
+	void* wave_tsan[MAX_LANES / 64] = {}; // this host thread's wave fibers (live as long as the worker)
+	bool race_mode = false;
+	char launch_token = 0, done_token = 0, barrier_token = 0; // addresses for __tsan_release / __tsan_acquire
 #endif
 	~Worker() {
 		if (stacks) munmap(stacks, stack_bytes * MAX_LANES);
@@ -140,6 +152,9 @@ Worker* worker() {
 		abort();
 	}
 	w->stacks = static_cast<char*>(p);
+#ifdef HOSTSIM_TSAN
+	w->race_mode = env_size("HOSTSIM_RACE", 0) != 0;
+#endif
 	holder.w = w;
 	t_worker = w;
 	return w;
@@ -150,14 +165,20 @@ Worker* worker() {
 #ifdef HOSTSIM_ASAN
 	__sanitizer_finish_switch_fiber(nullptr, &w->sched_bottom, &w->sched_size);
 #endif
+#ifdef HOSTSIM_TSAN
+	if (w->race_mode) __tsan_acquire(&w->launch_token);
+#endif
 	w->entry(w->closure);
 	Fiber* f = w->current;
 	f->state = DONE;
+#ifdef HOSTSIM_TSAN
+	if (w->race_mode) __tsan_release(&w->done_token);
+#endif
 #ifdef HOSTSIM_ASAN
 	__sanitizer_start_switch_fiber(nullptr, w->sched_bottom, w->sched_size); // this fiber's fake stack is released
 #endif
 #ifdef HOSTSIM_TSAN
-	__tsan_switch_to_fiber(w->sched_tsan, 0);
+	__tsan_switch_to_fiber(w->sched_tsan, w->race_mode ? 1u : 0u);
 #endif
 	hostsim_switch(&f->sp, w->sched_sp);
 	__builtin_unreachable();
@@ -170,7 +191,7 @@ void yield_to_scheduler() {
 	__sanitizer_start_switch_fiber(&f->fake_stack, w->sched_bottom, w->sched_size);
 #endif
 #ifdef HOSTSIM_TSAN
-	__tsan_switch_to_fiber(w->sched_tsan, 0);
+	__tsan_switch_to_fiber(w->sched_tsan, w->race_mode ? 1u : 0u);
 #endif
 	hostsim_switch(&f->sp, w->sched_sp);
 #ifdef HOSTSIM_ASAN
@@ -186,7 +207,8 @@ void resume(Worker* w, Fiber* f) {
 	__sanitizer_start_switch_fiber(&w->sched_fake, w->stacks + index * w->stack_bytes, w->stack_bytes);
 #endif
 #ifdef HOSTSIM_TSAN
-	__tsan_switch_to_fiber(f->tsan_fiber, 0);
+	if (w->race_mode) __tsan_switch_to_fiber(w->wave_tsan[f->ids.wave], 1u);
+	else __tsan_switch_to_fiber(f->tsan_fiber, 0);
 #endif
 	hostsim_switch(&w->sched_sp, f->sp);
 #ifdef HOSTSIM_ASAN
@@ -230,11 +252,21 @@ void run_block(Worker* w, const LaunchDesc& L, uint64_t linear_block) {
 		f.fake_stack = nullptr;
 #endif
 #ifdef HOSTSIM_TSAN
-		f.tsan_fiber = __tsan_create_fiber(0);
+		f.tsan_fiber = w->race_mode ? nullptr : __tsan_create_fiber(0);
 #endif
 	}
 #ifdef HOSTSIM_TSAN
+	if (getenv("HOSTSIM_DEBUG")) fprintf(stderr, "hostsim: block %llu race_mode %d waves %u\n", (unsigned long long)linear_block, (int)w->race_mode, n_waves);
 	w->sched_tsan = __tsan_get_current_fiber();
+	if (w->race_mode) {
+		// The blocks of a launch are spread over (at least) two host threads (run_grid): blocks on different threads are concurrent, as
+		// all blocks are on the GPU; the blocks one thread runs re-use its wave fibers - and its copy of every __shared__ object, which
+		// is thread-local storage - and are ordered one after the other. The host takes the waves' clocks after the whole grid.
+		for (uint32_t wv = 0; wv < n_waves; ++wv)
+			if (!w->wave_tsan[wv]) w->wave_tsan[wv] = __tsan_create_fiber(0);
+		__tsan_acquire(&w->done_token); // the blocks this thread ran before (their LDS is this block's LDS) ...
+		__tsan_release(&w->launch_token); // ... and the launch happen before every wave of this block
+	}
 #endif
 	uint32_t live = n_lanes;
 	while (live) {
@@ -280,7 +312,17 @@ void run_block(Worker* w, const LaunchDesc& L, uint64_t linear_block) {
 			if (w->fibers[i].state == WAIT_BLOCK) w->fibers[i].state = RUNNABLE;
 	}
 #ifdef HOSTSIM_TSAN
-	for (uint32_t i = 0; i < n_lanes; ++i) __tsan_destroy_fiber(w->fibers[i].tsan_fiber);
+	if (!w->race_mode) {
+		for (uint32_t i = 0; i < n_lanes; ++i) __tsan_destroy_fiber(w->fibers[i].tsan_fiber);
+	}
+#endif
+}
+
+void grid_done(Worker* w) {
+#ifdef HOSTSIM_TSAN
+	if (w->race_mode) __tsan_acquire(&w->done_token); // launch complete: the host is ordered after every wave of the grid
+#else
+	(void)w;
 #endif
 }
 
@@ -305,6 +347,7 @@ struct Pool {
 			if (b >= n_blocks) break;
 			run_block(w, L, b);
 		}
+		grid_done(w);
 	}
 	void thread_main() {
 		uint64_t seen = 0;
@@ -371,9 +414,16 @@ __attribute__((noinline, convergent)) const WaveSnapshot* wave_exchange(uint64_t
 }
 
 __attribute__((noinline, convergent)) void block_barrier() {
-	Fiber* f = t_worker->current;
+	Worker* w = t_worker;
+	Fiber* f = w->current;
 	f->state = WAIT_BLOCK;
+#ifdef HOSTSIM_TSAN
+	if (w->race_mode) __tsan_release(&w->barrier_token);
+#endif
 	yield_to_scheduler();
+#ifdef HOSTSIM_TSAN
+	if (w->race_mode) __tsan_acquire(&w->barrier_token);
+#endif
 }
 
 void* lds_pointer(uint32_t lds_byte_address) {
@@ -420,14 +470,16 @@ void run_grid(dim3 grid, dim3 block, size_t dyn_lds_bytes, const void* kernarg, 
 		return;
 	}
 	LaunchDesc L{grid, block, dyn_lds_bytes, kernarg, entry, closure};
-	static const uint32_t n_threads = (uint32_t)env_size("HOSTSIM_THREADS", 1);
-	if (n_threads > 1 && n_blocks >= 4) {
+	static const bool race_mode = env_size("HOSTSIM_RACE", 0) != 0; // (only acted on in a ThreadSanitizer build)
+	static const uint32_t n_threads = std::max<uint32_t>((uint32_t)env_size("HOSTSIM_THREADS", 1), race_mode ? 2u : 1u);
+	if (n_threads > 1 && n_blocks >= (race_mode ? 2u : 4u)) {
 		pool().run(L, n_blocks, n_threads);
 		return;
 	}
 	Worker* w = worker();
 	if (w->dyn_lds.size() < dyn_lds_bytes) w->dyn_lds.resize(dyn_lds_bytes);
 	for (uint64_t b = 0; b < n_blocks; ++b) run_block(w, L, b);
+	grid_done(w);
 }
 
 } // namespace hostsim

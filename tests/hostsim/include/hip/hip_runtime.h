@@ -324,14 +324,26 @@ template <typename T> static __forceinline__ T __shfl_xor(T v, int mask, int wid
 // Cache hints mean nothing here. A 3-element vector is stored element by element: clang widens vec3 accesses to vec4 on x86
 // (16 bytes written), while the AMDGPU target keeps `store <3 x float>` (global_store_dwordx3, 12 bytes).
 namespace hostsim {
-template <typename T> struct StoreBytes { static constexpr size_t value = sizeof(T); };
-template <typename E, int N> struct StoreBytes<E __attribute__((ext_vector_type(N)))> { static constexpr size_t value = sizeof(E) * N; };
-template <typename V> static __forceinline__ void nontemporal_store(const V& v, void* p) { memcpy(p, &v, StoreBytes<V>::value); }
-template <typename P> static __forceinline__ P nontemporal_load(const void* p) {
-	P v;
-	memcpy(&v, p, StoreBytes<P>::value);
-	return v;
-}
+template <typename T> struct NtAccess {
+	static __forceinline__ void store(const T& v, void* p) { memcpy(p, &v, sizeof(T)); }
+	static __forceinline__ T load(const void* p) { T v; memcpy(&v, p, sizeof(T)); return v; }
+};
+template <typename E, int N> struct NtAccess<E __attribute__((ext_vector_type(N)))> { // element by element: exactly N * sizeof(E) bytes
+	typedef E V __attribute__((ext_vector_type(N)));
+	typedef E Unaligned __attribute__((aligned(1), may_alias));
+	static __forceinline__ void store(const V& v, void* p) {
+		Unaligned* q = static_cast<Unaligned*>(p);
+		for (int i = 0; i < N; ++i) q[i] = v[i];
+	}
+	static __forceinline__ V load(const void* p) {
+		const Unaligned* q = static_cast<const Unaligned*>(p);
+		V v;
+		for (int i = 0; i < N; ++i) v[i] = q[i];
+		return v;
+	}
+};
+template <typename V> static __forceinline__ void nontemporal_store(const V& v, void* p) { NtAccess<V>::store(v, p); }
+template <typename P> static __forceinline__ P nontemporal_load(const void* p) { return NtAccess<P>::load(p); }
 } // namespace hostsim
 #define __builtin_nontemporal_store(value, pointer) ::hostsim::nontemporal_store((value), static_cast<void*>(pointer))
 #define __builtin_nontemporal_load(pointer) ::hostsim::nontemporal_load<std::remove_cv_t<std::remove_pointer_t<decltype(pointer)>>>(static_cast<const void*>(pointer))

@@ -38,3 +38,55 @@ def test_gpu_suite_on_the_simulated_device():
     assert r.returncode == 0, tail
     m = re.search(r"(\d+) passed", r.stdout)
     assert m and int(m.group(1)) >= 80 and "failed" not in r.stdout.splitlines()[-1], tail
+
+
+def _tsan_runtime():
+    import glob
+
+    libs = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so")
+    assert libs, "ThreadSanitizer runtime not found next to amdclang++"
+    return libs[0]
+
+
+def test_race_detector_reports_races_and_only_races(tmp_path):
+    """The kernel-level race detector (ThreadSanitizer build of the simulated device + HOSTSIM_RACE=1: every wave a fiber, no ordering but
+    the hardware's - launch, __syncthreads(), completion; blocks spread over two host threads): an LDS exchange between two waves without
+    a barrier and a plain read-modify-write of one global word by two blocks must be reported, the same exchanges behind the barriers /
+    through an atomic must not."""
+    hs = os.path.join(ROOT, "tests", "hostsim")
+    exe = str(tmp_path / "racetest")
+    common = [CLANG, "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-I" + os.path.join(hs, "include"), "-Wno-unknown-attributes", "-x", "c++", "-c"]
+    subprocess.run(common + ["-DHOSTSIM_WITH_TSAN=1", os.path.join(hs, "hostsim_runtime.cpp"), "-o", str(tmp_path / "rt.o")], check=True, capture_output=True)
+    subprocess.run(common + ["-fsanitize=thread", "-mllvm", "-tsan-instrument-func-entry-exit=0", os.path.join(hs, "racetest.cpp"), "-o", str(tmp_path / "k.o")],
+                   check=True, capture_output=True)
+    subprocess.run([CLANG, "-fsanitize=thread", str(tmp_path / "k.o"), str(tmp_path / "rt.o"), "-o", exe, "-pthread"], check=True, capture_output=True)
+    env = dict(os.environ, HOSTSIM_RACE="1", TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=0")
+    for kernel, racy in (("racy_lds", True), ("racy_global", True), ("clean", False)):
+        r = subprocess.run([exe, kernel], env=env, capture_output=True, text=True, timeout=120)
+        assert f"{kernel} done" in r.stdout, r.stdout + r.stderr
+        assert ("ThreadSanitizer: data race" in r.stderr) == racy, kernel + "\n" + r.stderr[-3000:]
+        if racy:
+            assert "racetest.cpp" in r.stderr
+
+
+def test_kernels_are_race_free_on_the_simulated_device(tmp_path):
+    """The product's kernels under that detector: culling (all tile variants, multi-frustum, dynamic set, patches, pack / finalize), the
+    world hierarchy, pose palettes and both vertex kernels, animation sampling, the sort-key kernels. The one pattern suppressed is
+    documented in tests/hostsim/tsan_suppressions.txt (clamped lanes re-storing identical bytes)."""
+    log = str(tmp_path / "tsan")
+    supp = os.path.join(ROOT, "tests", "hostsim", "tsan_suppressions.txt")
+    env = dict(os.environ, HOSTSIM_RACE="1", LD_PRELOAD=_tsan_runtime(),
+               TSAN_OPTIONS=f"halt_on_error=0 report_signal_unsafe=0 history_size=4 exitcode=0 log_path={log} suppressions={supp}")
+    env.pop("LMX_LIB_PATH", None)
+    subset = "golden or type_filter or empty or incremental or fuzz or sort_keys or animation or world_child or set_parent or many_instances or shared_mesh or pose_blend or bone_attach"
+    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "--hostsim", "thread", "-q", "-n", "4", "-p", "no:cacheprovider", "-k", subset]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-6000:]
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 40, r.stdout[-2000:]
+    import glob
+
+    reports = ""
+    for f in glob.glob(log + ".*"):
+        reports += open(f, errors="replace").read()
+    assert "ThreadSanitizer: data race" not in reports, reports[:6000]
