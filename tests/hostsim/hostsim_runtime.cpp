@@ -216,6 +216,31 @@ void resume(Worker* w, Fiber* f) {
 #endif
 }
 
+// HOSTSIM_ORDER = forward (default) | reverse | shuffle[:seed]: the order in which the runnable lanes of a block are resumed and the
+// blocks of a grid are started. The hardware promises neither; a result that changes with it depends on a schedule.
+struct Order {
+	int mode = 0; // 0 forward, 1 reverse, 2 shuffle
+	uint64_t seed = 1;
+	Order() {
+		const char* v = getenv("HOSTSIM_ORDER");
+		if (!v) return;
+		if (!strncmp(v, "reverse", 7)) mode = 1;
+		else if (!strncmp(v, "shuffle", 7)) {
+			mode = 2;
+			if (v[7] == ':') seed = strtoull(v + 8, nullptr, 10) * 2 + 1;
+		}
+	}
+	uint64_t block(uint64_t b, uint64_t n) const {
+		if (mode == 1) return n - 1 - b;
+		if (mode == 2) return (b * 2654435761ull + seed) % n; // a bijection: the multiplier is a prime larger than any grid
+		return b;
+	}
+};
+const Order& order() {
+	static const Order o;
+	return o;
+}
+
 struct LaunchDesc {
 	dim3 grid, block;
 	size_t dyn_lds;
@@ -269,8 +294,22 @@ void run_block(Worker* w, const LaunchDesc& L, uint64_t linear_block) {
 	}
 #endif
 	uint32_t live = n_lanes;
+	const Order& ord = order();
+	uint16_t lane_order[MAX_LANES];
+	for (uint32_t i = 0; i < n_lanes; ++i) lane_order[i] = (uint16_t)(ord.mode == 1 ? n_lanes - 1 - i : i);
+	if (ord.mode == 2) {
+		uint64_t x = ord.seed * 0x9E3779B97F4A7C15ull + linear_block;
+		for (uint32_t i = n_lanes; i > 1; --i) { // Fisher-Yates with a 64-bit LCG
+			x = x * 6364136223846793005ull + 1442695040888963407ull;
+			const uint32_t j = (uint32_t)((x >> 33) % i);
+			const uint16_t t = lane_order[i - 1];
+			lane_order[i - 1] = lane_order[j];
+			lane_order[j] = t;
+		}
+	}
 	while (live) {
-		for (uint32_t i = 0; i < n_lanes; ++i) {
+		for (uint32_t n = 0; n < n_lanes; ++n) {
+			const uint32_t i = lane_order[n];
 			Fiber& f = w->fibers[i];
 			if (f.state != RUNNABLE) continue;
 			resume(w, &f);
@@ -345,7 +384,7 @@ struct Pool {
 		for (;;) {
 			const uint64_t b = next.fetch_add(1, std::memory_order_relaxed);
 			if (b >= n_blocks) break;
-			run_block(w, L, b);
+			run_block(w, L, order().block(b, n_blocks));
 		}
 		grid_done(w);
 	}
@@ -478,7 +517,7 @@ void run_grid(dim3 grid, dim3 block, size_t dyn_lds_bytes, const void* kernarg, 
 	}
 	Worker* w = worker();
 	if (w->dyn_lds.size() < dyn_lds_bytes) w->dyn_lds.resize(dyn_lds_bytes);
-	for (uint64_t b = 0; b < n_blocks; ++b) run_block(w, L, b);
+	for (uint64_t b = 0; b < n_blocks; ++b) run_block(w, L, order().block(b, n_blocks));
 	grid_done(w);
 }
 

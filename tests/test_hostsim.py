@@ -11,6 +11,8 @@ import re
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 SLOW = "full_size or 100m or config2_10m or add_stream or slab_all or async_compaction_stream or update_stream or 10m_properties or bench_scenes"
@@ -29,8 +31,11 @@ def test_simulated_device_semantics():
         assert r.returncode == 0 and "selftest: ok" in r.stdout, opt + "\n" + r.stdout + r.stderr
 
 
-def test_gpu_suite_on_the_simulated_device():
-    env = dict(os.environ)
+@pytest.mark.parametrize("order", ["forward", "reverse", "shuffle:3"])
+def test_gpu_suite_on_the_simulated_device(order):
+    """`order` = the sequence in which the simulated device resumes a block's runnable lanes and starts a grid's blocks
+    (HOSTSIM_ORDER). The hardware promises neither: every result must be the same under all of them."""
+    env = dict(os.environ, HOSTSIM_ORDER=order)
     env.pop("LMX_LIB_PATH", None)
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "--hostsim", "-q", "-n", "4", "-p", "no:cacheprovider", "-k", f"not ({SLOW})"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=2400)
