@@ -935,3 +935,14 @@ def test_skin_fuzz(gpu_ctx, oracle_port, seed):
 
     st = fuzz_skin.run(seed, oracle_port, ctx=gpu_ctx)
     assert st["checked"] >= 3
+
+
+@pytest.mark.parametrize("seed", [0, 3, 4, 7, 9, 11])
+def test_world_fuzz(gpu_ctx, oracle_port, seed):
+    """tests/fuzz_world.py: random forests (depth <= 12), frames of interleaved root / child-local / child-world writes with duplicates,
+    re-parenting (incl. rejected cycles) between frames, both propagation forms, the moved-entity hand-back - world and stored local
+    transforms bit-exact after every step (world.cpp:255-282,337-342,619-753)."""
+    from tests import fuzz_world
+
+    st = fuzz_world.run(seed, 8, oracle_port, ctx=gpu_ctx)
+    assert st["entities"] >= 1
