@@ -54,6 +54,8 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyoracle" not in text and "lmx_oracle" not in text and "liblmx_ref" not in text, f"{f} references the oracle"
+                # ... nor the simulated device of tests/hostsim (the kernels carry two compile-time hooks for it, nothing loads it)
+                assert "liblumix_hostsim" not in text and "hostsim_runtime" not in text, f"{f} references the simulated device's library"
 
 
 def test_host_frustum_mirror_matches_oracle(api, oracle_port):

@@ -45,6 +45,15 @@ def test_gpu_suite_on_the_simulated_device(order):
     assert m and int(m.group(1)) >= 80 and "failed" not in r.stdout.splitlines()[-1], tail
 
 
+def test_smoke_entry_point_on_the_simulated_device():
+    """__graft_entry__.smoke() - what the driver runs on the GPU box before the bench - executed against the kernel sources on the CPU."""
+    from tests.hostsim import build as hostsim_build
+
+    env = dict(os.environ, LMX_LIB_PATH=hostsim_build.build(), LMX_HOSTSIM="1")
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "smoke OK" in r.stdout, r.stdout + r.stderr
+
+
 def _tsan_runtime():
     import glob
 
