@@ -14,6 +14,14 @@
 //   * the block barrier opens when no wave group is pending and every live lane waits at it.
 // Streams are synchronous: an operation is complete when its call returns (a legal, maximally ordered schedule).
 // Device and pinned memory are heap memory.
+//
+// Environment
+//   HOSTSIM_THREADS=n   blocks of a launch spread over n host threads (default 1; every thread has its own lane stacks and its own copy
+//                       of the kernels' __shared__ objects, which are thread-local storage here)
+//   HOSTSIM_ORDER=...   forward (default) | reverse | shuffle[:seed]: order in which runnable lanes are resumed and blocks are started
+//   HOSTSIM_RACE=1      ThreadSanitizer build only: kernel-level race detection (below)
+//   HOSTSIM_STACK_KB=n  stack of one lane (default 128, 512 under AddressSanitizer)
+//   HOSTSIM_DEBUG=1     ThreadSanitizer build only: one line per block
 #include <hip/hip_runtime.h>
 
 #include <sys/mman.h>
