@@ -26,8 +26,20 @@ def _sources():
     return list(product.SOURCES), list(product.HEADERS)
 
 
+def _extra():
+    """LMX_HOSTSIM_EXTRA="-DLMX_CULL_HDR_AHEAD=1 ...": experiment knobs of the kernels (the twin of LMX_HIPCC_EXTRA of the gfx950 build);
+    every set of flags gets its own build directory."""
+    return os.environ.get("LMX_HOSTSIM_EXTRA", "").split()
+
+
 def lib_path(sanitize: str = "") -> str:
-    return os.path.join(ROOT, "tests", "_build", "hostsim" + ("_" + sanitize.replace(",", "_") if sanitize else ""), "liblumix_hostsim.so")
+    tag = "hostsim" + ("_" + sanitize.replace(",", "_") if sanitize else "")
+    extra = _extra()
+    if extra:
+        import hashlib
+
+        tag += "_x" + hashlib.sha1(" ".join(extra).encode()).hexdigest()[:8]
+    return os.path.join(ROOT, "tests", "_build", tag, "liblumix_hostsim.so")
 
 
 def build(force: bool = False, sanitize: str = "", opt: str = "-O2") -> str:
@@ -40,7 +52,7 @@ def build(force: bool = False, sanitize: str = "", opt: str = "-O2") -> str:
     inc = os.path.join(HERE, "include")
     headers += [os.path.join(inc, "hip", "hip_runtime.h"), os.path.join(inc, "hip", "hip_ext.h"), os.path.join(inc, "hipcub", "hipcub.hpp"), os.path.abspath(__file__)]
     flags = ["-std=c++17", opt, "-g1", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-pthread", "-Wall", "-Wno-unused-function", "-Wno-unknown-attributes",
-             "-Wno-ignored-attributes", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-I" + inc, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+             "-Wno-ignored-attributes", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-I" + inc, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + _extra()
     if sanitize:
         flags += ["-fsanitize=" + sanitize, "-fno-omit-frame-pointer"]
         if "thread" in sanitize:
