@@ -396,8 +396,11 @@ LMX_API int lmx_keys_bind_world(LmxContext* ctx, int enable);
    also emit the slot of every visible id, and the key kernels read entities of the sorted set through that mirror (sequential instead
    of one random cache line per table and entity). ModelInstance::lod / Pose::frame of those entities then live in the mirror and are
    handed back to the entity-indexed records whenever a slot dies (removal, move to the overflow set, re-sort) and before
-   lmx_keys_read_state. 0: entity-indexed tables only. Results do not depend on it. */
-enum { LMX_KEYS_OPT_SLOT_ORDER = 0 };
+   lmx_keys_read_state. 0: entity-indexed tables only. Results do not depend on it.
+   LMX_KEYS_OPT_SPLIT_STATE (default 0; with SLOT_ORDER): ModelInstance::lod and Pose::frame of the sorted set's entities - the two fields
+   the key kernel WRITES - live in a dense 8-byte-per-slot array instead of inside the 64-byte mirror records: an update then dirties 8
+   bytes of a line its neighbours update too, not one sector per visible entity. Results do not depend on it. */
+enum { LMX_KEYS_OPT_SLOT_ORDER = 0, LMX_KEYS_OPT_SPLIT_STATE = 1 };
 LMX_API int lmx_keys_set_option(LmxContext* ctx, int option, int value);
 /* createSortKeys for (view, frustum) of the last lmx_cull on that slot. max_sort_key = Renderer::getMaxSortKey(). Async. */
 LMX_API int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeysView* kv, uint32_t max_sort_key);

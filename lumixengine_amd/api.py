@@ -24,7 +24,7 @@ LIB_PATH = os.environ.get("LMX_LIB_PATH") or os.path.join(PKG, "liblumix_mi355.s
 MAX_FRUSTA, MAX_TYPES, MAX_VIEWS = 8, 8, 8
 TYPE_ALL = 0xFF
 CULL_OPT_TILE_VARIANT, CULL_OPT_LANE_PARALLEL_TILE_TEST, CULL_OPT_MAX_SHARDS, CULL_OPT_COUNTER_PAD, CULL_OPT_AUTO_COMPACTION, CULL_OPT_DEVICE_OWNS_BOUND, CULL_OPT_OVERFLOW_RESERVE, CULL_OPT_ASYNC_COMPACTION, CULL_OPT_COMPACTION_MIN = range(9)
-KEYS_OPT_SLOT_ORDER = 0
+KEYS_OPT_SLOT_ORDER, KEYS_OPT_SPLIT_STATE = 0, 1
 WORLD_OPT_FUSED_LEVELS = 0
 (K_CULL_CLASSIFY, K_CULL_SPHERES, K_XFORM_LEVEL, K_SPHERE_REFRESH, K_POSE_PALETTE, K_SKIN_VERTICES, K_CULL_DYNAMIC) = range(7)
 KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices", "cull_dynamic", "sort_keys", "anim_update", "cull_patch"]

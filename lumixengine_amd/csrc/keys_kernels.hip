@@ -80,6 +80,8 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		bool moved = false, queue_dirty = false;
 		double px = 0, py = 0, pz = 0;
 		KeysInstance* rec = nullptr;                   // the entity's record: by slot for the sorted set, by entity otherwise
+		float* lod_at = nullptr;                       // where ModelInstance::lod and Pose::frame of the entity live: in the record, or
+		uint32_t* frame_at = nullptr;                  // (sorted set, LMX_KEYS_SPLIT_STATE) in the dense per-slot array
 		const LmxMeshMaterial* mmb = d.mesh_materials; // ... and the table its material_offset points into
 		if (i < n) {
 			e = (uint32_t)ids[i];
@@ -92,7 +94,17 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			} else if (e < d.n_entities) {
 				rec = d.inst + e;
 			}
-			if (rec != nullptr) in = *rec; // one 64-byte record
+			if (rec != nullptr) {
+				in = *rec; // one 64-byte record
+				lod_at = &rec->lod;
+				frame_at = &rec->pose_frame;
+				if (sl >= 0 && d.state_s != nullptr) {
+					lod_at = &d.state_s[sl].lod;
+					frame_at = &d.state_s[sl].pose_frame;
+					in.lod = *lod_at;
+					in.pose_frame = *frame_at;
+				}
+			}
 			const int32_t mdl = in.model;
 			if (mdl >= 0) {
 				const LmxKeysModel& m = d.models[mdl];
@@ -120,10 +132,10 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 						const float dl = (float)lod_idx - lod;
 						const float ad = fabsf(dl);
 						if (ad <= kv.time_delta) {
-							rec->lod = (float)lod_idx;
+							*lod_at = (float)lod_idx;
 							from0 = m.lod_indices[lod_idx].from; to0 = m.lod_indices[lod_idx].to;
 						} else {
-							if (!kv.is_shadow) { lod = lod + dl / ad * kv.time_delta; rec->lod = lod; }
+							if (!kv.is_shadow) { lod = lod + dl / ad * kv.time_delta; *lod_at = lod; }
 							const uint32_t cur = (uint32_t)lod;
 							from0 = m.lod_indices[cur].from; to0 = m.lod_indices[cur].to;
 							if (cur < 3) { from1 = m.lod_indices[cur + 1].from; to1 = m.lod_indices[cur + 1].to; }
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			if (mm._pad[0] == LMX_MESH_SKINNED) {
 				// Pose::frame stamp (:3889-3898): exactly one visit per frame hands the instance to the pose processor
 				if (!push_pose && pose_stamp != kv.frame_number) {
-					push_pose = atomicExch(&rec->pose_frame, kv.frame_number) != kv.frame_number;
+					push_pose = atomicExch(frame_at, kv.frame_number) != kv.frame_number;
 					pose_stamp = kv.frame_number;
 				}
 				++n_pairs;
@@ -391,7 +403,7 @@ __global__ __launch_bounds__(256) void k_keys_mirror_count(const int32_t* __rest
 
 __global__ __launch_bounds__(256) void k_keys_mirror_fill(const int32_t* __restrict__ slot_ids, uint32_t n_slots, const KeysInstance* __restrict__ inst,
 	uint32_t n_entities, const LmxKeysModel* __restrict__ models, const LmxMeshMaterial* __restrict__ mesh_materials, const uint32_t* __restrict__ offset,
-	KeysInstance* __restrict__ inst_s, LmxMeshMaterial* __restrict__ mm_s) {
+	KeysInstance* __restrict__ inst_s, LmxMeshMaterial* __restrict__ mm_s, KeysSlotState* __restrict__ state_s) {
 	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
 	if (s >= n_slots) return;
 	KeysInstance r;
@@ -407,29 +419,31 @@ __global__ __launch_bounds__(256) void k_keys_mirror_fill(const int32_t* __restr
 		}
 	}
 	inst_s[s] = r;
+	if (state_s != nullptr) state_s[s] = KeysSlotState{r.lod, r.pose_frame};
 }
 
 // lod / Pose::frame of the entities of slots [0, n_slots) (or of the slots the id patches are about to turn into tombstones) back
 // into the entity-indexed records
-__device__ __forceinline__ void mirror_hand_back(uint32_t s, const int32_t* slot_ids, const KeysInstance* inst_s, KeysInstance* inst, uint32_t n_entities) {
+__device__ __forceinline__ void mirror_hand_back(uint32_t s, const int32_t* slot_ids, const KeysInstance* inst_s, const KeysSlotState* state_s, KeysInstance* inst,
+	uint32_t n_entities) {
 	const int32_t e = slot_ids[s];
 	if (e < 0 || (uint32_t)e >= n_entities) return;
 	const KeysInstance& r = inst_s[s];
 	if (r.model < 0) return;
-	inst[e].lod = r.lod;
-	inst[e].pose_frame = r.pose_frame;
+	inst[e].lod = state_s != nullptr ? state_s[s].lod : r.lod;
+	inst[e].pose_frame = state_s != nullptr ? state_s[s].pose_frame : r.pose_frame;
 }
 __global__ __launch_bounds__(256) void k_keys_mirror_sync(const int32_t* __restrict__ slot_ids, uint32_t n_slots, const KeysInstance* __restrict__ inst_s,
-	KeysInstance* __restrict__ inst, uint32_t n_entities) {
+	const KeysSlotState* __restrict__ state_s, KeysInstance* __restrict__ inst, uint32_t n_entities) {
 	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-	if (s < n_slots) mirror_hand_back(s, slot_ids, inst_s, inst, n_entities);
+	if (s < n_slots) mirror_hand_back(s, slot_ids, inst_s, state_s, inst, n_entities);
 }
 __global__ __launch_bounds__(256) void k_keys_mirror_carry(const PatchId* __restrict__ patches, uint32_t n, const int32_t* __restrict__ slot_ids, uint32_t n_slots,
-	const KeysInstance* __restrict__ inst_s, KeysInstance* __restrict__ inst, uint32_t n_entities) {
+	const KeysInstance* __restrict__ inst_s, const KeysSlotState* __restrict__ state_s, KeysInstance* __restrict__ inst, uint32_t n_entities) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) return;
 	const PatchId p = patches[i];
-	if (p.id < 0 && p.slot < n_slots) mirror_hand_back(p.slot, slot_ids, inst_s, inst, n_entities);
+	if (p.id < 0 && p.slot < n_slots) mirror_hand_back(p.slot, slot_ids, inst_s, state_s, inst, n_entities);
 }
 
 } // namespace
@@ -439,20 +453,21 @@ hipError_t launch_keys_mirror_count(hipStream_t s, const int32_t* slot_ids, uint
 	return hipGetLastError();
 }
 hipError_t launch_keys_mirror_fill(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models,
-	const LmxMeshMaterial* mesh_materials, const uint32_t* offset, KeysInstance* inst_s, LmxMeshMaterial* mm_s) {
+	const LmxMeshMaterial* mesh_materials, const uint32_t* offset, KeysInstance* inst_s, LmxMeshMaterial* mm_s, KeysSlotState* state_s) {
 	if (!n_slots) return hipSuccess;
-	hipLaunchKernelGGL(k_keys_mirror_fill, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, slot_ids, n_slots, inst, n_entities, models, mesh_materials, offset, inst_s, mm_s);
+	hipLaunchKernelGGL(k_keys_mirror_fill, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, slot_ids, n_slots, inst, n_entities, models, mesh_materials, offset, inst_s, mm_s, state_s);
 	return hipGetLastError();
 }
-hipError_t launch_keys_mirror_sync(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, KeysInstance* inst, uint32_t n_entities) {
-	if (!n_slots) return hipSuccess;
-	hipLaunchKernelGGL(k_keys_mirror_sync, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, slot_ids, n_slots, inst_s, inst, n_entities);
-	return hipGetLastError();
-}
-hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint32_t n, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, KeysInstance* inst,
+hipError_t launch_keys_mirror_sync(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, const KeysSlotState* state_s, KeysInstance* inst,
 	uint32_t n_entities) {
+	if (!n_slots) return hipSuccess;
+	hipLaunchKernelGGL(k_keys_mirror_sync, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, slot_ids, n_slots, inst_s, state_s, inst, n_entities);
+	return hipGetLastError();
+}
+hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint32_t n, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s,
+	const KeysSlotState* state_s, KeysInstance* inst, uint32_t n_entities) {
 	if (!n) return hipSuccess;
-	hipLaunchKernelGGL(k_keys_mirror_carry, dim3((n + 255u) / 256u), dim3(256), 0, s, patches, n, slot_ids, n_slots, inst_s, inst, n_entities);
+	hipLaunchKernelGGL(k_keys_mirror_carry, dim3((n + 255u) / 256u), dim3(256), 0, s, patches, n, slot_ids, n_slots, inst_s, state_s, inst, n_entities);
 	return hipGetLastError();
 }
 

@@ -30,6 +30,7 @@ static int keys_build_mirror(LmxContext* ctx) {
 	if (!n_slots || !ks.d_inst.p) return LMX_OK; // nothing sorted / no tables: the entity-indexed path
 	LMX_HIP(ctx, ks.d_inst_s.reserve(n_slots));
 	LMX_HIP(ctx, ks.d_mm_s.reserve(std::max<size_t>(ks.n_mesh_materials, 1)));
+	if (ks.split_state) LMX_HIP(ctx, ks.d_state_s.reserve(n_slots));
 	LMX_HIP(ctx, ks.d_mm_count.reserve((size_t)n_slots + 1));
 	LMX_HIP(ctx, ks.d_mm_off.reserve((size_t)n_slots + 1));
 	LMX_HIP(ctx, launch_keys_mirror_count(ctx->stream, cs.ids.p, n_slots, ks.d_inst.p, ks.n_entities, ks.d_models.p, ks.d_mm_count.p));
@@ -38,7 +39,8 @@ static int keys_build_mirror(LmxContext* ctx) {
 	LMX_HIP(ctx, ks.d_scan_temp.reserve(temp));
 	LMX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ks.d_scan_temp.p, temp, ks.d_mm_count.p, ks.d_mm_off.p, (int)(n_slots + 1), ctx->stream));
 	LMX_HIP(ctx, launch_keys_mirror_fill(ctx->stream, cs.ids.p, n_slots, ks.d_inst.p, ks.n_entities, ks.d_models.p, ks.d_mesh_materials.p, ks.d_mm_off.p, ks.d_inst_s.p,
-		ks.d_mm_s.p));
+		ks.d_mm_s.p, ks.split_state ? ks.d_state_s.p : nullptr));
+	ks.mirror_split = ks.split_state;
 	ks.mirror_valid = true;
 	ks.mirror_generation = cs.layout_generation;
 	ks.mirror_slots = n_slots;
@@ -51,7 +53,8 @@ int keys_before_layout_change(LmxContext* ctx) {
 	KeysState& ks = ctx->keys;
 	if (!ks.mirror_valid) return LMX_OK;
 	ks.mirror_valid = false;
-	LMX_HIP(ctx, launch_keys_mirror_sync(ctx->stream, ctx->cull.ids.p, std::min(ks.mirror_slots, ctx->cull.n_padded), ks.d_inst_s.p, ks.d_inst.p, ks.n_entities));
+	LMX_HIP(ctx, launch_keys_mirror_sync(ctx->stream, ctx->cull.ids.p, std::min(ks.mirror_slots, ctx->cull.n_padded), ks.d_inst_s.p, ks.mirror_split ? ks.d_state_s.p : nullptr, ks.d_inst.p,
+		ks.n_entities));
 	return LMX_OK;
 }
 
@@ -59,7 +62,8 @@ int keys_before_layout_change(LmxContext* ctx) {
 int keys_before_tombstones(LmxContext* ctx, const PatchId* d_patches, uint32_t n) {
 	KeysState& ks = ctx->keys;
 	if (!ks.mirror_valid || !n) return LMX_OK;
-	LMX_HIP(ctx, launch_keys_mirror_carry(ctx->stream, d_patches, n, ctx->cull.ids.p, std::min(ks.mirror_slots, ctx->cull.n_padded), ks.d_inst_s.p, ks.d_inst.p, ks.n_entities));
+	LMX_HIP(ctx, launch_keys_mirror_carry(ctx->stream, d_patches, n, ctx->cull.ids.p, std::min(ks.mirror_slots, ctx->cull.n_padded), ks.d_inst_s.p,
+		ks.mirror_split ? ks.d_state_s.p : nullptr, ks.d_inst.p, ks.n_entities));
 	return LMX_OK;
 }
 
@@ -199,8 +203,15 @@ int lmx_keys_bind_world(LmxContext* ctx, int enable) {
 
 int lmx_keys_set_option(LmxContext* ctx, int option, int value) {
 	LMX_CHECK_CTX(ctx);
-	if (option != LMX_KEYS_OPT_SLOT_ORDER) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "unknown sort-key option %d", option);
 	KeysState& ks = ctx->keys;
+	if (option == LMX_KEYS_OPT_SPLIT_STATE) {
+		if ((value != 0) != ks.split_state) {
+			if (int rc = keys_before_layout_change(ctx)) return rc; // hand the state back, drop the mirror: the next run builds it in the other form
+			ks.split_state = value != 0;
+		}
+		return LMX_OK;
+	}
+	if (option != LMX_KEYS_OPT_SLOT_ORDER) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "unknown sort-key option %d", option);
 	if (!value) {
 		if (int rc = keys_before_layout_change(ctx)) return rc; // hand the state back, drop the mirror
 		ctx->cull.emit_slots = false;
@@ -294,6 +305,7 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 		d.models = ks.d_models.p;
 		d.inst_s = ks.mirror_valid ? ks.d_inst_s.p : nullptr;
 		d.mm_s = ks.mirror_valid ? ks.d_mm_s.p : nullptr;
+		d.state_s = ks.mirror_valid && ks.mirror_split ? ks.d_state_s.p : nullptr;
 	}
 	if (ks.have_decals) { d.decal_sort_key = ks.d_decal_key.p; d.decal_layer = ks.d_decal_layer.p; }
 	if (ks.have_curves) { d.curve_sort_key = ks.d_curve_key.p; d.curve_layer = ks.d_curve_layer.p; }
@@ -418,7 +430,7 @@ int lmx_keys_read_state(LmxContext* ctx, float* lod, uint32_t* pose_frame, uint3
 	if (n_entities != ks.n_entities) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "expected %u entities", ks.n_entities);
 	if (ks.inst_dirty) return fail(ctx, LMX_ERR_NOT_BUILT, "tables changed since the last lmx_keys_run");
 	if (ks.mirror_valid) // entities of the sorted set keep lod / Pose::frame in their slot records
-		LMX_HIP(ctx, launch_keys_mirror_sync(ctx->stream, ctx->cull.ids.p, ks.mirror_slots, ks.d_inst_s.p, ks.d_inst.p, ks.n_entities));
+		LMX_HIP(ctx, launch_keys_mirror_sync(ctx->stream, ctx->cull.ids.p, ks.mirror_slots, ks.d_inst_s.p, ks.mirror_split ? ks.d_state_s.p : nullptr, ks.d_inst.p, ks.n_entities));
 	const char* base = reinterpret_cast<const char*>(ks.d_inst.p);
 	if (lod && n_entities)
 		LMX_HIP(ctx, hipMemcpy2DAsync(lod, sizeof(float), base + offsetof(KeysInstance, lod), sizeof(KeysInstance), sizeof(float), n_entities, hipMemcpyDeviceToHost, ctx->stream));

@@ -391,6 +391,9 @@ struct KeysState {
 	size_t n_mesh_materials = 0;
 	DevBuf<KeysInstance> d_inst_s;
 	DevBuf<LmxMeshMaterial> d_mm_s;
+	DevBuf<KeysSlotState> d_state_s; // LMX_KEYS_OPT_SPLIT_STATE: lod / Pose::frame of the sorted set's entities, 8 bytes per slot
+	bool split_state = LMX_KEYS_SPLIT_STATE_DEFAULT != 0;
+	bool mirror_split = false;       // the current mirror was built with d_state_s
 	DevBuf<uint32_t> d_mm_count, d_mm_off;
 	DevBuf<char> d_scan_temp;
 };

@@ -217,6 +217,10 @@ struct alignas(64) KeysInstance {
 	uint8_t pad[22];
 };
 static_assert(sizeof(KeysInstance) == 64, "one record per 64-byte sector");
+struct KeysSlotState { float lod; uint32_t pose_frame; };
+#ifndef LMX_KEYS_SPLIT_STATE_DEFAULT
+#define LMX_KEYS_SPLIT_STATE_DEFAULT 0 // initial value of lmx_keys_set_option(LMX_KEYS_OPT_SPLIT_STATE); not timed on the GPU yet
+#endif
 struct KeysDevice {
 	// model instances by entity index: ONE 64-byte record per entity (the visible ids are in cell order, entity indices are not:
 	// seven separate per-entity arrays meant seven random 128-byte lines per visible entity and made the kernel traffic-bound)
@@ -227,6 +231,10 @@ struct KeysDevice {
 	// the sorted set are read with the locality of the set; ids of the dynamic set (slot -1) take the entity-indexed tables above
 	KeysInstance* inst_s;
 	const LmxMeshMaterial* mm_s;
+	// (LMX_KEYS_SPLIT_STATE, experiment) the two fields of a record the kernel WRITES - ModelInstance::lod and Pose::frame - of the sorted
+	// set's entities in a dense array of their own, 8 bytes per slot: a 4-byte update of a 64-byte record dirties a whole sector per visible
+	// entity (the traffic model of tests/hostsim and the PMC counters agree on ~230 B of traffic per visible entity against 87 algorithmic)
+	KeysSlotState* state_s; // nullptr: lod / pose_frame live in inst_s
 	const LmxKeysModel* models;
 	const uint32_t *decal_sort_key, *curve_sort_key;
 	const uint8_t *decal_layer, *curve_layer;
@@ -255,10 +263,11 @@ struct KeysDevice {
 };
 hipError_t launch_keys_mirror_count(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models, uint32_t* count);
 hipError_t launch_keys_mirror_fill(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models,
-	const LmxMeshMaterial* mesh_materials, const uint32_t* offset, KeysInstance* inst_s, LmxMeshMaterial* mm_s);
-hipError_t launch_keys_mirror_sync(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, KeysInstance* inst, uint32_t n_entities);
-hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint32_t n, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, KeysInstance* inst,
+	const LmxMeshMaterial* mesh_materials, const uint32_t* offset, KeysInstance* inst_s, LmxMeshMaterial* mm_s, KeysSlotState* state_s /* optional */);
+hipError_t launch_keys_mirror_sync(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, const KeysSlotState* state_s, KeysInstance* inst,
 	uint32_t n_entities);
+hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint32_t n, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s,
+	const KeysSlotState* state_s, KeysInstance* inst, uint32_t n_entities);
 hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const int32_t* mesh_ids, const int32_t* mesh_slots, const uint32_t* mesh_count,
 	uint32_t mesh_cap, const int32_t* decal_ids, const uint32_t* decal_count, uint32_t decal_cap, const int32_t* curve_ids,
 	const uint32_t* curve_count, uint32_t curve_cap);

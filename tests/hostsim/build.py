@@ -53,7 +53,10 @@ def build(force: bool = False, sanitize: str = "", opt: str = "-O2") -> str:
     headers += [os.path.join(inc, "hip", "hip_runtime.h"), os.path.join(inc, "hip", "hip_ext.h"), os.path.join(inc, "hipcub", "hipcub.hpp"), os.path.abspath(__file__)]
     flags = ["-std=c++17", opt, "-g1", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-pthread", "-Wall", "-Wno-unused-function", "-Wno-unknown-attributes",
              "-Wno-ignored-attributes", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-I" + inc, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + _extra()
-    if sanitize:
+    traffic = sanitize == "traffic"  # not a sanitizer: ThreadSanitizer's instrumentation linked against traffic_runtime.cpp (a traffic model)
+    if traffic:
+        flags += ["-fsanitize=thread", "-mllvm", "-tsan-instrument-func-entry-exit=0", "-mllvm", "-tsan-instrument-atomics=0", "-mllvm", "-tsan-compound-read-before-write=1"]
+    elif sanitize:
         flags += ["-fsanitize=" + sanitize, "-fno-omit-frame-pointer"]
         if "thread" in sanitize:
             flags += ["-mllvm", "-tsan-instrument-func-entry-exit=0"]  # lanes share their wave's fiber: no per-lane shadow call stacks
@@ -69,17 +72,19 @@ def build(force: bool = False, sanitize: str = "", opt: str = "-O2") -> str:
             use = list(flags)
             if "thread" in sanitize and os.path.basename(path) == "hostsim_runtime.cpp":  # the scheduler itself is not the subject
                 use = [f for f in use if not f.startswith("-fsanitize=")] + ["-DHOSTSIM_WITH_TSAN=1"]
+            if traffic and os.path.basename(path) in ("hostsim_runtime.cpp", "traffic_runtime.cpp"):
+                use = [f for f in use if not f.startswith("-fsanitize=") and not f.startswith("-tsan-") and f != "-mllvm"] + ["-DHOSTSIM_TRAFFIC=1"]
             r = subprocess.run([CLANG] + use + ["-x", "c++", "-c", path, "-o", obj], capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"hostsim: compiling {os.path.basename(path)} failed:\n{r.stdout}\n{r.stderr}")
         return obj
 
-    paths = [os.path.join(CSRC, s) for s in sources] + [os.path.join(HERE, "hostsim_runtime.cpp")]
+    paths = [os.path.join(CSRC, s) for s in sources] + [os.path.join(HERE, "hostsim_runtime.cpp")] + ([os.path.join(HERE, "traffic_runtime.cpp")] if traffic else [])
     with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(compile_one, paths))
     if stale(out, objs):
         cmd = [CLANG, "-shared", "-fPIC", "-pthread", "-o", out] + objs + ["-ldl"]
-        if sanitize:
+        if sanitize and not traffic:
             cmd += ["-fsanitize=" + sanitize, "-shared-libsan"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

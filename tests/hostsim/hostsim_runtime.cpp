@@ -89,6 +89,17 @@ namespace hostsim {
 
 thread_local Tls tls;
 
+#ifdef HOSTSIM_TRAFFIC // build mode "traffic": traffic_runtime.cpp records the kernels' accesses to device memory
+struct TrafficBlock;
+extern thread_local TrafficBlock* t_traffic;
+TrafficBlock* traffic_block_new();
+void traffic_alloc(void* p, size_t n);
+void traffic_free(void* p);
+void traffic_flush_block(TrafficBlock* b, void* launch_acc, uint32_t block_threads_x);
+void* traffic_launch_begin();
+void traffic_launch_end(const char* label, void* launch_acc, uint64_t lanes);
+#endif
+
 namespace {
 
 constexpr uint32_t MAX_LANES = 1024;
@@ -116,6 +127,9 @@ struct Worker {
 	LaneEntry entry = nullptr;
 	void* closure = nullptr;
 	std::vector<unsigned char> dyn_lds;
+#ifdef HOSTSIM_TRAFFIC
+	TrafficBlock* traffic = nullptr;
+#endif
 	Fiber fibers[MAX_LANES];
 	WaveSnapshot snap[MAX_LANES / 64];
 #ifdef HOSTSIM_ASAN
@@ -218,7 +232,13 @@ void resume(Worker* w, Fiber* f) {
 	if (w->race_mode) __tsan_switch_to_fiber(w->wave_tsan[f->ids.wave], 1u);
 	else __tsan_switch_to_fiber(f->tsan_fiber, 0);
 #endif
+#ifdef HOSTSIM_TRAFFIC
+	t_traffic = w->traffic;
+#endif
 	hostsim_switch(&w->sched_sp, f->sp);
+#ifdef HOSTSIM_TRAFFIC
+	t_traffic = nullptr;
+#endif
 #ifdef HOSTSIM_ASAN
 	__sanitizer_finish_switch_fiber(w->sched_fake, nullptr, nullptr);
 #endif
@@ -255,6 +275,7 @@ struct LaunchDesc {
 	const void* kernarg;
 	LaneEntry entry;
 	void* closure;
+	void* traffic_acc;
 };
 
 void run_block(Worker* w, const LaunchDesc& L, uint64_t linear_block) {
@@ -267,6 +288,9 @@ void run_block(Worker* w, const LaunchDesc& L, uint64_t linear_block) {
 	tls.dyn_lds = w->dyn_lds.data();
 	w->entry = L.entry;
 	w->closure = L.closure;
+#ifdef HOSTSIM_TRAFFIC
+	if (!w->traffic) w->traffic = traffic_block_new();
+#endif
 	for (uint32_t i = 0; i < n_lanes; ++i) {
 		Fiber& f = w->fibers[i];
 		f.ids.tid = Idx3{i % L.block.x, i / L.block.x % L.block.y, i / (L.block.x * L.block.y)};
@@ -365,6 +389,15 @@ void run_block(Worker* w, const LaunchDesc& L, uint64_t linear_block) {
 #endif
 }
 
+void block_done(Worker* w, const LaunchDesc& L) {
+#ifdef HOSTSIM_TRAFFIC
+	traffic_flush_block(w->traffic, L.traffic_acc, L.block.x);
+#else
+	(void)w;
+	(void)L;
+#endif
+}
+
 void grid_done(Worker* w) {
 #ifdef HOSTSIM_TSAN
 	if (w->race_mode) __tsan_acquire(&w->done_token); // launch complete: the host is ordered after every wave of the grid
@@ -393,6 +426,7 @@ struct Pool {
 			const uint64_t b = next.fetch_add(1, std::memory_order_relaxed);
 			if (b >= n_blocks) break;
 			run_block(w, L, order().block(b, n_blocks));
+			block_done(w, L);
 		}
 		grid_done(w);
 	}
@@ -509,23 +543,40 @@ int mov_dpp(int v, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
 	return (int)(uint32_t)s->val[src];
 }
 
-void run_grid(dim3 grid, dim3 block, size_t dyn_lds_bytes, const void* kernarg, LaneEntry entry, void* closure) {
+void run_grid(const char* label, dim3 grid, dim3 block, size_t dyn_lds_bytes, const void* kernarg, LaneEntry entry, void* closure) {
 	const uint64_t n_lanes = (uint64_t)block.x * block.y * block.z;
 	const uint64_t n_blocks = (uint64_t)grid.x * grid.y * grid.z;
 	if (!n_lanes || n_lanes > MAX_LANES || !n_blocks || dyn_lds_bytes > 160 * 1024) {
 		t_last_error = hipErrorInvalidValue;
 		return;
 	}
-	LaunchDesc L{grid, block, dyn_lds_bytes, kernarg, entry, closure};
+	LaunchDesc L{grid, block, dyn_lds_bytes, kernarg, entry, closure, nullptr};
+#ifdef HOSTSIM_TRAFFIC
+	struct TrafficScope { // one accumulator per launch; the blocks run on this thread only
+		const char* label; void* acc; uint64_t lanes;
+		~TrafficScope() { traffic_launch_end(label, acc, lanes); }
+	} traffic_scope{label, traffic_launch_begin(), n_lanes * n_blocks};
+	L.traffic_acc = traffic_scope.acc;
+#else
+	(void)label;
+#endif
 	static const bool race_mode = env_size("HOSTSIM_RACE", 0) != 0; // (only acted on in a ThreadSanitizer build)
 	static const uint32_t n_threads = std::max<uint32_t>((uint32_t)env_size("HOSTSIM_THREADS", 1), race_mode ? 2u : 1u);
+#ifndef HOSTSIM_TRAFFIC
 	if (n_threads > 1 && n_blocks >= (race_mode ? 2u : 4u)) {
 		pool().run(L, n_blocks, n_threads);
 		return;
 	}
+#else
+	(void)race_mode;
+	(void)n_threads;
+#endif
 	Worker* w = worker();
 	if (w->dyn_lds.size() < dyn_lds_bytes) w->dyn_lds.resize(dyn_lds_bytes);
-	for (uint64_t b = 0; b < n_blocks; ++b) run_block(w, L, order().block(b, n_blocks));
+	for (uint64_t b = 0; b < n_blocks; ++b) {
+		run_block(w, L, order().block(b, n_blocks));
+		block_done(w, L);
+	}
 	grid_done(w);
 }
 
@@ -581,18 +632,21 @@ hipError_t hipMalloc(void** p, size_t bytes) {
 	if (bytes > (64ull << 30)) return hipErrorOutOfMemory;
 	void* q = aligned_alloc(256, (bytes + 255) / 256 * 256);
 	if (!q) return hipErrorOutOfMemory;
+#ifdef HOSTSIM_TRAFFIC
+	hostsim::traffic_alloc(q, (bytes + 255) / 256 * 256);
+#endif
 	*p = q;
 	return hipSuccess;
 }
 hipError_t hipFree(void* p) {
+#ifdef HOSTSIM_TRAFFIC
+	if (p) hostsim::traffic_free(p);
+#endif
 	free(p);
 	return hipSuccess;
 }
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
-hipError_t hipHostFree(void* p) {
-	free(p);
-	return hipSuccess;
-}
+hipError_t hipHostFree(void* p) { return hipFree(p); }
 hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) {
 	*dev = host;
 	return hipSuccess;

@@ -5,6 +5,6 @@
 #define hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, start_event, stop_event, flags, ...) \
 	do {                                                                                                 \
 		if (start_event) (void)hipEventRecord(start_event, stream);                                      \
-		::hostsim::launch(kernel, grid, block, lds, stream, __VA_ARGS__);                                \
+		::hostsim::launch(#kernel, kernel, grid, block, lds, stream, __VA_ARGS__);                               \
 		if (stop_event) (void)hipEventRecord(stop_event, stream);                                        \
 	} while (0)

@@ -156,7 +156,7 @@ __attribute__((noinline, convergent)) void block_barrier();
 void* lds_pointer(uint32_t lds_byte_address);
 
 typedef void (*LaneEntry)(void* closure);
-void run_grid(dim3 grid, dim3 block, size_t dyn_lds_bytes, const void* kernarg, LaneEntry entry, void* closure);
+void run_grid(const char* label, dim3 grid, dim3 block, size_t dyn_lds_bytes, const void* kernarg, LaneEntry entry, void* closure);
 void note_launch_error(hipError_t e);
 
 template <typename T> static inline void pack_kernarg(unsigned char* buf, size_t& off, size_t cap, const T& v) {
@@ -167,7 +167,7 @@ template <typename T> static inline void pack_kernarg(unsigned char* buf, size_t
 }
 
 template <typename... KArgs, typename... Args>
-static inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t dyn_lds_bytes, hipStream_t, Args&&... args) {
+static inline void launch(const char* label, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t dyn_lds_bytes, hipStream_t, Args&&... args) {
 	static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel launched with a different number of arguments than it declares");
 	typedef std::tuple<std::decay_t<KArgs>...> Tuple;
 	struct Closure { void (*kernel)(KArgs...); Tuple args; };
@@ -176,7 +176,7 @@ static inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_
 	size_t off = 0;
 	std::apply([&](const auto&... a) { (pack_kernarg(kernarg, off, sizeof(kernarg), a), ...); }, c.args);
 	if (off > sizeof(kernarg)) { note_launch_error(hipErrorInvalidValue); return; }
-	run_grid(grid, block, dyn_lds_bytes, kernarg, [](void* p) {
+	run_grid(label, grid, block, dyn_lds_bytes, kernarg, [](void* p) {
 		Closure* cl = static_cast<Closure*>(p);
 		std::apply(cl->kernel, cl->args);
 	}, &c);
@@ -184,7 +184,7 @@ static inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_
 
 } // namespace hostsim
 
-#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) ::hostsim::launch(kernel, grid, block, lds, stream, __VA_ARGS__)
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) ::hostsim::launch(#kernel, kernel, grid, block, lds, stream, __VA_ARGS__)
 
 #define threadIdx (::hostsim::tls.ids->tid)
 #define blockIdx (::hostsim::tls.bid)

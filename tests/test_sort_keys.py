@@ -245,12 +245,13 @@ def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("slot_order", [1, 0])
+@pytest.mark.parametrize("slot_order", [1, 0, 2])
 def test_gpu_sort_keys_slot_order_under_updates(gpu_ctx, oracle_port, slot_order):
     """LMX_KEYS_OPT_SLOT_ORDER: the instance tables mirrored in the order of the culling system's sorted set. ModelInstance::lod and
     Pose::frame of an entity of the sorted set then live in its slot record and must follow the entity when the slot dies. Seven frames
     of cull -> createSortKeys with removals, moves out of the cell (to the overflow set), in-cell moves, re-adds and a re-sort in
-    between: every frame's pairs / groups / poses / dirty list and the carried state equal the oracle's, with the mirror and without."""
+    between: every frame's pairs / groups / poses / dirty list and the carried state equal the oracle's, with the mirror and without
+    (slot_order 2: the mirror with LMX_KEYS_OPT_SPLIT_STATE - lod / Pose::frame in the dense per-slot array)."""
     base = scenes.cull_scene(60_000, 2500.0, seed=33, big_fraction=0.002)
     n = len(base["entity"])
     types = make_types(n, 4)
@@ -261,7 +262,8 @@ def test_gpu_sort_keys_slot_order_under_updates(gpu_ctx, oracle_port, slot_order
     ocs = oracle_port.culling_system()
     sk = api.SortKeys(gpu_ctx)
     try:
-        sk.setOption(api.KEYS_OPT_SLOT_ORDER, slot_order)
+        sk.setOption(api.KEYS_OPT_SLOT_ORDER, 1 if slot_order else 0)
+        sk.setOption(api.KEYS_OPT_SPLIT_STATE, 1 if slot_order == 2 else 0)
         sk.setModels(sc["models"], sc["mesh_types"])
         sk.setInstances(sc["model"], sc["material_offset"], sc["mesh_materials"], sc["lod"], sc["flags"], sc["dirty"], sc["pose_frame"])
         sk.setDecals(n, sc["decal_key"], sc["decal_layer"], sc["curve_key"], sc["curve_layer"])
@@ -321,6 +323,7 @@ def test_gpu_sort_keys_slot_order_under_updates(gpu_ctx, oracle_port, slot_order
                 cs.compact()  # a re-sort: every slot changes
     finally:
         sk.setOption(api.KEYS_OPT_SLOT_ORDER, 1)
+        sk.setOption(api.KEYS_OPT_SPLIT_STATE, 0)
 
 
 @pytest.mark.gpu
