@@ -53,7 +53,7 @@ __device__ __forceinline__ uint32_t float_flip(uint32_t bits) {
 	return bits ^ mask;
 }
 
-constexpr int KEYS_BLOCK = 512; // 8 waves: 3 blocks per CU at 67 VGPRs
+constexpr int KEYS_BLOCK = 512; // 8 waves: 3 blocks per CU (79 VGPRs: 6 waves per SIMD)
 
 // The visible list is walked in tiles of 512 entities by a fixed-size grid. Per tile every lane first COUNTS what it will
 // emit, the block reserves its four output ranges with two 64-bit atomics on two cache lines (returning atomics on one line retire at
