@@ -48,6 +48,14 @@ __device__ __forceinline__ void wave_lds_sync() {
 // of (pose * inverse_bind).toMatrix() is the constant (0, 0, 0, 1) (math.cpp:887-890) and is re-attached on read-back.
 constexpr int POSE_LDS_BONES = 1024; // K * n_bones <= 1024: 16 x 64, 8 x 128, 4 x 196
 constexpr int POSE_WAVES = 4;
+#ifndef LMX_POSE_STAGE_OUT
+// (experiment, not timed yet) the output phase writes (instance, bone) pairs with the instance fastest across the lanes: a store instruction
+// puts 16 bytes at a 48-byte stride per lane and the traffic model (tools/traffic_model.py) counts 41 % sector use for the kernel's writes,
+// which are 73 % of its bytes. 1: the palette rows of a step go through an LDS staging buffer and leave as contiguous 16-byte pieces per
+// instance (12.3 KiB more LDS per block); 2: the absolute pose written back (28 B per bone, the worst of the stores) as well (+7.4 KiB).
+// Bit-exact by construction (the same values, another route); checked on the simulated device with LMX_HOSTSIM_EXTRA=-DLMX_POSE_STAGE_OUT=n.
+#define LMX_POSE_STAGE_OUT 0
+#endif
 
 // LDS slot of (bone, instance of the group): bone-major, plain. Every phase maps neighbouring lanes to neighbouring INSTANCES of one
 // bone (lane -> instance lane % K, bone lane / K), so a wave touches 64 consecutive slots: conflict-free for the 16-byte rotations
@@ -125,6 +133,81 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_pose_palette(const SkinInst
 		}
 		__syncthreads();
 	}
+#if LMX_POSE_STAGE_OUT
+	// palette (computeSkinMatrices), optional dual quaternions, optional absolute pose write-back - staged: a step's (instance, bone) pairs
+	// are computed with the instance fastest across the lanes (the conflict-free order of the LDS pose arrays), written to staging rows
+	// of one instance each, and leave as contiguous pieces of that instance's palette / pose
+	{
+		constexpr uint32_t ROW_PITCH = BONES_PER_STEP * 3 + 1;  // float4 per instance row (+1: lanes of neighbouring instances on distinct bank columns)
+		__shared__ float4 s_out[K * ROW_PITCH];
+#if LMX_POSE_STAGE_OUT > 1
+		constexpr uint32_t ROT_PITCH = BONES_PER_STEP + 1;
+		constexpr uint32_t POS_PITCH = BONES_PER_STEP * 3 + 1; // floats
+		__shared__ float4 s_rot_out[K * ROT_PITCH];
+		__shared__ float s_pos_out[K * POS_PITCH];
+#endif
+		const float* ipos = inv_pos + (size_t)in.model_offset * 3;
+		const float4* irot = inv_rot + in.model_offset;
+		for (uint32_t b0 = 0; b0 < nb; b0 += BONES_PER_STEP) { // block-uniform
+			const uint32_t b = b0 + b_lane;
+			const uint32_t n_step = nb - b0 < BONES_PER_STEP ? nb - b0 : BONES_PER_STEP; // bones of this step
+			if (k_live && b < nb) {
+				const float4 ir4 = irot[b];
+				const Q4 ir = Q4{ir4.x, ir4.y, ir4.z, ir4.w};
+				const V3 ip = V3{ipos[3 * b], ipos[3 * b + 1], ipos[3 * b + 2]};
+				const size_t i = bone0 + (size_t)k * nb + b;
+				const uint32_t ib = pose_slot<K>(b, k);
+				const float4 r4 = s_rot[ib];
+				const V3 p = V3{s_px[ib], s_py[ib], s_pz[ib]};
+				const Mat4 m = skin_matrix(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, ir);
+				if (dual_quats != nullptr) { // (the dual-quaternion palette keeps the direct stores)
+					const DualQ dq = skin_dual_quat(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, ir);
+					float4* o = dual_quats + i * 2;
+					o[0] = make_float4(dq.r.x, dq.r.y, dq.r.z, dq.r.w);
+					o[1] = make_float4(dq.d.x, dq.d.y, dq.d.z, dq.d.w);
+				}
+				float4* row = s_out + k * ROW_PITCH + b_lane * 3;
+				row[0] = make_float4(m.c[0][0], m.c[1][0], m.c[2][0], m.c[3][0]);
+				row[1] = make_float4(m.c[0][1], m.c[1][1], m.c[2][1], m.c[3][1]);
+				row[2] = make_float4(m.c[0][2], m.c[1][2], m.c[2][2], m.c[3][2]);
+#if LMX_POSE_STAGE_OUT > 1
+				if (pose_pos != nullptr) {
+					s_rot_out[k * ROT_PITCH + b_lane] = r4;
+					float* pp = s_pos_out + k * POS_PITCH + b_lane * 3;
+					pp[0] = p.x; pp[1] = p.y; pp[2] = p.z;
+				}
+#else
+				if (pose_pos != nullptr) { // the pose becomes absolute (Pose::is_absolute = true, pose.cpp:133)
+					float* gp = pose_pos + i * 3;
+					gp[0] = p.x; gp[1] = p.y; gp[2] = p.z;
+					pose_rot[i] = r4;
+				}
+#endif
+			}
+			__syncthreads();
+			// palette rows: n_step * 3 float4 per live instance, contiguous in memory from bone b0 of that instance
+			for (uint32_t j = tid; j < K * n_step * 3; j += THREADS) {
+				const uint32_t kk = j / (n_step * 3), within = j - kk * (n_step * 3);
+				if (kk < g.count) palette[(bone0 + (size_t)kk * nb + b0) * 3 + within] = s_out[kk * ROW_PITCH + within];
+			}
+#if LMX_POSE_STAGE_OUT > 1
+			if (pose_pos != nullptr) {
+				for (uint32_t j = tid; j < K * n_step; j += THREADS) {
+					const uint32_t kk = j / n_step, within = j - kk * n_step;
+					if (kk < g.count) pose_rot[bone0 + (size_t)kk * nb + b0 + within] = s_rot_out[kk * ROT_PITCH + within];
+				}
+				for (uint32_t j = tid; j < K * n_step * 3; j += THREADS) {
+					const uint32_t kk = j / (n_step * 3), within = j - kk * (n_step * 3);
+					if (kk < g.count) pose_pos[(bone0 + (size_t)kk * nb + b0) * 3 + within] = s_pos_out[kk * POS_PITCH + within];
+				}
+			}
+#endif
+			__syncthreads(); // the staging rows are rewritten by the next step
+		}
+	}
+}
+
+#else
 	// palette (computeSkinMatrices), optional dual quaternions, optional absolute pose write-back
 	const float* ipos = inv_pos + (size_t)in.model_offset * 3;
 	const float4* irot = inv_rot + in.model_offset;
@@ -156,6 +239,8 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_pose_palette(const SkinInst
 		}
 	}
 }
+
+#endif // LMX_POSE_STAGE_OUT
 
 // Pose::blend (renderer/pose.cpp:30-41) for every bone of every instance: positions = positions * inv + rhs * weight, rotations =
 // nlerp(rotations, rhs, weight) (core/math.cpp:677-691: left-to-right dot and length, t negated for the short way round)

@@ -13,3 +13,20 @@ bash tools/scratch/cull_ab.sh base hdr_ahead base hdr_ahead
 # compile-time default of the context: the variant re-compiles lmx_capi_ctx.hip (where LmxContext is constructed) with it switched on.
 python tools/build_variant.py keys_split lmx_capi_ctx.hip "-DLMX_KEYS_SPLIT_STATE_DEFAULT=1" > /dev/null
 bash tools/scratch/keys_ab.sh base keys_split base keys_split
+# k_pose_palette: output through LDS staging rows (LMX_POSE_STAGE_OUT=1: palette rows, 2: + the absolute pose written back). The traffic model
+# counts 0.41 -> 0.86 -> 1.00 sector use for the kernel's writes (73 % of its bytes); LDS per block 29.9 -> 42.4 -> 49.9 KiB (5 -> 3 blocks per
+# CU), so this one can go either way. Kernel time of the skin workload (2000 instances x 64 bones) under rocprofv3.
+ROOT=$(pwd); export TMPDIR=/tmp
+python tools/build_variant.py pose_stage1 skin_kernels.hip "-DLMX_POSE_STAGE_OUT=1" > /dev/null
+python tools/build_variant.py pose_stage2 skin_kernels.hip "-DLMX_POSE_STAGE_OUT=2" > /dev/null
+for v in base pose_stage1 pose_stage2 base pose_stage1 pose_stage2; do
+  OUT=gpurun_out/poseab_$v; rm -rf $OUT; mkdir -p $OUT
+  (cd /tmp && LMX_LIB_PATH=$ROOT/tools/_build/variants/$v/liblumix_mi355.so timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT -o p -- python $ROOT/tools/run_workload.py --workload skin --steps 20 > $ROOT/$OUT/log.txt 2>&1 < /dev/null)
+  python - "$v" <<'PY'
+import csv, sys
+v = sys.argv[1]
+for r in csv.DictReader(open(f"gpurun_out/poseab_{v}/p_kernel_stats.csv")):
+    if "k_pose_palette" in r["Name"] or "k_skin_shared" in r["Name"]:
+        print("%-12s %-40s calls %s avg %.1f us min %.1f" % (v, r["Name"][:40], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
+PY
+done
