@@ -54,6 +54,34 @@ def test_smoke_entry_point_on_the_simulated_device():
     assert r.returncode == 0 and "smoke OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_traffic_model_reproduces_the_algorithmic_bytes(tmp_path):
+    """tools/traffic_model.py (build mode "traffic": an instrumentation call in front of every load / store of the kernel sources, recorded
+    by tests/hostsim/traffic_runtime.cpp): the footprint of the all-test cull is DESIGN.md's 20 B per entity + cell keys / headers / ids
+    written (22.4 B / entity by the GPU's PMC counters), the pose palette's is 28 + 76 B per bone, the hierarchy's requested bytes are
+    156 B per moved child + index and mark - and the two access-pattern findings the model is quoted for stay visible."""
+    out = str(tmp_path / "traffic.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "traffic_model.py"), "--entities", "200000", "--instances", "32", "--out", out], cwd=ROOT,
+                       capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    import json
+
+    d = json.load(open(out))
+
+    def kernel(workload, name):
+        return next(v for k, v in d[workload]["kernels"].items() if name in k)
+
+    cull = kernel("cull_all_test", "k_cull_tile")
+    assert 20.0 <= cull["footprint_per_unit"] <= 26.0 and cull["read_coalescing"] > 0.85, cull
+    xf = kernel("xform", "k_xform_level")
+    assert 150.0 <= xf["bytes_per_unit"] <= 175.0, xf
+    pose = kernel("skin", "k_pose_palette")
+    bones = 32 * 64
+    assert 100.0 <= pose["footprint_bytes"] / bones <= 112.0, pose  # 28 B read + 76 B written per bone
+    assert pose["write_coalescing"] < 0.6  # the strided stores (LMX_POSE_STAGE_OUT is the experiment against them)
+    keys, split = kernel("keys", "k_keys_mesh"), kernel("keys_split_state", "k_keys_mesh")
+    assert split["footprint_bytes"] < 0.9 * keys["footprint_bytes"], (keys, split)
+
+
 def _tsan_runtime():
     import glob
 
