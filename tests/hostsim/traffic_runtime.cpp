@@ -11,6 +11,8 @@
 // It knows nothing about time, caches or the order in which the hardware issues anything.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <map>
@@ -36,6 +38,8 @@ struct KernelStats {
 		footprint_write_lines = 0;
 };
 std::map<std::string, KernelStats> g_stats;
+struct PcStats { uint64_t read_bytes = 0, write_bytes = 0, sectors64 = 0, wave_instr = 0; };
+std::map<std::string, std::map<uint64_t, PcStats>> g_by_pc; // HOSTSIM_TRAFFIC_BY_PC=1: per kernel label and code address
 thread_local Range t_last{1, 0};
 
 bool in_device_memory(uint64_t a) {
@@ -93,6 +97,8 @@ static inline void record(const void* addr, uint32_t size, bool write, const voi
 struct LaunchAccumulator {
 	KernelStats s;
 	std::unordered_set<uint64_t> read_lines, write_lines;
+	std::map<uint64_t, PcStats> by_pc;
+	bool want_pc = getenv("HOSTSIM_TRAFFIC_BY_PC") != nullptr;
 };
 
 // groups one block's records into wave-instructions and adds them to the launch
@@ -142,6 +148,12 @@ void traffic_flush_block(TrafficBlock* b, void* launch_acc, uint32_t block_threa
 		std::sort(lin.begin(), lin.end());
 		const uint64_t n_sec = (uint64_t)(std::unique(sec.begin(), sec.end()) - sec.begin());
 		acc->s.lines128 += (uint64_t)(std::unique(lin.begin(), lin.end()) - lin.begin());
+		if (acc->want_pc) {
+			PcStats& ps = acc->by_pc[first.pc];
+			(first.write ? ps.write_bytes : ps.read_bytes) += (!first.write && uniform && j - i > 1) ? first.size : bytes;
+			ps.sectors64 += n_sec;
+			ps.wave_instr += 1;
+		}
 		if (first.write) {
 			acc->s.write_bytes += bytes;
 			acc->s.write_sectors64 += n_sec;
@@ -174,6 +186,13 @@ void traffic_launch_end(const char* label, void* launch_acc, uint64_t lanes) {
 	k.lines128 += acc->s.lines128;
 	k.footprint_read_lines += acc->read_lines.size();
 	k.footprint_write_lines += acc->write_lines.size();
+	for (const auto& kv : acc->by_pc) {
+		PcStats& ps = g_by_pc[label][kv.first];
+		ps.read_bytes += kv.second.read_bytes;
+		ps.write_bytes += kv.second.write_bytes;
+		ps.sectors64 += kv.second.sectors64;
+		ps.wave_instr += kv.second.wave_instr;
+	}
 	delete acc;
 }
 
@@ -185,6 +204,22 @@ extern "C" {
 void hostsim_traffic_reset(void) {
 	std::lock_guard<std::mutex> guard(hostsim::g_mutex);
 	hostsim::g_stats.clear();
+	hostsim::g_by_pc.clear();
+}
+// HOSTSIM_TRAFFIC_BY_PC=1: one line per (kernel label, code address): "label<TAB>library offset (hex)<TAB>read bytes<TAB>written bytes<TAB>sector requests<TAB>wave-instructions"
+int hostsim_traffic_dump_by_pc(const char* path) {
+	std::lock_guard<std::mutex> guard(hostsim::g_mutex);
+	FILE* f = fopen(path, "w");
+	if (!f) return 1;
+	for (const auto& kv : hostsim::g_by_pc)
+		for (const auto& pc : kv.second) {
+			Dl_info info;
+			const uint64_t base = dladdr(reinterpret_cast<void*>(pc.first), &info) ? reinterpret_cast<uint64_t>(info.dli_fbase) : 0;
+			fprintf(f, "%s\t%llx\t%llu\t%llu\t%llu\t%llu\n", kv.first.c_str(), (unsigned long long)(pc.first - base - 1), (unsigned long long)pc.second.read_bytes,
+				(unsigned long long)pc.second.write_bytes, (unsigned long long)pc.second.sectors64, (unsigned long long)pc.second.wave_instr);
+		}
+	fclose(f);
+	return 0;
 }
 // one JSON object: kernel label -> totals since the last reset
 int hostsim_traffic_dump(const char* path) {

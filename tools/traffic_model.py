@@ -25,9 +25,12 @@ def main():
     ap.add_argument("--entities", type=int, default=1_000_000)
     ap.add_argument("--instances", type=int, default=64)
     ap.add_argument("--out", default="")
+    ap.add_argument("--by-line", default="", metavar="KERNEL", help="also print the source lines of kernels whose label contains KERNEL, by the bytes their accesses request")
     args = ap.parse_args()
     from tests.hostsim import build as hostsim_build
 
+    if args.by_line:
+        os.environ["HOSTSIM_TRAFFIC_BY_PC"] = "1"
     lib_path = hostsim_build.build(sanitize="traffic")
     os.environ["LMX_LIB_PATH"] = lib_path
     os.environ["LMX_HOSTSIM"] = "1"
@@ -48,11 +51,39 @@ def main():
             rows[k] = dict(v, requested_bytes=req, bytes_per_unit=req / units,
                            read_coalescing=v["read_bytes"] / max(1, 64 * v["read_sector64_requests"]), write_coalescing=v["write_bytes"] / max(1, 64 * v["write_sector64_requests"]),
                            footprint_bytes=v["footprint_read_bytes"] + v["footprint_write_bytes"], footprint_per_unit=(v["footprint_read_bytes"] + v["footprint_write_bytes"]) / units)
+        if args.by_line:
+            by_line(tag, units, unit_name)
         print(f"== {tag}  ({units} {unit_name})")
         for k, r in sorted(rows.items(), key=lambda kv: -kv[1]["requested_bytes"]):
             print(f"   {k[:58]:58s} x{r['launches']:<2d} requested {r['requested_bytes'] / 1e6:8.2f} MB = {r['bytes_per_unit']:7.2f} B/{unit_name} ({r['read_bytes'] / 1e6:.2f} R + {r['write_bytes'] / 1e6:.2f} W + "
                   f"{r['uniform_read_bytes'] / 1e6:.2f} scalar)  sector use R {r['read_coalescing']:.2f} W {r['write_coalescing']:.2f}  footprint {r['footprint_bytes'] / 1e6:8.2f} MB = {r['footprint_per_unit']:6.2f} B/{unit_name}")
         return {"units": units, "unit": unit_name, "kernels": rows}
+
+    def by_line(tag, units, unit_name):
+        import subprocess
+
+        path = os.path.join(tmp, "pc.tsv")
+        sim.hostsim_traffic_dump_by_pc(path.encode())
+        rows = [l.rstrip("\n").split("\t") for l in open(path)]
+        rows = [r for r in rows if args.by_line in r[0]]
+        if not rows:
+            return
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-symbolizer", "--obj=" + lib_path, "--inlines", "--output-style=JSON"] + ["0x" + r[1] for r in rows],
+                             capture_output=True, text=True).stdout
+        agg = {}
+        for r, entry in zip(rows, json.loads(out)):
+            loc = "?"
+            for frame in entry.get("Symbol", []):  # innermost frame first: the first one inside csrc/ is the kernel's own line
+                if "csrc/" in frame.get("FileName", ""):
+                    loc = f"{frame['FileName'].split('csrc/')[1]}:{frame['Line']}"
+                    break
+            a = agg.setdefault(loc, [0, 0, 0, 0])
+            for i in range(4):
+                a[i] += int(r[2 + i])
+        print(f"-- {tag}: source lines of *{args.by_line}* by requested bytes")
+        for loc, a in sorted(agg.items(), key=lambda kv: -(kv[1][0] + kv[1][1]))[:25]:
+            use = (a[0] + a[1]) / max(1, 64 * a[2])
+            print(f"   {loc:34s} {a[0] / units:8.2f} B read {a[1] / units:8.2f} B written per {unit_name}   sector use {use:.2f}   {a[3]} wave-instructions")
 
     report = {}
     ctx = api.Context(0)
