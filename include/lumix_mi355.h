@@ -399,7 +399,8 @@ LMX_API int lmx_keys_bind_world(LmxContext* ctx, int enable);
    lmx_keys_read_state. 0: entity-indexed tables only. Results do not depend on it.
    LMX_KEYS_OPT_SPLIT_STATE (default 0; with SLOT_ORDER): ModelInstance::lod and Pose::frame of the sorted set's entities - the two fields
    the key kernel WRITES - live in a dense 8-byte-per-slot array instead of inside the 64-byte mirror records: an update then dirties 8
-   bytes of a line its neighbours update too, not one sector per visible entity. Results do not depend on it. */
+   bytes of a line its neighbours update too, not one sector per visible entity. 2: the whole mirror is a structure of arrays (one dense array
+   per field the key kernel reads, 42 bytes per slot instead of the 64-byte records). Results do not depend on it. */
 enum { LMX_KEYS_OPT_SLOT_ORDER = 0, LMX_KEYS_OPT_SPLIT_STATE = 1 };
 LMX_API int lmx_keys_set_option(LmxContext* ctx, int option, int value);
 /* createSortKeys for (view, frustum) of the last lmx_cull on that slot. max_sort_key = Renderer::getMaxSortKey(). Async. */

@@ -53,6 +53,14 @@ __device__ __forceinline__ uint32_t float_flip(uint32_t bits) {
 	return bits ^ mask;
 }
 
+#ifndef LMX_KEYS_STAGE_PAIRS
+// (experiment, not timed yet) a tile's (key, value) pairs and instancer records are collected in LDS at their positions inside the tile's
+// output ranges and leave as contiguous stores, instead of 8-byte stores at every lane's own run of positions (sector use 0.26 by the
+// traffic model, 30 of the kernel's 122 requested bytes per visible entity). Tiles with more output than the buffers hold keep the direct
+// stores. Bit-exact by construction; checked on the simulated device with LMX_HOSTSIM_EXTRA=-DLMX_KEYS_STAGE_PAIRS=1.
+#define LMX_KEYS_STAGE_PAIRS 0
+#endif
+constexpr int KEYS_STAGE_PAIRS = 1536; // pairs (24 KiB) and records (18 KiB) of one 512-entity tile held in LDS
 constexpr int KEYS_BLOCK = 512; // 8 waves: 3 blocks per CU (79 VGPRs: 6 waves per SIMD)
 
 // The visible list is walked in tiles of 512 entities by a fixed-size grid. Per tile every lane first COUNTS what it will
@@ -65,7 +73,7 @@ constexpr int KEYS_BLOCK = 512; // 8 waves: 3 blocks per CU (79 VGPRs: 6 waves p
 __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(KeysDevice d, const KeysViewDevice kv /* by value: captured at launch */,
 	const int32_t* __restrict__ ids, const int32_t* __restrict__ slots /* optional: static-set slot per id, -1 = dynamic set */, const uint32_t* __restrict__ n_visible) {
 	__shared__ uint32_t s_wave[KEYS_BLOCK / 64][3]; // per wave: pairs | recs << 16, poses, dirty
-	__shared__ uint32_t s_base[4];
+	__shared__ uint32_t s_base[6]; // bases of the four lists; [4], [5]: this tile's pairs / records (LMX_KEYS_STAGE_PAIRS)
 	__shared__ uint32_t s_bucket[256]; // bucket_map: an LDS read instead of one more dependent global load per mesh
 	if (threadIdx.x < 255) s_bucket[threadIdx.x] = kv.bucket_map[threadIdx.x];
 	__syncthreads();
@@ -88,21 +96,35 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			KeysInstance in;
 			in.model = -1;
 			const int32_t sl = slots != nullptr ? slots[i] : -1;
-			if (sl >= 0) {
-				rec = d.inst_s + sl;
+			if (sl >= 0 && d.soa.model != nullptr) { // the mirror as a structure of arrays: every field a contiguous load across the wave
 				mmb = d.mm_s;
-			} else if (e < d.n_entities) {
-				rec = d.inst + e;
-			}
-			if (rec != nullptr) {
-				in = *rec; // one 64-byte record
-				lod_at = &rec->lod;
-				frame_at = &rec->pose_frame;
-				if (sl >= 0 && d.state_s != nullptr) {
-					lod_at = &d.state_s[sl].lod;
-					frame_at = &d.state_s[sl].pose_frame;
-					in.lod = *lod_at;
-					in.pose_frame = *frame_at;
+				in.model = d.soa.model[sl];
+				in.material_offset = d.soa.material_offset[sl];
+				const uint32_t fd = d.soa.flags_dirty[sl];
+				in.flags = (uint8_t)fd;
+				in.dirty = (uint8_t)(fd >> 8);
+				in.pos[0] = d.soa.px[sl]; in.pos[1] = d.soa.py[sl]; in.pos[2] = d.soa.pz[sl];
+				lod_at = &d.state_s[sl].lod;
+				frame_at = &d.state_s[sl].pose_frame;
+				in.lod = *lod_at;
+				in.pose_frame = *frame_at;
+			} else {
+				if (sl >= 0) {
+					rec = d.inst_s + sl;
+					mmb = d.mm_s;
+				} else if (e < d.n_entities) {
+					rec = d.inst + e;
+				}
+				if (rec != nullptr) {
+					in = *rec; // one 64-byte record
+					lod_at = &rec->lod;
+					frame_at = &rec->pose_frame;
+					if (sl >= 0 && d.state_s != nullptr) {
+						lod_at = &d.state_s[sl].lod;
+						frame_at = &d.state_s[sl].pose_frame;
+						in.lod = *lod_at;
+						in.pose_frame = *frame_at;
+					}
 				}
 			}
 			const int32_t mdl = in.model;
@@ -185,10 +207,19 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			if (lo | hi) base = atomicAdd(reinterpret_cast<unsigned long long*>(d.counters + (threadIdx.x == 0 ? KEYS_N_PAIRS : KEYS_N_POSES)), (unsigned long long)lo | ((unsigned long long)hi << 32));
 			s_base[2 * threadIdx.x] = (uint32_t)base;
 			s_base[2 * threadIdx.x + 1] = (uint32_t)(base >> 32);
+#if LMX_KEYS_STAGE_PAIRS
+			if (threadIdx.x == 0) { s_base[4] = lo; s_base[5] = hi; }
+#endif
 		}
 		__syncthreads();
 		uint32_t pair_at = s_base[0] + (incl & 0xffffu) - n_pairs, rec_at = s_base[1] + (incl >> 16) - n_recs;
 		uint32_t pose_at = s_base[2] + rank_in(pose_mask), dirty_at = s_base[3] + rank_in(dirty_mask);
+#if LMX_KEYS_STAGE_PAIRS
+		__shared__ uint64_t s_pair_key[KEYS_STAGE_PAIRS], s_pair_value[KEYS_STAGE_PAIRS], s_rec_value[KEYS_STAGE_PAIRS];
+		__shared__ uint32_t s_rec_key[KEYS_STAGE_PAIRS];
+		const uint32_t tile_pair0 = s_base[0], tile_rec0 = s_base[1], tile_pairs = s_base[4], tile_recs = s_base[5];
+		const bool stage = tile_pairs <= (uint32_t)KEYS_STAGE_PAIRS && tile_recs <= (uint32_t)KEYS_STAGE_PAIRS; // block-uniform
+#endif
 		for (uint32_t w = 0; w < wave; ++w) {
 			pair_at += s_wave[w][0] & 0xffffu;
 			rec_at += s_wave[w][0] >> 16;
@@ -228,6 +259,13 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 					key = (uint64_t)float_flip(__float_as_uint(sl)) | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT); // makeDepthSortKey
 					push_pair = true;
 				}
+#if LMX_KEYS_STAGE_PAIRS
+				if (stage) {
+					if (push_pair) { s_pair_key[pair_at - tile_pair0] = key; s_pair_value[pair_at - tile_pair0] = value; ++pair_at; }
+					if (add_inst) { s_rec_key[rec_at - tile_rec0] = mesh_sort_key | (copy << 24); s_rec_value[rec_at - tile_rec0] = value; ++rec_at; }
+				} else
+#endif
+				{
 				if (push_pair) {
 					if (pair_at < d.cap_pairs) { d.keys[pair_at] = key; d.values[pair_at] = value; } else d.counters[KEYS_OVERFLOW] = 1;
 					++pair_at;
@@ -235,6 +273,7 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 				if (add_inst) {
 					if (rec_at < d.cap_recs) { d.rec_key[rec_at] = mesh_sort_key | (copy << 24); d.rec_value[rec_at] = value; } else d.counters[KEYS_OVERFLOW] = 1;
 					++rec_at;
+				}
 				}
 			}
 			const bool in_range = add_inst && mesh_sort_key <= d.max_sort_key;
@@ -248,6 +287,20 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 				wave_histogram(in_range, mesh_sort_key, d.group_count + (size_t)copy * (d.max_sort_key + 1));
 			}
 		}
+#if LMX_KEYS_STAGE_PAIRS
+		if (stage) { // the tile's outputs leave in position order: consecutive lanes, consecutive 8-byte (4-byte) elements
+			__syncthreads();
+			for (uint32_t j = threadIdx.x; j < tile_pairs; j += KEYS_BLOCK) {
+				const uint32_t at = tile_pair0 + j;
+				if (at < d.cap_pairs) { d.keys[at] = s_pair_key[j]; d.values[at] = s_pair_value[j]; } else d.counters[KEYS_OVERFLOW] = 1;
+			}
+			for (uint32_t j = threadIdx.x; j < tile_recs; j += KEYS_BLOCK) {
+				const uint32_t at = tile_rec0 + j;
+				if (at < d.cap_recs) { d.rec_key[at] = s_rec_key[j]; d.rec_value[at] = s_rec_value[j]; } else d.counters[KEYS_OVERFLOW] = 1;
+			}
+			__syncthreads(); // the buffers are refilled by the next tile
+		}
+#endif
 	}
 }
 
@@ -403,7 +456,7 @@ __global__ __launch_bounds__(256) void k_keys_mirror_count(const int32_t* __rest
 
 __global__ __launch_bounds__(256) void k_keys_mirror_fill(const int32_t* __restrict__ slot_ids, uint32_t n_slots, const KeysInstance* __restrict__ inst,
 	uint32_t n_entities, const LmxKeysModel* __restrict__ models, const LmxMeshMaterial* __restrict__ mesh_materials, const uint32_t* __restrict__ offset,
-	KeysInstance* __restrict__ inst_s, LmxMeshMaterial* __restrict__ mm_s, KeysSlotState* __restrict__ state_s) {
+	KeysInstance* __restrict__ inst_s, KeysSoA soa, LmxMeshMaterial* __restrict__ mm_s, KeysSlotState* __restrict__ state_s) {
 	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
 	if (s >= n_slots) return;
 	KeysInstance r;
@@ -418,32 +471,38 @@ __global__ __launch_bounds__(256) void k_keys_mirror_fill(const int32_t* __restr
 			r.material_offset = to;
 		}
 	}
-	inst_s[s] = r;
+	if (soa.model != nullptr) {
+		soa.model[s] = r.model;
+		soa.material_offset[s] = r.material_offset;
+		soa.flags_dirty[s] = (uint16_t)(r.flags | (r.dirty << 8));
+		soa.px[s] = r.pos[0]; soa.py[s] = r.pos[1]; soa.pz[s] = r.pos[2];
+	} else {
+		inst_s[s] = r;
+	}
 	if (state_s != nullptr) state_s[s] = KeysSlotState{r.lod, r.pose_frame};
 }
 
 // lod / Pose::frame of the entities of slots [0, n_slots) (or of the slots the id patches are about to turn into tombstones) back
 // into the entity-indexed records
-__device__ __forceinline__ void mirror_hand_back(uint32_t s, const int32_t* slot_ids, const KeysInstance* inst_s, const KeysSlotState* state_s, KeysInstance* inst,
-	uint32_t n_entities) {
+__device__ __forceinline__ void mirror_hand_back(uint32_t s, const int32_t* slot_ids, const KeysInstance* inst_s, const int32_t* model_s, const KeysSlotState* state_s,
+	KeysInstance* inst, uint32_t n_entities) {
 	const int32_t e = slot_ids[s];
 	if (e < 0 || (uint32_t)e >= n_entities) return;
-	const KeysInstance& r = inst_s[s];
-	if (r.model < 0) return;
-	inst[e].lod = state_s != nullptr ? state_s[s].lod : r.lod;
-	inst[e].pose_frame = state_s != nullptr ? state_s[s].pose_frame : r.pose_frame;
+	if ((model_s != nullptr ? model_s[s] : inst_s[s].model) < 0) return;
+	inst[e].lod = state_s != nullptr ? state_s[s].lod : inst_s[s].lod;
+	inst[e].pose_frame = state_s != nullptr ? state_s[s].pose_frame : inst_s[s].pose_frame;
 }
 __global__ __launch_bounds__(256) void k_keys_mirror_sync(const int32_t* __restrict__ slot_ids, uint32_t n_slots, const KeysInstance* __restrict__ inst_s,
-	const KeysSlotState* __restrict__ state_s, KeysInstance* __restrict__ inst, uint32_t n_entities) {
+	const int32_t* __restrict__ model_s, const KeysSlotState* __restrict__ state_s, KeysInstance* __restrict__ inst, uint32_t n_entities) {
 	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-	if (s < n_slots) mirror_hand_back(s, slot_ids, inst_s, state_s, inst, n_entities);
+	if (s < n_slots) mirror_hand_back(s, slot_ids, inst_s, model_s, state_s, inst, n_entities);
 }
 __global__ __launch_bounds__(256) void k_keys_mirror_carry(const PatchId* __restrict__ patches, uint32_t n, const int32_t* __restrict__ slot_ids, uint32_t n_slots,
-	const KeysInstance* __restrict__ inst_s, const KeysSlotState* __restrict__ state_s, KeysInstance* __restrict__ inst, uint32_t n_entities) {
+	const KeysInstance* __restrict__ inst_s, const int32_t* __restrict__ model_s, const KeysSlotState* __restrict__ state_s, KeysInstance* __restrict__ inst, uint32_t n_entities) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) return;
 	const PatchId p = patches[i];
-	if (p.id < 0 && p.slot < n_slots) mirror_hand_back(p.slot, slot_ids, inst_s, state_s, inst, n_entities);
+	if (p.id < 0 && p.slot < n_slots) mirror_hand_back(p.slot, slot_ids, inst_s, model_s, state_s, inst, n_entities);
 }
 
 } // namespace
@@ -453,21 +512,22 @@ hipError_t launch_keys_mirror_count(hipStream_t s, const int32_t* slot_ids, uint
 	return hipGetLastError();
 }
 hipError_t launch_keys_mirror_fill(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models,
-	const LmxMeshMaterial* mesh_materials, const uint32_t* offset, KeysInstance* inst_s, LmxMeshMaterial* mm_s, KeysSlotState* state_s) {
+	const LmxMeshMaterial* mesh_materials, const uint32_t* offset, KeysInstance* inst_s, const KeysSoA& soa, LmxMeshMaterial* mm_s, KeysSlotState* state_s) {
 	if (!n_slots) return hipSuccess;
-	hipLaunchKernelGGL(k_keys_mirror_fill, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, slot_ids, n_slots, inst, n_entities, models, mesh_materials, offset, inst_s, mm_s, state_s);
+	hipLaunchKernelGGL(k_keys_mirror_fill, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, slot_ids, n_slots, inst, n_entities, models, mesh_materials, offset, inst_s, soa, mm_s,
+		state_s);
 	return hipGetLastError();
 }
-hipError_t launch_keys_mirror_sync(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, const KeysSlotState* state_s, KeysInstance* inst,
-	uint32_t n_entities) {
+hipError_t launch_keys_mirror_sync(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, const int32_t* model_s, const KeysSlotState* state_s,
+	KeysInstance* inst, uint32_t n_entities) {
 	if (!n_slots) return hipSuccess;
-	hipLaunchKernelGGL(k_keys_mirror_sync, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, slot_ids, n_slots, inst_s, state_s, inst, n_entities);
+	hipLaunchKernelGGL(k_keys_mirror_sync, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, slot_ids, n_slots, inst_s, model_s, state_s, inst, n_entities);
 	return hipGetLastError();
 }
-hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint32_t n, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s,
+hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint32_t n, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, const int32_t* model_s,
 	const KeysSlotState* state_s, KeysInstance* inst, uint32_t n_entities) {
 	if (!n) return hipSuccess;
-	hipLaunchKernelGGL(k_keys_mirror_carry, dim3((n + 255u) / 256u), dim3(256), 0, s, patches, n, slot_ids, n_slots, inst_s, state_s, inst, n_entities);
+	hipLaunchKernelGGL(k_keys_mirror_carry, dim3((n + 255u) / 256u), dim3(256), 0, s, patches, n, slot_ids, n_slots, inst_s, model_s, state_s, inst, n_entities);
 	return hipGetLastError();
 }
 

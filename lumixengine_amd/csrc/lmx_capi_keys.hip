@@ -28,7 +28,14 @@ static int keys_build_mirror(LmxContext* ctx) {
 	if (int rc = keys_before_layout_change(ctx)) return rc; // (a mirror of an older layout cannot exist here - the layout change dropped it - but be safe)
 	const uint32_t n_slots = cs.n_padded;
 	if (!n_slots || !ks.d_inst.p) return LMX_OK; // nothing sorted / no tables: the entity-indexed path
-	LMX_HIP(ctx, ks.d_inst_s.reserve(n_slots));
+	if (ks.split_state == 2) { // structure of arrays: 42 bytes per slot instead of the 64-byte records
+		LMX_HIP(ctx, ks.d_soa_pos.reserve((size_t)n_slots * 3));
+		LMX_HIP(ctx, ks.d_soa_model.reserve(n_slots));
+		LMX_HIP(ctx, ks.d_soa_mat.reserve(n_slots));
+		LMX_HIP(ctx, ks.d_soa_flags.reserve(n_slots));
+	} else {
+		LMX_HIP(ctx, ks.d_inst_s.reserve(n_slots));
+	}
 	LMX_HIP(ctx, ks.d_mm_s.reserve(std::max<size_t>(ks.n_mesh_materials, 1)));
 	if (ks.split_state) LMX_HIP(ctx, ks.d_state_s.reserve(n_slots));
 	LMX_HIP(ctx, ks.d_mm_count.reserve((size_t)n_slots + 1));
@@ -38,7 +45,10 @@ static int keys_build_mirror(LmxContext* ctx) {
 	LMX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, temp, ks.d_mm_count.p, ks.d_mm_off.p, (int)(n_slots + 1), ctx->stream));
 	LMX_HIP(ctx, ks.d_scan_temp.reserve(temp));
 	LMX_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(ks.d_scan_temp.p, temp, ks.d_mm_count.p, ks.d_mm_off.p, (int)(n_slots + 1), ctx->stream));
-	LMX_HIP(ctx, launch_keys_mirror_fill(ctx->stream, cs.ids.p, n_slots, ks.d_inst.p, ks.n_entities, ks.d_models.p, ks.d_mesh_materials.p, ks.d_mm_off.p, ks.d_inst_s.p,
+	LMX_HIP(ctx, launch_keys_mirror_fill(ctx->stream, cs.ids.p, n_slots, ks.d_inst.p, ks.n_entities, ks.d_models.p, ks.d_mesh_materials.p, ks.d_mm_off.p,
+		ks.split_state == 2 ? nullptr : ks.d_inst_s.p,
+		ks.split_state == 2 ? KeysSoA{ks.d_soa_pos.p, ks.d_soa_pos.p + n_slots, ks.d_soa_pos.p + 2 * (size_t)n_slots, ks.d_soa_model.p, ks.d_soa_mat.p, ks.d_soa_flags.p}
+		                    : KeysSoA{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
 		ks.d_mm_s.p, ks.split_state ? ks.d_state_s.p : nullptr));
 	ks.mirror_split = ks.split_state;
 	ks.mirror_valid = true;
@@ -53,8 +63,8 @@ int keys_before_layout_change(LmxContext* ctx) {
 	KeysState& ks = ctx->keys;
 	if (!ks.mirror_valid) return LMX_OK;
 	ks.mirror_valid = false;
-	LMX_HIP(ctx, launch_keys_mirror_sync(ctx->stream, ctx->cull.ids.p, std::min(ks.mirror_slots, ctx->cull.n_padded), ks.d_inst_s.p, ks.mirror_split ? ks.d_state_s.p : nullptr, ks.d_inst.p,
-		ks.n_entities));
+	LMX_HIP(ctx, launch_keys_mirror_sync(ctx->stream, ctx->cull.ids.p, std::min(ks.mirror_slots, ctx->cull.n_padded), ks.d_inst_s.p, ks.soa().model,
+		ks.mirror_split ? ks.d_state_s.p : nullptr, ks.d_inst.p, ks.n_entities));
 	return LMX_OK;
 }
 
@@ -62,7 +72,7 @@ int keys_before_layout_change(LmxContext* ctx) {
 int keys_before_tombstones(LmxContext* ctx, const PatchId* d_patches, uint32_t n) {
 	KeysState& ks = ctx->keys;
 	if (!ks.mirror_valid || !n) return LMX_OK;
-	LMX_HIP(ctx, launch_keys_mirror_carry(ctx->stream, d_patches, n, ctx->cull.ids.p, std::min(ks.mirror_slots, ctx->cull.n_padded), ks.d_inst_s.p,
+	LMX_HIP(ctx, launch_keys_mirror_carry(ctx->stream, d_patches, n, ctx->cull.ids.p, std::min(ks.mirror_slots, ctx->cull.n_padded), ks.d_inst_s.p, ks.soa().model,
 		ks.mirror_split ? ks.d_state_s.p : nullptr, ks.d_inst.p, ks.n_entities));
 	return LMX_OK;
 }
@@ -205,9 +215,10 @@ int lmx_keys_set_option(LmxContext* ctx, int option, int value) {
 	LMX_CHECK_CTX(ctx);
 	KeysState& ks = ctx->keys;
 	if (option == LMX_KEYS_OPT_SPLIT_STATE) {
-		if ((value != 0) != ks.split_state) {
+		if (value < 0 || value > 2) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "mirror form %d not in [0,2]", value);
+		if (value != ks.split_state) {
 			if (int rc = keys_before_layout_change(ctx)) return rc; // hand the state back, drop the mirror: the next run builds it in the other form
-			ks.split_state = value != 0;
+			ks.split_state = value;
 		}
 		return LMX_OK;
 	}
@@ -306,6 +317,7 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 		d.inst_s = ks.mirror_valid ? ks.d_inst_s.p : nullptr;
 		d.mm_s = ks.mirror_valid ? ks.d_mm_s.p : nullptr;
 		d.state_s = ks.mirror_valid && ks.mirror_split ? ks.d_state_s.p : nullptr;
+		if (ks.mirror_valid) d.soa = ks.soa();
 	}
 	if (ks.have_decals) { d.decal_sort_key = ks.d_decal_key.p; d.decal_layer = ks.d_decal_layer.p; }
 	if (ks.have_curves) { d.curve_sort_key = ks.d_curve_key.p; d.curve_layer = ks.d_curve_layer.p; }
@@ -430,7 +442,8 @@ int lmx_keys_read_state(LmxContext* ctx, float* lod, uint32_t* pose_frame, uint3
 	if (n_entities != ks.n_entities) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "expected %u entities", ks.n_entities);
 	if (ks.inst_dirty) return fail(ctx, LMX_ERR_NOT_BUILT, "tables changed since the last lmx_keys_run");
 	if (ks.mirror_valid) // entities of the sorted set keep lod / Pose::frame in their slot records
-		LMX_HIP(ctx, launch_keys_mirror_sync(ctx->stream, ctx->cull.ids.p, ks.mirror_slots, ks.d_inst_s.p, ks.mirror_split ? ks.d_state_s.p : nullptr, ks.d_inst.p, ks.n_entities));
+		LMX_HIP(ctx, launch_keys_mirror_sync(ctx->stream, ctx->cull.ids.p, ks.mirror_slots, ks.d_inst_s.p, ks.soa().model, ks.mirror_split ? ks.d_state_s.p : nullptr, ks.d_inst.p,
+			ks.n_entities));
 	const char* base = reinterpret_cast<const char*>(ks.d_inst.p);
 	if (lod && n_entities)
 		LMX_HIP(ctx, hipMemcpy2DAsync(lod, sizeof(float), base + offsetof(KeysInstance, lod), sizeof(KeysInstance), sizeof(float), n_entities, hipMemcpyDeviceToHost, ctx->stream));

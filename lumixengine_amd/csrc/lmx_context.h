@@ -392,8 +392,17 @@ struct KeysState {
 	DevBuf<KeysInstance> d_inst_s;
 	DevBuf<LmxMeshMaterial> d_mm_s;
 	DevBuf<KeysSlotState> d_state_s; // LMX_KEYS_OPT_SPLIT_STATE: lod / Pose::frame of the sorted set's entities, 8 bytes per slot
-	bool split_state = LMX_KEYS_SPLIT_STATE_DEFAULT != 0;
-	bool mirror_split = false;       // the current mirror was built with d_state_s
+	DevBuf<double> d_soa_pos;        // LMX_KEYS_OPT_SPLIT_STATE = 2: px | py | pz, n_slots each
+	DevBuf<int32_t> d_soa_model;
+	DevBuf<uint32_t> d_soa_mat;
+	DevBuf<uint16_t> d_soa_flags;
+	int split_state = LMX_KEYS_SPLIT_STATE_DEFAULT; // 0: AoS mirror, 1: + lod / Pose::frame in d_state_s, 2: structure-of-arrays mirror
+	int mirror_split = 0;            // the form the current mirror was built in
+	KeysSoA soa() const { // the current mirror's arrays (all null unless it was built as a structure of arrays)
+		KeysSoA a{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+		if (mirror_split == 2) a = KeysSoA{d_soa_pos.p, d_soa_pos.p + mirror_slots, d_soa_pos.p + 2 * (size_t)mirror_slots, d_soa_model.p, d_soa_mat.p, d_soa_flags.p};
+		return a;
+	}
 	DevBuf<uint32_t> d_mm_count, d_mm_off;
 	DevBuf<char> d_scan_temp;
 };

@@ -218,6 +218,9 @@ struct alignas(64) KeysInstance {
 };
 static_assert(sizeof(KeysInstance) == 64, "one record per 64-byte sector");
 struct KeysSlotState { float lod; uint32_t pose_frame; };
+// (LMX_KEYS_OPT_SPLIT_STATE = 2, experiment) the slot-ordered mirror as a structure of arrays: the 42 bytes of a record the key kernel reads,
+// one dense array per field, so that a wave's load of a field is one contiguous run instead of 64 pieces at a 64-byte stride
+struct KeysSoA { double *px, *py, *pz; int32_t* model; uint32_t* material_offset; uint16_t* flags_dirty; /* flags | dirty << 8 */ };
 #ifndef LMX_KEYS_SPLIT_STATE_DEFAULT
 #define LMX_KEYS_SPLIT_STATE_DEFAULT 0 // initial value of lmx_keys_set_option(LMX_KEYS_OPT_SPLIT_STATE); not timed on the GPU yet
 #endif
@@ -235,6 +238,7 @@ struct KeysDevice {
 	// set's entities in a dense array of their own, 8 bytes per slot: a 4-byte update of a 64-byte record dirties a whole sector per visible
 	// entity (the traffic model of tests/hostsim and the PMC counters agree on ~230 B of traffic per visible entity against 87 algorithmic)
 	KeysSlotState* state_s; // nullptr: lod / pose_frame live in inst_s
+	KeysSoA soa;            // soa.model != nullptr: the mirror's records are these arrays (inst_s is not allocated), state_s holds lod / pose_frame
 	const LmxKeysModel* models;
 	const uint32_t *decal_sort_key, *curve_sort_key;
 	const uint8_t *decal_layer, *curve_layer;
@@ -263,10 +267,10 @@ struct KeysDevice {
 };
 hipError_t launch_keys_mirror_count(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models, uint32_t* count);
 hipError_t launch_keys_mirror_fill(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models,
-	const LmxMeshMaterial* mesh_materials, const uint32_t* offset, KeysInstance* inst_s, LmxMeshMaterial* mm_s, KeysSlotState* state_s /* optional */);
-hipError_t launch_keys_mirror_sync(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, const KeysSlotState* state_s, KeysInstance* inst,
-	uint32_t n_entities);
-hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint32_t n, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s,
+	const LmxMeshMaterial* mesh_materials, const uint32_t* offset, KeysInstance* inst_s /* or */, const KeysSoA& soa, LmxMeshMaterial* mm_s, KeysSlotState* state_s /* optional */);
+hipError_t launch_keys_mirror_sync(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, const int32_t* model_s, const KeysSlotState* state_s,
+	KeysInstance* inst, uint32_t n_entities);
+hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint32_t n, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, const int32_t* model_s,
 	const KeysSlotState* state_s, KeysInstance* inst, uint32_t n_entities);
 hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const int32_t* mesh_ids, const int32_t* mesh_slots, const uint32_t* mesh_count,
 	uint32_t mesh_cap, const int32_t* decal_ids, const uint32_t* decal_count, uint32_t decal_cap, const int32_t* curve_ids,

@@ -245,13 +245,13 @@ def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("slot_order", [1, 0, 2])
+@pytest.mark.parametrize("slot_order", [1, 0, 2, 3])
 def test_gpu_sort_keys_slot_order_under_updates(gpu_ctx, oracle_port, slot_order):
     """LMX_KEYS_OPT_SLOT_ORDER: the instance tables mirrored in the order of the culling system's sorted set. ModelInstance::lod and
     Pose::frame of an entity of the sorted set then live in its slot record and must follow the entity when the slot dies. Seven frames
     of cull -> createSortKeys with removals, moves out of the cell (to the overflow set), in-cell moves, re-adds and a re-sort in
     between: every frame's pairs / groups / poses / dirty list and the carried state equal the oracle's, with the mirror and without
-    (slot_order 2: the mirror with LMX_KEYS_OPT_SPLIT_STATE - lod / Pose::frame in the dense per-slot array)."""
+    (slot_order 2: the mirror with LMX_KEYS_OPT_SPLIT_STATE - lod / Pose::frame in the dense per-slot array; 3: the mirror as a structure of arrays)."""
     base = scenes.cull_scene(60_000, 2500.0, seed=33, big_fraction=0.002)
     n = len(base["entity"])
     types = make_types(n, 4)
@@ -263,7 +263,7 @@ def test_gpu_sort_keys_slot_order_under_updates(gpu_ctx, oracle_port, slot_order
     sk = api.SortKeys(gpu_ctx)
     try:
         sk.setOption(api.KEYS_OPT_SLOT_ORDER, 1 if slot_order else 0)
-        sk.setOption(api.KEYS_OPT_SPLIT_STATE, 1 if slot_order == 2 else 0)
+        sk.setOption(api.KEYS_OPT_SPLIT_STATE, max(0, slot_order - 1))
         sk.setModels(sc["models"], sc["mesh_types"])
         sk.setInstances(sc["model"], sc["material_offset"], sc["mesh_materials"], sc["lod"], sc["flags"], sc["dirty"], sc["pose_frame"])
         sk.setDecals(n, sc["decal_key"], sc["decal_layer"], sc["curve_key"], sc["curve_layer"])

@@ -8,11 +8,16 @@ cd "$(dirname "$0")/../.." || exit 1
 python tools/build_variant.py base cull_kernels.hip "" > /dev/null
 python tools/build_variant.py hdr_ahead cull_kernels.hip "-DLMX_CULL_HDR_AHEAD=1" > /dev/null
 bash tools/scratch/cull_ab.sh base hdr_ahead base hdr_ahead
-# k_keys_mesh: lod / Pose::frame of the sorted set in a dense per-slot array (LMX_KEYS_OPT_SPLIT_STATE; bit-exact on the simulated device,
-# the traffic model of tools/traffic_model.py says 231 -> 186 B of footprint per visible entity). The option's initial value is a
-# compile-time default of the context: the variant re-compiles lmx_capi_ctx.hip (where LmxContext is constructed) with it switched on.
+# k_keys_mesh (94 us per 1.05 M visible; footprint 231 B per visible entity by the traffic model AND by the PMC counters, 87 algorithmic). Three steps,
+# all bit-exact on the simulated device (tests/test_sort_keys.py: removals / moves / re-sorts in every mode), none timed yet:
+#   keys_split      LMX_KEYS_OPT_SPLIT_STATE = 1: lod / Pose::frame of the sorted set in a dense 8-byte-per-slot array       footprint 186 B, write sector use 0.26
+#   keys_soa        ... = 2: the whole mirror as a structure of arrays (42 B per slot)                                       footprint 164 B, record loads 0.22 -> 0.70
+#   keys_soa_stage  + LMX_KEYS_STAGE_PAIRS: the tile's pairs / records leave through LDS in position order                   write sector use 0.72
+# The option's initial value is a compile-time default of the context: the variants re-compile lmx_capi_ctx.hip (where LmxContext is constructed).
 python tools/build_variant.py keys_split lmx_capi_ctx.hip "-DLMX_KEYS_SPLIT_STATE_DEFAULT=1" > /dev/null
-bash tools/scratch/keys_ab.sh base keys_split base keys_split
+python tools/build_variant.py keys_soa lmx_capi_ctx.hip "-DLMX_KEYS_SPLIT_STATE_DEFAULT=2" > /dev/null
+python tools/build_variant.py keys_soa_stage lmx_capi_ctx.hip,keys_kernels.hip "-DLMX_KEYS_SPLIT_STATE_DEFAULT=2 -DLMX_KEYS_STAGE_PAIRS=1" > /dev/null
+bash tools/scratch/keys_ab.sh base keys_split keys_soa keys_soa_stage base keys_split keys_soa keys_soa_stage
 # k_pose_palette: output through LDS staging rows (LMX_POSE_STAGE_OUT=1: palette rows, 2: + the absolute pose written back). The traffic model
 # counts 0.41 -> 0.86 -> 1.00 sector use for the kernel's writes (73 % of its bytes); LDS per block 29.9 -> 42.4 -> 49.9 KiB (5 -> 3 blocks per
 # CU), so this one can go either way. Kernel time of the skin workload (2000 instances x 64 bones) under rocprofv3.

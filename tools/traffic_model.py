@@ -157,6 +157,9 @@ def main():
     sk2.setOption(api.KEYS_OPT_SPLIT_STATE, 1)
     keys_frame()
     report["keys_split_state"] = measure("the same with LMX_KEYS_OPT_SPLIT_STATE (lod / Pose::frame in a dense per-slot array)", keys_frame, max(visible, 1), "visible entity")
+    sk2.setOption(api.KEYS_OPT_SPLIT_STATE, 2)
+    keys_frame()
+    report["keys_soa_mirror"] = measure("the same with the mirror as a structure of arrays (LMX_KEYS_OPT_SPLIT_STATE = 2)", keys_frame, max(visible, 1), "visible entity")
     sk2.setOption(api.KEYS_OPT_SPLIT_STATE, 0)
     ctx.close()
     if args.out:
