@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--ranks-share-gpu", action="store_true",
                     help="TEST MODE for the N > 1 code path on a one-GPU box: every rank uses cuda:0, torch.distributed runs on gloo, and the exchange's collective must be carried by LMX_RCCL_LIBRARY = tests/_build/libloopback_rccl.so (RCCL refuses two ranks on one device). Checks that the path runs and what it ships; its timings mean nothing")
     ap.add_argument("--big-entities", type=int, default=100_000_000, help="extras: entity count of the config-5-sized single-GPU legs (0 = skip)")
+    ap.add_argument("--no-ab", action="store_true", help="skip extra.ab_variants (tools/ab_variants.py: the not-yet-timed kernel experiments, one child process per leg, after every other measurement)")
+    ap.add_argument("--ab-budget", type=float, default=180.0, help="seconds the A/B children may take together")
     args = ap.parse_args()
 
     import torch
@@ -571,6 +573,17 @@ def main():
             result["extra"] = extras(ctx, api, scenes, torch, timed, N, log, args.big_entities)
         if baseline is not None:
             result["cpu_baseline"] = baseline.measure()
+        if not args.no_extras and not args.no_ab and not args.headline_only and "extra" in result:
+            # LAST: every number above is taken. The experiments run in child processes with contexts of their own and a hard timeout; this
+            # process makes no further HIP call that a misbehaving variant could hold up before the line is printed.
+            try:
+                torch.cuda.synchronize()
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import ab_variants
+
+                result["extra"]["ab_variants"] = ab_variants.run_all(log, budget_s=args.ab_budget)
+            except Exception as e:  # noqa: BLE001 - an extra must not take the line with it
+                result["extra"]["ab_variants"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:
