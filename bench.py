@@ -578,6 +578,9 @@ def main():
             # process makes no further HIP call that a misbehaving variant could hold up before the line is printed.
             try:
                 torch.cuda.synchronize()
+                # the like-for-like N = 1 point of the `--gpus N` curve: the N > 1 step (cull + pack + ncclAllGather on the side stream, two
+                # slots) with a world of ONE rank, in a child process (this one has no process group); `value` above is the step WITHOUT it
+                result["extra"]["exchange_path_one_rank"] = exchange_path_one_rank(args, log)
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import ab_variants
 
@@ -588,6 +591,28 @@ def main():
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def exchange_path_one_rank(args, log, timeout_s=150.0):
+    """`bench.py --force-collective --headline-only` as a child: ms per step / entities per second of the exchange path with one rank."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--force-collective", "--headline-only", "--no-cpu-baseline", "--no-live-traffic", "--no-extras",
+           "--steps", str(max(args.steps, 500)), "--warmup", str(args.warmup), "--entities", str(args.entities), "--variant", args.variant]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT, stdin=subprocess.DEVNULL)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
+        c = json.loads(lines[-1])
+        out = {"ms_per_step": c["ms_per_step"], "value": c["value"], "unit": c["unit"], "steps": c["steps"], "visible_ids": c["config"].get("visible_ids"),
+               "what": "cull + k_cull_pack into the send buffer + ONE ncclAllGather on the side stream per step, two slots in flight, world of one rank (bench.py --force-collective): "
+                       "the step `--gpus N` times for N > 1; host-bound (seven API calls), see DESIGN.md section 5"}
+        log(f"[exchange path, one rank] {out['ms_per_step'] * 1e3:.2f} us per step")
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
 
 
 class c_stdout_to_stderr:
