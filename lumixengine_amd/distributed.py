@@ -7,7 +7,11 @@ runs them over gloo with the oracle standing in for the per-rank cull).
 
 * culling shards by CELL (an entity's visibility depends only on the frustum and its own cell): `shard_by_cell`, the reference's
   CellIndicesHasher so that all entities of a cell land on the same rank;
-* skinned instances and hierarchy roots shard by index with no exchange: `shard_by_index`.
+* skinned instances and hierarchy roots shard by index with no exchange: `shard_by_index`;
+* the transform hierarchy shards by ROOT (a subtree never crosses GPUs, world.cpp:255-282 walks one subtree per write): `shard_by_root`
+  gives a rank its subtrees as a compact world of its own - local entity indices, as every `World` of the engine numbers its own
+  entities - and the table back to the scene's indices; a rank's visible list then carries local ids and the record's position in the
+  gathered buffer says whose table translates them.
 """
 from __future__ import annotations
 
@@ -36,6 +40,33 @@ def shard_by_cell(pos: np.ndarray, world_size: int, rank: int) -> np.ndarray:
 def shard_by_index(n: int, world_size: int, rank: int) -> np.ndarray:
     """Indices [rank::world_size] — skinned instances / hierarchy roots (SURVEY.md §8e)."""
     return np.arange(rank, n, world_size)
+
+
+def root_of(parent: np.ndarray) -> np.ndarray:
+    """Index of the root above every node (itself for a root): pointer jumping, O(n log depth)."""
+    parent = np.asarray(parent, np.int64)
+    up = np.where(parent < 0, np.arange(len(parent), dtype=np.int64), parent)
+    while True:
+        nxt = up[up]
+        if np.array_equal(nxt, up):
+            return up
+        up = nxt
+
+
+def shard_by_root(parent: np.ndarray, world_size: int, rank: int) -> Tuple[np.ndarray, np.ndarray]:
+    """The subtrees this rank owns - roots dealt out by their ordinal among the roots, `shard_by_index` - as a compact hierarchy:
+    (nodes, local_parent). `nodes` = the scene indices of the rank's entities in ascending order (local index i is scene entity
+    nodes[i]); local_parent[i] = local index of the parent, -1 for a root. No node's parent lives on another rank."""
+    parent = np.asarray(parent, np.int64)
+    roots = np.flatnonzero(parent < 0)
+    ordinal = np.full(len(parent), -1, np.int64)
+    ordinal[roots] = np.arange(len(roots))
+    mine = (ordinal[root_of(parent)] % world_size) == rank
+    nodes = np.flatnonzero(mine)
+    local_parent = np.full(len(nodes), -1, np.int32)
+    has_parent = parent[nodes] >= 0
+    local_parent[has_parent] = np.searchsorted(nodes, parent[nodes][has_parent]).astype(np.int32)
+    return nodes.astype(np.int32), local_parent
 
 
 def make_record(ids_by_type: List[np.ndarray], ids_per_rank: int) -> np.ndarray:

@@ -123,3 +123,52 @@ def test_shard_by_cell_keeps_cells_whole():
         assert len(np.unique(owner[key == k])) == 1
     idx = [D.shard_by_index(10, 4, r) for r in range(4)]
     assert sorted(np.concatenate(idx).tolist()) == list(range(10))
+
+
+def test_shard_by_root_keeps_subtrees_whole(oracle_port):
+    """the hierarchy shards by root. Random forest with parents on either side of their children in index order; for world
+    sizes 1..5 every entity lands on exactly one rank, no parent link leaves a rank, the roots are dealt out evenly, and a rank that
+    propagates ITS compact world (the oracle standing in for the kernels) gets, bit for bit, what the unsharded World holds for its entities."""
+    from lumixengine_amd import scenes
+
+    rng = np.random.default_rng(5)
+    n = 4000
+    order = rng.permutation(n)  # a random topological order: node order[i] may only hang under order[< i]
+    parent = np.full(n, -1, np.int32)
+    for i in range(1, n):
+        if rng.random() < 0.85:
+            parent[order[i]] = order[rng.integers(0, i)]
+    roots = np.flatnonzero(parent < 0).astype(np.int32)
+    kids = np.flatnonzero(parent >= 0).astype(np.int32)
+    local = scenes.random_transforms(rng, n, 500.0)
+    whole = oracle_port.world(n)
+    whole.init_transforms(roots, local[roots])
+    whole.set_parents(parent[kids], kids)
+    whole.set_local_transforms(kids, local[kids])
+    new_root = scenes.random_transforms(rng, len(roots), 800.0)
+    whole.set_transforms(roots, new_root)
+    want = whole.get_transforms()
+    by_scene_index = np.zeros(n, new_root.dtype)
+    by_scene_index[roots] = new_root
+    up = D.root_of(parent)
+    assert np.all(parent[up] < 0)
+    for world_size in (1, 2, 3, 5):
+        owned = np.zeros(n, np.int32)
+        for rank in range(world_size):
+            nodes, lparent = D.shard_by_root(parent, world_size, rank)
+            owned[nodes] += 1
+            assert np.all(np.diff(nodes) > 0)
+            has = lparent >= 0
+            assert np.array_equal(nodes[lparent[has]], parent[nodes][has]) and np.all(parent[nodes][~has] < 0)
+            n_roots = int((~has).sum())
+            assert abs(n_roots - len(roots) / world_size) < 1.0 + 1e-9
+            lroots, lkids = np.flatnonzero(~has).astype(np.int32), np.flatnonzero(has).astype(np.int32)
+            w = oracle_port.world(len(nodes))
+            w.init_transforms(lroots, local[nodes][lroots])
+            w.set_parents(lparent[lkids], lkids)
+            w.set_local_transforms(lkids, local[nodes][lkids])
+            w.set_transforms(lroots, by_scene_index[nodes[lroots]])
+            got = w.get_transforms()
+            for k in ("pos", "rot", "scale"):
+                assert np.ascontiguousarray(got[k]).tobytes() == np.ascontiguousarray(want[k][nodes]).tobytes(), (world_size, rank, k)
+        assert np.all(owned == 1)

@@ -946,3 +946,75 @@ def test_world_fuzz(gpu_ctx, oracle_port, seed):
 
     st = fuzz_world.run(seed, 8, oracle_port, ctx=gpu_ctx)
     assert st["entities"] >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world_size", [2, 4])
+@pytest.mark.parametrize("kind", ["chains", "fans"])
+def test_world_sharded_by_root_union_equals_unsharded(oracle_port, world_size, kind):
+    """SURVEY.md 8e, second row: the hierarchy partitioned by ROOT (distributed.shard_by_root: a subtree never crosses GPUs), every rank
+    a compact world + culling set of its own with local entity indices, no exchange for the transforms. Three frames of root moves:
+    each rank's world transforms are bit-identical to the unsharded World's for its entities, and the ranks' visible lists - local ids
+    translated through the rank's table, the way a consumer of the gathered records does - are disjoint and add up to the unsharded
+    visible set (one context per rank on the one device; the all-gather of such records has its own tests)."""
+    from lumixengine_amd import distributed as D
+
+    h = scenes.hierarchy_chains(1500, 4, seed=14, root_extent=1500.0) if kind == "chains" else scenes.hierarchy_fans(40, 5, 3, seed=15, root_extent=1500.0)
+    parent = h["parent"]
+    n = len(parent)
+    rng = np.random.default_rng(71)
+    model_radius = rng.uniform(0.5, 40.0, n).astype(np.float32)
+    ow, roots, kids = oracle_world(oracle_port, h)
+    ocs = oracle_port.culling_system()
+    tr0 = ow.get_transforms()
+    ent = np.arange(n, dtype=np.int32)
+    r0 = model_radius * tr0["scale"].max(axis=1)
+    ocs.add_bulk(ent, np.zeros(n, np.uint8), tr0["pos"], r0)
+    ow.bind_culling(ocs, ent, model_radius)
+    inputs = gpu_inputs(ow, parent, roots)
+    fr = np.concatenate([api.viewport_frustum(pos=(0, 0, 2000.0)), api.viewport_frustum(pos=(300.0, 50.0, -100.0), rot=H.quat_from_yaw_pitch(1.0, 0.1))])
+
+    ranks = []
+    try:
+        owned = np.zeros(n, np.int32)
+        for r in range(world_size):
+            nodes, lparent = D.shard_by_root(parent, world_size, r)
+            owned[nodes] += 1
+            assert np.all((lparent < 0) == (parent[nodes] < 0)) and np.array_equal(nodes[lparent[lparent >= 0]], parent[nodes][lparent >= 0])
+            ctx = api.Context(0)
+            w = api.World(ctx)
+            w.build(lparent, inputs[nodes])
+            cs = api.CullingSystem(ctx)
+            local = np.arange(len(nodes), dtype=np.int32)
+            cs.build(local, np.zeros(len(nodes), np.uint8), tr0["pos"][nodes], r0[nodes])
+            w.bindCulling(local, model_radius[nodes])
+            my_roots = np.flatnonzero(lparent < 0).astype(np.int32)
+            ranks.append(dict(ctx=ctx, w=w, cs=cs, nodes=nodes, my_roots=my_roots))
+        assert np.all(owned == 1), "every entity lives on exactly one rank"
+        assert abs(len(ranks[0]["my_roots"]) - len(roots) / world_size) <= 1
+        for frame in range(3):
+            extent = 1200.0 if frame % 2 else 30.0
+            new_root = ow.get_transforms()[roots]
+            new_root["pos"] += rng.uniform(-extent, extent, size=(len(roots), 3))
+            new_root["scale"] = rng.uniform(0.5, 2.0, size=(len(roots), 3)).astype(np.float32)
+            ow.set_transforms(roots, new_root)
+            want_tr = ow.get_transforms()
+            by_scene_index = np.zeros(n, new_root.dtype)
+            by_scene_index[roots] = new_root
+            seen = [[] for _ in range(len(fr))]
+            for rk in ranks:
+                rk["w"].setTransforms(rk["my_roots"], by_scene_index[rk["nodes"][rk["my_roots"]]])
+                rk["w"].propagate()
+                assert H.transforms_bits_equal(rk["w"].getTransforms(), want_tr[rk["nodes"]]), f"frame {frame}: a rank's world transforms"
+                res = rk["cs"].cull(fr)
+                for f in range(len(fr)):
+                    seen[f].append(rk["nodes"][res.all_ids(f)[0]])
+            for f in range(len(fr)):
+                want_ids, _, _ = ocs.cull(fr[f : f + 1])
+                got = np.concatenate(seen[f])
+                assert len(np.unique(got)) == len(got), "ranks' lists overlap"
+                assert np.array_equal(np.sort(got), np.sort(want_ids)) and len(got) > 0, f"frame {frame} frustum {f}: union of the ranks' lists != unsharded"
+    finally:
+        for rk in ranks:
+            del rk["w"], rk["cs"]
+            rk["ctx"].close()
