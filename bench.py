@@ -91,7 +91,7 @@ def main():
                     help="TEST MODE for the N > 1 code path on a one-GPU box: every rank uses cuda:0, torch.distributed runs on gloo, and the exchange's collective must be carried by LMX_RCCL_LIBRARY = tests/_build/libloopback_rccl.so (RCCL refuses two ranks on one device). Checks that the path runs and what it ships; its timings mean nothing")
     ap.add_argument("--big-entities", type=int, default=100_000_000, help="extras: entity count of the config-5-sized single-GPU legs (0 = skip)")
     ap.add_argument("--no-ab", action="store_true", help="skip extra.ab_variants (tools/ab_variants.py: the not-yet-timed kernel experiments, one child process per leg, after every other measurement)")
-    ap.add_argument("--ab-budget", type=float, default=180.0, help="seconds the A/B children may take together")
+    ap.add_argument("--ab-budget", type=float, default=210.0, help="seconds the A/B children may take together")
     args = ap.parse_args()
 
     import torch

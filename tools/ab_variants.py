@@ -163,6 +163,32 @@ def measure_cull(small: bool) -> dict:
             leg["nothing_visible_kernel_us"] = kernel_us(cs, away, reps, False)
         out[scene_name] = leg
         del cs
+    if os.environ.get("LMX_AB_ROUNDS_PROBE"):
+        # Does the launch's LAST, partly filled round of resident blocks cost the 10 M launch its distance to the 100 M one (0.62 vs 0.72 of
+        # HBM)? 10 M entities are 4883 tiles on 256 CUs x 7 or 8 resident blocks = 2.72 or 2.38 rounds. The same all-test scene (same
+        # density) at sizes that are whole numbers of rounds for either residency, next to sizes that are not: if ns per entity dips at the
+        # whole numbers, splitting the tiles of the last round is worth building; if it is flat, it is not.
+        probe = {}
+        sizes = [200_000, 300_000] if small else [7_340_032, 8_388_608, 9_175_040, 10_000_000, 11_010_048, 12_582_912]
+        for n in sizes:
+            h = 15000.0 * (n / 1e7) ** (1.0 / 3.0)
+            sc_p = scenes.cull_scene(n, h, seed=2)
+            sc_p["radius"] = scenes.all_test_radii(n)
+            cs = api.CullingSystem(ctx)
+            cs.build(sc_p["entity"], sc_p["type"], sc_p["pos"], sc_p["radius"])
+            for _ in range(5 if small else 60):
+                cs.cull(fr)
+            visible = int(cs.cull(fr).counts()[0].sum())
+            row = {"tiles": (n + 2047) // 2048, "rounds_at_8_blocks_per_cu": round((n + 2047) // 2048 / 2048.0, 3), "rounds_at_7_blocks_per_cu": round((n + 2047) // 2048 / 1792.0, 3),
+                   "visible": visible, "warm_kernel_us": kernel_us(cs, fr, reps, False)}
+            row["warm_ns_per_1000_entities"] = round(1e6 * row["warm_kernel_us"] / n, 3)
+            if scrub:
+                row["cold_kernel_us"] = kernel_us(cs, fr, max(5, reps // 2), True)
+                row["cold_ns_per_1000_entities"] = round(1e6 * row["cold_kernel_us"] / n, 3)
+                row["cold_frac_of_8TBps"] = round((20.0 * n + 4.0 * visible) / (row["cold_kernel_us"] * 1e-6) / 8e12, 4)
+            probe[str(n)] = row
+            del cs, sc_p
+        out["rounds_probe"] = probe
     ctx.close()
     return out
 
@@ -260,8 +286,9 @@ def _dig(d, path):
     return d
 
 
-def _child(group: str, lib, timeout_s: float, small: bool) -> dict:
+def _child(group: str, lib, timeout_s: float, small: bool, extra_env=None) -> dict:
     env = dict(os.environ)
+    env.update(extra_env or {})
     if lib:
         env["LMX_LIB_PATH"] = lib
     cmd = [sys.executable, os.path.abspath(__file__), "--measure", group] + (["--small"] if small else [])
@@ -297,7 +324,9 @@ def run_all(log=print, budget_s: float = 150.0, small: bool = False, base_lib=No
             if left < 20.0:
                 rows[name] = {"skipped": "time budget of the A/B spent"}
                 continue
-            rows[name] = _child(group, lib, min(per_child, left), small)
+            # (the base library's first cull child also carries the rounds probe: tile-granularity of the 10 M launch, measure_cull)
+            probe = {"LMX_AB_ROUNDS_PROBE": "1"} if (group == "cull" and name == "base") else None
+            rows[name] = _child(group, lib, min(per_child + (45.0 if probe else 0.0), left), small, probe)
             log(f"[ab_variants] {group} / {name}: {json.dumps(rows[name])[:400]}")
         base = rows.get("base", {})
         for name, row in rows.items():
