@@ -60,8 +60,12 @@ __device__ __forceinline__ uint32_t float_flip(uint32_t bits) {
 // stores. Bit-exact by construction; checked on the simulated device with LMX_HOSTSIM_EXTRA=-DLMX_KEYS_STAGE_PAIRS=1.
 #define LMX_KEYS_STAGE_PAIRS 0
 #endif
-constexpr int KEYS_STAGE_PAIRS = 1536; // pairs (24 KiB) and records (18 KiB) of one 512-entity tile held in LDS
-constexpr int KEYS_BLOCK = 512; // 8 waves: 3 blocks per CU (79 VGPRs: 6 waves per SIMD)
+#ifndef LMX_KEYS_BLOCK
+#define LMX_KEYS_BLOCK 512 // entities per tile = threads per block. 8 waves: 3 blocks per CU (79 VGPRs: 6 waves per SIMD). 256 / 1024 (experiment, tools/ab_variants.py): twice / half the same-address reservations per launch
+#endif
+constexpr int KEYS_BLOCK = LMX_KEYS_BLOCK;
+static_assert(KEYS_BLOCK == 256 || KEYS_BLOCK == 512 || KEYS_BLOCK == 1024, "whole waves, at most one block's worth of threads");
+constexpr int KEYS_STAGE_PAIRS = 3 * KEYS_BLOCK; // pairs (24 KiB) and records (18 KiB) of one 512-entity tile held in LDS
 
 // The visible list is walked in tiles of 512 entities by a fixed-size grid. Per tile every lane first COUNTS what it will
 // emit, the block reserves its four output ranges with two 64-bit atomics on two cache lines (returning atomics on one line retire at

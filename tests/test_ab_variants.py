@@ -43,6 +43,7 @@ def test_ab_table_on_the_simulated_device(monkeypatch):
                 assert row["results_equal_base"] is True, (group, name)
     keys = table["keys"]["base"]
     assert keys["split_state_0"]["pairs"] > 1000
+    assert set(table["keys"]["keys_block_1024"]) >= {"split_state_0", "split_state_2"} and "split_state_1" not in table["keys"]["keys_block_1024"]
     for form in ("split_state_1", "split_state_2", "split_state_0_again"):  # the run-time forms of the mirror: same pairs, same carried state
         assert keys[form]["pairs_sha"] == keys["split_state_0"]["pairs_sha"] and keys[form]["state_sha"] == keys["split_state_0"]["state_sha"], form
     assert table["cull"]["base"]["all_test"]["visible"] > 0 and table["pose"]["base"]["pose_palette_us"] > 0

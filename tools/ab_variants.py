@@ -37,6 +37,8 @@ VARIANTS = {
                        "k_cull_tile phase B resolves header -> cell -> class of all the wave's chunks before the first group's loads"),
     "keys_stage_pairs": ("keys", ["keys_kernels.hip"], ["-DLMX_KEYS_STAGE_PAIRS=1"],
                          "k_keys_mesh: a tile's (key, value) pairs / instancer records leave through LDS in position order"),
+    "keys_block_256": ("keys", ["keys_kernels.hip"], ["-DLMX_KEYS_BLOCK=256"], "k_keys_mesh: tiles of 256 entities (twice the same-address reservations per launch, 4-wave blocks)"),
+    "keys_block_1024": ("keys", ["keys_kernels.hip"], ["-DLMX_KEYS_BLOCK=1024"], "k_keys_mesh: tiles of 1024 entities (half the same-address reservations per launch, 16-wave blocks)"),
     "pose_stage1": ("pose", ["skin_kernels.hip"], ["-DLMX_POSE_STAGE_OUT=1"], "k_pose_palette: palette rows leave through LDS staging rows"),
     "pose_stage2": ("pose", ["skin_kernels.hip"], ["-DLMX_POSE_STAGE_OUT=2"], "k_pose_palette: palette rows and the absolute pose leave through LDS staging rows"),
 }
@@ -206,7 +208,10 @@ def measure_keys(small: bool) -> dict:
     fr = api.viewport_frustum()
     ks = scenes.keys_scene(N, sc["type"], seed=12, max_sort_key=255)
     out = {}
-    for form in (0, 1, 2, 0):  # LMX_KEYS_OPT_SPLIT_STATE: AoS mirror / + dense lod, Pose::frame array / structure of arrays; the base form twice (noise)
+    # LMX_KEYS_OPT_SPLIT_STATE: AoS mirror / + dense lod, Pose::frame array / structure of arrays; the base form twice (noise). Build variants
+    # run forms 0 and 2 only (LMX_AB_KEYS_FORMS, set by run_all)
+    forms = tuple(int(x) for x in os.environ.get("LMX_AB_KEYS_FORMS", "0,1,2,0").split(","))
+    for form in forms:
         sk = api.SortKeys(ctx)
         sk.setOption(api.KEYS_OPT_SPLIT_STATE, form)
         sk.setModels(ks["models"], ks["mesh_types"])
@@ -326,7 +331,9 @@ def run_all(log=print, budget_s: float = 150.0, small: bool = False, base_lib=No
                 continue
             # (the base library's first cull child also carries the rounds probe: tile-granularity of the 10 M launch, measure_cull)
             probe = {"LMX_AB_ROUNDS_PROBE": "1"} if (group == "cull" and name == "base") else None
-            rows[name] = _child(group, lib, min(per_child + (45.0 if probe else 0.0), left), small, probe)
+            if group == "keys" and name != "base":
+                probe = {"LMX_AB_KEYS_FORMS": "0,2"}
+            rows[name] = _child(group, lib, min(per_child + (45.0 if group == "cull" and probe else 0.0), left), small, probe)
             log(f"[ab_variants] {group} / {name}: {json.dumps(rows[name])[:400]}")
         base = rows.get("base", {})
         for name, row in rows.items():
