@@ -181,7 +181,7 @@ def measure_cull(small: bool) -> dict:
             for _ in range(5 if small else 60):
                 cs.cull(fr)
             visible = int(cs.cull(fr).counts()[0].sum())
-            row = {"tiles": (n + 2047) // 2048, "rounds_at_8_blocks_per_cu": round((n + 2047) // 2048 / 2048.0, 3), "rounds_at_7_blocks_per_cu": round((n + 2047) // 2048 / 1792.0, 3),
+            row = {"chunks_of_64": int(cs.stats()["chunks"]), "tiles": (n + 2047) // 2048, "rounds_at_8_blocks_per_cu": round((n + 2047) // 2048 / 2048.0, 3), "rounds_at_7_blocks_per_cu": round((n + 2047) // 2048 / 1792.0, 3),
                    "visible": visible, "warm_kernel_us": kernel_us(cs, fr, reps, False)}
             row["warm_ns_per_1000_entities"] = round(1e6 * row["warm_kernel_us"] / n, 3)
             if scrub:
