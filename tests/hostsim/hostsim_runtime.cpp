@@ -419,18 +419,28 @@ struct Pool {
 	uint32_t busy = 0;
 	bool stop = false;
 
-	void work(const LaunchDesc& L) {
+	// `index`: 0 = the launching thread, k = pool thread k. Blocks are handed out on demand - except under the race detector, where
+	// thread k takes blocks k, k + T, ...: with a shared counter the launching thread can be through a small grid before a pool thread
+	// has woken up, every block then ran on ONE host thread and an unordered exchange between two blocks goes unreported (seen as a
+	// flaky tests/test_hostsim.py::test_race_detector_reports_races_and_only_races on a loaded machine).
+	// ... and the launching thread starts its own blocks only once every pool thread is past the handshake: a pool thread that wakes up
+	// AFTER the launching thread has finished its blocks takes `m` behind the launching thread's cv_done.wait - a happens-before edge from
+	// all of block 0's accesses to all of block 1's that the hardware does not have. (Relaxed counter: no ordering of its own.)
+	bool static_split = false;
+	std::atomic<uint32_t> started{0};
+	void work(const LaunchDesc& L, uint32_t index) {
 		Worker* w = worker();
 		if (w->dyn_lds.size() < L.dyn_lds) w->dyn_lds.resize(L.dyn_lds);
-		for (;;) {
-			const uint64_t b = next.fetch_add(1, std::memory_order_relaxed);
+		const uint64_t stride = (uint64_t)threads.size() + 1;
+		for (uint64_t k = 0;; ++k) {
+			const uint64_t b = static_split ? index + k * stride : next.fetch_add(1, std::memory_order_relaxed);
 			if (b >= n_blocks) break;
 			run_block(w, L, order().block(b, n_blocks));
 			block_done(w, L);
 		}
 		grid_done(w);
 	}
-	void thread_main() {
+	void thread_main(uint32_t index) {
 		uint64_t seen = 0;
 		std::unique_lock<std::mutex> lk(m);
 		for (;;) {
@@ -439,24 +449,33 @@ struct Pool {
 			seen = generation;
 			const LaunchDesc* d = desc;
 			lk.unlock();
-			work(*d);
+			started.fetch_add(1, std::memory_order_relaxed);
+			work(*d, index);
 			lk.lock();
 			if (--busy == 0) cv_done.notify_all();
 		}
 	}
-	void run(const LaunchDesc& L, uint64_t blocks, uint32_t n_threads) {
+	void run(const LaunchDesc& L, uint64_t blocks, uint32_t n_threads, bool split) {
 		std::lock_guard<std::mutex> guard(launch_lock);
-		while (threads.size() + 1 < n_threads) threads.emplace_back([this] { thread_main(); });
+		while (threads.size() + 1 < n_threads) {
+			const uint32_t index = (uint32_t)threads.size() + 1;
+			threads.emplace_back([this, index] { thread_main(index); });
+		}
 		{
 			std::lock_guard<std::mutex> lk(m);
 			desc = &L;
 			n_blocks = blocks;
+			static_split = split;
+			started.store(0, std::memory_order_relaxed);
 			next.store(0);
 			busy = (uint32_t)threads.size();
 			++generation;
 		}
 		cv_work.notify_all();
-		work(L);
+		if (split) {
+			while (started.load(std::memory_order_relaxed) < threads.size()) std::this_thread::yield();
+		}
+		work(L, 0);
 		std::unique_lock<std::mutex> lk(m);
 		cv_done.wait(lk, [&] { return busy == 0; });
 	}
@@ -564,7 +583,7 @@ void run_grid(const char* label, dim3 grid, dim3 block, size_t dyn_lds_bytes, co
 	static const uint32_t n_threads = std::max<uint32_t>((uint32_t)env_size("HOSTSIM_THREADS", 1), race_mode ? 2u : 1u);
 #ifndef HOSTSIM_TRAFFIC
 	if (n_threads > 1 && n_blocks >= (race_mode ? 2u : 4u)) {
-		pool().run(L, n_blocks, n_threads);
+		pool().run(L, n_blocks, n_threads, race_mode);
 		return;
 	}
 #else
