@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--ranks-share-gpu", action="store_true",
                     help="TEST MODE for the N > 1 code path on a one-GPU box: every rank uses cuda:0, torch.distributed runs on gloo, and the exchange's collective must be carried by LMX_RCCL_LIBRARY = tests/_build/libloopback_rccl.so (RCCL refuses two ranks on one device). Checks that the path runs and what it ships; its timings mean nothing")
     ap.add_argument("--big-entities", type=int, default=100_000_000, help="extras: entity count of the config-5-sized single-GPU legs (0 = skip)")
+    ap.add_argument("--config5-frame", action="store_true",
+                    help="N > 1 (or --force-collective): also time BASELINE config 5's frame - the rank's entities under the 8 shadow-cascade frusta in ONE pass (pass width 8) and "
+                         "ONE collective (lmx_exchange_cull_many) -> config.config5_frame. Off by default: this mode has not run on hardware yet (no GPU budget was left when it was written)")
     ap.add_argument("--no-ab", action="store_true", help="skip extra.ab_variants (tools/ab_variants.py: the not-yet-timed kernel experiments, one child process per leg, after every other measurement)")
     ap.add_argument("--ab-budget", type=float, default=210.0, help="seconds the A/B children may take together")
     args = ap.parse_args()
@@ -377,6 +380,63 @@ def main():
             except Exception as e:  # noqa: BLE001 - an extra must not take the headline line with it
                 dist_info["config4_frame"] = {"error": repr(e)}
                 log(f"[rank {rank}] config 4 extra failed: {e!r}")
+        if args.config5_frame and not strong:
+            # BASELINE config 5 across GPUs: every rank's entities (weak: --entities per rank, config 5 has 12.5 M per GPU) under the frame's 8
+            # cascade frusta in one pass over the spheres and ONE all-gather of 8 sub-records (pipeline.cpp:1252-1258 culls them one by one).
+            # Every rank runs the same sequence of collectives whatever happens in between: failures are carried as a flag and agreed on
+            # (all_reduce MIN) before the timed loop, never raised between two collectives.
+            c5 = {"what": "8 ortho cascade frusta (scenes.config5_cascade_kwargs) over the rank's entities, pass width 8, lmx_exchange_cull_many: one ncclAllGather of 8 sub-records per frame"}
+            ok5, xchg5 = 1, None
+            try:
+                fr8 = np.concatenate([api.viewport_frustum(**kw) for kw in scenes.config5_cascade_kwargs()])
+                cs.setPassWidth(8)
+                local8 = cs.cull(fr8, view=2)
+                per_frustum = local8.counts().sum(axis=1)
+                c5["visible_per_frustum_this_rank"] = [int(x) for x in per_frustum]
+                most = int(per_frustum.max())
+            except Exception as e:  # noqa: BLE001
+                ok5, most = 0, 0
+                c5["error"] = repr(e)
+            t5 = torch.tensor([most], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+            cap5 = 8 * ((int(t5.item()) * 5 // 4 + 1023) // 1024 * 1024)
+            uid5 = torch.zeros(128, dtype=torch.uint8, device=red_dev)
+            if rank == 0:
+                uid5.copy_(torch.frombuffer(bytearray(api.exchange_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid5, 0)
+            try:
+                with c_stdout_to_stderr():
+                    xchg5 = api.VisibleExchange(ctx, rank, world, uid5.cpu().numpy().tobytes(), cap5)  # (every rank: a collective)
+                    slot5 = xchg5.cullMany(fr8)
+                    xchg5.wait(slot5)
+                if ok5:
+                    same = True
+                    for f in range(8):
+                        _, got = xchg5.readMany(slot5, rank, f)
+                        same = same and np.array_equal(np.sort(got), np.sort(local8.all_ids(f)[0]))
+                    c5["own_sub_records_equal_local_cull"] = bool(same)
+                    seen5 = [[int(xchg5.readMany(slot5, r, f)[0].sum()) for f in range(8)] for r in range(world)]
+                    c5["visible_per_rank_and_frustum"] = seen5
+                    c5["ids_per_rank_and_frustum"] = cap5 // 8
+            except Exception as e:  # noqa: BLE001
+                ok5 = 0
+                c5["error"] = repr(e)
+            t5ok = torch.tensor([ok5], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(t5ok, op=dist.ReduceOp.MIN)
+            if int(t5ok.item()) == 1:
+                step5 = lambda: xchg5.cullMany(fr8)  # noqa: E731
+                for _ in range(5):
+                    step5()
+                ms5 = timed(step5, 50)
+                c5["ms_per_frame_max_over_ranks"] = ms5
+                c5["entity_frustum_tests_per_sec_all_ranks"] = 8.0 * N * world / (ms5 * 1e-3)
+            elif "error" not in c5:
+                c5["error"] = "another rank failed"
+            if xchg5 is not None:
+                xchg5.close()
+            cs.setPassWidth(1)
+            dist_info["config5_frame"] = c5
+            log(f"[rank {rank}] config 5 frame: {c5}")
         xchg.close()
         log(f"[rank {rank}] exchange closed")
 
