@@ -385,56 +385,26 @@ def main():
             # cascade frusta in one pass over the spheres and ONE all-gather of 8 sub-records (pipeline.cpp:1252-1258 culls them one by one).
             # Every rank runs the same sequence of collectives whatever happens in between: failures are carried as a flag and agreed on
             # (all_reduce MIN) before the timed loop, never raised between two collectives.
-            c5 = {"what": "8 ortho cascade frusta (scenes.config5_cascade_kwargs) over the rank's entities, pass width 8, lmx_exchange_cull_many: one ncclAllGather of 8 sub-records per frame"}
-            ok5, xchg5 = 1, None
-            try:
-                fr8 = np.concatenate([api.viewport_frustum(**kw) for kw in scenes.config5_cascade_kwargs()])
-                cs.setPassWidth(8)
-                local8 = cs.cull(fr8, view=2)
-                per_frustum = local8.counts().sum(axis=1)
-                c5["visible_per_frustum_this_rank"] = [int(x) for x in per_frustum]
-                most = int(per_frustum.max())
-            except Exception as e:  # noqa: BLE001
-                ok5, most = 0, 0
-                c5["error"] = repr(e)
-            t5 = torch.tensor([most], dtype=torch.int64, device=red_dev)
-            dist.all_reduce(t5, op=dist.ReduceOp.MAX)
-            cap5 = 8 * ((int(t5.item()) * 5 // 4 + 1023) // 1024 * 1024)
-            uid5 = torch.zeros(128, dtype=torch.uint8, device=red_dev)
-            if rank == 0:
-                uid5.copy_(torch.frombuffer(bytearray(api.exchange_unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid5, 0)
-            try:
-                with c_stdout_to_stderr():
-                    xchg5 = api.VisibleExchange(ctx, rank, world, uid5.cpu().numpy().tobytes(), cap5)  # (every rank: a collective)
-                    slot5 = xchg5.cullMany(fr8)
-                    xchg5.wait(slot5)
-                if ok5:
-                    same = True
-                    for f in range(8):
-                        _, got = xchg5.readMany(slot5, rank, f)
-                        same = same and np.array_equal(np.sort(got), np.sort(local8.all_ids(f)[0]))
-                    c5["own_sub_records_equal_local_cull"] = bool(same)
-                    seen5 = [[int(xchg5.readMany(slot5, r, f)[0].sum()) for f in range(8)] for r in range(world)]
-                    c5["visible_per_rank_and_frustum"] = seen5
-                    c5["ids_per_rank_and_frustum"] = cap5 // 8
-            except Exception as e:  # noqa: BLE001
-                ok5 = 0
-                c5["error"] = repr(e)
-            t5ok = torch.tensor([ok5], dtype=torch.int64, device=red_dev)
-            dist.all_reduce(t5ok, op=dist.ReduceOp.MIN)
-            if int(t5ok.item()) == 1:
-                step5 = lambda: xchg5.cullMany(fr8)  # noqa: E731
-                for _ in range(5):
-                    step5()
-                ms5 = timed(step5, 50)
-                c5["ms_per_frame_max_over_ranks"] = ms5
-                c5["entity_frustum_tests_per_sec_all_ranks"] = 8.0 * N * world / (ms5 * 1e-3)
-            elif "error" not in c5:
-                c5["error"] = "another rank failed"
-            if xchg5 is not None:
-                xchg5.close()
-            cs.setPassWidth(1)
+            class TorchColl:  # the scalars the ranks agree on travel over torch.distributed (gloo in the --ranks-share-gpu test mode)
+                @staticmethod
+                def _reduce(v, op):
+                    t = torch.tensor([int(v)], dtype=torch.int64, device=red_dev)
+                    dist.all_reduce(t, op=op)
+                    return int(t.item())
+
+                max_int = staticmethod(lambda v: TorchColl._reduce(v, dist.ReduceOp.MAX))
+                min_int = staticmethod(lambda v: TorchColl._reduce(v, dist.ReduceOp.MIN))
+
+                @staticmethod
+                def bcast_bytes(b):
+                    u = torch.zeros(128, dtype=torch.uint8, device=red_dev)
+                    if b is not None:
+                        u.copy_(torch.frombuffer(bytearray(b), dtype=torch.uint8))
+                    dist.broadcast(u, 0)
+                    return u.cpu().numpy().tobytes()
+
+            fr8 = np.concatenate([api.viewport_frustum(**kw) for kw in scenes.config5_cascade_kwargs()])
+            c5 = D.config5_frame(api, fr8, ctx, cs, rank, world, N, TorchColl, timed, quiet=c_stdout_to_stderr)
             dist_info["config5_frame"] = c5
             log(f"[rank {rank}] config 5 frame: {c5}")
         xchg.close()

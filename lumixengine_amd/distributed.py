@@ -124,3 +124,62 @@ def parse_frame_records(records: np.ndarray, n_frusta: int, ids_per_rank: int):
         out.append(parsed)
         overflowed |= over
     return out, overflowed
+
+
+def config5_frame(api, frusta: np.ndarray, ctx, cs, rank: int, world: int, n_entities_per_rank: int, coll, timed, quiet=None, steps: int = 50) -> dict:
+    """BASELINE config 5's frame across GPUs, as bench.py --config5-frame times it: this rank's entities (culling system `cs` of `ctx`)
+    under the frame's `frusta` (the 8 shadow cascades) in ONE pass over the spheres (pass width = len(frusta)) and ONE all-gather of
+    len(frusta) sub-records (lmx_exchange_cull_many); the reference culls them one after the other (pipeline.cpp:1252-1258).
+
+    `coll` carries the few scalars the ranks must agree on - max_int(x), min_int(x), bcast_bytes(bytes on rank 0 / None elsewhere) - over
+    whatever the host has (torch.distributed in bench.py, files in the tests); `timed(fn, steps)` -> ms per call, max over ranks.
+    Every rank runs the SAME sequence of collectives whatever happens in between: a failure is carried as a flag and agreed on before the
+    timed loop, never raised between two collectives (the peer would wait in the next one for ever)."""
+    import contextlib
+
+    n_f = len(frusta)
+    out = {"what": f"{n_f} frusta over the rank's entities, pass width {n_f}, lmx_exchange_cull_many: one ncclAllGather of {n_f} sub-records per frame"}
+    ok, most, local, x = 1, 0, None, None
+    try:
+        cs.setPassWidth(n_f)
+        local = cs.cull(frusta, view=2)  # (views 0 / 1 are the exchange's slots)
+        per_frustum = local.counts().sum(axis=1)
+        out["visible_per_frustum_this_rank"] = [int(v) for v in per_frustum]
+        most = int(per_frustum.max())
+    except Exception as e:  # noqa: BLE001
+        ok = 0
+        out["error"] = repr(e)
+    cap_f = (coll.max_int(most) * 5 // 4 + 1023) // 1024 * 1024  # 1.25 x the largest list of any rank and frustum
+    uid = coll.bcast_bytes(api.exchange_unique_id() if rank == 0 else None)
+    try:
+        with (quiet() if quiet is not None else contextlib.nullcontext()):
+            x = api.VisibleExchange(ctx, rank, world, uid, cap_f * n_f)  # (a collective: every rank gets here)
+            slot = x.cullMany(frusta)
+            x.wait(slot)
+        if ok:
+            same = True
+            for f in range(n_f):
+                _, got = x.readMany(slot, rank, f)
+                same = same and np.array_equal(np.sort(got), np.sort(local.all_ids(f)[0]))
+            out["own_sub_records_equal_local_cull"] = bool(same)
+            out["visible_per_rank_and_frustum"] = [[int(x.readMany(slot, r, f)[0].sum()) for f in range(n_f)] for r in range(world)]
+            out["ids_per_rank_and_frustum"] = int(cap_f)
+    except Exception as e:  # noqa: BLE001
+        ok = 0
+        out["error"] = repr(e)
+    if coll.min_int(ok) == 1:
+        step = lambda: x.cullMany(frusta)  # noqa: E731
+        for _ in range(5):
+            step()
+        ms = timed(step, steps)
+        out["ms_per_frame_max_over_ranks"] = ms
+        out["entity_frustum_tests_per_sec_all_ranks"] = float(n_f) * n_entities_per_rank * world / (ms * 1e-3)
+    elif "error" not in out:
+        out["error"] = "another rank failed"
+    if x is not None:
+        x.close()
+    try:
+        cs.setPassWidth(1)
+    except Exception:  # noqa: BLE001
+        pass
+    return out

@@ -155,3 +155,44 @@ def test_exchange_ranks_on_one_gpu_loopback(tmp_path, oracle_port, world):
             total = sum(len(a) for a in want[0][r])
             assert int(c.sum()) == total and len(ids) == min(total, 64)  # the counts tell what the rank saw; the ids are clipped
             assert set(ids.tolist()) <= set(np.concatenate(want[0][r]).tolist())
+
+
+@pytest.mark.gpu
+def test_config5_frame_two_ranks_loopback(tmp_path, oracle_port):
+    """distributed.config5_frame - what `bench.py --gpus N --config5-frame` runs - with a world of two ranks on the one device: each rank
+    its own 150 k mixed-type entities under the 8 cascade frusta in one pass and ONE collective of 8 sub-records; the ranks agree on the
+    capacity and on success through files (torch.distributed in the bench). Both ranks finish the timed loop, each rank's own sub-records
+    are its local cull, every rank reads the same per-rank / per-frustum counts, and those are the oracle's."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    world = 2
+    lib = _loopback_library()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LMX_RCCL_LIBRARY=lib, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.config5_rank", str(r), str(world), str(tmp_path)], cwd=root, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=300)[0].decode(errors="replace"))
+        except subprocess.TimeoutExpired:
+            p.kill()  # (the exact process this test started)
+            logs.append(p.communicate()[0].decode(errors="replace") + "\n[timed out]")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    got = [json.load(open(tmp_path / f"config5_rank{r}.json")) for r in range(world)]
+    frusta = np.concatenate([api.viewport_frustum(**kw) for kw in scenes.config5_cascade_kwargs()])
+    for r in range(world):
+        assert "error" not in got[r], got[r]
+        assert got[r]["own_sub_records_equal_local_cull"] is True and got[r]["ms_per_frame_max_over_ranks"] > 0
+        assert got[r]["visible_per_rank_and_frustum"] == got[0]["visible_per_rank_and_frustum"]
+        assert got[r]["ms_per_frame_max_over_ranks"] == got[0]["ms_per_frame_max_over_ranks"]  # the MAX over ranks, agreed on
+    for r in range(world):  # the counts every rank read for rank r are the oracle's for r's scene
+        sc = scenes.cull_scene(150_000, 4000.0, seed=21 + r, mixed_types=True)
+        ocs = oracle_port.culling_system()
+        ocs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+        want = [len(ocs.cull(frusta[f : f + 1])[0]) for f in range(len(frusta))]
+        assert got[0]["visible_per_rank_and_frustum"][r] == want and got[r]["visible_per_frustum_this_rank"] == want, (r, want)
+        assert max(want) <= got[0]["ids_per_rank_and_frustum"] and sum(want) > 0
