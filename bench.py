@@ -611,6 +611,11 @@ def main():
                 # the like-for-like N = 1 point of the `--gpus N` curve: the N > 1 step (cull + pack + ncclAllGather on the side stream, two
                 # slots) with a world of ONE rank, in a child process (this one has no process group); `value` above is the step WITHOUT it
                 result["extra"]["exchange_path_one_rank"] = exchange_path_one_rank(args, log)
+                # the same step with the all-gather on the cull stream (LMX_EXCHANGE_INLINE=1: four API calls instead of seven, no overlap of
+                # the next cull with this frame's gather) - an experiment of the step's host cost, same records
+                inl = exchange_path_one_rank(args, log, extra_env={"LMX_EXCHANGE_INLINE": "1"})
+                inl.pop("what", None)
+                result["extra"]["exchange_path_one_rank"]["inline_gather"] = inl
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import ab_variants
 
@@ -623,13 +628,14 @@ def main():
         dist.destroy_process_group()
 
 
-def exchange_path_one_rank(args, log, timeout_s=150.0):
+def exchange_path_one_rank(args, log, timeout_s=150.0, extra_env=None):
     """`bench.py --force-collective --headline-only` as a child: ms per step / entities per second of the exchange path with one rank."""
     import subprocess
 
     cmd = [sys.executable, os.path.abspath(__file__), "--force-collective", "--headline-only", "--no-cpu-baseline", "--no-live-traffic", "--no-extras",
            "--steps", str(max(args.steps, 500)), "--warmup", str(args.warmup), "--entities", str(args.entities), "--variant", args.variant]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300 + (1 if extra_env else 0)), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env.update(extra_env or {})
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT, stdin=subprocess.DEVNULL)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -639,7 +645,7 @@ def exchange_path_one_rank(args, log, timeout_s=150.0):
         out = {"ms_per_step": c["ms_per_step"], "value": c["value"], "unit": c["unit"], "steps": c["steps"], "visible_ids": c["config"].get("visible_ids"),
                "what": "cull + k_cull_pack into the send buffer + ONE ncclAllGather on the side stream per step, two slots in flight, world of one rank (bench.py --force-collective): "
                        "the step `--gpus N` times for N > 1; host-bound (seven API calls), see DESIGN.md section 5"}
-        log(f"[exchange path, one rank] {out['ms_per_step'] * 1e3:.2f} us per step")
+        log(f"[exchange path, one rank{', ' + str(extra_env) if extra_env else ''}] {out['ms_per_step'] * 1e3:.2f} us per step")
         return out
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}

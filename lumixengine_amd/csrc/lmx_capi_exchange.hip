@@ -75,6 +75,11 @@ Rccl& rccl() {
 struct LmxExchange {
 	// LMX_EXCHANGE_TRACE=1: host time of every API call of a step, summed and printed by lmx_exchange_destroy (a measurement aid)
 	bool trace = false;
+	// LMX_EXCHANGE_INLINE=1 (experiment, read at creation): the all-gather is enqueued on the CULL stream, behind the pack kernel - no side
+	// stream, no event pair between the two, no wait for the slot's previous gather (stream order covers it): four API calls instead of
+	// seven per step, at the price of the cull of frame k + 1 not overlapping the gather of frame k. Which side wins depends on how long
+	// the gather takes with the real number of ranks; the results are the same (tests/test_gpu_exchange.py runs both).
+	bool inline_gather = false;
 	double t_host[8] = {};
 	uint64_t t_steps = 0;
 	LmxContext* ctx = nullptr;
@@ -114,6 +119,8 @@ int lmx_exchange_create(LmxContext* ctx, int rank, int world, const void* unique
 	LmxExchange* x = new LmxExchange;
 	x->ctx = ctx;
 	x->trace = getenv("LMX_EXCHANGE_TRACE") != nullptr;
+	const char* inl = getenv("LMX_EXCHANGE_INLINE");
+	x->inline_gather = inl != nullptr && inl[0] != '\0' && inl[0] != '0';
 	x->rank = rank;
 	x->world = world;
 	x->cap = ids_per_rank;
@@ -157,6 +164,7 @@ void lmx_exchange_destroy(LmxExchange* x) {
 			(unsigned long long)x->t_steps, x->t_host[0] / n, x->t_host[1] / n, x->t_host[2] / n, x->t_host[3] / n, x->t_host[4] / n, x->t_host[5] / n, x->t_host[6] / n);
 	}
 	(void)hipStreamSynchronize(x->side);
+	if (x->inline_gather && x->ctx) (void)hipStreamSynchronize(x->ctx->stream); // (the gathers of this mode run there)
 	if (x->comm) (void)rccl().CommDestroy(x->comm);
 	for (int i = 0; i < 2; ++i) {
 		if (x->culled[i]) (void)hipEventDestroy(x->culled[i]);
@@ -190,7 +198,7 @@ int lmx_exchange_cull_many(LmxExchange* x, const LmxShiftedFrustum* frusta, uint
 	};
 	auto t = now();
 	// the send / recv buffers of this slot are free once its previous gather has finished: the cull stream waits for it (device-side)
-	if (x->in_flight[k]) LMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, x->gathered[k], 0));
+	if (x->in_flight[k] && !x->inline_gather) LMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, x->gathered[k], 0));
 	lap(0, t);
 	if (int rc = lmx_cull(ctx, k, frusta, n_frusta, type)) return rc;
 	lap(1, t);
@@ -208,14 +216,19 @@ int lmx_exchange_cull_many(LmxExchange* x, const LmxShiftedFrustum* frusta, uint
 	x->cap_f[k] = cap_f;
 	x->record = n_frusta * sub;
 	lap(2, t);
-	LMX_HIP(ctx, hipEventRecord(x->culled[k], ctx->stream));
-	lap(3, t);
-	LMX_HIP(ctx, hipStreamWaitEvent(x->side, x->culled[k], 0));
-	lap(4, t);
-	const int rc = rccl().AllGather(x->send[k].p, x->recv[k].p, (size_t)n_frusta * sub, NCCL_INT32, x->comm, x->side);
+	hipStream_t gather_stream = x->side;
+	if (x->inline_gather) {
+		gather_stream = ctx->stream; // behind the pack kernel in stream order
+	} else {
+		LMX_HIP(ctx, hipEventRecord(x->culled[k], ctx->stream));
+		lap(3, t);
+		LMX_HIP(ctx, hipStreamWaitEvent(x->side, x->culled[k], 0));
+		lap(4, t);
+	}
+	const int rc = rccl().AllGather(x->send[k].p, x->recv[k].p, (size_t)n_frusta * sub, NCCL_INT32, x->comm, gather_stream);
 	if (rc != 0) return fail(ctx, LMX_ERR_HIP, "ncclAllGather failed: %s", rccl().GetErrorString ? rccl().GetErrorString(rc) : "?");
 	lap(5, t);
-	LMX_HIP(ctx, hipEventRecord(x->gathered[k], x->side));
+	LMX_HIP(ctx, hipEventRecord(x->gathered[k], gather_stream));
 	lap(6, t);
 	x->t_steps += x->trace ? 1 : 0;
 	x->in_flight[k] = true;

@@ -12,7 +12,9 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def test_exchange_single_rank_matches_oracle(gpu_ctx, oracle_port):
+@pytest.mark.parametrize("inline_gather", [0, 1])
+def test_exchange_single_rank_matches_oracle(gpu_ctx, oracle_port, inline_gather, monkeypatch):
+    monkeypatch.setenv("LMX_EXCHANGE_INLINE", str(inline_gather))  # (read when the exchange is created) 1: the gather on the cull stream
     sc = scenes.cull_scene(200_000, 4000.0, seed=13, mixed_types=True)
     cs = api.CullingSystem(gpu_ctx)
     cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
@@ -93,8 +95,8 @@ def _loopback_library():
     return out
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_exchange_ranks_on_one_gpu_loopback(tmp_path, oracle_port, world):
+@pytest.mark.parametrize("world,inline_gather", [(2, 0), (4, 0), (8, 0), (2, 1), (4, 1)])
+def test_exchange_ranks_on_one_gpu_loopback(tmp_path, oracle_port, world, inline_gather):
     """The exchange with a world of 2 / 4 ranks on this box's one GPU: one process per rank, each with its own context and its cell shard of one
     scene, the collective carried by a shared-memory test double of the five RCCL entry points (RCCL itself refuses two ranks on one
     device). Everything around the wire is the product's: the per-rank / per-frustum record layout, the peers' offsets in the receive
@@ -106,7 +108,9 @@ def test_exchange_ranks_on_one_gpu_loopback(tmp_path, oracle_port, world):
 
     lib = _loopback_library()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LMX_RCCL_LIBRARY=lib, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    # inline_gather: LMX_EXCHANGE_INLINE=1, the all-gather on the cull stream instead of the side stream (an experiment of the exchange's
+    # host cost): same records, same pipelining rules
+    env = dict(os.environ, LMX_RCCL_LIBRARY=lib, LMX_EXCHANGE_INLINE=str(inline_gather), PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     procs = [subprocess.Popen([sys.executable, "-m", "tests.exchange_rank", str(r), str(world), str(tmp_path)], cwd=root, env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
