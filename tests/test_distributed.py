@@ -172,3 +172,112 @@ def test_shard_by_root_keeps_subtrees_whole(oracle_port):
             for k in ("pos", "rot", "scale"):
                 assert np.ascontiguousarray(got[k]).tobytes() == np.ascontiguousarray(want[k][nodes]).tobytes(), (world_size, rank, k)
         assert np.all(owned == 1)
+
+
+def test_config5_frame_failure_on_one_rank_is_agreed_on_not_hung():
+    """distributed.config5_frame (bench.py --config5-frame): whatever happens on one rank, every rank runs the same sequence of collectives.
+    Two ranks as threads over stand-ins for the binding; rank 1's cull fails: both return, nobody enters the timed loop, rank 0 reports that
+    another rank failed, rank 1 its own error, and the exchange each one created is closed. With no failure both time the loop."""
+    import threading
+
+    class Coll:
+        def __init__(self, world):
+            self.bar = threading.Barrier(world, timeout=20)
+            self.vals = [None] * world
+            self.ops = [[] for _ in range(world)]
+
+        def _gather(self, rank, v, op):
+            self.ops[rank].append(op)
+            self.vals[rank] = v
+            self.bar.wait()
+            got = list(self.vals)
+            self.bar.wait()
+            return got
+
+    class RankColl:
+        def __init__(self, coll, rank):
+            self.c, self.r = coll, rank
+
+        def max_int(self, v):
+            return max(self.c._gather(self.r, v, "max"))
+
+        def min_int(self, v):
+            return min(self.c._gather(self.r, v, "min"))
+
+        def bcast_bytes(self, b):
+            return self.c._gather(self.r, b, "bcast")[0]
+
+    class FakeResult:
+        def counts(self):
+            return np.array([[3, 0, 0, 0, 0, 0, 0, 0], [5, 0, 0, 0, 0, 0, 0, 0]], np.uint32)
+
+        def all_ids(self, f):
+            return np.arange(3 if f == 0 else 5, dtype=np.int32), None
+
+    class FakeCs:
+        def __init__(self, fail):
+            self.fail, self.widths = fail, []
+
+        def setPassWidth(self, w):
+            self.widths.append(w)
+
+        def cull(self, frusta, view=0):
+            if self.fail:
+                raise RuntimeError("device lost")
+            return FakeResult()
+
+    class FakeExchange:
+        live = []
+
+        def __init__(self, ctx, rank, world, uid, cap):
+            assert uid == b"U" * 128 and cap == 2 * 1024
+            self.closed, self.steps = False, 0
+            FakeExchange.live.append(self)
+
+        def cullMany(self, frusta):
+            self.steps += 1
+            return 0
+
+        def wait(self, slot):
+            pass
+
+        def readMany(self, slot, rank, f):
+            n = 3 if f == 0 else 5
+            return np.array([n, 0, 0, 0, 0, 0, 0, 0], np.uint32), np.arange(n, dtype=np.int32)[::-1].copy()
+
+        def close(self):
+            self.closed = True
+
+    class FakeApi:
+        VisibleExchange = FakeExchange
+
+        @staticmethod
+        def exchange_unique_id():
+            return b"U" * 128
+
+    for failing in (True, False):
+        FakeExchange.live = []
+        coll = Coll(2)
+        out, css = [None, None], [FakeCs(False), FakeCs(failing)]
+
+        def run(rank):
+            out[rank] = D.config5_frame(FakeApi, np.zeros(2), None, css[rank], rank, 2, 1000, RankColl(coll, rank), lambda fn, steps: [fn() for _ in range(steps)] and 0.5, steps=3)
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(30)
+        assert not any(t.is_alive() for t in threads), "a rank hangs"
+        assert coll.ops[0] == coll.ops[1], "the ranks ran different sequences of collectives"
+        assert all(x.closed for x in FakeExchange.live) and len(FakeExchange.live) == 2
+        assert css[0].widths == [2, 1] and css[1].widths == [2, 1]
+        if failing:
+            assert out[0]["error"] == "another rank failed" and "device lost" in out[1]["error"]
+            assert "ms_per_frame_max_over_ranks" not in out[0] and "ms_per_frame_max_over_ranks" not in out[1]
+            assert all(x.steps == 1 for x in FakeExchange.live)
+        else:
+            for r in range(2):
+                assert "error" not in out[r] and out[r]["own_sub_records_equal_local_cull"] is True and out[r]["ms_per_frame_max_over_ranks"] == 0.5
+                assert out[r]["visible_per_rank_and_frustum"] == [[3, 5], [3, 5]] and out[r]["entity_frustum_tests_per_sec_all_ranks"] == 2.0 * 1000 * 2 / 0.5e-3
+            assert all(x.steps == 1 + 5 + 3 for x in FakeExchange.live)
