@@ -94,7 +94,7 @@ def main():
                     help="N > 1 (or --force-collective): also time BASELINE config 5's frame - the rank's entities under the 8 shadow-cascade frusta in ONE pass (pass width 8) and "
                          "ONE collective (lmx_exchange_cull_many) -> config.config5_frame. Off by default: this mode has not run on hardware yet (no GPU budget was left when it was written)")
     ap.add_argument("--no-ab", action="store_true", help="skip extra.ab_variants (tools/ab_variants.py: the not-yet-timed kernel experiments, one child process per leg, after every other measurement)")
-    ap.add_argument("--ab-budget", type=float, default=210.0, help="seconds the A/B children may take together")
+    ap.add_argument("--ab-budget", type=float, default=300.0, help="seconds the A/B children may take together")
     args = ap.parse_args()
 
     import torch

@@ -318,11 +318,15 @@ def run_all(log=print, budget_s: float = 150.0, small: bool = False, base_lib=No
                      "kernel time = the dispatches' own timestamps (lmx_profile_*); tools/ab_variants.py",
              "variants": {n: v[3] for n, v in VARIANTS.items()}}
     per_child = 75.0
-    for group in GROUPS:
+    for gi, group in enumerate(GROUPS):
         legs = [("base", base_lib)] + [(n, (libs or {}).get(n) or variant_lib(n)) for n, v in VARIANTS.items() if v[0] == group] + [("base_again", base_lib)]
         rows = {}
+        # a group may use what is left minus a reserve for the groups still to come (18 s per leg of theirs: enough for their base and
+        # variant legs) - a slow group cannot turn every later row into "skipped", and time a fast group leaves is handed on
+        reserve = 18.0 * sum(2 + sum(1 for v in VARIANTS.values() if v[0] == g) for g in GROUPS[gi + 1:])
+        group_end = t_start + max(budget_s - reserve, 0.0)
         for name, lib in legs:
-            left = budget_s - (time.time() - t_start)
+            left = min(budget_s - (time.time() - t_start), group_end - time.time())
             if lib and not os.path.exists(lib):
                 rows[name] = {"skipped": "library not built (python tools/ab_variants.py --build)"}
                 continue
