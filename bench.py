@@ -600,7 +600,15 @@ def main():
         result["config"]["TEST_MODE"] = "--ranks-share-gpu: all ranks on cuda:0, gloo + shared-memory collective (tests/cpp/loopback_rccl.cpp); timings are meaningless"
     if rank == 0 and world == 1:
         if not args.no_extras:
-            result["extra"] = extras(ctx, api, scenes, torch, timed, N, log, args.big_entities)
+            result["extra"] = {}
+            try:
+                extras(ctx, api, scenes, torch, timed, N, log, args.big_entities, out=result["extra"])
+            except Exception as e:  # noqa: BLE001 - a side measurement must not take the headline (already measured and digest-checked) with it
+                import traceback
+
+                result["extra"]["error"] = f"extras stopped at: {e!r}"
+                result["extra"]["error_traceback_tail"] = traceback.format_exc()[-1500:]
+                log("extras FAILED (the legs before the failure are kept):\n" + traceback.format_exc())
         if baseline is not None:
             result["cpu_baseline"] = baseline.measure()
         if not args.no_extras and not args.no_ab and not args.headline_only and "extra" in result:
@@ -740,9 +748,10 @@ def load_traffic(kernel):
         return None, f"unreadable traffic file: {e}"
 
 
-def extras(ctx, api, scenes, torch, timed, N, log, big_entities=0):
-    """Side measurements (not the headline `value`): dense config-2 variant, 8-frusta pass, config-3 transform + skin."""
-    out = {}
+def extras(ctx, api, scenes, torch, timed, N, log, big_entities=0, out=None):
+    """Side measurements (not the headline `value`): dense config-2 variant, 8-frusta pass, config-3 transform + skin.
+    `out`: the caller's dict, filled leg by leg (what was measured before a failing leg survives it)."""
+    out = {} if out is None else out
     # dense variant of config 2 (cube +-5000: ~37 k cells, ~270 spheres per cell)
     sc = scenes.cull_scene(N, 5000.0, seed=2)
     cs = api.CullingSystem(ctx)
