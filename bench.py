@@ -610,7 +610,10 @@ def main():
                 result["extra"]["error_traceback_tail"] = traceback.format_exc()[-1500:]
                 log("extras FAILED (the legs before the failure are kept):\n" + traceback.format_exc())
         if baseline is not None:
-            result["cpu_baseline"] = baseline.measure()
+            try:
+                result["cpu_baseline"] = baseline.measure()
+            except Exception as e:  # noqa: BLE001 - the GPU numbers above are measured; say what went wrong instead of losing the line
+                result["cpu_baseline"] = {"value": None, "unit": "entities/s", "cores": 0, "kind": "reference", "sample": "not measured", "error": repr(e)}
         if not args.no_extras and not args.no_ab and not args.headline_only and "extra" in result:
             # LAST: every number above is taken. The experiments run in child processes with contexts of their own and a hard timeout; this
             # process makes no further HIP call that a misbehaving variant could hold up before the line is printed.
