@@ -317,6 +317,13 @@ LMX_API int lmx_skin_set_pose_source_device(LmxContext* ctx, const void* d_posit
  * model-space positions from the dual-quaternion palette; a different deformation than linear blending by design. */
 enum { LMX_SKIN_FUSED = 0, LMX_SKIN_EXACT = 1, LMX_SKIN_DQS = 2 };
 LMX_API int lmx_skin_set_mode(LmxContext* ctx, int mode);
+/* How runs of consecutive instances that share a mesh are skinned (evaluateSkin, model.cpp:103-109, is per vertex: the grouping is
+ * ours). LMX_SKIN_OPT_INSTANCES_PER_BLOCK = I in {1, 2, 4, 8, 16}: k_skin_multi - one block stages the palettes of I instances ONCE
+ * (the 16 bank columns of the LDS palette hold I instances x 16 / I copies) and streams the run's vertex records past them; 0:
+ * k_skin_shared - one instance at a time against a register-resident vertex tile (rounds 2 / 3). Same results in every form
+ * (bit-identical positions in LMX_SKIN_EXACT). Takes effect at the next lmx_skin_run. */
+enum { LMX_SKIN_OPT_INSTANCES_PER_BLOCK = 0 };
+LMX_API int lmx_skin_set_option(LmxContext* ctx, int option, int value);
 /* Pose::computeAbsolute -> computeSkinMatrices -> evaluateSkin for every instance; outputs stay in HBM. */
 LMX_API int lmx_skin_run(LmxContext* ctx);
 LMX_API int lmx_skin_read_vertices(LmxContext* ctx, uint32_t instance, float* out_xyz, uint32_t cap_verts);
@@ -397,7 +404,7 @@ LMX_API int lmx_keys_bind_world(LmxContext* ctx, int enable);
    of one random cache line per table and entity). ModelInstance::lod / Pose::frame of those entities then live in the mirror and are
    handed back to the entity-indexed records whenever a slot dies (removal, move to the overflow set, re-sort) and before
    lmx_keys_read_state. 0: entity-indexed tables only. Results do not depend on it.
-   LMX_KEYS_OPT_SPLIT_STATE (default 0; with SLOT_ORDER): ModelInstance::lod and Pose::frame of the sorted set's entities - the two fields
+   LMX_KEYS_OPT_SPLIT_STATE (default 2; with SLOT_ORDER): 1 = ModelInstance::lod and Pose::frame of the sorted set's entities - the two fields
    the key kernel WRITES - live in a dense 8-byte-per-slot array instead of inside the 64-byte mirror records: an update then dirties 8
    bytes of a line its neighbours update too, not one sector per visible entity. 2: the whole mirror is a structure of arrays (one dense array
    per field the key kernel reads, 42 bytes per slot instead of the 64-byte records). Results do not depend on it. */

@@ -26,6 +26,8 @@ TYPE_ALL = 0xFF
 CULL_OPT_TILE_VARIANT, CULL_OPT_LANE_PARALLEL_TILE_TEST, CULL_OPT_MAX_SHARDS, CULL_OPT_COUNTER_PAD, CULL_OPT_AUTO_COMPACTION, CULL_OPT_DEVICE_OWNS_BOUND, CULL_OPT_OVERFLOW_RESERVE, CULL_OPT_ASYNC_COMPACTION, CULL_OPT_COMPACTION_MIN = range(9)
 KEYS_OPT_SLOT_ORDER, KEYS_OPT_SPLIT_STATE = 0, 1
 WORLD_OPT_FUSED_LEVELS = 0
+SKIN_OPT_INSTANCES_PER_BLOCK = 0
+SKIN_INSTANCES_PER_BLOCK_DEFAULT = 0  # what a fresh context uses (lmx_context.h: SkinState::multi)
 (K_CULL_CLASSIFY, K_CULL_SPHERES, K_XFORM_LEVEL, K_SPHERE_REFRESH, K_POSE_PALETTE, K_SKIN_VERTICES, K_CULL_DYNAMIC) = range(7)
 KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices", "cull_dynamic", "sort_keys", "anim_update", "cull_patch"]
 K_CULL_PATCH = 9
@@ -159,6 +161,7 @@ SYMBOLS = {
     "lmx_skin_blend_poses": (_ci, [_vp, _vp, _vp, _sz, _f32]),
     "lmx_skin_blend_poses_device": (_ci, [_vp, _vp, _vp, _sz, _f32]),
     "lmx_skin_set_mode": (_ci, [_vp, _ci]),
+    "lmx_skin_set_option": (_ci, [_vp, _ci, _ci]),
     "lmx_skin_run": (_ci, [_vp]),
     "lmx_skin_read_vertices": (_ci, [_vp, _u32, _vp, _u32]),
     "lmx_skin_read_vertices_range": (_ci, [_vp, _u32, _u32, _vp, C.c_size_t]),
@@ -853,6 +856,10 @@ class Skinning:
         """True / 1: FMA-free linear blend, bit-identical to the reference; False / 0 (default): fused multiply-adds, within 1e-5;
         2 (SKIN_DQS): the dual-quaternion blend of the reference's vertex shader."""
         self.ctx.check(self.lib.lmx_skin_set_mode(self.ctx.h, int(exact)))
+
+    def setOption(self, option: int, value: int):
+        """SKIN_OPT_INSTANCES_PER_BLOCK: 0 = k_skin_shared, 1 / 2 / 4 / 8 / 16 = k_skin_multi with that many instances per block."""
+        self.ctx.check(self.lib.lmx_skin_set_option(self.ctx.h, int(option), int(value)))
 
     def run(self):
         self.ctx.check(self.lib.lmx_skin_run(self.ctx.h))

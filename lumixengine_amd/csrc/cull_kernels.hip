@@ -166,9 +166,6 @@ __device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, 
 #ifndef LMX_PACK_EARLY_EXIT
 #define LMX_PACK_EARLY_EXIT 1 // k_cull_pack: blocks without a slice of their shard's window leave at once, the others fetch their first ids under the prefix of the counters
 #endif
-#ifndef LMX_CULL_HDR_AHEAD
-#define LMX_CULL_HDR_AHEAD 0  // 1 (experiment, not measured yet): phase B resolves the chunk headers -> cells -> classes of ALL the wave's chunks before the first group's loads go out, instead of group by group (the second group's header / class chain then no longer waits behind the first group's test); bit-exact on the simulated device (tests/hostsim, LMX_HOSTSIM_EXTRA=-DLMX_CULL_HDR_AHEAD=1). The default build's ISA is unchanged by the knob's existence
-#endif
 #ifndef LMX_CULL_MIN3
 #define LMX_CULL_MIN3 0       // 1: `any t < 0` as min(t...) < 0 (fminf ignores NaN like the comparisons do, -0.0 < 0 is false either way): no measurable change
 #endif
@@ -410,51 +407,12 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 	__shared__ int32_t s_stage_ids[STAGE ? WAVES : 1][STAGE ? CHW * 64 : 1];
 	__shared__ int32_t s_stage_slots[STAGE && SLOTS ? WAVES : 1][STAGE && SLOTS ? CHW * 64 : 1];
 	uint32_t staged = 0; // wave-uniform
-#if LMX_CULL_HDR_AHEAD
-	// (experiment) every chunk's header -> cell -> class chain first: the same statements as in the group loop below
-	uint32_t local_all[CHW];
-	uint32_t need_id_bits = 0, need_sphere_bits = 0; // wave-uniform, bit per chunk
-#pragma unroll
-	for (int c = 0; c < CHW; ++c) {
-			bool lane_live = false, lane_test = false;
-			local_all[c] = 0;
-			if (any_mixed) {
-				const ChunkHdr h = g_hdr[chunk0 + c]; // wave-uniform: one 16-byte scalar load
-				local_all[c] = h.cell + mbcnt64(h.flags >> 1) - first_cell; // cell boundaries at positions 1..lane: two v_mbcnt on a wave-uniform mask
-#pragma unroll 1
-				for (int f = 0; f < nf; ++f) {
-					if constexpr (F != 1) { // frusta the tile-level test settled carry no per-cell records
-						const uint32_t st = (st_bits >> (2 * f)) & 3u;
-						if (st == TILE_REJECT) continue;
-						if (st == TILE_ACCEPT) {
-							lane_live = true;
-							continue;
-						}
-					}
-					const uint32_t cls = s_info[f * a.cell_cap + local_all[c]].cls;
-					lane_live |= cls != CELL_REJECT;
-					lane_test |= cls == CELL_TEST;
-				}
-			} else {
-				lane_live = true; // no frustum is MIXED and at least one is ACCEPT
-			}
-			need_id_bits |= (__ballot(lane_live) != 0 ? 1u : 0u) << c;     // wave-uniform
-			need_sphere_bits |= (__ballot(lane_test) != 0 ? 1u : 0u) << c; // wave-uniform
-	}
-#endif
 #pragma unroll
 	for (int g = 0; g < CHW; g += GRP) {
 		__builtin_amdgcn_sched_barrier(0); // keep the groups' loads from being hoisted over each other (register peak)
 		uint32_t local[GRP];
 		bool need_id[GRP], need_sphere[GRP];
 #pragma unroll
-#if LMX_CULL_HDR_AHEAD
-		for (int i = 0; i < GRP; ++i) {
-			local[i] = local_all[g + i];
-			need_id[i] = ((need_id_bits >> (g + i)) & 1u) != 0;
-			need_sphere[i] = ((need_sphere_bits >> (g + i)) & 1u) != 0;
-		}
-#else
 		for (int i = 0; i < GRP; ++i) {
 			bool lane_live = false, lane_test = false;
 			local[i] = 0;
@@ -481,7 +439,6 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			need_id[i] = __ballot(lane_live) != 0;     // wave-uniform
 			need_sphere[i] = __ballot(lane_test) != 0; // wave-uniform
 		}
-#endif
 		float4 sp[GRP];
 #pragma unroll
 		for (int i = 0; i < GRP; ++i) {

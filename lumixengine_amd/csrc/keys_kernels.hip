@@ -53,18 +53,7 @@ __device__ __forceinline__ uint32_t float_flip(uint32_t bits) {
 	return bits ^ mask;
 }
 
-#ifndef LMX_KEYS_STAGE_PAIRS
-// (experiment, not timed yet) a tile's (key, value) pairs and instancer records are collected in LDS at their positions inside the tile's
-// output ranges and leave as contiguous stores, instead of 8-byte stores at every lane's own run of positions (sector use 0.26 by the
-// traffic model, 30 of the kernel's 122 requested bytes per visible entity). Tiles with more output than the buffers hold keep the direct
-// stores. Bit-exact by construction; checked on the simulated device with LMX_HOSTSIM_EXTRA=-DLMX_KEYS_STAGE_PAIRS=1.
-#define LMX_KEYS_STAGE_PAIRS 0
-#endif
-#ifndef LMX_KEYS_BLOCK
-#define LMX_KEYS_BLOCK 512 // entities per tile = threads per block. 8 waves: 3 blocks per CU (79 VGPRs: 6 waves per SIMD). 256 / 1024 (experiment, tools/ab_variants.py): twice / half the same-address reservations per launch
-#endif
-constexpr int KEYS_BLOCK = LMX_KEYS_BLOCK;
-static_assert(KEYS_BLOCK == 256 || KEYS_BLOCK == 512 || KEYS_BLOCK == 1024, "whole waves, at most one block's worth of threads");
+constexpr int KEYS_BLOCK = 512; // entities per tile = threads per block. 8 waves: 3 blocks per CU (79 VGPRs: 6 waves per SIMD). Tiles of 256 / 1024 entities measured slower (161.8 / 145.0 against 138.1 us for the whole chain, round 3's driver box)
 constexpr int KEYS_STAGE_PAIRS = 3 * KEYS_BLOCK; // pairs (24 KiB) and records (18 KiB) of one 512-entity tile held in LDS
 
 // The visible list is walked in tiles of 512 entities by a fixed-size grid. Per tile every lane first COUNTS what it will
@@ -211,19 +200,15 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			if (lo | hi) base = atomicAdd(reinterpret_cast<unsigned long long*>(d.counters + (threadIdx.x == 0 ? KEYS_N_PAIRS : KEYS_N_POSES)), (unsigned long long)lo | ((unsigned long long)hi << 32));
 			s_base[2 * threadIdx.x] = (uint32_t)base;
 			s_base[2 * threadIdx.x + 1] = (uint32_t)(base >> 32);
-#if LMX_KEYS_STAGE_PAIRS
 			if (threadIdx.x == 0) { s_base[4] = lo; s_base[5] = hi; }
-#endif
 		}
 		__syncthreads();
 		uint32_t pair_at = s_base[0] + (incl & 0xffffu) - n_pairs, rec_at = s_base[1] + (incl >> 16) - n_recs;
 		uint32_t pose_at = s_base[2] + rank_in(pose_mask), dirty_at = s_base[3] + rank_in(dirty_mask);
-#if LMX_KEYS_STAGE_PAIRS
 		__shared__ uint64_t s_pair_key[KEYS_STAGE_PAIRS], s_pair_value[KEYS_STAGE_PAIRS], s_rec_value[KEYS_STAGE_PAIRS];
 		__shared__ uint32_t s_rec_key[KEYS_STAGE_PAIRS];
 		const uint32_t tile_pair0 = s_base[0], tile_rec0 = s_base[1], tile_pairs = s_base[4], tile_recs = s_base[5];
 		const bool stage = tile_pairs <= (uint32_t)KEYS_STAGE_PAIRS && tile_recs <= (uint32_t)KEYS_STAGE_PAIRS; // block-uniform
-#endif
 		for (uint32_t w = 0; w < wave; ++w) {
 			pair_at += s_wave[w][0] & 0xffffu;
 			rec_at += s_wave[w][0] >> 16;
@@ -263,12 +248,10 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 					key = (uint64_t)float_flip(__float_as_uint(sl)) | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT); // makeDepthSortKey
 					push_pair = true;
 				}
-#if LMX_KEYS_STAGE_PAIRS
 				if (stage) {
 					if (push_pair) { s_pair_key[pair_at - tile_pair0] = key; s_pair_value[pair_at - tile_pair0] = value; ++pair_at; }
 					if (add_inst) { s_rec_key[rec_at - tile_rec0] = mesh_sort_key | (copy << 24); s_rec_value[rec_at - tile_rec0] = value; ++rec_at; }
 				} else
-#endif
 				{
 				if (push_pair) {
 					if (pair_at < d.cap_pairs) { d.keys[pair_at] = key; d.values[pair_at] = value; } else d.counters[KEYS_OVERFLOW] = 1;
@@ -291,7 +274,6 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 				wave_histogram(in_range, mesh_sort_key, d.group_count + (size_t)copy * (d.max_sort_key + 1));
 			}
 		}
-#if LMX_KEYS_STAGE_PAIRS
 		if (stage) { // the tile's outputs leave in position order: consecutive lanes, consecutive 8-byte (4-byte) elements
 			__syncthreads();
 			for (uint32_t j = threadIdx.x; j < tile_pairs; j += KEYS_BLOCK) {
@@ -304,7 +286,6 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			}
 			__syncthreads(); // the buffers are refilled by the next tile
 		}
-#endif
 	}
 }
 

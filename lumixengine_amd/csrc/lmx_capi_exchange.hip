@@ -75,11 +75,13 @@ Rccl& rccl() {
 struct LmxExchange {
 	// LMX_EXCHANGE_TRACE=1: host time of every API call of a step, summed and printed by lmx_exchange_destroy (a measurement aid)
 	bool trace = false;
-	// LMX_EXCHANGE_INLINE=1 (experiment, read at creation): the all-gather is enqueued on the CULL stream, behind the pack kernel - no side
-	// stream, no event pair between the two, no wait for the slot's previous gather (stream order covers it): four API calls instead of
-	// seven per step, at the price of the cull of frame k + 1 not overlapping the gather of frame k. Which side wins depends on how long
-	// the gather takes with the real number of ranks; the results are the same (tests/test_gpu_exchange.py runs both).
-	bool inline_gather = false;
+	// Default (round 4): the all-gather is enqueued on the CULL stream, behind the pack kernel - no side stream, no event pair between
+	// the two, no wait for the slot's previous gather (stream order covers it): four API calls instead of seven per step (20.5 against
+	// 36.6 us per step with one rank on the round-3 driver box), at the price of the cull of frame k + 1 not overlapping the gather of
+	// frame k. LMX_EXCHANGE_INLINE=0 (read at creation) selects the side-stream, double-buffered form again: which side wins with 8
+	// ranks depends on how long the gather takes over xGMI, and no multi-GPU number exists yet. Same results either way
+	// (tests/test_gpu_exchange.py runs both).
+	bool inline_gather = true;
 	double t_host[8] = {};
 	uint64_t t_steps = 0;
 	LmxContext* ctx = nullptr;
@@ -120,7 +122,7 @@ int lmx_exchange_create(LmxContext* ctx, int rank, int world, const void* unique
 	x->ctx = ctx;
 	x->trace = getenv("LMX_EXCHANGE_TRACE") != nullptr;
 	const char* inl = getenv("LMX_EXCHANGE_INLINE");
-	x->inline_gather = inl != nullptr && inl[0] != '\0' && inl[0] != '0';
+	x->inline_gather = !(inl != nullptr && inl[0] == '0');
 	x->rank = rank;
 	x->world = world;
 	x->cap = ids_per_rank;

@@ -195,6 +195,8 @@ int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* model, c
 	{
 		struct Run { uint32_t first, count, tiles, mesh; };
 		std::vector<Run> runs;
+		sk.runs.clear();
+		sk.multi_built = 0;
 		uint64_t run_tiles = 0;
 		for (uint32_t i = 0; i < n;) {
 			uint32_t c = 1;
@@ -202,6 +204,7 @@ int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* model, c
 			if (c >= 2 && inst[i].n_verts >= 2048) {
 				const uint32_t tiles = sk.meshes[mesh[i]].n_tiles;
 				runs.push_back(Run{i, c, tiles, mesh[i]});
+				sk.runs.push_back(SkinState::Run{i, c, mesh[i]});
 				run_tiles += (uint64_t)c * tiles;
 			} else {
 				for (uint32_t k = 0; k < c; ++k) {
@@ -332,6 +335,41 @@ int lmx_skin_set_mode(LmxContext* ctx, int mode) {
 	return LMX_OK;
 }
 
+int lmx_skin_set_option(LmxContext* ctx, int option, int value) {
+	LMX_CHECK_CTX(ctx);
+	if (option != LMX_SKIN_OPT_INSTANCES_PER_BLOCK) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "unknown skin option %d", option);
+	if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "instances per block %d not in {0, 1, 2, 4, 8, 16}", value);
+	ctx->skin.multi = (uint32_t)value;
+	return LMX_OK;
+}
+
+// k_skin_multi's work items: every run in groups of I instances, each group's vertices in as many ranges as give the chip ~3000 blocks
+static int skin_build_multi_chunks(LmxContext* ctx) {
+	SkinState& sk = ctx->skin;
+	if (sk.multi_built == sk.multi) return LMX_OK;
+	sk.multi_chunks.clear();
+	uint64_t groups = 0;
+	for (const SkinState::Run& r : sk.runs) {
+		const uint32_t per = skin_multi_instances(sk.multi, sk.inst[r.first].n_bones);
+		groups += (r.count + per - 1) / per;
+	}
+	for (const SkinState::Run& r : sk.runs) {
+		const SkinInstance& in = sk.inst[r.first];
+		const uint32_t per = skin_multi_instances(sk.multi, in.n_bones);
+		uint32_t splits = (uint32_t)std::max<uint64_t>(1, (3072 + groups - 1) / std::max<uint64_t>(groups, 1));
+		splits = std::min(splits, std::max(1u, in.n_verts / 1024u)); // a range is worth its 48 KiB palette staging from ~1000 vertices x I instances on
+		const uint32_t range = ((in.n_verts + splits - 1) / splits + 63u) & ~63u;
+		for (uint32_t f = 0; f < r.count; f += per)
+			for (uint32_t v = 0; v < in.n_verts; v += range)
+				sk.multi_chunks.push_back(SkinChunk{r.first + f, std::min(per, r.count - f), v, std::min(in.n_verts, v + range), in.vert_offset, 0u, 0u, 0u});
+	}
+	LMX_HIP(ctx, sk.d_multi_chunks.reserve(std::max<size_t>(sk.multi_chunks.size(), 1)));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (a launch of the previous frame may still read the old list)
+	if (!sk.multi_chunks.empty()) LMX_HIP(ctx, hipMemcpy(sk.d_multi_chunks.p, sk.multi_chunks.data(), sk.multi_chunks.size() * sizeof(SkinChunk), hipMemcpyHostToDevice));
+	sk.multi_built = sk.multi;
+	return LMX_OK;
+}
+
 int lmx_skin_run(LmxContext* ctx) {
 	LMX_CHECK_CTX(ctx);
 	SkinState& sk = ctx->skin;
@@ -351,7 +389,11 @@ int lmx_skin_run(LmxContext* ctx) {
 	{
 		ProfScope ps(ctx, LMX_K_SKIN_VERTICES);
 		const float4* vertex_palette = sk.mode == LMX_SKIN_DQS ? sk.d_dual_quats.p : sk.d_palette.p;
-		if (sk.chunks.empty() || sk.mode == LMX_SKIN_DQS) { // (DQS: k_skin_shared's resident records leave too few registers for the dual-quaternion blend)
+		if (!sk.chunks.empty() && sk.multi) { // runs of instances that share a mesh, several instances per block (every mode)
+			if (int rc = skin_build_multi_chunks(ctx)) return rc;
+			LMX_HIP(ctx, launch_skin_multi(ctx->stream, sk.multi, sk.d_inst.p, sk.d_multi_chunks.p, (uint32_t)sk.multi_chunks.size(), sk.d_mesh.p, vertex_palette, sk.d_out.p, sk.mode));
+			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, sk.d_solo.p, (uint32_t)sk.solo.size(), sk.solo_max_verts, sk.d_mesh.p, vertex_palette, sk.d_out.p, sk.mode));
+		} else if (sk.chunks.empty() || sk.mode == LMX_SKIN_DQS) { // (DQS: k_skin_shared's resident records leave too few registers for the dual-quaternion blend)
 			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, nullptr, n, sk.max_verts, sk.d_mesh.p, vertex_palette,
 				sk.d_out.p, sk.mode));
 		} else {

@@ -322,6 +322,12 @@ struct SkinState {
 	std::vector<PoseGroup> groups;     // sorted by capacity class (16, 8, 4 instances per group)
 	uint32_t n_groups[3] = {0, 0, 0};
 	std::vector<SkinChunk> chunks;     // k_skin_shared work items (runs of instances sharing a mesh)
+	struct Run { uint32_t first, count, mesh; };
+	std::vector<Run> runs;             // the runs themselves (lmx_skin_set_instances): k_skin_multi's work items are cut from them at run time
+	std::vector<SkinChunk> multi_chunks;
+	DevBuf<SkinChunk> d_multi_chunks;
+	uint32_t multi = 0;                // LMX_SKIN_OPT_INSTANCES_PER_BLOCK (0: k_skin_shared)
+	uint32_t multi_built = 0;          // the value multi_chunks were cut for (0: stale)
 	std::vector<uint32_t> solo;        // instances skinned by k_skin_vertices (empty + no chunks = all of them)
 	DevBuf<SkinChunk> d_chunks;
 	DevBuf<uint32_t> d_solo;

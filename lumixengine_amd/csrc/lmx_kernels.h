@@ -218,11 +218,11 @@ struct alignas(64) KeysInstance {
 };
 static_assert(sizeof(KeysInstance) == 64, "one record per 64-byte sector");
 struct KeysSlotState { float lod; uint32_t pose_frame; };
-// (LMX_KEYS_OPT_SPLIT_STATE = 2, experiment) the slot-ordered mirror as a structure of arrays: the 42 bytes of a record the key kernel reads,
+// (LMX_KEYS_OPT_SPLIT_STATE = 2, the default since round 4: createSortKeys 138 -> 129 us on the round-3 driver box) the slot-ordered mirror as a structure of arrays: the 42 bytes of a record the key kernel reads,
 // one dense array per field, so that a wave's load of a field is one contiguous run instead of 64 pieces at a 64-byte stride
 struct KeysSoA { double *px, *py, *pz; int32_t* model; uint32_t* material_offset; uint16_t* flags_dirty; /* flags | dirty << 8 */ };
 #ifndef LMX_KEYS_SPLIT_STATE_DEFAULT
-#define LMX_KEYS_SPLIT_STATE_DEFAULT 0 // initial value of lmx_keys_set_option(LMX_KEYS_OPT_SPLIT_STATE); not timed on the GPU yet
+#define LMX_KEYS_SPLIT_STATE_DEFAULT 2 // initial value of lmx_keys_set_option(LMX_KEYS_OPT_SPLIT_STATE)
 #endif
 struct KeysDevice {
 	// model instances by entity index: ONE 64-byte record per entity (the visible ids are in cell order, entity indices are not:
@@ -291,6 +291,11 @@ hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, const u
 // the same for runs of consecutive instances that share a mesh and a bone count (vertex records held in registers)
 hipError_t launch_skin_shared(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh_local,
 	const uint8_t* tile_bones, const float4* palette, float* out, int mode);
+// k_skin_multi: `per_block` instances per block (1, 2, 4, 8, 16; capped by skin_multi_instances for models above 64 bones); chunks =
+// (first_inst, count, [v_begin, v_end), rec_offset = the mesh's first record in `mesh` (global bone indices))
+uint32_t skin_multi_instances(uint32_t per_block, uint32_t n_bones);
+hipError_t launch_skin_multi(hipStream_t s, uint32_t per_block, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh,
+	const float4* palette, float* out, int mode);
 constexpr uint32_t SKIN_SHARED_TILE_VERTS = 5120; // k_skin_shared: 1024 lanes x 5 vertex records
 
 } // namespace lmx

@@ -48,14 +48,6 @@ __device__ __forceinline__ void wave_lds_sync() {
 // of (pose * inverse_bind).toMatrix() is the constant (0, 0, 0, 1) (math.cpp:887-890) and is re-attached on read-back.
 constexpr int POSE_LDS_BONES = 1024; // K * n_bones <= 1024: 16 x 64, 8 x 128, 4 x 196
 constexpr int POSE_WAVES = 4;
-#ifndef LMX_POSE_STAGE_OUT
-// (experiment, not timed yet) the output phase writes (instance, bone) pairs with the instance fastest across the lanes: a store instruction
-// puts 16 bytes at a 48-byte stride per lane and the traffic model (tools/traffic_model.py) counts 41 % sector use for the kernel's writes,
-// which are 73 % of its bytes. 1: the palette rows of a step go through an LDS staging buffer and leave as contiguous 16-byte pieces per
-// instance (12.3 KiB more LDS per block); 2: the absolute pose written back (28 B per bone, the worst of the stores) as well (+7.4 KiB).
-// Bit-exact by construction (the same values, another route); checked on the simulated device with LMX_HOSTSIM_EXTRA=-DLMX_POSE_STAGE_OUT=n.
-#define LMX_POSE_STAGE_OUT 0
-#endif
 
 // LDS slot of (bone, instance of the group): bone-major, plain. Every phase maps neighbouring lanes to neighbouring INSTANCES of one
 // bone (lane -> instance lane % K, bone lane / K), so a wave touches 64 consecutive slots: conflict-free for the 16-byte rotations
@@ -133,81 +125,6 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_pose_palette(const SkinInst
 		}
 		__syncthreads();
 	}
-#if LMX_POSE_STAGE_OUT
-	// palette (computeSkinMatrices), optional dual quaternions, optional absolute pose write-back - staged: a step's (instance, bone) pairs
-	// are computed with the instance fastest across the lanes (the conflict-free order of the LDS pose arrays), written to staging rows
-	// of one instance each, and leave as contiguous pieces of that instance's palette / pose
-	{
-		constexpr uint32_t ROW_PITCH = BONES_PER_STEP * 3 + 1;  // float4 per instance row (+1: lanes of neighbouring instances on distinct bank columns)
-		__shared__ float4 s_out[K * ROW_PITCH];
-#if LMX_POSE_STAGE_OUT > 1
-		constexpr uint32_t ROT_PITCH = BONES_PER_STEP + 1;
-		constexpr uint32_t POS_PITCH = BONES_PER_STEP * 3 + 1; // floats
-		__shared__ float4 s_rot_out[K * ROT_PITCH];
-		__shared__ float s_pos_out[K * POS_PITCH];
-#endif
-		const float* ipos = inv_pos + (size_t)in.model_offset * 3;
-		const float4* irot = inv_rot + in.model_offset;
-		for (uint32_t b0 = 0; b0 < nb; b0 += BONES_PER_STEP) { // block-uniform
-			const uint32_t b = b0 + b_lane;
-			const uint32_t n_step = nb - b0 < BONES_PER_STEP ? nb - b0 : BONES_PER_STEP; // bones of this step
-			if (k_live && b < nb) {
-				const float4 ir4 = irot[b];
-				const Q4 ir = Q4{ir4.x, ir4.y, ir4.z, ir4.w};
-				const V3 ip = V3{ipos[3 * b], ipos[3 * b + 1], ipos[3 * b + 2]};
-				const size_t i = bone0 + (size_t)k * nb + b;
-				const uint32_t ib = pose_slot<K>(b, k);
-				const float4 r4 = s_rot[ib];
-				const V3 p = V3{s_px[ib], s_py[ib], s_pz[ib]};
-				const Mat4 m = skin_matrix(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, ir);
-				if (dual_quats != nullptr) { // (the dual-quaternion palette keeps the direct stores)
-					const DualQ dq = skin_dual_quat(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, ir);
-					float4* o = dual_quats + i * 2;
-					o[0] = make_float4(dq.r.x, dq.r.y, dq.r.z, dq.r.w);
-					o[1] = make_float4(dq.d.x, dq.d.y, dq.d.z, dq.d.w);
-				}
-				float4* row = s_out + k * ROW_PITCH + b_lane * 3;
-				row[0] = make_float4(m.c[0][0], m.c[1][0], m.c[2][0], m.c[3][0]);
-				row[1] = make_float4(m.c[0][1], m.c[1][1], m.c[2][1], m.c[3][1]);
-				row[2] = make_float4(m.c[0][2], m.c[1][2], m.c[2][2], m.c[3][2]);
-#if LMX_POSE_STAGE_OUT > 1
-				if (pose_pos != nullptr) {
-					s_rot_out[k * ROT_PITCH + b_lane] = r4;
-					float* pp = s_pos_out + k * POS_PITCH + b_lane * 3;
-					pp[0] = p.x; pp[1] = p.y; pp[2] = p.z;
-				}
-#else
-				if (pose_pos != nullptr) { // the pose becomes absolute (Pose::is_absolute = true, pose.cpp:133)
-					float* gp = pose_pos + i * 3;
-					gp[0] = p.x; gp[1] = p.y; gp[2] = p.z;
-					pose_rot[i] = r4;
-				}
-#endif
-			}
-			__syncthreads();
-			// palette rows: n_step * 3 float4 per live instance, contiguous in memory from bone b0 of that instance
-			for (uint32_t j = tid; j < K * n_step * 3; j += THREADS) {
-				const uint32_t kk = j / (n_step * 3), within = j - kk * (n_step * 3);
-				if (kk < g.count) palette[(bone0 + (size_t)kk * nb + b0) * 3 + within] = s_out[kk * ROW_PITCH + within];
-			}
-#if LMX_POSE_STAGE_OUT > 1
-			if (pose_pos != nullptr) {
-				for (uint32_t j = tid; j < K * n_step; j += THREADS) {
-					const uint32_t kk = j / n_step, within = j - kk * n_step;
-					if (kk < g.count) pose_rot[bone0 + (size_t)kk * nb + b0 + within] = s_rot_out[kk * ROT_PITCH + within];
-				}
-				for (uint32_t j = tid; j < K * n_step * 3; j += THREADS) {
-					const uint32_t kk = j / (n_step * 3), within = j - kk * (n_step * 3);
-					if (kk < g.count) pose_pos[(bone0 + (size_t)kk * nb + b0) * 3 + within] = s_pos_out[kk * POS_PITCH + within];
-				}
-			}
-#endif
-			__syncthreads(); // the staging rows are rewritten by the next step
-		}
-	}
-}
-
-#else
 	// palette (computeSkinMatrices), optional dual quaternions, optional absolute pose write-back
 	const float* ipos = inv_pos + (size_t)in.model_offset * 3;
 	const float4* irot = inv_rot + in.model_offset;
@@ -240,7 +157,6 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_pose_palette(const SkinInst
 	}
 }
 
-#endif // LMX_POSE_STAGE_OUT
 
 // Pose::blend (renderer/pose.cpp:30-41) for every bone of every instance: positions = positions * inv + rhs * weight, rotations =
 // nlerp(rotations, rhs, weight) (core/math.cpp:677-691: left-to-right dot and length, t negated for the short way round)
@@ -701,7 +617,127 @@ __global__ __launch_bounds__(SHARED_THREADS) void k_skin_shared(const SkinInstan
 	else skin_shared_tile<4, MODE>(in0, ch, s_rows, mesh_local, tile_bones, palette, out);
 }
 
+// ---- shared-mesh runs, several instances per block: the palette is staged ONCE per block, the vertex records stream ------------------
+// k_skin_shared stages 48 KiB of replicated palette per 5120 outputs (one instance x one register-resident tile): 9.6 bytes of LDS
+// writes per skinned vertex, a barrier and an in-order vmcnt wait per instance - the 0.5 ms per 1e9 vertices round 2's term-by-term
+// probe put on "palette staging". Here the 16 bank columns of the replicated palette hold I DIFFERENT instances (16 / I copies each):
+// column c = (copy, instance c % I), and lane l - bank column l % 16 as before, so every lane of a ds_read_b128 service group still owns
+// its column whatever the bone indices - skins vertex l / I of the wave's step for instance l % I. One staging per block then serves
+// I instances x the block's whole vertex range (48 KiB per I x ~10 k outputs: under 1.3 B per vertex at I = 4), the steady state has no
+// barrier and no palette traffic, and the block is 8 waves with 48 KiB of LDS: three resident per CU instead of one.
+// The price: vertex records are no longer register-resident; they stream through a PIPE-deep software pipeline as in k_skin_vertices
+// (64 / I distinct records per wave-step, every one shared by I lanes: 32 / I bytes of L2 traffic per output), and a store instruction
+// writes I runs of 64 / I consecutive vertices (I = 4: four runs of 192 bytes) instead of one run of 768 bytes.
+template <int COLS, int I, int MODE, int PIPE>
+__device__ __forceinline__ void skin_multi_tile(const SkinInstance& in0, const SkinChunk& ch, float4* s_rows, const float4* __restrict__ mesh,
+	const float4* __restrict__ palette, float* __restrict__ out) {
+	static_assert(I >= 1 && I <= COLS && (COLS % I) == 0 && (64 % I) == 0, "instances per block divide the bank columns");
+	constexpr uint32_t VPW = 64 / I;                   // vertices per wave-step
+	constexpr uint32_t VPB = VPW * (SKIN_THREADS / 64); // vertices per block-step: consecutive across the block's waves
+	constexpr uint32_t ROWS = skin_rows(MODE);
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t last_inst = ch.count - 1;            // 1 <= count <= I; lanes of missing instances redo the last one (same bytes, same place)
+	const uint32_t inst_l = min(lane % I, last_inst);
+	const size_t pal_stride = (size_t)in0.n_bones * ROWS; // float4 per instance: consecutive instances, consecutive palettes
+	{
+		const float4* pal = palette + (size_t)in0.bone_offset * ROWS;
+		const uint32_t items = in0.n_bones * ROWS * COLS;
+		// consecutive lanes fill consecutive columns of one row: conflict-free ds_write_b128; the COLS / I lanes of one instance fetch the same
+		// 16 bytes. All of a lane's loads go out before the first is written (items past the palette's end re-read its first row).
+		constexpr uint32_t PER_LANE = SKIN_LDS_SLOTS / SKIN_THREADS;
+		float4 t[PER_LANE];
+#pragma unroll
+		for (uint32_t k = 0; k < PER_LANE; ++k) {
+			const uint32_t w = tid + k * SKIN_THREADS;
+			t[k] = pal[w < items ? min((w % COLS) % I, last_inst) * pal_stride + w / COLS : 0u];
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < PER_LANE; ++k) asm volatile("" : "+v"(t[k].x), "+v"(t[k].y), "+v"(t[k].z), "+v"(t[k].w)); // used HERE by every lane: the loads are not sunk into the branches below
+#pragma unroll
+		for (uint32_t k = 0; k < PER_LANE; ++k) {
+			const uint32_t w = tid + k * SKIN_THREADS;
+			if (w < items) s_rows[w] = t[k];
+		}
+	}
+	const float4* rows = s_rows + (lane & (COLS - 1));
+	const float4* mbase = mesh + 2 * (size_t)ch.rec_offset;
+	F3* obase = reinterpret_cast<F3*>(out) + in0.out_offset + (size_t)inst_l * in0.n_verts; // per-lane base: the lane's instance
+	const uint32_t v_last = ch.v_end - 1; // chunks are never empty
+	const uint32_t v0 = ch.v_begin + wave * VPW + lane / I;
+	auto load = [&](uint32_t v) { return load_vertex(mbase, v); };
+	RawVertex rec[PIPE];
+#pragma unroll
+	for (int d = 0; d < PIPE; ++d) rec[d] = load(min(v0 + d * VPB, v_last));
+#pragma unroll
+	for (int d = 0; d < PIPE; ++d) asm volatile("" : "+v"(rec[d].a), "+v"(rec[d].b)); // (issued here, ahead of the wait below)
+	// every load so far is complete before the loop: with loads possibly pending at the loop's entry the compiler merges that state into
+	// the steady state and tightens the wait at the loop head to cover the previous step's STORE (seen in the ISA: vmcnt(2) instead of
+	// vmcnt(2 * PIPE)). vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding).
+	__builtin_amdgcn_s_waitcnt(0x0F70);
+	__syncthreads();
+	const uint32_t n_steps = (ch.v_end - ch.v_begin + VPB - 1) / VPB; // block-uniform
+	// the pipeline of skin_tile: no branch around a load or a store (steps and lanes past the range's end are clamped to its last vertex),
+	// so that the compiler emits exact vmcnt counts: a wave waits for the record loaded PIPE steps ago, never for its newest stores
+	for (uint32_t it = 0; it < n_steps; it += PIPE) {
+#pragma unroll
+		for (int d = 0; d < PIPE; ++d) {
+			const uint32_t v = min(v0 + (it + d) * VPB, v_last);
+			asm volatile("" : "+v"(rec[d].a), "+v"(rec[d].b));
+			F3 o = skin_blend<COLS, MODE>(rows, rec[d]);
+			asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z));
+			__builtin_amdgcn_sched_barrier(0);
+			rec[d] = load(min(v0 + (it + d + PIPE) * VPB, v_last));
+			store_position(obase + v, o);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+}
+
+#ifndef LMX_MULTI_PIPE
+#define LMX_MULTI_PIPE 2
+#endif
+template <int I, int MODE>
+__global__ __launch_bounds__(SKIN_THREADS, SKIN_WAVES_PER_SIMD) void k_skin_multi(const SkinInstance* __restrict__ inst, const SkinChunk* __restrict__ chunks,
+	const float4* __restrict__ mesh, const float4* __restrict__ palette, float* __restrict__ out) {
+	__shared__ float4 s_rows[SKIN_LDS_SLOTS];
+	const SkinChunk ch = chunks[blockIdx.x];
+	const SkinInstance in0 = inst[ch.first_inst];
+	if (in0.n_bones <= 64) skin_multi_tile<16, I, MODE, LMX_MULTI_PIPE>(in0, ch, s_rows, mesh, palette, out);
+	else if (in0.n_bones <= 128) skin_multi_tile<8, (I < 8 ? I : 8), MODE, LMX_MULTI_PIPE>(in0, ch, s_rows, mesh, palette, out);
+	else skin_multi_tile<4, (I < 4 ? I : 4), MODE, LMX_MULTI_PIPE>(in0, ch, s_rows, mesh, palette, out);
+}
+
 } // namespace
+
+// instances one k_skin_multi block serves for a model of n_bones bones when the launch is asked for `per_block`
+uint32_t skin_multi_instances(uint32_t per_block, uint32_t n_bones) {
+	const uint32_t cols = n_bones <= 64 ? 16u : (n_bones <= 128 ? 8u : 4u);
+	return per_block < cols ? per_block : cols;
+}
+
+template <int I>
+static hipError_t launch_skin_multi_i(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh, const float4* palette,
+	float* out, int mode) {
+	const dim3 grid(n_chunks), block(SKIN_THREADS);
+	if (mode == LMX_SKIN_EXACT) hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_EXACT>), grid, block, 0, s, inst, chunks, mesh, palette, out);
+	else if (mode == LMX_SKIN_DQS) hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_DQS>), grid, block, 0, s, inst, chunks, mesh, palette, out);
+	else hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_FUSED>), grid, block, 0, s, inst, chunks, mesh, palette, out);
+	return hipGetLastError();
+}
+
+// chunks: (first_inst, count <= skin_multi_instances(per_block, bones), [v_begin, v_end), rec_offset = the mesh's first record in `mesh`)
+hipError_t launch_skin_multi(hipStream_t s, uint32_t per_block, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh,
+	const float4* palette, float* out, int mode) {
+	if (!n_chunks) return hipSuccess;
+	switch (per_block) {
+	case 1: return launch_skin_multi_i<1>(s, inst, chunks, n_chunks, mesh, palette, out, mode);
+	case 2: return launch_skin_multi_i<2>(s, inst, chunks, n_chunks, mesh, palette, out, mode);
+	case 4: return launch_skin_multi_i<4>(s, inst, chunks, n_chunks, mesh, palette, out, mode);
+	case 8: return launch_skin_multi_i<8>(s, inst, chunks, n_chunks, mesh, palette, out, mode);
+	case 16: return launch_skin_multi_i<16>(s, inst, chunks, n_chunks, mesh, palette, out, mode);
+	default: return hipErrorInvalidValue;
+	}
+}
 
 // groups are sorted by capacity class on the host: [0, n16) hold <= 16 instances of <= 64 bones, then 8 x <= 128, then 4 x <= 196
 hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, const PoseGroup* groups, const uint32_t n_groups[3], const float* rel_pos,

@@ -70,6 +70,8 @@ def run(seed: int, oracle, ctx=None, verbose: bool = False) -> dict:
             m = int(rng.choice(ok))
             pick += [(m, g)] * int(rng.choice([1, 1, 2, 3, 9, 20]))
         sk.setInstances([models[m] for m, _ in pick], [mesh_ids[g] for _, g in pick])
+        per_block = int(np.random.default_rng(9000 + seed).choice([0, 0, 1, 2, 4, 4, 8, 16]))  # (a stream of its own: the scenes of a seed stay what they were)
+        sk.setOption(api.SKIN_OPT_INSTANCES_PER_BLOCK, per_block)
         poses = [scenes.relative_poses(1, len(skel[m]["parents"]), seed=int(rng.integers(1 << 30))) for m, _ in pick]
         sk.uploadPoses(np.concatenate([p[0].reshape(-1, 3) for p in poses]), np.concatenate([p[1].reshape(-1, 4) for p in poses]))
         sk.run()
@@ -89,7 +91,8 @@ def run(seed: int, oracle, ctx=None, verbose: bool = False) -> dict:
                 assert H.bits_equal(got, want), f"seed {seed}: instance {i} vertices (exact mode)"
             checked += 1
         sk.setMode(False)
-        st = {"instances": len(pick), "checked": checked, "exact": exact, "bones": [len(s["parents"]) for s in skel], "verts": [len(v) for v, _ in meshes]}
+        sk.setOption(api.SKIN_OPT_INSTANCES_PER_BLOCK, api.SKIN_INSTANCES_PER_BLOCK_DEFAULT)
+        st = {"instances": len(pick), "checked": checked, "exact": exact, "per_block": per_block, "bones": [len(s["parents"]) for s in skel], "verts": [len(v) for v, _ in meshes]}
         if verbose:
             print(f"seed {seed}: {st}")
         return st

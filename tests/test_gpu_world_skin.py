@@ -680,13 +680,16 @@ def test_skin_dqs_bounded_by_exact_evaluation(gpu_ctx, oracle_port):
         sk.setMode(api.SKIN_FUSED)
 
 
+@pytest.mark.parametrize("per_block", [0, 1, 2, 4, 8, 16])
 @pytest.mark.parametrize("exact", [True, False])
-def test_skin_shared_mesh_runs(gpu_ctx, live_oracle, exact):
+def test_skin_shared_mesh_runs(gpu_ctx, live_oracle, exact, per_block):
     """Runs of instances that share a mesh take the register-resident path (k_skin_shared: ragged tiles, 2 tiles per mesh,
-    8-copy palettes for 100 bones), single instances and small meshes the streaming one; both in one instance table."""
+    8-copy palettes for 100 bones) or - per_block instances at a time - k_skin_multi (ragged last groups, 8 columns for 100 bones);
+    single instances and small meshes the streaming kernel; all in one instance table."""
     oracle_port = live_oracle
     sk = api.Skinning(gpu_ctx)
     sk.setMode(exact)
+    sk.setOption(api.SKIN_OPT_INSTANCES_PER_BLOCK, per_block)
     skel = [scenes.skeleton(64, seed=4), scenes.skeleton(100, seed=24), scenes.skeleton(64, seed=34)]
     meshes = [scenes.skinned_mesh(5121, 64, seed=6), scenes.skinned_mesh(2049, 100, seed=7), scenes.skinned_mesh(700, 64, seed=8)]
     models = [sk.addModel(s["parents"], s["bind"], s["first_nonroot"]) for s in skel]
@@ -706,7 +709,18 @@ def test_skin_shared_mesh_runs(gpu_ctx, live_oracle, exact):
         assert close_1e5(got, want), f"instance {i} vertices"
         if exact:
             assert H.bits_equal(got, want), f"instance {i} vertices (exact mode)"
+    if per_block:  # the dual-quaternion blend through k_skin_multi against the same blend through k_skin_vertices: the same bits
+        sk.setMode(api.SKIN_DQS)
+        sk.uploadPoses(np.concatenate([p[0].reshape(-1, 3) for p in poses]), np.concatenate([p[1].reshape(-1, 4) for p in poses]))
+        sk.run()
+        multi = [sk.readVertices(i) for i in range(len(pick))]
+        sk.setOption(api.SKIN_OPT_INSTANCES_PER_BLOCK, 0)
+        sk.uploadPoses(np.concatenate([p[0].reshape(-1, 3) for p in poses]), np.concatenate([p[1].reshape(-1, 4) for p in poses]))
+        sk.run()
+        for i in range(len(pick)):
+            assert H.bits_equal(multi[i], sk.readVertices(i)), f"instance {i}: DQS through k_skin_multi != k_skin_vertices"
     sk.setMode(False)
+    sk.setOption(api.SKIN_OPT_INSTANCES_PER_BLOCK, api.SKIN_INSTANCES_PER_BLOCK_DEFAULT)
 
 
 @pytest.mark.parametrize("exact", [True, False])

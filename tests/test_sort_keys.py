@@ -323,7 +323,7 @@ def test_gpu_sort_keys_slot_order_under_updates(gpu_ctx, oracle_port, slot_order
                 cs.compact()  # a re-sort: every slot changes
     finally:
         sk.setOption(api.KEYS_OPT_SLOT_ORDER, 1)
-        sk.setOption(api.KEYS_OPT_SPLIT_STATE, 0)
+        sk.setOption(api.KEYS_OPT_SPLIT_STATE, 2)  # the defaults
 
 
 @pytest.mark.gpu

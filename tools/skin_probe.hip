@@ -4,7 +4,6 @@
 //    64 per-instance barrier (k_skin_shared)      128 per-vertex scheduling barrier      256 staging without its global load
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DLMX_PROBE_MASK=<bits>] [-DLMX_SHARED_NT=0|1] [-DLMX_SHARED_ST16=0|1]
 //         [-DLMX_SHARED_ZSKIP=0|1] -I lumixengine_amd/csrc -I include tools/skin_probe.hip -o tools/_build/skin_probe_<name>
-//   round 2's kernels for an A/B in the same run: -DLMX_PROBE_R02 -I tools/scratch/r02 (first on the include path)
 //   skin_probe_<name> [instances] [instances per block] [1 = k_skin_shared, 0 = k_skin_vertices] [mesh: 0 = 4 random bones of 64 per
 //                     vertex (worst case), 1 = character-like: consecutive vertices follow one bone, 1-2 influences, zero-padded]
 // Round-2 readings, 20 000 instances x 10 000 vertices x 64 bones, ms per 1e9 vertices (k_skin_shared): all 3.1-3.2 | no stores 1.36 |
@@ -56,10 +55,6 @@ int main(int argc, char** argv) {
 	CK(hipMalloc(&d_out, (size_t)n_inst * nv * 12));
 	const uint32_t per_block = argc > 2 ? atoi(argv[2]) : 64, tile = 5056;
 	std::vector<SkinChunk> chunks;
-#ifdef LMX_PROBE_R02
-	for (uint32_t f = 0; f < n_inst; f += per_block)
-		for (uint32_t t = 0; t * tile < nv; ++t) chunks.push_back(SkinChunk{f, n_inst - f < per_block ? n_inst - f : per_block, t * tile, (t + 1) * tile < nv ? (t + 1) * tile : nv});
-#else
 	// per tile: the bones it references + records with tile-local indices (what lmx_skin_add_mesh builds)
 	std::vector<uint8_t> tile_bones;
 	std::vector<float4> mesh_local(mesh);
@@ -88,20 +83,37 @@ int main(int argc, char** argv) {
 	float4* d_mesh_local; uint8_t* d_tile_bones;
 	CK(hipMalloc(&d_mesh_local, mesh_local.size() * 16)); CK(hipMemcpy(d_mesh_local, mesh_local.data(), mesh_local.size() * 16, hipMemcpyHostToDevice));
 	CK(hipMalloc(&d_tile_bones, tile_bones.size())); CK(hipMemcpy(d_tile_bones, tile_bones.data(), tile_bones.size(), hipMemcpyHostToDevice));
-#endif
 	SkinChunk* d_chunks; CK(hipMalloc(&d_chunks, chunks.size() * sizeof(SkinChunk))); CK(hipMemcpy(d_chunks, chunks.data(), chunks.size() * sizeof(SkinChunk), hipMemcpyHostToDevice));
-	const bool shared = argc > 3 ? atoi(argv[3]) != 0 : true;
-	printf("%s kernel, %zu chunks of %u instances\n", shared ? "shared" : "streaming", chunks.size(), per_block);
+	const int kind = argc > 3 ? atoi(argv[3]) : 1; // 0: k_skin_vertices, 1: k_skin_shared, 2: k_skin_multi for I = 1, 2, 4, 8, 16 (x vertex-range splits 1, 2, 4)
+	const bool shared = kind == 1;
+	printf("%s kernel, %zu chunks of %u instances\n", kind == 2 ? "multi" : shared ? "shared" : "streaming", chunks.size(), per_block);
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	if (kind == 2) {
+		for (uint32_t I : {1u, 2u, 4u, 8u, 16u})
+			for (uint32_t splits : {1u, 2u, 4u}) {
+				std::vector<SkinChunk> mc;
+				const uint32_t range = ((nv + splits - 1) / splits + 63u) & ~63u;
+				for (uint32_t f = 0; f < n_inst; f += I)
+					for (uint32_t v = 0; v < nv; v += range) mc.push_back(SkinChunk{f, n_inst - f < I ? n_inst - f : I, v, v + range < nv ? v + range : nv, 0u, 0u, 0u, 0u});
+				SkinChunk* d_mc; CK(hipMalloc(&d_mc, mc.size() * sizeof(SkinChunk))); CK(hipMemcpy(d_mc, mc.data(), mc.size() * sizeof(SkinChunk), hipMemcpyHostToDevice));
+				float best = 1e9f;
+				for (int it = 0; it < 5; ++it) {
+					CK(hipEventRecord(e0));
+					CK(launch_skin_multi(0, I, d_inst, d_mc, (uint32_t)mc.size(), d_mesh, d_pal, d_out, LMX_SKIN_FUSED));
+					CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+					float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+					if (it && ms < best) best = ms;
+				}
+				printf("multi I=%2u splits=%u pipe=%d (%zu blocks): %.4f ms  = %.3f ms per 1e9 verts\n", I, splits, LMX_MULTI_PIPE, mc.size(), best, best * 1e9 / ((double)n_inst * nv));
+				CK(hipFree(d_mc));
+			}
+		return 0;
+	}
 	for (int mask : {LMX_PROBE_MASK}) {
 		float best = 1e9f;
 		for (int it = 0; it < 5; ++it) {
 			CK(hipEventRecord(e0));
-#ifdef LMX_PROBE_R02
-			if (shared) CK(launch_skin_shared(0, d_inst, d_chunks, (uint32_t)chunks.size(), d_mesh, d_pal, d_out, false));
-#else
 			if (shared) CK(launch_skin_shared(0, d_inst, d_chunks, (uint32_t)chunks.size(), d_mesh_local, d_tile_bones, d_pal, d_out, false));
-#endif
 			else CK(launch_skin_vertices(0, d_inst, nullptr, n_inst, nv, d_mesh, d_pal, d_out, false));
 			CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
 			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
