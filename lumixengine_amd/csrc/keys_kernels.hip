@@ -3,9 +3,9 @@
 //
 //   k_keys_mesh      one lane per visible MESH entity: LOD selection (fp64 squared distance to the LOD reference point
 //                    :3876, Model::getLODMeshIndices model.h:173-179, the ModelInstance::lod transition :3937-3957) and
-//                    create_key (:3884-3935) for every mesh of the selected LOD range(s). The lanes of a wave walk their
-//                    mesh lists in lockstep so that every output append is ONE atomic per wave and list (ballot + mbcnt),
-//                    not one per element: returning atomics on one address serialise at ~90 per microsecond.
+//                    create_key (:3884-3935) for every mesh of the selected LOD range(s): the materials are read ONCE (loads back to
+//                    back) and classified, a tile reserves its output ranges with two atomics, the pairs / records are built from
+//                    registers into LDS and leave as contiguous stores.
 //   k_keys_decal     DECAL / CURVE_DECAL pages (:3841-3868).
 //   k_keys_reduce_copies + k_keys_offsets   per-key sum over the private counter copies, then the exclusive scan of the group sizes (AutoInstancer::instances, :452-523) -> CSR offsets
 //   k_keys_scatter   instancer records -> CSR values
@@ -54,6 +54,10 @@ __device__ __forceinline__ uint32_t float_flip(uint32_t bits) {
 }
 
 constexpr int KEYS_BLOCK = 512; // entities per tile = threads per block. 8 waves: 3 blocks per CU (79 VGPRs: 6 waves per SIMD). Tiles of 256 / 1024 entities measured slower (161.8 / 145.0 against 138.1 us for the whole chain, round 3's driver box)
+#ifndef LMX_KEYS_MM_REGS
+#define LMX_KEYS_MM_REGS 4 // 3: no scratch at the 80-VGPR budget (6 waves per SIMD), 4: 12 bytes, 6: 32 bytes
+#endif
+constexpr int KEYS_MM_REGS = LMX_KEYS_MM_REGS; // meshes of an entity's LOD range(s) whose materials stay in registers between the count and the emit
 constexpr int KEYS_STAGE_PAIRS = 3 * KEYS_BLOCK; // pairs (24 KiB) and records (18 KiB) of one 512-entity tile held in LDS
 
 // The visible list is walked in tiles of 512 entities by a fixed-size grid. Per tile every lane first COUNTS what it will
@@ -77,18 +81,20 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		const uint32_t i = tile + threadIdx.x;
 		// ranges of mesh indices this lane emits keys for: [from0, to0] then [from1, to1]
 		int32_t from0 = 0, to0 = -1, from1 = 0, to1 = -1;
-		uint32_t e = 0, mat0 = 0, pose_stamp = 0;
+		uint32_t e = 0, pose_stamp = 0;
+		int32_t slot = -1; // the entity's slot in the sorted set's mirror, or -1
 		bool moved = false, queue_dirty = false;
-		double px = 0, py = 0, pz = 0;
+		uint32_t depth_key = 0; // makeDepthSortKey's floatFlip(squared distance to the camera), used by depth-sorted buckets only
 		KeysInstance* rec = nullptr;                   // the entity's record: by slot for the sorted set, by entity otherwise
 		float* lod_at = nullptr;                       // where ModelInstance::lod and Pose::frame of the entity live: in the record, or
-		uint32_t* frame_at = nullptr;                  // (sorted set, LMX_KEYS_SPLIT_STATE) in the dense per-slot array
-		const LmxMeshMaterial* mmb = d.mesh_materials; // ... and the table its material_offset points into
+		                                               // (sorted set, LMX_KEYS_SPLIT_STATE) in the dense per-slot array
+		const LmxMeshMaterial* mmb = d.mesh_materials; // ... and the table its material_offset points into; from the LOD ranges on: the entity's first material
 		if (i < n) {
 			e = (uint32_t)ids[i];
 			KeysInstance in;
 			in.model = -1;
 			const int32_t sl = slots != nullptr ? slots[i] : -1;
+			slot = sl;
 			if (sl >= 0 && d.soa.model != nullptr) { // the mirror as a structure of arrays: every field a contiguous load across the wave
 				mmb = d.mm_s;
 				in.model = d.soa.model[sl];
@@ -98,9 +104,8 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 				in.dirty = (uint8_t)(fd >> 8);
 				in.pos[0] = d.soa.px[sl]; in.pos[1] = d.soa.py[sl]; in.pos[2] = d.soa.pz[sl];
 				lod_at = &d.state_s[sl].lod;
-				frame_at = &d.state_s[sl].pose_frame;
 				in.lod = *lod_at;
-				in.pose_frame = *frame_at;
+				in.pose_frame = d.state_s[sl].pose_frame;
 			} else {
 				if (sl >= 0) {
 					rec = d.inst_s + sl;
@@ -111,22 +116,24 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 				if (rec != nullptr) {
 					in = *rec; // one 64-byte record
 					lod_at = &rec->lod;
-					frame_at = &rec->pose_frame;
 					if (sl >= 0 && d.state_s != nullptr) {
 						lod_at = &d.state_s[sl].lod;
-						frame_at = &d.state_s[sl].pose_frame;
 						in.lod = *lod_at;
-						in.pose_frame = *frame_at;
+						in.pose_frame = d.state_s[sl].pose_frame;
 					}
 				}
 			}
 			const int32_t mdl = in.model;
 			if (mdl >= 0) {
 				const LmxKeysModel& m = d.models[mdl];
-				px = in.pos[0]; py = in.pos[1]; pz = in.pos[2];
+				double px = in.pos[0], py = in.pos[1], pz = in.pos[2];
 				if (d.slot_of_entity != nullptr) { // World::getTransforms()[e].pos out of the hierarchy's SoA
 					const int32_t sl = d.slot_of_entity[e];
 					px = d.wpx[sl]; py = d.wpy[sl]; pz = d.wpz[sl];
+				}
+				{
+					const double cx = px - kv.cam[0], cy = py - kv.cam[1], cz = pz - kv.cam[2];
+					depth_key = float_flip(__float_as_uint((float)(cx * cx + cy * cy + cz * cz))); // :3925-3931
 				}
 				const double rx = px - kv.ref[0], ry = py - kv.ref[1], rz = pz - kv.ref[2];
 				const float squared_length = (float)(rx * rx + ry * ry + rz * rz); // float(squaredLength(pos - lod_ref_point)), math.cpp:397
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 				if (in.dirty) {
 					queue_dirty = true; // queueMaterialOverrideRefresh(e); continue;  (:3879-3882)
 				} else {
-					mat0 = in.material_offset;
+					mmb += in.material_offset;
 					moved = (in.flags & LMX_MODEL_INSTANCE_MOVED) != 0;
 					pose_stamp = in.pose_frame;
 					float lod = in.lod;
@@ -161,26 +168,52 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 				}
 			}
 		}
-		const int32_t len0 = to0 >= from0 ? to0 - from0 + 1 : 0, len1 = to1 >= from1 ? to1 - from1 + 1 : 0;
-		// ---- walk 1: count (create_key's branches, :3884-3935)
+		const int32_t len0 = to0 >= from0 ? to0 - from0 + 1 : 0, len1 = to1 >= from1 ? to1 - from1 + 1 : 0, total = len0 + len1;
+		auto mesh_index = [&](int32_t it) { return it < len0 ? from0 + it : from1 + (it - len0); };
+		// what create_key does with one mesh of the range (:3884-3935): 0 nothing, 1 skinned pair, 2 moved pair, 3 instancer record, 4 depth-sorted pair
+		auto classify = [&](const LmxMeshMaterial& mm, uint32_t bucket) -> uint32_t {
+			if (mm._pad[0] == LMX_MESH_SKINNED) return 1u; // device copy: _pad[0] = Mesh::type of the model's mesh
+			if (moved && !kv.is_shadow) return 2u;
+			if (bucket < 0xffu) return 3u;
+			if (bucket < 0xffffu) return 4u;
+			return 0u;
+		};
+		// ---- ONE walk over the materials: the first KEYS_MM_REGS meshes of the range(s) - all of them unless a model's LODs hold more than
+		// three meshes - are fetched with their loads back to back (one memory round trip, not one per mesh) and kept as (sort key | bucket,
+		// kind) in registers for the emit below. Rounds 1-3 walked the table twice (count, then emit) and every step waited for its own load.
+		uint32_t item[KEYS_MM_REGS]; // sort_key | (u8)bucket << 24
+		uint32_t kinds = 0;          // 3 bits per cached mesh
 		uint32_t n_pairs = 0, n_recs = 0;
-		bool push_pose = false;
-		for (int32_t it = 0; it < len0 + len1; ++it) {
-			const int32_t mesh_idx = it < len0 ? from0 + it : from1 + (it - len0);
-			const LmxMeshMaterial mm = mmb[mat0 + (uint32_t)mesh_idx]; // device copy: _pad[0] = Mesh::type of the model's mesh
-			const uint32_t bucket = s_bucket[mm.layer];
-			if (mm._pad[0] == LMX_MESH_SKINNED) {
-				// Pose::frame stamp (:3889-3898): exactly one visit per frame hands the instance to the pose processor
-				if (!push_pose && pose_stamp != kv.frame_number) {
-					push_pose = atomicExch(frame_at, kv.frame_number) != kv.frame_number;
-					pose_stamp = kv.frame_number;
-				}
-				++n_pairs;
-			} else if (moved && !kv.is_shadow) ++n_pairs;
-			else if (bucket < 0xffu) ++n_recs;
-			else if (bucket < 0xffffu) ++n_pairs;
+		bool any_skinned = false;
+		{
+			LmxMeshMaterial raw[KEYS_MM_REGS];
+#pragma unroll
+			for (int32_t k = 0; k < KEYS_MM_REGS; ++k) raw[k] = mmb[k < total ? mesh_index(k) : 0];
+#pragma unroll
+			for (int32_t k = 0; k < KEYS_MM_REGS; ++k) {
+				const uint32_t bucket = s_bucket[raw[k].layer];
+				const uint32_t kind = k < total ? classify(raw[k], bucket) : 0u;
+				item[k] = raw[k].sort_key | (bucket << 24);
+				kinds |= kind << (3 * k);
+				any_skinned |= kind == 1u;
+				n_pairs += (kind == 1u || kind == 2u || kind == 4u) ? 1u : 0u;
+				n_recs += kind == 3u ? 1u : 0u;
+			}
+			for (int32_t it = KEYS_MM_REGS; it < total; ++it) { // longer ranges: counted here, read again by the emit
+				const LmxMeshMaterial mm = mmb[mesh_index(it)];
+				const uint32_t kind = classify(mm, s_bucket[mm.layer]);
+				any_skinned |= kind == 1u;
+				n_pairs += (kind == 1u || kind == 2u || kind == 4u) ? 1u : 0u;
+				n_recs += kind == 3u ? 1u : 0u;
+			}
 		}
-		// ---- block-wide exclusive prefix of (pairs, recs) and ranks of the two flags; one atomic per list
+		// Pose::frame stamp (:3889-3898): exactly one visit per frame hands the instance to the pose processor
+		bool push_pose = false;
+		if (any_skinned && pose_stamp != kv.frame_number) { // (the address is rebuilt here instead of living in two registers since the record was read)
+			uint32_t* frame_at = slot >= 0 ? (d.state_s != nullptr ? &d.state_s[slot].pose_frame : &d.inst_s[slot].pose_frame) : &d.inst[e].pose_frame;
+			push_pose = atomicExch(frame_at, kv.frame_number) != kv.frame_number;
+		}
+		// ---- block-wide exclusive prefix of (pairs, recs) and ranks of the two flags; one atomic per pair of lists
 		uint32_t incl = n_pairs | (n_recs << 16); // <= 2 * span per lane, <= 64 * that per wave: 16 bits each
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1) {
@@ -190,7 +223,7 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		const uint64_t pose_mask = __ballot(push_pose), dirty_mask = __ballot(queue_dirty);
 		if (lane == 63) { s_wave[wave][0] = incl; s_wave[wave][1] = (uint32_t)__popcll(pose_mask); s_wave[wave][2] = (uint32_t)__popcll(dirty_mask); }
 		__syncthreads();
-		if (threadIdx.x < 2) { // thread 0: {pairs, recs}, thread 1: {poses, dirty} - one 64-bit returning atomic each
+		if (threadIdx.x < 2) { // thread 0: {pairs, recs}, thread 1: {poses, dirty} - one 64-bit returning atomic each, on two cache lines
 			uint32_t lo = 0, hi = 0;
 			for (int w = 0; w < KEYS_BLOCK / 64; ++w) {
 				lo += threadIdx.x == 0 ? (s_wave[w][0] & 0xffffu) : s_wave[w][1];
@@ -205,6 +238,9 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		__syncthreads();
 		uint32_t pair_at = s_base[0] + (incl & 0xffffu) - n_pairs, rec_at = s_base[1] + (incl >> 16) - n_recs;
 		uint32_t pose_at = s_base[2] + rank_in(pose_mask), dirty_at = s_base[3] + rank_in(dirty_mask);
+		// a tile's (key, value) pairs and instancer records are collected in LDS at their positions inside the tile's output ranges and leave
+		// as contiguous stores (8-byte stores at every lane's own run of positions used 26 % of the sectors they touched); tiles with more
+		// output than the buffers hold keep the direct stores
 		__shared__ uint64_t s_pair_key[KEYS_STAGE_PAIRS], s_pair_value[KEYS_STAGE_PAIRS], s_rec_value[KEYS_STAGE_PAIRS];
 		__shared__ uint32_t s_rec_key[KEYS_STAGE_PAIRS];
 		const uint32_t tile_pair0 = s_base[0], tile_rec0 = s_base[1], tile_pairs = s_base[4], tile_recs = s_base[5];
@@ -218,50 +254,37 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		__syncthreads(); // s_wave / s_base are rewritten by the next tile
 		if (queue_dirty) { if (dirty_at < d.cap_list) d.dirty_list[dirty_at] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
 		if (push_pose) { if (pose_at < d.cap_list) d.poses[pose_at] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
-		// ---- walk 2: emit, in lockstep over the wave so that the group histogram costs one atomic per distinct key and step
-		for (int32_t it = 0; __ballot(it < len0 + len1) != 0; ++it) {
-			const bool has = it < len0 + len1;
+		// ---- emit, in lockstep over the wave so that the group histogram costs one atomic per distinct key and step
+		auto emit = [&](int32_t it, uint32_t word, uint32_t kind) {
 			bool add_inst = false;
-			uint32_t mesh_sort_key = 0;
-			if (has) {
-				const int32_t mesh_idx = it < len0 ? from0 + it : from1 + (it - len0);
-				const LmxMeshMaterial mm = mmb[mat0 + (uint32_t)mesh_idx];
-				const uint32_t bucket = s_bucket[mm.layer];
-				mesh_sort_key = mm.sort_key;
-				bool push_pair = false;
-				uint64_t key = 0, value = 0;
-				if (mm._pad[0] == LMX_MESH_SKINNED) {
-					value = (uint64_t)e | ((uint64_t)LMX_DRAW_SKINNED << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
-					key = (uint64_t)mm.sort_key | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT); // makeMeshSortKey(mesh_mat, u8 bucket)
-					push_pair = true;
-				} else if (moved && !kv.is_shadow) {
-					value = (uint64_t)e | ((uint64_t)LMX_DRAW_MESH << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
-					key = (uint64_t)mm.sort_key | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT);
-					push_pair = true;
-				} else if (bucket < 0xffu) {
-					value = (uint64_t)e | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT); // instancer.add(mesh_sort_key, value)
-					add_inst = true;
-				} else if (bucket < 0xffffu) { // depth sorted
-					const double cx = px - kv.cam[0], cy = py - kv.cam[1], cz = pz - kv.cam[2];
-					const float sl = (float)(cx * cx + cy * cy + cz * cz);
-					value = (uint64_t)e | ((uint64_t)LMX_DRAW_MESH << LMX_SORT_VALUE_TYPE_SHIFT) | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
-					key = (uint64_t)float_flip(__float_as_uint(sl)) | ((uint64_t)(uint8_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT); // makeDepthSortKey
-					push_pair = true;
+			const uint32_t mesh_sort_key = word & 0xffffffu;
+			if (kind != 0u) {
+				const int32_t mesh_idx = mesh_index(it);
+				const uint64_t bucket_bits = (uint64_t)(word >> 24) << LMX_SORT_KEY_BUCKET_SHIFT; // makeMeshSortKey / makeDepthSortKey take the bucket as u8
+				uint64_t key = 0, value = (uint64_t)e | ((uint64_t)(uint32_t)mesh_idx << LMX_SORT_VALUE_MESH_IDX_SHIFT);
+				if (kind == 1u) {
+					value |= (uint64_t)LMX_DRAW_SKINNED << LMX_SORT_VALUE_TYPE_SHIFT;
+					key = (uint64_t)mesh_sort_key | bucket_bits;
+				} else if (kind == 2u) {
+					value |= (uint64_t)LMX_DRAW_MESH << LMX_SORT_VALUE_TYPE_SHIFT;
+					key = (uint64_t)mesh_sort_key | bucket_bits;
+				} else if (kind == 4u) { // depth sorted
+					value |= (uint64_t)LMX_DRAW_MESH << LMX_SORT_VALUE_TYPE_SHIFT;
+					key = (uint64_t)depth_key | bucket_bits;
+				} else {
+					add_inst = true; // instancer.add(mesh_sort_key, value)
 				}
 				if (stage) {
-					if (push_pair) { s_pair_key[pair_at - tile_pair0] = key; s_pair_value[pair_at - tile_pair0] = value; ++pair_at; }
-					if (add_inst) { s_rec_key[rec_at - tile_rec0] = mesh_sort_key | (copy << 24); s_rec_value[rec_at - tile_rec0] = value; ++rec_at; }
-				} else
-				{
-				if (push_pair) {
+					if (!add_inst) { s_pair_key[pair_at - tile_pair0] = key; s_pair_value[pair_at - tile_pair0] = value; }
+					else { s_rec_key[rec_at - tile_rec0] = mesh_sort_key | (copy << 24); s_rec_value[rec_at - tile_rec0] = value; }
+				} else if (!add_inst) {
 					if (pair_at < d.cap_pairs) { d.keys[pair_at] = key; d.values[pair_at] = value; } else d.counters[KEYS_OVERFLOW] = 1;
-					++pair_at;
-				}
-				if (add_inst) {
+				} else {
 					if (rec_at < d.cap_recs) { d.rec_key[rec_at] = mesh_sort_key | (copy << 24); d.rec_value[rec_at] = value; } else d.counters[KEYS_OVERFLOW] = 1;
-					++rec_at;
 				}
-				}
+				// (plain arithmetic: with `++pair_at` / `++rec_at` in the branches the compiler indexed the two cursors in scratch memory)
+				pair_at += add_inst ? 0u : 1u;
+				rec_at += add_inst ? 1u : 0u;
 			}
 			const bool in_range = add_inst && mesh_sort_key <= d.max_sort_key;
 			if (add_inst && !in_range) d.counters[KEYS_OVERFLOW] = 2; // a mesh sort key above Renderer::getMaxSortKey(): the reference indexes out of bounds
@@ -273,6 +296,24 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			} else {
 				wave_histogram(in_range, mesh_sort_key, d.group_count + (size_t)copy * (d.max_sort_key + 1));
 			}
+		};
+		// ONE rolled loop: the cached words rotate through item[0] (five register moves per step instead of six copies of the emit code)
+		for (int32_t it = 0; __ballot(it < total) != 0; ++it) {
+			uint32_t word = item[0], kind = kinds & 7u; // (kind 0 past the lane's own range)
+#pragma unroll
+			for (int k = 0; k + 1 < KEYS_MM_REGS; ++k) item[k] = item[k + 1];
+			kinds >>= 3;
+			if (it >= KEYS_MM_REGS) { // a range longer than the cache: read again
+				word = 0;
+				kind = 0;
+				if (it < total) {
+					const LmxMeshMaterial mm = mmb[mesh_index(it)];
+					const uint32_t bucket = s_bucket[mm.layer];
+					kind = classify(mm, bucket);
+					word = mm.sort_key | (bucket << 24);
+				}
+			}
+			emit(it, word, kind);
 		}
 		if (stage) { // the tile's outputs leave in position order: consecutive lanes, consecutive 8-byte (4-byte) elements
 			__syncthreads();
