@@ -402,6 +402,7 @@ struct KeysState {
 	DevBuf<int32_t> d_soa_model;
 	DevBuf<uint32_t> d_soa_mat;
 	DevBuf<uint16_t> d_soa_flags;
+	bool look_back = true; // LMX_KEYS_OPT_LOOK_BACK: tile reservations by ticket + decoupled look-back instead of two same-address atomics
 	int split_state = LMX_KEYS_SPLIT_STATE_DEFAULT; // 0: AoS mirror, 1: + lod / Pose::frame in d_state_s, 2: structure-of-arrays mirror
 	int mirror_split = 0;            // the form the current mirror was built in
 	KeysSoA soa() const { // the current mirror's arrays (all null unless it was built as a structure of arrays)

@@ -197,7 +197,8 @@ hipError_t launch_anim_update(hipStream_t s, const SkinInstance* inst, uint32_t 
 // Counter words. {pairs, recs} and {poses, dirty} are two 64-bit cells on their own 128-byte lines: k_keys_mesh reserves a tile's four
 // output ranges with two returning atomics on two lines instead of four on one (measured: no change of the kernel's 124 us per
 // million visible entities - it is bound by its random 64-byte gathers and line write-backs, see DESIGN.md - but half the atomics).
-enum { KEYS_N_PAIRS = 0, KEYS_N_RECS = 1, KEYS_N_POSES = 32, KEYS_N_DIRTY = 33, KEYS_OVERFLOW = 64, KEYS_N_GROUPS = 96, KEYS_COUNTERS = 128 };
+enum { KEYS_N_PAIRS = 0, KEYS_N_RECS = 1, KEYS_N_POSES = 32, KEYS_N_DIRTY = 33, KEYS_OVERFLOW = 64, KEYS_N_GROUPS = 96, KEYS_TICKET = 128, KEYS_COUNTERS = 160 };
+constexpr uint32_t KEYS_TILE = 512; // entities per tile of k_keys_mesh (keys_kernels.hip: KEYS_BLOCK): one look-back descriptor (2 x 8 bytes) per tile
 struct KeysViewDevice { // what the kernels read of a LmxKeysView, bucket_map as built at pipeline.cpp:3802-3812
 	uint32_t bucket_map[255];
 	uint8_t layer_to_bucket[255];
@@ -264,6 +265,7 @@ struct KeysDevice {
 	int32_t *poses, *dirty_list;
 	uint32_t cap_list;
 	uint32_t* counters;       // KEYS_*
+	uint64_t* desc;           // look-back descriptors, 2 words per tile, zeroed before the launch; nullptr: the tiles reserve with atomics (LMX_KEYS_OPT_LOOK_BACK 0)
 };
 hipError_t launch_keys_mirror_count(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models, uint32_t* count);
 hipError_t launch_keys_mirror_fill(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models,

@@ -628,12 +628,12 @@ __global__ __launch_bounds__(SHARED_THREADS) void k_skin_shared(const SkinInstan
 // The price: vertex records are no longer register-resident; they stream through a PIPE-deep software pipeline as in k_skin_vertices
 // (64 / I distinct records per wave-step, every one shared by I lanes: 32 / I bytes of L2 traffic per output), and a store instruction
 // writes I runs of 64 / I consecutive vertices (I = 4: four runs of 192 bytes) instead of one run of 768 bytes.
-template <int COLS, int I, int MODE, int PIPE>
+template <int COLS, int I, int MODE, int PIPE, int THREADS>
 __device__ __forceinline__ void skin_multi_tile(const SkinInstance& in0, const SkinChunk& ch, float4* s_rows, const float4* __restrict__ mesh,
 	const float4* __restrict__ palette, float* __restrict__ out) {
 	static_assert(I >= 1 && I <= COLS && (COLS % I) == 0 && (64 % I) == 0, "instances per block divide the bank columns");
 	constexpr uint32_t VPW = 64 / I;                   // vertices per wave-step
-	constexpr uint32_t VPB = VPW * (SKIN_THREADS / 64); // vertices per block-step: consecutive across the block's waves
+	constexpr uint32_t VPB = VPW * (THREADS / 64); // vertices per block-step: consecutive across the block's waves
 	constexpr uint32_t ROWS = skin_rows(MODE);
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const uint32_t last_inst = ch.count - 1;            // 1 <= count <= I; lanes of missing instances redo the last one (same bytes, same place)
@@ -644,18 +644,18 @@ __device__ __forceinline__ void skin_multi_tile(const SkinInstance& in0, const S
 		const uint32_t items = in0.n_bones * ROWS * COLS;
 		// consecutive lanes fill consecutive columns of one row: conflict-free ds_write_b128; the COLS / I lanes of one instance fetch the same
 		// 16 bytes. All of a lane's loads go out before the first is written (items past the palette's end re-read its first row).
-		constexpr uint32_t PER_LANE = SKIN_LDS_SLOTS / SKIN_THREADS;
+		constexpr uint32_t PER_LANE = SKIN_LDS_SLOTS / THREADS;
 		float4 t[PER_LANE];
 #pragma unroll
 		for (uint32_t k = 0; k < PER_LANE; ++k) {
-			const uint32_t w = tid + k * SKIN_THREADS;
+			const uint32_t w = tid + k * THREADS;
 			t[k] = pal[w < items ? min((w % COLS) % I, last_inst) * pal_stride + w / COLS : 0u];
 		}
 #pragma unroll
 		for (uint32_t k = 0; k < PER_LANE; ++k) asm volatile("" : "+v"(t[k].x), "+v"(t[k].y), "+v"(t[k].z), "+v"(t[k].w)); // used HERE by every lane: the loads are not sunk into the branches below
 #pragma unroll
 		for (uint32_t k = 0; k < PER_LANE; ++k) {
-			const uint32_t w = tid + k * SKIN_THREADS;
+			const uint32_t w = tid + k * THREADS;
 			if (w < items) s_rows[w] = t[k];
 		}
 	}
@@ -696,15 +696,19 @@ __device__ __forceinline__ void skin_multi_tile(const SkinInstance& in0, const S
 #ifndef LMX_MULTI_PIPE
 #define LMX_MULTI_PIPE 2
 #endif
+#ifndef LMX_MULTI_THREADS
+#define LMX_MULTI_THREADS 512 // 512: three 8-wave blocks per CU (48 KiB of LDS each); 1024: two 16-wave blocks (32 waves per CU, the VGPR budget of 64 holds)
+#endif
+constexpr int MULTI_THREADS = LMX_MULTI_THREADS;
 template <int I, int MODE>
-__global__ __launch_bounds__(SKIN_THREADS, SKIN_WAVES_PER_SIMD) void k_skin_multi(const SkinInstance* __restrict__ inst, const SkinChunk* __restrict__ chunks,
+__global__ __launch_bounds__(MULTI_THREADS, MULTI_THREADS == 1024 ? 8 : SKIN_WAVES_PER_SIMD) void k_skin_multi(const SkinInstance* __restrict__ inst, const SkinChunk* __restrict__ chunks,
 	const float4* __restrict__ mesh, const float4* __restrict__ palette, float* __restrict__ out) {
 	__shared__ float4 s_rows[SKIN_LDS_SLOTS];
 	const SkinChunk ch = chunks[blockIdx.x];
 	const SkinInstance in0 = inst[ch.first_inst];
-	if (in0.n_bones <= 64) skin_multi_tile<16, I, MODE, LMX_MULTI_PIPE>(in0, ch, s_rows, mesh, palette, out);
-	else if (in0.n_bones <= 128) skin_multi_tile<8, (I < 8 ? I : 8), MODE, LMX_MULTI_PIPE>(in0, ch, s_rows, mesh, palette, out);
-	else skin_multi_tile<4, (I < 4 ? I : 4), MODE, LMX_MULTI_PIPE>(in0, ch, s_rows, mesh, palette, out);
+	if (in0.n_bones <= 64) skin_multi_tile<16, I, MODE, LMX_MULTI_PIPE, MULTI_THREADS>(in0, ch, s_rows, mesh, palette, out);
+	else if (in0.n_bones <= 128) skin_multi_tile<8, (I < 8 ? I : 8), MODE, LMX_MULTI_PIPE, MULTI_THREADS>(in0, ch, s_rows, mesh, palette, out);
+	else skin_multi_tile<4, (I < 4 ? I : 4), MODE, LMX_MULTI_PIPE, MULTI_THREADS>(in0, ch, s_rows, mesh, palette, out);
 }
 
 } // namespace
@@ -718,7 +722,7 @@ uint32_t skin_multi_instances(uint32_t per_block, uint32_t n_bones) {
 template <int I>
 static hipError_t launch_skin_multi_i(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh, const float4* palette,
 	float* out, int mode) {
-	const dim3 grid(n_chunks), block(SKIN_THREADS);
+	const dim3 grid(n_chunks), block(MULTI_THREADS);
 	if (mode == LMX_SKIN_EXACT) hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_EXACT>), grid, block, 0, s, inst, chunks, mesh, palette, out);
 	else if (mode == LMX_SKIN_DQS) hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_DQS>), grid, block, 0, s, inst, chunks, mesh, palette, out);
 	else hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_FUSED>), grid, block, 0, s, inst, chunks, mesh, palette, out);

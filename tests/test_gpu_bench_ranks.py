@@ -27,7 +27,14 @@ def run_bench(extra, port):
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
     assert p.returncode == 0 and len(lines) == 1, p.stderr.decode(errors="replace")[-4000:]
-    return json.loads(lines[0])
+    assert len(lines[0]) <= 4096, "the one stdout line stays compact with N > 1 too"
+    line = json.loads(lines[0])
+    full = json.load(open(os.path.join(ROOT, "bench_extra.json")))  # rank 0's full record of the same run
+    assert full["value"] == line["value"] and full["n_gpus"] == line["n_gpus"]
+    for k in ("ranks_seen_by_rccl", "allgather_visible_counts"):
+        assert line["config"][k] == full["config"][k]
+    assert "ms_per_frame_max_over_ranks" in line["config"]["config4_frame"]
+    return full
 
 
 def check_contract(r):
@@ -44,6 +51,9 @@ def test_bench_weak_two_ranks():
     c4 = r["config"]["config4_frame"]  # the strong-scaling frame of BASELINE config 4 rides along the weak run
     assert "error" not in c4 and c4["scaling"] == "strong" and c4["skinned_instances_this_rank"] == 1000 and c4["frames_per_sec"] > 0
     assert 0 < c4["visible_total"] <= 1_000_000
+    c5 = r["config"]["config5_frame"]  # BASELINE config 5's frame (8 cascades, ONE collective) is part of the default --gpus N path
+    assert "error" not in c5 and c5["own_sub_records_equal_local_cull"] is True and c5["ms_per_frame_max_over_ranks"] > 0
+    assert len(c5["visible_per_rank_and_frustum"]) == 2 and len(c5["visible_per_rank_and_frustum"][0]) == 8
 
 
 def test_bench_strong_two_ranks():
