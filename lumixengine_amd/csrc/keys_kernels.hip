@@ -53,48 +53,9 @@ __device__ __forceinline__ uint32_t float_flip(uint32_t bits) {
 	return bits ^ mask;
 }
 
-static_assert(KEYS_TILE == 512, "host and kernel agree on the tile");
 constexpr int KEYS_BLOCK = 512; // entities per tile = threads per block. 8 waves: 3 blocks per CU (79 VGPRs: 6 waves per SIMD). Tiles of 256 / 1024 entities measured slower (161.8 / 145.0 against 138.1 us for the whole chain, round 3's driver box)
-// ---- tile reservations by decoupled look-back (round 4) ---------------------------------------------------------------------------------
-// Rounds 1-3 reserved a tile's output ranges with two returning atomics on two fixed addresses; returning atomics on one line retire at
-// ~90 per microsecond chip-wide, so 2048 tiles queue for ~23 us of a 60-90 us kernel, in the middle of every block. Now a tile takes
-// a TICKET (one atomic, issued when the tile starts: its latency hides behind the tile's loads) and publishes its (pairs, recs) /
-// (poses, dirty) counts in the ticket's own descriptor words; its bases are the sums over the tickets before it, read from THEIR words.
-// A word is one naturally aligned 8-byte granule {status:2 | a:31 | b:31} written with ONE agent-scope store and read with agent-scope
-// loads (per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs: MI355X_MICROARCH.md "Workgroup dispatch"); status 1 =
-// the tile's own counts, 2 = the inclusive prefix up to and including the tile. Order independence: a ticket is only ever taken by a
-// RUNNING block, and every ticket's owner publishes without waiting for anybody - a waiter only waits for blocks that are executing,
-// whatever order the hardware (or the simulated device) starts blocks in. Output ORDER is ticket order: as arbitrary as with the atomics.
-constexpr uint64_t DESC_COUNTS = 1ull << 62, DESC_PREFIX = 2ull << 62, DESC_VALUE = (1ull << 62) - 1;
-__device__ __forceinline__ uint64_t desc_pack(uint32_t a, uint32_t b) { return (uint64_t)a | ((uint64_t)b << 31); }
-__device__ __forceinline__ uint64_t desc_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void desc_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// exclusive prefix of word `which` (0 / 1) over tickets [0, ticket), by ONE wave: lane l looks at ticket - 1 - l of the window
-__device__ __forceinline__ uint64_t desc_look_back(const uint64_t* desc, uint32_t ticket, uint32_t which, uint32_t lane, uint32_t* counters) {
-	uint64_t sum = 0;
-	for (int64_t window = (int64_t)ticket - 1; window >= 0; window -= 64) { // wave-uniform
-		const int64_t idx = window - (int64_t)lane;
-		uint64_t w = DESC_PREFIX; // lanes before ticket 0: a prefix of zero
-		if (idx >= 0) {
-			uint32_t spins = 0;
-			while (((w = desc_load(desc + 2 * (size_t)idx + which)) >> 62) == 0) {
-				__builtin_amdgcn_s_sleep(2);
-				if (++spins > (1u << 22)) { counters[KEYS_OVERFLOW] = 3; w = DESC_PREFIX; break; } // a bounded spin: seconds, never reached by a running owner
-			}
-		}
-		const uint64_t has_prefix = __ballot((w >> 62) == 2);
-		const uint32_t first = has_prefix ? (uint32_t)__ffsll((long long)has_prefix) - 1u : 64u; // the nearest ticket that already knows its prefix
-		uint64_t v = lane <= first ? (w & DESC_VALUE) : 0; // both 31-bit fields add without carrying into each other (totals < 2^31)
-#pragma unroll
-		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-		sum += v;
-		if (has_prefix) break;
-	}
-	return sum;
-}
-
 #ifndef LMX_KEYS_MM_REGS
-#define LMX_KEYS_MM_REGS 4 // 3: no scratch at the 80-VGPR budget (6 waves per SIMD), 4: 12 bytes, 6: 32 bytes
+#define LMX_KEYS_MM_REGS 6 // every mesh of two LODs of three
 #endif
 constexpr int KEYS_MM_REGS = LMX_KEYS_MM_REGS; // meshes of an entity's LOD range(s) whose materials stay in registers between the count and the emit
 constexpr int KEYS_STAGE_PAIRS = 3 * KEYS_BLOCK; // pairs (24 KiB) and records (18 KiB) of one 512-entity tile held in LDS
@@ -104,7 +65,7 @@ constexpr int KEYS_STAGE_PAIRS = 3 * KEYS_BLOCK; // pairs (24 KiB) and records (
 // ~90 per microsecond chip-wide: one per wave and mesh was 15x slower than this kernel's memory work), and a second walk writes at
 // lane-private positions.
 #ifndef LMX_KEYS_MIN_WAVES
-#define LMX_KEYS_MIN_WAVES 6 // waves per SIMD the register allocation aims at. 8 (64 VGPRs + 44 B of scratch per lane) measured no gain: 91.3 / 95.2 us against 89.3 / 91.3 (tools/scratch/keys_ab.sh) - the kernel is not short of waves
+#define LMX_KEYS_MIN_WAVES 4 // waves per SIMD the register allocation aims at: 106 VGPRs, no scratch, two 8-wave blocks per CU. Round 4 (profiles/r04/keys_ab.txt, k_keys_mesh per 1.05 M visible): 6 waves (80 VGPRs, 32-44 B of scratch, three blocks) 65.5-70.5 us, 5 waves 59.1, 4 waves 60.2 - the kernel is not short of waves, spills cost it more
 #endif
 __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(KeysDevice d, const KeysViewDevice kv /* by value: captured at launch */,
 	const int32_t* __restrict__ ids, const int32_t* __restrict__ slots /* optional: static-set slot per id, -1 = dynamic set */, const uint32_t* __restrict__ n_visible) {
@@ -118,8 +79,6 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 	const uint32_t copy = blockIdx.x & (d.n_copies - 1); // this block's private row of the group counters
 	for (uint32_t tile = blockIdx.x * KEYS_BLOCK; tile < n; tile += gridDim.x * KEYS_BLOCK) {
 		const uint32_t i = tile + threadIdx.x;
-		uint32_t ticket = 0; // (thread 0) this tile's place in the reservation order; needed after the count, issued now
-		if (d.desc != nullptr && threadIdx.x == 0) ticket = atomicAdd(d.counters + KEYS_TICKET, 1u);
 		// ranges of mesh indices this lane emits keys for: [from0, to0] then [from1, to1]
 		int32_t from0 = 0, to0 = -1, from1 = 0, to1 = -1;
 		uint32_t e = 0, pose_stamp = 0;
@@ -264,29 +223,9 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		const uint64_t pose_mask = __ballot(push_pose), dirty_mask = __ballot(queue_dirty);
 		if (lane == 63) { s_wave[wave][0] = incl; s_wave[wave][1] = (uint32_t)__popcll(pose_mask); s_wave[wave][2] = (uint32_t)__popcll(dirty_mask); }
 		__syncthreads();
-		if (d.desc != nullptr) {
-			if (wave == 0) { // look-back: wave 0 sums the block's counts, publishes them and adds up the tickets before its own
-				const uint32_t t = (uint32_t)__shfl((int)ticket, 0);
-				uint32_t c[4] = {0, 0, 0, 0}; // pairs, recs, poses, dirty
-				for (int w = 0; w < KEYS_BLOCK / 64; ++w) { c[0] += s_wave[w][0] & 0xffffu; c[1] += s_wave[w][0] >> 16; c[2] += s_wave[w][1]; c[3] += s_wave[w][2]; }
-				uint64_t* mine = d.desc + 2 * (size_t)t;
-				const uint64_t own0 = desc_pack(c[0], c[1]), own1 = desc_pack(c[2], c[3]);
-				if (lane == 0 && t != 0) { desc_store(mine, DESC_COUNTS | own0); desc_store(mine + 1, DESC_COUNTS | own1); }
-				const uint64_t before0 = desc_look_back(d.desc, t, 0, lane, d.counters), before1 = desc_look_back(d.desc, t, 1, lane, d.counters);
-				if (lane == 0) {
-					desc_store(mine, DESC_PREFIX | (before0 + own0));
-					desc_store(mine + 1, DESC_PREFIX | (before1 + own1));
-					s_base[0] = (uint32_t)(before0 & 0x7fffffffu); s_base[1] = (uint32_t)(before0 >> 31);
-					s_base[2] = (uint32_t)(before1 & 0x7fffffffu); s_base[3] = (uint32_t)(before1 >> 31);
-					s_base[4] = c[0]; s_base[5] = c[1];
-					if ((t + 1) * (uint32_t)KEYS_BLOCK >= n) { // the last ticket: the lists' lengths (the decal / group kernels append behind them)
-						const uint64_t all0 = before0 + own0, all1 = before1 + own1;
-						d.counters[KEYS_N_PAIRS] = (uint32_t)(all0 & 0x7fffffffu); d.counters[KEYS_N_RECS] = (uint32_t)(all0 >> 31);
-						d.counters[KEYS_N_POSES] = (uint32_t)(all1 & 0x7fffffffu); d.counters[KEYS_N_DIRTY] = (uint32_t)(all1 >> 31);
-					}
-				}
-			}
-		} else if (threadIdx.x < 2) { // (LMX_KEYS_OPT_LOOK_BACK 0) thread 0: {pairs, recs}, thread 1: {poses, dirty} - one 64-bit returning atomic each, on two cache lines
+		if (threadIdx.x < 2) { // thread 0: {pairs, recs}, thread 1: {poses, dirty} - one 64-bit returning atomic each, on two cache lines. (Measured and NOT kept, round 4:
+			// a ticket per tile + decoupled look-back over per-tile descriptor words, agent-scope loads / stores - 81-88 us against 60-70 us with the atomics,
+			// profiles/r04/keys_ab_look_back.txt: the serial chain of cross-XCD hand-offs costs more than ~90 same-address atomics per microsecond.)
 			uint32_t lo = 0, hi = 0;
 			for (int w = 0; w < KEYS_BLOCK / 64; ++w) {
 				lo += threadIdx.x == 0 ? (s_wave[w][0] & 0xffffu) : s_wave[w][1];

@@ -222,10 +222,6 @@ int lmx_keys_set_option(LmxContext* ctx, int option, int value) {
 		}
 		return LMX_OK;
 	}
-	if (option == LMX_KEYS_OPT_LOOK_BACK) {
-		ks.look_back = value != 0;
-		return LMX_OK;
-	}
 	if (option != LMX_KEYS_OPT_SLOT_ORDER) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "unknown sort-key option %d", option);
 	if (!value) {
 		if (int rc = keys_before_layout_change(ctx)) return rc; // hand the state back, drop the mirror
@@ -287,11 +283,7 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	LMX_HIP(ctx, ks.d_groups.reserve(2 * n_copies * g + g + g + 1));
 	LMX_HIP(ctx, ks.d_poses.reserve(std::max<size_t>(mesh_cap, 1)));
 	LMX_HIP(ctx, ks.d_dirty_list.reserve(std::max<size_t>(mesh_cap, 1)));
-	// the tiles' look-back descriptors (2 x 8 bytes per tile) live behind the counters: one memset clears both. Their 31-bit fields hold
-	// list lengths: capacities of 2^31 and more keep the atomic reservations
-	const size_t n_tiles = ((size_t)mesh_cap + KEYS_TILE - 1) / KEYS_TILE;
-	const bool look_back = ks.look_back && cap_pairs < 0x7fffffffull && mesh_cap != 0;
-	LMX_HIP(ctx, ks.d_counters.reserve(KEYS_COUNTERS + (look_back ? 4 * n_tiles : 0)));
+	LMX_HIP(ctx, ks.d_counters.reserve(KEYS_COUNTERS));
 
 	if (ks.inst_dirty) { // the host mirror changed (tables or positions): lod / Pose::frame restart from the uploaded values
 		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -313,7 +305,7 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 		if (int rc = keys_before_layout_change(ctx)) return rc;
 	}
 	ProfScope ps(ctx, LMX_K_SORT_KEYS);
-	LMX_HIP(ctx, hipMemsetAsync(ks.d_counters.p, 0, (KEYS_COUNTERS + (look_back ? 4 * n_tiles : 0)) * sizeof(uint32_t), ctx->stream));
+	LMX_HIP(ctx, hipMemsetAsync(ks.d_counters.p, 0, KEYS_COUNTERS * sizeof(uint32_t), ctx->stream));
 	LMX_HIP(ctx, hipMemsetAsync(ks.d_groups.p, 0, n_copies * g * sizeof(uint32_t), ctx->stream));
 	KeysDevice d;
 	memset(&d, 0, sizeof(d));
@@ -342,7 +334,6 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	d.group_values = ks.d_group_values.p;
 	d.poses = ks.d_poses.p; d.dirty_list = ks.d_dirty_list.p; d.cap_list = mesh_cap;
 	d.counters = ks.d_counters.p;
-	d.desc = look_back ? reinterpret_cast<uint64_t*>(ks.d_counters.p + KEYS_COUNTERS) : nullptr;
 	if (int rc = cull_view_consolidate(ctx, v)) return rc; // the key kernels walk one contiguous list per type
 	const int32_t* row = v.cons_ptr() + (size_t)frustum * v.out_stride;
 	const uint32_t* counts = v.totals_ptr() + (size_t)frustum * MAX_TYPES;

@@ -361,11 +361,12 @@ static int skin_build_multi_chunks(LmxContext* ctx) {
 		const uint32_t range = ((in.n_verts + splits - 1) / splits + 63u) & ~63u;
 		for (uint32_t f = 0; f < r.count; f += per)
 			for (uint32_t v = 0; v < in.n_verts; v += range)
-				sk.multi_chunks.push_back(SkinChunk{r.first + f, std::min(per, r.count - f), v, std::min(in.n_verts, v + range), in.vert_offset, 0u, 0u, 0u});
+				sk.multi_chunks.push_back(SkinMultiChunk{sk.inst[r.first + f].bone_offset, in.n_bones, std::min(per, r.count - f), v, std::min(in.n_verts, v + range), in.vert_offset,
+					in.n_verts, sk.inst[r.first + f].out_offset});
 	}
 	LMX_HIP(ctx, sk.d_multi_chunks.reserve(std::max<size_t>(sk.multi_chunks.size(), 1)));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (a launch of the previous frame may still read the old list)
-	if (!sk.multi_chunks.empty()) LMX_HIP(ctx, hipMemcpy(sk.d_multi_chunks.p, sk.multi_chunks.data(), sk.multi_chunks.size() * sizeof(SkinChunk), hipMemcpyHostToDevice));
+	if (!sk.multi_chunks.empty()) LMX_HIP(ctx, hipMemcpy(sk.d_multi_chunks.p, sk.multi_chunks.data(), sk.multi_chunks.size() * sizeof(SkinMultiChunk), hipMemcpyHostToDevice));
 	sk.multi_built = sk.multi;
 	return LMX_OK;
 }
@@ -391,7 +392,7 @@ int lmx_skin_run(LmxContext* ctx) {
 		const float4* vertex_palette = sk.mode == LMX_SKIN_DQS ? sk.d_dual_quats.p : sk.d_palette.p;
 		if (!sk.chunks.empty() && sk.multi) { // runs of instances that share a mesh, several instances per block (every mode)
 			if (int rc = skin_build_multi_chunks(ctx)) return rc;
-			LMX_HIP(ctx, launch_skin_multi(ctx->stream, sk.multi, sk.d_inst.p, sk.d_multi_chunks.p, (uint32_t)sk.multi_chunks.size(), sk.d_mesh.p, vertex_palette, sk.d_out.p, sk.mode));
+			LMX_HIP(ctx, launch_skin_multi(ctx->stream, sk.multi, sk.d_multi_chunks.p, (uint32_t)sk.multi_chunks.size(), sk.d_mesh.p, vertex_palette, sk.d_out.p, sk.mode));
 			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, sk.d_solo.p, (uint32_t)sk.solo.size(), sk.solo_max_verts, sk.d_mesh.p, vertex_palette, sk.d_out.p, sk.mode));
 		} else if (sk.chunks.empty() || sk.mode == LMX_SKIN_DQS) { // (DQS: k_skin_shared's resident records leave too few registers for the dual-quaternion blend)
 			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, nullptr, n, sk.max_verts, sk.d_mesh.p, vertex_palette,

@@ -324,8 +324,8 @@ struct SkinState {
 	std::vector<SkinChunk> chunks;     // k_skin_shared work items (runs of instances sharing a mesh)
 	struct Run { uint32_t first, count, mesh; };
 	std::vector<Run> runs;             // the runs themselves (lmx_skin_set_instances): k_skin_multi's work items are cut from them at run time
-	std::vector<SkinChunk> multi_chunks;
-	DevBuf<SkinChunk> d_multi_chunks;
+	std::vector<SkinMultiChunk> multi_chunks;
+	DevBuf<SkinMultiChunk> d_multi_chunks;
 	uint32_t multi = 0;                // LMX_SKIN_OPT_INSTANCES_PER_BLOCK (0: k_skin_shared)
 	uint32_t multi_built = 0;          // the value multi_chunks were cut for (0: stale)
 	std::vector<uint32_t> solo;        // instances skinned by k_skin_vertices (empty + no chunks = all of them)
@@ -402,7 +402,6 @@ struct KeysState {
 	DevBuf<int32_t> d_soa_model;
 	DevBuf<uint32_t> d_soa_mat;
 	DevBuf<uint16_t> d_soa_flags;
-	bool look_back = true; // LMX_KEYS_OPT_LOOK_BACK: tile reservations by ticket + decoupled look-back instead of two same-address atomics
 	int split_state = LMX_KEYS_SPLIT_STATE_DEFAULT; // 0: AoS mirror, 1: + lod / Pose::frame in d_state_s, 2: structure-of-arrays mirror
 	int mirror_split = 0;            // the form the current mirror was built in
 	KeysSoA soa() const { // the current mirror's arrays (all null unless it was built as a structure of arrays)

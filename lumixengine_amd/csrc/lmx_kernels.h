@@ -197,8 +197,7 @@ hipError_t launch_anim_update(hipStream_t s, const SkinInstance* inst, uint32_t 
 // Counter words. {pairs, recs} and {poses, dirty} are two 64-bit cells on their own 128-byte lines: k_keys_mesh reserves a tile's four
 // output ranges with two returning atomics on two lines instead of four on one (measured: no change of the kernel's 124 us per
 // million visible entities - it is bound by its random 64-byte gathers and line write-backs, see DESIGN.md - but half the atomics).
-enum { KEYS_N_PAIRS = 0, KEYS_N_RECS = 1, KEYS_N_POSES = 32, KEYS_N_DIRTY = 33, KEYS_OVERFLOW = 64, KEYS_N_GROUPS = 96, KEYS_TICKET = 128, KEYS_COUNTERS = 160 };
-constexpr uint32_t KEYS_TILE = 512; // entities per tile of k_keys_mesh (keys_kernels.hip: KEYS_BLOCK): one look-back descriptor (2 x 8 bytes) per tile
+enum { KEYS_N_PAIRS = 0, KEYS_N_RECS = 1, KEYS_N_POSES = 32, KEYS_N_DIRTY = 33, KEYS_OVERFLOW = 64, KEYS_N_GROUPS = 96, KEYS_COUNTERS = 128 };
 struct KeysViewDevice { // what the kernels read of a LmxKeysView, bucket_map as built at pipeline.cpp:3802-3812
 	uint32_t bucket_map[255];
 	uint8_t layer_to_bucket[255];
@@ -265,7 +264,6 @@ struct KeysDevice {
 	int32_t *poses, *dirty_list;
 	uint32_t cap_list;
 	uint32_t* counters;       // KEYS_*
-	uint64_t* desc;           // look-back descriptors, 2 words per tile, zeroed before the launch; nullptr: the tiles reserve with atomics (LMX_KEYS_OPT_LOOK_BACK 0)
 };
 hipError_t launch_keys_mirror_count(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models, uint32_t* count);
 hipError_t launch_keys_mirror_fill(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models,
@@ -293,11 +291,13 @@ hipError_t launch_skin_vertices(hipStream_t s, const SkinInstance* inst, const u
 // the same for runs of consecutive instances that share a mesh and a bone count (vertex records held in registers)
 hipError_t launch_skin_shared(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh_local,
 	const uint8_t* tile_bones, const float4* palette, float* out, int mode);
-// k_skin_multi: `per_block` instances per block (1, 2, 4, 8, 16; capped by skin_multi_instances for models above 64 bones); chunks =
-// (first_inst, count, [v_begin, v_end), rec_offset = the mesh's first record in `mesh` (global bone indices))
+// k_skin_multi: `per_block` instances per block (1, 2, 4, 8, 16; capped by skin_multi_instances for models above 64 bones). A work item
+// carries everything the block needs (ONE dependent load at block start, not chunk -> instance -> palette): `count` consecutive
+// instances of one model and one mesh - their palettes start at bone `bone_offset` (n_bones each), their outputs at vertex `out_offset`
+// (n_verts each) - and the vertex range [v_begin, v_end) of the mesh whose first record in `mesh` (global bone indices) is rec_offset.
+struct SkinMultiChunk { uint32_t bone_offset, n_bones, count, v_begin, v_end, rec_offset, n_verts, out_offset; };
 uint32_t skin_multi_instances(uint32_t per_block, uint32_t n_bones);
-hipError_t launch_skin_multi(hipStream_t s, uint32_t per_block, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh,
-	const float4* palette, float* out, int mode);
+hipError_t launch_skin_multi(hipStream_t s, uint32_t per_block, const SkinMultiChunk* chunks, uint32_t n_chunks, const float4* mesh, const float4* palette, float* out, int mode);
 constexpr uint32_t SKIN_SHARED_TILE_VERTS = 5120; // k_skin_shared: 1024 lanes x 5 vertex records
 
 } // namespace lmx

@@ -629,8 +629,8 @@ __global__ __launch_bounds__(SHARED_THREADS) void k_skin_shared(const SkinInstan
 // (64 / I distinct records per wave-step, every one shared by I lanes: 32 / I bytes of L2 traffic per output), and a store instruction
 // writes I runs of 64 / I consecutive vertices (I = 4: four runs of 192 bytes) instead of one run of 768 bytes.
 template <int COLS, int I, int MODE, int PIPE, int THREADS>
-__device__ __forceinline__ void skin_multi_tile(const SkinInstance& in0, const SkinChunk& ch, float4* s_rows, const float4* __restrict__ mesh,
-	const float4* __restrict__ palette, float* __restrict__ out) {
+__device__ __forceinline__ void skin_multi_tile(const SkinMultiChunk& ch, float4* s_rows, const float4* __restrict__ mesh,
+	const float4* __restrict__ palette, float* __restrict__ out, uint32_t& sink0, uint32_t& sink1 /* destinations of the caller's uncounted touches */) {
 	static_assert(I >= 1 && I <= COLS && (COLS % I) == 0 && (64 % I) == 0, "instances per block divide the bank columns");
 	constexpr uint32_t VPW = 64 / I;                   // vertices per wave-step
 	constexpr uint32_t VPB = VPW * (THREADS / 64); // vertices per block-step: consecutive across the block's waves
@@ -638,10 +638,21 @@ __device__ __forceinline__ void skin_multi_tile(const SkinInstance& in0, const S
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const uint32_t last_inst = ch.count - 1;            // 1 <= count <= I; lanes of missing instances redo the last one (same bytes, same place)
 	const uint32_t inst_l = min(lane % I, last_inst);
-	const size_t pal_stride = (size_t)in0.n_bones * ROWS; // float4 per instance: consecutive instances, consecutive palettes
+	const size_t pal_stride = (size_t)ch.n_bones * ROWS; // float4 per instance: consecutive instances, consecutive palettes
+	const float4* rows = s_rows + (lane & (COLS - 1));
+	const float4* mbase = mesh + 2 * (size_t)ch.rec_offset;
+	F3* obase = reinterpret_cast<F3*>(out) + ch.out_offset + (size_t)inst_l * ch.n_verts; // per-lane base: the lane's instance
+	const uint32_t v_last = ch.v_end - 1; // chunks are never empty
+	const uint32_t v0 = ch.v_begin + wave * VPW + lane / I;
+	auto load = [&](uint32_t v) { return load_vertex(mbase, v); };
+	// the first PIPE vertex records and the palette rows: ONE round trip - all loads go out before anything waits
+	RawVertex rec[PIPE];
+#pragma unroll
+	for (int d = 0; d < PIPE; ++d) rec[d] = load(min(v0 + d * VPB, v_last));
+	__builtin_amdgcn_sched_barrier(0); // (issued here, ahead of the palette's loads and waits; an asm use of the records would WAIT for them here)
 	{
-		const float4* pal = palette + (size_t)in0.bone_offset * ROWS;
-		const uint32_t items = in0.n_bones * ROWS * COLS;
+		const float4* pal = palette + (size_t)ch.bone_offset * ROWS;
+		const uint32_t items = ch.n_bones * ROWS * COLS;
 		// consecutive lanes fill consecutive columns of one row: conflict-free ds_write_b128; the COLS / I lanes of one instance fetch the same
 		// 16 bytes. All of a lane's loads go out before the first is written (items past the palette's end re-read its first row).
 		constexpr uint32_t PER_LANE = SKIN_LDS_SLOTS / THREADS;
@@ -659,21 +670,11 @@ __device__ __forceinline__ void skin_multi_tile(const SkinInstance& in0, const S
 			if (w < items) s_rows[w] = t[k];
 		}
 	}
-	const float4* rows = s_rows + (lane & (COLS - 1));
-	const float4* mbase = mesh + 2 * (size_t)ch.rec_offset;
-	F3* obase = reinterpret_cast<F3*>(out) + in0.out_offset + (size_t)inst_l * in0.n_verts; // per-lane base: the lane's instance
-	const uint32_t v_last = ch.v_end - 1; // chunks are never empty
-	const uint32_t v0 = ch.v_begin + wave * VPW + lane / I;
-	auto load = [&](uint32_t v) { return load_vertex(mbase, v); };
-	RawVertex rec[PIPE];
-#pragma unroll
-	for (int d = 0; d < PIPE; ++d) rec[d] = load(min(v0 + d * VPB, v_last));
-#pragma unroll
-	for (int d = 0; d < PIPE; ++d) asm volatile("" : "+v"(rec[d].a), "+v"(rec[d].b)); // (issued here, ahead of the wait below)
 	// every load so far is complete before the loop: with loads possibly pending at the loop's entry the compiler merges that state into
 	// the steady state and tightens the wait at the loop head to cover the previous step's STORE (seen in the ISA: vmcnt(2) instead of
 	// vmcnt(2 * PIPE)). vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding).
 	__builtin_amdgcn_s_waitcnt(0x0F70);
+	asm volatile("" : : "v"(sink0), "v"(sink1)); // (the touches have landed: their registers are free from here on)
 	__syncthreads();
 	const uint32_t n_steps = (ch.v_end - ch.v_begin + VPB - 1) / VPB; // block-uniform
 	// the pipeline of skin_tile: no branch around a load or a store (steps and lanes past the range's end are clamped to its last vertex),
@@ -700,15 +701,41 @@ __device__ __forceinline__ void skin_multi_tile(const SkinInstance& in0, const S
 #define LMX_MULTI_THREADS 512 // 512: three 8-wave blocks per CU (48 KiB of LDS each); 1024: two 16-wave blocks (32 waves per CU, the VGPR budget of 64 holds)
 #endif
 constexpr int MULTI_THREADS = LMX_MULTI_THREADS;
+#ifndef LMX_MULTI_PREFETCH
+#define LMX_MULTI_PREFETCH 768 // blocks ahead (a multiple of 8: block b and block b + 768 run on the same XCD, i.e. behind the same L2)
+#endif
 template <int I, int MODE>
-__global__ __launch_bounds__(MULTI_THREADS, MULTI_THREADS == 1024 ? 8 : SKIN_WAVES_PER_SIMD) void k_skin_multi(const SkinInstance* __restrict__ inst, const SkinChunk* __restrict__ chunks,
+__global__ __launch_bounds__(MULTI_THREADS, MULTI_THREADS == 1024 ? 8 : SKIN_WAVES_PER_SIMD) void k_skin_multi(const SkinMultiChunk* __restrict__ chunks, uint32_t n_chunks,
 	const float4* __restrict__ mesh, const float4* __restrict__ palette, float* __restrict__ out) {
 	__shared__ float4 s_rows[SKIN_LDS_SLOTS];
-	const SkinChunk ch = chunks[blockIdx.x];
-	const SkinInstance in0 = inst[ch.first_inst];
-	if (in0.n_bones <= 64) skin_multi_tile<16, I, MODE, LMX_MULTI_PIPE, MULTI_THREADS>(in0, ch, s_rows, mesh, palette, out);
-	else if (in0.n_bones <= 128) skin_multi_tile<8, (I < 8 ? I : 8), MODE, LMX_MULTI_PIPE, MULTI_THREADS>(in0, ch, s_rows, mesh, palette, out);
-	else skin_multi_tile<4, (I < 4 ? I : 4), MODE, LMX_MULTI_PIPE, MULTI_THREADS>(in0, ch, s_rows, mesh, palette, out);
+	const SkinMultiChunk ch = chunks[blockIdx.x];
+	uint32_t sink0 = 0, sink1 = 0;
+	if (LMX_MULTI_PREFETCH != 0) {
+		// A block cannot blend a vertex before its palettes are in LDS, and with the memory system saturated by 12 bytes of stores per
+		// vertex a palette row that has to come from HBM takes several microseconds of a ~40 us block (100 k instances: 307 MB of
+		// palettes, more than the Infinity Cache; measured 3.56 ms per 1e9 vertices against 2.45 with 20 k instances, whose palettes stay
+		// cached). So every block also TOUCHES the palettes of the block that will run where it runs now - block b + 768: three resident
+		// blocks on each of 256 CUs, and the same XCD (b % 8) - with loads whose results nobody waits for: by the time that block
+		// starts, its rows sit in its XCD's L2. The touches are issued before anything else, so the in-order vmcnt waits of the
+		// staging below cover them without counting them.
+		const uint32_t ahead = blockIdx.x + LMX_MULTI_PREFETCH;
+		if (ahead < n_chunks) { // block-uniform
+			const SkinMultiChunk nx = chunks[ahead];
+			const uint32_t pieces = (nx.n_bones * skin_rows(MODE) * nx.count + 3u) / 4u; // 64-byte pieces of the next block's palettes (contiguous): <= 588
+			const char* src = reinterpret_cast<const char*>(palette + (size_t)nx.bone_offset * skin_rows(MODE));
+#ifndef LMX_HOSTSIM
+			// 4 bytes of a piece pull all of it in. The destination registers stay allocated until the staging's vmcnt(0) (skin_multi_tile
+			// consumes them there): a load the compiler does not know about must not land in a register it has handed to something else.
+			if (threadIdx.x < pieces) asm volatile("global_load_dword %0, %1, off" : "=v"(sink0) : "v"(src + 64u * threadIdx.x) : "memory");
+			if (threadIdx.x + MULTI_THREADS < pieces) asm volatile("global_load_dword %0, %1, off" : "=v"(sink1) : "v"(src + 64u * (threadIdx.x + MULTI_THREADS)) : "memory");
+#else
+			(void)pieces; (void)src;
+#endif
+		}
+	}
+	if (ch.n_bones <= 64) skin_multi_tile<16, I, MODE, LMX_MULTI_PIPE, MULTI_THREADS>(ch, s_rows, mesh, palette, out, sink0, sink1);
+	else if (ch.n_bones <= 128) skin_multi_tile<8, (I < 8 ? I : 8), MODE, LMX_MULTI_PIPE, MULTI_THREADS>(ch, s_rows, mesh, palette, out, sink0, sink1);
+	else skin_multi_tile<4, (I < 4 ? I : 4), MODE, LMX_MULTI_PIPE, MULTI_THREADS>(ch, s_rows, mesh, palette, out, sink0, sink1);
 }
 
 } // namespace
@@ -720,25 +747,22 @@ uint32_t skin_multi_instances(uint32_t per_block, uint32_t n_bones) {
 }
 
 template <int I>
-static hipError_t launch_skin_multi_i(hipStream_t s, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh, const float4* palette,
-	float* out, int mode) {
+static hipError_t launch_skin_multi_i(hipStream_t s, const SkinMultiChunk* chunks, uint32_t n_chunks, const float4* mesh, const float4* palette, float* out, int mode) {
 	const dim3 grid(n_chunks), block(MULTI_THREADS);
-	if (mode == LMX_SKIN_EXACT) hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_EXACT>), grid, block, 0, s, inst, chunks, mesh, palette, out);
-	else if (mode == LMX_SKIN_DQS) hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_DQS>), grid, block, 0, s, inst, chunks, mesh, palette, out);
-	else hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_FUSED>), grid, block, 0, s, inst, chunks, mesh, palette, out);
+	if (mode == LMX_SKIN_EXACT) hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_EXACT>), grid, block, 0, s, chunks, n_chunks, mesh, palette, out);
+	else if (mode == LMX_SKIN_DQS) hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_DQS>), grid, block, 0, s, chunks, n_chunks, mesh, palette, out);
+	else hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_FUSED>), grid, block, 0, s, chunks, n_chunks, mesh, palette, out);
 	return hipGetLastError();
 }
 
-// chunks: (first_inst, count <= skin_multi_instances(per_block, bones), [v_begin, v_end), rec_offset = the mesh's first record in `mesh`)
-hipError_t launch_skin_multi(hipStream_t s, uint32_t per_block, const SkinInstance* inst, const SkinChunk* chunks, uint32_t n_chunks, const float4* mesh,
-	const float4* palette, float* out, int mode) {
+hipError_t launch_skin_multi(hipStream_t s, uint32_t per_block, const SkinMultiChunk* chunks, uint32_t n_chunks, const float4* mesh, const float4* palette, float* out, int mode) {
 	if (!n_chunks) return hipSuccess;
 	switch (per_block) {
-	case 1: return launch_skin_multi_i<1>(s, inst, chunks, n_chunks, mesh, palette, out, mode);
-	case 2: return launch_skin_multi_i<2>(s, inst, chunks, n_chunks, mesh, palette, out, mode);
-	case 4: return launch_skin_multi_i<4>(s, inst, chunks, n_chunks, mesh, palette, out, mode);
-	case 8: return launch_skin_multi_i<8>(s, inst, chunks, n_chunks, mesh, palette, out, mode);
-	case 16: return launch_skin_multi_i<16>(s, inst, chunks, n_chunks, mesh, palette, out, mode);
+	case 1: return launch_skin_multi_i<1>(s, chunks, n_chunks, mesh, palette, out, mode);
+	case 2: return launch_skin_multi_i<2>(s, chunks, n_chunks, mesh, palette, out, mode);
+	case 4: return launch_skin_multi_i<4>(s, chunks, n_chunks, mesh, palette, out, mode);
+	case 8: return launch_skin_multi_i<8>(s, chunks, n_chunks, mesh, palette, out, mode);
+	case 16: return launch_skin_multi_i<16>(s, chunks, n_chunks, mesh, palette, out, mode);
 	default: return hipErrorInvalidValue;
 	}
 }

@@ -320,10 +320,6 @@ template <typename T> static __forceinline__ T __shfl_xor(T v, int mask, int wid
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
 #define __builtin_amdgcn_s_sleep(imm) ((void)0)
-// agent-scope atomic loads / stores of the kernels' hand-off words: host atomics (blocks may run on several host threads)
-#define __HIP_MEMORY_SCOPE_AGENT 4
-#define __hip_atomic_load(p, order, scope) __atomic_load_n(p, order)
-#define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, order)
 #define __builtin_amdgcn_kernarg_segment_ptr() (::hostsim::tls.kernarg)
 // Cache hints mean nothing here. A 3-element vector is stored element by element: clang widens vec3 accesses to vec4 on x86
 // (16 bytes written), while the AMDGPU target keeps `store <3 x float>` (global_store_dwordx3, 12 bytes).

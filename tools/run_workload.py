@@ -36,8 +36,6 @@ def main():
         fr = api.viewport_frustum()
         ks = scenes.keys_scene(args.entities, sc["type"], seed=12, max_sort_key=255)
         sk = api.SortKeys(ctx)
-        if os.environ.get("LMX_WORKLOAD_KEYS_LOOK_BACK") is not None:  # A/B of the tile reservations: 0 = two same-address atomics per tile
-            sk.setOption(api.KEYS_OPT_LOOK_BACK, int(os.environ["LMX_WORKLOAD_KEYS_LOOK_BACK"]))
         sk.setModels(ks["models"], ks["mesh_types"])
         sk.setInstances(ks["model"], ks["material_offset"], ks["mesh_materials"], ks["lod"], ks["flags"], ks["dirty"], ks["pose_frame"])
         sk.setPositions(sc["pos"])

@@ -84,27 +84,28 @@ int main(int argc, char** argv) {
 	CK(hipMalloc(&d_mesh_local, mesh_local.size() * 16)); CK(hipMemcpy(d_mesh_local, mesh_local.data(), mesh_local.size() * 16, hipMemcpyHostToDevice));
 	CK(hipMalloc(&d_tile_bones, tile_bones.size())); CK(hipMemcpy(d_tile_bones, tile_bones.data(), tile_bones.size(), hipMemcpyHostToDevice));
 	SkinChunk* d_chunks; CK(hipMalloc(&d_chunks, chunks.size() * sizeof(SkinChunk))); CK(hipMemcpy(d_chunks, chunks.data(), chunks.size() * sizeof(SkinChunk), hipMemcpyHostToDevice));
+	const bool hot_palettes = argc > 5 && atoi(argv[5]) != 0; // k_skin_multi: every block reads the first instances' palettes (cache-resident): what the palette loads' latency costs
 	const int kind = argc > 3 ? atoi(argv[3]) : 1; // 0: k_skin_vertices, 1: k_skin_shared, 2: k_skin_multi for I = 1, 2, 4, 8, 16 (x vertex-range splits 1, 2, 4)
 	const bool shared = kind == 1;
 	printf("%s kernel, %zu chunks of %u instances\n", kind == 2 ? "multi" : shared ? "shared" : "streaming", chunks.size(), per_block);
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	if (kind == 2) {
-		for (uint32_t I : {1u, 2u, 4u, 8u, 16u})
-			for (uint32_t splits : {1u, 2u, 4u}) {
-				std::vector<SkinChunk> mc;
+		for (uint32_t I : {1u, 2u, 4u})
+			for (uint32_t splits : {1u, 2u}) {
+				std::vector<SkinMultiChunk> mc;
 				const uint32_t range = ((nv + splits - 1) / splits + 63u) & ~63u;
 				for (uint32_t f = 0; f < n_inst; f += I)
-					for (uint32_t v = 0; v < nv; v += range) mc.push_back(SkinChunk{f, n_inst - f < I ? n_inst - f : I, v, v + range < nv ? v + range : nv, 0u, 0u, 0u, 0u});
-				SkinChunk* d_mc; CK(hipMalloc(&d_mc, mc.size() * sizeof(SkinChunk))); CK(hipMemcpy(d_mc, mc.data(), mc.size() * sizeof(SkinChunk), hipMemcpyHostToDevice));
+					for (uint32_t v = 0; v < nv; v += range) mc.push_back(SkinMultiChunk{hot_palettes ? 0u : f * nb, nb, n_inst - f < I ? n_inst - f : I, v, v + range < nv ? v + range : nv, 0u, nv, f * nv});
+				SkinMultiChunk* d_mc; CK(hipMalloc(&d_mc, mc.size() * sizeof(SkinMultiChunk))); CK(hipMemcpy(d_mc, mc.data(), mc.size() * sizeof(SkinMultiChunk), hipMemcpyHostToDevice));
 				float best = 1e9f;
 				for (int it = 0; it < 5; ++it) {
 					CK(hipEventRecord(e0));
-					CK(launch_skin_multi(0, I, d_inst, d_mc, (uint32_t)mc.size(), d_mesh, d_pal, d_out, LMX_SKIN_FUSED));
+					CK(launch_skin_multi(0, I, d_mc, (uint32_t)mc.size(), d_mesh, d_pal, d_out, LMX_SKIN_FUSED));
 					CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
 					float ms; CK(hipEventElapsedTime(&ms, e0, e1));
 					if (it && ms < best) best = ms;
 				}
-				printf("multi I=%2u splits=%u pipe=%d (%zu blocks): %.4f ms  = %.3f ms per 1e9 verts\n", I, splits, LMX_MULTI_PIPE, mc.size(), best, best * 1e9 / ((double)n_inst * nv));
+				printf("multi I=%2u splits=%u pipe=%d prefetch=%d (%zu blocks): %.4f ms  = %.3f ms per 1e9 verts\n", I, splits, LMX_MULTI_PIPE, LMX_MULTI_PREFETCH, mc.size(), best, best * 1e9 / ((double)n_inst * nv));
 				CK(hipFree(d_mc));
 			}
 		return 0;
