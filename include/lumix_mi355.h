@@ -320,7 +320,7 @@ LMX_API int lmx_skin_set_mode(LmxContext* ctx, int mode);
 /* How runs of consecutive instances that share a mesh are skinned (evaluateSkin, model.cpp:103-109, is per vertex: the grouping is
  * ours). LMX_SKIN_OPT_INSTANCES_PER_BLOCK = I in {1, 2, 4, 8, 16}: k_skin_multi - one block stages the palettes of I instances ONCE
  * (the 16 bank columns of the LDS palette hold I instances x 16 / I copies) and streams the run's vertex records past them; 0:
- * k_skin_shared - one instance at a time against a register-resident vertex tile (rounds 2 / 3). Same results in every form
+ * k_skin_shared - one instance at a time against a register-resident vertex tile (rounds 2 / 3). Default 2. Same results in every form
  * (bit-identical positions in LMX_SKIN_EXACT). Takes effect at the next lmx_skin_run. */
 enum { LMX_SKIN_OPT_INSTANCES_PER_BLOCK = 0 };
 LMX_API int lmx_skin_set_option(LmxContext* ctx, int option, int value);

@@ -27,7 +27,7 @@ CULL_OPT_TILE_VARIANT, CULL_OPT_LANE_PARALLEL_TILE_TEST, CULL_OPT_MAX_SHARDS, CU
 KEYS_OPT_SLOT_ORDER, KEYS_OPT_SPLIT_STATE = 0, 1
 WORLD_OPT_FUSED_LEVELS = 0
 SKIN_OPT_INSTANCES_PER_BLOCK = 0
-SKIN_INSTANCES_PER_BLOCK_DEFAULT = 0  # what a fresh context uses (lmx_context.h: SkinState::multi)
+SKIN_INSTANCES_PER_BLOCK_DEFAULT = 2  # what a fresh context uses (lmx_context.h: SkinState::multi)
 (K_CULL_CLASSIFY, K_CULL_SPHERES, K_XFORM_LEVEL, K_SPHERE_REFRESH, K_POSE_PALETTE, K_SKIN_VERTICES, K_CULL_DYNAMIC) = range(7)
 KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices", "cull_dynamic", "sort_keys", "anim_update", "cull_patch"]
 K_CULL_PATCH = 9

@@ -302,6 +302,46 @@ __device__ __forceinline__ F3 skin_blend_rows(const float4* r0, const float4* r1
 	return F3{o[0], o[1], o[2]};
 }
 
+// LMX_SKIN_FUSED over the first N of the vertex's four bone slots (the others carry weight 0 for EVERY lane of the wave): the same
+// operations as skin_blend_rows minus the fused multiply-adds whose product is an exact zero - bit-identical for finite palettes -
+// and minus their 3 x ds_read_b128 per slot. A rigged character binds most vertices to one or two bones (the reference's demo
+// character: 1.17 influences per control point), and consecutive vertices follow the same limb: whole waves take N = 1.
+template <int COPIES, int N>
+__device__ __forceinline__ F3 skin_blend_fused_n(const float4* rows, const RawVertex& rec) {
+	const uint32_t idx = __float_as_uint(rec.b.w);
+	constexpr uint32_t STRIDE = 3 * COPIES;
+	const float4* r0 = rows + (idx & 0xffu) * STRIDE;
+	const float4* r1 = rows + ((idx >> 8) & 0xffu) * STRIDE;
+	const float4* r2 = rows + ((idx >> 16) & 0xffu) * STRIDE;
+	const float4* r3 = rows + (idx >> 24) * STRIDE;
+	const v2f w01 = {rec.a.x, rec.a.y}, w23 = {rec.a.z, rec.a.w};
+	const v2f wx = __builtin_shufflevector(w01, w01, 0, 0), wy = __builtin_shufflevector(w01, w01, 1, 1);
+	const v2f wz = __builtin_shufflevector(w23, w23, 0, 0), ww = __builtin_shufflevector(w23, w23, 1, 1);
+	float o[3];
+#pragma unroll
+	for (int r = 0; r < 3; ++r) {
+		const float4 A = r0[r * COPIES];
+		v2f m01 = v2f{A.x, A.y} * wx, m23 = v2f{A.z, A.w} * wx;
+		if constexpr (N >= 2) {
+			const float4 B = r1[r * COPIES];
+			m01 = __builtin_elementwise_fma(v2f{B.x, B.y}, wy, m01);
+			m23 = __builtin_elementwise_fma(v2f{B.z, B.w}, wy, m23);
+		}
+		if constexpr (N >= 3) {
+			const float4 C = r2[r * COPIES];
+			m01 = __builtin_elementwise_fma(v2f{C.x, C.y}, wz, m01);
+			m23 = __builtin_elementwise_fma(v2f{C.z, C.w}, wz, m23);
+		}
+		if constexpr (N >= 4) {
+			const float4 D = r3[r * COPIES];
+			m01 = __builtin_elementwise_fma(v2f{D.x, D.y}, ww, m01);
+			m23 = __builtin_elementwise_fma(v2f{D.z, D.w}, ww, m23);
+		}
+		o[r] = fmaf(m23.x, rec.b.z, fmaf(m01.y, rec.b.y, m01.x * rec.b.x)) + m23.y;
+	}
+	return F3{o[0], o[1], o[2]};
+}
+
 // `rows` already points at the lane's copy
 template <int COPIES, int MODE>
 __device__ __forceinline__ F3 skin_blend(const float4* rows, const RawVertex& r) {
@@ -628,6 +668,9 @@ __global__ __launch_bounds__(SHARED_THREADS) void k_skin_shared(const SkinInstan
 // The price: vertex records are no longer register-resident; they stream through a PIPE-deep software pipeline as in k_skin_vertices
 // (64 / I distinct records per wave-step, every one shared by I lanes: 32 / I bytes of L2 traffic per output), and a store instruction
 // writes I runs of 64 / I consecutive vertices (I = 4: four runs of 192 bytes) instead of one run of 768 bytes.
+#ifndef LMX_MULTI_SKIP_ZERO
+#define LMX_MULTI_SKIP_ZERO 1 // LMX_SKIN_FUSED: bone slots whose weight is zero in every lane of the wave are neither read nor multiplied
+#endif
 template <int COLS, int I, int MODE, int PIPE, int THREADS>
 __device__ __forceinline__ void skin_multi_tile(const SkinMultiChunk& ch, float4* s_rows, const float4* __restrict__ mesh,
 	const float4* __restrict__ palette, float* __restrict__ out, uint32_t& sink0, uint32_t& sink1 /* destinations of the caller's uncounted touches */) {
@@ -684,7 +727,17 @@ __device__ __forceinline__ void skin_multi_tile(const SkinMultiChunk& ch, float4
 		for (int d = 0; d < PIPE; ++d) {
 			const uint32_t v = min(v0 + (it + d) * VPB, v_last);
 			asm volatile("" : "+v"(rec[d].a), "+v"(rec[d].b));
-			F3 o = skin_blend<COLS, MODE>(rows, rec[d]);
+			F3 o;
+			if constexpr (MODE == LMX_SKIN_FUSED && LMX_MULTI_SKIP_ZERO) {
+				// wave-uniform: how many of the four bone slots carry a weight in ANY lane (slots are used front to back by every rigging tool;
+				// a zero in the middle just counts as used)
+				const bool u2 = __ballot(rec[d].a.y != 0.f) != 0, u3 = __ballot(rec[d].a.z != 0.f) != 0, u4 = __ballot(rec[d].a.w != 0.f) != 0;
+				if (u3 || u4) o = skin_blend<COLS, MODE>(rows, rec[d]);
+				else if (u2) o = skin_blend_fused_n<COLS, 2>(rows, rec[d]);
+				else o = skin_blend_fused_n<COLS, 1>(rows, rec[d]);
+			} else {
+				o = skin_blend<COLS, MODE>(rows, rec[d]);
+			}
 			asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z));
 			__builtin_amdgcn_sched_barrier(0);
 			rec[d] = load(min(v0 + (it + d + PIPE) * VPB, v_last));
