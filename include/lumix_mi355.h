@@ -278,9 +278,10 @@ LMX_API int lmx_world_read_transforms(LmxContext* ctx, LmxTransform* out, uint32
  * (one compaction pass instead of the plain clear of the marks); lmx_world_read_moved copies the list - entity indices and their new
  * world transforms, in no particular order - to the host. out_n is the number moved, also when it exceeds `cap` (LMX_ERR_CAPACITY:
  * nothing is copied; read everything with lmx_world_read_transforms instead). The hand-back of a frame costs what moved, not n. */
-/* Tuning knob, results never depend on it. LMX_WORLD_OPT_FUSED_LEVELS (default 0: one launch per level): 1 = hierarchies of up to 8 levels
- * are propagated by ONE launch (every node re-composes down from its topmost written ancestor) + one finalising pass - fewer launches
- * for small worlds; at 10^6 nodes the repeated ancestor loads cost what the saved launches gain (profiles/r03/xform_fused.txt). */
+/* Tuning knob, results never depend on it. LMX_WORLD_OPT_FUSED_LEVELS (default 1): hierarchies of up to 16 levels are propagated by ONE
+ * launch - a block owns the subtrees of a run of consecutive roots, walks them level by level (a parent comes out of the block's own
+ * cache, not HBM) and also clears the marks, collects the moved list and refreshes the bound culling spheres; 0 = one launch per level
+ * + one each for the marks / the moved list and the spheres (rounds 1-3; also what deeper or very lop-sided hierarchies use). */
 enum { LMX_WORLD_OPT_FUSED_LEVELS = 0 };
 LMX_API int lmx_world_set_option(LmxContext* ctx, int option, int value);
 LMX_API int lmx_world_track_moved(LmxContext* ctx, int enable);

@@ -16,6 +16,7 @@ namespace {
 int world_rebuild(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxTransform* transforms, const LmxTransform* world_all) {
 	WorldState& w = ctx->world;
 	w.built = false;
+	w.n_sub_runs = 0;
 	// children lists (CSR by parent), then BFS from the roots: slot order = (level, parent slot)
 	std::vector<uint32_t> child_start((size_t)n + 1, 0);
 	for (uint32_t e = 0; e < n; ++e) {
@@ -65,7 +66,6 @@ int world_rebuild(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxT
 	LMX_HIP(ctx, w.d_slot_of_entity.reserve(cap));
 	LMX_HIP(ctx, w.d_entity_of_slot.reserve(cap));
 	LMX_HIP(ctx, w.d_dirty.reserve(cap));
-	LMX_HIP(ctx, w.d_moved_out.reserve(cap));
 	if (w.track_moved) { // two propagations per frame (staged writes, bone-attached subtrees) fit between two reads
 		LMX_HIP(ctx, w.d_moved_entity.reserve(cap * 2));
 		LMX_HIP(ctx, w.d_moved_tr.reserve(cap * 2));
@@ -74,25 +74,54 @@ int world_rebuild(LmxContext* ctx, uint32_t n, const int32_t* parent, const LmxT
 	// scene load from locals (no world values given): every node counts as moved, so the first propagation derives all world
 	// transforms; with world values (re-parenting, lmx_world_build_with_world) nothing is recomputed until something is written
 	LMX_HIP(ctx, hipMemset(w.d_dirty.p, world_all ? 0 : XF_MOVED, cap));
-	LMX_HIP(ctx, hipMemset(w.d_moved_out.p, 0, cap));
 	if (n) {
 		LMX_HIP(ctx, hipMemcpy(w.d_parent_slot.p, w.parent_slot.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(w.d_slot_of_entity.p, w.slot_of_entity.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(w.d_entity_of_slot.p, w.entity_of_slot.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
-		// ancestor table of shallow hierarchies: k-th ancestor slot per slot (k_xform_fused reads its chain with independent loads)
-		const size_t n_levels = w.level_start.size() - 1;
-		w.n_anc = 0;
-		if (n_levels >= 2 && n_levels <= XF_FUSED_LEVELS) {
-			w.n_anc = (uint32_t)n_levels - 1;
-			std::vector<int32_t> anc((size_t)w.n_anc * n);
-			for (uint32_t s = 0; s < n; ++s) anc[s] = w.parent_slot[s];
-			for (uint32_t k = 1; k < w.n_anc; ++k)
-				for (uint32_t s = 0; s < n; ++s) {
-					const int32_t a = anc[(size_t)(k - 1) * n + s];
-					anc[(size_t)k * n + s] = a >= 0 ? w.parent_slot[a] : -1;
+		// k_xform_subtree's table: the roots cut into runs of ~XF_SUBTREE_NODES nodes (subtrees included); per run and level the first slot.
+		// The subtrees of consecutive roots are contiguous in every level because a level is ordered by parent slot.
+		{
+			const size_t n_levels = w.level_start.size() - 1;
+			const uint32_t n_roots = n_levels ? w.level_start[1] : 0;
+			w.n_sub_runs = 0;
+			if (n_levels >= 1 && n_levels <= XF_SUBTREE_MAX_LEVELS && n_roots) {
+				// bound[l][r]: first slot of level l that belongs to root r or a later root (r = n_roots: the level's end)
+				std::vector<std::vector<uint32_t>> bound(n_levels, std::vector<uint32_t>((size_t)n_roots + 1));
+				for (uint32_t r = 0; r <= n_roots; ++r) bound[0][r] = r;
+				for (size_t l = 1; l < n_levels; ++l) {
+					uint32_t c = w.level_start[l];
+					for (uint32_t r = 0; r <= n_roots; ++r) { // children of slots below bound[l - 1][r] come first
+						const uint32_t pb = bound[l - 1][r];
+						while (c < w.level_start[l + 1] && (uint32_t)w.parent_slot[c] < pb) ++c;
+						bound[l][r] = c;
+					}
 				}
-			LMX_HIP(ctx, w.d_ancestors.reserve(anc.size()));
-			LMX_HIP(ctx, hipMemcpy(w.d_ancestors.p, anc.data(), anc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+				std::vector<uint32_t> table;
+				auto row = [&](uint32_t r) { for (size_t l = 0; l < n_levels; ++l) table.push_back(bound[l][r]); };
+				uint64_t heaviest = 0;
+				uint32_t run_first = 0;
+				uint64_t in_run = 0;
+				row(0);
+				for (uint32_t r = 0; r < n_roots; ++r) {
+					uint64_t size = 0;
+					for (size_t l = 0; l < n_levels; ++l) size += bound[l][r + 1] - bound[l][r];
+					if (in_run && in_run + size > XF_SUBTREE_NODES) { // close the run before this root
+						row(r);
+						heaviest = std::max(heaviest, in_run);
+						run_first = r;
+						in_run = 0;
+					}
+					in_run += size;
+				}
+				(void)run_first;
+				heaviest = std::max(heaviest, in_run);
+				row(n_roots);
+				if (heaviest <= XF_SUBTREE_MAX_RUN) {
+					w.n_sub_runs = (uint32_t)(table.size() / n_levels) - 1;
+					LMX_HIP(ctx, w.d_sub_table.reserve(table.size()));
+					LMX_HIP(ctx, hipMemcpy(w.d_sub_table.p, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+				}
+			}
 		}
 		// every entity's transform is staged through the scatter kernel (roots -> world, children -> local)
 		std::vector<int32_t> all(n);
@@ -331,6 +360,18 @@ static int world_upload_binding(LmxContext* ctx) {
 		LMX_HIP(ctx, hipMemcpy(w.d_bound_dyn.p, dyn.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(w.d_bound_radius.p, w.bound_radius.data(), n * sizeof(float), hipMemcpyHostToDevice));
 	}
+	{ // the same binding by slot (k_xform_subtree refreshes the spheres of the slots it walks)
+		std::vector<uint32_t> dyn_of_slot(std::max<size_t>(w.n, 1), 0xffffffffu);
+		std::vector<float> radius_of_slot(std::max<size_t>(w.n, 1), 0.f);
+		for (size_t i = 0; i < n; ++i) {
+			dyn_of_slot[slot[i]] = dyn[i];
+			radius_of_slot[slot[i]] = w.bound_radius[i];
+		}
+		LMX_HIP(ctx, w.d_bound_dyn_of_slot.reserve(dyn_of_slot.size()));
+		LMX_HIP(ctx, w.d_bound_radius_of_slot.reserve(radius_of_slot.size()));
+		LMX_HIP(ctx, hipMemcpy(w.d_bound_dyn_of_slot.p, dyn_of_slot.data(), dyn_of_slot.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+		LMX_HIP(ctx, hipMemcpy(w.d_bound_radius_of_slot.p, radius_of_slot.data(), radius_of_slot.size() * sizeof(float), hipMemcpyHostToDevice));
+	}
 	w.bound_generation = cs.dyn_generation;
 	return LMX_OK;
 }
@@ -341,14 +382,26 @@ int lmx_world_propagate(LmxContext* ctx) {
 	if (!w.built) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_world_build has not been called");
 	const WorldDevice dev = w.dev();
 	const size_t n_levels = w.level_start.size() - 1;
-	if (w.fused_levels && n_levels >= 1 && n_levels <= XF_FUSED_LEVELS) {
-		// shallow hierarchy: every level in one launch + one pass that re-derives written locals, collects the moved list, clears the marks
-		if (n_levels > 1) {
-			ProfScope ps(ctx, LMX_K_XFORM_LEVEL);
-			LMX_HIP(ctx, launch_xform_fused(ctx->stream, dev, w.d_moved_out.p, w.d_ancestors.p, w.n, w.n_anc, w.level_start[1], w.n - w.level_start[1]));
+	const bool bound = !w.bound_entity.empty();
+	if (bound) {
+		if (int rc = world_upload_binding(ctx)) return rc;
+	}
+	CullState& cs = ctx->cull;
+	if (w.fused_levels && w.n_sub_runs) {
+		// one launch: the levels, the marks, the moved list and the bound spheres (k_xform_subtree)
+		XformSubtree a;
+		memset(&a, 0, sizeof(a));
+		a.table = w.d_sub_table.p;
+		a.n_levels = (uint32_t)n_levels;
+		a.entity_of_slot = w.d_entity_of_slot.p;
+		a.cap = w.n * 2u;
+		if (w.track_moved) { a.out_entity = w.d_moved_entity.p; a.out_tr = w.d_moved_tr.p; a.count = w.d_moved_count.p; }
+		if (bound) {
+			a.bound_dyn_of_slot = w.d_bound_dyn_of_slot.p; a.bound_radius_of_slot = w.d_bound_radius_of_slot.p;
+			a.dyn_px = cs.dyn_px.p; a.dyn_py = cs.dyn_py.p; a.dyn_pz = cs.dyn_pz.p; a.dyn_radius = cs.dyn_radius.p;
 		}
-		LMX_HIP(ctx, launch_xform_finalize(ctx->stream, dev, w.d_moved_out.p, w.d_entity_of_slot.p, w.n, w.n * 2u, w.d_moved_entity.p, w.d_moved_tr.p,
-			w.track_moved ? w.d_moved_count.p : nullptr));
+		ProfScope ps(ctx, LMX_K_XFORM_LEVEL);
+		LMX_HIP(ctx, launch_xform_subtree(ctx->stream, dev, a, w.n_sub_runs));
 	} else {
 		for (size_t l = 1; l + 1 < w.level_start.size(); ++l) {
 			ProfScope ps(ctx, LMX_K_XFORM_LEVEL);
@@ -359,17 +412,13 @@ int lmx_world_propagate(LmxContext* ctx) {
 		} else if (w.n) {
 			LMX_HIP(ctx, hipMemsetAsync(w.d_dirty.p, 0, w.n, ctx->stream));
 		}
-	}
-	if (!w.bound_entity.empty()) {
-		if (int rc = world_upload_binding(ctx)) return rc;
-		CullState& cs = ctx->cull;
-		{
+		if (bound) {
 			ProfScope ps(ctx, LMX_K_SPHERE_REFRESH);
 			LMX_HIP(ctx, launch_sphere_refresh(ctx->stream, dev, w.d_bound_slot.p, w.d_bound_dyn.p, w.d_bound_radius.p, cs.dyn_px.p, cs.dyn_py.p,
 				cs.dyn_pz.p, cs.dyn_radius.p, (uint32_t)w.bound_entity.size()));
 		}
-		cs.dyn_mirror_stale = true; // the device copy of the bound entities is now newer than the host mirror
 	}
+	if (bound) cs.dyn_mirror_stale = true; // the device copy of the bound entities is now newer than the host mirror
 	return LMX_OK;
 }
 

@@ -268,10 +268,11 @@ struct WorldState {
 	DevBuf<float> scl[6];              // lsx lsy lsz wsx wsy wsz
 	DevBuf<int32_t> d_parent_slot, d_slot_of_entity, d_entity_of_slot;
 	DevBuf<uint8_t> d_dirty;
-	DevBuf<uint8_t> d_moved_out; // k_xform_fused: nodes recomputed this propagation (kept apart from d_dirty, which the kernel only reads)
-	DevBuf<int32_t> d_ancestors; // [levels - 1][n]: k-th ancestor slot of every slot, -1 beyond the root (k_xform_fused; hierarchies of <= 8 levels)
-	uint32_t n_anc = 0;
-	bool fused_levels = false;   // lmx_world_set_option(LMX_WORLD_OPT_FUSED_LEVELS): 1 = hierarchies of <= 8 levels in one launch (measured: no faster at 1 M nodes, see xform_kernels.hip)
+	DevBuf<uint32_t> d_sub_table; // k_xform_subtree: (n_sub_runs + 1) x n_levels first slots (runs of consecutive roots)
+	uint32_t n_sub_runs = 0;      // 0: the hierarchy does not fit the table (too deep, or one root too heavy): per-level launches
+	bool fused_levels = true;     // lmx_world_set_option(LMX_WORLD_OPT_FUSED_LEVELS): 1 = one launch per propagation where the table fits; 0 = one launch per level
+	DevBuf<uint32_t> d_bound_dyn_of_slot; // per slot: the bound entity's index in the culling system's dynamic set, or 0xffffffff
+	DevBuf<float> d_bound_radius_of_slot;
 	DevBuf<int32_t> d_stage_entity;
 	DevBuf<LmxTransform> d_stage_tr;
 	DevBuf<LmxTransform> d_export;

@@ -127,13 +127,26 @@ enum { XF_STAGE_RAW = 0, XF_STAGE_RAW_WORLD = 1, XF_STAGE_SET_LOCAL = 2, XF_STAG
 hipError_t launch_xform_level(hipStream_t s, const WorldDevice& w, uint32_t first, uint32_t n);
 // out[entity_of_slot[s]] = AoS Transform (56 B) for s in [0, n)
 hipError_t launch_xform_export(hipStream_t s, const WorldDevice& w, const int32_t* entity_of_slot, uint32_t n, void* out_transforms);
-// shallow hierarchies (<= XF_FUSED_LEVELS levels): every non-root node in ONE launch (each re-composes down from its topmost written
-// ancestor), then one pass that re-derives the locals of written children, collects the moved list (count != nullptr) and clears the marks
-constexpr uint32_t XF_FUSED_LEVELS = 8;
-hipError_t launch_xform_fused(hipStream_t s, const WorldDevice& w, uint8_t* moved_out, const int32_t* ancestors /* [n_anc][n_slots]: k-th ancestor slot or -1 */,
-	uint32_t n_slots, uint32_t n_anc, uint32_t first_nonroot, uint32_t n_nonroot);
-hipError_t launch_xform_finalize(hipStream_t s, const WorldDevice& w, uint8_t* moved_out, const int32_t* entity_of_slot, uint32_t n, uint32_t cap, int32_t* out_entity,
-	void* out_transforms, uint32_t* count);
+// every level in ONE launch (k_xform_subtree): run r of consecutive roots owns slots [table[r * n_levels + l], table[(r + 1) * n_levels + l]) of
+// level l. The block also clears its marks, appends its moved nodes to the hand-back lists (count != nullptr) and refreshes the culling
+// spheres of its bound entities (bound_dyn_of_slot != nullptr: dynamic-set index per slot or 0xffffffff, model radius per slot).
+constexpr uint32_t XF_SUBTREE_NODES = 1024;      // nodes a run aims at (4 per thread of its block)
+constexpr uint32_t XF_SUBTREE_MAX_RUN = 16384;   // ... and the most one root's subtree may hold before the per-level launches take over
+constexpr uint32_t XF_SUBTREE_MAX_LEVELS = 16;
+struct XformSubtree {
+	const uint32_t* table;
+	uint32_t n_levels;
+	const int32_t* entity_of_slot;
+	uint32_t cap;
+	int32_t* out_entity;
+	void* out_tr; // Transform AoS, 56 B
+	uint32_t* count;
+	const uint32_t* bound_dyn_of_slot;
+	const float* bound_radius_of_slot;
+	double *dyn_px, *dyn_py, *dyn_pz;
+	float* dyn_radius;
+};
+hipError_t launch_xform_subtree(hipStream_t s, const WorldDevice& w, const XformSubtree& a, uint32_t n_runs);
 // append {entity, world transform} of every slot marked XF_MOVED to the lists (ballot-compacted, one atomic per wave) and clear all marks
 hipError_t launch_xform_collect_moved(hipStream_t s, const WorldDevice& w, const int32_t* entity_of_slot, uint32_t n, uint32_t cap, int32_t* out_entity,
 	void* out_transforms, uint32_t* count);

@@ -741,7 +741,7 @@ __device__ __forceinline__ void skin_multi_tile(const SkinMultiChunk& ch, float4
 			asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z));
 			__builtin_amdgcn_sched_barrier(0);
 			rec[d] = load(min(v0 + (it + d + PIPE) * VPB, v_last));
-			store_position(obase + v, o);
+			if (!LMX_PROBE_SKIP(8) || o.x == 123.25f) store_position(obase + v, o);
 			__builtin_amdgcn_sched_barrier(0);
 		}
 	}

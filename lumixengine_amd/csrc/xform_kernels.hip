@@ -23,10 +23,7 @@ namespace {
 //                 transformEntity(update_local = true) :266-269): world = parent.compose(local), then the stored local is RE-DERIVED
 //                 as Transform::computeLocal(parent, world) (math.cpp:809-816) - lossy, and what later frames compose with
 //   XF_SET_WORLD  World::setTransform on an entity with a parent: the world transform is the staged one, local = computeLocal(parent, world)
-__global__ __launch_bounds__(256) void k_xform_level(WorldDevice w, uint32_t first, uint32_t n) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= n) return;
-	const uint32_t s = first + i;
+__device__ __forceinline__ void xform_node(const WorldDevice& w, uint32_t s) {
 	const int32_t p = w.parent_slot[s];
 	const uint8_t dirty = w.dirty[s] & 3u;
 	if (dirty == XF_CLEAN && !(w.dirty[p] & XF_MOVED)) return;
@@ -68,21 +65,73 @@ __global__ __launch_bounds__(256) void k_xform_level(WorldDevice w, uint32_t fir
 	w.dirty[s] = XF_MOVED;
 }
 
-// ---- shallow hierarchies: every level in ONE launch ------------------------------------------------------------------------------
-// One launch per level is bound by launch latency when a level holds a few hundred thousand nodes (3 launches x 9-11 us for 250 k nodes
-// each: 0.43 of HBM by algorithmic bytes). Here every non-root node walks UP its ancestor chain (<= XF_FUSED_MAX_DEPTH links), finds the
-// topmost ancestor that was written this frame, and re-composes DOWN from there in registers: child.world = parent.compose(child.local)
-// with the operations of k_xform_level in the same order, so the result is bit-identical - a node just does not wait for its parent's
-// thread. What makes that legal: during this kernel nothing a thread READS is written by another one - marks stay as staged (the
-// "moved" output goes to a second byte array), stored locals stay as staged (the re-derivation of a written child's local,
-// Transform::computeLocal, moves to k_xform_finalize, when every world value is final), and a world value is only read from a node
-// that is not recomputed (the untouched ancestor above the topmost written one, or a node whose world transform was staged).
-// The ancestors' work is repeated by their descendants (depth-4 chains: 6 composes AND 9 instead of 6 record loads for 3 nodes). MEASURED
-// (profiles/r03/xform_fused.txt; 250 k roots x depth-4 chains, every root moved): the three level launches take 33-35 us together, this
-// kernel 27.7 us with a parent_slot walk and 32 us with the ancestor table - the level kernels are bound by their ~20 separate 4-8-byte
-// SoA streams per node, not by launch latency, and the repeated loads eat what the saved launches give (whole step 32.7 vs 34.3 us).
-// Kept as an option (LMX_WORLD_OPT_FUSED_LEVELS, default off) for small worlds, where the launches dominate; bit-identical either way.
-constexpr int XF_FUSED_MAX_DEPTH = 7; // ancestors above a node: hierarchies of up to 8 levels
+__global__ __launch_bounds__(256) void k_xform_level(WorldDevice w, uint32_t first, uint32_t n) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n) xform_node(w, first + i);
+}
+
+struct TransformAoS { double pos[3]; float rot[4]; float scale[3]; float pad; }; // core/math.h:306-327, 56 B
+
+// ---- every level in ONE launch: a block owns the subtrees of a run of roots -------------------------------------------------------------
+// Slots are in (level, parent slot) order, so the subtrees of CONSECUTIVE roots occupy one contiguous range of slots in every level: the
+// children of a contiguous range of parents are a contiguous range (induction over the levels). The host cuts the roots into runs whose
+// subtrees hold ~XF_SUBTREE_NODES nodes and records every run's first slot per level (`table[run * n_levels + level]`, one more row at the
+// end); a block walks its run level by level - the very statements of k_xform_level per node - with a workgroup barrier in between: the
+// parent a node composes with was written by this block one step earlier and comes out of the CU's own L1 / L2 instead of HBM, and the
+// 2-7 dependent launches of a frame (one per level, each with its ramp and tail at a few hundred thousand nodes) become one. Behind
+// the last level the same block clears its marks, appends its moved nodes to the hand-back lists (k_xform_collect_moved's job) and
+// refreshes the culling spheres of its bound entities (k_sphere_refresh's): nothing of a frame's propagation is a launch of its own.
+// Bit-identical to the per-level launches: a node still sees exactly its parent's final value. Hierarchies the table does not fit
+// (more than XF_SUBTREE_MAX_LEVELS levels, or one root with more than XF_SUBTREE_MAX_RUN nodes under it - a block would walk them
+// alone) keep the per-level launches.
+__global__ __launch_bounds__(256) void k_xform_subtree(WorldDevice w, XformSubtree a) {
+	const uint32_t* t0 = a.table + (size_t)blockIdx.x * a.n_levels;
+	const uint32_t* t1 = t0 + a.n_levels;
+	for (uint32_t l = 1; l < a.n_levels; ++l) { // block-uniform
+		const uint32_t first = t0[l], end = t1[l];
+		for (uint32_t s = first + threadIdx.x; s < end; s += 256u) xform_node(w, s);
+		__syncthreads(); // (a workgroup-scope release / acquire: the next level's parents are this level's nodes)
+	}
+	const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	for (uint32_t l = 0; l < a.n_levels; ++l) {
+		const uint32_t first = t0[l], end = t1[l];
+		for (uint32_t base = first; base < end; base += 256u) { // whole waves take part in every step (ballot below)
+			const uint32_t s = base + threadIdx.x;
+			const bool live = s < end;
+			const uint8_t mark = live ? w.dirty[s] : (uint8_t)0;
+			if (mark != 0) w.dirty[s] = 0;
+			const bool moved = (mark & XF_MOVED) != 0;
+			const uint32_t dyn = (live && a.bound_dyn_of_slot != nullptr) ? a.bound_dyn_of_slot[s] : 0xffffffffu;
+			const bool collect = moved && a.count != nullptr;
+			if (dyn != 0xffffffffu || collect) {
+				const float4 r = w.wrot[s];
+				const double px = w.wpx[s], py = w.wpy[s], pz = w.wpz[s];
+				const float sx = w.wsx[s], sy = w.wsy[s], sz = w.wsz[s];
+				if (dyn != 0xffffffffu) { // onModelInstanceMoved (render_module.cpp:1544-1554), as k_sphere_refresh: every bound entity, every propagation
+					a.dyn_px[dyn] = px; a.dyn_py[dyn] = py; a.dyn_pz[dyn] = pz;
+					const float mr = a.bound_radius_of_slot[s];
+					if (!(mr < 0.f)) a.dyn_radius[dyn] = mr * maximum3(sx, sy, sz);
+				}
+				const uint64_t mask = __ballot(collect);
+				if (collect) { // (lanes that only refresh a sphere skip the list)
+					uint32_t at = 0;
+					const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+					if (lane == leader) at = atomicAdd(a.count, (uint32_t)__popcll(mask));
+					at = (uint32_t)__shfl((int)at, (int)leader) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+					if (at < a.cap) {
+						TransformAoS t;
+						t.pos[0] = px; t.pos[1] = py; t.pos[2] = pz;
+						t.rot[0] = r.x; t.rot[1] = r.y; t.rot[2] = r.z; t.rot[3] = r.w;
+						t.scale[0] = sx; t.scale[1] = sy; t.scale[2] = sz;
+						t.pad = 0.f;
+						a.out_entity[at] = a.entity_of_slot[s];
+						reinterpret_cast<TransformAoS*>(a.out_tr)[at] = t;
+					}
+				}
+			}
+		}
+	}
+}
 
 __device__ __forceinline__ Xform load_world(const WorldDevice& w, int32_t s) {
 	Xform x;
@@ -92,63 +141,6 @@ __device__ __forceinline__ Xform load_world(const WorldDevice& w, int32_t s) {
 	x.scale = V3{w.wsx[s], w.wsy[s], w.wsz[s]};
 	return x;
 }
-__device__ __forceinline__ Xform load_local(const WorldDevice& w, int32_t s) {
-	Xform x;
-	const float4 r = w.lrot[s];
-	x.pos = DV3{w.lpx[s], w.lpy[s], w.lpz[s]};
-	x.rot = Q4{r.x, r.y, r.z, r.w};
-	x.scale = V3{w.lsx[s], w.lsy[s], w.lsz[s]};
-	return x;
-}
-
-__global__ __launch_bounds__(256) void k_xform_fused(WorldDevice w, uint8_t* __restrict__ moved_out, const int32_t* __restrict__ ancestors, uint32_t n_slots,
-	uint32_t n_anc, uint32_t first, uint32_t n) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= n) return;
-	const int32_t s = (int32_t)(first + i);
-	// the chain: c[0] = the node, c[k] = its k-th ancestor, -1 beyond the root (static indices: the arrays stay in registers). The
-	// ancestors come from a table built with the hierarchy (ancestors[(k - 1) * n_slots + s], k <= n_anc = levels - 1): independent
-	// coalesced loads instead of a chain of parent_slot[parent_slot[...]] round trips
-	int32_t c[XF_FUSED_MAX_DEPTH + 2];
-	uint32_t m[XF_FUSED_MAX_DEPTH + 1];
-	c[0] = s;
-#pragma unroll
-	for (int k = 1; k <= XF_FUSED_MAX_DEPTH + 1; ++k) c[k] = (uint32_t)k <= n_anc ? ancestors[(size_t)(k - 1) * n_slots + s] : -1;
-#pragma unroll
-	for (int k = 0; k <= XF_FUSED_MAX_DEPTH; ++k) m[k] = c[k] >= 0 ? (uint32_t)w.dirty[c[k]] : 0u;
-	// topmost written node of the chain: a root counts when its world transform was staged (XF_MOVED), a child when a local or a
-	// world transform was staged for it
-	int top = -1;
-#pragma unroll
-	for (int k = 0; k <= XF_FUSED_MAX_DEPTH; ++k) {
-		if (c[k] < 0) continue;
-		const bool is_root = c[k + 1] < 0;
-		if (is_root ? (m[k] & XF_MOVED) != 0 : (m[k] & 3u) != 0) top = k;
-	}
-	if (top < 0) return; // nothing above (or at) this node was written: exactly the nodes the reference's DFS does not visit
-	Xform cur = {};
-#pragma unroll
-	for (int k = XF_FUSED_MAX_DEPTH; k >= 0; --k) {
-		if (k > top || c[k] < 0) continue;
-		const bool is_root = c[k + 1] < 0;
-		const uint32_t mark = m[k] & 3u;
-		if (is_root || mark == XF_SET_WORLD) cur = load_world(w, c[k]);          // staged world transform: taken as it is
-		else if (k == top) cur = compose(load_world(w, c[k + 1]), load_local(w, c[k])); // XF_SET_LOCAL under an untouched parent
-		else cur = compose(cur, load_local(w, c[k]));                             // World::transformEntity's descent (world.cpp:271-280)
-	}
-	if ((m[0] & 3u) != XF_SET_WORLD) {
-		w.wpx[s] = cur.pos.x;
-		w.wpy[s] = cur.pos.y;
-		w.wpz[s] = cur.pos.z;
-		w.wrot[s] = make_float4(cur.rot.x, cur.rot.y, cur.rot.z, cur.rot.w);
-		w.wsx[s] = cur.scale.x;
-		w.wsy[s] = cur.scale.y;
-		w.wsz[s] = cur.scale.z;
-	}
-	moved_out[s] = XF_MOVED;
-}
-
-struct TransformAoS { double pos[3]; float rot[4]; float scale[3]; float pad; }; // core/math.h:306-327, 56 B
 
 __global__ __launch_bounds__(256) void k_xform_export(WorldDevice w, const int32_t* __restrict__ entity_of_slot, uint32_t n,
 	TransformAoS* __restrict__ out) {
@@ -173,52 +165,6 @@ __global__ __launch_bounds__(256) void k_xform_collect_moved(WorldDevice w, cons
 	const bool moved = s < n && (w.dirty[s] & XF_MOVED) != 0;
 	const uint64_t mask = __ballot(moved);
 	if (s < n && w.dirty[s] != 0) w.dirty[s] = 0;
-	if (mask == 0) return;
-	const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-	uint32_t base = 0;
-	if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(mask));
-	base = __builtin_amdgcn_readfirstlane(base);
-	if (!moved) return;
-	const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-	if (at >= cap) return;
-	const float4 r = w.wrot[s];
-	TransformAoS t;
-	t.pos[0] = w.wpx[s]; t.pos[1] = w.wpy[s]; t.pos[2] = w.wpz[s];
-	t.rot[0] = r.x; t.rot[1] = r.y; t.rot[2] = r.z; t.rot[3] = r.w;
-	t.scale[0] = w.wsx[s]; t.scale[1] = w.wsy[s]; t.scale[2] = w.wsz[s];
-	t.pad = 0.f;
-	out_entity[at] = entity_of_slot[s];
-	out_tr[at] = t;
-}
-
-// After k_xform_fused, when every world value is final: written children get their stored local RE-DERIVED (World::transformEntity
-// with update_local, world.cpp:266-269: Transform::computeLocal(parent, world) - lossy, and what later frames compose with), the
-// moved nodes (staged roots + everything k_xform_fused recomputed) are appended to the hand-back lists when tracking is on, and both
-// mark arrays are cleared.
-__global__ __launch_bounds__(256) void k_xform_finalize(WorldDevice w, uint8_t* __restrict__ moved_out, const int32_t* __restrict__ entity_of_slot, uint32_t n, uint32_t cap,
-	int32_t* __restrict__ out_entity, TransformAoS* __restrict__ out_tr, uint32_t* __restrict__ count) {
-	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-	uint32_t mark = 0, mv = 0;
-	if (s < n) {
-		mark = w.dirty[s];
-		mv = moved_out[s];
-		if (mark != 0) w.dirty[s] = 0;
-		if (mv != 0) moved_out[s] = 0;
-		const int32_t p = w.parent_slot[s];
-		if ((mark & 3u) != 0 && p >= 0) {
-			const Xform l = compute_local(load_world(w, p), load_world(w, (int32_t)s));
-			w.lpx[s] = l.pos.x;
-			w.lpy[s] = l.pos.y;
-			w.lpz[s] = l.pos.z;
-			w.lrot[s] = make_float4(l.rot.x, l.rot.y, l.rot.z, l.rot.w);
-			w.lsx[s] = l.scale.x;
-			w.lsy[s] = l.scale.y;
-			w.lsz[s] = l.scale.z;
-		}
-	}
-	if (count == nullptr) return; // no hand-back list wanted
-	const bool moved = ((mark & XF_MOVED) | mv) != 0;
-	const uint64_t mask = __ballot(moved);
 	if (mask == 0) return;
 	const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 	uint32_t base = 0;
@@ -296,17 +242,9 @@ hipError_t launch_xform_collect_moved(hipStream_t s, const WorldDevice& w, const
 	return hipGetLastError();
 }
 
-hipError_t launch_xform_fused(hipStream_t s, const WorldDevice& w, uint8_t* moved_out, const int32_t* ancestors, uint32_t n_slots, uint32_t n_anc, uint32_t first_nonroot,
-	uint32_t n_nonroot) {
-	if (!n_nonroot) return hipSuccess;
-	hipLaunchKernelGGL(k_xform_fused, dim3((n_nonroot + 255u) / 256u), dim3(256), 0, s, w, moved_out, ancestors, n_slots, n_anc, first_nonroot, n_nonroot);
-	return hipGetLastError();
-}
-
-hipError_t launch_xform_finalize(hipStream_t s, const WorldDevice& w, uint8_t* moved_out, const int32_t* entity_of_slot, uint32_t n, uint32_t cap, int32_t* out_entity,
-	void* out_transforms, uint32_t* count) {
-	if (!n) return hipSuccess;
-	hipLaunchKernelGGL(k_xform_finalize, dim3((n + 255u) / 256u), dim3(256), 0, s, w, moved_out, entity_of_slot, n, cap, out_entity, (TransformAoS*)out_transforms, count);
+hipError_t launch_xform_subtree(hipStream_t s, const WorldDevice& w, const XformSubtree& a, uint32_t n_runs) {
+	if (!n_runs) return hipSuccess;
+	hipLaunchKernelGGL(k_xform_subtree, dim3(n_runs), dim3(256), 0, s, w, a);
 	return hipGetLastError();
 }
 

@@ -1,14 +1,8 @@
 #!/bin/bash
-# Round 4 A/B of the shared-mesh skinning kernels (tools/skin_probe.hip): <instances> x 10 000 vertices x 64 bones.
-# mesh 0 = worst case (4 random bones of 64 per vertex), 1 = character-like (a tile touches ~27 bones, 1-2 influences).
-#   skin_probe_pf<blocks ahead>_skip<0|1>: k_skin_multi (512 threads) with that L2 touch distance and with / without the wave-uniform skip of zero-weight bone slots
-#   arguments: instances, instances per k_skin_shared block, kind (0 k_skin_vertices, 1 k_skin_shared, 2 k_skin_multi), mesh, hot palettes
+# Round 4: what bounds k_skin_multi at 100 000 instances (sustained clocks)? I = 2, worst-case mesh; parts compiled out / knobs.
 cd "$(dirname "$0")/../_build" || exit 1
-for n in 100000; do
- for mesh in 0 1; do
-  echo "== $n instances, mesh=$mesh: k_skin_shared"; ./skin_probe_pf768_skip1 $n 64 1 $mesh | grep -v "^tile"
-  for p in pf768_skip1 pf768_skip0; do
-    echo "== $n instances, mesh=$mesh: k_skin_multi $p"; ./skin_probe_$p $n 64 2 $mesh | grep -v "^tile" | grep "splits=1" | grep -v "I= 4"
-  done
- done
+for p in base pipe4 pipe6 plain_stores t1024 nostores nolds neither base; do
+  echo "== $p"; ./skin_probe_$p 100000 64 2 0 | grep "I= 2 splits=1"
 done
+echo "== base, mesh 1"; ./skin_probe_base 100000 64 2 1 | grep "I= 2 splits=1"
+echo "== nostores, mesh 1"; ./skin_probe_nostores 100000 64 2 1 | grep "I= 2 splits=1"
