@@ -84,49 +84,129 @@ struct TransformAoS { double pos[3]; float rot[4]; float scale[3]; float pad; };
 // Bit-identical to the per-level launches: a node still sees exactly its parent's final value. Hierarchies the table does not fit
 // (more than XF_SUBTREE_MAX_LEVELS levels, or one root with more than XF_SUBTREE_MAX_RUN nodes under it - a block would walk them
 // alone) keep the per-level launches.
+// What a node's update reads that does NOT depend on its parent's new value: fetched one level ahead (prefetch), so that a level costs
+// one dependent round trip - its parents' values - instead of three (parent slot -> marks -> transforms).
+struct XformPre { int32_t p; uint8_t mark; Xform local; };
+__device__ __forceinline__ XformPre xform_prefetch(const WorldDevice& w, uint32_t s) {
+	XformPre x;
+	x.p = w.parent_slot[s];
+	x.mark = w.dirty[s] & 3u;
+	const float4 lr = w.lrot[s];
+	x.local.pos = DV3{w.lpx[s], w.lpy[s], w.lpz[s]};
+	x.local.rot = Q4{lr.x, lr.y, lr.z, lr.w};
+	x.local.scale = V3{w.lsx[s], w.lsy[s], w.lsz[s]};
+	return x;
+}
+// xform_node with the prefetched part: the same statements in the same order (the stored local is only read when the node is not XF_SET_WORLD)
+__device__ __forceinline__ void xform_node_pre(const WorldDevice& w, uint32_t s, const XformPre& x) {
+	const int32_t p = x.p;
+	const uint8_t dirty = x.mark;
+	if (dirty == XF_CLEAN && !(w.dirty[p] & XF_MOVED)) return;
+	Xform parent;
+	const float4 pr = w.wrot[p];
+	parent.pos = DV3{w.wpx[p], w.wpy[p], w.wpz[p]};
+	parent.rot = Q4{pr.x, pr.y, pr.z, pr.w};
+	parent.scale = V3{w.wsx[p], w.wsy[p], w.wsz[p]};
+	Xform r;
+	if (dirty != XF_SET_WORLD) {
+		r = compose(parent, x.local);
+		w.wpx[s] = r.pos.x;
+		w.wpy[s] = r.pos.y;
+		w.wpz[s] = r.pos.z;
+		w.wrot[s] = make_float4(r.rot.x, r.rot.y, r.rot.z, r.rot.w);
+		w.wsx[s] = r.scale.x;
+		w.wsy[s] = r.scale.y;
+		w.wsz[s] = r.scale.z;
+	} else {
+		const float4 wr = w.wrot[s];
+		r.pos = DV3{w.wpx[s], w.wpy[s], w.wpz[s]};
+		r.rot = Q4{wr.x, wr.y, wr.z, wr.w};
+		r.scale = V3{w.wsx[s], w.wsy[s], w.wsz[s]};
+	}
+	if (dirty != XF_CLEAN) {
+		const Xform l = compute_local(parent, r);
+		w.lpx[s] = l.pos.x;
+		w.lpy[s] = l.pos.y;
+		w.lpz[s] = l.pos.z;
+		w.lrot[s] = make_float4(l.rot.x, l.rot.y, l.rot.z, l.rot.w);
+		w.lsx[s] = l.scale.x;
+		w.lsy[s] = l.scale.y;
+		w.lsz[s] = l.scale.z;
+	}
+	w.dirty[s] = XF_MOVED;
+}
+
 __global__ __launch_bounds__(256) void k_xform_subtree(WorldDevice w, XformSubtree a) {
+	__shared__ uint32_t s_count[4];
+	__shared__ uint32_t s_base;
 	const uint32_t* t0 = a.table + (size_t)blockIdx.x * a.n_levels;
 	const uint32_t* t1 = t0 + a.n_levels;
-	for (uint32_t l = 1; l < a.n_levels; ++l) { // block-uniform
-		const uint32_t first = t0[l], end = t1[l];
-		for (uint32_t s = first + threadIdx.x; s < end; s += 256u) xform_node(w, s);
-		__syncthreads(); // (a workgroup-scope release / acquire: the next level's parents are this level's nodes)
+	const uint32_t tid = threadIdx.x;
+	// levels of at most 256 nodes (the common shape: a run holds ~1024 nodes): node `tid` of the NEXT level is prefetched while this one is composed
+	{
+		XformPre nx = {};
+		bool have = false;
+		if (a.n_levels > 1 && tid < t1[1] - t0[1]) { nx = xform_prefetch(w, t0[1] + tid); have = true; }
+		for (uint32_t l = 1; l < a.n_levels; ++l) { // block-uniform
+			const uint32_t first = t0[l], end = t1[l];
+			const XformPre cur = nx;
+			const bool mine = have;
+			have = false;
+			if (l + 1 < a.n_levels && tid < t1[l + 1] - t0[l + 1]) { nx = xform_prefetch(w, t0[l + 1] + tid); have = true; } // (reads nothing this level writes: another level's slots)
+			if (mine) xform_node_pre(w, first + tid, cur);
+			for (uint32_t s = first + 256u + tid; s < end; s += 256u) xform_node(w, s); // the rest of a wide level
+			__syncthreads(); // (a workgroup-scope release / acquire: the next level's parents are this level's nodes)
+		}
 	}
-	const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	// marks, moved list, bound spheres. The moved list takes ONE reservation per block: every wave appending for itself is an atomic on one
+	// address per 64 nodes - 15.6 k of them for 10^6 moved nodes, ~180 us at the ~90 per microsecond one address retires (measured: 203 us)
+	const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), wave = tid >> 6;
+	uint32_t my_base = 0;
+	if (a.count != nullptr) {
+		uint32_t mine = 0;
+		for (uint32_t l = 0; l < a.n_levels; ++l)
+			for (uint32_t s = t0[l] + tid; s < t1[l]; s += 256u) mine += (w.dirty[s] & XF_MOVED) ? 1u : 0u;
+		uint32_t incl = mine;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+			if (lane >= (uint32_t)o) incl += up;
+		}
+		if (lane == 63) s_count[wave] = incl;
+		__syncthreads();
+		if (tid == 0) {
+			const uint32_t total = s_count[0] + s_count[1] + s_count[2] + s_count[3];
+			s_base = total ? atomicAdd(a.count, total) : 0u;
+		}
+		__syncthreads();
+		my_base = s_base + incl - mine;
+		for (uint32_t k = 0; k < wave; ++k) my_base += s_count[k];
+	}
 	for (uint32_t l = 0; l < a.n_levels; ++l) {
-		const uint32_t first = t0[l], end = t1[l];
-		for (uint32_t base = first; base < end; base += 256u) { // whole waves take part in every step (ballot below)
-			const uint32_t s = base + threadIdx.x;
-			const bool live = s < end;
-			const uint8_t mark = live ? w.dirty[s] : (uint8_t)0;
+		for (uint32_t s = t0[l] + tid; s < t1[l]; s += 256u) { // the order of the count above: thread `tid` walks the same slots
+			const uint8_t mark = w.dirty[s];
 			if (mark != 0) w.dirty[s] = 0;
-			const bool moved = (mark & XF_MOVED) != 0;
-			const uint32_t dyn = (live && a.bound_dyn_of_slot != nullptr) ? a.bound_dyn_of_slot[s] : 0xffffffffu;
-			const bool collect = moved && a.count != nullptr;
-			if (dyn != 0xffffffffu || collect) {
-				const float4 r = w.wrot[s];
-				const double px = w.wpx[s], py = w.wpy[s], pz = w.wpz[s];
-				const float sx = w.wsx[s], sy = w.wsy[s], sz = w.wsz[s];
-				if (dyn != 0xffffffffu) { // onModelInstanceMoved (render_module.cpp:1544-1554), as k_sphere_refresh: every bound entity, every propagation
-					a.dyn_px[dyn] = px; a.dyn_py[dyn] = py; a.dyn_pz[dyn] = pz;
-					const float mr = a.bound_radius_of_slot[s];
-					if (!(mr < 0.f)) a.dyn_radius[dyn] = mr * maximum3(sx, sy, sz);
-				}
-				const uint64_t mask = __ballot(collect);
-				if (collect) { // (lanes that only refresh a sphere skip the list)
-					uint32_t at = 0;
-					const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-					if (lane == leader) at = atomicAdd(a.count, (uint32_t)__popcll(mask));
-					at = (uint32_t)__shfl((int)at, (int)leader) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-					if (at < a.cap) {
-						TransformAoS t;
-						t.pos[0] = px; t.pos[1] = py; t.pos[2] = pz;
-						t.rot[0] = r.x; t.rot[1] = r.y; t.rot[2] = r.z; t.rot[3] = r.w;
-						t.scale[0] = sx; t.scale[1] = sy; t.scale[2] = sz;
-						t.pad = 0.f;
-						a.out_entity[at] = a.entity_of_slot[s];
-						reinterpret_cast<TransformAoS*>(a.out_tr)[at] = t;
-					}
+			const bool collect = (mark & XF_MOVED) != 0 && a.count != nullptr;
+			const uint32_t dyn = a.bound_dyn_of_slot != nullptr ? a.bound_dyn_of_slot[s] : 0xffffffffu;
+			if (dyn == 0xffffffffu && !collect) continue;
+			const float4 r = w.wrot[s];
+			const double px = w.wpx[s], py = w.wpy[s], pz = w.wpz[s];
+			const float sx = w.wsx[s], sy = w.wsy[s], sz = w.wsz[s];
+			if (dyn != 0xffffffffu) { // onModelInstanceMoved (render_module.cpp:1544-1554), as k_sphere_refresh: every bound entity, every propagation
+				a.dyn_px[dyn] = px; a.dyn_py[dyn] = py; a.dyn_pz[dyn] = pz;
+				const float mr = a.bound_radius_of_slot[s];
+				if (!(mr < 0.f)) a.dyn_radius[dyn] = mr * maximum3(sx, sy, sz);
+			}
+			if (collect) {
+				const uint32_t at = my_base++;
+				if (at < a.cap) {
+					TransformAoS t;
+					t.pos[0] = px; t.pos[1] = py; t.pos[2] = pz;
+					t.rot[0] = r.x; t.rot[1] = r.y; t.rot[2] = r.z; t.rot[3] = r.w;
+					t.scale[0] = sx; t.scale[1] = sy; t.scale[2] = sz;
+					t.pad = 0.f;
+					a.out_entity[at] = a.entity_of_slot[s];
+					reinterpret_cast<TransformAoS*>(a.out_tr)[at] = t;
 				}
 			}
 		}
