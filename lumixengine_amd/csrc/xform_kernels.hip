@@ -97,64 +97,110 @@ __device__ __forceinline__ XformPre xform_prefetch(const WorldDevice& w, uint32_
 	x.local.scale = V3{w.lsx[s], w.lsy[s], w.lsz[s]};
 	return x;
 }
-// xform_node with the prefetched part: the same statements in the same order (the stored local is only read when the node is not XF_SET_WORLD)
-__device__ __forceinline__ void xform_node_pre(const WorldDevice& w, uint32_t s, const XformPre& x) {
-	const int32_t p = x.p;
-	const uint8_t dirty = x.mark;
-	if (dirty == XF_CLEAN && !(w.dirty[p] & XF_MOVED)) return;
-	Xform parent;
-	const float4 pr = w.wrot[p];
-	parent.pos = DV3{w.wpx[p], w.wpy[p], w.wpz[p]};
-	parent.rot = Q4{pr.x, pr.y, pr.z, pr.w};
-	parent.scale = V3{w.wsx[p], w.wsy[p], w.wsz[p]};
-	Xform r;
-	if (dirty != XF_SET_WORLD) {
-		r = compose(parent, x.local);
-		w.wpx[s] = r.pos.x;
-		w.wpy[s] = r.pos.y;
-		w.wpz[s] = r.pos.z;
-		w.wrot[s] = make_float4(r.rot.x, r.rot.y, r.rot.z, r.rot.w);
-		w.wsx[s] = r.scale.x;
-		w.wsy[s] = r.scale.y;
-		w.wsz[s] = r.scale.z;
-	} else {
-		const float4 wr = w.wrot[s];
-		r.pos = DV3{w.wpx[s], w.wpy[s], w.wpz[s]};
-		r.rot = Q4{wr.x, wr.y, wr.z, wr.w};
-		r.scale = V3{w.wsx[s], w.wsy[s], w.wsz[s]};
-	}
-	if (dirty != XF_CLEAN) {
-		const Xform l = compute_local(parent, r);
-		w.lpx[s] = l.pos.x;
-		w.lpy[s] = l.pos.y;
-		w.lpz[s] = l.pos.z;
-		w.lrot[s] = make_float4(l.rot.x, l.rot.y, l.rot.z, l.rot.w);
-		w.lsx[s] = l.scale.x;
-		w.lsy[s] = l.scale.y;
-		w.lsz[s] = l.scale.z;
-	}
-	w.dirty[s] = XF_MOVED;
+// LDS only has to be visible to the block's own waves: no need to drain the wave's global stores (vmcnt) as __syncthreads() does
+__device__ __forceinline__ void lds_barrier() {
+#ifdef LMX_HOSTSIM
+	__syncthreads();
+#else
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_xform_subtree(WorldDevice w, XformSubtree a) {
 	__shared__ uint32_t s_count[4];
 	__shared__ uint32_t s_base;
+	// the previous and the current level's world transforms of a narrow run (<= 256 nodes per level): a node's parent comes out of LDS
+	__shared__ double s_px[2][256], s_py[2][256], s_pz[2][256];
+	__shared__ float4 s_rot[2][256];
+	__shared__ float s_sx[2][256], s_sy[2][256], s_sz[2][256];
+	__shared__ uint8_t s_moved[2][256];
 	const uint32_t* t0 = a.table + (size_t)blockIdx.x * a.n_levels;
 	const uint32_t* t1 = t0 + a.n_levels;
 	const uint32_t tid = threadIdx.x;
-	// levels of at most 256 nodes (the common shape: a run holds ~1024 nodes): node `tid` of the NEXT level is prefetched while this one is composed
-	{
-		XformPre nx = {};
-		bool have = false;
-		if (a.n_levels > 1 && tid < t1[1] - t0[1]) { nx = xform_prefetch(w, t0[1] + tid); have = true; }
+	bool narrow = true; // block-uniform
+	for (uint32_t l = 0; l < a.n_levels; ++l) narrow = narrow && (t1[l] - t0[l] <= 256u);
+	if (narrow) {
+		// Every load that does not depend on a parent's NEW value goes out ahead: the roots' world transforms now, a node's parent slot /
+		// mark / stored local two levels ahead. A level then costs an LDS read, the compose and a barrier that only waits for LDS - the
+		// global stores of a level are never waited for (nobody of this block reads them back), so the chain of a run is its first loads
+		// plus arithmetic, not a memory round trip (plus a store drain) per level as in the per-level launches.
+		XformPre pre0 = {}, pre1 = {};
+		bool have0 = false, have1 = false;
+		if (a.n_levels > 1 && tid < t1[1] - t0[1]) { pre0 = xform_prefetch(w, t0[1] + tid); have0 = true; }
+		if (a.n_levels > 2 && tid < t1[2] - t0[2]) { pre1 = xform_prefetch(w, t0[2] + tid); have1 = true; }
+		if (tid < t1[0] - t0[0]) {
+			const uint32_t s = t0[0] + tid;
+			const float4 r = w.wrot[s];
+			s_px[0][tid] = w.wpx[s]; s_py[0][tid] = w.wpy[s]; s_pz[0][tid] = w.wpz[s];
+			s_rot[0][tid] = r;
+			s_sx[0][tid] = w.wsx[s]; s_sy[0][tid] = w.wsy[s]; s_sz[0][tid] = w.wsz[s];
+			s_moved[0][tid] = w.dirty[s] & XF_MOVED;
+		}
+		lds_barrier();
+		for (uint32_t l = 1; l < a.n_levels; ++l) { // block-uniform
+			const XformPre cur = pre0;
+			const bool mine = have0;
+			pre0 = pre1;
+			have0 = have1;
+			have1 = false;
+			if (l + 2 < a.n_levels && tid < t1[l + 2] - t0[l + 2]) { pre1 = xform_prefetch(w, t0[l + 2] + tid); have1 = true; }
+			if (mine) {
+				const uint32_t s = t0[l] + tid, from = (l - 1) & 1u, to = l & 1u;
+				const uint32_t pi = (uint32_t)cur.p - t0[l - 1];
+				Xform r;
+				bool moved = true;
+				if (cur.mark == XF_CLEAN && !s_moved[from][pi]) { // untouched (the reference's DFS does not come here): its children may still need its value
+					const float4 wr = w.wrot[s];
+					r.pos = DV3{w.wpx[s], w.wpy[s], w.wpz[s]};
+					r.rot = Q4{wr.x, wr.y, wr.z, wr.w};
+					r.scale = V3{w.wsx[s], w.wsy[s], w.wsz[s]};
+					moved = false;
+				} else { // xform_node's statements with the parent read from LDS
+					Xform parent;
+					const float4 pr = s_rot[from][pi];
+					parent.pos = DV3{s_px[from][pi], s_py[from][pi], s_pz[from][pi]};
+					parent.rot = Q4{pr.x, pr.y, pr.z, pr.w};
+					parent.scale = V3{s_sx[from][pi], s_sy[from][pi], s_sz[from][pi]};
+					if (cur.mark != XF_SET_WORLD) {
+						r = compose(parent, cur.local);
+						w.wpx[s] = r.pos.x;
+						w.wpy[s] = r.pos.y;
+						w.wpz[s] = r.pos.z;
+						w.wrot[s] = make_float4(r.rot.x, r.rot.y, r.rot.z, r.rot.w);
+						w.wsx[s] = r.scale.x;
+						w.wsy[s] = r.scale.y;
+						w.wsz[s] = r.scale.z;
+					} else {
+						const float4 wr = w.wrot[s];
+						r.pos = DV3{w.wpx[s], w.wpy[s], w.wpz[s]};
+						r.rot = Q4{wr.x, wr.y, wr.z, wr.w};
+						r.scale = V3{w.wsx[s], w.wsy[s], w.wsz[s]};
+					}
+					if (cur.mark != XF_CLEAN) {
+						const Xform lc = compute_local(parent, r);
+						w.lpx[s] = lc.pos.x;
+						w.lpy[s] = lc.pos.y;
+						w.lpz[s] = lc.pos.z;
+						w.lrot[s] = make_float4(lc.rot.x, lc.rot.y, lc.rot.z, lc.rot.w);
+						w.lsx[s] = lc.scale.x;
+						w.lsy[s] = lc.scale.y;
+						w.lsz[s] = lc.scale.z;
+					}
+					w.dirty[s] = XF_MOVED;
+				}
+				if (l + 1 < a.n_levels) { // (the last level has no readers)
+					s_px[to][tid] = r.pos.x; s_py[to][tid] = r.pos.y; s_pz[to][tid] = r.pos.z;
+					s_rot[to][tid] = make_float4(r.rot.x, r.rot.y, r.rot.z, r.rot.w);
+					s_sx[to][tid] = r.scale.x; s_sy[to][tid] = r.scale.y; s_sz[to][tid] = r.scale.z;
+					s_moved[to][tid] = moved ? XF_MOVED : 0;
+				}
+			}
+			lds_barrier();
+		}
+	} else {
 		for (uint32_t l = 1; l < a.n_levels; ++l) { // block-uniform
 			const uint32_t first = t0[l], end = t1[l];
-			const XformPre cur = nx;
-			const bool mine = have;
-			have = false;
-			if (l + 1 < a.n_levels && tid < t1[l + 1] - t0[l + 1]) { nx = xform_prefetch(w, t0[l + 1] + tid); have = true; } // (reads nothing this level writes: another level's slots)
-			if (mine) xform_node_pre(w, first + tid, cur);
-			for (uint32_t s = first + 256u + tid; s < end; s += 256u) xform_node(w, s); // the rest of a wide level
+			for (uint32_t s = first + tid; s < end; s += 256u) xform_node(w, s);
 			__syncthreads(); // (a workgroup-scope release / acquire: the next level's parents are this level's nodes)
 		}
 	}
