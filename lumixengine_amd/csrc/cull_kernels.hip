@@ -401,6 +401,8 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 	int32_t id[CHW];
 	uint32_t vis_bits = 0; // bit i * FS + f: sphere `lane` of chunk i is visible in frustum f
 	uint32_t mine = 0;     // lane f: this wave's visible count for frustum f
+	uint32_t cnt_pack[3] = {0, 0, 0}; // (F != 1) the lane's own visible spheres per frustum, 10 bits each: frusta 0-2 | 3-5 | 6-7
+	static_assert(CHW * 64 <= 1023, "a wave's count per frustum fits 10 bits");
 	// 1-frustum kernels: the wave's visible ids (and slots) are compacted in LDS as they are found - the write-out below is then a
 	// handful of full-width stores instead of one partial-width store per chunk (156 k of them on a launch with 43 % visible)
 	constexpr bool STAGE = F == 1 && GRP < CHW && LMX_CULL_STAGE_IDS != 0; // streaming variants only (as the non-temporal loads): the latency variant pays for the extra LDS and the wait at the wave's end
@@ -460,17 +462,67 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 				if (need_sphere[i]) sp[i] = g_spheres[e];
 			}
 		}
+		if constexpr (F != 1) {
+			// Several frusta over the same spheres (the frame's shadow cascades, BASELINE config 5). Rounds 2 / 3 ran the single-frustum body
+			// per (chunk, frustum): class from LDS -> wait -> branch -> frustum normals from the kernarg segment + distances from LDS ->
+			// wait -> test, i.e. two serialized waits and an 18-dword scalar load per 64 spheres and frustum - 224 us for 10 M spheres
+			// x 8 frusta, 0.13 of the VALU rate (profiles/r03). Now, per frustum: the normals are read ONCE into SGPRs, the (cell, frustum)
+			// records of all the group's chunks are fetched together (one LDS round trip), the chunks are tested back to back without a
+			// branch on a lane's class (the class selects the verdict), and the per-frustum counts are kept packed per lane
+			// (10 bits a frustum) and summed over the wave once, behind the loop.
+#pragma unroll 1
+			for (int f = 0; f < nf; ++f) {
+				const uint32_t st = (st_bits >> (2 * f)) & 3u;
+				if (st == TILE_REJECT) continue; // nothing of this tile is visible in frustum f
+				const bool mixed = any_mixed && st == TILE_MIXED; // wave-uniform
+				CellInfo ci[GRP];
+				if (mixed) {
+#pragma unroll
+					for (int i = 0; i < GRP; ++i) ci[i] = s_info[f * a.cell_cap + local[i]]; // two ds_read_b128 per chunk, all in flight together
+				}
+				float nx[6], ny[6], nz[6];
+#pragma unroll
+				for (int k = 0; k < 6; ++k) { nx[k] = frp[f].nx[k]; ny[k] = frp[f].ny[k]; nz[k] = frp[f].nz[k]; } // wave-uniform: scalar loads, once per frustum
+				const uint32_t one = 1u << (10 * (f % 3));
+#pragma unroll
+				for (int i = 0; i < GRP; ++i) {
+					if (!need_id[i]) continue; // wave-uniform
+					bool vis = st == TILE_ACCEPT;
+					if (mixed) {
+						const uint32_t cls = ci[i].cls;
+						vis = cls == CELL_ACCEPT;
+						if (need_sphere[i]) { // wave-uniform: some lane of the chunk is in a CELL_TEST cell of some frustum
+							// doCulling (culling_system.cpp:283-306), the operations of sphere_visible_d_pk: t = ((x*nx + y*ny) + z*nz) + d, t + r < 0 culls
+							const v2f x2 = {sp[i].x, sp[i].x}, y2 = {sp[i].y, sp[i].y}, z2 = {sp[i].z, sp[i].z}, r2 = {sp[i].w, sp[i].w};
+							bool culled = false;
+#pragma unroll
+							for (int k = 0; k < 6; k += 2) {
+								const v2f n_x = {nx[k], nx[k + 1]}, n_y = {ny[k], ny[k + 1]}, n_z = {nz[k], nz[k + 1]}, dd = {ci[i].d[k], ci[i].d[k + 1]};
+								v2f t = x2 * n_x;
+								t = t + y2 * n_y;
+								t = t + z2 * n_z;
+								t = t + dd;
+								t = t + r2;
+								culled = culled || (t.x < 0) || (t.y < 0);
+							}
+							vis = vis || (cls == CELL_TEST && !culled);
+						}
+					}
+					vis = vis && id[g + i] >= 0;
+					vis_bits |= (vis ? 1u : 0u) << ((g + i) * FS + f);
+					const uint32_t add = vis ? one : 0u;
+					if (f < 3) cnt_pack[0] += add; else if (f < 6) cnt_pack[1] += add; else cnt_pack[2] += add; // (f is wave-uniform)
+				}
+			}
+		} else {
 #pragma unroll 1
 		for (int f = 0; f < nf; ++f) {
 			const uint32_t st = (st_bits >> (2 * f)) & 3u;
-			if constexpr (F != 1) {
-				if (st == TILE_REJECT) continue; // nothing of this tile is visible in frustum f
-			}
 #pragma unroll
 			for (int i = 0; i < GRP; ++i) {
 				if (!need_id[i]) continue;
 				bool vis;
-				if (any_mixed && (F == 1 || st == TILE_MIXED)) {
+				if (any_mixed) {
 					const CellInfo* ci = &s_info[f * a.cell_cap + local[i]];
 					const uint32_t cls = ci->cls;
 					vis = cls == CELL_ACCEPT;
@@ -505,6 +557,18 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 				}
 			}
 		}
+		}
+	}
+	if constexpr (F != 1) {
+		// per-frustum counts of the wave: the lanes' packed counters (a lane sees at most CHW visible spheres per frustum, a wave 64 x CHW <= 1023)
+		// summed across the wave, then lane f keeps frustum f's
+#pragma unroll
+		for (int k = 0; k < 3; ++k) {
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) cnt_pack[k] += (uint32_t)__shfl_xor((int)cnt_pack[k], o);
+		}
+		const uint32_t word = lane < 3u ? cnt_pack[0] : (lane < 6u ? cnt_pack[1] : cnt_pack[2]);
+		mine = lane < (uint32_t)MAX_FRUSTA ? (word >> (10u * (lane % 3u))) & 0x3ffu : 0u;
 	}
 
 	if constexpr (STAGE) {
