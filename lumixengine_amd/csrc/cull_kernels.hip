@@ -241,6 +241,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 	constexpr bool PLANE_SKIP = LMX_CULL_PLANE_SKIP != 0 && GRP < CHW;
 	static_assert(CHW * FS <= 32, "visibility bits of a wave's chunks x frusta live in one register");
 	LMX_DYNAMIC_LDS(CellInfo, s_info); // [n_frusta * cell_cap] (MIXED tiles only)
+	__shared__ __attribute__((aligned(16))) float s_nrm[F != 1 ? MAX_FRUSTA : 1][F != 1 ? 20 : 4]; // (several frusta) plane normals nx[6] ny[6] nz[6] of every frustum, for phase B
 	// the frusta are read through the kernarg segment pointer: uniform scalar loads placed where they are used
 	const DevFrustum* __restrict__ frp = (const DevFrustum*)__builtin_amdgcn_kernarg_segment_ptr();
 	const int nf = F == 1 ? 1 : (int)a.n_frusta;
@@ -341,6 +342,12 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			for (uint32_t f = wave / wpf; f < (uint32_t)nf; f += (uint32_t)WAVES / wpf) {
 				if (((st_bits >> (2 * f)) & 3u) != TILE_MIXED) continue;
 				for (uint32_t t = (wave % wpf) * 64u + lane; t < n_cells; t += wpf * 64u) classify(t, (int)f, keys[t]);
+			}
+		}
+		if constexpr (F != 1) {
+			for (uint32_t t = threadIdx.x; t < (uint32_t)nf * 18u; t += THREADS) {
+				const uint32_t f = t / 18u, k = t % 18u;
+				s_nrm[f][k] = k < 6u ? frp[f].nx[k] : (k < 12u ? frp[f].ny[k - 6u] : frp[f].nz[k - 12u]);
 			}
 		}
 		// one barrier per MIXED tile. (A block-wide vote "does any cell survive" would let such a tile end here, but costs two more
@@ -475,44 +482,55 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 				const uint32_t st = (st_bits >> (2 * f)) & 3u;
 				if (st == TILE_REJECT) continue; // nothing of this tile is visible in frustum f
 				const bool mixed = any_mixed && st == TILE_MIXED; // wave-uniform
-				CellInfo ci[GRP];
+				// the frustum's plane normals out of LDS (phase 0 put them there), every lane the same address: a broadcast read. (From the
+				// kernarg segment they are scalar loads that share lgkmcnt with the LDS reads below and return out of order: the compiler
+				// waited for the one before it issued the other.)
+				float4 nq[5]; // nx[0..5] ny[0..5] nz[0..5] + 2 pad
 				if (mixed) {
 #pragma unroll
-					for (int i = 0; i < GRP; ++i) ci[i] = s_info[f * a.cell_cap + local[i]]; // two ds_read_b128 per chunk, all in flight together
+					for (int k = 0; k < 5; ++k) nq[k] = reinterpret_cast<const float4*>(s_nrm[f])[k];
 				}
-				float nx[6], ny[6], nz[6];
-#pragma unroll
-				for (int k = 0; k < 6; ++k) { nx[k] = frp[f].nx[k]; ny[k] = frp[f].ny[k]; nz[k] = frp[f].nz[k]; } // wave-uniform: scalar loads, once per frustum
+				const float* nrm = reinterpret_cast<const float*>(nq);
 				const uint32_t one = 1u << (10 * (f % 3));
+				uint32_t add_f = 0;
 #pragma unroll
-				for (int i = 0; i < GRP; ++i) {
-					if (!need_id[i]) continue; // wave-uniform
-					bool vis = st == TILE_ACCEPT;
+				for (int h = 0; h < GRP; h += 2) { // two chunks' cell records in flight at a time (16 VGPRs)
+					CellInfo ci[2];
 					if (mixed) {
-						const uint32_t cls = ci[i].cls;
-						vis = cls == CELL_ACCEPT;
-						if (need_sphere[i]) { // wave-uniform: some lane of the chunk is in a CELL_TEST cell of some frustum
-							// doCulling (culling_system.cpp:283-306), the operations of sphere_visible_d_pk: t = ((x*nx + y*ny) + z*nz) + d, t + r < 0 culls
-							const v2f x2 = {sp[i].x, sp[i].x}, y2 = {sp[i].y, sp[i].y}, z2 = {sp[i].z, sp[i].z}, r2 = {sp[i].w, sp[i].w};
-							bool culled = false;
 #pragma unroll
-							for (int k = 0; k < 6; k += 2) {
-								const v2f n_x = {nx[k], nx[k + 1]}, n_y = {ny[k], ny[k + 1]}, n_z = {nz[k], nz[k + 1]}, dd = {ci[i].d[k], ci[i].d[k + 1]};
-								v2f t = x2 * n_x;
-								t = t + y2 * n_y;
-								t = t + z2 * n_z;
-								t = t + dd;
-								t = t + r2;
-								culled = culled || (t.x < 0) || (t.y < 0);
-							}
-							vis = vis || (cls == CELL_TEST && !culled);
-						}
+						for (int j = 0; j < 2; ++j) ci[j] = s_info[f * a.cell_cap + local[h + j]];
 					}
-					vis = vis && id[g + i] >= 0;
-					vis_bits |= (vis ? 1u : 0u) << ((g + i) * FS + f);
-					const uint32_t add = vis ? one : 0u;
-					if (f < 3) cnt_pack[0] += add; else if (f < 6) cnt_pack[1] += add; else cnt_pack[2] += add; // (f is wave-uniform)
+#pragma unroll
+					for (int j = 0; j < 2; ++j) {
+						const int i = h + j;
+						if (!need_id[i]) continue; // wave-uniform
+						uint32_t vis = st == TILE_ACCEPT ? 1u : 0u;
+						if (mixed) {
+							const uint32_t cls = ci[j].cls;
+							uint32_t culled = 0;
+							if (need_sphere[i]) { // wave-uniform: some lane of the chunk is in a CELL_TEST cell of some frustum
+								// doCulling (culling_system.cpp:283-306), the operations of sphere_visible_d_pk: t = ((x*nx + y*ny) + z*nz) + d, t + r < 0 culls
+								const v2f x2 = {sp[i].x, sp[i].x}, y2 = {sp[i].y, sp[i].y}, z2 = {sp[i].z, sp[i].z}, r2 = {sp[i].w, sp[i].w};
+#pragma unroll
+								for (int k = 0; k < 6; k += 2) {
+									const v2f n_x = {nrm[k], nrm[k + 1]}, n_y = {nrm[6 + k], nrm[7 + k]}, n_z = {nrm[12 + k], nrm[13 + k]}, dd = {ci[j].d[k], ci[j].d[k + 1]};
+									v2f t = x2 * n_x;
+									t = t + y2 * n_y;
+									t = t + z2 * n_z;
+									t = t + dd;
+									t = t + r2;
+									culled |= (t.x < 0 ? 1u : 0u) | (t.y < 0 ? 1u : 0u); // (no short circuit: straight-line code)
+								}
+							}
+							vis = (cls == CELL_ACCEPT ? 1u : 0u) | ((cls == CELL_TEST ? 1u : 0u) & (culled ^ 1u));
+						}
+						vis &= id[g + i] >= 0 ? 1u : 0u;
+						vis_bits |= vis << ((g + i) * FS + f);
+						add_f += vis;
+					}
 				}
+				add_f *= one;
+				if (f < 3) cnt_pack[0] += add_f; else if (f < 6) cnt_pack[1] += add_f; else cnt_pack[2] += add_f; // (f is wave-uniform)
 			}
 		} else {
 #pragma unroll 1

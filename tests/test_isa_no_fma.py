@@ -49,8 +49,9 @@ def kernels(lines):
 
 @pytest.mark.parametrize("source, must_be_exact, may_fuse", [
     ("cull_kernels.hip", ["k_cull_tile", "k_cull_dynamic"], []),
-    ("xform_kernels.hip", ["k_xform_level", "k_xform_fused", "k_xform_finalize", "k_sphere_refresh", "k_bone_attach"], []),
-    ("skin_kernels.hip", ["k_pose_palette", "k_pose_blend", "k_skin_sharedILi1E", "k_skin_verticesILi1E"], ["k_skin_sharedILi0E", "k_skin_verticesILi0E", "k_skin_verticesILi2E"]),
+    ("xform_kernels.hip", ["k_xform_level", "k_xform_subtree", "k_sphere_refresh", "k_bone_attach"], []),
+    ("skin_kernels.hip", ["k_pose_palette", "k_pose_blend", "k_skin_sharedILi1E", "k_skin_verticesILi1E", "k_skin_multiILi1ELi1E", "k_skin_multiILi2ELi1E", "k_skin_multiILi4ELi1E", "k_skin_multiILi16ELi1E"],
+     ["k_skin_sharedILi0E", "k_skin_verticesILi0E", "k_skin_verticesILi2E"]),
     ("anim_kernels.hip", ["k_anim_update"], []),
 ])
 def test_bit_exact_kernels_contain_no_fused_multiply_add(tmp_path, source, must_be_exact, may_fuse):

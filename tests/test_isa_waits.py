@@ -76,3 +76,21 @@ def test_vertex_loops_keep_stores_in_flight(skin_isa, kernel, min_stores):
             loads = [k for k, i in enumerate(ins) if re.search(r"global_load_dwordx4", i) and "lds" not in i]
             assert 1 <= len(dma) <= 3 and len(loads) == 1, (h, dma, loads)
             assert all(" nt" in i for i in ins if "global_store_dwordx3" in i), f"loop {h}: the position stores are not non-temporal"
+
+
+@pytest.mark.parametrize("kernel", ["12k_skin_multiILi2ELi0E", "12k_skin_multiILi2ELi1E", "12k_skin_multiILi1ELi0E"])
+def test_multi_instance_loops_never_wait_for_their_stores(skin_isa, kernel):
+    """k_skin_multi (round 4): records stream through a two-deep pipeline; with two 16-byte loads and one store per step the wait for the
+    record loaded two steps ago is vmcnt(4) - it leaves the two newest stores (and the newest record's loads) in flight. The loop's entry
+    state holds no pending load (explicit vmcnt(0) behind the palette staging): merged into the steady state it would tighten the waits
+    to cover the previous step's store. The palettes of the block 768 ahead are touched by loads nobody waits for."""
+    body = kernel_body(skin_isa, kernel)
+    assert not any("scratch_" in l for l in body), "the kernel spills"
+    store_loops = {h: ins for h, ins in loops(body).items() if sum("global_store_dwordx3" in i for i in ins) >= 2}
+    assert len(store_loops) == 3, f"one vertex loop per palette-replication class expected, found {sorted(store_loops)}"
+    for h, ins in store_loops.items():
+        waits = [int(m.group(1)) for i in ins for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", i)] if m]
+        assert waits and min(waits) >= 4, f"loop {h} waits for its own stores: vmcnt {waits}"
+        assert all(" nt" in i for i in ins if "global_store_dwordx3" in i), f"loop {h}: the position stores are not non-temporal"
+        assert not any("s_barrier" in i for i in ins), f"loop {h}: a barrier in the steady state"
+    assert sum("global_load_dword " in l for l in body) >= 2, "the L2 touches of the next block's palettes are gone"

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["cull_default", "cull_stream", "cull_all_test", "cull_slab", "cull_dense", "cull8", "xform", "skin", "skin_distinct", "keys", "target"], required=True)
+    ap.add_argument("--workload", choices=["cull_default", "cull_stream", "cull_all_test", "cull8_all_test", "cull_slab", "cull_dense", "cull8", "xform", "skin", "skin_distinct", "keys", "target"], required=True)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--entities", type=int, default=10_000_000)
     ap.add_argument("--instances", type=int, default=2000)
@@ -47,7 +47,7 @@ def main():
     elif args.workload.startswith("cull"):
         half = 5000.0 if args.workload == "cull_dense" else 15000.0 * (args.entities / 1e7) ** (1.0 / 3.0)
         sc = scenes.cull_scene(args.entities, half, seed=2, mixed_types=args.workload == "cull8")
-        if args.workload == "cull_all_test":  # every sphere "big" (radius > 300): every cell CELL_TEST, every sphere fetched and tested
+        if args.workload in ("cull_all_test", "cull8_all_test"):  # every sphere "big" (radius > 300): every cell CELL_TEST, every sphere fetched and tested
             sc["radius"] = np.random.default_rng(5).uniform(300.5, 330.0, size=args.entities).astype(np.float32)
         if args.workload == "cull_slab":  # normal radii, one layer of cells, ortho slab camera: every cell CELL_TEST through the AABB pre-tests
             sc = scenes.slab_scene(args.entities, seed=2)
@@ -65,6 +65,9 @@ def main():
             fr = api.viewport_frustum(**scenes.slab_frustum_kwargs(sc["half"]))
         elif args.workload == "cull8":
             fr = H.cascade_frusta(api, 8)
+        elif args.workload == "cull8_all_test":  # bench.py's all_test_8_frusta_one_pass leg: config 5's 8 cascades in ONE pass over the spheres
+            fr = np.concatenate([api.viewport_frustum(**kw) for kw in scenes.config5_cascade_kwargs()])
+            cs.setPassWidth(8)
         else:
             fr = api.viewport_frustum()
         import time
