@@ -334,14 +334,21 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 				if (t < n_cells) classify(t, 0, key);
 			}
 		} else {
-			// Several frusta: the (cell, frustum) pairs are spread over the WAVES - a wave (or a group of waves) takes one frustum at a
-			// time, so the frustum stays wave-uniform (scalar loads) - and only the frusta whose tile verdict is MIXED are classified at
-			// all: a REJECTED / ACCEPTED frustum needs no per-cell work (phase B reads its verdict from st_bits). One thread per cell
-			// looping over all frusta kept ~100 of a block's 256-512 lanes busy for 8 x ~300 instructions: more than the spheres' own test.
-			const uint32_t wpf = (uint32_t)nf >= (uint32_t)WAVES ? 1u : (uint32_t)WAVES / (uint32_t)nf; // waves per frustum
-			for (uint32_t f = wave / wpf; f < (uint32_t)nf; f += (uint32_t)WAVES / wpf) {
-				if (((st_bits >> (2 * f)) & 3u) != TILE_MIXED) continue;
-				for (uint32_t t = (wave % wpf) * 64u + lane; t < n_cells; t += wpf * 64u) classify(t, (int)f, keys[t]);
+			// Several frusta: ONE lane per cell, the MIXED frusta in an inner, wave-uniform loop (scalar loads of the frustum). The cell's key is
+			// loaded once and its fp64 origin formed once for all frusta. Rounds 2 / 3 spread the (cell, frustum) PAIRS over the waves - every
+			// wave re-read every key and re-derived every origin for each of its frusta, with a load -> wait -> branch -> load chain in each of
+			// 16 half-empty wave iterations per tile: on the 10 M all-test scene (one cell per ~10 spheres) the classification issued more
+			// instructions than the 8 x 10 M sphere tests (72.6 M VALU wave-instructions a launch, 35 M of them the tests: profiles/r04/cull8_counters).
+			// Frusta whose tile verdict is not MIXED need no per-cell work (phase B reads their verdict from st_bits).
+			for (uint32_t t = threadIdx.x; t < n_cells; t += THREADS) {
+				const uint4 raw = reinterpret_cast<const uint4*>(keys)[t]; // ONE 16-byte load (ix, iy, iz, meta), not meta -> branch -> the rest
+				CellKey key;
+				key.ix = (int32_t)raw.x; key.iy = (int32_t)raw.y; key.iz = (int32_t)raw.z; key.meta = raw.w;
+#pragma unroll 1
+				for (int f = 0; f < nf; ++f) {
+					if (((st_bits >> (2 * f)) & 3u) != TILE_MIXED) continue; // wave-uniform
+					classify(t, f, key);
+				}
 			}
 		}
 		if constexpr (F != 1) {
