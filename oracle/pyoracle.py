@@ -291,6 +291,21 @@ class Oracle:
         f(_ptr(verts), _ptr(skin), _ptr(dq), _ptr(out), len(verts), n_bones, n_inst)
         return out
 
+    def evaluate_dq_skin_hlsl(self, verts, skin, dual_quats) -> np.ndarray:
+        """The same blend from the reference's OWN shader text (surface_base.hlsli:197-205 + transformByDualQuat, common.hlsli:632-636),
+        sliced at build time and compiled as C++ (oracle/ref/slice_hlsl.py, hlsl_shim.cpp). Reference oracle only."""
+        if self.kind != "reference":
+            raise RuntimeError("the sliced shader code lives in oracle/_ref/liblmx_ref.so: Oracle('reference')")
+        verts = np.ascontiguousarray(verts, np.float32)
+        skin = np.ascontiguousarray(skin, SKIN)
+        dq = np.ascontiguousarray(dual_quats, np.float32)
+        n_inst, n_bones = dq.shape[0], dq.shape[1]
+        out = np.zeros((n_inst, len(verts), 3), np.float32)
+        f = self.lib.ref_hlsl_dq_skin
+        f.restype, f.argtypes = None, [C.c_void_p] * 4 + [C.c_uint32] * 3
+        f(_ptr(verts), _ptr(skin), _ptr(dq), _ptr(out), len(verts), n_bones, n_inst)
+        return out
+
     def nlerp(self, q1, q2, t) -> np.ndarray:
         """simd_nlerp, core/simd_math.h:107-123 (port oracle only)."""
         q1, q2, t = np.ascontiguousarray(q1, np.float32).reshape(-1, 4), np.ascontiguousarray(q2, np.float32).reshape(-1, 4), np.ascontiguousarray(t, np.float32)

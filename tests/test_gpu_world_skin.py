@@ -597,10 +597,11 @@ def test_bone_attachments_golden_and_subtrees(gpu_ctx, oracle_port):
     sk.setMode(False)
 
 
-def test_skin_dual_quaternion_blend(gpu_ctx, oracle_port):
+def test_skin_dual_quaternion_blend(gpu_ctx, oracle_port, oracle_ref):
     """LMX_SKIN_DQS: the SKINNED branch of the reference's vertex shader (surface_base.hlsli:196-217, transformByDualQuat
     common.hlsli:632-636) on the bit-exact dual-quaternion palette, through both vertex kernels (a run of 6 instances on a
-    2500-vertex mesh -> k_skin_shared, 3 single small ones -> k_skin_vertices). Tolerance 1e-5: HLSL does not pin association."""
+    2500-vertex mesh -> k_skin_multi, 3 single small ones -> k_skin_vertices), against the reference's OWN shader text compiled as C++
+    (oracle/ref/slice_hlsl.py: f3 pinned) and the plain-C restatement. Tolerance 1e-5: HLSL does not pin association."""
     sk = api.Skinning(gpu_ctx)
     skel = [scenes.skeleton(64, seed=4), scenes.skeleton(100, seed=24)]
     meshes = [scenes.skinned_mesh(2500, 64, seed=6), scenes.skinned_mesh(300, 100, seed=7)]
@@ -617,9 +618,10 @@ def test_skin_dual_quaternion_blend(gpu_ctx, oracle_port):
         apos, arot = oracle_port.pose_compute_absolute(poses[i][0], poses[i][1], s["parents"], s["first_nonroot"])
         dq = oracle_port.dual_quats(apos, arot, oracle_port.invert_bind(s["bind"]))
         assert H.bits_equal(sk.readDualQuats(i), dq[0])
-        want = oracle_port.evaluate_dq_skin(meshes[k][0], meshes[k][1], dq)[0]
+        want = oracle_ref.evaluate_dq_skin_hlsl(meshes[k][0], meshes[k][1], dq)[0]  # the sliced shader text
         got = sk.readVertices(i)
         assert close_1e5(got, want), f"instance {i}"
+        assert H.bits_equal(want, oracle_port.evaluate_dq_skin(meshes[k][0], meshes[k][1], dq)[0])  # ... which the restatement reproduces bit for bit
         # a different deformation than linear blending, but of the same skeleton: same ballpark, not the same numbers
         lbs = oracle_port.evaluate_skin(meshes[k][0], meshes[k][1], oracle_port.skin_matrices(apos, arot, oracle_port.invert_bind(s["bind"])))[0]
         assert not np.allclose(got, lbs, rtol=1e-3, atol=1e-3)

@@ -352,3 +352,26 @@ def test_create_sort_keys_bit_exact(oracle_port, oracle_ref, vi):
         if f == 0:
             assert (len(a["poses"]) > 0 or vi == 2) and (a["lod"] != sc["lod"]).any()
     assert seen_types >= ({0, 1, 2, 3, 4} if vi != 2 else {0, 1, 3, 4})
+
+
+def test_dq_vertex_blend_restatement_equals_the_sliced_shader_text(oracle_port, oracle_ref):
+    """SURVEY.md 8f rank 3, pinned: the plain-C restatement of the reference's dual-quaternion vertex blend (oracle/lmx_oracle.c:
+    orc_evaluate_dq_skin) against the reference's OWN shader text - the SKINNED branch of data/shaders/surface_base.hlsli:197-205 and
+    transformByDualQuat, common.hlsli:632-636, cut out at build time (oracle/ref/slice_hlsl.py) and compiled as C++ with a float3 /
+    float4 / float2x4 shim (oracle/ref/hlsl_shim.cpp). Same expressions in the same order => the same bits, on ordinary skeletons and on
+    the adversarial case (antipodal quaternions, hemisphere tests decided by rounding, real parts with w ~ 0)."""
+    from lumixengine_amd import scenes
+    from tests import dq_exact as DQ
+
+    for nb, nv, seed in ((64, 4000, 6), (196, 700, 7), (3, 257, 8)):
+        s = scenes.skeleton(nb, seed=seed)
+        verts, skin = scenes.skinned_mesh(nv, nb, seed=seed + 10)
+        p, r = scenes.relative_poses(3, nb, seed=700 + seed)
+        apos, arot = oracle_port.pose_compute_absolute(p, r, s["parents"], s["first_nonroot"])
+        dq = oracle_port.dual_quats(apos, arot, oracle_port.invert_bind(s["bind"]))
+        assert H.bits_equal(oracle_port.evaluate_dq_skin(verts, skin, dq), oracle_ref.evaluate_dq_skin_hlsl(verts, skin, dq)), (nb, nv)
+    pos, rot, verts, skin = DQ.adversarial_case()
+    ident = np.zeros(len(pos), np.dtype([("pos", "<f4", 3), ("rot", "<f4", 4)], align=True))
+    ident["rot"][:, 3] = 1.0
+    dq = oracle_port.dual_quats(pos[None], rot[None], oracle_port.invert_bind(ident))
+    assert H.bits_equal(oracle_port.evaluate_dq_skin(verts, skin, dq), oracle_ref.evaluate_dq_skin_hlsl(verts, skin, dq)), "adversarial case"
