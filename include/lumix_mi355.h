@@ -167,6 +167,14 @@ LMX_API int lmx_cull_pack_device(LmxContext* ctx, uint32_t view, uint32_t frustu
  * view + a light query per frame, pipeline.cpp:1036-1045, :1252-1258) as one lmx_cull with n_frusta frusta and ONE host wait:
  * out_ids[f] / out_counts[f * LMX_MAX_TYPES + t] per frustum, valid until the next cull or map on this view. */
 LMX_API int lmx_cull_map_many(LmxContext* ctx, uint32_t view, uint32_t n_frusta, const int32_t** out_ids, uint32_t* out_counts);
+/* lmx_cull_map_many in two halves, for render jobs that cull DIFFERENT views at the same time (the reference culls the views of a frame
+ * from concurrent jobs: pipeline.cpp:1036-1041). lmx_cull_map_begin enqueues the pack + copy of the view's records behind its cull and
+ * records an event; like every entry point that enqueues, it needs the context lock (lmx_ctx_lock). lmx_cull_map_end waits for THAT
+ * view's event and hands out the pointers into the view's pinned buffer: it may be called WITHOUT the lock, concurrently with any
+ * other call that does not use the same view - the host wait and the consumer's copy out of the buffer overlap other threads'
+ * enqueues. host/gpu_culling_system.h is the caller; at most LMX_MAX_VIEWS results are in flight at a time. */
+LMX_API int lmx_cull_map_begin(LmxContext* ctx, uint32_t view, uint32_t n_frusta);
+LMX_API int lmx_cull_map_end(LmxContext* ctx, uint32_t view, uint32_t n_frusta, const int32_t** out_ids, uint32_t* out_counts);
 /* Device-side view of a result for GPU consumers (sort keys, RCCL all-gather): ids of (frustum, type) start at
  * d_ids + type_offsets[type] and number d_counts[frustum * LMX_MAX_TYPES + type]. All pointers are device memory
  * except type_offsets (host, LMX_MAX_TYPES entries, in ids). The cull kernels leave the visible ids in up to a few hundred

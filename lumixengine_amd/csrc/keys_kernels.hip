@@ -510,6 +510,18 @@ __global__ __launch_bounds__(256) void k_keys_mirror_fill(const int32_t* __restr
 	if (state_s != nullptr) state_s[s] = KeysSlotState{r.lod, r.pose_frame};
 }
 
+// new positions of the entity-indexed records into the mirror (lmx_keys_set_positions)
+__global__ __launch_bounds__(256) void k_keys_mirror_positions(const int32_t* __restrict__ slot_ids, uint32_t n_slots, const KeysInstance* __restrict__ inst, uint32_t n_entities,
+	KeysInstance* __restrict__ inst_s, KeysSoA soa) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s >= n_slots) return;
+	const int32_t e = slot_ids[s];
+	if (e < 0 || (uint32_t)e >= n_entities) return;
+	const double x = inst[e].pos[0], y = inst[e].pos[1], z = inst[e].pos[2];
+	if (soa.model != nullptr) { soa.px[s] = x; soa.py[s] = y; soa.pz[s] = z; }
+	else { inst_s[s].pos[0] = x; inst_s[s].pos[1] = y; inst_s[s].pos[2] = z; }
+}
+
 // lod / Pose::frame of the entities of slots [0, n_slots) (or of the slots the id patches are about to turn into tombstones) back
 // into the entity-indexed records
 __device__ __forceinline__ void mirror_hand_back(uint32_t s, const int32_t* slot_ids, const KeysInstance* inst_s, const int32_t* model_s, const KeysSlotState* state_s,
@@ -544,6 +556,11 @@ hipError_t launch_keys_mirror_fill(hipStream_t s, const int32_t* slot_ids, uint3
 	if (!n_slots) return hipSuccess;
 	hipLaunchKernelGGL(k_keys_mirror_fill, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, slot_ids, n_slots, inst, n_entities, models, mesh_materials, offset, inst_s, soa, mm_s,
 		state_s);
+	return hipGetLastError();
+}
+hipError_t launch_keys_mirror_positions(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, KeysInstance* inst_s, const KeysSoA& soa) {
+	if (!n_slots) return hipSuccess;
+	hipLaunchKernelGGL(k_keys_mirror_positions, dim3((n_slots + 255u) / 256u), dim3(256), 0, s, slot_ids, n_slots, inst, n_entities, inst_s, soa);
 	return hipGetLastError();
 }
 hipError_t launch_keys_mirror_sync(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, const int32_t* model_s, const KeysSlotState* state_s,

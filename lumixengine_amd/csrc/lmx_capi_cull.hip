@@ -51,6 +51,7 @@ struct CullAsync {
 	std::vector<CullOp> log_shared; // under `mu`: operations the shadow set has not seen yet
 	std::mutex mu;
 	std::condition_variable cv;
+	std::condition_variable cv_idle; // signalled by the worker when a job ends (async_wait_idle sleeps on it)
 	State state = IDLE;             // under `mu`
 	std::thread worker;
 	hipStream_t stream = nullptr;   // the worker's own (non-blocking) stream
@@ -787,9 +788,11 @@ void async_worker(LmxContext* ctx, CullAsync* a) {
 		else if (a->drain_only) {
 			a->state = CullAsync::IDLE;
 			a->drains++;
+			a->cv_idle.notify_all();
 			continue;
 		} else a->state = CullAsync::READY;
 		a->jobs_done++;
+		a->cv_idle.notify_all(); // (async_wait_idle)
 	}
 }
 
@@ -829,11 +832,10 @@ void async_reseed(CullState& cs) {
 }
 
 void async_wait_idle(CullAsync& a) { // update thread: let a running job finish (its result is discarded by the caller)
-	for (;;) {
-		const CullAsync::State st = async_state(a);
-		if (st != CullAsync::REQUESTED && st != CullAsync::RUNNING) return;
-		std::this_thread::yield();
-	}
+	// (a sleep on the worker's own condition variable, not a yield spin: the caller holds the context's lock for as long as the job
+	// runs - 0.5 s at 10 M entities - and should not burn a core next to the worker meanwhile)
+	std::unique_lock<std::mutex> g(a.mu);
+	a.cv_idle.wait(g, [&] { return a.state != CullAsync::REQUESTED && a.state != CullAsync::RUNNING; });
 }
 
 int recompute_out_layout(LmxContext* ctx);
@@ -1442,7 +1444,9 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 		ProfScope ps(ctx, LMX_K_CULL_SPHERES, true);
 		po.ev_start = ps.slot.a;
 		po.ev_stop = ps.slot.b;
-		LMX_HIP(ctx, launch_cull_tile(ctx->stream, dv, ent_begin, ent_end, cs.tt, sub, (int)fw, po, variant, cs.lane_parallel));
+		const hipError_t launched = launch_cull_tile(ctx->stream, dv, ent_begin, ent_end, cs.tt, sub, (int)fw, po, variant, cs.lane_parallel);
+		if (launched != hipSuccess) ps.cancel(); // (the launch fills the scope's events itself: none were recorded)
+		LMX_HIP(ctx, launched);
 	}
 	// dynamic set: its own shards of the same rows / counters
 	if (dyn_end > dyn_begin) {
@@ -1585,7 +1589,12 @@ int lmx_cull_read_all(LmxContext* ctx, uint32_t view, uint32_t frustum, int32_t*
 // Records [MAX_TYPES counts | ids, types back to back] of frusta [first, first + n) of a view, each packed by one k_cull_pack launch into
 // its own area of map_rec and copied into pinned host memory - counts + the first map_guess ids before the count is known - with ONE
 // host wait for all of them (a second one only for a frustum whose list outgrew its guess, this frame only).
-static int cull_map_range(LmxContext* ctx, CullView& v, uint32_t first, uint32_t n, const int32_t** out_ids, uint32_t* out_counts) {
+// The host read of a view's result in two halves, so that render jobs culling different views only serialise on the ENQUEUE:
+//   cull_map_begin  (context lock held) packs the shard windows into one record per frustum, enqueues its copy into the view's pinned
+//                   buffer - as many ids as the last frame on that view needed + 25 % - and records the view's event behind it;
+//   cull_map_end    (no lock needed: touches this view's buffers only) waits for THAT event, reads the counts, and - only if the list
+//                   outgrew the guess - takes the lock for a second copy.
+static int cull_map_begin(LmxContext* ctx, CullView& v, uint32_t first, uint32_t n) {
 	CullState& cs = ctx->cull;
 	const size_t need = (size_t)MAX_TYPES + v.out_stride; // words per record area
 	if (v.map_words < need || v.map_frusta < v.n_frusta) {
@@ -1600,18 +1609,37 @@ static int cull_map_range(LmxContext* ctx, CullView& v, uint32_t first, uint32_t
 		v.map_words = want;
 		v.map_frusta = areas;
 	}
+	if (!v.map_event) LMX_HIP(ctx, hipEventCreateWithFlags(&v.map_event, hipEventDisableTiming));
 	const uint32_t cnt_frustum_stride = cs.n_shards * cs.cnt_pad;
-	size_t guess[MAX_FRUSTA];
 	for (uint32_t k = 0; k < n; ++k) {
 		const uint32_t f = first + k;
 		const uint32_t* counts = v.counts_ptr() + (size_t)f * cnt_frustum_stride;
 		int32_t* rec = v.map_rec.p + (size_t)f * v.map_words;
 		LMX_HIP(ctx, launch_cull_pack(ctx->stream, v.out.p + (size_t)f * v.out_stride, cs.d_win_base.p, counts, cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, cs.max_shard_cap,
 			reinterpret_cast<uint32_t*>(rec), rec + MAX_TYPES, v.out_stride));
-		guess[k] = std::min<size_t>(v.out_stride, v.map_guess[f]);
-		LMX_HIP(ctx, hipMemcpyAsync(reinterpret_cast<int32_t*>(v.map_host) + (size_t)f * v.map_words, rec, (MAX_TYPES + guess[k]) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+		v.map_begin_guess[k] = std::min<size_t>(v.out_stride, v.map_guess[f]);
+		LMX_HIP(ctx, hipMemcpyAsync(reinterpret_cast<int32_t*>(v.map_host) + (size_t)f * v.map_words, rec, (MAX_TYPES + v.map_begin_guess[k]) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
 	}
-	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	LMX_HIP(ctx, hipEventRecord(v.map_event, ctx->stream));
+	v.map_begin_first = first;
+	v.map_begin_n = n;
+	return LMX_OK;
+}
+
+static int cull_map_end(LmxContext* ctx, CullView& v, uint32_t first, uint32_t n, const int32_t** out_ids, uint32_t* out_counts) {
+	struct Locked { // (error strings and stream operations belong to the context: taken only on the rare paths)
+		LmxContext* c;
+		explicit Locked(LmxContext* c_) : c(c_) { c->lock.lock(); }
+		~Locked() { c->lock.unlock(); }
+	};
+	if (!v.map_event || v.map_begin_n != n || v.map_begin_first != first) {
+		Locked l(ctx);
+		return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_cull_map_end without a matching lmx_cull_map_begin on this view");
+	}
+	if (hipEventSynchronize(v.map_event) != hipSuccess) {
+		Locked l(ctx);
+		return fail(ctx, LMX_ERR_HIP, "waiting for the view's record failed");
+	}
 	bool more = false;
 	for (uint32_t k = 0; k < n; ++k) {
 		const uint32_t f = first + k;
@@ -1619,20 +1647,33 @@ static int cull_map_range(LmxContext* ctx, CullView& v, uint32_t first, uint32_t
 		const uint32_t* h = reinterpret_cast<const uint32_t*>(host);
 		size_t total = 0;
 		for (int t = 0; t < MAX_TYPES; ++t) {
-			if (h[t] > v.out_cap[t]) return fail(ctx, LMX_ERR_HIP, "corrupt count %u > %u", h[t], v.out_cap[t]);
+			if (h[t] > v.out_cap[t]) {
+				Locked l(ctx);
+				return fail(ctx, LMX_ERR_HIP, "corrupt count %u > %u", h[t], v.out_cap[t]);
+			}
 			out_counts[k * MAX_TYPES + t] = h[t];
 			total += h[t];
 		}
-		if (total > guess[k]) { // the list outgrew the guess: fetch the rest (second wait, this frame only)
-			LMX_HIP(ctx, hipMemcpyAsync(host + MAX_TYPES + guess[k], v.map_rec.p + (size_t)f * v.map_words + MAX_TYPES + guess[k], (total - guess[k]) * sizeof(int32_t),
-				hipMemcpyDeviceToHost, ctx->stream));
+		if (total > v.map_begin_guess[k]) { // the list outgrew the guess: fetch the rest (second wait, this frame only)
+			Locked l(ctx);
+			LMX_HIP(ctx, hipMemcpyAsync(host + MAX_TYPES + v.map_begin_guess[k], v.map_rec.p + (size_t)f * v.map_words + MAX_TYPES + v.map_begin_guess[k],
+				(total - v.map_begin_guess[k]) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
 			more = true;
 		}
 		v.map_guess[f] = total + total / 4 + 1024;
 		out_ids[k] = host + MAX_TYPES;
 	}
-	if (more) LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (more) {
+		Locked l(ctx);
+		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	v.map_begin_n = 0;
 	return LMX_OK;
+}
+
+static int cull_map_range(LmxContext* ctx, CullView& v, uint32_t first, uint32_t n, const int32_t** out_ids, uint32_t* out_counts) {
+	if (int rc = cull_map_begin(ctx, v, first, n)) return rc;
+	return cull_map_end(ctx, v, first, n, out_ids, out_counts);
 }
 
 // The packed record of one frustum left in HBM, no host wait: what a device-side consumer of "one cull incl. compaction" reads
@@ -1674,6 +1715,21 @@ int lmx_cull_map_many(LmxContext* ctx, uint32_t view, uint32_t n_frusta, const i
 	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
 	if (n_frusta != v.n_frusta) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "the view holds %u frusta, not %u", v.n_frusta, n_frusta);
 	return cull_map_range(ctx, v, 0, n_frusta, out_ids, out_counts);
+}
+
+int lmx_cull_map_begin(LmxContext* ctx, uint32_t view, uint32_t n_frusta) {
+	LMX_CHECK_CTX(ctx);
+	if (view >= LMX_MAX_VIEWS) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad view");
+	CullView& v = ctx->cull.views[view];
+	if (!v.valid) return fail(ctx, LMX_ERR_NOT_BUILT, "view %u holds no cull result", view);
+	if (n_frusta != v.n_frusta) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "the view holds %u frusta, not %u", v.n_frusta, n_frusta);
+	return cull_map_begin(ctx, v, 0, n_frusta);
+}
+
+int lmx_cull_map_end(LmxContext* ctx, uint32_t view, uint32_t n_frusta, const int32_t** out_ids, uint32_t* out_counts) {
+	if (!ctx) return LMX_ERR_INVALID_ARGUMENT; // (LMX_CHECK_CTX selects the context's device: not needed to wait for an event and read host memory)
+	if (view >= LMX_MAX_VIEWS || !out_counts || !out_ids) return LMX_ERR_INVALID_ARGUMENT;
+	return cull_map_end(ctx, ctx->cull.views[view], 0, n_frusta, out_ids, out_counts);
 }
 
 int lmx_cull_bind_output(LmxContext* ctx, uint32_t view, void* d_ids, size_t ids_capacity, void* d_counts) {

@@ -191,14 +191,19 @@ int lmx_keys_set_positions(LmxContext* ctx, const double* xyz, uint32_t n_entiti
 		for (size_t e = old_n; e < n_entities; ++e) { memset(&ks.inst[e], 0, sizeof(KeysInstance)); ks.inst[e].model = -1; }
 	}
 	for (uint32_t e = 0; e < n_entities; ++e) memcpy(ks.inst[e].pos, xyz + 3 * (size_t)e, sizeof(double) * 3);
-	if (int rc = keys_before_layout_change(ctx)) return rc; // the slot-ordered mirror holds positions too: it is rebuilt by the next lmx_keys_run
 	if (!ks.inst_dirty && ks.d_inst.p && ks.d_inst.cap >= ks.inst.size() && ks.inst.size() == ks.inst_uploaded) {
 		// the records are on the device already: only the positions are replaced (24 of every 64 bytes), ModelInstance::lod and
 		// Pose::frame keep the state the kernels advanced
 		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		LMX_HIP(ctx, hipMemcpy2D(reinterpret_cast<char*>(ks.d_inst.p) + offsetof(KeysInstance, pos), sizeof(KeysInstance), xyz, sizeof(double) * 3, sizeof(double) * 3, n_entities,
 			hipMemcpyHostToDevice));
+		// ... and the slot-ordered mirror takes them from there (one gather over the slots) instead of being dropped and rebuilt - count,
+		// scan, fill, a copy of the material table - by the next run: a host that uploads positions every frame (no lmx_keys_bind_world)
+		// paid an O(sorted set) rebuild per frame for a mirror that exists to save time
+		if (ks.mirror_valid)
+			LMX_HIP(ctx, launch_keys_mirror_positions(ctx->stream, ctx->cull.ids.p, std::min(ks.mirror_slots, ctx->cull.n_padded), ks.d_inst.p, ks.n_entities, ks.d_inst_s.p, ks.soa()));
 	} else {
+		if (int rc = keys_before_layout_change(ctx)) return rc; // the whole table is uploaded again by the next run: the mirror is rebuilt from it
 		ks.inst_dirty = true;
 	}
 	ks.n_positions = n_entities;
@@ -300,6 +305,11 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 		cs.emit_slots = true;
 		if (v.has_slots) {
 			if (int rc = keys_build_mirror(ctx)) return rc;
+		} else if (ks.mirror_valid) {
+			// this view was culled before the culls emitted slots (or kept across a flush): it is walked through the entity-indexed tables,
+			// but ModelInstance::lod / Pose::frame of the sorted set's entities live in the mirror - hand them back first, or this run
+			// would read stale lod values and stamp a second copy of Pose::frame (a pose pushed twice in one frame)
+			if (int rc = keys_before_layout_change(ctx)) return rc;
 		}
 	} else if (ks.mirror_valid) {
 		if (int rc = keys_before_layout_change(ctx)) return rc;

@@ -79,10 +79,16 @@ struct CullView {
 	size_t map_guess[LMX_MAX_FRUSTA] = {4096, 4096, 4096, 4096, 4096, 4096, 4096, 4096}; // ids (per frustum) the next call copies before it knows the count
 	size_t map_frusta = 0;   // record areas the buffers were sized for
 	DevBuf<int32_t> map_rec;
+	hipEvent_t map_event = nullptr; // recorded behind the record's copies (lmx_cull_map_begin): lmx_cull_map_end waits for THIS view only
+	size_t map_begin_guess[LMX_MAX_FRUSTA] = {}; // what lmx_cull_map_begin asked the copies for
+	uint32_t map_begin_first = 0, map_begin_n = 0;
 	DevBuf<uint32_t> map_pref, map_start;
 	DevBuf<int32_t> pack_rec; // lmx_cull_pack_device: the packed record of one frustum, left on the device
 	size_t pack_words = 0;
-	~CullView() { if (map_host) (void)hipHostFree(map_host); }
+	~CullView() {
+		if (map_host) (void)hipHostFree(map_host);
+		if (map_event) (void)hipEventDestroy(map_event);
+	}
 	CullView() = default;
 	CullView(const CullView&) = delete;
 	CullView& operator=(const CullView&) = delete;
@@ -512,6 +518,14 @@ struct ProfScope { // records HIP events around one launch on the launch stream 
 		if (!on) return;
 		if (!ext) (void)hipEventRecord(slot.b, ctx->stream);
 		ctx->prof_pending.push_back(slot);
+	}
+	// the launch that should have filled the events failed before it was issued: the pair goes back to the pool unrecorded (queued, the
+	// drain would call hipEventElapsedTime on events nobody recorded and hide the launch's own error behind its own)
+	void cancel() {
+		if (!on) return;
+		ctx->event_pool.push_back(slot.a);
+		ctx->event_pool.push_back(slot.b);
+		on = false;
 	}
 	hipEvent_t take() {
 		if (!ctx->event_pool.empty()) {

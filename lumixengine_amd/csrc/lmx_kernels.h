@@ -281,6 +281,7 @@ struct KeysDevice {
 hipError_t launch_keys_mirror_count(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models, uint32_t* count);
 hipError_t launch_keys_mirror_fill(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models,
 	const LmxMeshMaterial* mesh_materials, const uint32_t* offset, KeysInstance* inst_s /* or */, const KeysSoA& soa, LmxMeshMaterial* mm_s, KeysSlotState* state_s /* optional */);
+hipError_t launch_keys_mirror_positions(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, KeysInstance* inst_s, const KeysSoA& soa);
 hipError_t launch_keys_mirror_sync(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, const int32_t* model_s, const KeysSlotState* state_s,
 	KeysInstance* inst, uint32_t n_entities);
 hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint32_t n, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, const int32_t* model_s,

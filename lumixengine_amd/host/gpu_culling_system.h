@@ -13,9 +13,11 @@
 // frame from render jobs. The C ABI context is not re-entrant, and it is SHARED with the plugin's module (one LmxContext per
 // World: the culling set, the transform hierarchy that refreshes its spheres and the skinning tables are one device-side
 // object, as the reference's CullingSystem and RenderModuleImpl::onModelInstanceMoved work on one object): every call takes
-// the context's own recursive lock (lmx_ctx_lock), not a lock of this adapter. Each cull() uses its own result slot
-// (LMX_MAX_VIEWS of them), so calls serialise on the GPU stream but never alias results; cullMany() culls all views of a
-// frame in one pass over the spheres with one host wait.
+// the context's own recursive lock (lmx_ctx_lock), not a lock of this adapter. A cull() holds it only while it ENQUEUES (the cull,
+// the pack of its record, the copy into the view's pinned buffer: lmx_cull_map_begin); the wait for its own view's event and the
+// page building (lmx_cull_map_end, toPages) run outside, so concurrent views overlap everything but the enqueue. Each cull() uses
+// its own result slot (LMX_MAX_VIEWS of them in flight); cullMany() culls all views of a frame in one pass over the spheres with
+// one host wait (INTEGRATION.md shows the Pipeline change that calls it).
 #pragma once
 
 #include <cstdio>
@@ -108,15 +110,20 @@ struct GpuCullingSystem final : CullingSystem {
 	bool cullMany(const ShiftedFrustum* frusta, u32 n_frusta, u8 type, CullResult** out) {
 		for (u32 f = 0; f < n_frusta; ++f) out[f] = nullptr;
 		if (!m_ctx || n_frusta == 0 || n_frusta > LMX_MAX_FRUSTA) return false;
-		CtxLock guard(m_ctx);
-		uint32_t n_static = 0, n_bound = 0, n_overflow = 0;
-		if (!check(lmx_cull_update_stats(m_ctx, &n_static, &n_bound, &n_overflow, nullptr))) return false;
-		if (n_static + n_bound + n_overflow == 0) return true; // no cells: culling_system.cpp:322
-		const uint32_t view = m_next_view++ % LMX_MAX_VIEWS;
-		if (!check(lmx_cull(m_ctx, view, reinterpret_cast<const LmxShiftedFrustum*>(frusta), n_frusta, type))) return false;
+		uint32_t view;
+		{ // enqueue under the context's lock: the cull, the pack of its records and their copy into the view's pinned buffer
+			CtxLock guard(m_ctx);
+			uint32_t n_static = 0, n_bound = 0, n_overflow = 0;
+			if (!check(lmx_cull_update_stats(m_ctx, &n_static, &n_bound, &n_overflow, nullptr))) return false;
+			if (n_static + n_bound + n_overflow == 0) return true; // no cells: culling_system.cpp:322
+			view = m_next_view++ % LMX_MAX_VIEWS;
+			if (!check(lmx_cull(m_ctx, view, reinterpret_cast<const LmxShiftedFrustum*>(frusta), n_frusta, type))) return false;
+			if (!check(lmx_cull_map_begin(m_ctx, view, n_frusta))) return false;
+		}
+		// the host wait and the page building run outside the lock: other render jobs enqueue their views meanwhile
 		uint32_t counts[LMX_MAX_FRUSTA * LMX_MAX_TYPES];
 		const int32_t* ids[LMX_MAX_FRUSTA];
-		if (!check(lmx_cull_map_many(m_ctx, view, n_frusta, ids, counts))) return false;
+		if (!checkUnlocked(lmx_cull_map_end(m_ctx, view, n_frusta, ids, counts))) return false;
 		for (u32 f = 0; f < n_frusta; ++f) out[f] = toPages(ids[f], counts + f * LMX_MAX_TYPES, type);
 		return true;
 	}
@@ -151,6 +158,12 @@ private:
 		return false;
 	}
 
+	bool checkUnlocked(int rc) { // (the error string belongs to the context: read it under its lock)
+		if (rc == LMX_OK) return true;
+		CtxLock guard(m_ctx);
+		return check(rc);
+	}
+
 	CullResult* newPage(u8 type) {
 		CullResult* page = new (m_page_allocator.allocate()) CullResult;
 		page->header.type = type;
@@ -182,17 +195,22 @@ private:
 
 	CullResult* cullInternal(const ShiftedFrustum& frustum, u8 type) {
 		if (!m_ctx) return nullptr;
-		CtxLock guard(m_ctx);
-		uint32_t n_static = 0, n_bound = 0, n_overflow = 0;
-		if (!check(lmx_cull_update_stats(m_ctx, &n_static, &n_bound, &n_overflow, nullptr))) return nullptr;
-		if (n_static + n_bound + n_overflow == 0) return nullptr; // no cells: culling_system.cpp:322
-		const uint32_t view = m_next_view++ % LMX_MAX_VIEWS;
-		static_assert(sizeof(ShiftedFrustum) == sizeof(LmxShiftedFrustum), "layout");
-		if (!check(lmx_cull(m_ctx, view, reinterpret_cast<const LmxShiftedFrustum*>(&frustum), 1, type))) return nullptr;
-		// normally one host wait per cull: totals + ids arrive as one record in the library's pinned host memory, read in place
+		uint32_t view;
+		{ // enqueue under the context's lock (several views may be in flight concurrently, pipeline.cpp:1036-1041: they only serialise HERE)
+			CtxLock guard(m_ctx);
+			uint32_t n_static = 0, n_bound = 0, n_overflow = 0;
+			if (!check(lmx_cull_update_stats(m_ctx, &n_static, &n_bound, &n_overflow, nullptr))) return nullptr;
+			if (n_static + n_bound + n_overflow == 0) return nullptr; // no cells: culling_system.cpp:322
+			view = m_next_view++ % LMX_MAX_VIEWS;
+			static_assert(sizeof(ShiftedFrustum) == sizeof(LmxShiftedFrustum), "layout");
+			if (!check(lmx_cull(m_ctx, view, reinterpret_cast<const LmxShiftedFrustum*>(&frustum), 1, type))) return nullptr;
+			if (!check(lmx_cull_map_begin(m_ctx, view, 1))) return nullptr;
+		}
+		// one host wait per cull, on this view's own event: totals + ids arrive as one record in the library's pinned host memory and
+		// are copied into the engine's pages here, outside the lock (up to LMX_MAX_VIEWS results in flight)
 		uint32_t counts[LMX_MAX_TYPES];
 		const int32_t* ids = nullptr;
-		if (!check(lmx_cull_map_all(m_ctx, view, 0, &ids, counts))) return nullptr;
+		if (!checkUnlocked(lmx_cull_map_end(m_ctx, view, 1, &ids, counts))) return nullptr;
 		return toPages(ids, counts, type);
 	}
 

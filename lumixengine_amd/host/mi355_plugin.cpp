@@ -42,10 +42,18 @@ namespace Lumix {
 // Drop-in for `m_culling_system = CullingSystem::create(m_allocator, engine.getPageAllocator())` (render_module.cpp:3569): same
 // ownership (UniquePtr destroyed through the same IAllocator), plus the World the RenderModule belongs to (RenderModuleImpl has it
 // as m_world) - the key under which the plugin's module finds the same context.
-UniquePtr<CullingSystem> createGpuCullingSystem(IAllocator& allocator, PageAllocator& page_allocator, World& world) {
+// async_compaction (default on): the re-sort of the sorted set runs on a worker thread against a SECOND host + device copy of the culling
+// sets (~40 bytes per entity on the device: 400 MB of HBM at 10 M entities, plus an operation log of up to 40 MB) and is traded with the
+// live set inside a later cull - no frame stalls, as the reference's add / remove / set* never do (culling_system.cpp:131-258). Pass false
+// where memory matters more than the worst frame (tools, tests, worlds that only change at level boundaries: the re-sort then happens
+// inside the flush that crosses the threshold, 0.5 s at 10 M entities, or when the host calls lmx_cull_compact).
+UniquePtr<CullingSystem> createGpuCullingSystem(IAllocator& allocator, PageAllocator& page_allocator, World& world, bool async_compaction) {
 	UniquePtr<GpuCullingSystem> cs = UniquePtr<GpuCullingSystem>::create(allocator, page_allocator, static_cast<const void*>(&world));
-	if (cs.get() && cs->isValid()) cs->setAsyncCompaction(true); // a game's culling system must never stall a frame (culling_system.cpp:131-258 do not)
+	if (async_compaction && cs.get() && cs->isValid()) cs->setAsyncCompaction(true);
 	return cs;
+}
+UniquePtr<CullingSystem> createGpuCullingSystem(IAllocator& allocator, PageAllocator& page_allocator, World& world) {
+	return createGpuCullingSystem(allocator, page_allocator, world, true);
 }
 
 struct Mi355Module final : IModule {

@@ -1,5 +1,5 @@
 // lumix_compat.h — the handful of LumixEngine declarations the hot-path seam touches, for STANDALONE builds of the
-// adapters in this directory (tests, tools). Inside a LumixEngine tree define LMX_WITH_LUMIX_HEADERS and the adapters
+// adapters of lumixengine_amd/host/ (TEST INFRASTRUCTURE: it lives in tests/cpp/, add -Itests/cpp). Inside a LumixEngine tree define LMX_WITH_LUMIX_HEADERS and the adapters
 // include the engine's own headers instead; the layouts below are byte-compatible with
 //   EntityRef / EntityPtr      src/engine/lumix.h:11-47
 //   Vec3 / DVec3 / Quat        src/core/math.h

@@ -23,6 +23,9 @@
 
 #include <algorithm>
 #include <vector>
+#include <thread>
+#include <atomic>
+#include <chrono>
 #include <unistd.h>
 
 #include "shell_engine.h" // oracle/ref: an Engine that owns an allocator (mine)
@@ -231,6 +234,62 @@ void testCullingSystem(IAllocator& heap, PageAllocator& pages) {
 		CHECK(a.v == b.v, "cullMany view %u: %zu vs reference %zu", f, a.v.size(), b.v.size());
 	}
 	printf("culling system: %u entities, 6000 interleaved calls, %zu views: identical to CullingSystemImpl\n", next, frusta.size());
+
+	// Several views in flight concurrently (the reference's render jobs cull the views of a frame from different threads,
+	// pipeline.cpp:1036-1041): six threads, one view each, 50 frames, started together. cull() serialises on the context's lock only
+	// while it enqueues; the waits (each on its own view's event) and the page building overlap. Every result is the reference's, and
+	// the host time of a frame's six views is reported three ways: one after the other, six threads, and ONE cullMany pass.
+	{
+		GpuCullingSystem* gc = static_cast<GpuCullingSystem*>(gpu.get());
+		std::vector<Visible> want(nf);
+		for (u32 f = 0; f < nf; ++f) want[f] = flatten(ref->cull(frusta[f]), pages);
+		auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		for (int warm = 0; warm < 5; ++warm)
+			for (u32 f = 0; f < nf; ++f) flatten(gpu->cull(frusta[f]), pages);
+		const int frames = 50;
+		double t0 = now();
+		for (int k = 0; k < frames; ++k)
+			for (u32 f = 0; f < nf; ++f) { CullResult* r = gpu->cull(frusta[f]); if (r) r->free(pages); }
+		const double ms_serial = (now() - t0) / frames;
+		std::atomic<int> bad{0}, arrived{0};
+		std::atomic<int> go{0};
+		std::vector<std::thread> threads;
+		std::vector<double> t_thread(nf, 0.0);
+		for (u32 f = 0; f < nf; ++f)
+			threads.emplace_back([&, f] {
+				for (int k = 0; k < frames; ++k) {
+					arrived.fetch_add(1);
+					while (go.load(std::memory_order_acquire) <= k) std::this_thread::yield(); // every frame's six culls start together
+					CullResult* r = gpu->cull(frusta[f]);
+					if (k % 10 == 0) { // (checking every frame would time the check)
+						Visible got = flatten(r, pages);
+						if (got.v != want[f].v) bad.fetch_add(1);
+					} else if (r) {
+						r->free(pages);
+					}
+				}
+			});
+		double t_conc = 0;
+		for (int k = 0; k < frames; ++k) {
+			while (arrived.load() < (int)nf * (k + 1)) std::this_thread::yield();
+			const double a = now();
+			go.store(k + 1, std::memory_order_release);
+			while (arrived.load() < (int)nf * (k + 2) && k + 1 < frames) std::this_thread::yield(); // all six are back at the gate = the frame's culls are done
+			if (k + 1 == frames) break;
+			t_conc += now() - a;
+		}
+		for (std::thread& t : threads) t.join();
+		const double ms_conc = t_conc / (frames - 1);
+		CHECK(bad.load() == 0, "%d concurrent culls differ from the reference's", bad.load());
+		t0 = now();
+		for (int k = 0; k < frames; ++k) {
+			CHECK(gc->cullMany(frusta.data(), nf, 0xff, many), "cullMany failed");
+			for (u32 f = 0; f < nf; ++f) if (many[f]) many[f]->free(pages);
+		}
+		const double ms_many = (now() - t0) / frames;
+		printf("culling system: %u views of a frame, host time incl. CullResult pages: %.3f ms one after the other, %.3f ms from %u concurrent threads, %.3f ms as ONE cullMany pass; "
+			   "every concurrent result identical to CullingSystemImpl\n", nf, ms_serial, ms_conc, nf, ms_many);
+	}
 
 	// what createGpuCullingSystem() switches on for the engine: the re-sort of the sorted set on a worker thread. 80 000 more entities
 	// push the overflow past the compaction threshold; updates and culls go on while the worker re-sorts, and after the sets have traded

@@ -16,12 +16,12 @@ EXE = os.path.join(ROOT, "tests", "_build", "test_adapter")
 
 def build_adapter_test():
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
-    deps = [SRC, os.path.join(ROOT, "lumixengine_amd", "host", "gpu_culling_system.h"), os.path.join(ROOT, "lumixengine_amd", "host", "lumix_compat.h")]
+    deps = [SRC, os.path.join(ROOT, "lumixengine_amd", "host", "gpu_culling_system.h"), os.path.join(ROOT, "tests", "cpp", "lumix_compat.h")]
     if os.path.exists(EXE) and all(os.path.getmtime(d) <= os.path.getmtime(EXE) for d in deps):
         return
     lib_dir = os.path.join(ROOT, "lumixengine_amd")
     subprocess.run(
-        ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "lumixengine_amd", "host"), SRC, "-o", EXE,
+        ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "lumixengine_amd", "host"), "-I" + os.path.join(ROOT, "tests", "cpp"), SRC, "-o", EXE,
          "-L" + lib_dir, "-llumix_mi355", "-Wl,-rpath," + lib_dir, "-pthread"],
         check=True,
     )

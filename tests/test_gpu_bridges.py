@@ -20,11 +20,11 @@ HOST = os.path.join(ROOT, "lumixengine_amd", "host")
 
 def build_exe():
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
-    deps = [SRC] + [os.path.join(HOST, h) for h in ("world_sync.h", "pose_bridge.h", "lumix_compat.h")]
+    deps = [SRC] + [os.path.join(HOST, h) for h in ("world_sync.h", "pose_bridge.h")] + [os.path.join(ROOT, "tests", "cpp", "lumix_compat.h")]
     if os.path.exists(EXE) and all(os.path.getmtime(d) <= os.path.getmtime(EXE) for d in deps):
         return
     lib_dir = os.path.join(ROOT, "lumixengine_amd")
-    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + HOST, SRC, "-o", EXE, "-L" + lib_dir, "-llumix_mi355",
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + HOST, "-I" + os.path.join(ROOT, "tests", "cpp"), SRC, "-o", EXE, "-L" + lib_dir, "-llumix_mi355",
                     "-Wl,-rpath," + lib_dir, "-pthread"], check=True)
 
 

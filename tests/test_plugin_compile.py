@@ -61,8 +61,8 @@ def test_plugin_entry_symbol(ref_src, tmp_path):
 
 
 def test_adapters_compile_standalone_too():
-    """The same headers against lumix_compat.h (no engine): what the functional C++ tests build."""
+    """The same headers against tests/cpp/lumix_compat.h (the interface mock of the tests, no engine): what the functional C++ tests build."""
     for h in ("gpu_culling_system.h", "world_sync.h", "pose_bridge.h"):
-        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + HOST, "-x", "c++", os.path.join(HOST, h)],
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + HOST, "-I" + os.path.join(ROOT, "tests", "cpp"), "-x", "c++", os.path.join(HOST, h)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
