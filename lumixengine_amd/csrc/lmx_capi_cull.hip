@@ -1486,6 +1486,7 @@ int lmx_cull_set_option(LmxContext* ctx, int option, int value) {
 			cs.compaction_min = (uint32_t)value;
 			return LMX_OK;
 		case LMX_CULL_OPT_DEVICE_OWNS_BOUND: cs.device_owns_bound = value != 0; return LMX_OK;
+		case LMX_CULL_OPT_MAP_ZERO_COPY: cs.map_zero_copy = value != 0; return LMX_OK;
 		case LMX_CULL_OPT_ASYNC_COMPACTION:
 			if (value) return async_enable(ctx);
 			async_disable(cs);
@@ -1611,14 +1612,25 @@ static int cull_map_begin(LmxContext* ctx, CullView& v, uint32_t first, uint32_t
 	}
 	if (!v.map_event) LMX_HIP(ctx, hipEventCreateWithFlags(&v.map_event, hipEventDisableTiming));
 	const uint32_t cnt_frustum_stride = cs.n_shards * cs.cnt_pad;
+	// Small lists (what a view of a game scene usually is: <= 64 k ids last frame): k_cull_pack writes the record STRAIGHT into the pinned
+	// host buffer (the buffer's device mapping: posted writes over PCIe, a few microseconds for tens of kilobytes) - no copy command
+	// behind the kernel, whose fixed cost (~10 us of a ~45 us cull of the harness's 40 k-entity scene) is what a host read of a small
+	// list consists of. Large lists keep the device record + one DMA copy of the ids the last frame needed: a kernel that streams
+	// megabytes over PCIe holds CUs for the duration.
+	int32_t* host_dev = nullptr;
+	bool zero_copy = cs.map_zero_copy;
+	for (uint32_t k = 0; k < n && zero_copy; ++k) zero_copy = v.map_guess[first + k] <= (64u << 10);
+	if (zero_copy && hipHostGetDevicePointer(reinterpret_cast<void**>(&host_dev), v.map_host, 0) != hipSuccess) zero_copy = false;
+	v.map_begin_zero_copy = zero_copy;
 	for (uint32_t k = 0; k < n; ++k) {
 		const uint32_t f = first + k;
 		const uint32_t* counts = v.counts_ptr() + (size_t)f * cnt_frustum_stride;
-		int32_t* rec = v.map_rec.p + (size_t)f * v.map_words;
+		int32_t* rec = (zero_copy ? host_dev : v.map_rec.p) + (size_t)f * v.map_words;
 		LMX_HIP(ctx, launch_cull_pack(ctx->stream, v.out.p + (size_t)f * v.out_stride, cs.d_win_base.p, counts, cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, cs.max_shard_cap,
 			reinterpret_cast<uint32_t*>(rec), rec + MAX_TYPES, v.out_stride));
-		v.map_begin_guess[k] = std::min<size_t>(v.out_stride, v.map_guess[f]);
-		LMX_HIP(ctx, hipMemcpyAsync(reinterpret_cast<int32_t*>(v.map_host) + (size_t)f * v.map_words, rec, (MAX_TYPES + v.map_begin_guess[k]) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+		v.map_begin_guess[k] = zero_copy ? (size_t)v.out_stride : std::min<size_t>(v.out_stride, v.map_guess[f]);
+		if (!zero_copy)
+			LMX_HIP(ctx, hipMemcpyAsync(reinterpret_cast<int32_t*>(v.map_host) + (size_t)f * v.map_words, rec, (MAX_TYPES + v.map_begin_guess[k]) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
 	}
 	LMX_HIP(ctx, hipEventRecord(v.map_event, ctx->stream));
 	v.map_begin_first = first;
@@ -1654,7 +1666,7 @@ static int cull_map_end(LmxContext* ctx, CullView& v, uint32_t first, uint32_t n
 			out_counts[k * MAX_TYPES + t] = h[t];
 			total += h[t];
 		}
-		if (total > v.map_begin_guess[k]) { // the list outgrew the guess: fetch the rest (second wait, this frame only)
+		if (total > v.map_begin_guess[k] && !v.map_begin_zero_copy) { // the list outgrew the guess: fetch the rest (second wait, this frame only)
 			Locked l(ctx);
 			LMX_HIP(ctx, hipMemcpyAsync(host + MAX_TYPES + v.map_begin_guess[k], v.map_rec.p + (size_t)f * v.map_words + MAX_TYPES + v.map_begin_guess[k],
 				(total - v.map_begin_guess[k]) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -82,6 +82,7 @@ struct CullView {
 	hipEvent_t map_event = nullptr; // recorded behind the record's copies (lmx_cull_map_begin): lmx_cull_map_end waits for THIS view only
 	size_t map_begin_guess[LMX_MAX_FRUSTA] = {}; // what lmx_cull_map_begin asked the copies for
 	uint32_t map_begin_first = 0, map_begin_n = 0;
+	bool map_begin_zero_copy = false; // the pack kernel wrote the whole record into map_host itself
 	DevBuf<uint32_t> map_pref, map_start;
 	DevBuf<int32_t> pack_rec; // lmx_cull_pack_device: the packed record of one frustum, left on the device
 	size_t pack_words = 0;
@@ -253,6 +254,7 @@ struct CullState : CullSet {
 	bool device_owns_bound = false; // LMX_CULL_OPT_DEVICE_OWNS_BOUND: set* calls on hierarchy-bound entities are dropped
 	bool auto_compaction = true; // false: overflow / tombstones accumulate until the host calls lmx_cull_compact
 	uint32_t compaction_min = 1u << 16; // overflow entities / tombstones tolerated before a compaction is considered at all (LMX_CULL_OPT_COMPACTION_MIN)
+	bool map_zero_copy = true;   // LMX_CULL_OPT_MAP_ZERO_COPY: small host records are written by the pack kernel straight into pinned host memory
 	CullAsync* async = nullptr;  // LMX_CULL_OPT_ASYNC_COMPACTION: shadow set + worker thread (owned; lmx_capi_cull.hip)
 	bool emit_slots = false;     // culls also write the static-set slot of every visible id (switched on by the sort-key tables' slot-ordered mirror)
 	uint64_t layout_generation = 0; // a process-wide unique number per build of the static layout (consumers that mirror it by slot compare)
