@@ -209,6 +209,15 @@ typedef struct LmxAnimation {
 	const float* root_pose_rotations;        /* RootMotion::pose_rotations, (frame_count + 1) x 4 */
 } LmxAnimation;
 
+/* One SAMPLE instruction of an Animator's blend stack (anim::BlendStackInstructions::SAMPLE, controller.cpp:282-289: slot, weight,
+ * time, looped as the controller's nodes wrote them; `animation` is the id lmx_anim_add returned for RuntimeContext::animations[slot]). */
+typedef struct LmxBlendSample {
+	uint32_t animation;
+	float weight;
+	uint32_t time;                           /* Time units; wrapped (looped) or clamped to the animation's length by getPose, controller.cpp:148 */
+	uint32_t looped;
+} LmxBlendSample;
+
 #define LMX_TIME_ONE_SECOND (1u << 15)       /* Time::ONE_SECOND, animation/animation.h:41 */
 #define LMX_ANIM_NONE 0xffffffffu
 

@@ -380,6 +380,13 @@ LMX_API int lmx_anim_set_model_pose(LmxContext* ctx, uint32_t model, const LmxLo
 LMX_API int lmx_anim_set_animables(LmxContext* ctx, uint32_t n_instances, const uint32_t* animation, const uint32_t* time);
 LMX_API int lmx_anim_set_weight(LmxContext* ctx, float weight); /* SampleContext::weight, default 1 */
 LMX_API int lmx_anim_update(LmxContext* ctx, float time_delta);
+/* AnimationModuleImpl::updateAnimator's pose work for every instance in one launch (animation_module.cpp:602-636): Model::getRelativePose
+ * into the pose, then evalBlendStack's SAMPLE instructions in order (controller.cpp:267-293, getPose :142-157) - instance i owns
+ * samples[first_sample[i] .. first_sample[i + 1]), first_sample has n_instances + 1 entries. An instruction whose animation does not
+ * fit the instance's skeleton is skipped, as Animation::getRelativePose does (animation.cpp:120). The controller's node graph that
+ * emits the instructions, bone masks and IK instructions stay on the CPU / out of scope. lmx_skin_run then does
+ * Pose::computeAbsolute and the palette. Host arrays; copied before the call returns. */
+LMX_API int lmx_anim_eval_blend_stacks(LmxContext* ctx, uint32_t n_instances, const uint32_t* first_sample, const LmxBlendSample* samples);
 LMX_API int lmx_anim_read_times(LmxContext* ctx, uint32_t* time, uint32_t n_instances);
 /* The relative pose of an instance after lmx_anim_update (before lmx_skin_run turns it into the absolute one). */
 LMX_API int lmx_anim_read_pose(LmxContext* ctx, uint32_t instance, float* out_pos, float* out_rot, uint32_t cap_bones);

@@ -43,6 +43,7 @@ SKIN = np.dtype([("weights", "<f4", 4), ("indices", "<i2", 4)], align=True)
 ANIM_CONST_TRANSLATION = np.dtype([("value", "<f4", 3), ("bone_index", "<u2"), ("_pad", "<u2")], align=True)
 ANIM_TRANSLATION_TRACK = np.dtype([("min", "<f4", 3), ("to_range", "<f4", 3), ("offset_bits", "<u2"), ("bone_index", "<u2"), ("bitsizes", "u1", 3), ("_pad", "u1")], align=True)
 ANIM_CONST_ROTATION = np.dtype([("value", "<f4", 4), ("bone_index", "<u2"), ("_pad", "<u2")], align=True)
+BLEND_SAMPLE = np.dtype([("animation", "<u4"), ("weight", "<f4"), ("time", "<u4"), ("looped", "<u4")], align=True)  # LmxBlendSample
 ANIM_ROTATION_TRACK = np.dtype([("min", "<f4", 3), ("to_range", "<f4", 3), ("offset_bits", "<u2"), ("bone_index", "<u2"), ("bitsizes", "u1", 3), ("skipped_channel", "u1")],
                                align=True)
 
@@ -178,6 +179,7 @@ SYMBOLS = {
     "lmx_anim_set_animables": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_anim_set_weight": (_ci, [_vp, _f32]),
     "lmx_anim_update": (_ci, [_vp, _f32]),
+    "lmx_anim_eval_blend_stacks": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_anim_read_times": (_ci, [_vp, _vp, _u32]),
     "lmx_anim_read_pose": (_ci, [_vp, _u32, _vp, _vp, _u32]),
     "lmx_keys_set_models": (_ci, [_vp, _vp, _u32, _vp, _u32]),
@@ -912,6 +914,20 @@ class Skinning:
 
     def updateAnimables(self, time_delta: float):
         self.ctx.check(self.lib.lmx_anim_update(self.ctx.h, float(time_delta)))
+
+    def evalBlendStacks(self, stacks):
+        """updateAnimator's pose work (animation_module.cpp:602-636): `stacks[i]` = instance i's SAMPLE instructions in order, each
+        (animation id, weight, time, looped)."""
+        first = np.zeros(len(stacks) + 1, np.uint32)
+        first[1:] = np.cumsum([len(s) for s in stacks])
+        samples = np.zeros(max(int(first[-1]), 1), BLEND_SAMPLE)
+        k = 0
+        for s in stacks:
+            for (a, w, t, looped) in s:
+                samples[k] = (a, w, t, 1 if looped else 0)
+                k += 1
+        self._n_animables = len(stacks)
+        self.ctx.check(self.lib.lmx_anim_eval_blend_stacks(self.ctx.h, len(stacks), _ptr(first), _ptr(samples)))
 
     def readTimes(self) -> np.ndarray:
         out = np.zeros(self._n_animables, np.uint32)

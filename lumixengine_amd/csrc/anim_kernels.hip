@@ -84,6 +84,44 @@ __device__ __forceinline__ float4 anim_rotation(const AnimDevice& a, const AnimT
 	return simd_nlerp(unpack_rotation(tr, packed1), unpack_rotation(tr, packed2), f);
 }
 
+// one bone of Animation::getRelativePose (animation.cpp:118-160, :294-311): the bone's tracks of `a` at (sample_idx, f), written over or
+// blended into (p, r) with `weight`
+__device__ __forceinline__ void anim_apply_bone(const AnimDevice& a, const AnimTables& t, uint32_t b, uint32_t sample_idx, float f, float weight, V3& p, float4& r) {
+	const bool use_weight = weight < 0.9999f; // :304
+	const float invw = 1.0f - weight;
+	const int32_t ts = t.src[a.src_off + 2 * b], rs = t.src[a.src_off + 2 * b + 1]; // -1 none, 2 * i const track i, 2 * i + 1 packed track i
+	if (ts >= 0) {
+		V3 v;
+		if (ts & 1) {
+			const V3 a0 = anim_translation(a, t, sample_idx, (uint32_t)ts >> 1), a1 = anim_translation(a, t, sample_idx + 1, (uint32_t)ts >> 1);
+			const float invt = 1.0f - f; // lerp(Vec3), math.cpp:194-201
+			v = V3{a0.x * invt + a1.x * f, a0.y * invt + a1.y * f, a0.z * invt + a1.z * f};
+		} else {
+			const LmxAnimConstTranslation c = t.const_translations[a.ct_off + ((uint32_t)ts >> 1)];
+			v = V3{c.value[0], c.value[1], c.value[2]};
+		}
+		p = use_weight ? V3{p.x * invw + v.x * weight, p.y * invw + v.y * weight, p.z * invw + v.z * weight} : v;
+	}
+	if (rs >= 0) {
+		float4 v;
+		if (rs & 1) v = anim_rotation(a, t, sample_idx, (uint32_t)rs >> 1, f);
+		else {
+			const LmxAnimConstRotation c = t.const_rotations[a.cr_off + ((uint32_t)rs >> 1)];
+			v = make_float4(c.value[0], c.value[1], c.value[2], c.value[3]);
+		}
+		r = use_weight ? simd_nlerp(r, v, weight) : v;
+	}
+}
+
+// float sample = clamp(time.toFrame(fps), 0.f, frame_count - 0.00001f), animation.cpp:132-134
+__device__ __forceinline__ void anim_sample_point(const AnimDevice& a, uint32_t time, uint32_t& sample_idx, float& f) {
+	float sample = (float)((double)time / (double)LMX_TIME_ONE_SECOND * (double)a.fps);
+	const float hi = (float)a.frame_count - 0.00001f;
+	sample = sample < 0.f ? 0.f : (sample > hi ? hi : sample);
+	sample_idx = (uint32_t)sample;
+	f = sample - (float)sample_idx;
+}
+
 __global__ __launch_bounds__(64) void k_anim_update(const SkinInstance* __restrict__ inst, uint32_t n_inst, const AnimDevice* __restrict__ anims, AnimTables t,
 	const uint32_t* __restrict__ anim_of_instance, uint32_t* __restrict__ time_of_instance, float time_delta, float weight,
 	const float* __restrict__ model_rel_pos, const float4* __restrict__ model_rel_rot, float* __restrict__ pose_pos, float4* __restrict__ pose_rot) {
@@ -96,42 +134,14 @@ __global__ __launch_bounds__(64) void k_anim_update(const SkinInstance* __restri
 	AnimDevice a = {};
 	if (has_anim) a = anims[anim_id];
 	const bool sampled = has_anim && a.max_bone < in.n_bones; // m_max_accessed_bone_index >= pose.count: skeletons do not match (:120)
-	// float sample = clamp(time.toFrame(fps), 0.f, frame_count - 0.00001f), :132-134
-	float sample = (float)((double)time / (double)LMX_TIME_ONE_SECOND * (double)a.fps);
-	const float hi = (float)a.frame_count - 0.00001f;
-	sample = sample < 0.f ? 0.f : (sample > hi ? hi : sample);
-	const uint32_t sample_idx = (uint32_t)sample;
-	const float f = sample - (float)sample_idx;
-	const bool use_weight = weight < 0.9999f; // :304
-	const float invw = 1.0f - weight;
+	uint32_t sample_idx;
+	float f;
+	anim_sample_point(a, time, sample_idx, f);
 	for (uint32_t b = threadIdx.x; b < in.n_bones; b += 64) {
 		// Model::getRelativePose, model.cpp:226-237
 		V3 p = V3{model_rel_pos[3 * (size_t)(in.model_offset + b)], model_rel_pos[3 * (size_t)(in.model_offset + b) + 1], model_rel_pos[3 * (size_t)(in.model_offset + b) + 2]};
 		float4 r = model_rel_rot[in.model_offset + b];
-		if (sampled && b <= a.max_bone) {
-			const int32_t ts = t.src[a.src_off + 2 * b], rs = t.src[a.src_off + 2 * b + 1]; // -1 none, 2 * i const track i, 2 * i + 1 packed track i
-			if (ts >= 0) {
-				V3 v;
-				if (ts & 1) {
-					const V3 a0 = anim_translation(a, t, sample_idx, (uint32_t)ts >> 1), a1 = anim_translation(a, t, sample_idx + 1, (uint32_t)ts >> 1);
-					const float invt = 1.0f - f; // lerp(Vec3), math.cpp:194-201
-					v = V3{a0.x * invt + a1.x * f, a0.y * invt + a1.y * f, a0.z * invt + a1.z * f};
-				} else {
-					const LmxAnimConstTranslation c = t.const_translations[a.ct_off + ((uint32_t)ts >> 1)];
-					v = V3{c.value[0], c.value[1], c.value[2]};
-				}
-				p = use_weight ? V3{p.x * invw + v.x * weight, p.y * invw + v.y * weight, p.z * invw + v.z * weight} : v;
-			}
-			if (rs >= 0) {
-				float4 v;
-				if (rs & 1) v = anim_rotation(a, t, sample_idx, (uint32_t)rs >> 1, f);
-				else {
-					const LmxAnimConstRotation c = t.const_rotations[a.cr_off + ((uint32_t)rs >> 1)];
-					v = make_float4(c.value[0], c.value[1], c.value[2], c.value[3]);
-				}
-				r = use_weight ? simd_nlerp(r, v, weight) : v;
-			}
-		}
+		if (sampled && b <= a.max_bone) anim_apply_bone(a, t, b, sample_idx, f, weight, p, r);
 		float* gp = pose_pos + 3 * (size_t)(in.bone_offset + b);
 		gp[0] = p.x; gp[1] = p.y; gp[2] = p.z;
 		pose_rot[in.bone_offset + b] = r;
@@ -150,6 +160,46 @@ __global__ __launch_bounds__(64) void k_anim_update(const SkinInstance* __restri
 	}
 }
 
+// updateAnimator's pose work for one Animator per block (animation_module.cpp:602-636): Model::getRelativePose into the pose, then
+// evalBlendStack's SAMPLE instructions in order (controller.cpp:267-293; getPose :142-157 wraps or clamps the time, then
+// Animation::getRelativePose with the instruction's weight). A bone's tracks of different layers only meet in that bone, so a lane
+// carries its bone through every layer in registers and the pose is written once. IK instructions are not on the path.
+__global__ __launch_bounds__(64) void k_anim_blend_stack(const SkinInstance* __restrict__ inst, uint32_t n_inst, const AnimDevice* __restrict__ anims, AnimTables t,
+	uint32_t n_anims, const LmxBlendSample* __restrict__ samples, const uint32_t* __restrict__ first_sample, const float* __restrict__ model_rel_pos,
+	const float4* __restrict__ model_rel_rot, float* __restrict__ pose_pos, float4* __restrict__ pose_rot) {
+	const uint32_t ii = blockIdx.x;
+	if (ii >= n_inst) return;
+	const SkinInstance in = inst[ii];
+	const uint32_t s0 = first_sample[ii], s1 = first_sample[ii + 1];
+	for (uint32_t b0 = 0; b0 < in.n_bones; b0 += 64) { // uniform trip count: the layer loop below reads uniform data
+		const uint32_t b = b0 + threadIdx.x;
+		const bool live = b < in.n_bones;
+		V3 p = V3{0, 0, 0};
+		float4 r = make_float4(0, 0, 0, 1);
+		if (live) { // Model::getRelativePose, model.cpp:226-237
+			const float* mp = model_rel_pos + 3 * (size_t)(in.model_offset + b);
+			p = V3{mp[0], mp[1], mp[2]};
+			r = model_rel_rot[in.model_offset + b];
+		}
+		for (uint32_t s = s0; s < s1; ++s) {
+			const LmxBlendSample ins = samples[s];
+			if (ins.animation >= n_anims) continue;
+			const AnimDevice a = anims[ins.animation];
+			if (a.max_bone >= in.n_bones) continue; // skeletons do not match, animation.cpp:120
+			const uint32_t time = ins.looped ? ins.time % a.length : (ins.time < a.length ? ins.time : a.length); // controller.cpp:148
+			uint32_t sample_idx;
+			float f;
+			anim_sample_point(a, time, sample_idx, f);
+			if (live && b <= a.max_bone) anim_apply_bone(a, t, b, sample_idx, f, ins.weight, p, r);
+		}
+		if (live) {
+			float* gp = pose_pos + 3 * (size_t)(in.bone_offset + b);
+			gp[0] = p.x; gp[1] = p.y; gp[2] = p.z;
+			pose_rot[in.bone_offset + b] = r;
+		}
+	}
+}
+
 } // namespace
 
 hipError_t launch_anim_update(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, const AnimDevice* anims, const AnimTables& t,
@@ -158,6 +208,14 @@ hipError_t launch_anim_update(hipStream_t s, const SkinInstance* inst, uint32_t 
 	if (!n_inst) return hipSuccess;
 	hipLaunchKernelGGL(k_anim_update, dim3(n_inst), dim3(64), 0, s, inst, n_inst, anims, t, anim_of_instance, time_of_instance, time_delta, weight,
 		model_rel_pos, model_rel_rot, pose_pos, pose_rot);
+	return hipGetLastError();
+}
+
+hipError_t launch_anim_blend_stack(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, const AnimDevice* anims, const AnimTables& t, uint32_t n_anims,
+	const LmxBlendSample* samples, const uint32_t* first_sample, const float* model_rel_pos, const float4* model_rel_rot, float* pose_pos, float4* pose_rot) {
+	if (!n_inst) return hipSuccess;
+	hipLaunchKernelGGL(k_anim_blend_stack, dim3(n_inst), dim3(64), 0, s, inst, n_inst, anims, t, n_anims, samples, first_sample, model_rel_pos, model_rel_rot,
+		pose_pos, pose_rot);
 	return hipGetLastError();
 }
 

@@ -181,6 +181,43 @@ int lmx_anim_update(LmxContext* ctx, float time_delta) {
 	return LMX_OK;
 }
 
+int lmx_anim_eval_blend_stacks(LmxContext* ctx, uint32_t n_instances, const uint32_t* first_sample, const LmxBlendSample* samples) {
+	LMX_CHECK_CTX(ctx);
+	SkinState& sk = ctx->skin;
+	AnimState& an = ctx->anim;
+	if (n_instances != sk.inst.size()) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "the skin instance table has %zu instances", sk.inst.size());
+	if (!n_instances) return LMX_OK;
+	if (!first_sample) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "null first_sample");
+	if (an.rel_rot.size() != sk.parents.size()) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_anim_set_model_pose is missing for a model added later");
+	for (uint32_t i = 0; i < n_instances; ++i)
+		if (first_sample[i + 1] < first_sample[i]) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "first_sample decreases at instance %u", i);
+	const uint32_t n_samples = first_sample[n_instances];
+	if (first_sample[0] != 0 || (n_samples && !samples)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "first_sample[0] must be 0 and samples non-null");
+	for (uint32_t k = 0; k < n_samples; ++k) {
+		if (samples[k].animation >= an.anims.size()) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "sample %u: unknown animation %u", k, samples[k].animation);
+		if (!(samples[k].weight >= 0.f && samples[k].weight <= 1.f)) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "sample %u: weight %g outside [0, 1]", k, (double)samples[k].weight);
+	}
+	if (int rc = anim_upload_tables(ctx)) return rc;
+	LMX_HIP(ctx, an.d_first_sample.reserve((size_t)n_instances + 1));
+	LMX_HIP(ctx, an.d_samples.reserve(std::max<size_t>(n_samples, 1)));
+	// the caller's arrays are pageable: the copies below complete before this returns, and the stream orders them against the
+	// previous frame's kernel that still reads the same device buffers
+	LMX_HIP(ctx, hipMemcpyAsync(an.d_first_sample.p, first_sample, ((size_t)n_instances + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	if (n_samples) LMX_HIP(ctx, hipMemcpyAsync(an.d_samples.p, samples, (size_t)n_samples * sizeof(LmxBlendSample), hipMemcpyHostToDevice, ctx->stream));
+	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	AnimTables t;
+	t.src = an.d_src.p; t.const_translations = an.d_ct.p; t.translations = an.d_tt.p; t.const_rotations = an.d_cr.p; t.rotations = an.d_rt.p;
+	t.translation_stream = an.d_tstream.p; t.rotation_stream = an.d_rstream.p; t.root_translations = an.d_root_t.p; t.root_rotations = an.d_root_r.p;
+	ProfScope ps(ctx, LMX_K_ANIM_UPDATE);
+	LMX_HIP(ctx, launch_anim_blend_stack(ctx->stream, sk.d_inst.p, (uint32_t)sk.inst.size(), an.d_anims.p, t, (uint32_t)an.anims.size(), an.d_samples.p,
+		an.d_first_sample.p, an.d_rel_pos.p, an.d_rel_rot.p, sk.d_pose_pos.p, sk.d_pose_rot.p));
+	sk.borrowed_pos = nullptr;
+	sk.borrowed_rot = nullptr;
+	sk.poses_uploaded = true;
+	sk.pose_is_absolute = false;
+	return LMX_OK;
+}
+
 int lmx_anim_read_times(LmxContext* ctx, uint32_t* time, uint32_t n_instances) {
 	LMX_CHECK_CTX(ctx);
 	AnimState& an = ctx->anim;

@@ -448,6 +448,8 @@ struct AnimState {
 	DevBuf<float> d_root_t, d_rel_pos;
 	DevBuf<float4> d_root_r, d_rel_rot;
 	DevBuf<uint32_t> d_anim_of, d_time_of;
+	DevBuf<LmxBlendSample> d_samples; // lmx_anim_eval_blend_stacks: the frame's SAMPLE instructions and their per-instance ranges
+	DevBuf<uint32_t> d_first_sample;
 };
 
 struct ProfSlot { hipEvent_t a, b; int kernel; };

@@ -205,6 +205,8 @@ struct AnimTables {
 hipError_t launch_anim_update(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, const AnimDevice* anims, const AnimTables& t,
 	const uint32_t* anim_of_instance, uint32_t* time_of_instance, float time_delta, float weight, const float* model_rel_pos,
 	const float4* model_rel_rot, float* pose_pos, float4* pose_rot);
+hipError_t launch_anim_blend_stack(hipStream_t s, const SkinInstance* inst, uint32_t n_inst, const AnimDevice* anims, const AnimTables& t, uint32_t n_anims,
+	const LmxBlendSample* samples, const uint32_t* first_sample, const float* model_rel_pos, const float4* model_rel_rot, float* pose_pos, float4* pose_rot);
 
 // ---- createSortKeys (keys_kernels.hip) ----
 // Counter words. {pairs, recs} and {poses, dirty} are two 64-bit cells on their own 128-byte lines: k_keys_mesh reserves a tile's four

@@ -1456,14 +1456,8 @@ static void orc_anim_rotation(const LmxAnimation* a, uint32_t frame, uint32_t tr
 	orc_simd_nlerp(q[0], q[1], t, out);
 }
 
-/* one Animable: pose (n_bones x {pos[3], rot[4]}) <- model relative pose <- animation at `time`; returns the advanced time */
-ORC_API uint32_t orc_update_animable(const LmxAnimation* a, uint32_t time, float time_delta, float weight, const LmxLocalRigidTransform* model_relative,
-	uint32_t n_bones, float* pos, float* rot) {
-	for (uint32_t i = 0; i < n_bones; ++i) { /* Model::getRelativePose, model.cpp:226-237 */
-		memcpy(pos + 3 * i, model_relative[i].pos, 12);
-		memcpy(rot + 4 * i, model_relative[i].rot, 16);
-	}
-	if (!a) return time;
+/* Animation::getRelativePose (animation.cpp:117-204, :294-311) of `a` at `time` with `weight` onto the pose pos / rot already hold */
+static void orc_sample_onto(const LmxAnimation* a, uint32_t time, float weight, uint32_t n_bones, float* pos, float* rot) {
 	uint32_t max_bone = 0; /* m_max_accessed_bone_index, animation.cpp:369-393 */
 	for (uint32_t i = 0; i < a->n_const_translations; ++i) if (a->const_translations[i].bone_index > max_bone) max_bone = a->const_translations[i].bone_index;
 	for (uint32_t i = 0; i < a->n_translations; ++i) if (a->translations[i].bone_index > max_bone) max_bone = a->translations[i].bone_index;
@@ -1504,6 +1498,24 @@ ORC_API uint32_t orc_update_animable(const LmxAnimation* a, uint32_t time, float
 			else memcpy(r, ar, 16);
 		}
 	}
+}
+
+/* one SAMPLE instruction of evalBlendStack (controller.cpp:282-289): getPose's time wrap / clamp (:148), then the sample with the
+ * instruction's weight and no bone mask */
+ORC_API void orc_blend_stack_sample(const LmxAnimation* a, uint32_t time, float weight, uint32_t looped, uint32_t n_bones, float* pos, float* rot) {
+	const uint32_t anim_time = looped ? time % a->length : (time < a->length ? time : a->length);
+	orc_sample_onto(a, anim_time, weight, n_bones, pos, rot);
+}
+
+/* one Animable: pose (n_bones x {pos[3], rot[4]}) <- model relative pose <- animation at `time`; returns the advanced time */
+ORC_API uint32_t orc_update_animable(const LmxAnimation* a, uint32_t time, float time_delta, float weight, const LmxLocalRigidTransform* model_relative,
+	uint32_t n_bones, float* pos, float* rot) {
+	for (uint32_t i = 0; i < n_bones; ++i) { /* Model::getRelativePose, model.cpp:226-237 */
+		memcpy(pos + 3 * i, model_relative[i].pos, 12);
+		memcpy(rot + 4 * i, model_relative[i].rot, 16);
+	}
+	if (!a) return time;
+	orc_sample_onto(a, time, weight, n_bones, pos, rot);
 	const uint32_t l = a->length; /* animation_module.cpp:458-470 */
 	if (time_delta > 0) {
 		return (time + (uint32_t)(time_delta * LMX_TIME_ONE_SECOND)) % l;

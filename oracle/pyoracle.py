@@ -334,6 +334,26 @@ class Oracle:
             out_t[i] = f(a, int(times[i]), float(time_delta), float(weight), _ptr(rel), nb, pos[i].ctypes.data, rot[i].ctypes.data)
         return pos, rot, out_t
 
+    def update_animators(self, anims, stacks, model_relative, parents=None, first_nonroot=0):
+        """AnimationModuleImpl::updateAnimator's pose work per Animator (animation_module.cpp:602-636): Model::getRelativePose, then
+        evalBlendStack's SAMPLE instructions in order (controller.cpp:267-293) - `stacks[i]` = [(animation index, weight, time, looped), ...] -
+        then, when `parents` is given, Pose::computeAbsolute. Returns (pos [n, bones, 3], rot [n, bones, 4])."""
+        from lumixengine_amd.api import animation_struct, LOCAL_RIGID
+        f = getattr(self.lib, self.prefix + "blend_stack_sample")
+        f.restype, f.argtypes = None, [C.c_void_p, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        structs = [animation_struct(a) for a in anims]
+        rel = np.ascontiguousarray(model_relative, LOCAL_RIGID)
+        nb, n = len(rel), len(stacks)
+        pos, rot = np.zeros((n, nb, 3), np.float32), np.zeros((n, nb, 4), np.float32)
+        for i, stack in enumerate(stacks):
+            pos[i], rot[i] = rel["pos"], rel["rot"]  # Model::getRelativePose, model.cpp:226-237
+            for (k, w, t, looped) in stack:
+                f(C.addressof(structs[k][0]), int(t), float(w), 1 if looped else 0, nb, pos[i].ctypes.data, rot[i].ctypes.data)
+            if parents is not None:
+                ap, ar = self.pose_compute_absolute(pos[i : i + 1], rot[i : i + 1], parents, first_nonroot)
+                pos[i], rot[i] = ap[0], ar[0]
+        return pos, rot
+
     def rand_fill(self, u: int, v: int, n: int) -> np.ndarray:
         out = np.zeros(n, np.uint32)
         self.f_rand_fill(u, v, n, _ptr(out))

@@ -75,16 +75,9 @@ Animation::Animation() : m_root_motion(*(IAllocator*)nullptr) {}
 using namespace Lumix;
 using namespace Lumix::anim_shim;
 
-// AnimationModuleImpl::updateAnimable for one Animable (animation/animation_module.cpp:439-472): Model::getRelativePose
-// (renderer/model.cpp:226-237) into the pose, the reference's Animation::getRelativePose on it, then the time advance (restated: five
-// lines of integer arithmetic on Time). Same signature as orc_update_animable of the plain-C restatement.
-extern "C" __attribute__((visibility("default"))) uint32_t ref_update_animable(const LmxAnimation* a, uint32_t time, float time_delta, float weight,
-	const LmxLocalRigidTransform* model_relative, uint32_t n_bones, float* pos, float* rot) {
-	for (uint32_t i = 0; i < n_bones; ++i) {
-		memcpy(pos + 3 * i, model_relative[i].pos, 12);
-		memcpy(rot + 4 * i, model_relative[i].rot, 16);
-	}
-	if (!a) return time;
+// Animation::getRelativePose (the reference's own, sliced from animation/animation.cpp) of `a` at `time` with `weight` onto the pose that
+// pos / rot already hold.
+static void sample_onto(const LmxAnimation* a, uint32_t time, float weight, uint32_t n_bones, float* pos, float* rot) {
 	struct Access : Animation { // the members are private in the engine's class; here the shell is mine
 		void fill(const LmxAnimation* a) {
 			u32 max_bone = 0;
@@ -153,6 +146,29 @@ extern "C" __attribute__((visibility("default"))) uint32_t ref_update_animable(c
 	ctx.time = Time(time);
 	ctx.weight = weight;
 	anim.getRelativePose(ctx);
+}
+
+// One SAMPLE instruction of evalBlendStack (animation/controller.cpp:282-289) onto an existing pose: getPose's time wrap / clamp
+// (controller.cpp:148, one line, restated - getPose itself is a static function over the controller's RuntimeContext) and then the
+// reference's Animation::getRelativePose with the instruction's weight and no bone mask.
+extern "C" __attribute__((visibility("default"))) void ref_blend_stack_sample(const LmxAnimation* a, uint32_t time, float weight, uint32_t looped, uint32_t n_bones,
+	float* pos, float* rot) {
+	const Time length(a->length);
+	const Time anim_time = looped ? Time(time) % length : minimum(Time(time), length);
+	sample_onto(a, anim_time.raw(), weight, n_bones, pos, rot);
+}
+
+// AnimationModuleImpl::updateAnimable for one Animable (animation/animation_module.cpp:439-472): Model::getRelativePose
+// (renderer/model.cpp:226-237) into the pose, the reference's Animation::getRelativePose on it, then the time advance (restated: five
+// lines of integer arithmetic on Time). Same signature as orc_update_animable of the plain-C restatement.
+extern "C" __attribute__((visibility("default"))) uint32_t ref_update_animable(const LmxAnimation* a, uint32_t time, float time_delta, float weight,
+	const LmxLocalRigidTransform* model_relative, uint32_t n_bones, float* pos, float* rot) {
+	for (uint32_t i = 0; i < n_bones; ++i) {
+		memcpy(pos + 3 * i, model_relative[i].pos, 12);
+		memcpy(rot + 4 * i, model_relative[i].rot, 16);
+	}
+	if (!a) return time;
+	sample_onto(a, time, weight, n_bones, pos, rot);
 	const uint32_t l = a->length; // animation_module.cpp:458-470
 	if (time_delta > 0) return (Time(time) + Time::fromSeconds(time_delta)).raw() % l;
 	const uint32_t dt = Time::fromSeconds(-time_delta).raw() % l;

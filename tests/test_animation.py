@@ -215,5 +215,64 @@ def test_gpu_animation_matches_oracle(gpu_ctx, live_oracle, weight, dt):
     sk.setAnimWeight(1.0)
 
 
+@pytest.mark.gpu
+def test_gpu_blend_stacks_match_oracle(gpu_ctx, live_oracle):
+    """The Animator path on the device: lmx_anim_eval_blend_stacks (Model::getRelativePose + evalBlendStack's SAMPLE instructions,
+    animation_module.cpp:602-636, controller.cpp:267-293) -> lmx_skin_run (Pose::computeAbsolute + palette), against the oracle doing
+    the same sequence layer by layer (the reference oracle runs the reference's own getRelativePose / computeAbsolute code). Two
+    skeletons (100 bones: two bone rounds per wave), clips that do not fit a skeleton, empty stacks, looped and clamped times."""
+    from tests.test_oracle_vs_ref import random_blend_stacks
+    skel = [scenes.skeleton(64, seed=5), scenes.skeleton(100, seed=25)]
+    anims = [scenes.animation(64, 30, 30.0, seed=51), scenes.animation(64, 9, 24.0, seed=52, root_motion=False), scenes.animation(100, 20, 60.0, seed=53),
+             scenes.animation(100, 6, 30.0, seed=54, bone_limit=90)]
+    sk = api.Skinning(gpu_ctx)
+    models = [sk.addModel(s["parents"], s["bind"], s["first_nonroot"]) for s in skel]
+    meshes = [sk.addMesh(*scenes.skinned_mesh(64, 64, seed=6)), sk.addMesh(*scenes.skinned_mesh(64, 100, seed=7))]
+    rng = np.random.default_rng(19)
+    inst_model = np.array([0] * 30 + [1] * 20 + [0] * 3)
+    sk.setInstances([models[m] for m in inst_model], [meshes[m] for m in inst_model])
+    for m in range(2):
+        sk.setModelPose(models[m], skel[m]["bind"])
+    ids = [sk.addAnimation(a) for a in anims]
+    fits = {0: [0, 1, 3], 1: [0, 1, 2, 3]}  # clip 3 reaches bone 89: skipped on the 64-bone skeleton; clips 0 and 1 animate bones 0..63 of the 100
+    stacks = [random_blend_stacks(rng, 1, fits[m])[0] for m in inst_model]
+    stacks[2] = []
+    stacks[3] = [(0, 1.0, anims[0]["length"], False), (1, 0.25, 7 * anims[1]["length"] + 3, True), (3, 0.5, 100, False)]
+    for frame in range(2):
+        sk.evalBlendStacks([[(ids[k], w, t, lp) for (k, w, t, lp) in st] for st in stacks])
+        for i, m in enumerate(inst_model):
+            wp, wr = live_oracle.update_animators(anims, [stacks[i]], skel[m]["bind"])
+            gp, gr = sk.readRelativePose(i)
+            assert H.bits_equal(gp, wp[0]) and H.bits_equal(gr, wr[0]), f"frame {frame} instance {i}: {stacks[i]}"
+        sk.run()
+        for i in range(0, len(inst_model), 3):
+            m = inst_model[i]
+            ap, ar = live_oracle.update_animators(anims, [stacks[i]], skel[m]["bind"], skel[m]["parents"], skel[m]["first_nonroot"])
+            pal = live_oracle.skin_matrices(ap, ar, live_oracle.invert_bind(skel[m]["bind"]))
+            assert H.bits_equal(sk.readPalette(i), pal[0])
+        # the next frame's instructions: every clock moved on by a 60 Hz tick, as the controller's nodes would emit them
+        stacks = [[(k, w, t + ONE_SECOND // 60, lp) for (k, w, t, lp) in st] for st in stacks]
+
+
+@pytest.mark.gpu
+def test_gpu_blend_stacks_reject_bad_arguments(gpu_ctx):
+    s = scenes.skeleton(16, seed=2)
+    sk = api.Skinning(gpu_ctx)
+    model = sk.addModel(s["parents"], s["bind"], s["first_nonroot"])
+    mesh = sk.addMesh(*scenes.skinned_mesh(16, 16, seed=3))
+    sk.setInstances([model] * 2, [mesh] * 2)
+    sk.setModelPose(model, s["bind"])
+    aid = sk.addAnimation(scenes.animation(16, 5, 30.0, seed=4))
+    with pytest.raises(api.LumixError):
+        sk.evalBlendStacks([[(aid, 1.0, 0, True)]])  # one stack for two instances
+    with pytest.raises(api.LumixError):
+        sk.evalBlendStacks([[(aid + 1000, 1.0, 0, True)], []])
+    with pytest.raises(api.LumixError):
+        sk.evalBlendStacks([[(aid, 1.5, 0, True)], []])
+    sk.evalBlendStacks([[], []])
+    gp, gr = sk.readRelativePose(1)
+    assert H.bits_equal(gp, s["bind"]["pos"]) and H.bits_equal(gr, s["bind"]["rot"])
+
+
 def api_none():
     return 0xFFFFFFFF
