@@ -122,7 +122,8 @@ static int skin_upload_static(LmxContext* ctx) {
 		LMX_HIP(ctx, hipMemcpy(sk.d_parents.p, sk.parents.data(), nb * sizeof(int16_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(sk.d_inv_pos.p, sk.inv_pos.data(), nb * 3 * sizeof(float), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(sk.d_inv_rot.p, sk.inv_rot.data(), nb * sizeof(float4), hipMemcpyHostToDevice));
-		LMX_HIP(ctx, sk.d_level_items.reserve(std::max<size_t>(sk.level_items.size(), 1)));
+		// (+ 256: k_pose_palette's lanes read a model's item list 64 words at a time, up to one bone count past its end - never used, never out of the buffer)
+		LMX_HIP(ctx, sk.d_level_items.reserve(sk.level_items.size() + 256));
 		LMX_HIP(ctx, sk.d_level_off.reserve(std::max<size_t>(sk.level_off.size(), 1)));
 		if (!sk.level_items.empty()) LMX_HIP(ctx, hipMemcpy(sk.d_level_items.p, sk.level_items.data(), sk.level_items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 		LMX_HIP(ctx, hipMemcpy(sk.d_level_off.p, sk.level_off.data(), sk.level_off.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -170,13 +171,13 @@ int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* model, c
 		verts += me.n_verts;
 		max_verts = std::max(max_verts, me.n_verts);
 	}
-	// pose groups: runs of consecutive instances of one model, at most 16 / 8 / 4 (<= 64 / 128 / 196 bones) per group, stored by
-	// capacity class (one launch of k_pose_palette<KSHIFT> per class)
+	// pose groups: runs of consecutive instances of one model, at most 4 / 2 / 1 (<= 64 / 128 / 196 bones) per group, stored by
+	// capacity class (one launch of k_pose_palette<NBMAX> per class)
 	std::vector<PoseGroup> groups[3];
 	for (uint32_t i = 0; i < n;) {
 		const uint32_t nbm = sk.models[model[i]].n_bones;
 		const uint32_t cls = nbm <= 64 ? 0u : (nbm <= 128 ? 1u : 2u);
-		const uint32_t cap = 16u >> cls;
+		const uint32_t cap = std::max(1u, POSE_GROUP_CAP >> cls);
 		uint32_t c = 1;
 		while (i + c < n && c < cap && model[i + c] == model[i]) ++c;
 		groups[cls].push_back(PoseGroup{i, c});

@@ -328,7 +328,7 @@ struct SkinState {
 	std::vector<uint16_t> level_off;   // per model: max_depth + 1 offsets into its level_items (k_pose_palette)
 	DevBuf<uint32_t> d_level_items;
 	DevBuf<uint16_t> d_level_off;
-	std::vector<PoseGroup> groups;     // sorted by capacity class (16, 8, 4 instances per group)
+	std::vector<PoseGroup> groups;     // sorted by capacity class (4, 2, 1 instances per group)
 	uint32_t n_groups[3] = {0, 0, 0};
 	std::vector<SkinChunk> chunks;     // k_skin_shared work items (runs of instances sharing a mesh)
 	struct Run { uint32_t first, count, mesh; };

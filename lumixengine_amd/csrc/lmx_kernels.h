@@ -175,7 +175,12 @@ struct SkinInstance {
 // (the tile's records live in the mesh table with TILE-LOCAL bone indices: rec_offset = the mesh's first record there, in vertices;
 // tile_bones[bones_at .. + n_tile_bones) = the model bones the tile references, in local-index order)
 struct SkinChunk { uint32_t first_inst, count, v_begin, v_end, rec_offset, bones_at, n_tile_bones, pad; };
-struct PoseGroup { uint32_t first_inst; uint32_t count; }; // consecutive instances of one model, count <= 16 / 8 / 4 by bone count
+struct PoseGroup { uint32_t first_inst; uint32_t count; }; // consecutive instances of one model, count <= 4 / 2 / 1 by bone count (<= 64 / 128 / 196)
+#ifndef LMX_POSE_GROUP_SHIFT
+#define LMX_POSE_GROUP_SHIFT 2
+#endif
+constexpr int POSE_GROUP_SHIFT = LMX_POSE_GROUP_SHIFT; // log2 of the instances per group of the smallest bone-count class; halves per class (k_pose_palette, skin_kernels.hip)
+constexpr uint32_t POSE_GROUP_CAP = 1u << POSE_GROUP_SHIFT;
 // ---- bone attachments (xform_kernels.hip) ----
 struct BoneAttachDevice { uint32_t slot, parent_slot, skin_instance, bone; float rel_pos[3]; float rel_rot[4]; };
 hipError_t launch_bone_attach(hipStream_t s, const WorldDevice& w, const BoneAttachDevice* att, uint32_t n, const SkinInstance* inst,
@@ -293,7 +298,7 @@ hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice&
 	const uint32_t* curve_count, uint32_t curve_cap);
 
 // Pose::computeAbsolute + computeSkinMatrices (+ optional dual-quaternion palette), one wave per PoseGroup
-hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, const PoseGroup* groups, const uint32_t n_groups[3] /* by capacity 16, 8, 4 */,
+hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, const PoseGroup* groups, const uint32_t n_groups[3] /* by capacity 4, 2, 1 */,
 	const float* rel_pos, const float4* rel_rot, float* pose_pos, float4* pose_rot, const uint32_t* level_items, const uint16_t* level_off,
 	const float* inv_pos, const float4* inv_rot, float4* palette, float4* dual_quats /* optional */);
 // Pose::blend over all bones of all instances

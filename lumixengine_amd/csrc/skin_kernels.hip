@@ -1,6 +1,6 @@
 // skin_kernels.hip — skeletal skinning on gfx950: absolute pose, matrix palette, linear-blend vertex transform.
 //
-//   k_pose_palette   one wave per group of up to 16 instances of one model. Pose::computeAbsolute (src/renderer/
+//   k_pose_palette   one wave per group of up to 4 instances of one model. Pose::computeAbsolute (src/renderer/
 //                    pose.cpp:63-134, scalar recurrence :129-130) is a chain over the bone tree: a bone only depends on
 //                    its parent's final value, so the wave walks the tree level by level with the group's poses in
 //                    LDS, lanes spread over (instance, bone of that level) pairs; every bone is computed by exactly the
@@ -35,128 +35,218 @@ __device__ __forceinline__ void wave_lds_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One block per GROUP of up to K consecutive instances of one model (K = 16 / 8 / 4 for <= 64 / 128 / 196 bones). A bone
-// only depends on its parent's final value, so the tree is walked level by level; the work items of a level are the
-// (instance, bone at that depth) pairs of the whole group, which fills the lanes even though a level of one skeleton holds
-// only a handful of bones. Poses live in LDS bone-major ([bone][instance]) so that neighbouring lanes (instances) touch
-// neighbouring banks. Every bone is computed by exactly the reference's operations (pose.cpp:129-130), so the result is
-// bit-identical to the index-order loop. The 4 waves of the block split the group's instances for the global loads and
-// stores (the kernel moves ~100 B per bone and is bound by the bytes the few LDS-limited blocks of a CU keep in flight) and
-// share the level walk; the global loads of a phase are issued back to back before anything waits on them.
+// Pose::computeAbsolute + computeSkinMatrices, one WAVE per group of K = 4 / 2 / 1 consecutive instances of one model (<= 64 / 128 / 196
+// bones, 256 bones per wave at most). A bone only depends on its parent's final value, so the tree is walked level by level; the work items
+// of a level are the (instance, bone at that depth) pairs of the group. Every bone is computed by exactly the reference's operations
+// (pose.cpp:129-130, model.cpp:132-137), so the result is bit-identical to the index-order loop. Nothing is shared between waves - no
+// barrier, and the load, walk and store phases of the ~20 waves a CU holds drift apart and overlap - and every global access is the
+// memory order itself:
+//   - LDS keeps the poses instance-major, as memory does: rotations s_rot[k * NBP + bone], positions as the AoS dwords
+//     s_pos[k * PS + 3 * bone + c]. Loads: lane = bone for the 16-byte rotations (1 KiB contiguous per instruction), lane = dword for the
+//     positions (256 B contiguous), all of a group's loads in flight before the first LDS write.
+//   - the walk's lanes are (instance k = lane % K, item lane / K); NBP = 16 / K and PS = 64 / K modulo the bank count put the K
+//     instances of one bone in different bank columns, so two lanes collide only when their BONES agree modulo 16 / K (b128) or modulo
+//     64 / K dwords (b32) - neighbouring bone indices, the common case within a level, never do. The LDS executes one wave's
+//     instructions in order: no barrier, only the compiler is held (wave_lds_sync).
+//   - palette rows: a lane computes its bone's 3 x float4, parks them in the (already consumed) rotation area at float4 3 * lane + r
+//     (3 is odd: a b128 service group's 16 lanes land in 16 different columns) and the wave reads them back as float4 64 * j + lane: three
+//     1 KiB stores per 64 bones. The absolute rotations leave from registers (1 KiB per instruction), the absolute positions as the
+//     dwords the LDS already holds in memory order. All stores are non-temporal.
+// Palette layout in HBM: 3 rows x float4 per bone ({c0[r], c1[r], c2[r], c3[r]}, 48 B) - the rows evaluateSkin reads; row 3 of
+// (pose * inverse_bind).toMatrix() is the constant (0, 0, 0, 1) (math.cpp:887-890) and is re-attached on read-back.
 //
-// Palette layout in HBM: 3 rows x float4 per bone ({c0[r], c1[r], c2[r], c3[r]}, 48 B) — the rows evaluateSkin reads; row 3
-// of (pose * inverse_bind).toMatrix() is the constant (0, 0, 0, 1) (math.cpp:887-890) and is re-attached on read-back.
-constexpr int POSE_LDS_BONES = 1024; // K * n_bones <= 1024: 16 x 64, 8 x 128, 4 x 196
-constexpr int POSE_WAVES = 4;
+// Round 3's kernel (a 4-wave block per 16 instances, (instance, bone) lanes in every phase, a barrier per level) moved 16-byte pieces -
+// a global instruction touched 64 different 128-byte lines - and took 172 us for 100 000 x 64 bones; this one 133 us, 105 us with
+// non-temporal stores (6.3 TB/s on the 104 B / bone; 8 instances per wave: 112 us; profiles/r04/pose_probe.txt, tools/pose_probe.hip).
+#ifndef LMX_POSE_NT
+#define LMX_POSE_NT 1 // non-temporal stores for the palette and the absolute pose (100 k x 64 bones: 133 -> 105 us, profiles/r04/pose_probe.txt)
+#endif
+__device__ __forceinline__ void pose_store(float* p, float v) {
+#if LMX_POSE_NT
+	__builtin_nontemporal_store(v, p);
+#else
+	*p = v;
+#endif
+}
+__device__ __forceinline__ void pose_store(float4* p, const float4& v) {
+#if LMX_POSE_NT
+	typedef float pose_v4f __attribute__((ext_vector_type(4)));
+	const pose_v4f t = {v.x, v.y, v.z, v.w};
+	__builtin_nontemporal_store(t, reinterpret_cast<pose_v4f*>(p));
+#else
+	*p = v;
+#endif
+}
 
-// LDS slot of (bone, instance of the group): bone-major, plain. Every phase maps neighbouring lanes to neighbouring INSTANCES of one
-// bone (lane -> instance lane % K, bone lane / K), so a wave touches 64 consecutive slots: conflict-free for the 16-byte rotations
-// and the 4-byte position planes alike. (Round 2 mapped the staging / palette lanes to neighbouring bones of one instance and
-// XOR-ed the instance index by the bone to spread them over the bank columns; that swizzle made two bones of the level walk that
-// share a ds_*_b128 service group collide instead - SQ_LDS_BANK_CONFLICT was 31 % of the kernel's LDS cycles.)
-template <uint32_t K> __device__ __forceinline__ uint32_t pose_slot(uint32_t bone, uint32_t k) { return bone * K + k; }
+template <int NBMAX, int KSHIFT> struct PoseWave {
+	static constexpr uint32_t K = 1u << KSHIFT;
+	static constexpr uint32_t CHUNKS = (NBMAX + 63) / 64;                            // 64-bone chunks per instance
+	static constexpr uint32_t Q = K * CHUNKS;                                        // (instance, chunk) pairs of a group = bones per lane
+	static constexpr uint32_t NBP = K == 1 ? NBMAX : ((NBMAX + 15) / 16) * 16 + 16 / K;       // float4 per instance: = 16 / K modulo 16
+	static constexpr uint32_t PS = K == 1 ? 3 * NBMAX : ((3 * NBMAX + 63) / 64) * 64 + 64 / K; // dwords per instance: = 64 / K modulo 64
+	static constexpr uint32_t PCH = (3 * NBMAX + 63) / 64;                           // dword loads per lane and instance
+	static constexpr uint32_t ICH = (NBMAX + 63) / 64;                               // item words per lane
+};
 
-template <int KSHIFT>
-__global__ __launch_bounds__(64 * POSE_WAVES) void k_pose_palette(const SkinInstance* __restrict__ inst, const PoseGroup* __restrict__ groups,
+template <int NBMAX, int KSHIFT>
+__global__ __launch_bounds__(64) void k_pose_palette(const SkinInstance* __restrict__ inst, const PoseGroup* __restrict__ groups,
 	const float* rel_pos, const float4* rel_rot, float* pose_pos, float4* pose_rot /* rel_* may alias pose_*: no __restrict__; null = no write-back */,
 	const uint32_t* __restrict__ level_items, const uint16_t* __restrict__ level_off, const float* __restrict__ inv_pos,
 	const float4* __restrict__ inv_rot, float4* __restrict__ palette, float4* __restrict__ dual_quats) {
-	constexpr uint32_t K = 1u << KSHIFT;
-	constexpr uint32_t THREADS = 64 * POSE_WAVES;
-	constexpr uint32_t BONES_PER_STEP = THREADS / K; // (instance, bone) pairs of one step: K instances x this many bones
-	constexpr uint32_t STEPS = 4;                    // loads of this many steps are issued before the first is used
-	__shared__ float4 s_rot[POSE_LDS_BONES];
-	__shared__ float s_px[POSE_LDS_BONES], s_py[POSE_LDS_BONES], s_pz[POSE_LDS_BONES];
-	__shared__ uint32_t s_item[SKIN_MAX_BONES];     // bone | parent << 16, sorted by depth (bones >= first_nonroot only)
-	__shared__ uint16_t s_off[SKIN_MAX_BONES + 1];  // s_off[d - 1] .. s_off[d]: items of depth d
-	const uint32_t tid = threadIdx.x;
+	using C = PoseWave<NBMAX, KSHIFT>;
+	constexpr uint32_t K = C::K, NBP = C::NBP, PS = C::PS, PCH = C::PCH, Q = C::Q, CHUNKS = C::CHUNKS, ICH = C::ICH;
+	static_assert(K * NBP >= 192, "the rotation area doubles as the staging rows of 64 bones' palette");
+	__shared__ float4 s_rot[K * NBP];
+	__shared__ float s_pos[K * PS];
+	__shared__ uint32_t s_item[NBMAX];     // bone | parent << 16, sorted by depth (bones >= first_nonroot only)
+	__shared__ uint16_t s_off[NBMAX + 1];  // s_off[d - 1] .. s_off[d]: items of depth d
+	const uint32_t lane = threadIdx.x;
 	const PoseGroup g = groups[blockIdx.x];
 	const SkinInstance in = inst[g.first_inst]; // all instances of the group share the model; their bones are consecutive in memory
 	const uint32_t nb = in.n_bones;
 	const size_t bone0 = in.bone_offset;
-	const uint32_t k = tid & (K - 1), b_lane = tid >> KSHIFT; // this thread's instance of the group and its bone within a step
-	const bool k_live = k < g.count;
-	const size_t inst_base = bone0 + (size_t)(k_live && !LMX_PROBE_SKIP(4) ? k : 0u) * nb; // instances past the group's end re-read its first one (no branch around the loads)
-	// stage relative poses into LDS, [bone][instance]. Per instruction a wave reads, for each of its K instances, 64 / K consecutive
-	// bones: runs of 64 bytes (rotations, K = 16) - the same number of 64-byte sectors as 64 consecutive bones of one instance
-	for (uint32_t b0 = 0; b0 < nb; b0 += BONES_PER_STEP * STEPS) {
-		float4 r[STEPS];
-		float px[STEPS], py[STEPS], pz[STEPS];
+	// ---- loads: the model's level tables first (loads return in order: the walk's tables are not queued behind the poses), then
+	// everything the group reads, all issued before anything is used
+	uint32_t item_w[ICH], off_w[ICH + 1];
 #pragma unroll
-		for (uint32_t st = 0; st < STEPS; ++st) {
-			const uint32_t b = b0 + st * BONES_PER_STEP + b_lane;
-			const size_t i = inst_base + (b < nb ? b : nb - 1); // bones past the skeleton's end re-read its last one
-			r[st] = rel_rot[i];
-			px[st] = rel_pos[i * 3];
-			py[st] = rel_pos[i * 3 + 1];
-			pz[st] = rel_pos[i * 3 + 2];
-		}
+	for (uint32_t c = 0; c < ICH; ++c) { // (n_items <= n_bones - 1 < 64 * ICH; an index past the end re-reads the model's neighbours, never out of the table: + 0)
+		const uint32_t i = c * 64 + lane;
+		item_w[c] = level_items[in.lv_items_offset + (i < nb ? i : 0u)];
+	}
 #pragma unroll
-		for (uint32_t st = 0; st < STEPS; ++st) {
-			const uint32_t b = b0 + st * BONES_PER_STEP + b_lane;
-			if (b < nb && k_live) {
-				const uint32_t slot = pose_slot<K>(b, k);
-				s_rot[slot] = r[st];
-				s_px[slot] = px[st];
-				s_py[slot] = py[st];
-				s_pz[slot] = pz[st];
-			}
+	for (uint32_t c = 0; c <= ICH; ++c) {
+		const uint32_t i = c * 64 + lane;
+		off_w[c] = level_off[in.lv_off_offset + (i <= in.max_depth ? i : 0u)];
+	}
+	float4 rv[Q];
+	float pv[K][PCH];
+#pragma unroll
+	for (uint32_t q = 0; q < Q; ++q) {
+		const uint32_t k = q / CHUNKS, b = (q % CHUNKS) * 64 + lane;
+		const uint32_t kk = k < g.count && !LMX_PROBE_SKIP(4) ? k : 0u; // instances past the group's end re-read its first one (no branch around the loads)
+		rv[q] = rel_rot[bone0 + (size_t)kk * nb + (b < nb ? b : nb - 1)];
+	}
+#pragma unroll
+	for (uint32_t k = 0; k < K; ++k) {
+		const uint32_t kk = k < g.count && !LMX_PROBE_SKIP(4) ? k : 0u;
+		const float* src = rel_pos + (bone0 + (size_t)kk * nb) * 3;
+#pragma unroll
+		for (uint32_t c = 0; c < PCH; ++c) {
+			const uint32_t j = c * 64 + lane;
+			pv[k][c] = src[j < 3 * nb ? j : 3 * nb - 1];
 		}
 	}
-	const uint32_t n_items = level_off[in.lv_off_offset + in.max_depth];
-	for (uint32_t i = tid; i < n_items; i += THREADS) s_item[i] = level_items[in.lv_items_offset + i];
-	for (uint32_t i = tid; i <= in.max_depth; i += THREADS) s_off[i] = level_off[in.lv_off_offset + i];
-	__syncthreads();
-	for (uint32_t d = 1; d <= in.max_depth && !LMX_PROBE_SKIP(1); ++d) {
-		const uint32_t start = s_off[d - 1];
-		const uint32_t items = (uint32_t)s_off[d] - start;
-		for (uint32_t j = b_lane; j < items; j += BONES_PER_STEP) {
-			if (k_live) {
-				const uint32_t it = s_item[start + j];
-				const uint32_t ib = pose_slot<K>(it & 0xffffu, k), ip = pose_slot<K>(it >> 16, k);
-				const float4 pr4 = s_rot[ip];
-				const float4 r4 = s_rot[ib];
-				const Q4 pr = Q4{pr4.x, pr4.y, pr4.z, pr4.w};
-				const V3 np = add(rotate(pr, V3{s_px[ib], s_py[ib], s_pz[ib]}), V3{s_px[ip], s_py[ip], s_pz[ip]});
-				const Q4 nr = qmul(pr, Q4{r4.x, r4.y, r4.z, r4.w});
-				s_px[ib] = np.x; s_py[ib] = np.y; s_pz[ib] = np.z;
-				s_rot[ib] = make_float4(nr.x, nr.y, nr.z, nr.w);
+#pragma unroll
+	for (uint32_t c = 0; c < ICH; ++c)
+		if (c * 64 + lane < (uint32_t)NBMAX) s_item[c * 64 + lane] = item_w[c];
+#pragma unroll
+	for (uint32_t c = 0; c <= ICH; ++c)
+		if (c * 64 + lane <= (uint32_t)NBMAX) s_off[c * 64 + lane] = (uint16_t)off_w[c];
+#pragma unroll
+	for (uint32_t q = 0; q < Q; ++q) {
+		const uint32_t k = q / CHUNKS, b = (q % CHUNKS) * 64 + lane;
+		if (b < nb) s_rot[k * NBP + b] = rv[q];
+	}
+#pragma unroll
+	for (uint32_t k = 0; k < K; ++k) {
+#pragma unroll
+		for (uint32_t c = 0; c < PCH; ++c) {
+			const uint32_t j = c * 64 + lane;
+			if (j < 3 * nb) s_pos[k * PS + j] = pv[k][c];
+		}
+	}
+	wave_lds_sync();
+	// ---- Pose::computeAbsolute, level by level; lanes = (instance, bone of the level). The next level's bounds and this lane's first
+	// item of it are read while the current level computes (three dependent LDS round trips per level otherwise)
+	{
+		const uint32_t k = lane & (K - 1), j0 = lane >> KSHIFT;
+		const bool k_live = k < g.count;
+		const uint32_t md = LMX_PROBE_SKIP(1) ? 0u : in.max_depth;
+		uint32_t start = s_off[0], end = md ? s_off[1] : start;
+		uint32_t it0 = s_item[start + j0 < (uint32_t)NBMAX ? start + j0 : 0u];
+		for (uint32_t d = 1; d <= md; ++d) {
+			const uint32_t n_start = end, n_end = s_off[d < md ? d + 1 : d];
+			const uint32_t n_it0 = s_item[n_start + j0 < (uint32_t)NBMAX ? n_start + j0 : 0u];
+			for (uint32_t j = j0; start + j < end; j += 64 / K) {
+				if (k_live) {
+					const uint32_t it = j == j0 ? it0 : s_item[start + j];
+					const uint32_t bi = it & 0xffffu, pi = it >> 16;
+					const float4 pr4 = s_rot[k * NBP + pi];
+					const float4 r4 = s_rot[k * NBP + bi];
+					const float* pp = s_pos + k * PS + 3 * pi;
+					float* bp = s_pos + k * PS + 3 * bi;
+					const Q4 pr = Q4{pr4.x, pr4.y, pr4.z, pr4.w};
+					const V3 np = add(rotate(pr, V3{bp[0], bp[1], bp[2]}), V3{pp[0], pp[1], pp[2]});
+					const Q4 nr = qmul(pr, Q4{r4.x, r4.y, r4.z, r4.w});
+					bp[0] = np.x; bp[1] = np.y; bp[2] = np.z;
+					s_rot[k * NBP + bi] = make_float4(nr.x, nr.y, nr.z, nr.w);
+				}
+			}
+			wave_lds_sync();
+			start = n_start; end = n_end; it0 = n_it0;
+		}
+	}
+	// ---- absolute poses back into registers (lane = bone), absolute positions out as the dwords the LDS holds in memory order
+	V3 ap[Q];
+#pragma unroll
+	for (uint32_t q = 0; q < Q; ++q) {
+		const uint32_t k = q / CHUNKS, b = (q % CHUNKS) * 64 + lane;
+		const uint32_t bb = b < nb ? b : nb - 1;
+		rv[q] = s_rot[k * NBP + bb];
+		const float* sp = s_pos + k * PS + 3 * bb;
+		ap[q] = V3{sp[0], sp[1], sp[2]};
+	}
+	if (pose_pos != nullptr && !LMX_PROBE_SKIP(2)) { // the pose becomes absolute (Pose::is_absolute = true, pose.cpp:133)
+#pragma unroll
+		for (uint32_t k = 0; k < K; ++k) {
+			float* dst = pose_pos + (bone0 + (size_t)k * nb) * 3;
+#pragma unroll
+			for (uint32_t c = 0; c < PCH; ++c) {
+				const uint32_t j = c * 64 + lane;
+				if (k < g.count && j < 3 * nb) pose_store(dst + j, s_pos[k * PS + j]);
 			}
 		}
-		__syncthreads();
+#pragma unroll
+		for (uint32_t q = 0; q < Q; ++q) {
+			const uint32_t k = q / CHUNKS, b = (q % CHUNKS) * 64 + lane;
+			if (k < g.count && b < nb) pose_store(pose_rot + bone0 + (size_t)k * nb + b, rv[q]);
+		}
 	}
-	// palette (computeSkinMatrices), optional dual quaternions, optional absolute pose write-back
+	wave_lds_sync(); // every lane holds its bones: the rotation area is free for the staging rows
+	// ---- palette (computeSkinMatrices), optional dual quaternions
 	const float* ipos = inv_pos + (size_t)in.model_offset * 3;
 	const float4* irot = inv_rot + in.model_offset;
-	for (uint32_t b = b_lane; b < nb; b += BONES_PER_STEP) {
-		if (!k_live) break;
-		const float4 ir4 = irot[b];
+#pragma unroll
+	for (uint32_t q = 0; q < Q; ++q) {
+		const uint32_t k = q / CHUNKS, cb = (q % CHUNKS) * 64, b = cb + lane;
+		if (k >= g.count || cb >= nb) continue; // wave-uniform
+		const uint32_t bb = b < nb ? b : nb - 1;
+		const float4 ir4 = irot[bb];
 		const Q4 ir = Q4{ir4.x, ir4.y, ir4.z, ir4.w};
-		const V3 ip = V3{ipos[3 * b], ipos[3 * b + 1], ipos[3 * b + 2]};
-		const size_t i = bone0 + (size_t)k * nb + b;
-		const uint32_t ib = pose_slot<K>(b, k);
-		const float4 r4 = s_rot[ib];
-		const V3 p = V3{s_px[ib], s_py[ib], s_pz[ib]};
-		const Mat4 m = skin_matrix(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, ir);
+		const V3 ip = V3{ipos[3 * bb], ipos[3 * bb + 1], ipos[3 * bb + 2]};
+		const Q4 r = Q4{rv[q].x, rv[q].y, rv[q].z, rv[q].w};
+		const Mat4 m = skin_matrix(ap[q], r, ip, ir);
 		if (LMX_PROBE_SKIP(2) && m.c[0][0] != 123.f) continue;
-		if (dual_quats != nullptr) { // the palette format of the reference's own GPU skinning path (32 B per bone)
-			const DualQ dq = skin_dual_quat(p, Q4{r4.x, r4.y, r4.z, r4.w}, ip, ir);
-			float4* o = dual_quats + i * 2;
+		const size_t i0 = bone0 + (size_t)k * nb + cb; // first bone of the chunk
+		if (dual_quats != nullptr && b < nb) { // the palette format of the reference's own GPU skinning path (32 B per bone)
+			const DualQ dq = skin_dual_quat(ap[q], r, ip, ir);
+			float4* o = dual_quats + (i0 + lane) * 2;
 			o[0] = make_float4(dq.r.x, dq.r.y, dq.r.z, dq.r.w);
 			o[1] = make_float4(dq.d.x, dq.d.y, dq.d.z, dq.d.w);
 		}
-		float4* out = palette + i * 3;
-		out[0] = make_float4(m.c[0][0], m.c[1][0], m.c[2][0], m.c[3][0]);
-		out[1] = make_float4(m.c[0][1], m.c[1][1], m.c[2][1], m.c[3][1]);
-		out[2] = make_float4(m.c[0][2], m.c[1][2], m.c[2][2], m.c[3][2]);
-		if (pose_pos != nullptr) { // the pose becomes absolute (Pose::is_absolute = true, pose.cpp:133)
-			float* gp = pose_pos + i * 3;
-			gp[0] = p.x; gp[1] = p.y; gp[2] = p.z;
-			pose_rot[i] = r4;
-		}
+		s_rot[3 * lane] = make_float4(m.c[0][0], m.c[1][0], m.c[2][0], m.c[3][0]);
+		s_rot[3 * lane + 1] = make_float4(m.c[0][1], m.c[1][1], m.c[2][1], m.c[3][1]);
+		s_rot[3 * lane + 2] = make_float4(m.c[0][2], m.c[1][2], m.c[2][2], m.c[3][2]);
+		wave_lds_sync();
+		const uint32_t n_rows = 3 * (nb - cb < 64 ? nb - cb : 64);
+		float4* out = palette + i0 * 3;
+		const float4 o0 = s_rot[lane], o1 = s_rot[64 + lane], o2 = s_rot[128 + lane];
+		if (lane < n_rows) pose_store(out + lane, o0);
+		if (64 + lane < n_rows) pose_store(out + 64 + lane, o1);
+		if (128 + lane < n_rows) pose_store(out + 128 + lane, o2);
+		wave_lds_sync(); // the rows are in registers before the next chunk overwrites them
 	}
 }
-
 
 // Pose::blend (renderer/pose.cpp:30-41) for every bone of every instance: positions = positions * inv + rhs * weight, rotations =
 // nlerp(rotations, rhs, weight) (core/math.cpp:677-691: left-to-right dot and length, t negated for the short way round)
@@ -820,19 +910,20 @@ hipError_t launch_skin_multi(hipStream_t s, uint32_t per_block, const SkinMultiC
 	}
 }
 
-// groups are sorted by capacity class on the host: [0, n16) hold <= 16 instances of <= 64 bones, then 8 x <= 128, then 4 x <= 196
+// groups are sorted by capacity class on the host: [0, n0) hold <= 4 instances of <= 64 bones, then 2 x <= 128, then 1 x <= 196
+// (POSE_GROUP_CAP_SHIFT, lmx_kernels.h)
 hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, const PoseGroup* groups, const uint32_t n_groups[3], const float* rel_pos,
 	const float4* rel_rot, float* pose_pos, float4* pose_rot, const uint32_t* level_items, const uint16_t* level_off, const float* inv_pos,
 	const float4* inv_rot, float4* palette, float4* dual_quats) {
 	if (n_groups[0])
-		hipLaunchKernelGGL(k_pose_palette<4>, dim3(n_groups[0]), dim3(64 * POSE_WAVES), 0, s, inst, groups, rel_pos, rel_rot, pose_pos, pose_rot, level_items,
-			level_off, inv_pos, inv_rot, palette, dual_quats);
+		hipLaunchKernelGGL((k_pose_palette<64, POSE_GROUP_SHIFT>), dim3(n_groups[0]), dim3(64), 0, s, inst, groups, rel_pos, rel_rot, pose_pos, pose_rot, level_items, level_off, inv_pos,
+			inv_rot, palette, dual_quats);
 	if (n_groups[1])
-		hipLaunchKernelGGL(k_pose_palette<3>, dim3(n_groups[1]), dim3(64 * POSE_WAVES), 0, s, inst, groups + n_groups[0], rel_pos, rel_rot, pose_pos, pose_rot,
-			level_items, level_off, inv_pos, inv_rot, palette, dual_quats);
+		hipLaunchKernelGGL((k_pose_palette<128, (POSE_GROUP_SHIFT > 1 ? POSE_GROUP_SHIFT - 1 : 0)>), dim3(n_groups[1]), dim3(64), 0, s, inst, groups + n_groups[0], rel_pos, rel_rot, pose_pos, pose_rot, level_items,
+			level_off, inv_pos, inv_rot, palette, dual_quats);
 	if (n_groups[2])
-		hipLaunchKernelGGL(k_pose_palette<2>, dim3(n_groups[2]), dim3(64 * POSE_WAVES), 0, s, inst, groups + n_groups[0] + n_groups[1], rel_pos, rel_rot, pose_pos,
-			pose_rot, level_items, level_off, inv_pos, inv_rot, palette, dual_quats);
+		hipLaunchKernelGGL((k_pose_palette<196, (POSE_GROUP_SHIFT > 2 ? POSE_GROUP_SHIFT - 2 : 0)>), dim3(n_groups[2]), dim3(64), 0, s, inst, groups + n_groups[0] + n_groups[1], rel_pos, rel_rot, pose_pos, pose_rot,
+			level_items, level_off, inv_pos, inv_rot, palette, dual_quats);
 	return hipGetLastError();
 }
 

@@ -77,7 +77,7 @@ def test_traffic_model_reproduces_the_algorithmic_bytes(tmp_path):
     pose = kernel("skin", "k_pose_palette")
     bones = 32 * 64
     assert 100.0 <= pose["footprint_bytes"] / bones <= 112.0, pose  # 28 B read + 76 B written per bone
-    assert pose["write_coalescing"] < 0.6  # the strided stores (LMX_POSE_STAGE_OUT is the experiment against them)
+    assert pose["write_coalescing"] > 0.9  # (round 4: every store instruction of the wave-per-group kernel writes one contiguous run; round 3's strided 16-byte pieces: 0.41)
     keys, split = kernel("keys", "k_keys_mesh"), kernel("keys_split_state", "k_keys_mesh")
     assert split["footprint_bytes"] < 0.9 * keys["footprint_bytes"], (keys, split)
 
