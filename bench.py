@@ -438,7 +438,7 @@ def main(argv=None):
                 "entity_frustum_tests_per_sec": None if (ms8 != ms8 or not ms8) else 8.0 * N / (ms8 * 1e-3),
                 "note": "k_cull_tile<F = 0> (runtime frustum count), pass width 8, cache-cold after a read-only 1 GiB scrub; 56 flop per sphere and frustum (SURVEY.md 8d)"}
         finally:
-            cs_t.setPassWidth(1)
+            cs_t.setPassWidth(0)
         del cs_t, sc_t
         # the same regime reached the config-2-faithful way: NORMAL radii, the cells classified by the AABB pre-tests, under an
         # orthographic slab camera that every cell of a one-layer scene straddles (scenes.slab_scene / slab_frustum_kwargs)

@@ -129,10 +129,11 @@ LMX_API int lmx_cull_stats(LmxContext* ctx, uint32_t* n_entities, uint32_t* n_ce
  * call (e.g. the 4 shadow cascades + main view of a frame). type == LMX_TYPE_ALL (0xff) culls every type. Asynchronous
  * on the context stream; the result stays in HBM in slot `view` until the next lmx_cull() on the same slot. */
 LMX_API int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, uint32_t n_frusta, uint8_t type);
-/* How many frusta of a call are tested per pass over the static set (1..LMX_MAX_FRUSTA, default 1). The cull kernel is
- * latency-bound rather than bandwidth-bound on MI355X, so one frustum per pass at full occupancy measured fastest
- * (8 frusta over 10 M spheres: 0.17 ms at width 1, 0.32 ms at width 8); wider passes read the spheres fewer times and are
- * the better choice when the set is far larger than the 256 MiB Infinity Cache. */
+/* How many frusta of a call are tested per pass over the static set (1..LMX_MAX_FRUSTA; 0 = automatic, the default: all of them
+ * in one launch when the set holds <= 1 M spheres - a game scene's views cost one launch gap instead of one per view - else 1).
+ * On a large set the kernel is latency-bound for a narrow camera, so one frustum per pass at full occupancy measured fastest
+ * (8 frusta over 10 M spheres, sparse scene: 119 us at width 1, 152 us at width 8); wider passes read the spheres fewer times and
+ * win when every sphere is tested (218 against 290 us) or the set is far larger than the 256 MiB Infinity Cache. */
 LMX_API int lmx_cull_set_pass_width(LmxContext* ctx, uint32_t frusta_per_pass);
 /* Kernel tuning knobs (no reference twin; results never depend on them). */
 enum {

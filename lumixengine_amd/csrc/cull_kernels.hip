@@ -794,12 +794,19 @@ __global__ __launch_bounds__(256) void k_cull_consolidate(const int32_t* __restr
 // (the exchange's send buffer, lmx_cull_map_all's host record). Shards are ordered by type (recompute_out_layout), so a shard's
 // place in the packed list is the plain exclusive prefix of the counts of ALL shards before it: every block sums those <= 575
 // counters itself (one per thread, separate cache lines, L2 hits) instead of waiting for a one-block scan kernel - 7 us of GPU time
-// and one launch less per frame. Block (0, 0) also writes the per-type totals. grid (n_shards, splits).
+// and one launch less per frame. Block (0, 0) also writes the per-type totals. grid (n_shards, splits, frusta): the frusta of one cull
+// (a frame's views, the exchange's sub-records) are packed by ONE launch, frustum f reading row f of the ids / counters and writing
+// record f (strides in words).
 __global__ __launch_bounds__(256) void k_cull_pack(const int32_t* __restrict__ src, const uint32_t* __restrict__ win_base, const uint32_t* __restrict__ counts,
-	uint32_t cnt_pad, const uint8_t* __restrict__ shard_type, uint32_t n_shards, uint32_t* __restrict__ header, int32_t* __restrict__ dst, uint32_t dst_cap) {
+	uint32_t cnt_pad, const uint8_t* __restrict__ shard_type, uint32_t n_shards, uint32_t* __restrict__ header, int32_t* __restrict__ dst, uint32_t dst_cap,
+	uint32_t src_stride, uint32_t cnt_stride, uint32_t rec_stride) {
 	__shared__ uint32_t s_part[4];
 	__shared__ uint32_t s_tot[MAX_TYPES];
 	const uint32_t s = blockIdx.x, t = threadIdx.x;
+	src += (size_t)blockIdx.z * src_stride;
+	counts += (size_t)blockIdx.z * cnt_stride;
+	header += (size_t)blockIdx.z * rec_stride;
+	dst += (size_t)blockIdx.z * rec_stride;
 	const bool totals_block = s == 0 && blockIdx.y == 0;
 	const uint32_t c = counts[s * cnt_pad];
 	// a block whose slice of the shard's window is empty has nothing to place (most of them when little is visible: the grid is sized
@@ -979,11 +986,18 @@ hipError_t launch_cull_consolidate(hipStream_t s, const int32_t* src, uint32_t s
 }
 
 hipError_t launch_cull_pack(hipStream_t s, const int32_t* src, const uint32_t* win_base, const uint32_t* counts, uint32_t cnt_pad, const uint8_t* shard_type,
-	uint32_t n_shards, uint32_t max_shard_cap, uint32_t* header, int32_t* dst, uint32_t dst_cap) {
-	if (!n_shards) return hipMemsetAsync(header, 0, MAX_TYPES * sizeof(uint32_t), s); // an empty set still reports its (zero) counts
+	uint32_t n_shards, uint32_t max_shard_cap, uint32_t* header, int32_t* dst, uint32_t dst_cap, uint32_t n_frusta, uint32_t src_stride, uint32_t cnt_stride,
+	uint32_t rec_stride) {
+	if (!n_frusta) return hipSuccess;
+	if (!n_shards) { // an empty set still reports its (zero) counts
+		for (uint32_t f = 0; f < n_frusta; ++f)
+			if (hipError_t e = hipMemsetAsync(header + (size_t)f * rec_stride, 0, MAX_TYPES * sizeof(uint32_t), s)) return e;
+		return hipSuccess;
+	}
 	if (n_shards > (uint32_t)FIN_MAX_SHARDS) return hipErrorInvalidValue;
 	const uint32_t splits = std::max(1u, std::min(64u, max_shard_cap / 4096u));
-	hipLaunchKernelGGL(k_cull_pack, dim3(n_shards, splits), dim3(256), 0, s, src, win_base, counts, cnt_pad, shard_type, n_shards, header, dst, dst_cap);
+	hipLaunchKernelGGL(k_cull_pack, dim3(n_shards, splits, n_frusta), dim3(256), 0, s, src, win_base, counts, cnt_pad, shard_type, n_shards, header, dst, dst_cap,
+		src_stride, cnt_stride, rec_stride);
 	return hipGetLastError();
 }
 

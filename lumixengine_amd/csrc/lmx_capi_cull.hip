@@ -1426,7 +1426,10 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 	const CullDeviceView dv = static_view(cs);
 	// The kernel is latency-bound for small frusta: wide variants (many frusta per pass) hold more state per wave and run at lower
 	// occupancy, so a batch is split into passes of at most `pass_width` frusta.
-	const uint32_t pass_width = cs.pass_width;
+	// pass_width 0 = automatic: a small set (a game scene: tens of thousands of entities, a handful of tiles) is one launch for all
+	// frusta - every launch of a latency-bound kernel costs its launch gap, and the harness's six views of 40 k entities are 6 gaps
+	// against 1; a large set goes frustum by frustum (measured at 10 M entities: profiles/r04/cull8_pass_widths.txt).
+	const uint32_t pass_width = cs.pass_width ? cs.pass_width : (ent_end - ent_begin <= (1u << 20) ? n_frusta : 1u);
 	for (uint32_t f0 = 0; f0 < n_frusta; f0 += pass_width) {
 		const uint32_t fw = std::min(pass_width, n_frusta - f0);
 		FrustaArg sub;
@@ -1463,7 +1466,7 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 
 int lmx_cull_set_pass_width(LmxContext* ctx, uint32_t frusta_per_pass) {
 	LMX_CHECK_CTX(ctx);
-	if (frusta_per_pass < 1 || frusta_per_pass > LMX_MAX_FRUSTA) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "pass width %u not in [1,%d]", frusta_per_pass, LMX_MAX_FRUSTA);
+	if (frusta_per_pass > LMX_MAX_FRUSTA) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "pass width %u not in [0,%d]", frusta_per_pass, LMX_MAX_FRUSTA);
 	ctx->cull.pass_width = frusta_per_pass;
 	return LMX_OK;
 }
@@ -1622,12 +1625,16 @@ static int cull_map_begin(LmxContext* ctx, CullView& v, uint32_t first, uint32_t
 	for (uint32_t k = 0; k < n && zero_copy; ++k) zero_copy = v.map_guess[first + k] <= (64u << 10);
 	if (zero_copy && hipHostGetDevicePointer(reinterpret_cast<void**>(&host_dev), v.map_host, 0) != hipSuccess) zero_copy = false;
 	v.map_begin_zero_copy = zero_copy;
+	{ // the records of all n frusta: ONE launch (a frame's six views cost six launch gaps otherwise)
+		int32_t* rec = (zero_copy ? host_dev : v.map_rec.p) + (size_t)first * v.map_words;
+		if (v.map_words > 0xffffffffull) return fail(ctx, LMX_ERR_CAPACITY, "record stride exceeds 32 bits");
+		LMX_HIP(ctx, launch_cull_pack(ctx->stream, v.out.p + (size_t)first * v.out_stride, cs.d_win_base.p, v.counts_ptr() + (size_t)first * cnt_frustum_stride, cs.cnt_pad,
+			cs.d_shard_type.p, cs.n_shards, cs.max_shard_cap, reinterpret_cast<uint32_t*>(rec), rec + MAX_TYPES, v.out_stride, n, (uint32_t)v.out_stride, cnt_frustum_stride,
+			(uint32_t)v.map_words));
+	}
 	for (uint32_t k = 0; k < n; ++k) {
 		const uint32_t f = first + k;
-		const uint32_t* counts = v.counts_ptr() + (size_t)f * cnt_frustum_stride;
-		int32_t* rec = (zero_copy ? host_dev : v.map_rec.p) + (size_t)f * v.map_words;
-		LMX_HIP(ctx, launch_cull_pack(ctx->stream, v.out.p + (size_t)f * v.out_stride, cs.d_win_base.p, counts, cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, cs.max_shard_cap,
-			reinterpret_cast<uint32_t*>(rec), rec + MAX_TYPES, v.out_stride));
+		const int32_t* rec = v.map_rec.p + (size_t)f * v.map_words;
 		v.map_begin_guess[k] = zero_copy ? (size_t)v.out_stride : std::min<size_t>(v.out_stride, v.map_guess[f]);
 		if (!zero_copy)
 			LMX_HIP(ctx, hipMemcpyAsync(reinterpret_cast<int32_t*>(v.map_host) + (size_t)f * v.map_words, rec, (MAX_TYPES + v.map_begin_guess[k]) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

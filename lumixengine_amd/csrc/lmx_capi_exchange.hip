@@ -209,10 +209,10 @@ int lmx_exchange_cull_many(LmxExchange* x, const LmxShiftedFrustum* frusta, uint
 	// per frustum: per-type totals straight into its sub-record's header and the ids behind it (clipped to cap_f), one launch each (k_cull_pack)
 	const uint32_t sub = MAX_TYPES + cap_f;
 	const uint32_t cnt_frustum_stride = cs.n_shards * cs.cnt_pad;
-	for (uint32_t f = 0; f < n_frusta; ++f) {
-		int32_t* rec = x->send[k].p + (size_t)f * sub;
-		LMX_HIP(ctx, launch_cull_pack(ctx->stream, v.out.p + (size_t)f * v.out_stride, cs.d_win_base.p, v.counts_ptr() + (size_t)f * cnt_frustum_stride, cs.cnt_pad, cs.d_shard_type.p,
-			cs.n_shards, cs.max_shard_cap, reinterpret_cast<uint32_t*>(rec), rec + MAX_TYPES, cap_f));
+	{ // (one launch for all sub-records)
+		int32_t* rec = x->send[k].p;
+		LMX_HIP(ctx, launch_cull_pack(ctx->stream, v.out.p, cs.d_win_base.p, v.counts_ptr(), cs.cnt_pad, cs.d_shard_type.p, cs.n_shards, cs.max_shard_cap,
+			reinterpret_cast<uint32_t*>(rec), rec + MAX_TYPES, cap_f, n_frusta, (uint32_t)v.out_stride, cnt_frustum_stride, sub));
 	}
 	x->n_frusta[k] = n_frusta;
 	x->cap_f[k] = cap_f;

@@ -248,7 +248,7 @@ struct CullState : CullSet {
 	DevBuf<uint8_t> d_shard_type;
 	uint32_t type_start[MAX_TYPES] = {}, type_cap[MAX_TYPES] = {};
 	// ---- tuning (lmx_cull_set_option) -------------------------------------------------------------------------
-	uint32_t pass_width = 1;   // frusta tested per pass over the static set
+	uint32_t pass_width = 0;   // frusta tested per pass over the static set; 0 = automatic (all of them for a set of <= 1 M spheres, else 1)
 	int tile_variant = -1;     // -1: chosen per cull from the frustum's coverage of the scene
 	uint32_t overflow_reserve = 0; // LMX_CULL_OPT_OVERFLOW_RESERVE: slots kept free in the dynamic set for entities added / re-celled between compactions
 	bool device_owns_bound = false; // LMX_CULL_OPT_DEVICE_OWNS_BOUND: set* calls on hierarchy-bound entities are dropped

@@ -106,9 +106,11 @@ hipError_t launch_cull_finalize(hipStream_t s, const uint32_t* counts, uint32_t 
 	uint32_t n_shards, uint32_t n_frusta, uint32_t* totals, uint32_t* pref, uint32_t* packed_start);
 // One contiguous list per (frustum, type): dst[f * dst_stride + type_start[f * type_start_stride + type] + pref + k] = src[f * src_stride + win_base[s] + k],
 // clipped to dst_cap ids per frustum row
-// finalize + consolidate of ONE frustum in one launch, into the packed record [MAX_TYPES counts | ids, types back to back]
+// finalize + consolidate in one launch, into the packed record [MAX_TYPES counts | ids, types back to back] of each of n_frusta frusta
+// (frustum f: ids row src + f * src_stride, counters counts + f * cnt_stride, record header / dst + f * rec_stride; strides in words)
 hipError_t launch_cull_pack(hipStream_t s, const int32_t* src, const uint32_t* win_base, const uint32_t* counts, uint32_t cnt_pad, const uint8_t* shard_type,
-	uint32_t n_shards, uint32_t max_shard_cap, uint32_t* header, int32_t* dst /* behind the header */, uint32_t dst_cap);
+	uint32_t n_shards, uint32_t max_shard_cap, uint32_t* header, int32_t* dst /* behind the header */, uint32_t dst_cap, uint32_t n_frusta = 1,
+	uint32_t src_stride = 0, uint32_t cnt_stride = 0, uint32_t rec_stride = 0);
 hipError_t launch_cull_consolidate(hipStream_t s, const int32_t* src, uint32_t src_stride, const uint32_t* win_base, const uint32_t* counts,
 	uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* shard_type, const uint32_t* type_start /* device */, uint32_t type_start_stride,
 	const uint32_t* pref, uint32_t n_shards, uint32_t n_frusta, uint32_t max_shard_cap, int32_t* dst, uint32_t dst_stride, uint32_t dst_cap);

@@ -47,7 +47,7 @@ def test_cull_matches_golden(gpu_ctx, fixture):
             for k in range(min(8, len(frusta))):
                 H.assert_same_visible(gpu_visible(res, k), H.sorted_by_type(g[f"vis_ids_{k}"], g[f"vis_types_{k}"]), f"width {width} frustum {k}")
     finally:
-        cs.setPassWidth(1)
+        cs.setPassWidth(0)  # back to the default (automatic)
 
 
 def test_cull_config1_golden(gpu_ctx):
@@ -216,7 +216,7 @@ def test_cull_config2_10m_bit_exact(gpu_ctx, scene):
             for k in range(8):
                 check(res, rec["cascades"][k], f"cascade {k}, pass width {width}", frustum=k)
     finally:
-        cs.setPassWidth(1)
+        cs.setPassWidth(0)  # back to the default (automatic)
     # update stream: O(1) patches, no rebuild of the sorted set (the overflow stays far below the compaction threshold)
     fr = cams[0][1]
     for _ in range(3):
@@ -325,7 +325,7 @@ def test_cull_config5_100m_digest(gpu_ctx, name):
             for k in range(8):
                 _check_digest(res, rec["cameras"][f"cascade{k}"], f"{name} cascade {k}, pass width {width}", frustum=k)
     finally:
-        cs.setPassWidth(1)
+        cs.setPassWidth(0)  # back to the default (automatic)
 
 
 def test_cull_add_stream_never_stalls(gpu_ctx, oracle_port):
