@@ -205,35 +205,39 @@ __global__ __launch_bounds__(256) void k_xform_subtree(WorldDevice w, XformSubtr
 		}
 	}
 	// marks, moved list, bound spheres. The moved list takes ONE reservation per block: every wave appending for itself is an atomic on one
-	// address per 64 nodes - 15.6 k of them for 10^6 moved nodes, ~180 us at the ~90 per microsecond one address retires (measured: 203 us)
+	// address per 64 nodes - 15.6 k of them for 10^6 moved nodes, ~180 us at the ~90 per microsecond one address retires (measured: 203 us).
+	// Inside the block's range a wave's entries of one step are consecutive (ballot + mbcnt ranks): a step writes one run of <= 64
+	// 56-byte transforms and one of ids, not 64 scattered ones (a thread numbering its own slots: 65 us for 10^6 moved nodes, 23 untracked).
 	const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), wave = tid >> 6;
-	uint32_t my_base = 0;
+	uint32_t wave_at = 0; // wave-uniform: the wave's next free entry
 	if (a.count != nullptr) {
-		uint32_t mine = 0;
+		uint32_t wave_total = 0;
 		for (uint32_t l = 0; l < a.n_levels; ++l)
-			for (uint32_t s = t0[l] + tid; s < t1[l]; s += 256u) mine += (w.dirty[s] & XF_MOVED) ? 1u : 0u;
-		uint32_t incl = mine;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-			if (lane >= (uint32_t)o) incl += up;
-		}
-		if (lane == 63) s_count[wave] = incl;
+			for (uint32_t s0 = t0[l] + wave * 64u; s0 < t1[l]; s0 += 256u) { // wave-uniform trip count
+				const uint32_t s = s0 + lane;
+				wave_total += (uint32_t)__popcll(__ballot(s < t1[l] && (w.dirty[s] & XF_MOVED) != 0));
+			}
+		if (lane == 0) s_count[wave] = wave_total;
 		__syncthreads();
 		if (tid == 0) {
 			const uint32_t total = s_count[0] + s_count[1] + s_count[2] + s_count[3];
 			s_base = total ? atomicAdd(a.count, total) : 0u;
 		}
 		__syncthreads();
-		my_base = s_base + incl - mine;
-		for (uint32_t k = 0; k < wave; ++k) my_base += s_count[k];
+		wave_at = s_base;
+		for (uint32_t k = 0; k < wave; ++k) wave_at += s_count[k];
 	}
 	for (uint32_t l = 0; l < a.n_levels; ++l) {
-		for (uint32_t s = t0[l] + tid; s < t1[l]; s += 256u) { // the order of the count above: thread `tid` walks the same slots
-			const uint8_t mark = w.dirty[s];
+		for (uint32_t s0 = t0[l] + wave * 64u; s0 < t1[l]; s0 += 256u) { // the order of the count above
+			const uint32_t s = s0 + lane;
+			const bool live = s < t1[l];
+			const uint8_t mark = live ? w.dirty[s] : 0;
 			if (mark != 0) w.dirty[s] = 0;
 			const bool collect = (mark & XF_MOVED) != 0 && a.count != nullptr;
-			const uint32_t dyn = a.bound_dyn_of_slot != nullptr ? a.bound_dyn_of_slot[s] : 0xffffffffu;
+			const uint64_t mask = __ballot(collect);
+			const uint32_t at = wave_at + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+			wave_at += (uint32_t)__popcll(mask);
+			const uint32_t dyn = live && a.bound_dyn_of_slot != nullptr ? a.bound_dyn_of_slot[s] : 0xffffffffu;
 			if (dyn == 0xffffffffu && !collect) continue;
 			const float4 r = w.wrot[s];
 			const double px = w.wpx[s], py = w.wpy[s], pz = w.wpz[s];
@@ -243,17 +247,14 @@ __global__ __launch_bounds__(256) void k_xform_subtree(WorldDevice w, XformSubtr
 				const float mr = a.bound_radius_of_slot[s];
 				if (!(mr < 0.f)) a.dyn_radius[dyn] = mr * maximum3(sx, sy, sz);
 			}
-			if (collect) {
-				const uint32_t at = my_base++;
-				if (at < a.cap) {
-					TransformAoS t;
-					t.pos[0] = px; t.pos[1] = py; t.pos[2] = pz;
-					t.rot[0] = r.x; t.rot[1] = r.y; t.rot[2] = r.z; t.rot[3] = r.w;
-					t.scale[0] = sx; t.scale[1] = sy; t.scale[2] = sz;
-					t.pad = 0.f;
-					a.out_entity[at] = a.entity_of_slot[s];
-					reinterpret_cast<TransformAoS*>(a.out_tr)[at] = t;
-				}
+			if (collect && at < a.cap) {
+				TransformAoS t;
+				t.pos[0] = px; t.pos[1] = py; t.pos[2] = pz;
+				t.rot[0] = r.x; t.rot[1] = r.y; t.rot[2] = r.z; t.rot[3] = r.w;
+				t.scale[0] = sx; t.scale[1] = sy; t.scale[2] = sz;
+				t.pad = 0.f;
+				a.out_entity[at] = a.entity_of_slot[s];
+				reinterpret_cast<TransformAoS*>(a.out_tr)[at] = t;
 			}
 		}
 	}
