@@ -219,6 +219,9 @@ static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustu
 // F == 1: the single-frustum kernel (the common case: one launch per view). F == 0: n_frusta (2..8) is a runtime value and every
 // per-frustum loop is a real loop, so registers do not scale with the number of frusta (8 unrolled copies needed 172 VGPRs and
 // 600 spilled SGPRs); FS is the stride of a chunk's visibility bits.
+#ifndef LMX_CULL8_SHAPE
+#define LMX_CULL8_SHAPE 0     // block shape of the 5..8-frusta kernel over 1024-sphere tiles: 0 = 4 waves x 4 chunks, 1 = 8 waves x 2 chunks
+#endif
 #ifndef LMX_CULL_MAX_SGPR
 #define LMX_CULL_MAX_SGPR 0   // n > 0: cap the kernel's SGPRs (256-thread blocks are admitted 8 per CU only up to 80 SGPRs, 7 at 82-96: MI355X_MICROARCH.md "Residency")
 #endif
@@ -456,16 +459,28 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			need_sphere[i] = __ballot(lane_test) != 0; // wave-uniform
 		}
 		float4 sp[GRP];
+		typedef float v4f __attribute__((ext_vector_type(4)));
+		v4f spv[F != 1 ? GRP : 1]; // (several frusta) the spheres as register tuples
 #pragma unroll
 		for (int i = 0; i < GRP; ++i) {
 			const uint32_t e = ((chunk0 + g + i) << 6) + lane;
 			id[g + i] = -1;
 			sp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+			if constexpr (F != 1) {
+				// Several frusta: the loads are UNCONDITIONAL. Under `if (need_sphere[i])` each load's destination merges with the zeros of the
+				// other branch, the compiler resolved that with copies right behind the load - and an s_waitcnt vmcnt(0) in front of them, i.e.
+				// in front of the next chunk's loads: four serialised round trips to memory per wave (seen in the ISA; the 1-frustum kernels
+				// issue all their loads first). A chunk that needs nothing reads one 16-byte sphere / one id at a wave-uniform address instead
+				// (the wave's first entity: one cache line, usually the one its neighbour chunk fetches anyway) and ignores the value.
+				const uint32_t e0 = chunk0 << 6;
+				id[g + i] = g_ids[need_id[i] ? e : e0];
+				sp[i] = g_spheres[need_sphere[i] ? e : e0];
+				continue;
+			}
 #if LMX_CULL_NT_LOADS
 			if constexpr (GRP < CHW) { // the streaming variants: every sphere is read once per cull and nothing of it is reused
 				if (need_id[i]) id[g + i] = __builtin_nontemporal_load(g_ids + e);
 				if (need_sphere[i]) {
-					typedef float v4f __attribute__((ext_vector_type(4)));
 					const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g_spheres) + e);
 					sp[i] = make_float4(t.x, t.y, t.z, t.w);
 				}
@@ -477,6 +492,17 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			}
 		}
 		if constexpr (F != 1) {
+			// (the values pass through here together: all eight loads are in flight before the first wait)
+#pragma unroll
+			for (int i = 0; i < GRP; ++i) {
+				v4f t = {sp[i].x, sp[i].y, sp[i].z, sp[i].w}; // (as ONE register tuple: the tests below use its halves as packed operands)
+				asm volatile("" : "+v"(t), "+v"(id[g + i]));
+				spv[i] = t;
+			}
+#pragma unroll
+			for (int i = 0; i < GRP; ++i) {
+				if (!need_id[i]) id[g + i] = -1; // (wave-uniform select behind the loads)
+			}
 			// Several frusta over the same spheres (the frame's shadow cascades, BASELINE config 5). Rounds 2 / 3 ran the single-frustum body
 			// per (chunk, frustum): class from LDS -> wait -> branch -> frustum normals from the kernarg segment + distances from LDS ->
 			// wait -> test, i.e. two serialized waits and an 18-dword scalar load per 64 spheres and frustum - 224 us for 10 M spheres
@@ -517,7 +543,13 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 							uint32_t culled = 0;
 							if (need_sphere[i]) { // wave-uniform: some lane of the chunk is in a CELL_TEST cell of some frustum
 								// doCulling (culling_system.cpp:283-306), the operations of sphere_visible_d_pk: t = ((x*nx + y*ny) + z*nz) + d, t + r < 0 culls
-								const v2f x2 = {sp[i].x, sp[i].x}, y2 = {sp[i].y, sp[i].y}, z2 = {sp[i].z, sp[i].z}, r2 = {sp[i].w, sp[i].w};
+								// (the {c, c} operands as shuffles of the loaded register pairs: the broadcast folds into op_sel of v_pk_*_f32 - as explicit
+								// pairs they were 8 instead of 4 VGPRs per chunk and six v_mov each)
+								// (the empty asm keeps the shuffles inside the frustum loop: hoisted, they become the explicit pairs again)
+							asm volatile("" : "+v"(spv[i]));
+							const v2f xy = __builtin_shufflevector(spv[i], spv[i], 0, 1), zw = __builtin_shufflevector(spv[i], spv[i], 2, 3);
+								const v2f x2 = __builtin_shufflevector(xy, xy, 0, 0), y2 = __builtin_shufflevector(xy, xy, 1, 1);
+								const v2f z2 = __builtin_shufflevector(zw, zw, 0, 0), r2 = __builtin_shufflevector(zw, zw, 1, 1);
 #pragma unroll
 								for (int k = 0; k < 6; k += 2) {
 									const v2f n_x = {nrm[k], nrm[k + 1]}, n_y = {nrm[6 + k], nrm[7 + k]}, n_z = {nrm[12 + k], nrm[13 + k]}, dd = {ci[j].d[k], ci[j].d[k + 1]};
@@ -529,7 +561,8 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 									culled |= (t.x < 0 ? 1u : 0u) | (t.y < 0 ? 1u : 0u); // (no short circuit: straight-line code)
 								}
 							}
-							vis = (cls == CELL_ACCEPT ? 1u : 0u) | ((cls == CELL_TEST ? 1u : 0u) & (culled ^ 1u));
+							static_assert(CELL_REJECT == 0 && CELL_ACCEPT == 1 && CELL_TEST == 2, "a class that is not CELL_TEST is its own verdict");
+							vis = cls == CELL_TEST ? culled ^ 1u : cls;
 						}
 						vis &= id[g + i] >= 0 ? 1u : 0u;
 						vis_bits |= vis << ((g + i) * FS + f);
@@ -905,7 +938,11 @@ hipError_t launch_cull_tile(hipStream_t s, const CullDeviceView& v, uint32_t ent
 #undef LMX_TILE_VARIANTS
 	}
 	if (n_frusta <= 4) LMX_TILE(0, 8, 4, 4, 0); // 2048-sphere tiles, <= 4 x 32 B of LDS per cell
+#if LMX_CULL8_SHAPE == 1
+	LMX_TILE(0, 8, 2, 2, 0);                    // 1024-sphere tiles, eight waves of two chunks: half the LDS cell records per wave
+#else
 	LMX_TILE(0, 4, 4, 4, 0);                    // 1024-sphere tiles
+#endif
 #undef LMX_TILE
 }
 

@@ -95,6 +95,10 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			in.model = -1;
 			const int32_t sl = slots != nullptr ? slots[i] : -1;
 			slot = sl;
+			// (world binding) the entity's slot in the hierarchy: depends on `e` alone, so it travels with the record's loads - read where the
+			// position is needed it was one more link in the chain of dependent loads, behind the model table's
+			int32_t world_slot = -1;
+			if (d.slot_of_entity != nullptr && e < d.n_entities) world_slot = d.slot_of_entity[e];
 			if (sl >= 0 && d.soa.model != nullptr) { // the mirror as a structure of arrays: every field a contiguous load across the wave
 				mmb = d.mm_s;
 				in.model = d.soa.model[sl];
@@ -125,11 +129,25 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			}
 			const int32_t mdl = in.model;
 			if (mdl >= 0) {
-				const LmxKeysModel& m = d.models[mdl];
+				// The model's LOD table in ONE round trip: the four distances as one 16-byte load and the five index pairs as 8-byte loads, all
+				// unconditional and back to back (a record is 64 bytes, hipMalloc'ed table: 16-byte aligned). Read where they are used - the
+				// `else if` chain over lod_distances[k], then lod_indices[lod_idx] - they were up to five DEPENDENT loads, each behind its own
+				// s_waitcnt vmcnt(0) (seen in the ISA), in a kernel whose time is the length of its chain of dependent loads.
+				static_assert(sizeof(LmxKeysModel) == 64 && offsetof(LmxKeysModel, lod_indices) == 16, "the model record is read as 16 + 5 x 8 bytes");
+				const LmxKeysModel* mp = d.models + mdl;
+				const float4 lod_d = *reinterpret_cast<const float4*>(mp->lod_distances);
+				int2 lod_i[5];
+#pragma unroll
+				for (int k = 0; k < 5; ++k) lod_i[k] = *reinterpret_cast<const int2*>(&mp->lod_indices[k]);
+				auto lod_range = [&](uint32_t k) { // lod_indices[k] out of registers (a dynamic index would put the array into scratch)
+					int2 r = lod_i[0];
+#pragma unroll
+					for (uint32_t j = 1; j < 5; ++j) r = k == j ? lod_i[j] : r;
+					return r;
+				};
 				double px = in.pos[0], py = in.pos[1], pz = in.pos[2];
-				if (d.slot_of_entity != nullptr) { // World::getTransforms()[e].pos out of the hierarchy's SoA
-					const int32_t sl = d.slot_of_entity[e];
-					px = d.wpx[sl]; py = d.wpy[sl]; pz = d.wpz[sl];
+				if (world_slot >= 0) { // World::getTransforms()[e].pos out of the hierarchy's SoA
+					px = d.wpx[world_slot]; py = d.wpy[world_slot]; pz = d.wpz[world_slot];
 				}
 				{
 					const double cx = px - kv.cam[0], cy = py - kv.cam[1], cz = pz - kv.cam[2];
@@ -139,10 +157,10 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 				const float squared_length = (float)(rx * rx + ry * ry + rz * rz); // float(squaredLength(pos - lod_ref_point)), math.cpp:397
 				const float sd = squared_length * kv.lod_multiplier_rcp;
 				uint32_t lod_idx = 4; // Model::getLODMeshIndices, model.h:173-179
-				if (sd < m.lod_distances[0]) lod_idx = 0;
-				else if (sd < m.lod_distances[1]) lod_idx = 1;
-				else if (sd < m.lod_distances[2]) lod_idx = 2;
-				else if (sd < m.lod_distances[3]) lod_idx = 3;
+				if (sd < lod_d.x) lod_idx = 0;
+				else if (sd < lod_d.y) lod_idx = 1;
+				else if (sd < lod_d.z) lod_idx = 2;
+				else if (sd < lod_d.w) lod_idx = 3;
 				if (in.dirty) {
 					queue_dirty = true; // queueMaterialOverrideRefresh(e); continue;  (:3879-3882)
 				} else {
@@ -155,15 +173,18 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 						const float ad = fabsf(dl);
 						if (ad <= kv.time_delta) {
 							*lod_at = (float)lod_idx;
-							from0 = m.lod_indices[lod_idx].from; to0 = m.lod_indices[lod_idx].to;
+							const int2 r = lod_range(lod_idx);
+							from0 = r.x; to0 = r.y;
 						} else {
 							if (!kv.is_shadow) { lod = lod + dl / ad * kv.time_delta; *lod_at = lod; }
 							const uint32_t cur = (uint32_t)lod;
-							from0 = m.lod_indices[cur].from; to0 = m.lod_indices[cur].to;
-							if (cur < 3) { from1 = m.lod_indices[cur + 1].from; to1 = m.lod_indices[cur + 1].to; }
+							const int2 r = lod_range(cur);
+							from0 = r.x; to0 = r.y;
+							if (cur < 3) { const int2 r1 = lod_range(cur + 1); from1 = r1.x; to1 = r1.y; }
 						}
 					} else {
-						from0 = m.lod_indices[lod_idx].from; to0 = m.lod_indices[lod_idx].to;
+						const int2 r = lod_range(lod_idx);
+						from0 = r.x; to0 = r.y;
 					}
 				}
 			}
