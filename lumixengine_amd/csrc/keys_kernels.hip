@@ -64,6 +64,13 @@ constexpr int KEYS_STAGE_PAIRS = 3 * KEYS_BLOCK; // pairs (24 KiB) and records (
 // emit, the block reserves its four output ranges with two 64-bit atomics on two cache lines (returning atomics on one line retire at
 // ~90 per microsecond chip-wide: one per wave and mesh was 15x slower than this kernel's memory work), and a second walk writes at
 // lane-private positions.
+#ifndef LMX_KEYS_PROBE
+#define LMX_KEYS_PROBE 0 // timing probes (tools/build_variant.py): 1 = no group histogram, 4 = no tile reservations; results are wrong
+#endif
+#ifndef LMX_KEYS_LDS_HIST
+#define LMX_KEYS_LDS_HIST 1 // the instancer's group histogram per tile in LDS, one global atomic per (tile, key) instead of one per record
+#endif
+constexpr int KEYS_HIST_LDS = 4096; // keys (16 KiB): larger ranges keep the global atomics
 #ifndef LMX_KEYS_MIN_WAVES
 #define LMX_KEYS_MIN_WAVES 4 // waves per SIMD the register allocation aims at: 106 VGPRs, no scratch, two 8-wave blocks per CU. Round 4 (profiles/r04/keys_ab.txt, k_keys_mesh per 1.05 M visible): 6 waves (80 VGPRs, 32-44 B of scratch, three blocks) 65.5-70.5 us, 5 waves 59.1, 4 waves 60.2 - the kernel is not short of waves, spills cost it more
 #endif
@@ -73,12 +80,34 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 	__shared__ uint32_t s_base[6]; // bases of the four lists; [4], [5]: this tile's pairs / records (LMX_KEYS_STAGE_PAIRS)
 	__shared__ uint32_t s_bucket[256]; // bucket_map: an LDS read instead of one more dependent global load per mesh
 	if (threadIdx.x < 255) s_bucket[threadIdx.x] = kv.bucket_map[threadIdx.x];
+	// The instancer's group histogram of a TILE is collected in LDS (key ranges up to KEYS_HIST_LDS) and leaves as one atomic per key the
+	// tile saw, from consecutive lanes - one global atomic per instancer record, from inside the emit loop, was 10 of the kernel's 56 us
+	// (profiles/r04/keys_probes2.txt): they are executed memory-side, a few tens of thousands per microsecond over the whole chip.
+	__shared__ uint32_t s_hist[KEYS_HIST_LDS];
+	const bool lds_hist = LMX_KEYS_LDS_HIST != 0 && d.max_sort_key < (uint32_t)KEYS_HIST_LDS; // launch-uniform
+	if (lds_hist) {
+		for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) s_hist[k] = 0;
+	}
 	__syncthreads();
 	const uint32_t n = *n_visible;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t copy = blockIdx.x & (d.n_copies - 1); // this block's private row of the group counters
+	// A block walks its tiles one after the other and a tile is a chain of dependent loads (id -> record -> model -> materials) in front of
+	// three barriers: the next tile's id and slot - the chain's first link - are fetched at the top of the current tile.
+	uint32_t e_next = 0;
+	int32_t slot_next = -1;
+	{
+		const uint32_t i0 = blockIdx.x * KEYS_BLOCK + threadIdx.x;
+		if (i0 < n) { e_next = (uint32_t)ids[i0]; slot_next = slots != nullptr ? slots[i0] : -1; }
+	}
 	for (uint32_t tile = blockIdx.x * KEYS_BLOCK; tile < n; tile += gridDim.x * KEYS_BLOCK) {
 		const uint32_t i = tile + threadIdx.x;
+		const uint32_t e_now = e_next;
+		const int32_t slot_now = slot_next;
+		{
+			const uint32_t i1 = i + gridDim.x * KEYS_BLOCK;
+			if (i1 < n) { e_next = (uint32_t)ids[i1]; slot_next = slots != nullptr ? slots[i1] : -1; }
+		}
 		// ranges of mesh indices this lane emits keys for: [from0, to0] then [from1, to1]
 		int32_t from0 = 0, to0 = -1, from1 = 0, to1 = -1;
 		uint32_t e = 0, pose_stamp = 0;
@@ -90,10 +119,10 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		                                               // (sorted set, LMX_KEYS_SPLIT_STATE) in the dense per-slot array
 		const LmxMeshMaterial* mmb = d.mesh_materials; // ... and the table its material_offset points into; from the LOD ranges on: the entity's first material
 		if (i < n) {
-			e = (uint32_t)ids[i];
+			e = e_now;
 			KeysInstance in;
 			in.model = -1;
-			const int32_t sl = slots != nullptr ? slots[i] : -1;
+			const int32_t sl = slot_now;
 			slot = sl;
 			// (world binding) the entity's slot in the hierarchy: depends on `e` alone, so it travels with the record's loads - read where the
 			// position is needed it was one more link in the chain of dependent loads, behind the model table's
@@ -232,7 +261,11 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		bool push_pose = false;
 		if (any_skinned && pose_stamp != kv.frame_number) { // (the address is rebuilt here instead of living in two registers since the record was read)
 			uint32_t* frame_at = slot >= 0 ? (d.state_s != nullptr ? &d.state_s[slot].pose_frame : &d.inst_s[slot].pose_frame) : &d.inst[e].pose_frame;
-			push_pose = atomicExch(frame_at, kv.frame_number) != kv.frame_number;
+			// A plain store: the stamp this lane read at the top of the tile is still the truth - an entity is in the visible list once, and
+			// the launches of a context run one after the other on its stream (the reference needs its CAS loop because its views are
+			// concurrent jobs). As a returning atomic per skinned instance it was 6.5 of the kernel's 62 us (profiles/r04/keys_probes.txt).
+			*frame_at = kv.frame_number;
+			push_pose = true;
 		}
 		// ---- block-wide exclusive prefix of (pairs, recs) and ranks of the two flags; one atomic per pair of lists
 		uint32_t incl = n_pairs | (n_recs << 16); // <= 2 * span per lane, <= 64 * that per wave: 16 bits each
@@ -244,39 +277,47 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		const uint64_t pose_mask = __ballot(push_pose), dirty_mask = __ballot(queue_dirty);
 		if (lane == 63) { s_wave[wave][0] = incl; s_wave[wave][1] = (uint32_t)__popcll(pose_mask); s_wave[wave][2] = (uint32_t)__popcll(dirty_mask); }
 		__syncthreads();
-		if (threadIdx.x < 2) { // thread 0: {pairs, recs}, thread 1: {poses, dirty} - one 64-bit returning atomic each, on two cache lines. (Measured and NOT kept, round 4:
-			// a ticket per tile + decoupled look-back over per-tile descriptor words, agent-scope loads / stores - 81-88 us against 60-70 us with the atomics,
-			// profiles/r04/keys_ab_look_back.txt: the serial chain of cross-XCD hand-offs costs more than ~90 same-address atomics per microsecond.)
-			uint32_t lo = 0, hi = 0;
-			for (int w = 0; w < KEYS_BLOCK / 64; ++w) {
-				lo += threadIdx.x == 0 ? (s_wave[w][0] & 0xffffu) : s_wave[w][1];
-				hi += threadIdx.x == 0 ? (s_wave[w][0] >> 16) : s_wave[w][2];
-			}
-			unsigned long long base = 0;
-			if (lo | hi) base = atomicAdd(reinterpret_cast<unsigned long long*>(d.counters + (threadIdx.x == 0 ? KEYS_N_PAIRS : KEYS_N_POSES)), (unsigned long long)lo | ((unsigned long long)hi << 32));
-			s_base[2 * threadIdx.x] = (uint32_t)base;
-			s_base[2 * threadIdx.x + 1] = (uint32_t)(base >> 32);
-			if (threadIdx.x == 0) { s_base[4] = lo; s_base[5] = hi; }
+		// Every thread sums the waves' counts itself (8 LDS words): the tile's totals and this wave's offsets inside the tile need no second
+		// barrier, and they are all the LDS-staged emit below needs - it writes at positions RELATIVE to the tile's ranges.
+		uint32_t tile_pairs = 0, tile_recs = 0, tile_poses = 0, tile_dirty = 0;
+		uint32_t pair_at = (incl & 0xffffu) - n_pairs, rec_at = (incl >> 16) - n_recs; // relative to the tile's ranges (direct stores: absolute from `publish_bases` on)
+		uint32_t pose_at = rank_in(pose_mask), dirty_at = rank_in(dirty_mask);
+#pragma unroll
+		for (uint32_t w = 0; w < KEYS_BLOCK / 64; ++w) {
+			const uint32_t c0 = s_wave[w][0], c1 = s_wave[w][1], c2 = s_wave[w][2];
+			tile_pairs += c0 & 0xffffu; tile_recs += c0 >> 16; tile_poses += c1; tile_dirty += c2;
+			if (w < wave) { pair_at += c0 & 0xffffu; rec_at += c0 >> 16; pose_at += c1; dirty_at += c2; }
 		}
-		__syncthreads();
-		uint32_t pair_at = s_base[0] + (incl & 0xffffu) - n_pairs, rec_at = s_base[1] + (incl >> 16) - n_recs;
-		uint32_t pose_at = s_base[2] + rank_in(pose_mask), dirty_at = s_base[3] + rank_in(dirty_mask);
 		// a tile's (key, value) pairs and instancer records are collected in LDS at their positions inside the tile's output ranges and leave
 		// as contiguous stores (8-byte stores at every lane's own run of positions used 26 % of the sectors they touched); tiles with more
 		// output than the buffers hold keep the direct stores
 		__shared__ uint64_t s_pair_key[KEYS_STAGE_PAIRS], s_pair_value[KEYS_STAGE_PAIRS], s_rec_value[KEYS_STAGE_PAIRS];
 		__shared__ uint32_t s_rec_key[KEYS_STAGE_PAIRS];
-		const uint32_t tile_pair0 = s_base[0], tile_rec0 = s_base[1], tile_pairs = s_base[4], tile_recs = s_base[5];
 		const bool stage = tile_pairs <= (uint32_t)KEYS_STAGE_PAIRS && tile_recs <= (uint32_t)KEYS_STAGE_PAIRS; // block-uniform
-		for (uint32_t w = 0; w < wave; ++w) {
-			pair_at += s_wave[w][0] & 0xffffu;
-			rec_at += s_wave[w][0] >> 16;
-			pose_at += s_wave[w][1];
-			dirty_at += s_wave[w][2];
+		// The two reservations - thread 0: {pairs, recs}, thread 1: {poses, dirty}; one 64-bit returning atomic each, on two cache lines - are
+		// ISSUED here and their results consumed behind the emit: the ranges' bases are needed when the staged outputs leave LDS, not while
+		// they are collected, so the atomics' round trip (same-address atomics retire at ~90 per microsecond chip-wide: a block's turn in that
+		// queue is microseconds away) runs under the emit instead of in front of it, and the tile has three barriers instead of five.
+		// (Measured and NOT kept, round 4: a ticket per tile + decoupled look-back over per-tile descriptor words, agent-scope loads / stores -
+		// 81-88 us against 60-70 us with the atomics, profiles/r04/keys_ab_look_back.txt: the serial chain of cross-XCD hand-offs costs more.)
+		unsigned long long reservation = 0;
+		if (threadIdx.x < 2) {
+			const uint32_t lo = threadIdx.x == 0 ? tile_pairs : tile_poses, hi = threadIdx.x == 0 ? tile_recs : tile_dirty;
+			if ((lo | hi) && !(LMX_KEYS_PROBE & 4)) reservation = atomicAdd(reinterpret_cast<unsigned long long*>(d.counters + (threadIdx.x == 0 ? KEYS_N_PAIRS : KEYS_N_POSES)), (unsigned long long)lo | ((unsigned long long)hi << 32));
 		}
-		__syncthreads(); // s_wave / s_base are rewritten by the next tile
-		if (queue_dirty) { if (dirty_at < d.cap_list) d.dirty_list[dirty_at] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
-		if (push_pose) { if (pose_at < d.cap_list) d.poses[pose_at] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
+		auto publish_bases = [&]() { // threads 0 / 1 hand the ranges' bases to the block (the first use of the atomics' results)
+			if (threadIdx.x < 2) {
+				s_base[2 * threadIdx.x] = (uint32_t)reservation;
+				s_base[2 * threadIdx.x + 1] = (uint32_t)(reservation >> 32);
+			}
+		};
+		uint32_t tile_pair0 = 0, tile_rec0 = 0; // staged: the emit works on relative positions
+		if (!stage) { // direct stores need the bases now
+			publish_bases();
+			__syncthreads();
+			tile_pair0 = s_base[0]; tile_rec0 = s_base[1];
+			pair_at += tile_pair0; rec_at += tile_rec0;
+		}
 		// ---- emit, in lockstep over the wave so that the group histogram costs one atomic per distinct key and step
 		auto emit = [&](int32_t it, uint32_t word, uint32_t kind) {
 			bool add_inst = false;
@@ -298,8 +339,8 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 					add_inst = true; // instancer.add(mesh_sort_key, value)
 				}
 				if (stage) {
-					if (!add_inst) { s_pair_key[pair_at - tile_pair0] = key; s_pair_value[pair_at - tile_pair0] = value; }
-					else { s_rec_key[rec_at - tile_rec0] = mesh_sort_key | (copy << 24); s_rec_value[rec_at - tile_rec0] = value; }
+					if (!add_inst) { s_pair_key[pair_at] = key; s_pair_value[pair_at] = value; }
+					else { s_rec_key[rec_at] = mesh_sort_key | (copy << 24); s_rec_value[rec_at] = value; }
 				} else if (!add_inst) {
 					if (pair_at < d.cap_pairs) { d.keys[pair_at] = key; d.values[pair_at] = value; } else d.counters[KEYS_OVERFLOW] = 1;
 				} else {
@@ -314,7 +355,10 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			// with many private copies the counters are spread thinly enough for one atomic per lane; the per-wave de-duplication
 			// (one atomic per distinct key, ~15 scalar + vector instructions per key: 60 % of this kernel's time at 256 live keys)
 			// is kept for key ranges too large to privatise
-			if (d.n_copies >= 8) {
+			if (LMX_KEYS_PROBE & 1) { // (timing probe only: no group histogram - the instancer's groups come out wrong)
+			} else if (lds_hist) {
+				if (in_range) atomicAdd(&s_hist[mesh_sort_key], 1u); // ds_add_u32, nothing returned
+			} else if (d.n_copies >= 8) {
 				if (in_range) atomicAdd(d.group_count + (size_t)copy * (d.max_sort_key + 1) + mesh_sort_key, 1u);
 			} else {
 				wave_histogram(in_range, mesh_sort_key, d.group_count + (size_t)copy * (d.max_sort_key + 1));
@@ -338,8 +382,24 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			}
 			emit(it, word, kind);
 		}
+		if (stage) publish_bases();
+		__syncthreads(); // the staged outputs and the bases are in LDS
+		{
+			const uint32_t pose0 = s_base[2], dirty0 = s_base[3];
+			if (queue_dirty) { if (dirty0 + dirty_at < d.cap_list) d.dirty_list[dirty0 + dirty_at] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
+			if (push_pose) { if (pose0 + pose_at < d.cap_list) d.poses[pose0 + pose_at] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
+		}
+		if (lds_hist && tile_recs != 0) { // (behind the barrier: every lane's LDS increments are in)
+			for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) {
+				const uint32_t c = s_hist[k];
+				if (c != 0) {
+					atomicAdd(d.group_count + (size_t)copy * (d.max_sort_key + 1) + k, c);
+					s_hist[k] = 0; // ready for the next tile (the tile's last barrier is ahead)
+				}
+			}
+		}
 		if (stage) { // the tile's outputs leave in position order: consecutive lanes, consecutive 8-byte (4-byte) elements
-			__syncthreads();
+			tile_pair0 = s_base[0]; tile_rec0 = s_base[1];
 			for (uint32_t j = threadIdx.x; j < tile_pairs; j += KEYS_BLOCK) {
 				const uint32_t at = tile_pair0 + j;
 				if (at < d.cap_pairs) { d.keys[at] = s_pair_key[j]; d.values[at] = s_pair_value[j]; } else d.counters[KEYS_OVERFLOW] = 1;
@@ -348,8 +408,8 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 				const uint32_t at = tile_rec0 + j;
 				if (at < d.cap_recs) { d.rec_key[at] = s_rec_key[j]; d.rec_value[at] = s_rec_value[j]; } else d.counters[KEYS_OVERFLOW] = 1;
 			}
-			__syncthreads(); // the buffers are refilled by the next tile
 		}
+		__syncthreads(); // s_wave, s_base and the staging buffers are rewritten by the next tile
 	}
 }
 
@@ -375,26 +435,31 @@ __global__ __launch_bounds__(256) void k_keys_decal(KeysDevice d, const KeysView
 	if (push) { if (idx < d.cap_pairs) { d.keys[idx] = key; d.values[idx] = value; } else d.counters[KEYS_OVERFLOW] = 1; }
 }
 
-// one wave per key: lane c holds copy c's count; total[k] = their sum, group_count[c][k] becomes copy c's base inside group k
-// (exclusive prefix over the copies), cursors zeroed
+// one wave per key: lane c holds the counts of copies c, c + 64, ... in turn; total[k] = their sum, group_count[c][k] becomes copy c's base
+// inside group k (exclusive prefix over the copies), cursors zeroed
 __global__ __launch_bounds__(256) void k_keys_reduce_copies(KeysDevice d) {
 	const uint32_t n = d.max_sort_key + 1;
 	const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6);
 	const uint32_t lane = threadIdx.x & 63u;
 	if (k >= n) return;
-	const size_t at = (size_t)lane * n + k;
-	const uint32_t v = lane < d.n_copies ? d.group_count[at] : 0;
-	uint32_t incl = v;
+	uint32_t carry = 0; // wave-uniform: the copies before this round's
+	for (uint32_t c0 = 0; c0 < d.n_copies; c0 += 64u) {
+		const uint32_t c = c0 + lane;
+		const size_t at = (size_t)c * n + k;
+		const uint32_t v = c < d.n_copies ? d.group_count[at] : 0;
+		uint32_t incl = v;
 #pragma unroll
-	for (int o = 1; o < 64; o <<= 1) {
-		const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-		if (lane >= (uint32_t)o) incl += up;
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+			if (lane >= (uint32_t)o) incl += up;
+		}
+		if (c < d.n_copies) {
+			d.group_count[at] = carry + incl - v;
+			d.group_cursor[at] = 0;
+		}
+		carry += (uint32_t)__shfl((int)incl, 63);
 	}
-	if (lane < d.n_copies) {
-		d.group_count[at] = incl - v;
-		d.group_cursor[at] = 0;
-	}
-	if (lane == 63) d.group_total[k] = incl;
+	if (lane == 63) d.group_total[k] = carry;
 }
 
 // one block: offsets[k] = sum of total[0..k), offsets[n] = grand total; non-empty groups counted

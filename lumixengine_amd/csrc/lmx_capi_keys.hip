@@ -281,8 +281,9 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	LMX_HIP(ctx, ks.d_rec_key.reserve(std::max<size_t>(cap_recs, 1)));
 	LMX_HIP(ctx, ks.d_rec_value.reserve(std::max<size_t>(cap_recs, 1)));
 	LMX_HIP(ctx, ks.d_group_values.reserve(std::max<size_t>(cap_recs, 1)));
-	// privatised group counters: as many copies as keep the table under 256 k entries (64 for <= 4096 keys, 1 for > 128 k)
-	uint32_t n_copies = 64;
+	// privatised group counters: as many copies as keep the table under 256 k entries (256 for <= 1024 keys, 64 for <= 4096, 1 for > 128 k);
+	// a record remembers its copy in the top 8 bits of rec_key
+	uint32_t n_copies = LMX_KEYS_MAX_COPIES;
 	while (n_copies > 1 && (uint64_t)n_copies * (max_sort_key + 1) > 262144) n_copies >>= 1;
 	const size_t g = (size_t)max_sort_key + 1;
 	LMX_HIP(ctx, ks.d_groups.reserve(2 * n_copies * g + g + g + 1));

@@ -242,6 +242,9 @@ static_assert(sizeof(KeysInstance) == 64, "one record per 64-byte sector");
 struct KeysSlotState { float lod; uint32_t pose_frame; };
 // (LMX_KEYS_OPT_SPLIT_STATE = 2, the default since round 4: createSortKeys 138 -> 129 us on the round-3 driver box) the slot-ordered mirror as a structure of arrays: the 42 bytes of a record the key kernel reads,
 // one dense array per field, so that a wave's load of a field is one contiguous run instead of 64 pieces at a 64-byte stride
+#ifndef LMX_KEYS_MAX_COPIES
+#define LMX_KEYS_MAX_COPIES 256 // copies of the instancer's per-key counters (power of two, <= 256: 8 bits of rec_key)
+#endif
 struct KeysSoA { double *px, *py, *pz; int32_t* model; uint32_t* material_offset; uint16_t* flags_dirty; /* flags | dirty << 8 */ };
 #ifndef LMX_KEYS_SPLIT_STATE_DEFAULT
 #define LMX_KEYS_SPLIT_STATE_DEFAULT 2 // initial value of lmx_keys_set_option(LMX_KEYS_OPT_SPLIT_STATE)
@@ -276,8 +279,8 @@ struct KeysDevice {
 	uint32_t max_sort_key;
 	// auto-instancer groups. The per-key counters are PRIVATISED: copy c (= block index mod n_copies) has its own count / cursor
 	// row, so the atomics of a scene with few distinct mesh sort keys (all of them on a handful of cache lines) spread over
-	// n_copies times as many lines. A record remembers its copy in bits 24..29 of rec_key.
-	uint32_t n_copies;         // power of two, <= 64
+	// n_copies times as many lines. A record remembers its copy in bits 24..31 of rec_key.
+	uint32_t n_copies;         // power of two, <= LMX_KEYS_MAX_COPIES
 	uint32_t *group_count;     // [n_copies][max_sort_key + 1]: per-copy sizes, turned into per-copy bases by k_keys_offsets
 	uint32_t *group_cursor;    // [n_copies][max_sort_key + 1]
 	uint32_t *group_total;     // [max_sort_key + 1]

@@ -180,7 +180,7 @@ def skinned_mesh_character(n_verts: int, n_bones: int = 52, seed: int = 6, run: 
     return verts, skin
 
 
-def keys_scene(n_entities: int, types: np.ndarray, seed: int = 11, n_models: int = 6, max_sort_key: int = 63):
+def keys_scene(n_entities: int, types: np.ndarray, seed: int = 11, n_models: int = 6, max_sort_key: int = 63, meshes_per_lod=(1, 4), moved_fraction: float = 0.2):
     """Model-instance / material tables for createSortKeys over `n_entities` entities whose renderable types are `types`:
     models with 1-4 LODs of 1-3 meshes (some skinned), per-entity material spans, LOD state in [0, 4], MOVED / dirty flags.
     A mesh sort key identifies (mesh, material), so every key maps to one layer (pipeline.cpp:3958-3968 relies on it)."""
@@ -196,7 +196,7 @@ def keys_scene(n_entities: int, types: np.ndarray, seed: int = 11, n_models: int
         first = len(mesh_types)
         k = 0
         for lod in range(n_lods):
-            c = int(rng.integers(1, 4))
+            c = int(rng.integers(meshes_per_lod[0], meshes_per_lod[1]))
             models["lod_indices"][m][lod] = (k, k + c - 1)
             models["lod_distances"][m][lod] = dist[lod]
             k += c
@@ -214,7 +214,7 @@ def keys_scene(n_entities: int, types: np.ndarray, seed: int = 11, n_models: int
     lod = rng.integers(0, 5, size=n_entities).astype(np.float32)
     frac = rng.random(n_entities) < 0.3
     lod = np.where(frac, np.minimum(lod + rng.random(n_entities).astype(np.float32), np.float32(4.0)), lod).astype(np.float32)
-    flags = (rng.random(n_entities) < 0.2).astype(np.uint8) * 8 | 6  # MOVED | VALID | ENABLED
+    flags = (rng.random(n_entities) < moved_fraction).astype(np.uint8) * 8 | 6  # MOVED | VALID | ENABLED
     dirty = (rng.random(n_entities) < 0.05).astype(np.uint8)
     pose_frame = np.where(rng.random(n_entities) < 0.5, 7, 6).astype(np.uint32)  # half already processed in frame 7
     decal_key = rng.integers(0, 1 << 24, size=n_entities).astype(np.uint32)

@@ -245,6 +245,50 @@ def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("moved_fraction,meshes", [(0.9, (6, 10)), (0.0, (12, 16))])
+def test_gpu_sort_keys_tiles_beyond_the_staging_buffers(gpu_ctx, live_oracle, moved_fraction, meshes):
+    """Models with 6-9 meshes per LOD: a 512-entity tile of k_keys_mesh emits more pairs (most instances MOVED) or more instancer
+    records (none MOVED) than its LDS staging holds (3 x 512) and more meshes per entity than it keeps in registers, so the kernel's
+    other path runs - bases published BEFORE the emit, direct stores, materials read again - next to staged tiles (the list's tail)."""
+    base = scenes.cull_scene(20_000, 1500.0, seed=33, big_fraction=0.0)
+    n = len(base["entity"])
+    types = np.zeros(n, np.uint8)
+    pos = base["pos"]
+    sc = scenes.keys_scene(n, types, seed=47, meshes_per_lod=meshes, moved_fraction=moved_fraction)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(base["entity"], types, pos, base["radius"])
+    fr = api.viewport_frustum(pos=(0, 0, 0), far=3000.0)
+    sk = api.SortKeys(gpu_ctx)
+    sk.setModels(sc["models"], sc["mesh_types"])
+    sk.setInstances(sc["model"], sc["material_offset"], sc["mesh_materials"], sc["lod"], sc["flags"], sc["dirty"], sc["pose_frame"])
+    sk.setDecals(n, sc["decal_key"], sc["decal_layer"], sc["curve_key"], sc["curve_layer"])
+    sk.setPositions(pos)
+    lod, pose_frame = sc["lod"], sc["pose_frame"]
+    for frame in range(2):
+        view = dict(VIEWS[0])
+        view["frame_number"] += frame
+        kv = api.keys_view(layer_to_bucket=sc["layer_to_bucket"], bucket_depth_sorted=sc["bucket_depth_sorted"], **view)
+        res = cs.cull(fr)
+        ids = res.ids(0, 0)
+        assert len(ids) > 2000
+        sk.run(kv, sc["max_sort_key"])
+        cnt = sk.counts()
+        assert cnt["overflow"] == 0
+        empty = np.zeros(0, np.int32)
+        want = live_oracle.create_sort_keys(kv, sc["max_sort_key"], ids, empty, empty, sc, pos, lod=lod, pose_frame=pose_frame)
+        assert max(len(want["keys"]), len(want["group_values"])) > 3 * len(ids), "the scene does not overflow a tile's staging"
+        keys, values = sk.readPairs()
+        offsets, gvalues = sk.readInstancer()
+        got = canon(keys, values, offsets, gvalues, sk.readPoses(), sk.readDirty())
+        exp = canon(want["keys"], want["values"], want["group_offsets"], want["group_values"], want["poses"], want["dirty"])
+        for k in ("pairs", "groups", "poses", "dirty"):
+            assert got[k] == exp[k], f"frame {frame}: {k}"
+        lod, pose_frame = want["lod"], want["pose_frame"]
+        glod, gframe = sk.readState()
+        assert H.bits_equal(glod, lod) and H.bits_equal(gframe, pose_frame)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("slot_order", [1, 0, 2, 3])
 def test_gpu_sort_keys_slot_order_under_updates(gpu_ctx, oracle_port, slot_order):
     """LMX_KEYS_OPT_SLOT_ORDER: the instance tables mirrored in the order of the culling system's sorted set. ModelInstance::lod and
