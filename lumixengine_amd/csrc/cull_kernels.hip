@@ -219,6 +219,9 @@ static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustu
 // F == 1: the single-frustum kernel (the common case: one launch per view). F == 0: n_frusta (2..8) is a runtime value and every
 // per-frustum loop is a real loop, so registers do not scale with the number of frusta (8 unrolled copies needed 172 VGPRs and
 // 600 spilled SGPRs); FS is the stride of a chunk's visibility bits.
+#ifndef LMX_CULL8_PROBE
+#define LMX_CULL8_PROBE 0     // timing probes of k_cull_tile<F = 0> (tools/build_variant.py; results wrong): 1 = tile-level tests only, 2 = no cell classification, 4 = no sphere tests
+#endif
 #ifndef LMX_CULL8_SHAPE
 #define LMX_CULL8_SHAPE 0     // block shape of the 5..8-frusta kernel over 1024-sphere tiles: 0 = 4 waves x 4 chunks, 1 = 8 waves x 2 chunks
 #endif
@@ -305,6 +308,15 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 		}
 	}
 	if (!any_live) return;
+	if constexpr (F != 1) { if (LMX_CULL8_PROBE & 1) return; } // (timing probe: the tile-level tests alone)
+	// (several frusta) the class word of a cell: CellClass of frustum f in bits 2f, 2f + 1. tile_word = what the tile-level test settled.
+	uint32_t tile_word = 0;
+	uint32_t* s_word = reinterpret_cast<uint32_t*>(s_info + (F != 1 ? (size_t)nf * a.cell_cap : 0)); // [cell_cap], behind the records
+	if constexpr (F != 1) {
+		static_assert(TILE_ACCEPT < 4 && CELL_ACCEPT == 1, "a settled frustum contributes CELL_ACCEPT or nothing");
+#pragma unroll 1
+		for (int f = 0; f < nf; ++f) tile_word |= (((st_bits >> (2 * f)) & 3u) == TILE_ACCEPT ? (uint32_t)CELL_ACCEPT : 0u) << (2 * f);
+	}
 
 	uint32_t first_cell = 0;
 	if (any_mixed) {
@@ -312,7 +324,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 		first_cell = g_tile_tab[2 * tile_index];
 		const uint32_t n_cells = g_tile_tab[2 * tile_index + 1];
 		const CellKey* keys = g_tile_cells + (size_t)tile_index * a.cell_cap;
-		auto classify = [&](uint32_t t, int f, const CellKey key) {
+		auto classify = [&](uint32_t t, int f, const CellKey key) -> uint32_t {
 			const bool dead = (key.meta & CELL_DEAD) != 0;
 			const bool big = (key.meta & 0x100u) != 0;
 			CellInfo ci;
@@ -330,6 +342,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 				}
 			}
 			s_info[f * a.cell_cap + t] = ci;
+			return ci.cls;
 		};
 		if constexpr (F == 1) {
 			for (uint32_t t = threadIdx.x; t < a.cell_cap; t += THREADS) {
@@ -343,15 +356,22 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			// 16 half-empty wave iterations per tile: on the 10 M all-test scene (one cell per ~10 spheres) the classification issued more
 			// instructions than the 8 x 10 M sphere tests (72.6 M VALU wave-instructions a launch, 35 M of them the tests: profiles/r04/cull8_counters).
 			// Frusta whose tile verdict is not MIXED need no per-cell work (phase B reads their verdict from st_bits).
+			// The classes of a cell under ALL frusta are also packed into one word (2 bits a frustum; a frustum the tile-level test settled
+			// contributes its verdict): phase B learns what a chunk needs from ONE LDS read per chunk instead of one per (chunk, frustum) - a
+			// chain of 32 dependent LDS round trips per wave in front of its loads (profiles/r04/cull8_probes.txt: 96 of the launch's 201 us
+			// were neither classification nor sphere tests).
 			for (uint32_t t = threadIdx.x; t < n_cells; t += THREADS) {
 				const uint4 raw = reinterpret_cast<const uint4*>(keys)[t]; // ONE 16-byte load (ix, iy, iz, meta), not meta -> branch -> the rest
 				CellKey key;
 				key.ix = (int32_t)raw.x; key.iy = (int32_t)raw.y; key.iz = (int32_t)raw.z; key.meta = raw.w;
+				uint32_t word = tile_word;
 #pragma unroll 1
 				for (int f = 0; f < nf; ++f) {
 					if (((st_bits >> (2 * f)) & 3u) != TILE_MIXED) continue; // wave-uniform
-					classify(t, f, key);
+					if (LMX_CULL8_PROBE & 2) { s_info[f * a.cell_cap + t] = CellInfo{{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, CELL_TEST, 7u}; word |= (uint32_t)CELL_TEST << (2 * f); continue; } // (timing probe: no classification)
+					word |= classify(t, f, key) << (2 * f);
 				}
+				s_word[t] = word;
 			}
 		}
 		if constexpr (F != 1) {
@@ -430,6 +450,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 	for (int g = 0; g < CHW; g += GRP) {
 		__builtin_amdgcn_sched_barrier(0); // keep the groups' loads from being hoisted over each other (register peak)
 		uint32_t local[GRP];
+		uint32_t cls_word[F != 1 ? GRP : 1]; // (several frusta) the lane's cell under every frustum
 		bool need_id[GRP], need_sphere[GRP];
 #pragma unroll
 		for (int i = 0; i < GRP; ++i) {
@@ -438,22 +459,18 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			if (any_mixed) {
 				const ChunkHdr h = g_hdr[chunk0 + g + i]; // wave-uniform: one 16-byte scalar load
 				local[i] = h.cell + mbcnt64(h.flags >> 1) - first_cell; // cell boundaries at positions 1..lane: two v_mbcnt on a wave-uniform mask
-#pragma unroll 1
-				for (int f = 0; f < nf; ++f) {
-					if constexpr (F != 1) { // frusta the tile-level test settled carry no per-cell records
-						const uint32_t st = (st_bits >> (2 * f)) & 3u;
-						if (st == TILE_REJECT) continue;
-						if (st == TILE_ACCEPT) {
-							lane_live = true;
-							continue;
-						}
-					}
-					const uint32_t cls = s_info[f * a.cell_cap + local[i]].cls;
-					lane_live |= cls != CELL_REJECT;
-					lane_test |= cls == CELL_TEST;
+				if constexpr (F != 1) {
+					cls_word[i] = s_word[local[i]];
+					lane_live = cls_word[i] != 0;
+					lane_test = (cls_word[i] & 0xaaaau) != 0; // CELL_TEST = 2: the odd bits
+				} else {
+					const uint32_t cls = s_info[local[i]].cls;
+					lane_live = cls != CELL_REJECT;
+					lane_test = cls == CELL_TEST;
 				}
 			} else {
 				lane_live = true; // no frustum is MIXED and at least one is ACCEPT
+				if constexpr (F != 1) cls_word[i] = tile_word;
 			}
 			need_id[i] = __ballot(lane_live) != 0;     // wave-uniform
 			need_sphere[i] = __ballot(lane_test) != 0; // wave-uniform
@@ -503,6 +520,9 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			for (int i = 0; i < GRP; ++i) {
 				if (!need_id[i]) id[g + i] = -1; // (wave-uniform select behind the loads)
 			}
+			uint32_t word_or = 0; // the lane's classes over the group's chunks
+#pragma unroll
+			for (int i = 0; i < GRP; ++i) word_or |= cls_word[i];
 			// Several frusta over the same spheres (the frame's shadow cascades, BASELINE config 5). Rounds 2 / 3 ran the single-frustum body
 			// per (chunk, frustum): class from LDS -> wait -> branch -> frustum normals from the kernarg segment + distances from LDS ->
 			// wait -> test, i.e. two serialized waits and an 18-dword scalar load per 64 spheres and frustum - 224 us for 10 M spheres
@@ -514,12 +534,23 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			for (int f = 0; f < nf; ++f) {
 				const uint32_t st = (st_bits >> (2 * f)) & 3u;
 				if (st == TILE_REJECT) continue; // nothing of this tile is visible in frustum f
+				if (LMX_CULL8_PROBE & 4) continue; // (timing probe: no sphere tests)
 				const bool mixed = any_mixed && st == TILE_MIXED; // wave-uniform
+				// what this wave's chunks hold for frustum f, from the class words (wave-uniform): nothing at all -> next frustum; the chunks with
+				// a lane in a CELL_TEST cell (bit i) -> only those are tested, only for them the cell records are read
+				if (__ballot(((word_or >> (2 * f)) & 3u) != 0) == 0) continue;
+				uint32_t test_chunks = 0;
+				if (mixed) {
+#pragma unroll
+					for (int i = 0; i < GRP; ++i) {
+						if (need_sphere[i] && __ballot(((cls_word[i] >> (2 * f)) & 3u) == CELL_TEST) != 0) test_chunks |= 1u << i;
+					}
+				}
 				// the frustum's plane normals out of LDS (phase 0 put them there), every lane the same address: a broadcast read. (From the
 				// kernarg segment they are scalar loads that share lgkmcnt with the LDS reads below and return out of order: the compiler
 				// waited for the one before it issued the other.)
 				float4 nq[5]; // nx[0..5] ny[0..5] nz[0..5] + 2 pad
-				if (mixed) {
+				if (test_chunks != 0) {
 #pragma unroll
 					for (int k = 0; k < 5; ++k) nq[k] = reinterpret_cast<const float4*>(s_nrm[f])[k];
 				}
@@ -527,43 +558,44 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 				const uint32_t one = 1u << (10 * (f % 3));
 				uint32_t add_f = 0;
 #pragma unroll
-				for (int h = 0; h < GRP; h += 2) { // two chunks' cell records in flight at a time (16 VGPRs)
-					CellInfo ci[2];
-					if (mixed) {
+				for (int h = 0; h < GRP; h += 2) { // two chunks' cell records in flight at a time
+					float dq[2][8]; // d[0..5] of the lane's cell (+ the record's two other words)
+					if ((test_chunks >> h) & 3u) {
 #pragma unroll
-						for (int j = 0; j < 2; ++j) ci[j] = s_info[f * a.cell_cap + local[h + j]];
+						for (int j = 0; j < 2; ++j) {
+							const float4* rec = reinterpret_cast<const float4*>(&s_info[f * a.cell_cap + local[h + j]]);
+							const float4 lo = rec[0], hi = rec[1];
+							dq[j][0] = lo.x; dq[j][1] = lo.y; dq[j][2] = lo.z; dq[j][3] = lo.w; dq[j][4] = hi.x; dq[j][5] = hi.y;
+						}
 					}
 #pragma unroll
 					for (int j = 0; j < 2; ++j) {
 						const int i = h + j;
 						if (!need_id[i]) continue; // wave-uniform
-						uint32_t vis = st == TILE_ACCEPT ? 1u : 0u;
-						if (mixed) {
-							const uint32_t cls = ci[j].cls;
-							uint32_t culled = 0;
-							if (need_sphere[i]) { // wave-uniform: some lane of the chunk is in a CELL_TEST cell of some frustum
-								// doCulling (culling_system.cpp:283-306), the operations of sphere_visible_d_pk: t = ((x*nx + y*ny) + z*nz) + d, t + r < 0 culls
-								// (the {c, c} operands as shuffles of the loaded register pairs: the broadcast folds into op_sel of v_pk_*_f32 - as explicit
-								// pairs they were 8 instead of 4 VGPRs per chunk and six v_mov each)
-								// (the empty asm keeps the shuffles inside the frustum loop: hoisted, they become the explicit pairs again)
+						const uint32_t cls = (cls_word[i] >> (2 * f)) & 3u; // (a frustum the tile test accepted: CELL_ACCEPT from tile_word)
+						uint32_t culled = 0;
+						if ((test_chunks >> i) & 1u) { // wave-uniform: some lane of the chunk is in a CELL_TEST cell of THIS frustum
+							// doCulling (culling_system.cpp:283-306), the operations of sphere_visible_d_pk: t = ((x*nx + y*ny) + z*nz) + d, t + r < 0 culls
+							// (the {c, c} operands as shuffles of the loaded register pairs: the broadcast folds into op_sel of v_pk_*_f32 - as explicit
+							// pairs they were 8 instead of 4 VGPRs per chunk and six v_mov each; the empty asm keeps the shuffles inside the frustum
+							// loop: hoisted, they become the explicit pairs again)
 							asm volatile("" : "+v"(spv[i]));
 							const v2f xy = __builtin_shufflevector(spv[i], spv[i], 0, 1), zw = __builtin_shufflevector(spv[i], spv[i], 2, 3);
-								const v2f x2 = __builtin_shufflevector(xy, xy, 0, 0), y2 = __builtin_shufflevector(xy, xy, 1, 1);
-								const v2f z2 = __builtin_shufflevector(zw, zw, 0, 0), r2 = __builtin_shufflevector(zw, zw, 1, 1);
+							const v2f x2 = __builtin_shufflevector(xy, xy, 0, 0), y2 = __builtin_shufflevector(xy, xy, 1, 1);
+							const v2f z2 = __builtin_shufflevector(zw, zw, 0, 0), r2 = __builtin_shufflevector(zw, zw, 1, 1);
 #pragma unroll
-								for (int k = 0; k < 6; k += 2) {
-									const v2f n_x = {nrm[k], nrm[k + 1]}, n_y = {nrm[6 + k], nrm[7 + k]}, n_z = {nrm[12 + k], nrm[13 + k]}, dd = {ci[j].d[k], ci[j].d[k + 1]};
-									v2f t = x2 * n_x;
-									t = t + y2 * n_y;
-									t = t + z2 * n_z;
-									t = t + dd;
-									t = t + r2;
-									culled |= (t.x < 0 ? 1u : 0u) | (t.y < 0 ? 1u : 0u); // (no short circuit: straight-line code)
-								}
+							for (int k = 0; k < 6; k += 2) {
+								const v2f n_x = {nrm[k], nrm[k + 1]}, n_y = {nrm[6 + k], nrm[7 + k]}, n_z = {nrm[12 + k], nrm[13 + k]}, dd = {dq[j][k], dq[j][k + 1]};
+								v2f t = x2 * n_x;
+								t = t + y2 * n_y;
+								t = t + z2 * n_z;
+								t = t + dd;
+								t = t + r2;
+								culled |= (t.x < 0 ? 1u : 0u) | (t.y < 0 ? 1u : 0u); // (no short circuit: straight-line code)
 							}
-							static_assert(CELL_REJECT == 0 && CELL_ACCEPT == 1 && CELL_TEST == 2, "a class that is not CELL_TEST is its own verdict");
-							vis = cls == CELL_TEST ? culled ^ 1u : cls;
 						}
+						static_assert(CELL_REJECT == 0 && CELL_ACCEPT == 1 && CELL_TEST == 2, "a class that is not CELL_TEST is its own verdict");
+						uint32_t vis = cls == CELL_TEST ? culled ^ 1u : cls;
 						vis &= id[g + i] >= 0 ? 1u : 0u;
 						vis_bits |= vis << ((g + i) * FS + f);
 						add_f += vis;
@@ -911,7 +943,7 @@ hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, ui
 
 } // namespace
 
-size_t cull_tile_lds_bytes(int n_frusta, uint32_t cell_cap) { return (size_t)n_frusta * cell_cap * sizeof(CellInfo); }
+size_t cull_tile_lds_bytes(int n_frusta, uint32_t cell_cap) { return (size_t)n_frusta * cell_cap * sizeof(CellInfo) + (n_frusta > 1 ? (size_t)cell_cap * sizeof(uint32_t) : 0); } // (several frusta: + the cells' class words)
 
 uint32_t cull_tile_size(int n_frusta, int variant) {
 	if (n_frusta <= 1) return (variant == 0 || variant == 5) ? 4096u : (variant == 3 ? 1024u : 2048u);

@@ -15,7 +15,7 @@ for name in ("all_test", "sparse_mixed"):
         sc["radius"] = scenes.all_test_radii(N)
     cs = api.CullingSystem(ctx)
     cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
-    for width in (1, 4, 8):
+    for width in [int(w) for w in os.environ.get("LMX_CULL8_WIDTHS", "1,4,8").split(",")]:
         cs.setPassWidth(width)
         for _ in range(5):
             cs.cull(fr8)
