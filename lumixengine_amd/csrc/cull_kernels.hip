@@ -220,7 +220,7 @@ static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustu
 // per-frustum loop is a real loop, so registers do not scale with the number of frusta (8 unrolled copies needed 172 VGPRs and
 // 600 spilled SGPRs); FS is the stride of a chunk's visibility bits.
 #ifndef LMX_CULL8_PROBE
-#define LMX_CULL8_PROBE 0     // timing probes of k_cull_tile<F = 0> (tools/build_variant.py; results wrong): 1 = tile-level tests only, 2 = no cell classification, 4 = no sphere tests
+#define LMX_CULL8_PROBE 0     // timing probes of k_cull_tile<F = 0> (tools/build_variant.py; results wrong): 1 = tile-level tests only, 2 = no cell classification, 4 = no sphere tests, 8 = spheres / ids not fetched, 16 = nothing written
 #endif
 #ifndef LMX_CULL8_SHAPE
 #define LMX_CULL8_SHAPE 0     // block shape of the 5..8-frusta kernel over 1024-sphere tiles: 0 = 4 waves x 4 chunks, 1 = 8 waves x 2 chunks
@@ -311,7 +311,10 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 	if constexpr (F != 1) { if (LMX_CULL8_PROBE & 1) return; } // (timing probe: the tile-level tests alone)
 	// (several frusta) the class word of a cell: CellClass of frustum f in bits 2f, 2f + 1. tile_word = what the tile-level test settled.
 	uint32_t tile_word = 0;
-	uint32_t* s_word = reinterpret_cast<uint32_t*>(s_info + (F != 1 ? (size_t)nf * a.cell_cap : 0)); // [cell_cap], behind the records
+	// (several frusta) a cell's record under a frustum is its six plane distances, 24 bytes - the class lives in the word: 25 % less LDS per
+	// block than the 32-byte CellInfo, and LDS is what bounds the resident blocks of this kernel (8 frusta x ~140 cells per tile)
+	v2f* s_d2 = reinterpret_cast<v2f*>(s_info);                                                  // [n_frusta * cell_cap][3]
+	uint32_t* s_word = reinterpret_cast<uint32_t*>(s_d2 + (F != 1 ? (size_t)nf * a.cell_cap * 3 : 0)); // [cell_cap], behind the records
 	if constexpr (F != 1) {
 		static_assert(TILE_ACCEPT < 4 && CELL_ACCEPT == 1, "a settled frustum contributes CELL_ACCEPT or nothing");
 #pragma unroll 1
@@ -341,7 +344,12 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 					if constexpr (PLANE_SKIP) ci.pairs = relevant_plane_pairs(frp[f], IV3{key.ix, key.iy, key.iz}, ci.d);
 				}
 			}
-			s_info[f * a.cell_cap + t] = ci;
+			if constexpr (F != 1) {
+				v2f* rec = s_d2 + (size_t)(f * a.cell_cap + t) * 3;
+				rec[0] = v2f{ci.d[0], ci.d[1]}; rec[1] = v2f{ci.d[2], ci.d[3]}; rec[2] = v2f{ci.d[4], ci.d[5]};
+			} else {
+				s_info[f * a.cell_cap + t] = ci;
+			}
 			return ci.cls;
 		};
 		if constexpr (F == 1) {
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 #pragma unroll 1
 				for (int f = 0; f < nf; ++f) {
 					if (((st_bits >> (2 * f)) & 3u) != TILE_MIXED) continue; // wave-uniform
-					if (LMX_CULL8_PROBE & 2) { s_info[f * a.cell_cap + t] = CellInfo{{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, CELL_TEST, 7u}; word |= (uint32_t)CELL_TEST << (2 * f); continue; } // (timing probe: no classification)
+					if (LMX_CULL8_PROBE & 2) { word |= (uint32_t)CELL_TEST << (2 * f); continue; } // (timing probe: no classification, stale distances)
 					word |= classify(t, f, key) << (2 * f);
 				}
 				s_word[t] = word;
@@ -438,7 +446,9 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 	int32_t id[CHW];
 	uint32_t vis_bits = 0; // bit i * FS + f: sphere `lane` of chunk i is visible in frustum f
 	uint32_t mine = 0;     // lane f: this wave's visible count for frustum f
-	uint32_t cnt_pack[3] = {0, 0, 0}; // (F != 1) the lane's own visible spheres per frustum, 10 bits each: frusta 0-2 | 3-5 | 6-7
+	uint32_t vis2[F != 1 ? CHW : 1]; // (F != 1) bit 2f: sphere `lane` of chunk i is visible in frustum f (the class words' spacing)
+#pragma unroll
+	for (int i = 0; i < (F != 1 ? CHW : 1); ++i) vis2[i] = 0;
 	static_assert(CHW * 64 <= 1023, "a wave's count per frustum fits 10 bits");
 	// 1-frustum kernels: the wave's visible ids (and slots) are compacted in LDS as they are found - the write-out below is then a
 	// handful of full-width stores instead of one partial-width store per chunk (156 k of them on a launch with 43 % visible)
@@ -490,6 +500,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 				// issue all their loads first). A chunk that needs nothing reads one 16-byte sphere / one id at a wave-uniform address instead
 				// (the wave's first entity: one cache line, usually the one its neighbour chunk fetches anyway) and ignores the value.
 				const uint32_t e0 = chunk0 << 6;
+				if (LMX_CULL8_PROBE & 8) { id[g + i] = (int32_t)e; sp[i] = make_float4(1.f, 2.f, 3.f, 4.f); continue; } // (timing probe: nothing fetched)
 				id[g + i] = g_ids[need_id[i] ? e : e0];
 				sp[i] = g_spheres[need_sphere[i] ? e : e0];
 				continue;
@@ -520,6 +531,9 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			for (int i = 0; i < GRP; ++i) {
 				if (!need_id[i]) id[g + i] = -1; // (wave-uniform select behind the loads)
 			}
+			uint32_t culled2[GRP]; // bit 2f: frustum f culls the lane's sphere of chunk i (read where the cell's class is CELL_TEST)
+#pragma unroll
+			for (int i = 0; i < GRP; ++i) culled2[i] = 0;
 			uint32_t word_or = 0; // the lane's classes over the group's chunks
 #pragma unroll
 			for (int i = 0; i < GRP; ++i) word_or |= cls_word[i];
@@ -555,24 +569,20 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 					for (int k = 0; k < 5; ++k) nq[k] = reinterpret_cast<const float4*>(s_nrm[f])[k];
 				}
 				const float* nrm = reinterpret_cast<const float*>(nq);
-				const uint32_t one = 1u << (10 * (f % 3));
-				uint32_t add_f = 0;
 #pragma unroll
 				for (int h = 0; h < GRP; h += 2) { // two chunks' cell records in flight at a time
-					float dq[2][8]; // d[0..5] of the lane's cell (+ the record's two other words)
+					float dq[2][6]; // d[0..5] of the lane's cell
 					if ((test_chunks >> h) & 3u) {
 #pragma unroll
 						for (int j = 0; j < 2; ++j) {
-							const float4* rec = reinterpret_cast<const float4*>(&s_info[f * a.cell_cap + local[h + j]]);
-							const float4 lo = rec[0], hi = rec[1];
-							dq[j][0] = lo.x; dq[j][1] = lo.y; dq[j][2] = lo.z; dq[j][3] = lo.w; dq[j][4] = hi.x; dq[j][5] = hi.y;
+							const v2f* rec = s_d2 + (size_t)(f * a.cell_cap + local[h + j]) * 3; // three ds_read_b64
+							const v2f d01 = rec[0], d23 = rec[1], d45 = rec[2];
+							dq[j][0] = d01.x; dq[j][1] = d01.y; dq[j][2] = d23.x; dq[j][3] = d23.y; dq[j][4] = d45.x; dq[j][5] = d45.y;
 						}
 					}
 #pragma unroll
 					for (int j = 0; j < 2; ++j) {
 						const int i = h + j;
-						if (!need_id[i]) continue; // wave-uniform
-						const uint32_t cls = (cls_word[i] >> (2 * f)) & 3u; // (a frustum the tile test accepted: CELL_ACCEPT from tile_word)
 						uint32_t culled = 0;
 						if ((test_chunks >> i) & 1u) { // wave-uniform: some lane of the chunk is in a CELL_TEST cell of THIS frustum
 							// doCulling (culling_system.cpp:283-306), the operations of sphere_visible_d_pk: t = ((x*nx + y*ny) + z*nz) + d, t + r < 0 culls
@@ -593,16 +603,20 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 								t = t + r2;
 								culled |= (t.x < 0 ? 1u : 0u) | (t.y < 0 ? 1u : 0u); // (no short circuit: straight-line code)
 							}
+							culled2[i] |= culled << (2 * f);
 						}
-						static_assert(CELL_REJECT == 0 && CELL_ACCEPT == 1 && CELL_TEST == 2, "a class that is not CELL_TEST is its own verdict");
-						uint32_t vis = cls == CELL_TEST ? culled ^ 1u : cls;
-						vis &= id[g + i] >= 0 ? 1u : 0u;
-						vis_bits |= vis << ((g + i) * FS + f);
-						add_f += vis;
 					}
 				}
-				add_f *= one;
-				if (f < 3) cnt_pack[0] += add_f; else if (f < 6) cnt_pack[1] += add_f; else cnt_pack[2] += add_f; // (f is wave-uniform)
+			}
+			// the verdicts of all frusta at once, per chunk, from the class words: visible = CELL_TEST and not culled, or CELL_ACCEPT (a frustum
+			// the tile test rejected, a cell classified CELL_REJECT: 0). Per (chunk, frustum) this was a class extract, two selects, a shift-or and
+			// a count - a quarter of the loop's instructions on a launch that is bound by their issue (profiles/r04/cull8_probe_counters.txt).
+			static_assert(CELL_REJECT == 0 && CELL_ACCEPT == 1 && CELL_TEST == 2, "bit 0 of a class: accepted, bit 1: to be tested");
+#pragma unroll
+			for (int i = 0; i < GRP; ++i) {
+				const uint32_t w = cls_word[i];
+				const uint32_t v = (((w >> 1) & ~culled2[i]) | w) & 0x5555u;
+				vis2[g + i] = id[g + i] >= 0 ? v : 0u;
 			}
 		} else {
 #pragma unroll 1
@@ -650,15 +664,15 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 		}
 	}
 	if constexpr (F != 1) {
-		// per-frustum counts of the wave: the lanes' packed counters (a lane sees at most CHW visible spheres per frustum, a wave 64 x CHW <= 1023)
-		// summed across the wave, then lane f keeps frustum f's
+		// per-frustum counts of the wave by ballots over the verdict bits (scalar population counts), lane f keeps frustum f's
+#pragma unroll 1
+		for (int f = 0; f < nf; ++f) {
+			if (((st_bits >> (2 * f)) & 3u) == TILE_REJECT) continue;
+			uint32_t c = 0;
 #pragma unroll
-		for (int k = 0; k < 3; ++k) {
-#pragma unroll
-			for (int o = 32; o > 0; o >>= 1) cnt_pack[k] += (uint32_t)__shfl_xor((int)cnt_pack[k], o);
+			for (int i = 0; i < CHW; ++i) c += (uint32_t)__popcll(__ballot(((vis2[i] >> (2 * f)) & 1u) != 0));
+			mine = lane == (uint32_t)f ? c : mine;
 		}
-		const uint32_t word = lane < 3u ? cnt_pack[0] : (lane < 6u ? cnt_pack[1] : cnt_pack[2]);
-		mine = lane < (uint32_t)MAX_FRUSTA ? (word >> (10u * (lane % 3u))) & 0x3ffu : 0u;
 	}
 
 	if constexpr (STAGE) {
@@ -676,6 +690,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 		}
 		return;
 	}
+	if constexpr (F != 1) { if (LMX_CULL8_PROBE & 16) return; } // (timing probe: nothing reserved, nothing written)
 	// C. reserve: lane f adds this wave's count for frustum f to the shard's counter (one atomic instruction for all frusta),
 	// then the ids go from registers to the reserved ranges in chunk order
 	uint32_t base_v = 0;
@@ -687,7 +702,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 		int32_t* dst = g_out_ids + (size_t)f * a.out_stride;
 #pragma unroll
 		for (int i = 0; i < CHW; ++i) {
-			const bool v = ((vis_bits >> (i * FS + f)) & 1u) != 0;
+			const bool v = F != 1 ? ((vis2[F != 1 ? i : 0] >> (2 * f)) & 1u) != 0 : ((vis_bits >> (i * FS + f)) & 1u) != 0;
 			const uint64_t mask = __ballot(v);
 			if (v) dst[run + mbcnt64(mask)] = id[i];
 			if constexpr (SLOTS) {
@@ -943,7 +958,9 @@ hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, ui
 
 } // namespace
 
-size_t cull_tile_lds_bytes(int n_frusta, uint32_t cell_cap) { return (size_t)n_frusta * cell_cap * sizeof(CellInfo) + (n_frusta > 1 ? (size_t)cell_cap * sizeof(uint32_t) : 0); } // (several frusta: + the cells' class words)
+size_t cull_tile_lds_bytes(int n_frusta, uint32_t cell_cap) { // several frusta: 24-byte records + the cells' class words
+	return n_frusta > 1 ? (size_t)n_frusta * cell_cap * 24 + (size_t)cell_cap * sizeof(uint32_t) : (size_t)cell_cap * sizeof(CellInfo);
+}
 
 uint32_t cull_tile_size(int n_frusta, int variant) {
 	if (n_frusta <= 1) return (variant == 0 || variant == 5) ? 4096u : (variant == 3 ? 1024u : 2048u);
