@@ -350,20 +350,23 @@ static int skin_build_multi_chunks(LmxContext* ctx) {
 	if (sk.multi_built == sk.multi) return LMX_OK;
 	sk.multi_chunks.clear();
 	uint64_t groups = 0;
+	auto staged = [&](const SkinState::Run& r) { return std::min(sk.inst[r.first].n_bones, sk.meshes[r.mesh].max_bone + 1); }; // bones a block stages
+	sk.multi_max_stage = 0;
 	for (const SkinState::Run& r : sk.runs) {
-		const uint32_t per = skin_multi_instances(sk.multi, sk.inst[r.first].n_bones);
+		const uint32_t per = skin_multi_instances(sk.multi, staged(r));
 		groups += (r.count + per - 1) / per;
+		sk.multi_max_stage = std::max(sk.multi_max_stage, skin_multi_lds_slots(staged(r)));
 	}
 	for (const SkinState::Run& r : sk.runs) {
 		const SkinInstance& in = sk.inst[r.first];
-		const uint32_t per = skin_multi_instances(sk.multi, in.n_bones);
+		const uint32_t per = skin_multi_instances(sk.multi, staged(r));
 		uint32_t splits = (uint32_t)std::max<uint64_t>(1, (3072 + groups - 1) / std::max<uint64_t>(groups, 1));
 		splits = std::min(splits, std::max(1u, in.n_verts / 1024u)); // a range is worth its 48 KiB palette staging from ~1000 vertices x I instances on
 		const uint32_t range = ((in.n_verts + splits - 1) / splits + 63u) & ~63u;
 		for (uint32_t f = 0; f < r.count; f += per)
 			for (uint32_t v = 0; v < in.n_verts; v += range)
 				sk.multi_chunks.push_back(SkinMultiChunk{sk.inst[r.first + f].bone_offset, in.n_bones, std::min(per, r.count - f), v, std::min(in.n_verts, v + range), in.vert_offset,
-					in.n_verts, sk.inst[r.first + f].out_offset});
+					in.n_verts, sk.inst[r.first + f].out_offset, staged(r)});
 	}
 	LMX_HIP(ctx, sk.d_multi_chunks.reserve(std::max<size_t>(sk.multi_chunks.size(), 1)));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (a launch of the previous frame may still read the old list)
@@ -393,7 +396,7 @@ int lmx_skin_run(LmxContext* ctx) {
 		const float4* vertex_palette = sk.mode == LMX_SKIN_DQS ? sk.d_dual_quats.p : sk.d_palette.p;
 		if (!sk.chunks.empty() && sk.multi) { // runs of instances that share a mesh, several instances per block (every mode)
 			if (int rc = skin_build_multi_chunks(ctx)) return rc;
-			LMX_HIP(ctx, launch_skin_multi(ctx->stream, sk.multi, sk.d_multi_chunks.p, (uint32_t)sk.multi_chunks.size(), sk.d_mesh.p, vertex_palette, sk.d_out.p, sk.mode));
+			LMX_HIP(ctx, launch_skin_multi(ctx->stream, sk.multi, sk.d_multi_chunks.p, (uint32_t)sk.multi_chunks.size(), sk.multi_max_stage, sk.d_mesh.p, vertex_palette, sk.d_out.p, sk.mode));
 			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, sk.d_solo.p, (uint32_t)sk.solo.size(), sk.solo_max_verts, sk.d_mesh.p, vertex_palette, sk.d_out.p, sk.mode));
 		} else if (sk.chunks.empty() || sk.mode == LMX_SKIN_DQS) { // (DQS: k_skin_shared's resident records leave too few registers for the dual-quaternion blend)
 			LMX_HIP(ctx, launch_skin_vertices(ctx->stream, sk.d_inst.p, nullptr, n, sk.max_verts, sk.d_mesh.p, vertex_palette,

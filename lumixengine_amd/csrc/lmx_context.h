@@ -337,6 +337,7 @@ struct SkinState {
 	DevBuf<SkinMultiChunk> d_multi_chunks;
 	uint32_t multi = 2;                // LMX_SKIN_OPT_INSTANCES_PER_BLOCK (0: k_skin_shared). 2: a store instruction writes two runs of 32 vertices = 384 bytes = three whole 128-byte lines each; 4 (runs of 192 bytes) measured 3.3-3.5 against 2.4-2.7 ms per 1e9 vertices, 8 / 16 7 / 13 ms (profiles/r04/skin_ab_*.txt)
 	uint32_t multi_built = 0;          // the value multi_chunks were cut for (0: stale)
+	uint32_t multi_max_stage = 0;      // the largest staging of a chunk in float4 slots (skin_multi_lds_slots): sizes the launch's LDS
 	std::vector<uint32_t> solo;        // instances skinned by k_skin_vertices (empty + no chunks = all of them)
 	DevBuf<SkinChunk> d_chunks;
 	DevBuf<uint32_t> d_solo;

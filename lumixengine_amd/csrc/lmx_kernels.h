@@ -321,9 +321,10 @@ hipError_t launch_skin_shared(hipStream_t s, const SkinInstance* inst, const Ski
 // carries everything the block needs (ONE dependent load at block start, not chunk -> instance -> palette): `count` consecutive
 // instances of one model and one mesh - their palettes start at bone `bone_offset` (n_bones each), their outputs at vertex `out_offset`
 // (n_verts each) - and the vertex range [v_begin, v_end) of the mesh whose first record in `mesh` (global bone indices) is rec_offset.
-struct SkinMultiChunk { uint32_t bone_offset, n_bones, count, v_begin, v_end, rec_offset, n_verts, out_offset; };
+struct SkinMultiChunk { uint32_t bone_offset, n_bones, count, v_begin, v_end, rec_offset, n_verts, out_offset, n_stage /* bones staged in LDS: the mesh's largest bone index + 1 */; };
 uint32_t skin_multi_instances(uint32_t per_block, uint32_t n_bones);
-hipError_t launch_skin_multi(hipStream_t s, uint32_t per_block, const SkinMultiChunk* chunks, uint32_t n_chunks, const float4* mesh, const float4* palette, float* out, int mode);
+uint32_t skin_multi_lds_slots(uint32_t n_stage);
+hipError_t launch_skin_multi(hipStream_t s, uint32_t per_block, const SkinMultiChunk* chunks, uint32_t n_chunks, uint32_t lds_slots /* largest skin_multi_lds_slots(n_stage) of the chunks */, const float4* mesh, const float4* palette, float* out, int mode);
 constexpr uint32_t SKIN_SHARED_TILE_VERTS = 5120; // k_skin_shared: 1024 lanes x 5 vertex records
 
 } // namespace lmx

@@ -785,7 +785,7 @@ __device__ __forceinline__ void skin_multi_tile(const SkinMultiChunk& ch, float4
 	__builtin_amdgcn_sched_barrier(0); // (issued here, ahead of the palette's loads and waits; an asm use of the records would WAIT for them here)
 	{
 		const float4* pal = palette + (size_t)ch.bone_offset * ROWS;
-		const uint32_t items = ch.n_bones * ROWS * COLS;
+		const uint32_t items = ch.n_stage * ROWS * COLS; // only the bones the mesh references are staged (n_stage = its largest bone index + 1)
 		// consecutive lanes fill consecutive columns of one row: conflict-free ds_write_b128; the COLS / I lanes of one instance fetch the same
 		// 16 bytes. All of a lane's loads go out before the first is written (items past the palette's end re-read its first row).
 		constexpr uint32_t PER_LANE = SKIN_LDS_SLOTS / THREADS;
@@ -850,7 +850,9 @@ constexpr int MULTI_THREADS = LMX_MULTI_THREADS;
 template <int I, int MODE>
 __global__ __launch_bounds__(MULTI_THREADS, MULTI_THREADS == 1024 ? 8 : SKIN_WAVES_PER_SIMD) void k_skin_multi(const SkinMultiChunk* __restrict__ chunks, uint32_t n_chunks,
 	const float4* __restrict__ mesh, const float4* __restrict__ palette, float* __restrict__ out) {
-	__shared__ float4 s_rows[SKIN_LDS_SLOTS];
+	// sized by the launch for the largest staging of its chunks (<= SKIN_LDS_SLOTS): a 52-bone character stages 39 KiB, not 48, and a CU
+	// holds four blocks of it instead of three
+	LMX_DYNAMIC_LDS(float4, s_rows);
 	const SkinMultiChunk ch = chunks[blockIdx.x];
 	uint32_t sink0 = 0, sink1 = 0;
 	if (LMX_MULTI_PREFETCH != 0) {
@@ -876,8 +878,8 @@ __global__ __launch_bounds__(MULTI_THREADS, MULTI_THREADS == 1024 ? 8 : SKIN_WAV
 #endif
 		}
 	}
-	if (ch.n_bones <= 64) skin_multi_tile<16, I, MODE, LMX_MULTI_PIPE, MULTI_THREADS>(ch, s_rows, mesh, palette, out, sink0, sink1);
-	else if (ch.n_bones <= 128) skin_multi_tile<8, (I < 8 ? I : 8), MODE, LMX_MULTI_PIPE, MULTI_THREADS>(ch, s_rows, mesh, palette, out, sink0, sink1);
+	if (ch.n_stage <= 64) skin_multi_tile<16, I, MODE, LMX_MULTI_PIPE, MULTI_THREADS>(ch, s_rows, mesh, palette, out, sink0, sink1);
+	else if (ch.n_stage <= 128) skin_multi_tile<8, (I < 8 ? I : 8), MODE, LMX_MULTI_PIPE, MULTI_THREADS>(ch, s_rows, mesh, palette, out, sink0, sink1);
 	else skin_multi_tile<4, (I < 4 ? I : 4), MODE, LMX_MULTI_PIPE, MULTI_THREADS>(ch, s_rows, mesh, palette, out, sink0, sink1);
 }
 
@@ -890,22 +892,31 @@ uint32_t skin_multi_instances(uint32_t per_block, uint32_t n_bones) {
 }
 
 template <int I>
-static hipError_t launch_skin_multi_i(hipStream_t s, const SkinMultiChunk* chunks, uint32_t n_chunks, const float4* mesh, const float4* palette, float* out, int mode) {
+static hipError_t launch_skin_multi_i(hipStream_t s, const SkinMultiChunk* chunks, uint32_t n_chunks, const float4* mesh, const float4* palette, float* out, int mode, size_t lds) {
 	const dim3 grid(n_chunks), block(MULTI_THREADS);
-	if (mode == LMX_SKIN_EXACT) hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_EXACT>), grid, block, 0, s, chunks, n_chunks, mesh, palette, out);
-	else if (mode == LMX_SKIN_DQS) hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_DQS>), grid, block, 0, s, chunks, n_chunks, mesh, palette, out);
-	else hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_FUSED>), grid, block, 0, s, chunks, n_chunks, mesh, palette, out);
+	if (mode == LMX_SKIN_EXACT) hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_EXACT>), grid, block, lds, s, chunks, n_chunks, mesh, palette, out);
+	else if (mode == LMX_SKIN_DQS) hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_DQS>), grid, block, lds, s, chunks, n_chunks, mesh, palette, out);
+	else hipLaunchKernelGGL((k_skin_multi<I, LMX_SKIN_FUSED>), grid, block, lds, s, chunks, n_chunks, mesh, palette, out);
 	return hipGetLastError();
 }
 
-hipError_t launch_skin_multi(hipStream_t s, uint32_t per_block, const SkinMultiChunk* chunks, uint32_t n_chunks, const float4* mesh, const float4* palette, float* out, int mode) {
+// float4 slots of LDS a k_skin_multi block stages for a mesh that references bones [0, n_stage) (3 rows a bone; the dual-quaternion mode's 2 fit).
+// NOT monotonic in n_stage - the bank columns halve at 65 and 129 bones - so a launch is sized by the largest value over its chunks.
+uint32_t skin_multi_lds_slots(uint32_t n_stage) {
+	const uint32_t cols = n_stage <= 64 ? 16u : (n_stage <= 128 ? 8u : 4u);
+	return n_stage * 3u * cols;
+}
+
+hipError_t launch_skin_multi(hipStream_t s, uint32_t per_block, const SkinMultiChunk* chunks, uint32_t n_chunks, uint32_t slots, const float4* mesh, const float4* palette, float* out, int mode) {
 	if (!n_chunks) return hipSuccess;
+	if (slots == 0 || slots > (uint32_t)SKIN_LDS_SLOTS) return hipErrorInvalidValue;
+	const size_t lds = (size_t)slots * sizeof(float4);
 	switch (per_block) {
-	case 1: return launch_skin_multi_i<1>(s, chunks, n_chunks, mesh, palette, out, mode);
-	case 2: return launch_skin_multi_i<2>(s, chunks, n_chunks, mesh, palette, out, mode);
-	case 4: return launch_skin_multi_i<4>(s, chunks, n_chunks, mesh, palette, out, mode);
-	case 8: return launch_skin_multi_i<8>(s, chunks, n_chunks, mesh, palette, out, mode);
-	case 16: return launch_skin_multi_i<16>(s, chunks, n_chunks, mesh, palette, out, mode);
+	case 1: return launch_skin_multi_i<1>(s, chunks, n_chunks, mesh, palette, out, mode, lds);
+	case 2: return launch_skin_multi_i<2>(s, chunks, n_chunks, mesh, palette, out, mode, lds);
+	case 4: return launch_skin_multi_i<4>(s, chunks, n_chunks, mesh, palette, out, mode, lds);
+	case 8: return launch_skin_multi_i<8>(s, chunks, n_chunks, mesh, palette, out, mode, lds);
+	case 16: return launch_skin_multi_i<16>(s, chunks, n_chunks, mesh, palette, out, mode, lds);
 	default: return hipErrorInvalidValue;
 	}
 }

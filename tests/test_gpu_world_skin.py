@@ -693,11 +693,14 @@ def test_skin_shared_mesh_runs(gpu_ctx, live_oracle, exact, per_block):
     sk.setMode(exact)
     sk.setOption(api.SKIN_OPT_INSTANCES_PER_BLOCK, per_block)
     skel = [scenes.skeleton(64, seed=4), scenes.skeleton(100, seed=24), scenes.skeleton(64, seed=34)]
-    meshes = [scenes.skinned_mesh(5121, 64, seed=6), scenes.skinned_mesh(2049, 100, seed=7), scenes.skinned_mesh(700, 64, seed=8)]
+    # mesh 3 references 60 of its model's 100 bones, mesh 4 40 of 64: k_skin_multi stages only the bones a mesh references (and picks its bank
+    # columns by that number: 16 for the 100-bone model's 60), the palettes keep their models' strides
+    meshes = [scenes.skinned_mesh(5121, 64, seed=6), scenes.skinned_mesh(2049, 100, seed=7), scenes.skinned_mesh(700, 64, seed=8),
+              scenes.skinned_mesh(2300, 60, seed=9), scenes.skinned_mesh(1900, 40, seed=10)]
     models = [sk.addModel(s["parents"], s["bind"], s["first_nonroot"]) for s in skel]
     mesh_ids = [sk.addMesh(v, s) for v, s in meshes]
     # (model, mesh): a run of 9 on mesh 0 (two models with 64 bones: still one run), a single, a run of 3 on mesh 1, small meshes
-    pick = [(0, 0)] * 5 + [(2, 0)] * 4 + [(1, 1)] + [(0, 2)] * 3 + [(1, 1)] * 3 + [(0, 0)]
+    pick = [(0, 0)] * 5 + [(2, 0)] * 4 + [(1, 1)] + [(0, 2)] * 3 + [(1, 1)] * 3 + [(0, 0)] + [(1, 3)] * 5 + [(2, 4)] * 3
     sk.setInstances([models[m] for m, _ in pick], [mesh_ids[g] for _, g in pick])
     poses = [scenes.relative_poses(1, len(skel[m]["parents"]), seed=500 + i) for i, (m, _) in enumerate(pick)]
     sk.uploadPoses(np.concatenate([p[0].reshape(-1, 3) for p in poses]), np.concatenate([p[1].reshape(-1, 4) for p in poses]))

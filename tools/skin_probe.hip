@@ -93,16 +93,19 @@ int main(int argc, char** argv) {
 		for (uint32_t I : {1u, 2u, 4u})
 			for (uint32_t splits : {1u, 2u}) {
 				std::vector<SkinMultiChunk> mc;
+				const uint32_t stage_bones = argc > 6 ? (uint32_t)atoi(argv[6]) : nb; // bones staged per block (the mesh's largest bone index + 1)
 				const uint32_t range = ((nv + splits - 1) / splits + 63u) & ~63u;
 				for (uint32_t f = 0; f < n_inst; f += I)
-					for (uint32_t v = 0; v < nv; v += range) mc.push_back(SkinMultiChunk{hot_palettes ? 0u : f * nb, nb, n_inst - f < I ? n_inst - f : I, v, v + range < nv ? v + range : nv, 0u, nv, f * nv});
+					for (uint32_t v = 0; v < nv; v += range) mc.push_back(SkinMultiChunk{hot_palettes ? 0u : f * nb, nb, n_inst - f < I ? n_inst - f : I, v, v + range < nv ? v + range : nv, 0u, nv, f * nv, stage_bones});
 				SkinMultiChunk* d_mc; CK(hipMalloc(&d_mc, mc.size() * sizeof(SkinMultiChunk))); CK(hipMemcpy(d_mc, mc.data(), mc.size() * sizeof(SkinMultiChunk), hipMemcpyHostToDevice));
 				float best = 1e9f;
+				const int repeat = getenv("PROBE_REPEAT") ? atoi(getenv("PROBE_REPEAT")) : 1; // launches back to back per timed region (sustained clocks: is a long launch slower per vertex than a short one?)
 				for (int it = 0; it < 5; ++it) {
 					CK(hipEventRecord(e0));
-					CK(launch_skin_multi(0, I, d_mc, (uint32_t)mc.size(), d_mesh, d_pal, d_out, LMX_SKIN_FUSED));
+					for (int r = 0; r < repeat; ++r) CK(launch_skin_multi(0, I, d_mc, (uint32_t)mc.size(), skin_multi_lds_slots(stage_bones), d_mesh, d_pal, d_out, LMX_SKIN_FUSED));
 					CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
 					float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+					ms /= (float)repeat;
 					if (it && ms < best) best = ms;
 				}
 				printf("multi I=%2u splits=%u pipe=%d prefetch=%d (%zu blocks): %.4f ms  = %.3f ms per 1e9 verts\n", I, splits, LMX_MULTI_PIPE, LMX_MULTI_PREFETCH, mc.size(), best, best * 1e9 / ((double)n_inst * nv));
