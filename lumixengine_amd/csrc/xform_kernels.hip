@@ -106,7 +106,10 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
-__global__ __launch_bounds__(256) void k_xform_subtree(WorldDevice w, XformSubtree a) {
+#ifndef LMX_XFORM_MIN_WAVES
+#define LMX_XFORM_MIN_WAVES 4 // waves per SIMD the register allocation aims at: 4 = 108 VGPRs, 5 = 96 (five 27-KiB blocks per CU, what LDS admits), 6 spills
+#endif
+__global__ __launch_bounds__(256, LMX_XFORM_MIN_WAVES) void k_xform_subtree(WorldDevice w, XformSubtree a) {
 	__shared__ uint32_t s_count[4];
 	__shared__ uint32_t s_base;
 	// the previous and the current level's world transforms of a narrow run (<= 256 nodes per level): a node's parent comes out of LDS
