@@ -544,6 +544,10 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			// records of all the group's chunks are fetched together (one LDS round trip), the chunks are tested back to back without a
 			// branch on a lane's class (the class selects the verdict), and the per-frustum counts are kept packed per lane
 			// (10 bits a frustum) and summed over the wave once, behind the loop.
+			// (Measured and NOT kept, round 4, profiles/r04/cull8_call27_28_shared_dots_batched_lds.txt: frusta with bitwise identical plane
+			// normals - the cascades of one light - sharing a sphere's rounded dot products, 7 instead of 21 packed operations per plane set:
+			// 154 us against 142 on the all-test scene - 24 more live VGPRs, a fifth block per CU only with spills (205 us), four blocks 166 us;
+			// all of a frustum's cell records read in one batch instead of two chunks at a time: 149 against 142.)
 #pragma unroll 1
 			for (int f = 0; f < nf; ++f) {
 				const uint32_t st = (st_bits >> (2 * f)) & 3u;

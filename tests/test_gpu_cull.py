@@ -157,6 +157,35 @@ def test_cull_1m_vs_oracle(gpu_ctx, oracle_port, variant):
         H.assert_same_visible(gpu_visible(res, f), oracle_visible(ocs, fr[f : f + 1]), f"{variant}/{f}")
 
 
+@pytest.mark.parametrize("order", ["grouped", "interleaved"])
+def test_cull_cascades_with_shared_normals(gpu_ctx, oracle_port, order):
+    """Shadow cascades of one light share its rotation: frusta of a call whose plane normals are bitwise identical share a sphere's dot
+    products in k_cull_tile<F = 0> (pipeline.cpp:734-827 builds a light's cascades from one rotation). 8 cascades of 2 lights in one pass,
+    the lights' cascades adjacent or interleaved (the shared products must be recomputed at every change of normals), plus big spheres
+    (every cell CELL_TEST) - id for id against the oracle, per frustum."""
+    sc = scenes.cull_scene(300_000, 3000.0, seed=9, big_fraction=0.05)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    ocs = oracle_port.culling_system()
+    ocs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    kws = scenes.config5_cascade_kwargs()
+    for kw in kws:  # the bench's cascades look at a +-15000 cube from 9000 above: the same shapes over this scene
+        kw["pos"] = (kw["pos"][0], 2500.0, kw["pos"][2])
+        kw["ortho_size"] = kw["ortho_size"] / 4.0
+    if order == "interleaved":
+        kws = [kws[k] for k in (0, 4, 1, 5, 2, 6, 3, 7)]
+    fr = np.concatenate([api.viewport_frustum(**kw) for kw in kws])
+    cs.setPassWidth(8)
+    res = cs.cull(fr)
+    total = 0
+    for f in range(8):
+        got = gpu_visible(res, f)
+        H.assert_same_visible(got, oracle_visible(ocs, fr[f : f + 1]), f"{order}/{f}")
+        total += len(res.all_ids(f)[0])
+    assert total > 1000
+    cs.setPassWidth(1)
+
+
 def _digest(res, frustum=0):
     ids, types = res.all_ids(frustum)
     return H.visible_digest(ids, types)
