@@ -49,9 +49,13 @@ def test_smoke_entry_point_on_the_simulated_device():
     """__graft_entry__.smoke() - what the driver runs on the GPU box before the bench - executed against the kernel sources on the CPU."""
     from tests.hostsim import build as hostsim_build
 
-    env = dict(os.environ, LMX_LIB_PATH=hostsim_build.build(), LMX_HOSTSIM="1")
+    env = dict(os.environ, LMX_LIB_PATH=hostsim_build.build(), LMX_HOSTSIM="1", LMX_SMOKE_SELFTEST_HOSTSIM="1")
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "smoke OK" in r.stdout, r.stdout + r.stderr
+    # ... and without the explicit opt-in smoke() refuses a stand-in library (a hostsim or variant build can never pass for the product's)
+    env.pop("LMX_SMOKE_SELFTEST_HOSTSIM")
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "refuses" in r.stderr, r.stdout + r.stderr
 
 
 def test_traffic_model_reproduces_the_algorithmic_bytes(tmp_path):
