@@ -863,15 +863,19 @@ __global__ __launch_bounds__(FIN_THREADS) void k_cull_finalize(const uint32_t* _
 __global__ __launch_bounds__(256) void k_cull_consolidate(const int32_t* __restrict__ src, uint32_t src_stride, const uint32_t* __restrict__ win_base,
 	const uint32_t* __restrict__ counts, uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* __restrict__ shard_type,
 	const uint32_t* __restrict__ type_start, uint32_t type_start_stride, const uint32_t* __restrict__ pref, uint32_t n_shards, int32_t* __restrict__ dst,
-	uint32_t dst_stride, uint32_t dst_cap) {
+	uint32_t dst_stride, uint32_t dst_cap, const int32_t* __restrict__ src2 /* optional: a second array with the same windows (the visible ids' slots) */,
+	int32_t* __restrict__ dst2) {
 	const uint32_t s = blockIdx.x, f = blockIdx.y;
 	const uint32_t c = counts[f * cnt_frustum_stride + s * cnt_pad];
-	const int32_t* from = src + (size_t)f * src_stride + win_base[s];
+	const size_t from_at = (size_t)f * src_stride + win_base[s];
 	const uint32_t at = type_start[f * type_start_stride + shard_type[s]] + pref[f * n_shards + s];
-	int32_t* to = dst + (size_t)f * dst_stride + at;
+	const size_t to_at = (size_t)f * dst_stride + at;
 	const uint32_t room = at < dst_cap ? dst_cap - at : 0u;
 	const uint32_t n = c < room ? c : room;
-	for (uint32_t k = blockIdx.z * 256u + threadIdx.x; k < n; k += gridDim.z * 256u) to[k] = from[k];
+	for (uint32_t k = blockIdx.z * 256u + threadIdx.x; k < n; k += gridDim.z * 256u) {
+		dst[to_at + k] = src[from_at + k];
+		if (src2 != nullptr) dst2[to_at + k] = src2[from_at + k];
+	}
 }
 
 // One launch instead of finalize + consolidate for the PACKED record [MAX_TYPES counts | ids, types back to back] of ONE frustum
@@ -1067,11 +1071,11 @@ hipError_t launch_cull_finalize(hipStream_t s, const uint32_t* counts, uint32_t 
 
 hipError_t launch_cull_consolidate(hipStream_t s, const int32_t* src, uint32_t src_stride, const uint32_t* win_base, const uint32_t* counts,
 	uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* shard_type, const uint32_t* type_start, uint32_t type_start_stride, const uint32_t* pref,
-	uint32_t n_shards, uint32_t n_frusta, uint32_t max_shard_cap, int32_t* dst, uint32_t dst_stride, uint32_t dst_cap) {
+	uint32_t n_shards, uint32_t n_frusta, uint32_t max_shard_cap, int32_t* dst, uint32_t dst_stride, uint32_t dst_cap, const int32_t* src2, int32_t* dst2) {
 	if (!n_frusta || !n_shards) return hipSuccess;
 	const uint32_t splits = std::max(1u, std::min(64u, max_shard_cap / 4096u));
 	hipLaunchKernelGGL(k_cull_consolidate, dim3(n_shards, n_frusta, splits), dim3(256), 0, s, src, src_stride, win_base, counts, cnt_pad, cnt_frustum_stride,
-		shard_type, type_start, type_start_stride, pref, n_shards, dst, dst_stride, dst_cap);
+		shard_type, type_start, type_start_stride, pref, n_shards, dst, dst_stride, dst_cap, src2, dst2);
 	return hipGetLastError();
 }
 

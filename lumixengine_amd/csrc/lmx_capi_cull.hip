@@ -1123,13 +1123,10 @@ int cull_view_consolidate(LmxContext* ctx, CullView& v) {
 		LMX_HIP(ctx, v.cons.reserve(std::max<size_t>((size_t)v.out_stride * v.n_frusta, 1)));
 		dst = v.cons.p;
 	}
+	if (v.has_slots) LMX_HIP(ctx, v.cons_slots.reserve(std::max<size_t>((size_t)v.out_stride * v.n_frusta, 1))); // the same gather for the slots, in the same launch
 	LMX_HIP(ctx, launch_cull_consolidate(ctx->stream, v.out.p, v.out_stride, cs.d_win_base.p, v.counts_ptr(), cs.cnt_pad, cs.n_shards * cs.cnt_pad, cs.d_shard_type.p,
-		cs.d_type_start.p, 0, v.pref.p, cs.n_shards, v.n_frusta, cs.max_shard_cap, dst, v.out_stride, 0xffffffffu));
-	if (v.has_slots) { // the same gather for the slots
-		LMX_HIP(ctx, v.cons_slots.reserve(std::max<size_t>((size_t)v.out_stride * v.n_frusta, 1)));
-		LMX_HIP(ctx, launch_cull_consolidate(ctx->stream, v.out_slots.p, v.out_stride, cs.d_win_base.p, v.counts_ptr(), cs.cnt_pad, cs.n_shards * cs.cnt_pad, cs.d_shard_type.p,
-			cs.d_type_start.p, 0, v.pref.p, cs.n_shards, v.n_frusta, cs.max_shard_cap, v.cons_slots.p, v.out_stride, 0xffffffffu));
-	}
+		cs.d_type_start.p, 0, v.pref.p, cs.n_shards, v.n_frusta, cs.max_shard_cap, dst, v.out_stride, 0xffffffffu, v.has_slots ? v.out_slots.p : nullptr,
+		v.has_slots ? v.cons_slots.p : nullptr));
 	v.consolidated = true;
 	return LMX_OK;
 }

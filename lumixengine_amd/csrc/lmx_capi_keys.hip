@@ -286,10 +286,13 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	uint32_t n_copies = LMX_KEYS_MAX_COPIES;
 	while (n_copies > 1 && (uint64_t)n_copies * (max_sort_key + 1) > 262144) n_copies >>= 1;
 	const size_t g = (size_t)max_sort_key + 1;
-	LMX_HIP(ctx, ks.d_groups.reserve(2 * n_copies * g + g + g + 1));
+	// [group_count n_copies * g | counters KEYS_COUNTERS | group_cursor n_copies * g | group_total g | group_offset g + 1]: what a run starts
+	// from zero - the group counters and the list counters - is one range, cleared by ONE fill (two were two launches of ~5 us each in a chain
+	// of seven)
+	const size_t gc = (n_copies * g + 31) & ~(size_t)31; // the group counters, padded so that the list counters start on a 128-byte line (64-bit atomics)
+	LMX_HIP(ctx, ks.d_groups.reserve(gc + KEYS_COUNTERS + n_copies * g + g + g + 1));
 	LMX_HIP(ctx, ks.d_poses.reserve(std::max<size_t>(mesh_cap, 1)));
 	LMX_HIP(ctx, ks.d_dirty_list.reserve(std::max<size_t>(mesh_cap, 1)));
-	LMX_HIP(ctx, ks.d_counters.reserve(KEYS_COUNTERS));
 
 	if (ks.inst_dirty) { // the host mirror changed (tables or positions): lod / Pose::frame restart from the uploaded values
 		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -316,8 +319,8 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 		if (int rc = keys_before_layout_change(ctx)) return rc;
 	}
 	ProfScope ps(ctx, LMX_K_SORT_KEYS);
-	LMX_HIP(ctx, hipMemsetAsync(ks.d_counters.p, 0, KEYS_COUNTERS * sizeof(uint32_t), ctx->stream));
-	LMX_HIP(ctx, hipMemsetAsync(ks.d_groups.p, 0, n_copies * g * sizeof(uint32_t), ctx->stream));
+	ks.counters_at = gc;
+	LMX_HIP(ctx, hipMemsetAsync(ks.d_groups.p, 0, (gc + KEYS_COUNTERS) * sizeof(uint32_t), ctx->stream));
 	KeysDevice d;
 	memset(&d, 0, sizeof(d));
 	d.n_entities = ks.n_entities;
@@ -340,11 +343,11 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	d.rec_key = ks.d_rec_key.p; d.rec_value = ks.d_rec_value.p; d.cap_recs = (uint32_t)cap_recs;
 	d.max_sort_key = max_sort_key;
 	d.n_copies = n_copies;
-	d.group_count = ks.d_groups.p; d.group_cursor = ks.d_groups.p + n_copies * g; d.group_total = ks.d_groups.p + 2 * n_copies * g; d.group_offset = d.group_total + g;
-	ks.offsets_at = 2 * n_copies * g + g;
+	d.group_count = ks.d_groups.p; d.group_cursor = ks.d_groups.p + gc + KEYS_COUNTERS; d.group_total = d.group_cursor + n_copies * g; d.group_offset = d.group_total + g;
+	ks.offsets_at = gc + KEYS_COUNTERS + n_copies * g + g;
 	d.group_values = ks.d_group_values.p;
 	d.poses = ks.d_poses.p; d.dirty_list = ks.d_dirty_list.p; d.cap_list = mesh_cap;
-	d.counters = ks.d_counters.p;
+	d.counters = ks.d_groups.p + ks.counters_at;
 	if (int rc = cull_view_consolidate(ctx, v)) return rc; // the key kernels walk one contiguous list per type
 	const int32_t* row = v.cons_ptr() + (size_t)frustum * v.out_stride;
 	const uint32_t* counts = v.totals_ptr() + (size_t)frustum * MAX_TYPES;
@@ -360,7 +363,7 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 static int keys_host_counters(LmxContext* ctx, uint32_t* c) {
 	KeysState& ks = ctx->keys;
 	if (!ks.ran) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_keys_run has not run");
-	LMX_HIP(ctx, hipMemcpyAsync(c, ks.d_counters.p, KEYS_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	LMX_HIP(ctx, hipMemcpyAsync(c, ks.d_groups.p + ks.counters_at, KEYS_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return LMX_OK;
 }
@@ -471,7 +474,7 @@ int lmx_keys_device_pairs(LmxContext* ctx, const uint64_t** d_keys, const uint64
 	if (!ks.ran) return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_keys_run has not run");
 	if (d_keys) *d_keys = ks.d_keys.p;
 	if (d_values) *d_values = ks.d_values.p;
-	if (d_count) *d_count = ks.d_counters.p + KEYS_N_PAIRS;
+	if (d_count) *d_count = ks.d_groups.p + ks.counters_at + KEYS_N_PAIRS;
 	return LMX_OK;
 }
 

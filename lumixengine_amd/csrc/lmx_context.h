@@ -385,6 +385,7 @@ struct KeysState {
 	uint32_t n_meshes = 0, max_lod_span = 1;
 	uint32_t n_entities = 0, n_positions = 0, max_sort_key = 0;
 	size_t offsets_at = 0; // where the CSR offsets of the last run start inside d_groups
+	size_t counters_at = 0; // ... and the list counters (KEYS_COUNTERS words, right behind the group counters: one fill clears both)
 	bool have_instances = false, have_decals = false, have_curves = false, use_world = false, ran = false, sorted = false;
 	DevBuf<LmxKeysModel> d_models;
 	DevBuf<uint8_t> d_mesh_types;
@@ -396,7 +397,7 @@ struct KeysState {
 	DevBuf<uint32_t> d_decal_key, d_curve_key;
 	DevBuf<uint8_t> d_decal_layer, d_curve_layer;
 	DevBuf<uint64_t> d_keys, d_values, d_keys_alt, d_values_alt, d_rec_value, d_group_values;
-	DevBuf<uint32_t> d_rec_key, d_groups, d_counters;
+	DevBuf<uint32_t> d_rec_key, d_groups;
 	DevBuf<int32_t> d_poses, d_dirty_list;
 	DevBuf<char> d_sort_temp;
 	// slot-ordered mirror of d_inst / d_mesh_materials for the entities of the culling system's sorted set (keys_kernels.hip)
