@@ -52,8 +52,13 @@ __device__ __forceinline__ void wave_lds_sync() {
 //     (3 is odd: a b128 service group's 16 lanes land in 16 different columns) and the wave reads them back as float4 64 * j + lane: three
 //     1 KiB stores per 64 bones. The absolute rotations leave from registers (1 KiB per instruction), the absolute positions as the
 //     dwords the LDS already holds in memory order. All stores are non-temporal.
-// Palette layout in HBM: 3 rows x float4 per bone ({c0[r], c1[r], c2[r], c3[r]}, 48 B) - the rows evaluateSkin reads; row 3 of
-// (pose * inverse_bind).toMatrix() is the constant (0, 0, 0, 1) (math.cpp:887-890) and is re-attached on read-back.
+// Palette layout in HBM: 3 x float4 per bone (48 B) holding rows 0..2 of the matrix - what evaluateSkin reads; row 3 of
+// (pose * inverse_bind).toMatrix() is the constant (0, 0, 0, 1) (math.cpp:887-890) and is re-attached on read-back. With row r =
+// (c0[r], c1[r], c2[r], c3[r]):  P0 = (r0.x, r1.x, r0.y, r1.y)   P1 = (r0.z, r1.z, r0.w, r1.w)   P2 = r2.
+// Rows 0 and 1 are interleaved by column so that the blended {row 0, row 1} components are register PAIRS as they come out of the
+// packed blend, and the transform of a vertex by rows 0 and 1 is four packed operations on them (round 4: with plain rows the compiler
+// packed the transform itself and paid eight v_mov per vertex to build the pairs - 61 VALU wave-instructions per 64 vertices on a
+// kernel that is VALU- and power-bound, profiles/r04/final/target_counters_summary.json).
 //
 // Round 3's kernel (a 4-wave block per 16 instances, (instance, bone) lanes in every phase, a barrier per level) moved 16-byte pieces -
 // a global instruction touched 64 different 128-byte lines - and took 172 us for 100 000 x 64 bones; this one 133 us, 105 us with
@@ -234,8 +239,9 @@ __global__ __launch_bounds__(64) void k_pose_palette(const SkinInstance* __restr
 			o[0] = make_float4(dq.r.x, dq.r.y, dq.r.z, dq.r.w);
 			o[1] = make_float4(dq.d.x, dq.d.y, dq.d.z, dq.d.w);
 		}
-		s_rot[3 * lane] = make_float4(m.c[0][0], m.c[1][0], m.c[2][0], m.c[3][0]);
-		s_rot[3 * lane + 1] = make_float4(m.c[0][1], m.c[1][1], m.c[2][1], m.c[3][1]);
+		// the three float4 of a bone (see "Palette layout" above): rows 0 and 1 interleaved by column, then row 2
+		s_rot[3 * lane] = make_float4(m.c[0][0], m.c[0][1], m.c[1][0], m.c[1][1]);
+		s_rot[3 * lane + 1] = make_float4(m.c[2][0], m.c[2][1], m.c[3][0], m.c[3][1]);
 		s_rot[3 * lane + 2] = make_float4(m.c[0][2], m.c[1][2], m.c[2][2], m.c[3][2]);
 		wave_lds_sync();
 		const uint32_t n_rows = 3 * (nb - cb < 64 ? nb - cb : 64);
@@ -270,11 +276,11 @@ __global__ __launch_bounds__(256) void k_pose_blend(float* __restrict__ pos, flo
 __global__ __launch_bounds__(256) void k_palette_expand(const float4* __restrict__ rows, uint32_t n_bones, float4* __restrict__ out) {
 	const uint32_t b = blockIdx.x * 256 + threadIdx.x;
 	if (b >= n_bones) return;
-	const float4 r0 = rows[3 * b], r1 = rows[3 * b + 1], r2 = rows[3 * b + 2];
-	out[4 * b] = make_float4(r0.x, r1.x, r2.x, 0.f);
-	out[4 * b + 1] = make_float4(r0.y, r1.y, r2.y, 0.f);
-	out[4 * b + 2] = make_float4(r0.z, r1.z, r2.z, 0.f);
-	out[4 * b + 3] = make_float4(r0.w, r1.w, r2.w, 1.f);
+	const float4 p0 = rows[3 * b], p1 = rows[3 * b + 1], r2 = rows[3 * b + 2]; // P0 = (r0.x, r1.x, r0.y, r1.y), P1 = (r0.z, r1.z, r0.w, r1.w), P2 = r2
+	out[4 * b] = make_float4(p0.x, p0.y, r2.x, 0.f);
+	out[4 * b + 1] = make_float4(p0.z, p0.w, r2.y, 0.f);
+	out[4 * b + 2] = make_float4(p1.x, p1.y, r2.z, 0.f);
+	out[4 * b + 3] = make_float4(p1.z, p1.w, r2.w, 1.f);
 }
 
 // ---- linear-blend skinning ----------------------------------------------------------------------------------
@@ -356,40 +362,50 @@ __device__ __forceinline__ F3 skin_blend_rows(const float4* r0, const float4* r1
 			tz = (qr.w * qd.z - qd.w * qr.z) + (qr.x * qd.y - qr.y * qd.x);
 		return F3{(c.px + 2 * ox) + 2 * tx, (c.py + 2 * oy) + 2 * ty, (c.pz + 2 * oz) + 2 * tz};
 	}
-	float o[3];
-#pragma unroll
-	for (int r = 0; r < 3; ++r) {
+	// the three float4 of the four bones (P0, P1, P2 of "Palette layout"), each consumed as soon as it is blended (12 blended floats alive at
+	// once cost the kernel its register budget): P2 -> the z row; P0 -> {row 0, row 1} columns x, y -> the packed transform's first two
+	// terms; P1 -> columns z, w -> its last two
+	const v2f w01 = {w.x, w.y}, w23 = {w.z, w.w};
+	// (the weight splats are shuffles of the loaded pairs, so that the broadcast folds into op_sel of v_pk_*_f32)
+	const v2f wx = __builtin_shufflevector(w01, w01, 0, 0), wy = __builtin_shufflevector(w01, w01, 1, 1);
+	const v2f wz = __builtin_shufflevector(w23, w23, 0, 0), ww = __builtin_shufflevector(w23, w23, 1, 1);
+	auto blend = [&](int slot, v2f& lo, v2f& hi) {
 		float4 A, B, C, D;
 		if (LMX_PROBE_SKIP(16)) { A = w; B = c.w; C = make_float4(c.px, c.py, c.pz, w.x); D = make_float4(w.y, c.px, w.z, c.py); }
-		else { A = r0[r * COPIES]; B = r1[r * COPIES]; C = r2[r * COPIES]; D = r3[r * COPIES]; }
+		else { A = r0[slot * COPIES]; B = r1[slot * COPIES]; C = r2[slot * COPIES]; D = r3[slot * COPIES]; }
+		// (the four floats of an LDS slot land in consecutive VGPRs: {x, y} and {z, w} are packed operands as they are)
+		const v2f a01 = {A.x, A.y}, a23 = {A.z, A.w}, b01 = {B.x, B.y}, b23 = {B.z, B.w};
+		const v2f c01 = {C.x, C.y}, c23 = {C.z, C.w}, d01 = {D.x, D.y}, d23 = {D.z, D.w};
 		if constexpr (MODE == LMX_SKIN_EXACT) {
-			// Matrix::operator*(float) and operator+ (math.cpp:1022-1071), left to right: ((A*w.x + B*w.y) + C*w.z) + D*w.w
-			const float m0 = A.x * w.x + B.x * w.y + C.x * w.z + D.x * w.w;
-			const float m1 = A.y * w.x + B.y * w.y + C.y * w.z + D.y * w.w;
-			const float m2 = A.z * w.x + B.z * w.y + C.z * w.z + D.z * w.w;
-			const float m3 = A.w * w.x + B.w * w.y + C.w * w.z + D.w * w.w;
-			// Matrix::transformPoint (math.cpp:1231-1235): c0.r*p.x + c1.r*p.y + c2.r*p.z + c3.r
-			o[r] = m0 * c.px + m1 * c.py + m2 * c.pz + m3;
+			// Matrix::operator*(float) and operator+ (math.cpp:1022-1071), left to right per component: ((A*w.x + B*w.y) + C*w.z) + D*w.w,
+			// every product and sum rounded on its own (-ffp-contract=off: v_pk_mul_f32 / v_pk_add_f32)
+			lo = a01 * wx; lo = lo + b01 * wy; lo = lo + c01 * wz; lo = lo + d01 * ww;
+			hi = a23 * wx; hi = hi + b23 * wy; hi = hi + c23 * wz; hi = hi + d23 * ww;
 		} else {
-			// same association with the products fused into the adds, on register pairs (v_pk_fma_f32): the four
-			// floats of an LDS row land in consecutive VGPRs, so {x,y} and {z,w} are packed operands as they are.
-			const v2f a01 = {A.x, A.y}, a23 = {A.z, A.w}, b01 = {B.x, B.y}, b23 = {B.z, B.w};
-			const v2f c01 = {C.x, C.y}, c23 = {C.z, C.w}, d01 = {D.x, D.y}, d23 = {D.z, D.w};
-			// weight splats as shuffles of the loaded pairs, so that the broadcast folds into op_sel of v_pk_*_f32
-			const v2f w01 = {w.x, w.y}, w23 = {w.z, w.w};
-			const v2f wx = __builtin_shufflevector(w01, w01, 0, 0), wy = __builtin_shufflevector(w01, w01, 1, 1);
-			const v2f wz = __builtin_shufflevector(w23, w23, 0, 0), ww = __builtin_shufflevector(w23, w23, 1, 1);
-			v2f m01 = a01 * wx, m23 = a23 * wx;
-			m01 = __builtin_elementwise_fma(b01, wy, m01);
-			m23 = __builtin_elementwise_fma(b23, wy, m23);
-			m01 = __builtin_elementwise_fma(c01, wz, m01);
-			m23 = __builtin_elementwise_fma(c23, wz, m23);
-			m01 = __builtin_elementwise_fma(d01, ww, m01);
-			m23 = __builtin_elementwise_fma(d23, ww, m23);
-			o[r] = fmaf(m23.x, c.pz, fmaf(m01.y, c.py, m01.x * c.px)) + m23.y;
+			// the same association with the products fused into the adds (v_pk_fma_f32)
+			lo = a01 * wx; hi = a23 * wx;
+			lo = __builtin_elementwise_fma(b01, wy, lo); hi = __builtin_elementwise_fma(b23, wy, hi);
+			lo = __builtin_elementwise_fma(c01, wz, lo); hi = __builtin_elementwise_fma(c23, wz, hi);
+			lo = __builtin_elementwise_fma(d01, ww, lo); hi = __builtin_elementwise_fma(d23, ww, hi);
 		}
-	}
-	return F3{o[0], o[1], o[2]};
+	};
+	const v2f px2 = {c.px, c.px}, py2 = {c.py, c.py}, pz2 = {c.pz, c.pz};
+	v2f lo, hi, o01;
+	float o2;
+	blend(2, lo, hi); // row 2: (x, y), (z, w)
+	if constexpr (MODE == LMX_SKIN_EXACT) o2 = lo.x * c.px + lo.y * c.py + hi.x * c.pz + hi.y; // Matrix::transformPoint (math.cpp:1231-1235), left to right
+	else o2 = fmaf(hi.x, c.pz, fmaf(lo.y, c.py, lo.x * c.px)) + hi.y;
+	asm volatile("" : "+v"(o2)); // (row 2 is done before the next slot's reads are issued: their 16 registers are the ones just freed)
+	blend(0, lo, hi); // {row 0, row 1}: column x, column y
+	if constexpr (MODE == LMX_SKIN_EXACT) { o01 = lo * px2; o01 = o01 + hi * py2; }
+	else o01 = __builtin_elementwise_fma(hi, py2, lo * px2);
+#ifndef LMX_HOSTSIM
+	asm volatile("" : "+v"(o01)); // (a scheduling fence only; the simulated device's compiler has no register class for an 8-byte vector)
+#endif
+	blend(1, lo, hi); // {row 0, row 1}: column z, column w
+	if constexpr (MODE == LMX_SKIN_EXACT) { o01 = o01 + lo * pz2; o01 = o01 + hi; }
+	else o01 = __builtin_elementwise_fma(lo, pz2, o01) + hi;
+	return F3{o01.x, o01.y, o2};
 }
 
 // LMX_SKIN_FUSED over the first N of the vertex's four bone slots (the others carry weight 0 for EVERY lane of the wave): the same
@@ -407,29 +423,32 @@ __device__ __forceinline__ F3 skin_blend_fused_n(const float4* rows, const RawVe
 	const v2f w01 = {rec.a.x, rec.a.y}, w23 = {rec.a.z, rec.a.w};
 	const v2f wx = __builtin_shufflevector(w01, w01, 0, 0), wy = __builtin_shufflevector(w01, w01, 1, 1);
 	const v2f wz = __builtin_shufflevector(w23, w23, 0, 0), ww = __builtin_shufflevector(w23, w23, 1, 1);
-	float o[3];
+	v2f q[4], m2[2];
 #pragma unroll
-	for (int r = 0; r < 3; ++r) {
-		const float4 A = r0[r * COPIES];
-		v2f m01 = v2f{A.x, A.y} * wx, m23 = v2f{A.z, A.w} * wx;
+	for (int slot = 0; slot < 3; ++slot) {
+		const float4 A = r0[slot * COPIES];
+		v2f lo = v2f{A.x, A.y} * wx, hi = v2f{A.z, A.w} * wx;
 		if constexpr (N >= 2) {
-			const float4 B = r1[r * COPIES];
-			m01 = __builtin_elementwise_fma(v2f{B.x, B.y}, wy, m01);
-			m23 = __builtin_elementwise_fma(v2f{B.z, B.w}, wy, m23);
+			const float4 B = r1[slot * COPIES];
+			lo = __builtin_elementwise_fma(v2f{B.x, B.y}, wy, lo);
+			hi = __builtin_elementwise_fma(v2f{B.z, B.w}, wy, hi);
 		}
 		if constexpr (N >= 3) {
-			const float4 C = r2[r * COPIES];
-			m01 = __builtin_elementwise_fma(v2f{C.x, C.y}, wz, m01);
-			m23 = __builtin_elementwise_fma(v2f{C.z, C.w}, wz, m23);
+			const float4 C = r2[slot * COPIES];
+			lo = __builtin_elementwise_fma(v2f{C.x, C.y}, wz, lo);
+			hi = __builtin_elementwise_fma(v2f{C.z, C.w}, wz, hi);
 		}
 		if constexpr (N >= 4) {
-			const float4 D = r3[r * COPIES];
-			m01 = __builtin_elementwise_fma(v2f{D.x, D.y}, ww, m01);
-			m23 = __builtin_elementwise_fma(v2f{D.z, D.w}, ww, m23);
+			const float4 D = r3[slot * COPIES];
+			lo = __builtin_elementwise_fma(v2f{D.x, D.y}, ww, lo);
+			hi = __builtin_elementwise_fma(v2f{D.z, D.w}, ww, hi);
 		}
-		o[r] = fmaf(m23.x, rec.b.z, fmaf(m01.y, rec.b.y, m01.x * rec.b.x)) + m23.y;
+		if (slot == 0) { q[0] = lo; q[1] = hi; } else if (slot == 1) { q[2] = lo; q[3] = hi; } else { m2[0] = lo; m2[1] = hi; }
 	}
-	return F3{o[0], o[1], o[2]};
+	const v2f px2 = {rec.b.x, rec.b.x}, py2 = {rec.b.y, rec.b.y}, pz2 = {rec.b.z, rec.b.z};
+	const v2f o01 = __builtin_elementwise_fma(q[2], pz2, __builtin_elementwise_fma(q[1], py2, q[0] * px2)) + q[3];
+	const float o2 = fmaf(m2[1].x, rec.b.z, fmaf(m2[0].y, rec.b.y, m2[0].x * rec.b.x)) + m2[1].y;
+	return F3{o01.x, o01.y, o2};
 }
 
 // `rows` already points at the lane's copy
