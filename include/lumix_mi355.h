@@ -130,10 +130,11 @@ LMX_API int lmx_cull_stats(LmxContext* ctx, uint32_t* n_entities, uint32_t* n_ce
  * on the context stream; the result stays in HBM in slot `view` until the next lmx_cull() on the same slot. */
 LMX_API int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, uint32_t n_frusta, uint8_t type);
 /* How many frusta of a call are tested per pass over the static set (1..LMX_MAX_FRUSTA; 0 = automatic, the default: all of them
- * in one launch when the set holds <= 1 M spheres - a game scene's views cost one launch gap instead of one per view - else 1).
- * On a large set the kernel is latency-bound for a narrow camera, so one frustum per pass at full occupancy measured fastest
- * (8 frusta over 10 M spheres, sparse scene: 119 us at width 1, 152 us at width 8); wider passes read the spheres fewer times and
- * win when every sphere is tested (218 against 290 us) or the set is far larger than the 256 MiB Infinity Cache. */
+ * in ONE launch when the set holds <= 32 M spheres, frustum by frustum above). Measured on one MI355X (profiles/r04): at 10 M spheres one
+ * pass beats eight in every regime - a frame's 6 views 39 against 66 us, 8 cascades over a sparse scene 84 against 119 us, every sphere
+ * tested against 8 frusta 141 against 298 us; at 100 M the 1-frustum launches win (a frame's 6 views 185 against 207 us): the
+ * several-frusta kernel walks smaller tiles with more LDS per block, and the blocks that only reject their tile are what a launch over
+ * 100 M spheres is made of. */
 LMX_API int lmx_cull_set_pass_width(LmxContext* ctx, uint32_t frusta_per_pass);
 /* Kernel tuning knobs (no reference twin; results never depend on them). */
 enum {

@@ -1423,10 +1423,14 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 	const CullDeviceView dv = static_view(cs);
 	// The kernel is latency-bound for small frusta: wide variants (many frusta per pass) hold more state per wave and run at lower
 	// occupancy, so a batch is split into passes of at most `pass_width` frusta.
-	// pass_width 0 = automatic: a small set (a game scene: tens of thousands of entities, a handful of tiles) is one launch for all
-	// frusta - every launch of a latency-bound kernel costs its launch gap, and the harness's six views of 40 k entities are 6 gaps
-	// against 1; a large set goes frustum by frustum (measured at 10 M entities: profiles/r04/cull8_pass_widths.txt).
-	const uint32_t pass_width = cs.pass_width ? cs.pass_width : (ent_end - ent_begin <= (1u << 20) ? n_frusta : 1u);
+	// pass_width 0 = automatic: ONE launch for all frusta of the call up to 32 M spheres, frustum by frustum above. Every launch of this
+	// latency-bound kernel costs its floor (launch + one round of block start-ups), and since round 4's rework of the several-frusta kernel
+	// one pass over the spheres beats eight at 10 M in every regime measured (profiles/r04/width_rule_call39.txt: a frame's 6 views
+	// 66 -> 39 us, 8 small cascades 82 -> 49; every sphere tested against 8 frusta 298 -> 141, cull8_pass_widths_call23_*.txt). At 100 M
+	// it is the other way round (6 views 185 vs 207 us, config 5's cascades 281 vs 373): the several-frusta kernel walks 1024-sphere tiles
+	// with 28 KiB of LDS each - 98 k blocks, five resident per CU - and the blocks that only reject their tile are what the launch is
+	// made of there; the 1-frustum kernels walk 2048- / 4096-sphere tiles, eight blocks per CU.
+	const uint32_t pass_width = cs.pass_width ? cs.pass_width : (ent_end - ent_begin <= (1u << 25) ? n_frusta : 1u);
 	for (uint32_t f0 = 0; f0 < n_frusta; f0 += pass_width) {
 		const uint32_t fw = std::min(pass_width, n_frusta - f0);
 		FrustaArg sub;
