@@ -79,3 +79,26 @@ def test_keys_and_xform_do_not_spill(tmp_path):
         for tag in tags:
             for k in pick(meta, tag):
                 assert k["private_segment_fixed_size"] == 0, (tag, k)
+
+
+def test_round4_kernels_keep_their_residency(tmp_path):
+    """The budgets round 4's measurements rest on (profiles/r04): the several-frusta cull kernel is held by LDS to five 4-wave blocks per CU
+    (24-byte cell records + class words) - its registers must not be what cuts that further (<= 96 VGPRs) and 24 more live registers cost it
+    12 % when tried (shared dot products); k_keys_mesh runs two 8-wave blocks per CU: <= 128 VGPRs, <= 80 KiB of LDS, and spills cost it more
+    than waves; k_skin_multi's LDS is sized by the launch (dynamic), its FUSED / EXACT forms stay within the 6-waves-per-SIMD budget of
+    their launch bounds without scratch; k_xform_subtree: <= 128 VGPRs, five 27-KiB blocks per CU."""
+    cull = metadata("cull_kernels.hip", tmp_path)
+    for k in pick(cull, "k_cull_tileILi0E"):
+        assert k["private_segment_fixed_size"] == 0 and k["next_free_vgpr"] <= 96, k
+        assert k["group_segment_fixed_size"] <= 1024, k  # static LDS only (normals, verdicts): the cell records are the launch's dynamic LDS
+    keys = metadata("keys_kernels.hip", tmp_path)
+    for k in pick(keys, "k_keys_mesh"):
+        assert k["private_segment_fixed_size"] == 0 and k["next_free_vgpr"] <= 128 and k["group_segment_fixed_size"] <= 80 * 1024, k
+    skin = metadata("skin_kernels.hip", tmp_path)
+    for tag in ("k_skin_multiILi2ELi0E", "k_skin_multiILi2ELi1E", "k_skin_multiILi1ELi0E"):
+        for k in pick(skin, tag):
+            assert k["private_segment_fixed_size"] == 0 and k["next_free_vgpr"] <= 80, (tag, k)
+            assert k["group_segment_fixed_size"] == 0, (tag, k)  # the palette staging is dynamic LDS, sized by the bones the launch's meshes reference
+    xform = metadata("xform_kernels.hip", tmp_path)
+    for k in pick(xform, "k_xform_subtree"):
+        assert k["private_segment_fixed_size"] == 0 and k["next_free_vgpr"] <= 128 and k["group_segment_fixed_size"] <= 28 * 1024, k
