@@ -147,7 +147,7 @@ enum {
 	LMX_CULL_OPT_OVERFLOW_RESERVE = 6,        /* n >= 0 (default 0): free slots kept in the unsorted overflow set for entities added (or moved to another cell) after the sorted set was built. The reference's add / remove never stall (culling_system.cpp:131-190); here an add takes a free overflow slot in O(1), and only when a type's overflow region is FULL is the whole overflow set laid out again (a host pass + re-upload: milliseconds at 10^6 entities). With AUTO_COMPACTION = 0 and a reserve that covers the churn between two lmx_cull_compact calls (a loading screen, a streaming boundary) no frame ever pays for either; the overflow entities cost k_cull_dynamic's ~350 instead of ~27 instructions per cull until then */
 	LMX_CULL_OPT_ASYNC_COMPACTION = 7,        /* 1: the re-sort of the sorted set runs on a worker thread, on a second complete copy of the sets (host mirror + device arrays: twice the memory), and the copy trades places with the live set inside a flush in O(1) + a replay of the operations of the last frame or two: no frame pays the O(n) step (the reference's add / remove / set never stall, culling_system.cpp:131-258). Every effective add / remove / set* / bind is also appended to a 40-byte operation log. Switching it on copies the host mirror once (O(n)); lmx_cull_build and lmx_cull_compact stay synchronous and re-seed the copy. Results are the same id sets as without it; 0 (default): the re-sort happens inside the flush that finds the thresholds exceeded */
 	LMX_CULL_OPT_COMPACTION_MIN = 8,          /* n >= 1 (default 65536): the floor of AUTO_COMPACTION's thresholds - a re-sort is considered once the overflow set holds more than max(n, static / 8) entities or the sorted set more than max(n, static / 4) tombstones. The default keeps small scenes from re-sorting at all (their overflow set costs microseconds per cull); a host whose scene is small but churns for hours lowers it, and the tests do, to reach the re-sort - synchronous or on the worker - with a few thousand entities */
-	LMX_CULL_OPT_MAP_ZERO_COPY = 9            /* 1 (default): lmx_cull_map_* of a view whose lists held <= 64 k ids last frame has the pack kernel write the record straight into the pinned host buffer (posted PCIe writes, no copy command behind the kernel); 0: always pack on the device + one DMA copy. Results do not depend on it */
+	LMX_CULL_OPT_MAP_ZERO_COPY = 9            /* 1 (default): lmx_cull_map_* of a view whose lists held <= 1 M ids last frame has the pack kernel write the record straight into the pinned host buffer (posted PCIe writes, no copy command behind the kernel); 0: always pack on the device + one DMA copy; n > 1: the same with a threshold of n ids. Results do not depend on it */
 };
 LMX_API int lmx_cull_set_option(LmxContext* ctx, int option, int value);
 /* counts[f * LMX_MAX_TYPES + t] = visible entities of type t for frustum f (synchronizes the stream). */

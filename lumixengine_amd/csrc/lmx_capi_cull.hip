@@ -1490,7 +1490,7 @@ int lmx_cull_set_option(LmxContext* ctx, int option, int value) {
 			cs.compaction_min = (uint32_t)value;
 			return LMX_OK;
 		case LMX_CULL_OPT_DEVICE_OWNS_BOUND: cs.device_owns_bound = value != 0; return LMX_OK;
-		case LMX_CULL_OPT_MAP_ZERO_COPY: cs.map_zero_copy = value != 0; return LMX_OK;
+		case LMX_CULL_OPT_MAP_ZERO_COPY: cs.map_zero_copy = value != 0; cs.map_zero_copy_max = value > 1 ? (uint32_t)value : (1u << 20); return LMX_OK; // (value > 1: the threshold in ids)
 		case LMX_CULL_OPT_ASYNC_COMPACTION:
 			if (value) return async_enable(ctx);
 			async_disable(cs);
@@ -1616,14 +1616,15 @@ static int cull_map_begin(LmxContext* ctx, CullView& v, uint32_t first, uint32_t
 	}
 	if (!v.map_event) LMX_HIP(ctx, hipEventCreateWithFlags(&v.map_event, hipEventDisableTiming));
 	const uint32_t cnt_frustum_stride = cs.n_shards * cs.cnt_pad;
-	// Small lists (what a view of a game scene usually is: <= 64 k ids last frame): k_cull_pack writes the record STRAIGHT into the pinned
-	// host buffer (the buffer's device mapping: posted writes over PCIe, a few microseconds for tens of kilobytes) - no copy command
-	// behind the kernel, whose fixed cost (~10 us of a ~45 us cull of the harness's 40 k-entity scene) is what a host read of a small
-	// list consists of. Large lists keep the device record + one DMA copy of the ids the last frame needed: a kernel that streams
-	// megabytes over PCIe holds CUs for the duration.
+	// Lists of up to 1 M ids last frame: k_cull_pack writes the record STRAIGHT into the pinned host buffer (the buffer's device mapping:
+	// posted writes over PCIe) - no copy command behind the kernel, whose fixed cost (~10 us of a ~45 us cull of the harness's 40 k-entity
+	// scene) is what a host read of a small list consists of; at the headline camera's 334 k ids (1.3 MB) the host read is still 20 us
+	// shorter this way (104 against 124 us per cull + read through the Python wrapper, profiles/r04/readback_zero_copy_call43.txt; round 4's
+	// first cut stopped at 64 k ids). Larger lists keep the device record + one DMA copy of the ids the last frame needed: a kernel that
+	// streams many megabytes over PCIe holds its CUs for the duration.
 	int32_t* host_dev = nullptr;
 	bool zero_copy = cs.map_zero_copy;
-	for (uint32_t k = 0; k < n && zero_copy; ++k) zero_copy = v.map_guess[first + k] <= (64u << 10);
+	for (uint32_t k = 0; k < n && zero_copy; ++k) zero_copy = v.map_guess[first + k] <= cs.map_zero_copy_max;
 	if (zero_copy && hipHostGetDevicePointer(reinterpret_cast<void**>(&host_dev), v.map_host, 0) != hipSuccess) zero_copy = false;
 	v.map_begin_zero_copy = zero_copy;
 	{ // the records of all n frusta: ONE launch (a frame's six views cost six launch gaps otherwise)

@@ -255,6 +255,7 @@ struct CullState : CullSet {
 	bool auto_compaction = true; // false: overflow / tombstones accumulate until the host calls lmx_cull_compact
 	uint32_t compaction_min = 1u << 16; // overflow entities / tombstones tolerated before a compaction is considered at all (LMX_CULL_OPT_COMPACTION_MIN)
 	bool map_zero_copy = true;   // LMX_CULL_OPT_MAP_ZERO_COPY: small host records are written by the pack kernel straight into pinned host memory
+	uint32_t map_zero_copy_max = 1u << 20; // ... for views whose lists held at most this many ids last frame
 	CullAsync* async = nullptr;  // LMX_CULL_OPT_ASYNC_COMPACTION: shadow set + worker thread (owned; lmx_capi_cull.hip)
 	bool emit_slots = false;     // culls also write the static-set slot of every visible id (switched on by the sort-key tables' slot-ordered mirror)
 	uint64_t layout_generation = 0; // a process-wide unique number per build of the static layout (consumers that mirror it by slot compare)
