@@ -35,7 +35,8 @@ enum {
 	LMX_ERR_HIP = 3,           /* a HIP runtime call failed; see lmx_last_error() */
 	LMX_ERR_OUT_OF_MEMORY = 4,
 	LMX_ERR_CAPACITY = 5,      /* caller buffer too small / too many views, frusta or types */
-	LMX_ERR_NOT_BUILT = 6      /* operation needs data that has not been uploaded yet */
+	LMX_ERR_NOT_BUILT = 6,     /* operation needs data that has not been uploaded yet */
+	LMX_ERR_BUSY = 7           /* every result slot is held by a caller that has not released it (lmx_cull_view_acquire timed out) */
 };
 
 enum {
@@ -175,9 +176,19 @@ LMX_API int lmx_cull_map_many(LmxContext* ctx, uint32_t view, uint32_t n_frusta,
  * records an event; like every entry point that enqueues, it needs the context lock (lmx_ctx_lock). lmx_cull_map_end waits for THAT
  * view's event and hands out the pointers into the view's pinned buffer: it may be called WITHOUT the lock, concurrently with any
  * other call that does not use the same view - the host wait and the consumer's copy out of the buffer overlap other threads'
- * enqueues. host/gpu_culling_system.h is the caller; at most LMX_MAX_VIEWS results are in flight at a time. */
+ * enqueues. host/gpu_culling_system.h is the caller; at most LMX_MAX_VIEWS results are in flight at a time, which the slot
+ * reservation below enforces. */
 LMX_API int lmx_cull_map_begin(LmxContext* ctx, uint32_t view, uint32_t n_frusta);
 LMX_API int lmx_cull_map_end(LmxContext* ctx, uint32_t view, uint32_t n_frusta, const int32_t** out_ids, uint32_t* out_counts);
+/* Result slots that cannot alias. CullingSystem::cull hands every caller an independent list (culling_system.cpp:321-369; callers
+ * pipeline.cpp:1036-1045, :3380, editor/scene_view.cpp:144), here a caller reads its ids out of the slot's pinned record AFTER the
+ * enqueue, outside the context lock - so a slot must not be culled into again before that reader is done. lmx_cull_view_acquire
+ * reserves a free slot (round robin); with all LMX_MAX_VIEWS reserved it waits up to timeout_ms for a release and then returns
+ * LMX_ERR_BUSY. lmx_cull_view_release frees the slot once the ids have been copied out. Both are thread safe, take no context
+ * lock, and must NOT be called with the context lock held (a waiter would keep the enqueuing threads out). Callers that name
+ * their view slots themselves (one thread, or one fixed slot per thread) do not need them. */
+LMX_API int lmx_cull_view_acquire(LmxContext* ctx, uint32_t* view, uint32_t timeout_ms);
+LMX_API int lmx_cull_view_release(LmxContext* ctx, uint32_t view);
 /* Device-side view of a result for GPU consumers (sort keys, RCCL all-gather): ids of (frustum, type) start at
  * d_ids + type_offsets[type] and number d_counts[frustum * LMX_MAX_TYPES + type]. All pointers are device memory
  * except type_offsets (host, LMX_MAX_TYPES entries, in ids). The cull kernels leave the visible ids in up to a few hundred
@@ -450,7 +461,8 @@ LMX_API int lmx_keys_read_poses(LmxContext* ctx, int32_t* entities, uint32_t cap
 LMX_API int lmx_keys_read_dirty(LmxContext* ctx, int32_t* entities, uint32_t cap);
 /* ModelInstance::lod and Pose::frame after the run (both are updated in place on the device). */
 LMX_API int lmx_keys_read_state(LmxContext* ctx, float* lod, uint32_t* pose_frame, uint32_t n_entities);
-/* Device pointers of the last run for GPU consumers: pairs (keys, values, count on the device). */
+/* Device pointers of the last run for GPU consumers: pairs (keys, values, count on the device). Valid until the next lmx_keys_run /
+ * lmx_keys_set_*: the buffers (d_count included) are re-reserved when the key range or the copy count grows - fetch them again after every run. */
 LMX_API int lmx_keys_device_pairs(LmxContext* ctx, const uint64_t** d_keys, const uint64_t** d_values, const uint32_t** d_count);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -120,6 +120,8 @@ SYMBOLS = {
     "lmx_cull_map_many": (_ci, [_vp, _u32, _u32, _vp, _vp]),
     "lmx_cull_map_begin": (_ci, [_vp, _u32, _u32]),
     "lmx_cull_map_end": (_ci, [_vp, _u32, _u32, _vp, _vp]),
+    "lmx_cull_view_acquire": (_ci, [_vp, _vp, _u32]),
+    "lmx_cull_view_release": (_ci, [_vp, _u32]),
     "lmx_cull_pack_device": (_ci, [_vp, _u32, _u32, _vp, _vp]),
     "lmx_cull_device_shards": (_ci, [_vp, _u32, _u32, _vp]),
     "lmx_cull_stats": (_ci, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),

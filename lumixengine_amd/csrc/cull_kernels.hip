@@ -43,6 +43,7 @@ struct TileScalars {
 	uint32_t ent_begin, cell_cap, n_frusta;
 	uint32_t out_stride, cnt_pad, cnt_frustum_stride, n_zero;
 	int32_t* out_slots; // SLOTS kernels only
+	float pretest_n1s;  // (several frusta) 2^27 x the largest |n|_1 of the call's planes, rounded up; +inf switches the matrix-pipe pre-test off
 };
 
 // float index of DevFrustum members inside the kernarg segment (frustum 0)
@@ -179,6 +180,17 @@ __device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, 
 // the loop around the tile body, all-test launch 37.3 -> 43.5 us back to back, 43.0 -> 47.9 us cache-cold.
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// {bf16(a), bf16(b) << 16}, round to nearest even: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) { const v2f v = {a, b}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t)); }
+typedef float v8f_t __attribute__((ext_vector_type(8)));
+// min of three, NaN operands dropped (all NaN: NaN): the compiler folds the nested fminf into ONE v_min3_f32 without canonicalising
+// its operands (a two-operand fminf gets a v_max_f32 x, x in front of every operand it cannot prove quiet: always spell three)
+__device__ __forceinline__ float min3_drop_nan(float a, float b, float c) { return fminf(fminf(a, b), c); }
 __device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const float d[6], float cx, float cy, float cz, float radius, uint32_t pairs = 7u) {
 	const v2f x2 = {cx, cx}, y2 = {cy, cy}, z2 = {cz, cz}, r2 = {radius, radius};
 #if LMX_CULL_MIN3
@@ -212,6 +224,39 @@ __device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const f
 #endif
 }
 
+// ---- sphere x plane pre-test on the matrix pipe (several frusta) ---------------------------------------------------------------
+// The 8-frusta pass is bound by VALU work: doCulling's unfused arithmetic is 21 packed operations + 4 min / compare per (64 spheres,
+// frustum), 62.6 M VALU wave-instructions per launch at 10 M all-test (profiles/r04/final/counters_summary.json), and sharing dot
+// products between frusta does not apply to real cascades: of the 48 planes of config 5's frusta 34 have bitwise distinct directions
+// even up to sign (the reference builds every plane from cross products of corner differences, geometry.cpp:324-337: the cascades of
+// one light differ in the last bits, near / far are not exact negations) - profiles/r05/README.md.
+// What the test needs bit for bit is only the SIGN of u_k = fl(fl(fl(fl(fl(x nx) + fl(y ny)) + fl(z nz)) + d_k) + r) for six planes.
+// v_mfma_f32_32x32x2_f32 computes, for 32 spheres x 32 plane rows at a time, u'_k = fma(r, 1, fma(z, nz, fma(y, ny, fma(x, nx, d_k))))
+// (two instructions, K = 4; bit for bit that fmaf chain: tools/mfma_contract_probe.hip) on the MATRIX pipe, which this kernel does
+// not use otherwise. Both values approximate T_k = x nx + y ny + z nz + d_k + r: |u_k - T_k| <= ((1 + u)^5 - 1) M_k and
+// |u'_k - T_k| <= ((1 + u)^4 - 1) M_k with u = 2^-24 and M_k = |x nx| + |y ny| + |z nz| + |d_k| + |r| (no underflow: see tau; no
+// overflow: see the scale). With G >= |x nx| + |y ny| + |z nz| + |r|: |d_k| <= |T_k| + G, so M_k <= 2 G + |T_k| <= (2 G + |u'_k|) /
+// (1 - 4.0001 u) and |u_k - u'_k| <= 9.001 u (2 G + |u'_k|). Hence |u'_k| > 18.01 u G  =>  sign(u_k) == sign(u'_k), u_k != 0.
+// The kernel uses eps = 32 u G' + tau, G' = max(|x|, |y|, |z|) * n1 + |r| evaluated in fp32 (n1 >= every plane's |n|_1, rounded up on
+// the host; three roundings of relative size u against a margin of 1.77), and per (sphere, frustum) with m = min_k u'_k (NaNs dropped):
+//     m < -eps                    some plane has u_k < 0: culled, as the reference
+//     m >  eps                    every plane has u_k > 0 (a NaN u'_k means d_k is NaN - everything else is finite here - so u_k is NaN
+//                                 too and culls nothing): visible, as the reference
+//     otherwise (also eps = NaN)  undecided: the chunk is evaluated again by the exact loop below, all frusta
+// tau = 2^-120 covers products that underflow (absolute error <= 8 x 2^-150 instead of relative u). G' is formed 2^27 times too large and
+// scaled back by the last multiplication: any G >= 2^101 makes eps infinite, so sums that could overflow in one evaluation order and
+// not in the other (partial sums are bounded by M_k (1 + 5 u)) are never decided here; +inf / NaN coordinates, radii and bounds end in
+// eps = inf / NaN the same way, and d_k = +-inf gives u'_k = u_k = +-inf. Expected rate of undecided (sphere, plane) pairs on a scene of
+// extent 3e4: 2 eps / 6e4 ~ 1e-7.
+// Layout: rows = planes. Row i of a group of four frusta 4 g .. 4 g + 3 is plane p = (i & 3) + 4 ((i >> 3) & 1) of frustum
+// 4 g + 2 h + q with h = (i >> 2) & 1, q = i >> 4, so that accumulator registers 8 q + p of a lane in half h (= lane >> 5) are the
+// six values of ONE sphere (column lane & 31) and ONE frustum: the minimum is lane-local. Columns = 32 spheres: a chunk's 64 spheres are
+// two column groups; v_permlane32_swap hands each half-wave the partner sphere's components it needs as the K = 1 / K = 3 operands, and
+// brings the verdict bits of the other four frusta back (tools/mfma_contract_probe.hip pins both instructions).
+#ifndef LMX_CULL8_MFMA
+#define LMX_CULL8_MFMA 2      // 0: every (chunk, frustum) through the exact loop (rounds 2-4), 1: f32-input MFMA, 2: bf16 MFMA on two-term splits
+#endif
+
 // LDS record of one (cell, frustum): the six cell-relative plane distances of ShiftedFrustum::getRelative and the cell's class
 struct alignas(16) CellInfo { float d[6]; uint32_t cls, pairs; }; // pairs: relevant_plane_pairs() of a CELL_TEST cell
 static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustum)");
@@ -220,7 +265,7 @@ static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustu
 // per-frustum loop is a real loop, so registers do not scale with the number of frusta (8 unrolled copies needed 172 VGPRs and
 // 600 spilled SGPRs); FS is the stride of a chunk's visibility bits.
 #ifndef LMX_CULL8_PROBE
-#define LMX_CULL8_PROBE 0     // timing probes of k_cull_tile<F = 0> (tools/build_variant.py; results wrong): 1 = tile-level tests only, 2 = no cell classification, 4 = no sphere tests, 8 = spheres / ids not fetched, 16 = nothing written
+#define LMX_CULL8_PROBE 0     // timing probes of k_cull_tile<F = 0> (tools/build_variant.py; results wrong): 1 = tile-level tests only, 2 = no cell classification, 4 = no sphere tests (everything tested counts as culled), 8 = spheres / ids not fetched, 16 = nothing written
 #endif
 #ifndef LMX_CULL8_SHAPE
 #define LMX_CULL8_SHAPE 0     // block shape of the 5..8-frusta kernel over 1024-sphere tiles: 0 = 4 waves x 4 chunks, 1 = 8 waves x 2 chunks
@@ -233,9 +278,13 @@ static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustu
 #else
 #define LMX_CULL_SGPR_ATTR
 #endif
+// (several frusta) at least 5 waves per SIMD, i.e. at most 96 VGPRs: the residency the LDS of the cell records allows anyway (5 blocks of 4
+// waves per CU) - and with a register budget of <= 256 the compiler selects the VGPR form of the MFMA (accumulators in plain VGPRs, where the
+// ds_reads put the plane distances and the v_min3 read the results) instead of AGPR accumulators + a v_accvgpr_write / _read per value
+#define LMX_CULL_WAVES_ATTR(F) __attribute__((amdgpu_waves_per_eu((F) == 1 ? 1 : 5)))
 
 template <int F, int WAVES, int CHW, int GRP, int LANEPAR, int SLOTS_I>
-__global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(const FrustaArg fr_arg, const float4* __restrict__ g_spheres, const int32_t* __restrict__ g_ids,
+__global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(F) void k_cull_tile(const FrustaArg fr_arg, const float4* __restrict__ g_spheres, const int32_t* __restrict__ g_ids,
 	const ChunkHdr* __restrict__ g_hdr, const CellKey* __restrict__ g_tile_cells, const uint32_t* __restrict__ g_tile_tab, const TileBox* __restrict__ g_tile_box,
 	const uint32_t* __restrict__ g_win_base, int32_t* __restrict__ g_out_ids, uint32_t* __restrict__ g_counts, uint32_t* __restrict__ g_counts_next, const TileScalars a) {
 	constexpr bool SLOTS = SLOTS_I != 0; // also write the slot of every visible id (CullOut::slots)
@@ -438,6 +487,58 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 		}
 	}
 
+	// (several frusta) per-tile operands of the matrix-pipe pre-test: the plane rows of each group of four frusta (the A operands of the
+	// two instructions: {nx | ny} and {nz | 1} by half-wave), where a lane's two frustum slots keep their cell records, and which of
+	// them the tile-level test left MIXED (only those can leave a sphere undecided: the records of the others were never written)
+	constexpr int NG = F != 1 ? (WAVES == 4 ? 2 : 1) : 1; // groups of four frusta: the 5..8-frusta shape has 4 waves, the 2..4-frusta shape 8
+	constexpr bool PRETEST = F != 1 && LMX_CULL8_MFMA != 0;
+	constexpr bool PRE_BF16 = LMX_CULL8_MFMA == 2; // the bf16 form: ONE v_mfma_f32_32x32x16_bf16 per (32 spheres, four frusta) instead of two f32-input ones
+	float pre_a1[NG], pre_a2[NG]; // f32 form: {nx | ny}, {nz | 1}
+	u32x4_t pre_ab[NG];           // bf16 form: eight K slots per half-wave
+	uint32_t pre_off[NG][2];
+	uint64_t pre_care[NG][2];
+	// The pre-test evaluates ALL frusta of a group for a chunk at once; the exact loop only the (chunk, frustum) pairs with a lane in a
+	// CELL_TEST cell. A tile that few frusta left MIXED (a sparse scene: most cells are settled by the cell tests) is cheaper there.
+#ifndef LMX_CULL8_MFMA_MIN_MIXED
+#define LMX_CULL8_MFMA_MIN_MIXED 3
+#endif
+	bool pretest_tile = false;
+	if constexpr (PRETEST) {
+		uint32_t n_mixed = 0;
+#pragma unroll 1
+		for (int f = 0; f < nf; ++f) n_mixed += ((st_bits >> (2 * f)) & 3u) == TILE_MIXED ? 1u : 0u;
+		pretest_tile = any_mixed && n_mixed >= (uint32_t)LMX_CULL8_MFMA_MIN_MIXED;
+		if (pretest_tile) {
+			const uint32_t row = lane & 31u, k = lane >> 5;
+			const uint32_t rp = (row & 3u) + 4u * ((row >> 3) & 1u), rh = (row >> 2) & 1u, rq = row >> 4;
+#pragma unroll
+			for (int gq = 0; gq < NG; ++gq) {
+				const uint32_t rf = 4u * gq + 2u * rh + rq;
+				const bool row_on = rp < 6u && rf < (uint32_t)nf;
+				const uint32_t fs = row_on ? rf : 0u, ps = row_on ? rp : 0u;
+				const float v1 = s_nrm[fs][(k ? 6u : 0u) + ps], v2 = s_nrm[fs][12u + ps];
+				pre_a1[gq] = row_on ? v1 : 0.f;
+				pre_a2[gq] = row_on ? (k ? 1.0f : v2) : 0.f;
+				if constexpr (PRE_BF16) {
+					// K slots of a plane row: lanes < 32 hold {nx1 ny1 nz1 1 nx1 ny1 nz1 1} (against {x1 y1 z1 r1 x2 y2 z2 r2} of a sphere), lanes >= 32
+					// {nx2 ny2 nz2 0 0 0 0 0} (against {x1 y1 z1 r1 0 0 0 0}): n1 = bf16(n), n2 = bf16(n - n1), both rounded to nearest
+					const float nx = row_on ? s_nrm[fs][ps] : 0.f, ny = row_on ? s_nrm[fs][6u + ps] : 0.f, nz = row_on ? s_nrm[fs][12u + ps] : 0.f;
+					const uint32_t hi_xy = pk_bf16(nx, ny), hi_z1 = pk_bf16(nz, row_on ? 1.0f : 0.f);
+					const uint32_t lo_xy = pk_bf16(nx - __uint_as_float(hi_xy << 16), ny - __uint_as_float(hi_xy & 0xffff0000u)), lo_z0 = pk_bf16(nz - __uint_as_float(hi_z1 << 16), 0.f);
+					pre_ab[gq] = k ? u32x4_t{lo_xy, lo_z0, 0u, 0u} : u32x4_t{hi_xy, hi_z1, hi_xy, hi_z1};
+				}
+#pragma unroll
+				for (int q = 0; q < 2; ++q) {
+					const uint32_t fl = 4u * gq + 2u * k + q; // the frustum whose six values this lane finds in accumulators 8 q .. 8 q + 5
+					pre_off[gq][q] = (fl < (uint32_t)nf ? fl : (uint32_t)nf - 1u) * a.cell_cap * 3u;
+					const uint32_t f_lo = 4u * gq + q, f_hi = f_lo + 2u;
+					pre_care[gq][q] = (f_lo < (uint32_t)nf && ((st_bits >> (2 * f_lo)) & 3u) == TILE_MIXED ? 0x00000000ffffffffull : 0ull) |
+						(f_hi < (uint32_t)nf && ((st_bits >> (2 * f_hi)) & 3u) == TILE_MIXED ? 0xffffffff00000000ull : 0ull);
+				}
+			}
+		}
+	}
+
 	// B. this wave's CHW chunks, in groups of GRP so that at most GRP chunks' worth of spheres are live in registers
 	// (VGPR count decides how many tiles a CU keeps in flight). Fetching the headers at kernel start through lanes (one vector
 	// load + v_readlane) instead of scalar loads here measured no gain, HBM-cold included: other waves cover the load.
@@ -537,6 +638,84 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			uint32_t word_or = 0; // the lane's classes over the group's chunks
 #pragma unroll
 			for (int i = 0; i < GRP; ++i) word_or |= cls_word[i];
+			// The pre-test on the matrix pipe (see "sphere x plane pre-test" above): per chunk with a lane in a CELL_TEST cell, the verdict
+			// bits of all frusta; a chunk with an undecided (sphere, frustum) pair of a MIXED frustum is left to the exact loop below.
+			uint32_t exact_chunks = (1u << GRP) - 1u; // chunks the exact loop evaluates
+			if constexpr (PRETEST) {
+				if (pretest_tile) {
+					exact_chunks = 0;
+#pragma unroll
+					for (int i = 0; i < GRP; ++i) {
+						if (!need_sphere[i]) continue; // wave-uniform
+						const float x = spv[i].x, y = spv[i].y, z = spv[i].z, r = spv[i].w;
+						// eps of the lane's own sphere (the bound above; formed 2^27 too large so that huge operands end in inf)
+						const float gs = ((__builtin_fabsf(x) + __builtin_fabsf(y)) + __builtin_fabsf(z)) * a.pretest_n1s + __builtin_fabsf(r) * 134217728.0f;
+						const float eps_own = gs * (PRE_BF16 ? 6.821210263296962e-13f /* 1.5 x 2^-14 x 2^-27 */ : 1.4210854715202004e-14f /* 2^-46 = 32 u 2^-27 */) + 7.52316384526264e-37f /* tau = 2^-120 */;
+						// what each half-wave needs of the partner sphere: [own | partner] per column group
+						const auto sw_eps = __builtin_amdgcn_permlane32_swap(__float_as_uint(eps_own), __float_as_uint(eps_own), false, false);
+						const auto sw_loc = __builtin_amdgcn_permlane32_swap(local[i] * 3u, local[i] * 3u, false, false);
+						// f32 form: K = 0: x, K = 1: y | K = 2: z, K = 3: r. bf16 form: {x1 y1 z1 r1 x2 y2 z2 r2} for the lanes < 32, {x1 y1 z1 r1 0 0 0 0} for the
+						// others (v1 = bf16(v), v2 = bf16(v - v1), round to nearest: v_cvt_pk_bf16_f32; v - v1 is exact)
+						uint32_t o0 = __float_as_uint(x), o1 = __float_as_uint(y), o2 = __float_as_uint(z), o3 = __float_as_uint(r), o1b = 0, o3b = 0;
+						if constexpr (PRE_BF16) {
+							o0 = pk_bf16(x, y);
+							o2 = pk_bf16(z, r);
+							o1 = pk_bf16(x - __uint_as_float(o0 << 16), y - __uint_as_float(o0 & 0xffff0000u));
+							o3 = pk_bf16(z - __uint_as_float(o2 << 16), r - __uint_as_float(o2 & 0xffff0000u));
+						}
+						const auto sw_xy = PRE_BF16 ? __builtin_amdgcn_permlane32_swap(o0, o0, false, false) : __builtin_amdgcn_permlane32_swap(o0, o1, false, false);
+						const auto sw_zr = PRE_BF16 ? __builtin_amdgcn_permlane32_swap(o2, o2, false, false) : __builtin_amdgcn_permlane32_swap(o2, o3, false, false);
+						const auto sw_lo0 = __builtin_amdgcn_permlane32_swap(o1, o1b, false, false), sw_lo1 = __builtin_amdgcn_permlane32_swap(o3, o3b, false, false); // (bf16 form only)
+						uint64_t unsure = 0; // lanes with an undecided pair (wave-uniform accumulation of compare masks)
+						uint32_t w_cg[2];
+#pragma unroll
+						for (int cg = 0; cg < 2; ++cg) { // column group: spheres 32 cg .. 32 cg + 31 of the chunk
+							const float eps = __uint_as_float(sw_eps[cg]);
+							const float b1 = __uint_as_float(sw_xy[cg]), b2 = __uint_as_float(sw_zr[cg]);
+							f32x16 acc[NG];
+#pragma unroll
+							for (int gq = 0; gq < NG; ++gq) {
+								// the (cell, frustum) records of the lane's two frustum slots: three ds_read_b64 each, straight into accumulators 8 q .. 8 q + 5
+								// (6, 7 stay undefined - rows of zero planes, never read: spelled as shuffles with undefined lanes, a zero there costs a v_mov each)
+								v8f_t half[2];
+#pragma unroll
+								for (int q = 0; q < 2; ++q) {
+									const v2f* rec = s_d2 + pre_off[gq][q] + sw_loc[cg];
+									const v2f d01 = rec[0], d23 = rec[1], d45 = rec[2];
+									const v4f_t lo = __builtin_shufflevector(d01, d23, 0, 1, 2, 3), hi = __builtin_shufflevector(d45, d45, 0, 1, -1, -1);
+									half[q] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+								}
+								acc[gq] = __builtin_shufflevector(half[0], half[1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+							}
+							if constexpr (PRE_BF16) {
+								const u32x4_t bb = {sw_xy[cg], sw_zr[cg], sw_lo0[cg], sw_lo1[cg]};
+#pragma unroll
+								for (int gq = 0; gq < NG; ++gq) acc[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, pre_ab[gq]), __builtin_bit_cast(bf16x8_t, bb), acc[gq], 0, 0, 0);
+							} else {
+#pragma unroll
+								for (int gq = 0; gq < NG; ++gq) acc[gq] = __builtin_amdgcn_mfma_f32_32x32x2f32(pre_a1[gq], b1, acc[gq], 0, 0, 0);
+#pragma unroll
+								for (int gq = 0; gq < NG; ++gq) acc[gq] = __builtin_amdgcn_mfma_f32_32x32x2f32(pre_a2[gq], b2, acc[gq], 0, 0, 0);
+							}
+							uint32_t w = 0;
+#pragma unroll
+							for (int gq = 0; gq < NG; ++gq) {
+#pragma unroll
+								for (int q = 0; q < 2; ++q) {
+									const float m = min3_drop_nan(min3_drop_nan(acc[gq][8 * q], acc[gq][8 * q + 1], acc[gq][8 * q + 2]), acc[gq][8 * q + 3], min3_drop_nan(acc[gq][8 * q + 4], acc[gq][8 * q + 5], acc[gq][8 * q])); // (the first value twice: three v_min3)
+									w |= m < -eps ? 1u << (8 * gq + 2 * q) : 0u;
+									unsure |= __ballot(!(__builtin_fabsf(m) > eps)) & pre_care[gq][q];
+								}
+							}
+							w_cg[cg] = w << (4u * (lane >> 5)); // frustum 4 g + 2 h + q: bit 8 g + 4 h + 2 q
+						}
+						// [own column group | the other one] back: lanes < 32 own group 0's bits, lanes >= 32 group 1's; the partner lane holds the other four frusta
+						const auto sw_w = __builtin_amdgcn_permlane32_swap(w_cg[0], w_cg[1], false, false);
+						culled2[i] = sw_w[0] | sw_w[1];
+						if (unsure != 0) exact_chunks |= 1u << i;
+					}
+				}
+			}
 			// Several frusta over the same spheres (the frame's shadow cascades, BASELINE config 5). Rounds 2 / 3 ran the single-frustum body
 			// per (chunk, frustum): class from LDS -> wait -> branch -> frustum normals from the kernarg segment + distances from LDS ->
 			// wait -> test, i.e. two serialized waits and an 18-dword scalar load per 64 spheres and frustum - 224 us for 10 M spheres
@@ -548,8 +727,16 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 			// normals - the cascades of one light - sharing a sphere's rounded dot products, 7 instead of 21 packed operations per plane set:
 			// 154 us against 142 on the all-test scene - 24 more live VGPRs, a fifth block per CU only with spills (205 us), four blocks 166 us;
 			// all of a frustum's cell records read in one batch instead of two chunks at a time: 149 against 142.)
+			if constexpr (PRETEST) {
+#pragma unroll
+				for (int i = 0; i < GRP; ++i) culled2[i] = (exact_chunks >> i) & 1u ? 0u : culled2[i]; // (wave-uniform: an undecided chunk starts over)
+			}
+			if (LMX_CULL8_PROBE & 4) { // (timing probe: no sphere tests - every tested sphere counts as culled, so that what follows has the real launch's volume)
+#pragma unroll
+				for (int i = 0; i < GRP; ++i) culled2[i] = 0xffffu;
+			}
 #pragma unroll 1
-			for (int f = 0; f < nf; ++f) {
+			for (int f = 0; f < (exact_chunks != 0 ? nf : 0); ++f) {
 				const uint32_t st = (st_bits >> (2 * f)) & 3u;
 				if (st == TILE_REJECT) continue; // nothing of this tile is visible in frustum f
 				if (LMX_CULL8_PROBE & 4) continue; // (timing probe: no sphere tests)
@@ -561,7 +748,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR void k_cull_tile(con
 				if (mixed) {
 #pragma unroll
 					for (int i = 0; i < GRP; ++i) {
-						if (need_sphere[i] && __ballot(((cls_word[i] >> (2 * f)) & 3u) == CELL_TEST) != 0) test_chunks |= 1u << i;
+						if (need_sphere[i] && ((exact_chunks >> i) & 1u) && __ballot(((cls_word[i] >> (2 * f)) & 3u) == CELL_TEST) != 0) test_chunks |= 1u << i;
 					}
 				}
 				// the frustum's plane normals out of LDS (phase 0 put them there), every lane the same address: a broadcast read. (From the
@@ -955,6 +1142,18 @@ hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, ui
 	a.cnt_frustum_stride = out.cnt_frustum_stride;
 	a.n_zero = out.n_zero;
 	a.out_slots = out.slots;
+	{ // the pre-test's bound scale: 2^27 x the largest |n|_1 of the call's planes, rounded up; anything not finite switches the pre-test off
+		float n1 = 0.f;
+		bool finite = true;
+		for (int f = 0; f < n_frusta; ++f) {
+			for (int k = 0; k < 6; ++k) {
+				const float v = (__builtin_fabsf(fr.f[f].nx[k]) + __builtin_fabsf(fr.f[f].ny[k])) + __builtin_fabsf(fr.f[f].nz[k]);
+				finite = finite && v <= 3.0e38f; // (false for NaN)
+				n1 = v > n1 ? v : n1;
+			}
+		}
+		a.pretest_n1s = finite ? n1 * 1.000001f * 134217728.0f : __builtin_inff();
+	}
 	if (out.ev_start != nullptr) // profiling: the events receive the dispatch's own begin / end timestamps
 		hipExtLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, LANEPAR, SLOTS_I>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, out.ev_start, out.ev_stop, 0, fr,
 			v.spheres, v.ids, v.hdr, v.tile_cells[K], v.tile_tab[K], v.tile_box[K], out.win_base, out.ids, out.counts, out.counts_next, a);

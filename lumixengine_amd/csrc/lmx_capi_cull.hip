@@ -17,6 +17,7 @@
 #include "lmx_context.h"
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <thread>
 
@@ -1440,6 +1441,10 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 		po.ids = out.ids + (size_t)f0 * out.stride;
 		if (out.slots) po.slots = out.slots + (size_t)f0 * out.stride;
 		po.counts = out.counts + (size_t)f0 * cnt_frustum_stride;
+		if (f0 != 0) { // the first pass of the cull has cleared the next cull's counters already
+			po.counts_next = nullptr;
+			po.n_zero = 0;
+		}
 		// 2048-sphere tiles of 4 waves x 8 chunks measured best in every regime (default camera, all-accept, all-test; 10 M and 100 M).
 		// With all 8 chunks' loads in flight (variant 4, 66 VGPRs) a launch in which few tiles survive the tile-level test is 7 % shorter
 		// (its duration is the latency of the surviving tiles), a launch that streams the whole set 2 % longer: picked by how much of the
@@ -1623,10 +1628,18 @@ static int cull_map_begin(LmxContext* ctx, CullView& v, uint32_t first, uint32_t
 	// first cut stopped at 64 k ids). Larger lists keep the device record + one DMA copy of the ids the last frame needed: a kernel that
 	// streams many megabytes over PCIe holds its CUs for the duration.
 	int32_t* host_dev = nullptr;
-	bool zero_copy = cs.map_zero_copy;
-	for (uint32_t k = 0; k < n && zero_copy; ++k) zero_copy = v.map_guess[first + k] <= cs.map_zero_copy_max;
+	// (only once a count has been read back on this view: the initial guess says nothing about the list, and a zero-copy record streams
+	// ALL its ids over PCIe with the CUs held - a first map of a 10 M-id list would be tens of megabytes of posted writes)
+	bool zero_copy = cs.map_zero_copy && v.map_seen;
+	for (uint32_t k = 0; k < n && zero_copy; ++k) zero_copy = v.map_guess[first + k].load(std::memory_order_relaxed) <= cs.map_zero_copy_max;
 	if (zero_copy && hipHostGetDevicePointer(reinterpret_cast<void**>(&host_dev), v.map_host, 0) != hipSuccess) zero_copy = false;
-	v.map_begin_zero_copy = zero_copy;
+	CullView::MapTicket& tk = v.ticket;
+	tk.n = 0;
+	tk.zero_copy = zero_copy;
+	tk.host = reinterpret_cast<int32_t*>(v.map_host);
+	tk.rec = v.map_rec.p;
+	tk.words = v.map_words;
+	memcpy(tk.out_cap, v.out_cap, sizeof(tk.out_cap));
 	{ // the records of all n frusta: ONE launch (a frame's six views cost six launch gaps otherwise)
 		int32_t* rec = (zero_copy ? host_dev : v.map_rec.p) + (size_t)first * v.map_words;
 		if (v.map_words > 0xffffffffull) return fail(ctx, LMX_ERR_CAPACITY, "record stride exceeds 32 bits");
@@ -1637,13 +1650,14 @@ static int cull_map_begin(LmxContext* ctx, CullView& v, uint32_t first, uint32_t
 	for (uint32_t k = 0; k < n; ++k) {
 		const uint32_t f = first + k;
 		const int32_t* rec = v.map_rec.p + (size_t)f * v.map_words;
-		v.map_begin_guess[k] = zero_copy ? (size_t)v.out_stride : std::min<size_t>(v.out_stride, v.map_guess[f]);
+		tk.guess[k] = zero_copy ? (size_t)v.out_stride : std::min<size_t>(v.out_stride, v.map_guess[f].load(std::memory_order_relaxed));
 		if (!zero_copy)
-			LMX_HIP(ctx, hipMemcpyAsync(reinterpret_cast<int32_t*>(v.map_host) + (size_t)f * v.map_words, rec, (MAX_TYPES + v.map_begin_guess[k]) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+			LMX_HIP(ctx, hipMemcpyAsync(tk.host + (size_t)f * v.map_words, rec, (MAX_TYPES + tk.guess[k]) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
 	}
 	LMX_HIP(ctx, hipEventRecord(v.map_event, ctx->stream));
-	v.map_begin_first = first;
-	v.map_begin_n = n;
+	tk.first = first;
+	tk.n = n;
+	v.map_seen = true; // (the matching map_end reads the counts before the next map_begin on this view can run)
 	return LMX_OK;
 }
 
@@ -1653,7 +1667,10 @@ static int cull_map_end(LmxContext* ctx, CullView& v, uint32_t first, uint32_t n
 		explicit Locked(LmxContext* c_) : c(c_) { c->lock.lock(); }
 		~Locked() { c->lock.unlock(); }
 	};
-	if (!v.map_event || v.map_begin_n != n || v.map_begin_first != first) {
+	// everything read here is the view's ticket (filled by map_begin under the lock, untouched until the next map_begin on this view), its
+	// event and the pinned buffer the ticket names
+	const CullView::MapTicket& tk = v.ticket;
+	if (!v.map_event || tk.n != n || tk.first != first) {
 		Locked l(ctx);
 		return fail(ctx, LMX_ERR_NOT_BUILT, "lmx_cull_map_end without a matching lmx_cull_map_begin on this view");
 	}
@@ -1664,31 +1681,32 @@ static int cull_map_end(LmxContext* ctx, CullView& v, uint32_t first, uint32_t n
 	bool more = false;
 	for (uint32_t k = 0; k < n; ++k) {
 		const uint32_t f = first + k;
-		int32_t* host = reinterpret_cast<int32_t*>(v.map_host) + (size_t)f * v.map_words;
+		int32_t* host = tk.host + (size_t)f * tk.words;
 		const uint32_t* h = reinterpret_cast<const uint32_t*>(host);
 		size_t total = 0;
 		for (int t = 0; t < MAX_TYPES; ++t) {
-			if (h[t] > v.out_cap[t]) {
+			if (h[t] > tk.out_cap[t]) {
 				Locked l(ctx);
-				return fail(ctx, LMX_ERR_HIP, "corrupt count %u > %u", h[t], v.out_cap[t]);
+				return fail(ctx, LMX_ERR_HIP, "corrupt count %u > %u", h[t], tk.out_cap[t]);
 			}
 			out_counts[k * MAX_TYPES + t] = h[t];
 			total += h[t];
 		}
-		if (total > v.map_begin_guess[k] && !v.map_begin_zero_copy) { // the list outgrew the guess: fetch the rest (second wait, this frame only)
+		if (total > tk.guess[k] && !tk.zero_copy) { // the list outgrew the guess: fetch the rest (second wait, this frame only)
 			Locked l(ctx);
-			LMX_HIP(ctx, hipMemcpyAsync(host + MAX_TYPES + v.map_begin_guess[k], v.map_rec.p + (size_t)f * v.map_words + MAX_TYPES + v.map_begin_guess[k],
-				(total - v.map_begin_guess[k]) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+			LMX_HIP(ctx, hipSetDevice(ctx->device)); // (this thread may never have selected the context's device)
+			LMX_HIP(ctx, hipMemcpyAsync(host + MAX_TYPES + tk.guess[k], tk.rec + (size_t)f * tk.words + MAX_TYPES + tk.guess[k],
+				(total - tk.guess[k]) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
 			more = true;
 		}
-		v.map_guess[f] = total + total / 4 + 1024;
+		v.map_guess[f].store((uint32_t)std::min<size_t>(total + total / 4 + 1024, 0xffffffffu), std::memory_order_relaxed);
 		out_ids[k] = host + MAX_TYPES;
 	}
 	if (more) {
 		Locked l(ctx);
 		LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	}
-	v.map_begin_n = 0;
+	v.ticket.n = 0;
 	return LMX_OK;
 }
 
@@ -1751,6 +1769,43 @@ int lmx_cull_map_end(LmxContext* ctx, uint32_t view, uint32_t n_frusta, const in
 	if (!ctx) return LMX_ERR_INVALID_ARGUMENT; // (LMX_CHECK_CTX selects the context's device: not needed to wait for an event and read host memory)
 	if (view >= LMX_MAX_VIEWS || !out_counts || !out_ids) return LMX_ERR_INVALID_ARGUMENT;
 	return cull_map_end(ctx, ctx->cull.views[view], 0, n_frusta, out_ids, out_counts);
+}
+
+// Result slots that cannot alias (CullingSystem::cull returns an independent list per call, culling_system.cpp:321-369; callers
+// pipeline.cpp:1036-1045, :3380, editor/scene_view.cpp:144): a slot handed out here is not handed out again before its holder has
+// released it, i.e. before it has copied the ids out of the slot's pinned record. With every slot taken the caller waits for the
+// next release - bounded: a holder that never releases turns into LMX_ERR_BUSY, not into a hang.
+int lmx_cull_view_acquire(LmxContext* ctx, uint32_t* view, uint32_t timeout_ms) {
+	if (!ctx || !view) return LMX_ERR_INVALID_ARGUMENT;
+	CullState& cs = ctx->cull;
+	std::unique_lock<std::mutex> l(cs.views_mutex);
+	constexpr uint32_t ALL = (1u << LMX_MAX_VIEWS) - 1u;
+	if ((cs.views_busy & ALL) == ALL) {
+		const bool got = cs.views_cv.wait_for(l, std::chrono::milliseconds(timeout_ms), [&] { return (cs.views_busy & ALL) != ALL; });
+		if (!got) return LMX_ERR_BUSY; // (no fail(): the error string belongs to the context's lock, which this path never takes)
+	}
+	for (uint32_t k = 0; k < (uint32_t)LMX_MAX_VIEWS; ++k) { // round robin: consecutive culls of a frame land on different slots (their buffers stay sized for their view)
+		const uint32_t s = (cs.views_next + k) % (uint32_t)LMX_MAX_VIEWS;
+		if (!((cs.views_busy >> s) & 1u)) {
+			cs.views_busy |= 1u << s;
+			cs.views_next = (s + 1u) % (uint32_t)LMX_MAX_VIEWS;
+			*view = s;
+			return LMX_OK;
+		}
+	}
+	return LMX_ERR_BUSY; // (unreachable)
+}
+
+int lmx_cull_view_release(LmxContext* ctx, uint32_t view) {
+	if (!ctx || view >= (uint32_t)LMX_MAX_VIEWS) return LMX_ERR_INVALID_ARGUMENT;
+	CullState& cs = ctx->cull;
+	{
+		std::lock_guard<std::mutex> l(cs.views_mutex);
+		if (!((cs.views_busy >> view) & 1u)) return LMX_ERR_INVALID_ARGUMENT; // released twice / never acquired
+		cs.views_busy &= ~(1u << view);
+	}
+	cs.views_cv.notify_one();
+	return LMX_OK;
 }
 
 int lmx_cull_bind_output(LmxContext* ctx, uint32_t view, void* d_ids, size_t ids_capacity, void* d_counts) {

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -76,13 +78,23 @@ struct CullView {
 	// lmx_cull_map_all: [MAX_TYPES counts | ids, type 0 first] gathered into map_rec, copied into pinned host memory
 	void* map_host = nullptr;
 	size_t map_words = 0;
-	size_t map_guess[LMX_MAX_FRUSTA] = {4096, 4096, 4096, 4096, 4096, 4096, 4096, 4096}; // ids (per frustum) the next call copies before it knows the count
+	// ids (per frustum) the next call copies before it knows the count. Written by lmx_cull_map_end WITHOUT the context lock (a hint; relaxed atomics)
+	std::atomic<uint32_t> map_guess[LMX_MAX_FRUSTA] = {{4096}, {4096}, {4096}, {4096}, {4096}, {4096}, {4096}, {4096}};
+	bool map_seen = false;   // a count has been read back on this view: until then nothing is known about the list's size (no zero-copy record)
 	size_t map_frusta = 0;   // record areas the buffers were sized for
 	DevBuf<int32_t> map_rec;
 	hipEvent_t map_event = nullptr; // recorded behind the record's copies (lmx_cull_map_begin): lmx_cull_map_end waits for THIS view only
-	size_t map_begin_guess[LMX_MAX_FRUSTA] = {}; // what lmx_cull_map_begin asked the copies for
-	uint32_t map_begin_first = 0, map_begin_n = 0;
-	bool map_begin_zero_copy = false; // the pack kernel wrote the whole record into map_host itself
+	// What lmx_cull_map_begin enqueued, as lmx_cull_map_end needs it: map_end runs WITHOUT the context lock and reads nothing else of the
+	// view (out_cap, map_words, map_host are touched by locked code paths of other threads: recompute_out_layout, the counter padding)
+	struct MapTicket {
+		uint32_t first = 0, n = 0;      // n == 0: no map_begin outstanding
+		bool zero_copy = false;         // the pack kernel wrote the whole record into the pinned buffer itself
+		int32_t* host = nullptr;        // the pinned buffer
+		const int32_t* rec = nullptr;   // the device records
+		size_t words = 0;               // words per record area
+		size_t guess[LMX_MAX_FRUSTA] = {}; // ids the copies were asked for
+		uint32_t out_cap[MAX_TYPES] = {};
+	} ticket;
 	DevBuf<uint32_t> map_pref, map_start;
 	DevBuf<int32_t> pack_rec; // lmx_cull_pack_device: the packed record of one frustum, left on the device
 	size_t pack_words = 0;
@@ -248,7 +260,7 @@ struct CullState : CullSet {
 	DevBuf<uint8_t> d_shard_type;
 	uint32_t type_start[MAX_TYPES] = {}, type_cap[MAX_TYPES] = {};
 	// ---- tuning (lmx_cull_set_option) -------------------------------------------------------------------------
-	uint32_t pass_width = 0;   // frusta tested per pass over the static set; 0 = automatic (all of them for a set of <= 1 M spheres, else 1)
+	uint32_t pass_width = 0;   // frusta tested per pass over the static set; 0 = automatic (all of them for a set of <= 32 M spheres, else 1: lmx_cull)
 	int tile_variant = -1;     // -1: chosen per cull from the frustum's coverage of the scene
 	uint32_t overflow_reserve = 0; // LMX_CULL_OPT_OVERFLOW_RESERVE: slots kept free in the dynamic set for entities added / re-celled between compactions
 	bool device_owns_bound = false; // LMX_CULL_OPT_DEVICE_OWNS_BOUND: set* calls on hierarchy-bound entities are dropped
@@ -264,6 +276,11 @@ struct CullState : CullSet {
 	uint32_t cnt_pad = 32;     // words between shard counters (32 = one 128-byte line each)
 	uint32_t out_total = 0;    // ids per frustum row = sum of the shard capacities
 	CullView views[LMX_MAX_VIEWS];
+	// lmx_cull_view_acquire / _release: result slots whose record a caller is still reading are not handed out again. Own mutex (not the
+	// context's recursive lock: a waiter must be able to sleep while other threads enqueue and release)
+	std::mutex views_mutex;
+	std::condition_variable views_cv;
+	uint32_t views_busy = 0, views_next = 0;
 };
 
 struct WorldState {

@@ -15,9 +15,12 @@
 // object, as the reference's CullingSystem and RenderModuleImpl::onModelInstanceMoved work on one object): every call takes
 // the context's own recursive lock (lmx_ctx_lock), not a lock of this adapter. A cull() holds it only while it ENQUEUES (the cull,
 // the pack of its record, the copy into the view's pinned buffer: lmx_cull_map_begin); the wait for its own view's event and the
-// page building (lmx_cull_map_end, toPages) run outside, so concurrent views overlap everything but the enqueue. Each cull() uses
-// its own result slot (LMX_MAX_VIEWS of them in flight); cullMany() culls all views of a frame in one pass over the spheres with
-// one host wait (INTEGRATION.md shows the Pipeline change that calls it).
+// page building (lmx_cull_map_end, toPages) run outside, so concurrent views overlap everything but the enqueue. Each cull()
+// RESERVES its result slot (lmx_cull_view_acquire) before it enqueues and releases it when the ids are in the engine's pages: the
+// reference hands every caller an independent list (culling_system.cpp:321-369), so a slot whose record is still being read is never
+// culled into again - with all LMX_MAX_VIEWS slots held, the next caller waits for a release (any number of concurrent callers is
+// correct; LMX_MAX_VIEWS of them overlap). cullMany() culls all views of a frame in one pass over the spheres with one host wait
+// (INTEGRATION.md shows the Pipeline change that calls it).
 #pragma once
 
 #include <cstdio>
@@ -110,13 +113,14 @@ struct GpuCullingSystem final : CullingSystem {
 	bool cullMany(const ShiftedFrustum* frusta, u32 n_frusta, u8 type, CullResult** out) {
 		for (u32 f = 0; f < n_frusta; ++f) out[f] = nullptr;
 		if (!m_ctx || n_frusta == 0 || n_frusta > LMX_MAX_FRUSTA) return false;
-		uint32_t view;
+		ViewSlot slot(m_ctx); // reserved until the ids are in the engine's pages (released by the destructor)
+		if (!slot.ok) return busy();
+		const uint32_t view = slot.view;
 		{ // enqueue under the context's lock: the cull, the pack of its records and their copy into the view's pinned buffer
 			CtxLock guard(m_ctx);
 			uint32_t n_static = 0, n_bound = 0, n_overflow = 0;
 			if (!check(lmx_cull_update_stats(m_ctx, &n_static, &n_bound, &n_overflow, nullptr))) return false;
 			if (n_static + n_bound + n_overflow == 0) return true; // no cells: culling_system.cpp:322
-			view = m_next_view++ % LMX_MAX_VIEWS;
 			if (!check(lmx_cull(m_ctx, view, reinterpret_cast<const LmxShiftedFrustum*>(frusta), n_frusta, type))) return false;
 			if (!check(lmx_cull_map_begin(m_ctx, view, n_frusta))) return false;
 		}
@@ -136,6 +140,25 @@ private:
 		CtxLock& operator=(const CtxLock&) = delete;
 		LmxContext* ctx;
 	};
+
+	// A result slot of the context, reserved for the lifetime of this object. Taken BEFORE the context lock (lmx_cull_view_acquire may
+	// wait for another caller's release, and that caller needs the lock to get there).
+	struct ViewSlot {
+		explicit ViewSlot(LmxContext* c) : ctx(c) { ok = c && lmx_cull_view_acquire(c, &view, 5000) == LMX_OK; }
+		~ViewSlot() { if (ok) lmx_cull_view_release(ctx, view); }
+		ViewSlot(const ViewSlot&) = delete;
+		ViewSlot& operator=(const ViewSlot&) = delete;
+		LmxContext* ctx;
+		uint32_t view = 0;
+		bool ok = false;
+	};
+
+	bool busy() {
+		CtxLock guard(m_ctx);
+		m_error = "every result slot stayed reserved for 5 s: a caller never returned from cull()";
+		report();
+		return false;
+	}
 
 	void report() { // the reference's error convention: log and carry on (no exceptions)
 #ifdef LMX_WITH_LUMIX_HEADERS
@@ -195,19 +218,20 @@ private:
 
 	CullResult* cullInternal(const ShiftedFrustum& frustum, u8 type) {
 		if (!m_ctx) return nullptr;
-		uint32_t view;
+		ViewSlot slot(m_ctx); // reserved until toPages() has copied the ids out of the slot's pinned record
+		if (!slot.ok) { busy(); return nullptr; }
+		const uint32_t view = slot.view;
 		{ // enqueue under the context's lock (several views may be in flight concurrently, pipeline.cpp:1036-1041: they only serialise HERE)
 			CtxLock guard(m_ctx);
 			uint32_t n_static = 0, n_bound = 0, n_overflow = 0;
 			if (!check(lmx_cull_update_stats(m_ctx, &n_static, &n_bound, &n_overflow, nullptr))) return nullptr;
 			if (n_static + n_bound + n_overflow == 0) return nullptr; // no cells: culling_system.cpp:322
-			view = m_next_view++ % LMX_MAX_VIEWS;
 			static_assert(sizeof(ShiftedFrustum) == sizeof(LmxShiftedFrustum), "layout");
 			if (!check(lmx_cull(m_ctx, view, reinterpret_cast<const LmxShiftedFrustum*>(&frustum), 1, type))) return nullptr;
 			if (!check(lmx_cull_map_begin(m_ctx, view, 1))) return nullptr;
 		}
 		// one host wait per cull, on this view's own event: totals + ids arrive as one record in the library's pinned host memory and
-		// are copied into the engine's pages here, outside the lock (up to LMX_MAX_VIEWS results in flight)
+		// are copied into the engine's pages here, outside the lock (the slot stays reserved until that copy is done)
 		uint32_t counts[LMX_MAX_TYPES];
 		const int32_t* ids = nullptr;
 		if (!checkUnlocked(lmx_cull_map_end(m_ctx, view, 1, &ids, counts))) return nullptr;
@@ -217,7 +241,6 @@ private:
 	PageAllocator& m_page_allocator;
 	LmxContext* m_ctx = nullptr;
 	bool m_shared = false;
-	uint32_t m_next_view = 0;
 	std::string m_error;
 };
 

@@ -295,6 +295,50 @@ void testCullingSystem(IAllocator& heap, PageAllocator& pages) {
 			   "every concurrent result identical to CullingSystemImpl\n", nf, ms_serial, ms_conc, nf, ms_many);
 	}
 
+	// More callers in flight than result slots (culling_system.cpp:321-369: every cull() returns an independent list; callers beyond the
+	// frame's six views: pipeline.cpp:3380, editor/scene_view.cpp:144). Twelve threads cull without any gate between them, every one
+	// of their lists is compared with CullingSystemImpl's: a slot that were culled into again while its previous holder still copies
+	// its ids out of the pinned record (round 4's round-robin slots did exactly that with a ninth caller) shows up as a torn list here.
+	// Half of the callers dawdle between the enqueue's result and its release by reading the list twice.
+	{
+		std::vector<Visible> want(nf);
+		for (u32 f = 0; f < nf; ++f) want[f] = flatten(ref->cull(frusta[f]), pages);
+		const u32 callers = 12;
+		std::atomic<int> bad{0}, failed{0};
+		std::vector<std::thread> threads;
+		for (u32 c = 0; c < callers; ++c)
+			threads.emplace_back([&, c] {
+				for (int k = 0; k < 40; ++k) {
+					const u32 f = (c + (u32)k) % nf;
+					CullResult* r = gpu->cull(frusta[f]);
+					if (!r) { failed.fetch_add(1); continue; }
+					Visible got = flatten(r, pages);
+					if (got.v != want[f].v) bad.fetch_add(1);
+				}
+			});
+		for (std::thread& t : threads) t.join();
+		CHECK(failed.load() == 0, "%d of the 12 callers' culls returned nothing", failed.load());
+		CHECK(bad.load() == 0, "%d culls of 12 concurrent callers differ from the reference's (a result slot was reused while it was being read)", bad.load());
+		// the reservation itself: with every slot held, a further acquire times out with LMX_ERR_BUSY instead of handing out a held slot
+		LmxContext* c = static_cast<GpuCullingSystem*>(gpu.get())->context();
+		uint32_t held[LMX_MAX_VIEWS], extra = 99;
+		uint32_t seen = 0;
+		for (int k = 0; k < LMX_MAX_VIEWS; ++k) {
+			CHECK(lmx_cull_view_acquire(c, &held[k], 100) == LMX_OK, "acquire %d failed", k);
+			seen |= 1u << held[k];
+		}
+		CHECK(seen == (1u << LMX_MAX_VIEWS) - 1u, "the %d acquired slots are not distinct: mask %x", (int)LMX_MAX_VIEWS, seen);
+		CHECK(lmx_cull_view_acquire(c, &extra, 50) == LMX_ERR_BUSY, "a ninth acquire succeeded with all slots held");
+		std::thread late([&] { std::this_thread::sleep_for(std::chrono::milliseconds(30)); lmx_cull_view_release(c, held[3]); });
+		CHECK(lmx_cull_view_acquire(c, &extra, 2000) == LMX_OK && extra == held[3], "a waiter was not woken by the release (got slot %u)", extra);
+		late.join();
+		CHECK(lmx_cull_view_release(c, extra) == LMX_OK, "release of the re-acquired slot failed");
+		for (int k = 0; k < LMX_MAX_VIEWS; ++k)
+			if (k != 3) CHECK(lmx_cull_view_release(c, held[k]) == LMX_OK, "release %d failed", k);
+		CHECK(lmx_cull_view_release(c, held[0]) != LMX_OK, "releasing a free slot was accepted");
+		printf("culling system: 12 concurrent callers x 40 culls on %d result slots: every list identical to CullingSystemImpl; a ninth reservation waits, times out with LMX_ERR_BUSY, is woken by a release\n", (int)LMX_MAX_VIEWS);
+	}
+
 	// what createGpuCullingSystem() switches on for the engine: the re-sort of the sorted set on a worker thread. 80 000 more entities
 	// push the overflow past the compaction threshold; updates and culls go on while the worker re-sorts, and after the sets have traded
 	// places every view is still the reference's.

@@ -55,6 +55,25 @@ def test_real_header_harness_one_context_per_world():
     assert "real-header harness OK" in r.stdout
     assert "identical to CullingSystemImpl" in r.stdout and "transforms bit-identical" in r.stdout
     assert "asynchronous compaction of" in r.stdout  # the worker re-sorted and the sets traded places under the update stream
+    assert "12 concurrent callers x 40 culls on 8 result slots: every list identical" in r.stdout  # more callers than result slots never alias
+
+
+def test_real_header_harness_on_the_simulated_device():
+    """CPU check of the same binary: the simulated device's library (tests/hostsim: the product's kernel + C-ABI sources compiled for the
+    CPU) is put in front of liblumix_mi355.so, so the adapter's slot reservation, the 12 concurrent callers and the module's hand-back run
+    here too - against the reference's CullingSystemImpl / World as on the GPU."""
+    import torch
+
+    _build()
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the -m gpu tests run the harness on it")
+    from tests.hostsim import build as hostsim_build
+
+    lib = hostsim_build.build()
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=900, env=dict(os.environ, LD_PRELOAD=lib))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "real-header harness OK" in r.stdout
+    assert "12 concurrent callers x 40 culls on 8 result slots: every list identical" in r.stdout
 
 
 @pytest.mark.gpu

@@ -1,7 +1,7 @@
 """kernel time of the multi-frustum cull (8 cascade frusta, pass widths 1 / 4 / 8) on the all-test and the sparse mixed 10 M scenes"""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lumixengine_amd import api, scenes
 ctx = api.Context(0)
