@@ -225,36 +225,43 @@ __device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const f
 }
 
 // ---- sphere x plane pre-test on the matrix pipe (several frusta) ---------------------------------------------------------------
-// The 8-frusta pass is bound by VALU work: doCulling's unfused arithmetic is 21 packed operations + 4 min / compare per (64 spheres,
+// The 8-frusta pass is bound by instruction issue: doCulling's unfused arithmetic is 21 packed operations + 4 min / compare per (64 spheres,
 // frustum), 62.6 M VALU wave-instructions per launch at 10 M all-test (profiles/r04/final/counters_summary.json), and sharing dot
 // products between frusta does not apply to real cascades: of the 48 planes of config 5's frusta 34 have bitwise distinct directions
 // even up to sign (the reference builds every plane from cross products of corner differences, geometry.cpp:324-337: the cascades of
 // one light differ in the last bits, near / far are not exact negations) - profiles/r05/README.md.
-// What the test needs bit for bit is only the SIGN of u_k = fl(fl(fl(fl(fl(x nx) + fl(y ny)) + fl(z nz)) + d_k) + r) for six planes.
-// v_mfma_f32_32x32x2_f32 computes, for 32 spheres x 32 plane rows at a time, u'_k = fma(r, 1, fma(z, nz, fma(y, ny, fma(x, nx, d_k))))
-// (two instructions, K = 4; bit for bit that fmaf chain: tools/mfma_contract_probe.hip) on the MATRIX pipe, which this kernel does
-// not use otherwise. Both values approximate T_k = x nx + y ny + z nz + d_k + r: |u_k - T_k| <= ((1 + u)^5 - 1) M_k and
-// |u'_k - T_k| <= ((1 + u)^4 - 1) M_k with u = 2^-24 and M_k = |x nx| + |y ny| + |z nz| + |d_k| + |r| (no underflow: see tau; no
-// overflow: see the scale). With G >= |x nx| + |y ny| + |z nz| + |r|: |d_k| <= |T_k| + G, so M_k <= 2 G + |T_k| <= (2 G + |u'_k|) /
-// (1 - 4.0001 u) and |u_k - u'_k| <= 9.001 u (2 G + |u'_k|). Hence |u'_k| > 18.01 u G  =>  sign(u_k) == sign(u'_k), u_k != 0.
-// The kernel uses eps = 32 u G' + tau, G' = max(|x|, |y|, |z|) * n1 + |r| evaluated in fp32 (n1 >= every plane's |n|_1, rounded up on
-// the host; three roundings of relative size u against a margin of 1.77), and per (sphere, frustum) with m = min_k u'_k (NaNs dropped):
+// What the test needs bit for bit is only the SIGN of u_k = fl(fl(fl(fl(fl(x nx) + fl(y ny)) + fl(z nz)) + d_k) + r) for six planes. ONE
+// v_mfma_f32_32x32x16_bf16 evaluates, for 32 spheres x 32 plane rows (four frusta), u'_k = d_k + sum over the K slots
+//     x1 nx1 + y1 ny1 + z1 nz1 + r1 + x2 nx1 + y2 ny1 + z2 nz1 + r2 + x1 nx2 + y1 ny2 + z1 nz2        (v1 = bf16(v), v2 = bf16(v - v1), RNE)
+// with d_k in the fp32 accumulator: the leading terms of the two-term splits of every factor. Both values approximate
+// T_k = x nx + y ny + z nz + d_k + r. With u = 2^-24, G >= |x nx| + |y ny| + |z nz| + |r| and M_k = G + |d_k| <= 2 G + |T_k|:
+//   * |u_k - T_k| <= ((1 + u)^5 - 1) M_k                                                 (five roundings on the longest path)
+//   * the splits: |v - v1 - v2| <= 2^-16 |v|, |v2| <= 2^-8 (1 + 2^-8) |v|, so the terms left out (x2 nx2, the remainders times the other
+//     factor) are <= 3.01 x 2^-16 |x nx| per axis and 2^-16 |r|: <= 3.01 x 2^-16 G in all
+//   * the instruction's own accumulation: <= 16 u x (|d_k| + sum |a b|) assumed, 4.5 u measured over wide exponent ranges, cancellation
+//     and |C| >> products (tools/mfma_contract_probe.hip, which also pins the operand maps and the conversion)
+// so |u_k - u'_k| <= 21.01 u (2 G + |u'_k|) + 3.01 x 2^-16 G (1.01), and |u'_k| > 4.9e-5 G  =>  sign(u_k) == sign(u'_k), u_k != 0.
+// The kernel uses eps = 1.5 x 2^-14 G' + tau = 9.2e-5 G' + tau, G' = (|x| + |y| + |z|) n1 + |r| evaluated in fp32 (n1 >= every plane's
+// |n|_1, rounded up on the host), and per (sphere, frustum) with m = min_k u'_k (NaNs dropped):
 //     m < -eps                    some plane has u_k < 0: culled, as the reference
-//     m >  eps                    every plane has u_k > 0 (a NaN u'_k means d_k is NaN - everything else is finite here - so u_k is NaN
-//                                 too and culls nothing): visible, as the reference
+//     m >  eps                    every plane has u_k > 0 (a NaN u'_k with finite G' means d_k is NaN, so u_k is NaN too and culls
+//                                 nothing): visible, as the reference
 //     otherwise (also eps = NaN)  undecided: the chunk is evaluated again by the exact loop below, all frusta
-// tau = 2^-120 covers products that underflow (absolute error <= 8 x 2^-150 instead of relative u). G' is formed 2^27 times too large and
-// scaled back by the last multiplication: any G >= 2^101 makes eps infinite, so sums that could overflow in one evaluation order and
-// not in the other (partial sums are bounded by M_k (1 + 5 u)) are never decided here; +inf / NaN coordinates, radii and bounds end in
-// eps = inf / NaN the same way, and d_k = +-inf gives u'_k = u_k = +-inf. Expected rate of undecided (sphere, plane) pairs on a scene of
-// extent 3e4: 2 eps / 6e4 ~ 1e-7.
+// tau = 2^-120 covers products that underflow (absolute instead of relative error). G' is formed 2^27 times too large and scaled back by
+// the last multiplication: any G >= 2^101 makes eps infinite, so sums that could overflow in one evaluation order and not in the other
+// are never decided here; infinite / NaN coordinates and radii end in eps = inf / NaN (an infinite v has v - v1 = NaN besides), and
+// d_k = +-inf gives u'_k = u_k = +-inf. Undecided (sphere, plane) pairs on a scene of extent 3e4: 2 eps / 6e4 ~ 3e-6 at G ~ 1e3, i.e.
+// about 1 % of the chunks take the exact loop.
 // Layout: rows = planes. Row i of a group of four frusta 4 g .. 4 g + 3 is plane p = (i & 3) + 4 ((i >> 3) & 1) of frustum
 // 4 g + 2 h + q with h = (i >> 2) & 1, q = i >> 4, so that accumulator registers 8 q + p of a lane in half h (= lane >> 5) are the
-// six values of ONE sphere (column lane & 31) and ONE frustum: the minimum is lane-local. Columns = 32 spheres: a chunk's 64 spheres are
-// two column groups; v_permlane32_swap hands each half-wave the partner sphere's components it needs as the K = 1 / K = 3 operands, and
-// brings the verdict bits of the other four frusta back (tools/mfma_contract_probe.hip pins both instructions).
+// six values of ONE sphere (column lane & 31) and ONE frustum: the minimum is lane-local, and the six d_k are three ds_read_b64 straight
+// into the accumulator. Columns = 32 spheres: a chunk's 64 spheres are two column groups; v_permlane32_swap hands each half-wave the
+// partner sphere's K slots, and brings the verdict bits of the other four frusta back.
+// Measured (profiles/r05/cull8_*): 8 frusta x 10 M all-test 141 us (exact loop) -> 137 (the same pre-test on v_mfma_f32_32x32x2_f32, two
+// per set: the f32-input MFMA runs at the vector rate and, as tools/mfma_overlap_probe.hip shows, VALU work does not hide behind it in
+// compiler-scheduled code - deleted) -> 117 us cold / 110 warm (this form); VALU wave-instructions 62.6 M -> 38.8 M.
 #ifndef LMX_CULL8_MFMA
-#define LMX_CULL8_MFMA 2      // 0: every (chunk, frustum) through the exact loop (rounds 2-4), 1: f32-input MFMA, 2: bf16 MFMA on two-term splits
+#define LMX_CULL8_MFMA 1      // 0: every (chunk, frustum) through the exact loop (rounds 2-4)
 #endif
 
 // LDS record of one (cell, frustum): the six cell-relative plane distances of ShiftedFrustum::getRelative and the cell's class
@@ -492,9 +499,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(
 	// them the tile-level test left MIXED (only those can leave a sphere undecided: the records of the others were never written)
 	constexpr int NG = F != 1 ? (WAVES == 4 ? 2 : 1) : 1; // groups of four frusta: the 5..8-frusta shape has 4 waves, the 2..4-frusta shape 8
 	constexpr bool PRETEST = F != 1 && LMX_CULL8_MFMA != 0;
-	constexpr bool PRE_BF16 = LMX_CULL8_MFMA == 2; // the bf16 form: ONE v_mfma_f32_32x32x16_bf16 per (32 spheres, four frusta) instead of two f32-input ones
-	float pre_a1[NG], pre_a2[NG]; // f32 form: {nx | ny}, {nz | 1}
-	u32x4_t pre_ab[NG];           // bf16 form: eight K slots per half-wave
+	u32x4_t pre_ab[NG]; // the plane rows of a group: eight K slots per half-wave
 	uint32_t pre_off[NG][2];
 	uint64_t pre_care[NG][2];
 	// The pre-test evaluates ALL frusta of a group for a chunk at once; the exact loop only the (chunk, frustum) pairs with a lane in a
@@ -516,17 +521,12 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(
 				const uint32_t rf = 4u * gq + 2u * rh + rq;
 				const bool row_on = rp < 6u && rf < (uint32_t)nf;
 				const uint32_t fs = row_on ? rf : 0u, ps = row_on ? rp : 0u;
-				const float v1 = s_nrm[fs][(k ? 6u : 0u) + ps], v2 = s_nrm[fs][12u + ps];
-				pre_a1[gq] = row_on ? v1 : 0.f;
-				pre_a2[gq] = row_on ? (k ? 1.0f : v2) : 0.f;
-				if constexpr (PRE_BF16) {
-					// K slots of a plane row: lanes < 32 hold {nx1 ny1 nz1 1 nx1 ny1 nz1 1} (against {x1 y1 z1 r1 x2 y2 z2 r2} of a sphere), lanes >= 32
-					// {nx2 ny2 nz2 0 0 0 0 0} (against {x1 y1 z1 r1 0 0 0 0}): n1 = bf16(n), n2 = bf16(n - n1), both rounded to nearest
-					const float nx = row_on ? s_nrm[fs][ps] : 0.f, ny = row_on ? s_nrm[fs][6u + ps] : 0.f, nz = row_on ? s_nrm[fs][12u + ps] : 0.f;
-					const uint32_t hi_xy = pk_bf16(nx, ny), hi_z1 = pk_bf16(nz, row_on ? 1.0f : 0.f);
-					const uint32_t lo_xy = pk_bf16(nx - __uint_as_float(hi_xy << 16), ny - __uint_as_float(hi_xy & 0xffff0000u)), lo_z0 = pk_bf16(nz - __uint_as_float(hi_z1 << 16), 0.f);
-					pre_ab[gq] = k ? u32x4_t{lo_xy, lo_z0, 0u, 0u} : u32x4_t{hi_xy, hi_z1, hi_xy, hi_z1};
-				}
+				// K slots of a plane row: lanes < 32 hold {nx1 ny1 nz1 1 nx1 ny1 nz1 1} (against {x1 y1 z1 r1 x2 y2 z2 r2} of a sphere), lanes >= 32
+				// {nx2 ny2 nz2 0 0 0 0 0} (against {x1 y1 z1 r1 0 0 0 0}): n1 = bf16(n), n2 = bf16(n - n1), both rounded to nearest
+				const float nx = row_on ? s_nrm[fs][ps] : 0.f, ny = row_on ? s_nrm[fs][6u + ps] : 0.f, nz = row_on ? s_nrm[fs][12u + ps] : 0.f;
+				const uint32_t hi_xy = pk_bf16(nx, ny), hi_z1 = pk_bf16(nz, row_on ? 1.0f : 0.f);
+				const uint32_t lo_xy = pk_bf16(nx - __uint_as_float(hi_xy << 16), ny - __uint_as_float(hi_xy & 0xffff0000u)), lo_z0 = pk_bf16(nz - __uint_as_float(hi_z1 << 16), 0.f);
+				pre_ab[gq] = k ? u32x4_t{lo_xy, lo_z0, 0u, 0u} : u32x4_t{hi_xy, hi_z1, hi_xy, hi_z1};
 #pragma unroll
 				for (int q = 0; q < 2; ++q) {
 					const uint32_t fl = 4u * gq + 2u * k + q; // the frustum whose six values this lane finds in accumulators 8 q .. 8 q + 5
@@ -650,28 +650,21 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(
 						const float x = spv[i].x, y = spv[i].y, z = spv[i].z, r = spv[i].w;
 						// eps of the lane's own sphere (the bound above; formed 2^27 too large so that huge operands end in inf)
 						const float gs = ((__builtin_fabsf(x) + __builtin_fabsf(y)) + __builtin_fabsf(z)) * a.pretest_n1s + __builtin_fabsf(r) * 134217728.0f;
-						const float eps_own = gs * (PRE_BF16 ? 6.821210263296962e-13f /* 1.5 x 2^-14 x 2^-27 */ : 1.4210854715202004e-14f /* 2^-46 = 32 u 2^-27 */) + 7.52316384526264e-37f /* tau = 2^-120 */;
+						const float eps_own = gs * 6.821210263296962e-13f /* 1.5 x 2^-14 x 2^-27 */ + 7.52316384526264e-37f /* tau = 2^-120 */;
 						// what each half-wave needs of the partner sphere: [own | partner] per column group
 						const auto sw_eps = __builtin_amdgcn_permlane32_swap(__float_as_uint(eps_own), __float_as_uint(eps_own), false, false);
 						const auto sw_loc = __builtin_amdgcn_permlane32_swap(local[i] * 3u, local[i] * 3u, false, false);
-						// f32 form: K = 0: x, K = 1: y | K = 2: z, K = 3: r. bf16 form: {x1 y1 z1 r1 x2 y2 z2 r2} for the lanes < 32, {x1 y1 z1 r1 0 0 0 0} for the
-						// others (v1 = bf16(v), v2 = bf16(v - v1), round to nearest: v_cvt_pk_bf16_f32; v - v1 is exact)
-						uint32_t o0 = __float_as_uint(x), o1 = __float_as_uint(y), o2 = __float_as_uint(z), o3 = __float_as_uint(r), o1b = 0, o3b = 0;
-						if constexpr (PRE_BF16) {
-							o0 = pk_bf16(x, y);
-							o2 = pk_bf16(z, r);
-							o1 = pk_bf16(x - __uint_as_float(o0 << 16), y - __uint_as_float(o0 & 0xffff0000u));
-							o3 = pk_bf16(z - __uint_as_float(o2 << 16), r - __uint_as_float(o2 & 0xffff0000u));
-						}
-						const auto sw_xy = PRE_BF16 ? __builtin_amdgcn_permlane32_swap(o0, o0, false, false) : __builtin_amdgcn_permlane32_swap(o0, o1, false, false);
-						const auto sw_zr = PRE_BF16 ? __builtin_amdgcn_permlane32_swap(o2, o2, false, false) : __builtin_amdgcn_permlane32_swap(o2, o3, false, false);
-						const auto sw_lo0 = __builtin_amdgcn_permlane32_swap(o1, o1b, false, false), sw_lo1 = __builtin_amdgcn_permlane32_swap(o3, o3b, false, false); // (bf16 form only)
+						// the sphere as K slots: {x1 y1 z1 r1 x2 y2 z2 r2} for the lanes < 32, {x1 y1 z1 r1 0 0 0 0} for the others (v1 = bf16(v), v2 = bf16(v - v1),
+						// round to nearest: v_cvt_pk_bf16_f32; v - v1 is exact)
+						const uint32_t hi_xy = pk_bf16(x, y), hi_zr = pk_bf16(z, r);
+						const uint32_t lo_xy = pk_bf16(x - __uint_as_float(hi_xy << 16), y - __uint_as_float(hi_xy & 0xffff0000u)), lo_zr = pk_bf16(z - __uint_as_float(hi_zr << 16), r - __uint_as_float(hi_zr & 0xffff0000u));
+						const auto sw_xy = __builtin_amdgcn_permlane32_swap(hi_xy, hi_xy, false, false), sw_zr = __builtin_amdgcn_permlane32_swap(hi_zr, hi_zr, false, false);
+						const auto sw_lo0 = __builtin_amdgcn_permlane32_swap(lo_xy, 0u, false, false), sw_lo1 = __builtin_amdgcn_permlane32_swap(lo_zr, 0u, false, false);
 						uint64_t unsure = 0; // lanes with an undecided pair (wave-uniform accumulation of compare masks)
 						uint32_t w_cg[2];
 #pragma unroll
 						for (int cg = 0; cg < 2; ++cg) { // column group: spheres 32 cg .. 32 cg + 31 of the chunk
 							const float eps = __uint_as_float(sw_eps[cg]);
-							const float b1 = __uint_as_float(sw_xy[cg]), b2 = __uint_as_float(sw_zr[cg]);
 							f32x16 acc[NG];
 #pragma unroll
 							for (int gq = 0; gq < NG; ++gq) {
@@ -687,16 +680,9 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(
 								}
 								acc[gq] = __builtin_shufflevector(half[0], half[1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
 							}
-							if constexpr (PRE_BF16) {
-								const u32x4_t bb = {sw_xy[cg], sw_zr[cg], sw_lo0[cg], sw_lo1[cg]};
+							const u32x4_t bb = {sw_xy[cg], sw_zr[cg], sw_lo0[cg], sw_lo1[cg]};
 #pragma unroll
-								for (int gq = 0; gq < NG; ++gq) acc[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, pre_ab[gq]), __builtin_bit_cast(bf16x8_t, bb), acc[gq], 0, 0, 0);
-							} else {
-#pragma unroll
-								for (int gq = 0; gq < NG; ++gq) acc[gq] = __builtin_amdgcn_mfma_f32_32x32x2f32(pre_a1[gq], b1, acc[gq], 0, 0, 0);
-#pragma unroll
-								for (int gq = 0; gq < NG; ++gq) acc[gq] = __builtin_amdgcn_mfma_f32_32x32x2f32(pre_a2[gq], b2, acc[gq], 0, 0, 0);
-							}
+							for (int gq = 0; gq < NG; ++gq) acc[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, pre_ab[gq]), __builtin_bit_cast(bf16x8_t, bb), acc[gq], 0, 0, 0);
 							uint32_t w = 0;
 #pragma unroll
 							for (int gq = 0; gq < NG; ++gq) {
@@ -708,6 +694,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(
 								}
 							}
 							w_cg[cg] = w << (4u * (lane >> 5)); // frustum 4 g + 2 h + q: bit 8 g + 4 h + 2 q
+							if constexpr (SLOTS) __builtin_amdgcn_sched_barrier(0); // (the variant that also carries the slots: one column group's accumulators at a time, or one register spills)
 						}
 						// [own column group | the other one] back: lanes < 32 own group 0's bits, lanes >= 32 group 1's; the partner lane holds the other four frusta
 						const auto sw_w = __builtin_amdgcn_permlane32_swap(w_cg[0], w_cg[1], false, false);

@@ -186,6 +186,49 @@ def test_cull_cascades_with_shared_normals(gpu_ctx, oracle_port, order):
     cs.setPassWidth(1)
 
 
+@pytest.mark.parametrize("seed", [31, 32])
+def test_cull_pretest_undecided_band(gpu_ctx, oracle_port, seed):
+    """The several-frusta kernel decides most (sphere, frustum) pairs from a bf16 MFMA evaluation of the six plane expressions and leaves the
+    pairs within its error bound of zero to the exact loop (cull_kernels.hip, "sphere x plane pre-test"). Here every sphere is tangent, up
+    to a perturbation between 0 and 1e-2, to one plane of one of config 5's eight cascades (culling_system.cpp:283-306: `t + r < 0` culls -
+    the sign of a sum within a few ulps of zero): the centre lies outside the plane at a distance rho, the radius is rho + delta. Wrong by
+    one rounding anywhere and an id is missing or extra; every frustum is compared with the oracle id for id."""
+    rng = np.random.default_rng(seed)
+    kws = scenes.config5_cascade_kwargs()
+    for kw in kws:
+        kw["pos"] = (kw["pos"][0], 2500.0, kw["pos"][2])
+        kw["ortho_size"] = kw["ortho_size"] / 4.0
+    fr = np.concatenate([api.viewport_frustum(**kw) for kw in kws])
+    n = 120_000
+    f_of = rng.integers(0, 8, n)
+    k_of = rng.integers(0, 6, n)
+    nrm = np.stack([fr["xs"][f_of, k_of], fr["ys"][f_of, k_of], fr["zs"][f_of, k_of]], 1).astype(np.float64)
+    origin = fr["origin"][f_of].astype(np.float64)
+    # a point of the plane: n . p + d = 0 in the frustum's frame (ShiftedFrustum: planes relative to origin)
+    on_plane = origin - nrm * (fr["ds"][f_of, k_of].astype(np.float64) / (nrm * nrm).sum(1))[:, None]
+    tangent = np.cross(nrm, rng.normal(size=(n, 3)))
+    tangent /= np.linalg.norm(tangent, axis=1, keepdims=True)
+    rho = np.exp(rng.uniform(np.log(0.5), np.log(60.0), n))
+    pos = on_plane + tangent * rng.uniform(-800.0, 800.0, (n, 1)) - nrm * (rho / np.linalg.norm(nrm, axis=1))[:, None]
+    delta = rng.choice([0.0, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4, 1e-3, -1e-3, 1e-2, -1e-2], n) * rng.uniform(0.0, 1.0, n)
+    radius = (rho + delta).astype(np.float32)
+    entity = np.arange(n, dtype=np.int32)
+    types = (entity % 3).astype(np.uint8)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(entity, types, pos, radius)
+    ocs = oracle_port.culling_system()
+    ocs.add_bulk(entity, types, pos, radius)
+    cs.setPassWidth(8)
+    res = cs.cull(fr)
+    seen = 0
+    for f in range(8):
+        got = gpu_visible(res, f)
+        H.assert_same_visible(got, oracle_visible(ocs, fr[f : f + 1]), f"tangent spheres, frustum {f}")
+        seen += len(res.all_ids(f)[0])
+    assert 0.05 * n < seen < 7.5 * n  # neither everything nor nothing: the tangent plane decides
+    cs.setPassWidth(1)
+
+
 def _digest(res, frustum=0):
     ids, types = res.all_ids(frustum)
     return H.visible_digest(ids, types)

@@ -61,6 +61,17 @@ def test_cull_tile_register_budgets(tmp_path):
         assert k["private_segment_fixed_size"] == 0, k
     for k in pick(meta, "k_cull_pack") + pick(meta, "k_cull_dynamic") + pick(meta, "k_apply_patches"):
         assert k["private_segment_fixed_size"] == 0, k
+    # the several-frusta kernels (F = 0): <= 96 VGPRs = 5 waves per SIMD, what the LDS of the cell records admits anyway; and the pre-test's
+    # MFMA in its VGPR form - with accumulators in AGPRs every plane distance going in and every result coming out costs a v_accvgpr move
+    # (504 of them per kernel when the register budget was left at 512: round 5)
+    for k in pick(meta, "k_cull_tileILi0E"):
+        assert k["next_free_vgpr"] <= 96, k
+    text = (tmp_path / "cull_kernels.s").read_text()
+    bodies = re.findall(r"^(_ZN3lmx\S*k_cull_tileILi0E\S*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
+    assert len(bodies) == 4, [b[0] for b in bodies]
+    for name, body in bodies:
+        assert "v_mfma_f32_32x32x16_bf16" in body, name
+        assert "v_accvgpr" not in body, name
 
 
 def test_skin_and_pose_register_budgets(tmp_path):

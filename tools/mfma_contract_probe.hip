@@ -4,7 +4,7 @@
 //   1. v_mfma_f32_32x32x2_f32 is, bit for bit, the k-ordered chain D = fmaf(a_k1, b_k1, fmaf(a_k0, b_k0, C)) with the operand maps
 //      A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31], D[row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)][col = lane & 31]
 //      (MI355X guide, "FP32-input MFMA"): two of them in a row are the 4-term chain fmaf(r, 1, fmaf(z, nz, fmaf(y, ny, fmaf(x, nx, d)))),
-//      including subnormal, infinite and NaN operands (tests/hostsim emulates the instruction as exactly that chain).
+//      including subnormal, infinite and NaN operands (tests/tests/hostsim emulates the instruction as exactly that chain; the product kernel uses the bf16 form of check 3, the f32 form is kept here as the measured alternative).
 //   2. v_permlane32_swap_b32 vdst, src: lanes 32..63 of vdst trade places with lanes 0..31 of src.
 //
 //   hipcc --offload-arch=gfx950 -O2 -ffp-contract=off tools/mfma_contract_probe.hip -o tools/_build/mfma_contract_probe && tools/_build/mfma_contract_probe
