@@ -105,6 +105,25 @@ class TorchDev:
         t = self.torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
         return _Buf(t, t.data_ptr())
 
+    def copy_ceiling_gbps(self):
+        """GB/s (read + written bytes) of a 1 GiB device-to-device copy of 16-byte elements on this box, now: the achieved-copy ceiling SURVEY.md
+        8d asks the roofline fraction to be quoted against besides the 8 TB/s peak. Timed with events on the current stream, 20 repetitions."""
+        torch = self.torch
+        n = (1 << 30) // 16
+        src = torch.empty((n, 4), dtype=torch.float32, device="cuda").fill_(1.0)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            dst.copy_(src)
+        b.record()
+        b.synchronize()
+        ms = a.elapsed_time(b) / 20.0
+        del src, dst
+        return 2.0 * (1 << 30) / (ms * 1e-3) / 1e9
+
     def scrubber(self):
         """evicts the 256 MiB Infinity Cache: a 1 GiB read-only reduction ("read": the cache is left full of CLEAN lines) or a 1 GiB
         read-modify-write ("write": full of DIRTY lines, every later miss first writes a victim back)"""
@@ -170,7 +189,8 @@ def main(argv=None):
                     help="TEST MODE for the N > 1 code path on a one-GPU box: every rank uses cuda:0, torch.distributed runs on gloo, and the exchange's collective must be carried by LMX_RCCL_LIBRARY = tests/_build/libloopback_rccl.so (RCCL refuses two ranks on one device). Its timings mean nothing")
     ap.add_argument("--big-entities", type=int, default=100_000_000, help="extras: entity count of the config-5-sized single-GPU legs (0 = skip)")
     ap.add_argument("--no-config5-frame", action="store_true", help="N > 1: skip BASELINE config 5's frame (8 cascade frusta in one pass + ONE collective, lmx_exchange_cull_many)")
-    ap.add_argument("--exchange-probe", action="store_true", help="after everything else: the N > 1 step with a world of ONE rank in child processes (inline gather and side-stream gather) -> bench_extra.json")
+    ap.add_argument("--exchange-probe", action="store_true", help="after everything else, besides the default one-rank exchange step: the same with the side-stream gather -> bench_extra.json")
+    ap.add_argument("--no-exchange-step", action="store_true", help="skip the N > 1 step with a world of ONE rank (a child process; `also.exchange_step_one_rank_ms`)")
     ap.add_argument("--min-timed-steps", type=int, default=200, help="repeat the K-step timed region until at least this many steps were timed")
     ap.add_argument("--selftest-hostsim", action="store_true", help="TEST MODE (CPU, tests/test_bench_contract.py): run this file's code path against tests/hostsim's build of the library with tiny scenes")
     args = ap.parse_args(argv)
@@ -468,14 +488,21 @@ def main(argv=None):
     if traffic is None:
         traffic, traffic_note = load_traffic("k_cull_tile:all_test")
     have_test = test_cold_ms == test_cold_ms and test_cold_ms > 0
+    copy_gbps = None  # the device-to-device copy this box reaches right now: 1 GiB of float4, 20 repetitions, read + written bytes
+    if rank == 0 and not selftest and not args.headline_only:
+        try:
+            copy_gbps = dev.copy_ceiling_gbps()
+            log(f"[copy ceiling] 1 GiB device-to-device copy, 20 repetitions: {copy_gbps:.0f} GB/s (read + written bytes)")
+        except Exception as e:  # noqa: BLE001 - a side measurement
+            log(f"[copy ceiling] not measured: {e!r}")
     roof_ms = test_cold_ms if have_test else avg_default_ms
     roof_bytes = test_bytes if have_test else alg_bytes
     roof_gbps = roof_bytes / (roof_ms * 1e-3) / 1e9 if roof_ms else 0.0
     roofline = {
         "kernel": "k_cull_tile",
         "bound": "hbm",
-        "leg": f"all_test {N} entities, cache-cold after a read-only 1 GiB scrub: every sphere fetched and tested (moved bytes == 20 B/entity + 4 B/visible id)" if have_test
-               else "default camera only (--headline-only): effective rate, NOT a roofline fraction",
+        "leg": f"NOT the timed step: a separate launch over the all_test scene ({N} entities, every sphere fetched and tested: 20 B/entity + 4 B/visible id), cache-cold after a read-only 1 GiB scrub" if have_test
+               else "NOT the timed step and NOT a roofline fraction: default camera only (--headline-only), effective rate",
         "achieved": round(roof_gbps, 1),
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
@@ -485,7 +512,8 @@ def main(argv=None):
         "algorithmic_bytes_per_launch": roof_bytes,
         "avg_launch_ms": round(roof_ms, 5),
         "avg_launch_ms_is": "mean over the leg's launches of hipEventElapsedTime on the event pair the launch itself fills (hipExtLaunchKernelGGL start / stop events on the launch stream): the dispatch's begin -> end, as in rocprofv3's kernel trace",
-        "measured_copy_ceiling_GBps": 6290.0,
+        "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,  # measured in THIS run (not the guide's figure): 1 GiB float4 copy, read + written bytes
+        "frac_of_measured_copy": round(roof_gbps / copy_gbps, 4) if copy_gbps else None,
         "legs": legs,
     }
 
@@ -551,14 +579,16 @@ def main(argv=None):
                 result["cpu_baseline"] = baseline.measure()
             except Exception as e:  # noqa: BLE001 - the GPU numbers above are measured; say what went wrong instead of losing the line
                 result["cpu_baseline"] = {"value": None, "unit": "entities/s", "cores": 0, "kind": "reference", "sample": "not measured", "error": repr(e)}
-        if args.exchange_probe and not selftest:
-            # LAST: every number above is taken; child processes with contexts of their own and a hard timeout
+        if not args.no_exchange_step and not args.headline_only and not selftest:
+            # LAST: every number above is taken; a child process with a context of its own and a hard timeout. The like-for-like N = 1 point
+            # of the scaling curve: the step `--gpus N` times (cull + pack into the send buffer + ONE ncclAllGather), with a world of one rank
             result.setdefault("extra", {})
             dev.sync()
-            result["extra"]["exchange_path_one_rank"] = exchange_path_one_rank(args, log)
-            side = exchange_path_one_rank(args, log, extra_env={"LMX_EXCHANGE_INLINE": "0"})
-            side.pop("what", None)
-            result["extra"]["exchange_path_one_rank"]["side_stream_gather"] = side
+            result["extra"]["exchange_path_one_rank"] = exchange_path_one_rank(args, log, timeout_s=120.0)
+            if args.exchange_probe:
+                side = exchange_path_one_rank(args, log, extra_env={"LMX_EXCHANGE_INLINE": "0"})
+                side.pop("what", None)
+                result["extra"]["exchange_path_one_rank"]["side_stream_gather"] = side
     if rank == 0:
         emit(result, log)
     if use_dist:
@@ -720,7 +750,7 @@ def exchange_checks_and_frames(args, api, scenes, D, dev, ctx, cs, sc, xchg, ste
 
 # ---- the one stdout line -------------------------------------------------------------------------------------------------------
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
-ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "leg")
+ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "measured_copy_GBps", "frac_of_measured_copy", "leg")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "host_cores", "single_thread_value", "error")
 CONFIG_KEYS = ("workload", "entities_per_gpu", "frusta", "visible_per_gpu", "visible_ids", "sharding", "timed_steps", "repetitions", "ranks_seen_by_rccl",
                "allgather_visible_counts", "union_equals_unsharded", "visible_total", "xgmi_curve", "TEST_MODE")
@@ -749,9 +779,15 @@ def compact_line(result):
             also[k] = result[k]
     ex = result.get("extra", {})
     for k in ("skinned_verts_per_sec", "transforms_per_sec", "target_frames_per_sec_1gpu", "target_skinned_verts_per_sec", "target_skin_ms_per_1e9_verts", "config3_frames_per_sec",
-              "keys_kernels_ms", "xform_level_kernel_avg_ms", "pose_palette_kernel_avg_ms", "transform_ms_per_frame"):
+              "keys_kernels_ms", "xform_level_kernel_avg_ms", "xform_with_moved_list_ms", "pose_palette_kernel_avg_ms", "transform_ms_per_frame"):
         if k in ex:
             also[k] = ex[k]
+    leg8 = result.get("roofline", {}).get("legs", {}).get("all_test_8_frusta_one_pass")
+    if isinstance(leg8, dict) and leg8.get("cold_avg_launch_ms"):
+        also["cull8_all_test_kernel_ms"] = leg8["cold_avg_launch_ms"]  # config 5's pass: 8 cascade frusta x 10 M spheres in ONE launch, every sphere tested, cache-cold
+    if isinstance(ex.get("exchange_path_one_rank"), dict) and "ms_per_step" in ex["exchange_path_one_rank"]:
+        also["exchange_step_one_rank_ms"] = ex["exchange_path_one_rank"]["ms_per_step"]
+        also["exchange_step_note"] = "N>1 step (cull+pack+ONE ncclAllGather) with a world of ONE rank; no xGMI curve measured by the builder"
     if isinstance(ex.get("target_character_mesh"), dict):
         also["target_character_mesh_skin_ms_per_1e9_verts"] = ex["target_character_mesh"].get("skin_ms_per_1e9_verts")
     if "error" in ex:
@@ -971,8 +1007,8 @@ class CpuBaseline:
             "unit": "entities/s",
             "cores": best,
             "kind": self.kind,
-            "sample": f"the full headline workload ({n} entities, same scene and frustum as the GPU run): median of {sweep[best]['culls']} culls at {best} thread(s), "
-                      f"best of the sweep {list(sweep)}; {pages} CullResult pages per cull, as in the reference",
+            "sample": f"the full headline workload ({n} entities, same scene and frustum as the GPU run): median of {sweep[best]['culls']} culls; cores_used {best} of host_cores {host} - "
+                      f"the best of the thread sweep {list(sweep)}: more threads are SLOWER here, the reference pushes all {pages} CullResult pages of a cull through one mutexed PageAllocator",
             "host_cores": host,
             "thread_sweep": {str(k): v for k, v in sweep.items()},
             "single_thread_value": sweep[1]["entities_per_s"],
@@ -991,12 +1027,12 @@ class CpuBaseline:
         try:
             sk = scenes.skeleton(64, seed=4)
             verts, skin = scenes.skinned_mesh(10_000, 64, seed=6)
-            n_inst = 1000  # a tenth of BASELINE config 3's 10 k instances of the 10 k-vertex mesh: 10^7 vertices per frame
+            n_inst = 10_000  # BASELINE config 3 at FULL size: 10 k instances of the 10 k-vertex mesh, 10^8 vertices per frame (1.2 GB of positions)
             rp, rr = scenes.relative_poses(n_inst, 64, seed=5)
             inv = o.invert_bind(sk["bind"])
             for threads in (1, 8):
                 t_pose, t_skin, t_start = [], [], time.time()
-                while len(t_skin) < 20 and (time.time() - t_start) < 8.0:  # >= 20 timed frames, bounded
+                while len(t_skin) < (3 if threads == 1 else 8) and (time.time() - t_start) < 12.0:  # a frame is ~3 s at 1 thread: bounded, the count is reported
                     t0 = time.perf_counter()
                     apos, arot = o.pose_compute_absolute(rp, rr, sk["parents"], sk["first_nonroot"], n_threads=threads)
                     pal = o.skin_matrices(apos, arot, inv, n_threads=threads)
@@ -1025,7 +1061,7 @@ class CpuBaseline:
                 t_x.append(time.perf_counter() - t0)
             other["transforms_per_sec_1thread"] = len(kids) / float(np.median(t_x))
             other["transform_frames_timed"] = len(t_x)
-            other["other_samples"] = (f"skin: {n_inst} instances x 64 bones x {len(verts)} verts of one mesh (a tenth of config 3), median of <= 20 frames at 1 and 8 threads; "
+            other["other_samples"] = (f"skin: {n_inst} instances x 64 bones x {len(verts)} verts of one mesh (config 3 at full size: 10^8 vertices per frame), median of <= 3 frames at 1 thread and <= 8 at 8 threads; "
                                       f"transforms: {len(roots)} roots x depth-4 chains (config 3 at full size), every root moved per frame, median of 10 frames, 1 thread "
                                       "(World is single-writer by design)")
         except Exception as e:  # noqa: BLE001 - the headline baseline must survive a problem in the side measurements

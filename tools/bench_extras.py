@@ -362,6 +362,20 @@ def extras(ctx, api, scenes, dev, timed, N, log, check_ids, big_entities=0, out=
     out["transforms_per_sec"] = n_child / (ms * 1e-3)
     out["transform_ms_per_frame"] = ms
     out["transform_GBps_algorithmic"] = 156.0 * n_child / (ms * 1e-3) / 1e9
+    # the same propagation with the moved list on (lmx_world_track_moved): what the engine-side module pays every frame, because it replays
+    # the `transformed` delegates of the entities a propagation moved (world.cpp:255-282)
+    w.trackMoved(True)
+    for _ in range(5):
+        xform_step()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    for _ in range(20):
+        xform_step()
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    t_mv, n_mv = ctx.profile_get(api.K_XFORM_LEVEL)
+    out["xform_with_moved_list_ms"] = t_mv / max(n_mv, 1)
+    w.trackMoved(False)
     del w
 
     # config 3 slice: skinned instances x 64 bones x 10 k verts, shared mesh (2 k instances = 20 M verts per frame)

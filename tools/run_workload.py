@@ -110,10 +110,23 @@ def main():
         pos, rot = scenes.relative_poses(n_inst, 64, seed=8)
         d_pos, d_rot = torch.from_numpy(pos).cuda(), torch.from_numpy(rot).cuda()
         sk.setPoseSourceDevice(d_pos.data_ptr(), d_rot.data_ptr(), n_inst * 64)
+        for _ in range(2):
+            cs.cull(fr)
+            sk.run()
+        ctx.synchronize()
+        # the workload's OWN view of its kernels (the launches' begin / end timestamps through hipExtLaunchKernelGGL events, as bench.py reads
+        # them) next to its wall time: run once plain and once under rocprofv3 to see what the profiler does to the launches it watches
+        import time
+        ctx.profile_reset(); ctx.profile_enable(True)
+        t0 = time.perf_counter()
         for _ in range(args.steps):
             cs.cull(fr)
             sk.run()
         ctx.synchronize()
+        wall = (time.perf_counter() - t0) / args.steps
+        ctx.profile_enable(False)
+        own = {api.KERNEL_NAMES[k]: round(ctx.profile_get(k)[0] / args.steps, 4) for k in range(len(api.KERNEL_NAMES)) if ctx.profile_get(k)[1]}
+        print(f"target frame: wall {wall * 1e3:.3f} ms per frame; kernel ms per frame by the launches' own timestamps: {own}")
     else:
         n_inst, n_verts = args.instances, 10_000
         s = scenes.skeleton(64, seed=4)
