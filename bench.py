@@ -331,7 +331,8 @@ def main(argv=None):
         with c_stdout_to_stderr():
             xchg = api.VisibleExchange(ctx, rank, world, uid.cpu().numpy().tobytes(), cap)
             xchg.wait(xchg.cull(frustum))  # the first collective creates RCCL's channels (and may print)
-        log(f"[rank {rank}] exchange ready")
+        exchange_info = xchg.info()  # which of the three step forms this rank's exchange took, and the gather time it took it on
+        log(f"[rank {rank}] exchange ready: {exchange_info}")
         x_cull, xh, slot_c = ctx.lib.lmx_exchange_cull, xchg.h, C.c_uint32(0)
 
         def step():
@@ -557,6 +558,10 @@ def main(argv=None):
     result["config"]["visible_ids"] = ids_checked  # 'reference': sha256 of the sorted ids == the reference CullingSystemImpl's on the same seeded scene
     result["config"].update(dist_info)
     if use_dist:
+        result["config"]["exchange_mode"] = exchange_info["mode"]
+        result["config"]["exchange_gather_us_at_creation"] = exchange_info["gather_us"]
+        result["config"]["exchange_mode_why"] = exchange_info["why"]
+    if use_dist:
         result["config"]["xgmi_curve"] = "this line is ONE point; no 1/2/4/8 xGMI curve has been measured by the builder (no multi-GPU node): the driver computes scaling from its own runs"
     if args.ranks_share_gpu:
         result["config"]["TEST_MODE"] = "--ranks-share-gpu: all ranks on cuda:0, gloo + shared-memory collective (tests/cpp/loopback_rccl.cpp); timings are meaningless"
@@ -752,7 +757,7 @@ def exchange_checks_and_frames(args, api, scenes, D, dev, ctx, cs, sc, xchg, ste
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "measured_copy_GBps", "frac_of_measured_copy", "leg")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "host_cores", "single_thread_value", "error")
-CONFIG_KEYS = ("workload", "entities_per_gpu", "frusta", "visible_per_gpu", "visible_ids", "sharding", "timed_steps", "repetitions", "ranks_seen_by_rccl",
+CONFIG_KEYS = ("workload", "entities_per_gpu", "frusta", "visible_per_gpu", "visible_ids", "sharding", "timed_steps", "repetitions", "exchange_mode", "exchange_gather_us_at_creation", "ranks_seen_by_rccl",
                "allgather_visible_counts", "union_equals_unsharded", "visible_total", "xgmi_curve", "TEST_MODE")
 
 
@@ -787,6 +792,7 @@ def compact_line(result):
         also["cull8_all_test_kernel_ms"] = leg8["cold_avg_launch_ms"]  # config 5's pass: 8 cascade frusta x 10 M spheres in ONE launch, every sphere tested, cache-cold
     if isinstance(ex.get("exchange_path_one_rank"), dict) and "ms_per_step" in ex["exchange_path_one_rank"]:
         also["exchange_step_one_rank_ms"] = ex["exchange_path_one_rank"]["ms_per_step"]
+        also["exchange_mode"] = ex["exchange_path_one_rank"].get("exchange_mode")
         also["exchange_step_note"] = "N>1 step (cull+pack+ONE ncclAllGather) with a world of ONE rank; no xGMI curve measured by the builder"
     if isinstance(ex.get("target_character_mesh"), dict):
         also["target_character_mesh_skin_ms_per_1e9_verts"] = ex["target_character_mesh"].get("skin_ms_per_1e9_verts")
@@ -845,6 +851,7 @@ def exchange_path_one_rank(args, log, timeout_s=150.0, extra_env=None):
             return {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
         c = json.loads(lines[-1])
         out = {"ms_per_step": c["ms_per_step"], "value": c["value"], "unit": c["unit"], "steps": c["steps"], "visible_ids": c["config"].get("visible_ids"),
+               "exchange_mode": c["config"].get("exchange_mode"), "exchange_gather_us_at_creation": c["config"].get("exchange_gather_us_at_creation"),
                "what": "cull + k_cull_pack into the send buffer + ONE ncclAllGather per step, world of one rank (bench.py --force-collective): the step `--gpus N` times for N > 1"}
         log(f"[exchange path, one rank{', ' + str(extra_env) if extra_env else ''}] {out['ms_per_step'] * 1e3:.2f} us per step")
         return out

@@ -220,7 +220,17 @@ LMX_API int lmx_cull_bind_output(LmxContext* ctx, uint32_t view, void* d_ids, si
  * One process per GPU, every rank's context holds a disjoint share of the entities (partition by the reference's cell hash, or by
  * index). Culling needs no communication; the one exchange step per frame is a single ncclAllGather (RCCL over xGMI) of a fixed-size
  * record per rank: LMX_MAX_TYPES counts followed by ids_per_rank ids (types packed back to back). The record is written by the
- * cull's gather kernels, the collective runs on a side stream, frames are double-buffered. RCCL is loaded on first use. */
+ * cull's gather kernels, frames are double-buffered. RCCL is loaded on first use.
+ * How the step runs is chosen at lmx_exchange_create (environment LMX_EXCHANGE_MODE, read once):
+ *   auto (default)  time 32 all-gathers of the record; the collective goes on a SIDE stream (the next cull overlaps it, ~16 us more host
+ *                   work per step) when one gather takes longer than LMX_EXCHANGE_OVERLAP_US (default 16), else INLINE behind the pack kernel
+ *   inline / side   force one of the two (LMX_EXCHANGE_INLINE=1 / 0 of earlier rounds still works)
+ *   p2p             no collective in the step: every rank stores the USED part of its record (counts + the ids it has) into each peer's
+ *                   receive buffer through hipIpc mappings and raises a sequence flag; consumers wait on the device with a bounded spin
+ *                   (LMX_EXCHANGE_P2P_TIMEOUT_MS, default 2000). A peer that never shows up costs the frame: lmx_exchange_wait returns
+ *                   LMX_ERR_BUSY and the exchange refuses further steps (a rank cannot fall back to a collective on its own - the others
+ *                   would not join it; destroy and re-create). One node (<= 8 ranks). Opt-in: unmeasured over xGMI.
+ * lmx_exchange_info says which mode was taken, the gather time it was taken on, and why. */
 typedef struct LmxExchange LmxExchange;
 /* ncclGetUniqueId: rank 0 calls this and ships the 128 bytes to the other ranks over any side channel (the engine's network layer,
  * a file, torch.distributed in bench.py). */
@@ -240,6 +250,9 @@ LMX_API int lmx_exchange_wait(LmxExchange* x, uint32_t slot);
  * list was clipped (re-create the exchange with a larger capacity). gathered_event: hipEvent_t recorded after the collective. */
 LMX_API int lmx_exchange_result(LmxExchange* x, uint32_t slot, const int32_t** d_records, uint32_t* record_words, void** gathered_event);
 LMX_API int lmx_exchange_read(LmxExchange* x, uint32_t slot, int rank, uint32_t* out_counts, int32_t* out_ids, uint32_t cap);
+/* mode: 0 = all-gather on the cull stream, 1 = on a side stream, 2 = P2P stores; gather_us: one all-gather as timed at creation (< 0: the
+ * mode was forced, nothing was timed); why: a static string. Any pointer may be NULL. */
+LMX_API int lmx_exchange_info(LmxExchange* x, int* mode, double* gather_us, const char** why);
 
 /* ---- world transforms: World hierarchy, src/engine/world.cpp:255-282 ---------------------------------------
  * The reference propagates eagerly (one recursive DFS per setTransform). The batch form: stage new root/local

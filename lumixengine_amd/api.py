@@ -140,6 +140,7 @@ SYMBOLS = {
     "lmx_exchange_wait": (_ci, [_vp, _u32]),
     "lmx_exchange_result": (_ci, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_vp)]),
     "lmx_exchange_read": (_ci, [_vp, _u32, _ci, _vp, _vp, _u32]),
+    "lmx_exchange_info": (_ci, [_vp, _vp, _vp, _vp]),
     "lmx_world_build": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_world_build_with_world": (_ci, [_vp, _u32, _vp, _vp, _vp]),
     "lmx_world_set_parent": (_ci, [_vp, _i32, _i32]),
@@ -211,7 +212,8 @@ SYMBOLS = {
     "lmx_version": (C.c_char_p, []),
 }
 
-ERROR_NAMES = {1: "INVALID_ARGUMENT", 2: "NO_DEVICE", 3: "HIP", 4: "OUT_OF_MEMORY", 5: "CAPACITY", 6: "NOT_BUILT"}
+ERROR_NAMES = {1: "INVALID_ARGUMENT", 2: "NO_DEVICE", 3: "HIP", 4: "OUT_OF_MEMORY", 5: "CAPACITY", 6: "NOT_BUILT", 7: "BUSY"}
+ERR_BUSY = 7
 
 
 class LumixError(RuntimeError):
@@ -555,6 +557,12 @@ class VisibleExchange:
 
     def wait(self, slot: int):
         self.ctx.check(self.lib.lmx_exchange_wait(self.h, slot))
+
+    def info(self) -> dict:
+        """how the step runs: {"mode": "inline" | "side" | "p2p", "gather_us": one all-gather as timed at creation (None: forced), "why"}"""
+        mode, us, why = C.c_int(0), C.c_double(-1.0), C.c_char_p()
+        self.ctx.check(self.lib.lmx_exchange_info(self.h, C.byref(mode), C.byref(us), C.byref(why)))
+        return {"mode": ("inline", "side", "p2p")[mode.value], "gather_us": us.value if us.value >= 0 else None, "why": (why.value or b"").decode()}
 
     def read(self, slot: int, rank: int):
         """(counts[8], ids) of one rank's gathered record (ids of type 0 first; clipped to the exchange capacity)."""

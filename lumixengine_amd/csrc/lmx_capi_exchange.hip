@@ -7,11 +7,23 @@
 // stream ordered by events, and frames are double-buffered so that the next cull overlaps the previous frame's gather. No torch,
 // no host wait in the steady state. RCCL is loaded with dlopen at the first lmx_exchange_* call: single-GPU users of the library
 // do not need it.
+//
+// Three ways to run the step (LmxExchange::mode; same records, same results - tests/test_gpu_exchange.py runs all of them):
+//   INLINE   the all-gather on the cull stream behind the pack kernel: four API calls per step, no overlap with the next cull
+//   SIDE     the all-gather on a side stream between two events: ~16 us more host work per step, the next cull overlaps the gather
+//   P2P      no collective: every rank STORES the used part of its record (counts + the ids it has, not the fixed-size slot) into each
+//            peer's receive buffer through hipIpc mappings and raises a sequence flag there; consumers wait for the flags on the
+//            device with a BOUNDED spin. Opt-in (LMX_EXCHANGE_MODE=p2p): no multi-GPU box has run it, RCCL stays the default.
+// LMX_EXCHANGE_MODE=auto (the default when nothing is forced) times K gathers at creation and takes SIDE when one gather is longer
+// than the host work SIDE adds (LMX_EXCHANGE_OVERLAP_US, default 16), INLINE otherwise: with one rank the gather is a local copy of a few
+// microseconds, over xGMI with eight it is not - the choice is made where the exchange runs, not where it was written.
 #include <dlfcn.h>
 
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 
 #include "lmx_context.h"
 
@@ -72,7 +84,70 @@ Rccl& rccl() {
 
 } // namespace
 
+namespace {
+
+constexpr int P2P_MAX_RANKS = 8;   // one node
+constexpr uint32_t P2P_FLAG_PAD = 32; // words between flags (a 128-byte line each: peers write neighbouring flags concurrently)
+enum { P2P_READY = 0, P2P_DATA = 1 }; // flag kinds: "my receive slot may be overwritten for sequence s" / "my record of sequence s is in your slot"
+struct P2PTargets { int32_t* recv[P2P_MAX_RANKS]; uint32_t* flags[P2P_MAX_RANKS]; };
+__host__ __device__ inline uint32_t p2p_flag_index(uint32_t kind, uint32_t slot, uint32_t src) { return ((kind * 2u + slot) * (uint32_t)P2P_MAX_RANKS + src) * P2P_FLAG_PAD; }
+
+// thread p raises flag (kind, slot, me) at peer p. One tiny launch BEHIND the stores it announces: a kernel boundary orders them (a fence per
+// storing block would be an L2 write-back each on this chip, profiles/r05/keys_last_block_fences.txt); the release below makes them
+// visible beyond this device before the flag.
+__global__ __launch_bounds__(64) void k_p2p_signal(P2PTargets t, uint32_t world, uint32_t index, uint32_t value) {
+	if (threadIdx.x < world) {
+		__threadfence_system();
+		__hip_atomic_store(t.flags[threadIdx.x] + index, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+// thread r waits until the flag (kind, slot, r) in THIS rank's memory has reached `value`. BOUNDED: after timeout_ticks of the 100 MHz
+// wall clock the kernel gives up, says so in *error (rank and kind of the missing flag) and ends - a peer that died or fell out of step
+// costs the frame and an error code, never the device.
+__global__ __launch_bounds__(64) void k_p2p_wait(const uint32_t* flags, uint32_t world, uint32_t base_index, uint32_t value, uint64_t timeout_ticks, uint32_t* error, uint32_t code) {
+	if (threadIdx.x >= world) return;
+	const uint32_t* f = flags + base_index + threadIdx.x * P2P_FLAG_PAD;
+	const uint64_t t0 = wall_clock64();
+	while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) { // (sequence numbers wrap)
+		if (wall_clock64() - t0 > timeout_ticks) {
+			atomicExch(error, code | (threadIdx.x << 8) | 0x80000000u);
+			return;
+		}
+		__builtin_amdgcn_s_sleep(16);
+	}
+}
+// block (peer, frustum, piece): the used part of this rank's sub-record f - its 8 counts and min(sum, cap_f) ids - into peer's receive slot
+__global__ __launch_bounds__(256) void k_p2p_scatter(const int32_t* __restrict__ send, P2PTargets t, uint32_t slot_words_offset, uint32_t sub, uint32_t cap_f, const uint32_t* error) {
+	if (*error != 0) return; // a peer did not free its slot in time: nothing of it is overwritten
+	const int32_t* rec = send + (size_t)blockIdx.y * sub;
+	int32_t* dst = t.recv[blockIdx.x] + slot_words_offset + (size_t)blockIdx.y * sub;
+	uint32_t total = 0;
+#pragma unroll
+	for (int k = 0; k < MAX_TYPES; ++k) total += (uint32_t)rec[k];
+	const uint32_t words = MAX_TYPES + (total < cap_f ? total : cap_f);
+	for (uint32_t w = blockIdx.z * 256u + threadIdx.x; w < words; w += gridDim.z * 256u) dst[w] = rec[w];
+}
+
+} // namespace
+
 struct LmxExchange {
+	enum Mode { INLINE = 0, SIDE = 1, P2P = 2 };
+	int mode = INLINE;
+	double gather_us = -1.0;   // one all-gather of this exchange's record, timed at creation (LMX_EXCHANGE_MODE=auto); < 0: not measured
+	const char* mode_why = "default";
+	// P2P: one allocation per rank [recv slot 0 | recv slot 1 | flags], shared with the peers through hipIpc handles
+	struct {
+		void* block = nullptr;
+		size_t slot_words = 0;            // words of one receive slot (max_record * world)
+		P2PTargets targets = {};
+		void* opened[P2P_MAX_RANKS] = {};  // what hipIpcCloseMemHandle takes
+		uint32_t* my_flags = nullptr;
+		uint32_t seq[2] = {0, 0};
+		uint32_t* h_error = nullptr;      // pinned, mapped: the wait kernels report a timeout here
+		uint32_t* d_error = nullptr;
+		uint64_t timeout_ticks = 0;
+		bool failed = false;
+	} p2p;
 	// LMX_EXCHANGE_TRACE=1: host time of every API call of a step, summed and printed by lmx_exchange_destroy (a measurement aid)
 	bool trace = false;
 	// Default (round 4): the all-gather is enqueued on the CULL stream, behind the pack kernel - no side stream, no event pair between
@@ -98,9 +173,65 @@ struct LmxExchange {
 	uint32_t next = 0;
 };
 
-extern "C" {
+extern "C" void lmx_exchange_destroy(LmxExchange* x);
 
-void lmx_exchange_destroy(LmxExchange* x);
+namespace {
+
+const int32_t* recv_base(const LmxExchange* x, uint32_t slot) {
+	return x->mode == LmxExchange::P2P ? static_cast<const int32_t*>(x->p2p.block) + (size_t)slot * x->p2p.slot_words : x->recv[slot].p;
+}
+
+// P2P mode: this rank's receive slots + flags in ONE allocation, its hipIpc handle all-gathered through the communicator (the only use of
+// RCCL in this mode), every peer's allocation mapped here. Collective: every rank runs it inside lmx_exchange_create.
+int p2p_setup(LmxExchange* x, size_t max_record) {
+	LmxContext* ctx = x->ctx;
+	Rccl& r = rccl();
+	if (x->world > P2P_MAX_RANKS) return fail(ctx, LMX_ERR_CAPACITY, "LMX_EXCHANGE_MODE=p2p serves up to %d ranks (one node), not %d", P2P_MAX_RANKS, x->world);
+	const size_t flag_words = (size_t)2 * 2 * P2P_MAX_RANKS * P2P_FLAG_PAD; // kinds x slots x sources
+	x->p2p.slot_words = max_record * (size_t)x->world;
+	const size_t bytes = (2 * x->p2p.slot_words + flag_words) * sizeof(int32_t);
+	// fine-grained memory where the runtime has it: what a peer GPU stores here must not be shadowed by a stale line of this GPU's L2
+	if (hipExtMallocWithFlags(&x->p2p.block, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+		(void)hipGetLastError();
+		x->p2p.block = nullptr;
+		LMX_HIP(ctx, hipMalloc(&x->p2p.block, bytes));
+	}
+	LMX_HIP(ctx, hipMemset(x->p2p.block, 0, bytes));
+	x->p2p.my_flags = static_cast<uint32_t*>(x->p2p.block) + 2 * x->p2p.slot_words;
+	hipIpcMemHandle_t mine;
+	static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 16 int32");
+	if (hipIpcGetMemHandle(&mine, x->p2p.block) != hipSuccess) return fail(ctx, LMX_ERR_HIP, "hipIpcGetMemHandle failed: the receive buffer cannot be shared with the other ranks");
+	DevBuf<int32_t> h_send, h_recv;
+	LMX_HIP(ctx, h_send.reserve(16));
+	LMX_HIP(ctx, h_recv.reserve((size_t)16 * x->world));
+	LMX_HIP(ctx, hipMemcpy(h_send.p, &mine, 64, hipMemcpyHostToDevice));
+	if (r.AllGather(h_send.p, h_recv.p, 16, NCCL_INT32, x->comm, x->side) != 0) return fail(ctx, LMX_ERR_HIP, "all-gather of the hipIpc handles failed");
+	LMX_HIP(ctx, hipStreamSynchronize(x->side));
+	hipIpcMemHandle_t all[P2P_MAX_RANKS];
+	LMX_HIP(ctx, hipMemcpy(all, h_recv.p, (size_t)64 * x->world, hipMemcpyDeviceToHost));
+	for (int p = 0; p < x->world; ++p) {
+		void* base = x->p2p.block;
+		if (p != x->rank) {
+			if (hipIpcOpenMemHandle(&base, all[p], hipIpcMemLazyEnablePeerAccess) != hipSuccess) return fail(ctx, LMX_ERR_HIP, "hipIpcOpenMemHandle of rank %d's receive buffer failed", p);
+			x->p2p.opened[p] = base;
+		}
+		x->p2p.targets.recv[p] = static_cast<int32_t*>(base);
+		x->p2p.targets.flags[p] = static_cast<uint32_t*>(base) + 2 * x->p2p.slot_words;
+	}
+	LMX_HIP(ctx, hipHostMalloc(&x->p2p.h_error, sizeof(uint32_t), hipHostMallocMapped));
+	*x->p2p.h_error = 0;
+	LMX_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&x->p2p.d_error), x->p2p.h_error, 0));
+	const char* to = getenv("LMX_EXCHANGE_P2P_TIMEOUT_MS");
+	x->p2p.timeout_ticks = (uint64_t)(to ? atof(to) : 2000.0) * 100000ull; // the wall clock of the wait kernels ticks at 100 MHz
+	// nobody stores into a peer before every peer has zeroed its flags and mapped everybody: one more collective as the barrier
+	if (r.AllGather(h_send.p, h_recv.p, 16, NCCL_INT32, x->comm, x->side) != 0) return fail(ctx, LMX_ERR_HIP, "the barrier behind the hipIpc mappings failed");
+	LMX_HIP(ctx, hipStreamSynchronize(x->side));
+	return LMX_OK;
+}
+
+} // namespace
+
+extern "C" {
 
 int lmx_exchange_unique_id(void* out_id_128_bytes) {
 	if (!out_id_128_bytes) return LMX_ERR_INVALID_ARGUMENT;
@@ -154,6 +285,49 @@ int lmx_exchange_create(LmxContext* ctx, int rank, int world, const void* unique
 		lmx_exchange_destroy(x);
 		return rc2;
 	}
+	// ---- how the step runs
+	const char* mode_env = getenv("LMX_EXCHANGE_MODE");
+	std::string mode = mode_env ? mode_env : (inl ? (x->inline_gather ? "inline" : "side") : "auto");
+	auto time_gathers = [&]() -> int { // K gathers of the 1-frustum record back to back on the side stream, by events: what ONE gather costs there
+		const int K = 32;
+		hipEvent_t a = nullptr, b = nullptr;
+		LMX_HIP(ctx, hipEventCreate(&a));
+		LMX_HIP(ctx, hipEventCreate(&b));
+		int rc = 0;
+		for (int k = 0; k < 4 && rc == 0; ++k) rc = r.AllGather(x->send[0].p, x->recv[0].p, x->record, NCCL_INT32, x->comm, x->side); // (connection set-up is not the gather)
+		if (rc == 0 && hipEventRecord(a, x->side) != hipSuccess) rc = -1;
+		for (int k = 0; k < K && rc == 0; ++k) rc = r.AllGather(x->send[0].p, x->recv[0].p, x->record, NCCL_INT32, x->comm, x->side);
+		float ms = 0;
+		if (rc == 0 && (hipEventRecord(b, x->side) != hipSuccess || hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess)) rc = -1;
+		(void)hipEventDestroy(a);
+		(void)hipEventDestroy(b);
+		if (rc != 0) return fail(ctx, LMX_ERR_HIP, "timing the all-gather failed");
+		x->gather_us = 1e3 * ms / K;
+		return LMX_OK;
+	};
+	int rc3 = LMX_OK;
+	if (mode == "auto") {
+		LMX_HIP(ctx, hipMemsetAsync(x->send[0].p, 0, max_record * sizeof(int32_t), x->side));
+		rc3 = time_gathers();
+		const char* thr = getenv("LMX_EXCHANGE_OVERLAP_US");
+		const double threshold = thr ? atof(thr) : 16.0;
+		x->mode = x->gather_us > threshold ? LmxExchange::SIDE : LmxExchange::INLINE;
+		x->mode_why = x->mode == LmxExchange::SIDE ? "auto: one gather takes longer than the host work the side stream adds" : "auto: one gather is shorter than the host work the side stream adds";
+	} else if (mode == "side") {
+		x->mode = LmxExchange::SIDE; x->mode_why = "forced";
+	} else if (mode == "inline") {
+		x->mode = LmxExchange::INLINE; x->mode_why = "forced";
+	} else if (mode == "p2p") {
+		x->mode = LmxExchange::P2P; x->mode_why = "forced";
+		rc3 = p2p_setup(x, max_record);
+	} else {
+		rc3 = fail(ctx, LMX_ERR_INVALID_ARGUMENT, "LMX_EXCHANGE_MODE=%s: auto, inline, side or p2p", mode.c_str());
+	}
+	if (rc3 != LMX_OK) {
+		lmx_exchange_destroy(x);
+		return rc3;
+	}
+	x->inline_gather = x->mode != LmxExchange::SIDE;
 	*out = x;
 	return LMX_OK;
 }
@@ -167,6 +341,10 @@ void lmx_exchange_destroy(LmxExchange* x) {
 	}
 	(void)hipStreamSynchronize(x->side);
 	if (x->inline_gather && x->ctx) (void)hipStreamSynchronize(x->ctx->stream); // (the gathers of this mode run there)
+	for (int p = 0; p < P2P_MAX_RANKS; ++p)
+		if (x->p2p.opened[p]) (void)hipIpcCloseMemHandle(x->p2p.opened[p]);
+	if (x->p2p.block) (void)hipFree(x->p2p.block);
+	if (x->p2p.h_error) (void)hipHostFree(x->p2p.h_error);
 	if (x->comm) (void)rccl().CommDestroy(x->comm);
 	for (int i = 0; i < 2; ++i) {
 		if (x->culled[i]) (void)hipEventDestroy(x->culled[i]);
@@ -199,6 +377,15 @@ int lmx_exchange_cull_many(LmxExchange* x, const LmxShiftedFrustum* frusta, uint
 		t = t1;
 	};
 	auto t = now();
+	const bool p2p = x->mode == LmxExchange::P2P;
+	uint32_t seq = 0;
+	if (p2p) {
+		if (x->p2p.failed) return fail(ctx, LMX_ERR_BUSY, "this exchange's P2P mode has failed before (a peer fell out of step): destroy it and create one in another mode");
+		// this rank's slot k may be overwritten for sequence `seq` (the caller is done with its previous contents: the API contract) - said
+		// first, so that the peers' stores never wait for this rank's cull
+		seq = ++x->p2p.seq[k];
+		hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(64), 0, ctx->stream, x->p2p.targets, (uint32_t)x->world, p2p_flag_index(P2P_READY, k, (uint32_t)x->rank), seq);
+	}
 	// the send / recv buffers of this slot are free once its previous gather has finished: the cull stream waits for it (device-side)
 	if (x->in_flight[k] && !x->inline_gather) LMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, x->gathered[k], 0));
 	lap(0, t);
@@ -218,6 +405,21 @@ int lmx_exchange_cull_many(LmxExchange* x, const LmxShiftedFrustum* frusta, uint
 	x->cap_f[k] = cap_f;
 	x->record = n_frusta * sub;
 	lap(2, t);
+	if (p2p) {
+		// every peer's slot k is free -> the used part of this rank's record into all of them -> "my record of sequence seq is there" ->
+		// everybody's record of this sequence is here. Two bounded waits; a timeout is reported by lmx_exchange_wait.
+		const uint32_t record = n_frusta * sub;
+		hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, ctx->stream, x->p2p.my_flags, (uint32_t)x->world, p2p_flag_index(P2P_READY, k, 0), seq, x->p2p.timeout_ticks, x->p2p.d_error, 1u);
+		hipLaunchKernelGGL(k_p2p_scatter, dim3((uint32_t)x->world, n_frusta, std::max(1u, std::min(64u, cap_f / 16384u))), dim3(256), 0, ctx->stream, x->send[k].p, x->p2p.targets,
+			(uint32_t)((size_t)k * x->p2p.slot_words + (size_t)x->rank * record), sub, cap_f, x->p2p.d_error);
+		hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(64), 0, ctx->stream, x->p2p.targets, (uint32_t)x->world, p2p_flag_index(P2P_DATA, k, (uint32_t)x->rank), seq);
+		hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, ctx->stream, x->p2p.my_flags, (uint32_t)x->world, p2p_flag_index(P2P_DATA, k, 0), seq, x->p2p.timeout_ticks, x->p2p.d_error, 2u);
+		LMX_HIP(ctx, hipGetLastError());
+		LMX_HIP(ctx, hipEventRecord(x->gathered[k], ctx->stream));
+		x->in_flight[k] = true;
+		if (out_slot) *out_slot = k;
+		return LMX_OK;
+	}
 	hipStream_t gather_stream = x->side;
 	if (x->inline_gather) {
 		gather_stream = ctx->stream; // behind the pack kernel in stream order
@@ -246,6 +448,22 @@ int lmx_exchange_wait(LmxExchange* x, uint32_t slot) {
 	LmxContext* ctx = x->ctx;
 	LMX_CHECK_CTX(ctx);
 	if (x->in_flight[slot]) LMX_HIP(ctx, hipEventSynchronize(x->gathered[slot]));
+	if (x->mode == LmxExchange::P2P && *x->p2p.h_error != 0) {
+		const uint32_t e = *x->p2p.h_error;
+		x->p2p.failed = true;
+		return fail(ctx, LMX_ERR_BUSY, "P2P exchange: rank %u's %s flag did not arrive within the bounded wait (a peer died or fell out of step); the frame is lost, the exchange unusable",
+			(e >> 8) & 0xffu, (e & 0xffu) == 1u ? "slot-free" : "record-stored");
+	}
+	return LMX_OK;
+}
+
+// How this exchange runs its step and why: mode 0 = all-gather on the cull stream, 1 = on a side stream (overlaps the next cull), 2 = P2P stores;
+// gather_us = one all-gather as timed at creation (< 0: not timed, the mode was forced).
+int lmx_exchange_info(LmxExchange* x, int* mode, double* gather_us, const char** why) {
+	if (!x) return LMX_ERR_INVALID_ARGUMENT;
+	if (mode) *mode = x->mode;
+	if (gather_us) *gather_us = x->gather_us;
+	if (why) *why = x->mode_why;
 	return LMX_OK;
 }
 
@@ -254,7 +472,7 @@ int lmx_exchange_wait(LmxExchange* x, uint32_t slot) {
 // type 0 first. `gathered_event` (hipEvent_t as void*) is recorded when the collective has finished.
 int lmx_exchange_result(LmxExchange* x, uint32_t slot, const int32_t** d_records, uint32_t* record_words, void** gathered_event) {
 	if (!x || slot > 1) return LMX_ERR_INVALID_ARGUMENT;
-	if (d_records) *d_records = x->recv[slot].p;
+	if (d_records) *d_records = recv_base(x, slot);
 	if (record_words) *record_words = x->n_frusta[slot] * (MAX_TYPES + x->cap_f[slot]);
 	if (gathered_event) *gathered_event = x->gathered[slot];
 	return LMX_OK;
@@ -268,7 +486,7 @@ int lmx_exchange_read_many(LmxExchange* x, uint32_t slot, int rank, uint32_t fru
 	LMX_CHECK_CTX(ctx);
 	if (int rc = lmx_exchange_wait(x, slot)) return rc;
 	const uint32_t sub = MAX_TYPES + x->cap_f[slot];
-	const int32_t* rec = x->recv[slot].p + (size_t)rank * x->n_frusta[slot] * sub + (size_t)frustum * sub;
+	const int32_t* rec = recv_base(x, slot) + (size_t)rank * x->n_frusta[slot] * sub + (size_t)frustum * sub;
 	LMX_HIP(ctx, hipMemcpy(out_counts, rec, sizeof(uint32_t) * MAX_TYPES, hipMemcpyDeviceToHost));
 	uint64_t total = 0;
 	for (int t = 0; t < MAX_TYPES; ++t) total += out_counts[t];

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
 #include <sched.h>
@@ -117,6 +118,10 @@ int ncclAllGather(const void* send, void* recv, size_t count, int type, void* co
 	const size_t bytes = count * type_bytes(type);
 	if (!c || bytes > SLOT_BYTES) { g_error = "record larger than the loopback slot"; return 4; }
 	if (hipStreamSynchronize(stream) != hipSuccess) { g_error = "hipStreamSynchronize failed"; return 1; }
+	// LOOPBACK_RCCL_DELAY_US: a gather that takes this long (what a collective over several links costs, where this one is a memcpy): the
+	// exchange's choice of mode by measured gather time is tested with it (tests/test_gpu_exchange.py, "auto_slow_gather")
+	static const long delay_us = getenv("LOOPBACK_RCCL_DELAY_US") ? atol(getenv("LOOPBACK_RCCL_DELAY_US")) : 0;
+	if (delay_us > 0) usleep((useconds_t)delay_us);
 	if (hipMemcpy(c->data + SLOT_BYTES * (size_t)c->rank, send, bytes, hipMemcpyDeviceToHost) != hipSuccess) { g_error = "D2H failed"; return 1; }
 	std::atomic_thread_fence(std::memory_order_seq_cst);
 	if (!barrier(c)) return 2;

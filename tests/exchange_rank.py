@@ -31,6 +31,34 @@ def shared_uid(api, rank, directory, name):
     return wait_for(path)
 
 
+def missing_peer(api, ctx, rank, world, directory, cams, cap):
+    """tests/test_gpu_exchange.py::test_p2p_exchange_gives_up_on_a_missing_peer: both ranks create the exchange, rank 1 never steps"""
+    x = api.VisibleExchange(ctx, rank, world, shared_uid(api, rank, directory, "uid_m"), cap)
+    try:
+        if rank == 0:
+            t0 = time.time()
+            slot = x.cull(cams[0])
+            try:
+                x.wait(slot)
+                print("rank 0: the step completed without its peer?!")
+                sys.exit(3)
+            except api.LumixError as e:
+                assert e.code == api.ERR_BUSY, e
+                print(f"rank 0: step gave up with LMX_ERR_BUSY after {time.time() - t0:.2f} s: {e}")
+            try:
+                x.cull(cams[0])
+                print("rank 0: a failed P2P exchange accepted another step")
+                sys.exit(4)
+            except api.LumixError as e:
+                assert e.code == api.ERR_BUSY, e
+                print("rank 0: the exchange refuses further steps")
+        else:
+            time.sleep(1.5)  # stays away from the step; leaves after rank 0 has given up
+    finally:
+        x.close()
+    ctx.close()
+
+
 def main():
     rank, world, directory = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     from lumixengine_amd import api, scenes
@@ -45,8 +73,13 @@ def main():
     cams = H.frusta(api, names=["origin_identity", "origin_yaw_pitch", "narrow_fov", "ortho_cascade_large"])
     out = {"owned": sc["entity"][mine]}
     cap = 120_000  # the whole scene fits: nothing is clipped in the first two exchanges
+    if len(sys.argv) > 4 and sys.argv[4] == "missing_peer":
+        return missing_peer(api, ctx, rank, world, directory, cams, cap)
     x = api.VisibleExchange(ctx, rank, world, shared_uid(api, rank, directory, "uid_a"), cap)
     try:
+        want_mode = os.environ.get("LMX_EXPECT_EXCHANGE_MODE")
+        if want_mode:  # the parent test says what lmx_exchange_info must report (e.g. "side" when the double's gathers are slow and the mode is "auto")
+            assert x.info()["mode"] == want_mode, x.info()
         slots = []
         for frame in range(6):  # pipelined: read one frame late, both slots re-used twice
             slots.append(x.cull(cams[frame % len(cams)]))

@@ -27,6 +27,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <tuple>
 #include <type_traits>
 #include <utility>
@@ -123,6 +124,13 @@ hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventQuery(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 }
+// Inter-process mappings do not exist on the simulated device: the calls fail, and with them LMX_EXCHANGE_MODE=p2p - loudly, at creation.
+struct hipIpcMemHandle_t { char reserved[64]; };
+enum { hipIpcMemLazyEnablePeerAccess = 1, hipDeviceMallocFinegrained = 1 };
+static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*) { return hipErrorUnknown; }
+static inline hipError_t hipIpcOpenMemHandle(void**, hipIpcMemHandle_t, unsigned) { return hipErrorUnknown; }
+static inline hipError_t hipIpcCloseMemHandle(void*) { return hipErrorUnknown; }
+static inline hipError_t hipExtMallocWithFlags(void** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
 #pragma GCC visibility pop
 // the C++ overloads of the HIP headers
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(p), bytes); }
@@ -258,6 +266,11 @@ template <typename T> static inline T atomicMin(T* p, T v) {
 	return cur;
 }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+static inline unsigned long long wall_clock64() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (unsigned long long)ts.tv_sec * 100000000ull + (unsigned long long)ts.tv_nsec / 10ull; } // 100 MHz, as the device's
 static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 // ---- wave64 cross-lane operations ---------------------------------------------------------------------------------------------

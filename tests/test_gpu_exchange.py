@@ -2,6 +2,8 @@
 cull's gather kernels write the [8 counts | ids] record, ncclAllGather ships it on the side stream, frames alternate between two
 slots - and the gathered record must hold exactly the oracle's visible ids per type. (More ranks: tests/test_distributed.py checks
 the partition and the record format over gloo; the 8-GPU run is the driver's.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,9 +14,11 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("inline_gather", [0, 1])
-def test_exchange_single_rank_matches_oracle(gpu_ctx, oracle_port, inline_gather, monkeypatch):
-    monkeypatch.setenv("LMX_EXCHANGE_INLINE", str(inline_gather))  # (read when the exchange is created) 1: the gather on the cull stream
+@pytest.mark.parametrize("mode", ["side", "inline", "auto", "p2p"])
+def test_exchange_single_rank_matches_oracle(gpu_ctx, oracle_port, mode, monkeypatch):
+    if mode == "p2p" and os.environ.get("LMX_HOSTSIM") == "1":
+        pytest.skip("hipIpc mappings do not exist on the simulated device")
+    monkeypatch.setenv("LMX_EXCHANGE_MODE", mode)  # (read when the exchange is created): where the all-gather runs, or no collective at all
     sc = scenes.cull_scene(200_000, 4000.0, seed=13, mixed_types=True)
     cs = api.CullingSystem(gpu_ctx)
     cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
@@ -28,6 +32,9 @@ def test_exchange_single_rank_matches_oracle(gpu_ctx, oracle_port, inline_gather
     cap = max(sum(len(a) for a in w) for w in want) + 100
     x = api.VisibleExchange(gpu_ctx, 0, 1, api.exchange_unique_id(), cap)
     try:
+        info = x.info()
+        assert info["mode"] == (mode if mode != "auto" else info["mode"]) and info["mode"] in ("inline", "side", "p2p")
+        assert (info["gather_us"] is not None and info["gather_us"] > 0) == (mode == "auto"), info  # timed only when the choice is made by measurement
         # pipelined: two frames in flight, read back one frame late (what a renderer consuming last frame's list does)
         slots = []
         for frame in range(8):
@@ -95,8 +102,8 @@ def _loopback_library():
     return out
 
 
-@pytest.mark.parametrize("world,inline_gather", [(2, 0), (4, 0), (8, 0), (2, 1), (4, 1)])
-def test_exchange_ranks_on_one_gpu_loopback(tmp_path, oracle_port, world, inline_gather):
+@pytest.mark.parametrize("world,mode", [(2, "side"), (4, "side"), (8, "side"), (2, "inline"), (4, "inline"), (2, "auto_slow_gather"), (2, "p2p"), (4, "p2p")])
+def test_exchange_ranks_on_one_gpu_loopback(tmp_path, oracle_port, world, mode):
     """The exchange with a world of 2 / 4 ranks on this box's one GPU: one process per rank, each with its own context and its cell shard of one
     scene, the collective carried by a shared-memory test double of the five RCCL entry points (RCCL itself refuses two ranks on one
     device). Everything around the wire is the product's: the per-rank / per-frustum record layout, the peers' offsets in the receive
@@ -106,11 +113,18 @@ def test_exchange_ranks_on_one_gpu_loopback(tmp_path, oracle_port, world, inline
     import subprocess
     import sys
 
+    if mode == "p2p" and os.environ.get("LMX_HOSTSIM") == "1":
+        pytest.skip("hipIpc mappings do not exist on the simulated device")
     lib = _loopback_library()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # inline_gather: LMX_EXCHANGE_INLINE=1, the all-gather on the cull stream instead of the side stream (an experiment of the exchange's
-    # host cost): same records, same pipelining rules
-    env = dict(os.environ, LMX_RCCL_LIBRARY=lib, LMX_EXCHANGE_INLINE=str(inline_gather), PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    # mode: where the all-gather runs (side stream / cull stream: same records, same pipelining rules), chosen by measurement ("auto": the double is
+    # told to take 200 us per gather, so the exchange must pick the side stream - exchange_rank.py asserts what lmx_exchange_info reports), or
+    # "p2p": no collective in the step at all - the ranks store into each other's receive buffers through REAL hipIpc mappings (one device, one
+    # process per rank) and wait for sequence flags; the double only carries the handles at creation
+    env = dict(os.environ, LMX_RCCL_LIBRARY=lib, LMX_EXCHANGE_MODE="auto" if mode.startswith("auto") else mode, LMX_EXPECT_EXCHANGE_MODE="side" if mode.startswith("auto") else mode,
+               PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    if mode == "auto_slow_gather":
+        env["LOOPBACK_RCCL_DELAY_US"] = "200"
     procs = [subprocess.Popen([sys.executable, "-m", "tests.exchange_rank", str(r), str(world), str(tmp_path)], cwd=root, env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
@@ -200,3 +214,31 @@ def test_config5_frame_two_ranks_loopback(tmp_path, oracle_port):
         want = [len(ocs.cull(frusta[f : f + 1])[0]) for f in range(len(frusta))]
         assert got[0]["visible_per_rank_and_frustum"][r] == want and got[r]["visible_per_frustum_this_rank"] == want, (r, want)
         assert max(want) <= got[0]["ids_per_rank_and_frustum"] and sum(want) > 0
+
+
+def test_p2p_exchange_gives_up_on_a_missing_peer(tmp_path):
+    """LMX_EXCHANGE_MODE=p2p never waits without a bound: rank 1 of a world of two creates the exchange (the hipIpc mappings exist) and then
+    stays away from the step. Rank 0's step must come back - lmx_exchange_wait returns LMX_ERR_BUSY within the configured 300 ms - the
+    exchange must refuse further steps, and the process must exit by itself (no hung kernel left on the device)."""
+    import subprocess
+    import sys
+    import time
+
+    if os.environ.get("LMX_HOSTSIM") == "1":
+        pytest.skip("hipIpc mappings do not exist on the simulated device")
+    lib = _loopback_library()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LMX_RCCL_LIBRARY=lib, LMX_EXCHANGE_MODE="p2p", LMX_EXCHANGE_P2P_TIMEOUT_MS="300", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.exchange_rank", str(r), "2", str(tmp_path), "missing_peer"], cwd=root, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=120)[0].decode(errors="replace"))
+        except subprocess.TimeoutExpired:
+            p.kill()  # (the exact process this test started)
+            logs.append(p.communicate()[0].decode(errors="replace") + "\n[timed out: the bounded wait did not end]")
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    assert "rank 0: step gave up with LMX_ERR_BUSY" in logs[0] and "refuses further steps" in logs[0], logs[0]
+    assert time.time() - t0 < 100
