@@ -356,12 +356,9 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(
 		__syncthreads();
 		st_bits = __builtin_amdgcn_readfirstlane(s_verdict_multi[0]);
 		tile_flags = __builtin_amdgcn_readfirstlane(s_verdict_multi[1]);
-#pragma unroll 1
-		for (int f = 0; f < nf; ++f) {
-			const uint32_t st = (st_bits >> (2 * f)) & 3u;
-			any_mixed |= st == TILE_MIXED;
-			any_live |= st != TILE_REJECT;
-		}
+		static_assert(TILE_REJECT == 0 && TILE_ACCEPT == 1 && TILE_MIXED == 2, "the verdicts of all frusta are read off the 2-bit fields by bit logic");
+		any_mixed = ((st_bits >> 1) & ~st_bits & 0x5555u) != 0; // (frusta >= nf hold TILE_REJECT)
+		any_live = st_bits != 0;
 	}
 	if (!any_live) return;
 	if constexpr (F != 1) { if (LMX_CULL8_PROBE & 1) return; } // (timing probe: the tile-level tests alone)
@@ -372,9 +369,8 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(
 	v2f* s_d2 = reinterpret_cast<v2f*>(s_info);                                                  // [n_frusta * cell_cap][3]
 	uint32_t* s_word = reinterpret_cast<uint32_t*>(s_d2 + (F != 1 ? (size_t)nf * a.cell_cap * 3 : 0)); // [cell_cap], behind the records
 	if constexpr (F != 1) {
-		static_assert(TILE_ACCEPT < 4 && CELL_ACCEPT == 1, "a settled frustum contributes CELL_ACCEPT or nothing");
-#pragma unroll 1
-		for (int f = 0; f < nf; ++f) tile_word |= (((st_bits >> (2 * f)) & 3u) == TILE_ACCEPT ? (uint32_t)CELL_ACCEPT : 0u) << (2 * f);
+		static_assert(TILE_ACCEPT == 1 && CELL_ACCEPT == 1, "a settled frustum contributes CELL_ACCEPT or nothing: its verdict field IS its class field");
+		tile_word = st_bits & ~(st_bits >> 1) & 0x5555u;
 	}
 
 	uint32_t first_cell = 0;
@@ -395,8 +391,22 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(
 				V3 off;
 				ci.cls = classify_cell(frp[f], IV3{key.ix, key.iy, key.iz}, big, &off, F == 1 ? plane_skip : 0u);
 				if (ci.cls == CELL_TEST) {
+					if constexpr (F != 1) {
+						// relative_plane_d for two planes at a time (the frustum's arrays hold planes k, k + 1 side by side: packed operands out of the
+						// kernarg segment): q = point + offset, d = -((q.x n.x + q.y n.y) + q.z n.z), every operation rounded on its own as the scalar form
+						const v2f ox = {off.x, off.x}, oy = {off.y, off.y}, oz = {off.z, off.z};
 #pragma unroll
-					for (int k = 0; k < 6; ++k) ci.d[k] = relative_plane_d(frp[f], off, k);
+						for (int k = 0; k < 6; k += 2) {
+							const v2f qx = v2f{frp[f].px[k], frp[f].px[k + 1]} + ox, qy = v2f{frp[f].py[k], frp[f].py[k + 1]} + oy, qz = v2f{frp[f].pz[k], frp[f].pz[k + 1]} + oz;
+							v2f t = qx * v2f{frp[f].nx[k], frp[f].nx[k + 1]};
+							t = t + qy * v2f{frp[f].ny[k], frp[f].ny[k + 1]};
+							t = t + qz * v2f{frp[f].nz[k], frp[f].nz[k + 1]};
+							ci.d[k] = -t.x; ci.d[k + 1] = -t.y;
+						}
+					} else {
+#pragma unroll
+						for (int k = 0; k < 6; ++k) ci.d[k] = relative_plane_d(frp[f], off, k);
+					}
 					if constexpr (PLANE_SKIP) ci.pairs = relevant_plane_pairs(frp[f], IV3{key.ix, key.iy, key.iz}, ci.d);
 				}
 			}
@@ -509,10 +519,8 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(
 #endif
 	bool pretest_tile = false;
 	if constexpr (PRETEST) {
-		uint32_t n_mixed = 0;
-#pragma unroll 1
-		for (int f = 0; f < nf; ++f) n_mixed += ((st_bits >> (2 * f)) & 3u) == TILE_MIXED ? 1u : 0u;
-		pretest_tile = any_mixed && n_mixed >= (uint32_t)LMX_CULL8_MFMA_MIN_MIXED;
+		const uint32_t mixed_bits = (st_bits >> 1) & ~st_bits & 0x5555u; // bit 2 f: frustum f is MIXED
+		pretest_tile = (uint32_t)__popc(mixed_bits) >= (uint32_t)LMX_CULL8_MFMA_MIN_MIXED;
 		if (pretest_tile) {
 			const uint32_t row = lane & 31u, k = lane >> 5;
 			const uint32_t rp = (row & 3u) + 4u * ((row >> 3) & 1u), rh = (row >> 2) & 1u, rq = row >> 4;
@@ -532,8 +540,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(
 					const uint32_t fl = 4u * gq + 2u * k + q; // the frustum whose six values this lane finds in accumulators 8 q .. 8 q + 5
 					pre_off[gq][q] = (fl < (uint32_t)nf ? fl : (uint32_t)nf - 1u) * a.cell_cap * 3u;
 					const uint32_t f_lo = 4u * gq + q, f_hi = f_lo + 2u;
-					pre_care[gq][q] = (f_lo < (uint32_t)nf && ((st_bits >> (2 * f_lo)) & 3u) == TILE_MIXED ? 0x00000000ffffffffull : 0ull) |
-						(f_hi < (uint32_t)nf && ((st_bits >> (2 * f_hi)) & 3u) == TILE_MIXED ? 0xffffffff00000000ull : 0ull);
+					pre_care[gq][q] = ((mixed_bits >> (2 * f_lo)) & 1u ? 0x00000000ffffffffull : 0ull) | ((mixed_bits >> (2 * f_hi)) & 1u ? 0xffffffff00000000ull : 0ull);
 				}
 			}
 		}
@@ -842,13 +849,30 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(
 		}
 	}
 	if constexpr (F != 1) {
-		// per-frustum counts of the wave by ballots over the verdict bits (scalar population counts), lane f keeps frustum f's
-#pragma unroll 1
-		for (int f = 0; f < nf; ++f) {
-			if (((st_bits >> (2 * f)) & 3u) == TILE_REJECT) continue;
-			uint32_t c = 0;
+		// Per-frustum counts of the wave, lane f keeps frustum f's. A lane's four chunks are summed in packed fields first (a verdict bit per
+		// 2-bit field: two words of sums <= 2, then nibbles <= 4 for the even and the odd frusta, spread to 16-bit fields), the four words are
+		// summed over the wave by four DPP steps inside every row of 16 lanes + one v_readlane per row. (Per frustum and chunk a ballot and a
+		// scalar population count - 32 of each per wave, with their extract / compare - were ~440 of a wave's ~2400 instructions.)
+		static_assert(CHW == 4, "the packed sums hold four chunks");
+		const uint32_t s01 = vis2[0] + vis2[1], s23 = vis2[2] + vis2[3];
+		const uint32_t ev = (s01 & 0x3333u) + (s23 & 0x3333u), od = ((s01 >> 2) & 0x3333u) + ((s23 >> 2) & 0x3333u); // nibble j: frustum 2 j / 2 j + 1
+		uint32_t word[4] = {(ev & 0xfu) | ((ev & 0xf0u) << 12), ((ev >> 8) & 0xfu) | ((ev & 0xf000u) << 4),   // {f0 | f2 << 16}, {f4 | f6 << 16}
+			(od & 0xfu) | ((od & 0xf0u) << 12), ((od >> 8) & 0xfu) | ((od & 0xf000u) << 4)};                  // {f1 | f3 << 16}, {f5 | f7 << 16}
+		uint32_t tot[4];
 #pragma unroll
-			for (int i = 0; i < CHW; ++i) c += (uint32_t)__popcll(__ballot(((vis2[i] >> (2 * f)) & 1u) != 0));
+		for (int k = 0; k < 4; ++k) {
+			uint32_t v = word[k];
+			v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]: + lane ^ 1
+			v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);  // quad_perm [2, 3, 0, 1]: + lane ^ 2 -> the quad's sum
+			v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true); // row_half_mirror: + the other quad of the 8 lanes
+			v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true); // row_mirror: + the other half of the row of 16
+			tot[k] = (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32) +
+				(uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+		}
+		// frustum f: word (f & 1) * 2 + (f >> 2), field (f >> 1) & 1
+#pragma unroll
+		for (int f = 0; f < MAX_FRUSTA; ++f) {
+			const uint32_t c = (tot[(f & 1) * 2 + (f >> 2)] >> (16 * ((f >> 1) & 1))) & 0xffffu;
 			mine = lane == (uint32_t)f ? c : mine;
 		}
 	}
