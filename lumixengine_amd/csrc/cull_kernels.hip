@@ -167,12 +167,6 @@ __device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, 
 #ifndef LMX_PACK_EARLY_EXIT
 #define LMX_PACK_EARLY_EXIT 1 // k_cull_pack: blocks without a slice of their shard's window leave at once, the others fetch their first ids under the prefix of the counters
 #endif
-#ifndef LMX_CULL_MIN3
-#define LMX_CULL_MIN3 0       // 1: `any t < 0` as min(t...) < 0 (fminf ignores NaN like the comparisons do, -0.0 < 0 is false either way): no measurable change
-#endif
-#ifndef LMX_CULL_PLANE_SKIP
-#define LMX_CULL_PLANE_SKIP 0 // 1: phase A notes per CELL_TEST cell which plane pairs can cull one of its spheres at all (lmx_math.h: relevant_plane_pairs, checked by tests/test_emulation.py), a wave evaluates the union over its lanes. Measured and NOT kept: on the all-test scene only 21 % of the pairs drop out (a cell outside the frustum is usually outside one plane of two or three pairs), and the uniform branches around the packed pairs cost 14 VGPRs, 56 more scalar loads and 2 SGPRs (82: 7 instead of 8 resident blocks per CU) - all-test launch 37.7 -> 45.0 us back to back, 43.0 -> 51.3 us cache-cold, even the nothing-visible launch 9.3 -> 10.8 us (profiles/r03/cull_ab_variants.txt)
-#endif
 // Measured and NOT kept (profiles/r03/cull_ab_variants.txt): touching the NEXT tile's box / cell keys / chunk headers at block start
 // (global_load_lds into a scratch corner, nothing waits): +2-3 us in every regime, cold included; capping the kernel at 80 SGPRs so
 // that 8 instead of 7 blocks are resident per CU (MI355X_MICROARCH.md "Residency"): within noise; a persistent grid for the streaming
@@ -191,27 +185,11 @@ typedef float v8f_t __attribute__((ext_vector_type(8)));
 // min of three, NaN operands dropped (all NaN: NaN): the compiler folds the nested fminf into ONE v_min3_f32 without canonicalising
 // its operands (a two-operand fminf gets a v_max_f32 x, x in front of every operand it cannot prove quiet: always spell three)
 __device__ __forceinline__ float min3_drop_nan(float a, float b, float c) { return fminf(fminf(a, b), c); }
-__device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const float d[6], float cx, float cy, float cz, float radius, uint32_t pairs = 7u) {
+__device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const float d[6], float cx, float cy, float cz, float radius) {
 	const v2f x2 = {cx, cx}, y2 = {cy, cy}, z2 = {cz, cz}, r2 = {radius, radius};
-#if LMX_CULL_MIN3
-	v2f tt[3];
-#pragma unroll
-	for (int k = 0; k < 6; k += 2) {
-		const v2f nx = {f.nx[k], f.nx[k + 1]}, ny = {f.ny[k], f.ny[k + 1]}, nz = {f.nz[k], f.nz[k + 1]}, dd = {d[k], d[k + 1]};
-		v2f t = x2 * nx;
-		t = t + y2 * ny;
-		t = t + z2 * nz;
-		t = t + dd;
-		tt[k / 2] = t + r2;
-	}
-	// culled <=> some t < 0 <=> the minimum over the non-NaN t is < 0 (fminf returns the other operand for a NaN, all NaN -> NaN < 0 false)
-	const float m = fminf(fminf(fminf(tt[0].x, tt[0].y), fminf(tt[1].x, tt[1].y)), fminf(tt[2].x, tt[2].y));
-	return !(m < 0);
-#else
 	bool culled = false;
 #pragma unroll
 	for (int k = 0; k < 6; k += 2) {
-		if (!((pairs >> (k >> 1)) & 1u)) continue; // wave-uniform
 		const v2f nx = {f.nx[k], f.nx[k + 1]}, ny = {f.ny[k], f.ny[k + 1]}, nz = {f.nz[k], f.nz[k + 1]}, dd = {d[k], d[k + 1]};
 		v2f t = x2 * nx;
 		t = t + y2 * ny;
@@ -221,7 +199,6 @@ __device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const f
 		culled = culled || (t.x < 0) || (t.y < 0);
 	}
 	return !culled;
-#endif
 }
 
 // ---- sphere x plane pre-test on the matrix pipe (several frusta) ---------------------------------------------------------------
@@ -265,7 +242,7 @@ __device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const f
 #endif
 
 // LDS record of one (cell, frustum): the six cell-relative plane distances of ShiftedFrustum::getRelative and the cell's class
-struct alignas(16) CellInfo { float d[6]; uint32_t cls, pairs; }; // pairs: relevant_plane_pairs() of a CELL_TEST cell
+struct alignas(16) CellInfo { float d[6]; uint32_t cls, pad; };
 static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustum)");
 
 // F == 1: the single-frustum kernel (the common case: one launch per view). F == 0: n_frusta (2..8) is a runtime value and every
@@ -274,33 +251,19 @@ static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustu
 #ifndef LMX_CULL8_PROBE
 #define LMX_CULL8_PROBE 0     // timing probes of k_cull_tile<F = 0> (tools/build_variant.py; results wrong): 1 = tile-level tests only, 2 = no cell classification, 4 = no sphere tests (everything tested counts as culled), 8 = spheres / ids not fetched, 16 = nothing written
 #endif
-#ifndef LMX_CULL8_SHAPE
-#define LMX_CULL8_SHAPE 0     // block shape of the 5..8-frusta kernel over 1024-sphere tiles: 0 = 4 waves x 4 chunks, 1 = 8 waves x 2 chunks
-#endif
-#ifndef LMX_CULL_MAX_SGPR
-#define LMX_CULL_MAX_SGPR 0   // n > 0: cap the kernel's SGPRs (256-thread blocks are admitted 8 per CU only up to 80 SGPRs, 7 at 82-96: MI355X_MICROARCH.md "Residency")
-#endif
-#if LMX_CULL_MAX_SGPR
-#define LMX_CULL_SGPR_ATTR __attribute__((amdgpu_num_sgpr(LMX_CULL_MAX_SGPR)))
-#else
-#define LMX_CULL_SGPR_ATTR
-#endif
 // (several frusta) at least 5 waves per SIMD, i.e. at most 96 VGPRs: the residency the LDS of the cell records allows anyway (5 blocks of 4
 // waves per CU) - and with a register budget of <= 256 the compiler selects the VGPR form of the MFMA (accumulators in plain VGPRs, where the
 // ds_reads put the plane distances and the v_min3 read the results) instead of AGPR accumulators + a v_accvgpr_write / _read per value
 #define LMX_CULL_WAVES_ATTR(F) __attribute__((amdgpu_waves_per_eu((F) == 1 ? 1 : 5)))
 
 template <int F, int WAVES, int CHW, int GRP, int LANEPAR, int SLOTS_I>
-__global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(F) void k_cull_tile(const FrustaArg fr_arg, const float4* __restrict__ g_spheres, const int32_t* __restrict__ g_ids,
+__global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile(const FrustaArg fr_arg, const float4* __restrict__ g_spheres, const int32_t* __restrict__ g_ids,
 	const ChunkHdr* __restrict__ g_hdr, const CellKey* __restrict__ g_tile_cells, const uint32_t* __restrict__ g_tile_tab, const TileBox* __restrict__ g_tile_box,
 	const uint32_t* __restrict__ g_win_base, int32_t* __restrict__ g_out_ids, uint32_t* __restrict__ g_counts, uint32_t* __restrict__ g_counts_next, const TileScalars a) {
 	constexpr bool SLOTS = SLOTS_I != 0; // also write the slot of every visible id (CullOut::slots)
 	constexpr uint32_t TILE = WAVES * CHW * 64;
 	constexpr uint32_t THREADS = WAVES * 64;
 	constexpr int FS = F == 1 ? 1 : MAX_FRUSTA;
-	// plane-pair skipping in the streaming variants only (as the non-temporal loads): its uniform branches cost the all-loads-in-flight
-	// variant 22 VGPRs (60 -> 82: 5 instead of 8 waves per SIMD), and that variant runs where few chunks are tested at all
-	constexpr bool PLANE_SKIP = LMX_CULL_PLANE_SKIP != 0 && GRP < CHW;
 	static_assert(CHW * FS <= 32, "visibility bits of a wave's chunks x frusta live in one register");
 	LMX_DYNAMIC_LDS(CellInfo, s_info); // [n_frusta * cell_cap] (MIXED tiles only)
 	__shared__ __attribute__((aligned(16))) float s_nrm[F != 1 ? MAX_FRUSTA : 1][F != 1 ? 20 : 4]; // (several frusta) plane normals nx[6] ny[6] nz[6] of every frustum, for phase B
@@ -384,7 +347,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(
 			const bool big = (key.meta & 0x100u) != 0;
 			CellInfo ci;
 			ci.cls = CELL_REJECT;
-			ci.pairs = 7u;
+			ci.pad = 0u;
 #pragma unroll
 			for (int k = 0; k < 6; ++k) ci.d[k] = 0.f;
 			if (!dead) {
@@ -407,7 +370,6 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(
 #pragma unroll
 						for (int k = 0; k < 6; ++k) ci.d[k] = relative_plane_d(frp[f], off, k);
 					}
-					if constexpr (PLANE_SKIP) ci.pairs = relevant_plane_pairs(frp[f], IV3{key.ix, key.iy, key.iz}, ci.d);
 				}
 			}
 			if constexpr (F != 1) {
@@ -816,17 +778,10 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_SGPR_ATTR LMX_CULL_WAVES_ATTR(
 					const uint32_t cls = ci->cls;
 					vis = cls == CELL_ACCEPT;
 					if (cls == CELL_TEST) {
-						// the plane pairs this wave evaluates for the chunk: the union over its CELL_TEST lanes - the lanes active here (a lane
-						// whose radius is negative or NaN keeps all three: relevant_plane_pairs bounds t, not t + r)
-						uint32_t pairs = 7u;
-						if constexpr (PLANE_SKIP) {
-							const uint32_t lane_pairs = sp[i].w >= 0.f ? ci->pairs : 7u;
-							pairs = (__ballot((lane_pairs & 1u) != 0) != 0 ? 1u : 0u) | (__ballot((lane_pairs & 2u) != 0) != 0 ? 2u : 0u) | (__ballot((lane_pairs & 4u) != 0) != 0 ? 4u : 0u);
-						}
 						float d[6];
 #pragma unroll
 						for (int k = 0; k < 6; ++k) d[k] = ci->d[k];
-						vis = sphere_visible_d_pk(frp[f], d, sp[i].x, sp[i].y, sp[i].z, sp[i].w, pairs);
+						vis = sphere_visible_d_pk(frp[f], d, sp[i].x, sp[i].y, sp[i].z, sp[i].w);
 					}
 				} else {
 					vis = st == TILE_ACCEPT;
@@ -1205,11 +1160,7 @@ hipError_t launch_cull_tile(hipStream_t s, const CullDeviceView& v, uint32_t ent
 #undef LMX_TILE_VARIANTS
 	}
 	if (n_frusta <= 4) LMX_TILE(0, 8, 4, 4, 0); // 2048-sphere tiles, <= 4 x 32 B of LDS per cell
-#if LMX_CULL8_SHAPE == 1
-	LMX_TILE(0, 8, 2, 2, 0);                    // 1024-sphere tiles, eight waves of two chunks: half the LDS cell records per wave
-#else
 	LMX_TILE(0, 4, 4, 4, 0);                    // 1024-sphere tiles
-#endif
 #undef LMX_TILE
 }
 

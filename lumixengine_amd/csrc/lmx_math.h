@@ -273,38 +273,6 @@ LMX_HD bool sphere_visible_d(const DevFrustum& f, const float d[6], float cx, fl
 	}
 	return !culled;
 }
-// Which plane PAIRS (bit p: planes 2p, 2p + 1 - the packed test of k_cull_tile works on pairs) can cull a sphere of a CELL_TEST cell at
-// all. No reference twin: a conservative bound on sphere_visible_d. A sphere of cell `idx` has its cell-relative centre within
-// |c_i| <= ext_i = 300 * (1 + 1.2e-7 * |idx_i|): CellIndices truncates pos * float(1/300) toward zero (so centres of one cell lie on
-// either side of its origin only for idx 0, and the product's relative error of <= 6e-8 moves the index by up to 6e-8 * |idx| cells).
-// Plane k then evaluates to t >= d_k - sum_i |n_i| ext_i for every such centre; when that is > 1e-3 * (sum_i |n_i| ext_i + |d_k|) -
-// four orders of magnitude above the rounding of the fp32 expression - the computed t is >= 0 and `t + r < 0` is false for every
-// r >= 0 (the caller keeps the plane for lanes whose radius is negative or NaN). NaN / overflowing planes compare false -> kept;
-// indices that CellIndices saturated (INT32_MIN: positions beyond int32 cells, NaN) bound nothing -> all pairs kept.
-LMX_HD uint32_t relevant_plane_pairs(const DevFrustum& f, IV3 idx, const float d[6]) {
-	if (idx.x == INT32_MIN || idx.y == INT32_MIN || idx.z == INT32_MIN) return 7u;
-	const float ex = CELL_SIZE * (1.f + 1.2e-7f * __builtin_fabsf((float)idx.x)), ey = CELL_SIZE * (1.f + 1.2e-7f * __builtin_fabsf((float)idx.y)),
-				ez = CELL_SIZE * (1.f + 1.2e-7f * __builtin_fabsf((float)idx.z));
-	uint32_t pairs = 0;
-	for (int k = 0; k < 6; ++k) {
-		const float l1 = __builtin_fabsf(f.nx[k]) * ex + __builtin_fabsf(f.ny[k]) * ey + __builtin_fabsf(f.nz[k]) * ez;
-		const bool never_culls = d[k] - l1 > 1e-3f * (l1 + __builtin_fabsf(d[k]));
-		if (!never_culls) pairs |= 1u << (k >> 1);
-	}
-	return pairs;
-}
-// sphere_visible_d restricted to the plane pairs in `pairs` (what a wave of k_cull_tile evaluates: the union of its lanes' pairs)
-LMX_HD bool sphere_visible_d_pairs(const DevFrustum& f, const float d[6], float cx, float cy, float cz, float radius, uint32_t pairs) {
-	const float r = -radius;
-	bool culled = false;
-	for (int k = 0; k < 6; ++k) {
-		if (!((pairs >> (k >> 1)) & 1u)) continue;
-		float t = cx * f.nx[k] + cy * f.ny[k] + cz * f.nz[k] + d[k];
-		t = t - r;
-		culled = culled || (t < 0);
-	}
-	return !culled;
-}
 LMX_HD bool sphere_visible(const DevFrustum& f, V3 offset, float cx, float cy, float cz, float radius) {
 	float d[6];
 	for (int k = 0; k < 6; ++k) d[k] = relative_plane_d(f, offset, k);

@@ -18,13 +18,11 @@ using namespace lmx;
 
 // tiles visited, tiles ended by TILE_REJECT, tiles whose cells are all CELL_REJECT, tiles taken by TILE_ACCEPT, tiles whose live cells are all CELL_ACCEPT
 static uint32_t g_tile_stats[5];
-static uint64_t g_pair_stats[2];
-static uint64_t g_skip_stats[2]; // planes of MIXED tiles: {possible, left out by tile_plane_skip_mask} // plane pairs of MIXED-tile chunks holding CELL_TEST lanes: {possible, evaluated}
+static uint64_t g_skip_stats[2]; // planes of MIXED tiles: {possible, left out by tile_plane_skip_mask}
 
 extern "C" {
 
 void emul_tile_stats(uint32_t* out) { memcpy(out, g_tile_stats, sizeof(g_tile_stats)); }
-void emul_pair_stats(uint64_t* out) { memcpy(out, g_pair_stats, sizeof(g_pair_stats)); }
 void emul_skip_stats(uint64_t* out) { memcpy(out, g_skip_stats, sizeof(g_skip_stats)); }
 
 // tile_status for a hand-built box (tests of the margin with scaled / adversarial planes)
@@ -41,27 +39,6 @@ uint32_t emul_classify_cell(const LmxShiftedFrustum* f, const int32_t* idx, int 
 // emulates lmx_cull_build + lmx_cull over n_frusta frusta; out_ids / out_types are [n_frusta][n] (first
 // sum(out_counts[f]) entries used), out_counts [n_frusta][8]. `tile_variant`: tile size of the 1-frustum kernel
 // (0: 4096, 1 / 2: 2048, 3: 1024), as lmx_cull_set_option(LMX_CULL_OPT_TILE_VARIANT).
-// relevant_plane_pairs() against the full six-plane test for spheres of ONE cell given by their cell-relative centres (+ radius):
-// 0 = every sphere's verdict is the same with the skipped pairs left out; 12 = a skipped plane would have culled one; `out_pairs`
-// receives the cell's pair mask (7 when the cell is not CELL_TEST)
-int emul_pairs_check(const LmxShiftedFrustum* f, const int32_t* idx, int big, const float* spheres, uint32_t n, uint32_t* out_pairs) {
-	const DevFrustum fr = to_dev_frustum(*f);
-	V3 off;
-	const uint32_t cls = classify_cell(fr, IV3{idx[0], idx[1], idx[2]}, big != 0, &off);
-	*out_pairs = 7u;
-	if (cls != CELL_TEST) return 0;
-	float d[6];
-	for (int k = 0; k < 6; ++k) d[k] = relative_plane_d(fr, off, k);
-	const uint32_t pairs = relevant_plane_pairs(fr, IV3{idx[0], idx[1], idx[2]}, d);
-	*out_pairs = pairs;
-	for (uint32_t i = 0; i < n; ++i) {
-		const float* s = spheres + 4 * i;
-		const uint32_t p = s[3] >= 0.f ? pairs : 7u;
-		if (sphere_visible_d_pairs(fr, d, s[0], s[1], s[2], s[3], p) != sphere_visible_d(fr, d, s[0], s[1], s[2], s[3])) return 12;
-	}
-	return 0;
-}
-
 int emul_cull_variant(uint32_t n, const int32_t* entity, const uint8_t* type, const double* pos, const float* radius,
 	const LmxShiftedFrustum* frusta, uint32_t n_frusta, uint8_t type_filter, int tile_variant, int32_t* out_ids, uint8_t* out_types, uint32_t* out_counts) {
 	std::vector<CullRec> recs(n);
@@ -71,7 +48,6 @@ int emul_cull_variant(uint32_t n, const int32_t* entity, const uint8_t* type, co
 	const size_t n_cells = lay.cells.size();
 	memset(out_counts, 0, sizeof(uint32_t) * n_frusta * LAYOUT_MAX_TYPES);
 	memset(g_tile_stats, 0, sizeof(g_tile_stats));
-	memset(g_pair_stats, 0, sizeof(g_pair_stats));
 	memset(g_skip_stats, 0, sizeof(g_skip_stats));
 	// the live ids of every TILE_ALIGN block must add up to what the shard windows are sized for
 	if (lay.block_live.size() != lay.n_padded / LAYOUT_TILE_ALIGN) return 9;
@@ -80,7 +56,7 @@ int emul_cull_variant(uint32_t n, const int32_t* entity, const uint8_t* type, co
 		for (uint32_t b : lay.block_live) live += b;
 		if (live != n) return 9;
 	}
-	struct Info { float d[6]; uint32_t cls, pairs; };
+	struct Info { float d[6]; uint32_t cls; };
 	for (uint32_t f = 0; f < n_frusta; ++f) {
 		uint32_t total = 0;
 		const DevFrustum fr = to_dev_frustum(frusta[f]);
@@ -88,13 +64,12 @@ int emul_cull_variant(uint32_t n, const int32_t* entity, const uint8_t* type, co
 		std::vector<Info> info(n_cells);
 		for (size_t c = 0; c < n_cells; ++c) {
 			const LayoutCell key = lay.cells[c];
-			Info ci = {{0, 0, 0, 0, 0, 0}, CELL_REJECT, 7u};
+			Info ci = {{0, 0, 0, 0, 0, 0}, CELL_REJECT};
 			if (!(key.meta & LAYOUT_CELL_DEAD)) {
 				V3 off;
 				ci.cls = classify_cell(fr, IV3{key.ix, key.iy, key.iz}, (key.meta & 0x100u) != 0, &off);
 				if (ci.cls == CELL_TEST) {
 					for (int k = 0; k < 6; ++k) ci.d[k] = relative_plane_d(fr, off, k);
-					ci.pairs = relevant_plane_pairs(fr, IV3{key.ix, key.iy, key.iz}, ci.d);
 				}
 			}
 			info[c] = ci;
@@ -164,23 +139,6 @@ int emul_cull_variant(uint32_t n, const int32_t* entity, const uint8_t* type, co
 			for (int k = 0; k < LAYOUT_MAX_TYPES; ++k)
 				if (chunk * 64 >= lay.ent_start[k] && chunk * 64 < lay.ent_end[k]) t = (uint32_t)k;
 			const LayoutChunkHdr h = lay.hdr[chunk];
-			// the plane pairs the wave evaluates for this chunk: the union over its lanes in CELL_TEST cells (all pairs for a lane whose
-			// radius is negative or NaN), as phase B of k_cull_tile forms it with ballots when built with LMX_CULL_PLANE_SKIP
-			uint32_t wave_pairs = 0;
-			for (uint32_t lane = 0; lane < 64; ++lane) {
-				const uint32_t cell = lay.slot_cell[chunk * 64 + lane];
-				if (cell >= n_cells || info[cell].cls != CELL_TEST) continue;
-				wave_pairs |= lay.spheres[chunk * 64 + lane].radius >= 0.f ? info[cell].pairs : 7u;
-			}
-			bool any_test = false;
-			for (uint32_t lane = 0; lane < 64; ++lane) {
-				const uint32_t cell = lay.slot_cell[chunk * 64 + lane];
-				any_test = any_test || (cell < n_cells && info[cell].cls == CELL_TEST);
-			}
-			if (st == TILE_MIXED && any_test) {
-				g_pair_stats[0] += 3;
-				g_pair_stats[1] += (uint32_t)__builtin_popcount(wave_pairs);
-			}
 			for (uint32_t lane = 0; lane < 64; ++lane) {
 				const uint64_t le_mask = (~0ull >> (63u - lane)) & ~1ull;
 				const uint32_t cell = h.cell + (uint32_t)__builtin_popcountll(h.flags & le_mask);
@@ -199,8 +157,6 @@ int emul_cull_variant(uint32_t n, const int32_t* entity, const uint8_t* type, co
 					if (ci.cls == CELL_TEST) {
 						const LayoutSphere s = lay.spheres[e];
 						vis = sphere_visible_d(fr, ci.d, s.x, s.y, s.z, s.radius);
-						// the LMX_CULL_PLANE_SKIP build of the kernel (off by default) leaves plane pairs out: it must never change a verdict
-						if (vis != sphere_visible_d_pairs(fr, ci.d, s.x, s.y, s.z, s.radius, wave_pairs)) return 12;
 					}
 				} else {
 					vis = true; // TILE_ACCEPT: ids are copied without looking at cells or spheres

@@ -349,84 +349,6 @@ def test_tile_status_margin_under_plane_scaling_and_adversarial_boxes(emul_lib, 
                             assert emul_lib.emul_classify_cell(_p(f2), _p(np.array([ix, iy, iz], np.int32)), C.c_int(0)) == st
 
 
-def test_plane_pair_skipping_never_changes_a_verdict(emul_lib, oracle_port):
-    """Built with LMX_CULL_PLANE_SKIP (off by default: measured slower, csrc/cull_kernels.hip) k_cull_tile evaluates, per chunk, only the
-    plane pairs that can cull a sphere of the chunk's CELL_TEST cells (lmx_math.h: relevant_plane_pairs - no reference twin, a bound
-    with a margin). For cells around random cameras - planes scaled by
-    1e-3 .. 1e5, origins up to 1e9, cells up to index 2^30 - spheres at the corners of the bound's box (cell-relative +-300 on every
-    axis, further out than a real centre gets), on its faces and inside, with radius 0 (the tightest case), tiny, typical, big, negative
-    and NaN radii: the verdict with the skipped pairs left out equals the six-plane verdict, and the bound does skip most pairs."""
-    rng = np.random.default_rng(77)
-    corners = np.array([[x, y, z] for x in (-300.0, 0.0, 300.0) for y in (-300.0, 0.0, 300.0) for z in (-300.0, 0.0, 300.0)], np.float32)
-    radii = np.array([0.0, 1e-30, 0.5, 40.0, 299.0, 330.0, -1.0, -400.0, np.nan, np.inf], np.float32)
-    pairs_total, pairs_kept, cells_test = 0, 0, 0
-    for trial in range(120):
-        origin = rng.uniform(-1, 1, 3) * (10.0 ** rng.uniform(0, 9))
-        q = rng.normal(size=4)
-        q /= np.linalg.norm(q)
-        if trial % 3 == 0:
-            fr = oracle_port.viewport_frustum(is_ortho=True, ortho_size=float(rng.uniform(200, 3000)), w=1024, h=1024, near=0.0, far=float(rng.uniform(600, 9000)), pos=tuple(origin),
-                                              rot=(0, 0, 0, 1) if trial % 6 == 0 else tuple(q))
-        else:
-            fr = oracle_port.viewport_frustum(fov=float(np.deg2rad(rng.uniform(20, 110))), near=float(rng.uniform(0.1, 2)), far=float(rng.uniform(900, 20000)), pos=tuple(origin), rot=tuple(q))
-        fr = fr.copy()
-        scale = np.float32(10.0 ** rng.uniform(-3, 5)) if trial % 2 else np.float32(1.0)
-        for k in ("xs", "ys", "zs", "ds"):
-            fr[k] = (fr[k] * scale).astype(np.float32)
-        base = np.floor(origin / 300.0).astype(np.int64)
-        inner = rng.uniform(-300, 300, (40, 3)).astype(np.float32)
-        centres = np.concatenate([corners, inner])
-        sph = np.concatenate([np.concatenate([centres, np.full((len(centres), 1), r, np.float32)], axis=1) for r in radii]).astype(np.float32)
-        for _ in range(80):
-            idx = (base + rng.integers(-40, 40, 3)).astype(np.int64)
-            if np.abs(idx).max() > 2**30:
-                continue
-            idx32 = idx.astype(np.int32)
-            for big in (0, 1):
-                out = C.c_uint32(0)
-                rc = emul_lib.emul_pairs_check(_p(fr), _p(idx32), C.c_int(big), _p(sph), C.c_uint32(len(sph)), C.byref(out))
-                assert rc == 0, f"trial {trial}: a skipped plane would have culled a sphere of cell {idx32} (big {big}, plane scale {scale}, origin {origin}, pairs {out.value})"
-                if emul_lib.emul_classify_cell(_p(fr), _p(idx32), C.c_int(big)) == 2:  # CELL_TEST
-                    cells_test += 1
-                    pairs_total += 3
-                    pairs_kept += bin(out.value).count("1")
-    assert cells_test > 3000
-    assert pairs_kept < 0.9 * pairs_total, (pairs_kept, pairs_total)  # the bound is not vacuous
-    # saturated indices (CellIndices of a NaN / out-of-range position) bound nothing: every pair is kept
-    fr = oracle_port.viewport_frustum()
-    out = C.c_uint32(0)
-    far = np.array([[1e30, 0, 0, 1.0], [-1e30, 1e30, 0, 1.0]], np.float32)
-    assert emul_lib.emul_pairs_check(_p(fr), _p(np.array([-(2**31), 0, 0], np.int32)), C.c_int(1), _p(far), C.c_uint32(2), C.byref(out)) == 0
-    assert out.value == 7
-
-
-def test_plane_pair_skipping_on_scenes(emul_lib, oracle_port):
-    """The same through the whole emulated cull (code 12 = a skipped plane would have culled): scenes with big spheres, negative / NaN
-    radii and far-away entities, the default and random cameras; the ids stay the oracle's, and on the all-test scene (every cell a
-    big-sphere cell, every sphere fetched and tested) most plane pairs are never evaluated."""
-    sc = scenes.cull_scene(120_000, 6000.0, seed=23, big_fraction=0.01)
-    sc["radius"] = sc["radius"].copy()
-    sc["radius"][::977] = -5.0
-    sc["radius"][5::1409] = np.nan
-    sc["pos"] = sc["pos"].copy()
-    sc["pos"][3::2203] *= 1e7
-    sc["pos"][11::4001, 0] = 1e15  # beyond int32 cells: INT32_MIN index on x
-    cs = oracle_port.culling_system()
-    cs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
-    frusta = H.frusta(oracle_port)
-    for f in range(len(frusta)):
-        got, _ = emul_cull(emul_lib, sc, frusta[f : f + 1])  # asserts rc == 0
-        ids, types, _ = cs.cull(frusta[f : f + 1])
-        H.assert_same_visible(got[0], H.sorted_by_type(ids, types), f"frustum {f}")
-    n = 200_000
-    at = scenes.cull_scene(n, 15000.0 * (n / 10e6) ** (1 / 3), seed=2)
-    at["radius"] = scenes.all_test_radii(n)
-    got, _ = emul_cull(emul_lib, at, frusta[:1])
-    st = np.zeros(2, np.uint64)
-    emul_lib.emul_pair_stats(_p(st))
-    assert st[0] > 0 and st[1] < 0.9 * st[0], st  # (10 M entities: 79 % of the pairs stay - why the knob does not pay)
-
-
 def test_tile_plane_skip_mask_on_scenes(emul_lib, oracle_port):
     """Phase A of k_cull_tile classifies a MIXED tile's cells against the planes tile_plane_skip_mask() leaves (the others every cell of
     the tile is known to pass in both AABB tests): the emulation re-classifies every cell of every MIXED tile with the mask and

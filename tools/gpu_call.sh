@@ -42,7 +42,7 @@ baseline) # the round's first call: hardware contracts of the planned MFMA pre-t
 	pmc_summary
 	;;
 suite) # the GPU suite + smoke of the current tree
-	timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/gpu_suite.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/gpu_suite.log"; tail -n 5 "$OUT/gpu_suite.log"
+	timeout 2400 python -m pytest tests -m gpu -q > "$OUT/gpu_suite.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/gpu_suite.log"; tail -n 5 "$OUT/gpu_suite.log"
 	timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?" | tee -a "$OUT/smoke.log"; tail -n 2 "$OUT/smoke.log"
 	;;
 *) # any other case: a script of that name under tools/gpu_cases/ (kept short; one per experiment family, arguments instead of copies)
