@@ -436,7 +436,10 @@ def test_cull_add_stream_never_stalls(gpu_ctx, oracle_port):
         st = cs.updateStats()
         assert st["overflow"] == frames * per and st["tombstones"] == 0, st
         t = np.array(t_frames[3:])
-        assert H.TIMELESS or t.max() < 2e-3, f"slowest frame {1e3 * t.max():.2f} ms (median {1e6 * np.median(t):.0f} us): an add stalled"
+        # a re-layout of this set costs > 100 ms (0.5 s at 10 M entities) and a re-upload tens of ms in EVERY frame; one frame of 400 may catch a
+        # scheduling hiccup of the host (20 ms seen once on a shared 256-core box): the slowest frame stays far below a re-layout, all others below 2 ms
+        ts = np.sort(t)
+        assert H.TIMELESS or (ts[-1] < 50e-3 and ts[-2] < 2e-3), f"slowest frames {1e3 * ts[-1]:.2f} / {1e3 * ts[-2]:.2f} ms (median {1e6 * np.median(t):.0f} us): an add stalled"
     finally:
         cs.setOption(api.CULL_OPT_OVERFLOW_RESERVE, 0)
         cs.setOption(api.CULL_OPT_AUTO_COMPACTION, 1)
