@@ -794,8 +794,6 @@ def compact_line(result):
         also["exchange_step_one_rank_ms"] = ex["exchange_path_one_rank"]["ms_per_step"]
         also["exchange_mode"] = ex["exchange_path_one_rank"].get("exchange_mode")
         also["exchange_step_note"] = "N>1 step (cull+pack+ONE ncclAllGather) with a world of ONE rank; no xGMI curve measured by the builder"
-    if isinstance(ex.get("target_character_mesh_sorted"), dict):
-        also["target_character_mesh_sorted_skin_ms_per_1e9_verts"] = ex["target_character_mesh_sorted"].get("skin_ms_per_1e9_verts")
     if isinstance(ex.get("target_character_mesh"), dict):
         also["target_character_mesh_skin_ms_per_1e9_verts"] = ex["target_character_mesh"].get("skin_ms_per_1e9_verts")
     if "error" in ex:

@@ -358,15 +358,9 @@ LMX_API int lmx_skin_set_mode(LmxContext* ctx, int mode);
  * (the 16 bank columns of the LDS palette hold I instances x 16 / I copies) and streams the run's vertex records past them; 0:
  * k_skin_shared - one instance at a time against a register-resident vertex tile (rounds 2 / 3). Default 2. Same results in every form
  * (bit-identical positions in LMX_SKIN_EXACT). Takes effect at the next lmx_skin_run. */
-enum { LMX_SKIN_OPT_INSTANCES_PER_BLOCK = 0, LMX_SKIN_OPT_SORT_VERTICES = 1 };
+enum { LMX_SKIN_OPT_INSTANCES_PER_BLOCK = 0 };
 LMX_API int lmx_skin_set_option(LmxContext* ctx, int option, int value);
 /* Pose::computeAbsolute -> computeSkinMatrices -> evaluateSkin for every instance; outputs stay in HBM. */
-/* LMX_SKIN_OPT_SORT_VERTICES = 1: meshes added AFTERWARDS are stored by the number of bone slots a vertex uses (stable inside a class), so that whole
- * wavefronts of a real character mesh take the one-bone / two-bone forms of the blend (model.cpp:103-109 evaluated for the slots that carry a
- * weight). lmx_skin_device_output then holds an instance's positions in that stored order; lmx_skin_mesh_permutation tells which vertex is where
- * (out[i] = index into the arrays given to lmx_skin_add_mesh: an engine remaps its index buffer once, at load). The host readers
- * (lmx_skin_read_vertices*) return the caller's order either way. Off by default. */
-LMX_API int lmx_skin_mesh_permutation(LmxContext* ctx, uint32_t mesh, uint32_t* out, uint32_t cap_verts);
 LMX_API int lmx_skin_run(LmxContext* ctx);
 LMX_API int lmx_skin_read_vertices(LmxContext* ctx, uint32_t instance, float* out_xyz, uint32_t cap_verts);
 /* Instances [first, first + n) in ONE copy: their outputs are consecutive in HBM in instance order (out = sum of the meshes' vertex

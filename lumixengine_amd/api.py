@@ -27,7 +27,6 @@ CULL_OPT_TILE_VARIANT, CULL_OPT_LANE_PARALLEL_TILE_TEST, CULL_OPT_MAX_SHARDS, CU
 KEYS_OPT_SLOT_ORDER, KEYS_OPT_SPLIT_STATE = 0, 1
 WORLD_OPT_FUSED_LEVELS = 0
 SKIN_OPT_INSTANCES_PER_BLOCK = 0
-SKIN_OPT_SORT_VERTICES = 1
 SKIN_INSTANCES_PER_BLOCK_DEFAULT = 2  # what a fresh context uses (lmx_context.h: SkinState::multi)
 (K_CULL_CLASSIFY, K_CULL_SPHERES, K_XFORM_LEVEL, K_SPHERE_REFRESH, K_POSE_PALETTE, K_SKIN_VERTICES, K_CULL_DYNAMIC) = range(7)
 KERNEL_NAMES = ["cull_classify", "cull_spheres", "xform_level", "sphere_refresh", "pose_palette", "skin_vertices", "cull_dynamic", "sort_keys", "anim_update", "cull_patch"]
@@ -170,7 +169,6 @@ SYMBOLS = {
     "lmx_skin_set_mode": (_ci, [_vp, _ci]),
     "lmx_skin_set_option": (_ci, [_vp, _ci, _ci]),
     "lmx_skin_run": (_ci, [_vp]),
-    "lmx_skin_mesh_permutation": (_ci, [_vp, _u32, _vp, _u32]),
     "lmx_skin_read_vertices": (_ci, [_vp, _u32, _vp, _u32]),
     "lmx_skin_read_vertices_range": (_ci, [_vp, _u32, _u32, _vp, C.c_size_t]),
     "lmx_skin_device_output": (_ci, [_vp, _vp, _vp]),
@@ -873,15 +871,8 @@ class Skinning:
         2 (SKIN_DQS): the dual-quaternion blend of the reference's vertex shader."""
         self.ctx.check(self.lib.lmx_skin_set_mode(self.ctx.h, int(exact)))
 
-    def meshPermutation(self, mesh: int, n_verts: int) -> np.ndarray:
-        """out[i] = the caller's vertex stored at position i of the mesh (identity unless added under SKIN_OPT_SORT_VERTICES)"""
-        out = np.zeros(n_verts, np.uint32)
-        self.ctx.check(self.lib.lmx_skin_mesh_permutation(self.ctx.h, mesh, _ptr(out), n_verts))
-        return out
-
     def setOption(self, option: int, value: int):
-        """SKIN_OPT_INSTANCES_PER_BLOCK: 0 = k_skin_shared, 1 / 2 / 4 / 8 / 16 = k_skin_multi with that many instances per block.
-        SKIN_OPT_SORT_VERTICES: meshes added afterwards are stored by influence count (device output in that order, host readers un-permute)."""
+        """SKIN_OPT_INSTANCES_PER_BLOCK: 0 = k_skin_shared, 1 / 2 / 4 / 8 / 16 = k_skin_multi with that many instances per block."""
         self.ctx.check(self.lib.lmx_skin_set_option(self.ctx.h, int(option), int(value)))
 
     def run(self):

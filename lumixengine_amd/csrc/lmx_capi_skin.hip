@@ -67,23 +67,8 @@ int lmx_skin_add_mesh(LmxContext* ctx, uint32_t n_verts, const float* positions_
 	for (uint32_t v = 0; v < n_verts; ++v)
 		for (int k = 0; k < 4; ++k) m.max_bone = std::max<uint32_t>(m.max_bone, (uint32_t)skin[v].indices[k]);
 	static_assert(LMX_MAX_BONES <= 256, "bone indices are packed as u8");
-	// LMX_SKIN_OPT_SORT_VERTICES: the records are stored by the number of bone slots a vertex uses (stable inside a class). The vertex kernels
-	// skip, per WAVE, the slots that carry no weight in any of its lanes (skin_blend_fused_n): on a mesh whose one-bone and two-bone vertices
-	// alternate - every sixth vertex of a limb sits on a joint - no wave ever qualifies unless they are stored apart. The skinned positions
-	// leave in the stored order; lmx_skin_mesh_permutation says which vertex is where (an engine remaps its index buffer once, at load),
-	// the host readers put them back.
-	std::vector<uint32_t> order(n_verts);
-	for (uint32_t v = 0; v < n_verts; ++v) order[v] = v;
-	m.sorted = sk.sort_vertices;
-	if (m.sorted) {
-		auto slots_used = [&](uint32_t v) { return skin[v].weights[3] != 0.f ? 4 : (skin[v].weights[2] != 0.f ? 3 : (skin[v].weights[1] != 0.f ? 2 : 1)); };
-		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return slots_used(a) < slots_used(b); });
-	}
-	sk.mesh_perm.resize((size_t)m.vert_offset + n_verts);
-	for (uint32_t i = 0; i < n_verts; ++i) sk.mesh_perm[(size_t)m.vert_offset + i] = order[i];
 	sk.mesh.reserve(sk.mesh.size() + 2 * (size_t)n_verts);
-	for (uint32_t i = 0; i < n_verts; ++i) {
-		const uint32_t v = order[i];
+	for (uint32_t v = 0; v < n_verts; ++v) {
 		const uint32_t idx = (uint32_t)skin[v].indices[0] | ((uint32_t)skin[v].indices[1] << 8) | ((uint32_t)skin[v].indices[2] << 16) | ((uint32_t)skin[v].indices[3] << 24);
 		float idx_bits;
 		std::memcpy(&idx_bits, &idx, 4);
@@ -102,11 +87,10 @@ int lmx_skin_add_mesh(LmxContext* ctx, uint32_t n_verts, const float* positions_
 		int16_t local_of[LMX_MAX_BONES];
 		std::fill(local_of, local_of + LMX_MAX_BONES, (int16_t)-1);
 		SkinTile tile{(uint32_t)sk.tile_bones.size(), 0};
-		for (uint32_t i = v0; i < v1; ++i) {
-			const uint32_t v = i, vs = order[i]; // stored position / the caller's vertex
+		for (uint32_t v = v0; v < v1; ++v) {
 			uint32_t idx = 0;
 			for (int k = 0; k < 4; ++k) {
-				const int b = skin[vs].indices[k];
+				const int b = skin[v].indices[k];
 				if (local_of[b] < 0) {
 					local_of[b] = (int16_t)tile.n_bones++;
 					sk.tile_bones.push_back((uint8_t)b);
@@ -179,8 +163,6 @@ int lmx_skin_set_instances(LmxContext* ctx, uint32_t n, const uint32_t* model, c
 		in.first_nonroot = mo.first_nonroot;
 		in.vert_offset = me.vert_offset;
 		in.n_verts = me.n_verts;
-		sk.inst_mesh.resize(n);
-		sk.inst_mesh[i] = mesh[i];
 		in.out_offset = (uint32_t)verts;
 		in.max_depth = mo.max_depth;
 		in.lv_items_offset = mo.lv_items_offset;
@@ -356,10 +338,6 @@ int lmx_skin_set_mode(LmxContext* ctx, int mode) {
 
 int lmx_skin_set_option(LmxContext* ctx, int option, int value) {
 	LMX_CHECK_CTX(ctx);
-	if (option == LMX_SKIN_OPT_SORT_VERTICES) {
-		ctx->skin.sort_vertices = value != 0;
-		return LMX_OK;
-	}
 	if (option != LMX_SKIN_OPT_INSTANCES_PER_BLOCK) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "unknown skin option %d", option);
 	if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "instances per block %d not in {0, 1, 2, 4, 8, 16}", value);
 	ctx->skin.multi = (uint32_t)value;
@@ -436,19 +414,6 @@ int lmx_skin_run(LmxContext* ctx) {
 	return LMX_OK;
 }
 
-// host readers hand the positions back in the order of the caller's vertex arrays (evaluateSkin's out[i] is vertex i, model.cpp:103-109)
-static void skin_unpermute(const SkinState& sk, uint32_t instance, float* xyz) {
-	const SkinMesh& me = sk.meshes[sk.inst_mesh[instance]];
-	if (!me.sorted) return;
-	const uint32_t* perm = sk.mesh_perm.data() + me.vert_offset;
-	std::vector<float> tmp(xyz, xyz + (size_t)me.n_verts * 3);
-	for (uint32_t i = 0; i < me.n_verts; ++i) {
-		xyz[3 * (size_t)perm[i]] = tmp[3 * (size_t)i];
-		xyz[3 * (size_t)perm[i] + 1] = tmp[3 * (size_t)i + 1];
-		xyz[3 * (size_t)perm[i] + 2] = tmp[3 * (size_t)i + 2];
-	}
-}
-
 int lmx_skin_read_vertices(LmxContext* ctx, uint32_t instance, float* out_xyz, uint32_t cap_verts) {
 	LMX_CHECK_CTX(ctx);
 	SkinState& sk = ctx->skin;
@@ -457,7 +422,6 @@ int lmx_skin_read_vertices(LmxContext* ctx, uint32_t instance, float* out_xyz, u
 	if (cap_verts < in.n_verts) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u vertices", in.n_verts);
 	LMX_HIP(ctx, hipMemcpyAsync(out_xyz, sk.d_out.p + (size_t)in.out_offset * 3, (size_t)in.n_verts * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	skin_unpermute(sk, instance, out_xyz);
 	return LMX_OK;
 }
 
@@ -472,19 +436,6 @@ int lmx_skin_read_vertices_range(LmxContext* ctx, uint32_t first_instance, uint3
 	if (cap_verts < n) return fail(ctx, LMX_ERR_CAPACITY, "need room for %zu vertices", n);
 	LMX_HIP(ctx, hipMemcpyAsync(out_xyz, sk.d_out.p + (size_t)a.out_offset * 3, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
 	LMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	for (uint32_t i = 0; i < n_instances; ++i) skin_unpermute(sk, first_instance + i, out_xyz + ((size_t)sk.inst[first_instance + i].out_offset - a.out_offset) * 3);
-	return LMX_OK;
-}
-
-// out[i] = the vertex of the caller's arrays whose record (and skinned position, in lmx_skin_device_output) sits at position i of the mesh:
-// the identity unless the mesh was added under LMX_SKIN_OPT_SORT_VERTICES
-int lmx_skin_mesh_permutation(LmxContext* ctx, uint32_t mesh, uint32_t* out, uint32_t cap_verts) {
-	LMX_CHECK_CTX(ctx);
-	SkinState& sk = ctx->skin;
-	if (mesh >= sk.meshes.size() || !out) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "bad mesh/out");
-	const SkinMesh& me = sk.meshes[mesh];
-	if (cap_verts < me.n_verts) return fail(ctx, LMX_ERR_CAPACITY, "need room for %u vertices", me.n_verts);
-	std::memcpy(out, sk.mesh_perm.data() + me.vert_offset, (size_t)me.n_verts * sizeof(uint32_t));
 	return LMX_OK;
 }
 

@@ -333,15 +333,12 @@ struct WorldState {
 struct SkinModel { uint32_t bone_offset, n_bones, max_depth; int32_t first_nonroot; uint32_t lv_items_offset, lv_off_offset; };
 // max_bone: the largest bone index its vertices reference. k_skin_shared's view of the mesh: tiles of tile_verts vertices
 // (tiles_at .. + n_tiles in SkinState::tiles), each with the list of bones it references and records that index into that list.
-struct SkinMesh { uint32_t vert_offset, n_verts, max_bone, tile_verts, n_tiles, tiles_at; bool sorted; }; // sorted: stored in the order SkinState::mesh_perm says
+struct SkinMesh { uint32_t vert_offset, n_verts, max_bone, tile_verts, n_tiles, tiles_at; };
 struct SkinTile { uint32_t bones_at, n_bones; }; // into SkinState::tile_bones
 
 struct SkinState {
 	std::vector<SkinModel> models;
 	std::vector<SkinMesh> meshes;
-	bool sort_vertices = false;          // LMX_SKIN_OPT_SORT_VERTICES: meshes added from now on are stored by influence count
-	std::vector<uint32_t> mesh_perm;     // by stored vertex (vert_offset + i): the vertex of the caller's arrays kept there
-	std::vector<uint32_t> inst_mesh;     // by instance: its mesh
 	// concatenated host copies (re-uploaded when models/meshes are added)
 	std::vector<int16_t> parents;
 	std::vector<uint8_t> depth;

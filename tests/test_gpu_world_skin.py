@@ -729,61 +729,6 @@ def test_skin_shared_mesh_runs(gpu_ctx, live_oracle, exact, per_block):
 
 
 @pytest.mark.parametrize("exact", [True, False])
-def test_skin_vertices_sorted_by_influences(gpu_ctx, live_oracle, exact):
-    """SKIN_OPT_SORT_VERTICES: a character-like mesh (every sixth vertex on a joint: two bones, the others one) and a mesh with 1..4
-    influences at random are stored by the number of bone slots they use, so that whole waves take the one- / two-bone forms of the blend.
-    The host reader returns the caller's vertex order (evaluateSkin's out[i] is vertex i, model.cpp:103-109) - compared with the oracle as
-    every other skin test - the device output is in the stored order, which lmx_skin_mesh_permutation describes: a permutation, stable
-    inside a class, classes ascending; a mesh added before the option was set stays as it was."""
-    oracle_port = live_oracle
-    sk = api.Skinning(gpu_ctx)
-    sk.setMode(exact)
-    skel = scenes.skeleton(64, seed=4)
-    model = sk.addModel(skel["parents"], skel["bind"], skel["first_nonroot"])
-    plain = scenes.skinned_mesh_character(3000, 52, seed=3)
-    m_plain = sk.addMesh(*plain)  # before the option: identity
-    sk.setOption(api.SKIN_OPT_SORT_VERTICES, 1)
-    char = scenes.skinned_mesh_character(7001, 52, seed=6)
-    rng = np.random.default_rng(5)
-    mixed = scenes.skinned_mesh(5000, 64, seed=9)
-    used = rng.integers(1, 5, 5000)
-    w = mixed[1]["weights"].copy()
-    for k in range(4):
-        w[used <= k, k] = 0.0
-    w /= w.sum(axis=1, keepdims=True)
-    mixed[1]["weights"] = w.astype(np.float32)
-    m_char, m_mixed = sk.addMesh(*char), sk.addMesh(*mixed)
-    sk.setOption(api.SKIN_OPT_SORT_VERTICES, 0)
-    meshes = {m_plain: plain, m_char: char, m_mixed: mixed}
-    pick = [m_char] * 5 + [m_plain] + [m_mixed] * 3 + [m_char]
-    sk.setInstances([model] * len(pick), pick)
-    pos, rot = scenes.relative_poses(len(pick), 64, seed=12)
-    sk.uploadPoses(pos, rot)
-    sk.run()
-    inv = oracle_port.invert_bind(skel["bind"])
-    apos, arot = oracle_port.pose_compute_absolute(pos, rot, skel["parents"], skel["first_nonroot"])
-    pal = oracle_port.skin_matrices(apos, arot, inv)
-    for i, m in enumerate(pick):
-        want = oracle_port.evaluate_skin(meshes[m][0], meshes[m][1], pal[i : i + 1])[0]
-        got = sk.readVertices(i)
-        assert close_1e5(got, want), f"instance {i}"
-        if exact:
-            assert H.bits_equal(got, want), f"instance {i} (exact mode)"
-    for m, (verts, skin) in meshes.items():
-        perm = sk.meshPermutation(m, len(verts))
-        assert np.array_equal(np.sort(perm), np.arange(len(verts)))
-        slots = 1 + (skin["weights"][:, 1] != 0).astype(int) + ((skin["weights"][:, 2] != 0) | (skin["weights"][:, 3] != 0)).astype(int) + (skin["weights"][:, 3] != 0).astype(int)
-        if m == m_plain:
-            assert np.array_equal(perm, np.arange(len(verts)))
-        else:
-            stored = slots[perm]
-            assert np.all(np.diff(stored) >= 0) and len(np.unique(stored)) >= 2  # classes ascending ...
-            for c in np.unique(stored):
-                assert np.all(np.diff(perm[stored == c]) > 0)  # ... and the caller's order inside a class
-    sk.setMode(False)
-
-
-@pytest.mark.parametrize("exact", [True, False])
 def test_skin_many_instances_vs_oracle(gpu_ctx, live_oracle, exact):
     """Two models (64 and 196 bones = Model::Bone::MAX_COUNT), three meshes with ragged vertex counts."""
     oracle_port = live_oracle

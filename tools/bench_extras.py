@@ -532,26 +532,6 @@ def extras(ctx, api, scenes, dev, timed, N, log, check_ids, big_entities=0, out=
     out["target_character_mesh"] = {"frame_ms": ms4c, "frames_per_sec_1gpu": 1e3 / ms4c, "kernel_ms": k4c,
                                     "skin_ms_per_1e9_verts": k4c.get("skin_vertices", float("nan")) * 1e9 / (n_inst4 * n_verts),
                                     "mesh": "scenes.skinned_mesh_character(10 000 vertices, 52 bones of the 64-bone skeleton): 1.17 influences per vertex, 28 bones per tile"}
-    # ... and the character mesh stored by influence count (LMX_SKIN_OPT_SORT_VERTICES: every sixth vertex of this mesh sits on a joint, so in
-    # the caller's order no wave is free of two-bone vertices; stored apart, 5 waves of 6 blend one bone per vertex)
-    sk4.setOption(api.SKIN_OPT_SORT_VERTICES, 1)
-    mesh4s = sk4.addMesh(verts_c, skin_c)
-    sk4.setOption(api.SKIN_OPT_SORT_VERTICES, 0)
-    sk4.setInstances(np.full(n_inst4, model4, np.uint32), np.full(n_inst4, mesh4s, np.uint32))
-    sk4.setPoseSourceDevice(d_pos4.ptr, d_rot4.ptr, n_inst4 * 64)
-    for _ in range(2):
-        frame4()
-    ms4s = timed(frame4, R(10))
-    ctx.profile_reset()
-    ctx.profile_enable(True)
-    for _ in range(5):
-        frame4()
-    ctx.synchronize()
-    ctx.profile_enable(False)
-    k4s = {api.KERNEL_NAMES[k]: round(ctx.profile_get(k)[0] / 5, 5) for k in range(len(api.KERNEL_NAMES)) if ctx.profile_get(k)[1]}
-    out["target_character_mesh_sorted"] = {"frame_ms": ms4s, "frames_per_sec_1gpu": 1e3 / ms4s, "kernel_ms": k4s,
-                                           "skin_ms_per_1e9_verts": k4s.get("skin_vertices", float("nan")) * 1e9 / (n_inst4 * n_verts),
-                                           "mesh": "the same character mesh stored by influence count (LMX_SKIN_OPT_SORT_VERTICES; positions leave in the stored order)"}
     sk4.setInstances(np.full(n_inst4, model4, np.uint32), np.full(n_inst4, mesh4, np.uint32))
     sk4.setPoseSourceDevice(d_pos4.ptr, d_rot4.ptr, n_inst4 * 64)
     # the same frame for a renderer that consumes only palettes / vertices (no absolute-pose store, lmx_skin_set_pose_writeback)
