@@ -1,4 +1,5 @@
 """k_skin_multi per 1e9 vertices on the north-star frame's skinning load (100 k instances x 10 k vertices, 64 bones, one shared mesh): the worst-case
+mesh (4 random bones per vertex) and the character-like mesh.
 Launch begin / end timestamps of the kernels themselves, 12 frames after 12 of warm-up (the first launches first-touch the 12 GB output)."""
 import os
 import sys
