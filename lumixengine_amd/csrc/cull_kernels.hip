@@ -39,7 +39,6 @@ __device__ __forceinline__ float readlane_f(float v, int lane) { return __uint_a
 // the lane-parallel tile test reads plane k's coefficients with a per-lane load from there.
 // (pointers are separate __restrict__ kernel parameters: only then are the wave-uniform loads selected as scalar loads)
 struct TileScalars {
-	TypeTable tt;
 	uint32_t ent_begin, cell_cap, n_frusta;
 	uint32_t out_stride, cnt_pad, cnt_frustum_stride, n_zero;
 	int32_t* out_slots; // SLOTS kernels only
@@ -259,7 +258,7 @@ static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustu
 template <int F, int WAVES, int CHW, int GRP, int LANEPAR, int SLOTS_I>
 __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile(const FrustaArg fr_arg, const float4* __restrict__ g_spheres, const int32_t* __restrict__ g_ids,
 	const ChunkHdr* __restrict__ g_hdr, const CellKey* __restrict__ g_tile_cells, const uint32_t* __restrict__ g_tile_tab, const TileBox* __restrict__ g_tile_box,
-	const uint32_t* __restrict__ g_win_base, int32_t* __restrict__ g_out_ids, uint32_t* __restrict__ g_counts, uint32_t* __restrict__ g_counts_next, const TileScalars a) {
+	const uint2* __restrict__ g_tile_out, int32_t* __restrict__ g_out_ids, uint32_t* __restrict__ g_counts, uint32_t* __restrict__ g_counts_next, const TileScalars a) {
 	constexpr bool SLOTS = SLOTS_I != 0; // also write the slot of every visible id (CullOut::slots)
 	constexpr uint32_t TILE = WAVES * CHW * 64;
 	constexpr uint32_t THREADS = WAVES * 64;
@@ -421,14 +420,10 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 		__syncthreads();
 	}
 
-	// the tile's type and output shard (type ranges are TILE_ALIGN-aligned, so a tile never straddles two types)
-	uint32_t type = 0;
-#pragma unroll
-	for (int t = 0; t < MAX_TYPES; ++t) {
-		if (tile_ent >= a.tt.ent_start[t] && tile_ent < a.tt.ent_end[t]) type = t;
-	}
-	const uint32_t shard = a.tt.shard_first[type] + ((tile_ent - a.tt.ent_start[type]) / TILE_ALIGN) % a.tt.shard_n[type];
-	const uint32_t win = g_win_base[shard];
+	// the tile's output shard and where that shard's window starts: one entry of a table the host derives from the type ranges and the
+	// output layout (CullDeviceView::tile_out)
+	const uint2 tile_out = g_tile_out[tile_index];
+	const uint32_t shard = tile_out.x, win = tile_out.y;
 
 	// Accepted tile without padding or tombstones (1-frustum kernels): its ids are a straight copy. The wave's count is known
 	// (CHW x 64), so the reservation does not have to wait for the loads' results, and ids move 16 bytes per lane.
@@ -1099,7 +1094,7 @@ hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, ui
 		return hipSuccess;
 	}
 	TileScalars a;
-	a.tt = tt;
+	(void)tt; // (the tiles' shards come out of CullDeviceView::tile_out)
 	a.ent_begin = ent_begin;
 	a.cell_cap = v.tile_cap[K];
 	a.n_frusta = (uint32_t)n_frusta;
@@ -1122,10 +1117,10 @@ hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, ui
 	}
 	if (out.ev_start != nullptr) // profiling: the events receive the dispatch's own begin / end timestamps
 		hipExtLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, LANEPAR, SLOTS_I>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, out.ev_start, out.ev_stop, 0, fr,
-			v.spheres, v.ids, v.hdr, v.tile_cells[K], v.tile_tab[K], v.tile_box[K], out.win_base, out.ids, out.counts, out.counts_next, a);
+			v.spheres, v.ids, v.hdr, v.tile_cells[K], v.tile_tab[K], v.tile_box[K], v.tile_out[K], out.ids, out.counts, out.counts_next, a);
 	else
 		hipLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, LANEPAR, SLOTS_I>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, fr, v.spheres, v.ids, v.hdr,
-			v.tile_cells[K], v.tile_tab[K], v.tile_box[K], out.win_base, out.ids, out.counts, out.counts_next, a);
+			v.tile_cells[K], v.tile_tab[K], v.tile_box[K], v.tile_out[K], out.ids, out.counts, out.counts_next, a);
 	return hipGetLastError();
 }
 

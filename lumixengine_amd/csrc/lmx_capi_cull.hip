@@ -496,6 +496,18 @@ int recompute_out_layout(LmxContext* ctx) {
 		LMX_HIP(ctx, hipMemcpy(cs.d_shard_type.p, cs.shard_type.data(), cs.n_shards, hipMemcpyHostToDevice));
 	}
 	LMX_HIP(ctx, hipMemcpy(cs.d_type_start.p, cs.type_start, sizeof(cs.type_start), hipMemcpyHostToDevice));
+	for (int k = 0; k < 3; ++k) { // every tile's shard and window start, per tile size (k_cull_tile reads one 8-byte entry instead of deriving them)
+		const uint32_t tile = TILE_ALIGN >> k;
+		std::vector<uint2> tab(cs.n_padded / tile);
+		for (int t = 0; t < MAX_TYPES; ++t) {
+			for (uint32_t e = cs.tt.ent_start[t]; e < cs.tt.ent_end[t]; e += tile) {
+				const uint32_t shard = cs.tt.shard_first[t] + ((e - cs.tt.ent_start[t]) / TILE_ALIGN) % cs.tt.shard_n[t];
+				tab[e / tile] = make_uint2(shard, cs.win_base[shard]);
+			}
+		}
+		LMX_HIP(ctx, cs.d_tile_out[k].reserve(std::max<size_t>(tab.size(), 1)));
+		if (!tab.empty()) LMX_HIP(ctx, hipMemcpy(cs.d_tile_out[k].p, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice));
+	}
 	for (CullView& v : cs.views) {
 		v.valid = v.finalized = v.consolidated = false;
 		v.cnt_words = 0; // counters are re-sized (and zeroed) by the next cull on the view
@@ -1055,6 +1067,7 @@ CullDeviceView static_view(const CullSet& cs) {
 		v.tile_tab[k] = cs.tile_tab[k].p;
 		v.tile_box[k] = cs.tile_box[k].p;
 		v.tile_cap[k] = cs.tile_cap[k];
+		v.tile_out[k] = nullptr; // (belongs to the output layout: the caller fills it)
 	}
 	return v;
 }
@@ -1421,7 +1434,8 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 	out.counts_next = v.counts_other();
 	out.n_zero = cnt_words;
 	out.slots = cs.emit_slots ? v.out_slots.p : nullptr;
-	const CullDeviceView dv = static_view(cs);
+	CullDeviceView dv = static_view(cs);
+	for (int k = 0; k < 3; ++k) dv.tile_out[k] = cs.d_tile_out[k].p;
 	// The kernel is latency-bound for small frusta: wide variants (many frusta per pass) hold more state per wave and run at lower
 	// occupancy, so a batch is split into passes of at most `pass_width` frusta.
 	// pass_width 0 = automatic: ONE launch for all frusta of the call up to 32 M spheres, frustum by frustum above. Every launch of this

@@ -275,6 +275,7 @@ struct CullState : CullSet {
 	uint32_t max_shards = LAYOUT_MAX_SHARDS; // output shards per type of the static set
 	uint32_t cnt_pad = 32;     // words between shard counters (32 = one 128-byte line each)
 	uint32_t out_total = 0;    // ids per frustum row = sum of the shard capacities
+	DevBuf<uint2> d_tile_out[3]; // CullDeviceView::tile_out of the LIVE set under the current output layout (recompute_out_layout)
 	CullView views[LMX_MAX_VIEWS];
 	// lmx_cull_view_acquire / _release: result slots whose record a caller is still reading are not handed out again. Own mutex (not the
 	// context's recursive lock: a waiter must be able to sleep while other threads enqueue and release)

@@ -46,6 +46,9 @@ struct CullDeviceView {
 	const uint32_t* tile_tab[3];
 	const TileBox* tile_box[3];
 	uint32_t tile_cap[3];
+	// per tile: {output shard, start of that shard's window in an ids row} - what a surviving tile needs to reserve and write (a function of the
+	// tile's type range and of the output layout: looked up, it was ~90 scalar instructions incl. an integer modulo, and two dependent loads)
+	const uint2* tile_out[3];
 };
 
 // Where a cull writes. The visible ids of (frustum f, shard s) go to ids[f * stride + win_base[s] + k], k < the shard's counter
