@@ -930,7 +930,7 @@ def measure_traffic_live(log):
 
 
 def load_traffic(kernel):
-    """HBM bytes per launch of the roofline leg, measured by separate rocprofv3 PMC passes (tools/collect_traffic.sh) and COMMITTED as
+    """HBM bytes per launch of the roofline leg, measured by separate rocprofv3 PMC passes (tools/collect_traffic.sh; the passes of a whole round: tools/gpu_call.sh final counters) and COMMITTED as
     profiles/rNN/traffic.json - a builder-side measurement of the same command, not of this run. None when no such file exists."""
     import glob
 
