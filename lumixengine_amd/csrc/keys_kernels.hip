@@ -8,8 +8,10 @@
 //                    registers into LDS and leave as contiguous stores.
 //   k_keys_decal     DECAL / CURVE_DECAL pages (:3841-3868).
 //   k_keys_reduce_copies + k_keys_offsets   per-key sum over the private counter copies, then the exclusive scan of the group sizes (AutoInstancer::instances, :452-523) -> CSR offsets
-//   k_keys_scatter   instancer records -> CSR values
-//   k_keys_groups    one AUTOINSTANCED pair per non-empty group (:3958-3968)
+//   k_keys_scatter   instancer records -> CSR values; the lane that places a group's FIRST value also pushes the group's
+//                    AUTOINSTANCED pair (:3958-3968)
+// The visible ids are read where the cull kernels left them (KeysShardList: one window per output shard); no fill, no gather and
+// no single-purpose launch in the chain: 4 launches (round 4: 8).
 // Integer work is bit-exact by construction; the two fp64 -> fp32 distances use the reference's operation order.
 #include "lmx_kernels.h"
 
@@ -53,6 +55,25 @@ __device__ __forceinline__ uint32_t float_flip(uint32_t bits) {
 	return bits ^ mask;
 }
 
+// ---- walking a KeysShardList -------------------------------------------------------------------------------------------------------
+// A block first copies the list's shard counts and window starts into LDS (s_cnt / s_win, KEYS_MAX_SHARDS words each) and forms
+// s_first[s] = the sum of unit(count) over the shards before s (s_first[n] = the total), all from threads < KEYS_MAX_SHARDS.
+template <typename Unit> __device__ __forceinline__ void shard_list_to_lds(const KeysShardList& L, uint32_t* s_cnt, uint32_t* s_win, uint32_t* s_first, Unit unit) {
+	const uint32_t t = threadIdx.x;
+	if (t < (uint32_t)KEYS_MAX_SHARDS) {
+		const bool in = t < L.n;
+		s_cnt[t] = in ? L.counts[(size_t)t * L.cnt_pad] : 0u;
+		s_win[t] = in && L.win_base != nullptr ? L.win_base[t] : 0u;
+	}
+	__syncthreads();
+	if (t <= (uint32_t)KEYS_MAX_SHARDS) {
+		uint32_t run = 0;
+		for (uint32_t k = 0; k < t && k < L.n; ++k) run += unit(s_cnt[k]);
+		s_first[t] = run;
+	}
+	__syncthreads();
+}
+
 constexpr int KEYS_BLOCK = 512; // entities per tile = threads per block. 8 waves: 3 blocks per CU (79 VGPRs: 6 waves per SIMD). Tiles of 256 / 1024 entities measured slower (161.8 / 145.0 against 138.1 us for the whole chain, round 3's driver box)
 #ifndef LMX_KEYS_MM_REGS
 #define LMX_KEYS_MM_REGS 6 // every mesh of two LODs of three
@@ -75,7 +96,11 @@ constexpr int KEYS_HIST_LDS = 4096; // keys (16 KiB): larger ranges keep the glo
 #define LMX_KEYS_MIN_WAVES 4 // waves per SIMD the register allocation aims at: 106 VGPRs, no scratch, two 8-wave blocks per CU. Round 4 (profiles/r04/keys_ab.txt, k_keys_mesh per 1.05 M visible): 6 waves (80 VGPRs, 32-44 B of scratch, three blocks) 65.5-70.5 us, 5 waves 59.1, 4 waves 60.2 - the kernel is not short of waves, spills cost it more
 #endif
 __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(KeysDevice d, const KeysViewDevice kv /* by value: captured at launch */,
-	const int32_t* __restrict__ ids, const int32_t* __restrict__ slots /* optional: static-set slot per id, -1 = dynamic set */, const uint32_t* __restrict__ n_visible) {
+	const KeysShardList L /* the visible MESH entities; L.slots optional: static-set slot per id, -1 = dynamic set */) {
+	const int32_t* __restrict__ ids = L.ids;
+	const int32_t* __restrict__ slots = L.slots;
+	// tiles are cut per shard window (a window's last tile is partial): s_sh_first[s] = the first tile of shard s
+	__shared__ uint32_t s_sh_cnt[KEYS_MAX_SHARDS], s_sh_win[KEYS_MAX_SHARDS], s_sh_first[KEYS_MAX_SHARDS + 1];
 	__shared__ uint32_t s_wave[KEYS_BLOCK / 64][3]; // per wave: pairs | recs << 16, poses, dirty
 	__shared__ uint32_t s_base[6]; // bases of the four lists; [4], [5]: this tile's pairs / records (LMX_KEYS_STAGE_PAIRS)
 	__shared__ uint32_t s_bucket[256]; // bucket_map: an LDS read instead of one more dependent global load per mesh
@@ -88,25 +113,35 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 	if (lds_hist) {
 		for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) s_hist[k] = 0;
 	}
-	__syncthreads();
-	const uint32_t n = *n_visible;
+	shard_list_to_lds(L, s_sh_cnt, s_sh_win, s_sh_first, [](uint32_t c) { return (c + (uint32_t)KEYS_BLOCK - 1u) / (uint32_t)KEYS_BLOCK; }); // (two barriers: s_bucket / s_hist are in too)
+	const uint32_t n_tiles = s_sh_first[L.n < (uint32_t)KEYS_MAX_SHARDS ? L.n : (uint32_t)KEYS_MAX_SHARDS];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t copy = blockIdx.x & (d.n_copies - 1); // this block's private row of the group counters
+	// where tile t's ids start and how many it holds; `sh` only moves forward (a block's tiles come in increasing order)
+	uint32_t sh = 0;
+	auto locate = [&](uint32_t t, uint32_t& at, uint32_t& cnt) {
+		while (s_sh_first[sh + 1] <= t) ++sh; // (t < n_tiles = s_sh_first[n]: stops inside the list)
+		const uint32_t j0 = (t - s_sh_first[sh]) * (uint32_t)KEYS_BLOCK;
+		at = s_sh_win[sh] + j0;
+		cnt = min(s_sh_cnt[sh] - j0, (uint32_t)KEYS_BLOCK);
+	};
 	// A block walks its tiles one after the other and a tile is a chain of dependent loads (id -> record -> model -> materials) in front of
 	// three barriers: the next tile's id and slot - the chain's first link - are fetched at the top of the current tile.
-	uint32_t e_next = 0;
+	uint32_t e_next = 0, cnt_next = 0;
 	int32_t slot_next = -1;
-	{
-		const uint32_t i0 = blockIdx.x * KEYS_BLOCK + threadIdx.x;
-		if (i0 < n) { e_next = (uint32_t)ids[i0]; slot_next = slots != nullptr ? slots[i0] : -1; }
+	if (blockIdx.x < n_tiles) {
+		uint32_t at;
+		locate(blockIdx.x, at, cnt_next);
+		if (threadIdx.x < cnt_next) { e_next = (uint32_t)ids[at + threadIdx.x]; slot_next = slots != nullptr ? slots[at + threadIdx.x] : -1; }
 	}
-	for (uint32_t tile = blockIdx.x * KEYS_BLOCK; tile < n; tile += gridDim.x * KEYS_BLOCK) {
-		const uint32_t i = tile + threadIdx.x;
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const bool has = threadIdx.x < cnt_next; // this lane holds an entity of the tile
 		const uint32_t e_now = e_next;
 		const int32_t slot_now = slot_next;
-		{
-			const uint32_t i1 = i + gridDim.x * KEYS_BLOCK;
-			if (i1 < n) { e_next = (uint32_t)ids[i1]; slot_next = slots != nullptr ? slots[i1] : -1; }
+		if (tile + gridDim.x < n_tiles) {
+			uint32_t at;
+			locate(tile + gridDim.x, at, cnt_next);
+			if (threadIdx.x < cnt_next) { e_next = (uint32_t)ids[at + threadIdx.x]; slot_next = slots != nullptr ? slots[at + threadIdx.x] : -1; }
 		}
 		// ranges of mesh indices this lane emits keys for: [from0, to0] then [from1, to1]
 		int32_t from0 = 0, to0 = -1, from1 = 0, to1 = -1;
@@ -118,7 +153,7 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		float* lod_at = nullptr;                       // where ModelInstance::lod and Pose::frame of the entity live: in the record, or
 		                                               // (sorted set, LMX_KEYS_SPLIT_STATE) in the dense per-slot array
 		const LmxMeshMaterial* mmb = d.mesh_materials; // ... and the table its material_offset points into; from the LOD ranges on: the entity's first material
-		if (i < n) {
+		if (has) {
 			e = e_now;
 			KeysInstance in;
 			in.model = -1;
@@ -413,34 +448,44 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 	}
 }
 
-__global__ __launch_bounds__(256) void k_keys_decal(KeysDevice d, const KeysViewDevice kv, const int32_t* __restrict__ ids,
-	const uint32_t* __restrict__ n_visible, const uint32_t* __restrict__ sort_key, const uint8_t* __restrict__ layer, uint32_t draw_type) {
-	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-	const uint32_t n = *n_visible;
-	if (i - (i & 63u) >= n) return;
-	bool push = false;
-	uint64_t key = 0, value = 0;
-	if (i < n) {
-		const uint32_t e = (uint32_t)ids[i];
-		if (e < d.n_entities) {
-			const uint8_t bucket = (uint8_t)kv.bucket_map[layer[e]]; // const u8 bucket = bucket_map[layer], :3845
-			if (bucket < 0xff) {
-				key = (uint64_t)sort_key[e] | ((uint64_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT); // makeDecalSortKey, :83-89
-				value = (uint64_t)e | ((uint64_t)draw_type << LMX_SORT_VALUE_TYPE_SHIFT);      // make(Curve)DecalSortValue, :125-131
-				push = true;
+__global__ __launch_bounds__(256) void k_keys_decal(KeysDevice d, const KeysViewDevice kv, const KeysShardList L, const uint32_t* __restrict__ sort_key,
+	const uint8_t* __restrict__ layer, uint32_t draw_type) {
+	__shared__ uint32_t s_sh_cnt[KEYS_MAX_SHARDS], s_sh_win[KEYS_MAX_SHARDS], s_sh_first[KEYS_MAX_SHARDS + 1]; // s_sh_first[s]: ids in the shards before s
+	shard_list_to_lds(L, s_sh_cnt, s_sh_win, s_sh_first, [](uint32_t c) { return c; });
+	const uint32_t ns = L.n < (uint32_t)KEYS_MAX_SHARDS ? L.n : (uint32_t)KEYS_MAX_SHARDS;
+	const uint32_t n = s_sh_first[ns];
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i - (i & 63u) < n; i += gridDim.x * 256) {
+		bool push = false;
+		uint64_t key = 0, value = 0;
+		if (i < n) {
+			uint32_t lo = 0, hi = ns; // the shard that holds list position i: the last s with s_sh_first[s] <= i (empty shards share their start with the next one)
+			while (hi - lo > 1) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (s_sh_first[mid] <= i) lo = mid; else hi = mid;
+			}
+			const uint32_t e = (uint32_t)L.ids[s_sh_win[lo] + (i - s_sh_first[lo])];
+			if (e < d.n_entities) {
+				const uint8_t bucket = (uint8_t)kv.bucket_map[layer[e]]; // const u8 bucket = bucket_map[layer], :3845
+				if (bucket < 0xff) {
+					key = (uint64_t)sort_key[e] | ((uint64_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT); // makeDecalSortKey, :83-89
+					value = (uint64_t)e | ((uint64_t)draw_type << LMX_SORT_VALUE_TYPE_SHIFT);      // make(Curve)DecalSortValue, :125-131
+					push = true;
+				}
 			}
 		}
+		const uint32_t idx = wave_append(push, d.counters + KEYS_N_PAIRS);
+		if (push) { if (idx < d.cap_pairs) { d.keys[idx] = key; d.values[idx] = value; } else d.counters[KEYS_OVERFLOW] = 1; }
 	}
-	const uint32_t idx = wave_append(push, d.counters + KEYS_N_PAIRS);
-	if (push) { if (idx < d.cap_pairs) { d.keys[idx] = key; d.values[idx] = value; } else d.counters[KEYS_OVERFLOW] = 1; }
 }
 
-// one wave per key: lane c holds the counts of copies c, c + 64, ... in turn; total[k] = their sum, group_count[c][k] becomes copy c's base
-// inside group k (exclusive prefix over the copies), cursors zeroed
+// one wave per key: lane c holds the counts of copies c, c + 64, ... in turn; total[k] = their sum, group_base[c][k] = copy c's base
+// inside group k (exclusive prefix over the copies). The histogram itself is zeroed - it is the scatter's cursor table from here on -
+// and so are the other table (the previous run's cursors: the next run's histogram) and the next run's list counters.
 __global__ __launch_bounds__(256) void k_keys_reduce_copies(KeysDevice d) {
 	const uint32_t n = d.max_sort_key + 1;
 	const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6);
 	const uint32_t lane = threadIdx.x & 63u;
+	if (blockIdx.x == 0 && threadIdx.x < (uint32_t)KEYS_COUNTERS) d.counters_next[threadIdx.x] = 0;
 	if (k >= n) return;
 	uint32_t carry = 0; // wave-uniform: the copies before this round's
 	for (uint32_t c0 = 0; c0 < d.n_copies; c0 += 64u) {
@@ -454,8 +499,9 @@ __global__ __launch_bounds__(256) void k_keys_reduce_copies(KeysDevice d) {
 			if (lane >= (uint32_t)o) incl += up;
 		}
 		if (c < d.n_copies) {
-			d.group_count[at] = carry + incl - v;
-			d.group_cursor[at] = 0;
+			d.group_base[at] = carry + incl - v;
+			d.group_count[at] = 0;
+			d.group_count_next[at] = 0;
 		}
 		carry += (uint32_t)__shfl((int)incl, 63);
 	}
@@ -497,7 +543,10 @@ __global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
 	if (lane == 0 && total) atomicAdd(d.counters + KEYS_N_GROUPS, total);
 }
 
-__global__ __launch_bounds__(256) void k_keys_scatter(KeysDevice d) {
+// Instancer records -> CSR values. The lane whose record lands on its group's FIRST position also pushes the group's AUTOINSTANCED
+// pair (:3958-3968, instancer index 0: `instances[i].begin->renderables[0]` is any member - they share the material): every
+// non-empty group has exactly one such record, so the pairs need no launch of their own (k_keys_groups, rounds 1-4).
+__global__ __launch_bounds__(256) void k_keys_scatter(KeysDevice d, const KeysViewDevice kv) {
 	const uint32_t n = min(d.counters[KEYS_N_RECS], d.cap_recs);
 	const uint32_t stride = d.max_sort_key + 1;
 	for (uint32_t tile = blockIdx.x * 256; tile < n; tile += gridDim.x * 256) {
@@ -505,47 +554,45 @@ __global__ __launch_bounds__(256) void k_keys_scatter(KeysDevice d) {
 		const uint32_t packed = i < n ? d.rec_key[i] : 0; // mesh sort key | copy << 24
 		const uint32_t key = packed & 0xffffffu;
 		const bool has = i < n && key <= d.max_sort_key;
-		// per distinct (copy, key) of the wave: its first lane (leader), the number of lanes holding it and every lane's rank among
-		// them - ALU only; then ALL leaders reserve their cursor ranges at once (one memory round trip per wave, not one per key)
 		const size_t at = (size_t)(packed >> 24) * stride + key;
+		uint32_t in_group = 0; // the record's position inside its group
 		if (d.n_copies >= 8) { // privatised cursors: one returning atomic per lane, all in flight together
-			if (has) d.group_values[d.group_offset[key] + d.group_count[at] + atomicAdd(d.group_cursor + at, 1u)] = d.rec_value[i];
-			continue;
+			if (has) in_group = d.group_base[at] + atomicAdd(d.group_count + at, 1u);
+		} else {
+			// per distinct (copy, key) of the wave: its first lane (leader), the number of lanes holding it and every lane's rank among
+			// them - ALU only; then ALL leaders reserve their cursor ranges at once (one memory round trip per wave, not one per key)
+			uint64_t todo = __ballot(has);
+			uint32_t leader_of = 0, rank = 0, count = 0;
+			while (todo) {
+				const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+				const uint32_t k = (uint32_t)__shfl((int)packed, (int)leader);
+				const uint64_t same = __ballot(has && packed == k) & todo;
+				if ((same >> lane_id()) & 1ull) { leader_of = leader; rank = rank_in(same); count = (uint32_t)__popcll(same); }
+				todo &= ~same;
+			}
+			uint32_t base = 0;
+			if (has && leader_of == lane_id()) base = atomicAdd(d.group_count + at, count);
+			base = (uint32_t)__shfl((int)base, (int)leader_of);
+			if (has) in_group = d.group_base[at] + base + rank;
 		}
-		uint64_t todo = __ballot(has);
-		uint32_t leader_of = 0, rank = 0, count = 0;
-		while (todo) {
-			const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
-			const uint32_t k = (uint32_t)__shfl((int)packed, (int)leader);
-			const uint64_t same = __ballot(has && packed == k) & todo;
-			if ((same >> lane_id()) & 1ull) { leader_of = leader; rank = rank_in(same); count = (uint32_t)__popcll(same); }
-			todo &= ~same;
+		bool push = false;
+		uint64_t pair_key = 0, pair_value = 0;
+		if (has) {
+			const uint64_t renderable = d.rec_value[i];
+			d.group_values[d.group_offset[key] + in_group] = renderable;
+			if (in_group == 0) {
+				const uint32_t entity_index = (uint32_t)(renderable & 0xffFFffull);
+				const uint32_t mesh_idx = (uint32_t)(renderable >> LMX_SORT_VALUE_MESH_IDX_SHIFT);
+				const uint8_t layer = d.mesh_materials[d.inst[entity_index].material_offset + mesh_idx].layer;
+				const uint8_t bucket = kv.layer_to_bucket[layer];
+				pair_value = (uint64_t)key | ((uint64_t)LMX_DRAW_AUTOINSTANCED << LMX_SORT_VALUE_TYPE_SHIFT);               // makeAutoInstancedSortValue(i, 0)
+				pair_key = (uint64_t)key | LMX_SORT_KEY_INSTANCED_FLAG | ((uint64_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT);  // makeAutoInstancedSortKey(i, bucket)
+				push = true;
+			}
 		}
-		uint32_t base = 0;
-		if (has && leader_of == lane_id()) base = atomicAdd(d.group_cursor + at, count);
-		base = (uint32_t)__shfl((int)base, (int)leader_of);
-		if (has) d.group_values[d.group_offset[key] + d.group_count[at] + base + rank] = d.rec_value[i];
+		const uint32_t idx = wave_append(push, d.counters + KEYS_N_PAIRS);
+		if (push) { if (idx < d.cap_pairs) { d.keys[idx] = pair_key; d.values[idx] = pair_value; } else d.counters[KEYS_OVERFLOW] = 1; }
 	}
-}
-
-__global__ __launch_bounds__(256) void k_keys_groups(KeysDevice d, const KeysViewDevice kv) {
-	const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-	const uint32_t n = d.max_sort_key + 1;
-	if (k - (k & 63u) >= n) return;
-	bool push = false;
-	uint64_t key = 0, value = 0;
-	if (k < n && d.group_total[k] != 0) { // :3958-3968, instancer index 0
-		const uint64_t renderable = d.group_values[d.group_offset[k]]; // instances[i].begin->renderables[0]: any member, they share the material
-		const uint32_t entity_index = (uint32_t)(renderable & 0xffFFffull);
-		const uint32_t mesh_idx = (uint32_t)(renderable >> LMX_SORT_VALUE_MESH_IDX_SHIFT);
-		const uint8_t layer = d.mesh_materials[d.inst[entity_index].material_offset + mesh_idx].layer;
-		const uint8_t bucket = kv.layer_to_bucket[layer];
-		value = (uint64_t)k | ((uint64_t)LMX_DRAW_AUTOINSTANCED << LMX_SORT_VALUE_TYPE_SHIFT);               // makeAutoInstancedSortValue(i, 0)
-		key = (uint64_t)k | LMX_SORT_KEY_INSTANCED_FLAG | ((uint64_t)bucket << LMX_SORT_KEY_BUCKET_SHIFT);  // makeAutoInstancedSortKey(i, bucket)
-		push = true;
-	}
-	const uint32_t idx = wave_append(push, d.counters + KEYS_N_PAIRS);
-	if (push) { if (idx < d.cap_pairs) { d.keys[idx] = key; d.values[idx] = value; } else d.counters[KEYS_OVERFLOW] = 1; }
 }
 
 // ---- slot-ordered mirror of the instance tables ------------------------------------------------------------------------------------
@@ -662,22 +709,18 @@ hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint3
 	return hipGetLastError();
 }
 
-hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const int32_t* mesh_ids, const int32_t* mesh_slots, const uint32_t* mesh_count,
-	uint32_t mesh_cap, const int32_t* decal_ids, const uint32_t* decal_count, uint32_t decal_cap, const int32_t* curve_ids,
-	const uint32_t* curve_count, uint32_t curve_cap) {
+hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const KeysShardList& meshes, const KeysShardList& decals, const KeysShardList& curves) {
 	const uint32_t grid_cap = 256 * 8; // fixed-size grids walk the lists in tiles: the counts live on the device
-	if (mesh_cap && d.inst != nullptr)
-		hipLaunchKernelGGL(k_keys_mesh, dim3(std::min((mesh_cap + KEYS_BLOCK - 1) / KEYS_BLOCK, grid_cap)), dim3(KEYS_BLOCK), 0, s, d, view, mesh_ids, mesh_slots, mesh_count);
-	if (decal_cap && d.decal_sort_key != nullptr)
-		hipLaunchKernelGGL(k_keys_decal, dim3((decal_cap + 255) / 256), dim3(256), 0, s, d, view, decal_ids, decal_count, d.decal_sort_key, d.decal_layer,
-			(uint32_t)LMX_DRAW_DECAL);
-	if (curve_cap && d.curve_sort_key != nullptr)
-		hipLaunchKernelGGL(k_keys_decal, dim3((curve_cap + 255) / 256), dim3(256), 0, s, d, view, curve_ids, curve_count, d.curve_sort_key, d.curve_layer,
-			(uint32_t)LMX_DRAW_CURVE_DECAL);
+	if (meshes.n > (uint32_t)KEYS_MAX_SHARDS || decals.n > (uint32_t)KEYS_MAX_SHARDS || curves.n > (uint32_t)KEYS_MAX_SHARDS) return hipErrorInvalidValue;
+	if (meshes.cap && d.inst != nullptr)
+		hipLaunchKernelGGL(k_keys_mesh, dim3(std::min((meshes.cap + KEYS_BLOCK - 1) / KEYS_BLOCK + meshes.n, grid_cap)), dim3(KEYS_BLOCK), 0, s, d, view, meshes);
+	if (decals.cap && d.decal_sort_key != nullptr)
+		hipLaunchKernelGGL(k_keys_decal, dim3(std::min((decals.cap + 255) / 256, grid_cap)), dim3(256), 0, s, d, view, decals, d.decal_sort_key, d.decal_layer, (uint32_t)LMX_DRAW_DECAL);
+	if (curves.cap && d.curve_sort_key != nullptr)
+		hipLaunchKernelGGL(k_keys_decal, dim3(std::min((curves.cap + 255) / 256, grid_cap)), dim3(256), 0, s, d, view, curves, d.curve_sort_key, d.curve_layer, (uint32_t)LMX_DRAW_CURVE_DECAL);
 	hipLaunchKernelGGL(k_keys_reduce_copies, dim3((d.max_sort_key + 4) / 4), dim3(256), 0, s, d);
 	hipLaunchKernelGGL(k_keys_offsets, dim3(1), dim3(1024), 0, s, d);
-	if (d.cap_recs) hipLaunchKernelGGL(k_keys_scatter, dim3(std::min((d.cap_recs + 255) / 256, grid_cap * 4)), dim3(256), 0, s, d);
-	hipLaunchKernelGGL(k_keys_groups, dim3((d.max_sort_key + 256) / 256), dim3(256), 0, s, d, view);
+	if (d.cap_recs) hipLaunchKernelGGL(k_keys_scatter, dim3(std::min((d.cap_recs + 255) / 256, grid_cap * 4)), dim3(256), 0, s, d, view);
 	return hipGetLastError();
 }
 

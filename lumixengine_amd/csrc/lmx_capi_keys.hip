@@ -227,6 +227,10 @@ int lmx_keys_set_option(LmxContext* ctx, int option, int value) {
 		}
 		return LMX_OK;
 	}
+	if (option == LMX_KEYS_OPT_WALK_SHARDS) {
+		ks.walk_shards = value != 0;
+		return LMX_OK;
+	}
 	if (option != LMX_KEYS_OPT_SLOT_ORDER) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "unknown sort-key option %d", option);
 	if (!value) {
 		if (int rc = keys_before_layout_change(ctx)) return rc; // hand the state back, drop the mirror
@@ -286,11 +290,18 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	uint32_t n_copies = LMX_KEYS_MAX_COPIES;
 	while (n_copies > 1 && (uint64_t)n_copies * (max_sort_key + 1) > 262144) n_copies >>= 1;
 	const size_t g = (size_t)max_sort_key + 1;
-	// [group_count n_copies * g | counters KEYS_COUNTERS | group_cursor n_copies * g | group_total g | group_offset g + 1]: what a run starts
-	// from zero - the group counters and the list counters - is one range, cleared by ONE fill (two were two launches of ~5 us each in a chain
-	// of seven)
-	const size_t gc = (n_copies * g + 31) & ~(size_t)31; // the group counters, padded so that the list counters start on a 128-byte line (64-bit atomics)
-	LMX_HIP(ctx, ks.d_groups.reserve(gc + KEYS_COUNTERS + n_copies * g + g + g + 1));
+	// [table 0 | table 1 | counters 0 | counters 1 | group_base n_copies * g | group_total g | group_offset g + 1]. The two counter tables
+	// and the two blocks of list counters take turns from run to run: what a run needs zeroed is zeroed by the run before it
+	// (k_keys_reduce_copies), so the chain has no fill of its own - it was one launch of ~5 us in a chain of eight. Only a new layout
+	// (key range, copy count, a new allocation) or a failed run starts from a fill.
+	const size_t gc = (n_copies * g + 31) & ~(size_t)31; // a table, padded so that the list counters start on a 128-byte line (64-bit atomics)
+	LMX_HIP(ctx, ks.d_groups.reserve(2 * gc + 2 * KEYS_COUNTERS + n_copies * g + g + g + 1));
+	if (!ks.groups_clean || ks.groups_at != ks.d_groups.p || ks.groups_copies != n_copies || ks.groups_keys != g) {
+		LMX_HIP(ctx, hipMemsetAsync(ks.d_groups.p, 0, (2 * gc + 2 * KEYS_COUNTERS) * sizeof(uint32_t), ctx->stream));
+		ks.groups_at = ks.d_groups.p; ks.groups_copies = n_copies; ks.groups_keys = g;
+		ks.run_parity = 0;
+	}
+	ks.groups_clean = false; // until this run's launches are enqueued
 	LMX_HIP(ctx, ks.d_poses.reserve(std::max<size_t>(mesh_cap, 1)));
 	LMX_HIP(ctx, ks.d_dirty_list.reserve(std::max<size_t>(mesh_cap, 1)));
 
@@ -304,7 +315,6 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	// slot order: from now on the culls also emit the static-set slot of every visible id; a view culled before that (or with the
 	// option off) is walked through the entity-indexed tables
 	CullState& cs = ctx->cull;
-	const int32_t* mesh_slots = nullptr;
 	if (ks.slot_order && ks.have_instances) {
 		cs.emit_slots = true;
 		if (v.has_slots) {
@@ -319,8 +329,8 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 		if (int rc = keys_before_layout_change(ctx)) return rc;
 	}
 	ProfScope ps(ctx, LMX_K_SORT_KEYS);
-	ks.counters_at = gc;
-	LMX_HIP(ctx, hipMemsetAsync(ks.d_groups.p, 0, (gc + KEYS_COUNTERS) * sizeof(uint32_t), ctx->stream));
+	const uint32_t parity = ks.run_parity;
+	ks.counters_at = 2 * gc + parity * KEYS_COUNTERS;
 	KeysDevice d;
 	memset(&d, 0, sizeof(d));
 	d.n_entities = ks.n_entities;
@@ -343,17 +353,58 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	d.rec_key = ks.d_rec_key.p; d.rec_value = ks.d_rec_value.p; d.cap_recs = (uint32_t)cap_recs;
 	d.max_sort_key = max_sort_key;
 	d.n_copies = n_copies;
-	d.group_count = ks.d_groups.p; d.group_cursor = ks.d_groups.p + gc + KEYS_COUNTERS; d.group_total = d.group_cursor + n_copies * g; d.group_offset = d.group_total + g;
-	ks.offsets_at = gc + KEYS_COUNTERS + n_copies * g + g;
+	d.group_count = ks.d_groups.p + parity * gc; d.group_count_next = ks.d_groups.p + (parity ^ 1u) * gc;
+	d.group_base = ks.d_groups.p + 2 * gc + 2 * KEYS_COUNTERS; d.group_total = d.group_base + n_copies * g; d.group_offset = d.group_total + g;
+	ks.offsets_at = 2 * gc + 2 * KEYS_COUNTERS + n_copies * g + g;
 	d.group_values = ks.d_group_values.p;
 	d.poses = ks.d_poses.p; d.dirty_list = ks.d_dirty_list.p; d.cap_list = mesh_cap;
 	d.counters = ks.d_groups.p + ks.counters_at;
-	if (int rc = cull_view_consolidate(ctx, v)) return rc; // the key kernels walk one contiguous list per type
-	const int32_t* row = v.cons_ptr() + (size_t)frustum * v.out_stride;
-	const uint32_t* counts = v.totals_ptr() + (size_t)frustum * MAX_TYPES;
-	if (ks.mirror_valid && v.has_slots && ks.slot_order) mesh_slots = v.cons_slots.p + (size_t)frustum * v.out_stride + v.out_start[LMX_TYPE_MESH];
-	LMX_HIP(ctx, launch_keys(ctx->stream, d, hv, row + v.out_start[LMX_TYPE_MESH], mesh_slots, counts + LMX_TYPE_MESH, mesh_cap, row + v.out_start[LMX_TYPE_DECAL],
-		counts + LMX_TYPE_DECAL, decal_cap, row + v.out_start[LMX_TYPE_CURVE_DECAL], counts + LMX_TYPE_CURVE_DECAL, curve_cap));
+	d.counters_next = ks.d_groups.p + 2 * gc + (parity ^ 1u) * KEYS_COUNTERS;
+	// The visible ids, per type, where the cull left them: one window per output shard (shards of a type are contiguous in shard order).
+	// Gathering them into one list per type first (k_cull_finalize + k_cull_consolidate) was 14 of the chain's 94 us.
+	const bool use_slots = ks.mirror_valid && v.has_slots && ks.slot_order;
+	uint32_t first[MAX_TYPES], count[MAX_TYPES];
+	bool walk = ks.walk_shards;
+	for (int t = 0; t < MAX_TYPES; ++t) { first[t] = 0; count[t] = 0; }
+	for (uint32_t sidx = 0; sidx < cs.n_shards; ++sidx) {
+		const uint8_t t = cs.shard_type[sidx];
+		if (count[t]++ == 0) first[t] = sidx;
+		else if (first[t] + count[t] - 1 != sidx) walk = false; // (never: the layout builder keeps a type's shards together)
+	}
+	for (int t : {LMX_TYPE_MESH, LMX_TYPE_DECAL, LMX_TYPE_CURVE_DECAL}) if (count[t] > (uint32_t)KEYS_MAX_SHARDS) walk = false;
+	KeysShardList lists[3];
+	const int list_type[3] = {LMX_TYPE_MESH, LMX_TYPE_DECAL, LMX_TYPE_CURVE_DECAL};
+	const uint32_t list_cap[3] = {mesh_cap, decal_cap, curve_cap};
+	if (walk) {
+		const uint32_t* counts = v.counts_ptr() + (size_t)frustum * cs.n_shards * cs.cnt_pad;
+		for (int k = 0; k < 3; ++k) {
+			const int t = list_type[k];
+			lists[k].ids = v.out.p + (size_t)frustum * v.out_stride;
+			lists[k].slots = k == 0 && use_slots ? v.out_slots.p + (size_t)frustum * v.out_stride : nullptr;
+			lists[k].counts = counts + (size_t)first[t] * cs.cnt_pad;
+			lists[k].win_base = cs.d_win_base.p + first[t];
+			lists[k].cnt_pad = cs.cnt_pad;
+			lists[k].n = count[t];
+			lists[k].cap = list_cap[k];
+		}
+	} else { // LMX_KEYS_OPT_WALK_SHARDS 0: one contiguous list per type, gathered first
+		if (int rc = cull_view_consolidate(ctx, v)) return rc;
+		const int32_t* row = v.cons_ptr() + (size_t)frustum * v.out_stride;
+		const uint32_t* counts = v.totals_ptr() + (size_t)frustum * MAX_TYPES;
+		for (int k = 0; k < 3; ++k) {
+			const int t = list_type[k];
+			lists[k].ids = row + v.out_start[t];
+			lists[k].slots = k == 0 && use_slots ? v.cons_slots.p + (size_t)frustum * v.out_stride + v.out_start[t] : nullptr;
+			lists[k].counts = counts + t;
+			lists[k].win_base = nullptr;
+			lists[k].cnt_pad = 0;
+			lists[k].n = 1;
+			lists[k].cap = list_cap[k];
+		}
+	}
+	LMX_HIP(ctx, launch_keys(ctx->stream, d, hv, lists[0], lists[1], lists[2]));
+	ks.groups_clean = true;
+	ks.run_parity = parity ^ 1u;
 	ks.max_sort_key = max_sort_key;
 	ks.ran = true;
 	ks.sorted = false;

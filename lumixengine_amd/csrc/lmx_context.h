@@ -404,7 +404,15 @@ struct KeysState {
 	uint32_t n_meshes = 0, max_lod_span = 1;
 	uint32_t n_entities = 0, n_positions = 0, max_sort_key = 0;
 	size_t offsets_at = 0; // where the CSR offsets of the last run start inside d_groups
-	size_t counters_at = 0; // ... and the list counters (KEYS_COUNTERS words, right behind the group counters: one fill clears both)
+	size_t counters_at = 0; // ... and the list counters of the last run (KEYS_COUNTERS words)
+	// the instancer's counter tables and the list counters take turns from run to run (lmx_keys_run): which of the two this run uses, and
+	// the layout the pair was last zeroed for
+	uint32_t run_parity = 0;
+	bool groups_clean = false;
+	const uint32_t* groups_at = nullptr;
+	uint32_t groups_copies = 0;
+	size_t groups_keys = 0;
+	bool walk_shards = true; // lmx_keys_set_option(LMX_KEYS_OPT_WALK_SHARDS)
 	bool have_instances = false, have_decals = false, have_curves = false, use_world = false, ran = false, sorted = false;
 	DevBuf<LmxKeysModel> d_models;
 	DevBuf<uint8_t> d_mesh_types;

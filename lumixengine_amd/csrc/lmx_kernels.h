@@ -284,14 +284,31 @@ struct KeysDevice {
 	// row, so the atomics of a scene with few distinct mesh sort keys (all of them on a handful of cache lines) spread over
 	// n_copies times as many lines. A record remembers its copy in bits 24..31 of rec_key.
 	uint32_t n_copies;         // power of two, <= LMX_KEYS_MAX_COPIES
-	uint32_t *group_count;     // [n_copies][max_sort_key + 1]: per-copy sizes, turned into per-copy bases by k_keys_offsets
-	uint32_t *group_cursor;    // [n_copies][max_sort_key + 1]
-	uint32_t *group_total;     // [max_sort_key + 1]
-	uint32_t *group_offset;    // [max_sort_key + 2]
+	// Two counter tables take turns (round 5: the chain had a fill of its own): a run's key kernels build the histogram in group_count,
+	// which arrives ZERO; k_keys_reduce_copies turns it into per-copy bases (group_base), zeroes it - it is the scatter's cursor table
+	// from then on - and zeroes the OTHER table (group_count_next: the previous run's cursors), which is the next run's histogram.
+	uint32_t *group_count;      // [n_copies][max_sort_key + 1]: per-copy sizes, then the scatter's cursors
+	uint32_t *group_count_next; // the same table of the next run
+	uint32_t *group_base;       // [n_copies][max_sort_key + 1]: where copy c's records of group k start inside the group
+	uint32_t *group_total;      // [max_sort_key + 1]
+	uint32_t *group_offset;     // [max_sort_key + 2]
 	uint64_t* group_values;
 	int32_t *poses, *dirty_list;
 	uint32_t cap_list;
-	uint32_t* counters;       // KEYS_*
+	uint32_t* counters;       // KEYS_*: arrive zero
+	uint32_t* counters_next;  // the next run's (the previous run's results: valid until this run starts), zeroed by k_keys_reduce_copies
+};
+// The visible ids of ONE renderable type as the cull kernels leave them (lmx_cull_device_shards): `n` shards, shard s holding
+// counts[s * cnt_pad] ids at ids + win_base[s] (and their static-set slots at slots + win_base[s]). The key kernels walk the windows
+// themselves: gathering them into one list first (k_cull_finalize + k_cull_consolidate) was 14 of the chain's 94 us. win_base == nullptr:
+// one contiguous list (n == 1, counts -> its length) - what a type with more than KEYS_MAX_SHARDS shards falls back to.
+constexpr int KEYS_MAX_SHARDS = 128; // the layout builder gives a type <= 64 shards for the sorted set + <= 8 for the dynamic one
+struct KeysShardList {
+	const int32_t* ids;
+	const int32_t* slots; // optional
+	const uint32_t* counts;
+	const uint32_t* win_base;
+	uint32_t cnt_pad, n, cap; // cap: an upper bound of the ids (grid size)
 };
 hipError_t launch_keys_mirror_count(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models, uint32_t* count);
 hipError_t launch_keys_mirror_fill(hipStream_t s, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst, uint32_t n_entities, const LmxKeysModel* models,
@@ -301,9 +318,7 @@ hipError_t launch_keys_mirror_sync(hipStream_t s, const int32_t* slot_ids, uint3
 	KeysInstance* inst, uint32_t n_entities);
 hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint32_t n, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, const int32_t* model_s,
 	const KeysSlotState* state_s, KeysInstance* inst, uint32_t n_entities);
-hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const int32_t* mesh_ids, const int32_t* mesh_slots, const uint32_t* mesh_count,
-	uint32_t mesh_cap, const int32_t* decal_ids, const uint32_t* decal_count, uint32_t decal_cap, const int32_t* curve_ids,
-	const uint32_t* curve_count, uint32_t curve_cap);
+hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const KeysShardList& meshes, const KeysShardList& decals, const KeysShardList& curves);
 
 // Pose::computeAbsolute + computeSkinMatrices (+ optional dual-quaternion palette), one wave per PoseGroup
 hipError_t launch_pose_palette(hipStream_t s, const SkinInstance* inst, const PoseGroup* groups, const uint32_t n_groups[3] /* by capacity 4, 2, 1 */,

@@ -194,9 +194,12 @@ def test_gpu_sort_keys_match_committed_fixture(gpu_ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("walk_shards", [1, 0])
 @pytest.mark.parametrize("vi", range(len(VIEWS)))
-def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi):
-    """cull -> createSortKeys on the device, two consecutive frames (LOD / pose-frame state carried on the device)."""
+def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi, walk_shards):
+    """cull -> createSortKeys on the device, three consecutive frames (LOD / pose-frame state carried on the device; the instancer's two
+    counter tables, which take turns from run to run and are zeroed by the run before, have each been used and reused by then).
+    walk_shards 1: the key kernels read the visible ids out of the cull's per-shard windows, 0: out of one gathered list per type."""
     oracle_port = live_oracle
     base = scenes.cull_scene(60_000, 2500.0, seed=31, big_fraction=0.002)
     n = len(base["entity"])
@@ -212,9 +215,10 @@ def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi):
     sk.setInstances(sc["model"], sc["material_offset"], sc["mesh_materials"], sc["lod"], sc["flags"], sc["dirty"], sc["pose_frame"])
     sk.setDecals(n, sc["decal_key"], sc["decal_layer"], sc["curve_key"], sc["curve_layer"])
     sk.setPositions(pos)
+    sk.setOption(api.KEYS_OPT_WALK_SHARDS, walk_shards)
     lod, pose_frame = sc["lod"], sc["pose_frame"]
-    for frame in range(2):
-        if frame == 1:
+    for frame in range(3):
+        if frame >= 1:
             sk.setPositions(pos)  # per-frame position refresh: ModelInstance::lod / Pose::frame must keep the state of frame 0
         view = dict(VIEWS[vi])
         view["frame_number"] += frame
@@ -242,6 +246,7 @@ def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi):
         skeys, svalues = sk.readPairs()
         assert np.all(skeys[1:] >= skeys[:-1])
         assert sorted(zip(map(int, skeys), map(int, svalues))) == exp["pairs"]
+    sk.setOption(api.KEYS_OPT_WALK_SHARDS, 1)  # (the context is the session's)
 
 
 @pytest.mark.gpu

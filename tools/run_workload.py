@@ -44,6 +44,24 @@ def main():
             sk.run(api.keys_view(layer_to_bucket=ks["layer_to_bucket"], bucket_depth_sorted=ks["bucket_depth_sorted"], frame_number=100 + f), 255)
         ctx.synchronize()
         print(sk.counts())
+        # the span of the chain as bench.py reports it (also.keys_kernels_ms: first launch's begin -> last launch's end), both list forms
+        kid = api.KERNEL_NAMES.index("sort_keys")
+        for walk in (1, 0, 1):
+            sk.setOption(api.KEYS_OPT_WALK_SHARDS, walk)
+            spans = []
+            for rep in range(3):
+                for f in range(3):
+                    cs.cull(fr)
+                    sk.run(api.keys_view(layer_to_bucket=ks["layer_to_bucket"], bucket_depth_sorted=ks["bucket_depth_sorted"], frame_number=500 + 10 * rep + f), 255)
+                ctx.profile_reset()
+                ctx.profile_enable(True)
+                for f in range(5):
+                    cs.cull(fr)
+                    sk.run(api.keys_view(layer_to_bucket=ks["layer_to_bucket"], bucket_depth_sorted=ks["bucket_depth_sorted"], frame_number=600 + 10 * rep + f), 255)
+                ctx.synchronize()
+                ctx.profile_enable(False)
+                spans.append(ctx.profile_get(kid)[0] / 5 * 1e3)
+            print(f"createSortKeys span, walk_shards {walk}: " + " ".join(f"{x:.1f}" for x in spans) + " us", sk.counts())
     elif args.workload.startswith("cull"):
         half = 5000.0 if args.workload == "cull_dense" else 15000.0 * (args.entities / 1e7) ** (1.0 / 3.0)
         sc = scenes.cull_scene(args.entities, half, seed=2, mixed_types=args.workload == "cull8")
