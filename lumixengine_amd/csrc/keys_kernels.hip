@@ -11,7 +11,7 @@
 //   k_keys_scatter   instancer records -> CSR values; the lane that places a group's FIRST value also pushes the group's
 //                    AUTOINSTANCED pair (:3958-3968)
 // The visible ids are read where the cull kernels left them (KeysShardList: one window per output shard); no fill, no gather and
-// no single-purpose launch in the chain: 4 launches (round 4: 8).
+// no single-purpose launch in the chain: 3 launches for key ranges up to 1024, else 4 (round 4: 8).
 // Integer work is bit-exact by construction; the two fp64 -> fp32 distances use the reference's operation order.
 #include "lmx_kernels.h"
 
@@ -74,6 +74,47 @@ template <typename Unit> __device__ __forceinline__ void shard_list_to_lds(const
 	__syncthreads();
 }
 
+// The same walk out of registers, per wave and without LDS or barriers (k_keys_mesh: a block has about one tile, so what stands in front
+// of the tile's first load is paid per tile - through LDS and two barriers the kernel was 53.5 us instead of 48): lane l holds shards l
+// and l + 64, first[] = units in the shards before (wave scan), a unit's shard = the last one whose first[] is <= it (empty shards share
+// their first[] with the next non-empty one and are never that).
+struct ShardWalk {
+	uint32_t cnt[2], win[2], first[2], total;
+	template <typename Unit> __device__ __forceinline__ void load(const KeysShardList& L, uint32_t lane, Unit unit) {
+		uint32_t u[2];
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const uint32_t sh = lane + 64u * h;
+			const bool in = sh < L.n;
+			cnt[h] = in ? L.counts[(size_t)sh * L.cnt_pad] : 0u;
+			win[h] = in && L.win_base != nullptr ? L.win_base[sh] : 0u;
+		}
+		uint32_t before = 0;
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			u[h] = unit(cnt[h]);
+			uint32_t incl = u[h];
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+				if (lane >= (uint32_t)o) incl += up;
+			}
+			first[h] = before + incl - u[h];
+			before += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		}
+		total = before;
+	}
+	// unit t < total: its shard's count, window start and first unit (wave-uniform)
+	__device__ __forceinline__ void locate(uint32_t t, uint32_t& sh_cnt, uint32_t& sh_win, uint32_t& sh_first) const {
+		const uint32_t below = (uint32_t)__popcll(__ballot(first[0] <= t)) + (uint32_t)__popcll(__ballot(first[1] <= t)); // >= 1: first[0] of lane 0 is 0
+		const uint32_t sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)(below - 1u));
+		const bool hi = sh >= 64u;
+		sh_cnt = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? cnt[1] : cnt[0]), (int)(sh & 63u));
+		sh_win = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? win[1] : win[0]), (int)(sh & 63u));
+		sh_first = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? first[1] : first[0]), (int)(sh & 63u));
+	}
+};
+
 constexpr int KEYS_BLOCK = 512; // entities per tile = threads per block. 8 waves: 3 blocks per CU (79 VGPRs: 6 waves per SIMD). Tiles of 256 / 1024 entities measured slower (161.8 / 145.0 against 138.1 us for the whole chain, round 3's driver box)
 #ifndef LMX_KEYS_MM_REGS
 #define LMX_KEYS_MM_REGS 6 // every mesh of two LODs of three
@@ -99,8 +140,7 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 	const KeysShardList L /* the visible MESH entities; L.slots optional: static-set slot per id, -1 = dynamic set */) {
 	const int32_t* __restrict__ ids = L.ids;
 	const int32_t* __restrict__ slots = L.slots;
-	// tiles are cut per shard window (a window's last tile is partial): s_sh_first[s] = the first tile of shard s
-	__shared__ uint32_t s_sh_cnt[KEYS_MAX_SHARDS], s_sh_win[KEYS_MAX_SHARDS], s_sh_first[KEYS_MAX_SHARDS + 1];
+	// tiles are cut per shard window (a window's last tile is partial)
 	__shared__ uint32_t s_wave[KEYS_BLOCK / 64][3]; // per wave: pairs | recs << 16, poses, dirty
 	__shared__ uint32_t s_base[6]; // bases of the four lists; [4], [5]: this tile's pairs / records (LMX_KEYS_STAGE_PAIRS)
 	__shared__ uint32_t s_bucket[256]; // bucket_map: an LDS read instead of one more dependent global load per mesh
@@ -113,17 +153,19 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 	if (lds_hist) {
 		for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) s_hist[k] = 0;
 	}
-	shard_list_to_lds(L, s_sh_cnt, s_sh_win, s_sh_first, [](uint32_t c) { return (c + (uint32_t)KEYS_BLOCK - 1u) / (uint32_t)KEYS_BLOCK; }); // (two barriers: s_bucket / s_hist are in too)
-	const uint32_t n_tiles = s_sh_first[L.n < (uint32_t)KEYS_MAX_SHARDS ? L.n : (uint32_t)KEYS_MAX_SHARDS];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	ShardWalk walk;
+	walk.load(L, lane, [](uint32_t c) { return (c + (uint32_t)KEYS_BLOCK - 1u) / (uint32_t)KEYS_BLOCK; });
+	const uint32_t n_tiles = walk.total;
+	__syncthreads(); // s_bucket / s_hist are in
 	const uint32_t copy = blockIdx.x & (d.n_copies - 1); // this block's private row of the group counters
-	// where tile t's ids start and how many it holds; `sh` only moves forward (a block's tiles come in increasing order)
-	uint32_t sh = 0;
+	// where tile t's ids start and how many it holds
 	auto locate = [&](uint32_t t, uint32_t& at, uint32_t& cnt) {
-		while (s_sh_first[sh + 1] <= t) ++sh; // (t < n_tiles = s_sh_first[n]: stops inside the list)
-		const uint32_t j0 = (t - s_sh_first[sh]) * (uint32_t)KEYS_BLOCK;
-		at = s_sh_win[sh] + j0;
-		cnt = min(s_sh_cnt[sh] - j0, (uint32_t)KEYS_BLOCK);
+		uint32_t sh_cnt, sh_win, sh_first;
+		walk.locate(t, sh_cnt, sh_win, sh_first);
+		const uint32_t j0 = (t - sh_first) * (uint32_t)KEYS_BLOCK;
+		at = sh_win + j0;
+		cnt = min(sh_cnt - j0, (uint32_t)KEYS_BLOCK);
 	};
 	// A block walks its tiles one after the other and a tile is a chain of dependent loads (id -> record -> model -> materials) in front of
 	// three barriers: the next tile's id and slot - the chain's first link - are fetched at the top of the current tile.
@@ -546,9 +588,45 @@ __global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
 // Instancer records -> CSR values. The lane whose record lands on its group's FIRST position also pushes the group's AUTOINSTANCED
 // pair (:3958-3968, instancer index 0: `instances[i].begin->renderables[0]` is any member - they share the material): every
 // non-empty group has exactly one such record, so the pairs need no launch of their own (k_keys_groups, rounds 1-4).
-__global__ __launch_bounds__(256) void k_keys_scatter(KeysDevice d, const KeysViewDevice kv) {
+// OWN_OFFSETS (key ranges up to KEYS_SCATTER_OFFSETS): every block forms the exclusive scan of the group sizes itself, in LDS - 1 to 4
+// loads per thread and one block-wide scan, issued next to the tile's first loads - and block 0 also writes it out (group_offset, the
+// number of non-empty groups): k_keys_offsets, a single-block launch of ~5 us between two launch gaps, leaves the chain.
+constexpr int KEYS_SCATTER_OFFSETS = 1024;
+template <bool OWN_OFFSETS> __global__ __launch_bounds__(256) void k_keys_scatter(KeysDevice d, const KeysViewDevice kv) {
+	__shared__ uint32_t s_off[OWN_OFFSETS ? KEYS_SCATTER_OFFSETS : 1];
+	__shared__ uint32_t s_wave_sum[4];
 	const uint32_t n = min(d.counters[KEYS_N_RECS], d.cap_recs);
 	const uint32_t stride = d.max_sort_key + 1;
+	if (OWN_OFFSETS) {
+		if (blockIdx.x != 0 && blockIdx.x * 256u >= n) return; // (block 0 stays: it writes the offsets out)
+		const uint32_t k0 = threadIdx.x * 4u, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+		uint32_t c[4], sum = 0, non_empty = 0;
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j) { c[j] = k0 + j < stride ? d.group_total[k0 + j] : 0u; sum += c[j]; non_empty += c[j] != 0u; }
+		uint32_t incl = sum;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+			if (lane >= (uint32_t)o) incl += up;
+		}
+		if (lane == 63) s_wave_sum[wave] = incl;
+		__syncthreads();
+		uint32_t run = incl - sum;
+		for (uint32_t w = 0; w < wave; ++w) run += s_wave_sum[w];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j) {
+			if (k0 + j < stride) { s_off[k0 + j] = run; if (blockIdx.x == 0) d.group_offset[k0 + j] = run; }
+			run += c[j];
+		}
+		if (blockIdx.x == 0) {
+			if (threadIdx.x == 255) d.group_offset[stride] = run; // (thread 255 holds the grand total: keys past the range count 0)
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) non_empty += (uint32_t)__shfl_down((int)non_empty, o);
+			if (lane == 0 && non_empty) atomicAdd(d.counters + KEYS_N_GROUPS, non_empty);
+		}
+		__syncthreads();
+	}
+	auto offset_of = [&](uint32_t key) { return OWN_OFFSETS ? s_off[key] : d.group_offset[key]; };
 	for (uint32_t tile = blockIdx.x * 256; tile < n; tile += gridDim.x * 256) {
 		const uint32_t i = tile + threadIdx.x;
 		const uint32_t packed = i < n ? d.rec_key[i] : 0; // mesh sort key | copy << 24
@@ -579,7 +657,7 @@ __global__ __launch_bounds__(256) void k_keys_scatter(KeysDevice d, const KeysVi
 		uint64_t pair_key = 0, pair_value = 0;
 		if (has) {
 			const uint64_t renderable = d.rec_value[i];
-			d.group_values[d.group_offset[key] + in_group] = renderable;
+			d.group_values[offset_of(key) + in_group] = renderable;
 			if (in_group == 0) {
 				const uint32_t entity_index = (uint32_t)(renderable & 0xffFFffull);
 				const uint32_t mesh_idx = (uint32_t)(renderable >> LMX_SORT_VALUE_MESH_IDX_SHIFT);
@@ -719,8 +797,13 @@ hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice&
 	if (curves.cap && d.curve_sort_key != nullptr)
 		hipLaunchKernelGGL(k_keys_decal, dim3(std::min((curves.cap + 255) / 256, grid_cap)), dim3(256), 0, s, d, view, curves, d.curve_sort_key, d.curve_layer, (uint32_t)LMX_DRAW_CURVE_DECAL);
 	hipLaunchKernelGGL(k_keys_reduce_copies, dim3((d.max_sort_key + 4) / 4), dim3(256), 0, s, d);
-	hipLaunchKernelGGL(k_keys_offsets, dim3(1), dim3(1024), 0, s, d);
-	if (d.cap_recs) hipLaunchKernelGGL(k_keys_scatter, dim3(std::min((d.cap_recs + 255) / 256, grid_cap * 4)), dim3(256), 0, s, d, view);
+	const dim3 scatter_grid(std::max(1u, std::min((d.cap_recs + 255) / 256, grid_cap * 4)));
+	if (d.max_sort_key < (uint32_t)KEYS_SCATTER_OFFSETS) {
+		hipLaunchKernelGGL(k_keys_scatter<true>, scatter_grid, dim3(256), 0, s, d, view);
+	} else {
+		hipLaunchKernelGGL(k_keys_offsets, dim3(1), dim3(1024), 0, s, d);
+		if (d.cap_recs) hipLaunchKernelGGL(k_keys_scatter<false>, scatter_grid, dim3(256), 0, s, d, view);
+	}
 	return hipGetLastError();
 }
 

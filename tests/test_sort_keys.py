@@ -250,6 +250,48 @@ def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi, walk_shards):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("max_sort_key", [1023, 1024, 5000, 200_000])
+def test_gpu_sort_keys_key_ranges(gpu_ctx, live_oracle, max_sort_key):
+    """Renderer::getMaxSortKey() decides which form of the instancer's kernels runs: up to 1024 keys the scatter forms the group offsets
+    itself (three launches), beyond that k_keys_offsets does; beyond 4096 keys a tile's histogram no longer fits LDS; beyond 32 k the
+    counter table has fewer than 8 private copies (per-wave de-duplicated atomics), 200 k: one. Three frames each: the two counter tables,
+    which take turns and are zeroed by the run before, have been reused by then."""
+    base = scenes.cull_scene(30_000, 1500.0, seed=35, big_fraction=0.0)
+    n = len(base["entity"])
+    types = np.zeros(n, np.uint8)
+    pos = base["pos"]
+    sc = scenes.keys_scene(n, types, seed=53, max_sort_key=max_sort_key, moved_fraction=0.05)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(base["entity"], types, pos, base["radius"])
+    fr = api.viewport_frustum(pos=(0, 0, 0), far=3000.0)
+    sk = api.SortKeys(gpu_ctx)
+    sk.setModels(sc["models"], sc["mesh_types"])
+    sk.setInstances(sc["model"], sc["material_offset"], sc["mesh_materials"], sc["lod"], sc["flags"], sc["dirty"], sc["pose_frame"])
+    sk.setDecals(n, sc["decal_key"], sc["decal_layer"], sc["curve_key"], sc["curve_layer"])
+    sk.setPositions(pos)
+    lod, pose_frame = sc["lod"], sc["pose_frame"]
+    empty = np.zeros(0, np.int32)
+    for frame in range(3):
+        view = dict(VIEWS[0])
+        view["frame_number"] += frame
+        kv = api.keys_view(layer_to_bucket=sc["layer_to_bucket"], bucket_depth_sorted=sc["bucket_depth_sorted"], **view)
+        ids = cs.cull(fr).ids(0, 0)
+        assert len(ids) > 3000
+        sk.run(kv, max_sort_key)
+        cnt = sk.counts()
+        assert cnt["overflow"] == 0
+        want = live_oracle.create_sort_keys(kv, max_sort_key, ids, empty, empty, sc, pos, lod=lod, pose_frame=pose_frame)
+        keys, values = sk.readPairs()
+        offsets, gvalues = sk.readInstancer()
+        assert np.array_equal(offsets, want["group_offsets"]) and cnt["groups"] == want["groups"] and cnt["instanced"] == len(want["group_values"]) > 1000
+        got = canon(keys, values, offsets, gvalues, sk.readPoses(), sk.readDirty())
+        exp = canon(want["keys"], want["values"], want["group_offsets"], want["group_values"], want["poses"], want["dirty"])
+        for k in ("pairs", "groups", "poses", "dirty"):
+            assert got[k] == exp[k], f"frame {frame}: {k}"
+        lod, pose_frame = want["lod"], want["pose_frame"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("moved_fraction,meshes", [(0.9, (6, 10)), (0.0, (12, 16))])
 def test_gpu_sort_keys_tiles_beyond_the_staging_buffers(gpu_ctx, live_oracle, moved_fraction, meshes):
     """Models with 6-9 meshes per LOD: a 512-entity tile of k_keys_mesh emits more pairs (most instances MOVED) or more instancer
