@@ -478,7 +478,8 @@ LMX_API int lmx_keys_read_dirty(LmxContext* ctx, int32_t* entities, uint32_t cap
 /* ModelInstance::lod and Pose::frame after the run (both are updated in place on the device). */
 LMX_API int lmx_keys_read_state(LmxContext* ctx, float* lod, uint32_t* pose_frame, uint32_t n_entities);
 /* Device pointers of the last run for GPU consumers: pairs (keys, values, count on the device). Valid until the next lmx_keys_run /
- * lmx_keys_set_*: the buffers (d_count included) are re-reserved when the key range or the copy count grows - fetch them again after every run. */
+ * lmx_keys_set_*: fetch them again after every run - d_count alternates between two addresses from run to run (the next run's counters
+ * are zeroed by this run's kernels, not by a fill), and the buffers are re-reserved when the key range or the copy count grows. */
 LMX_API int lmx_keys_device_pairs(LmxContext* ctx, const uint64_t** d_keys, const uint64_t** d_values, const uint32_t** d_count);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -133,7 +133,6 @@ constexpr int KEYS_STAGE_PAIRS = 3 * KEYS_BLOCK; // pairs (24 KiB) and records (
 #define LMX_KEYS_LDS_HIST 1 // the instancer's group histogram per tile in LDS, one global atomic per (tile, key) instead of one per record
 #endif
 constexpr int KEYS_HIST_LDS = 4096; // keys (16 KiB): larger ranges keep the global atomics
-constexpr int KEYS_MODELS_LDS = 256; // models whose LOD tables a block keeps in LDS (16 KiB)
 #ifndef LMX_KEYS_MIN_WAVES
 #define LMX_KEYS_MIN_WAVES 4 // waves per SIMD the register allocation aims at: 106 VGPRs, no scratch, two 8-wave blocks per CU. Round 4 (profiles/r04/keys_ab.txt, k_keys_mesh per 1.05 M visible): 6 waves (80 VGPRs, 32-44 B of scratch, three blocks) 65.5-70.5 us, 5 waves 59.1, 4 waves 60.2 - the kernel is not short of waves, spills cost it more
 #endif
@@ -154,15 +153,6 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 	if (lds_hist) {
 		for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) s_hist[k] = 0;
 	}
-	// The models' LOD tables (64 B each) of a scene with up to KEYS_MODELS_LDS models: the third link of a tile's chain of dependent loads
-	// (id -> record -> MODEL -> materials) becomes an LDS read. 16 KiB on top of 59: still two blocks per CU.
-	__shared__ LmxKeysModel s_models[KEYS_MODELS_LDS];
-	const bool models_in_lds = d.n_models <= (uint32_t)KEYS_MODELS_LDS; // launch-uniform
-	if (models_in_lds) {
-		const uint4* src = reinterpret_cast<const uint4*>(d.models);
-		uint4* dst = reinterpret_cast<uint4*>(s_models);
-		for (uint32_t k = threadIdx.x; k < d.n_models * 4u; k += KEYS_BLOCK) dst[k] = src[k];
-	}
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	ShardWalk walk;
 	walk.load(L, lane, [](uint32_t c) { return (c + (uint32_t)KEYS_BLOCK - 1u) / (uint32_t)KEYS_BLOCK; });
@@ -178,33 +168,10 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		cnt = min(sh_cnt - j0, (uint32_t)KEYS_BLOCK);
 	};
 	// A block walks its tiles one after the other and a tile is a chain of dependent loads (id -> record -> model -> materials) in front of
-	// three barriers. The chain's first two links are taken off it (round 5; the grid is the resident blocks, a block has ~4 tiles): the
-	// next tile's id and slot are fetched at the top of the current tile, and the next tile's RECORD (the mirror's structure of arrays:
-	// what depends on id and slot alone) behind the current tile's first barrier, under its emit and store-out.
-	struct Fetched { // of one lane's entity
-		int32_t model, world_slot;
-		uint32_t material_offset, flags_dirty, pose_frame;
-		float lod;
-		double px, py, pz;
-	};
-	auto fetch = [&](uint32_t e_of, int32_t slot_of, bool has_of) {
-		Fetched r;
-		r.model = -1; r.world_slot = -1; r.material_offset = 0; r.flags_dirty = 0; r.pose_frame = 0; r.lod = 0.f; r.px = r.py = r.pz = 0.0;
-		if (has_of) {
-			// (world binding) the entity's slot in the hierarchy: depends on `e` alone, so it travels with the record's loads - read where the
-			// position is needed it was one more link in the chain of dependent loads, behind the model table's
-			if (d.slot_of_entity != nullptr && e_of < d.n_entities) r.world_slot = d.slot_of_entity[e_of];
-			if (slot_of >= 0 && d.soa.model != nullptr) { // the mirror as a structure of arrays: every field a contiguous load across the wave
-				r.model = d.soa.model[slot_of];
-				r.material_offset = d.soa.material_offset[slot_of];
-				r.flags_dirty = d.soa.flags_dirty[slot_of];
-				r.px = d.soa.px[slot_of]; r.py = d.soa.py[slot_of]; r.pz = d.soa.pz[slot_of];
-				r.lod = d.state_s[slot_of].lod; // (an entity is in the visible list once: nobody writes these two before its own tile does)
-				r.pose_frame = d.state_s[slot_of].pose_frame;
-			}
-		}
-		return r;
-	};
+	// three barriers: the next tile's id and slot - the chain's first link - are fetched at the top of the current tile.
+	// (Measured and NOT kept, round 5, profiles/r05/keys_record_prefetch_and_lds_models.txt: the next tile's whole record fetched under the
+	// current tile's emit + the models' LOD tables staged in LDS - two links fewer - 43.8 against 44.3 us, 123 VGPRs: with the atomics
+	// compiled out the kernel still takes 37 us for 150 MB of scattered 32-64 B accesses; it is the memory system, not the chain.)
 	uint32_t e_next = 0, cnt_next = 0;
 	int32_t slot_next = -1;
 	if (blockIdx.x < n_tiles) {
@@ -212,14 +179,11 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		locate(blockIdx.x, at, cnt_next);
 		if (threadIdx.x < cnt_next) { e_next = (uint32_t)ids[at + threadIdx.x]; slot_next = slots != nullptr ? slots[at + threadIdx.x] : -1; }
 	}
-	Fetched f_next = fetch(e_next, slot_next, threadIdx.x < cnt_next);
 	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		const bool has = threadIdx.x < cnt_next; // this lane holds an entity of the tile
 		const uint32_t e_now = e_next;
 		const int32_t slot_now = slot_next;
-		const Fetched f_now = f_next;
-		const bool more = tile + gridDim.x < n_tiles; // block-uniform
-		if (more) {
+		if (tile + gridDim.x < n_tiles) {
 			uint32_t at;
 			locate(tile + gridDim.x, at, cnt_next);
 			if (threadIdx.x < cnt_next) { e_next = (uint32_t)ids[at + threadIdx.x]; slot_next = slots != nullptr ? slots[at + threadIdx.x] : -1; }
@@ -240,17 +204,21 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			in.model = -1;
 			const int32_t sl = slot_now;
 			slot = sl;
-			const int32_t world_slot = f_now.world_slot;
-			if (sl >= 0 && d.soa.model != nullptr) { // the mirror as a structure of arrays: fetched a tile ahead
+			// (world binding) the entity's slot in the hierarchy: depends on `e` alone, so it travels with the record's loads - read where the
+			// position is needed it was one more link in the chain of dependent loads, behind the model table's
+			int32_t world_slot = -1;
+			if (d.slot_of_entity != nullptr && e < d.n_entities) world_slot = d.slot_of_entity[e];
+			if (sl >= 0 && d.soa.model != nullptr) { // the mirror as a structure of arrays: every field a contiguous load across the wave
 				mmb = d.mm_s;
-				in.model = f_now.model;
-				in.material_offset = f_now.material_offset;
-				in.flags = (uint8_t)f_now.flags_dirty;
-				in.dirty = (uint8_t)(f_now.flags_dirty >> 8);
-				in.pos[0] = f_now.px; in.pos[1] = f_now.py; in.pos[2] = f_now.pz;
+				in.model = d.soa.model[sl];
+				in.material_offset = d.soa.material_offset[sl];
+				const uint32_t fd = d.soa.flags_dirty[sl];
+				in.flags = (uint8_t)fd;
+				in.dirty = (uint8_t)(fd >> 8);
+				in.pos[0] = d.soa.px[sl]; in.pos[1] = d.soa.py[sl]; in.pos[2] = d.soa.pz[sl];
 				lod_at = &d.state_s[sl].lod;
-				in.lod = f_now.lod;
-				in.pose_frame = f_now.pose_frame;
+				in.lod = *lod_at;
+				in.pose_frame = d.state_s[sl].pose_frame;
 			} else {
 				if (sl >= 0) {
 					rec = d.inst_s + sl;
@@ -275,19 +243,11 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 				// `else if` chain over lod_distances[k], then lod_indices[lod_idx] - they were up to five DEPENDENT loads, each behind its own
 				// s_waitcnt vmcnt(0) (seen in the ISA), in a kernel whose time is the length of its chain of dependent loads.
 				static_assert(sizeof(LmxKeysModel) == 64 && offsetof(LmxKeysModel, lod_indices) == 16, "the model record is read as 16 + 5 x 8 bytes");
-				float4 lod_d;
+				const LmxKeysModel* mp = d.models + mdl;
+				const float4 lod_d = *reinterpret_cast<const float4*>(mp->lod_distances);
 				int2 lod_i[5];
-				if (models_in_lds) { // (launch-uniform) a scene of up to KEYS_MODELS_LDS models: the table was staged once per block
-					const LmxKeysModel* mp = s_models + mdl;
-					lod_d = *reinterpret_cast<const float4*>(mp->lod_distances);
 #pragma unroll
-					for (int k = 0; k < 5; ++k) lod_i[k] = *reinterpret_cast<const int2*>(&mp->lod_indices[k]);
-				} else {
-					const LmxKeysModel* mp = d.models + mdl;
-					lod_d = *reinterpret_cast<const float4*>(mp->lod_distances);
-#pragma unroll
-					for (int k = 0; k < 5; ++k) lod_i[k] = *reinterpret_cast<const int2*>(&mp->lod_indices[k]);
-				}
+				for (int k = 0; k < 5; ++k) lod_i[k] = *reinterpret_cast<const int2*>(&mp->lod_indices[k]);
 				auto lod_range = [&](uint32_t k) { // lod_indices[k] out of registers (a dynamic index would put the array into scratch)
 					int2 r = lod_i[0];
 #pragma unroll
@@ -397,7 +357,6 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		const uint64_t pose_mask = __ballot(push_pose), dirty_mask = __ballot(queue_dirty);
 		if (lane == 63) { s_wave[wave][0] = incl; s_wave[wave][1] = (uint32_t)__popcll(pose_mask); s_wave[wave][2] = (uint32_t)__popcll(dirty_mask); }
 		__syncthreads();
-		if (more) f_next = fetch(e_next, slot_next, threadIdx.x < cnt_next); // the next tile's record: in flight under this tile's emit and store-out
 		// Every thread sums the waves' counts itself (8 LDS words): the tile's totals and this wave's offsets inside the tile need no second
 		// barrier, and they are all the LDS-staged emit below needs - it writes at positions RELATIVE to the tile's ranges.
 		uint32_t tile_pairs = 0, tile_recs = 0, tile_poses = 0, tile_dirty = 0;
@@ -639,6 +598,15 @@ constexpr int KEYS_SCATTER_OFFSETS = 1024;
 template <bool OWN_OFFSETS> __global__ __launch_bounds__(256) void k_keys_scatter(KeysDevice d, const KeysViewDevice kv) {
 	__shared__ uint32_t s_off[OWN_OFFSETS ? KEYS_SCATTER_OFFSETS : 1];
 	__shared__ uint32_t s_wave_sum[4];
+	// A block has about one tile and a tile is a chain of dependent round trips (the ISA waited for every load where it was issued:
+	// record key -> cursor atomic -> base -> record value -> store, behind the number of records): the tile's two record loads are issued
+	// FIRST, bounded by the capacity instead of the count, next to the count's and the offsets' loads; base and cursor go out together.
+	uint32_t packed_next = 0;
+	uint64_t value_next = 0;
+	{
+		const uint32_t i0 = blockIdx.x * 256u + threadIdx.x;
+		if (i0 < d.cap_recs) { packed_next = d.rec_key[i0]; value_next = d.rec_value[i0]; }
+	}
 	const uint32_t n = min(d.counters[KEYS_N_RECS], d.cap_recs);
 	const uint32_t stride = d.max_sort_key + 1;
 	if (OWN_OFFSETS) {
@@ -673,13 +641,21 @@ template <bool OWN_OFFSETS> __global__ __launch_bounds__(256) void k_keys_scatte
 	auto offset_of = [&](uint32_t key) { return OWN_OFFSETS ? s_off[key] : d.group_offset[key]; };
 	for (uint32_t tile = blockIdx.x * 256; tile < n; tile += gridDim.x * 256) {
 		const uint32_t i = tile + threadIdx.x;
-		const uint32_t packed = i < n ? d.rec_key[i] : 0; // mesh sort key | copy << 24
+		const uint32_t packed = i < n ? packed_next : 0; // mesh sort key | copy << 24
+		const uint64_t renderable = value_next;
+		{
+			const uint32_t i1 = i + gridDim.x * 256u;
+			if (i1 < n) { packed_next = d.rec_key[i1]; value_next = d.rec_value[i1]; }
+		}
 		const uint32_t key = packed & 0xffffffu;
 		const bool has = i < n && key <= d.max_sort_key;
 		const size_t at = (size_t)(packed >> 24) * stride + key;
 		uint32_t in_group = 0; // the record's position inside its group
 		if (d.n_copies >= 8) { // privatised cursors: one returning atomic per lane, all in flight together
-			if (has) in_group = d.group_base[at] + atomicAdd(d.group_count + at, 1u);
+			if (has) {
+				const uint32_t base = d.group_base[at];
+				in_group = base + atomicAdd(d.group_count + at, 1u);
+			}
 		} else {
 			// per distinct (copy, key) of the wave: its first lane (leader), the number of lanes holding it and every lane's rank among
 			// them - ALU only; then ALL leaders reserve their cursor ranges at once (one memory round trip per wave, not one per key)
@@ -700,7 +676,6 @@ template <bool OWN_OFFSETS> __global__ __launch_bounds__(256) void k_keys_scatte
 		bool push = false;
 		uint64_t pair_key = 0, pair_value = 0;
 		if (has) {
-			const uint64_t renderable = d.rec_value[i];
 			d.group_values[offset_of(key) + in_group] = renderable;
 			if (in_group == 0) {
 				const uint32_t entity_index = (uint32_t)(renderable & 0xffFFffull);

@@ -338,7 +338,6 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 		d.inst = ks.d_inst.p;
 		d.mesh_materials = ks.d_mesh_materials.p;
 		d.models = ks.d_models.p;
-		d.n_models = (uint32_t)ks.models.size();
 		d.inst_s = ks.mirror_valid ? ks.d_inst_s.p : nullptr;
 		d.mm_s = ks.mirror_valid ? ks.d_mm_s.p : nullptr;
 		d.state_s = ks.mirror_valid && ks.mirror_split ? ks.d_state_s.p : nullptr;

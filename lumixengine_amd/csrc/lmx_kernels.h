@@ -268,7 +268,6 @@ struct KeysDevice {
 	KeysSlotState* state_s; // nullptr: lod / pose_frame live in inst_s
 	KeysSoA soa;            // soa.model != nullptr: the mirror's records are these arrays (inst_s is not allocated), state_s holds lod / pose_frame
 	const LmxKeysModel* models;
-	uint32_t n_models;
 	const uint32_t *decal_sort_key, *curve_sort_key;
 	const uint8_t *decal_layer, *curve_layer;
 	// positions: KeysInstance::pos, or the world hierarchy's SoA through slot_of_entity when bound
