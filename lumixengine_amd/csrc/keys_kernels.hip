@@ -127,12 +127,14 @@ constexpr int KEYS_STAGE_PAIRS = 3 * KEYS_BLOCK; // pairs (24 KiB) and records (
 // ~90 per microsecond chip-wide: one per wave and mesh was 15x slower than this kernel's memory work), and a second walk writes at
 // lane-private positions.
 #ifndef LMX_KEYS_PROBE
-#define LMX_KEYS_PROBE 0 // timing probes (tools/build_variant.py): 1 = no group histogram, 4 = no tile reservations; results are wrong
+#define LMX_KEYS_PROBE 0 // timing probes (tools/build_variant.py): 1 = no group histogram, 4 = no tile reservations, 8 = k_keys_scatter without its cursor atomics, 16 = without its stores; results are wrong
 #endif
 #ifndef LMX_KEYS_LDS_HIST
 #define LMX_KEYS_LDS_HIST 1 // the instancer's group histogram per tile in LDS, one global atomic per (tile, key) instead of one per record
 #endif
 constexpr int KEYS_HIST_LDS = 4096; // keys (16 KiB): larger ranges keep the global atomics
+constexpr int KEYS_TILE_SHIFT = 12;  // tile ranks: rec_key = key (< KEYS_HIST_LDS) | tile << 12
+static_assert((1 << KEYS_TILE_SHIFT) == KEYS_HIST_LDS, "a record's key and tile share 32 bits");
 #ifndef LMX_KEYS_MIN_WAVES
 #define LMX_KEYS_MIN_WAVES 4 // waves per SIMD the register allocation aims at: 106 VGPRs, no scratch, two 8-wave blocks per CU. Round 4 (profiles/r04/keys_ab.txt, k_keys_mesh per 1.05 M visible): 6 waves (80 VGPRs, 32-44 B of scratch, three blocks) 65.5-70.5 us, 5 waves 59.1, 4 waves 60.2 - the kernel is not short of waves, spills cost it more
 #endif
@@ -150,6 +152,12 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 	// (profiles/r04/keys_probes2.txt): they are executed memory-side, a few tens of thousands per microsecond over the whole chip.
 	__shared__ uint32_t s_hist[KEYS_HIST_LDS];
 	const bool lds_hist = LMX_KEYS_LDS_HIST != 0 && d.max_sort_key < (uint32_t)KEYS_HIST_LDS; // launch-uniform
+	// TILE RANKS (round 5; the host offers d.tile_rows for key ranges that fit the LDS histogram): a tile's histogram is not added to a
+	// private copy of the group counters but stored as the tile's own row of a table, and every instancer record carries its rank among
+	// the tile's records of its key (what the LDS increment returns). k_keys_reduce_tiles turns the columns into exclusive prefixes and a
+	// record's place in its group is offset + prefix[tile][key] + rank: neither this kernel's ~300 k global histogram adds nor the
+	// scatter's 560 k returning cursor atomics (7 of its 18 us, profiles/r05/keys_scatter_probes.txt) exist any more.
+	const bool tile_ranks = lds_hist && d.tile_rows != nullptr; // launch-uniform
 	if (lds_hist) {
 		for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) s_hist[k] = 0;
 	}
@@ -157,6 +165,7 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 	ShardWalk walk;
 	walk.load(L, lane, [](uint32_t c) { return (c + (uint32_t)KEYS_BLOCK - 1u) / (uint32_t)KEYS_BLOCK; });
 	const uint32_t n_tiles = walk.total;
+	if (tile_ranks && blockIdx.x == 0 && threadIdx.x == 0) d.counters[KEYS_N_TILES] = n_tiles; // the rows k_keys_reduce_tiles reads
 	__syncthreads(); // s_bucket / s_hist are in
 	const uint32_t copy = blockIdx.x & (d.n_copies - 1); // this block's private row of the group counters
 	// where tile t's ids start and how many it holds
@@ -372,7 +381,7 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		// as contiguous stores (8-byte stores at every lane's own run of positions used 26 % of the sectors they touched); tiles with more
 		// output than the buffers hold keep the direct stores
 		__shared__ uint64_t s_pair_key[KEYS_STAGE_PAIRS], s_pair_value[KEYS_STAGE_PAIRS], s_rec_value[KEYS_STAGE_PAIRS];
-		__shared__ uint32_t s_rec_key[KEYS_STAGE_PAIRS];
+		__shared__ uint32_t s_rec_key[KEYS_STAGE_PAIRS], s_rec_rank[KEYS_STAGE_PAIRS];
 		const bool stage = tile_pairs <= (uint32_t)KEYS_STAGE_PAIRS && tile_recs <= (uint32_t)KEYS_STAGE_PAIRS; // block-uniform
 		// The two reservations - thread 0: {pairs, recs}, thread 1: {poses, dirty}; one 64-bit returning atomic each, on two cache lines - are
 		// ISSUED here and their results consumed behind the emit: the ranges' bases are needed when the staged outputs leave LDS, not while
@@ -418,13 +427,19 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 				} else {
 					add_inst = true; // instancer.add(mesh_sort_key, value)
 				}
+				// the record's first word: its key and where its counter lives - the tile's row (tile ranks) or the block's private copy
+				uint32_t rec_word = mesh_sort_key | (copy << 24), rank = 0;
+				if (tile_ranks && add_inst) {
+					rec_word = (mesh_sort_key & (uint32_t)(KEYS_HIST_LDS - 1)) | (tile << KEYS_TILE_SHIFT);
+					if (mesh_sort_key <= d.max_sort_key) rank = atomicAdd(&s_hist[mesh_sort_key], 1u); // ds_add_rtn_u32: the record's rank among the tile's records of its key
+				}
 				if (stage) {
 					if (!add_inst) { s_pair_key[pair_at] = key; s_pair_value[pair_at] = value; }
-					else { s_rec_key[rec_at] = mesh_sort_key | (copy << 24); s_rec_value[rec_at] = value; }
+					else { s_rec_key[rec_at] = rec_word; s_rec_value[rec_at] = value; if (tile_ranks) s_rec_rank[rec_at] = rank; }
 				} else if (!add_inst) {
 					if (pair_at < d.cap_pairs) { d.keys[pair_at] = key; d.values[pair_at] = value; } else d.counters[KEYS_OVERFLOW] = 1;
 				} else {
-					if (rec_at < d.cap_recs) { d.rec_key[rec_at] = mesh_sort_key | (copy << 24); d.rec_value[rec_at] = value; } else d.counters[KEYS_OVERFLOW] = 1;
+					if (rec_at < d.cap_recs) { d.rec_key[rec_at] = rec_word; d.rec_value[rec_at] = value; if (tile_ranks) d.rec_rank[rec_at] = rank; } else d.counters[KEYS_OVERFLOW] = 1;
 				}
 				// (plain arithmetic: with `++pair_at` / `++rec_at` in the branches the compiler indexed the two cursors in scratch memory)
 				pair_at += add_inst ? 0u : 1u;
@@ -436,6 +451,7 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			// (one atomic per distinct key, ~15 scalar + vector instructions per key: 60 % of this kernel's time at 256 live keys)
 			// is kept for key ranges too large to privatise
 			if (LMX_KEYS_PROBE & 1) { // (timing probe only: no group histogram - the instancer's groups come out wrong)
+			} else if (tile_ranks) { // (counted above, where the rank was taken)
 			} else if (lds_hist) {
 				if (in_range) atomicAdd(&s_hist[mesh_sort_key], 1u); // ds_add_u32, nothing returned
 			} else if (d.n_copies >= 8) {
@@ -469,7 +485,13 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			if (queue_dirty) { if (dirty0 + dirty_at < d.cap_list) d.dirty_list[dirty0 + dirty_at] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
 			if (push_pose) { if (pose0 + pose_at < d.cap_list) d.poses[pose0 + pose_at] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
 		}
-		if (lds_hist && tile_recs != 0) { // (behind the barrier: every lane's LDS increments are in)
+		if (tile_ranks) { // the tile's histogram is its ROW of the table (plain stores, zeros included: k_keys_reduce_tiles reads whole rows)
+			uint32_t* row = d.tile_rows + (size_t)tile * (d.max_sort_key + 1);
+			for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) {
+				row[k] = s_hist[k];
+				s_hist[k] = 0;
+			}
+		} else if (lds_hist && tile_recs != 0) { // (behind the barrier: every lane's LDS increments are in)
 			for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) {
 				const uint32_t c = s_hist[k];
 				if (c != 0) {
@@ -486,7 +508,7 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			}
 			for (uint32_t j = threadIdx.x; j < tile_recs; j += KEYS_BLOCK) {
 				const uint32_t at = tile_rec0 + j;
-				if (at < d.cap_recs) { d.rec_key[at] = s_rec_key[j]; d.rec_value[at] = s_rec_value[j]; } else d.counters[KEYS_OVERFLOW] = 1;
+				if (at < d.cap_recs) { d.rec_key[at] = s_rec_key[j]; d.rec_value[at] = s_rec_value[j]; if (tile_ranks) d.rec_rank[at] = s_rec_rank[j]; } else d.counters[KEYS_OVERFLOW] = 1;
 			}
 		}
 		__syncthreads(); // s_wave, s_base and the staging buffers are rewritten by the next tile
@@ -553,6 +575,47 @@ __global__ __launch_bounds__(256) void k_keys_reduce_copies(KeysDevice d) {
 	if (lane == 63) d.group_total[k] = carry;
 }
 
+// Tile ranks: one wave per key turns column k of the tiles' table into exclusive prefixes (tile_rows[t][k] = the records of key k in the
+// tiles before t) and total[k]. Lane l owns the tiles [l * chunk, (l + 1) * chunk): its loads are independent of each other (8 in flight),
+// one wave scan joins the lanes' sums, a second walk over the (cached) chunk writes the prefixes.
+__global__ __launch_bounds__(256) void k_keys_reduce_tiles(KeysDevice d) {
+	const uint32_t n = d.max_sort_key + 1;
+	const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63u;
+	if (blockIdx.x == 0 && threadIdx.x < (uint32_t)KEYS_COUNTERS) d.counters_next[threadIdx.x] = 0;
+	if (k >= n) return;
+	const uint32_t n_tiles = d.counters[KEYS_N_TILES];
+	const uint32_t chunk = (n_tiles + 63u) / 64u;
+	const uint32_t t0 = min(lane * chunk, n_tiles), t1 = min(t0 + chunk, n_tiles);
+	uint32_t* col = d.tile_rows + k;
+	uint32_t sum = 0;
+	for (uint32_t t = t0; t < t1; t += 8u) {
+		uint32_t v[8];
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) v[j] = t + j < t1 ? col[(size_t)(t + j) * n] : 0u;
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) sum += v[j];
+	}
+	uint32_t incl = sum;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+		if (lane >= (uint32_t)o) incl += up;
+	}
+	uint32_t run = incl - sum;
+	for (uint32_t t = t0; t < t1; t += 8u) {
+		uint32_t v[8];
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) v[j] = t + j < t1 ? col[(size_t)(t + j) * n] : 0u;
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) {
+			if (t + j < t1) col[(size_t)(t + j) * n] = run;
+			run += v[j];
+		}
+	}
+	if (lane == 63) d.group_total[k] = incl;
+}
+
 // one block: offsets[k] = sum of total[0..k), offsets[n] = grand total; non-empty groups counted
 __global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
 	__shared__ uint32_t s_wave[16];
@@ -601,11 +664,12 @@ template <bool OWN_OFFSETS> __global__ __launch_bounds__(256) void k_keys_scatte
 	// A block has about one tile and a tile is a chain of dependent round trips (the ISA waited for every load where it was issued:
 	// record key -> cursor atomic -> base -> record value -> store, behind the number of records): the tile's two record loads are issued
 	// FIRST, bounded by the capacity instead of the count, next to the count's and the offsets' loads; base and cursor go out together.
-	uint32_t packed_next = 0;
+	const bool tile_ranks = d.tile_rows != nullptr; // launch-uniform
+	uint32_t packed_next = 0, rank_next = 0;
 	uint64_t value_next = 0;
 	{
 		const uint32_t i0 = blockIdx.x * 256u + threadIdx.x;
-		if (i0 < d.cap_recs) { packed_next = d.rec_key[i0]; value_next = d.rec_value[i0]; }
+		if (i0 < d.cap_recs) { packed_next = d.rec_key[i0]; value_next = d.rec_value[i0]; if (tile_ranks) rank_next = d.rec_rank[i0]; }
 	}
 	const uint32_t n = min(d.counters[KEYS_N_RECS], d.cap_recs);
 	const uint32_t stride = d.max_sort_key + 1;
@@ -641,20 +705,28 @@ template <bool OWN_OFFSETS> __global__ __launch_bounds__(256) void k_keys_scatte
 	auto offset_of = [&](uint32_t key) { return OWN_OFFSETS ? s_off[key] : d.group_offset[key]; };
 	for (uint32_t tile = blockIdx.x * 256; tile < n; tile += gridDim.x * 256) {
 		const uint32_t i = tile + threadIdx.x;
-		const uint32_t packed = i < n ? packed_next : 0; // mesh sort key | copy << 24
+		const uint32_t packed = i < n ? packed_next : 0; // mesh sort key | copy << 24, or (tile ranks) | tile << 12
 		const uint64_t renderable = value_next;
+		const uint32_t rank_next_now = rank_next;
 		{
 			const uint32_t i1 = i + gridDim.x * 256u;
-			if (i1 < n) { packed_next = d.rec_key[i1]; value_next = d.rec_value[i1]; }
+			if (i1 < n) { packed_next = d.rec_key[i1]; value_next = d.rec_value[i1]; if (tile_ranks) rank_next = d.rec_rank[i1]; }
 		}
-		const uint32_t key = packed & 0xffffffu;
+		const uint32_t key = tile_ranks ? packed & (uint32_t)(KEYS_HIST_LDS - 1) : packed & 0xffffffu;
 		const bool has = i < n && key <= d.max_sort_key;
-		const size_t at = (size_t)(packed >> 24) * stride + key;
+		const size_t at = tile_ranks ? (size_t)(packed >> KEYS_TILE_SHIFT) * stride + key : (size_t)(packed >> 24) * stride + key;
 		uint32_t in_group = 0; // the record's position inside its group
-		if (d.n_copies >= 8) { // privatised cursors: one returning atomic per lane, all in flight together
+		if (tile_ranks) { // no atomics: the records of key k in the tiles before this record's + its rank inside its tile
+			const uint32_t rank = rank_next_now;
+			if (has) in_group = d.tile_rows[at] + rank;
+		} else if (d.n_copies >= 8) { // privatised cursors: one returning atomic per lane, all in flight together
 			if (has) {
 				const uint32_t base = d.group_base[at];
+#if LMX_KEYS_PROBE & 8 // (timing probe: no cursor atomics - the groups come out wrong)
+				in_group = base + (i & 3u);
+#else
 				in_group = base + atomicAdd(d.group_count + at, 1u);
+#endif
 			}
 		} else {
 			// per distinct (copy, key) of the wave: its first lane (leader), the number of lanes holding it and every lane's rank among
@@ -676,7 +748,7 @@ template <bool OWN_OFFSETS> __global__ __launch_bounds__(256) void k_keys_scatte
 		bool push = false;
 		uint64_t pair_key = 0, pair_value = 0;
 		if (has) {
-			d.group_values[offset_of(key) + in_group] = renderable;
+			if (!(LMX_KEYS_PROBE & 16)) d.group_values[offset_of(key) + in_group] = renderable; // (16: timing probe, no scatter stores)
 			if (in_group == 0) {
 				const uint32_t entity_index = (uint32_t)(renderable & 0xffFFffull);
 				const uint32_t mesh_idx = (uint32_t)(renderable >> LMX_SORT_VALUE_MESH_IDX_SHIFT);
@@ -818,7 +890,8 @@ hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice&
 		hipLaunchKernelGGL(k_keys_decal, dim3(std::min((decals.cap + 255) / 256, grid_cap)), dim3(256), 0, s, d, view, decals, d.decal_sort_key, d.decal_layer, (uint32_t)LMX_DRAW_DECAL);
 	if (curves.cap && d.curve_sort_key != nullptr)
 		hipLaunchKernelGGL(k_keys_decal, dim3(std::min((curves.cap + 255) / 256, grid_cap)), dim3(256), 0, s, d, view, curves, d.curve_sort_key, d.curve_layer, (uint32_t)LMX_DRAW_CURVE_DECAL);
-	hipLaunchKernelGGL(k_keys_reduce_copies, dim3((d.max_sort_key + 4) / 4), dim3(256), 0, s, d);
+	if (d.tile_rows != nullptr) hipLaunchKernelGGL(k_keys_reduce_tiles, dim3((d.max_sort_key + 4) / 4), dim3(256), 0, s, d);
+	else hipLaunchKernelGGL(k_keys_reduce_copies, dim3((d.max_sort_key + 4) / 4), dim3(256), 0, s, d);
 	const dim3 scatter_grid(std::max(1u, std::min((d.cap_recs + 255) / 256, grid_cap * 4)));
 	if (d.max_sort_key < (uint32_t)KEYS_SCATTER_OFFSETS) {
 		hipLaunchKernelGGL(k_keys_scatter<true>, scatter_grid, dim3(256), 0, s, d, view);
