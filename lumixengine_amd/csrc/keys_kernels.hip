@@ -575,45 +575,64 @@ __global__ __launch_bounds__(256) void k_keys_reduce_copies(KeysDevice d) {
 	if (lane == 63) d.group_total[k] = carry;
 }
 
-// Tile ranks: one wave per key turns column k of the tiles' table into exclusive prefixes (tile_rows[t][k] = the records of key k in the
-// tiles before t) and total[k]. Lane l owns the tiles [l * chunk, (l + 1) * chunk): its loads are independent of each other (8 in flight),
-// one wave scan joins the lanes' sums, a second walk over the (cached) chunk writes the prefixes.
-__global__ __launch_bounds__(256) void k_keys_reduce_tiles(KeysDevice d) {
+// Tile ranks: the columns of the tiles' table become exclusive prefixes (tile_rows[t][k] = the records of key k in the tiles before t)
+// and total[k] their sums. A block owns 8 adjacent keys; a wave-wide access covers 8 tiles x those 8 keys (lane = 8 * stripe + key: eight
+// 32-byte row segments - a lane per tile of ONE key touched 64 lines per instruction and took 25 us for 2114 tiles x 256 keys); the 16
+// waves split the tiles into contiguous ranges, sum theirs (loads independent, 8 in flight), meet once in LDS, and a second walk over the
+// (cached) range writes the prefixes.
+constexpr int KEYS_RT_WAVES = 16;
+__global__ __launch_bounds__(KEYS_RT_WAVES * 64) void k_keys_reduce_tiles(KeysDevice d) {
+	__shared__ uint32_t s_tot[KEYS_RT_WAVES][8];
 	const uint32_t n = d.max_sort_key + 1;
-	const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6);
-	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t ks = lane & 7u, stripe = lane >> 3;
+	const uint32_t k = blockIdx.x * 8u + ks;
 	if (blockIdx.x == 0 && threadIdx.x < (uint32_t)KEYS_COUNTERS) d.counters_next[threadIdx.x] = 0;
-	if (k >= n) return;
 	const uint32_t n_tiles = d.counters[KEYS_N_TILES];
-	const uint32_t chunk = (n_tiles + 63u) / 64u;
-	const uint32_t t0 = min(lane * chunk, n_tiles), t1 = min(t0 + chunk, n_tiles);
-	uint32_t* col = d.tile_rows + k;
-	uint32_t sum = 0;
-	for (uint32_t t = t0; t < t1; t += 8u) {
+	const uint32_t per_wave = ((n_tiles + KEYS_RT_WAVES * 8u - 1u) / (KEYS_RT_WAVES * 8u)) * 8u; // a multiple of the 8 stripes
+	const uint32_t t0 = min(wave * per_wave, n_tiles), t1 = min(t0 + per_wave, n_tiles);
+	uint32_t* col = d.tile_rows + (k < n ? k : 0u);
+	const bool live = k < n;
+	uint32_t sum = 0; // of this lane's stripe of the wave's range
+	for (uint32_t t = t0 + stripe; t < t1; t += 64u) {
 		uint32_t v[8];
 #pragma unroll
-		for (uint32_t j = 0; j < 8; ++j) v[j] = t + j < t1 ? col[(size_t)(t + j) * n] : 0u;
+		for (uint32_t j = 0; j < 8; ++j) v[j] = live && t + 8u * j < t1 ? col[(size_t)(t + 8u * j) * n] : 0u;
 #pragma unroll
 		for (uint32_t j = 0; j < 8; ++j) sum += v[j];
 	}
-	uint32_t incl = sum;
+	// the wave's total of key ks: over the 8 stripes (lanes ks, ks + 8, ...)
+	uint32_t wave_total = sum;
+	wave_total += (uint32_t)__shfl_xor((int)wave_total, 8);
+	wave_total += (uint32_t)__shfl_xor((int)wave_total, 16);
+	wave_total += (uint32_t)__shfl_xor((int)wave_total, 32);
+	if (stripe == 0) s_tot[wave][ks] = wave_total;
+	__syncthreads();
+	uint32_t run = 0, total = 0; // the tiles before this wave's range; all tiles
 #pragma unroll
-	for (int o = 1; o < 64; o <<= 1) {
-		const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-		if (lane >= (uint32_t)o) incl += up;
+	for (uint32_t w = 0; w < (uint32_t)KEYS_RT_WAVES; ++w) {
+		const uint32_t c = s_tot[w][ks];
+		total += c;
+		if (w < wave) run += c;
 	}
-	uint32_t run = incl - sum;
-	for (uint32_t t = t0; t < t1; t += 8u) {
+	if (wave == 0 && stripe == 0 && live) d.group_total[k] = total;
+	for (uint32_t t = t0; t < t1; t += 64u) { // (wave-uniform bounds: the shuffles below see every lane)
 		uint32_t v[8];
 #pragma unroll
-		for (uint32_t j = 0; j < 8; ++j) v[j] = t + j < t1 ? col[(size_t)(t + j) * n] : 0u;
+		for (uint32_t j = 0; j < 8; ++j) v[j] = live && t + 8u * j + stripe < t1 ? col[(size_t)(t + 8u * j + stripe) * n] : 0u;
 #pragma unroll
-		for (uint32_t j = 0; j < 8; ++j) {
-			if (t + j < t1) col[(size_t)(t + j) * n] = run;
-			run += v[j];
+		for (uint32_t j = 0; j < 8; ++j) { // step j: the 8 tiles t + 8 j .. t + 8 j + 7, one per stripe
+			uint32_t incl = v[j]; // inclusive over the stripes (lanes 8 apart hold the same key)
+			uint32_t up = (uint32_t)__shfl_up((int)incl, 8);
+			if (stripe >= 1u) incl += up;
+			up = (uint32_t)__shfl_up((int)incl, 16);
+			if (stripe >= 2u) incl += up;
+			up = (uint32_t)__shfl_up((int)incl, 32);
+			if (stripe >= 4u) incl += up;
+			if (live && t + 8u * j + stripe < t1) col[(size_t)(t + 8u * j + stripe) * n] = run + incl - v[j];
+			run += (uint32_t)__shfl((int)incl, (int)(56u + ks));
 		}
 	}
-	if (lane == 63) d.group_total[k] = incl;
 }
 
 // one block: offsets[k] = sum of total[0..k), offsets[n] = grand total; non-empty groups counted
@@ -890,7 +909,7 @@ hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice&
 		hipLaunchKernelGGL(k_keys_decal, dim3(std::min((decals.cap + 255) / 256, grid_cap)), dim3(256), 0, s, d, view, decals, d.decal_sort_key, d.decal_layer, (uint32_t)LMX_DRAW_DECAL);
 	if (curves.cap && d.curve_sort_key != nullptr)
 		hipLaunchKernelGGL(k_keys_decal, dim3(std::min((curves.cap + 255) / 256, grid_cap)), dim3(256), 0, s, d, view, curves, d.curve_sort_key, d.curve_layer, (uint32_t)LMX_DRAW_CURVE_DECAL);
-	if (d.tile_rows != nullptr) hipLaunchKernelGGL(k_keys_reduce_tiles, dim3((d.max_sort_key + 4) / 4), dim3(256), 0, s, d);
+	if (d.tile_rows != nullptr) hipLaunchKernelGGL(k_keys_reduce_tiles, dim3((d.max_sort_key + 8) / 8), dim3(KEYS_RT_WAVES * 64), 0, s, d);
 	else hipLaunchKernelGGL(k_keys_reduce_copies, dim3((d.max_sort_key + 4) / 4), dim3(256), 0, s, d);
 	const dim3 scatter_grid(std::max(1u, std::min((d.cap_recs + 255) / 256, grid_cap * 4)));
 	if (d.max_sort_key < (uint32_t)KEYS_SCATTER_OFFSETS) {
