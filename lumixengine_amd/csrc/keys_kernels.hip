@@ -576,23 +576,24 @@ __global__ __launch_bounds__(256) void k_keys_reduce_copies(KeysDevice d) {
 }
 
 // Tile ranks: the columns of the tiles' table become exclusive prefixes (tile_rows[t][k] = the records of key k in the tiles before t)
-// and total[k] their sums. A block owns 8 adjacent keys; a wave-wide access covers 8 tiles x those 8 keys (lane = 8 * stripe + key: eight
+// and total[k] their sums. A block owns 8 adjacent keys; a wave-wide access covers 8 tiles x those 8 keys (lane = 8 * key + stripe: eight
 // 32-byte row segments - a lane per tile of ONE key touched 64 lines per instruction and took 25 us for 2114 tiles x 256 keys); the 16
 // waves split the tiles into contiguous ranges, sum theirs (loads independent, 8 in flight), meet once in LDS, and a second walk over the
-// (cached) range writes the prefixes.
+// (cached) range writes the prefixes: per step a 3-stage DPP scan over the 8 stripes (row_shr 1, 2, 4 - as ds_bpermute shuffles, four
+// dependent ones per step, the kernel took 12 us), the steps of a batch independent of each other until the running sum joins them.
 constexpr int KEYS_RT_WAVES = 16;
 __global__ __launch_bounds__(KEYS_RT_WAVES * 64) void k_keys_reduce_tiles(KeysDevice d) {
 	__shared__ uint32_t s_tot[KEYS_RT_WAVES][8];
 	const uint32_t n = d.max_sort_key + 1;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const uint32_t ks = lane & 7u, stripe = lane >> 3;
+	const uint32_t stripe = lane & 7u, ks = lane >> 3;
 	const uint32_t k = blockIdx.x * 8u + ks;
 	if (blockIdx.x == 0 && threadIdx.x < (uint32_t)KEYS_COUNTERS) d.counters_next[threadIdx.x] = 0;
 	const uint32_t n_tiles = d.counters[KEYS_N_TILES];
 	const uint32_t per_wave = ((n_tiles + KEYS_RT_WAVES * 8u - 1u) / (KEYS_RT_WAVES * 8u)) * 8u; // a multiple of the 8 stripes
 	const uint32_t t0 = min(wave * per_wave, n_tiles), t1 = min(t0 + per_wave, n_tiles);
-	uint32_t* col = d.tile_rows + (k < n ? k : 0u);
 	const bool live = k < n;
+	uint32_t* col = d.tile_rows + (live ? k : 0u);
 	uint32_t sum = 0; // of this lane's stripe of the wave's range
 	for (uint32_t t = t0 + stripe; t < t1; t += 64u) {
 		uint32_t v[8];
@@ -601,11 +602,11 @@ __global__ __launch_bounds__(KEYS_RT_WAVES * 64) void k_keys_reduce_tiles(KeysDe
 #pragma unroll
 		for (uint32_t j = 0; j < 8; ++j) sum += v[j];
 	}
-	// the wave's total of key ks: over the 8 stripes (lanes ks, ks + 8, ...)
+	// the wave's total of key ks: over the 8 stripes (8 adjacent lanes)
 	uint32_t wave_total = sum;
-	wave_total += (uint32_t)__shfl_xor((int)wave_total, 8);
-	wave_total += (uint32_t)__shfl_xor((int)wave_total, 16);
-	wave_total += (uint32_t)__shfl_xor((int)wave_total, 32);
+	wave_total += (uint32_t)__shfl_xor((int)wave_total, 1);
+	wave_total += (uint32_t)__shfl_xor((int)wave_total, 2);
+	wave_total += (uint32_t)__shfl_xor((int)wave_total, 4);
 	if (stripe == 0) s_tot[wave][ks] = wave_total;
 	__syncthreads();
 	uint32_t run = 0, total = 0; // the tiles before this wave's range; all tiles
@@ -616,21 +617,27 @@ __global__ __launch_bounds__(KEYS_RT_WAVES * 64) void k_keys_reduce_tiles(KeysDe
 		if (w < wave) run += c;
 	}
 	if (wave == 0 && stripe == 0 && live) d.group_total[k] = total;
-	for (uint32_t t = t0; t < t1; t += 64u) { // (wave-uniform bounds: the shuffles below see every lane)
-		uint32_t v[8];
+	for (uint32_t t = t0; t < t1; t += 64u) { // (wave-uniform bounds: the cross-lane steps below see every lane)
+		uint32_t v[8], incl[8], step_total[8];
 #pragma unroll
 		for (uint32_t j = 0; j < 8; ++j) v[j] = live && t + 8u * j + stripe < t1 ? col[(size_t)(t + 8u * j + stripe) * n] : 0u;
 #pragma unroll
-		for (uint32_t j = 0; j < 8; ++j) { // step j: the 8 tiles t + 8 j .. t + 8 j + 7, one per stripe
-			uint32_t incl = v[j]; // inclusive over the stripes (lanes 8 apart hold the same key)
-			uint32_t up = (uint32_t)__shfl_up((int)incl, 8);
-			if (stripe >= 1u) incl += up;
-			up = (uint32_t)__shfl_up((int)incl, 16);
-			if (stripe >= 2u) incl += up;
-			up = (uint32_t)__shfl_up((int)incl, 32);
-			if (stripe >= 4u) incl += up;
-			if (live && t + 8u * j + stripe < t1) col[(size_t)(t + 8u * j + stripe) * n] = run + incl - v[j];
-			run += (uint32_t)__shfl((int)incl, (int)(56u + ks));
+		for (uint32_t j = 0; j < 8; ++j) { // step j: the 8 tiles t + 8 j .. t + 8 j + 7, one per stripe; inclusive scan over the stripes
+			uint32_t x = v[j];
+			uint32_t up = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x111, 0xf, 0xf, true); // row_shr:1
+			if (stripe >= 1u) x += up;
+			up = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x112, 0xf, 0xf, true); // row_shr:2
+			if (stripe >= 2u) x += up;
+			up = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x114, 0xf, 0xf, true); // row_shr:4
+			if (stripe >= 4u) x += up;
+			incl[j] = x;
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) step_total[j] = (uint32_t)__shfl((int)incl[j], (int)(lane | 7u));
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) {
+			if (live && t + 8u * j + stripe < t1) col[(size_t)(t + 8u * j + stripe) * n] = run + incl[j] - v[j];
+			run += step_total[j];
 		}
 	}
 }
