@@ -454,10 +454,10 @@ LMX_API int lmx_keys_bind_world(LmxContext* ctx, int enable);
    LMX_KEYS_OPT_WALK_SHARDS (default 1): the key kernels read the visible ids out of the per-shard windows the cull kernels wrote
    (lmx_cull_device_shards); 0: the windows are gathered into one list per type first (two more launches). Results do not depend on it
    (the order of the unsorted pairs / of the renderables inside an instancer group is unspecified either way).
-   LMX_KEYS_OPT_TILE_RANKS (default 1): for max_sort_key < 4096 the auto-instancer's groups are built without global atomics - every
-   512-entity tile of the visible list owns a row of per-key counts and every record carries its rank inside its tile; 0 (and larger
-   key ranges): privatised global counters + one cursor atomic per record. Results do not depend on it. */
-enum { LMX_KEYS_OPT_SLOT_ORDER = 0, LMX_KEYS_OPT_SPLIT_STATE = 1, LMX_KEYS_OPT_WALK_SHARDS = 2, LMX_KEYS_OPT_TILE_RANKS = 3 };
+   LMX_KEYS_OPT_BLOCK_RANKS (default 1): for max_sort_key < 4096 the auto-instancer's groups are built without global atomics - every
+   block of the key kernel owns a row of per-key counts and every record carries its rank inside its block; 0 (and larger key
+   ranges): privatised global counters + one cursor atomic per record. Results do not depend on it. */
+enum { LMX_KEYS_OPT_SLOT_ORDER = 0, LMX_KEYS_OPT_SPLIT_STATE = 1, LMX_KEYS_OPT_WALK_SHARDS = 2, LMX_KEYS_OPT_BLOCK_RANKS = 3 };
 LMX_API int lmx_keys_set_option(LmxContext* ctx, int option, int value);
 /* createSortKeys for (view, frustum) of the last lmx_cull on that slot. max_sort_key = Renderer::getMaxSortKey(). Async. */
 LMX_API int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeysView* kv, uint32_t max_sort_key);

@@ -133,8 +133,8 @@ constexpr int KEYS_STAGE_PAIRS = 3 * KEYS_BLOCK; // pairs (24 KiB) and records (
 #define LMX_KEYS_LDS_HIST 1 // the instancer's group histogram per tile in LDS, one global atomic per (tile, key) instead of one per record
 #endif
 constexpr int KEYS_HIST_LDS = 4096; // keys (16 KiB): larger ranges keep the global atomics
-constexpr int KEYS_TILE_SHIFT = 12;  // tile ranks: rec_key = key (< KEYS_HIST_LDS) | tile << 12
-static_assert((1 << KEYS_TILE_SHIFT) == KEYS_HIST_LDS, "a record's key and tile share 32 bits");
+constexpr int KEYS_ROW_SHIFT = 12;   // block ranks: rec_key = key (< KEYS_HIST_LDS) | k_keys_mesh block << 12
+static_assert((1 << KEYS_ROW_SHIFT) == KEYS_HIST_LDS, "a record's key and row share 32 bits");
 #ifndef LMX_KEYS_MIN_WAVES
 #define LMX_KEYS_MIN_WAVES 4 // waves per SIMD the register allocation aims at: 106 VGPRs, no scratch, two 8-wave blocks per CU. Round 4 (profiles/r04/keys_ab.txt, k_keys_mesh per 1.05 M visible): 6 waves (80 VGPRs, 32-44 B of scratch, three blocks) 65.5-70.5 us, 5 waves 59.1, 4 waves 60.2 - the kernel is not short of waves, spills cost it more
 #endif
@@ -152,12 +152,13 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 	// (profiles/r04/keys_probes2.txt): they are executed memory-side, a few tens of thousands per microsecond over the whole chip.
 	__shared__ uint32_t s_hist[KEYS_HIST_LDS];
 	const bool lds_hist = LMX_KEYS_LDS_HIST != 0 && d.max_sort_key < (uint32_t)KEYS_HIST_LDS; // launch-uniform
-	// TILE RANKS (round 5; the host offers d.tile_rows for key ranges that fit the LDS histogram): a tile's histogram is not added to a
-	// private copy of the group counters but stored as the tile's own row of a table, and every instancer record carries its rank among
-	// the tile's records of its key (what the LDS increment returns). k_keys_reduce_tiles turns the columns into exclusive prefixes and a
-	// record's place in its group is offset + prefix[tile][key] + rank: neither this kernel's ~300 k global histogram adds nor the
-	// scatter's 560 k returning cursor atomics (7 of its 18 us, profiles/r05/keys_scatter_probes.txt) exist any more.
-	const bool tile_ranks = lds_hist && d.tile_rows != nullptr; // launch-uniform
+	// BLOCK RANKS (round 5; the host offers d.block_rows for key ranges that fit the LDS histogram): the histogram stays in LDS over ALL
+	// tiles of the block and leaves once, as the block's own row of a table, and every instancer record carries its rank among the
+	// block's records of its key (what the LDS increment returns). k_keys_reduce_rows turns the columns into exclusive prefixes and a
+	// record's place in its group is offset + prefix[block][key] + rank: neither this kernel's ~300 k global histogram adds nor the
+	// scatter's 560 k returning cursor atomics (7 of its 18 us, profiles/r05/keys_scatter_probes.txt) exist any more. (A row per TILE,
+	// 2114 of them for the headline view, made the column scan a 12-25 us kernel: profiles/r05/keys_rows_per_tile.txt.)
+	const bool block_ranks = lds_hist && d.block_rows != nullptr; // launch-uniform
 	if (lds_hist) {
 		for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) s_hist[k] = 0;
 	}
@@ -165,7 +166,6 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 	ShardWalk walk;
 	walk.load(L, lane, [](uint32_t c) { return (c + (uint32_t)KEYS_BLOCK - 1u) / (uint32_t)KEYS_BLOCK; });
 	const uint32_t n_tiles = walk.total;
-	if (tile_ranks && blockIdx.x == 0 && threadIdx.x == 0) d.counters[KEYS_N_TILES] = n_tiles; // the rows k_keys_reduce_tiles reads
 	__syncthreads(); // s_bucket / s_hist are in
 	const uint32_t copy = blockIdx.x & (d.n_copies - 1); // this block's private row of the group counters
 	// where tile t's ids start and how many it holds
@@ -429,17 +429,17 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 				}
 				// the record's first word: its key and where its counter lives - the tile's row (tile ranks) or the block's private copy
 				uint32_t rec_word = mesh_sort_key | (copy << 24), rank = 0;
-				if (tile_ranks && add_inst) {
-					rec_word = (mesh_sort_key & (uint32_t)(KEYS_HIST_LDS - 1)) | (tile << KEYS_TILE_SHIFT);
-					if (mesh_sort_key <= d.max_sort_key) rank = atomicAdd(&s_hist[mesh_sort_key], 1u); // ds_add_rtn_u32: the record's rank among the tile's records of its key
+				if (block_ranks && add_inst) {
+					rec_word = (mesh_sort_key & (uint32_t)(KEYS_HIST_LDS - 1)) | (blockIdx.x << KEYS_ROW_SHIFT);
+					if (mesh_sort_key <= d.max_sort_key) rank = atomicAdd(&s_hist[mesh_sort_key], 1u); // ds_add_rtn_u32: the record's rank among the block's records of its key
 				}
 				if (stage) {
 					if (!add_inst) { s_pair_key[pair_at] = key; s_pair_value[pair_at] = value; }
-					else { s_rec_key[rec_at] = rec_word; s_rec_value[rec_at] = value; if (tile_ranks) s_rec_rank[rec_at] = rank; }
+					else { s_rec_key[rec_at] = rec_word; s_rec_value[rec_at] = value; if (block_ranks) s_rec_rank[rec_at] = rank; }
 				} else if (!add_inst) {
 					if (pair_at < d.cap_pairs) { d.keys[pair_at] = key; d.values[pair_at] = value; } else d.counters[KEYS_OVERFLOW] = 1;
 				} else {
-					if (rec_at < d.cap_recs) { d.rec_key[rec_at] = rec_word; d.rec_value[rec_at] = value; if (tile_ranks) d.rec_rank[rec_at] = rank; } else d.counters[KEYS_OVERFLOW] = 1;
+					if (rec_at < d.cap_recs) { d.rec_key[rec_at] = rec_word; d.rec_value[rec_at] = value; if (block_ranks) d.rec_rank[rec_at] = rank; } else d.counters[KEYS_OVERFLOW] = 1;
 				}
 				// (plain arithmetic: with `++pair_at` / `++rec_at` in the branches the compiler indexed the two cursors in scratch memory)
 				pair_at += add_inst ? 0u : 1u;
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			// (one atomic per distinct key, ~15 scalar + vector instructions per key: 60 % of this kernel's time at 256 live keys)
 			// is kept for key ranges too large to privatise
 			if (LMX_KEYS_PROBE & 1) { // (timing probe only: no group histogram - the instancer's groups come out wrong)
-			} else if (tile_ranks) { // (counted above, where the rank was taken)
+			} else if (block_ranks) { // (counted above, where the rank was taken)
 			} else if (lds_hist) {
 				if (in_range) atomicAdd(&s_hist[mesh_sort_key], 1u); // ds_add_u32, nothing returned
 			} else if (d.n_copies >= 8) {
@@ -485,12 +485,7 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			if (queue_dirty) { if (dirty0 + dirty_at < d.cap_list) d.dirty_list[dirty0 + dirty_at] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
 			if (push_pose) { if (pose0 + pose_at < d.cap_list) d.poses[pose0 + pose_at] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
 		}
-		if (tile_ranks) { // the tile's histogram is its ROW of the table (plain stores, zeros included: k_keys_reduce_tiles reads whole rows)
-			uint32_t* row = d.tile_rows + (size_t)tile * (d.max_sort_key + 1);
-			for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) {
-				row[k] = s_hist[k];
-				s_hist[k] = 0;
-			}
+		if (block_ranks) { // (the histogram runs on: it leaves behind the block's last tile)
 		} else if (lds_hist && tile_recs != 0) { // (behind the barrier: every lane's LDS increments are in)
 			for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) {
 				const uint32_t c = s_hist[k];
@@ -508,10 +503,14 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			}
 			for (uint32_t j = threadIdx.x; j < tile_recs; j += KEYS_BLOCK) {
 				const uint32_t at = tile_rec0 + j;
-				if (at < d.cap_recs) { d.rec_key[at] = s_rec_key[j]; d.rec_value[at] = s_rec_value[j]; if (tile_ranks) d.rec_rank[at] = s_rec_rank[j]; } else d.counters[KEYS_OVERFLOW] = 1;
+				if (at < d.cap_recs) { d.rec_key[at] = s_rec_key[j]; d.rec_value[at] = s_rec_value[j]; if (block_ranks) d.rec_rank[at] = s_rec_rank[j]; } else d.counters[KEYS_OVERFLOW] = 1;
 			}
 		}
 		__syncthreads(); // s_wave, s_base and the staging buffers are rewritten by the next tile
+	}
+	if (block_ranks) { // the block's histogram is its ROW of the table (plain stores, zeros included: k_keys_reduce_rows reads whole rows)
+		uint32_t* row = d.block_rows + (size_t)blockIdx.x * (d.max_sort_key + 1);
+		for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) row[k] = s_hist[k];
 	}
 }
 
@@ -575,69 +574,62 @@ __global__ __launch_bounds__(256) void k_keys_reduce_copies(KeysDevice d) {
 	if (lane == 63) d.group_total[k] = carry;
 }
 
-// Tile ranks: the columns of the tiles' table become exclusive prefixes (tile_rows[t][k] = the records of key k in the tiles before t)
-// and total[k] their sums. A block owns 8 adjacent keys; a wave-wide access covers 8 tiles x those 8 keys (lane = 8 * key + stripe: eight
-// 32-byte row segments - a lane per tile of ONE key touched 64 lines per instruction and took 25 us for 2114 tiles x 256 keys); the 16
-// waves split the tiles into contiguous ranges, sum theirs (loads independent, 8 in flight), meet once in LDS, and a second walk over the
-// (cached) range writes the prefixes: per step a 3-stage DPP scan over the 8 stripes (row_shr 1, 2, 4 - as ds_bpermute shuffles, four
-// dependent ones per step, the kernel took 12 us), the steps of a batch independent of each other until the running sum joins them.
-constexpr int KEYS_RT_WAVES = 16;
-__global__ __launch_bounds__(KEYS_RT_WAVES * 64) void k_keys_reduce_tiles(KeysDevice d) {
-	__shared__ uint32_t s_tot[KEYS_RT_WAVES][8];
+// Block ranks: the columns of the rows' table become exclusive prefixes (block_rows[b][k] = the records of key k in the rows before b)
+// and total[k] their sums. A block owns 8 adjacent keys; a wave-wide access covers 8 rows x those 8 keys (lane = 8 * stripe + key: eight
+// 32-byte row segments; adjacent lanes on adjacent keys - with adjacent lanes on adjacent ROWS the same kernel was a third slower, with a
+// lane per row of ONE key twice); the 16 waves split the rows into contiguous ranges, sum theirs (loads independent, 8 in flight), meet
+// once in LDS, and a second walk over the (cached) range writes the prefixes.
+constexpr int KEYS_RR_WAVES = 16;
+__global__ __launch_bounds__(KEYS_RR_WAVES * 64) void k_keys_reduce_rows(KeysDevice d) {
+	__shared__ uint32_t s_tot[KEYS_RR_WAVES][8];
 	const uint32_t n = d.max_sort_key + 1;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const uint32_t stripe = lane & 7u, ks = lane >> 3;
+	const uint32_t ks = lane & 7u, stripe = lane >> 3;
 	const uint32_t k = blockIdx.x * 8u + ks;
 	if (blockIdx.x == 0 && threadIdx.x < (uint32_t)KEYS_COUNTERS) d.counters_next[threadIdx.x] = 0;
-	const uint32_t n_tiles = d.counters[KEYS_N_TILES];
-	const uint32_t per_wave = ((n_tiles + KEYS_RT_WAVES * 8u - 1u) / (KEYS_RT_WAVES * 8u)) * 8u; // a multiple of the 8 stripes
-	const uint32_t t0 = min(wave * per_wave, n_tiles), t1 = min(t0 + per_wave, n_tiles);
+	const uint32_t n_rows = d.n_rows;
+	const uint32_t per_wave = ((n_rows + KEYS_RR_WAVES * 8u - 1u) / (KEYS_RR_WAVES * 8u)) * 8u; // a multiple of the 8 stripes
+	const uint32_t r0 = min(wave * per_wave, n_rows), r1 = min(r0 + per_wave, n_rows);
 	const bool live = k < n;
-	uint32_t* col = d.tile_rows + (live ? k : 0u);
+	uint32_t* col = d.block_rows + (live ? k : 0u);
 	uint32_t sum = 0; // of this lane's stripe of the wave's range
-	for (uint32_t t = t0 + stripe; t < t1; t += 64u) {
+	for (uint32_t r = r0 + stripe; r < r1; r += 64u) {
 		uint32_t v[8];
 #pragma unroll
-		for (uint32_t j = 0; j < 8; ++j) v[j] = live && t + 8u * j < t1 ? col[(size_t)(t + 8u * j) * n] : 0u;
+		for (uint32_t j = 0; j < 8; ++j) v[j] = live && r + 8u * j < r1 ? col[(size_t)(r + 8u * j) * n] : 0u;
 #pragma unroll
 		for (uint32_t j = 0; j < 8; ++j) sum += v[j];
 	}
-	// the wave's total of key ks: over the 8 stripes (8 adjacent lanes)
+	// the wave's total of key ks: over the 8 stripes (lanes ks, ks + 8, ...)
 	uint32_t wave_total = sum;
-	wave_total += (uint32_t)__shfl_xor((int)wave_total, 1);
-	wave_total += (uint32_t)__shfl_xor((int)wave_total, 2);
-	wave_total += (uint32_t)__shfl_xor((int)wave_total, 4);
+	wave_total += (uint32_t)__shfl_xor((int)wave_total, 8);
+	wave_total += (uint32_t)__shfl_xor((int)wave_total, 16);
+	wave_total += (uint32_t)__shfl_xor((int)wave_total, 32);
 	if (stripe == 0) s_tot[wave][ks] = wave_total;
 	__syncthreads();
-	uint32_t run = 0, total = 0; // the tiles before this wave's range; all tiles
+	uint32_t run = 0, total = 0; // the rows before this wave's range; all rows
 #pragma unroll
-	for (uint32_t w = 0; w < (uint32_t)KEYS_RT_WAVES; ++w) {
+	for (uint32_t w = 0; w < (uint32_t)KEYS_RR_WAVES; ++w) {
 		const uint32_t c = s_tot[w][ks];
 		total += c;
 		if (w < wave) run += c;
 	}
 	if (wave == 0 && stripe == 0 && live) d.group_total[k] = total;
-	for (uint32_t t = t0; t < t1; t += 64u) { // (wave-uniform bounds: the cross-lane steps below see every lane)
-		uint32_t v[8], incl[8], step_total[8];
+	for (uint32_t r = r0; r < r1; r += 64u) { // (wave-uniform bounds: the shuffles below see every lane)
+		uint32_t v[8];
 #pragma unroll
-		for (uint32_t j = 0; j < 8; ++j) v[j] = live && t + 8u * j + stripe < t1 ? col[(size_t)(t + 8u * j + stripe) * n] : 0u;
+		for (uint32_t j = 0; j < 8; ++j) v[j] = live && r + 8u * j + stripe < r1 ? col[(size_t)(r + 8u * j + stripe) * n] : 0u;
 #pragma unroll
-		for (uint32_t j = 0; j < 8; ++j) { // step j: the 8 tiles t + 8 j .. t + 8 j + 7, one per stripe; inclusive scan over the stripes
-			uint32_t x = v[j];
-			uint32_t up = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x111, 0xf, 0xf, true); // row_shr:1
-			if (stripe >= 1u) x += up;
-			up = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x112, 0xf, 0xf, true); // row_shr:2
-			if (stripe >= 2u) x += up;
-			up = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x114, 0xf, 0xf, true); // row_shr:4
-			if (stripe >= 4u) x += up;
-			incl[j] = x;
-		}
-#pragma unroll
-		for (uint32_t j = 0; j < 8; ++j) step_total[j] = (uint32_t)__shfl((int)incl[j], (int)(lane | 7u));
-#pragma unroll
-		for (uint32_t j = 0; j < 8; ++j) {
-			if (live && t + 8u * j + stripe < t1) col[(size_t)(t + 8u * j + stripe) * n] = run + incl[j] - v[j];
-			run += step_total[j];
+		for (uint32_t j = 0; j < 8; ++j) { // step j: the 8 rows r + 8 j .. r + 8 j + 7, one per stripe
+			uint32_t incl = v[j]; // inclusive over the stripes (lanes 8 apart hold the same key)
+			uint32_t up = (uint32_t)__shfl_up((int)incl, 8);
+			if (stripe >= 1u) incl += up;
+			up = (uint32_t)__shfl_up((int)incl, 16);
+			if (stripe >= 2u) incl += up;
+			up = (uint32_t)__shfl_up((int)incl, 32);
+			if (stripe >= 4u) incl += up;
+			if (live && r + 8u * j + stripe < r1) col[(size_t)(r + 8u * j + stripe) * n] = run + incl - v[j];
+			run += (uint32_t)__shfl((int)incl, (int)(56u + ks));
 		}
 	}
 }
@@ -690,12 +682,12 @@ template <bool OWN_OFFSETS> __global__ __launch_bounds__(256) void k_keys_scatte
 	// A block has about one tile and a tile is a chain of dependent round trips (the ISA waited for every load where it was issued:
 	// record key -> cursor atomic -> base -> record value -> store, behind the number of records): the tile's two record loads are issued
 	// FIRST, bounded by the capacity instead of the count, next to the count's and the offsets' loads; base and cursor go out together.
-	const bool tile_ranks = d.tile_rows != nullptr; // launch-uniform
+	const bool block_ranks = d.block_rows != nullptr; // launch-uniform
 	uint32_t packed_next = 0, rank_next = 0;
 	uint64_t value_next = 0;
 	{
 		const uint32_t i0 = blockIdx.x * 256u + threadIdx.x;
-		if (i0 < d.cap_recs) { packed_next = d.rec_key[i0]; value_next = d.rec_value[i0]; if (tile_ranks) rank_next = d.rec_rank[i0]; }
+		if (i0 < d.cap_recs) { packed_next = d.rec_key[i0]; value_next = d.rec_value[i0]; if (block_ranks) rank_next = d.rec_rank[i0]; }
 	}
 	const uint32_t n = min(d.counters[KEYS_N_RECS], d.cap_recs);
 	const uint32_t stride = d.max_sort_key + 1;
@@ -731,20 +723,20 @@ template <bool OWN_OFFSETS> __global__ __launch_bounds__(256) void k_keys_scatte
 	auto offset_of = [&](uint32_t key) { return OWN_OFFSETS ? s_off[key] : d.group_offset[key]; };
 	for (uint32_t tile = blockIdx.x * 256; tile < n; tile += gridDim.x * 256) {
 		const uint32_t i = tile + threadIdx.x;
-		const uint32_t packed = i < n ? packed_next : 0; // mesh sort key | copy << 24, or (tile ranks) | tile << 12
+		const uint32_t packed = i < n ? packed_next : 0; // mesh sort key | copy << 24, or (block ranks) | row << 12
 		const uint64_t renderable = value_next;
 		const uint32_t rank_next_now = rank_next;
 		{
 			const uint32_t i1 = i + gridDim.x * 256u;
-			if (i1 < n) { packed_next = d.rec_key[i1]; value_next = d.rec_value[i1]; if (tile_ranks) rank_next = d.rec_rank[i1]; }
+			if (i1 < n) { packed_next = d.rec_key[i1]; value_next = d.rec_value[i1]; if (block_ranks) rank_next = d.rec_rank[i1]; }
 		}
-		const uint32_t key = tile_ranks ? packed & (uint32_t)(KEYS_HIST_LDS - 1) : packed & 0xffffffu;
+		const uint32_t key = block_ranks ? packed & (uint32_t)(KEYS_HIST_LDS - 1) : packed & 0xffffffu;
 		const bool has = i < n && key <= d.max_sort_key;
-		const size_t at = tile_ranks ? (size_t)(packed >> KEYS_TILE_SHIFT) * stride + key : (size_t)(packed >> 24) * stride + key;
+		const size_t at = block_ranks ? (size_t)(packed >> KEYS_ROW_SHIFT) * stride + key : (size_t)(packed >> 24) * stride + key;
 		uint32_t in_group = 0; // the record's position inside its group
-		if (tile_ranks) { // no atomics: the records of key k in the tiles before this record's + its rank inside its tile
+		if (block_ranks) { // no atomics: the records of key k in the rows before this record's + its rank inside its row
 			const uint32_t rank = rank_next_now;
-			if (has) in_group = d.tile_rows[at] + rank;
+			if (has) in_group = d.block_rows[at] + rank;
 		} else if (d.n_copies >= 8) { // privatised cursors: one returning atomic per lane, all in flight together
 			if (has) {
 				const uint32_t base = d.group_base[at];
@@ -904,19 +896,25 @@ hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint3
 	return hipGetLastError();
 }
 
-hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const KeysShardList& meshes, const KeysShardList& decals, const KeysShardList& curves) {
+hipError_t launch_keys(hipStream_t s, const KeysDevice& d_in, const KeysViewDevice& view, const KeysShardList& meshes, const KeysShardList& decals, const KeysShardList& curves) {
+	KeysDevice d = d_in;
 	const uint32_t grid_cap = 256 * 8; // fixed-size grids walk the lists in tiles: the counts live on the device
 #ifndef LMX_KEYS_MESH_GRID
 #define LMX_KEYS_MESH_GRID 512 // k_keys_mesh: as many blocks as are resident (2 per CU: LDS), each walking ~4 tiles of the headline view - the next tile's first loads run under the current tile and a block's set-up is paid once. k_keys_mesh per 1.05 M visible (profiles/r05/keys_ab_grid.txt): 512 blocks 44.1 us, 768 49.4, 1024 45.2, 1536 46.1, 2048 48.5
 #endif
 	if (meshes.n > (uint32_t)KEYS_MAX_SHARDS || decals.n > (uint32_t)KEYS_MAX_SHARDS || curves.n > (uint32_t)KEYS_MAX_SHARDS) return hipErrorInvalidValue;
-	if (meshes.cap && d.inst != nullptr)
-		hipLaunchKernelGGL(k_keys_mesh, dim3(std::min((meshes.cap + KEYS_BLOCK - 1) / KEYS_BLOCK + meshes.n, (uint32_t)LMX_KEYS_MESH_GRID)), dim3(KEYS_BLOCK), 0, s, d, view, meshes);
+	d.n_rows = 0;
+	if (meshes.cap && d.inst != nullptr) {
+		const uint32_t grid = std::min((meshes.cap + KEYS_BLOCK - 1) / KEYS_BLOCK + meshes.n, (uint32_t)LMX_KEYS_MESH_GRID);
+		if (d.block_rows != nullptr && grid > d.cap_rows) return hipErrorInvalidValue;
+		d.n_rows = grid; // block ranks: one row of the table per block of this launch
+		hipLaunchKernelGGL(k_keys_mesh, dim3(grid), dim3(KEYS_BLOCK), 0, s, d, view, meshes);
+	}
 	if (decals.cap && d.decal_sort_key != nullptr)
 		hipLaunchKernelGGL(k_keys_decal, dim3(std::min((decals.cap + 255) / 256, grid_cap)), dim3(256), 0, s, d, view, decals, d.decal_sort_key, d.decal_layer, (uint32_t)LMX_DRAW_DECAL);
 	if (curves.cap && d.curve_sort_key != nullptr)
 		hipLaunchKernelGGL(k_keys_decal, dim3(std::min((curves.cap + 255) / 256, grid_cap)), dim3(256), 0, s, d, view, curves, d.curve_sort_key, d.curve_layer, (uint32_t)LMX_DRAW_CURVE_DECAL);
-	if (d.tile_rows != nullptr) hipLaunchKernelGGL(k_keys_reduce_tiles, dim3((d.max_sort_key + 8) / 8), dim3(KEYS_RT_WAVES * 64), 0, s, d);
+	if (d.block_rows != nullptr) hipLaunchKernelGGL(k_keys_reduce_rows, dim3((d.max_sort_key + 8) / 8), dim3(KEYS_RR_WAVES * 64), 0, s, d);
 	else hipLaunchKernelGGL(k_keys_reduce_copies, dim3((d.max_sort_key + 4) / 4), dim3(256), 0, s, d);
 	const dim3 scatter_grid(std::max(1u, std::min((d.cap_recs + 255) / 256, grid_cap * 4)));
 	if (d.max_sort_key < (uint32_t)KEYS_SCATTER_OFFSETS) {

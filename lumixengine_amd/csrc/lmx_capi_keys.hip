@@ -231,8 +231,8 @@ int lmx_keys_set_option(LmxContext* ctx, int option, int value) {
 		ks.walk_shards = value != 0;
 		return LMX_OK;
 	}
-	if (option == LMX_KEYS_OPT_TILE_RANKS) {
-		ks.tile_ranks = value != 0;
+	if (option == LMX_KEYS_OPT_BLOCK_RANKS) {
+		ks.block_ranks = value != 0;
 		return LMX_OK;
 	}
 	if (option != LMX_KEYS_OPT_SLOT_ORDER) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "unknown sort-key option %d", option);
@@ -306,12 +306,12 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 		ks.run_parity = 0;
 	}
 	ks.groups_clean = false; // until this run's launches are enqueued
-	// tile ranks: a row of per-key counts for every 512-entity tile the view can have (one partial tile per shard window on top), for key
-	// ranges that fit the key kernel's LDS histogram and tables of up to 8 M entries; otherwise the private copies above do the counting
-	const size_t tiles_cap = (mesh_cap + 511) / 512 + KEYS_MAX_SHARDS;
-	const bool tile_ranks = ks.tile_ranks && ks.have_instances && mesh_cap != 0 && max_sort_key < 4096 && tiles_cap < (1u << 20) && tiles_cap * g <= ((size_t)8 << 20);
-	if (tile_ranks) {
-		LMX_HIP(ctx, ks.d_tile_rows.reserve(tiles_cap * g));
+	// block ranks: a row of per-key counts for every block of k_keys_mesh (a fixed-size grid), for key ranges that fit the key kernel's
+	// LDS histogram; otherwise the private copies above do the counting
+	const size_t rows_cap = 4096; // >= the key kernel's grid (launch_keys checks)
+	const bool block_ranks = ks.block_ranks && ks.have_instances && mesh_cap != 0 && max_sort_key < 4096;
+	if (block_ranks) {
+		LMX_HIP(ctx, ks.d_block_rows.reserve(rows_cap * g));
 		LMX_HIP(ctx, ks.d_rec_rank.reserve(std::max<size_t>(cap_recs, 1)));
 	}
 	LMX_HIP(ctx, ks.d_poses.reserve(std::max<size_t>(mesh_cap, 1)));
@@ -369,8 +369,9 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	d.group_base = ks.d_groups.p + 2 * gc + 2 * KEYS_COUNTERS; d.group_total = d.group_base + n_copies * g; d.group_offset = d.group_total + g;
 	ks.offsets_at = 2 * gc + 2 * KEYS_COUNTERS + n_copies * g + g;
 	d.group_values = ks.d_group_values.p;
-	d.tile_rows = tile_ranks ? ks.d_tile_rows.p : nullptr;
-	d.rec_rank = tile_ranks ? ks.d_rec_rank.p : nullptr;
+	d.block_rows = block_ranks ? ks.d_block_rows.p : nullptr;
+	d.cap_rows = (uint32_t)rows_cap;
+	d.rec_rank = block_ranks ? ks.d_rec_rank.p : nullptr;
 	d.poses = ks.d_poses.p; d.dirty_list = ks.d_dirty_list.p; d.cap_list = mesh_cap;
 	d.counters = ks.d_groups.p + ks.counters_at;
 	d.counters_next = ks.d_groups.p + 2 * gc + (parity ^ 1u) * KEYS_COUNTERS;

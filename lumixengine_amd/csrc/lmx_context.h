@@ -413,8 +413,8 @@ struct KeysState {
 	uint32_t groups_copies = 0;
 	size_t groups_keys = 0;
 	bool walk_shards = true; // lmx_keys_set_option(LMX_KEYS_OPT_WALK_SHARDS)
-	bool tile_ranks = true;  // lmx_keys_set_option(LMX_KEYS_OPT_TILE_RANKS)
-	DevBuf<uint32_t> d_tile_rows, d_rec_rank;
+	bool block_ranks = true; // lmx_keys_set_option(LMX_KEYS_OPT_BLOCK_RANKS)
+	DevBuf<uint32_t> d_block_rows, d_rec_rank;
 	bool have_instances = false, have_decals = false, have_curves = false, use_world = false, ran = false, sorted = false;
 	DevBuf<LmxKeysModel> d_models;
 	DevBuf<uint8_t> d_mesh_types;

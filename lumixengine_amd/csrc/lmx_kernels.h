@@ -222,7 +222,7 @@ hipError_t launch_anim_blend_stack(hipStream_t s, const SkinInstance* inst, uint
 // Counter words. {pairs, recs} and {poses, dirty} are two 64-bit cells on their own 128-byte lines: k_keys_mesh reserves a tile's four
 // output ranges with two returning atomics on two lines instead of four on one (measured: no change of the kernel's 124 us per
 // million visible entities - it is bound by its random 64-byte gathers and line write-backs, see DESIGN.md - but half the atomics).
-enum { KEYS_N_PAIRS = 0, KEYS_N_RECS = 1, KEYS_N_POSES = 32, KEYS_N_DIRTY = 33, KEYS_OVERFLOW = 64, KEYS_N_GROUPS = 96, KEYS_N_TILES = 97, KEYS_COUNTERS = 128 };
+enum { KEYS_N_PAIRS = 0, KEYS_N_RECS = 1, KEYS_N_POSES = 32, KEYS_N_DIRTY = 33, KEYS_OVERFLOW = 64, KEYS_N_GROUPS = 96, KEYS_COUNTERS = 128 };
 struct KeysViewDevice { // what the kernels read of a LmxKeysView, bucket_map as built at pipeline.cpp:3802-3812
 	uint32_t bucket_map[255];
 	uint8_t layer_to_bucket[255];
@@ -293,10 +293,11 @@ struct KeysDevice {
 	uint32_t *group_total;      // [max_sort_key + 1]
 	uint32_t *group_offset;     // [max_sort_key + 2]
 	uint64_t* group_values;
-	// tile ranks (key ranges that fit k_keys_mesh's LDS histogram; nullptr: the private copies above): every 512-entity tile owns a row
-	// [max_sort_key + 1] of per-key counts, turned into exclusive prefixes over the tiles by k_keys_reduce_tiles; a record carries its
-	// rank among its tile's records of its key (rec_rank) and its tile in bits 12..31 of rec_key
-	uint32_t* tile_rows;
+	// block ranks (key ranges that fit k_keys_mesh's LDS histogram; nullptr: the private copies above): every block of k_keys_mesh owns
+	// a row [max_sort_key + 1] of per-key counts, turned into exclusive prefixes over the rows by k_keys_reduce_rows; a record carries
+	// its rank among its block's records of its key (rec_rank) and its row in bits 12..31 of rec_key
+	uint32_t* block_rows;
+	uint32_t cap_rows, n_rows; // rows allocated; rows of this run (= k_keys_mesh's grid: set by launch_keys)
 	uint32_t* rec_rank;
 	int32_t *poses, *dirty_list;
 	uint32_t cap_list;

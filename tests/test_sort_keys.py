@@ -194,13 +194,13 @@ def test_gpu_sort_keys_match_committed_fixture(gpu_ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("walk_shards,tile_ranks", [(1, 1), (0, 1), (1, 0)])
+@pytest.mark.parametrize("walk_shards,block_ranks", [(1, 1), (0, 1), (1, 0)])
 @pytest.mark.parametrize("vi", range(len(VIEWS)))
-def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi, walk_shards, tile_ranks):
+def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi, walk_shards, block_ranks):
     """cull -> createSortKeys on the device, three consecutive frames (LOD / pose-frame state carried on the device; the instancer's two
     counter tables, which take turns from run to run and are zeroed by the run before, have each been used and reused by then).
     walk_shards 1: the key kernels read the visible ids out of the cull's per-shard windows, 0: out of one gathered list per type.
-    tile_ranks 1: the instancer's groups from per-tile count rows + per-record ranks (no global atomics), 0: privatised global counters."""
+    block_ranks 1: the instancer's groups from per-tile count rows + per-record ranks (no global atomics), 0: privatised global counters."""
     oracle_port = live_oracle
     base = scenes.cull_scene(60_000, 2500.0, seed=31, big_fraction=0.002)
     n = len(base["entity"])
@@ -217,7 +217,7 @@ def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi, walk_shards, tile_
     sk.setDecals(n, sc["decal_key"], sc["decal_layer"], sc["curve_key"], sc["curve_layer"])
     sk.setPositions(pos)
     sk.setOption(api.KEYS_OPT_WALK_SHARDS, walk_shards)
-    sk.setOption(api.KEYS_OPT_TILE_RANKS, tile_ranks)
+    sk.setOption(api.KEYS_OPT_BLOCK_RANKS, block_ranks)
     lod, pose_frame = sc["lod"], sc["pose_frame"]
     for frame in range(3):
         if frame >= 1:
@@ -249,7 +249,7 @@ def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi, walk_shards, tile_
         assert np.all(skeys[1:] >= skeys[:-1])
         assert sorted(zip(map(int, skeys), map(int, svalues))) == exp["pairs"]
     sk.setOption(api.KEYS_OPT_WALK_SHARDS, 1)  # (the context is the session's)
-    sk.setOption(api.KEYS_OPT_TILE_RANKS, 1)
+    sk.setOption(api.KEYS_OPT_BLOCK_RANKS, 1)
 
 
 @pytest.mark.gpu

@@ -48,7 +48,7 @@ def main():
         kid = api.KERNEL_NAMES.index("sort_keys")
         for walk, ranks in ((1, 1), (1, 0), (0, 0), (1, 1)):
             sk.setOption(api.KEYS_OPT_WALK_SHARDS, walk)
-            sk.setOption(api.KEYS_OPT_TILE_RANKS, ranks)
+            sk.setOption(api.KEYS_OPT_BLOCK_RANKS, ranks)
             spans = []
             for rep in range(3):
                 for f in range(3):
@@ -62,7 +62,7 @@ def main():
                 ctx.synchronize()
                 ctx.profile_enable(False)
                 spans.append(ctx.profile_get(kid)[0] / 5 * 1e3)
-            print(f"createSortKeys span, walk_shards {walk} tile_ranks {ranks}: " + " ".join(f"{x:.1f}" for x in spans) + " us", sk.counts())
+            print(f"createSortKeys span, walk_shards {walk} block_ranks {ranks}: " + " ".join(f"{x:.1f}" for x in spans) + " us", sk.counts())
     elif args.workload.startswith("cull"):
         half = 5000.0 if args.workload == "cull_dense" else 15000.0 * (args.entities / 1e7) ** (1.0 / 3.0)
         sc = scenes.cull_scene(args.entities, half, seed=2, mixed_types=args.workload == "cull8")
