@@ -896,12 +896,14 @@ hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint3
 	return hipGetLastError();
 }
 
-hipError_t launch_keys(hipStream_t s, const KeysDevice& d_in, const KeysViewDevice& view, const KeysShardList& meshes, const KeysShardList& decals, const KeysShardList& curves) {
-	KeysDevice d = d_in;
-	const uint32_t grid_cap = 256 * 8; // fixed-size grids walk the lists in tiles: the counts live on the device
 #ifndef LMX_KEYS_MESH_GRID
 #define LMX_KEYS_MESH_GRID 512 // k_keys_mesh: as many blocks as are resident (2 per CU: LDS), each walking ~4 tiles of the headline view - the next tile's first loads run under the current tile and a block's set-up is paid once. k_keys_mesh per 1.05 M visible (profiles/r05/keys_ab_grid.txt): 512 blocks 44.1 us, 768 49.4, 1024 45.2, 1536 46.1, 2048 48.5
 #endif
+uint32_t keys_mesh_grid_cap() { return (uint32_t)LMX_KEYS_MESH_GRID; }
+
+hipError_t launch_keys(hipStream_t s, const KeysDevice& d_in, const KeysViewDevice& view, const KeysShardList& meshes, const KeysShardList& decals, const KeysShardList& curves) {
+	KeysDevice d = d_in;
+	const uint32_t grid_cap = 256 * 8; // fixed-size grids walk the lists in tiles: the counts live on the device
 	if (meshes.n > (uint32_t)KEYS_MAX_SHARDS || decals.n > (uint32_t)KEYS_MAX_SHARDS || curves.n > (uint32_t)KEYS_MAX_SHARDS) return hipErrorInvalidValue;
 	d.n_rows = 0;
 	if (meshes.cap && d.inst != nullptr) {

@@ -304,11 +304,12 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 		LMX_HIP(ctx, hipMemsetAsync(ks.d_groups.p, 0, (2 * gc + 2 * KEYS_COUNTERS) * sizeof(uint32_t), ctx->stream));
 		ks.groups_at = ks.d_groups.p; ks.groups_copies = n_copies; ks.groups_keys = g;
 		ks.run_parity = 0;
+		ks.table_parity = 0;
 	}
 	ks.groups_clean = false; // until this run's launches are enqueued
 	// block ranks: a row of per-key counts for every block of k_keys_mesh (a fixed-size grid), for key ranges that fit the key kernel's
 	// LDS histogram; otherwise the private copies above do the counting
-	const size_t rows_cap = 4096; // >= the key kernel's grid (launch_keys checks)
+	const size_t rows_cap = keys_mesh_grid_cap();
 	const bool block_ranks = ks.block_ranks && ks.have_instances && mesh_cap != 0 && max_sort_key < 4096;
 	if (block_ranks) {
 		LMX_HIP(ctx, ks.d_block_rows.reserve(rows_cap * g));
@@ -365,7 +366,10 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	d.rec_key = ks.d_rec_key.p; d.rec_value = ks.d_rec_value.p; d.cap_recs = (uint32_t)cap_recs;
 	d.max_sort_key = max_sort_key;
 	d.n_copies = n_copies;
-	d.group_count = ks.d_groups.p + parity * gc; d.group_count_next = ks.d_groups.p + (parity ^ 1u) * gc;
+	// (the counter TABLES only change hands on runs that use them: a block-ranks run in between leaves both as they are - with one
+	// parity for tables and list counters such a run handed the next one the table that still held the previous scatter's cursors)
+	const uint32_t table = ks.table_parity;
+	d.group_count = ks.d_groups.p + table * gc; d.group_count_next = ks.d_groups.p + (table ^ 1u) * gc;
 	d.group_base = ks.d_groups.p + 2 * gc + 2 * KEYS_COUNTERS; d.group_total = d.group_base + n_copies * g; d.group_offset = d.group_total + g;
 	ks.offsets_at = 2 * gc + 2 * KEYS_COUNTERS + n_copies * g + g;
 	d.group_values = ks.d_group_values.p;
@@ -420,6 +424,7 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	LMX_HIP(ctx, launch_keys(ctx->stream, d, hv, lists[0], lists[1], lists[2]));
 	ks.groups_clean = true;
 	ks.run_parity = parity ^ 1u;
+	if (!block_ranks) ks.table_parity = table ^ 1u;
 	ks.max_sort_key = max_sort_key;
 	ks.ran = true;
 	ks.sorted = false;

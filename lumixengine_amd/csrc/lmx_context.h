@@ -407,7 +407,7 @@ struct KeysState {
 	size_t counters_at = 0; // ... and the list counters of the last run (KEYS_COUNTERS words)
 	// the instancer's counter tables and the list counters take turns from run to run (lmx_keys_run): which of the two this run uses, and
 	// the layout the pair was last zeroed for
-	uint32_t run_parity = 0;
+	uint32_t run_parity = 0, table_parity = 0;
 	bool groups_clean = false;
 	const uint32_t* groups_at = nullptr;
 	uint32_t groups_copies = 0;

@@ -324,6 +324,7 @@ hipError_t launch_keys_mirror_sync(hipStream_t s, const int32_t* slot_ids, uint3
 	KeysInstance* inst, uint32_t n_entities);
 hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint32_t n, const int32_t* slot_ids, uint32_t n_slots, const KeysInstance* inst_s, const int32_t* model_s,
 	const KeysSlotState* state_s, KeysInstance* inst, uint32_t n_entities);
+uint32_t keys_mesh_grid_cap(); // the largest grid of k_keys_mesh = the rows a block-ranks table needs
 hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const KeysShardList& meshes, const KeysShardList& decals, const KeysShardList& curves);
 
 // Pose::computeAbsolute + computeSkinMatrices (+ optional dual-quaternion palette), one wave per PoseGroup

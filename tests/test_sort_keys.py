@@ -193,14 +193,23 @@ def test_gpu_sort_keys_match_committed_fixture(gpu_ctx):
     assert H.bits_equal(lod, g["lod"]) and np.array_equal(frame, g["pose_frame"])
 
 
+MODES = {  # (walk_shards, block_ranks) per frame
+    "shards+ranks": [(1, 1)] * 3,
+    "gathered+ranks": [(0, 1)] * 3,
+    "shards+copies": [(1, 0)] * 3,
+    # the two forms of the instancer take turns: the counter tables of the private copies only change hands on the runs that use them
+    "interleaved": [(1, 0), (1, 1), (1, 0), (0, 0), (1, 1), (1, 1), (1, 0)],
+}
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("walk_shards,block_ranks", [(1, 1), (0, 1), (1, 0)])
+@pytest.mark.parametrize("modes", list(MODES))
 @pytest.mark.parametrize("vi", range(len(VIEWS)))
-def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi, walk_shards, block_ranks):
-    """cull -> createSortKeys on the device, three consecutive frames (LOD / pose-frame state carried on the device; the instancer's two
-    counter tables, which take turns from run to run and are zeroed by the run before, have each been used and reused by then).
+def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi, modes):
+    """cull -> createSortKeys on the device, three or more consecutive frames (LOD / pose-frame state carried on the device; the instancer's
+    two counter tables, which take turns from run to run and are zeroed by the run before, have each been used and reused by then).
     walk_shards 1: the key kernels read the visible ids out of the cull's per-shard windows, 0: out of one gathered list per type.
-    block_ranks 1: the instancer's groups from per-tile count rows + per-record ranks (no global atomics), 0: privatised global counters."""
+    block_ranks 1: the instancer's groups from per-block count rows + per-record ranks (no global atomics), 0: privatised global counters."""
     oracle_port = live_oracle
     base = scenes.cull_scene(60_000, 2500.0, seed=31, big_fraction=0.002)
     n = len(base["entity"])
@@ -216,10 +225,10 @@ def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi, walk_shards, block
     sk.setInstances(sc["model"], sc["material_offset"], sc["mesh_materials"], sc["lod"], sc["flags"], sc["dirty"], sc["pose_frame"])
     sk.setDecals(n, sc["decal_key"], sc["decal_layer"], sc["curve_key"], sc["curve_layer"])
     sk.setPositions(pos)
-    sk.setOption(api.KEYS_OPT_WALK_SHARDS, walk_shards)
-    sk.setOption(api.KEYS_OPT_BLOCK_RANKS, block_ranks)
     lod, pose_frame = sc["lod"], sc["pose_frame"]
-    for frame in range(3):
+    for frame, (walk_shards, block_ranks) in enumerate(MODES[modes]):
+        sk.setOption(api.KEYS_OPT_WALK_SHARDS, walk_shards)
+        sk.setOption(api.KEYS_OPT_BLOCK_RANKS, block_ranks)
         if frame >= 1:
             sk.setPositions(pos)  # per-frame position refresh: ModelInstance::lod / Pose::frame must keep the state of frame 0
         view = dict(VIEWS[vi])
