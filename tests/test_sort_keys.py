@@ -461,3 +461,14 @@ def test_gpu_sort_keys_read_world_positions(gpu_ctx, oracle_port):
     exp = canon(want["keys"], want["values"], want["group_offsets"], want["group_values"], want["poses"], want["dirty"])
     assert got == exp
     sk.bindWorld(False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_sort_keys_fuzz(gpu_ctx, live_oracle, seed):
+    """tests/fuzz_keys.py: random scenes, key ranges on both sides of every threshold of the device path, views, 3-6 frames with the device
+    options drawn anew per frame and removals / moves / re-adds / re-sorts of the culling system in between, against both CPU checkers."""
+    from tests import fuzz_keys
+
+    st = fuzz_keys.run(seed, live_oracle, ctx=gpu_ctx)
+    assert st["frames"] >= 3 and st["pairs"] > 0

@@ -23,12 +23,14 @@ if [ "$WHAT" = counters ] || [ "$WHAT" = all ]; then
 	pmc cull8_all_test_write WRITE_SIZE -- $W --workload cull8_all_test --steps 4
 	sq cull8_all_test
 	pmc cull8_all_test_mfma SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS -- $W --workload cull8_all_test --steps 4
+	pmc keys_fetch FETCH_SIZE -- $W --workload keys --steps 4
+	pmc keys_write WRITE_SIZE -- $W --workload keys --steps 4
 	pmc_summary
 fi
 if [ "$WHAT" = suite ] || [ "$WHAT" = all ]; then
 	timeout 2400 python -m pytest tests -m gpu -q > "$OUT/gpu_suite.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/gpu_suite.log"; tail -n 4 "$OUT/gpu_suite.log"
 	timeout 300 python -c "import __graft_entry__ as g; g.smoke()" >> "$OUT/gpu_suite.log" 2>&1; echo "smoke rc=$?" | tee -a "$OUT/gpu_suite.log"
-	(S=$(date +%s); timeout 300 python -m tests.fuzz_cull --seeds 30-69 --steps 300; echo "fuzz_cull rc=$? seconds=$(( $(date +%s) - S ))"; timeout 150 python -m tests.fuzz_skin --seeds 20-39; echo "fuzz_skin rc=$?"; timeout 150 python -m tests.fuzz_world --seeds 20-39; echo "fuzz_world rc=$?") > "$OUT/fuzz_on_gpu.log" 2>&1
+	(S=$(date +%s); timeout 300 python -m tests.fuzz_cull --seeds 30-69 --steps 300; echo "fuzz_cull rc=$? seconds=$(( $(date +%s) - S ))"; timeout 150 python -m tests.fuzz_skin --seeds 20-39; echo "fuzz_skin rc=$?"; timeout 150 python -m tests.fuzz_world --seeds 20-39; echo "fuzz_world rc=$?"; timeout 300 python -m tests.fuzz_keys --seeds 6-65 --oracle reference; echo "fuzz_keys rc=$?") > "$OUT/fuzz_on_gpu.log" 2>&1
 	grep -E "rc=" "$OUT/fuzz_on_gpu.log"
 	./tools/_build/mfma_contract_probe > "$OUT/mfma_contract_probe.txt" 2>&1; ./tools/_build/mfma_overlap_probe > "$OUT/mfma_overlap_probe.txt" 2>&1
 fi
