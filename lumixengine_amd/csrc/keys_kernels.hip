@@ -918,7 +918,10 @@ hipError_t launch_keys(hipStream_t s, const KeysDevice& d_in, const KeysViewDevi
 		hipLaunchKernelGGL(k_keys_decal, dim3(std::min((curves.cap + 255) / 256, grid_cap)), dim3(256), 0, s, d, view, curves, d.curve_sort_key, d.curve_layer, (uint32_t)LMX_DRAW_CURVE_DECAL);
 	if (d.block_rows != nullptr) hipLaunchKernelGGL(k_keys_reduce_rows, dim3((d.max_sort_key + 8) / 8), dim3(KEYS_RR_WAVES * 64), 0, s, d);
 	else hipLaunchKernelGGL(k_keys_reduce_copies, dim3((d.max_sort_key + 4) / 4), dim3(256), 0, s, d);
-	const dim3 scatter_grid(std::max(1u, std::min((d.cap_recs + 255) / 256, grid_cap * 4)));
+#ifndef LMX_KEYS_SCATTER_GRID
+#define LMX_KEYS_SCATTER_GRID (256 * 32)
+#endif
+	const dim3 scatter_grid(std::max(1u, std::min((d.cap_recs + 255) / 256, (uint32_t)LMX_KEYS_SCATTER_GRID)));
 	if (d.max_sort_key < (uint32_t)KEYS_SCATTER_OFFSETS) {
 		hipLaunchKernelGGL(k_keys_scatter<true>, scatter_grid, dim3(256), 0, s, d, view);
 	} else {
