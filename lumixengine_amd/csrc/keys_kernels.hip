@@ -919,7 +919,7 @@ hipError_t launch_keys(hipStream_t s, const KeysDevice& d_in, const KeysViewDevi
 	if (d.block_rows != nullptr) hipLaunchKernelGGL(k_keys_reduce_rows, dim3((d.max_sort_key + 8) / 8), dim3(KEYS_RR_WAVES * 64), 0, s, d);
 	else hipLaunchKernelGGL(k_keys_reduce_copies, dim3((d.max_sort_key + 4) / 4), dim3(256), 0, s, d);
 #ifndef LMX_KEYS_SCATTER_GRID
-#define LMX_KEYS_SCATTER_GRID (256 * 32)
+#define LMX_KEYS_SCATTER_GRID 2048 // the capacity of the record list is a multiple of the list (every mesh of two LODs of every entity of the type): with 8192 blocks most of them only fetched the first tile's records - issued before the count is known - to find nothing to do. Span of the chain (profiles/r05/keys_scatter_grid.txt): 8192 blocks 68.5 us, 4096 65.8, 2048 65.3, 1024 65.8
 #endif
 	const dim3 scatter_grid(std::max(1u, std::min((d.cap_recs + 255) / 256, (uint32_t)LMX_KEYS_SCATTER_GRID)));
 	if (d.max_sort_key < (uint32_t)KEYS_SCATTER_OFFSETS) {
