@@ -472,3 +472,57 @@ def test_sort_keys_fuzz(gpu_ctx, live_oracle, seed):
 
     st = fuzz_keys.run(seed, live_oracle, ctx=gpu_ctx)
     assert st["frames"] >= 3 and st["pairs"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block_ranks", [1, 0])
+def test_gpu_sort_keys_full_size_scene(gpu_ctx, oracle_port, block_ranks):
+    """1.5 M entities, ~1 M of them visible MESH entities: every one of the key kernel's 512 blocks walks several tiles (block ranks: the LDS
+    histogram and the ranks run over all of them), the cull leaves the ids in all 64 shard windows of the type, the scatter's blocks loop.
+    Pairs, groups, pose / dirty lists and the carried state against the oracle, two frames. (Compared through numpy sorts: the lists
+    hold millions of entries.)"""
+    import os
+
+    if os.environ.get("LMX_HOSTSIM") == "1":
+        pytest.skip("millions of entities: hours on the simulated device (the same paths run there at 60 k entities)")
+    base = scenes.cull_scene(1_500_000, 2500.0, seed=37, big_fraction=0.001)
+    n = len(base["entity"])
+    types = make_types(n, 8)
+    pos = base["pos"]
+    sc = scenes.keys_scene(n, types, seed=59, n_models=9, max_sort_key=255)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(base["entity"], types, pos, base["radius"])
+    fr = api.viewport_frustum(pos=(0.0, 0.0, 2600.0), far=6000.0)
+    sk = api.SortKeys(gpu_ctx)
+    sk.setModels(sc["models"], sc["mesh_types"])
+    sk.setInstances(sc["model"], sc["material_offset"], sc["mesh_materials"], sc["lod"], sc["flags"], sc["dirty"], sc["pose_frame"])
+    sk.setDecals(n, sc["decal_key"], sc["decal_layer"], sc["curve_key"], sc["curve_layer"])
+    sk.setPositions(pos)
+    sk.setOption(api.KEYS_OPT_BLOCK_RANKS, block_ranks)
+    try:
+        lod, pose_frame = sc["lod"], sc["pose_frame"]
+        for frame in range(2):
+            view = dict(camera_pos=(0.0, 0.0, 2600.0), time_delta=1 / 60, frame_number=7 + frame)
+            kv = api.keys_view(layer_to_bucket=sc["layer_to_bucket"], bucket_depth_sorted=sc["bucket_depth_sorted"], **view)
+            res = cs.cull(fr)
+            ids = {t: res.ids(0, t) for t in (0, 1, 3)}
+            assert len(ids[0]) > 600_000, len(ids[0])
+            sk.run(kv, 255)
+            cnt = sk.counts()
+            assert cnt["overflow"] == 0
+            want = oracle_port.create_sort_keys(kv, 255, ids[0], ids[1], ids[3], sc, pos, lod=lod, pose_frame=pose_frame)
+            keys, values = sk.readPairs()
+            assert len(keys) == len(want["keys"]) == cnt["pairs"]
+            o_got, o_exp = np.lexsort((values, keys)), np.lexsort((want["values"], want["keys"]))
+            assert np.array_equal(keys[o_got], want["keys"][o_exp]) and np.array_equal(values[o_got], want["values"][o_exp]), f"frame {frame}: pairs"
+            offsets, gvalues = sk.readInstancer()
+            assert np.array_equal(offsets, want["group_offsets"]) and cnt["instanced"] == len(want["group_values"]) > 300_000 and cnt["groups"] == want["groups"]
+            group_of = np.repeat(np.arange(len(offsets) - 1), np.diff(offsets))
+            wvalues = np.asarray(want["group_values"], np.uint64)
+            assert np.array_equal(gvalues[np.lexsort((gvalues, group_of))], wvalues[np.lexsort((wvalues, group_of))]), f"frame {frame}: groups"
+            assert np.array_equal(np.sort(sk.readPoses()), np.sort(want["poses"])) and np.array_equal(np.sort(sk.readDirty()), np.sort(want["dirty"]))
+            lod, pose_frame = want["lod"], want["pose_frame"]
+        glod, gframe = sk.readState()
+        assert H.bits_equal(glod, lod) and H.bits_equal(gframe, pose_frame)
+    finally:
+        sk.setOption(api.KEYS_OPT_BLOCK_RANKS, 1)
