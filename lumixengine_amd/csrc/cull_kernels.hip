@@ -107,12 +107,11 @@ __device__ __forceinline__ uint32_t tile_status_lanes(const TileBox* box, uint32
 // verdicts come out of two ballots. ~110 instructions for one wave instead of ~300 uniform ones per frustum for every wave: with the
 // per-frustum loop a launch of the 8-cascade pass spent most of its instructions here. Returns 2 status bits per frustum; *flags = the
 // tile's flags.
-__device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, uint32_t lane, int nf, uint32_t* flags_out, uint64_t* skip_out) {
+__device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, uint32_t lane, int nf, uint32_t* flags_out) {
 	const float* ka = (const float*)__builtin_amdgcn_kernarg_segment_ptr();
 	const int32_t* bi = reinterpret_cast<const int32_t*>(box);
 	const uint32_t flags = (uint32_t)bi[6];
 	*flags_out = flags;
-	*skip_out = 0; // bit 6 f + k: every cell of the tile passes plane k of frustum f in both per-cell tests (lmx_math.h: tile_plane_skip_mask)
 	if (flags & TILE_EMPTY) return 0u; // TILE_REJECT == 0 for every frustum
 	uint32_t all_mixed = 0;
 	for (int f = 0; f < nf; ++f) all_mixed |= (uint32_t)TILE_MIXED << (2 * f);
@@ -143,13 +142,6 @@ __device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, 
 		in = dp > -d + margin;
 	}
 	const uint64_t rej_mask = __ballot(plane_lane && rej), out_mask = __ballot(plane_lane && !in);
-#if LMX_CULL_TILE_PLANE_MASK
-	{ // (round 5) the same bound as the 1-frustum kernels', per (frustum, plane) lane: phase A of a MIXED frustum walks the remaining planes only
-		const float bx = nx < 0.0f ? chx : lx, by = ny < 0.0f ? chy : ly, bz = nz < 0.0f ? chz : lz;
-		const float dp = (nx * bx) + (ny * by) + (nz * bz);
-		*skip_out = __ballot(plane_lane && dp > -d + margin);
-	}
-#endif
 	uint32_t st_bits = 0;
 	for (int g = 0; g < nf; ++g) {
 		const uint32_t r = (uint32_t)(rej_mask >> (6 * g)) & 63u, o = (uint32_t)(out_mask >> (6 * g)) & 63u;
@@ -288,7 +280,6 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 
 	// 0. tile-level test per frustum (2 bits each). Everything read here sits at addresses that depend on blockIdx only.
 	uint32_t st_bits = 0, tile_flags = 0, plane_skip = 0;
-	uint64_t plane_skip48 = 0; // (several frusta) 6 bits per frustum
 	bool any_mixed = false, any_live = false;
 	if constexpr (LANEPAR != 0) {
 		static_assert(F == 1, "the lane-parallel tile test handles one frustum");
@@ -315,22 +306,18 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 		any_live = st_bits != TILE_REJECT;
 	} else {
 		// several frusta: wave 0 evaluates every (frustum, plane) pair on its own lane and hands the verdicts to the other waves
-		__shared__ uint32_t s_verdict_multi[4];
+		__shared__ uint32_t s_verdict_multi[2];
 		if (wave == 0) {
 			uint32_t fl;
-			uint64_t sk;
-			const uint32_t v = tile_status_lanes_multi(g_tile_box + tile_index, lane, nf, &fl, &sk);
+			const uint32_t v = tile_status_lanes_multi(g_tile_box + tile_index, lane, nf, &fl);
 			if (lane == 0) {
 				s_verdict_multi[0] = v;
 				s_verdict_multi[1] = fl;
-				s_verdict_multi[2] = (uint32_t)sk;
-				s_verdict_multi[3] = (uint32_t)(sk >> 32);
 			}
 		}
 		__syncthreads();
 		st_bits = __builtin_amdgcn_readfirstlane(s_verdict_multi[0]);
 		tile_flags = __builtin_amdgcn_readfirstlane(s_verdict_multi[1]);
-		plane_skip48 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(s_verdict_multi[2]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(s_verdict_multi[3]) << 32);
 		static_assert(TILE_REJECT == 0 && TILE_ACCEPT == 1 && TILE_MIXED == 2, "the verdicts of all frusta are read off the 2-bit fields by bit logic");
 		any_mixed = ((st_bits >> 1) & ~st_bits & 0x5555u) != 0; // (frusta >= nf hold TILE_REJECT)
 		any_live = st_bits != 0;
@@ -364,7 +351,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 			for (int k = 0; k < 6; ++k) ci.d[k] = 0.f;
 			if (!dead) {
 				V3 off;
-				ci.cls = classify_cell(frp[f], IV3{key.ix, key.iy, key.iz}, big, &off, F == 1 ? plane_skip : (uint32_t)(plane_skip48 >> (6 * f)) & 63u);
+				ci.cls = classify_cell(frp[f], IV3{key.ix, key.iy, key.iz}, big, &off, F == 1 ? plane_skip : 0u);
 				if (ci.cls == CELL_TEST) {
 					if constexpr (F != 1) {
 						// relative_plane_d for two planes at a time (the frustum's arrays hold planes k, k + 1 side by side: packed operands out of the
