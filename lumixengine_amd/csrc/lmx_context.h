@@ -414,7 +414,9 @@ struct KeysState {
 	size_t groups_keys = 0;
 	bool walk_shards = true; // lmx_keys_set_option(LMX_KEYS_OPT_WALK_SHARDS)
 	bool block_ranks = true; // lmx_keys_set_option(LMX_KEYS_OPT_BLOCK_RANKS)
-	DevBuf<uint32_t> d_block_rows, d_rec_rank;
+	DevBuf<uint32_t> d_block_rows, d_rec_rank, d_total_pad;
+	size_t pad_keys = 0;
+	uint32_t pad_parity = 0;
 	bool have_instances = false, have_decals = false, have_curves = false, use_world = false, ran = false, sorted = false;
 	DevBuf<LmxKeysModel> d_models;
 	DevBuf<uint8_t> d_mesh_types;

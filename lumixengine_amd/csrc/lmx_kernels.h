@@ -294,10 +294,14 @@ struct KeysDevice {
 	uint32_t *group_offset;     // [max_sort_key + 2]
 	uint64_t* group_values;
 	// block ranks (key ranges that fit k_keys_mesh's LDS histogram; nullptr: the private copies above): every block of k_keys_mesh owns
-	// a row [max_sort_key + 1] of per-key counts, turned into exclusive prefixes over the rows by k_keys_reduce_rows; a record carries
-	// its rank among its block's records of its key (rec_rank) and its row in bits 12..31 of rec_key
+	// a row [max_sort_key + 1]: per key the records of the blocks that finished before it; a record carries its rank among its block's
+	// records of its key (rec_rank) and its row in bits 12..31 of rec_key
 	uint32_t* block_rows;
-	uint32_t cap_rows, n_rows; // rows allocated; rows of this run (= k_keys_mesh's grid: set by launch_keys)
+	// ... one counter per key on a cache line of its own: a block adds its row's counts at its end, what the add returns is the row's entry
+	// (the records of the key in the blocks before), the counters end up as the groups' sizes. total_pad_next: the next run's, zeroed by
+	// this run's last kernel.
+	uint32_t *total_pad, *total_pad_next;
+	uint32_t cap_rows; // rows allocated (>= k_keys_mesh's grid: launch_keys checks)
 	uint32_t* rec_rank;
 	int32_t *poses, *dirty_list;
 	uint32_t cap_list;
@@ -308,6 +312,7 @@ struct KeysDevice {
 // counts[s * cnt_pad] ids at ids + win_base[s] (and their static-set slots at slots + win_base[s]). The key kernels walk the windows
 // themselves: gathering them into one list first (k_cull_finalize + k_cull_consolidate) was 14 of the chain's 94 us. win_base == nullptr:
 // one contiguous list (n == 1, counts -> its length) - what a type with more than KEYS_MAX_SHARDS shards falls back to.
+constexpr int KEYS_PAD_WORDS = 32; // a padded per-key counter: one 128-byte line
 constexpr int KEYS_MAX_SHARDS = 128; // the layout builder gives a type <= 64 shards for the sorted set + <= 8 for the dynamic one
 struct KeysShardList {
 	const int32_t* ids;
