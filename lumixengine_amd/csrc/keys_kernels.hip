@@ -11,7 +11,7 @@
 //   k_keys_scatter   instancer records -> CSR values; the lane that places a group's FIRST value also pushes the group's
 //                    AUTOINSTANCED pair (:3958-3968)
 // The visible ids are read where the cull kernels left them (KeysShardList: one window per output shard); no fill, no gather and
-// no single-purpose launch in the chain: TWO launches for key ranges up to 1024 (k_keys_mesh, k_keys_scatter), three up to 4096, four beyond (round 4: 8).
+// no single-purpose launch in the chain: TWO launches for key ranges up to 1024 (k_keys_mesh, k_keys_scatter), four beyond (round 4: 8).
 // Integer work is bit-exact by construction; the two fp64 -> fp32 distances use the reference's operation order.
 #include "lmx_kernels.h"
 
@@ -510,14 +510,18 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		__syncthreads(); // s_wave, s_base and the staging buffers are rewritten by the next tile
 	}
 	if (block_ranks) { // the block's histogram becomes its ROW of the table ...
-		// ... and its entries are the records of key k in the blocks that got there before: what a returning add on the key's counter hands
+		// ... and (key ranges up to KEYS_SCATTER_OFFSETS) its entries are the records of key k in the blocks that got there before: what a returning add on the key's counter hands
 		// back (one counter per 128-byte line: a block's adds go out together, 512 blocks x the keys they saw, at the very end of the
 		// kernel - k_keys_mesh 44.2 -> 44.3 us; the column scan this replaces, k_keys_reduce_rows, was a launch of 5.4 us between two gaps:
 		// chain 65.3 -> 61.5 us, profiles/r05/keys_row_prefix_by_atomics.txt). The counters end up as the groups' sizes.
 		uint32_t* row = d.block_rows + (size_t)blockIdx.x * (d.max_sort_key + 1);
-		for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) {
-			const uint32_t c = s_hist[k];
-			row[k] = c != 0 ? atomicAdd(d.total_pad + (size_t)k * KEYS_PAD_WORDS, c) : 0u;
+		if (d.total_pad != nullptr) {
+			for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) {
+				const uint32_t c = s_hist[k];
+				row[k] = c != 0 ? atomicAdd(d.total_pad + (size_t)k * KEYS_PAD_WORDS, c) : 0u;
+			}
+		} else { // larger key ranges: the counts themselves (zeros included), k_keys_reduce_rows scans the columns
+			for (uint32_t k = threadIdx.x; k <= d.max_sort_key; k += KEYS_BLOCK) row[k] = s_hist[k];
 		}
 	}
 }
@@ -582,6 +586,68 @@ __global__ __launch_bounds__(256) void k_keys_reduce_copies(KeysDevice d) {
 	if (lane == 63) d.group_total[k] = carry;
 }
 
+// Block ranks, key ranges beyond KEYS_SCATTER_OFFSETS (up to there the blocks of k_keys_mesh fetch their rows' entries with returning adds;
+// with thousands of live keys per block that is a million atomics at the kernel's end - 4096 random keys: chain 84 us with this kernel,
+// 94 us with the adds): the columns of the rows' table become exclusive prefixes (block_rows[b][k] = the records of key k in the rows
+// before b) and total[k] their sums. A block owns 8 adjacent keys; a wave-wide access covers 8 rows x those 8 keys (lane = 8 * stripe + key: eight
+// 32-byte row segments; adjacent lanes on adjacent keys - with adjacent lanes on adjacent ROWS the same kernel was a third slower, with a
+// lane per row of ONE key twice); the 16 waves split the rows into contiguous ranges, sum theirs (loads independent, 8 in flight), meet
+// once in LDS, and a second walk over the (cached) range writes the prefixes.
+constexpr int KEYS_RR_WAVES = 16;
+__global__ __launch_bounds__(KEYS_RR_WAVES * 64) void k_keys_reduce_rows(KeysDevice d) {
+	__shared__ uint32_t s_tot[KEYS_RR_WAVES][8];
+	const uint32_t n = d.max_sort_key + 1;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t ks = lane & 7u, stripe = lane >> 3;
+	const uint32_t k = blockIdx.x * 8u + ks;
+	if (blockIdx.x == 0 && threadIdx.x < (uint32_t)KEYS_COUNTERS) d.counters_next[threadIdx.x] = 0;
+	const uint32_t n_rows = d.n_rows;
+	const uint32_t per_wave = ((n_rows + KEYS_RR_WAVES * 8u - 1u) / (KEYS_RR_WAVES * 8u)) * 8u; // a multiple of the 8 stripes
+	const uint32_t r0 = min(wave * per_wave, n_rows), r1 = min(r0 + per_wave, n_rows);
+	const bool live = k < n;
+	uint32_t* col = d.block_rows + (live ? k : 0u);
+	uint32_t sum = 0; // of this lane's stripe of the wave's range
+	for (uint32_t r = r0 + stripe; r < r1; r += 64u) {
+		uint32_t v[8];
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) v[j] = live && r + 8u * j < r1 ? col[(size_t)(r + 8u * j) * n] : 0u;
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) sum += v[j];
+	}
+	// the wave's total of key ks: over the 8 stripes (lanes ks, ks + 8, ...)
+	uint32_t wave_total = sum;
+	wave_total += (uint32_t)__shfl_xor((int)wave_total, 8);
+	wave_total += (uint32_t)__shfl_xor((int)wave_total, 16);
+	wave_total += (uint32_t)__shfl_xor((int)wave_total, 32);
+	if (stripe == 0) s_tot[wave][ks] = wave_total;
+	__syncthreads();
+	uint32_t run = 0, total = 0; // the rows before this wave's range; all rows
+#pragma unroll
+	for (uint32_t w = 0; w < (uint32_t)KEYS_RR_WAVES; ++w) {
+		const uint32_t c = s_tot[w][ks];
+		total += c;
+		if (w < wave) run += c;
+	}
+	if (wave == 0 && stripe == 0 && live) d.group_total[k] = total;
+	for (uint32_t r = r0; r < r1; r += 64u) { // (wave-uniform bounds: the shuffles below see every lane)
+		uint32_t v[8];
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) v[j] = live && r + 8u * j + stripe < r1 ? col[(size_t)(r + 8u * j + stripe) * n] : 0u;
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) { // step j: the 8 rows r + 8 j .. r + 8 j + 7, one per stripe
+			uint32_t incl = v[j]; // inclusive over the stripes (lanes 8 apart hold the same key)
+			uint32_t up = (uint32_t)__shfl_up((int)incl, 8);
+			if (stripe >= 1u) incl += up;
+			up = (uint32_t)__shfl_up((int)incl, 16);
+			if (stripe >= 2u) incl += up;
+			up = (uint32_t)__shfl_up((int)incl, 32);
+			if (stripe >= 4u) incl += up;
+			if (live && r + 8u * j + stripe < r1) col[(size_t)(r + 8u * j + stripe) * n] = run + incl - v[j];
+			run += (uint32_t)__shfl((int)incl, (int)(56u + ks));
+		}
+	}
+}
+
 // one block: offsets[k] = sum of total[0..k), offsets[n] = grand total; non-empty groups counted
 __global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
 	__shared__ uint32_t s_wave[16];
@@ -593,9 +659,8 @@ __global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
 	uint32_t non_empty = 0;
 	for (uint32_t base = 0; base < n; base += 1024) {
 		const uint32_t k = base + tid;
-		const uint32_t c = k < n ? (d.total_pad != nullptr ? d.total_pad[(size_t)k * KEYS_PAD_WORDS] : d.group_total[k]) : 0;
+		const uint32_t c = k < n ? d.group_total[k] : 0;
 		non_empty += c != 0;
-		if (d.total_pad != nullptr && k < n) d.total_pad_next[(size_t)k * KEYS_PAD_WORDS] = 0; // block ranks: no k_keys_reduce_copies ran - the next run's counters are zeroed here
 		uint32_t incl = c; // inclusive scan inside the wave
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1) {
@@ -612,7 +677,6 @@ __global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
 		__syncthreads();
 	}
 	if (tid == 0) d.group_offset[n] = s_carry;
-	if (d.total_pad != nullptr && tid < (uint32_t)KEYS_COUNTERS) d.counters_next[tid] = 0;
 	uint32_t total = non_empty;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) total += (uint32_t)__shfl_down((int)total, o);
@@ -625,7 +689,6 @@ __global__ __launch_bounds__(1024) void k_keys_offsets(KeysDevice d) {
 // OWN_OFFSETS (key ranges up to KEYS_SCATTER_OFFSETS): every block forms the exclusive scan of the group sizes itself, in LDS - 1 to 4
 // loads per thread and one block-wide scan, issued next to the tile's first loads - and block 0 also writes it out (group_offset, the
 // number of non-empty groups): k_keys_offsets, a single-block launch of ~5 us between two launch gaps, leaves the chain.
-constexpr int KEYS_SCATTER_OFFSETS = 1024;
 template <bool OWN_OFFSETS> __global__ __launch_bounds__(256) void k_keys_scatter(KeysDevice d, const KeysViewDevice kv) {
 	__shared__ uint32_t s_off[OWN_OFFSETS ? KEYS_SCATTER_OFFSETS : 1];
 	__shared__ uint32_t s_wave_sum[4];
@@ -858,19 +921,23 @@ hipError_t launch_keys_mirror_carry(hipStream_t s, const PatchId* patches, uint3
 #endif
 uint32_t keys_mesh_grid_cap() { return (uint32_t)LMX_KEYS_MESH_GRID; }
 
-hipError_t launch_keys(hipStream_t s, const KeysDevice& d, const KeysViewDevice& view, const KeysShardList& meshes, const KeysShardList& decals, const KeysShardList& curves) {
+hipError_t launch_keys(hipStream_t s, const KeysDevice& d_in, const KeysViewDevice& view, const KeysShardList& meshes, const KeysShardList& decals, const KeysShardList& curves) {
+	KeysDevice d = d_in;
+	d.n_rows = 0;
 	const uint32_t grid_cap = 256 * 8; // fixed-size grids walk the lists in tiles: the counts live on the device
 	if (meshes.n > (uint32_t)KEYS_MAX_SHARDS || decals.n > (uint32_t)KEYS_MAX_SHARDS || curves.n > (uint32_t)KEYS_MAX_SHARDS) return hipErrorInvalidValue;
 	if (meshes.cap && d.inst != nullptr) {
 		const uint32_t grid = std::min((meshes.cap + KEYS_BLOCK - 1) / KEYS_BLOCK + meshes.n, (uint32_t)LMX_KEYS_MESH_GRID);
 		if (d.block_rows != nullptr && grid > d.cap_rows) return hipErrorInvalidValue;
+		d.n_rows = grid; // block ranks: one row of the table per block of this launch
 		hipLaunchKernelGGL(k_keys_mesh, dim3(grid), dim3(KEYS_BLOCK), 0, s, d, view, meshes);
 	}
 	if (decals.cap && d.decal_sort_key != nullptr)
 		hipLaunchKernelGGL(k_keys_decal, dim3(std::min((decals.cap + 255) / 256, grid_cap)), dim3(256), 0, s, d, view, decals, d.decal_sort_key, d.decal_layer, (uint32_t)LMX_DRAW_DECAL);
 	if (curves.cap && d.curve_sort_key != nullptr)
 		hipLaunchKernelGGL(k_keys_decal, dim3(std::min((curves.cap + 255) / 256, grid_cap)), dim3(256), 0, s, d, view, curves, d.curve_sort_key, d.curve_layer, (uint32_t)LMX_DRAW_CURVE_DECAL);
-	if (d.block_rows == nullptr) hipLaunchKernelGGL(k_keys_reduce_copies, dim3((d.max_sort_key + 4) / 4), dim3(256), 0, s, d); // (block ranks: the rows' prefixes came out of the key kernel's own adds)
+	if (d.block_rows == nullptr) hipLaunchKernelGGL(k_keys_reduce_copies, dim3((d.max_sort_key + 4) / 4), dim3(256), 0, s, d);
+	else if (d.total_pad == nullptr) hipLaunchKernelGGL(k_keys_reduce_rows, dim3((d.max_sort_key + 8) / 8), dim3(KEYS_RR_WAVES * 64), 0, s, d); // (with the padded counters the rows' entries came out of the key kernel's own adds)
 #ifndef LMX_KEYS_SCATTER_GRID
 #define LMX_KEYS_SCATTER_GRID 2048 // the capacity of the record list is a multiple of the list (every mesh of two LODs of every entity of the type): with 8192 blocks most of them only fetched the first tile's records - issued before the count is known - to find nothing to do. Span of the chain (profiles/r05/keys_scatter_grid.txt): 8192 blocks 68.5 us, 4096 65.8, 2048 65.3, 1024 65.8
 #endif

@@ -311,7 +311,8 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	// LDS histogram; otherwise the private copies above do the counting
 	const size_t rows_cap = keys_mesh_grid_cap();
 	const bool block_ranks = ks.block_ranks && ks.have_instances && mesh_cap != 0 && max_sort_key < 4096;
-	if (block_ranks) { // one counter per key, a cache line each, two sets taking turns (a run's last kernel zeroes the next run's)
+	const bool row_adds = block_ranks && max_sort_key < (uint32_t)KEYS_SCATTER_OFFSETS;
+	if (row_adds) { // one counter per key, a cache line each, two sets taking turns (a run's last kernel zeroes the next run's)
 		const uint32_t* before = ks.d_total_pad.p;
 		LMX_HIP(ctx, ks.d_total_pad.reserve(2 * g * KEYS_PAD_WORDS));
 		if (before != ks.d_total_pad.p || ks.pad_keys != g) {
@@ -385,8 +386,8 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	d.block_rows = block_ranks ? ks.d_block_rows.p : nullptr;
 	d.cap_rows = (uint32_t)rows_cap;
 	d.rec_rank = block_ranks ? ks.d_rec_rank.p : nullptr;
-	d.total_pad = block_ranks ? ks.d_total_pad.p + (size_t)ks.pad_parity * g * KEYS_PAD_WORDS : nullptr;
-	d.total_pad_next = block_ranks ? ks.d_total_pad.p + (size_t)(ks.pad_parity ^ 1u) * g * KEYS_PAD_WORDS : nullptr;
+	d.total_pad = row_adds ? ks.d_total_pad.p + (size_t)ks.pad_parity * g * KEYS_PAD_WORDS : nullptr;
+	d.total_pad_next = row_adds ? ks.d_total_pad.p + (size_t)(ks.pad_parity ^ 1u) * g * KEYS_PAD_WORDS : nullptr;
 	d.poses = ks.d_poses.p; d.dirty_list = ks.d_dirty_list.p; d.cap_list = mesh_cap;
 	d.counters = ks.d_groups.p + ks.counters_at;
 	d.counters_next = ks.d_groups.p + 2 * gc + (parity ^ 1u) * KEYS_COUNTERS;
@@ -436,7 +437,7 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	ks.groups_clean = true;
 	ks.run_parity = parity ^ 1u;
 	if (!block_ranks) ks.table_parity = table ^ 1u;
-	if (block_ranks) ks.pad_parity ^= 1u;
+	if (row_adds) ks.pad_parity ^= 1u;
 	ks.max_sort_key = max_sort_key;
 	ks.ran = true;
 	ks.sorted = false;

@@ -297,11 +297,11 @@ struct KeysDevice {
 	// a row [max_sort_key + 1]: per key the records of the blocks that finished before it; a record carries its rank among its block's
 	// records of its key (rec_rank) and its row in bits 12..31 of rec_key
 	uint32_t* block_rows;
-	// ... one counter per key on a cache line of its own: a block adds its row's counts at its end, what the add returns is the row's entry
-	// (the records of the key in the blocks before), the counters end up as the groups' sizes. total_pad_next: the next run's, zeroed by
-	// this run's last kernel.
+	// ... (key ranges up to 1024; nullptr beyond: k_keys_reduce_rows scans the columns) one counter per key on a cache line of its own: a
+	// block adds its row's counts at its end, what the add returns is the row's entry (the records of the key in the blocks before),
+	// the counters end up as the groups' sizes. total_pad_next: the next run's, zeroed by this run's last kernel.
 	uint32_t *total_pad, *total_pad_next;
-	uint32_t cap_rows; // rows allocated (>= k_keys_mesh's grid: launch_keys checks)
+	uint32_t cap_rows, n_rows; // rows allocated; rows of this run (= k_keys_mesh's grid: set by launch_keys)
 	uint32_t* rec_rank;
 	int32_t *poses, *dirty_list;
 	uint32_t cap_list;
@@ -313,6 +313,7 @@ struct KeysDevice {
 // themselves: gathering them into one list first (k_cull_finalize + k_cull_consolidate) was 14 of the chain's 94 us. win_base == nullptr:
 // one contiguous list (n == 1, counts -> its length) - what a type with more than KEYS_MAX_SHARDS shards falls back to.
 constexpr int KEYS_PAD_WORDS = 32; // a padded per-key counter: one 128-byte line
+constexpr int KEYS_SCATTER_OFFSETS = 1024; // key ranges up to here: k_keys_scatter forms the group offsets itself and (block ranks) the rows' entries come out of returning adds
 constexpr int KEYS_MAX_SHARDS = 128; // the layout builder gives a type <= 64 shards for the sorted set + <= 8 for the dynamic one
 struct KeysShardList {
 	const int32_t* ids;

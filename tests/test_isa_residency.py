@@ -85,7 +85,7 @@ def test_skin_and_pose_register_budgets(tmp_path):
 
 
 def test_keys_and_xform_do_not_spill(tmp_path):
-    for source, tags in (("keys_kernels.hip", ["k_keys_mesh", "k_keys_scatter"]), ("xform_kernels.hip", ["k_xform_level", "k_sphere_refresh"])):
+    for source, tags in (("keys_kernels.hip", ["k_keys_mesh", "k_keys_scatter", "k_keys_reduce_rows"]), ("xform_kernels.hip", ["k_xform_level", "k_sphere_refresh"])):
         meta = metadata(source, tmp_path)
         for tag in tags:
             for k in pick(meta, tag):

@@ -17,7 +17,7 @@ def short(name):
 
     for k in ("k_cull_tile", "k_cull_finalize", "k_cull_consolidate", "k_apply_patches", "k_cull_fused", "k_cull_spheres", "k_cull_classify", "k_cull_dynamic", "k_xform_level", "k_xform_scatter", "k_xform_export", "k_sphere_refresh",
               "k_pose_palette", "k_skin_vertices", "k_skin_shared", "k_patch_spheres", "k_keys_mesh", "k_keys_decal", "k_keys_offsets", "k_keys_scatter",
-              "k_keys_reduce_copies", "k_anim_update", "k_anim_blend_stack", "k_bone_attach", "k_palette_expand", "k_xform_subtree", "k_skin_multi", "k_cull_pack"):
+              "k_keys_reduce_rows", "k_keys_reduce_copies", "k_anim_update", "k_anim_blend_stack", "k_bone_attach", "k_palette_expand", "k_xform_subtree", "k_skin_multi", "k_cull_pack"):
         if k in name:
             m = re.search(re.escape(k) + r"(<[^>(]*>)?", name)
             return m.group(0) if m else k
