@@ -202,8 +202,8 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        if world == 1 and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            return self_launch(args.gpus, sys.argv[1:] if argv is None else list(argv))  # plain `python bench.py --gpus N`: this process becomes the launcher
         args.gpus = world
     selftest = args.selftest_hostsim
     if selftest:
@@ -348,6 +348,12 @@ def main(argv=None):
 
     for _ in range(args.warmup):
         step()
+    gather_probe = None
+    if use_dist and exchange_info["mode"] != "p2p":
+        # one all-gather of the record THIS step ships, timed over 32 gathers (a collective: every rank is here), outside the timed region
+        gather_probe = xchg.timeGather(1)
+        for _ in range(max(2, min(args.warmup, 5))):
+            step()
     ms_per_step, reps_ms = timed_repeated(step, args.steps)  # (the closing synchronize of `timed` also drains the side stream's last gathers)
     value = (N if strong else N * world) * n_frusta / (ms_per_step * 1e-3)
     ms_cull_only = ms_host_list = None
@@ -374,8 +380,14 @@ def main(argv=None):
     log(f"[rank {rank}] headline: {ms_per_step * 1e3:.2f} us per step (median of {len(reps_ms)} x {args.steps} steps: "
         f"{', '.join(f'{m * 1e3:.2f}' for m in reps_ms[:12])}), {visible} visible, ids {ids_checked}")
 
-    dist_info = {}
+    dist_info, headline_exchange = {}, {}
     if use_dist:
+        st = xchg.stats(step())  # one more frame of the timed kind: what it ships, what of that is counts + ids
+        headline_exchange = {
+            "exchange_bytes_shipped_per_rank": st["bytes_shipped_per_peer"],  # towards EACH peer: the fixed-size record (collective forms) or its used part (P2P)
+            "exchange_bytes_used_per_rank": st["bytes_used"],                 # counts + the ids this rank has
+            "exchange_bytes_arriving_per_rank": st["bytes_shipped_per_peer"] * (world - 1),
+            "exchange_overflow_mask": st["overflow_mask"]}
         dist_info, ids_checked = exchange_checks_and_frames(args, api, scenes, D, dev, ctx, cs, sc, xchg, step, frustum, fr_ptr, timed, reduce_int, rank, world, local_rank,
                                                             red_dev, strong, half, visible, at_headline_size, ids_checked, torch, dist)
 
@@ -559,10 +571,13 @@ def main(argv=None):
     result["config"].update(dist_info)
     if use_dist:
         result["config"]["exchange_mode"] = exchange_info["mode"]
-        result["config"]["exchange_gather_us_at_creation"] = exchange_info["gather_us"]
+        result["config"]["exchange_gather_us_first_frame"] = exchange_info["gather_us"]  # what `auto` decided on: the first frame's record
         result["config"]["exchange_mode_why"] = exchange_info["why"]
-    if use_dist:
-        result["config"]["xgmi_curve"] = "this line is ONE point; no 1/2/4/8 xGMI curve has been measured by the builder (no multi-GPU node): the driver computes scaling from its own runs"
+        if gather_probe is not None:
+            result["config"]["exchange_gather_us"] = round(gather_probe[0], 2)  # one gather of the record the timed step ships, 32 back to back on the side stream
+            result["config"]["exchange_gather_record_bytes"] = 4 * gather_probe[1]
+        result["config"].update(headline_exchange)
+        result["config"]["xgmi_curve"] = "ONE point; before this run NO 1/2/4/8 xGMI curve existed (the builder's boxes have one GPU): the driver computes scaling from its own runs"
     if args.ranks_share_gpu:
         result["config"]["TEST_MODE"] = "--ranks-share-gpu: all ranks on cuda:0, gloo + shared-memory collective (tests/cpp/loopback_rccl.cpp); timings are meaningless"
     if rank == 0 and world == 1:
@@ -620,7 +635,9 @@ def exchange_checks_and_frames(args, api, scenes, D, dev, ctx, cs, sc, xchg, ste
         seen.append(int(counts.sum()))
         parsed.append(ids)
     info["allgather_visible_counts"] = seen
-    info["exchange"] = f"one ncclAllGather per frame of [8 counts | {xchg.cap} ids] per rank ({'inline on the cull stream' if os.environ.get('LMX_EXCHANGE_INLINE', '1') != '0' else 'side stream, double-buffered'}; lmx_exchange_*)"
+    how = {"inline": "one ncclAllGather per frame, in place, on the cull stream behind the pack kernel", "side": "one ncclAllGather per frame, in place, on a side stream (double-buffered: the next cull overlaps it)",
+           "p2p": "no collective: the used part of the record stored into every peer through hipIpc mappings + sequence flags"}[xchg.info()["mode"]]
+    info["exchange"] = f"[8 counts | {xchg.cap} ids] per rank; {how} (lmx_exchange_*; the mode is lmx_exchange_info's, not an environment guess)"
     info["ranks_seen_by_rccl"] = len(seen)
     assert len(seen) == world and max(seen) <= xchg.cap, (seen, xchg.cap)
     local = cs.cull(frustum, view=2)  # (view 0 / 1 hold exchange frames)
@@ -757,7 +774,8 @@ def exchange_checks_and_frames(args, api, scenes, D, dev, ctx, cs, sc, xchg, ste
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "measured_copy_GBps", "frac_of_measured_copy", "leg")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "host_cores", "single_thread_value", "error")
-CONFIG_KEYS = ("workload", "entities_per_gpu", "frusta", "visible_per_gpu", "visible_ids", "sharding", "timed_steps", "repetitions", "exchange_mode", "exchange_gather_us_at_creation", "ranks_seen_by_rccl",
+CONFIG_KEYS = ("workload", "entities_per_gpu", "frusta", "visible_per_gpu", "visible_ids", "sharding", "timed_steps", "repetitions", "exchange_mode", "exchange_gather_us", "exchange_gather_record_bytes",
+               "exchange_bytes_shipped_per_rank", "exchange_bytes_used_per_rank", "exchange_bytes_arriving_per_rank", "exchange_overflow_mask", "ranks_seen_by_rccl",
                "allgather_visible_counts", "union_equals_unsharded", "visible_total", "xgmi_curve", "TEST_MODE")
 
 
@@ -775,6 +793,8 @@ def compact_line(result):
         f = cfg.get(frame)
         if isinstance(f, dict):
             line["config"][frame] = {k: f[k] for k in ("ms_per_frame_max_over_ranks", "frames_per_sec", "skinned_verts_per_sec_all_ranks", "entity_frustum_tests_per_sec_all_ranks", "error") if k in f}
+            if isinstance(f.get("exchange"), dict):  # config 5's frame: what its 8-sub-record exchange ships
+                line["config"][frame]["exchange"] = {k: f["exchange"][k] for k in ("mode", "bytes_shipped_per_peer", "bytes_used_this_rank", "shipped_over_used", "gather_us_of_this_record", "overflow_mask") if k in f["exchange"]}
     line["roofline"] = {k: _short(result["roofline"].get(k), 160) for k in ROOFLINE_KEYS}
     if "cpu_baseline" in result:
         line["cpu_baseline"] = {k: _short(result["cpu_baseline"][k], 260) for k in CPU_KEYS if k in result["cpu_baseline"]}
@@ -851,12 +871,57 @@ def exchange_path_one_rank(args, log, timeout_s=150.0, extra_env=None):
             return {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
         c = json.loads(lines[-1])
         out = {"ms_per_step": c["ms_per_step"], "value": c["value"], "unit": c["unit"], "steps": c["steps"], "visible_ids": c["config"].get("visible_ids"),
-               "exchange_mode": c["config"].get("exchange_mode"), "exchange_gather_us_at_creation": c["config"].get("exchange_gather_us_at_creation"),
+               "exchange_mode": c["config"].get("exchange_mode"), "exchange_gather_us": c["config"].get("exchange_gather_us"),
                "what": "cull + k_cull_pack into the send buffer + ONE ncclAllGather per step, world of one rank (bench.py --force-collective): the step `--gpus N` times for N > 1"}
         log(f"[exchange path, one rank{', ' + str(extra_env) if extra_env else ''}] {out['ms_per_step'] * 1e3:.2f} us per step")
         return out
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start the N ranks the way the driver's multi-GPU line does -
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <a free port> bench.py <the same
+    arguments> - and hand rank 0's ONE JSON line through on stdout. Everything else the ranks (or the launcher) write to stdout goes to
+    stderr: stdout carries the line and nothing else, as with N = 1."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    if "--ranks-share-gpu" not in argv:
+        try:
+            import torch
+
+            have = torch.cuda.device_count()
+        except Exception:  # noqa: BLE001
+            have = 0
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s) (one rank per GPU; --ranks-share-gpu is the one-GPU TEST mode)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    log(f"bench.py --gpus {n}: WORLD_SIZE is not set, launching the ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (the host driver only supports dmabuf IPC: RCCL needs it across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stdin=subprocess.DEVNULL, text=True, errors="replace")
+    line = None
+    for out in p.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and out.endswith("}"):
+            if line is not None:
+                log(line)
+            line = out
+        elif out:
+            log(out)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc != 0:
+        log(f"bench.py --gpus {n}: the launcher ended with {rc}")
+        return rc
+    return 0 if line is not None else 1
 
 
 class c_stdout_to_stderr:

@@ -219,18 +219,26 @@ LMX_API int lmx_cull_bind_output(LmxContext* ctx, uint32_t view, void* d_ids, si
 /* ---- exchange: multi-GPU all-gather of visible-entity lists (no reference twin: the reference is single-process) -------------
  * One process per GPU, every rank's context holds a disjoint share of the entities (partition by the reference's cell hash, or by
  * index). Culling needs no communication; the one exchange step per frame is a single ncclAllGather (RCCL over xGMI) of a fixed-size
- * record per rank: LMX_MAX_TYPES counts followed by ids_per_rank ids (types packed back to back). The record is written by the
- * cull's gather kernels, frames are double-buffered. RCCL is loaded on first use.
- * How the step runs is chosen at lmx_exchange_create (environment LMX_EXCHANGE_MODE, read once):
- *   auto (default)  time 32 all-gathers of the record; the collective goes on a SIDE stream (the next cull overlaps it, ~16 us more host
- *                   work per step) when one gather takes longer than LMX_EXCHANGE_OVERLAP_US (default 16), else INLINE behind the pack kernel
+ * record per rank: per frustum of the frame LMX_MAX_TYPES counts followed by that frustum's capacity of ids (types packed back to back).
+ * The record is written by the cull's gather kernels IN PLACE (where the collective would put it), frames are double-buffered. RCCL is
+ * loaded on first use.
+ * How the step runs (environment LMX_EXCHANGE_MODE, read once at lmx_exchange_create):
+ *   auto (default)  PER FRAME SHAPE (number of frusta): at the first frame of a shape - and again when the shape's record has grown or shrunk
+ *                   2x since - 32 all-gathers of the record that shape ships are timed (a collective every rank runs in the same call); the
+ *                   collective goes on a SIDE stream (the next cull overlaps it, ~16 us more host work per step) when one gather takes longer
+ *                   than LMX_EXCHANGE_OVERLAP_US (default 16), else INLINE behind the pack kernel
  *   inline / side   force one of the two (LMX_EXCHANGE_INLINE=1 / 0 of earlier rounds still works)
  *   p2p             no collective in the step: every rank stores the USED part of its record (counts + the ids it has) into each peer's
  *                   receive buffer through hipIpc mappings and raises a sequence flag; consumers wait on the device with a bounded spin
  *                   (LMX_EXCHANGE_P2P_TIMEOUT_MS, default 2000). A peer that never shows up costs the frame: lmx_exchange_wait returns
  *                   LMX_ERR_BUSY and the exchange refuses further steps (a rank cannot fall back to a collective on its own - the others
- *                   would not join it; destroy and re-create). One node (<= 8 ranks). Opt-in: unmeasured over xGMI.
- * lmx_exchange_info says which mode was taken, the gather time it was taken on, and why. */
+ *                   would not join it; destroy and re-create). One node (<= 8 ranks). Needs fine-grained device memory for the receive
+ *                   slots: lmx_exchange_create FAILS (LMX_ERR_NO_DEVICE) where the runtime has none. Opt-in: unmeasured over xGMI.
+ * lmx_exchange_info says which mode the last frame's shape takes, the gather time it was taken on, and why.
+ * Capacities: a frame of n frusta ships n sub-records [counts | cap[f] ids]. They start as ids_per_rank / n each (or lmx_exchange_set_caps)
+ * and - frames of >= 2 frusta by default, LMX_EXCHANGE_AUTO_CAPS=1 / 0: all / no frames - follow the lists: cap[f] of frame j is derived from
+ * the largest list ANY rank gathered for frustum f in frame j - 2 (+20 %, 256-id grain; the same numbers on every rank, so the ranks agree
+ * without another collective). A sub-record that overflowed is flagged in lmx_exchange_stats and regrown when its slot comes round again. */
 typedef struct LmxExchange LmxExchange;
 /* ncclGetUniqueId: rank 0 calls this and ships the 128 bytes to the other ranks over any side channel (the engine's network layer,
  * a file, torch.distributed in bench.py). */
@@ -241,18 +249,45 @@ LMX_API void lmx_exchange_destroy(LmxExchange* x);
  * the all-gather of its record, asynchronously. *out_slot identifies the frame for the calls below. */
 LMX_API int lmx_exchange_cull(LmxExchange* x, const LmxShiftedFrustum* frustum, uint8_t type, uint32_t* out_slot);
 /* The frame's views in ONE collective: cull n_frusta frusta (<= LMX_MAX_FRUSTA; every rank the same number) in one pass over the rank's
- * spheres and all-gather n_frusta x [LMX_MAX_TYPES counts | ids_per_rank / n_frusta ids] per rank - config 5's 8 cascades are one
+ * spheres and all-gather n_frusta x [LMX_MAX_TYPES counts | cap[f] ids] per rank (capacities: above) - config 5's 8 cascades are one
  * exchange step, not eight. lmx_exchange_cull is the n_frusta = 1 case. lmx_exchange_read_many reads one (rank, frustum) sub-record. */
 LMX_API int lmx_exchange_cull_many(LmxExchange* x, const LmxShiftedFrustum* frusta, uint32_t n_frusta, uint8_t type, uint32_t* out_slot);
 LMX_API int lmx_exchange_read_many(LmxExchange* x, uint32_t slot, int rank, uint32_t frustum, uint32_t* out_counts, int32_t* out_ids, uint32_t cap);
 LMX_API int lmx_exchange_wait(LmxExchange* x, uint32_t slot);
-/* Device view: rank r's record = d_records + r * record_words (counts, then ids). sum(counts) > ids_per_rank means that rank's
- * list was clipped (re-create the exchange with a larger capacity). gathered_event: hipEvent_t recorded after the collective. */
+/* Device view: rank r's record = d_records + r * record_words (sub-records as lmx_exchange_layout says: counts, then ids). sum(counts) >
+ * the sub-record's capacity means that list was clipped. gathered_event: hipEvent_t recorded after the collective (P2P mode: a device-side
+ * consumer must also see lmx_exchange_wait succeed - a frame whose bounded wait gave up holds stale records). */
 LMX_API int lmx_exchange_result(LmxExchange* x, uint32_t slot, const int32_t** d_records, uint32_t* record_words, void** gathered_event);
 LMX_API int lmx_exchange_read(LmxExchange* x, uint32_t slot, int rank, uint32_t* out_counts, int32_t* out_ids, uint32_t cap);
-/* mode: 0 = all-gather on the cull stream, 1 = on a side stream, 2 = P2P stores; gather_us: one all-gather as timed at creation (< 0: the
- * mode was forced, nothing was timed); why: a static string. Any pointer may be NULL. */
+/* mode: 0 = all-gather on the cull stream, 1 = on a side stream, 2 = P2P stores - of the frame shape that ran last; gather_us: one all-gather
+ * of that shape's record as last timed (< 0: never - the mode was forced, or no frame has run); why: a static string. Any pointer may be NULL. */
 LMX_API int lmx_exchange_info(LmxExchange* x, int* mode, double* gather_us, const char** why);
+/* Capacities (ids per frustum, sum <= ids_per_rank) of the sub-records of frames of n_frusta frusta from now on. EVERY rank makes the same call
+ * between the same two frames. keep_fixed != 0: no regrowth from the gathered counts for this shape. */
+LMX_API int lmx_exchange_set_caps(LmxExchange* x, uint32_t n_frusta, const uint32_t* caps, int keep_fixed);
+/* One all-gather of the record frames of n_frusta frusta ship now, timed over 32 gathers (us; the record's words per rank). A COLLECTIVE: every
+ * rank calls it at the same point; waits for everything the exchange has in flight. Not in P2P mode. */
+LMX_API int lmx_exchange_time_gather(LmxExchange* x, uint32_t n_frusta, double* out_us, uint32_t* out_record_words);
+/* Layout of the gathered records of `slot`: rank r's record at r * record_words, its sub-record f at offsets[f] from there (LMX_MAX_TYPES
+ * counts, then caps[f] ids). caps / offsets: LMX_MAX_FRUSTA entries. Any pointer may be NULL. */
+LMX_API int lmx_exchange_layout(LmxExchange* x, uint32_t slot, uint32_t* n_frusta, uint32_t* caps, uint32_t* offsets, uint32_t* record_words);
+/* What the frame in `slot` shipped and what of it was used (waits for the frame's gather). */
+typedef struct LmxExchangeStats {
+	uint32_t n_frusta;
+	uint32_t record_words;               /* words per rank in the receive buffer = what a collective form ships per rank */
+	uint32_t caps[LMX_MAX_FRUSTA];        /* ids per sub-record */
+	uint32_t max_visible[LMX_MAX_FRUSTA]; /* the largest list any rank saw, per frustum */
+	uint32_t overflow_mask;              /* bit f: some rank's list of frustum f was clipped in this frame */
+	uint32_t used_words_own;             /* counts + ids this rank's record actually holds */
+	uint32_t used_words_max;             /* the same, largest over the ranks */
+	int32_t mode;                        /* 0 inline, 1 side, 2 p2p: how this frame was shipped */
+	uint64_t bytes_shipped_per_peer;     /* record_words * 4 (collective forms), used_words_own * 4 (P2P) */
+	uint64_t bytes_used;                 /* used_words_own * 4 */
+	double gather_us;                    /* one all-gather of this shape's record as last timed (< 0: never) ... */
+	uint32_t gather_us_record_words;     /* ... and the record size it was timed on */
+	uint32_t reserved;
+} LmxExchangeStats;
+LMX_API int lmx_exchange_stats(LmxExchange* x, uint32_t slot, LmxExchangeStats* out);
 
 /* ---- world transforms: World hierarchy, src/engine/world.cpp:255-282 ---------------------------------------
  * The reference propagates eagerly (one recursive DFS per setTransform). The batch form: stage new root/local

@@ -141,6 +141,10 @@ SYMBOLS = {
     "lmx_exchange_result": (_ci, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_vp)]),
     "lmx_exchange_read": (_ci, [_vp, _u32, _ci, _vp, _vp, _u32]),
     "lmx_exchange_info": (_ci, [_vp, _vp, _vp, _vp]),
+    "lmx_exchange_set_caps": (_ci, [_vp, _u32, _vp, _ci]),
+    "lmx_exchange_time_gather": (_ci, [_vp, _u32, _vp, _vp]),
+    "lmx_exchange_layout": (_ci, [_vp, _u32, _vp, _vp, _vp, _vp]),
+    "lmx_exchange_stats": (_ci, [_vp, _u32, _vp]),
     "lmx_world_build": (_ci, [_vp, _u32, _vp, _vp]),
     "lmx_world_build_with_world": (_ci, [_vp, _u32, _vp, _vp, _vp]),
     "lmx_world_set_parent": (_ci, [_vp, _i32, _i32]),
@@ -518,6 +522,13 @@ def exchange_unique_id() -> bytes:
     return buf.tobytes()
 
 
+class ExchangeStats(C.Structure):
+    """LmxExchangeStats (include/lumix_mi355.h)"""
+    _fields_ = [("n_frusta", C.c_uint32), ("record_words", C.c_uint32), ("caps", C.c_uint32 * 8), ("max_visible", C.c_uint32 * 8), ("overflow_mask", C.c_uint32),
+                ("used_words_own", C.c_uint32), ("used_words_max", C.c_uint32), ("mode", C.c_int32), ("bytes_shipped_per_peer", C.c_uint64), ("bytes_used", C.c_uint64),
+                ("gather_us", C.c_double), ("gather_us_record_words", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class VisibleExchange:
     """lmx_exchange_*: per frame one cull of this rank's entities + one RCCL all-gather of [8 counts | cap ids] per rank."""
 
@@ -537,6 +548,7 @@ class VisibleExchange:
         frustum = np.ascontiguousarray(frustum, SHIFTED_FRUSTUM).reshape(-1)
         slot = C.c_uint32(0)
         self.ctx.check(self.lib.lmx_exchange_cull(self.h, _ptr(frustum), type_, C.byref(slot)))
+        self.last_slot = slot.value
         return slot.value
 
     def cullMany(self, frusta: np.ndarray, type_: int = TYPE_ALL) -> int:
@@ -544,32 +556,57 @@ class VisibleExchange:
         frusta = np.ascontiguousarray(frusta, SHIFTED_FRUSTUM).reshape(-1)
         slot = C.c_uint32(0)
         self.ctx.check(self.lib.lmx_exchange_cull_many(self.h, _ptr(frusta), len(frusta), type_, C.byref(slot)))
-        self._n_frusta = len(frusta)
+        self.last_slot = slot.value
         return slot.value
 
+    def layout(self, slot: int) -> dict:
+        """lmx_exchange_layout: {"n_frusta", "caps"[n], "offsets"[n] (words from a rank's record start), "record_words"} of the slot's last frame"""
+        n, rec = C.c_uint32(0), C.c_uint32(0)
+        caps, offs = np.zeros(8, np.uint32), np.zeros(8, np.uint32)
+        self.ctx.check(self.lib.lmx_exchange_layout(self.h, slot, C.byref(n), _ptr(caps), _ptr(offs), C.byref(rec)))
+        return {"n_frusta": n.value, "caps": [int(c) for c in caps[: n.value]], "offsets": [int(o) for o in offs[: n.value]], "record_words": rec.value}
+
     def readMany(self, slot: int, rank: int, frustum: int):
-        """(counts[8], ids) of one (rank, frustum) sub-record; ids clipped to ids_per_rank // n_frusta."""
-        cap_f = self.cap // max(getattr(self, "_n_frusta", 1), 1)
+        """(counts[8], ids) of one (rank, frustum) sub-record; ids clipped to the sub-record's capacity (layout(slot)["caps"][frustum])."""
+        cap_f = self.layout(slot)["caps"][frustum]
         counts = np.zeros(MAX_TYPES, np.uint32)
-        ids = np.zeros(cap_f, np.int32)
+        ids = np.zeros(max(cap_f, 1), np.int32)
         self.ctx.check(self.lib.lmx_exchange_read_many(self.h, slot, rank, frustum, _ptr(counts), _ptr(ids), cap_f))
         return counts, ids[: min(int(counts.sum()), cap_f)]
+
+    def setCaps(self, caps, keep_fixed: bool = False):
+        """capacities of the sub-records of frames of len(caps) frusta from now on (every rank: the same call at the same point)"""
+        caps = np.ascontiguousarray(caps, np.uint32)
+        self.ctx.check(self.lib.lmx_exchange_set_caps(self.h, len(caps), _ptr(caps), 1 if keep_fixed else 0))
+
+    def timeGather(self, n_frusta: int = 1):
+        """COLLECTIVE: (us per all-gather of the record a frame of n_frusta frusta ships now, that record's words per rank)"""
+        us, words = C.c_double(-1.0), C.c_uint32(0)
+        self.ctx.check(self.lib.lmx_exchange_time_gather(self.h, n_frusta, C.byref(us), C.byref(words)))
+        return us.value, words.value
+
+    def stats(self, slot: int) -> dict:
+        """lmx_exchange_stats of the slot's last frame (waits for its gather)"""
+        st = ExchangeStats()
+        self.ctx.check(self.lib.lmx_exchange_stats(self.h, slot, C.byref(st)))
+        n = st.n_frusta
+        return {"n_frusta": n, "record_words": st.record_words, "caps": list(st.caps[:n]), "max_visible": list(st.max_visible[:n]), "overflow_mask": st.overflow_mask,
+                "used_words_own": st.used_words_own, "used_words_max": st.used_words_max, "mode": ("inline", "side", "p2p")[st.mode],
+                "bytes_shipped_per_peer": int(st.bytes_shipped_per_peer), "bytes_used": int(st.bytes_used),
+                "gather_us": st.gather_us if st.gather_us >= 0 else None, "gather_us_record_words": st.gather_us_record_words}
 
     def wait(self, slot: int):
         self.ctx.check(self.lib.lmx_exchange_wait(self.h, slot))
 
     def info(self) -> dict:
-        """how the step runs: {"mode": "inline" | "side" | "p2p", "gather_us": one all-gather as timed at creation (None: forced), "why"}"""
+        """how frames of the shape that ran last run: {"mode": "inline" | "side" | "p2p", "gather_us": one all-gather of that shape's record as last timed (None: never), "why"}"""
         mode, us, why = C.c_int(0), C.c_double(-1.0), C.c_char_p()
         self.ctx.check(self.lib.lmx_exchange_info(self.h, C.byref(mode), C.byref(us), C.byref(why)))
         return {"mode": ("inline", "side", "p2p")[mode.value], "gather_us": us.value if us.value >= 0 else None, "why": (why.value or b"").decode()}
 
     def read(self, slot: int, rank: int):
-        """(counts[8], ids) of one rank's gathered record (ids of type 0 first; clipped to the exchange capacity)."""
-        counts = np.zeros(MAX_TYPES, np.uint32)
-        ids = np.zeros(self.cap, np.int32)
-        self.ctx.check(self.lib.lmx_exchange_read(self.h, slot, rank, _ptr(counts), _ptr(ids), self.cap))
-        return counts, ids[: min(int(counts.sum()), self.cap)]
+        """(counts[8], ids) of one rank's gathered record of a one-frustum frame (ids of type 0 first; clipped to the record's capacity)."""
+        return self.readMany(slot, rank, 0)
 
 
 class World:

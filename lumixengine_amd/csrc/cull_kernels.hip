@@ -1033,16 +1033,19 @@ __global__ __launch_bounds__(256) void k_cull_consolidate(const int32_t* __restr
 // and one launch less per frame. Block (0, 0) also writes the per-type totals. grid (n_shards, splits, frusta): the frusta of one cull
 // (a frame's views, the exchange's sub-records) are packed by ONE launch, frustum f reading row f of the ids / counters and writing
 // record f (strides in words).
+// Record f = [MAX_TYPES counts | lay.cap[f] ids] at rec_base + lay.off[f]: the records of a launch need neither the same capacity nor a
+// common stride (the exchange's sub-records carry per-frustum capacities, lmx_capi_exchange.hip).
 __global__ __launch_bounds__(256) void k_cull_pack(const int32_t* __restrict__ src, const uint32_t* __restrict__ win_base, const uint32_t* __restrict__ counts,
-	uint32_t cnt_pad, const uint8_t* __restrict__ shard_type, uint32_t n_shards, uint32_t* __restrict__ header, int32_t* __restrict__ dst, uint32_t dst_cap,
-	uint32_t src_stride, uint32_t cnt_stride, uint32_t rec_stride) {
+	uint32_t cnt_pad, const uint8_t* __restrict__ shard_type, uint32_t n_shards, int32_t* __restrict__ rec_base, PackLayout lay,
+	uint32_t src_stride, uint32_t cnt_stride) {
 	__shared__ uint32_t s_part[4];
 	__shared__ uint32_t s_tot[MAX_TYPES];
 	const uint32_t s = blockIdx.x, t = threadIdx.x;
 	src += (size_t)blockIdx.z * src_stride;
 	counts += (size_t)blockIdx.z * cnt_stride;
-	header += (size_t)blockIdx.z * rec_stride;
-	dst += (size_t)blockIdx.z * rec_stride;
+	uint32_t* const header = reinterpret_cast<uint32_t*>(rec_base + lay.off[blockIdx.z]);
+	int32_t* const dst = rec_base + lay.off[blockIdx.z] + MAX_TYPES;
+	const uint32_t dst_cap = lay.cap[blockIdx.z];
 	const bool totals_block = s == 0 && blockIdx.y == 0;
 	const uint32_t c = counts[s * cnt_pad];
 	// a block whose slice of the shard's window is empty has nothing to place (most of them when little is visible: the grid is sized
@@ -1235,20 +1238,32 @@ hipError_t launch_cull_consolidate(hipStream_t s, const int32_t* src, uint32_t s
 	return hipGetLastError();
 }
 
-hipError_t launch_cull_pack(hipStream_t s, const int32_t* src, const uint32_t* win_base, const uint32_t* counts, uint32_t cnt_pad, const uint8_t* shard_type,
-	uint32_t n_shards, uint32_t max_shard_cap, uint32_t* header, int32_t* dst, uint32_t dst_cap, uint32_t n_frusta, uint32_t src_stride, uint32_t cnt_stride,
-	uint32_t rec_stride) {
+hipError_t launch_cull_pack_layout(hipStream_t s, const int32_t* src, const uint32_t* win_base, const uint32_t* counts, uint32_t cnt_pad, const uint8_t* shard_type,
+	uint32_t n_shards, uint32_t max_shard_cap, int32_t* rec_base, const PackLayout& lay, uint32_t n_frusta, uint32_t src_stride, uint32_t cnt_stride) {
 	if (!n_frusta) return hipSuccess;
+	if (n_frusta > (uint32_t)MAX_FRUSTA) return hipErrorInvalidValue;
 	if (!n_shards) { // an empty set still reports its (zero) counts
 		for (uint32_t f = 0; f < n_frusta; ++f)
-			if (hipError_t e = hipMemsetAsync(header + (size_t)f * rec_stride, 0, MAX_TYPES * sizeof(uint32_t), s)) return e;
+			if (hipError_t e = hipMemsetAsync(rec_base + lay.off[f], 0, MAX_TYPES * sizeof(uint32_t), s)) return e;
 		return hipSuccess;
 	}
 	if (n_shards > (uint32_t)FIN_MAX_SHARDS) return hipErrorInvalidValue;
 	const uint32_t splits = std::max(1u, std::min(64u, max_shard_cap / 4096u));
-	hipLaunchKernelGGL(k_cull_pack, dim3(n_shards, splits, n_frusta), dim3(256), 0, s, src, win_base, counts, cnt_pad, shard_type, n_shards, header, dst, dst_cap,
-		src_stride, cnt_stride, rec_stride);
+	hipLaunchKernelGGL(k_cull_pack, dim3(n_shards, splits, n_frusta), dim3(256), 0, s, src, win_base, counts, cnt_pad, shard_type, n_shards, rec_base, lay, src_stride,
+		cnt_stride);
 	return hipGetLastError();
+}
+
+hipError_t launch_cull_pack(hipStream_t s, const int32_t* src, const uint32_t* win_base, const uint32_t* counts, uint32_t cnt_pad, const uint8_t* shard_type,
+	uint32_t n_shards, uint32_t max_shard_cap, uint32_t* header, int32_t* dst, uint32_t dst_cap, uint32_t n_frusta, uint32_t src_stride, uint32_t cnt_stride,
+	uint32_t rec_stride) {
+	if (n_frusta > (uint32_t)MAX_FRUSTA || dst != reinterpret_cast<int32_t*>(header) + MAX_TYPES) return hipErrorInvalidValue; // (a record's ids sit behind its header)
+	PackLayout lay = {};
+	for (uint32_t f = 0; f < n_frusta; ++f) {
+		lay.off[f] = (uint64_t)f * rec_stride;
+		lay.cap[f] = dst_cap;
+	}
+	return launch_cull_pack_layout(s, src, win_base, counts, cnt_pad, shard_type, n_shards, max_shard_cap, reinterpret_cast<int32_t*>(header), lay, n_frusta, src_stride, cnt_stride);
 }
 
 } // namespace lmx

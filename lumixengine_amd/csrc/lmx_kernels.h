@@ -114,6 +114,13 @@ hipError_t launch_cull_finalize(hipStream_t s, const uint32_t* counts, uint32_t 
 hipError_t launch_cull_pack(hipStream_t s, const int32_t* src, const uint32_t* win_base, const uint32_t* counts, uint32_t cnt_pad, const uint8_t* shard_type,
 	uint32_t n_shards, uint32_t max_shard_cap, uint32_t* header, int32_t* dst /* behind the header */, uint32_t dst_cap, uint32_t n_frusta = 1,
 	uint32_t src_stride = 0, uint32_t cnt_stride = 0, uint32_t rec_stride = 0);
+// the same with a place and a capacity PER record: record f = [MAX_TYPES counts | lay.cap[f] ids] at rec_base + lay.off[f] (words)
+struct PackLayout {
+	uint64_t off[MAX_FRUSTA];
+	uint32_t cap[MAX_FRUSTA];
+};
+hipError_t launch_cull_pack_layout(hipStream_t s, const int32_t* src, const uint32_t* win_base, const uint32_t* counts, uint32_t cnt_pad, const uint8_t* shard_type,
+	uint32_t n_shards, uint32_t max_shard_cap, int32_t* rec_base, const PackLayout& lay, uint32_t n_frusta, uint32_t src_stride, uint32_t cnt_stride);
 hipError_t launch_cull_consolidate(hipStream_t s, const int32_t* src, uint32_t src_stride, const uint32_t* win_base, const uint32_t* counts,
 	uint32_t cnt_pad, uint32_t cnt_frustum_stride, const uint8_t* shard_type, const uint32_t* type_start /* device */, uint32_t type_start_stride,
 	const uint32_t* pref, uint32_t n_shards, uint32_t n_frusta, uint32_t max_shard_cap, int32_t* dst, uint32_t dst_stride, uint32_t dst_cap, const int32_t* src2 = nullptr /* a second array with the same windows, gathered by the same launch */, int32_t* dst2 = nullptr);

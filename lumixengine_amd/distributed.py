@@ -105,25 +105,43 @@ def merge_ranks(parsed: List[List[np.ndarray]]) -> List[np.ndarray]:
     return [np.concatenate([rank[t] for rank in parsed]) if parsed else np.zeros(0, np.int32) for t in range(MAX_TYPES)]
 
 
-def make_frame_record(ids_by_frustum_and_type: List[List[np.ndarray]], ids_per_rank: int) -> np.ndarray:
+def frame_caps(n_frusta: int, ids_per_rank: int, caps=None) -> List[int]:
+    """capacities of a frame's sub-records: as given, else the equal split lmx_exchange_cull_many starts from"""
+    return [int(c) for c in caps] if caps is not None else [ids_per_rank // n_frusta] * n_frusta
+
+
+def cap_for(most_visible: int) -> int:
+    """lmx_capi_exchange.hip cap_for: the capacity a list whose largest instance over the ranks holds `most_visible` ids is given -
+    20 % head room (at least 64 ids), rounded up to the 256-id grain"""
+    m = int(most_visible)
+    return (m + max(m // 5, 64) + 255) // 256 * 256
+
+
+def make_frame_record(ids_by_frustum_and_type: List[List[np.ndarray]], ids_per_rank: int, caps=None) -> np.ndarray:
     """One rank's record of a FRAME of n_frusta views as lmx_exchange_cull_many writes it: n_frusta sub-records
-    [MAX_TYPES counts | ids_per_rank // n_frusta ids], one collective for all of them (config 5: 8 cascades = one all-gather)."""
-    n = len(ids_by_frustum_and_type)
-    cap_f = ids_per_rank // n
-    return np.concatenate([make_record(by_type, cap_f) for by_type in ids_by_frustum_and_type])
+    [MAX_TYPES counts | caps[f] ids] back to back, one collective for all of them (config 5: 8 cascades = one all-gather)."""
+    caps = frame_caps(len(ids_by_frustum_and_type), ids_per_rank, caps)
+    return np.concatenate([make_record(by_type, c) for by_type, c in zip(ids_by_frustum_and_type, caps)])
 
 
-def parse_frame_records(records: np.ndarray, n_frusta: int, ids_per_rank: int):
+def parse_frame_records(records: np.ndarray, n_frusta: int, ids_per_rank: int, caps=None):
     """all-gathered frame records -> (ids[frustum][rank][type], overflowed)."""
-    cap_f = ids_per_rank // n_frusta
-    sub = MAX_TYPES + cap_f
-    records = np.asarray(records).reshape(-1, n_frusta, sub)
-    out, overflowed = [], False
+    caps = frame_caps(n_frusta, ids_per_rank, caps)
+    record = sum(MAX_TYPES + c for c in caps)
+    records = np.asarray(records).reshape(-1, record)
+    out, overflowed, at = [], False, 0
     for f in range(n_frusta):
-        parsed, over = parse_records(records[:, f, :], cap_f)
+        parsed, over = parse_records(records[:, at : at + MAX_TYPES + caps[f]], caps[f])
         out.append(parsed)
         overflowed |= over
+        at += MAX_TYPES + caps[f]
     return out, overflowed
+
+
+def slot_of_last(x) -> int:
+    """the slot the exchange's most recent frame went to (frames alternate 0 / 1; lmx_exchange_cull_many returns it - this is for callers that
+    only kept the exchange)"""
+    return getattr(x, "last_slot", 0)
 
 
 def config5_frame(api, frusta: np.ndarray, ctx, cs, rank: int, world: int, n_entities_per_rank: int, coll, timed, quiet=None, steps: int = 50) -> dict:
@@ -139,21 +157,25 @@ def config5_frame(api, frusta: np.ndarray, ctx, cs, rank: int, world: int, n_ent
 
     n_f = len(frusta)
     out = {"what": f"{n_f} frusta over the rank's entities, pass width {n_f}, lmx_exchange_cull_many: one ncclAllGather of {n_f} sub-records per frame"}
-    ok, most, local, x = 1, 0, None, None
+    ok, local, x = 1, None, None
     try:
         cs.setPassWidth(n_f)
         local = cs.cull(frusta, view=2)  # (views 0 / 1 are the exchange's slots)
         per_frustum = local.counts().sum(axis=1)
         out["visible_per_frustum_this_rank"] = [int(v) for v in per_frustum]
-        most = int(per_frustum.max())
     except Exception as e:  # noqa: BLE001
         ok = 0
         out["error"] = repr(e)
-    cap_f = (coll.max_int(most) * 5 // 4 + 1023) // 1024 * 1024  # 1.25 x the largest list of any rank and frustum
+    # capacities PER FRUSTUM (round 6): what the largest list of any rank needs, frustum by frustum - config 5's cascades see 535 ... 1.15 M ids on a
+    # 10 M-entity rank, one capacity for all of them shipped 4.6x the ids. The exchange keeps them on the lists from here on (regrowth from the
+    # gathered counts: no further collective); the buffers are sized for twice the first frame's sum.
+    per_frustum = [0] * n_f if local is None else [int(v) for v in local.counts().sum(axis=1)]
+    caps = [cap_for(coll.max_int(v)) for v in per_frustum]
     uid = coll.bcast_bytes(api.exchange_unique_id() if rank == 0 else None)
     try:
         with (quiet() if quiet is not None else contextlib.nullcontext()):
-            x = api.VisibleExchange(ctx, rank, world, uid, cap_f * n_f)  # (a collective: every rank gets here)
+            x = api.VisibleExchange(ctx, rank, world, uid, 2 * sum(caps))  # (a collective: every rank gets here)
+            x.setCaps(caps)
             slot = x.cullMany(frusta)
             x.wait(slot)
         if ok:
@@ -163,7 +185,7 @@ def config5_frame(api, frusta: np.ndarray, ctx, cs, rank: int, world: int, n_ent
                 same = same and np.array_equal(np.sort(got), np.sort(local.all_ids(f)[0]))
             out["own_sub_records_equal_local_cull"] = bool(same)
             out["visible_per_rank_and_frustum"] = [[int(x.readMany(slot, r, f)[0].sum()) for f in range(n_f)] for r in range(world)]
-            out["ids_per_rank_and_frustum"] = int(cap_f)
+            out["ids_per_rank_and_frustum"] = caps
     except Exception as e:  # noqa: BLE001
         ok = 0
         out["error"] = repr(e)
@@ -171,9 +193,19 @@ def config5_frame(api, frusta: np.ndarray, ctx, cs, rank: int, world: int, n_ent
         step = lambda: x.cullMany(frusta)  # noqa: E731
         for _ in range(5):
             step()
+        gather_us = None
+        if x.info()["mode"] != "p2p":
+            gather_us, gather_words = x.timeGather(n_f)  # (a collective, like everything in this branch: the ranks agreed to be here)
+            for _ in range(2):
+                step()
         ms = timed(step, steps)
         out["ms_per_frame_max_over_ranks"] = ms
         out["entity_frustum_tests_per_sec_all_ranks"] = float(n_f) * n_entities_per_rank * world / (ms * 1e-3)
+        st = x.stats(slot_of_last(x))
+        out["exchange"] = {"mode": st["mode"], "record_bytes_per_rank": 4 * st["record_words"], "bytes_shipped_per_peer": st["bytes_shipped_per_peer"], "bytes_used_this_rank": st["bytes_used"],
+                           "shipped_over_used": round(st["bytes_shipped_per_peer"] / max(st["bytes_used"], 1), 3), "caps": st["caps"], "max_visible_any_rank": st["max_visible"],
+                           "overflow_mask": st["overflow_mask"], "gather_us_of_this_record": gather_us,
+                           "bytes_arriving_per_rank_per_frame": st["bytes_shipped_per_peer"] * (world - 1) if st["mode"] != "p2p" else None}
     elif "error" not in out:
         out["error"] = "another rank failed"
     if x is not None:

@@ -79,6 +79,25 @@ def _worker(rank, world, port, out_dir):
             merged = D.merge_ranks(frame[f])
             for k in range(D.MAX_TYPES):
                 assert np.array_equal(np.sort(merged[k]), np.sort(out[f"f{f}_t{k}"])), "one collective per frame != one collective per view"
+        # the NEXT frame's capacities follow the lists, frustum by frustum (lmx_capi_exchange.hip `regrow`): every rank derives them from the
+        # counts it has just gathered - the largest list of any rank per frustum, + 20 % - so the ranks agree on the new record size WITHOUT
+        # another collective (an all-gather of different sizes would not complete), and the record shrinks to what the lists need
+        gathered = recv.view(world, -1).numpy()
+        at, caps = 0, []
+        for f in range(len(fr)):
+            caps.append(D.cap_for(int(gathered[:, at : at + D.MAX_TYPES].sum(axis=1).max())))
+            at += D.MAX_TYPES + cap // len(fr)
+        send2 = torch.from_numpy(D.make_frame_record(per_frustum, cap, caps))
+        assert len(send2) == sum(D.MAX_TYPES + c for c in caps)
+        recv2 = torch.empty(world * len(send2), dtype=torch.int32)
+        dist.all_gather_into_tensor(recv2, send2)
+        frame2, overflowed2 = D.parse_frame_records(recv2.numpy(), len(fr), cap, caps)
+        assert not overflowed2
+        for f in range(len(fr)):
+            for r in range(world):
+                for k in range(D.MAX_TYPES):
+                    assert np.array_equal(frame2[f][r][k], frame[f][r][k])
+        out["caps"] = np.array(caps, np.int64)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
     finally:
         dist.destroy_process_group()
@@ -93,6 +112,7 @@ def test_sharded_cull_allgather_equals_unsharded(tmp_path, oracle_port, world):
     cs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
     results = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
     assert sum(int(r["owned"][0]) for r in results) == N  # shards are a partition
+    assert all(np.array_equal(r["caps"], results[0]["caps"]) for r in results)  # every rank derived the same per-frustum capacities from the gathered counts
     for f in range(len(fr)):
         want, wt, _ = cs.cull(fr[f : f + 1])
         for r in results:  # every rank ends up with the full list, per type
@@ -230,12 +250,30 @@ def test_config5_frame_failure_on_one_rank_is_agreed_on_not_hung():
         live = []
 
         def __init__(self, ctx, rank, world, uid, cap):
-            assert uid == b"U" * 128 and cap == 2 * 1024
-            self.closed, self.steps = False, 0
+            # per-frustum capacities: cap_for(3) = cap_for(5) = 256 ids (a healthy rank's lists; the failing one reports 0 - the MAX over the
+            # ranks decides), the buffers hold twice their sum
+            assert uid == b"U" * 128 and cap == 2 * (256 + 256)
+            self.closed, self.steps, self.caps, self.timed = False, 0, None, 0
             FakeExchange.live.append(self)
+
+        def setCaps(self, caps, keep_fixed=False):
+            self.caps = list(caps)
+
+        def info(self):
+            return {"mode": "inline", "gather_us": None, "why": "fake"}
+
+        def timeGather(self, n_frusta):
+            self.timed += 1
+            return 7.0, sum(8 + c for c in self.caps)
+
+        def stats(self, slot):
+            words = sum(8 + c for c in self.caps)
+            return {"mode": "inline", "record_words": words, "bytes_shipped_per_peer": 4 * words, "bytes_used": 4 * (8 + 3 + 8 + 5), "caps": self.caps, "max_visible": [3, 5],
+                    "overflow_mask": 0}
 
         def cullMany(self, frusta):
             self.steps += 1
+            self.last_slot = 0
             return 0
 
         def wait(self, slot):
@@ -280,4 +318,5 @@ def test_config5_frame_failure_on_one_rank_is_agreed_on_not_hung():
             for r in range(2):
                 assert "error" not in out[r] and out[r]["own_sub_records_equal_local_cull"] is True and out[r]["ms_per_frame_max_over_ranks"] == 0.5
                 assert out[r]["visible_per_rank_and_frustum"] == [[3, 5], [3, 5]] and out[r]["entity_frustum_tests_per_sec_all_ranks"] == 2.0 * 1000 * 2 / 0.5e-3
-            assert all(x.steps == 1 + 5 + 3 for x in FakeExchange.live)
+                assert out[r]["exchange"]["caps"] == [256, 256] and out[r]["exchange"]["gather_us_of_this_record"] == 7.0 and out[r]["exchange"]["bytes_used_this_rank"] == 4 * 24
+            assert all(x.steps == 1 + 5 + 2 + 3 and x.timed == 1 and x.caps == [256, 256] for x in FakeExchange.live)

@@ -32,9 +32,11 @@ def test_exchange_single_rank_matches_oracle(gpu_ctx, oracle_port, mode, monkeyp
     cap = max(sum(len(a) for a in w) for w in want) + 100
     x = api.VisibleExchange(gpu_ctx, 0, 1, api.exchange_unique_id(), cap)
     try:
+        assert x.info()["gather_us"] is None  # nothing is timed before a frame says what record it ships
+        x.wait(x.cull(cams[0]))
         info = x.info()
         assert info["mode"] == (mode if mode != "auto" else info["mode"]) and info["mode"] in ("inline", "side", "p2p")
-        assert (info["gather_us"] is not None and info["gather_us"] > 0) == (mode == "auto"), info  # timed only when the choice is made by measurement
+        assert (info["gather_us"] is not None and info["gather_us"] > 0) == (mode == "auto"), info  # timed only when the choice is made by measurement: on the first frame's record
         # pipelined: two frames in flight, read back one frame late (what a renderer consuming last frame's list does)
         slots = []
         for frame in range(8):
@@ -166,6 +168,27 @@ def test_exchange_ranks_on_one_gpu_loopback(tmp_path, oracle_port, world, mode):
             for r in range(world):
                 for f in range(len(cams)):
                     check(g[f"many_f{frame}_r{r}_c{f}_counts"], g[f"many_f{frame}_r{r}_c{f}_ids"], want[f][r], ("many", reader, frame, r, f))
+        # capacities that follow the lists (exchange_rank.py "grow"): frames 0 / 1 clip frustum 0 at 256 ids and say so, from frame 2 on every
+        # list is whole, the record has shrunk to what the lists need, and every rank computed the same layout from the gathered counts alone
+        most = [max(sum(len(a) for a in want[f][r]) for r in range(world)) for f in range(len(cams))]
+        for frame in range(5):
+            caps, misc = g[f"grow_f{frame}_caps"].tolist(), g[f"grow_f{frame}_misc"].tolist()
+            assert caps == got[0][f"grow_f{frame}_caps"].tolist() and g[f"grow_f{frame}_max"].tolist() == most, (reader, frame)
+            assert misc[1] == sum(8 + c for c in caps) and misc[4] == (4 * misc[1] if mode != "p2p" else misc[5])
+            mine = [sum(len(a) for a in want[f][reader]) for f in range(len(cams))]
+            assert misc[2] == sum(8 + min(v, c) for v, c in zip(mine, caps)) and misc[5] == 4 * misc[2]
+            if frame < 2:
+                assert caps[0] == 256 and misc[0] == (1 if most[0] > 256 else 0)
+            else:
+                assert misc[0] == 0 and caps == [D.cap_for(m) for m in most], (frame, caps, most)
+            for r in range(world):
+                for f in range(len(cams)):
+                    c, ids = g[f"grow_f{frame}_r{r}_c{f}_counts"], g[f"grow_f{frame}_r{r}_c{f}_ids"]
+                    total = sum(len(a) for a in want[f][r])
+                    if total <= caps[f]:
+                        check(c, ids, want[f][r], ("grow", reader, frame, r, f))
+                    else:
+                        assert int(c.sum()) == total and len(ids) == caps[f] and set(ids.tolist()) <= set(np.concatenate(want[f][r]).tolist())
         for r in range(world):
             c, ids = g[f"type2_r{r}_counts"], g[f"type2_r{r}_ids"]
             assert int(c[2]) == len(want[0][r][2]) and int(c.sum()) == int(c[2]) and np.array_equal(np.sort(ids), want[0][r][2])
@@ -213,7 +236,17 @@ def test_config5_frame_two_ranks_loopback(tmp_path, oracle_port):
         ocs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
         want = [len(ocs.cull(frusta[f : f + 1])[0]) for f in range(len(frusta))]
         assert got[0]["visible_per_rank_and_frustum"][r] == want and got[r]["visible_per_frustum_this_rank"] == want, (r, want)
-        assert max(want) <= got[0]["ids_per_rank_and_frustum"] and sum(want) > 0
+        assert all(w <= c for w, c in zip(want, got[0]["ids_per_rank_and_frustum"])) and sum(want) > 0
+    # what the frame ships: per-frustum capacities that follow the lists - the record of the timed frames is within 1.3x of the bytes the
+    # rank with the fullest record uses (round 5's equal split: 4.6x at config 5's size), nothing overflowed, every rank has the same layout
+    for r in range(world):
+        e = got[r]["exchange"]
+        assert e["caps"] == got[0]["exchange"]["caps"] and e["record_bytes_per_rank"] == got[0]["exchange"]["record_bytes_per_rank"]
+        assert e["overflow_mask"] == 0 and e["max_visible_any_rank"] == [max(v[f] for v in got[0]["visible_per_rank_and_frustum"]) for f in range(len(frusta))]
+        assert all(m <= c for m, c in zip(e["max_visible_any_rank"], e["caps"]))
+        assert e["bytes_used_this_rank"] == 4 * sum(8 + v for v in got[0]["visible_per_rank_and_frustum"][r])
+    fullest = max(got[r]["exchange"]["bytes_used_this_rank"] for r in range(world))
+    assert got[0]["exchange"]["record_bytes_per_rank"] <= 1.3 * fullest, (got[0]["exchange"], fullest)
 
 
 def test_p2p_exchange_gives_up_on_a_missing_peer(tmp_path):

@@ -1,10 +1,10 @@
 #!/bin/bash
 # One GPU call of the round, by name (replaces the per-call scripts of earlier rounds):
 #   gpurun --timeout 900 -- 'bash tools/gpu_call.sh <case> [args...]'
-# Everything lands under gpurun_out/r05/<case>/; what is worth keeping is copied to profiles/r05/ by hand afterwards.
+# Everything lands under gpurun_out/r06/<case>/; what is worth keeping is copied to profiles/r06/ by hand afterwards.
 CASE=${1:-help}; shift
 ROOT=$(pwd)
-OUT=gpurun_out/r05/$CASE
+OUT=gpurun_out/r06/$CASE
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 W="python $ROOT/tools/run_workload.py"

@@ -1,5 +1,5 @@
 # the round's final evidence, one call: the driver's bench line, rocprofv3 kernel stats of the workloads the numbers in DESIGN.md come from, SQ / traffic
-# counters of the several-frusta launch, the GPU suite + smoke, fuzzers. Everything under gpurun_out/r05/final -> profiles/r05/final.
+# counters of the several-frusta launch, the GPU suite + smoke, fuzzers. Everything under gpurun_out/r06/final -> profiles/r06/final.
 #   bash tools/gpu_call.sh final [stats|counters|suite|bench|all]
 WHAT=${1:-all}
 if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
