@@ -139,8 +139,8 @@ LMX_API int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* fr
 LMX_API int lmx_cull_set_pass_width(LmxContext* ctx, uint32_t frusta_per_pass);
 /* Kernel tuning knobs (no reference twin; results never depend on them). */
 enum {
-	LMX_CULL_OPT_TILE_VARIANT = 0,            /* 1-frustum kernel tile: -1 auto (default: 4 when the frustum's box overlaps < 25 % of the set's box, else 1), 0 = 8 waves x 8 chunks (4096 spheres), 1 = 4 x 8, 2 = 8 x 4 (2048), 3 = 4 x 4 (1024), 4 / 5 = 1 / 0 with all 8 chunks' loads in flight */
-	LMX_CULL_OPT_LANE_PARALLEL_TILE_TEST = 1, /* tile-level box test of the 1-frustum kernel: 0 = uniform code in every wave, 1 = one plane per lane in every wave, 2 (default) = one plane per lane in wave 0 only, verdict handed over through LDS */
+	LMX_CULL_OPT_TILE_VARIANT = 0,            /* form of the 1-frustum kernel (4 waves x 8 chunks, 2048-sphere tiles): -1 auto (default: 4 when the frustum's box overlaps < 25 % of the set's box, else 1), 1 = streaming (4 chunks' loads in flight per wave, non-temporal loads, ids staged in LDS), 4 = all 8 chunks' loads in flight (few surviving tiles: the launch is their latency) */
+	/* (1 was the tile-level-test mode of rounds 2-5: only its default form - one plane per lane in wave 0, verdict through LDS - is left) */
 	LMX_CULL_OPT_MAX_SHARDS = 2,              /* output shards (reservation counters) per renderable type, 1..64 (default 64) */
 	LMX_CULL_OPT_COUNTER_PAD = 3,             /* 32-bit words between two shard counters, 1..64 (default 32 = one 128-byte line each) */
 	LMX_CULL_OPT_AUTO_COMPACTION = 4,         /* 1 (default): the sorted set is re-built (O(n log n) on the host, ~0.5 s at 10 M) when the overflow set exceeds max(COMPACTION_MIN, n/8) or the tombstones max(COMPACTION_MIN, n/4); 0: never on its own - the host calls lmx_cull_compact when a hitch is acceptable */

@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("LMX_LIB_PATH") or os.path.join(PKG, "liblumix_mi355.s
 
 MAX_FRUSTA, MAX_TYPES, MAX_VIEWS = 8, 8, 8
 TYPE_ALL = 0xFF
-CULL_OPT_TILE_VARIANT, CULL_OPT_LANE_PARALLEL_TILE_TEST, CULL_OPT_MAX_SHARDS, CULL_OPT_COUNTER_PAD, CULL_OPT_AUTO_COMPACTION, CULL_OPT_DEVICE_OWNS_BOUND, CULL_OPT_OVERFLOW_RESERVE, CULL_OPT_ASYNC_COMPACTION, CULL_OPT_COMPACTION_MIN, CULL_OPT_MAP_ZERO_COPY = range(10)
+CULL_OPT_TILE_VARIANT, CULL_OPT_MAX_SHARDS, CULL_OPT_COUNTER_PAD, CULL_OPT_AUTO_COMPACTION, CULL_OPT_DEVICE_OWNS_BOUND, CULL_OPT_OVERFLOW_RESERVE, CULL_OPT_ASYNC_COMPACTION, CULL_OPT_COMPACTION_MIN, CULL_OPT_MAP_ZERO_COPY = 0, 2, 3, 4, 5, 6, 7, 8, 9  # (1: retired)
 KEYS_OPT_SLOT_ORDER, KEYS_OPT_SPLIT_STATE, KEYS_OPT_WALK_SHARDS, KEYS_OPT_BLOCK_RANKS = 0, 1, 2, 3
 WORLD_OPT_FUSED_LEVELS = 0
 SKIN_OPT_INSTANCES_PER_BLOCK = 0

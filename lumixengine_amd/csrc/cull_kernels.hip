@@ -153,7 +153,7 @@ __device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, 
 // sphere_visible_d() of lmx_math.h on packed fp32: two planes per v_pk_mul_f32 / v_pk_add_f32, every product and sum rounded on its own
 // exactly like the scalar expression ((cx*nx + cy*ny) + cz*nz) + d, then t - (-r) == t + r. The all-test launch was issue-bound (69 % of
 // all SIMD cycles were VALU, profiles/r02/cull_all_test_counters_before_packed_fp32.json); the plane arithmetic is half of its VALU instructions.
-// experiment knobs (tools/cull_sweep.py over build variants; the defaults are what measured best)
+// experiment knobs (tools/build_variant.py + tools/run_workload.py; the defaults are what measured best)
 #ifndef LMX_CULL_NT_LOADS
 #define LMX_CULL_NT_LOADS 1   // the streamed spheres / ids are loaded non-temporally in the streaming tile variants (every sphere is read once per cull): cache-cold all-test launch 43.8-44.3 -> 42.8 us, back-to-back 37.0-37.4 -> 37.9 us (profiles/r03/cull_ab_variants.txt)
 #endif
@@ -247,6 +247,9 @@ static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustu
 // F == 1: the single-frustum kernel (the common case: one launch per view). F == 0: n_frusta (2..8) is a runtime value and every
 // per-frustum loop is a real loop, so registers do not scale with the number of frusta (8 unrolled copies needed 172 VGPRs and
 // 600 spilled SGPRs); FS is the stride of a chunk's visibility bits.
+#ifndef LMX_ASM_SGPR
+#define LMX_ASM_SGPR(x) "+s"(x) // an empty asm's operand that pins a wave-uniform value in a scalar register (tests/hostsim's runtime header maps it to a general register)
+#endif
 #ifndef LMX_CULL8_PROBE
 #define LMX_CULL8_PROBE 0     // timing probes of k_cull_tile<F = 0> (tools/build_variant.py; results wrong): 1 = tile-level tests only, 2 = no cell classification, 4 = no sphere tests (everything tested counts as culled), 8 = spheres / ids not fetched, 16 = nothing written
 #endif
@@ -283,22 +286,17 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 	bool any_mixed = false, any_live = false;
 	if constexpr (LANEPAR != 0) {
 		static_assert(F == 1, "the lane-parallel tile test handles one frustum");
-		uint32_t r;
-		if constexpr (LANEPAR == 2) {
-			// wave 0 alone evaluates the verdict and hands it to the others through LDS: on a launch where most tiles are rejected
-			// here, the other waves' ~80 VALU instructions each were most of what the chip executed (all-rejected launch of 4883
-			// tiles: 8.9 -> 7.3 us, the headline camera 13.1 -> 11.9 us; a launch of the same shape that does nothing takes 1.8 us,
-			// with one dependent load per block 2.8 us - tools/launch_floor_probe.hip)
-			__shared__ uint32_t s_verdict;
-			if (wave == 0) {
-				const uint32_t v = tile_status_lanes(g_tile_box + tile_index, lane);
-				if (lane == 0) s_verdict = v;
-			}
-			__syncthreads();
-			r = s_verdict;
-		} else {
-			r = tile_status_lanes(g_tile_box + tile_index, lane);
+		// wave 0 alone evaluates the verdict and hands it to the others through LDS: on a launch where most tiles are rejected
+		// here, the other waves' ~80 VALU instructions each were most of what the chip executed (all-rejected launch of 4883
+		// tiles: 8.9 -> 7.3 us, the headline camera 13.1 -> 11.9 us; a launch of the same shape that does nothing takes 1.8 us,
+		// with one dependent load per block 2.8 us - tools/launch_floor_probe.hip)
+		__shared__ uint32_t s_verdict;
+		if (wave == 0) {
+			const uint32_t v = tile_status_lanes(g_tile_box + tile_index, lane);
+			if (lane == 0) s_verdict = v;
 		}
+		__syncthreads();
+		const uint32_t r = s_verdict;
 		st_bits = r & 3u;
 		tile_flags = (r >> 2) & 63u;
 		plane_skip = __builtin_amdgcn_readfirstlane((r >> 8) & 63u);
@@ -517,7 +515,8 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 	static_assert(CHW * 64 <= 1023, "a wave's count per frustum fits 10 bits");
 	// 1-frustum kernels: the wave's visible ids (and slots) are compacted in LDS as they are found - the write-out below is then a
 	// handful of full-width stores instead of one partial-width store per chunk (156 k of them on a launch with 43 % visible)
-	constexpr bool STAGE = F == 1 && GRP < CHW && LMX_CULL_STAGE_IDS != 0; // streaming variants only (as the non-temporal loads): the latency variant pays for the extra LDS and the wait at the wave's end
+	constexpr bool STREAMING = F == 1 && LANEPAR == 2; // (template slot 5: 0 = several frusta, 1 = one frustum, latency form, 2 = one frustum, streaming form)
+	constexpr bool STAGE = STREAMING && LMX_CULL_STAGE_IDS != 0; // streaming variants only (as the non-temporal loads): the latency variant pays for the extra LDS and the wait at the wave's end
 	__shared__ int32_t s_stage_ids[STAGE ? WAVES : 1][STAGE ? CHW * 64 : 1];
 	__shared__ int32_t s_stage_slots[STAGE && SLOTS ? WAVES : 1][STAGE && SLOTS ? CHW * 64 : 1];
 	uint32_t staged = 0; // wave-uniform
@@ -525,64 +524,81 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 	for (int g = 0; g < CHW; g += GRP) {
 		__builtin_amdgcn_sched_barrier(0); // keep the groups' loads from being hoisted over each other (register peak)
 		uint32_t local[GRP];
-		uint32_t cls_word[F != 1 ? GRP : 1]; // (several frusta) the lane's cell under every frustum
-		bool need_id[GRP], need_sphere[GRP];
+		uint32_t cls_word[GRP]; // the class of the lane's cell: one frustum - the CellClass itself; several - 2 bits per frustum
+		// bit i: chunk i of the group has a lane in a live cell (its ids are needed) / in a CELL_TEST cell (its spheres are). Wave-uniform, ONE scalar
+		// register each (GRP bools of this kind live as GRP 64-bit lane masks: 16 scalar registers of a kernel that sits at its limit of 80)
+		uint32_t need_id_bits = 0, need_sphere_bits = 0;
+		// The group's chunk headers, then the classes of the lanes' cells, each as ONE batch: all headers requested (they are adjacent: a
+		// 64-byte scalar load for four chunks) before the first is used, all class reads issued before the first is looked at. Round 5 had
+		// header -> wait -> LDS read -> wait per chunk inside one `if (any_mixed)` per chunk: 2 x GRP serialised round trips in front of the
+		// group's first sphere load (seen in the ISA, profiles/r06/cull1_isa_before_after.txt), and the class read again in front of every test.
+		if (any_mixed) {
+			ChunkHdr hdr_g[GRP];
+#pragma unroll
+			for (int i = 0; i < GRP; ++i) hdr_g[i] = g_hdr[chunk0 + g + i]; // wave-uniform
+#pragma unroll
+			for (int i = 0; i < GRP; ++i) local[i] = hdr_g[i].cell + mbcnt64(hdr_g[i].flags >> 1) - first_cell; // cell boundaries at positions 1..lane: two v_mbcnt on a wave-uniform mask
+#pragma unroll
+			for (int i = 0; i < GRP; ++i) cls_word[i] = F != 1 ? s_word[local[i]] : s_info[local[i]].cls;
+			if constexpr (F == 1) { // one frustum: from here on a lane's cell is the byte offset of its 32-byte record, with the class in the free low bits (ONE register per chunk)
+#pragma unroll
+				for (int i = 0; i < GRP; ++i) cls_word[i] |= local[i] << 5;
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < GRP; ++i) {
+				local[i] = 0;
+				cls_word[i] = F != 1 ? tile_word : (uint32_t)CELL_ACCEPT; // no frustum is MIXED and at least one is ACCEPT
+			}
+		}
 #pragma unroll
 		for (int i = 0; i < GRP; ++i) {
-			bool lane_live = false, lane_test = false;
-			local[i] = 0;
-			if (any_mixed) {
-				const ChunkHdr h = g_hdr[chunk0 + g + i]; // wave-uniform: one 16-byte scalar load
-				local[i] = h.cell + mbcnt64(h.flags >> 1) - first_cell; // cell boundaries at positions 1..lane: two v_mbcnt on a wave-uniform mask
-				if constexpr (F != 1) {
-					cls_word[i] = s_word[local[i]];
-					lane_live = cls_word[i] != 0;
-					lane_test = (cls_word[i] & 0xaaaau) != 0; // CELL_TEST = 2: the odd bits
-				} else {
-					const uint32_t cls = s_info[local[i]].cls;
-					lane_live = cls != CELL_REJECT;
-					lane_test = cls == CELL_TEST;
-				}
-			} else {
-				lane_live = true; // no frustum is MIXED and at least one is ACCEPT
-				if constexpr (F != 1) cls_word[i] = tile_word;
-			}
-			need_id[i] = __ballot(lane_live) != 0;     // wave-uniform
-			need_sphere[i] = __ballot(lane_test) != 0; // wave-uniform
+			const bool lane_live = F != 1 ? cls_word[i] != 0 : (cls_word[i] & 3u) != CELL_REJECT;
+			const bool lane_test = F != 1 ? (cls_word[i] & 0xaaaau) != 0 /* CELL_TEST = 2: the odd bits */ : (cls_word[i] & 3u) == CELL_TEST;
+			// (population counts of the ballots: scalar instructions all the way - spelled as `ballot != 0 ? 1 : 0` the bits were assembled in vector registers)
+			need_id_bits |= ((uint32_t)__popcll(__ballot(lane_live)) != 0u ? 1u : 0u) << i;
+			need_sphere_bits |= ((uint32_t)__popcll(__ballot(lane_test)) != 0u ? 1u : 0u) << i;
 		}
+#define need_id(i) (((need_id_bits >> (i)) & 1u) != 0)
+#define need_sphere(i) (((need_sphere_bits >> (i)) & 1u) != 0)
 		float4 sp[GRP];
 		typedef float v4f __attribute__((ext_vector_type(4)));
 		v4f spv[F != 1 ? GRP : 1]; // (several frusta) the spheres as register tuples
 #pragma unroll
 		for (int i = 0; i < GRP; ++i) {
 			const uint32_t e = ((chunk0 + g + i) << 6) + lane;
-			id[g + i] = -1;
-			sp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 			if constexpr (F != 1) {
-				// Several frusta: the loads are UNCONDITIONAL. Under `if (need_sphere[i])` each load's destination merges with the zeros of the
+				// Several frusta: the loads are UNCONDITIONAL. Under `if (need_sphere(i))` each load's destination merges with the zeros of the
 				// other branch, the compiler resolved that with copies right behind the load - and an s_waitcnt vmcnt(0) in front of them, i.e.
 				// in front of the next chunk's loads: four serialised round trips to memory per wave (seen in the ISA; the 1-frustum kernels
 				// issue all their loads first). A chunk that needs nothing reads one 16-byte sphere / one id at a wave-uniform address instead
 				// (the wave's first entity: one cache line, usually the one its neighbour chunk fetches anyway) and ignores the value.
 				const uint32_t e0 = chunk0 << 6;
 				if (LMX_CULL8_PROBE & 8) { id[g + i] = (int32_t)e; sp[i] = make_float4(1.f, 2.f, 3.f, 4.f); continue; } // (timing probe: nothing fetched)
-				id[g + i] = g_ids[need_id[i] ? e : e0];
-				sp[i] = g_spheres[need_sphere[i] ? e : e0];
+				id[g + i] = g_ids[need_id(i) ? e : e0];
+				sp[i] = g_spheres[need_sphere(i) ? e : e0];
 				continue;
 			}
+			// One frustum: the loads are UNCONDITIONAL too (round 6). Under `if (need_sphere(i))` every load cost a branch, five moves for the zeros of the
+			// other arm and a 64-bit address of its own, and the first test waited for ALL of the group's loads (the compiler cannot count loads behind
+			// branches): ~12 of a chunk's ~63 vector instructions on a launch bound by their issue (profiles/r06/cull1_probes.txt). Now: the group's
+			// uniform base + ONE lane offset + an immediate per chunk; a chunk that needs nothing reads one line at lane offset 0 and ignores it (its
+			// lanes' classes are CELL_REJECT: whatever the registers hold, nothing of it is visible).
+			const uint32_t off_i = (lane * 4u) & (0u - ((need_id_bits >> i) & 1u)), off_s = (lane * 16u) & (0u - ((need_sphere_bits >> i) & 1u)); // (bytes: one select each)
+			const int32_t* id_at = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(g_ids + ((size_t)(chunk0 + g) << 6) + i * 64) + off_i);
+			const v4f* sp_at = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(g_spheres + ((size_t)(chunk0 + g) << 6) + i * 64) + off_s);
+			v4f t;
 #if LMX_CULL_NT_LOADS
-			if constexpr (GRP < CHW) { // the streaming variants: every sphere is read once per cull and nothing of it is reused
-				if (need_id[i]) id[g + i] = __builtin_nontemporal_load(g_ids + e);
-				if (need_sphere[i]) {
-					const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g_spheres) + e);
-					sp[i] = make_float4(t.x, t.y, t.z, t.w);
-				}
+			if constexpr (F == 1 && LANEPAR == 2) { // the streaming form: every sphere is read once per cull and nothing of it is reused
+				id[g + i] = __builtin_nontemporal_load(id_at);
+				t = __builtin_nontemporal_load(sp_at);
 			} else
 #endif
 			{
-				if (need_id[i]) id[g + i] = g_ids[e];
-				if (need_sphere[i]) sp[i] = g_spheres[e];
+				id[g + i] = *id_at;
+				t = *sp_at;
 			}
+			sp[i] = make_float4(t.x, t.y, t.z, t.w);
 		}
 		if constexpr (F != 1) {
 			// (the values pass through here together: all eight loads are in flight before the first wait)
@@ -594,7 +610,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 			}
 #pragma unroll
 			for (int i = 0; i < GRP; ++i) {
-				if (!need_id[i]) id[g + i] = -1; // (wave-uniform select behind the loads)
+				if (!need_id(i)) id[g + i] = -1; // (wave-uniform select behind the loads)
 			}
 			uint32_t culled2[GRP]; // bit 2f: frustum f culls the lane's sphere of chunk i (read where the cell's class is CELL_TEST)
 #pragma unroll
@@ -610,7 +626,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 					exact_chunks = 0;
 #pragma unroll
 					for (int i = 0; i < GRP; ++i) {
-						if (!need_sphere[i]) continue; // wave-uniform
+						if (!need_sphere(i)) continue; // wave-uniform
 						const float x = spv[i].x, y = spv[i].y, z = spv[i].z, r = spv[i].w;
 						// eps of the lane's own sphere (the bound above; formed 2^27 too large so that huge operands end in inf)
 						const float gs = ((__builtin_fabsf(x) + __builtin_fabsf(y)) + __builtin_fabsf(z)) * a.pretest_n1s + __builtin_fabsf(r) * 134217728.0f;
@@ -699,7 +715,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 				if (mixed) {
 #pragma unroll
 					for (int i = 0; i < GRP; ++i) {
-						if (need_sphere[i] && ((exact_chunks >> i) & 1u) && __ballot(((cls_word[i] >> (2 * f)) & 3u) == CELL_TEST) != 0) test_chunks |= 1u << i;
+						if (need_sphere(i) && ((exact_chunks >> i) & 1u) && __ballot(((cls_word[i] >> (2 * f)) & 3u) == CELL_TEST) != 0) test_chunks |= 1u << i;
 					}
 				}
 				// the frustum's plane normals out of LDS (phase 0 put them there), every lane the same address: a broadcast read. (From the
@@ -761,43 +777,64 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 				vis2[g + i] = id[g + i] >= 0 ? v : 0u;
 			}
 		} else {
-#pragma unroll 1
-		for (int f = 0; f < nf; ++f) {
-			const uint32_t st = (st_bits >> (2 * f)) & 3u;
+			// One frustum. The lanes' classes are in registers since the header batch; the cell records (six plane distances each) of the chunks that
+			// test are read DB chunks at a time, ahead of the arithmetic, so that no test waits for LDS behind the wait for its sphere (round 5: class
+			// read -> wait -> branch -> record read + 16-dword scalar load of the planes -> wait, per chunk: with every wave of a SIMD in that
+			// pattern the vector unit idled half the time on a launch whose loads were free, profiles/r06/cull1_probes.txt). The test runs on every
+			// lane of a chunk that has a CELL_TEST lane (the records of the other cells hold zeros) and the class selects the verdict: no divergent branch.
+			constexpr int DB = GRP < CHW ? 2 : 1; // records in flight (six registers per chunk; the latency form has all eight chunks' spheres live)
+			// the frustum's plane normals, read ONCE per group and pinned in scalar registers (the compiler otherwise re-reads all 18 from the kernarg
+			// segment in front of every chunk's arithmetic - cheap to issue, but a scalar-cache round trip that nothing hides once the spheres are in)
+			DevFrustum fn; // (only nx / ny / nz are used)
+			if (need_sphere_bits != 0) {
 #pragma unroll
-			for (int i = 0; i < GRP; ++i) {
-				if (!need_id[i]) continue;
-				bool vis;
-				if (any_mixed) {
-					const CellInfo* ci = &s_info[f * a.cell_cap + local[i]];
-					const uint32_t cls = ci->cls;
-					vis = cls == CELL_ACCEPT;
-					if (cls == CELL_TEST) {
-						float d[6];
-#pragma unroll
-						for (int k = 0; k < 6; ++k) d[k] = ci->d[k];
-						vis = sphere_visible_d_pk(frp[f], d, sp[i].x, sp[i].y, sp[i].z, sp[i].w);
-					}
-				} else {
-					vis = st == TILE_ACCEPT;
+				for (int k = 0; k < 6; ++k) {
+					fn.nx[k] = frp[0].nx[k]; fn.ny[k] = frp[0].ny[k]; fn.nz[k] = frp[0].nz[k];
+					asm volatile("" : LMX_ASM_SGPR(fn.nx[k]), LMX_ASM_SGPR(fn.ny[k]), LMX_ASM_SGPR(fn.nz[k]));
 				}
-				vis = vis && id[g + i] >= 0;
-				if constexpr (STAGE) {
-					const uint64_t mask = __ballot(vis);
-					if (vis) {
-						s_stage_ids[wave][staged + mbcnt64(mask)] = id[g + i];
-						if constexpr (SLOTS) s_stage_slots[wave][staged + mbcnt64(mask)] = (int32_t)(((chunk0 + g + i) << 6) + lane);
+			}
+			static_assert(CELL_REJECT == 0 && CELL_ACCEPT == 1 && CELL_TEST == 2, "class encoding");
+#pragma unroll
+			for (int h = 0; h < GRP; h += DB) {
+				v4f d03[DB];
+				v2f d45[DB];
+#pragma unroll
+				for (int j = 0; j < DB; ++j) {
+					// (unconditional: a lane's offset is always that of a record of this tile - of record 0 on a tile without classified cells - and what a
+					// chunk without a CELL_TEST lane reads is never looked at; behind `if (need_sphere)` the other arm's zeros were six moves per chunk)
+					const char* ci = reinterpret_cast<const char*>(s_info) + (cls_word[h + j] & ~31u);
+					d03[j] = *reinterpret_cast<const v4f*>(ci); // d[0..3]: ds_read_b128, d[4..5]: ds_read_b64
+					d45[j] = *reinterpret_cast<const v2f*>(ci + 16);
+				}
+#pragma unroll
+				for (int j = 0; j < DB; ++j) {
+					const int i = h + j;
+					if (!need_id(i)) continue; // wave-uniform
+					bool vis = (cls_word[i] & 3u) == CELL_ACCEPT;
+					if (need_sphere(i)) {
+						const float d[6] = {d03[j].x, d03[j].y, d03[j].z, d03[j].w, d45[j].x, d45[j].y};
+						const bool pass = sphere_visible_d_pk(fn, d, sp[i].x, sp[i].y, sp[i].z, sp[i].w);
+						vis = vis || ((cls_word[i] & 3u) == CELL_TEST && pass);
 					}
-					staged += (uint32_t)__popcll(mask);
-				} else {
-					const uint32_t c = (uint32_t)__popcll(__ballot(vis));
-					mine += lane == (uint32_t)f ? c : 0u;
-					vis_bits |= (vis ? 1u : 0u) << ((g + i) * FS + f);
+					vis = vis && id[g + i] >= 0;
+					if constexpr (STAGE) {
+						const uint64_t mask = __ballot(vis);
+						if (vis) {
+							s_stage_ids[wave][staged + mbcnt64(mask)] = id[g + i];
+							if constexpr (SLOTS) s_stage_slots[wave][staged + mbcnt64(mask)] = (int32_t)(((chunk0 + g + i) << 6) + lane);
+						}
+						staged += (uint32_t)__popcll(mask);
+					} else {
+						const uint32_t c = (uint32_t)__popcll(__ballot(vis));
+						mine += lane == 0u ? c : 0u;
+						vis_bits |= (vis ? 1u : 0u) << ((g + i) * FS);
+					}
 				}
 			}
 		}
-		}
 	}
+#undef need_id
+#undef need_sphere
 	if constexpr (F != 1) {
 		// Per-frustum counts of the wave, lane f keeps frustum f's. A lane's four chunks are summed in packed fields first (a verdict bit per
 		// 2-bit field: two words of sums <= 2, then nibbles <= 4 for the even and the odd frusta, spread to 16-bit fields), the four words are
@@ -1134,28 +1171,21 @@ size_t cull_tile_lds_bytes(int n_frusta, uint32_t cell_cap) { // several frusta:
 }
 
 uint32_t cull_tile_size(int n_frusta, int variant) {
-	if (n_frusta <= 1) return (variant == 0 || variant == 5) ? 4096u : (variant == 3 ? 1024u : 2048u);
+	(void)variant; // (both forms of the 1-frustum kernel walk 2048-sphere tiles)
 	return n_frusta <= 4 ? 2048u : 1024u;
 }
 
+// The 1-frustum kernel exists in two forms, both 4 waves x 8 chunks (2048-sphere tiles) with the tile-level test on the lanes of wave 0:
+// variant 1 streams (two groups of four chunks, non-temporal loads, LDS-staged ids), variant 4 keeps all eight chunks' loads in flight (the
+// latency form: launches in which few tiles survive the tile-level test). Rounds 2-5 carried four more tile shapes and two more forms of
+// the tile-level test that no selection rule ever picked: removed with their test parametrisations.
 hipError_t launch_cull_tile(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt, const FrustaArg& fr,
-	int n_frusta, const CullOut& out, int variant, int lane_parallel_status) {
+	int n_frusta, const CullOut& out, int variant) {
 #define LMX_TILE(F, W, C, G, L) return out.slots ? tile_f<F, W, C, G, L, 1>(s, v, ent_begin, ent_end, tt, fr, n_frusta, out) : tile_f<F, W, C, G, L, 0>(s, v, ent_begin, ent_end, tt, fr, n_frusta, out)
 	if (n_frusta < 1 || n_frusta > MAX_FRUSTA) return hipErrorInvalidValue;
 	if (n_frusta == 1) {
-#define LMX_TILE_VARIANTS(L) \
-		switch (variant) { \
-			case 0: LMX_TILE(1, 8, 8, 4, L); \
-			case 1: LMX_TILE(1, 4, 8, 4, L); \
-			case 2: LMX_TILE(1, 8, 4, 4, L); \
-			case 3: LMX_TILE(1, 4, 4, 4, L); \
-			case 4: LMX_TILE(1, 4, 8, 8, L); \
-			default: LMX_TILE(1, 8, 8, 8, L); \
-		}
-		if (lane_parallel_status == 2) LMX_TILE_VARIANTS(2)
-		if (lane_parallel_status == 1) LMX_TILE_VARIANTS(1)
-		LMX_TILE_VARIANTS(0)
-#undef LMX_TILE_VARIANTS
+		if (variant == 4) LMX_TILE(1, 4, 8, 8, 1);
+		LMX_TILE(1, 4, 8, 4, 2); // (all eight chunks in flight in the streaming form as well: 41.0 vs 37.9 us on the all-test launch, profiles/r06/cull1_ab_grp8.txt)
 	}
 	if (n_frusta <= 4) LMX_TILE(0, 8, 4, 4, 0); // 2048-sphere tiles, <= 4 x 32 B of LDS per cell
 	LMX_TILE(0, 4, 4, 4, 0);                    // 1024-sphere tiles

@@ -1467,7 +1467,7 @@ int lmx_cull(LmxContext* ctx, uint32_t view, const LmxShiftedFrustum* frusta, ui
 		ProfScope ps(ctx, LMX_K_CULL_SPHERES, true);
 		po.ev_start = ps.slot.a;
 		po.ev_stop = ps.slot.b;
-		const hipError_t launched = launch_cull_tile(ctx->stream, dv, ent_begin, ent_end, cs.tt, sub, (int)fw, po, variant, cs.lane_parallel);
+		const hipError_t launched = launch_cull_tile(ctx->stream, dv, ent_begin, ent_end, cs.tt, sub, (int)fw, po, variant);
 		if (launched != hipSuccess) ps.cancel(); // (the launch fills the scope's events itself: none were recorded)
 		LMX_HIP(ctx, launched);
 	}
@@ -1496,12 +1496,8 @@ int lmx_cull_set_option(LmxContext* ctx, int option, int value) {
 	CullState& cs = ctx->cull;
 	switch (option) {
 		case LMX_CULL_OPT_TILE_VARIANT:
-			if (value < -1 || value > 5) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "tile variant %d not in [-1,5]", value);
+			if (value != -1 && value != 1 && value != 4) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "tile variant %d: -1 (auto), 1 (streaming) or 4 (all loads in flight)", value);
 			cs.tile_variant = value;
-			return LMX_OK;
-		case LMX_CULL_OPT_LANE_PARALLEL_TILE_TEST:
-			if (value < 0 || value > 2) return fail(ctx, LMX_ERR_INVALID_ARGUMENT, "tile test mode %d not in [0,2]", value);
-			cs.lane_parallel = value;
 			return LMX_OK;
 		case LMX_CULL_OPT_AUTO_COMPACTION: cs.auto_compaction = value != 0; return LMX_OK;
 		case LMX_CULL_OPT_COMPACTION_MIN:

@@ -271,7 +271,6 @@ struct CullState : CullSet {
 	CullAsync* async = nullptr;  // LMX_CULL_OPT_ASYNC_COMPACTION: shadow set + worker thread (owned; lmx_capi_cull.hip)
 	bool emit_slots = false;     // culls also write the static-set slot of every visible id (switched on by the sort-key tables' slot-ordered mirror)
 	uint64_t layout_generation = 0; // a process-wide unique number per build of the static layout (consumers that mirror it by slot compare)
-	int lane_parallel = 2;     // tile-level box test of the 1-frustum kernels: 0 = uniform code in every wave, 1 = one plane per lane in every wave, 2 = one plane per lane in wave 0, verdict through LDS
 	uint32_t max_shards = LAYOUT_MAX_SHARDS; // output shards per type of the static set
 	uint32_t cnt_pad = 32;     // words between shard counters (32 = one 128-byte line each)
 	uint32_t out_total = 0;    // ids per frustum row = sum of the shard capacities

@@ -70,14 +70,12 @@ struct CullOut {
 	int32_t* slots = nullptr;
 };
 
-// k_cull_tile over the static set's slots [ent_begin, ent_end) (multiples of TILE_ALIGN). `variant` picks the tile shape of the
-// 1-frustum kernel: 0 = 8 waves x 8 chunks (4096), 1 = 4 x 8 (2048), 2 = 8 x 4 (2048), 3 = 4 x 4 (1024) with 4 chunks' loads in flight per
-// wave, 4 = 4 x 8 and 5 = 8 x 8 with all 8 in flight; ignored for n_frusta > 1.
-// lane_parallel_status: the tile-level box test is evaluated one plane per lane (1-frustum kernels only).
+// k_cull_tile over the static set's slots [ent_begin, ent_end) (multiples of TILE_ALIGN). `variant` picks the form of the 1-frustum kernel
+// (both: 4 waves x 8 chunks, 2048-sphere tiles): 1 = streaming (4 chunks' loads in flight per wave), 4 = all 8 in flight; ignored for n_frusta > 1.
 size_t cull_tile_lds_bytes(int n_frusta, uint32_t cell_cap);
 uint32_t cull_tile_size(int n_frusta, int variant);
 hipError_t launch_cull_tile(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt,
-	const FrustaArg& fr, int n_frusta, const CullOut& out, int variant, int lane_parallel_status);
+	const FrustaArg& fr, int n_frusta, const CullOut& out, int variant);
 
 // Dynamic set: entities whose transform changes every frame (bound to the world hierarchy) and entities added / re-celled since
 // the last compaction of the static set are kept UNSORTED as world position (fp64) + radius + id. Their cell, cell-relative

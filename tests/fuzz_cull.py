@@ -104,8 +104,7 @@ def run(seed: int, steps: int, oracle, verbose: bool = False) -> dict:
             type_ = 0xFF if rng.random() < 0.7 else int(rng.integers(0, 8))
             view = int(rng.integers(0, 3))
             if rng.random() < 0.5:
-                cs.setOption(api.CULL_OPT_TILE_VARIANT, int(rng.integers(-1, 6)))
-                cs.setOption(api.CULL_OPT_LANE_PARALLEL_TILE_TEST, int(rng.integers(0, 3)))
+                cs.setOption(api.CULL_OPT_TILE_VARIANT, int(rng.choice([-1, 1, 4])))
             if rng.random() < 0.3:
                 cs.setPassWidth(int(rng.integers(1, 9)))
             res = cs.cull(fr, type_, view)

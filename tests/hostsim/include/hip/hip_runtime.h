@@ -40,6 +40,7 @@
 #define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 #define amdgpu_waves_per_eu(...) /* __attribute__((amdgpu_waves_per_eu(n))) of a kernel: an empty attribute here */
+#define LMX_ASM_SGPR(x) "+r"(x) /* the "+s" (scalar register) operand of an empty asm: any general register here */
 #define __shared__ static thread_local
 // `extern __shared__ T name[];` (dynamic LDS) is spelled LMX_DYNAMIC_LDS(T, name) in the kernels; here it is a pointer to the
 // launch's dynamic LDS block

@@ -66,6 +66,30 @@ def test_cull_config1_golden(gpu_ctx):
         assert all(len(p) == 1020 for p in pages[:-1]) and sum(len(p) for p in pages) == len(g[f"vis_ids_{f}"])
 
 
+def test_cull_both_kernel_forms_match_golden(gpu_ctx):
+    """The two forms of the 1-frustum kernel (LMX_CULL_OPT_TILE_VARIANT 1 = streaming, 4 = all loads in flight; -1 picks by how much of the set
+    the frustum covers) on the config-1 fixture: rejected, accepted, dense and mixed tiles all occur under its cameras. The tile shapes of rounds
+    2-5 that no rule ever selected are gone: asking for one is an error."""
+    g = np.load(os.path.join(G, "cull_config1.npz"))
+    sc = scenes.cull_scene(100_000, 3000.0, seed=1)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    frusta = g["frusta"]
+    try:
+        for variant in (1, 4, -1):
+            cs.setOption(api.CULL_OPT_TILE_VARIANT, variant)
+            for f in range(len(frusta)):
+                res = cs.cull(np.ascontiguousarray(frusta[f : f + 1]))
+                H.assert_same_visible(gpu_visible(res, 0), H.sorted_by_type(g[f"vis_ids_{f}"], g[f"vis_types_{f}"]), f"variant {variant} camera {f}")
+    finally:
+        cs.setOption(api.CULL_OPT_TILE_VARIANT, -1)
+    for gone in (0, 2, 3, 5):
+        with pytest.raises(api.LumixError):
+            cs.setOption(api.CULL_OPT_TILE_VARIANT, gone)
+    with pytest.raises(api.LumixError):
+        cs.setOption(1, 0)  # (the retired tile-level-test option)
+
+
 def test_cull_type_filter_and_views(gpu_ctx, oracle_port):
     sc = H.mixed_scene()
     cs = api.CullingSystem(gpu_ctx)
@@ -259,15 +283,12 @@ def test_cull_config2_10m_bit_exact(gpu_ctx, scene):
     for cam, fr in cams:
         check(cs.cull(fr), rec["cameras"][cam], cam)
     try:
-        for variant in range(6):
-            for lanepar in (0, 1):
-                cs.setOption(api.CULL_OPT_TILE_VARIANT, variant)
-                cs.setOption(api.CULL_OPT_LANE_PARALLEL_TILE_TEST, lanepar)
-                for cam, fr in cams:
-                    if cam in ("default", "narrow", "all_visible"):
-                        check(cs.cull(fr, view=1), rec["cameras"][cam], f"{cam} variant {variant} lane-parallel {lanepar}")
+        for variant in (1, 4):  # the two forms of the 1-frustum kernel
+            cs.setOption(api.CULL_OPT_TILE_VARIANT, variant)
+            for cam, fr in cams:
+                if cam in ("default", "narrow", "all_visible"):
+                    check(cs.cull(fr, view=1), rec["cameras"][cam], f"{cam} variant {variant}")
         cs.setOption(api.CULL_OPT_TILE_VARIANT, -1)
-        cs.setOption(api.CULL_OPT_LANE_PARALLEL_TILE_TEST, 1)
         for shards, pad in ((1, 1), (7, 16), (64, 32)):
             cs.setOption(api.CULL_OPT_MAX_SHARDS, shards)
             cs.setOption(api.CULL_OPT_COUNTER_PAD, pad)
@@ -275,7 +296,6 @@ def test_cull_config2_10m_bit_exact(gpu_ctx, scene):
             check(cs.cull(cams[0][1], view=2), rec["cameras"]["default"], f"{shards} shards, pad {pad}")
     finally:
         cs.setOption(api.CULL_OPT_TILE_VARIANT, -1)
-        cs.setOption(api.CULL_OPT_LANE_PARALLEL_TILE_TEST, 1)
         cs.setOption(api.CULL_OPT_MAX_SHARDS, 64)
         cs.setOption(api.CULL_OPT_COUNTER_PAD, 32)
     if not mixed:
@@ -367,7 +387,7 @@ def test_cull_slab_all_cell_test_digest(gpu_ctx):
     assert cs.stats()["cells"] == rec["cells"]
     fr = api.viewport_frustum(**scenes.slab_frustum_kwargs(sc["half"]))
     try:
-        for variant in (-1, 0, 1, 2, 3, 4, 5):
+        for variant in (-1, 1, 4):
             cs.setOption(api.CULL_OPT_TILE_VARIANT, variant)
             _check_digest(cs.cull(fr), rec["cameras"]["slab"], f"slab variant {variant}")
     finally:

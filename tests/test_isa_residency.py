@@ -51,7 +51,10 @@ def test_cull_tile_register_budgets(tmp_path):
     meta = metadata("cull_kernels.hip", tmp_path)
     # k_cull_tile<F = 1, 4 waves, 8 chunks, GRP, lane-parallel verdict by wave 0, no slots>: GRP 8 = the latency variant (headline camera),
     # GRP 4 = the streaming variant (roofline legs)
-    for tag, max_vgpr in (("k_cull_tileILi1ELi4ELi8ELi8ELi2ELi0E", 64), ("k_cull_tileILi1ELi4ELi8ELi4ELi2ELi0E", 48)):
+    # (round 6: the latency form keeps every chunk's cell-record offset + class in a register next to its eight chunks' spheres and ids: 68 VGPRs = 7 waves
+    # per SIMD instead of 8. It runs where few tiles survive the tile-level test - the launch is the latency of the survivors, not their number:
+    # 10.8 vs 11.0 us on the headline camera against round 5's 60-VGPR form, profiles/r06/cull1_ab_restructured.txt)
+    for tag, max_vgpr in (("k_cull_tileILi1ELi4ELi8ELi8ELi1ELi0E", 72), ("k_cull_tileILi1ELi4ELi8ELi4ELi2ELi0E", 48)):
         for k in pick(meta, tag):
             assert k["private_segment_fixed_size"] == 0, (tag, k)
             assert k["next_free_sgpr"] <= 80, f"{tag}: {k['next_free_sgpr']} SGPRs - 8 resident blocks per CU need <= 80"

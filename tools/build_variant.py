@@ -4,7 +4,7 @@ other objects of the regular build.
 
     python tools/build_variant.py <name> <source.hip>[,<source2.hip>...] "<extra hipcc flags>"     ->  tools/_build/variants/<name>/liblumix_mi355.so
 
-Use with LMX_LIB_PATH=<that file> (lumixengine_amd/api.py) - e.g. tools/cull_sweep.py, tools/run_workload.py, bench.py."""
+Use with LMX_LIB_PATH=<that file> (lumixengine_amd/api.py) - e.g. tools/run_workload.py, bench.py."""
 import os
 import subprocess
 import sys

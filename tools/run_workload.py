@@ -72,8 +72,6 @@ def main():
             sc = scenes.slab_scene(args.entities, seed=2)
         cs = api.CullingSystem(ctx)
         cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
-        if "LMX_TILE_TEST_MODE" in os.environ:
-            cs.setOption(api.CULL_OPT_LANE_PARALLEL_TILE_TEST, int(os.environ["LMX_TILE_TEST_MODE"]))
         if "LMX_TILE_VARIANT" in os.environ:
             cs.setOption(api.CULL_OPT_TILE_VARIANT, int(os.environ["LMX_TILE_VARIANT"]))
         if args.workload == "cull_stream" or os.environ.get("LMX_WORKLOAD_CAMERA") == "far":
