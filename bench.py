@@ -527,6 +527,12 @@ def main(argv=None):
         "avg_launch_ms_is": "mean over the leg's launches of hipEventElapsedTime on the event pair the launch itself fills (hipExtLaunchKernelGGL start / stop events on the launch stream): the dispatch's begin -> end, as in rocprofv3's kernel trace",
         "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,  # measured in THIS run (not the guide's figure): 1 GiB float4 copy, read + written bytes
         "frac_of_measured_copy": round(roof_gbps / copy_gbps, 4) if copy_gbps else None,
+        # the same kernel's weaker relatives, in the record: NORMAL radii, every cell classified CELL_TEST by the AABB pre-tests
+        # (slab scene, cache-cold; its algorithmic bytes include 4 B per visible id, 43 % visible), and the all-test launch behind a DIRTY scrub -
+        # the state the cache is in behind 12 GB of skinning stores
+        "frac_normal_radii": legs.get("all_cell_test_normal_radii", {}).get("cold_frac"),
+        "frac_dirty_cache": legs.get("all_test", {}).get("cold_after_dirty_scrub_frac"),
+        "read_ceiling_note": "a pure read of the same 20 B per entity in the kernel's access pattern reaches 0.80 of the 8 TB/s peak at 10 M entities and 0.86 at 100 M (tools/read_probe.hip, profiles/r06/read_probe_cull_footprint.txt)",
         "legs": legs,
     }
 
@@ -772,7 +778,8 @@ def exchange_checks_and_frames(args, api, scenes, D, dev, ctx, cs, sc, xchg, ste
 
 # ---- the one stdout line -------------------------------------------------------------------------------------------------------
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
-ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "measured_copy_GBps", "frac_of_measured_copy", "leg")
+ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "measured_copy_GBps", "frac_of_measured_copy", "frac_normal_radii",
+                 "frac_dirty_cache", "leg")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "host_cores", "single_thread_value", "error")
 CONFIG_KEYS = ("workload", "entities_per_gpu", "frusta", "visible_per_gpu", "visible_ids", "sharding", "timed_steps", "repetitions", "exchange_mode", "exchange_gather_us", "exchange_gather_record_bytes",
                "exchange_bytes_shipped_per_rank", "exchange_bytes_used_per_rank", "exchange_bytes_arriving_per_rank", "exchange_overflow_mask", "ranks_seen_by_rccl",
@@ -797,7 +804,7 @@ def compact_line(result):
                 line["config"][frame]["exchange"] = {k: f["exchange"][k] for k in ("mode", "bytes_shipped_per_peer", "bytes_used_this_rank", "shipped_over_used", "gather_us_of_this_record", "overflow_mask") if k in f["exchange"]}
     line["roofline"] = {k: _short(result["roofline"].get(k), 160) for k in ROOFLINE_KEYS}
     if "cpu_baseline" in result:
-        line["cpu_baseline"] = {k: _short(result["cpu_baseline"][k], 260) for k in CPU_KEYS if k in result["cpu_baseline"]}
+        line["cpu_baseline"] = {k: _short(result["cpu_baseline"][k], 340) for k in CPU_KEYS if k in result["cpu_baseline"]}
     also = {}
     for k in ("value_cull_only", "value_incl_host_readback", "value_streaming"):
         if k in result:
@@ -1079,8 +1086,8 @@ class CpuBaseline:
             "unit": "entities/s",
             "cores": best,
             "kind": self.kind,
-            "sample": f"the full headline workload ({n} entities, same scene and frustum as the GPU run): median of {sweep[best]['culls']} culls; cores_used {best} of host_cores {host} - "
-                      f"the best of the thread sweep {list(sweep)}: more threads are SLOWER here, the reference pushes all {pages} CullResult pages of a cull through one mutexed PageAllocator",
+            "sample": f"full headline workload ({n} entities, same scene + frustum as the GPU run), median of {sweep[best]['culls']} culls on {best} of {host} cores = best of thread sweep {list(sweep)}: more threads are slower "
+                      f"({pages} result pages through ONE mutexed PageAllocator; Mutex / job threads are pthread stand-ins - the sweep's shape may be theirs, not the engine's)",
             "host_cores": host,
             "thread_sweep": {str(k): v for k, v in sweep.items()},
             "single_thread_value": sweep[1]["entities_per_s"],
