@@ -811,9 +811,10 @@ def compact_line(result):
             also[k] = result[k]
     ex = result.get("extra", {})
     for k in ("skinned_verts_per_sec", "transforms_per_sec", "target_frames_per_sec_1gpu", "target_skinned_verts_per_sec", "target_skin_ms_per_1e9_verts", "config3_frames_per_sec",
-              "keys_kernels_ms", "xform_level_kernel_avg_ms", "xform_with_moved_list_ms", "pose_palette_kernel_avg_ms", "transform_ms_per_frame"):
+              "keys_kernels_ms", "xform_level_kernel_avg_ms", "xform_with_moved_list_ms", "pose_palette_kernel_avg_ms", "transform_ms_per_frame",
+              "skin_distinct_meshes_instances", "skin_distinct_meshes_verts_per_sec", "skin_distinct_meshes_positions", "config5_frame_1gpu_ms", "config5_frame_1gpu_is"):
         if k in ex:
-            also[k] = ex[k]
+            also[k] = _short(ex[k], 150)
     leg8 = result.get("roofline", {}).get("legs", {}).get("all_test_8_frusta_one_pass")
     if isinstance(leg8, dict) and leg8.get("cold_avg_launch_ms"):
         also["cull8_all_test_kernel_ms"] = leg8["cold_avg_launch_ms"]  # config 5's pass: 8 cascade frusta x 10 M spheres in ONE launch, every sphere tested, cache-cold

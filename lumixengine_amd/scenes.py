@@ -146,6 +146,19 @@ def relative_poses(n_instances: int, n_bones: int, seed: int = 5):
     return pos, rot
 
 
+DISTINCT_MESH_POSES = 10_000  # relative_poses() draws positions before rotations: an instance's pose depends on how many instances are drawn with it
+
+
+def distinct_mesh(base_verts, base_skin, i: int):
+    """Mesh i of BASELINE config 3's distinct-mesh variant ("10 k skinned meshes, 64 bones, 10 k verts each": every instance its OWN 10 k-vertex
+    mesh): the base mesh rotated by i vertices - different records at every vertex index, the same statistics. One definition for bench.py's leg,
+    the -m gpu test and tests/golden/make_golden_skin_distinct.py."""
+    return np.roll(base_verts, i, axis=0), np.roll(base_skin, i, axis=0)
+
+
+DISTINCT_MESH_SAMPLE = (0, 1, 2, 777, 1499, 4999, 9999)  # instances whose skinned positions the reference's digests cover (tests/golden/skin_distinct.json)
+
+
 def skinned_mesh(n_verts: int, n_bones: int = 64, seed: int = 6):
     """Vertex positions + Mesh::Skin{weights decoded from u16/65535 (model.cpp:542-550), 4 bone indices}."""
     rng = np.random.default_rng(seed)

@@ -840,6 +840,43 @@ def test_skin_full_size_digest(gpu_ctx, oracle_port, config):
         sk.setMode(api.SKIN_FUSED)
 
 
+def test_skin_distinct_meshes_sampled_digest(gpu_ctx):
+    """BASELINE config 3's distinct-mesh variant (every instance its own 10 k-vertex mesh, scenes.distinct_mesh), 1 500 instances here (bench.py runs the
+    stated 10 000 and makes the same comparison): LMX_SKIN_EXACT positions of the sampled instances, bit for bit against the digests the reference's
+    own evaluateSkin produced (tests/golden/make_golden_skin_distinct.py); LMX_SKIN_FUSED of the same instances within 1e-5 of the EXACT result."""
+    import hashlib
+    import json
+
+    g = json.load(open(os.path.join(G, "skin_distinct.json")))
+    n_inst = 1500 if os.environ.get("LMX_HOSTSIM") != "1" else 3  # (the simulated device skins three 10 k-vertex meshes in seconds, not 1500)
+    s = scenes.skeleton(g["n_bones"], seed=4)
+    verts, skin = scenes.skinned_mesh(g["n_verts"], g["n_bones"], seed=6)
+    pos, rot = scenes.relative_poses(g["poses_drawn"], g["n_bones"], seed=5)
+    assert H.array_digest(s["parents"], s["bind"], verts, skin, pos, rot) == g["inputs_sha"], "the generators' random streams differ from the ones the digests were made with"
+    sk = api.Skinning(gpu_ctx)
+    model = sk.addModel(s["parents"], s["bind"], s["first_nonroot"])
+    meshes = [sk.addMesh(*scenes.distinct_mesh(verts, skin, i)) for i in range(n_inst)]
+    sk.setInstances(np.full(n_inst, model, np.uint32), np.array(meshes, np.uint32))
+    sk.setPoseWriteback(False)
+    sample = [i for i in scenes.DISTINCT_MESH_SAMPLE if i < n_inst]
+    assert len(sample) >= min(5, n_inst)
+    try:
+        sk.setMode(api.SKIN_EXACT)
+        sk.uploadPoses(pos[:n_inst], rot[:n_inst])
+        sk.run()
+        exact = {}
+        for i in sample:
+            exact[i] = sk.readVertices(i)
+            assert hashlib.sha256(np.ascontiguousarray(exact[i], np.float32).tobytes()).hexdigest() == g["instances"][str(i)], f"instance {i} (its own mesh) differs from the reference"
+        sk.setMode(api.SKIN_FUSED)
+        sk.run()
+        for i in sample:
+            assert close_1e5(sk.readVertices(i), exact[i]), f"FUSED instance {i}"
+    finally:
+        sk.setPoseWriteback(True)
+        sk.setMode(api.SKIN_FUSED)
+
+
 @pytest.mark.parametrize("fixture", ["cull_edge.npz", "cull_mixed.npz"])
 def test_dynamic_set_matches_golden(gpu_ctx, fixture):
     """Every culling entity bound to a (flat) world: they all live in the dynamic set, get their sphere from the world

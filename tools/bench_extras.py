@@ -25,9 +25,9 @@ def extras(ctx, api, scenes, dev, timed, N, log, check_ids, big_entities=0, out=
     out = {} if out is None else out
     # sizes: the real ones, or (small) the CPU self-test's - same code path, nothing worth reading in the numbers
     Z = dict(upd=1000, add_frames=2000 if N >= 10_000_000 else 200, async_adds=300_000 if N >= 10_000_000 else 30_000, chains=250_000, skin_inst=2000, verts=10_000,
-             c3_inst=10_000, target_inst=100_000, distinct=1500, reps=1.0)
+             c3_inst=10_000, target_inst=100_000, distinct=10_000, c5_skinned=200_000, reps=1.0)
     if small:
-        Z = dict(upd=8, add_frames=6, async_adds=200, chains=200, skin_inst=3, verts=700, c3_inst=3, target_inst=5, distinct=2, reps=0.0)
+        Z = dict(upd=8, add_frames=6, async_adds=200, chains=200, skin_inst=3, verts=700, c3_inst=3, target_inst=5, distinct=2, c5_skinned=3, reps=0.0)
     R = lambda n: max(2, int(n * Z["reps"]))  # noqa: E731 - loop counts (2 in the self-test)
     # dense variant of config 2 (cube +-5000: ~37 k cells, ~270 spheres per cell)
     sc = scenes.cull_scene(N, 5000.0, seed=2)
@@ -306,6 +306,36 @@ def extras(ctx, api, scenes, dev, timed, N, log, check_ids, big_entities=0, out=
         if at_size:
             res8 = cs_b.cull(fr8b)
             big["cascades_8_frusta"]["visible_ids"] = [check_ids(res8, "config5_100m", f"cascade{k}", frustum=k) for k in range(8)]
+        # BASELINE config 5 as ONE single-GPU frame (round 6): the 100 M entities under the frame's 8 cascade frusta + the skinned share. The config's
+        # "mixed static/skinned" scene has 1 % of its entities skinned - 1 M instances x 10 k vertices = 120 GB of positions per frame, which one GPU holds
+        # but no frame budget does; the share is SCALED to Z["c5_skinned"] instances (200 k = 0.2 %: 2 x 10^9 vertices, 24 GB of positions per frame; the 8-GPU
+        # configuration gives each GPU 125 k), shared 10 k-vertex mesh, 64 bones, poses resident in HBM.
+        n_c5 = Z["c5_skinned"]
+        s5 = scenes.skeleton(64, seed=4)
+        verts5, skin5 = scenes.skinned_mesh(10_000 if not small else 700, 64, seed=6)
+        sk5 = api.Skinning(ctx)
+        model5 = sk5.addModel(s5["parents"], s5["bind"], s5["first_nonroot"])
+        mesh5 = sk5.addMesh(verts5, skin5)
+        sk5.setInstances(np.full(n_c5, model5, np.uint32), np.full(n_c5, mesh5, np.uint32))
+        pos5, rot5 = scenes.relative_poses(n_c5, 64, seed=11)
+        d_pos5, d_rot5 = dev.upload(pos5), dev.upload(rot5)
+        del pos5, rot5
+        sk5.setPoseSourceDevice(d_pos5.ptr, d_rot5.ptr, n_c5 * 64)
+
+        def frame5():
+            cs_b.cull(fr8b)
+            sk5.run()
+
+        for _ in range(2):
+            frame5()
+        ms5 = timed(frame5, 5)
+        big["frame_8_cascades_plus_skinned_share"] = {
+            "ms_per_frame": ms5, "frames_per_sec": 1e3 / ms5, "entities": NB, "frusta": 8, "skinned_instances": n_c5, "verts_per_instance": len(verts5),
+            "skinned_share_of_entities": n_c5 / NB, "entity_frustum_tests_per_sec": 8.0 * NB / (ms5 * 1e-3), "skinned_verts_per_sec": n_c5 * len(verts5) / (ms5 * 1e-3),
+            "note": "config 5's 1 % skinned share would be 1 M instances (120 GB of positions per frame): scaled to what a frame can carry; cull of all 8 cascades + pose -> palette -> vertices per frame"}
+        out["config5_frame_1gpu_ms"] = ms5
+        out["config5_frame_1gpu_is"] = f"{NB} entities x 8 cascade frusta + {n_c5} skinned instances x {len(verts5)} vertices (the config's 1 % skinned share scaled to {100.0 * n_c5 / NB:.2f} %), one GPU"
+        del sk5, d_pos5, d_rot5
         del cs_b
         sc_b["radius"] = scenes.all_test_radii(NB)
         cs_b = api.CullingSystem(ctx)
@@ -567,33 +597,55 @@ def extras(ctx, api, scenes, dev, timed, N, log, check_ids, big_entities=0, out=
     out["target_animated_frames_per_sec_1gpu"] = 1e3 / ms4a
     out["target_animated_kernel_ms"] = {api.KERNEL_NAMES[k]: round(ctx.profile_get(k)[0] / 5, 5) for k in range(len(api.KERNEL_NAMES)) if ctx.profile_get(k)[1]}
     del cs4, sk4, d_pos4, d_rot4
-    # distinct meshes: every instance streams its own 32-byte vertex records from HBM (44 B/vertex moved; SURVEY.md's algorithmic figure is 48)
-    n_inst2 = Z["distinct"]  # 1500: 540 MB of mesh data + 180 MB of output: well beyond the 256 MiB Infinity Cache
+    # BASELINE config 3's distinct-mesh variant AT ITS STATED SIZE (round 6): 10 000 instances, every one its own 10 k-vertex mesh (scenes.distinct_mesh) - 3.2 GB of vertex
+    # records streamed from HBM per frame + 1.2 GB of positions written (44 B per vertex moved; SURVEY.md's algorithmic figure is 48)
+    n_inst2 = Z["distinct"]
     sk = api.Skinning(ctx)
     model = sk.addModel(s["parents"], s["bind"], s["first_nonroot"])
-    rng = np.random.default_rng(9)
-    mesh_ids = []
-    for i in range(n_inst2):
-        v2 = np.roll(verts, i, axis=0)
-        mesh_ids.append(sk.addMesh(v2, np.roll(skin, i, axis=0)))
+    t0 = time.time()
+    mesh_ids = [sk.addMesh(*scenes.distinct_mesh(verts, skin, i)) for i in range(n_inst2)]
     sk.setInstances(np.full(n_inst2, model, np.uint32), np.array(mesh_ids, np.uint32))
-    d_pos2, d_rot2 = dev.upload(pos[:n_inst2]), dev.upload(rot[:n_inst2])
+    pos_d, rot_d = scenes.relative_poses(scenes.DISTINCT_MESH_POSES if not small else n_inst2, 64, seed=5)
+    d_pos2, d_rot2 = dev.upload(pos_d[:n_inst2]), dev.upload(rot_d[:n_inst2])
 
     def skin_step2():
         sk.uploadPosesDevice(d_pos2.ptr, d_rot2.ptr, n_inst2 * 64)
         sk.run()
 
-    for _ in range(5):
+    skin_step2()
+    out["skin_distinct_meshes_setup_s"] = round(time.time() - t0, 1)
+    # identity first: LMX_SKIN_EXACT positions of the sampled instances against the digests the reference's evaluateSkin produced for them
+    # (tests/golden/skin_distinct.json, written by tests/golden/make_golden_skin_distinct.py; bench.py itself never touches the oracle)
+    checked = "unchecked"
+    try:
+        import hashlib
+
+        g = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "skin_distinct.json")))
+        if not small and n_verts == g["n_verts"] and n_inst2 <= g["poses_drawn"]:
+            sk.setMode(api.SKIN_EXACT)
+            skin_step2()
+            sample = [i for i in scenes.DISTINCT_MESH_SAMPLE if i < n_inst2]
+            bad = [i for i in sample if hashlib.sha256(np.ascontiguousarray(sk.readVertices(i), np.float32).tobytes()).hexdigest() != g["instances"][str(i)]]
+            if bad:
+                raise SystemExit(f"bench: skinned positions of the distinct-mesh instances {bad} differ from the reference's")
+            checked = f"reference (LMX_SKIN_EXACT sha256 of instances {sample})"
+    finally:
+        sk.setMode(api.SKIN_FUSED)
+    out["skin_distinct_meshes_positions"] = checked
+    for _ in range(3):
         skin_step2()
+    ms_d = timed(skin_step2, 10 if not small else 1)
     ctx.profile_reset()
     ctx.profile_enable(True)
-    for _ in range(20):
+    for _ in range(10 if not small else 1):
         skin_step2()
     ctx.synchronize()
     ctx.profile_enable(False)
     t_sv, n_sv = ctx.profile_get(api.K_SKIN_VERTICES)
     out["skin_distinct_meshes_instances"] = n_inst2
+    out["skin_distinct_meshes_ms_per_frame"] = ms_d
     out["skin_distinct_meshes_kernel_avg_ms"] = t_sv / max(n_sv, 1)
     out["skin_distinct_meshes_verts_per_sec"] = n_inst2 * n_verts / (t_sv / max(n_sv, 1) * 1e-3)
     out["skin_distinct_meshes_GBps_48B"] = 48.0 * n_inst2 * n_verts / (t_sv / max(n_sv, 1) * 1e-3) / 1e9
+    del sk, d_pos2, d_rot2
     return out
