@@ -134,6 +134,7 @@ constexpr int KEYS_STAGE_PAIRS = 3 * KEYS_BLOCK; // pairs (24 KiB) and records (
 #endif
 constexpr int KEYS_HIST_LDS = 4096; // keys (16 KiB): larger ranges keep the global atomics
 constexpr int KEYS_ROW_SHIFT = 12;   // block ranks: rec_key = key (< KEYS_HIST_LDS) | k_keys_mesh block << 12
+constexpr uint32_t KEYS_RANK_DEAD = 0xffffffffu; // block ranks: the rank of a record whose mesh sort key lies above max_sort_key (dropped by the scatter, as the privatised-counter path drops it)
 static_assert((1 << KEYS_ROW_SHIFT) == KEYS_HIST_LDS, "a record's key and row share 32 bits");
 #ifndef LMX_KEYS_MIN_WAVES
 #define LMX_KEYS_MIN_WAVES 4 // waves per SIMD the register allocation aims at: 106 VGPRs, no scratch, two 8-wave blocks per CU. Round 4 (profiles/r04/keys_ab.txt, k_keys_mesh per 1.05 M visible): 6 waves (80 VGPRs, 32-44 B of scratch, three blocks) 65.5-70.5 us, 5 waves 59.1, 4 waves 60.2 - the kernel is not short of waves, spills cost it more
@@ -433,6 +434,7 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 				if (block_ranks && add_inst) {
 					rec_word = (mesh_sort_key & (uint32_t)(KEYS_HIST_LDS - 1)) | (blockIdx.x << KEYS_ROW_SHIFT);
 					if (mesh_sort_key <= d.max_sort_key) rank = atomicAdd(&s_hist[mesh_sort_key], 1u); // ds_add_rtn_u32: the record's rank among the block's records of its key
+					else rank = KEYS_RANK_DEAD; // a key above the range: its 12-bit field would ALIAS a valid key - the scatter drops the record by its rank (the run is flagged KEYS_OVERFLOW = 2 below)
 				}
 				if (stage) {
 					if (!add_inst) { s_pair_key[pair_at] = key; s_pair_value[pair_at] = value; }
@@ -751,7 +753,7 @@ template <bool OWN_OFFSETS> __global__ __launch_bounds__(256) void k_keys_scatte
 			if (i1 < n) { packed_next = d.rec_key[i1]; value_next = d.rec_value[i1]; if (block_ranks) rank_next = d.rec_rank[i1]; }
 		}
 		const uint32_t key = block_ranks ? packed & (uint32_t)(KEYS_HIST_LDS - 1) : packed & 0xffffffu;
-		const bool has = i < n && key <= d.max_sort_key;
+		const bool has = i < n && key <= d.max_sort_key && !(block_ranks && rank_next_now == KEYS_RANK_DEAD);
 		const size_t at = block_ranks ? (size_t)(packed >> KEYS_ROW_SHIFT) * stride + key : (size_t)(packed >> 24) * stride + key;
 		uint32_t in_group = 0; // the record's position inside its group
 		if (block_ranks) { // no atomics: the records of key k in the rows before this record's + its rank inside its row

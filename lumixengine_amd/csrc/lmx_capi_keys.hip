@@ -306,6 +306,7 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 		ks.run_parity = 0;
 		ks.table_parity = 0;
 	}
+	const bool counters_were_clean = ks.groups_clean;
 	ks.groups_clean = false; // until this run's launches are enqueued
 	// block ranks: a row of per-key counts for every block of k_keys_mesh (a fixed-size grid), for key ranges that fit the key kernel's
 	// LDS histogram; otherwise the private copies above do the counting
@@ -315,7 +316,8 @@ int lmx_keys_run(LmxContext* ctx, uint32_t view, uint32_t frustum, const LmxKeys
 	if (row_adds) { // one counter per key, a cache line each, two sets taking turns (a run's last kernel zeroes the next run's)
 		const uint32_t* before = ks.d_total_pad.p;
 		LMX_HIP(ctx, ks.d_total_pad.reserve(2 * g * KEYS_PAD_WORDS));
-		if (before != ks.d_total_pad.p || ks.pad_keys != g) {
+		// (a failed or aborted run may have left its adds in the per-key counters without flipping the parity: they start over with the group tables)
+		if (before != ks.d_total_pad.p || ks.pad_keys != g || !counters_were_clean) {
 			LMX_HIP(ctx, hipMemsetAsync(ks.d_total_pad.p, 0, 2 * g * KEYS_PAD_WORDS * sizeof(uint32_t), ctx->stream));
 			ks.pad_keys = g;
 			ks.pad_parity = 0;

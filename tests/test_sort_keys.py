@@ -264,6 +264,52 @@ def test_gpu_sort_keys_match_oracle(gpu_ctx, live_oracle, vi, modes):
 
 
 @pytest.mark.gpu
+def test_gpu_sort_keys_key_above_the_range(gpu_ctx, live_oracle):
+    """A mesh sort key above the max_sort_key the caller passes (the reference indexes its group table out of bounds there): the run is flagged
+    (overflow == 2), its instancer is refused by the readers (LMX_ERR_CAPACITY), and - both forms of the instancer - the record is dropped on the
+    device (with block ranks a record carries 12 bits of its key: a key above the range used to alias a valid one). The run AFTER the
+    flagged one - the same scene with its real key range - must be the oracle's again: the per-key counters of the flagged run start over."""
+    real_max, passed_max = 1500, 999
+    base = scenes.cull_scene(30_000, 1500.0, seed=35, big_fraction=0.0)
+    n = len(base["entity"])
+    types = np.zeros(n, np.uint8)
+    pos = base["pos"]
+    sc = scenes.keys_scene(n, types, seed=57, max_sort_key=real_max, moved_fraction=0.0)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(base["entity"], types, pos, base["radius"])
+    fr = api.viewport_frustum(pos=(0, 0, 0), far=3000.0)
+    sk = api.SortKeys(gpu_ctx)
+    sk.setModels(sc["models"], sc["mesh_types"])
+    sk.setInstances(sc["model"], sc["material_offset"], sc["mesh_materials"], sc["lod"], sc["flags"], sc["dirty"], sc["pose_frame"])
+    sk.setDecals(n, sc["decal_key"], sc["decal_layer"], sc["curve_key"], sc["curve_layer"])
+    empty = np.zeros(0, np.int32)
+    try:
+        for block_ranks in (1, 0, 1):
+            sk.setOption(api.KEYS_OPT_BLOCK_RANKS, block_ranks)
+            reset = lambda: (sk.setInstances(sc["model"], sc["material_offset"], sc["mesh_materials"], sc["lod"], sc["flags"], sc["dirty"], sc["pose_frame"]), sk.setPositions(pos))  # noqa: E731 - lod / pose frames restart from the uploaded values: every run sees the same state
+            reset()
+            kv = api.keys_view(layer_to_bucket=sc["layer_to_bucket"], bucket_depth_sorted=sc["bucket_depth_sorted"], **VIEWS[0])
+            ids = cs.cull(fr).ids(0, 0)
+            sk.run(kv, passed_max)
+            assert sk.counts()["overflow"] == 2
+            with pytest.raises(api.LumixError):
+                sk.readInstancer()
+            reset()
+            sk.run(kv, real_max)
+            cnt = sk.counts()
+            assert cnt["overflow"] == 0
+            want = live_oracle.create_sort_keys(kv, real_max, ids, empty, empty, sc, pos, lod=sc["lod"], pose_frame=sc["pose_frame"])
+            keys, values = sk.readPairs()
+            offsets, gvalues = sk.readInstancer()
+            assert np.array_equal(offsets, want["group_offsets"]) and cnt["groups"] == want["groups"] and len(gvalues) > 500
+            got = canon(keys, values, offsets, gvalues, sk.readPoses(), sk.readDirty())
+            exp = canon(want["keys"], want["values"], want["group_offsets"], want["group_values"], want["poses"], want["dirty"])
+            assert got["pairs"] == exp["pairs"] and got["groups"] == exp["groups"], f"block ranks {block_ranks}: the run behind a flagged one"
+    finally:
+        sk.setOption(api.KEYS_OPT_BLOCK_RANKS, 1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("max_sort_key", [1023, 1024, 5000, 200_000])
 def test_gpu_sort_keys_key_ranges(gpu_ctx, live_oracle, max_sort_key):
     """Renderer::getMaxSortKey() decides which form of the instancer's kernels runs: up to 1024 keys the scatter forms the group offsets
