@@ -440,16 +440,16 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 					if (!add_inst) { s_pair_key[pair_at] = key; s_pair_value[pair_at] = value; }
 					else { s_rec_key[rec_at] = rec_word; s_rec_value[rec_at] = value; if (block_ranks) s_rec_rank[rec_at] = rank; }
 				} else if (!add_inst) {
-					if (pair_at < d.cap_pairs) { d.keys[pair_at] = key; d.values[pair_at] = value; } else d.counters[KEYS_OVERFLOW] = 1;
+					if (pair_at < d.cap_pairs) { d.keys[pair_at] = key; d.values[pair_at] = value; } else atomicMax(&d.counters[KEYS_OVERFLOW], 1u);
 				} else {
-					if (rec_at < d.cap_recs) { d.rec_key[rec_at] = rec_word; d.rec_value[rec_at] = value; if (block_ranks) d.rec_rank[rec_at] = rank; } else d.counters[KEYS_OVERFLOW] = 1;
+					if (rec_at < d.cap_recs) { d.rec_key[rec_at] = rec_word; d.rec_value[rec_at] = value; if (block_ranks) d.rec_rank[rec_at] = rank; } else atomicMax(&d.counters[KEYS_OVERFLOW], 1u);
 				}
 				// (plain arithmetic: with `++pair_at` / `++rec_at` in the branches the compiler indexed the two cursors in scratch memory)
 				pair_at += add_inst ? 0u : 1u;
 				rec_at += add_inst ? 1u : 0u;
 			}
 			const bool in_range = add_inst && mesh_sort_key <= d.max_sort_key;
-			if (add_inst && !in_range) d.counters[KEYS_OVERFLOW] = 2; // a mesh sort key above Renderer::getMaxSortKey(): the reference indexes out of bounds
+			if (add_inst && !in_range) atomicMax(&d.counters[KEYS_OVERFLOW], 2u); // a mesh sort key above Renderer::getMaxSortKey(): the reference indexes out of bounds
 			// with many private copies the counters are spread thinly enough for one atomic per lane; the per-wave de-duplication
 			// (one atomic per distinct key, ~15 scalar + vector instructions per key: 60 % of this kernel's time at 256 live keys)
 			// is kept for key ranges too large to privatise
@@ -485,8 +485,8 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 		__syncthreads(); // the staged outputs and the bases are in LDS
 		{
 			const uint32_t pose0 = s_base[2], dirty0 = s_base[3];
-			if (queue_dirty) { if (dirty0 + dirty_at < d.cap_list) d.dirty_list[dirty0 + dirty_at] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
-			if (push_pose) { if (pose0 + pose_at < d.cap_list) d.poses[pose0 + pose_at] = (int32_t)e; else d.counters[KEYS_OVERFLOW] = 1; }
+			if (queue_dirty) { if (dirty0 + dirty_at < d.cap_list) d.dirty_list[dirty0 + dirty_at] = (int32_t)e; else atomicMax(&d.counters[KEYS_OVERFLOW], 1u); }
+			if (push_pose) { if (pose0 + pose_at < d.cap_list) d.poses[pose0 + pose_at] = (int32_t)e; else atomicMax(&d.counters[KEYS_OVERFLOW], 1u); }
 		}
 		if (block_ranks) { // (the histogram runs on: it leaves behind the block's last tile)
 		} else if (lds_hist && tile_recs != 0) { // (behind the barrier: every lane's LDS increments are in)
@@ -502,11 +502,11 @@ __global__ __launch_bounds__(KEYS_BLOCK, LMX_KEYS_MIN_WAVES) void k_keys_mesh(Ke
 			tile_pair0 = s_base[0]; tile_rec0 = s_base[1];
 			for (uint32_t j = threadIdx.x; j < tile_pairs; j += KEYS_BLOCK) {
 				const uint32_t at = tile_pair0 + j;
-				if (at < d.cap_pairs) { d.keys[at] = s_pair_key[j]; d.values[at] = s_pair_value[j]; } else d.counters[KEYS_OVERFLOW] = 1;
+				if (at < d.cap_pairs) { d.keys[at] = s_pair_key[j]; d.values[at] = s_pair_value[j]; } else atomicMax(&d.counters[KEYS_OVERFLOW], 1u);
 			}
 			for (uint32_t j = threadIdx.x; j < tile_recs; j += KEYS_BLOCK) {
 				const uint32_t at = tile_rec0 + j;
-				if (at < d.cap_recs) { d.rec_key[at] = s_rec_key[j]; d.rec_value[at] = s_rec_value[j]; if (block_ranks) d.rec_rank[at] = s_rec_rank[j]; } else d.counters[KEYS_OVERFLOW] = 1;
+				if (at < d.cap_recs) { d.rec_key[at] = s_rec_key[j]; d.rec_value[at] = s_rec_value[j]; if (block_ranks) d.rec_rank[at] = s_rec_rank[j]; } else atomicMax(&d.counters[KEYS_OVERFLOW], 1u);
 			}
 		}
 		__syncthreads(); // s_wave, s_base and the staging buffers are rewritten by the next tile
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void k_keys_decal(KeysDevice d, const KeysView
 			}
 		}
 		const uint32_t idx = wave_append(push, d.counters + KEYS_N_PAIRS);
-		if (push) { if (idx < d.cap_pairs) { d.keys[idx] = key; d.values[idx] = value; } else d.counters[KEYS_OVERFLOW] = 1; }
+		if (push) { if (idx < d.cap_pairs) { d.keys[idx] = key; d.values[idx] = value; } else atomicMax(&d.counters[KEYS_OVERFLOW], 1u); }
 	}
 }
 
@@ -800,7 +800,7 @@ template <bool OWN_OFFSETS> __global__ __launch_bounds__(256) void k_keys_scatte
 			}
 		}
 		const uint32_t idx = wave_append(push, d.counters + KEYS_N_PAIRS);
-		if (push) { if (idx < d.cap_pairs) { d.keys[idx] = pair_key; d.values[idx] = pair_value; } else d.counters[KEYS_OVERFLOW] = 1; }
+		if (push) { if (idx < d.cap_pairs) { d.keys[idx] = pair_key; d.values[idx] = pair_value; } else atomicMax(&d.counters[KEYS_OVERFLOW], 1u); }
 	}
 }
 
