@@ -125,6 +125,10 @@ LMX_API int lmx_cull_async_stats(LmxContext* ctx, int* state, uint64_t* jobs, ui
  * row in units of 64 ids: a bound output buffer needs 64 * n_chunks ids per frustum. Compacts the static set first (the cell
  * count is that of the sorted layout). */
 LMX_API int lmx_cull_stats(LmxContext* ctx, uint32_t* n_entities, uint32_t* n_cells, uint32_t* n_chunks);
+/* The per-tile tables of the device layout: *cell_key_bytes = 8 (cell keys relative to their tile's box; any scene whose tiles span <= 65535 cell
+ * indices per axis) or 16, *table_bytes = cell keys + tile tables + chunk headers a cull of the whole static set reads besides spheres and ids
+ * (2048-sphere tiles). Either pointer may be NULL. (Environment LMX_CULL_WIDE_KEYS, read when a layout is built, forces 16-byte keys: tests.) */
+LMX_API int lmx_cull_layout_info(LmxContext* ctx, uint32_t* cell_key_bytes, uint64_t* table_bytes);
 
 /* CullingSystem::cull(frustum[, type]) (culling_system.cpp:310-369) for n_frusta <= LMX_MAX_FRUSTA frusta in one
  * call (e.g. the 4 shadow cascades + main view of a frame). type == LMX_TYPE_ALL (0xff) culls every type. Asynchronous

@@ -125,6 +125,7 @@ SYMBOLS = {
     "lmx_cull_pack_device": (_ci, [_vp, _u32, _u32, _vp, _vp]),
     "lmx_cull_device_shards": (_ci, [_vp, _u32, _u32, _vp]),
     "lmx_cull_stats": (_ci, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "lmx_cull_layout_info": (_ci, [_vp, C.POINTER(_u32), C.POINTER(C.c_uint64)]),
     "lmx_cull": (_ci, [_vp, _u32, _vp, _u32, _u8]),
     "lmx_cull_set_pass_width": (_ci, [_vp, _u32]),
     "lmx_cull_counts": (_ci, [_vp, _u32, _vp]),
@@ -492,6 +493,12 @@ class CullingSystem:
         a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
         self.ctx.check(self.lib.lmx_cull_stats(self.ctx.h, C.byref(a), C.byref(b), C.byref(c)))
         return {"entities": a.value, "cells": b.value, "chunks": c.value}
+
+    def layoutInfo(self):
+        """{"cell_key_bytes": 8 (keys relative to the tile's box) | 16, "table_bytes": per-tile tables + chunk headers a full cull reads}"""
+        kb, tb = C.c_uint32(0), C.c_uint64(0)
+        self.ctx.check(self.lib.lmx_cull_layout_info(self.ctx.h, C.byref(kb), C.byref(tb)))
+        return {"cell_key_bytes": kb.value, "table_bytes": tb.value}
 
     def bindOutput(self, view: int, d_ids: Optional[int], ids_capacity: int, d_counts: Optional[int]):
         """Result slot `view` writes into caller-owned device memory (raw pointers, e.g. torch tensors' data_ptr())."""

@@ -40,6 +40,7 @@ __device__ __forceinline__ float readlane_f(float v, int lane) { return __uint_a
 // (pointers are separate __restrict__ kernel parameters: only then are the wave-uniform loads selected as scalar loads)
 struct TileScalars {
 	uint32_t ent_begin, cell_cap, n_frusta;
+	uint32_t keys_packed; // the cell tables hold PackedCellKey (8 bytes, offsets against the tile's box) instead of CellKey
 	uint32_t out_stride, cnt_pad, cnt_frustum_stride, n_zero;
 	int32_t* out_slots; // SLOTS kernels only
 	float pretest_n1s;  // (several frusta) 2^27 x the largest |n|_1 of the call's planes, rounded up; +inf switches the matrix-pipe pre-test off
@@ -258,7 +259,7 @@ static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustu
 // ds_reads put the plane distances and the v_min3 read the results) instead of AGPR accumulators + a v_accvgpr_write / _read per value
 #define LMX_CULL_WAVES_ATTR(F) __attribute__((amdgpu_waves_per_eu((F) == 1 ? 1 : 5)))
 
-template <int F, int WAVES, int CHW, int GRP, int LANEPAR, int SLOTS_I>
+template <int F, int WAVES, int CHW, int GRP, int FORM, int SLOTS_I>
 __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile(const FrustaArg fr_arg, const float4* __restrict__ g_spheres, const int32_t* __restrict__ g_ids,
 	const ChunkHdr* __restrict__ g_hdr, const CellKey* __restrict__ g_tile_cells, const uint32_t* __restrict__ g_tile_tab, const TileBox* __restrict__ g_tile_box,
 	const uint2* __restrict__ g_tile_out, int32_t* __restrict__ g_out_ids, uint32_t* __restrict__ g_counts, uint32_t* __restrict__ g_counts_next, const TileScalars a) {
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 	// 0. tile-level test per frustum (2 bits each). Everything read here sits at addresses that depend on blockIdx only.
 	uint32_t st_bits = 0, tile_flags = 0, plane_skip = 0;
 	bool any_mixed = false, any_live = false;
-	if constexpr (LANEPAR != 0) {
+	if constexpr (FORM != 0) {
 		static_assert(F == 1, "the lane-parallel tile test handles one frustum");
 		// wave 0 alone evaluates the verdict and hands it to the others through LDS: on a launch where most tiles are rejected
 		// here, the other waves' ~80 VALU instructions each were most of what the chip executed (all-rejected launch of 4883
@@ -338,7 +339,31 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 		// A. classify the tile's cells into LDS: class + the cell-relative plane distances (per cell, as the reference's getRelative)
 		first_cell = g_tile_tab[2 * tile_index];
 		const uint32_t n_cells = g_tile_tab[2 * tile_index + 1];
-		const CellKey* keys = g_tile_cells + (size_t)tile_index * a.cell_cap;
+		// a tile's cell table: 16-byte keys or (the common case) 8-byte ones relative to the tile's box, whose low corner is a uniform 12-byte load.
+		// ONE base pointer for both forms (the streaming kernel sits at its limit of 80 scalar registers)
+		// (one frustum: the key format is part of the instantiation - FORM 1 / 2 packed, 3 / 4 wide - because both decoders in one body cost the streaming
+		// kernel the 80-SGPR limit of 8 resident blocks per CU; the several-frusta kernels, at 5 blocks per CU by their LDS, branch on a launch-uniform flag)
+		const bool packed_keys = F == 1 ? FORM <= 2 : a.keys_packed != 0;
+		const char* keys = reinterpret_cast<const char*>(g_tile_cells) + ((size_t)tile_index * a.cell_cap << (packed_keys ? 3 : 4));
+		auto load_key = [&](uint32_t t) -> CellKey {
+			CellKey key;
+			if (packed_keys) { // launch-uniform
+				const uint2 raw = reinterpret_cast<const uint2*>(keys)[t];
+				// (the box's low corner through the VECTOR memory path - an opaque zero in the address - so that it lands in vector registers, of which
+				// phase A has plenty: as scalars it puts the streaming form at 81 SGPRs, one over what 8 resident blocks per CU allow)
+				uint32_t zero = 0;
+				asm volatile("" : "+v"(zero));
+				const int32_t* box_lo = reinterpret_cast<const int32_t*>(g_tile_box + tile_index) + zero;
+				key.ix = box_lo[0] + (int32_t)(raw.x & 0xffffu);
+				key.iy = box_lo[1] + (int32_t)(raw.x >> 16);
+				key.iz = box_lo[2] + (int32_t)(raw.y & 0xffffu);
+				key.meta = ((raw.y & PACKED_CELL_BIG) ? 0x100u : 0u) | ((raw.y & PACKED_CELL_DEAD) ? (uint32_t)CELL_DEAD : 0u);
+			} else {
+				const uint4 raw = reinterpret_cast<const uint4*>(keys)[t]; // ONE 16-byte load (ix, iy, iz, meta), not meta -> branch -> the rest
+				key.ix = (int32_t)raw.x; key.iy = (int32_t)raw.y; key.iz = (int32_t)raw.z; key.meta = raw.w;
+			}
+			return key;
+		};
 		auto classify = [&](uint32_t t, int f, const CellKey key) -> uint32_t {
 			const bool dead = (key.meta & CELL_DEAD) != 0;
 			const bool big = (key.meta & 0x100u) != 0;
@@ -379,7 +404,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 		};
 		if constexpr (F == 1) {
 			for (uint32_t t = threadIdx.x; t < a.cell_cap; t += THREADS) {
-				const CellKey key = keys[t]; // issued before n_cells is known; the tail of the slice holds dead keys
+				const CellKey key = load_key(t); // issued before n_cells is known; the tail of the slice holds dead keys
 				if (t < n_cells) classify(t, 0, key);
 			}
 		} else {
@@ -394,9 +419,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 			// chain of 32 dependent LDS round trips per wave in front of its loads (profiles/r04/cull8_probes.txt: 96 of the launch's 201 us
 			// were neither classification nor sphere tests).
 			for (uint32_t t = threadIdx.x; t < n_cells; t += THREADS) {
-				const uint4 raw = reinterpret_cast<const uint4*>(keys)[t]; // ONE 16-byte load (ix, iy, iz, meta), not meta -> branch -> the rest
-				CellKey key;
-				key.ix = (int32_t)raw.x; key.iy = (int32_t)raw.y; key.iz = (int32_t)raw.z; key.meta = raw.w;
+				const CellKey key = load_key(t);
 				uint32_t word = tile_word;
 #pragma unroll 1
 				for (int f = 0; f < nf; ++f) {
@@ -515,7 +538,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 	static_assert(CHW * 64 <= 1023, "a wave's count per frustum fits 10 bits");
 	// 1-frustum kernels: the wave's visible ids (and slots) are compacted in LDS as they are found - the write-out below is then a
 	// handful of full-width stores instead of one partial-width store per chunk (156 k of them on a launch with 43 % visible)
-	constexpr bool STREAMING = F == 1 && LANEPAR == 2; // (template slot 5: 0 = several frusta, 1 = one frustum, latency form, 2 = one frustum, streaming form)
+	constexpr bool STREAMING = F == 1 && (FORM == 2 || FORM == 4); // (template slot FORM: 0 = several frusta; one frustum: 1 = latency form, 2 = streaming form, 3 / 4 = the same two with 16-byte cell keys)
 	constexpr bool STAGE = STREAMING && LMX_CULL_STAGE_IDS != 0; // streaming variants only (as the non-temporal loads): the latency variant pays for the extra LDS and the wait at the wave's end
 	__shared__ int32_t s_stage_ids[STAGE ? WAVES : 1][STAGE ? CHW * 64 : 1];
 	__shared__ int32_t s_stage_slots[STAGE && SLOTS ? WAVES : 1][STAGE && SLOTS ? CHW * 64 : 1];
@@ -589,7 +612,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 			const v4f* sp_at = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(g_spheres + ((size_t)(chunk0 + g) << 6) + i * 64) + off_s);
 			v4f t;
 #if LMX_CULL_NT_LOADS
-			if constexpr (F == 1 && LANEPAR == 2) { // the streaming form: every sphere is read once per cull and nothing of it is reused
+			if constexpr (F == 1 && (FORM == 2 || FORM == 4)) { // the streaming form: every sphere is read once per cull and nothing of it is reused
 				id[g + i] = __builtin_nontemporal_load(id_at);
 				t = __builtin_nontemporal_load(sp_at);
 			} else
@@ -1119,7 +1142,7 @@ __global__ __launch_bounds__(256) void k_cull_pack(const int32_t* __restrict__ s
 #endif
 }
 
-template <int F, int WAVES, int CHW, int GRP, int LANEPAR, int SLOTS_I>
+template <int F, int WAVES, int CHW, int GRP, int FORM, int SLOTS_I>
 hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, uint32_t ent_end, const TypeTable& tt, const FrustaArg& fr, int n_frusta,
 	const CullOut& out) {
 	constexpr uint32_t TILE = WAVES * CHW * 64;
@@ -1137,6 +1160,7 @@ hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, ui
 	(void)tt; // (the tiles' shards come out of CullDeviceView::tile_out)
 	a.ent_begin = ent_begin;
 	a.cell_cap = v.tile_cap[K];
+	a.keys_packed = v.keys_packed ? 1u : 0u;
 	a.n_frusta = (uint32_t)n_frusta;
 	a.out_stride = out.stride;
 	a.cnt_pad = out.cnt_pad;
@@ -1156,10 +1180,10 @@ hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, ui
 		a.pretest_n1s = finite ? n1 * 1.000001f * 134217728.0f : __builtin_inff();
 	}
 	if (out.ev_start != nullptr) // profiling: the events receive the dispatch's own begin / end timestamps
-		hipExtLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, LANEPAR, SLOTS_I>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, out.ev_start, out.ev_stop, 0, fr,
+		hipExtLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, FORM, SLOTS_I>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, out.ev_start, out.ev_stop, 0, fr,
 			v.spheres, v.ids, v.hdr, v.tile_cells[K], v.tile_tab[K], v.tile_box[K], v.tile_out[K], out.ids, out.counts, out.counts_next, a);
 	else
-		hipLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, LANEPAR, SLOTS_I>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, fr, v.spheres, v.ids, v.hdr,
+		hipLaunchKernelGGL((k_cull_tile<F, WAVES, CHW, GRP, FORM, SLOTS_I>), dim3(tiles), dim3(WAVES * 64), cull_tile_lds_bytes(n_frusta, a.cell_cap), s, fr, v.spheres, v.ids, v.hdr,
 			v.tile_cells[K], v.tile_tab[K], v.tile_box[K], v.tile_out[K], out.ids, out.counts, out.counts_next, a);
 	return hipGetLastError();
 }
@@ -1184,7 +1208,9 @@ hipError_t launch_cull_tile(hipStream_t s, const CullDeviceView& v, uint32_t ent
 #define LMX_TILE(F, W, C, G, L) return out.slots ? tile_f<F, W, C, G, L, 1>(s, v, ent_begin, ent_end, tt, fr, n_frusta, out) : tile_f<F, W, C, G, L, 0>(s, v, ent_begin, ent_end, tt, fr, n_frusta, out)
 	if (n_frusta < 1 || n_frusta > MAX_FRUSTA) return hipErrorInvalidValue;
 	if (n_frusta == 1) {
-		if (variant == 4) LMX_TILE(1, 4, 8, 8, 1);
+		const int wide = v.keys_packed ? 0 : 2; // (the instantiations with 16-byte cell keys: scenes whose tiles span more than 65535 cells on an axis)
+		if (variant == 4) { if (wide) LMX_TILE(1, 4, 8, 8, 3); LMX_TILE(1, 4, 8, 8, 1); }
+		if (wide) LMX_TILE(1, 4, 8, 4, 4);
 		LMX_TILE(1, 4, 8, 4, 2); // (all eight chunks in flight in the streaming form as well: 41.0 vs 37.9 us on the all-test launch, profiles/r06/cull1_ab_grp8.txt)
 	}
 	if (n_frusta <= 4) LMX_TILE(0, 8, 4, 4, 0); // 2048-sphere tiles, <= 4 x 32 B of LDS per cell

@@ -355,13 +355,49 @@ int rebuild_static_on(LmxContext* ctx, CullSet& cs, hipStream_t stream, uint32_t
 		LMX_HIP(ctx, upload(up, cs.ids.p, lay.ids.data(), n_padded * sizeof(int32_t), stream));
 		LMX_HIP(ctx, upload(up, cs.hdr.p, lay.hdr.data(), n_chunks * sizeof(ChunkHdr), stream));
 	}
+	// Cell keys travel in 8 bytes where every tile's cells lie within 65535 cell indices of its box's low corner (any scene that is not a handful
+	// of entities millions of units apart): offsets against TileBox::lo + the two flags the kernel reads (PackedCellKey). 4096-sphere tiles (k = 0)
+	// are walked by no kernel since round 6: their keys are not uploaded at all (their boxes are: k_apply_patches clears TILE_DENSE in all three).
+	bool packable = getenv("LMX_CULL_WIDE_KEYS") == nullptr;
+	for (int k = 1; k < 3 && packable; ++k) {
+		const size_t cap = lay.tile_cap[k];
+		for (size_t ti = 0; ti < lay.tile_box[k].size() && packable; ++ti) {
+			const TileBox& b = lay.tile_box[k][ti];
+			if (b.flags & TILE_EMPTY) continue;
+			for (int a = 0; a < 3; ++a) packable = packable && (int64_t)b.hi[a] - (int64_t)b.lo[a] <= 65535;
+		}
+		(void)cap;
+	}
+	cs.keys_packed = packable;
+	std::vector<PackedCellKey> packed_k[3]; // (alive until the synchronize below: the copies are asynchronous)
 	for (int k = 0; k < 3; ++k) {
 		cs.tile_cap[k] = lay.tile_cap[k];
-		LMX_HIP(ctx, cs.tile_cells[k].reserve(std::max<size_t>(lay.tile_cells[k].size(), 1)));
+		const bool keys_used = k != 0;
+		const size_t key_bytes = !keys_used ? 0 : lay.tile_cells[k].size() * (packable ? sizeof(PackedCellKey) : sizeof(CellKey));
+		LMX_HIP(ctx, cs.tile_cells[k].reserve(std::max<size_t>((key_bytes + sizeof(CellKey) - 1) / sizeof(CellKey), 1)));
 		LMX_HIP(ctx, cs.tile_tab[k].reserve(std::max<size_t>(lay.tile_tab[k].size(), 1)));
 		LMX_HIP(ctx, cs.tile_box[k].reserve(std::max<size_t>(lay.tile_box[k].size(), 1)));
 		if (!lay.tile_cells[k].empty()) {
-			LMX_HIP(ctx, upload(up, cs.tile_cells[k].p, lay.tile_cells[k].data(), lay.tile_cells[k].size() * sizeof(CellKey), stream));
+			if (keys_used && packable) {
+				const size_t cap = lay.tile_cap[k];
+				std::vector<PackedCellKey>& packed = packed_k[k];
+				packed.resize(lay.tile_cells[k].size());
+				parallel_ranges(lay.tile_box[k].size(), [&](size_t tb, size_t te) {
+					for (size_t ti = tb; ti < te; ++ti) {
+						const TileBox& b = lay.tile_box[k][ti];
+						for (size_t j = 0; j < cap; ++j) {
+							const LayoutCell& c = lay.tile_cells[k][ti * cap + j];
+							PackedCellKey pk{0u, PACKED_CELL_DEAD};
+							if (!(c.meta & LAYOUT_CELL_DEAD))
+								pk = PackedCellKey{(uint32_t)(c.ix - b.lo[0]) | ((uint32_t)(c.iy - b.lo[1]) << 16), (uint32_t)(c.iz - b.lo[2]) | ((c.meta & 0x100u) ? PACKED_CELL_BIG : 0u)};
+							packed[ti * cap + j] = pk;
+						}
+					}
+				});
+				LMX_HIP(ctx, upload(up, cs.tile_cells[k].p, packed.data(), key_bytes, stream));
+			} else if (keys_used) {
+				LMX_HIP(ctx, upload(up, cs.tile_cells[k].p, lay.tile_cells[k].data(), key_bytes, stream));
+			}
 			LMX_HIP(ctx, upload(up, cs.tile_tab[k].p, lay.tile_tab[k].data(), lay.tile_tab[k].size() * sizeof(uint32_t), stream));
 			LMX_HIP(ctx, upload(up, cs.tile_box[k].p, lay.tile_box[k].data(), lay.tile_box[k].size() * sizeof(TileBox), stream));
 		}
@@ -1062,6 +1098,7 @@ CullDeviceView static_view(const CullSet& cs) {
 	v.ids = cs.ids.p;
 	v.hdr = cs.hdr.p;
 	v.n_padded = cs.n_padded;
+	v.keys_packed = cs.keys_packed;
 	for (int k = 0; k < 3; ++k) {
 		v.tile_cells[k] = cs.tile_cells[k].p;
 		v.tile_tab[k] = cs.tile_tab[k].p;
@@ -1330,6 +1367,21 @@ int lmx_cull_stats(LmxContext* ctx, uint32_t* n_entities, uint32_t* n_cells, uin
 	if (n_entities) *n_entities = (uint32_t)(cs.recs.size() + cs.dyn.size());
 	if (n_cells) *n_cells = cs.n_cells - cs.n_dead_cells;
 	if (n_chunks) *n_chunks = (cs.out_total + CHUNK - 1) / CHUNK;
+	return LMX_OK;
+}
+
+// What the device layout's per-tile tables look like: *cell_key_bytes = 8 (keys relative to the tile's box: every tile spans <= 65535 cell indices per
+// axis) or 16; *table_bytes = the cell keys + tile tables + chunk headers a cull of the whole static set reads besides spheres and ids.
+int lmx_cull_layout_info(LmxContext* ctx, uint32_t* cell_key_bytes, uint64_t* table_bytes) {
+	LMX_CHECK_CTX(ctx);
+	if (int rc = flush_impl(ctx, true)) return rc;
+	const CullState& cs = ctx->cull;
+	const uint32_t kb = cs.keys_packed ? (uint32_t)sizeof(PackedCellKey) : (uint32_t)sizeof(CellKey);
+	if (cell_key_bytes) *cell_key_bytes = kb;
+	if (table_bytes) { // (the 2048-sphere tiles' tables: what the 1-frustum kernels walk)
+		const uint64_t tiles = cs.n_padded / 2048u;
+		*table_bytes = tiles * ((uint64_t)cs.tile_cap[1] * kb + 2 * sizeof(uint32_t) + sizeof(TileBox) + sizeof(uint2)) + (uint64_t)(cs.n_padded / CHUNK) * sizeof(ChunkHdr);
+	}
 	return LMX_OK;
 }
 

@@ -168,6 +168,7 @@ struct CullSet {
 	DevBuf<uint32_t> tile_tab[3];
 	DevBuf<TileBox> tile_box[3];
 	uint32_t tile_cap[3] = {16, 16, 16};
+	bool keys_packed = false; // tile_cells hold PackedCellKey (8 bytes) instead of CellKey
 	uint32_t n_padded = 0, n_cells = 0, n_dead_cells = 0;
 	uint32_t max_tile_cells[3] = {0, 0, 0};
 	std::vector<uint32_t> block_live; // live ids per TILE_ALIGN-slot block at build time (capacity of the output shards)
@@ -217,6 +218,7 @@ struct CullSet {
 			std::swap(scene_lo[k], o.scene_lo[k]);
 			std::swap(scene_hi[k], o.scene_hi[k]);
 		}
+		std::swap(keys_packed, o.keys_packed);
 		std::swap(n_padded, o.n_padded);
 		std::swap(n_cells, o.n_cells);
 		std::swap(n_dead_cells, o.n_dead_cells);

@@ -23,6 +23,11 @@ constexpr uint32_t CELL_DEAD = 0x80000000u;
 
 // One (cell index, type, is_big) group. meta = type | is_big << 8 | CELL_DEAD.
 struct CellKey { int32_t ix, iy, iz; uint32_t meta; };
+// The same group in 8 bytes, relative to its TILE's box (TileBox::lo): xy = dx | dy << 16, zf = dz | flags << 16 with flags bit 0 = is_big,
+// bit 15 = dead. The per-tile cell tables are the largest part of what k_cull_tile reads besides the spheres and ids themselves (16 B x ~1 M
+// cells per 10 M entities, padded per tile: 18.7 of the launch's 224.5 MB); the type is not needed on the device (the tile's shard says it).
+struct PackedCellKey { uint32_t xy, zf; };
+constexpr uint32_t PACKED_CELL_BIG = 1u << 16, PACKED_CELL_DEAD = 1u << 31;
 // Header of a 64-sphere chunk: cell slot of its first sphere, bit l of flags = "sphere l starts the next cell".
 struct ChunkHdr { uint32_t cell, pad; uint64_t flags; };
 
@@ -42,7 +47,8 @@ struct CullDeviceView {
 	const ChunkHdr* hdr;         // [n_padded / 64]
 	uint32_t n_padded;
 	// per tile-size variant k (tile = 4096 >> k): tile-major cell keys + {first cell, n cells} + cell-index box per tile
-	const CellKey* tile_cells[3];
+	const CellKey* tile_cells[3];   // 16-byte keys - or, keys_packed, 8-byte ones (PackedCellKey) behind the same pointers
+	bool keys_packed;               // every tile's cells lie within 65535 cell indices of its box's low corner on every axis (any real scene)
 	const uint32_t* tile_tab[3];
 	const TileBox* tile_box[3];
 	uint32_t tile_cap[3];

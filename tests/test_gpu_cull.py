@@ -90,6 +90,62 @@ def test_cull_both_kernel_forms_match_golden(gpu_ctx):
         cs.setOption(1, 0)  # (the retired tile-level-test option)
 
 
+def test_cull_cell_key_formats(gpu_ctx, oracle_port, monkeypatch):
+    """The per-tile cell tables carry 8-byte keys relative to the tile's box wherever every tile spans <= 65535 cell indices per axis, 16-byte keys
+    otherwise (the 1-frustum kernels: separate instantiations; the several-frusta kernels: a launch-uniform branch). The same scene under both
+    (LMX_CULL_WIDE_KEYS forces the wide form at build time) against the config-1 fixture, one frustum and eight in one pass, both 1-frustum forms; and a
+    scene that is wide by itself - two clusters 4 x 10^7 units apart whose spheres share tiles - against the oracle."""
+    g = np.load(os.path.join(G, "cull_config1.npz"))
+    sc = scenes.cull_scene(100_000, 3000.0, seed=1)
+    frusta = g["frusta"]
+    for wide in (False, True):
+        if wide:
+            monkeypatch.setenv("LMX_CULL_WIDE_KEYS", "1")
+        cs = api.CullingSystem(gpu_ctx)
+        cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+        info = cs.layoutInfo()
+        assert info["cell_key_bytes"] == (16 if wide else 8) and info["table_bytes"] > 0
+        try:
+            for variant in (1, 4):
+                cs.setOption(api.CULL_OPT_TILE_VARIANT, variant)
+                for f in range(len(frusta)):
+                    res = cs.cull(np.ascontiguousarray(frusta[f : f + 1]))
+                    H.assert_same_visible(gpu_visible(res, 0), H.sorted_by_type(g[f"vis_ids_{f}"], g[f"vis_types_{f}"]), f"wide {wide} variant {variant} camera {f}")
+            cs.setPassWidth(8)
+            res = cs.cull(np.ascontiguousarray(frusta[:8]), view=1)
+            for k in range(min(8, len(frusta))):
+                H.assert_same_visible(gpu_visible(res, k), H.sorted_by_type(g[f"vis_ids_{k}"], g[f"vis_types_{k}"]), f"wide {wide} 8 frusta, frustum {k}")
+        finally:
+            cs.setOption(api.CULL_OPT_TILE_VARIANT, -1)
+            cs.setPassWidth(0)
+    monkeypatch.delenv("LMX_CULL_WIDE_KEYS")
+    # wide by itself: 3000 spheres around x = -2e7 and 3000 around x = +2e7 (cell indices +-66 667: one 2048-sphere tile holds cells of both clusters)
+    rng = np.random.default_rng(5)
+    n = 6000
+    pos = rng.uniform(-900.0, 900.0, size=(n, 3))
+    pos[: n // 2, 0] -= 2.0e7
+    pos[n // 2 :, 0] += 2.0e7
+    radius = rng.uniform(0.5, 40.0, n).astype(np.float32)
+    ent, types = np.arange(n, dtype=np.int32), np.zeros(n, np.uint8)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(ent, types, pos, radius)
+    assert cs.layoutInfo()["cell_key_bytes"] == 16
+    ocs = oracle_port.culling_system()
+    ocs.add_bulk(ent, types, pos, radius)
+    cams = np.concatenate([api.viewport_frustum(pos=(-2.0e7, 0.0, 2500.0), far=6000.0), api.viewport_frustum(pos=(2.0e7 + 300.0, 100.0, 2000.0), far=4000.0),
+                           api.viewport_frustum(pos=(0.0, 0.0, 0.0), far=5.0e7, rot=(0.0, 0.70710678, 0.0, 0.70710678))])
+    seen = 0
+    for f in range(len(cams)):
+        res = cs.cull(cams[f : f + 1])
+        want = oracle_visible(ocs, cams[f : f + 1])
+        H.assert_same_visible(gpu_visible(res, 0), want, f"wide scene camera {f}")
+        seen += sum(len(v) for v in want.values()) if isinstance(want, dict) else len(want)
+    assert seen > 500
+    res = cs.cull(cams, view=1)
+    for f in range(len(cams)):
+        H.assert_same_visible(gpu_visible(res, f), oracle_visible(ocs, cams[f : f + 1]), f"wide scene, one pass, camera {f}")
+
+
 def test_cull_type_filter_and_views(gpu_ctx, oracle_port):
     sc = H.mixed_scene()
     cs = api.CullingSystem(gpu_ctx)

@@ -54,10 +54,12 @@ def test_cull_tile_register_budgets(tmp_path):
     # (round 6: the latency form keeps every chunk's cell-record offset + class in a register next to its eight chunks' spheres and ids: 68 VGPRs = 7 waves
     # per SIMD instead of 8. It runs where few tiles survive the tile-level test - the launch is the latency of the survivors, not their number:
     # 10.8 vs 11.0 us on the headline camera against round 5's 60-VGPR form, profiles/r06/cull1_ab_restructured.txt)
-    for tag, max_vgpr in (("k_cull_tileILi1ELi4ELi8ELi8ELi1ELi0E", 72), ("k_cull_tileILi1ELi4ELi8ELi4ELi2ELi0E", 48)):
+    # (the latency form is at 7 blocks per CU by its 68 VGPRs: up to 96 SGPRs cost it nothing; the streaming form - 8 blocks - must stay at <= 80,
+    # with 8-byte cell keys (FORM 2) and with 16-byte ones (FORM 4))
+    for tag, max_vgpr, max_sgpr in (("k_cull_tileILi1ELi4ELi8ELi8ELi1ELi0E", 72, 96), ("k_cull_tileILi1ELi4ELi8ELi4ELi2ELi0E", 48, 80), ("k_cull_tileILi1ELi4ELi8ELi4ELi4ELi0E", 48, 80)):
         for k in pick(meta, tag):
             assert k["private_segment_fixed_size"] == 0, (tag, k)
-            assert k["next_free_sgpr"] <= 80, f"{tag}: {k['next_free_sgpr']} SGPRs - 8 resident blocks per CU need <= 80"
+            assert k["next_free_sgpr"] <= max_sgpr, f"{tag}: {k['next_free_sgpr']} SGPRs - 8 resident blocks per CU need <= 80, 7 <= 96"
             assert k["next_free_vgpr"] <= max_vgpr, f"{tag}: {k['next_free_vgpr']} VGPRs"
             assert k["group_segment_fixed_size"] <= 8300, (tag, k)  # + <= 7.7 KiB of dynamic cell records: 8 blocks fit 160 KiB
     for k in pick(meta, "k_cull_tile"):  # every instantiation, the multi-frustum ones included: no spills
