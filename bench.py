@@ -780,7 +780,7 @@ def exchange_checks_and_frames(args, api, scenes, D, dev, ctx, cs, sc, xchg, ste
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "measured_copy_GBps", "frac_of_measured_copy", "frac_normal_radii",
                  "frac_dirty_cache", "leg")
-CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "host_cores", "single_thread_value", "error")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "host_cores", "single_thread_value", "O3_avx2_port_value", "error")
 CONFIG_KEYS = ("workload", "entities_per_gpu", "frusta", "visible_per_gpu", "visible_ids", "sharding", "timed_steps", "repetitions", "exchange_mode", "exchange_gather_us", "exchange_gather_record_bytes",
                "exchange_bytes_shipped_per_rank", "exchange_bytes_used_per_rank", "exchange_bytes_arriving_per_rank", "exchange_overflow_mask", "ranks_seen_by_rccl",
                "allgather_visible_counts", "union_equals_unsharded", "visible_total", "xgmi_curve", "TEST_MODE")
@@ -1098,8 +1098,29 @@ class CpuBaseline:
             "describe": self.o.describe(),
         }
         if not self.quick:
+            out.update(self._o3_line(n))
             out.update(self._other())
         return out
+
+    def _o3_line(self, n):
+        """SURVEY.md 8d's SECOND CPU line: the plain-C restatement built -O3 -march=x86-64-v3 (AVX2 + FMA allowed: NOT an oracle, the rounding may differ),
+        one thread, the same scene and frustum - clearly labelled, never `value`."""
+        try:
+            from oracle import pyoracle
+
+            o3 = pyoracle.Oracle("port_o3")
+            ocs = o3.culling_system()
+            ocs.add_bulk(self.sc["entity"], self.sc["type"], self.sc["pos"], self.sc["radius"])
+            ocs.cull(self.fr, n_threads=1, want_ids=False, cap=0)
+            times, t_start = [], time.time()
+            while len(times) < 10 and (time.time() - t_start) < 8.0:
+                t0 = time.perf_counter()
+                ocs.cull(self.fr, n_threads=1, want_ids=False, cap=0)
+                times.append(time.perf_counter() - t0)
+            med = float(np.median(times))
+            return {"O3_avx2_port_value": n / med, "O3_avx2_port_is": f"the plain-C restatement built -O3 -march=x86-64-v3 (FMA allowed: not an oracle), 1 thread, median of {len(times)} culls of the same workload"}
+        except Exception as e:  # noqa: BLE001 - an optional line
+            return {"O3_avx2_port_error": repr(e)}
 
     def _other(self):
         """the other two metrics of SURVEY.md 8d, bounded samples, one thread and 8 threads (parallel over instances / roots)"""

@@ -70,6 +70,8 @@ class Oracle:
     def __init__(self, kind: str = "port"):
         if kind == "port":
             path, self.prefix = ORACLE_SO, "orc_"
+        elif kind == "port_o3":  # -O3 -march=x86-64-v3 build of the port: a labelled CPU baseline (bench.py), never a checker - FMA changes the rounding
+            path, self.prefix = ORACLE_SO.replace("liblmx_oracle.so", "liblmx_oracle_o3.so"), "orc_"
         elif kind == "reference":
             path, self.prefix = REF_SO, "ref_"
         else:
