@@ -89,7 +89,6 @@ __device__ __forceinline__ uint32_t tile_status_lanes(const TileBox* box, uint32
 	const bool plane_lane = lane < 6u;
 	if (__ballot(plane_lane && rej) != 0) return TILE_REJECT | hi;
 	if (__ballot(plane_lane && !in) == 0) return TILE_ACCEPT | hi;
-#if LMX_CULL_TILE_PLANE_MASK
 	// MIXED: the planes every cell of the tile passes in both per-cell tests (lmx_math.h: tile_plane_skip_mask) go into bits 8..13
 	bool skip;
 	{
@@ -98,9 +97,6 @@ __device__ __forceinline__ uint32_t tile_status_lanes(const TileBox* box, uint32
 		skip = dp > -d + margin;
 	}
 	return TILE_MIXED | hi | (((uint32_t)__ballot(plane_lane && skip) & 63u) << 8);
-#else
-	return TILE_MIXED | hi;
-#endif
 }
 
 // tile_status() for up to 8 frusta at once: lane 6 f + k evaluates plane k of frustum f (<= 48 lanes), every lane forms the box
@@ -154,19 +150,14 @@ __device__ __forceinline__ uint32_t tile_status_lanes_multi(const TileBox* box, 
 // sphere_visible_d() of lmx_math.h on packed fp32: two planes per v_pk_mul_f32 / v_pk_add_f32, every product and sum rounded on its own
 // exactly like the scalar expression ((cx*nx + cy*ny) + cz*nz) + d, then t - (-r) == t + r. The all-test launch was issue-bound (69 % of
 // all SIMD cycles were VALU, profiles/r02/cull_all_test_counters_before_packed_fp32.json); the plane arithmetic is half of its VALU instructions.
-// experiment knobs (tools/build_variant.py + tools/run_workload.py; the defaults are what measured best)
-#ifndef LMX_CULL_NT_LOADS
-#define LMX_CULL_NT_LOADS 1   // the streamed spheres / ids are loaded non-temporally in the streaming tile variants (every sphere is read once per cull): cache-cold all-test launch 43.8-44.3 -> 42.8 us, back-to-back 37.0-37.4 -> 37.9 us (profiles/r03/cull_ab_variants.txt)
-#endif
-#ifndef LMX_CULL_STAGE_IDS
-#define LMX_CULL_STAGE_IDS 1 // (1-frustum STREAMING variants) a wave compacts its visible ids in LDS and writes them with full-width stores instead of one partial-width store per chunk: the launch with 43 % visible 47.6 -> 46.0 us. In the latency variant (all 8 chunks in flight: the headline camera) it cost +0.3 us per step and +0.9 us cache-cold (8 KiB more LDS per block, one more wait at the wave's end): not compiled in there (profiles/r03/cull_ab_variants.txt)
-#endif
-#ifndef LMX_CULL_TILE_PLANE_MASK
-#define LMX_CULL_TILE_PLANE_MASK 1 // 1-frustum kernels: phase A leaves out the planes the whole tile is known to pass (lmx_math.h: tile_plane_skip_mask; the emulation re-classifies every cell with and without). Launch with every cell CELL_TEST through the AABB pre-tests: 49.9 -> 47.6 us; nothing else moves
-#endif
-#ifndef LMX_PACK_EARLY_EXIT
-#define LMX_PACK_EARLY_EXIT 1 // k_cull_pack: blocks without a slice of their shard's window leave at once, the others fetch their first ids under the prefix of the counters
-#endif
+// Choices of the 1-frustum kernels that were build knobs while they were measured (rounds 3-5; each had one value ever since, the knobs went in round 6):
+//   * non-temporal loads of the streamed spheres / ids in the streaming form (every sphere is read once per cull): cache-cold all-test launch 43.8-44.3 -> 42.8 us,
+//     back to back 37.0-37.4 -> 37.9 us (profiles/r03/cull_ab_variants.txt)
+//   * the streaming form compacts a wave's visible ids in LDS and writes them with full-width stores instead of one partial-width store per chunk: the launch with
+//     43 % visible 47.6 -> 46.0 us. In the latency form (all 8 chunks in flight: the headline camera) it cost +0.3 us per step and +0.9 us cache-cold: not there
+//   * phase A leaves out the planes the whole tile is known to pass (lmx_math.h: tile_plane_skip_mask; the emulation re-classifies every cell with and without):
+//     launch with every cell CELL_TEST through the AABB pre-tests 49.9 -> 47.6 us; nothing else moves
+//   * k_cull_pack: blocks without a slice of their shard's window leave at once, the others fetch their first ids under the prefix of the counters
 // Measured and NOT kept (profiles/r03/cull_ab_variants.txt): touching the NEXT tile's box / cell keys / chunk headers at block start
 // (global_load_lds into a scratch corner, nothing waits): +2-3 us in every regime, cold included; capping the kernel at 80 SGPRs so
 // that 8 instead of 7 blocks are resident per CU (MI355X_MICROARCH.md "Residency"): within noise; a persistent grid for the streaming
@@ -237,9 +228,6 @@ __device__ __forceinline__ bool sphere_visible_d_pk(const DevFrustum& f, const f
 // Measured (profiles/r05/cull8_*): 8 frusta x 10 M all-test 141 us (exact loop) -> 137 (the same pre-test on v_mfma_f32_32x32x2_f32, two
 // per set: the f32-input MFMA runs at the vector rate and, as tools/mfma_overlap_probe.hip shows, VALU work does not hide behind it in
 // compiler-scheduled code - deleted) -> 117 us cold / 110 warm (this form); VALU wave-instructions 62.6 M -> 38.8 M.
-#ifndef LMX_CULL8_MFMA
-#define LMX_CULL8_MFMA 1      // 0: every (chunk, frustum) through the exact loop (rounds 2-4)
-#endif
 
 // LDS record of one (cell, frustum): the six cell-relative plane distances of ShiftedFrustum::getRelative and the cell's class
 struct alignas(16) CellInfo { float d[6]; uint32_t cls, pad; };
@@ -250,9 +238,6 @@ static_assert(sizeof(CellInfo) == 32, "two ds_read_b128 per (lane, chunk, frustu
 // 600 spilled SGPRs); FS is the stride of a chunk's visibility bits.
 #ifndef LMX_ASM_SGPR
 #define LMX_ASM_SGPR(x) "+s"(x) // an empty asm's operand that pins a wave-uniform value in a scalar register (tests/hostsim's runtime header maps it to a general register)
-#endif
-#ifndef LMX_CULL8_PROBE
-#define LMX_CULL8_PROBE 0     // timing probes of k_cull_tile<F = 0> (tools/build_variant.py; results wrong): 1 = tile-level tests only, 2 = no cell classification, 4 = no sphere tests (everything tested counts as culled), 8 = spheres / ids not fetched, 16 = nothing written
 #endif
 // (several frusta) at least 5 waves per SIMD, i.e. at most 96 VGPRs: the residency the LDS of the cell records allows anyway (5 blocks of 4
 // waves per CU) - and with a register budget of <= 256 the compiler selects the VGPR form of the MFMA (accumulators in plain VGPRs, where the
@@ -322,7 +307,6 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 		any_live = st_bits != 0;
 	}
 	if (!any_live) return;
-	if constexpr (F != 1) { if (LMX_CULL8_PROBE & 1) return; } // (timing probe: the tile-level tests alone)
 	// (several frusta) the class word of a cell: CellClass of frustum f in bits 2f, 2f + 1. tile_word = what the tile-level test settled.
 	uint32_t tile_word = 0;
 	// (several frusta) a cell's record under a frustum is its six plane distances, 24 bytes - the class lives in the word: 25 % less LDS per
@@ -424,7 +408,6 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 #pragma unroll 1
 				for (int f = 0; f < nf; ++f) {
 					if (((st_bits >> (2 * f)) & 3u) != TILE_MIXED) continue; // wave-uniform
-					if (LMX_CULL8_PROBE & 2) { word |= (uint32_t)CELL_TEST << (2 * f); continue; } // (timing probe: no classification, stale distances)
 					word |= classify(t, f, key) << (2 * f);
 				}
 				s_word[t] = word;
@@ -486,19 +469,17 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 	// two instructions: {nx | ny} and {nz | 1} by half-wave), where a lane's two frustum slots keep their cell records, and which of
 	// them the tile-level test left MIXED (only those can leave a sphere undecided: the records of the others were never written)
 	constexpr int NG = F != 1 ? (WAVES == 4 ? 2 : 1) : 1; // groups of four frusta: the 5..8-frusta shape has 4 waves, the 2..4-frusta shape 8
-	constexpr bool PRETEST = F != 1 && LMX_CULL8_MFMA != 0;
+	constexpr bool PRETEST = F != 1;
 	u32x4_t pre_ab[NG]; // the plane rows of a group: eight K slots per half-wave
 	uint32_t pre_off[NG][2];
 	uint64_t pre_care[NG][2];
 	// The pre-test evaluates ALL frusta of a group for a chunk at once; the exact loop only the (chunk, frustum) pairs with a lane in a
 	// CELL_TEST cell. A tile that few frusta left MIXED (a sparse scene: most cells are settled by the cell tests) is cheaper there.
-#ifndef LMX_CULL8_MFMA_MIN_MIXED
-#define LMX_CULL8_MFMA_MIN_MIXED 3
-#endif
+	constexpr uint32_t PRETEST_MIN_MIXED = 3;
 	bool pretest_tile = false;
 	if constexpr (PRETEST) {
 		const uint32_t mixed_bits = (st_bits >> 1) & ~st_bits & 0x5555u; // bit 2 f: frustum f is MIXED
-		pretest_tile = (uint32_t)__popc(mixed_bits) >= (uint32_t)LMX_CULL8_MFMA_MIN_MIXED;
+		pretest_tile = (uint32_t)__popc(mixed_bits) >= PRETEST_MIN_MIXED;
 		if (pretest_tile) {
 			const uint32_t row = lane & 31u, k = lane >> 5;
 			const uint32_t rp = (row & 3u) + 4u * ((row >> 3) & 1u), rh = (row >> 2) & 1u, rq = row >> 4;
@@ -539,7 +520,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 	// 1-frustum kernels: the wave's visible ids (and slots) are compacted in LDS as they are found - the write-out below is then a
 	// handful of full-width stores instead of one partial-width store per chunk (156 k of them on a launch with 43 % visible)
 	constexpr bool STREAMING = F == 1 && (FORM == 2 || FORM == 4); // (template slot FORM: 0 = several frusta; one frustum: 1 = latency form, 2 = streaming form, 3 / 4 = the same two with 16-byte cell keys)
-	constexpr bool STAGE = STREAMING && LMX_CULL_STAGE_IDS != 0; // streaming variants only (as the non-temporal loads): the latency variant pays for the extra LDS and the wait at the wave's end
+	constexpr bool STAGE = STREAMING; // streaming variants only (as the non-temporal loads): the latency variant pays for the extra LDS and the wait at the wave's end
 	__shared__ int32_t s_stage_ids[STAGE ? WAVES : 1][STAGE ? CHW * 64 : 1];
 	__shared__ int32_t s_stage_slots[STAGE && SLOTS ? WAVES : 1][STAGE && SLOTS ? CHW * 64 : 1];
 	uint32_t staged = 0; // wave-uniform
@@ -597,7 +578,6 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 				// issue all their loads first). A chunk that needs nothing reads one 16-byte sphere / one id at a wave-uniform address instead
 				// (the wave's first entity: one cache line, usually the one its neighbour chunk fetches anyway) and ignores the value.
 				const uint32_t e0 = chunk0 << 6;
-				if (LMX_CULL8_PROBE & 8) { id[g + i] = (int32_t)e; sp[i] = make_float4(1.f, 2.f, 3.f, 4.f); continue; } // (timing probe: nothing fetched)
 				id[g + i] = g_ids[need_id(i) ? e : e0];
 				sp[i] = g_spheres[need_sphere(i) ? e : e0];
 				continue;
@@ -611,13 +591,10 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 			const int32_t* id_at = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(g_ids + ((size_t)(chunk0 + g) << 6) + i * 64) + off_i);
 			const v4f* sp_at = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(g_spheres + ((size_t)(chunk0 + g) << 6) + i * 64) + off_s);
 			v4f t;
-#if LMX_CULL_NT_LOADS
 			if constexpr (F == 1 && (FORM == 2 || FORM == 4)) { // the streaming form: every sphere is read once per cull and nothing of it is reused
 				id[g + i] = __builtin_nontemporal_load(id_at);
 				t = __builtin_nontemporal_load(sp_at);
-			} else
-#endif
-			{
+			} else {
 				id[g + i] = *id_at;
 				t = *sp_at;
 			}
@@ -721,15 +698,10 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 #pragma unroll
 				for (int i = 0; i < GRP; ++i) culled2[i] = (exact_chunks >> i) & 1u ? 0u : culled2[i]; // (wave-uniform: an undecided chunk starts over)
 			}
-			if (LMX_CULL8_PROBE & 4) { // (timing probe: no sphere tests - every tested sphere counts as culled, so that what follows has the real launch's volume)
-#pragma unroll
-				for (int i = 0; i < GRP; ++i) culled2[i] = 0xffffu;
-			}
 #pragma unroll 1
 			for (int f = 0; f < (exact_chunks != 0 ? nf : 0); ++f) {
 				const uint32_t st = (st_bits >> (2 * f)) & 3u;
 				if (st == TILE_REJECT) continue; // nothing of this tile is visible in frustum f
-				if (LMX_CULL8_PROBE & 4) continue; // (timing probe: no sphere tests)
 				const bool mixed = any_mixed && st == TILE_MIXED; // wave-uniform
 				// what this wave's chunks hold for frustum f, from the class words (wave-uniform): nothing at all -> next frustum; the chunks with
 				// a lane in a CELL_TEST cell (bit i) -> only those are tested, only for them the cell records are read
@@ -902,7 +874,6 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 		}
 		return;
 	}
-	if constexpr (F != 1) { if (LMX_CULL8_PROBE & 16) return; } // (timing probe: nothing reserved, nothing written)
 	// C. reserve: lane f adds this wave's count for frustum f to the shard's counter (one atomic instruction for all frusta),
 	// then the ids go from registers to the reserved ranges in chunk order
 	uint32_t base_v = 0;
@@ -1110,14 +1081,10 @@ __global__ __launch_bounds__(256) void k_cull_pack(const int32_t* __restrict__ s
 	const uint32_t c = counts[s * cnt_pad];
 	// a block whose slice of the shard's window is empty has nothing to place (most of them when little is visible: the grid is sized
 	// for a full window), and the others fetch their first ids now, under the prefix of the counters instead of behind it
-#if LMX_PACK_EARLY_EXIT
 	if (blockIdx.y * 256u >= c && !totals_block) return;
-#endif
 	const int32_t* from = src + win_base[s];
 	const uint32_t k0 = blockIdx.y * 256u + t;
-#if LMX_PACK_EARLY_EXIT
 	const int32_t first = k0 < c ? from[k0] : 0;
-#endif
 	uint32_t before = 0;
 	for (uint32_t k = t; k < s; k += 256u) before += counts[k * cnt_pad]; // (<= 3 iterations)
 #pragma unroll
@@ -1134,12 +1101,8 @@ __global__ __launch_bounds__(256) void k_cull_pack(const int32_t* __restrict__ s
 	int32_t* to = dst + at;
 	const uint32_t room = at < dst_cap ? dst_cap - at : 0u;
 	const uint32_t n = c < room ? c : room;
-#if LMX_PACK_EARLY_EXIT
 	if (k0 < n) to[k0] = first;
 	for (uint32_t k = k0 + gridDim.y * 256u; k < n; k += gridDim.y * 256u) to[k] = from[k];
-#else
-	for (uint32_t k = k0; k < n; k += gridDim.y * 256u) to[k] = from[k];
-#endif
 }
 
 template <int F, int WAVES, int CHW, int GRP, int FORM, int SLOTS_I>

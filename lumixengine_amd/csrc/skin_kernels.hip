@@ -492,9 +492,6 @@ constexpr uint32_t palette_items(uint32_t max_rows, uint32_t copies) { return ma
 #ifndef LMX_SHARED_NT
 #define LMX_SHARED_NT 1    // non-temporal output stores (the 12 GB of positions are never read back by this kernel)
 #endif
-#ifndef LMX_SHARED_ST16
-#define LMX_SHARED_ST16 0  // 1: four lanes' 12-byte results transposed (DPP) into three 16-byte stores (measured: slower)
-#endif
 
 typedef float v3f_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -507,31 +504,6 @@ __device__ __forceinline__ void store_position(F3* dst, const F3& r) {
 #else
 	*dst = r;
 #endif
-}
-
-// The same 768 bytes as three 16-byte stores per four lanes: lane p of a quad stores words [4p, 4p + 4) of the quad's twelve
-// floats (x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3), lane 3 stores nothing. Three quad-permute DPP moves + selects.
-// `wave_dst` = &out[first vertex of the wave]; only for waves whose 64 vertices are consecutive (not clamped at the tile's end).
-__device__ __forceinline__ void store_position_quad16(F3* wave_dst, const F3& r, uint32_t lane) {
-	const uint32_t p = lane & 3u;
-	const int xi = __float_as_int(r.x), yi = __float_as_int(r.y), zi = __float_as_int(r.z);
-	// quad_perm [a, b, c, d] = a | b << 2 | c << 4 | d << 6: lane k of a quad reads lane perm[k]
-	const int xs = __builtin_amdgcn_mov_dpp(xi, 1 | 2 << 2 | 3 << 4 | 3 << 6, 0xf, 0xf, true); // lane0 <- x1, lane1 <- x2, lane2 <- x3
-	const int ys = __builtin_amdgcn_mov_dpp(yi, 0 | 2 << 2 | 3 << 4 | 3 << 6, 0xf, 0xf, true); // lane1 <- y2, lane2 <- y3
-	const int zs = __builtin_amdgcn_mov_dpp(zi, 0 | 1 << 2 | 3 << 4 | 3 << 6, 0xf, 0xf, true); // lane2 <- z3
-	const int w0 = p == 0 ? xi : (p == 1 ? yi : zi);
-	const int w1 = p == 0 ? yi : (p == 1 ? zi : xs);
-	const int w2 = p == 0 ? zi : (p == 1 ? xs : ys);
-	const int w3 = p == 0 ? xs : (p == 1 ? ys : zs);
-	if (p != 3u) {
-		v4f_a4 t = {__int_as_float(w0), __int_as_float(w1), __int_as_float(w2), __int_as_float(w3)};
-		v4f_a4* dst = reinterpret_cast<v4f_a4*>(reinterpret_cast<float*>(wave_dst) + (lane >> 2) * 12u + p * 4u);
-#if LMX_SHARED_NT
-		__builtin_nontemporal_store(t, dst);
-#else
-		*dst = t;
-#endif
-	}
 }
 
 template <int COPIES, int MODE>
@@ -734,12 +706,7 @@ __device__ __forceinline__ void skin_shared_tile(const SkinInstance& in0, const 
 			asm volatile("" : "+v"(vin[k].a), "+v"(vin[k].b));
 			const F3 r = skin_blend<COPIES, MODE>(rows, vin[k]);
 			if (!LMX_PROBE_SKIP(8) || r.x == 123.25f) {
-#if LMX_SHARED_ST16
-				if (v_wave + 63u <= v_last) store_position_quad16(o + v_wave, r, lane); // wave-uniform: 64 consecutive vertices
-				else store_position(o + v, r);
-#else
 				store_position(o + v, r);
-#endif
 			}
 			__builtin_amdgcn_sched_barrier(0); // one vertex's 12 palette rows (48 VGPRs) in flight at a time
 			if (k == SHARED_SPREAD_AFTER) {
