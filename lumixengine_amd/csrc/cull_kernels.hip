@@ -387,10 +387,12 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 			return ci.cls;
 		};
 		if constexpr (F == 1) {
-			for (uint32_t t = threadIdx.x; t < a.cell_cap; t += THREADS) {
-				const CellKey key = load_key(t); // issued before n_cells is known; the tail of the slice holds dead keys
-				if (t < n_cells) classify(t, 0, key);
-			}
+			// The lane's first key is requested NOW, next to the tile table's scalar load, and pinned: written as `key = load(t); if (t < n_cells) ...` the compiler
+			// sank the load behind the wait for n_cells (seen in the ISA: table -> wait -> key -> wait -> classify; the tail of a tile's slice holds dead keys
+			// precisely so that the load needs no bound). Tiles of more than 256 cells (<= 480) take a second, ordinary iteration.
+			CellKey key0 = load_key(threadIdx.x < a.cell_cap ? threadIdx.x : 0u);
+			asm volatile("" : "+v"(key0.ix), "+v"(key0.iy), "+v"(key0.iz), "+v"(key0.meta));
+			for (uint32_t t = threadIdx.x; t < n_cells; t += THREADS) classify(t, 0, t == threadIdx.x ? key0 : load_key(t));
 		} else {
 			// Several frusta: ONE lane per cell, the MIXED frusta in an inner, wave-uniform loop (scalar loads of the frustum). The cell's key is
 			// loaded once and its fp64 origin formed once for all frusta. Rounds 2 / 3 spread the (cell, frustum) PAIRS over the waves - every
