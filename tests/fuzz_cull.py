@@ -1,6 +1,6 @@
 """Randomised stress of the culling C ABI against the CPU oracle (CullingSystem::add / remove / set* / cull,
 src/renderer/culling_system.cpp:131-369): random scenes, random interleavings of single and batched updates, explicit and automatic
-re-sorts (synchronous and on the worker thread), overflow reserves, every tile variant / tile-test mode / pass width, type filters,
+re-sorts (synchronous and on the worker thread), overflow reserves, both forms of the 1-frustum kernel, every pass width, type filters,
 several result views, all three read paths. After every cull the id sets must equal the oracle's.
 
     python -m tests.fuzz_cull [--seeds 0-19] [--steps 400]            # on the GPU
