@@ -1,6 +1,8 @@
 """The bench line's contract (keys the driver and the judge read), checked on the committed output of the round's last full run
 (profiles/rNN/bench_full_run.json = stdout of `python bench.py` on an MI355X): no GPU needed."""
 import glob
+import subprocess
+import sys
 import json
 import os
 
@@ -108,3 +110,12 @@ def test_compact_line_holds_its_limit_whatever_the_legs_return():
         assert k in d, k
     assert bench.library_is_the_product(os.path.join(ROOT, "lumixengine_amd", "liblumix_mi355.so"))
     assert not bench.library_is_the_product(os.path.join(ROOT, "tests", "_build", "hostsim", "liblumix_hostsim.so"))  # bench.py never times the simulated device
+
+
+def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks_or_says_why_not():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver's N = 1 line would look with another N): bench.py becomes the launcher. On a box with
+    fewer GPUs than ranks - this container has none - it must say so and exit non-zero at once, not hang in a rendezvous and not print a JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LMX_LIB_PATH", "LMX_HOSTSIM")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s)" in r.stderr and "--gpus 2" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
