@@ -87,6 +87,43 @@ def test_exchange_single_rank_matches_oracle(gpu_ctx, oracle_port, mode, monkeyp
         empty.close()
 
 
+def test_exchange_capacities_follow_a_one_frustum_list_when_asked(gpu_ctx, oracle_port, monkeypatch):
+    """LMX_EXCHANGE_AUTO_CAPS=1 extends the capacities-follow-the-lists rule to frames of ONE frustum (off by default: the headline step keeps its caller-given
+    capacity and pays neither the statistics kernel nor the host wait): created for 200 000 ids, the record shrinks to what the list needs two frames later,
+    grows again when the camera sees more, and every frame's ids stay the oracle's; `keep_fixed` pins a shape."""
+    monkeypatch.setenv("LMX_EXCHANGE_AUTO_CAPS", "1")
+    monkeypatch.setenv("LMX_EXCHANGE_MODE", "inline")
+    sc = scenes.cull_scene(200_000, 4000.0, seed=13, mixed_types=True)
+    cs = api.CullingSystem(gpu_ctx)
+    cs.build(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    ocs = oracle_port.culling_system()
+    ocs.add_bulk(sc["entity"], sc["type"], sc["pos"], sc["radius"])
+    cams = H.frusta(api, names=["narrow_fov", "origin_identity"])
+    want = [np.sort(ocs.cull(cams[f : f + 1])[0]) for f in range(2)]
+    if len(want[0]) > len(want[1]):  # camera 0 = the one that sees less
+        cams, want = cams[::-1].copy(), want[::-1]
+    assert 0 < len(want[0]) * 2 < len(want[1]) < 150_000
+    x = api.VisibleExchange(gpu_ctx, 0, 1, api.exchange_unique_id(), 200_000)
+    try:
+        caps = []
+        for frame, cam in enumerate([0, 0, 0, 0, 1, 1, 1, 1]):
+            slot = x.cull(cams[cam])
+            st = x.stats(slot)
+            counts, ids = x.read(slot, 0)
+            caps.append(st["caps"][0])
+            if st["overflow_mask"] == 0:
+                assert np.array_equal(np.sort(ids), want[cam]), frame
+            else:  # the two frames after the camera change: flagged, clipped, never out of bounds
+                assert int(counts.sum()) == len(want[cam]) > st["caps"][0] == len(ids) and set(ids.tolist()) <= set(want[cam].tolist()), frame
+        assert caps[0] == caps[1] == 200_000 and caps[2] == caps[3] == D.cap_for(len(want[0])), caps
+        assert caps[4] == caps[5] == caps[2] and caps[6] == caps[7] == D.cap_for(len(want[1])), caps  # frames 4 / 5 overflow, frame 6 (slot 0 again) has regrown
+        x.setCaps([200_000], keep_fixed=True)
+        for _ in range(4):
+            assert x.layout(x.cull(cams[0]))["caps"] == [200_000]
+    finally:
+        x.close()
+
+
 def _loopback_library():
     """tests/cpp/loopback_rccl.cpp -> tests/_build/libloopback_rccl.so (g++ against the HIP runtime; host code only)"""
     import os
