@@ -26,6 +26,33 @@ __global__ void k_hdr_strided(const uint4* __restrict__ hdr, unsigned n_tiles, u
 	}
 }
 
+// the tile test's shape: wave 0 reads the block's 32-byte box, a few dozen dependent operations, verdict through LDS + barrier, everybody exits
+__global__ void k_box_verdict(const uint4* __restrict__ hdr, unsigned* __restrict__ out) {
+	__shared__ unsigned s_v;
+	if (threadIdx.x < 64) {
+		const uint4 h = hdr[blockIdx.x * 2 + (threadIdx.x & 1)];
+		float v = (float)h.x + (float)threadIdx.x;
+#pragma unroll
+		for (int k = 0; k < 40; ++k) v = v * 1.0001f + (float)h.y;
+		if (threadIdx.x == 0) s_v = v == 12345.f ? 1u : 0u;
+	}
+	__syncthreads();
+	if (s_v) out[threadIdx.x] = s_v; // never
+}
+// the same for TWO tiles per block of twice the threads (waves of the upper half would take the second tile)
+__global__ void k_box_verdict2(const uint4* __restrict__ hdr, unsigned* __restrict__ out) {
+	__shared__ unsigned s_v;
+	if (threadIdx.x < 64) {
+		const uint4 h = hdr[blockIdx.x * 4 + (threadIdx.x & 3)];
+		float v = (float)h.x + (float)threadIdx.x;
+#pragma unroll
+		for (int k = 0; k < 40; ++k) v = v * 1.0001f + (float)h.y;
+		if (threadIdx.x == 0) s_v = v == 12345.f ? 1u : 0u;
+	}
+	__syncthreads();
+	if (s_v) out[threadIdx.x] = s_v;
+}
+
 template <typename F> static void time_it(const char* name, int grid, int block, F launch, bool last = false) {
 	hipStream_t s;
 	hipStreamCreate(&s);
@@ -62,6 +89,12 @@ int main() {
 	}
 	time_it("empty", 2442, 64, [&](hipStream_t s) { hipLaunchKernelGGL(k_empty, dim3(2442), dim3(64), 0, s); });
 	time_it("empty", 2442, 1024, [&](hipStream_t s) { hipLaunchKernelGGL(k_empty, dim3(2442), dim3(1024), 0, s); });
+	// round 6: what the headline camera's launch is made of (95 % of its 4883 tiles end at the box test) - and whether fewer, larger blocks would make it cheaper
+	time_it("box_verdict", 4884, 256, [&](hipStream_t s) { hipLaunchKernelGGL(k_box_verdict, dim3(4884), dim3(256), 0, s, hdr, out); });
+	time_it("box_verdict", 4884, 64, [&](hipStream_t s) { hipLaunchKernelGGL(k_box_verdict, dim3(4884), dim3(64), 0, s, hdr, out); });
+	time_it("box_verdict 2 tiles per block", 2442, 512, [&](hipStream_t s) { hipLaunchKernelGGL(k_box_verdict2, dim3(2442), dim3(512), 0, s, hdr, out); });
+	time_it("box_verdict 2 tiles per block", 2442, 256, [&](hipStream_t s) { hipLaunchKernelGGL(k_box_verdict2, dim3(2442), dim3(256), 0, s, hdr, out); });
+	time_it("box_verdict 2 tiles per block", 2442, 64, [&](hipStream_t s) { hipLaunchKernelGGL(k_box_verdict2, dim3(2442), dim3(64), 0, s, hdr, out); });
 	time_it("hdr_strided", 39, 256, [&](hipStream_t s) { hipLaunchKernelGGL(k_hdr_strided, dim3(39), dim3(256), 0, s, hdr, n_tiles, out); });
 	time_it("hdr_strided", 256, 256, [&](hipStream_t s) { hipLaunchKernelGGL(k_hdr_strided, dim3(256), dim3(256), 0, s, hdr, n_tiles, out); }, true);
 	printf("]\n");
