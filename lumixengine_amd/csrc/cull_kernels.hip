@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "lmx_kernels.h"
+#include <type_traits>
 
 #include <hip/hip_ext.h>
 
@@ -318,6 +319,24 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 		tile_word = st_bits & ~(st_bits >> 1) & 0x5555u;
 	}
 
+	// (streaming forms) the wave's first group of spheres and ids, requested UNDER phase A: a MIXED tile's blocks otherwise have nothing in flight from the
+	// verdict to the barrier behind the classification (keys -> classes -> barrier -> headers), and a launch's first round of blocks all sit there at once.
+	// Requested behind the keys: loads return in order, the classification waits for the keys only. What a chunk turns out not to need is ignored.
+	constexpr bool STREAMING = F == 1 && (FORM == 2 || FORM == 4); // (template slot FORM: 0 = several frusta; one frustum: 1 = latency form, 2 = streaming form, 3 / 4 = the same two with 16-byte cell keys)
+	constexpr bool PRELOAD = STREAMING;
+	typedef float v4f_pre __attribute__((ext_vector_type(4)));
+	v4f_pre pre_sp[PRELOAD ? GRP : 1];
+	int32_t pre_id[PRELOAD ? GRP : 1];
+	auto preload_group0 = [&](auto with_spheres) {
+		if constexpr (PRELOAD) {
+			const size_t e0 = ((size_t)((tile_ent >> 6) + wave * CHW) << 6) + lane;
+#pragma unroll
+			for (int i = 0; i < GRP; ++i) {
+				pre_id[i] = __builtin_nontemporal_load(g_ids + e0 + i * 64);
+				if constexpr (decltype(with_spheres)::value) pre_sp[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f_pre*>(g_spheres + e0 + i * 64));
+			}
+		}
+	};
 	uint32_t first_cell = 0;
 	if (any_mixed) {
 		// A. classify the tile's cells into LDS: class + the cell-relative plane distances (per cell, as the reference's getRelative)
@@ -329,25 +348,37 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 		// kernel the 80-SGPR limit of 8 resident blocks per CU; the several-frusta kernels, at 5 blocks per CU by their LDS, branch on a launch-uniform flag)
 		const bool packed_keys = F == 1 ? FORM <= 2 : a.keys_packed != 0;
 		const char* keys = reinterpret_cast<const char*>(g_tile_cells) + ((size_t)tile_index * a.cell_cap << (packed_keys ? 3 : 4));
-		auto load_key = [&](uint32_t t) -> CellKey {
-			CellKey key;
+		struct FetchedKey { uint4 raw; int32_t lo[3]; }; // a key as it comes out of memory (+ the tile box's low corner, for a packed one): requested in one place, decoded in another
+		auto fetch_key = [&](uint32_t t) -> FetchedKey {
+			FetchedKey k;
 			if (packed_keys) { // launch-uniform
 				const uint2 raw = reinterpret_cast<const uint2*>(keys)[t];
+				k.raw = uint4{raw.x, raw.y, 0u, 0u};
 				// (the box's low corner through the VECTOR memory path - an opaque zero in the address - so that it lands in vector registers, of which
 				// phase A has plenty: as scalars it puts the streaming form at 81 SGPRs, one over what 8 resident blocks per CU allow)
 				uint32_t zero = 0;
 				asm volatile("" : "+v"(zero));
 				const int32_t* box_lo = reinterpret_cast<const int32_t*>(g_tile_box + tile_index) + zero;
-				key.ix = box_lo[0] + (int32_t)(raw.x & 0xffffu);
-				key.iy = box_lo[1] + (int32_t)(raw.x >> 16);
-				key.iz = box_lo[2] + (int32_t)(raw.y & 0xffffu);
-				key.meta = ((raw.y & PACKED_CELL_BIG) ? 0x100u : 0u) | ((raw.y & PACKED_CELL_DEAD) ? (uint32_t)CELL_DEAD : 0u);
+				k.lo[0] = box_lo[0]; k.lo[1] = box_lo[1]; k.lo[2] = box_lo[2];
 			} else {
-				const uint4 raw = reinterpret_cast<const uint4*>(keys)[t]; // ONE 16-byte load (ix, iy, iz, meta), not meta -> branch -> the rest
-				key.ix = (int32_t)raw.x; key.iy = (int32_t)raw.y; key.iz = (int32_t)raw.z; key.meta = raw.w;
+				k.raw = reinterpret_cast<const uint4*>(keys)[t]; // ONE 16-byte load (ix, iy, iz, meta), not meta -> branch -> the rest
+				k.lo[0] = k.lo[1] = k.lo[2] = 0;
+			}
+			return k;
+		};
+		auto decode_key = [&](const FetchedKey& k) -> CellKey {
+			CellKey key;
+			if (packed_keys) {
+				key.ix = k.lo[0] + (int32_t)(k.raw.x & 0xffffu);
+				key.iy = k.lo[1] + (int32_t)(k.raw.x >> 16);
+				key.iz = k.lo[2] + (int32_t)(k.raw.y & 0xffffu);
+				key.meta = ((k.raw.y & PACKED_CELL_BIG) ? 0x100u : 0u) | ((k.raw.y & PACKED_CELL_DEAD) ? (uint32_t)CELL_DEAD : 0u);
+			} else {
+				key.ix = (int32_t)k.raw.x; key.iy = (int32_t)k.raw.y; key.iz = (int32_t)k.raw.z; key.meta = k.raw.w;
 			}
 			return key;
 		};
+		auto load_key = [&](uint32_t t) -> CellKey { return decode_key(fetch_key(t)); };
 		auto classify = [&](uint32_t t, int f, const CellKey key) -> uint32_t {
 			const bool dead = (key.meta & CELL_DEAD) != 0;
 			const bool big = (key.meta & 0x100u) != 0;
@@ -390,7 +421,11 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 			// The lane's first key is requested NOW, next to the tile table's scalar load, and pinned: written as `key = load(t); if (t < n_cells) ...` the compiler
 			// sank the load behind the wait for n_cells (seen in the ISA: table -> wait -> key -> wait -> classify; the tail of a tile's slice holds dead keys
 			// precisely so that the load needs no bound). Tiles of more than 256 cells (<= 480) take a second, ordinary iteration.
-			CellKey key0 = load_key(threadIdx.x < a.cell_cap ? threadIdx.x : 0u);
+			const FetchedKey fetched0 = fetch_key(threadIdx.x < a.cell_cap ? threadIdx.x : 0u);
+			__builtin_amdgcn_sched_barrier(0);
+			preload_group0(std::true_type{});
+			__builtin_amdgcn_sched_barrier(0);
+			CellKey key0 = decode_key(fetched0);
 			asm volatile("" : "+v"(key0.ix), "+v"(key0.iy), "+v"(key0.iz), "+v"(key0.meta));
 			for (uint32_t t = threadIdx.x; t < n_cells; t += THREADS) classify(t, 0, t == threadIdx.x ? key0 : load_key(t));
 		} else {
@@ -467,6 +502,10 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 		}
 	}
 
+	if constexpr (PRELOAD) {
+		if (!any_mixed) preload_group0(std::false_type{}); // an accepted tile with padding or tombstones: its first group's ids (no sphere of it is ever tested)
+	}
+
 	// (several frusta) per-tile operands of the matrix-pipe pre-test: the plane rows of each group of four frusta (the A operands of the
 	// two instructions: {nx | ny} and {nz | 1} by half-wave), where a lane's two frustum slots keep their cell records, and which of
 	// them the tile-level test left MIXED (only those can leave a sphere undecided: the records of the others were never written)
@@ -521,7 +560,6 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 	static_assert(CHW * 64 <= 1023, "a wave's count per frustum fits 10 bits");
 	// 1-frustum kernels: the wave's visible ids (and slots) are compacted in LDS as they are found - the write-out below is then a
 	// handful of full-width stores instead of one partial-width store per chunk (156 k of them on a launch with 43 % visible)
-	constexpr bool STREAMING = F == 1 && (FORM == 2 || FORM == 4); // (template slot FORM: 0 = several frusta; one frustum: 1 = latency form, 2 = streaming form, 3 / 4 = the same two with 16-byte cell keys)
 	constexpr bool STAGE = STREAMING; // streaming variants only (as the non-temporal loads): the latency variant pays for the extra LDS and the wait at the wave's end
 	__shared__ int32_t s_stage_ids[STAGE ? WAVES : 1][STAGE ? CHW * 64 : 1];
 	__shared__ int32_t s_stage_slots[STAGE && SLOTS ? WAVES : 1][STAGE && SLOTS ? CHW * 64 : 1];
@@ -589,6 +627,13 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 			// branches): ~12 of a chunk's ~63 vector instructions on a launch bound by their issue (profiles/r06/cull1_probes.txt). Now: the group's
 			// uniform base + ONE lane offset + an immediate per chunk; a chunk that needs nothing reads one line at lane offset 0 and ignores it (its
 			// lanes' classes are CELL_REJECT: whatever the registers hold, nothing of it is visible).
+			if constexpr (PRELOAD) {
+				if (g == 0) { // requested under phase A (an accepted tile's ids: below the dense copy)
+					id[i] = pre_id[i];
+					sp[i] = make_float4(pre_sp[i].x, pre_sp[i].y, pre_sp[i].z, pre_sp[i].w);
+					continue;
+				}
+			}
 			const uint32_t off_i = (lane * 4u) & (0u - ((need_id_bits >> i) & 1u)), off_s = (lane * 16u) & (0u - ((need_sphere_bits >> i) & 1u)); // (bytes: one select each)
 			const int32_t* id_at = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(g_ids + ((size_t)(chunk0 + g) << 6) + i * 64) + off_i);
 			const v4f* sp_at = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(g_spheres + ((size_t)(chunk0 + g) << 6) + i * 64) + off_s);
