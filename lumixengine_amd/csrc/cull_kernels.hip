@@ -323,7 +323,7 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 	// verdict to the barrier behind the classification (keys -> classes -> barrier -> headers), and a launch's first round of blocks all sit there at once.
 	// Requested behind the keys: loads return in order, the classification waits for the keys only. What a chunk turns out not to need is ignored.
 	constexpr bool STREAMING = F == 1 && (FORM == 2 || FORM == 4); // (template slot FORM: 0 = several frusta; one frustum: 1 = latency form, 2 = streaming form, 3 / 4 = the same two with 16-byte cell keys)
-	constexpr bool PRELOAD = STREAMING;
+	constexpr bool PRELOAD = STREAMING || F != 1; // (the several-frusta kernels: their one group)
 	typedef float v4f_pre __attribute__((ext_vector_type(4)));
 	v4f_pre pre_sp[PRELOAD ? GRP : 1];
 	int32_t pre_id[PRELOAD ? GRP : 1];
@@ -439,8 +439,12 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 			// contributes its verdict): phase B learns what a chunk needs from ONE LDS read per chunk instead of one per (chunk, frustum) - a
 			// chain of 32 dependent LDS round trips per wave in front of its loads (profiles/r04/cull8_probes.txt: 96 of the launch's 201 us
 			// were neither classification nor sphere tests).
+			const FetchedKey fetched0 = fetch_key(threadIdx.x < a.cell_cap ? threadIdx.x : 0u); // (the tail of a tile's slice holds dead keys: no bound needed)
+			__builtin_amdgcn_sched_barrier(0);
+			preload_group0(std::true_type{});
+			__builtin_amdgcn_sched_barrier(0);
 			for (uint32_t t = threadIdx.x; t < n_cells; t += THREADS) {
-				const CellKey key = load_key(t);
+				const CellKey key = t == threadIdx.x ? decode_key(fetched0) : load_key(t);
 				uint32_t word = tile_word;
 #pragma unroll 1
 				for (int f = 0; f < nf; ++f) {
@@ -617,9 +621,11 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 				// in front of the next chunk's loads: four serialised round trips to memory per wave (seen in the ISA; the 1-frustum kernels
 				// issue all their loads first). A chunk that needs nothing reads one 16-byte sphere / one id at a wave-uniform address instead
 				// (the wave's first entity: one cache line, usually the one its neighbour chunk fetches anyway) and ignores the value.
-				const uint32_t e0 = chunk0 << 6;
-				id[g + i] = g_ids[need_id(i) ? e : e0];
-				sp[i] = g_spheres[need_sphere(i) ? e : e0];
+				// (round 6: requested under phase A, all of them - what a chunk turns out not to need is ignored)
+				static_assert(F == 1 || GRP == CHW, "one group");
+				(void)e;
+				id[g + i] = pre_id[i];
+				sp[i] = make_float4(pre_sp[i].x, pre_sp[i].y, pre_sp[i].z, pre_sp[i].w);
 				continue;
 			}
 			// One frustum: the loads are UNCONDITIONAL too (round 6). Under `if (need_sphere(i))` every load cost a branch, five moves for the zeros of the
