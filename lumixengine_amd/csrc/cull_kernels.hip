@@ -314,6 +314,11 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 	// block than the 32-byte CellInfo, and LDS is what bounds the resident blocks of this kernel (8 frusta x ~140 cells per tile)
 	v2f* s_d2 = reinterpret_cast<v2f*>(s_info);                                                  // [n_frusta * cell_cap][3]
 	uint32_t* s_word = reinterpret_cast<uint32_t*>(s_d2 + (F != 1 ? (size_t)nf * a.cell_cap * 3 : 0)); // [cell_cap], behind the records
+	// (the 5..8-frusta shape) classification is split over the WAVES by frustum: wave w classifies frusta w, w + 4 for ALL the tile's cells, 64 cells per iteration.
+	// With a lane per cell and all frusta in every wave, a tile of ~100 cells (the 10 M all-test scene) ran 8 frustum bodies per wave with 100 of 256 lanes busy;
+	// now 2 iterations x 2 frusta. A cell's class word is the OR of the four waves' 16-bit parts: s_w16[4 t + w], read back as one 8-byte LDS load.
+	constexpr bool SPLIT = F != 1 && WAVES == 4;
+	uint16_t* s_w16 = reinterpret_cast<uint16_t*>(s_word); // [cell_cap][4] (SPLIT)
 	if constexpr (F != 1) {
 		static_assert(TILE_ACCEPT == 1 && CELL_ACCEPT == 1, "a settled frustum contributes CELL_ACCEPT or nothing: its verdict field IS its class field");
 		tile_word = st_bits & ~(st_bits >> 1) & 0x5555u;
@@ -439,19 +444,22 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 			// contributes its verdict): phase B learns what a chunk needs from ONE LDS read per chunk instead of one per (chunk, frustum) - a
 			// chain of 32 dependent LDS round trips per wave in front of its loads (profiles/r04/cull8_probes.txt: 96 of the launch's 201 us
 			// were neither classification nor sphere tests).
-			const FetchedKey fetched0 = fetch_key(threadIdx.x < a.cell_cap ? threadIdx.x : 0u); // (the tail of a tile's slice holds dead keys: no bound needed)
+			const uint32_t t_first = SPLIT ? lane : threadIdx.x, t_step = SPLIT ? 64u : THREADS;
+			const FetchedKey fetched0 = fetch_key(t_first < a.cell_cap ? t_first : 0u); // (the tail of a tile's slice holds dead keys: no bound needed)
 			__builtin_amdgcn_sched_barrier(0);
 			preload_group0(std::true_type{});
 			__builtin_amdgcn_sched_barrier(0);
-			for (uint32_t t = threadIdx.x; t < n_cells; t += THREADS) {
-				const CellKey key = t == threadIdx.x ? decode_key(fetched0) : load_key(t);
-				uint32_t word = tile_word;
+			const uint32_t my_fields = SPLIT ? 0x0303u << (2u * wave) : 0xffffu; // the class fields of this wave's frusta (w, w + 4)
+			for (uint32_t t = t_first; t < n_cells; t += t_step) {
+				const CellKey key = t == t_first ? decode_key(fetched0) : load_key(t);
+				uint32_t word = tile_word & my_fields;
 #pragma unroll 1
-				for (int f = 0; f < nf; ++f) {
+				for (int f = SPLIT ? (int)wave : 0; f < nf; f += SPLIT ? WAVES : 1) {
 					if (((st_bits >> (2 * f)) & 3u) != TILE_MIXED) continue; // wave-uniform
 					word |= classify(t, f, key) << (2 * f);
 				}
-				s_word[t] = word;
+				if constexpr (SPLIT) s_w16[4u * t + wave] = (uint16_t)word;
+				else s_word[t] = word;
 			}
 		}
 		if constexpr (F != 1) {
@@ -587,7 +595,15 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 #pragma unroll
 			for (int i = 0; i < GRP; ++i) local[i] = hdr_g[i].cell + mbcnt64(hdr_g[i].flags >> 1) - first_cell; // cell boundaries at positions 1..lane: two v_mbcnt on a wave-uniform mask
 #pragma unroll
-			for (int i = 0; i < GRP; ++i) cls_word[i] = F != 1 ? s_word[local[i]] : s_info[local[i]].cls;
+			for (int i = 0; i < GRP; ++i) {
+				if constexpr (SPLIT) {
+					const uint2 parts = *reinterpret_cast<const uint2*>(s_w16 + 4u * local[i]); // the four waves' parts of the cell's class word
+					const uint32_t both = parts.x | parts.y;
+					cls_word[i] = (both | (both >> 16)) & 0xffffu;
+				} else {
+					cls_word[i] = F != 1 ? s_word[local[i]] : s_info[local[i]].cls;
+				}
+			}
 			if constexpr (F == 1) { // one frustum: from here on a lane's cell is the byte offset of its 32-byte record, with the class in the free low bits (ONE register per chunk)
 #pragma unroll
 				for (int i = 0; i < GRP; ++i) cls_word[i] |= local[i] << 5;
@@ -1206,8 +1222,8 @@ hipError_t tile_f(hipStream_t s, const CullDeviceView& v, uint32_t ent_begin, ui
 
 } // namespace
 
-size_t cull_tile_lds_bytes(int n_frusta, uint32_t cell_cap) { // several frusta: 24-byte records + the cells' class words
-	return n_frusta > 1 ? (size_t)n_frusta * cell_cap * 24 + (size_t)cell_cap * sizeof(uint32_t) : (size_t)cell_cap * sizeof(CellInfo);
+size_t cull_tile_lds_bytes(int n_frusta, uint32_t cell_cap) { // several frusta: 24-byte records + the cells' class words (5..8 frusta: in four 16-bit parts)
+	return n_frusta > 1 ? (size_t)n_frusta * cell_cap * 24 + (size_t)cell_cap * (n_frusta > 4 ? 8 : 4) : (size_t)cell_cap * sizeof(CellInfo);
 }
 
 uint32_t cull_tile_size(int n_frusta, int variant) {
