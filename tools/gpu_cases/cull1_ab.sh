@@ -16,6 +16,7 @@ for v in product "$@"; do
 	if [ "$v" = product ]; then unset LMX_LIB_PATH; else export LMX_LIB_PATH=$ROOT/tools/_build/variants/$v/liblumix_mi355.so; fi
 	prof ${v}_cull8_cold $W --workload cull8_all_test --steps 20 --cold read
 	prof ${v}_cull8_warm $W --workload cull8_all_test --steps 20
-	for w in cull8_cold cull8_warm; do echo "$v $w: $(grep k_cull_tile "$OUT/${v}_${w}_kernel_stats.csv" | awk -F, '{print "calls", $(NF-6), "avg_ns", $(NF-4), "min", $(NF-2), "max", $(NF-1)}' | head -2 | tr '\n' ' ')"; done
+	LMX_WORKLOAD_PASS_WIDTH=4 prof ${v}_cull4x2_cold $W --workload cull8_all_test --steps 20 --cold read # the 2..4-frusta shape: the same cascades as two passes of four
+	for w in cull8_cold cull8_warm cull4x2_cold; do echo "$v $w: $(grep k_cull_tile "$OUT/${v}_${w}_kernel_stats.csv" | awk -F, '{print "calls", $(NF-6), "avg_ns", $(NF-4), "min", $(NF-2), "max", $(NF-1)}' | head -2 | tr '\n' ' ')"; done
 done 2>&1 | tee -a "$OUT/cull1_ab.txt"
 unset LMX_LIB_PATH

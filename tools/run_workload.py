@@ -84,7 +84,7 @@ def main():
             fr = H.cascade_frusta(api, 8)
         elif args.workload == "cull8_all_test":  # bench.py's all_test_8_frusta_one_pass leg: config 5's 8 cascades in ONE pass over the spheres
             fr = np.concatenate([api.viewport_frustum(**kw) for kw in scenes.config5_cascade_kwargs()])
-            cs.setPassWidth(8)
+            cs.setPassWidth(int(os.environ.get("LMX_WORKLOAD_PASS_WIDTH", "8")))  # (4: two passes of the 2..4-frusta kernel shape)
         else:
             fr = api.viewport_frustum()
         import time
