@@ -446,12 +446,15 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 			// were neither classification nor sphere tests).
 			const uint32_t t_first = SPLIT ? lane : threadIdx.x, t_step = SPLIT ? 64u : THREADS;
 			const FetchedKey fetched0 = fetch_key(t_first < a.cell_cap ? t_first : 0u); // (the tail of a tile's slice holds dead keys: no bound needed)
+			// (split form: the lane's second cell as well - a tile of the 10 M scenes holds ~100 cells, two iterations of 64 lanes - instead of a load and its wait inside the loop)
+			FetchedKey fetched1 = fetched0;
+			if constexpr (SPLIT) fetched1 = fetch_key(t_first + t_step < a.cell_cap ? t_first + t_step : 0u);
 			__builtin_amdgcn_sched_barrier(0);
 			preload_group0(std::true_type{});
 			__builtin_amdgcn_sched_barrier(0);
 			const uint32_t my_fields = SPLIT ? 0x0303u << (2u * wave) : 0xffffu; // the class fields of this wave's frusta (w, w + 4)
 			for (uint32_t t = t_first; t < n_cells; t += t_step) {
-				const CellKey key = t == t_first ? decode_key(fetched0) : load_key(t);
+				const CellKey key = t == t_first ? decode_key(fetched0) : (SPLIT && t == t_first + t_step ? decode_key(fetched1) : load_key(t));
 				uint32_t word = tile_word & my_fields;
 #pragma unroll 1
 				for (int f = SPLIT ? (int)wave : 0; f < nf; f += SPLIT ? WAVES : 1) {
