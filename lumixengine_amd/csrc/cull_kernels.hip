@@ -434,11 +434,12 @@ __global__ __launch_bounds__(WAVES * 64) LMX_CULL_WAVES_ATTR(F) void k_cull_tile
 			asm volatile("" : "+v"(key0.ix), "+v"(key0.iy), "+v"(key0.iz), "+v"(key0.meta));
 			for (uint32_t t = threadIdx.x; t < n_cells; t += THREADS) classify(t, 0, t == threadIdx.x ? key0 : load_key(t));
 		} else {
-			// Several frusta: ONE lane per cell, the MIXED frusta in an inner, wave-uniform loop (scalar loads of the frustum). The cell's key is
-			// loaded once and its fp64 origin formed once for all frusta. Rounds 2 / 3 spread the (cell, frustum) PAIRS over the waves - every
-			// wave re-read every key and re-derived every origin for each of its frusta, with a load -> wait -> branch -> load chain in each of
-			// 16 half-empty wave iterations per tile: on the 10 M all-test scene (one cell per ~10 spheres) the classification issued more
-			// instructions than the 8 x 10 M sphere tests (72.6 M VALU wave-instructions a launch, 35 M of them the tests: profiles/r04/cull8_counters).
+			// Several frusta: a lane per cell, the MIXED frusta in an inner, wave-uniform loop (scalar loads of the frustum); the cell's key is loaded once
+			// and its fp64 origin formed once for the frusta of the loop. The 8-wave shape (<= 4 frusta) runs all frusta in every wave, a cell per thread;
+			// the 4-wave shape (5..8 frusta) gives wave w the frusta w and w + 4 and ALL the tile's cells, 64 per iteration (SPLIT above: round 6 - full lanes
+			// weigh more than the keys and origins formed four times over). Rounds 2 / 3 spread (cell, frustum) PAIRS over the waves with a load -> wait ->
+			// branch -> load chain in each of 16 half-empty wave iterations per tile: on the 10 M all-test scene (one cell per ~10 spheres) the classification
+			// issued more instructions than the 8 x 10 M sphere tests (72.6 M VALU wave-instructions a launch, 35 M of them the tests: profiles/r04/cull8_counters).
 			// Frusta whose tile verdict is not MIXED need no per-cell work (phase B reads their verdict from st_bits).
 			// The classes of a cell under ALL frusta are also packed into one word (2 bits a frustum; a frustum the tile-level test settled
 			// contributes its verdict): phase B learns what a chunk needs from ONE LDS read per chunk instead of one per (chunk, frustum) - a
