@@ -326,9 +326,9 @@ def extras(ctx, api, scenes, dev, timed, N, log, check_ids, big_entities=0, out=
             cs_b.cull(fr8b)
             sk5.run()
 
-        for _ in range(2):
+        for _ in range(3):
             frame5()
-        ms5 = timed(frame5, 5)
+        ms5 = timed(frame5, R(12))
         big["frame_8_cascades_plus_skinned_share"] = {
             "ms_per_frame": ms5, "frames_per_sec": 1e3 / ms5, "entities": NB, "frusta": 8, "skinned_instances": n_c5, "verts_per_instance": len(verts5),
             "skinned_share_of_entities": n_c5 / NB, "entity_frustum_tests_per_sec": 8.0 * NB / (ms5 * 1e-3), "skinned_verts_per_sec": n_c5 * len(verts5) / (ms5 * 1e-3),
